@@ -1,0 +1,189 @@
+"""ctypes binding of libburst_hip.so (C ABI declared in include/burst_hip.h).
+
+This is the only door from Python to the device path; there is no CPU fallback.  If the library has not
+been built (`python -c "import __graft_entry__ as g; g.build()"` or `make -C burst_amd/csrc`) importing
+this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libburst_hip.so")
+
+BHIP_OK, BHIP_E_ARG, BHIP_E_DEVICE, BHIP_E_CAPACITY, BHIP_E_QUERYLEN, BHIP_E_INTERNAL = 0, -1, -2, -3, -4, -5
+BHIP_Q_PREFILTER, BHIP_Q_EXHAUSTIVE = 0, 1
+BHIP_MAX_QLEN = 1024
+
+# BhipHit, 20 bytes (include/burst_hip.h)
+HIT_DTYPE = np.dtype([("q", "<u4"), ("refIx", "<u4"), ("finalPos", "<u4"), ("score", "<f4"),
+                      ("ed", "u1"), ("gapR", "u1"), ("gapQ", "u1"), ("rc", "u1")])
+assert HIT_DTYPE.itemsize == 20
+
+
+class BhipStats(C.Structure):
+    _fields_ = [("n_queries", C.c_uint64), ("n_pairs", C.c_uint64), ("n_columns", C.c_uint64),
+                ("n_raw_hits", C.c_uint64), ("n_hits", C.c_uint64), ("acx_entries_read", C.c_uint64),
+                ("bytes_algorithmic", C.c_uint64),
+                ("ms_h2d", C.c_float), ("ms_prefilter", C.c_float), ("ms_peq", C.c_float), ("ms_myers", C.c_float),
+                ("ms_rescore", C.c_float), ("ms_d2h", C.c_float), ("ms_total", C.c_float),
+                ("myers_launches", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+EXPORTS = ["bhip_init", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_get_stats",
+           "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version"]
+
+
+class BurstHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libburst_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: the HIP extension has not been built (run __graft_entry__.build()); "
+                          "burst_amd has no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    lib.bhip_init.argtypes = [i32, vp, vp, u32, u32, vp, vp, i32, i32, vp, u32, vp, i32, C.POINTER(vp)]
+    lib.bhip_init.restype = i32
+    lib.bhip_align_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, u32, i32, vp, u64, C.POINTER(u64)]
+    lib.bhip_align_batch.restype = i32
+    lib.bhip_align_pairs.argtypes = [vp, vp, vp, vp, u32, vp, vp, u64, vp]
+    lib.bhip_align_pairs.restype = i32
+    lib.bhip_prefilter.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, u64, C.POINTER(u64)]
+    lib.bhip_prefilter.restype = i32
+    lib.bhip_get_stats.argtypes = [vp, C.POINTER(BhipStats)]
+    lib.bhip_get_stats.restype = i32
+    lib.bhip_device_info.argtypes = [vp, C.c_char_p, i32, C.POINTER(i32), C.POINTER(u64)]
+    lib.bhip_device_info.restype = i32
+    lib.bhip_destroy.argtypes = [vp]
+    lib.bhip_destroy.restype = None
+    lib.bhip_last_error.argtypes = []
+    lib.bhip_last_error.restype = C.c_char_p
+    lib.bhip_abi_version.argtypes = []
+    lib.bhip_abi_version.restype = i32
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(rc):
+    if rc != BHIP_OK:
+        raise BurstHipError(rc, lib().bhip_last_error().decode("utf-8", "replace"))
+
+
+def _arr(a, dtype):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+class Queries:
+    """Flat query batch in the layout bhip_align_batch takes."""
+
+    def __init__(self, seqs, emac, six=None, rc=None, flags=None):
+        lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+        self.off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=self.off[1:])
+        self.codes = (np.concatenate([np.asarray(s, dtype=np.uint8) for s in seqs]) if len(seqs) and self.off[-1]
+                      else np.zeros(1, np.uint8))
+        self.emac = _arr(emac, np.uint16)
+        self.six = _arr(six, np.uint32)
+        self.rc = _arr(rc, np.uint8)
+        self.flags = _arr(flags, np.uint8)
+        self.n = len(seqs)
+        self.n_shared = int(self.six.max()) + 1 if self.six is not None and self.n else self.n
+
+
+class Device:
+    """One handle = one database resident on one GPU (bhip_init .. bhip_destroy)."""
+
+    def __init__(self, edx_packed, clump_len, tot_refs, score_lut, acx_lens=None, acx_lists=None, acx_fmt=0, K=12,
+                 badlist=None, device=0, xalpha=0):
+        self._h = C.c_void_p()
+        edx_packed = _arr(edx_packed, np.uint8)
+        clump_len = _arr(clump_len, np.uint32)
+        score_lut = _arr(score_lut, np.uint8)
+        acx_lens = _arr(acx_lens, np.uint32)
+        acx_lists = _arr(acx_lists, np.uint8)
+        badlist = _arr(badlist, np.uint32)
+        nbad = 0 if badlist is None else len(badlist)
+        self.n_clumps = len(clump_len)
+        self.clump_len = clump_len
+        _chk(lib().bhip_init(device, _ptr(edx_packed), _ptr(clump_len), len(clump_len), tot_refs, _ptr(acx_lens), _ptr(acx_lists),
+                             acx_fmt, K, _ptr(badlist), nbad, _ptr(score_lut), xalpha, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().bhip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        ncu = C.c_int()
+        hbm = C.c_uint64()
+        _chk(lib().bhip_device_info(self._h, name, 256, C.byref(ncu), C.byref(hbm)))
+        return {"name": name.value.decode(), "n_cu": ncu.value, "hbm_bytes": hbm.value}
+
+    def stats(self):
+        s = BhipStats()
+        _chk(lib().bhip_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def align_batch(self, q, all_hits=False, cap=None):
+        cap = cap or max(1 << 16, 4 * q.n)
+        while True:
+            hits = np.zeros(cap, dtype=HIT_DTYPE)
+            n = C.c_uint64()
+            rc = lib().bhip_align_batch(self._h, _ptr(q.codes), _ptr(q.off), _ptr(q.emac), _ptr(q.six), _ptr(q.rc), _ptr(q.flags),
+                                        q.n, q.n_shared, int(bool(all_hits)), _ptr(hits), cap, C.byref(n))
+            if rc == BHIP_E_CAPACITY:
+                cap = int(n.value) + 16
+                continue
+            _chk(rc)
+            return hits[:n.value]
+
+    def align_pairs(self, q, pair_q, pair_clump):
+        pair_q = _arr(pair_q, np.uint32)
+        pair_clump = _arr(pair_clump, np.uint32)
+        mins = np.zeros(len(pair_q) * 16, dtype=np.uint8)
+        _chk(lib().bhip_align_pairs(self._h, _ptr(q.codes), _ptr(q.off), _ptr(q.emac), q.n, _ptr(pair_q), _ptr(pair_clump),
+                                    len(pair_q), _ptr(mins)))
+        return mins.reshape(-1, 16)
+
+    def prefilter(self, q, cap=None):
+        cap = cap or max(1 << 16, 64 * q.n)
+        while True:
+            oq = np.zeros(cap, np.uint32)
+            oc = np.zeros(cap, np.uint32)
+            on = np.zeros(cap, np.uint32)
+            n = C.c_uint64()
+            rc = lib().bhip_prefilter(self._h, _ptr(q.codes), _ptr(q.off), _ptr(q.emac), q.n, _ptr(oq), _ptr(oc), _ptr(on), cap, C.byref(n))
+            if rc == BHIP_E_CAPACITY:
+                cap = int(n.value) + 16
+                continue
+            _chk(rc)
+            k = n.value
+            return oq[:k], oc[:k], on[:k]

@@ -1,0 +1,515 @@
+// burst_amd/csrc/bhip_api.hip -- C-ABI entry points of libburst_hip.so (include/burst_hip.h).
+// Owns device memory, one HIP stream per handle, HIP-event timing of every phase, and the batch driver
+// that replaces the bodies of the two OpenMP loops in do_alignments (burst.c:4077-4289, 4343-4484).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "burst_hip.h"
+#include "bhip_internal.h"
+
+// ---- kernels (bhip_kernels.hip) -------------------------------------------------------------------
+__global__ void k_transpose_refs(const uint8_t *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint4 *);
+__global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, int, BhipMatchMask, uint32_t *);
+template <bool LDS_CNT> __global__ void k_prefilter(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
+	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t,
+	unsigned long long *);
+template <int NW> __global__ void k_myers(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
+	const uint64_t *, const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t,
+	BhipRawHit *, uint32_t *, uint32_t, uint32_t *, uint8_t *, unsigned long long *, unsigned long long *);
+template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *,
+	const uint32_t *, int, const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t *, const uint64_t *,
+	const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *,
+	unsigned long long, uint32_t *);
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+static int fail(int code, const char *fmt, ...) {
+	va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+	return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+	return fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
+
+// grow-only device buffer
+struct DBuf {
+	void *p = nullptr; size_t cap = 0;
+	int reserve(size_t bytes) {
+		if (bytes <= cap) return 0;
+		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+		size_t want = bytes + bytes / 4 + 256;
+		hipError_t e = hipMalloc(&p, want);
+		if (e != hipSuccess) { p = nullptr; return fail(BHIP_E_DEVICE, "hipMalloc(%zu): %s", want, hipGetErrorString(e)); }
+		cap = want; return 0;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	template <class T> T *as() const { return (T *)p; }
+};
+
+static const int kClasses[] = {2, 4, 6, 8, 10, 16, 32};
+static const int kNumClasses = 7;
+static int class_of_len(uint32_t len) {
+	for (int i = 0; i < kNumClasses; ++i) if (len <= 32u * kClasses[i]) return i;
+	return -1;
+}
+
+// device-side counters, one block copied back per call
+struct Counters {
+	uint32_t n_cand, n_raw, n_out, n_wide, err, pad0;
+	unsigned long long col_sum, qlen_sum, ent_read, scratch_used;
+};
+
+struct Handle {
+	int device = 0, n_cu = 0;
+	char dev_name[256];
+	uint64_t hbm = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[10];
+	// database
+	uint32_t n_clumps = 0, tot_refs = 0, max_clump_len = 0;
+	DBuf ref, ref_off, clump_len, lut;
+	BhipMatchMask mm;
+	bool has_acx = false; int K = 0;
+	DBuf acx_off, acx_ent, bad; uint32_t n_bad = 0; uint64_t n_ent = 0;
+	// batch buffers
+	DBuf qcodes, qoff, qemac, qsix, qrc, qlist, peq, cand, candcnt, raw, best, out, wide, scratch, gcnt, counters, mins, pairs;
+	uint64_t cand_cap = 1 << 20, raw_cap = 1 << 20, out_cap = 1 << 20, scratch_cap = 1 << 20;
+	std::vector<uint32_t> h_clump_len;
+	BhipStats stats;
+};
+
+extern "C" const char *bhip_last_error(void) { return g_err; }
+extern "C" int bhip_abi_version(void) { return BHIP_ABI_VERSION; }
+
+extern "C" void bhip_destroy(void *handle) {
+	Handle *h = (Handle *)handle;
+	if (!h) return;
+	(void)hipSetDevice(h->device);
+	if (h->stream) (void)hipStreamSynchronize(h->stream);
+	DBuf *all[] = {&h->ref, &h->ref_off, &h->clump_len, &h->lut, &h->acx_off, &h->acx_ent, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
+		&h->qsix, &h->qrc, &h->qlist, &h->peq, &h->cand, &h->candcnt, &h->raw, &h->best, &h->out, &h->wide, &h->scratch, &h->gcnt,
+		&h->counters, &h->mins, &h->pairs};
+	for (DBuf *b : all) b->release();
+	for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+	if (h->stream) (void)hipStreamDestroy(h->stream);
+	delete h;
+}
+
+extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clump_len, uint32_t n_clumps, uint32_t tot_refs,
+                         const uint32_t *acx_lens, const void *acx_lists, int acx_fmt, int K,
+                         const uint32_t *badlist, uint32_t n_bad, const uint8_t score_lut[256], int xalpha, void **handle) {
+	if (!handle) return fail(BHIP_E_ARG, "handle is NULL");
+	*handle = nullptr;
+	if (xalpha) return fail(BHIP_E_ARG, "xalpha (-x) databases are not supported on the device");
+	if (!edx_packed || !clump_len || !n_clumps || !score_lut) return fail(BHIP_E_ARG, "empty database");
+	if (acx_lens && (K < 4 || K > 15 || !acx_lists || (acx_fmt != 0 && acx_fmt != 1)))
+		return fail(BHIP_E_ARG, "bad accelerator arguments (K=%d fmt=%d)", K, acx_fmt);
+	int ndev = 0;
+	HIPCHK(hipGetDeviceCount(&ndev));
+	if (device < 0 || device >= ndev) return fail(BHIP_E_DEVICE, "device %d not present (%d visible)", device, ndev);
+	HIPCHK(hipSetDevice(device));
+	Handle *h = new Handle();
+	memset(h->ev, 0, sizeof h->ev);
+	memset(&h->stats, 0, sizeof h->stats);
+	h->device = device;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+		h->n_cu = prop.multiProcessorCount; h->hbm = prop.totalGlobalMem;
+		snprintf(h->dev_name, sizeof h->dev_name, "%s (%s)", prop.name, prop.gcnArchName);
+	}
+	if (h->n_cu <= 0) h->n_cu = 256;
+	#define INITCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+		fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); bhip_destroy(h); return BHIP_E_DEVICE; } } while (0)
+	#define INITRC(x) do { int rc_ = (x); if (rc_) { bhip_destroy(h); return rc_; } } while (0)
+	INITCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+	for (auto &e : h->ev) INITCHK(hipEventCreate(&e));
+	h->n_clumps = n_clumps; h->tot_refs = tot_refs;
+	h->h_clump_len.assign(clump_len, clump_len + n_clumps);
+	for (int a = 0; a < 16; ++a) {
+		uint16_t m = 0;
+		for (int b = 0; b < 16; ++b) if (score_lut[16 * a + b] == 0) m |= (uint16_t)(1u << b);
+		h->mm.m[a] = m;
+	}
+	// reference area: upload as on disk, transpose on the device
+	std::vector<uint64_t> src_off(n_clumps + 1), dst_off(n_clumps + 1);
+	src_off[0] = dst_off[0] = 0;
+	for (uint32_t c = 0; c < n_clumps; ++c) {
+		src_off[c + 1] = src_off[c] + clump_len[c] / 2u + (clump_len[c] & 1);
+		dst_off[c + 1] = dst_off[c] + (clump_len[c] + 31) / 32u;
+		if (clump_len[c] > h->max_clump_len) h->max_clump_len = clump_len[c];
+	}
+	{
+		DBuf d_src, d_srcoff;
+		INITRC(d_src.reserve(src_off[n_clumps] * 16 + 16));
+		INITRC(d_srcoff.reserve((n_clumps + 1) * sizeof(uint64_t)));
+		INITRC(h->ref.reserve(dst_off[n_clumps] * 256 + 256));
+		INITRC(h->ref_off.reserve((n_clumps + 1) * sizeof(uint64_t)));
+		INITRC(h->clump_len.reserve(n_clumps * sizeof(uint32_t)));
+		INITRC(h->lut.reserve(256));
+		INITCHK(hipMemcpyAsync(d_src.p, edx_packed, src_off[n_clumps] * 16, hipMemcpyHostToDevice, h->stream));
+		INITCHK(hipMemcpyAsync(d_srcoff.p, src_off.data(), (n_clumps + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+		INITCHK(hipMemcpyAsync(h->ref_off.p, dst_off.data(), (n_clumps + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+		INITCHK(hipMemcpyAsync(h->clump_len.p, clump_len, n_clumps * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+		INITCHK(hipMemcpyAsync(h->lut.p, score_lut, 256, hipMemcpyHostToDevice, h->stream));
+		const uint32_t grid = std::min<uint32_t>(n_clumps, (uint32_t)h->n_cu * 8);
+		hipLaunchKernelGGL(k_transpose_refs, dim3(grid), dim3(256), 0, h->stream, d_src.as<uint8_t>(), d_srcoff.as<uint64_t>(),
+			h->clump_len.as<uint32_t>(), h->ref_off.as<uint64_t>(), n_clumps, h->ref.as<uint4>());
+		INITCHK(hipGetLastError());
+		INITCHK(hipStreamSynchronize(h->stream));
+		d_src.release(); d_srcoff.release();
+	}
+	if (acx_lens) {
+		const uint64_t nw = 1ull << (2 * K);
+		std::vector<uint32_t> off(nw + 1);
+		uint64_t tot = 0;
+		for (uint64_t i = 0; i < nw; ++i) { off[i] = (uint32_t)tot; tot += acx_lens[i]; }
+		if (tot >= 0xFFFFFFFFull) { fail(BHIP_E_ARG, "accelerator with %llu entries exceeds the 32-bit offset table", (unsigned long long)tot); bhip_destroy(h); return BHIP_E_ARG; }
+		off[nw] = (uint32_t)tot;
+		// decode the packed lists (burst.c:3265-3274 SMALL, 3245-3248 LARGE) to one u32 per entry
+		std::vector<uint32_t> ent(tot + 1);
+		const uint8_t *p = (const uint8_t *)acx_lists;
+		uint64_t e = 0;
+		if (acx_fmt == 1) {
+			for (uint64_t i = 0; i < tot; ++i, p += 3) ent[e++] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+		} else {
+			for (uint64_t w = 0; w < nw; ++w) {
+				uint32_t n = acx_lens[w];
+				for (; n >= 2; n -= 2, p += 5) {
+					uint64_t v = (uint64_t)p[0] | ((uint64_t)p[1] << 8) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 24) | ((uint64_t)p[4] << 32);
+					ent[e++] = (uint32_t)(v & 0xFFFFF); ent[e++] = (uint32_t)((v >> 20) & 0xFFFFF);
+				}
+				if (n) { ent[e++] = ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)) & 0xFFFFF; p += 3; }
+			}
+		}
+		for (uint64_t i = 0; i < tot; ++i) if (ent[i] >= n_clumps) {
+			fail(BHIP_E_ARG, "accelerator entry %llu refers to clump %u >= %u", (unsigned long long)i, ent[i], n_clumps); bhip_destroy(h); return BHIP_E_ARG; }
+		INITRC(h->acx_off.reserve((nw + 1) * sizeof(uint32_t)));
+		INITRC(h->acx_ent.reserve((tot + 1) * sizeof(uint32_t)));
+		INITCHK(hipMemcpy(h->acx_off.p, off.data(), (nw + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+		INITCHK(hipMemcpy(h->acx_ent.p, ent.data(), (tot + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+		h->n_bad = n_bad;
+		INITRC(h->bad.reserve((n_bad + 1) * sizeof(uint32_t)));
+		if (n_bad) {
+			for (uint32_t i = 0; i < n_bad; ++i) if (badlist[i] >= n_clumps) { fail(BHIP_E_ARG, "BadList entry out of range"); bhip_destroy(h); return BHIP_E_ARG; }
+			INITCHK(hipMemcpy(h->bad.p, badlist, n_bad * sizeof(uint32_t), hipMemcpyHostToDevice));
+		}
+		h->has_acx = true; h->K = K; h->n_ent = tot;
+	}
+	INITRC(h->counters.reserve(sizeof(Counters)));
+	*handle = h;
+	return BHIP_OK;
+}
+
+extern "C" int bhip_device_info(void *handle, char *name, int name_cap, int *n_cu, uint64_t *hbm_bytes) {
+	Handle *h = (Handle *)handle;
+	if (!h) return fail(BHIP_E_ARG, "null handle");
+	if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", h->dev_name);
+	if (n_cu) *n_cu = h->n_cu;
+	if (hbm_bytes) *hbm_bytes = h->hbm;
+	return BHIP_OK;
+}
+
+extern "C" int bhip_get_stats(void *handle, BhipStats *out) {
+	Handle *h = (Handle *)handle;
+	if (!h || !out) return fail(BHIP_E_ARG, "null argument");
+	*out = h->stats;
+	return BHIP_OK;
+}
+
+template <int NW> static void launch_myers_t(Handle *h, uint32_t grid, const uint2 *pairs, const uint32_t *n_pairs_dev, uint64_t n_pairs_host,
+		uint32_t li_base, const uint32_t *qlist, BhipRawHit *raw, uint32_t *n_raw, uint32_t raw_cap, uint32_t *best, uint8_t *mins,
+		Counters *dc) {
+	hipLaunchKernelGGL(k_myers<NW>, dim3(grid), dim3(256), 0, h->stream, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist,
+		h->peq.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), best ? h->qsix.as<uint32_t>() : nullptr,
+		h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->tot_refs,
+		raw, n_raw, raw_cap, best, mins, &dc->col_sum, &dc->qlen_sum);
+}
+static void launch_myers(Handle *h, int cls, uint32_t grid, const uint2 *pairs, const uint32_t *n_pairs_dev, uint64_t n_pairs_host,
+		uint32_t li_base, const uint32_t *qlist, BhipRawHit *raw, uint32_t *n_raw, uint32_t raw_cap, uint32_t *best, uint8_t *mins,
+		Counters *dc) {
+	switch (kClasses[cls]) {
+	case 2:  launch_myers_t<2>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
+	case 4:  launch_myers_t<4>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
+	case 6:  launch_myers_t<6>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
+	case 8:  launch_myers_t<8>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
+	case 10: launch_myers_t<10>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
+	case 16: launch_myers_t<16>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
+	default: launch_myers_t<32>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
+	}
+}
+
+static int upload_queries(Handle *h, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
+                          const uint32_t *q_six, const uint8_t *q_rc, uint32_t n_q) {
+	const uint64_t nb = q_off[n_q];
+	int rc;
+	if ((rc = h->qcodes.reserve(nb + 16))) return rc;
+	if ((rc = h->qoff.reserve((n_q + 1) * sizeof(uint64_t)))) return rc;
+	if ((rc = h->qemac.reserve((n_q + 1) * sizeof(uint16_t)))) return rc;
+	if ((rc = h->qsix.reserve((n_q + 1) * sizeof(uint32_t)))) return rc;
+	if ((rc = h->qrc.reserve(n_q + 1))) return rc;
+	HIPCHK(hipMemcpyAsync(h->qcodes.p, q_codes, nb, hipMemcpyHostToDevice, h->stream));
+	HIPCHK(hipMemcpyAsync(h->qoff.p, q_off, (n_q + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+	HIPCHK(hipMemcpyAsync(h->qemac.p, q_emac, n_q * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+	if (q_six) HIPCHK(hipMemcpyAsync(h->qsix.p, q_six, n_q * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+	if (q_rc) HIPCHK(hipMemcpyAsync(h->qrc.p, q_rc, n_q, hipMemcpyHostToDevice, h->stream));
+	return 0;
+}
+
+static int launch_prefilter(Handle *h, const uint32_t *d_qlist, uint32_t n_list, uint2 *cand, uint32_t *candcnt, uint32_t cand_cap,
+                            bool with_bad, Counters *dc) {
+	const uint32_t nw32 = (h->n_clumps + 1) / 2;
+	const size_t lds = (size_t)nw32 * 4;
+	const uint32_t *bad = with_bad ? h->bad.as<uint32_t>() : nullptr;
+	const uint32_t n_bad = with_bad ? h->n_bad : 0;
+	if (lds <= 128 * 1024) {
+		uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
+		uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * per_cu);
+		if (lds > 64 * 1024)
+			HIPCHK(hipFuncSetAttribute((const void *)k_prefilter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		hipLaunchKernelGGL(k_prefilter<true>, dim3(grid), dim3(256), lds, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps,
+			(uint32_t *)nullptr, bad, n_bad, cand, candcnt, &dc->n_cand, cand_cap, &dc->ent_read);
+	} else {
+		uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * 4);
+		int rc = h->gcnt.reserve((size_t)grid * nw32 * 4);
+		if (rc) return rc;
+		hipLaunchKernelGGL(k_prefilter<false>, dim3(grid), dim3(256), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps,
+			h->gcnt.as<uint32_t>(), bad, n_bad, cand, candcnt, &dc->n_cand, cand_cap, &dc->ent_read);
+	}
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+
+extern "C" int bhip_align_batch(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
+                                const uint32_t *q_six, const uint8_t *q_rc, const uint8_t *q_flags,
+                                uint32_t n_q, uint32_t n_shared, int all_hits,
+                                BhipHit *hits, uint64_t cap, uint64_t *n_hits) {
+	Handle *h = (Handle *)handle;
+	if (!h || !n_hits) return fail(BHIP_E_ARG, "null argument");
+	*n_hits = 0;
+	memset(&h->stats, 0, sizeof h->stats);
+	if (!n_q) return BHIP_OK;
+	if (!q_codes || !q_off || !q_emac) return fail(BHIP_E_ARG, "null query arrays");
+	if (!q_six) n_shared = n_q;
+	HIPCHK(hipSetDevice(h->device));
+	// host-side routing: class by length, prefilter vs exhaustive
+	std::vector<uint32_t> lists[kNumClasses][2];
+	for (uint32_t i = 0; i < n_q; ++i) {
+		const uint64_t len = q_off[i + 1] - q_off[i];
+		if (len == 0) continue;
+		if (len > BHIP_MAX_QLEN) return fail(BHIP_E_QUERYLEN, "query %u has %llu symbols (max %d)", i, (unsigned long long)len, BHIP_MAX_QLEN);
+		if (q_six && q_six[i] >= n_shared) return fail(BHIP_E_ARG, "q_six[%u] out of range", i);
+		const int cls = class_of_len((uint32_t)len);
+		int ex = q_flags ? (q_flags[i] == BHIP_Q_EXHAUSTIVE) : !h->has_acx;
+		if (!h->has_acx) ex = 1;
+		lists[cls][ex].push_back(i);
+	}
+	Counters hc;
+	for (int attempt = 0; attempt < 6; ++attempt) {
+		int rc;
+		HIPCHK(hipEventRecord(h->ev[0], h->stream));
+		if ((rc = upload_queries(h, q_codes, q_off, q_emac, q_six, q_rc, n_q))) return rc;
+		if ((rc = h->best.reserve((size_t)(n_shared + 1) * 4))) return rc;
+		if ((rc = h->cand.reserve(h->cand_cap * sizeof(uint2)))) return rc;
+		if ((rc = h->raw.reserve(h->raw_cap * sizeof(BhipRawHit)))) return rc;
+		if ((rc = h->wide.reserve(h->raw_cap * sizeof(uint32_t)))) return rc;
+		if ((rc = h->out.reserve(h->out_cap * sizeof(BhipHit)))) return rc;
+		if ((rc = h->scratch.reserve(h->scratch_cap * sizeof(uint32_t)))) return rc;
+		HIPCHK(hipMemsetAsync(h->best.p, 0xFF, (size_t)n_shared * 4, h->stream));
+		HIPCHK(hipMemsetAsync(h->counters.p, 0, sizeof(Counters), h->stream));
+		Counters *dc = h->counters.as<Counters>();
+		HIPCHK(hipEventRecord(h->ev[1], h->stream));
+		float ms_pf = 0, ms_peq = 0, ms_my = 0;
+		uint64_t n_pairs_ex = 0;
+		uint32_t launches = 0;
+		bool cand_overflow = false;
+		for (int cls = 0; cls < kNumClasses; ++cls) {
+			const uint32_t n_pf = (uint32_t)lists[cls][0].size(), n_ex = (uint32_t)lists[cls][1].size(), n_list = n_pf + n_ex;
+			if (!n_list) continue;
+			const int NW = kClasses[cls];
+			std::vector<uint32_t> ql(lists[cls][0]);
+			ql.insert(ql.end(), lists[cls][1].begin(), lists[cls][1].end());
+			if ((rc = h->qlist.reserve((size_t)n_list * 4))) return rc;
+			if ((rc = h->peq.reserve((size_t)n_list * 16 * NW * 4))) return rc;
+			// the previous class may still be reading qlist/peq on the stream: same stream, so ordering is implicit
+			HIPCHK(hipMemcpyAsync(h->qlist.p, ql.data(), (size_t)n_list * 4, hipMemcpyHostToDevice, h->stream));
+			HIPCHK(hipStreamSynchronize(h->stream));   // ql is a stack vector; keep it alive until copied
+			HIPCHK(hipEventRecord(h->ev[2], h->stream));
+			{
+				const uint64_t total = (uint64_t)n_list * 16 * NW;
+				const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16);
+				hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+					h->qlist.as<uint32_t>(), n_list, NW, h->mm, h->peq.as<uint32_t>());
+				HIPCHK(hipGetLastError());
+			}
+			HIPCHK(hipEventRecord(h->ev[3], h->stream));
+			const uint32_t grid_my = (uint32_t)h->n_cu * 8;
+			if (n_pf) {
+				HIPCHK(hipMemsetAsync(&dc->n_cand, 0, 4, h->stream));
+				if ((rc = launch_prefilter(h, h->qlist.as<uint32_t>(), n_pf, h->cand.as<uint2>(), nullptr, (uint32_t)h->cand_cap, true, dc))) return rc;
+				HIPCHK(hipEventRecord(h->ev[4], h->stream));
+				launch_myers(h, cls, grid_my, h->cand.as<uint2>(), &dc->n_cand, 0, 0, h->qlist.as<uint32_t>(), h->raw.as<BhipRawHit>(),
+					&dc->n_raw, (uint32_t)h->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
+				HIPCHK(hipGetLastError());
+				++launches;
+				// the candidate count is needed on the host only to detect overflow and for the stats
+				uint32_t nc = 0;
+				HIPCHK(hipMemcpyAsync(&nc, &dc->n_cand, 4, hipMemcpyDeviceToHost, h->stream));
+				HIPCHK(hipEventRecord(h->ev[5], h->stream));
+				HIPCHK(hipStreamSynchronize(h->stream));
+				ms_pf += ev_ms(h->ev[3], h->ev[4]); ms_my += ev_ms(h->ev[4], h->ev[5]);
+				if (nc > h->cand_cap) { h->cand_cap = (uint64_t)nc + nc / 8 + 1024; cand_overflow = true; break; }
+				h->stats.n_pairs += nc;
+			} else HIPCHK(hipEventRecord(h->ev[4], h->stream));
+			if (n_ex) {
+				const uint64_t np = (uint64_t)n_ex * h->n_clumps;
+				HIPCHK(hipEventRecord(h->ev[6], h->stream));
+				launch_myers(h, cls, (uint32_t)std::min<uint64_t>((np + 15) / 16, grid_my), nullptr, nullptr, np, n_pf, h->qlist.as<uint32_t>(),
+					h->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)h->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
+				HIPCHK(hipGetLastError());
+				++launches;
+				HIPCHK(hipEventRecord(h->ev[7], h->stream));
+				HIPCHK(hipStreamSynchronize(h->stream));
+				ms_my += ev_ms(h->ev[6], h->ev[7]);
+				n_pairs_ex += np;
+			}
+			ms_peq += ev_ms(h->ev[2], h->ev[3]);
+		}
+		if (cand_overflow) continue;
+		// rescoring of the kept lanes
+		HIPCHK(hipEventRecord(h->ev[6], h->stream));
+		const uint32_t grid_rs = (uint32_t)h->n_cu * 16;
+		hipLaunchKernelGGL(k_rescore<false>, dim3(grid_rs), dim3(64), 0, h->stream, h->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)h->raw_cap,
+			(const uint32_t *)nullptr, (const uint32_t *)nullptr, h->best.as<uint32_t>(), all_hits, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+			q_six ? h->qsix.as<uint32_t>() : nullptr, q_rc ? h->qrc.as<uint8_t>() : nullptr, h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(),
+			h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &dc->n_out, (uint32_t)h->out_cap, h->wide.as<uint32_t>(),
+			&dc->n_wide, (uint32_t *)nullptr, &dc->scratch_used, 0ull, &dc->err);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		if (hc.n_raw > h->raw_cap) { h->raw_cap = (uint64_t)hc.n_raw + hc.n_raw / 8 + 1024; continue; }
+		if (hc.n_wide) {
+			hipLaunchKernelGGL(k_rescore<true>, dim3(std::min<uint32_t>((hc.n_wide + 63) / 64, grid_rs)), dim3(64), 0, h->stream,
+				h->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)h->raw_cap, h->wide.as<uint32_t>(), &dc->n_wide, h->best.as<uint32_t>(), all_hits,
+				h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), q_six ? h->qsix.as<uint32_t>() : nullptr, q_rc ? h->qrc.as<uint8_t>() : nullptr,
+				h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(),
+				&dc->n_out, (uint32_t)h->out_cap, (uint32_t *)nullptr, (uint32_t *)nullptr, h->scratch.as<uint32_t>(), &dc->scratch_used,
+				(unsigned long long)h->scratch_cap, &dc->err);
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipStreamSynchronize(h->stream));
+			if (hc.err & 2u) { h->scratch_cap = (uint64_t)hc.scratch_used + 1024; continue; }
+		}
+		HIPCHK(hipEventRecord(h->ev[7], h->stream));
+		if (hc.err & 1u) return fail(BHIP_E_INTERNAL, "re-scoring could not reproduce a hit found by the edit-distance kernel");
+		if (hc.n_out > h->out_cap) { h->out_cap = (uint64_t)hc.n_out + hc.n_out / 8 + 1024; continue; }
+		*n_hits = hc.n_out;
+		h->stats.n_queries = n_q; h->stats.n_pairs += n_pairs_ex; h->stats.n_columns = hc.col_sum; h->stats.n_raw_hits = hc.n_raw;
+		h->stats.n_hits = hc.n_out; h->stats.acx_entries_read = hc.ent_read; h->stats.myers_launches = launches;
+		h->stats.bytes_algorithmic = 8ull * hc.col_sum + hc.qlen_sum / 2 + 192ull * h->stats.n_pairs;
+		if (hc.n_out > cap) return fail(BHIP_E_CAPACITY, "hit buffer holds %llu records, %u needed", (unsigned long long)cap, hc.n_out);
+		HIPCHK(hipEventRecord(h->ev[8], h->stream));
+		if (hc.n_out) HIPCHK(hipMemcpyAsync(hits, h->out.p, (size_t)hc.n_out * sizeof(BhipHit), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipEventRecord(h->ev[9], h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		std::sort(hits, hits + hc.n_out, [](const BhipHit &a, const BhipHit &b) { return a.q != b.q ? a.q < b.q : a.refIx < b.refIx; });
+		h->stats.ms_h2d = ev_ms(h->ev[0], h->ev[1]); h->stats.ms_prefilter = ms_pf; h->stats.ms_peq = ms_peq; h->stats.ms_myers = ms_my;
+		h->stats.ms_rescore = ev_ms(h->ev[6], h->ev[7]); h->stats.ms_d2h = ev_ms(h->ev[8], h->ev[9]); h->stats.ms_total = ev_ms(h->ev[0], h->ev[9]);
+		return BHIP_OK;
+	}
+	return fail(BHIP_E_INTERNAL, "buffers kept overflowing");
+}
+
+extern "C" int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
+                                uint32_t n_q, const uint32_t *pair_q, const uint32_t *pair_clump, uint64_t n_pairs, uint8_t *mins) {
+	Handle *h = (Handle *)handle;
+	if (!h || !q_codes || !q_off || !q_emac || !pair_q || !pair_clump || !mins) return fail(BHIP_E_ARG, "null argument");
+	memset(&h->stats, 0, sizeof h->stats);
+	if (!n_pairs || !n_q) return BHIP_OK;
+	HIPCHK(hipSetDevice(h->device));
+	uint32_t maxlen = 0;
+	for (uint32_t i = 0; i < n_q; ++i) maxlen = std::max<uint32_t>(maxlen, (uint32_t)(q_off[i + 1] - q_off[i]));
+	if (maxlen > BHIP_MAX_QLEN) return fail(BHIP_E_QUERYLEN, "query longer than %d", BHIP_MAX_QLEN);
+	const int cls = class_of_len(std::max<uint32_t>(maxlen, 1)), NW = kClasses[cls];
+	std::vector<uint2> pr(n_pairs);
+	for (uint64_t p = 0; p < n_pairs; ++p) {
+		if (pair_q[p] >= n_q || pair_clump[p] >= h->n_clumps) return fail(BHIP_E_ARG, "pair %llu out of range", (unsigned long long)p);
+		pr[p] = make_uint2(pair_q[p], pair_clump[p]);
+	}
+	int rc;
+	if ((rc = upload_queries(h, q_codes, q_off, q_emac, nullptr, nullptr, n_q))) return rc;
+	if ((rc = h->peq.reserve((size_t)n_q * 16 * NW * 4))) return rc;
+	if ((rc = h->pairs.reserve(n_pairs * sizeof(uint2)))) return rc;
+	if ((rc = h->mins.reserve(n_pairs * 16))) return rc;
+	HIPCHK(hipMemcpyAsync(h->pairs.p, pr.data(), n_pairs * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
+	HIPCHK(hipMemsetAsync(h->counters.p, 0, sizeof(Counters), h->stream));
+	Counters *dc = h->counters.as<Counters>();
+	const uint64_t total = (uint64_t)n_q * 16 * NW;
+	hipLaunchKernelGGL(k_build_peq, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
+		h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), (const uint32_t *)nullptr, n_q, NW, h->mm, h->peq.as<uint32_t>());
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(h->ev[0], h->stream));
+	launch_myers(h, cls, (uint32_t)std::min<uint64_t>((n_pairs + 15) / 16, (uint64_t)h->n_cu * 8), h->pairs.as<uint2>(), nullptr, n_pairs, 0, nullptr,
+		nullptr, nullptr, 0, nullptr, h->mins.as<uint8_t>(), dc);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(h->ev[1], h->stream));
+	HIPCHK(hipMemcpyAsync(mins, h->mins.p, n_pairs * 16, hipMemcpyDeviceToHost, h->stream));
+	Counters hc;
+	HIPCHK(hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	h->stats.n_queries = n_q; h->stats.n_pairs = n_pairs; h->stats.n_columns = hc.col_sum; h->stats.myers_launches = 1;
+	h->stats.bytes_algorithmic = 8ull * hc.col_sum + hc.qlen_sum / 2 + 192ull * n_pairs;
+	h->stats.ms_myers = ev_ms(h->ev[0], h->ev[1]); h->stats.ms_total = h->stats.ms_myers;
+	return BHIP_OK;
+}
+
+extern "C" int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac, uint32_t n_q,
+                              uint32_t *out_q, uint32_t *out_clump, uint32_t *out_count, uint64_t cap, uint64_t *n_out) {
+	Handle *h = (Handle *)handle;
+	if (!h || !q_codes || !q_off || !q_emac || !n_out) return fail(BHIP_E_ARG, "null argument");
+	if (!h->has_acx) return fail(BHIP_E_ARG, "handle has no accelerator");
+	*n_out = 0;
+	if (!n_q) return BHIP_OK;
+	HIPCHK(hipSetDevice(h->device));
+	for (int attempt = 0; attempt < 4; ++attempt) {
+		int rc;
+		if ((rc = upload_queries(h, q_codes, q_off, q_emac, nullptr, nullptr, n_q))) return rc;
+		if ((rc = h->cand.reserve(h->cand_cap * sizeof(uint2)))) return rc;
+		if ((rc = h->candcnt.reserve(h->cand_cap * sizeof(uint32_t)))) return rc;
+		HIPCHK(hipMemsetAsync(h->counters.p, 0, sizeof(Counters), h->stream));
+		Counters *dc = h->counters.as<Counters>();
+		HIPCHK(hipEventRecord(h->ev[0], h->stream));
+		if ((rc = launch_prefilter(h, nullptr, n_q, h->cand.as<uint2>(), h->candcnt.as<uint32_t>(), (uint32_t)h->cand_cap, false, dc))) return rc;
+		HIPCHK(hipEventRecord(h->ev[1], h->stream));
+		Counters hc;
+		HIPCHK(hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		if (hc.n_cand > h->cand_cap) { h->cand_cap = (uint64_t)hc.n_cand + 1024; continue; }
+		*n_out = hc.n_cand;
+		memset(&h->stats, 0, sizeof h->stats);
+		h->stats.n_queries = n_q; h->stats.n_pairs = hc.n_cand; h->stats.acx_entries_read = hc.ent_read; h->stats.ms_prefilter = ev_ms(h->ev[0], h->ev[1]);
+		if (hc.n_cand > cap) return fail(BHIP_E_CAPACITY, "candidate buffer holds %llu, %u needed", (unsigned long long)cap, hc.n_cand);
+		std::vector<uint2> c(hc.n_cand); std::vector<uint32_t> cc(hc.n_cand);
+		if (hc.n_cand) {
+			HIPCHK(hipMemcpy(c.data(), h->cand.p, hc.n_cand * sizeof(uint2), hipMemcpyDeviceToHost));
+			HIPCHK(hipMemcpy(cc.data(), h->candcnt.p, hc.n_cand * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		}
+		std::vector<uint32_t> ord(hc.n_cand);
+		for (uint32_t i = 0; i < hc.n_cand; ++i) ord[i] = i;
+		std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return c[a].x != c[b].x ? c[a].x < c[b].x : c[a].y < c[b].y; });
+		for (uint32_t i = 0; i < hc.n_cand; ++i) {
+			if (out_q) out_q[i] = c[ord[i]].x;
+			if (out_clump) out_clump[i] = c[ord[i]].y;
+			if (out_count) out_count[i] = cc[ord[i]];
+		}
+		return BHIP_OK;
+	}
+	return fail(BHIP_E_INTERNAL, "candidate buffer kept overflowing");
+}

@@ -1,0 +1,415 @@
+// burst_amd/csrc/bhip_kernels.hip -- gfx950 (MI355X) kernels of the BURST alignment hot path.
+//
+// What the reference computes with 16-lane SSE rows (burst.c:1003-1204 aded_*, 713-886 reScoreM_*,
+// 3238-3282 postScour*) is re-designed here for 64-wide wavefronts:
+//
+//   k_transpose_refs : .edx clump area (16 lanes interleaved per byte, burst.c:2810-2824) -> device layout
+//                      [clump][chunk of 32 positions][lane][16 B], so that a 16-lane group streams 256
+//                      contiguous bytes per load and each thread owns one reference lane.
+//   k_build_peq      : per query, 16 match bit-vectors (one per reference symbol) from the 16x16 cost table.
+//   k_prefilter      : one workgroup per query; k-mer words -> .acx lists -> dense per-clump counters in LDS
+//                      (global memory for very large DBs) -> candidate (query, clump) pairs.
+//   k_myers<NW>      : one thread per (query, reference lane); Myers/Hyyro bit-parallel semi-global edit
+//                      distance over NW 32-bit words (carry chains via v_addc_co_u32); 16-lane group = one
+//                      (query, clump) unit = one aded_mat16 call.  Emits ed, first/last end column of the minimum.
+//   k_rescore        : one thread per surviving hit; 3-plane (score, gapQ, gapR) DP restricted to the
+//                      diagonals that can reach a minimal end cell, with the reference's exact tie-breaks.
+//
+// No MFMA: the recurrence is integer min-plus / bit logic (VALU + LDS bound).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "burst_hip.h"
+#include "bhip_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// DB upload: byte transpose of the .edx clump area
+// src: for clump c, rows j = 0..ceil(L/2)-1 of 16 bytes (byte z = lane z, nibbles = positions 2j, 2j+1)
+// dst: for clump c, chunk t, lane z: 16 bytes, byte i = src row (16t+i) byte z  (zero beyond the clump)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_transpose_refs(const uint8_t *__restrict__ src, const uint64_t *__restrict__ src_off,
+                                 const uint32_t *__restrict__ clump_len, const uint64_t *__restrict__ dst_off,
+                                 uint32_t n_clumps, uint4 *__restrict__ dst) {
+	// one 16-thread group per (clump, chunk); grid-stride over clumps
+	const uint32_t z = threadIdx.x & 15, g = threadIdx.x >> 4, gpb = blockDim.x >> 4;
+	for (uint32_t c = blockIdx.x; c < n_clumps; c += gridDim.x) {
+		const uint32_t L = clump_len[c], nrows = (L + 1) >> 1, nchunks = (L + 31) >> 5;
+		const uint8_t *s = src + src_off[c] * 16;
+		for (uint32_t t = g; t < nchunks; t += gpb) {
+			uint32_t w[4] = {0, 0, 0, 0};
+			#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				uint32_t row = 16 * t + i;
+				uint32_t b = row < nrows ? s[(uint64_t)row * 16 + z] : 0u;
+				w[i >> 2] |= b << (8 * (i & 3));
+			}
+			dst[(dst_off[c] + t) * 16 + z] = make_uint4(w[0], w[1], w[2], w[3]);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Match bit-vectors (DIAGSC_MAT16, burst.c:700: SCOREFAST[qLet] shuffled by the reference symbol).
+// The query is TOP-aligned in its NW x 32-bit vector: query symbol i lives at bit i + (32*NW - len), so the
+// last symbol is always bit 31 of word NW-1 and k_myers needs no per-query bit index.  The low 32*NW - len
+// "filler rows" match every symbol and start with vertical delta 0, which keeps them identically 0 = the
+// free-start boundary row D[0][x] = 0 of the reference (burst.c:4052 calloc'd row 0).
+// peq[(li*16 + c)*NW + w] bit k = 1 iff k is a filler row or cost(query[32w+k-shift], c) == 0.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_build_peq(const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff,
+                            const uint32_t *__restrict__ qlist, uint32_t n_list, int NW,
+                            BhipMatchMask mm, uint32_t *__restrict__ peq) {
+	const uint64_t total = (uint64_t)n_list * 16 * NW;
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t w = i % NW, c = (i / NW) & 15, li = i / ((uint64_t)NW * 16);
+		const uint32_t q = qlist ? qlist[li] : li;
+		const uint64_t b = qoff[q];
+		const int len = (int)(qoff[q + 1] - b), shift = 32 * NW - len;
+		uint32_t bits = 0;
+		for (int k = 0; k < 32; ++k) {
+			const int pos = 32 * (int)w + k - shift;
+			const uint32_t bit = pos < 0 ? 1u : ((mm.m[qcodes[b + pos] & 15] >> c) & 1u);
+			bits |= bit << k;
+		}
+		peq[((uint64_t)li * 16 + c) * NW + w] = bits;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prefilter (burst.c:4096-4133 + postScour 3238-3282, per query instead of per bunch of 16).
+// counter[c] = number of query k-mer positions whose word occurs in clump c.  A clump is a candidate iff
+// counter > mmatch, mmatch = max(len - (E+1)K, 0): every alignment with <= E edits keeps at least
+// len-K+1-E*K = mmatch+1 intact words (burst.c:4091-4092, 4163-4164), so no valid clump is dropped.
+// Words containing a symbol outside A/C/G/T are skipped here; the host routes such queries to the
+// exhaustive path.
+// ------------------------------------------------------------------------------------------------
+template <bool LDS_CNT>
+__global__ __launch_bounds__(256) void k_prefilter(
+		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint16_t *__restrict__ qemac,
+		const uint32_t *__restrict__ qlist, uint32_t n_list,
+		const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, int K, uint32_t n_clumps,
+		uint32_t *__restrict__ g_cnt, const uint32_t *__restrict__ bad, uint32_t n_bad,
+		uint2 *__restrict__ cand, uint32_t *__restrict__ cand_cnt_out, uint32_t *__restrict__ n_cand, uint32_t cand_cap,
+		unsigned long long *__restrict__ ent_read) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];
+	const uint32_t nw32 = (n_clumps + 1) >> 1;
+	uint32_t *cnt = LDS_CNT ? s_cnt : g_cnt + (uint64_t)blockIdx.x * nw32;
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
+	unsigned long long my_ent = 0;
+	for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+		const uint32_t q = qlist ? qlist[li] : li;
+		const uint64_t b = qoff[q];
+		const uint32_t len = (uint32_t)(qoff[q + 1] - b), E = qemac[q];
+		for (uint32_t i = tid; i < nw32; i += 256) cnt[i] = 0;
+		__syncthreads();
+		if (len >= (uint32_t)K) {
+			const uint32_t nwords = len - K + 1;
+			// 64 word positions per wave pass: lane j builds the word starting at base+j
+			for (uint32_t base = wave * 64; base < nwords; base += 256) {
+				const uint32_t p = base + lane;
+				uint32_t w = 0, ok = p < nwords;
+				if (ok) for (int k = 0; k < K; ++k) {
+					uint32_t c = qcodes[b + p + k];
+					ok &= (c - 1u) < 4u;
+					w = (w << 2) | ((c - 1u) & 3u);
+				}
+				w &= wmask;
+				uint32_t beg = 0, end = 0;
+				if (ok) beg = acx_off[w], end = acx_off[w + 1];
+				my_ent += end - beg;
+				// short lists: each lane walks its own; long lists: the wave walks them together
+				const uint32_t n = end - beg;
+				unsigned long long longm = __ballot(n > 32);
+				if (n <= 32) for (uint32_t e = beg; e < end; ++e) {
+					uint32_t c = acx_ent[e];
+					atomicAdd(&cnt[c >> 1], 1u << ((c & 1) * 16));
+				}
+				while (longm) {
+					const int src = __builtin_ctzll(longm);
+					longm &= longm - 1;
+					const uint32_t lb = __shfl(beg, src), le = __shfl(end, src);
+					for (uint32_t e = lb + lane; e < le; e += 64) {
+						uint32_t c = acx_ent[e];
+						atomicAdd(&cnt[c >> 1], 1u << ((c & 1) * 16));
+					}
+				}
+			}
+		}
+		__syncthreads();
+		const uint32_t kload = E * K + K, mmatch = kload < len ? len - kload : 0;
+		for (uint32_t c = tid; c < n_clumps; c += 256) {
+			const uint32_t v = (cnt[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu;
+			if (v > mmatch) {
+				const uint32_t pos = atomicAdd(n_cand, 1u);
+				if (pos < cand_cap) { cand[pos] = make_uint2(li, c); if (cand_cnt_out) cand_cnt_out[pos] = v; }
+			}
+		}
+		for (uint32_t i = tid; i < n_bad; i += 256) {          // burst.c:4136-4138, 4282-4283
+			const uint32_t pos = atomicAdd(n_cand, 1u);
+			if (pos < cand_cap) { cand[pos] = make_uint2(li, bad[i]); if (cand_cnt_out) cand_cnt_out[pos] = 0xFFFFFFFFu; }
+		}
+		__syncthreads();
+	}
+	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
+}
+
+template __global__ void k_prefilter<true>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
+	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *);
+template __global__ void k_prefilter<false>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
+	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *);
+
+
+// ------------------------------------------------------------------------------------------------
+// Bit-parallel semi-global edit distance (Myers 1999 / Hyyro 2003), NW x 32-bit words per DP column.
+// State per (query, reference lane): vertical deltas Pv/Mv of the current column; the tracked score is
+// D[m][x] = min over start positions of the edit distance of the query against ref[..x], i.e. the last-row
+// cell of the reference's recurrence (burst.c:1155-1159 with D[0][x]=0, D[y][0]=y).  Its minimum over x is
+// MinA[lane] of aded_mat16 (burst.c:1187-1192).  Pad symbols (code 0) match nothing but filler rows;
+// trailing pads cannot lower the minimum.
+// ------------------------------------------------------------------------------------------------
+template <int NW>
+__device__ __forceinline__ void myers_step(const uint32_t (&Eq)[NW], uint32_t (&Pv)[NW], uint32_t (&Mv)[NW], int &score) {
+	uint32_t Ph[NW], Mh[NW];
+	uint32_t carry = 0;
+	#pragma unroll
+	for (int w = 0; w < NW; ++w) {
+		uint32_t co;
+		const uint32_t s = __builtin_addc(Eq[w] & Pv[w], Pv[w], carry, &co);
+		carry = co;
+		const uint32_t Xh = (s ^ Pv[w]) | Eq[w];
+		Ph[w] = Mv[w] | ~(Xh | Pv[w]);
+		Mh[w] = Pv[w] & Xh;
+	}
+	score += (int)(Ph[NW - 1] >> 31) - (int)(Mh[NW - 1] >> 31);
+	// shift the horizontal deltas down one row; the delta entering the first row is 0 (free start)
+	#pragma unroll
+	for (int w = NW - 1; w >= 0; --w) {
+		const uint32_t Phs = w ? __builtin_amdgcn_alignbit(Ph[w], Ph[w - 1], 31) : Ph[0] << 1;
+		const uint32_t Mhs = w ? __builtin_amdgcn_alignbit(Mh[w], Mh[w - 1], 31) : Mh[0] << 1;
+		const uint32_t Xv = Eq[w] | Mv[w];
+		Pv[w] = Mhs | ~(Xv | Phs);
+		Mv[w] = Phs & Xv;
+	}
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void k_myers(
+		const uint2 *__restrict__ pairs, const uint32_t *__restrict__ n_pairs_dev, uint64_t n_pairs_host,
+		uint32_t n_clumps_implicit,        // pairs == nullptr: p -> (list position li_base + p / n_clumps, clump p % n_clumps)
+		uint32_t li_base,
+		const uint32_t *__restrict__ qlist, // list position -> batch query index (nullptr: identity)
+		const uint32_t *__restrict__ peq, const uint64_t *__restrict__ qoff, const uint16_t *__restrict__ qemac,
+		const uint32_t *__restrict__ qsix,
+		const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
+		uint32_t tot_refs,
+		BhipRawHit *__restrict__ raw, uint32_t *__restrict__ n_raw, uint32_t raw_cap, uint32_t *__restrict__ best,
+		uint8_t *__restrict__ mins_out, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum) {
+	// per 16-lane group: 16 symbol rows of NW words; rows rotated by 4*(group&3) so that the two groups a
+	// ds_read_b128 service set can mix never collide on the A/C/G/T rows
+	__shared__ __attribute__((aligned(16))) uint32_t s_peq[16][16 * NW];
+	const uint32_t tid = threadIdx.x, g = tid >> 4, z = tid & 15, rot = 4 * (g & 3);
+	const uint64_t n_pairs = n_pairs_dev ? (uint64_t)*n_pairs_dev : n_pairs_host;
+	const uint64_t n_tiles = (n_pairs + 15) >> 4;
+	unsigned long long my_cols = 0, my_qlen = 0;
+	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint64_t p = tile * 16 + g;
+		const bool live = p < n_pairs;
+		uint32_t li = 0, c = 0;
+		if (live) {
+			if (pairs) { const uint2 pr = pairs[p]; li = pr.x; c = pr.y; }
+			else { li = li_base + (uint32_t)(p / n_clumps_implicit); c = (uint32_t)(p % n_clumps_implicit); }
+		}
+		__syncthreads();   // the previous tile's tables are no longer in use
+		if (live) {
+			const uint32_t *src = peq + ((uint64_t)li * 16 + z) * NW;
+			uint32_t *dstrow = &s_peq[g][((z + rot) & 15) * NW];
+			#pragma unroll
+			for (int w = 0; w < NW; ++w) dstrow[w] = src[w];
+		}
+		__syncthreads();
+		if (!live) continue;
+		const uint32_t q = qlist ? qlist[li] : li;
+		const uint32_t m = (uint32_t)(qoff[q + 1] - qoff[q]), E = qemac[q];
+		const uint32_t L = clump_len[c], nchunks = (L + 31) >> 5;
+		// column 0: D[y][0] = y on the query rows (delta +1), 0 on the filler rows
+		uint32_t Pv[NW], Mv[NW];
+		#pragma unroll
+		for (int w = 0; w < NW; ++w) {
+			const int lo = 32 * NW - (int)m - 32 * w;   // first query bit within this word
+			Pv[w] = lo <= 0 ? 0xFFFFFFFFu : (lo >= 32 ? 0u : (0xFFFFFFFFu << lo));
+			Mv[w] = 0;
+		}
+		int score = (int)m, bestS = 0x7FFFFFFF;
+		uint32_t first = 0, last = 0;
+		const uint4 *rp = ref + ref_off[c] * 16 + z;
+		const uint32_t *tab = &s_peq[g][0];
+		for (uint32_t t = 0; t < nchunks; ++t) {
+			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
+			#pragma unroll
+			for (int i = 0; i < 32; ++i) {
+				const uint32_t sym = (dw[i >> 3] >> (4 * (i & 7))) & 15u;
+				const uint32_t *row = tab + ((sym + rot) & 15u) * NW;
+				uint32_t Eq[NW];
+				#pragma unroll
+				for (int w = 0; w < NW; ++w) Eq[w] = row[w];
+				myers_step<NW>(Eq, Pv, Mv, score);
+				const uint32_t col = t * 32 + i + 1;
+				const bool lt = score < bestS, le = score <= bestS;
+				bestS = lt ? score : bestS;
+				first = lt ? col : first;
+				last = le ? col : last;
+			}
+		}
+		const uint32_t refIx = c * 16 + z;
+		const bool hit = (uint32_t)bestS <= E && refIx < tot_refs;
+		if (mins_out) mins_out[p * 16 + z] = (uint32_t)bestS <= E ? (uint8_t)bestS : (uint8_t)255;
+		if (hit && raw) {
+			const uint32_t pos = atomicAdd(n_raw, 1u);
+			if (pos < raw_cap) {
+				BhipRawHit h; h.q = q; h.refIx = refIx; h.ed = (uint32_t)bestS; h.e_first = first; h.e_last = last;
+				raw[pos] = h;
+			}
+			if (best) atomicMin(&best[qsix ? qsix[q] : q], (uint32_t)bestS);
+		}
+		if (z == 0) { my_cols += L; my_qlen += m; }
+	}
+	if (col_sum && my_cols) { atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
+}
+
+#define BHIP_INST_MYERS(NW) \
+	template __global__ void k_myers<NW>(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *, \
+		const uint64_t *, const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t, \
+		BhipRawHit *, uint32_t *, uint32_t, uint32_t *, uint8_t *, unsigned long long *, unsigned long long *);
+BHIP_INST_MYERS(2) BHIP_INST_MYERS(4) BHIP_INST_MYERS(6) BHIP_INST_MYERS(8) BHIP_INST_MYERS(10)
+BHIP_INST_MYERS(16) BHIP_INST_MYERS(32)
+
+// ------------------------------------------------------------------------------------------------
+// Re-scoring (reScoreM_mat16, burst.c:713-886; scalar spec in SURVEY.md Appendix C).  One thread per hit.
+// Only the diagonals x - y in [e_first - m - B, e_last - m + B] can hold an ancestor of a final cell with
+// score <= B (every gap costs 1), so the three planes (score D, gapQ "shift" H, gapR "shiftR" V) are kept
+// for that band only, one packed word (D | H<<8 | V<<16) per diagonal, updated in place row by row:
+//   diag pred = band[k] (previous row), up pred = band[k+1] (previous row), left pred = carried register.
+// Cells outside the band or the matrix count as 255; cells >= B+1 are forced to 255 (burst.c:802-803).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sat8u(uint32_t v) { return v > 255u ? 255u : v; }
+
+__device__ __forceinline__ uint32_t ref_code(const uint8_t *__restrict__ refb, uint64_t clump_base, uint32_t z, uint32_t pos0) {
+	const uint8_t b = refb[((clump_base + (pos0 >> 5)) * 16 + z) * 16 + ((pos0 & 31) >> 1)];
+	return (pos0 & 1) ? (uint32_t)(b >> 4) : (uint32_t)(b & 15);
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(64) void k_rescore(
+		const BhipRawHit *__restrict__ raw, const uint32_t *__restrict__ n_raw_dev, uint32_t raw_cap,
+		const uint32_t *__restrict__ wide_in, const uint32_t *__restrict__ n_wide_in,
+		const uint32_t *__restrict__ best, int all_hits,
+		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff,
+		const uint32_t *__restrict__ qsix, const uint8_t *__restrict__ qrc,
+		const uint8_t *__restrict__ refb, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
+		const uint8_t *__restrict__ lut,
+		BhipHit *__restrict__ out, uint32_t *__restrict__ n_out, uint32_t out_cap,
+		uint32_t *__restrict__ wide_out, uint32_t *__restrict__ n_wide_out,
+		uint32_t *__restrict__ g_scratch, unsigned long long *__restrict__ scratch_used, unsigned long long scratch_cap,
+		uint32_t *__restrict__ err_flags) {
+	__shared__ uint32_t s_band[WIDE ? 1 : (BHIP_RESCORE_WMAX + 1)][64];
+	uint32_t n = WIDE ? *n_wide_in : *n_raw_dev;
+	if (!WIDE && n > raw_cap) n = raw_cap;
+	const uint32_t tid = threadIdx.x;
+	for (uint32_t i = blockIdx.x * 64 + tid; i < n; i += gridDim.x * 64) {
+		const BhipRawHit h = raw[WIDE ? wide_in[i] : i];
+		const uint32_t q = h.q, six = qsix ? qsix[q] : q;
+		if (!all_hits && h.ed != best[six]) continue;
+		const uint32_t B = h.ed, c = h.refIx >> 4, z = h.refIx & 15, L = clump_len[c];
+		const uint64_t qb = qoff[q];
+		const int m = (int)(qoff[q + 1] - qb);
+		const int e1 = (int)h.e_first, e2 = (int)(h.e_last < L ? h.e_last : L);
+		const int dlo = e1 - m - (int)B, dhi = e2 - m + (int)B, Wd = dhi - dlo + 1;
+		uint32_t *band; uint32_t stride;
+		if (!WIDE) {
+			if (Wd > BHIP_RESCORE_WMAX) {   // rare (repeats inside one shear): defer to the global-scratch variant
+				const uint32_t pos = atomicAdd(n_wide_out, 1u);
+				wide_out[pos] = i;
+				continue;
+			}
+			band = &s_band[0][tid]; stride = 64;
+		} else {
+			const unsigned long long off = atomicAdd(scratch_used, (unsigned long long)(Wd + 1));
+			if (off + Wd + 1 > scratch_cap) { atomicOr(err_flags, 2u); continue; }
+			band = g_scratch + off; stride = 1;
+		}
+		const uint64_t cbase = ref_off[c];
+		const uint32_t INVALID = 255u;
+		// row 0: D = 0 wherever the column exists (burst.c:4052), else invalid
+		for (int k = 0; k <= Wd; ++k) {
+			const int x = dlo + k;
+			band[(uint32_t)k * stride] = (k < Wd && x >= 0 && x <= (int)L) ? 0u : INVALID;
+		}
+		for (int y = 1; y <= m; ++y) {
+			const uint32_t qc = qcodes[qb + y - 1];
+			const uint8_t *lrow = lut + 16 * qc;
+			const uint32_t col0 = sat8u((uint32_t)y) | (sat8u((uint32_t)y) << 16);   // D=y, H=0, V=y (burst.c:747-750)
+			const int x0 = y + dlo;
+			uint32_t left = (x0 - 1 == 0) ? col0 : INVALID;
+			for (int k = 0; k < Wd; ++k) {
+				const int x = x0 + k;
+				const uint32_t dg = band[(uint32_t)k * stride], up = band[(uint32_t)(k + 1) * stride];
+				uint32_t cell;
+				if (x < 1) cell = (x == 0) ? col0 : INVALID;
+				else if (x > (int)L) cell = INVALID;
+				else {
+					const uint32_t cst = lrow[ref_code(refb, cbase, z, (uint32_t)(x - 1))];
+					if (y == 1) {   // burst.c:722-739
+						uint32_t hh = 0;
+						if (cst == 1 && x >= 2) hh = lrow[ref_code(refb, cbase, z, (uint32_t)(x - 2))] == 0;
+						cell = cst | (hh << 8);
+					} else {
+						const uint32_t sD = sat8u((dg & 255u) + cst), hD = (dg >> 8) & 255u, vD = (dg >> 16) & 255u;
+						const uint32_t sU = sat8u((up & 255u) + 1u), hU = (up >> 8) & 255u, vU = sat8u(((up >> 16) & 255u) + 1u);
+						uint32_t s = sD < sU ? sD : sU, hv, vv;
+						const bool keepD = (sD == s) && !((sU == sD) && (hU > hD));          // burst.c:771-779
+						hv = keepD ? hD : hU; vv = keepD ? vD : vU;
+						const uint32_t sL = sat8u((left & 255u) + 1u), hL = sat8u(((left >> 8) & 255u) + 1u), vL = (left >> 16) & 255u;
+						const uint32_t s2 = s < sL ? s : sL;
+						const bool keep = (s == s2) && !((sL == s) && (hL > hv));            // burst.c:789-798
+						hv = keep ? hv : hL; vv = keep ? vv : vL;
+						s = s2 >= B + 1 ? 255u : s2;                                          // burst.c:802-803
+						cell = s | (hv << 8) | (vv << 16);
+					}
+				}
+				band[(uint32_t)k * stride] = cell;
+				left = cell;
+			}
+		}
+		// final selection over the last row (burst.c:824-842) and end position (862-879)
+		uint32_t bs = 255, bh = 0, bv = 0, fin = 0xFFFFFFFFu;
+		for (int k = 0; k < Wd; ++k) {
+			const int x = m + dlo + k;
+			if (x < 1 || x > (int)L) continue;
+			const uint32_t cell = band[(uint32_t)k * stride], s = cell & 255u, hh = (cell >> 8) & 255u;
+			if (s < bs || (s == bs && hh > bh)) { bs = s; bh = hh; bv = (cell >> 16) & 255u; }
+		}
+		for (int k = 0; k < Wd; ++k) {
+			const int x = m + dlo + k;
+			if (x < 1 || x > (int)L) continue;
+			const uint32_t cell = band[(uint32_t)k * stride];
+			if ((cell & 255u) == bs && ((cell >> 8) & 255u) == bh) fin = (uint32_t)x;
+		}
+		if (bs != B) { atomicOr(err_flags, 1u); continue; }   // the reference would abort here (burst.c:812-816)
+		const uint32_t pos = atomicAdd(n_out, 1u);
+		if (pos < out_cap) {
+			BhipHit o;
+			o.q = q; o.refIx = h.refIx; o.finalPos = fin;
+			o.score = 1.0f - (float)bs / ((float)m + (float)bh);                                  // burst.c:844-847
+			o.ed = (uint8_t)B; o.gapR = (uint8_t)bv; o.gapQ = (uint8_t)bh; o.rc = qrc ? qrc[q] : 0;
+			out[pos] = o;
+		}
+	}
+}
+
+template __global__ void k_rescore<false>(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, int,
+	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *,
+	BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long, uint32_t *);
+template __global__ void k_rescore<true>(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, int,
+	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *,
+	BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long, uint32_t *);

@@ -1,0 +1,124 @@
+/* include/burst_hip.h -- C ABI of libburst_hip.so, the MI355X (gfx950) device side of the BURST
+ * alignment hot path.  Plain pointers and sizes only; no C++ or torch types cross this line.
+ *
+ * The reference (knights-lab/BURST, burst.c @ 2024_08_07) has no plugin/FFI interface; what this
+ * library replaces are the four kernel call sites inside do_alignments() and the k-mer scour block:
+ *
+ *   aded_mat16L(...)                burst.c:4215   \  banded edit distance of one query vs one 16-lane clump
+ *   aded_mat16 / aded_xalpha(...)   burst.c:4423-4426 /  -> bhip_align_batch (kernel "myers"), bhip_align_pairs
+ *   reScoreM_mat16 / _xalpha(...)   burst.c:4226, 4439-4442  -> bhip_align_batch (kernel "rescore")
+ *   qsort + postScour + selection   burst.c:4096-4133, 3238-3282 -> bhip_align_batch (kernel "prefilter"),
+ *                                                                   bhip_prefilter
+ *   4-bit clump unpack              burst.c:4141-4150          -> folded into bhip_init (device layout)
+ *
+ * Conventions mirror those call sites: the caller owns every host buffer, the library owns device
+ * memory, failures are return codes (never exit()), a handle is single-threaded, one handle per device.
+ * Return values: 0 = ok, negative = BHIP_E_*; bhip_last_error() gives the text.
+ */
+#ifndef BURST_HIP_H
+#define BURST_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BHIP_OK            0
+#define BHIP_E_ARG        -1   /* invalid argument */
+#define BHIP_E_DEVICE     -2   /* HIP runtime error (no device, OOM, launch failure) */
+#define BHIP_E_CAPACITY   -3   /* caller's hit buffer too small: *n_hits holds the required count */
+#define BHIP_E_QUERYLEN   -4   /* query longer than BHIP_MAX_QLEN */
+#define BHIP_E_INTERNAL   -5
+
+#define BHIP_MAX_QLEN   1024   /* bit-vector kernels are instantiated up to 32 x 32-bit words */
+
+/* One alignment result = ResultPod (burst.c:3998-4004) minus the list pointer, plus the query index. */
+typedef struct BhipHit {
+	uint32_t q;         /* index of the query entry in the batch (forward or reverse-complement entry) */
+	uint32_t refIx;     /* 16*clump + lane, burst.c:4234 */
+	uint32_t finalPos;  /* MetaPack.finalPos, burst.c:862-883: 1-based end column in the sheared reference */
+	float    score;     /* MetaPack.score, burst.c:844-860: 1 - ed/(len + numGapQ), IEEE f32 division */
+	uint8_t  ed;        /* ResultPod.mismatches = MinA[lane], burst.c:4232 */
+	uint8_t  gapR;      /* numGapR */
+	uint8_t  gapQ;      /* numGapQ */
+	uint8_t  rc;        /* strand of the query entry, burst.c:4238 */
+} BhipHit;              /* 20 bytes */
+
+/* Query flags (q_flags[i]) */
+#define BHIP_Q_PREFILTER   0   /* candidate clumps come from the .acx prefilter + BadList (burst.c:4078-4284) */
+#define BHIP_Q_EXHAUSTIVE  1   /* align against every clump (burst.c:4320-4488: no -a, or "bad"-bin queries) */
+
+/* Counters and timings of the most recent bhip_align_batch / bhip_align_pairs call on a handle.
+ * Times are HIP-event milliseconds measured on the library's own stream. */
+typedef struct BhipStats {
+	uint64_t n_queries;        /* query entries in the call */
+	uint64_t n_pairs;          /* (query, clump) units of work aligned */
+	uint64_t n_columns;        /* sum over pairs of ClumpLen: DP columns swept (x16 lanes x qlen rows of cells) */
+	uint64_t n_raw_hits;       /* (query, ref) lanes with ed <= budget */
+	uint64_t n_hits;           /* records returned */
+	uint64_t acx_entries_read; /* list entries gathered by the prefilter */
+	uint64_t bytes_algorithmic;/* per-launch algorithmic bytes of the myers kernel */
+	float ms_h2d, ms_prefilter, ms_peq, ms_myers, ms_rescore, ms_d2h, ms_total;
+	uint32_t myers_launches;
+	uint32_t reserved;
+} BhipStats;
+
+/* Upload a database to device `device` and create a handle.
+ *   edx_packed : the clump area of an .edx exactly as on disk (burst.c:2810-2824): for clump c,
+ *                ceil(clump_len[c]/2) 16-byte words; byte k of a word = lane k; low nibble = even position.
+ *   clump_len  : ClumpLen[n_clumps] (burst.c:2918);  tot_refs = totR (lanes >= tot_refs never hit, burst.c:4229)
+ *   acx_lens   : Lens[4^K] of the .acx (burst.c:3558) or NULL when no accelerator is used
+ *   acx_lists  : the packed list area (burst.c:3569); acx_fmt 0 = SMALL 20-bit pairs (3265-3274), 1 = LARGE 24-bit (3245-3248)
+ *   badlist    : BadList[n_bad] (burst.c:3571): clumps every prefiltered query must be aligned against
+ *   score_lut  : 16x16 cost table lut[16*q + r] in {0,1,255} = SCOREFAST after setScore() (burst.c:1310-1328)
+ *   xalpha     : must be 0 (alphabet-agnostic -x mode is not implemented on the device)
+ */
+int bhip_init(int device, const void *edx_packed, const uint32_t *clump_len, uint32_t n_clumps, uint32_t tot_refs,
+              const uint32_t *acx_lens, const void *acx_lists, int acx_fmt, int K,
+              const uint32_t *badlist, uint32_t n_bad,
+              const uint8_t score_lut[256], int xalpha, void **handle);
+
+/* Prefilter + banded edit distance + re-scoring for a batch of query entries (the body of the OpenMP
+ * loops burst.c:4077-4289 and 4343-4484).
+ *   q_codes : concatenated 1-byte symbol codes (0..15, burst.c:1288-1307), entry i = [q_off[i], q_off[i+1])
+ *   q_emac  : per-entry error budget (ShrBin.ed, burst.c:3074-3076)
+ *   q_six   : per-entry shared slot (UniBin.six, burst.c:3078, 3106): a forward entry and its reverse
+ *             complement carry the same value in [0, n_shared) and share the running minimum (burst.c:4218-4220)
+ *   q_rc    : per-entry strand flag copied into BhipHit.rc
+ *   q_flags : BHIP_Q_PREFILTER / BHIP_Q_EXHAUSTIVE per entry (NULL = all exhaustive when the handle has no
+ *             accelerator, all prefiltered otherwise)
+ *   all_hits: 0 = BEST/ALLPATHS/CAPITALIST semantics (only lanes with ed == minimum over the shared slot),
+ *             1 = FORAGE semantics (every lane with ed <= budget, burst.c:4224)
+ *   hits/cap: caller's buffer; on BHIP_E_CAPACITY *n_hits is the number required and nothing is returned.
+ * Records are returned sorted by (q, refIx). */
+int bhip_align_batch(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
+                     const uint32_t *q_six, const uint8_t *q_rc, const uint8_t *q_flags,
+                     uint32_t n_q, uint32_t n_shared, int all_hits,
+                     BhipHit *hits, uint64_t cap, uint64_t *n_hits);
+
+/* Kernel-level entry (what one aded_mat16 call returns, burst.c:1078-1094): for explicit (query, clump)
+ * pairs, mins[16*p + z] = edit distance of lane z (255 when > budget of the pair's query). */
+int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
+                     uint32_t n_q, const uint32_t *pair_q, const uint32_t *pair_clump, uint64_t n_pairs,
+                     uint8_t *mins);
+
+/* Kernel-level entry for the prefilter alone: candidate (query, clump, count) triples with
+ * count > max(len-(E+1)K, 0) (burst.c:4091-4092, 4126), BadList clumps not included.
+ * Output sorted by (q, clump).  On BHIP_E_CAPACITY *n_out is the number required. */
+int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
+                   uint32_t n_q, uint32_t *out_q, uint32_t *out_clump, uint32_t *out_count,
+                   uint64_t cap, uint64_t *n_out);
+
+/* Stats of the last call; device properties (name, CU count) for reports. */
+int bhip_get_stats(void *handle, BhipStats *out);
+int bhip_device_info(void *handle, char *name, int name_cap, int *n_cu, uint64_t *hbm_bytes);
+
+void bhip_destroy(void *handle);
+const char *bhip_last_error(void);
+/* ABI version of this header */
+int bhip_abi_version(void);
+#define BHIP_ABI_VERSION 1
+
+#ifdef __cplusplus
+}
+#endif
+#endif

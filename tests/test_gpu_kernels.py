@@ -1,0 +1,164 @@
+"""Parity of the HIP path (through the C ABI of include/burst_hip.h) against the oracle on seeded inputs.
+Bit-exact: edit distances, hit sets, gap counts, end positions and the f32 identity score."""
+import numpy as np
+import pytest
+
+import dbutil
+import oraclelib as ol
+from burst_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def family_db(seed, n_base, n_var, length, rate=0.03, short=False, iupac=0.0):
+    rng = np.random.default_rng(seed)
+    seqs = []
+    for b in range(n_base):
+        base = rng.integers(1, 5, size=int(length + rng.integers(-20, 20)), dtype=np.uint8)
+        for v in synth.mutate_family(base, n_var, rate, rng):
+            if short and rng.random() < 0.2:
+                v = v[:int(rng.integers(len(v) // 2, len(v)))]
+            if iupac:
+                m = np.flatnonzero(rng.random(len(v)) < iupac)
+                v[m] = rng.integers(5, 16, size=len(m))
+            seqs.append(v)
+    order = rng.permutation(len(seqs))
+    return [seqs[i] for i in order]
+
+
+def budget(thres, n):
+    return int(ol.oracle().orc_error_budget(thres, n))
+
+
+def make_queries(seqs, n, qlen, edits, seed, rc_frac=0.5, iupac=0.0, thres=0.97):
+    """forward entries followed by their reverse complements (the layout process_queries builds, burst.c:3087-3107)"""
+    from burst_amd.capi import Queries
+    reads, _ = synth.make_reads(seqs, n, qlen, edits, seed, rc_frac=rc_frac, iupac_frac=iupac)
+    fwd = reads
+    rcs = [synth.revcomp(r) for r in reads]
+    allq = fwd + rcs
+    E = [budget(thres, len(r)) for r in fwd] * 2
+    six = list(range(n)) * 2
+    rc = [0] * n + [1] * n
+    return Queries(allq, E, six, rc), allq
+
+
+def oracle_hits(packed, clump_len, tot, q, lut, all_hits):
+    return ol.search(packed, clump_len, tot, q.codes, q.off, q.emac.astype(np.uint32), q.six, q.rc, q.n_shared, lut, all_hits)
+
+
+def assert_hits_equal(got, exp):
+    assert len(got) == len(exp), (len(got), len(exp))
+    assert got.tobytes() == exp.tobytes()
+
+
+@pytest.mark.parametrize("qlen,edits,thres,seed", [(100, [0, 1, 2, 3], 0.97, 11), (60, [0, 1], 0.95, 12), (150, [0, 2, 4, 6], 0.95, 13),
+                                                   (292, [0, 3, 9], 0.97, 14), (320, [0, 5, 16], 0.95, 15), (33, [0, 1], 0.9, 16),
+                                                   (128, [1], 0.97, 17), (129, [1], 0.97, 18), (600, [0, 7], 0.98, 19)])
+def test_align_pairs_matches_oracle(qlen, edits, thres, seed):
+    from burst_amd import capi
+    seqs = family_db(seed, 6, 11, qlen + 150, short=True)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lut = ol.score_lut(1)
+    dev = capi.Device(packed, clump_len, tot, lut)
+    q, allq = make_queries(seqs, 24, qlen, edits, seed, thres=thres)
+    nc = len(clump_len)
+    pq = np.repeat(np.arange(q.n, dtype=np.uint32), nc)
+    pc = np.tile(np.arange(nc, dtype=np.uint32), q.n)
+    mins = dev.align_pairs(q, pq, pc)
+    n_le = 0
+    for p in range(len(pq)):
+        rows = dbutil.clump_rows(seqs, int(pc[p]))
+        _, omins = ol.aded_clump(rows, allq[pq[p]], int(q.emac[pq[p]]), lut)
+        assert np.array_equal(mins[p], omins), (p, mins[p], omins)
+        n_le += int((omins != 255).sum())
+    assert n_le > 0
+    st = dev.stats()
+    assert st["n_pairs"] == len(pq) and st["n_columns"] == int(clump_len[pc].sum())
+    dev.close()
+
+
+@pytest.mark.parametrize("all_hits", [False, True])
+@pytest.mark.parametrize("qlen,edits,thres,iupac,seed", [(100, [0, 1, 2, 3, 5], 0.97, 0.0, 21), (292, [0, 4, 9, 12], 0.97, 0.0, 22),
+                                                         (320, [0, 8, 16], 0.95, 0.01, 23), (50, [0, 1, 2], 0.95, 0.03, 24)])
+def test_align_batch_exhaustive_matches_oracle(qlen, edits, thres, iupac, seed, all_hits):
+    from burst_amd import capi
+    seqs = family_db(seed, 5, 13, qlen + 200, short=True, iupac=iupac / 2)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lut = ol.score_lut(1)
+    dev = capi.Device(packed, clump_len, tot, lut)
+    q, _ = make_queries(seqs, 40, qlen, edits, seed, iupac=iupac, thres=thres)
+    got = dev.align_batch(q, all_hits=all_hits)
+    exp = oracle_hits(packed, clump_len, tot, q, lut, all_hits)
+    assert len(exp) > 20
+    assert_hits_equal(got, exp)
+    dev.close()
+
+
+def test_mixed_lengths_and_empty():
+    from burst_amd import capi
+    seqs = family_db(31, 4, 16, 500)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lut = ol.score_lut(1)
+    dev = capi.Device(packed, clump_len, tot, lut)
+    rng = np.random.default_rng(5)
+    reads = []
+    for L in [20, 64, 65, 100, 128, 129, 192, 193, 256, 257, 320, 321, 400, 30, 100, 100]:
+        r, _ = synth.make_reads(seqs, 1, L, [0, 1, 2], int(rng.integers(1 << 30)))
+        reads += r
+    E = [budget(0.96, len(r)) for r in reads]
+    q = capi.Queries(reads, E, list(range(len(reads))), [0] * len(reads))
+    got = dev.align_batch(q)
+    exp = oracle_hits(packed, clump_len, tot, q, lut, False)
+    assert_hits_equal(got, exp)
+    # empty batch
+    q0 = capi.Queries([], [], [], [])
+    assert len(dev.align_batch(q0)) == 0
+    dev.close()
+
+
+@pytest.mark.parametrize("K,fmt", [(8, 0), (9, 1), (12, 0)])
+def test_prefilter_matches_oracle(K, fmt):
+    from burst_amd import capi
+    seqs = family_db(41 + K, 12, 9, 420)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lens, entries, offs = dbutil.build_acx(seqs, K)
+    lists = dbutil.pack_acx_lists(lens, entries, fmt)
+    lut = ol.score_lut(1)
+    dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=lists, acx_fmt=fmt, K=K)
+    q, allq = make_queries(seqs, 30, 100, [0, 1, 2, 3], 43, thres=0.97)
+    oq, oc, on = dev.prefilter(q)
+    exp = []
+    for j in range(q.n):
+        _, counts = ol.prefilter_counts(allq[j], int(q.emac[j]), K, offs, entries, len(clump_len))
+        E = int(q.emac[j]); m = len(allq[j])
+        mm = m - (E * K + K) if E * K + K < m else 0
+        for c in np.flatnonzero(counts > mm):
+            exp.append((j, int(c), int(counts[c])))
+    got = list(zip(oq.tolist(), oc.tolist(), on.tolist()))
+    assert got == exp and len(exp) > 0
+    dev.close()
+
+
+@pytest.mark.parametrize("all_hits", [False, True])
+def test_align_batch_with_accelerator_equals_exhaustive(all_hits):
+    from burst_amd import capi
+    K = 10
+    seqs = family_db(51, 20, 8, 450, short=True)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lens, entries, offs = dbutil.build_acx(seqs, K)
+    lists = dbutil.pack_acx_lists(lens, entries, 0)
+    lut = ol.score_lut(1)
+    nc = len(clump_len)
+    bad = np.array([nc - 1], np.uint32)
+    dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=lists, acx_fmt=0, K=K, badlist=bad)
+    q, _ = make_queries(seqs, 60, 100, [0, 1, 2, 3, 6], 53, thres=0.97)
+    q.flags = np.zeros(q.n, np.uint8)
+    q.flags[::7] = capi.BHIP_Q_EXHAUSTIVE
+    got = dev.align_batch(q, all_hits=all_hits)
+    exp = oracle_hits(packed, clump_len, tot, q, lut, all_hits)
+    assert len(exp) > 30
+    assert_hits_equal(got, exp)
+    st = dev.stats()
+    assert st["n_pairs"] < q.n * nc          # the prefilter really pruned
+    dev.close()
