@@ -30,14 +30,14 @@ def clump_rows(seqs, c):
     return rows
 
 
-def build_acx(seqs, K):
+def build_acx(seqs, K, skip_clumps=()):
     """Word -> sorted unique clump ids for unambiguous words (burst.c:3378-3388).  Returns
     (lens uint32[4^K], entries uint32[...], offs uint64[4^K+1]); words containing a code outside 1..4 are skipped."""
     nw = 1 << (2 * K)
     pairs = []
     for i, s in enumerate(seqs):
         s = np.asarray(s, np.int64)
-        if len(s) < K:
+        if len(s) < K or (i // 16) in skip_clumps:
             continue
         ok = (s >= 1) & (s <= 4)
         v = np.where(ok, s - 1, 0)
@@ -64,7 +64,7 @@ def pack_acx_lists(lens, entries, fmt):
             out += int(e).to_bytes(3, "little")
         return np.frombuffer(bytes(out), np.uint8)
     nz = np.flatnonzero(lens)
-    offs = np.concatenate([[0], np.cumsum(lens)])
+    offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))]).astype(np.int64)
     for w in nz:
         lst = entries[offs[w]:offs[w + 1]]
         for i in range(0, len(lst) - 1, 2):

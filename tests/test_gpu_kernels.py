@@ -146,10 +146,10 @@ def test_align_batch_with_accelerator_equals_exhaustive(all_hits):
     K = 10
     seqs = family_db(51, 20, 8, 450, short=True)
     packed, clump_len, tot = dbutil.pack_clumps(seqs)
-    lens, entries, offs = dbutil.build_acx(seqs, K)
+    nc = len(clump_len)
+    lens, entries, offs = dbutil.build_acx(seqs, K, skip_clumps=(nc - 1,))   # BadList clumps carry no words (burst.c:3432-3437)
     lists = dbutil.pack_acx_lists(lens, entries, 0)
     lut = ol.score_lut(1)
-    nc = len(clump_len)
     bad = np.array([nc - 1], np.uint32)
     dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=lists, acx_fmt=0, K=K, badlist=bad)
     q, _ = make_queries(seqs, 60, 100, [0, 1, 2, 3, 6], 53, thres=0.97)
