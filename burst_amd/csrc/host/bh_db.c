@@ -1,0 +1,454 @@
+/* bh_db.c -- database side of the host: .edx / .acx readers (burst.c:2842-2975, 3535-3594), the direct-FASTA
+ * clumping used when -r is not a database (process_references QUICK path, burst.c:1840-1858, 2109-2190, 2687-2741),
+ * and writers/builders for both formats (dump_edb 2758-2839, make_accelerator 3304-3532) used by the tests and the bench.
+ */
+#include "burst_host.h"
+#include <stdlib.h>
+#include <string.h>
+#include <omp.h>
+
+static void *own(BhDb *db, void *p) { if (p && db->nOwned < 32) db->owned[db->nOwned++] = p; return p; }
+
+void bh_db_free(BhDb *db) {
+	if (!db) return;
+	for (int i = 0; i < db->nOwned; ++i) free(db->owned[i]);
+	memset(db, 0, sizeof *db);
+}
+
+int bh_is_edx(const char *path) {
+	FILE *f = fopen(path, "rb");
+	if (!f) return bh_set_error(BH_E_USAGE, "ERROR: invalid input file.");
+	int c = fgetc(f);
+	fclose(f);
+	if (c == EOF) return bh_set_error(BH_E_USAGE, "ERROR: invalid input file.");
+	return (c & 0x80) ? 1 : 0;
+}
+
+#define RD(ptr, size, n) do { if (fread((ptr), (size), (n), in) != (size_t)(n)) { fclose(in); bh_db_free(db); \
+	return bh_set_error(BH_E_USAGE, "ERROR: truncated database %s", path); } } while (0)
+#define ALLOC(dst, bytes) do { (dst) = own(db, malloc((size_t)(bytes) + 1)); if (!(dst)) { fclose(in); bh_db_free(db); \
+	return bh_set_error(BH_E_OOM, "OOM:read_edb"); } } while (0)
+
+static void derive_refixsrt(BhDb *db) {
+	if (db->refDedupIx) {                                        /* burst.c:3688-3693 */
+		db->refIxSrt = own(db, malloc((size_t)db->totR * sizeof(uint32_t)));
+		for (uint32_t i = 0; i < db->totR; ++i) db->refIxSrt[i] = db->tmpRIX[db->refDedupIx[i]];
+	} else db->refIxSrt = db->tmpRIX;
+}
+
+int bh_edx_read(const char *path, BhDb *db) {
+	memset(db, 0, sizeof *db);
+	FILE *in = fopen(path, "rb");
+	if (!in) return bh_set_error(BH_E_USAGE, "ERROR: cannot parse EDB");
+	int cb = fgetc(in);
+	if (cb == EOF) { fclose(in); return bh_set_error(BH_E_USAGE, "ERROR: invalid input file."); }
+	int ver = cb & 0xF;
+	if (ver == 2) { fclose(in); return bh_set_error(BH_E_IO, "ERROR: Old DB version. Re-make with new version."); }
+	if (ver != 3) { fclose(in); return bh_set_error(BH_E_USAGE, "ERROR: invalid database version %d", ver); }
+	db->rebase = (cb >> 6) & 1;
+	int hasFP = (cb >> 5) & 1;
+	db->xalpha = (cb >> 4) & 1;
+	uint64_t totRefHeadLen = 0;
+	RD(&totRefHeadLen, 8, 1); RD(&db->shear, 4, 1); RD(&db->totR, 4, 1); RD(&db->origTotR, 4, 1);
+	RD(&db->numRclumps, 4, 1); RD(&db->maxLenR, 4, 1);
+	ALLOC(db->headDump, totRefHeadLen + 1);
+	RD(db->headDump, 1, totRefHeadLen);
+	db->headDump[totRefHeadLen] = 0;
+	RD(&db->numRefHeads, 4, 1);
+	char **uniq;
+	ALLOC(uniq, (size_t)db->numRefHeads * sizeof(char *));
+	{
+		char *p = db->headDump, *end = db->headDump + totRefHeadLen;
+		for (uint32_t i = 0; i < db->numRefHeads; ++i) {
+			uniq[i] = p;
+			while (p < end && *p) ++p;
+			if (p < end) ++p;
+		}
+	}
+	ALLOC(db->refMap, (size_t)db->origTotR * 4);
+	RD(db->refMap, 4, db->origTotR);
+	ALLOC(db->refHead, (size_t)db->origTotR * sizeof(char *));
+	for (uint32_t i = 0; i < db->origTotR; ++i) {
+		if (db->refMap[i] >= db->numRefHeads) { fclose(in); bh_db_free(db); return bh_set_error(BH_E_USAGE, "ERROR: corrupt RefMap in %s", path); }
+		db->refHead[i] = uniq[db->refMap[i]];
+	}
+	if (db->rebase) { ALLOC(db->refStart, (size_t)db->origTotR * 4); RD(db->refStart, 4, db->origTotR); }
+	if (db->totR != db->origTotR) { ALLOC(db->refDedupIx, ((size_t)db->totR + 1) * 4); RD(db->refDedupIx, 4, db->totR + 1); }
+	ALLOC(db->tmpRIX, (size_t)db->origTotR * 4);
+	RD(db->tmpRIX, 4, db->origTotR);
+	ALLOC(db->clumpLen, (size_t)db->numRclumps * 4);
+	RD(db->clumpLen, 4, db->numRclumps);
+	uint64_t words = 0; uint32_t maxL = db->maxLenR;
+	for (uint32_t i = 0; i < db->numRclumps; ++i) {
+		if (db->clumpLen[i] > maxL) maxL = db->clumpLen[i];
+		words += db->clumpLen[i] / 2u + (db->clumpLen[i] & 1);
+	}
+	db->maxLenR = maxL;
+	ALLOC(db->packed, (words + 1) * 16);
+	RD(db->packed, 16, words);
+	db->packedWords = words;
+	(void)hasFP;   /* fingerprint tables, if any, follow and are ignored (-f is out of scope) */
+	fclose(in);
+	derive_refixsrt(db);
+	return BH_OK;
+}
+#undef RD
+#undef ALLOC
+
+int bh_acx_read(const char *path, int K, int z, BhDb *db) {
+	FILE *in = fopen(path, "rb");
+	if (!in) return bh_set_error(BH_E_USAGE, "Cannot read accelerator '%s'", path);
+	int cb = fgetc(in);
+	int ver = cb & 0xF, didZ = (cb >> 6) & 1;
+	if (cb == EOF || cb < 128 || (ver != 0 && ver != 1)) { fclose(in); return bh_set_error(BH_E_USAGE, "ERROR: invalid accelerator [%d:%d]", cb, ver); }
+	if (didZ && !z) { fclose(in); return bh_set_error(BH_E_USAGE, "ERROR: Accelerator built without '-y'; can't use '-y'"); }
+	uint32_t szBL = 0;
+	const uint64_t nw = 1ull << (2 * K);
+	int bad = fread(&szBL, 4, 1, in) != 1;
+	uint32_t *lens = own(db, malloc(nw * 4));
+	uint32_t *bl = own(db, malloc(((size_t)szBL + 1) * 4));
+	if (!lens || !bl) { fclose(in); return bh_set_error(BH_E_OOM, "OOM:BadList_rd"); }
+	bad |= fread(lens, 4, nw, in) != nw;
+	uint64_t bytes = 0;
+	if (!bad) for (uint64_t i = 0; i < nw; ++i) bytes += ver == 0 ? (uint64_t)(lens[i] / 2u) * 5 + (lens[i] & 1) * 3 : (uint64_t)lens[i] * 3;
+	uint8_t *lists = own(db, malloc(bytes + 16));
+	if (!lists) { fclose(in); return bh_set_error(BH_E_OOM, "OOM:WordDump_rd"); }
+	bad |= fread(lists, 1, bytes, in) != bytes;
+	bad |= fread(bl, 4, szBL, in) != szBL;
+	fclose(in);
+	if (bad) return bh_set_error(BH_E_USAGE, "ERROR: truncated accelerator %s (was it built with K=%d?)", path, K);
+	memset(lists + bytes, 0, 16);
+	db->hasAcx = 1; db->K = K; db->acxFmt = ver; db->acxZ = didZ;
+	db->acxLens = lens; db->acxLists = lists; db->acxListBytes = bytes; db->badList = bl; db->badSz = szBL;
+	return BH_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Direct FASTA -> clumps.  Line-based parser as parse_tl_fasta (burst.c:484-533): a record starts at a line whose
+ * first byte is '>', sequence lines are concatenated, lines starting with ' ' or empty are skipped. */
+typedef struct { char *head; uint8_t *seq; uint32_t len; } RefRec;
+
+static int parse_ref_fasta(const char *path, RefRec **out, uint32_t *n_out, char **dump_out) {
+	FILE *f = fopen(path, "rb");
+	if (!f) return bh_set_error(BH_E_IO, "Cannot open FASTA file: %s.", path);
+	fseeko(f, 0, SEEK_END); uint64_t sz = (uint64_t)ftello(f); rewind(f);
+	char *dump = malloc(sz + 2);
+	if (!dump) { fclose(f); return bh_set_error(BH_E_OOM, "OOM:parse_tl_fasta"); }
+	if (fread(dump, 1, sz, f) != sz) { fclose(f); free(dump); return bh_set_error(BH_E_IO, "short read on %s", path); }
+	fclose(f);
+	dump[sz] = '\n'; dump[sz + 1] = 0;
+	uint8_t c2n[256]; bh_char2code(c2n);
+	uint32_t cap = 1024, n = 0; int lastHd = 0;
+	RefRec *R = malloc(cap * sizeof(*R));
+	uint8_t *wr = NULL;     /* sequences are compacted in place, behind the read cursor */
+	for (char *p = dump, *end = dump + sz; p < end;) {
+		char *nl = memchr(p, '\n', (size_t)(end + 1 - p));
+		char *le = nl;
+		if (le > p && le[-1] == '\r') --le;
+		if (*p == '>') {
+			if (!lastHd) {
+				if (n == cap) { cap *= 2; R = realloc(R, cap * sizeof(*R)); }
+				if (n) *wr = 0;
+				*le = 0;
+				R[n].head = p + 1; R[n].seq = (uint8_t *)le + 1; R[n].len = 0;
+				wr = R[n].seq; ++n; lastHd = 1;
+			}
+		} else if (le > p && *p != ' ' && n) {
+			lastHd = 0;
+			for (char *s = p; s < le; ++s) *wr++ = c2n[(uint8_t)*s];
+			R[n - 1].len = (uint32_t)(wr - R[n - 1].seq);
+		}
+		p = nl + 1;
+	}
+	if (wr) *wr = 0;
+	if (lastHd && n) --n;
+	*out = R; *n_out = n; *dump_out = dump;
+	return BH_OK;
+}
+
+typedef struct { const uint8_t *s; uint32_t len, ix; } Tux;
+static int tux_len_cmp(const void *a, const void *b) {
+	const Tux *A = a, *B = b;
+	if (A->len != B->len) return A->len < B->len ? -1 : 1;
+	return A->ix < B->ix ? -1 : (A->ix > B->ix);
+}
+static int tux_seq_cmp(const void *a, const void *b) {
+	const Tux *A = a, *B = b;
+	uint32_t n = A->len < B->len ? A->len : B->len;
+	int c = memcmp(A->s, B->s, n);
+	if (c) return c;
+	if (A->len != B->len) return A->len < B->len ? -1 : 1;
+	return A->ix < B->ix ? -1 : (A->ix > B->ix);
+}
+
+int bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_shear, long shear_len, int dedupe, BhDb *db) {
+	memset(db, 0, sizeof *db);
+	RefRec *R = NULL; uint32_t nR = 0; char *dump = NULL;
+	int rc = parse_ref_fasta(path, &R, &nR, &dump);
+	if (rc) return rc;
+	own(db, dump);
+	if (!nR) { free(R); bh_db_free(db); return bh_set_error(BH_E_USAGE, "ERROR: no references in %s", path); }
+	/* shear (burst.c:1852-1858, 2109-2141) */
+	uint32_t totR = nR;
+	char **head; const uint8_t **seq; uint32_t *len, *start = NULL;
+	if (do_shear && shear_len > 0) {
+		uint32_t minShear = (uint32_t)(maxLenQ / thres), shear = minShear > (uint32_t)shear_len ? minShear : (uint32_t)shear_len, ov = minShear;
+		uint64_t cnt = 0;
+		for (uint32_t i = 0; i < nR; ++i) {
+			long unit = (long)R[i].len - (long)ov; if (unit < 0) unit = 1;
+			cnt += (uint64_t)(unit / shear + (unit % shear != 0));
+		}
+		totR = (uint32_t)cnt;
+		head = malloc((size_t)totR * sizeof(*head)); seq = malloc((size_t)totR * sizeof(*seq));
+		len = malloc((size_t)totR * 4); start = own(db, malloc((size_t)totR * 4));
+		uint32_t maxL = shear + ov, x = 0;
+		for (uint32_t i = 0; i < nR; ++i) {
+			long unit = (long)R[i].len - (long)ov; if (unit < 0) unit = 1;
+			for (long j = 0; j < unit; j += shear) {
+				head[x] = R[i].head; seq[x] = R[i].seq + j; start[x] = (uint32_t)j;
+				uint32_t l = R[i].len - (uint32_t)j;
+				len[x++] = l > maxL ? maxL : l;
+			}
+		}
+		db->rebase = 1; db->shear = minShear;
+	} else {
+		head = malloc((size_t)totR * sizeof(*head)); seq = malloc((size_t)totR * sizeof(*seq)); len = malloc((size_t)totR * 4);
+		for (uint32_t i = 0; i < nR; ++i) head[i] = R[i].head, seq[i] = R[i].seq, len[i] = R[i].len;
+	}
+	/* order: by length, then lexicographically inside pods whose lengths differ by at most LATENCY = 16 (burst.c:2149-2186) */
+	Tux *T = malloc((size_t)totR * sizeof(*T));
+	for (uint32_t i = 0; i < totR; ++i) T[i].s = seq[i], T[i].len = len[i], T[i].ix = i;
+	qsort(T, totR, sizeof(*T), tux_len_cmp);
+	uint32_t maxLenR = T[totR - 1].len;
+	for (uint32_t i = 1, prev = 0, tol = T[0].len; i <= totR; ++i) {
+		if (i == totR || T[i].len > tol + 16) {
+			if (i - prev > 1) qsort(T + prev, i - prev, sizeof(*T), tux_seq_cmp);
+			prev = i; if (i < totR) tol = T[i].len;
+		}
+	}
+	uint32_t *srt = own(db, malloc(((size_t)totR + 1) * 4));
+	for (uint32_t i = 0; i < totR; ++i) srt[i] = T[i].ix;
+	free(T);
+	db->origTotR = totR; db->tmpRIX = srt; db->refIxSrt = srt; db->totR = totR;
+	if (dedupe) {                                                /* burst.c:2192-2230 */
+		uint32_t *dd = own(db, calloc((size_t)totR + 2, 4)), uix = 0;
+		for (uint32_t i = 1; i < totR; ++i) {
+			uint32_t a = srt[i], b = srt[i - 1];
+			if (!(len[a] == len[b] && !memcmp(seq[a], seq[b], len[a]))) dd[++uix] = i;
+		}
+		dd[++uix] = totR;
+		for (uint32_t i = 0; i < uix; ++i) {                     /* lowest original index leads each duplicate set (2213-2220) */
+			uint32_t lo = dd[i];
+			for (uint32_t m = dd[i] + 1; m < dd[i + 1]; ++m) if (srt[m] < srt[lo]) lo = m;
+			uint32_t t = srt[dd[i]]; srt[dd[i]] = srt[lo]; srt[lo] = t;
+		}
+		if (uix != totR) {
+			uint32_t *u = own(db, malloc(((size_t)uix + 1) * 4));
+			for (uint32_t i = 0; i < uix; ++i) u[i] = srt[dd[i]];
+			db->refIxSrt = u; db->refDedupIx = dd; db->totR = uix;
+		}
+	}
+	/* clumps of 16 (burst.c:2687-2737).  The reference copies symbol j while RefLen >= j, i.e. one symbol past a
+	 * shorter lane's end: the terminator (0) or, for a shear, the next base of the parent sequence.  Reproduced. */
+	const uint32_t nU = db->totR, nC = (nU + 15) / 16;
+	uint32_t *cl = own(db, malloc(((size_t)nC + 1) * 4));
+	uint64_t words = 0;
+	for (uint32_t c = 0; c < nC; ++c) {
+		uint32_t m = 0;
+		for (uint32_t k = 16 * c; k < nU && k < 16 * c + 16; ++k) if (len[db->refIxSrt[k]] > m) m = len[db->refIxSrt[k]];
+		cl[c] = m; words += m / 2u + (m & 1);
+	}
+	uint8_t *packed = own(db, calloc(words + 1, 16));
+	if (!packed) { free(head); free(seq); free(len); free(R); bh_db_free(db); return bh_set_error(BH_E_OOM, "OOM:RefClump"); }
+	uint64_t w0 = 0;
+	for (uint32_t c = 0; c < nC; ++c) {
+		for (uint32_t k = 16 * c; k < nU && k < 16 * c + 16; ++k) {
+			const uint32_t r = db->refIxSrt[k], L = len[r];
+			const uint8_t *s = seq[r];
+			for (uint32_t j = 0; j < cl[c] && j <= L; ++j)
+				packed[(w0 + j / 2) * 16 + (k & 15)] |= (uint8_t)((s[j] & 15) << (4 * (j & 1)));
+		}
+		w0 += cl[c] / 2u + (cl[c] & 1);
+	}
+	db->clumpLen = cl; db->numRclumps = nC; db->packed = packed; db->packedWords = words; db->maxLenR = maxLenR;
+	/* headers: one per sheared reference; RefMap = unique header index, built as dump_edb does (burst.c:2769-2786) */
+	db->refHead = own(db, malloc((size_t)totR * sizeof(char *)));
+	db->refMap = own(db, malloc((size_t)totR * 4));
+	for (uint32_t i = 0; i < totR; ++i) db->refHead[i] = head[i];
+	{
+		typedef struct { const char *s; uint32_t ix; } HP;
+		HP *H = malloc((size_t)totR * sizeof(*H));
+		for (uint32_t i = 0; i < totR; ++i) H[i].s = head[i], H[i].ix = i;
+		int hp_cmp(const void *a, const void *b) { return strcmp(((const HP *)a)->s, ((const HP *)b)->s); }
+		qsort(H, totR, sizeof(*H), hp_cmp);
+		uint32_t nix = 0;
+		for (uint32_t i = 0; i < totR; ++i) {
+			if (i && strcmp(H[i].s, H[i - 1].s)) ++nix;
+			db->refMap[H[i].ix] = nix;
+		}
+		db->numRefHeads = nix + 1;
+		free(H);
+	}
+	db->refStart = start;
+	db->identityMap = 1;
+	free(head); free(seq); free(len); free(R);
+	return BH_OK;
+}
+
+int bh_edx_write(const BhDb *db, const char *path, long db_qlen, float thres) {
+	FILE *o = fopen(path, "wb");
+	if (!o) return bh_set_error(BH_E_IO, "ERROR: Cannot open output: %s", path);
+	/* unique sorted headers (burst.c:2769-2786) */
+	uint32_t nH = db->numRefHeads;
+	const char **uh = calloc(nH, sizeof(*uh));
+	for (uint32_t i = 0; i < db->origTotR; ++i) uh[db->refMap[i]] = db->refHead[i];
+	uint64_t hl = 0;
+	for (uint32_t i = 0; i < nH; ++i) hl += strlen(uh[i]) + 1;
+	uint8_t ctrl = (uint8_t)(1 << 7 | (db->rebase ? 1 : 0) << 6 | 0 << 5 | 0 << 4 | 3);
+	uint32_t shear = db->rebase ? (uint32_t)(db_qlen / thres) : 0;
+	fwrite(&ctrl, 1, 1, o); fwrite(&hl, 8, 1, o); fwrite(&shear, 4, 1, o);
+	fwrite(&db->totR, 4, 1, o); fwrite(&db->origTotR, 4, 1, o); fwrite(&db->numRclumps, 4, 1, o); fwrite(&db->maxLenR, 4, 1, o);
+	for (uint32_t i = 0; i < nH; ++i) fwrite(uh[i], 1, strlen(uh[i]) + 1, o);
+	fwrite(&nH, 4, 1, o);
+	fwrite(db->refMap, 4, db->origTotR, o);
+	if (db->rebase) fwrite(db->refStart, 4, db->origTotR, o);
+	if (db->totR != db->origTotR) fwrite(db->refDedupIx, 4, (size_t)db->totR + 1, o);
+	fwrite(db->tmpRIX, 4, db->origTotR, o);
+	fwrite(db->clumpLen, 4, db->numRclumps, o);
+	fwrite(db->packed, 16, db->packedWords, o);
+	free(uh);
+	if (fclose(o)) return bh_set_error(BH_E_IO, "ERROR: write failed: %s", path);
+	return BH_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Accelerator: for every clump the set of K-mers (2 bits per base, first base most significant, burst.c:4097-4102)
+ * occurring in any of its 16 lanes, expanded over IUPAC codes (AMBIGS, burst.c:1372-1375); words containing N are
+ * skipped when N is penalised (burst.c:3368-3374); clumps whose expansion exceeds the budget go to the BadList
+ * (burst.c:3341-3354).  Lists are written in ascending clump order (the reference's order with -t 1). */
+static const uint8_t AMB_N[16] = {0, 1, 1, 1, 1, 4, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3};
+static const uint8_t AMB[16][4] = {{0}, {0}, {1}, {2}, {3}, {0, 1, 2, 3}, {2, 3}, {0, 1}, {0, 2}, {1, 3}, {1, 2}, {0, 3}, {1, 2, 3}, {0, 1, 2}, {0, 1, 3}, {0, 2, 3}};
+
+static void lane_codes(const BhDb *db, uint64_t w0, uint32_t L, uint32_t z, uint8_t *out) {
+	for (uint32_t j = 0; j < L; ++j) {
+		uint8_t b = db->packed[(w0 + j / 2) * 16 + z];
+		out[j] = (j & 1) ? b >> 4 : b & 15;
+	}
+}
+
+static void expand_word(const uint8_t *s, int K, int ix, uint32_t w, uint8_t *seen, uint32_t *cache, uint32_t *n) {
+	if (ix == K) { if (!(seen[w >> 3] & (1 << (w & 7)))) { seen[w >> 3] |= (uint8_t)(1 << (w & 7)); cache[(*n)++] = w; } return; }
+	for (int i = 0; i < AMB_N[s[ix]]; ++i) expand_word(s, K, ix + 1, (w << 2) | AMB[s[ix]][i], seen, cache, n);
+}
+
+int bh_acx_build(BhDb *db, int K, int z) {
+	const uint64_t nw = 1ull << (2 * K);
+	const uint32_t nC = db->numRclumps;
+	const uint64_t fullSize = K > 14 ? 0x7FFFFFFFull : (1ull << 24);
+	uint32_t *lens = own(db, calloc(nw, 4));
+	uint64_t *coff = malloc(((size_t)nC + 1) * 8);
+	uint8_t *isBad = calloc(nC, 1);
+	if (!lens || !coff || !isBad) return bh_set_error(BH_E_OOM, "OOM:AccelerantF");
+	coff[0] = 0;
+	for (uint32_t c = 0; c < nC; ++c) coff[c + 1] = coff[c] + db->clumpLen[c] / 2u + (db->clumpLen[c] & 1);
+	/* per-clump word sets, kept to fill the lists in a second sweep */
+	uint32_t **words = calloc(nC, sizeof(*words)); uint32_t *nwords = calloc(nC, 4);
+	int oom = 0;
+	#pragma omp parallel
+	{
+		uint8_t *seen = calloc(nw >> 3 ? nw >> 3 : 1, 1);
+		uint32_t capc = 1u << 16; uint32_t *cache = malloc((size_t)capc * 4);
+		uint8_t *lane = malloc((size_t)db->maxLenR + 64);
+		#pragma omp for schedule(dynamic, 16)
+		for (uint32_t c = 0; c < nC; ++c) {
+			const uint32_t L = db->clumpLen[c];
+			uint32_t n = 0; int bad = 0;
+			uint64_t tsum = 0;
+			for (uint32_t zz = 0; zz < 16 && !bad; ++zz) {
+				if (16ull * c + zz >= db->totR) break;
+				lane_codes(db, coff[c], L, zz, lane);
+				uint32_t ll = L; while (ll && lane[ll - 1] == 0) --ll;      /* lane's own length (pads are code 0) */
+				if (ll < (uint32_t)K) continue;
+				/* expansion budget as the reference estimates it: 3^a (N penalised) or 4^a per window (burst.c:3322-3353) */
+				uint32_t asum = 0;
+				for (uint32_t j = 0; j < ll; ++j) {
+					if (j >= (uint32_t)K - 1) {
+						uint64_t p = 1; for (uint32_t t = 0; t < asum; ++t) p *= z ? 3 : 4;
+						tsum += p;
+						if (lane[j - (K - 1)] > 4 + z) --asum;
+					}
+					if (lane[j] > 4 + z) ++asum;
+					if (tsum >= fullSize) { bad = 1; break; }
+				}
+				if (bad) break;
+				for (uint32_t j = 0; j + K <= ll; ++j) {
+					int skip = 0;
+					if (z) for (int k = 0; k < K; ++k) if (lane[j + k] == 5) { j += k; skip = 1; break; }
+					if (skip) continue;
+					uint64_t need = 1; for (int k = 0; k < K; ++k) need *= AMB_N[lane[j + k]];
+					if (n + need > capc) { while (n + need > capc) capc *= 2; cache = realloc(cache, (size_t)capc * 4); }
+					expand_word(lane + j, K, 0, 0, seen, cache, &n);
+				}
+			}
+			for (uint32_t i = 0; i < n; ++i) seen[cache[i] >> 3] = 0;
+			if (bad) { isBad[c] = 1; continue; }
+			words[c] = malloc((size_t)(n ? n : 1) * 4);
+			if (!words[c]) { oom = 1; continue; }
+			memcpy(words[c], cache, (size_t)n * 4); nwords[c] = n;
+			for (uint32_t i = 0; i < n; ++i) {
+				#pragma omp atomic
+				++lens[cache[i]];
+			}
+		}
+		free(seen); free(cache); free(lane);
+	}
+	if (oom) return bh_set_error(BH_E_OOM, "OOM:Accelerant.Refs");
+	uint64_t tot = 0;
+	uint64_t *offs = malloc((nw + 1) * 8);
+	for (uint64_t w = 0; w < nw; ++w) { offs[w] = tot; tot += lens[w]; }
+	offs[nw] = tot;
+	uint32_t *ent = malloc((tot + 1) * 4);
+	uint64_t *fill = malloc(nw * 8);
+	if (!ent || !fill) return bh_set_error(BH_E_OOM, "OOM:Accelerant.Refs");
+	memcpy(fill, offs, nw * 8);
+	for (uint32_t c = 0; c < nC; ++c) { for (uint32_t i = 0; i < nwords[c]; ++i) ent[fill[words[c][i]]++] = c; free(words[c]); }
+	free(words); free(nwords); free(fill);
+	uint32_t nb = 0;
+	for (uint32_t c = 0; c < nC; ++c) nb += isBad[c];
+	uint32_t *bl = own(db, malloc(((size_t)nb + 1) * 4));
+	nb = 0; for (uint32_t c = 0; c < nC; ++c) if (isBad[c]) bl[nb++] = c;
+	free(isBad); free(coff);
+	/* pack (burst.c:3501-3528) */
+	int fmt = nC > 1048574 ? 1 : 0;
+	uint64_t bytes = 0;
+	for (uint64_t w = 0; w < nw; ++w) bytes += fmt ? (uint64_t)lens[w] * 3 : (uint64_t)(lens[w] / 2u) * 5 + (lens[w] & 1) * 3;
+	uint8_t *lists = own(db, malloc(bytes + 16)), *p = lists;
+	if (!lists) return bh_set_error(BH_E_OOM, "OOM:WordDump");
+	for (uint64_t w = 0; w < nw; ++w) {
+		const uint32_t *l = ent + offs[w]; uint32_t n = lens[w];
+		if (fmt) for (uint32_t i = 0; i < n; ++i) { p[0] = (uint8_t)l[i]; p[1] = (uint8_t)(l[i] >> 8); p[2] = (uint8_t)(l[i] >> 16); p += 3; }
+		else {
+			uint32_t i = 0;
+			for (; i + 1 < n; i += 2) { uint64_t v = (uint64_t)l[i] | ((uint64_t)l[i + 1] << 20); memcpy(p, &v, 5); p += 5; }
+			if (i < n) { uint64_t v = l[i]; memcpy(p, &v, 3); p += 3; }
+		}
+	}
+	memset(p, 0, 16);
+	free(ent); free(offs);
+	db->hasAcx = 1; db->K = K; db->acxFmt = fmt; db->acxZ = z ? 1 : 0;
+	db->acxLens = lens; db->acxLists = lists; db->acxListBytes = bytes; db->badList = bl; db->badSz = nb;
+	return BH_OK;
+}
+
+int bh_acx_write(const BhDb *db, const char *path) {
+	if (!db->hasAcx) return bh_set_error(BH_E_USAGE, "no accelerator to write");
+	FILE *o = fopen(path, "wb");
+	if (!o) return bh_set_error(BH_E_USAGE, "Cannot write accelerator '%s'", path);
+	uint8_t vers = (uint8_t)(1 << 7 | (db->acxZ ? 1 : 0) << 6 | db->acxFmt);
+	fwrite(&vers, 1, 1, o); fwrite(&db->badSz, 4, 1, o);
+	fwrite(db->acxLens, 4, 1ull << (2 * db->K), o);
+	fwrite(db->acxLists, 1, db->acxListBytes, o);
+	fwrite(db->badList, 4, db->badSz, o);
+	if (fclose(o)) return bh_set_error(BH_E_IO, "ERROR: write failed: %s", path);
+	return BH_OK;
+}

@@ -1,0 +1,195 @@
+/* bh_queries.c -- query pipeline (mirror of process_queries, burst.c:2980-3223, and its parser 636-690).
+ *
+ * parse 2-line FASTA -> symbol codes -> sort -> dedupe (Offset) -> per-query error budget -> reverse-complement
+ * entries -> accelerator bins.  The prefix-"div"/cache bookkeeping of the reference (3187-3206) exists only to
+ * let its CPU kernel reuse DP rows; the device path aligns every (query, clump) independently, so it is omitted.
+ */
+#include "burst_host.h"
+#include <stdlib.h>
+#include <string.h>
+#include <omp.h>
+
+typedef struct { const uint8_t *s; uint32_t len; uint64_t ix; } QRef;
+
+static int qref_cmp(const void *a, const void *b) {
+	const QRef *A = a, *B = b;
+	uint32_t n = A->len < B->len ? A->len : B->len;
+	int c = memcmp(A->s, B->s, n);           /* codes are 0..15, so memcmp == the reference's strcmp order (burst.c:363-366) */
+	if (c) return c;
+	if (A->len != B->len) return A->len < B->len ? -1 : 1;
+	return A->ix < B->ix ? -1 : (A->ix > B->ix);
+}
+
+static inline uint32_t prefix_bucket(const QRef *r) {   /* first 5 symbols, 4 bits each (NIB5, burst.c:383) */
+	uint32_t v = 0;
+	for (uint32_t i = 0; i < 5; ++i) v = (v << 4) | (i < r->len ? r->s[i] : 0);
+	return v;
+}
+
+static int sort_qrefs(QRef *a, uint64_t n) {
+	if (n < 1u << 16) { qsort(a, n, sizeof(*a), qref_cmp); return 0; }
+	const uint32_t NB = 1u << 20;
+	uint64_t *cnt = calloc((size_t)NB + 1, sizeof(*cnt));
+	QRef *tmp = malloc(n * sizeof(*tmp));
+	if (!cnt || !tmp) { free(cnt); free(tmp); return bh_set_error(BH_E_OOM, "OOM sorting queries"); }
+	for (uint64_t i = 0; i < n; ++i) ++cnt[prefix_bucket(a + i) + 1];
+	for (uint32_t b = 0; b < NB; ++b) cnt[b + 1] += cnt[b];
+	uint64_t *pos = malloc((size_t)NB * sizeof(*pos));
+	if (!pos) { free(cnt); free(tmp); return bh_set_error(BH_E_OOM, "OOM sorting queries"); }
+	memcpy(pos, cnt, (size_t)NB * sizeof(*pos));
+	for (uint64_t i = 0; i < n; ++i) tmp[pos[prefix_bucket(a + i)]++] = a[i];
+	#pragma omp parallel for schedule(dynamic, 64)
+	for (uint32_t b = 0; b < NB; ++b) if (cnt[b + 1] - cnt[b] > 1)
+		qsort(tmp + cnt[b], cnt[b + 1] - cnt[b], sizeof(*tmp), qref_cmp);
+	memcpy(a, tmp, n * sizeof(*a));
+	free(cnt); free(tmp); free(pos);
+	return 0;
+}
+
+void bh_queries_free(BhQueries *q) {
+	if (!q) return;
+	free(q->dump); free(q->heads); free(q->offset); free(q->codes); free(q->qoff); free(q->six); free(q->rc);
+	free(q->flags); free(q->emac); free(q->len); free(q->ed);
+	memset(q, 0, sizeof *q);
+}
+
+int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespace, int do_accel, int K, int z,
+                    int skip_ambig, BhQueries *Q) {
+	memset(Q, 0, sizeof *Q);
+	(void)skip_ambig;
+	FILE *f = fopen(fasta, "rb");
+	if (!f) return bh_set_error(BH_E_IO, "Cannot open FASTA file: %s.", fasta);
+	fseeko(f, 0, SEEK_END);
+	uint64_t sz = (uint64_t)ftello(f);
+	rewind(f);
+	char *dump = malloc(sz + 17);
+	if (!dump) { fclose(f); return bh_set_error(BH_E_OOM, "OOM reading queries"); }
+	if (fread(dump, 1, sz, f) != sz) { fclose(f); free(dump); return bh_set_error(BH_E_IO, "short read on %s", fasta); }
+	fclose(f);
+	memset(dump + sz, 0, 17);
+	Q->dump = dump;
+	if (!sz || *dump != '>') { bh_queries_free(Q); return bh_set_error(BH_E_USAGE, "ERROR: Malformatted FASTA file."); }
+	/* strict two-line records: (number of newlines, rounded up to even) / 2 must equal the number of '>' (burst.c:648-654) */
+	uint64_t numNL = 0, numLT = 0;
+	#pragma omp parallel for reduction(+:numNL, numLT)
+	for (uint64_t i = 0; i < sz; ++i) { numNL += dump[i] == '\n'; numLT += dump[i] == '>'; }
+	numNL += numNL & 1;
+	if (numLT != numNL / 2) { bh_queries_free(Q); return bh_set_error(BH_E_USAGE, "ERROR: line count != '>' * 2"); }
+	const uint64_t totQ = numLT;
+	char **heads = malloc(totQ * sizeof(*heads));
+	QRef *refs = malloc(totQ * sizeof(*refs));
+	if (!heads || !refs) { free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_OOM, "OOM indexing queries"); }
+	uint8_t c2n[256];
+	bh_char2code(c2n);
+	{
+		uint64_t i = 0, n = 0;
+		while (i < sz && n < totQ) {
+			/* header line */
+			char *h = dump + i + 1;
+			char *nl = memchr(h, '\n', sz - (i + 1));
+			if (!nl) nl = dump + sz;
+			char *he = nl;
+			if (he > h && he[-1] == '\r') --he;
+			*he = 0; *nl = 0;
+			if (!incl_whitespace) for (char *p = h; *p; ++p) if (*p == ' ' || *p == '\t') { *p = 0; break; }   /* burst.c:2987-2992 */
+			/* sequence line */
+			char *s = nl + 1 <= dump + sz ? nl + 1 : dump + sz;
+			char *nl2 = s < dump + sz ? memchr(s, '\n', (size_t)(dump + sz - s)) : NULL;
+			if (!nl2) nl2 = dump + sz;
+			char *se = nl2;
+			if (se > s && se[-1] == '\r') --se;
+			heads[n] = h;
+			refs[n].s = (uint8_t *)s; refs[n].len = (uint32_t)(se - s); refs[n].ix = n;
+			++n;
+			i = (uint64_t)(nl2 - dump) + 1;
+		}
+		if (n != totQ) { free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_USAGE, "ERROR: line count != '>' * 2"); }
+	}
+	uint32_t maxLen = 0, minLen = UINT32_MAX;
+	#pragma omp parallel for reduction(max:maxLen) reduction(min:minLen)
+	for (uint64_t i = 0; i < totQ; ++i) {
+		uint8_t *s = (uint8_t *)refs[i].s;
+		for (uint32_t k = 0; k < refs[i].len; ++k) s[k] = c2n[s[k]];                     /* translateNV, burst.c:1207 */
+		if (refs[i].len > maxLen) maxLen = refs[i].len;
+		if (refs[i].len < minLen) minLen = refs[i].len;
+	}
+	if (maxLen > BHIP_MAX_QLEN) {
+		free(heads); free(refs); bh_queries_free(Q);
+		return bh_set_error(BH_E_USAGE, "ERROR: query of %u symbols exceeds the device limit of %d", maxLen, BHIP_MAX_QLEN);
+	}
+	int rc = sort_qrefs(refs, totQ);
+	if (rc) { free(heads); free(refs); bh_queries_free(Q); return rc; }
+	/* uniqueness (burst.c:3036-3053) */
+	uint64_t numUniq = 0;
+	for (uint64_t i = 0; i < totQ; ++i)
+		if (!i || refs[i].len != refs[i - 1].len || memcmp(refs[i].s, refs[i - 1].s, refs[i].len)) ++numUniq;
+	const uint64_t numEntries = numUniq * (do_rc ? 2 : 1);
+	Q->heads = malloc(totQ * sizeof(*Q->heads));
+	Q->offset = malloc((numUniq + 1) * sizeof(*Q->offset));
+	Q->qoff = malloc((numEntries + 1) * sizeof(*Q->qoff));
+	Q->six = malloc(numEntries * sizeof(*Q->six));
+	Q->rc = calloc(numEntries, 1);
+	Q->flags = calloc(numEntries, 1);
+	Q->emac = malloc(numEntries * sizeof(*Q->emac));
+	Q->len = malloc(numUniq * sizeof(*Q->len));
+	Q->ed = malloc(numUniq * sizeof(*Q->ed));
+	if (!Q->heads || !Q->offset || !Q->qoff || !Q->six || !Q->rc || !Q->flags || !Q->emac || !Q->len || !Q->ed) {
+		free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_OOM, "OOM building query tables");
+	}
+	uint64_t u = 0, totLen = 0;
+	for (uint64_t i = 0; i < totQ; ++i) {
+		Q->heads[i] = heads[refs[i].ix];
+		if (!i || refs[i].len != refs[i - 1].len || memcmp(refs[i].s, refs[i - 1].s, refs[i].len)) {
+			Q->offset[u] = i;
+			Q->len[u] = refs[i].len;
+			Q->ed[u] = (uint16_t)bh_error_budget(thres, refs[i].len);                  /* burst.c:3074-3076 */
+			totLen += refs[i].len;
+			++u;
+		}
+	}
+	Q->offset[numUniq] = totQ;
+	Q->codes = malloc(totLen * (do_rc ? 2 : 1) + 16);
+	if (!Q->codes) { free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_OOM, "OOM copying queries"); }
+	Q->qoff[0] = 0;
+	for (uint64_t i = 0; i < numUniq; ++i) Q->qoff[i + 1] = Q->qoff[i] + Q->len[i];
+	if (do_rc) for (uint64_t i = 0; i < numUniq; ++i) Q->qoff[numUniq + i + 1] = Q->qoff[numUniq + i] + Q->len[i];
+	uint32_t maxED = 0;
+	#pragma omp parallel for reduction(max:maxED)
+	for (uint64_t i = 0; i < numUniq; ++i) {
+		const uint8_t *s = refs[Q->offset[i]].s;
+		const uint32_t len = Q->len[i];
+		memcpy(Q->codes + Q->qoff[i], s, len);
+		Q->six[i] = (uint32_t)i; Q->emac[i] = Q->ed[i];
+		if (Q->ed[i] > maxED) maxED = Q->ed[i];
+		if (do_rc) {                                                                      /* burst.c:3095-3107 */
+			uint8_t *d = Q->codes + Q->qoff[numUniq + i];
+			for (uint32_t j = 0; j < len; ++j) d[j] = bh_rc_code(s[len - j - 1]);
+			Q->six[numUniq + i] = (uint32_t)i; Q->rc[numUniq + i] = 1; Q->emac[numUniq + i] = Q->ed[i];
+		}
+	}
+	/* accelerator bins (burst.c:3124-3141): bad = too short / too many errors for the k-mer guarantee / > 5 strongly
+	 * ambiguous symbols; ambiguous = any symbol beyond A/C/G/T.  Only clear entries use the device prefilter; the other
+	 * two bins take the exhaustive route (the reference sends bad ones there too, burst.c:4320). */
+	uint64_t nClear = 0, nAmbig = 0, nBad = 0;
+	for (uint64_t e = 0; e < numEntries; ++e) {
+		if (!do_accel) { Q->flags[e] = BHIP_Q_EXHAUSTIVE; continue; }
+		const uint32_t len = Q->len[Q->six[e]], ed = Q->ed[Q->six[e]];
+		const uint8_t *s = Q->codes + Q->qoff[e];
+		int stat = 1;
+		if (len < (uint32_t)K || ed >= len / (uint32_t)K) stat = 2;
+		else {
+			uint32_t totN = 0;
+			for (uint32_t j = 0; j < len; ++j) {
+				if ((totN += s[j] > 4 + z) > 5) { stat = 2; break; }
+				else if (s[j] > 4) stat = 0;
+			}
+		}
+		Q->flags[e] = stat == 1 ? BHIP_Q_PREFILTER : BHIP_Q_EXHAUSTIVE;
+		if (stat == 1) ++nClear; else if (stat == 0) ++nAmbig; else ++nBad;
+	}
+	Q->totQ = totQ; Q->numUniq = numUniq; Q->numEntries = numEntries;
+	Q->maxLen = maxLen; Q->minLen = minLen; Q->maxED = maxED;
+	Q->nClear = nClear; Q->nAmbig = nAmbig; Q->nBad = nBad;
+	free(heads); free(refs);
+	return BH_OK;
+}

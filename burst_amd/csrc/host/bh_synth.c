@@ -1,0 +1,113 @@
+/* bh_synth.c -- seeded synthetic references and reads for the tests and the bench (no datasets are reachable
+ * offline).  Behaviour modelled on the reference's read simulator embalmlets/LLsim.c:175-231: uniform start,
+ * fixed window, an exact number of edits per read at distinct positions with substitution : deletion : insertion
+ * = 3 : 1 : 1, optional reverse complement of half the reads.  Not part of the alignment path.
+ */
+#include "burst_host.h"
+#include <stdlib.h>
+#include <string.h>
+
+static inline uint64_t rng_next(uint64_t *s) {            /* xorshift64* */
+	uint64_t x = *s; x ^= x >> 12; x ^= x << 25; x ^= x >> 27; *s = x;
+	return x * 0x2545F4914F6CDD1DULL;
+}
+static inline double rng_unit(uint64_t *s) { return (rng_next(s) >> 11) * (1.0 / 9007199254740992.0); }
+static const char BASES[4] = {'A', 'C', 'G', 'T'};
+
+int bh_synth_refs(const char *fasta_out, uint32_t n_base, uint32_t n_variants, uint32_t length, double rate, uint64_t seed) {
+	FILE *o = fopen(fasta_out, "wb");
+	if (!o) return bh_set_error(BH_E_IO, "cannot write %s", fasta_out);
+	setvbuf(o, NULL, _IOFBF, 1 << 22);
+	uint64_t s = seed * 0x9E3779B97F4A7C15ULL + 0x1234567ULL;
+	char *base = malloc(length + 1), *var = malloc(2 * (size_t)length + 16);
+	for (uint32_t b = 0; b < n_base; ++b) {
+		for (uint32_t i = 0; i < length; ++i) base[i] = BASES[rng_next(&s) & 3];
+		for (uint32_t v = 0; v < n_variants; ++v) {
+			uint32_t n = 0;
+			for (uint32_t i = 0; i < length; ++i) {
+				if (v && rng_unit(&s) < rate) {
+					uint32_t k = (uint32_t)(rng_next(&s) % 5);
+					if (k < 3) { char c; do c = BASES[rng_next(&s) & 3]; while (c == base[i]); var[n++] = c; }
+					else if (k == 3) { /* deletion */ }
+					else { var[n++] = BASES[rng_next(&s) & 3]; var[n++] = base[i]; }
+				} else var[n++] = base[i];
+			}
+			fprintf(o, ">ref_b%u_v%u\n", b, v);
+			fwrite(var, 1, n, o); fputc('\n', o);
+		}
+	}
+	free(base); free(var);
+	if (fclose(o)) return bh_set_error(BH_E_IO, "write failed: %s", fasta_out);
+	return BH_OK;
+}
+
+static const char RCMAP[128] = {['A'] = 'T', ['C'] = 'G', ['G'] = 'C', ['T'] = 'A'};
+/* IUPAC symbols whose base set contains the given base */
+static const char *COMPAT[4] = {"MRWVHD", "MYSBVH", "KRSBVD", "KYWBHD"};
+
+int bh_synth_reads(const char *refs_fasta, const char *fasta_out, uint64_t n_reads, uint32_t read_len, const uint32_t *edit_choices,
+                   uint32_t n_choices, int rc, double iupac_rate, uint64_t seed) {
+	FILE *f = fopen(refs_fasta, "rb");
+	if (!f) return bh_set_error(BH_E_IO, "Cannot open FASTA file: %s.", refs_fasta);
+	fseeko(f, 0, SEEK_END); uint64_t sz = (uint64_t)ftello(f); rewind(f);
+	char *dump = malloc(sz + 2);
+	if (!dump || fread(dump, 1, sz, f) != sz) { fclose(f); free(dump); return bh_set_error(BH_E_IO, "cannot read %s", refs_fasta); }
+	fclose(f); dump[sz] = '\n';
+	/* single-line records only (what bh_synth_refs writes) */
+	uint64_t cap = 1024, n = 0; char **seq = malloc(cap * sizeof(*seq)); uint32_t *len = malloc(cap * 4);
+	for (char *p = dump, *end = dump + sz; p < end;) {
+		char *nl = memchr(p, '\n', (size_t)(end + 1 - p));
+		if (*p != '>' && nl > p) {
+			if (n == cap) { cap *= 2; seq = realloc(seq, cap * sizeof(*seq)); len = realloc(len, cap * 4); }
+			seq[n] = p; len[n] = (uint32_t)(nl - p); if (len[n] && p[len[n] - 1] == '\r') --len[n];
+			++n;
+		}
+		p = nl + 1;
+	}
+	uint64_t nOk = 0;
+	for (uint64_t i = 0; i < n; ++i) nOk += len[i] > read_len;
+	if (!nOk) { free(dump); free(seq); free(len); return bh_set_error(BH_E_USAGE, "no reference longer than %u", read_len); }
+	FILE *o = fopen(fasta_out, "wb");
+	if (!o) { free(dump); free(seq); free(len); return bh_set_error(BH_E_IO, "cannot write %s", fasta_out); }
+	setvbuf(o, NULL, _IOFBF, 1 << 22);
+	uint64_t s = seed * 0xD1B54A32D192ED03ULL + 0x7654321ULL;
+	char *rd = malloc(2 * (size_t)read_len + 16);
+	uint32_t *pos = malloc(((size_t)read_len + 1) * 4);
+	uint8_t *kind = calloc((size_t)read_len + 1, 1);
+	for (uint64_t r = 0; r < n_reads; ++r) {
+		uint64_t gi; do gi = rng_next(&s) % n; while (len[gi] <= read_len);
+		const uint32_t st = (uint32_t)(rng_next(&s) % (len[gi] - read_len));
+		const char *w = seq[gi] + st;
+		uint32_t ne = n_choices ? edit_choices[rng_next(&s) % n_choices] : 0;
+		if (ne > read_len) ne = read_len;
+		/* ne distinct positions: partial Fisher-Yates */
+		for (uint32_t i = 0; i < read_len; ++i) pos[i] = i;
+		for (uint32_t i = 0; i < ne; ++i) { uint32_t j = i + (uint32_t)(rng_next(&s) % (read_len - i)); uint32_t t = pos[i]; pos[i] = pos[j]; pos[j] = t; }
+		memset(kind, 0, read_len);
+		for (uint32_t i = 0; i < ne; ++i) { uint32_t k = (uint32_t)(rng_next(&s) % 5); kind[pos[i]] = (uint8_t)(k < 3 ? 1 : (k == 3 ? 2 : 3)); }
+		uint32_t m = 0;
+		for (uint32_t i = 0; i < read_len; ++i) {
+			char c = w[i];
+			if (kind[i] == 1) { char x; do x = BASES[rng_next(&s) & 3]; while (x == c); rd[m++] = x; }
+			else if (kind[i] == 2) { }
+			else if (kind[i] == 3) { rd[m++] = BASES[rng_next(&s) & 3]; rd[m++] = c; }
+			else rd[m++] = c;
+		}
+		if (iupac_rate > 0) for (uint32_t i = 0; i < m; ++i) if (rng_unit(&s) < iupac_rate) {
+			const char *b = memchr(BASES, rd[i], 4);
+			if (b) rd[i] = COMPAT[b - BASES][rng_next(&s) % 6];
+		}
+		int isrc = rc && (rng_next(&s) & 1);
+		if (isrc) {
+			for (uint32_t i = 0; i < m / 2; ++i) { char a = rd[i], b = rd[m - 1 - i]; rd[i] = b; rd[m - 1 - i] = a; }
+			for (uint32_t i = 0; i < m; ++i) { char c = RCMAP[(int)rd[i] & 127]; if (c) rd[i] = c; else {
+				/* complement of an IUPAC symbol */
+				static const char *from = "KMRYSWBVHDN", *to = "MKYRSWVBDHN"; const char *q = strchr(from, rd[i]); if (q) rd[i] = to[q - from]; } }
+		}
+		fprintf(o, ">read%lu_g%lu_p%u_e%u%s\n", (unsigned long)r, (unsigned long)gi, st, ne, isrc ? "_rc" : "");
+		fwrite(rd, 1, m, o); fputc('\n', o);
+	}
+	free(rd); free(pos); free(kind); free(dump); free(seq); free(len);
+	if (fclose(o)) return bh_set_error(BH_E_IO, "write failed: %s", fasta_out);
+	return BH_OK;
+}

@@ -1,0 +1,125 @@
+/* burst_amd/csrc/host/burst_host.h -- C host side of the alignment path (libburst_host.so + the burst_hip CLI).
+ *
+ * Mirrors, in plain C, the parts of the reference's single translation unit that sit either side of the
+ * kernels: query pipeline (process_queries, burst.c:2980-3223), database readers (read_edb 2842-2975,
+ * read_accelerator 3535-3594), direct-FASTA clumping (process_references QUICK path 1840-1858, 2109-2190,
+ * 2687-2741), the batch scheduler that replaces the OpenMP loops of do_alignments (4018-4488) by calls into
+ * libburst_hip.so, and the per-mode consolidation + .b6 writer (4490-4891).
+ * Errors are return codes (<0) with bh_last_error(); nothing here calls exit().
+ */
+#ifndef BURST_HOST_H
+#define BURST_HOST_H
+#include <stdint.h>
+#include <stdio.h>
+#include "burst_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BH_OK        0
+#define BH_E_USAGE  -1   /* reference exit(1): usage / format */
+#define BH_E_IO     -2   /* reference exit(2): cannot open */
+#define BH_E_OOM    -3   /* reference exit(3) */
+#define BH_E_INTERNAL -4
+#define BH_E_DEVICE -5
+
+typedef enum { BH_FORAGE = 0, BH_BEST, BH_ALLPATHS, BH_CAPITALIST, BH_ANY } BhMode;   /* burst.c:75-78 */
+
+/* ---- tables (burst.c:164-192, 1237-1329) ---- */
+void bh_score_lut(int z, uint8_t lut[256]);        /* SCOREFAST after setScore(): lut[16*q+r] in {0,1,255} */
+void bh_char2code(uint8_t map[256]);               /* CHAR2NUM, bytes >= 128 map to 0 */
+uint8_t bh_rc_code(uint8_t c);                     /* RVT */
+uint32_t bh_error_budget(float thres, uint32_t len);   /* burst.c:3069-3076 */
+
+/* ---- database ---- */
+typedef struct BhDb {
+	/* .edx (burst.c:2842-2975) */
+	int rebase, xalpha;
+	uint32_t shear, totR, origTotR, numRclumps, maxLenR, numRefHeads;
+	char *headDump;          /* NUL-separated unique headers */
+	char **refHead;          /* [origTotR] header of each sheared reference (through RefMap) */
+	uint32_t *refMap;        /* [origTotR] sheared ref -> unique header index */
+	uint32_t *refStart;      /* [origTotR] or NULL */
+	uint32_t *refDedupIx;    /* [totR+1] or NULL */
+	uint32_t *tmpRIX;        /* [origTotR] */
+	uint32_t *refIxSrt;      /* [totR] = TmpRIX[RefDedupIx[i]] or TmpRIX (burst.c:3688-3693) */
+	uint32_t *clumpLen;      /* [numRclumps] */
+	uint8_t  *packed;        /* clump area, 16-byte words */
+	uint64_t packedWords;
+	/* .acx (burst.c:3535-3594), optional */
+	int hasAcx, K, acxFmt, acxZ;
+	uint32_t *acxLens;       /* [4^K] */
+	uint8_t  *acxLists; uint64_t acxListBytes;
+	uint32_t *badList; uint32_t badSz;
+	/* bookkeeping */
+	int identityMap;         /* direct-FASTA runs: RefMap is the identity (burst.c:4545-4551) */
+	void *owned[32]; int nOwned;
+} BhDb;
+
+int  bh_is_edx(const char *path);                       /* burst.c:4894-4901: first byte has bit 7 set; <0 on IO error */
+int  bh_edx_read(const char *path, BhDb *db);
+int  bh_acx_read(const char *path, int K, int z, BhDb *db);
+/* direct -r fasta (no DB): QUICK pipeline; shear_len = 0 disables shearing (burst.c:5046-5053) */
+int  bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_shear, long shear_len, int dedupe, BhDb *db);
+/* DB construction (tooling for tests/bench) */
+int  bh_edx_write(const BhDb *db, const char *path, long db_qlen, float thres);
+int  bh_acx_build(BhDb *db, int K, int z);
+int  bh_acx_write(const BhDb *db, const char *path);
+void bh_db_free(BhDb *db);
+
+/* ---- queries (burst.c:2980-3223) ---- */
+typedef struct BhQueries {
+	uint64_t totQ, numUniq, numEntries;   /* entries = unique forward queries, then (with -fr) their reverse complements */
+	char *dump;            /* file contents; heads point into it */
+	char **heads;          /* [totQ] headers in sorted-sequence order (QHead after burst.c:3055-3060) */
+	uint64_t *offset;      /* [numUniq+1] Offset: reads of unique query i are heads[offset[i]..offset[i+1]) */
+	uint8_t *codes;        /* concatenated symbol codes of all entries */
+	uint64_t *qoff;        /* [numEntries+1] */
+	uint32_t *six;         /* [numEntries] shared slot = unique query index */
+	uint8_t *rc;           /* [numEntries] */
+	uint8_t *flags;        /* [numEntries] BHIP_Q_PREFILTER / BHIP_Q_EXHAUSTIVE (query binning, burst.c:3113-3141) */
+	uint16_t *emac;        /* [numEntries] budget of the entry's shared slot */
+	uint32_t *len;         /* [numUniq] ShrBin.len */
+	uint16_t *ed;          /* [numUniq] ShrBin.ed (initial budget) */
+	uint32_t maxLen, minLen, maxED;
+	uint64_t nClear, nAmbig, nBad;
+} BhQueries;
+
+int  bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespace, int do_accel, int K, int z,
+                     int skip_ambig, BhQueries *q);
+void bh_queries_free(BhQueries *q);
+
+/* ---- alignment driver: batches of entries through bhip_align_batch ---- */
+typedef struct BhRun {
+	BhipHit *hits; uint64_t nHits;        /* all records, q = entry index, sorted by (q, refIx) */
+	double secAlign;                      /* wall time inside the device calls */
+	BhipStats total;                      /* summed over batches (times in ms) */
+	uint32_t nBatches;
+} BhRun;
+/* entry range [e0, e1) of unique queries [u0, u1): forward entries u0..u1-1 and (if numEntries > numUniq) their RC twins
+ * are always sent together because they share the running minimum (burst.c:277-280, 4218). */
+int  bh_align(void *hip_handle, const BhQueries *q, uint64_t u0, uint64_t u1, BhMode mode, uint64_t batch_uniq, BhRun *run);
+void bh_run_free(BhRun *run);
+int  bh_device_open(const BhDb *db, int device, int z, void **hip_handle);
+
+/* ---- consolidation and .b6 output (burst.c:4553-4891); hits must be sorted by (q, refIx) ---- */
+int  bh_report(FILE *out, const BhDb *db, const BhQueries *q, const BhipHit *hits, uint64_t nHits, BhMode mode, uint64_t *nLines);
+/* flags: BH_REP_MERGED_LIST = rebuild each query's hit list the way the reference's exhaustive path does (one list per
+ * unique query shared by both strands, burst.c:4368, instead of forward list + appended reverse list, 4218/4299-4312);
+ * BH_REP_NO_DUPE_HUNT = print every (hit, reference) expansion (diagnostics / tests). */
+#define BH_REP_MERGED_LIST  1
+#define BH_REP_NO_DUPE_HUNT 2
+int  bh_report_ex(FILE *out, const BhDb *db, const BhQueries *q, const BhipHit *hits, uint64_t nHits, BhMode mode, int flags, uint64_t *nLines);
+
+const char *bh_last_error(void);
+int bh_set_error(int code, const char *fmt, ...);
+
+/* ---- synthetic data (tests / bench tooling; behaviour modelled on embalmlets/LLsim.c:175-231) ---- */
+int bh_synth_refs(const char *fasta_out, uint32_t n_base, uint32_t n_variants, uint32_t length, double variant_rate, uint64_t seed);
+int bh_synth_reads(const char *refs_fasta, const char *fasta_out, uint64_t n_reads, uint32_t read_len, const uint32_t *edit_choices,
+                   uint32_t n_choices, int rc, double iupac_rate, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,173 @@
+/* main.c -- `burst_hip`: the reference's command line (burst.c:4902-5164) in front of the MI355X device path.
+ *
+ *   burst_hip -r DB.edx -a DB.acx -q reads.fa -o out.b6 -m {BEST|ALLPATHS|CAPITALIST|FORAGE|ANY} -i 0.97 [-fr] [-y] [-w]
+ *   burst_hip -r refs.fa -q reads.fa -o out.b6 [-s [len]]            direct FASTA (exhaustive, no accelerator)
+ *   burst_hip -r refs.fa -d [QUICK|DNA|RNA] [qLen] -o DB.edx [-a DB.acx] [-s [len]] -i 0.97      database construction
+ *
+ * Flags not on the hot path (-b taxonomy, -f fingerprints, -p prepass, -x alphabet, -hr) are refused with the
+ * reference's exit code 1.  Extra flags: --device N, --batch N (unique queries per device call), -k {12|15}.
+ */
+#include "burst_host.h"
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <omp.h>
+
+static double wall(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+static int code_to_exit(int rc) { return rc == BH_E_USAGE ? 1 : rc == BH_E_IO ? 2 : rc == BH_E_OOM ? 3 : 4; }
+#define DIE(rc) do { fprintf(stderr, "%s\n", bh_last_error()); return code_to_exit(rc); } while (0)
+#define NEEDARG(name) do { if (++i == argc || argv[i][0] == '-') { printf("ERROR: %s requires an argument\n", name); return 1; } } while (0)
+
+static void usage(void) {
+	puts("\nburst_hip: BURST-compatible optimal aligner, MI355X (gfx950) device path");
+	puts("--references (-r) <name>: FASTA/edx DB of reference sequences [required]");
+	puts("--accelerator (-a) <name>: Creates/uses a helper DB (acx) [optional]");
+	puts("--queries (-q) <name>: FASTA file of queries to search [required if aligning]");
+	puts("--output (-o) <name>: Blast6/edx file for output alignments/database [required]");
+	puts("--forwardreverse (-fr), --whitespace (-w), --nwildcard (-y), --mode (-m) BEST|ALLPATHS|CAPITALIST|FORAGE|ANY");
+	puts("--makedb (-d) [name qLen], --id (-i) <decimal>, --threads (-t) <int>, --shear (-s) [len], --noprogress");
+	puts("--device <int>, --batch <int>, -k <12|15>, --make-acx <name> (with -r DB.edx: rebuild the accelerator of a database)");
+}
+
+int main(int argc, char **argv) {
+	BhMode mode = BH_CAPITALIST;                    /* burst.c:81 */
+	float thres = 0.97f;                            /* burst.c:93 */
+	int z = 1, do_rc = 0, incl_ws = 0, makedb = 0, do_shear = 0, do_accel = 0, dedupe = 0, device = 0, K = 0, skip_ambig = 0, threads = 0, rep_flags = 0;
+	long shear_amt = 500, db_qlen = 500;            /* burst.c:94 */
+	uint64_t batch = 1u << 18;
+	const char *ref_FN = 0, *query_FN = 0, *output_FN = 0, *xcel_FN = 0, *mkacx_FN = 0;
+	printf("This is burst_hip [MI355X device path; BURST v1.0 semantics]\n");
+	if (argc < 2) { usage(); return 1; }
+	for (int i = 1; i < argc; ++i) {
+		const char *a = argv[i];
+		if (!strcmp(a, "--references") || !strcmp(a, "-r")) { NEEDARG("--references"); ref_FN = argv[i]; }
+		else if (!strcmp(a, "--queries") || !strcmp(a, "-q")) { NEEDARG("--queries"); query_FN = argv[i]; }
+		else if (!strcmp(a, "--output") || !strcmp(a, "-o")) { NEEDARG("--output"); output_FN = argv[i]; }
+		else if (!strcmp(a, "--accelerator") || !strcmp(a, "-a")) { NEEDARG("--accelerator"); xcel_FN = argv[i]; do_accel = 1; }
+		else if (!strcmp(a, "--forwardreverse") || !strcmp(a, "-fr")) do_rc = 1;
+		else if (!strcmp(a, "--whitespace") || !strcmp(a, "-w")) incl_ws = 1;
+		else if (!strcmp(a, "--npenalize") || !strcmp(a, "-n")) z = 1;
+		else if (!strcmp(a, "--nwildcard") || !strcmp(a, "-y")) z = 0;
+		else if (!strcmp(a, "--mode") || !strcmp(a, "-m")) {
+			NEEDARG("--mode");
+			if (!strcmp(argv[i], "BEST")) mode = BH_BEST; else if (!strcmp(argv[i], "ALLPATHS")) mode = BH_ALLPATHS;
+			else if (!strcmp(argv[i], "CAPITALIST")) mode = BH_CAPITALIST; else if (!strcmp(argv[i], "FORAGE")) mode = BH_FORAGE;
+			else if (!strcmp(argv[i], "ANY")) mode = BH_ANY;
+			else { printf("Unsupported run mode '%s'\n", argv[i]); return 1; }
+		}
+		else if (!strcmp(a, "--makedb") || !strcmp(a, "-d")) {
+			makedb = 1;
+			if (i + 1 != argc && argv[i + 1][0] != '-' && !atol(argv[i + 1])) {
+				++i;
+				if (strcmp(argv[i], "DNA") && strcmp(argv[i], "RNA") && strcmp(argv[i], "QUICK")) { printf("Unsupported makedb mode '%s'\n", argv[i]); return 1; }
+			}
+			if (i + 1 != argc && argv[i + 1][0] != '-') { db_qlen = atol(argv[++i]); if (db_qlen <= 0) { fprintf(stderr, "ERROR: bad max query length '%s'\n", argv[i]); return 1; } }
+		}
+		else if (!strcmp(a, "--id") || !strcmp(a, "-i")) {
+			NEEDARG("--id"); thres = (float)atof(argv[i]);
+			if (thres > 1.f || thres < 0.f) { puts("Invalid id range [0-1]"); return 1; }
+			if (thres < 0.01f) thres = 0.01f;
+		}
+		else if (!strcmp(a, "--threads") || !strcmp(a, "-t")) { NEEDARG("--threads"); threads = atoi(argv[i]); }
+		else if (!strcmp(a, "--shear") || !strcmp(a, "-s")) {
+			do_shear = 1;
+			if (i + 1 != argc && argv[i + 1][0] != '-') { shear_amt = atol(argv[++i]); if (shear_amt < 0) { printf("ERROR: bad shear length '%s'\n", argv[i]); return 1; } }
+			if (!shear_amt) do_shear = 0;
+		}
+		else if (!strcmp(a, "--unique") || !strcmp(a, "-u")) dedupe = 1;
+		else if (!strcmp(a, "--skipambig") || !strcmp(a, "-sa")) skip_ambig = 1;
+		else if (!strcmp(a, "--noprogress")) { }
+		else if (!strcmp(a, "--no-dupe-hunt")) rep_flags |= BH_REP_NO_DUPE_HUNT;   /* diagnostics: print every (hit, reference) expansion */
+		else if (!strcmp(a, "--make-acx")) { NEEDARG("--make-acx"); mkacx_FN = argv[i]; }
+		else if (!strcmp(a, "--device")) { NEEDARG("--device"); device = atoi(argv[i]); }
+		else if (!strcmp(a, "--batch")) { NEEDARG("--batch"); batch = strtoull(argv[i], 0, 10); }
+		else if (!strcmp(a, "-k")) { NEEDARG("-k"); K = atoi(argv[i]); if (K != 12 && K != 15) { puts("ERROR: -k must be 12 or 15"); return 1; } }
+		else if (!strcmp(a, "--help") || !strcmp(a, "-h")) { usage(); return 1; }
+		else if (!strcmp(a, "--taxonomy") || !strcmp(a, "-b") || !strcmp(a, "--fingerprint") || !strcmp(a, "-f") || !strcmp(a, "--prepass") ||
+		         !strcmp(a, "-p") || !strcmp(a, "--xalphabet") || !strcmp(a, "-x") || !strcmp(a, "--heuristic") || !strcmp(a, "-hr") ||
+		         !strcmp(a, "--taxacut") || !strcmp(a, "-bc") || !strcmp(a, "--taxa_ncbi") || !strcmp(a, "-bn") || !strcmp(a, "--taxasuppress") || !strcmp(a, "-bs")) {
+			printf("ERROR: option %s is outside the device hot path and not supported by burst_hip\n", a); return 1;
+		}
+		else { printf("ERROR: Unrecognized command-line option: %s\n", a); puts("See help by running with just '-h'"); return 1; }
+	}
+	if (mkacx_FN) {   /* (re)build an accelerator for an existing .edx:  burst_hip -r DB.edx --make-acx DB.acx [-k 12|15] [-y] */
+		if (!ref_FN) { puts("ERROR: --make-acx needs -r DB.edx"); return 1; }
+		BhDb db; int rc0;
+		if ((rc0 = bh_edx_read(ref_FN, &db))) DIE(rc0);
+		if ((rc0 = bh_acx_build(&db, K ? K : 12, z))) DIE(rc0);
+		if ((rc0 = bh_acx_write(&db, mkacx_FN))) DIE(rc0);
+		printf("Accelerator written: K=%d, %s format, %u ambiguous clumps\n", db.K, db.acxFmt ? "LARGE" : "SMALL", db.badSz);
+		bh_db_free(&db);
+		return 0;
+	}
+	if (!ref_FN || !output_FN) { puts("ERROR: --references and --output are required"); return 1; }
+	if (threads > 0) omp_set_num_threads(threads);
+	FILE *output = fopen(output_FN, "wb");
+	if (!output) { fprintf(stderr, "ERROR: Cannot open output: %s\n", output_FN); return 2; }
+	const double start = wall();
+	int rc;
+	if (makedb) {
+		fclose(output);
+		int e = bh_is_edx(ref_FN);
+		if (e < 0) DIE(e);
+		if (e) { fputs("ERROR: DBs can't make DBs.\n", stderr); return 1; }
+		BhDb db;
+		if (!do_shear) db_qlen = 0;                                             /* burst.c:5121 */
+		if ((rc = bh_db_from_fasta(ref_FN, (uint32_t)db_qlen, thres, do_shear, shear_amt, 1, &db))) DIE(rc);
+		puts("Writing database...");
+		if ((rc = bh_edx_write(&db, output_FN, db_qlen, thres))) DIE(rc);
+		printf("Database written: %u refs [%u orig], %u clumps, %u maxR\n", db.totR, db.origTotR, db.numRclumps, db.maxLenR);
+		if (do_accel) {
+			if (!K) K = 12;
+			printf("Generating accelerator '%s' (K=%d)\n", xcel_FN, K);
+			if ((rc = bh_acx_build(&db, K, z))) DIE(rc);
+			if ((rc = bh_acx_write(&db, xcel_FN))) DIE(rc);
+		}
+		bh_db_free(&db);
+		return 0;
+	}
+	if (!query_FN) { puts("ERROR: --queries is required when aligning"); return 1; }
+	BhDb db; memset(&db, 0, sizeof db);
+	int usedb = bh_is_edx(ref_FN);
+	if (usedb < 0) DIE(usedb);
+	if (usedb) {
+		puts("\nEDB database provided. Parsing...");
+		if ((rc = bh_edx_read(ref_FN, &db))) DIE(rc);
+		if (db.xalpha) { fputs("ERROR: DB made with Xalpha; queries can't use Xalpha.\n", stderr); return 1; }
+		printf(" --> EDB: %u refs [%u orig], %u clumps, %u maxR\n", db.totR, db.origTotR, db.numRclumps, db.maxLenR);
+	}
+	if (do_accel) {
+		if (!usedb) { fputs("ERROR: an accelerator needs an .edx database\n", stderr); return 1; }
+		if (!K) { struct stat sb; K = (!stat(xcel_FN, &sb) && (uint64_t)sb.st_size >= 5 + 4 * (1ull << 30)) ? 15 : 12; }
+		if ((rc = bh_acx_read(xcel_FN, K, z, &db))) DIE(rc);
+		printf(" --> [Accel] K=%d, %s format, %u ambiguous clumps\n", K, db.acxFmt ? "LARGE" : "SMALL", db.badSz);
+	}
+	BhQueries Q;
+	if ((rc = bh_queries_load(query_FN, thres, do_rc, incl_ws, do_accel, K ? K : 12, z, skip_ambig, &Q))) DIE(rc);
+	printf("Parsed %lu queries, %lu unique [min %u, max %u, maxED %u]; clear %lu, ambiguous %lu, bad %lu\n", (unsigned long)Q.totQ,
+	       (unsigned long)Q.numUniq, Q.minLen, Q.maxLen, Q.maxED, (unsigned long)Q.nClear, (unsigned long)Q.nAmbig, (unsigned long)Q.nBad);
+	if (!usedb) {
+		if ((rc = bh_db_from_fasta(ref_FN, Q.maxLen, thres, do_shear, shear_amt, dedupe, &db))) DIE(rc);
+		printf("There are %u references and hence %u clumps\n", db.totR, db.numRclumps);
+	} else if (db.shear && (uint32_t)(Q.maxLen / thres) > db.shear) {                /* burst.c:5152-5156 */
+		fputs("ERROR: DB incompatible with selected queries/identity.\n", stderr); return 1;
+	}
+	void *hh = NULL;
+	if ((rc = bh_device_open(&db, device, z, &hh))) { fprintf(stderr, "%s\n", bh_last_error()); return 4; }
+	{ char nm[256]; int ncu = 0; uint64_t hbm = 0; if (!bhip_device_info(hh, nm, sizeof nm, &ncu, &hbm)) printf("Device %d: %s, %d CUs, %.0f GiB\n", device, nm, ncu, hbm / 1073741824.0); }
+	BhRun run;
+	const double t0 = wall();
+	if ((rc = bh_align(hh, &Q, 0, Q.numUniq, mode, batch, &run))) { fprintf(stderr, "%s\n", bh_last_error()); return 4; }
+	const double t1 = wall();
+	printf("Search complete [%f s, %u batches, %lu candidate (query, clump) pairs, %lu hits]. Consolidating results...\n", t1 - t0, run.nBatches,
+	       (unsigned long)run.total.n_pairs, (unsigned long)run.nHits);
+	uint64_t lines = 0;
+	setvbuf(output, NULL, _IOFBF, 1 << 22);
+	if ((rc = bh_report_ex(output, &db, &Q, run.hits, run.nHits, mode, (do_accel ? 0 : BH_REP_MERGED_LIST) | rep_flags, &lines))) DIE(rc);
+	fclose(output);
+	printf("Wrote %lu alignments\n", (unsigned long)lines);
+	bhip_destroy(hh); bh_run_free(&run); bh_queries_free(&Q); bh_db_free(&db);
+	printf("\nAlignment time: %f seconds\n", wall() - start);
+	return 0;
+}

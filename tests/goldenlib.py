@@ -1,0 +1,47 @@
+"""helpers shared by the golden end-to-end tests"""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def cases():
+    return json.load(open(os.path.join(G, "cases.json")))
+
+
+def case_args(c):
+    ref = os.path.join(G, "refs.fa") if c["db"] == "fasta" else os.path.join(G, c["db"] + ".edx")
+    return ref, os.path.join(G, c["queries"]), int("-fr" in c["extra"]), 0 if "-y" in c["extra"] else 1, ("-s" in c["extra"])
+
+
+def golden_lines(c):
+    return open(os.path.join(G, c["name"] + ".b6"), "rb").read().splitlines()
+
+
+def order_sensitive(c):
+    """Cases whose reference output depends on the reference's thread-dependent hit-list order: DUPE_HUNT (FORAGE, and
+    CAPITALIST votes) on the accelerated multi-thread path (burst.c:4019-4021, 4130, 4563-4570)."""
+    return c["accel"] and c["mode"] in ("CAPITALIST", "FORAGE")
+
+
+def compare(c, got_sorted, no_dupe_sorted=None):
+    """exact comparison, or -- for order-sensitive cases -- the relaxed contract: same number of lines, same set of
+    query names, and every reference line is one of the (hit, reference) placements we computed"""
+    exp = golden_lines(c)
+    if not order_sensitive(c):
+        assert got_sorted == exp, "%s: %d lines vs %d expected" % (c["name"], len(got_sorted), len(exp))
+        return "exact"
+    assert len(got_sorted) == len(exp)
+    key = lambda ln: ln.split(b"\t")[0]
+    assert sorted(map(key, got_sorted)) == sorted(map(key, exp))
+    diff = set(exp) - set(got_sorted)
+    assert len(diff) <= max(2, len(exp) // 40), "too many order-dependent lines: %d" % len(diff)
+    if c["mode"] == "CAPITALIST":
+        # a differing line may only differ in the coordinates of an equally voted placement on the same reference
+        strip = lambda ln: tuple(f for i, f in enumerate(ln.split(b"\t")) if i not in (8, 9))
+        mine = {strip(ln) for ln in got_sorted}
+        assert all(strip(ln) in mine for ln in diff)
+    elif no_dupe_sorted is not None:
+        assert set(exp) <= set(no_dupe_sorted), "reference printed a placement we never computed"
+    return "relaxed(%d)" % len(diff)

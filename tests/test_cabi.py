@@ -1,0 +1,51 @@
+"""The C-ABI library loads and exports every symbol include/burst_hip.h declares (no compute without a GPU),
+and refuses to work without a device instead of falling back to the CPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "burst_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bhip_[a-z_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from burst_amd import capi
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    syms = declared_symbols()
+    assert set(capi.EXPORTS) == set(syms)
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert lib.bhip_abi_version() == 1
+    assert ctypes.sizeof(capi.BhipStats) == 96   # 7 u64 + 7 f32 + 2 u32, padded to 8
+    assert capi.HIT_DTYPE.itemsize == 20
+
+
+def test_host_library_exports():
+    lib = ctypes.CDLL(os.path.join(ROOT, "burst_amd", "libburst_host.so"))
+    for s in ["bh_queries_load", "bh_edx_read", "bh_acx_read", "bh_db_from_fasta", "bh_align", "bh_report", "bh_report_ex", "bh_device_open",
+              "bh_acx_build", "bh_edx_write", "bh_score_lut", "bh_error_budget"]:
+        assert hasattr(lib, s), s
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful on a machine without a GPU")
+def test_no_cpu_fallback_without_device():
+    from burst_amd import capi
+    lut = np.zeros(256, np.uint8)
+    with pytest.raises(capi.BurstHipError) as e:
+        capi.Device(np.zeros(64, np.uint8), np.array([8], np.uint32), 1, lut)
+    assert e.value.code == capi.BHIP_E_DEVICE
+
+
+def test_argument_validation():
+    from burst_amd import capi
+    with pytest.raises(capi.BurstHipError) as e:
+        capi.Device(np.zeros(64, np.uint8), np.array([8], np.uint32), 1, np.zeros(256, np.uint8), xalpha=1)
+    assert e.value.code == capi.BHIP_E_ARG

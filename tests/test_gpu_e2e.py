@@ -1,0 +1,58 @@
+"""End to end on the MI355X: the burst_hip command line (C host + libburst_hip.so) against the reference's golden
+.b6 for every case in tests/golden/cases.json -- all modes, with/without accelerator, -fr, -y, direct FASTA."""
+import os
+import subprocess
+
+import pytest
+
+import goldenlib as gl
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(gl.ROOT, "burst_amd", "burst_hip")
+_acx = {}
+
+
+def acx_for(db, z, tmpdir):
+    key = (db, z)
+    if key not in _acx:
+        path = os.path.join(tmpdir, "%s_%d.acx" % (db, z))
+        cmd = [CLI, "-r", os.path.join(gl.G, db + ".edx"), "--make-acx", path] + ([] if z else ["-y"])
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+        _acx[key] = path
+    return _acx[key]
+
+
+@pytest.mark.parametrize("c", gl.cases(), ids=lambda c: c["name"])
+def test_cli_matches_reference(c, tmp_path_factory):
+    tmp = str(tmp_path_factory.getbasetemp())
+    ref, q, fr, z, shear = gl.case_args(c)
+    out = os.path.join(tmp, c["name"] + ".out")
+    cmd = [CLI, "-r", ref, "-q", q, "-o", out, "-m", c["mode"], "-i", c["id"]] + c["extra"]
+    if c["accel"] and c["db"] != "fasta":
+        cmd += ["-a", acx_for(c["db"], z, tmp)]
+
+    def run(extra=()):
+        r = subprocess.run(cmd + list(extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+        return sorted(open(out, "rb").read().splitlines())
+    got = run()
+    nd = run(["--no-dupe-hunt"]) if gl.order_sensitive(c) else None
+    gl.compare(c, got, nd)
+
+
+def test_cli_small_batches_equal_one_batch(tmp_path):
+    """the batch scheduler must not change results: 37 unique queries per device call vs one call"""
+    c = [x for x in gl.cases() if x["name"] == "dna_q100_allpaths_fr"][0]
+    ref, q, fr, z, shear = gl.case_args(c)
+    out = str(tmp_path / "o.b6")
+    acx = acx_for("dna", 1, str(tmp_path))
+    subprocess.check_call([CLI, "-r", ref, "-a", acx, "-q", q, "-o", out, "-m", "ALLPATHS", "-i", "0.95", "-fr", "--batch", "37"], stdout=subprocess.DEVNULL)
+    assert sorted(open(out, "rb").read().splitlines()) == gl.golden_lines(c)
+
+
+def test_cli_error_codes(tmp_path):
+    out = str(tmp_path / "o.b6")
+    r = subprocess.run([CLI, "-r", os.path.join(gl.G, "dna.edx"), "-q", "/nonexistent.fa", "-o", out])
+    assert r.returncode == 2            # cannot open queries (burst.c:639)
+    r = subprocess.run([CLI, "-r", os.path.join(gl.G, "dna.edx"), "-q", os.path.join(gl.G, "q100.fa"), "-o", out, "-m", "NOPE"], stdout=subprocess.DEVNULL)
+    assert r.returncode == 1            # usage (burst.c:4966)

@@ -1,0 +1,41 @@
+"""Host logic without a GPU: the C host library on both sides of the ORACLE (tests/csrc/cpu_e2e.c) must reproduce
+the reference's .b6 for the golden cases -- parsers, query pipeline, .edx reader, direct-FASTA clumping,
+per-mode consolidation, coordinates and formatting.  A subset of the cases keeps the CPU suite short; the GPU
+suite (test_gpu_e2e.py) runs all of them through the real device path."""
+import os
+import subprocess
+
+import pytest
+
+import goldenlib as gl
+
+ROOT = gl.ROOT
+EXE = "/tmp/burst_amd_cpu_e2e"
+SUBSET = ["dna_q100_best_fr", "dna_q100_allpaths_y", "dna_q100_capitalist_noacx_t1_fr", "dna_q292_forage_noacx_t1_fr",
+          "quick_q100_capitalist_fr", "fasta_q100_allpaths_fr", "fasta_q100_best_noshear"]
+
+
+@pytest.fixture(scope="module")
+def exe():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+    subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-fopenmp", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "burst_amd", "csrc", "host"), "-I" + os.path.join(ROOT, "oracle"),
+                           os.path.join(ROOT, "tests", "csrc", "cpu_e2e.c"), "-o", EXE,
+                           "-L" + os.path.join(ROOT, "burst_amd"), "-lburst_host", "-lburst_hip", "-L" + os.path.join(ROOT, "oracle"), "-loracle",
+                           "-Wl,-rpath," + os.path.join(ROOT, "burst_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lm"])
+    return EXE
+
+
+@pytest.mark.parametrize("name", SUBSET)
+def test_host_pipeline_matches_reference(exe, name, tmp_path):
+    c = [x for x in gl.cases() if x["name"] == name][0]
+    ref, q, fr, z, shear = gl.case_args(c)
+    out = str(tmp_path / "o.b6")
+
+    def run(flags):
+        subprocess.check_call([exe, ref, q, out, c["mode"], c["id"], str(fr), str(z), "0" if shear else "-1", str(flags)])
+        return sorted(open(out, "rb").read().splitlines())
+    base = 0 if c["accel"] else 1
+    got = run(base)
+    nd = run(base | 2) if gl.order_sensitive(c) else None
+    gl.compare(c, got, nd)
