@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned reads/sec of the BURST alignment hot path on MI355X.
+
+Workload (BASELINE.json configs[1], the largest single-GPU configuration): 1 M synthetic 100-bp reads (0-3 edits,
+LLsim-style) against a Greengenes-13.8-97%-like database (3 300 base sequences x 30 variants of 1.4 kb = 99 000
+references / 139 Mbp, sheared at 500+113, K=12 accelerator), -m CAPITALIST -i 0.97.  Real Greengenes/RefSeq are
+not reachable offline; sizes and generators are in DESIGN.md section 5.
+
+A step = one pass of the whole hot path (k-mer prefilter -> bit-parallel edit distance -> re-scoring -> hit
+records on the host, sorted) over the batch, with the queries already resident in HBM (bhip_stage_queries) when
+the timed region starts.  N > 1: one process per GPU (torch.distributed / RCCL), the database replicated, every
+rank aligns its own shard of reads (weak scaling), then one variable-length gather of the 20-byte hit records to
+rank 0 inside the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_myers): algorithmic bytes per launch
+(8*ClumpLen + len/2 + 192 per (query, clump) unit) / HIP-event time of that launch.
+`cpu_baseline` is the compiled reference itself (oracle/_ref/burst12, all host cores) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_inputs(workdir, args, rank, world):
+    """rank 0 writes the shared database; every rank writes its own reads"""
+    from burst_amd import host
+    os.makedirs(workdir, exist_ok=True)
+    tag = "b%d_v%d_l%d" % (args.n_base, args.n_variants, args.ref_len)
+    refs = os.path.join(workdir, "refs_%s.fa" % tag)
+    edx = os.path.join(workdir, "db_%s.edx" % tag)
+    acx = os.path.join(workdir, "db_%s.acx" % tag)
+    done = edx + ".done"
+    if rank == 0 and not os.path.exists(done):
+        t = time.time()
+        host.synth_refs(refs, args.n_base, args.n_variants, args.ref_len, args.variant_rate, 7)
+        db = host.Db.from_fasta(refs, 110, args.id, shear_len=500, K=12)
+        db.write(edx, acx, db_qlen=110, thres=args.id)
+        db.close()
+        open(done, "w").write("ok")
+        log("[bench] database built in %.1f s" % (time.time() - t))
+    return refs, edx, acx, done
+
+
+def cpu_baseline(edx, acx, reads_fa, args):
+    """the compiled reference on the host cores: differential timing of two sample sizes cancels its DB load time"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "burst12")
+    if args.no_cpu_baseline or not os.path.exists(exe):
+        return None
+    cores = os.cpu_count() or 1
+    n1, n2 = args.cpu_sample // 6, args.cpu_sample
+    tmp = os.path.dirname(reads_fa)
+    times = []
+    for n in (n1, n2):
+        sample = os.path.join(tmp, "cpu_sample_%d.fa" % n)
+        with open(reads_fa, "rb") as f, open(sample, "wb") as o:
+            for _ in range(2 * n):
+                o.write(f.readline())
+        t = time.time()
+        r = subprocess.run([exe, "-r", edx, "-a", acx, "-q", sample, "-o", sample + ".b6", "-m", "CAPITALIST", "-i", str(args.id),
+                            "-t", str(cores), "--noprogress"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            log("[bench] reference failed:", r.stdout[-400:])
+            return None
+        times.append(time.time() - t)
+    dt = max(times[1] - times[0], 1e-6)
+    return {"value": (n2 - n1) / dt, "unit": "reads/s", "cores": cores, "kind": "reference",
+            "sample": "oracle/_ref/burst12 (reference compiled with gcc -O3 -march=x86-64-v3 -fopenmp) -t %d, same .edx/.acx, "
+                      "-m CAPITALIST -i %s; differential wall time of the first %d vs %d reads (%.2f s vs %.2f s) to cancel DB load"
+                      % (cores, args.id, n1, n2, times[0], times[1])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=1000000)
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--n-base", type=int, default=3300)
+    ap.add_argument("--n-variants", type=int, default=30)
+    ap.add_argument("--ref-len", type=int, default=1400)
+    ap.add_argument("--variant-rate", type=float, default=0.05)
+    ap.add_argument("--id", type=float, default=0.97)
+    ap.add_argument("--mode", default="CAPITALIST")
+    ap.add_argument("--workdir", default=os.environ.get("BURST_BENCH_DIR", "/tmp/burst_amd_bench"))
+    ap.add_argument("--cpu-sample", type=int, default=600000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from burst_amd import capi, host
+    refs, edx, acx, done = build_inputs(args.workdir, args, rank, world)
+    if world > 1:
+        dist.barrier()
+    while not os.path.exists(done):
+        time.sleep(0.2)
+    reads_fa = os.path.join(args.workdir, "reads_%d_r%d.fa" % (args.reads, rank))
+    if not os.path.exists(reads_fa):
+        host.synth_reads(refs, reads_fa, args.reads, args.read_len, [0, 1, 2, 3], rc=False, seed=42 + rank)
+
+    t = time.time()
+    db = host.Db.read(edx, acx, K=12)
+    qs = host.QuerySet(reads_fa, args.id, rc=False, accel=True, K=12)
+    dev = db.open_device(local_rank)
+    info = dev.info()
+    q = qs.batch()
+    dev.stage(q)
+    log("[bench] rank %d: db %d refs / %d clumps, %d reads -> %d unique entries, load+stage %.1f s on %s"
+        % (rank, db.c.totR, db.c.numRclumps, qs.n_reads, q.n, time.time() - t, info["name"]))
+    all_hits = args.mode == "FORAGE"
+    buf = None
+
+    def gather_hits(hits):
+        """one variable-length gather of hit records to rank 0 (all_gather of counts + padded gather over RCCL)"""
+        if world == 1:
+            return hits
+        cnt = torch.tensor([len(hits)], dtype=torch.int64, device="cuda")
+        counts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(counts, cnt)
+        mx = int(max(int(c.item()) for c in counts))
+        pad = torch.zeros(max(mx, 1) * 20, dtype=torch.uint8, device="cuda")
+        if len(hits):
+            pad[:len(hits) * 20] = torch.from_numpy(hits.view(np.uint8).reshape(-1)).cuda()
+        out = [torch.zeros_like(pad) for _ in range(world)] if rank == 0 else None
+        dist.gather(pad, out, dst=0)
+        if rank == 0:
+            return [o[:int(c.item()) * 20].cpu().numpy().view(capi.HIT_DTYPE) for o, c in zip(out, counts)]
+        return None
+
+    def step():
+        nonlocal buf
+        hits, buf = dev.align_staged(all_hits, buf)
+        g = gather_hits(hits)
+        return hits, g
+
+    for _ in range(args.warmup):
+        step()
+    per_step = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        hits, _g = step()
+        per_step.append(dev.stats())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        nr = torch.tensor([qs.n_reads], dtype=torch.int64, device="cuda")
+        dist.all_reduce(nr)
+        total_reads = int(nr.item())
+    else:
+        total_reads = qs.n_reads
+
+    if rank == 0:
+        st = per_step[-1]
+        ms_myers = float(np.mean([s["ms_myers"] for s in per_step]))
+        launches = max(1, st["myers_launches"])
+        achieved = st["bytes_algorithmic"] / launches / (ms_myers / launches * 1e-3) / 1e9 if ms_myers > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_k_myers.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        cells = st["n_columns"] * 16.0 * args.read_len
+        res = {
+            "metric": "aligned reads/sec (node), 100-bp synthetic reads vs GG97-like .edx/.acx, -m %s -i %s" % (args.mode, args.id),
+            "value": total_reads * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 bit-vectors (u8 edit distances)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d synthetic %d-bp reads per GPU vs GG97-like DB (%d refs x %d bp, %d clumps, K=12 .acx), -m %s -i %s"
+                                   % (args.reads, args.read_len, args.n_base * args.n_variants, args.ref_len, db.c.numRclumps, args.mode, args.id),
+                       "parallelism": "query-sharded x%d, DB replicated, RCCL gather of hit records" % world,
+                       "device": info["name"], "n_cu": info["n_cu"]},
+            "roofline": {"bound": "hbm", "kernel": "k_myers<4>", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": traffic,
+                         "note": "integer bit-vector recurrence: VALU-bound by construction (SURVEY 8d); GCUPS below is the truthful figure of merit",
+                         "algorithmic_bytes_per_launch": st["bytes_algorithmic"] / launches, "ms_per_launch": ms_myers / launches,
+                         "gcups_equivalent": cells / (ms_myers * 1e-3) / 1e9 if ms_myers > 0 else 0.0},
+            "phases_ms": {k: float(np.mean([s[k] for s in per_step])) for k in ("ms_peq", "ms_prefilter", "ms_myers", "ms_rescore", "ms_d2h", "ms_total")},
+            "work": {"pairs_per_read": st["n_pairs"] / max(1, q.n), "raw_hits": st["n_raw_hits"], "hits": st["n_hits"],
+                     "acx_entries_per_read": st["acx_entries_read"] / max(1, q.n), "dp_columns": st["n_columns"]},
+        }
+        res["cpu_baseline"] = cpu_baseline(edx, acx, reads_fa, args)
+        if res["cpu_baseline"]:
+            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,7 +34,7 @@ class BhipStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
 
 
-EXPORTS = ["bhip_init", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_get_stats",
+EXPORTS = ["bhip_init", "bhip_stage_queries", "bhip_align_staged", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_get_stats",
            "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version"]
 
 
@@ -54,6 +54,10 @@ def _load():
     lib.bhip_init.restype = i32
     lib.bhip_align_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, u32, i32, vp, u64, C.POINTER(u64)]
     lib.bhip_align_batch.restype = i32
+    lib.bhip_stage_queries.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, u32]
+    lib.bhip_stage_queries.restype = i32
+    lib.bhip_align_staged.argtypes = [vp, i32, vp, u64, C.POINTER(u64)]
+    lib.bhip_align_staged.restype = i32
     lib.bhip_align_pairs.argtypes = [vp, vp, vp, vp, u32, vp, vp, u64, vp]
     lib.bhip_align_pairs.restype = i32
     lib.bhip_prefilter.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, u64, C.POINTER(u64)]
@@ -164,6 +168,23 @@ class Device:
                 continue
             _chk(rc)
             return hits[:n.value]
+
+    def stage(self, q):
+        """upload a batch once (bhip_stage_queries); align_staged() then runs on the resident copy"""
+        self._staged = q     # keep the host arrays alive
+        _chk(lib().bhip_stage_queries(self._h, _ptr(q.codes), _ptr(q.off), _ptr(q.emac), _ptr(q.six), _ptr(q.rc), _ptr(q.flags), q.n, q.n_shared))
+
+    def align_staged(self, all_hits=False, out=None):
+        """out: optional preallocated HIT_DTYPE array reused between calls"""
+        hits = out if out is not None else np.zeros(max(1 << 16, 4 * self._staged.n), dtype=HIT_DTYPE)
+        while True:
+            n = C.c_uint64()
+            rc = lib().bhip_align_staged(self._h, int(bool(all_hits)), _ptr(hits), len(hits), C.byref(n))
+            if rc == BHIP_E_CAPACITY:
+                hits = np.zeros(int(n.value) + 16, dtype=HIT_DTYPE)
+                continue
+            _chk(rc)
+            return hits[:n.value], hits
 
     def align_pairs(self, q, pair_q, pair_clump):
         pair_q = _arr(pair_q, np.uint32)

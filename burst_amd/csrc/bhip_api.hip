@@ -60,6 +60,7 @@ static int class_of_len(uint32_t len) {
 // device-side counters, one block copied back per call
 struct Counters {
 	uint32_t n_cand, n_raw, n_out, n_wide, err, pad0;
+	uint32_t n_cand_cls[8];
 	unsigned long long col_sum, qlen_sum, ent_read, scratch_used;
 };
 
@@ -80,7 +81,15 @@ struct Handle {
 	uint64_t cand_cap = 1 << 20, raw_cap = 1 << 20, out_cap = 1 << 20, scratch_cap = 1 << 20;
 	std::vector<uint32_t> h_clump_len;
 	BhipStats stats;
+	// staged batch (bhip_stage_queries)
+	bool st_valid = false, st_has_six = false, st_has_rc = false;
+	uint32_t st_nq = 0, st_nshared = 0, st_npf[kNumClasses] = {0}, st_nex[kNumClasses] = {0};
+	float st_ms_h2d = 0;
+	DBuf qlist_cls[kNumClasses];
+	hipEvent_t ev_cls[kNumClasses][5];
 };
+
+static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 
 extern "C" const char *bhip_last_error(void) { return g_err; }
 extern "C" int bhip_abi_version(void) { return BHIP_ABI_VERSION; }
@@ -95,6 +104,8 @@ extern "C" void bhip_destroy(void *handle) {
 		&h->counters, &h->mins, &h->pairs};
 	for (DBuf *b : all) b->release();
 	for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+	for (auto &ce : h->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
+	for (auto &b : h->qlist_cls) b.release();
 	if (h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -114,6 +125,7 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 	HIPCHK(hipSetDevice(device));
 	Handle *h = new Handle();
 	memset(h->ev, 0, sizeof h->ev);
+	memset(h->ev_cls, 0, sizeof h->ev_cls);
 	memset(&h->stats, 0, sizeof h->stats);
 	h->device = device;
 	hipDeviceProp_t prop;
@@ -127,6 +139,7 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 	#define INITRC(x) do { int rc_ = (x); if (rc_) { bhip_destroy(h); return rc_; } } while (0)
 	INITCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 	for (auto &e : h->ev) INITCHK(hipEventCreate(&e));
+	for (auto &ce : h->ev_cls) for (auto &e : ce) INITCHK(hipEventCreate(&e));
 	h->n_clumps = n_clumps; h->tot_refs = tot_refs;
 	h->h_clump_len.assign(clump_len, clump_len + n_clumps);
 	for (int a = 0; a < 16; ++a) {
@@ -260,7 +273,7 @@ static int upload_queries(Handle *h, const uint8_t *q_codes, const uint64_t *q_o
 }
 
 static int launch_prefilter(Handle *h, const uint32_t *d_qlist, uint32_t n_list, uint2 *cand, uint32_t *candcnt, uint32_t cand_cap,
-                            bool with_bad, Counters *dc) {
+                            bool with_bad, uint32_t *n_cand_dev, Counters *dc) {
 	const uint32_t nw32 = (h->n_clumps + 1) / 2;
 	const size_t lds = (size_t)nw32 * 4;
 	const uint32_t *bad = with_bad ? h->bad.as<uint32_t>() : nullptr;
@@ -272,32 +285,31 @@ static int launch_prefilter(Handle *h, const uint32_t *d_qlist, uint32_t n_list,
 			HIPCHK(hipFuncSetAttribute((const void *)k_prefilter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		hipLaunchKernelGGL(k_prefilter<true>, dim3(grid), dim3(256), lds, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps,
-			(uint32_t *)nullptr, bad, n_bad, cand, candcnt, &dc->n_cand, cand_cap, &dc->ent_read);
+			(uint32_t *)nullptr, bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read);
 	} else {
 		uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * 4);
 		int rc = h->gcnt.reserve((size_t)grid * nw32 * 4);
 		if (rc) return rc;
 		hipLaunchKernelGGL(k_prefilter<false>, dim3(grid), dim3(256), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps,
-			h->gcnt.as<uint32_t>(), bad, n_bad, cand, candcnt, &dc->n_cand, cand_cap, &dc->ent_read);
+			h->gcnt.as<uint32_t>(), bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
 }
 
-static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 
-extern "C" int bhip_align_batch(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
-                                const uint32_t *q_six, const uint8_t *q_rc, const uint8_t *q_flags,
-                                uint32_t n_q, uint32_t n_shared, int all_hits,
-                                BhipHit *hits, uint64_t cap, uint64_t *n_hits) {
+// ---- staged batch: inputs resident in HBM, then any number of runs over them ---------------------------------
+extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
+                                  const uint32_t *q_six, const uint8_t *q_rc, const uint8_t *q_flags, uint32_t n_q, uint32_t n_shared) {
 	Handle *h = (Handle *)handle;
-	if (!h || !n_hits) return fail(BHIP_E_ARG, "null argument");
-	*n_hits = 0;
-	memset(&h->stats, 0, sizeof h->stats);
-	if (!n_q) return BHIP_OK;
+	if (!h) return fail(BHIP_E_ARG, "null handle");
+	h->st_valid = false;
+	h->st_nq = n_q; h->st_has_six = q_six != nullptr; h->st_has_rc = q_rc != nullptr;
+	h->st_nshared = q_six ? n_shared : n_q;
+	for (int c = 0; c < kNumClasses; ++c) { h->st_npf[c] = h->st_nex[c] = 0; }
+	if (!n_q) { h->st_valid = true; return BHIP_OK; }
 	if (!q_codes || !q_off || !q_emac) return fail(BHIP_E_ARG, "null query arrays");
-	if (!q_six) n_shared = n_q;
 	HIPCHK(hipSetDevice(h->device));
 	// host-side routing: class by length, prefilter vs exhaustive
 	std::vector<uint32_t> lists[kNumClasses][2];
@@ -311,94 +323,105 @@ extern "C" int bhip_align_batch(void *handle, const uint8_t *q_codes, const uint
 		if (!h->has_acx) ex = 1;
 		lists[cls][ex].push_back(i);
 	}
+	HIPCHK(hipEventRecord(h->ev[0], h->stream));
+	int rc;
+	if ((rc = upload_queries(h, q_codes, q_off, q_emac, q_six, q_rc, n_q))) return rc;
+	for (int cls = 0; cls < kNumClasses; ++cls) {
+		const size_t n_pf = lists[cls][0].size(), n_ex = lists[cls][1].size();
+		h->st_npf[cls] = (uint32_t)n_pf; h->st_nex[cls] = (uint32_t)n_ex;
+		if (!(n_pf + n_ex)) continue;
+		std::vector<uint32_t> ql(lists[cls][0]);
+		ql.insert(ql.end(), lists[cls][1].begin(), lists[cls][1].end());
+		if ((rc = h->qlist_cls[cls].reserve(ql.size() * 4))) return rc;
+		HIPCHK(hipMemcpy(h->qlist_cls[cls].p, ql.data(), ql.size() * 4, hipMemcpyHostToDevice));
+	}
+	HIPCHK(hipEventRecord(h->ev[1], h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	h->st_ms_h2d = ev_ms(h->ev[0], h->ev[1]);
+	h->st_valid = true;
+	return BHIP_OK;
+}
+
+extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint64_t cap, uint64_t *n_hits) {
+	Handle *h = (Handle *)handle;
+	if (!h || !n_hits) return fail(BHIP_E_ARG, "null argument");
+	*n_hits = 0;
+	memset(&h->stats, 0, sizeof h->stats);
+	if (!h->st_valid) return fail(BHIP_E_ARG, "no staged queries (call bhip_stage_queries first)");
+	const uint32_t n_q = h->st_nq, n_shared = h->st_nshared;
+	if (!n_q) return BHIP_OK;
+	HIPCHK(hipSetDevice(h->device));
 	Counters hc;
 	for (int attempt = 0; attempt < 6; ++attempt) {
 		int rc;
-		HIPCHK(hipEventRecord(h->ev[0], h->stream));
-		if ((rc = upload_queries(h, q_codes, q_off, q_emac, q_six, q_rc, n_q))) return rc;
 		if ((rc = h->best.reserve((size_t)(n_shared + 1) * 4))) return rc;
 		if ((rc = h->cand.reserve(h->cand_cap * sizeof(uint2)))) return rc;
 		if ((rc = h->raw.reserve(h->raw_cap * sizeof(BhipRawHit)))) return rc;
 		if ((rc = h->wide.reserve(h->raw_cap * sizeof(uint32_t)))) return rc;
 		if ((rc = h->out.reserve(h->out_cap * sizeof(BhipHit)))) return rc;
 		if ((rc = h->scratch.reserve(h->scratch_cap * sizeof(uint32_t)))) return rc;
+		for (int cls = 0; cls < kNumClasses; ++cls) if (h->st_npf[cls] + h->st_nex[cls])
+			if ((rc = h->peq.reserve((size_t)(h->st_npf[cls] + h->st_nex[cls]) * 16 * kClasses[cls] * 4))) return rc;
+		HIPCHK(hipEventRecord(h->ev[0], h->stream));
 		HIPCHK(hipMemsetAsync(h->best.p, 0xFF, (size_t)n_shared * 4, h->stream));
 		HIPCHK(hipMemsetAsync(h->counters.p, 0, sizeof(Counters), h->stream));
 		Counters *dc = h->counters.as<Counters>();
-		HIPCHK(hipEventRecord(h->ev[1], h->stream));
-		float ms_pf = 0, ms_peq = 0, ms_my = 0;
 		uint64_t n_pairs_ex = 0;
 		uint32_t launches = 0;
-		bool cand_overflow = false;
+		const uint32_t grid_my = (uint32_t)h->n_cu * 8;
 		for (int cls = 0; cls < kNumClasses; ++cls) {
-			const uint32_t n_pf = (uint32_t)lists[cls][0].size(), n_ex = (uint32_t)lists[cls][1].size(), n_list = n_pf + n_ex;
+			const uint32_t n_pf = h->st_npf[cls], n_ex = h->st_nex[cls], n_list = n_pf + n_ex;
 			if (!n_list) continue;
 			const int NW = kClasses[cls];
-			std::vector<uint32_t> ql(lists[cls][0]);
-			ql.insert(ql.end(), lists[cls][1].begin(), lists[cls][1].end());
-			if ((rc = h->qlist.reserve((size_t)n_list * 4))) return rc;
-			if ((rc = h->peq.reserve((size_t)n_list * 16 * NW * 4))) return rc;
-			// the previous class may still be reading qlist/peq on the stream: same stream, so ordering is implicit
-			HIPCHK(hipMemcpyAsync(h->qlist.p, ql.data(), (size_t)n_list * 4, hipMemcpyHostToDevice, h->stream));
-			HIPCHK(hipStreamSynchronize(h->stream));   // ql is a stack vector; keep it alive until copied
-			HIPCHK(hipEventRecord(h->ev[2], h->stream));
+			const uint32_t *qlist = h->qlist_cls[cls].as<uint32_t>();
+			hipEvent_t *ce = h->ev_cls[cls];
+			HIPCHK(hipEventRecord(ce[0], h->stream));
 			{
 				const uint64_t total = (uint64_t)n_list * 16 * NW;
 				const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16);
 				hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-					h->qlist.as<uint32_t>(), n_list, NW, h->mm, h->peq.as<uint32_t>());
+					qlist, n_list, NW, h->mm, h->peq.as<uint32_t>());
 				HIPCHK(hipGetLastError());
 			}
-			HIPCHK(hipEventRecord(h->ev[3], h->stream));
-			const uint32_t grid_my = (uint32_t)h->n_cu * 8;
+			HIPCHK(hipEventRecord(ce[1], h->stream));
 			if (n_pf) {
-				HIPCHK(hipMemsetAsync(&dc->n_cand, 0, 4, h->stream));
-				if ((rc = launch_prefilter(h, h->qlist.as<uint32_t>(), n_pf, h->cand.as<uint2>(), nullptr, (uint32_t)h->cand_cap, true, dc))) return rc;
-				HIPCHK(hipEventRecord(h->ev[4], h->stream));
-				launch_myers(h, cls, grid_my, h->cand.as<uint2>(), &dc->n_cand, 0, 0, h->qlist.as<uint32_t>(), h->raw.as<BhipRawHit>(),
+				if ((rc = launch_prefilter(h, qlist, n_pf, h->cand.as<uint2>(), nullptr, (uint32_t)h->cand_cap, true, &dc->n_cand_cls[cls], dc))) return rc;
+				HIPCHK(hipEventRecord(ce[2], h->stream));
+				launch_myers(h, cls, grid_my, h->cand.as<uint2>(), &dc->n_cand_cls[cls], 0, 0, qlist, h->raw.as<BhipRawHit>(),
 					&dc->n_raw, (uint32_t)h->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
 				HIPCHK(hipGetLastError());
 				++launches;
-				// the candidate count is needed on the host only to detect overflow and for the stats
-				uint32_t nc = 0;
-				HIPCHK(hipMemcpyAsync(&nc, &dc->n_cand, 4, hipMemcpyDeviceToHost, h->stream));
-				HIPCHK(hipEventRecord(h->ev[5], h->stream));
-				HIPCHK(hipStreamSynchronize(h->stream));
-				ms_pf += ev_ms(h->ev[3], h->ev[4]); ms_my += ev_ms(h->ev[4], h->ev[5]);
-				if (nc > h->cand_cap) { h->cand_cap = (uint64_t)nc + nc / 8 + 1024; cand_overflow = true; break; }
-				h->stats.n_pairs += nc;
-			} else HIPCHK(hipEventRecord(h->ev[4], h->stream));
+			} else HIPCHK(hipEventRecord(ce[2], h->stream));
+			HIPCHK(hipEventRecord(ce[3], h->stream));
 			if (n_ex) {
 				const uint64_t np = (uint64_t)n_ex * h->n_clumps;
-				HIPCHK(hipEventRecord(h->ev[6], h->stream));
-				launch_myers(h, cls, (uint32_t)std::min<uint64_t>((np + 15) / 16, grid_my), nullptr, nullptr, np, n_pf, h->qlist.as<uint32_t>(),
+				launch_myers(h, cls, (uint32_t)std::min<uint64_t>((np + 15) / 16, grid_my), nullptr, nullptr, np, n_pf, qlist,
 					h->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)h->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
 				HIPCHK(hipGetLastError());
 				++launches;
-				HIPCHK(hipEventRecord(h->ev[7], h->stream));
-				HIPCHK(hipStreamSynchronize(h->stream));
-				ms_my += ev_ms(h->ev[6], h->ev[7]);
 				n_pairs_ex += np;
 			}
-			ms_peq += ev_ms(h->ev[2], h->ev[3]);
+			HIPCHK(hipEventRecord(ce[4], h->stream));
 		}
-		if (cand_overflow) continue;
 		// rescoring of the kept lanes
 		HIPCHK(hipEventRecord(h->ev[6], h->stream));
 		const uint32_t grid_rs = (uint32_t)h->n_cu * 16;
 		hipLaunchKernelGGL(k_rescore<false>, dim3(grid_rs), dim3(64), 0, h->stream, h->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)h->raw_cap,
 			(const uint32_t *)nullptr, (const uint32_t *)nullptr, h->best.as<uint32_t>(), all_hits, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-			q_six ? h->qsix.as<uint32_t>() : nullptr, q_rc ? h->qrc.as<uint8_t>() : nullptr, h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(),
+			h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr, h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(),
 			h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &dc->n_out, (uint32_t)h->out_cap, h->wide.as<uint32_t>(),
 			&dc->n_wide, (uint32_t *)nullptr, &dc->scratch_used, 0ull, &dc->err);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
-		if (hc.n_raw > h->raw_cap) { h->raw_cap = (uint64_t)hc.n_raw + hc.n_raw / 8 + 1024; continue; }
+		bool retry = false;
+		for (int cls = 0; cls < kNumClasses; ++cls) if (hc.n_cand_cls[cls] > h->cand_cap) { h->cand_cap = (uint64_t)hc.n_cand_cls[cls] + hc.n_cand_cls[cls] / 8 + 1024; retry = true; }
+		if (hc.n_raw > h->raw_cap) { h->raw_cap = (uint64_t)hc.n_raw + hc.n_raw / 8 + 1024; retry = true; }
+		if (retry) continue;
 		if (hc.n_wide) {
 			hipLaunchKernelGGL(k_rescore<true>, dim3(std::min<uint32_t>((hc.n_wide + 63) / 64, grid_rs)), dim3(64), 0, h->stream,
 				h->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)h->raw_cap, h->wide.as<uint32_t>(), &dc->n_wide, h->best.as<uint32_t>(), all_hits,
-				h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), q_six ? h->qsix.as<uint32_t>() : nullptr, q_rc ? h->qrc.as<uint8_t>() : nullptr,
+				h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr,
 				h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(),
 				&dc->n_out, (uint32_t)h->out_cap, (uint32_t *)nullptr, (uint32_t *)nullptr, h->scratch.as<uint32_t>(), &dc->scratch_used,
 				(unsigned long long)h->scratch_cap, &dc->err);
@@ -411,7 +434,8 @@ extern "C" int bhip_align_batch(void *handle, const uint8_t *q_codes, const uint
 		if (hc.err & 1u) return fail(BHIP_E_INTERNAL, "re-scoring could not reproduce a hit found by the edit-distance kernel");
 		if (hc.n_out > h->out_cap) { h->out_cap = (uint64_t)hc.n_out + hc.n_out / 8 + 1024; continue; }
 		*n_hits = hc.n_out;
-		h->stats.n_queries = n_q; h->stats.n_pairs += n_pairs_ex; h->stats.n_columns = hc.col_sum; h->stats.n_raw_hits = hc.n_raw;
+		h->stats.n_queries = n_q; h->stats.n_pairs = n_pairs_ex; h->stats.n_columns = hc.col_sum; h->stats.n_raw_hits = hc.n_raw;
+		for (int cls = 0; cls < kNumClasses; ++cls) h->stats.n_pairs += hc.n_cand_cls[cls];
 		h->stats.n_hits = hc.n_out; h->stats.acx_entries_read = hc.ent_read; h->stats.myers_launches = launches;
 		h->stats.bytes_algorithmic = 8ull * hc.col_sum + hc.qlen_sum / 2 + 192ull * h->stats.n_pairs;
 		if (hc.n_out > cap) return fail(BHIP_E_CAPACITY, "hit buffer holds %llu records, %u needed", (unsigned long long)cap, hc.n_out);
@@ -420,11 +444,28 @@ extern "C" int bhip_align_batch(void *handle, const uint8_t *q_codes, const uint
 		HIPCHK(hipEventRecord(h->ev[9], h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		std::sort(hits, hits + hc.n_out, [](const BhipHit &a, const BhipHit &b) { return a.q != b.q ? a.q < b.q : a.refIx < b.refIx; });
-		h->stats.ms_h2d = ev_ms(h->ev[0], h->ev[1]); h->stats.ms_prefilter = ms_pf; h->stats.ms_peq = ms_peq; h->stats.ms_myers = ms_my;
+		for (int cls = 0; cls < kNumClasses; ++cls) if (h->st_npf[cls] + h->st_nex[cls]) {
+			hipEvent_t *ce = h->ev_cls[cls];
+			h->stats.ms_peq += ev_ms(ce[0], ce[1]);
+			if (h->st_npf[cls]) { h->stats.ms_prefilter += ev_ms(ce[1], ce[2]); h->stats.ms_myers += ev_ms(ce[2], ce[3]); }
+			if (h->st_nex[cls]) h->stats.ms_myers += ev_ms(ce[3], ce[4]);
+		}
+		h->stats.ms_h2d = h->st_ms_h2d;
 		h->stats.ms_rescore = ev_ms(h->ev[6], h->ev[7]); h->stats.ms_d2h = ev_ms(h->ev[8], h->ev[9]); h->stats.ms_total = ev_ms(h->ev[0], h->ev[9]);
 		return BHIP_OK;
 	}
 	return fail(BHIP_E_INTERNAL, "buffers kept overflowing");
+}
+
+extern "C" int bhip_align_batch(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
+                                const uint32_t *q_six, const uint8_t *q_rc, const uint8_t *q_flags,
+                                uint32_t n_q, uint32_t n_shared, int all_hits,
+                                BhipHit *hits, uint64_t cap, uint64_t *n_hits) {
+	if (!n_hits) return fail(BHIP_E_ARG, "null argument");
+	*n_hits = 0;
+	int rc = bhip_stage_queries(handle, q_codes, q_off, q_emac, q_six, q_rc, q_flags, n_q, n_shared);
+	if (rc) return rc;
+	return bhip_align_staged(handle, all_hits, hits, cap, n_hits);
 }
 
 extern "C" int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
@@ -486,7 +527,7 @@ extern "C" int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64
 		HIPCHK(hipMemsetAsync(h->counters.p, 0, sizeof(Counters), h->stream));
 		Counters *dc = h->counters.as<Counters>();
 		HIPCHK(hipEventRecord(h->ev[0], h->stream));
-		if ((rc = launch_prefilter(h, nullptr, n_q, h->cand.as<uint2>(), h->candcnt.as<uint32_t>(), (uint32_t)h->cand_cap, false, dc))) return rc;
+		if ((rc = launch_prefilter(h, nullptr, n_q, h->cand.as<uint2>(), h->candcnt.as<uint32_t>(), (uint32_t)h->cand_cap, false, &dc->n_cand, dc))) return rc;
 		HIPCHK(hipEventRecord(h->ev[1], h->stream));
 		Counters hc;
 		HIPCHK(hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, h->stream));

@@ -1,0 +1,211 @@
+"""ctypes binding of libburst_host.so (C host: burst_amd/csrc/host/burst_host.h) for the tests, the bench and the
+multi-GPU driver.  All logic lives in C; this module only moves pointers."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libburst_host.so")
+MODES = {"FORAGE": 0, "BEST": 1, "ALLPATHS": 2, "CAPITALIST": 3, "ANY": 4}
+REP_MERGED_LIST, REP_NO_DUPE_HUNT = 1, 2
+
+u8p, u16p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+
+
+class BhDb(C.Structure):
+    _fields_ = [("rebase", C.c_int), ("xalpha", C.c_int),
+                ("shear", C.c_uint32), ("totR", C.c_uint32), ("origTotR", C.c_uint32), ("numRclumps", C.c_uint32),
+                ("maxLenR", C.c_uint32), ("numRefHeads", C.c_uint32),
+                ("headDump", C.c_void_p), ("refHead", C.c_void_p), ("refMap", u32p), ("refStart", u32p), ("refDedupIx", u32p),
+                ("tmpRIX", u32p), ("refIxSrt", u32p), ("clumpLen", u32p), ("packed", u8p), ("packedWords", C.c_uint64),
+                ("hasAcx", C.c_int), ("K", C.c_int), ("acxFmt", C.c_int), ("acxZ", C.c_int),
+                ("acxLens", u32p), ("acxLists", u8p), ("acxListBytes", C.c_uint64), ("badList", u32p), ("badSz", C.c_uint32),
+                ("identityMap", C.c_int), ("owned", C.c_void_p * 32), ("nOwned", C.c_int)]
+
+
+class BhQueries(C.Structure):
+    _fields_ = [("totQ", C.c_uint64), ("numUniq", C.c_uint64), ("numEntries", C.c_uint64),
+                ("dump", C.c_void_p), ("heads", C.c_void_p), ("offset", u64p), ("codes", u8p), ("qoff", u64p),
+                ("six", u32p), ("rc", u8p), ("flags", u8p), ("emac", u16p), ("len", u32p), ("ed", u16p),
+                ("maxLen", C.c_uint32), ("minLen", C.c_uint32), ("maxED", C.c_uint32),
+                ("nClear", C.c_uint64), ("nAmbig", C.c_uint64), ("nBad", C.c_uint64)]
+
+
+class BhRun(C.Structure):
+    _fields_ = [("hits", C.c_void_p), ("nHits", C.c_uint64), ("secAlign", C.c_double), ("total", capi.BhipStats), ("nBatches", C.c_uint32)]
+
+
+class HostError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run __graft_entry__.build()" % LIB_PATH)
+        capi.lib()   # libburst_hip.so first (rpath covers it, this gives the clearer error)
+        L = C.CDLL(LIB_PATH)
+        L.bh_last_error.restype = C.c_char_p
+        L.bh_queries_load.argtypes = [C.c_char_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(BhQueries)]
+        L.bh_queries_free.argtypes = [C.POINTER(BhQueries)]
+        L.bh_edx_read.argtypes = [C.c_char_p, C.POINTER(BhDb)]
+        L.bh_acx_read.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(BhDb)]
+        L.bh_db_from_fasta.argtypes = [C.c_char_p, C.c_uint32, C.c_float, C.c_int, C.c_long, C.c_int, C.POINTER(BhDb)]
+        L.bh_edx_write.argtypes = [C.POINTER(BhDb), C.c_char_p, C.c_long, C.c_float]
+        L.bh_acx_build.argtypes = [C.POINTER(BhDb), C.c_int, C.c_int]
+        L.bh_acx_write.argtypes = [C.POINTER(BhDb), C.c_char_p]
+        L.bh_db_free.argtypes = [C.POINTER(BhDb)]
+        L.bh_device_open.argtypes = [C.POINTER(BhDb), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.bh_align.argtypes = [C.c_void_p, C.POINTER(BhQueries), C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(BhRun)]
+        L.bh_run_free.argtypes = [C.POINTER(BhRun)]
+        L.bh_report_ex.argtypes = [C.c_void_p, C.POINTER(BhDb), C.POINTER(BhQueries), C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+        L.bh_synth_refs.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint64]
+        L.bh_synth_reads.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint32, u32p, C.c_uint32, C.c_int, C.c_double, C.c_uint64]
+        L.bh_score_lut.argtypes = [C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise HostError("libburst_host error %d: %s" % (rc, lib().bh_last_error().decode("utf-8", "replace")))
+
+
+def _view(ptr, n, dtype):
+    if not n or not ptr:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(int(n),)).view(dtype)
+
+
+class Db:
+    def __init__(self):
+        self.c = BhDb()
+        self._open = False
+
+    @classmethod
+    def read(cls, edx, acx=None, K=12, z=1):
+        d = cls()
+        _chk(lib().bh_edx_read(edx.encode(), C.byref(d.c)))
+        d._open = True
+        if acx:
+            _chk(lib().bh_acx_read(acx.encode(), K, z, C.byref(d.c)))
+        return d
+
+    @classmethod
+    def from_fasta(cls, fasta, max_len_q, thres, shear_len=500, dedupe=True, K=None, z=1):
+        d = cls()
+        _chk(lib().bh_db_from_fasta(fasta.encode(), max_len_q, thres, 1 if shear_len else 0, shear_len or 0, int(dedupe), C.byref(d.c)))
+        d._open = True
+        d.c.identityMap = 0            # a database, not a direct-FASTA run
+        if K:
+            _chk(lib().bh_acx_build(C.byref(d.c), K, z))
+        return d
+
+    def write(self, edx, acx=None, db_qlen=0, thres=0.97):
+        _chk(lib().bh_edx_write(C.byref(self.c), edx.encode(), db_qlen, thres))
+        if acx:
+            _chk(lib().bh_acx_write(C.byref(self.c), acx.encode()))
+
+    def open_device(self, device=0, z=1):
+        h = C.c_void_p()
+        _chk(lib().bh_device_open(C.byref(self.c), device, z, C.byref(h)))
+        dev = capi.Device.__new__(capi.Device)
+        dev._h = h
+        dev.n_clumps = self.c.numRclumps
+        dev.clump_len = _view(self.c.clumpLen, self.c.numRclumps, np.uint32)
+        return dev
+
+    def close(self):
+        if self._open:
+            lib().bh_db_free(C.byref(self.c))
+            self._open = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class QuerySet:
+    def __init__(self, fasta, thres, rc=False, accel=True, K=12, z=1, whitespace=False):
+        self.c = BhQueries()
+        _chk(lib().bh_queries_load(fasta.encode(), thres, int(rc), int(whitespace), int(accel), K, z, 0, C.byref(self.c)))
+        c = self.c
+        self.n_reads, self.n_uniq, self.n_entries = int(c.totQ), int(c.numUniq), int(c.numEntries)
+
+    def batch(self, u0=0, u1=None):
+        """capi.Queries view (no copy for the forward-only case) of unique queries [u0, u1) with their RC twins"""
+        c = self.c
+        u1 = self.n_uniq if u1 is None else min(u1, self.n_uniq)
+        qoff = _view(c.qoff, self.n_entries + 1, np.uint64)
+        codes = _view(c.codes, int(qoff[-1]), np.uint8)
+        ent = np.arange(u0, u1, dtype=np.int64)
+        if self.n_entries > self.n_uniq:
+            ent = np.concatenate([ent, ent + self.n_uniq])
+        q = capi.Queries.__new__(capi.Queries)
+        lens = (qoff[ent + 1] - qoff[ent]).astype(np.uint64)
+        q.off = np.zeros(len(ent) + 1, np.uint64)
+        np.cumsum(lens, out=q.off[1:])
+        if self.n_entries == self.n_uniq:
+            q.codes = codes[int(qoff[u0]):int(qoff[u1])]
+        else:
+            q.codes = np.concatenate([codes[int(qoff[u0]):int(qoff[u1])], codes[int(qoff[self.n_uniq + u0]):int(qoff[self.n_uniq + u1])]])
+        q.emac = np.ascontiguousarray(_view(c.emac, self.n_entries, np.uint16)[ent])
+        q.six = (np.ascontiguousarray(_view(c.six, self.n_entries, np.uint32)[ent]) - np.uint32(u0)).astype(np.uint32)
+        q.rc = np.ascontiguousarray(_view(c.rc, self.n_entries, np.uint8)[ent])
+        q.flags = np.ascontiguousarray(_view(c.flags, self.n_entries, np.uint8)[ent])
+        q.n = len(ent)
+        q.n_shared = u1 - u0
+        q.entry_index = ent
+        return q
+
+    def reads_in(self, u0, u1):
+        off = _view(self.c.offset, self.n_uniq + 1, np.uint64)
+        return int(off[min(u1, self.n_uniq)] - off[u0])
+
+    def close(self):
+        if self.c.codes:
+            lib().bh_queries_free(C.byref(self.c))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+libc = C.CDLL(None)
+libc.fopen.restype = C.c_void_p
+libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+libc.fclose.argtypes = [C.c_void_p]
+
+
+def report(path, db, qs, hits, mode, flags=0):
+    """hits: HIT_DTYPE array with q = global entry index, records of one entry contiguous"""
+    f = libc.fopen(path.encode(), b"wb")
+    if not f:
+        raise HostError("cannot open %s" % path)
+    n = C.c_uint64()
+    hits = np.ascontiguousarray(hits)
+    try:
+        _chk(lib().bh_report_ex(f, C.byref(db.c), C.byref(qs.c), hits.ctypes.data_as(C.c_void_p), len(hits), MODES[mode], flags, C.byref(n)))
+    finally:
+        libc.fclose(f)
+    return int(n.value)
+
+
+def synth_refs(path, n_base, n_variants, length, rate, seed):
+    _chk(lib().bh_synth_refs(path.encode(), n_base, n_variants, length, rate, seed))
+
+
+def synth_reads(refs, path, n_reads, read_len, edits, rc=False, iupac=0.0, seed=42):
+    e = np.ascontiguousarray(edits, np.uint32)
+    _chk(lib().bh_synth_reads(refs.encode(), path.encode(), n_reads, read_len, e.ctypes.data_as(u32p), len(e), int(rc), iupac, seed))
