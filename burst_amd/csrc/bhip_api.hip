@@ -2,6 +2,7 @@
 // Owns device memory, one HIP stream per handle, HIP-event timing of every phase, and the batch driver
 // that replaces the bodies of the two OpenMP loops in do_alignments (burst.c:4077-4289, 4343-4484).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -25,6 +26,17 @@ template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_
 	const uint32_t *, int, const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t *, const uint64_t *,
 	const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *,
 	unsigned long long, uint32_t *);
+
+// ---- ordering of the output records: (q, refIx) ascending, done on the device (radix sort of 64-bit keys) ----
+__global__ void k_hit_keys(const BhipHit *__restrict__ hits, uint32_t n, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		keys[i] = ((uint64_t)hits[i].q << 32) | hits[i].refIx;
+		idx[i] = i;
+	}
+}
+__global__ void k_hit_gather(const BhipHit *__restrict__ in, const uint32_t *__restrict__ idx, uint32_t n, BhipHit *__restrict__ out) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[idx[i]];
+}
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -78,6 +90,7 @@ struct Handle {
 	DBuf acx_off, acx_ent, bad; uint32_t n_bad = 0; uint64_t n_ent = 0;
 	// batch buffers
 	DBuf qcodes, qoff, qemac, qsix, qrc, qlist, peq, cand, candcnt, raw, best, out, wide, scratch, gcnt, counters, mins, pairs;
+	DBuf sort_keys, sort_keys2, sort_idx, sort_idx2, sort_tmp, out_sorted;
 	uint64_t cand_cap = 1 << 20, raw_cap = 1 << 20, out_cap = 1 << 20, scratch_cap = 1 << 20;
 	std::vector<uint32_t> h_clump_len;
 	BhipStats stats;
@@ -101,7 +114,7 @@ extern "C" void bhip_destroy(void *handle) {
 	if (h->stream) (void)hipStreamSynchronize(h->stream);
 	DBuf *all[] = {&h->ref, &h->ref_off, &h->clump_len, &h->lut, &h->acx_off, &h->acx_ent, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
 		&h->qsix, &h->qrc, &h->qlist, &h->peq, &h->cand, &h->candcnt, &h->raw, &h->best, &h->out, &h->wide, &h->scratch, &h->gcnt,
-		&h->counters, &h->mins, &h->pairs};
+		&h->counters, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx, &h->sort_idx2, &h->sort_tmp, &h->out_sorted};
 	for (DBuf *b : all) b->release();
 	for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &ce : h->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
@@ -387,7 +400,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			if (n_pf) {
 				if ((rc = launch_prefilter(h, qlist, n_pf, h->cand.as<uint2>(), nullptr, (uint32_t)h->cand_cap, true, &dc->n_cand_cls[cls], dc))) return rc;
 				HIPCHK(hipEventRecord(ce[2], h->stream));
-				launch_myers(h, cls, grid_my, h->cand.as<uint2>(), &dc->n_cand_cls[cls], 0, 0, qlist, h->raw.as<BhipRawHit>(),
+				launch_myers(h, cls, grid_my, h->cand.as<uint2>(), &dc->n_cand_cls[cls], h->cand_cap, 0, qlist, h->raw.as<BhipRawHit>(),
 					&dc->n_raw, (uint32_t)h->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
 				HIPCHK(hipGetLastError());
 				++launches;
@@ -440,10 +453,25 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		h->stats.bytes_algorithmic = 8ull * hc.col_sum + hc.qlen_sum / 2 + 192ull * h->stats.n_pairs;
 		if (hc.n_out > cap) return fail(BHIP_E_CAPACITY, "hit buffer holds %llu records, %u needed", (unsigned long long)cap, hc.n_out);
 		HIPCHK(hipEventRecord(h->ev[8], h->stream));
-		if (hc.n_out) HIPCHK(hipMemcpyAsync(hits, h->out.p, (size_t)hc.n_out * sizeof(BhipHit), hipMemcpyDeviceToHost, h->stream));
+		if (hc.n_out) {
+			const uint32_t n = hc.n_out;
+			if ((rc = h->sort_keys.reserve((size_t)n * 8)) || (rc = h->sort_keys2.reserve((size_t)n * 8)) || (rc = h->sort_idx.reserve((size_t)n * 4)) ||
+			    (rc = h->sort_idx2.reserve((size_t)n * 4)) || (rc = h->out_sorted.reserve((size_t)n * sizeof(BhipHit)))) return rc;
+			const uint32_t g = std::min<uint32_t>((n + 255) / 256, (uint32_t)h->n_cu * 8);
+			hipLaunchKernelGGL(k_hit_keys, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, h->sort_keys.as<uint64_t>(), h->sort_idx.as<uint32_t>());
+			size_t tmp_bytes = 0;
+			int qbits = 32; while (qbits > 1 && !((n_q - 1) >> (qbits - 1))) --qbits;   // significant bits of the query index
+			HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->sort_keys.as<uint64_t>(), h->sort_keys2.as<uint64_t>(), h->sort_idx.as<uint32_t>(),
+				h->sort_idx2.as<uint32_t>(), (int)n, 0, 32 + qbits, h->stream));
+			if ((rc = h->sort_tmp.reserve(tmp_bytes))) return rc;
+			HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp.p, tmp_bytes, h->sort_keys.as<uint64_t>(), h->sort_keys2.as<uint64_t>(), h->sort_idx.as<uint32_t>(),
+				h->sort_idx2.as<uint32_t>(), (int)n, 0, 32 + qbits, h->stream));
+			hipLaunchKernelGGL(k_hit_gather, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), h->sort_idx2.as<uint32_t>(), n, h->out_sorted.as<BhipHit>());
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipMemcpyAsync(hits, h->out_sorted.p, (size_t)n * sizeof(BhipHit), hipMemcpyDeviceToHost, h->stream));
+		}
 		HIPCHK(hipEventRecord(h->ev[9], h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
-		std::sort(hits, hits + hc.n_out, [](const BhipHit &a, const BhipHit &b) { return a.q != b.q ? a.q < b.q : a.refIx < b.refIx; });
 		for (int cls = 0; cls < kNumClasses; ++cls) if (h->st_npf[cls] + h->st_nex[cls]) {
 			hipEvent_t *ce = h->ev_cls[cls];
 			h->stats.ms_peq += ev_ms(ce[0], ce[1]);

@@ -194,7 +194,7 @@ __device__ __forceinline__ void myers_step(const uint32_t (&Eq)[NW], uint32_t (&
 
 template <int NW>
 __global__ __launch_bounds__(256) void k_myers(
-		const uint2 *__restrict__ pairs, const uint32_t *__restrict__ n_pairs_dev, uint64_t n_pairs_host,
+		const uint2 *__restrict__ pairs, const uint32_t *__restrict__ n_pairs_dev, uint64_t n_pairs_host,   // device count is clamped to n_pairs_host (buffer capacity)
 		uint32_t n_clumps_implicit,        // pairs == nullptr: p -> (list position li_base + p / n_clumps, clump p % n_clumps)
 		uint32_t li_base,
 		const uint32_t *__restrict__ qlist, // list position -> batch query index (nullptr: identity)
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_myers(
 	// ds_read_b128 service set can mix never collide on the A/C/G/T rows
 	__shared__ __attribute__((aligned(16))) uint32_t s_peq[16][16 * NW];
 	const uint32_t tid = threadIdx.x, g = tid >> 4, z = tid & 15, rot = 4 * (g & 3);
-	const uint64_t n_pairs = n_pairs_dev ? (uint64_t)*n_pairs_dev : n_pairs_host;
+	const uint64_t n_pairs = n_pairs_dev ? ((uint64_t)*n_pairs_dev < n_pairs_host ? (uint64_t)*n_pairs_dev : n_pairs_host) : n_pairs_host;
 	const uint64_t n_tiles = (n_pairs + 15) >> 4;
 	unsigned long long my_cols = 0, my_qlen = 0;
 	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
