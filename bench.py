@@ -131,22 +131,11 @@ def main():
     all_hits = args.mode == "FORAGE"
     buf = None
 
+    from burst_amd import dist as bdist
+
     def gather_hits(hits):
-        """one variable-length gather of hit records to rank 0 (all_gather of counts + padded gather over RCCL)"""
-        if world == 1:
-            return hits
-        cnt = torch.tensor([len(hits)], dtype=torch.int64, device="cuda")
-        counts = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(counts, cnt)
-        mx = int(max(int(c.item()) for c in counts))
-        pad = torch.zeros(max(mx, 1) * 20, dtype=torch.uint8, device="cuda")
-        if len(hits):
-            pad[:len(hits) * 20] = torch.from_numpy(hits.view(np.uint8).reshape(-1)).cuda()
-        out = [torch.zeros_like(pad) for _ in range(world)] if rank == 0 else None
-        dist.gather(pad, out, dst=0)
-        if rank == 0:
-            return [o[:int(c.item()) * 20].cpu().numpy().view(capi.HIT_DTYPE) for o, c in zip(out, counts)]
-        return None
+        """one variable-length gather of hit records to rank 0 (burst_amd.dist: all_gather of counts + padded gather over RCCL)"""
+        return bdist.gather_hits(hits, rank, world, "cuda" if world > 1 else "cpu")
 
     def step():
         nonlocal buf

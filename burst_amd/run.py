@@ -1,0 +1,63 @@
+"""Multi-GPU front end: one process per GPU (torchrun), same flags as the burst_hip command line.
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      -m burst_amd.run -r DB.edx -a DB.acx -q reads.fa -o out.b6 -m CAPITALIST -i 0.97 [-fr] [-y]
+
+Every rank loads the database and the queries through the C host (libburst_host.so), aligns its contiguous shard of
+unique queries with the C batch scheduler (bh_align -> libburst_hip.so), the hit records are gathered to rank 0 over
+RCCL, and rank 0 writes the .b6 with the C consolidation code.  With one process it is equivalent to burst_hip."""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="burst_amd.run")
+    ap.add_argument("-r", "--references", required=True)
+    ap.add_argument("-a", "--accelerator")
+    ap.add_argument("-q", "--queries", required=True)
+    ap.add_argument("-o", "--output", required=True)
+    ap.add_argument("-m", "--mode", default="CAPITALIST", choices=["BEST", "ALLPATHS", "CAPITALIST", "FORAGE", "ANY"])
+    ap.add_argument("-i", "--id", type=float, default=0.97)
+    ap.add_argument("-fr", "--forwardreverse", action="store_true")
+    ap.add_argument("-y", "--nwildcard", action="store_true")
+    ap.add_argument("-k", type=int, default=12, choices=[12, 15])
+    ap.add_argument("--batch", type=int, default=1 << 18)
+    args = ap.parse_args(argv)
+    rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from burst_amd import capi, dist as bdist, host
+    z = 0 if args.nwildcard else 1
+    db = host.Db.read(args.references, args.accelerator, K=args.k, z=z)
+    qs = host.QuerySet(args.queries, args.id, rc=args.forwardreverse, accel=bool(args.accelerator), K=args.k, z=z)
+    dev = db.open_device(local_rank, z)
+    L = host.lib()
+
+    def align_range(u0, u1):
+        run = host.BhRun()
+        host._chk(L.bh_align(dev._h, C.byref(qs.c), u0, u1, host.MODES[args.mode], args.batch, C.byref(run)))
+        n = int(run.nHits)
+        out = np.ctypeslib.as_array(C.cast(run.hits, C.POINTER(C.c_uint8)), shape=(n * 20,)).view(capi.HIT_DTYPE).copy() if n else np.zeros(0, capi.HIT_DTYPE)
+        L.bh_run_free(C.byref(run))
+        return out
+    t0 = time.time()
+    hits = bdist.run_sharded(qs.n_uniq, align_range, rank, world, "cuda" if world > 1 else "cpu")
+    if rank == 0:
+        n = host.report(args.output, db, qs, hits, args.mode, 0 if args.accelerator else host.REP_MERGED_LIST)
+        print("rank 0: %d hit records from %d rank(s) in %.3f s, %d alignments written" % (len(hits), world, time.time() - t0, n))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,62 @@
+"""The N > 1 path on CPU: two gloo processes shard the unique queries, produce hit records for their shard (here with
+the ORACLE in place of the device call), gather them to rank 0 with burst_amd.dist, and rank 0 consolidates with the
+C host.  The .b6 must equal the reference's golden output -- this pins shard boundaries, the entry-index mapping,
+the variable-length gather and the global CAPITALIST vote."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import goldenlib as gl
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch.distributed as dist
+from burst_amd import capi, dist as bdist, host
+import oraclelib as ol
+edx, qfa, out, mode, ident, fr = sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], float(sys.argv[6]), int(sys.argv[7])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+db = host.Db.read(edx)
+qs = host.QuerySet(qfa, ident, rc=bool(fr), accel=False)
+lut = ol.score_lut(1)
+clump_len = host._view(db.c.clumpLen, db.c.numRclumps, np.uint32)
+packed = host._view(db.c.packed, db.c.packedWords * 16, np.uint8)
+def align_range(u0, u1):
+    q = qs.batch(u0, u1)
+    h = ol.search(packed, clump_len, db.c.totR, q.codes, q.off, q.emac.astype(np.uint32), q.six, q.rc, q.n_shared, lut, mode == "FORAGE")
+    h = h.copy(); h["q"] = q.entry_index[h["q"]].astype(np.uint32)      # local entry -> global entry
+    return h.view(capi.HIT_DTYPE)
+hits = bdist.run_sharded(qs.n_uniq, align_range, rank, world, "cpu")
+if rank == 0:
+    host.report(out, db, qs, hits, mode, host.REP_MERGED_LIST)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("name", ["dna_q100_capitalist_noacx_t1_fr", "quick_q292_best_fr"])
+def test_two_rank_gloo_matches_reference(name, tmp_path):
+    c = [x for x in gl.cases() if x["name"] == name][0]
+    ref, q, fr, z, shear = gl.case_args(c)
+    out = str(tmp_path / "o.b6")
+    w = tmp_path / "worker.py"
+    w.write_text(WORKER)
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", str(w), gl.ROOT, ref, q, out, c["mode"], c["id"], str(fr)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    got = sorted(open(out, "rb").read().splitlines())
+    assert got == gl.golden_lines(c)
+
+
+def test_shard_ranges_partition():
+    from burst_amd import dist as bdist
+    for n in (0, 1, 7, 8, 1000003):
+        for w in (1, 2, 3, 8):
+            r = [bdist.shard_range(n, w, k) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
