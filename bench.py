@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--workdir", default=os.environ.get("BURST_BENCH_DIR", "/tmp/burst_amd_bench"))
     ap.add_argument("--cpu-sample", type=int, default=600000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prefilter-stride", type=int, default=0, help="0 = automatic sparse seeds (default), 1 = every word (reference scheme)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -123,6 +124,7 @@ def main():
     db = host.Db.read(edx, acx, K=12)
     qs = host.QuerySet(reads_fa, args.id, rc=False, accel=True, K=12)
     dev = db.open_device(local_rank)
+    dev.set_option("prefilter_stride", args.prefilter_stride)
     info = dev.info()
     q = qs.batch()
     dev.stage(q)

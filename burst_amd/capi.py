@@ -34,7 +34,7 @@ class BhipStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
 
 
-EXPORTS = ["bhip_init", "bhip_stage_queries", "bhip_align_staged", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_get_stats",
+EXPORTS = ["bhip_init", "bhip_stage_queries", "bhip_align_staged", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_set_option", "bhip_get_stats",
            "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version"]
 
 
@@ -62,6 +62,8 @@ def _load():
     lib.bhip_align_pairs.restype = i32
     lib.bhip_prefilter.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, u64, C.POINTER(u64)]
     lib.bhip_prefilter.restype = i32
+    lib.bhip_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
+    lib.bhip_set_option.restype = i32
     lib.bhip_get_stats.argtypes = [vp, C.POINTER(BhipStats)]
     lib.bhip_get_stats.restype = i32
     lib.bhip_device_info.argtypes = [vp, C.c_char_p, i32, C.POINTER(i32), C.POINTER(u64)]
@@ -150,6 +152,9 @@ class Device:
         hbm = C.c_uint64()
         _chk(lib().bhip_device_info(self._h, name, 256, C.byref(ncu), C.byref(hbm)))
         return {"name": name.value.decode(), "n_cu": ncu.value, "hbm_bytes": hbm.value}
+
+    def set_option(self, name, value):
+        _chk(lib().bhip_set_option(self._h, name.encode(), int(value)))
 
     def stats(self):
         s = BhipStats()

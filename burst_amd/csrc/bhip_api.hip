@@ -19,6 +19,8 @@ __global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *,
 template <bool LDS_CNT> __global__ void k_prefilter(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
 	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t,
 	unsigned long long *);
+template <typename CNT> __global__ void k_prefilter_wave(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
+	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, int);
 template <int NW> __global__ void k_myers(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
 	const uint64_t *, const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t,
 	BhipRawHit *, uint32_t *, uint32_t, uint32_t *, uint8_t *, unsigned long long *, unsigned long long *);
@@ -98,6 +100,8 @@ struct Handle {
 	bool st_valid = false, st_has_six = false, st_has_rc = false;
 	uint32_t st_nq = 0, st_nshared = 0, st_npf[kNumClasses] = {0}, st_nex[kNumClasses] = {0};
 	float st_ms_h2d = 0;
+	uint32_t st_maxlen_pf = 0;   // longest query of the uploaded batch
+	int opt_prefilter_stride = 0; // 0 = automatic sparse seeds, s > 0 = every s-th word (1 = the reference's scheme)
 	DBuf qlist_cls[kNumClasses];
 	hipEvent_t ev_cls[kNumClasses][5];
 };
@@ -239,6 +243,16 @@ extern "C" int bhip_device_info(void *handle, char *name, int name_cap, int *n_c
 	return BHIP_OK;
 }
 
+extern "C" int bhip_set_option(void *handle, const char *name, long long value) {
+	Handle *h = (Handle *)handle;
+	if (!h || !name) return fail(BHIP_E_ARG, "null argument");
+	if (!strcmp(name, "prefilter_stride")) {
+		if (value < 0 || value > 15) return fail(BHIP_E_ARG, "prefilter_stride must be 0 (auto) .. 15");
+		h->opt_prefilter_stride = (int)value; return BHIP_OK;
+	}
+	return fail(BHIP_E_ARG, "unknown option '%s'", name);
+}
+
 extern "C" int bhip_get_stats(void *handle, BhipStats *out) {
 	Handle *h = (Handle *)handle;
 	if (!h || !out) return fail(BHIP_E_ARG, "null argument");
@@ -272,6 +286,8 @@ static int upload_queries(Handle *h, const uint8_t *q_codes, const uint64_t *q_o
                           const uint32_t *q_six, const uint8_t *q_rc, uint32_t n_q) {
 	const uint64_t nb = q_off[n_q];
 	int rc;
+	h->st_maxlen_pf = 0;
+	for (uint32_t i = 0; i < n_q; ++i) h->st_maxlen_pf = std::max<uint32_t>(h->st_maxlen_pf, (uint32_t)(q_off[i + 1] - q_off[i]));
 	if ((rc = h->qcodes.reserve(nb + 16))) return rc;
 	if ((rc = h->qoff.reserve((n_q + 1) * sizeof(uint64_t)))) return rc;
 	if ((rc = h->qemac.reserve((n_q + 1) * sizeof(uint16_t)))) return rc;
@@ -291,7 +307,20 @@ static int launch_prefilter(Handle *h, const uint32_t *d_qlist, uint32_t n_list,
 	const size_t lds = (size_t)nw32 * 4;
 	const uint32_t *bad = with_bad ? h->bad.as<uint32_t>() : nullptr;
 	const uint32_t n_bad = with_bad ? h->n_bad : 0;
-	if (lds <= 128 * 1024) {
+	// wave-per-query variant: byte counters while every possible count fits (max query length of the batch), else 16-bit
+	const bool narrow = h->st_maxlen_pf < 255u + (uint32_t)h->K;
+	const int diag = h->opt_prefilter_stride;
+	const size_t lds_w = ((size_t)(h->n_clumps + (narrow ? 3 : 1)) / (narrow ? 4 : 2)) * 4 + 1536u * 4 + 512u * 8 + 512u * 4 + 16;
+	if (lds_w <= 64 * 1024) {
+		const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / lds_w));
+		const uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * per_cu);
+		if (narrow) hipLaunchKernelGGL(k_prefilter_wave<uint8_t>, dim3(grid), dim3(64), lds_w, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
+			n_cand_dev, cand_cap, &dc->ent_read, diag);
+		else hipLaunchKernelGGL(k_prefilter_wave<uint16_t>, dim3(grid), dim3(64), lds_w, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
+			n_cand_dev, cand_cap, &dc->ent_read, diag);
+	} else if (lds <= 128 * 1024) {
 		uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
 		uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * per_cu);
 		if (lds > 64 * 1024)

@@ -160,6 +160,154 @@ template __global__ void k_prefilter<false>(const uint8_t *, const uint64_t *, c
 
 
 // ------------------------------------------------------------------------------------------------
+// Prefilter, wave-per-query variant (used whenever the per-clump counters of one query fit a wave's LDS slice).
+// Differences to k_prefilter above, all aimed at what the round-1 profile showed to dominate (profiles/r01_*):
+//   * one 64-lane wave owns a query (no workgroup barriers), several waves per CU run independent queries;
+//   * counters are bytes (CNT = uint8_t, four per dword) while len-K+1 <= 255, else 16-bit;
+//   * no dense zero/scan per query: the first increment of a counter (atomic returns 0) appends the clump to a
+//     touched list; only touched counters are tested against the threshold and reset.  Dense fallback if the list overflows;
+//   * candidates are staged in LDS and flushed with ONE global atomic per flush instead of one returning atomic per
+//     candidate (2.2 M same-address atomics per launch saturated the L2 atomic unit at ~90/us).
+// ------------------------------------------------------------------------------------------------
+// Seed plan of one query: sample word starts 0, s, 2s, ... <= len-K.  One edit destroys at most ceil(K/s) sampled
+// words, so an alignment with <= E edits keeps need(s) = W_s - E*ceil(K/s) of the W_s = (len-K)/s + 1 sampled words.
+// s = 1 is the reference's scheme (need = len-K+1-E*K = mmatch+1, burst.c:4091-4092).  stride_opt > 0 forces s; 0 picks
+// the largest s <= K that still guarantees >= 3 words (fewest list look-ups, same no-false-negative guarantee).
+__device__ __host__ inline void bhip_seed_plan(uint32_t len, uint32_t E, uint32_t K, int stride_opt, uint32_t &stride, uint32_t &need) {
+	auto need_of = [&](uint32_t s) -> int { return (int)((len - K) / s + 1) - (int)(E * ((K + s - 1) / s)); };
+	uint32_t s = 1;
+	if (stride_opt > 0) s = (uint32_t)stride_opt;
+	else for (uint32_t t = K; t >= 1; --t) if (need_of(t) >= 3) { s = t; break; }
+	const int n = need_of(s);
+	stride = s; need = n > 0 ? (uint32_t)n : 0u;
+}
+
+#define PF2_TL 1536u      // touched-list capacity (clump ids, u32)
+#define PF2_STAGE 512u    // staged candidates (uint2)
+template <typename CNT>
+__global__ __launch_bounds__(64) void k_prefilter_wave(
+		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint16_t *__restrict__ qemac,
+		const uint32_t *__restrict__ qlist, uint32_t n_list,
+		const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, int K, uint32_t n_clumps,
+		const uint32_t *__restrict__ bad, uint32_t n_bad,
+		uint2 *__restrict__ cand, uint32_t *__restrict__ cand_cnt_out, uint32_t *__restrict__ n_cand, uint32_t cand_cap,
+		unsigned long long *__restrict__ ent_read, int stride_opt) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+	constexpr uint32_t PER = 4 / sizeof(CNT), BITS = 8 * sizeof(CNT), MASK = (1u << BITS) - 1u;
+	const uint32_t nw32 = (n_clumps + PER - 1) / PER;
+	uint32_t *cnt = smem;                       // [nw32]
+	uint32_t *tl = cnt + nw32;                  // [PF2_TL]
+	uint2 *stage = (uint2 *)(tl + PF2_TL);      // [PF2_STAGE]
+	uint32_t *stage_v = (uint32_t *)(stage + PF2_STAGE);   // [PF2_STAGE] counts (only written when cand_cnt_out)
+	uint32_t *ctr = stage_v + PF2_STAGE;        // [0] touched count, [1] staged count
+	const uint32_t lane = threadIdx.x;
+	const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
+	for (uint32_t i = lane; i < nw32; i += 64) cnt[i] = 0;
+	if (lane < 2) ctr[lane] = 0;
+	__syncthreads();
+	unsigned long long my_ent = 0;
+
+	auto push = [&](uint32_t li, uint32_t c, uint32_t v) {
+		const uint32_t pos = atomicAdd(&ctr[1], 1u);
+		if (pos < PF2_STAGE) { stage[pos] = make_uint2(li, c); if (cand_cnt_out) stage_v[pos] = v; }
+		else {   // staging buffer full inside one query (very permissive threshold): direct append
+			const uint32_t g = atomicAdd(n_cand, 1u);
+			if (g < cand_cap) { cand[g] = make_uint2(li, c); if (cand_cnt_out) cand_cnt_out[g] = v; }
+		}
+	};
+	auto flush = [&]() {
+		__syncthreads();
+		const uint32_t n = ctr[1] < PF2_STAGE ? ctr[1] : PF2_STAGE;
+		uint32_t base = 0;
+		if (n) {
+			if (lane == 0) base = atomicAdd(n_cand, n);
+			base = __shfl(base, 0);
+			for (uint32_t i = lane; i < n; i += 64) if (base + i < cand_cap) { cand[base + i] = stage[i]; if (cand_cnt_out) cand_cnt_out[base + i] = stage_v[i]; }
+		}
+		__syncthreads();
+		if (lane == 0) ctr[1] = 0;
+		__syncthreads();
+	};
+	auto bump = [&](uint32_t c) {
+		const uint32_t sh = (c % PER) * BITS;
+		const uint32_t old = atomicAdd(&cnt[c / PER], 1u << sh);
+		if (((old >> sh) & MASK) == 0) {
+			const uint32_t pos = atomicAdd(&ctr[0], 1u);
+			if (pos < PF2_TL) tl[pos] = c;
+		}
+	};
+
+	for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+		const uint32_t q = qlist ? qlist[li] : li;
+		const uint64_t b = qoff[q];
+		const uint32_t len = (uint32_t)(qoff[q + 1] - b), E = qemac[q];
+		uint32_t stride = 1, need = 0;
+		if (len >= (uint32_t)K) {
+			bhip_seed_plan(len, E, (uint32_t)K, stride_opt, stride, need);
+			const uint32_t nwords = (len - K) / stride + 1;
+			for (uint32_t base = 0; base < nwords; base += 64) {
+				const uint32_t j = base + lane, p = j * stride;
+				uint32_t w = 0, ok = j < nwords;
+				if (ok) for (int k = 0; k < K; ++k) {
+					const uint32_t c = qcodes[b + p + k];
+					ok &= (c - 1u) < 4u;
+					w = (w << 2) | ((c - 1u) & 3u);
+				}
+				w &= wmask;
+				uint32_t beg = 0, end = 0;
+				if (ok) { beg = acx_off[w]; end = acx_off[w + 1]; }
+				uint32_t n = end - beg;
+				my_ent += n;
+				unsigned long long longm = __ballot(n > 32);
+				if (n <= 32) {
+					uint32_t e = beg;
+					for (; e + 4 <= end; e += 4) {   // four independent loads in flight
+						const uint32_t c0 = acx_ent[e], c1 = acx_ent[e + 1], c2 = acx_ent[e + 2], c3 = acx_ent[e + 3];
+						bump(c0); bump(c1); bump(c2); bump(c3);
+					}
+					for (; e < end; ++e) bump(acx_ent[e]);
+				}
+				while (longm) {
+					const int src = __builtin_ctzll(longm);
+					longm &= longm - 1;
+					const uint32_t lb = __shfl(beg, src), le = __shfl(end, src);
+					for (uint32_t e = lb + lane; e < le; e += 64) bump(acx_ent[e]);
+				}
+			}
+		}
+		__syncthreads();
+		const uint32_t mmatch = need ? need - 1 : 0;      // candidate iff count >= need (count > 0 when no words are guaranteed)
+		const uint32_t nt = ctr[0];
+		if (nt <= PF2_TL) {
+			for (uint32_t i = lane; i < nt; i += 64) {
+				const uint32_t c = tl[i], sh = (c % PER) * BITS;
+				const uint32_t v = (cnt[c / PER] >> sh) & MASK;
+				atomicAnd(&cnt[c / PER], ~(MASK << sh));
+				if (v > mmatch) push(li, c, v);
+			}
+		} else {   // touched list overflowed: dense pass
+			for (uint32_t i = lane; i < nw32; i += 64) {
+				const uint32_t word = cnt[i];
+				if (word) {
+					cnt[i] = 0;
+					for (uint32_t j = 0; j < PER; ++j) { const uint32_t v = (word >> (j * BITS)) & MASK; if (v > mmatch && i * PER + j < n_clumps) push(li, i * PER + j, v); }
+				}
+			}
+		}
+		for (uint32_t i = lane; i < n_bad; i += 64) push(li, bad[i], 0xFFFFFFFFu);          // burst.c:4136-4138, 4282-4283
+		__syncthreads();
+		if (lane == 0) ctr[0] = 0;
+		if (ctr[1] >= PF2_STAGE / 2) flush(); else __syncthreads();
+	}
+	flush();
+	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
+}
+template __global__ void k_prefilter_wave<uint8_t>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
+	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, int);
+template __global__ void k_prefilter_wave<uint16_t>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
+	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, int);
+
+// ------------------------------------------------------------------------------------------------
 // Bit-parallel semi-global edit distance (Myers 1999 / Hyyro 2003), NW x 32-bit words per DP column.
 // State per (query, reference lane): vertical deltas Pv/Mv of the current column; the tracked score is
 // D[m][x] = min over start positions of the edit distance of the query against ref[..x], i.e. the last-row

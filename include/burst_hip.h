@@ -115,6 +115,12 @@ int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64_t *q_off, 
                    uint32_t n_q, uint32_t *out_q, uint32_t *out_clump, uint32_t *out_count,
                    uint64_t cap, uint64_t *n_out);
 
+/* Tuning knobs.  "prefilter_stride": 0 (default) = automatic sparse seeds -- per query the largest stride s <= K for
+ * which an alignment within budget still keeps >= 3 of the words starting at 0, s, 2s, ... (one edit destroys at most
+ * ceil(K/s) of them), fewest .acx look-ups with the same no-false-negative guarantee; s >= 1 forces every s-th word,
+ * 1 = every word = the reference's own threshold count > len-(E+1)K (burst.c:4091-4092, 4126). */
+int bhip_set_option(void *handle, const char *name, long long value);
+
 /* Stats of the last call; device properties (name, CU count) for reports. */
 int bhip_get_stats(void *handle, BhipStats *out);
 int bhip_device_info(void *handle, char *name, int name_cap, int *n_cu, uint64_t *hbm_bytes);

@@ -213,22 +213,25 @@ uint64_t orc_search(const uint8_t *packed, const uint32_t *clumpLen, uint32_t nC
 	return nh;
 }
 
-uint32_t orc_prefilter_counts(const uint8_t *q, uint32_t m, uint32_t E, int K,
+uint32_t orc_prefilter_counts(const uint8_t *q, uint32_t m, uint32_t E, int K, uint32_t stride,
                               const uint64_t *offs, const uint32_t *entries,
                               uint32_t nClumps, uint16_t *counts) {
 	memset(counts, 0, (size_t)nClumps * sizeof(*counts));
 	if (m < (uint32_t)K) return 0;
+	if (!stride) stride = 1;
 	uint32_t mask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1);
-	uint32_t w = 0;
-	for (uint32_t k = 0; k < m; ++k) {                    /* burst.c:4097-4104: w = w<<2 | (code-1) */
-		w = (w << 2) | (uint32_t)(q[k] - 1);
-		if (k + 1 < (uint32_t)K) continue;
+	for (uint32_t p = 0; p + K <= m; p += stride) {        /* burst.c:4097-4104: w = w<<2 | (code-1), first base most significant */
+		uint32_t w = 0; int ok = 1;
+		for (int k = 0; k < K; ++k) { uint32_t c = q[p + k]; if (c < 1 || c > 4) ok = 0; w = (w << 2) | ((c - 1) & 3); }
+		if (!ok) continue;
 		uint32_t t = w & mask;
-		for (uint64_t p = offs[t]; p < offs[t + 1]; ++p)    /* burst.c:3245-3249: one count per (position, clump) */
-			if (counts[entries[p]] < UINT16_MAX) ++counts[entries[p]];
+		for (uint64_t e = offs[t]; e < offs[t + 1]; ++e)    /* burst.c:3245-3249: one count per (position, clump) */
+			if (counts[entries[e]] < UINT16_MAX) ++counts[entries[e]];
 	}
-	uint32_t kload = E * K + K, mmatch = kload < m ? m - kload : 0;   /* burst.c:4091-4092 */
+	/* stride 1: need = len-K+1-E*K = mmatch+1 (burst.c:4091-4092).  stride s: one edit destroys at most ceil(K/s) sampled words */
+	int need = (int)((m - K) / stride + 1) - (int)(E * ((K + stride - 1) / stride));
+	uint32_t thr = need > 0 ? (uint32_t)need - 1 : 0;
 	uint32_t n = 0;
-	for (uint32_t c = 0; c < nClumps; ++c) n += counts[c] > mmatch;
+	for (uint32_t c = 0; c < nClumps; ++c) n += counts[c] > thr;
 	return n;
 }

@@ -36,7 +36,7 @@ def oracle():
         L.orc_aded_clump.argtypes = [vp, u32, vp, u32, u32, vp, vp]; L.orc_aded_clump.restype = u32
         L.orc_rescore_lane.argtypes = [vp, u32, vp, u32, u32, vp, vp]; L.orc_rescore_lane.restype = i32
         L.orc_search.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp, vp, u32, u32, vp, i32, vp, u64]; L.orc_search.restype = u64
-        L.orc_prefilter_counts.argtypes = [vp, u32, u32, i32, vp, vp, u32, vp]; L.orc_prefilter_counts.restype = u32
+        L.orc_prefilter_counts.argtypes = [vp, u32, u32, i32, u32, vp, vp, u32, vp]; L.orc_prefilter_counts.restype = u32
         _orc = L
     return _orc
 
@@ -101,10 +101,10 @@ def search(packed, clump_len, tot_refs, qcodes, qoff, qE, qsix, qrc, n_shared, l
     return hits[:n]
 
 
-def prefilter_counts(q, E, K, offs, entries, n_clumps):
+def prefilter_counts(q, E, K, offs, entries, n_clumps, stride=1):
     q = np.ascontiguousarray(q, np.uint8)
     counts = np.zeros(n_clumps, np.uint16)
-    n = oracle().orc_prefilter_counts(_p(q), len(q), E, K, _p(offs), _p(entries), n_clumps, _p(counts))
+    n = oracle().orc_prefilter_counts(_p(q), len(q), E, K, stride, _p(offs), _p(entries), n_clumps, _p(counts))
     return n, counts
 
 

@@ -117,8 +117,9 @@ def test_mixed_lengths_and_empty():
     dev.close()
 
 
-@pytest.mark.parametrize("K,fmt", [(8, 0), (9, 1), (12, 0)])
-def test_prefilter_matches_oracle(K, fmt):
+@pytest.mark.parametrize("K,fmt,stride", [(8, 0, 1), (9, 1, 1), (12, 0, 1), (12, 0, 4), (12, 0, 12), (10, 0, 3)])
+def test_prefilter_matches_oracle(K, fmt, stride):
+    """stride 1 = the reference's scheme (every word, count > len-(E+1)K); larger strides = sparse seeds"""
     from burst_amd import capi
     seqs = family_db(41 + K, 12, 9, 420)
     packed, clump_len, tot = dbutil.pack_clumps(seqs)
@@ -126,17 +127,41 @@ def test_prefilter_matches_oracle(K, fmt):
     lists = dbutil.pack_acx_lists(lens, entries, fmt)
     lut = ol.score_lut(1)
     dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=lists, acx_fmt=fmt, K=K)
+    dev.set_option("prefilter_stride", stride)
     q, allq = make_queries(seqs, 30, 100, [0, 1, 2, 3], 43, thres=0.97)
     oq, oc, on = dev.prefilter(q)
     exp = []
     for j in range(q.n):
-        _, counts = ol.prefilter_counts(allq[j], int(q.emac[j]), K, offs, entries, len(clump_len))
+        _, counts = ol.prefilter_counts(allq[j], int(q.emac[j]), K, offs, entries, len(clump_len), stride)
         E = int(q.emac[j]); m = len(allq[j])
-        mm = m - (E * K + K) if E * K + K < m else 0
-        for c in np.flatnonzero(counts > mm):
+        need = ((m - K) // stride + 1) - E * ((K + stride - 1) // stride)
+        for c in np.flatnonzero(counts > max(need - 1, 0)):
             exp.append((j, int(c), int(counts[c])))
     got = list(zip(oq.tolist(), oc.tolist(), on.tolist()))
     assert got == exp and len(exp) > 0
+    dev.close()
+
+
+def test_sparse_seed_prefilter_never_loses_a_hit():
+    """automatic stride: every (query, clump) holding a lane within budget must be a candidate"""
+    from burst_amd import capi
+    K = 12
+    seqs = family_db(77, 16, 10, 500, rate=0.06)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lens, entries, offs = dbutil.build_acx(seqs, K)
+    lists = dbutil.pack_acx_lists(lens, entries, 0)
+    lut = ol.score_lut(1)
+    dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=lists, acx_fmt=0, K=K)
+    for thres, edits in ((0.97, [0, 1, 2, 3]), (0.93, [0, 3, 5, 7]), (0.98, [0, 1, 2])):
+        q, allq = make_queries(seqs, 40, 100, edits, 78, thres=thres)
+        oq, oc, _ = dev.prefilter(q)
+        cand = set(zip(oq.tolist(), oc.tolist()))
+        nc = len(clump_len)
+        mins = dev.align_pairs(q, np.repeat(np.arange(q.n, dtype=np.uint32), nc), np.tile(np.arange(nc, dtype=np.uint32), q.n)).reshape(q.n, nc, 16)
+        need = {(j, c) for j in range(q.n) for c in range(nc) if (mins[j, c] != 255).any() and len(allq[j]) >= K
+                and int(q.emac[j]) < len(allq[j]) // K}
+        assert need and need <= cand
+        assert len(cand) < q.n * nc // 2
     dev.close()
 
 
