@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--workdir", default=os.environ.get("BURST_BENCH_DIR", "/tmp/burst_amd_bench"))
     ap.add_argument("--cpu-sample", type=int, default=600000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-stage", action="store_true", help="disable the prefix-filter stage of the edit-distance kernels")
     ap.add_argument("--prefilter-stride", type=int, default=0, help="0 = automatic sparse seeds (default), 1 = every word (reference scheme)")
     args = ap.parse_args()
 
@@ -125,6 +126,7 @@ def main():
     qs = host.QuerySet(reads_fa, args.id, rc=False, accel=True, K=12)
     dev = db.open_device(local_rank)
     dev.set_option("prefilter_stride", args.prefilter_stride)
+    dev.set_option("two_stage", 0 if args.one_stage else 1)
     info = dev.info()
     q = qs.batch()
     dev.stage(q)
@@ -171,7 +173,9 @@ def main():
 
     if rank == 0:
         st = per_step[-1]
-        ms_myers = float(np.mean([s["ms_myers"] for s in per_step]))
+        two_stage = st["prefix_words"] > 0
+        # dominant kernel: the column sweep over every candidate lane (k_myers_prefix on the two-stage path, else k_myers)
+        ms_myers = float(np.mean([s["ms_myers_prefix"] if two_stage else s["ms_myers"] for s in per_step]))
         launches = max(1, st["myers_launches"])
         achieved = st["bytes_algorithmic"] / launches / (ms_myers / launches * 1e-3) / 1e9 if ms_myers > 0 else 0.0
         traffic = None
@@ -191,14 +195,15 @@ def main():
                                    % (args.reads, args.read_len, args.n_base * args.n_variants, args.ref_len, db.c.numRclumps, args.mode, args.id),
                        "parallelism": "query-sharded x%d, DB replicated, RCCL gather of hit records" % world,
                        "device": info["name"], "n_cu": info["n_cu"]},
-            "roofline": {"bound": "hbm", "kernel": "k_myers<4>", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "roofline": {"bound": "hbm", "kernel": ("k_myers_prefix<%d>" % st["prefix_words"]) if two_stage else "k_myers<4>", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic,
                          "note": "integer bit-vector recurrence: VALU-bound by construction (SURVEY 8d); GCUPS below is the truthful figure of merit",
                          "algorithmic_bytes_per_launch": st["bytes_algorithmic"] / launches, "ms_per_launch": ms_myers / launches,
                          "gcups_equivalent": cells / (ms_myers * 1e-3) / 1e9 if ms_myers > 0 else 0.0},
-            "phases_ms": {k: float(np.mean([s[k] for s in per_step])) for k in ("ms_peq", "ms_prefilter", "ms_myers", "ms_rescore", "ms_d2h", "ms_total")},
+            "phases_ms": {k: float(np.mean([s[k] for s in per_step])) for k in ("ms_peq", "ms_prefilter", "ms_myers", "ms_myers_prefix", "ms_myers_window", "ms_rescore", "ms_d2h", "ms_total")},
             "work": {"pairs_per_read": st["n_pairs"] / max(1, q.n), "raw_hits": st["n_raw_hits"], "hits": st["n_hits"],
-                     "acx_entries_per_read": st["acx_entries_read"] / max(1, q.n), "dp_columns": st["n_columns"]},
+                     "acx_entries_per_read": st["acx_entries_read"] / max(1, q.n), "dp_columns": st["n_columns"],
+                     "windows": st["n_windows"], "window_columns": st["n_window_columns"]},
         }
         res["cpu_baseline"] = cpu_baseline(edx, acx, reads_fa, args)
         if res["cpu_baseline"]:

@@ -25,13 +25,14 @@ assert HIT_DTYPE.itemsize == 20
 class BhipStats(C.Structure):
     _fields_ = [("n_queries", C.c_uint64), ("n_pairs", C.c_uint64), ("n_columns", C.c_uint64),
                 ("n_raw_hits", C.c_uint64), ("n_hits", C.c_uint64), ("acx_entries_read", C.c_uint64),
-                ("bytes_algorithmic", C.c_uint64),
+                ("bytes_algorithmic", C.c_uint64), ("n_windows", C.c_uint64), ("n_window_columns", C.c_uint64),
                 ("ms_h2d", C.c_float), ("ms_prefilter", C.c_float), ("ms_peq", C.c_float), ("ms_myers", C.c_float),
                 ("ms_rescore", C.c_float), ("ms_d2h", C.c_float), ("ms_total", C.c_float),
-                ("myers_launches", C.c_uint32), ("reserved", C.c_uint32)]
+                ("ms_myers_prefix", C.c_float), ("ms_myers_window", C.c_float),
+                ("myers_launches", C.c_uint32), ("prefix_words", C.c_uint32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 EXPORTS = ["bhip_init", "bhip_stage_queries", "bhip_align_staged", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_set_option", "bhip_get_stats",

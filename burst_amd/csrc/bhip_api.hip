@@ -15,7 +15,7 @@
 
 // ---- kernels (bhip_kernels.hip) -------------------------------------------------------------------
 __global__ void k_transpose_refs(const uint8_t *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint4 *);
-__global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, int, BhipMatchMask, uint32_t *);
+__global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, int, int, BhipMatchMask, uint32_t *);
 template <bool LDS_CNT> __global__ void k_prefilter(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
 	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t,
 	unsigned long long *);
@@ -24,6 +24,12 @@ template <typename CNT> __global__ void k_prefilter_wave(const uint8_t *, const 
 template <int NW> __global__ void k_myers(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
 	const uint64_t *, const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t,
 	BhipRawHit *, uint32_t *, uint32_t, uint32_t *, uint8_t *, unsigned long long *, unsigned long long *);
+template <int NWP> __global__ void k_myers_prefix(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
+	const uint64_t *, const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t, BhipWin *, uint32_t *, uint32_t,
+	unsigned long long *, unsigned long long *);
+template <int NW> __global__ void k_myers_window(const BhipWin *, const uint32_t *, uint32_t, int, const uint32_t *, const uint32_t *, const uint64_t *,
+	const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *,
+	unsigned long long *);
 template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *,
 	const uint32_t *, int, const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t *, const uint64_t *,
 	const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *,
@@ -75,6 +81,8 @@ static int class_of_len(uint32_t len) {
 struct Counters {
 	uint32_t n_cand, n_raw, n_out, n_wide, err, pad0;
 	uint32_t n_cand_cls[8];
+	uint32_t n_wins_cls[8];
+	unsigned long long wcol_sum;
 	unsigned long long col_sum, qlen_sum, ent_read, scratch_used;
 };
 
@@ -92,18 +100,20 @@ struct Handle {
 	DBuf acx_off, acx_ent, bad; uint32_t n_bad = 0; uint64_t n_ent = 0;
 	// batch buffers
 	DBuf qcodes, qoff, qemac, qsix, qrc, qlist, peq, cand, candcnt, raw, best, out, wide, scratch, gcnt, counters, mins, pairs;
-	DBuf sort_keys, sort_keys2, sort_idx, sort_idx2, sort_tmp, out_sorted;
+	DBuf sort_keys, sort_keys2, sort_idx, sort_idx2, sort_tmp, out_sorted, peqp, wins;
+	uint64_t win_cap = 1 << 22;
 	uint64_t cand_cap = 1 << 20, raw_cap = 1 << 20, out_cap = 1 << 20, scratch_cap = 1 << 20;
 	std::vector<uint32_t> h_clump_len;
 	BhipStats stats;
 	// staged batch (bhip_stage_queries)
 	bool st_valid = false, st_has_six = false, st_has_rc = false;
-	uint32_t st_nq = 0, st_nshared = 0, st_npf[kNumClasses] = {0}, st_nex[kNumClasses] = {0};
+	uint32_t st_nq = 0, st_nshared = 0, st_npf[kNumClasses] = {0}, st_nex[kNumClasses] = {0}, st_maxE[kNumClasses] = {0};
+	int opt_two_stage = 1;        // 1 = prefix filter + windowed full-length stage when it pays, 0 = always the one-stage sweep
 	float st_ms_h2d = 0;
 	uint32_t st_maxlen_pf = 0;   // longest query of the uploaded batch
 	int opt_prefilter_stride = 0; // 0 = automatic sparse seeds, s > 0 = every s-th word (1 = the reference's scheme)
 	DBuf qlist_cls[kNumClasses];
-	hipEvent_t ev_cls[kNumClasses][5];
+	hipEvent_t ev_cls[kNumClasses][8];
 };
 
 static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
@@ -118,7 +128,7 @@ extern "C" void bhip_destroy(void *handle) {
 	if (h->stream) (void)hipStreamSynchronize(h->stream);
 	DBuf *all[] = {&h->ref, &h->ref_off, &h->clump_len, &h->lut, &h->acx_off, &h->acx_ent, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
 		&h->qsix, &h->qrc, &h->qlist, &h->peq, &h->cand, &h->candcnt, &h->raw, &h->best, &h->out, &h->wide, &h->scratch, &h->gcnt,
-		&h->counters, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx, &h->sort_idx2, &h->sort_tmp, &h->out_sorted};
+		&h->counters, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx, &h->sort_idx2, &h->sort_tmp, &h->out_sorted, &h->peqp, &h->wins};
 	for (DBuf *b : all) b->release();
 	for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &ce : h->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
@@ -250,6 +260,7 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 		if (value < 0 || value > 15) return fail(BHIP_E_ARG, "prefilter_stride must be 0 (auto) .. 15");
 		h->opt_prefilter_stride = (int)value; return BHIP_OK;
 	}
+	if (!strcmp(name, "two_stage")) { h->opt_two_stage = value != 0; return BHIP_OK; }
 	return fail(BHIP_E_ARG, "unknown option '%s'", name);
 }
 
@@ -280,6 +291,23 @@ static void launch_myers(Handle *h, int cls, uint32_t grid, const uint2 *pairs, 
 	case 16: launch_myers_t<16>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
 	default: launch_myers_t<32>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
 	}
+}
+
+static void launch_prefix(Handle *h, int NWP, uint32_t grid, const uint2 *pairs, const uint32_t *n_pairs_dev, uint64_t n_pairs_host,
+		uint32_t li_base, const uint32_t *qlist, uint32_t *n_wins, Counters *dc) {
+	#define LP(N) hipLaunchKernelGGL(k_myers_prefix<N>, dim3(grid), dim3(256), 0, h->stream, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist, \
+		h->peqp.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
+		h->tot_refs, h->wins.as<BhipWin>(), n_wins, (uint32_t)h->win_cap, &dc->col_sum, &dc->qlen_sum)
+	if (NWP == 1) LP(1); else if (NWP == 2) LP(2); else LP(3);
+	#undef LP
+}
+static void launch_window(Handle *h, int cls, int NWP, uint32_t grid, const uint32_t *qlist, const uint32_t *n_wins, Counters *dc) {
+	#define LW(N) hipLaunchKernelGGL(k_myers_window<N>, dim3(grid), dim3(256), 0, h->stream, h->wins.as<BhipWin>(), n_wins, (uint32_t)h->win_cap, NWP, qlist, \
+		h->peq.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->ref.as<uint4>(), \
+		h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)h->raw_cap, h->best.as<uint32_t>(), &dc->wcol_sum)
+	switch (kClasses[cls]) { case 2: LW(2); break; case 4: LW(4); break; case 6: LW(6); break; case 8: LW(8); break; case 10: LW(10); break;
+		case 16: LW(16); break; default: LW(32); break; }
+	#undef LW
 }
 
 static int upload_queries(Handle *h, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
@@ -349,7 +377,7 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 	h->st_valid = false;
 	h->st_nq = n_q; h->st_has_six = q_six != nullptr; h->st_has_rc = q_rc != nullptr;
 	h->st_nshared = q_six ? n_shared : n_q;
-	for (int c = 0; c < kNumClasses; ++c) { h->st_npf[c] = h->st_nex[c] = 0; }
+	for (int c = 0; c < kNumClasses; ++c) { h->st_npf[c] = h->st_nex[c] = h->st_maxE[c] = 0; }
 	if (!n_q) { h->st_valid = true; return BHIP_OK; }
 	if (!q_codes || !q_off || !q_emac) return fail(BHIP_E_ARG, "null query arrays");
 	HIPCHK(hipSetDevice(h->device));
@@ -364,6 +392,7 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 		int ex = q_flags ? (q_flags[i] == BHIP_Q_EXHAUSTIVE) : !h->has_acx;
 		if (!h->has_acx) ex = 1;
 		lists[cls][ex].push_back(i);
+		h->st_maxE[cls] = std::max<uint32_t>(h->st_maxE[cls], q_emac[i]);
 	}
 	HIPCHK(hipEventRecord(h->ev[0], h->stream));
 	int rc;
@@ -402,6 +431,10 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		if ((rc = h->wide.reserve(h->raw_cap * sizeof(uint32_t)))) return rc;
 		if ((rc = h->out.reserve(h->out_cap * sizeof(BhipHit)))) return rc;
 		if ((rc = h->scratch.reserve(h->scratch_cap * sizeof(uint32_t)))) return rc;
+		if ((rc = h->wins.reserve(h->win_cap * sizeof(BhipWin)))) return rc;
+		for (int cls = 0; cls < kNumClasses; ++cls) if (h->st_npf[cls] + h->st_nex[cls]) {
+			if ((rc = h->peqp.reserve((size_t)(h->st_npf[cls] + h->st_nex[cls]) * 16 * 3 * 4))) return rc;
+		}
 		for (int cls = 0; cls < kNumClasses; ++cls) if (h->st_npf[cls] + h->st_nex[cls])
 			if ((rc = h->peq.reserve((size_t)(h->st_npf[cls] + h->st_nex[cls]) * 16 * kClasses[cls] * 4))) return rc;
 		HIPCHK(hipEventRecord(h->ev[0], h->stream));
@@ -409,7 +442,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		HIPCHK(hipMemsetAsync(h->counters.p, 0, sizeof(Counters), h->stream));
 		Counters *dc = h->counters.as<Counters>();
 		uint64_t n_pairs_ex = 0;
-		uint32_t launches = 0;
+		uint32_t launches = 0, prefix_words = 0;
 		const uint32_t grid_my = (uint32_t)h->n_cu * 8;
 		for (int cls = 0; cls < kNumClasses; ++cls) {
 			const uint32_t n_pf = h->st_npf[cls], n_ex = h->st_nex[cls], n_list = n_pf + n_ex;
@@ -422,14 +455,26 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 				const uint64_t total = (uint64_t)n_list * 16 * NW;
 				const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16);
 				hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-					qlist, n_list, NW, h->mm, h->peq.as<uint32_t>());
+					qlist, n_list, NW, 0, h->mm, h->peq.as<uint32_t>());
 				HIPCHK(hipGetLastError());
 			}
+			// two-stage edit distance when a prefix of 32*NWP symbols is selective for this class's budgets
+			int NWP = 0;
+			if (h->opt_two_stage) { const uint32_t mE = h->st_maxE[cls]; NWP = mE <= 5 ? 1 : (mE <= 10 ? 2 : (mE <= 16 ? 3 : 0)); if (NWP >= NW) NWP = 0; }
+			if (NWP) {
+				const uint64_t total = (uint64_t)n_list * 16 * NWP;
+				const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16);
+				hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+					qlist, n_list, NWP, 32 * NWP, h->mm, h->peqp.as<uint32_t>());
+				HIPCHK(hipGetLastError());
+			}
+			prefix_words = (uint32_t)NWP;
 			HIPCHK(hipEventRecord(ce[1], h->stream));
 			if (n_pf) {
 				if ((rc = launch_prefilter(h, qlist, n_pf, h->cand.as<uint2>(), nullptr, (uint32_t)h->cand_cap, true, &dc->n_cand_cls[cls], dc))) return rc;
 				HIPCHK(hipEventRecord(ce[2], h->stream));
-				launch_myers(h, cls, grid_my, h->cand.as<uint2>(), &dc->n_cand_cls[cls], h->cand_cap, 0, qlist, h->raw.as<BhipRawHit>(),
+				if (NWP) launch_prefix(h, NWP, grid_my, h->cand.as<uint2>(), &dc->n_cand_cls[cls], h->cand_cap, 0, qlist, &dc->n_wins_cls[cls], dc);
+				else launch_myers(h, cls, grid_my, h->cand.as<uint2>(), &dc->n_cand_cls[cls], h->cand_cap, 0, qlist, h->raw.as<BhipRawHit>(),
 					&dc->n_raw, (uint32_t)h->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
 				HIPCHK(hipGetLastError());
 				++launches;
@@ -437,13 +482,17 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			HIPCHK(hipEventRecord(ce[3], h->stream));
 			if (n_ex) {
 				const uint64_t np = (uint64_t)n_ex * h->n_clumps;
-				launch_myers(h, cls, (uint32_t)std::min<uint64_t>((np + 15) / 16, grid_my), nullptr, nullptr, np, n_pf, qlist,
+				const uint32_t g = (uint32_t)std::min<uint64_t>((np + 15) / 16, grid_my);
+				if (NWP) launch_prefix(h, NWP, g, nullptr, nullptr, np, n_pf, qlist, &dc->n_wins_cls[cls], dc);
+				else launch_myers(h, cls, g, nullptr, nullptr, np, n_pf, qlist,
 					h->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)h->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
 				HIPCHK(hipGetLastError());
 				++launches;
 				n_pairs_ex += np;
 			}
 			HIPCHK(hipEventRecord(ce[4], h->stream));
+			if (NWP) { launch_window(h, cls, NWP, grid_my, qlist, &dc->n_wins_cls[cls], dc); HIPCHK(hipGetLastError()); }
+			HIPCHK(hipEventRecord(ce[5], h->stream));
 		}
 		// rescoring of the kept lanes
 		HIPCHK(hipEventRecord(h->ev[6], h->stream));
@@ -458,6 +507,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		HIPCHK(hipStreamSynchronize(h->stream));
 		bool retry = false;
 		for (int cls = 0; cls < kNumClasses; ++cls) if (hc.n_cand_cls[cls] > h->cand_cap) { h->cand_cap = (uint64_t)hc.n_cand_cls[cls] + hc.n_cand_cls[cls] / 8 + 1024; retry = true; }
+		for (int cls = 0; cls < kNumClasses; ++cls) if (hc.n_wins_cls[cls] > h->win_cap) { h->win_cap = (uint64_t)hc.n_wins_cls[cls] + hc.n_wins_cls[cls] / 8 + 1024; retry = true; }
 		if (hc.n_raw > h->raw_cap) { h->raw_cap = (uint64_t)hc.n_raw + hc.n_raw / 8 + 1024; retry = true; }
 		if (retry) continue;
 		if (hc.n_wide) {
@@ -479,6 +529,8 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		h->stats.n_queries = n_q; h->stats.n_pairs = n_pairs_ex; h->stats.n_columns = hc.col_sum; h->stats.n_raw_hits = hc.n_raw;
 		for (int cls = 0; cls < kNumClasses; ++cls) h->stats.n_pairs += hc.n_cand_cls[cls];
 		h->stats.n_hits = hc.n_out; h->stats.acx_entries_read = hc.ent_read; h->stats.myers_launches = launches;
+		h->stats.prefix_words = prefix_words; h->stats.n_window_columns = hc.wcol_sum;
+		for (int cls = 0; cls < kNumClasses; ++cls) h->stats.n_windows += hc.n_wins_cls[cls];
 		h->stats.bytes_algorithmic = 8ull * hc.col_sum + hc.qlen_sum / 2 + 192ull * h->stats.n_pairs;
 		if (hc.n_out > cap) return fail(BHIP_E_CAPACITY, "hit buffer holds %llu records, %u needed", (unsigned long long)cap, hc.n_out);
 		HIPCHK(hipEventRecord(h->ev[8], h->stream));
@@ -504,8 +556,9 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		for (int cls = 0; cls < kNumClasses; ++cls) if (h->st_npf[cls] + h->st_nex[cls]) {
 			hipEvent_t *ce = h->ev_cls[cls];
 			h->stats.ms_peq += ev_ms(ce[0], ce[1]);
-			if (h->st_npf[cls]) { h->stats.ms_prefilter += ev_ms(ce[1], ce[2]); h->stats.ms_myers += ev_ms(ce[2], ce[3]); }
-			if (h->st_nex[cls]) h->stats.ms_myers += ev_ms(ce[3], ce[4]);
+			if (h->st_npf[cls]) h->stats.ms_prefilter += ev_ms(ce[1], ce[2]);
+			h->stats.ms_myers += ev_ms(ce[2], ce[5]);
+			if (prefix_words) { h->stats.ms_myers_prefix += ev_ms(ce[2], ce[4]); h->stats.ms_myers_window += ev_ms(ce[4], ce[5]); }
 		}
 		h->stats.ms_h2d = h->st_ms_h2d;
 		h->stats.ms_rescore = ev_ms(h->ev[6], h->ev[7]); h->stats.ms_d2h = ev_ms(h->ev[8], h->ev[9]); h->stats.ms_total = ev_ms(h->ev[0], h->ev[9]);
@@ -551,7 +604,7 @@ extern "C" int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint
 	Counters *dc = h->counters.as<Counters>();
 	const uint64_t total = (uint64_t)n_q * 16 * NW;
 	hipLaunchKernelGGL(k_build_peq, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
-		h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), (const uint32_t *)nullptr, n_q, NW, h->mm, h->peq.as<uint32_t>());
+		h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), (const uint32_t *)nullptr, n_q, NW, 0, h->mm, h->peq.as<uint32_t>());
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(h->ev[0], h->stream));
 	launch_myers(h, cls, (uint32_t)std::min<uint64_t>((n_pairs + 15) / 16, (uint64_t)h->n_cu * 8), h->pairs.as<uint2>(), nullptr, n_pairs, 0, nullptr,

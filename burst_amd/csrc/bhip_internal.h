@@ -15,6 +15,13 @@ struct BhipRawHit {
 	uint32_t e_last;   // (may run into trailing pad columns; k_rescore clamps to ClumpLen)
 };
 
+// A reference lane whose prefix filter fired: flags bit b covers chunks [b << fshift, (b+1) << fshift) of 32 columns.
+struct BhipWin {
+	uint32_t li;       // list position of the query (peq row)
+	uint32_t refIx;
+	uint32_t flags;
+};
+
 #define BHIP_RESCORE_WMAX 48   // band widths up to this many diagonals are handled in LDS
 
 #endif

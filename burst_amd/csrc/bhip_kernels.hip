@@ -56,14 +56,16 @@ __global__ void k_transpose_refs(const uint8_t *__restrict__ src, const uint64_t
 // peq[(li*16 + c)*NW + w] bit k = 1 iff k is a filler row or cost(query[32w+k-shift], c) == 0.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_build_peq(const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff,
-                            const uint32_t *__restrict__ qlist, uint32_t n_list, int NW,
+                            const uint32_t *__restrict__ qlist, uint32_t n_list, int NW, int prefix_len,
                             BhipMatchMask mm, uint32_t *__restrict__ peq) {
 	const uint64_t total = (uint64_t)n_list * 16 * NW;
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t w = i % NW, c = (i / NW) & 15, li = i / ((uint64_t)NW * 16);
 		const uint32_t q = qlist ? qlist[li] : li;
 		const uint64_t b = qoff[q];
-		const int len = (int)(qoff[q + 1] - b), shift = 32 * NW - len;
+		int len = (int)(qoff[q + 1] - b);
+		if (prefix_len > 0 && len > prefix_len) len = prefix_len;     // table of the first prefix_len symbols only (k_myers_prefix)
+		const int shift = 32 * NW - len;
 		uint32_t bits = 0;
 		for (int k = 0; k < 32; ++k) {
 			const int pos = 32 * (int)w + k - shift;
@@ -424,6 +426,165 @@ __global__ __launch_bounds__(256) void k_myers(
 	}
 	if (col_sum && my_cols) { atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Two-stage edit distance.  An alignment of the whole query with <= E edits contains an alignment of its first
+// P symbols with <= E edits, ending at some column x.  Stage A (k_myers_prefix<NWP>) therefore sweeps every column of
+// every candidate lane with a P = 32*NWP-symbol bit-vector only (~2.5x fewer instructions per column than the
+// 4-word kernel) and records, per lane, which 32-column chunks contain a column with prefix score <= E.  Stage B
+// (k_myers_window<NW>) runs the full-length recurrence only over the columns an alignment through a flagged chunk can
+// touch: [first flagged column - P - E, last flagged column + (m - P) + E].  Every end column with D[m][x] <= E lies
+// in that window with its whole alignment, so ed / first / last end column are identical to the full sweep.
+// ------------------------------------------------------------------------------------------------
+template <int NWP>
+__global__ __launch_bounds__(256) void k_myers_prefix(
+		const uint2 *__restrict__ pairs, const uint32_t *__restrict__ n_pairs_dev, uint64_t n_pairs_host,
+		uint32_t n_clumps_implicit, uint32_t li_base,
+		const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ peqp, const uint64_t *__restrict__ qoff,
+		const uint16_t *__restrict__ qemac,
+		const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
+		uint32_t tot_refs, BhipWin *__restrict__ wins, uint32_t *__restrict__ n_wins, uint32_t win_cap,
+		unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum) {
+	__shared__ __attribute__((aligned(16))) uint32_t s_peq[16][16 * NWP];
+	const uint32_t tid = threadIdx.x, g = tid >> 4, z = tid & 15;
+	const uint64_t n_pairs = n_pairs_dev ? ((uint64_t)*n_pairs_dev < n_pairs_host ? (uint64_t)*n_pairs_dev : n_pairs_host) : n_pairs_host;
+	const uint64_t n_tiles = (n_pairs + 15) >> 4;
+	unsigned long long my_cols = 0, my_qlen = 0;
+	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint64_t p = tile * 16 + g;
+		const bool live = p < n_pairs;
+		uint32_t li = 0, c = 0;
+		if (live) {
+			if (pairs) { const uint2 pr = pairs[p]; li = pr.x; c = pr.y; }
+			else { li = li_base + (uint32_t)(p / n_clumps_implicit); c = (uint32_t)(p % n_clumps_implicit); }
+		}
+		__syncthreads();
+		if (live) {
+			const uint32_t *src = peqp + ((uint64_t)li * 16 + z) * NWP;
+			#pragma unroll
+			for (int w = 0; w < NWP; ++w) s_peq[g][z * NWP + w] = src[w];
+		}
+		__syncthreads();
+		if (!live) continue;
+		const uint32_t q = qlist ? qlist[li] : li;
+		const uint32_t m = (uint32_t)(qoff[q + 1] - qoff[q]), E = qemac[q];
+		const uint32_t P = m < 32u * NWP ? m : 32u * NWP;
+		const uint32_t L = clump_len[c], nchunks = (L + 31) >> 5;
+		uint32_t fshift = 0;
+		while ((nchunks >> fshift) > 32) ++fshift;
+		uint32_t Pv[NWP], Mv[NWP];
+		#pragma unroll
+		for (int w = 0; w < NWP; ++w) {
+			const int lo = 32 * NWP - (int)P - 32 * w;
+			Pv[w] = lo <= 0 ? 0xFFFFFFFFu : (lo >= 32 ? 0u : (0xFFFFFFFFu << lo));
+			Mv[w] = 0;
+		}
+		int score = (int)P;
+		uint32_t flags = 0;
+		const uint4 *rp = ref + ref_off[c] * 16 + z;
+		const uint32_t *tab = &s_peq[g][0];
+		for (uint32_t t = 0; t < nchunks; ++t) {
+			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
+			int cmin = 0x7FFFFFFF;
+			#pragma unroll
+			for (int i = 0; i < 32; ++i) {
+				const uint32_t sym = (dw[i >> 3] >> (4 * (i & 7))) & 15u;
+				uint32_t Eq[NWP];
+				#pragma unroll
+				for (int w = 0; w < NWP; ++w) Eq[w] = tab[sym * NWP + w];
+				myers_step<NWP>(Eq, Pv, Mv, score);
+				cmin = score < cmin ? score : cmin;
+			}
+			flags |= ((uint32_t)cmin <= E ? 1u : 0u) << (t >> fshift);
+		}
+		const uint32_t refIx = c * 16 + z;
+		if (flags && refIx < tot_refs) {
+			const uint32_t pos = atomicAdd(n_wins, 1u);
+			if (pos < win_cap) { BhipWin w; w.li = li; w.refIx = refIx; w.flags = flags; wins[pos] = w; }
+		}
+		if (z == 0) { my_cols += L; my_qlen += m; }
+	}
+	if (col_sum && my_cols) { atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void k_myers_window(
+		const BhipWin *__restrict__ wins, const uint32_t *__restrict__ n_wins_dev, uint32_t win_cap, int NWP,
+		const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ peq, const uint64_t *__restrict__ qoff,
+		const uint16_t *__restrict__ qemac, const uint32_t *__restrict__ qsix,
+		const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
+		BhipRawHit *__restrict__ raw, uint32_t *__restrict__ n_raw, uint32_t raw_cap, uint32_t *__restrict__ best,
+		unsigned long long *__restrict__ wcol_sum) {
+	uint32_t n = *n_wins_dev;
+	if (n > win_cap) n = win_cap;
+	unsigned long long my_cols = 0;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const BhipWin w = wins[i];
+		const uint32_t li = w.li, q = qlist ? qlist[li] : li;
+		const uint32_t m = (uint32_t)(qoff[q + 1] - qoff[q]), E = qemac[q];
+		const uint32_t P = m < 32u * (uint32_t)NWP ? m : 32u * (uint32_t)NWP;
+		const uint32_t c = w.refIx >> 4, z = w.refIx & 15, L = clump_len[c], nchunks = (L + 31) >> 5;
+		uint32_t fshift = 0;
+		while ((nchunks >> fshift) > 32) ++fshift;
+		const uint32_t fA = (uint32_t)__builtin_ctz(w.flags) << fshift;                       // first flagged chunk
+		uint32_t fB = ((32u - (uint32_t)__builtin_clz(w.flags)) << fshift) - 1u;             // last flagged chunk
+		if (fB >= nchunks) fB = nchunks - 1;
+		const int col_lo = (int)(fA * 32 + 2) - (int)(P + E), col_hi = (int)((fB + 1) * 32 + (m - P) + E);
+		const uint32_t tA = col_lo > 1 ? (uint32_t)(col_lo - 1) >> 5 : 0u;
+		uint32_t tB = (uint32_t)(col_hi - 1) >> 5;
+		if (tB >= nchunks) tB = nchunks - 1;
+		uint32_t Pv[NW], Mv[NW];
+		#pragma unroll
+		for (int k = 0; k < NW; ++k) {
+			const int lo = 32 * NW - (int)m - 32 * k;
+			Pv[k] = lo <= 0 ? 0xFFFFFFFFu : (lo >= 32 ? 0u : (0xFFFFFFFFu << lo));
+			Mv[k] = 0;
+		}
+		int score = (int)m, bestS = 0x7FFFFFFF;
+		uint32_t first = 0, last = 0;
+		const uint4 *rp = ref + ref_off[c] * 16 + z;
+		const uint32_t *tab = peq + (uint64_t)li * 16 * NW;
+		for (uint32_t t = tA; t <= tB; ++t) {
+			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
+			#pragma unroll 8
+			for (int k = 0; k < 32; ++k) {
+				const uint32_t sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
+				uint32_t Eq[NW];
+				#pragma unroll
+				for (int x = 0; x < NW; ++x) Eq[x] = tab[sym * NW + x];
+				myers_step<NW>(Eq, Pv, Mv, score);
+				const uint32_t col = t * 32 + k + 1;
+				const bool lt = score < bestS, le = score <= bestS;
+				bestS = lt ? score : bestS;
+				first = lt ? col : first;
+				last = le ? col : last;
+			}
+		}
+		my_cols += (tB - tA + 1) * 32;
+		if ((uint32_t)bestS <= E) {
+			const uint32_t pos = atomicAdd(n_raw, 1u);
+			if (pos < raw_cap) {
+				BhipRawHit h; h.q = q; h.refIx = w.refIx; h.ed = (uint32_t)bestS; h.e_first = first; h.e_last = last;
+				raw[pos] = h;
+			}
+			if (best) atomicMin(&best[qsix ? qsix[q] : q], (uint32_t)bestS);
+		}
+	}
+	if (wcol_sum && my_cols) atomicAdd(wcol_sum, my_cols);
+}
+
+#define BHIP_INST_PREFIX(NWP) \
+	template __global__ void k_myers_prefix<NWP>(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *, \
+		const uint64_t *, const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t, BhipWin *, uint32_t *, uint32_t, \
+		unsigned long long *, unsigned long long *);
+BHIP_INST_PREFIX(1) BHIP_INST_PREFIX(2) BHIP_INST_PREFIX(3)
+#define BHIP_INST_WINDOW(NW) \
+	template __global__ void k_myers_window<NW>(const BhipWin *, const uint32_t *, uint32_t, int, const uint32_t *, const uint32_t *, const uint64_t *, \
+		const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *, \
+		unsigned long long *);
+BHIP_INST_WINDOW(2) BHIP_INST_WINDOW(4) BHIP_INST_WINDOW(6) BHIP_INST_WINDOW(8) BHIP_INST_WINDOW(10) BHIP_INST_WINDOW(16) BHIP_INST_WINDOW(32)
 
 #define BHIP_INST_MYERS(NW) \
 	template __global__ void k_myers<NW>(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *, \

@@ -57,9 +57,13 @@ typedef struct BhipStats {
 	uint64_t n_hits;           /* records returned */
 	uint64_t acx_entries_read; /* list entries gathered by the prefilter */
 	uint64_t bytes_algorithmic;/* per-launch algorithmic bytes of the myers kernel */
+	uint64_t n_windows;        /* reference lanes that passed the prefix stage of the two-stage edit distance */
+	uint64_t n_window_columns; /* columns swept by the full-length stage over those windows */
 	float ms_h2d, ms_prefilter, ms_peq, ms_myers, ms_rescore, ms_d2h, ms_total;
-	uint32_t myers_launches;
-	uint32_t reserved;
+	float ms_myers_prefix;     /* part of ms_myers spent in k_myers_prefix (the dominant kernel when the two-stage path runs) */
+	float ms_myers_window;     /* part of ms_myers spent in k_myers_window */
+	uint32_t myers_launches;   /* launches of the column-sweeping kernel (k_myers_prefix, or k_myers on the one-stage path) */
+	uint32_t prefix_words;     /* NWP of the last launch, 0 = one-stage path */
 } BhipStats;
 
 /* Upload a database to device `device` and create a handle.
