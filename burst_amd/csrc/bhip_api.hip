@@ -452,7 +452,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			hipEvent_t *ce = h->ev_cls[cls];
 			HIPCHK(hipEventRecord(ce[0], h->stream));
 			{
-				const uint64_t total = (uint64_t)n_list * 16 * NW;
+				const uint64_t total = (uint64_t)n_list * NW;
 				const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16);
 				hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 					qlist, n_list, NW, 0, h->mm, h->peq.as<uint32_t>());
@@ -462,7 +462,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			int NWP = 0;
 			if (h->opt_two_stage) { const uint32_t mE = h->st_maxE[cls]; NWP = mE <= 5 ? 1 : (mE <= 10 ? 2 : (mE <= 16 ? 3 : 0)); if (NWP >= NW) NWP = 0; }
 			if (NWP) {
-				const uint64_t total = (uint64_t)n_list * 16 * NWP;
+				const uint64_t total = (uint64_t)n_list * NWP;
 				const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16);
 				hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 					qlist, n_list, NWP, 32 * NWP, h->mm, h->peqp.as<uint32_t>());
@@ -602,7 +602,7 @@ extern "C" int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint
 	HIPCHK(hipMemcpyAsync(h->pairs.p, pr.data(), n_pairs * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
 	HIPCHK(hipMemsetAsync(h->counters.p, 0, sizeof(Counters), h->stream));
 	Counters *dc = h->counters.as<Counters>();
-	const uint64_t total = (uint64_t)n_q * 16 * NW;
+	const uint64_t total = (uint64_t)n_q * NW;
 	hipLaunchKernelGGL(k_build_peq, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
 		h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), (const uint32_t *)nullptr, n_q, NW, 0, h->mm, h->peq.as<uint32_t>());
 	HIPCHK(hipGetLastError());

@@ -58,21 +58,29 @@ __global__ void k_transpose_refs(const uint8_t *__restrict__ src, const uint64_t
 __global__ void k_build_peq(const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff,
                             const uint32_t *__restrict__ qlist, uint32_t n_list, int NW, int prefix_len,
                             BhipMatchMask mm, uint32_t *__restrict__ peq) {
-	const uint64_t total = (uint64_t)n_list * 16 * NW;
+	// one thread per (query, word): reads its 32 symbols once and emits the 16 symbol rows of that word
+	__shared__ uint32_t s_mm[16];
+	if (threadIdx.x < 16) s_mm[threadIdx.x] = mm.m[threadIdx.x];
+	__syncthreads();
+	const uint64_t total = (uint64_t)n_list * NW;
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-		const uint32_t w = i % NW, c = (i / NW) & 15, li = i / ((uint64_t)NW * 16);
+		const uint32_t w = (uint32_t)(i % NW), li = (uint32_t)(i / NW);
 		const uint32_t q = qlist ? qlist[li] : li;
 		const uint64_t b = qoff[q];
 		int len = (int)(qoff[q + 1] - b);
 		if (prefix_len > 0 && len > prefix_len) len = prefix_len;     // table of the first prefix_len symbols only (k_myers_prefix)
 		const int shift = 32 * NW - len;
-		uint32_t bits = 0;
+		uint32_t row[16];
+		#pragma unroll
+		for (int c = 0; c < 16; ++c) row[c] = 0;
 		for (int k = 0; k < 32; ++k) {
 			const int pos = 32 * (int)w + k - shift;
-			const uint32_t bit = pos < 0 ? 1u : ((mm.m[qcodes[b + pos] & 15] >> c) & 1u);
-			bits |= bit << k;
+			const uint32_t m16 = pos < 0 ? 0xFFFFu : s_mm[qcodes[b + pos] & 15];
+			#pragma unroll
+			for (int c = 0; c < 16; ++c) row[c] |= ((m16 >> c) & 1u) << k;
 		}
-		peq[((uint64_t)li * 16 + c) * NW + w] = bits;
+		#pragma unroll
+		for (int c = 0; c < 16; ++c) peq[((uint64_t)li * 16 + c) * NW + w] = row[c];
 	}
 }
 
@@ -603,9 +611,10 @@ BHIP_INST_MYERS(16) BHIP_INST_MYERS(32)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t sat8u(uint32_t v) { return v > 255u ? 255u : v; }
 
-__device__ __forceinline__ uint32_t ref_code(const uint8_t *__restrict__ refb, uint64_t clump_base, uint32_t z, uint32_t pos0) {
-	const uint8_t b = refb[((clump_base + (pos0 >> 5)) * 16 + z) * 16 + ((pos0 & 31) >> 1)];
-	return (pos0 & 1) ? (uint32_t)(b >> 4) : (uint32_t)(b & 15);
+// 8 consecutive reference symbols (positions 8*j8 .. 8*j8+7 of lane z) as one dword of nibbles; 0 outside the clump
+__device__ __forceinline__ uint32_t ref_dword(const uint32_t *__restrict__ refw, uint64_t clump_base, uint32_t z, int j8, uint32_t nchunks) {
+	if (j8 < 0 || (uint32_t)j8 >= nchunks * 4) return 0u;
+	return refw[((clump_base + ((uint32_t)j8 >> 2)) * 16 + z) * 4 + ((uint32_t)j8 & 3)];
 }
 
 template <bool WIDE>
@@ -622,17 +631,33 @@ __global__ __launch_bounds__(64) void k_rescore(
 		uint32_t *__restrict__ g_scratch, unsigned long long *__restrict__ scratch_used, unsigned long long scratch_cap,
 		uint32_t *__restrict__ err_flags) {
 	__shared__ uint32_t s_band[WIDE ? 1 : (BHIP_RESCORE_WMAX + 1)][64];
+	__shared__ uint32_t s_mm[16];      // match masks: bit r of s_mm[q] = (cost(q, r) == 0)
+	const uint32_t tid = threadIdx.x;
+	if (tid < 16) { uint32_t m = 0; for (int r = 0; r < 16; ++r) m |= (lut[16 * tid + r] == 0 ? 1u : 0u) << r; s_mm[tid] = m; }
+	__syncthreads();
+	const uint32_t *refw = (const uint32_t *)refb;
 	uint32_t n = WIDE ? *n_wide_in : *n_raw_dev;
 	if (!WIDE && n > raw_cap) n = raw_cap;
-	const uint32_t tid = threadIdx.x;
 	for (uint32_t i = blockIdx.x * 64 + tid; i < n; i += gridDim.x * 64) {
 		const BhipRawHit h = raw[WIDE ? wide_in[i] : i];
 		const uint32_t q = h.q, six = qsix ? qsix[q] : q;
 		if (!all_hits && h.ed != best[six]) continue;
-		const uint32_t B = h.ed, c = h.refIx >> 4, z = h.refIx & 15, L = clump_len[c];
+		const uint32_t B = h.ed, c = h.refIx >> 4, z = h.refIx & 15, L = clump_len[c], nchunks = (L + 31) >> 5;
 		const uint64_t qb = qoff[q];
 		const int m = (int)(qoff[q + 1] - qb);
-		const int e1 = (int)h.e_first, e2 = (int)(h.e_last < L ? h.e_last : L);
+		const int e2 = (int)(h.e_last < L ? h.e_last : L);
+		if (B == 0) {
+			// exact match: the only final cells with score 0 are gap-free, so gapQ = gapR = 0, the end is the LAST column
+			// with score 0 (burst.c:862-879) and the identity is 1 - 0/len
+			const uint32_t pos = atomicAdd(n_out, 1u);
+			if (pos < out_cap) {
+				BhipHit o; o.q = q; o.refIx = h.refIx; o.finalPos = (uint32_t)e2; o.score = 1.0f - 0.0f / (float)m;
+				o.ed = 0; o.gapR = 0; o.gapQ = 0; o.rc = qrc ? qrc[q] : 0;
+				out[pos] = o;
+			}
+			continue;
+		}
+		const int e1 = (int)h.e_first;
 		const int dlo = e1 - m - (int)B, dhi = e2 - m + (int)B, Wd = dhi - dlo + 1;
 		uint32_t *band; uint32_t stride;
 		if (!WIDE) {
@@ -655,22 +680,28 @@ __global__ __launch_bounds__(64) void k_rescore(
 			band[(uint32_t)k * stride] = (k < Wd && x >= 0 && x <= (int)L) ? 0u : INVALID;
 		}
 		for (int y = 1; y <= m; ++y) {
-			const uint32_t qc = qcodes[qb + y - 1];
-			const uint8_t *lrow = lut + 16 * qc;
+			const uint32_t qc = qcodes[qb + y - 1] & 15u;
+			const uint32_t mrow = s_mm[qc];
 			const uint32_t col0 = sat8u((uint32_t)y) | (sat8u((uint32_t)y) << 16);   // D=y, H=0, V=y (burst.c:747-750)
 			const int x0 = y + dlo;
 			uint32_t left = (x0 - 1 == 0) ? col0 : INVALID;
-			for (int k = 0; k < Wd; ++k) {
+			// reference symbols of this row: positions x0-1+k (0-based), fetched 8 at a time
+			int pos = x0 - 1;
+			uint32_t dw = ref_dword(refw, cbase, z, pos >> 3, nchunks);
+			uint32_t prev_sym = (y == 1) ? ((ref_dword(refw, cbase, z, (pos - 1) >> 3, nchunks) >> (4 * ((pos - 1) & 7))) & 15u) : 0u;
+			for (int k = 0; k < Wd; ++k, ++pos) {
 				const int x = x0 + k;
+				if ((pos & 7) == 0 && k) dw = ref_dword(refw, cbase, z, pos >> 3, nchunks);
+				const uint32_t r = (dw >> (4 * (pos & 7))) & 15u;
 				const uint32_t dg = band[(uint32_t)k * stride], up = band[(uint32_t)(k + 1) * stride];
 				uint32_t cell;
 				if (x < 1) cell = (x == 0) ? col0 : INVALID;
 				else if (x > (int)L) cell = INVALID;
 				else {
-					const uint32_t cst = lrow[ref_code(refb, cbase, z, (uint32_t)(x - 1))];
+					const uint32_t cst = ((mrow >> r) & 1u) ? 0u : ((r && qc) ? 1u : 255u);
 					if (y == 1) {   // burst.c:722-739
 						uint32_t hh = 0;
-						if (cst == 1 && x >= 2) hh = lrow[ref_code(refb, cbase, z, (uint32_t)(x - 2))] == 0;
+						if (cst == 1 && x >= 2) hh = (mrow >> prev_sym) & 1u;      // left cell of row 1 is 0 iff its symbol matches
 						cell = cst | (hh << 8);
 					} else {
 						const uint32_t sD = sat8u((dg & 255u) + cst), hD = (dg >> 8) & 255u, vD = (dg >> 16) & 255u;
@@ -686,6 +717,7 @@ __global__ __launch_bounds__(64) void k_rescore(
 						cell = s | (hv << 8) | (vv << 16);
 					}
 				}
+				prev_sym = r;
 				band[(uint32_t)k * stride] = cell;
 				left = cell;
 			}
