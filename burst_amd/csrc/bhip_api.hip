@@ -18,9 +18,12 @@ __global__ void k_transpose_refs(const uint8_t *, const uint64_t *, const uint32
 __global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, int, int, BhipMatchMask, uint32_t *);
 template <bool LDS_CNT> __global__ void k_prefilter(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
 	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t,
-	unsigned long long *);
+	unsigned long long *, const uint32_t *, const uint32_t *);
+__global__ void k_prefilter_hash(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, int,
+	const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, int, uint32_t *, uint32_t *);
 template <typename CNT> __global__ void k_prefilter_wave(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, int);
+	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, int,
+	const uint32_t *, const uint32_t *);
 template <int NW> __global__ void k_myers(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
 	const uint64_t *, const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t,
 	BhipRawHit *, uint32_t *, uint32_t, uint32_t *, uint8_t *, unsigned long long *, unsigned long long *);
@@ -82,6 +85,7 @@ struct Counters {
 	uint32_t n_cand, n_raw, n_out, n_wide, err, pad0;
 	uint32_t n_cand_cls[8];
 	uint32_t n_wins_cls[8];
+	uint32_t n_fb, pad2;
 	unsigned long long wcol_sum;
 	unsigned long long col_sum, qlen_sum, ent_read, scratch_used;
 };
@@ -100,7 +104,7 @@ struct Handle {
 	DBuf acx_off, acx_ent, bad; uint32_t n_bad = 0; uint64_t n_ent = 0;
 	// batch buffers
 	DBuf qcodes, qoff, qemac, qsix, qrc, qlist, peq, cand, candcnt, raw, best, out, wide, scratch, gcnt, counters, mins, pairs;
-	DBuf sort_keys, sort_keys2, sort_idx, sort_idx2, sort_tmp, out_sorted, peqp, wins;
+	DBuf sort_keys, sort_keys2, sort_idx, sort_idx2, sort_tmp, out_sorted, peqp, wins, fb_list;
 	uint64_t win_cap = 1 << 22;
 	uint64_t cand_cap = 1 << 20, raw_cap = 1 << 20, out_cap = 1 << 20, scratch_cap = 1 << 20;
 	std::vector<uint32_t> h_clump_len;
@@ -128,7 +132,7 @@ extern "C" void bhip_destroy(void *handle) {
 	if (h->stream) (void)hipStreamSynchronize(h->stream);
 	DBuf *all[] = {&h->ref, &h->ref_off, &h->clump_len, &h->lut, &h->acx_off, &h->acx_ent, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
 		&h->qsix, &h->qrc, &h->qlist, &h->peq, &h->cand, &h->candcnt, &h->raw, &h->best, &h->out, &h->wide, &h->scratch, &h->gcnt,
-		&h->counters, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx, &h->sort_idx2, &h->sort_tmp, &h->out_sorted, &h->peqp, &h->wins};
+		&h->counters, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx, &h->sort_idx2, &h->sort_tmp, &h->out_sorted, &h->peqp, &h->wins, &h->fb_list};
 	for (DBuf *b : all) b->release();
 	for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &ce : h->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
@@ -331,43 +335,45 @@ static int upload_queries(Handle *h, const uint8_t *q_codes, const uint64_t *q_o
 
 static int launch_prefilter(Handle *h, const uint32_t *d_qlist, uint32_t n_list, uint2 *cand, uint32_t *candcnt, uint32_t cand_cap,
                             bool with_bad, uint32_t *n_cand_dev, Counters *dc) {
-	const uint32_t nw32 = (h->n_clumps + 1) / 2;
-	const size_t lds = (size_t)nw32 * 4;
 	const uint32_t *bad = with_bad ? h->bad.as<uint32_t>() : nullptr;
 	const uint32_t n_bad = with_bad ? h->n_bad : 0;
-	// wave-per-query variant: byte counters while every possible count fits (max query length of the batch), else 16-bit
+	const int stride = h->opt_prefilter_stride;
+	int rc;
+	// main pass: hashed counters, four queries per wave (any database size)
+	if ((rc = h->fb_list.reserve((size_t)n_list * 4 + 16))) return rc;
+	HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 4, h->stream));
+	{
+		const uint32_t n_quads = (n_list + 3) / 4;
+		const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * 6);
+		hipLaunchKernelGGL(k_prefilter_hash, dim3(grid), dim3(64), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(),
+			d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read,
+			stride, h->fb_list.as<uint32_t>(), &dc->n_fb);
+		HIPCHK(hipGetLastError());
+	}
+	// fallback pass for the (rare) queries whose table overflowed: dense per-clump counters, LDS if they fit, else global memory
 	const bool narrow = h->st_maxlen_pf < 255u + (uint32_t)h->K;
-	const int diag = h->opt_prefilter_stride;
 	const size_t lds_w = ((size_t)(h->n_clumps + (narrow ? 3 : 1)) / (narrow ? 4 : 2)) * 4 + 1536u * 4 + 512u * 8 + 512u * 4 + 16;
+	const uint32_t nw32 = (h->n_clumps + 1) / 2;
 	if (lds_w <= 64 * 1024) {
 		const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / lds_w));
 		const uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * per_cu);
 		if (narrow) hipLaunchKernelGGL(k_prefilter_wave<uint8_t>, dim3(grid), dim3(64), lds_w, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
-			n_cand_dev, cand_cap, &dc->ent_read, diag);
+			n_cand_dev, cand_cap, &dc->ent_read, stride, h->fb_list.as<uint32_t>(), &dc->n_fb);
 		else hipLaunchKernelGGL(k_prefilter_wave<uint16_t>, dim3(grid), dim3(64), lds_w, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
-			n_cand_dev, cand_cap, &dc->ent_read, diag);
-	} else if (lds <= 128 * 1024) {
-		uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
-		uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * per_cu);
-		if (lds > 64 * 1024)
-			HIPCHK(hipFuncSetAttribute((const void *)k_prefilter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		hipLaunchKernelGGL(k_prefilter<true>, dim3(grid), dim3(256), lds, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps,
-			(uint32_t *)nullptr, bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read);
+			n_cand_dev, cand_cap, &dc->ent_read, stride, h->fb_list.as<uint32_t>(), &dc->n_fb);
 	} else {
-		uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * 4);
-		int rc = h->gcnt.reserve((size_t)grid * nw32 * 4);
-		if (rc) return rc;
+		// stride-1 dense counters in global memory, one workgroup per query (very large databases only)
+		uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * 2);
+		if ((rc = h->gcnt.reserve((size_t)grid * nw32 * 4))) return rc;
 		hipLaunchKernelGGL(k_prefilter<false>, dim3(grid), dim3(256), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps,
-			h->gcnt.as<uint32_t>(), bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read);
+			h->gcnt.as<uint32_t>(), bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read, h->fb_list.as<uint32_t>(), &dc->n_fb);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
 }
-
 
 // ---- staged batch: inputs resident in HBM, then any number of runs over them ---------------------------------
 extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,

@@ -99,14 +99,16 @@ __global__ __launch_bounds__(256) void k_prefilter(
 		const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, int K, uint32_t n_clumps,
 		uint32_t *__restrict__ g_cnt, const uint32_t *__restrict__ bad, uint32_t n_bad,
 		uint2 *__restrict__ cand, uint32_t *__restrict__ cand_cnt_out, uint32_t *__restrict__ n_cand, uint32_t cand_cap,
-		unsigned long long *__restrict__ ent_read) {
+		unsigned long long *__restrict__ ent_read, const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel_dev) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];
 	const uint32_t nw32 = (n_clumps + 1) >> 1;
 	uint32_t *cnt = LDS_CNT ? s_cnt : g_cnt + (uint64_t)blockIdx.x * nw32;
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
 	unsigned long long my_ent = 0;
-	for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+	const uint32_t n_iter = sel ? (*n_sel_dev < n_list ? *n_sel_dev : n_list) : n_list;
+	for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+		const uint32_t li = sel ? sel[it] : it;
 		const uint32_t q = qlist ? qlist[li] : li;
 		const uint64_t b = qoff[q];
 		const uint32_t len = (uint32_t)(qoff[q + 1] - b), E = qemac[q];
@@ -164,9 +166,11 @@ __global__ __launch_bounds__(256) void k_prefilter(
 }
 
 template __global__ void k_prefilter<true>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *);
+	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *,
+	const uint32_t *, const uint32_t *);
 template __global__ void k_prefilter<false>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *);
+	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *,
+	const uint32_t *, const uint32_t *);
 
 
 // ------------------------------------------------------------------------------------------------
@@ -201,7 +205,8 @@ __global__ __launch_bounds__(64) void k_prefilter_wave(
 		const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, int K, uint32_t n_clumps,
 		const uint32_t *__restrict__ bad, uint32_t n_bad,
 		uint2 *__restrict__ cand, uint32_t *__restrict__ cand_cnt_out, uint32_t *__restrict__ n_cand, uint32_t cand_cap,
-		unsigned long long *__restrict__ ent_read, int stride_opt) {
+		unsigned long long *__restrict__ ent_read, int stride_opt,
+		const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel_dev) {   // optional: only list positions sel[0..*n_sel_dev)
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	constexpr uint32_t PER = 4 / sizeof(CNT), BITS = 8 * sizeof(CNT), MASK = (1u << BITS) - 1u;
 	const uint32_t nw32 = (n_clumps + PER - 1) / PER;
@@ -247,7 +252,9 @@ __global__ __launch_bounds__(64) void k_prefilter_wave(
 		}
 	};
 
-	for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+	const uint32_t n_iter = sel ? (*n_sel_dev < n_list ? *n_sel_dev : n_list) : n_list;
+	for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+		const uint32_t li = sel ? sel[it] : it;
 		const uint32_t q = qlist ? qlist[li] : li;
 		const uint64_t b = qoff[q];
 		const uint32_t len = (uint32_t)(qoff[q + 1] - b), E = qemac[q];
@@ -313,9 +320,162 @@ __global__ __launch_bounds__(64) void k_prefilter_wave(
 	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
 }
 template __global__ void k_prefilter_wave<uint8_t>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, int);
+	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, int,
+	const uint32_t *, const uint32_t *);
 template __global__ void k_prefilter_wave<uint16_t>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, int);
+	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, int,
+	const uint32_t *, const uint32_t *);
+
+// ------------------------------------------------------------------------------------------------
+// Prefilter, hashed variant: FOUR queries per wave (16 lanes each), per-query open-addressing table in LDS instead of
+// dense per-clump counters, so LDS use no longer depends on the database size (RefSeq-scale DBs have millions of
+// clumps) and 4-6x more queries are in flight per CU -- the kernel is bound by the latency of the random .acx list
+// reads, not by arithmetic.  Slot = (clump+1) << 8 | count (clump ids are < 2^24 by the .acx format, burst.c:3509;
+// counts <= 255 is guaranteed by the seed plan).  New keys go to a per-query touched list; the final pass reads and
+// clears only touched slots.  A query that overflows its table or list is handed to the dense kernel (sel list).
+// ------------------------------------------------------------------------------------------------
+#define PFH_HT 1024u
+#define PFH_TL 448u
+#define PFH_STAGE 512u
+__global__ __launch_bounds__(64) void k_prefilter_hash(
+		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint16_t *__restrict__ qemac,
+		const uint32_t *__restrict__ qlist, uint32_t n_list,
+		const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, int K,
+		const uint32_t *__restrict__ bad, uint32_t n_bad,
+		uint2 *__restrict__ cand, uint32_t *__restrict__ cand_cnt_out, uint32_t *__restrict__ n_cand, uint32_t cand_cap,
+		unsigned long long *__restrict__ ent_read, int stride_opt,
+		uint32_t *__restrict__ fb_list, uint32_t *__restrict__ n_fb) {
+	__shared__ uint32_t s_tab[4][PFH_HT];
+	__shared__ uint16_t s_tl[4][PFH_TL];
+	__shared__ uint2 s_stage[PFH_STAGE];
+	__shared__ uint32_t s_stage_v[PFH_STAGE];
+	__shared__ uint32_t s_ctr[8];           // [g] touched count of group g, [4] staged, [5+..] unused
+	__shared__ uint32_t s_ovf[4];
+	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
+	const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
+	for (uint32_t i = lane; i < 4 * PFH_HT; i += 64) (&s_tab[0][0])[i] = 0;
+	if (lane < 8) s_ctr[lane] = 0;
+	if (lane < 4) s_ovf[lane] = 0;
+	__syncthreads();
+	unsigned long long my_ent = 0;
+
+	auto push = [&](uint32_t li, uint32_t c, uint32_t v) {
+		const uint32_t pos = atomicAdd(&s_ctr[4], 1u);
+		if (pos < PFH_STAGE) { s_stage[pos] = make_uint2(li, c); if (cand_cnt_out) s_stage_v[pos] = v; }
+		else {
+			const uint32_t gp = atomicAdd(n_cand, 1u);
+			if (gp < cand_cap) { cand[gp] = make_uint2(li, c); if (cand_cnt_out) cand_cnt_out[gp] = v; }
+		}
+	};
+	auto flush = [&]() {
+		__syncthreads();
+		const uint32_t n = s_ctr[4] < PFH_STAGE ? s_ctr[4] : PFH_STAGE;
+		uint32_t base = 0;
+		if (n) {
+			if (lane == 0) base = atomicAdd(n_cand, n);
+			base = __shfl(base, 0);
+			for (uint32_t i = lane; i < n; i += 64) if (base + i < cand_cap) { cand[base + i] = s_stage[i]; if (cand_cnt_out) cand_cnt_out[base + i] = s_stage_v[i]; }
+		}
+		__syncthreads();
+		if (lane == 0) s_ctr[4] = 0;
+		__syncthreads();
+	};
+	// insert-or-increment clump c in the table of group tg
+	auto bump = [&](uint32_t tg, uint32_t c) {
+		const uint32_t key = (c + 1u) << 8;
+		uint32_t slot = (c * 0x9E3779B1u) >> (32 - 10);
+		uint32_t *tab = s_tab[tg];
+		for (uint32_t probes = 0; probes < PFH_HT; ++probes, slot = (slot + 1) & (PFH_HT - 1)) {
+			uint32_t old = tab[slot];
+			if (old == 0) {
+				old = atomicCAS(&tab[slot], 0u, key | 1u);
+				if (old == 0) {   // new key
+					const uint32_t pos = atomicAdd(&s_ctr[tg], 1u);
+					if (pos < PFH_TL) s_tl[tg][pos] = (uint16_t)slot; else s_ovf[tg] = 1;
+					return;
+				}
+			}
+			if ((old & 0xFFFFFF00u) == key) { atomicAdd(&tab[slot], 1u); return; }
+		}
+		s_ovf[tg] = 1;
+	};
+
+	const uint32_t n_quads = (n_list + 3) >> 2;
+	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
+		const uint32_t li = quad * 4 + g;
+		const bool live = li < n_list;
+		uint32_t q = 0, len = 0, E = 0, stride = 1, need = 0, nwords = 0;
+		uint64_t b = 0;
+		if (live) {
+			q = qlist ? qlist[li] : li;
+			b = qoff[q];
+			len = (uint32_t)(qoff[q + 1] - b); E = qemac[q];
+			if (len >= (uint32_t)K) {
+				bhip_seed_plan(len, E, (uint32_t)K, stride_opt, stride, need);
+				nwords = (len - K) / stride + 1;
+				if (nwords > 255) {   // keep every count within the 8-bit field: coarser stride, guarantee recomputed
+					stride = (len - K) / 254 + 1;
+					const int nd = (int)((len - K) / stride + 1) - (int)(E * (((uint32_t)K + stride - 1) / stride));
+					need = nd > 0 ? (uint32_t)nd : 0u;
+					nwords = (len - K) / stride + 1;
+				}
+			}
+		}
+		uint32_t maxw = nwords;
+		#pragma unroll
+		for (int o = 32; o >= 1; o >>= 1) { const uint32_t t = __shfl_xor(maxw, o); maxw = t > maxw ? t : maxw; }
+		for (uint32_t base = 0; base < maxw; base += 16) {
+			const uint32_t j = base + gl, p = j * stride;
+			uint32_t w = 0, ok = live && j < nwords;
+			if (ok) for (int k = 0; k < K; ++k) {
+				const uint32_t c = qcodes[b + p + k];
+				ok &= (c - 1u) < 4u;
+				w = (w << 2) | ((c - 1u) & 3u);
+			}
+			w &= wmask;
+			uint32_t beg = 0, end = 0;
+			if (ok) { beg = acx_off[w]; end = acx_off[w + 1]; }
+			const uint32_t n = end - beg;
+			my_ent += n;
+			unsigned long long longm = __ballot(n > 48);
+			if (n <= 48) {
+				uint32_t e = beg;
+				for (; e + 4 <= end; e += 4) {
+					const uint32_t c0 = acx_ent[e], c1 = acx_ent[e + 1], c2 = acx_ent[e + 2], c3 = acx_ent[e + 3];
+					bump(g, c0); bump(g, c1); bump(g, c2); bump(g, c3);
+				}
+				for (; e < end; ++e) bump(g, acx_ent[e]);
+			}
+			while (longm) {   // long lists: the whole wave walks them, inserting into the owner's table
+				const int src = __builtin_ctzll(longm);
+				longm &= longm - 1;
+				const uint32_t lb = __shfl(beg, src), le = __shfl(end, src), tg = (uint32_t)src >> 4;
+				for (uint32_t e = lb + lane; e < le; e += 64) bump(tg, acx_ent[e]);
+			}
+		}
+		__syncthreads();
+		// evaluate and clear the touched slots of the own group
+		const uint32_t nt = s_ctr[g] < PFH_TL ? s_ctr[g] : PFH_TL;
+		const uint32_t ovf = s_ovf[g];
+		const uint32_t thr = need ? need - 1 : 0;
+		if (live && !ovf) {
+			for (uint32_t i = gl; i < nt; i += 16) {
+				const uint32_t slot = s_tl[g][i], v = s_tab[g][slot];
+				s_tab[g][slot] = 0;
+				if ((v & 255u) > thr) push(li, (v >> 8) - 1u, v & 255u);
+			}
+			for (uint32_t i = gl; i < n_bad; i += 16) push(li, bad[i], 0xFFFFFFFFu);       // burst.c:4136-4138, 4282-4283
+		} else if (ovf) {
+			for (uint32_t i = gl; i < PFH_HT; i += 16) s_tab[g][i] = 0;
+			if (live && gl == 0) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
+		}
+		__syncthreads();
+		if (gl == 0) { s_ctr[g] = 0; s_ovf[g] = 0; }
+		if (s_ctr[4] >= PFH_STAGE / 2) flush(); else __syncthreads();
+	}
+	flush();
+	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Bit-parallel semi-global edit distance (Myers 1999 / Hyyro 2003), NW x 32-bit words per DP column.
