@@ -39,7 +39,8 @@ template <int NW> __global__ void k_myers_window(const BhipWin *, const uint32_t
 template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *,
 	const uint32_t *, int, const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t *, const uint64_t *,
 	const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *,
-	unsigned long long, uint32_t *);
+	unsigned long long, uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t);
+__global__ void k_pack_queries(const uint8_t *, const uint64_t *, uint32_t, uint32_t, uint32_t *);
 
 // ---- ordering of the output records: (q, refIx) ascending, done on the device (radix sort of 64-bit keys) ----
 __global__ void k_hit_keys(const BhipHit *__restrict__ hits, uint32_t n, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx) {
@@ -107,7 +108,7 @@ struct Handle {
 	DBuf acx_off, acx_ent, bad; uint32_t n_bad = 0; uint64_t n_ent = 0;
 	// batch buffers
 	DBuf qcodes, qoff, qemac, qsix, qrc, qlist, peq, cand, candcnt, raw, best, out, wide, scratch, gcnt, counters, mins, pairs;
-	DBuf sort_keys, sort_keys2, sort_idx, sort_idx2, sort_tmp, out_sorted, peqp, wins, fb_list;
+	DBuf sort_keys, sort_keys2, sort_idx, sort_idx2, sort_tmp, out_sorted, peqp, wins, fb_list, qpack;
 	uint64_t win_cap = 1 << 22;
 	uint64_t cand_cap = 1 << 20, raw_cap = 1 << 20, out_cap = 1 << 20, scratch_cap = 1 << 20;
 	std::vector<uint32_t> h_clump_len;
@@ -135,7 +136,7 @@ extern "C" void bhip_destroy(void *handle) {
 	if (h->stream) (void)hipStreamSynchronize(h->stream);
 	DBuf *all[] = {&h->ref, &h->ref_off, &h->clump_len, &h->lut, &h->acx_off, &h->acx_ent, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
 		&h->qsix, &h->qrc, &h->qlist, &h->peq, &h->cand, &h->candcnt, &h->raw, &h->best, &h->out, &h->wide, &h->scratch, &h->gcnt,
-		&h->counters, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx, &h->sort_idx2, &h->sort_tmp, &h->out_sorted, &h->peqp, &h->wins, &h->fb_list};
+		&h->counters, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx, &h->sort_idx2, &h->sort_tmp, &h->out_sorted, &h->peqp, &h->wins, &h->fb_list, &h->qpack};
 	for (DBuf *b : all) b->release();
 	for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &ce : h->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
@@ -506,11 +507,23 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		// rescoring of the kept lanes
 		HIPCHK(hipEventRecord(h->ev[6], h->stream));
 		const uint32_t grid_rs = (uint32_t)h->n_cu * 16;
-		hipLaunchKernelGGL(k_rescore<false>, dim3(grid_rs), dim3(64), 0, h->stream, h->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)h->raw_cap,
+		// LDS plan of the re-scorer: band rows for the widest expected band (2*maxE+1 plus slack), query and reference staging
+		uint32_t maxE = 0; for (int cls = 0; cls < kNumClasses; ++cls) maxE = std::max(maxE, h->st_maxE[cls]);
+		const uint32_t band_rows = std::min<uint32_t>(BHIP_RESCORE_WMAX, 2 * maxE + 1 + 9);
+		uint32_t qw = (h->st_maxlen_pf + 7) / 8, rw = (h->st_maxlen_pf + band_rows + 24) / 8 + 2;
+		if ((size_t)(band_rows + 1 + qw + rw) * 256 > 40 * 1024) { qw = 0; rw = 0; }      // long queries: per-row global reads instead
+		const size_t lds_rs = (size_t)(band_rows + 1 + qw + rw) * 256;
+		if (qw) {
+			if ((rc = h->qpack.reserve((size_t)n_q * qw * 4))) return rc;
+			const uint64_t total = (uint64_t)n_q * qw;
+			hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
+				h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), n_q, qw, h->qpack.as<uint32_t>());
+		}
+		hipLaunchKernelGGL(k_rescore<false>, dim3(grid_rs), dim3(64), lds_rs, h->stream, h->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)h->raw_cap,
 			(const uint32_t *)nullptr, (const uint32_t *)nullptr, h->best.as<uint32_t>(), all_hits, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 			h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr, h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(),
 			h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &dc->n_out, (uint32_t)h->out_cap, h->wide.as<uint32_t>(),
-			&dc->n_wide, (uint32_t *)nullptr, &dc->scratch_used, 0ull, &dc->err);
+			&dc->n_wide, (uint32_t *)nullptr, &dc->scratch_used, 0ull, &dc->err, qw ? h->qpack.as<uint32_t>() : nullptr, band_rows, qw, rw);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
@@ -520,12 +533,12 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		if (hc.n_raw > h->raw_cap) { h->raw_cap = (uint64_t)hc.n_raw + hc.n_raw / 8 + 1024; retry = true; }
 		if (retry) continue;
 		if (hc.n_wide) {
-			hipLaunchKernelGGL(k_rescore<true>, dim3(std::min<uint32_t>((hc.n_wide + 63) / 64, grid_rs)), dim3(64), 0, h->stream,
+			hipLaunchKernelGGL(k_rescore<true>, dim3(std::min<uint32_t>((hc.n_wide + 63) / 64, grid_rs)), dim3(64), 256, h->stream,
 				h->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)h->raw_cap, h->wide.as<uint32_t>(), &dc->n_wide, h->best.as<uint32_t>(), all_hits,
 				h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr,
 				h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(),
 				&dc->n_out, (uint32_t)h->out_cap, (uint32_t *)nullptr, (uint32_t *)nullptr, h->scratch.as<uint32_t>(), &dc->scratch_used,
-				(unsigned long long)h->scratch_cap, &dc->err);
+				(unsigned long long)h->scratch_cap, &dc->err, (const uint32_t *)nullptr, 0u, 0u, 0u);
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, h->stream));
 			HIPCHK(hipStreamSynchronize(h->stream));

@@ -874,6 +874,22 @@ __device__ __forceinline__ uint32_t ref_dword(const uint32_t *__restrict__ refw,
 	return refw[((clump_base + ((uint32_t)j8 >> 2)) * 16 + z) * 4 + ((uint32_t)j8 & 3)];
 }
 
+// 4-bit packing of the queries at a fixed stride of qw dwords per query (k_rescore preloads them into LDS)
+__global__ void k_pack_queries(const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, uint32_t n_q, uint32_t qw,
+                               uint32_t *__restrict__ qpack) {
+	const uint64_t total = (uint64_t)n_q * qw;
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t q = (uint32_t)(i / qw), j = (uint32_t)(i % qw);
+		const uint64_t b = qoff[q];
+		const uint32_t len = (uint32_t)(qoff[q + 1] - b);
+		uint32_t v = 0;
+		for (uint32_t k = 0; k < 8; ++k) { const uint32_t pos = 8 * j + k; if (pos < len) v |= (uint32_t)(qcodes[b + pos] & 15) << (4 * k); }
+		qpack[i] = v;
+	}
+}
+
+// Dynamic LDS layout (dwords, all [row][64 threads]): band[band_rows + 1] | qbuf[qw] | rbuf[rw].
+// A hit uses the LDS copies when m <= 8*qw and its reference segment fits rw dwords, else it reads global memory per row.
 template <bool WIDE>
 __global__ __launch_bounds__(64) void k_rescore(
 		const BhipRawHit *__restrict__ raw, const uint32_t *__restrict__ n_raw_dev, uint32_t raw_cap,
@@ -886,10 +902,14 @@ __global__ __launch_bounds__(64) void k_rescore(
 		BhipHit *__restrict__ out, uint32_t *__restrict__ n_out, uint32_t out_cap,
 		uint32_t *__restrict__ wide_out, uint32_t *__restrict__ n_wide_out,
 		uint32_t *__restrict__ g_scratch, unsigned long long *__restrict__ scratch_used, unsigned long long scratch_cap,
-		uint32_t *__restrict__ err_flags) {
-	__shared__ uint32_t s_band[WIDE ? 1 : (BHIP_RESCORE_WMAX + 1)][64];
+		uint32_t *__restrict__ err_flags,
+		const uint32_t *__restrict__ qpack, uint32_t band_rows, uint32_t qw, uint32_t rw) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	__shared__ uint32_t s_mm[16];      // match masks: bit r of s_mm[q] = (cost(q, r) == 0)
 	const uint32_t tid = threadIdx.x;
+	uint32_t *s_band = smem + tid;                              // [k * 64]
+	uint32_t *s_q = smem + (size_t)(band_rows + 1) * 64 + tid;  // [j * 64]
+	uint32_t *s_r = s_q + (size_t)qw * 64;                      // [j * 64]
 	if (tid < 16) { uint32_t m = 0; for (int r = 0; r < 16; ++r) m |= (lut[16 * tid + r] == 0 ? 1u : 0u) << r; s_mm[tid] = m; }
 	__syncthreads();
 	const uint32_t *refw = (const uint32_t *)refb;
@@ -918,12 +938,12 @@ __global__ __launch_bounds__(64) void k_rescore(
 		const int dlo = e1 - m - (int)B, dhi = e2 - m + (int)B, Wd = dhi - dlo + 1;
 		uint32_t *band; uint32_t stride;
 		if (!WIDE) {
-			if (Wd > BHIP_RESCORE_WMAX) {   // rare (repeats inside one shear): defer to the global-scratch variant
+			if (Wd > (int)band_rows) {   // rare (repeats inside one shear): defer to the global-scratch variant
 				const uint32_t pos = atomicAdd(n_wide_out, 1u);
 				wide_out[pos] = i;
 				continue;
 			}
-			band = &s_band[0][tid]; stride = 64;
+			band = s_band; stride = 64;
 		} else {
 			const unsigned long long off = atomicAdd(scratch_used, (unsigned long long)(Wd + 1));
 			if (off + Wd + 1 > scratch_cap) { atomicOr(err_flags, 2u); continue; }
@@ -931,24 +951,36 @@ __global__ __launch_bounds__(64) void k_rescore(
 		}
 		const uint64_t cbase = ref_off[c];
 		const uint32_t INVALID = 255u;
+		// stage the query and the reference segment [dlo-1, dlo+m+Wd] in LDS when they fit
+		const int j8_0 = (dlo - 1) >> 3, j8_1 = (dlo + m + Wd) >> 3;
+		const bool pre = qpack && (uint32_t)m <= 8 * qw && (uint32_t)(j8_1 - j8_0 + 1) <= rw;
+		if (pre) {
+			const uint32_t *qp = qpack + (uint64_t)q * qw;
+			for (uint32_t j = 0; j < (uint32_t)(m + 7) >> 3; ++j) s_q[j * 64] = qp[j];
+			for (int j = j8_0; j <= j8_1; ++j) s_r[(uint32_t)(j - j8_0) * 64] = ref_dword(refw, cbase, z, j, nchunks);
+		}
+		auto rdw = [&](int j8) -> uint32_t { return pre ? s_r[(uint32_t)(j8 - j8_0) * 64] : ref_dword(refw, cbase, z, j8, nchunks); };
 		// row 0: D = 0 wherever the column exists (burst.c:4052), else invalid
 		for (int k = 0; k <= Wd; ++k) {
 			const int x = dlo + k;
 			band[(uint32_t)k * stride] = (k < Wd && x >= 0 && x <= (int)L) ? 0u : INVALID;
 		}
+		uint32_t qdw = 0;
 		for (int y = 1; y <= m; ++y) {
-			const uint32_t qc = qcodes[qb + y - 1] & 15u;
+			uint32_t qc;
+			if (pre) { if (((y - 1) & 7) == 0) qdw = s_q[(uint32_t)((y - 1) >> 3) * 64]; qc = (qdw >> (4 * ((y - 1) & 7))) & 15u; }
+			else qc = qcodes[qb + y - 1] & 15u;
 			const uint32_t mrow = s_mm[qc];
 			const uint32_t col0 = sat8u((uint32_t)y) | (sat8u((uint32_t)y) << 16);   // D=y, H=0, V=y (burst.c:747-750)
 			const int x0 = y + dlo;
 			uint32_t left = (x0 - 1 == 0) ? col0 : INVALID;
 			// reference symbols of this row: positions x0-1+k (0-based), fetched 8 at a time
 			int pos = x0 - 1;
-			uint32_t dw = ref_dword(refw, cbase, z, pos >> 3, nchunks);
-			uint32_t prev_sym = (y == 1) ? ((ref_dword(refw, cbase, z, (pos - 1) >> 3, nchunks) >> (4 * ((pos - 1) & 7))) & 15u) : 0u;
+			uint32_t dw = rdw(pos >> 3);
+			uint32_t prev_sym = (y == 1) ? ((rdw((pos - 1) >> 3) >> (4 * ((pos - 1) & 7))) & 15u) : 0u;
 			for (int k = 0; k < Wd; ++k, ++pos) {
 				const int x = x0 + k;
-				if ((pos & 7) == 0 && k) dw = ref_dword(refw, cbase, z, pos >> 3, nchunks);
+				if ((pos & 7) == 0 && k) dw = rdw(pos >> 3);
 				const uint32_t r = (dw >> (4 * (pos & 7))) & 15u;
 				const uint32_t dg = band[(uint32_t)k * stride], up = band[(uint32_t)(k + 1) * stride];
 				uint32_t cell;
@@ -1007,7 +1039,9 @@ __global__ __launch_bounds__(64) void k_rescore(
 
 template __global__ void k_rescore<false>(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, int,
 	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *,
-	BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long, uint32_t *);
+	BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long, uint32_t *,
+	const uint32_t *, uint32_t, uint32_t, uint32_t);
 template __global__ void k_rescore<true>(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, int,
 	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *,
-	BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long, uint32_t *);
+	BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long, uint32_t *,
+	const uint32_t *, uint32_t, uint32_t, uint32_t);
