@@ -18,11 +18,11 @@ __global__ void k_transpose_refs(const uint8_t *, const uint64_t *, const uint32
 __global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, int, int, BhipMatchMask, uint32_t *);
 template <bool LDS_CNT> __global__ void k_prefilter(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
 	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t,
-	unsigned long long *, const uint32_t *, const uint32_t *);
+	unsigned long long *, const uint32_t *, const uint32_t *, const uint32_t *);
 __global__ void k_prefilter_hash(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, int,
-	const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, int, uint32_t *, uint32_t *);
+	const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *, uint32_t *, uint32_t *);
 template <typename CNT> __global__ void k_prefilter_wave(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, int,
+	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *,
 	const uint32_t *, const uint32_t *);
 template <int NW> __global__ void k_myers(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
 	const uint64_t *, const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t,
@@ -108,7 +108,7 @@ struct Handle {
 	DBuf acx_off, acx_ent, bad; uint32_t n_bad = 0; uint64_t n_ent = 0;
 	// batch buffers
 	DBuf qcodes, qoff, qemac, qsix, qrc, qlist, peq, cand, candcnt, raw, best, out, wide, scratch, gcnt, counters, mins, pairs;
-	DBuf sort_keys, sort_keys2, sort_idx, sort_idx2, sort_tmp, out_sorted, peqp, wins, fb_list, qpack;
+	DBuf sort_keys, sort_keys2, sort_idx, sort_idx2, sort_tmp, out_sorted, peqp, wins, fb_list, qpack, plan;
 	uint64_t win_cap = 1 << 22;
 	uint64_t cand_cap = 1 << 20, raw_cap = 1 << 20, out_cap = 1 << 20, scratch_cap = 1 << 20;
 	std::vector<uint32_t> h_clump_len;
@@ -136,7 +136,7 @@ extern "C" void bhip_destroy(void *handle) {
 	if (h->stream) (void)hipStreamSynchronize(h->stream);
 	DBuf *all[] = {&h->ref, &h->ref_off, &h->clump_len, &h->lut, &h->acx_off, &h->acx_ent, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
 		&h->qsix, &h->qrc, &h->qlist, &h->peq, &h->cand, &h->candcnt, &h->raw, &h->best, &h->out, &h->wide, &h->scratch, &h->gcnt,
-		&h->counters, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx, &h->sort_idx2, &h->sort_tmp, &h->out_sorted, &h->peqp, &h->wins, &h->fb_list, &h->qpack};
+		&h->counters, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx, &h->sort_idx2, &h->sort_tmp, &h->out_sorted, &h->peqp, &h->wins, &h->fb_list, &h->qpack, &h->plan};
 	for (DBuf *b : all) b->release();
 	for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &ce : h->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
@@ -318,6 +318,37 @@ static void launch_window(Handle *h, int cls, int NWP, uint32_t grid, const uint
 	#undef LW
 }
 
+// Seed plan of one query entry (see bhip_kernels.hip): returns stride | need << 8, need = 0 when no stride guarantees a
+// surviving word (the caller then aligns the entry against every clump).  stride_opt > 0 forces the stride.
+static uint32_t make_seed_plan(const uint8_t *s, uint32_t len, uint32_t E, uint32_t K, int stride_opt) {
+	if (len < K) return 1u;
+	const uint32_t npos = len - K + 1;
+	bool clean = true;
+	for (uint32_t i = 0; i < len; ++i) if ((uint32_t)(s[i] - 1u) >= 4u) { clean = false; break; }
+	std::vector<uint8_t> valid;
+	if (!clean) {           // valid[p] = word starting at p contains only A/C/G/T
+		valid.assign(npos, 0);
+		uint32_t run = 0;
+		for (uint32_t i = 0; i < len; ++i) { run = ((uint32_t)(s[i] - 1u) < 4u) ? run + 1 : 0; if (i + 1 >= K && run >= K) valid[i + 1 - K] = 1; }
+	}
+	auto need_of = [&](uint32_t st) -> int {
+		uint32_t W = 0;
+		if (clean) W = (len - K) / st + 1; else for (uint32_t p = 0; p < npos; p += st) W += valid[p];
+		return (int)W - (int)(E * ((K + st - 1) / st));
+	};
+	const uint32_t smin = (len - K) / 254 + 1;      // keeps the number of sampled words <= 255 (8-bit counters)
+	uint32_t best_s = 0; int best_n = 0;
+	if (stride_opt > 0) { best_s = std::max<uint32_t>((uint32_t)stride_opt, smin); best_n = need_of(best_s); }
+	else {
+		for (uint32_t st = std::max(K, smin); st >= smin; --st) { const int n = need_of(st); if (n >= 3) { best_s = st; best_n = n; break; } if (st == smin) break; }
+		if (!best_s) for (uint32_t st = smin; st <= std::max(K, smin); ++st) { const int n = need_of(st); if (n > best_n) { best_n = n; best_s = st; } }
+		if (!best_s) { best_s = smin; best_n = need_of(smin); }
+	}
+	if (best_n < 1) best_n = 0;
+	if (best_n > 0xFFFF) best_n = 0xFFFF;
+	return (best_s & 255u) | ((uint32_t)best_n << 8);
+}
+
 static int upload_queries(Handle *h, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
                           const uint32_t *q_six, const uint8_t *q_rc, uint32_t n_q) {
 	const uint64_t nb = q_off[n_q];
@@ -341,7 +372,7 @@ static int launch_prefilter(Handle *h, const uint32_t *d_qlist, uint32_t n_list,
                             bool with_bad, uint32_t *n_cand_dev, Counters *dc) {
 	const uint32_t *bad = with_bad ? h->bad.as<uint32_t>() : nullptr;
 	const uint32_t n_bad = with_bad ? h->n_bad : 0;
-	const int stride = h->opt_prefilter_stride;
+	const uint32_t *plan = h->plan.as<uint32_t>();
 	int rc;
 	// main pass: hashed counters, four queries per wave (any database size)
 	if ((rc = h->fb_list.reserve((size_t)n_list * 4 + 16))) return rc;
@@ -351,7 +382,7 @@ static int launch_prefilter(Handle *h, const uint32_t *d_qlist, uint32_t n_list,
 		const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * 6);
 		hipLaunchKernelGGL(k_prefilter_hash, dim3(grid), dim3(64), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(),
 			d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read,
-			stride, h->fb_list.as<uint32_t>(), &dc->n_fb);
+			plan, h->fb_list.as<uint32_t>(), &dc->n_fb);
 		HIPCHK(hipGetLastError());
 	}
 	// fallback pass for the (rare) queries whose table overflowed: dense per-clump counters, LDS if they fit, else global memory
@@ -363,17 +394,17 @@ static int launch_prefilter(Handle *h, const uint32_t *d_qlist, uint32_t n_list,
 		const uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * per_cu);
 		if (narrow) hipLaunchKernelGGL(k_prefilter_wave<uint8_t>, dim3(grid), dim3(64), lds_w, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
-			n_cand_dev, cand_cap, &dc->ent_read, stride, h->fb_list.as<uint32_t>(), &dc->n_fb);
+			n_cand_dev, cand_cap, &dc->ent_read, plan, h->fb_list.as<uint32_t>(), &dc->n_fb);
 		else hipLaunchKernelGGL(k_prefilter_wave<uint16_t>, dim3(grid), dim3(64), lds_w, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
-			n_cand_dev, cand_cap, &dc->ent_read, stride, h->fb_list.as<uint32_t>(), &dc->n_fb);
+			n_cand_dev, cand_cap, &dc->ent_read, plan, h->fb_list.as<uint32_t>(), &dc->n_fb);
 	} else {
 		// stride-1 dense counters in global memory, one workgroup per query (very large databases only)
 		uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * 2);
 		if ((rc = h->gcnt.reserve((size_t)grid * nw32 * 4))) return rc;
 		hipLaunchKernelGGL(k_prefilter<false>, dim3(grid), dim3(256), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps,
-			h->gcnt.as<uint32_t>(), bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read, h->fb_list.as<uint32_t>(), &dc->n_fb);
+			h->gcnt.as<uint32_t>(), bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read, h->fb_list.as<uint32_t>(), &dc->n_fb, plan);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -393,6 +424,7 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 	HIPCHK(hipSetDevice(h->device));
 	// host-side routing: class by length, prefilter vs exhaustive
 	std::vector<uint32_t> lists[kNumClasses][2];
+	std::vector<uint32_t> plan(n_q, 1u);
 	for (uint32_t i = 0; i < n_q; ++i) {
 		const uint64_t len = q_off[i + 1] - q_off[i];
 		if (len == 0) continue;
@@ -401,12 +433,18 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 		const int cls = class_of_len((uint32_t)len);
 		int ex = q_flags ? (q_flags[i] == BHIP_Q_EXHAUSTIVE) : !h->has_acx;
 		if (!h->has_acx) ex = 1;
+		if (!ex) {
+			plan[i] = make_seed_plan(q_codes + q_off[i], (uint32_t)len, q_emac[i], (uint32_t)h->K, h->opt_prefilter_stride);
+			if ((plan[i] >> 8) == 0) ex = 1;           // no word is guaranteed to survive: exhaustive (burst.c:3130-3131 does the same for "bad" queries)
+		}
 		lists[cls][ex].push_back(i);
 		h->st_maxE[cls] = std::max<uint32_t>(h->st_maxE[cls], q_emac[i]);
 	}
 	HIPCHK(hipEventRecord(h->ev[0], h->stream));
 	int rc;
 	if ((rc = upload_queries(h, q_codes, q_off, q_emac, q_six, q_rc, n_q))) return rc;
+	if ((rc = h->plan.reserve((size_t)n_q * 4))) return rc;
+	HIPCHK(hipMemcpy(h->plan.p, plan.data(), (size_t)n_q * 4, hipMemcpyHostToDevice));
 	for (int cls = 0; cls < kNumClasses; ++cls) {
 		const size_t n_pf = lists[cls][0].size(), n_ex = lists[cls][1].size();
 		h->st_npf[cls] = (uint32_t)n_pf; h->st_nex[cls] = (uint32_t)n_ex;
@@ -654,6 +692,12 @@ extern "C" int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64
 	for (int attempt = 0; attempt < 4; ++attempt) {
 		int rc;
 		if ((rc = upload_queries(h, q_codes, q_off, q_emac, nullptr, nullptr, n_q))) return rc;
+		{
+			std::vector<uint32_t> plan(n_q, 1u);
+			for (uint32_t i = 0; i < n_q; ++i) plan[i] = make_seed_plan(q_codes + q_off[i], (uint32_t)(q_off[i + 1] - q_off[i]), q_emac[i], (uint32_t)h->K, h->opt_prefilter_stride);
+			if ((rc = h->plan.reserve((size_t)n_q * 4))) return rc;
+			HIPCHK(hipMemcpy(h->plan.p, plan.data(), (size_t)n_q * 4, hipMemcpyHostToDevice));
+		}
 		if ((rc = h->cand.reserve(h->cand_cap * sizeof(uint2)))) return rc;
 		if ((rc = h->candcnt.reserve(h->cand_cap * sizeof(uint32_t)))) return rc;
 		HIPCHK(hipMemsetAsync(h->counters.p, 0, sizeof(Counters), h->stream));

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void k_prefilter(
 		const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, int K, uint32_t n_clumps,
 		uint32_t *__restrict__ g_cnt, const uint32_t *__restrict__ bad, uint32_t n_bad,
 		uint2 *__restrict__ cand, uint32_t *__restrict__ cand_cnt_out, uint32_t *__restrict__ n_cand, uint32_t cand_cap,
-		unsigned long long *__restrict__ ent_read, const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel_dev) {
+		unsigned long long *__restrict__ ent_read, const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel_dev,
+		const uint32_t *__restrict__ plan) {   // plan made with stride 1 for this kernel
 	extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];
 	const uint32_t nw32 = (n_clumps + 1) >> 1;
 	uint32_t *cnt = LDS_CNT ? s_cnt : g_cnt + (uint64_t)blockIdx.x * nw32;
@@ -148,7 +149,8 @@ __global__ __launch_bounds__(256) void k_prefilter(
 			}
 		}
 		__syncthreads();
-		const uint32_t kload = E * K + K, mmatch = kload < len ? len - kload : 0;
+		const uint32_t need1 = plan ? plan[q] >> 8 : 0u;
+		const uint32_t kload = E * K + K, mmatch = plan ? (need1 ? need1 - 1 : 0u) : (kload < len ? len - kload : 0);
 		for (uint32_t c = tid; c < n_clumps; c += 256) {
 			const uint32_t v = (cnt[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu;
 			if (v > mmatch) {
@@ -167,10 +169,10 @@ __global__ __launch_bounds__(256) void k_prefilter(
 
 template __global__ void k_prefilter<true>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
 	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *,
-	const uint32_t *, const uint32_t *);
+	const uint32_t *, const uint32_t *, const uint32_t *);
 template __global__ void k_prefilter<false>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
 	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *,
-	const uint32_t *, const uint32_t *);
+	const uint32_t *, const uint32_t *, const uint32_t *);
 
 
 // ------------------------------------------------------------------------------------------------
@@ -183,19 +185,12 @@ template __global__ void k_prefilter<false>(const uint8_t *, const uint64_t *, c
 //   * candidates are staged in LDS and flushed with ONE global atomic per flush instead of one returning atomic per
 //     candidate (2.2 M same-address atomics per launch saturated the L2 atomic unit at ~90/us).
 // ------------------------------------------------------------------------------------------------
-// Seed plan of one query: sample word starts 0, s, 2s, ... <= len-K.  One edit destroys at most ceil(K/s) sampled
-// words, so an alignment with <= E edits keeps need(s) = W_s - E*ceil(K/s) of the W_s = (len-K)/s + 1 sampled words.
-// s = 1 is the reference's scheme (need = len-K+1-E*K = mmatch+1, burst.c:4091-4092).  stride_opt > 0 forces s; 0 picks
-// the largest s <= K that still guarantees >= 3 words (fewest list look-ups, same no-false-negative guarantee).
-__device__ __host__ inline void bhip_seed_plan(uint32_t len, uint32_t E, uint32_t K, int stride_opt, uint32_t &stride, uint32_t &need) {
-	auto need_of = [&](uint32_t s) -> int { return (int)((len - K) / s + 1) - (int)(E * ((K + s - 1) / s)); };
-	uint32_t s = 1;
-	if (stride_opt > 0) s = (uint32_t)stride_opt;
-	else for (uint32_t t = K; t >= 1; --t) if (need_of(t) >= 3) { s = t; break; }
-	const int n = need_of(s);
-	stride = s; need = n > 0 ? (uint32_t)n : 0u;
-}
-
+// Seed plan of one query (made on the host at staging time, bhip_api.hip make_seed_plan): word starts 0, s, 2s, ... <= len-K
+// are sampled; words containing a symbol outside A/C/G/T are skipped (storeAmbigWords expansion, burst.c:3232-3236, is
+// not needed: a skipped word simply does not vote).  One edit destroys at most ceil(K/s) sampled words, so an alignment
+// with <= E edits keeps need = W_valid - E*ceil(K/s) of them.  s = 1 with no ambiguity is the reference's scheme
+// (need = len-K+1-E*K = mmatch+1, burst.c:4091-4092).  plan[q] = stride | need << 8; queries with need < 1 never reach
+// these kernels (the host routes them to the exhaustive path).
 #define PF2_TL 1536u      // touched-list capacity (clump ids, u32)
 #define PF2_STAGE 512u    // staged candidates (uint2)
 template <typename CNT>
@@ -205,7 +200,7 @@ __global__ __launch_bounds__(64) void k_prefilter_wave(
 		const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, int K, uint32_t n_clumps,
 		const uint32_t *__restrict__ bad, uint32_t n_bad,
 		uint2 *__restrict__ cand, uint32_t *__restrict__ cand_cnt_out, uint32_t *__restrict__ n_cand, uint32_t cand_cap,
-		unsigned long long *__restrict__ ent_read, int stride_opt,
+		unsigned long long *__restrict__ ent_read, const uint32_t *__restrict__ plan,
 		const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel_dev) {   // optional: only list positions sel[0..*n_sel_dev)
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	constexpr uint32_t PER = 4 / sizeof(CNT), BITS = 8 * sizeof(CNT), MASK = (1u << BITS) - 1u;
@@ -258,9 +253,9 @@ __global__ __launch_bounds__(64) void k_prefilter_wave(
 		const uint32_t q = qlist ? qlist[li] : li;
 		const uint64_t b = qoff[q];
 		const uint32_t len = (uint32_t)(qoff[q + 1] - b), E = qemac[q];
-		uint32_t stride = 1, need = 0;
+		const uint32_t stride = plan[q] & 255u, need = plan[q] >> 8;
+		(void)E;
 		if (len >= (uint32_t)K) {
-			bhip_seed_plan(len, E, (uint32_t)K, stride_opt, stride, need);
 			const uint32_t nwords = (len - K) / stride + 1;
 			for (uint32_t base = 0; base < nwords; base += 64) {
 				const uint32_t j = base + lane, p = j * stride;
@@ -320,10 +315,10 @@ __global__ __launch_bounds__(64) void k_prefilter_wave(
 	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
 }
 template __global__ void k_prefilter_wave<uint8_t>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, int,
+	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *,
 	const uint32_t *, const uint32_t *);
 template __global__ void k_prefilter_wave<uint16_t>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, int,
+	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *,
 	const uint32_t *, const uint32_t *);
 
 // ------------------------------------------------------------------------------------------------
@@ -343,7 +338,7 @@ __global__ __launch_bounds__(64) void k_prefilter_hash(
 		const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, int K,
 		const uint32_t *__restrict__ bad, uint32_t n_bad,
 		uint2 *__restrict__ cand, uint32_t *__restrict__ cand_cnt_out, uint32_t *__restrict__ n_cand, uint32_t cand_cap,
-		unsigned long long *__restrict__ ent_read, int stride_opt,
+		unsigned long long *__restrict__ ent_read, const uint32_t *__restrict__ plan,
 		uint32_t *__restrict__ fb_list, uint32_t *__restrict__ n_fb) {
 	__shared__ uint32_t s_tab[4][PFH_HT];
 	__shared__ uint16_t s_tl[4][PFH_TL];
@@ -404,21 +399,15 @@ __global__ __launch_bounds__(64) void k_prefilter_hash(
 	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
 		const uint32_t li = quad * 4 + g;
 		const bool live = li < n_list;
-		uint32_t q = 0, len = 0, E = 0, stride = 1, need = 0, nwords = 0;
+		uint32_t q = 0, len = 0, stride = 1, need = 0, nwords = 0;
 		uint64_t b = 0;
 		if (live) {
 			q = qlist ? qlist[li] : li;
 			b = qoff[q];
-			len = (uint32_t)(qoff[q + 1] - b); E = qemac[q];
+			len = (uint32_t)(qoff[q + 1] - b);
 			if (len >= (uint32_t)K) {
-				bhip_seed_plan(len, E, (uint32_t)K, stride_opt, stride, need);
+				stride = plan[q] & 255u; need = plan[q] >> 8;      // the host keeps (len-K)/stride + 1 <= 255 (8-bit counts)
 				nwords = (len - K) / stride + 1;
-				if (nwords > 255) {   // keep every count within the 8-bit field: coarser stride, guarantee recomputed
-					stride = (len - K) / 254 + 1;
-					const int nd = (int)((len - K) / stride + 1) - (int)(E * (((uint32_t)K + stride - 1) / stride));
-					need = nd > 0 ? (uint32_t)nd : 0u;
-					nwords = (len - K) / stride + 1;
-				}
 			}
 		}
 		uint32_t maxw = nwords;

@@ -168,8 +168,9 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 		}
 	}
 	/* accelerator bins (burst.c:3124-3141): bad = too short / too many errors for the k-mer guarantee / > 5 strongly
-	 * ambiguous symbols; ambiguous = any symbol beyond A/C/G/T.  Only clear entries use the device prefilter; the other
-	 * two bins take the exhaustive route (the reference sends bad ones there too, burst.c:4320). */
+	 * ambiguous symbols; ambiguous = any symbol beyond A/C/G/T.  Clear and ambiguous entries use the device prefilter
+	 * (words with ambiguous symbols simply do not vote there and the guaranteed count shrinks accordingly; the library
+	 * falls back to the exhaustive route by itself when no word is guaranteed); bad ones are exhaustive (burst.c:4320). */
 	uint64_t nClear = 0, nAmbig = 0, nBad = 0;
 	for (uint64_t e = 0; e < numEntries; ++e) {
 		if (!do_accel) { Q->flags[e] = BHIP_Q_EXHAUSTIVE; continue; }
@@ -184,7 +185,7 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 				else if (s[j] > 4) stat = 0;
 			}
 		}
-		Q->flags[e] = stat == 1 ? BHIP_Q_PREFILTER : BHIP_Q_EXHAUSTIVE;
+		Q->flags[e] = stat == 2 ? BHIP_Q_EXHAUSTIVE : BHIP_Q_PREFILTER;
 		if (stat == 1) ++nClear; else if (stat == 0) ++nAmbig; else ++nBad;
 	}
 	Q->totQ = totQ; Q->numUniq = numUniq; Q->numEntries = numEntries;

@@ -187,3 +187,26 @@ def test_align_batch_with_accelerator_equals_exhaustive(all_hits):
     st = dev.stats()
     assert st["n_pairs"] < q.n * nc          # the prefilter really pruned
     dev.close()
+
+
+@pytest.mark.parametrize("thres,iupac", [(0.97, 0.02), (0.94, 0.04)])
+def test_ambiguous_queries_through_the_prefilter(thres, iupac):
+    """queries with IUPAC codes / N take the accelerated route: words containing them do not vote and the guaranteed
+    count shrinks; entries left without any guaranteed word are aligned exhaustively by the library itself"""
+    from burst_amd import capi
+    K = 12
+    seqs = family_db(91, 14, 9, 480, iupac=0.003)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lens, entries, offs = dbutil.build_acx(seqs, K)
+    lists = dbutil.pack_acx_lists(lens, entries, 0)
+    lut = ol.score_lut(1)
+    dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=lists, acx_fmt=0, K=K)
+    q, allq = make_queries(seqs, 80, 100, [0, 1, 2, 3], 93, iupac=iupac, thres=thres)
+    assert sum(int((np.asarray(r) > 4).any()) for r in allq) > 20
+    q.flags = np.zeros(q.n, np.uint8)
+    for all_hits in (False, True):
+        got = dev.align_batch(q, all_hits=all_hits)
+        exp = oracle_hits(packed, clump_len, tot, q, lut, all_hits)
+        assert len(exp) > 20
+        assert_hits_equal(got, exp)
+    dev.close()
