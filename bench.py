@@ -37,7 +37,8 @@ def build_inputs(workdir, args, rank, world):
     """rank 0 writes the shared database; every rank writes its own reads"""
     from burst_amd import host
     os.makedirs(workdir, exist_ok=True)
-    tag = "b%d_v%d_l%d" % (args.n_base, args.n_variants, args.ref_len)
+    args.db_qlen = args.read_len + max(10, args.read_len // 10)
+    tag = "b%d_v%d_l%d_q%d_i%s" % (args.n_base, args.n_variants, args.ref_len, args.db_qlen, args.id)
     refs = os.path.join(workdir, "refs_%s.fa" % tag)
     edx = os.path.join(workdir, "db_%s.edx" % tag)
     acx = os.path.join(workdir, "db_%s.acx" % tag)
@@ -45,8 +46,8 @@ def build_inputs(workdir, args, rank, world):
     if rank == 0 and not os.path.exists(done):
         t = time.time()
         host.synth_refs(refs, args.n_base, args.n_variants, args.ref_len, args.variant_rate, 7)
-        db = host.Db.from_fasta(refs, 110, args.id, shear_len=500, K=12)
-        db.write(edx, acx, db_qlen=110, thres=args.id)
+        db = host.Db.from_fasta(refs, args.db_qlen, args.id, shear_len=500, K=12)
+        db.write(edx, acx, db_qlen=args.db_qlen, thres=args.id)
         db.close()
         open(done, "w").write("ok")
         log("[bench] database built in %.1f s" % (time.time() - t))
@@ -68,8 +69,8 @@ def cpu_baseline(edx, acx, reads_fa, args):
             for _ in range(2 * n):
                 o.write(f.readline())
         t = time.time()
-        r = subprocess.run([exe, "-r", edx, "-a", acx, "-q", sample, "-o", sample + ".b6", "-m", "CAPITALIST", "-i", str(args.id),
-                            "-t", str(cores), "--noprogress"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        r = subprocess.run([exe, "-r", edx, "-a", acx, "-q", sample, "-o", sample + ".b6", "-m", args.mode, "-i", str(args.id),
+                            "-t", str(cores), "--noprogress"] + (["-fr"] if args.fr else []), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             log("[bench] reference failed:", r.stdout[-400:])
             return None
@@ -77,8 +78,8 @@ def cpu_baseline(edx, acx, reads_fa, args):
     dt = max(times[1] - times[0], 1e-6)
     return {"value": (n2 - n1) / dt, "unit": "reads/s", "cores": cores, "kind": "reference",
             "sample": "oracle/_ref/burst12 (reference compiled with gcc -O3 -march=x86-64-v3 -fopenmp) -t %d, same .edx/.acx, "
-                      "-m CAPITALIST -i %s; differential wall time of the first %d vs %d reads (%.2f s vs %.2f s) to cancel DB load"
-                      % (cores, args.id, n1, n2, times[0], times[1])}
+                      "-m %s -i %s; differential wall time of the first %d vs %d reads (%.2f s vs %.2f s) to cancel DB load"
+                      % (cores, args.mode, args.id, n1, n2, times[0], times[1])}
 
 
 def main():
@@ -97,6 +98,9 @@ def main():
     ap.add_argument("--workdir", default=os.environ.get("BURST_BENCH_DIR", "/tmp/burst_amd_bench"))
     ap.add_argument("--cpu-sample", type=int, default=600000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fr", action="store_true", help="also search reverse complements (-fr)")
+    ap.add_argument("--iupac", type=float, default=0.0, help="fraction of read bases replaced by a compatible IUPAC code")
+    ap.add_argument("--edits", default="0,1,2,3", help="edit counts sampled per read")
     ap.add_argument("--one-stage", action="store_true", help="disable the prefix-filter stage of the edit-distance kernels")
     ap.add_argument("--prefilter-stride", type=int, default=0, help="0 = automatic sparse seeds (default), 1 = every word (reference scheme)")
     args = ap.parse_args()
@@ -117,13 +121,14 @@ def main():
         dist.barrier()
     while not os.path.exists(done):
         time.sleep(0.2)
-    reads_fa = os.path.join(args.workdir, "reads_%d_r%d.fa" % (args.reads, rank))
+    edits = [int(x) for x in args.edits.split(",")]
+    reads_fa = os.path.join(args.workdir, "reads_%d_l%d_e%s_u%s_f%d_r%d.fa" % (args.reads, args.read_len, "-".join(map(str, edits)), args.iupac, int(args.fr), rank))
     if not os.path.exists(reads_fa):
-        host.synth_reads(refs, reads_fa, args.reads, args.read_len, [0, 1, 2, 3], rc=False, seed=42 + rank)
+        host.synth_reads(refs, reads_fa, args.reads, args.read_len, edits, rc=args.fr, iupac=args.iupac, seed=42 + rank)
 
     t = time.time()
     db = host.Db.read(edx, acx, K=12)
-    qs = host.QuerySet(reads_fa, args.id, rc=False, accel=True, K=12)
+    qs = host.QuerySet(reads_fa, args.id, rc=args.fr, accel=True, K=12)
     dev = db.open_device(local_rank)
     dev.set_option("prefilter_stride", args.prefilter_stride)
     dev.set_option("two_stage", 0 if args.one_stage else 1)

@@ -306,7 +306,7 @@ static void launch_prefix(Handle *h, int NWP, uint32_t grid, const uint2 *pairs,
 	#define LP(N) hipLaunchKernelGGL(k_myers_prefix<N>, dim3(grid), dim3(256), 0, h->stream, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist, \
 		h->peqp.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
 		h->tot_refs, h->wins.as<BhipWin>(), n_wins, (uint32_t)h->win_cap, &dc->col_sum, &dc->qlen_sum)
-	if (NWP == 1) LP(1); else if (NWP == 2) LP(2); else LP(3);
+	if (NWP == 1) LP(1); else if (NWP == 2) LP(2); else if (NWP == 3) LP(3); else if (NWP == 4) LP(4); else LP(6);
 	#undef LP
 }
 static void launch_window(Handle *h, int cls, int NWP, uint32_t grid, const uint32_t *qlist, const uint32_t *n_wins, Counters *dc) {
@@ -481,7 +481,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		if ((rc = h->scratch.reserve(h->scratch_cap * sizeof(uint32_t)))) return rc;
 		if ((rc = h->wins.reserve(h->win_cap * sizeof(BhipWin)))) return rc;
 		for (int cls = 0; cls < kNumClasses; ++cls) if (h->st_npf[cls] + h->st_nex[cls]) {
-			if ((rc = h->peqp.reserve((size_t)(h->st_npf[cls] + h->st_nex[cls]) * 16 * 3 * 4))) return rc;
+			if ((rc = h->peqp.reserve((size_t)(h->st_npf[cls] + h->st_nex[cls]) * 16 * 6 * 4))) return rc;
 		}
 		for (int cls = 0; cls < kNumClasses; ++cls) if (h->st_npf[cls] + h->st_nex[cls])
 			if ((rc = h->peq.reserve((size_t)(h->st_npf[cls] + h->st_nex[cls]) * 16 * kClasses[cls] * 4))) return rc;
@@ -508,7 +508,11 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			}
 			// two-stage edit distance when a prefix of 32*NWP symbols is selective for this class's budgets
 			int NWP = 0;
-			if (h->opt_two_stage) { const uint32_t mE = h->st_maxE[cls]; NWP = mE <= 5 ? 1 : (mE <= 10 ? 2 : (mE <= 16 ? 3 : 0)); if (NWP >= NW) NWP = 0; }
+			if (h->opt_two_stage) {   // prefix of about 6 symbols per allowed edit, in words; must be shorter than the query vector to pay
+				const uint32_t mE = h->st_maxE[cls], want = (6 * mE + 31) / 32;
+				NWP = want <= 1 ? 1 : (want <= 2 ? 2 : (want <= 3 ? 3 : (want <= 4 ? 4 : (want <= 6 ? 6 : 0))));
+				if (NWP >= NW) NWP = 0;
+			}
 			if (NWP) {
 				const uint64_t total = (uint64_t)n_list * NWP;
 				const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16);

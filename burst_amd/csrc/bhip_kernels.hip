@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256) void k_myers_window(
 	template __global__ void k_myers_prefix<NWP>(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *, \
 		const uint64_t *, const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t, BhipWin *, uint32_t *, uint32_t, \
 		unsigned long long *, unsigned long long *);
-BHIP_INST_PREFIX(1) BHIP_INST_PREFIX(2) BHIP_INST_PREFIX(3)
+BHIP_INST_PREFIX(1) BHIP_INST_PREFIX(2) BHIP_INST_PREFIX(3) BHIP_INST_PREFIX(4) BHIP_INST_PREFIX(6)
 #define BHIP_INST_WINDOW(NW) \
 	template __global__ void k_myers_window<NW>(const BhipWin *, const uint32_t *, uint32_t, int, const uint32_t *, const uint32_t *, const uint64_t *, \
 		const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *, \

@@ -185,7 +185,10 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 				else if (s[j] > 4) stat = 0;
 			}
 		}
-		Q->flags[e] = stat == 2 ? BHIP_Q_EXHAUSTIVE : BHIP_Q_PREFILTER;
+		/* the reference demotes every "bad" entry to the exhaustive path because its word expansion explodes (burst.c:3134);
+		 * on the device only entries shorter than K must go there -- for the rest libburst_hip works out per entry whether
+		 * any k-mer is still guaranteed (and aligns exhaustively by itself if not), with identical results */
+		Q->flags[e] = len < (uint32_t)K ? BHIP_Q_EXHAUSTIVE : BHIP_Q_PREFILTER;
 		if (stat == 1) ++nClear; else if (stat == 0) ++nAmbig; else ++nBad;
 	}
 	Q->totQ = totQ; Q->numUniq = numUniq; Q->numEntries = numEntries;
