@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--iupac", type=float, default=0.0, help="fraction of read bases replaced by a compatible IUPAC code")
     ap.add_argument("--edits", default="0,1,2,3", help="edit counts sampled per read")
     ap.add_argument("--one-stage", action="store_true", help="disable the prefix-filter stage of the edit-distance kernels")
+    ap.add_argument("--lanes", type=int, default=6, help="sub-pipelines (HIP streams) per batch inside the library")
+    ap.add_argument("--sweep-blocks", type=int, default=0, help="256-thread blocks per CU for the column sweep (0 = library default)")
     ap.add_argument("--prefilter-stride", type=int, default=0, help="0 = automatic sparse seeds (default), 1 = every word (reference scheme)")
     args = ap.parse_args()
 
@@ -132,6 +134,9 @@ def main():
     dev = db.open_device(local_rank)
     dev.set_option("prefilter_stride", args.prefilter_stride)
     dev.set_option("two_stage", 0 if args.one_stage else 1)
+    dev.set_option("lanes", args.lanes)
+    if args.sweep_blocks:
+        dev.set_option("sweep_blocks", args.sweep_blocks)
     info = dev.info()
     q = qs.batch()
     dev.stage(q)
@@ -152,6 +157,7 @@ def main():
         g = gather_hits(hits)
         return hits, g
 
+    step()          # sizes the library's grow-only device buffers for this workload (setup, not a warmup step)
     for _ in range(args.warmup):
         step()
     per_step = []

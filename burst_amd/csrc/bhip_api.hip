@@ -94,11 +94,33 @@ struct Counters {
 	unsigned long long col_sum, qlen_sum, ent_read, scratch_used;
 };
 
+// One independent sub-pipeline of a staged batch: its own stream and scratch, a contiguous range of shared slots
+// (so a forward entry and its reverse-complement twin are always in the same lane and `best[six]` is final when the
+// lane's re-scorer runs).  Lanes overlap each other's latency-bound kernels (prefilter, window, re-scorer) with the
+// VALU-bound column sweep, which itself is serialised on one dedicated stream (Handle::sweep_stream).
+struct Lane {
+	hipStream_t stream = nullptr;
+	hipEvent_t ev_cls[kNumClasses][8];   // per class: 0 start, 1 peq done, 2 prefilter done, 3 sweep(pf) done, 4 sweep(ex) done, 5 window done
+	hipEvent_t ev_rs[2];
+	DBuf qlist_cls[kNumClasses], peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters;
+	uint64_t cand_cap = 1 << 18, raw_cap = 1 << 18, win_cap = 1 << 20, scratch_cap = 1 << 18;
+	uint32_t npf[kNumClasses] = {0}, nex[kNumClasses] = {0}, maxE[kNumClasses] = {0}, maxlen = 0, n_entries = 0;
+	Counters *hc_pinned = nullptr;        // pinned, so that the read-back of the counters does not block the enqueueing thread
+	Counters hc;
+	uint32_t launches = 0, prefix_words = 0;
+	uint64_t n_pairs_ex = 0;
+};
+
 struct Handle {
 	int device = 0, n_cu = 0;
 	char dev_name[256];
 	uint64_t hbm = 0;
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr;         // staging, sort, copies
+	// software pipeline over lanes: stage streams run the same stage of consecutive lanes back to back, so that lane k+1's
+	// prefilter and lane k-1's window/re-scoring overlap lane k's column sweep
+	hipStream_t pf_stream = nullptr;      // peq + prefilter of every lane, in lane order
+	hipStream_t sweep_stream = nullptr;   // every k_myers_prefix / k_myers launch, in lane order
+	hipStream_t post_stream = nullptr;    // window stage + re-scorer + counter read-back, in lane order
 	hipEvent_t ev[10];
 	// database
 	uint32_t n_clumps = 0, tot_refs = 0, max_clump_len = 0;
@@ -106,44 +128,78 @@ struct Handle {
 	BhipMatchMask mm;
 	bool has_acx = false; int K = 0;
 	DBuf acx_off, acx_ent, bad; uint32_t n_bad = 0; uint64_t n_ent = 0;
-	// batch buffers
-	DBuf qcodes, qoff, qemac, qsix, qrc, qlist, peq, cand, candcnt, raw, best, out, wide, scratch, gcnt, counters, mins, pairs;
-	DBuf sort_keys, sort_keys2, sort_idx, sort_idx2, sort_tmp, out_sorted, peqp, wins, fb_list, qpack, plan;
-	uint64_t win_cap = 1 << 22;
-	uint64_t cand_cap = 1 << 20, raw_cap = 1 << 20, out_cap = 1 << 20, scratch_cap = 1 << 20;
+	// batch-wide buffers
+	DBuf qcodes, qoff, qemac, qsix, qrc, best, out, shared_ctr, mins, pairs;
+	DBuf sort_keys, sort_keys2, sort_idx, sort_idx2, sort_tmp, out_sorted, qpack, plan;
+	uint64_t out_cap = 1 << 20;
 	std::vector<uint32_t> h_clump_len;
 	BhipStats stats;
+	std::vector<Lane *> lanes;
 	// staged batch (bhip_stage_queries)
 	bool st_valid = false, st_has_six = false, st_has_rc = false;
-	uint32_t st_nq = 0, st_nshared = 0, st_npf[kNumClasses] = {0}, st_nex[kNumClasses] = {0}, st_maxE[kNumClasses] = {0};
-	int opt_two_stage = 1;        // 1 = prefix filter + windowed full-length stage when it pays, 0 = always the one-stage sweep
+	uint32_t st_nq = 0, st_nshared = 0, st_maxlen = 0, st_maxE = 0, st_lanes = 1;
 	float st_ms_h2d = 0;
-	uint32_t st_maxlen_pf = 0;   // longest query of the uploaded batch
+	int opt_two_stage = 1;        // 1 = prefix filter + windowed full-length stage when it pays, 0 = always the one-stage sweep
 	int opt_prefilter_stride = 0; // 0 = automatic sparse seeds, s > 0 = every s-th word (1 = the reference's scheme)
-	DBuf qlist_cls[kNumClasses];
-	hipEvent_t ev_cls[kNumClasses][8];
+	int opt_lanes = 6;            // sub-pipelines per batch (1 = everything in order on one stream)
+	int opt_sweep_blocks = 8;     // 256-thread blocks per CU of the column-sweep kernels
 };
+struct SharedCtr { uint32_t n_out, err; };
 
 static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 
 extern "C" const char *bhip_last_error(void) { return g_err; }
 extern "C" int bhip_abi_version(void) { return BHIP_ABI_VERSION; }
 
+static void lane_destroy(Lane *L) {
+	if (!L) return;
+	if (L->stream) (void)hipStreamSynchronize(L->stream);
+	DBuf *all[] = {&L->peq, &L->peqp, &L->cand, &L->candcnt, &L->wins, &L->raw, &L->wide, &L->scratch, &L->fb_list, &L->gcnt, &L->counters};
+	for (DBuf *b : all) b->release();
+	for (auto &b : L->qlist_cls) b.release();
+	for (auto &ce : L->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
+	for (auto &e : L->ev_rs) if (e) (void)hipEventDestroy(e);
+	if (L->stream) (void)hipStreamDestroy(L->stream);
+	if (L->hc_pinned) (void)hipHostFree(L->hc_pinned);
+	delete L;
+}
+
+static int lane_create(Handle *h, Lane **out) {
+	Lane *L = new Lane();
+	memset(L->ev_cls, 0, sizeof L->ev_cls); memset(L->ev_rs, 0, sizeof L->ev_rs);
+	if (hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipStreamCreate failed"); }
+	for (auto &ce : L->ev_cls) for (auto &e : ce) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
+	for (auto &e : L->ev_rs) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
+	int rc = L->counters.reserve(sizeof(Counters));
+	if (rc) { lane_destroy(L); return rc; }
+	if (hipHostMalloc((void **)&L->hc_pinned, sizeof(Counters), hipHostMallocDefault) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipHostMalloc failed"); }
+	(void)h;
+	*out = L;
+	return 0;
+}
+
 extern "C" void bhip_destroy(void *handle) {
 	Handle *h = (Handle *)handle;
 	if (!h) return;
 	(void)hipSetDevice(h->device);
 	if (h->stream) (void)hipStreamSynchronize(h->stream);
+	if (h->sweep_stream) (void)hipStreamSynchronize(h->sweep_stream);
+	if (h->pf_stream) (void)hipStreamSynchronize(h->pf_stream);
+	if (h->post_stream) (void)hipStreamSynchronize(h->post_stream);
+	for (Lane *L : h->lanes) lane_destroy(L);
 	DBuf *all[] = {&h->ref, &h->ref_off, &h->clump_len, &h->lut, &h->acx_off, &h->acx_ent, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
-		&h->qsix, &h->qrc, &h->qlist, &h->peq, &h->cand, &h->candcnt, &h->raw, &h->best, &h->out, &h->wide, &h->scratch, &h->gcnt,
-		&h->counters, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx, &h->sort_idx2, &h->sort_tmp, &h->out_sorted, &h->peqp, &h->wins, &h->fb_list, &h->qpack, &h->plan};
+		&h->qsix, &h->qrc, &h->best, &h->out, &h->shared_ctr, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx, &h->sort_idx2,
+		&h->sort_tmp, &h->out_sorted, &h->qpack, &h->plan};
 	for (DBuf *b : all) b->release();
 	for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
-	for (auto &ce : h->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
-	for (auto &b : h->qlist_cls) b.release();
 	if (h->stream) (void)hipStreamDestroy(h->stream);
+	if (h->sweep_stream) (void)hipStreamDestroy(h->sweep_stream);
+	if (h->pf_stream) (void)hipStreamDestroy(h->pf_stream);
+	if (h->post_stream) (void)hipStreamDestroy(h->post_stream);
 	delete h;
 }
+
+static int ensure_lanes(Handle *h, uint32_t n);
 
 extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clump_len, uint32_t n_clumps, uint32_t tot_refs,
                          const uint32_t *acx_lens, const void *acx_lists, int acx_fmt, int K,
@@ -160,7 +216,6 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 	HIPCHK(hipSetDevice(device));
 	Handle *h = new Handle();
 	memset(h->ev, 0, sizeof h->ev);
-	memset(h->ev_cls, 0, sizeof h->ev_cls);
 	memset(&h->stats, 0, sizeof h->stats);
 	h->device = device;
 	hipDeviceProp_t prop;
@@ -173,8 +228,10 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); bhip_destroy(h); return BHIP_E_DEVICE; } } while (0)
 	#define INITRC(x) do { int rc_ = (x); if (rc_) { bhip_destroy(h); return rc_; } } while (0)
 	INITCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+	INITCHK(hipStreamCreateWithFlags(&h->sweep_stream, hipStreamNonBlocking));
+	INITCHK(hipStreamCreateWithFlags(&h->pf_stream, hipStreamNonBlocking));
+	INITCHK(hipStreamCreateWithFlags(&h->post_stream, hipStreamNonBlocking));
 	for (auto &e : h->ev) INITCHK(hipEventCreate(&e));
-	for (auto &ce : h->ev_cls) for (auto &e : ce) INITCHK(hipEventCreate(&e));
 	h->n_clumps = n_clumps; h->tot_refs = tot_refs;
 	h->h_clump_len.assign(clump_len, clump_len + n_clumps);
 	for (int a = 0; a < 16; ++a) {
@@ -247,10 +304,11 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		}
 		h->has_acx = true; h->K = K; h->n_ent = tot;
 	}
-	INITRC(h->counters.reserve(sizeof(Counters)));
+	INITRC(ensure_lanes(h, 1));
 	*handle = h;
 	return BHIP_OK;
 }
+
 
 extern "C" int bhip_device_info(void *handle, char *name, int name_cap, int *n_cu, uint64_t *hbm_bytes) {
 	Handle *h = (Handle *)handle;
@@ -269,6 +327,11 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 		h->opt_prefilter_stride = (int)value; return BHIP_OK;
 	}
 	if (!strcmp(name, "two_stage")) { h->opt_two_stage = value != 0; return BHIP_OK; }
+	if (!strcmp(name, "sweep_blocks")) { if (value < 1 || value > 8) return fail(BHIP_E_ARG, "sweep_blocks must be 1 .. 8"); h->opt_sweep_blocks = (int)value; return BHIP_OK; }
+	if (!strcmp(name, "lanes")) {
+		if (value < 1 || value > 16) return fail(BHIP_E_ARG, "lanes must be 1 .. 16");
+		h->opt_lanes = (int)value; h->st_valid = false; return BHIP_OK;
+	}
 	return fail(BHIP_E_ARG, "unknown option '%s'", name);
 }
 
@@ -279,40 +342,29 @@ extern "C" int bhip_get_stats(void *handle, BhipStats *out) {
 	return BHIP_OK;
 }
 
-template <int NW> static void launch_myers_t(Handle *h, uint32_t grid, const uint2 *pairs, const uint32_t *n_pairs_dev, uint64_t n_pairs_host,
-		uint32_t li_base, const uint32_t *qlist, BhipRawHit *raw, uint32_t *n_raw, uint32_t raw_cap, uint32_t *best, uint8_t *mins,
-		Counters *dc) {
-	hipLaunchKernelGGL(k_myers<NW>, dim3(grid), dim3(256), 0, h->stream, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist,
-		h->peq.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), best ? h->qsix.as<uint32_t>() : nullptr,
-		h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->tot_refs,
-		raw, n_raw, raw_cap, best, mins, &dc->col_sum, &dc->qlen_sum);
+// ---- kernel launch helpers (st = stream to launch on) ---------------------------------------------------------------
+static void launch_myers(Handle *h, Lane *L, hipStream_t st, int cls, uint32_t grid, const uint2 *pairs, const uint32_t *n_pairs_dev,
+		uint64_t n_pairs_host, uint32_t li_base, const uint32_t *qlist, BhipRawHit *raw, uint32_t *n_raw, uint32_t raw_cap, uint32_t *best,
+		uint8_t *mins, Counters *dc) {
+	#define LM(N) hipLaunchKernelGGL(k_myers<N>, dim3(grid), dim3(256), 0, st, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist, \
+		L->peq.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), (best && h->st_has_six) ? h->qsix.as<uint32_t>() : nullptr, \
+		h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->tot_refs, raw, n_raw, raw_cap, best, mins, &dc->col_sum, &dc->qlen_sum)
+	switch (kClasses[cls]) { case 2: LM(2); break; case 4: LM(4); break; case 6: LM(6); break; case 8: LM(8); break; case 10: LM(10); break;
+		case 16: LM(16); break; default: LM(32); break; }
+	#undef LM
 }
-static void launch_myers(Handle *h, int cls, uint32_t grid, const uint2 *pairs, const uint32_t *n_pairs_dev, uint64_t n_pairs_host,
-		uint32_t li_base, const uint32_t *qlist, BhipRawHit *raw, uint32_t *n_raw, uint32_t raw_cap, uint32_t *best, uint8_t *mins,
-		Counters *dc) {
-	switch (kClasses[cls]) {
-	case 2:  launch_myers_t<2>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
-	case 4:  launch_myers_t<4>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
-	case 6:  launch_myers_t<6>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
-	case 8:  launch_myers_t<8>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
-	case 10: launch_myers_t<10>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
-	case 16: launch_myers_t<16>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
-	default: launch_myers_t<32>(h, grid, pairs, n_pairs_dev, n_pairs_host, li_base, qlist, raw, n_raw, raw_cap, best, mins, dc); break;
-	}
-}
-
-static void launch_prefix(Handle *h, int NWP, uint32_t grid, const uint2 *pairs, const uint32_t *n_pairs_dev, uint64_t n_pairs_host,
-		uint32_t li_base, const uint32_t *qlist, uint32_t *n_wins, Counters *dc) {
-	#define LP(N) hipLaunchKernelGGL(k_myers_prefix<N>, dim3(grid), dim3(256), 0, h->stream, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist, \
-		h->peqp.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
-		h->tot_refs, h->wins.as<BhipWin>(), n_wins, (uint32_t)h->win_cap, &dc->col_sum, &dc->qlen_sum)
+static void launch_prefix(Handle *h, Lane *L, hipStream_t st, int NWP, uint32_t grid, const uint2 *pairs, const uint32_t *n_pairs_dev,
+		uint64_t n_pairs_host, uint32_t li_base, const uint32_t *qlist, uint32_t *n_wins, Counters *dc) {
+	#define LP(N) hipLaunchKernelGGL(k_myers_prefix<N>, dim3(grid), dim3(256), 0, st, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist, \
+		L->peqp.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
+		h->tot_refs, L->wins.as<BhipWin>(), n_wins, (uint32_t)L->win_cap, &dc->col_sum, &dc->qlen_sum)
 	if (NWP == 1) LP(1); else if (NWP == 2) LP(2); else if (NWP == 3) LP(3); else if (NWP == 4) LP(4); else LP(6);
 	#undef LP
 }
-static void launch_window(Handle *h, int cls, int NWP, uint32_t grid, const uint32_t *qlist, const uint32_t *n_wins, Counters *dc) {
-	#define LW(N) hipLaunchKernelGGL(k_myers_window<N>, dim3(grid), dim3(256), 0, h->stream, h->wins.as<BhipWin>(), n_wins, (uint32_t)h->win_cap, NWP, qlist, \
-		h->peq.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->ref.as<uint4>(), \
-		h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)h->raw_cap, h->best.as<uint32_t>(), &dc->wcol_sum)
+static void launch_window(Handle *h, Lane *L, hipStream_t wst, int cls, int NWP, uint32_t grid, const uint32_t *qlist, const uint32_t *n_wins, Counters *dc) {
+	#define LW(N) hipLaunchKernelGGL(k_myers_window<N>, dim3(grid), dim3(256), 0, wst, L->wins.as<BhipWin>(), n_wins, (uint32_t)L->win_cap, NWP, qlist, \
+		L->peq.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->ref.as<uint4>(), \
+		h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), &dc->wcol_sum)
 	switch (kClasses[cls]) { case 2: LW(2); break; case 4: LW(4); break; case 6: LW(6); break; case 8: LW(8); break; case 10: LW(10); break;
 		case 16: LW(16); break; default: LW(32); break; }
 	#undef LW
@@ -349,12 +401,16 @@ static uint32_t make_seed_plan(const uint8_t *s, uint32_t len, uint32_t E, uint3
 	return (best_s & 255u) | ((uint32_t)best_n << 8);
 }
 
+
 static int upload_queries(Handle *h, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
                           const uint32_t *q_six, const uint8_t *q_rc, uint32_t n_q) {
 	const uint64_t nb = q_off[n_q];
 	int rc;
-	h->st_maxlen_pf = 0;
-	for (uint32_t i = 0; i < n_q; ++i) h->st_maxlen_pf = std::max<uint32_t>(h->st_maxlen_pf, (uint32_t)(q_off[i + 1] - q_off[i]));
+	h->st_maxlen = 0; h->st_maxE = 0;
+	for (uint32_t i = 0; i < n_q; ++i) {
+		h->st_maxlen = std::max<uint32_t>(h->st_maxlen, (uint32_t)(q_off[i + 1] - q_off[i]));
+		h->st_maxE = std::max<uint32_t>(h->st_maxE, q_emac[i]);
+	}
 	if ((rc = h->qcodes.reserve(nb + 16))) return rc;
 	if ((rc = h->qoff.reserve((n_q + 1) * sizeof(uint64_t)))) return rc;
 	if ((rc = h->qemac.reserve((n_q + 1) * sizeof(uint16_t)))) return rc;
@@ -368,45 +424,61 @@ static int upload_queries(Handle *h, const uint8_t *q_codes, const uint64_t *q_o
 	return 0;
 }
 
-static int launch_prefilter(Handle *h, const uint32_t *d_qlist, uint32_t n_list, uint2 *cand, uint32_t *candcnt, uint32_t cand_cap,
+static int upload_plan(Handle *h, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac, uint32_t n_q, std::vector<uint32_t> &plan) {
+	int rc;
+	if ((rc = h->plan.reserve((size_t)n_q * 4 + 16))) return rc;
+	(void)q_codes; (void)q_off; (void)q_emac;
+	HIPCHK(hipMemcpyAsync(h->plan.p, plan.data(), (size_t)n_q * 4, hipMemcpyHostToDevice, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	return 0;
+}
+
+// prefilter of list positions [0, n_list) of `d_qlist` on the lane's stream
+static int launch_prefilter(Handle *h, Lane *L, hipStream_t pf_st, const uint32_t *d_qlist, uint32_t n_list, uint2 *cand, uint32_t *candcnt, uint32_t cand_cap,
                             bool with_bad, uint32_t *n_cand_dev, Counters *dc) {
 	const uint32_t *bad = with_bad ? h->bad.as<uint32_t>() : nullptr;
 	const uint32_t n_bad = with_bad ? h->n_bad : 0;
 	const uint32_t *plan = h->plan.as<uint32_t>();
+	hipStream_t st = pf_st;
 	int rc;
 	// main pass: hashed counters, four queries per wave (any database size)
-	if ((rc = h->fb_list.reserve((size_t)n_list * 4 + 16))) return rc;
-	HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 4, h->stream));
+	if ((rc = L->fb_list.reserve((size_t)n_list * 4 + 16))) return rc;
+	HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 4, st));
 	{
 		const uint32_t n_quads = (n_list + 3) / 4;
 		const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * 6);
-		hipLaunchKernelGGL(k_prefilter_hash, dim3(grid), dim3(64), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(),
+		hipLaunchKernelGGL(k_prefilter_hash, dim3(grid), dim3(64), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(),
 			d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read,
-			plan, h->fb_list.as<uint32_t>(), &dc->n_fb);
+			plan, L->fb_list.as<uint32_t>(), &dc->n_fb);
 		HIPCHK(hipGetLastError());
 	}
 	// fallback pass for the (rare) queries whose table overflowed: dense per-clump counters, LDS if they fit, else global memory
-	const bool narrow = h->st_maxlen_pf < 255u + (uint32_t)h->K;
+	const bool narrow = h->st_maxlen < 255u + (uint32_t)h->K;
 	const size_t lds_w = ((size_t)(h->n_clumps + (narrow ? 3 : 1)) / (narrow ? 4 : 2)) * 4 + 1536u * 4 + 512u * 8 + 512u * 4 + 16;
 	const uint32_t nw32 = (h->n_clumps + 1) / 2;
 	if (lds_w <= 64 * 1024) {
 		const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / lds_w));
 		const uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * per_cu);
-		if (narrow) hipLaunchKernelGGL(k_prefilter_wave<uint8_t>, dim3(grid), dim3(64), lds_w, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+		if (narrow) hipLaunchKernelGGL(k_prefilter_wave<uint8_t>, dim3(grid), dim3(64), lds_w, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
-			n_cand_dev, cand_cap, &dc->ent_read, plan, h->fb_list.as<uint32_t>(), &dc->n_fb);
-		else hipLaunchKernelGGL(k_prefilter_wave<uint16_t>, dim3(grid), dim3(64), lds_w, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+			n_cand_dev, cand_cap, &dc->ent_read, plan, L->fb_list.as<uint32_t>(), &dc->n_fb);
+		else hipLaunchKernelGGL(k_prefilter_wave<uint16_t>, dim3(grid), dim3(64), lds_w, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
-			n_cand_dev, cand_cap, &dc->ent_read, plan, h->fb_list.as<uint32_t>(), &dc->n_fb);
+			n_cand_dev, cand_cap, &dc->ent_read, plan, L->fb_list.as<uint32_t>(), &dc->n_fb);
 	} else {
-		// stride-1 dense counters in global memory, one workgroup per query (very large databases only)
+		// dense counters in global memory, one workgroup per query (very large databases only)
 		uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * 2);
-		if ((rc = h->gcnt.reserve((size_t)grid * nw32 * 4))) return rc;
-		hipLaunchKernelGGL(k_prefilter<false>, dim3(grid), dim3(256), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+		if ((rc = L->gcnt.reserve((size_t)grid * nw32 * 4))) return rc;
+		hipLaunchKernelGGL(k_prefilter<false>, dim3(grid), dim3(256), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps,
-			h->gcnt.as<uint32_t>(), bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read, h->fb_list.as<uint32_t>(), &dc->n_fb, plan);
+			L->gcnt.as<uint32_t>(), bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read, L->fb_list.as<uint32_t>(), &dc->n_fb, plan);
 	}
 	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+static int ensure_lanes(Handle *h, uint32_t n) {
+	while (h->lanes.size() < n) { Lane *L = nullptr; int rc = lane_create(h, &L); if (rc) return rc; h->lanes.push_back(L); }
 	return 0;
 }
 
@@ -418,18 +490,27 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 	h->st_valid = false;
 	h->st_nq = n_q; h->st_has_six = q_six != nullptr; h->st_has_rc = q_rc != nullptr;
 	h->st_nshared = q_six ? n_shared : n_q;
-	for (int c = 0; c < kNumClasses; ++c) { h->st_npf[c] = h->st_nex[c] = h->st_maxE[c] = 0; }
-	if (!n_q) { h->st_valid = true; return BHIP_OK; }
+	if (!n_q) { h->st_valid = true; h->st_lanes = 0; return BHIP_OK; }
 	if (!q_codes || !q_off || !q_emac) return fail(BHIP_E_ARG, "null query arrays");
 	HIPCHK(hipSetDevice(h->device));
-	// host-side routing: class by length, prefilter vs exhaustive
-	std::vector<uint32_t> lists[kNumClasses][2];
+	// number of lanes: enough entries per lane to fill the chip
+	uint32_t nl = (uint32_t)h->opt_lanes;
+	while (nl > 1 && n_q / nl < 32768) --nl;
+	int rc;
+	if ((rc = ensure_lanes(h, nl))) return rc;
+	h->st_lanes = nl;
+	const uint32_t nsh = h->st_nshared;
+	// host-side routing: lane by shared slot, class by length, prefilter vs exhaustive (entries nobody can guarantee a k-mer for)
+	std::vector<std::vector<uint32_t>> lists((size_t)nl * kNumClasses * 2);
 	std::vector<uint32_t> plan(n_q, 1u);
+	for (uint32_t l = 0; l < nl; ++l) { Lane *L = h->lanes[l]; for (int c = 0; c < kNumClasses; ++c) L->npf[c] = L->nex[c] = L->maxE[c] = 0; L->maxlen = 0; L->n_entries = 0; }
 	for (uint32_t i = 0; i < n_q; ++i) {
 		const uint64_t len = q_off[i + 1] - q_off[i];
 		if (len == 0) continue;
 		if (len > BHIP_MAX_QLEN) return fail(BHIP_E_QUERYLEN, "query %u has %llu symbols (max %d)", i, (unsigned long long)len, BHIP_MAX_QLEN);
 		if (q_six && q_six[i] >= n_shared) return fail(BHIP_E_ARG, "q_six[%u] out of range", i);
+		const uint32_t six = q_six ? q_six[i] : i;
+		const uint32_t l = (uint32_t)(((uint64_t)six * nl) / nsh);
 		const int cls = class_of_len((uint32_t)len);
 		int ex = q_flags ? (q_flags[i] == BHIP_Q_EXHAUSTIVE) : !h->has_acx;
 		if (!h->has_acx) ex = 1;
@@ -437,22 +518,24 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 			plan[i] = make_seed_plan(q_codes + q_off[i], (uint32_t)len, q_emac[i], (uint32_t)h->K, h->opt_prefilter_stride);
 			if ((plan[i] >> 8) == 0) ex = 1;           // no word is guaranteed to survive: exhaustive (burst.c:3130-3131 does the same for "bad" queries)
 		}
-		lists[cls][ex].push_back(i);
-		h->st_maxE[cls] = std::max<uint32_t>(h->st_maxE[cls], q_emac[i]);
+		lists[((size_t)l * kNumClasses + cls) * 2 + ex].push_back(i);
+		Lane *L = h->lanes[l];
+		L->maxE[cls] = std::max<uint32_t>(L->maxE[cls], q_emac[i]);
+		L->maxlen = std::max<uint32_t>(L->maxlen, (uint32_t)len);
+		++L->n_entries;
 	}
 	HIPCHK(hipEventRecord(h->ev[0], h->stream));
-	int rc;
 	if ((rc = upload_queries(h, q_codes, q_off, q_emac, q_six, q_rc, n_q))) return rc;
-	if ((rc = h->plan.reserve((size_t)n_q * 4))) return rc;
-	HIPCHK(hipMemcpy(h->plan.p, plan.data(), (size_t)n_q * 4, hipMemcpyHostToDevice));
-	for (int cls = 0; cls < kNumClasses; ++cls) {
-		const size_t n_pf = lists[cls][0].size(), n_ex = lists[cls][1].size();
-		h->st_npf[cls] = (uint32_t)n_pf; h->st_nex[cls] = (uint32_t)n_ex;
-		if (!(n_pf + n_ex)) continue;
-		std::vector<uint32_t> ql(lists[cls][0]);
-		ql.insert(ql.end(), lists[cls][1].begin(), lists[cls][1].end());
-		if ((rc = h->qlist_cls[cls].reserve(ql.size() * 4))) return rc;
-		HIPCHK(hipMemcpy(h->qlist_cls[cls].p, ql.data(), ql.size() * 4, hipMemcpyHostToDevice));
+	if ((rc = upload_plan(h, q_codes, q_off, q_emac, n_q, plan))) return rc;
+	for (uint32_t l = 0; l < nl; ++l) for (int cls = 0; cls < kNumClasses; ++cls) {
+		Lane *L = h->lanes[l];
+		std::vector<uint32_t> &pf = lists[((size_t)l * kNumClasses + cls) * 2], &ex = lists[((size_t)l * kNumClasses + cls) * 2 + 1];
+		L->npf[cls] = (uint32_t)pf.size(); L->nex[cls] = (uint32_t)ex.size();
+		if (pf.empty() && ex.empty()) continue;
+		std::vector<uint32_t> ql(pf);
+		ql.insert(ql.end(), ex.begin(), ex.end());
+		if ((rc = L->qlist_cls[cls].reserve(ql.size() * 4))) return rc;
+		HIPCHK(hipMemcpy(L->qlist_cls[cls].p, ql.data(), ql.size() * 4, hipMemcpyHostToDevice));
 	}
 	HIPCHK(hipEventRecord(h->ev[1], h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
@@ -461,145 +544,203 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 	return BHIP_OK;
 }
 
+// enqueue one lane's whole chain (no host synchronisation).  `start` = event every stream must wait for (buffers reset).
+static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint32_t band_rows, uint32_t qw, uint32_t rw) {
+	int rc;
+	if ((rc = L->cand.reserve(L->cand_cap * sizeof(uint2)))) return rc;
+	if ((rc = L->raw.reserve(L->raw_cap * sizeof(BhipRawHit)))) return rc;
+	if ((rc = L->wide.reserve(L->raw_cap * sizeof(uint32_t)))) return rc;
+	if ((rc = L->scratch.reserve(L->scratch_cap * sizeof(uint32_t)))) return rc;
+	if ((rc = L->wins.reserve(L->win_cap * sizeof(BhipWin)))) return rc;
+	for (int cls = 0; cls < kNumClasses; ++cls) if (L->npf[cls] + L->nex[cls]) {
+		if ((rc = L->peq.reserve((size_t)(L->npf[cls] + L->nex[cls]) * 16 * kClasses[cls] * 4))) return rc;
+		if ((rc = L->peqp.reserve((size_t)(L->npf[cls] + L->nex[cls]) * 16 * 6 * 4))) return rc;
+	}
+	hipStream_t pf = h->pf_stream, sw = h->sweep_stream, po = h->post_stream;
+	HIPCHK(hipMemsetAsync(L->counters.p, 0, sizeof(Counters), pf));
+	Counters *dc = L->counters.as<Counters>();
+	SharedCtr *sc = h->shared_ctr.as<SharedCtr>();
+	L->launches = 0; L->prefix_words = 0; L->n_pairs_ex = 0;
+	const uint32_t grid_my = (uint32_t)h->n_cu * (uint32_t)h->opt_sweep_blocks;   // < 8 leaves wave slots for the other stages' kernels
+	(void)start;
+	for (int cls = 0; cls < kNumClasses; ++cls) {
+		const uint32_t n_pf = L->npf[cls], n_ex = L->nex[cls], n_list = n_pf + n_ex;
+		if (!n_list) continue;
+		const int NW = kClasses[cls];
+		const uint32_t *qlist = L->qlist_cls[cls].as<uint32_t>();
+		hipEvent_t *ce = L->ev_cls[cls];
+		// the lane's peq buffers are reused class after class: do not rebuild them before the previous class's window stage is done
+		if (L->launches) HIPCHK(hipStreamWaitEvent(pf, L->ev_rs[0], 0));
+		HIPCHK(hipEventRecord(ce[0], pf));
+		{
+			const uint64_t total = (uint64_t)n_list * NW;
+			const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16);
+			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, pf, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+				qlist, n_list, NW, 0, h->mm, L->peq.as<uint32_t>());
+			HIPCHK(hipGetLastError());
+		}
+		// two-stage edit distance when a prefix of 32*NWP symbols is selective for this class's budgets
+		int NWP = 0;
+		if (h->opt_two_stage) {   // prefix of about 6 symbols per allowed edit, in words; must be shorter than the query vector to pay
+			const uint32_t mE = L->maxE[cls], want = (6 * mE + 31) / 32;
+			NWP = want <= 1 ? 1 : (want <= 2 ? 2 : (want <= 3 ? 3 : (want <= 4 ? 4 : (want <= 6 ? 6 : 0))));
+			if (NWP >= NW) NWP = 0;
+		}
+		if (NWP) {
+			const uint64_t total = (uint64_t)n_list * NWP;
+			const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16);
+			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, pf, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+				qlist, n_list, NWP, 32 * NWP, h->mm, L->peqp.as<uint32_t>());
+			HIPCHK(hipGetLastError());
+		}
+		L->prefix_words = (uint32_t)NWP;
+		HIPCHK(hipEventRecord(ce[1], pf));
+		if (n_pf) if ((rc = launch_prefilter(h, L, pf, qlist, n_pf, L->cand.as<uint2>(), nullptr, (uint32_t)L->cand_cap, true, &dc->n_cand_cls[cls], dc))) return rc;
+		HIPCHK(hipEventRecord(ce[2], pf));
+		// column sweep on the sweep stream, behind this lane's prefilter
+		HIPCHK(hipStreamWaitEvent(sw, ce[2], 0));
+		HIPCHK(hipEventRecord(ce[6], sw));
+		if (n_pf) {
+			if (NWP) launch_prefix(h, L, sw, NWP, grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, &dc->n_wins_cls[cls], dc);
+			else launch_myers(h, L, sw, cls, grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, L->raw.as<BhipRawHit>(),
+				&dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
+			HIPCHK(hipGetLastError());
+			++L->launches;
+		}
+		HIPCHK(hipEventRecord(ce[3], sw));
+		if (n_ex) {
+			const uint64_t np = (uint64_t)n_ex * h->n_clumps;
+			const uint32_t g = (uint32_t)std::min<uint64_t>((np + 15) / 16, grid_my);
+			if (NWP) launch_prefix(h, L, sw, NWP, g, nullptr, nullptr, np, n_pf, qlist, &dc->n_wins_cls[cls], dc);
+			else launch_myers(h, L, sw, cls, g, nullptr, nullptr, np, n_pf, qlist, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap,
+				h->best.as<uint32_t>(), nullptr, dc);
+			HIPCHK(hipGetLastError());
+			++L->launches;
+			L->n_pairs_ex += np;
+		}
+		HIPCHK(hipEventRecord(ce[4], sw));
+		HIPCHK(hipStreamWaitEvent(po, ce[4], 0));
+		if (NWP) { launch_window(h, L, po, cls, NWP, grid_my, qlist, &dc->n_wins_cls[cls], dc); HIPCHK(hipGetLastError()); }
+		HIPCHK(hipEventRecord(ce[5], po));
+		HIPCHK(hipEventRecord(L->ev_rs[0], po));
+	}
+	// re-scoring of the kept reference lanes of this lane's shared slots
+	HIPCHK(hipEventRecord(L->ev_rs[0], po));
+	const uint32_t grid_rs = (uint32_t)h->n_cu * 16;
+	const size_t lds_rs = (size_t)(band_rows + 1 + qw + rw) * 256;
+	hipLaunchKernelGGL(k_rescore<false>, dim3(grid_rs), dim3(64), lds_rs, po, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap,
+		(const uint32_t *)nullptr, (const uint32_t *)nullptr, h->best.as<uint32_t>(), all_hits, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+		h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr, h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(),
+		h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, L->wide.as<uint32_t>(),
+		&dc->n_wide, (uint32_t *)nullptr, &dc->scratch_used, 0ull, &sc->err, qw ? h->qpack.as<uint32_t>() : nullptr, band_rows, qw, rw);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(L->ev_rs[1], po));
+	HIPCHK(hipMemcpyAsync(L->hc_pinned, dc, sizeof(Counters), hipMemcpyDeviceToHost, po));
+	return 0;
+}
+
 extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint64_t cap, uint64_t *n_hits) {
 	Handle *h = (Handle *)handle;
 	if (!h || !n_hits) return fail(BHIP_E_ARG, "null argument");
 	*n_hits = 0;
 	memset(&h->stats, 0, sizeof h->stats);
 	if (!h->st_valid) return fail(BHIP_E_ARG, "no staged queries (call bhip_stage_queries first)");
-	const uint32_t n_q = h->st_nq, n_shared = h->st_nshared;
+	const uint32_t n_q = h->st_nq, n_shared = h->st_nshared, nl = h->st_lanes;
 	if (!n_q) return BHIP_OK;
 	HIPCHK(hipSetDevice(h->device));
-	Counters hc;
-	for (int attempt = 0; attempt < 6; ++attempt) {
+	// LDS plan of the re-scorer: band rows for the widest expected band (2*maxE+1 plus slack), query and reference staging
+	const uint32_t band_rows = std::min<uint32_t>(BHIP_RESCORE_WMAX, 2 * h->st_maxE + 1 + 9);
+	uint32_t qw = (h->st_maxlen + 7) / 8, rw = (h->st_maxlen + band_rows + 24) / 8 + 2;
+	if ((size_t)(band_rows + 1 + qw + rw) * 256 > 40 * 1024) { qw = 0; rw = 0; }      // long queries: per-row global reads instead
+	SharedCtr hsc;
+	for (int attempt = 0; attempt < 8; ++attempt) {
 		int rc;
 		if ((rc = h->best.reserve((size_t)(n_shared + 1) * 4))) return rc;
-		if ((rc = h->cand.reserve(h->cand_cap * sizeof(uint2)))) return rc;
-		if ((rc = h->raw.reserve(h->raw_cap * sizeof(BhipRawHit)))) return rc;
-		if ((rc = h->wide.reserve(h->raw_cap * sizeof(uint32_t)))) return rc;
 		if ((rc = h->out.reserve(h->out_cap * sizeof(BhipHit)))) return rc;
-		if ((rc = h->scratch.reserve(h->scratch_cap * sizeof(uint32_t)))) return rc;
-		if ((rc = h->wins.reserve(h->win_cap * sizeof(BhipWin)))) return rc;
-		for (int cls = 0; cls < kNumClasses; ++cls) if (h->st_npf[cls] + h->st_nex[cls]) {
-			if ((rc = h->peqp.reserve((size_t)(h->st_npf[cls] + h->st_nex[cls]) * 16 * 6 * 4))) return rc;
-		}
-		for (int cls = 0; cls < kNumClasses; ++cls) if (h->st_npf[cls] + h->st_nex[cls])
-			if ((rc = h->peq.reserve((size_t)(h->st_npf[cls] + h->st_nex[cls]) * 16 * kClasses[cls] * 4))) return rc;
+		if ((rc = h->shared_ctr.reserve(sizeof(SharedCtr)))) return rc;
+		if (qw) if ((rc = h->qpack.reserve((size_t)n_q * qw * 4))) return rc;
 		HIPCHK(hipEventRecord(h->ev[0], h->stream));
 		HIPCHK(hipMemsetAsync(h->best.p, 0xFF, (size_t)n_shared * 4, h->stream));
-		HIPCHK(hipMemsetAsync(h->counters.p, 0, sizeof(Counters), h->stream));
-		Counters *dc = h->counters.as<Counters>();
-		uint64_t n_pairs_ex = 0;
-		uint32_t launches = 0, prefix_words = 0;
-		const uint32_t grid_my = (uint32_t)h->n_cu * 8;
-		for (int cls = 0; cls < kNumClasses; ++cls) {
-			const uint32_t n_pf = h->st_npf[cls], n_ex = h->st_nex[cls], n_list = n_pf + n_ex;
-			if (!n_list) continue;
-			const int NW = kClasses[cls];
-			const uint32_t *qlist = h->qlist_cls[cls].as<uint32_t>();
-			hipEvent_t *ce = h->ev_cls[cls];
-			HIPCHK(hipEventRecord(ce[0], h->stream));
-			{
-				const uint64_t total = (uint64_t)n_list * NW;
-				const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16);
-				hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-					qlist, n_list, NW, 0, h->mm, h->peq.as<uint32_t>());
-				HIPCHK(hipGetLastError());
-			}
-			// two-stage edit distance when a prefix of 32*NWP symbols is selective for this class's budgets
-			int NWP = 0;
-			if (h->opt_two_stage) {   // prefix of about 6 symbols per allowed edit, in words; must be shorter than the query vector to pay
-				const uint32_t mE = h->st_maxE[cls], want = (6 * mE + 31) / 32;
-				NWP = want <= 1 ? 1 : (want <= 2 ? 2 : (want <= 3 ? 3 : (want <= 4 ? 4 : (want <= 6 ? 6 : 0))));
-				if (NWP >= NW) NWP = 0;
-			}
-			if (NWP) {
-				const uint64_t total = (uint64_t)n_list * NWP;
-				const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16);
-				hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, h->stream, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-					qlist, n_list, NWP, 32 * NWP, h->mm, h->peqp.as<uint32_t>());
-				HIPCHK(hipGetLastError());
-			}
-			prefix_words = (uint32_t)NWP;
-			HIPCHK(hipEventRecord(ce[1], h->stream));
-			if (n_pf) {
-				if ((rc = launch_prefilter(h, qlist, n_pf, h->cand.as<uint2>(), nullptr, (uint32_t)h->cand_cap, true, &dc->n_cand_cls[cls], dc))) return rc;
-				HIPCHK(hipEventRecord(ce[2], h->stream));
-				if (NWP) launch_prefix(h, NWP, grid_my, h->cand.as<uint2>(), &dc->n_cand_cls[cls], h->cand_cap, 0, qlist, &dc->n_wins_cls[cls], dc);
-				else launch_myers(h, cls, grid_my, h->cand.as<uint2>(), &dc->n_cand_cls[cls], h->cand_cap, 0, qlist, h->raw.as<BhipRawHit>(),
-					&dc->n_raw, (uint32_t)h->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
-				HIPCHK(hipGetLastError());
-				++launches;
-			} else HIPCHK(hipEventRecord(ce[2], h->stream));
-			HIPCHK(hipEventRecord(ce[3], h->stream));
-			if (n_ex) {
-				const uint64_t np = (uint64_t)n_ex * h->n_clumps;
-				const uint32_t g = (uint32_t)std::min<uint64_t>((np + 15) / 16, grid_my);
-				if (NWP) launch_prefix(h, NWP, g, nullptr, nullptr, np, n_pf, qlist, &dc->n_wins_cls[cls], dc);
-				else launch_myers(h, cls, g, nullptr, nullptr, np, n_pf, qlist,
-					h->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)h->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
-				HIPCHK(hipGetLastError());
-				++launches;
-				n_pairs_ex += np;
-			}
-			HIPCHK(hipEventRecord(ce[4], h->stream));
-			if (NWP) { launch_window(h, cls, NWP, grid_my, qlist, &dc->n_wins_cls[cls], dc); HIPCHK(hipGetLastError()); }
-			HIPCHK(hipEventRecord(ce[5], h->stream));
-		}
-		// rescoring of the kept lanes
-		HIPCHK(hipEventRecord(h->ev[6], h->stream));
-		const uint32_t grid_rs = (uint32_t)h->n_cu * 16;
-		// LDS plan of the re-scorer: band rows for the widest expected band (2*maxE+1 plus slack), query and reference staging
-		uint32_t maxE = 0; for (int cls = 0; cls < kNumClasses; ++cls) maxE = std::max(maxE, h->st_maxE[cls]);
-		const uint32_t band_rows = std::min<uint32_t>(BHIP_RESCORE_WMAX, 2 * maxE + 1 + 9);
-		uint32_t qw = (h->st_maxlen_pf + 7) / 8, rw = (h->st_maxlen_pf + band_rows + 24) / 8 + 2;
-		if ((size_t)(band_rows + 1 + qw + rw) * 256 > 40 * 1024) { qw = 0; rw = 0; }      // long queries: per-row global reads instead
-		const size_t lds_rs = (size_t)(band_rows + 1 + qw + rw) * 256;
+		HIPCHK(hipMemsetAsync(h->shared_ctr.p, 0, sizeof(SharedCtr), h->stream));
 		if (qw) {
-			if ((rc = h->qpack.reserve((size_t)n_q * qw * 4))) return rc;
 			const uint64_t total = (uint64_t)n_q * qw;
 			hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
 				h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), n_q, qw, h->qpack.as<uint32_t>());
+			HIPCHK(hipGetLastError());
 		}
-		hipLaunchKernelGGL(k_rescore<false>, dim3(grid_rs), dim3(64), lds_rs, h->stream, h->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)h->raw_cap,
-			(const uint32_t *)nullptr, (const uint32_t *)nullptr, h->best.as<uint32_t>(), all_hits, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-			h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr, h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(),
-			h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &dc->n_out, (uint32_t)h->out_cap, h->wide.as<uint32_t>(),
-			&dc->n_wide, (uint32_t *)nullptr, &dc->scratch_used, 0ull, &dc->err, qw ? h->qpack.as<uint32_t>() : nullptr, band_rows, qw, rw);
-		HIPCHK(hipGetLastError());
-		HIPCHK(hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, h->stream));
-		HIPCHK(hipStreamSynchronize(h->stream));
+		HIPCHK(hipEventRecord(h->ev[1], h->stream));
+		HIPCHK(hipStreamWaitEvent(h->sweep_stream, h->ev[1], 0));
+		HIPCHK(hipStreamWaitEvent(h->pf_stream, h->ev[1], 0));
+		HIPCHK(hipStreamWaitEvent(h->post_stream, h->ev[1], 0));
+		for (uint32_t l = 0; l < nl; ++l) if (h->lanes[l]->n_entries) if ((rc = enqueue_lane(h, h->lanes[l], all_hits, h->ev[1], band_rows, qw, rw))) return rc;
+		HIPCHK(hipStreamSynchronize(h->pf_stream));
+		HIPCHK(hipStreamSynchronize(h->sweep_stream));
+		HIPCHK(hipStreamSynchronize(h->post_stream));
+		for (uint32_t l = 0; l < nl; ++l) if (h->lanes[l]->n_entries) h->lanes[l]->hc = *h->lanes[l]->hc_pinned;
+		// capacity checks (first call of a workload: grow and redo)
 		bool retry = false;
-		for (int cls = 0; cls < kNumClasses; ++cls) if (hc.n_cand_cls[cls] > h->cand_cap) { h->cand_cap = (uint64_t)hc.n_cand_cls[cls] + hc.n_cand_cls[cls] / 8 + 1024; retry = true; }
-		for (int cls = 0; cls < kNumClasses; ++cls) if (hc.n_wins_cls[cls] > h->win_cap) { h->win_cap = (uint64_t)hc.n_wins_cls[cls] + hc.n_wins_cls[cls] / 8 + 1024; retry = true; }
-		if (hc.n_raw > h->raw_cap) { h->raw_cap = (uint64_t)hc.n_raw + hc.n_raw / 8 + 1024; retry = true; }
+		for (uint32_t l = 0; l < nl; ++l) {
+			Lane *L = h->lanes[l];
+			if (!L->n_entries) continue;
+			const Counters &c = L->hc;
+			for (int cls = 0; cls < kNumClasses; ++cls) {
+				if (c.n_cand_cls[cls] > L->cand_cap) { L->cand_cap = (uint64_t)c.n_cand_cls[cls] + c.n_cand_cls[cls] / 8 + 1024; retry = true; }
+				if (c.n_wins_cls[cls] > L->win_cap) { L->win_cap = (uint64_t)c.n_wins_cls[cls] + c.n_wins_cls[cls] / 8 + 1024; retry = true; }
+			}
+			if (c.n_raw > L->raw_cap) { L->raw_cap = (uint64_t)c.n_raw + c.n_raw / 8 + 1024; retry = true; }
+		}
 		if (retry) continue;
-		if (hc.n_wide) {
-			hipLaunchKernelGGL(k_rescore<true>, dim3(std::min<uint32_t>((hc.n_wide + 63) / 64, grid_rs)), dim3(64), 256, h->stream,
-				h->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)h->raw_cap, h->wide.as<uint32_t>(), &dc->n_wide, h->best.as<uint32_t>(), all_hits,
+		// rare: bands wider than the LDS plan (repeats inside one shear) -> global-scratch variant, lane by lane
+		bool scratch_retry = false;
+		for (uint32_t l = 0; l < nl; ++l) {
+			Lane *L = h->lanes[l];
+			if (!L->n_entries || !L->hc.n_wide) continue;
+			Counters *dc = L->counters.as<Counters>();
+			SharedCtr *sc = h->shared_ctr.as<SharedCtr>();
+			hipLaunchKernelGGL(k_rescore<true>, dim3(std::min<uint32_t>((L->hc.n_wide + 63) / 64, (uint32_t)h->n_cu * 16)), dim3(64), 256, h->post_stream,
+				L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, L->wide.as<uint32_t>(), &dc->n_wide, h->best.as<uint32_t>(), all_hits,
 				h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr,
 				h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(),
-				&dc->n_out, (uint32_t)h->out_cap, (uint32_t *)nullptr, (uint32_t *)nullptr, h->scratch.as<uint32_t>(), &dc->scratch_used,
-				(unsigned long long)h->scratch_cap, &dc->err, (const uint32_t *)nullptr, 0u, 0u, 0u);
+				&sc->n_out, (uint32_t)h->out_cap, (uint32_t *)nullptr, (uint32_t *)nullptr, L->scratch.as<uint32_t>(), &dc->scratch_used,
+				(unsigned long long)L->scratch_cap, &sc->err, (const uint32_t *)nullptr, 0u, 0u, 0u);
 			HIPCHK(hipGetLastError());
-			HIPCHK(hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(hipStreamSynchronize(h->stream));
-			if (hc.err & 2u) { h->scratch_cap = (uint64_t)hc.scratch_used + 1024; continue; }
+			HIPCHK(hipMemcpyAsync(&L->hc, dc, sizeof(Counters), hipMemcpyDeviceToHost, h->post_stream));
+			HIPCHK(hipStreamSynchronize(h->post_stream));
+			if (L->hc.scratch_used > L->scratch_cap) { L->scratch_cap = (uint64_t)L->hc.scratch_used + 1024; scratch_retry = true; }
 		}
-		HIPCHK(hipEventRecord(h->ev[7], h->stream));
-		if (hc.err & 1u) return fail(BHIP_E_INTERNAL, "re-scoring could not reproduce a hit found by the edit-distance kernel");
-		if (hc.n_out > h->out_cap) { h->out_cap = (uint64_t)hc.n_out + hc.n_out / 8 + 1024; continue; }
-		*n_hits = hc.n_out;
-		h->stats.n_queries = n_q; h->stats.n_pairs = n_pairs_ex; h->stats.n_columns = hc.col_sum; h->stats.n_raw_hits = hc.n_raw;
-		for (int cls = 0; cls < kNumClasses; ++cls) h->stats.n_pairs += hc.n_cand_cls[cls];
-		h->stats.n_hits = hc.n_out; h->stats.acx_entries_read = hc.ent_read; h->stats.myers_launches = launches;
-		h->stats.prefix_words = prefix_words; h->stats.n_window_columns = hc.wcol_sum;
-		for (int cls = 0; cls < kNumClasses; ++cls) h->stats.n_windows += hc.n_wins_cls[cls];
-		h->stats.bytes_algorithmic = 8ull * hc.col_sum + hc.qlen_sum / 2 + 192ull * h->stats.n_pairs;
-		if (hc.n_out > cap) return fail(BHIP_E_CAPACITY, "hit buffer holds %llu records, %u needed", (unsigned long long)cap, hc.n_out);
+		HIPCHK(hipMemcpy(&hsc, h->shared_ctr.p, sizeof hsc, hipMemcpyDeviceToHost));
+		if (scratch_retry || (hsc.err & 2u)) continue;
+		if (hsc.err & 1u) return fail(BHIP_E_INTERNAL, "re-scoring could not reproduce a hit found by the edit-distance kernel");
+		if (hsc.n_out > h->out_cap) { h->out_cap = (uint64_t)hsc.n_out + hsc.n_out / 8 + 1024; continue; }
+		*n_hits = hsc.n_out;
+		// statistics
+		BhipStats &S = h->stats;
+		S.n_queries = n_q; S.n_hits = hsc.n_out;
+		uint64_t qlen_sum = 0;
+		for (uint32_t l = 0; l < nl; ++l) {
+			Lane *L = h->lanes[l];
+			if (!L->n_entries) continue;
+			const Counters &c = L->hc;
+			S.n_pairs += L->n_pairs_ex; S.n_columns += c.col_sum; S.n_raw_hits += c.n_raw; S.acx_entries_read += c.ent_read;
+			S.myers_launches += L->launches; S.n_window_columns += c.wcol_sum; qlen_sum += c.qlen_sum;
+			if (L->prefix_words) S.prefix_words = L->prefix_words;
+			for (int cls = 0; cls < kNumClasses; ++cls) {
+				S.n_pairs += c.n_cand_cls[cls]; S.n_windows += c.n_wins_cls[cls];
+				if (!(L->npf[cls] + L->nex[cls])) continue;
+				hipEvent_t *ce = L->ev_cls[cls];
+				S.ms_peq += ev_ms(ce[0], ce[1]);
+				if (L->npf[cls]) S.ms_prefilter += ev_ms(ce[1], ce[2]);
+				const float sweep = ev_ms(ce[6], ce[4]), win = ev_ms(ce[4], ce[5]);
+				S.ms_myers += sweep + win;
+				if (L->prefix_words) { S.ms_myers_prefix += sweep; S.ms_myers_window += win; }
+			}
+			S.ms_rescore += ev_ms(L->ev_rs[0], L->ev_rs[1]);
+		}
+		S.bytes_algorithmic = 8ull * S.n_columns + qlen_sum / 2 + 192ull * S.n_pairs;
+		if (hsc.n_out > cap) return fail(BHIP_E_CAPACITY, "hit buffer holds %llu records, %u needed", (unsigned long long)cap, hsc.n_out);
 		HIPCHK(hipEventRecord(h->ev[8], h->stream));
-		if (hc.n_out) {
-			const uint32_t n = hc.n_out;
+		if (hsc.n_out) {
+			const uint32_t n = hsc.n_out;
 			if ((rc = h->sort_keys.reserve((size_t)n * 8)) || (rc = h->sort_keys2.reserve((size_t)n * 8)) || (rc = h->sort_idx.reserve((size_t)n * 4)) ||
 			    (rc = h->sort_idx2.reserve((size_t)n * 4)) || (rc = h->out_sorted.reserve((size_t)n * sizeof(BhipHit)))) return rc;
 			const uint32_t g = std::min<uint32_t>((n + 255) / 256, (uint32_t)h->n_cu * 8);
@@ -617,15 +758,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		}
 		HIPCHK(hipEventRecord(h->ev[9], h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
-		for (int cls = 0; cls < kNumClasses; ++cls) if (h->st_npf[cls] + h->st_nex[cls]) {
-			hipEvent_t *ce = h->ev_cls[cls];
-			h->stats.ms_peq += ev_ms(ce[0], ce[1]);
-			if (h->st_npf[cls]) h->stats.ms_prefilter += ev_ms(ce[1], ce[2]);
-			h->stats.ms_myers += ev_ms(ce[2], ce[5]);
-			if (prefix_words) { h->stats.ms_myers_prefix += ev_ms(ce[2], ce[4]); h->stats.ms_myers_window += ev_ms(ce[4], ce[5]); }
-		}
-		h->stats.ms_h2d = h->st_ms_h2d;
-		h->stats.ms_rescore = ev_ms(h->ev[6], h->ev[7]); h->stats.ms_d2h = ev_ms(h->ev[8], h->ev[9]); h->stats.ms_total = ev_ms(h->ev[0], h->ev[9]);
+		S.ms_h2d = h->st_ms_h2d; S.ms_d2h = ev_ms(h->ev[8], h->ev[9]); S.ms_total = ev_ms(h->ev[0], h->ev[9]);
 		return BHIP_OK;
 	}
 	return fail(BHIP_E_INTERNAL, "buffers kept overflowing");
@@ -647,8 +780,12 @@ extern "C" int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint
 	Handle *h = (Handle *)handle;
 	if (!h || !q_codes || !q_off || !q_emac || !pair_q || !pair_clump || !mins) return fail(BHIP_E_ARG, "null argument");
 	memset(&h->stats, 0, sizeof h->stats);
+	h->st_valid = false;
 	if (!n_pairs || !n_q) return BHIP_OK;
 	HIPCHK(hipSetDevice(h->device));
+	int rc;
+	if ((rc = ensure_lanes(h, 1))) return rc;
+	Lane *L = h->lanes[0];
 	uint32_t maxlen = 0;
 	for (uint32_t i = 0; i < n_q; ++i) maxlen = std::max<uint32_t>(maxlen, (uint32_t)(q_off[i + 1] - q_off[i]));
 	if (maxlen > BHIP_MAX_QLEN) return fail(BHIP_E_QUERYLEN, "query longer than %d", BHIP_MAX_QLEN);
@@ -658,27 +795,28 @@ extern "C" int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint
 		if (pair_q[p] >= n_q || pair_clump[p] >= h->n_clumps) return fail(BHIP_E_ARG, "pair %llu out of range", (unsigned long long)p);
 		pr[p] = make_uint2(pair_q[p], pair_clump[p]);
 	}
-	int rc;
+	h->st_has_six = false; h->st_has_rc = false;
 	if ((rc = upload_queries(h, q_codes, q_off, q_emac, nullptr, nullptr, n_q))) return rc;
-	if ((rc = h->peq.reserve((size_t)n_q * 16 * NW * 4))) return rc;
+	if ((rc = L->peq.reserve((size_t)n_q * 16 * NW * 4))) return rc;
 	if ((rc = h->pairs.reserve(n_pairs * sizeof(uint2)))) return rc;
 	if ((rc = h->mins.reserve(n_pairs * 16))) return rc;
-	HIPCHK(hipMemcpyAsync(h->pairs.p, pr.data(), n_pairs * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
-	HIPCHK(hipMemsetAsync(h->counters.p, 0, sizeof(Counters), h->stream));
-	Counters *dc = h->counters.as<Counters>();
+	hipStream_t st = h->stream;
+	HIPCHK(hipMemcpyAsync(h->pairs.p, pr.data(), n_pairs * sizeof(uint2), hipMemcpyHostToDevice, st));
+	HIPCHK(hipMemsetAsync(L->counters.p, 0, sizeof(Counters), st));
+	Counters *dc = L->counters.as<Counters>();
 	const uint64_t total = (uint64_t)n_q * NW;
-	hipLaunchKernelGGL(k_build_peq, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
-		h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), (const uint32_t *)nullptr, n_q, NW, 0, h->mm, h->peq.as<uint32_t>());
+	hipLaunchKernelGGL(k_build_peq, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, st,
+		h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), (const uint32_t *)nullptr, n_q, NW, 0, h->mm, L->peq.as<uint32_t>());
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(h->ev[0], h->stream));
-	launch_myers(h, cls, (uint32_t)std::min<uint64_t>((n_pairs + 15) / 16, (uint64_t)h->n_cu * 8), h->pairs.as<uint2>(), nullptr, n_pairs, 0, nullptr,
+	HIPCHK(hipEventRecord(h->ev[0], st));
+	launch_myers(h, L, st, cls, (uint32_t)std::min<uint64_t>((n_pairs + 15) / 16, (uint64_t)h->n_cu * 8), h->pairs.as<uint2>(), nullptr, n_pairs, 0, nullptr,
 		nullptr, nullptr, 0, nullptr, h->mins.as<uint8_t>(), dc);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(h->ev[1], h->stream));
-	HIPCHK(hipMemcpyAsync(mins, h->mins.p, n_pairs * 16, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipEventRecord(h->ev[1], st));
+	HIPCHK(hipMemcpyAsync(mins, h->mins.p, n_pairs * 16, hipMemcpyDeviceToHost, st));
 	Counters hc;
-	HIPCHK(hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, h->stream));
-	HIPCHK(hipStreamSynchronize(h->stream));
+	HIPCHK(hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
 	h->stats.n_queries = n_q; h->stats.n_pairs = n_pairs; h->stats.n_columns = hc.col_sum; h->stats.myers_launches = 1;
 	h->stats.bytes_algorithmic = 8ull * hc.col_sum + hc.qlen_sum / 2 + 192ull * n_pairs;
 	h->stats.ms_myers = ev_ms(h->ev[0], h->ev[1]); h->stats.ms_total = h->stats.ms_myers;
@@ -691,36 +829,39 @@ extern "C" int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64
 	if (!h || !q_codes || !q_off || !q_emac || !n_out) return fail(BHIP_E_ARG, "null argument");
 	if (!h->has_acx) return fail(BHIP_E_ARG, "handle has no accelerator");
 	*n_out = 0;
+	h->st_valid = false;
 	if (!n_q) return BHIP_OK;
 	HIPCHK(hipSetDevice(h->device));
+	int rc;
+	if ((rc = ensure_lanes(h, 1))) return rc;
+	Lane *L = h->lanes[0];
 	for (int attempt = 0; attempt < 4; ++attempt) {
-		int rc;
 		if ((rc = upload_queries(h, q_codes, q_off, q_emac, nullptr, nullptr, n_q))) return rc;
 		{
 			std::vector<uint32_t> plan(n_q, 1u);
 			for (uint32_t i = 0; i < n_q; ++i) plan[i] = make_seed_plan(q_codes + q_off[i], (uint32_t)(q_off[i + 1] - q_off[i]), q_emac[i], (uint32_t)h->K, h->opt_prefilter_stride);
-			if ((rc = h->plan.reserve((size_t)n_q * 4))) return rc;
-			HIPCHK(hipMemcpy(h->plan.p, plan.data(), (size_t)n_q * 4, hipMemcpyHostToDevice));
+			if ((rc = upload_plan(h, q_codes, q_off, q_emac, n_q, plan))) return rc;
 		}
-		if ((rc = h->cand.reserve(h->cand_cap * sizeof(uint2)))) return rc;
-		if ((rc = h->candcnt.reserve(h->cand_cap * sizeof(uint32_t)))) return rc;
-		HIPCHK(hipMemsetAsync(h->counters.p, 0, sizeof(Counters), h->stream));
-		Counters *dc = h->counters.as<Counters>();
-		HIPCHK(hipEventRecord(h->ev[0], h->stream));
-		if ((rc = launch_prefilter(h, nullptr, n_q, h->cand.as<uint2>(), h->candcnt.as<uint32_t>(), (uint32_t)h->cand_cap, false, &dc->n_cand, dc))) return rc;
-		HIPCHK(hipEventRecord(h->ev[1], h->stream));
-		Counters hc;
-		HIPCHK(hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, h->stream));
+		if ((rc = L->cand.reserve(L->cand_cap * sizeof(uint2)))) return rc;
+		if ((rc = L->candcnt.reserve(L->cand_cap * sizeof(uint32_t)))) return rc;
 		HIPCHK(hipStreamSynchronize(h->stream));
-		if (hc.n_cand > h->cand_cap) { h->cand_cap = (uint64_t)hc.n_cand + 1024; continue; }
+		HIPCHK(hipMemsetAsync(L->counters.p, 0, sizeof(Counters), L->stream));
+		Counters *dc = L->counters.as<Counters>();
+		HIPCHK(hipEventRecord(h->ev[0], L->stream));
+		if ((rc = launch_prefilter(h, L, L->stream, nullptr, n_q, L->cand.as<uint2>(), L->candcnt.as<uint32_t>(), (uint32_t)L->cand_cap, false, &dc->n_cand, dc))) return rc;
+		HIPCHK(hipEventRecord(h->ev[1], L->stream));
+		Counters hc;
+		HIPCHK(hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, L->stream));
+		HIPCHK(hipStreamSynchronize(L->stream));
+		if (hc.n_cand > L->cand_cap) { L->cand_cap = (uint64_t)hc.n_cand + 1024; continue; }
 		*n_out = hc.n_cand;
 		memset(&h->stats, 0, sizeof h->stats);
 		h->stats.n_queries = n_q; h->stats.n_pairs = hc.n_cand; h->stats.acx_entries_read = hc.ent_read; h->stats.ms_prefilter = ev_ms(h->ev[0], h->ev[1]);
 		if (hc.n_cand > cap) return fail(BHIP_E_CAPACITY, "candidate buffer holds %llu, %u needed", (unsigned long long)cap, hc.n_cand);
 		std::vector<uint2> c(hc.n_cand); std::vector<uint32_t> cc(hc.n_cand);
 		if (hc.n_cand) {
-			HIPCHK(hipMemcpy(c.data(), h->cand.p, hc.n_cand * sizeof(uint2), hipMemcpyDeviceToHost));
-			HIPCHK(hipMemcpy(cc.data(), h->candcnt.p, hc.n_cand * sizeof(uint32_t), hipMemcpyDeviceToHost));
+			HIPCHK(hipMemcpy(c.data(), L->cand.p, hc.n_cand * sizeof(uint2), hipMemcpyDeviceToHost));
+			HIPCHK(hipMemcpy(cc.data(), L->candcnt.p, hc.n_cand * sizeof(uint32_t), hipMemcpyDeviceToHost));
 		}
 		std::vector<uint32_t> ord(hc.n_cand);
 		for (uint32_t i = 0; i < hc.n_cand; ++i) ord[i] = i;

@@ -122,7 +122,10 @@ int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64_t *q_off, 
 /* Tuning knobs.  "prefilter_stride": 0 (default) = automatic sparse seeds -- per query the largest stride s <= K for
  * which an alignment within budget still keeps >= 3 of the words starting at 0, s, 2s, ... (one edit destroys at most
  * ceil(K/s) of them), fewest .acx look-ups with the same no-false-negative guarantee; s >= 1 forces every s-th word,
- * 1 = every word = the reference's own threshold count > len-(E+1)K (burst.c:4091-4092, 4126). */
+ * 1 = every word = the reference's own threshold count > len-(E+1)K (burst.c:4091-4092, 4126).
+ * "two_stage": 1 (default) = prefix filter + windowed full-length edit distance, 0 = one full-length sweep.
+ * "lanes": 1..16 (default 6) sub-pipelines a staged batch is cut into; their prefilter / sweep / window+re-score stages
+ * run as a software pipeline on three HIP streams.  "sweep_blocks": 1..8 workgroups per CU of the sweep kernels. */
 int bhip_set_option(void *handle, const char *name, long long value);
 
 /* Stats of the last call; device properties (name, CU count) for reports. */
