@@ -36,6 +36,13 @@ template <int NWP> __global__ void k_myers_prefix2(const uint2 *, const uint32_t
 template <int NW> __global__ void k_myers_window(const BhipWin *, const uint32_t *, uint32_t, int, const uint32_t *, const uint32_t *, const uint64_t *,
 	const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *,
 	unsigned long long *);
+__global__ void k_extract_kmers(const uint4 *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, int, unsigned long long *, uint16_t *, uint32_t *);
+__global__ void k_attach_masks(const uint32_t *, const uint32_t *, uint64_t, uint32_t, const unsigned long long *, const uint16_t *, uint32_t, const uint32_t *, uint16_t *);
+__global__ void k_prefilter_mask(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint16_t *, int,
+	const uint32_t *, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *, uint32_t *, uint32_t *,
+	unsigned long long *, unsigned long long *, unsigned long long *);
+template <int NWP> __global__ void k_myers_prefix_task(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *,
+	const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *);
 template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *,
 	const uint32_t *, int, const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t *, const uint64_t *,
 	const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *,
@@ -90,7 +97,8 @@ struct Counters {
 	uint32_t n_cand_cls[8];
 	uint32_t n_wins_cls[8];
 	uint32_t n_fb, pad2;
-	unsigned long long wcol_sum;
+	uint32_t n_tasks_cls[8];
+	unsigned long long wcol_sum, tcol_sum, unit_sum;
 	unsigned long long col_sum, qlen_sum, ent_read, scratch_used;
 };
 
@@ -102,13 +110,15 @@ struct Lane {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev_cls[kNumClasses][8];   // per class: 0 start, 1 peq done, 2 prefilter done, 3 sweep(pf) done, 4 sweep(ex) done, 5 window done
 	hipEvent_t ev_rs[2];
-	DBuf qlist_cls[kNumClasses], peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters;
+	DBuf qlist_cls[kNumClasses], peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters, tasks;
+	uint64_t task_cap = 1 << 20;
 	uint64_t cand_cap = 1 << 18, raw_cap = 1 << 18, win_cap = 1 << 20, scratch_cap = 1 << 18;
 	uint32_t npf[kNumClasses] = {0}, nex[kNumClasses] = {0}, maxE[kNumClasses] = {0}, maxlen = 0, n_entries = 0;
 	Counters *hc_pinned = nullptr;        // pinned, so that the read-back of the counters does not block the enqueueing thread
 	Counters hc;
 	uint32_t launches = 0, prefix_words = 0;
 	uint64_t n_pairs_ex = 0;
+	bool masked = false;
 };
 
 struct Handle {
@@ -127,7 +137,9 @@ struct Handle {
 	DBuf ref, ref_off, clump_len, lut;
 	BhipMatchMask mm;
 	bool has_acx = false; int K = 0;
-	DBuf acx_off, acx_ent, bad; uint32_t n_bad = 0; uint64_t n_ent = 0;
+	DBuf acx_off, acx_ent, bad, ent_mask; uint32_t n_bad = 0; uint64_t n_ent = 0;
+	bool has_masks = false;       // per-entry lane masks were built at upload (lane-resolved prefilter)
+	int opt_lane_masks = 1;       // use them
 	// batch-wide buffers
 	DBuf qcodes, qoff, qemac, qsix, qrc, best, out, shared_ctr, mins, pairs;
 	DBuf sort_keys, sort_keys2, sort_idx, sort_idx2, sort_tmp, out_sorted, qpack, plan;
@@ -154,7 +166,7 @@ extern "C" int bhip_abi_version(void) { return BHIP_ABI_VERSION; }
 static void lane_destroy(Lane *L) {
 	if (!L) return;
 	if (L->stream) (void)hipStreamSynchronize(L->stream);
-	DBuf *all[] = {&L->peq, &L->peqp, &L->cand, &L->candcnt, &L->wins, &L->raw, &L->wide, &L->scratch, &L->fb_list, &L->gcnt, &L->counters};
+	DBuf *all[] = {&L->peq, &L->peqp, &L->cand, &L->candcnt, &L->wins, &L->raw, &L->wide, &L->scratch, &L->fb_list, &L->gcnt, &L->counters, &L->tasks};
 	for (DBuf *b : all) b->release();
 	for (auto &b : L->qlist_cls) b.release();
 	for (auto &ce : L->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
@@ -189,7 +201,7 @@ extern "C" void bhip_destroy(void *handle) {
 	for (Lane *L : h->lanes) lane_destroy(L);
 	DBuf *all[] = {&h->ref, &h->ref_off, &h->clump_len, &h->lut, &h->acx_off, &h->acx_ent, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
 		&h->qsix, &h->qrc, &h->best, &h->out, &h->shared_ctr, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx, &h->sort_idx2,
-		&h->sort_tmp, &h->out_sorted, &h->qpack, &h->plan};
+		&h->sort_tmp, &h->out_sorted, &h->qpack, &h->plan, &h->ent_mask};
 	for (DBuf *b : all) b->release();
 	for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -200,6 +212,58 @@ extern "C" void bhip_destroy(void *handle) {
 }
 
 static int ensure_lanes(Handle *h, uint32_t n);
+
+// per-entry lane masks (see bhip_kernels.hip, "Lane-resolved accelerator").  Skipped (has_masks stays false, clump-level
+// behaviour) when the database has >= 2^31 reference positions (device-sort item limit) or the scratch does not fit.
+struct BitOrU16 { __host__ __device__ uint16_t operator()(const uint16_t &a, const uint16_t &b) const { return (uint16_t)(a | b); } };
+static int build_lane_masks(Handle *h, const std::vector<uint64_t> &chunk_off) {
+	(void)chunk_off;
+	const uint32_t nC = h->n_clumps;
+	std::vector<uint64_t> key_off(nC + 1);
+	key_off[0] = 0;
+	for (uint32_t c = 0; c < nC; ++c) key_off[c + 1] = key_off[c] + 16ull * h->h_clump_len[c];
+	const uint64_t n_items = key_off[nC];
+	if (n_items == 0 || n_items >= 0x7FFFFFFFull || !h->n_ent) return 0;
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < 26.0 * (double)n_items + 3.0 * (double)h->n_ent) return 0;
+	DBuf d_koff, k0, k1, v0, v1, uk, um, nruns, tmp, amb;
+	int rc;
+	#define BLM(x) do { if ((rc = (x))) { d_koff.release(); k0.release(); k1.release(); v0.release(); v1.release(); uk.release(); um.release(); nruns.release(); tmp.release(); amb.release(); return rc; } } while (0)
+	#define BLMH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { BLM(fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_))); } } while (0)
+	BLM(d_koff.reserve((nC + 1) * 8)); BLM(k0.reserve(n_items * 8)); BLM(k1.reserve(n_items * 8)); BLM(v0.reserve(n_items * 2)); BLM(v1.reserve(n_items * 2));
+	BLM(nruns.reserve(16)); BLM(h->ent_mask.reserve((h->n_ent + 1) * 2)); BLM(amb.reserve((size_t)nC * 4 + 16));
+	BLMH(hipMemsetAsync(amb.p, 0, (size_t)nC * 4, h->stream));
+	BLMH(hipMemcpyAsync(d_koff.p, key_off.data(), (nC + 1) * 8, hipMemcpyHostToDevice, h->stream));
+	hipLaunchKernelGGL(k_extract_kmers, dim3(std::min<uint32_t>((nC * 16 + 255) / 256, (uint32_t)h->n_cu * 16)), dim3(256), 0, h->stream, h->ref.as<uint4>(),
+		h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_koff.as<uint64_t>(), nC, h->K, k0.as<unsigned long long>(), v0.as<uint16_t>(), amb.as<uint32_t>());
+	BLMH(hipGetLastError());
+	size_t tb = 0;
+	const int end_bit = 2 * h->K + 24;
+	hipcub::DoubleBuffer<unsigned long long> dk(k0.as<unsigned long long>(), k1.as<unsigned long long>());
+	hipcub::DoubleBuffer<uint16_t> dv(v0.as<uint16_t>(), v1.as<uint16_t>());
+	BLMH(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (int)n_items, 0, end_bit, h->stream));
+	BLM(tmp.reserve(tb));
+	BLMH(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, dk, dv, (int)n_items, 0, end_bit, h->stream));
+	// invalid slots carry key ~0, which after masking to end_bit sorts last (all ones) -- their run is simply never looked up
+	unsigned long long *skeys = dk.Current(); uint16_t *svals = dv.Current();
+	unsigned long long *ukeys = dk.Alternate(); uint16_t *umasks = dv.Alternate();
+	size_t tb2 = 0;
+	BLMH(hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, skeys, ukeys, svals, umasks, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
+	BLM(tmp.reserve(tb2));
+	BLMH(hipcub::DeviceReduce::ReduceByKey(tmp.p, tb2, skeys, ukeys, svals, umasks, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
+	uint32_t n_unique = 0;
+	BLMH(hipMemcpyAsync(&n_unique, nruns.p, 4, hipMemcpyDeviceToHost, h->stream));
+	BLMH(hipStreamSynchronize(h->stream));
+	hipLaunchKernelGGL(k_attach_masks, dim3((uint32_t)std::min<uint64_t>((h->n_ent + 255) / 256, (uint64_t)h->n_cu * 32)), dim3(256), 0, h->stream,
+		h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->n_ent, (uint32_t)(1ull << (2 * h->K)), ukeys, umasks, n_unique, amb.as<uint32_t>(), h->ent_mask.as<uint16_t>());
+	BLMH(hipGetLastError());
+	BLMH(hipStreamSynchronize(h->stream));
+	#undef BLM
+	#undef BLMH
+	d_koff.release(); k0.release(); k1.release(); v0.release(); v1.release(); uk.release(); um.release(); nruns.release(); tmp.release(); amb.release();
+	h->has_masks = true;
+	return 0;
+}
 
 extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clump_len, uint32_t n_clumps, uint32_t tot_refs,
                          const uint32_t *acx_lens, const void *acx_lists, int acx_fmt, int K,
@@ -303,6 +367,7 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 			INITCHK(hipMemcpy(h->bad.p, badlist, n_bad * sizeof(uint32_t), hipMemcpyHostToDevice));
 		}
 		h->has_acx = true; h->K = K; h->n_ent = tot;
+		if (!getenv("BHIP_NO_LANE_MASKS")) { int rcm = build_lane_masks(h, dst_off); if (rcm) { bhip_destroy(h); return rcm; } }
 	}
 	INITRC(ensure_lanes(h, 1));
 	*handle = h;
@@ -327,6 +392,7 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 		h->opt_prefilter_stride = (int)value; return BHIP_OK;
 	}
 	if (!strcmp(name, "two_stage")) { h->opt_two_stage = value != 0; return BHIP_OK; }
+	if (!strcmp(name, "lane_masks")) { h->opt_lane_masks = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "sweep_blocks")) { if (value < 1 || value > 8) return fail(BHIP_E_ARG, "sweep_blocks must be 1 .. 8"); h->opt_sweep_blocks = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "lanes")) {
 		if (value < 1 || value > 16) return fail(BHIP_E_ARG, "lanes must be 1 .. 16");
@@ -360,6 +426,14 @@ static void launch_prefix(Handle *h, Lane *L, hipStream_t st, int NWP, uint32_t 
 		h->tot_refs, L->wins.as<BhipWin>(), n_wins, (uint32_t)L->win_cap, &dc->col_sum, &dc->qlen_sum)
 	if (NWP == 1) LP(1); else if (NWP == 2) LP(2); else if (NWP == 3) LP(3); else if (NWP == 4) LP(4); else LP(6);
 	#undef LP
+}
+static void launch_prefix_task(Handle *h, Lane *L, hipStream_t st, int NWP, uint32_t grid, const uint32_t *n_tasks_dev, const uint32_t *qlist,
+		uint32_t *n_wins, Counters *dc) {
+	#define LT(N) hipLaunchKernelGGL(k_myers_prefix_task<N>, dim3(grid), dim3(64), 0, st, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, qlist, \
+		L->peqp.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
+		L->wins.as<BhipWin>(), n_wins, (uint32_t)L->win_cap, &dc->tcol_sum)
+	if (NWP == 1) LT(1); else if (NWP == 2) LT(2); else if (NWP == 3) LT(3); else if (NWP == 4) LT(4); else LT(6);
+	#undef LT
 }
 static void launch_window(Handle *h, Lane *L, hipStream_t wst, int cls, int NWP, uint32_t grid, const uint32_t *qlist, const uint32_t *n_wins, Counters *dc) {
 	#define LW(N) hipLaunchKernelGGL(k_myers_window<N>, dim3(grid), dim3(256), 0, wst, L->wins.as<BhipWin>(), n_wins, (uint32_t)L->win_cap, NWP, qlist, \
@@ -477,6 +551,46 @@ static int launch_prefilter(Handle *h, Lane *L, hipStream_t pf_st, const uint32_
 	return 0;
 }
 
+// lane-resolved prefilter: tasks (list position, reference lane) into L->tasks; queries whose table overflowed go through the
+// dense clump-level kernels into L->cand as (list position, clump) pairs
+static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, const uint32_t *d_qlist, uint32_t n_list, uint32_t *n_tasks_dev,
+                                 uint32_t *n_cand_dev, Counters *dc) {
+	int rc;
+	if ((rc = L->fb_list.reserve((size_t)n_list * 4 + 16))) return rc;
+	HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 4, st));
+	const uint32_t n_quads = (n_list + 3) / 4;
+	const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * 5);
+	hipLaunchKernelGGL(k_prefilter_mask, dim3(grid), dim3(64), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), d_qlist, n_list,
+		h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->ent_mask.as<uint16_t>(), h->K, h->bad.as<uint32_t>(), h->n_bad,
+		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, h->plan.as<uint32_t>(),
+		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum);
+	HIPCHK(hipGetLastError());
+	// dense fallback for overflowed queries (clump-level pairs)
+	const uint32_t *bad = h->bad.as<uint32_t>();
+	const bool narrow = h->st_maxlen < 255u + (uint32_t)h->K;
+	const size_t lds_w = ((size_t)(h->n_clumps + (narrow ? 3 : 1)) / (narrow ? 4 : 2)) * 4 + 1536u * 4 + 512u * 8 + 512u * 4 + 16;
+	const uint32_t nw32 = (h->n_clumps + 1) / 2;
+	if (lds_w <= 64 * 1024) {
+		const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / lds_w));
+		const uint32_t g2 = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * per_cu);
+		if (narrow) hipLaunchKernelGGL(k_prefilter_wave<uint8_t>, dim3(g2), dim3(64), lds_w, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, h->n_bad, L->cand.as<uint2>(),
+			(uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read, h->plan.as<uint32_t>(), L->fb_list.as<uint32_t>(), &dc->n_fb);
+		else hipLaunchKernelGGL(k_prefilter_wave<uint16_t>, dim3(g2), dim3(64), lds_w, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, h->n_bad, L->cand.as<uint2>(),
+			(uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read, h->plan.as<uint32_t>(), L->fb_list.as<uint32_t>(), &dc->n_fb);
+	} else {
+		uint32_t g2 = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * 2);
+		if ((rc = L->gcnt.reserve((size_t)g2 * nw32 * 4))) return rc;
+		hipLaunchKernelGGL(k_prefilter<false>, dim3(g2), dim3(256), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps,
+			L->gcnt.as<uint32_t>(), bad, h->n_bad, L->cand.as<uint2>(), (uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read,
+			L->fb_list.as<uint32_t>(), &dc->n_fb, h->plan.as<uint32_t>());
+	}
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
 static int ensure_lanes(Handle *h, uint32_t n) {
 	while (h->lanes.size() < n) { Lane *L = nullptr; int rc = lane_create(h, &L); if (rc) return rc; h->lanes.push_back(L); }
 	return 0;
@@ -552,6 +666,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	if ((rc = L->wide.reserve(L->raw_cap * sizeof(uint32_t)))) return rc;
 	if ((rc = L->scratch.reserve(L->scratch_cap * sizeof(uint32_t)))) return rc;
 	if ((rc = L->wins.reserve(L->win_cap * sizeof(BhipWin)))) return rc;
+	if ((rc = L->tasks.reserve(L->task_cap * sizeof(uint2)))) return rc;
 	for (int cls = 0; cls < kNumClasses; ++cls) if (L->npf[cls] + L->nex[cls]) {
 		if ((rc = L->peq.reserve((size_t)(L->npf[cls] + L->nex[cls]) * 16 * kClasses[cls] * 4))) return rc;
 		if ((rc = L->peqp.reserve((size_t)(L->npf[cls] + L->nex[cls]) * 16 * 6 * 4))) return rc;
@@ -595,12 +710,18 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		}
 		L->prefix_words = (uint32_t)NWP;
 		HIPCHK(hipEventRecord(ce[1], pf));
-		if (n_pf) if ((rc = launch_prefilter(h, L, pf, qlist, n_pf, L->cand.as<uint2>(), nullptr, (uint32_t)L->cand_cap, true, &dc->n_cand_cls[cls], dc))) return rc;
+		const bool masked = NWP && n_pf && h->has_masks && h->opt_lane_masks;
+		if (n_pf) {
+			if (masked) { if ((rc = launch_prefilter_mask(h, L, pf, qlist, n_pf, &dc->n_tasks_cls[cls], &dc->n_cand_cls[cls], dc))) return rc; }
+			else if ((rc = launch_prefilter(h, L, pf, qlist, n_pf, L->cand.as<uint2>(), nullptr, (uint32_t)L->cand_cap, true, &dc->n_cand_cls[cls], dc))) return rc;
+		}
+		L->masked = masked;
 		HIPCHK(hipEventRecord(ce[2], pf));
 		// column sweep on the sweep stream, behind this lane's prefilter
 		HIPCHK(hipStreamWaitEvent(sw, ce[2], 0));
 		HIPCHK(hipEventRecord(ce[6], sw));
 		if (n_pf) {
+			if (masked) launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 32, &dc->n_tasks_cls[cls], qlist, &dc->n_wins_cls[cls], dc);
 			if (NWP) launch_prefix(h, L, sw, NWP, grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, &dc->n_wins_cls[cls], dc);
 			else launch_myers(h, L, sw, cls, grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, L->raw.as<BhipRawHit>(),
 				&dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
@@ -685,6 +806,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			const Counters &c = L->hc;
 			for (int cls = 0; cls < kNumClasses; ++cls) {
 				if (c.n_cand_cls[cls] > L->cand_cap) { L->cand_cap = (uint64_t)c.n_cand_cls[cls] + c.n_cand_cls[cls] / 8 + 1024; retry = true; }
+				if (c.n_tasks_cls[cls] > L->task_cap) { L->task_cap = (uint64_t)c.n_tasks_cls[cls] + c.n_tasks_cls[cls] / 8 + 1024; retry = true; }
 				if (c.n_wins_cls[cls] > L->win_cap) { L->win_cap = (uint64_t)c.n_wins_cls[cls] + c.n_wins_cls[cls] / 8 + 1024; retry = true; }
 			}
 			if (c.n_raw > L->raw_cap) { L->raw_cap = (uint64_t)c.n_raw + c.n_raw / 8 + 1024; retry = true; }
@@ -721,11 +843,11 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			Lane *L = h->lanes[l];
 			if (!L->n_entries) continue;
 			const Counters &c = L->hc;
-			S.n_pairs += L->n_pairs_ex; S.n_columns += c.col_sum; S.n_raw_hits += c.n_raw; S.acx_entries_read += c.ent_read;
+			S.n_pairs += L->n_pairs_ex + c.unit_sum; S.n_columns += c.col_sum; S.n_task_columns += c.tcol_sum; S.n_raw_hits += c.n_raw; S.acx_entries_read += c.ent_read;
 			S.myers_launches += L->launches; S.n_window_columns += c.wcol_sum; qlen_sum += c.qlen_sum;
 			if (L->prefix_words) S.prefix_words = L->prefix_words;
 			for (int cls = 0; cls < kNumClasses; ++cls) {
-				S.n_pairs += c.n_cand_cls[cls]; S.n_windows += c.n_wins_cls[cls];
+				S.n_pairs += c.n_cand_cls[cls]; S.n_windows += c.n_wins_cls[cls]; S.n_lane_tasks += c.n_tasks_cls[cls];
 				if (!(L->npf[cls] + L->nex[cls])) continue;
 				hipEvent_t *ce = L->ev_cls[cls];
 				S.ms_peq += ev_ms(ce[0], ce[1]);

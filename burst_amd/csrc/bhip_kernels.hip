@@ -467,6 +467,219 @@ __global__ __launch_bounds__(64) void k_prefilter_hash(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Lane-resolved accelerator.  The .acx says which CLUMPS contain a word; at upload we also work out which of the 16
+// LANES of the clump contain it (a 16-bit mask per list entry), so that the prefilter can count seed words per reference
+// lane and hand only the lanes that can hold an alignment to the edit-distance kernels (2-3 lanes per candidate clump
+// instead of all 16).  k_extract_kmers emits (word << 24 | clump, 1 << lane) for every A/C/G/T-only K-mer of every lane,
+// a device radix sort + OR-reduce-by-key gives one mask per (word, clump), and k_attach_masks looks every .acx entry up.
+// Entries the extraction does not know (words the reference added by IUPAC expansion, burst.c:3368-3377) get 0xFFFF:
+// every lane, i.e. the clump-level behaviour.  Masks only ever add lanes, never drop one, so results are unchanged.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_extract_kmers(const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
+                                const uint64_t *__restrict__ key_off, uint32_t n_clumps, int K,
+                                unsigned long long *__restrict__ keys, uint16_t *__restrict__ vals, uint32_t *__restrict__ ambig_lanes) {
+	const uint64_t n_threads = (uint64_t)n_clumps * 16;
+	const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_threads; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t c = (uint32_t)(i >> 4), z = (uint32_t)(i & 15), L = clump_len[c], nchunks = (L + 31) >> 5;
+		const uint4 *rp = ref + ref_off[c] * 16 + z;
+		unsigned long long *kout = keys + key_off[c] + (uint64_t)z * L;
+		uint16_t *vout = vals + key_off[c] + (uint64_t)z * L;
+		uint32_t w = 0, run = 0, amb = 0;
+		for (uint32_t t = 0; t < nchunks; ++t) {
+			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
+			for (uint32_t k = 0; k < 32; ++k) {
+				const uint32_t pos = t * 32 + k;
+				if (pos >= L) break;
+				const uint32_t sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
+				amb |= sym > 4u;
+				run = (sym - 1u) < 4u ? run + 1 : 0;
+				w = ((w << 2) | ((sym - 1u) & 3u)) & wmask;
+				// the word ENDING at pos is stored in slot pos (slots 0..K-2 and words with other symbols are invalid)
+				kout[pos] = run >= (uint32_t)K ? (((unsigned long long)w << 24) | c) : ~0ull;
+				vout[pos] = (uint16_t)(1u << z);
+			}
+		}
+		// a lane with IUPAC / N symbols can match words it does not literally contain (the .acx lists them for the clump
+		// through the reference's expansion): such a lane takes part in every entry of its clump
+		if (amb) atomicOr(&ambig_lanes[c], 1u << z);
+	}
+}
+
+__global__ void k_attach_masks(const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, uint64_t n_ent, uint32_t n_words,
+                               const unsigned long long *__restrict__ ukeys, const uint16_t *__restrict__ umasks, uint32_t n_unique,
+                               const uint32_t *__restrict__ ambig_lanes, uint16_t *__restrict__ ent_mask) {
+	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n_ent; e += (uint64_t)gridDim.x * blockDim.x) {
+		// word of entry e: last w with acx_off[w] <= e
+		uint32_t lo = 0, hi = n_words;
+		while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (acx_off[mid] <= e) lo = mid; else hi = mid; }
+		const unsigned long long key = ((unsigned long long)lo << 24) | acx_ent[e];
+		uint32_t a = 0, b = n_unique;
+		while (a < b) { const uint32_t mid = a + ((b - a) >> 1); if (ukeys[mid] < key) a = mid + 1; else b = mid; }
+		const uint16_t m = (a < n_unique && ukeys[a] == key) ? umasks[a] : (uint16_t)0xFFFFu;
+		ent_mask[e] = (uint16_t)(m | ambig_lanes[acx_ent[e]]);
+	}
+}
+
+// Prefilter with per-lane counts.  Table slot = key (clump+1) + two 64-bit words of eight 8-bit counters (lanes 0-7,
+// 8-15); an entry adds 1 to the counter of every lane of its mask with at most two LDS 64-bit atomics.  Candidates are
+// (list position, reference lane) TASKS for k_myers_prefix_task.  Layout and flow otherwise as k_prefilter_hash.
+#define PFM_HT 256u
+#define PFM_TL 160u
+#define PFM_STAGE 768u
+__device__ __forceinline__ unsigned long long spread8(uint32_t m8) {   // bit i of m8 -> bit 8*i
+	unsigned long long x = m8;
+	x = (x | (x << 28)) & 0x0000000F0000000Full;
+	x = (x | (x << 14)) & 0x0003000300030003ull;
+	x = (x | (x << 7)) & 0x0101010101010101ull;
+	return x;
+}
+__global__ __launch_bounds__(64) void k_prefilter_mask(
+		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff,
+		const uint32_t *__restrict__ qlist, uint32_t n_list,
+		const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, const uint16_t *__restrict__ ent_mask, int K,
+		const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ clump_len, uint32_t tot_refs,
+		uint2 *__restrict__ tasks, uint32_t *__restrict__ n_tasks, uint32_t task_cap,
+		unsigned long long *__restrict__ ent_read, const uint32_t *__restrict__ plan,
+		uint32_t *__restrict__ fb_list, uint32_t *__restrict__ n_fb,
+		unsigned long long *__restrict__ unit_sum, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum) {
+	__shared__ uint32_t s_key[4][PFM_HT];
+	__shared__ unsigned long long s_cnt[4][PFM_HT][2];
+	__shared__ uint16_t s_tl[4][PFM_TL];
+	__shared__ uint2 s_stage[PFM_STAGE];
+	__shared__ uint32_t s_ctr[8];           // [g] touched count of group g, [4] staged
+	__shared__ uint32_t s_ovf[4];
+	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
+	const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
+	for (uint32_t i = lane; i < 4 * PFM_HT; i += 64) { (&s_key[0][0])[i] = 0; (&s_cnt[0][0][0])[2 * i] = 0; (&s_cnt[0][0][0])[2 * i + 1] = 0; }
+	if (lane < 8) s_ctr[lane] = 0;
+	if (lane < 4) s_ovf[lane] = 0;
+	__syncthreads();
+	unsigned long long my_ent = 0, my_units = 0, my_cols = 0, my_qlen = 0;
+
+	auto push = [&](uint32_t li, uint32_t refIx) {
+		const uint32_t pos = atomicAdd(&s_ctr[4], 1u);
+		if (pos < PFM_STAGE) s_stage[pos] = make_uint2(li, refIx);
+		else { const uint32_t gp = atomicAdd(n_tasks, 1u); if (gp < task_cap) tasks[gp] = make_uint2(li, refIx); }
+	};
+	auto flush = [&]() {
+		__syncthreads();
+		const uint32_t n = s_ctr[4] < PFM_STAGE ? s_ctr[4] : PFM_STAGE;
+		uint32_t base = 0;
+		if (n) {
+			if (lane == 0) base = atomicAdd(n_tasks, n);
+			base = __shfl(base, 0);
+			for (uint32_t i = lane; i < n; i += 64) if (base + i < task_cap) tasks[base + i] = s_stage[i];
+		}
+		__syncthreads();
+		if (lane == 0) s_ctr[4] = 0;
+		__syncthreads();
+	};
+	auto bump = [&](uint32_t tg, uint32_t c, uint32_t mask) {
+		const uint32_t key = c + 1u;
+		uint32_t slot = (c * 0x9E3779B1u) >> (32 - 8);
+		for (uint32_t probes = 0; probes < PFM_HT; ++probes, slot = (slot + 1) & (PFM_HT - 1)) {
+			uint32_t old = s_key[tg][slot];
+			if (old == 0) {
+				old = atomicCAS(&s_key[tg][slot], 0u, key);
+				if (old == 0) {
+					const uint32_t pos = atomicAdd(&s_ctr[tg], 1u);
+					if (pos < PFM_TL) s_tl[tg][pos] = (uint16_t)slot; else s_ovf[tg] = 1;
+					old = key;
+				}
+			}
+			if (old == key) {
+				if (mask & 0xFFu) atomicAdd(&s_cnt[tg][slot][0], spread8(mask & 0xFFu));
+				if (mask >> 8) atomicAdd(&s_cnt[tg][slot][1], spread8(mask >> 8));
+				return;
+			}
+		}
+		s_ovf[tg] = 1;
+	};
+
+	const uint32_t n_quads = (n_list + 3) >> 2;
+	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
+		const uint32_t li = quad * 4 + g;
+		const bool live = li < n_list;
+		uint32_t q = 0, len = 0, stride = 1, need = 0, nwords = 0;
+		uint64_t b = 0;
+		if (live) {
+			q = qlist ? qlist[li] : li;
+			b = qoff[q];
+			len = (uint32_t)(qoff[q + 1] - b);
+			if (len >= (uint32_t)K) { stride = plan[q] & 255u; need = plan[q] >> 8; nwords = (len - K) / stride + 1; }
+		}
+		uint32_t maxw = nwords;
+		#pragma unroll
+		for (int o = 32; o >= 1; o >>= 1) { const uint32_t t = __shfl_xor(maxw, o); maxw = t > maxw ? t : maxw; }
+		for (uint32_t base = 0; base < maxw; base += 16) {
+			const uint32_t j = base + gl, p = j * stride;
+			uint32_t w = 0, ok = live && j < nwords;
+			if (ok) for (int k = 0; k < K; ++k) {
+				const uint32_t c = qcodes[b + p + k];
+				ok &= (c - 1u) < 4u;
+				w = (w << 2) | ((c - 1u) & 3u);
+			}
+			w &= wmask;
+			uint32_t beg = 0, end = 0;
+			if (ok) { beg = acx_off[w]; end = acx_off[w + 1]; }
+			const uint32_t n = end - beg;
+			my_ent += n;
+			unsigned long long longm = __ballot(n > 48);
+			if (n <= 48) {
+				uint32_t e = beg;
+				for (; e + 4 <= end; e += 4) {
+					const uint32_t c0 = acx_ent[e], c1 = acx_ent[e + 1], c2 = acx_ent[e + 2], c3 = acx_ent[e + 3];
+					const uint32_t m0 = ent_mask[e], m1 = ent_mask[e + 1], m2 = ent_mask[e + 2], m3 = ent_mask[e + 3];
+					bump(g, c0, m0); bump(g, c1, m1); bump(g, c2, m2); bump(g, c3, m3);
+				}
+				for (; e < end; ++e) bump(g, acx_ent[e], ent_mask[e]);
+			}
+			while (longm) {
+				const int src = __builtin_ctzll(longm);
+				longm &= longm - 1;
+				const uint32_t lb = __shfl(beg, src), le = __shfl(end, src), tg = (uint32_t)src >> 4;
+				for (uint32_t e = lb + lane; e < le; e += 64) bump(tg, acx_ent[e], ent_mask[e]);
+			}
+		}
+		__syncthreads();
+		const uint32_t nt = s_ctr[g] < PFM_TL ? s_ctr[g] : PFM_TL;
+		const uint32_t ovf = s_ovf[g];
+		const uint32_t thr = need ? need : 1u;          // a lane is a candidate iff its count >= max(need, 1)
+		if (live && !ovf) {
+			for (uint32_t i = gl; i < nt; i += 16) {
+				const uint32_t slot = s_tl[g][i], c = s_key[g][slot] - 1u;
+				const unsigned long long lo = s_cnt[g][slot][0], hi = s_cnt[g][slot][1];
+				s_key[g][slot] = 0; s_cnt[g][slot][0] = 0; s_cnt[g][slot][1] = 0;
+				uint32_t any = 0;
+				#pragma unroll
+				for (uint32_t z = 0; z < 16; ++z) {
+					const uint32_t v = (uint32_t)(((z < 8 ? lo : hi) >> (8 * (z & 7))) & 255u);
+					const uint32_t refIx = c * 16 + z;
+					if (v >= thr && refIx < tot_refs) { push(li, refIx); any = 1; }
+				}
+				if (any) { ++my_units; my_cols += clump_len[c]; my_qlen += len; }
+			}
+			for (uint32_t i = gl; i < n_bad; i += 16) {        // burst.c:4136-4138, 4282-4283: every lane of the ambiguous clumps
+				const uint32_t c = bad[i];
+				for (uint32_t z = 0; z < 16; ++z) if (c * 16 + z < tot_refs) push(li, c * 16 + z);
+				++my_units; my_cols += clump_len[c]; my_qlen += len;
+			}
+		} else if (ovf) {
+			for (uint32_t i = gl; i < PFM_HT; i += 16) { s_key[g][i] = 0; s_cnt[g][i][0] = 0; s_cnt[g][i][1] = 0; }
+			if (live && gl == 0) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
+		}
+		__syncthreads();
+		if (gl == 0) { s_ctr[g] = 0; s_ovf[g] = 0; }
+		if (s_ctr[4] >= PFM_STAGE / 2) flush(); else __syncthreads();
+	}
+	flush();
+	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
+	if (my_units) { atomicAdd(unit_sum, my_units); atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Bit-parallel semi-global edit distance (Myers 1999 / Hyyro 2003), NW x 32-bit words per DP column.
 // State per (query, reference lane): vertical deltas Pv/Mv of the current column; the tracked score is
 // D[m][x] = min over start positions of the edit distance of the query against ref[..x], i.e. the last-row
@@ -761,6 +974,77 @@ __global__ __launch_bounds__(256) void k_myers_prefix2(
 		const uint64_t *, const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t, BhipWin *, uint32_t *, uint32_t, \
 		unsigned long long *, unsigned long long *);
 BHIP_INST_PREFIX2(1) BHIP_INST_PREFIX2(2) BHIP_INST_PREFIX2(3)
+
+// Stage A over lane TASKS (list position, reference lane) from k_prefilter_mask: one thread per task, each with its own
+// 16-row prefix table in LDS ([row][thread] layout: conflict-free for any symbol mix).  Same recurrence and flags as
+// k_myers_prefix.
+template <int NWP>
+__global__ __launch_bounds__(64) void k_myers_prefix_task(
+		const uint2 *__restrict__ tasks, const uint32_t *__restrict__ n_tasks_dev, uint32_t task_cap,
+		const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ peqp, const uint64_t *__restrict__ qoff,
+		const uint16_t *__restrict__ qemac,
+		const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
+		BhipWin *__restrict__ wins, uint32_t *__restrict__ n_wins, uint32_t win_cap, unsigned long long *__restrict__ tcol_sum) {
+	__shared__ uint32_t s_peq[16 * NWP][64];
+	const uint32_t tid = threadIdx.x;
+	uint32_t n = *n_tasks_dev;
+	if (n > task_cap) n = task_cap;
+	unsigned long long my_cols = 0;
+	for (uint32_t i0 = blockIdx.x * 64; i0 < n; i0 += gridDim.x * 64) {
+		const uint32_t i = i0 + tid;
+		const bool live = i < n;
+		uint2 tk = make_uint2(0, 0);
+		if (live) {
+			tk = tasks[i];
+			const uint32_t *src = peqp + (uint64_t)tk.x * 16 * NWP;
+			#pragma unroll
+			for (int r = 0; r < 16 * NWP; ++r) s_peq[r][tid] = src[r];
+		}
+		if (!live) continue;        // the table column is private to the thread: no barrier needed
+		const uint32_t li = tk.x, refIx = tk.y, c = refIx >> 4, z = refIx & 15;
+		const uint32_t q = qlist ? qlist[li] : li;
+		const uint32_t m = (uint32_t)(qoff[q + 1] - qoff[q]), E = qemac[q];
+		const uint32_t P = m < 32u * NWP ? m : 32u * NWP;
+		const uint32_t L = clump_len[c], nchunks = (L + 31) >> 5;
+		uint32_t fshift = 0;
+		while ((nchunks >> fshift) > 32) ++fshift;
+		uint32_t Pv[NWP], Mv[NWP];
+		#pragma unroll
+		for (int w = 0; w < NWP; ++w) {
+			const int lo = 32 * NWP - (int)P - 32 * w;
+			Pv[w] = lo <= 0 ? 0xFFFFFFFFu : (lo >= 32 ? 0u : (0xFFFFFFFFu << lo));
+			Mv[w] = 0;
+		}
+		int score = (int)P;
+		uint32_t flags = 0;
+		const uint4 *rp = ref + ref_off[c] * 16 + z;
+		for (uint32_t t = 0; t < nchunks; ++t) {
+			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
+			int cmin = 0x7FFFFFFF;
+			#pragma unroll
+			for (int k = 0; k < 32; ++k) {
+				const uint32_t sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
+				uint32_t Eq[NWP];
+				#pragma unroll
+				for (int w = 0; w < NWP; ++w) Eq[w] = s_peq[sym * NWP + w][tid];
+				myers_step<NWP>(Eq, Pv, Mv, score);
+				cmin = score < cmin ? score : cmin;
+			}
+			flags |= ((uint32_t)cmin <= E ? 1u : 0u) << (t >> fshift);
+		}
+		if (flags) {
+			const uint32_t pos = atomicAdd(n_wins, 1u);
+			if (pos < win_cap) { BhipWin w; w.li = li; w.refIx = refIx; w.flags = flags; wins[pos] = w; }
+		}
+		my_cols += L;
+	}
+	if (tcol_sum && my_cols) atomicAdd(tcol_sum, my_cols);
+}
+#define BHIP_INST_PREFIX_TASK(NWP) \
+	template __global__ void k_myers_prefix_task<NWP>(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *, \
+		const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *);
+BHIP_INST_PREFIX_TASK(1) BHIP_INST_PREFIX_TASK(2) BHIP_INST_PREFIX_TASK(3) BHIP_INST_PREFIX_TASK(4) BHIP_INST_PREFIX_TASK(6)
 
 template <int NW>
 __global__ __launch_bounds__(256) void k_myers_window(

@@ -27,7 +27,7 @@ static void add_stats(BhipStats *t, const BhipStats *s) {
 	t->n_hits += s->n_hits; t->acx_entries_read += s->acx_entries_read; t->bytes_algorithmic += s->bytes_algorithmic;
 	t->ms_h2d += s->ms_h2d; t->ms_prefilter += s->ms_prefilter; t->ms_peq += s->ms_peq; t->ms_myers += s->ms_myers;
 	t->ms_rescore += s->ms_rescore; t->ms_d2h += s->ms_d2h; t->ms_total += s->ms_total; t->myers_launches += s->myers_launches;
-	t->n_windows += s->n_windows; t->n_window_columns += s->n_window_columns; t->ms_myers_prefix += s->ms_myers_prefix;
+	t->n_windows += s->n_windows; t->n_window_columns += s->n_window_columns; t->n_lane_tasks += s->n_lane_tasks; t->n_task_columns += s->n_task_columns; t->ms_myers_prefix += s->ms_myers_prefix;
 	t->ms_myers_window += s->ms_myers_window; t->prefix_words = s->prefix_words;
 }
 

@@ -59,6 +59,8 @@ typedef struct BhipStats {
 	uint64_t bytes_algorithmic;/* per-launch algorithmic bytes of the myers kernel */
 	uint64_t n_windows;        /* reference lanes that passed the prefix stage of the two-stage edit distance */
 	uint64_t n_window_columns; /* columns swept by the full-length stage over those windows */
+	uint64_t n_lane_tasks;     /* (query, reference lane) tasks emitted by the lane-resolved prefilter (0 = clump-level path) */
+	uint64_t n_task_columns;   /* columns swept by the prefix stage over those tasks */
 	float ms_h2d, ms_prefilter, ms_peq, ms_myers, ms_rescore, ms_d2h, ms_total;
 	float ms_myers_prefix;     /* part of ms_myers spent in k_myers_prefix (the dominant kernel when the two-stage path runs) */
 	float ms_myers_window;     /* part of ms_myers spent in k_myers_window */
