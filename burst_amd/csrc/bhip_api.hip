@@ -37,10 +37,10 @@ template <int NW> __global__ void k_myers_window(const BhipWin *, const uint32_t
 	const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *,
 	unsigned long long *);
 __global__ void k_extract_kmers(const uint4 *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, int, unsigned long long *, uint16_t *, uint32_t *);
-__global__ void k_attach_masks(const uint32_t *, const uint32_t *, uint64_t, uint32_t, const unsigned long long *, const uint16_t *, uint32_t, const uint32_t *, uint16_t *);
-__global__ void k_prefilter_mask(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint16_t *, int,
+__global__ void k_attach_masks(const uint32_t *, const uint32_t *, uint64_t, uint32_t, const unsigned long long *, const uint16_t *, uint32_t, const uint32_t *, uint2 *);
+__global__ void k_prefilter_mask(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, const uint2 *, int,
 	const uint32_t *, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *, uint32_t *, uint32_t *,
-	unsigned long long *, unsigned long long *, unsigned long long *);
+	unsigned long long *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, uint32_t);
 template <int NWP> __global__ void k_myers_prefix_task(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *,
 	const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *);
 template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *,
@@ -225,13 +225,13 @@ static int build_lane_masks(Handle *h, const std::vector<uint64_t> &chunk_off) {
 	const uint64_t n_items = key_off[nC];
 	if (n_items == 0 || n_items >= 0x7FFFFFFFull || !h->n_ent) return 0;
 	size_t free_b = 0, total_b = 0;
-	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < 26.0 * (double)n_items + 3.0 * (double)h->n_ent) return 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < 26.0 * (double)n_items + 10.0 * (double)h->n_ent) return 0;
 	DBuf d_koff, k0, k1, v0, v1, uk, um, nruns, tmp, amb;
 	int rc;
 	#define BLM(x) do { if ((rc = (x))) { d_koff.release(); k0.release(); k1.release(); v0.release(); v1.release(); uk.release(); um.release(); nruns.release(); tmp.release(); amb.release(); return rc; } } while (0)
 	#define BLMH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { BLM(fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_))); } } while (0)
 	BLM(d_koff.reserve((nC + 1) * 8)); BLM(k0.reserve(n_items * 8)); BLM(k1.reserve(n_items * 8)); BLM(v0.reserve(n_items * 2)); BLM(v1.reserve(n_items * 2));
-	BLM(nruns.reserve(16)); BLM(h->ent_mask.reserve((h->n_ent + 1) * 2)); BLM(amb.reserve((size_t)nC * 4 + 16));
+	BLM(nruns.reserve(16)); BLM(h->ent_mask.reserve((h->n_ent + 1) * 8)); BLM(amb.reserve((size_t)nC * 4 + 16));
 	BLMH(hipMemsetAsync(amb.p, 0, (size_t)nC * 4, h->stream));
 	BLMH(hipMemcpyAsync(d_koff.p, key_off.data(), (nC + 1) * 8, hipMemcpyHostToDevice, h->stream));
 	hipLaunchKernelGGL(k_extract_kmers, dim3(std::min<uint32_t>((nC * 16 + 255) / 256, (uint32_t)h->n_cu * 16)), dim3(256), 0, h->stream, h->ref.as<uint4>(),
@@ -255,7 +255,7 @@ static int build_lane_masks(Handle *h, const std::vector<uint64_t> &chunk_off) {
 	BLMH(hipMemcpyAsync(&n_unique, nruns.p, 4, hipMemcpyDeviceToHost, h->stream));
 	BLMH(hipStreamSynchronize(h->stream));
 	hipLaunchKernelGGL(k_attach_masks, dim3((uint32_t)std::min<uint64_t>((h->n_ent + 255) / 256, (uint64_t)h->n_cu * 32)), dim3(256), 0, h->stream,
-		h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->n_ent, (uint32_t)(1ull << (2 * h->K)), ukeys, umasks, n_unique, amb.as<uint32_t>(), h->ent_mask.as<uint16_t>());
+		h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->n_ent, (uint32_t)(1ull << (2 * h->K)), ukeys, umasks, n_unique, amb.as<uint32_t>(), h->ent_mask.as<uint2>());
 	BLMH(hipGetLastError());
 	BLMH(hipStreamSynchronize(h->stream));
 	#undef BLM
@@ -559,11 +559,11 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, const uint3
 	if ((rc = L->fb_list.reserve((size_t)n_list * 4 + 16))) return rc;
 	HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 4, st));
 	const uint32_t n_quads = (n_list + 3) / 4;
-	const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * 5);
+	const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * 6);
 	hipLaunchKernelGGL(k_prefilter_mask, dim3(grid), dim3(64), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), d_qlist, n_list,
-		h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->ent_mask.as<uint16_t>(), h->K, h->bad.as<uint32_t>(), h->n_bad,
+		h->acx_off.as<uint32_t>(), h->ent_mask.as<uint2>(), h->K, h->bad.as<uint32_t>(), h->n_bad,
 		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, h->plan.as<uint32_t>(),
-		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum);
+		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, L->cand.as<uint2>(), n_cand_dev, (uint32_t)L->cand_cap);
 	HIPCHK(hipGetLastError());
 	// dense fallback for overflowed queries (clump-level pairs)
 	const uint32_t *bad = h->bad.as<uint32_t>();

@@ -509,7 +509,7 @@ __global__ void k_extract_kmers(const uint4 *__restrict__ ref, const uint64_t *_
 
 __global__ void k_attach_masks(const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, uint64_t n_ent, uint32_t n_words,
                                const unsigned long long *__restrict__ ukeys, const uint16_t *__restrict__ umasks, uint32_t n_unique,
-                               const uint32_t *__restrict__ ambig_lanes, uint16_t *__restrict__ ent_mask) {
+                               const uint32_t *__restrict__ ambig_lanes, uint2 *__restrict__ ent_mask) {   // (clump, lane mask) records
 	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n_ent; e += (uint64_t)gridDim.x * blockDim.x) {
 		// word of entry e: last w with acx_off[w] <= e
 		uint32_t lo = 0, hi = n_words;
@@ -518,16 +518,24 @@ __global__ void k_attach_masks(const uint32_t *__restrict__ acx_off, const uint3
 		uint32_t a = 0, b = n_unique;
 		while (a < b) { const uint32_t mid = a + ((b - a) >> 1); if (ukeys[mid] < key) a = mid + 1; else b = mid; }
 		const uint16_t m = (a < n_unique && ukeys[a] == key) ? umasks[a] : (uint16_t)0xFFFFu;
-		ent_mask[e] = (uint16_t)(m | ambig_lanes[acx_ent[e]]);
+		ent_mask[e] = make_uint2(acx_ent[e], (uint32_t)(m | ambig_lanes[acx_ent[e]]) & 0xFFFFu);
 	}
 }
 
-// Prefilter with per-lane counts.  Table slot = key (clump+1) + two 64-bit words of eight 8-bit counters (lanes 0-7,
-// 8-15); an entry adds 1 to the counter of every lane of its mask with at most two LDS 64-bit atomics.  Candidates are
-// (list position, reference lane) TASKS for k_myers_prefix_task.  Layout and flow otherwise as k_prefilter_hash.
-#define PFM_HT 256u
-#define PFM_TL 160u
-#define PFM_STAGE 768u
+// Prefilter with per-lane counts, in two passes over the query's .acx lists so that the wide per-lane counters are
+// touched only for clumps that can matter:
+//   pass 1  clump-level counts exactly as k_prefilter_hash (slot = (clump+1) << 8 | count);
+//   select  clumps with count >= need become "candidates" (a clump-level count below need implies every lane is below);
+//           the slot's low byte is re-used for the candidate index, all other touched slots keep their key (probe chains
+//           stay intact) with a zero byte;
+//   pass 2  the lists are walked again (L2-resident by now); entries of candidate clumps add their 16-bit lane mask into
+//           sixteen 8-bit lane counters (two 64-bit LDS atomics, ~3 % of the entries);
+//   emit    (list position, reference lane) TASKS for lanes with count >= need -> k_myers_prefix_task.
+// More candidates than PFM_CAND in one query: the surplus clumps are emitted as clump-level pairs (16-lane kernel).
+#define PFM_HT 1024u
+#define PFM_TL 448u
+#define PFM_STAGE 512u
+#define PFM_CAND 24u
 __device__ __forceinline__ unsigned long long spread8(uint32_t m8) {   // bit i of m8 -> bit 8*i
 	unsigned long long x = m8;
 	x = (x | (x << 28)) & 0x0000000F0000000Full;
@@ -538,22 +546,25 @@ __device__ __forceinline__ unsigned long long spread8(uint32_t m8) {   // bit i 
 __global__ __launch_bounds__(64) void k_prefilter_mask(
 		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff,
 		const uint32_t *__restrict__ qlist, uint32_t n_list,
-		const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, const uint16_t *__restrict__ ent_mask, int K,
+		const uint32_t *__restrict__ acx_off, const uint2 *__restrict__ ent, int K,   // ent = (clump, lane mask) records
 		const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ clump_len, uint32_t tot_refs,
 		uint2 *__restrict__ tasks, uint32_t *__restrict__ n_tasks, uint32_t task_cap,
 		unsigned long long *__restrict__ ent_read, const uint32_t *__restrict__ plan,
 		uint32_t *__restrict__ fb_list, uint32_t *__restrict__ n_fb,
-		unsigned long long *__restrict__ unit_sum, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum) {
-	__shared__ uint32_t s_key[4][PFM_HT];
-	__shared__ unsigned long long s_cnt[4][PFM_HT][2];
+		unsigned long long *__restrict__ unit_sum, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum,
+		uint2 *__restrict__ pairs, uint32_t *__restrict__ n_pairs, uint32_t pair_cap) {
+	__shared__ uint32_t s_tab[4][PFM_HT];
 	__shared__ uint16_t s_tl[4][PFM_TL];
+	__shared__ unsigned long long s_cc[4][PFM_CAND][2];
+	__shared__ uint32_t s_cclump[4][PFM_CAND];
 	__shared__ uint2 s_stage[PFM_STAGE];
-	__shared__ uint32_t s_ctr[8];           // [g] touched count of group g, [4] staged
+	__shared__ uint32_t s_ctr[12];          // [g] touched count, [4] staged, [5+g] candidates of group g
 	__shared__ uint32_t s_ovf[4];
 	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
 	const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
-	for (uint32_t i = lane; i < 4 * PFM_HT; i += 64) { (&s_key[0][0])[i] = 0; (&s_cnt[0][0][0])[2 * i] = 0; (&s_cnt[0][0][0])[2 * i + 1] = 0; }
-	if (lane < 8) s_ctr[lane] = 0;
+	for (uint32_t i = lane; i < 4 * PFM_HT; i += 64) (&s_tab[0][0])[i] = 0;
+	for (uint32_t i = lane; i < 4 * PFM_CAND * 2; i += 64) (&s_cc[0][0][0])[i] = 0;
+	if (lane < 12) s_ctr[lane] = 0;
 	if (lane < 4) s_ovf[lane] = 0;
 	__syncthreads();
 	unsigned long long my_ent = 0, my_units = 0, my_cols = 0, my_qlen = 0;
@@ -576,26 +587,40 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 		if (lane == 0) s_ctr[4] = 0;
 		__syncthreads();
 	};
-	auto bump = [&](uint32_t tg, uint32_t c, uint32_t mask) {
-		const uint32_t key = c + 1u;
-		uint32_t slot = (c * 0x9E3779B1u) >> (32 - 8);
+	auto bump = [&](uint32_t tg, uint32_t c) {           // pass 1: insert or increment
+		const uint32_t key = (c + 1u) << 8;
+		uint32_t slot = (c * 0x9E3779B1u) >> (32 - 10);
+		uint32_t *tab = s_tab[tg];
 		for (uint32_t probes = 0; probes < PFM_HT; ++probes, slot = (slot + 1) & (PFM_HT - 1)) {
-			uint32_t old = s_key[tg][slot];
+			uint32_t old = tab[slot];
 			if (old == 0) {
-				old = atomicCAS(&s_key[tg][slot], 0u, key);
+				old = atomicCAS(&tab[slot], 0u, key | 1u);
 				if (old == 0) {
 					const uint32_t pos = atomicAdd(&s_ctr[tg], 1u);
 					if (pos < PFM_TL) s_tl[tg][pos] = (uint16_t)slot; else s_ovf[tg] = 1;
-					old = key;
+					return;
 				}
 			}
-			if (old == key) {
-				if (mask & 0xFFu) atomicAdd(&s_cnt[tg][slot][0], spread8(mask & 0xFFu));
-				if (mask >> 8) atomicAdd(&s_cnt[tg][slot][1], spread8(mask >> 8));
+			if ((old & 0xFFFFFF00u) == key) { atomicAdd(&tab[slot], 1u); return; }
+		}
+		s_ovf[tg] = 1;
+	};
+	auto lanes_add = [&](uint32_t tg, uint32_t c, uint32_t mask) {   // pass 2: only candidate clumps have a non-zero low byte
+		const uint32_t key = (c + 1u) << 8;
+		uint32_t slot = (c * 0x9E3779B1u) >> (32 - 10);
+		const uint32_t *tab = s_tab[tg];
+		for (uint32_t probes = 0; probes < PFM_HT; ++probes, slot = (slot + 1) & (PFM_HT - 1)) {
+			const uint32_t v = tab[slot];
+			if (v == 0) return;
+			if ((v & 0xFFFFFF00u) == key) {
+				const uint32_t ci = v & 255u;
+				if (ci) {
+					if (mask & 0xFFu) atomicAdd(&s_cc[tg][ci - 1][0], spread8(mask & 0xFFu));
+					if (mask >> 8) atomicAdd(&s_cc[tg][ci - 1][1], spread8(mask >> 8));
+				}
 				return;
 			}
 		}
-		s_ovf[tg] = 1;
 	};
 
 	const uint32_t n_quads = (n_list + 3) >> 2;
@@ -613,8 +638,8 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 		uint32_t maxw = nwords;
 		#pragma unroll
 		for (int o = 32; o >= 1; o >>= 1) { const uint32_t t = __shfl_xor(maxw, o); maxw = t > maxw ? t : maxw; }
-		for (uint32_t base = 0; base < maxw; base += 16) {
-			const uint32_t j = base + gl, p = j * stride;
+		auto word_range = [&](uint32_t j, uint32_t &beg, uint32_t &end) {
+			const uint32_t p = j * stride;
 			uint32_t w = 0, ok = live && j < nwords;
 			if (ok) for (int k = 0; k < K; ++k) {
 				const uint32_t c = qcodes[b + p + k];
@@ -622,36 +647,86 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 				w = (w << 2) | ((c - 1u) & 3u);
 			}
 			w &= wmask;
-			uint32_t beg = 0, end = 0;
+			beg = end = 0;
 			if (ok) { beg = acx_off[w]; end = acx_off[w + 1]; }
+		};
+		// ---- pass 1: clump-level counts
+		uint32_t beg0 = 0, end0 = 0;      // range of the first word of this lane, reused by pass 2 when one pass covers the query
+		for (uint32_t base = 0; base < maxw; base += 16) {
+			uint32_t beg, end;
+			word_range(base + gl, beg, end);
+			if (base == 0) { beg0 = beg; end0 = end; }
 			const uint32_t n = end - beg;
 			my_ent += n;
 			unsigned long long longm = __ballot(n > 48);
 			if (n <= 48) {
 				uint32_t e = beg;
 				for (; e + 4 <= end; e += 4) {
-					const uint32_t c0 = acx_ent[e], c1 = acx_ent[e + 1], c2 = acx_ent[e + 2], c3 = acx_ent[e + 3];
-					const uint32_t m0 = ent_mask[e], m1 = ent_mask[e + 1], m2 = ent_mask[e + 2], m3 = ent_mask[e + 3];
-					bump(g, c0, m0); bump(g, c1, m1); bump(g, c2, m2); bump(g, c3, m3);
+					const uint2 r0 = ent[e], r1 = ent[e + 1], r2 = ent[e + 2], r3 = ent[e + 3];
+					bump(g, r0.x); bump(g, r1.x); bump(g, r2.x); bump(g, r3.x);
 				}
-				for (; e < end; ++e) bump(g, acx_ent[e], ent_mask[e]);
+				for (; e < end; ++e) bump(g, ent[e].x);
 			}
 			while (longm) {
 				const int src = __builtin_ctzll(longm);
 				longm &= longm - 1;
 				const uint32_t lb = __shfl(beg, src), le = __shfl(end, src), tg = (uint32_t)src >> 4;
-				for (uint32_t e = lb + lane; e < le; e += 64) bump(tg, acx_ent[e], ent_mask[e]);
+				for (uint32_t e = lb + lane; e < le; e += 64) bump(tg, ent[e].x);
 			}
 		}
 		__syncthreads();
+		// ---- select candidates
 		const uint32_t nt = s_ctr[g] < PFM_TL ? s_ctr[g] : PFM_TL;
 		const uint32_t ovf = s_ovf[g];
-		const uint32_t thr = need ? need : 1u;          // a lane is a candidate iff its count >= max(need, 1)
+		const uint32_t thr = need ? need : 1u;          // a lane (hence its clump) is a candidate iff count >= max(need, 1)
 		if (live && !ovf) {
 			for (uint32_t i = gl; i < nt; i += 16) {
-				const uint32_t slot = s_tl[g][i], c = s_key[g][slot] - 1u;
-				const unsigned long long lo = s_cnt[g][slot][0], hi = s_cnt[g][slot][1];
-				s_key[g][slot] = 0; s_cnt[g][slot][0] = 0; s_cnt[g][slot][1] = 0;
+				const uint32_t slot = s_tl[g][i], v = s_tab[g][slot];
+				uint32_t tag = 0;
+				if ((v & 255u) >= thr) {
+					const uint32_t ci = atomicAdd(&s_ctr[5 + g], 1u);
+					const uint32_t c = (v >> 8) - 1u;
+					if (ci < PFM_CAND) { tag = ci + 1; s_cclump[g][ci] = c; }
+					else {   // too many candidate clumps for the lane counters: hand the clump to the 16-lane kernel
+						const uint32_t gp = atomicAdd(n_pairs, 1u);
+						if (gp < pair_cap) pairs[gp] = make_uint2(li, c);
+					}
+				}
+				s_tab[g][slot] = (v & 0xFFFFFF00u) | tag;
+			}
+		}
+		__syncthreads();
+		// ---- pass 2: lane counters of the candidate clumps
+		const uint32_t ncand = s_ctr[5 + g] < PFM_CAND ? s_ctr[5 + g] : PFM_CAND;
+		const bool any_cand = __any(live && !ovf && ncand > 0);
+		if (any_cand) for (uint32_t base = 0; base < maxw; base += 16) {
+			uint32_t beg = beg0, end = end0;
+			if (base) word_range(base + gl, beg, end);
+			if (ovf || !ncand) beg = end = 0;
+			const uint32_t n = end - beg;
+			unsigned long long longm = __ballot(n > 48);
+			if (n <= 48) {
+				uint32_t e = beg;
+				for (; e + 4 <= end; e += 4) {
+					const uint2 r0 = ent[e], r1 = ent[e + 1], r2 = ent[e + 2], r3 = ent[e + 3];
+					lanes_add(g, r0.x, r0.y); lanes_add(g, r1.x, r1.y); lanes_add(g, r2.x, r2.y); lanes_add(g, r3.x, r3.y);
+				}
+				for (; e < end; ++e) { const uint2 r = ent[e]; lanes_add(g, r.x, r.y); }
+			}
+			while (longm) {
+				const int src = __builtin_ctzll(longm);
+				longm &= longm - 1;
+				const uint32_t lb = __shfl(beg, src), le = __shfl(end, src), tg = (uint32_t)src >> 4;
+				for (uint32_t e = lb + lane; e < le; e += 64) { const uint2 r = ent[e]; lanes_add(tg, r.x, r.y); }
+			}
+		}
+		__syncthreads();
+		// ---- emit tasks, clear
+		if (live && !ovf) {
+			for (uint32_t i = gl; i < ncand; i += 16) {
+				const uint32_t c = s_cclump[g][i];
+				const unsigned long long lo = s_cc[g][i][0], hi = s_cc[g][i][1];
+				s_cc[g][i][0] = 0; s_cc[g][i][1] = 0;
 				uint32_t any = 0;
 				#pragma unroll
 				for (uint32_t z = 0; z < 16; ++z) {
@@ -661,17 +736,19 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 				}
 				if (any) { ++my_units; my_cols += clump_len[c]; my_qlen += len; }
 			}
+			for (uint32_t i = gl; i < nt; i += 16) s_tab[g][s_tl[g][i]] = 0;
 			for (uint32_t i = gl; i < n_bad; i += 16) {        // burst.c:4136-4138, 4282-4283: every lane of the ambiguous clumps
 				const uint32_t c = bad[i];
 				for (uint32_t z = 0; z < 16; ++z) if (c * 16 + z < tot_refs) push(li, c * 16 + z);
 				++my_units; my_cols += clump_len[c]; my_qlen += len;
 			}
 		} else if (ovf) {
-			for (uint32_t i = gl; i < PFM_HT; i += 16) { s_key[g][i] = 0; s_cnt[g][i][0] = 0; s_cnt[g][i][1] = 0; }
+			for (uint32_t i = gl; i < PFM_HT; i += 16) s_tab[g][i] = 0;
+			for (uint32_t i = gl; i < PFM_CAND; i += 16) { s_cc[g][i][0] = 0; s_cc[g][i][1] = 0; }
 			if (live && gl == 0) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
 		}
 		__syncthreads();
-		if (gl == 0) { s_ctr[g] = 0; s_ovf[g] = 0; }
+		if (gl == 0) { s_ctr[g] = 0; s_ctr[5 + g] = 0; s_ovf[g] = 0; }
 		if (s_ctr[4] >= PFM_STAGE / 2) flush(); else __syncthreads();
 	}
 	flush();
