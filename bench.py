@@ -182,6 +182,15 @@ def main():
     else:
         total_reads = qs.n_reads
 
+    if rank == 0 and os.environ.get("BHIP_PROF"):      # library built with EXTRA_HIPFLAGS=-DPFM_PROF: wave-cycles per prefilter phase
+        import ctypes
+        from burst_amd import capi as _capi
+        lib = _capi.lib()
+        if hasattr(lib, "bhip_debug_prof"):
+            arr = (ctypes.c_ulonglong * 8)()
+            lib.bhip_debug_prof(arr, 1)
+            tot = float(sum(arr)) or 1.0
+            log("[bench] prefilter phase share: " + " ".join("%d:%.1f%%" % (i, 100.0 * v / tot) for i, v in enumerate(arr)) + "  total wave-cycles %.3g" % tot)
     if rank == 0:
         st = per_step[-1]
         two_stage = st["prefix_words"] > 0

@@ -38,9 +38,10 @@ template <int NW> __global__ void k_myers_window(const BhipWin *, const uint32_t
 	unsigned long long *);
 __global__ void k_extract_kmers(const uint4 *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, int, unsigned long long *, uint16_t *, uint32_t *);
 __global__ void k_attach_masks(const uint32_t *, const uint32_t *, uint64_t, uint32_t, const unsigned long long *, const uint16_t *, uint32_t, const uint32_t *, uint2 *);
-__global__ void k_prefilter_mask(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, const uint2 *, int,
-	const uint32_t *, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *, uint32_t *, uint32_t *,
-	unsigned long long *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, uint32_t);
+__global__ void k_prefilter_mask(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *,
+	uint2 *, uint32_t *, uint32_t);
+__global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, int, const uint32_t *, uint32_t, uint2 *, uint2 *);
 template <int NWP> __global__ void k_myers_prefix_task(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *,
 	const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *);
 template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *,
@@ -110,10 +111,10 @@ struct Lane {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev_cls[kNumClasses][8];   // per class: 0 start, 1 peq done, 2 prefilter done, 3 sweep(pf) done, 4 sweep(ex) done, 5 window done
 	hipEvent_t ev_rs[2];
-	DBuf qlist_cls[kNumClasses], peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters, tasks;
+	DBuf qlist_cls[kNumClasses], peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters, tasks, ranges, hdr;
 	uint64_t task_cap = 1 << 20;
 	uint64_t cand_cap = 1 << 18, raw_cap = 1 << 18, win_cap = 1 << 20, scratch_cap = 1 << 18;
-	uint32_t npf[kNumClasses] = {0}, nex[kNumClasses] = {0}, maxE[kNumClasses] = {0}, maxlen = 0, n_entries = 0;
+	uint32_t npf[kNumClasses] = {0}, nex[kNumClasses] = {0}, maxE[kNumClasses] = {0}, maxwords[kNumClasses] = {0}, maxlen = 0, n_entries = 0;
 	Counters *hc_pinned = nullptr;        // pinned, so that the read-back of the counters does not block the enqueueing thread
 	Counters hc;
 	uint32_t launches = 0, prefix_words = 0;
@@ -166,7 +167,7 @@ extern "C" int bhip_abi_version(void) { return BHIP_ABI_VERSION; }
 static void lane_destroy(Lane *L) {
 	if (!L) return;
 	if (L->stream) (void)hipStreamSynchronize(L->stream);
-	DBuf *all[] = {&L->peq, &L->peqp, &L->cand, &L->candcnt, &L->wins, &L->raw, &L->wide, &L->scratch, &L->fb_list, &L->gcnt, &L->counters, &L->tasks};
+	DBuf *all[] = {&L->peq, &L->peqp, &L->cand, &L->candcnt, &L->wins, &L->raw, &L->wide, &L->scratch, &L->fb_list, &L->gcnt, &L->counters, &L->tasks, &L->ranges, &L->hdr};
 	for (DBuf *b : all) b->release();
 	for (auto &b : L->qlist_cls) b.release();
 	for (auto &ce : L->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
@@ -553,16 +554,22 @@ static int launch_prefilter(Handle *h, Lane *L, hipStream_t pf_st, const uint32_
 
 // lane-resolved prefilter: tasks (list position, reference lane) into L->tasks; queries whose table overflowed go through the
 // dense clump-level kernels into L->cand as (list position, clump) pairs
-static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, const uint32_t *d_qlist, uint32_t n_list, uint32_t *n_tasks_dev,
+static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, const uint32_t *d_qlist, uint32_t n_list, uint32_t maxwords, uint32_t *n_tasks_dev,
                                  uint32_t *n_cand_dev, Counters *dc) {
 	int rc;
 	if ((rc = L->fb_list.reserve((size_t)n_list * 4 + 16))) return rc;
 	HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 4, st));
+	const uint32_t W16 = std::max<uint32_t>(16u, (maxwords + 15u) & ~15u);
+	if ((rc = L->ranges.reserve((size_t)n_list * W16 * 8 + 16))) return rc;
+	if ((rc = L->hdr.reserve((size_t)n_list * 8 + 16))) return rc;
+	const uint64_t n_thr = (uint64_t)n_list * W16;
+	hipLaunchKernelGGL(k_seed_ranges, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), d_qlist, n_list,
+		h->acx_off.as<uint32_t>(), h->K, h->plan.as<uint32_t>(), W16, L->ranges.as<uint2>(), L->hdr.as<uint2>());
 	const uint32_t n_quads = (n_list + 3) / 4;
 	const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * 6);
-	hipLaunchKernelGGL(k_prefilter_mask, dim3(grid), dim3(64), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), d_qlist, n_list,
-		h->acx_off.as<uint32_t>(), h->ent_mask.as<uint2>(), h->K, h->bad.as<uint32_t>(), h->n_bad,
-		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, h->plan.as<uint32_t>(),
+	hipLaunchKernelGGL(k_prefilter_mask, dim3(grid), dim3(64), 0, st, L->ranges.as<uint2>(), L->hdr.as<uint2>(), W16, n_list,
+		h->ent_mask.as<uint2>(), h->bad.as<uint32_t>(), h->n_bad,
+		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read,
 		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, L->cand.as<uint2>(), n_cand_dev, (uint32_t)L->cand_cap);
 	HIPCHK(hipGetLastError());
 	// dense fallback for overflowed queries (clump-level pairs)
@@ -617,7 +624,7 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 	// host-side routing: lane by shared slot, class by length, prefilter vs exhaustive (entries nobody can guarantee a k-mer for)
 	std::vector<std::vector<uint32_t>> lists((size_t)nl * kNumClasses * 2);
 	std::vector<uint32_t> plan(n_q, 1u);
-	for (uint32_t l = 0; l < nl; ++l) { Lane *L = h->lanes[l]; for (int c = 0; c < kNumClasses; ++c) L->npf[c] = L->nex[c] = L->maxE[c] = 0; L->maxlen = 0; L->n_entries = 0; }
+	for (uint32_t l = 0; l < nl; ++l) { Lane *L = h->lanes[l]; for (int c = 0; c < kNumClasses; ++c) L->npf[c] = L->nex[c] = L->maxE[c] = L->maxwords[c] = 0; L->maxlen = 0; L->n_entries = 0; }
 	for (uint32_t i = 0; i < n_q; ++i) {
 		const uint64_t len = q_off[i + 1] - q_off[i];
 		if (len == 0) continue;
@@ -635,6 +642,7 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 		lists[((size_t)l * kNumClasses + cls) * 2 + ex].push_back(i);
 		Lane *L = h->lanes[l];
 		L->maxE[cls] = std::max<uint32_t>(L->maxE[cls], q_emac[i]);
+		if (!ex && len >= (uint64_t)h->K) L->maxwords[cls] = std::max<uint32_t>(L->maxwords[cls], (uint32_t)((len - h->K) / (plan[i] & 255u) + 1));
 		L->maxlen = std::max<uint32_t>(L->maxlen, (uint32_t)len);
 		++L->n_entries;
 	}
@@ -712,7 +720,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		HIPCHK(hipEventRecord(ce[1], pf));
 		const bool masked = NWP && n_pf && h->has_masks && h->opt_lane_masks;
 		if (n_pf) {
-			if (masked) { if ((rc = launch_prefilter_mask(h, L, pf, qlist, n_pf, &dc->n_tasks_cls[cls], &dc->n_cand_cls[cls], dc))) return rc; }
+			if (masked) { if ((rc = launch_prefilter_mask(h, L, pf, qlist, n_pf, L->maxwords[cls], &dc->n_tasks_cls[cls], &dc->n_cand_cls[cls], dc))) return rc; }
 			else if ((rc = launch_prefilter(h, L, pf, qlist, n_pf, L->cand.as<uint2>(), nullptr, (uint32_t)L->cand_cap, true, &dc->n_cand_cls[cls], dc))) return rc;
 		}
 		L->masked = masked;

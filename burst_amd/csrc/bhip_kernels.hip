@@ -532,6 +532,12 @@ __global__ void k_attach_masks(const uint32_t *__restrict__ acx_off, const uint3
 //           sixteen 8-bit lane counters (two 64-bit LDS atomics, ~3 % of the entries);
 //   emit    (list position, reference lane) TASKS for lanes with count >= need -> k_myers_prefix_task.
 // More candidates than PFM_CAND in one query: the surplus clumps are emitted as clump-level pairs (16-lane kernel).
+#ifdef PFM_PROF
+__device__ unsigned long long g_pfm_prof[8];
+#define PFM_T(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = wall_clock64(); if (lane == 0) my_t[i] += t_ - t_last; t_last = t_; } while (0)
+#else
+#define PFM_T(i) do {} while (0)
+#endif
 #define PFM_HT 1024u
 #define PFM_TL 448u
 #define PFM_STAGE 512u
@@ -543,16 +549,77 @@ __device__ __forceinline__ unsigned long long spread8(uint32_t m8) {   // bit i 
 	x = (x | (x << 7)) & 0x0101010101010101ull;
 	return x;
 }
+// Four hash-table updates in lock step (independent LDS round trips overlap).  CAS first: most updates of a
+// query are first sightings of a clump, which complete in one round trip; a key hit costs one more (no-return) add.
+__device__ __forceinline__ void pfm_bump4(uint32_t *tab, uint32_t *dummy, const uint32_t (&c)[4], const bool (&valid)[4], uint32_t (&slot)[4], bool (&ins)[4], bool &fail) {
+	uint32_t key[4]; bool act[4];
+	#pragma unroll
+	for (int k = 0; k < 4; ++k) { key[k] = (c[k] + 1u) << 8; slot[k] = (c[k] * 0x9E3779B1u) >> (32 - 10); act[k] = valid[k]; ins[k] = false; }
+	bool any = valid[0] | valid[1] | valid[2] | valid[3];
+	for (uint32_t probes = 0; any && probes < PFM_HT; ++probes) {
+		uint32_t old[4];
+		// finished chains compare-and-swap a private dummy word with a value that never matches: no branches between the
+		// four LDS round trips, so they are in flight together
+		#pragma unroll
+		for (int k = 0; k < 4; ++k) old[k] = atomicCAS(act[k] ? &tab[slot[k]] : dummy, act[k] ? 0u : 0xFFFFFFFFu, key[k] | 1u);
+		any = false;
+		#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const bool hit = act[k] && (old[k] & 0xFFFFFF00u) == key[k];
+			const bool fresh = act[k] && old[k] == 0;
+			const bool step = act[k] && !hit && !fresh;
+			if (hit) atomicAdd(&tab[slot[k]], 1u);
+			ins[k] |= fresh;
+			slot[k] = step ? (slot[k] + 1) & (PFM_HT - 1) : slot[k];
+			act[k] = step;
+			any |= step;
+		}
+	}
+	fail = any;
+}
+// Seed lookup for the lane-resolved prefilter: one thread per (query of the list, sampled word) turns the word into its
+// .acx list range; the header carries need | words << 16 and the length.  Keeps the dependent chain
+// list -> offsets -> symbols -> acx offsets out of the hash kernel (fully parallel here, four round trips there).
+__global__ __launch_bounds__(256) void k_seed_ranges(
+		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint32_t *__restrict__ qlist, uint32_t n_list,
+		const uint32_t *__restrict__ acx_off, int K, const uint32_t *__restrict__ plan, uint32_t W16,
+		uint2 *__restrict__ ranges, uint2 *__restrict__ hdr) {
+	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	const uint32_t li = (uint32_t)(t / W16), j = (uint32_t)(t % W16);
+	if (li >= n_list) return;
+	const uint32_t q = qlist ? qlist[li] : li;
+	const uint64_t b = qoff[q];
+	const uint32_t len = (uint32_t)(qoff[q + 1] - b);
+	uint32_t stride = 1, need = 0, nwords = 0;
+	if (len >= (uint32_t)K) { const uint32_t pl = plan[q]; stride = pl & 255u; need = pl >> 8; nwords = (len - K) / stride + 1; }
+	if (nwords > W16) nwords = W16;
+	uint2 r = make_uint2(0, 0);
+	if (j < nwords) {
+		const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
+		const uint32_t p = j * stride;
+		uint32_t w = 0, ok = 1;
+		for (int k = 0; k < K; ++k) {
+			const uint32_t c = qcodes[b + p + k];
+			ok &= (c - 1u) < 4u;
+			w = (w << 2) | ((c - 1u) & 3u);
+		}
+		w &= wmask;
+		if (ok) { r.x = acx_off[w]; r.y = acx_off[w + 1]; }
+	}
+	ranges[t] = r;
+	if (j == 0) hdr[li] = make_uint2((need > 0xFFFFu ? 0xFFFFu : need) | nwords << 16, len);
+}
+
 __global__ __launch_bounds__(64) void k_prefilter_mask(
-		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff,
-		const uint32_t *__restrict__ qlist, uint32_t n_list,
-		const uint32_t *__restrict__ acx_off, const uint2 *__restrict__ ent, int K,   // ent = (clump, lane mask) records
+		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
+		const uint2 *__restrict__ ent,   // ent = (clump, lane mask) records
 		const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ clump_len, uint32_t tot_refs,
 		uint2 *__restrict__ tasks, uint32_t *__restrict__ n_tasks, uint32_t task_cap,
-		unsigned long long *__restrict__ ent_read, const uint32_t *__restrict__ plan,
+		unsigned long long *__restrict__ ent_read,
 		uint32_t *__restrict__ fb_list, uint32_t *__restrict__ n_fb,
 		unsigned long long *__restrict__ unit_sum, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum,
 		uint2 *__restrict__ pairs, uint32_t *__restrict__ n_pairs, uint32_t pair_cap) {
+
 	__shared__ uint32_t s_tab[4][PFM_HT];
 	__shared__ uint16_t s_tl[4][PFM_TL];
 	__shared__ unsigned long long s_cc[4][PFM_CAND][2];
@@ -560,14 +627,18 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 	__shared__ uint2 s_stage[PFM_STAGE];
 	__shared__ uint32_t s_ctr[12];          // [g] touched count, [4] staged, [5+g] candidates of group g
 	__shared__ uint32_t s_ovf[4];
+	__shared__ uint32_t s_dummy[64];
 	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
-	const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
+	s_dummy[lane] = 0;
 	for (uint32_t i = lane; i < 4 * PFM_HT; i += 64) (&s_tab[0][0])[i] = 0;
 	for (uint32_t i = lane; i < 4 * PFM_CAND * 2; i += 64) (&s_cc[0][0][0])[i] = 0;
 	if (lane < 12) s_ctr[lane] = 0;
 	if (lane < 4) s_ovf[lane] = 0;
 	__syncthreads();
 	unsigned long long my_ent = 0, my_units = 0, my_cols = 0, my_qlen = 0;
+#ifdef PFM_PROF
+	unsigned long long my_t[8] = {0,0,0,0,0,0,0,0}, t_last = wall_clock64();
+#endif
 
 	auto push = [&](uint32_t li, uint32_t refIx) {
 		const uint32_t pos = atomicAdd(&s_ctr[4], 1u);
@@ -587,23 +658,34 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 		if (lane == 0) s_ctr[4] = 0;
 		__syncthreads();
 	};
-	auto bump = [&](uint32_t tg, uint32_t c) {           // pass 1: insert or increment
+	uint32_t tcnt = 0;                      // touched slots of this lane's own group (replicated in its 16 lanes)
+	auto bump_wave = [&](uint32_t tg, uint32_t c, bool valid) -> uint32_t {     // wave-uniform call: any lane may update table tg
 		const uint32_t key = (c + 1u) << 8;
 		uint32_t slot = (c * 0x9E3779B1u) >> (32 - 10);
 		uint32_t *tab = s_tab[tg];
-		for (uint32_t probes = 0; probes < PFM_HT; ++probes, slot = (slot + 1) & (PFM_HT - 1)) {
-			uint32_t old = tab[slot];
-			if (old == 0) {
-				old = atomicCAS(&tab[slot], 0u, key | 1u);
-				if (old == 0) {
-					const uint32_t pos = atomicAdd(&s_ctr[tg], 1u);
-					if (pos < PFM_TL) s_tl[tg][pos] = (uint16_t)slot; else s_ovf[tg] = 1;
-					return;
-				}
-			}
-			if ((old & 0xFFFFFF00u) == key) { atomicAdd(&tab[slot], 1u); return; }
+		bool ins = false, act = valid;
+		for (uint32_t probes = 0; act && probes < PFM_HT; ++probes) {
+			const uint32_t old = atomicCAS(&tab[slot], 0u, key | 1u);
+			if (old == 0) { ins = true; act = false; }
+			else if ((old & 0xFFFFFF00u) == key) { atomicAdd(&tab[slot], 1u); act = false; }
+			else slot = (slot + 1) & (PFM_HT - 1);
 		}
-		s_ovf[tg] = 1;
+		if (act) s_ovf[tg] = 1;
+		const unsigned long long bm = __ballot(ins);
+		const uint32_t t0 = __shfl(tcnt, tg * 16);
+		if (ins) {
+			const uint32_t pos = t0 + __popcll(bm & ((1ull << lane) - 1ull));
+			if (pos < PFM_TL) s_tl[tg][pos] = (uint16_t)slot; else s_ovf[tg] = 1;
+		}
+		if (g == tg) tcnt += __popcll(bm);
+		return slot;
+	};
+	auto lanes_at = [&](uint32_t tg, uint32_t slot, uint32_t mask) {   // pass 2 for a record whose slot is known
+		const uint32_t ci = s_tab[tg][slot] & 255u;
+		if (ci) {
+			if (mask & 0xFFu) atomicAdd(&s_cc[tg][ci - 1][0], spread8(mask & 0xFFu));
+			if (mask >> 8) atomicAdd(&s_cc[tg][ci - 1][1], spread8(mask >> 8));
+		}
 	};
 	auto lanes_add = [&](uint32_t tg, uint32_t c, uint32_t mask) {   // pass 2: only candidate clumps have a non-zero low byte
 		const uint32_t key = (c + 1u) << 8;
@@ -624,59 +706,107 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 	};
 
 	const uint32_t n_quads = (n_list + 3) >> 2;
+	// (need, words, length) and the first 16 list ranges of the next quad are fetched one iteration ahead (k_seed_ranges
+	// produced them), so the only exposed memory round trip per quad is the list records themselves
+	uint2 hd_n = make_uint2(0, 0), rg_n = make_uint2(0, 0);
+	if (blockIdx.x * 4 + g < n_list) { hd_n = hdr[blockIdx.x * 4 + g]; rg_n = ranges[(size_t)(blockIdx.x * 4 + g) * W16 + gl]; }
 	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
 		const uint32_t li = quad * 4 + g;
 		const bool live = li < n_list;
-		uint32_t q = 0, len = 0, stride = 1, need = 0, nwords = 0;
-		uint64_t b = 0;
-		if (live) {
-			q = qlist ? qlist[li] : li;
-			b = qoff[q];
-			len = (uint32_t)(qoff[q + 1] - b);
-			if (len >= (uint32_t)K) { stride = plan[q] & 255u; need = plan[q] >> 8; nwords = (len - K) / stride + 1; }
+		tcnt = 0;
+		const uint2 hd = hd_n, rg = rg_n;
+		{
+			const uint32_t li_n = (quad + gridDim.x) * 4 + g;
+			hd_n = make_uint2(0, 0); rg_n = make_uint2(0, 0);
+			if (quad + gridDim.x < n_quads && li_n < n_list) { hd_n = hdr[li_n]; rg_n = ranges[(size_t)li_n * W16 + gl]; }
 		}
+		const uint32_t need = hd.x & 0xFFFFu, nwords = live ? hd.x >> 16 : 0u, len = hd.y;
 		uint32_t maxw = nwords;
 		#pragma unroll
 		for (int o = 32; o >= 1; o >>= 1) { const uint32_t t = __shfl_xor(maxw, o); maxw = t > maxw ? t : maxw; }
 		auto word_range = [&](uint32_t j, uint32_t &beg, uint32_t &end) {
-			const uint32_t p = j * stride;
-			uint32_t w = 0, ok = live && j < nwords;
-			if (ok) for (int k = 0; k < K; ++k) {
-				const uint32_t c = qcodes[b + p + k];
-				ok &= (c - 1u) < 4u;
-				w = (w << 2) | ((c - 1u) & 3u);
-			}
-			w &= wmask;
-			beg = end = 0;
-			if (ok) { beg = acx_off[w]; end = acx_off[w + 1]; }
+			uint2 r = make_uint2(0, 0);
+			if (live && j < nwords) r = ranges[(size_t)li * W16 + j];
+			beg = r.x; end = r.y;
 		};
-		// ---- pass 1: clump-level counts
-		uint32_t beg0 = 0, end0 = 0;      // range of the first word of this lane, reused by pass 2 when one pass covers the query
-		for (uint32_t base = 0; base < maxw; base += 16) {
-			uint32_t beg, end;
-			word_range(base + gl, beg, end);
-			if (base == 0) { beg0 = beg; end0 = end; }
-			const uint32_t n = end - beg;
-			my_ent += n;
-			unsigned long long longm = __ballot(n > 48);
-			if (n <= 48) {
-				uint32_t e = beg;
-				for (; e + 4 <= end; e += 4) {
-					const uint2 r0 = ent[e], r1 = ent[e + 1], r2 = ent[e + 2], r3 = ent[e + 3];
-					bump(g, r0.x); bump(g, r1.x); bump(g, r2.x); bump(g, r3.x);
-				}
-				for (; e < end; ++e) bump(g, ent[e].x);
+		PFM_T(0);
+		// ---- pass 1: clump-level counts.  Each 16-lane group walks its own query's lists one list at a time, two records per
+		// lane (32 per list covers 94 % of the lists of the headline workload); all loads are issued before the first LDS
+		// update, and the records stay in registers for pass 2.  Longer lists: the tail goes wave-wide.
+		uint2 r0[16], r1[16];          // .y = lane mask, later | slot << 16
+		const uint32_t beg = live ? rg.x : 0u, end = live ? rg.y : 0u;
+		const uint32_t wcount = maxw < 16 ? maxw : 16;
+		PFM_T(1);
+		my_ent += end - beg;
+		const unsigned long long longm = __ballot(end - beg > 32);
+		unsigned long long lm = longm;
+		uint2 x[4]; uint32_t xs[4] = {0, 0, 0, 0}, xtg[4]; bool xv[4], xhave[4];
+		{
+			#pragma unroll
+			for (uint32_t j = 0; j < 16; ++j) if (j < wcount) {
+				const uint32_t lb = __shfl(beg, (lane & 48u) | j), le = __shfl(end, (lane & 48u) | j);
+				r0[j] = lb + gl < le ? ent[lb + gl] : make_uint2(0xFFFFFFFFu, 0);
+				r1[j] = lb + 16 + gl < le ? ent[lb + 16 + gl] : make_uint2(0xFFFFFFFFu, 0);
 			}
+			// tails of the (few) lists longer than 32: the first four are prefetched wave-wide, 64 records each
+			#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				xhave[k] = lm != 0; xv[k] = false; xtg[k] = 0; x[k] = make_uint2(0, 0);
+				if (lm) {
+					const int src = __builtin_ctzll(lm);
+					lm &= lm - 1;
+					const uint32_t lb = __shfl(beg, src) + 32, le = __shfl(end, src);
+					xtg[k] = (uint32_t)src >> 4;
+					xv[k] = lb + lane < le;
+					if (xv[k]) x[k] = ent[lb + lane];
+				}
+			}
+			PFM_T(6);
+			#pragma unroll
+			for (uint32_t j = 0; j < 16; j += 2) if (j < wcount) {
+				const uint32_t c[4] = {r0[j].x, r1[j].x, r0[j + 1].x, r1[j + 1].x};
+				const bool valid[4] = {c[0] != 0xFFFFFFFFu, c[1] != 0xFFFFFFFFu, j + 1 < wcount && c[2] != 0xFFFFFFFFu, j + 1 < wcount && c[3] != 0xFFFFFFFFu};
+				uint32_t slot[4]; bool ins[4], fail;
+				pfm_bump4(s_tab[g], &s_dummy[lane], c, valid, slot, ins, fail);
+				if (fail) s_ovf[g] = 1;
+				r0[j].y |= slot[0] << 16; r1[j].y |= slot[1] << 16; r0[j + 1].y |= slot[2] << 16; r1[j + 1].y |= slot[3] << 16;
+				#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const uint32_t m16 = (uint32_t)(__ballot(ins[k]) >> (lane & 48u)) & 0xFFFFu;
+					if (ins[k]) {
+						const uint32_t pos = tcnt + __popc(m16 & ((1u << gl) - 1u));
+						if (pos < PFM_TL) s_tl[g][pos] = (uint16_t)slot[k]; else s_ovf[g] = 1;
+					}
+					tcnt += __popc(m16);
+				}
+			}
+			PFM_T(7);
+			#pragma unroll
+			for (int k = 0; k < 4; ++k) if (xhave[k]) xs[k] = bump_wave(xtg[k], x[k].x, xv[k]);
+			lm = longm;
+			for (uint32_t idx = 0; lm; ++idx) {          // what the prefetch did not cover: lists beyond 96 records, 5th+ long list
+				const int src = __builtin_ctzll(lm);
+				lm &= lm - 1;
+				const uint32_t lb = __shfl(beg, src) + (idx < 4 ? 96u : 32u), le = __shfl(end, src), tg = (uint32_t)src >> 4;
+				for (uint32_t e = lb; e < le; e += 64) { const bool v = e + lane < le; bump_wave(tg, v ? ent[e + lane].x : 0u, v); }
+			}
+		}
+		for (uint32_t base = 16; base < maxw; base += 16) {       // queries with more than 16 sampled words: plain walk
+			uint32_t xb, xe;
+			word_range(base + gl, xb, xe);
+			my_ent += xe - xb;
+			unsigned long long longm = __ballot(xe > xb);
 			while (longm) {
 				const int src = __builtin_ctzll(longm);
 				longm &= longm - 1;
-				const uint32_t lb = __shfl(beg, src), le = __shfl(end, src), tg = (uint32_t)src >> 4;
-				for (uint32_t e = lb + lane; e < le; e += 64) bump(tg, ent[e].x);
+				const uint32_t lb = __shfl(xb, src), le = __shfl(xe, src), tg = (uint32_t)src >> 4;
+				for (uint32_t e = lb; e < le; e += 64) { const bool v = e + lane < le; bump_wave(tg, v ? ent[e + lane].x : 0u, v); }
 			}
 		}
 		__syncthreads();
+		PFM_T(2);
 		// ---- select candidates
-		const uint32_t nt = s_ctr[g] < PFM_TL ? s_ctr[g] : PFM_TL;
+		const uint32_t nt = tcnt < PFM_TL ? tcnt : PFM_TL;
 		const uint32_t ovf = s_ovf[g];
 		const uint32_t thr = need ? need : 1u;          // a lane (hence its clump) is a candidate iff count >= max(need, 1)
 		if (live && !ovf) {
@@ -696,31 +826,42 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 			}
 		}
 		__syncthreads();
+		PFM_T(3);
 		// ---- pass 2: lane counters of the candidate clumps
 		const uint32_t ncand = s_ctr[5 + g] < PFM_CAND ? s_ctr[5 + g] : PFM_CAND;
-		const bool any_cand = __any(live && !ovf && ncand > 0);
-		if (any_cand) for (uint32_t base = 0; base < maxw; base += 16) {
-			uint32_t beg = beg0, end = end0;
-			if (base) word_range(base + gl, beg, end);
-			if (ovf || !ncand) beg = end = 0;
-			const uint32_t n = end - beg;
-			unsigned long long longm = __ballot(n > 48);
-			if (n <= 48) {
-				uint32_t e = beg;
-				for (; e + 4 <= end; e += 4) {
-					const uint2 r0 = ent[e], r1 = ent[e + 1], r2 = ent[e + 2], r3 = ent[e + 3];
-					lanes_add(g, r0.x, r0.y); lanes_add(g, r1.x, r1.y); lanes_add(g, r2.x, r2.y); lanes_add(g, r3.x, r3.y);
+		const bool mine = live && !ovf && ncand > 0;
+		if (__any(mine)) {
+			if (mine) {
+				#pragma unroll
+				for (uint32_t j = 0; j < 16; ++j) if (j < wcount) {
+					if (r0[j].x != 0xFFFFFFFFu) lanes_at(g, r0[j].y >> 16, r0[j].y & 0xFFFFu);
+					if (r1[j].x != 0xFFFFFFFFu) lanes_at(g, r1[j].y >> 16, r1[j].y & 0xFFFFu);
 				}
-				for (; e < end; ++e) { const uint2 r = ent[e]; lanes_add(g, r.x, r.y); }
 			}
-			while (longm) {
-				const int src = __builtin_ctzll(longm);
-				longm &= longm - 1;
-				const uint32_t lb = __shfl(beg, src), le = __shfl(end, src), tg = (uint32_t)src >> 4;
-				for (uint32_t e = lb + lane; e < le; e += 64) { const uint2 r = ent[e]; lanes_add(tg, r.x, r.y); }
+			const unsigned long long minem = __ballot(mine);
+			#pragma unroll
+			for (int k = 0; k < 4; ++k) if (xhave[k] && ((minem >> (xtg[k] * 16)) & 1ull) && xv[k]) lanes_at(xtg[k], xs[k], x[k].y);
+			lm = longm;
+			for (uint32_t idx = 0; lm; ++idx) {
+				const int src = __builtin_ctzll(lm);
+				lm &= lm - 1;
+				const uint32_t lb = __shfl(beg, src) + (idx < 4 ? 96u : 32u), le = __shfl(end, src), tg = (uint32_t)src >> 4;
+				if ((minem >> (tg * 16)) & 1ull) for (uint32_t e = lb + lane; e < le; e += 64) { const uint2 r = ent[e]; lanes_add(tg, r.x, r.y); }
+			}
+			for (uint32_t base = 16; base < maxw; base += 16) {
+				uint32_t xb, xe;
+				word_range(base + gl, xb, xe);
+				unsigned long long lm = __ballot(mine && xe > xb);
+				while (lm) {
+					const int src = __builtin_ctzll(lm);
+					lm &= lm - 1;
+					const uint32_t lb = __shfl(xb, src), le = __shfl(xe, src), tg = (uint32_t)src >> 4;
+					for (uint32_t e = lb + lane; e < le; e += 64) { const uint2 r = ent[e]; lanes_add(tg, r.x, r.y); }
+				}
 			}
 		}
 		__syncthreads();
+		PFM_T(4);
 		// ---- emit tasks, clear
 		if (live && !ovf) {
 			for (uint32_t i = gl; i < ncand; i += 16) {
@@ -750,8 +891,12 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 		__syncthreads();
 		if (gl == 0) { s_ctr[g] = 0; s_ctr[5 + g] = 0; s_ovf[g] = 0; }
 		if (s_ctr[4] >= PFM_STAGE / 2) flush(); else __syncthreads();
+		PFM_T(5);
 	}
 	flush();
+#ifdef PFM_PROF
+	if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_pfm_prof[i], my_t[i]);
+#endif
 	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
 	if (my_units) { atomicAdd(unit_sum, my_units); atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
 }
@@ -1395,3 +1540,11 @@ template __global__ void k_rescore<true>(const BhipRawHit *, const uint32_t *, u
 	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *,
 	BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long, uint32_t *,
 	const uint32_t *, uint32_t, uint32_t, uint32_t);
+
+#ifdef PFM_PROF
+extern "C" int bhip_debug_prof(unsigned long long *out, int reset) {
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pfm_prof), 64) != hipSuccess) return -1;
+	if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pfm_prof), z, 64) != hipSuccess) return -1; }
+	return 0;
+}
+#endif
