@@ -38,7 +38,7 @@ template <int NW> __global__ void k_myers_window(const BhipWin *, const uint32_t
 	unsigned long long *);
 __global__ void k_extract_kmers(const uint4 *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, int, unsigned long long *, uint16_t *, uint32_t *);
 __global__ void k_attach_masks(const uint32_t *, const uint32_t *, uint64_t, uint32_t, const unsigned long long *, const uint16_t *, uint32_t, const uint32_t *, uint2 *);
-__global__ void k_prefilter_mask(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+template <int HTB> __global__ void k_prefilter_mask(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *,
 	uint2 *, uint32_t *, uint32_t);
 __global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, int, const uint32_t *, uint32_t, uint2 *, uint2 *);
@@ -156,6 +156,9 @@ struct Handle {
 	int opt_prefilter_stride = 0; // 0 = automatic sparse seeds, s > 0 = every s-th word (1 = the reference's scheme)
 	int opt_lanes = 6;            // sub-pipelines per batch (1 = everything in order on one stream)
 	int opt_sweep_blocks = 8;     // 256-thread blocks per CU of the column-sweep kernels
+	int opt_pf_waves = 0;         // single-wave blocks per CU of the lane-resolved prefilter (0 = as many as the LDS allows, <= 12)
+	int opt_pf_table = 0;         // log2 of the per-query hash table (0 = from the workload: 9, 10 or 11)
+	double acx_wmean = 0.0;       // occurrence-weighted mean .acx list length
 };
 struct SharedCtr { uint32_t n_out, err; };
 
@@ -336,7 +339,9 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		const uint64_t nw = 1ull << (2 * K);
 		std::vector<uint32_t> off(nw + 1);
 		uint64_t tot = 0;
-		for (uint64_t i = 0; i < nw; ++i) { off[i] = (uint32_t)tot; tot += acx_lens[i]; }
+		double sq = 0.0;
+		for (uint64_t i = 0; i < nw; ++i) { off[i] = (uint32_t)tot; tot += acx_lens[i]; sq += (double)acx_lens[i] * (double)acx_lens[i]; }
+		h->acx_wmean = tot ? sq / (double)tot : 0.0;
 		if (tot >= 0xFFFFFFFFull) { fail(BHIP_E_ARG, "accelerator with %llu entries exceeds the 32-bit offset table", (unsigned long long)tot); bhip_destroy(h); return BHIP_E_ARG; }
 		off[nw] = (uint32_t)tot;
 		// decode the packed lists (burst.c:3265-3274 SMALL, 3245-3248 LARGE) to one u32 per entry
@@ -395,6 +400,8 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 	if (!strcmp(name, "two_stage")) { h->opt_two_stage = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "lane_masks")) { h->opt_lane_masks = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "sweep_blocks")) { if (value < 1 || value > 8) return fail(BHIP_E_ARG, "sweep_blocks must be 1 .. 8"); h->opt_sweep_blocks = (int)value; return BHIP_OK; }
+	if (!strcmp(name, "prefilter_waves")) { if (value < 0 || value > 16) return fail(BHIP_E_ARG, "prefilter_waves must be 0 .. 16"); h->opt_pf_waves = (int)value; return BHIP_OK; }
+	if (!strcmp(name, "prefilter_table")) { if (value != 0 && (value < 9 || value > 11)) return fail(BHIP_E_ARG, "prefilter_table must be 0, 9, 10 or 11"); h->opt_pf_table = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "lanes")) {
 		if (value < 1 || value > 16) return fail(BHIP_E_ARG, "lanes must be 1 .. 16");
 		h->opt_lanes = (int)value; h->st_valid = false; return BHIP_OK;
@@ -566,11 +573,20 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, const uint3
 	hipLaunchKernelGGL(k_seed_ranges, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), d_qlist, n_list,
 		h->acx_off.as<uint32_t>(), h->K, h->plan.as<uint32_t>(), W16, L->ranges.as<uint2>(), L->hdr.as<uint2>());
 	const uint32_t n_quads = (n_list + 3) / 4;
-	const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * 6);
-	hipLaunchKernelGGL(k_prefilter_mask, dim3(grid), dim3(64), 0, st, L->ranges.as<uint2>(), L->hdr.as<uint2>(), W16, n_list,
-		h->ent_mask.as<uint2>(), h->bad.as<uint32_t>(), h->n_bad,
-		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read,
-		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, L->cand.as<uint2>(), n_cand_dev, (uint32_t)L->cand_cap);
+	// hash table size per query from the expected number of distinct clumps (sampled words x occurrence-weighted mean list
+	// length): 512 slots keep 12 single-wave blocks on a CU, 1024 -> 7, 2048 -> 4
+	const double expect = (double)maxwords * h->acx_wmean;
+	const int htb = h->opt_pf_table ? h->opt_pf_table : (expect <= 150.0 ? 9 : expect <= 320.0 ? 10 : 11);
+	const uint32_t lds_b = (4u << htb) * 4 + (4u << (htb - 1)) * 2 + 4 * 24 * 16 + 4 * 24 * 4 + 128 * 8 + 64 + 256 + 64;
+	const uint32_t fit = std::max<uint32_t>(1, std::min<uint32_t>(12, (160u * 1024u) / ((lds_b + 511u) & ~511u)));
+	const uint32_t waves = h->opt_pf_waves ? std::min<uint32_t>((uint32_t)h->opt_pf_waves, fit) : fit;
+	const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * waves);
+#define PFM_LAUNCH(B) hipLaunchKernelGGL(k_prefilter_mask<B>, dim3(grid), dim3(64), 0, st, L->ranges.as<uint2>(), L->hdr.as<uint2>(), W16, n_list, \
+		h->ent_mask.as<uint2>(), h->bad.as<uint32_t>(), h->n_bad, \
+		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
+		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, L->cand.as<uint2>(), n_cand_dev, (uint32_t)L->cand_cap)
+	if (htb == 9) PFM_LAUNCH(9); else if (htb == 10) PFM_LAUNCH(10); else PFM_LAUNCH(11);
+#undef PFM_LAUNCH
 	HIPCHK(hipGetLastError());
 	// dense fallback for overflowed queries (clump-level pairs)
 	const uint32_t *bad = h->bad.as<uint32_t>();

@@ -538,10 +538,9 @@ __device__ unsigned long long g_pfm_prof[8];
 #else
 #define PFM_T(i) do {} while (0)
 #endif
-#define PFM_HT 1024u
-#define PFM_TL 448u
-#define PFM_STAGE 512u
+#define PFM_STAGE 128u
 #define PFM_CAND 24u
+#define PFM_RB 3u            // blocks of 64 records per query kept in registers between the passes
 __device__ __forceinline__ unsigned long long spread8(uint32_t m8) {   // bit i of m8 -> bit 8*i
 	unsigned long long x = m8;
 	x = (x | (x << 28)) & 0x0000000F0000000Full;
@@ -551,12 +550,13 @@ __device__ __forceinline__ unsigned long long spread8(uint32_t m8) {   // bit i 
 }
 // Four hash-table updates in lock step (independent LDS round trips overlap).  CAS first: most updates of a
 // query are first sightings of a clump, which complete in one round trip; a key hit costs one more (no-return) add.
+template <int HTB>
 __device__ __forceinline__ void pfm_bump4(uint32_t *tab, uint32_t *dummy, const uint32_t (&c)[4], const bool (&valid)[4], uint32_t (&slot)[4], bool (&ins)[4], bool &fail) {
 	uint32_t key[4]; bool act[4];
 	#pragma unroll
-	for (int k = 0; k < 4; ++k) { key[k] = (c[k] + 1u) << 8; slot[k] = (c[k] * 0x9E3779B1u) >> (32 - 10); act[k] = valid[k]; ins[k] = false; }
+	for (int k = 0; k < 4; ++k) { key[k] = (c[k] + 1u) << 8; slot[k] = (c[k] * 0x9E3779B1u) >> (32 - HTB); act[k] = valid[k]; ins[k] = false; }
 	bool any = valid[0] | valid[1] | valid[2] | valid[3];
-	for (uint32_t probes = 0; any && probes < PFM_HT; ++probes) {
+	for (uint32_t probes = 0; any && probes < (1u << HTB); ++probes) {
 		uint32_t old[4];
 		// finished chains compare-and-swap a private dummy word with a value that never matches: no branches between the
 		// four LDS round trips, so they are in flight together
@@ -570,7 +570,7 @@ __device__ __forceinline__ void pfm_bump4(uint32_t *tab, uint32_t *dummy, const 
 			const bool step = act[k] && !hit && !fresh;
 			if (hit) atomicAdd(&tab[slot[k]], 1u);
 			ins[k] |= fresh;
-			slot[k] = step ? (slot[k] + 1) & (PFM_HT - 1) : slot[k];
+			slot[k] = step ? (slot[k] + 1) & ((1u << HTB) - 1) : slot[k];
 			act[k] = step;
 			any |= step;
 		}
@@ -610,6 +610,7 @@ __global__ __launch_bounds__(256) void k_seed_ranges(
 	if (j == 0) hdr[li] = make_uint2((need > 0xFFFFu ? 0xFFFFu : need) | nwords << 16, len);
 }
 
+template <int HTB>
 __global__ __launch_bounds__(64) void k_prefilter_mask(
 		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
 		const uint2 *__restrict__ ent,   // ent = (clump, lane mask) records
@@ -620,8 +621,8 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 		unsigned long long *__restrict__ unit_sum, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum,
 		uint2 *__restrict__ pairs, uint32_t *__restrict__ n_pairs, uint32_t pair_cap) {
 
-	__shared__ uint32_t s_tab[4][PFM_HT];
-	__shared__ uint16_t s_tl[4][PFM_TL];
+	__shared__ uint32_t s_tab[4][(1u << HTB)];
+	__shared__ uint16_t s_tl[4][(1u << (HTB - 1))];
 	__shared__ unsigned long long s_cc[4][PFM_CAND][2];
 	__shared__ uint32_t s_cclump[4][PFM_CAND];
 	__shared__ uint2 s_stage[PFM_STAGE];
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 	__shared__ uint32_t s_dummy[64];
 	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
 	s_dummy[lane] = 0;
-	for (uint32_t i = lane; i < 4 * PFM_HT; i += 64) (&s_tab[0][0])[i] = 0;
+	for (uint32_t i = lane; i < 4 * (1u << HTB); i += 64) (&s_tab[0][0])[i] = 0;
 	for (uint32_t i = lane; i < 4 * PFM_CAND * 2; i += 64) (&s_cc[0][0][0])[i] = 0;
 	if (lane < 12) s_ctr[lane] = 0;
 	if (lane < 4) s_ovf[lane] = 0;
@@ -659,39 +660,11 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 		__syncthreads();
 	};
 	uint32_t tcnt = 0;                      // touched slots of this lane's own group (replicated in its 16 lanes)
-	auto bump_wave = [&](uint32_t tg, uint32_t c, bool valid) -> uint32_t {     // wave-uniform call: any lane may update table tg
-		const uint32_t key = (c + 1u) << 8;
-		uint32_t slot = (c * 0x9E3779B1u) >> (32 - 10);
-		uint32_t *tab = s_tab[tg];
-		bool ins = false, act = valid;
-		for (uint32_t probes = 0; act && probes < PFM_HT; ++probes) {
-			const uint32_t old = atomicCAS(&tab[slot], 0u, key | 1u);
-			if (old == 0) { ins = true; act = false; }
-			else if ((old & 0xFFFFFF00u) == key) { atomicAdd(&tab[slot], 1u); act = false; }
-			else slot = (slot + 1) & (PFM_HT - 1);
-		}
-		if (act) s_ovf[tg] = 1;
-		const unsigned long long bm = __ballot(ins);
-		const uint32_t t0 = __shfl(tcnt, tg * 16);
-		if (ins) {
-			const uint32_t pos = t0 + __popcll(bm & ((1ull << lane) - 1ull));
-			if (pos < PFM_TL) s_tl[tg][pos] = (uint16_t)slot; else s_ovf[tg] = 1;
-		}
-		if (g == tg) tcnt += __popcll(bm);
-		return slot;
-	};
-	auto lanes_at = [&](uint32_t tg, uint32_t slot, uint32_t mask) {   // pass 2 for a record whose slot is known
-		const uint32_t ci = s_tab[tg][slot] & 255u;
-		if (ci) {
-			if (mask & 0xFFu) atomicAdd(&s_cc[tg][ci - 1][0], spread8(mask & 0xFFu));
-			if (mask >> 8) atomicAdd(&s_cc[tg][ci - 1][1], spread8(mask >> 8));
-		}
-	};
 	auto lanes_add = [&](uint32_t tg, uint32_t c, uint32_t mask) {   // pass 2: only candidate clumps have a non-zero low byte
 		const uint32_t key = (c + 1u) << 8;
-		uint32_t slot = (c * 0x9E3779B1u) >> (32 - 10);
+		uint32_t slot = (c * 0x9E3779B1u) >> (32 - HTB);
 		const uint32_t *tab = s_tab[tg];
-		for (uint32_t probes = 0; probes < PFM_HT; ++probes, slot = (slot + 1) & (PFM_HT - 1)) {
+		for (uint32_t probes = 0; probes < (1u << HTB); ++probes, slot = (slot + 1) & ((1u << HTB) - 1)) {
 			const uint32_t v = tab[slot];
 			if (v == 0) return;
 			if ((v & 0xFFFFFF00u) == key) {
@@ -730,83 +703,78 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 			beg = r.x; end = r.y;
 		};
 		PFM_T(0);
-		// ---- pass 1: clump-level counts.  Each 16-lane group walks its own query's lists one list at a time, two records per
-		// lane (32 per list covers 94 % of the lists of the headline workload); all loads are issued before the first LDS
-		// update, and the records stay in registers for pass 2.  Longer lists: the tail goes wave-wide.
-		uint2 r0[16], r1[16];          // .y = lane mask, later | slot << 16
-		const uint32_t beg = live ? rg.x : 0u, end = live ? rg.y : 0u;
-		const uint32_t wcount = maxw < 16 ? maxw : 16;
-		PFM_T(1);
-		my_ent += end - beg;
-		const unsigned long long longm = __ballot(end - beg > 32);
-		unsigned long long lm = longm;
-		uint2 x[4]; uint32_t xs[4] = {0, 0, 0, 0}, xtg[4]; bool xv[4], xhave[4];
-		{
+		// ---- pass 1: clump-level counts.  The (up to 16) lists of a query are walked as ONE flattened record stream by the
+		// 16 lanes of its group: record i belongs to the list k with excl[k] <= i < excl[k+1] (4-step search over the group's
+		// exclusive prefix sums), so the lanes stay busy whatever the individual list lengths.  Blocks of 4 rounds (64
+		// records per query) are loaded together and updated in lock step; the first PFM_RB blocks stay in registers for pass 2.
+		const uint32_t beg = live ? rg.x : 0u, n0 = live ? rg.y - rg.x : 0u;
+		my_ent += n0;
+		auto group_scan = [&](uint32_t n, uint32_t &T, uint32_t &excl) {
+			uint32_t ps = n;
 			#pragma unroll
-			for (uint32_t j = 0; j < 16; ++j) if (j < wcount) {
-				const uint32_t lb = __shfl(beg, (lane & 48u) | j), le = __shfl(end, (lane & 48u) | j);
-				r0[j] = lb + gl < le ? ent[lb + gl] : make_uint2(0xFFFFFFFFu, 0);
-				r1[j] = lb + 16 + gl < le ? ent[lb + 16 + gl] : make_uint2(0xFFFFFFFFu, 0);
+			for (uint32_t o = 1; o < 16; o <<= 1) { const uint32_t t = __shfl_up(ps, o, 16); if (gl >= o) ps += t; }
+			T = __shfl(ps, 15, 16);
+			excl = ps - n;
+		};
+		auto wave_blocks = [&](uint32_t T) -> uint32_t {
+			uint32_t m = T, t;
+			t = __shfl_xor(m, 16); m = t > m ? t : m;
+			t = __shfl_xor(m, 32); m = t > m ? t : m;
+			return (m + 63) >> 6;
+		};
+		auto load4 = [&](uint32_t ex, uint32_t dl, uint32_t T, uint32_t b, uint2 (&rec)[4]) {
+			#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u) {
+				const uint32_t i = (b * 4 + u) * 16 + gl;
+				uint32_t kk = 0;
+				kk += __shfl(ex, 8, 16) <= i ? 8u : 0u;
+				kk += __shfl(ex, kk + 4, 16) <= i ? 4u : 0u;
+				kk += __shfl(ex, kk + 2, 16) <= i ? 2u : 0u;
+				kk += __shfl(ex, kk + 1, 16) <= i ? 1u : 0u;
+				const uint32_t addr = __shfl(dl, kk, 16) + i;
+				rec[u] = i < T ? ent[addr] : make_uint2(0xFFFFFFFFu, 0);
 			}
-			// tails of the (few) lists longer than 32: the first four are prefetched wave-wide, 64 records each
+		};
+		auto bump_block = [&](uint2 (&rec)[4]) {
+			const uint32_t c[4] = {rec[0].x, rec[1].x, rec[2].x, rec[3].x};
+			const bool valid[4] = {c[0] != 0xFFFFFFFFu, c[1] != 0xFFFFFFFFu, c[2] != 0xFFFFFFFFu, c[3] != 0xFFFFFFFFu};
+			uint32_t slot[4]; bool ins[4], fail;
+			pfm_bump4<HTB>(s_tab[g], &s_dummy[lane], c, valid, slot, ins, fail);
+			if (fail) s_ovf[g] = 1;
 			#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				xhave[k] = lm != 0; xv[k] = false; xtg[k] = 0; x[k] = make_uint2(0, 0);
-				if (lm) {
-					const int src = __builtin_ctzll(lm);
-					lm &= lm - 1;
-					const uint32_t lb = __shfl(beg, src) + 32, le = __shfl(end, src);
-					xtg[k] = (uint32_t)src >> 4;
-					xv[k] = lb + lane < le;
-					if (xv[k]) x[k] = ent[lb + lane];
+			for (int u = 0; u < 4; ++u) {
+				rec[u].y |= slot[u] << 16;
+				const uint32_t m16 = (uint32_t)(__ballot(ins[u]) >> (lane & 48u)) & 0xFFFFu;
+				if (ins[u]) {
+					const uint32_t pos = tcnt + __popc(m16 & ((1u << gl) - 1u));
+					if (pos < (1u << (HTB - 1))) s_tl[g][pos] = (uint16_t)slot[u]; else s_ovf[g] = 1;
 				}
+				tcnt += __popc(m16);
 			}
-			PFM_T(6);
-			#pragma unroll
-			for (uint32_t j = 0; j < 16; j += 2) if (j < wcount) {
-				const uint32_t c[4] = {r0[j].x, r1[j].x, r0[j + 1].x, r1[j + 1].x};
-				const bool valid[4] = {c[0] != 0xFFFFFFFFu, c[1] != 0xFFFFFFFFu, j + 1 < wcount && c[2] != 0xFFFFFFFFu, j + 1 < wcount && c[3] != 0xFFFFFFFFu};
-				uint32_t slot[4]; bool ins[4], fail;
-				pfm_bump4(s_tab[g], &s_dummy[lane], c, valid, slot, ins, fail);
-				if (fail) s_ovf[g] = 1;
-				r0[j].y |= slot[0] << 16; r1[j].y |= slot[1] << 16; r0[j + 1].y |= slot[2] << 16; r1[j + 1].y |= slot[3] << 16;
-				#pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					const uint32_t m16 = (uint32_t)(__ballot(ins[k]) >> (lane & 48u)) & 0xFFFFu;
-					if (ins[k]) {
-						const uint32_t pos = tcnt + __popc(m16 & ((1u << gl) - 1u));
-						if (pos < PFM_TL) s_tl[g][pos] = (uint16_t)slot[k]; else s_ovf[g] = 1;
-					}
-					tcnt += __popc(m16);
-				}
-			}
-			PFM_T(7);
-			#pragma unroll
-			for (int k = 0; k < 4; ++k) if (xhave[k]) xs[k] = bump_wave(xtg[k], x[k].x, xv[k]);
-			lm = longm;
-			for (uint32_t idx = 0; lm; ++idx) {          // what the prefetch did not cover: lists beyond 96 records, 5th+ long list
-				const int src = __builtin_ctzll(lm);
-				lm &= lm - 1;
-				const uint32_t lb = __shfl(beg, src) + (idx < 4 ? 96u : 32u), le = __shfl(end, src), tg = (uint32_t)src >> 4;
-				for (uint32_t e = lb; e < le; e += 64) { const bool v = e + lane < le; bump_wave(tg, v ? ent[e + lane].x : 0u, v); }
-			}
-		}
-		for (uint32_t base = 16; base < maxw; base += 16) {       // queries with more than 16 sampled words: plain walk
-			uint32_t xb, xe;
+		};
+		uint32_t T0, ex0;
+		group_scan(n0, T0, ex0);
+		const uint32_t dl0 = beg - ex0, nblk0 = wave_blocks(T0);
+		uint2 rc[PFM_RB][4];           // .x = clump, .y = lane mask | slot << 16
+		#pragma unroll
+		for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) load4(ex0, dl0, T0, b, rc[b]);
+		PFM_T(6);
+		#pragma unroll
+		for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) bump_block(rc[b]);
+		PFM_T(7);
+		for (uint32_t b = PFM_RB; b < nblk0; ++b) { uint2 rec[4]; load4(ex0, dl0, T0, b, rec); bump_block(rec); }
+		for (uint32_t base = 16; base < maxw; base += 16) {       // queries with more than 16 sampled words: further chunks, not cached
+			uint32_t xb, xe, T, ex;
 			word_range(base + gl, xb, xe);
 			my_ent += xe - xb;
-			unsigned long long longm = __ballot(xe > xb);
-			while (longm) {
-				const int src = __builtin_ctzll(longm);
-				longm &= longm - 1;
-				const uint32_t lb = __shfl(xb, src), le = __shfl(xe, src), tg = (uint32_t)src >> 4;
-				for (uint32_t e = lb; e < le; e += 64) { const bool v = e + lane < le; bump_wave(tg, v ? ent[e + lane].x : 0u, v); }
-			}
+			group_scan(xe - xb, T, ex);
+			const uint32_t nb = wave_blocks(T);
+			for (uint32_t b = 0; b < nb; ++b) { uint2 rec[4]; load4(ex, xb - ex, T, b, rec); bump_block(rec); }
 		}
 		__syncthreads();
 		PFM_T(2);
 		// ---- select candidates
-		const uint32_t nt = tcnt < PFM_TL ? tcnt : PFM_TL;
+		const uint32_t nt = tcnt < (1u << (HTB - 1)) ? tcnt : (1u << (HTB - 1));
 		const uint32_t ovf = s_ovf[g];
 		const uint32_t thr = need ? need : 1u;          // a lane (hence its clump) is a candidate iff count >= max(need, 1)
 		if (live && !ovf) {
@@ -831,32 +799,36 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 		const uint32_t ncand = s_ctr[5 + g] < PFM_CAND ? s_ctr[5 + g] : PFM_CAND;
 		const bool mine = live && !ovf && ncand > 0;
 		if (__any(mine)) {
-			if (mine) {
+			#pragma unroll
+			for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) {
+				uint32_t ci[4];
 				#pragma unroll
-				for (uint32_t j = 0; j < 16; ++j) if (j < wcount) {
-					if (r0[j].x != 0xFFFFFFFFu) lanes_at(g, r0[j].y >> 16, r0[j].y & 0xFFFFu);
-					if (r1[j].x != 0xFFFFFFFFu) lanes_at(g, r1[j].y >> 16, r1[j].y & 0xFFFFu);
+				for (int u = 0; u < 4; ++u) ci[u] = s_tab[g][rc[b][u].y >> 16];      // slot 0 for padding records: harmless read
+				#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const uint32_t tag = ci[u] & 255u, mask = rc[b][u].y & 0xFFFFu;
+					if (mine && rc[b][u].x != 0xFFFFFFFFu && tag) {
+						if (mask & 0xFFu) atomicAdd(&s_cc[g][tag - 1][0], spread8(mask & 0xFFu));
+						if (mask >> 8) atomicAdd(&s_cc[g][tag - 1][1], spread8(mask >> 8));
+					}
 				}
 			}
-			const unsigned long long minem = __ballot(mine);
-			#pragma unroll
-			for (int k = 0; k < 4; ++k) if (xhave[k] && ((minem >> (xtg[k] * 16)) & 1ull) && xv[k]) lanes_at(xtg[k], xs[k], x[k].y);
-			lm = longm;
-			for (uint32_t idx = 0; lm; ++idx) {
-				const int src = __builtin_ctzll(lm);
-				lm &= lm - 1;
-				const uint32_t lb = __shfl(beg, src) + (idx < 4 ? 96u : 32u), le = __shfl(end, src), tg = (uint32_t)src >> 4;
-				if ((minem >> (tg * 16)) & 1ull) for (uint32_t e = lb + lane; e < le; e += 64) { const uint2 r = ent[e]; lanes_add(tg, r.x, r.y); }
+			for (uint32_t b = PFM_RB; b < nblk0; ++b) {
+				uint2 rec[4];
+				load4(ex0, dl0, T0, b, rec);
+				#pragma unroll
+				for (int u = 0; u < 4; ++u) if (mine && rec[u].x != 0xFFFFFFFFu) lanes_add(g, rec[u].x, rec[u].y);
 			}
 			for (uint32_t base = 16; base < maxw; base += 16) {
-				uint32_t xb, xe;
+				uint32_t xb, xe, T, ex;
 				word_range(base + gl, xb, xe);
-				unsigned long long lm = __ballot(mine && xe > xb);
-				while (lm) {
-					const int src = __builtin_ctzll(lm);
-					lm &= lm - 1;
-					const uint32_t lb = __shfl(xb, src), le = __shfl(xe, src), tg = (uint32_t)src >> 4;
-					for (uint32_t e = lb + lane; e < le; e += 64) { const uint2 r = ent[e]; lanes_add(tg, r.x, r.y); }
+				group_scan(xe - xb, T, ex);
+				const uint32_t nb = wave_blocks(T);
+				for (uint32_t b = 0; b < nb; ++b) {
+					uint2 rec[4];
+					load4(ex, xb - ex, T, b, rec);
+					#pragma unroll
+					for (int u = 0; u < 4; ++u) if (mine && rec[u].x != 0xFFFFFFFFu) lanes_add(g, rec[u].x, rec[u].y);
 				}
 			}
 		}
@@ -884,7 +856,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 				++my_units; my_cols += clump_len[c]; my_qlen += len;
 			}
 		} else if (ovf) {
-			for (uint32_t i = gl; i < PFM_HT; i += 16) s_tab[g][i] = 0;
+			for (uint32_t i = gl; i < (1u << HTB); i += 16) s_tab[g][i] = 0;
 			for (uint32_t i = gl; i < PFM_CAND; i += 16) { s_cc[g][i][0] = 0; s_cc[g][i][1] = 0; }
 			if (live && gl == 0) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
 		}
@@ -900,6 +872,13 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
 	if (my_units) { atomicAdd(unit_sum, my_units); atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
 }
+
+template __global__ void k_prefilter_mask<9>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, uint32_t);
+template __global__ void k_prefilter_mask<10>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, uint32_t);
+template __global__ void k_prefilter_mask<11>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, uint32_t);
 
 // ------------------------------------------------------------------------------------------------
 // Bit-parallel semi-global edit distance (Myers 1999 / Hyyro 2003), NW x 32-bit words per DP column.
