@@ -49,6 +49,10 @@ template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_
 	const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *,
 	unsigned long long, uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t);
 __global__ void k_pack_queries(const uint8_t *, const uint64_t *, uint32_t, uint32_t, uint32_t *);
+__global__ void k_rescore_classify(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, int, const uint64_t *, const uint32_t *, const uint8_t *,
+	const uint32_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t, int);
+__global__ void k_rescore_reg(const BhipRawHit *, const uint32_t *, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, const uint32_t *, uint32_t,
+	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *);
 
 // ---- ordering of the output records: (q, refIx) ascending, done on the device (radix sort of 64-bit keys) ----
 __global__ void k_hit_keys(const BhipHit *__restrict__ hits, uint32_t n, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx) {
@@ -99,6 +103,7 @@ struct Counters {
 	uint32_t n_wins_cls[8];
 	uint32_t n_fb, pad2;
 	uint32_t n_tasks_cls[8];
+	uint32_t n_rs[8];          // re-scorer buckets: hits per band-width class
 	unsigned long long wcol_sum, tcol_sum, unit_sum;
 	unsigned long long col_sum, qlen_sum, ent_read, scratch_used;
 };
@@ -111,7 +116,7 @@ struct Lane {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev_cls[kNumClasses][8];   // per class: 0 start, 1 peq done, 2 prefilter done, 3 sweep(pf) done, 4 sweep(ex) done, 5 window done
 	hipEvent_t ev_rs[2];
-	DBuf qlist_cls[kNumClasses], peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters, tasks, ranges, hdr;
+	DBuf qlist_cls[kNumClasses], peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters, tasks, ranges, hdr, rs_lists;
 	uint64_t task_cap = 1 << 20;
 	uint64_t cand_cap = 1 << 18, raw_cap = 1 << 18, win_cap = 1 << 20, scratch_cap = 1 << 18;
 	uint32_t npf[kNumClasses] = {0}, nex[kNumClasses] = {0}, maxE[kNumClasses] = {0}, maxwords[kNumClasses] = {0}, maxlen = 0, n_entries = 0;
@@ -156,6 +161,7 @@ struct Handle {
 	int opt_prefilter_stride = 0; // 0 = automatic sparse seeds, s > 0 = every s-th word (1 = the reference's scheme)
 	int opt_lanes = 6;            // sub-pipelines per batch (1 = everything in order on one stream)
 	int opt_sweep_blocks = 8;     // 256-thread blocks per CU of the column-sweep kernels
+	int opt_rescore_reg = 1;      // register-band re-scorer for narrow bands (0 = LDS band only)
 	int opt_pf_waves = 0;         // single-wave blocks per CU of the lane-resolved prefilter (0 = as many as the LDS allows, <= 12)
 	int opt_pf_table = 0;         // log2 of the per-query hash table (0 = from the workload: 9, 10 or 11)
 	double acx_wmean = 0.0;       // occurrence-weighted mean .acx list length
@@ -170,7 +176,7 @@ extern "C" int bhip_abi_version(void) { return BHIP_ABI_VERSION; }
 static void lane_destroy(Lane *L) {
 	if (!L) return;
 	if (L->stream) (void)hipStreamSynchronize(L->stream);
-	DBuf *all[] = {&L->peq, &L->peqp, &L->cand, &L->candcnt, &L->wins, &L->raw, &L->wide, &L->scratch, &L->fb_list, &L->gcnt, &L->counters, &L->tasks, &L->ranges, &L->hdr};
+	DBuf *all[] = {&L->peq, &L->peqp, &L->cand, &L->candcnt, &L->wins, &L->raw, &L->wide, &L->scratch, &L->fb_list, &L->gcnt, &L->counters, &L->tasks, &L->ranges, &L->hdr, &L->rs_lists};
 	for (DBuf *b : all) b->release();
 	for (auto &b : L->qlist_cls) b.release();
 	for (auto &ce : L->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
@@ -400,6 +406,7 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 	if (!strcmp(name, "two_stage")) { h->opt_two_stage = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "lane_masks")) { h->opt_lane_masks = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "sweep_blocks")) { if (value < 1 || value > 8) return fail(BHIP_E_ARG, "sweep_blocks must be 1 .. 8"); h->opt_sweep_blocks = (int)value; return BHIP_OK; }
+	if (!strcmp(name, "rescore_reg")) { h->opt_rescore_reg = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_waves")) { if (value < 0 || value > 16) return fail(BHIP_E_ARG, "prefilter_waves must be 0 .. 16"); h->opt_pf_waves = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_table")) { if (value != 0 && (value < 9 || value > 11)) return fail(BHIP_E_ARG, "prefilter_table must be 0, 9, 10 or 11"); h->opt_pf_table = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "lanes")) {
@@ -688,6 +695,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	if ((rc = L->cand.reserve(L->cand_cap * sizeof(uint2)))) return rc;
 	if ((rc = L->raw.reserve(L->raw_cap * sizeof(BhipRawHit)))) return rc;
 	if ((rc = L->wide.reserve(L->raw_cap * sizeof(uint32_t)))) return rc;
+	if ((rc = L->rs_lists.reserve(L->raw_cap * sizeof(uint32_t) * 6))) return rc;
 	if ((rc = L->scratch.reserve(L->scratch_cap * sizeof(uint32_t)))) return rc;
 	if ((rc = L->wins.reserve(L->win_cap * sizeof(BhipWin)))) return rc;
 	if ((rc = L->tasks.reserve(L->task_cap * sizeof(uint2)))) return rc;
@@ -771,10 +779,23 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	}
 	// re-scoring of the kept reference lanes of this lane's shared slots
 	HIPCHK(hipEventRecord(L->ev_rs[0], po));
-	const uint32_t grid_rs = (uint32_t)h->n_cu * 16;
+	// classify (exact matches leave here), register-band variants for the narrow bands, LDS band for the rest
+	const uint32_t qw_g = (h->st_maxlen + 7) / 8;
+	hipLaunchKernelGGL(k_rescore_classify, dim3((uint32_t)h->n_cu * 8), dim3(256), 0, po, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap,
+		h->best.as<uint32_t>(), all_hits, h->qoff.as<uint64_t>(), h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr,
+		h->clump_len.as<uint32_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, L->rs_lists.as<uint32_t>(), dc->n_rs, L->wide.as<uint32_t>(), &dc->n_wide,
+		band_rows, h->opt_rescore_reg);
+	HIPCHK(hipGetLastError());
+	if (h->opt_rescore_reg) {
+		hipLaunchKernelGGL(k_rescore_reg, dim3((uint32_t)h->n_cu * 12), dim3(64), 0, po, L->raw.as<BhipRawHit>(), L->rs_lists.as<uint32_t>(), dc->n_rs, (uint32_t)L->raw_cap,
+			h->qoff.as<uint64_t>(), h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr, h->qpack.as<uint32_t>(), qw_g,
+			h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, &sc->err);
+		HIPCHK(hipGetLastError());
+	}
+	const uint32_t grid_rs = (uint32_t)h->n_cu * (h->opt_rescore_reg ? 4 : 16);
 	const size_t lds_rs = (size_t)(band_rows + 1 + qw + rw) * 256;
 	hipLaunchKernelGGL(k_rescore<false>, dim3(grid_rs), dim3(64), lds_rs, po, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap,
-		(const uint32_t *)nullptr, (const uint32_t *)nullptr, h->best.as<uint32_t>(), all_hits, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+		L->rs_lists.as<uint32_t>() + (size_t)5 * L->raw_cap, &dc->n_rs[5], h->best.as<uint32_t>(), all_hits, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 		h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr, h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(),
 		h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, L->wide.as<uint32_t>(),
 		&dc->n_wide, (uint32_t *)nullptr, &dc->scratch_used, 0ull, &sc->err, qw ? h->qpack.as<uint32_t>() : nullptr, band_rows, qw, rw);
@@ -803,14 +824,15 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		if ((rc = h->best.reserve((size_t)(n_shared + 1) * 4))) return rc;
 		if ((rc = h->out.reserve(h->out_cap * sizeof(BhipHit)))) return rc;
 		if ((rc = h->shared_ctr.reserve(sizeof(SharedCtr)))) return rc;
-		if (qw) if ((rc = h->qpack.reserve((size_t)n_q * qw * 4))) return rc;
+		const uint32_t qw_g = (h->st_maxlen + 7) / 8;
+		if ((rc = h->qpack.reserve((size_t)n_q * qw_g * 4 + 16))) return rc;
 		HIPCHK(hipEventRecord(h->ev[0], h->stream));
 		HIPCHK(hipMemsetAsync(h->best.p, 0xFF, (size_t)n_shared * 4, h->stream));
 		HIPCHK(hipMemsetAsync(h->shared_ctr.p, 0, sizeof(SharedCtr), h->stream));
-		if (qw) {
-			const uint64_t total = (uint64_t)n_q * qw;
+		{
+			const uint64_t total = (uint64_t)n_q * qw_g;
 			hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
-				h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), n_q, qw, h->qpack.as<uint32_t>());
+				h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), n_q, qw_g, h->qpack.as<uint32_t>());
 			HIPCHK(hipGetLastError());
 		}
 		HIPCHK(hipEventRecord(h->ev[1], h->stream));

@@ -1387,10 +1387,11 @@ __global__ __launch_bounds__(64) void k_rescore(
 	if (tid < 16) { uint32_t m = 0; for (int r = 0; r < 16; ++r) m |= (lut[16 * tid + r] == 0 ? 1u : 0u) << r; s_mm[tid] = m; }
 	__syncthreads();
 	const uint32_t *refw = (const uint32_t *)refb;
-	uint32_t n = WIDE ? *n_wide_in : *n_raw_dev;
-	if (!WIDE && n > raw_cap) n = raw_cap;
-	for (uint32_t i = blockIdx.x * 64 + tid; i < n; i += gridDim.x * 64) {
-		const BhipRawHit h = raw[WIDE ? wide_in[i] : i];
+	uint32_t n = wide_in ? *n_wide_in : *n_raw_dev;
+	if (n > raw_cap) n = raw_cap;
+	for (uint32_t ii = blockIdx.x * 64 + tid; ii < n; ii += gridDim.x * 64) {
+		const uint32_t i = wide_in ? wide_in[ii] : ii;       // index into raw[]
+		const BhipRawHit h = raw[i];
 		const uint32_t q = h.q, six = qsix ? qsix[q] : q;
 		if (!all_hits && h.ed != best[six]) continue;
 		const uint32_t B = h.ed, c = h.refIx >> 4, z = h.refIx & 15, L = clump_len[c], nchunks = (L + 31) >> 5;
@@ -1424,7 +1425,14 @@ __global__ __launch_bounds__(64) void k_rescore(
 			band = g_scratch + off; stride = 1;
 		}
 		const uint64_t cbase = ref_off[c];
-		const uint32_t INVALID = 255u;
+		if (B > 254u) { atomicOr(err_flags, 1u); continue; }     // beyond the reference's 8-bit DP
+		// One cell = one word ordered exactly like the reference's tie-breaks (burst.c:771-798): score in the top bits, then
+		// 255 - gapQ (larger gapQ wins a score tie), then the predecessor priority diag < up < left, then gapR as payload; the
+		// three-way choice is a single unsigned minimum.  Cells above the budget collapse to one INVALID value: they can
+		// never be the predecessor of a cell within the budget, so their gap counts are never observed.
+		constexpr uint32_t SS = 18, GS = 10;
+		const uint32_t INVALID = (512u << SS) | (255u << GS);
+		const uint32_t STEP_U = (1u << SS) + 1u + (1u << 8), STEP_L = (1u << SS) - (1u << GS) + (2u << 8);
 		// stage the query and the reference segment [dlo-1, dlo+m+Wd] in LDS when they fit
 		const int j8_0 = (dlo - 1) >> 3, j8_1 = (dlo + m + Wd) >> 3;
 		const bool pre = qpack && (uint32_t)m <= 8 * qw && (uint32_t)(j8_1 - j8_0 + 1) <= rw;
@@ -1437,68 +1445,64 @@ __global__ __launch_bounds__(64) void k_rescore(
 		// row 0: D = 0 wherever the column exists (burst.c:4052), else invalid
 		for (int k = 0; k <= Wd; ++k) {
 			const int x = dlo + k;
-			band[(uint32_t)k * stride] = (k < Wd && x >= 0 && x <= (int)L) ? 0u : INVALID;
+			band[(uint32_t)k * stride] = (k < Wd && x >= 0 && x <= (int)L) ? (255u << GS) : INVALID;
 		}
 		uint32_t qdw = 0;
 		for (int y = 1; y <= m; ++y) {
 			uint32_t qc;
 			if (pre) { if (((y - 1) & 7) == 0) qdw = s_q[(uint32_t)((y - 1) >> 3) * 64]; qc = (qdw >> (4 * ((y - 1) & 7))) & 15u; }
 			else qc = qcodes[qb + y - 1] & 15u;
-			const uint32_t mrow = s_mm[qc];
-			const uint32_t col0 = sat8u((uint32_t)y) | (sat8u((uint32_t)y) << 16);   // D=y, H=0, V=y (burst.c:747-750)
+			const uint32_t mrow = s_mm[qc], m1 = qc ? 0xFFFEu : 0u;
+			const uint32_t col0 = (uint32_t)y <= B ? (((uint32_t)y << SS) | (255u << GS) | (uint32_t)y) : INVALID;   // D=y, H=0, V=y (burst.c:747-750)
 			const int x0 = y + dlo;
 			uint32_t left = (x0 - 1 == 0) ? col0 : INVALID;
 			// reference symbols of this row: positions x0-1+k (0-based), fetched 8 at a time
 			int pos = x0 - 1;
 			uint32_t dw = rdw(pos >> 3);
 			uint32_t prev_sym = (y == 1) ? ((rdw((pos - 1) >> 3) >> (4 * ((pos - 1) & 7))) & 15u) : 0u;
+			uint32_t dg = band[0];
 			for (int k = 0; k < Wd; ++k, ++pos) {
 				const int x = x0 + k;
 				if ((pos & 7) == 0 && k) dw = rdw(pos >> 3);
 				const uint32_t r = (dw >> (4 * (pos & 7))) & 15u;
-				const uint32_t dg = band[(uint32_t)k * stride], up = band[(uint32_t)(k + 1) * stride];
+				const uint32_t up = band[(uint32_t)(k + 1) * stride];
 				uint32_t cell;
 				if (x < 1) cell = (x == 0) ? col0 : INVALID;
 				else if (x > (int)L) cell = INVALID;
 				else {
-					const uint32_t cst = ((mrow >> r) & 1u) ? 0u : ((r && qc) ? 1u : 255u);
+					const uint32_t cst = ((mrow >> r) & 1u) ? 0u : (((m1 >> r) & 1u) ? 1u : 255u);
 					if (y == 1) {   // burst.c:722-739
 						uint32_t hh = 0;
 						if (cst == 1 && x >= 2) hh = (mrow >> prev_sym) & 1u;      // left cell of row 1 is 0 iff its symbol matches
-						cell = cst | (hh << 8);
+						cell = cst == 255u ? INVALID : ((cst << SS) | ((255u - hh) << GS));
 					} else {
-						const uint32_t sD = sat8u((dg & 255u) + cst), hD = (dg >> 8) & 255u, vD = (dg >> 16) & 255u;
-						const uint32_t sU = sat8u((up & 255u) + 1u), hU = (up >> 8) & 255u, vU = sat8u(((up >> 16) & 255u) + 1u);
-						uint32_t s = sD < sU ? sD : sU, hv, vv;
-						const bool keepD = (sD == s) && !((sU == sD) && (hU > hD));          // burst.c:771-779
-						hv = keepD ? hD : hU; vv = keepD ? vD : vU;
-						const uint32_t sL = sat8u((left & 255u) + 1u), hL = sat8u(((left >> 8) & 255u) + 1u), vL = (left >> 16) & 255u;
-						const uint32_t s2 = s < sL ? s : sL;
-						const bool keep = (s == s2) && !((sL == s) && (hL > hv));            // burst.c:789-798
-						hv = keep ? hv : hL; vv = keep ? vv : vL;
-						s = s2 >= B + 1 ? 255u : s2;                                          // burst.c:802-803
-						cell = s | (hv << 8) | (vv << 16);
+						const uint32_t cD = dg + (cst << SS), cU = up + STEP_U, cL = left + STEP_L;
+						uint32_t cm = cD < cU ? cD : cU;
+						cm = cm < cL ? cm : cL;
+						cm &= ~0x300u;
+						cell = (cm >> SS) > B ? INVALID : cm;                                // burst.c:802-803
 					}
 				}
 				prev_sym = r;
 				band[(uint32_t)k * stride] = cell;
 				left = cell;
+				dg = up;
 			}
 		}
 		// final selection over the last row (burst.c:824-842) and end position (862-879)
-		uint32_t bs = 255, bh = 0, bv = 0, fin = 0xFFFFFFFFu;
+		uint32_t bkey = 0xFFFFFFFFu, bv = 0, fin = 0xFFFFFFFFu;
 		for (int k = 0; k < Wd; ++k) {
 			const int x = m + dlo + k;
 			if (x < 1 || x > (int)L) continue;
-			const uint32_t cell = band[(uint32_t)k * stride], s = cell & 255u, hh = (cell >> 8) & 255u;
-			if (s < bs || (s == bs && hh > bh)) { bs = s; bh = hh; bv = (cell >> 16) & 255u; }
+			const uint32_t cell = band[(uint32_t)k * stride], key = cell >> GS;
+			if (key < bkey) { bkey = key; bv = cell & 255u; }
 		}
 		for (int k = 0; k < Wd; ++k) {
 			const int x = m + dlo + k;
 			if (x < 1 || x > (int)L) continue;
-			const uint32_t cell = band[(uint32_t)k * stride];
-			if ((cell & 255u) == bs && ((cell >> 8) & 255u) == bh) fin = (uint32_t)x;
+			if ((band[(uint32_t)k * stride] >> GS) == bkey) fin = (uint32_t)x;
 		}
+		const uint32_t bs = bkey >> 8, bh = 255u - (bkey & 255u);
 		if (bs != B) { atomicOr(err_flags, 1u); continue; }   // the reference would abort here (burst.c:812-816)
 		const uint32_t pos = atomicAdd(n_out, 1u);
 		if (pos < out_cap) {
@@ -1509,6 +1513,225 @@ __global__ __launch_bounds__(64) void k_rescore(
 			out[pos] = o;
 		}
 	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Re-scoring, fast path.  k_rescore_classify filters the raw hits (best-of-slot unless all hits are wanted), emits
+// the exact matches directly and sorts the rest by band width into index lists; k_rescore_reg<WB> then runs the same
+// banded 3-plane recurrence as k_rescore with the band (<= WB diagonals) in REGISTERS, fully unrolled, all 64 lanes of
+// a wave busy with hits of similar width.  Bands beyond the widest register variant go to k_rescore (LDS band) and
+// beyond that to its global-scratch variant.
+// ------------------------------------------------------------------------------------------------
+#define BHIP_RS_BUCKETS 7      // 0..4 register variants (6, 8, 12, 16, 24 diagonals), 5 LDS band, 6 global scratch
+__global__ __launch_bounds__(256) void k_rescore_classify(
+		const BhipRawHit *__restrict__ raw, const uint32_t *__restrict__ n_raw_dev, uint32_t raw_cap,
+		const uint32_t *__restrict__ best, int all_hits, const uint64_t *__restrict__ qoff,
+		const uint32_t *__restrict__ qsix, const uint8_t *__restrict__ qrc, const uint32_t *__restrict__ clump_len,
+		BhipHit *__restrict__ out, uint32_t *__restrict__ n_out, uint32_t out_cap,
+		uint32_t *__restrict__ lists, uint32_t *__restrict__ counts, uint32_t *__restrict__ wide, uint32_t *__restrict__ n_wide,
+		uint32_t band_rows, int use_reg) {
+	uint32_t n = *n_raw_dev;
+	if (n > raw_cap) n = raw_cap;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t n_round = (n + 63u) & ~63u;
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_round; i += gridDim.x * 256) {
+		int bucket = -1;           // -1 dropped, -2 exact match
+		BhipRawHit h; h.q = 0; h.refIx = 0; h.ed = 0; h.e_first = 0; h.e_last = 0;
+		uint32_t m = 0, e2 = 0;
+		if (i < n) {
+			h = raw[i];
+			const uint32_t six = qsix ? qsix[h.q] : h.q;
+			if (all_hits || h.ed == best[six]) {
+				const uint32_t L = clump_len[h.refIx >> 4];
+				m = (uint32_t)(qoff[h.q + 1] - qoff[h.q]);
+				e2 = h.e_last < L ? h.e_last : L;
+				if (h.ed == 0) bucket = -2;
+				else {
+					const uint32_t Wd = e2 - h.e_first + 2 * h.ed + 1;
+					bucket = !use_reg || h.ed > 254u ? 5 : Wd <= 6 ? 0 : Wd <= 8 ? 1 : Wd <= 12 ? 2 : Wd <= 16 ? 3 : Wd <= 24 ? 4 : 5;
+					if (Wd > band_rows && bucket == 5) bucket = 6;
+				}
+			}
+		}
+		// exact matches: gap-free, end = LAST column with score 0 (burst.c:862-879), identity 1 - 0/len
+		{
+			const unsigned long long bm = __ballot(bucket == -2);
+			if (bm) {
+				uint32_t base = 0;
+				if (lane == (uint32_t)__builtin_ctzll(bm)) base = atomicAdd(n_out, (uint32_t)__popcll(bm));
+				base = __shfl(base, __builtin_ctzll(bm));
+				if (bucket == -2) {
+					const uint32_t pos = base + __popcll(bm & ((1ull << lane) - 1ull));
+					if (pos < out_cap) {
+						BhipHit o; o.q = h.q; o.refIx = h.refIx; o.finalPos = e2; o.score = 1.0f - 0.0f / (float)m;
+						o.ed = 0; o.gapR = 0; o.gapQ = 0; o.rc = qrc ? qrc[h.q] : 0;
+						out[pos] = o;
+					}
+				}
+			}
+		}
+		#pragma unroll
+		for (int b = 0; b < BHIP_RS_BUCKETS; ++b) {
+			const unsigned long long bm = __ballot(bucket == b);
+			if (!bm) continue;
+			uint32_t *ctr = b == 6 ? n_wide : &counts[b];
+			uint32_t base = 0;
+			if (lane == (uint32_t)__builtin_ctzll(bm)) base = atomicAdd(ctr, (uint32_t)__popcll(bm));
+			base = __shfl(base, __builtin_ctzll(bm));
+			if (bucket == b) {
+				const uint32_t pos = base + __popcll(bm & ((1ull << lane) - 1ull));
+				if (b == 6) wide[pos] = i; else lists[(size_t)b * raw_cap + pos] = i;
+			}
+		}
+	}
+}
+
+template <int WB>
+__device__ __forceinline__ void rescore_reg_one(
+		const BhipRawHit *__restrict__ hp, bool live, uint32_t *s_mm, uint32_t lane,
+		const uint64_t *__restrict__ qoff, const uint8_t *__restrict__ qrc, const uint32_t *__restrict__ qpack, uint32_t qw,
+		const uint32_t *__restrict__ refw, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
+		BhipHit *__restrict__ out, uint32_t *__restrict__ n_out, uint32_t out_cap, uint32_t *__restrict__ err_flags) {
+	constexpr int NW = (WB + 7) / 8 + 1;
+	constexpr uint32_t SS = 18, GS = 10;
+	const uint32_t INVALID = (512u << SS) | (255u << GS), Z0 = 255u << GS;
+	const uint32_t STEP_U = (1u << SS) + 1u + (1u << 8), STEP_L = (1u << SS) - (1u << GS) + (2u << 8);
+	uint32_t bkey = 0xFFFFFFFFu, bv = 0, fin = 0xFFFFFFFFu, m = 0, B = 0, hq = 0, hrefIx = 0;
+	if (live) {
+		const uint32_t q = hp->q;
+		hq = q; hrefIx = hp->refIx;
+		B = hp->ed;
+		const uint32_t h_first = hp->e_first, h_last = hp->e_last;
+		const uint32_t c = hrefIx >> 4, z = hrefIx & 15, L = clump_len[c], nchunks = (L + 31) >> 5;
+		const uint64_t qb = qoff[q];
+		m = (uint32_t)(qoff[q + 1] - qb);
+		const int e2 = (int)(h_last < L ? h_last : L), e1 = (int)h_first;
+		const int dlo = e1 - (int)m - (int)B, Wd = e2 - e1 + 2 * (int)B + 1;
+		const uint64_t cbase = ref_off[c];
+		const uint32_t LIM = (B + 1) << SS;
+		uint32_t bd[WB + 1];
+		#pragma unroll
+		for (int k = 0; k < WB; ++k) { const int x = dlo + k; bd[k] = (k < Wd && x >= 0 && x <= (int)L) ? Z0 : INVALID; }   // row 0 (burst.c:4052)
+		bd[WB] = INVALID;
+		int p = dlo, j8 = dlo >> 3;               // p = 0-based reference position under cell k = 0 of the current row
+		uint32_t d[NW];
+		#pragma unroll
+		for (int i = 0; i < NW; ++i) d[i] = ref_dword(refw, cbase, z, j8 + i, nchunks);
+		uint32_t d_next = ref_dword(refw, cbase, z, j8 + NW, nchunks);
+		const uint32_t *qp = qpack + (uint64_t)q * qw;
+		uint32_t qd = qp[0], q_next = qw > 1 ? qp[1] : 0u;
+		uint32_t prev_sym = (ref_dword(refw, cbase, z, (p - 1) >> 3, nchunks) >> (4 * ((p - 1) & 7))) & 15u;
+		for (int y = 1; y <= (int)m; ++y) {
+			const uint32_t qi = (uint32_t)(y - 1);
+			if ((qi & 7u) == 0 && qi) { qd = q_next; q_next = (qi >> 3) + 1 < qw ? qp[(qi >> 3) + 1] : 0u; }
+			const uint32_t qc = (qd >> (4 * (qi & 7u))) & 15u;
+			const uint32_t mrow = s_mm[qc], m1 = qc ? 0xFFFEu : 0u;
+			const uint32_t col0 = (uint32_t)y <= B ? (((uint32_t)y << SS) | Z0 | (uint32_t)y) : INVALID;   // D=y, H=0, V=y (burst.c:747-750)
+			const int x0 = y + dlo;
+			uint32_t dd[NW - 1];
+			{
+				const uint32_t sh = 4u * ((uint32_t)p & 7u);
+				#pragma unroll
+				for (int i = 0; i < NW - 1; ++i) dd[i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], sh);
+			}
+			const int kmax = (Wd - 1) < ((int)L - x0) ? (Wd - 1) : ((int)L - x0);      // cells beyond are outside the band or the matrix
+			if (y == 1) {   // burst.c:722-739
+				#pragma unroll
+				for (int k = 0; k < WB; ++k) {
+					const int x = x0 + k;
+					const uint32_t r = (dd[k >> 3] >> (4 * (k & 7))) & 15u;
+					const uint32_t cst = ((mrow >> r) & 1u) ? 0u : (((m1 >> r) & 1u) ? 1u : 255u);
+					uint32_t hh = 0;
+					if (cst == 1 && x >= 2) hh = (mrow >> prev_sym) & 1u;          // left cell of row 1 is 0 iff its symbol matches
+					uint32_t cell = cst == 255u ? INVALID : ((cst << SS) | ((255u - hh) << GS));
+					if (x < 1) cell = x == 0 ? col0 : INVALID;
+					if (k > kmax) cell = INVALID;
+					prev_sym = r;
+					bd[k] = cell;
+				}
+			} else {
+				uint32_t left = (x0 - 1 == 0) ? col0 : INVALID;
+				uint32_t dg = bd[0];
+				#pragma unroll
+				for (int k = 0; k < WB; ++k) {
+					const uint32_t r = (dd[k >> 3] >> (4 * (k & 7))) & 15u;
+					const uint32_t up = bd[k + 1];
+					const uint32_t cstS = ((mrow >> r) & 1u) ? 0u : (((m1 >> r) & 1u) ? (1u << SS) : (255u << SS));
+					const uint32_t cD = dg + cstS, cU = up + STEP_U, cL = left + STEP_L;
+					uint32_t cm = cD < cU ? cD : cU;
+					cm = cm < cL ? cm : cL;
+					cm &= ~0x300u;
+					uint32_t cell = cm >= LIM ? INVALID : cm;                          // burst.c:802-803
+					if (x0 < 1) { const int x = x0 + k; if (x < 1) cell = x == 0 ? col0 : INVALID; }
+					if (k > kmax) cell = INVALID;
+					bd[k] = cell;
+					left = cell;
+					dg = up;
+				}
+			}
+			++p;
+			if ((p & 7) == 0) {
+				#pragma unroll
+				for (int i = 0; i < NW - 1; ++i) d[i] = d[i + 1];
+				d[NW - 1] = d_next;
+				++j8;
+				d_next = ref_dword(refw, cbase, z, j8 + NW, nchunks);
+			}
+		}
+		// final selection over the last row (burst.c:824-842) and end position (862-879)
+		#pragma unroll
+		for (int k = 0; k < WB; ++k) {
+			const int x = (int)m + dlo + k;
+			if (k < Wd && x >= 1 && x <= (int)L) { const uint32_t key = bd[k] >> GS; if (key < bkey) { bkey = key; bv = bd[k] & 255u; } }
+		}
+		#pragma unroll
+		for (int k = 0; k < WB; ++k) {
+			const int x = (int)m + dlo + k;
+			if (k < Wd && x >= 1 && x <= (int)L && (bd[k] >> GS) == bkey) fin = (uint32_t)x;
+		}
+	}
+	const uint32_t bs = bkey >> 8, bh = 255u - (bkey & 255u);
+	const bool ok = live && bs == B;
+	if (live && !ok) atomicOr(err_flags, 1u);                     // the reference would abort here (burst.c:812-816)
+	const unsigned long long bm = __ballot(ok);
+	if (bm) {
+		uint32_t base = 0;
+		if (lane == (uint32_t)__builtin_ctzll(bm)) base = atomicAdd(n_out, (uint32_t)__popcll(bm));
+		base = __shfl(base, __builtin_ctzll(bm));
+		if (ok) {
+			const uint32_t pos = base + __popcll(bm & ((1ull << lane) - 1ull));
+			if (pos < out_cap) {
+				BhipHit o;
+				o.q = hq; o.refIx = hrefIx; o.finalPos = fin;
+				o.score = 1.0f - (float)bs / ((float)m + (float)bh);                                  // burst.c:844-847
+				o.ed = (uint8_t)B; o.gapR = (uint8_t)bv; o.gapQ = (uint8_t)bh; o.rc = qrc ? qrc[hq] : 0;
+				out[pos] = o;
+			}
+		}
+	}
+}
+
+__global__ __launch_bounds__(64) void k_rescore_reg(
+		const BhipRawHit *__restrict__ raw, const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint32_t raw_cap,
+		const uint64_t *__restrict__ qoff, const uint8_t *__restrict__ qrc, const uint32_t *__restrict__ qpack, uint32_t qw,
+		const uint8_t *__restrict__ refb, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
+		const uint8_t *__restrict__ lut,
+		BhipHit *__restrict__ out, uint32_t *__restrict__ n_out, uint32_t out_cap, uint32_t *__restrict__ err_flags) {
+	__shared__ uint32_t s_mm[16];      // match masks: bit r of s_mm[q] = (cost(q, r) == 0)
+	const uint32_t tid = threadIdx.x;
+	if (tid < 16) { uint32_t mm = 0; for (int r = 0; r < 16; ++r) mm |= (lut[16 * tid + r] == 0 ? 1u : 0u) << r; s_mm[tid] = mm; }
+	__syncthreads();
+	const uint32_t *refw = (const uint32_t *)refb;
+#define BHIP_RS_RUN(b, WB) { \
+		uint32_t n = counts[b]; if (n > raw_cap) n = raw_cap; \
+		const uint32_t *lst = lists + (size_t)(b) * raw_cap; \
+		const uint32_t n_round = (n + 63u) & ~63u; \
+		for (uint32_t i = blockIdx.x * 64 + tid; i < n_round; i += gridDim.x * 64) { \
+			const bool live = i < n; \
+			rescore_reg_one<WB>(raw + (live ? lst[i] : 0u), live, s_mm, tid, qoff, qrc, qpack, qw, refw, ref_off, clump_len, out, n_out, out_cap, err_flags); \
+		} }
+	BHIP_RS_RUN(0, 6) BHIP_RS_RUN(1, 8) BHIP_RS_RUN(2, 12) BHIP_RS_RUN(3, 16) BHIP_RS_RUN(4, 24)
+#undef BHIP_RS_RUN
 }
 
 template __global__ void k_rescore<false>(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, int,
