@@ -15,7 +15,7 @@
 
 // ---- kernels (bhip_kernels.hip) -------------------------------------------------------------------
 __global__ void k_transpose_refs(const uint8_t *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint4 *);
-__global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, int, int, BhipMatchMask, uint32_t *);
+__global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, int, int, BhipMatchMask, uint32_t *, const uint32_t *, uint32_t);
 template <bool LDS_CNT> __global__ void k_prefilter(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
 	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t,
 	unsigned long long *, const uint32_t *, const uint32_t *, const uint32_t *);
@@ -41,7 +41,7 @@ __global__ void k_attach_masks(const uint32_t *, const uint32_t *, uint64_t, uin
 template <int HTB> __global__ void k_prefilter_mask(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *,
 	uint2 *, uint32_t *, uint32_t);
-__global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, int, const uint32_t *, uint32_t, uint2 *, uint2 *);
+__global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t);
 template <int NWP> __global__ void k_myers_prefix_task(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *,
 	const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *);
 template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *,
@@ -578,7 +578,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, const uint3
 	if ((rc = L->hdr.reserve((size_t)n_list * 8 + 16))) return rc;
 	const uint64_t n_thr = (uint64_t)n_list * W16;
 	hipLaunchKernelGGL(k_seed_ranges, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), d_qlist, n_list,
-		h->acx_off.as<uint32_t>(), h->K, h->plan.as<uint32_t>(), W16, L->ranges.as<uint2>(), L->hdr.as<uint2>());
+		h->acx_off.as<uint32_t>(), h->K, h->plan.as<uint32_t>(), W16, L->ranges.as<uint2>(), L->hdr.as<uint2>(), h->qpack.as<uint32_t>(), (h->st_maxlen + 7) / 8);
 	const uint32_t n_quads = (n_list + 3) / 4;
 	// hash table size per query from the expected number of distinct clumps (sampled words x occurrence-weighted mean list
 	// length): 512 slots keep 12 single-wave blocks on a CU, 1024 -> 7, 2048 -> 4
@@ -672,6 +672,14 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 	HIPCHK(hipEventRecord(h->ev[0], h->stream));
 	if ((rc = upload_queries(h, q_codes, q_off, q_emac, q_six, q_rc, n_q))) return rc;
 	if ((rc = upload_plan(h, q_codes, q_off, q_emac, n_q, plan))) return rc;
+	{	// 4-bit packed copy of the queries at a fixed stride (layout used by the seed, profile and re-scoring kernels)
+		const uint32_t qw_g = (h->st_maxlen + 7) / 8;
+		if ((rc = h->qpack.reserve((size_t)n_q * qw_g * 4 + 16))) return rc;
+		const uint64_t total = (uint64_t)n_q * qw_g;
+		hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
+			h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), n_q, qw_g, h->qpack.as<uint32_t>());
+		HIPCHK(hipGetLastError());
+	}
 	for (uint32_t l = 0; l < nl; ++l) for (int cls = 0; cls < kNumClasses; ++cls) {
 		Lane *L = h->lanes[l];
 		std::vector<uint32_t> &pf = lists[((size_t)l * kNumClasses + cls) * 2], &ex = lists[((size_t)l * kNumClasses + cls) * 2 + 1];
@@ -720,10 +728,10 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		if (L->launches) HIPCHK(hipStreamWaitEvent(pf, L->ev_rs[0], 0));
 		HIPCHK(hipEventRecord(ce[0], pf));
 		{
-			const uint64_t total = (uint64_t)n_list * NW;
-			const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16);
+			const uint32_t qb = 256u / (uint32_t)NW;
+			const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + qb - 1) / qb, (uint64_t)h->n_cu * 16);
 			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, pf, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-				qlist, n_list, NW, 0, h->mm, L->peq.as<uint32_t>());
+				qlist, n_list, NW, 0, h->mm, L->peq.as<uint32_t>(), h->qpack.as<uint32_t>(), (h->st_maxlen + 7) / 8);
 			HIPCHK(hipGetLastError());
 		}
 		// two-stage edit distance when a prefix of 32*NWP symbols is selective for this class's budgets
@@ -734,10 +742,10 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 			if (NWP >= NW) NWP = 0;
 		}
 		if (NWP) {
-			const uint64_t total = (uint64_t)n_list * NWP;
-			const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16);
+			const uint32_t qb = 256u / (uint32_t)NWP;
+			const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + qb - 1) / qb, (uint64_t)h->n_cu * 16);
 			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, pf, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-				qlist, n_list, NWP, 32 * NWP, h->mm, L->peqp.as<uint32_t>());
+				qlist, n_list, NWP, 32 * NWP, h->mm, L->peqp.as<uint32_t>(), h->qpack.as<uint32_t>(), (h->st_maxlen + 7) / 8);
 			HIPCHK(hipGetLastError());
 		}
 		L->prefix_words = (uint32_t)NWP;
@@ -824,17 +832,9 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		if ((rc = h->best.reserve((size_t)(n_shared + 1) * 4))) return rc;
 		if ((rc = h->out.reserve(h->out_cap * sizeof(BhipHit)))) return rc;
 		if ((rc = h->shared_ctr.reserve(sizeof(SharedCtr)))) return rc;
-		const uint32_t qw_g = (h->st_maxlen + 7) / 8;
-		if ((rc = h->qpack.reserve((size_t)n_q * qw_g * 4 + 16))) return rc;
 		HIPCHK(hipEventRecord(h->ev[0], h->stream));
 		HIPCHK(hipMemsetAsync(h->best.p, 0xFF, (size_t)n_shared * 4, h->stream));
 		HIPCHK(hipMemsetAsync(h->shared_ctr.p, 0, sizeof(SharedCtr), h->stream));
-		{
-			const uint64_t total = (uint64_t)n_q * qw_g;
-			hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
-				h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), n_q, qw_g, h->qpack.as<uint32_t>());
-			HIPCHK(hipGetLastError());
-		}
 		HIPCHK(hipEventRecord(h->ev[1], h->stream));
 		HIPCHK(hipStreamWaitEvent(h->sweep_stream, h->ev[1], 0));
 		HIPCHK(hipStreamWaitEvent(h->pf_stream, h->ev[1], 0));
@@ -972,9 +972,9 @@ extern "C" int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint
 	HIPCHK(hipMemcpyAsync(h->pairs.p, pr.data(), n_pairs * sizeof(uint2), hipMemcpyHostToDevice, st));
 	HIPCHK(hipMemsetAsync(L->counters.p, 0, sizeof(Counters), st));
 	Counters *dc = L->counters.as<Counters>();
-	const uint64_t total = (uint64_t)n_q * NW;
-	hipLaunchKernelGGL(k_build_peq, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, st,
-		h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), (const uint32_t *)nullptr, n_q, NW, 0, h->mm, L->peq.as<uint32_t>());
+	const uint32_t qb = 256u / (uint32_t)NW;
+	hipLaunchKernelGGL(k_build_peq, dim3((uint32_t)std::min<uint64_t>(((uint64_t)n_q + qb - 1) / qb, (uint64_t)h->n_cu * 16)), dim3(256), 0, st,
+		h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), (const uint32_t *)nullptr, n_q, NW, 0, h->mm, L->peq.as<uint32_t>(), (const uint32_t *)nullptr, 0u);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(h->ev[0], st));
 	launch_myers(h, L, st, cls, (uint32_t)std::min<uint64_t>((n_pairs + 15) / 16, (uint64_t)h->n_cu * 8), h->pairs.as<uint2>(), nullptr, n_pairs, 0, nullptr,
@@ -1009,6 +1009,14 @@ extern "C" int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64
 			std::vector<uint32_t> plan(n_q, 1u);
 			for (uint32_t i = 0; i < n_q; ++i) plan[i] = make_seed_plan(q_codes + q_off[i], (uint32_t)(q_off[i + 1] - q_off[i]), q_emac[i], (uint32_t)h->K, h->opt_prefilter_stride);
 			if ((rc = upload_plan(h, q_codes, q_off, q_emac, n_q, plan))) return rc;
+	{	// 4-bit packed copy of the queries at a fixed stride (layout used by the seed, profile and re-scoring kernels)
+		const uint32_t qw_g = (h->st_maxlen + 7) / 8;
+		if ((rc = h->qpack.reserve((size_t)n_q * qw_g * 4 + 16))) return rc;
+		const uint64_t total = (uint64_t)n_q * qw_g;
+		hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
+			h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), n_q, qw_g, h->qpack.as<uint32_t>());
+		HIPCHK(hipGetLastError());
+	}
 		}
 		if ((rc = L->cand.reserve(L->cand_cap * sizeof(uint2)))) return rc;
 		if ((rc = L->candcnt.reserve(L->cand_cap * sizeof(uint32_t)))) return rc;

@@ -55,32 +55,76 @@ __global__ void k_transpose_refs(const uint8_t *__restrict__ src, const uint64_t
 // free-start boundary row D[0][x] = 0 of the reference (burst.c:4052 calloc'd row 0).
 // peq[(li*16 + c)*NW + w] bit k = 1 iff k is a filler row or cost(query[32w+k-shift], c) == 0.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_build_peq(const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff,
+__global__ __launch_bounds__(256) void k_build_peq(const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff,
                             const uint32_t *__restrict__ qlist, uint32_t n_list, int NW, int prefix_len,
-                            BhipMatchMask mm, uint32_t *__restrict__ peq) {
-	// one thread per (query, word): reads its 32 symbols once and emits the 16 symbol rows of that word
+                            BhipMatchMask mm, uint32_t *__restrict__ peq, const uint32_t *__restrict__ qpack, uint32_t qw) {
+	// One thread per (query, word) reads its 32 symbols once and produces the 16 symbol rows of that word.  A block owns
+	// QB = 256 / NW whole queries; the rows go through LDS so that the block's 16*NW*QB output words leave as one
+	// contiguous, fully coalesced stream (the natural per-thread stores hit 16 B pieces of 16 different lines).
 	__shared__ uint32_t s_mm[16];
-	if (threadIdx.x < 16) s_mm[threadIdx.x] = mm.m[threadIdx.x];
-	__syncthreads();
-	const uint64_t total = (uint64_t)n_list * NW;
-	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-		const uint32_t w = (uint32_t)(i % NW), li = (uint32_t)(i / NW);
-		const uint32_t q = qlist ? qlist[li] : li;
-		const uint64_t b = qoff[q];
-		int len = (int)(qoff[q + 1] - b);
-		if (prefix_len > 0 && len > prefix_len) len = prefix_len;     // table of the first prefix_len symbols only (k_myers_prefix)
-		const int shift = 32 * NW - len;
-		uint32_t row[16];
-		#pragma unroll
-		for (int c = 0; c < 16; ++c) row[c] = 0;
-		for (int k = 0; k < 32; ++k) {
-			const int pos = 32 * (int)w + k - shift;
-			const uint32_t m16 = pos < 0 ? 0xFFFFu : s_mm[qcodes[b + pos] & 15];
+	__shared__ uint32_t s_out[256 * 16 + 256];
+	const uint32_t tid = threadIdx.x;
+	if (tid < 16) s_mm[tid] = mm.m[tid];
+	const uint32_t QB = 256u / (uint32_t)NW, per_q = 16u * (uint32_t)NW;
+	const uint32_t lq = tid / (uint32_t)NW, w = tid % (uint32_t)NW;
+	const uint32_t step_q = 256u / per_q, step_r = 256u % per_q;
+	for (uint32_t q0 = blockIdx.x * QB; q0 < n_list; q0 += gridDim.x * QB) {
+		__syncthreads();
+		const uint32_t li = q0 + lq;
+		if (lq < QB && li < n_list) {
+			const uint32_t q = qlist ? qlist[li] : li;
+			const uint64_t b = qoff[q];
+			int len = (int)(qoff[q + 1] - b);
+			if (prefix_len > 0 && len > prefix_len) len = prefix_len;     // table of the first prefix_len symbols only (k_myers_prefix)
+			const int shift = 32 * NW - len;
+			// X[j] = 16-bit match mask of symbol j (low half) and of symbol j + 16 (high half); a 16 x 16 bit transpose done on
+			// both halves at once turns the 16 words into the 16 symbol rows (bit k of row c = bit c of the mask of symbol k)
+			uint32_t row[16];
+			if (qpack) {   // 4-bit packed symbols: five dwords cover the 32 positions at any alignment
+				const int pb = 32 * (int)w - shift, j0 = pb >> 3;
+				const uint32_t *qp = qpack + (uint64_t)q * qw;
+				uint32_t D[5], dd[4];
+				#pragma unroll
+				for (int i = 0; i < 5; ++i) D[i] = (j0 + i >= 0 && (uint32_t)(j0 + i) < qw) ? qp[j0 + i] : 0u;
+				#pragma unroll
+				for (int i = 0; i < 4; ++i) dd[i] = __builtin_amdgcn_alignbit(D[i + 1], D[i], 4u * ((uint32_t)pb & 7u));
+				#pragma unroll
+				for (int j = 0; j < 16; ++j) {
+					const uint32_t lo = pb + j < 0 ? 0xFFFFu : s_mm[(dd[j >> 3] >> (4 * (j & 7))) & 15u];
+					const uint32_t hi = pb + j + 16 < 0 ? 0xFFFFu : s_mm[(dd[2 + (j >> 3)] >> (4 * (j & 7))) & 15u];
+					row[j] = lo | (hi << 16);
+				}
+			} else {
+				#pragma unroll
+				for (int j = 0; j < 16; ++j) {
+					const int p0 = 32 * (int)w + j - shift, p1 = p0 + 16;
+					const uint32_t lo = p0 < 0 ? 0xFFFFu : s_mm[qcodes[b + p0] & 15], hi = p1 < 0 ? 0xFFFFu : s_mm[qcodes[b + p1] & 15];
+					row[j] = lo | (hi << 16);
+				}
+			}
 			#pragma unroll
-			for (int c = 0; c < 16; ++c) row[c] |= ((m16 >> c) & 1u) << k;
+			for (int st = 0; st < 4; ++st) {
+				const int j = 8 >> st;
+				const uint32_t msk = st == 0 ? 0x00FF00FFu : st == 1 ? 0x0F0F0F0Fu : st == 2 ? 0x33333333u : 0x55555555u;
+				#pragma unroll
+				for (int k = 0; k < 16; ++k) if (!(k & j)) {
+					const uint32_t t = ((row[k] >> j) ^ row[k + j]) & msk;
+					row[k + j] ^= t;
+					row[k] ^= t << j;
+				}
+			}
+			#pragma unroll
+			for (int c = 0; c < 16; ++c) s_out[lq * (per_q + 1) + (uint32_t)c * (uint32_t)NW + w] = row[c];     // +1: bank spread
 		}
-		#pragma unroll
-		for (int c = 0; c < 16; ++c) peq[((uint64_t)li * 16 + c) * NW + w] = row[c];
+		__syncthreads();
+		const uint32_t nq = n_list - q0 < QB ? n_list - q0 : QB, total = nq * per_q;
+		uint32_t *dst = peq + (uint64_t)q0 * per_q;
+		uint32_t oq = tid / per_q, orr = tid % per_q;
+		for (uint32_t idx = tid; idx < total; idx += 256) {
+			dst[idx] = s_out[oq * (per_q + 1) + orr];
+			oq += step_q; orr += step_r;
+			if (orr >= per_q) { orr -= per_q; ++oq; }
+		}
 	}
 }
 
@@ -583,7 +627,7 @@ __device__ __forceinline__ void pfm_bump4(uint32_t *tab, uint32_t *dummy, const 
 __global__ __launch_bounds__(256) void k_seed_ranges(
 		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint32_t *__restrict__ qlist, uint32_t n_list,
 		const uint32_t *__restrict__ acx_off, int K, const uint32_t *__restrict__ plan, uint32_t W16,
-		uint2 *__restrict__ ranges, uint2 *__restrict__ hdr) {
+		uint2 *__restrict__ ranges, uint2 *__restrict__ hdr, const uint32_t *__restrict__ qpack, uint32_t qw) {
 	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	const uint32_t li = (uint32_t)(t / W16), j = (uint32_t)(t % W16);
 	if (li >= n_list) return;
@@ -598,7 +642,17 @@ __global__ __launch_bounds__(256) void k_seed_ranges(
 		const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
 		const uint32_t p = j * stride;
 		uint32_t w = 0, ok = 1;
-		for (int k = 0; k < K; ++k) {
+		if (qpack) {   // K <= 15 symbols = at most three dwords of 4-bit codes
+			const uint32_t *qp = qpack + (uint64_t)q * qw;
+			const uint32_t j0 = p >> 3, sh = 4u * (p & 7u);
+			const uint32_t d0 = qp[j0], d1 = j0 + 1 < qw ? qp[j0 + 1] : 0u, d2 = j0 + 2 < qw ? qp[j0 + 2] : 0u;
+			const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+			for (int k = 0; k < K; ++k) {
+				const uint32_t c = ((k < 8 ? lo : hi) >> (4 * (k & 7))) & 15u;
+				ok &= (c - 1u) < 4u;
+				w = (w << 2) | ((c - 1u) & 3u);
+			}
+		} else for (int k = 0; k < K; ++k) {
 			const uint32_t c = qcodes[b + p + k];
 			ok &= (c - 1u) < 4u;
 			w = (w << 2) | ((c - 1u) & 3u);
@@ -1530,59 +1584,56 @@ __global__ __launch_bounds__(256) void k_rescore_classify(
 		BhipHit *__restrict__ out, uint32_t *__restrict__ n_out, uint32_t out_cap,
 		uint32_t *__restrict__ lists, uint32_t *__restrict__ counts, uint32_t *__restrict__ wide, uint32_t *__restrict__ n_wide,
 		uint32_t band_rows, int use_reg) {
+	// one global reservation per bucket and 1024-hit chunk (ranks inside the chunk come from LDS counters)
+	__shared__ uint32_t s_cnt[8], s_base[8];
 	uint32_t n = *n_raw_dev;
 	if (n > raw_cap) n = raw_cap;
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t n_round = (n + 63u) & ~63u;
-	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_round; i += gridDim.x * 256) {
-		int bucket = -1;           // -1 dropped, -2 exact match
-		BhipRawHit h; h.q = 0; h.refIx = 0; h.ed = 0; h.e_first = 0; h.e_last = 0;
-		uint32_t m = 0, e2 = 0;
-		if (i < n) {
-			h = raw[i];
-			const uint32_t six = qsix ? qsix[h.q] : h.q;
-			if (all_hits || h.ed == best[six]) {
-				const uint32_t L = clump_len[h.refIx >> 4];
-				m = (uint32_t)(qoff[h.q + 1] - qoff[h.q]);
-				e2 = h.e_last < L ? h.e_last : L;
-				if (h.ed == 0) bucket = -2;
-				else {
-					const uint32_t Wd = e2 - h.e_first + 2 * h.ed + 1;
-					bucket = !use_reg || h.ed > 254u ? 5 : Wd <= 6 ? 0 : Wd <= 8 ? 1 : Wd <= 12 ? 2 : Wd <= 16 ? 3 : Wd <= 24 ? 4 : 5;
-					if (Wd > band_rows && bucket == 5) bucket = 6;
-				}
-			}
-		}
-		// exact matches: gap-free, end = LAST column with score 0 (burst.c:862-879), identity 1 - 0/len
-		{
-			const unsigned long long bm = __ballot(bucket == -2);
-			if (bm) {
-				uint32_t base = 0;
-				if (lane == (uint32_t)__builtin_ctzll(bm)) base = atomicAdd(n_out, (uint32_t)__popcll(bm));
-				base = __shfl(base, __builtin_ctzll(bm));
-				if (bucket == -2) {
-					const uint32_t pos = base + __popcll(bm & ((1ull << lane) - 1ull));
-					if (pos < out_cap) {
-						BhipHit o; o.q = h.q; o.refIx = h.refIx; o.finalPos = e2; o.score = 1.0f - 0.0f / (float)m;
-						o.ed = 0; o.gapR = 0; o.gapQ = 0; o.rc = qrc ? qrc[h.q] : 0;
-						out[pos] = o;
-					}
-				}
-			}
-		}
+	const uint32_t tid = threadIdx.x;
+	for (uint32_t chunk = blockIdx.x * 1024u; chunk < n; chunk += gridDim.x * 1024u) {
+		if (tid < 8) s_cnt[tid] = 0;
+		__syncthreads();
+		int bucket[4]; uint32_t rank[4], e2v[4], mv[4], qv[4], rv[4];
 		#pragma unroll
-		for (int b = 0; b < BHIP_RS_BUCKETS; ++b) {
-			const unsigned long long bm = __ballot(bucket == b);
-			if (!bm) continue;
-			uint32_t *ctr = b == 6 ? n_wide : &counts[b];
-			uint32_t base = 0;
-			if (lane == (uint32_t)__builtin_ctzll(bm)) base = atomicAdd(ctr, (uint32_t)__popcll(bm));
-			base = __shfl(base, __builtin_ctzll(bm));
-			if (bucket == b) {
-				const uint32_t pos = base + __popcll(bm & ((1ull << lane) - 1ull));
-				if (b == 6) wide[pos] = i; else lists[(size_t)b * raw_cap + pos] = i;
+		for (int t = 0; t < 4; ++t) {
+			const uint32_t i = chunk + (uint32_t)t * 256u + tid;
+			bucket[t] = -1; rank[t] = 0; e2v[t] = 0; mv[t] = 0; qv[t] = 0; rv[t] = 0;
+			if (i < n) {
+				const BhipRawHit h = raw[i];
+				const uint32_t six = qsix ? qsix[h.q] : h.q;
+				if (all_hits || h.ed == best[six]) {
+					const uint32_t L = clump_len[h.refIx >> 4];
+					const uint32_t e2 = h.e_last < L ? h.e_last : L;
+					qv[t] = h.q; rv[t] = h.refIx; e2v[t] = e2;
+					if (h.ed == 0) { bucket[t] = 7; mv[t] = (uint32_t)(qoff[h.q + 1] - qoff[h.q]); }     // exact match
+					else {
+						const uint32_t Wd = e2 - h.e_first + 2 * h.ed + 1;
+						int bk = !use_reg || h.ed > 254u ? 5 : Wd <= 6 ? 0 : Wd <= 8 ? 1 : Wd <= 12 ? 2 : Wd <= 16 ? 3 : Wd <= 24 ? 4 : 5;
+						if (Wd > band_rows && bk == 5) bk = 6;
+						bucket[t] = bk;
+					}
+					rank[t] = atomicAdd(&s_cnt[bucket[t]], 1u);
+				}
 			}
 		}
+		__syncthreads();
+		if (tid < 8 && s_cnt[tid]) s_base[tid] = atomicAdd(tid == 7 ? n_out : tid == 6 ? n_wide : &counts[tid], s_cnt[tid]);
+		__syncthreads();
+		#pragma unroll
+		for (int t = 0; t < 4; ++t) {
+			const uint32_t i = chunk + (uint32_t)t * 256u + tid;
+			const int bk = bucket[t];
+			if (bk < 0) continue;
+			const uint32_t pos = s_base[bk] + rank[t];
+			if (bk == 7) {   // gap-free, end = LAST column with score 0 (burst.c:862-879), identity 1 - 0/len
+				if (pos < out_cap) {
+					BhipHit o; o.q = qv[t]; o.refIx = rv[t]; o.finalPos = e2v[t]; o.score = 1.0f - 0.0f / (float)mv[t];
+					o.ed = 0; o.gapR = 0; o.gapQ = 0; o.rc = qrc ? qrc[qv[t]] : 0;
+					out[pos] = o;
+				}
+			} else if (bk == 6) wide[pos] = i;
+			else lists[(size_t)bk * raw_cap + pos] = i;
+		}
+		__syncthreads();
 	}
 }
 
