@@ -161,6 +161,7 @@ struct Handle {
 	int opt_prefilter_stride = 0; // 0 = automatic sparse seeds, s > 0 = every s-th word (1 = the reference's scheme)
 	int opt_lanes = 6;            // sub-pipelines per batch (1 = everything in order on one stream)
 	int opt_sweep_blocks = 8;     // 256-thread blocks per CU of the column-sweep kernels
+	int opt_lane_min = 32768;     // fewest entries a sub-pipeline is worth opening for
 	int opt_rescore_reg = 1;      // register-band re-scorer for narrow bands (0 = LDS band only)
 	int opt_pf_waves = 0;         // single-wave blocks per CU of the lane-resolved prefilter (0 = as many as the LDS allows, <= 12)
 	int opt_pf_table = 0;         // log2 of the per-query hash table (0 = from the workload: 9, 10 or 11)
@@ -406,6 +407,7 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 	if (!strcmp(name, "two_stage")) { h->opt_two_stage = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "lane_masks")) { h->opt_lane_masks = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "sweep_blocks")) { if (value < 1 || value > 8) return fail(BHIP_E_ARG, "sweep_blocks must be 1 .. 8"); h->opt_sweep_blocks = (int)value; return BHIP_OK; }
+	if (!strcmp(name, "lane_min_entries")) { if (value < 1) return fail(BHIP_E_ARG, "lane_min_entries must be >= 1"); h->opt_lane_min = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "rescore_reg")) { h->opt_rescore_reg = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_waves")) { if (value < 0 || value > 16) return fail(BHIP_E_ARG, "prefilter_waves must be 0 .. 16"); h->opt_pf_waves = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_table")) { if (value != 0 && (value < 9 || value > 11)) return fail(BHIP_E_ARG, "prefilter_table must be 0, 9, 10 or 11"); h->opt_pf_table = (int)value; return BHIP_OK; }
@@ -639,7 +641,7 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 	HIPCHK(hipSetDevice(h->device));
 	// number of lanes: enough entries per lane to fill the chip
 	uint32_t nl = (uint32_t)h->opt_lanes;
-	while (nl > 1 && n_q / nl < 32768) --nl;
+	while (nl > 1 && n_q / nl < (uint32_t)h->opt_lane_min) --nl;
 	int rc;
 	if ((rc = ensure_lanes(h, nl))) return rc;
 	h->st_lanes = nl;

@@ -127,7 +127,12 @@ int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64_t *q_off, 
  * 1 = every word = the reference's own threshold count > len-(E+1)K (burst.c:4091-4092, 4126).
  * "two_stage": 1 (default) = prefix filter + windowed full-length edit distance, 0 = one full-length sweep.
  * "lanes": 1..16 (default 6) sub-pipelines a staged batch is cut into; their prefilter / sweep / window+re-score stages
- * run as a software pipeline on three HIP streams.  "sweep_blocks": 1..8 workgroups per CU of the sweep kernels. */
+ * run as a software pipeline on three HIP streams; "lane_min_entries" (default 32768) = fewest entries worth a lane.
+ * "sweep_blocks": 1..8 workgroups per CU of the sweep kernels.  "lane_masks": 1 (default) = lane-resolved prefilter.
+ * "prefilter_table": 0 (default, chosen from the accelerator's list lengths) or 9/10/11 = log2 slots of the per-query
+ * hash table; "prefilter_waves": 0 (default, as many as fit) .. 16 single-wave prefilter blocks per CU.
+ * "rescore_reg": 1 (default) = register-band re-scorer for narrow bands, 0 = LDS band only.
+ * None of these changes a result. */
 int bhip_set_option(void *handle, const char *name, long long value);
 
 /* Stats of the last call; device properties (name, CU count) for reports. */

@@ -210,3 +210,61 @@ def test_ambiguous_queries_through_the_prefilter(thres, iupac):
         assert len(exp) > 20
         assert_hits_equal(got, exp)
     dev.close()
+
+
+@pytest.mark.parametrize("qlen,stride,thres", [(100, 0, 0.97), (250, 4, 0.96), (250, 0, 0.95)])
+def test_tuning_options_do_not_change_results(qlen, stride, thres):
+    """table size of the lane-resolved prefilter, register vs LDS band re-scorer, number of sub-pipelines and seed stride are
+    performance knobs only: every combination must return the oracle's records (250-bp reads at stride 4 sample 60 words:
+    more than one 16-word chunk per query and more list records than stay in registers between the two passes)"""
+    from burst_amd import capi
+    K = 12
+    seqs = family_db(131, 6, 48, 520, rate=0.04)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lens, entries, offs = dbutil.build_acx(seqs, K)
+    lists = dbutil.pack_acx_lists(lens, entries, 0)
+    lut = ol.score_lut(1)
+    dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=lists, acx_fmt=0, K=K)
+    q, _ = make_queries(seqs, 90, qlen, [0, 1, 2, 3, 5, 8], 133, thres=thres)
+    q.flags = np.zeros(q.n, np.uint8)
+    exp = oracle_hits(packed, clump_len, tot, q, lut, False)
+    assert len(exp) > 40
+    dev.set_option("prefilter_stride", stride)
+    dev.set_option("lane_min_entries", 8)
+    for table in (9, 10, 11):
+        for reg in (1, 0):
+            for lanes in (1, 3):
+                dev.set_option("prefilter_table", table)
+                dev.set_option("rescore_reg", reg)
+                dev.set_option("lanes", lanes)
+                got = dev.align_batch(q, all_hits=False)
+                assert_hits_equal(got, exp)
+    dev.set_option("prefilter_table", 0)
+    dev.set_option("rescore_reg", 1)
+    exp_all = oracle_hits(packed, clump_len, tot, q, lut, True)
+    assert_hits_equal(dev.align_batch(q, all_hits=True), exp_all)
+    dev.close()
+
+
+def test_prefilter_overflow_paths():
+    """one huge family: every query meets > 300 clumps.  With the 512-slot table the per-query hash overflows (dense
+    fallback kernel); with 2048 slots it fits but there are far more than 24 candidate clumps per query (clump-level
+    pairs handed to the 16-lane sweep).  Same records either way."""
+    from burst_amd import capi
+    K = 12
+    seqs = family_db(141, 1, 5200, 300, rate=0.02)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    assert len(clump_len) > 300
+    lens, entries, offs = dbutil.build_acx(seqs, K)
+    lists = dbutil.pack_acx_lists(lens, entries, 0)
+    lut = ol.score_lut(1)
+    dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=lists, acx_fmt=0, K=K)
+    q, _ = make_queries(seqs, 12, 100, [0, 1, 3], 143, thres=0.97)
+    q.flags = np.zeros(q.n, np.uint8)
+    for all_hits in (False, True):
+        exp = oracle_hits(packed, clump_len, tot, q, lut, all_hits)
+        assert len(exp) > 12
+        for table in (9, 11, 0):
+            dev.set_option("prefilter_table", table)
+            assert_hits_equal(dev.align_batch(q, all_hits=all_hits), exp)
+    dev.close()
