@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--iupac", type=float, default=0.0, help="fraction of read bases replaced by a compatible IUPAC code")
     ap.add_argument("--edits", default="0,1,2,3", help="edit counts sampled per read")
     ap.add_argument("--one-stage", action="store_true", help="disable the prefix-filter stage of the edit-distance kernels")
-    ap.add_argument("--lanes", type=int, default=6, help="sub-pipelines (HIP streams) per batch inside the library")
+    ap.add_argument("--lanes", type=int, default=0, help="sub-pipelines (HIP streams) per batch inside the library")
     ap.add_argument("--sweep-blocks", type=int, default=0, help="256-thread blocks per CU for the column sweep (0 = library default)")
     ap.add_argument("--prefilter-waves", type=int, default=0, help="single-wave prefilter blocks per CU (0 = library default)")
     ap.add_argument("--prefilter-stride", type=int, default=0, help="0 = automatic sparse seeds (default), 1 = every word (reference scheme)")
@@ -135,7 +135,8 @@ def main():
     dev = db.open_device(local_rank)
     dev.set_option("prefilter_stride", args.prefilter_stride)
     dev.set_option("two_stage", 0 if args.one_stage else 1)
-    dev.set_option("lanes", args.lanes)
+    if args.lanes:
+        dev.set_option("lanes", args.lanes)
     if args.sweep_blocks:
         dev.set_option("sweep_blocks", args.sweep_blocks)
     if args.prefilter_waves:
@@ -196,19 +197,36 @@ def main():
             log("[bench] prefilter phase share: " + " ".join("%d:%.1f%%" % (i, 100.0 * v / tot) for i, v in enumerate(arr)) + "  total wave-cycles %.3g" % tot)
     if rank == 0:
         st = per_step[-1]
+        mean = lambda k: float(np.mean([s[k] for s in per_step]))
         two_stage = st["prefix_words"] > 0
-        # dominant kernel: the column sweep over every candidate lane (k_myers_prefix on the two-stage path, else k_myers)
-        ms_myers = float(np.mean([s["ms_myers_prefix"] if two_stage else s["ms_myers"] for s in per_step]))
-        launches = max(1, st["myers_launches"])
-        achieved = st["bytes_algorithmic"] / launches / (ms_myers / launches * 1e-3) / 1e9 if ms_myers > 0 else 0.0
+        masked = st["prefilter_launches"] > 0
+        # Algorithmic bytes per kernel launch (SURVEY.md 8d figures): prefilter = 8 B offset pair per
+        # sampled word + 3 B per list entry (the SMALL .acx size) + 8 B per emitted task; column sweeps = 0.5 B (one 4-bit
+        # symbol) per swept column of one reference lane + len/2 B of query and 12 B of result per unit.
+        kernels = {}
+        if masked and mean("ms_prefilter_hash") > 0:
+            n = max(1, st["prefilter_launches"])
+            kernels["k_prefilter_mask"] = (mean("ms_prefilter_hash") / n, (8.0 * st["n_seed_words"] + 3.0 * st["acx_entries_read"] + 8.0 * st["n_lane_tasks"]) / n)
+        n = max(1, st["myers_launches"])
+        if two_stage:
+            cols = st["n_task_columns"] if masked else st["n_columns"] * 16
+            units = st["n_lane_tasks"] if masked else st["n_pairs"] * 16
+            kernels["k_myers_prefix%s<%d>" % ("_task" if masked else "", st["prefix_words"])] = (mean("ms_myers_prefix") / n, (0.5 * cols + units * (args.read_len / 2.0 + 12.0)) / n)
+            kernels["k_myers_window<%d>" % ((args.read_len + 31) // 32)] = (mean("ms_myers_window") / n, (0.5 * st["n_window_columns"] + st["n_windows"] * (args.read_len / 2.0 + 12.0)) / n)
+        else:
+            kernels["k_myers<%d>" % ((args.read_len + 31) // 32)] = (mean("ms_myers") / n, st["bytes_algorithmic"] / n)
+        dom = max(kernels, key=lambda k: kernels[k][0] * (st["prefilter_launches"] if k == "k_prefilter_mask" else n))
+        ms_dom, bytes_dom = kernels[dom]
+        achieved = bytes_dom / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic_k_myers.json")
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tf)).get(dom.split("<")[0], {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        cells = st["n_columns"] * 16.0 * args.read_len
+        cells = (st["n_task_columns"] if masked else st["n_columns"] * 16.0) * min(args.read_len, 32.0 * max(1, st["prefix_words"])) + st["n_window_columns"] * float(args.read_len)
+        ms_sweeps = mean("ms_myers")
         res = {
             "metric": "aligned reads/sec (node), 100-bp synthetic reads vs GG97-like .edx/.acx, -m %s -i %s" % (args.mode, args.id),
             "value": total_reads * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -218,15 +236,17 @@ def main():
                                    % (args.reads, args.read_len, args.n_base * args.n_variants, args.ref_len, db.c.numRclumps, args.mode, args.id),
                        "parallelism": "query-sharded x%d, DB replicated, RCCL gather of hit records" % world,
                        "device": info["name"], "n_cu": info["n_cu"]},
-            "roofline": {"bound": "hbm", "kernel": ("k_myers_prefix<%d>" % st["prefix_words"]) if two_stage else "k_myers<4>", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic,
-                         "note": "integer bit-vector recurrence: VALU-bound by construction (SURVEY 8d); GCUPS below is the truthful figure of merit",
-                         "algorithmic_bytes_per_launch": st["bytes_algorithmic"] / launches, "ms_per_launch": ms_myers / launches,
-                         "gcups_equivalent": cells / (ms_myers * 1e-3) / 1e9 if ms_myers > 0 else 0.0},
-            "phases_ms": {k: float(np.mean([s[k] for s in per_step])) for k in ("ms_peq", "ms_prefilter", "ms_myers", "ms_myers_prefix", "ms_myers_window", "ms_rescore", "ms_d2h", "ms_total")},
+                         "note": "dominant kernel by time; k_prefilter_mask is bound by HBM/LDS latency of short random list gathers, the k_myers_* sweeps by integer VALU issue (SURVEY 8d): their GCUPS is the truthful figure of merit",
+                         "algorithmic_bytes_per_launch": bytes_dom, "ms_per_launch": ms_dom,
+                         "per_kernel": {k: {"ms_per_launch": v[0], "algorithmic_bytes_per_launch": v[1], "GBps": (v[1] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else 0.0)} for k, v in kernels.items()},
+                         "gcups_sweeps": cells / (ms_sweeps * 1e-3) / 1e9 if ms_sweeps > 0 else 0.0},
+            "phases_ms": {k: float(np.mean([s[k] for s in per_step])) for k in ("ms_peq", "ms_prefilter", "ms_seed", "ms_prefilter_hash", "ms_myers", "ms_myers_prefix", "ms_myers_window", "ms_rescore", "ms_d2h", "ms_total")},
             "work": {"pairs_per_read": st["n_pairs"] / max(1, q.n), "raw_hits": st["n_raw_hits"], "hits": st["n_hits"],
                      "acx_entries_per_read": st["acx_entries_read"] / max(1, q.n), "dp_columns": st["n_columns"],
-                     "windows": st["n_windows"], "window_columns": st["n_window_columns"]},
+                     "windows": st["n_windows"], "window_columns": st["n_window_columns"], "lane_tasks": st["n_lane_tasks"], "task_columns": st["n_task_columns"],
+                     "seed_words_per_read": st["n_seed_words"] / max(1, q.n)},
         }
         res["cpu_baseline"] = cpu_baseline(edx, acx, reads_fa, args)
         if res["cpu_baseline"]:

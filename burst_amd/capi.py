@@ -26,11 +26,11 @@ class BhipStats(C.Structure):
     _fields_ = [("n_queries", C.c_uint64), ("n_pairs", C.c_uint64), ("n_columns", C.c_uint64),
                 ("n_raw_hits", C.c_uint64), ("n_hits", C.c_uint64), ("acx_entries_read", C.c_uint64),
                 ("bytes_algorithmic", C.c_uint64), ("n_windows", C.c_uint64), ("n_window_columns", C.c_uint64),
-                ("n_lane_tasks", C.c_uint64), ("n_task_columns", C.c_uint64),
+                ("n_lane_tasks", C.c_uint64), ("n_task_columns", C.c_uint64), ("n_seed_words", C.c_uint64),
                 ("ms_h2d", C.c_float), ("ms_prefilter", C.c_float), ("ms_peq", C.c_float), ("ms_myers", C.c_float),
                 ("ms_rescore", C.c_float), ("ms_d2h", C.c_float), ("ms_total", C.c_float),
-                ("ms_myers_prefix", C.c_float), ("ms_myers_window", C.c_float),
-                ("myers_launches", C.c_uint32), ("prefix_words", C.c_uint32)]
+                ("ms_myers_prefix", C.c_float), ("ms_myers_window", C.c_float), ("ms_prefilter_hash", C.c_float), ("ms_seed", C.c_float),
+                ("myers_launches", C.c_uint32), ("prefix_words", C.c_uint32), ("prefilter_launches", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

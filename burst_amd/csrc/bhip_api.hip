@@ -116,6 +116,10 @@ struct Lane {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev_cls[kNumClasses][8];   // per class: 0 start, 1 peq done, 2 prefilter done, 3 sweep(pf) done, 4 sweep(ex) done, 5 window done
 	hipEvent_t ev_rs[2];
+	hipEvent_t ev_pf[kNumClasses][3];    // per class: seed lookup start, hash kernel start, hash kernel done
+	uint64_t seed_words[kNumClasses] = {0};
+	uint32_t pf_launches = 0;
+	bool pf_masked[kNumClasses] = {false};
 	DBuf qlist_cls[kNumClasses], peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters, tasks, ranges, hdr, rs_lists;
 	uint64_t task_cap = 1 << 20;
 	uint64_t cand_cap = 1 << 18, raw_cap = 1 << 18, win_cap = 1 << 20, scratch_cap = 1 << 18;
@@ -159,7 +163,7 @@ struct Handle {
 	float st_ms_h2d = 0;
 	int opt_two_stage = 1;        // 1 = prefix filter + windowed full-length stage when it pays, 0 = always the one-stage sweep
 	int opt_prefilter_stride = 0; // 0 = automatic sparse seeds, s > 0 = every s-th word (1 = the reference's scheme)
-	int opt_lanes = 6;            // sub-pipelines per batch (1 = everything in order on one stream)
+	int opt_lanes = 1;            // sub-pipelines per staged batch (the stage kernels fill the chip on their own; > 1 only helps small batches)
 	int opt_sweep_blocks = 8;     // 256-thread blocks per CU of the column-sweep kernels
 	int opt_lane_min = 32768;     // fewest entries a sub-pipeline is worth opening for
 	int opt_rescore_reg = 1;      // register-band re-scorer for narrow bands (0 = LDS band only)
@@ -182,6 +186,7 @@ static void lane_destroy(Lane *L) {
 	for (auto &b : L->qlist_cls) b.release();
 	for (auto &ce : L->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
 	for (auto &e : L->ev_rs) if (e) (void)hipEventDestroy(e);
+	for (auto &ce : L->ev_pf) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
 	if (L->stream) (void)hipStreamDestroy(L->stream);
 	if (L->hc_pinned) (void)hipHostFree(L->hc_pinned);
 	delete L;
@@ -189,10 +194,11 @@ static void lane_destroy(Lane *L) {
 
 static int lane_create(Handle *h, Lane **out) {
 	Lane *L = new Lane();
-	memset(L->ev_cls, 0, sizeof L->ev_cls); memset(L->ev_rs, 0, sizeof L->ev_rs);
+	memset(L->ev_cls, 0, sizeof L->ev_cls); memset(L->ev_rs, 0, sizeof L->ev_rs); memset(L->ev_pf, 0, sizeof L->ev_pf);
 	if (hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipStreamCreate failed"); }
 	for (auto &ce : L->ev_cls) for (auto &e : ce) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
 	for (auto &e : L->ev_rs) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
+	for (auto &ce : L->ev_pf) for (auto &e : ce) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
 	int rc = L->counters.reserve(sizeof(Counters));
 	if (rc) { lane_destroy(L); return rc; }
 	if (hipHostMalloc((void **)&L->hc_pinned, sizeof(Counters), hipHostMallocDefault) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipHostMalloc failed"); }
@@ -570,7 +576,7 @@ static int launch_prefilter(Handle *h, Lane *L, hipStream_t pf_st, const uint32_
 
 // lane-resolved prefilter: tasks (list position, reference lane) into L->tasks; queries whose table overflowed go through the
 // dense clump-level kernels into L->cand as (list position, clump) pairs
-static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, const uint32_t *d_qlist, uint32_t n_list, uint32_t maxwords, uint32_t *n_tasks_dev,
+static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, const uint32_t *d_qlist, uint32_t n_list, uint32_t maxwords, uint32_t *n_tasks_dev,
                                  uint32_t *n_cand_dev, Counters *dc) {
 	int rc;
 	if ((rc = L->fb_list.reserve((size_t)n_list * 4 + 16))) return rc;
@@ -579,6 +585,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, const uint3
 	if ((rc = L->ranges.reserve((size_t)n_list * W16 * 8 + 16))) return rc;
 	if ((rc = L->hdr.reserve((size_t)n_list * 8 + 16))) return rc;
 	const uint64_t n_thr = (uint64_t)n_list * W16;
+	HIPCHK(hipEventRecord(L->ev_pf[cls][0], st));
 	hipLaunchKernelGGL(k_seed_ranges, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), d_qlist, n_list,
 		h->acx_off.as<uint32_t>(), h->K, h->plan.as<uint32_t>(), W16, L->ranges.as<uint2>(), L->hdr.as<uint2>(), h->qpack.as<uint32_t>(), (h->st_maxlen + 7) / 8);
 	const uint32_t n_quads = (n_list + 3) / 4;
@@ -594,9 +601,12 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, const uint3
 		h->ent_mask.as<uint2>(), h->bad.as<uint32_t>(), h->n_bad, \
 		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
 		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, L->cand.as<uint2>(), n_cand_dev, (uint32_t)L->cand_cap)
+	HIPCHK(hipEventRecord(L->ev_pf[cls][1], st));
 	if (htb == 9) PFM_LAUNCH(9); else if (htb == 10) PFM_LAUNCH(10); else PFM_LAUNCH(11);
 #undef PFM_LAUNCH
 	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(L->ev_pf[cls][2], st));
+	++L->pf_launches;
 	// dense fallback for overflowed queries (clump-level pairs)
 	const uint32_t *bad = h->bad.as<uint32_t>();
 	const bool narrow = h->st_maxlen < 255u + (uint32_t)h->K;
@@ -649,7 +659,7 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 	// host-side routing: lane by shared slot, class by length, prefilter vs exhaustive (entries nobody can guarantee a k-mer for)
 	std::vector<std::vector<uint32_t>> lists((size_t)nl * kNumClasses * 2);
 	std::vector<uint32_t> plan(n_q, 1u);
-	for (uint32_t l = 0; l < nl; ++l) { Lane *L = h->lanes[l]; for (int c = 0; c < kNumClasses; ++c) L->npf[c] = L->nex[c] = L->maxE[c] = L->maxwords[c] = 0; L->maxlen = 0; L->n_entries = 0; }
+	for (uint32_t l = 0; l < nl; ++l) { Lane *L = h->lanes[l]; for (int c = 0; c < kNumClasses; ++c) { L->npf[c] = L->nex[c] = L->maxE[c] = L->maxwords[c] = 0; L->seed_words[c] = 0; } L->maxlen = 0; L->n_entries = 0; }
 	for (uint32_t i = 0; i < n_q; ++i) {
 		const uint64_t len = q_off[i + 1] - q_off[i];
 		if (len == 0) continue;
@@ -667,7 +677,11 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 		lists[((size_t)l * kNumClasses + cls) * 2 + ex].push_back(i);
 		Lane *L = h->lanes[l];
 		L->maxE[cls] = std::max<uint32_t>(L->maxE[cls], q_emac[i]);
-		if (!ex && len >= (uint64_t)h->K) L->maxwords[cls] = std::max<uint32_t>(L->maxwords[cls], (uint32_t)((len - h->K) / (plan[i] & 255u) + 1));
+		if (!ex && len >= (uint64_t)h->K) {
+			const uint32_t nwd = (uint32_t)((len - h->K) / (plan[i] & 255u) + 1);
+			L->maxwords[cls] = std::max<uint32_t>(L->maxwords[cls], nwd);
+			L->seed_words[cls] += nwd;
+		}
 		L->maxlen = std::max<uint32_t>(L->maxlen, (uint32_t)len);
 		++L->n_entries;
 	}
@@ -717,7 +731,8 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	HIPCHK(hipMemsetAsync(L->counters.p, 0, sizeof(Counters), pf));
 	Counters *dc = L->counters.as<Counters>();
 	SharedCtr *sc = h->shared_ctr.as<SharedCtr>();
-	L->launches = 0; L->prefix_words = 0; L->n_pairs_ex = 0;
+	L->launches = 0; L->prefix_words = 0; L->n_pairs_ex = 0; L->pf_launches = 0;
+	for (int c = 0; c < kNumClasses; ++c) L->pf_masked[c] = false;
 	const uint32_t grid_my = (uint32_t)h->n_cu * (uint32_t)h->opt_sweep_blocks;   // < 8 leaves wave slots for the other stages' kernels
 	(void)start;
 	for (int cls = 0; cls < kNumClasses; ++cls) {
@@ -754,10 +769,11 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		HIPCHK(hipEventRecord(ce[1], pf));
 		const bool masked = NWP && n_pf && h->has_masks && h->opt_lane_masks;
 		if (n_pf) {
-			if (masked) { if ((rc = launch_prefilter_mask(h, L, pf, qlist, n_pf, L->maxwords[cls], &dc->n_tasks_cls[cls], &dc->n_cand_cls[cls], dc))) return rc; }
+			if (masked) { if ((rc = launch_prefilter_mask(h, L, pf, cls, qlist, n_pf, L->maxwords[cls], &dc->n_tasks_cls[cls], &dc->n_cand_cls[cls], dc))) return rc; }
 			else if ((rc = launch_prefilter(h, L, pf, qlist, n_pf, L->cand.as<uint2>(), nullptr, (uint32_t)L->cand_cap, true, &dc->n_cand_cls[cls], dc))) return rc;
 		}
 		L->masked = masked;
+		L->pf_masked[cls] = masked && n_pf;
 		HIPCHK(hipEventRecord(ce[2], pf));
 		// column sweep on the sweep stream, behind this lane's prefilter
 		HIPCHK(hipStreamWaitEvent(sw, ce[2], 0));
@@ -892,7 +908,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			if (!L->n_entries) continue;
 			const Counters &c = L->hc;
 			S.n_pairs += L->n_pairs_ex + c.unit_sum; S.n_columns += c.col_sum; S.n_task_columns += c.tcol_sum; S.n_raw_hits += c.n_raw; S.acx_entries_read += c.ent_read;
-			S.myers_launches += L->launches; S.n_window_columns += c.wcol_sum; qlen_sum += c.qlen_sum;
+			S.myers_launches += L->launches; S.prefilter_launches += L->pf_launches; S.n_window_columns += c.wcol_sum; qlen_sum += c.qlen_sum;
 			if (L->prefix_words) S.prefix_words = L->prefix_words;
 			for (int cls = 0; cls < kNumClasses; ++cls) {
 				S.n_pairs += c.n_cand_cls[cls]; S.n_windows += c.n_wins_cls[cls]; S.n_lane_tasks += c.n_tasks_cls[cls];
@@ -900,6 +916,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 				hipEvent_t *ce = L->ev_cls[cls];
 				S.ms_peq += ev_ms(ce[0], ce[1]);
 				if (L->npf[cls]) S.ms_prefilter += ev_ms(ce[1], ce[2]);
+				if (L->npf[cls] && L->pf_masked[cls]) { S.ms_seed += ev_ms(L->ev_pf[cls][0], L->ev_pf[cls][1]); S.ms_prefilter_hash += ev_ms(L->ev_pf[cls][1], L->ev_pf[cls][2]); S.n_seed_words += L->seed_words[cls]; }
 				const float sweep = ev_ms(ce[6], ce[4]), win = ev_ms(ce[4], ce[5]);
 				S.ms_myers += sweep + win;
 				if (L->prefix_words) { S.ms_myers_prefix += sweep; S.ms_myers_window += win; }

@@ -61,11 +61,15 @@ typedef struct BhipStats {
 	uint64_t n_window_columns; /* columns swept by the full-length stage over those windows */
 	uint64_t n_lane_tasks;     /* (query, reference lane) tasks emitted by the lane-resolved prefilter (0 = clump-level path) */
 	uint64_t n_task_columns;   /* columns swept by the prefix stage over those tasks */
+	uint64_t n_seed_words;     /* sampled query words looked up in the accelerator by the lane-resolved prefilter */
 	float ms_h2d, ms_prefilter, ms_peq, ms_myers, ms_rescore, ms_d2h, ms_total;
 	float ms_myers_prefix;     /* part of ms_myers spent in k_myers_prefix (the dominant kernel when the two-stage path runs) */
 	float ms_myers_window;     /* part of ms_myers spent in k_myers_window */
+	float ms_prefilter_hash;   /* part of ms_prefilter spent in k_prefilter_mask (HIP events around that kernel alone) */
+	float ms_seed;             /* part of ms_prefilter spent in k_seed_ranges */
 	uint32_t myers_launches;   /* launches of the column-sweeping kernel (k_myers_prefix, or k_myers on the one-stage path) */
 	uint32_t prefix_words;     /* NWP of the last launch, 0 = one-stage path */
+	uint32_t prefilter_launches; /* launches of k_prefilter_mask */
 } BhipStats;
 
 /* Upload a database to device `device` and create a handle.
@@ -126,7 +130,7 @@ int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64_t *q_off, 
  * ceil(K/s) of them), fewest .acx look-ups with the same no-false-negative guarantee; s >= 1 forces every s-th word,
  * 1 = every word = the reference's own threshold count > len-(E+1)K (burst.c:4091-4092, 4126).
  * "two_stage": 1 (default) = prefix filter + windowed full-length edit distance, 0 = one full-length sweep.
- * "lanes": 1..16 (default 6) sub-pipelines a staged batch is cut into; their prefilter / sweep / window+re-score stages
+ * "lanes": 1..16 (default 1) sub-pipelines a staged batch is cut into; their prefilter / sweep / window+re-score stages
  * run as a software pipeline on three HIP streams; "lane_min_entries" (default 32768) = fewest entries worth a lane.
  * "sweep_blocks": 1..8 workgroups per CU of the sweep kernels.  "lane_masks": 1 (default) = lane-resolved prefilter.
  * "prefilter_table": 0 (default, chosen from the accelerator's list lengths) or 9/10/11 = log2 slots of the per-query

@@ -24,7 +24,7 @@ def test_header_symbols_exported():
     for s in syms:
         assert hasattr(lib, s), s
     assert lib.bhip_abi_version() == 1
-    assert ctypes.sizeof(capi.BhipStats) == 11 * 8 + 9 * 4 + 2 * 4 + 4   # 11 u64 + 9 f32 + 2 u32, padded to 8
+    assert ctypes.sizeof(capi.BhipStats) == 12 * 8 + 11 * 4 + 3 * 4          # 12 u64 + 11 f32 + 3 u32
     assert capi.HIT_DTYPE.itemsize == 20
 
 
