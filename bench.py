@@ -151,17 +151,24 @@ def main():
 
     from burst_amd import dist as bdist
 
-    def gather_hits(hits):
-        """one variable-length gather of hit records to rank 0 (burst_amd.dist: all_gather of counts + padded gather over RCCL)"""
-        return bdist.gather_hits(hits, rank, world, "cuda" if world > 1 else "cpu")
+    # N > 1: every rank hands its records to its own host (as at N = 1) AND one RCCL gather per step brings all records into
+    # rank 0's HBM, where they stay resident (burst_amd.dist.PaddedGather: device buffers filled by a device-to-device copy
+    # from the library, asynchronous, double-buffered so the xGMI transfer overlaps the next step's alignment)
+    pg = None
 
     def step():
         nonlocal buf
         hits, buf = dev.align_staged(all_hits, buf)
-        g = gather_hits(hits)
-        return hits, g
+        if pg is not None:
+            n = dev.copy_hits_device(pg.payload_ptr(), pg.cap)
+            pg.post(n)
+        return hits, None
 
-    step()          # sizes the library's grow-only device buffers for this workload (setup, not a warmup step)
+    hits0, _ = step()          # sizes the library's grow-only device buffers for this workload (setup, not a warmup step)
+    if world > 1:           # same capacity on every rank: the largest shard's record count plus slack
+        mx = torch.tensor([len(hits0)], dtype=torch.int64, device="cuda")
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        pg = bdist.PaddedGather(int(mx.item()) + int(mx.item()) // 8 + 4096, rank, world, torch.device("cuda", local_rank))
     for _ in range(args.warmup):
         step()
     per_step = []
@@ -172,6 +179,8 @@ def main():
     for _ in range(args.steps):
         hits, _g = step()
         per_step.append(dev.stats())
+    if pg is not None:
+        pg.wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -37,7 +37,7 @@ class BhipStats(C.Structure):
 
 
 EXPORTS = ["bhip_init", "bhip_stage_queries", "bhip_align_staged", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_set_option", "bhip_get_stats",
-           "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version"]
+           "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version", "bhip_copy_hits_device"]
 
 
 class BurstHipError(RuntimeError):
@@ -70,6 +70,8 @@ def _load():
     lib.bhip_get_stats.restype = i32
     lib.bhip_device_info.argtypes = [vp, C.c_char_p, i32, C.POINTER(i32), C.POINTER(u64)]
     lib.bhip_device_info.restype = i32
+    lib.bhip_copy_hits_device.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    lib.bhip_copy_hits_device.restype = i32
     lib.bhip_destroy.argtypes = [vp]
     lib.bhip_destroy.restype = None
     lib.bhip_last_error.argtypes = []
@@ -192,6 +194,12 @@ class Device:
                 continue
             _chk(rc)
             return hits[:n.value], hits
+
+    def copy_hits_device(self, dst_ptr, cap_records):
+        """device-to-device copy of the last call's records into caller-owned device memory (e.g. a torch tensor's data_ptr())"""
+        n = C.c_uint64()
+        _chk(lib().bhip_copy_hits_device(self._h, C.c_void_p(int(dst_ptr)), int(cap_records), C.byref(n)))
+        return int(n.value)
 
     def align_pairs(self, q, pair_q, pair_clump):
         pair_q = _arr(pair_q, np.uint32)

@@ -14,7 +14,7 @@
 #include "bhip_internal.h"
 
 // ---- kernels (bhip_kernels.hip) -------------------------------------------------------------------
-__global__ void k_transpose_refs(const uint8_t *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint4 *);
+__global__ void k_transpose_refs(const uint8_t *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint4 *, uint4 *);
 __global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, int, int, BhipMatchMask, uint32_t *, const uint32_t *, uint32_t);
 template <bool LDS_CNT> __global__ void k_prefilter(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
 	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t,
@@ -144,7 +144,7 @@ struct Handle {
 	hipEvent_t ev[10];
 	// database
 	uint32_t n_clumps = 0, tot_refs = 0, max_clump_len = 0;
-	DBuf ref, ref_off, clump_len, lut;
+	DBuf ref, ref_lane, ref_off, clump_len, lut;      // ref: 16 lanes interleaved per 32-column chunk; ref_lane: each lane contiguous
 	BhipMatchMask mm;
 	bool has_acx = false; int K = 0;
 	DBuf acx_off, acx_ent, bad, ent_mask; uint32_t n_bad = 0; uint64_t n_ent = 0;
@@ -165,6 +165,7 @@ struct Handle {
 	int opt_prefilter_stride = 0; // 0 = automatic sparse seeds, s > 0 = every s-th word (1 = the reference's scheme)
 	int opt_lanes = 1;            // sub-pipelines per staged batch (the stage kernels fill the chip on their own; > 1 only helps small batches)
 	int opt_sweep_blocks = 8;     // 256-thread blocks per CU of the column-sweep kernels
+	uint64_t last_n_out = 0;      // records of the last bhip_align_staged call, still resident (sorted) in out_sorted
 	int opt_lane_min = 32768;     // fewest entries a sub-pipeline is worth opening for
 	int opt_rescore_reg = 1;      // register-band re-scorer for narrow bands (0 = LDS band only)
 	int opt_pf_waves = 0;         // single-wave blocks per CU of the lane-resolved prefilter (0 = as many as the LDS allows, <= 12)
@@ -216,7 +217,7 @@ extern "C" void bhip_destroy(void *handle) {
 	if (h->pf_stream) (void)hipStreamSynchronize(h->pf_stream);
 	if (h->post_stream) (void)hipStreamSynchronize(h->post_stream);
 	for (Lane *L : h->lanes) lane_destroy(L);
-	DBuf *all[] = {&h->ref, &h->ref_off, &h->clump_len, &h->lut, &h->acx_off, &h->acx_ent, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
+	DBuf *all[] = {&h->ref, &h->ref_lane, &h->ref_off, &h->clump_len, &h->lut, &h->acx_off, &h->acx_ent, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
 		&h->qsix, &h->qrc, &h->best, &h->out, &h->shared_ctr, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx, &h->sort_idx2,
 		&h->sort_tmp, &h->out_sorted, &h->qpack, &h->plan, &h->ent_mask};
 	for (DBuf *b : all) b->release();
@@ -333,6 +334,7 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		INITRC(d_src.reserve(src_off[n_clumps] * 16 + 16));
 		INITRC(d_srcoff.reserve((n_clumps + 1) * sizeof(uint64_t)));
 		INITRC(h->ref.reserve(dst_off[n_clumps] * 256 + 256));
+		INITRC(h->ref_lane.reserve(dst_off[n_clumps] * 256 + 256));
 		INITRC(h->ref_off.reserve((n_clumps + 1) * sizeof(uint64_t)));
 		INITRC(h->clump_len.reserve(n_clumps * sizeof(uint32_t)));
 		INITRC(h->lut.reserve(256));
@@ -343,7 +345,7 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		INITCHK(hipMemcpyAsync(h->lut.p, score_lut, 256, hipMemcpyHostToDevice, h->stream));
 		const uint32_t grid = std::min<uint32_t>(n_clumps, (uint32_t)h->n_cu * 8);
 		hipLaunchKernelGGL(k_transpose_refs, dim3(grid), dim3(256), 0, h->stream, d_src.as<uint8_t>(), d_srcoff.as<uint64_t>(),
-			h->clump_len.as<uint32_t>(), h->ref_off.as<uint64_t>(), n_clumps, h->ref.as<uint4>());
+			h->clump_len.as<uint32_t>(), h->ref_off.as<uint64_t>(), n_clumps, h->ref.as<uint4>(), h->ref_lane.as<uint4>());
 		INITCHK(hipGetLastError());
 		INITCHK(hipStreamSynchronize(h->stream));
 		d_src.release(); d_srcoff.release();
@@ -407,7 +409,7 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 	Handle *h = (Handle *)handle;
 	if (!h || !name) return fail(BHIP_E_ARG, "null argument");
 	if (!strcmp(name, "prefilter_stride")) {
-		if (value < 0 || value > 15) return fail(BHIP_E_ARG, "prefilter_stride must be 0 (auto) .. 15");
+		if (value < 0 || value > 64) return fail(BHIP_E_ARG, "prefilter_stride must be 0 (auto) .. 64");
 		h->opt_prefilter_stride = (int)value; return BHIP_OK;
 	}
 	if (!strcmp(name, "two_stage")) { h->opt_two_stage = value != 0; return BHIP_OK; }
@@ -453,14 +455,14 @@ static void launch_prefix(Handle *h, Lane *L, hipStream_t st, int NWP, uint32_t 
 static void launch_prefix_task(Handle *h, Lane *L, hipStream_t st, int NWP, uint32_t grid, const uint32_t *n_tasks_dev, const uint32_t *qlist,
 		uint32_t *n_wins, Counters *dc) {
 	#define LT(N) hipLaunchKernelGGL(k_myers_prefix_task<N>, dim3(grid), dim3(64), 0, st, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, qlist, \
-		L->peqp.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
+		L->peqp.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
 		L->wins.as<BhipWin>(), n_wins, (uint32_t)L->win_cap, &dc->tcol_sum)
 	if (NWP == 1) LT(1); else if (NWP == 2) LT(2); else if (NWP == 3) LT(3); else if (NWP == 4) LT(4); else LT(6);
 	#undef LT
 }
 static void launch_window(Handle *h, Lane *L, hipStream_t wst, int cls, int NWP, uint32_t grid, const uint32_t *qlist, const uint32_t *n_wins, Counters *dc) {
 	#define LW(N) hipLaunchKernelGGL(k_myers_window<N>, dim3(grid), dim3(256), 0, wst, L->wins.as<BhipWin>(), n_wins, (uint32_t)L->win_cap, NWP, qlist, \
-		L->peq.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->ref.as<uint4>(), \
+		L->peq.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->ref_lane.as<uint4>(), \
 		h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), &dc->wcol_sum)
 	switch (kClasses[cls]) { case 2: LW(2); break; case 4: LW(4); break; case 6: LW(6); break; case 8: LW(8); break; case 10: LW(10); break;
 		case 16: LW(16); break; default: LW(32); break; }
@@ -815,7 +817,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	if (h->opt_rescore_reg) {
 		hipLaunchKernelGGL(k_rescore_reg, dim3((uint32_t)h->n_cu * 12), dim3(64), 0, po, L->raw.as<BhipRawHit>(), L->rs_lists.as<uint32_t>(), dc->n_rs, (uint32_t)L->raw_cap,
 			h->qoff.as<uint64_t>(), h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr, h->qpack.as<uint32_t>(), qw_g,
-			h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, &sc->err);
+			h->ref_lane.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, &sc->err);
 		HIPCHK(hipGetLastError());
 	}
 	const uint32_t grid_rs = (uint32_t)h->n_cu * (h->opt_rescore_reg ? 4 : 16);
@@ -899,6 +901,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		if (hsc.err & 1u) return fail(BHIP_E_INTERNAL, "re-scoring could not reproduce a hit found by the edit-distance kernel");
 		if (hsc.n_out > h->out_cap) { h->out_cap = (uint64_t)hsc.n_out + hsc.n_out / 8 + 1024; continue; }
 		*n_hits = hsc.n_out;
+		h->last_n_out = 0;
 		// statistics
 		BhipStats &S = h->stats;
 		S.n_queries = n_q; S.n_hits = hsc.n_out;
@@ -924,7 +927,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			S.ms_rescore += ev_ms(L->ev_rs[0], L->ev_rs[1]);
 		}
 		S.bytes_algorithmic = 8ull * S.n_columns + qlen_sum / 2 + 192ull * S.n_pairs;
-		if (hsc.n_out > cap) return fail(BHIP_E_CAPACITY, "hit buffer holds %llu records, %u needed", (unsigned long long)cap, hsc.n_out);
+		if (hits && hsc.n_out > cap) return fail(BHIP_E_CAPACITY, "hit buffer holds %llu records, %u needed", (unsigned long long)cap, hsc.n_out);
 		HIPCHK(hipEventRecord(h->ev[8], h->stream));
 		if (hsc.n_out) {
 			const uint32_t n = hsc.n_out;
@@ -941,7 +944,8 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 				h->sort_idx2.as<uint32_t>(), (int)n, 0, 32 + qbits, h->stream));
 			hipLaunchKernelGGL(k_hit_gather, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), h->sort_idx2.as<uint32_t>(), n, h->out_sorted.as<BhipHit>());
 			HIPCHK(hipGetLastError());
-			HIPCHK(hipMemcpyAsync(hits, h->out_sorted.p, (size_t)n * sizeof(BhipHit), hipMemcpyDeviceToHost, h->stream));
+			if (hits) HIPCHK(hipMemcpyAsync(hits, h->out_sorted.p, (size_t)n * sizeof(BhipHit), hipMemcpyDeviceToHost, h->stream));
+			h->last_n_out = n;
 		}
 		HIPCHK(hipEventRecord(h->ev[9], h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
@@ -1069,4 +1073,18 @@ extern "C" int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64
 		return BHIP_OK;
 	}
 	return fail(BHIP_E_INTERNAL, "candidate buffer kept overflowing");
+}
+
+// Device-resident copy of the last call's records (same order as the host copy): for device-side collectives.
+extern "C" int bhip_copy_hits_device(void *handle, void *dst_device, uint64_t cap_records, uint64_t *n_records) {
+	Handle *h = (Handle *)handle;
+	if (!h || !n_records) return fail(BHIP_E_ARG, "null argument");
+	*n_records = h->last_n_out;
+	if (!h->last_n_out) return BHIP_OK;
+	if (!dst_device) return fail(BHIP_E_ARG, "null destination");
+	if (h->last_n_out > cap_records) return fail(BHIP_E_CAPACITY, "device buffer holds %llu records, %llu needed", (unsigned long long)cap_records, (unsigned long long)h->last_n_out);
+	HIPCHK(hipSetDevice(h->device));
+	HIPCHK(hipMemcpyAsync(dst_device, h->out_sorted.p, (size_t)h->last_n_out * sizeof(BhipHit), hipMemcpyDeviceToDevice, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	return BHIP_OK;
 }

@@ -28,8 +28,11 @@
 // ------------------------------------------------------------------------------------------------
 __global__ void k_transpose_refs(const uint8_t *__restrict__ src, const uint64_t *__restrict__ src_off,
                                  const uint32_t *__restrict__ clump_len, const uint64_t *__restrict__ dst_off,
-                                 uint32_t n_clumps, uint4 *__restrict__ dst) {
-	// one 16-thread group per (clump, chunk); grid-stride over clumps
+                                 uint32_t n_clumps, uint4 *__restrict__ dst, uint4 *__restrict__ dst_lane) {
+	// one 16-thread group per (clump, chunk); grid-stride over clumps.  Two layouts of the same words: `dst` interleaves the
+	// 16 lanes of a chunk (16 threads of the clump-level kernels read 256 contiguous bytes), `dst_lane` keeps each lane's
+	// chunks contiguous inside the clump's area (the one-thread-per-lane kernels stream 16 B after 16 B of one cache line
+	// instead of touching a new 128-byte line for every 32 columns)
 	const uint32_t z = threadIdx.x & 15, g = threadIdx.x >> 4, gpb = blockDim.x >> 4;
 	for (uint32_t c = blockIdx.x; c < n_clumps; c += gridDim.x) {
 		const uint32_t L = clump_len[c], nrows = (L + 1) >> 1, nchunks = (L + 31) >> 5;
@@ -43,6 +46,7 @@ __global__ void k_transpose_refs(const uint8_t *__restrict__ src, const uint64_t
 				w[i >> 2] |= b << (8 * (i & 3));
 			}
 			dst[(dst_off[c] + t) * 16 + z] = make_uint4(w[0], w[1], w[2], w[3]);
+			dst_lane[dst_off[c] * 16 + (uint64_t)z * nchunks + t] = make_uint4(w[0], w[1], w[2], w[3]);
 		}
 	}
 }
@@ -1272,9 +1276,9 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 		}
 		int score = (int)P;
 		uint32_t flags = 0;
-		const uint4 *rp = ref + ref_off[c] * 16 + z;
+		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)z * nchunks;        // lane-major copy
 		for (uint32_t t = 0; t < nchunks; ++t) {
-			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint4 ch = rp[t];
 			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
 			int cmin = 0x7FFFFFFF;
 			#pragma unroll
@@ -1336,10 +1340,10 @@ __global__ __launch_bounds__(256) void k_myers_window(
 		}
 		int score = (int)m, bestS = 0x7FFFFFFF;
 		uint32_t first = 0, last = 0;
-		const uint4 *rp = ref + ref_off[c] * 16 + z;
+		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)z * nchunks;        // lane-major copy
 		const uint32_t *tab = peq + (uint64_t)li * 16 * NW;
 		for (uint32_t t = tA; t <= tB; ++t) {
-			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint4 ch = rp[t];
 			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
 			#pragma unroll 8
 			for (int k = 0; k < 32; ++k) {
@@ -1400,6 +1404,11 @@ __device__ __forceinline__ uint32_t sat8u(uint32_t v) { return v > 255u ? 255u :
 __device__ __forceinline__ uint32_t ref_dword(const uint32_t *__restrict__ refw, uint64_t clump_base, uint32_t z, int j8, uint32_t nchunks) {
 	if (j8 < 0 || (uint32_t)j8 >= nchunks * 4) return 0u;
 	return refw[((clump_base + ((uint32_t)j8 >> 2)) * 16 + z) * 4 + ((uint32_t)j8 & 3)];
+}
+
+__device__ __forceinline__ uint32_t ref_dword_lane(const uint32_t *__restrict__ refw_lane, uint64_t clump_base, uint32_t z, int j8, uint32_t nchunks) {
+	if (j8 < 0 || (uint32_t)j8 >= nchunks * 4) return 0u;
+	return refw_lane[(clump_base * 16 + (uint64_t)z * nchunks) * 4 + (uint32_t)j8];
 }
 
 // 4-bit packing of the queries at a fixed stride of qw dwords per query (k_rescore preloads them into LDS)
@@ -1667,11 +1676,11 @@ __device__ __forceinline__ void rescore_reg_one(
 		int p = dlo, j8 = dlo >> 3;               // p = 0-based reference position under cell k = 0 of the current row
 		uint32_t d[NW];
 		#pragma unroll
-		for (int i = 0; i < NW; ++i) d[i] = ref_dword(refw, cbase, z, j8 + i, nchunks);
-		uint32_t d_next = ref_dword(refw, cbase, z, j8 + NW, nchunks);
+		for (int i = 0; i < NW; ++i) d[i] = ref_dword_lane(refw, cbase, z, j8 + i, nchunks);
+		uint32_t d_next = ref_dword_lane(refw, cbase, z, j8 + NW, nchunks);
 		const uint32_t *qp = qpack + (uint64_t)q * qw;
 		uint32_t qd = qp[0], q_next = qw > 1 ? qp[1] : 0u;
-		uint32_t prev_sym = (ref_dword(refw, cbase, z, (p - 1) >> 3, nchunks) >> (4 * ((p - 1) & 7))) & 15u;
+		uint32_t prev_sym = (ref_dword_lane(refw, cbase, z, (p - 1) >> 3, nchunks) >> (4 * ((p - 1) & 7))) & 15u;
 		for (int y = 1; y <= (int)m; ++y) {
 			const uint32_t qi = (uint32_t)(y - 1);
 			if ((qi & 7u) == 0 && qi) { qd = q_next; q_next = (qi >> 3) + 1 < qw ? qp[(qi >> 3) + 1] : 0u; }
@@ -1726,7 +1735,7 @@ __device__ __forceinline__ void rescore_reg_one(
 				for (int i = 0; i < NW - 1; ++i) d[i] = d[i + 1];
 				d[NW - 1] = d_next;
 				++j8;
-				d_next = ref_dword(refw, cbase, z, j8 + NW, nchunks);
+				d_next = ref_dword_lane(refw, cbase, z, j8 + NW, nchunks);
 			}
 		}
 		// final selection over the last row (burst.c:824-842) and end position (862-879)

@@ -125,6 +125,11 @@ int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64_t *q_off, 
                    uint32_t n_q, uint32_t *out_q, uint32_t *out_clump, uint32_t *out_count,
                    uint64_t cap, uint64_t *n_out);
 
+/* The records of the last bhip_align_staged / bhip_align_batch call stay resident on the device (same order as the host
+ * copy; `hits` may be NULL there to skip the host copy altogether).  This copies them into caller-owned DEVICE memory,
+ * e.g. the send buffer of an RCCL gather (no reference counterpart: multi-GPU).  Synchronous. */
+int bhip_copy_hits_device(void *handle, void *dst_device, uint64_t cap_records, uint64_t *n_records);
+
 /* Tuning knobs.  "prefilter_stride": 0 (default) = automatic sparse seeds -- per query the largest stride s <= K for
  * which an alignment within budget still keeps >= 3 of the words starting at 0, s, 2s, ... (one edit destroys at most
  * ceil(K/s) of them), fewest .acx look-ups with the same no-false-negative guarantee; s >= 1 forces every s-th word,

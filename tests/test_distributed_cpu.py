@@ -60,3 +60,45 @@ def test_shard_ranges_partition():
             r = [bdist.shard_range(n, w, k) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+PG_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from burst_amd import capi, dist as bdist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+pg = bdist.PaddedGather(100, rank, world, "cpu")
+exp = []
+for step in range(5):                      # more steps than buffer sets: exercises the reuse of a posted buffer
+    n = (7 * step + 13 * rank) % 90
+    rec = np.zeros(n, capi.HIT_DTYPE); rec["q"] = np.arange(n) + 1000 * rank + 100000 * step; rec["refIx"] = step
+    buf = pg.buffer()
+    buf[pg.HDR:pg.HDR + rec.nbytes] = torch.from_numpy(rec.view(np.uint8).reshape(-1))
+    t = pg.post(n)
+    pg.wait(t)
+    got = pg.records(t)
+    if rank == 0:
+        want = []
+        for r in range(world):
+            m = (7 * step + 13 * r) % 90
+            w = np.zeros(m, capi.HIT_DTYPE); w["q"] = np.arange(m) + 1000 * r + 100000 * step; w["refIx"] = step
+            want.append(w)
+        want = np.concatenate(want)
+        assert got.tobytes() == want.tobytes(), step
+    else:
+        assert got is None
+dist.barrier(); dist.destroy_process_group()
+print("ok")
+"""
+
+
+def test_padded_gather_two_ranks(tmp_path):
+    """the per-step device-side gather of bench.py (fixed-capacity buffers, count in a header, two alternating buffer sets)"""
+    w = tmp_path / "pg_worker.py"
+    w.write_text(PG_WORKER)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", str(w), gl.ROOT], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.count("ok") == 2, r.stdout[-3000:]
