@@ -1277,20 +1277,27 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 		int score = (int)P;
 		uint32_t flags = 0;
 		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)z * nchunks;        // lane-major copy
-		for (uint32_t t = 0; t < nchunks; ++t) {
-			const uint4 ch = rp[t];
-			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
-			int cmin = 0x7FFFFFFF;
+		for (uint32_t t0 = 0; t0 < nchunks; t0 += 4) {      // 4 chunks = 64 contiguous bytes of this lane per round of loads
+			uint4 chs[4];
 			#pragma unroll
-			for (int k = 0; k < 32; ++k) {
-				const uint32_t sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
-				uint32_t Eq[NWP];
+			for (uint32_t u = 0; u < 4; ++u) chs[u] = t0 + u < nchunks ? rp[t0 + u] : make_uint4(0, 0, 0, 0);
+			#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u) {
+				const uint32_t t = t0 + u;
+				if (t >= nchunks) break;
+				const uint32_t dw[4] = {chs[u].x, chs[u].y, chs[u].z, chs[u].w};
+				int cmin = 0x7FFFFFFF;
 				#pragma unroll
-				for (int w = 0; w < NWP; ++w) Eq[w] = s_peq[sym * NWP + w][tid];
-				myers_step<NWP>(Eq, Pv, Mv, score);
-				cmin = score < cmin ? score : cmin;
+				for (int k = 0; k < 32; ++k) {
+					const uint32_t sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
+					uint32_t Eq[NWP];
+					#pragma unroll
+					for (int w = 0; w < NWP; ++w) Eq[w] = s_peq[sym * NWP + w][tid];
+					myers_step<NWP>(Eq, Pv, Mv, score);
+					cmin = score < cmin ? score : cmin;
+				}
+				flags |= ((uint32_t)cmin <= E ? 1u : 0u) << (t >> fshift);
 			}
-			flags |= ((uint32_t)cmin <= E ? 1u : 0u) << (t >> fshift);
 		}
 		if (flags) {
 			const uint32_t pos = atomicAdd(n_wins, 1u);
@@ -1342,8 +1349,10 @@ __global__ __launch_bounds__(256) void k_myers_window(
 		uint32_t first = 0, last = 0;
 		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)z * nchunks;        // lane-major copy
 		const uint32_t *tab = peq + (uint64_t)li * 16 * NW;
+		uint4 ch_next = rp[tA];
 		for (uint32_t t = tA; t <= tB; ++t) {
-			const uint4 ch = rp[t];
+			const uint4 ch = ch_next;
+			if (t < tB) ch_next = rp[t + 1];          // the next 16 bytes of this lane while this chunk is swept
 			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
 			#pragma unroll 8
 			for (int k = 0; k < 32; ++k) {
