@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--one-stage", action="store_true", help="disable the prefix-filter stage of the edit-distance kernels")
     ap.add_argument("--lanes", type=int, default=0, help="sub-pipelines (HIP streams) per batch inside the library")
     ap.add_argument("--sweep-blocks", type=int, default=0, help="256-thread blocks per CU for the column sweep (0 = library default)")
+    ap.add_argument("--opt", action="append", default=[], help="library tuning option name=value (bhip_set_option), repeatable")
     ap.add_argument("--prefilter-waves", type=int, default=0, help="single-wave prefilter blocks per CU (0 = library default)")
     ap.add_argument("--prefilter-stride", type=int, default=0, help="0 = automatic sparse seeds (default), 1 = every word (reference scheme)")
     args = ap.parse_args()
@@ -141,6 +142,9 @@ def main():
         dev.set_option("sweep_blocks", args.sweep_blocks)
     if args.prefilter_waves:
         dev.set_option("prefilter_waves", args.prefilter_waves)
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        dev.set_option(name, int(val))
     info = dev.info()
     q = qs.batch()
     dev.stage(q)

@@ -594,7 +594,9 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	// hash table size per query from the expected number of distinct clumps (sampled words x occurrence-weighted mean list
 	// length): 512 slots keep 12 single-wave blocks on a CU, 1024 -> 7, 2048 -> 4
 	const double expect = (double)maxwords * h->acx_wmean;
-	const int htb = h->opt_pf_table ? h->opt_pf_table : (expect <= 150.0 ? 9 : expect <= 320.0 ? 10 : 11);
+	// (the touched list holds half the slots; a query that exceeds it is re-done by the dense fallback, so the estimate -- an
+	// upper bound, every repeated clump counted once per word -- may be cut close)
+	const int htb = h->opt_pf_table ? h->opt_pf_table : (expect <= 230.0 ? 9 : expect <= 470.0 ? 10 : 11);
 	const uint32_t lds_b = (4u << htb) * 4 + (4u << (htb - 1)) * 2 + 4 * 24 * 16 + 4 * 24 * 4 + 128 * 8 + 64 + 256 + 64;
 	const uint32_t fit = std::max<uint32_t>(1, std::min<uint32_t>(12, (160u * 1024u) / ((lds_b + 511u) & ~511u)));
 	const uint32_t waves = h->opt_pf_waves ? std::min<uint32_t>((uint32_t)h->opt_pf_waves, fit) : fit;
