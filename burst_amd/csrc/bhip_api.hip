@@ -51,7 +51,7 @@ template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_
 __global__ void k_pack_queries(const uint8_t *, const uint64_t *, uint32_t, uint32_t, uint32_t *);
 __global__ void k_rescore_classify(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, int, const uint64_t *, const uint32_t *, const uint8_t *,
 	const uint32_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t, int);
-__global__ void k_rescore_reg(const BhipRawHit *, const uint32_t *, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, const uint32_t *, uint32_t,
+template <int SET> __global__ void k_rescore_reg(const BhipRawHit *, const uint32_t *, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, const uint32_t *, uint32_t,
 	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *);
 
 // ---- ordering of the output records: (q, refIx) ascending, done on the device (radix sort of 64-bit keys) ----
@@ -103,7 +103,7 @@ struct Counters {
 	uint32_t n_wins_cls[8];
 	uint32_t n_fb, pad2;
 	uint32_t n_tasks_cls[8];
-	uint32_t n_rs[8];          // re-scorer buckets: hits per band-width class
+	uint32_t n_rs[12];         // re-scorer buckets: hits per band-width class
 	unsigned long long wcol_sum, tcol_sum, unit_sum;
 	unsigned long long col_sum, qlen_sum, ent_read, scratch_used;
 };
@@ -593,11 +593,12 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	const uint32_t n_quads = (n_list + 3) / 4;
 	// hash table size per query from the expected number of distinct clumps (sampled words x occurrence-weighted mean list
 	// length): 512 slots keep 12 single-wave blocks on a CU, 1024 -> 7, 2048 -> 4
-	const double expect = (double)maxwords * h->acx_wmean;
+	const double expect = (n_list ? (double)L->seed_words[cls] / (double)n_list : (double)maxwords) * h->acx_wmean;   // mean, not max: outliers use the fallback
 	// (the touched list holds half the slots; a query that exceeds it is re-done by the dense fallback, so the estimate -- an
 	// upper bound, every repeated clump counted once per word -- may be cut close)
 	const int htb = h->opt_pf_table ? h->opt_pf_table : (expect <= 230.0 ? 9 : expect <= 470.0 ? 10 : 11);
-	const uint32_t lds_b = (4u << htb) * 4 + (4u << (htb - 1)) * 2 + 4 * 24 * 16 + 4 * 24 * 4 + 128 * 8 + 64 + 256 + 64;
+	const uint32_t n_cc = htb <= 9 ? 24u : 80u;
+	const uint32_t lds_b = (4u << htb) * 4 + (4u << (htb - 1)) * 2 + 4 * n_cc * 16 + 4 * n_cc * 4 + 128 * 8 + 64 + 256 + 64;
 	const uint32_t fit = std::max<uint32_t>(1, std::min<uint32_t>(12, (160u * 1024u) / ((lds_b + 511u) & ~511u)));
 	const uint32_t waves = h->opt_pf_waves ? std::min<uint32_t>((uint32_t)h->opt_pf_waves, fit) : fit;
 	const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * waves);
@@ -723,7 +724,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	if ((rc = L->cand.reserve(L->cand_cap * sizeof(uint2)))) return rc;
 	if ((rc = L->raw.reserve(L->raw_cap * sizeof(BhipRawHit)))) return rc;
 	if ((rc = L->wide.reserve(L->raw_cap * sizeof(uint32_t)))) return rc;
-	if ((rc = L->rs_lists.reserve(L->raw_cap * sizeof(uint32_t) * 6))) return rc;
+	if ((rc = L->rs_lists.reserve(L->raw_cap * sizeof(uint32_t) * 9))) return rc;
 	if ((rc = L->scratch.reserve(L->scratch_cap * sizeof(uint32_t)))) return rc;
 	if ((rc = L->wins.reserve(L->win_cap * sizeof(BhipWin)))) return rc;
 	if ((rc = L->tasks.reserve(L->task_cap * sizeof(uint2)))) return rc;
@@ -817,15 +818,21 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		band_rows, h->opt_rescore_reg);
 	HIPCHK(hipGetLastError());
 	if (h->opt_rescore_reg) {
-		hipLaunchKernelGGL(k_rescore_reg, dim3((uint32_t)h->n_cu * 12), dim3(64), 0, po, L->raw.as<BhipRawHit>(), L->rs_lists.as<uint32_t>(), dc->n_rs, (uint32_t)L->raw_cap,
-			h->qoff.as<uint64_t>(), h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr, h->qpack.as<uint32_t>(), qw_g,
-			h->ref_lane.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, &sc->err);
+#define RS_LAUNCH(SET, BLOCKS) hipLaunchKernelGGL(k_rescore_reg<SET>, dim3((uint32_t)h->n_cu * BLOCKS), dim3(64), 0, po, L->raw.as<BhipRawHit>(), L->rs_lists.as<uint32_t>(), dc->n_rs, (uint32_t)L->raw_cap, \
+			h->qoff.as<uint64_t>(), h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr, h->qpack.as<uint32_t>(), qw_g, \
+			h->ref_lane.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, &sc->err)
+		RS_LAUNCH(0, 16);
 		HIPCHK(hipGetLastError());
+		RS_LAUNCH(1, 12);
+		HIPCHK(hipGetLastError());
+		RS_LAUNCH(2, 8);          // 32 / 40 / 48 diagonals (usually empty lists: large budgets, or repeats that stretch the end-column range)
+		HIPCHK(hipGetLastError());
+#undef RS_LAUNCH
 	}
 	const uint32_t grid_rs = (uint32_t)h->n_cu * (h->opt_rescore_reg ? 4 : 16);
 	const size_t lds_rs = (size_t)(band_rows + 1 + qw + rw) * 256;
 	hipLaunchKernelGGL(k_rescore<false>, dim3(grid_rs), dim3(64), lds_rs, po, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap,
-		L->rs_lists.as<uint32_t>() + (size_t)5 * L->raw_cap, &dc->n_rs[5], h->best.as<uint32_t>(), all_hits, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+		L->rs_lists.as<uint32_t>() + (size_t)8 * L->raw_cap, &dc->n_rs[8], h->best.as<uint32_t>(), all_hits, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 		h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr, h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(),
 		h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, L->wide.as<uint32_t>(),
 		&dc->n_wide, (uint32_t *)nullptr, &dc->scratch_used, 0ull, &sc->err, qw ? h->qpack.as<uint32_t>() : nullptr, band_rows, qw, rw);
@@ -866,6 +873,13 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		HIPCHK(hipStreamSynchronize(h->sweep_stream));
 		HIPCHK(hipStreamSynchronize(h->post_stream));
 		for (uint32_t l = 0; l < nl; ++l) if (h->lanes[l]->n_entries) h->lanes[l]->hc = *h->lanes[l]->hc_pinned;
+		if (getenv("BHIP_DEBUG")) for (uint32_t l = 0; l < nl; ++l) {
+			const Lane *L = h->lanes[l];
+			if (!L->n_entries) continue;
+			for (int cls = 0; cls < kNumClasses; ++cls) if (L->npf[cls] + L->nex[cls])
+				fprintf(stderr, "[bhip] lane %u class NW=%d: prefiltered %u exhaustive %u maxE %u maxwords %u | tasks %u clump pairs %u windows %u | fallback queries(last class) %u raw %u\n",
+					l, kClasses[cls], L->npf[cls], L->nex[cls], L->maxE[cls], L->maxwords[cls], L->hc.n_tasks_cls[cls], L->hc.n_cand_cls[cls], L->hc.n_wins_cls[cls], L->hc.n_fb, L->hc.n_raw);
+		}
 		// capacity checks (first call of a workload: grow and redo)
 		bool retry = false;
 		for (uint32_t l = 0; l < nl; ++l) {

@@ -579,7 +579,7 @@ __global__ void k_attach_masks(const uint32_t *__restrict__ acx_off, const uint3
 //   pass 2  the lists are walked again (L2-resident by now); entries of candidate clumps add their 16-bit lane mask into
 //           sixteen 8-bit lane counters (two 64-bit LDS atomics, ~3 % of the entries);
 //   emit    (list position, reference lane) TASKS for lanes with count >= need -> k_myers_prefix_task.
-// More candidates than PFM_CAND in one query: the surplus clumps are emitted as clump-level pairs (16-lane kernel).
+// More candidate clumps in one query than the lane counters hold (24 with the 512-slot table, 80 above): the surplus clumps are emitted as clump-level pairs (16-lane kernel).
 #ifdef PFM_PROF
 __device__ unsigned long long g_pfm_prof[8];
 #define PFM_T(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = wall_clock64(); if (lane == 0) my_t[i] += t_ - t_last; t_last = t_; } while (0)
@@ -587,7 +587,6 @@ __device__ unsigned long long g_pfm_prof[8];
 #define PFM_T(i) do {} while (0)
 #endif
 #define PFM_STAGE 128u
-#define PFM_CAND 24u
 #define PFM_RB 3u            // blocks of 64 records per query kept in registers between the passes
 __device__ __forceinline__ unsigned long long spread8(uint32_t m8) {   // bit i of m8 -> bit 8*i
 	unsigned long long x = m8;
@@ -681,8 +680,9 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 
 	__shared__ uint32_t s_tab[4][(1u << HTB)];
 	__shared__ uint16_t s_tl[4][(1u << (HTB - 1))];
-	__shared__ unsigned long long s_cc[4][PFM_CAND][2];
-	__shared__ uint32_t s_cclump[4][PFM_CAND];
+	constexpr uint32_t CAND = HTB <= 9 ? 24u : 80u;      // candidate clumps per query with lane counters (LDS: 20 B each)
+	__shared__ unsigned long long s_cc[4][CAND][2];
+	__shared__ uint32_t s_cclump[4][CAND];
 	__shared__ uint2 s_stage[PFM_STAGE];
 	__shared__ uint32_t s_ctr[12];          // [g] touched count, [4] staged, [5+g] candidates of group g
 	__shared__ uint32_t s_ovf[4];
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
 	s_dummy[lane] = 0;
 	for (uint32_t i = lane; i < 4 * (1u << HTB); i += 64) (&s_tab[0][0])[i] = 0;
-	for (uint32_t i = lane; i < 4 * PFM_CAND * 2; i += 64) (&s_cc[0][0][0])[i] = 0;
+	for (uint32_t i = lane; i < 4 * CAND * 2; i += 64) (&s_cc[0][0][0])[i] = 0;
 	if (lane < 12) s_ctr[lane] = 0;
 	if (lane < 4) s_ovf[lane] = 0;
 	__syncthreads();
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 				if ((v & 255u) >= thr) {
 					const uint32_t ci = atomicAdd(&s_ctr[5 + g], 1u);
 					const uint32_t c = (v >> 8) - 1u;
-					if (ci < PFM_CAND) { tag = ci + 1; s_cclump[g][ci] = c; }
+					if (ci < CAND) { tag = ci + 1; s_cclump[g][ci] = c; }
 					else {   // too many candidate clumps for the lane counters: hand the clump to the 16-lane kernel
 						const uint32_t gp = atomicAdd(n_pairs, 1u);
 						if (gp < pair_cap) pairs[gp] = make_uint2(li, c);
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 		__syncthreads();
 		PFM_T(3);
 		// ---- pass 2: lane counters of the candidate clumps
-		const uint32_t ncand = s_ctr[5 + g] < PFM_CAND ? s_ctr[5 + g] : PFM_CAND;
+		const uint32_t ncand = s_ctr[5 + g] < CAND ? s_ctr[5 + g] : CAND;
 		const bool mine = live && !ovf && ncand > 0;
 		if (__any(mine)) {
 			#pragma unroll
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 			}
 		} else if (ovf) {
 			for (uint32_t i = gl; i < (1u << HTB); i += 16) s_tab[g][i] = 0;
-			for (uint32_t i = gl; i < PFM_CAND; i += 16) { s_cc[g][i][0] = 0; s_cc[g][i][1] = 0; }
+			for (uint32_t i = gl; i < CAND; i += 16) { s_cc[g][i][0] = 0; s_cc[g][i][1] = 0; }
 			if (live && gl == 0) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
 		}
 		__syncthreads();
@@ -1244,7 +1244,10 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 		const uint16_t *__restrict__ qemac,
 		const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
 		BhipWin *__restrict__ wins, uint32_t *__restrict__ n_wins, uint32_t win_cap, unsigned long long *__restrict__ tcol_sum) {
-	__shared__ uint32_t s_peq[16 * NWP][64];
+	// NWP <= 2: the 16-row prefix table of the task sits in a private LDS column; wider prefixes would leave room for only
+	// 2-3 waves per SIMD that way, so they read the rows from global memory (L1/L2 hits, one dwordx2/x4 load per column)
+	constexpr bool LDS_TAB = NWP <= 2;
+	__shared__ uint32_t s_peq[LDS_TAB ? 16 * NWP : 1][64];
 	const uint32_t tid = threadIdx.x;
 	uint32_t n = *n_tasks_dev;
 	if (n > task_cap) n = task_cap;
@@ -1255,9 +1258,11 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 		uint2 tk = make_uint2(0, 0);
 		if (live) {
 			tk = tasks[i];
-			const uint32_t *src = peqp + (uint64_t)tk.x * 16 * NWP;
-			#pragma unroll
-			for (int r = 0; r < 16 * NWP; ++r) s_peq[r][tid] = src[r];
+			if (LDS_TAB) {
+				const uint32_t *src = peqp + (uint64_t)tk.x * 16 * NWP;
+				#pragma unroll
+				for (int r = 0; r < (LDS_TAB ? 16 * NWP : 1); ++r) s_peq[r][tid] = src[r];
+			}
 		}
 		if (!live) continue;        // the table column is private to the thread: no barrier needed
 		const uint32_t li = tk.x, refIx = tk.y, c = refIx >> 4, z = refIx & 15;
@@ -1277,6 +1282,7 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 		int score = (int)P;
 		uint32_t flags = 0;
 		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)z * nchunks;        // lane-major copy
+		const uint32_t *gtab = peqp + (uint64_t)li * 16 * NWP;
 		for (uint32_t t0 = 0; t0 < nchunks; t0 += 4) {      // 4 chunks = 64 contiguous bytes of this lane per round of loads
 			uint4 chs[4];
 			#pragma unroll
@@ -1292,7 +1298,7 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 					const uint32_t sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
 					uint32_t Eq[NWP];
 					#pragma unroll
-					for (int w = 0; w < NWP; ++w) Eq[w] = s_peq[sym * NWP + w][tid];
+					for (int w = 0; w < NWP; ++w) Eq[w] = LDS_TAB ? s_peq[LDS_TAB ? sym * NWP + w : 0][tid] : gtab[sym * NWP + w];
 					myers_step<NWP>(Eq, Pv, Mv, score);
 					cmin = score < cmin ? score : cmin;
 				}
@@ -1594,7 +1600,7 @@ __global__ __launch_bounds__(64) void k_rescore(
 // a wave busy with hits of similar width.  Bands beyond the widest register variant go to k_rescore (LDS band) and
 // beyond that to its global-scratch variant.
 // ------------------------------------------------------------------------------------------------
-#define BHIP_RS_BUCKETS 7      // 0..4 register variants (6, 8, 12, 16, 24 diagonals), 5 LDS band, 6 global scratch
+// index lists: 0..7 register variants (6, 8, 12, 16, 24, 32, 40, 48 diagonals), 8 LDS band; 9 = global scratch (`wide`), 10 = exact match (emitted)
 __global__ __launch_bounds__(256) void k_rescore_classify(
 		const BhipRawHit *__restrict__ raw, const uint32_t *__restrict__ n_raw_dev, uint32_t raw_cap,
 		const uint32_t *__restrict__ best, int all_hits, const uint64_t *__restrict__ qoff,
@@ -1603,12 +1609,12 @@ __global__ __launch_bounds__(256) void k_rescore_classify(
 		uint32_t *__restrict__ lists, uint32_t *__restrict__ counts, uint32_t *__restrict__ wide, uint32_t *__restrict__ n_wide,
 		uint32_t band_rows, int use_reg) {
 	// one global reservation per bucket and 1024-hit chunk (ranks inside the chunk come from LDS counters)
-	__shared__ uint32_t s_cnt[8], s_base[8];
+	__shared__ uint32_t s_cnt[12], s_base[12];
 	uint32_t n = *n_raw_dev;
 	if (n > raw_cap) n = raw_cap;
 	const uint32_t tid = threadIdx.x;
 	for (uint32_t chunk = blockIdx.x * 1024u; chunk < n; chunk += gridDim.x * 1024u) {
-		if (tid < 8) s_cnt[tid] = 0;
+		if (tid < 12) s_cnt[tid] = 0;
 		__syncthreads();
 		int bucket[4]; uint32_t rank[4], e2v[4], mv[4], qv[4], rv[4];
 		#pragma unroll
@@ -1622,11 +1628,11 @@ __global__ __launch_bounds__(256) void k_rescore_classify(
 					const uint32_t L = clump_len[h.refIx >> 4];
 					const uint32_t e2 = h.e_last < L ? h.e_last : L;
 					qv[t] = h.q; rv[t] = h.refIx; e2v[t] = e2;
-					if (h.ed == 0) { bucket[t] = 7; mv[t] = (uint32_t)(qoff[h.q + 1] - qoff[h.q]); }     // exact match
+					if (h.ed == 0) { bucket[t] = 10; mv[t] = (uint32_t)(qoff[h.q + 1] - qoff[h.q]); }     // exact match
 					else {
 						const uint32_t Wd = e2 - h.e_first + 2 * h.ed + 1;
-						int bk = !use_reg || h.ed > 254u ? 5 : Wd <= 6 ? 0 : Wd <= 8 ? 1 : Wd <= 12 ? 2 : Wd <= 16 ? 3 : Wd <= 24 ? 4 : 5;
-						if (Wd > band_rows && bk == 5) bk = 6;
+						int bk = !use_reg || h.ed > 254u ? 8 : Wd <= 6 ? 0 : Wd <= 8 ? 1 : Wd <= 12 ? 2 : Wd <= 16 ? 3 : Wd <= 24 ? 4 : Wd <= 32 ? 5 : Wd <= 40 ? 6 : Wd <= 48 ? 7 : 8;
+						if (Wd > band_rows && bk == 8) bk = 9;
 						bucket[t] = bk;
 					}
 					rank[t] = atomicAdd(&s_cnt[bucket[t]], 1u);
@@ -1634,7 +1640,7 @@ __global__ __launch_bounds__(256) void k_rescore_classify(
 			}
 		}
 		__syncthreads();
-		if (tid < 8 && s_cnt[tid]) s_base[tid] = atomicAdd(tid == 7 ? n_out : tid == 6 ? n_wide : &counts[tid], s_cnt[tid]);
+		if (tid < 11 && s_cnt[tid]) s_base[tid] = atomicAdd(tid == 10 ? n_out : tid == 9 ? n_wide : &counts[tid], s_cnt[tid]);
 		__syncthreads();
 		#pragma unroll
 		for (int t = 0; t < 4; ++t) {
@@ -1642,13 +1648,13 @@ __global__ __launch_bounds__(256) void k_rescore_classify(
 			const int bk = bucket[t];
 			if (bk < 0) continue;
 			const uint32_t pos = s_base[bk] + rank[t];
-			if (bk == 7) {   // gap-free, end = LAST column with score 0 (burst.c:862-879), identity 1 - 0/len
+			if (bk == 10) {   // gap-free, end = LAST column with score 0 (burst.c:862-879), identity 1 - 0/len
 				if (pos < out_cap) {
 					BhipHit o; o.q = qv[t]; o.refIx = rv[t]; o.finalPos = e2v[t]; o.score = 1.0f - 0.0f / (float)mv[t];
 					o.ed = 0; o.gapR = 0; o.gapQ = 0; o.rc = qrc ? qrc[qv[t]] : 0;
 					out[pos] = o;
 				}
-			} else if (bk == 6) wide[pos] = i;
+			} else if (bk == 9) wide[pos] = i;
 			else lists[(size_t)bk * raw_cap + pos] = i;
 		}
 		__syncthreads();
@@ -1780,6 +1786,7 @@ __device__ __forceinline__ void rescore_reg_one(
 	}
 }
 
+template <int SET>       // 0: bands of 6 / 8 / 12 diagonals, 1: 16 / 24, 2: 32 / 40 / 48 (separate kernels: the register budget of the wide ones would halve the occupancy of the narrow ones)
 __global__ __launch_bounds__(64) void k_rescore_reg(
 		const BhipRawHit *__restrict__ raw, const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint32_t raw_cap,
 		const uint64_t *__restrict__ qoff, const uint8_t *__restrict__ qrc, const uint32_t *__restrict__ qpack, uint32_t qw,
@@ -1799,9 +1806,17 @@ __global__ __launch_bounds__(64) void k_rescore_reg(
 			const bool live = i < n; \
 			rescore_reg_one<WB>(raw + (live ? lst[i] : 0u), live, s_mm, tid, qoff, qrc, qpack, qw, refw, ref_off, clump_len, out, n_out, out_cap, err_flags); \
 		} }
-	BHIP_RS_RUN(0, 6) BHIP_RS_RUN(1, 8) BHIP_RS_RUN(2, 12) BHIP_RS_RUN(3, 16) BHIP_RS_RUN(4, 24)
+	if (SET == 0) { BHIP_RS_RUN(0, 6) BHIP_RS_RUN(1, 8) BHIP_RS_RUN(2, 12) }
+	else if (SET == 1) { BHIP_RS_RUN(3, 16) BHIP_RS_RUN(4, 24) }
+	else { BHIP_RS_RUN(5, 32) BHIP_RS_RUN(6, 40) BHIP_RS_RUN(7, 48) }
 #undef BHIP_RS_RUN
 }
+template __global__ void k_rescore_reg<0>(const BhipRawHit *, const uint32_t *, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, const uint32_t *, uint32_t,
+	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *);
+template __global__ void k_rescore_reg<1>(const BhipRawHit *, const uint32_t *, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, const uint32_t *, uint32_t,
+	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *);
+template __global__ void k_rescore_reg<2>(const BhipRawHit *, const uint32_t *, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, const uint32_t *, uint32_t,
+	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *);
 
 template __global__ void k_rescore<false>(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, int,
 	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *,
