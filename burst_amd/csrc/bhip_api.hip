@@ -10,6 +10,8 @@
 #include <string.h>
 #include <algorithm>
 #include <vector>
+#include <chrono>
+#include <thread>
 #include "burst_hip.h"
 #include "bhip_internal.h"
 
@@ -661,38 +663,85 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 	if ((rc = ensure_lanes(h, nl))) return rc;
 	h->st_lanes = nl;
 	const uint32_t nsh = h->st_nshared;
+	const bool dbg = getenv("BHIP_DEBUG") != nullptr;
+	const auto t_begin = std::chrono::steady_clock::now();
+	auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
 	// host-side routing: lane by shared slot, class by length, prefilter vs exhaustive (entries nobody can guarantee a k-mer for)
-	std::vector<std::vector<uint32_t>> lists((size_t)nl * kNumClasses * 2);
+	// (a few host threads share the pass: ~35 ns per entry single-threaded would otherwise be 8x the device time of the batch)
+	const size_t n_keys = (size_t)nl * kNumClasses * 2;
 	std::vector<uint32_t> plan(n_q, 1u);
 	for (uint32_t l = 0; l < nl; ++l) { Lane *L = h->lanes[l]; for (int c = 0; c < kNumClasses; ++c) { L->npf[c] = L->nex[c] = L->maxE[c] = L->maxwords[c] = 0; L->seed_words[c] = 0; } L->maxlen = 0; L->n_entries = 0; }
-	for (uint32_t i = 0; i < n_q; ++i) {
-		const uint64_t len = q_off[i + 1] - q_off[i];
-		if (len == 0) continue;
-		if (len > BHIP_MAX_QLEN) return fail(BHIP_E_QUERYLEN, "query %u has %llu symbols (max %d)", i, (unsigned long long)len, BHIP_MAX_QLEN);
-		if (q_six && q_six[i] >= n_shared) return fail(BHIP_E_ARG, "q_six[%u] out of range", i);
-		const uint32_t six = q_six ? q_six[i] : i;
-		const uint32_t l = (uint32_t)(((uint64_t)six * nl) / nsh);
-		const int cls = class_of_len((uint32_t)len);
-		int ex = q_flags ? (q_flags[i] == BHIP_Q_EXHAUSTIVE) : !h->has_acx;
-		if (!h->has_acx) ex = 1;
-		if (!ex) {
-			plan[i] = make_seed_plan(q_codes + q_off[i], (uint32_t)len, q_emac[i], (uint32_t)h->K, h->opt_prefilter_stride);
-			if ((plan[i] >> 8) == 0) ex = 1;           // no word is guaranteed to survive: exhaustive (burst.c:3130-3131 does the same for "bad" queries)
+	struct Part {
+		std::vector<std::vector<uint32_t>> lists;
+		std::vector<uint32_t> maxE, maxwords, maxlen, n_entries;
+		std::vector<uint64_t> seed_words;
+		int err = 0; uint32_t err_i = 0; uint64_t err_len = 0;
+	};
+	const uint32_t n_thr = n_q < 65536 ? 1u : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+	std::vector<Part> parts(n_thr);
+	auto work = [&](uint32_t t) {
+		Part &P = parts[t];
+		P.lists.resize(n_keys); P.maxE.assign((size_t)nl * kNumClasses, 0); P.maxwords.assign((size_t)nl * kNumClasses, 0);
+		P.seed_words.assign((size_t)nl * kNumClasses, 0); P.maxlen.assign(nl, 0); P.n_entries.assign(nl, 0);
+		const uint32_t i0 = (uint32_t)((uint64_t)n_q * t / n_thr), i1 = (uint32_t)((uint64_t)n_q * (t + 1) / n_thr);
+		for (uint32_t i = i0; i < i1; ++i) {
+			const uint64_t len = q_off[i + 1] - q_off[i];
+			if (len == 0) continue;
+			if (len > BHIP_MAX_QLEN) { P.err = 1; P.err_i = i; P.err_len = len; return; }
+			if (q_six && q_six[i] >= n_shared) { P.err = 2; P.err_i = i; return; }
+			const uint32_t six = q_six ? q_six[i] : i;
+			const uint32_t l = (uint32_t)(((uint64_t)six * nl) / nsh);
+			const int cls = class_of_len((uint32_t)len);
+			int ex = q_flags ? (q_flags[i] == BHIP_Q_EXHAUSTIVE) : !h->has_acx;
+			if (!h->has_acx) ex = 1;
+			if (!ex) {
+				plan[i] = make_seed_plan(q_codes + q_off[i], (uint32_t)len, q_emac[i], (uint32_t)h->K, h->opt_prefilter_stride);
+				if ((plan[i] >> 8) == 0) ex = 1;           // no word is guaranteed to survive: exhaustive (burst.c:3130-3131 does the same for "bad" queries)
+			}
+			const size_t lc = (size_t)l * kNumClasses + cls;
+			P.lists[lc * 2 + ex].push_back(i);
+			P.maxE[lc] = std::max<uint32_t>(P.maxE[lc], q_emac[i]);
+			if (!ex && len >= (uint64_t)h->K) {
+				const uint32_t nwd = (uint32_t)((len - h->K) / (plan[i] & 255u) + 1);
+				P.maxwords[lc] = std::max<uint32_t>(P.maxwords[lc], nwd);
+				P.seed_words[lc] += nwd;
+			}
+			P.maxlen[l] = std::max<uint32_t>(P.maxlen[l], (uint32_t)len);
+			++P.n_entries[l];
 		}
-		lists[((size_t)l * kNumClasses + cls) * 2 + ex].push_back(i);
-		Lane *L = h->lanes[l];
-		L->maxE[cls] = std::max<uint32_t>(L->maxE[cls], q_emac[i]);
-		if (!ex && len >= (uint64_t)h->K) {
-			const uint32_t nwd = (uint32_t)((len - h->K) / (plan[i] & 255u) + 1);
-			L->maxwords[cls] = std::max<uint32_t>(L->maxwords[cls], nwd);
-			L->seed_words[cls] += nwd;
-		}
-		L->maxlen = std::max<uint32_t>(L->maxlen, (uint32_t)len);
-		++L->n_entries;
+	};
+	if (n_thr == 1) work(0);
+	else {
+		std::vector<std::thread> th;
+		for (uint32_t t = 0; t < n_thr; ++t) th.emplace_back(work, t);
+		for (auto &x : th) x.join();
 	}
+	for (const Part &P : parts) {
+		if (P.err == 1) return fail(BHIP_E_QUERYLEN, "query %u has %llu symbols (max %d)", P.err_i, (unsigned long long)P.err_len, BHIP_MAX_QLEN);
+		if (P.err == 2) return fail(BHIP_E_ARG, "q_six[%u] out of range", P.err_i);
+	}
+	std::vector<std::vector<uint32_t>> lists(n_keys);       // thread order = entry order: the lists come out exactly as a single pass would build them
+	for (size_t k = 0; k < n_keys; ++k) {
+		size_t tot = 0;
+		for (const Part &P : parts) tot += P.lists[k].size();
+		lists[k].reserve(tot);
+		for (const Part &P : parts) lists[k].insert(lists[k].end(), P.lists[k].begin(), P.lists[k].end());
+	}
+	for (uint32_t l = 0; l < nl; ++l) {
+		Lane *L = h->lanes[l];
+		for (const Part &P : parts) {
+			for (int c = 0; c < kNumClasses; ++c) {
+				const size_t lc = (size_t)l * kNumClasses + c;
+				L->maxE[c] = std::max(L->maxE[c], P.maxE[lc]); L->maxwords[c] = std::max(L->maxwords[c], P.maxwords[lc]); L->seed_words[c] += P.seed_words[lc];
+			}
+			L->maxlen = std::max(L->maxlen, P.maxlen[l]); L->n_entries += P.n_entries[l];
+		}
+	}
+	const double t_route = since();
 	HIPCHK(hipEventRecord(h->ev[0], h->stream));
 	if ((rc = upload_queries(h, q_codes, q_off, q_emac, q_six, q_rc, n_q))) return rc;
 	if ((rc = upload_plan(h, q_codes, q_off, q_emac, n_q, plan))) return rc;
+	const double t_up = since();
 	{	// 4-bit packed copy of the queries at a fixed stride (layout used by the seed, profile and re-scoring kernels)
 		const uint32_t qw_g = (h->st_maxlen + 7) / 8;
 		if ((rc = h->qpack.reserve((size_t)n_q * qw_g * 4 + 16))) return rc;
@@ -715,6 +764,7 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 	HIPCHK(hipStreamSynchronize(h->stream));
 	h->st_ms_h2d = ev_ms(h->ev[0], h->ev[1]);
 	h->st_valid = true;
+	if (dbg) fprintf(stderr, "[bhip] stage: routing+plans %.2f ms, uploads %.2f ms, lists+pack %.2f ms (total %.2f ms, %u entries)\n", t_route, t_up - t_route, since() - t_up, since(), n_q);
 	return BHIP_OK;
 }
 
