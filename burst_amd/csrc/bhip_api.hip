@@ -57,9 +57,9 @@ template <int SET> __global__ void k_rescore_reg(const BhipRawHit *, const uint3
 	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *);
 
 // ---- ordering of the output records: (q, refIx) ascending, done on the device (radix sort of 64-bit keys) ----
-__global__ void k_hit_keys(const BhipHit *__restrict__ hits, uint32_t n, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+__global__ void k_hit_keys(const BhipHit *__restrict__ hits, uint32_t n, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx, int rbits) {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		keys[i] = ((uint64_t)hits[i].q << 32) | hits[i].refIx;
+		keys[i] = ((uint64_t)hits[i].q << rbits) | hits[i].refIx;        // only the significant bits of refIx: fewer radix passes
 		idx[i] = i;
 	}
 }
@@ -1000,14 +1000,15 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			if ((rc = h->sort_keys.reserve((size_t)n * 8)) || (rc = h->sort_keys2.reserve((size_t)n * 8)) || (rc = h->sort_idx.reserve((size_t)n * 4)) ||
 			    (rc = h->sort_idx2.reserve((size_t)n * 4)) || (rc = h->out_sorted.reserve((size_t)n * sizeof(BhipHit)))) return rc;
 			const uint32_t g = std::min<uint32_t>((n + 255) / 256, (uint32_t)h->n_cu * 8);
-			hipLaunchKernelGGL(k_hit_keys, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, h->sort_keys.as<uint64_t>(), h->sort_idx.as<uint32_t>());
-			size_t tmp_bytes = 0;
 			int qbits = 32; while (qbits > 1 && !((n_q - 1) >> (qbits - 1))) --qbits;   // significant bits of the query index
+			int rbits = 32; while (rbits > 1 && !(((uint64_t)h->n_clumps * 16 - 1) >> (rbits - 1))) --rbits;   // and of refIx (< 16 * clumps)
+			hipLaunchKernelGGL(k_hit_keys, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, h->sort_keys.as<uint64_t>(), h->sort_idx.as<uint32_t>(), rbits);
+			size_t tmp_bytes = 0;
 			HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->sort_keys.as<uint64_t>(), h->sort_keys2.as<uint64_t>(), h->sort_idx.as<uint32_t>(),
-				h->sort_idx2.as<uint32_t>(), (int)n, 0, 32 + qbits, h->stream));
+				h->sort_idx2.as<uint32_t>(), (int)n, 0, rbits + qbits, h->stream));
 			if ((rc = h->sort_tmp.reserve(tmp_bytes))) return rc;
 			HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp.p, tmp_bytes, h->sort_keys.as<uint64_t>(), h->sort_keys2.as<uint64_t>(), h->sort_idx.as<uint32_t>(),
-				h->sort_idx2.as<uint32_t>(), (int)n, 0, 32 + qbits, h->stream));
+				h->sort_idx2.as<uint32_t>(), (int)n, 0, rbits + qbits, h->stream));
 			hipLaunchKernelGGL(k_hit_gather, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), h->sort_idx2.as<uint32_t>(), n, h->out_sorted.as<BhipHit>());
 			HIPCHK(hipGetLastError());
 			if (hits) HIPCHK(hipMemcpyAsync(hits, h->out_sorted.p, (size_t)n * sizeof(BhipHit), hipMemcpyDeviceToHost, h->stream));
