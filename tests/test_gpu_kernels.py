@@ -1,5 +1,7 @@
 """Parity of the HIP path (through the C ABI of include/burst_hip.h) against the oracle on seeded inputs.
 Bit-exact: edit distances, hit sets, gap counts, end positions and the f32 identity score."""
+import os
+
 import numpy as np
 import pytest
 
@@ -268,3 +270,13 @@ def test_prefilter_overflow_paths():
             dev.set_option("prefilter_table", table)
             assert_hits_equal(dev.align_batch(q, all_hits=all_hits), exp)
     dev.close()
+
+
+def test_randomised_configurations():
+    """a short run of tools/fuzz_gpu.py: random databases, read sets, budgets and tuning options against the oracle
+    (a 7-minute run of the same script, 1331 configurations / 193 k records, is the round's parity stress test)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "20", "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-3000:]

@@ -1,0 +1,58 @@
+"""Randomised parity run on the GPU box: random small databases / read sets / options, device records vs the oracle.
+   python tools/fuzz_gpu.py [seconds] [seed]   -- exits non-zero and prints the failing configuration on the first mismatch."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import test_gpu_kernels as T          # family_db, make_queries, oracle_hits
+import dbutil, oraclelib as ol
+from burst_amd import capi
+
+budget_s = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed0)
+t0 = time.time(); it = 0; recs = 0
+while time.time() - t0 < budget_s:
+    it += 1
+    cfg = dict(seed=int(rng.integers(1 << 30)), n_base=int(rng.integers(1, 8)), n_var=int(rng.choice([3, 9, 17, 40, 120])), length=int(rng.integers(150, 700)),
+               rate=float(rng.choice([0.01, 0.03, 0.06, 0.1])), short=bool(rng.integers(2)), db_iupac=float(rng.choice([0, 0, 0.003])),
+               qlen=int(rng.choice([20, 33, 64, 65, 100, 100, 128, 150, 200, 250, 292, 320, 400])), thres=float(rng.choice([0.9, 0.93, 0.95, 0.97, 0.98, 0.99])),
+               q_iupac=float(rng.choice([0, 0, 0.01, 0.03])), K=int(rng.choice([8, 10, 12, 12])), fmt=int(rng.integers(2)), accel=bool(rng.integers(4) > 0),
+               all_hits=bool(rng.integers(2)), nq=int(rng.integers(5, 60)),
+               stride=int(rng.choice([0, 0, 0, 1, 3, 7, 12, 18])), table=int(rng.choice([0, 0, 9, 10, 11])), reg=int(rng.integers(2)), lanes=int(rng.choice([1, 1, 2, 5])),
+               two_stage=int(rng.integers(4) > 0), lane_masks=int(rng.integers(4) > 0), y=int(rng.integers(4) == 0))
+    seqs = T.family_db(cfg["seed"], cfg["n_base"], cfg["n_var"], cfg["length"], rate=cfg["rate"], short=cfg["short"], iupac=cfg["db_iupac"])
+    if cfg["qlen"] + 10 > min(len(s) for s in seqs):
+        cfg["qlen"] = max(20, min(len(s) for s in seqs) - 10)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lut = ol.score_lut(0 if cfg["y"] else 1)
+    kw = {}
+    if cfg["accel"]:
+        # clumps holding an ambiguous reference symbol go to the BadList (aligned unconditionally, burst.c:3432-3437): the test
+        # builder does not expand ambiguous reference words the way make_accelerator does, so they must not rely on votes
+        bad = sorted({i // 16 for i, s in enumerate(seqs) if (np.asarray(s) > 4).any()})
+        lens, entries, offs = dbutil.build_acx(seqs, cfg["K"], skip_clumps=tuple(bad))
+        kw = dict(acx_lens=lens, acx_lists=dbutil.pack_acx_lists(lens, entries, cfg["fmt"]), acx_fmt=cfg["fmt"], K=cfg["K"],
+                  badlist=np.array(bad, np.uint32) if bad else None)
+    edits = [0, 1, 2, max(0, T.budget(cfg["thres"], cfg["qlen"])), T.budget(cfg["thres"], cfg["qlen"]) + 2]
+    q, _ = T.make_queries(seqs, cfg["nq"], cfg["qlen"], edits, cfg["seed"] + 1, iupac=cfg["q_iupac"], thres=cfg["thres"])
+    if cfg["accel"]:
+        q.flags = np.zeros(q.n, np.uint8)
+    dev = capi.Device(packed, clump_len, tot, lut, **kw)
+    try:
+        for name, key in (("prefilter_stride", "stride"), ("prefilter_table", "table"), ("rescore_reg", "reg"), ("lanes", "lanes"), ("two_stage", "two_stage"), ("lane_masks", "lane_masks")):
+            dev.set_option(name, cfg[key])
+        dev.set_option("lane_min_entries", 4)
+        got = dev.align_batch(q, all_hits=cfg["all_hits"])
+        exp = T.oracle_hits(packed, clump_len, tot, q, lut, cfg["all_hits"])
+        if len(got) != len(exp) or got.tobytes() != exp.tobytes():
+            print("MISMATCH at iteration %d: %r\n got %d records, expected %d" % (it, cfg, len(got), len(exp)))
+            n = min(len(got), len(exp))
+            bad = [i for i in range(n) if got[i].tobytes() != exp[i].tobytes()][:5]
+            for i in bad:
+                print("  first differing record", i, got[i], exp[i])
+            sys.exit(1)
+        recs += len(exp)
+    finally:
+        dev.close()
+print("fuzz ok: %d configurations, %d records compared in %.0f s (seed %d)" % (it, recs, time.time() - t0, seed0))
