@@ -1421,6 +1421,12 @@ __device__ __forceinline__ uint32_t ref_dword(const uint32_t *__restrict__ refw,
 	return refw[((clump_base + ((uint32_t)j8 >> 2)) * 16 + z) * 4 + ((uint32_t)j8 & 3)];
 }
 
+// 32 consecutive reference symbols of one lane (chunk t4 of the lane-major copy); zeros outside the clump
+__device__ __forceinline__ uint4 ref_chunk_lane(const uint32_t *__restrict__ refw_lane, uint64_t clump_base, uint32_t z, int t4, uint32_t nchunks) {
+	if (t4 < 0 || (uint32_t)t4 >= nchunks) return make_uint4(0, 0, 0, 0);
+	return ((const uint4 *)refw_lane)[clump_base * 16 + (uint64_t)z * nchunks + (uint32_t)t4];
+}
+__device__ __forceinline__ uint32_t pick4(const uint4 v, uint32_t i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 __device__ __forceinline__ uint32_t ref_dword_lane(const uint32_t *__restrict__ refw_lane, uint64_t clump_base, uint32_t z, int j8, uint32_t nchunks) {
 	if (j8 < 0 || (uint32_t)j8 >= nchunks * 4) return 0u;
 	return refw_lane[(clump_base * 16 + (uint64_t)z * nchunks) * 4 + (uint32_t)j8];
@@ -1692,7 +1698,9 @@ __device__ __forceinline__ void rescore_reg_one(
 		uint32_t d[NW];
 		#pragma unroll
 		for (int i = 0; i < NW; ++i) d[i] = ref_dword_lane(refw, cbase, z, j8 + i, nchunks);
-		uint32_t d_next = ref_dword_lane(refw, cbase, z, j8 + NW, nchunks);
+		// the symbols ahead of the window come 32 at a time (one 16-byte load per 32 rows instead of a 4-byte load per 8 rows)
+		int jn = j8 + NW;                                      // dword index of the next refill
+		uint4 ahead = ref_chunk_lane(refw, cbase, z, jn >> 2, nchunks);
 		const uint32_t *qp = qpack + (uint64_t)q * qw;
 		uint32_t qd = qp[0], q_next = qw > 1 ? qp[1] : 0u;
 		uint32_t prev_sym = (ref_dword_lane(refw, cbase, z, (p - 1) >> 3, nchunks) >> (4 * ((p - 1) & 7))) & 15u;
@@ -1748,9 +1756,9 @@ __device__ __forceinline__ void rescore_reg_one(
 			if ((p & 7) == 0) {
 				#pragma unroll
 				for (int i = 0; i < NW - 1; ++i) d[i] = d[i + 1];
-				d[NW - 1] = d_next;
-				++j8;
-				d_next = ref_dword_lane(refw, cbase, z, j8 + NW, nchunks);
+				d[NW - 1] = pick4(ahead, (uint32_t)jn & 3u);
+				++j8; ++jn;
+				if ((jn & 3) == 0) ahead = ref_chunk_lane(refw, cbase, z, jn >> 2, nchunks);
 			}
 		}
 		// final selection over the last row (burst.c:824-842) and end position (862-879)
