@@ -219,7 +219,8 @@ def main():
         kernels = {}
         if masked and mean("ms_prefilter_hash") > 0:
             n = max(1, st["prefilter_launches"])
-            kernels["k_prefilter_mask"] = (mean("ms_prefilter_hash") / n, (8.0 * st["n_seed_words"] + 3.0 * st["acx_entries_read"] + 8.0 * st["n_lane_tasks"]) / n)
+            pf_name = "k_prefilter_cf" if st["prefilter_algo"] == 0 else "k_prefilter_mask"
+            kernels[pf_name] = (mean("ms_prefilter_hash") / n, (8.0 * st["n_seed_words"] + 3.0 * st["acx_entries_read"] + 8.0 * st["n_lane_tasks"]) / n)
         n = max(1, st["myers_launches"])
         if two_stage:
             cols = st["n_task_columns"] if masked else st["n_columns"] * 16
@@ -228,7 +229,7 @@ def main():
             kernels["k_myers_window<%d>" % ((args.read_len + 31) // 32)] = (mean("ms_myers_window") / n, (0.5 * st["n_window_columns"] + st["n_windows"] * (args.read_len / 2.0 + 12.0)) / n)
         else:
             kernels["k_myers<%d>" % ((args.read_len + 31) // 32)] = (mean("ms_myers") / n, st["bytes_algorithmic"] / n)
-        dom = max(kernels, key=lambda k: kernels[k][0] * (st["prefilter_launches"] if k == "k_prefilter_mask" else n))
+        dom = max(kernels, key=lambda k: kernels[k][0] * (st["prefilter_launches"] if k.startswith("k_prefilter") else n))
         ms_dom, bytes_dom = kernels[dom]
         achieved = bytes_dom / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
         traffic = None
@@ -251,7 +252,7 @@ def main():
                        "device": info["name"], "n_cu": info["n_cu"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic,
-                         "note": "dominant kernel by time; k_prefilter_mask is bound by HBM/LDS latency of short random list gathers, the k_myers_* sweeps by integer VALU issue (SURVEY 8d): their GCUPS is the truthful figure of merit",
+                         "note": "dominant kernel by time; the prefilter is bound by HBM/LDS latency of short random list gathers, the k_myers_* sweeps by integer VALU issue (SURVEY 8d): their GCUPS is the truthful figure of merit",
                          "algorithmic_bytes_per_launch": bytes_dom, "ms_per_launch": ms_dom,
                          "per_kernel": {k: {"ms_per_launch": v[0], "algorithmic_bytes_per_launch": v[1], "GBps": (v[1] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else 0.0)} for k, v in kernels.items()},
                          "gcups_sweeps": cells / (ms_sweeps * 1e-3) / 1e9 if ms_sweeps > 0 else 0.0},

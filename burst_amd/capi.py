@@ -30,7 +30,7 @@ class BhipStats(C.Structure):
                 ("ms_h2d", C.c_float), ("ms_prefilter", C.c_float), ("ms_peq", C.c_float), ("ms_myers", C.c_float),
                 ("ms_rescore", C.c_float), ("ms_d2h", C.c_float), ("ms_total", C.c_float),
                 ("ms_myers_prefix", C.c_float), ("ms_myers_window", C.c_float), ("ms_prefilter_hash", C.c_float), ("ms_seed", C.c_float),
-                ("myers_launches", C.c_uint32), ("prefix_words", C.c_uint32), ("prefilter_launches", C.c_uint32)]
+                ("myers_launches", C.c_uint32), ("prefix_words", C.c_uint32), ("prefilter_launches", C.c_uint32), ("prefilter_algo", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -43,6 +43,8 @@ __global__ void k_attach_masks(const uint32_t *, const uint32_t *, uint64_t, uin
 template <int HTB> __global__ void k_prefilter_mask(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *,
 	uint2 *, uint32_t *, uint32_t);
+template <int CB> __global__ void k_prefilter_cf(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *);
 __global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t);
 template <int NWP> __global__ void k_myers_prefix_task(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *,
 	const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *);
@@ -108,6 +110,7 @@ struct Counters {
 	uint32_t n_rs[12];         // re-scorer buckets: hits per band-width class
 	unsigned long long wcol_sum, tcol_sum, unit_sum;
 	unsigned long long col_sum, qlen_sum, ent_read, scratch_used;
+	unsigned long long surv_sum;           // list records that passed the counting filter (k_prefilter_cf)
 };
 
 // One independent sub-pipeline of a staged batch: its own stream and scratch, a contiguous range of shared slots
@@ -122,6 +125,8 @@ struct Lane {
 	uint64_t seed_words[kNumClasses] = {0};
 	uint32_t pf_launches = 0;
 	bool pf_masked[kNumClasses] = {false};
+	int pf_algo_used = 0;
+	int pf_algo = 0;              // algorithm of this lane's next prefilter launches (follows opt_pf_algo: -1 = adapt)
 	DBuf qlist_cls[kNumClasses], peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters, tasks, ranges, hdr, rs_lists;
 	uint64_t task_cap = 1 << 20;
 	uint64_t cand_cap = 1 << 18, raw_cap = 1 << 18, win_cap = 1 << 20, scratch_cap = 1 << 18;
@@ -171,6 +176,8 @@ struct Handle {
 	int opt_lane_min = 32768;     // fewest entries a sub-pipeline is worth opening for
 	int opt_rescore_reg = 1;      // register-band re-scorer for narrow bands (0 = LDS band only)
 	int opt_pf_waves = 0;         // single-wave blocks per CU of the lane-resolved prefilter (0 = as many as the LDS allows, <= 12)
+	int opt_pf_algo = -1;         // 0 = counting filter + exact lane table (k_prefilter_cf), 1 = exact clump hash table in two passes
+	                              // (k_prefilter_mask), -1 = start with 0 and switch a lane to 1 when more than 30 % of its records survive the filter
 	int opt_pf_table = 0;         // log2 of the per-query hash table (0 = from the workload: 9, 10 or 11)
 	double acx_wmean = 0.0;       // occurrence-weighted mean .acx list length
 };
@@ -420,6 +427,7 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 	if (!strcmp(name, "lane_min_entries")) { if (value < 1) return fail(BHIP_E_ARG, "lane_min_entries must be >= 1"); h->opt_lane_min = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "rescore_reg")) { h->opt_rescore_reg = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_waves")) { if (value < 0 || value > 16) return fail(BHIP_E_ARG, "prefilter_waves must be 0 .. 16"); h->opt_pf_waves = (int)value; return BHIP_OK; }
+	if (!strcmp(name, "prefilter_algo")) { if (value < -1 || value > 1) return fail(BHIP_E_ARG, "prefilter_algo must be -1, 0 or 1"); h->opt_pf_algo = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_table")) { if (value != 0 && (value < 9 || value > 11)) return fail(BHIP_E_ARG, "prefilter_table must be 0, 9, 10 or 11"); h->opt_pf_table = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "lanes")) {
 		if (value < 1 || value > 16) return fail(BHIP_E_ARG, "lanes must be 1 .. 16");
@@ -592,28 +600,52 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	HIPCHK(hipEventRecord(L->ev_pf[cls][0], st));
 	hipLaunchKernelGGL(k_seed_ranges, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), d_qlist, n_list,
 		h->acx_off.as<uint32_t>(), h->K, h->plan.as<uint32_t>(), W16, L->ranges.as<uint2>(), L->hdr.as<uint2>(), h->qpack.as<uint32_t>(), (h->st_maxlen + 7) / 8);
+	const int algo = h->opt_pf_algo >= 0 ? h->opt_pf_algo : L->pf_algo;
 	const uint32_t n_quads = (n_list + 3) / 4;
 	// hash table size per query from the expected number of distinct clumps (sampled words x occurrence-weighted mean list
 	// length): 512 slots keep 12 single-wave blocks on a CU, 1024 -> 7, 2048 -> 4
 	const double expect = (n_list ? (double)L->seed_words[cls] / (double)n_list : (double)maxwords) * h->acx_wmean;   // mean, not max: outliers use the fallback
 	// (the touched list holds half the slots; a query that exceeds it is re-done by the dense fallback, so the estimate -- an
 	// upper bound, every repeated clump counted once per word -- may be cut close)
-	const int htb = h->opt_pf_table ? h->opt_pf_table : (expect <= 230.0 ? 9 : expect <= 470.0 ? 10 : 11);
-	const uint32_t n_cc = htb <= 9 ? 24u : 80u;
-	const uint32_t lds_b = (4u << htb) * 4 + (4u << (htb - 1)) * 2 + 4 * n_cc * 16 + 4 * n_cc * 4 + 128 * 8 + 64 + 256 + 64;
-	const uint32_t fit = std::max<uint32_t>(1, std::min<uint32_t>(12, (160u * 1024u) / ((lds_b + 511u) & ~511u)));
+	// (counting filter: the approximate counters tolerate a load around 1 -- false survivors only cost work)
+	const int htb = h->opt_pf_table ? h->opt_pf_table : algo == 0 ? (expect <= 600.0 ? 9 : expect <= 1200.0 ? 10 : 11) : (expect <= 230.0 ? 9 : expect <= 470.0 ? 10 : 11);
+	// resident single-wave blocks per CU from the kernel's static LDS / register use (measured on gfx950: LDS is granted in
+	// 2 KB steps of the CU's 160 KB; 512 VGPRs per SIMD lane in steps of 8).  The kernel is a persistent loop over a static
+	// partition of the list: one block too many per CU would run after the others and double the time.
+	hipFuncAttributes fa;
+	memset(&fa, 0, sizeof fa);
+	{
+		const void *fp = algo == 0
+			? (htb == 9 ? (const void *)k_prefilter_cf<9> : htb == 10 ? (const void *)k_prefilter_cf<10> : (const void *)k_prefilter_cf<11>)
+			: (htb == 9 ? (const void *)k_prefilter_mask<9> : htb == 10 ? (const void *)k_prefilter_mask<10> : (const void *)k_prefilter_mask<11>);
+		if (hipFuncGetAttributes(&fa, fp) != hipSuccess) { fa.sharedSizeBytes = 48 * 1024; fa.numRegs = 128; }
+	}
+	const uint32_t by_lds = (160u * 1024u) / (uint32_t)std::max<size_t>(2048, (fa.sharedSizeBytes + 2047) & ~(size_t)2047);
+	const uint32_t by_reg = 4u * (512u / (uint32_t)std::max(8, (fa.numRegs + 7) & ~7));
+	const uint32_t fit = std::max<uint32_t>(1u, std::min<uint32_t>(12u, std::min(by_lds, by_reg)));
+	if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] prefilter kernel: table 2^%d, %zu B LDS, %d VGPRs -> %u blocks per CU\n", htb, fa.sharedSizeBytes, fa.numRegs, fit);
 	const uint32_t waves = h->opt_pf_waves ? std::min<uint32_t>((uint32_t)h->opt_pf_waves, fit) : fit;
 	const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * waves);
+	HIPCHK(hipEventRecord(L->ev_pf[cls][1], st));
+	if (algo == 0) {
+#define PFC_LAUNCH(B) hipLaunchKernelGGL(k_prefilter_cf<B>, dim3(grid), dim3(64), 0, st, L->ranges.as<uint2>(), L->hdr.as<uint2>(), W16, n_list, \
+		h->ent_mask.as<uint2>(), h->bad.as<uint32_t>(), h->n_bad, \
+		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
+		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum)
+		if (htb == 9) PFC_LAUNCH(9); else if (htb == 10) PFC_LAUNCH(10); else PFC_LAUNCH(11);
+#undef PFC_LAUNCH
+	} else {
 #define PFM_LAUNCH(B) hipLaunchKernelGGL(k_prefilter_mask<B>, dim3(grid), dim3(64), 0, st, L->ranges.as<uint2>(), L->hdr.as<uint2>(), W16, n_list, \
 		h->ent_mask.as<uint2>(), h->bad.as<uint32_t>(), h->n_bad, \
 		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
 		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, L->cand.as<uint2>(), n_cand_dev, (uint32_t)L->cand_cap)
-	HIPCHK(hipEventRecord(L->ev_pf[cls][1], st));
-	if (htb == 9) PFM_LAUNCH(9); else if (htb == 10) PFM_LAUNCH(10); else PFM_LAUNCH(11);
+		if (htb == 9) PFM_LAUNCH(9); else if (htb == 10) PFM_LAUNCH(10); else PFM_LAUNCH(11);
 #undef PFM_LAUNCH
+	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(L->ev_pf[cls][2], st));
 	++L->pf_launches;
+	L->pf_algo_used = algo;
 	// dense fallback for overflowed queries (clump-level pairs)
 	const uint32_t *bad = h->bad.as<uint32_t>();
 	const bool narrow = h->st_maxlen < 255u + (uint32_t)h->K;
@@ -923,9 +955,14 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		HIPCHK(hipStreamSynchronize(h->sweep_stream));
 		HIPCHK(hipStreamSynchronize(h->post_stream));
 		for (uint32_t l = 0; l < nl; ++l) if (h->lanes[l]->n_entries) h->lanes[l]->hc = *h->lanes[l]->hc_pinned;
+		for (uint32_t l = 0; l < nl; ++l) {      // a lane whose records mostly survive the counting filter does better with the exact table
+			Lane *L = h->lanes[l];
+			if (L->n_entries && L->pf_algo == 0 && L->hc.ent_read > 100000 && (double)L->hc.surv_sum > 0.30 * (double)L->hc.ent_read) L->pf_algo = 1;
+		}
 		if (getenv("BHIP_DEBUG")) for (uint32_t l = 0; l < nl; ++l) {
 			const Lane *L = h->lanes[l];
 			if (!L->n_entries) continue;
+			fprintf(stderr, "[bhip] lane %u: %llu list records, %llu survived the counting filter, next prefilter algorithm %d\n", l, (unsigned long long)L->hc.ent_read, (unsigned long long)L->hc.surv_sum, L->pf_algo);
 			for (int cls = 0; cls < kNumClasses; ++cls) if (L->npf[cls] + L->nex[cls])
 				fprintf(stderr, "[bhip] lane %u class NW=%d: prefiltered %u exhaustive %u maxE %u maxwords %u | tasks %u clump pairs %u windows %u | fallback queries(last class) %u raw %u\n",
 					l, kClasses[cls], L->npf[cls], L->nex[cls], L->maxE[cls], L->maxwords[cls], L->hc.n_tasks_cls[cls], L->hc.n_cand_cls[cls], L->hc.n_wins_cls[cls], L->hc.n_fb, L->hc.n_raw);
@@ -977,7 +1014,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			if (!L->n_entries) continue;
 			const Counters &c = L->hc;
 			S.n_pairs += L->n_pairs_ex + c.unit_sum; S.n_columns += c.col_sum; S.n_task_columns += c.tcol_sum; S.n_raw_hits += c.n_raw; S.acx_entries_read += c.ent_read;
-			S.myers_launches += L->launches; S.prefilter_launches += L->pf_launches; S.n_window_columns += c.wcol_sum; qlen_sum += c.qlen_sum;
+			S.myers_launches += L->launches; S.prefilter_launches += L->pf_launches; if (L->pf_launches) S.prefilter_algo = (uint32_t)L->pf_algo_used; S.n_window_columns += c.wcol_sum; qlen_sum += c.qlen_sum;
 			if (L->prefix_words) S.prefix_words = L->prefix_words;
 			for (int cls = 0; cls < kNumClasses; ++cls) {
 				S.n_pairs += c.n_cand_cls[cls]; S.n_windows += c.n_wins_cls[cls]; S.n_lane_tasks += c.n_tasks_cls[cls];

@@ -931,6 +931,269 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 	if (my_units) { atomicAdd(unit_sum, my_units); atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lane-resolved prefilter, counting-filter variant (same inputs and outputs as k_prefilter_mask).
+// Most list records of a query belong to clumps that share only one or two words with it; the exact per-clump hash
+// table of k_prefilter_mask pays a returning compare-and-swap for each of them.  Here every record first bumps one of
+// 1 << CB approximate 16-bit counters (hash of the clump id, fire-and-forget LDS adds, no key, no probing).  A record
+// whose counter stays below `need` cannot belong to a candidate clump (its counter is an upper bound of its clump's
+// count), so only the survivors -- about one record in six on the bench workload -- are looked at again: they are
+// compacted through a small LDS ring so that 16 lanes work on 16 survivors, inserted by clump id into a small exact
+// table that carries the sixteen 8-bit lane counters directly, and the lanes that reach `need` are emitted.  No
+// false negatives: a record of a clump with count >= need always survives; false survivors only cost work.
+// ------------------------------------------------------------------------------------------------
+template <int CB>
+__global__ __launch_bounds__(64) void k_prefilter_cf(
+		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
+		const uint2 *__restrict__ ent,   // ent = (clump, lane mask) records
+		const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ clump_len, uint32_t tot_refs,
+		uint2 *__restrict__ tasks, uint32_t *__restrict__ n_tasks, uint32_t task_cap,
+		unsigned long long *__restrict__ ent_read,
+		uint32_t *__restrict__ fb_list, uint32_t *__restrict__ n_fb,
+		unsigned long long *__restrict__ unit_sum, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum,
+		unsigned long long *__restrict__ surv_sum) {
+	constexpr uint32_t NCNT = 1u << CB;                                   // approximate counters per query (16 bit each)
+	constexpr uint32_t LT = CB <= 9 ? 64u : (CB == 10 ? 128u : 256u);     // exact lane-table slots per query
+	constexpr uint32_t RING = 80u;                                         // >= 15 pending + 64 new survivors
+	__shared__ __attribute__((aligned(16))) uint32_t s_cnt[4][NCNT / 2];
+	__shared__ uint32_t s_key[4][LT];
+	__shared__ unsigned long long s_lc[4][LT][2];
+	__shared__ uint2 s_ring[4][RING];
+	__shared__ uint8_t s_used[4][LT];                                      // slots of the lane table in use (LT <= 256)
+	__shared__ uint2 s_stage[PFM_STAGE];
+	__shared__ uint32_t s_nstage;
+	__shared__ uint32_t s_ovf[4];
+	__shared__ uint32_t s_dummy[16];          // compare-and-swap target of idle lanes (never written: the compare value cannot match)
+	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
+	if (lane < 16) s_dummy[lane] = 0;
+	for (uint32_t i = lane; i < 4 * NCNT / 2; i += 64) (&s_cnt[0][0])[i] = 0;
+	for (uint32_t i = lane; i < 4 * LT; i += 64) { (&s_key[0][0])[i] = 0; (&s_lc[0][0][0])[2 * i] = 0; (&s_lc[0][0][0])[2 * i + 1] = 0; }
+	if (lane == 0) s_nstage = 0;
+	if (lane < 4) s_ovf[lane] = 0;
+	__syncthreads();
+	unsigned long long my_ent = 0, my_units = 0, my_cols = 0, my_qlen = 0, my_surv = 0;
+#ifdef PFM_PROF
+	unsigned long long my_t[8] = {0,0,0,0,0,0,0,0}, t_last = wall_clock64();
+#endif
+
+	auto push = [&](uint32_t li, uint32_t refIx) {
+		const uint32_t pos = atomicAdd(&s_nstage, 1u);
+		if (pos < PFM_STAGE) s_stage[pos] = make_uint2(li, refIx);
+		else { const uint32_t gp = atomicAdd(n_tasks, 1u); if (gp < task_cap) tasks[gp] = make_uint2(li, refIx); }
+	};
+	auto flush = [&]() {
+		__syncthreads();
+		const uint32_t n = s_nstage < PFM_STAGE ? s_nstage : PFM_STAGE;
+		uint32_t base = 0;
+		if (n) {
+			if (lane == 0) base = atomicAdd(n_tasks, n);
+			base = __shfl(base, 0);
+			for (uint32_t i = lane; i < n; i += 64) if (base + i < task_cap) tasks[base + i] = s_stage[i];
+		}
+		__syncthreads();
+		if (lane == 0) s_nstage = 0;
+		__syncthreads();
+	};
+
+	const uint32_t n_quads = (n_list + 3) >> 2;
+	uint2 hd_n = make_uint2(0, 0), rg_n = make_uint2(0, 0);
+	if (blockIdx.x * 4 + g < n_list) { hd_n = hdr[blockIdx.x * 4 + g]; rg_n = ranges[(size_t)(blockIdx.x * 4 + g) * W16 + gl]; }
+	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
+		const uint32_t li = quad * 4 + g;
+		const bool live = li < n_list;
+		const uint2 hd = hd_n, rg = rg_n;
+		{
+			const uint32_t li_n = (quad + gridDim.x) * 4 + g;
+			hd_n = make_uint2(0, 0); rg_n = make_uint2(0, 0);
+			if (quad + gridDim.x < n_quads && li_n < n_list) { hd_n = hdr[li_n]; rg_n = ranges[(size_t)li_n * W16 + gl]; }
+		}
+		const uint32_t need = hd.x & 0xFFFFu, nwords = live ? hd.x >> 16 : 0u, len = hd.y;
+		const uint32_t thr = need ? need : 1u;
+		uint32_t maxw = nwords;
+		#pragma unroll
+		for (int o = 32; o >= 1; o >>= 1) { const uint32_t t = __shfl_xor(maxw, o); maxw = t > maxw ? t : maxw; }
+		auto word_range = [&](uint32_t j, uint32_t &beg, uint32_t &end) {
+			uint2 r = make_uint2(0, 0);
+			if (live && j < nwords) r = ranges[(size_t)li * W16 + j];
+			beg = r.x; end = r.y;
+		};
+		auto group_scan = [&](uint32_t n, uint32_t &T, uint32_t &excl) {
+			uint32_t ps = n;
+			#pragma unroll
+			for (uint32_t o = 1; o < 16; o <<= 1) { const uint32_t t = __shfl_up(ps, o, 16); if (gl >= o) ps += t; }
+			T = __shfl(ps, 15, 16);
+			excl = ps - n;
+		};
+		auto wave_blocks = [&](uint32_t T) -> uint32_t {
+			uint32_t m = T, t;
+			t = __shfl_xor(m, 16); m = t > m ? t : m;
+			t = __shfl_xor(m, 32); m = t > m ? t : m;
+			return (m + 63) >> 6;
+		};
+		auto load4 = [&](uint32_t ex, uint32_t dl, uint32_t T, uint32_t b, uint2 (&rec)[4]) {      // see k_prefilter_mask
+			#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u) {
+				const uint32_t i = (b * 4 + u) * 16 + gl;
+				uint32_t kk = 0;
+				kk += __shfl(ex, 8, 16) <= i ? 8u : 0u;
+				kk += __shfl(ex, kk + 4, 16) <= i ? 4u : 0u;
+				kk += __shfl(ex, kk + 2, 16) <= i ? 2u : 0u;
+				kk += __shfl(ex, kk + 1, 16) <= i ? 1u : 0u;
+				const uint32_t addr = __shfl(dl, kk, 16) + i;
+				rec[u] = i < T ? ent[addr] : make_uint2(0xFFFFFFFFu, 0);
+			}
+		};
+		auto count4 = [&](const uint2 (&rec)[4]) {     // phase A: approximate counters, no return values
+			#pragma unroll
+			for (int u = 0; u < 4; ++u) if (rec[u].x != 0xFFFFFFFFu) {
+				const uint32_t h = (rec[u].x * 0x9E3779B1u) >> (32 - CB);
+				atomicAdd(&s_cnt[g][h >> 1], 1u << (16 * (h & 1u)));
+			}
+		};
+		uint32_t pending = 0, head = 0;          // survivors waiting in this group's ring (replicated in its 16 lanes)
+		uint32_t nused = 0;                      // slots of this group's lane table in use (replicated)
+		auto c_round = [&]() {                    // wave-uniform: every group moves up to 16 survivors into its lane table
+			const uint32_t take = pending < 16 ? pending : 16;
+			const bool active = gl < take;
+			uint32_t hpos = head + gl; hpos = hpos >= RING ? hpos - RING : hpos;
+			const uint2 rec = active ? s_ring[g][hpos] : make_uint2(0, 0);
+			const uint32_t key = rec.x + 1u;
+			uint32_t slot = (rec.x * 0x85EBCA6Bu) >> (32 - (CB <= 9 ? 6 : (CB == 10 ? 7 : 8)));
+			bool act = active, found = false, fresh = false;
+			for (uint32_t probes = 0; __any(act) && probes < LT; ++probes) {
+				const uint32_t old = atomicCAS(act ? &s_key[g][slot] : &s_dummy[gl], act ? 0u : 0xFFFFFFFFu, key);
+				const bool ok = act && (old == 0 || old == key);
+				fresh |= act && old == 0;
+				found |= ok;
+				act = act && !ok;
+				slot = act ? (slot + 1) & (LT - 1) : slot;
+			}
+			if (act) s_ovf[g] = 1;
+			{
+				const uint32_t m16 = (uint32_t)(__ballot(fresh) >> (lane & 48u)) & 0xFFFFu;
+				if (fresh) s_used[g][nused + __popc(m16 & ((1u << gl) - 1u))] = (uint8_t)slot;
+				nused += __popc(m16);
+			}
+			if (found) {
+				const uint32_t mask = rec.y;
+				if (mask & 0xFFu) atomicAdd(&s_lc[g][slot][0], spread8(mask & 0xFFu));
+				if (mask >> 8) atomicAdd(&s_lc[g][slot][1], spread8(mask >> 8));
+			}
+			head += take; head = head >= RING ? head - RING : head;
+			pending -= take;
+		};
+		auto offer4 = [&](const uint2 (&rec)[4]) {    // phase B: survivors of the counter test go to the ring
+			uint32_t cv[4];
+			#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const uint32_t h = rec[u].x != 0xFFFFFFFFu ? (rec[u].x * 0x9E3779B1u) >> (32 - CB) : 0u;
+				cv[u] = (s_cnt[g][h >> 1] >> (16 * (h & 1u))) & 0xFFFFu;
+			}
+			#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const bool surv = rec[u].x != 0xFFFFFFFFu && cv[u] >= thr;
+				const uint32_t m16 = (uint32_t)(__ballot(surv) >> (lane & 48u)) & 0xFFFFu;
+				if (surv) {
+					uint32_t pos = head + pending + __popc(m16 & ((1u << gl) - 1u));
+					pos = pos >= RING ? pos - RING : pos;
+					pos = pos >= RING ? pos - RING : pos;
+					s_ring[g][pos] = make_uint2(rec[u].x, rec[u].y & 0xFFFFu);
+				}
+				pending += __popc(m16);
+				if (gl == 0) my_surv += __popc(m16);
+			}
+			while (__any(pending >= 16)) c_round();
+		};
+
+		PFM_T(0);
+		const uint32_t beg = live ? rg.x : 0u, n0 = live ? rg.y - rg.x : 0u;
+		my_ent += n0;
+		uint32_t T0, ex0;
+		group_scan(n0, T0, ex0);
+		const uint32_t dl0 = beg - ex0, nblk0 = wave_blocks(T0);
+		uint2 rc[PFM_RB][4];
+		#pragma unroll
+		for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) load4(ex0, dl0, T0, b, rc[b]);
+		PFM_T(6);
+		// ---- phase A over every record of the query
+		#pragma unroll
+		for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) count4(rc[b]);
+		for (uint32_t b = PFM_RB; b < nblk0; ++b) { uint2 rec[4]; load4(ex0, dl0, T0, b, rec); count4(rec); }
+		for (uint32_t base = 16; base < maxw; base += 16) {
+			uint32_t xb, xe, T, ex;
+			word_range(base + gl, xb, xe);
+			my_ent += xe - xb;
+			group_scan(xe - xb, T, ex);
+			const uint32_t nb = wave_blocks(T);
+			for (uint32_t b = 0; b < nb; ++b) { uint2 rec[4]; load4(ex, xb - ex, T, b, rec); count4(rec); }
+		}
+		__syncthreads();
+		PFM_T(7);
+		// ---- phase B: second look at every record (registers for the first blocks, L2 for the rest)
+		#pragma unroll
+		for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) offer4(rc[b]);
+		for (uint32_t b = PFM_RB; b < nblk0; ++b) { uint2 rec[4]; load4(ex0, dl0, T0, b, rec); offer4(rec); }
+		for (uint32_t base = 16; base < maxw; base += 16) {
+			uint32_t xb, xe, T, ex;
+			word_range(base + gl, xb, xe);
+			group_scan(xe - xb, T, ex);
+			const uint32_t nb = wave_blocks(T);
+			for (uint32_t b = 0; b < nb; ++b) { uint2 rec[4]; load4(ex, xb - ex, T, b, rec); offer4(rec); }
+		}
+		PFM_T(2);
+		while (__any(pending > 0)) c_round();
+		__syncthreads();
+		PFM_T(3);
+		// ---- emit the lanes that reach the threshold, clear the tables
+		const uint32_t ovf = s_ovf[g];
+		if (live && !ovf) {
+			for (uint32_t iu = gl; iu < nused; iu += 16) {
+				const uint32_t i = s_used[g][iu];
+				const uint32_t key = s_key[g][i];
+				const uint32_t c = key - 1u;
+				const unsigned long long lo = s_lc[g][i][0], hi = s_lc[g][i][1];
+				s_key[g][i] = 0; s_lc[g][i][0] = 0; s_lc[g][i][1] = 0;
+				uint32_t any = 0;
+				#pragma unroll
+				for (uint32_t z = 0; z < 16; ++z) {
+					const uint32_t v = (uint32_t)(((z < 8 ? lo : hi) >> (8 * (z & 7))) & 255u);
+					const uint32_t refIx = c * 16 + z;
+					if (v >= thr && refIx < tot_refs) { push(li, refIx); any = 1; }
+				}
+				if (any) { ++my_units; my_cols += clump_len[c]; my_qlen += len; }
+			}
+			for (uint32_t i = gl; i < n_bad; i += 16) {        // burst.c:4136-4138, 4282-4283: every lane of the ambiguous clumps
+				const uint32_t c = bad[i];
+				for (uint32_t z = 0; z < 16; ++z) if (c * 16 + z < tot_refs) push(li, c * 16 + z);
+				++my_units; my_cols += clump_len[c]; my_qlen += len;
+			}
+		} else if (ovf) {
+			for (uint32_t i = gl; i < LT; i += 16) { s_key[g][i] = 0; s_lc[g][i][0] = 0; s_lc[g][i][1] = 0; }
+			if (live && gl == 0) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
+		}
+		PFM_T(4);
+		{
+			uint4 *cz = (uint4 *)&s_cnt[g][0];
+			for (uint32_t i = gl; i < NCNT / 8; i += 16) cz[i] = make_uint4(0, 0, 0, 0);
+		}
+		__syncthreads();
+		if (gl == 0) s_ovf[g] = 0;
+		if (s_nstage >= PFM_STAGE / 2) flush(); else __syncthreads();
+		PFM_T(5);
+	}
+	flush();
+#ifdef PFM_PROF
+	if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_pfm_prof[i], my_t[i]);
+#endif
+	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
+	if (surv_sum && my_surv) atomicAdd(surv_sum, my_surv);
+	if (my_units) { atomicAdd(unit_sum, my_units); atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
+}
+#define BHIP_INST_PFCF(CB) \
+	template __global__ void k_prefilter_cf<CB>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, \
+		uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *);
+BHIP_INST_PFCF(9) BHIP_INST_PFCF(10) BHIP_INST_PFCF(11)
+
 template __global__ void k_prefilter_mask<9>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, uint32_t);
 template __global__ void k_prefilter_mask<10>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,

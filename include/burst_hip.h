@@ -69,7 +69,8 @@ typedef struct BhipStats {
 	float ms_seed;             /* part of ms_prefilter spent in k_seed_ranges */
 	uint32_t myers_launches;   /* launches of the column-sweeping kernel (k_myers_prefix, or k_myers on the one-stage path) */
 	uint32_t prefix_words;     /* NWP of the last launch, 0 = one-stage path */
-	uint32_t prefilter_launches; /* launches of k_prefilter_mask */
+	uint32_t prefilter_launches; /* launches of the lane-resolved prefilter kernel */
+	uint32_t prefilter_algo;   /* kernel of the last such launch: 0 = k_prefilter_cf (counting filter), 1 = k_prefilter_mask (exact hash) */
 } BhipStats;
 
 /* Upload a database to device `device` and create a handle.
@@ -139,7 +140,8 @@ int bhip_copy_hits_device(void *handle, void *dst_device, uint64_t cap_records, 
  * run as a software pipeline on three HIP streams; "lane_min_entries" (default 32768) = fewest entries worth a lane.
  * "sweep_blocks": 1..8 workgroups per CU of the sweep kernels.  "lane_masks": 1 (default) = lane-resolved prefilter.
  * "prefilter_table": 0 (default, chosen from the accelerator's list lengths) or 9/10/11 = log2 slots of the per-query
- * hash table; "prefilter_waves": 0 (default, as many as fit) .. 16 single-wave prefilter blocks per CU.
+ * tables; "prefilter_algo": -1 (default) = counting-filter kernel, switching to the exact-hash kernel for workloads where
+ * more than 30 % of the list records survive the filter, 0 / 1 = force one of them; "prefilter_waves": 0 (default, as many as fit) .. 16 single-wave prefilter blocks per CU.
  * "rescore_reg": 1 (default) = register-band re-scorer for narrow bands, 0 = LDS band only.
  * None of these changes a result. */
 int bhip_set_option(void *handle, const char *name, long long value);
