@@ -1153,12 +1153,23 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 				const uint32_t c = key - 1u;
 				const unsigned long long lo = s_lc[g][i][0], hi = s_lc[g][i][1];
 				s_key[g][i] = 0; s_lc[g][i][0] = 0; s_lc[g][i][1] = 0;
+				// lanes with count >= thr: byte-parallel compare (counts and thr below 128: (b | 0x80) - thr keeps its top bit iff
+				// b >= thr), the eight top bits gathered into one byte by a multiply
+				uint32_t m16 = 0;
+				if (nwords < 128) {
+					const unsigned long long H = 0x8080808080808080ull, L1 = 0x0101010101010101ull, G = 0x0102040810204080ull;
+					const unsigned long long tl = ((lo | H) - thr * L1) & H, th = ((hi | H) - thr * L1) & H;
+					m16 = (uint32_t)(((tl >> 7) * G) >> 56) | ((uint32_t)(((th >> 7) * G) >> 56) << 8);
+				} else {
+					#pragma unroll
+					for (uint32_t z = 0; z < 16; ++z) m16 |= ((uint32_t)(((z < 8 ? lo : hi) >> (8 * (z & 7))) & 255u) >= thr ? 1u : 0u) << z;
+				}
 				uint32_t any = 0;
-				#pragma unroll
-				for (uint32_t z = 0; z < 16; ++z) {
-					const uint32_t v = (uint32_t)(((z < 8 ? lo : hi) >> (8 * (z & 7))) & 255u);
+				while (m16) {
+					const uint32_t z = (uint32_t)__builtin_ctz(m16);
+					m16 &= m16 - 1;
 					const uint32_t refIx = c * 16 + z;
-					if (v >= thr && refIx < tot_refs) { push(li, refIx); any = 1; }
+					if (refIx < tot_refs) { push(li, refIx); any = 1; }
 				}
 				if (any) { ++my_units; my_cols += clump_len[c]; my_qlen += len; }
 			}
