@@ -32,9 +32,6 @@ template <int NW> __global__ void k_myers(const uint2 *, const uint32_t *, uint6
 template <int NWP> __global__ void k_myers_prefix(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
 	const uint64_t *, const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t, BhipWin *, uint32_t *, uint32_t,
 	unsigned long long *, unsigned long long *);
-template <int NWP> __global__ void k_myers_prefix2(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
-	const uint64_t *, const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t, BhipWin *, uint32_t *, uint32_t,
-	unsigned long long *, unsigned long long *);
 template <int NW> __global__ void k_myers_window(const BhipWin *, const uint32_t *, uint32_t, int, const uint32_t *, const uint32_t *, const uint64_t *,
 	const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *,
 	unsigned long long *);

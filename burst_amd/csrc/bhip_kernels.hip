@@ -1421,93 +1421,6 @@ __global__ __launch_bounds__(256) void k_myers_prefix(
 	if (col_sum && my_cols) { atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
 }
 
-// Same stage A with TWO reference lanes per thread (z and z+8 of one clump): two independent recurrences interleave in
-// one instruction stream, which hides the ~4-deep VALU dependency chain that left the one-lane version at ~58 % of the
-// VALU issue rate (profiles/r01b: SQ_WAIT_INST_ANY = 41 % of wave cycles).  8 threads = one (query, clump), 32 per block.
-template <int NWP>
-__global__ __launch_bounds__(256) void k_myers_prefix2(
-		const uint2 *__restrict__ pairs, const uint32_t *__restrict__ n_pairs_dev, uint64_t n_pairs_host,
-		uint32_t n_clumps_implicit, uint32_t li_base,
-		const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ peqp, const uint64_t *__restrict__ qoff,
-		const uint16_t *__restrict__ qemac,
-		const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
-		uint32_t tot_refs, BhipWin *__restrict__ wins, uint32_t *__restrict__ n_wins, uint32_t win_cap,
-		unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum) {
-	__shared__ __attribute__((aligned(16))) uint32_t s_peq[32][16 * NWP];
-	const uint32_t tid = threadIdx.x, g = tid >> 3, zl = tid & 7;
-	const uint64_t n_pairs = n_pairs_dev ? ((uint64_t)*n_pairs_dev < n_pairs_host ? (uint64_t)*n_pairs_dev : n_pairs_host) : n_pairs_host;
-	const uint64_t n_tiles = (n_pairs + 31) >> 5;
-	unsigned long long my_cols = 0, my_qlen = 0;
-	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-		const uint64_t p = tile * 32 + g;
-		const bool live = p < n_pairs;
-		uint32_t li = 0, c = 0;
-		if (live) {
-			if (pairs) { const uint2 pr = pairs[p]; li = pr.x; c = pr.y; }
-			else { li = li_base + (uint32_t)(p / n_clumps_implicit); c = (uint32_t)(p % n_clumps_implicit); }
-		}
-		__syncthreads();
-		if (live) {
-			const uint32_t *src = peqp + (uint64_t)li * 16 * NWP;
-			#pragma unroll
-			for (int w = 0; w < 2 * NWP; ++w) s_peq[g][zl * 2 * NWP + w] = src[zl * 2 * NWP + w];
-		}
-		__syncthreads();
-		if (!live) continue;
-		const uint32_t q = qlist ? qlist[li] : li;
-		const uint32_t m = (uint32_t)(qoff[q + 1] - qoff[q]), E = qemac[q];
-		const uint32_t P = m < 32u * NWP ? m : 32u * NWP;
-		const uint32_t L = clump_len[c], nchunks = (L + 31) >> 5;
-		uint32_t fshift = 0;
-		while ((nchunks >> fshift) > 32) ++fshift;
-		uint32_t PvA[NWP], MvA[NWP], PvB[NWP], MvB[NWP];
-		#pragma unroll
-		for (int w = 0; w < NWP; ++w) {
-			const int lo = 32 * NWP - (int)P - 32 * w;
-			PvA[w] = PvB[w] = lo <= 0 ? 0xFFFFFFFFu : (lo >= 32 ? 0u : (0xFFFFFFFFu << lo));
-			MvA[w] = MvB[w] = 0;
-		}
-		int scoreA = (int)P, scoreB = (int)P;
-		uint32_t flagsA = 0, flagsB = 0;
-		const uint4 *rpA = ref + ref_off[c] * 16 + zl, *rpB = rpA + 8;
-		const uint32_t *tab = &s_peq[g][0];
-		for (uint32_t t = 0; t < nchunks; ++t) {
-			const uint4 chA = rpA[(uint64_t)t * 16], chB = rpB[(uint64_t)t * 16];
-			const uint32_t dA[4] = {chA.x, chA.y, chA.z, chA.w}, dB[4] = {chB.x, chB.y, chB.z, chB.w};
-			int cminA = 0x7FFFFFFF, cminB = 0x7FFFFFFF;
-			#pragma unroll
-			for (int i = 0; i < 32; ++i) {
-				const uint32_t symA = (dA[i >> 3] >> (4 * (i & 7))) & 15u, symB = (dB[i >> 3] >> (4 * (i & 7))) & 15u;
-				uint32_t EqA[NWP], EqB[NWP];
-				#pragma unroll
-				for (int w = 0; w < NWP; ++w) { EqA[w] = tab[symA * NWP + w]; EqB[w] = tab[symB * NWP + w]; }
-				myers_step<NWP>(EqA, PvA, MvA, scoreA);
-				myers_step<NWP>(EqB, PvB, MvB, scoreB);
-				cminA = scoreA < cminA ? scoreA : cminA;
-				cminB = scoreB < cminB ? scoreB : cminB;
-			}
-			flagsA |= ((uint32_t)cminA <= E ? 1u : 0u) << (t >> fshift);
-			flagsB |= ((uint32_t)cminB <= E ? 1u : 0u) << (t >> fshift);
-		}
-		const uint32_t refA = c * 16 + zl, refB = refA + 8;
-		if (flagsA && refA < tot_refs) {
-			const uint32_t pos = atomicAdd(n_wins, 1u);
-			if (pos < win_cap) { BhipWin w; w.li = li; w.refIx = refA; w.flags = flagsA; wins[pos] = w; }
-		}
-		if (flagsB && refB < tot_refs) {
-			const uint32_t pos = atomicAdd(n_wins, 1u);
-			if (pos < win_cap) { BhipWin w; w.li = li; w.refIx = refB; w.flags = flagsB; wins[pos] = w; }
-		}
-		if (zl == 0) { my_cols += L; my_qlen += m; }
-	}
-	if (col_sum && my_cols) { atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
-}
-#define BHIP_INST_PREFIX2(NWP) \
-	template __global__ void k_myers_prefix2<NWP>(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *, \
-		const uint64_t *, const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t, BhipWin *, uint32_t *, uint32_t, \
-		unsigned long long *, unsigned long long *);
-BHIP_INST_PREFIX2(1) BHIP_INST_PREFIX2(2) BHIP_INST_PREFIX2(3)
-
 // Stage A over lane TASKS (list position, reference lane) from k_prefilter_mask: one thread per task, each with its own
 // 16-row prefix table in LDS ([row][thread] layout: conflict-free for any symbol mix).  Same recurrence and flags as
 // k_myers_prefix.
