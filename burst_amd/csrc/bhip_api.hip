@@ -41,8 +41,10 @@ template <int HTB> __global__ void k_prefilter_mask(const uint2 *, const uint2 *
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *,
 	uint2 *, uint32_t *, uint32_t);
 template <int CB> __global__ void k_prefilter_cf(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
-	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *);
-__global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t);
+	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *,
+	uint2 *, uint32_t *, int);
+__global__ void k_task_filter(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, uint2 *, uint32_t *);
+__global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t, const uint16_t *);
 template <int NWP> __global__ void k_myers_prefix_task(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *,
 	const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *);
 template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *,
@@ -104,6 +106,9 @@ struct Counters {
 	uint32_t n_wins_cls[8];
 	uint32_t n_fb, pad2;
 	uint32_t n_tasks_cls[8];
+	uint32_t n_tasks2_cls[8];  // deferred lane tasks (lower bound above the query's best bound)
+	uint32_t n_tasks2k_cls[8]; // ... of which kept by k_task_filter
+	uint32_t n_wins2_cls[8];   // windows flagged by the second sweep
 	uint32_t n_rs[12];         // re-scorer buckets: hits per band-width class
 	unsigned long long wcol_sum, tcol_sum, unit_sum;
 	unsigned long long col_sum, qlen_sum, ent_read, scratch_used;
@@ -118,13 +123,15 @@ struct Lane {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev_cls[kNumClasses][8];   // per class: 0 start, 1 peq done, 2 prefilter done, 3 sweep(pf) done, 4 sweep(ex) done, 5 window done
 	hipEvent_t ev_rs[2];
+	hipEvent_t ev_ph[kNumClasses][2];    // per class: first window sweep done, second task sweep done
 	hipEvent_t ev_pf[kNumClasses][3];    // per class: seed lookup start, hash kernel start, hash kernel done
 	uint64_t seed_words[kNumClasses] = {0};
 	uint32_t pf_launches = 0;
 	bool pf_masked[kNumClasses] = {false};
+	bool pruned[kNumClasses] = {false};   // a second (filtered) sweep ran for this class
 	int pf_algo_used = 0;
 	int pf_algo = 0;              // algorithm of this lane's next prefilter launches (follows opt_pf_algo: -1 = adapt)
-	DBuf qlist_cls[kNumClasses], peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters, tasks, ranges, hdr, rs_lists;
+	DBuf qlist_cls[kNumClasses], peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters, tasks, tasks2, tasks2k, wins2, ranges, hdr, rs_lists;
 	uint64_t task_cap = 1 << 20;
 	uint64_t cand_cap = 1 << 18, raw_cap = 1 << 18, win_cap = 1 << 20, scratch_cap = 1 << 18;
 	uint32_t npf[kNumClasses] = {0}, nex[kNumClasses] = {0}, maxE[kNumClasses] = {0}, maxwords[kNumClasses] = {0}, maxlen = 0, n_entries = 0;
@@ -170,6 +177,7 @@ struct Handle {
 	int opt_lanes = 1;            // sub-pipelines per staged batch (the stage kernels fill the chip on their own; > 1 only helps small batches)
 	int opt_sweep_blocks = 8;     // 256-thread blocks per CU of the column-sweep kernels
 	uint64_t last_n_out = 0;      // records of the last bhip_align_staged call, still resident (sorted) in out_sorted
+	int opt_prune = 1;            // second sweep for lanes whose seed count bounds their edit distance above the first sweep's best
 	int opt_lane_min = 32768;     // fewest entries a sub-pipeline is worth opening for
 	int opt_rescore_reg = 1;      // register-band re-scorer for narrow bands (0 = LDS band only)
 	int opt_pf_waves = 0;         // single-wave blocks per CU of the lane-resolved prefilter (0 = as many as the LDS allows, <= 12)
@@ -188,12 +196,13 @@ extern "C" int bhip_abi_version(void) { return BHIP_ABI_VERSION; }
 static void lane_destroy(Lane *L) {
 	if (!L) return;
 	if (L->stream) (void)hipStreamSynchronize(L->stream);
-	DBuf *all[] = {&L->peq, &L->peqp, &L->cand, &L->candcnt, &L->wins, &L->raw, &L->wide, &L->scratch, &L->fb_list, &L->gcnt, &L->counters, &L->tasks, &L->ranges, &L->hdr, &L->rs_lists};
+	DBuf *all[] = {&L->peq, &L->peqp, &L->cand, &L->candcnt, &L->wins, &L->raw, &L->wide, &L->scratch, &L->fb_list, &L->gcnt, &L->counters, &L->tasks, &L->tasks2, &L->tasks2k, &L->wins2, &L->ranges, &L->hdr, &L->rs_lists};
 	for (DBuf *b : all) b->release();
 	for (auto &b : L->qlist_cls) b.release();
 	for (auto &ce : L->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
 	for (auto &e : L->ev_rs) if (e) (void)hipEventDestroy(e);
 	for (auto &ce : L->ev_pf) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
+	for (auto &ce : L->ev_ph) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
 	if (L->stream) (void)hipStreamDestroy(L->stream);
 	if (L->hc_pinned) (void)hipHostFree(L->hc_pinned);
 	delete L;
@@ -201,11 +210,12 @@ static void lane_destroy(Lane *L) {
 
 static int lane_create(Handle *h, Lane **out) {
 	Lane *L = new Lane();
-	memset(L->ev_cls, 0, sizeof L->ev_cls); memset(L->ev_rs, 0, sizeof L->ev_rs); memset(L->ev_pf, 0, sizeof L->ev_pf);
+	memset(L->ev_cls, 0, sizeof L->ev_cls); memset(L->ev_rs, 0, sizeof L->ev_rs); memset(L->ev_pf, 0, sizeof L->ev_pf); memset(L->ev_ph, 0, sizeof L->ev_ph);
 	if (hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipStreamCreate failed"); }
 	for (auto &ce : L->ev_cls) for (auto &e : ce) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
 	for (auto &e : L->ev_rs) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
 	for (auto &ce : L->ev_pf) for (auto &e : ce) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
+	for (auto &ce : L->ev_ph) for (auto &e : ce) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
 	int rc = L->counters.reserve(sizeof(Counters));
 	if (rc) { lane_destroy(L); return rc; }
 	if (hipHostMalloc((void **)&L->hc_pinned, sizeof(Counters), hipHostMallocDefault) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipHostMalloc failed"); }
@@ -422,6 +432,7 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 	if (!strcmp(name, "lane_masks")) { h->opt_lane_masks = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "sweep_blocks")) { if (value < 1 || value > 8) return fail(BHIP_E_ARG, "sweep_blocks must be 1 .. 8"); h->opt_sweep_blocks = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "lane_min_entries")) { if (value < 1) return fail(BHIP_E_ARG, "lane_min_entries must be >= 1"); h->opt_lane_min = (int)value; return BHIP_OK; }
+	if (!strcmp(name, "prune")) { h->opt_prune = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "rescore_reg")) { h->opt_rescore_reg = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_waves")) { if (value < 0 || value > 16) return fail(BHIP_E_ARG, "prefilter_waves must be 0 .. 16"); h->opt_pf_waves = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_algo")) { if (value < -1 || value > 1) return fail(BHIP_E_ARG, "prefilter_algo must be -1, 0 or 1"); h->opt_pf_algo = (int)value; return BHIP_OK; }
@@ -459,18 +470,34 @@ static void launch_prefix(Handle *h, Lane *L, hipStream_t st, int NWP, uint32_t 
 	if (NWP == 1) LP(1); else if (NWP == 2) LP(2); else if (NWP == 3) LP(3); else if (NWP == 4) LP(4); else LP(6);
 	#undef LP
 }
-static void launch_prefix_task(Handle *h, Lane *L, hipStream_t st, int NWP, uint32_t grid, const uint32_t *n_tasks_dev, const uint32_t *qlist,
-		uint32_t *n_wins, Counters *dc) {
-	#define LT(N) hipLaunchKernelGGL(k_myers_prefix_task<N>, dim3(grid), dim3(64), 0, st, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, qlist, \
+static void launch_prefix_task(Handle *h, Lane *L, hipStream_t st, int NWP, uint32_t grid, const uint2 *tasks, const uint32_t *n_tasks_dev, const uint32_t *qlist,
+		BhipWin *wins, uint32_t *n_wins, Counters *dc) {
+	#define LT(N) hipLaunchKernelGGL(k_myers_prefix_task<N>, dim3(grid), dim3(64), 0, st, tasks, n_tasks_dev, (uint32_t)L->task_cap, qlist, \
 		L->peqp.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
-		L->wins.as<BhipWin>(), n_wins, (uint32_t)L->win_cap, &dc->tcol_sum)
+		wins, n_wins, (uint32_t)L->win_cap, &dc->tcol_sum)
 	if (NWP == 1) LT(1); else if (NWP == 2) LT(2); else if (NWP == 3) LT(3); else if (NWP == 4) LT(4); else LT(6);
 	#undef LT
 }
-static void launch_window(Handle *h, Lane *L, hipStream_t wst, int cls, int NWP, uint32_t grid, const uint32_t *qlist, const uint32_t *n_wins, Counters *dc) {
-	#define LW(N) hipLaunchKernelGGL(k_myers_window<N>, dim3(grid), dim3(256), 0, wst, L->wins.as<BhipWin>(), n_wins, (uint32_t)L->win_cap, NWP, qlist, \
+// Resident blocks per CU of a kernel from its static register / LDS use (512 VGPRs per SIMD lane granted in steps of 8, at
+// most 8 waves per SIMD; about 148 KB of LDS): the persistent grid-stride kernels are launched with exactly that many
+// blocks, a block that has to wait for a free slot would run its whole share after the others.
+static uint32_t blocks_per_cu(const void *fn, uint32_t threads, size_t dyn_lds) {
+	hipFuncAttributes fa;
+	memset(&fa, 0, sizeof fa);
+	if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return 4;
+	const uint32_t waves_per_block = (threads + 63) / 64;
+	const uint32_t by_reg = 4u * std::min(8u, 512u / (uint32_t)std::max(8, (fa.numRegs + 7) & ~7)) / waves_per_block;
+	const size_t lds = fa.sharedSizeBytes + dyn_lds;
+	const uint32_t by_lds = lds ? (uint32_t)((148u * 1024u) / std::max<size_t>(512, (lds + 511) & ~(size_t)511)) : 64u;
+	return std::max(1u, std::min(by_reg, by_lds));
+}
+
+static void launch_window(Handle *h, Lane *L, hipStream_t wst, int cls, int NWP, uint32_t grid_cap, const uint32_t *qlist, const BhipWin *wins, const uint32_t *n_wins, Counters *dc) {
+	#define LW(N) { const uint32_t thr = (N) <= 8 ? 64u : 256u;      /* NW <= 8: per-thread A/C/G/T profile rows in LDS, 64-thread blocks */ \
+		const uint32_t grid = std::min<uint32_t>(grid_cap * (256u / thr), (uint32_t)h->n_cu * blocks_per_cu((const void *)k_myers_window<N>, thr, 0)); \
+		hipLaunchKernelGGL(k_myers_window<N>, dim3(grid), dim3(thr), 0, wst, wins, n_wins, (uint32_t)L->win_cap, NWP, qlist, \
 		L->peq.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->ref_lane.as<uint4>(), \
-		h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), &dc->wcol_sum)
+		h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), &dc->wcol_sum); }
 	switch (kClasses[cls]) { case 2: LW(2); break; case 4: LW(4); break; case 6: LW(6); break; case 8: LW(8); break; case 10: LW(10); break;
 		case 16: LW(16); break; default: LW(32); break; }
 	#undef LW
@@ -586,7 +613,7 @@ static int launch_prefilter(Handle *h, Lane *L, hipStream_t pf_st, const uint32_
 // lane-resolved prefilter: tasks (list position, reference lane) into L->tasks; queries whose table overflowed go through the
 // dense clump-level kernels into L->cand as (list position, clump) pairs
 static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, const uint32_t *d_qlist, uint32_t n_list, uint32_t maxwords, uint32_t *n_tasks_dev,
-                                 uint32_t *n_cand_dev, Counters *dc) {
+                                 uint32_t *n_cand_dev, Counters *dc, int prune) {
 	int rc;
 	if ((rc = L->fb_list.reserve((size_t)n_list * 4 + 16))) return rc;
 	HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 4, st));
@@ -596,7 +623,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	const uint64_t n_thr = (uint64_t)n_list * W16;
 	HIPCHK(hipEventRecord(L->ev_pf[cls][0], st));
 	hipLaunchKernelGGL(k_seed_ranges, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), d_qlist, n_list,
-		h->acx_off.as<uint32_t>(), h->K, h->plan.as<uint32_t>(), W16, L->ranges.as<uint2>(), L->hdr.as<uint2>(), h->qpack.as<uint32_t>(), (h->st_maxlen + 7) / 8);
+		h->acx_off.as<uint32_t>(), h->K, h->plan.as<uint32_t>(), W16, L->ranges.as<uint2>(), L->hdr.as<uint2>(), h->qpack.as<uint32_t>(), (h->st_maxlen + 7) / 8, h->qemac.as<uint16_t>());
 	const int algo = h->opt_pf_algo >= 0 ? h->opt_pf_algo : L->pf_algo;
 	const uint32_t n_quads = (n_list + 3) / 4;
 	// hash table size per query from the expected number of distinct clumps (sampled words x occurrence-weighted mean list
@@ -606,8 +633,8 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	// upper bound, every repeated clump counted once per word -- may be cut close)
 	// (counting filter: the approximate counters tolerate a load around 1 -- false survivors only cost work)
 	const int htb = h->opt_pf_table ? h->opt_pf_table : algo == 0 ? (expect <= 600.0 ? 9 : expect <= 1200.0 ? 10 : 11) : (expect <= 230.0 ? 9 : expect <= 470.0 ? 10 : 11);
-	// resident single-wave blocks per CU from the kernel's static LDS / register use (measured on gfx950: LDS is granted in
-	// 2 KB steps of the CU's 160 KB; 512 VGPRs per SIMD lane in steps of 8).  The kernel is a persistent loop over a static
+	// resident single-wave blocks per CU from the kernel's static LDS / register use (measured on gfx950: 11 blocks of 13 144 B
+	// fit a CU and 12 do not, 10 of 14 168 B fit and 11 do not: about 148 KB of the 160 KB are available to them; 512 VGPRs per SIMD lane in steps of 8).  The kernel is a persistent loop over a static
 	// partition of the list: one block too many per CU would run after the others and double the time.
 	hipFuncAttributes fa;
 	memset(&fa, 0, sizeof fa);
@@ -617,7 +644,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 			: (htb == 9 ? (const void *)k_prefilter_mask<9> : htb == 10 ? (const void *)k_prefilter_mask<10> : (const void *)k_prefilter_mask<11>);
 		if (hipFuncGetAttributes(&fa, fp) != hipSuccess) { fa.sharedSizeBytes = 48 * 1024; fa.numRegs = 128; }
 	}
-	const uint32_t by_lds = (160u * 1024u) / (uint32_t)std::max<size_t>(2048, (fa.sharedSizeBytes + 2047) & ~(size_t)2047);
+	const uint32_t by_lds = (148u * 1024u) / (uint32_t)std::max<size_t>(512, (fa.sharedSizeBytes + 511) & ~(size_t)511);
 	const uint32_t by_reg = 4u * (512u / (uint32_t)std::max(8, (fa.numRegs + 7) & ~7));
 	const uint32_t fit = std::max<uint32_t>(1u, std::min<uint32_t>(12u, std::min(by_lds, by_reg)));
 	if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] prefilter kernel: table 2^%d, %zu B LDS, %d VGPRs -> %u blocks per CU\n", htb, fa.sharedSizeBytes, fa.numRegs, fit);
@@ -628,7 +655,8 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 #define PFC_LAUNCH(B) hipLaunchKernelGGL(k_prefilter_cf<B>, dim3(grid), dim3(64), 0, st, L->ranges.as<uint2>(), L->hdr.as<uint2>(), W16, n_list, \
 		h->ent_mask.as<uint2>(), h->bad.as<uint32_t>(), h->n_bad, \
 		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
-		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum)
+		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum, \
+		L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], prune)
 		if (htb == 9) PFC_LAUNCH(9); else if (htb == 10) PFC_LAUNCH(10); else PFC_LAUNCH(11);
 #undef PFC_LAUNCH
 	} else {
@@ -807,6 +835,9 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	if ((rc = L->scratch.reserve(L->scratch_cap * sizeof(uint32_t)))) return rc;
 	if ((rc = L->wins.reserve(L->win_cap * sizeof(BhipWin)))) return rc;
 	if ((rc = L->tasks.reserve(L->task_cap * sizeof(uint2)))) return rc;
+	if ((rc = L->tasks2.reserve(L->task_cap * sizeof(uint2)))) return rc;
+	if ((rc = L->tasks2k.reserve(L->task_cap * sizeof(uint2)))) return rc;
+	if ((rc = L->wins2.reserve(L->win_cap * sizeof(BhipWin)))) return rc;
 	for (int cls = 0; cls < kNumClasses; ++cls) if (L->npf[cls] + L->nex[cls]) {
 		if ((rc = L->peq.reserve((size_t)(L->npf[cls] + L->nex[cls]) * 16 * kClasses[cls] * 4))) return rc;
 		if ((rc = L->peqp.reserve((size_t)(L->npf[cls] + L->nex[cls]) * 16 * 6 * 4))) return rc;
@@ -816,7 +847,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	Counters *dc = L->counters.as<Counters>();
 	SharedCtr *sc = h->shared_ctr.as<SharedCtr>();
 	L->launches = 0; L->prefix_words = 0; L->n_pairs_ex = 0; L->pf_launches = 0;
-	for (int c = 0; c < kNumClasses; ++c) L->pf_masked[c] = false;
+	for (int c = 0; c < kNumClasses; ++c) { L->pf_masked[c] = false; L->pruned[c] = false; }
 	const uint32_t grid_my = (uint32_t)h->n_cu * (uint32_t)h->opt_sweep_blocks;   // < 8 leaves wave slots for the other stages' kernels
 	(void)start;
 	for (int cls = 0; cls < kNumClasses; ++cls) {
@@ -852,8 +883,11 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		L->prefix_words = (uint32_t)NWP;
 		HIPCHK(hipEventRecord(ce[1], pf));
 		const bool masked = NWP && n_pf && h->has_masks && h->opt_lane_masks;
+		// lower-bound pruning (second sweep) only when the minimum per shared slot is all that is wanted, with the counting-filter
+		// kernel (it sees all lane counts of a query at once) and while a list position fits the 24 bits next to the bound
+		const int prune = masked && !all_hits && h->opt_prune && n_list < (1u << 24) && (h->opt_pf_algo >= 0 ? h->opt_pf_algo : L->pf_algo) == 0;
 		if (n_pf) {
-			if (masked) { if ((rc = launch_prefilter_mask(h, L, pf, cls, qlist, n_pf, L->maxwords[cls], &dc->n_tasks_cls[cls], &dc->n_cand_cls[cls], dc))) return rc; }
+			if (masked) { if ((rc = launch_prefilter_mask(h, L, pf, cls, qlist, n_pf, L->maxwords[cls], &dc->n_tasks_cls[cls], &dc->n_cand_cls[cls], dc, prune))) return rc; }
 			else if ((rc = launch_prefilter(h, L, pf, qlist, n_pf, L->cand.as<uint2>(), nullptr, (uint32_t)L->cand_cap, true, &dc->n_cand_cls[cls], dc))) return rc;
 		}
 		L->masked = masked;
@@ -863,7 +897,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		HIPCHK(hipStreamWaitEvent(sw, ce[2], 0));
 		HIPCHK(hipEventRecord(ce[6], sw));
 		if (n_pf) {
-			if (masked) launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 32, &dc->n_tasks_cls[cls], qlist, &dc->n_wins_cls[cls], dc);
+			if (masked) launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 32, L->tasks.as<uint2>(), &dc->n_tasks_cls[cls], qlist, L->wins.as<BhipWin>(), &dc->n_wins_cls[cls], dc);
 			if (NWP) launch_prefix(h, L, sw, NWP, grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, &dc->n_wins_cls[cls], dc);
 			else launch_myers(h, L, sw, cls, grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, L->raw.as<BhipRawHit>(),
 				&dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
@@ -883,7 +917,21 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		}
 		HIPCHK(hipEventRecord(ce[4], sw));
 		HIPCHK(hipStreamWaitEvent(po, ce[4], 0));
-		if (NWP) { launch_window(h, L, po, cls, NWP, grid_my, qlist, &dc->n_wins_cls[cls], dc); HIPCHK(hipGetLastError()); }
+		if (NWP) { launch_window(h, L, po, cls, NWP, grid_my, qlist, L->wins.as<BhipWin>(), &dc->n_wins_cls[cls], dc); HIPCHK(hipGetLastError()); }
+		L->pruned[cls] = masked && prune && n_pf;
+		if (masked && prune && n_pf) {
+			// second sweep: the deferred lanes whose lower bound is not above the minimum found by the first sweep
+			HIPCHK(hipEventRecord(L->ev_ph[cls][0], po));
+			HIPCHK(hipStreamWaitEvent(sw, L->ev_ph[cls][0], 0));
+			hipLaunchKernelGGL(k_task_filter, dim3((uint32_t)h->n_cu * 8), dim3(256), 0, sw, L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], (uint32_t)L->task_cap, qlist,
+				h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->best.as<uint32_t>(), L->tasks2k.as<uint2>(), &dc->n_tasks2k_cls[cls]);
+			launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 32, L->tasks2k.as<uint2>(), &dc->n_tasks2k_cls[cls], qlist, L->wins2.as<BhipWin>(), &dc->n_wins2_cls[cls], dc);
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipEventRecord(L->ev_ph[cls][1], sw));
+			HIPCHK(hipStreamWaitEvent(po, L->ev_ph[cls][1], 0));
+			launch_window(h, L, po, cls, NWP, grid_my, qlist, L->wins2.as<BhipWin>(), &dc->n_wins2_cls[cls], dc);
+			HIPCHK(hipGetLastError());
+		}
 		HIPCHK(hipEventRecord(ce[5], po));
 		HIPCHK(hipEventRecord(L->ev_rs[0], po));
 	}
@@ -961,8 +1009,8 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			if (!L->n_entries) continue;
 			fprintf(stderr, "[bhip] lane %u: %llu list records, %llu survived the counting filter, next prefilter algorithm %d\n", l, (unsigned long long)L->hc.ent_read, (unsigned long long)L->hc.surv_sum, L->pf_algo);
 			for (int cls = 0; cls < kNumClasses; ++cls) if (L->npf[cls] + L->nex[cls])
-				fprintf(stderr, "[bhip] lane %u class NW=%d: prefiltered %u exhaustive %u maxE %u maxwords %u | tasks %u clump pairs %u windows %u | fallback queries(last class) %u raw %u\n",
-					l, kClasses[cls], L->npf[cls], L->nex[cls], L->maxE[cls], L->maxwords[cls], L->hc.n_tasks_cls[cls], L->hc.n_cand_cls[cls], L->hc.n_wins_cls[cls], L->hc.n_fb, L->hc.n_raw);
+				fprintf(stderr, "[bhip] lane %u class NW=%d: prefiltered %u exhaustive %u maxE %u maxwords %u | tasks %u + deferred %u (kept %u) clump pairs %u windows %u + %u | fallback queries(last class) %u raw %u\n",
+					l, kClasses[cls], L->npf[cls], L->nex[cls], L->maxE[cls], L->maxwords[cls], L->hc.n_tasks_cls[cls], L->hc.n_tasks2_cls[cls], L->hc.n_tasks2k_cls[cls], L->hc.n_cand_cls[cls], L->hc.n_wins_cls[cls], L->hc.n_wins2_cls[cls], L->hc.n_fb, L->hc.n_raw);
 		}
 		// capacity checks (first call of a workload: grow and redo)
 		bool retry = false;
@@ -973,6 +1021,8 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			for (int cls = 0; cls < kNumClasses; ++cls) {
 				if (c.n_cand_cls[cls] > L->cand_cap) { L->cand_cap = (uint64_t)c.n_cand_cls[cls] + c.n_cand_cls[cls] / 8 + 1024; retry = true; }
 				if (c.n_tasks_cls[cls] > L->task_cap) { L->task_cap = (uint64_t)c.n_tasks_cls[cls] + c.n_tasks_cls[cls] / 8 + 1024; retry = true; }
+				if (c.n_tasks2_cls[cls] > L->task_cap) { L->task_cap = (uint64_t)c.n_tasks2_cls[cls] + c.n_tasks2_cls[cls] / 8 + 1024; retry = true; }
+				if (c.n_wins2_cls[cls] > L->win_cap) { L->win_cap = (uint64_t)c.n_wins2_cls[cls] + c.n_wins2_cls[cls] / 8 + 1024; retry = true; }
 				if (c.n_wins_cls[cls] > L->win_cap) { L->win_cap = (uint64_t)c.n_wins_cls[cls] + c.n_wins_cls[cls] / 8 + 1024; retry = true; }
 			}
 			if (c.n_raw > L->raw_cap) { L->raw_cap = (uint64_t)c.n_raw + c.n_raw / 8 + 1024; retry = true; }
@@ -1014,13 +1064,14 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			S.myers_launches += L->launches; S.prefilter_launches += L->pf_launches; if (L->pf_launches) S.prefilter_algo = (uint32_t)L->pf_algo_used; S.n_window_columns += c.wcol_sum; qlen_sum += c.qlen_sum;
 			if (L->prefix_words) S.prefix_words = L->prefix_words;
 			for (int cls = 0; cls < kNumClasses; ++cls) {
-				S.n_pairs += c.n_cand_cls[cls]; S.n_windows += c.n_wins_cls[cls]; S.n_lane_tasks += c.n_tasks_cls[cls];
+				S.n_pairs += c.n_cand_cls[cls]; S.n_windows += c.n_wins_cls[cls] + c.n_wins2_cls[cls]; S.n_lane_tasks += c.n_tasks_cls[cls] + c.n_tasks2k_cls[cls];
 				if (!(L->npf[cls] + L->nex[cls])) continue;
 				hipEvent_t *ce = L->ev_cls[cls];
 				S.ms_peq += ev_ms(ce[0], ce[1]);
 				if (L->npf[cls]) S.ms_prefilter += ev_ms(ce[1], ce[2]);
 				if (L->npf[cls] && L->pf_masked[cls]) { S.ms_seed += ev_ms(L->ev_pf[cls][0], L->ev_pf[cls][1]); S.ms_prefilter_hash += ev_ms(L->ev_pf[cls][1], L->ev_pf[cls][2]); S.n_seed_words += L->seed_words[cls]; }
-				const float sweep = ev_ms(ce[6], ce[4]), win = ev_ms(ce[4], ce[5]);
+				float sweep = ev_ms(ce[6], ce[4]), win = ev_ms(ce[4], ce[5]);
+				if (L->pruned[cls]) { const float second = ev_ms(L->ev_ph[cls][0], L->ev_ph[cls][1]); sweep += second; win -= second; }   // filter + second task sweep sit between the two window launches
 				S.ms_myers += sweep + win;
 				if (L->prefix_words) { S.ms_myers_prefix += sweep; S.ms_myers_window += win; }
 			}

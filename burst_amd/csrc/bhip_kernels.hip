@@ -630,7 +630,7 @@ __device__ __forceinline__ void pfm_bump4(uint32_t *tab, uint32_t *dummy, const 
 __global__ __launch_bounds__(256) void k_seed_ranges(
 		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint32_t *__restrict__ qlist, uint32_t n_list,
 		const uint32_t *__restrict__ acx_off, int K, const uint32_t *__restrict__ plan, uint32_t W16,
-		uint2 *__restrict__ ranges, uint2 *__restrict__ hdr, const uint32_t *__restrict__ qpack, uint32_t qw) {
+		uint2 *__restrict__ ranges, uint2 *__restrict__ hdr, const uint32_t *__restrict__ qpack, uint32_t qw, const uint16_t *__restrict__ qemac) {
 	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	const uint32_t li = (uint32_t)(t / W16), j = (uint32_t)(t % W16);
 	if (li >= n_list) return;
@@ -664,7 +664,8 @@ __global__ __launch_bounds__(256) void k_seed_ranges(
 		if (ok) { r.x = acx_off[w]; r.y = acx_off[w + 1]; }
 	}
 	ranges[t] = r;
-	if (j == 0) hdr[li] = make_uint2((need > 0xFFFFu ? 0xFFFFu : need) | nwords << 16, len);
+	// header: need | words << 16 ; length | budget << 12 | (words one edit can destroy = ceil(K / stride)) << 20
+	if (j == 0) hdr[li] = make_uint2((need > 0xFFFFu ? 0xFFFFu : need) | nwords << 16, len | (uint32_t)(qemac[q] > 255 ? 255 : qemac[q]) << 12 | ((uint32_t)(K + stride - 1) / stride) << 20);
 }
 
 template <int HTB>
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 			hd_n = make_uint2(0, 0); rg_n = make_uint2(0, 0);
 			if (quad + gridDim.x < n_quads && li_n < n_list) { hd_n = hdr[li_n]; rg_n = ranges[(size_t)li_n * W16 + gl]; }
 		}
-		const uint32_t need = hd.x & 0xFFFFu, nwords = live ? hd.x >> 16 : 0u, len = hd.y;
+		const uint32_t need = hd.x & 0xFFFFu, nwords = live ? hd.x >> 16 : 0u, len = hd.y & 0xFFFu;
 		uint32_t maxw = nwords;
 		#pragma unroll
 		for (int o = 32; o >= 1; o >>= 1) { const uint32_t t = __shfl_xor(maxw, o); maxw = t > maxw ? t : maxw; }
@@ -951,24 +952,26 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 		unsigned long long *__restrict__ ent_read,
 		uint32_t *__restrict__ fb_list, uint32_t *__restrict__ n_fb,
 		unsigned long long *__restrict__ unit_sum, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum,
-		unsigned long long *__restrict__ surv_sum) {
+		unsigned long long *__restrict__ surv_sum,
+		uint2 *__restrict__ tasks2, uint32_t *__restrict__ n_tasks2, int prune) {   // prune: lanes that cannot hold a minimum go to tasks2 with their lower bound
 	constexpr uint32_t NCNT = 1u << CB;                                   // approximate counters per query (16 bit each)
 	constexpr uint32_t LT = CB <= 9 ? 64u : (CB == 10 ? 128u : 256u);     // exact lane-table slots per query
+	constexpr uint32_t CF_STAGE = 64u;                                     // staged tasks per output list
 	constexpr uint32_t RING = 80u;                                         // >= 15 pending + 64 new survivors
 	__shared__ __attribute__((aligned(16))) uint32_t s_cnt[4][NCNT / 2];
 	__shared__ uint32_t s_key[4][LT];
 	__shared__ unsigned long long s_lc[4][LT][2];
 	__shared__ uint2 s_ring[4][RING];
 	__shared__ uint8_t s_used[4][LT];                                      // slots of the lane table in use (LT <= 256)
-	__shared__ uint2 s_stage[PFM_STAGE];
-	__shared__ uint32_t s_nstage;
+	__shared__ uint2 s_stage[2][CF_STAGE];
+	__shared__ uint32_t s_nstage[2];
 	__shared__ uint32_t s_ovf[4];
 	__shared__ uint32_t s_dummy[16];          // compare-and-swap target of idle lanes (never written: the compare value cannot match)
 	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
 	if (lane < 16) s_dummy[lane] = 0;
 	for (uint32_t i = lane; i < 4 * NCNT / 2; i += 64) (&s_cnt[0][0])[i] = 0;
 	for (uint32_t i = lane; i < 4 * LT; i += 64) { (&s_key[0][0])[i] = 0; (&s_lc[0][0][0])[2 * i] = 0; (&s_lc[0][0][0])[2 * i + 1] = 0; }
-	if (lane == 0) s_nstage = 0;
+	if (lane < 2) s_nstage[lane] = 0;
 	if (lane < 4) s_ovf[lane] = 0;
 	__syncthreads();
 	unsigned long long my_ent = 0, my_units = 0, my_cols = 0, my_qlen = 0, my_surv = 0;
@@ -976,22 +979,29 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 	unsigned long long my_t[8] = {0,0,0,0,0,0,0,0}, t_last = wall_clock64();
 #endif
 
-	auto push = [&](uint32_t li, uint32_t refIx) {
-		const uint32_t pos = atomicAdd(&s_nstage, 1u);
-		if (pos < PFM_STAGE) s_stage[pos] = make_uint2(li, refIx);
-		else { const uint32_t gp = atomicAdd(n_tasks, 1u); if (gp < task_cap) tasks[gp] = make_uint2(li, refIx); }
+	auto push = [&](uint32_t which, uint32_t li_lb, uint32_t refIx) {        // which = 0: first sweep, 1: deferred (li_lb = li | bound << 24)
+		const uint32_t pos = atomicAdd(&s_nstage[which], 1u);
+		if (pos < CF_STAGE) s_stage[which][pos] = make_uint2(li_lb, refIx);
+		else {
+			const uint32_t gp = atomicAdd(which ? n_tasks2 : n_tasks, 1u);
+			if (gp < task_cap) (which ? tasks2 : tasks)[gp] = make_uint2(li_lb, refIx);
+		}
 	};
 	auto flush = [&]() {
 		__syncthreads();
-		const uint32_t n = s_nstage < PFM_STAGE ? s_nstage : PFM_STAGE;
-		uint32_t base = 0;
-		if (n) {
-			if (lane == 0) base = atomicAdd(n_tasks, n);
-			base = __shfl(base, 0);
-			for (uint32_t i = lane; i < n; i += 64) if (base + i < task_cap) tasks[base + i] = s_stage[i];
+		#pragma unroll
+		for (uint32_t which = 0; which < 2; ++which) {
+			const uint32_t n = s_nstage[which] < CF_STAGE ? s_nstage[which] : CF_STAGE;
+			uint32_t base = 0;
+			if (n) {
+				if (lane == 0) base = atomicAdd(which ? n_tasks2 : n_tasks, n);
+				base = __shfl(base, 0);
+				uint2 *dst = which ? tasks2 : tasks;
+				for (uint32_t i = lane; i < n; i += 64) if (base + i < task_cap) dst[base + i] = s_stage[which][i];
+			}
 		}
 		__syncthreads();
-		if (lane == 0) s_nstage = 0;
+		if (lane < 2) s_nstage[lane] = 0;
 		__syncthreads();
 	};
 
@@ -1007,7 +1017,8 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 			hd_n = make_uint2(0, 0); rg_n = make_uint2(0, 0);
 			if (quad + gridDim.x < n_quads && li_n < n_list) { hd_n = hdr[li_n]; rg_n = ranges[(size_t)li_n * W16 + gl]; }
 		}
-		const uint32_t need = hd.x & 0xFFFFu, nwords = live ? hd.x >> 16 : 0u, len = hd.y;
+		const uint32_t need = hd.x & 0xFFFFu, nwords = live ? hd.x >> 16 : 0u, len = hd.y & 0xFFFu;
+		const uint32_t budget = (hd.y >> 12) & 255u, dper = (hd.y >> 20) & 15u ? (hd.y >> 20) & 15u : 1u;
 		const uint32_t thr = need ? need : 1u;
 		uint32_t maxw = nwords;
 		#pragma unroll
@@ -1147,16 +1158,13 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 		// ---- emit the lanes that reach the threshold, clear the tables
 		const uint32_t ovf = s_ovf[g];
 		if (live && !ovf) {
-			for (uint32_t iu = gl; iu < nused; iu += 16) {
-				const uint32_t i = s_used[g][iu];
-				const uint32_t key = s_key[g][i];
-				const uint32_t c = key - 1u;
-				const unsigned long long lo = s_lc[g][i][0], hi = s_lc[g][i][1];
-				s_key[g][i] = 0; s_lc[g][i][0] = 0; s_lc[g][i][1] = 0;
-				// lanes with count >= thr: byte-parallel compare (counts and thr below 128: (b | 0x80) - thr keeps its top bit iff
-				// b >= thr), the eight top bits gathered into one byte by a multiply
+			// A lane with c matching words lost (W_valid - c) words, one edit destroys at most `dper` of them: its edit distance
+			// is at least budget - (c - need) / dper.  Unless every hit within budget is wanted, only the lanes with the
+			// smallest bound are swept at once; the others wait for the minimum those produce (k_task_filter).
+			auto lanes_of = [&](uint32_t i, unsigned long long &lo, unsigned long long &hi) -> uint32_t {
+				lo = s_lc[g][i][0]; hi = s_lc[g][i][1];
 				uint32_t m16 = 0;
-				if (nwords < 128) {
+				if (nwords < 128) {      // byte-parallel compare: (b | 0x80) - thr keeps its top bit iff b >= thr; top bits gathered by a multiply
 					const unsigned long long H = 0x8080808080808080ull, L1 = 0x0101010101010101ull, G = 0x0102040810204080ull;
 					const unsigned long long tl = ((lo | H) - thr * L1) & H, th = ((hi | H) - thr * L1) & H;
 					m16 = (uint32_t)(((tl >> 7) * G) >> 56) | ((uint32_t)(((th >> 7) * G) >> 56) << 8);
@@ -1164,18 +1172,53 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 					#pragma unroll
 					for (uint32_t z = 0; z < 16; ++z) m16 |= ((uint32_t)(((z < 8 ? lo : hi) >> (8 * (z & 7))) & 255u) >= thr ? 1u : 0u) << z;
 				}
+				return m16;
+			};
+			uint32_t cmax = 0;
+			if (prune) {
+				for (uint32_t iu = gl; iu < nused; iu += 16) {
+					unsigned long long lo, hi;
+					const uint32_t i = s_used[g][iu], c = s_key[g][i] - 1u;
+					uint32_t m16 = lanes_of(i, lo, hi);
+					while (m16) {
+						const uint32_t z = (uint32_t)__builtin_ctz(m16);
+						m16 &= m16 - 1;
+						const uint32_t v = (uint32_t)(((z < 8 ? lo : hi) >> (8 * (z & 7))) & 255u);
+						if (c * 16 + z < tot_refs) cmax = v > cmax ? v : cmax;
+					}
+				}
+			}
+			uint32_t cmax_all = cmax;
+			#pragma unroll
+			for (int o = 8; o >= 1; o >>= 1) { const uint32_t t = __shfl_xor(cmax_all, o, 16); cmax_all = t > cmax_all ? t : cmax_all; }
+			const uint32_t any_bad = n_bad;                 // BadList lanes carry no bound (0): they are always in the first sweep
+			for (uint32_t iu = gl; iu < nused; iu += 16) {
+				unsigned long long lo, hi;
+				const uint32_t i = s_used[g][iu], c = s_key[g][i] - 1u;
+				uint32_t m16 = lanes_of(i, lo, hi);
+				s_key[g][i] = 0; s_lc[g][i][0] = 0; s_lc[g][i][1] = 0;
+				(void)any_bad;
 				uint32_t any = 0;
 				while (m16) {
 					const uint32_t z = (uint32_t)__builtin_ctz(m16);
 					m16 &= m16 - 1;
 					const uint32_t refIx = c * 16 + z;
-					if (refIx < tot_refs) { push(li, refIx); any = 1; }
+					if (refIx >= tot_refs) continue;
+					uint32_t which = 0, lb = 0;
+					if (prune) {
+						const uint32_t v = (uint32_t)(((z < 8 ? lo : hi) >> (8 * (z & 7))) & 255u);
+						const uint32_t gain = (v - need) / dper;
+						lb = gain >= budget ? 0u : budget - gain;
+						which = v < cmax_all ? 1u : 0u;
+					}
+					push(which, li | lb << 24, refIx);
+					any = 1;
 				}
 				if (any) { ++my_units; my_cols += clump_len[c]; my_qlen += len; }
 			}
 			for (uint32_t i = gl; i < n_bad; i += 16) {        // burst.c:4136-4138, 4282-4283: every lane of the ambiguous clumps
 				const uint32_t c = bad[i];
-				for (uint32_t z = 0; z < 16; ++z) if (c * 16 + z < tot_refs) push(li, c * 16 + z);
+				for (uint32_t z = 0; z < 16; ++z) if (c * 16 + z < tot_refs) push(0, li, c * 16 + z);
 				++my_units; my_cols += clump_len[c]; my_qlen += len;
 			}
 		} else if (ovf) {
@@ -1189,7 +1232,7 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 		}
 		__syncthreads();
 		if (gl == 0) s_ovf[g] = 0;
-		if (s_nstage >= PFM_STAGE / 2) flush(); else __syncthreads();
+		if (s_nstage[0] >= CF_STAGE / 2 || s_nstage[1] >= CF_STAGE / 2) flush(); else __syncthreads();
 		PFM_T(5);
 	}
 	flush();
@@ -1202,7 +1245,8 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 }
 #define BHIP_INST_PFCF(CB) \
 	template __global__ void k_prefilter_cf<CB>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, \
-		uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *);
+		uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *, \
+		uint2 *, uint32_t *, int);
 BHIP_INST_PFCF(9) BHIP_INST_PFCF(10) BHIP_INST_PFCF(11)
 
 template __global__ void k_prefilter_mask<9>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
@@ -1445,6 +1489,7 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 		uint2 tk = make_uint2(0, 0);
 		if (live) {
 			tk = tasks[i];
+			tk.x &= 0xFFFFFFu;                 // the top byte is the lower bound used by k_task_filter
 			if (LDS_TAB) {
 				const uint32_t *src = peqp + (uint64_t)tk.x * 16 * NWP;
 				#pragma unroll
@@ -1500,6 +1545,40 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 	}
 	if (tcol_sum && my_cols) atomicAdd(tcol_sum, my_cols);
 }
+// Deferred lane tasks (li | bound << 24, refIx): keep those whose lower bound does not exceed the minimum edit distance
+// found so far for their shared slot (equal bounds stay: ties are hits too).  One reservation per wave.
+__global__ __launch_bounds__(256) void k_task_filter(const uint2 *__restrict__ in, const uint32_t *__restrict__ n_in_dev, uint32_t cap,
+		const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ qsix, const uint32_t *__restrict__ best,
+		uint2 *__restrict__ out, uint32_t *__restrict__ n_out) {
+	__shared__ uint32_t s_n, s_base;
+	uint32_t n = *n_in_dev;
+	if (n > cap) n = cap;
+	const uint32_t tid = threadIdx.x;
+	for (uint32_t chunk = blockIdx.x * 2048u; chunk < n; chunk += gridDim.x * 2048u) {      // one global reservation per 2048 tasks
+		if (tid == 0) s_n = 0;
+		__syncthreads();
+		uint2 tk[8]; uint32_t rank[8]; bool keep[8];
+		#pragma unroll
+		for (int t = 0; t < 8; ++t) {
+			const uint32_t i = chunk + (uint32_t)t * 256u + tid;
+			keep[t] = false; rank[t] = 0; tk[t] = make_uint2(0, 0);
+			if (i < n) {
+				tk[t] = in[i];
+				const uint32_t li = tk[t].x & 0xFFFFFFu, q = qlist ? qlist[li] : li;
+				keep[t] = (tk[t].x >> 24) <= best[qsix ? qsix[q] : q];
+			}
+		}
+		#pragma unroll
+		for (int t = 0; t < 8; ++t) if (keep[t]) rank[t] = atomicAdd(&s_n, 1u);
+		__syncthreads();
+		if (tid == 0 && s_n) s_base = atomicAdd(n_out, s_n);
+		__syncthreads();
+		#pragma unroll
+		for (int t = 0; t < 8; ++t) if (keep[t]) out[s_base + rank[t]] = tk[t];
+		__syncthreads();
+	}
+}
+
 #define BHIP_INST_PREFIX_TASK(NWP) \
 	template __global__ void k_myers_prefix_task<NWP>(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *, \
 		const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *);
@@ -1513,6 +1592,11 @@ __global__ __launch_bounds__(256) void k_myers_window(
 		const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
 		BhipRawHit *__restrict__ raw, uint32_t *__restrict__ n_raw, uint32_t raw_cap, uint32_t *__restrict__ best,
 		unsigned long long *__restrict__ wcol_sum) {
+	// NW <= 8: the profile rows of A, C, G, T (all a reference without IUPAC codes ever asks for) sit in a private LDS column
+	// (64-thread blocks, 16 * NW bytes per thread); the other twelve rows stay in global memory.  Read from global memory
+	// alone the tables fight over the 32 KB L1 (the kernel then ran fastest at 2 of 8 possible waves per SIMD).
+	constexpr bool LDS_TAB = NW <= 8;
+	__shared__ uint32_t s_tab[LDS_TAB ? 4 * NW : 1][LDS_TAB ? 64 : 1];
 	uint32_t n = *n_wins_dev;
 	if (n > win_cap) n = win_cap;
 	unsigned long long my_cols = 0;
@@ -1542,6 +1626,10 @@ __global__ __launch_bounds__(256) void k_myers_window(
 		uint32_t first = 0, last = 0;
 		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)z * nchunks;        // lane-major copy
 		const uint32_t *tab = peq + (uint64_t)li * 16 * NW;
+		if (LDS_TAB) {          // rows of the codes 1..4 = dwords NW .. 5 * NW - 1 of the table
+			#pragma unroll
+			for (int r = 0; r < (LDS_TAB ? 4 * NW : 1); ++r) s_tab[LDS_TAB ? r : 0][LDS_TAB ? threadIdx.x : 0] = tab[NW + r];
+		}
 		uint4 ch_next = rp[tA];
 		for (uint32_t t = tA; t <= tB; ++t) {
 			const uint4 ch = ch_next;
@@ -1551,8 +1639,13 @@ __global__ __launch_bounds__(256) void k_myers_window(
 			for (int k = 0; k < 32; ++k) {
 				const uint32_t sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
 				uint32_t Eq[NW];
-				#pragma unroll
-				for (int x = 0; x < NW; ++x) Eq[x] = tab[sym * NW + x];
+				if (LDS_TAB && sym - 1u < 4u) {
+					#pragma unroll
+					for (int x = 0; x < NW; ++x) Eq[x] = s_tab[LDS_TAB ? (sym - 1u) * NW + x : 0][LDS_TAB ? threadIdx.x : 0];
+				} else {
+					#pragma unroll
+					for (int x = 0; x < NW; ++x) Eq[x] = tab[sym * NW + x];
+				}
 				myers_step<NW>(Eq, Pv, Mv, score);
 				const uint32_t col = t * 32 + k + 1;
 				const bool lt = score < bestS, le = score <= bestS;
