@@ -1,7 +1,7 @@
 """BASELINE configs[1] at full size (1 M synthetic 100-bp reads vs the 99 k-reference GG97-like database of bench.py):
 the oracle cannot finish this in reasonable time, so parity is checked through properties that do not depend on size --
 determinism, invariance under every tuning option (the one-stage sweep, the LDS re-scorer and the clump-level prefilter
-are independent implementations of the same result), full sensitivity (every read carries <= 3 edits = its budget, so
+are independent implementations of the same result, and the lower-bound pruning must never drop a minimum), full sensitivity (every read carries <= 3 edits = its budget, so
 every entry must be found with ed <= its number of edits), and the arithmetic identities of a record."""
 import os
 import re
@@ -41,7 +41,8 @@ def test_one_million_reads_properties(tmp_path_factory):
     again, _ = dev.align_staged(False)
     assert again.tobytes() == base.tobytes()
     # invariance under the tuning options (independent code paths)
-    for opts in ({"lanes": 3}, {"prefilter_table": 10, "rescore_reg": 0}, {"lane_masks": 0}, {"two_stage": 0}, {"prefilter_stride": 6}):
+    for opts in ({"lanes": 3}, {"prefilter_table": 10, "rescore_reg": 0}, {"lane_masks": 0}, {"two_stage": 0}, {"prefilter_stride": 6}, {"prune": 0},
+                 {"prefilter_algo": 1}, {"prefilter_algo": 0, "prune": 1}):
         for k, v in opts.items():
             dev.set_option(k, v)
         if "lanes" in opts:
@@ -49,7 +50,7 @@ def test_one_million_reads_properties(tmp_path_factory):
         got, _ = dev.align_staged(False)
         assert got.tobytes() == base.tobytes(), opts
         for k in opts:
-            dev.set_option(k, {"lanes": 1, "prefilter_table": 0, "rescore_reg": 1, "lane_masks": 1, "two_stage": 1, "prefilter_stride": 0}[k])
+            dev.set_option(k, {"lanes": 1, "prefilter_table": 0, "rescore_reg": 1, "lane_masks": 1, "two_stage": 1, "prefilter_stride": 0, "prune": 1, "prefilter_algo": -1}[k])
         if "lanes" in opts:
             dev.stage(q)
     # sensitivity: a read carries at most 3 edits, so every entry whose budget is 3 must be found; the only entries that may
