@@ -182,7 +182,7 @@ struct Handle {
 	int opt_rescore_reg = 1;      // register-band re-scorer for narrow bands (0 = LDS band only)
 	int opt_pf_waves = 0;         // single-wave blocks per CU of the lane-resolved prefilter (0 = as many as the LDS allows, <= 12)
 	int opt_pf_algo = -1;         // 0 = counting filter + exact lane table (k_prefilter_cf), 1 = exact clump hash table in two passes
-	                              // (k_prefilter_mask), -1 = start with 0 and switch a lane to 1 when more than 30 % of its records survive the filter
+	                              // (k_prefilter_mask), -1 = start with 0 and switch a lane to 1 when more than 20 % of its records survive the filter
 	int opt_pf_table = 0;         // log2 of the per-query hash table (0 = from the workload: 9, 10 or 11)
 	double acx_wmean = 0.0;       // occurrence-weighted mean .acx list length
 };
@@ -1002,7 +1002,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		for (uint32_t l = 0; l < nl; ++l) if (h->lanes[l]->n_entries) h->lanes[l]->hc = *h->lanes[l]->hc_pinned;
 		for (uint32_t l = 0; l < nl; ++l) {      // a lane whose records mostly survive the counting filter does better with the exact table
 			Lane *L = h->lanes[l];
-			if (L->n_entries && L->pf_algo == 0 && L->hc.ent_read > 100000 && (double)L->hc.surv_sum > 0.30 * (double)L->hc.ent_read) L->pf_algo = 1;
+			if (L->n_entries && L->pf_algo == 0 && L->hc.ent_read > 100000 && (double)L->hc.surv_sum > 0.20 * (double)L->hc.ent_read) L->pf_algo = 1;
 		}
 		if (getenv("BHIP_DEBUG")) for (uint32_t l = 0; l < nl; ++l) {
 			const Lane *L = h->lanes[l];

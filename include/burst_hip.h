@@ -141,7 +141,7 @@ int bhip_copy_hits_device(void *handle, void *dst_device, uint64_t cap_records, 
  * "sweep_blocks": 1..8 workgroups per CU of the sweep kernels.  "lane_masks": 1 (default) = lane-resolved prefilter.
  * "prefilter_table": 0 (default, chosen from the accelerator's list lengths) or 9/10/11 = log2 slots of the per-query
  * tables; "prefilter_algo": -1 (default) = counting-filter kernel, switching to the exact-hash kernel for workloads where
- * more than 30 % of the list records survive the filter, 0 / 1 = force one of them; "prefilter_waves": 0 (default, as many as fit) .. 16 single-wave prefilter blocks per CU.
+ * more than 20 % of the list records survive the filter, 0 / 1 = force one of them; "prefilter_waves": 0 (default, as many as fit) .. 16 single-wave prefilter blocks per CU.
  * "prune": 1 (default) = when only the minimum per shared slot is wanted, lanes whose seed count bounds their edit distance
  * above the query's best bound are swept only if the first sweep leaves room for them (exact: the bound is a lower bound).
  * "rescore_reg": 1 (default) = register-band re-scorer for narrow bands, 0 = LDS band only.
