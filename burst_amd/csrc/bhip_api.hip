@@ -57,15 +57,31 @@ __global__ void k_rescore_classify(const BhipRawHit *, const uint32_t *, uint32_
 template <int SET> __global__ void k_rescore_reg(const BhipRawHit *, const uint32_t *, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, const uint32_t *, uint32_t,
 	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *);
 
-// ---- ordering of the output records: (q, refIx) ascending, done on the device (radix sort of 64-bit keys) ----
-__global__ void k_hit_keys(const BhipHit *__restrict__ hits, uint32_t n, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx, int rbits) {
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		keys[i] = ((uint64_t)hits[i].q << rbits) | hits[i].refIx;        // only the significant bits of refIx: fewer radix passes
-		idx[i] = i;
-	}
+// ---- ordering of the output records: (q, refIx) ascending, done on the device.  A query has one or two records, rarely
+// more, so a counting sort by query (rank inside the query from the counting atomic, offsets from one exclusive scan)
+// followed by a tiny in-place sort of the few multi-record groups replaces a 7-pass radix sort of 64-bit keys ----
+__global__ void k_hit_count(const BhipHit *__restrict__ hits, uint32_t n, uint32_t *__restrict__ cnt, uint32_t *__restrict__ rank) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) rank[i] = atomicAdd(&cnt[hits[i].q], 1u);
 }
-__global__ void k_hit_gather(const BhipHit *__restrict__ in, const uint32_t *__restrict__ idx, uint32_t n, BhipHit *__restrict__ out) {
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[idx[i]];
+__global__ void k_hit_scatter(const BhipHit *__restrict__ in, uint32_t n, const uint32_t *__restrict__ off, const uint32_t *__restrict__ rank,
+                              BhipHit *__restrict__ out) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const BhipHit h = in[i]; out[off[h.q] + rank[i]] = h; }
+}
+__global__ void k_hit_fix(BhipHit *__restrict__ out, const uint32_t *__restrict__ off, const uint32_t *__restrict__ cnt, uint32_t n_q) {
+	for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_q; q += gridDim.x * blockDim.x) {
+		const uint32_t n = cnt[q];
+		if (n < 2) continue;
+		BhipHit *a = out + off[q];
+		uint32_t gap = 1;
+		while (gap < n / 3) gap = 3 * gap + 1;          // Shell sort (plain insertion sort for the usual 2..4 records)
+		for (; gap >= 1; gap /= 3)
+			for (uint32_t i = gap; i < n; ++i) {
+				const BhipHit v = a[i];
+				uint32_t j = i;
+				for (; j >= gap && a[j - gap].refIx > v.refIx; j -= gap) a[j] = a[j - gap];
+				a[j] = v;
+			}
+	}
 }
 
 static thread_local char g_err[512] = "";
@@ -1082,19 +1098,18 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		HIPCHK(hipEventRecord(h->ev[8], h->stream));
 		if (hsc.n_out) {
 			const uint32_t n = hsc.n_out;
-			if ((rc = h->sort_keys.reserve((size_t)n * 8)) || (rc = h->sort_keys2.reserve((size_t)n * 8)) || (rc = h->sort_idx.reserve((size_t)n * 4)) ||
-			    (rc = h->sort_idx2.reserve((size_t)n * 4)) || (rc = h->out_sorted.reserve((size_t)n * sizeof(BhipHit)))) return rc;
+			if ((rc = h->sort_idx.reserve((size_t)n * 4)) || (rc = h->sort_keys.reserve((size_t)(n_q + 1) * 4)) || (rc = h->sort_keys2.reserve((size_t)(n_q + 1) * 4)) ||
+			    (rc = h->out_sorted.reserve((size_t)n * sizeof(BhipHit)))) return rc;
+			uint32_t *cnt = h->sort_keys.as<uint32_t>(), *off = h->sort_keys2.as<uint32_t>(), *rank = h->sort_idx.as<uint32_t>();
 			const uint32_t g = std::min<uint32_t>((n + 255) / 256, (uint32_t)h->n_cu * 8);
-			int qbits = 32; while (qbits > 1 && !((n_q - 1) >> (qbits - 1))) --qbits;   // significant bits of the query index
-			int rbits = 32; while (rbits > 1 && !(((uint64_t)h->n_clumps * 16 - 1) >> (rbits - 1))) --rbits;   // and of refIx (< 16 * clumps)
-			hipLaunchKernelGGL(k_hit_keys, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, h->sort_keys.as<uint64_t>(), h->sort_idx.as<uint32_t>(), rbits);
+			HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(n_q + 1) * 4, h->stream));
+			hipLaunchKernelGGL(k_hit_count, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, cnt, rank);
 			size_t tmp_bytes = 0;
-			HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, h->sort_keys.as<uint64_t>(), h->sort_keys2.as<uint64_t>(), h->sort_idx.as<uint32_t>(),
-				h->sort_idx2.as<uint32_t>(), (int)n, 0, rbits + qbits, h->stream));
+			HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, off, (int)(n_q + 1), h->stream));
 			if ((rc = h->sort_tmp.reserve(tmp_bytes))) return rc;
-			HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp.p, tmp_bytes, h->sort_keys.as<uint64_t>(), h->sort_keys2.as<uint64_t>(), h->sort_idx.as<uint32_t>(),
-				h->sort_idx2.as<uint32_t>(), (int)n, 0, rbits + qbits, h->stream));
-			hipLaunchKernelGGL(k_hit_gather, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), h->sort_idx2.as<uint32_t>(), n, h->out_sorted.as<BhipHit>());
+			HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->sort_tmp.p, tmp_bytes, cnt, off, (int)(n_q + 1), h->stream));
+			hipLaunchKernelGGL(k_hit_scatter, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, off, rank, h->out_sorted.as<BhipHit>());
+			hipLaunchKernelGGL(k_hit_fix, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, h->stream, h->out_sorted.as<BhipHit>(), off, cnt, n_q);
 			HIPCHK(hipGetLastError());
 			if (hits) HIPCHK(hipMemcpyAsync(hits, h->out_sorted.p, (size_t)n * sizeof(BhipHit), hipMemcpyDeviceToHost, h->stream));
 			h->last_n_out = n;
