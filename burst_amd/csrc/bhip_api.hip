@@ -847,7 +847,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	if ((rc = L->cand.reserve(L->cand_cap * sizeof(uint2)))) return rc;
 	if ((rc = L->raw.reserve(L->raw_cap * sizeof(BhipRawHit)))) return rc;
 	if ((rc = L->wide.reserve(L->raw_cap * sizeof(uint32_t)))) return rc;
-	if ((rc = L->rs_lists.reserve(L->raw_cap * sizeof(uint32_t) * 9))) return rc;
+	if ((rc = L->rs_lists.reserve(L->raw_cap * sizeof(uint32_t) * 10))) return rc;
 	if ((rc = L->scratch.reserve(L->scratch_cap * sizeof(uint32_t)))) return rc;
 	if ((rc = L->wins.reserve(L->win_cap * sizeof(BhipWin)))) return rc;
 	if ((rc = L->tasks.reserve(L->task_cap * sizeof(uint2)))) return rc;
@@ -961,7 +961,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		band_rows, h->opt_rescore_reg);
 	HIPCHK(hipGetLastError());
 	if (h->opt_rescore_reg) {
-#define RS_LAUNCH(SET, BLOCKS) hipLaunchKernelGGL(k_rescore_reg<SET>, dim3((uint32_t)h->n_cu * BLOCKS), dim3(64), 0, po, L->raw.as<BhipRawHit>(), L->rs_lists.as<uint32_t>(), dc->n_rs, (uint32_t)L->raw_cap, \
+#define RS_LAUNCH(SET, BLOCKS) hipLaunchKernelGGL(k_rescore_reg<SET>, dim3((uint32_t)h->n_cu * std::min<uint32_t>(32u, blocks_per_cu((const void *)k_rescore_reg<SET>, 64, 0))), dim3(64), 0, po, L->raw.as<BhipRawHit>(), L->rs_lists.as<uint32_t>(), dc->n_rs, (uint32_t)L->raw_cap, \
 			h->qoff.as<uint64_t>(), h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr, h->qpack.as<uint32_t>(), qw_g, \
 			h->ref_lane.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, &sc->err)
 		RS_LAUNCH(0, 16);
@@ -975,7 +975,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	const uint32_t grid_rs = (uint32_t)h->n_cu * (h->opt_rescore_reg ? 4 : 16);
 	const size_t lds_rs = (size_t)(band_rows + 1 + qw + rw) * 256;
 	hipLaunchKernelGGL(k_rescore<false>, dim3(grid_rs), dim3(64), lds_rs, po, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap,
-		L->rs_lists.as<uint32_t>() + (size_t)8 * L->raw_cap, &dc->n_rs[8], h->best.as<uint32_t>(), all_hits, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
+		L->rs_lists.as<uint32_t>() + (size_t)9 * L->raw_cap, &dc->n_rs[9], h->best.as<uint32_t>(), all_hits, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
 		h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr, h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(),
 		h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, L->wide.as<uint32_t>(),
 		&dc->n_wide, (uint32_t *)nullptr, &dc->scratch_used, 0ull, &sc->err, qw ? h->qpack.as<uint32_t>() : nullptr, band_rows, qw, rw);

@@ -1886,7 +1886,7 @@ __global__ __launch_bounds__(64) void k_rescore(
 // a wave busy with hits of similar width.  Bands beyond the widest register variant go to k_rescore (LDS band) and
 // beyond that to its global-scratch variant.
 // ------------------------------------------------------------------------------------------------
-// index lists: 0..7 register variants (6, 8, 12, 16, 24, 32, 40, 48 diagonals), 8 LDS band; 9 = global scratch (`wide`), 10 = exact match (emitted)
+// index lists: 0..8 register variants (4, 6, 8, 12, 16, 24, 32, 40, 48 diagonals), 9 LDS band; 10 = global scratch (`wide`), 11 = exact match (emitted)
 __global__ __launch_bounds__(256) void k_rescore_classify(
 		const BhipRawHit *__restrict__ raw, const uint32_t *__restrict__ n_raw_dev, uint32_t raw_cap,
 		const uint32_t *__restrict__ best, int all_hits, const uint64_t *__restrict__ qoff,
@@ -1914,11 +1914,11 @@ __global__ __launch_bounds__(256) void k_rescore_classify(
 					const uint32_t L = clump_len[h.refIx >> 4];
 					const uint32_t e2 = h.e_last < L ? h.e_last : L;
 					qv[t] = h.q; rv[t] = h.refIx; e2v[t] = e2;
-					if (h.ed == 0) { bucket[t] = 10; mv[t] = (uint32_t)(qoff[h.q + 1] - qoff[h.q]); }     // exact match
+					if (h.ed == 0) { bucket[t] = 11; mv[t] = (uint32_t)(qoff[h.q + 1] - qoff[h.q]); }     // exact match
 					else {
 						const uint32_t Wd = e2 - h.e_first + 2 * h.ed + 1;
-						int bk = !use_reg || h.ed > 254u ? 8 : Wd <= 6 ? 0 : Wd <= 8 ? 1 : Wd <= 12 ? 2 : Wd <= 16 ? 3 : Wd <= 24 ? 4 : Wd <= 32 ? 5 : Wd <= 40 ? 6 : Wd <= 48 ? 7 : 8;
-						if (Wd > band_rows && bk == 8) bk = 9;
+						int bk = !use_reg || h.ed > 254u ? 9 : Wd <= 4 ? 0 : Wd <= 6 ? 1 : Wd <= 8 ? 2 : Wd <= 12 ? 3 : Wd <= 16 ? 4 : Wd <= 24 ? 5 : Wd <= 32 ? 6 : Wd <= 40 ? 7 : Wd <= 48 ? 8 : 9;
+						if (Wd > band_rows && bk == 9) bk = 10;
 						bucket[t] = bk;
 					}
 					rank[t] = atomicAdd(&s_cnt[bucket[t]], 1u);
@@ -1926,7 +1926,7 @@ __global__ __launch_bounds__(256) void k_rescore_classify(
 			}
 		}
 		__syncthreads();
-		if (tid < 11 && s_cnt[tid]) s_base[tid] = atomicAdd(tid == 10 ? n_out : tid == 9 ? n_wide : &counts[tid], s_cnt[tid]);
+		if (tid < 12 && s_cnt[tid]) s_base[tid] = atomicAdd(tid == 11 ? n_out : tid == 10 ? n_wide : &counts[tid], s_cnt[tid]);
 		__syncthreads();
 		#pragma unroll
 		for (int t = 0; t < 4; ++t) {
@@ -1934,13 +1934,13 @@ __global__ __launch_bounds__(256) void k_rescore_classify(
 			const int bk = bucket[t];
 			if (bk < 0) continue;
 			const uint32_t pos = s_base[bk] + rank[t];
-			if (bk == 10) {   // gap-free, end = LAST column with score 0 (burst.c:862-879), identity 1 - 0/len
+			if (bk == 11) {   // gap-free, end = LAST column with score 0 (burst.c:862-879), identity 1 - 0/len
 				if (pos < out_cap) {
 					BhipHit o; o.q = qv[t]; o.refIx = rv[t]; o.finalPos = e2v[t]; o.score = 1.0f - 0.0f / (float)mv[t];
 					o.ed = 0; o.gapR = 0; o.gapQ = 0; o.rc = qrc ? qrc[qv[t]] : 0;
 					out[pos] = o;
 				}
-			} else if (bk == 9) wide[pos] = i;
+			} else if (bk == 10) wide[pos] = i;
 			else lists[(size_t)bk * raw_cap + pos] = i;
 		}
 		__syncthreads();
@@ -2074,7 +2074,7 @@ __device__ __forceinline__ void rescore_reg_one(
 	}
 }
 
-template <int SET>       // 0: bands of 6 / 8 / 12 diagonals, 1: 16 / 24, 2: 32 / 40 / 48 (separate kernels: the register budget of the wide ones would halve the occupancy of the narrow ones)
+template <int SET>       // 0: bands of 4 / 6 / 8 / 12 diagonals, 1: 16 / 24, 2: 32 / 40 / 48 (separate kernels: the register budget of the wide ones would halve the occupancy of the narrow ones)
 __global__ __launch_bounds__(64) void k_rescore_reg(
 		const BhipRawHit *__restrict__ raw, const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint32_t raw_cap,
 		const uint64_t *__restrict__ qoff, const uint8_t *__restrict__ qrc, const uint32_t *__restrict__ qpack, uint32_t qw,
@@ -2094,9 +2094,9 @@ __global__ __launch_bounds__(64) void k_rescore_reg(
 			const bool live = i < n; \
 			rescore_reg_one<WB>(raw + (live ? lst[i] : 0u), live, s_mm, tid, qoff, qrc, qpack, qw, refw, ref_off, clump_len, out, n_out, out_cap, err_flags); \
 		} }
-	if (SET == 0) { BHIP_RS_RUN(0, 6) BHIP_RS_RUN(1, 8) BHIP_RS_RUN(2, 12) }
-	else if (SET == 1) { BHIP_RS_RUN(3, 16) BHIP_RS_RUN(4, 24) }
-	else { BHIP_RS_RUN(5, 32) BHIP_RS_RUN(6, 40) BHIP_RS_RUN(7, 48) }
+	if (SET == 0) { BHIP_RS_RUN(0, 4) BHIP_RS_RUN(1, 6) BHIP_RS_RUN(2, 8) BHIP_RS_RUN(3, 12) }
+	else if (SET == 1) { BHIP_RS_RUN(4, 16) BHIP_RS_RUN(5, 24) }
+	else { BHIP_RS_RUN(6, 32) BHIP_RS_RUN(7, 40) BHIP_RS_RUN(8, 48) }
 #undef BHIP_RS_RUN
 }
 template __global__ void k_rescore_reg<0>(const BhipRawHit *, const uint32_t *, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, const uint32_t *, uint32_t,
