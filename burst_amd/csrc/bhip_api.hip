@@ -633,7 +633,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	int rc;
 	if ((rc = L->fb_list.reserve((size_t)n_list * 4 + 16))) return rc;
 	HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 4, st));
-	const uint32_t W16 = std::max<uint32_t>(16u, (maxwords + 15u) & ~15u);
+	const uint32_t W16 = maxwords <= 8 ? 8u : std::max<uint32_t>(16u, (maxwords + 15u) & ~15u);   // words per query in the range table (8 when no query samples more)
 	if ((rc = L->ranges.reserve((size_t)n_list * W16 * 8 + 16))) return rc;
 	if ((rc = L->hdr.reserve((size_t)n_list * 8 + 16))) return rc;
 	const uint64_t n_thr = (uint64_t)n_list * W16;

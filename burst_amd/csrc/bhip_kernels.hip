@@ -741,7 +741,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 	// (need, words, length) and the first 16 list ranges of the next quad are fetched one iteration ahead (k_seed_ranges
 	// produced them), so the only exposed memory round trip per quad is the list records themselves
 	uint2 hd_n = make_uint2(0, 0), rg_n = make_uint2(0, 0);
-	if (blockIdx.x * 4 + g < n_list) { hd_n = hdr[blockIdx.x * 4 + g]; rg_n = ranges[(size_t)(blockIdx.x * 4 + g) * W16 + gl]; }
+	if (blockIdx.x * 4 + g < n_list) { hd_n = hdr[blockIdx.x * 4 + g]; if (gl < W16) rg_n = ranges[(size_t)(blockIdx.x * 4 + g) * W16 + gl]; }
 	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
 		const uint32_t li = quad * 4 + g;
 		const bool live = li < n_list;
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 		{
 			const uint32_t li_n = (quad + gridDim.x) * 4 + g;
 			hd_n = make_uint2(0, 0); rg_n = make_uint2(0, 0);
-			if (quad + gridDim.x < n_quads && li_n < n_list) { hd_n = hdr[li_n]; rg_n = ranges[(size_t)li_n * W16 + gl]; }
+			if (quad + gridDim.x < n_quads && li_n < n_list) { hd_n = hdr[li_n]; if (gl < W16) rg_n = ranges[(size_t)li_n * W16 + gl]; }
 		}
 		const uint32_t need = hd.x & 0xFFFFu, nwords = live ? hd.x >> 16 : 0u, len = hd.y & 0xFFFu;
 		uint32_t maxw = nwords;
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 
 	const uint32_t n_quads = (n_list + 3) >> 2;
 	uint2 hd_n = make_uint2(0, 0), rg_n = make_uint2(0, 0);
-	if (blockIdx.x * 4 + g < n_list) { hd_n = hdr[blockIdx.x * 4 + g]; rg_n = ranges[(size_t)(blockIdx.x * 4 + g) * W16 + gl]; }
+	if (blockIdx.x * 4 + g < n_list) { hd_n = hdr[blockIdx.x * 4 + g]; if (gl < W16) rg_n = ranges[(size_t)(blockIdx.x * 4 + g) * W16 + gl]; }
 	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
 		const uint32_t li = quad * 4 + g;
 		const bool live = li < n_list;
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 		{
 			const uint32_t li_n = (quad + gridDim.x) * 4 + g;
 			hd_n = make_uint2(0, 0); rg_n = make_uint2(0, 0);
-			if (quad + gridDim.x < n_quads && li_n < n_list) { hd_n = hdr[li_n]; rg_n = ranges[(size_t)li_n * W16 + gl]; }
+			if (quad + gridDim.x < n_quads && li_n < n_list) { hd_n = hdr[li_n]; if (gl < W16) rg_n = ranges[(size_t)li_n * W16 + gl]; }
 		}
 		const uint32_t need = hd.x & 0xFFFFu, nwords = live ? hd.x >> 16 : 0u, len = hd.y & 0xFFFu;
 		const uint32_t budget = (hd.y >> 12) & 255u, dper = (hd.y >> 20) & 15u ? (hd.y >> 20) & 15u : 1u;
