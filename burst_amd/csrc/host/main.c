@@ -129,6 +129,8 @@ int main(int argc, char **argv) {
 	}
 	if (!query_FN) { puts("ERROR: --queries is required when aligning"); return 1; }
 	BhDb db; memset(&db, 0, sizeof db);
+	double tp = wall();
+	#define PHASE(name) do { const double t_ = wall(); printf(" [%-28s %8.3f s]\n", name, t_ - tp); tp = t_; } while (0)
 	int usedb = bh_is_edx(ref_FN);
 	if (usedb < 0) DIE(usedb);
 	if (usedb) {
@@ -143,10 +145,12 @@ int main(int argc, char **argv) {
 		if ((rc = bh_acx_read(xcel_FN, K, z, &db))) DIE(rc);
 		printf(" --> [Accel] K=%d, %s format, %u ambiguous clumps\n", K, db.acxFmt ? "LARGE" : "SMALL", db.badSz);
 	}
+	PHASE("database read");
 	BhQueries Q;
 	if ((rc = bh_queries_load(query_FN, thres, do_rc, incl_ws, do_accel, K ? K : 12, z, skip_ambig, &Q))) DIE(rc);
 	printf("Parsed %lu queries, %lu unique [min %u, max %u, maxED %u]; clear %lu, ambiguous %lu, bad %lu\n", (unsigned long)Q.totQ,
 	       (unsigned long)Q.numUniq, Q.minLen, Q.maxLen, Q.maxED, (unsigned long)Q.nClear, (unsigned long)Q.nAmbig, (unsigned long)Q.nBad);
+	PHASE("queries parsed, sorted");
 	if (!usedb) {
 		if ((rc = bh_db_from_fasta(ref_FN, Q.maxLen, thres, do_shear, shear_amt, dedupe, &db))) DIE(rc);
 		printf("There are %u references and hence %u clumps\n", db.totR, db.numRclumps);
@@ -156,17 +160,20 @@ int main(int argc, char **argv) {
 	void *hh = NULL;
 	if ((rc = bh_device_open(&db, device, z, &hh))) { fprintf(stderr, "%s\n", bh_last_error()); return 4; }
 	{ char nm[256]; int ncu = 0; uint64_t hbm = 0; if (!bhip_device_info(hh, nm, sizeof nm, &ncu, &hbm)) printf("Device %d: %s, %d CUs, %.0f GiB\n", device, nm, ncu, hbm / 1073741824.0); }
+	PHASE("device database upload");
 	BhRun run;
 	const double t0 = wall();
 	if ((rc = bh_align(hh, &Q, 0, Q.numUniq, mode, batch, &run))) { fprintf(stderr, "%s\n", bh_last_error()); return 4; }
 	const double t1 = wall();
 	printf("Search complete [%f s, %u batches, %lu candidate (query, clump) pairs, %lu hits]. Consolidating results...\n", t1 - t0, run.nBatches,
 	       (unsigned long)run.total.n_pairs, (unsigned long)run.nHits);
+	PHASE("search (all batches)");
 	uint64_t lines = 0;
 	setvbuf(output, NULL, _IOFBF, 1 << 22);
 	if ((rc = bh_report_ex(output, &db, &Q, run.hits, run.nHits, mode, (do_accel ? 0 : BH_REP_MERGED_LIST) | rep_flags, &lines))) DIE(rc);
 	fclose(output);
 	printf("Wrote %lu alignments\n", (unsigned long)lines);
+	PHASE("consolidation, output");
 	bhip_destroy(hh); bh_run_free(&run); bh_queries_free(&Q); bh_db_free(&db);
 	printf("\nAlignment time: %f seconds\n", wall() - start);
 	return 0;
