@@ -24,12 +24,27 @@ static inline void coords(const BhDb *db, const BhipHit *rp, uint32_t rix, uint3
 	if (rp->rc) { *st = b; *ed = a; } else { *st = a; *ed = b; }
 }
 
-static void print_line(FILE *out, const char *qh, const char *rh, const BhipHit *rp, uint32_t qlen, uint32_t st, uint32_t ed, uint64_t col12) {
+static void print_line_tax(FILE *out, const char *qh, const char *rh, const BhipHit *rp, uint32_t qlen, uint32_t st, uint32_t ed, uint64_t col12,
+                           int with_tax, const char *taxon) {
 	uint32_t numGap = (uint32_t)rp->gapR + rp->gapQ, numMis = rp->ed - numGap, alLen = qlen + numGap;
 	float pct = rp->score * 100;                                                           /* f32 product, then %f (burst.c:4555) */
-	fprintf(out, "%s\t%s\t%f\t%u\t%u\t%u\t%u\t%u\t%d\t%u\t%u\t%lu\n", qh, rh, pct, alLen, numMis, numGap, 1, qlen, (int)st, ed,
-	        (unsigned)rp->ed, (unsigned long)col12);
+	if (!with_tax)
+		fprintf(out, "%s\t%s\t%f\t%u\t%u\t%u\t%u\t%u\t%d\t%u\t%u\t%lu\n", qh, rh, pct, alLen, numMis, numGap, 1, qlen, (int)st, ed,
+		        (unsigned)rp->ed, (unsigned long)col12);
+	else                                                                                   /* PRINT_MATCH_TAX, burst.c:4558-4562 */
+		fprintf(out, "%s\t%s\t%f\t%u\t%u\t%u\t%u\t%u\t%d\t%u\t%u\t%lu\t%s\n", qh, rh, pct, alLen, numMis, numGap, 1, qlen, (int)st, ed,
+		        (unsigned)rp->ed, (unsigned long)col12, taxon ? taxon : "(null)");
 }
+static void print_line(FILE *out, const char *qh, const char *rh, const BhipHit *rp, uint32_t qlen, uint32_t st, uint32_t ed, uint64_t col12) {
+	print_line_tax(out, qh, rh, rp, qlen, st, ed, col12, 0, NULL);
+}
+
+/* identity a placement needs to keep taxonomic level lm + 1 (TAXLEVELS, burst.c:264-266).  The reference scans the table
+ * without a bound; for identities above its last entry the scan runs into whatever follows it in memory (the LENIENT table
+ * after the STRICT one, then a pointer).  The sentinel reproduces where that scan stops for every identity <= 1. */
+static const float LEVELS_STRICT[] = {.65f, .75f, .78f, .82f, .86f, .94f, .98f, .995f, .55f, .70f, .75f, .80f, .84f, .93f, .97f, .985f, 3.0e38f};
+static const float LEVELS_LENIENT[] = {.55f, .70f, .75f, .80f, .84f, .93f, .97f, .985f, 3.0e38f};
+static int cmp_str(const void *a, const void *b) { return strcmp(*(char *const *)a, *(char *const *)b); }
 
 /* DUPE_HUNT (burst.c:4563-4570): reject a (hit, rix) whose original reference and start lie within qlen/2 of an
  * accepted one.  wide = 1 reproduces the 64-bit ql2 of the ALLPATHS/FORAGE blocks, 0 the 32-bit one of CAPITALIST. */
@@ -56,18 +71,30 @@ static int rc_sorts_later(const BhQueries *Q, uint64_t i) {
 }
 
 int bh_report_ex(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *hits, uint64_t nHits, BhMode mode, int flags, uint64_t *nLines) {
+	return bh_report_tax(out, db, Q, hits, nHits, mode, flags, NULL, nLines);
+}
+
+int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *hits, uint64_t nHits, BhMode mode, int flags, const BhTaxOpts *tx,
+                  uint64_t *nLines) {
 	const uint64_t nU = Q->numUniq, nE = Q->numEntries;
+	const BhTax *T = tx ? tx->tax : NULL;
+	const int wt = T != NULL, ncbi = tx ? tx->ncbi : 0, suppress = tx ? tx->suppress : 0;
+	const uint32_t taxacut = tx && tx->taxacut >= 2 ? tx->taxacut : 10;
+	const float *LEVELS = tx && tx->strict ? LEVELS_STRICT : LEVELS_LENIENT;
+	char *Taxon = wt ? calloc(1, 1000000) : NULL;          /* scratch of the interpolated / suppressed string (burst.c:4741, 4852) */
+	const char *FinalTaxon = NULL;                           /* BEST keeps the last value when a taxonomy is empty (burst.c:4852-4885) */
+	const char **Taxa = NULL; uint32_t *Divergence = NULL;
 	const int merged = flags & BH_REP_MERGED_LIST, nodupe = flags & BH_REP_NO_DUPE_HUNT;
 	uint64_t lines = 0;
 	g_nodupe = nodupe;
 	/* per-entry ranges (records of one entry are contiguous) */
 	uint64_t *start = calloc(nE + 1, sizeof(*start)); uint32_t *count = calloc(nE + 1, sizeof(*count));
-	if (!start || !count) { free(start); free(count); return bh_set_error(BH_E_OOM, "OOM:report"); }
+	if (!start || !count) { free(start); free(count); free(Taxon); return bh_set_error(BH_E_OOM, "OOM:report"); }
 	for (uint64_t k = 0; k < nHits; ++k) {
 		const uint32_t e = hits[k].q;
-		if (e >= nE) { free(start); free(count); return bh_set_error(BH_E_INTERNAL, "hit refers to entry %u of %lu", e, (unsigned long)nE); }
+		if (e >= nE) { free(start); free(count); free(Taxon); return bh_set_error(BH_E_INTERNAL, "hit refers to entry %u of %lu", e, (unsigned long)nE); }
 		if (!count[e]) start[e] = k;
-		else if (start[e] + count[e] != k) { free(start); free(count); return bh_set_error(BH_E_INTERNAL, "hit records of entry %u are not contiguous", e); }
+		else if (start[e] + count[e] != k) { free(start); free(count); free(Taxon); return bh_set_error(BH_E_INTERNAL, "hit records of entry %u are not contiguous", e); }
 		++count[e];
 	}
 	uint32_t maxIX = 0;
@@ -83,14 +110,16 @@ int bh_report_ex(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *h
 	uint32_t *RefCache = malloc(capX * 4 + 4), *StCache = malloc(capX * 4 + 4), *RIXcache = malloc(capX * 4 + 4);
 	const BhipHit **RPcache = malloc((capX + 1) * sizeof(*RPcache));
 	size_t *RefCounts = mode == BH_CAPITALIST ? calloc(numBins + 1, sizeof(*RefCounts)) : NULL;
+	if (wt && mode == BH_CAPITALIST) { Taxa = malloc((capX + 1) * sizeof(*Taxa)); Divergence = calloc(capX + 1, sizeof(*Divergence)); }
 	uint32_t maxList = 0;
 	for (uint64_t i = 0; i < nU; ++i) {
 		uint32_t n = count[i] + (nE > nU ? count[nU + i] : 0);
 		if (n > maxList) maxList = n;
 	}
 	const BhipHit **list = malloc(((size_t)maxList + 1) * sizeof(*list));
-	if (!RefCache || !StCache || !RIXcache || !RPcache || !list || (mode == BH_CAPITALIST && !RefCounts)) {
-		free(start); free(count); free(RefCache); free(StCache); free(RIXcache); free(RPcache); free(RefCounts); free(list);
+	if (!RefCache || !StCache || !RIXcache || !RPcache || !list || (mode == BH_CAPITALIST && !RefCounts) || (wt && !Taxon) ||
+	    (wt && mode == BH_CAPITALIST && (!Taxa || !Divergence))) {
+		free(start); free(count); free(RefCache); free(StCache); free(RIXcache); free(RPcache); free(RefCounts); free(list); free(Taxon); free(Taxa); free(Divergence);
 		return bh_set_error(BH_E_OOM, "OOM:report");
 	}
 	#define MAPPED(rix) (db->identityMap ? (rix) : db->refMap[rix])
@@ -147,7 +176,20 @@ int bh_report_ex(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *h
 			}
 			const uint32_t rix = db->refIxSrt[best->refIx];
 			uint32_t st, ed; coords(db, best, rix, qlen, &st, &ed);
-			for (uint64_t j = Q->offset[i]; j < Q->offset[i + 1]; ++j) { print_line(out, Q->heads[j], db->refHead[rix], best, qlen, st, ed, i); ++lines; }
+			if (wt) {                                                              /* burst.c:4872-4887 */
+				const char *tt = bh_tax_lookup(T, db->refHead[rix], ncbi);
+				if (suppress) {
+					uint32_t lm = 0, sc = 0;
+					strcpy(Taxon, tt);
+					while (LEVELS[lm] < best->score) ++lm;
+					if (!lm) FinalTaxon = "";
+					else for (int x = 0; Taxon[x]; ++x) {
+						if (Taxon[x] == ';' && ++sc == lm) { Taxon[x] = 0; break; }
+						FinalTaxon = Taxon;          /* only reached when the string has a character before the cut: an empty taxonomy keeps the previous query's */
+					}
+				} else FinalTaxon = tt;
+			}
+			for (uint64_t j = Q->offset[i]; j < Q->offset[i + 1]; ++j) { print_line_tax(out, Q->heads[j], db->refHead[rix], best, qlen, st, ed, i, wt, FinalTaxon); ++lines; }
 		} else if (mode == BH_ANY) {                                         /* any valid hit; column 12 = duplicate flag (burst.c:4268-4272) */
 			const BhipHit *rp = list[0];
 			const uint32_t rix = db->refIxSrt[rp->refIx];
@@ -171,13 +213,14 @@ int bh_report_ex(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *h
 			for (uint64_t j = Q->offset[i]; j < Q->offset[i + 1]; ++j) for (uint64_t zz = 0; zz < rix_ix; ++zz) {
 				const BhipHit *rp = RPcache[zz]; const uint32_t rix = RIXcache[zz];
 				uint32_t st, ed; coords(db, rp, rix, qlen, &st, &ed);
-				print_line(out, Q->heads[j], db->refHead[rix], rp, qlen, st, ed, i); ++lines;
+				print_line_tax(out, Q->heads[j], db->refHead[rix], rp, qlen, st, ed, i, wt, wt ? bh_tax_lookup(T, db->refHead[rix], ncbi) : NULL); ++lines;   /* burst.c:4631-4633, 4685-4687 */
 			}
 		} else {                                                             /* CAPITALIST pass B (burst.c:4746-4779, 4831-4843) */
 			uint32_t b = 0;
 			for (uint32_t k = 1; k < n; ++k) if (list[k]->ed < list[b]->ed) b = k;
 			const BhipHit *best = list[b]; uint32_t bestmap = 0, bestrix = 0; int have = 0;
 			uint64_t ddix = 0;
+			uint32_t tix = 0; float best_score = -1.f;
 			const BhipHit *first = list[b];
 			for (uint32_t k = b; k < n; ++k) {
 				const BhipHit *rp = list[k];
@@ -186,6 +229,7 @@ int bh_report_ex(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *h
 					uint32_t st, ed; coords(db, rp, rix, qlen, &st, &ed); (void)ed;
 					uint32_t mapped = MAPPED(rix);
 					if (!dupe_hunt(RefCache, StCache, &ddix, mapped, st, ql2, 0)) {
+						if (wt) { Taxa[tix++] = bh_tax_lookup(T, db->refHead[rix], ncbi); best_score = rp->score > best_score ? rp->score : best_score; }   /* burst.c:4760-4762 */
 						if (best == rp || RefCounts[mapped] > RefCounts[bestmap] || (RefCounts[mapped] == RefCounts[bestmap] && mapped < bestmap)) {
 							best = rp; bestmap = mapped; bestrix = rix; have = 1;
 						}
@@ -194,11 +238,53 @@ int bh_report_ex(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *h
 			}
 			(void)first;
 			if (!have) continue;   /* cannot happen: the first expansion of the first pod is always accepted */
+			const char *Final = NULL;
+			if (wt) {              /* taxonomy interpolation over the accepted placements (burst.c:4781-4829) */
+				uint32_t lv = UINT32_MAX;
+				if (tix == 1) { strcpy(Taxon, Taxa[0]); Final = Taxon; }
+				else {
+					qsort(Taxa, tix, sizeof(*Taxa), cmp_str);
+					uint32_t maxDiv = 0;
+					for (uint32_t zq = 1; zq < tix; ++zq) {   /* shared leading levels of neighbours (+1 when the previous one is a prefix) */
+						uint32_t x = 0, dv = 0;
+						for (; Taxa[zq - 1][x] && Taxa[zq - 1][x] == Taxa[zq][x]; ++x) dv += Taxa[zq][x] == ';';
+						dv += !Taxa[zq - 1][x];
+						Divergence[zq] = dv;
+						if (dv > maxDiv) maxDiv = dv;
+					}
+					if (!maxDiv) { Taxon[0] = 0; Final = Taxon; }
+					else {
+						uint32_t cutoff = tix - tix / taxacut, s0 = 0, e0 = tix;   /* deepest level on which all but 1/taxacut agree */
+						for (lv = 1; lv <= maxDiv; ++lv) {
+							uint32_t accum = 1;
+							for (uint32_t zq = s0 + 1; zq < e0; ++zq) {
+								if (Divergence[zq] >= lv) ++accum;
+								else if (accum >= cutoff) { e0 = zq; break; }
+								else { accum = 1; s0 = zq; }
+							}
+							if (accum < cutoff) break;
+							cutoff = accum - accum / taxacut;
+						}
+						uint32_t sc = 0, x = 0;
+						if (e0) --e0;
+						--lv;
+						for (; Taxa[e0][x] && (sc += Taxa[e0][x] == ';') < lv; ++x) Taxon[x] = Taxa[e0][x];
+						Taxon[x] = 0;
+						Final = Taxon;
+					}
+				}
+				if (suppress) {                                                  /* burst.c:4820-4828 */
+					uint32_t lm = 0, sc = 0;
+					while (lm < lv && LEVELS[lm] < best_score) ++lm;
+					if (!lm) Final = "";
+					else if (lm < lv) for (int x = 0; Taxon[x]; ++x) if (Taxon[x] == ';' && ++sc == lm) { Taxon[x] = 0; break; }
+				}
+			}
 			uint32_t st, ed; coords(db, best, bestrix, qlen, &st, &ed);
-			for (uint64_t j = Q->offset[i]; j < Q->offset[i + 1]; ++j) { print_line(out, Q->heads[j], db->refHead[bestrix], best, qlen, st, ed, i); ++lines; }
+			for (uint64_t j = Q->offset[i]; j < Q->offset[i + 1]; ++j) { print_line_tax(out, Q->heads[j], db->refHead[bestrix], best, qlen, st, ed, i, wt, Final); ++lines; }
 		}
 	}
-	free(start); free(count); free(RefCache); free(StCache); free(RIXcache); free(RPcache); free(RefCounts); free(list);
+	free(start); free(count); free(RefCache); free(StCache); free(RIXcache); free(RPcache); free(RefCounts); free(list); free(Taxon); free(Taxa); free(Divergence);
 	if (nLines) *nLines = lines;
 	return BH_OK;
 }

@@ -111,6 +111,20 @@ int  bh_report(FILE *out, const BhDb *db, const BhQueries *q, const BhipHit *hit
 #define BH_REP_NO_DUPE_HUNT 2
 int  bh_report_ex(FILE *out, const BhDb *db, const BhQueries *q, const BhipHit *hits, uint64_t nHits, BhMode mode, int flags, uint64_t *nLines);
 
+/* ---- taxonomy (column 13; parse_taxonomy burst.c:447-479, taxa_lookup 409-440, CAPITALIST interpolation 4781-4829, -bs 4820-4828) ---- */
+typedef struct { uint64_t n; char **pair; char *blob; } BhTax;        /* pair[2i] = header, pair[2i+1] = taxonomy, sorted by header */
+typedef struct {
+	const BhTax *tax;     /* NULL = no taxonomy column */
+	int suppress;         /* -bs: cut the taxonomy at the level the identity supports */
+	int strict;           /* -bs STRICT */
+	uint32_t taxacut;     /* -bc (default 10): 1/taxacut of the placements may disagree at a level (CAPITALIST) */
+	int ncbi;             /* -bn: headers are '>xxx|accession.version...' */
+} BhTaxOpts;
+int  bh_tax_load(const char *file, BhTax *T);
+void bh_tax_free(BhTax *T);
+const char *bh_tax_lookup(const BhTax *T, const char *ref_header, int ncbi);
+int  bh_report_tax(FILE *out, const BhDb *db, const BhQueries *q, const BhipHit *hits, uint64_t nHits, BhMode mode, int flags, const BhTaxOpts *tx, uint64_t *nLines);
+
 const char *bh_last_error(void);
 int bh_set_error(int code, const char *fmt, ...);
 

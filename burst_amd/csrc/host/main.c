@@ -4,7 +4,7 @@
  *   burst_hip -r refs.fa -q reads.fa -o out.b6 [-s [len]]            direct FASTA (exhaustive, no accelerator)
  *   burst_hip -r refs.fa -d [QUICK|DNA|RNA] [qLen] -o DB.edx [-a DB.acx] [-s [len]] -i 0.97      database construction
  *
- * Flags not on the hot path (-b taxonomy, -f fingerprints, -p prepass, -x alphabet, -hr) are refused with the
+ * Flags not on the hot path (-f fingerprints, -p prepass, -x alphabet, -hr) are refused with the
  * reference's exit code 1.  Extra flags: --device N, --batch N (unique queries per device call), -k {12|15}.
  */
 #include "burst_host.h"
@@ -27,6 +27,7 @@ static void usage(void) {
 	puts("--output (-o) <name>: Blast6/edx file for output alignments/database [required]");
 	puts("--forwardreverse (-fr), --whitespace (-w), --nwildcard (-y), --mode (-m) BEST|ALLPATHS|CAPITALIST|FORAGE|ANY");
 	puts("--makedb (-d) [name qLen], --id (-i) <decimal>, --threads (-t) <int>, --shear (-s) [len], --noprogress");
+	puts("--taxonomy (-b) <name>, --taxacut (-bc) <num>, --taxa_ncbi (-bn), --taxasuppress (-bs) [STRICT]: taxonomy column (interpolated in CAPITALIST)");
 	puts("--device <int>, --batch <int>, -k <12|15>, --make-acx <name> (with -r DB.edx: rebuild the accelerator of a database)");
 }
 
@@ -36,7 +37,9 @@ int main(int argc, char **argv) {
 	int z = 1, do_rc = 0, incl_ws = 0, makedb = 0, do_shear = 0, do_accel = 0, dedupe = 0, device = 0, K = 0, skip_ambig = 0, threads = 0, rep_flags = 0;
 	long shear_amt = 500, db_qlen = 500;            /* burst.c:94 */
 	uint64_t batch = 1u << 18;
-	const char *ref_FN = 0, *query_FN = 0, *output_FN = 0, *xcel_FN = 0, *mkacx_FN = 0;
+	const char *ref_FN = 0, *query_FN = 0, *output_FN = 0, *xcel_FN = 0, *mkacx_FN = 0, *tax_FN = 0;
+	BhTax taxonomy; memset(&taxonomy, 0, sizeof taxonomy);
+	BhTaxOpts txo; memset(&txo, 0, sizeof txo); txo.taxacut = 10;   /* burst.c:92 */
 	printf("This is burst_hip [MI355X device path; BURST v1.0 semantics]\n");
 	if (argc < 2) { usage(); return 1; }
 	for (int i = 1; i < argc; ++i) {
@@ -84,9 +87,30 @@ int main(int argc, char **argv) {
 		else if (!strcmp(a, "--batch")) { NEEDARG("--batch"); batch = strtoull(argv[i], 0, 10); }
 		else if (!strcmp(a, "-k")) { NEEDARG("-k"); K = atoi(argv[i]); if (K != 12 && K != 15) { puts("ERROR: -k must be 12 or 15"); return 1; } }
 		else if (!strcmp(a, "--help") || !strcmp(a, "-h")) { usage(); return 1; }
-		else if (!strcmp(a, "--taxonomy") || !strcmp(a, "-b") || !strcmp(a, "--fingerprint") || !strcmp(a, "-f") || !strcmp(a, "--prepass") ||
-		         !strcmp(a, "-p") || !strcmp(a, "--xalphabet") || !strcmp(a, "-x") || !strcmp(a, "--heuristic") || !strcmp(a, "-hr") ||
-		         !strcmp(a, "--taxacut") || !strcmp(a, "-bc") || !strcmp(a, "--taxa_ncbi") || !strcmp(a, "-bn") || !strcmp(a, "--taxasuppress") || !strcmp(a, "-bs")) {
+		else if (!strcmp(a, "--taxonomy") || !strcmp(a, "-b")) {                       /* burst.c:4949-4954 */
+			if (++i == argc || argv[i][0] == '-') { puts("ERROR: --taxonomy requires filename argument"); return 1; }
+			tax_FN = argv[i];
+			printf(" --> Assigning taxonomy based on mapping file: %s\n", tax_FN);
+		}
+		else if (!strcmp(a, "--taxacut") || !strcmp(a, "-bc")) {                        /* burst.c:5001-5014 */
+			if (++i == argc || argv[i][0] == '-') { puts("ERROR: --taxacut requires numeric argument"); return 1; }
+			int temp = atoi(argv[i]);
+			if (temp < 2) { double fl = 1.0 / (1.0 - atof(argv[i])); temp = (int)(fl + 0.5); printf(" --> Taxacut: converting %s to %d...\n", argv[i], temp); }
+			if (temp < 2) { fputs("ERROR: taxacut must be >= 2\n", stderr); return 1; }
+			txo.taxacut = (uint32_t)temp;
+			printf(" --> Ignoring 1/%d disagreeing taxonomy calls\n", temp);
+		}
+		else if (!strcmp(a, "--taxa_ncbi") || !strcmp(a, "-bn")) { txo.ncbi = 1; printf(" --> Using NCBI header formatting for taxonomy lookups\n"); }
+		else if (!strcmp(a, "--taxasuppress") || !strcmp(a, "-bs")) {                   /* burst.c:5023-5031 */
+			txo.suppress = 1;
+			if (i + 1 != argc && argv[i + 1][0] != '-') {
+				if (!strcmp(argv[++i], "STRICT")) txo.strict = 1;
+				else { fprintf(stderr, "ERROR: Unrecognized taxasuppress '%s'\n", argv[i]); return 1; }
+			}
+			printf(" --> Surpressing taxonomic specificity by alignment identity%s\n", txo.strict ? " [STRICT]" : "");
+		}
+		else if (!strcmp(a, "--fingerprint") || !strcmp(a, "-f") || !strcmp(a, "--prepass") ||
+		         !strcmp(a, "-p") || !strcmp(a, "--xalphabet") || !strcmp(a, "-x") || !strcmp(a, "--heuristic") || !strcmp(a, "-hr")) {
 			printf("ERROR: option %s is outside the device hot path and not supported by burst_hip\n", a); return 1;
 		}
 		else { printf("ERROR: Unrecognized command-line option: %s\n", a); puts("See help by running with just '-h'"); return 1; }
@@ -145,6 +169,10 @@ int main(int argc, char **argv) {
 		if ((rc = bh_acx_read(xcel_FN, K, z, &db))) DIE(rc);
 		printf(" --> [Accel] K=%d, %s format, %u ambiguous clumps\n", K, db.acxFmt ? "LARGE" : "SMALL", db.badSz);
 	}
+	if (tax_FN) {                                                                    /* burst.c:5142-5149 */
+		if ((rc = bh_tax_load(tax_FN, &taxonomy))) DIE(rc);
+		txo.tax = &taxonomy;
+	}
 	PHASE("database read");
 	BhQueries Q;
 	if ((rc = bh_queries_load(query_FN, thres, do_rc, incl_ws, do_accel, K ? K : 12, z, skip_ambig, &Q))) DIE(rc);
@@ -170,11 +198,11 @@ int main(int argc, char **argv) {
 	PHASE("search (all batches)");
 	uint64_t lines = 0;
 	setvbuf(output, NULL, _IOFBF, 1 << 22);
-	if ((rc = bh_report_ex(output, &db, &Q, run.hits, run.nHits, mode, (do_accel ? 0 : BH_REP_MERGED_LIST) | rep_flags, &lines))) DIE(rc);
+	if ((rc = bh_report_tax(output, &db, &Q, run.hits, run.nHits, mode, (do_accel ? 0 : BH_REP_MERGED_LIST) | rep_flags, tax_FN ? &txo : NULL, &lines))) DIE(rc);
 	fclose(output);
 	printf("Wrote %lu alignments\n", (unsigned long)lines);
 	PHASE("consolidation, output");
-	bhip_destroy(hh); bh_run_free(&run); bh_queries_free(&Q); bh_db_free(&db);
+	bhip_destroy(hh); bh_run_free(&run); bh_queries_free(&Q); bh_db_free(&db); bh_tax_free(&taxonomy);
 	printf("\nAlignment time: %f seconds\n", wall() - start);
 	return 0;
 }

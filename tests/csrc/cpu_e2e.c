@@ -3,6 +3,7 @@
  * database readers, consolidation and the .b6 writer can be checked against the golden reference outputs on a
  * machine without a GPU.  Never shipped, never measured.
  *   cpu_e2e <db.edx|refs.fa> <queries.fa> <out.b6> <MODE> <id> <fr:0|1> <z:0|1> <shear:-1|len> <report flags>
+ *           [<taxonomy file or ""> <suppress:0|1> <strict:0|1> <taxacut>]
  */
 #include "burst_host.h"
 #include "burst_oracle.h"
@@ -29,7 +30,12 @@ int main(int argc, char **argv) {
 	if (n > cap) { fprintf(stderr, "too many hits\n"); return 3; }
 	FILE *o = fopen(outp, "wb");
 	uint64_t lines = 0;
-	if ((rc = bh_report_ex(o, &db, &Q, (const BhipHit *)hits, n, mode, atoi(argv[9]), &lines))) { fprintf(stderr, "%s\n", bh_last_error()); return 4; }
+	BhTax tax; BhTaxOpts txo; memset(&tax, 0, sizeof tax); memset(&txo, 0, sizeof txo); txo.taxacut = 10;
+	if (argc >= 14 && argv[10][0]) {
+		if ((rc = bh_tax_load(argv[10], &tax))) { fprintf(stderr, "%s\n", bh_last_error()); return 2; }
+		txo.tax = &tax; txo.suppress = atoi(argv[11]); txo.strict = atoi(argv[12]); txo.taxacut = (uint32_t)atoi(argv[13]);
+	}
+	if ((rc = bh_report_tax(o, &db, &Q, (const BhipHit *)hits, n, mode, atoi(argv[9]), txo.tax ? &txo : NULL, &lines))) { fprintf(stderr, "%s\n", bh_last_error()); return 4; }
 	fclose(o);
 	printf("%lu hits, %lu lines\n", (unsigned long)n, (unsigned long)lines);
 	return 0;

@@ -140,6 +140,67 @@ def make_b6():
     json.dump(cases, open(os.path.join(HERE, "cases.json"), "w"), indent=1)
 
 
+def make_taxonomy():
+    """taxonomy map for refs.fa: 7-level strings shared family-wise, a few shallower ones, one empty, some headers absent;
+    keys with and without the description so that either form of the stored reference header finds its line"""
+    names = [ln[1:].rstrip("\n") for ln in open(os.path.join(HERE, "refs.fa")) if ln.startswith(">")]
+    lines = []
+    for nm in names:
+        key = nm.split()[0]
+        if key.startswith("ref"):
+            b, v = int(key[3:5]), int(key.split("_")[1])
+            if b == 11:
+                continue                                   # no taxonomy for this family
+            tax = "k__Bacteria;p__P%d;c__C%d;o__O%d;f__F%d;g__G%d;s__S%d_%d" % (b % 2, b % 3, b % 5, b // 2, b, b, v % 3)
+            if b == 7:
+                tax = ";".join(tax.split(";")[:4 + v % 3])  # shallower assignments
+            if b == 9 and v == 1:
+                tax = ""                                    # empty taxonomy string
+        elif key.startswith("dup_of_ref00"):
+            tax = "k__Bacteria;p__P0;c__C0;o__O0;f__F0;g__G0;s__S0_0"
+        elif key.startswith("multicopy"):
+            tax = "k__Bacteria;p__P1;c__C1;o__O1;f__F0;g__G1"
+        else:
+            continue
+        lines.append("%s\t%s" % (key, tax))
+        if nm != key:
+            lines.append("%s\t%s" % (nm, tax))
+    with open(os.path.join(HERE, "tax.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def make_tax_cases():
+    """column 13: the reference with -b / -bs / -bc on the committed inputs; appended to cases.json"""
+    os.makedirs(TMP, exist_ok=True)
+    make_taxonomy()
+    tax = os.path.join(HERE, "tax.txt")
+    refs = os.path.join(HERE, "refs.fa")
+    acx = os.path.join(TMP, "dna.acx")
+    if not os.path.exists(acx):
+        run([BURST12, "-r", refs, "-d", "DNA", "320", "-o", os.path.join(TMP, "dna_again.edx"), "-a", acx, "-s", "500", "-i", "0.95", "-t", "1"])
+    cases = [c for c in json.load(open(os.path.join(HERE, "cases.json"))) if "-b" not in c["extra"]]
+
+    def case(name, db, q, mode, ident, extra=(), accel=True, threads=4):
+        out = os.path.join(TMP, name + ".raw")
+        cmd = [BURST12, "-q", os.path.join(HERE, q), "-o", out, "-m", mode, "-i", ident, "-t", str(threads), "--noprogress", "-r", os.path.join(HERE, db + ".edx")]
+        if accel:
+            cmd += ["-a", acx]
+        cmd += [tax if a == "tax.txt" else a for a in extra]
+        run(cmd)
+        n = sorted_b6(out, os.path.join(HERE, name + ".b6"))
+        cases.append({"name": name, "db": db, "queries": q, "mode": mode, "id": ident, "extra": list(extra), "accel": accel, "threads": threads, "lines": n})
+        print("%-40s %6d lines" % (name, n))
+    case("dna_q100_capitalist_tax_noacx_t1_fr", "dna", "q100.fa", "CAPITALIST", "0.95", ["-fr", "-b", "tax.txt"], accel=False, threads=1)
+    case("dna_q100_capitalist_tax_bs_noacx_t1_fr", "dna", "q100.fa", "CAPITALIST", "0.95", ["-fr", "-b", "tax.txt", "-bs"], accel=False, threads=1)
+    case("dna_q100_capitalist_tax_bc3_noacx_t1_fr", "dna", "q100.fa", "CAPITALIST", "0.95", ["-fr", "-b", "tax.txt", "-bc", "3"], accel=False, threads=1)
+    case("dna_q292_capitalist_tax_bs_strict_noacx_t1_fr", "dna", "q292.fa", "CAPITALIST", "0.95", ["-fr", "-b", "tax.txt", "-bs", "STRICT"], accel=False, threads=1)
+    case("dna_q100_best_tax_fr", "dna", "q100.fa", "BEST", "0.95", ["-fr", "-b", "tax.txt"])
+    case("dna_q100_best_tax_bs_strict_fr", "dna", "q100.fa", "BEST", "0.95", ["-fr", "-b", "tax.txt", "-bs", "STRICT"])
+    case("dna_q100_allpaths_tax_fr", "dna", "q100.fa", "ALLPATHS", "0.95", ["-fr", "-b", "tax.txt"])
+    case("dna_q100_forage_tax_noacx_t1_fr", "dna", "q100.fa", "FORAGE", "0.95", ["-fr", "-b", "tax.txt"], accel=False, threads=1)
+    json.dump(cases, open(os.path.join(HERE, "cases.json"), "w"), indent=1)
+
+
 def make_kernel_vectors():
     rng = np.random.default_rng(7)
     R = ol.reference()
@@ -194,6 +255,10 @@ def make_kernel_vectors():
 if __name__ == "__main__":
     if not os.path.exists(BURST12):
         raise SystemExit("build the reference first: make -C oracle ref")
+    if len(sys.argv) > 1 and sys.argv[1] == "tax":      # only (re)generate the taxonomy cases
+        make_tax_cases()
+        raise SystemExit(0)
     make_inputs()
     make_b6()
+    make_tax_cases()
     make_kernel_vectors()

@@ -15,6 +15,21 @@ def case_args(c):
     return ref, os.path.join(G, c["queries"]), int("-fr" in c["extra"]), 0 if "-y" in c["extra"] else 1, ("-s" in c["extra"])
 
 
+def cli_extra(c):
+    """the case's extra command-line flags with the taxonomy map resolved to its path in tests/golden"""
+    return [os.path.join(G, a) if a == "tax.txt" else a for a in c["extra"]]
+
+
+def tax_args(c):
+    """(taxonomy file or "", suppress, strict, taxacut) of a case"""
+    e = c["extra"]
+    if "-b" not in e:
+        return "", 0, 0, 10
+    strict = int("STRICT" in e)
+    cut = int(e[e.index("-bc") + 1]) if "-bc" in e else 10
+    return os.path.join(G, "tax.txt"), int("-bs" in e), strict, cut
+
+
 def golden_lines(c):
     return open(os.path.join(G, c["name"] + ".b6"), "rb").read().splitlines()
 

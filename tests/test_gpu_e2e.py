@@ -27,7 +27,7 @@ def test_cli_matches_reference(c, tmp_path_factory):
     tmp = str(tmp_path_factory.getbasetemp())
     ref, q, fr, z, shear = gl.case_args(c)
     out = os.path.join(tmp, c["name"] + ".out")
-    cmd = [CLI, "-r", ref, "-q", q, "-o", out, "-m", c["mode"], "-i", c["id"]] + c["extra"]
+    cmd = [CLI, "-r", ref, "-q", q, "-o", out, "-m", c["mode"], "-i", c["id"]] + gl.cli_extra(c)
     if c["accel"] and c["db"] != "fasta":
         cmd += ["-a", acx_for(c["db"], z, tmp)]
 

@@ -12,7 +12,11 @@ import goldenlib as gl
 ROOT = gl.ROOT
 EXE = "/tmp/burst_amd_cpu_e2e"
 SUBSET = ["dna_q100_best_fr", "dna_q100_allpaths_y", "dna_q100_capitalist_noacx_t1_fr", "dna_q292_forage_noacx_t1_fr",
-          "quick_q100_capitalist_fr", "fasta_q100_allpaths_fr", "fasta_q100_best_noshear"]
+          "quick_q100_capitalist_fr", "fasta_q100_allpaths_fr", "fasta_q100_best_noshear",
+          # column 13 (taxonomy): lookup, CAPITALIST interpolation, -bc, -bs / -bs STRICT
+          # (the other taxonomy cases run through the command line in the gpu suite)
+          "dna_q100_capitalist_tax_noacx_t1_fr", "dna_q100_capitalist_tax_bs_noacx_t1_fr", "dna_q100_capitalist_tax_bc3_noacx_t1_fr",
+          "dna_q100_best_tax_bs_strict_fr", "dna_q100_forage_tax_noacx_t1_fr"]
 
 
 @pytest.fixture(scope="module")
@@ -33,7 +37,8 @@ def test_host_pipeline_matches_reference(exe, name, tmp_path):
     out = str(tmp_path / "o.b6")
 
     def run(flags):
-        subprocess.check_call([exe, ref, q, out, c["mode"], c["id"], str(fr), str(z), "0" if shear else "-1", str(flags)])
+        tax, bs, strict, cut = gl.tax_args(c)
+        subprocess.check_call([exe, ref, q, out, c["mode"], c["id"], str(fr), str(z), "0" if shear else "-1", str(flags), tax, str(bs), str(strict), str(cut)])
         return sorted(open(out, "rb").read().splitlines())
     base = 0 if c["accel"] else 1
     got = run(base)
