@@ -11,6 +11,10 @@
 
 typedef struct { const uint8_t *s; uint32_t len; uint64_t ix; } QRef;
 
+/* the ingest loops are short and memory-bound: beyond a few dozen threads the fork/join of a 256-thread host costs more than
+ * the loop (measured on 2 x EPYC 9575F: 0.84 s with all 256 threads) */
+static int bh_ingest_threads(void) { const int n = omp_get_max_threads(); return n > 32 ? 32 : n; }
+
 static int qref_cmp(const void *a, const void *b) {
 	const QRef *A = a, *B = b;
 	uint32_t n = A->len < B->len ? A->len : B->len;
@@ -38,7 +42,7 @@ static int sort_qrefs(QRef *a, uint64_t n) {
 	if (!pos) { free(cnt); free(tmp); return bh_set_error(BH_E_OOM, "OOM sorting queries"); }
 	memcpy(pos, cnt, (size_t)NB * sizeof(*pos));
 	for (uint64_t i = 0; i < n; ++i) tmp[pos[prefix_bucket(a + i)]++] = a[i];
-	#pragma omp parallel for schedule(dynamic, 64)
+	#pragma omp parallel for num_threads(bh_ingest_threads()) schedule(dynamic, 64)
 	for (uint32_t b = 0; b < NB; ++b) if (cnt[b + 1] - cnt[b] > 1)
 		qsort(tmp + cnt[b], cnt[b + 1] - cnt[b], sizeof(*tmp), qref_cmp);
 	memcpy(a, tmp, n * sizeof(*a));
@@ -57,6 +61,9 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
                     int skip_ambig, BhQueries *Q) {
 	memset(Q, 0, sizeof *Q);
 	(void)skip_ambig;
+	const int dbg = getenv("BURST_HOST_DEBUG") != NULL;
+	double t_ = omp_get_wtime();
+	#define QPH(name) do { if (dbg) { const double n_ = omp_get_wtime(); fprintf(stderr, "[bh_queries] %-22s %.3f s\n", name, n_ - t_); t_ = n_; } } while (0)
 	FILE *f = fopen(fasta, "rb");
 	if (!f) return bh_set_error(BH_E_IO, "Cannot open FASTA file: %s.", fasta);
 	fseeko(f, 0, SEEK_END);
@@ -68,14 +75,16 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 	fclose(f);
 	memset(dump + sz, 0, 17);
 	Q->dump = dump;
+	QPH("file read");
 	if (!sz || *dump != '>') { bh_queries_free(Q); return bh_set_error(BH_E_USAGE, "ERROR: Malformatted FASTA file."); }
 	/* strict two-line records: (number of newlines, rounded up to even) / 2 must equal the number of '>' (burst.c:648-654) */
 	uint64_t numNL = 0, numLT = 0;
-	#pragma omp parallel for reduction(+:numNL, numLT)
+	#pragma omp parallel for num_threads(bh_ingest_threads()) reduction(+:numNL, numLT)
 	for (uint64_t i = 0; i < sz; ++i) { numNL += dump[i] == '\n'; numLT += dump[i] == '>'; }
 	numNL += numNL & 1;
 	if (numLT != numNL / 2) { bh_queries_free(Q); return bh_set_error(BH_E_USAGE, "ERROR: line count != '>' * 2"); }
 	const uint64_t totQ = numLT;
+	QPH("line count");
 	char **heads = malloc(totQ * sizeof(*heads));
 	QRef *refs = malloc(totQ * sizeof(*refs));
 	if (!heads || !refs) { free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_OOM, "OOM indexing queries"); }
@@ -105,8 +114,9 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 		}
 		if (n != totQ) { free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_USAGE, "ERROR: line count != '>' * 2"); }
 	}
+	QPH("record index");
 	uint32_t maxLen = 0, minLen = UINT32_MAX;
-	#pragma omp parallel for reduction(max:maxLen) reduction(min:minLen)
+	#pragma omp parallel for num_threads(bh_ingest_threads()) reduction(max:maxLen) reduction(min:minLen)
 	for (uint64_t i = 0; i < totQ; ++i) {
 		uint8_t *s = (uint8_t *)refs[i].s;
 		for (uint32_t k = 0; k < refs[i].len; ++k) s[k] = c2n[s[k]];                     /* translateNV, burst.c:1207 */
@@ -117,12 +127,19 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 		free(heads); free(refs); bh_queries_free(Q);
 		return bh_set_error(BH_E_USAGE, "ERROR: query of %u symbols exceeds the device limit of %d", maxLen, BHIP_MAX_QLEN);
 	}
+	QPH("translate");
 	int rc = sort_qrefs(refs, totQ);
+	QPH("sort");
 	if (rc) { free(heads); free(refs); bh_queries_free(Q); return rc; }
 	/* uniqueness (burst.c:3036-3053) */
 	uint64_t numUniq = 0;
-	for (uint64_t i = 0; i < totQ; ++i)
-		if (!i || refs[i].len != refs[i - 1].len || memcmp(refs[i].s, refs[i - 1].s, refs[i].len)) ++numUniq;
+	uint8_t *isNew = malloc(totQ + 1);            /* 1 where a sorted record differs from its predecessor */
+	if (!isNew) { free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_OOM, "OOM:dedupe"); }
+	#pragma omp parallel for num_threads(bh_ingest_threads()) reduction(+:numUniq) schedule(static)
+	for (uint64_t i = 0; i < totQ; ++i) {
+		isNew[i] = !i || refs[i].len != refs[i - 1].len || memcmp(refs[i].s, refs[i - 1].s, refs[i].len);
+		numUniq += isNew[i];
+	}
 	const uint64_t numEntries = numUniq * (do_rc ? 2 : 1);
 	Q->heads = malloc(totQ * sizeof(*Q->heads));
 	Q->offset = malloc((numUniq + 1) * sizeof(*Q->offset));
@@ -134,12 +151,12 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 	Q->len = malloc(numUniq * sizeof(*Q->len));
 	Q->ed = malloc(numUniq * sizeof(*Q->ed));
 	if (!Q->heads || !Q->offset || !Q->qoff || !Q->six || !Q->rc || !Q->flags || !Q->emac || !Q->len || !Q->ed) {
-		free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_OOM, "OOM building query tables");
+		free(isNew); free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_OOM, "OOM building query tables");
 	}
 	uint64_t u = 0, totLen = 0;
 	for (uint64_t i = 0; i < totQ; ++i) {
 		Q->heads[i] = heads[refs[i].ix];
-		if (!i || refs[i].len != refs[i - 1].len || memcmp(refs[i].s, refs[i - 1].s, refs[i].len)) {
+		if (isNew[i]) {
 			Q->offset[u] = i;
 			Q->len[u] = refs[i].len;
 			Q->ed[u] = (uint16_t)bh_error_budget(thres, refs[i].len);                  /* burst.c:3074-3076 */
@@ -148,13 +165,15 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 		}
 	}
 	Q->offset[numUniq] = totQ;
+	free(isNew);
+	QPH("dedupe");
 	Q->codes = malloc(totLen * (do_rc ? 2 : 1) + 16);
 	if (!Q->codes) { free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_OOM, "OOM copying queries"); }
 	Q->qoff[0] = 0;
 	for (uint64_t i = 0; i < numUniq; ++i) Q->qoff[i + 1] = Q->qoff[i] + Q->len[i];
 	if (do_rc) for (uint64_t i = 0; i < numUniq; ++i) Q->qoff[numUniq + i + 1] = Q->qoff[numUniq + i] + Q->len[i];
 	uint32_t maxED = 0;
-	#pragma omp parallel for reduction(max:maxED)
+	#pragma omp parallel for num_threads(bh_ingest_threads()) reduction(max:maxED)
 	for (uint64_t i = 0; i < numUniq; ++i) {
 		const uint8_t *s = refs[Q->offset[i]].s;
 		const uint32_t len = Q->len[i];
@@ -171,7 +190,9 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 	 * ambiguous symbols; ambiguous = any symbol beyond A/C/G/T.  Clear and ambiguous entries use the device prefilter
 	 * (words with ambiguous symbols simply do not vote there and the guaranteed count shrinks accordingly; the library
 	 * falls back to the exhaustive route by itself when no word is guaranteed); bad ones are exhaustive (burst.c:4320). */
+	QPH("copy + reverse complement");
 	uint64_t nClear = 0, nAmbig = 0, nBad = 0;
+	#pragma omp parallel for num_threads(bh_ingest_threads()) reduction(+:nClear, nAmbig, nBad) schedule(static)
 	for (uint64_t e = 0; e < numEntries; ++e) {
 		if (!do_accel) { Q->flags[e] = BHIP_Q_EXHAUSTIVE; continue; }
 		const uint32_t len = Q->len[Q->six[e]], ed = Q->ed[Q->six[e]];
@@ -191,6 +212,7 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 		Q->flags[e] = len < (uint32_t)K ? BHIP_Q_EXHAUSTIVE : BHIP_Q_PREFILTER;
 		if (stat == 1) ++nClear; else if (stat == 0) ++nAmbig; else ++nBad;
 	}
+	QPH("bins");
 	Q->totQ = totQ; Q->numUniq = numUniq; Q->numEntries = numEntries;
 	Q->maxLen = maxLen; Q->minLen = minLen; Q->maxED = maxED;
 	Q->nClear = nClear; Q->nAmbig = nAmbig; Q->nBad = nBad;
