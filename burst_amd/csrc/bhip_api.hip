@@ -16,6 +16,7 @@
 #include "bhip_internal.h"
 
 // ---- kernels (bhip_kernels.hip) -------------------------------------------------------------------
+__global__ void k_acx_decode(const uint8_t *, const unsigned long long *, const uint32_t *, uint64_t, int, uint32_t, uint32_t *, uint32_t *);
 __global__ void k_transpose_refs(const uint8_t *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint4 *, uint4 *);
 __global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, int, int, BhipMatchMask, uint32_t *, const uint32_t *, uint32_t);
 template <bool LDS_CNT> __global__ void k_prefilter(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
@@ -385,34 +386,39 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 	if (acx_lens) {
 		const uint64_t nw = 1ull << (2 * K);
 		std::vector<uint32_t> off(nw + 1);
-		uint64_t tot = 0;
+		std::vector<unsigned long long> boff(nw + 1);       // byte offset of each word's packed list
+		uint64_t tot = 0, bytes = 0;
 		double sq = 0.0;
-		for (uint64_t i = 0; i < nw; ++i) { off[i] = (uint32_t)tot; tot += acx_lens[i]; sq += (double)acx_lens[i] * (double)acx_lens[i]; }
+		for (uint64_t i = 0; i < nw; ++i) {
+			const uint32_t n = acx_lens[i];
+			off[i] = (uint32_t)tot; boff[i] = bytes;
+			tot += n; sq += (double)n * (double)n;
+			bytes += acx_fmt == 1 ? 3ull * n : 5ull * (n >> 1) + 3ull * (n & 1);
+		}
 		h->acx_wmean = tot ? sq / (double)tot : 0.0;
 		if (tot >= 0xFFFFFFFFull) { fail(BHIP_E_ARG, "accelerator with %llu entries exceeds the 32-bit offset table", (unsigned long long)tot); bhip_destroy(h); return BHIP_E_ARG; }
-		off[nw] = (uint32_t)tot;
-		// decode the packed lists (burst.c:3265-3274 SMALL, 3245-3248 LARGE) to one u32 per entry
-		std::vector<uint32_t> ent(tot + 1);
-		const uint8_t *p = (const uint8_t *)acx_lists;
-		uint64_t e = 0;
-		if (acx_fmt == 1) {
-			for (uint64_t i = 0; i < tot; ++i, p += 3) ent[e++] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
-		} else {
-			for (uint64_t w = 0; w < nw; ++w) {
-				uint32_t n = acx_lens[w];
-				for (; n >= 2; n -= 2, p += 5) {
-					uint64_t v = (uint64_t)p[0] | ((uint64_t)p[1] << 8) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 24) | ((uint64_t)p[4] << 32);
-					ent[e++] = (uint32_t)(v & 0xFFFFF); ent[e++] = (uint32_t)((v >> 20) & 0xFFFFF);
-				}
-				if (n) { ent[e++] = ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)) & 0xFFFFF; p += 3; }
-			}
-		}
-		for (uint64_t i = 0; i < tot; ++i) if (ent[i] >= n_clumps) {
-			fail(BHIP_E_ARG, "accelerator entry %llu refers to clump %u >= %u", (unsigned long long)i, ent[i], n_clumps); bhip_destroy(h); return BHIP_E_ARG; }
+		off[nw] = (uint32_t)tot; boff[nw] = bytes;
+		// the packed list area goes up as it is on disk and is decoded to one u32 per entry by the device
 		INITRC(h->acx_off.reserve((nw + 1) * sizeof(uint32_t)));
 		INITRC(h->acx_ent.reserve((tot + 1) * sizeof(uint32_t)));
-		INITCHK(hipMemcpy(h->acx_off.p, off.data(), (nw + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
-		INITCHK(hipMemcpy(h->acx_ent.p, ent.data(), (tot + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+		{
+			DBuf d_lists, d_boff, d_flag;
+			INITRC(d_lists.reserve(bytes + 16));
+			INITRC(d_boff.reserve((nw + 1) * sizeof(unsigned long long)));
+			INITRC(d_flag.reserve(16));
+			INITCHK(hipMemcpyAsync(h->acx_off.p, off.data(), (nw + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+			INITCHK(hipMemcpyAsync(d_boff.p, boff.data(), (nw + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+			if (bytes) INITCHK(hipMemcpyAsync(d_lists.p, acx_lists, bytes, hipMemcpyHostToDevice, h->stream));
+			INITCHK(hipMemsetAsync(d_flag.p, 0, 16, h->stream));
+			hipLaunchKernelGGL(k_acx_decode, dim3((uint32_t)h->n_cu * 32), dim3(256), 0, h->stream, d_lists.as<uint8_t>(), d_boff.as<unsigned long long>(),
+				h->acx_off.as<uint32_t>(), nw, acx_fmt, n_clumps, h->acx_ent.as<uint32_t>(), d_flag.as<uint32_t>());
+			INITCHK(hipGetLastError());
+			uint32_t worst = 0;
+			INITCHK(hipMemcpyAsync(&worst, d_flag.p, 4, hipMemcpyDeviceToHost, h->stream));
+			INITCHK(hipStreamSynchronize(h->stream));
+			d_lists.release(); d_boff.release(); d_flag.release();
+			if (worst) { fail(BHIP_E_ARG, "an accelerator entry refers to clump %u >= %u", worst, n_clumps); bhip_destroy(h); return BHIP_E_ARG; }
+		}
 		h->n_bad = n_bad;
 		INITRC(h->bad.reserve((n_bad + 1) * sizeof(uint32_t)));
 		if (n_bad) {

@@ -52,6 +52,35 @@ __global__ void k_transpose_refs(const uint8_t *__restrict__ src, const uint64_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// .acx list area -> one u32 clump id per entry, on the device (the packed bytes are what is uploaded): SMALL lists are
+// pairs of 20-bit ids in 5 bytes with a 3-byte odd tail (burst.c:3265-3274), LARGE lists 3 bytes per id (3245-3248).
+// One thread per word; `bad` is raised when an id is not a clump of the database.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_acx_decode(const uint8_t *__restrict__ lists, const unsigned long long *__restrict__ byte_off, const uint32_t *__restrict__ off,
+                             uint64_t n_words, int fmt, uint32_t n_clumps, uint32_t *__restrict__ ent, uint32_t *__restrict__ bad) {
+	for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t e0 = off[w];
+		uint32_t n = off[w + 1] - e0;
+		if (!n) continue;
+		const uint8_t *p = lists + byte_off[w];
+		uint32_t e = e0, worst = 0;
+		if (fmt == 1) {
+			for (; n; --n, p += 3) { const uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); ent[e++] = v; worst = v > worst ? v : worst; }
+		} else {
+			for (; n >= 2; n -= 2, p += 5) {
+				const unsigned long long v = (unsigned long long)p[0] | ((unsigned long long)p[1] << 8) | ((unsigned long long)p[2] << 16) |
+				                             ((unsigned long long)p[3] << 24) | ((unsigned long long)p[4] << 32);
+				const uint32_t a = (uint32_t)(v & 0xFFFFF), b = (uint32_t)((v >> 20) & 0xFFFFF);
+				ent[e++] = a; ent[e++] = b;
+				worst = a > worst ? a : worst; worst = b > worst ? b : worst;
+			}
+			if (n) { const uint32_t v = ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)) & 0xFFFFF; ent[e++] = v; worst = v > worst ? v : worst; }
+		}
+		if (worst >= n_clumps) atomicMax(bad, worst);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // Match bit-vectors (DIAGSC_MAT16, burst.c:700: SCOREFAST[qLet] shuffled by the reference symbol).
 // The query is TOP-aligned in its NW x 32-bit vector: query symbol i lives at bit i + (32*NW - len), so the
 // last symbol is always bit 31 of word NW-1 and k_myers needs no per-query bit index.  The low 32*NW - len
