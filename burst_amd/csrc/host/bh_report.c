@@ -12,9 +12,11 @@
  *     in sorted order, lanes ascending (4344-4476).  With one thread this is deterministic and BH_REP_MERGED_LIST
  *     reproduces it exactly: clump descending; inside a clump the strand whose sequence sorts later first; lanes descending.
  */
+#define _GNU_SOURCE            /* open_memstream */
 #include "burst_host.h"
 #include <stdlib.h>
 #include <string.h>
+#include <omp.h>
 
 typedef struct { const BhipHit *h; } Pod;
 
@@ -77,24 +79,22 @@ int bh_report_ex(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *h
 int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *hits, uint64_t nHits, BhMode mode, int flags, const BhTaxOpts *tx,
                   uint64_t *nLines) {
 	const uint64_t nU = Q->numUniq, nE = Q->numEntries;
+	FILE *const real_out = out;
 	const BhTax *T = tx ? tx->tax : NULL;
 	const int wt = T != NULL, ncbi = tx ? tx->ncbi : 0, suppress = tx ? tx->suppress : 0;
 	const uint32_t taxacut = tx && tx->taxacut >= 2 ? tx->taxacut : 10;
 	const float *LEVELS = tx && tx->strict ? LEVELS_STRICT : LEVELS_LENIENT;
-	char *Taxon = wt ? calloc(1, 1000000) : NULL;          /* scratch of the interpolated / suppressed string (burst.c:4741, 4852) */
-	const char *FinalTaxon = NULL;                           /* BEST keeps the last value when a taxonomy is empty (burst.c:4852-4885) */
-	const char **Taxa = NULL; uint32_t *Divergence = NULL;
 	const int merged = flags & BH_REP_MERGED_LIST, nodupe = flags & BH_REP_NO_DUPE_HUNT;
 	uint64_t lines = 0;
 	g_nodupe = nodupe;
 	/* per-entry ranges (records of one entry are contiguous) */
 	uint64_t *start = calloc(nE + 1, sizeof(*start)); uint32_t *count = calloc(nE + 1, sizeof(*count));
-	if (!start || !count) { free(start); free(count); free(Taxon); return bh_set_error(BH_E_OOM, "OOM:report"); }
+	if (!start || !count) { free(start); free(count); return bh_set_error(BH_E_OOM, "OOM:report"); }
 	for (uint64_t k = 0; k < nHits; ++k) {
 		const uint32_t e = hits[k].q;
-		if (e >= nE) { free(start); free(count); free(Taxon); return bh_set_error(BH_E_INTERNAL, "hit refers to entry %u of %lu", e, (unsigned long)nE); }
+		if (e >= nE) { free(start); free(count); return bh_set_error(BH_E_INTERNAL, "hit refers to entry %u of %lu", e, (unsigned long)nE); }
 		if (!count[e]) start[e] = k;
-		else if (start[e] + count[e] != k) { free(start); free(count); free(Taxon); return bh_set_error(BH_E_INTERNAL, "hit records of entry %u are not contiguous", e); }
+		else if (start[e] + count[e] != k) { free(start); free(count); return bh_set_error(BH_E_INTERNAL, "hit records of entry %u are not contiguous", e); }
 		++count[e];
 	}
 	uint32_t maxIX = 0;
@@ -107,21 +107,25 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 	for (uint64_t i = 0; i < nU; ++i) { uint32_t n = count[i] + (nE > nU ? count[nU + i] : 0); if (n > maxList0) maxList0 = n; }
 	uint64_t capX = numBins + 1;
 	if ((uint64_t)maxList0 * maxDup + 1 > capX) capX = (uint64_t)maxList0 * maxDup + 1;
-	uint32_t *RefCache = malloc(capX * 4 + 4), *StCache = malloc(capX * 4 + 4), *RIXcache = malloc(capX * 4 + 4);
-	const BhipHit **RPcache = malloc((capX + 1) * sizeof(*RPcache));
 	size_t *RefCounts = mode == BH_CAPITALIST ? calloc(numBins + 1, sizeof(*RefCounts)) : NULL;
-	if (wt && mode == BH_CAPITALIST) { Taxa = malloc((capX + 1) * sizeof(*Taxa)); Divergence = calloc(capX + 1, sizeof(*Divergence)); }
 	uint32_t maxList = 0;
 	for (uint64_t i = 0; i < nU; ++i) {
 		uint32_t n = count[i] + (nE > nU ? count[nU + i] : 0);
 		if (n > maxList) maxList = n;
 	}
-	const BhipHit **list = malloc(((size_t)maxList + 1) * sizeof(*list));
-	if (!RefCache || !StCache || !RIXcache || !RPcache || !list || (mode == BH_CAPITALIST && !RefCounts) || (wt && !Taxon) ||
-	    (wt && mode == BH_CAPITALIST && (!Taxa || !Divergence))) {
-		free(start); free(count); free(RefCache); free(StCache); free(RIXcache); free(RPcache); free(RefCounts); free(list); free(Taxon); free(Taxa); free(Divergence);
-		return bh_set_error(BH_E_OOM, "OOM:report");
+	if (mode == BH_CAPITALIST && !RefCounts) { free(start); free(count); return bh_set_error(BH_E_OOM, "OOM:report"); }
+	/* Queries are independent once the CAPITALIST votes are in: chunks of unique queries are rendered by a team of threads,
+	 * each into its own memory stream with its own scratch, and written out in order.  The one sequential case is BEST with
+	 * -b -bs, where an empty taxonomy inherits the string of the previous query (burst.c:4852-4885). */
+	int nThreads = omp_get_max_threads() > 32 ? 32 : omp_get_max_threads();
+	uint64_t chunkQ = 8192;
+	{	/* test hook: BURST_HOST_REPORT_THREADS=<n>[:<queries per chunk>] forces the threaded path on small inputs */
+		const char *ev = getenv("BURST_HOST_REPORT_THREADS");
+		if (ev && atoi(ev) > 0) { nThreads = atoi(ev); const char *c = strchr(ev, ':'); if (c && atoll(c + 1) > 0) chunkQ = (uint64_t)atoll(c + 1); }
+		else if (nU < 4096) nThreads = 1;
 	}
+	if (wt && suppress && mode == BH_BEST) nThreads = 1;
+	int oom = 0;
 	#define MAPPED(rix) (db->identityMap ? (rix) : db->refMap[rix])
 	#define BUILD_LIST(i, n) do { n = 0; \
 		if (merged && nE > nU) { \
@@ -146,24 +150,67 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 		else { uint32_t rixvar = db->refIxSrt[(rp)->refIx]; __VA_ARGS__ } } while (0)
 
 	if (mode == BH_CAPITALIST) {   /* pass A: one vote per unique query and accepted (hit, reference) (burst.c:4700-4727) */
-		for (uint64_t i = 0; i < nU; ++i) {
-			uint32_t n; BUILD_LIST(i, n);
-			if (!n) continue;
-			uint32_t b = 0;
-			for (uint32_t k = 1; k < n; ++k) if (list[k]->ed < list[b]->ed) b = k;
-			uint64_t ddix = 0; const uint32_t qlen = Q->len[i], ql2 = qlen >> 1;
-			for (uint32_t k = b; k < n; ++k) {
-				const BhipHit *rp = list[k];
-				if (rp->ed != list[b]->ed) continue;
-				FOR_EXPANSIONS(rp, rix, {
-					uint32_t st, ed; coords(db, rp, rix, qlen, &st, &ed); (void)ed;
-					uint32_t mapped = MAPPED(rix);
-					if (!dupe_hunt(RefCache, StCache, &ddix, mapped, rp->rc ? st : st, ql2, 0)) ++RefCounts[mapped];
-				});
+		#pragma omp parallel num_threads(nThreads)
+		{
+			uint32_t *RefCache = malloc(capX * 4 + 4), *StCache = malloc(capX * 4 + 4);
+			const BhipHit **list = malloc(((size_t)maxList + 1) * sizeof(*list));
+			if (!RefCache || !StCache || !list) {
+				#pragma omp atomic write
+				oom = 1;
 			}
+			#pragma omp barrier
+			if (!oom) {
+				#pragma omp for schedule(static)
+				for (uint64_t i = 0; i < nU; ++i) {
+					uint32_t n; BUILD_LIST(i, n);
+					if (!n) continue;
+					uint32_t b = 0;
+					for (uint32_t k = 1; k < n; ++k) if (list[k]->ed < list[b]->ed) b = k;
+					uint64_t ddix = 0; const uint32_t qlen = Q->len[i], ql2 = qlen >> 1;
+					for (uint32_t k = b; k < n; ++k) {
+						const BhipHit *rp = list[k];
+						if (rp->ed != list[b]->ed) continue;
+						FOR_EXPANSIONS(rp, rix, {
+							uint32_t st, ed; coords(db, rp, rix, qlen, &st, &ed); (void)ed;
+							uint32_t mapped = MAPPED(rix);
+							if (!dupe_hunt(RefCache, StCache, &ddix, mapped, st, ql2, 0)) { _Pragma("omp atomic") ++RefCounts[mapped]; }
+						});
+					}
+				}
+			}
+			free(RefCache); free(StCache); free(list);
 		}
+		if (oom) { free(start); free(count); free(RefCounts); return bh_set_error(BH_E_OOM, "OOM:report"); }
 	}
-	for (uint64_t i = 0; i < nU; ++i) {
+	const uint64_t CH = nThreads > 1 ? chunkQ : (nU ? nU : 1), nChunks = (nU + CH - 1) / CH;
+	char **cbuf = calloc(nChunks + 1, sizeof(*cbuf)); size_t *clen = calloc(nChunks + 1, sizeof(*clen));
+	if (!cbuf || !clen) { free(cbuf); free(clen); free(start); free(count); free(RefCounts); return bh_set_error(BH_E_OOM, "OOM:report"); }
+	#pragma omp parallel num_threads(nThreads) reduction(+:lines)
+	{
+	uint32_t *RefCache = malloc(capX * 4 + 4), *StCache = malloc(capX * 4 + 4), *RIXcache = malloc(capX * 4 + 4);
+	const BhipHit **RPcache = malloc((capX + 1) * sizeof(*RPcache));
+	const BhipHit **list = malloc(((size_t)maxList + 1) * sizeof(*list));
+	char *Taxon = wt ? calloc(1, 1000000) : NULL;          /* scratch of the interpolated / suppressed string (burst.c:4741, 4852) */
+	const char *FinalTaxon = NULL;                           /* BEST keeps the last value when a taxonomy is empty (burst.c:4852-4885) */
+	const char **Taxa = NULL; uint32_t *Divergence = NULL;
+	if (wt && mode == BH_CAPITALIST) { Taxa = malloc((capX + 1) * sizeof(*Taxa)); Divergence = calloc(capX + 1, sizeof(*Divergence)); }
+	if (!RefCache || !StCache || !RIXcache || !RPcache || !list || (wt && !Taxon) || (wt && mode == BH_CAPITALIST && (!Taxa || !Divergence))) {
+		#pragma omp atomic write
+		oom = 1;
+	}
+	#pragma omp barrier
+	#pragma omp for schedule(dynamic, 1)
+	for (uint64_t ch = 0; ch < nChunks; ++ch) {
+	if (oom) continue;
+	FILE *cs = open_memstream(&cbuf[ch], &clen[ch]);
+	if (!cs) {
+		#pragma omp atomic write
+		oom = 1;
+		continue;
+	}
+	FILE *out = cs;                                          /* the loop body below prints to `out` */
+	const uint64_t i0 = ch * CH, i1 = i0 + CH < nU ? i0 + CH : nU;
+	for (uint64_t i = i0; i < i1; ++i) {
 		uint32_t n; BUILD_LIST(i, n);
 		if (!n) continue;
 		const uint32_t qlen = Q->len[i], ql2 = qlen >> 1;
@@ -284,7 +331,19 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 			for (uint64_t j = Q->offset[i]; j < Q->offset[i + 1]; ++j) { print_line_tax(out, Q->heads[j], db->refHead[bestrix], best, qlen, st, ed, i, wt, Final); ++lines; }
 		}
 	}
-	free(start); free(count); free(RefCache); free(StCache); free(RIXcache); free(RPcache); free(RefCounts); free(list); free(Taxon); free(Taxa); free(Divergence);
+	fclose(cs);
+	}
+	free(RefCache); free(StCache); free(RIXcache); free(RPcache); free(list); free(Taxon); free(Taxa); free(Divergence);
+	}
+	int wr = 0;
+	for (uint64_t ch = 0; ch < nChunks; ++ch) {              /* chunks in query order */
+		if (!oom && cbuf[ch] && clen[ch] && fwrite(cbuf[ch], 1, clen[ch], real_out) != clen[ch]) wr = 1;
+		free(cbuf[ch]);
+	}
+	free(cbuf); free(clen);
+	free(start); free(count); free(RefCounts);
+	if (oom) return bh_set_error(BH_E_OOM, "OOM:report");
+	if (wr) return bh_set_error(BH_E_IO, "short write on the output file");
 	if (nLines) *nLines = lines;
 	return BH_OK;
 }

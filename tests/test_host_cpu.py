@@ -44,3 +44,19 @@ def test_host_pipeline_matches_reference(exe, name, tmp_path):
     got = run(base)
     nd = run(base | 2) if gl.order_sensitive(c) else None
     gl.compare(c, got, nd)
+
+
+@pytest.mark.parametrize("name", ["dna_q100_capitalist_tax_noacx_t1_fr", "dna_q292_forage_noacx_t1_fr", "dna_q100_allpaths_y"])
+def test_threaded_report_equals_sequential(exe, name, tmp_path, monkeypatch):
+    """the consolidation renders chunks of queries on several threads and writes them in order: forced on with small chunks"""
+    monkeypatch.setenv("BURST_HOST_REPORT_THREADS", "5:37")
+    c = [x for x in gl.cases() if x["name"] == name][0]
+    ref, q, fr, z, shear = gl.case_args(c)
+    out = str(tmp_path / "o.b6")
+    tax, bs, strict, cut = gl.tax_args(c)
+    subprocess.check_call([exe, ref, q, out, c["mode"], c["id"], str(fr), str(z), "0" if shear else "-1", "0" if c["accel"] else "1", tax, str(bs), str(strict), str(cut)])
+    threaded = open(out, "rb").read()
+    monkeypatch.setenv("BURST_HOST_REPORT_THREADS", "1")
+    subprocess.check_call([exe, ref, q, out, c["mode"], c["id"], str(fr), str(z), "0" if shear else "-1", "0" if c["accel"] else "1", tax, str(bs), str(strict), str(cut)])
+    assert threaded == open(out, "rb").read()                 # same bytes in the same order
+    gl.compare(c, sorted(threaded.splitlines()), None if not gl.order_sensitive(c) else sorted(threaded.splitlines()))
