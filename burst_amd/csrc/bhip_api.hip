@@ -180,7 +180,7 @@ struct Handle {
 	int opt_lane_masks = 1;       // use them
 	// batch-wide buffers
 	DBuf qcodes, qoff, qemac, qsix, qrc, best, out, shared_ctr, mins, pairs;
-	DBuf sort_keys, sort_keys2, sort_idx, sort_idx2, sort_tmp, out_sorted, qpack, plan;
+	DBuf sort_keys, sort_keys2, sort_idx, sort_tmp, out_sorted, qpack, plan;   // sort_keys / sort_keys2: per-query record counts / offsets; sort_idx: rank of a record inside its query
 	uint64_t out_cap = 1 << 20;
 	std::vector<uint32_t> h_clump_len;
 	BhipStats stats;
@@ -251,7 +251,7 @@ extern "C" void bhip_destroy(void *handle) {
 	if (h->post_stream) (void)hipStreamSynchronize(h->post_stream);
 	for (Lane *L : h->lanes) lane_destroy(L);
 	DBuf *all[] = {&h->ref, &h->ref_lane, &h->ref_off, &h->clump_len, &h->lut, &h->acx_off, &h->acx_ent, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
-		&h->qsix, &h->qrc, &h->best, &h->out, &h->shared_ctr, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx, &h->sort_idx2,
+		&h->qsix, &h->qrc, &h->best, &h->out, &h->shared_ctr, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx,
 		&h->sort_tmp, &h->out_sorted, &h->qpack, &h->plan, &h->ent_mask};
 	for (DBuf *b : all) b->release();
 	for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);

@@ -3,17 +3,17 @@
 // What the reference computes with 16-lane SSE rows (burst.c:1003-1204 aded_*, 713-886 reScoreM_*,
 // 3238-3282 postScour*) is re-designed here for 64-wide wavefronts:
 //
-//   k_transpose_refs : .edx clump area (16 lanes interleaved per byte, burst.c:2810-2824) -> device layout
-//                      [clump][chunk of 32 positions][lane][16 B], so that a 16-lane group streams 256
-//                      contiguous bytes per load and each thread owns one reference lane.
-//   k_build_peq      : per query, 16 match bit-vectors (one per reference symbol) from the 16x16 cost table.
-//   k_prefilter      : one workgroup per query; k-mer words -> .acx lists -> dense per-clump counters in LDS
-//                      (global memory for very large DBs) -> candidate (query, clump) pairs.
-//   k_myers<NW>      : one thread per (query, reference lane); Myers/Hyyro bit-parallel semi-global edit
-//                      distance over NW 32-bit words (carry chains via v_addc_co_u32); 16-lane group = one
-//                      (query, clump) unit = one aded_mat16 call.  Emits ed, first/last end column of the minimum.
-//   k_rescore        : one thread per surviving hit; 3-plane (score, gapQ, gapR) DP restricted to the
-//                      diagonals that can reach a minimal end cell, with the reference's exact tie-breaks.
+//   k_transpose_refs, k_acx_decode, k_extract_kmers, k_attach_masks : database set-up (two reference layouts, u32 list
+//                      entries from the packed .acx, 16-bit lane masks per list entry derived from the references).
+//   k_pack_queries, k_build_peq : 4-bit packed queries; per query 16 match bit-vectors (one per reference symbol).
+//   k_seed_ranges, k_prefilter_cf / k_prefilter_mask : sampled words -> .acx list ranges -> per-query counts in LDS,
+//                      resolved to single reference lanes -> (query, lane) tasks, split by a lower bound on their
+//                      edit distance.  k_prefilter_hash / k_prefilter_wave / k_prefilter: clump-level fallbacks.
+//   k_myers_prefix_task, k_task_filter, k_myers_window : two-stage Myers/Hyyro bit-parallel semi-global edit distance, one
+//                      thread per (query, reference lane) (carry chains via v_add_co / v_addc_co); k_myers_prefix and
+//                      k_myers are the 16-lane (one aded_mat16 call per group) variants for clump-level units.
+//   k_rescore_classify, k_rescore_reg, k_rescore : one thread per surviving hit; 3-plane (score, gapQ, gapR) DP restricted
+//                      to the diagonals that can reach a minimal end cell, with the reference's exact tie-breaks.
 //
 // No MFMA: the recurrence is integer min-plus / bit logic (VALU + LDS bound).
 #include <hip/hip_runtime.h>
