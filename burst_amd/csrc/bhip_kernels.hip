@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 			for (uint32_t u = 0; u < 4; ++u) {
 				const uint32_t i = (b * 4 + u) * 16 + gl;
 				uint32_t kk = 0;
-				kk += __shfl(ex, 8, 16) <= i ? 8u : 0u;
+				if (W16 > 8) kk += __shfl(ex, 8, 16) <= i ? 8u : 0u;      // (uniform) with 8 words per query the upper half is empty
 				kk += __shfl(ex, kk + 4, 16) <= i ? 4u : 0u;
 				kk += __shfl(ex, kk + 2, 16) <= i ? 2u : 0u;
 				kk += __shfl(ex, kk + 1, 16) <= i ? 1u : 0u;
