@@ -34,8 +34,20 @@ while time.time() - t0 < budget_s:
         lens, entries, offs = dbutil.build_acx(seqs, cfg["K"], skip_clumps=tuple(bad))
         kw = dict(acx_lens=lens, acx_lists=dbutil.pack_acx_lists(lens, entries, cfg["fmt"]), acx_fmt=cfg["fmt"], K=cfg["K"],
                   badlist=np.array(bad, np.uint32) if bad else None)
-    edits = [0, 1, 2, max(0, T.budget(cfg["thres"], cfg["qlen"])), T.budget(cfg["thres"], cfg["qlen"]) + 2]
-    q, _ = T.make_queries(seqs, cfg["nq"], cfg["qlen"], edits, cfg["seed"] + 1, iupac=cfg["q_iupac"], thres=cfg["thres"])
+    lens = [cfg["qlen"]]
+    if rng.integers(3) == 0:                       # a batch of mixed lengths: several length classes in one call
+        lens += [int(x) for x in rng.choice([24, 40, 70, 100, 130, 200, 260], size=int(rng.integers(1, 3)))]
+    lens = [min(L, max(20, min(len(s) for s in seqs) - 10)) for L in lens]
+    cfg["lens"] = lens
+    from burst_amd import synth as _synth
+    reads = []
+    for li_, L in enumerate(lens):
+        bud = T.budget(cfg["thres"], L)
+        r, _ = _synth.make_reads(seqs, max(2, cfg["nq"] // len(lens)), L, [0, 1, 2, max(0, bud), bud + 2], cfg["seed"] + 1 + li_, rc_frac=0.5, iupac_frac=cfg["q_iupac"])
+        reads += r
+    nq_ = len(reads)
+    allq = reads + [_synth.revcomp(r) for r in reads]
+    q = capi.Queries(allq, [T.budget(cfg["thres"], len(r)) for r in reads] * 2, list(range(nq_)) * 2, [0] * nq_ + [1] * nq_)
     if cfg["accel"]:
         q.flags = np.zeros(q.n, np.uint8)
     dev = capi.Device(packed, clump_len, tot, lut, **kw)
