@@ -36,8 +36,8 @@ template <int NWP> __global__ void k_myers_prefix(const uint2 *, const uint32_t 
 template <int NW> __global__ void k_myers_window(const BhipWin *, const uint32_t *, uint32_t, int, const uint32_t *, const uint32_t *, const uint64_t *,
 	const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *,
 	unsigned long long *);
-__global__ void k_extract_kmers(const uint4 *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, int, unsigned long long *, uint16_t *, uint32_t *);
-__global__ void k_attach_masks(const uint32_t *, const uint32_t *, uint64_t, uint32_t, const unsigned long long *, const uint16_t *, uint32_t, const uint32_t *, uint2 *);
+__global__ void k_extract_kmers(const uint4 *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint32_t, int, unsigned long long *, uint16_t *, uint32_t *);
+__global__ void k_attach_masks(const uint32_t *, const uint32_t *, uint64_t, uint32_t, const unsigned long long *, const uint16_t *, uint32_t, const uint32_t *, uint2 *, uint32_t, uint32_t);
 template <int HTB> __global__ void k_prefilter_mask(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *,
 	uint2 *, uint32_t *, uint32_t);
@@ -273,45 +273,65 @@ static int build_lane_masks(Handle *h, const std::vector<uint64_t> &chunk_off) {
 	std::vector<uint64_t> key_off(nC + 1);
 	key_off[0] = 0;
 	for (uint32_t c = 0; c < nC; ++c) key_off[c + 1] = key_off[c] + 16ull * h->h_clump_len[c];
-	const uint64_t n_items = key_off[nC];
-	if (n_items == 0 || n_items >= 0x7FFFFFFFull || !h->n_ent) return 0;
+	if (key_off[nC] == 0 || !h->n_ent) return 0;
+	// The (word, clump, lane) tuples of the whole database may not fit next to it (26 bytes of sort space per reference
+	// position): the clumps are processed in slices, each slice sorted and folded on its own and joined to the list entries
+	// of its clumps.  BHIP_MASK_SLICE (reference positions per slice) is the test hook for small databases.
 	size_t free_b = 0, total_b = 0;
-	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < 26.0 * (double)n_items + 10.0 * (double)h->n_ent) return 0;
-	DBuf d_koff, k0, k1, v0, v1, uk, um, nruns, tmp, amb;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+	const double after_masks = (double)free_b - 8.0 * (double)(h->n_ent + 1) - 4.0 * (double)nC - 65536.0;
+	if (after_masks <= 0) return 0;
+	uint64_t slice_items = (uint64_t)std::min<double>(2147483000.0, after_masks * 0.8 / 26.0);
+	if (const char *ev = getenv("BHIP_MASK_SLICE")) { const long long v = atoll(ev); if (v > 0) slice_items = (uint64_t)v; }
+	uint64_t biggest = 0;
+	for (uint32_t c = 0; c < nC; ++c) biggest = std::max(biggest, key_off[c + 1] - key_off[c]);
+	if (slice_items < biggest) { if ((double)biggest * 26.0 > after_masks) return 0; slice_items = biggest; }
+	DBuf d_koff, k0, k1, v0, v1, nruns, tmp, amb;
 	int rc;
-	#define BLM(x) do { if ((rc = (x))) { d_koff.release(); k0.release(); k1.release(); v0.release(); v1.release(); uk.release(); um.release(); nruns.release(); tmp.release(); amb.release(); return rc; } } while (0)
+	#define BLM(x) do { if ((rc = (x))) { d_koff.release(); k0.release(); k1.release(); v0.release(); v1.release(); nruns.release(); tmp.release(); amb.release(); return rc; } } while (0)
 	#define BLMH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { BLM(fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_))); } } while (0)
-	BLM(d_koff.reserve((nC + 1) * 8)); BLM(k0.reserve(n_items * 8)); BLM(k1.reserve(n_items * 8)); BLM(v0.reserve(n_items * 2)); BLM(v1.reserve(n_items * 2));
+	const uint64_t cap_items = std::min<uint64_t>(slice_items, key_off[nC]);
+	BLM(d_koff.reserve((nC + 1) * 8)); BLM(k0.reserve(cap_items * 8)); BLM(k1.reserve(cap_items * 8)); BLM(v0.reserve(cap_items * 2)); BLM(v1.reserve(cap_items * 2));
 	BLM(nruns.reserve(16)); BLM(h->ent_mask.reserve((h->n_ent + 1) * 8)); BLM(amb.reserve((size_t)nC * 4 + 16));
 	BLMH(hipMemsetAsync(amb.p, 0, (size_t)nC * 4, h->stream));
 	BLMH(hipMemcpyAsync(d_koff.p, key_off.data(), (nC + 1) * 8, hipMemcpyHostToDevice, h->stream));
-	hipLaunchKernelGGL(k_extract_kmers, dim3(std::min<uint32_t>((nC * 16 + 255) / 256, (uint32_t)h->n_cu * 16)), dim3(256), 0, h->stream, h->ref.as<uint4>(),
-		h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_koff.as<uint64_t>(), nC, h->K, k0.as<unsigned long long>(), v0.as<uint16_t>(), amb.as<uint32_t>());
-	BLMH(hipGetLastError());
-	size_t tb = 0;
 	const int end_bit = 2 * h->K + 24;
-	hipcub::DoubleBuffer<unsigned long long> dk(k0.as<unsigned long long>(), k1.as<unsigned long long>());
-	hipcub::DoubleBuffer<uint16_t> dv(v0.as<uint16_t>(), v1.as<uint16_t>());
-	BLMH(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (int)n_items, 0, end_bit, h->stream));
-	BLM(tmp.reserve(tb));
-	BLMH(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, dk, dv, (int)n_items, 0, end_bit, h->stream));
-	// invalid slots carry key ~0, which after masking to end_bit sorts last (all ones) -- their run is simply never looked up
-	unsigned long long *skeys = dk.Current(); uint16_t *svals = dv.Current();
-	unsigned long long *ukeys = dk.Alternate(); uint16_t *umasks = dv.Alternate();
-	size_t tb2 = 0;
-	BLMH(hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, skeys, ukeys, svals, umasks, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
-	BLM(tmp.reserve(tb2));
-	BLMH(hipcub::DeviceReduce::ReduceByKey(tmp.p, tb2, skeys, ukeys, svals, umasks, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
-	uint32_t n_unique = 0;
-	BLMH(hipMemcpyAsync(&n_unique, nruns.p, 4, hipMemcpyDeviceToHost, h->stream));
-	BLMH(hipStreamSynchronize(h->stream));
-	hipLaunchKernelGGL(k_attach_masks, dim3((uint32_t)std::min<uint64_t>((h->n_ent + 255) / 256, (uint64_t)h->n_cu * 32)), dim3(256), 0, h->stream,
-		h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->n_ent, (uint32_t)(1ull << (2 * h->K)), ukeys, umasks, n_unique, amb.as<uint32_t>(), h->ent_mask.as<uint2>());
-	BLMH(hipGetLastError());
-	BLMH(hipStreamSynchronize(h->stream));
+	uint32_t n_slices = 0;
+	for (uint32_t c0 = 0; c0 < nC;) {
+		uint32_t c1 = c0 + 1;
+		while (c1 < nC && key_off[c1 + 1] - key_off[c0] <= slice_items) ++c1;
+		const uint64_t n_items = key_off[c1] - key_off[c0];
+		++n_slices;
+		hipLaunchKernelGGL(k_extract_kmers, dim3(std::min<uint32_t>(((c1 - c0) * 16 + 255) / 256, (uint32_t)h->n_cu * 16)), dim3(256), 0, h->stream, h->ref.as<uint4>(),
+			h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_koff.as<uint64_t>(), c0, c1, h->K, k0.as<unsigned long long>(), v0.as<uint16_t>(), amb.as<uint32_t>());
+		BLMH(hipGetLastError());
+		size_t tb = 0;
+		hipcub::DoubleBuffer<unsigned long long> dk(k0.as<unsigned long long>(), k1.as<unsigned long long>());
+		hipcub::DoubleBuffer<uint16_t> dv(v0.as<uint16_t>(), v1.as<uint16_t>());
+		BLMH(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (int)n_items, 0, end_bit, h->stream));
+		BLM(tmp.reserve(tb));
+		BLMH(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, dk, dv, (int)n_items, 0, end_bit, h->stream));
+		// invalid slots carry key ~0, which after masking to end_bit sorts last (all ones) -- their run is simply never looked up
+		unsigned long long *skeys = dk.Current(); uint16_t *svals = dv.Current();
+		unsigned long long *ukeys = dk.Alternate(); uint16_t *umasks = dv.Alternate();
+		size_t tb2 = 0;
+		BLMH(hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, skeys, ukeys, svals, umasks, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
+		BLM(tmp.reserve(tb2));
+		BLMH(hipcub::DeviceReduce::ReduceByKey(tmp.p, tb2, skeys, ukeys, svals, umasks, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
+		uint32_t n_unique = 0;
+		BLMH(hipMemcpyAsync(&n_unique, nruns.p, 4, hipMemcpyDeviceToHost, h->stream));
+		BLMH(hipStreamSynchronize(h->stream));
+		hipLaunchKernelGGL(k_attach_masks, dim3((uint32_t)std::min<uint64_t>((h->n_ent + 255) / 256, (uint64_t)h->n_cu * 32)), dim3(256), 0, h->stream,
+			h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->n_ent, (uint32_t)(1ull << (2 * h->K)), ukeys, umasks, n_unique, amb.as<uint32_t>(), h->ent_mask.as<uint2>(),
+			c0, c1);
+		BLMH(hipGetLastError());
+		BLMH(hipStreamSynchronize(h->stream));
+		c0 = c1;
+	}
 	#undef BLM
 	#undef BLMH
-	d_koff.release(); k0.release(); k1.release(); v0.release(); v1.release(); uk.release(); um.release(); nruns.release(); tmp.release(); amb.release();
+	d_koff.release(); k0.release(); k1.release(); v0.release(); v1.release(); nruns.release(); tmp.release(); amb.release();
+	if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] lane masks: %llu reference positions in %u slice(s)\n", (unsigned long long)key_off[nC], n_slices);
 	h->has_masks = true;
 	return 0;
 }

@@ -553,15 +553,15 @@ __global__ __launch_bounds__(64) void k_prefilter_hash(
 // every lane, i.e. the clump-level behaviour.  Masks only ever add lanes, never drop one, so results are unchanged.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_extract_kmers(const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
-                                const uint64_t *__restrict__ key_off, uint32_t n_clumps, int K,
+                                const uint64_t *__restrict__ key_off, uint32_t c0, uint32_t c1, int K,     // clumps [c0, c1): one slice of the database
                                 unsigned long long *__restrict__ keys, uint16_t *__restrict__ vals, uint32_t *__restrict__ ambig_lanes) {
-	const uint64_t n_threads = (uint64_t)n_clumps * 16;
+	const uint64_t n_threads = (uint64_t)(c1 - c0) * 16;
 	const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_threads; i += (uint64_t)gridDim.x * blockDim.x) {
-		const uint32_t c = (uint32_t)(i >> 4), z = (uint32_t)(i & 15), L = clump_len[c], nchunks = (L + 31) >> 5;
+		const uint32_t c = c0 + (uint32_t)(i >> 4), z = (uint32_t)(i & 15), L = clump_len[c], nchunks = (L + 31) >> 5;
 		const uint4 *rp = ref + ref_off[c] * 16 + z;
-		unsigned long long *kout = keys + key_off[c] + (uint64_t)z * L;
-		uint16_t *vout = vals + key_off[c] + (uint64_t)z * L;
+		unsigned long long *kout = keys + (key_off[c] - key_off[c0]) + (uint64_t)z * L;
+		uint16_t *vout = vals + (key_off[c] - key_off[c0]) + (uint64_t)z * L;
 		uint32_t w = 0, run = 0, amb = 0;
 		for (uint32_t t = 0; t < nchunks; ++t) {
 			const uint4 ch = rp[(uint64_t)t * 16];
@@ -586,8 +586,10 @@ __global__ void k_extract_kmers(const uint4 *__restrict__ ref, const uint64_t *_
 
 __global__ void k_attach_masks(const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, uint64_t n_ent, uint32_t n_words,
                                const unsigned long long *__restrict__ ukeys, const uint16_t *__restrict__ umasks, uint32_t n_unique,
-                               const uint32_t *__restrict__ ambig_lanes, uint2 *__restrict__ ent_mask) {   // (clump, lane mask) records
+                               const uint32_t *__restrict__ ambig_lanes, uint2 *__restrict__ ent_mask,    // (clump, lane mask) records
+                               uint32_t c0, uint32_t c1) {                                                 // only entries of clumps [c0, c1)
 	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n_ent; e += (uint64_t)gridDim.x * blockDim.x) {
+		{ const uint32_t ce = acx_ent[e]; if (ce < c0 || ce >= c1) continue; }
 		// word of entry e: last w with acx_off[w] <= e
 		uint32_t lo = 0, hi = n_words;
 		while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (acx_off[mid] <= e) lo = mid; else hi = mid; }

@@ -280,3 +280,36 @@ def test_randomised_configurations():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "20", "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_lane_masks_built_in_slices():
+    """databases whose (word, clump, lane) tuples do not fit next to them get their lane masks slice by slice; forced here
+    with a slice of 5 000 reference positions (3 clumps): same tasks and records as with one slice"""
+    import subprocess
+    import sys
+    code = r'''
+import sys, os
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+import test_gpu_kernels as T, dbutil, oraclelib as ol
+from burst_amd import capi
+seqs = T.family_db(151, 9, 21, 480, rate=0.05)
+packed, clump_len, tot = dbutil.pack_clumps(seqs)
+lens, entries, offs = dbutil.build_acx(seqs, 12)
+lut = ol.score_lut(1)
+dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=dbutil.pack_acx_lists(lens, entries, 0), acx_fmt=0, K=12)
+q, _ = T.make_queries(seqs, 70, 100, [0, 1, 2, 3, 5], 153, thres=0.97)
+q.flags = np.zeros(q.n, np.uint8)
+got = dev.align_batch(q, all_hits=False)
+exp = T.oracle_hits(packed, clump_len, tot, q, lut, False)
+assert len(exp) > 40 and got.tobytes() == exp.tobytes()
+print("tasks", dev.stats()["n_lane_tasks"])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"BHIP_MASK_SLICE": "5000"}):
+        r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, BHIP_DEBUG="1", **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append((r.stdout.strip().splitlines()[-1], [ln for ln in r.stderr.splitlines() if "lane masks" in ln][-1]))
+    assert outs[0][0] == outs[1][0] and int(outs[0][0].split()[1]) > 0          # same number of lane tasks
+    assert "in 1 slice" in outs[0][1] and "in 1 slice" not in outs[1][1]
