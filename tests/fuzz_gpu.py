@@ -1,5 +1,5 @@
 """Randomised parity run on the GPU box: random small databases / read sets / options, device records vs the oracle.
-   python tools/fuzz_gpu.py [seconds] [seed]   -- exits non-zero and prints the failing configuration on the first mismatch."""
+   python tests/fuzz_gpu.py [seconds] [seed]   -- exits non-zero and prints the failing configuration on the first mismatch."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

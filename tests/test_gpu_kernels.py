@@ -273,12 +273,12 @@ def test_prefilter_overflow_paths():
 
 
 def test_randomised_configurations():
-    """a short run of tools/fuzz_gpu.py: random databases, read sets, budgets and tuning options against the oracle
+    """a short run of tests/fuzz_gpu.py: random databases, read sets, budgets and tuning options against the oracle
     (a 7-minute run of the same script, 1331 configurations / 193 k records, is the round's parity stress test)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "20", "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_gpu.py"), "20", "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-3000:]
 
 
