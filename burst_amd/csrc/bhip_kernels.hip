@@ -1643,9 +1643,12 @@ __global__ __launch_bounds__(256) void k_myers_window(
 		uint32_t fB = ((32u - (uint32_t)__builtin_clz(w.flags)) << fshift) - 1u;             // last flagged chunk
 		if (fB >= nchunks) fB = nchunks - 1;
 		const int col_lo = (int)(fA * 32 + 2) - (int)(P + E), col_hi = (int)((fB + 1) * 32 + (m - P) + E);
-		const uint32_t tA = col_lo > 1 ? (uint32_t)(col_lo - 1) >> 5 : 0u;
-		uint32_t tB = (uint32_t)(col_hi - 1) >> 5;
-		if (tB >= nchunks) tB = nchunks - 1;
+		// swept columns [c_lo, c_hi] (0-based), at a granularity of 8 (one dword of reference symbols): a fresh column state is a
+		// valid start anywhere (free start of the semi-global alignment), so nothing before the first needed column is swept
+		const uint32_t c_lo = col_lo > 1 ? (uint32_t)(col_lo - 1) : 0u;
+		uint32_t c_hi = (uint32_t)(col_hi - 1);
+		if (c_hi >= nchunks * 32) c_hi = nchunks * 32 - 1;
+		const uint32_t tA = c_lo >> 5, tB = c_hi >> 5, gA = (c_lo & 31u) >> 3, gB = (c_hi & 31u) >> 3;
 		uint32_t Pv[NW], Mv[NW];
 		#pragma unroll
 		for (int k = 0; k < NW; ++k) {
@@ -1665,27 +1668,30 @@ __global__ __launch_bounds__(256) void k_myers_window(
 		for (uint32_t t = tA; t <= tB; ++t) {
 			const uint4 ch = ch_next;
 			if (t < tB) ch_next = rp[t + 1];          // the next 16 bytes of this lane while this chunk is swept
-			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
-			#pragma unroll 8
-			for (int k = 0; k < 32; ++k) {
-				const uint32_t sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
-				uint32_t Eq[NW];
-				if (LDS_TAB && sym - 1u < 4u) {
-					#pragma unroll
-					for (int x = 0; x < NW; ++x) Eq[x] = s_tab[LDS_TAB ? (sym - 1u) * NW + x : 0][LDS_TAB ? threadIdx.x : 0];
-				} else {
-					#pragma unroll
-					for (int x = 0; x < NW; ++x) Eq[x] = tab[sym * NW + x];
+			const uint32_t g0 = t == tA ? gA : 0u, g1 = t == tB ? gB : 3u;
+			for (uint32_t gq = g0; gq <= g1; ++gq) {
+				const uint32_t d = gq == 0 ? ch.x : gq == 1 ? ch.y : gq == 2 ? ch.z : ch.w;
+				#pragma unroll
+				for (int k8 = 0; k8 < 8; ++k8) {
+					const uint32_t sym = (d >> (4 * k8)) & 15u;
+					uint32_t Eq[NW];
+					if (LDS_TAB && sym - 1u < 4u) {
+						#pragma unroll
+						for (int x = 0; x < NW; ++x) Eq[x] = s_tab[LDS_TAB ? (sym - 1u) * NW + x : 0][LDS_TAB ? threadIdx.x : 0];
+					} else {
+						#pragma unroll
+						for (int x = 0; x < NW; ++x) Eq[x] = tab[sym * NW + x];
+					}
+					myers_step<NW>(Eq, Pv, Mv, score);
+					const uint32_t col = t * 32 + gq * 8 + (uint32_t)k8 + 1;
+					const bool lt = score < bestS, le = score <= bestS;
+					bestS = lt ? score : bestS;
+					first = lt ? col : first;
+					last = le ? col : last;
 				}
-				myers_step<NW>(Eq, Pv, Mv, score);
-				const uint32_t col = t * 32 + k + 1;
-				const bool lt = score < bestS, le = score <= bestS;
-				bestS = lt ? score : bestS;
-				first = lt ? col : first;
-				last = le ? col : last;
 			}
 		}
-		my_cols += (tB - tA + 1) * 32;
+		my_cols += ((tB * 4 + gB) - (tA * 4 + gA) + 1) * 8;
 		if ((uint32_t)bestS <= E) {
 			const uint32_t pos = atomicAdd(n_raw, 1u);
 			if (pos < raw_cap) {
