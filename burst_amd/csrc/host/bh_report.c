@@ -125,7 +125,7 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 		else if (nU < 4096) nThreads = 1;
 	}
 	if (wt && suppress && mode == BH_BEST) nThreads = 1;
-	int oom = 0;
+	int oom = 0, wr = 0;
 	#define MAPPED(rix) (db->identityMap ? (rix) : db->refMap[rix])
 	#define BUILD_LIST(i, n) do { n = 0; \
 		if (merged && nE > nU) { \
@@ -182,7 +182,7 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 		}
 		if (oom) { free(start); free(count); free(RefCounts); return bh_set_error(BH_E_OOM, "OOM:report"); }
 	}
-	const uint64_t CH = nThreads > 1 ? chunkQ : (nU ? nU : 1), nChunks = (nU + CH - 1) / CH;
+	const uint64_t CH = chunkQ, nChunks = (nU + CH - 1) / CH, chunkGroup = (uint64_t)nThreads * 8;
 	char **cbuf = calloc(nChunks + 1, sizeof(*cbuf)); size_t *clen = calloc(nChunks + 1, sizeof(*clen));
 	if (!cbuf || !clen) { free(cbuf); free(clen); free(start); free(count); free(RefCounts); return bh_set_error(BH_E_OOM, "OOM:report"); }
 	#pragma omp parallel num_threads(nThreads) reduction(+:lines)
@@ -199,8 +199,12 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 		oom = 1;
 	}
 	#pragma omp barrier
+	/* groups of chunks: rendered by the team, then written and released by one thread, so that the rendered text held in
+	 * memory stays bounded however many queries there are */
+	for (uint64_t cg0 = 0; cg0 < nChunks; cg0 += chunkGroup) {
+	const uint64_t cg1 = cg0 + chunkGroup < nChunks ? cg0 + chunkGroup : nChunks;
 	#pragma omp for schedule(dynamic, 1)
-	for (uint64_t ch = 0; ch < nChunks; ++ch) {
+	for (uint64_t ch = cg0; ch < cg1; ++ch) {
 	if (oom) continue;
 	FILE *cs = open_memstream(&cbuf[ch], &clen[ch]);
 	if (!cs) {
@@ -333,12 +337,13 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 	}
 	fclose(cs);
 	}
-	free(RefCache); free(StCache); free(RIXcache); free(RPcache); free(list); free(Taxon); free(Taxa); free(Divergence);
-	}
-	int wr = 0;
-	for (uint64_t ch = 0; ch < nChunks; ++ch) {              /* chunks in query order */
+	#pragma omp single
+	for (uint64_t ch = cg0; ch < cg1; ++ch) {                /* chunks in query order */
 		if (!oom && cbuf[ch] && clen[ch] && fwrite(cbuf[ch], 1, clen[ch], real_out) != clen[ch]) wr = 1;
-		free(cbuf[ch]);
+		free(cbuf[ch]); cbuf[ch] = NULL;
+	}
+	}
+	free(RefCache); free(StCache); free(RIXcache); free(RPcache); free(list); free(Taxon); free(Taxa); free(Divergence);
 	}
 	free(cbuf); free(clen);
 	free(start); free(count); free(RefCounts);
