@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--one-stage", action="store_true", help="disable the prefix-filter stage of the edit-distance kernels")
     ap.add_argument("--lanes", type=int, default=0, help="sub-pipelines (HIP streams) per batch inside the library")
     ap.add_argument("--sweep-blocks", type=int, default=0, help="256-thread blocks per CU for the column sweep (0 = library default)")
+    ap.add_argument("--sync-d2h", action="store_true", help="copy the records to the host inside every step (default: asynchronous hand-over, the copy of step k overlaps step k+1)")
     ap.add_argument("--opt", action="append", default=[], help="library tuning option name=value (bhip_set_option), repeatable")
     ap.add_argument("--prefilter-waves", type=int, default=0, help="single-wave prefilter blocks per CU (0 = library default)")
     ap.add_argument("--prefilter-stride", type=int, default=0, help="0 = automatic sparse seeds (default), 1 = every word (reference scheme)")
@@ -142,6 +143,7 @@ def main():
         dev.set_option("sweep_blocks", args.sweep_blocks)
     if args.prefilter_waves:
         dev.set_option("prefilter_waves", args.prefilter_waves)
+    dev.set_option("async_d2h", 0 if args.sync_d2h else 1)
     for kv in args.opt:
         name, _, val = kv.partition("=")
         dev.set_option(name, int(val))
@@ -160,21 +162,27 @@ def main():
     # from the library, asynchronous, double-buffered so the xGMI transfer overlaps the next step's alignment)
     pg = None
 
+    bufs = [None, None]        # two host result buffers alternate: with the asynchronous hand-over the records of step k are
+    turn = 0                   # still arriving while step k+1 runs (every copy is complete before the clock stops)
+
     def step():
-        nonlocal buf
-        hits, buf = dev.align_staged(all_hits, buf)
+        nonlocal turn
+        hits, bufs[turn] = dev.align_staged(all_hits, bufs[turn])
+        turn ^= 1
         if pg is not None:
             n = dev.copy_hits_device(pg.payload_ptr(), pg.cap)
             pg.post(n)
         return hits, None
 
     hits0, _ = step()          # sizes the library's grow-only device buffers for this workload (setup, not a warmup step)
+    dev.sync_hits()
     if world > 1:           # same capacity on every rank: the largest shard's record count plus slack
         mx = torch.tensor([len(hits0)], dtype=torch.int64, device="cuda")
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         pg = bdist.PaddedGather(int(mx.item()) + int(mx.item()) // 8 + 4096, rank, world, torch.device("cuda", local_rank))
     for _ in range(args.warmup):
         step()
+    dev.sync_hits()
     per_step = []
     if world > 1:
         dist.barrier()
@@ -183,6 +191,7 @@ def main():
     for _ in range(args.steps):
         hits, _g = step()
         per_step.append(dev.stats())
+    dev.sync_hits()            # the last records are in host memory
     if pg is not None:
         pg.wait()
     torch.cuda.synchronize()

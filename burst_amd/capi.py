@@ -37,7 +37,7 @@ class BhipStats(C.Structure):
 
 
 EXPORTS = ["bhip_init", "bhip_stage_queries", "bhip_align_staged", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_set_option", "bhip_get_stats",
-           "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version", "bhip_copy_hits_device"]
+           "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version", "bhip_copy_hits_device", "bhip_sync_hits"]
 
 
 class BurstHipError(RuntimeError):
@@ -72,6 +72,8 @@ def _load():
     lib.bhip_device_info.restype = i32
     lib.bhip_copy_hits_device.argtypes = [vp, vp, u64, C.POINTER(u64)]
     lib.bhip_copy_hits_device.restype = i32
+    lib.bhip_sync_hits.argtypes = [vp]
+    lib.bhip_sync_hits.restype = i32
     lib.bhip_destroy.argtypes = [vp]
     lib.bhip_destroy.restype = None
     lib.bhip_last_error.argtypes = []
@@ -194,6 +196,10 @@ class Device:
                 continue
             _chk(rc)
             return hits[:n.value], hits
+
+    def sync_hits(self):
+        """with option async_d2h: wait until the records of the previous calls are in their host buffers"""
+        _chk(lib().bhip_sync_hits(self._h))
 
     def copy_hits_device(self, dst_ptr, cap_records):
         """device-to-device copy of the last call's records into caller-owned device memory (e.g. a torch tensor's data_ptr())"""

@@ -180,7 +180,7 @@ struct Handle {
 	int opt_lane_masks = 1;       // use them
 	// batch-wide buffers
 	DBuf qcodes, qoff, qemac, qsix, qrc, best, out, shared_ctr, mins, pairs;
-	DBuf sort_keys, sort_keys2, sort_idx, sort_tmp, out_sorted, qpack, plan;   // sort_keys / sort_keys2: per-query record counts / offsets; sort_idx: rank of a record inside its query
+	DBuf sort_keys, sort_keys2, sort_idx, sort_tmp, out_sorted, out_sorted2, qpack, plan;   // sort_keys / sort_keys2: per-query record counts / offsets; sort_idx: rank of a record inside its query
 	uint64_t out_cap = 1 << 20;
 	std::vector<uint32_t> h_clump_len;
 	BhipStats stats;
@@ -193,6 +193,14 @@ struct Handle {
 	int opt_prefilter_stride = 0; // 0 = automatic sparse seeds, s > 0 = every s-th word (1 = the reference's scheme)
 	int opt_lanes = 1;            // sub-pipelines per staged batch (the stage kernels fill the chip on their own; > 1 only helps small batches)
 	int opt_sweep_blocks = 8;     // 256-thread blocks per CU of the column-sweep kernels
+	// asynchronous hand-over of the records (option "async_d2h"): two device buffers alternate, the copy of call k runs on its
+	// own stream while call k+1 computes; the caller's buffers are page-locked once and stay registered
+	int opt_async_d2h = 0, out_idx = 0;
+	hipStream_t copy_stream = nullptr;
+	hipEvent_t ev_sorted = nullptr, ev_copied[2] = {nullptr, nullptr};
+	bool copy_pending[2] = {false, false};
+	void *reg_ptr[2] = {nullptr, nullptr}; size_t reg_bytes[2] = {0, 0};
+	int last_out = 0;             // which of the two sorted buffers holds the last call's records
 	uint64_t last_n_out = 0;      // records of the last bhip_align_staged call, still resident (sorted) in out_sorted
 	int opt_prune = 1;            // second sweep for lanes whose seed count bounds their edit distance above the first sweep's best
 	int opt_lane_min = 32768;     // fewest entries a sub-pipeline is worth opening for
@@ -252,7 +260,14 @@ extern "C" void bhip_destroy(void *handle) {
 	for (Lane *L : h->lanes) lane_destroy(L);
 	DBuf *all[] = {&h->ref, &h->ref_lane, &h->ref_off, &h->clump_len, &h->lut, &h->acx_off, &h->acx_ent, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
 		&h->qsix, &h->qrc, &h->best, &h->out, &h->shared_ctr, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx,
-		&h->sort_tmp, &h->out_sorted, &h->qpack, &h->plan, &h->ent_mask};
+		&h->sort_tmp, &h->out_sorted, &h->out_sorted2, &h->qpack, &h->plan, &h->ent_mask};
+	for (int o = 0; o < 2; ++o) {
+		if (h->copy_pending[o] && h->ev_copied[o]) (void)hipEventSynchronize(h->ev_copied[o]);
+		if (h->reg_ptr[o]) (void)hipHostUnregister(h->reg_ptr[o]);
+		if (h->ev_copied[o]) (void)hipEventDestroy(h->ev_copied[o]);
+	}
+	if (h->ev_sorted) (void)hipEventDestroy(h->ev_sorted);
+	if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
 	for (DBuf *b : all) b->release();
 	for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -474,6 +489,7 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 	if (!strcmp(name, "lane_masks")) { h->opt_lane_masks = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "sweep_blocks")) { if (value < 1 || value > 8) return fail(BHIP_E_ARG, "sweep_blocks must be 1 .. 8"); h->opt_sweep_blocks = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "lane_min_entries")) { if (value < 1) return fail(BHIP_E_ARG, "lane_min_entries must be >= 1"); h->opt_lane_min = (int)value; return BHIP_OK; }
+	if (!strcmp(name, "async_d2h")) { h->opt_async_d2h = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "prune")) { h->opt_prune = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "rescore_reg")) { h->opt_rescore_reg = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_waves")) { if (value < 0 || value > 16) return fail(BHIP_E_ARG, "prefilter_waves must be 0 .. 16"); h->opt_pf_waves = (int)value; return BHIP_OK; }
@@ -1125,7 +1141,12 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		if (hsc.n_out) {
 			const uint32_t n = hsc.n_out;
 			if ((rc = h->sort_idx.reserve((size_t)n * 4)) || (rc = h->sort_keys.reserve((size_t)(n_q + 1) * 4)) || (rc = h->sort_keys2.reserve((size_t)(n_q + 1) * 4)) ||
-			    (rc = h->out_sorted.reserve((size_t)n * sizeof(BhipHit)))) return rc;
+			    0) return rc;
+			const bool async = h->opt_async_d2h && hits;
+			const int o = async ? (h->out_idx ^= 1) : 0;
+			DBuf &sorted = o ? h->out_sorted2 : h->out_sorted;
+			if (h->copy_pending[o]) { HIPCHK(hipEventSynchronize(h->ev_copied[o])); h->copy_pending[o] = false; }    // the copy that last read this buffer
+			if ((rc = sorted.reserve((size_t)n * sizeof(BhipHit)))) return rc;
 			uint32_t *cnt = h->sort_keys.as<uint32_t>(), *off = h->sort_keys2.as<uint32_t>(), *rank = h->sort_idx.as<uint32_t>();
 			const uint32_t g = std::min<uint32_t>((n + 255) / 256, (uint32_t)h->n_cu * 8);
 			HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(n_q + 1) * 4, h->stream));
@@ -1134,11 +1155,35 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, off, (int)(n_q + 1), h->stream));
 			if ((rc = h->sort_tmp.reserve(tmp_bytes))) return rc;
 			HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->sort_tmp.p, tmp_bytes, cnt, off, (int)(n_q + 1), h->stream));
-			hipLaunchKernelGGL(k_hit_scatter, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, off, rank, h->out_sorted.as<BhipHit>());
-			hipLaunchKernelGGL(k_hit_fix, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, h->stream, h->out_sorted.as<BhipHit>(), off, cnt, n_q);
+			hipLaunchKernelGGL(k_hit_scatter, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, off, rank, sorted.as<BhipHit>());
+			hipLaunchKernelGGL(k_hit_fix, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, h->stream, sorted.as<BhipHit>(), off, cnt, n_q);
 			HIPCHK(hipGetLastError());
-			if (hits) HIPCHK(hipMemcpyAsync(hits, h->out_sorted.p, (size_t)n * sizeof(BhipHit), hipMemcpyDeviceToHost, h->stream));
-			h->last_n_out = n;
+			const size_t bytes = (size_t)n * sizeof(BhipHit);
+			bool queued = false;
+			if (async) {
+				// page-lock the caller's buffer (kept registered: callers alternate between two buffers), then copy on the copy stream
+				if (!h->copy_stream) { HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&h->ev_sorted, hipEventDisableTiming));
+					for (auto &e : h->ev_copied) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+				const size_t want = (size_t)cap * sizeof(BhipHit);
+				bool reg_ok = h->reg_ptr[o] == (void *)hits && h->reg_bytes[o] >= bytes;
+				if (!reg_ok) {
+					if (h->reg_ptr[o]) { (void)hipHostUnregister(h->reg_ptr[o]); h->reg_ptr[o] = nullptr; }
+					if (h->reg_ptr[o ^ 1] == (void *)hits) { if (h->copy_pending[o ^ 1]) { HIPCHK(hipEventSynchronize(h->ev_copied[o ^ 1])); h->copy_pending[o ^ 1] = false; }
+						(void)hipHostUnregister(h->reg_ptr[o ^ 1]); h->reg_ptr[o ^ 1] = nullptr; }
+					if (hipHostRegister((void *)hits, want, hipHostRegisterDefault) == hipSuccess) { h->reg_ptr[o] = (void *)hits; h->reg_bytes[o] = want; reg_ok = true; }
+					else (void)hipGetLastError();
+				}
+				if (reg_ok) {
+					HIPCHK(hipEventRecord(h->ev_sorted, h->stream));
+					HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_sorted, 0));
+					HIPCHK(hipMemcpyAsync(hits, sorted.p, bytes, hipMemcpyDeviceToHost, h->copy_stream));
+					HIPCHK(hipEventRecord(h->ev_copied[o], h->copy_stream));
+					h->copy_pending[o] = true;
+					queued = true;
+				}
+			}
+			if (hits && !queued) HIPCHK(hipMemcpyAsync(hits, sorted.p, bytes, hipMemcpyDeviceToHost, h->stream));
+			h->last_n_out = n; h->last_out = o;
 		}
 		HIPCHK(hipEventRecord(h->ev[9], h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
@@ -1277,7 +1322,17 @@ extern "C" int bhip_copy_hits_device(void *handle, void *dst_device, uint64_t ca
 	if (!dst_device) return fail(BHIP_E_ARG, "null destination");
 	if (h->last_n_out > cap_records) return fail(BHIP_E_CAPACITY, "device buffer holds %llu records, %llu needed", (unsigned long long)cap_records, (unsigned long long)h->last_n_out);
 	HIPCHK(hipSetDevice(h->device));
-	HIPCHK(hipMemcpyAsync(dst_device, h->out_sorted.p, (size_t)h->last_n_out * sizeof(BhipHit), hipMemcpyDeviceToDevice, h->stream));
+	HIPCHK(hipMemcpyAsync(dst_device, (h->last_out ? h->out_sorted2 : h->out_sorted).p, (size_t)h->last_n_out * sizeof(BhipHit), hipMemcpyDeviceToDevice, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
+	return BHIP_OK;
+}
+
+// With option "async_d2h" the records of bhip_align_staged / bhip_align_batch arrive in the caller's buffer behind the call
+// (the count is final at return); this waits for every copy still in flight.
+extern "C" int bhip_sync_hits(void *handle) {
+	Handle *h = (Handle *)handle;
+	if (!h) return fail(BHIP_E_ARG, "null handle");
+	HIPCHK(hipSetDevice(h->device));
+	for (int o = 0; o < 2; ++o) if (h->copy_pending[o]) { HIPCHK(hipEventSynchronize(h->ev_copied[o])); h->copy_pending[o] = false; }
 	return BHIP_OK;
 }

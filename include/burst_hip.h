@@ -131,6 +131,12 @@ int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64_t *q_off, 
  * e.g. the send buffer of an RCCL gather (no reference counterpart: multi-GPU).  Synchronous. */
 int bhip_copy_hits_device(void *handle, void *dst_device, uint64_t cap_records, uint64_t *n_records);
 
+/* With option "async_d2h" = 1 the records of bhip_align_staged / bhip_align_batch reach the caller's buffer BEHIND the call:
+ * *n_hits is final at return, the bytes are not until bhip_sync_hits() (or bhip_destroy).  The copy of call k then
+ * overlaps the kernels of call k+1; callers alternate between two result buffers (the library page-locks them once).
+ * No reference counterpart (the reference appends ResultPods in place, burst.c:4230-4238). */
+int bhip_sync_hits(void *handle);
+
 /* Tuning knobs.  "prefilter_stride": 0 (default) = automatic sparse seeds -- per query the largest stride s <= K for
  * which an alignment within budget still keeps >= 3 of the words starting at 0, s, 2s, ... (one edit destroys at most
  * ceil(K/s) of them), fewest .acx look-ups with the same no-false-negative guarantee; s >= 1 forces every s-th word,
@@ -144,6 +150,7 @@ int bhip_copy_hits_device(void *handle, void *dst_device, uint64_t cap_records, 
  * more than 20 % of the list records survive the filter, 0 / 1 = force one of them; "prefilter_waves": 0 (default, as many as fit) .. 16 single-wave prefilter blocks per CU.
  * "prune": 1 (default) = when only the minimum per shared slot is wanted, lanes whose seed count bounds their edit distance
  * above the query's best bound are swept only if the first sweep leaves room for them (exact: the bound is a lower bound).
+ * "async_d2h": 0 (default) / 1 = asynchronous hand-over of the records, see bhip_sync_hits.
  * "rescore_reg": 1 (default) = register-band re-scorer for narrow bands, 0 = LDS band only.
  * None of these changes a result. */
 int bhip_set_option(void *handle, const char *name, long long value);

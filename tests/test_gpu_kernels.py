@@ -313,3 +313,31 @@ print("tasks", dev.stats()["n_lane_tasks"])
         outs.append((r.stdout.strip().splitlines()[-1], [ln for ln in r.stderr.splitlines() if "lane masks" in ln][-1]))
     assert outs[0][0] == outs[1][0] and int(outs[0][0].split()[1]) > 0          # same number of lane tasks
     assert "in 1 slice" in outs[0][1] and "in 1 slice" not in outs[1][1]
+
+
+def test_asynchronous_record_handover():
+    """option async_d2h: the count is final at return, the bytes after sync_hits(); two alternating host buffers; the
+    device-resident copy (bhip_copy_hits_device) refers to the last call"""
+    from burst_amd import capi
+    seqs = family_db(161, 8, 12, 500)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lens, entries, offs = dbutil.build_acx(seqs, 12)
+    lut = ol.score_lut(1)
+    dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=dbutil.pack_acx_lists(lens, entries, 0), acx_fmt=0, K=12)
+    q, _ = make_queries(seqs, 80, 100, [0, 1, 2, 3, 5], 163, thres=0.97)
+    q.flags = np.zeros(q.n, np.uint8)
+    exp = oracle_hits(packed, clump_len, tot, q, lut, False)
+    dev.stage(q)
+    dev.set_option("async_d2h", 1)
+    bufs = [None, None]
+    views = []
+    for k in range(5):
+        h, bufs[k & 1] = dev.align_staged(False, bufs[k & 1])
+        assert len(h) == len(exp)
+        views.append(h)
+    dev.sync_hits()
+    assert views[-1].tobytes() == exp.tobytes() and views[-2].tobytes() == exp.tobytes()
+    dev.set_option("async_d2h", 0)
+    h, _ = dev.align_staged(False)
+    assert h.tobytes() == exp.tobytes()
+    dev.close()
