@@ -6,15 +6,18 @@ LLsim-style) against a Greengenes-13.8-97%-like database (3 300 base sequences x
 references / 139 Mbp, sheared at 500+113, K=12 accelerator), -m CAPITALIST -i 0.97.  Real Greengenes/RefSeq are
 not reachable offline; sizes and generators are in DESIGN.md section 5.
 
-A step = one pass of the whole hot path (k-mer prefilter -> bit-parallel edit distance -> re-scoring -> hit
-records on the host, sorted) over the batch, with the queries already resident in HBM (bhip_stage_queries) when
-the timed region starts.  N > 1: one process per GPU (torch.distributed / RCCL), the database replicated, every
-rank aligns its own shard of reads (weak scaling), then one variable-length gather of the 20-byte hit records to
-rank 0 inside the timed region.
+A step = one pass of the whole hot path (profiles -> k-mer prefilter -> two-stage bit-parallel edit distance ->
+re-scoring -> sorted hit records) over the batch, with the queries already resident in HBM (bhip_stage_queries) when
+the timed region starts.  The records of a step reach host memory through the library's asynchronous hand-over: the
+copy of step k runs while step k+1 computes, and all copies have landed before the clock stops (--sync-d2h copies
+inside every step).  N > 1: one process per GPU (torch.distributed / RCCL), the database replicated, every rank aligns
+its own shard of reads (weak scaling), and one padded gather of the 20-byte hit records per step brings them into
+rank 0's HBM inside the timed region (device to device, asynchronous, double-buffered).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_myers): algorithmic bytes per launch
-(8*ClumpLen + len/2 + 192 per (query, clump) unit) / HIP-event time of that launch.
-`cpu_baseline` is the compiled reference itself (oracle/_ref/burst12, all host cores) on a bounded sample.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel by time (at the moment the lane-resolved
+prefilter): algorithmic bytes per launch (SURVEY.md section 8d, DESIGN.md section 4) / HIP-event time of that launch;
+`roofline.per_kernel` lists the sweeps as well.  `cpu_baseline` is the compiled reference itself (oracle/_ref/burst12,
+all host cores) on a bounded sample, N = 1 only.
 """
 import argparse
 import json
