@@ -193,7 +193,7 @@ def main():
     t0 = time.time()
     for _ in range(args.steps):
         hits, _g = step()
-        per_step.append(dev.stats())
+        per_step.append(dev.stats(raw=True))
     dev.sync_hits()            # the last records are in host memory
     if pg is not None:
         pg.wait()
@@ -201,6 +201,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.time() - t0
+    per_step = [s.as_dict() for s in per_step]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

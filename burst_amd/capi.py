@@ -162,10 +162,11 @@ class Device:
     def set_option(self, name, value):
         _chk(lib().bhip_set_option(self._h, name.encode(), int(value)))
 
-    def stats(self):
+    def stats(self, raw=False):
+        """statistics of the last call (raw=True: the ctypes struct, no dict -- for timed loops)"""
         s = BhipStats()
         _chk(lib().bhip_get_stats(self._h, C.byref(s)))
-        return s.as_dict()
+        return s if raw else s.as_dict()
 
     def align_batch(self, q, all_hits=False, cap=None):
         cap = cap or max(1 << 16, 4 * q.n)
