@@ -41,7 +41,7 @@ def build_inputs(workdir, args, rank, world):
     from burst_amd import host
     os.makedirs(workdir, exist_ok=True)
     args.db_qlen = args.read_len + max(10, args.read_len // 10)
-    tag = "b%d_v%d_l%d_q%d_i%s" % (args.n_base, args.n_variants, args.ref_len, args.db_qlen, args.id)
+    tag = "b%d_v%d_l%d_q%d_i%s%s" % (args.n_base, args.n_variants, args.ref_len, args.db_qlen, args.id, "" if args.K == 12 else "_k%d" % args.K)
     refs = os.path.join(workdir, "refs_%s.fa" % tag)
     edx = os.path.join(workdir, "db_%s.edx" % tag)
     acx = os.path.join(workdir, "db_%s.acx" % tag)
@@ -49,7 +49,7 @@ def build_inputs(workdir, args, rank, world):
     if rank == 0 and not os.path.exists(done):
         t = time.time()
         host.synth_refs(refs, args.n_base, args.n_variants, args.ref_len, args.variant_rate, 7)
-        db = host.Db.from_fasta(refs, args.db_qlen, args.id, shear_len=500, K=12)
+        db = host.Db.from_fasta(refs, args.db_qlen, args.id, shear_len=500, K=args.K)
         db.write(edx, acx, db_qlen=args.db_qlen, thres=args.id)
         db.close()
         open(done, "w").write("ok")
@@ -59,7 +59,7 @@ def build_inputs(workdir, args, rank, world):
 
 def cpu_baseline(edx, acx, reads_fa, args):
     """the compiled reference on the host cores: differential timing of two sample sizes cancels its DB load time"""
-    exe = os.path.join(ROOT, "oracle", "_ref", "burst12")
+    exe = os.path.join(ROOT, "oracle", "_ref", "burst%d" % args.K)
     if args.no_cpu_baseline or not os.path.exists(exe):
         return None
     cores = os.cpu_count() or 1
@@ -80,9 +80,9 @@ def cpu_baseline(edx, acx, reads_fa, args):
         times.append(time.time() - t)
     dt = max(times[1] - times[0], 1e-6)
     return {"value": (n2 - n1) / dt, "unit": "reads/s", "cores": cores, "kind": "reference",
-            "sample": "oracle/_ref/burst12 (reference compiled with gcc -O3 -march=x86-64-v3 -fopenmp) -t %d, same .edx/.acx, "
+            "sample": "oracle/_ref/burst%d (reference compiled with gcc -O3 -march=x86-64-v3 -fopenmp) -t %d, same .edx/.acx, "
                       "-m %s -i %s; differential wall time of the first %d vs %d reads (%.2f s vs %.2f s) to cancel DB load"
-                      % (cores, args.mode, args.id, n1, n2, times[0], times[1])}
+                      % (args.K, cores, args.mode, args.id, n1, n2, times[0], times[1])}
 
 
 def main():
@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--ref-len", type=int, default=1400)
     ap.add_argument("--variant-rate", type=float, default=0.05)
     ap.add_argument("--id", type=float, default=0.97)
+    ap.add_argument("--K", type=int, default=12, choices=[12, 15], help="accelerator word length (the reference's DB12 / DB15 builds)")
     ap.add_argument("--mode", default="CAPITALIST")
     ap.add_argument("--workdir", default=os.environ.get("BURST_BENCH_DIR", "/tmp/burst_amd_bench"))
     ap.add_argument("--cpu-sample", type=int, default=600000)
@@ -135,8 +136,8 @@ def main():
         host.synth_reads(refs, reads_fa, args.reads, args.read_len, edits, rc=args.fr, iupac=args.iupac, seed=42 + rank)
 
     t = time.time()
-    db = host.Db.read(edx, acx, K=12)
-    qs = host.QuerySet(reads_fa, args.id, rc=args.fr, accel=True, K=12)
+    db = host.Db.read(edx, acx, K=args.K)
+    qs = host.QuerySet(reads_fa, args.id, rc=args.fr, accel=True, K=args.K)
     dev = db.open_device(local_rank)
     dev.set_option("prefilter_stride", args.prefilter_stride)
     dev.set_option("two_stage", 0 if args.one_stage else 1)
@@ -259,8 +260,8 @@ def main():
             "value": total_reads * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 bit-vectors (u8 edit distances)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d synthetic %d-bp reads per GPU vs GG97-like DB (%d refs x %d bp, %d clumps, K=12 .acx), -m %s -i %s"
-                                   % (args.reads, args.read_len, args.n_base * args.n_variants, args.ref_len, db.c.numRclumps, args.mode, args.id),
+            "config": {"workload": "BASELINE configs[1]: %d synthetic %d-bp reads per GPU vs GG97-like DB (%d refs x %d bp, %d clumps, K=%d .acx), -m %s -i %s"
+                                   % (args.reads, args.read_len, args.n_base * args.n_variants, args.ref_len, db.c.numRclumps, args.K, args.mode, args.id),
                        "parallelism": "query-sharded x%d, DB replicated, RCCL gather of hit records" % world,
                        "device": info["name"], "n_cu": info["n_cu"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,

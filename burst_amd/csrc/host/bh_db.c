@@ -354,7 +354,15 @@ int bh_acx_build(BhDb *db, int K, int z) {
 	/* per-clump word sets, kept to fill the lists in a second sweep */
 	uint32_t **words = calloc(nC, sizeof(*words)); uint32_t *nwords = calloc(nC, 4);
 	int oom = 0;
-	#pragma omp parallel
+	/* every thread owns a 4^K-bit "seen" map (128 MB at K = 15): bound the team so that the maps stay below ~2 GB */
+	int team = omp_get_max_threads();
+	if (K > 13 && team > 16) team = 16;
+	/* expansion estimate per window with a ambiguous symbols: 3^a (N penalised) or 4^a -- the reference's table holds
+	 * 61 for 4^3 (burst.c:3324), kept so that the same clumps land in the BadList */
+	static const uint64_t POW3[16] = {1, 3, 9, 27, 81, 243, 729, 2187, 6561, 19683, 59049, 177147, 531441, 1594323, 4782969, 14348907};
+	static const uint64_t POW4[16] = {1, 4, 16, 61, 256, 1024, 4096, 16384, 65536, 262144, 1048576, 4194304, 16777216, 67108864, 268435456, 1073741824};
+	const uint64_t *powx = z ? POW3 : POW4;
+	#pragma omp parallel num_threads(team)
 	{
 		uint8_t *seen = calloc(nw >> 3 ? nw >> 3 : 1, 1);
 		uint32_t capc = 1u << 16; uint32_t *cache = malloc((size_t)capc * 4);
@@ -373,8 +381,7 @@ int bh_acx_build(BhDb *db, int K, int z) {
 				uint32_t asum = 0;
 				for (uint32_t j = 0; j < ll; ++j) {
 					if (j >= (uint32_t)K - 1) {
-						uint64_t p = 1; for (uint32_t t = 0; t < asum; ++t) p *= z ? 3 : 4;
-						tsum += p;
+						tsum += powx[asum & 15];
 						if (lane[j - (K - 1)] > 4 + z) --asum;
 					}
 					if (lane[j] > 4 + z) ++asum;
@@ -404,15 +411,14 @@ int bh_acx_build(BhDb *db, int K, int z) {
 	}
 	if (oom) return bh_set_error(BH_E_OOM, "OOM:Accelerant.Refs");
 	uint64_t tot = 0;
-	uint64_t *offs = malloc((nw + 1) * 8);
+	uint64_t *offs = malloc((nw + 1) * 8);      /* running fill position of every word; ends as the END of its list */
+	if (!offs) return bh_set_error(BH_E_OOM, "OOM:Accelerant.Refs");
 	for (uint64_t w = 0; w < nw; ++w) { offs[w] = tot; tot += lens[w]; }
 	offs[nw] = tot;
 	uint32_t *ent = malloc((tot + 1) * 4);
-	uint64_t *fill = malloc(nw * 8);
-	if (!ent || !fill) return bh_set_error(BH_E_OOM, "OOM:Accelerant.Refs");
-	memcpy(fill, offs, nw * 8);
-	for (uint32_t c = 0; c < nC; ++c) { for (uint32_t i = 0; i < nwords[c]; ++i) ent[fill[words[c][i]]++] = c; free(words[c]); }
-	free(words); free(nwords); free(fill);
+	if (!ent) return bh_set_error(BH_E_OOM, "OOM:Accelerant.Refs");
+	for (uint32_t c = 0; c < nC; ++c) { for (uint32_t i = 0; i < nwords[c]; ++i) ent[offs[words[c][i]]++] = c; free(words[c]); }
+	free(words); free(nwords);
 	uint32_t nb = 0;
 	for (uint32_t c = 0; c < nC; ++c) nb += isBad[c];
 	uint32_t *bl = own(db, malloc(((size_t)nb + 1) * 4));
@@ -425,7 +431,9 @@ int bh_acx_build(BhDb *db, int K, int z) {
 	uint8_t *lists = own(db, malloc(bytes + 16)), *p = lists;
 	if (!lists) return bh_set_error(BH_E_OOM, "OOM:WordDump");
 	for (uint64_t w = 0; w < nw; ++w) {
-		const uint32_t *l = ent + offs[w]; uint32_t n = lens[w];
+		uint32_t n = lens[w];
+		if (!n) continue;
+		const uint32_t *l = ent + (offs[w] - n);
 		if (fmt) for (uint32_t i = 0; i < n; ++i) { p[0] = (uint8_t)l[i]; p[1] = (uint8_t)(l[i] >> 8); p[2] = (uint8_t)(l[i] >> 16); p += 3; }
 		else {
 			uint32_t i = 0;

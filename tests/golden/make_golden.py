@@ -100,6 +100,16 @@ def make_b6():
     run([BURST12, "-r", refs, "-d", "DNA", "320", "-o", edx_y, "-a", acx_y, "-s", "500", "-i", "0.95", "-t", "1", "-y"])
     assert open(edx_y, "rb").read() == open(os.path.join(HERE, "dna.edx"), "rb").read()
     shas["dna_y.acx"] = hashlib.sha256(open(acx_y, "rb").read()).hexdigest()
+    # DB15 (15-mers, 4 GiB length table): the QUICK database again with the reference compiled with -DSCOUR_N=15
+    edx15, acx15 = os.path.join(TMP, "quick15.edx"), os.path.join(TMP, "quick15.acx")
+    run([BURST12[:-2] + "15", "-r", refs, "-d", "QUICK", "320", "-o", edx15, "-a", acx15, "-s", "500", "-i", "0.95", "-t", "1"])
+    assert open(edx15, "rb").read() == open(os.path.join(HERE, "quick.edx"), "rb").read()
+    h15 = hashlib.sha256()
+    with open(acx15, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h15.update(blk)
+    shas["quick_k15.acx"] = h15.hexdigest()
+    os.remove(acx15)
     json.dump(shas, open(os.path.join(HERE, "acx.sha256"), "w"), indent=1)
     cases = []
 

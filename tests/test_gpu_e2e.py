@@ -56,3 +56,36 @@ def test_cli_error_codes(tmp_path):
     assert r.returncode == 2            # cannot open queries (burst.c:639)
     r = subprocess.run([CLI, "-r", os.path.join(gl.G, "dna.edx"), "-q", os.path.join(gl.G, "q100.fa"), "-o", out, "-m", "NOPE"], stdout=subprocess.DEVNULL)
     assert r.returncode == 1            # usage (burst.c:4966)
+
+
+def test_cli_k15_accelerator(tmp_path_factory):
+    """DB15 (burst.c:96-99, the build the reference ships for large databases): 15-mers, a 4 GiB length table.  The
+    accelerator our builder writes for the QUICK database has the sha256 of the one the reference (compiled with
+    -DSCOUR_N=15) wrote, and alignments through it give the golden outputs (which do not depend on K)."""
+    import hashlib
+    import json
+    tmp = str(tmp_path_factory.getbasetemp())
+    acx = os.path.join(tmp, "quick_k15.acx")
+    subprocess.check_call([CLI, "-r", os.path.join(gl.G, "quick.edx"), "--make-acx", acx, "-k", "15"], stdout=subprocess.DEVNULL)
+    h = hashlib.sha256()
+    with open(acx, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    assert h.hexdigest() == json.load(open(os.path.join(gl.G, "acx.sha256")))["quick_k15.acx"]
+    try:
+        for name in ("quick_q100_capitalist_fr", "quick_q292_best_fr", "quick_q100_forage"):
+            c = [x for x in gl.cases() if x["name"] == name][0]
+            ref, q, fr, z, shear = gl.case_args(c)
+            out = os.path.join(tmp, name + ".k15.out")
+            cmd = [CLI, "-r", ref, "-q", q, "-o", out, "-m", c["mode"], "-i", c["id"], "-a", acx, "-k", "15"] + gl.cli_extra(c)
+
+            def run(extra=()):
+                r = subprocess.run(cmd + list(extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                assert r.returncode == 0, r.stdout
+                assert "K=15" in r.stdout
+                return sorted(open(out, "rb").read().splitlines())
+            got = run()
+            nd = run(["--no-dupe-hunt"]) if gl.order_sensitive(c) else None
+            gl.compare(c, got, nd)
+    finally:
+        os.remove(acx)

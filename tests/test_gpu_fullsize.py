@@ -22,7 +22,7 @@ def test_one_million_reads_properties(tmp_path_factory):
     class A:
         pass
     a = A()
-    a.read_len, a.n_base, a.n_variants, a.ref_len, a.variant_rate, a.id = 100, 3300, 30, 1400, 0.05, 0.97
+    a.read_len, a.n_base, a.n_variants, a.ref_len, a.variant_rate, a.id, a.K = 100, 3300, 30, 1400, 0.05, 0.97, 12
     work = os.environ.get("BURST_BENCH_DIR", "/tmp/burst_amd_bench")
     refs, edx, acx, done = bench.build_inputs(work, a, 0, 1)
     reads = os.path.join(work, "fullsize_reads.fa")

@@ -60,3 +60,29 @@ def test_threaded_report_equals_sequential(exe, name, tmp_path, monkeypatch):
     subprocess.check_call([exe, ref, q, out, c["mode"], c["id"], str(fr), str(z), "0" if shear else "-1", "0" if c["accel"] else "1", tax, str(bs), str(strict), str(cut)])
     assert threaded == open(out, "rb").read()                 # same bytes in the same order
     gl.compare(c, sorted(threaded.splitlines()), None if not gl.order_sensitive(c) else sorted(threaded.splitlines()))
+
+
+def _sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 22), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def test_database_builders_write_the_reference_bytes(tmp_path):
+    """`-d QUICK` + shear (burst.c:1840-1858, 2109-2190, 2687-2741), dump_edb (2758-2839) and
+    make_accelerator (3304-3532).  The .edx must be byte-identical to the one the reference wrote for the same FASTA and
+    the .acx must have the sha256 of the reference's; --make-acx from the finished .edx must give the same accelerator.
+    (No device is involved in database construction.)"""
+    import json
+    cli = os.path.join(ROOT, "burst_amd", "burst_hip")
+    want = json.load(open(os.path.join(gl.G, "acx.sha256")))
+    edx, acx, acx2 = str(tmp_path / "q.edx"), str(tmp_path / "q.acx"), str(tmp_path / "q2.acx")
+    subprocess.check_call([cli, "-r", os.path.join(gl.G, "refs.fa"), "-d", "QUICK", "320", "-o", edx, "-a", acx, "-s", "500", "-i", "0.95"],
+                          stdout=subprocess.DEVNULL)
+    assert open(edx, "rb").read() == open(os.path.join(gl.G, "quick.edx"), "rb").read()
+    assert _sha256(acx) == want["quick.acx"]
+    subprocess.check_call([cli, "-r", os.path.join(gl.G, "quick.edx"), "--make-acx", acx2], stdout=subprocess.DEVNULL)
+    assert _sha256(acx2) == want["quick.acx"]
