@@ -460,3 +460,80 @@ int bh_acx_write(const BhDb *db, const char *path) {
 	if (fclose(o)) return bh_set_error(BH_E_IO, "ERROR: write failed: %s", path);
 	return BH_OK;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Database sharding (multi-GPU mode for databases that do not fit one device, burst_amd/dist.py): a view of the
+ * clumps [c0, c1) of `db` -- clump area, lengths and reference count are pointers into `db` (which must outlive the
+ * view), the accelerator is the sub-list of every word restricted to those clumps, renumbered from 0, in the .acx
+ * packing (burst.c:3501-3528) its clump count asks for.  Reference index of a slice hit + 16*c0 = index in `db`. */
+static inline uint32_t acx_entry(const uint8_t *base, int fmt, uint32_t i) {
+	if (fmt) { const uint8_t *p = base + (size_t)i * 3; return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16; }
+	const uint8_t *p = base + (size_t)(i >> 1) * 5;
+	uint64_t v = 0; memcpy(&v, p, (i & 1) ? 5 : 3);
+	return (i & 1) ? (uint32_t)(v >> 20) & 0xFFFFFu : (uint32_t)v & 0xFFFFFu;
+}
+
+int bh_db_slice(const BhDb *db, uint32_t c0, uint32_t c1, BhDb *out) {
+	if (c1 > db->numRclumps) c1 = db->numRclumps;
+	if (c0 >= c1) return bh_set_error(BH_E_USAGE, "empty database slice [%u, %u)", c0, c1);
+	memset(out, 0, sizeof *out);
+	uint64_t w0 = 0, wn = 0;
+	for (uint32_t c = 0; c < c1; ++c) { const uint64_t w = db->clumpLen[c] / 2u + (db->clumpLen[c] & 1); if (c < c0) w0 += w; else wn += w; }
+	out->rebase = db->rebase; out->xalpha = db->xalpha; out->shear = db->shear; out->maxLenR = db->maxLenR;
+	out->numRclumps = c1 - c0;
+	out->totR = (uint32_t)((16ull * c1 < db->totR ? 16ull * c1 : db->totR) - 16ull * c0);
+	out->origTotR = out->totR;
+	out->clumpLen = db->clumpLen + c0;
+	out->packed = db->packed + w0 * 16;
+	out->packedWords = wn;
+	out->identityMap = 1;                 /* header tables stay with the full database */
+	if (!db->hasAcx) return BH_OK;
+	const int K = db->K, fmtIn = db->acxFmt, fmtOut = out->numRclumps > 1048574 ? 1 : 0;
+	const uint64_t nw = 1ull << (2 * K);
+	uint32_t *lens = own(out, calloc(nw, 4));
+	uint64_t *inOff = malloc((nw + 1) * 8), *outOff = malloc((nw + 1) * 8);
+	if (!lens || !inOff || !outOff) { free(inOff); free(outOff); bh_db_free(out); return bh_set_error(BH_E_OOM, "OOM:slice"); }
+	uint64_t pos = 0;
+	for (uint64_t w = 0; w < nw; ++w) { inOff[w] = pos; const uint32_t n = db->acxLens[w]; pos += fmtIn ? (uint64_t)n * 3 : (uint64_t)(n / 2u) * 5 + (n & 1) * 3; }
+	/* a list is in the order its builder's threads filled it (ascending only for a single-threaded build): linear filter */
+	#pragma omp parallel for schedule(dynamic, 65536)
+	for (uint64_t w = 0; w < nw; ++w) {
+		const uint32_t n = db->acxLens[w];
+		const uint8_t *base = db->acxLists + inOff[w];
+		uint32_t k = 0;
+		for (uint32_t i = 0; i < n; ++i) { const uint32_t c = acx_entry(base, fmtIn, i); k += c >= c0 && c < c1; }
+		lens[w] = k;
+	}
+	uint64_t bytes = 0;
+	for (uint64_t w = 0; w < nw; ++w) { outOff[w] = bytes; const uint32_t n = lens[w]; bytes += fmtOut ? (uint64_t)n * 3 : (uint64_t)(n / 2u) * 5 + (n & 1) * 3; }
+	uint8_t *lists = own(out, malloc(bytes + 16));
+	if (!lists) { free(inOff); free(outOff); bh_db_free(out); return bh_set_error(BH_E_OOM, "OOM:slice"); }
+	#pragma omp parallel for schedule(dynamic, 65536)
+	for (uint64_t w = 0; w < nw; ++w) {
+		if (!lens[w]) continue;
+		const uint32_t n = db->acxLens[w];
+		const uint8_t *base = db->acxLists + inOff[w];
+		uint8_t *p = lists + outOff[w];
+		uint32_t k = 0, held = 0;
+		for (uint32_t i = 0; i < n; ++i) {
+			const uint32_t c = acx_entry(base, fmtIn, i);
+			if (c < c0 || c >= c1) continue;
+			const uint32_t v = c - c0;
+			if (fmtOut) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p += 3; }
+			else if (k & 1) { const uint64_t pair = (uint64_t)held | (uint64_t)v << 20; memcpy(p, &pair, 5); p += 5; }
+			else held = v;
+			++k;
+		}
+		if (!fmtOut && (k & 1)) { const uint64_t last = held; memcpy(p, &last, 3); }
+	}
+	memset(lists + bytes, 0, 16);
+	free(inOff); free(outOff);
+	uint32_t nb = 0;
+	for (uint32_t i = 0; i < db->badSz; ++i) nb += db->badList[i] >= c0 && db->badList[i] < c1;
+	uint32_t *bl = own(out, malloc(((size_t)nb + 1) * 4));
+	nb = 0;
+	for (uint32_t i = 0; i < db->badSz; ++i) if (db->badList[i] >= c0 && db->badList[i] < c1) bl[nb++] = db->badList[i] - c0;
+	out->hasAcx = 1; out->K = K; out->acxFmt = fmtOut; out->acxZ = db->acxZ;
+	out->acxLens = lens; out->acxLists = lists; out->acxListBytes = bytes; out->badList = bl; out->badSz = nb;
+	return BH_OK;
+}

@@ -64,6 +64,8 @@ int  bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_sh
 /* DB construction (tooling for tests/bench) */
 int  bh_edx_write(const BhDb *db, const char *path, long db_qlen, float thres);
 int  bh_acx_build(BhDb *db, int K, int z);
+/* view of the clumps [c0, c1) with the accelerator restricted to them (database sharding); `db` must outlive the view */
+int  bh_db_slice(const BhDb *db, uint32_t c0, uint32_t c1, BhDb *out);
 int  bh_acx_write(const BhDb *db, const char *path);
 void bh_db_free(BhDb *db);
 

@@ -61,6 +61,7 @@ def lib():
         L.bh_edx_write.argtypes = [C.POINTER(BhDb), C.c_char_p, C.c_long, C.c_float]
         L.bh_acx_build.argtypes = [C.POINTER(BhDb), C.c_int, C.c_int]
         L.bh_acx_write.argtypes = [C.POINTER(BhDb), C.c_char_p]
+        L.bh_db_slice.argtypes = [C.POINTER(BhDb), C.c_uint32, C.c_uint32, C.POINTER(BhDb)]
         L.bh_db_free.argtypes = [C.POINTER(BhDb)]
         L.bh_device_open.argtypes = [C.POINTER(BhDb), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.bh_align.argtypes = [C.c_void_p, C.POINTER(BhQueries), C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(BhRun)]
@@ -112,6 +113,15 @@ class Db:
         _chk(lib().bh_edx_write(C.byref(self.c), edx.encode(), db_qlen, thres))
         if acx:
             _chk(lib().bh_acx_write(C.byref(self.c), acx.encode()))
+
+    def slice(self, c0, c1):
+        """view of the clumps [c0, c1) with the accelerator restricted to them (bh_db_slice); reference index of a hit
+        against the slice + 16 * c0 = index in this database"""
+        d = Db()
+        _chk(lib().bh_db_slice(C.byref(self.c), c0, c1, C.byref(d.c)))
+        d._open = True
+        d._parent = self               # the view points into the parent's clump area
+        return d
 
     def open_device(self, device=0, z=1):
         h = C.c_void_p()

@@ -5,7 +5,9 @@
 
 Every rank loads the database and the queries through the C host (libburst_host.so), aligns its contiguous shard of
 unique queries with the C batch scheduler (bh_align -> libburst_hip.so), the hit records are gathered to rank 0 over
-RCCL, and rank 0 writes the .b6 with the C consolidation code.  With one process it is equivalent to burst_hip."""
+RCCL, and rank 0 writes the .b6 with the C consolidation code.  With one process it is equivalent to burst_hip.
+`--shard db` cuts the database instead of the queries (burst_amd/dist.py: one all_reduce(MIN) of the per-query minimum
+before the gather) for databases that do not fit one device."""
 import argparse
 import ctypes as C
 import os
@@ -27,6 +29,9 @@ def main(argv=None):
     ap.add_argument("-y", "--nwildcard", action="store_true")
     ap.add_argument("-k", type=int, default=12, choices=[12, 15])
     ap.add_argument("--batch", type=int, default=1 << 18)
+    ap.add_argument("--shard", default="queries", choices=["queries", "db"],
+                    help="queries: database replicated, every rank aligns its range of queries (default); db: every rank holds a "
+                         "range of the database's clumps and aligns all queries (for databases larger than one device)")
     args = ap.parse_args(argv)
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     import torch
@@ -38,8 +43,13 @@ def main(argv=None):
     z = 0 if args.nwildcard else 1
     db = host.Db.read(args.references, args.accelerator, K=args.k, z=z)
     qs = host.QuerySet(args.queries, args.id, rc=args.forwardreverse, accel=bool(args.accelerator), K=args.k, z=z)
-    dev = db.open_device(local_rank, z)
     L = host.lib()
+    c0 = 0
+    part = db
+    if args.shard == "db" and world > 1:
+        c0, c1 = bdist.clump_shard_range(host._view(db.c.clumpLen, db.c.numRclumps, np.uint32), world, rank)
+        part = db.slice(c0, c1) if c1 > c0 else None
+    dev = part.open_device(local_rank, z) if part is not None else None
 
     def align_range(u0, u1):
         run = host.BhRun()
@@ -48,8 +58,16 @@ def main(argv=None):
         out = np.ctypeslib.as_array(C.cast(run.hits, C.POINTER(C.c_uint8)), shape=(n * 20,)).view(capi.HIT_DTYPE).copy() if n else np.zeros(0, capi.HIT_DTYPE)
         L.bh_run_free(C.byref(run))
         return out
+    def align_slice(_c0, _c1):
+        h = align_range(0, qs.n_uniq)
+        h["refIx"] += np.uint32(16 * c0)
+        return h
     t0 = time.time()
-    hits = bdist.run_sharded(qs.n_uniq, align_range, rank, world, "cuda" if world > 1 else "cpu")
+    if args.shard == "db" and world > 1:
+        hits = bdist.run_db_sharded(host._view(db.c.clumpLen, db.c.numRclumps, np.uint32), host._view(qs.c.six, qs.n_entries, np.uint32),
+                                    qs.n_uniq, align_slice, rank, world, "cuda", args.mode == "FORAGE")
+    else:
+        hits = bdist.run_sharded(qs.n_uniq, align_range, rank, world, "cuda" if world > 1 else "cpu")
     if rank == 0:
         n = host.report(args.output, db, qs, hits, args.mode, 0 if args.accelerator else host.REP_MERGED_LIST)
         print("rank 0: %d hit records from %d rank(s) in %.3f s, %d alignments written" % (len(hits), world, time.time() - t0, n))

@@ -102,3 +102,77 @@ def test_padded_gather_two_ranks(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29519", str(w), gl.ROOT], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.count("ok") == 2, r.stdout[-3000:]
+
+
+DB_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch.distributed as dist
+from burst_amd import capi, dist as bdist, host
+import oraclelib as ol
+edx, qfa, out, mode, ident, fr = sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], float(sys.argv[6]), int(sys.argv[7])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+db = host.Db.read(edx)
+qs = host.QuerySet(qfa, ident, rc=bool(fr), accel=False)
+lut = ol.score_lut(1)
+q = qs.batch()
+def align_slice(c0, c1):
+    part = db.slice(c0, c1)
+    cl = host._view(part.c.clumpLen, part.c.numRclumps, np.uint32)
+    pk = host._view(part.c.packed, part.c.packedWords * 16, np.uint8)
+    h = ol.search(pk, cl, part.c.totR, q.codes, q.off, q.emac.astype(np.uint32), q.six, q.rc, q.n_shared, lut, mode == "FORAGE")
+    h = h.view(capi.HIT_DTYPE).copy()
+    h["q"] = q.entry_index[h["q"]].astype(np.uint32)
+    h["refIx"] += np.uint32(16 * c0)
+    return h
+hits = bdist.run_db_sharded(host._view(db.c.clumpLen, db.c.numRclumps, np.uint32), host._view(qs.c.six, qs.n_entries, np.uint32), qs.n_uniq,
+                            align_slice, rank, world, "cpu", mode == "FORAGE")
+if rank == 0:
+    host.report(out, db, qs, hits, mode, host.REP_MERGED_LIST)
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("name", ["dna_q100_capitalist_noacx_t1_fr", "dna_q292_forage_noacx_t1_fr"])
+def test_two_rank_database_sharding_matches_reference(name, tmp_path):
+    """the second multi-GPU mode: the DATABASE is cut (bh_db_slice), every rank searches all queries in its clumps (oracle in
+    place of the device), one all_reduce(MIN) of the per-query minimum decides which records survive, then the gather"""
+    c = [x for x in gl.cases() if x["name"] == name][0]
+    ref, q, fr, z, shear = gl.case_args(c)
+    out = str(tmp_path / "o.b6")
+    w = tmp_path / "db_worker.py"
+    w.write_text(DB_WORKER)
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29521", str(w), gl.ROOT, ref, q, out, c["mode"], c["id"], str(fr)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert sorted(open(out, "rb").read().splitlines()) == gl.golden_lines(c)
+
+
+def test_database_slice_accelerator_equals_rebuilt():
+    """bh_db_slice restricts every accelerator list to the slice's clumps: the result must be the accelerator bh_acx_build
+    makes for the slice alone (same lengths, same packed lists, same BadList), and the slices partition the entries"""
+    import ctypes as C
+    import numpy as np
+    from burst_amd import dist as bdist, host
+    db = host.Db.read(os.path.join(gl.G, "dna.edx"))
+    host._chk(host.lib().bh_acx_build(C.byref(db.c), 12, 1))
+    plain = host.Db.read(os.path.join(gl.G, "dna.edx"))
+    cl = host._view(db.c.clumpLen, db.c.numRclumps, np.uint32)
+    total = 0
+    for world in (1, 3):
+        total = 0
+        for rank in range(world):
+            c0, c1 = bdist.clump_shard_range(cl, world, rank)
+            a = db.slice(c0, c1)
+            b = plain.slice(c0, c1)
+            host._chk(host.lib().bh_acx_build(C.byref(b.c), 12, 1))
+            la, lb = host._view(a.c.acxLens, 1 << 24, np.uint32), host._view(b.c.acxLens, 1 << 24, np.uint32)
+            assert (la == lb).all() and a.c.acxListBytes == b.c.acxListBytes and a.c.acxFmt == b.c.acxFmt
+            assert host._view(a.c.acxLists, a.c.acxListBytes, np.uint8).tobytes() == host._view(b.c.acxLists, b.c.acxListBytes, np.uint8).tobytes()
+            assert a.c.badSz == b.c.badSz and a.c.totR == min(db.c.totR, 16 * c1) - 16 * c0
+            total += int(la.sum(dtype=np.uint64))
+        assert total == int(host._view(db.c.acxLens, 1 << 24, np.uint32).sum(dtype=np.uint64))

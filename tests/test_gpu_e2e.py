@@ -89,3 +89,43 @@ def test_cli_k15_accelerator(tmp_path_factory):
             gl.compare(c, got, nd)
     finally:
         os.remove(acx)
+
+
+@pytest.mark.parametrize("mode,ident", [("ALLPATHS", 0.95), ("FORAGE", 0.95), ("BEST", 0.97)])
+def test_database_shards_on_one_device_equal_whole(mode, ident):
+    """database sharding (burst_amd.run --shard db) without a second GPU: the clump ranges three ranks would hold are
+    searched one after the other through the device path (bh_db_slice -> bhip_init -> bh_align), the per-query minimum is
+    combined as the all_reduce would, and the surviving records must be byte-identical to the whole database's"""
+    import ctypes as C
+    import numpy as np
+    from burst_amd import capi, dist as bdist, host
+    db = host.Db.read(os.path.join(gl.G, "dna.edx"))
+    host._chk(host.lib().bh_acx_build(C.byref(db.c), 12, 1))
+    qs = host.QuerySet(os.path.join(gl.G, "q100.fa"), ident, rc=True, accel=True, K=12)
+    L = host.lib()
+
+    def search(part):
+        dev = part.open_device(0, 1)
+        run = host.BhRun()
+        host._chk(L.bh_align(dev._h, C.byref(qs.c), 0, qs.n_uniq, host.MODES[mode], 1 << 18, C.byref(run)))
+        n = int(run.nHits)
+        out = np.ctypeslib.as_array(C.cast(run.hits, C.POINTER(C.c_uint8)), shape=(n * 20,)).view(capi.HIT_DTYPE).copy() if n else np.zeros(0, capi.HIT_DTYPE)
+        L.bh_run_free(C.byref(run))
+        dev.close()
+        return out
+    whole = search(db)
+    assert len(whole) > 100
+    cl = host._view(db.c.clumpLen, db.c.numRclumps, np.uint32)
+    six = host._view(qs.c.six, qs.n_entries, np.uint32)
+    parts = []
+    for rank in range(3):
+        c0, c1 = bdist.clump_shard_range(cl, 3, rank)
+        h = search(db.slice(c0, c1))
+        h["refIx"] += np.uint32(16 * c0)
+        parts.append(h)
+    if mode != "FORAGE":
+        gmin = np.minimum.reduce([bdist.local_minimum(h, six, qs.n_uniq) for h in parts])
+        parts = [bdist.filter_minimum(h, six, gmin) for h in parts]
+    got = np.concatenate(parts)
+    got = got[np.lexsort((got["refIx"], got["q"]))]
+    assert got.tobytes() == whole[np.lexsort((whole["refIx"], whole["q"]))].tobytes()
