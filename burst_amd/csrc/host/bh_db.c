@@ -181,6 +181,9 @@ static int tux_seq_cmp(const void *a, const void *b) {
 	return A->ix < B->ix ? -1 : (A->ix > B->ix);
 }
 
+static uint32_t g_latency = 16;
+void bh_set_latency(uint32_t bases) { g_latency = bases; }
+
 int bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_shear, long shear_len, int dedupe, BhDb *db) {
 	memset(db, 0, sizeof *db);
 	RefRec *R = NULL; uint32_t nR = 0; char *dump = NULL;
@@ -215,20 +218,24 @@ int bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_she
 		head = malloc((size_t)totR * sizeof(*head)); seq = malloc((size_t)totR * sizeof(*seq)); len = malloc((size_t)totR * 4);
 		for (uint32_t i = 0; i < nR; ++i) head[i] = R[i].head, seq[i] = R[i].seq, len[i] = R[i].len;
 	}
-	/* order: by length, then lexicographically inside pods whose lengths differ by at most LATENCY = 16 (burst.c:2149-2186) */
-	Tux *T = malloc((size_t)totR * sizeof(*T));
-	for (uint32_t i = 0; i < totR; ++i) T[i].s = seq[i], T[i].len = len[i], T[i].ix = i;
-	qsort(T, totR, sizeof(*T), tux_len_cmp);
-	uint32_t maxLenR = T[totR - 1].len;
-	for (uint32_t i = 1, prev = 0, tol = T[0].len; i <= totR; ++i) {
-		if (i == totR || T[i].len > tol + 16) {
-			if (i - prev > 1) qsort(T + prev, i - prev, sizeof(*T), tux_seq_cmp);
-			prev = i; if (i < totR) tol = T[i].len;
-		}
-	}
+	/* order: by length, then lexicographically inside pods whose lengths differ by at most LATENCY (default 16, `-l`)
+	 * (burst.c:2149-2186); `-l 0` keeps the input order (2187-2189) */
 	uint32_t *srt = own(db, malloc(((size_t)totR + 1) * 4));
-	for (uint32_t i = 0; i < totR; ++i) srt[i] = T[i].ix;
-	free(T);
+	uint32_t maxLenR = 0;
+	if (g_latency) {
+		Tux *T = malloc((size_t)totR * sizeof(*T));
+		for (uint32_t i = 0; i < totR; ++i) T[i].s = seq[i], T[i].len = len[i], T[i].ix = i;
+		qsort(T, totR, sizeof(*T), tux_len_cmp);
+		maxLenR = T[totR - 1].len;
+		for (uint32_t i = 1, prev = 0, tol = T[0].len; i <= totR; ++i) {
+			if (i == totR || T[i].len > tol + g_latency) {
+				if (i - prev > 1) qsort(T + prev, i - prev, sizeof(*T), tux_seq_cmp);
+				prev = i; if (i < totR) tol = T[i].len;
+			}
+		}
+		for (uint32_t i = 0; i < totR; ++i) srt[i] = T[i].ix;
+		free(T);
+	} else for (uint32_t i = 0; i < totR; ++i) { srt[i] = i; if (len[i] > maxLenR) maxLenR = len[i]; }
 	db->origTotR = totR; db->tmpRIX = srt; db->refIxSrt = srt; db->totR = totR;
 	if (dedupe) {                                                /* burst.c:2192-2230 */
 		uint32_t *dd = own(db, calloc((size_t)totR + 2, 4)), uix = 0;

@@ -63,6 +63,8 @@ int  bh_acx_read(const char *path, int K, int z, BhDb *db);
 int  bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_shear, long shear_len, int dedupe, BhDb *db);
 /* DB construction (tooling for tests/bench) */
 int  bh_edx_write(const BhDb *db, const char *path, long db_qlen, float thres);
+/* clump formation tolerance of bh_db_from_fasta, the reference's `-l` (LATENCY, burst.c:83): default 16, 0 = input order */
+void bh_set_latency(uint32_t bases);
 int  bh_acx_build(BhDb *db, int K, int z);
 /* view of the clumps [c0, c1) with the accelerator restricted to them (database sharding); `db` must outlive the view */
 int  bh_db_slice(const BhDb *db, uint32_t c0, uint32_t c1, BhDb *out);

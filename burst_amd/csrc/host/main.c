@@ -64,6 +64,7 @@ int main(int argc, char **argv) {
 			if (i + 1 != argc && argv[i + 1][0] != '-' && !atol(argv[i + 1])) {
 				++i;
 				if (strcmp(argv[i], "DNA") && strcmp(argv[i], "RNA") && strcmp(argv[i], "QUICK")) { printf("Unsupported makedb mode '%s'\n", argv[i]); return 1; }
+				if (strcmp(argv[i], "QUICK")) printf(" --> NOTE: -d %s: the compressive clustering of the reference's builder is not included; the database is laid out as -d QUICK (same alignments, less compact)\n", argv[i]);
 			}
 			if (i + 1 != argc && argv[i + 1][0] != '-') { db_qlen = atol(argv[++i]); if (db_qlen <= 0) { fprintf(stderr, "ERROR: bad max query length '%s'\n", argv[i]); return 1; } }
 		}
@@ -108,6 +109,18 @@ int main(int argc, char **argv) {
 				else { fprintf(stderr, "ERROR: Unrecognized taxasuppress '%s'\n", argv[i]); return 1; }
 			}
 			printf(" --> Surpressing taxonomic specificity by alignment identity%s\n", txo.strict ? " [STRICT]" : "");
+		}
+		else if (!strcmp(a, "--cache") || !strcmp(a, "-c")) {                           /* burst.c:5079-5084 */
+			if (++i == argc || argv[i][0] == '-') { puts("ERROR: --cache requires integer argument"); return 1; }
+			printf(" --> Cached matrix lines (%d) are a CPU-side optimisation; ignored on the device path\n", atoi(argv[i]));
+		}
+		else if (!strcmp(a, "--latency") || !strcmp(a, "-l")) {                         /* burst.c:5085-5090 */
+			if (++i == argc || argv[i][0] == '-') { puts("ERROR: --latency requires integer argument"); return 1; }
+			bh_set_latency((uint32_t)atoi(argv[i]));
+			printf(" --> Setting clump formation latency to %d bases\n", atoi(argv[i]));
+		}
+		else if (!strcmp(a, "--clustradius") || !strcmp(a, "-cr") || !strcmp(a, "--dbpartition") || !strcmp(a, "-dp")) {
+			printf("ERROR: option %s belongs to the compressive (-d DNA/RNA) database builder, which burst_hip does not include; use -d QUICK\n", a); return 1;
 		}
 		else if (!strcmp(a, "--fingerprint") || !strcmp(a, "-f") || !strcmp(a, "--prepass") ||
 		         !strcmp(a, "-p") || !strcmp(a, "--xalphabet") || !strcmp(a, "-x") || !strcmp(a, "--heuristic") || !strcmp(a, "-hr")) {

@@ -5,7 +5,8 @@ from /root/reference).  Run in the build container only:  python tests/golden/ma
 Outputs (small, data only -- no reference source or binaries):
   refs.fa, q100.fa, q292.fa          seeded synthetic inputs (burst_amd.synth)
   dna.edx, quick.edx                 databases written by the reference (`-d DNA 320 -s 500`, `-d QUICK 320 -s 500`)
-  acx.sha256                         sha256 of the .acx files the reference wrote (64 MiB each, not committed)
+  acx.sha256                         sha256 of the .acx files the reference wrote (64 MiB / 4 GiB each, not committed) and of
+                                     the QUICK .edx it wrote with -l 0 / -l 40
   *.b6                               sorted reference outputs, one per (db, queries, mode, flags) case; cases.json lists them
   kernel_vectors.npz                 (clump, query, budget) -> MinA, MetaPack from the reference's own kernels
 """
@@ -110,6 +111,11 @@ def make_b6():
             h15.update(blk)
     shas["quick_k15.acx"] = h15.hexdigest()
     os.remove(acx15)
+    # clump formation tolerance -l (LATENCY): 0 = input order, 40 = wider pods than the default 16
+    for lat in (0, 40):
+        e = os.path.join(TMP, "quick_l%d.edx" % lat)
+        run([BURST12, "-r", refs, "-d", "QUICK", "320", "-o", e, "-s", "500", "-i", "0.95", "-t", "1", "-l", str(lat)])
+        shas["quick_l%d.edx" % lat] = hashlib.sha256(open(e, "rb").read()).hexdigest()
     json.dump(shas, open(os.path.join(HERE, "acx.sha256"), "w"), indent=1)
     cases = []
 

@@ -86,3 +86,7 @@ def test_database_builders_write_the_reference_bytes(tmp_path):
     assert _sha256(acx) == want["quick.acx"]
     subprocess.check_call([cli, "-r", os.path.join(gl.G, "quick.edx"), "--make-acx", acx2], stdout=subprocess.DEVNULL)
     assert _sha256(acx2) == want["quick.acx"]
+    for lat in (0, 40):                # clump formation tolerance -l (burst.c:83, 2149-2189)
+        subprocess.check_call([cli, "-r", os.path.join(gl.G, "refs.fa"), "-d", "QUICK", "320", "-o", edx, "-s", "500", "-i", "0.95", "-l", str(lat)],
+                              stdout=subprocess.DEVNULL)
+        assert _sha256(edx) == want["quick_l%d.edx" % lat]
