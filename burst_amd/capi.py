@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libburst_hip.so")
 
-BHIP_OK, BHIP_E_ARG, BHIP_E_DEVICE, BHIP_E_CAPACITY, BHIP_E_QUERYLEN, BHIP_E_INTERNAL = 0, -1, -2, -3, -4, -5
+BHIP_OK, BHIP_E_ARG, BHIP_E_DEVICE, BHIP_E_CAPACITY, BHIP_E_QUERYLEN, BHIP_E_INTERNAL, BHIP_E_RESCORE = 0, -1, -2, -3, -4, -5, -6
 BHIP_Q_PREFILTER, BHIP_Q_EXHAUSTIVE = 0, 1
 BHIP_MAX_QLEN = 1024
 

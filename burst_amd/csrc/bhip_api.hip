@@ -68,6 +68,19 @@ __global__ void k_hit_scatter(const BhipHit *__restrict__ in, uint32_t n, const 
                               BhipHit *__restrict__ out) {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const BhipHit h = in[i]; out[off[h.q] + rank[i]] = h; }
 }
+// Batches with query symbols of code 0 (see Handle::qcodes_s): the sweeps ran on the queries without those symbols; every
+// such symbol costs exactly one edit more (it can only face a gap), so its count goes onto the raw hits and onto the
+// running minima before the re-scorer -- which sees the original queries -- takes over.
+__global__ void k_junk_adjust_raw(BhipRawHit *__restrict__ raw, const uint32_t *__restrict__ n_raw_dev, uint32_t raw_cap, const uint8_t *__restrict__ nx) {
+	uint32_t n = *n_raw_dev;
+	if (n > raw_cap) n = raw_cap;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) raw[i].ed += nx[raw[i].q];
+}
+__global__ void k_junk_adjust_best(uint32_t *__restrict__ best, const uint8_t *__restrict__ nx_six, uint32_t s0, uint32_t s1) {
+	for (uint32_t s = s0 + blockIdx.x * blockDim.x + threadIdx.x; s < s1; s += gridDim.x * blockDim.x)
+		if (nx_six[s] && best[s] != 0xFFFFFFFFu) best[s] += nx_six[s];
+}
+
 __global__ void k_hit_fix(BhipHit *__restrict__ out, const uint32_t *__restrict__ off, const uint32_t *__restrict__ cnt, uint32_t n_q) {
 	for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_q; q += gridDim.x * blockDim.x) {
 		const uint32_t n = cnt[q];
@@ -180,6 +193,18 @@ struct Handle {
 	int opt_lane_masks = 1;       // use them
 	// batch-wide buffers
 	DBuf qcodes, qoff, qemac, qsix, qrc, best, out, shared_ctr, mins, pairs;
+	// Query symbols with code 0 (anything outside the IUPAC nucleotide alphabet) cost 255 against every reference symbol
+	// (burst.c:170-190): such a symbol can only be aligned opposite a gap, so the edit distance of the query is
+	// (number of such symbols) + edit distance of the query without them, end columns unchanged.  When a staged batch
+	// holds any, the SEARCH kernels (seeds, prefilter, profiles, sweeps) work on a second view of the batch with those
+	// symbols removed and the budgets reduced; k_junk_adjust adds the counts back before the re-scorer, which works on
+	// the original queries with the real cost table.  Without such symbols the search view is the batch itself.
+	DBuf qcodes_s, qoff_s, qemac_s, qpack_s, nx, nx_six;
+	bool st_has_junk = false;
+	const uint8_t *s_codes() const { return st_has_junk ? qcodes_s.as<uint8_t>() : qcodes.as<uint8_t>(); }
+	const uint64_t *s_off() const { return st_has_junk ? qoff_s.as<uint64_t>() : qoff.as<uint64_t>(); }
+	const uint16_t *s_emac() const { return st_has_junk ? qemac_s.as<uint16_t>() : qemac.as<uint16_t>(); }
+	const uint32_t *s_pack() const { return st_has_junk ? qpack_s.as<uint32_t>() : qpack.as<uint32_t>(); }
 	DBuf sort_keys, sort_keys2, sort_idx, sort_tmp, out_sorted, out_sorted2, qpack, plan;   // sort_keys / sort_keys2: per-query record counts / offsets; sort_idx: rank of a record inside its query
 	uint64_t out_cap = 1 << 20;
 	std::vector<uint32_t> h_clump_len;
@@ -260,7 +285,7 @@ extern "C" void bhip_destroy(void *handle) {
 	for (Lane *L : h->lanes) lane_destroy(L);
 	DBuf *all[] = {&h->ref, &h->ref_lane, &h->ref_off, &h->clump_len, &h->lut, &h->acx_off, &h->acx_ent, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
 		&h->qsix, &h->qrc, &h->best, &h->out, &h->shared_ctr, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx,
-		&h->sort_tmp, &h->out_sorted, &h->out_sorted2, &h->qpack, &h->plan, &h->ent_mask};
+		&h->sort_tmp, &h->out_sorted, &h->out_sorted2, &h->qpack, &h->plan, &h->ent_mask, &h->qcodes_s, &h->qoff_s, &h->qemac_s, &h->qpack_s, &h->nx, &h->nx_six};
 	for (int o = 0; o < 2; ++o) {
 		if (h->copy_pending[o] && h->ev_copied[o]) (void)hipEventSynchronize(h->ev_copied[o]);
 		if (h->reg_ptr[o]) (void)hipHostUnregister(h->reg_ptr[o]);
@@ -514,7 +539,7 @@ static void launch_myers(Handle *h, Lane *L, hipStream_t st, int cls, uint32_t g
 		uint64_t n_pairs_host, uint32_t li_base, const uint32_t *qlist, BhipRawHit *raw, uint32_t *n_raw, uint32_t raw_cap, uint32_t *best,
 		uint8_t *mins, Counters *dc) {
 	#define LM(N) hipLaunchKernelGGL(k_myers<N>, dim3(grid), dim3(256), 0, st, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist, \
-		L->peq.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), (best && h->st_has_six) ? h->qsix.as<uint32_t>() : nullptr, \
+		L->peq.as<uint32_t>(), h->s_off(), h->s_emac(), (best && h->st_has_six) ? h->qsix.as<uint32_t>() : nullptr, \
 		h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->tot_refs, raw, n_raw, raw_cap, best, mins, &dc->col_sum, &dc->qlen_sum)
 	switch (kClasses[cls]) { case 2: LM(2); break; case 4: LM(4); break; case 6: LM(6); break; case 8: LM(8); break; case 10: LM(10); break;
 		case 16: LM(16); break; default: LM(32); break; }
@@ -523,7 +548,7 @@ static void launch_myers(Handle *h, Lane *L, hipStream_t st, int cls, uint32_t g
 static void launch_prefix(Handle *h, Lane *L, hipStream_t st, int NWP, uint32_t grid, const uint2 *pairs, const uint32_t *n_pairs_dev,
 		uint64_t n_pairs_host, uint32_t li_base, const uint32_t *qlist, uint32_t *n_wins, Counters *dc) {
 	#define LP(N) hipLaunchKernelGGL(k_myers_prefix<N>, dim3(grid), dim3(256), 0, st, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist, \
-		L->peqp.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
+		L->peqp.as<uint32_t>(), h->s_off(), h->s_emac(), h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
 		h->tot_refs, L->wins.as<BhipWin>(), n_wins, (uint32_t)L->win_cap, &dc->col_sum, &dc->qlen_sum)
 	if (NWP == 1) LP(1); else if (NWP == 2) LP(2); else if (NWP == 3) LP(3); else if (NWP == 4) LP(4); else LP(6);
 	#undef LP
@@ -531,7 +556,7 @@ static void launch_prefix(Handle *h, Lane *L, hipStream_t st, int NWP, uint32_t 
 static void launch_prefix_task(Handle *h, Lane *L, hipStream_t st, int NWP, uint32_t grid, const uint2 *tasks, const uint32_t *n_tasks_dev, const uint32_t *qlist,
 		BhipWin *wins, uint32_t *n_wins, Counters *dc) {
 	#define LT(N) hipLaunchKernelGGL(k_myers_prefix_task<N>, dim3(grid), dim3(64), 0, st, tasks, n_tasks_dev, (uint32_t)L->task_cap, qlist, \
-		L->peqp.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
+		L->peqp.as<uint32_t>(), h->s_off(), h->s_emac(), h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
 		wins, n_wins, (uint32_t)L->win_cap, &dc->tcol_sum)
 	if (NWP == 1) LT(1); else if (NWP == 2) LT(2); else if (NWP == 3) LT(3); else if (NWP == 4) LT(4); else LT(6);
 	#undef LT
@@ -554,7 +579,7 @@ static void launch_window(Handle *h, Lane *L, hipStream_t wst, int cls, int NWP,
 	#define LW(N) { const uint32_t thr = (N) <= 8 ? 64u : 256u;      /* NW <= 8: per-thread A/C/G/T profile rows in LDS, 64-thread blocks */ \
 		const uint32_t grid = std::min<uint32_t>(grid_cap * (256u / thr), (uint32_t)h->n_cu * blocks_per_cu((const void *)k_myers_window<N>, thr, 0)); \
 		hipLaunchKernelGGL(k_myers_window<N>, dim3(grid), dim3(thr), 0, wst, wins, n_wins, (uint32_t)L->win_cap, NWP, qlist, \
-		L->peq.as<uint32_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(), h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->ref_lane.as<uint4>(), \
+		L->peq.as<uint32_t>(), h->s_off(), h->s_emac(), h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->ref_lane.as<uint4>(), \
 		h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), &dc->wcol_sum); }
 	switch (kClasses[cls]) { case 2: LW(2); break; case 4: LW(4); break; case 6: LW(6); break; case 8: LW(8); break; case 10: LW(10); break;
 		case 16: LW(16); break; default: LW(32); break; }
@@ -597,6 +622,7 @@ static int upload_queries(Handle *h, const uint8_t *q_codes, const uint64_t *q_o
                           const uint32_t *q_six, const uint8_t *q_rc, uint32_t n_q) {
 	const uint64_t nb = q_off[n_q];
 	int rc;
+	h->st_has_junk = false;      // bhip_stage_queries builds the search view after this upload when the batch needs one
 	h->st_maxlen = 0; h->st_maxE = 0;
 	for (uint32_t i = 0; i < n_q; ++i) {
 		h->st_maxlen = std::max<uint32_t>(h->st_maxlen, (uint32_t)(q_off[i + 1] - q_off[i]));
@@ -638,7 +664,7 @@ static int launch_prefilter(Handle *h, Lane *L, hipStream_t pf_st, const uint32_
 	{
 		const uint32_t n_quads = (n_list + 3) / 4;
 		const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * 6);
-		hipLaunchKernelGGL(k_prefilter_hash, dim3(grid), dim3(64), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), h->qemac.as<uint16_t>(),
+		hipLaunchKernelGGL(k_prefilter_hash, dim3(grid), dim3(64), 0, st, h->s_codes(), h->s_off(), h->s_emac(),
 			d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read,
 			plan, L->fb_list.as<uint32_t>(), &dc->n_fb);
 		HIPCHK(hipGetLastError());
@@ -650,18 +676,18 @@ static int launch_prefilter(Handle *h, Lane *L, hipStream_t pf_st, const uint32_
 	if (lds_w <= 64 * 1024) {
 		const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / lds_w));
 		const uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * per_cu);
-		if (narrow) hipLaunchKernelGGL(k_prefilter_wave<uint8_t>, dim3(grid), dim3(64), lds_w, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
+		if (narrow) hipLaunchKernelGGL(k_prefilter_wave<uint8_t>, dim3(grid), dim3(64), lds_w, st, h->s_codes(), h->s_off(),
+			h->s_emac(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
 			n_cand_dev, cand_cap, &dc->ent_read, plan, L->fb_list.as<uint32_t>(), &dc->n_fb);
-		else hipLaunchKernelGGL(k_prefilter_wave<uint16_t>, dim3(grid), dim3(64), lds_w, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
+		else hipLaunchKernelGGL(k_prefilter_wave<uint16_t>, dim3(grid), dim3(64), lds_w, st, h->s_codes(), h->s_off(),
+			h->s_emac(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
 			n_cand_dev, cand_cap, &dc->ent_read, plan, L->fb_list.as<uint32_t>(), &dc->n_fb);
 	} else {
 		// dense counters in global memory, one workgroup per query (very large databases only)
 		uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * 2);
 		if ((rc = L->gcnt.reserve((size_t)grid * nw32 * 4))) return rc;
-		hipLaunchKernelGGL(k_prefilter<false>, dim3(grid), dim3(256), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps,
+		hipLaunchKernelGGL(k_prefilter<false>, dim3(grid), dim3(256), 0, st, h->s_codes(), h->s_off(),
+			h->s_emac(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps,
 			L->gcnt.as<uint32_t>(), bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read, L->fb_list.as<uint32_t>(), &dc->n_fb, plan);
 	}
 	HIPCHK(hipGetLastError());
@@ -680,8 +706,8 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	if ((rc = L->hdr.reserve((size_t)n_list * 8 + 16))) return rc;
 	const uint64_t n_thr = (uint64_t)n_list * W16;
 	HIPCHK(hipEventRecord(L->ev_pf[cls][0], st));
-	hipLaunchKernelGGL(k_seed_ranges, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), d_qlist, n_list,
-		h->acx_off.as<uint32_t>(), h->K, h->plan.as<uint32_t>(), W16, L->ranges.as<uint2>(), L->hdr.as<uint2>(), h->qpack.as<uint32_t>(), (h->st_maxlen + 7) / 8, h->qemac.as<uint16_t>());
+	hipLaunchKernelGGL(k_seed_ranges, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, h->s_codes(), h->s_off(), d_qlist, n_list,
+		h->acx_off.as<uint32_t>(), h->K, h->plan.as<uint32_t>(), W16, L->ranges.as<uint2>(), L->hdr.as<uint2>(), h->s_pack(), (h->st_maxlen + 7) / 8, h->s_emac());
 	const int algo = h->opt_pf_algo >= 0 ? h->opt_pf_algo : L->pf_algo;
 	const uint32_t n_quads = (n_list + 3) / 4;
 	// hash table size per query from the expected number of distinct clumps (sampled words x occurrence-weighted mean list
@@ -737,17 +763,17 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	if (lds_w <= 64 * 1024) {
 		const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / lds_w));
 		const uint32_t g2 = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * per_cu);
-		if (narrow) hipLaunchKernelGGL(k_prefilter_wave<uint8_t>, dim3(g2), dim3(64), lds_w, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, h->n_bad, L->cand.as<uint2>(),
+		if (narrow) hipLaunchKernelGGL(k_prefilter_wave<uint8_t>, dim3(g2), dim3(64), lds_w, st, h->s_codes(), h->s_off(),
+			h->s_emac(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, h->n_bad, L->cand.as<uint2>(),
 			(uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read, h->plan.as<uint32_t>(), L->fb_list.as<uint32_t>(), &dc->n_fb);
-		else hipLaunchKernelGGL(k_prefilter_wave<uint16_t>, dim3(g2), dim3(64), lds_w, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, h->n_bad, L->cand.as<uint2>(),
+		else hipLaunchKernelGGL(k_prefilter_wave<uint16_t>, dim3(g2), dim3(64), lds_w, st, h->s_codes(), h->s_off(),
+			h->s_emac(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, h->n_bad, L->cand.as<uint2>(),
 			(uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read, h->plan.as<uint32_t>(), L->fb_list.as<uint32_t>(), &dc->n_fb);
 	} else {
 		uint32_t g2 = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * 2);
 		if ((rc = L->gcnt.reserve((size_t)g2 * nw32 * 4))) return rc;
-		hipLaunchKernelGGL(k_prefilter<false>, dim3(g2), dim3(256), 0, st, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-			h->qemac.as<uint16_t>(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps,
+		hipLaunchKernelGGL(k_prefilter<false>, dim3(g2), dim3(256), 0, st, h->s_codes(), h->s_off(),
+			h->s_emac(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps,
 			L->gcnt.as<uint32_t>(), bad, h->n_bad, L->cand.as<uint2>(), (uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read,
 			L->fb_list.as<uint32_t>(), &dc->n_fb, h->plan.as<uint32_t>());
 	}
@@ -785,12 +811,14 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 	// (a few host threads share the pass: ~35 ns per entry single-threaded would otherwise be 8x the device time of the batch)
 	const size_t n_keys = (size_t)nl * kNumClasses * 2;
 	std::vector<uint32_t> plan(n_q, 1u);
+	std::vector<uint8_t> nxv(n_q, 0);          // symbols of code 0 per entry (255 = more than any budget: never searched)
 	for (uint32_t l = 0; l < nl; ++l) { Lane *L = h->lanes[l]; for (int c = 0; c < kNumClasses; ++c) { L->npf[c] = L->nex[c] = L->maxE[c] = L->maxwords[c] = 0; L->seed_words[c] = 0; } L->maxlen = 0; L->n_entries = 0; }
 	struct Part {
 		std::vector<std::vector<uint32_t>> lists;
 		std::vector<uint32_t> maxE, maxwords, maxlen, n_entries;
 		std::vector<uint64_t> seed_words;
 		int err = 0; uint32_t err_i = 0; uint64_t err_len = 0;
+		bool junk = false;
 	};
 	const uint32_t n_thr = n_q < 65536 ? 1u : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 	std::vector<Part> parts(n_thr);
@@ -799,29 +827,43 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 		P.lists.resize(n_keys); P.maxE.assign((size_t)nl * kNumClasses, 0); P.maxwords.assign((size_t)nl * kNumClasses, 0);
 		P.seed_words.assign((size_t)nl * kNumClasses, 0); P.maxlen.assign(nl, 0); P.n_entries.assign(nl, 0);
 		const uint32_t i0 = (uint32_t)((uint64_t)n_q * t / n_thr), i1 = (uint32_t)((uint64_t)n_q * (t + 1) / n_thr);
+		std::vector<uint8_t> clean;
 		for (uint32_t i = i0; i < i1; ++i) {
-			const uint64_t len = q_off[i + 1] - q_off[i];
-			if (len == 0) continue;
-			if (len > BHIP_MAX_QLEN) { P.err = 1; P.err_i = i; P.err_len = len; return; }
+			const uint64_t len_all = q_off[i + 1] - q_off[i];
+			if (len_all == 0) continue;
+			if (len_all > BHIP_MAX_QLEN) { P.err = 1; P.err_i = i; P.err_len = len_all; return; }
 			if (q_six && q_six[i] >= n_shared) { P.err = 2; P.err_i = i; return; }
+			// search view of the entry: symbols of code 0 removed, budget reduced by their number
+			const uint8_t *codes_i = q_codes + q_off[i];
+			uint64_t len = len_all;
+			uint32_t E_i = q_emac[i];
+			if (memchr(codes_i, 0, len_all)) {
+				clean.clear();
+				for (uint64_t k = 0; k < len_all; ++k) if (codes_i[k]) clean.push_back(codes_i[k]);
+				const uint64_t nx_i = len_all - clean.size();
+				P.junk = true;
+				nxv[i] = (uint8_t)std::min<uint64_t>(nx_i, 255);
+				if (nx_i > E_i || clean.empty()) { nxv[i] = 255; continue; }      // cannot be aligned within its budget
+				E_i -= (uint32_t)nx_i; len = clean.size(); codes_i = clean.data();
+			}
 			const uint32_t six = q_six ? q_six[i] : i;
 			const uint32_t l = (uint32_t)(((uint64_t)six * nl) / nsh);
 			const int cls = class_of_len((uint32_t)len);
 			int ex = q_flags ? (q_flags[i] == BHIP_Q_EXHAUSTIVE) : !h->has_acx;
 			if (!h->has_acx) ex = 1;
 			if (!ex) {
-				plan[i] = make_seed_plan(q_codes + q_off[i], (uint32_t)len, q_emac[i], (uint32_t)h->K, h->opt_prefilter_stride);
+				plan[i] = make_seed_plan(codes_i, (uint32_t)len, E_i, (uint32_t)h->K, h->opt_prefilter_stride);
 				if ((plan[i] >> 8) == 0) ex = 1;           // no word is guaranteed to survive: exhaustive (burst.c:3130-3131 does the same for "bad" queries)
 			}
 			const size_t lc = (size_t)l * kNumClasses + cls;
 			P.lists[lc * 2 + ex].push_back(i);
-			P.maxE[lc] = std::max<uint32_t>(P.maxE[lc], q_emac[i]);
+			P.maxE[lc] = std::max<uint32_t>(P.maxE[lc], E_i);
 			if (!ex && len >= (uint64_t)h->K) {
 				const uint32_t nwd = (uint32_t)((len - h->K) / (plan[i] & 255u) + 1);
 				P.maxwords[lc] = std::max<uint32_t>(P.maxwords[lc], nwd);
 				P.seed_words[lc] += nwd;
 			}
-			P.maxlen[l] = std::max<uint32_t>(P.maxlen[l], (uint32_t)len);
+			P.maxlen[l] = std::max<uint32_t>(P.maxlen[l], (uint32_t)len_all);
 			++P.n_entries[l];
 		}
 	};
@@ -856,6 +898,41 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 	HIPCHK(hipEventRecord(h->ev[0], h->stream));
 	if ((rc = upload_queries(h, q_codes, q_off, q_emac, q_six, q_rc, n_q))) return rc;
 	if ((rc = upload_plan(h, q_codes, q_off, q_emac, n_q, plan))) return rc;
+	h->st_has_junk = false;
+	for (const Part &P : parts) h->st_has_junk |= P.junk;
+	if (h->st_has_junk) {       // rare: second view of the batch without the symbols of code 0 (see Handle::qcodes_s)
+		std::vector<uint64_t> off_s((size_t)n_q + 1, 0);
+		std::vector<uint16_t> emac_s(n_q);
+		std::vector<uint8_t> codes_s; codes_s.reserve(q_off[n_q] + 16);
+		std::vector<uint8_t> nxs(nsh + 1, 0);
+		for (uint32_t i = 0; i < n_q; ++i) {
+			const uint8_t *c = q_codes + q_off[i]; const uint64_t len = q_off[i + 1] - q_off[i];
+			if (!nxv[i]) codes_s.insert(codes_s.end(), c, c + len);
+			else if (nxv[i] != 255) for (uint64_t k = 0; k < len; ++k) { if (c[k]) codes_s.push_back(c[k]); }
+			off_s[i + 1] = codes_s.size();
+			emac_s[i] = (uint16_t)(nxv[i] == 255 ? 0 : q_emac[i] - nxv[i]);
+			if (nxv[i] == 255) nxv[i] = 0;            // never searched: nothing to add back
+			nxs[q_six ? q_six[i] : i] = nxv[i];
+		}
+		codes_s.resize(codes_s.size() + 16, 0);
+		if ((rc = h->qcodes_s.reserve(codes_s.size()))) return rc;
+		if ((rc = h->qoff_s.reserve(((size_t)n_q + 1) * 8))) return rc;
+		if ((rc = h->qemac_s.reserve(((size_t)n_q + 1) * 2))) return rc;
+		if ((rc = h->nx.reserve((size_t)n_q + 16))) return rc;
+		if ((rc = h->nx_six.reserve((size_t)nsh + 16))) return rc;
+		HIPCHK(hipMemcpyAsync(h->qcodes_s.p, codes_s.data(), codes_s.size(), hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipMemcpyAsync(h->qoff_s.p, off_s.data(), ((size_t)n_q + 1) * 8, hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipMemcpyAsync(h->qemac_s.p, emac_s.data(), (size_t)n_q * 2, hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipMemcpyAsync(h->nx.p, nxv.data(), n_q, hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipMemcpyAsync(h->nx_six.p, nxs.data(), nsh, hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));      // the host vectors go out of scope
+		const uint32_t qw_g = (h->st_maxlen + 7) / 8;
+		if ((rc = h->qpack_s.reserve((size_t)n_q * qw_g * 4 + 16))) return rc;
+		const uint64_t total = (uint64_t)n_q * qw_g;
+		hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
+			h->qcodes_s.as<uint8_t>(), h->qoff_s.as<uint64_t>(), n_q, qw_g, h->qpack_s.as<uint32_t>());
+		HIPCHK(hipGetLastError());
+	}
 	const double t_up = since();
 	{	// 4-bit packed copy of the queries at a fixed stride (layout used by the seed, profile and re-scoring kernels)
 		const uint32_t qw_g = (h->st_maxlen + 7) / 8;
@@ -920,8 +997,8 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		{
 			const uint32_t qb = 256u / (uint32_t)NW;
 			const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + qb - 1) / qb, (uint64_t)h->n_cu * 16);
-			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, pf, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-				qlist, n_list, NW, 0, h->mm, L->peq.as<uint32_t>(), h->qpack.as<uint32_t>(), (h->st_maxlen + 7) / 8);
+			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, pf, h->s_codes(), h->s_off(),
+				qlist, n_list, NW, 0, h->mm, L->peq.as<uint32_t>(), h->s_pack(), (h->st_maxlen + 7) / 8);
 			HIPCHK(hipGetLastError());
 		}
 		// two-stage edit distance when a prefix of 32*NWP symbols is selective for this class's budgets
@@ -934,8 +1011,8 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		if (NWP) {
 			const uint32_t qb = 256u / (uint32_t)NWP;
 			const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + qb - 1) / qb, (uint64_t)h->n_cu * 16);
-			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, pf, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-				qlist, n_list, NWP, 32 * NWP, h->mm, L->peqp.as<uint32_t>(), h->qpack.as<uint32_t>(), (h->st_maxlen + 7) / 8);
+			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, pf, h->s_codes(), h->s_off(),
+				qlist, n_list, NWP, 32 * NWP, h->mm, L->peqp.as<uint32_t>(), h->s_pack(), (h->st_maxlen + 7) / 8);
 			HIPCHK(hipGetLastError());
 		}
 		L->prefix_words = (uint32_t)NWP;
@@ -995,6 +1072,15 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	}
 	// re-scoring of the kept reference lanes of this lane's shared slots
 	HIPCHK(hipEventRecord(L->ev_rs[0], po));
+	if (h->st_has_junk) {       // back to the units of the original queries (see Handle::qcodes_s); this lane owns the shared slots [s0, s1)
+		const uint32_t nl_ = h->st_lanes, nsh_ = h->st_nshared;
+		uint32_t li_ = 0;
+		for (uint32_t l = 0; l < nl_; ++l) if (h->lanes[l] == L) li_ = l;
+		const uint32_t s0 = (uint32_t)(((uint64_t)li_ * nsh_ + nl_ - 1) / nl_), s1 = (uint32_t)(((uint64_t)(li_ + 1) * nsh_ + nl_ - 1) / nl_);
+		hipLaunchKernelGGL(k_junk_adjust_raw, dim3((uint32_t)h->n_cu * 4), dim3(256), 0, po, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, h->nx.as<uint8_t>());
+		if (s1 > s0) hipLaunchKernelGGL(k_junk_adjust_best, dim3(std::min<uint32_t>((s1 - s0 + 255) / 256, (uint32_t)h->n_cu * 4)), dim3(256), 0, po, h->best.as<uint32_t>(), h->nx_six.as<uint8_t>(), s0, s1);
+		HIPCHK(hipGetLastError());
+	}
 	// classify (exact matches leave here), register-band variants for the narrow bands, LDS band for the rest
 	const uint32_t qw_g = (h->st_maxlen + 7) / 8;
 	hipLaunchKernelGGL(k_rescore_classify, dim3((uint32_t)h->n_cu * 8), dim3(256), 0, po, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap,
@@ -1106,7 +1192,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		}
 		HIPCHK(hipMemcpy(&hsc, h->shared_ctr.p, sizeof hsc, hipMemcpyDeviceToHost));
 		if (scratch_retry || (hsc.err & 2u)) continue;
-		if (hsc.err & 1u) return fail(BHIP_E_INTERNAL, "re-scoring could not reproduce a hit found by the edit-distance kernel");
+		if (hsc.err & 1u) return fail(BHIP_E_RESCORE, "re-scoring could not reproduce a hit found by the edit-distance kernel (a query starting with a symbol outside the alphabet? the reference stops here as well: CRITICAL ERROR: Truncation within known good path, burst.c:812-816)");
 		if (hsc.n_out > h->out_cap) { h->out_cap = (uint64_t)hsc.n_out + hsc.n_out / 8 + 1024; continue; }
 		*n_hits = hsc.n_out;
 		h->last_n_out = 0;

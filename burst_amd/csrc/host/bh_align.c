@@ -80,6 +80,10 @@ int bh_align(void *hh, const BhQueries *Q, uint64_t u0, uint64_t u1, BhMode mode
 				hits = nh;
 				continue;
 			}
+			if (r == BHIP_E_RESCORE) {   /* the reference's own stop (burst.c:812-816, exit(1)) */
+				printf("\nCRITICAL ERROR: Truncation within known good path.\n");
+				rc = bh_set_error(BH_E_USAGE, "libburst_hip: %s", bhip_last_error()); break;
+			}
 			if (r) { rc = bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error()); break; }
 			for (uint64_t k = nHits; k < nHits + n; ++k) {        /* local entry index -> global entry index */
 				const uint32_t lq = hits[k].q;

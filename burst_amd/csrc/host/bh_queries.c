@@ -98,7 +98,9 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 			char *nl = memchr(h, '\n', sz - (i + 1));
 			if (!nl) nl = dump + sz;
 			char *he = nl;
-			if (he > h && he[-1] == '\r') --he;
+			/* the reference strips a carriage return from every record but the FIRST (burst.c:664-668 vs 677-684): there it
+			 * stays in the header and becomes a last query symbol of code 0 */
+			if (n && he > h && he[-1] == '\r') --he;
 			*he = 0; *nl = 0;
 			if (!incl_whitespace) for (char *p = h; *p; ++p) if (*p == ' ' || *p == '\t') { *p = 0; break; }   /* burst.c:2987-2992 */
 			/* sequence line */
@@ -106,7 +108,7 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 			char *nl2 = s < dump + sz ? memchr(s, '\n', (size_t)(dump + sz - s)) : NULL;
 			if (!nl2) nl2 = dump + sz;
 			char *se = nl2;
-			if (se > s && se[-1] == '\r') --se;
+			if (n && se > s && se[-1] == '\r') --se;
 			heads[n] = h;
 			refs[n].s = (uint8_t *)s; refs[n].len = (uint32_t)(se - s); refs[n].ix = n;
 			++n;

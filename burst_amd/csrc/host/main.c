@@ -204,7 +204,7 @@ int main(int argc, char **argv) {
 	PHASE("device database upload");
 	BhRun run;
 	const double t0 = wall();
-	if ((rc = bh_align(hh, &Q, 0, Q.numUniq, mode, batch, &run))) { fprintf(stderr, "%s\n", bh_last_error()); return 4; }
+	if ((rc = bh_align(hh, &Q, 0, Q.numUniq, mode, batch, &run))) { fprintf(stderr, "%s\n", bh_last_error()); return rc == BH_E_USAGE ? 1 : 4; }
 	const double t1 = wall();
 	printf("Search complete [%f s, %u batches, %lu candidate (query, clump) pairs, %lu hits]. Consolidating results...\n", t1 - t0, run.nBatches,
 	       (unsigned long)run.total.n_pairs, (unsigned long)run.nHits);

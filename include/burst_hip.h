@@ -28,6 +28,9 @@ extern "C" {
 #define BHIP_E_CAPACITY   -3   /* caller's hit buffer too small: *n_hits holds the required count */
 #define BHIP_E_QUERYLEN   -4   /* query longer than BHIP_MAX_QLEN */
 #define BHIP_E_INTERNAL   -5
+#define BHIP_E_RESCORE    -6   /* the re-scorer cannot reproduce a hit of the search: the state in which the reference prints "CRITICAL ERROR:
+                                 Truncation within known good path" and exits (burst.c:812-816) -- a query whose FIRST symbol has code 0
+                                 (row 1 of reScoreM takes the substitution cost alone, burst.c:722-739, while the search may gap it) */
 
 #define BHIP_MAX_QLEN   1024   /* bit-vector kernels are instantiated up to 32 x 32-bit words */
 
@@ -90,7 +93,8 @@ int bhip_init(int device, const void *edx_packed, const uint32_t *clump_len, uin
 
 /* Prefilter + banded edit distance + re-scoring for a batch of query entries (the body of the OpenMP
  * loops burst.c:4077-4289 and 4343-4484).
- *   q_codes : concatenated 1-byte symbol codes (0..15, burst.c:1288-1307), entry i = [q_off[i], q_off[i+1])
+ *   q_codes : concatenated 1-byte symbol codes (0..15, burst.c:1288-1307), entry i = [q_off[i], q_off[i+1]); code 0 (a character
+ *             outside the IUPAC nucleotide alphabet) costs 255 against everything, i.e. it can only face a gap
  *   q_emac  : per-entry error budget (ShrBin.ed, burst.c:3074-3076)
  *   q_six   : per-entry shared slot (UniBin.six, burst.c:3078, 3106): a forward entry and its reverse
  *             complement carry the same value in [0, n_shared) and share the running minimum (burst.c:4218-4220)

@@ -45,6 +45,13 @@ while time.time() - t0 < budget_s:
         bud = T.budget(cfg["thres"], L)
         r, _ = _synth.make_reads(seqs, max(2, cfg["nq"] // len(lens)), L, [0, 1, 2, max(0, bud), bud + 2], cfg["seed"] + 1 + li_, rc_frac=0.5, iupac_frac=cfg["q_iupac"])
         reads += r
+    cfg["junk"] = int(rng.integers(4) == 0)
+    if cfg["junk"]:                                # symbols of code 0 (outside the alphabet: cost 255, can only face a gap) inside some reads;
+        for ri_ in range(0, len(reads), 3):        # never first or last, where the reference's re-scorer stops (burst.c:812-816)
+            r_ = np.array(reads[ri_], np.uint8)
+            if len(r_) > 8:
+                r_[1 + rng.choice(len(r_) - 2, size=int(rng.integers(1, 3)), replace=False)] = 0
+            reads[ri_] = r_
     nq_ = len(reads)
     allq = reads + [_synth.revcomp(r) for r in reads]
     q = capi.Queries(allq, [T.budget(cfg["thres"], len(r)) for r in reads] * 2, list(range(nq_)) * 2, [0] * nq_ + [1] * nq_)

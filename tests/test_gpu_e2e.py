@@ -129,3 +129,16 @@ def test_database_shards_on_one_device_equal_whole(mode, ident):
     got = np.concatenate(parts)
     got = got[np.lexsort((got["refIx"], got["q"]))]
     assert got.tobytes() == whole[np.lexsort((whole["refIx"], whole["q"]))].tobytes()
+
+
+def test_cli_differential_on_awkward_inputs(tmp_path):
+    """tools/cli_diff.py: burst_hip next to the compiled reference (oracle/_ref/burst12, built by __graft_entry__.build()
+    where /root/reference exists; it travels with the snapshot) on query files with lower case, CRLF, duplicates, very short
+    reads, N runs, IUPAC codes, symbols outside the alphabet, long and mixed-length reads -- every mode, same lines, same exit
+    codes (including the reference's own stop on a query that starts with a symbol outside the alphabet)."""
+    import sys
+    if not os.path.exists(os.path.join(gl.ROOT, "oracle", "_ref", "burst12")):
+        pytest.skip("compiled reference not present")
+    r = subprocess.run([sys.executable, os.path.join(gl.ROOT, "tools", "cli_diff.py"), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert "ALL OK" in r.stdout

@@ -341,3 +341,65 @@ def test_asynchronous_record_handover():
     h, _ = dev.align_staged(False)
     assert h.tobytes() == exp.tobytes()
     dev.close()
+
+
+@pytest.mark.parametrize("accel", [False, True])
+@pytest.mark.parametrize("all_hits", [False, True])
+def test_query_symbols_outside_the_alphabet(accel, all_hits):
+    """A query symbol of code 0 (anything the reference's character table does not know, burst.c:1288-1307) costs 255 against
+    every reference symbol (burst.c:170-190): it can only face a gap.  The device searches such queries without those
+    symbols and adds their number back before re-scoring; records must equal the oracle's full-cost DP -- near the start, in
+    the middle and near the end of a read, several per read, more than the budget, on both strands."""
+    from burst_amd import capi, synth
+    seqs = family_db(171, 6, 10, 600)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lut = ol.score_lut(1)
+    kw = {}
+    if accel:
+        lens, entries, offs = dbutil.build_acx(seqs, 12)
+        kw = dict(acx_lens=lens, acx_lists=dbutil.pack_acx_lists(lens, entries, 0), acx_fmt=0, K=12)
+    reads, _ = synth.make_reads(seqs, 90, 100, [0, 1, 2, 3], 173, rc_frac=0.5)
+    rng = np.random.default_rng(7)
+    for i, r in enumerate(reads):
+        r = np.array(r, np.uint8)
+        k = i % 6                                   # 0 = untouched, 1..4 symbols of code 0, 5 = more than any budget
+        # (never the first symbol of either strand: there the reference's re-scorer cannot follow its own search, see the next test)
+        pos = {0: [], 1: [1], 2: [len(r) - 2], 3: [int(rng.integers(1, len(r) - 1))]}.get(k)
+        if pos is None:
+            pos = list(1 + rng.choice(len(r) - 2, size=(2 if k == 4 else 9), replace=False))
+        r[pos] = 0
+        reads[i] = r
+    n = len(reads)
+    allq = reads + [synth.revcomp(r) for r in reads]
+    q = capi.Queries(allq, [budget(0.95, len(r)) for r in reads] * 2, list(range(n)) * 2, [0] * n + [1] * n)
+    if accel:
+        q.flags = np.zeros(q.n, np.uint8)
+    dev = capi.Device(packed, clump_len, tot, lut, **kw)
+    exp = oracle_hits(packed, clump_len, tot, q, lut, all_hits)
+    got = dev.align_batch(q, all_hits=all_hits)
+    touched = np.array([(np.asarray(allq[e]) == 0).any() for e in exp["q"]])
+    assert touched.sum() > 20 and (~touched).sum() > 10
+    assert got.tobytes() == exp.tobytes()
+    for opts in ({"two_stage": 0}, {"prune": 0, "rescore_reg": 0}, {"lanes": 3, "lane_min_entries": 4}):
+        for k_, v in opts.items():
+            dev.set_option(k_, v)
+        assert dev.align_batch(q, all_hits=all_hits).tobytes() == exp.tobytes(), opts
+    dev.close()
+
+
+def test_first_symbol_outside_the_alphabet_stops_like_the_reference():
+    """Row 1 of reScoreM takes the substitution cost alone (burst.c:722-739), so a query whose FIRST symbol has code 0 cannot
+    be re-scored although the search finds it (by gapping that symbol): the reference prints "CRITICAL ERROR: Truncation
+    within known good path" and exits (burst.c:812-816); the library returns BHIP_E_RESCORE."""
+    from burst_amd import capi, synth
+    seqs = family_db(181, 3, 6, 400)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    reads, _ = synth.make_reads(seqs, 8, 80, [0, 1], 183)
+    reads = [np.array(r, np.uint8) for r in reads]
+    reads[3][0] = 0
+    q = capi.Queries(reads, [budget(0.95, len(r)) for r in reads])
+    dev = capi.Device(packed, clump_len, tot, ol.score_lut(1))
+    with pytest.raises(capi.BurstHipError) as e:
+        dev.align_batch(q, all_hits=False)
+    assert e.value.code == capi.BHIP_E_RESCORE
+    dev.close()

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Differential run of the two command lines on awkward query files (GPU box): burst_hip vs the compiled reference
+(oracle/_ref/burst12, which travels with the snapshot) on the golden database, no accelerator, -t 1 -- the
+configuration in which the reference is deterministic -- for every mode.  Prints one line per case and exits non-zero
+on the first difference.
+   python tools/cli_diff.py [workdir]"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+REF = os.path.join(ROOT, "oracle", "_ref", "burst12")
+CLI = os.path.join(ROOT, "burst_amd", "burst_hip")
+work = sys.argv[1] if len(sys.argv) > 1 else "/tmp/cli_diff"
+os.makedirs(work, exist_ok=True)
+
+
+def read_fasta(path):
+    out = []
+    for line in open(path):
+        line = line.rstrip("\n")
+        if line.startswith(">"):
+            out.append([line[1:], ""])
+        elif out:
+            out[-1][1] += line
+    return out
+
+
+base = read_fasta(os.path.join(G, "q100.fa"))[:120]
+long_ = read_fasta(os.path.join(G, "q292.fa"))[:40]
+rng = np.random.default_rng(5)
+
+
+def write(name, recs, eol="\n", wrap=0, tail=""):
+    p = os.path.join(work, name)
+    with open(p, "w", newline="") as f:
+        for h, s in recs:
+            f.write(">" + h + eol)
+            if wrap:
+                for i in range(0, len(s), wrap):
+                    f.write(s[i:i + wrap] + eol)
+            else:
+                f.write(s + eol)
+        f.write(tail)
+    return p
+
+
+def mutate(s, frac, alphabet):
+    s = list(s)
+    for i in range(len(s)):
+        if rng.random() < frac:
+            s[i] = alphabet[int(rng.integers(len(alphabet)))]
+    return "".join(s)
+
+
+cases = []
+cases.append(("plain", write("plain.fa", base)))
+cases.append(("lowercase", write("lower.fa", [(h, s.lower()) for h, s in base])))
+cases.append(("mixedcase", write("mixed.fa", [(h, "".join(c.lower() if i % 3 else c for i, c in enumerate(s))) for h, s in base])))
+cases.append(("crlf", write("crlf.fa", base, eol="\r\n")))
+cases.append(("no_final_newline", write("nonl.fa", base[:-1]) and write("nonl.fa", base[:-1] + [(base[-1][0], base[-1][1])], tail="")))
+cases.append(("duplicates", write("dups.fa", [base[i % 17] if i % 3 else (base[i][0] + "_x", base[i % 17][1]) for i in range(len(base))])))
+cases.append(("short_reads", write("short.fa", [(h, s[:n]) for (h, s), n in zip(base, [5, 8, 11, 12, 13, 14, 20, 24, 25, 30, 36, 37, 40] * 10)])))
+cases.append(("all_n", write("alln.fa", base[:30] + [("allN", "N" * 100), ("halfN", "N" * 50 + base[3][1][50:]), ("fewN", mutate(base[4][1], 0.04, "N"))])))
+cases.append(("iupac", write("iupac.fa", [(h, mutate(s, 0.05, "RYKMSWBDHVN")) for h, s in base])))
+cases.append(("heavy_iupac", write("iupac2.fa", [(h, mutate(s, 0.15, "RYKMSWBDHV")) for h, s in base[:60]])))
+cases.append(("junk_symbols", write("junk.fa", [(h, mutate(s, 0.02, "XZ*-.")) for h, s in base[:60]])))
+cases.append(("header_spaces", write("hdr.fa", [(h + " some description\twith tab", s) for h, s in base])))
+cases.append(("long_reads", write("long.fa", long_)))
+cases.append(("mixed_lengths", write("mixlen.fa", [(h, s[:int(rng.integers(20, len(s) + 1))]) for h, s in base + long_])))
+cases.append(("single", write("single.fa", base[:1])))
+cases.append(("u_ascii", write("uracil.fa", [(h, s.replace("T", "U")) for h, s in base[:60]])))
+
+runs = [("BEST", "0.97", []), ("ALLPATHS", "0.95", ["-fr"]), ("CAPITALIST", "0.95", ["-fr"]), ("FORAGE", "0.93", []), ("ALLPATHS", "0.9", ["-fr", "-y"]),
+        ("BEST", "0.95", ["-w"])]
+bad = 0
+for name, q in cases:
+    for mode, ident, extra in runs:
+        outs = []
+        for exe, tail in ((REF, ["-t", "1", "--noprogress"]), (CLI, [])):
+            o = os.path.join(work, "out_%s.b6" % ("ref" if exe == REF else "hip"))
+            if os.path.exists(o):
+                os.remove(o)
+            r = subprocess.run([exe, "-r", os.path.join(G, "dna.edx"), "-q", q, "-o", o, "-m", mode, "-i", ident] + extra + tail,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            lines = sorted(open(o, "rb").read().splitlines()) if os.path.exists(o) else None
+            outs.append((r.returncode, lines, r.stdout[-300:]))
+        same = outs[0][0] == outs[1][0] and (outs[0][1] == outs[1][1] or outs[0][0] != 0)      # after an error stop the partial output is not compared
+        if outs[0][0] < 0:
+            print("%-18s %-10s %-5s %-8s the reference crashed (signal %d); burst_hip rc=%d, %d lines -- not compared" % (name, mode, ident, " ".join(extra), -outs[0][0], outs[1][0], len(outs[1][1] or [])))
+            continue
+        print("%-18s %-10s %-5s %-8s ref rc=%d %s lines | hip rc=%d %s lines  %s" % (name, mode, ident, " ".join(extra), outs[0][0], len(outs[0][1] or []), outs[1][0],
+                                                                                 len(outs[1][1] or []), "ok" if same else "DIFF"))
+        if not same:
+            bad += 1
+            if outs[0][1] is not None and outs[1][1] is not None:
+                a, b = set(outs[0][1]), set(outs[1][1])
+                for ln in sorted(a - b)[:3]:
+                    print("   only ref:", ln.decode("utf-8", "replace"))
+                for ln in sorted(b - a)[:3]:
+                    print("   only hip:", ln.decode("utf-8", "replace"))
+            else:
+                print("   ref tail:", outs[0][2].replace("\n", " | "))
+                print("   hip tail:", outs[1][2].replace("\n", " | "))
+print("cli_diff:", "ALL OK" if not bad else "%d differing runs" % bad)
+sys.exit(1 if bad else 0)
