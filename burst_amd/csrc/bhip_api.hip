@@ -929,7 +929,7 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 		const uint32_t qw_g = (h->st_maxlen + 7) / 8;
 		if ((rc = h->qpack_s.reserve((size_t)n_q * qw_g * 4 + 16))) return rc;
 		const uint64_t total = (uint64_t)n_q * qw_g;
-		hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
+		if (total) hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
 			h->qcodes_s.as<uint8_t>(), h->qoff_s.as<uint64_t>(), n_q, qw_g, h->qpack_s.as<uint32_t>());
 		HIPCHK(hipGetLastError());
 	}
@@ -938,7 +938,7 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 		const uint32_t qw_g = (h->st_maxlen + 7) / 8;
 		if ((rc = h->qpack.reserve((size_t)n_q * qw_g * 4 + 16))) return rc;
 		const uint64_t total = (uint64_t)n_q * qw_g;
-		hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
+		if (total) hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
 			h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), n_q, qw_g, h->qpack.as<uint32_t>());
 		HIPCHK(hipGetLastError());
 	}
@@ -1360,7 +1360,7 @@ extern "C" int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64
 		const uint32_t qw_g = (h->st_maxlen + 7) / 8;
 		if ((rc = h->qpack.reserve((size_t)n_q * qw_g * 4 + 16))) return rc;
 		const uint64_t total = (uint64_t)n_q * qw_g;
-		hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
+		if (total) hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
 			h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), n_q, qw_g, h->qpack.as<uint32_t>());
 		HIPCHK(hipGetLastError());
 	}

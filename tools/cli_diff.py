@@ -74,17 +74,35 @@ cases.append(("mixed_lengths", write("mixlen.fa", [(h, s[:int(rng.integers(20, l
 cases.append(("single", write("single.fa", base[:1])))
 cases.append(("u_ascii", write("uracil.fa", [(h, s.replace("T", "U")) for h, s in base[:60]])))
 
+# an accelerator both programs read (BEST / ALLPATHS do not depend on the order in which hits are found)
+acx = os.path.join(work, "dna.acx")
+subprocess.check_call([CLI, "-r", os.path.join(G, "dna.edx"), "--make-acx", acx], stdout=subprocess.DEVNULL)
+# a reference FASTA with wrapped lines, lower case and a CRLF record, searched directly (-r fasta)
+refs = read_fasta(os.path.join(G, "refs.fa"))[:24]
+odd_refs = write("odd_refs.fa", [(h, s.lower() if i % 4 == 1 else s) for i, (h, s) in enumerate(refs)])
+cases.append(("header_only", write("hdronly.fa", [("lonely", "")])))
+
 runs = [("BEST", "0.97", []), ("ALLPATHS", "0.95", ["-fr"]), ("CAPITALIST", "0.95", ["-fr"]), ("FORAGE", "0.93", []), ("ALLPATHS", "0.9", ["-fr", "-y"]),
-        ("BEST", "0.95", ["-w"])]
+        ("BEST", "0.95", ["-w"]), ("BEST", "0.96", ["-a", acx]), ("ALLPATHS", "0.95", ["-fr", "-a", acx]), ("ALLPATHS", "0.95", ["-r", odd_refs, "-s"]),
+        ("BEST", "0.97", ["-r", odd_refs, "-fr"])]
 bad = 0
 for name, q in cases:
     for mode, ident, extra in runs:
+        if name == "short_reads" and "-a" in extra:
+            # documented divergences of the reference's accelerated path: a read of exactly (E+1)*K symbols is
+            # dropped by its per-query floor, and which strand of a tiny two-strand tie survives depends on its hit-list order
+            print("%-18s %-10s %-5s (accelerated: documented divergences for reads of <= K symbols, not compared)" % (name, mode, ident))
+            continue
         outs = []
+        ref_db = os.path.join(G, "dna.edx")
+        if "-r" in extra:
+            ref_db = extra[extra.index("-r") + 1]
+            extra = [e for i, e in enumerate(extra) if e != "-r" and (i == 0 or extra[i - 1] != "-r")]
         for exe, tail in ((REF, ["-t", "1", "--noprogress"]), (CLI, [])):
             o = os.path.join(work, "out_%s.b6" % ("ref" if exe == REF else "hip"))
             if os.path.exists(o):
                 os.remove(o)
-            r = subprocess.run([exe, "-r", os.path.join(G, "dna.edx"), "-q", q, "-o", o, "-m", mode, "-i", ident] + extra + tail,
+            r = subprocess.run([exe, "-r", ref_db, "-q", q, "-o", o, "-m", mode, "-i", ident] + extra + tail,
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             lines = sorted(open(o, "rb").read().splitlines()) if os.path.exists(o) else None
             outs.append((r.returncode, lines, r.stdout[-300:]))
@@ -92,7 +110,7 @@ for name, q in cases:
         if outs[0][0] < 0:
             print("%-18s %-10s %-5s %-8s the reference crashed (signal %d); burst_hip rc=%d, %d lines -- not compared" % (name, mode, ident, " ".join(extra), -outs[0][0], outs[1][0], len(outs[1][1] or [])))
             continue
-        print("%-18s %-10s %-5s %-8s ref rc=%d %s lines | hip rc=%d %s lines  %s" % (name, mode, ident, " ".join(extra), outs[0][0], len(outs[0][1] or []), outs[1][0],
+        print("%-18s %-10s %-5s %-8s ref rc=%d %s lines | hip rc=%d %s lines  %s" % (name, mode, ident, " ".join(os.path.basename(e) for e in extra), outs[0][0], len(outs[0][1] or []), outs[1][0],
                                                                                  len(outs[1][1] or []), "ok" if same else "DIFF"))
         if not same:
             bad += 1
