@@ -166,19 +166,55 @@ static int parse_ref_fasta(const char *path, RefRec **out, uint32_t *n_out, char
 	return BH_OK;
 }
 
+/* Clump formation order (burst.c:2149-2186).  The reference's tie order among identical fragments is whatever its sort
+ * calls leave behind, so the same calls are made here -- the same libc qsort on 16-byte records with comparators of
+ * the same meaning -- and the .edx comes out byte-identical to a single-threaded reference run also when the
+ * database holds duplicate fragments:
+ *   1. all fragments by length (cmpPackLen, 1335-1338);
+ *   2. pods of lengths within LATENCY: up to 256 members by strcmp of the NUL-terminated rest of the original sequence
+ *      from the fragment's start (cmpPackSeq, 1341-1344 -- it reads past the fragment's own length);
+ *   3. larger pods and always the last pod: buckets by the first five symbols in input order, inside a bucket by the
+ *      symbols from the sixth up to the shorter length, then shorter first, never "equal" (parallel_sort_tuxedo, 390-405). */
 typedef struct { const uint8_t *s; uint32_t len, ix; } Tux;
 static int tux_len_cmp(const void *a, const void *b) {
 	const Tux *A = a, *B = b;
-	if (A->len != B->len) return A->len < B->len ? -1 : 1;
-	return A->ix < B->ix ? -1 : (A->ix > B->ix);
+	return A->len < B->len ? -1 : A->len > B->len;
 }
-static int tux_seq_cmp(const void *a, const void *b) {
+static int tux_rest_cmp(const void *a, const void *b) {
+	return strcmp((const char *)((const Tux *)a)->s, (const char *)((const Tux *)b)->s);
+}
+static int tux_bucket_cmp(const void *a, const void *b) {
 	const Tux *A = a, *B = b;
-	uint32_t n = A->len < B->len ? A->len : B->len;
-	int c = memcmp(A->s, B->s, n);
-	if (c) return c;
-	if (A->len != B->len) return A->len < B->len ? -1 : 1;
-	return A->ix < B->ix ? -1 : (A->ix > B->ix);
+	const uint32_t ml = A->len < B->len ? A->len : B->len;
+	uint32_t i = 5;
+	for (; i < ml; ++i) if (A->s[i] != B->s[i]) break;
+	if (i < ml) return (int)A->s[i] - (int)B->s[i];
+	return A->len < B->len ? -1 : 1;
+}
+typedef struct { uint32_t nib, pos; } NibPos;
+static int nibpos_cmp(const void *a, const void *b) {
+	const NibPos *A = a, *B = b;
+	if (A->nib != B->nib) return A->nib < B->nib ? -1 : 1;
+	return A->pos < B->pos ? -1 : (A->pos > B->pos);
+}
+static void tux_bucket_sort(Tux *pack, uint32_t n) {
+	NibPos *np = malloc((size_t)n * sizeof(*np));
+	Tux *tmp = malloc((size_t)n * sizeof(*tmp));
+	for (uint32_t i = 0; i < n; ++i) {
+		const uint8_t *s = pack[i].s;
+		np[i].nib = (uint32_t)s[0] << 16 | (uint32_t)s[1] << 12 | (uint32_t)s[2] << 8 | (uint32_t)s[3] << 4 | (uint32_t)s[4];
+		np[i].nib &= 0xFFFFFu; np[i].pos = i;
+	}
+	qsort(np, n, sizeof(*np), nibpos_cmp);                 /* buckets ascending, members in input order */
+	for (uint32_t i = 0; i < n; ++i) tmp[i] = pack[np[i].pos];
+	for (uint32_t a = 0; a < n;) {
+		uint32_t b = a + 1;
+		while (b < n && np[b].nib == np[a].nib) ++b;
+		qsort(tmp + a, b - a, sizeof(*tmp), tux_bucket_cmp);
+		a = b;
+	}
+	memcpy(pack, tmp, (size_t)n * sizeof(*tmp));
+	free(np); free(tmp);
 }
 
 static uint32_t g_latency = 16;
@@ -194,6 +230,7 @@ int bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_she
 	/* shear (burst.c:1852-1858, 2109-2141) */
 	uint32_t totR = nR;
 	char **head; const uint8_t **seq; uint32_t *len, *start = NULL;
+	uint32_t shear_cap = 0;
 	if (do_shear && shear_len > 0) {
 		uint32_t minShear = (uint32_t)(maxLenQ / thres), shear = minShear > (uint32_t)shear_len ? minShear : (uint32_t)shear_len, ov = minShear;
 		uint64_t cnt = 0;
@@ -205,6 +242,7 @@ int bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_she
 		head = malloc((size_t)totR * sizeof(*head)); seq = malloc((size_t)totR * sizeof(*seq));
 		len = malloc((size_t)totR * 4); start = own(db, malloc((size_t)totR * 4));
 		uint32_t maxL = shear + ov, x = 0;
+		shear_cap = maxL;
 		for (uint32_t i = 0; i < nR; ++i) {
 			long unit = (long)R[i].len - (long)ov; if (unit < 0) unit = 1;
 			for (long j = 0; j < unit; j += shear) {
@@ -227,15 +265,21 @@ int bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_she
 		for (uint32_t i = 0; i < totR; ++i) T[i].s = seq[i], T[i].len = len[i], T[i].ix = i;
 		qsort(T, totR, sizeof(*T), tux_len_cmp);
 		maxLenR = T[totR - 1].len;
-		for (uint32_t i = 1, prev = 0, tol = T[0].len; i <= totR; ++i) {
-			if (i == totR || T[i].len > tol + g_latency) {
-				if (i - prev > 1) qsort(T + prev, i - prev, sizeof(*T), tux_seq_cmp);
-				prev = i; if (i < totR) tol = T[i].len;
+		uint32_t prev = 0, tol = T[0].len;
+		for (uint32_t i = 1; i < totR; ++i) {
+			if (T[i].len > tol + g_latency) {
+				tol = T[i].len;
+				if (i - prev > 1) { if (i - prev > 256) tux_bucket_sort(T + prev, i - prev); else qsort(T + prev, i - prev, sizeof(*T), tux_rest_cmp); }
+				prev = i;
 			}
 		}
+		if (prev < totR - 1) tux_bucket_sort(T + prev, totR - prev);
 		for (uint32_t i = 0; i < totR; ++i) srt[i] = T[i].ix;
 		free(T);
-	} else for (uint32_t i = 0; i < totR; ++i) { srt[i] = i; if (len[i] > maxLenR) maxLenR = len[i]; }
+	} else {
+		if (shear_cap) maxLenR = shear_cap;       /* the reference starts from shear + overlap here ("may actually be less", burst.c:2133) */
+		for (uint32_t i = 0; i < totR; ++i) { srt[i] = i; if (len[i] > maxLenR) maxLenR = len[i]; }
+	}
 	db->origTotR = totR; db->tmpRIX = srt; db->refIxSrt = srt; db->totR = totR;
 	if (dedupe) {                                                /* burst.c:2192-2230 */
 		uint32_t *dd = own(db, calloc((size_t)totR + 2, 4)), uix = 0;
@@ -244,10 +288,9 @@ int bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_she
 			if (!(len[a] == len[b] && !memcmp(seq[a], seq[b], len[a]))) dd[++uix] = i;
 		}
 		dd[++uix] = totR;
-		for (uint32_t i = 0; i < uix; ++i) {                     /* lowest original index leads each duplicate set (2213-2220) */
-			uint32_t lo = dd[i];
-			for (uint32_t m = dd[i] + 1; m < dd[i + 1]; ++m) if (srt[m] < srt[lo]) lo = m;
-			uint32_t t = srt[dd[i]]; srt[dd[i]] = srt[lo]; srt[lo] = t;
+		for (uint32_t i = 0; i < uix; ++i) {                     /* lowest original index leads each duplicate set: the same chain of */
+			uint32_t bix = srt[dd[i]];                            /* swaps with the running minimum as burst.c:2213-2220 */
+			for (uint32_t m = dd[i] + 1; m < dd[i + 1]; ++m) if (srt[m] < bix) { bix = srt[m]; srt[m] = srt[dd[i]]; srt[dd[i]] = bix; }
 		}
 		if (uix != totR) {
 			uint32_t *u = own(db, malloc(((size_t)uix + 1) * 4));

@@ -90,3 +90,16 @@ def test_database_builders_write_the_reference_bytes(tmp_path):
         subprocess.check_call([cli, "-r", os.path.join(gl.G, "refs.fa"), "-d", "QUICK", "320", "-o", edx, "-s", "500", "-i", "0.95", "-l", str(lat)],
                               stdout=subprocess.DEVNULL)
         assert _sha256(edx) == want["quick_l%d.edx" % lat]
+
+
+def test_database_builders_differential(tmp_path):
+    """tools/db_diff.py: `-d QUICK` of burst_hip next to the compiled reference on random and awkward reference FASTA files
+    (duplicate sequences and fragments, sequences shorter than K, IUPAC codes, N runs, lower case, CRLF, wrapped lines, no
+    final newline, 1 and 17 sequences) x five parameter sets (shear lengths, query lengths, identities, -y, -l 0): .edx and
+    .acx byte-identical.  The order of identical fragments is whatever the reference's sort calls leave behind; the same
+    calls are made (bh_db.c, "Clump formation order")."""
+    import sys
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "burst12")):
+        pytest.skip("compiled reference not present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "db_diff.py"), "2", str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-4000:]
