@@ -41,7 +41,7 @@ int bh_tax_load(const char *file, BhTax *T) {
 		char *line = blob + i, *e = memchr(line, '\n', sz + 1 - i);
 		const uint64_t next = (uint64_t)(e - blob) + 1;
 		char *tab = memchr(line, '\t', (size_t)(e - line));
-		if (!tab) { free(pair); free(blob); return bh_set_error(BH_E_USAGE, "ERROR: invalid taxonomy [%lu]", (unsigned long)n); }   /* burst.c:462 */
+		if (!tab) { free(pair); free(blob); return bh_set_error(BH_E_IO, "ERROR: invalid taxonomy [%lu]", (unsigned long)n); }   /* burst.c:462, exit(2) */
 		*tab = 0;
 		char *tx = tab + 1, *te = tx;
 		while (te < e && *te != '\r' && *te != '\t') ++te;   /* the taxonomy ends at newline, CR or a further tab (burst.c:467) */

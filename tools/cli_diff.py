@@ -82,7 +82,21 @@ refs = read_fasta(os.path.join(G, "refs.fa"))[:24]
 odd_refs = write("odd_refs.fa", [(h, s.lower() if i % 4 == 1 else s) for i, (h, s) in enumerate(refs)])
 cases.append(("header_only", write("hdronly.fa", [("lonely", "")])))
 
-runs = [("BEST", "0.97", []), ("ALLPATHS", "0.95", ["-fr"]), ("CAPITALIST", "0.95", ["-fr"]), ("FORAGE", "0.93", []), ("ALLPATHS", "0.9", ["-fr", "-y"]),
+# taxonomy maps: the golden one, and a shuffled copy with CRLF on some lines, a repeated key, an empty taxonomy and a line without tab
+tax = os.path.join(G, "tax.txt")
+tl = open(tax).read().splitlines()
+order = rng.permutation(len(tl))
+odd = [tl[k] + ("\r" if i % 5 == 0 else "") for i, k in enumerate(order)]
+odd.insert(3, tl[0].split("\t")[0] + "\tk__Other;p__Repeated")
+odd.insert(9, tl[1].split("\t")[0] + "_x\t")
+odd_tax = os.path.join(work, "odd_tax.txt")
+open(odd_tax, "w", newline="").write("\n".join(odd) + "\n")
+bad_tax = os.path.join(work, "bad_tax.txt")              # a line without a tab: both programs stop with exit code 2
+open(bad_tax, "w").write("\n".join(tl[:5] + ["orphan_without_tab"] + tl[5:9]) + "\n")
+
+runs = [("CAPITALIST", "0.95", ["-fr", "-b", tax]), ("BEST", "0.95", ["-b", tax, "-bs"]), ("ALLPATHS", "0.95", ["-fr", "-b", tax, "-bs", "STRICT"]),
+        ("CAPITALIST", "0.93", ["-b", tax, "-bc", "3", "-bs"]), ("CAPITALIST", "0.95", ["-b", odd_tax]), ("BEST", "0.95", ["-b", odd_tax, "-bs"]), ("BEST", "0.95", ["-b", bad_tax]),
+        ("BEST", "0.97", []), ("ALLPATHS", "0.95", ["-fr"]), ("CAPITALIST", "0.95", ["-fr"]), ("FORAGE", "0.93", []), ("ALLPATHS", "0.9", ["-fr", "-y"]),
         ("BEST", "0.95", ["-w"]), ("BEST", "0.96", ["-a", acx]), ("ALLPATHS", "0.95", ["-fr", "-a", acx]), ("ALLPATHS", "0.95", ["-r", odd_refs, "-s"]),
         ("BEST", "0.97", ["-r", odd_refs, "-fr"])]
 bad = 0
