@@ -1,0 +1,35 @@
+#!/bin/bash
+# Parity at the size of the bench workload (GPU box): the compiled reference (all host threads, accelerator) and burst_hip
+# on the same reads / database.  BEST does not depend on the order in which the reference's threads find hits and must be
+# identical; in ALLPATHS the reference's DUPE_HUNT keeps the first placement it met among overlapping shears
+# (burst.c:4563-4570, 4604), so there the contract is the relaxed one of tests/goldenlib.py: same number of lines, and
+# every reference line is one of the placements burst_hip computes (--no-dupe-hunt prints all of them).
+#   bash tools/scale_diff.sh [reads]      (after bench.py has built /tmp/burst_amd_bench)
+set -u
+N=${1:-200000}
+W=${BURST_BENCH_DIR:-/tmp/burst_amd_bench}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+EDX=$(ls $W/db_*.edx | head -1); ACX=${EDX%.edx}.acx
+READS=$(ls $W/reads_*_r0.fa | head -1)
+head -n $((2 * N)) $READS > $W/sd_reads.fa
+secs() { awk -v a=$1 -v b=$2 'BEGIN { printf "%.2f", b - a }'; }
+for MODE in BEST ALLPATHS; do
+  for ID in 0.97 0.98; do
+    T0=$(date +%s.%N); $ROOT/oracle/_ref/burst12 -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_ref.b6 -m $MODE -i $ID -t $(nproc) --noprogress > $W/sd_ref.log 2>&1; T1=$(date +%s.%N)
+    $ROOT/burst_amd/burst_hip -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_hip.b6 -m $MODE -i $ID > $W/sd_hip.log 2>&1; T2=$(date +%s.%N)
+    sort $W/sd_ref.b6 > $W/sd_ref.s; sort $W/sd_hip.b6 > $W/sd_hip.s
+    NR=$(wc -l < $W/sd_ref.s); NH=$(wc -l < $W/sd_hip.s)
+    if cmp -s $W/sd_ref.s $W/sd_hip.s; then R=IDENTICAL
+    else
+      ND=$(diff $W/sd_ref.s $W/sd_hip.s | grep -c '^<')
+      R="$ND of $NR lines differ"
+      if [ $MODE = ALLPATHS ]; then
+        $ROOT/burst_amd/burst_hip -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_nd.b6 -m $MODE -i $ID --no-dupe-hunt > /dev/null 2>&1
+        sort -u $W/sd_nd.b6 > $W/sd_nd.s
+        MISSING=$(comm -23 $W/sd_ref.s $W/sd_nd.s | wc -l)
+        R="$R; reference lines that are not a placement burst_hip computed: $MISSING; line counts $NR / $NH"
+      fi
+    fi
+    echo "$MODE -i $ID: $N reads, $NR reference lines, $NH burst_hip lines: $R   [reference $(secs $T0 $T1) s on $(nproc) threads, burst_hip $(secs $T1 $T2) s, both incl. database load]"
+  done
+done
