@@ -256,7 +256,7 @@ def main():
         cells = (st["n_task_columns"] if masked else st["n_columns"] * 16.0) * min(args.read_len, 32.0 * max(1, st["prefix_words"])) + st["n_window_columns"] * float(args.read_len)
         ms_sweeps = mean("ms_myers")
         res = {
-            "metric": "aligned reads/sec (node), 100-bp synthetic reads vs GG97-like .edx/.acx, -m %s -i %s" % (args.mode, args.id),
+            "metric": "aligned reads/sec (node), %d-bp synthetic reads vs GG97-like .edx/.acx, -m %s -i %s" % (args.read_len, args.mode, args.id),
             "value": total_reads * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 bit-vectors (u8 edit distances)", "data": "synthetic",
