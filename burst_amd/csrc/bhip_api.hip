@@ -445,29 +445,55 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 	}
 	if (acx_lens) {
 		const uint64_t nw = 1ull << (2 * K);
-		std::vector<uint32_t> off(nw + 1);
-		std::vector<unsigned long long> boff(nw + 1);       // byte offset of each word's packed list
-		uint64_t tot = 0, bytes = 0;
-		double sq = 0.0;
-		for (uint64_t i = 0; i < nw; ++i) {
-			const uint32_t n = acx_lens[i];
-			off[i] = (uint32_t)tot; boff[i] = bytes;
-			tot += n; sq += (double)n * (double)n;
-			bytes += acx_fmt == 1 ? 3ull * n : 5ull * (n >> 1) + 3ull * (n & 1);
-		}
-		h->acx_wmean = tot ? sq / (double)tot : 0.0;
-		if (tot >= 0xFFFFFFFFull) { fail(BHIP_E_ARG, "accelerator with %llu entries exceeds the 32-bit offset table", (unsigned long long)tot); bhip_destroy(h); return BHIP_E_ARG; }
-		off[nw] = (uint32_t)tot; boff[nw] = bytes;
-		// the packed list area goes up as it is on disk and is decoded to one u32 per entry by the device
+		// Lens[4^K] goes up as it is; entry offsets, byte offsets of the packed lists, the total and the occurrence-weighted
+		// mean list length are scans / reductions on the device (at K = 15 the table has 2^30 words: a host pass over it and
+		// 12 GB of host-built offset tables used to cost more than everything else in bhip_init)
+		DBuf d_lens, d_red, d_tmp;
+		INITRC(d_lens.reserve(nw * sizeof(uint32_t)));
+		INITRC(d_red.reserve(64));
 		INITRC(h->acx_off.reserve((nw + 1) * sizeof(uint32_t)));
+		INITCHK(hipMemcpyAsync(d_lens.p, acx_lens, nw * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+		const int fmt_ = acx_fmt;
+		auto to_u64 = [] __host__ __device__(uint32_t n) -> unsigned long long { return n; };
+		auto to_sq = [] __host__ __device__(uint32_t n) -> double { return (double)n * (double)n; };
+		auto to_bytes = [fmt_] __host__ __device__(uint32_t n) -> unsigned long long { return fmt_ == 1 ? 3ull * n : 5ull * (n >> 1) + 3ull * (n & 1); };
+		hipcub::TransformInputIterator<unsigned long long, decltype(to_u64), const uint32_t *> it_u64(d_lens.as<uint32_t>(), to_u64);
+		hipcub::TransformInputIterator<double, decltype(to_sq), const uint32_t *> it_sq(d_lens.as<uint32_t>(), to_sq);
+		hipcub::TransformInputIterator<unsigned long long, decltype(to_bytes), const uint32_t *> it_bytes(d_lens.as<uint32_t>(), to_bytes);
+		unsigned long long *r_tot = d_red.as<unsigned long long>(), *r_bytes = r_tot + 1; double *r_sq = (double *)(r_tot + 2);
+		size_t tb = 0, tb1 = 0;
+		INITCHK(hipcub::DeviceReduce::Sum(nullptr, tb1, it_u64, r_tot, (int)nw, h->stream)); tb = std::max(tb, tb1);
+		INITCHK(hipcub::DeviceReduce::Sum(nullptr, tb1, it_bytes, r_bytes, (int)nw, h->stream)); tb = std::max(tb, tb1);
+		INITCHK(hipcub::DeviceReduce::Sum(nullptr, tb1, it_sq, r_sq, (int)nw, h->stream)); tb = std::max(tb, tb1);
+		INITCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, d_lens.as<uint32_t>(), h->acx_off.as<uint32_t>(), (int)nw, h->stream)); tb = std::max(tb, tb1);
+		INITRC(d_tmp.reserve(tb + 16));
+		tb1 = tb; INITCHK(hipcub::DeviceReduce::Sum(d_tmp.p, tb1, it_u64, r_tot, (int)nw, h->stream));
+		tb1 = tb; INITCHK(hipcub::DeviceReduce::Sum(d_tmp.p, tb1, it_bytes, r_bytes, (int)nw, h->stream));
+		tb1 = tb; INITCHK(hipcub::DeviceReduce::Sum(d_tmp.p, tb1, it_sq, r_sq, (int)nw, h->stream));
+		unsigned long long red[3];
+		INITCHK(hipMemcpyAsync(red, d_red.p, 24, hipMemcpyDeviceToHost, h->stream));
+		INITCHK(hipStreamSynchronize(h->stream));
+		const uint64_t tot = red[0], bytes = red[1];
+		double sq; memcpy(&sq, &red[2], 8);
+		h->acx_wmean = tot ? sq / (double)tot : 0.0;
+		if (tot >= 0xFFFFFFFFull) { d_lens.release(); d_red.release(); d_tmp.release(); fail(BHIP_E_ARG, "accelerator with %llu entries exceeds the 32-bit offset table", (unsigned long long)tot); bhip_destroy(h); return BHIP_E_ARG; }
+		// the packed list area goes up as it is on disk and is decoded to one u32 per entry by the device
 		INITRC(h->acx_ent.reserve((tot + 1) * sizeof(uint32_t)));
 		{
 			DBuf d_lists, d_boff, d_flag;
 			INITRC(d_lists.reserve(bytes + 16));
 			INITRC(d_boff.reserve((nw + 1) * sizeof(unsigned long long)));
 			INITRC(d_flag.reserve(16));
-			INITCHK(hipMemcpyAsync(h->acx_off.p, off.data(), (nw + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-			INITCHK(hipMemcpyAsync(d_boff.p, boff.data(), (nw + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+			tb1 = tb; INITCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tb1, d_lens.as<uint32_t>(), h->acx_off.as<uint32_t>(), (int)nw, h->stream));
+			{
+				size_t tb2 = 0;
+				INITCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, it_bytes, d_boff.as<unsigned long long>(), (int)nw, h->stream));
+				INITRC(d_tmp.reserve(tb2 + 16));
+				INITCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tb2, it_bytes, d_boff.as<unsigned long long>(), (int)nw, h->stream));
+			}
+			const uint32_t tot32 = (uint32_t)tot; const unsigned long long bytes64 = bytes;
+			INITCHK(hipMemcpyAsync(h->acx_off.as<uint32_t>() + nw, &tot32, 4, hipMemcpyHostToDevice, h->stream));
+			INITCHK(hipMemcpyAsync(d_boff.as<unsigned long long>() + nw, &bytes64, 8, hipMemcpyHostToDevice, h->stream));
 			if (bytes) INITCHK(hipMemcpyAsync(d_lists.p, acx_lists, bytes, hipMemcpyHostToDevice, h->stream));
 			INITCHK(hipMemsetAsync(d_flag.p, 0, 16, h->stream));
 			hipLaunchKernelGGL(k_acx_decode, dim3((uint32_t)h->n_cu * 32), dim3(256), 0, h->stream, d_lists.as<uint8_t>(), d_boff.as<unsigned long long>(),
@@ -476,7 +502,7 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 			uint32_t worst = 0;
 			INITCHK(hipMemcpyAsync(&worst, d_flag.p, 4, hipMemcpyDeviceToHost, h->stream));
 			INITCHK(hipStreamSynchronize(h->stream));
-			d_lists.release(); d_boff.release(); d_flag.release();
+			d_lists.release(); d_boff.release(); d_flag.release(); d_lens.release(); d_red.release(); d_tmp.release();
 			if (worst) { fail(BHIP_E_ARG, "an accelerator entry refers to clump %u >= %u", worst, n_clumps); bhip_destroy(h); return BHIP_E_ARG; }
 		}
 		h->n_bad = n_bad;

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <omp.h>
+#include <sys/stat.h>
 
 static void *own(BhDb *db, void *p) { if (p && db->nOwned < 32) db->owned[db->nOwned++] = p; return p; }
 
@@ -95,6 +96,34 @@ int bh_edx_read(const char *path, BhDb *db) {
 #undef RD
 #undef ALLOC
 
+/* large sequential read split over a few threads (the copy out of the page cache is what limits a 7 GB accelerator) */
+static int read_region(const char *path, uint64_t off, void *dst, uint64_t n) {
+	if (!n) return 0;
+	const uint64_t chunk = 64ull << 20;
+	const uint64_t nchunks = (n + chunk - 1) / chunk;
+	int bad = 0;
+	int team = omp_get_max_threads(); if (team > 8) team = 8;
+	#pragma omp parallel num_threads(team)
+	{
+		FILE *f = fopen(path, "rb");
+		if (!f) {
+			#pragma omp atomic write
+			bad = 1;
+		}
+		#pragma omp for schedule(dynamic, 1)
+		for (uint64_t c = 0; c < nchunks; ++c) {
+			if (!f) continue;
+			const uint64_t o = c * chunk, m = n - o < chunk ? n - o : chunk;
+			if (fseeko(f, (off_t)(off + o), SEEK_SET) || fread((uint8_t *)dst + o, 1, m, f) != m) {
+				#pragma omp atomic write
+				bad = 1;
+			}
+		}
+		if (f) fclose(f);
+	}
+	return bad;
+}
+
 int bh_acx_read(const char *path, int K, int z, BhDb *db) {
 	FILE *in = fopen(path, "rb");
 	if (!in) return bh_set_error(BH_E_USAGE, "Cannot read accelerator '%s'", path);
@@ -108,13 +137,20 @@ int bh_acx_read(const char *path, int K, int z, BhDb *db) {
 	uint32_t *lens = own(db, malloc(nw * 4));
 	uint32_t *bl = own(db, malloc(((size_t)szBL + 1) * 4));
 	if (!lens || !bl) { fclose(in); return bh_set_error(BH_E_OOM, "OOM:BadList_rd"); }
-	bad |= fread(lens, 4, nw, in) != nw;
+	bad |= read_region(path, 5, lens, nw * 4);
 	uint64_t bytes = 0;
-	if (!bad) for (uint64_t i = 0; i < nw; ++i) bytes += ver == 0 ? (uint64_t)(lens[i] / 2u) * 5 + (lens[i] & 1) * 3 : (uint64_t)lens[i] * 3;
+	if (!bad) {
+		#pragma omp parallel for reduction(+:bytes) schedule(static)
+		for (uint64_t i = 0; i < nw; ++i) bytes += ver == 0 ? (uint64_t)(lens[i] / 2u) * 5 + (lens[i] & 1) * 3 : (uint64_t)lens[i] * 3;
+	}
 	uint8_t *lists = own(db, malloc(bytes + 16));
 	if (!lists) { fclose(in); return bh_set_error(BH_E_OOM, "OOM:WordDump_rd"); }
-	bad |= fread(lists, 1, bytes, in) != bytes;
-	bad |= fread(bl, 4, szBL, in) != szBL;
+	if (!bad) {
+		struct stat sb;
+		if (stat(path, &sb) || (uint64_t)sb.st_size < 5 + nw * 4 + bytes + (uint64_t)szBL * 4) bad = 1;
+	}
+	if (!bad) bad |= read_region(path, 5 + nw * 4, lists, bytes);
+	if (!bad) bad |= fseeko(in, (off_t)(5 + nw * 4 + bytes), SEEK_SET) != 0 || fread(bl, 4, szBL, in) != szBL;
 	fclose(in);
 	if (bad) return bh_set_error(BH_E_USAGE, "ERROR: truncated accelerator %s (was it built with K=%d?)", path, K);
 	memset(lists + bytes, 0, 16);

@@ -13,12 +13,14 @@ EDX=${SD_EDX:-$(ls $W/db_*_q110_*.edx | head -1)}; ACX=${EDX%.edx}.acx          
 READS=${SD_READS:-$(ls $W/reads_*_l100_*_r0.fa | head -1)}
 IDS=${SD_IDS:-"0.97 0.98"}
 EXTRA=${SD_EXTRA:-}
+REFBIN=${SD_REF:-$ROOT/oracle/_ref/burst12}      # DB15 accelerators: SD_REF=oracle/_ref/burst15 SD_HIP_EXTRA="-k 15"
+HIPX=${SD_HIP_EXTRA:-}
 head -n $((2 * N)) $READS > $W/sd_reads.fa
 secs() { awk -v a=$1 -v b=$2 'BEGIN { printf "%.2f", b - a }'; }
 for MODE in BEST ALLPATHS; do
   for ID in $IDS; do
-    T0=$(date +%s.%N); $ROOT/oracle/_ref/burst12 -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_ref.b6 -m $MODE -i $ID $EXTRA -t $(nproc) --noprogress > $W/sd_ref.log 2>&1; T1=$(date +%s.%N)
-    $ROOT/burst_amd/burst_hip -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_hip.b6 -m $MODE -i $ID $EXTRA > $W/sd_hip.log 2>&1; T2=$(date +%s.%N)
+    T0=$(date +%s.%N); $REFBIN -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_ref.b6 -m $MODE -i $ID $EXTRA -t $(nproc) --noprogress > $W/sd_ref.log 2>&1; T1=$(date +%s.%N)
+    $ROOT/burst_amd/burst_hip -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_hip.b6 -m $MODE -i $ID $EXTRA $HIPX > $W/sd_hip.log 2>&1; T2=$(date +%s.%N)
     sort $W/sd_ref.b6 > $W/sd_ref.s; sort $W/sd_hip.b6 > $W/sd_hip.s
     NR=$(wc -l < $W/sd_ref.s); NH=$(wc -l < $W/sd_hip.s)
     if cmp -s $W/sd_ref.s $W/sd_hip.s; then R=IDENTICAL
@@ -26,7 +28,7 @@ for MODE in BEST ALLPATHS; do
       ND=$(diff $W/sd_ref.s $W/sd_hip.s | grep -c '^<')
       R="$ND of $NR lines differ"
       if [ $MODE = ALLPATHS ]; then
-        $ROOT/burst_amd/burst_hip -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_nd.b6 -m $MODE -i $ID $EXTRA --no-dupe-hunt > /dev/null 2>&1
+        $ROOT/burst_amd/burst_hip -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_nd.b6 -m $MODE -i $ID $EXTRA $HIPX --no-dupe-hunt > /dev/null 2>&1
         sort -u $W/sd_nd.b6 > $W/sd_nd.s
         MISSING=$(comm -23 $W/sd_ref.s $W/sd_nd.s | wc -l)
         R="$R; reference lines that are not a placement burst_hip computed: $MISSING; line counts $NR / $NH"
