@@ -151,7 +151,7 @@ struct Counters {
 // VALU-bound column sweep, which itself is serialised on one dedicated stream (Handle::sweep_stream).
 struct Lane {
 	hipStream_t stream = nullptr;
-	hipEvent_t ev_cls[kNumClasses][8];   // per class: 0 start, 1 peq done, 2 prefilter done, 3 sweep(pf) done, 4 sweep(ex) done, 5 window done
+	hipEvent_t ev_cls[kNumClasses][8];   // per class: 0 start, 1 peq done (sweep stream), 7 prefilter start, 2 prefilter done, 6 sweep start, 3 sweep(pf) done, 4 sweep(ex) done, 5 window done
 	hipEvent_t ev_rs[2];
 	hipEvent_t ev_ph[kNumClasses][2];    // per class: first window sweep done, second task sweep done
 	hipEvent_t ev_pf[kNumClasses][3];    // per class: seed lookup start, hash kernel start, hash kernel done
@@ -1018,12 +1018,13 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		const uint32_t *qlist = L->qlist_cls[cls].as<uint32_t>();
 		hipEvent_t *ce = L->ev_cls[cls];
 		// the lane's peq buffers are reused class after class: do not rebuild them before the previous class's window stage is done
-		if (L->launches) HIPCHK(hipStreamWaitEvent(pf, L->ev_rs[0], 0));
-		HIPCHK(hipEventRecord(ce[0], pf));
+		// (the profiles are built on the sweep stream, which is idle while this class's seeds and prefilter run on theirs)
+		if (L->launches) { HIPCHK(hipStreamWaitEvent(pf, L->ev_rs[0], 0)); HIPCHK(hipStreamWaitEvent(sw, L->ev_rs[0], 0)); }
+		HIPCHK(hipEventRecord(ce[0], sw));
 		{
 			const uint32_t qb = 256u / (uint32_t)NW;
 			const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + qb - 1) / qb, (uint64_t)h->n_cu * 16);
-			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, pf, h->s_codes(), h->s_off(),
+			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, sw, h->s_codes(), h->s_off(),
 				qlist, n_list, NW, 0, h->mm, L->peq.as<uint32_t>(), h->s_pack(), (h->st_maxlen + 7) / 8);
 			HIPCHK(hipGetLastError());
 		}
@@ -1037,12 +1038,13 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		if (NWP) {
 			const uint32_t qb = 256u / (uint32_t)NWP;
 			const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + qb - 1) / qb, (uint64_t)h->n_cu * 16);
-			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, pf, h->s_codes(), h->s_off(),
+			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, sw, h->s_codes(), h->s_off(),
 				qlist, n_list, NWP, 32 * NWP, h->mm, L->peqp.as<uint32_t>(), h->s_pack(), (h->st_maxlen + 7) / 8);
 			HIPCHK(hipGetLastError());
 		}
 		L->prefix_words = (uint32_t)NWP;
-		HIPCHK(hipEventRecord(ce[1], pf));
+		HIPCHK(hipEventRecord(ce[1], sw));
+		HIPCHK(hipEventRecord(ce[7], pf));
 		const bool masked = NWP && n_pf && h->has_masks && h->opt_lane_masks;
 		// lower-bound pruning (second sweep) only when the minimum per shared slot is all that is wanted, with the counting-filter
 		// kernel (it sees all lane counts of a query at once) and while a list position fits the 24 bits next to the bound
@@ -1238,7 +1240,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 				if (!(L->npf[cls] + L->nex[cls])) continue;
 				hipEvent_t *ce = L->ev_cls[cls];
 				S.ms_peq += ev_ms(ce[0], ce[1]);
-				if (L->npf[cls]) S.ms_prefilter += ev_ms(ce[1], ce[2]);
+				if (L->npf[cls]) S.ms_prefilter += ev_ms(ce[7], ce[2]);
 				if (L->npf[cls] && L->pf_masked[cls]) { S.ms_seed += ev_ms(L->ev_pf[cls][0], L->ev_pf[cls][1]); S.ms_prefilter_hash += ev_ms(L->ev_pf[cls][1], L->ev_pf[cls][2]); S.n_seed_words += L->seed_words[cls]; }
 				float sweep = ev_ms(ce[6], ce[4]), win = ev_ms(ce[4], ce[5]);
 				if (L->pruned[cls]) { const float second = ev_ms(L->ev_ph[cls][0], L->ev_ph[cls][1]); sweep += second; win -= second; }   // filter + second task sweep sit between the two window launches
