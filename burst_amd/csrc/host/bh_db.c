@@ -427,6 +427,9 @@ static void expand_word(const uint8_t *s, int K, int ix, uint32_t w, uint8_t *se
 	for (int i = 0; i < AMB_N[s[ix]]; ++i) expand_word(s, K, ix + 1, (w << 2) | AMB[s[ix]][i], seen, cache, n);
 }
 
+static int g_skip_ambig = 0;
+void bh_set_skip_ambig(int on) { g_skip_ambig = on; }     /* -sa: words holding any ambiguous symbol are left out, no BadList (burst.c:3341, 3360-3366) */
+
 int bh_acx_build(BhDb *db, int K, int z) {
 	const uint64_t nw = 1ull << (2 * K);
 	const uint32_t nC = db->numRclumps;
@@ -465,7 +468,7 @@ int bh_acx_build(BhDb *db, int K, int z) {
 				if (ll < (uint32_t)K) continue;
 				/* expansion budget as the reference estimates it: 3^a (N penalised) or 4^a per window (burst.c:3322-3353) */
 				uint32_t asum = 0;
-				for (uint32_t j = 0; j < ll; ++j) {
+				for (uint32_t j = 0; j < ll && !g_skip_ambig; ++j) {
 					if (j >= (uint32_t)K - 1) {
 						tsum += powx[asum & 15];
 						if (lane[j - (K - 1)] > 4 + z) --asum;
@@ -476,7 +479,8 @@ int bh_acx_build(BhDb *db, int K, int z) {
 				if (bad) break;
 				for (uint32_t j = 0; j + K <= ll; ++j) {
 					int skip = 0;
-					if (z) for (int k = 0; k < K; ++k) if (lane[j + k] == 5) { j += k; skip = 1; break; }
+					if (g_skip_ambig) { for (int k = 0; k < K; ++k) if (lane[j + k] >= 5) { j += k; skip = 1; break; } }
+					else if (z) for (int k = 0; k < K; ++k) if (lane[j + k] == 5) { j += k; skip = 1; break; }
 					if (skip) continue;
 					uint64_t need = 1; for (int k = 0; k < K; ++k) need *= AMB_N[lane[j + k]];
 					if (n + need > capc) { while (n + need > capc) capc *= 2; cache = realloc(cache, (size_t)capc * 4); }

@@ -65,6 +65,8 @@ int  bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_sh
 int  bh_edx_write(const BhDb *db, const char *path, long db_qlen, float thres);
 /* clump formation tolerance of bh_db_from_fasta, the reference's `-l` (LATENCY, burst.c:83): default 16, 0 = input order */
 void bh_set_latency(uint32_t bases);
+/* -sa for the accelerator builder: leave out every word that holds an ambiguous symbol (burst.c:3360-3366) */
+void bh_set_skip_ambig(int on);
 int  bh_acx_build(BhDb *db, int K, int z);
 /* view of the clumps [c0, c1) with the accelerator restricted to them (database sharding); `db` must outlive the view */
 int  bh_db_slice(const BhDb *db, uint32_t c0, uint32_t c1, BhDb *out);

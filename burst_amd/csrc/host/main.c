@@ -80,7 +80,7 @@ int main(int argc, char **argv) {
 			if (!shear_amt) do_shear = 0;
 		}
 		else if (!strcmp(a, "--unique") || !strcmp(a, "-u")) dedupe = 1;
-		else if (!strcmp(a, "--skipambig") || !strcmp(a, "-sa")) skip_ambig = 1;
+		else if (!strcmp(a, "--skipambig") || !strcmp(a, "-sa")) { skip_ambig = 1; bh_set_skip_ambig(1); }
 		else if (!strcmp(a, "--noprogress")) { }
 		else if (!strcmp(a, "--no-dupe-hunt")) rep_flags |= BH_REP_NO_DUPE_HUNT;   /* diagnostics: print every (hit, reference) expansion */
 		else if (!strcmp(a, "--make-acx")) { NEEDARG("--make-acx"); mkacx_FN = argv[i]; }

@@ -98,7 +98,8 @@ runs = [("CAPITALIST", "0.95", ["-fr", "-b", tax]), ("BEST", "0.95", ["-b", tax,
         ("CAPITALIST", "0.93", ["-b", tax, "-bc", "3", "-bs"]), ("CAPITALIST", "0.95", ["-b", odd_tax]), ("BEST", "0.95", ["-b", odd_tax, "-bs"]), ("BEST", "0.95", ["-b", bad_tax]),
         ("BEST", "0.97", []), ("ALLPATHS", "0.95", ["-fr"]), ("CAPITALIST", "0.95", ["-fr"]), ("FORAGE", "0.93", []), ("ALLPATHS", "0.9", ["-fr", "-y"]),
         ("BEST", "0.95", ["-w"]), ("BEST", "0.96", ["-a", acx]), ("ALLPATHS", "0.95", ["-fr", "-a", acx]), ("ALLPATHS", "0.95", ["-r", odd_refs, "-s"]),
-        ("BEST", "0.97", ["-r", odd_refs, "-fr"])]
+        ("BEST", "0.97", ["-r", odd_refs, "-fr"]), ("ALLPATHS", "0.95", ["-fr", "-sa"]), ("BEST", "0.95", ["-r", odd_refs, "-u"]),
+        ("CAPITALIST", "0.95", ["-r", odd_refs, "-s", "-u", "-sa"])]
 bad = 0
 for name, q in cases:
     for mode, ident, extra in runs:

@@ -79,7 +79,8 @@ write(os.path.join(work, "ambig.fa"), family(2, 4, 700, 0.01, iupac=0.08)); case
 write(os.path.join(work, "nrun.fa"), [(h, s[:200] + "N" * 60 + s[260:]) for h, s in awk]); cases.append(("n_runs", os.path.join(work, "nrun.fa")))
 
 params = [["-d", "QUICK", "100", "-s", "500", "-i", "0.97"], ["-d", "QUICK", "320", "-s", "-i", "0.95"], ["-d", "QUICK", "150", "-i", "0.98"],
-          ["-d", "QUICK", "100", "-s", "200", "-i", "0.9", "-y"], ["-d", "QUICK", "250", "-s", "1000", "-i", "0.97", "-l", "0"]]
+          ["-d", "QUICK", "100", "-s", "200", "-i", "0.9", "-y"], ["-d", "QUICK", "250", "-s", "1000", "-i", "0.97", "-l", "0"],
+          ["-d", "QUICK", "120", "-s", "400", "-i", "0.96", "-sa"]]
 bad = 0
 for name, fa in cases:
     for par in params:
