@@ -17,7 +17,7 @@ REFBIN=${SD_REF:-$ROOT/oracle/_ref/burst12}      # DB15 accelerators: SD_REF=ora
 HIPX=${SD_HIP_EXTRA:-}
 head -n $((2 * N)) $READS > $W/sd_reads.fa
 secs() { awk -v a=$1 -v b=$2 'BEGIN { printf "%.2f", b - a }'; }
-for MODE in BEST ALLPATHS; do
+for MODE in ${SD_MODES:-BEST ALLPATHS}; do
   for ID in $IDS; do
     T0=$(date +%s.%N); $REFBIN -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_ref.b6 -m $MODE -i $ID $EXTRA -t $(nproc) --noprogress > $W/sd_ref.log 2>&1; T1=$(date +%s.%N)
     $ROOT/burst_amd/burst_hip -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_hip.b6 -m $MODE -i $ID $EXTRA $HIPX > $W/sd_hip.log 2>&1; T2=$(date +%s.%N)
@@ -27,11 +27,15 @@ for MODE in BEST ALLPATHS; do
     else
       ND=$(diff $W/sd_ref.s $W/sd_hip.s | grep -c '^<')
       R="$ND of $NR lines differ"
-      if [ $MODE = ALLPATHS ]; then
+      if [ $MODE = CAPITALIST ]; then
+        QD=$(diff <(cut -f1 $W/sd_ref.s | uniq) <(cut -f1 $W/sd_hip.s | uniq) | wc -l)
+        R="$R (equally voted placements, decided by the reference's hit order); queries reported by only one program: $QD; line counts $NR / $NH"
+      elif [ $MODE != BEST ]; then
         $ROOT/burst_amd/burst_hip -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_nd.b6 -m $MODE -i $ID $EXTRA $HIPX --no-dupe-hunt > /dev/null 2>&1
         sort -u $W/sd_nd.b6 > $W/sd_nd.s
         MISSING=$(comm -23 $W/sd_ref.s $W/sd_nd.s | wc -l)
-        R="$R; reference lines that are not a placement burst_hip computed: $MISSING; line counts $NR / $NH"
+        QD=$(diff <(cut -f1 $W/sd_ref.s | uniq) <(cut -f1 $W/sd_hip.s | uniq) | wc -l)
+        R="$R; reference lines that are not a placement burst_hip computed: $MISSING; queries reported by only one program: $QD; line counts $NR / $NH"
       fi
     fi
     echo "$MODE -i $ID: $N reads, $NR reference lines, $NH burst_hip lines: $R   [reference $(secs $T0 $T1) s on $(nproc) threads, burst_hip $(secs $T1 $T2) s, both incl. database load]"
