@@ -119,14 +119,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     import torch
-    if world > 1:
+    # BURST_BENCH_DIST1=1 (test hook, under torch.distributed.run with one process): take the N > 1 code path -- process group,
+    # padded device-side gather, reductions -- on a single GPU
+    use_dist = world > 1 or (os.environ.get("BURST_BENCH_DIST1") == "1" and "MASTER_ADDR" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from burst_amd import capi, host
     refs, edx, acx, done = build_inputs(args.workdir, args, rank, world)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     while not os.path.exists(done):
         time.sleep(0.2)
@@ -180,7 +183,7 @@ def main():
 
     hits0, _ = step()          # sizes the library's grow-only device buffers for this workload (setup, not a warmup step)
     dev.sync_hits()
-    if world > 1:           # same capacity on every rank: the largest shard's record count plus slack
+    if use_dist:            # same capacity on every rank: the largest shard's record count plus slack
         mx = torch.tensor([len(hits0)], dtype=torch.int64, device="cuda")
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         pg = bdist.PaddedGather(int(mx.item()) + int(mx.item()) // 8 + 4096, rank, world, torch.device("cuda", local_rank))
@@ -188,7 +191,7 @@ def main():
         step()
     dev.sync_hits()
     per_step = []
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
@@ -199,11 +202,11 @@ def main():
     if pg is not None:
         pg.wait()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.time() - t0
     per_step = [s.as_dict() for s in per_step]
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -280,7 +283,7 @@ def main():
         if res["cpu_baseline"]:
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
