@@ -142,3 +142,18 @@ def test_cli_differential_on_awkward_inputs(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(gl.ROOT, "tools", "cli_diff.py"), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:]
     assert "ALL OK" in r.stdout
+
+
+def test_python_launcher_single_process(tmp_path):
+    """python -m burst_amd.run (the multi-GPU front end) with one process is equivalent to burst_hip"""
+    import sys
+    c = [x for x in gl.cases() if x["name"] == "dna_q100_allpaths_fr"][0]
+    ref, q, fr, z, shear = gl.case_args(c)
+    out = str(tmp_path / "o.b6")
+    env = dict(os.environ, PYTHONPATH=gl.ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "burst_amd.run", "-r", ref, "-a", acx_for("dna", 1, str(tmp_path)), "-q", q, "-o", out, "-m", "ALLPATHS", "-i", "0.95", "-fr"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=gl.ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert sorted(open(out, "rb").read().splitlines()) == gl.golden_lines(c)
