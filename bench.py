@@ -41,7 +41,8 @@ def build_inputs(workdir, args, rank, world):
     from burst_amd import host
     os.makedirs(workdir, exist_ok=True)
     args.db_qlen = args.read_len + max(10, args.read_len // 10)
-    tag = "b%d_v%d_l%d_q%d_i%s%s" % (args.n_base, args.n_variants, args.ref_len, args.db_qlen, args.id, "" if args.K == 12 else "_k%d" % args.K)
+    K = getattr(args, "K", 12)
+    tag = "b%d_v%d_l%d_q%d_i%s%s" % (args.n_base, args.n_variants, args.ref_len, args.db_qlen, args.id, "" if K == 12 else "_k%d" % K)
     refs = os.path.join(workdir, "refs_%s.fa" % tag)
     edx = os.path.join(workdir, "db_%s.edx" % tag)
     acx = os.path.join(workdir, "db_%s.acx" % tag)
@@ -49,7 +50,7 @@ def build_inputs(workdir, args, rank, world):
     if rank == 0 and not os.path.exists(done):
         t = time.time()
         host.synth_refs(refs, args.n_base, args.n_variants, args.ref_len, args.variant_rate, 7)
-        db = host.Db.from_fasta(refs, args.db_qlen, args.id, shear_len=500, K=args.K)
+        db = host.Db.from_fasta(refs, args.db_qlen, args.id, shear_len=500, K=K)
         db.write(edx, acx, db_qlen=args.db_qlen, thres=args.id)
         db.close()
         open(done, "w").write("ok")

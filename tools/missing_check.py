@@ -6,7 +6,7 @@ import numpy as np
 import bench
 from burst_amd import host, capi
 class A: pass
-a = A(); a.read_len, a.n_base, a.n_variants, a.ref_len, a.variant_rate, a.id = 100, 3300, 30, 1400, 0.05, 0.97
+a = A(); a.read_len, a.n_base, a.n_variants, a.ref_len, a.variant_rate, a.id, a.K = 100, 3300, 30, 1400, 0.05, 0.97, 12
 work = "/tmp/burst_amd_bench"
 refs, edx, acx, done = bench.build_inputs(work, a, 0, 1)
 reads = os.path.join(work, "fullsize_reads.fa")
