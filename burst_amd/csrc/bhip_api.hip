@@ -3,6 +3,7 @@
 // that replaces the bodies of the two OpenMP loops in do_alignments (burst.c:4077-4289, 4343-4484).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <string>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -846,7 +847,8 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 		int err = 0; uint32_t err_i = 0; uint64_t err_len = 0;
 		bool junk = false;
 	};
-	const uint32_t n_thr = n_q < 65536 ? 1u : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+	uint32_t n_thr = n_q < 65536 ? 1u : std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+	if (const char *ev = getenv("BHIP_STAGE_THREADS")) { const int v = atoi(ev); if (v > 0 && n_q >= 65536) n_thr = (uint32_t)std::min(v, 64); }      // tuning hook
 	std::vector<Part> parts(n_thr);
 	auto work = [&](uint32_t t) {
 		Part &P = parts[t];
@@ -893,12 +895,19 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 			++P.n_entries[l];
 		}
 	};
+	// the upload of the batch does not depend on the routing: it runs on its own host thread meanwhile (a copy from pageable
+	// memory keeps its caller busy for most of its duration)
+	HIPCHK(hipEventRecord(h->ev[0], h->stream));
+	int up_rc = 0;
+	std::string up_msg;          // the error text is thread-local: carry it over
+	std::thread uploader([&]() { (void)hipSetDevice(h->device); up_rc = upload_queries(h, q_codes, q_off, q_emac, q_six, q_rc, n_q); if (up_rc) up_msg = g_err; });
 	if (n_thr == 1) work(0);
 	else {
 		std::vector<std::thread> th;
 		for (uint32_t t = 0; t < n_thr; ++t) th.emplace_back(work, t);
 		for (auto &x : th) x.join();
 	}
+	uploader.join();
 	for (const Part &P : parts) {
 		if (P.err == 1) return fail(BHIP_E_QUERYLEN, "query %u has %llu symbols (max %d)", P.err_i, (unsigned long long)P.err_len, BHIP_MAX_QLEN);
 		if (P.err == 2) return fail(BHIP_E_ARG, "q_six[%u] out of range", P.err_i);
@@ -921,8 +930,7 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 		}
 	}
 	const double t_route = since();
-	HIPCHK(hipEventRecord(h->ev[0], h->stream));
-	if ((rc = upload_queries(h, q_codes, q_off, q_emac, q_six, q_rc, n_q))) return rc;
+	if (up_rc) return fail(up_rc, "%s", up_msg.c_str());
 	if ((rc = upload_plan(h, q_codes, q_off, q_emac, n_q, plan))) return rc;
 	h->st_has_junk = false;
 	for (const Part &P : parts) h->st_has_junk |= P.junk;
