@@ -17,16 +17,17 @@
 #include "bhip_internal.h"
 
 // ---- kernels (bhip_kernels.hip) -------------------------------------------------------------------
-__global__ void k_acx_decode(const uint8_t *, const unsigned long long *, const uint32_t *, uint64_t, int, uint32_t, uint32_t *, uint32_t *);
+__global__ void k_acx_offsets(const uint32_t *, uint64_t, int, uint32_t *, unsigned long long *);
+__global__ void k_acx_decode(const uint8_t *, const unsigned long long *, const uint32_t *, BhipAcxView, uint64_t, int, uint32_t, uint8_t *, uint32_t *);
 __global__ void k_transpose_refs(const uint8_t *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint4 *, uint4 *);
 __global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, int, int, BhipMatchMask, uint32_t *, const uint32_t *, uint32_t);
 template <bool LDS_CNT> __global__ void k_prefilter(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t,
+	BhipAcxView, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t,
 	unsigned long long *, const uint32_t *, const uint32_t *, const uint32_t *);
-__global__ void k_prefilter_hash(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, int,
+__global__ void k_prefilter_hash(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t, BhipAcxView, int,
 	const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *, uint32_t *, uint32_t *);
 template <typename CNT> __global__ void k_prefilter_wave(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *,
+	BhipAcxView, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *,
 	const uint32_t *, const uint32_t *);
 template <int NW> __global__ void k_myers(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
 	const uint64_t *, const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t,
@@ -38,15 +39,15 @@ template <int NW> __global__ void k_myers_window(const BhipWin *, const uint32_t
 	const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *,
 	unsigned long long *);
 __global__ void k_extract_kmers(const uint4 *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint32_t, int, unsigned long long *, uint16_t *, uint32_t *);
-__global__ void k_attach_masks(const uint32_t *, const uint32_t *, uint64_t, uint32_t, const unsigned long long *, const uint16_t *, uint32_t, const uint32_t *, uint2 *, uint32_t, uint32_t);
-template <int HTB> __global__ void k_prefilter_mask(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+__global__ void k_attach_masks(BhipAcxView, uint64_t, const unsigned long long *, const uint16_t *, uint32_t, const uint32_t *, uint8_t *, uint32_t, uint32_t);
+template <int HTB> __global__ void k_prefilter_mask(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *,
 	uint2 *, uint32_t *, uint32_t);
-template <int CB> __global__ void k_prefilter_cf(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+template <int CB> __global__ void k_prefilter_cf(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *,
 	uint2 *, uint32_t *, int);
 __global__ void k_task_filter(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, uint2 *, uint32_t *);
-__global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, const uint32_t *, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t, const uint16_t *);
+__global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, BhipAcxView, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t, const uint16_t *);
 template <int NWP> __global__ void k_myers_prefix_task(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *,
 	const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *);
 template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *,
@@ -189,7 +190,13 @@ struct Handle {
 	DBuf ref, ref_lane, ref_off, clump_len, lut;      // ref: 16 lanes interleaved per 32-column chunk; ref_lane: each lane contiguous
 	BhipMatchMask mm;
 	bool has_acx = false; int K = 0;
-	DBuf acx_off, acx_ent, bad, ent_mask; uint32_t n_bad = 0; uint64_t n_ent = 0;
+	// accelerator: two-level offsets + 5-byte (clump, lane mask) records (bhip_internal.h); entry numbers start at acx_bias
+	// (0, or the test hook BHIP_TEST_ENTRY_BIAS that pushes a small database's offsets beyond 2^32)
+	DBuf acx_delta, acx_base, acx_rec, bad; uint32_t n_bad = 0; uint64_t n_ent = 0, acx_bias = 0;
+	BhipAcxView acx_view() const {
+		BhipAcxView v; v.delta = acx_delta.as<uint32_t>(); v.base = acx_base.as<unsigned long long>();
+		v.rec = acx_rec.as<uint8_t>() - acx_bias * (uint64_t)BHIP_REC_BYTES; return v;
+	}
 	bool has_masks = false;       // per-entry lane masks were built at upload (lane-resolved prefilter)
 	int opt_lane_masks = 1;       // use them
 	// batch-wide buffers
@@ -284,9 +291,9 @@ extern "C" void bhip_destroy(void *handle) {
 	if (h->pf_stream) (void)hipStreamSynchronize(h->pf_stream);
 	if (h->post_stream) (void)hipStreamSynchronize(h->post_stream);
 	for (Lane *L : h->lanes) lane_destroy(L);
-	DBuf *all[] = {&h->ref, &h->ref_lane, &h->ref_off, &h->clump_len, &h->lut, &h->acx_off, &h->acx_ent, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
+	DBuf *all[] = {&h->ref, &h->ref_lane, &h->ref_off, &h->clump_len, &h->lut, &h->acx_delta, &h->acx_base, &h->acx_rec, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
 		&h->qsix, &h->qrc, &h->best, &h->out, &h->shared_ctr, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx,
-		&h->sort_tmp, &h->out_sorted, &h->out_sorted2, &h->qpack, &h->plan, &h->ent_mask, &h->qcodes_s, &h->qoff_s, &h->qemac_s, &h->qpack_s, &h->nx, &h->nx_six};
+		&h->sort_tmp, &h->out_sorted, &h->out_sorted2, &h->qpack, &h->plan, &h->qcodes_s, &h->qoff_s, &h->qemac_s, &h->qpack_s, &h->nx, &h->nx_six};
 	for (int o = 0; o < 2; ++o) {
 		if (h->copy_pending[o] && h->ev_copied[o]) (void)hipEventSynchronize(h->ev_copied[o]);
 		if (h->reg_ptr[o]) (void)hipHostUnregister(h->reg_ptr[o]);
@@ -320,7 +327,7 @@ static int build_lane_masks(Handle *h, const std::vector<uint64_t> &chunk_off) {
 	// of its clumps.  BHIP_MASK_SLICE (reference positions per slice) is the test hook for small databases.
 	size_t free_b = 0, total_b = 0;
 	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
-	const double after_masks = (double)free_b - 8.0 * (double)(h->n_ent + 1) - 4.0 * (double)nC - 65536.0;
+	const double after_masks = (double)free_b - 4.0 * (double)nC - 65536.0;      // the masks go into the records that are already there
 	if (after_masks <= 0) return 0;
 	uint64_t slice_items = (uint64_t)std::min<double>(2147483000.0, after_masks * 0.8 / 26.0);
 	if (const char *ev = getenv("BHIP_MASK_SLICE")) { const long long v = atoll(ev); if (v > 0) slice_items = (uint64_t)v; }
@@ -333,7 +340,7 @@ static int build_lane_masks(Handle *h, const std::vector<uint64_t> &chunk_off) {
 	#define BLMH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { BLM(fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_))); } } while (0)
 	const uint64_t cap_items = std::min<uint64_t>(slice_items, key_off[nC]);
 	BLM(d_koff.reserve((nC + 1) * 8)); BLM(k0.reserve(cap_items * 8)); BLM(k1.reserve(cap_items * 8)); BLM(v0.reserve(cap_items * 2)); BLM(v1.reserve(cap_items * 2));
-	BLM(nruns.reserve(16)); BLM(h->ent_mask.reserve((h->n_ent + 1) * 8)); BLM(amb.reserve((size_t)nC * 4 + 16));
+	BLM(nruns.reserve(16)); BLM(amb.reserve((size_t)nC * 4 + 16));
 	BLMH(hipMemsetAsync(amb.p, 0, (size_t)nC * 4, h->stream));
 	BLMH(hipMemcpyAsync(d_koff.p, key_off.data(), (nC + 1) * 8, hipMemcpyHostToDevice, h->stream));
 	const int end_bit = 2 * h->K + 24;
@@ -362,9 +369,8 @@ static int build_lane_masks(Handle *h, const std::vector<uint64_t> &chunk_off) {
 		uint32_t n_unique = 0;
 		BLMH(hipMemcpyAsync(&n_unique, nruns.p, 4, hipMemcpyDeviceToHost, h->stream));
 		BLMH(hipStreamSynchronize(h->stream));
-		hipLaunchKernelGGL(k_attach_masks, dim3((uint32_t)std::min<uint64_t>((h->n_ent + 255) / 256, (uint64_t)h->n_cu * 32)), dim3(256), 0, h->stream,
-			h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->n_ent, (uint32_t)(1ull << (2 * h->K)), ukeys, umasks, n_unique, amb.as<uint32_t>(), h->ent_mask.as<uint2>(),
-			c0, c1);
+		hipLaunchKernelGGL(k_attach_masks, dim3((uint32_t)h->n_cu * 32), dim3(256), 0, h->stream,
+			h->acx_view(), (uint64_t)(1ull << (2 * h->K)), ukeys, umasks, n_unique, amb.as<uint32_t>(), (uint8_t *)h->acx_view().rec, c0, c1);
 		BLMH(hipGetLastError());
 		BLMH(hipStreamSynchronize(h->stream));
 		c0 = c1;
@@ -445,67 +451,81 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		d_src.release(); d_srcoff.release();
 	}
 	if (acx_lens) {
-		const uint64_t nw = 1ull << (2 * K);
-		// Lens[4^K] goes up as it is; entry offsets, byte offsets of the packed lists, the total and the occurrence-weighted
-		// mean list length are scans / reductions on the device (at K = 15 the table has 2^30 words: a host pass over it and
-		// 12 GB of host-built offset tables used to cost more than everything else in bhip_init)
-		DBuf d_lens, d_red, d_tmp;
-		INITRC(d_lens.reserve(nw * sizeof(uint32_t)));
-		INITRC(d_red.reserve(64));
-		INITRC(h->acx_off.reserve((nw + 1) * sizeof(uint32_t)));
-		INITCHK(hipMemcpyAsync(d_lens.p, acx_lens, nw * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-		const int fmt_ = acx_fmt;
-		auto to_u64 = [] __host__ __device__(uint32_t n) -> unsigned long long { return n; };
+		const uint64_t nw = 1ull << (2 * K), nblk = (nw + 255) >> 8;
+		// Lens[4^K] goes up as it is; block-relative offsets, block bases, byte offsets of the packed lists, the total and the
+		// occurrence-weighted mean list length are scans / reductions on the device (at K = 15 the table has 2^30 words)
+		DBuf d_lens, d_red, d_tmp, d_bsum, d_bdelta, d_bbase;
+		#define ACXFREE() do { d_lens.release(); d_red.release(); d_tmp.release(); d_bsum.release(); d_bdelta.release(); d_bbase.release(); } while (0)
+		#define ACXRC(x) do { int rc_ = (x); if (rc_) { ACXFREE(); bhip_destroy(h); return rc_; } } while (0)
+		#define ACXCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ACXFREE(); \
+			fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); bhip_destroy(h); return BHIP_E_DEVICE; } } while (0)
+		if (const char *ev = getenv("BHIP_TEST_ENTRY_BIAS")) h->acx_bias = strtoull(ev, nullptr, 0);
+		ACXRC(d_lens.reserve(nw * sizeof(uint32_t)));
+		ACXRC(d_red.reserve(64));
+		ACXRC(d_bsum.reserve((nblk + 2) * 8));
+		ACXRC(d_bdelta.reserve(nw * sizeof(uint32_t) + 16));
+		ACXRC(d_bbase.reserve((nblk + 2) * 8));
+		ACXRC(h->acx_delta.reserve(nw * sizeof(uint32_t) + 16));
+		ACXRC(h->acx_base.reserve((nblk + 2) * 8));
+		ACXCHK(hipMemcpyAsync(d_lens.p, acx_lens, nw * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
 		auto to_sq = [] __host__ __device__(uint32_t n) -> double { return (double)n * (double)n; };
-		auto to_bytes = [fmt_] __host__ __device__(uint32_t n) -> unsigned long long { return fmt_ == 1 ? 3ull * n : 5ull * (n >> 1) + 3ull * (n & 1); };
-		hipcub::TransformInputIterator<unsigned long long, decltype(to_u64), const uint32_t *> it_u64(d_lens.as<uint32_t>(), to_u64);
 		hipcub::TransformInputIterator<double, decltype(to_sq), const uint32_t *> it_sq(d_lens.as<uint32_t>(), to_sq);
-		hipcub::TransformInputIterator<unsigned long long, decltype(to_bytes), const uint32_t *> it_bytes(d_lens.as<uint32_t>(), to_bytes);
-		unsigned long long *r_tot = d_red.as<unsigned long long>(), *r_bytes = r_tot + 1; double *r_sq = (double *)(r_tot + 2);
+		unsigned long long *r_tot = d_red.as<unsigned long long>(); double *r_sq = (double *)(r_tot + 1); uint32_t *r_max = (uint32_t *)(r_tot + 2);
 		size_t tb = 0, tb1 = 0;
-		INITCHK(hipcub::DeviceReduce::Sum(nullptr, tb1, it_u64, r_tot, (int)nw, h->stream)); tb = std::max(tb, tb1);
-		INITCHK(hipcub::DeviceReduce::Sum(nullptr, tb1, it_bytes, r_bytes, (int)nw, h->stream)); tb = std::max(tb, tb1);
-		INITCHK(hipcub::DeviceReduce::Sum(nullptr, tb1, it_sq, r_sq, (int)nw, h->stream)); tb = std::max(tb, tb1);
-		INITCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, d_lens.as<uint32_t>(), h->acx_off.as<uint32_t>(), (int)nw, h->stream)); tb = std::max(tb, tb1);
-		INITRC(d_tmp.reserve(tb + 16));
-		tb1 = tb; INITCHK(hipcub::DeviceReduce::Sum(d_tmp.p, tb1, it_u64, r_tot, (int)nw, h->stream));
-		tb1 = tb; INITCHK(hipcub::DeviceReduce::Sum(d_tmp.p, tb1, it_bytes, r_bytes, (int)nw, h->stream));
-		tb1 = tb; INITCHK(hipcub::DeviceReduce::Sum(d_tmp.p, tb1, it_sq, r_sq, (int)nw, h->stream));
-		unsigned long long red[3];
-		INITCHK(hipMemcpyAsync(red, d_red.p, 24, hipMemcpyDeviceToHost, h->stream));
-		INITCHK(hipStreamSynchronize(h->stream));
-		const uint64_t tot = red[0], bytes = red[1];
-		double sq; memcpy(&sq, &red[2], 8);
+		ACXCHK(hipcub::DeviceReduce::Sum(nullptr, tb1, it_sq, r_sq, (int)nw, h->stream)); tb = std::max(tb, tb1);
+		ACXCHK(hipcub::DeviceReduce::Max(nullptr, tb1, d_lens.as<uint32_t>(), r_max, (int)nw, h->stream)); tb = std::max(tb, tb1);
+		ACXCHK(hipcub::DeviceScan::ExclusiveScan(nullptr, tb1, d_bsum.as<unsigned long long>(), h->acx_base.as<unsigned long long>(), hipcub::Sum(), 0ull, (int)(nblk + 1), h->stream)); tb = std::max(tb, tb1);
+		ACXRC(d_tmp.reserve(tb + 16));
+		tb1 = tb; ACXCHK(hipcub::DeviceReduce::Sum(d_tmp.p, tb1, it_sq, r_sq, (int)nw, h->stream));
+		tb1 = tb; ACXCHK(hipcub::DeviceReduce::Max(d_tmp.p, tb1, d_lens.as<uint32_t>(), r_max, (int)nw, h->stream));
+		const uint32_t og = (uint32_t)std::min<uint64_t>(nblk, (uint64_t)h->n_cu * 16);
+		// entry offsets
+		ACXCHK(hipMemsetAsync(d_bsum.p, 0, (nblk + 2) * 8, h->stream));
+		hipLaunchKernelGGL(k_acx_offsets, dim3(og), dim3(256), 0, h->stream, d_lens.as<uint32_t>(), nw, 0, h->acx_delta.as<uint32_t>(), d_bsum.as<unsigned long long>());
+		ACXCHK(hipGetLastError());
+		tb1 = tb; ACXCHK(hipcub::DeviceScan::ExclusiveScan(d_tmp.p, tb1, d_bsum.as<unsigned long long>(), h->acx_base.as<unsigned long long>(), hipcub::Sum(), (unsigned long long)h->acx_bias, (int)(nblk + 1), h->stream));
+		// byte offsets of the packed lists on disk
+		ACXCHK(hipMemsetAsync(d_bsum.p, 0, (nblk + 2) * 8, h->stream));
+		hipLaunchKernelGGL(k_acx_offsets, dim3(og), dim3(256), 0, h->stream, d_lens.as<uint32_t>(), nw, acx_fmt == 1 ? 2 : 1, d_bdelta.as<uint32_t>(), d_bsum.as<unsigned long long>());
+		ACXCHK(hipGetLastError());
+		tb1 = tb; ACXCHK(hipcub::DeviceScan::ExclusiveScan(d_tmp.p, tb1, d_bsum.as<unsigned long long>(), d_bbase.as<unsigned long long>(), hipcub::Sum(), 0ull, (int)(nblk + 1), h->stream));
+		unsigned long long red[3], tot_b = 0, bytes = 0;
+		ACXCHK(hipMemcpyAsync(red, d_red.p, 24, hipMemcpyDeviceToHost, h->stream));
+		ACXCHK(hipMemcpyAsync(&tot_b, h->acx_base.as<unsigned long long>() + nblk, 8, hipMemcpyDeviceToHost, h->stream));
+		ACXCHK(hipMemcpyAsync(&bytes, d_bbase.as<unsigned long long>() + nblk, 8, hipMemcpyDeviceToHost, h->stream));
+		ACXCHK(hipStreamSynchronize(h->stream));
+		const uint64_t tot = tot_b - h->acx_bias;
+		double sq; memcpy(&sq, &red[1], 8);
+		uint32_t maxlen; memcpy(&maxlen, &red[2], 4);
 		h->acx_wmean = tot ? sq / (double)tot : 0.0;
-		if (tot >= 0xFFFFFFFFull) { d_lens.release(); d_red.release(); d_tmp.release(); fail(BHIP_E_ARG, "accelerator with %llu entries exceeds the 32-bit offset table", (unsigned long long)tot); bhip_destroy(h); return BHIP_E_ARG; }
-		// the packed list area goes up as it is on disk and is decoded to one u32 per entry by the device
-		INITRC(h->acx_ent.reserve((tot + 1) * sizeof(uint32_t)));
+		if (maxlen > n_clumps || maxlen >= (1u << 24)) { ACXFREE(); fail(BHIP_E_ARG, "an accelerator list has %u entries, the database %u clumps (wrong K for this file?)", maxlen, n_clumps); bhip_destroy(h); return BHIP_E_ARG; }
+		if (tot_b >= (1ull << 40)) { ACXFREE(); fail(BHIP_E_ARG, "accelerator with %llu entries exceeds the 40-bit entry numbers of the device layout", (unsigned long long)tot); bhip_destroy(h); return BHIP_E_ARG; }
+		// the packed list area goes up as it is on disk and is decoded to 5-byte records by the device
+		ACXRC(h->acx_rec.reserve(tot * BHIP_REC_BYTES + 16));
 		{
-			DBuf d_lists, d_boff, d_flag;
-			INITRC(d_lists.reserve(bytes + 16));
-			INITRC(d_boff.reserve((nw + 1) * sizeof(unsigned long long)));
-			INITRC(d_flag.reserve(16));
-			tb1 = tb; INITCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tb1, d_lens.as<uint32_t>(), h->acx_off.as<uint32_t>(), (int)nw, h->stream));
-			{
-				size_t tb2 = 0;
-				INITCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, it_bytes, d_boff.as<unsigned long long>(), (int)nw, h->stream));
-				INITRC(d_tmp.reserve(tb2 + 16));
-				INITCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tb2, it_bytes, d_boff.as<unsigned long long>(), (int)nw, h->stream));
-			}
-			const uint32_t tot32 = (uint32_t)tot; const unsigned long long bytes64 = bytes;
-			INITCHK(hipMemcpyAsync(h->acx_off.as<uint32_t>() + nw, &tot32, 4, hipMemcpyHostToDevice, h->stream));
-			INITCHK(hipMemcpyAsync(d_boff.as<unsigned long long>() + nw, &bytes64, 8, hipMemcpyHostToDevice, h->stream));
-			if (bytes) INITCHK(hipMemcpyAsync(d_lists.p, acx_lists, bytes, hipMemcpyHostToDevice, h->stream));
-			INITCHK(hipMemsetAsync(d_flag.p, 0, 16, h->stream));
-			hipLaunchKernelGGL(k_acx_decode, dim3((uint32_t)h->n_cu * 32), dim3(256), 0, h->stream, d_lists.as<uint8_t>(), d_boff.as<unsigned long long>(),
-				h->acx_off.as<uint32_t>(), nw, acx_fmt, n_clumps, h->acx_ent.as<uint32_t>(), d_flag.as<uint32_t>());
-			INITCHK(hipGetLastError());
+			DBuf d_lists, d_flag;
+			int rcl;
+			if ((rcl = d_lists.reserve(bytes + 16)) || (rcl = d_flag.reserve(16))) { d_lists.release(); d_flag.release(); ACXRC(rcl); }
+			#define ACXCHK2(x) do { hipError_t e2_ = (x); if (e2_ != hipSuccess) { d_lists.release(); d_flag.release(); ACXFREE(); \
+				fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e2_)); bhip_destroy(h); return BHIP_E_DEVICE; } } while (0)
+			if (bytes) ACXCHK2(hipMemcpyAsync(d_lists.p, acx_lists, bytes, hipMemcpyHostToDevice, h->stream));
+			ACXCHK2(hipMemsetAsync(d_flag.p, 0, 16, h->stream));
+			hipLaunchKernelGGL(k_acx_decode, dim3((uint32_t)h->n_cu * 32), dim3(256), 0, h->stream, d_lists.as<uint8_t>(), d_bbase.as<unsigned long long>(),
+				d_bdelta.as<uint32_t>(), h->acx_view(), nw, acx_fmt, n_clumps, (uint8_t *)h->acx_view().rec, d_flag.as<uint32_t>());
+			ACXCHK2(hipGetLastError());
 			uint32_t worst = 0;
-			INITCHK(hipMemcpyAsync(&worst, d_flag.p, 4, hipMemcpyDeviceToHost, h->stream));
-			INITCHK(hipStreamSynchronize(h->stream));
-			d_lists.release(); d_boff.release(); d_flag.release(); d_lens.release(); d_red.release(); d_tmp.release();
+			ACXCHK2(hipMemcpyAsync(&worst, d_flag.p, 4, hipMemcpyDeviceToHost, h->stream));
+			ACXCHK2(hipStreamSynchronize(h->stream));
+			#undef ACXCHK2
+			d_lists.release(); d_flag.release();
+			ACXFREE();
 			if (worst) { fail(BHIP_E_ARG, "an accelerator entry refers to clump %u >= %u", worst, n_clumps); bhip_destroy(h); return BHIP_E_ARG; }
 		}
+		#undef ACXFREE
+		#undef ACXRC
+		#undef ACXCHK
+		if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] accelerator: K=%d, %llu entries (first entry number %llu), %.2f B per entry on the device (records %d B + offsets)\n", K,
+			(unsigned long long)tot, (unsigned long long)h->acx_bias, tot ? (double)(tot * BHIP_REC_BYTES + nw * 4 + nblk * 8) / (double)tot : 0.0, BHIP_REC_BYTES);
 		h->n_bad = n_bad;
 		INITRC(h->bad.reserve((n_bad + 1) * sizeof(uint32_t)));
 		if (n_bad) {
@@ -692,7 +712,7 @@ static int launch_prefilter(Handle *h, Lane *L, hipStream_t pf_st, const uint32_
 		const uint32_t n_quads = (n_list + 3) / 4;
 		const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * 6);
 		hipLaunchKernelGGL(k_prefilter_hash, dim3(grid), dim3(64), 0, st, h->s_codes(), h->s_off(), h->s_emac(),
-			d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read,
+			d_qlist, n_list, h->acx_view(), h->K, bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read,
 			plan, L->fb_list.as<uint32_t>(), &dc->n_fb);
 		HIPCHK(hipGetLastError());
 	}
@@ -704,17 +724,17 @@ static int launch_prefilter(Handle *h, Lane *L, hipStream_t pf_st, const uint32_
 		const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / lds_w));
 		const uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * per_cu);
 		if (narrow) hipLaunchKernelGGL(k_prefilter_wave<uint8_t>, dim3(grid), dim3(64), lds_w, st, h->s_codes(), h->s_off(),
-			h->s_emac(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
+			h->s_emac(), d_qlist, n_list, h->acx_view(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
 			n_cand_dev, cand_cap, &dc->ent_read, plan, L->fb_list.as<uint32_t>(), &dc->n_fb);
 		else hipLaunchKernelGGL(k_prefilter_wave<uint16_t>, dim3(grid), dim3(64), lds_w, st, h->s_codes(), h->s_off(),
-			h->s_emac(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
+			h->s_emac(), d_qlist, n_list, h->acx_view(), h->K, h->n_clumps, bad, n_bad, cand, candcnt,
 			n_cand_dev, cand_cap, &dc->ent_read, plan, L->fb_list.as<uint32_t>(), &dc->n_fb);
 	} else {
 		// dense counters in global memory, one workgroup per query (very large databases only)
 		uint32_t grid = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * 2);
 		if ((rc = L->gcnt.reserve((size_t)grid * nw32 * 4))) return rc;
 		hipLaunchKernelGGL(k_prefilter<false>, dim3(grid), dim3(256), 0, st, h->s_codes(), h->s_off(),
-			h->s_emac(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps,
+			h->s_emac(), d_qlist, n_list, h->acx_view(), h->K, h->n_clumps,
 			L->gcnt.as<uint32_t>(), bad, n_bad, cand, candcnt, n_cand_dev, cand_cap, &dc->ent_read, L->fb_list.as<uint32_t>(), &dc->n_fb, plan);
 	}
 	HIPCHK(hipGetLastError());
@@ -734,7 +754,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	const uint64_t n_thr = (uint64_t)n_list * W16;
 	HIPCHK(hipEventRecord(L->ev_pf[cls][0], st));
 	hipLaunchKernelGGL(k_seed_ranges, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, h->s_codes(), h->s_off(), d_qlist, n_list,
-		h->acx_off.as<uint32_t>(), h->K, h->plan.as<uint32_t>(), W16, L->ranges.as<uint2>(), L->hdr.as<uint2>(), h->s_pack(), (h->st_maxlen + 7) / 8, h->s_emac());
+		h->acx_view(), h->K, h->plan.as<uint32_t>(), W16, L->ranges.as<uint2>(), L->hdr.as<uint2>(), h->s_pack(), (h->st_maxlen + 7) / 8, h->s_emac());
 	const int algo = h->opt_pf_algo >= 0 ? h->opt_pf_algo : L->pf_algo;
 	const uint32_t n_quads = (n_list + 3) / 4;
 	// hash table size per query from the expected number of distinct clumps (sampled words x occurrence-weighted mean list
@@ -764,7 +784,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	HIPCHK(hipEventRecord(L->ev_pf[cls][1], st));
 	if (algo == 0) {
 #define PFC_LAUNCH(B) hipLaunchKernelGGL(k_prefilter_cf<B>, dim3(grid), dim3(64), 0, st, L->ranges.as<uint2>(), L->hdr.as<uint2>(), W16, n_list, \
-		h->ent_mask.as<uint2>(), h->bad.as<uint32_t>(), h->n_bad, \
+		h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, \
 		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
 		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum, \
 		L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], prune)
@@ -772,7 +792,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 #undef PFC_LAUNCH
 	} else {
 #define PFM_LAUNCH(B) hipLaunchKernelGGL(k_prefilter_mask<B>, dim3(grid), dim3(64), 0, st, L->ranges.as<uint2>(), L->hdr.as<uint2>(), W16, n_list, \
-		h->ent_mask.as<uint2>(), h->bad.as<uint32_t>(), h->n_bad, \
+		h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, \
 		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
 		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, L->cand.as<uint2>(), n_cand_dev, (uint32_t)L->cand_cap)
 		if (htb == 9) PFM_LAUNCH(9); else if (htb == 10) PFM_LAUNCH(10); else PFM_LAUNCH(11);
@@ -791,16 +811,16 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 		const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / lds_w));
 		const uint32_t g2 = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * per_cu);
 		if (narrow) hipLaunchKernelGGL(k_prefilter_wave<uint8_t>, dim3(g2), dim3(64), lds_w, st, h->s_codes(), h->s_off(),
-			h->s_emac(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, h->n_bad, L->cand.as<uint2>(),
+			h->s_emac(), d_qlist, n_list, h->acx_view(), h->K, h->n_clumps, bad, h->n_bad, L->cand.as<uint2>(),
 			(uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read, h->plan.as<uint32_t>(), L->fb_list.as<uint32_t>(), &dc->n_fb);
 		else hipLaunchKernelGGL(k_prefilter_wave<uint16_t>, dim3(g2), dim3(64), lds_w, st, h->s_codes(), h->s_off(),
-			h->s_emac(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps, bad, h->n_bad, L->cand.as<uint2>(),
+			h->s_emac(), d_qlist, n_list, h->acx_view(), h->K, h->n_clumps, bad, h->n_bad, L->cand.as<uint2>(),
 			(uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read, h->plan.as<uint32_t>(), L->fb_list.as<uint32_t>(), &dc->n_fb);
 	} else {
 		uint32_t g2 = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * 2);
 		if ((rc = L->gcnt.reserve((size_t)g2 * nw32 * 4))) return rc;
 		hipLaunchKernelGGL(k_prefilter<false>, dim3(g2), dim3(256), 0, st, h->s_codes(), h->s_off(),
-			h->s_emac(), d_qlist, n_list, h->acx_off.as<uint32_t>(), h->acx_ent.as<uint32_t>(), h->K, h->n_clumps,
+			h->s_emac(), d_qlist, n_list, h->acx_view(), h->K, h->n_clumps,
 			L->gcnt.as<uint32_t>(), bad, h->n_bad, L->cand.as<uint2>(), (uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read,
 			L->fb_list.as<uint32_t>(), &dc->n_fb, h->plan.as<uint32_t>());
 	}

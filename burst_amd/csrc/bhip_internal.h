@@ -24,4 +24,44 @@ struct BhipWin {
 
 #define BHIP_RESCORE_WMAX 48   // band widths up to this many diagonals are handled in LDS
 
+// ------------------------------------------------------------------------------------------------
+// Accelerator (.acx, burst.c:3535-3594) as it lives in HBM.
+//   Lists: one 5-byte record per list entry, in the file's word order: bytes 0-2 = clump id (the 24 bits of the LARGE format,
+//   burst.c:3245-3248), bytes 3-4 = 16-bit lane mask (bit z: lane z of the clump really holds the word; 0xFFFF when the
+//   masks were not built).  Offsets: the file's Lens[4^K] (burst.c:3558) becomes a two-level table -- `base`, a 64-bit
+//   entry offset per block of 256 words, and `delta`, the 32-bit exclusive prefix of the lengths inside the block.  A list is
+//   shorter than 2^24 entries (one per clump at most, burst.c:3385-3386, clump ids have 24 bits), so 256 of them always fit
+//   32 bits, while the whole accelerator may hold far more than 2^32 entries (RefSeq scale: ~5 * 10^10).
+//   `rec` may point BEFORE the allocation (test hook BHIP_TEST_ENTRY_BIAS: entry numbers start at the bias, so that small
+//   databases exercise offsets beyond 2^32); only entry numbers >= the bias are ever dereferenced.
+// ------------------------------------------------------------------------------------------------
+#define BHIP_ACX_BLOCK_LOG 8
+#define BHIP_REC_BYTES 5
+struct BhipAcxView {
+	const uint32_t *delta;               // [n_words + 1]
+	const unsigned long long *base;      // [(n_words >> 8) + 2]
+	const uint8_t *rec;                  // 5 bytes per entry
+};
+
+#ifdef __HIPCC__
+// entry range of word w: first entry and length
+__device__ __forceinline__ void bhip_acx_range(const BhipAcxView &a, uint32_t w, unsigned long long &beg, uint32_t &n) {
+	const uint32_t blk = w >> BHIP_ACX_BLOCK_LOG;
+	const unsigned long long b0 = a.base[blk];
+	const uint32_t d0 = a.delta[w];
+	beg = b0 + d0;
+	if ((w & ((1u << BHIP_ACX_BLOCK_LOG) - 1u)) == (1u << BHIP_ACX_BLOCK_LOG) - 1u) n = (uint32_t)(a.base[blk + 1] - beg);
+	else n = a.delta[w + 1] - d0;
+}
+// record e as (clump, lane mask): two aligned dword loads around the 5 bytes
+__device__ __forceinline__ uint2 bhip_acx_rec(const uint8_t *rec, unsigned long long e) {
+	const uintptr_t addr = (uintptr_t)rec + e * (unsigned long long)BHIP_REC_BYTES;
+	const uint32_t *p = (const uint32_t *)(addr & ~(uintptr_t)3);
+	const uint32_t d0 = p[0], d1 = p[1];
+	const unsigned long long v = (((unsigned long long)d1 << 32) | d0) >> (8u * (uint32_t)(addr & 3u));
+	return make_uint2((uint32_t)v & 0xFFFFFFu, (uint32_t)(v >> 24) & 0xFFFFu);
+}
+__device__ __forceinline__ uint32_t bhip_acx_clump(const uint8_t *rec, unsigned long long e) { return bhip_acx_rec(rec, e).x; }
+#endif
+
 #endif

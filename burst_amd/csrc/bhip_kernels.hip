@@ -52,29 +52,61 @@ __global__ void k_transpose_refs(const uint8_t *__restrict__ src, const uint64_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// .acx list area -> one u32 clump id per entry, on the device (the packed bytes are what is uploaded): SMALL lists are
-// pairs of 20-bit ids in 5 bytes with a 3-byte odd tail (burst.c:3265-3274), LARGE lists 3 bytes per id (3245-3248).
-// One thread per word; `bad` is raised when an id is not a clump of the database.
+// .acx offsets: Lens[4^K] (burst.c:3558) -> exclusive prefix inside each block of 256 words (`delta`) and the block sums
+// (scanned to 64-bit block bases by the caller).  WHAT = 0: list lengths (entries); 1: bytes of the packed SMALL lists
+// (pairs of 20-bit ids in 5 bytes with a 3-byte odd tail, burst.c:3516-3527); 2: bytes of the LARGE lists (3 per id).
+// One 256-thread workgroup per block of words.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_acx_decode(const uint8_t *__restrict__ lists, const unsigned long long *__restrict__ byte_off, const uint32_t *__restrict__ off,
-                             uint64_t n_words, int fmt, uint32_t n_clumps, uint32_t *__restrict__ ent, uint32_t *__restrict__ bad) {
+__global__ __launch_bounds__(256) void k_acx_offsets(const uint32_t *__restrict__ lens, uint64_t n_words, int what,
+                                                     uint32_t *__restrict__ delta, unsigned long long *__restrict__ blocksum) {
+	__shared__ uint32_t s_w[4];
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint64_t n_blocks = (n_words + 255) >> 8;
+	for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+		const uint64_t w = blk * 256 + tid;
+		const uint32_t len = w < n_words ? lens[w] : 0u;
+		const uint32_t v = what == 0 ? len : what == 1 ? 5u * (len >> 1) + 3u * (len & 1u) : 3u * len;
+		uint32_t ps = v;
+		#pragma unroll
+		for (uint32_t o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(ps, o); if (lane >= o) ps += t; }
+		__syncthreads();
+		if (lane == 63) s_w[wv] = ps;
+		__syncthreads();
+		uint32_t add = 0;
+		for (uint32_t k = 0; k < wv; ++k) add += s_w[k];
+		if (w < n_words) delta[w] = add + ps - v;
+		if (tid == 255) blocksum[blk] = (unsigned long long)add + ps;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// .acx list area -> 5-byte records (24-bit clump id, 16-bit lane mask preset to "every lane"), on the device (the packed bytes
+// are what is uploaded): SMALL lists are pairs of 20-bit ids in 5 bytes with a 3-byte odd tail (burst.c:3265-3274), LARGE
+// lists 3 bytes per id (3245-3248).  One thread per word; `bad` is raised when an id is not a clump of the database.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bhip_rec_store(uint8_t *rec, unsigned long long e, uint32_t clump, uint32_t mask) {
+	uint8_t *p = rec + e * (unsigned long long)BHIP_REC_BYTES;
+	p[0] = (uint8_t)clump; p[1] = (uint8_t)(clump >> 8); p[2] = (uint8_t)(clump >> 16); p[3] = (uint8_t)mask; p[4] = (uint8_t)(mask >> 8);
+}
+__global__ void k_acx_decode(const uint8_t *__restrict__ lists, const unsigned long long *__restrict__ byte_base, const uint32_t *__restrict__ byte_delta,
+                             BhipAcxView acx, uint64_t n_words, int fmt, uint32_t n_clumps, uint8_t *__restrict__ rec, uint32_t *__restrict__ bad) {
 	for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
-		const uint32_t e0 = off[w];
-		uint32_t n = off[w + 1] - e0;
+		unsigned long long e; uint32_t n;
+		bhip_acx_range(acx, (uint32_t)w, e, n);
 		if (!n) continue;
-		const uint8_t *p = lists + byte_off[w];
-		uint32_t e = e0, worst = 0;
+		const uint8_t *p = lists + byte_base[w >> BHIP_ACX_BLOCK_LOG] + byte_delta[w];
+		uint32_t worst = 0;
 		if (fmt == 1) {
-			for (; n; --n, p += 3) { const uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); ent[e++] = v; worst = v > worst ? v : worst; }
+			for (; n; --n, p += 3) { const uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); bhip_rec_store(rec, e++, v, 0xFFFFu); worst = v > worst ? v : worst; }
 		} else {
 			for (; n >= 2; n -= 2, p += 5) {
 				const unsigned long long v = (unsigned long long)p[0] | ((unsigned long long)p[1] << 8) | ((unsigned long long)p[2] << 16) |
 				                             ((unsigned long long)p[3] << 24) | ((unsigned long long)p[4] << 32);
 				const uint32_t a = (uint32_t)(v & 0xFFFFF), b = (uint32_t)((v >> 20) & 0xFFFFF);
-				ent[e++] = a; ent[e++] = b;
+				bhip_rec_store(rec, e++, a, 0xFFFFu); bhip_rec_store(rec, e++, b, 0xFFFFu);
 				worst = a > worst ? a : worst; worst = b > worst ? b : worst;
 			}
-			if (n) { const uint32_t v = ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)) & 0xFFFFF; ent[e++] = v; worst = v > worst ? v : worst; }
+			if (n) { const uint32_t v = ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)) & 0xFFFFF; bhip_rec_store(rec, e++, v, 0xFFFFu); worst = v > worst ? v : worst; }
 		}
 		if (worst >= n_clumps) atomicMax(bad, worst);
 	}
@@ -173,7 +205,7 @@ template <bool LDS_CNT>
 __global__ __launch_bounds__(256) void k_prefilter(
 		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint16_t *__restrict__ qemac,
 		const uint32_t *__restrict__ qlist, uint32_t n_list,
-		const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, int K, uint32_t n_clumps,
+		BhipAcxView acx, int K, uint32_t n_clumps,
 		uint32_t *__restrict__ g_cnt, const uint32_t *__restrict__ bad, uint32_t n_bad,
 		uint2 *__restrict__ cand, uint32_t *__restrict__ cand_cnt_out, uint32_t *__restrict__ n_cand, uint32_t cand_cap,
 		unsigned long long *__restrict__ ent_read, const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel_dev,
@@ -204,22 +236,21 @@ __global__ __launch_bounds__(256) void k_prefilter(
 					w = (w << 2) | ((c - 1u) & 3u);
 				}
 				w &= wmask;
-				uint32_t beg = 0, end = 0;
-				if (ok) beg = acx_off[w], end = acx_off[w + 1];
-				my_ent += end - beg;
+				unsigned long long beg = 0; uint32_t n = 0;
+				if (ok) bhip_acx_range(acx, w, beg, n);
+				my_ent += n;
 				// short lists: each lane walks its own; long lists: the wave walks them together
-				const uint32_t n = end - beg;
 				unsigned long long longm = __ballot(n > 32);
-				if (n <= 32) for (uint32_t e = beg; e < end; ++e) {
-					uint32_t c = acx_ent[e];
+				if (n <= 32) for (uint32_t e = 0; e < n; ++e) {
+					uint32_t c = bhip_acx_clump(acx.rec, beg + e);
 					atomicAdd(&cnt[c >> 1], 1u << ((c & 1) * 16));
 				}
 				while (longm) {
 					const int src = __builtin_ctzll(longm);
 					longm &= longm - 1;
-					const uint32_t lb = __shfl(beg, src), le = __shfl(end, src);
-					for (uint32_t e = lb + lane; e < le; e += 64) {
-						uint32_t c = acx_ent[e];
+					const unsigned long long lb = __shfl(beg, src); const uint32_t ln = __shfl(n, src);
+					for (uint32_t e = lane; e < ln; e += 64) {
+						uint32_t c = bhip_acx_clump(acx.rec, lb + e);
 						atomicAdd(&cnt[c >> 1], 1u << ((c & 1) * 16));
 					}
 				}
@@ -244,11 +275,8 @@ __global__ __launch_bounds__(256) void k_prefilter(
 	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
 }
 
-template __global__ void k_prefilter<true>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *,
-	const uint32_t *, const uint32_t *, const uint32_t *);
 template __global__ void k_prefilter<false>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	const uint32_t *, const uint32_t *, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *,
+	BhipAcxView, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *,
 	const uint32_t *, const uint32_t *, const uint32_t *);
 
 
@@ -274,7 +302,7 @@ template <typename CNT>
 __global__ __launch_bounds__(64) void k_prefilter_wave(
 		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint16_t *__restrict__ qemac,
 		const uint32_t *__restrict__ qlist, uint32_t n_list,
-		const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, int K, uint32_t n_clumps,
+		BhipAcxView acx, int K, uint32_t n_clumps,
 		const uint32_t *__restrict__ bad, uint32_t n_bad,
 		uint2 *__restrict__ cand, uint32_t *__restrict__ cand_cnt_out, uint32_t *__restrict__ n_cand, uint32_t cand_cap,
 		unsigned long long *__restrict__ ent_read, const uint32_t *__restrict__ plan,
@@ -343,24 +371,23 @@ __global__ __launch_bounds__(64) void k_prefilter_wave(
 					w = (w << 2) | ((c - 1u) & 3u);
 				}
 				w &= wmask;
-				uint32_t beg = 0, end = 0;
-				if (ok) { beg = acx_off[w]; end = acx_off[w + 1]; }
-				uint32_t n = end - beg;
+				unsigned long long beg = 0; uint32_t n = 0;
+				if (ok) bhip_acx_range(acx, w, beg, n);
 				my_ent += n;
 				unsigned long long longm = __ballot(n > 32);
 				if (n <= 32) {
-					uint32_t e = beg;
-					for (; e + 4 <= end; e += 4) {   // four independent loads in flight
-						const uint32_t c0 = acx_ent[e], c1 = acx_ent[e + 1], c2 = acx_ent[e + 2], c3 = acx_ent[e + 3];
+					uint32_t e = 0;
+					for (; e + 4 <= n; e += 4) {   // four independent loads in flight
+						const uint32_t c0 = bhip_acx_clump(acx.rec, beg + e), c1 = bhip_acx_clump(acx.rec, beg + e + 1), c2 = bhip_acx_clump(acx.rec, beg + e + 2), c3 = bhip_acx_clump(acx.rec, beg + e + 3);
 						bump(c0); bump(c1); bump(c2); bump(c3);
 					}
-					for (; e < end; ++e) bump(acx_ent[e]);
+					for (; e < n; ++e) bump(bhip_acx_clump(acx.rec, beg + e));
 				}
 				while (longm) {
 					const int src = __builtin_ctzll(longm);
 					longm &= longm - 1;
-					const uint32_t lb = __shfl(beg, src), le = __shfl(end, src);
-					for (uint32_t e = lb + lane; e < le; e += 64) bump(acx_ent[e]);
+					const unsigned long long lb = __shfl(beg, src); const uint32_t ln = __shfl(n, src);
+					for (uint32_t e = lane; e < ln; e += 64) bump(bhip_acx_clump(acx.rec, lb + e));
 				}
 			}
 		}
@@ -392,10 +419,10 @@ __global__ __launch_bounds__(64) void k_prefilter_wave(
 	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
 }
 template __global__ void k_prefilter_wave<uint8_t>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *,
+	BhipAcxView, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *,
 	const uint32_t *, const uint32_t *);
 template __global__ void k_prefilter_wave<uint16_t>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	const uint32_t *, const uint32_t *, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *,
+	BhipAcxView, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *,
 	const uint32_t *, const uint32_t *);
 
 // ------------------------------------------------------------------------------------------------
@@ -412,7 +439,7 @@ template __global__ void k_prefilter_wave<uint16_t>(const uint8_t *, const uint6
 __global__ __launch_bounds__(64) void k_prefilter_hash(
 		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint16_t *__restrict__ qemac,
 		const uint32_t *__restrict__ qlist, uint32_t n_list,
-		const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, int K,
+		BhipAcxView acx, int K,
 		const uint32_t *__restrict__ bad, uint32_t n_bad,
 		uint2 *__restrict__ cand, uint32_t *__restrict__ cand_cnt_out, uint32_t *__restrict__ n_cand, uint32_t cand_cap,
 		unsigned long long *__restrict__ ent_read, const uint32_t *__restrict__ plan,
@@ -499,24 +526,23 @@ __global__ __launch_bounds__(64) void k_prefilter_hash(
 				w = (w << 2) | ((c - 1u) & 3u);
 			}
 			w &= wmask;
-			uint32_t beg = 0, end = 0;
-			if (ok) { beg = acx_off[w]; end = acx_off[w + 1]; }
-			const uint32_t n = end - beg;
+			unsigned long long beg = 0; uint32_t n = 0;
+			if (ok) bhip_acx_range(acx, w, beg, n);
 			my_ent += n;
 			unsigned long long longm = __ballot(n > 48);
 			if (n <= 48) {
-				uint32_t e = beg;
-				for (; e + 4 <= end; e += 4) {
-					const uint32_t c0 = acx_ent[e], c1 = acx_ent[e + 1], c2 = acx_ent[e + 2], c3 = acx_ent[e + 3];
+				uint32_t e = 0;
+				for (; e + 4 <= n; e += 4) {
+					const uint32_t c0 = bhip_acx_clump(acx.rec, beg + e), c1 = bhip_acx_clump(acx.rec, beg + e + 1), c2 = bhip_acx_clump(acx.rec, beg + e + 2), c3 = bhip_acx_clump(acx.rec, beg + e + 3);
 					bump(g, c0); bump(g, c1); bump(g, c2); bump(g, c3);
 				}
-				for (; e < end; ++e) bump(g, acx_ent[e]);
+				for (; e < n; ++e) bump(g, bhip_acx_clump(acx.rec, beg + e));
 			}
 			while (longm) {   // long lists: the whole wave walks them, inserting into the owner's table
 				const int src = __builtin_ctzll(longm);
 				longm &= longm - 1;
-				const uint32_t lb = __shfl(beg, src), le = __shfl(end, src), tg = (uint32_t)src >> 4;
-				for (uint32_t e = lb + lane; e < le; e += 64) bump(tg, acx_ent[e]);
+				const unsigned long long lb = __shfl(beg, src); const uint32_t ln = __shfl(n, src), tg = (uint32_t)src >> 4;
+				for (uint32_t e = lane; e < ln; e += 64) bump(tg, bhip_acx_clump(acx.rec, lb + e));
 			}
 		}
 		__syncthreads();
@@ -584,20 +610,24 @@ __global__ void k_extract_kmers(const uint4 *__restrict__ ref, const uint64_t *_
 	}
 }
 
-__global__ void k_attach_masks(const uint32_t *__restrict__ acx_off, const uint32_t *__restrict__ acx_ent, uint64_t n_ent, uint32_t n_words,
+__global__ void k_attach_masks(BhipAcxView acx, uint64_t n_words,
                                const unsigned long long *__restrict__ ukeys, const uint16_t *__restrict__ umasks, uint32_t n_unique,
-                               const uint32_t *__restrict__ ambig_lanes, uint2 *__restrict__ ent_mask,    // (clump, lane mask) records
+                               const uint32_t *__restrict__ ambig_lanes, uint8_t *__restrict__ rec,     // mask bytes of the 5-byte records
                                uint32_t c0, uint32_t c1) {                                                 // only entries of clumps [c0, c1)
-	for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n_ent; e += (uint64_t)gridDim.x * blockDim.x) {
-		{ const uint32_t ce = acx_ent[e]; if (ce < c0 || ce >= c1) continue; }
-		// word of entry e: last w with acx_off[w] <= e
-		uint32_t lo = 0, hi = n_words;
-		while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (acx_off[mid] <= e) lo = mid; else hi = mid; }
-		const unsigned long long key = ((unsigned long long)lo << 24) | acx_ent[e];
-		uint32_t a = 0, b = n_unique;
-		while (a < b) { const uint32_t mid = a + ((b - a) >> 1); if (ukeys[mid] < key) a = mid + 1; else b = mid; }
-		const uint16_t m = (a < n_unique && ukeys[a] == key) ? umasks[a] : (uint16_t)0xFFFFu;
-		ent_mask[e] = make_uint2(acx_ent[e], (uint32_t)(m | ambig_lanes[acx_ent[e]]) & 0xFFFFu);
+	// one thread per word walks its list (a few entries); the key of an entry is (word, clump), looked up in the folded tuples
+	for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+		unsigned long long e; uint32_t n;
+		bhip_acx_range(acx, (uint32_t)w, e, n);
+		for (; n; --n, ++e) {
+			const uint32_t ce = bhip_acx_clump(acx.rec, e);
+			if (ce < c0 || ce >= c1) continue;
+			const unsigned long long key = ((unsigned long long)w << 24) | ce;
+			uint32_t a = 0, b = n_unique;
+			while (a < b) { const uint32_t mid = a + ((b - a) >> 1); if (ukeys[mid] < key) a = mid + 1; else b = mid; }
+			const uint32_t m = ((a < n_unique && ukeys[a] == key) ? (uint32_t)umasks[a] : 0xFFFFu) | (ambig_lanes[ce] & 0xFFFFu);
+			uint8_t *p = rec + e * (unsigned long long)BHIP_REC_BYTES;
+			p[3] = (uint8_t)m; p[4] = (uint8_t)(m >> 8);
+		}
 	}
 }
 
@@ -660,7 +690,7 @@ __device__ __forceinline__ void pfm_bump4(uint32_t *tab, uint32_t *dummy, const 
 // list -> offsets -> symbols -> acx offsets out of the hash kernel (fully parallel here, four round trips there).
 __global__ __launch_bounds__(256) void k_seed_ranges(
 		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint32_t *__restrict__ qlist, uint32_t n_list,
-		const uint32_t *__restrict__ acx_off, int K, const uint32_t *__restrict__ plan, uint32_t W16,
+		BhipAcxView acx, int K, const uint32_t *__restrict__ plan, uint32_t W16,
 		uint2 *__restrict__ ranges, uint2 *__restrict__ hdr, const uint32_t *__restrict__ qpack, uint32_t qw, const uint16_t *__restrict__ qemac) {
 	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	const uint32_t li = (uint32_t)(t / W16), j = (uint32_t)(t % W16);
@@ -692,7 +722,11 @@ __global__ __launch_bounds__(256) void k_seed_ranges(
 			w = (w << 2) | ((c - 1u) & 3u);
 		}
 		w &= wmask;
-		if (ok) { r.x = acx_off[w]; r.y = acx_off[w + 1]; }
+		if (ok) {      // range = first entry (40 bits) and length (24 bits): x = low 32 bits of the entry, y = length | high bits << 24
+			unsigned long long beg; uint32_t n;
+			bhip_acx_range(acx, w, beg, n);
+			r.x = (uint32_t)beg; r.y = n | (uint32_t)(beg >> 32) << 24;
+		}
 	}
 	ranges[t] = r;
 	// header: need | words << 16 ; length | budget << 12 | (words one edit can destroy = ceil(K / stride)) << 20
@@ -702,7 +736,7 @@ __global__ __launch_bounds__(256) void k_seed_ranges(
 template <int HTB>
 __global__ __launch_bounds__(64) void k_prefilter_mask(
 		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
-		const uint2 *__restrict__ ent,   // ent = (clump, lane mask) records
+		const uint8_t *__restrict__ ent,   // 5-byte (clump, lane mask) records
 		const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ clump_len, uint32_t tot_refs,
 		uint2 *__restrict__ tasks, uint32_t *__restrict__ n_tasks, uint32_t task_cap,
 		unsigned long long *__restrict__ ent_read,
@@ -787,17 +821,18 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 		uint32_t maxw = nwords;
 		#pragma unroll
 		for (int o = 32; o >= 1; o >>= 1) { const uint32_t t = __shfl_xor(maxw, o); maxw = t > maxw ? t : maxw; }
-		auto word_range = [&](uint32_t j, uint32_t &beg, uint32_t &end) {
+		auto word_range = [&](uint32_t j, unsigned long long &beg, uint32_t &n) {
 			uint2 r = make_uint2(0, 0);
 			if (live && j < nwords) r = ranges[(size_t)li * W16 + j];
-			beg = r.x; end = r.y;
+			beg = (unsigned long long)r.x | (unsigned long long)(r.y >> 24) << 32; n = r.y & 0xFFFFFFu;
 		};
 		PFM_T(0);
 		// ---- pass 1: clump-level counts.  The (up to 16) lists of a query are walked as ONE flattened record stream by the
 		// 16 lanes of its group: record i belongs to the list k with excl[k] <= i < excl[k+1] (4-step search over the group's
 		// exclusive prefix sums), so the lanes stay busy whatever the individual list lengths.  Blocks of 4 rounds (64
 		// records per query) are loaded together and updated in lock step; the first PFM_RB blocks stay in registers for pass 2.
-		const uint32_t beg = live ? rg.x : 0u, n0 = live ? rg.y - rg.x : 0u;
+		const unsigned long long beg = live ? ((unsigned long long)rg.x | (unsigned long long)(rg.y >> 24) << 32) : 0ull;
+		const uint32_t n0 = live ? rg.y & 0xFFFFFFu : 0u;
 		my_ent += n0;
 		auto group_scan = [&](uint32_t n, uint32_t &T, uint32_t &excl) {
 			uint32_t ps = n;
@@ -812,7 +847,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 			t = __shfl_xor(m, 32); m = t > m ? t : m;
 			return (m + 63) >> 6;
 		};
-		auto load4 = [&](uint32_t ex, uint32_t dl, uint32_t T, uint32_t b, uint2 (&rec)[4]) {
+		auto load4 = [&](uint32_t ex, unsigned long long dl, uint32_t T, uint32_t b, uint2 (&rec)[4]) {
 			#pragma unroll
 			for (uint32_t u = 0; u < 4; ++u) {
 				const uint32_t i = (b * 4 + u) * 16 + gl;
@@ -821,8 +856,8 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 				kk += __shfl(ex, kk + 4, 16) <= i ? 4u : 0u;
 				kk += __shfl(ex, kk + 2, 16) <= i ? 2u : 0u;
 				kk += __shfl(ex, kk + 1, 16) <= i ? 1u : 0u;
-				const uint32_t addr = __shfl(dl, kk, 16) + i;
-				rec[u] = i < T ? ent[addr] : make_uint2(0xFFFFFFFFu, 0);
+				const unsigned long long addr = __shfl(dl, kk, 16) + i;
+				rec[u] = i < T ? bhip_acx_rec(ent, addr) : make_uint2(0xFFFFFFFFu, 0);
 			}
 		};
 		auto bump_block = [&](uint2 (&rec)[4]) {
@@ -844,7 +879,8 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 		};
 		uint32_t T0, ex0;
 		group_scan(n0, T0, ex0);
-		const uint32_t dl0 = beg - ex0, nblk0 = wave_blocks(T0);
+		const unsigned long long dl0 = beg - ex0;
+		const uint32_t nblk0 = wave_blocks(T0);
 		uint2 rc[PFM_RB][4];           // .x = clump, .y = lane mask | slot << 16
 		#pragma unroll
 		for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) load4(ex0, dl0, T0, b, rc[b]);
@@ -854,10 +890,10 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 		PFM_T(7);
 		for (uint32_t b = PFM_RB; b < nblk0; ++b) { uint2 rec[4]; load4(ex0, dl0, T0, b, rec); bump_block(rec); }
 		for (uint32_t base = 16; base < maxw; base += 16) {       // queries with more than 16 sampled words: further chunks, not cached
-			uint32_t xb, xe, T, ex;
-			word_range(base + gl, xb, xe);
-			my_ent += xe - xb;
-			group_scan(xe - xb, T, ex);
+			unsigned long long xb; uint32_t xn, T, ex;
+			word_range(base + gl, xb, xn);
+			my_ent += xn;
+			group_scan(xn, T, ex);
 			const uint32_t nb = wave_blocks(T);
 			for (uint32_t b = 0; b < nb; ++b) { uint2 rec[4]; load4(ex, xb - ex, T, b, rec); bump_block(rec); }
 		}
@@ -910,9 +946,9 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 				for (int u = 0; u < 4; ++u) if (mine && rec[u].x != 0xFFFFFFFFu) lanes_add(g, rec[u].x, rec[u].y);
 			}
 			for (uint32_t base = 16; base < maxw; base += 16) {
-				uint32_t xb, xe, T, ex;
-				word_range(base + gl, xb, xe);
-				group_scan(xe - xb, T, ex);
+				unsigned long long xb; uint32_t xn, T, ex;
+				word_range(base + gl, xb, xn);
+				group_scan(xn, T, ex);
 				const uint32_t nb = wave_blocks(T);
 				for (uint32_t b = 0; b < nb; ++b) {
 					uint2 rec[4];
@@ -977,7 +1013,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 template <int CB>
 __global__ __launch_bounds__(64) void k_prefilter_cf(
 		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
-		const uint2 *__restrict__ ent,   // ent = (clump, lane mask) records
+		const uint8_t *__restrict__ ent,   // 5-byte (clump, lane mask) records
 		const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ clump_len, uint32_t tot_refs,
 		uint2 *__restrict__ tasks, uint32_t *__restrict__ n_tasks, uint32_t task_cap,
 		unsigned long long *__restrict__ ent_read,
@@ -1054,10 +1090,10 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 		uint32_t maxw = nwords;
 		#pragma unroll
 		for (int o = 32; o >= 1; o >>= 1) { const uint32_t t = __shfl_xor(maxw, o); maxw = t > maxw ? t : maxw; }
-		auto word_range = [&](uint32_t j, uint32_t &beg, uint32_t &end) {
+		auto word_range = [&](uint32_t j, unsigned long long &beg, uint32_t &n) {
 			uint2 r = make_uint2(0, 0);
 			if (live && j < nwords) r = ranges[(size_t)li * W16 + j];
-			beg = r.x; end = r.y;
+			beg = (unsigned long long)r.x | (unsigned long long)(r.y >> 24) << 32; n = r.y & 0xFFFFFFu;
 		};
 		auto group_scan = [&](uint32_t n, uint32_t &T, uint32_t &excl) {
 			uint32_t ps = n;
@@ -1072,7 +1108,7 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 			t = __shfl_xor(m, 32); m = t > m ? t : m;
 			return (m + 63) >> 6;
 		};
-		auto load4 = [&](uint32_t ex, uint32_t dl, uint32_t T, uint32_t b, uint2 (&rec)[4]) {      // see k_prefilter_mask
+		auto load4 = [&](uint32_t ex, unsigned long long dl, uint32_t T, uint32_t b, uint2 (&rec)[4]) {      // see k_prefilter_mask
 			#pragma unroll
 			for (uint32_t u = 0; u < 4; ++u) {
 				const uint32_t i = (b * 4 + u) * 16 + gl;
@@ -1081,8 +1117,8 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 				kk += __shfl(ex, kk + 4, 16) <= i ? 4u : 0u;
 				kk += __shfl(ex, kk + 2, 16) <= i ? 2u : 0u;
 				kk += __shfl(ex, kk + 1, 16) <= i ? 1u : 0u;
-				const uint32_t addr = __shfl(dl, kk, 16) + i;
-				rec[u] = i < T ? ent[addr] : make_uint2(0xFFFFFFFFu, 0);
+				const unsigned long long addr = __shfl(dl, kk, 16) + i;
+				rec[u] = i < T ? bhip_acx_rec(ent, addr) : make_uint2(0xFFFFFFFFu, 0);
 			}
 		};
 		auto count4 = [&](const uint2 (&rec)[4]) {     // phase A: approximate counters, no return values
@@ -1148,11 +1184,13 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 		};
 
 		PFM_T(0);
-		const uint32_t beg = live ? rg.x : 0u, n0 = live ? rg.y - rg.x : 0u;
+		const unsigned long long beg = live ? ((unsigned long long)rg.x | (unsigned long long)(rg.y >> 24) << 32) : 0ull;
+		const uint32_t n0 = live ? rg.y & 0xFFFFFFu : 0u;
 		my_ent += n0;
 		uint32_t T0, ex0;
 		group_scan(n0, T0, ex0);
-		const uint32_t dl0 = beg - ex0, nblk0 = wave_blocks(T0);
+		const unsigned long long dl0 = beg - ex0;
+		const uint32_t nblk0 = wave_blocks(T0);
 		uint2 rc[PFM_RB][4];
 		#pragma unroll
 		for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) load4(ex0, dl0, T0, b, rc[b]);
@@ -1162,10 +1200,10 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 		for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) count4(rc[b]);
 		for (uint32_t b = PFM_RB; b < nblk0; ++b) { uint2 rec[4]; load4(ex0, dl0, T0, b, rec); count4(rec); }
 		for (uint32_t base = 16; base < maxw; base += 16) {
-			uint32_t xb, xe, T, ex;
-			word_range(base + gl, xb, xe);
-			my_ent += xe - xb;
-			group_scan(xe - xb, T, ex);
+			unsigned long long xb; uint32_t xn, T, ex;
+			word_range(base + gl, xb, xn);
+			my_ent += xn;
+			group_scan(xn, T, ex);
 			const uint32_t nb = wave_blocks(T);
 			for (uint32_t b = 0; b < nb; ++b) { uint2 rec[4]; load4(ex, xb - ex, T, b, rec); count4(rec); }
 		}
@@ -1176,9 +1214,9 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 		for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) offer4(rc[b]);
 		for (uint32_t b = PFM_RB; b < nblk0; ++b) { uint2 rec[4]; load4(ex0, dl0, T0, b, rec); offer4(rec); }
 		for (uint32_t base = 16; base < maxw; base += 16) {
-			uint32_t xb, xe, T, ex;
-			word_range(base + gl, xb, xe);
-			group_scan(xe - xb, T, ex);
+			unsigned long long xb; uint32_t xn, T, ex;
+			word_range(base + gl, xb, xn);
+			group_scan(xn, T, ex);
 			const uint32_t nb = wave_blocks(T);
 			for (uint32_t b = 0; b < nb; ++b) { uint2 rec[4]; load4(ex, xb - ex, T, b, rec); offer4(rec); }
 		}
@@ -1275,16 +1313,16 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 	if (my_units) { atomicAdd(unit_sum, my_units); atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
 }
 #define BHIP_INST_PFCF(CB) \
-	template __global__ void k_prefilter_cf<CB>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, \
+	template __global__ void k_prefilter_cf<CB>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, \
 		uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *, \
 		uint2 *, uint32_t *, int);
 BHIP_INST_PFCF(9) BHIP_INST_PFCF(10) BHIP_INST_PFCF(11)
 
-template __global__ void k_prefilter_mask<9>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+template __global__ void k_prefilter_mask<9>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, uint32_t);
-template __global__ void k_prefilter_mask<10>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+template __global__ void k_prefilter_mask<10>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, uint32_t);
-template __global__ void k_prefilter_mask<11>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+template __global__ void k_prefilter_mask<11>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, uint32_t);
 
 // ------------------------------------------------------------------------------------------------

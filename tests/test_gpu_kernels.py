@@ -315,6 +315,60 @@ print("tasks", dev.stats()["n_lane_tasks"])
     assert "in 1 slice" in outs[0][1] and "in 1 slice" not in outs[1][1]
 
 
+def test_entry_numbers_beyond_32_bits():
+    """The device accelerator numbers its list entries with 40 bits (64-bit block bases + 32-bit offsets inside a block of 256
+    words, 5-byte records).  A RefSeq-scale accelerator (~5 * 10^10 entries) does not fit a test, so the test hook
+    BHIP_TEST_ENTRY_BIAS makes the entry numbers of a small database START near 2^32 (and, second run, beyond 2^36): every
+    offset the kernels compute crosses the 32-bit limit.  Lane-resolved and clump-level prefilter, SMALL and LARGE lists, the
+    kernel-level prefilter entry: all must equal the oracle, and the device layout must stay <= 5 bytes per entry + offsets."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, os
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+import test_gpu_kernels as T, dbutil, oraclelib as ol
+from burst_amd import capi
+K = 12
+seqs = T.family_db(191, 10, 20, 480, rate=0.05)
+packed, clump_len, tot = dbutil.pack_clumps(seqs)
+lens, entries, offs = dbutil.build_acx(seqs, K)
+lut = ol.score_lut(1)
+for fmt in (0, 1):
+    dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=dbutil.pack_acx_lists(lens, entries, fmt), acx_fmt=fmt, K=K)
+    q, allq = T.make_queries(seqs, 70, 100, [0, 1, 2, 3, 5], 193, thres=0.97)
+    q.flags = np.zeros(q.n, np.uint8)
+    for all_hits in (False, True):
+        exp = T.oracle_hits(packed, clump_len, tot, q, lut, all_hits)
+        assert len(exp) > 40
+        for opts in ({"lane_masks": 1, "prefilter_algo": 0}, {"lane_masks": 1, "prefilter_algo": 1}, {"lane_masks": 0}):
+            for k, v in opts.items():
+                dev.set_option(k, v)
+            got = dev.align_batch(q, all_hits=all_hits)
+            assert got.tobytes() == exp.tobytes(), (fmt, all_hits, opts)
+    dev.set_option("prefilter_stride", 1)
+    oq, oc, on = dev.prefilter(q)
+    n_exp = 0
+    for j in range(q.n):
+        _, counts = ol.prefilter_counts(allq[j], int(q.emac[j]), K, offs, entries, len(clump_len), 1)
+        need = (len(allq[j]) - K + 1) - int(q.emac[j]) * K
+        sel = np.flatnonzero(counts > max(need - 1, 0))
+        got_j = oc[oq == j]
+        assert np.array_equal(got_j, sel.astype(np.uint32)), j
+        n_exp += len(sel)
+    assert n_exp == len(oq) and n_exp > 0
+    dev.close()
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for bias in ("0", str((1 << 32) - 1000), str((1 << 36) + 12345)):
+        r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, BHIP_DEBUG="1", BHIP_TEST_ENTRY_BIAS=bias), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
+        acc = [ln for ln in r.stderr.splitlines() if "[bhip] accelerator:" in ln]
+        assert acc and ("first entry number %s)" % bias) in acc[-1], acc
+        assert "records 5 B" in acc[-1]
+
+
 def test_asynchronous_record_handover():
     """option async_d2h: the count is final at return, the bytes after sync_hits(); two alternating host buffers; the
     device-resident copy (bhip_copy_hits_device) refers to the last call"""
