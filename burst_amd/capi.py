@@ -36,8 +36,14 @@ class BhipStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class BhipQuerySpan(C.Structure):
+    _fields_ = [("codes", C.c_void_p), ("off", C.c_void_p), ("emac", C.c_void_p), ("rc", C.c_void_p), ("flags", C.c_void_p),
+                ("n", C.c_uint32), ("q_base", C.c_uint32)]
+
+
 EXPORTS = ["bhip_init", "bhip_stage_queries", "bhip_align_staged", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_set_option", "bhip_get_stats",
-           "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version", "bhip_copy_hits_device", "bhip_sync_hits"]
+           "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version", "bhip_copy_hits_device", "bhip_sync_hits",
+           "bhip_stage_spans", "bhip_alloc_host", "bhip_free_host", "bhip_host_register", "bhip_host_unregister"]
 
 
 class BurstHipError(RuntimeError):
@@ -80,6 +86,16 @@ def _load():
     lib.bhip_last_error.restype = C.c_char_p
     lib.bhip_abi_version.argtypes = []
     lib.bhip_abi_version.restype = i32
+    lib.bhip_stage_spans.argtypes = [vp, C.POINTER(BhipQuerySpan), u32, u32, u32]
+    lib.bhip_stage_spans.restype = i32
+    lib.bhip_alloc_host.argtypes = [u64]
+    lib.bhip_alloc_host.restype = vp
+    lib.bhip_free_host.argtypes = [vp]
+    lib.bhip_free_host.restype = None
+    lib.bhip_host_register.argtypes = [vp, u64]
+    lib.bhip_host_register.restype = i32
+    lib.bhip_host_unregister.argtypes = [vp]
+    lib.bhip_host_unregister.restype = i32
     return lib
 
 
@@ -186,9 +202,30 @@ class Device:
         self._staged = q     # keep the host arrays alive
         _chk(lib().bhip_stage_queries(self._h, _ptr(q.codes), _ptr(q.off), _ptr(q.emac), _ptr(q.six), _ptr(q.rc), _ptr(q.flags), q.n, q.n_shared))
 
+    def stage_spans(self, spans, n_shared, max_len=0):
+        """asynchronous staging (bhip_stage_spans).  spans: list of dicts with numpy arrays codes, off (n + 1 offsets into codes),
+        emac and optional rc / flags, plus q_base; entry j of every span shares slot j.  The arrays are kept alive here until
+        the next two batches have been staged (the library reads them until the batch has been aligned)."""
+        arr = (BhipQuerySpan * max(1, len(spans)))()
+        keep = []
+        n_tot = 0
+        for k, sp in enumerate(spans):
+            codes, off, emac = _arr(sp["codes"], np.uint8), _arr(sp["off"], np.uint64), _arr(sp["emac"], np.uint16)
+            rc, fl = _arr(sp.get("rc"), np.uint8), _arr(sp.get("flags"), np.uint8)
+            keep += [codes, off, emac, rc, fl]
+            n = len(off) - 1
+            arr[k].codes, arr[k].off, arr[k].emac = codes.ctypes.data, off.ctypes.data, emac.ctypes.data
+            arr[k].rc = rc.ctypes.data if rc is not None else None
+            arr[k].flags = fl.ctypes.data if fl is not None else None
+            arr[k].n, arr[k].q_base = n, int(sp.get("q_base", 0))
+            n_tot += n
+        self._span_keep = getattr(self, "_span_keep", [])[-2:] + [keep]
+        self._staged_n = n_tot
+        _chk(lib().bhip_stage_spans(self._h, arr, len(spans), int(n_shared), int(max_len)))
+
     def align_staged(self, all_hits=False, out=None):
         """out: optional preallocated HIT_DTYPE array reused between calls"""
-        hits = out if out is not None else np.zeros(max(1 << 16, 4 * self._staged.n), dtype=HIT_DTYPE)
+        hits = out if out is not None else np.zeros(max(1 << 16, 4 * (self._staged.n if getattr(self, "_staged", None) is not None else getattr(self, "_staged_n", 0))), dtype=HIT_DTYPE)
         while True:
             n = C.c_uint64()
             rc = lib().bhip_align_staged(self._h, int(bool(all_hits)), _ptr(hits), len(hits), C.byref(n))

@@ -55,6 +55,9 @@ template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_
 	const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *,
 	unsigned long long, uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t);
 __global__ void k_pack_queries(const uint8_t *, const uint64_t *, uint32_t, uint32_t, uint32_t *);
+__global__ void k_span_fill(const uint64_t *, uint32_t, uint32_t, uint64_t, uint32_t, uint64_t *, uint32_t *, uint32_t *);
+__global__ void k_route(const uint64_t *, const uint32_t *, uint32_t, const uint16_t *, const uint32_t *, const uint8_t *, uint32_t, uint32_t, uint32_t, int, int, int,
+	uint32_t *, uint8_t *, uint32_t *, BhipStageInfo *);
 __global__ void k_rescore_classify(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, int, const uint64_t *, const uint32_t *, const uint8_t *,
 	const uint32_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t, int);
 template <int SET> __global__ void k_rescore_reg(const BhipRawHit *, const uint32_t *, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, const uint32_t *, uint32_t,
@@ -67,8 +70,13 @@ __global__ void k_hit_count(const BhipHit *__restrict__ hits, uint32_t n, uint32
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) rank[i] = atomicAdd(&cnt[hits[i].q], 1u);
 }
 __global__ void k_hit_scatter(const BhipHit *__restrict__ in, uint32_t n, const uint32_t *__restrict__ off, const uint32_t *__restrict__ rank,
-                              BhipHit *__restrict__ out) {
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const BhipHit h = in[i]; out[off[h.q] + rank[i]] = h; }
+                              BhipHit *__restrict__ out, const uint32_t *__restrict__ qmap) {      // qmap: batch entry -> query number reported to the caller
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		BhipHit h = in[i];
+		const uint32_t dst = off[h.q] + rank[i];
+		if (qmap) h.q = qmap[h.q];
+		out[dst] = h;
+	}
 }
 // Batches with query symbols of code 0 (see Handle::qcodes_s): the sweeps ran on the queries without those symbols; every
 // such symbol costs exactly one edit more (it can only face a gap), so its count goes onto the raw hits and onto the
@@ -147,6 +155,37 @@ struct Counters {
 	unsigned long long surv_sum;           // list records that passed the counting filter (k_prefilter_cf)
 };
 
+// One staged batch.  Query symbols with code 0 (anything outside the IUPAC nucleotide alphabet) cost 255 against every
+// reference symbol (burst.c:170-190): such a symbol can only be aligned opposite a gap, so the edit distance of the query is
+// (number of such symbols) + edit distance of the query without them, end columns unchanged.  When a staged batch holds any,
+// the SEARCH kernels (seeds, prefilter, profiles, sweeps) work on a second view of the batch with those symbols removed and
+// the budgets reduced (qcodes_s ...); k_junk_adjust adds the counts back before the re-scorer, which works on the original
+// queries with the real cost table.  Without such symbols the search view is the batch itself.
+struct StageSlot {
+	DBuf qcodes, qoff, qemac, qsix, qrc, qflags, qmap, off_raw, plan, qpack, key, key_sorted, idx, idx_sorted, sort_tmp, info;
+	DBuf qcodes_s, qoff_s, qemac_s, qpack_s, nx, nx_six;
+	BhipStageInfo *info_pinned = nullptr;
+	hipEvent_t ev_begin = nullptr, ev_done = nullptr;
+	int state = 0;                        // 0 empty, 1 staged (not aligned yet), 2 active (aligned; may be run again)
+	uint64_t seq = 0;
+	bool resolved = false;                // routing read back, lists assigned
+	bool st_valid = false, st_has_six = false, st_has_rc = false, st_has_junk = false, has_flags = false, has_qmap = false;
+	uint32_t st_nq = 0, st_nshared = 0, st_maxlen = 0, st_maxE = 0, st_lanes = 1;
+	float st_ms_h2d = 0;
+	std::vector<BhipQuerySpan> spans;     // the caller's arrays (valid until the batch has been aligned): the host pass reads them
+	const uint32_t *six_explicit = nullptr;
+	uint32_t npf[16][7], nex[16][7], maxE[16][7], maxwords[16][7], qlist_off[16][7], maxlen_lane[16], n_entries_lane[16];
+	uint64_t seed_words[16][7];
+	void release_all() {
+		DBuf *b[] = {&qcodes, &qoff, &qemac, &qsix, &qrc, &qflags, &qmap, &off_raw, &plan, &qpack, &key, &key_sorted, &idx, &idx_sorted,
+			&sort_tmp, &info, &qcodes_s, &qoff_s, &qemac_s, &qpack_s, &nx, &nx_six};
+		for (DBuf *x : b) x->release();
+		if (info_pinned) { (void)hipHostFree(info_pinned); info_pinned = nullptr; }
+		if (ev_begin) { (void)hipEventDestroy(ev_begin); ev_begin = nullptr; }
+		if (ev_done) { (void)hipEventDestroy(ev_done); ev_done = nullptr; }
+	}
+};
+
 // One independent sub-pipeline of a staged batch: its own stream and scratch, a contiguous range of shared slots
 // (so a forward entry and its reverse-complement twin are always in the same lane and `best[six]` is final when the
 // lane's re-scorer runs).  Lanes overlap each other's latency-bound kernels (prefilter, window, re-scorer) with the
@@ -163,7 +202,8 @@ struct Lane {
 	bool pruned[kNumClasses] = {false};   // a second (filtered) sweep ran for this class
 	int pf_algo_used = 0;
 	int pf_algo = 0;              // algorithm of this lane's next prefilter launches (follows opt_pf_algo: -1 = adapt)
-	DBuf qlist_cls[kNumClasses], peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters, tasks, tasks2, tasks2k, wins2, ranges, hdr, rs_lists;
+	const uint32_t *qlist[kNumClasses] = {nullptr};      // (lane, class) lists of the current batch: entries of the slot's sorted index array
+	DBuf peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters, tasks, tasks2, tasks2k, wins2, ranges, hdr, rs_lists;
 	uint64_t task_cap = 1 << 20;
 	uint64_t cand_cap = 1 << 18, raw_cap = 1 << 18, win_cap = 1 << 20, scratch_cap = 1 << 18;
 	uint32_t npf[kNumClasses] = {0}, nex[kNumClasses] = {0}, maxE[kNumClasses] = {0}, maxwords[kNumClasses] = {0}, maxlen = 0, n_entries = 0;
@@ -199,29 +239,25 @@ struct Handle {
 	}
 	bool has_masks = false;       // per-entry lane masks were built at upload (lane-resolved prefilter)
 	int opt_lane_masks = 1;       // use them
+	// staged batches: two slots, so that the upload and routing of batch k+1 (stage_stream) run while batch k is aligned
+	StageSlot slots[2];
+	StageSlot *cur = &slots[0];           // slot of the batch being aligned
+	uint64_t stage_seq = 0;
+	hipStream_t stage_stream = nullptr;
+	// records of the last aligned batch, complete but not delivered (the caller's buffer was too small): delivered by the next call
+	bool res_valid = false; uint64_t res_seq = 0; int res_all_hits = 0; uint32_t res_n = 0; BhipStats res_stats;
+	int opt_host_routing = 0;             // 1 = route every batch on the host (the pass that handles symbols of code 0); test hook
 	// batch-wide buffers
-	DBuf qcodes, qoff, qemac, qsix, qrc, best, out, shared_ctr, mins, pairs;
-	// Query symbols with code 0 (anything outside the IUPAC nucleotide alphabet) cost 255 against every reference symbol
-	// (burst.c:170-190): such a symbol can only be aligned opposite a gap, so the edit distance of the query is
-	// (number of such symbols) + edit distance of the query without them, end columns unchanged.  When a staged batch
-	// holds any, the SEARCH kernels (seeds, prefilter, profiles, sweeps) work on a second view of the batch with those
-	// symbols removed and the budgets reduced; k_junk_adjust adds the counts back before the re-scorer, which works on
-	// the original queries with the real cost table.  Without such symbols the search view is the batch itself.
-	DBuf qcodes_s, qoff_s, qemac_s, qpack_s, nx, nx_six;
-	bool st_has_junk = false;
-	const uint8_t *s_codes() const { return st_has_junk ? qcodes_s.as<uint8_t>() : qcodes.as<uint8_t>(); }
-	const uint64_t *s_off() const { return st_has_junk ? qoff_s.as<uint64_t>() : qoff.as<uint64_t>(); }
-	const uint16_t *s_emac() const { return st_has_junk ? qemac_s.as<uint16_t>() : qemac.as<uint16_t>(); }
-	const uint32_t *s_pack() const { return st_has_junk ? qpack_s.as<uint32_t>() : qpack.as<uint32_t>(); }
-	DBuf sort_keys, sort_keys2, sort_idx, sort_tmp, out_sorted, out_sorted2, qpack, plan;   // sort_keys / sort_keys2: per-query record counts / offsets; sort_idx: rank of a record inside its query
+	DBuf best, out, shared_ctr, mins, pairs;
+	const uint8_t *s_codes() const { return cur->st_has_junk ? cur->qcodes_s.as<uint8_t>() : cur->qcodes.as<uint8_t>(); }
+	const uint64_t *s_off() const { return cur->st_has_junk ? cur->qoff_s.as<uint64_t>() : cur->qoff.as<uint64_t>(); }
+	const uint16_t *s_emac() const { return cur->st_has_junk ? cur->qemac_s.as<uint16_t>() : cur->qemac.as<uint16_t>(); }
+	const uint32_t *s_pack() const { return cur->st_has_junk ? cur->qpack_s.as<uint32_t>() : cur->qpack.as<uint32_t>(); }
+	DBuf sort_keys, sort_keys2, sort_idx, sort_tmp, out_sorted, out_sorted2;   // sort_keys / sort_keys2: per-query record counts / offsets; sort_idx: rank of a record inside its query
 	uint64_t out_cap = 1 << 20;
 	std::vector<uint32_t> h_clump_len;
 	BhipStats stats;
 	std::vector<Lane *> lanes;
-	// staged batch (bhip_stage_queries)
-	bool st_valid = false, st_has_six = false, st_has_rc = false;
-	uint32_t st_nq = 0, st_nshared = 0, st_maxlen = 0, st_maxE = 0, st_lanes = 1;
-	float st_ms_h2d = 0;
 	int opt_two_stage = 1;        // 1 = prefix filter + windowed full-length stage when it pays, 0 = always the one-stage sweep
 	int opt_prefilter_stride = 0; // 0 = automatic sparse seeds, s > 0 = every s-th word (1 = the reference's scheme)
 	int opt_lanes = 1;            // sub-pipelines per staged batch (the stage kernels fill the chip on their own; > 1 only helps small batches)
@@ -256,7 +292,6 @@ static void lane_destroy(Lane *L) {
 	if (L->stream) (void)hipStreamSynchronize(L->stream);
 	DBuf *all[] = {&L->peq, &L->peqp, &L->cand, &L->candcnt, &L->wins, &L->raw, &L->wide, &L->scratch, &L->fb_list, &L->gcnt, &L->counters, &L->tasks, &L->tasks2, &L->tasks2k, &L->wins2, &L->ranges, &L->hdr, &L->rs_lists};
 	for (DBuf *b : all) b->release();
-	for (auto &b : L->qlist_cls) b.release();
 	for (auto &ce : L->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
 	for (auto &e : L->ev_rs) if (e) (void)hipEventDestroy(e);
 	for (auto &ce : L->ev_pf) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
@@ -290,10 +325,12 @@ extern "C" void bhip_destroy(void *handle) {
 	if (h->sweep_stream) (void)hipStreamSynchronize(h->sweep_stream);
 	if (h->pf_stream) (void)hipStreamSynchronize(h->pf_stream);
 	if (h->post_stream) (void)hipStreamSynchronize(h->post_stream);
+	if (h->stage_stream) (void)hipStreamSynchronize(h->stage_stream);
+	for (StageSlot &S : h->slots) S.release_all();
 	for (Lane *L : h->lanes) lane_destroy(L);
-	DBuf *all[] = {&h->ref, &h->ref_lane, &h->ref_off, &h->clump_len, &h->lut, &h->acx_delta, &h->acx_base, &h->acx_rec, &h->bad, &h->qcodes, &h->qoff, &h->qemac,
-		&h->qsix, &h->qrc, &h->best, &h->out, &h->shared_ctr, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx,
-		&h->sort_tmp, &h->out_sorted, &h->out_sorted2, &h->qpack, &h->plan, &h->qcodes_s, &h->qoff_s, &h->qemac_s, &h->qpack_s, &h->nx, &h->nx_six};
+	DBuf *all[] = {&h->ref, &h->ref_lane, &h->ref_off, &h->clump_len, &h->lut, &h->acx_delta, &h->acx_base, &h->acx_rec, &h->bad,
+		&h->best, &h->out, &h->shared_ctr, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx,
+		&h->sort_tmp, &h->out_sorted, &h->out_sorted2};
 	for (int o = 0; o < 2; ++o) {
 		if (h->copy_pending[o] && h->ev_copied[o]) (void)hipEventSynchronize(h->ev_copied[o]);
 		if (h->reg_ptr[o]) (void)hipHostUnregister(h->reg_ptr[o]);
@@ -307,6 +344,7 @@ extern "C" void bhip_destroy(void *handle) {
 	if (h->sweep_stream) (void)hipStreamDestroy(h->sweep_stream);
 	if (h->pf_stream) (void)hipStreamDestroy(h->pf_stream);
 	if (h->post_stream) (void)hipStreamDestroy(h->post_stream);
+	if (h->stage_stream) (void)hipStreamDestroy(h->stage_stream);
 	delete h;
 }
 
@@ -413,6 +451,7 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 	INITCHK(hipStreamCreateWithFlags(&h->sweep_stream, hipStreamNonBlocking));
 	INITCHK(hipStreamCreateWithFlags(&h->pf_stream, hipStreamNonBlocking));
 	INITCHK(hipStreamCreateWithFlags(&h->post_stream, hipStreamNonBlocking));
+	INITCHK(hipStreamCreateWithFlags(&h->stage_stream, hipStreamNonBlocking));
 	for (auto &e : h->ev) INITCHK(hipEventCreate(&e));
 	h->n_clumps = n_clumps; h->tot_refs = tot_refs;
 	h->h_clump_len.assign(clump_len, clump_len + n_clumps);
@@ -558,6 +597,8 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 		h->opt_prefilter_stride = (int)value; return BHIP_OK;
 	}
 	if (!strcmp(name, "two_stage")) { h->opt_two_stage = value != 0; return BHIP_OK; }
+	if (!strcmp(name, "host_routing")) { h->opt_host_routing = value != 0; return BHIP_OK; }
+	if (!strcmp(name, "discard_staged")) { for (StageSlot &S : h->slots) if (S.state == 1) S.state = 0; h->res_valid = false; return BHIP_OK; }
 	if (!strcmp(name, "lane_masks")) { h->opt_lane_masks = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "sweep_blocks")) { if (value < 1 || value > 8) return fail(BHIP_E_ARG, "sweep_blocks must be 1 .. 8"); h->opt_sweep_blocks = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "lane_min_entries")) { if (value < 1) return fail(BHIP_E_ARG, "lane_min_entries must be >= 1"); h->opt_lane_min = (int)value; return BHIP_OK; }
@@ -569,7 +610,7 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 	if (!strcmp(name, "prefilter_table")) { if (value != 0 && (value < 9 || value > 11)) return fail(BHIP_E_ARG, "prefilter_table must be 0, 9, 10 or 11"); h->opt_pf_table = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "lanes")) {
 		if (value < 1 || value > 16) return fail(BHIP_E_ARG, "lanes must be 1 .. 16");
-		h->opt_lanes = (int)value; h->st_valid = false; return BHIP_OK;
+		h->opt_lanes = (int)value; for (StageSlot &S : h->slots) { S.state = 0; S.st_valid = false; } return BHIP_OK;
 	}
 	return fail(BHIP_E_ARG, "unknown option '%s'", name);
 }
@@ -586,7 +627,7 @@ static void launch_myers(Handle *h, Lane *L, hipStream_t st, int cls, uint32_t g
 		uint64_t n_pairs_host, uint32_t li_base, const uint32_t *qlist, BhipRawHit *raw, uint32_t *n_raw, uint32_t raw_cap, uint32_t *best,
 		uint8_t *mins, Counters *dc) {
 	#define LM(N) hipLaunchKernelGGL(k_myers<N>, dim3(grid), dim3(256), 0, st, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist, \
-		L->peq.as<uint32_t>(), h->s_off(), h->s_emac(), (best && h->st_has_six) ? h->qsix.as<uint32_t>() : nullptr, \
+		L->peq.as<uint32_t>(), h->s_off(), h->s_emac(), (best && h->cur->st_has_six) ? h->cur->qsix.as<uint32_t>() : nullptr, \
 		h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->tot_refs, raw, n_raw, raw_cap, best, mins, &dc->col_sum, &dc->qlen_sum)
 	switch (kClasses[cls]) { case 2: LM(2); break; case 4: LM(4); break; case 6: LM(6); break; case 8: LM(8); break; case 10: LM(10); break;
 		case 16: LM(16); break; default: LM(32); break; }
@@ -626,7 +667,7 @@ static void launch_window(Handle *h, Lane *L, hipStream_t wst, int cls, int NWP,
 	#define LW(N) { const uint32_t thr = (N) <= 8 ? 64u : 256u;      /* NW <= 8: per-thread A/C/G/T profile rows in LDS, 64-thread blocks */ \
 		const uint32_t grid = std::min<uint32_t>(grid_cap * (256u / thr), (uint32_t)h->n_cu * blocks_per_cu((const void *)k_myers_window<N>, thr, 0)); \
 		hipLaunchKernelGGL(k_myers_window<N>, dim3(grid), dim3(thr), 0, wst, wins, n_wins, (uint32_t)L->win_cap, NWP, qlist, \
-		L->peq.as<uint32_t>(), h->s_off(), h->s_emac(), h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->ref_lane.as<uint4>(), \
+		L->peq.as<uint32_t>(), h->s_off(), h->s_emac(), h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr, h->ref_lane.as<uint4>(), \
 		h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), &dc->wcol_sum); }
 	switch (kClasses[cls]) { case 2: LW(2); break; case 4: LW(4); break; case 6: LW(6); break; case 8: LW(8); break; case 10: LW(10); break;
 		case 16: LW(16); break; default: LW(32); break; }
@@ -669,30 +710,30 @@ static int upload_queries(Handle *h, const uint8_t *q_codes, const uint64_t *q_o
                           const uint32_t *q_six, const uint8_t *q_rc, uint32_t n_q) {
 	const uint64_t nb = q_off[n_q];
 	int rc;
-	h->st_has_junk = false;      // bhip_stage_queries builds the search view after this upload when the batch needs one
-	h->st_maxlen = 0; h->st_maxE = 0;
+	h->cur->st_has_junk = false;      // bhip_stage_queries builds the search view after this upload when the batch needs one
+	h->cur->st_maxlen = 0; h->cur->st_maxE = 0;
 	for (uint32_t i = 0; i < n_q; ++i) {
-		h->st_maxlen = std::max<uint32_t>(h->st_maxlen, (uint32_t)(q_off[i + 1] - q_off[i]));
-		h->st_maxE = std::max<uint32_t>(h->st_maxE, q_emac[i]);
+		h->cur->st_maxlen = std::max<uint32_t>(h->cur->st_maxlen, (uint32_t)(q_off[i + 1] - q_off[i]));
+		h->cur->st_maxE = std::max<uint32_t>(h->cur->st_maxE, q_emac[i]);
 	}
-	if ((rc = h->qcodes.reserve(nb + 16))) return rc;
-	if ((rc = h->qoff.reserve((n_q + 1) * sizeof(uint64_t)))) return rc;
-	if ((rc = h->qemac.reserve((n_q + 1) * sizeof(uint16_t)))) return rc;
-	if ((rc = h->qsix.reserve((n_q + 1) * sizeof(uint32_t)))) return rc;
-	if ((rc = h->qrc.reserve(n_q + 1))) return rc;
-	HIPCHK(hipMemcpyAsync(h->qcodes.p, q_codes, nb, hipMemcpyHostToDevice, h->stream));
-	HIPCHK(hipMemcpyAsync(h->qoff.p, q_off, (n_q + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
-	HIPCHK(hipMemcpyAsync(h->qemac.p, q_emac, n_q * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
-	if (q_six) HIPCHK(hipMemcpyAsync(h->qsix.p, q_six, n_q * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-	if (q_rc) HIPCHK(hipMemcpyAsync(h->qrc.p, q_rc, n_q, hipMemcpyHostToDevice, h->stream));
+	if ((rc = h->cur->qcodes.reserve(nb + 16))) return rc;
+	if ((rc = h->cur->qoff.reserve((n_q + 1) * sizeof(uint64_t)))) return rc;
+	if ((rc = h->cur->qemac.reserve((n_q + 1) * sizeof(uint16_t)))) return rc;
+	if ((rc = h->cur->qsix.reserve((n_q + 1) * sizeof(uint32_t)))) return rc;
+	if ((rc = h->cur->qrc.reserve(n_q + 1))) return rc;
+	HIPCHK(hipMemcpyAsync(h->cur->qcodes.p, q_codes, nb, hipMemcpyHostToDevice, h->stream));
+	HIPCHK(hipMemcpyAsync(h->cur->qoff.p, q_off, (n_q + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+	HIPCHK(hipMemcpyAsync(h->cur->qemac.p, q_emac, n_q * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+	if (q_six) HIPCHK(hipMemcpyAsync(h->cur->qsix.p, q_six, n_q * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+	if (q_rc) HIPCHK(hipMemcpyAsync(h->cur->qrc.p, q_rc, n_q, hipMemcpyHostToDevice, h->stream));
 	return 0;
 }
 
 static int upload_plan(Handle *h, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac, uint32_t n_q, std::vector<uint32_t> &plan) {
 	int rc;
-	if ((rc = h->plan.reserve((size_t)n_q * 4 + 16))) return rc;
+	if ((rc = h->cur->plan.reserve((size_t)n_q * 4 + 16))) return rc;
 	(void)q_codes; (void)q_off; (void)q_emac;
-	HIPCHK(hipMemcpyAsync(h->plan.p, plan.data(), (size_t)n_q * 4, hipMemcpyHostToDevice, h->stream));
+	HIPCHK(hipMemcpyAsync(h->cur->plan.p, plan.data(), (size_t)n_q * 4, hipMemcpyHostToDevice, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
 	return 0;
 }
@@ -702,7 +743,7 @@ static int launch_prefilter(Handle *h, Lane *L, hipStream_t pf_st, const uint32_
                             bool with_bad, uint32_t *n_cand_dev, Counters *dc) {
 	const uint32_t *bad = with_bad ? h->bad.as<uint32_t>() : nullptr;
 	const uint32_t n_bad = with_bad ? h->n_bad : 0;
-	const uint32_t *plan = h->plan.as<uint32_t>();
+	const uint32_t *plan = h->cur->plan.as<uint32_t>();
 	hipStream_t st = pf_st;
 	int rc;
 	// main pass: hashed counters, four queries per wave (any database size)
@@ -717,7 +758,7 @@ static int launch_prefilter(Handle *h, Lane *L, hipStream_t pf_st, const uint32_
 		HIPCHK(hipGetLastError());
 	}
 	// fallback pass for the (rare) queries whose table overflowed: dense per-clump counters, LDS if they fit, else global memory
-	const bool narrow = h->st_maxlen < 255u + (uint32_t)h->K;
+	const bool narrow = h->cur->st_maxlen < 255u + (uint32_t)h->K;
 	const size_t lds_w = ((size_t)(h->n_clumps + (narrow ? 3 : 1)) / (narrow ? 4 : 2)) * 4 + 1536u * 4 + 512u * 8 + 512u * 4 + 16;
 	const uint32_t nw32 = (h->n_clumps + 1) / 2;
 	if (lds_w <= 64 * 1024) {
@@ -754,7 +795,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	const uint64_t n_thr = (uint64_t)n_list * W16;
 	HIPCHK(hipEventRecord(L->ev_pf[cls][0], st));
 	hipLaunchKernelGGL(k_seed_ranges, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, h->s_codes(), h->s_off(), d_qlist, n_list,
-		h->acx_view(), h->K, h->plan.as<uint32_t>(), W16, L->ranges.as<uint2>(), L->hdr.as<uint2>(), h->s_pack(), (h->st_maxlen + 7) / 8, h->s_emac());
+		h->acx_view(), h->K, h->cur->plan.as<uint32_t>(), W16, L->ranges.as<uint2>(), L->hdr.as<uint2>(), h->s_pack(), (h->cur->st_maxlen + 7) / 8, h->s_emac());
 	const int algo = h->opt_pf_algo >= 0 ? h->opt_pf_algo : L->pf_algo;
 	const uint32_t n_quads = (n_list + 3) / 4;
 	// hash table size per query from the expected number of distinct clumps (sampled words x occurrence-weighted mean list
@@ -804,7 +845,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	L->pf_algo_used = algo;
 	// dense fallback for overflowed queries (clump-level pairs)
 	const uint32_t *bad = h->bad.as<uint32_t>();
-	const bool narrow = h->st_maxlen < 255u + (uint32_t)h->K;
+	const bool narrow = h->cur->st_maxlen < 255u + (uint32_t)h->K;
 	const size_t lds_w = ((size_t)(h->n_clumps + (narrow ? 3 : 1)) / (narrow ? 4 : 2)) * 4 + 1536u * 4 + 512u * 8 + 512u * 4 + 16;
 	const uint32_t nw32 = (h->n_clumps + 1) / 2;
 	if (lds_w <= 64 * 1024) {
@@ -812,17 +853,17 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 		const uint32_t g2 = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * per_cu);
 		if (narrow) hipLaunchKernelGGL(k_prefilter_wave<uint8_t>, dim3(g2), dim3(64), lds_w, st, h->s_codes(), h->s_off(),
 			h->s_emac(), d_qlist, n_list, h->acx_view(), h->K, h->n_clumps, bad, h->n_bad, L->cand.as<uint2>(),
-			(uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read, h->plan.as<uint32_t>(), L->fb_list.as<uint32_t>(), &dc->n_fb);
+			(uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read, h->cur->plan.as<uint32_t>(), L->fb_list.as<uint32_t>(), &dc->n_fb);
 		else hipLaunchKernelGGL(k_prefilter_wave<uint16_t>, dim3(g2), dim3(64), lds_w, st, h->s_codes(), h->s_off(),
 			h->s_emac(), d_qlist, n_list, h->acx_view(), h->K, h->n_clumps, bad, h->n_bad, L->cand.as<uint2>(),
-			(uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read, h->plan.as<uint32_t>(), L->fb_list.as<uint32_t>(), &dc->n_fb);
+			(uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read, h->cur->plan.as<uint32_t>(), L->fb_list.as<uint32_t>(), &dc->n_fb);
 	} else {
 		uint32_t g2 = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * 2);
 		if ((rc = L->gcnt.reserve((size_t)g2 * nw32 * 4))) return rc;
 		hipLaunchKernelGGL(k_prefilter<false>, dim3(g2), dim3(256), 0, st, h->s_codes(), h->s_off(),
 			h->s_emac(), d_qlist, n_list, h->acx_view(), h->K, h->n_clumps,
 			L->gcnt.as<uint32_t>(), bad, h->n_bad, L->cand.as<uint2>(), (uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read,
-			L->fb_list.as<uint32_t>(), &dc->n_fb, h->plan.as<uint32_t>());
+			L->fb_list.as<uint32_t>(), &dc->n_fb, h->cur->plan.as<uint32_t>());
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -833,33 +874,157 @@ static int ensure_lanes(Handle *h, uint32_t n) {
 	return 0;
 }
 
-// ---- staged batch: inputs resident in HBM, then any number of runs over them ---------------------------------
-extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
-                                  const uint32_t *q_six, const uint8_t *q_rc, const uint8_t *q_flags, uint32_t n_q, uint32_t n_shared) {
-	Handle *h = (Handle *)handle;
-	if (!h) return fail(BHIP_E_ARG, "null handle");
-	h->st_valid = false;
-	h->st_nq = n_q; h->st_has_six = q_six != nullptr; h->st_has_rc = q_rc != nullptr;
-	h->st_nshared = q_six ? n_shared : n_q;
-	if (!n_q) { h->st_valid = true; h->st_lanes = 0; return BHIP_OK; }
-	if (!q_codes || !q_off || !q_emac) return fail(BHIP_E_ARG, "null query arrays");
-	HIPCHK(hipSetDevice(h->device));
-	// number of lanes: enough entries per lane to fill the chip
+// ---- staged batches -------------------------------------------------------------------------------------------------
+// A batch is staged into one of two slots.  Everything is enqueued on stage_stream and nothing is waited for: the copies
+// of the caller's arrays, k_span_fill (batch offsets, shared slots, reported query numbers), k_pack_queries, k_route
+// (class / lane / route / seed plan per entry, per-list counts) and a stable radix sort of the entry numbers by list key.
+// The batch that is being aligned meanwhile uses the other slot and other streams.  resolve_slot() -- called when the
+// batch is about to be aligned -- waits for the slot's event, reads the routing summary from pinned memory and, for the
+// rare batch with query symbols of code 0, runs the host pass that builds the search view.
+static int slot_init(StageSlot *S) {
+	if (S->ev_done) return 0;
+	if (hipEventCreate(&S->ev_begin) != hipSuccess || hipEventCreate(&S->ev_done) != hipSuccess) return fail(BHIP_E_DEVICE, "hipEventCreate failed");
+	if (hipHostMalloc((void **)&S->info_pinned, sizeof(BhipStageInfo), hipHostMallocDefault) != hipSuccess) return fail(BHIP_E_DEVICE, "hipHostMalloc failed");
+	int rc = S->info.reserve(sizeof(BhipStageInfo));
+	return rc;
+}
+
+static uint32_t lanes_for(const Handle *h, uint32_t n_q) {
 	uint32_t nl = (uint32_t)h->opt_lanes;
 	while (nl > 1 && n_q / nl < (uint32_t)h->opt_lane_min) --nl;
+	return nl;
+}
+
+static int stage_enqueue(Handle *h, StageSlot *S, const BhipQuerySpan *spans, uint32_t n_spans, const uint32_t *six_explicit, bool share_by_position,
+                         uint32_t n_shared, uint32_t max_len) {
 	int rc;
-	if ((rc = ensure_lanes(h, nl))) return rc;
-	h->st_lanes = nl;
-	const uint32_t nsh = h->st_nshared;
-	const bool dbg = getenv("BHIP_DEBUG") != nullptr;
-	const auto t_begin = std::chrono::steady_clock::now();
-	auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-	// host-side routing: lane by shared slot, class by length, prefilter vs exhaustive (entries nobody can guarantee a k-mer for)
-	// (a few host threads share the pass: ~35 ns per entry single-threaded would otherwise be 8x the device time of the batch)
+	if ((rc = slot_init(S))) return rc;
+	hipStream_t st = h->stage_stream;
+	uint64_t n_q64 = 0, nb = 0;
+	bool any_rc = false, any_flags = false, all_flags = true, any_qbase = false;
+	for (uint32_t k = 0; k < n_spans; ++k) {
+		const BhipQuerySpan &sp = spans[k];
+		if (!sp.n) continue;
+		if (!sp.codes || !sp.off || !sp.emac) return fail(BHIP_E_ARG, "null query arrays");
+		if (share_by_position && sp.n > n_shared) return fail(BHIP_E_ARG, "span %u has %u entries for %u shared slots", k, sp.n, n_shared);
+		n_q64 += sp.n; nb += sp.off[sp.n] - sp.off[0];
+		any_rc |= sp.rc != nullptr; any_flags |= sp.flags != nullptr; all_flags &= sp.flags != nullptr; any_qbase |= sp.q_base != 0 || k > 0;
+	}
+	if (n_q64 > 0xFFFFFFF0ull) return fail(BHIP_E_ARG, "too many entries in one batch");
+	if (any_flags && !all_flags) return fail(BHIP_E_ARG, "q_flags given for some spans only");
+	const uint32_t n_q = (uint32_t)n_q64;
+	S->spans.assign(spans, spans + n_spans);
+	S->six_explicit = six_explicit;
+	S->resolved = false; S->st_valid = false; S->st_has_junk = false;
+	S->st_nq = n_q; S->st_has_six = six_explicit != nullptr || share_by_position; S->st_has_rc = any_rc; S->has_flags = any_flags; S->has_qmap = any_qbase;
+	S->st_nshared = S->st_has_six ? n_shared : n_q;
+	S->st_lanes = n_q ? lanes_for(h, n_q) : 0;
+	S->seq = ++h->stage_seq;
+	if (!n_q) { S->st_maxlen = 0; return 0; }
+	if ((rc = ensure_lanes(h, S->st_lanes))) return rc;
+	if (!max_len) {         // longest entry: from the offsets (host pass over 8 bytes per entry)
+		for (uint32_t k = 0; k < n_spans; ++k) for (uint32_t j = 0; j < spans[k].n; ++j) {
+			const uint64_t len = spans[k].off[j + 1] - spans[k].off[j];
+			if (len > BHIP_MAX_QLEN) return fail(BHIP_E_QUERYLEN, "query %u has %llu symbols (max %d)", j, (unsigned long long)len, BHIP_MAX_QLEN);
+			max_len = std::max<uint32_t>(max_len, (uint32_t)len);
+		}
+	}
+	if (max_len > BHIP_MAX_QLEN) return fail(BHIP_E_QUERYLEN, "queries of up to %u symbols (max %d)", max_len, BHIP_MAX_QLEN);
+	S->st_maxlen = max_len;
+	const uint32_t qw = (max_len + 7) / 8;
+	if ((rc = S->qcodes.reserve(nb + 16)) || (rc = S->qoff.reserve(((size_t)n_q + 1) * 8)) || (rc = S->qemac.reserve(((size_t)n_q + 1) * 2)) ||
+	    (rc = S->qsix.reserve(((size_t)n_q + 1) * 4)) || (rc = S->qrc.reserve((size_t)n_q + 1)) || (rc = S->qflags.reserve((size_t)n_q + 1)) ||
+	    (rc = S->qmap.reserve(((size_t)n_q + 1) * 4)) || (rc = S->off_raw.reserve(((size_t)n_q + n_spans + 1) * 8)) || (rc = S->plan.reserve((size_t)n_q * 4 + 16)) ||
+	    (rc = S->qpack.reserve((size_t)n_q * qw * 4 + 64)) || (rc = S->key.reserve((size_t)n_q + 16)) || (rc = S->key_sorted.reserve((size_t)n_q + 16)) ||
+	    (rc = S->idx.reserve((size_t)n_q * 4 + 16)) || (rc = S->idx_sorted.reserve((size_t)n_q * 4 + 16))) return rc;
+	HIPCHK(hipEventRecord(S->ev_begin, st));
+	uint32_t ebase = 0; uint64_t pos = 0;
+	for (uint32_t k = 0; k < n_spans; ++k) {
+		const BhipQuerySpan &sp = spans[k];
+		if (!sp.n) continue;
+		const uint64_t bytes = sp.off[sp.n] - sp.off[0];
+		if (bytes) HIPCHK(hipMemcpyAsync(S->qcodes.as<uint8_t>() + pos, sp.codes + sp.off[0], bytes, hipMemcpyHostToDevice, st));
+		uint64_t *raw = S->off_raw.as<uint64_t>() + ebase + k;
+		HIPCHK(hipMemcpyAsync(raw, sp.off, ((size_t)sp.n + 1) * 8, hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(S->qemac.as<uint16_t>() + ebase, sp.emac, (size_t)sp.n * 2, hipMemcpyHostToDevice, st));
+		if (sp.rc) HIPCHK(hipMemcpyAsync(S->qrc.as<uint8_t>() + ebase, sp.rc, sp.n, hipMemcpyHostToDevice, st));
+		else if (any_rc) HIPCHK(hipMemsetAsync(S->qrc.as<uint8_t>() + ebase, 0, sp.n, st));
+		if (sp.flags) HIPCHK(hipMemcpyAsync(S->qflags.as<uint8_t>() + ebase, sp.flags, sp.n, hipMemcpyHostToDevice, st));
+		if (six_explicit) HIPCHK(hipMemcpyAsync(S->qsix.as<uint32_t>() + ebase, six_explicit + ebase, (size_t)sp.n * 4, hipMemcpyHostToDevice, st));
+		hipLaunchKernelGGL(k_span_fill, dim3(std::min<uint32_t>((sp.n + 256) / 256, (uint32_t)h->n_cu * 4)), dim3(256), 0, st, raw, sp.n, ebase, pos, sp.q_base,
+			S->qoff.as<uint64_t>(), share_by_position ? S->qsix.as<uint32_t>() : (uint32_t *)nullptr, S->qmap.as<uint32_t>());
+		HIPCHK(hipGetLastError());
+		ebase += sp.n; pos += bytes;
+	}
+	{	// 4-bit packed copy of the queries at a fixed stride (layout used by the routing, seed, profile and re-scoring kernels)
+		const uint64_t total = (uint64_t)n_q * qw;
+		if (total) hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, st,
+			S->qcodes.as<uint8_t>(), S->qoff.as<uint64_t>(), n_q, qw, S->qpack.as<uint32_t>());
+		HIPCHK(hipGetLastError());
+	}
+	HIPCHK(hipMemsetAsync(S->info.p, 0, sizeof(BhipStageInfo), st));
+	hipLaunchKernelGGL(k_route, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, st, S->qoff.as<uint64_t>(), S->qpack.as<uint32_t>(), qw,
+		S->qemac.as<uint16_t>(), S->st_has_six ? S->qsix.as<uint32_t>() : (const uint32_t *)nullptr, any_flags ? S->qflags.as<uint8_t>() : (const uint8_t *)nullptr,
+		n_q, S->st_nshared, S->st_lanes, h->has_acx ? 1 : 0, h->K, h->opt_prefilter_stride, S->plan.as<uint32_t>(), S->key.as<uint8_t>(), S->idx.as<uint32_t>(),
+		S->info.as<BhipStageInfo>());
+	HIPCHK(hipGetLastError());
+	{
+		size_t tb = 0;
+		HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, S->key.as<uint8_t>(), S->key_sorted.as<uint8_t>(), S->idx.as<uint32_t>(), S->idx_sorted.as<uint32_t>(), (int)n_q, 0, 8, st));
+		if ((rc = S->sort_tmp.reserve(tb + 16))) return rc;
+		HIPCHK(hipcub::DeviceRadixSort::SortPairs(S->sort_tmp.p, tb, S->key.as<uint8_t>(), S->key_sorted.as<uint8_t>(), S->idx.as<uint32_t>(), S->idx_sorted.as<uint32_t>(), (int)n_q, 0, 8, st));
+	}
+	HIPCHK(hipMemcpyAsync(S->info_pinned, S->info.p, sizeof(BhipStageInfo), hipMemcpyDeviceToHost, st));
+	HIPCHK(hipEventRecord(S->ev_done, st));
+	return 0;
+}
+
+// lists and maxima of a slot from a routing summary
+static void slot_take_info(StageSlot *S, const BhipStageInfo &I) {
+	uint32_t off = 0;
+	for (uint32_t l = 0; l < 16; ++l) {
+		for (int c = 0; c < kNumClasses; ++c) {
+			const uint32_t lc = l * 7 + (uint32_t)c;
+			S->npf[l][c] = I.count[lc * 2]; S->nex[l][c] = I.count[lc * 2 + 1];
+			S->qlist_off[l][c] = off; off += S->npf[l][c] + S->nex[l][c];
+			S->maxE[l][c] = I.maxE[lc]; S->maxwords[l][c] = I.maxwords[lc]; S->seed_words[l][c] = I.seed_words[lc];
+		}
+		S->maxlen_lane[l] = I.maxlen_lane[l]; S->n_entries_lane[l] = I.n_entries_lane[l];
+	}
+	S->st_maxE = I.maxE_all;
+}
+
+// Host pass: routing, seed plans and -- when the batch holds symbols of code 0 -- the search view without them, from the
+// caller's arrays (the device copies of the batch itself are already in place).
+static int host_route(Handle *h, StageSlot *S) {
+	const uint32_t n_q = S->st_nq, nl = S->st_lanes, nsh = S->st_nshared;
+	int rc;
+	// flat host view of the batch
+	std::vector<uint8_t> f_codes, f_rc, f_flags; std::vector<uint64_t> f_off; std::vector<uint16_t> f_emac; std::vector<uint32_t> f_six;
+	const uint8_t *q_codes; const uint64_t *q_off; const uint16_t *q_emac; const uint32_t *q_six = S->six_explicit; const uint8_t *q_flags = nullptr;
+	uint32_t n_live = 0, first = 0;
+	for (uint32_t k = 0; k < S->spans.size(); ++k) if (S->spans[k].n) { if (!n_live) first = k; ++n_live; }
+	const bool share_by_position = S->st_has_six && !S->six_explicit;
+	if (n_live == 1 && S->spans[first].off[0] == 0 && !share_by_position) {
+		q_codes = S->spans[first].codes; q_off = S->spans[first].off; q_emac = S->spans[first].emac; q_flags = S->spans[first].flags;
+	} else {
+		f_off.assign(1, 0);
+		for (const BhipQuerySpan &sp : S->spans) {
+			if (!sp.n) continue;
+			f_codes.insert(f_codes.end(), sp.codes + sp.off[0], sp.codes + sp.off[sp.n]);
+			const uint64_t base = f_off.back() - sp.off[0];
+			for (uint32_t j = 0; j < sp.n; ++j) { f_off.push_back(sp.off[j + 1] + base); if (share_by_position) f_six.push_back(j); }
+			f_emac.insert(f_emac.end(), sp.emac, sp.emac + sp.n);
+			if (S->has_flags) f_flags.insert(f_flags.end(), sp.flags, sp.flags + sp.n);
+		}
+		f_codes.resize(f_codes.size() + 16, 0);
+		q_codes = f_codes.data(); q_off = f_off.data(); q_emac = f_emac.data();
+		if (share_by_position) q_six = f_six.data();
+		if (S->has_flags) q_flags = f_flags.data();
+	}
 	const size_t n_keys = (size_t)nl * kNumClasses * 2;
 	std::vector<uint32_t> plan(n_q, 1u);
 	std::vector<uint8_t> nxv(n_q, 0);          // symbols of code 0 per entry (255 = more than any budget: never searched)
-	for (uint32_t l = 0; l < nl; ++l) { Lane *L = h->lanes[l]; for (int c = 0; c < kNumClasses; ++c) { L->npf[c] = L->nex[c] = L->maxE[c] = L->maxwords[c] = 0; L->seed_words[c] = 0; } L->maxlen = 0; L->n_entries = 0; }
 	struct Part {
 		std::vector<std::vector<uint32_t>> lists;
 		std::vector<uint32_t> maxE, maxwords, maxlen, n_entries;
@@ -880,7 +1045,7 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 			const uint64_t len_all = q_off[i + 1] - q_off[i];
 			if (len_all == 0) continue;
 			if (len_all > BHIP_MAX_QLEN) { P.err = 1; P.err_i = i; P.err_len = len_all; return; }
-			if (q_six && q_six[i] >= n_shared) { P.err = 2; P.err_i = i; return; }
+			if (q_six && q_six[i] >= nsh) { P.err = 2; P.err_i = i; return; }
 			// search view of the entry: symbols of code 0 removed, budget reduced by their number
 			const uint8_t *codes_i = q_codes + q_off[i];
 			uint64_t len = len_all;
@@ -915,46 +1080,37 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 			++P.n_entries[l];
 		}
 	};
-	// the upload of the batch does not depend on the routing: it runs on its own host thread meanwhile (a copy from pageable
-	// memory keeps its caller busy for most of its duration)
-	HIPCHK(hipEventRecord(h->ev[0], h->stream));
-	int up_rc = 0;
-	std::string up_msg;          // the error text is thread-local: carry it over
-	std::thread uploader([&]() { (void)hipSetDevice(h->device); up_rc = upload_queries(h, q_codes, q_off, q_emac, q_six, q_rc, n_q); if (up_rc) up_msg = g_err; });
 	if (n_thr == 1) work(0);
 	else {
 		std::vector<std::thread> th;
 		for (uint32_t t = 0; t < n_thr; ++t) th.emplace_back(work, t);
 		for (auto &x : th) x.join();
 	}
-	uploader.join();
 	for (const Part &P : parts) {
 		if (P.err == 1) return fail(BHIP_E_QUERYLEN, "query %u has %llu symbols (max %d)", P.err_i, (unsigned long long)P.err_len, BHIP_MAX_QLEN);
 		if (P.err == 2) return fail(BHIP_E_ARG, "q_six[%u] out of range", P.err_i);
 	}
-	std::vector<std::vector<uint32_t>> lists(n_keys);       // thread order = entry order: the lists come out exactly as a single pass would build them
-	for (size_t k = 0; k < n_keys; ++k) {
-		size_t tot = 0;
-		for (const Part &P : parts) tot += P.lists[k].size();
-		lists[k].reserve(tot);
-		for (const Part &P : parts) lists[k].insert(lists[k].end(), P.lists[k].begin(), P.lists[k].end());
-	}
-	for (uint32_t l = 0; l < nl; ++l) {
-		Lane *L = h->lanes[l];
-		for (const Part &P : parts) {
-			for (int c = 0; c < kNumClasses; ++c) {
-				const size_t lc = (size_t)l * kNumClasses + c;
-				L->maxE[c] = std::max(L->maxE[c], P.maxE[lc]); L->maxwords[c] = std::max(L->maxwords[c], P.maxwords[lc]); L->seed_words[c] += P.seed_words[lc];
-			}
-			L->maxlen = std::max(L->maxlen, P.maxlen[l]); L->n_entries += P.n_entries[l];
+	// summary + sorted entry numbers in key order (thread order = entry order: the lists come out as a single pass would build them)
+	BhipStageInfo I;
+	memset(&I, 0, sizeof I);
+	std::vector<uint32_t> sorted; sorted.reserve(n_q);
+	for (uint32_t l = 0; l < nl; ++l) for (int c = 0; c < kNumClasses; ++c) for (int ex = 0; ex < 2; ++ex) {
+		const size_t lc = (size_t)l * kNumClasses + c, k = lc * 2 + ex;
+		for (const Part &P : parts) { sorted.insert(sorted.end(), P.lists[k].begin(), P.lists[k].end()); I.count[(l * 7 + c) * 2 + ex] += (uint32_t)P.lists[k].size(); }
+		if (!ex) for (const Part &P : parts) {
+			I.maxE[l * 7 + c] = std::max(I.maxE[l * 7 + c], P.maxE[lc]); I.maxwords[l * 7 + c] = std::max(I.maxwords[l * 7 + c], P.maxwords[lc]);
+			I.seed_words[l * 7 + c] += P.seed_words[lc];
 		}
 	}
-	const double t_route = since();
-	if (up_rc) return fail(up_rc, "%s", up_msg.c_str());
-	if ((rc = upload_plan(h, q_codes, q_off, q_emac, n_q, plan))) return rc;
-	h->st_has_junk = false;
-	for (const Part &P : parts) h->st_has_junk |= P.junk;
-	if (h->st_has_junk) {       // rare: second view of the batch without the symbols of code 0 (see Handle::qcodes_s)
+	for (uint32_t l = 0; l < nl; ++l) for (const Part &P : parts) { I.maxlen_lane[l] = std::max(I.maxlen_lane[l], P.maxlen[l]); I.n_entries_lane[l] += P.n_entries[l]; }
+	for (uint32_t i = 0; i < n_q; ++i) I.maxE_all = std::max<uint32_t>(I.maxE_all, q_emac[i]);
+	slot_take_info(S, I);
+	hipStream_t st = h->stage_stream;
+	HIPCHK(hipMemcpyAsync(S->plan.p, plan.data(), (size_t)n_q * 4, hipMemcpyHostToDevice, st));
+	if (!sorted.empty()) HIPCHK(hipMemcpyAsync(S->idx_sorted.p, sorted.data(), sorted.size() * 4, hipMemcpyHostToDevice, st));
+	S->st_has_junk = false;
+	for (const Part &P : parts) S->st_has_junk |= P.junk;
+	if (S->st_has_junk) {       // rare: second view of the batch without the symbols of code 0 (see StageSlot)
 		std::vector<uint64_t> off_s((size_t)n_q + 1, 0);
 		std::vector<uint16_t> emac_s(n_q);
 		std::vector<uint8_t> codes_s; codes_s.reserve(q_off[n_q] + 16);
@@ -969,48 +1125,109 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 			nxs[q_six ? q_six[i] : i] = nxv[i];
 		}
 		codes_s.resize(codes_s.size() + 16, 0);
-		if ((rc = h->qcodes_s.reserve(codes_s.size()))) return rc;
-		if ((rc = h->qoff_s.reserve(((size_t)n_q + 1) * 8))) return rc;
-		if ((rc = h->qemac_s.reserve(((size_t)n_q + 1) * 2))) return rc;
-		if ((rc = h->nx.reserve((size_t)n_q + 16))) return rc;
-		if ((rc = h->nx_six.reserve((size_t)nsh + 16))) return rc;
-		HIPCHK(hipMemcpyAsync(h->qcodes_s.p, codes_s.data(), codes_s.size(), hipMemcpyHostToDevice, h->stream));
-		HIPCHK(hipMemcpyAsync(h->qoff_s.p, off_s.data(), ((size_t)n_q + 1) * 8, hipMemcpyHostToDevice, h->stream));
-		HIPCHK(hipMemcpyAsync(h->qemac_s.p, emac_s.data(), (size_t)n_q * 2, hipMemcpyHostToDevice, h->stream));
-		HIPCHK(hipMemcpyAsync(h->nx.p, nxv.data(), n_q, hipMemcpyHostToDevice, h->stream));
-		HIPCHK(hipMemcpyAsync(h->nx_six.p, nxs.data(), nsh, hipMemcpyHostToDevice, h->stream));
-		HIPCHK(hipStreamSynchronize(h->stream));      // the host vectors go out of scope
-		const uint32_t qw_g = (h->st_maxlen + 7) / 8;
-		if ((rc = h->qpack_s.reserve((size_t)n_q * qw_g * 4 + 16))) return rc;
+		if ((rc = S->qcodes_s.reserve(codes_s.size()))) return rc;
+		if ((rc = S->qoff_s.reserve(((size_t)n_q + 1) * 8))) return rc;
+		if ((rc = S->qemac_s.reserve(((size_t)n_q + 1) * 2))) return rc;
+		if ((rc = S->nx.reserve((size_t)n_q + 16))) return rc;
+		if ((rc = S->nx_six.reserve((size_t)nsh + 16))) return rc;
+		HIPCHK(hipMemcpyAsync(S->qcodes_s.p, codes_s.data(), codes_s.size(), hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(S->qoff_s.p, off_s.data(), ((size_t)n_q + 1) * 8, hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(S->qemac_s.p, emac_s.data(), (size_t)n_q * 2, hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(S->nx.p, nxv.data(), n_q, hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(S->nx_six.p, nxs.data(), nsh, hipMemcpyHostToDevice, st));
+		const uint32_t qw_g = (S->st_maxlen + 7) / 8;
+		if ((rc = S->qpack_s.reserve((size_t)n_q * qw_g * 4 + 64))) return rc;
 		const uint64_t total = (uint64_t)n_q * qw_g;
-		if (total) hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
-			h->qcodes_s.as<uint8_t>(), h->qoff_s.as<uint64_t>(), n_q, qw_g, h->qpack_s.as<uint32_t>());
+		if (total) hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, st,
+			S->qcodes_s.as<uint8_t>(), S->qoff_s.as<uint64_t>(), n_q, qw_g, S->qpack_s.as<uint32_t>());
 		HIPCHK(hipGetLastError());
 	}
-	const double t_up = since();
-	{	// 4-bit packed copy of the queries at a fixed stride (layout used by the seed, profile and re-scoring kernels)
-		const uint32_t qw_g = (h->st_maxlen + 7) / 8;
-		if ((rc = h->qpack.reserve((size_t)n_q * qw_g * 4 + 16))) return rc;
-		const uint64_t total = (uint64_t)n_q * qw_g;
-		if (total) hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
-			h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), n_q, qw_g, h->qpack.as<uint32_t>());
-		HIPCHK(hipGetLastError());
-	}
-	for (uint32_t l = 0; l < nl; ++l) for (int cls = 0; cls < kNumClasses; ++cls) {
+	HIPCHK(hipStreamSynchronize(st));      // the host vectors go out of scope
+	return 0;
+}
+
+static int resolve_slot(Handle *h, StageSlot *S) {
+	if (S->resolved) return 0;
+	if (!S->st_nq) { S->resolved = true; S->st_valid = true; S->st_lanes = 0; return 0; }
+	HIPCHK(hipEventSynchronize(S->ev_done));
+	const BhipStageInfo &I = *S->info_pinned;
+	if (I.err == 1) return fail(BHIP_E_QUERYLEN, "query %u has %u symbols (max %d)", I.err_i, I.err_len, BHIP_MAX_QLEN);
+	if (I.err == 2) return fail(BHIP_E_ARG, "q_six[%u] out of range", I.err_i);
+	S->st_ms_h2d = ev_ms(S->ev_begin, S->ev_done);
+	if (I.junk || h->opt_host_routing) { int rc = host_route(h, S); if (rc) return rc; }
+	else slot_take_info(S, I);
+	S->resolved = true; S->st_valid = true;
+	if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] stage: %u entries, %s routing, copies + routing %.2f ms on the staging stream\n", S->st_nq,
+		(I.junk || h->opt_host_routing) ? "host" : "device", S->st_ms_h2d);
+	return 0;
+}
+
+// the slot becomes the batch the alignment kernels work on
+static void apply_slot(Handle *h, StageSlot *S) {
+	h->cur = S;
+	for (uint32_t l = 0; l < S->st_lanes && l < h->lanes.size(); ++l) {
 		Lane *L = h->lanes[l];
-		std::vector<uint32_t> &pf = lists[((size_t)l * kNumClasses + cls) * 2], &ex = lists[((size_t)l * kNumClasses + cls) * 2 + 1];
-		L->npf[cls] = (uint32_t)pf.size(); L->nex[cls] = (uint32_t)ex.size();
-		if (pf.empty() && ex.empty()) continue;
-		std::vector<uint32_t> ql(pf);
-		ql.insert(ql.end(), ex.begin(), ex.end());
-		if ((rc = L->qlist_cls[cls].reserve(ql.size() * 4))) return rc;
-		HIPCHK(hipMemcpy(L->qlist_cls[cls].p, ql.data(), ql.size() * 4, hipMemcpyHostToDevice));
+		for (int c = 0; c < kNumClasses; ++c) {
+			L->npf[c] = S->npf[l][c]; L->nex[c] = S->nex[l][c]; L->maxE[c] = S->maxE[l][c]; L->maxwords[c] = S->maxwords[l][c]; L->seed_words[c] = S->seed_words[l][c];
+			L->qlist[c] = S->idx_sorted.as<uint32_t>() + S->qlist_off[l][c];
+		}
+		L->maxlen = S->maxlen_lane[l]; L->n_entries = S->n_entries_lane[l];
 	}
-	HIPCHK(hipEventRecord(h->ev[1], h->stream));
-	HIPCHK(hipStreamSynchronize(h->stream));
-	h->st_ms_h2d = ev_ms(h->ev[0], h->ev[1]);
-	h->st_valid = true;
-	if (dbg) fprintf(stderr, "[bhip] stage: routing+plans %.2f ms, uploads %.2f ms, lists+pack %.2f ms (total %.2f ms, %u entries)\n", t_route, t_up - t_route, since() - t_up, since(), n_q);
+}
+
+static StageSlot *free_slot(Handle *h) {        // a slot that holds no batch waiting to be aligned (an already aligned batch may be overwritten)
+	for (StageSlot &S : h->slots) if (S.state == 0) return &S;
+	for (StageSlot &S : h->slots) if (S.state == 2) return &S;
+	return nullptr;
+}
+
+extern "C" int bhip_stage_spans(void *handle, const BhipQuerySpan *spans, uint32_t n_spans, uint32_t n_shared, uint32_t max_len) {
+	Handle *h = (Handle *)handle;
+	if (!h || (!spans && n_spans)) return fail(BHIP_E_ARG, "null argument");
+	HIPCHK(hipSetDevice(h->device));
+	StageSlot *S = free_slot(h);
+	if (!S) return fail(BHIP_E_ARG, "two batches are staged already: align one first");
+	S->state = 0;
+	int rc = stage_enqueue(h, S, spans, n_spans, nullptr, true, n_shared, max_len);
+	if (rc) return rc;
+	S->state = 1;
+	return BHIP_OK;
+}
+
+extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
+                                  const uint32_t *q_six, const uint8_t *q_rc, const uint8_t *q_flags, uint32_t n_q, uint32_t n_shared) {
+	Handle *h = (Handle *)handle;
+	if (!h) return fail(BHIP_E_ARG, "null handle");
+	if (n_q && (!q_codes || !q_off || !q_emac)) return fail(BHIP_E_ARG, "null query arrays");
+	HIPCHK(hipSetDevice(h->device));
+	for (StageSlot &S : h->slots) if (S.state == 1) S.state = 0;      // this entry point replaces whatever was waiting
+	StageSlot *S = free_slot(h);
+	S->state = 0;
+	BhipQuerySpan sp;
+	memset(&sp, 0, sizeof sp);
+	sp.codes = q_codes; sp.off = q_off; sp.emac = q_emac; sp.rc = q_rc; sp.flags = q_flags; sp.n = n_q; sp.q_base = 0;
+	int rc = stage_enqueue(h, S, &sp, n_q ? 1u : 0u, q_six, false, n_shared, 0);
+	if (rc) return rc;
+	if ((rc = resolve_slot(h, S))) return rc;      // synchronous: the caller's arrays are free again at return
+	S->spans.clear(); S->six_explicit = nullptr;
+	S->state = 1;
+	return BHIP_OK;
+}
+
+// page-locked host memory for the arrays handed to bhip_stage_spans and the result buffers of bhip_align_staged
+extern "C" void *bhip_alloc_host(uint64_t bytes) {
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	return p;
+}
+extern "C" void bhip_free_host(void *p) { if (p) (void)hipHostFree(p); }
+extern "C" int bhip_host_register(void *p, uint64_t bytes) {
+	if (!p || !bytes) return BHIP_OK;
+	if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return fail(BHIP_E_DEVICE, "hipHostRegister(%llu bytes) failed", (unsigned long long)bytes); }
+	return BHIP_OK;
+}
+extern "C" int bhip_host_unregister(void *p) {
+	if (p && hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return fail(BHIP_E_DEVICE, "hipHostUnregister failed"); }
 	return BHIP_OK;
 }
 
@@ -1043,7 +1260,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		const uint32_t n_pf = L->npf[cls], n_ex = L->nex[cls], n_list = n_pf + n_ex;
 		if (!n_list) continue;
 		const int NW = kClasses[cls];
-		const uint32_t *qlist = L->qlist_cls[cls].as<uint32_t>();
+		const uint32_t *qlist = L->qlist[cls];
 		hipEvent_t *ce = L->ev_cls[cls];
 		// the lane's peq buffers are reused class after class: do not rebuild them before the previous class's window stage is done
 		// (the profiles are built on the sweep stream, which is idle while this class's seeds and prefilter run on theirs)
@@ -1053,7 +1270,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 			const uint32_t qb = 256u / (uint32_t)NW;
 			const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + qb - 1) / qb, (uint64_t)h->n_cu * 16);
 			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, sw, h->s_codes(), h->s_off(),
-				qlist, n_list, NW, 0, h->mm, L->peq.as<uint32_t>(), h->s_pack(), (h->st_maxlen + 7) / 8);
+				qlist, n_list, NW, 0, h->mm, L->peq.as<uint32_t>(), h->s_pack(), (h->cur->st_maxlen + 7) / 8);
 			HIPCHK(hipGetLastError());
 		}
 		// two-stage edit distance when a prefix of 32*NWP symbols is selective for this class's budgets
@@ -1067,7 +1284,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 			const uint32_t qb = 256u / (uint32_t)NWP;
 			const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + qb - 1) / qb, (uint64_t)h->n_cu * 16);
 			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, sw, h->s_codes(), h->s_off(),
-				qlist, n_list, NWP, 32 * NWP, h->mm, L->peqp.as<uint32_t>(), h->s_pack(), (h->st_maxlen + 7) / 8);
+				qlist, n_list, NWP, 32 * NWP, h->mm, L->peqp.as<uint32_t>(), h->s_pack(), (h->cur->st_maxlen + 7) / 8);
 			HIPCHK(hipGetLastError());
 		}
 		L->prefix_words = (uint32_t)NWP;
@@ -1115,7 +1332,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 			HIPCHK(hipEventRecord(L->ev_ph[cls][0], po));
 			HIPCHK(hipStreamWaitEvent(sw, L->ev_ph[cls][0], 0));
 			hipLaunchKernelGGL(k_task_filter, dim3((uint32_t)h->n_cu * 8), dim3(256), 0, sw, L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], (uint32_t)L->task_cap, qlist,
-				h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->best.as<uint32_t>(), L->tasks2k.as<uint2>(), &dc->n_tasks2k_cls[cls]);
+				h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr, h->best.as<uint32_t>(), L->tasks2k.as<uint2>(), &dc->n_tasks2k_cls[cls]);
 			launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 32, L->tasks2k.as<uint2>(), &dc->n_tasks2k_cls[cls], qlist, L->wins2.as<BhipWin>(), &dc->n_wins2_cls[cls], dc);
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipEventRecord(L->ev_ph[cls][1], sw));
@@ -1128,25 +1345,25 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	}
 	// re-scoring of the kept reference lanes of this lane's shared slots
 	HIPCHK(hipEventRecord(L->ev_rs[0], po));
-	if (h->st_has_junk) {       // back to the units of the original queries (see Handle::qcodes_s); this lane owns the shared slots [s0, s1)
-		const uint32_t nl_ = h->st_lanes, nsh_ = h->st_nshared;
+	if (h->cur->st_has_junk) {       // back to the units of the original queries (see Handle::qcodes_s); this lane owns the shared slots [s0, s1)
+		const uint32_t nl_ = h->cur->st_lanes, nsh_ = h->cur->st_nshared;
 		uint32_t li_ = 0;
 		for (uint32_t l = 0; l < nl_; ++l) if (h->lanes[l] == L) li_ = l;
 		const uint32_t s0 = (uint32_t)(((uint64_t)li_ * nsh_ + nl_ - 1) / nl_), s1 = (uint32_t)(((uint64_t)(li_ + 1) * nsh_ + nl_ - 1) / nl_);
-		hipLaunchKernelGGL(k_junk_adjust_raw, dim3((uint32_t)h->n_cu * 4), dim3(256), 0, po, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, h->nx.as<uint8_t>());
-		if (s1 > s0) hipLaunchKernelGGL(k_junk_adjust_best, dim3(std::min<uint32_t>((s1 - s0 + 255) / 256, (uint32_t)h->n_cu * 4)), dim3(256), 0, po, h->best.as<uint32_t>(), h->nx_six.as<uint8_t>(), s0, s1);
+		hipLaunchKernelGGL(k_junk_adjust_raw, dim3((uint32_t)h->n_cu * 4), dim3(256), 0, po, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, h->cur->nx.as<uint8_t>());
+		if (s1 > s0) hipLaunchKernelGGL(k_junk_adjust_best, dim3(std::min<uint32_t>((s1 - s0 + 255) / 256, (uint32_t)h->n_cu * 4)), dim3(256), 0, po, h->best.as<uint32_t>(), h->cur->nx_six.as<uint8_t>(), s0, s1);
 		HIPCHK(hipGetLastError());
 	}
 	// classify (exact matches leave here), register-band variants for the narrow bands, LDS band for the rest
-	const uint32_t qw_g = (h->st_maxlen + 7) / 8;
+	const uint32_t qw_g = (h->cur->st_maxlen + 7) / 8;
 	hipLaunchKernelGGL(k_rescore_classify, dim3((uint32_t)h->n_cu * 8), dim3(256), 0, po, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap,
-		h->best.as<uint32_t>(), all_hits, h->qoff.as<uint64_t>(), h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr,
+		h->best.as<uint32_t>(), all_hits, h->cur->qoff.as<uint64_t>(), h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr, h->cur->st_has_rc ? h->cur->qrc.as<uint8_t>() : nullptr,
 		h->clump_len.as<uint32_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, L->rs_lists.as<uint32_t>(), dc->n_rs, L->wide.as<uint32_t>(), &dc->n_wide,
 		band_rows, h->opt_rescore_reg);
 	HIPCHK(hipGetLastError());
 	if (h->opt_rescore_reg) {
 #define RS_LAUNCH(SET, BLOCKS) hipLaunchKernelGGL(k_rescore_reg<SET>, dim3((uint32_t)h->n_cu * std::min<uint32_t>(32u, blocks_per_cu((const void *)k_rescore_reg<SET>, 64, 0))), dim3(64), 0, po, L->raw.as<BhipRawHit>(), L->rs_lists.as<uint32_t>(), dc->n_rs, (uint32_t)L->raw_cap, \
-			h->qoff.as<uint64_t>(), h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr, h->qpack.as<uint32_t>(), qw_g, \
+			h->cur->qoff.as<uint64_t>(), h->cur->st_has_rc ? h->cur->qrc.as<uint8_t>() : nullptr, h->cur->qpack.as<uint32_t>(), qw_g, \
 			h->ref_lane.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, &sc->err)
 		RS_LAUNCH(0, 16);
 		HIPCHK(hipGetLastError());
@@ -1159,10 +1376,10 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	const uint32_t grid_rs = (uint32_t)h->n_cu * (h->opt_rescore_reg ? 4 : 16);
 	const size_t lds_rs = (size_t)(band_rows + 1 + qw + rw) * 256;
 	hipLaunchKernelGGL(k_rescore<false>, dim3(grid_rs), dim3(64), lds_rs, po, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap,
-		L->rs_lists.as<uint32_t>() + (size_t)9 * L->raw_cap, &dc->n_rs[9], h->best.as<uint32_t>(), all_hits, h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(),
-		h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr, h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(),
+		L->rs_lists.as<uint32_t>() + (size_t)9 * L->raw_cap, &dc->n_rs[9], h->best.as<uint32_t>(), all_hits, h->cur->qcodes.as<uint8_t>(), h->cur->qoff.as<uint64_t>(),
+		h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr, h->cur->st_has_rc ? h->cur->qrc.as<uint8_t>() : nullptr, h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(),
 		h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, L->wide.as<uint32_t>(),
-		&dc->n_wide, (uint32_t *)nullptr, &dc->scratch_used, 0ull, &sc->err, qw ? h->qpack.as<uint32_t>() : nullptr, band_rows, qw, rw);
+		&dc->n_wide, (uint32_t *)nullptr, &dc->scratch_used, 0ull, &sc->err, qw ? h->cur->qpack.as<uint32_t>() : nullptr, band_rows, qw, rw);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(L->ev_rs[1], po));
 	HIPCHK(hipMemcpyAsync(L->hc_pinned, dc, sizeof(Counters), hipMemcpyDeviceToHost, po));
@@ -1174,17 +1391,27 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 	if (!h || !n_hits) return fail(BHIP_E_ARG, "null argument");
 	*n_hits = 0;
 	memset(&h->stats, 0, sizeof h->stats);
-	if (!h->st_valid) return fail(BHIP_E_ARG, "no staged queries (call bhip_stage_queries first)");
-	const uint32_t n_q = h->st_nq, n_shared = h->st_nshared, nl = h->st_lanes;
-	if (!n_q) return BHIP_OK;
 	HIPCHK(hipSetDevice(h->device));
+	// the batch: the oldest one staged and not aligned yet, else the one aligned last (staged once, run any number of times)
+	StageSlot *slot = nullptr;
+	for (StageSlot &S : h->slots) if (S.state == 1 && (!slot || S.seq < slot->seq)) slot = &S;
+	if (!slot) for (StageSlot &S : h->slots) if (S.state == 2 && (!slot || S.seq > slot->seq)) slot = &S;
+	if (!slot) return fail(BHIP_E_ARG, "no staged queries (call bhip_stage_queries first)");
+	{ int rcs = resolve_slot(h, slot); if (rcs) { slot->state = 0; return rcs; } }
+	apply_slot(h, slot);
+	const uint32_t n_q = h->cur->st_nq, n_shared = h->cur->st_nshared, nl = h->cur->st_lanes;
+	if (!n_q) { slot->state = 2; return BHIP_OK; }
 	// LDS plan of the re-scorer: band rows for the widest expected band (2*maxE+1 plus slack), query and reference staging
-	const uint32_t band_rows = std::min<uint32_t>(BHIP_RESCORE_WMAX, 2 * h->st_maxE + 1 + 9);
-	uint32_t qw = (h->st_maxlen + 7) / 8, rw = (h->st_maxlen + band_rows + 24) / 8 + 2;
+	const uint32_t band_rows = std::min<uint32_t>(BHIP_RESCORE_WMAX, 2 * h->cur->st_maxE + 1 + 9);
+	uint32_t qw = (h->cur->st_maxlen + 7) / 8, rw = (h->cur->st_maxlen + band_rows + 24) / 8 + 2;
 	if ((size_t)(band_rows + 1 + qw + rw) * 256 > 40 * 1024) { qw = 0; rw = 0; }      // long queries: per-row global reads instead
 	SharedCtr hsc;
-	for (int attempt = 0; attempt < 8; ++attempt) {
+	for (int attempt = 0; attempt < 24; ++attempt) {
 		int rc;
+		// the records of this batch are still resident when the previous call only failed for the size of the caller's buffer
+		if (h->res_valid && h->res_seq == slot->seq && h->res_all_hits == all_hits) { hsc.n_out = h->res_n; hsc.err = 0; h->stats = h->res_stats; *n_hits = hsc.n_out; }
+		else {
+		h->res_valid = false;
 		if ((rc = h->best.reserve((size_t)(n_shared + 1) * 4))) return rc;
 		if ((rc = h->out.reserve(h->out_cap * sizeof(BhipHit)))) return rc;
 		if ((rc = h->shared_ctr.reserve(sizeof(SharedCtr)))) return rc;
@@ -1237,7 +1464,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			SharedCtr *sc = h->shared_ctr.as<SharedCtr>();
 			hipLaunchKernelGGL(k_rescore<true>, dim3(std::min<uint32_t>((L->hc.n_wide + 63) / 64, (uint32_t)h->n_cu * 16)), dim3(64), 256, h->post_stream,
 				L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, L->wide.as<uint32_t>(), &dc->n_wide, h->best.as<uint32_t>(), all_hits,
-				h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), h->st_has_six ? h->qsix.as<uint32_t>() : nullptr, h->st_has_rc ? h->qrc.as<uint8_t>() : nullptr,
+				h->cur->qcodes.as<uint8_t>(), h->cur->qoff.as<uint64_t>(), h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr, h->cur->st_has_rc ? h->cur->qrc.as<uint8_t>() : nullptr,
 				h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(),
 				&sc->n_out, (uint32_t)h->out_cap, (uint32_t *)nullptr, (uint32_t *)nullptr, L->scratch.as<uint32_t>(), &dc->scratch_used,
 				(unsigned long long)L->scratch_cap, &sc->err, (const uint32_t *)nullptr, 0u, 0u, 0u);
@@ -1278,6 +1505,9 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			S.ms_rescore += ev_ms(L->ev_rs[0], L->ev_rs[1]);
 		}
 		S.bytes_algorithmic = 8ull * S.n_columns + qlen_sum / 2 + 192ull * S.n_pairs;
+		h->res_valid = true; h->res_seq = slot->seq; h->res_all_hits = all_hits; h->res_n = hsc.n_out; h->res_stats = h->stats;
+		}
+		BhipStats &S = h->stats;
 		if (hits && hsc.n_out > cap) return fail(BHIP_E_CAPACITY, "hit buffer holds %llu records, %u needed", (unsigned long long)cap, hsc.n_out);
 		HIPCHK(hipEventRecord(h->ev[8], h->stream));
 		if (hsc.n_out) {
@@ -1297,7 +1527,8 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, off, (int)(n_q + 1), h->stream));
 			if ((rc = h->sort_tmp.reserve(tmp_bytes))) return rc;
 			HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->sort_tmp.p, tmp_bytes, cnt, off, (int)(n_q + 1), h->stream));
-			hipLaunchKernelGGL(k_hit_scatter, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, off, rank, sorted.as<BhipHit>());
+			hipLaunchKernelGGL(k_hit_scatter, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, off, rank, sorted.as<BhipHit>(),
+				h->cur->has_qmap ? h->cur->qmap.as<uint32_t>() : (const uint32_t *)nullptr);
 			hipLaunchKernelGGL(k_hit_fix, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, h->stream, sorted.as<BhipHit>(), off, cnt, n_q);
 			HIPCHK(hipGetLastError());
 			const size_t bytes = (size_t)n * sizeof(BhipHit);
@@ -1308,6 +1539,12 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 					for (auto &e : h->ev_copied) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
 				const size_t want = (size_t)cap * sizeof(BhipHit);
 				bool reg_ok = h->reg_ptr[o] == (void *)hits && h->reg_bytes[o] >= bytes;
+				if (!reg_ok) {      // already page-locked by the caller (bhip_alloc_host / bhip_host_register)?
+					hipPointerAttribute_t at;
+					memset(&at, 0, sizeof at);
+					if (hipPointerGetAttributes(&at, (const void *)hits) == hipSuccess && at.type == hipMemoryTypeHost) reg_ok = true;
+					else (void)hipGetLastError();
+				}
 				if (!reg_ok) {
 					if (h->reg_ptr[o]) { (void)hipHostUnregister(h->reg_ptr[o]); h->reg_ptr[o] = nullptr; }
 					if (h->reg_ptr[o ^ 1] == (void *)hits) { if (h->copy_pending[o ^ 1]) { HIPCHK(hipEventSynchronize(h->ev_copied[o ^ 1])); h->copy_pending[o ^ 1] = false; }
@@ -1329,7 +1566,9 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		}
 		HIPCHK(hipEventRecord(h->ev[9], h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
-		S.ms_h2d = h->st_ms_h2d; S.ms_d2h = ev_ms(h->ev[8], h->ev[9]); S.ms_total = ev_ms(h->ev[0], h->ev[9]);
+		S.ms_h2d = h->cur->st_ms_h2d; S.ms_d2h = ev_ms(h->ev[8], h->ev[9]); S.ms_total = ev_ms(h->ev[0], h->ev[9]);
+		slot->state = 2;
+		h->res_valid = false;
 		return BHIP_OK;
 	}
 	return fail(BHIP_E_INTERNAL, "buffers kept overflowing");
@@ -1351,7 +1590,8 @@ extern "C" int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint
 	Handle *h = (Handle *)handle;
 	if (!h || !q_codes || !q_off || !q_emac || !pair_q || !pair_clump || !mins) return fail(BHIP_E_ARG, "null argument");
 	memset(&h->stats, 0, sizeof h->stats);
-	h->st_valid = false;
+	for (StageSlot &S : h->slots) { S.state = 0; S.st_valid = false; }
+	h->cur = &h->slots[0];
 	if (!n_pairs || !n_q) return BHIP_OK;
 	HIPCHK(hipSetDevice(h->device));
 	int rc;
@@ -1366,7 +1606,7 @@ extern "C" int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint
 		if (pair_q[p] >= n_q || pair_clump[p] >= h->n_clumps) return fail(BHIP_E_ARG, "pair %llu out of range", (unsigned long long)p);
 		pr[p] = make_uint2(pair_q[p], pair_clump[p]);
 	}
-	h->st_has_six = false; h->st_has_rc = false;
+	h->cur->st_has_six = false; h->cur->st_has_rc = false;
 	if ((rc = upload_queries(h, q_codes, q_off, q_emac, nullptr, nullptr, n_q))) return rc;
 	if ((rc = L->peq.reserve((size_t)n_q * 16 * NW * 4))) return rc;
 	if ((rc = h->pairs.reserve(n_pairs * sizeof(uint2)))) return rc;
@@ -1377,7 +1617,7 @@ extern "C" int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint
 	Counters *dc = L->counters.as<Counters>();
 	const uint32_t qb = 256u / (uint32_t)NW;
 	hipLaunchKernelGGL(k_build_peq, dim3((uint32_t)std::min<uint64_t>(((uint64_t)n_q + qb - 1) / qb, (uint64_t)h->n_cu * 16)), dim3(256), 0, st,
-		h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), (const uint32_t *)nullptr, n_q, NW, 0, h->mm, L->peq.as<uint32_t>(), (const uint32_t *)nullptr, 0u);
+		h->cur->qcodes.as<uint8_t>(), h->cur->qoff.as<uint64_t>(), (const uint32_t *)nullptr, n_q, NW, 0, h->mm, L->peq.as<uint32_t>(), (const uint32_t *)nullptr, 0u);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(h->ev[0], st));
 	launch_myers(h, L, st, cls, (uint32_t)std::min<uint64_t>((n_pairs + 15) / 16, (uint64_t)h->n_cu * 8), h->pairs.as<uint2>(), nullptr, n_pairs, 0, nullptr,
@@ -1400,7 +1640,8 @@ extern "C" int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64
 	if (!h || !q_codes || !q_off || !q_emac || !n_out) return fail(BHIP_E_ARG, "null argument");
 	if (!h->has_acx) return fail(BHIP_E_ARG, "handle has no accelerator");
 	*n_out = 0;
-	h->st_valid = false;
+	for (StageSlot &S : h->slots) { S.state = 0; S.st_valid = false; }
+	h->cur = &h->slots[0];
 	if (!n_q) return BHIP_OK;
 	HIPCHK(hipSetDevice(h->device));
 	int rc;
@@ -1413,11 +1654,11 @@ extern "C" int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64
 			for (uint32_t i = 0; i < n_q; ++i) plan[i] = make_seed_plan(q_codes + q_off[i], (uint32_t)(q_off[i + 1] - q_off[i]), q_emac[i], (uint32_t)h->K, h->opt_prefilter_stride);
 			if ((rc = upload_plan(h, q_codes, q_off, q_emac, n_q, plan))) return rc;
 	{	// 4-bit packed copy of the queries at a fixed stride (layout used by the seed, profile and re-scoring kernels)
-		const uint32_t qw_g = (h->st_maxlen + 7) / 8;
-		if ((rc = h->qpack.reserve((size_t)n_q * qw_g * 4 + 16))) return rc;
+		const uint32_t qw_g = (h->cur->st_maxlen + 7) / 8;
+		if ((rc = h->cur->qpack.reserve((size_t)n_q * qw_g * 4 + 16))) return rc;
 		const uint64_t total = (uint64_t)n_q * qw_g;
 		if (total) hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, h->stream,
-			h->qcodes.as<uint8_t>(), h->qoff.as<uint64_t>(), n_q, qw_g, h->qpack.as<uint32_t>());
+			h->cur->qcodes.as<uint8_t>(), h->cur->qoff.as<uint64_t>(), n_q, qw_g, h->cur->qpack.as<uint32_t>());
 		HIPCHK(hipGetLastError());
 	}
 		}

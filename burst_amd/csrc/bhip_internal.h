@@ -22,6 +22,20 @@ struct BhipWin {
 	uint32_t flags;
 };
 
+// Routing of a staged batch, filled on the device by k_route (or by the host pass that handles batches with query symbols
+// outside the alphabet): a query entry belongs to the list of its key = ((lane * 7 + length class) * 2 + exhaustive).
+#define BHIP_ROUTE_KEYS 224          // 16 lanes x 7 classes x {prefilter, exhaustive}
+#define BHIP_ROUTE_SKIP 255          // empty entries (and entries a batch error was raised for): in no list
+struct BhipStageInfo {
+	uint32_t count[256];               // entries per key
+	uint32_t maxE[BHIP_ROUTE_KEYS / 2], maxwords[BHIP_ROUTE_KEYS / 2];
+	unsigned long long seed_words[BHIP_ROUTE_KEYS / 2];
+	uint32_t maxlen_lane[16], n_entries_lane[16];
+	uint32_t junk;                     // entries with symbols of code 0 (the host pass takes over)
+	uint32_t err, err_i, err_len;      // 1 = query longer than BHIP_MAX_QLEN, 2 = shared slot out of range
+	uint32_t maxE_all, maxlen_all;
+};
+
 #define BHIP_RESCORE_WMAX 48   // band widths up to this many diagonals are handled in LDS
 
 // ------------------------------------------------------------------------------------------------

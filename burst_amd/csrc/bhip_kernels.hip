@@ -1801,6 +1801,120 @@ __global__ void k_pack_queries(const uint8_t *__restrict__ qcodes, const uint64_
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// Staging of a batch on the device (the host only enqueues copies): k_span_fill turns the offsets of a caller's span of
+// entries into batch offsets, shared slots and reported query numbers; k_route does what the host pass of round 1 did per
+// entry -- length class, sub-pipeline, prefilter or exhaustive route, seed plan (stride and guaranteed count, see
+// k_prefilter_wave above) -- and leaves per-list counts and maxima in a BhipStageInfo; a stable 8-bit radix sort of the
+// entry numbers by key then yields every (lane, class) list in entry order.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_span_fill(const uint64_t *__restrict__ off_raw, uint32_t n, uint32_t ebase, uint64_t pos_base, uint32_t q_base,
+                            uint64_t *__restrict__ qoff, uint32_t *__restrict__ qsix, uint32_t *__restrict__ qmap) {
+	const uint64_t o0 = off_raw[0];
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j <= n; j += gridDim.x * blockDim.x) {
+		qoff[ebase + j] = off_raw[j] - o0 + pos_base;
+		if (j < n) { if (qsix) qsix[ebase + j] = j; qmap[ebase + j] = q_base + j; }
+	}
+}
+
+// seed plan of one entry: same choice as make_seed_plan (bhip_api.hip); vb = bit p set iff the word at p holds only A/C/G/T
+__device__ uint32_t bhip_seed_plan(uint32_t len, uint32_t E, uint32_t K, int stride_opt, bool clean, const uint32_t *vb) {
+	if (len < K) return 1u;
+	const uint32_t npos = len - K + 1;
+	auto need_of = [&](uint32_t st) -> int {
+		uint32_t W = 0;
+		if (clean) W = (len - K) / st + 1; else for (uint32_t p = 0; p < npos; p += st) W += (vb[p >> 5] >> (p & 31u)) & 1u;
+		return (int)W - (int)(E * ((K + st - 1) / st));
+	};
+	const uint32_t smin = (len - K) / 254 + 1, smax = K > smin ? K : smin;
+	uint32_t best_s = 0; int best_n = 0;
+	if (stride_opt > 0) { best_s = (uint32_t)stride_opt > smin ? (uint32_t)stride_opt : smin; best_n = need_of(best_s); }
+	else {
+		for (uint32_t st = smax; st >= smin; --st) { const int n = need_of(st); if (n >= 3) { best_s = st; best_n = n; break; } if (st == smin) break; }
+		if (!best_s) for (uint32_t st = smin; st <= smax; ++st) { const int n = need_of(st); if (n > best_n) { best_n = n; best_s = st; } }
+		if (!best_s) { best_s = smin; best_n = need_of(smin); }
+	}
+	if (best_n < 1) best_n = 0;
+	if (best_n > 0xFFFF) best_n = 0xFFFF;
+	return (best_s & 255u) | ((uint32_t)best_n << 8);
+}
+
+__global__ __launch_bounds__(256) void k_route(
+		const uint64_t *__restrict__ qoff, const uint32_t *__restrict__ qpack, uint32_t qw, const uint16_t *__restrict__ qemac,
+		const uint32_t *__restrict__ qsix, const uint8_t *__restrict__ qflags, uint32_t n_q, uint32_t n_shared, uint32_t n_lanes,
+		int has_acx, int K, int stride_opt,
+		uint32_t *__restrict__ plan, uint8_t *__restrict__ key_out, uint32_t *__restrict__ idx_out, BhipStageInfo *__restrict__ info) {
+	__shared__ uint32_t s_count[256], s_maxE[BHIP_ROUTE_KEYS / 2], s_maxw[BHIP_ROUTE_KEYS / 2], s_seed[BHIP_ROUTE_KEYS / 2], s_maxlen[16], s_nent[16], s_misc[4];
+	const uint32_t tid = threadIdx.x;
+	s_count[tid] = 0;
+	if (tid < BHIP_ROUTE_KEYS / 2) { s_maxE[tid] = 0; s_maxw[tid] = 0; s_seed[tid] = 0; }
+	if (tid < 16) { s_maxlen[tid] = 0; s_nent[tid] = 0; }
+	if (tid < 4) s_misc[tid] = 0;
+	__syncthreads();
+	for (uint32_t i = blockIdx.x * 256 + tid; i < n_q; i += gridDim.x * 256) {
+		const uint64_t b = qoff[i];
+		const uint64_t len64 = qoff[i + 1] - b;
+		uint32_t key = BHIP_ROUTE_SKIP, pl = 1u;
+		if (len64 > BHIP_MAX_QLEN || len64 > 8ull * qw) { if (!atomicExch(&info->err, 1u)) { info->err_i = i; info->err_len = (uint32_t)(len64 > 0xFFFFFFFFull ? 0xFFFFFFFFull : len64); } }
+		else if (qsix && qsix[i] >= n_shared) { if (!atomicExch(&info->err, 2u)) info->err_i = i; }
+		else if (len64) {
+			const uint32_t len = (uint32_t)len64, E = qemac[i];
+			const uint32_t *qp = qpack + (uint64_t)i * qw;
+			// one pass over the symbols: anything outside A/C/G/T? any code 0?
+			uint32_t n_zero = 0, n_other = 0;
+			for (uint32_t j = 0; j < (len + 7) >> 3; ++j) {
+				const uint32_t d = qp[j], nsym = len - 8 * j < 8 ? len - 8 * j : 8u;
+				for (uint32_t k = 0; k < nsym; ++k) { const uint32_t c = (d >> (4 * k)) & 15u; n_zero += c == 0; n_other += (c - 1u) >= 4u; }
+			}
+			if (n_zero) atomicOr(&s_misc[0], 1u);
+			const uint32_t six = qsix ? qsix[i] : i;
+			const uint32_t l = (uint32_t)(((unsigned long long)six * n_lanes) / n_shared);
+			const uint32_t cls = len <= 64 ? 0u : len <= 128 ? 1u : len <= 192 ? 2u : len <= 256 ? 3u : len <= 320 ? 4u : len <= 512 ? 5u : 6u;
+			uint32_t ex = qflags ? (qflags[i] == BHIP_Q_EXHAUSTIVE) : !has_acx;
+			if (!has_acx) ex = 1;
+			if (!ex) {
+				uint32_t vb[32];
+				const bool clean = n_other == 0;
+				if (!clean && len >= (uint32_t)K) {
+					for (uint32_t w = 0; w < 32; ++w) vb[w] = 0;
+					uint32_t run = 0;
+					for (uint32_t p = 0; p < len; ++p) {
+						const uint32_t c = (qp[p >> 3] >> (4 * (p & 7u))) & 15u;
+						run = (c - 1u) < 4u ? run + 1 : 0;
+						if (p + 1 >= (uint32_t)K && run >= (uint32_t)K) { const uint32_t w0 = p + 1 - K; vb[w0 >> 5] |= 1u << (w0 & 31u); }
+					}
+				}
+				pl = bhip_seed_plan(len, E, (uint32_t)K, stride_opt, clean, vb);
+				if ((pl >> 8) == 0) ex = 1;        // no word is guaranteed to survive: exhaustive (burst.c:3130-3131 does the same for "bad" queries)
+			}
+			const uint32_t lc = l * 7 + cls;
+			key = lc * 2 + ex;
+			atomicAdd(&s_count[key], 1u);
+			atomicMax(&s_maxE[lc], E);
+			if (!ex && len >= (uint32_t)K) {
+				const uint32_t nwd = (len - K) / (pl & 255u) + 1;
+				atomicMax(&s_maxw[lc], nwd);
+				atomicAdd(&s_seed[lc], nwd);
+			}
+			atomicMax(&s_maxlen[l], len);
+			atomicAdd(&s_nent[l], 1u);
+			atomicMax(&s_misc[1], E);
+		}
+		plan[i] = pl;
+		key_out[i] = (uint8_t)key;
+		idx_out[i] = i;
+	}
+	__syncthreads();
+	if (s_count[tid]) atomicAdd(&info->count[tid], s_count[tid]);
+	if (tid < BHIP_ROUTE_KEYS / 2) {
+		if (s_maxE[tid]) atomicMax(&info->maxE[tid], s_maxE[tid]);
+		if (s_maxw[tid]) atomicMax(&info->maxwords[tid], s_maxw[tid]);
+		if (s_seed[tid]) atomicAdd(&info->seed_words[tid], (unsigned long long)s_seed[tid]);
+	}
+	if (tid < 16) { if (s_maxlen[tid]) { atomicMax(&info->maxlen_lane[tid], s_maxlen[tid]); atomicMax(&info->maxlen_all, s_maxlen[tid]); } if (s_nent[tid]) atomicAdd(&info->n_entries_lane[tid], s_nent[tid]); }
+	if (tid == 0) { if (s_misc[0]) atomicOr(&info->junk, 1u); if (s_misc[1]) atomicMax(&info->maxE_all, s_misc[1]); }
+}
+
 // Dynamic LDS layout (dwords, all [row][64 threads]): band[band_rows + 1] | qbuf[qw] | rbuf[rw].
 // A hit uses the LDS copies when m <= 8*qw and its reference segment fits rw dwords, else it reads global memory per row.
 template <bool WIDE>

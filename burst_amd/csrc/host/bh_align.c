@@ -1,7 +1,8 @@
 /* bh_align.c -- GPU batch scheduler: the replacement of the two OpenMP loops of do_alignments
  * (burst.c:4050-4289 accelerated, 4326-4488 exhaustive).  Unique queries are cut into contiguous batches in
  * sorted order; a forward entry and its reverse-complement twin always travel in the same batch because they
- * share the running minimum (ShrBin.ed, burst.c:277-280, 4218-4220).  Each batch is one bhip_align_batch call.
+ * share the running minimum (ShrBin.ed, burst.c:277-280, 4218-4220).  Batches are staged (bhip_stage_spans) one ahead of
+ * the batch being aligned (bhip_align_staged).
  */
 #include "burst_host.h"
 #include <stdlib.h>
@@ -20,8 +21,6 @@ int bh_device_open(const BhDb *db, int device, int z, void **hip_handle) {
 	return BH_OK;
 }
 
-void bh_run_free(BhRun *run) { if (run) { free(run->hits); memset(run, 0, sizeof *run); } }
-
 static void add_stats(BhipStats *t, const BhipStats *s) {
 	t->n_queries += s->n_queries; t->n_pairs += s->n_pairs; t->n_columns += s->n_columns; t->n_raw_hits += s->n_raw_hits;
 	t->n_hits += s->n_hits; t->acx_entries_read += s->acx_entries_read; t->bytes_algorithmic += s->bytes_algorithmic;
@@ -32,52 +31,111 @@ static void add_stats(BhipStats *t, const BhipStats *s) {
 	t->n_seed_words += s->n_seed_words; t->ms_prefilter_hash += s->ms_prefilter_hash; t->ms_seed += s->ms_seed; t->prefilter_launches += s->prefilter_launches; t->prefilter_algo = s->prefilter_algo;
 }
 
-int bh_align(void *hh, const BhQueries *Q, uint64_t u0, uint64_t u1, BhMode mode, uint64_t batch_uniq, BhRun *run) {
+/* page-locked result buffer: the records of batch k are copied out behind bhip_align_staged while batch k+1 computes */
+static BhipHit *hits_alloc(uint64_t cap, int *pinned) {
+	BhipHit *p = bhip_alloc_host(cap * sizeof(BhipHit));
+	*pinned = p != NULL;
+	if (!p) p = malloc(cap * sizeof(BhipHit));
+	return p;
+}
+static void hits_free(BhipHit *p, int pinned) { if (pinned) bhip_free_host(p); else free(p); }
+
+void bh_run_free(BhRun *run) { if (run) { if (run->hits) hits_free(run->hits, run->hitsPinned); memset(run, 0, sizeof *run); } }
+
+/* page-lock the arrays the batches are copied from (optional: pageable arrays work, the copies then keep the host thread busy) */
+int bh_queries_pin(BhQueries *Q) {
+	if (Q->pinned || !Q->numEntries) return BH_OK;
+	if (bhip_host_register(Q->codes, Q->qoff[Q->numEntries] + 16)) return BH_OK;          /* no device / no room: stay pageable */
+	if (bhip_host_register(Q->qoff, (Q->numEntries + 1) * sizeof(*Q->qoff))) { bhip_host_unregister(Q->codes); return BH_OK; }
+	Q->pinned = 1;
+	if (!bhip_host_register(Q->emac, Q->numEntries * sizeof(*Q->emac))) Q->pinned |= 2;
+	if (!bhip_host_register(Q->rc, Q->numEntries)) Q->pinned |= 4;
+	if (!bhip_host_register(Q->flags, Q->numEntries)) Q->pinned |= 8;
+	return BH_OK;
+}
+
+/* Double-buffered batch loop (the reference's `omp for schedule(dynamic,1)` over bunches, burst.c:4050-4078): batch k+1 is
+ * handed to the device -- straight from the query arrays, as one span of forward entries and one of reverse complements --
+ * before batch k is aligned, so its copies and routing run beside batch k's kernels; the records of batch k travel back
+ * behind the call that produced them (option async_d2h).  The batches are the ranges [u0[i], u1[i]) of unique queries, each
+ * cut into pieces of at most batch_uniq, in the order given. */
+/* page-locked record buffer of a zeroed or used BhRun for at least cap records (bh_align_ranges_reuse then allocates nothing) */
+int bh_run_reserve(BhRun *run, uint64_t cap) {
+	if (run->hits && run->capHits >= cap) return BH_OK;
+	if (run->hits) hits_free(run->hits, run->hitsPinned);
+	run->hits = hits_alloc(cap, &run->hitsPinned); run->capHits = run->hits ? cap : 0; run->nHits = 0;
+	return run->hits ? BH_OK : bh_set_error(BH_E_OOM, "OOM:hits");
+}
+static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const uint64_t *r1, uint32_t n_ranges, BhMode mode, uint64_t batch_uniq, BhRun *run);
+int bh_align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const uint64_t *r1, uint32_t n_ranges, BhMode mode, uint64_t batch_uniq, BhRun *run) {
 	memset(run, 0, sizeof *run);
-	if (u1 > Q->numUniq) u1 = Q->numUniq;
-	if (u0 >= u1) return BH_OK;
+	return align_ranges(hh, Q, r0, r1, n_ranges, mode, batch_uniq, run);
+}
+/* the same into a BhRun that has been used before (or zeroed by the caller): its page-locked record buffer is kept and grown
+ * only when needed -- page-locking hundreds of megabytes costs more than aligning a batch */
+int bh_align_ranges_reuse(void *hh, const BhQueries *Q, const uint64_t *r0, const uint64_t *r1, uint32_t n_ranges, BhMode mode, uint64_t batch_uniq, BhRun *run) {
+	BhipHit *keep = run->hits; const uint64_t cap = run->capHits; const int pin = run->hitsPinned;
+	memset(run, 0, sizeof *run);
+	run->hits = keep; run->capHits = cap; run->hitsPinned = pin;
+	return align_ranges(hh, Q, r0, r1, n_ranges, mode, batch_uniq, run);
+}
+static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const uint64_t *r1, uint32_t n_ranges, BhMode mode, uint64_t batch_uniq, BhRun *run) {
 	if (!batch_uniq) batch_uniq = 1u << 18;
+	if (batch_uniq > 0x7FFFFFFFu) batch_uniq = 0x7FFFFFFFu;
+	/* batch list */
+	uint64_t nBatches = 0, totU = 0;
+	for (uint32_t i = 0; i < n_ranges; ++i) {
+		const uint64_t b = r1[i] > Q->numUniq ? Q->numUniq : r1[i];
+		if (r0[i] < b) { nBatches += (b - r0[i] + batch_uniq - 1) / batch_uniq; totU += b - r0[i]; }
+	}
+	if (!nBatches) return BH_OK;
+	uint64_t *bu = malloc(nBatches * 2 * sizeof(*bu));
+	if (!bu) return bh_set_error(BH_E_OOM, "OOM:batches");
+	{
+		uint64_t k = 0;
+		for (uint32_t i = 0; i < n_ranges; ++i) {
+			const uint64_t b = r1[i] > Q->numUniq ? Q->numUniq : r1[i];
+			for (uint64_t u = r0[i]; u < b; u += batch_uniq) { bu[2 * k] = u; bu[2 * k + 1] = u + batch_uniq <= b ? batch_uniq : b - u; ++k; }
+		}
+	}
 	const int twoStrand = Q->numEntries > Q->numUniq;
 	const int all_hits = mode == BH_FORAGE;
-	uint64_t capHits = 1u << 20, nHits = 0;
-	BhipHit *hits = malloc(capHits * sizeof(*hits));
-	/* scratch for one batch */
-	const uint64_t maxB = batch_uniq < (u1 - u0) ? batch_uniq : (u1 - u0), maxE = maxB * (twoStrand ? 2 : 1);
-	uint64_t *qoff = malloc((maxE + 1) * sizeof(*qoff));
-	uint16_t *emac = malloc(maxE * sizeof(*emac));
-	uint32_t *six = malloc(maxE * sizeof(*six));
-	uint8_t *rcf = malloc(maxE), *flags = malloc(maxE);
-	uint8_t *codes = NULL; uint64_t capCodes = 0;
-	if (!hits || !qoff || !emac || !six || !rcf || !flags) { free(hits); free(qoff); free(emac); free(six); free(rcf); free(flags); return bh_set_error(BH_E_OOM, "OOM:batch"); }
+	uint64_t capHits = totU * (twoStrand ? 2 : 1) + totU / 2 + (1u << 20), nHits = 0;
+	int pinned = run->hitsPinned;
+	BhipHit *hits = run->hits;
+	if (hits && run->capHits >= capHits) capHits = run->capHits;
+	else { if (hits) hits_free(hits, pinned); hits = hits_alloc(capHits, &pinned); }
+	run->hits = NULL; run->capHits = 0;
+	if (!hits) { free(bu); return bh_set_error(BH_E_OOM, "OOM:hits"); }
+	bhip_set_option(hh, "async_d2h", 1);
 	int rc = BH_OK;
-	for (uint64_t u = u0; u < u1 && rc == BH_OK; u += batch_uniq) {
-		const uint64_t B = (u + batch_uniq <= u1 ? batch_uniq : u1 - u), nE = B * (twoStrand ? 2 : 1);
-		const uint64_t fb = Q->qoff[u], fe = Q->qoff[u + B];
-		const uint64_t rb = twoStrand ? Q->qoff[Q->numUniq + u] : 0, re = twoStrand ? Q->qoff[Q->numUniq + u + B] : 0;
-		const uint64_t nb = (fe - fb) + (re - rb);
-		if (nb + 16 > capCodes) { free(codes); capCodes = nb + nb / 4 + 64; codes = malloc(capCodes); if (!codes) { rc = bh_set_error(BH_E_OOM, "OOM:batch codes"); break; } }
-		memcpy(codes, Q->codes + fb, fe - fb);
-		if (twoStrand) memcpy(codes + (fe - fb), Q->codes + rb, re - rb);
-		for (uint64_t j = 0; j < B; ++j) {
-			const uint64_t e = u + j;
-			qoff[j] = Q->qoff[e] - fb; emac[j] = Q->emac[e]; six[j] = (uint32_t)j; rcf[j] = Q->rc[e]; flags[j] = Q->flags[e];
-			if (twoStrand) {
-				const uint64_t er = Q->numUniq + u + j;
-				qoff[B + j] = (fe - fb) + (Q->qoff[er] - rb); emac[B + j] = Q->emac[er]; six[B + j] = (uint32_t)j; rcf[B + j] = Q->rc[er]; flags[B + j] = Q->flags[er];
-			}
-		}
-		qoff[nE] = nb;
+	#define STAGE(k) do { \
+		const uint64_t u_ = bu[2 * (k)], B_ = bu[2 * (k) + 1]; \
+		BhipQuerySpan sp_[2]; \
+		memset(sp_, 0, sizeof sp_); \
+		sp_[0].codes = Q->codes; sp_[0].off = Q->qoff + u_; sp_[0].emac = Q->emac + u_; sp_[0].rc = Q->rc + u_; sp_[0].flags = Q->flags + u_; sp_[0].n = (uint32_t)B_; sp_[0].q_base = (uint32_t)u_; \
+		if (twoStrand) { const uint64_t e_ = Q->numUniq + u_; \
+			sp_[1].codes = Q->codes; sp_[1].off = Q->qoff + e_; sp_[1].emac = Q->emac + e_; sp_[1].rc = Q->rc + e_; sp_[1].flags = Q->flags + e_; sp_[1].n = (uint32_t)B_; sp_[1].q_base = (uint32_t)e_; } \
+		const double ts_ = now_sec(); \
+		if (bhip_stage_spans(hh, sp_, twoStrand ? 2 : 1, (uint32_t)B_, Q->maxLen)) rc = bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error()); \
+		run->secAlign += now_sec() - ts_; } while (0)
+	STAGE((uint64_t)0);
+	for (uint64_t k = 0; k < nBatches && rc == BH_OK; ++k) {
+		if (k + 1 < nBatches) { STAGE(k + 1); if (rc) break; }
 		for (;;) {
 			uint64_t n = 0;
 			const double t0 = now_sec();
-			int r = bhip_align_batch(hh, codes, qoff, emac, six, rcf, flags, (uint32_t)nE, (uint32_t)B, all_hits,
-			                         hits + nHits, capHits - nHits, &n);
+			int r = bhip_align_staged(hh, all_hits, hits + nHits, capHits - nHits, &n);
 			run->secAlign += now_sec() - t0;
-			if (r == BHIP_E_CAPACITY) {
-				capHits = nHits + n + (nHits + n) / 2 + 1024;
-				BhipHit *nh = realloc(hits, capHits * sizeof(*hits));
+			if (r == BHIP_E_CAPACITY) {          /* grow; the records of the batch stay resident on the device and are delivered by the next call */
+				const uint64_t ncap = nHits + n + (nHits + n) / 2 + 1024;
+				int npin = 0;
+				bhip_sync_hits(hh);
+				BhipHit *nh = hits_alloc(ncap, &npin);
 				if (!nh) { rc = bh_set_error(BH_E_OOM, "OOM:hits"); break; }
-				hits = nh;
+				memcpy(nh, hits, nHits * sizeof(*hits));
+				hits_free(hits, pinned);
+				hits = nh; pinned = npin; capHits = ncap;
 				continue;
 			}
 			if (r == BHIP_E_RESCORE) {   /* the reference's own stop (burst.c:812-816, exit(1)) */
@@ -85,10 +143,6 @@ int bh_align(void *hh, const BhQueries *Q, uint64_t u0, uint64_t u1, BhMode mode
 				rc = bh_set_error(BH_E_USAGE, "libburst_hip: %s", bhip_last_error()); break;
 			}
 			if (r) { rc = bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error()); break; }
-			for (uint64_t k = nHits; k < nHits + n; ++k) {        /* local entry index -> global entry index */
-				const uint32_t lq = hits[k].q;
-				hits[k].q = (uint32_t)(lq < B ? u + lq : Q->numUniq + u + (lq - B));
-			}
 			nHits += n;
 			BhipStats st;
 			if (!bhip_get_stats(hh, &st)) add_stats(&run->total, &st);
@@ -96,8 +150,15 @@ int bh_align(void *hh, const BhQueries *Q, uint64_t u0, uint64_t u1, BhMode mode
 			break;
 		}
 	}
-	free(qoff); free(emac); free(six); free(rcf); free(flags); free(codes);
-	if (rc) { free(hits); return rc; }
-	run->hits = hits; run->nHits = nHits;
+	#undef STAGE
+	free(bu);
+	{ const double t0 = now_sec(); bhip_sync_hits(hh); run->secAlign += now_sec() - t0; }
+	bhip_set_option(hh, "async_d2h", 0);
+	if (rc) { bhip_set_option(hh, "discard_staged", 1); hits_free(hits, pinned); return rc; }
+	run->hits = hits; run->nHits = nHits; run->hitsPinned = pinned; run->capHits = capHits;
 	return BH_OK;
+}
+
+int bh_align(void *hh, const BhQueries *Q, uint64_t u0, uint64_t u1, BhMode mode, uint64_t batch_uniq, BhRun *run) {
+	return bh_align_ranges(hh, Q, &u0, &u1, 1, mode, batch_uniq, run);
 }

@@ -52,6 +52,12 @@ static int sort_qrefs(QRef *a, uint64_t n) {
 
 void bh_queries_free(BhQueries *q) {
 	if (!q) return;
+	if (q->pinned) {
+		bhip_host_unregister(q->codes); bhip_host_unregister(q->qoff);
+		if (q->pinned & 2) bhip_host_unregister(q->emac);
+		if (q->pinned & 4) bhip_host_unregister(q->rc);
+		if (q->pinned & 8) bhip_host_unregister(q->flags);
+	}
 	free(q->dump); free(q->heads); free(q->offset); free(q->codes); free(q->qoff); free(q->six); free(q->rc);
 	free(q->flags); free(q->emac); free(q->len); free(q->ed);
 	memset(q, 0, sizeof *q);

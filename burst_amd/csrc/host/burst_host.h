@@ -89,11 +89,15 @@ typedef struct BhQueries {
 	uint16_t *ed;          /* [numUniq] ShrBin.ed (initial budget) */
 	uint32_t maxLen, minLen, maxED;
 	uint64_t nClear, nAmbig, nBad;
+	int pinned;            /* codes / qoff are page-locked (bh_queries_pin) */
 } BhQueries;
 
 int  bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespace, int do_accel, int K, int z,
                      int skip_ambig, BhQueries *q);
 void bh_queries_free(BhQueries *q);
+/* page-lock the arrays the device batches are copied from, so that the copies of batch k+1 run beside the kernels of batch k
+ * (optional; needs a device) */
+int  bh_queries_pin(BhQueries *q);
 
 /* ---- alignment driver: batches of entries through bhip_align_batch ---- */
 typedef struct BhRun {
@@ -101,10 +105,18 @@ typedef struct BhRun {
 	double secAlign;                      /* wall time inside the device calls */
 	BhipStats total;                      /* summed over batches (times in ms) */
 	uint32_t nBatches;
+	int hitsPinned;                       /* hits is page-locked memory of the device library */
+	uint64_t capHits;                     /* records the buffer holds */
 } BhRun;
 /* entry range [e0, e1) of unique queries [u0, u1): forward entries u0..u1-1 and (if numEntries > numUniq) their RC twins
  * are always sent together because they share the running minimum (burst.c:277-280, 4218). */
 int  bh_align(void *hip_handle, const BhQueries *q, uint64_t u0, uint64_t u1, BhMode mode, uint64_t batch_uniq, BhRun *run);
+/* the same over several ranges of unique queries, in the order given (a range is cut into batches of at most batch_uniq);
+ * bh_align is the one-range case */
+int  bh_align_ranges(void *hip_handle, const BhQueries *q, const uint64_t *u0, const uint64_t *u1, uint32_t n_ranges, BhMode mode, uint64_t batch_uniq, BhRun *run);
+/* into a BhRun used before (or zeroed): keeps its page-locked record buffer */
+int  bh_align_ranges_reuse(void *hip_handle, const BhQueries *q, const uint64_t *u0, const uint64_t *u1, uint32_t n_ranges, BhMode mode, uint64_t batch_uniq, BhRun *run);
+int  bh_run_reserve(BhRun *run, uint64_t cap_records);
 void bh_run_free(BhRun *run);
 int  bh_device_open(const BhDb *db, int device, int z, void **hip_handle);
 

@@ -202,6 +202,8 @@ int main(int argc, char **argv) {
 	if ((rc = bh_device_open(&db, device, z, &hh))) { fprintf(stderr, "%s\n", bh_last_error()); return 4; }
 	{ char nm[256]; int ncu = 0; uint64_t hbm = 0; if (!bhip_device_info(hh, nm, sizeof nm, &ncu, &hbm)) printf("Device %d: %s, %d CUs, %.0f GiB\n", device, nm, ncu, hbm / 1073741824.0); }
 	PHASE("device database upload");
+	bh_queries_pin(&Q);
+	PHASE("query arrays page-locked");
 	BhRun run;
 	const double t0 = wall();
 	if ((rc = bh_align(hh, &Q, 0, Q.numUniq, mode, batch, &run))) { fprintf(stderr, "%s\n", bh_last_error()); return rc == BH_E_USAGE ? 1 : 4; }

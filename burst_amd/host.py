@@ -31,11 +31,11 @@ class BhQueries(C.Structure):
                 ("dump", C.c_void_p), ("heads", C.c_void_p), ("offset", u64p), ("codes", u8p), ("qoff", u64p),
                 ("six", u32p), ("rc", u8p), ("flags", u8p), ("emac", u16p), ("len", u32p), ("ed", u16p),
                 ("maxLen", C.c_uint32), ("minLen", C.c_uint32), ("maxED", C.c_uint32),
-                ("nClear", C.c_uint64), ("nAmbig", C.c_uint64), ("nBad", C.c_uint64)]
+                ("nClear", C.c_uint64), ("nAmbig", C.c_uint64), ("nBad", C.c_uint64), ("pinned", C.c_int)]
 
 
 class BhRun(C.Structure):
-    _fields_ = [("hits", C.c_void_p), ("nHits", C.c_uint64), ("secAlign", C.c_double), ("total", capi.BhipStats), ("nBatches", C.c_uint32)]
+    _fields_ = [("hits", C.c_void_p), ("nHits", C.c_uint64), ("secAlign", C.c_double), ("total", capi.BhipStats), ("nBatches", C.c_uint32), ("hitsPinned", C.c_int), ("capHits", C.c_uint64)]
 
 
 class HostError(RuntimeError):
@@ -55,6 +55,7 @@ def lib():
         L.bh_last_error.restype = C.c_char_p
         L.bh_queries_load.argtypes = [C.c_char_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(BhQueries)]
         L.bh_queries_free.argtypes = [C.POINTER(BhQueries)]
+        L.bh_queries_pin.argtypes = [C.POINTER(BhQueries)]
         L.bh_edx_read.argtypes = [C.c_char_p, C.POINTER(BhDb)]
         L.bh_acx_read.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(BhDb)]
         L.bh_db_from_fasta.argtypes = [C.c_char_p, C.c_uint32, C.c_float, C.c_int, C.c_long, C.c_int, C.POINTER(BhDb)]
@@ -65,6 +66,9 @@ def lib():
         L.bh_db_free.argtypes = [C.POINTER(BhDb)]
         L.bh_device_open.argtypes = [C.POINTER(BhDb), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.bh_align.argtypes = [C.c_void_p, C.POINTER(BhQueries), C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(BhRun)]
+        L.bh_align_ranges.argtypes = [C.c_void_p, C.POINTER(BhQueries), u64p, u64p, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(BhRun)]
+        L.bh_align_ranges_reuse.argtypes = L.bh_align_ranges.argtypes
+        L.bh_run_reserve.argtypes = [C.POINTER(BhRun), C.c_uint64]
         L.bh_run_free.argtypes = [C.POINTER(BhRun)]
         L.bh_report_ex.argtypes = [C.c_void_p, C.POINTER(BhDb), C.POINTER(BhQueries), C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         L.bh_synth_refs.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint64]
@@ -177,6 +181,10 @@ class QuerySet:
         q.entry_index = ent
         return q
 
+    def pin(self):
+        """page-lock the arrays the batches are copied from (bh_queries_pin)"""
+        _chk(lib().bh_queries_pin(C.byref(self.c)))
+
     def reads_in(self, u0, u1):
         off = _view(self.c.offset, self.n_uniq + 1, np.uint64)
         return int(off[min(u1, self.n_uniq)] - off[u0])
@@ -190,6 +198,47 @@ class QuerySet:
             self.close()
         except Exception:
             pass
+
+
+class Run:
+    """records and statistics of bh_align / bh_align_ranges (the C batch scheduler: double-buffered staging, asynchronous
+    hand-over of the records)"""
+
+    def __init__(self):
+        self.c = BhRun()
+
+    @property
+    def hits(self):
+        n = int(self.c.nHits)
+        if not n:
+            return np.zeros(0, capi.HIT_DTYPE)
+        buf = (C.c_uint8 * (n * capi.HIT_DTYPE.itemsize)).from_address(self.c.hits)
+        return np.frombuffer(buf, dtype=capi.HIT_DTYPE)
+
+    def stats(self):
+        return self.c.total.as_dict()
+
+    def reserve(self, cap_records):
+        _chk(lib().bh_run_reserve(C.byref(self.c), int(cap_records)))
+
+    def close(self):
+        lib().bh_run_free(C.byref(self.c))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def align_ranges(dev, qs, ranges, mode, batch_uniq=1 << 18, run=None):
+    """bh_align_ranges: ranges = [(u0, u1), ...] of unique queries, aligned in order through the device handle of `dev`;
+    run = a Run used before: its page-locked record buffer is reused (bh_align_ranges_reuse)"""
+    r0 = np.ascontiguousarray([r[0] for r in ranges], np.uint64)
+    r1 = np.ascontiguousarray([r[1] for r in ranges], np.uint64)
+    run = run or Run()
+    _chk(lib().bh_align_ranges_reuse(dev._h, C.byref(qs.c), r0.ctypes.data_as(u64p), r1.ctypes.data_as(u64p), len(ranges), MODES[mode], batch_uniq, C.byref(run.c)))
+    return run
 
 
 libc = C.CDLL(None)

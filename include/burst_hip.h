@@ -110,12 +110,40 @@ int bhip_align_batch(void *handle, const uint8_t *q_codes, const uint64_t *q_off
                      uint32_t n_q, uint32_t n_shared, int all_hits,
                      BhipHit *hits, uint64_t cap, uint64_t *n_hits);
 
-/* The same in two steps, for callers that keep a batch resident in HBM and run it more than once (bench.py times
- * bhip_align_staged only: inputs are already on the device when the timed region starts).
+/* The same in two steps.  bhip_stage_queries is synchronous (the caller's arrays are free again at return) and replaces any
+ * batch that was waiting; bhip_align_staged may then run any number of times on the resident batch.
  * bhip_align_batch(...) == bhip_stage_queries(...) followed by bhip_align_staged(...). */
 int bhip_stage_queries(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
                        const uint32_t *q_six, const uint8_t *q_rc, const uint8_t *q_flags, uint32_t n_q, uint32_t n_shared);
 int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint64_t cap, uint64_t *n_hits);
+
+/* Pipelined staging for a batch scheduler (the replacement of the OpenMP loops burst.c:4050-4078 / 4326-4344 hands batch k+1
+ * to the device while batch k is being aligned).  A batch is given as up to a few SPANS of consecutive entries of the caller's
+ * own arrays (process_queries keeps all forward entries and then all reverse complements, burst.c:3087-3109: a batch of
+ * unique queries [u, u+B) is two spans), so nothing is gathered on the host.  Entry j of EVERY span shares slot j (a forward
+ * entry and its reverse complement: UniBin.six, burst.c:3106) and is reported as BhipHit.q = q_base + j.
+ * The call only ENQUEUES the copies and the device-side routing (length classes, prefilter / exhaustive route, seed plans)
+ * on the library's staging stream and returns; the arrays must stay valid until the batch has been aligned.  Two batches
+ * can be staged at a time; bhip_align_staged always takes the oldest one that has not been aligned yet (and, when none
+ * is waiting, runs the last one again).  Page-locked arrays (bhip_alloc_host / bhip_host_register) make the copies
+ * asynchronous; pageable ones work too.  max_len = an upper bound of the entry lengths (0 = computed from the offsets). */
+typedef struct BhipQuerySpan {
+	const uint8_t  *codes;   /* symbol codes; entry j = codes[off[j] .. off[j+1]) */
+	const uint64_t *off;     /* n + 1 offsets into codes (off[0] need not be 0) */
+	const uint16_t *emac;    /* n budgets */
+	const uint8_t  *rc;      /* n strand flags, or NULL = 0 */
+	const uint8_t  *flags;   /* n BHIP_Q_*, or NULL (all spans or none) */
+	uint32_t n;
+	uint32_t q_base;         /* BhipHit.q of the span's first entry */
+} BhipQuerySpan;
+int bhip_stage_spans(void *handle, const BhipQuerySpan *spans, uint32_t n_spans, uint32_t n_shared, uint32_t max_len);
+
+/* Page-locked host memory (hipHostMalloc / hipHostRegister behind the C ABI, for callers that are plain C): copies from and to
+ * it run asynchronously beside the kernels.  bhip_alloc_host returns NULL when no device is present. */
+void *bhip_alloc_host(uint64_t bytes);
+void  bhip_free_host(void *p);
+int   bhip_host_register(void *p, uint64_t bytes);
+int   bhip_host_unregister(void *p);
 
 /* Kernel-level entry (what one aded_mat16 call returns, burst.c:1078-1094): for explicit (query, clump)
  * pairs, mins[16*p + z] = edit distance of lane z (255 when > budget of the pair's query). */
@@ -156,6 +184,9 @@ int bhip_sync_hits(void *handle);
  * above the query's best bound are swept only if the first sweep leaves room for them (exact: the bound is a lower bound).
  * "async_d2h": 0 (default) / 1 = asynchronous hand-over of the records, see bhip_sync_hits.
  * "rescore_reg": 1 (default) = register-band re-scorer for narrow bands, 0 = LDS band only.
+ * "host_routing": 0 (default) = batches are routed (length classes, seed plans, lists) by a device kernel, 1 = by the host pass
+ * that otherwise only handles batches with query symbols outside the alphabet.  "discard_staged": forget batches that were
+ * staged and not aligned (after an error).
  * None of these changes a result. */
 int bhip_set_option(void *handle, const char *name, long long value);
 
@@ -167,7 +198,7 @@ void bhip_destroy(void *handle);
 const char *bhip_last_error(void);
 /* ABI version of this header */
 int bhip_abi_version(void);
-#define BHIP_ABI_VERSION 1
+#define BHIP_ABI_VERSION 2
 
 #ifdef __cplusplus
 }

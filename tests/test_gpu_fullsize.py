@@ -24,7 +24,7 @@ def test_one_million_reads_properties(tmp_path_factory):
     a = A()
     a.read_len, a.n_base, a.n_variants, a.ref_len, a.variant_rate, a.id, a.K = 100, 3300, 30, 1400, 0.05, 0.97, 12
     work = os.environ.get("BURST_BENCH_DIR", "/tmp/burst_amd_bench")
-    refs, edx, acx, done = bench.build_inputs(work, a, 0, 1)
+    refs, edx, acx, done = bench.build_db(work, a)
     reads = os.path.join(work, "fullsize_reads.fa")
     n_reads = 1000000
     if not os.path.exists(reads):
@@ -97,7 +97,7 @@ def test_reference_binary_parity_at_bench_size():
     a = A()
     a.read_len, a.n_base, a.n_variants, a.ref_len, a.variant_rate, a.id, a.K = 100, 3300, 30, 1400, 0.05, 0.97, 12
     work = os.environ.get("BURST_BENCH_DIR", "/tmp/burst_amd_bench")
-    refs, edx, acx, done = bench.build_inputs(work, a, 0, 1)
+    refs, edx, acx, done = bench.build_db(work, a)
     from burst_amd import host
     if not [f for f in os.listdir(work) if f.startswith("reads_") and f.endswith("_r0.fa")]:
         host.synth_reads(refs, os.path.join(work, "reads_1000000_l100_e0-1-2-3_u0.0_f0_r0.fa"), 1000000, 100, [0, 1, 2, 3], rc=False, iupac=0.0, seed=42)

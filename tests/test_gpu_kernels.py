@@ -369,6 +369,66 @@ print("ok")
         assert "records 5 B" in acc[-1]
 
 
+@pytest.mark.parametrize("junk", [False, True])
+def test_pipelined_spans_equal_one_call_batches(junk):
+    """bhip_stage_spans: a batch = a span of forward entries + a span of their reverse complements, taken straight from the
+    caller's arrays (offsets that do not start at 0), staged asynchronously TWO batches ahead and routed by the device kernel
+    (k_route) -- every batch must give the oracle's records with the caller's query numbers, with device and host routing
+    alike, also when one batch holds symbols of code 0 (the host pass takes over for that batch only)."""
+    from burst_amd import capi
+    seqs = family_db(201, 8, 12, 520)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lens, entries, offs = dbutil.build_acx(seqs, 12)
+    lut = ol.score_lut(1)
+    dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=dbutil.pack_acx_lists(lens, entries, 0), acx_fmt=0, K=12)
+    reads = []
+    for L, n, sd in ((100, 70, 203), (150, 30, 204), (64, 20, 205), (20, 8, 206)):
+        r, _ = synth.make_reads(seqs, n, L, [0, 1, 2, 3], sd, rc_frac=0.5)
+        reads += [np.array(x, np.uint8) for x in r]
+    if junk:
+        for i in (5, 40, 41, 77):
+            reads[i][3 + i % 20] = 0
+    U = len(reads)
+    allq = reads + [synth.revcomp(r) for r in reads]
+    E = [budget(0.96, len(r)) for r in reads] * 2
+    big = capi.Queries(allq, E, list(range(U)) * 2, [0] * U + [1] * U)
+    big.flags = np.zeros(big.n, np.uint8)
+    big.flags[np.array([len(r) < 12 for r in allq])] = capi.BHIP_Q_EXHAUSTIVE
+    cuts = [0, 50, 51, 100, U]
+    def spans_of(u0, u1):
+        out = []
+        for base in (0, U):
+            out.append(dict(codes=big.codes, off=big.off[base + u0:base + u1 + 1], emac=big.emac[base + u0:base + u1], rc=big.rc[base + u0:base + u1],
+                            flags=big.flags[base + u0:base + u1], q_base=base + u0))
+        return out
+    def expected(u0, u1, all_hits):
+        sub = capi.Queries(reads[u0:u1] + allq[U + u0:U + u1], E[u0:u1] * 2, list(range(u1 - u0)) * 2, [0] * (u1 - u0) + [1] * (u1 - u0))
+        exp = oracle_hits(packed, clump_len, tot, sub, lut, all_hits).copy()
+        q = exp["q"].astype(np.int64)
+        exp["q"] = np.where(q < u1 - u0, u0 + q, U + u0 + (q - (u1 - u0))).astype(np.uint32)
+        return exp
+    for host_routing in (0, 1):
+        dev.set_option("host_routing", host_routing)
+        for all_hits in (False, True):
+            dev.stage_spans(spans_of(cuts[0], cuts[1]), cuts[1] - cuts[0], 150)
+            total = 0
+            for k in range(len(cuts) - 1):
+                if k + 2 < len(cuts):
+                    dev.stage_spans(spans_of(cuts[k + 1], cuts[k + 2]), cuts[k + 2] - cuts[k + 1], 0 if k % 2 else 150)      # one ahead
+                got, _ = dev.align_staged(all_hits)
+                exp = expected(cuts[k], cuts[k + 1], all_hits)
+                assert got.tobytes() == exp.tobytes(), (host_routing, all_hits, k)
+                total += len(got)
+            assert total > 100
+    # a third batch cannot be staged before one has been aligned
+    dev.stage_spans(spans_of(0, 10), 10)
+    dev.stage_spans(spans_of(10, 20), 10)
+    with pytest.raises(capi.BurstHipError):
+        dev.stage_spans(spans_of(20, 30), 10)
+    dev.set_option("discard_staged", 1)
+    dev.close()
+
+
 def test_asynchronous_record_handover():
     """option async_d2h: the count is final at return, the bytes after sync_hits(); two alternating host buffers; the
     device-resident copy (bhip_copy_hits_device) refers to the last call"""
