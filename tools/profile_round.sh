@@ -45,5 +45,28 @@ for k in sorted(sa, key=lambda k: -sa[k].get('SQ_WAVE_CYCLES', 0)):
     lines.append('%-50s ' % k + ' '.join('%s=%.4g' % (c, x) for c, x in sorted(v.items())) + '  | active %.0f%% wait_any %.0f%% wait_inst %.0f%%' % (100 * v.get('SQ_ACTIVE_INST_ANY', 0) / wc_, 100 * v.get('SQ_WAIT_ANY', 0) / wc_, 100 * v.get('SQ_WAIT_INST_ANY', 0) / wc_))
 open('%s/%s_pmc.txt' % (O, TAG), 'w').write('\n'.join(lines) + '\n')
 json.dump(traffic, open('%s/%s_traffic.json' % (O, TAG), 'w'), indent=1)
+# per-kernel summary bench.py reads (profiles/pmc_summary.json): HBM bytes per launch and the share of the VALU issue peak
+# (wave-level VALU instructions x 2 cycles on a SIMD32, against 1024 SIMDs x 2.4 GHz over the kernel's average duration)
+avg_ns = {}
+for f in glob.glob('%s/%s_kt/**/*kernel_stats.csv' % (O, TAG), recursive=True):
+    for r in csv.DictReader(open(f)):
+        avg_ns[short(r['Name'])] = float(r['AverageNs'])
+summary = {}
+for k in set(list(fa) + list(sa)):
+    name = k.replace('void ', '').split('<')[0]
+    e = summary.setdefault(name, {"kernel": k})
+    if k in fa:
+        e.update(traffic.get(name, {}))
+    if k in sa:
+        n = max(1, sc.get(k, 1)); insts = sa[k].get('SQ_INSTS_VALU', 0.0) / n; dur = avg_ns.get(k)
+        e["valu_insts_per_launch"] = insts
+        if dur:
+            e["avg_ns"] = dur; e["valu_frac"] = insts * 2.0 / (dur * 1e-9 * 1024 * 2.4e9)
+        wc_ = max(1.0, sa[k].get('SQ_WAVE_CYCLES', 1.0))
+        e["issue_stall_frac"] = sa[k].get('SQ_WAIT_INST_ANY', 0.0) / wc_; e["wait_frac"] = sa[k].get('SQ_WAIT_ANY', 0.0) / wc_
+        v2 = s2.get(k, {})
+        if v2.get('SQ_LDS_IDX_ACTIVE'):
+            e["lds_bank_conflict_frac"] = v2.get('SQ_LDS_BANK_CONFLICT', 0.0) / v2['SQ_LDS_IDX_ACTIVE']
+json.dump(summary, open('%s/%s_pmc_summary.json' % (O, TAG), 'w'), indent=1)
 print('\n'.join(out[:16])); print('\n'.join(lines[:8]))
 PY
