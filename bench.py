@@ -32,6 +32,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the HIP runtime multiplexes all streams of a process onto 4 hardware queues by default; the library needs 4 of its own
+# (chain, prefilter, staging, record hand-over) next to whatever torch uses.  Must be set before the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def log(*a):
@@ -124,7 +127,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=1000000, help="reads per step (whole job, all GPUs together)")
+    ap.add_argument("--reads", type=int, default=2000000, help="reads per step (whole job, all GPUs together)")
     ap.add_argument("--pool", type=int, default=4, help="distinct batches the steps cycle through")
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--db-scale", type=float, default=1.0, help="multiplies --n-base (1 = 990 000 references / 1.39 Gbp, 3 = 4.2 Gbp)")

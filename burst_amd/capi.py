@@ -37,7 +37,7 @@ class BhipStats(C.Structure):
 
 
 class BhipQuerySpan(C.Structure):
-    _fields_ = [("codes", C.c_void_p), ("off", C.c_void_p), ("emac", C.c_void_p), ("rc", C.c_void_p), ("flags", C.c_void_p),
+    _fields_ = [("codes", C.c_void_p), ("codes4", C.c_void_p), ("off", C.c_void_p), ("emac", C.c_void_p), ("rc", C.c_void_p), ("flags", C.c_void_p),
                 ("n", C.c_uint32), ("q_base", C.c_uint32)]
 
 
@@ -215,6 +215,9 @@ class Device:
             keep += [codes, off, emac, rc, fl]
             n = len(off) - 1
             arr[k].codes, arr[k].off, arr[k].emac = codes.ctypes.data, off.ctypes.data, emac.ctypes.data
+            c4 = _arr(sp.get("codes4"), np.uint8)
+            keep.append(c4)
+            arr[k].codes4 = c4.ctypes.data if c4 is not None else None
             arr[k].rc = rc.ctypes.data if rc is not None else None
             arr[k].flags = fl.ctypes.data if fl is not None else None
             arr[k].n, arr[k].q_base = n, int(sp.get("q_base", 0))

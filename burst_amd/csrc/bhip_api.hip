@@ -55,6 +55,7 @@ template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_
 	const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *,
 	unsigned long long, uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t);
 __global__ void k_pack_queries(const uint8_t *, const uint64_t *, uint32_t, uint32_t, uint32_t *);
+__global__ void k_unpack4(const uint8_t *, uint64_t, uint64_t, uint8_t *);
 __global__ void k_span_fill(const uint64_t *, uint32_t, uint32_t, uint64_t, uint32_t, uint64_t *, uint32_t *, uint32_t *);
 __global__ void k_route(const uint64_t *, const uint32_t *, uint32_t, const uint16_t *, const uint32_t *, const uint8_t *, uint32_t, uint32_t, uint32_t, int, int, int,
 	uint32_t *, uint8_t *, uint32_t *, BhipStageInfo *);
@@ -162,7 +163,7 @@ struct Counters {
 // the budgets reduced (qcodes_s ...); k_junk_adjust adds the counts back before the re-scorer, which works on the original
 // queries with the real cost table.  Without such symbols the search view is the batch itself.
 struct StageSlot {
-	DBuf qcodes, qoff, qemac, qsix, qrc, qflags, qmap, off_raw, plan, qpack, key, key_sorted, idx, idx_sorted, sort_tmp, info;
+	DBuf qcodes, qcodes4, qoff, qemac, qsix, qrc, qflags, qmap, off_raw, plan, qpack, key, key_sorted, idx, idx_sorted, sort_tmp, info;
 	DBuf qcodes_s, qoff_s, qemac_s, qpack_s, nx, nx_six;
 	BhipStageInfo *info_pinned = nullptr;
 	hipEvent_t ev_begin = nullptr, ev_done = nullptr;
@@ -177,7 +178,7 @@ struct StageSlot {
 	uint32_t npf[16][7], nex[16][7], maxE[16][7], maxwords[16][7], qlist_off[16][7], maxlen_lane[16], n_entries_lane[16];
 	uint64_t seed_words[16][7];
 	void release_all() {
-		DBuf *b[] = {&qcodes, &qoff, &qemac, &qsix, &qrc, &qflags, &qmap, &off_raw, &plan, &qpack, &key, &key_sorted, &idx, &idx_sorted,
+		DBuf *b[] = {&qcodes, &qcodes4, &qoff, &qemac, &qsix, &qrc, &qflags, &qmap, &off_raw, &plan, &qpack, &key, &key_sorted, &idx, &idx_sorted,
 			&sort_tmp, &info, &qcodes_s, &qoff_s, &qemac_s, &qpack_s, &nx, &nx_six};
 		for (DBuf *x : b) x->release();
 		if (info_pinned) { (void)hipHostFree(info_pinned); info_pinned = nullptr; }
@@ -289,14 +290,12 @@ extern "C" int bhip_abi_version(void) { return BHIP_ABI_VERSION; }
 
 static void lane_destroy(Lane *L) {
 	if (!L) return;
-	if (L->stream) (void)hipStreamSynchronize(L->stream);
 	DBuf *all[] = {&L->peq, &L->peqp, &L->cand, &L->candcnt, &L->wins, &L->raw, &L->wide, &L->scratch, &L->fb_list, &L->gcnt, &L->counters, &L->tasks, &L->tasks2, &L->tasks2k, &L->wins2, &L->ranges, &L->hdr, &L->rs_lists};
 	for (DBuf *b : all) b->release();
 	for (auto &ce : L->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
 	for (auto &e : L->ev_rs) if (e) (void)hipEventDestroy(e);
 	for (auto &ce : L->ev_pf) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
 	for (auto &ce : L->ev_ph) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
-	if (L->stream) (void)hipStreamDestroy(L->stream);
 	if (L->hc_pinned) (void)hipHostFree(L->hc_pinned);
 	delete L;
 }
@@ -304,7 +303,7 @@ static void lane_destroy(Lane *L) {
 static int lane_create(Handle *h, Lane **out) {
 	Lane *L = new Lane();
 	memset(L->ev_cls, 0, sizeof L->ev_cls); memset(L->ev_rs, 0, sizeof L->ev_rs); memset(L->ev_pf, 0, sizeof L->ev_pf); memset(L->ev_ph, 0, sizeof L->ev_ph);
-	if (hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipStreamCreate failed"); }
+	L->stream = h->stream;      // (the kernel-level entry points run a lane on the handle's own stream)
 	for (auto &ce : L->ev_cls) for (auto &e : ce) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
 	for (auto &e : L->ev_rs) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
 	for (auto &ce : L->ev_pf) for (auto &e : ce) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
@@ -340,10 +339,8 @@ extern "C" void bhip_destroy(void *handle) {
 	if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
 	for (DBuf *b : all) b->release();
 	for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
-	if (h->stream) (void)hipStreamDestroy(h->stream);
-	if (h->sweep_stream) (void)hipStreamDestroy(h->sweep_stream);
+	if (h->stream) (void)hipStreamDestroy(h->stream);        // sweep_stream and post_stream are aliases of it
 	if (h->pf_stream) (void)hipStreamDestroy(h->pf_stream);
-	if (h->post_stream) (void)hipStreamDestroy(h->post_stream);
 	if (h->stage_stream) (void)hipStreamDestroy(h->stage_stream);
 	delete h;
 }
@@ -447,10 +444,13 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 	#define INITCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
 		fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); bhip_destroy(h); return BHIP_E_DEVICE; } } while (0)
 	#define INITRC(x) do { int rc_ = (x); if (rc_) { bhip_destroy(h); return rc_; } } while (0)
+	// Four streams in all -- the HIP runtime multiplexes streams onto 4 hardware queues by default (GPU_MAX_HW_QUEUES), and
+	// streams that share a queue serialise (measured: with seven streams the staging kernels of batch k+1 delayed the window
+	// sweep of batch k by 0.25 ms and the hand-over copy sat in front of the next batch: 248 -> 326 M reads/s with more queues).
+	// One chain (profiles, sweeps, re-scoring, sort), the seed/prefilter stream beside it, staging, record hand-over.
 	INITCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-	INITCHK(hipStreamCreateWithFlags(&h->sweep_stream, hipStreamNonBlocking));
+	h->sweep_stream = h->stream; h->post_stream = h->stream;
 	INITCHK(hipStreamCreateWithFlags(&h->pf_stream, hipStreamNonBlocking));
-	INITCHK(hipStreamCreateWithFlags(&h->post_stream, hipStreamNonBlocking));
 	INITCHK(hipStreamCreateWithFlags(&h->stage_stream, hipStreamNonBlocking));
 	for (auto &e : h->ev) INITCHK(hipEventCreate(&e));
 	h->n_clumps = n_clumps; h->tot_refs = tot_refs;
@@ -901,13 +901,14 @@ static int stage_enqueue(Handle *h, StageSlot *S, const BhipQuerySpan *spans, ui
 	if ((rc = slot_init(S))) return rc;
 	hipStream_t st = h->stage_stream;
 	uint64_t n_q64 = 0, nb = 0;
-	bool any_rc = false, any_flags = false, all_flags = true, any_qbase = false;
+	bool any_rc = false, any_flags = false, all_flags = true, any_qbase = false, all_packed = true;
 	for (uint32_t k = 0; k < n_spans; ++k) {
 		const BhipQuerySpan &sp = spans[k];
 		if (!sp.n) continue;
 		if (!sp.codes || !sp.off || !sp.emac) return fail(BHIP_E_ARG, "null query arrays");
 		if (share_by_position && sp.n > n_shared) return fail(BHIP_E_ARG, "span %u has %u entries for %u shared slots", k, sp.n, n_shared);
 		n_q64 += sp.n; nb += sp.off[sp.n] - sp.off[0];
+		all_packed &= sp.codes4 != nullptr;
 		any_rc |= sp.rc != nullptr; any_flags |= sp.flags != nullptr; all_flags &= sp.flags != nullptr; any_qbase |= sp.q_base != 0 || k > 0;
 	}
 	if (n_q64 > 0xFFFFFFF0ull) return fail(BHIP_E_ARG, "too many entries in one batch");
@@ -932,18 +933,28 @@ static int stage_enqueue(Handle *h, StageSlot *S, const BhipQuerySpan *spans, ui
 	if (max_len > BHIP_MAX_QLEN) return fail(BHIP_E_QUERYLEN, "queries of up to %u symbols (max %d)", max_len, BHIP_MAX_QLEN);
 	S->st_maxlen = max_len;
 	const uint32_t qw = (max_len + 7) / 8;
-	if ((rc = S->qcodes.reserve(nb + 16)) || (rc = S->qoff.reserve(((size_t)n_q + 1) * 8)) || (rc = S->qemac.reserve(((size_t)n_q + 1) * 2)) ||
+	if (all_packed && (rc = S->qcodes4.reserve(nb / 2 + 2 * (size_t)n_spans + 64))) return rc;
+	if ((rc = S->qcodes.reserve(nb + 2 * (size_t)n_spans + 64)) || (rc = S->qoff.reserve(((size_t)n_q + 1) * 8)) || (rc = S->qemac.reserve(((size_t)n_q + 1) * 2)) ||
 	    (rc = S->qsix.reserve(((size_t)n_q + 1) * 4)) || (rc = S->qrc.reserve((size_t)n_q + 1)) || (rc = S->qflags.reserve((size_t)n_q + 1)) ||
 	    (rc = S->qmap.reserve(((size_t)n_q + 1) * 4)) || (rc = S->off_raw.reserve(((size_t)n_q + n_spans + 1) * 8)) || (rc = S->plan.reserve((size_t)n_q * 4 + 16)) ||
 	    (rc = S->qpack.reserve((size_t)n_q * qw * 4 + 64)) || (rc = S->key.reserve((size_t)n_q + 16)) || (rc = S->key_sorted.reserve((size_t)n_q + 16)) ||
 	    (rc = S->idx.reserve((size_t)n_q * 4 + 16)) || (rc = S->idx_sorted.reserve((size_t)n_q * 4 + 16))) return rc;
 	HIPCHK(hipEventRecord(S->ev_begin, st));
-	uint32_t ebase = 0; uint64_t pos = 0;
+	uint32_t ebase = 0; uint64_t pos = 0, pos4 = 0;      // pos: symbols of the batch so far; pos4: nibbles of the packed staging area
 	for (uint32_t k = 0; k < n_spans; ++k) {
 		const BhipQuerySpan &sp = spans[k];
 		if (!sp.n) continue;
 		const uint64_t bytes = sp.off[sp.n] - sp.off[0];
-		if (bytes) HIPCHK(hipMemcpyAsync(S->qcodes.as<uint8_t>() + pos, sp.codes + sp.off[0], bytes, hipMemcpyHostToDevice, st));
+		if (all_packed) {      // in the staging area the span starts on a byte of its own, at the nibble parity it has in the caller's array
+			pos4 = ((pos4 + 1) & ~1ull) + (sp.off[0] & 1ull);
+			if (bytes) {
+				HIPCHK(hipMemcpyAsync(S->qcodes4.as<uint8_t>() + (pos4 >> 1), sp.codes4 + (sp.off[0] >> 1), ((sp.off[sp.n] + 1) >> 1) - (sp.off[0] >> 1), hipMemcpyHostToDevice, st));
+				hipLaunchKernelGGL(k_unpack4, dim3((uint32_t)std::min<uint64_t>((bytes / 4 + 256) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, st, S->qcodes4.as<uint8_t>(), pos4, bytes,
+					S->qcodes.as<uint8_t>() + pos);
+				HIPCHK(hipGetLastError());
+			}
+			pos4 += bytes;
+		} else if (bytes) HIPCHK(hipMemcpyAsync(S->qcodes.as<uint8_t>() + pos, sp.codes + sp.off[0], bytes, hipMemcpyHostToDevice, st));
 		uint64_t *raw = S->off_raw.as<uint64_t>() + ebase + k;
 		HIPCHK(hipMemcpyAsync(raw, sp.off, ((size_t)sp.n + 1) * 8, hipMemcpyHostToDevice, st));
 		HIPCHK(hipMemcpyAsync(S->qemac.as<uint16_t>() + ebase, sp.emac, (size_t)sp.n * 2, hipMemcpyHostToDevice, st));
@@ -1429,7 +1440,9 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		for (uint32_t l = 0; l < nl; ++l) if (h->lanes[l]->n_entries) h->lanes[l]->hc = *h->lanes[l]->hc_pinned;
 		for (uint32_t l = 0; l < nl; ++l) {      // a lane whose records mostly survive the counting filter does better with the exact table
 			Lane *L = h->lanes[l];
-			if (L->n_entries && L->pf_algo == 0 && L->hc.ent_read > 100000 && (double)L->hc.surv_sum > 0.20 * (double)L->hc.ent_read) L->pf_algo = 1;
+			// (with the minimum-only semantics the counting-filter kernel also splits off the lanes that cannot hold a minimum --
+			// the second sweep -- which the exact-table kernel does not: it only takes over when most records survive)
+			if (L->n_entries && L->pf_algo == 0 && L->hc.ent_read > 100000 && (double)L->hc.surv_sum > (all_hits ? 0.20 : 0.50) * (double)L->hc.ent_read) L->pf_algo = 1;
 		}
 		if (getenv("BHIP_DEBUG")) for (uint32_t l = 0; l < nl; ++l) {
 			const Lane *L = h->lanes[l];

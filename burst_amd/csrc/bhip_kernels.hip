@@ -1817,6 +1817,33 @@ __global__ void k_span_fill(const uint64_t *__restrict__ off_raw, uint32_t n, ui
 	}
 }
 
+// symbols uploaded two per byte -> one per byte (the kernels that walk single symbols read bytes): n_sym symbols starting at
+// nibble src0 of `packed` go to dst[0 .. n_sym).  One thread per aligned output dword: its four nibbles sit in two aligned
+// input dwords (funnel shift), whatever the alignment of either side.
+__global__ void k_unpack4(const uint8_t *__restrict__ packed, uint64_t src0, uint64_t n_sym, uint8_t *__restrict__ dst) {
+	const uint32_t head = (uint32_t)((uintptr_t)dst & 3u);
+	uint8_t *base = dst - head;
+	const uint32_t phead = (uint32_t)((uintptr_t)packed & 3u);
+	const uint32_t *pw = (const uint32_t *)(packed - phead);
+	const uint64_t n_words = (head + n_sym + 3) >> 2;
+	for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < n_words; t += (uint64_t)gridDim.x * blockDim.x) {
+		const long long i0 = (long long)(4 * t) - (long long)head;            // symbol index of byte 0 of this output dword
+		const long long sn = (long long)src0 + i0 + 8ll * phead;              // its nibble, counted from pw
+		uint32_t nib = 0;
+		if (sn >= 0) {
+			const uint64_t w = (uint64_t)sn >> 3;
+			const unsigned long long two = (unsigned long long)pw[w] | (unsigned long long)pw[w + 1] << 32;
+			nib = (uint32_t)(two >> (4u * (uint32_t)(sn & 7))) & 0xFFFFu;
+		} else {      // only the first dword of a span can start before the data
+			const unsigned long long two = (unsigned long long)pw[0] | (unsigned long long)pw[1] << 32;
+			nib = (uint32_t)(two << (4u * (uint32_t)(-sn))) & 0xFFFFu;
+		}
+		const uint32_t v = (nib & 15u) | (nib & 0xF0u) << 4 | (nib & 0xF00u) << 8 | (nib & 0xF000u) << 12;
+		if (i0 >= 0 && (uint64_t)i0 + 4 <= n_sym) ((uint32_t *)base)[t] = v;
+		else for (uint32_t b2 = 0; b2 < 4; ++b2) { const long long idx = i0 + b2; if (idx >= 0 && (uint64_t)idx < n_sym) base[4 * t + b2] = (uint8_t)(v >> (8 * b2)); }
+	}
+}
+
 // seed plan of one entry: same choice as make_seed_plan (bhip_api.hip); vb = bit p set iff the word at p holds only A/C/G/T
 __device__ uint32_t bhip_seed_plan(uint32_t len, uint32_t E, uint32_t K, int stride_opt, bool clean, const uint32_t *vb) {
 	if (len < K) return 1u;

@@ -45,8 +45,9 @@ void bh_run_free(BhRun *run) { if (run) { if (run->hits) hits_free(run->hits, ru
 /* page-lock the arrays the batches are copied from (optional: pageable arrays work, the copies then keep the host thread busy) */
 int bh_queries_pin(BhQueries *Q) {
 	if (Q->pinned || !Q->numEntries) return BH_OK;
-	if (bhip_host_register(Q->codes, Q->qoff[Q->numEntries] + 16)) return BH_OK;          /* no device / no room: stay pageable */
-	if (bhip_host_register(Q->qoff, (Q->numEntries + 1) * sizeof(*Q->qoff))) { bhip_host_unregister(Q->codes); return BH_OK; }
+	void *cp = Q->codes4 ? (void *)Q->codes4 : (void *)Q->codes;
+	if (bhip_host_register(cp, Q->codes4 ? (Q->qoff[Q->numEntries] + 1) / 2 + 16 : Q->qoff[Q->numEntries] + 16)) return BH_OK;          /* no device / no room: stay pageable */
+	if (bhip_host_register(Q->qoff, (Q->numEntries + 1) * sizeof(*Q->qoff))) { bhip_host_unregister(cp); return BH_OK; }
 	Q->pinned = 1;
 	if (!bhip_host_register(Q->emac, Q->numEntries * sizeof(*Q->emac))) Q->pinned |= 2;
 	if (!bhip_host_register(Q->rc, Q->numEntries)) Q->pinned |= 4;
@@ -113,9 +114,9 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 		const uint64_t u_ = bu[2 * (k)], B_ = bu[2 * (k) + 1]; \
 		BhipQuerySpan sp_[2]; \
 		memset(sp_, 0, sizeof sp_); \
-		sp_[0].codes = Q->codes; sp_[0].off = Q->qoff + u_; sp_[0].emac = Q->emac + u_; sp_[0].rc = Q->rc + u_; sp_[0].flags = Q->flags + u_; sp_[0].n = (uint32_t)B_; sp_[0].q_base = (uint32_t)u_; \
+		sp_[0].codes = Q->codes; sp_[0].codes4 = Q->codes4; sp_[0].off = Q->qoff + u_; sp_[0].emac = Q->emac + u_; sp_[0].rc = Q->rc + u_; sp_[0].flags = Q->flags + u_; sp_[0].n = (uint32_t)B_; sp_[0].q_base = (uint32_t)u_; \
 		if (twoStrand) { const uint64_t e_ = Q->numUniq + u_; \
-			sp_[1].codes = Q->codes; sp_[1].off = Q->qoff + e_; sp_[1].emac = Q->emac + e_; sp_[1].rc = Q->rc + e_; sp_[1].flags = Q->flags + e_; sp_[1].n = (uint32_t)B_; sp_[1].q_base = (uint32_t)e_; } \
+			sp_[1].codes = Q->codes; sp_[1].codes4 = Q->codes4; sp_[1].off = Q->qoff + e_; sp_[1].emac = Q->emac + e_; sp_[1].rc = Q->rc + e_; sp_[1].flags = Q->flags + e_; sp_[1].n = (uint32_t)B_; sp_[1].q_base = (uint32_t)e_; } \
 		const double ts_ = now_sec(); \
 		if (bhip_stage_spans(hh, sp_, twoStrand ? 2 : 1, (uint32_t)B_, Q->maxLen)) rc = bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error()); \
 		run->secAlign += now_sec() - ts_; } while (0)

@@ -8,7 +8,11 @@
 #include <omp.h>
 #include <sys/stat.h>
 
-static void *own(BhDb *db, void *p) { if (p && db->nOwned < 32) db->owned[db->nOwned++] = p; return p; }
+static void *own(BhDb *db, void *p) {      /* a full table does not lose track of the block: it is given back and the caller sees an allocation failure */
+	if (p && db->nOwned >= 32) { free(p); return NULL; }
+	if (p) db->owned[db->nOwned++] = p;
+	return p;
+}
 
 void bh_db_free(BhDb *db) {
 	if (!db) return;
@@ -30,11 +34,13 @@ int bh_is_edx(const char *path) {
 #define ALLOC(dst, bytes) do { (dst) = own(db, malloc((size_t)(bytes) + 1)); if (!(dst)) { fclose(in); bh_db_free(db); \
 	return bh_set_error(BH_E_OOM, "OOM:read_edb"); } } while (0)
 
-static void derive_refixsrt(BhDb *db) {
+static int derive_refixsrt(BhDb *db) {
 	if (db->refDedupIx) {                                        /* burst.c:3688-3693 */
-		db->refIxSrt = own(db, malloc((size_t)db->totR * sizeof(uint32_t)));
+		db->refIxSrt = own(db, malloc((size_t)db->totR * sizeof(uint32_t) + 4));
+		if (!db->refIxSrt) return bh_set_error(BH_E_OOM, "OOM:RefIxSrt");
 		for (uint32_t i = 0; i < db->totR; ++i) db->refIxSrt[i] = db->tmpRIX[db->refDedupIx[i]];
 	} else db->refIxSrt = db->tmpRIX;
+	return BH_OK;
 }
 
 int bh_edx_read(const char *path, BhDb *db) {
@@ -90,7 +96,14 @@ int bh_edx_read(const char *path, BhDb *db) {
 	db->packedWords = words;
 	(void)hasFP;   /* fingerprint tables, if any, follow and are ignored (-f is out of scope) */
 	fclose(in);
-	derive_refixsrt(db);
+	/* the tables index each other (and the report indexes refHead / refStart through them): refuse anything out of range */
+	if ((uint64_t)db->numRclumps * 16 < db->totR || db->totR > db->origTotR) { bh_db_free(db); return bh_set_error(BH_E_USAGE, "ERROR: corrupt header counts in %s", path); }
+	for (uint32_t i = 0; i < db->origTotR; ++i) if (db->tmpRIX[i] >= db->origTotR) { bh_db_free(db); return bh_set_error(BH_E_USAGE, "ERROR: corrupt TmpRIX in %s", path); }
+	if (db->refDedupIx) {
+		if (db->refDedupIx[db->totR] > db->origTotR) { bh_db_free(db); return bh_set_error(BH_E_USAGE, "ERROR: corrupt RefDedupIx in %s", path); }
+		for (uint32_t i = 0; i < db->totR; ++i) if (db->refDedupIx[i] > db->refDedupIx[i + 1] || db->refDedupIx[i] >= db->origTotR) { bh_db_free(db); return bh_set_error(BH_E_USAGE, "ERROR: corrupt RefDedupIx in %s", path); }
+	}
+	{ int rcx = derive_refixsrt(db); if (rcx) { bh_db_free(db); return rcx; } }
 	return BH_OK;
 }
 #undef RD
@@ -124,6 +137,9 @@ static int read_region(const char *path, uint64_t off, void *dst, uint64_t n) {
 	return bad;
 }
 
+/* K = 12 or 15 (the reference's two builds, burst.c:96-99), or 0 = work it out: the file size must be EXACTLY
+ * 5 + 4 * 4^K + list bytes + 4 * badSz for the K it was written with (a DB15 file read as DB12 would otherwise pass a
+ * "large enough" check and decode part of its length table as list entries). */
 int bh_acx_read(const char *path, int K, int z, BhDb *db) {
 	FILE *in = fopen(path, "rb");
 	if (!in) return bh_set_error(BH_E_USAGE, "Cannot read accelerator '%s'", path);
@@ -132,24 +148,34 @@ int bh_acx_read(const char *path, int K, int z, BhDb *db) {
 	if (cb == EOF || cb < 128 || (ver != 0 && ver != 1)) { fclose(in); return bh_set_error(BH_E_USAGE, "ERROR: invalid accelerator [%d:%d]", cb, ver); }
 	if (didZ && !z) { fclose(in); return bh_set_error(BH_E_USAGE, "ERROR: Accelerator built without '-y'; can't use '-y'"); }
 	uint32_t szBL = 0;
-	const uint64_t nw = 1ull << (2 * K);
-	int bad = fread(&szBL, 4, 1, in) != 1;
-	uint32_t *lens = own(db, malloc(nw * 4));
-	uint32_t *bl = own(db, malloc(((size_t)szBL + 1) * 4));
-	if (!lens || !bl) { fclose(in); return bh_set_error(BH_E_OOM, "OOM:BadList_rd"); }
-	bad |= read_region(path, 5, lens, nw * 4);
-	uint64_t bytes = 0;
-	if (!bad) {
+	struct stat sb;
+	if (fread(&szBL, 4, 1, in) != 1 || stat(path, &sb)) { fclose(in); return bh_set_error(BH_E_USAGE, "ERROR: truncated accelerator %s", path); }
+	const uint64_t fsize = (uint64_t)sb.st_size;
+	const int tryK[2] = {K ? K : 12, K ? 0 : 15};
+	uint32_t *lens = NULL; uint64_t bytes = 0, nw = 0; int foundK = 0;
+	for (int t = 0; t < 2 && !foundK && tryK[t]; ++t) {
+		nw = 1ull << (2 * tryK[t]);
+		if (fsize < 5 + nw * 4 + (uint64_t)szBL * 4) continue;
+		lens = malloc(nw * 4);
+		if (!lens) { fclose(in); return bh_set_error(BH_E_OOM, "OOM:Lens_rd"); }
+		if (read_region(path, 5, lens, nw * 4)) { free(lens); lens = NULL; continue; }
+		bytes = 0;
 		#pragma omp parallel for reduction(+:bytes) schedule(static)
 		for (uint64_t i = 0; i < nw; ++i) bytes += ver == 0 ? (uint64_t)(lens[i] / 2u) * 5 + (lens[i] & 1) * 3 : (uint64_t)lens[i] * 3;
+		if (fsize == 5 + nw * 4 + bytes + (uint64_t)szBL * 4) foundK = tryK[t];
+		else { free(lens); lens = NULL; }
 	}
+	if (!foundK) {
+		fclose(in);
+		if (K) return bh_set_error(BH_E_USAGE, "ERROR: accelerator %s does not have the size of a K=%d accelerator (truncated, or built with the other K?)", path, K);
+		return bh_set_error(BH_E_USAGE, "ERROR: accelerator %s is neither a complete K=12 nor a complete K=15 accelerator", path);
+	}
+	K = foundK;
+	own(db, lens);
+	uint32_t *bl = own(db, malloc(((size_t)szBL + 1) * 4));
 	uint8_t *lists = own(db, malloc(bytes + 16));
-	if (!lists) { fclose(in); return bh_set_error(BH_E_OOM, "OOM:WordDump_rd"); }
-	if (!bad) {
-		struct stat sb;
-		if (stat(path, &sb) || (uint64_t)sb.st_size < 5 + nw * 4 + bytes + (uint64_t)szBL * 4) bad = 1;
-	}
-	if (!bad) bad |= read_region(path, 5 + nw * 4, lists, bytes);
+	if (!bl || !lists) { fclose(in); return bh_set_error(BH_E_OOM, "OOM:WordDump_rd"); }
+	int bad = read_region(path, 5 + nw * 4, lists, bytes);
 	if (!bad) bad |= fseeko(in, (off_t)(5 + nw * 4 + bytes), SEEK_SET) != 0 || fread(bl, 4, szBL, in) != szBL;
 	fclose(in);
 	if (bad) return bh_set_error(BH_E_USAGE, "ERROR: truncated accelerator %s (was it built with K=%d?)", path, K);

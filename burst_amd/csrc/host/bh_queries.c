@@ -53,12 +53,12 @@ static int sort_qrefs(QRef *a, uint64_t n) {
 void bh_queries_free(BhQueries *q) {
 	if (!q) return;
 	if (q->pinned) {
-		bhip_host_unregister(q->codes); bhip_host_unregister(q->qoff);
+		bhip_host_unregister(q->codes4 ? q->codes4 : q->codes); bhip_host_unregister(q->qoff);
 		if (q->pinned & 2) bhip_host_unregister(q->emac);
 		if (q->pinned & 4) bhip_host_unregister(q->rc);
 		if (q->pinned & 8) bhip_host_unregister(q->flags);
 	}
-	free(q->dump); free(q->heads); free(q->offset); free(q->codes); free(q->qoff); free(q->six); free(q->rc);
+	free(q->dump); free(q->heads); free(q->offset); free(q->codes); free(q->codes4); free(q->qoff); free(q->six); free(q->rc);
 	free(q->flags); free(q->emac); free(q->len); free(q->ed);
 	memset(q, 0, sizeof *q);
 }
@@ -198,6 +198,15 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 	 * ambiguous symbols; ambiguous = any symbol beyond A/C/G/T.  Clear and ambiguous entries use the device prefilter
 	 * (words with ambiguous symbols simply do not vote there and the guaranteed count shrinks accordingly; the library
 	 * falls back to the exhaustive route by itself when no word is guaranteed); bad ones are exhaustive (burst.c:4320). */
+	{	/* nibble-packed copy: half the bytes over PCIe per batch */
+		const uint64_t tot = Q->qoff[numEntries], nb4 = (tot + 1) / 2;
+		Q->codes4 = malloc(nb4 + 16);
+		if (!Q->codes4) { free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_OOM, "OOM packing queries"); }
+		Q->codes[tot] = 0;
+		#pragma omp parallel for num_threads(bh_ingest_threads()) schedule(static)
+		for (uint64_t b = 0; b < nb4; ++b) Q->codes4[b] = (uint8_t)((Q->codes[2 * b] & 15) | (Q->codes[2 * b + 1] & 15) << 4);
+		memset(Q->codes4 + nb4, 0, 16);
+	}
 	QPH("copy + reverse complement");
 	uint64_t nClear = 0, nAmbig = 0, nBad = 0;
 	#pragma omp parallel for num_threads(bh_ingest_threads()) reduction(+:nClear, nAmbig, nBad) schedule(static)

@@ -80,6 +80,7 @@ typedef struct BhQueries {
 	char **heads;          /* [totQ] headers in sorted-sequence order (QHead after burst.c:3055-3060) */
 	uint64_t *offset;      /* [numUniq+1] Offset: reads of unique query i are heads[offset[i]..offset[i+1]) */
 	uint8_t *codes;        /* concatenated symbol codes of all entries */
+	uint8_t *codes4;       /* the same, two symbols per byte (low nibble first): what the device batches are copied from */
 	uint64_t *qoff;        /* [numEntries+1] */
 	uint32_t *six;         /* [numEntries] shared slot = unique query index */
 	uint8_t *rc;           /* [numEntries] */

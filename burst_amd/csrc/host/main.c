@@ -36,10 +36,11 @@ int main(int argc, char **argv) {
 	float thres = 0.97f;                            /* burst.c:93 */
 	int z = 1, do_rc = 0, incl_ws = 0, makedb = 0, do_shear = 0, do_accel = 0, dedupe = 0, device = 0, K = 0, skip_ambig = 0, threads = 0, rep_flags = 0;
 	long shear_amt = 500, db_qlen = 500;            /* burst.c:94 */
-	uint64_t batch = 1u << 18;
+	uint64_t batch = 1u << 21;      /* unique queries per device batch: the fixed cost of a batch (launches, synchronisation) is about 1 ms of device time */
 	const char *ref_FN = 0, *query_FN = 0, *output_FN = 0, *xcel_FN = 0, *mkacx_FN = 0, *tax_FN = 0;
 	BhTax taxonomy; memset(&taxonomy, 0, sizeof taxonomy);
 	BhTaxOpts txo; memset(&txo, 0, sizeof txo); txo.taxacut = 10;   /* burst.c:92 */
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);      /* HIP runtime: hardware queues for the library's four streams (read when the runtime starts) */
 	printf("This is burst_hip [MI355X device path; BURST v1.0 semantics]\n");
 	if (argc < 2) { usage(); return 1; }
 	for (int i = 1; i < argc; ++i) {
@@ -178,8 +179,8 @@ int main(int argc, char **argv) {
 	}
 	if (do_accel) {
 		if (!usedb) { fputs("ERROR: an accelerator needs an .edx database\n", stderr); return 1; }
-		if (!K) { struct stat sb; K = (!stat(xcel_FN, &sb) && (uint64_t)sb.st_size >= 5 + 4 * (1ull << 30)) ? 15 : 12; }
-		if ((rc = bh_acx_read(xcel_FN, K, z, &db))) DIE(rc);
+		if ((rc = bh_acx_read(xcel_FN, K, z, &db))) DIE(rc);      /* K = 0: 12 or 15, whichever the file's exact size says */
+		K = db.K;
 		printf(" --> [Accel] K=%d, %s format, %u ambiguous clumps\n", K, db.acxFmt ? "LARGE" : "SMALL", db.badSz);
 	}
 	if (tax_FN) {                                                                    /* burst.c:5142-5149 */

@@ -28,7 +28,7 @@ class BhDb(C.Structure):
 
 class BhQueries(C.Structure):
     _fields_ = [("totQ", C.c_uint64), ("numUniq", C.c_uint64), ("numEntries", C.c_uint64),
-                ("dump", C.c_void_p), ("heads", C.c_void_p), ("offset", u64p), ("codes", u8p), ("qoff", u64p),
+                ("dump", C.c_void_p), ("heads", C.c_void_p), ("offset", u64p), ("codes", u8p), ("codes4", u8p), ("qoff", u64p),
                 ("six", u32p), ("rc", u8p), ("flags", u8p), ("emac", u16p), ("len", u32p), ("ed", u16p),
                 ("maxLen", C.c_uint32), ("minLen", C.c_uint32), ("maxED", C.c_uint32),
                 ("nClear", C.c_uint64), ("nAmbig", C.c_uint64), ("nBad", C.c_uint64), ("pinned", C.c_int)]
@@ -95,7 +95,8 @@ class Db:
         self._open = False
 
     @classmethod
-    def read(cls, edx, acx=None, K=12, z=1):
+    def read(cls, edx, acx=None, K=0, z=1):
+        """K = 0: the accelerator's own K (12 or 15, from its exact size)"""
         d = cls()
         _chk(lib().bh_edx_read(edx.encode(), C.byref(d.c)))
         d._open = True

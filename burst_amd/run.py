@@ -1,4 +1,5 @@
-"""Multi-GPU front end: one process per GPU (torchrun), same flags as the burst_hip command line.
+"""Multi-GPU front end: one process per GPU (torchrun), the alignment flags of the burst_hip command line (-r -a -q -o -m -i
+-fr -y -k; the taxonomy flags -b*, -w, -t and direct-FASTA references are burst_hip only).
 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       -m burst_amd.run -r DB.edx -a DB.acx -q reads.fa -o out.b6 -m CAPITALIST -i 0.97 [-fr] [-y]
@@ -27,8 +28,8 @@ def main(argv=None):
     ap.add_argument("-i", "--id", type=float, default=0.97)
     ap.add_argument("-fr", "--forwardreverse", action="store_true")
     ap.add_argument("-y", "--nwildcard", action="store_true")
-    ap.add_argument("-k", type=int, default=12, choices=[12, 15])
-    ap.add_argument("--batch", type=int, default=1 << 18)
+    ap.add_argument("-k", type=int, default=0, choices=[0, 12, 15], help="accelerator word length (0 = from the file's size)")
+    ap.add_argument("--batch", type=int, default=1 << 21)
     ap.add_argument("--shard", default="queries", choices=["queries", "db"],
                     help="queries: database replicated, every rank aligns its range of queries (default); db: every rank holds a "
                          "range of the database's clumps and aligns all queries (for databases larger than one device)")
@@ -42,7 +43,13 @@ def main(argv=None):
     from burst_amd import capi, dist as bdist, host
     z = 0 if args.nwildcard else 1
     db = host.Db.read(args.references, args.accelerator, K=args.k, z=z)
-    qs = host.QuerySet(args.queries, args.id, rc=args.forwardreverse, accel=bool(args.accelerator), K=args.k, z=z)
+    K = int(db.c.K) if args.accelerator else 12
+    qs = host.QuerySet(args.queries, args.id, rc=args.forwardreverse, accel=bool(args.accelerator), K=K, z=z)
+    # the database was sheared for queries up to shear * id long: longer ones would lose alignments across shear boundaries
+    # (burst.c:5152-5156: "DB incompatible with selected queries/identity", exit 1)
+    if db.c.shear and int(np.float32(qs.c.maxLen) / np.float32(args.id)) > db.c.shear:
+        sys.stderr.write("ERROR: DB incompatible with selected queries/identity.\n")
+        return 1
     L = host.lib()
     c0 = 0
     part = db
@@ -50,6 +57,8 @@ def main(argv=None):
         c0, c1 = bdist.clump_shard_range(host._view(db.c.clumpLen, db.c.numRclumps, np.uint32), world, rank)
         part = db.slice(c0, c1) if c1 > c0 else None
     dev = part.open_device(local_rank, z) if part is not None else None
+    if dev is not None:
+        qs.pin()
 
     def align_range(u0, u1):
         run = host.BhRun()

@@ -129,6 +129,8 @@ int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint64_t cap, u
  * asynchronous; pageable ones work too.  max_len = an upper bound of the entry lengths (0 = computed from the offsets). */
 typedef struct BhipQuerySpan {
 	const uint8_t  *codes;   /* symbol codes; entry j = codes[off[j] .. off[j+1]) */
+	const uint8_t  *codes4;  /* optional: the same array packed two symbols per byte (symbol i = (codes4[i >> 1] >> 4 * (i & 1)) & 15, i counted
+	                            from the start of `codes`); when every span has it, this is what crosses PCIe (half the bytes) */
 	const uint64_t *off;     /* n + 1 offsets into codes (off[0] need not be 0) */
 	const uint16_t *emac;    /* n budgets */
 	const uint8_t  *rc;      /* n strand flags, or NULL = 0 */

@@ -51,7 +51,8 @@ def compare(c, got_sorted, no_dupe_sorted=None):
     key = lambda ln: ln.split(b"\t")[0]
     assert sorted(map(key, got_sorted)) == sorted(map(key, exp))
     diff = set(exp) - set(got_sorted)
-    assert len(diff) <= max(2, len(exp) // 40), "too many order-dependent lines: %d" % len(diff)
+    # at most 0.5 % of the lines (2 on the small golden files), and every one of them must be EXPLAINED below
+    assert len(diff) <= max(2, (len(exp) + 199) // 200), "too many order-dependent lines: %d of %d" % (len(diff), len(exp))
     if c["mode"] == "CAPITALIST":
         # a differing line may only differ in the coordinates of an equally voted placement on the same reference
         strip = lambda ln: tuple(f for i, f in enumerate(ln.split(b"\t")) if i not in (8, 9))

@@ -157,3 +157,23 @@ def test_python_launcher_single_process(tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=gl.ROOT, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     assert sorted(open(out, "rb").read().splitlines()) == gl.golden_lines(c)
+
+
+@pytest.mark.parametrize("c", [x for x in gl.cases() if x["db"] != "fasta" and (x["mode"] == "BEST" or (x["mode"] == "ALLPATHS" and x["accel"])) and "-b" not in x["extra"]], ids=lambda c: c["name"])
+def test_reference_host_with_device_binding(c, tmp_path_factory):
+    """INTEGRATION.md made executable: oracle/_ref/burst12_hip is the reference's own burst.c with oracle/burst_hip_binding.inc
+    spliced into do_alignments (built by oracle/make_ref_hip.py in the build container) -- its parser, query pipeline, database
+    readers, consolidation and .b6 writer, with bhip_init / bhip_align_batch in place of the two OpenMP loops.  Its output must
+    be the golden output of the unmodified reference."""
+    exe = os.path.join(gl.ROOT, "oracle", "_ref", "burst12_hip")
+    if not os.path.exists(exe):
+        pytest.skip("patched reference not built (oracle/make_ref_hip.py needs /root/reference)")
+    tmp = str(tmp_path_factory.getbasetemp())
+    ref, q, fr, z, shear = gl.case_args(c)
+    out = os.path.join(tmp, c["name"] + ".refhip.out")
+    cmd = [exe, "-r", ref, "-q", q, "-o", out, "-m", c["mode"], "-i", c["id"], "--noprogress"] + gl.cli_extra(c)
+    if c["accel"]:
+        cmd += ["-a", acx_for(c["db"], z, tmp)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and "records from the device path" in r.stdout, r.stdout[-2000:]
+    assert sorted(open(out, "rb").read().splitlines()) == gl.golden_lines(c)

@@ -81,35 +81,108 @@ def test_one_million_reads_properties(tmp_path_factory):
     dev.close()
 
 
-def test_reference_binary_parity_at_bench_size():
-    """tools/scale_diff.sh: the compiled reference (oracle/_ref/burst12, all host threads, with the accelerator) and the
-    burst_hip command line on 200 000 reads of the bench workload.  BEST must be identical line for line; ALLPATHS may
-    differ only where the reference's DUPE_HUNT kept a different one of two placements in overlapping shears (it keeps
-    the one its threads met first): same number of lines, every reference line is a placement burst_hip computes."""
-    import subprocess
-    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "burst12")):
-        pytest.skip("compiled reference not present")
+def _bench_db(read_len, thres, K=12):
     sys.path.insert(0, ROOT)
     import bench
 
     class A:
         pass
     a = A()
-    a.read_len, a.n_base, a.n_variants, a.ref_len, a.variant_rate, a.id, a.K = 100, 3300, 30, 1400, 0.05, 0.97, 12
+    a.read_len, a.n_base, a.n_variants, a.ref_len, a.variant_rate, a.id, a.K = read_len, 3300, 30, 1400, 0.05, thres, K
     work = os.environ.get("BURST_BENCH_DIR", "/tmp/burst_amd_bench")
     refs, edx, acx, done = bench.build_db(work, a)
-    from burst_amd import host
-    if not [f for f in os.listdir(work) if f.startswith("reads_") and f.endswith("_r0.fa")]:
-        host.synth_reads(refs, os.path.join(work, "reads_1000000_l100_e0-1-2-3_u0.0_f0_r0.fa"), 1000000, 100, [0, 1, 2, 3], rc=False, iupac=0.0, seed=42)
-    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_diff.sh"), "200000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200,
-                       env=dict(os.environ, BURST_BENCH_DIR=work))
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("BEST", "ALLPATHS"))]
-    assert len(lines) == 4, r.stdout[-3000:]
+    return work, refs, edx, acx
+
+
+def _scale_diff(n_reads, env):
+    import subprocess
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_diff.sh"), str(n_reads)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500,
+                       env=dict(os.environ, **env))
+    return [ln for ln in r.stdout.splitlines() if ln.startswith(("BEST", "ALLPATHS", "CAPITALIST", "FORAGE"))], r.stdout
+
+
+def _check_diff_lines(lines, n_reads):
+    """BEST: identical.  The other modes print, where the reference's own thread timing decides (DUPE_HUNT between overlapping
+    shears, burst.c:4563-4570; equally voted references in CAPITALIST, 4763-4776), one of several placements: there the
+    contract is: same number of lines, same queries, at most 0.5 % of the lines differ and every differing reference line is
+    EXPLAINED -- one of the placements burst_hip computes for that query (--no-dupe-hunt prints them all; for CAPITALIST: one
+    of the query's minimum placements)."""
     for ln in lines:
-        if ln.startswith("BEST"):
+        if ln.startswith("BEST") or "IDENTICAL" in ln:
             assert "IDENTICAL" in ln, ln
-        else:
-            assert "IDENTICAL" in ln or "not a placement burst_hip computed: 0;" in ln, ln
-            if "line counts" in ln:
-                a_, b_ = ln.split("line counts")[1].split("[")[0].split("/")
-                assert int(a_) == int(b_), ln
+            continue
+        m = re.search(r"(\d+) of (\d+) lines differ", ln)
+        n_diff, n_lines = int(m.group(1)), int(m.group(2))
+        assert n_diff <= max(2, n_lines // 200), ln
+        assert "queries reported by only one program: 0;" in ln, ln
+        a_, b_ = ln.split("line counts")[1].split("[")[0].split("/")
+        assert int(a_) == int(b_), ln
+        assert "not a placement burst_hip computed: 0;" in ln, ln
+
+
+def test_reference_binary_parity_at_bench_size():
+    """tools/scale_diff.sh: the compiled reference (oracle/_ref/burst12, all host threads, with the accelerator) and the
+    burst_hip command line on 200 000 reads of the configs[1] workload, in all four modes the reference consolidates."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "burst12")):
+        pytest.skip("compiled reference not present")
+    work, refs, edx, acx = _bench_db(100, 0.97)
+    from burst_amd import host
+    reads = os.path.join(work, "reads_1000000_l100_e0-1-2-3_u0.0_f0_r0.fa")
+    if not os.path.exists(reads):
+        host.synth_reads(refs, reads, 1000000, 100, [0, 1, 2, 3], rc=False, iupac=0.0, seed=42)
+    env = dict(BURST_BENCH_DIR=work, SD_EDX=edx, SD_READS=reads)
+    lines, out = _scale_diff(200000, dict(env, SD_MODES="BEST ALLPATHS", SD_IDS="0.97 0.98"))
+    assert len(lines) == 4, out[-3000:]
+    _check_diff_lines(lines, 200000)
+    lines, out = _scale_diff(200000, dict(env, SD_MODES="CAPITALIST FORAGE", SD_IDS="0.97"))
+    assert len(lines) == 2, out[-3000:]
+    _check_diff_lines(lines, 200000)
+
+
+def test_configs2_twelve_million_292bp_reads_allpaths():
+    """BASELINE configs[2] at its defining size: 12 M 292-bp amplicon-like reads vs the GG97-like database, -m ALLPATHS -i 0.97,
+    through the product's batch scheduler (bh_align_ranges: 2 M-read batches, staged one ahead).  Size-independent properties:
+    full sensitivity (every read carries <= 8 edits <= its budget, so every unique query must be reported), every record within
+    budget and at its query's minimum (ALLPATHS), the f32 identity of every record, positions inside the clump, records of a
+    query contiguous and ordered; and the first 100 000 reads are diffed against the compiled reference."""
+    work, refs, edx, acx = _bench_db(292, 0.97)
+    from burst_amd import host
+    n_reads = 12000000
+    reads = os.path.join(work, "cfg2_reads_12m_292.fa")
+    if not os.path.exists(reads + ".done"):
+        host.synth_reads(refs, reads, n_reads, 292, list(range(9)), rc=False, iupac=0.0, seed=77)
+        open(reads + ".done", "w").write("ok")
+    db = host.Db.read(edx, acx)
+    qs = host.QuerySet(reads, 0.97, rc=False, accel=True, K=int(db.c.K))
+    assert qs.n_reads == n_reads
+    dev = db.open_device(0)
+    qs.pin()
+    run = host.align_ranges(dev, qs, [(0, qs.n_uniq)], "ALLPATHS", 1 << 21)
+    h = run.hits
+    assert int(run.c.nBatches) == (qs.n_uniq + (1 << 21) - 1) >> 21
+    q = h["q"].astype(np.int64)
+    emac = host._view(qs.c.emac, qs.n_entries, np.uint16)
+    qoff = host._view(qs.c.qoff, qs.n_entries + 1, np.uint64).astype(np.int64)
+    found = np.zeros(qs.n_uniq, bool)
+    found[q] = True
+    assert found.all(), "%d unique queries without a record" % (~found).sum()
+    assert (h["ed"] <= emac[q]).all()
+    best = np.full(qs.n_uniq, 255, np.int64)
+    np.minimum.at(best, q, h["ed"])
+    assert (h["ed"] == best[q]).all()                        # ALLPATHS: only the minimum of the query survives
+    ln = (qoff[q + 1] - qoff[q]).astype(np.float32)
+    want = (np.float32(1.0) - h["ed"].astype(np.float32) / (ln + h["gapQ"].astype(np.float32))).astype(np.float32)
+    assert want.tobytes() == h["score"].astype(np.float32).tobytes()
+    clump_len = host._view(db.c.clumpLen, db.c.numRclumps, np.uint32)
+    assert (h["refIx"] < db.c.totR).all()
+    assert (h["finalPos"] >= 1).all() and (h["finalPos"] <= clump_len[h["refIx"] >> 4]).all()
+    key = (q << 32) | h["refIx"].astype(np.int64)
+    assert (np.diff(key) > 0).all()                          # sorted by (query, reference), no duplicates
+    n_rec = len(h)
+    run.close()
+    dev.close()
+    assert n_rec >= qs.n_uniq
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "burst12")):
+        lines, out = _scale_diff(100000, dict(BURST_BENCH_DIR=work, SD_EDX=edx, SD_READS=reads, SD_MODES="BEST ALLPATHS", SD_IDS="0.97"))
+        assert len(lines) == 2, out[-3000:]
+        _check_diff_lines(lines, 100000)

@@ -395,11 +395,16 @@ def test_pipelined_spans_equal_one_call_batches(junk):
     big.flags = np.zeros(big.n, np.uint8)
     big.flags[np.array([len(r) < 12 for r in allq])] = capi.BHIP_Q_EXHAUSTIVE
     cuts = [0, 50, 51, 100, U]
+    padded = np.concatenate([big.codes, np.zeros(2, np.uint8)])
+    codes4 = (padded[0:len(big.codes) + 1:2][:(len(big.codes) + 1) // 2] & 15) | ((padded[1:len(big.codes) + 2:2][:(len(big.codes) + 1) // 2] & 15) << 4)
+    packed_upload = [False]
     def spans_of(u0, u1):
         out = []
         for base in (0, U):
             out.append(dict(codes=big.codes, off=big.off[base + u0:base + u1 + 1], emac=big.emac[base + u0:base + u1], rc=big.rc[base + u0:base + u1],
                             flags=big.flags[base + u0:base + u1], q_base=base + u0))
+            if packed_upload[0]:
+                out[-1]["codes4"] = codes4        # two symbols per byte: what then crosses PCIe
         return out
     def expected(u0, u1, all_hits):
         sub = capi.Queries(reads[u0:u1] + allq[U + u0:U + u1], E[u0:u1] * 2, list(range(u1 - u0)) * 2, [0] * (u1 - u0) + [1] * (u1 - u0))
@@ -410,6 +415,7 @@ def test_pipelined_spans_equal_one_call_batches(junk):
     for host_routing in (0, 1):
         dev.set_option("host_routing", host_routing)
         for all_hits in (False, True):
+            packed_upload[0] = all_hits != bool(host_routing)
             dev.stage_spans(spans_of(cuts[0], cuts[1]), cuts[1] - cuts[0], 150)
             total = 0
             for k in range(len(cuts) - 1):
