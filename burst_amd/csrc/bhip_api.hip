@@ -115,6 +115,11 @@ static int fail(int code, const char *fmt, ...) {
 	va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
 	return code;
 }
+// (for the other translation units of the library)
+int bhip_fail_msg(int code, const char *fmt, ...) {
+	va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+	return code;
+}
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
 	return fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
 
@@ -1228,13 +1233,13 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 // page-locked host memory for the arrays handed to bhip_stage_spans and the result buffers of bhip_align_staged
 extern "C" void *bhip_alloc_host(uint64_t bytes) {
 	void *p = nullptr;
-	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
 	return p;
 }
 extern "C" void bhip_free_host(void *p) { if (p) (void)hipHostFree(p); }
 extern "C" int bhip_host_register(void *p, uint64_t bytes) {
 	if (!p || !bytes) return BHIP_OK;
-	if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return fail(BHIP_E_DEVICE, "hipHostRegister(%llu bytes) failed", (unsigned long long)bytes); }
+	if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return fail(BHIP_E_DEVICE, "hipHostRegister(%llu bytes) failed", (unsigned long long)bytes); }
 	return BHIP_OK;
 }
 extern "C" int bhip_host_unregister(void *p) {

@@ -8,8 +8,61 @@
 #include <stdlib.h>
 #include <string.h>
 #include <omp.h>
+#include <zlib.h>
 
 typedef struct { const uint8_t *s; uint32_t len; uint64_t ix; } QRef;
+
+/* Whole query file into memory.  gzip files (magic 1f 8b) are inflated; FASTQ (first byte '@': four-line records) is rewritten
+ * in place into the two-line FASTA layout the reference's parser takes (burst.c:636-690; the reference itself reads neither). */
+static int slurp_queries(const char *path, char **out, uint64_t *out_sz) {
+	FILE *f = fopen(path, "rb");
+	if (!f) return bh_set_error(BH_E_IO, "Cannot open FASTA file: %s.", path);
+	unsigned char magic[2] = {0, 0};
+	const size_t got = fread(magic, 1, 2, f);
+	char *dump = NULL; uint64_t sz = 0;
+	if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+		fclose(f);
+		gzFile g = gzopen(path, "rb");
+		if (!g) return bh_set_error(BH_E_IO, "Cannot open FASTA file: %s.", path);
+		gzbuffer(g, 1 << 20);
+		uint64_t cap = 1ull << 26;
+		dump = malloc(cap + 17);
+		if (!dump) { gzclose(g); return bh_set_error(BH_E_OOM, "OOM reading queries"); }
+		for (;;) {
+			if (cap - sz < (1u << 24)) { cap *= 2; char *nd = realloc(dump, cap + 17); if (!nd) { free(dump); gzclose(g); return bh_set_error(BH_E_OOM, "OOM reading queries"); } dump = nd; }
+			const int n = gzread(g, dump + sz, (unsigned)((cap - sz) > (1u << 30) ? (1u << 30) : (cap - sz)));
+			if (n < 0) { free(dump); gzclose(g); return bh_set_error(BH_E_IO, "cannot inflate %s", path); }
+			if (!n) break;
+			sz += (uint64_t)n;
+		}
+		gzclose(g);
+	} else {
+		fseeko(f, 0, SEEK_END);
+		sz = (uint64_t)ftello(f);
+		rewind(f);
+		dump = malloc(sz + 17);
+		if (!dump) { fclose(f); return bh_set_error(BH_E_OOM, "OOM reading queries"); }
+		if (fread(dump, 1, sz, f) != sz) { fclose(f); free(dump); return bh_set_error(BH_E_IO, "short read on %s", path); }
+		fclose(f);
+	}
+	if (sz && dump[0] == '@') {      /* FASTQ: keep lines 1 and 2 of every four, '@' -> '>' */
+		uint64_t r = 0, w = 0, line = 0;
+		while (r < sz) {
+			char *nl = memchr(dump + r, '\n', sz - r);
+			const uint64_t e = nl ? (uint64_t)(nl - dump) + 1 : sz;
+			if ((line & 3) < 2) {
+				if ((line & 3) == 0) { if (dump[r] != '@') { free(dump); return bh_set_error(BH_E_USAGE, "ERROR: Malformatted FASTQ file (record %lu).", (unsigned long)(line / 4 + 1)); } dump[r] = '>'; }
+				memmove(dump + w, dump + r, e - r);
+				w += e - r;
+			}
+			r = e; ++line;
+		}
+		sz = w;
+	}
+	memset(dump + sz, 0, 17);
+	*out = dump; *out_sz = sz;
+	return BH_OK;
+}
 
 /* the ingest loops are short and memory-bound: beyond a few dozen threads the fork/join of a 256-thread host costs more than
  * the loop (measured on 2 x EPYC 9575F: 0.84 s with all 256 threads) */
@@ -70,16 +123,8 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 	const int dbg = getenv("BURST_HOST_DEBUG") != NULL;
 	double t_ = omp_get_wtime();
 	#define QPH(name) do { if (dbg) { const double n_ = omp_get_wtime(); fprintf(stderr, "[bh_queries] %-22s %.3f s\n", name, n_ - t_); t_ = n_; } } while (0)
-	FILE *f = fopen(fasta, "rb");
-	if (!f) return bh_set_error(BH_E_IO, "Cannot open FASTA file: %s.", fasta);
-	fseeko(f, 0, SEEK_END);
-	uint64_t sz = (uint64_t)ftello(f);
-	rewind(f);
-	char *dump = malloc(sz + 17);
-	if (!dump) { fclose(f); return bh_set_error(BH_E_OOM, "OOM reading queries"); }
-	if (fread(dump, 1, sz, f) != sz) { fclose(f); free(dump); return bh_set_error(BH_E_IO, "short read on %s", fasta); }
-	fclose(f);
-	memset(dump + sz, 0, 17);
+	char *dump = NULL; uint64_t sz = 0;
+	{ const int rcs = slurp_queries(fasta, &dump, &sz); if (rcs) return rcs; }
 	Q->dump = dump;
 	QPH("file read");
 	if (!sz || *dump != '>') { bh_queries_free(Q); return bh_set_error(BH_E_USAGE, "ERROR: Malformatted FASTA file."); }

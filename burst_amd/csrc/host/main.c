@@ -14,6 +14,7 @@
 #include <time.h>
 #include <omp.h>
 
+#define BH_MAX_GPUS 16
 static double wall(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 static int code_to_exit(int rc) { return rc == BH_E_USAGE ? 1 : rc == BH_E_IO ? 2 : rc == BH_E_OOM ? 3 : 4; }
 #define DIE(rc) do { fprintf(stderr, "%s\n", bh_last_error()); return code_to_exit(rc); } while (0)
@@ -28,6 +29,7 @@ static void usage(void) {
 	puts("--forwardreverse (-fr), --whitespace (-w), --nwildcard (-y), --mode (-m) BEST|ALLPATHS|CAPITALIST|FORAGE|ANY");
 	puts("--makedb (-d) [name qLen], --id (-i) <decimal>, --threads (-t) <int>, --shear (-s) [len], --noprogress");
 	puts("--taxonomy (-b) <name>, --taxacut (-bc) <num>, --taxa_ncbi (-bn), --taxasuppress (-bs) [STRICT]: taxonomy column (interpolated in CAPITALIST)");
+	puts("--gpus <int> [--devices a,b,...] [--gather rccl|host]: shard the queries over the GPUs of this node (one RCCL gather of the records)");
 	puts("--device <int>, --batch <int>, -k <12|15>, --make-acx <name> (with -r DB.edx: rebuild the accelerator of a database)");
 }
 
@@ -36,6 +38,7 @@ int main(int argc, char **argv) {
 	float thres = 0.97f;                            /* burst.c:93 */
 	int z = 1, do_rc = 0, incl_ws = 0, makedb = 0, do_shear = 0, do_accel = 0, dedupe = 0, device = 0, K = 0, skip_ambig = 0, threads = 0, rep_flags = 0;
 	long shear_amt = 500, db_qlen = 500;            /* burst.c:94 */
+	int n_gpus = 1, n_gpus_given = 0, gather_host = 0, n_dev_list = 0, dev_list[BH_MAX_GPUS];
 	uint64_t batch = 1u << 21;      /* unique queries per device batch: the fixed cost of a batch (launches, synchronisation) is about 1 ms of device time */
 	const char *ref_FN = 0, *query_FN = 0, *output_FN = 0, *xcel_FN = 0, *mkacx_FN = 0, *tax_FN = 0;
 	BhTax taxonomy; memset(&taxonomy, 0, sizeof taxonomy);
@@ -86,6 +89,12 @@ int main(int argc, char **argv) {
 		else if (!strcmp(a, "--no-dupe-hunt")) rep_flags |= BH_REP_NO_DUPE_HUNT;   /* diagnostics: print every (hit, reference) expansion */
 		else if (!strcmp(a, "--make-acx")) { NEEDARG("--make-acx"); mkacx_FN = argv[i]; }
 		else if (!strcmp(a, "--device")) { NEEDARG("--device"); device = atoi(argv[i]); }
+		else if (!strcmp(a, "--gpus")) { NEEDARG("--gpus"); n_gpus = atoi(argv[i]); n_gpus_given = 1; if (n_gpus < 1) { puts("ERROR: --gpus must be >= 1"); return 1; } }
+		else if (!strcmp(a, "--devices")) {      /* explicit device of every rank, e.g. 0,1,2,3 (the same device twice only with --gather host) */
+			NEEDARG("--devices");
+			for (char *t = strtok(argv[i], ","); t && n_dev_list < BH_MAX_GPUS; t = strtok(NULL, ",")) dev_list[n_dev_list++] = atoi(t);
+		}
+		else if (!strcmp(a, "--gather")) { NEEDARG("--gather"); gather_host = !strcmp(argv[i], "host"); if (!gather_host && strcmp(argv[i], "rccl")) { puts("ERROR: --gather rccl|host"); return 1; } }
 		else if (!strcmp(a, "--batch")) { NEEDARG("--batch"); batch = strtoull(argv[i], 0, 10); }
 		else if (!strcmp(a, "-k")) { NEEDARG("-k"); K = atoi(argv[i]); if (K != 12 && K != 15) { puts("ERROR: -k must be 12 or 15"); return 1; } }
 		else if (!strcmp(a, "--help") || !strcmp(a, "-h")) { usage(); return 1; }
@@ -129,6 +138,8 @@ int main(int argc, char **argv) {
 		}
 		else { printf("ERROR: Unrecognized command-line option: %s\n", a); puts("See help by running with just '-h'"); return 1; }
 	}
+	if (n_dev_list && !n_gpus_given) { n_gpus = n_dev_list; n_gpus_given = 1; }
+	if (n_dev_list && n_dev_list != n_gpus) { puts("ERROR: --devices must name one device per --gpus rank"); return 1; }
 	if (mkacx_FN) {   /* (re)build an accelerator for an existing .edx:  burst_hip -r DB.edx --make-acx DB.acx [-k 12|15] [-y] */
 		if (!ref_FN) { puts("ERROR: --make-acx needs -r DB.edx"); return 1; }
 		BhDb db; int rc0;
@@ -199,15 +210,63 @@ int main(int argc, char **argv) {
 	} else if (db.shear && (uint32_t)(Q.maxLen / thres) > db.shear) {                /* burst.c:5152-5156 */
 		fputs("ERROR: DB incompatible with selected queries/identity.\n", stderr); return 1;
 	}
-	void *hh = NULL;
-	if ((rc = bh_device_open(&db, device, z, &hh))) { fprintf(stderr, "%s\n", bh_last_error()); return 4; }
-	{ char nm[256]; int ncu = 0; uint64_t hbm = 0; if (!bhip_device_info(hh, nm, sizeof nm, &ncu, &hbm)) printf("Device %d: %s, %d CUs, %.0f GiB\n", device, nm, ncu, hbm / 1073741824.0); }
+	/* Multi-GPU (--gpus N): one host thread and one device handle per GPU, the database replicated, unique queries [r U / N,
+	 * (r+1) U / N) on rank r (a forward entry and its reverse complement stay together), then ONE gather of the hit records to
+	 * rank 0 over RCCL / xGMI (bhip_comm_gather_hits: ncclAllGather of the counts + grouped ncclSend / ncclRecv), where the
+	 * reference's consolidation (incl. CAPITALIST's global vote) runs.  --gpus 1 takes the same path with one rank. */
+	if (n_gpus > BH_MAX_GPUS) { printf("ERROR: --gpus %d (max %d)\n", n_gpus, BH_MAX_GPUS); return 1; }
+	void *hhs[BH_MAX_GPUS]; BhRun runs[BH_MAX_GPUS]; int rcs[BH_MAX_GPUS]; char errs[BH_MAX_GPUS][512];
+	memset(hhs, 0, sizeof hhs); memset(runs, 0, sizeof runs); memset(rcs, 0, sizeof rcs);
+	void *comm = NULL;
+	const int use_rccl = n_gpus_given && !gather_host;
+	if (!n_dev_list) for (int r = 0; r < n_gpus; ++r) dev_list[r] = n_gpus_given ? r : device;
+	if (use_rccl && bhip_comm_create(n_gpus, dev_list, &comm)) { fprintf(stderr, "libburst_hip: %s\n", bhip_last_error()); return 4; }
+	#pragma omp parallel num_threads(n_gpus)
+	{
+		const int r = omp_get_thread_num();
+		if ((rcs[r] = bh_device_open(&db, dev_list[r], z, &hhs[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
+	}
+	for (int r = 0; r < n_gpus; ++r) if (rcs[r]) { fprintf(stderr, "%s\n", errs[r]); return 4; }
+	void *hh = hhs[0];
+	for (int r = 0; r < n_gpus; ++r) { char nm[256]; int ncu = 0; uint64_t hbm = 0; if (!bhip_device_info(hhs[r], nm, sizeof nm, &ncu, &hbm)) printf("Device %d: %s, %d CUs, %.0f GiB\n", dev_list[r], nm, ncu, hbm / 1073741824.0); }
 	PHASE("device database upload");
 	bh_queries_pin(&Q);
 	PHASE("query arrays page-locked");
-	BhRun run;
+	BhRun run; memset(&run, 0, sizeof run);
 	const double t0 = wall();
-	if ((rc = bh_align(hh, &Q, 0, Q.numUniq, mode, batch, &run))) { fprintf(stderr, "%s\n", bh_last_error()); return rc == BH_E_USAGE ? 1 : 4; }
+	uint64_t cnts[BH_MAX_GPUS]; memset(cnts, 0, sizeof cnts);
+	#pragma omp parallel num_threads(n_gpus)
+	{
+		const int r = omp_get_thread_num();
+		const uint64_t u0 = Q.numUniq * (uint64_t)r / (uint64_t)n_gpus, u1 = Q.numUniq * (uint64_t)(r + 1) / (uint64_t)n_gpus;
+		if ((rcs[r] = bh_align(hhs[r], &Q, u0, u1, mode, batch, &runs[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
+	}
+	for (int r = 0; r < n_gpus; ++r) if (rcs[r]) { fprintf(stderr, "%s\n", errs[r]); return rcs[r] == BH_E_USAGE ? 1 : 4; }
+	if (n_gpus == 1 && !use_rccl) run = runs[0];
+	else {
+		uint64_t tot = 0;
+		for (int r = 0; r < n_gpus; ++r) tot += runs[r].nHits;
+		if (bh_run_reserve(&run, tot + 1)) DIE(BH_E_OOM);
+		if (use_rccl) {
+			#pragma omp parallel num_threads(n_gpus)
+			{
+				const int r = omp_get_thread_num();
+				uint64_t n_total = 0;
+				if ((rcs[r] = bhip_comm_gather_hits(comm, r, runs[r].hits, runs[r].nHits, r ? NULL : run.hits, tot + 1, &n_total, r ? NULL : cnts)))
+					snprintf(errs[r], sizeof errs[r], "libburst_hip: %s", bhip_last_error());
+			}
+			for (int r = 0; r < n_gpus; ++r) if (rcs[r]) { fprintf(stderr, "%s\n", errs[r]); return 4; }
+			printf("RCCL gather: %d rank(s), records per rank:", n_gpus);
+			for (int r = 0; r < n_gpus; ++r) printf(" %lu", (unsigned long)cnts[r]);
+			printf("\n");
+		} else {        /* --gather host: the ranks are threads of one process, their records are already in its memory */
+			uint64_t o = 0;
+			for (int r = 0; r < n_gpus; ++r) { if (runs[r].nHits) memcpy(run.hits + o, runs[r].hits, runs[r].nHits * sizeof(BhipHit)); o += runs[r].nHits; }
+			printf("host gather: %d rank(s)\n", n_gpus);
+		}
+		run.nHits = tot;
+		for (int r = 0; r < n_gpus; ++r) { run.nBatches += runs[r].nBatches; run.total.n_pairs += runs[r].total.n_pairs; bh_run_free(&runs[r]); }
+	}
 	const double t1 = wall();
 	printf("Search complete [%f s, %u batches, %lu candidate (query, clump) pairs, %lu hits]. Consolidating results...\n", t1 - t0, run.nBatches,
 	       (unsigned long)run.total.n_pairs, (unsigned long)run.nHits);
@@ -218,7 +277,10 @@ int main(int argc, char **argv) {
 	fclose(output);
 	printf("Wrote %lu alignments\n", (unsigned long)lines);
 	PHASE("consolidation, output");
-	bhip_destroy(hh); bh_run_free(&run); bh_queries_free(&Q); bh_db_free(&db); bh_tax_free(&taxonomy);
+	if (comm) bhip_comm_destroy(comm);
+	for (int r = 0; r < n_gpus; ++r) bhip_destroy(hhs[r]);
+	(void)hh;
+	bh_run_free(&run); bh_queries_free(&Q); bh_db_free(&db); bh_tax_free(&taxonomy);
 	printf("\nAlignment time: %f seconds\n", wall() - start);
 	return 0;
 }

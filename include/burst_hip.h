@@ -147,6 +147,15 @@ void  bhip_free_host(void *p);
 int   bhip_host_register(void *p, uint64_t bytes);
 int   bhip_host_unregister(void *p);
 
+/* Multi-GPU (no reference counterpart): the unique queries are sharded across the GPUs of a node -- one handle and
+ * one host thread per device, the database replicated -- and the hit records travel to rank 0 in one variable-length gather
+ * over RCCL / xGMI (ncclAllGather of the counts + grouped ncclSend / ncclRecv of the 20-byte records).  bhip_comm_create sets up
+ * the ranks of THIS process (ncclCommInitAll); every rank's thread then calls bhip_comm_gather_hits with its records (host
+ * memory); rank 0 gets all of them in rank order, counts[n_ranks] the per-rank numbers.  BHIP_E_CAPACITY: *n_total needed. */
+int  bhip_comm_create(int n_ranks, const int *devices, void **comm);
+int  bhip_comm_gather_hits(void *comm, int rank, const BhipHit *hits, uint64_t n, BhipHit *out, uint64_t cap, uint64_t *n_total, uint64_t *counts);
+void bhip_comm_destroy(void *comm);
+
 /* Kernel-level entry (what one aded_mat16 call returns, burst.c:1078-1094): for explicit (query, clump)
  * pairs, mins[16*p + z] = edit distance of lane z (255 when > budget of the pair's query). */
 int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,

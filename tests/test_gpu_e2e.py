@@ -177,3 +177,38 @@ def test_reference_host_with_device_binding(c, tmp_path_factory):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0 and "records from the device path" in r.stdout, r.stdout[-2000:]
     assert sorted(open(out, "rb").read().splitlines()) == gl.golden_lines(c)
+
+
+@pytest.mark.parametrize("name,flags,expect", [("dna_q100_best_fr", ["--gpus", "1"], "RCCL gather: 1 rank(s)"),
+                                               ("dna_q100_allpaths_fr", ["--gpus", "1", "--batch", "29"], "RCCL gather: 1 rank(s)"),
+                                               ("dna_q100_allpaths_fr", ["--gpus", "3", "--devices", "0,0,0", "--gather", "host"], "host gather: 3 rank(s)"),
+                                               ("dna_q100_capitalist_noacx_t1_fr", ["--gpus", "2", "--devices", "0,0", "--gather", "host"], "host gather: 2 rank(s)")])
+def test_cli_multi_gpu_paths(name, flags, expect, tmp_path):
+    """burst_hip --gpus N: one host thread + one device handle per rank, the unique queries sharded, the records gathered to
+    rank 0 (ncclAllGather of the counts + grouped ncclSend / ncclRecv in libburst_hip; `--gather host` when the ranks share a
+    device, as they must on a one-GPU box).  --gpus 1 goes through the RCCL code with one rank.  Same .b6 as one device."""
+    c = [x for x in gl.cases() if x["name"] == name][0]
+    ref, q, fr, z, shear = gl.case_args(c)
+    out = str(tmp_path / "o.b6")
+    cmd = [CLI, "-r", ref, "-q", q, "-o", out, "-m", c["mode"], "-i", c["id"]] + gl.cli_extra(c) + flags
+    if c["accel"]:
+        cmd += ["-a", acx_for(c["db"], z, str(tmp_path))]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and expect in r.stdout, r.stdout[-2000:]
+    assert sorted(open(out, "rb").read().splitlines()) == gl.golden_lines(c)
+
+
+def test_cli_reads_fastq_gz(tmp_path):
+    """a gzip-compressed FASTQ file of the golden reads gives the golden lines (the reference, which reads neither, was run on the
+    same reads as two-line FASTA)"""
+    import gzip
+    c = [x for x in gl.cases() if x["name"] == "dna_q100_allpaths_fr"][0]
+    ref, q, fr, z, shear = gl.case_args(c)
+    recs = [r for r in open(q).read().split("\n") if r != ""]
+    fq = str(tmp_path / "q.fastq.gz")
+    with gzip.open(fq, "wt") as g:
+        for h, s in zip(recs[0::2], recs[1::2]):
+            g.write("@%s\n%s\n+\n%s\n" % (h[1:], s, "F" * len(s)))
+    out = str(tmp_path / "o.b6")
+    subprocess.check_call([CLI, "-r", ref, "-a", acx_for("dna", 1, str(tmp_path)), "-q", fq, "-o", out, "-m", "ALLPATHS", "-i", "0.95", "-fr"], stdout=subprocess.DEVNULL)
+    assert sorted(open(out, "rb").read().splitlines()) == gl.golden_lines(c)

@@ -103,3 +103,42 @@ def test_database_builders_differential(tmp_path):
         pytest.skip("compiled reference not present")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "db_diff.py"), "2", str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-4000:]
+
+
+def test_fastq_and_gzip_queries_load_like_fasta(tmp_path):
+    """bh_queries_load reads gzip (magic 1f 8b) and FASTQ ('@' records of four lines) besides the reference's two-line FASTA
+    (burst.c:636-690; the reference itself reads neither): the query tables must come out identical."""
+    import gzip
+    import numpy as np
+    from burst_amd import host
+    src = os.path.join(gl.G, "q100.fa")
+    recs = open(src).read().split("\n")
+    recs = [r for r in recs if r != ""]
+    fq = tmp_path / "q.fastq"
+    with open(fq, "w") as f:
+        for h, s in zip(recs[0::2], recs[1::2]):
+            f.write("@%s\n%s\n+\n%s\n" % (h[1:], s, "I" * len(s)))
+    fagz, fqgz = tmp_path / "q.fa.gz", tmp_path / "q.fastq.gz"
+    with gzip.open(fagz, "wb") as g:
+        g.write(open(src, "rb").read())
+    with gzip.open(fqgz, "wb") as g:
+        g.write(open(fq, "rb").read())
+
+    def tables(path):
+        qs = host.QuerySet(str(path), 0.95, rc=True, accel=True, K=12)
+        c = qs.c
+        off = host._view(c.qoff, qs.n_entries + 1, np.uint64).copy()
+        t = (qs.n_reads, qs.n_uniq, off.tobytes(), host._view(c.codes, int(off[-1]), np.uint8).tobytes(), host._view(c.emac, qs.n_entries, np.uint16).tobytes(),
+             host._view(c.offset, qs.n_uniq + 1, np.uint64).tobytes(), host._view(c.flags, qs.n_entries, np.uint8).tobytes(),
+             host._view(c.codes4, (int(off[-1]) + 1) // 2, np.uint8).tobytes())
+        qs.close()
+        return t
+    base = tables(src)
+    assert base[0] == len(recs) // 2 and base[1] > 0
+    for p in (fq, fagz, fqgz):
+        assert tables(p) == base, p
+    # packed copy: two symbols per byte, low nibble first
+    codes = np.frombuffer(base[3], np.uint8)
+    c4 = np.frombuffer(base[7], np.uint8)
+    pad = np.concatenate([codes, np.zeros(1, np.uint8)])
+    assert np.array_equal(c4, (pad[0:len(c4) * 2:2] & 15) | ((pad[1:len(c4) * 2:2] & 15) << 4))
