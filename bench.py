@@ -236,6 +236,14 @@ def main():
         elapsed = float(tt.item())
     total_reads = sum(reads_per_pool_batch[(args.warmup + k) % P] for k in range(args.steps))
 
+    if rank == 0 and os.environ.get("BHIP_PROF"):      # library built with EXTRA_HIPFLAGS=-DPFM_PROF: wave-cycles per prefilter phase
+        import ctypes
+        lib = capi.lib()
+        if hasattr(lib, "bhip_debug_prof"):
+            arr = (ctypes.c_ulonglong * 8)()
+            lib.bhip_debug_prof(arr, 1)
+            tot = float(sum(arr)) or 1.0
+            log("[bench] prefilter phase share: " + " ".join("%d:%.1f%%" % (i, 100.0 * v / tot) for i, v in enumerate(arr)) + "  total wave-cycles %.3g" % tot)
     if rank == 0:
         st = run.stats()
         nb = max(1, int(run.c.nBatches))

@@ -1,8 +1,25 @@
-# end-to-end timing of the burst_hip command line on the bench workload (database + 1 M reads made by bench.py)
-cd /root/repo
-python bench.py --no-cpu-baseline --steps 1 --warmup 0 > /dev/null 2>&1
-D=/tmp/burst_amd_bench
-R=$(ls $D/reads_1000000_l100_*_r0.fa | head -1)
-E=$(ls $D/db_*_q110_*.edx | head -1); A=${E%.edx}.acx
-for t in 1 2; do time burst_amd/burst_hip -r $E -a $A -q $R -o /tmp/out.b6 -m CAPITALIST -i 0.97 2>&1 | tail -12; done
-wc -l /tmp/out.b6
+# end-to-end timing of the burst_hip command line on the bench workload (database + read pool made by bench.py):
+#   bash tools/cli_time.sh [out file]      -> per-phase wall times printed by the CLI, and its search-phase reads/s
+R=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${1:-$R/gpurun_out/cli_phases.txt}
+D=${BURST_BENCH_DIR:-/tmp/burst_amd_bench}
+python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2>&1
+EDX=$(ls $D/db_*_k15.edx | head -1); ACX=${EDX%.edx}.acx; READS=$(ls $D/reads_8000000_l100_*.fa | head -1)
+{
+  echo "# burst_hip -r $(basename $EDX) -a $(basename $ACX) -q $(basename $READS) -m BEST -i 0.98   (8 M reads, 2 M-read batches)"
+  for i in 1 2; do
+    $R/burst_amd/burst_hip -r $EDX -a $ACX -q $READS -o $D/cli.b6 -m BEST -i 0.98 | grep -E "^ \[|Search complete|Parsed|Alignment time|Wrote"
+    echo
+  done
+  NR=$(grep -c '^>' $READS)
+  echo "reads: $NR"
+} > $OUT 2>&1
+python3 - "$OUT" <<'PY'
+import re, sys
+t = open(sys.argv[1]).read()
+n = int(re.search(r"reads: (\d+)", t).group(1))
+s = [float(x) for x in re.findall(r"\[search \(all batches\)\s+([\d.]+) s\]", t)]
+if s:
+    open(sys.argv[1], "a").write("search phase (second run): %.4f s -> %.1f M reads/s\n" % (s[-1], n / s[-1] / 1e6))
+print(open(sys.argv[1]).read())
+PY
