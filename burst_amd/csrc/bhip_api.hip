@@ -1178,6 +1178,15 @@ static int resolve_slot(Handle *h, StageSlot *S) {
 	return 0;
 }
 
+// Grow-only buffers start at sizes a batch of n entries normally stays within (a couple of lane tasks, windows and records
+// per entry): the capacity check of bhip_align_staged re-runs a batch whose buffers overflowed, which is what a first batch
+// sized for nothing would always do.
+static void lane_capacity_floor(Handle *h, Lane *L, uint64_t n) {
+	L->task_cap = std::max<uint64_t>(L->task_cap, 3 * n + 4096); L->win_cap = std::max<uint64_t>(L->win_cap, 2 * n + 4096);
+	L->raw_cap = std::max<uint64_t>(L->raw_cap, 2 * n + 4096); L->cand_cap = std::max<uint64_t>(L->cand_cap, n / 4 + 4096);
+	h->out_cap = std::max<uint64_t>(h->out_cap, 2 * n + 4096);
+}
+
 // the slot becomes the batch the alignment kernels work on
 static void apply_slot(Handle *h, StageSlot *S) {
 	h->cur = S;
@@ -1188,6 +1197,7 @@ static void apply_slot(Handle *h, StageSlot *S) {
 			L->qlist[c] = S->idx_sorted.as<uint32_t>() + S->qlist_off[l][c];
 		}
 		L->maxlen = S->maxlen_lane[l]; L->n_entries = S->n_entries_lane[l];
+		lane_capacity_floor(h, L, L->n_entries);
 	}
 }
 
@@ -1227,6 +1237,49 @@ extern "C" int bhip_stage_queries(void *handle, const uint8_t *q_codes, const ui
 	if ((rc = resolve_slot(h, S))) return rc;      // synchronous: the caller's arrays are free again at return
 	S->spans.clear(); S->six_explicit = nullptr;
 	S->state = 1;
+	return BHIP_OK;
+}
+
+// Allocate, ahead of the first batch, what batches of up to n_entries entries of up to max_len symbols need (both staging slots,
+// the scratch of the alignment kernels, the record buffers): a batch scheduler calls it once so that no allocation -- each one
+// synchronises the device -- falls into its first batches.
+extern "C" int bhip_reserve(void *handle, uint32_t n_entries, uint32_t max_len) {
+	Handle *h = (Handle *)handle;
+	if (!h) return fail(BHIP_E_ARG, "null handle");
+	if (!n_entries) return BHIP_OK;
+	if (!max_len || max_len > BHIP_MAX_QLEN) max_len = BHIP_MAX_QLEN;
+	HIPCHK(hipSetDevice(h->device));
+	int rc;
+	const size_t n = n_entries, nb = n * max_len, qw = (max_len + 7) / 8;
+	for (StageSlot &S : h->slots) {
+		if ((rc = slot_init(&S))) return rc;
+		if ((rc = S.qcodes4.reserve(nb / 2 + 128)) || (rc = S.qcodes.reserve(nb + 128)) || (rc = S.qoff.reserve((n + 1) * 8)) || (rc = S.qemac.reserve((n + 1) * 2)) ||
+		    (rc = S.qsix.reserve((n + 1) * 4)) || (rc = S.qrc.reserve(n + 1)) || (rc = S.qflags.reserve(n + 1)) || (rc = S.qmap.reserve((n + 1) * 4)) ||
+		    (rc = S.off_raw.reserve((n + 8) * 8)) || (rc = S.plan.reserve(n * 4 + 16)) || (rc = S.qpack.reserve(n * qw * 4 + 64)) || (rc = S.key.reserve(n + 16)) ||
+		    (rc = S.key_sorted.reserve(n + 16)) || (rc = S.idx.reserve(n * 4 + 16)) || (rc = S.idx_sorted.reserve(n * 4 + 16))) return rc;
+		size_t tb = 0;
+		HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, S.key.as<uint8_t>(), S.key_sorted.as<uint8_t>(), S.idx.as<uint32_t>(), S.idx_sorted.as<uint32_t>(), (int)n, 0, 8, h->stage_stream));
+		if ((rc = S.sort_tmp.reserve(tb + 16))) return rc;
+	}
+	if ((rc = ensure_lanes(h, 1))) return rc;
+	Lane *L = h->lanes[0];
+	lane_capacity_floor(h, L, n);
+	const int cls = class_of_len(max_len);
+	if ((rc = L->cand.reserve(L->cand_cap * sizeof(uint2))) || (rc = L->raw.reserve(L->raw_cap * sizeof(BhipRawHit))) || (rc = L->wide.reserve(L->raw_cap * sizeof(uint32_t))) ||
+	    (rc = L->rs_lists.reserve(L->raw_cap * sizeof(uint32_t) * 10)) || (rc = L->scratch.reserve(L->scratch_cap * sizeof(uint32_t))) || (rc = L->wins.reserve(L->win_cap * sizeof(BhipWin))) ||
+	    (rc = L->tasks.reserve(L->task_cap * sizeof(uint2))) || (rc = L->tasks2.reserve(L->task_cap * sizeof(uint2))) || (rc = L->tasks2k.reserve(L->task_cap * sizeof(uint2))) ||
+	    (rc = L->wins2.reserve(L->win_cap * sizeof(BhipWin))) || (rc = L->peq.reserve(n * 16 * kClasses[cls] * 4)) || (rc = L->peqp.reserve(n * 16 * 6 * 4)) ||
+	    (rc = L->fb_list.reserve(n * 4 + 16)) || (rc = L->ranges.reserve(n * 16 * 8 + 16)) || (rc = L->hdr.reserve(n * 8 + 16))) return rc;
+	if ((rc = h->best.reserve((n + 1) * 4)) || (rc = h->out.reserve(h->out_cap * sizeof(BhipHit))) || (rc = h->shared_ctr.reserve(sizeof(SharedCtr))) ||
+	    (rc = h->sort_idx.reserve(h->out_cap * 4)) || (rc = h->sort_keys.reserve((n + 1) * 4)) || (rc = h->sort_keys2.reserve((n + 1) * 4)) ||
+	    (rc = h->out_sorted.reserve(h->out_cap * sizeof(BhipHit))) || (rc = h->out_sorted2.reserve(h->out_cap * sizeof(BhipHit)))) return rc;
+	{
+		size_t tb = 0;
+		HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, h->sort_keys.as<uint32_t>(), h->sort_keys2.as<uint32_t>(), (int)(n + 1), h->stream));
+		if ((rc = h->sort_tmp.reserve(tb))) return rc;
+	}
+	if (!h->copy_stream) { HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&h->ev_sorted, hipEventDisableTiming));
+		for (auto &e : h->ev_copied) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
 	return BHIP_OK;
 }
 

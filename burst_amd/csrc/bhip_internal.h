@@ -70,10 +70,43 @@ __device__ __forceinline__ void bhip_acx_range(const BhipAcxView &a, uint32_t w,
 // record e as (clump, lane mask): two aligned dword loads around the 5 bytes
 __device__ __forceinline__ uint2 bhip_acx_rec(const uint8_t *rec, unsigned long long e) {
 	const uintptr_t addr = (uintptr_t)rec + e * (unsigned long long)BHIP_REC_BYTES;
-	const uint32_t *p = (const uint32_t *)(addr & ~(uintptr_t)3);
+	typedef const uint32_t __attribute__((address_space(1))) *gptr_t;
+	gptr_t p = (gptr_t)(addr & ~(uintptr_t)3);
 	const uint32_t d0 = p[0], d1 = p[1];
 	const unsigned long long v = (((unsigned long long)d1 << 32) | d0) >> (8u * (uint32_t)(addr & 3u));
 	return make_uint2((uint32_t)v & 0xFFFFFFu, (uint32_t)(v >> 24) & 0xFFFFu);
+}
+// the same without a branch around the loads: lanes without a record read `dummy` (any mapped, 8-byte readable address) and get
+// the padding record.  A conditional load is compiled as a divergent branch with its own s_waitcnt vmcnt(0) -- a sequence of
+// them is fully serialised, one memory latency each -- and the compiler turns a select around a load back into that branch
+// unless the loaded words are used on every path: they are folded into `sink`, which the caller stores under a condition
+// that never holds.
+__device__ __forceinline__ uint2 bhip_acx_rec_or_pad(const uint8_t *rec, unsigned long long e, bool valid, const void *dummy, uint32_t &sink) {
+	const uintptr_t addr = valid ? (uintptr_t)rec + e * (unsigned long long)BHIP_REC_BYTES : (uintptr_t)dummy;
+	// (a global-address-space pointer: a flat load also counts as an LDS operation, and every s_waitcnt lgkmcnt(0) in front of
+	// the next ds_bpermute would wait for it)
+	typedef const uint32_t __attribute__((address_space(1))) *gptr_t;
+	gptr_t p = (gptr_t)(addr & ~(uintptr_t)3);
+	const uint32_t d0 = p[0], d1 = p[1];
+	sink ^= d0 + d1;
+	const unsigned long long v = (((unsigned long long)d1 << 32) | d0) >> (8u * (uint32_t)(addr & 3u));
+	// (mask arithmetic instead of a select around the decoding, which the compiler would put -- with its wait -- under a branch)
+	const uint32_t m = valid ? 0xFFFFFFFFu : 0u;
+	return make_uint2(((uint32_t)v & 0xFFFFFFu) | ~m, (uint32_t)(v >> 24) & 0xFFFFu & m);
+}
+// split form for a software pipeline: issue the two loads now (raw words), decode where the record is consumed
+__device__ __forceinline__ uint2 bhip_acx_rec_issue(const uint8_t *rec, unsigned long long e, bool valid, const void *dummy, uint32_t &shift8) {
+	typedef const uint32_t __attribute__((address_space(1))) *gptr_t;
+	const uintptr_t addr = valid ? (uintptr_t)rec + e * (unsigned long long)BHIP_REC_BYTES : (uintptr_t)dummy;
+	gptr_t p = (gptr_t)(addr & ~(uintptr_t)3);
+	shift8 = 8u * (uint32_t)(addr & 3u);
+	return make_uint2(p[0], p[1]);
+}
+__device__ __forceinline__ uint2 bhip_acx_rec_decode(uint2 raw, uint32_t shift8, bool valid, uint32_t &sink) {
+	sink ^= raw.x + raw.y;
+	const unsigned long long v = (((unsigned long long)raw.y << 32) | raw.x) >> shift8;
+	const uint32_t m = valid ? 0xFFFFFFFFu : 0u;
+	return make_uint2(((uint32_t)v & 0xFFFFFFu) | ~m, (uint32_t)(v >> 24) & 0xFFFFu & m);
 }
 __device__ __forceinline__ uint32_t bhip_acx_clump(const uint8_t *rec, unsigned long long e) { return bhip_acx_rec(rec, e).x; }
 #endif

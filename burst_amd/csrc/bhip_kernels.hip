@@ -761,6 +761,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 	if (lane < 4) s_ovf[lane] = 0;
 	__syncthreads();
 	unsigned long long my_ent = 0, my_units = 0, my_cols = 0, my_qlen = 0;
+	uint32_t sink = 0;                      // see bhip_acx_rec_or_pad
 #ifdef PFM_PROF
 	unsigned long long my_t[8] = {0,0,0,0,0,0,0,0}, t_last = wall_clock64();
 #endif
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 				kk += __shfl(ex, kk + 2, 16) <= i ? 2u : 0u;
 				kk += __shfl(ex, kk + 1, 16) <= i ? 1u : 0u;
 				const unsigned long long addr = __shfl(dl, kk, 16) + i;
-				rec[u] = i < T ? bhip_acx_rec(ent, addr) : make_uint2(0xFFFFFFFFu, 0);
+				rec[u] = bhip_acx_rec_or_pad(ent, addr, i < T, hdr, sink);
 			}
 		};
 		auto bump_block = [&](uint2 (&rec)[4]) {
@@ -997,6 +998,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 #endif
 	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
 	if (my_units) { atomicAdd(unit_sum, my_units); atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
+	if (n_list == 0xFFFFFFFFu) fb_list[0] = sink;       // never: keeps the record loads unconditional
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1010,8 +1012,11 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 // table that carries the sixteen 8-bit lane counters directly, and the lanes that reach `need` are emitted.  No
 // false negatives: a record of a clump with count >= need always survives; false survivors only cost work.
 // ------------------------------------------------------------------------------------------------
+#ifndef CF_MINWAVES
+#define CF_MINWAVES 3
+#endif
 template <int CB>
-__global__ __launch_bounds__(64) void k_prefilter_cf(
+__global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
 		const uint8_t *__restrict__ ent,   // 5-byte (clump, lane mask) records
 		const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ clump_len, uint32_t tot_refs,
@@ -1042,6 +1047,7 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 	if (lane < 4) s_ovf[lane] = 0;
 	__syncthreads();
 	unsigned long long my_ent = 0, my_units = 0, my_cols = 0, my_qlen = 0, my_surv = 0;
+	uint32_t sink = 0;                      // see bhip_acx_rec_or_pad
 #ifdef PFM_PROF
 	unsigned long long my_t[8] = {0,0,0,0,0,0,0,0}, t_last = wall_clock64();
 #endif
@@ -1073,17 +1079,108 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 	};
 
 	const uint32_t n_quads = (n_list + 3) >> 2;
-	uint2 hd_n = make_uint2(0, 0), rg_n = make_uint2(0, 0);
-	if (blockIdx.x * 4 + g < n_list) { hd_n = hdr[blockIdx.x * 4 + g]; if (gl < W16) rg_n = ranges[(size_t)(blockIdx.x * 4 + g) * W16 + gl]; }
+	constexpr uint32_t RB = 2;               // blocks of 64 records per query that stay in registers between the two looks
+	auto group_scan = [&](uint32_t n, uint32_t &T, uint32_t &excl) {
+		uint32_t ps = n;
+		#pragma unroll
+		for (uint32_t o = 1; o < 16; o <<= 1) { const uint32_t t = __shfl_up(ps, o, 16); if (gl >= o) ps += t; }
+		T = __shfl(ps, 15, 16);
+		excl = ps - n;
+	};
+	auto wave_blocks = [&](uint32_t T) -> uint32_t {
+		uint32_t m = T, t;
+		t = __shfl_xor(m, 16); m = t > m ? t : m;
+		t = __shfl_xor(m, 32); m = t > m ? t : m;
+		return (m + 63) >> 6;
+	};
+	auto load4 = [&](uint32_t ex, unsigned long long dl, uint32_t T, uint32_t b, uint2 (&rec)[4]) {      // see k_prefilter_mask
+		#pragma unroll
+		for (uint32_t u = 0; u < 4; ++u) {
+			const uint32_t i = (b * 4 + u) * 16 + gl;
+			uint32_t kk = 0;
+			if (W16 > 8) kk += __shfl(ex, 8, 16) <= i ? 8u : 0u;      // (uniform) with 8 words per query the upper half is empty
+			kk += __shfl(ex, kk + 4, 16) <= i ? 4u : 0u;
+			kk += __shfl(ex, kk + 2, 16) <= i ? 2u : 0u;
+			kk += __shfl(ex, kk + 1, 16) <= i ? 1u : 0u;
+			const unsigned long long addr = __shfl(dl, kk, 16) + i;
+			rec[u] = bhip_acx_rec_or_pad(ent, addr, i < T, hdr, sink);
+		}
+	};
+	// Software pipeline over the quads of this block: the header and list ranges (k_seed_ranges made them) are fetched TWO
+	// iterations ahead and the first RB blocks of list records ONE iteration ahead, so that the gather of a quad's records --
+	// short reads at random addresses, 43 % of the wave cycles when it was waited for in place -- runs while the previous
+	// quad is counted.
+	auto fetch_hdr = [&](uint32_t quad, uint2 &hd, uint2 &rg) {
+		hd = make_uint2(0, 0); rg = make_uint2(0, 0);
+		const uint32_t li = quad * 4 + g;
+		if (quad < n_quads && li < n_list) { hd = hdr[li]; if (gl < W16) rg = ranges[(size_t)li * W16 + gl]; }
+	};
+	// issue: the raw words of the first RB blocks of a quad's record stream (nothing here waits for them); sh = byte shift of each
+	auto start_stream = [&](uint32_t quad, const uint2 &rg, uint32_t &T, uint32_t &ex, unsigned long long &dl, uint32_t &nblk, uint2 (&raw)[RB][4], uint32_t (&sh)[RB]) -> uint32_t {
+		const bool lv = quad < n_quads && quad * 4 + g < n_list;
+		const unsigned long long beg = lv ? ((unsigned long long)rg.x | (unsigned long long)(rg.y >> 24) << 32) : 0ull;
+		const uint32_t n0 = lv ? rg.y & 0xFFFFFFu : 0u;
+		group_scan(n0, T, ex);
+		dl = beg - ex;
+		nblk = wave_blocks(T);
+		// which list does stream position i belong to: the search over the group's exclusive prefix sums, all RB * 4 positions of
+		// this lane stage by stage (their cross-lane reads are in flight together: one LDS round trip per stage, not per position)
+		uint32_t kk[RB * 4];
+		#pragma unroll
+		for (uint32_t j = 0; j < RB * 4; ++j) kk[j] = 0;
+		if (W16 > 8) {
+			const uint32_t e8 = __shfl(ex, 8, 16);
+			#pragma unroll
+			for (uint32_t j = 0; j < RB * 4; ++j) kk[j] = e8 <= j * 16 + gl ? 8u : 0u;
+		}
+		#pragma unroll
+		for (uint32_t step = 4; step >= 1; step >>= 1) {
+			uint32_t t[RB * 4];
+			#pragma unroll
+			for (uint32_t j = 0; j < RB * 4; ++j) t[j] = __shfl(ex, kk[j] + step, 16);
+			#pragma unroll
+			for (uint32_t j = 0; j < RB * 4; ++j) kk[j] += t[j] <= j * 16 + gl ? step : 0u;
+		}
+		unsigned long long base[RB * 4];
+		#pragma unroll
+		for (uint32_t j = 0; j < RB * 4; ++j) base[j] = __shfl(dl, kk[j], 16);
+		#pragma unroll
+		for (uint32_t b = 0; b < RB; ++b) {
+			sh[b] = 0;
+			#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u) {
+				const uint32_t i = (b * 4 + u) * 16 + gl;
+				uint32_t s8;
+				raw[b][u] = bhip_acx_rec_issue(ent, base[b * 4 + u] + i, i < T, hdr, s8);
+				sh[b] |= s8 << (5 * u);                  // 0, 8, 16 or 24: five bits each
+			}
+		}
+		return n0;
+	};
+	// consume: raw words -> (clump, mask) records, padding where the stream has ended
+	auto finish_stream = [&](uint32_t T, const uint2 (&raw)[RB][4], const uint32_t (&sh)[RB], uint2 (&r)[RB][4]) {
+		#pragma unroll
+		for (uint32_t b = 0; b < RB; ++b) {
+			#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u) r[b][u] = bhip_acx_rec_decode(raw[b][u], (sh[b] >> (5 * u)) & 31u, (b * 4 + u) * 16 + gl < T, sink);
+		}
+	};
+	uint2 hd_c, rg_c, hd_n, rg_n;
+	fetch_hdr(blockIdx.x, hd_c, rg_c);
+	fetch_hdr(blockIdx.x + gridDim.x, hd_n, rg_n);
+	uint32_t T0, ex0, nblk0; unsigned long long dl0;
+	uint2 rc[RB][4], raw[RB][4];
+	uint32_t shf[RB];
+	uint32_t n0 = start_stream(blockIdx.x, rg_c, T0, ex0, dl0, nblk0, raw, shf);
+	finish_stream(T0, raw, shf, rc);
 	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
 		const uint32_t li = quad * 4 + g;
 		const bool live = li < n_list;
-		const uint2 hd = hd_n, rg = rg_n;
-		{
-			const uint32_t li_n = (quad + gridDim.x) * 4 + g;
-			hd_n = make_uint2(0, 0); rg_n = make_uint2(0, 0);
-			if (quad + gridDim.x < n_quads && li_n < n_list) { hd_n = hdr[li_n]; if (gl < W16) rg_n = ranges[(size_t)li_n * W16 + gl]; }
-		}
+		const uint2 hd = hd_c;
+		uint2 hd_nn, rg_nn;
+		fetch_hdr(quad + 2 * gridDim.x, hd_nn, rg_nn);
+		uint32_t T1, ex1, nblk1; unsigned long long dl1;
+		const uint32_t n1 = start_stream(quad + gridDim.x, rg_n, T1, ex1, dl1, nblk1, raw, shf);
 		const uint32_t need = hd.x & 0xFFFFu, nwords = live ? hd.x >> 16 : 0u, len = hd.y & 0xFFFu;
 		const uint32_t budget = (hd.y >> 12) & 255u, dper = (hd.y >> 20) & 15u ? (hd.y >> 20) & 15u : 1u;
 		const uint32_t thr = need ? need : 1u;
@@ -1094,32 +1191,6 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 			uint2 r = make_uint2(0, 0);
 			if (live && j < nwords) r = ranges[(size_t)li * W16 + j];
 			beg = (unsigned long long)r.x | (unsigned long long)(r.y >> 24) << 32; n = r.y & 0xFFFFFFu;
-		};
-		auto group_scan = [&](uint32_t n, uint32_t &T, uint32_t &excl) {
-			uint32_t ps = n;
-			#pragma unroll
-			for (uint32_t o = 1; o < 16; o <<= 1) { const uint32_t t = __shfl_up(ps, o, 16); if (gl >= o) ps += t; }
-			T = __shfl(ps, 15, 16);
-			excl = ps - n;
-		};
-		auto wave_blocks = [&](uint32_t T) -> uint32_t {
-			uint32_t m = T, t;
-			t = __shfl_xor(m, 16); m = t > m ? t : m;
-			t = __shfl_xor(m, 32); m = t > m ? t : m;
-			return (m + 63) >> 6;
-		};
-		auto load4 = [&](uint32_t ex, unsigned long long dl, uint32_t T, uint32_t b, uint2 (&rec)[4]) {      // see k_prefilter_mask
-			#pragma unroll
-			for (uint32_t u = 0; u < 4; ++u) {
-				const uint32_t i = (b * 4 + u) * 16 + gl;
-				uint32_t kk = 0;
-				if (W16 > 8) kk += __shfl(ex, 8, 16) <= i ? 8u : 0u;      // (uniform) with 8 words per query the upper half is empty
-				kk += __shfl(ex, kk + 4, 16) <= i ? 4u : 0u;
-				kk += __shfl(ex, kk + 2, 16) <= i ? 2u : 0u;
-				kk += __shfl(ex, kk + 1, 16) <= i ? 1u : 0u;
-				const unsigned long long addr = __shfl(dl, kk, 16) + i;
-				rec[u] = i < T ? bhip_acx_rec(ent, addr) : make_uint2(0xFFFFFFFFu, 0);
-			}
 		};
 		auto count4 = [&](const uint2 (&rec)[4]) {     // phase A: approximate counters, no return values
 			#pragma unroll
@@ -1184,21 +1255,12 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 		};
 
 		PFM_T(0);
-		const unsigned long long beg = live ? ((unsigned long long)rg.x | (unsigned long long)(rg.y >> 24) << 32) : 0ull;
-		const uint32_t n0 = live ? rg.y & 0xFFFFFFu : 0u;
 		my_ent += n0;
-		uint32_t T0, ex0;
-		group_scan(n0, T0, ex0);
-		const unsigned long long dl0 = beg - ex0;
-		const uint32_t nblk0 = wave_blocks(T0);
-		uint2 rc[PFM_RB][4];
-		#pragma unroll
-		for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) load4(ex0, dl0, T0, b, rc[b]);
 		PFM_T(6);
 		// ---- phase A over every record of the query
 		#pragma unroll
-		for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) count4(rc[b]);
-		for (uint32_t b = PFM_RB; b < nblk0; ++b) { uint2 rec[4]; load4(ex0, dl0, T0, b, rec); count4(rec); }
+		for (uint32_t b = 0; b < RB; ++b) if (b < nblk0) count4(rc[b]);
+		for (uint32_t b = RB; b < nblk0; ++b) { uint2 rec[4]; load4(ex0, dl0, T0, b, rec); count4(rec); }
 		for (uint32_t base = 16; base < maxw; base += 16) {
 			unsigned long long xb; uint32_t xn, T, ex;
 			word_range(base + gl, xb, xn);
@@ -1211,8 +1273,8 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 		PFM_T(7);
 		// ---- phase B: second look at every record (registers for the first blocks, L2 for the rest)
 		#pragma unroll
-		for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) offer4(rc[b]);
-		for (uint32_t b = PFM_RB; b < nblk0; ++b) { uint2 rec[4]; load4(ex0, dl0, T0, b, rec); offer4(rec); }
+		for (uint32_t b = 0; b < RB; ++b) if (b < nblk0) offer4(rc[b]);
+		for (uint32_t b = RB; b < nblk0; ++b) { uint2 rec[4]; load4(ex0, dl0, T0, b, rec); offer4(rec); }
 		for (uint32_t base = 16; base < maxw; base += 16) {
 			unsigned long long xb; uint32_t xn, T, ex;
 			word_range(base + gl, xb, xn);
@@ -1303,6 +1365,10 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 		if (gl == 0) s_ovf[g] = 0;
 		if (s_nstage[0] >= CF_STAGE / 2 || s_nstage[1] >= CF_STAGE / 2) flush(); else __syncthreads();
 		PFM_T(5);
+		// rotate the pipeline
+		hd_c = hd_n; hd_n = hd_nn; rg_n = rg_nn;
+		T0 = T1; ex0 = ex1; dl0 = dl1; nblk0 = nblk1; n0 = n1;
+		finish_stream(T0, raw, shf, rc);          // the records fetched during this iteration are first looked at here
 	}
 	flush();
 #ifdef PFM_PROF
@@ -1310,6 +1376,7 @@ __global__ __launch_bounds__(64) void k_prefilter_cf(
 #endif
 	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
 	if (surv_sum && my_surv) atomicAdd(surv_sum, my_surv);
+	if (n_list == 0xFFFFFFFFu) fb_list[0] = sink;       // never: keeps the record loads unconditional
 	if (my_units) { atomicAdd(unit_sum, my_units); atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
 }
 #define BHIP_INST_PFCF(CB) \

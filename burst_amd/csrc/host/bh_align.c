@@ -120,9 +120,13 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 		const double ts_ = now_sec(); \
 		if (bhip_stage_spans(hh, sp_, twoStrand ? 2 : 1, (uint32_t)B_, Q->maxLen)) rc = bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error()); \
 		run->secAlign += now_sec() - ts_; } while (0)
+	const int dbg = getenv("BURST_HOST_DEBUG") != NULL;
+	const double tb0 = now_sec();
 	STAGE((uint64_t)0);
 	for (uint64_t k = 0; k < nBatches && rc == BH_OK; ++k) {
+		const double tk0 = now_sec();
 		if (k + 1 < nBatches) { STAGE(k + 1); if (rc) break; }
+		const double tk1 = now_sec();
 		for (;;) {
 			uint64_t n = 0;
 			const double t0 = now_sec();
@@ -148,6 +152,8 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 			BhipStats st;
 			if (!bhip_get_stats(hh, &st)) add_stats(&run->total, &st);
 			++run->nBatches;
+			if (dbg) fprintf(stderr, "[bh_align] batch %lu: %lu entries, staging the next one %.3f ms, align %.3f ms (device %.3f ms), %lu records; %.3f ms since the start\n",
+			                 (unsigned long)k, (unsigned long)bu[2 * k + 1], 1e3 * (tk1 - tk0), 1e3 * (now_sec() - tk1), st.ms_total, (unsigned long)n, 1e3 * (now_sec() - tb0));
 			break;
 		}
 	}

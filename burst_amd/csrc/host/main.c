@@ -232,6 +232,16 @@ int main(int argc, char **argv) {
 	PHASE("device database upload");
 	bh_queries_pin(&Q);
 	PHASE("query arrays page-locked");
+	{	/* device and record buffers for the batches to come (allocations synchronise the device: not inside the search) */
+		const uint64_t perRank = Q.numUniq / (uint64_t)n_gpus + 1, B = perRank < batch ? perRank : batch, strands = Q.numEntries > Q.numUniq ? 2 : 1;
+		#pragma omp parallel num_threads(n_gpus)
+		{
+			const int r = omp_get_thread_num();
+			bhip_reserve(hhs[r], (uint32_t)(B * strands), Q.maxLen);
+			bh_run_reserve(&runs[r], perRank * strands + perRank / 2 + (1u << 20));
+		}
+	}
+	PHASE("batch buffers");
 	BhRun run; memset(&run, 0, sizeof run);
 	const double t0 = wall();
 	uint64_t cnts[BH_MAX_GPUS]; memset(cnts, 0, sizeof cnts);
@@ -239,7 +249,7 @@ int main(int argc, char **argv) {
 	{
 		const int r = omp_get_thread_num();
 		const uint64_t u0 = Q.numUniq * (uint64_t)r / (uint64_t)n_gpus, u1 = Q.numUniq * (uint64_t)(r + 1) / (uint64_t)n_gpus;
-		if ((rcs[r] = bh_align(hhs[r], &Q, u0, u1, mode, batch, &runs[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
+		if ((rcs[r] = bh_align_ranges_reuse(hhs[r], &Q, &u0, &u1, 1, mode, batch, &runs[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
 	}
 	for (int r = 0; r < n_gpus; ++r) if (rcs[r]) { fprintf(stderr, "%s\n", errs[r]); return rcs[r] == BH_E_USAGE ? 1 : 4; }
 	if (n_gpus == 1 && !use_rccl) run = runs[0];

@@ -140,6 +140,10 @@ typedef struct BhipQuerySpan {
 } BhipQuerySpan;
 int bhip_stage_spans(void *handle, const BhipQuerySpan *spans, uint32_t n_spans, uint32_t n_shared, uint32_t max_len);
 
+/* Optional: allocate now what batches of up to n_entries entries of up to max_len symbols will need, so that no allocation
+ * (each one synchronises the device) falls into the first batches. */
+int bhip_reserve(void *handle, uint32_t n_entries, uint32_t max_len);
+
 /* Page-locked host memory (hipHostMalloc / hipHostRegister behind the C ABI, for callers that are plain C): copies from and to
  * it run asynchronously beside the kernels.  bhip_alloc_host returns NULL when no device is present. */
 void *bhip_alloc_host(uint64_t bytes);
