@@ -1280,6 +1280,56 @@ extern "C" int bhip_reserve(void *handle, uint32_t n_entries, uint32_t max_len) 
 	}
 	if (!h->copy_stream) { HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&h->ev_sorted, hipEventDisableTiming));
 		for (auto &e : h->ev_copied) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+	{	// A synthetic batch through the whole path, the way a batch scheduler drives it (page-locked arrays, asynchronous copies
+		// in and out): the first launch of every kernel, the first use of the copy engines from the staging and hand-over
+		// streams and the first touch of the new buffers cost tens of milliseconds that would otherwise land in the caller's
+		// first real batch; an idle device also clocks down, and a few milliseconds of work bring it back up.
+		const uint32_t nw = std::min<uint32_t>(n_entries, 1u << 17), len = std::min<uint32_t>(max_len, 100u);
+		const size_t nb_w = (size_t)nw * len + 16;
+		uint8_t *pin = nullptr;
+		const size_t bytes = nb_w + nb_w / 2 + 16 + ((size_t)nw + 1) * 8 + (size_t)nw * 2 + 64 + (size_t)nw * 4 * sizeof(BhipHit);
+		HIPCHK(hipHostMalloc((void **)&pin, bytes, hipHostMallocPortable));
+		uint8_t *codes = pin, *codes4 = pin + nb_w;
+		uint64_t *off = (uint64_t *)(pin + ((nb_w + nb_w / 2 + 16 + 7) & ~(size_t)7));
+		uint16_t *emac = (uint16_t *)(off + nw + 1);
+		BhipHit *hbuf = (BhipHit *)(((uintptr_t)(emac + nw) + 63) & ~(uintptr_t)63);
+		uint64_t x = 88172645463325252ull;
+		for (size_t i = 0; i < nb_w; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; codes[i] = (uint8_t)(1 + (x & 3)); }
+		for (size_t i = 0; i < nb_w / 2; ++i) codes4[i] = (uint8_t)(codes[2 * i] | codes[2 * i + 1] << 4);
+		for (uint32_t i = 0; i <= nw; ++i) off[i] = (uint64_t)i * len;
+		for (uint32_t i = 0; i < nw; ++i) emac[i] = (uint16_t)(len / 40);
+		BhipQuerySpan sp;
+		memset(&sp, 0, sizeof sp);
+		sp.codes = codes; sp.codes4 = codes4; sp.off = off; sp.emac = emac; sp.n = nw;
+		uint64_t n_out = 0;
+		const int async = h->opt_async_d2h;
+		h->opt_async_d2h = 1;
+		for (StageSlot &S : h->slots) { S.state = 0; S.st_valid = false; }
+		rc = 0;
+		for (int rep = 0; rep < 4 && !rc; ++rep) {
+			rc = bhip_stage_spans(h, &sp, 1, nw, len);
+			if (!rc) rc = bhip_align_staged(h, 0, hbuf, (uint64_t)nw * 4, &n_out);
+		}
+		(void)bhip_sync_hits(h);
+		{	// the first LARGE asynchronous copy in each direction takes another path through the runtime than the small ones above
+			// and blocks its caller for ~19 ms once per process (measured in front of the first 43 MB hand-over copy): make it here
+			const size_t big = std::min<size_t>(64u << 20, h->out_sorted.cap);
+			void *tmp = nullptr;
+			if (big && hipHostMalloc(&tmp, big, hipHostMallocPortable) == hipSuccess) {
+				(void)hipMemcpyAsync(tmp, h->out_sorted.p, big, hipMemcpyDeviceToHost, h->copy_stream);
+				(void)hipStreamSynchronize(h->copy_stream);
+				(void)hipMemcpyAsync(h->out_sorted.p, tmp, big, hipMemcpyHostToDevice, h->stage_stream);
+				(void)hipStreamSynchronize(h->stage_stream);
+				(void)hipHostFree(tmp);
+			}
+			(void)hipGetLastError();
+		}
+		h->opt_async_d2h = async;
+		for (StageSlot &S : h->slots) { S.state = 0; S.st_valid = false; S.spans.clear(); }
+		h->res_valid = false;
+		(void)hipHostFree(pin);
+		if (rc) return rc;
+	}
 	return BHIP_OK;
 }
 
@@ -1287,6 +1337,18 @@ extern "C" int bhip_reserve(void *handle, uint32_t n_entries, uint32_t max_len) 
 extern "C" void *bhip_alloc_host(uint64_t bytes) {
 	void *p = nullptr;
 	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	// The first ASYNCHRONOUS copy into a new page-locked allocation blocks its caller for tens of milliseconds (measured: 19 ms
+	// in front of the first hand-over copy of a run into a 260 MB buffer, 7 us for every later copy into the same allocation;
+	// a synchronous hipMemcpy does not take that path): make that first copy here.
+	void *d = nullptr; hipStream_t st = nullptr;
+	if (hipMalloc(&d, 256) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
+		(void)hipMemcpyAsync(p, d, bytes < 64 ? bytes : 64, hipMemcpyDeviceToHost, st);
+		(void)hipMemcpyAsync(d, p, bytes < 64 ? bytes : 64, hipMemcpyHostToDevice, st);
+		(void)hipStreamSynchronize(st);
+	}
+	(void)hipGetLastError();
+	if (st) (void)hipStreamDestroy(st);
+	if (d) (void)hipFree(d);
 	return p;
 }
 extern "C" void bhip_free_host(void *p) { if (p) (void)hipHostFree(p); }
@@ -1581,6 +1643,10 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		BhipStats &S = h->stats;
 		if (hits && hsc.n_out > cap) return fail(BHIP_E_CAPACITY, "hit buffer holds %llu records, %u needed", (unsigned long long)cap, hsc.n_out);
 		HIPCHK(hipEventRecord(h->ev[8], h->stream));
+		const bool dbg_t = getenv("BHIP_DEBUG_TIMES") != nullptr;
+		const auto tq0 = std::chrono::steady_clock::now();
+		auto tq = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count(); };
+		double tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0;
 		if (hsc.n_out) {
 			const uint32_t n = hsc.n_out;
 			if ((rc = h->sort_idx.reserve((size_t)n * 4)) || (rc = h->sort_keys.reserve((size_t)(n_q + 1) * 4)) || (rc = h->sort_keys2.reserve((size_t)(n_q + 1) * 4)) ||
@@ -1593,6 +1659,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			uint32_t *cnt = h->sort_keys.as<uint32_t>(), *off = h->sort_keys2.as<uint32_t>(), *rank = h->sort_idx.as<uint32_t>();
 			const uint32_t g = std::min<uint32_t>((n + 255) / 256, (uint32_t)h->n_cu * 8);
 			HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(n_q + 1) * 4, h->stream));
+			tq1 = tq();
 			hipLaunchKernelGGL(k_hit_count, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, cnt, rank);
 			size_t tmp_bytes = 0;
 			HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, off, (int)(n_q + 1), h->stream));
@@ -1602,6 +1669,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 				h->cur->has_qmap ? h->cur->qmap.as<uint32_t>() : (const uint32_t *)nullptr);
 			hipLaunchKernelGGL(k_hit_fix, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, h->stream, sorted.as<BhipHit>(), off, cnt, n_q);
 			HIPCHK(hipGetLastError());
+			tq2 = tq();
 			const size_t bytes = (size_t)n * sizeof(BhipHit);
 			bool queued = false;
 			if (async) {
@@ -1623,6 +1691,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 					if (hipHostRegister((void *)hits, want, hipHostRegisterDefault) == hipSuccess) { h->reg_ptr[o] = (void *)hits; h->reg_bytes[o] = want; reg_ok = true; }
 					else (void)hipGetLastError();
 				}
+				tq3 = tq();
 				if (reg_ok) {
 					HIPCHK(hipEventRecord(h->ev_sorted, h->stream));
 					HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_sorted, 0));
@@ -1635,8 +1704,10 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			if (hits && !queued) HIPCHK(hipMemcpyAsync(hits, sorted.p, bytes, hipMemcpyDeviceToHost, h->stream));
 			h->last_n_out = n; h->last_out = o;
 		}
+		tq4 = tq();
 		HIPCHK(hipEventRecord(h->ev[9], h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
+		if (dbg_t) fprintf(stderr, "[bhip] delivery host ms: reserve+memset %.3f, sort launches %.3f, pointer check %.3f, copy enqueue %.3f, sync %.3f\n", tq1, tq2 - tq1, tq3 - tq2, tq4 - tq3, tq() - tq4);
 		S.ms_h2d = h->cur->st_ms_h2d; S.ms_d2h = ev_ms(h->ev[8], h->ev[9]); S.ms_total = ev_ms(h->ev[0], h->ev[9]);
 		slot->state = 2;
 		h->res_valid = false;

@@ -154,6 +154,8 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 			++run->nBatches;
 			if (dbg) fprintf(stderr, "[bh_align] batch %lu: %lu entries, staging the next one %.3f ms, align %.3f ms (device %.3f ms), %lu records; %.3f ms since the start\n",
 			                 (unsigned long)k, (unsigned long)bu[2 * k + 1], 1e3 * (tk1 - tk0), 1e3 * (now_sec() - tk1), st.ms_total, (unsigned long)n, 1e3 * (now_sec() - tb0));
+			if (dbg) fprintf(stderr, "[bh_align]   device ms: staging %.2f, profiles %.2f, seeds %.2f, prefilter %.2f, prefix sweep %.2f, window sweep %.2f, re-scoring %.2f, sort + hand-over %.2f\n",
+			                 st.ms_h2d, st.ms_peq, st.ms_seed, st.ms_prefilter_hash, st.ms_myers_prefix, st.ms_myers_window, st.ms_rescore, st.ms_d2h);
 			break;
 		}
 	}

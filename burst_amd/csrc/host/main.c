@@ -237,8 +237,8 @@ int main(int argc, char **argv) {
 		#pragma omp parallel num_threads(n_gpus)
 		{
 			const int r = omp_get_thread_num();
-			bhip_reserve(hhs[r], (uint32_t)(B * strands), Q.maxLen);
 			bh_run_reserve(&runs[r], perRank * strands + perRank / 2 + (1u << 20));
+			bhip_reserve(hhs[r], (uint32_t)(B * strands), Q.maxLen);      /* last: it ends with a warm-up pass, the search follows at once */
 		}
 	}
 	PHASE("batch buffers");

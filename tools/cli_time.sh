@@ -5,8 +5,13 @@ OUT=${1:-$R/gpurun_out/cli_phases.txt}
 D=${BURST_BENCH_DIR:-/tmp/burst_amd_bench}
 python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2>&1
 EDX=$(ls $D/db_*_k15.edx | head -1); ACX=${EDX%.edx}.acx; READS=$(ls $D/reads_8000000_l100_*.fa | head -1)
+if [ -n "$CLI_READS_X" ]; then      # a longer job: the 8 M-read pool CLI_READS_X times over (headers made unique by the copy number)
+  BIG=$D/cli_reads_x$CLI_READS_X.fa
+  [ -f $BIG ] || for i in $(seq $CLI_READS_X); do sed "s/^>/>c${i}_/" $READS; done > $BIG
+  READS=$BIG
+fi
 {
-  echo "# burst_hip -r $(basename $EDX) -a $(basename $ACX) -q $(basename $READS) -m BEST -i 0.98   (8 M reads, 2 M-read batches)"
+  echo "# burst_hip -r $(basename $EDX) -a $(basename $ACX) -q $(basename $READS) -m BEST -i 0.98   (2 M-read batches)"
   for i in 1 2; do
     $R/burst_amd/burst_hip -r $EDX -a $ACX -q $READS -o $D/cli.b6 -m BEST -i 0.98 | grep -E "^ \[|Search complete|Parsed|Alignment time|Wrote"
     echo
