@@ -5,9 +5,13 @@ OUT=${1:-$R/gpurun_out/cli_phases.txt}
 D=${BURST_BENCH_DIR:-/tmp/burst_amd_bench}
 python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2>&1
 EDX=$(ls $D/db_*_k15.edx | head -1); ACX=${EDX%.edx}.acx; READS=$(ls $D/reads_8000000_l100_*.fa | head -1)
-if [ -n "$CLI_READS_X" ]; then      # a longer job: the 8 M-read pool CLI_READS_X times over (headers made unique by the copy number)
-  BIG=$D/cli_reads_x$CLI_READS_X.fa
-  [ -f $BIG ] || for i in $(seq $CLI_READS_X); do sed "s/^>/>c${i}_/" $READS; done > $BIG
+if [ -n "$CLI_READS" ]; then      # a longer job: CLI_READS distinct synthetic reads of the same kind (other seed)
+  BIG=$D/cli_reads_$CLI_READS.fa
+  [ -f $BIG ] || python3 -c "
+import sys; sys.path.insert(0, '$R')
+from burst_amd import host
+import glob
+host.synth_reads(glob.glob('$D/refs_*_k15.fa')[0], '$BIG', $CLI_READS, 100, [0, 1, 2], rc=False, iupac=0.0, seed=4711)"
   READS=$BIG
 fi
 {

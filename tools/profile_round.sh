@@ -52,9 +52,11 @@ for f in glob.glob('%s/%s_kt/**/*kernel_stats.csv' % (O, TAG), recursive=True):
     for r in csv.DictReader(open(f)):
         avg_ns[short(r['Name'])] = float(r['AverageNs'])
 summary = {}
-for k in set(list(fa) + list(sa)):
+def weight(k):
+    return avg_ns.get(k, 0.0) * max(1, sc.get(k, fc.get(k, 1)))
+for k in sorted(set(list(fa) + list(sa)), key=weight):      # template variants share a name: the one with the most time wins
     name = k.replace('void ', '').split('<')[0]
-    e = summary.setdefault(name, {"kernel": k})
+    e = summary[name] = {"kernel": k}
     if k in fa:
         e.update(traffic.get(name, {}))
     if k in sa:
