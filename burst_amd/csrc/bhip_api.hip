@@ -18,6 +18,7 @@
 
 // ---- kernels (bhip_kernels.hip) -------------------------------------------------------------------
 __global__ void k_acx_offsets(const uint32_t *, uint64_t, int, uint32_t *, unsigned long long *);
+__global__ void k_acx_lines(const uint32_t *, uint64_t, int, unsigned long long *, uint4 *);
 __global__ void k_acx_decode(const uint8_t *, const unsigned long long *, const uint32_t *, BhipAcxView, uint64_t, int, uint32_t, uint8_t *, uint32_t *);
 __global__ void k_transpose_refs(const uint8_t *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint4 *, uint4 *);
 __global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, int, int, BhipMatchMask, uint32_t *, const uint32_t *, uint32_t);
@@ -238,9 +239,9 @@ struct Handle {
 	bool has_acx = false; int K = 0;
 	// accelerator: two-level offsets + 5-byte (clump, lane mask) records (bhip_internal.h); entry numbers start at acx_bias
 	// (0, or the test hook BHIP_TEST_ENTRY_BIAS that pushes a small database's offsets beyond 2^32)
-	DBuf acx_delta, acx_base, acx_rec, bad; uint32_t n_bad = 0; uint64_t n_ent = 0, acx_bias = 0;
+	DBuf acx_lines, acx_rec, bad; uint32_t n_bad = 0; uint64_t n_ent = 0, acx_bias = 0;
 	BhipAcxView acx_view() const {
-		BhipAcxView v; v.delta = acx_delta.as<uint32_t>(); v.base = acx_base.as<unsigned long long>();
+		BhipAcxView v; v.lines = acx_lines.as<uint4>();
 		v.rec = acx_rec.as<uint8_t>() - acx_bias * (uint64_t)BHIP_REC_BYTES; return v;
 	}
 	bool has_masks = false;       // per-entry lane masks were built at upload (lane-resolved prefilter)
@@ -332,7 +333,7 @@ extern "C" void bhip_destroy(void *handle) {
 	if (h->stage_stream) (void)hipStreamSynchronize(h->stage_stream);
 	for (StageSlot &S : h->slots) S.release_all();
 	for (Lane *L : h->lanes) lane_destroy(L);
-	DBuf *all[] = {&h->ref, &h->ref_lane, &h->ref_off, &h->clump_len, &h->lut, &h->acx_delta, &h->acx_base, &h->acx_rec, &h->bad,
+	DBuf *all[] = {&h->ref, &h->ref_lane, &h->ref_off, &h->clump_len, &h->lut, &h->acx_lines, &h->acx_rec, &h->bad,
 		&h->best, &h->out, &h->shared_ctr, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx,
 		&h->sort_tmp, &h->out_sorted, &h->out_sorted2};
 	for (int o = 0; o < 2; ++o) {
@@ -498,8 +499,8 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		const uint64_t nw = 1ull << (2 * K), nblk = (nw + 255) >> 8;
 		// Lens[4^K] goes up as it is; block-relative offsets, block bases, byte offsets of the packed lists, the total and the
 		// occurrence-weighted mean list length are scans / reductions on the device (at K = 15 the table has 2^30 words)
-		DBuf d_lens, d_red, d_tmp, d_bsum, d_bdelta, d_bbase;
-		#define ACXFREE() do { d_lens.release(); d_red.release(); d_tmp.release(); d_bsum.release(); d_bdelta.release(); d_bbase.release(); } while (0)
+		DBuf d_lens, d_red, d_tmp, d_bsum, d_bdelta, d_bbase, d_lsum, d_lbase;
+		#define ACXFREE() do { d_lens.release(); d_red.release(); d_tmp.release(); d_bsum.release(); d_bdelta.release(); d_bbase.release(); d_lsum.release(); d_lbase.release(); } while (0)
 		#define ACXRC(x) do { int rc_ = (x); if (rc_) { ACXFREE(); bhip_destroy(h); return rc_; } } while (0)
 		#define ACXCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ACXFREE(); \
 			fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); bhip_destroy(h); return BHIP_E_DEVICE; } } while (0)
@@ -509,8 +510,10 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		ACXRC(d_bsum.reserve((nblk + 2) * 8));
 		ACXRC(d_bdelta.reserve(nw * sizeof(uint32_t) + 16));
 		ACXRC(d_bbase.reserve((nblk + 2) * 8));
-		ACXRC(h->acx_delta.reserve(nw * sizeof(uint32_t) + 16));
-		ACXRC(h->acx_base.reserve((nblk + 2) * 8));
+		const uint64_t n_lines = (nw + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS;
+		ACXRC(h->acx_lines.reserve((n_lines + 1) * 64));
+		ACXRC(d_lsum.reserve((n_lines + 2) * 8));
+		ACXRC(d_lbase.reserve((n_lines + 2) * 8));
 		ACXCHK(hipMemcpyAsync(d_lens.p, acx_lens, nw * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
 		auto to_sq = [] __host__ __device__(uint32_t n) -> double { return (double)n * (double)n; };
 		hipcub::TransformInputIterator<double, decltype(to_sq), const uint32_t *> it_sq(d_lens.as<uint32_t>(), to_sq);
@@ -518,16 +521,21 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		size_t tb = 0, tb1 = 0;
 		ACXCHK(hipcub::DeviceReduce::Sum(nullptr, tb1, it_sq, r_sq, (int)nw, h->stream)); tb = std::max(tb, tb1);
 		ACXCHK(hipcub::DeviceReduce::Max(nullptr, tb1, d_lens.as<uint32_t>(), r_max, (int)nw, h->stream)); tb = std::max(tb, tb1);
-		ACXCHK(hipcub::DeviceScan::ExclusiveScan(nullptr, tb1, d_bsum.as<unsigned long long>(), h->acx_base.as<unsigned long long>(), hipcub::Sum(), 0ull, (int)(nblk + 1), h->stream)); tb = std::max(tb, tb1);
+		ACXCHK(hipcub::DeviceScan::ExclusiveScan(nullptr, tb1, d_lsum.as<unsigned long long>(), d_lbase.as<unsigned long long>(), hipcub::Sum(), 0ull, (int)(n_lines + 1), h->stream)); tb = std::max(tb, tb1);
 		ACXRC(d_tmp.reserve(tb + 16));
 		tb1 = tb; ACXCHK(hipcub::DeviceReduce::Sum(d_tmp.p, tb1, it_sq, r_sq, (int)nw, h->stream));
 		tb1 = tb; ACXCHK(hipcub::DeviceReduce::Max(d_tmp.p, tb1, d_lens.as<uint32_t>(), r_max, (int)nw, h->stream));
 		const uint32_t og = (uint32_t)std::min<uint64_t>(nblk, (uint64_t)h->n_cu * 16);
-		// entry offsets
-		ACXCHK(hipMemsetAsync(d_bsum.p, 0, (nblk + 2) * 8, h->stream));
-		hipLaunchKernelGGL(k_acx_offsets, dim3(og), dim3(256), 0, h->stream, d_lens.as<uint32_t>(), nw, 0, h->acx_delta.as<uint32_t>(), d_bsum.as<unsigned long long>());
-		ACXCHK(hipGetLastError());
-		tb1 = tb; ACXCHK(hipcub::DeviceScan::ExclusiveScan(d_tmp.p, tb1, d_bsum.as<unsigned long long>(), h->acx_base.as<unsigned long long>(), hipcub::Sum(), (unsigned long long)h->acx_bias, (int)(nblk + 1), h->stream));
+		// entry offsets: block sums -> 64-bit bases -> lines
+		{
+			const uint32_t lg = (uint32_t)std::min<uint64_t>((n_lines + 255) / 256, (uint64_t)h->n_cu * 32);
+			ACXCHK(hipMemsetAsync(d_lsum.p, 0, (n_lines + 2) * 8, h->stream));
+			hipLaunchKernelGGL(k_acx_lines, dim3(lg), dim3(256), 0, h->stream, d_lens.as<uint32_t>(), nw, 0, d_lsum.as<unsigned long long>(), h->acx_lines.as<uint4>());
+			ACXCHK(hipGetLastError());
+			tb1 = tb; ACXCHK(hipcub::DeviceScan::ExclusiveScan(d_tmp.p, tb1, d_lsum.as<unsigned long long>(), d_lbase.as<unsigned long long>(), hipcub::Sum(), (unsigned long long)h->acx_bias, (int)(n_lines + 1), h->stream));
+			hipLaunchKernelGGL(k_acx_lines, dim3(lg), dim3(256), 0, h->stream, d_lens.as<uint32_t>(), nw, 1, d_lbase.as<unsigned long long>(), h->acx_lines.as<uint4>());
+			ACXCHK(hipGetLastError());
+		}
 		// byte offsets of the packed lists on disk
 		ACXCHK(hipMemsetAsync(d_bsum.p, 0, (nblk + 2) * 8, h->stream));
 		hipLaunchKernelGGL(k_acx_offsets, dim3(og), dim3(256), 0, h->stream, d_lens.as<uint32_t>(), nw, acx_fmt == 1 ? 2 : 1, d_bdelta.as<uint32_t>(), d_bsum.as<unsigned long long>());
@@ -535,9 +543,10 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		tb1 = tb; ACXCHK(hipcub::DeviceScan::ExclusiveScan(d_tmp.p, tb1, d_bsum.as<unsigned long long>(), d_bbase.as<unsigned long long>(), hipcub::Sum(), 0ull, (int)(nblk + 1), h->stream));
 		unsigned long long red[3], tot_b = 0, bytes = 0;
 		ACXCHK(hipMemcpyAsync(red, d_red.p, 24, hipMemcpyDeviceToHost, h->stream));
-		ACXCHK(hipMemcpyAsync(&tot_b, h->acx_base.as<unsigned long long>() + nblk, 8, hipMemcpyDeviceToHost, h->stream));
+		ACXCHK(hipMemcpyAsync(&tot_b, d_lbase.as<unsigned long long>() + n_lines, 8, hipMemcpyDeviceToHost, h->stream));
 		ACXCHK(hipMemcpyAsync(&bytes, d_bbase.as<unsigned long long>() + nblk, 8, hipMemcpyDeviceToHost, h->stream));
 		ACXCHK(hipStreamSynchronize(h->stream));
+		d_lsum.release(); d_lbase.release();
 		const uint64_t tot = tot_b - h->acx_bias;
 		double sq; memcpy(&sq, &red[1], 8);
 		uint32_t maxlen; memcpy(&maxlen, &red[2], 4);
@@ -569,7 +578,7 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		#undef ACXRC
 		#undef ACXCHK
 		if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] accelerator: K=%d, %llu entries (first entry number %llu), %.2f B per entry on the device (records %d B + offsets)\n", K,
-			(unsigned long long)tot, (unsigned long long)h->acx_bias, tot ? (double)(tot * BHIP_REC_BYTES + nw * 4 + nblk * 8) / (double)tot : 0.0, BHIP_REC_BYTES);
+			(unsigned long long)tot, (unsigned long long)h->acx_bias, tot ? (double)(tot * BHIP_REC_BYTES + n_lines * 64) / (double)tot : 0.0, BHIP_REC_BYTES);
 		h->n_bad = n_bad;
 		INITRC(h->bad.reserve((n_bad + 1) * sizeof(uint32_t)));
 		if (n_bad) {

@@ -42,30 +42,32 @@ struct BhipStageInfo {
 // Accelerator (.acx, burst.c:3535-3594) as it lives in HBM.
 //   Lists: one 5-byte record per list entry, in the file's word order: bytes 0-2 = clump id (the 24 bits of the LARGE format,
 //   burst.c:3245-3248), bytes 3-4 = 16-bit lane mask (bit z: lane z of the clump really holds the word; 0xFFFF when the
-//   masks were not built).  Offsets: the file's Lens[4^K] (burst.c:3558) becomes a two-level table -- `base`, a 64-bit
-//   entry offset per block of 256 words, and `delta`, the 32-bit exclusive prefix of the lengths inside the block.  A list is
-//   shorter than 2^24 entries (one per clump at most, burst.c:3385-3386, clump ids have 24 bits), so 256 of them always fit
-//   32 bits, while the whole accelerator may hold far more than 2^32 entries (RefSeq scale: ~5 * 10^10).
+//   masks were not built).  Offsets: the file's Lens[4^K] (burst.c:3558) becomes a table of 64-byte LINES, one per block of 14
+//   words: a 64-bit entry number of the block's first list followed by the fourteen 32-bit inclusive prefix sums of the list
+//   lengths inside the block -- the range of a word is ONE 64-byte sector at a random address (a flat offset array costs two,
+//   a two-level table three).  A list is shorter than 2^24 entries (one per clump at most, burst.c:3385-3386, clump ids have
+//   24 bits), so 14 of them always fit 32 bits, while the whole accelerator may hold far more than 2^32 entries (RefSeq
+//   scale: ~5 * 10^10).
 //   `rec` may point BEFORE the allocation (test hook BHIP_TEST_ENTRY_BIAS: entry numbers start at the bias, so that small
 //   databases exercise offsets beyond 2^32); only entry numbers >= the bias are ever dereferenced.
 // ------------------------------------------------------------------------------------------------
-#define BHIP_ACX_BLOCK_LOG 8
+#define BHIP_ACX_LINE_WORDS 14u
 #define BHIP_REC_BYTES 5
 struct BhipAcxView {
-	const uint32_t *delta;               // [n_words + 1]
-	const unsigned long long *base;      // [(n_words >> 8) + 2]
+	const uint4 *lines;                  // [ceil(n_words / 14)] x 64 bytes
 	const uint8_t *rec;                  // 5 bytes per entry
 };
 
 #ifdef __HIPCC__
 // entry range of word w: first entry and length
 __device__ __forceinline__ void bhip_acx_range(const BhipAcxView &a, uint32_t w, unsigned long long &beg, uint32_t &n) {
-	const uint32_t blk = w >> BHIP_ACX_BLOCK_LOG;
-	const unsigned long long b0 = a.base[blk];
-	const uint32_t d0 = a.delta[w];
-	beg = b0 + d0;
-	if ((w & ((1u << BHIP_ACX_BLOCK_LOG) - 1u)) == (1u << BHIP_ACX_BLOCK_LOG) - 1u) n = (uint32_t)(a.base[blk + 1] - beg);
-	else n = a.delta[w + 1] - d0;
+	const uint32_t blk = w / BHIP_ACX_LINE_WORDS, j = w - blk * BHIP_ACX_LINE_WORDS;
+	const uint32_t *L = (const uint32_t *)(a.lines + 4ull * blk);
+	const unsigned long long b0 = (unsigned long long)L[0] | (unsigned long long)L[1] << 32;
+	const uint32_t hi = L[2 + j], lo_raw = L[1 + j];      // (for j = 0 lo_raw is the high word of the base: not used)
+	const uint32_t lo = j ? lo_raw : 0u;
+	beg = b0 + lo;
+	n = hi - lo;
 }
 // record e as (clump, lane mask): two aligned dword loads around the 5 bytes
 __device__ __forceinline__ uint2 bhip_acx_rec(const uint8_t *rec, unsigned long long e) {

@@ -79,6 +79,23 @@ __global__ __launch_bounds__(256) void k_acx_offsets(const uint32_t *__restrict_
 	}
 }
 
+// .acx offsets as 64-byte lines (BhipAcxView): pass 0 writes the sum of every block of 14 lengths, the caller scans them into
+// 64-bit bases (hipCUB), pass 1 writes base + inclusive prefix sums.  One thread per line.
+__global__ void k_acx_lines(const uint32_t *__restrict__ lens, uint64_t n_words, int pass, unsigned long long *__restrict__ blk, uint4 *__restrict__ lines) {
+	const uint64_t n_lines = (n_words + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS;
+	for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < n_lines; b += (uint64_t)gridDim.x * blockDim.x) {
+		uint32_t d[14], run = 0;
+		#pragma unroll
+		for (uint32_t j = 0; j < 14; ++j) { const uint64_t w = b * BHIP_ACX_LINE_WORDS + j; run += w < n_words ? lens[w] : 0u; d[j] = run; }
+		if (pass == 0) { blk[b] = run; continue; }
+		const unsigned long long base = blk[b];
+		lines[4 * b + 0] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), d[0], d[1]);
+		lines[4 * b + 1] = make_uint4(d[2], d[3], d[4], d[5]);
+		lines[4 * b + 2] = make_uint4(d[6], d[7], d[8], d[9]);
+		lines[4 * b + 3] = make_uint4(d[10], d[11], d[12], d[13]);
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // .acx list area -> 5-byte records (24-bit clump id, 16-bit lane mask preset to "every lane"), on the device (the packed bytes
 // are what is uploaded): SMALL lists are pairs of 20-bit ids in 5 bytes with a 3-byte odd tail (burst.c:3265-3274), LARGE
@@ -94,7 +111,7 @@ __global__ void k_acx_decode(const uint8_t *__restrict__ lists, const unsigned l
 		unsigned long long e; uint32_t n;
 		bhip_acx_range(acx, (uint32_t)w, e, n);
 		if (!n) continue;
-		const uint8_t *p = lists + byte_base[w >> BHIP_ACX_BLOCK_LOG] + byte_delta[w];
+		const uint8_t *p = lists + byte_base[w >> 8] + byte_delta[w];
 		uint32_t worst = 0;
 		if (fmt == 1) {
 			for (; n; --n, p += 3) { const uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); bhip_rec_store(rec, e++, v, 0xFFFFu); worst = v > worst ? v : worst; }
@@ -711,11 +728,26 @@ __global__ __launch_bounds__(256) void k_seed_ranges(
 			const uint32_t j0 = p >> 3, sh = 4u * (p & 7u);
 			const uint32_t d0 = qp[j0], d1 = j0 + 1 < qw ? qp[j0 + 1] : 0u, d2 = j0 + 2 < qw ? qp[j0 + 2] : 0u;
 			const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
-			for (int k = 0; k < K; ++k) {
-				const uint32_t c = ((k < 8 ? lo : hi) >> (4 * (k & 7))) & 15u;
-				ok &= (c - 1u) < 4u;
-				w = (w << 2) | ((c - 1u) & 3u);
-			}
+			// eight 4-bit codes -> eight 2-bit symbols, first symbol most significant, all at once (codes 1..4 = A C G T;
+			// any other code in the word's first n nibbles clears `good`)
+			auto pack8 = [](uint32_t x, uint32_t n, bool &good) -> uint32_t {
+				const uint32_t keep = n >= 8 ? 0xFFFFFFFFu : ((1u << (4 * n)) - 1u);
+				const uint32_t xm = (x & keep) | (0x11111111u & ~keep);            // unused nibbles read as A
+				const uint32_t zero = (xm - 0x11111111u) & ~xm & 0x88888888u;       // a nibble of code 0 (would borrow below)
+				const uint32_t t = xm - 0x11111111u;                                // code - 1 per nibble
+				good = good && !zero && !(t & 0xCCCCCCCCu);
+				uint32_t y = (t | (t >> 2)) & 0x0F0F0F0Fu;
+				y = (y | (y >> 4)) & 0x00FF00FFu;
+				y = (y | (y >> 8)) & 0xFFFFu;                                       // symbol k at bits 2k, 2k + 1
+				const uint32_t r = __brev(y) >> 16;                                 // order reversed, bits of a pair swapped
+				return ((r & 0x5555u) << 1) | ((r >> 1) & 0x5555u);               // 16 bits, symbol 0 on top
+			};
+			bool good = true;
+			const uint32_t Ku = (uint32_t)K;
+			const uint32_t w_lo = pack8(lo, Ku < 8 ? Ku : 8u, good);
+			if (Ku <= 8) w = w_lo >> (16 - 2 * Ku);
+			else { const uint32_t w_hi = pack8(hi, Ku - 8, good); w = (w_lo << (2 * (Ku - 8))) | (w_hi >> (16 - 2 * (Ku - 8))); }
+			ok = good ? 1u : 0u;
 		} else for (int k = 0; k < K; ++k) {
 			const uint32_t c = qcodes[b + p + k];
 			ok &= (c - 1u) < 4u;
