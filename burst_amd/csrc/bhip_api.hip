@@ -1445,7 +1445,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		HIPCHK(hipStreamWaitEvent(sw, ce[2], 0));
 		HIPCHK(hipEventRecord(ce[6], sw));
 		if (n_pf) {
-			if (masked) launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 32, L->tasks.as<uint2>(), &dc->n_tasks_cls[cls], qlist, L->wins.as<BhipWin>(), &dc->n_wins_cls[cls], dc);
+			if (masked) launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 4u * (uint32_t)h->opt_sweep_blocks, L->tasks.as<uint2>(), &dc->n_tasks_cls[cls], qlist, L->wins.as<BhipWin>(), &dc->n_wins_cls[cls], dc);
 			if (NWP) launch_prefix(h, L, sw, NWP, grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, &dc->n_wins_cls[cls], dc);
 			else launch_myers(h, L, sw, cls, grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, L->raw.as<BhipRawHit>(),
 				&dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
@@ -1473,7 +1473,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 			HIPCHK(hipStreamWaitEvent(sw, L->ev_ph[cls][0], 0));
 			hipLaunchKernelGGL(k_task_filter, dim3((uint32_t)h->n_cu * 8), dim3(256), 0, sw, L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], (uint32_t)L->task_cap, qlist,
 				h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr, h->best.as<uint32_t>(), L->tasks2k.as<uint2>(), &dc->n_tasks2k_cls[cls]);
-			launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 32, L->tasks2k.as<uint2>(), &dc->n_tasks2k_cls[cls], qlist, L->wins2.as<BhipWin>(), &dc->n_wins2_cls[cls], dc);
+			launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 4u * (uint32_t)h->opt_sweep_blocks, L->tasks2k.as<uint2>(), &dc->n_tasks2k_cls[cls], qlist, L->wins2.as<BhipWin>(), &dc->n_wins2_cls[cls], dc);
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipEventRecord(L->ev_ph[cls][1], sw));
 			HIPCHK(hipStreamWaitEvent(po, L->ev_ph[cls][1], 0));

@@ -1112,19 +1112,29 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 
 	const uint32_t n_quads = (n_list + 3) >> 2;
 	constexpr uint32_t RB = 2;               // blocks of 64 records per query that stay in registers between the two looks
+	// (cross-lane moves by data-parallel primitives and lane reads where the pattern is fixed: a shuffle is an LDS round trip, and
+	// this kernel's time is the sum of its dependent LDS round trips)
+	auto group_pick = [&](uint32_t v, uint32_t l) -> uint32_t {      // lane l (0..15) of the own group, l a constant
+		const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16 + (int)l),
+			c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32 + (int)l), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48 + (int)l);
+		return g == 0 ? a : (g == 1 ? b : (g == 2 ? c : d));
+	};
+	auto wave_max4 = [&](uint32_t v) -> uint32_t {                    // maximum over the four groups of a group-uniform value
+		const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
+			c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+		const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+		return ab > cd ? ab : cd;
+	};
 	auto group_scan = [&](uint32_t n, uint32_t &T, uint32_t &excl) {
-		uint32_t ps = n;
-		#pragma unroll
-		for (uint32_t o = 1; o < 16; o <<= 1) { const uint32_t t = __shfl_up(ps, o, 16); if (gl >= o) ps += t; }
-		T = __shfl(ps, 15, 16);
-		excl = ps - n;
+		int ps = (int)n;
+		ps += __builtin_amdgcn_update_dpp(0, ps, 0x111, 0xF, 0xF, false);    // row_shr:1 (a row = the 16 lanes of a group; lanes without a source add 0)
+		ps += __builtin_amdgcn_update_dpp(0, ps, 0x112, 0xF, 0xF, false);    // row_shr:2
+		ps += __builtin_amdgcn_update_dpp(0, ps, 0x114, 0xF, 0xF, false);    // row_shr:4
+		ps += __builtin_amdgcn_update_dpp(0, ps, 0x118, 0xF, 0xF, false);    // row_shr:8
+		T = group_pick((uint32_t)ps, 15);
+		excl = (uint32_t)ps - n;
 	};
-	auto wave_blocks = [&](uint32_t T) -> uint32_t {
-		uint32_t m = T, t;
-		t = __shfl_xor(m, 16); m = t > m ? t : m;
-		t = __shfl_xor(m, 32); m = t > m ? t : m;
-		return (m + 63) >> 6;
-	};
+	auto wave_blocks = [&](uint32_t T) -> uint32_t { return (wave_max4(T) + 63) >> 6; };
 	auto load4 = [&](uint32_t ex, unsigned long long dl, uint32_t T, uint32_t b, uint2 (&rec)[4]) {      // see k_prefilter_mask
 		#pragma unroll
 		for (uint32_t u = 0; u < 4; ++u) {
@@ -1161,7 +1171,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		#pragma unroll
 		for (uint32_t j = 0; j < RB * 4; ++j) kk[j] = 0;
 		if (W16 > 8) {
-			const uint32_t e8 = __shfl(ex, 8, 16);
+			const uint32_t e8 = group_pick(ex, 8);
 			#pragma unroll
 			for (uint32_t j = 0; j < RB * 4; ++j) kk[j] = e8 <= j * 16 + gl ? 8u : 0u;
 		}
@@ -1216,9 +1226,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		const uint32_t need = hd.x & 0xFFFFu, nwords = live ? hd.x >> 16 : 0u, len = hd.y & 0xFFFu;
 		const uint32_t budget = (hd.y >> 12) & 255u, dper = (hd.y >> 20) & 15u ? (hd.y >> 20) & 15u : 1u;
 		const uint32_t thr = need ? need : 1u;
-		uint32_t maxw = nwords;
-		#pragma unroll
-		for (int o = 32; o >= 1; o >>= 1) { const uint32_t t = __shfl_xor(maxw, o); maxw = t > maxw ? t : maxw; }
+		const uint32_t maxw = wave_max4(nwords);          // (nwords is the same in the 16 lanes of a group)
 		auto word_range = [&](uint32_t j, unsigned long long &beg, uint32_t &n) {
 			uint2 r = make_uint2(0, 0);
 			if (live && j < nwords) r = ranges[(size_t)li * W16 + j];
@@ -1352,8 +1360,13 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 				}
 			}
 			uint32_t cmax_all = cmax;
-			#pragma unroll
-			for (int o = 8; o >= 1; o >>= 1) { const uint32_t t = __shfl_xor(cmax_all, o, 16); cmax_all = t > cmax_all ? t : cmax_all; }
+			{       // maximum over the 16 lanes of the group: neighbours, pairs of neighbours, then the two mirror moves
+				int t;
+				t = __builtin_amdgcn_update_dpp(0, (int)cmax_all, 0xB1, 0xF, 0xF, false); cmax_all = (uint32_t)t > cmax_all ? (uint32_t)t : cmax_all;     // quad_perm:[1,0,3,2]
+				t = __builtin_amdgcn_update_dpp(0, (int)cmax_all, 0x4E, 0xF, 0xF, false); cmax_all = (uint32_t)t > cmax_all ? (uint32_t)t : cmax_all;     // quad_perm:[2,3,0,1]
+				t = __builtin_amdgcn_update_dpp(0, (int)cmax_all, 0x141, 0xF, 0xF, false); cmax_all = (uint32_t)t > cmax_all ? (uint32_t)t : cmax_all;    // row_half_mirror
+				t = __builtin_amdgcn_update_dpp(0, (int)cmax_all, 0x140, 0xF, 0xF, false); cmax_all = (uint32_t)t > cmax_all ? (uint32_t)t : cmax_all;    // row_mirror
+			}
 			const uint32_t any_bad = n_bad;                 // BadList lanes carry no bound (0): they are always in the first sweep
 			for (uint32_t iu = gl; iu < nused; iu += 16) {
 				unsigned long long lo, hi;
