@@ -660,7 +660,11 @@ __global__ void k_attach_masks(BhipAcxView acx, uint64_t n_words,
 // More candidate clumps in one query than the lane counters hold (24 with the 512-slot table, 80 above): the surplus clumps are emitted as clump-level pairs (16-lane kernel).
 #ifdef PFM_PROF
 __device__ unsigned long long g_pfm_prof[8];
+#if PFM_PROF == 2      // without draining the memory pipeline: issue + stall time of each phase as it really runs
+#define PFM_T(i) do { const unsigned long long t_ = wall_clock64(); if (lane == 0) my_t[i] += t_ - t_last; t_last = t_; } while (0)
+#else
 #define PFM_T(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = wall_clock64(); if (lane == 0) my_t[i] += t_ - t_last; t_last = t_; } while (0)
+#endif
 #else
 #define PFM_T(i) do {} while (0)
 #endif
@@ -1047,6 +1051,18 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 #ifndef CF_MINWAVES
 #define CF_MINWAVES 3
 #endif
+// inclusive prefix sum over the 64 lanes of a wave (all lanes active): four shifts inside each row of 16 lanes, then lane 15 of
+// rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3 -- data-parallel-primitive moves, no LDS round trip
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
+	int v = (int)x;
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);    // row_shr:1
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);    // row_shr:2
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);    // row_shr:4
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);    // row_shr:8
+	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);    // row_bcast:15 -> rows 1, 3
+	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);    // row_bcast:31 -> rows 2, 3
+	return (uint32_t)v;
+}
 template <int CB>
 __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
@@ -1068,57 +1084,52 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 	__shared__ uint2 s_ring[4][RING];
 	__shared__ uint8_t s_used[4][LT];                                      // slots of the lane table in use (LT <= 256)
 	__shared__ uint2 s_stage[2][CF_STAGE];
-	__shared__ uint32_t s_nstage[2];
 	__shared__ uint32_t s_ovf[4];
 	__shared__ uint32_t s_dummy[16];          // compare-and-swap target of idle lanes (never written: the compare value cannot match)
 	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
 	if (lane < 16) s_dummy[lane] = 0;
 	for (uint32_t i = lane; i < 4 * NCNT / 2; i += 64) (&s_cnt[0][0])[i] = 0;
 	for (uint32_t i = lane; i < 4 * LT; i += 64) { (&s_key[0][0])[i] = 0; (&s_lc[0][0][0])[2 * i] = 0; (&s_lc[0][0][0])[2 * i + 1] = 0; }
-	if (lane < 2) s_nstage[lane] = 0;
 	if (lane < 4) s_ovf[lane] = 0;
 	__syncthreads();
 	unsigned long long my_ent = 0, my_units = 0, my_cols = 0, my_qlen = 0, my_surv = 0;
-	uint32_t sink = 0;                      // see bhip_acx_rec_or_pad
+	uint32_t sink = 0, sink_h = 0;          // see bhip_acx_rec_or_pad
 #ifdef PFM_PROF
 	unsigned long long my_t[8] = {0,0,0,0,0,0,0,0}, t_last = wall_clock64();
 #endif
 
-	auto push = [&](uint32_t which, uint32_t li_lb, uint32_t refIx) {        // which = 0: first sweep, 1: deferred (li_lb = li | bound << 24)
-		const uint32_t pos = atomicAdd(&s_nstage[which], 1u);
-		if (pos < CF_STAGE) s_stage[which][pos] = make_uint2(li_lb, refIx);
-		else {
-			const uint32_t gp = atomicAdd(which ? n_tasks2 : n_tasks, 1u);
-			if (gp < task_cap) (which ? tasks2 : tasks)[gp] = make_uint2(li_lb, refIx);
-		}
-	};
-	auto flush = [&]() {
-		__syncthreads();
-		#pragma unroll
-		for (uint32_t which = 0; which < 2; ++which) {
-			const uint32_t n = s_nstage[which] < CF_STAGE ? s_nstage[which] : CF_STAGE;
+	// Staged tasks: this block is ONE wave, so the fill counts of the two output lists are wave-uniform registers and the
+	// positions of a lane's tasks come from a prefix sum over the wave: no LDS atomics, no per-task round trip.
+	// which = 0: first sweep, 1: deferred (li_lb = li | bound << 24).
+	uint32_t nst[2] = {0u, 0u};
+	const unsigned long long lt_mask = (1ull << lane) - 1ull;
+	auto flush_one = [&](uint32_t which) {
+		const uint32_t n = nst[which];
+		if (n) {
 			uint32_t base = 0;
-			if (n) {
-				if (lane == 0) base = atomicAdd(which ? n_tasks2 : n_tasks, n);
-				base = __shfl(base, 0);
-				uint2 *dst = which ? tasks2 : tasks;
-				for (uint32_t i = lane; i < n; i += 64) if (base + i < task_cap) dst[base + i] = s_stage[which][i];
-			}
+			if (lane == 0) base = atomicAdd(which ? n_tasks2 : n_tasks, n);
+			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+			uint2 *dst = which ? tasks2 : tasks;
+			if (lane < n && base + lane < task_cap) dst[base + lane] = s_stage[which][lane];
+			__syncthreads();
 		}
-		__syncthreads();
-		if (lane < 2) s_nstage[lane] = 0;
-		__syncthreads();
+		nst[which] = 0;
 	};
+	auto put_row = [&](uint32_t which, bool mine, uint32_t li_lb, uint32_t refIx) {     // wave-uniform call; `mine`: this lane has a task for list `which`
+		const unsigned long long m = __ballot(mine);
+		const uint32_t cnt = (uint32_t)__popcll(m);
+		if (!cnt) return;
+		if (nst[which] + cnt > CF_STAGE) flush_one(which);
+		if (mine) s_stage[which][nst[which] + (uint32_t)__popcll(m & lt_mask)] = make_uint2(li_lb, refIx);
+		nst[which] += cnt;
+	};
+	auto flush = [&]() { flush_one(0); flush_one(1); };
 
 	const uint32_t n_quads = (n_list + 3) >> 2;
 	constexpr uint32_t RB = 2;               // blocks of 64 records per query that stay in registers between the two looks
 	// (cross-lane moves by data-parallel primitives and lane reads where the pattern is fixed: a shuffle is an LDS round trip, and
 	// this kernel's time is the sum of its dependent LDS round trips)
-	auto group_pick = [&](uint32_t v, uint32_t l) -> uint32_t {      // lane l (0..15) of the own group, l a constant
-		const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16 + (int)l),
-			c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32 + (int)l), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48 + (int)l);
-		return g == 0 ? a : (g == 1 ? b : (g == 2 ? c : d));
-	};
+#define GROUP_PICK(v, l) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x150 + (l), 0xF, 0xF, false))      /* lane l (0..15, a constant) of the own group: row_newbcast */
 	auto wave_max4 = [&](uint32_t v) -> uint32_t {                    // maximum over the four groups of a group-uniform value
 		const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
 			c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
@@ -1131,7 +1142,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		ps += __builtin_amdgcn_update_dpp(0, ps, 0x112, 0xF, 0xF, false);    // row_shr:2
 		ps += __builtin_amdgcn_update_dpp(0, ps, 0x114, 0xF, 0xF, false);    // row_shr:4
 		ps += __builtin_amdgcn_update_dpp(0, ps, 0x118, 0xF, 0xF, false);    // row_shr:8
-		T = group_pick((uint32_t)ps, 15);
+		T = GROUP_PICK(ps, 15);
 		excl = (uint32_t)ps - n;
 	};
 	auto wave_blocks = [&](uint32_t T) -> uint32_t { return (wave_max4(T) + 63) >> 6; };
@@ -1152,11 +1163,25 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 	// iterations ahead and the first RB blocks of list records ONE iteration ahead, so that the gather of a quad's records --
 	// short reads at random addresses, 43 % of the wave cycles when it was waited for in place -- runs while the previous
 	// quad is counted.
-	auto fetch_hdr = [&](uint32_t quad, uint2 &hd, uint2 &rg) {
-		hd = make_uint2(0, 0); rg = make_uint2(0, 0);
+	// (unconditional loads from clamped, always valid addresses, masked afterwards: a load under a condition is compiled as a
+	// branch with an s_waitcnt vmcnt(0) at its join, which would expose the latency this prefetch is there to hide -- and wait
+	// for every other load in flight)
+	typedef const unsigned long long __attribute__((address_space(1))) *g64_t;
+	auto fetch_hdr_issue = [&](uint32_t quad, unsigned long long &h, unsigned long long &r) {      // raw words; nothing here waits for them
 		const uint32_t li = quad * 4 + g;
-		if (quad < n_quads && li < n_list) { hd = hdr[li]; if (gl < W16) rg = ranges[(size_t)li * W16 + gl]; }
+		const bool ok = li < n_list, okw = ok && gl < W16;         // (li < n_list implies quad < n_quads)
+		const uint32_t lic = ok ? li : 0u;
+		h = ((g64_t)(uintptr_t)(hdr + lic))[0]; r = ((g64_t)(uintptr_t)(ranges + ((size_t)lic * W16 + (okw ? gl : 0u))))[0];
 	};
+	auto fetch_hdr_finish = [&](uint32_t quad, unsigned long long h, unsigned long long r, uint2 &hd, uint2 &rg) {
+		const uint32_t li = quad * 4 + g;
+		const bool ok = li < n_list, okw = ok && gl < W16;
+		sink_h ^= (uint32_t)h + (uint32_t)r;         // (its own chain: folded into `sink`, the compiler consumes the words where that chain is first touched)
+		const uint32_t mh = ok ? 0xFFFFFFFFu : 0u, mr = okw ? 0xFFFFFFFFu : 0u;
+		hd = make_uint2((uint32_t)h & mh, (uint32_t)(h >> 32) & mh);
+		rg = make_uint2((uint32_t)r & mr, (uint32_t)(r >> 32) & mr);
+	};
+	auto fetch_hdr = [&](uint32_t quad, uint2 &hd, uint2 &rg) { unsigned long long h, r; fetch_hdr_issue(quad, h, r); fetch_hdr_finish(quad, h, r, hd, rg); };
 	// issue: the raw words of the first RB blocks of a quad's record stream (nothing here waits for them); sh = byte shift of each
 	auto start_stream = [&](uint32_t quad, const uint2 &rg, uint32_t &T, uint32_t &ex, unsigned long long &dl, uint32_t &nblk, uint2 (&raw)[RB][4], uint32_t (&sh)[RB]) -> uint32_t {
 		const bool lv = quad < n_quads && quad * 4 + g < n_list;
@@ -1168,20 +1193,32 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		// which list does stream position i belong to: the search over the group's exclusive prefix sums, all RB * 4 positions of
 		// this lane stage by stage (their cross-lane reads are in flight together: one LDS round trip per stage, not per position)
 		uint32_t kk[RB * 4];
-		#pragma unroll
-		for (uint32_t j = 0; j < RB * 4; ++j) kk[j] = 0;
-		if (W16 > 8) {
-			const uint32_t e8 = group_pick(ex, 8);
+		if (W16 <= 8) {
+			// eight lists: the seven inner boundaries are broadcast inside the group (data-parallel moves) and the binary search
+			// becomes a selection tree in registers -- no LDS round trip at all
+			const uint32_t e1 = GROUP_PICK(ex, 1), e2 = GROUP_PICK(ex, 2), e3 = GROUP_PICK(ex, 3), e4 = GROUP_PICK(ex, 4),
+				e5 = GROUP_PICK(ex, 5), e6 = GROUP_PICK(ex, 6), e7 = GROUP_PICK(ex, 7);
+			#pragma unroll
+			for (uint32_t j = 0; j < RB * 4; ++j) {
+				const uint32_t i = j * 16 + gl;
+				const bool a = e4 <= i;
+				const bool b = (a ? e6 : e2) <= i;
+				const uint32_t lo13 = b ? e3 : e1, hi57 = b ? e7 : e5;
+				const bool c = (a ? hi57 : lo13) <= i;
+				kk[j] = (a ? 4u : 0u) + (b ? 2u : 0u) + (c ? 1u : 0u);
+			}
+		} else {
+			const uint32_t e8 = GROUP_PICK(ex, 8);
 			#pragma unroll
 			for (uint32_t j = 0; j < RB * 4; ++j) kk[j] = e8 <= j * 16 + gl ? 8u : 0u;
-		}
-		#pragma unroll
-		for (uint32_t step = 4; step >= 1; step >>= 1) {
-			uint32_t t[RB * 4];
 			#pragma unroll
-			for (uint32_t j = 0; j < RB * 4; ++j) t[j] = __shfl(ex, kk[j] + step, 16);
-			#pragma unroll
-			for (uint32_t j = 0; j < RB * 4; ++j) kk[j] += t[j] <= j * 16 + gl ? step : 0u;
+			for (uint32_t step = 4; step >= 1; step >>= 1) {
+				uint32_t t[RB * 4];
+				#pragma unroll
+				for (uint32_t j = 0; j < RB * 4; ++j) t[j] = __shfl(ex, kk[j] + step, 16);
+				#pragma unroll
+				for (uint32_t j = 0; j < RB * 4; ++j) kk[j] += t[j] <= j * 16 + gl ? step : 0u;
+			}
 		}
 		unsigned long long base[RB * 4];
 		#pragma unroll
@@ -1219,8 +1256,8 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		const uint32_t li = quad * 4 + g;
 		const bool live = li < n_list;
 		const uint2 hd = hd_c;
-		uint2 hd_nn, rg_nn;
-		fetch_hdr(quad + 2 * gridDim.x, hd_nn, rg_nn);
+		unsigned long long h_raw, r_raw;
+		fetch_hdr_issue(quad + 2 * gridDim.x, h_raw, r_raw);
 		uint32_t T1, ex1, nblk1; unsigned long long dl1;
 		const uint32_t n1 = start_stream(quad + gridDim.x, rg_n, T1, ex1, dl1, nblk1, raw, shf);
 		const uint32_t need = hd.x & 0xFFFFu, nwords = live ? hd.x >> 16 : 0u, len = hd.y & 0xFFFu;
@@ -1296,7 +1333,6 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 
 		PFM_T(0);
 		my_ent += n0;
-		PFM_T(6);
 		// ---- phase A over every record of the query
 		#pragma unroll
 		for (uint32_t b = 0; b < RB; ++b) if (b < nblk0) count4(rc[b]);
@@ -1327,77 +1363,99 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		__syncthreads();
 		PFM_T(3);
 		// ---- emit the lanes that reach the threshold, clear the tables
+		// Slot-parallel: lane gl of a group owns the group's gl-th used slot.  The positions of its tasks in the two staged lists
+		// come from ONE wave-wide prefix sum over the per-lane counts (DPP, no LDS round trip); the stores are fire-and-forget.
+		// A lane with c matching words lost (W_valid - c) words, one edit destroys at most `dper` of them: its edit distance
+		// is at least budget - (c - need) / dper.  Unless every hit within budget is wanted, only the lanes with the
+		// smallest bound are swept at once; the others wait for the minimum those produce (k_task_filter).
 		const uint32_t ovf = s_ovf[g];
-		if (live && !ovf) {
-			// A lane with c matching words lost (W_valid - c) words, one edit destroys at most `dper` of them: its edit distance
-			// is at least budget - (c - need) / dper.  Unless every hit within budget is wanted, only the lanes with the
-			// smallest bound are swept at once; the others wait for the minimum those produce (k_task_filter).
-			auto lanes_of = [&](uint32_t i, unsigned long long &lo, unsigned long long &hi) -> uint32_t {
-				lo = s_lc[g][i][0]; hi = s_lc[g][i][1];
-				uint32_t m16 = 0;
-				if (nwords < 128) {      // byte-parallel compare: (b | 0x80) - thr keeps its top bit iff b >= thr; top bits gathered by a multiply
-					const unsigned long long H = 0x8080808080808080ull, L1 = 0x0101010101010101ull, G = 0x0102040810204080ull;
-					const unsigned long long tl = ((lo | H) - thr * L1) & H, th = ((hi | H) - thr * L1) & H;
-					m16 = (uint32_t)(((tl >> 7) * G) >> 56) | ((uint32_t)(((th >> 7) * G) >> 56) << 8);
-				} else {
-					#pragma unroll
-					for (uint32_t z = 0; z < 16; ++z) m16 |= ((uint32_t)(((z < 8 ? lo : hi) >> (8 * (z & 7))) & 255u) >= thr ? 1u : 0u) << z;
-				}
-				return m16;
-			};
+		const bool em = live && !ovf;
+		const uint32_t nu = em ? nused : 0u;
+		const uint32_t nu_max = wave_max4(nu);
+		const uint32_t inv_dper = 65536u / dper + 1u;        // x / dper == (x * inv_dper) >> 16 for x < 256, dper < 16
+		auto lanes_ge = [&](unsigned long long lo, unsigned long long hi, uint32_t t) -> uint32_t {
+			uint32_t m16 = 0;
+			if (nwords < 128) {      // byte-parallel compare: (b | 0x80) - t keeps its top bit iff b >= t; top bits gathered by a multiply
+				const unsigned long long H = 0x8080808080808080ull, L1 = 0x0101010101010101ull, G = 0x0102040810204080ull;
+				const unsigned long long tl = ((lo | H) - t * L1) & H, th = ((hi | H) - t * L1) & H;
+				m16 = (uint32_t)(((tl >> 7) * G) >> 56) | ((uint32_t)(((th >> 7) * G) >> 56) << 8);
+			} else {
+				#pragma unroll
+				for (uint32_t z = 0; z < 16; ++z) m16 |= ((uint32_t)(((z < 8 ? lo : hi) >> (8 * (z & 7))) & 255u) >= t ? 1u : 0u) << z;
+			}
+			return m16;
+		};
+		auto look = [&](uint32_t iu, uint32_t &slot, uint32_t &c, unsigned long long &lo, unsigned long long &hi) -> uint32_t {
+			const bool has = iu < nu;
+			slot = has ? (uint32_t)s_used[g][iu] : 0u;
+			c = s_key[g][slot] - 1u; lo = s_lc[g][slot][0]; hi = s_lc[g][slot][1];
+			const uint32_t first = c * 16u, nv = first < tot_refs ? (tot_refs - first < 16u ? tot_refs - first : 16u) : 0u;     // lanes of the clump that exist
+			return has ? lanes_ge(lo, hi, thr) & ((1u << nv) - 1u) : 0u;
+		};
+		auto byte_of = [&](unsigned long long lo, unsigned long long hi, uint32_t z) -> uint32_t { return (uint32_t)((z < 8 ? lo : hi) >> (8u * (z & 7u))) & 255u; };
+		auto group_max = [&](uint32_t v) -> uint32_t {      // maximum over the 16 lanes of the group: neighbours, pairs of neighbours, then the two mirror moves
+			int t;
+			t = __builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;     // quad_perm:[1,0,3,2]
+			t = __builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;     // quad_perm:[2,3,0,1]
+			t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;    // row_half_mirror
+			t = __builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;    // row_mirror
+			return v;
+		};
+		uint32_t slot0, c0; unsigned long long lo0, hi0;
+		const uint32_t m16_0 = look(gl, slot0, c0, lo0, hi0);
+		uint32_t cmax_all = 0;
+		if (prune) {
 			uint32_t cmax = 0;
-			if (prune) {
-				for (uint32_t iu = gl; iu < nused; iu += 16) {
-					unsigned long long lo, hi;
-					const uint32_t i = s_used[g][iu], c = s_key[g][i] - 1u;
-					uint32_t m16 = lanes_of(i, lo, hi);
-					while (m16) {
-						const uint32_t z = (uint32_t)__builtin_ctz(m16);
-						m16 &= m16 - 1;
-						const uint32_t v = (uint32_t)(((z < 8 ? lo : hi) >> (8 * (z & 7))) & 255u);
-						if (c * 16 + z < tot_refs) cmax = v > cmax ? v : cmax;
-					}
-				}
+			for (uint32_t m = m16_0; m; m &= m - 1) { const uint32_t v = byte_of(lo0, hi0, (uint32_t)__builtin_ctz(m)); cmax = v > cmax ? v : cmax; }
+			for (uint32_t iu0 = 16; iu0 < nu_max; iu0 += 16) {
+				uint32_t sl, c; unsigned long long lo, hi;
+				for (uint32_t m = look(iu0 + gl, sl, c, lo, hi); m; m &= m - 1) { const uint32_t v = byte_of(lo, hi, (uint32_t)__builtin_ctz(m)); cmax = v > cmax ? v : cmax; }
 			}
-			uint32_t cmax_all = cmax;
-			{       // maximum over the 16 lanes of the group: neighbours, pairs of neighbours, then the two mirror moves
-				int t;
-				t = __builtin_amdgcn_update_dpp(0, (int)cmax_all, 0xB1, 0xF, 0xF, false); cmax_all = (uint32_t)t > cmax_all ? (uint32_t)t : cmax_all;     // quad_perm:[1,0,3,2]
-				t = __builtin_amdgcn_update_dpp(0, (int)cmax_all, 0x4E, 0xF, 0xF, false); cmax_all = (uint32_t)t > cmax_all ? (uint32_t)t : cmax_all;     // quad_perm:[2,3,0,1]
-				t = __builtin_amdgcn_update_dpp(0, (int)cmax_all, 0x141, 0xF, 0xF, false); cmax_all = (uint32_t)t > cmax_all ? (uint32_t)t : cmax_all;    // row_half_mirror
-				t = __builtin_amdgcn_update_dpp(0, (int)cmax_all, 0x140, 0xF, 0xF, false); cmax_all = (uint32_t)t > cmax_all ? (uint32_t)t : cmax_all;    // row_mirror
+			cmax_all = group_max(cmax);
+		}
+		PFM_T(1);
+		auto emit_slots = [&](uint32_t iu, uint32_t slot, uint32_t c, unsigned long long lo, unsigned long long hi, uint32_t m16) {
+			if (iu < nu) { s_key[g][slot] = 0; s_lc[g][slot][0] = 0; s_lc[g][slot][1] = 0; }     // (this wave's reads of the slot are done: LDS operations of one wave stay in order)
+			const uint32_t m0 = prune ? m16 & lanes_ge(lo, hi, cmax_all > thr ? cmax_all : thr) : m16, m1 = m16 & ~m0;
+			const uint32_t cnt = (uint32_t)__popc(m0) | (uint32_t)__popc(m1) << 16;
+			const uint32_t incl = wave_incl_scan_u32(cnt), tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), excl = incl - cnt;
+			if (!tot) return;                         // wave-uniform
+			const uint32_t tot0 = tot & 0xFFFFu, tot1 = tot >> 16;
+			uint32_t p[2]; bool direct[2];
+			#pragma unroll
+			for (uint32_t w = 0; w < 2; ++w) {
+				const uint32_t tw = w ? tot1 : tot0, ew = w ? excl >> 16 : excl & 0xFFFFu;
+				direct[w] = false;
+				if (tw && nst[w] + tw > CF_STAGE) flush_one(w);
+				if (tw > CF_STAGE) {                  // more than the stage holds in one go: straight to the list
+					uint32_t base = 0;
+					if (lane == 0) base = atomicAdd(w ? n_tasks2 : n_tasks, tw);
+					p[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + ew; direct[w] = true;
+				} else { p[w] = nst[w] + ew; nst[w] += tw; }
 			}
-			const uint32_t any_bad = n_bad;                 // BadList lanes carry no bound (0): they are always in the first sweep
-			for (uint32_t iu = gl; iu < nused; iu += 16) {
-				unsigned long long lo, hi;
-				const uint32_t i = s_used[g][iu], c = s_key[g][i] - 1u;
-				uint32_t m16 = lanes_of(i, lo, hi);
-				s_key[g][i] = 0; s_lc[g][i][0] = 0; s_lc[g][i][1] = 0;
-				(void)any_bad;
-				uint32_t any = 0;
-				while (m16) {
-					const uint32_t z = (uint32_t)__builtin_ctz(m16);
-					m16 &= m16 - 1;
-					const uint32_t refIx = c * 16 + z;
-					if (refIx >= tot_refs) continue;
-					uint32_t which = 0, lb = 0;
-					if (prune) {
-						const uint32_t v = (uint32_t)(((z < 8 ? lo : hi) >> (8 * (z & 7))) & 255u);
-						const uint32_t gain = (v - need) / dper;
-						lb = gain >= budget ? 0u : budget - gain;
-						which = v < cmax_all ? 1u : 0u;
-					}
-					push(which, li | lb << 24, refIx);
-					any = 1;
-				}
-				if (any) { ++my_units; my_cols += clump_len[c]; my_qlen += len; }
+			for (uint32_t m = m16; m; m &= m - 1) {
+				const uint32_t z = (uint32_t)__builtin_ctz(m), w = (m1 >> z) & 1u;
+				uint32_t lb = 0;
+				if (prune) { const uint32_t gain = ((byte_of(lo, hi, z) - need) * inv_dper) >> 16; lb = gain >= budget ? 0u : budget - gain; }
+				const uint2 task = make_uint2(li | lb << 24, c * 16u + z);
+				const uint32_t pos = p[w]; p[w] = pos + 1;
+				if (direct[w]) { if (pos < task_cap) (w ? tasks2 : tasks)[pos] = task; }
+				else s_stage[w][pos] = task;
 			}
-			for (uint32_t i = gl; i < n_bad; i += 16) {        // burst.c:4136-4138, 4282-4283: every lane of the ambiguous clumps
-				const uint32_t c = bad[i];
-				for (uint32_t z = 0; z < 16; ++z) if (c * 16 + z < tot_refs) push(0, li, c * 16 + z);
-				++my_units; my_cols += clump_len[c]; my_qlen += len;
-			}
-		} else if (ovf) {
+			if (m16) { ++my_units; my_qlen += len; }       // (the swept columns of lane tasks are counted by the sweep: tcol_sum)
+		};
+		emit_slots(gl, slot0, c0, lo0, hi0, m16_0);
+		for (uint32_t iu0 = 16; iu0 < nu_max; iu0 += 16) {
+			uint32_t sl, c; unsigned long long lo, hi;
+			const uint32_t m16 = look(iu0 + gl, sl, c, lo, hi);
+			emit_slots(iu0 + gl, sl, c, lo, hi, m16);
+		}
+		for (uint32_t i = 0; i < n_bad; ++i) {         // burst.c:4136-4138, 4282-4283: every lane of the ambiguous clumps
+			const uint32_t c = bad[i];
+			put_row(0, em && c * 16u + gl < tot_refs, li, c * 16u + gl);
+			if (em && gl == 0) { ++my_units; my_qlen += len; }
+		}
+		if (ovf) {
 			for (uint32_t i = gl; i < LT; i += 16) { s_key[g][i] = 0; s_lc[g][i][0] = 0; s_lc[g][i][1] = 0; }
 			if (live && gl == 0) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
 		}
@@ -1408,12 +1466,15 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		}
 		__syncthreads();
 		if (gl == 0) s_ovf[g] = 0;
-		if (s_nstage[0] >= CF_STAGE / 2 || s_nstage[1] >= CF_STAGE / 2) flush(); else __syncthreads();
+		__syncthreads();
 		PFM_T(5);
 		// rotate the pipeline
+		uint2 hd_nn, rg_nn;
+		fetch_hdr_finish(quad + 2 * gridDim.x, h_raw, r_raw, hd_nn, rg_nn);
 		hd_c = hd_n; hd_n = hd_nn; rg_n = rg_nn;
 		T0 = T1; ex0 = ex1; dl0 = dl1; nblk0 = nblk1; n0 = n1;
 		finish_stream(T0, raw, shf, rc);          // the records fetched during this iteration are first looked at here
+		PFM_T(6);
 	}
 	flush();
 #ifdef PFM_PROF
@@ -1421,7 +1482,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 #endif
 	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
 	if (surv_sum && my_surv) atomicAdd(surv_sum, my_surv);
-	if (n_list == 0xFFFFFFFFu) fb_list[0] = sink;       // never: keeps the record loads unconditional
+	if (n_list == 0xFFFFFFFFu) { fb_list[0] = sink; fb_list[1] = sink_h; }       // never: keeps the record loads unconditional
 	if (my_units) { atomicAdd(unit_sum, my_units); atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
 }
 #define BHIP_INST_PFCF(CB) \
