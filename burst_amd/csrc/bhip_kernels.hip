@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 	constexpr uint32_t NCNT = 1u << CB;                                   // approximate counters per query (16 bit each)
 	constexpr uint32_t LT = CB <= 9 ? 64u : (CB == 10 ? 128u : 256u);     // exact lane-table slots per query
 	constexpr uint32_t CF_STAGE = 64u;                                     // staged tasks per output list
-	constexpr uint32_t RING = 80u;                                         // >= 15 pending + 64 new survivors
+	constexpr uint32_t RING = 32u;                                         // >= 15 pending + 16 new survivors (the ring is drained after every 16 offered records); a power of two
 	__shared__ __attribute__((aligned(16))) uint32_t s_cnt[4][NCNT / 2];
 	__shared__ uint32_t s_key[4][LT];
 	__shared__ unsigned long long s_lc[4][LT][2];
@@ -1281,7 +1281,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		auto c_round = [&]() {                    // wave-uniform: every group moves up to 16 survivors into its lane table
 			const uint32_t take = pending < 16 ? pending : 16;
 			const bool active = gl < take;
-			uint32_t hpos = head + gl; hpos = hpos >= RING ? hpos - RING : hpos;
+			const uint32_t hpos = (head + gl) & (RING - 1);
 			const uint2 rec = active ? s_ring[g][hpos] : make_uint2(0, 0);
 			const uint32_t key = rec.x + 1u;
 			uint32_t slot = (rec.x * 0x85EBCA6Bu) >> (32 - (CB <= 9 ? 6 : (CB == 10 ? 7 : 8)));
@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 				if (mask & 0xFFu) atomicAdd(&s_lc[g][slot][0], spread8(mask & 0xFFu));
 				if (mask >> 8) atomicAdd(&s_lc[g][slot][1], spread8(mask >> 8));
 			}
-			head += take; head = head >= RING ? head - RING : head;
+			head = (head + take) & (RING - 1);
 			pending -= take;
 		};
 		auto offer4 = [&](const uint2 (&rec)[4]) {    // phase B: survivors of the counter test go to the ring
@@ -1321,14 +1321,13 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 				const uint32_t m16 = (uint32_t)(__ballot(surv) >> (lane & 48u)) & 0xFFFFu;
 				if (surv) {
 					uint32_t pos = head + pending + __popc(m16 & ((1u << gl) - 1u));
-					pos = pos >= RING ? pos - RING : pos;
-					pos = pos >= RING ? pos - RING : pos;
+					pos &= RING - 1;
 					s_ring[g][pos] = make_uint2(rec[u].x, rec[u].y & 0xFFFFu);
 				}
 				pending += __popc(m16);
 				if (gl == 0) my_surv += __popc(m16);
+				while (__any(pending >= 16)) c_round();       // (at most 15 + 16 pending: the ring holds 32)
 			}
-			while (__any(pending >= 16)) c_round();
 		};
 
 		PFM_T(0);
