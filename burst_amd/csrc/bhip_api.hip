@@ -210,7 +210,20 @@ struct Lane {
 	int pf_algo_used = 0;
 	int pf_algo = 0;              // algorithm of this lane's next prefilter launches (follows opt_pf_algo: -1 = adapt)
 	const uint32_t *qlist[kNumClasses] = {nullptr};      // (lane, class) lists of the current batch: entries of the slot's sorted index array
-	DBuf peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters, tasks, tasks2, tasks2k, wins2, ranges, hdr, rs_lists;
+	DBuf peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters, tasks, tasks2, tasks2k, wins2, rs_lists;
+	// seed lookups (k_seed_ranges) per class: list ranges + query headers for the prefilter.  They depend on the staged batch alone,
+	// so the lookups of batch k+1 run on the prefilter stream WHILE batch k is swept and re-scored (seed_ahead): memory-latency-bound
+	// work beside VALU-bound work.  seeded_* say which staged batch the buffers of a class hold.
+	DBuf ranges_c[kNumClasses], hdr_c[kNumClasses];
+	bool seeded_ok[kNumClasses] = {false};
+	uint64_t seeded_seq[kNumClasses] = {0};
+	uint32_t seeded_n[kNumClasses] = {0}, seeded_W16[kNumClasses] = {0};
+	hipEvent_t ev_seed[2][kNumClasses][2];   // [batch parity][class]: seed lookup start, done
+	// match profiles built ahead for the next staged batch (when it has a single class in this lane): swapped in by enqueue_lane
+	DBuf peq_alt, peqp_alt;
+	bool alt_ok = false; uint64_t alt_seq = 0; int alt_cls = 0, alt_nwp = 0; uint32_t alt_n = 0;
+	hipEvent_t ev_peq_alt[2], ev_peq_cur[2];  // profile build start, done: of the buffers built ahead / of the ones in use
+	bool peq_ahead[kNumClasses] = {false};    // this batch's profiles of the class came from the build ahead
 	uint64_t task_cap = 1 << 20;
 	uint64_t cand_cap = 1 << 18, raw_cap = 1 << 18, win_cap = 1 << 20, scratch_cap = 1 << 18;
 	uint32_t npf[kNumClasses] = {0}, nex[kNumClasses] = {0}, maxE[kNumClasses] = {0}, maxwords[kNumClasses] = {0}, maxlen = 0, n_entries = 0;
@@ -247,7 +260,7 @@ struct Handle {
 	bool has_masks = false;       // per-entry lane masks were built at upload (lane-resolved prefilter)
 	int opt_lane_masks = 1;       // use them
 	// staged batches: two slots, so that the upload and routing of batch k+1 (stage_stream) run while batch k is aligned
-	StageSlot slots[2];
+	StageSlot slots[3];                   // one batch being aligned, one staged (its seed lookups and profiles run ahead), one being staged
 	StageSlot *cur = &slots[0];           // slot of the batch being aligned
 	uint64_t stage_seq = 0;
 	hipStream_t stage_stream = nullptr;
@@ -285,6 +298,7 @@ struct Handle {
 	int opt_pf_algo = -1;         // 0 = counting filter + exact lane table (k_prefilter_cf), 1 = exact clump hash table in two passes
 	                              // (k_prefilter_mask), -1 = start with 0 and switch a lane to 1 when more than 20 % of its records survive the filter
 	int opt_pf_table = 0;         // log2 of the per-query hash table (0 = from the workload: 9, 10 or 11)
+	int opt_seed_ahead = 1;       // seed lookups of the next staged batch run while the current one is swept
 	double acx_wmean = 0.0;       // occurrence-weighted mean .acx list length
 };
 struct SharedCtr { uint32_t n_out, err; };
@@ -296,8 +310,14 @@ extern "C" int bhip_abi_version(void) { return BHIP_ABI_VERSION; }
 
 static void lane_destroy(Lane *L) {
 	if (!L) return;
-	DBuf *all[] = {&L->peq, &L->peqp, &L->cand, &L->candcnt, &L->wins, &L->raw, &L->wide, &L->scratch, &L->fb_list, &L->gcnt, &L->counters, &L->tasks, &L->tasks2, &L->tasks2k, &L->wins2, &L->ranges, &L->hdr, &L->rs_lists};
+	DBuf *all[] = {&L->peq, &L->peqp, &L->cand, &L->candcnt, &L->wins, &L->raw, &L->wide, &L->scratch, &L->fb_list, &L->gcnt, &L->counters, &L->tasks, &L->tasks2, &L->tasks2k, &L->wins2, &L->rs_lists};
 	for (DBuf *b : all) b->release();
+	L->peq_alt.release(); L->peqp_alt.release();
+	for (auto &e : L->ev_peq_alt) if (e) (void)hipEventDestroy(e);
+	for (auto &e : L->ev_peq_cur) if (e) (void)hipEventDestroy(e);
+	for (DBuf &b : L->ranges_c) b.release();
+	for (DBuf &b : L->hdr_c) b.release();
+	for (auto &pe : L->ev_seed) for (auto &ce : pe) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
 	for (auto &ce : L->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
 	for (auto &e : L->ev_rs) if (e) (void)hipEventDestroy(e);
 	for (auto &ce : L->ev_pf) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
@@ -308,12 +328,15 @@ static void lane_destroy(Lane *L) {
 
 static int lane_create(Handle *h, Lane **out) {
 	Lane *L = new Lane();
-	memset(L->ev_cls, 0, sizeof L->ev_cls); memset(L->ev_rs, 0, sizeof L->ev_rs); memset(L->ev_pf, 0, sizeof L->ev_pf); memset(L->ev_ph, 0, sizeof L->ev_ph);
+	memset(L->ev_cls, 0, sizeof L->ev_cls); memset(L->ev_rs, 0, sizeof L->ev_rs); memset(L->ev_pf, 0, sizeof L->ev_pf); memset(L->ev_ph, 0, sizeof L->ev_ph); memset(L->ev_seed, 0, sizeof L->ev_seed); memset(L->ev_peq_alt, 0, sizeof L->ev_peq_alt); memset(L->ev_peq_cur, 0, sizeof L->ev_peq_cur);
 	L->stream = h->stream;      // (the kernel-level entry points run a lane on the handle's own stream)
 	for (auto &ce : L->ev_cls) for (auto &e : ce) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
 	for (auto &e : L->ev_rs) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
 	for (auto &ce : L->ev_pf) for (auto &e : ce) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
 	for (auto &ce : L->ev_ph) for (auto &e : ce) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
+	for (auto &pe : L->ev_seed) for (auto &ce : pe) for (auto &e : ce) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
+	for (auto &e : L->ev_peq_alt) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
+	for (auto &e : L->ev_peq_cur) if (hipEventCreate(&e) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipEventCreate failed"); }
 	int rc = L->counters.reserve(sizeof(Counters));
 	if (rc) { lane_destroy(L); return rc; }
 	if (hipHostMalloc((void **)&L->hc_pinned, sizeof(Counters), hipHostMallocDefault) != hipSuccess) { lane_destroy(L); return fail(BHIP_E_DEVICE, "hipHostMalloc failed"); }
@@ -617,6 +640,7 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 	if (!strcmp(name, "sweep_blocks")) { if (value < 1 || value > 8) return fail(BHIP_E_ARG, "sweep_blocks must be 1 .. 8"); h->opt_sweep_blocks = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "lane_min_entries")) { if (value < 1) return fail(BHIP_E_ARG, "lane_min_entries must be >= 1"); h->opt_lane_min = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "async_d2h")) { h->opt_async_d2h = value != 0; return BHIP_OK; }
+	if (!strcmp(name, "seed_ahead")) { h->opt_seed_ahead = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "prune")) { h->opt_prune = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "rescore_reg")) { h->opt_rescore_reg = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_waves")) { if (value < 0 || value > 16) return fail(BHIP_E_ARG, "prefilter_waves must be 0 .. 16"); h->opt_pf_waves = (int)value; return BHIP_OK; }
@@ -797,19 +821,70 @@ static int launch_prefilter(Handle *h, Lane *L, hipStream_t pf_st, const uint32_
 }
 
 // lane-resolved prefilter: tasks (list position, reference lane) into L->tasks; queries whose table overflowed go through the
+// words per query row of the range table (8 when no query of the class samples more)
+static uint32_t seed_row_words(uint32_t maxwords) { return maxwords <= 8 ? 8u : std::max<uint32_t>(16u, (maxwords + 15u) & ~15u); }
+// prefix words of the two-stage sweep for a class (0 = one-stage sweep): about 6 prefix symbols per allowed edit, shorter than the query vector
+static int class_prefix_words(const Handle *h, uint32_t maxE, int NW) {
+	if (!h->opt_two_stage) return 0;
+	const uint32_t want = (6 * maxE + 31) / 32;
+	int NWP = want <= 1 ? 1 : (want <= 2 ? 2 : (want <= 3 ? 3 : (want <= 4 ? 4 : (want <= 6 ? 6 : 0))));
+	if (NWP >= NW) NWP = 0;
+	return NWP;
+}
+// match profiles (k_build_peq) of one (lane, class) list of staged batch S: full-length rows into `peq`, prefix rows into `peqp`
+static int launch_peq(Handle *h, hipStream_t st, StageSlot *S, const uint32_t *d_qlist, uint32_t n_list, int NW, int NWP, DBuf &peq, DBuf &peqp) {
+	int rc;
+	if ((rc = peq.reserve((size_t)n_list * 16 * NW * 4))) return rc;
+	if ((rc = peqp.reserve((size_t)n_list * 16 * 6 * 4))) return rc;
+	const bool junk = S->st_has_junk;
+	const uint8_t *codes = junk ? S->qcodes_s.as<uint8_t>() : S->qcodes.as<uint8_t>();
+	const uint64_t *off = junk ? S->qoff_s.as<uint64_t>() : S->qoff.as<uint64_t>();
+	const uint32_t *pack = junk ? S->qpack_s.as<uint32_t>() : S->qpack.as<uint32_t>();
+	{
+		const uint32_t qb = 256u / (uint32_t)NW;
+		const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + qb - 1) / qb, (uint64_t)h->n_cu * 16);
+		hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, st, codes, off, d_qlist, n_list, NW, 0, h->mm, peq.as<uint32_t>(), pack, (S->st_maxlen + 7) / 8);
+		HIPCHK(hipGetLastError());
+	}
+	if (NWP) {
+		const uint32_t qb = 256u / (uint32_t)NWP;
+		const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + qb - 1) / qb, (uint64_t)h->n_cu * 16);
+		hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, st, codes, off, d_qlist, n_list, NWP, 32 * NWP, h->mm, peqp.as<uint32_t>(), pack, (S->st_maxlen + 7) / 8);
+		HIPCHK(hipGetLastError());
+	}
+	return 0;
+}
+// k_seed_ranges for one (lane, class) list of staged batch S into the lane's per-class buffers
+static int launch_seed(Handle *h, Lane *L, hipStream_t st, StageSlot *S, int cls, const uint32_t *d_qlist, uint32_t n_list, uint32_t maxwords) {
+	int rc;
+	const uint32_t W16 = seed_row_words(maxwords);
+	L->seeded_ok[cls] = false;
+	if ((rc = L->ranges_c[cls].reserve((size_t)n_list * W16 * 8 + 16))) return rc;
+	if ((rc = L->hdr_c[cls].reserve((size_t)n_list * 8 + 16))) return rc;
+	const uint64_t n_thr = (uint64_t)n_list * W16;
+	hipEvent_t *ev = L->ev_seed[S->seq & 1][cls];
+	const bool junk = S->st_has_junk;
+	HIPCHK(hipEventRecord(ev[0], st));
+	hipLaunchKernelGGL(k_seed_ranges, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st,
+		junk ? S->qcodes_s.as<uint8_t>() : S->qcodes.as<uint8_t>(), junk ? S->qoff_s.as<uint64_t>() : S->qoff.as<uint64_t>(), d_qlist, n_list,
+		h->acx_view(), h->K, S->plan.as<uint32_t>(), W16, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(),
+		junk ? S->qpack_s.as<uint32_t>() : S->qpack.as<uint32_t>(), (S->st_maxlen + 7) / 8, junk ? S->qemac_s.as<uint16_t>() : S->qemac.as<uint16_t>());
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(ev[1], st));
+	L->seeded_ok[cls] = true; L->seeded_seq[cls] = S->seq; L->seeded_n[cls] = n_list; L->seeded_W16[cls] = W16;
+	return 0;
+}
+
 // dense clump-level kernels into L->cand as (list position, clump) pairs
 static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, const uint32_t *d_qlist, uint32_t n_list, uint32_t maxwords, uint32_t *n_tasks_dev,
                                  uint32_t *n_cand_dev, Counters *dc, int prune) {
 	int rc;
 	if ((rc = L->fb_list.reserve((size_t)n_list * 4 + 16))) return rc;
 	HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 4, st));
-	const uint32_t W16 = maxwords <= 8 ? 8u : std::max<uint32_t>(16u, (maxwords + 15u) & ~15u);   // words per query in the range table (8 when no query samples more)
-	if ((rc = L->ranges.reserve((size_t)n_list * W16 * 8 + 16))) return rc;
-	if ((rc = L->hdr.reserve((size_t)n_list * 8 + 16))) return rc;
-	const uint64_t n_thr = (uint64_t)n_list * W16;
-	HIPCHK(hipEventRecord(L->ev_pf[cls][0], st));
-	hipLaunchKernelGGL(k_seed_ranges, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, h->s_codes(), h->s_off(), d_qlist, n_list,
-		h->acx_view(), h->K, h->cur->plan.as<uint32_t>(), W16, L->ranges.as<uint2>(), L->hdr.as<uint2>(), h->s_pack(), (h->cur->st_maxlen + 7) / 8, h->s_emac());
+	const uint32_t W16 = seed_row_words(maxwords);
+	// the lookups of this batch may have run ahead (seed_next_batch, during the previous call)
+	if (!(L->seeded_ok[cls] && L->seeded_seq[cls] == h->cur->seq && L->seeded_n[cls] == n_list && L->seeded_W16[cls] == W16))
+		if ((rc = launch_seed(h, L, st, h->cur, cls, d_qlist, n_list, maxwords))) return rc;
 	const int algo = h->opt_pf_algo >= 0 ? h->opt_pf_algo : L->pf_algo;
 	const uint32_t n_quads = (n_list + 3) / 4;
 	// hash table size per query from the expected number of distinct clumps (sampled words x occurrence-weighted mean list
@@ -838,7 +913,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * waves);
 	HIPCHK(hipEventRecord(L->ev_pf[cls][1], st));
 	if (algo == 0) {
-#define PFC_LAUNCH(B) hipLaunchKernelGGL(k_prefilter_cf<B>, dim3(grid), dim3(64), 0, st, L->ranges.as<uint2>(), L->hdr.as<uint2>(), W16, n_list, \
+#define PFC_LAUNCH(B) hipLaunchKernelGGL(k_prefilter_cf<B>, dim3(grid), dim3(64), 0, st, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list, \
 		h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, \
 		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
 		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum, \
@@ -846,7 +921,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 		if (htb == 9) PFC_LAUNCH(9); else if (htb == 10) PFC_LAUNCH(10); else PFC_LAUNCH(11);
 #undef PFC_LAUNCH
 	} else {
-#define PFM_LAUNCH(B) hipLaunchKernelGGL(k_prefilter_mask<B>, dim3(grid), dim3(64), 0, st, L->ranges.as<uint2>(), L->hdr.as<uint2>(), W16, n_list, \
+#define PFM_LAUNCH(B) hipLaunchKernelGGL(k_prefilter_mask<B>, dim3(grid), dim3(64), 0, st, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list, \
 		h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, \
 		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
 		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, L->cand.as<uint2>(), n_cand_dev, (uint32_t)L->cand_cap)
@@ -1221,7 +1296,7 @@ extern "C" int bhip_stage_spans(void *handle, const BhipQuerySpan *spans, uint32
 	if (!h || (!spans && n_spans)) return fail(BHIP_E_ARG, "null argument");
 	HIPCHK(hipSetDevice(h->device));
 	StageSlot *S = free_slot(h);
-	if (!S) return fail(BHIP_E_ARG, "two batches are staged already: align one first");
+	if (!S) return fail(BHIP_E_ARG, "every staging slot holds a batch that has not been aligned yet: align one first");
 	S->state = 0;
 	int rc = stage_enqueue(h, S, spans, n_spans, nullptr, true, n_shared, max_len);
 	if (rc) return rc;
@@ -1278,7 +1353,8 @@ extern "C" int bhip_reserve(void *handle, uint32_t n_entries, uint32_t max_len) 
 	    (rc = L->rs_lists.reserve(L->raw_cap * sizeof(uint32_t) * 10)) || (rc = L->scratch.reserve(L->scratch_cap * sizeof(uint32_t))) || (rc = L->wins.reserve(L->win_cap * sizeof(BhipWin))) ||
 	    (rc = L->tasks.reserve(L->task_cap * sizeof(uint2))) || (rc = L->tasks2.reserve(L->task_cap * sizeof(uint2))) || (rc = L->tasks2k.reserve(L->task_cap * sizeof(uint2))) ||
 	    (rc = L->wins2.reserve(L->win_cap * sizeof(BhipWin))) || (rc = L->peq.reserve(n * 16 * kClasses[cls] * 4)) || (rc = L->peqp.reserve(n * 16 * 6 * 4)) ||
-	    (rc = L->fb_list.reserve(n * 4 + 16)) || (rc = L->ranges.reserve(n * 16 * 8 + 16)) || (rc = L->hdr.reserve(n * 8 + 16))) return rc;
+	    (rc = L->peq_alt.reserve(n * 16 * kClasses[cls] * 4)) || (rc = L->peqp_alt.reserve(n * 16 * 6 * 4)) ||
+	    (rc = L->fb_list.reserve(n * 4 + 16)) || (rc = L->ranges_c[cls].reserve(n * 16 * 8 + 16)) || (rc = L->hdr_c[cls].reserve(n * 8 + 16))) return rc;
 	if ((rc = h->best.reserve((n + 1) * 4)) || (rc = h->out.reserve(h->out_cap * sizeof(BhipHit))) || (rc = h->shared_ctr.reserve(sizeof(SharedCtr))) ||
 	    (rc = h->sort_idx.reserve(h->out_cap * 4)) || (rc = h->sort_keys.reserve((n + 1) * 4)) || (rc = h->sort_keys2.reserve((n + 1) * 4)) ||
 	    (rc = h->out_sorted.reserve(h->out_cap * sizeof(BhipHit))) || (rc = h->out_sorted2.reserve(h->out_cap * sizeof(BhipHit)))) return rc;
@@ -1384,10 +1460,6 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	if ((rc = L->tasks2.reserve(L->task_cap * sizeof(uint2)))) return rc;
 	if ((rc = L->tasks2k.reserve(L->task_cap * sizeof(uint2)))) return rc;
 	if ((rc = L->wins2.reserve(L->win_cap * sizeof(BhipWin)))) return rc;
-	for (int cls = 0; cls < kNumClasses; ++cls) if (L->npf[cls] + L->nex[cls]) {
-		if ((rc = L->peq.reserve((size_t)(L->npf[cls] + L->nex[cls]) * 16 * kClasses[cls] * 4))) return rc;
-		if ((rc = L->peqp.reserve((size_t)(L->npf[cls] + L->nex[cls]) * 16 * 6 * 4))) return rc;
-	}
 	hipStream_t pf = h->pf_stream, sw = h->sweep_stream, po = h->post_stream;
 	HIPCHK(hipMemsetAsync(L->counters.p, 0, sizeof(Counters), pf));
 	Counters *dc = L->counters.as<Counters>();
@@ -1405,28 +1477,15 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		// the lane's peq buffers are reused class after class: do not rebuild them before the previous class's window stage is done
 		// (the profiles are built on the sweep stream, which is idle while this class's seeds and prefilter run on theirs)
 		if (L->launches) { HIPCHK(hipStreamWaitEvent(pf, L->ev_rs[0], 0)); HIPCHK(hipStreamWaitEvent(sw, L->ev_rs[0], 0)); }
+		const int NWP = class_prefix_words(h, L->maxE[cls], NW);   // two-stage edit distance when a prefix of 32*NWP symbols is selective for this class's budgets
 		HIPCHK(hipEventRecord(ce[0], sw));
-		{
-			const uint32_t qb = 256u / (uint32_t)NW;
-			const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + qb - 1) / qb, (uint64_t)h->n_cu * 16);
-			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, sw, h->s_codes(), h->s_off(),
-				qlist, n_list, NW, 0, h->mm, L->peq.as<uint32_t>(), h->s_pack(), (h->cur->st_maxlen + 7) / 8);
-			HIPCHK(hipGetLastError());
-		}
-		// two-stage edit distance when a prefix of 32*NWP symbols is selective for this class's budgets
-		int NWP = 0;
-		if (h->opt_two_stage) {   // prefix of about 6 symbols per allowed edit, in words; must be shorter than the query vector to pay
-			const uint32_t mE = L->maxE[cls], want = (6 * mE + 31) / 32;
-			NWP = want <= 1 ? 1 : (want <= 2 ? 2 : (want <= 3 ? 3 : (want <= 4 ? 4 : (want <= 6 ? 6 : 0))));
-			if (NWP >= NW) NWP = 0;
-		}
-		if (NWP) {
-			const uint32_t qb = 256u / (uint32_t)NWP;
-			const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + qb - 1) / qb, (uint64_t)h->n_cu * 16);
-			hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, sw, h->s_codes(), h->s_off(),
-				qlist, n_list, NWP, 32 * NWP, h->mm, L->peqp.as<uint32_t>(), h->s_pack(), (h->cur->st_maxlen + 7) / 8);
-			HIPCHK(hipGetLastError());
-		}
+		L->peq_ahead[cls] = false;
+		if (L->alt_ok && L->alt_seq == h->cur->seq && L->alt_cls == cls && L->alt_n == n_list && L->alt_nwp == NWP && !L->launches) {
+			// built ahead during the previous batch (seed_next_batch): that batch is through, its profiles are not needed any more
+			std::swap(L->peq, L->peq_alt); std::swap(L->peqp, L->peqp_alt);
+			std::swap(L->ev_peq_cur[0], L->ev_peq_alt[0]); std::swap(L->ev_peq_cur[1], L->ev_peq_alt[1]);
+			L->alt_ok = false; L->peq_ahead[cls] = true;
+		} else if ((rc = launch_peq(h, sw, h->cur, qlist, n_list, NW, NWP, L->peq, L->peqp))) return rc;
 		L->prefix_words = (uint32_t)NWP;
 		HIPCHK(hipEventRecord(ce[1], sw));
 		HIPCHK(hipEventRecord(ce[7], pf));
@@ -1526,6 +1585,53 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	return 0;
 }
 
+// Seed lookups of the NEXT staged batch, enqueued on the prefilter stream behind the current batch's prefilter: they run
+// beside the current batch's sweeps and re-scoring (k_seed_ranges waits for HBM 70 % of its time and issues VALU work 6 % of
+// it; the sweeps are VALU-bound).  Called with the current batch fully enqueued; waits (host) for the staging of the next batch
+// or the end of the current one, whichever comes first.  Failures only mean the lookups run in place later.
+static void seed_next_batch(Handle *h, StageSlot *cur, hipEvent_t cur_done) {
+	if (!h->opt_seed_ahead || !h->has_acx || !h->has_masks || !h->opt_lane_masks || h->opt_host_routing) return;
+	StageSlot *N = nullptr;
+	for (StageSlot &S : h->slots) if (&S != cur && S.state == 1 && (!N || S.seq < N->seq)) N = &S;      // the batch that is aligned next
+	if (!N || !N->st_nq) return;
+	if (!N->resolved) {
+		for (;;) {
+			const hipError_t e = hipEventQuery(N->ev_done);
+			if (e == hipSuccess) break;
+			if (e != hipErrorNotReady) { (void)hipGetLastError(); return; }
+			if (hipEventQuery(cur_done) != hipErrorNotReady) { (void)hipGetLastError(); return; }      // the current batch is through: nothing left to hide behind
+			std::this_thread::yield();
+		}
+		(void)hipGetLastError();
+		const BhipStageInfo &I = *N->info_pinned;
+		if (I.err || I.junk) return;             // errors and the host routing pass are bhip_align_staged's business
+		if (resolve_slot(h, N)) return;
+	}
+	if (N->st_has_junk || ensure_lanes(h, N->st_lanes)) return;
+	for (uint32_t l = 0; l < N->st_lanes && l < h->lanes.size(); ++l) {
+		Lane *L = h->lanes[l];
+		for (int cls = 0; cls < kNumClasses; ++cls) {
+			const uint32_t n_pf = N->npf[l][cls];
+			if (!n_pf || !class_prefix_words(h, N->maxE[l][cls], kClasses[cls])) continue;      // (lane-resolved prefilter only)
+			if (L->seeded_ok[cls] && L->seeded_seq[cls] == N->seq) continue;
+			if (launch_seed(h, L, h->pf_stream, N, cls, N->idx_sorted.as<uint32_t>() + N->qlist_off[l][cls], n_pf, N->maxwords[l][cls])) { (void)hipGetLastError(); return; }
+		}
+		// the match profiles as well, when the lane has a single class (its two buffer pairs then simply alternate): built in place
+		// they would run beside the prefilter -- which no longer has its seed lookups in front -- and slow it down
+		int only = -1, n_cls = 0;
+		for (int cls = 0; cls < kNumClasses; ++cls) if (N->npf[l][cls] + N->nex[l][cls]) { only = cls; ++n_cls; }
+		if (n_cls == 1 && !(L->alt_ok && L->alt_seq == N->seq)) {
+			const uint32_t n_list = N->npf[l][only] + N->nex[l][only];
+			const int NW = kClasses[only], NWP = class_prefix_words(h, N->maxE[l][only], NW);
+			L->alt_ok = false;
+			if (hipEventRecord(L->ev_peq_alt[0], h->pf_stream) != hipSuccess ||
+			    launch_peq(h, h->pf_stream, N, N->idx_sorted.as<uint32_t>() + N->qlist_off[l][only], n_list, NW, NWP, L->peq_alt, L->peqp_alt) ||
+			    hipEventRecord(L->ev_peq_alt[1], h->pf_stream) != hipSuccess) { (void)hipGetLastError(); return; }
+			L->alt_ok = true; L->alt_seq = N->seq; L->alt_cls = only; L->alt_nwp = NWP; L->alt_n = n_list;
+		}
+	}
+}
+
 extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint64_t cap, uint64_t *n_hits) {
 	Handle *h = (Handle *)handle;
 	if (!h || !n_hits) return fail(BHIP_E_ARG, "null argument");
@@ -1563,7 +1669,10 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		HIPCHK(hipStreamWaitEvent(h->pf_stream, h->ev[1], 0));
 		HIPCHK(hipStreamWaitEvent(h->post_stream, h->ev[1], 0));
 		for (uint32_t l = 0; l < nl; ++l) if (h->lanes[l]->n_entries) if ((rc = enqueue_lane(h, h->lanes[l], all_hits, h->ev[1], band_rows, qw, rw))) return rc;
-		HIPCHK(hipStreamSynchronize(h->pf_stream));
+		HIPCHK(hipEventRecord(h->ev[2], h->pf_stream));          // this batch's share of the prefilter stream ends here
+		HIPCHK(hipEventRecord(h->ev[3], h->post_stream));
+		seed_next_batch(h, slot, h->ev[3]);
+		HIPCHK(hipEventSynchronize(h->ev[2]));
 		HIPCHK(hipStreamSynchronize(h->sweep_stream));
 		HIPCHK(hipStreamSynchronize(h->post_stream));
 		for (uint32_t l = 0; l < nl; ++l) if (h->lanes[l]->n_entries) h->lanes[l]->hc = *h->lanes[l]->hc_pinned;
@@ -1636,9 +1745,9 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 				S.n_pairs += c.n_cand_cls[cls]; S.n_windows += c.n_wins_cls[cls] + c.n_wins2_cls[cls]; S.n_lane_tasks += c.n_tasks_cls[cls] + c.n_tasks2k_cls[cls];
 				if (!(L->npf[cls] + L->nex[cls])) continue;
 				hipEvent_t *ce = L->ev_cls[cls];
-				S.ms_peq += ev_ms(ce[0], ce[1]);
+				S.ms_peq += L->peq_ahead[cls] ? ev_ms(L->ev_peq_cur[0], L->ev_peq_cur[1]) : ev_ms(ce[0], ce[1]);
 				if (L->npf[cls]) S.ms_prefilter += ev_ms(ce[7], ce[2]);
-				if (L->npf[cls] && L->pf_masked[cls]) { S.ms_seed += ev_ms(L->ev_pf[cls][0], L->ev_pf[cls][1]); S.ms_prefilter_hash += ev_ms(L->ev_pf[cls][1], L->ev_pf[cls][2]); S.n_seed_words += L->seed_words[cls]; }
+				if (L->npf[cls] && L->pf_masked[cls]) { { hipEvent_t *es = L->ev_seed[h->cur->seq & 1][cls]; S.ms_seed += ev_ms(es[0], es[1]); } S.ms_prefilter_hash += ev_ms(L->ev_pf[cls][1], L->ev_pf[cls][2]); S.n_seed_words += L->seed_words[cls]; }
 				float sweep = ev_ms(ce[6], ce[4]), win = ev_ms(ce[4], ce[5]);
 				if (L->pruned[cls]) { const float second = ev_ms(L->ev_ph[cls][0], L->ev_ph[cls][1]); sweep += second; win -= second; }   // filter + second task sweep sit between the two window launches
 				S.ms_myers += sweep + win;

@@ -372,7 +372,7 @@ print("ok")
 @pytest.mark.parametrize("junk", [False, True])
 def test_pipelined_spans_equal_one_call_batches(junk):
     """bhip_stage_spans: a batch = a span of forward entries + a span of their reverse complements, taken straight from the
-    caller's arrays (offsets that do not start at 0), staged asynchronously TWO batches ahead and routed by the device kernel
+    caller's arrays (offsets that do not start at 0), staged asynchronously two batches ahead and routed by the device kernel
     (k_route) -- every batch must give the oracle's records with the caller's query numbers, with device and host routing
     alike, also when one batch holds symbols of code 0 (the host pass takes over for that batch only)."""
     from burst_amd import capi
@@ -416,21 +416,25 @@ def test_pipelined_spans_equal_one_call_batches(junk):
         dev.set_option("host_routing", host_routing)
         for all_hits in (False, True):
             packed_upload[0] = all_hits != bool(host_routing)
+            # two batches ahead, as bh_align does: the seed lookups and profiles of batch k+1 run while batch k is aligned
             dev.stage_spans(spans_of(cuts[0], cuts[1]), cuts[1] - cuts[0], 150)
+            dev.stage_spans(spans_of(cuts[1], cuts[2]), cuts[2] - cuts[1], 0)
             total = 0
             for k in range(len(cuts) - 1):
-                if k + 2 < len(cuts):
-                    dev.stage_spans(spans_of(cuts[k + 1], cuts[k + 2]), cuts[k + 2] - cuts[k + 1], 0 if k % 2 else 150)      # one ahead
+                if k + 3 < len(cuts):
+                    dev.stage_spans(spans_of(cuts[k + 2], cuts[k + 3]), cuts[k + 3] - cuts[k + 2], 0 if k % 2 else 150)
                 got, _ = dev.align_staged(all_hits)
                 exp = expected(cuts[k], cuts[k + 1], all_hits)
                 assert got.tobytes() == exp.tobytes(), (host_routing, all_hits, k)
                 total += len(got)
             assert total > 100
-    # a third batch cannot be staged before one has been aligned
+    # three staging slots (one batch aligned, one staged with its seed lookups running ahead, one being staged): a fourth batch
+    # cannot be staged before one has been aligned
     dev.stage_spans(spans_of(0, 10), 10)
     dev.stage_spans(spans_of(10, 20), 10)
+    dev.stage_spans(spans_of(20, 30), 10)
     with pytest.raises(capi.BurstHipError):
-        dev.stage_spans(spans_of(20, 30), 10)
+        dev.stage_spans(spans_of(30, 40), 10)
     dev.set_option("discard_staged", 1)
     dev.close()
 
