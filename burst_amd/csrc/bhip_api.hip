@@ -68,11 +68,14 @@ template <int SET> __global__ void k_rescore_reg(const BhipRawHit *, const uint3
 // ---- ordering of the output records: (q, refIx) ascending, done on the device.  A query has one or two records, rarely
 // more, so a counting sort by query (rank inside the query from the counting atomic, offsets from one exclusive scan)
 // followed by a tiny in-place sort of the few multi-record groups replaces a 7-pass radix sort of 64-bit keys ----
-__global__ void k_hit_count(const BhipHit *__restrict__ hits, uint32_t n, uint32_t *__restrict__ cnt, uint32_t *__restrict__ rank) {
+// (n_dev: the record count still lives on the device -- the sort is enqueued behind the re-scorer before the host has seen it)
+__global__ void k_hit_count(const BhipHit *__restrict__ hits, uint32_t n, const uint32_t *__restrict__ n_dev, uint32_t *__restrict__ cnt, uint32_t *__restrict__ rank) {
+	if (n_dev) n = *n_dev < n ? *n_dev : n;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) rank[i] = atomicAdd(&cnt[hits[i].q], 1u);
 }
-__global__ void k_hit_scatter(const BhipHit *__restrict__ in, uint32_t n, const uint32_t *__restrict__ off, const uint32_t *__restrict__ rank,
+__global__ void k_hit_scatter(const BhipHit *__restrict__ in, uint32_t n, const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ off, const uint32_t *__restrict__ rank,
                               BhipHit *__restrict__ out, const uint32_t *__restrict__ qmap) {      // qmap: batch entry -> query number reported to the caller
+	if (n_dev) n = *n_dev < n ? *n_dev : n;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		BhipHit h = in[i];
 		const uint32_t dst = off[h.q] + rank[i];
@@ -1652,8 +1655,10 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 	uint32_t qw = (h->cur->st_maxlen + 7) / 8, rw = (h->cur->st_maxlen + band_rows + 24) / 8 + 2;
 	if ((size_t)(band_rows + 1 + qw + rw) * 256 > 40 * 1024) { qw = 0; rw = 0; }      // long queries: per-row global reads instead
 	SharedCtr hsc;
+	bool sorted_ahead = false; int o_ahead = 0;
 	for (int attempt = 0; attempt < 24; ++attempt) {
 		int rc;
+		sorted_ahead = false;
 		// the records of this batch are still resident when the previous call only failed for the size of the caller's buffer
 		if (h->res_valid && h->res_seq == slot->seq && h->res_all_hits == all_hits) { hsc.n_out = h->res_n; hsc.err = 0; h->stats = h->res_stats; *n_hits = hsc.n_out; }
 		else {
@@ -1670,6 +1675,34 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		HIPCHK(hipStreamWaitEvent(h->post_stream, h->ev[1], 0));
 		for (uint32_t l = 0; l < nl; ++l) if (h->lanes[l]->n_entries) if ((rc = enqueue_lane(h, h->lanes[l], all_hits, h->ev[1], band_rows, qw, rw))) return rc;
 		HIPCHK(hipEventRecord(h->ev[2], h->pf_stream));          // this batch's share of the prefilter stream ends here
+		// the records are grouped by query (counting sort) right behind the re-scorer, with the record count read on the device: no
+		// host round trip between the two.  Set aside when a lane needs the wide-band re-scorer afterwards (sorted again then).
+		sorted_ahead = false;
+		{
+			const bool async = h->opt_async_d2h && hits;
+			o_ahead = async ? (h->out_idx ^ 1) : 0;
+			DBuf &sorted = o_ahead ? h->out_sorted2 : h->out_sorted;
+			size_t tmp_bytes = 0;
+			uint32_t *cnt = nullptr, *off = nullptr, *rank = nullptr;
+			if ((rc = h->sort_idx.reserve((size_t)h->out_cap * 4)) || (rc = h->sort_keys.reserve((size_t)(n_q + 1) * 4)) || (rc = h->sort_keys2.reserve((size_t)(n_q + 1) * 4)) ||
+			    (rc = sorted.reserve((size_t)h->out_cap * sizeof(BhipHit)))) return rc;
+			cnt = h->sort_keys.as<uint32_t>(); off = h->sort_keys2.as<uint32_t>(); rank = h->sort_idx.as<uint32_t>();
+			HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, off, (int)(n_q + 1), h->post_stream));
+			if ((rc = h->sort_tmp.reserve(tmp_bytes))) return rc;
+			SharedCtr *sc = h->shared_ctr.as<SharedCtr>();
+			const uint32_t g = (uint32_t)h->n_cu * 8;
+			if (h->copy_pending[o_ahead]) HIPCHK(hipStreamWaitEvent(h->post_stream, h->ev_copied[o_ahead], 0));      // the copy that last read this buffer
+			HIPCHK(hipEventRecord(h->ev[4], h->post_stream));
+			HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(n_q + 1) * 4, h->post_stream));
+			hipLaunchKernelGGL(k_hit_count, dim3(g), dim3(256), 0, h->post_stream, h->out.as<BhipHit>(), (uint32_t)h->out_cap, &sc->n_out, cnt, rank);
+			HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->sort_tmp.p, tmp_bytes, cnt, off, (int)(n_q + 1), h->post_stream));
+			hipLaunchKernelGGL(k_hit_scatter, dim3(g), dim3(256), 0, h->post_stream, h->out.as<BhipHit>(), (uint32_t)h->out_cap, &sc->n_out, off, rank, sorted.as<BhipHit>(),
+				h->cur->has_qmap ? h->cur->qmap.as<uint32_t>() : (const uint32_t *)nullptr);
+			hipLaunchKernelGGL(k_hit_fix, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, h->post_stream, sorted.as<BhipHit>(), off, cnt, n_q);
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipEventRecord(h->ev[5], h->post_stream));
+			sorted_ahead = true;
+		}
 		HIPCHK(hipEventRecord(h->ev[3], h->post_stream));
 		seed_next_batch(h, slot, h->ev[3]);
 		HIPCHK(hipEventSynchronize(h->ev[2]));
@@ -1711,6 +1744,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		for (uint32_t l = 0; l < nl; ++l) {
 			Lane *L = h->lanes[l];
 			if (!L->n_entries || !L->hc.n_wide) continue;
+			sorted_ahead = false;                  // more records are on their way
 			Counters *dc = L->counters.as<Counters>();
 			SharedCtr *sc = h->shared_ctr.as<SharedCtr>();
 			hipLaunchKernelGGL(k_rescore<true>, dim3(std::min<uint32_t>((L->hc.n_wide + 63) / 64, (uint32_t)h->n_cu * 16)), dim3(64), 256, h->post_stream,
@@ -1772,21 +1806,24 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			const bool async = h->opt_async_d2h && hits;
 			const int o = async ? (h->out_idx ^= 1) : 0;
 			DBuf &sorted = o ? h->out_sorted2 : h->out_sorted;
+			if (sorted_ahead && o == o_ahead) tq1 = tq();          // grouped already, behind the re-scorer
+			else {
 			if (h->copy_pending[o]) { HIPCHK(hipEventSynchronize(h->ev_copied[o])); h->copy_pending[o] = false; }    // the copy that last read this buffer
 			if ((rc = sorted.reserve((size_t)n * sizeof(BhipHit)))) return rc;
 			uint32_t *cnt = h->sort_keys.as<uint32_t>(), *off = h->sort_keys2.as<uint32_t>(), *rank = h->sort_idx.as<uint32_t>();
 			const uint32_t g = std::min<uint32_t>((n + 255) / 256, (uint32_t)h->n_cu * 8);
 			HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(n_q + 1) * 4, h->stream));
 			tq1 = tq();
-			hipLaunchKernelGGL(k_hit_count, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, cnt, rank);
+			hipLaunchKernelGGL(k_hit_count, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, (const uint32_t *)nullptr, cnt, rank);
 			size_t tmp_bytes = 0;
 			HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, off, (int)(n_q + 1), h->stream));
 			if ((rc = h->sort_tmp.reserve(tmp_bytes))) return rc;
 			HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->sort_tmp.p, tmp_bytes, cnt, off, (int)(n_q + 1), h->stream));
-			hipLaunchKernelGGL(k_hit_scatter, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, off, rank, sorted.as<BhipHit>(),
+			hipLaunchKernelGGL(k_hit_scatter, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, (const uint32_t *)nullptr, off, rank, sorted.as<BhipHit>(),
 				h->cur->has_qmap ? h->cur->qmap.as<uint32_t>() : (const uint32_t *)nullptr);
 			hipLaunchKernelGGL(k_hit_fix, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, h->stream, sorted.as<BhipHit>(), off, cnt, n_q);
 			HIPCHK(hipGetLastError());
+			}
 			tq2 = tq();
 			const size_t bytes = (size_t)n * sizeof(BhipHit);
 			bool queued = false;
@@ -1826,7 +1863,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		HIPCHK(hipEventRecord(h->ev[9], h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		if (dbg_t) fprintf(stderr, "[bhip] delivery host ms: reserve+memset %.3f, sort launches %.3f, pointer check %.3f, copy enqueue %.3f, sync %.3f\n", tq1, tq2 - tq1, tq3 - tq2, tq4 - tq3, tq() - tq4);
-		S.ms_h2d = h->cur->st_ms_h2d; S.ms_d2h = ev_ms(h->ev[8], h->ev[9]); S.ms_total = ev_ms(h->ev[0], h->ev[9]);
+		S.ms_h2d = h->cur->st_ms_h2d; S.ms_d2h = ev_ms(h->ev[8], h->ev[9]) + (sorted_ahead ? ev_ms(h->ev[4], h->ev[5]) : 0.0f); S.ms_total = ev_ms(h->ev[0], h->ev[9]);
 		slot->state = 2;
 		h->res_valid = false;
 		return BHIP_OK;
