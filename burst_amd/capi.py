@@ -87,6 +87,8 @@ def _load():
     lib.bhip_abi_version.argtypes = []
     lib.bhip_abi_version.restype = i32
     lib.bhip_stage_spans.argtypes = [vp, C.POINTER(BhipQuerySpan), u32, u32, u32]
+    lib.bhip_reserve.argtypes = [vp, u32, u32]
+    lib.bhip_reserve.restype = i32
     lib.bhip_stage_spans.restype = i32
     lib.bhip_alloc_host.argtypes = [u64]
     lib.bhip_alloc_host.restype = vp
@@ -177,6 +179,11 @@ class Device:
 
     def set_option(self, name, value):
         _chk(lib().bhip_set_option(self._h, name.encode(), int(value)))
+
+    def reserve(self, n_entries, max_len):
+        """bhip_reserve: size the device buffers for batches of n_entries query entries of at most max_len symbols and run the
+        library's warm-up pass (what the burst_hip command line does once per job, before the search phase)"""
+        _chk(lib().bhip_reserve(self._h, int(n_entries), int(max_len)))
 
     def stats(self, raw=False):
         """statistics of the last call (raw=True: the ctypes struct, no dict -- for timed loops)"""

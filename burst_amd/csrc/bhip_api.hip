@@ -1401,13 +1401,28 @@ extern "C" int bhip_reserve(void *handle, uint32_t n_entries, uint32_t max_len) 
 		(void)bhip_sync_hits(h);
 		{	// the first LARGE asynchronous copy in each direction takes another path through the runtime than the small ones above
 			// and blocks its caller for ~19 ms once per process (measured in front of the first 43 MB hand-over copy): make it here
-			const size_t big = std::min<size_t>(64u << 20, h->out_sorted.cap);
+			// ... and so does the first copy that is enqueued while another one is still in flight on the same stream (measured: 16 ms in
+			// front of the second hand-over copy of a process): two of each, back to back
+			const size_t big = std::min<size_t>(64u << 20, std::min(h->out_sorted.cap, h->out_sorted2.cap));
 			void *tmp = nullptr;
-			if (big && hipHostMalloc(&tmp, big, hipHostMallocPortable) == hipSuccess) {
+			if (big && hipHostMalloc(&tmp, 2 * big, hipHostMallocPortable) == hipSuccess) {
+				(void)hipMemcpyAsync(tmp, h->out_sorted.p, big, hipMemcpyDeviceToHost, h->copy_stream);
+				(void)hipMemcpyAsync((char *)tmp + big, h->out_sorted2.p, big, hipMemcpyDeviceToHost, h->copy_stream);
 				(void)hipMemcpyAsync(tmp, h->out_sorted.p, big, hipMemcpyDeviceToHost, h->copy_stream);
 				(void)hipStreamSynchronize(h->copy_stream);
 				(void)hipMemcpyAsync(h->out_sorted.p, tmp, big, hipMemcpyHostToDevice, h->stage_stream);
+				(void)hipMemcpyAsync(h->out_sorted2.p, (char *)tmp + big, big, hipMemcpyHostToDevice, h->stage_stream);
+				(void)hipMemcpyAsync(h->out_sorted.p, tmp, big, hipMemcpyHostToDevice, h->stage_stream);
 				(void)hipStreamSynchronize(h->stage_stream);
+				// ... and a hand-over copy enqueued while the staging copies of two batches are still queued (15-17 ms once, measured
+				// in front of the second batch's hand-over of the first call that stages two batches ahead)
+				const size_t piece = big / 16;
+				if (piece) {
+					for (int i = 0; i < 12; ++i) (void)hipMemcpyAsync((char *)h->out_sorted.p + (size_t)i * piece, (char *)tmp + (size_t)i * piece, piece, hipMemcpyHostToDevice, h->stage_stream);
+					(void)hipMemcpyAsync((char *)tmp + big, h->out_sorted2.p, big, hipMemcpyDeviceToHost, h->copy_stream);
+					(void)hipStreamSynchronize(h->copy_stream);
+					(void)hipStreamSynchronize(h->stage_stream);
+				}
 				(void)hipHostFree(tmp);
 			}
 			(void)hipGetLastError();
@@ -1433,6 +1448,19 @@ extern "C" void *bhip_alloc_host(uint64_t bytes) {
 		(void)hipMemcpyAsync(p, d, bytes < 64 ? bytes : 64, hipMemcpyDeviceToHost, st);
 		(void)hipMemcpyAsync(d, p, bytes < 64 ? bytes : 64, hipMemcpyHostToDevice, st);
 		(void)hipStreamSynchronize(st);
+		// ... and so do the first query of the allocation's attributes (15-29 ms: bhip_align_staged asks whether its record buffer is
+		// page-locked) and the first copy to an address INSIDE the allocation (10-16 ms, measured in front of the second batch's
+		// hand-over copy): both here, once
+		hipPointerAttribute_t at;
+		memset(&at, 0, sizeof at);
+		(void)hipPointerGetAttributes(&at, p);
+		if (bytes > 4096) {
+			char *mid = (char *)p + ((bytes / 2) & ~(uint64_t)63);
+			(void)hipPointerGetAttributes(&at, mid);
+			(void)hipMemcpyAsync(mid, d, 64, hipMemcpyDeviceToHost, st);
+			(void)hipMemcpyAsync(d, mid, 64, hipMemcpyHostToDevice, st);
+			(void)hipStreamSynchronize(st);
+		}
 	}
 	(void)hipGetLastError();
 	if (st) (void)hipStreamDestroy(st);
