@@ -125,8 +125,8 @@ def pmc_table():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=2000000, help="reads per step (whole job, all GPUs together)")
     ap.add_argument("--pool", type=int, default=4, help="distinct batches the steps cycle through")
     ap.add_argument("--read-len", type=int, default=100)
@@ -287,6 +287,8 @@ def main():
             pk = pmc_of(k)
             if pk.get("hbm_bytes_per_launch") is not None:
                 e["traffic"] = pk["hbm_bytes_per_launch"]
+                if v[2] == "hbm" and pk.get("hbm_bytes_per_launch_gather_calibrated"):      # sector gathers: profiles/r02k_fetch_calibration.txt
+                    e["traffic_gather_calibrated"] = pk["hbm_bytes_per_launch_gather_calibrated"]
             if pk.get("valu_frac") is not None:
                 e["valu_frac"] = pk["valu_frac"]
             per_kernel[k] = e
@@ -303,7 +305,7 @@ def main():
                                    % (world, args.reads, args.read_len, args.mode, args.id, args.n_base * args.n_variants, args.ref_len,
                                       args.n_base * args.n_variants * args.ref_len / 1e9, db.c.numRclumps, edx_bytes / 1e9, args.K, acx_bytes / 1e9),
                        "parallelism": "query-sharded x%d, DB replicated, one RCCL gather of hit records" % world,
-                       "timed_region": "bh_align_ranges over %d batches (copies + device routing one batch ahead, alignment, records to host memory)%s" % (nb, " + RCCL gather" if use_dist else ""),
+                       "timed_region": "bh_align_ranges over %d batches (copies + device routing two batches ahead, seed lookups + profiles one batch ahead, alignment, records to host memory)%s" % (nb, " + RCCL gather" if use_dist else ""),
                        "extrapolation": {"metric_database": "31.5 GB RefSeq .edx", "this_edx_bytes": edx_bytes, "size_ratio": scale_to_metric,
                                          "acx_records_per_read_here": st["acx_entries_read"] / max(1.0, float(st["n_queries"])),
                                          "note": "K = 15 lists grow linearly with the database: about size_ratio x the records per read at the metric's size; "
@@ -311,8 +313,9 @@ def main():
                        "device": info["name"], "n_cu": info["n_cu"]},
             "roofline": {"bound": "hbm" if bound_dom == "hbm" else "valu", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": pmc_of(dom).get("hbm_bytes_per_launch"),
+                         "traffic_gather_calibrated": pmc_of(dom).get("hbm_bytes_per_launch_gather_calibrated") if bound_dom == "hbm" else None,
                          "note": "dominant kernel by time (HIP events on its stream); per_kernel gives each kernel's own bound: the prefilter and the re-scorer are "
-                                 "bound by HBM/LDS latency of short gathers, the k_myers_* sweeps by integer VALU issue (valu_frac = issued VALU cycles / peak, from the PMC pass)",
+                                 "bound by HBM/LDS latency of short gathers, the k_myers_* sweeps by integer VALU issue (valu_frac = issued VALU instructions x 2 cycles / peak, from the PMC pass; half-rate VOP3 forms count once). traffic follows the guide's 2 x FETCH_SIZE rule; traffic_gather_calibrated = FETCH_SIZE + WRITE_SIZE, which is what a sector gather really moves (profiles/r02k_fetch_calibration.txt)",
                          "algorithmic_bytes_per_launch": bytes_dom, "ms_per_launch": ms_dom,
                          "per_kernel": per_kernel,
                          "gcups_sweeps": cells / (ms_sweeps * 1e-3) / 1e9 if ms_sweeps > 0 else 0.0},

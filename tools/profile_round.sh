@@ -39,6 +39,8 @@ for k in sorted(fa, key=lambda k: -fa[k].get('FETCH_SIZE', 0)):
     lines.append('%-50s dispatches %5d FETCH_SIZE_KB %14.1f WRITE_SIZE_KB %14.1f  hbm_bytes/launch (2*fetch+write) %14.0f' % (k, n, fetch_kb, write_kb, hbm))
     if k.replace('void ', '').split('<')[0] in traffic: continue      # template variants share a name: sorted by bytes, the heaviest is first
     traffic[k.replace('void ', '').split('<')[0]] = {"kernel": k, "dispatches": n, "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB_raw": write_kb, "hbm_bytes_per_launch": hbm,
+        "hbm_bytes_per_launch_gather_calibrated": (fetch_kb * 1024 + write_kb * 1024) / n,
+        "gather_note": "for kernels whose reads are random 64-byte sectors (k_seed_ranges, k_prefilter_cf, k_rescore_*) FETCH_SIZE already counts the full bytes (profiles/r02k_fetch_calibration.txt: ratio 1.00 on a kernel with known traffic): fetch + write without the factor 2",
         "correction": "gfx950: FETCH_SIZE reports half the bytes of a coalesced read stream (MI355X_MICROARCH.md, HBM section): fetch bytes = 2 * FETCH_SIZE KB * 1024; WRITE_SIZE as reported"}
 lines.append('')
 for k in sorted(sa, key=lambda k: -sa[k].get('SQ_WAVE_CYCLES', 0)):
