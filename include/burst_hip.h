@@ -55,7 +55,7 @@ typedef struct BhipHit {
 typedef struct BhipStats {
 	uint64_t n_queries;        /* query entries in the call */
 	uint64_t n_pairs;          /* (query, clump) units of work aligned */
-	uint64_t n_columns;        /* sum over pairs of ClumpLen: DP columns swept (x16 lanes x qlen rows of cells) */
+	uint64_t n_columns;        /* sum over clump-level pairs of ClumpLen: DP columns swept (x16 lanes x qlen rows of cells); lane tasks: n_task_columns */
 	uint64_t n_raw_hits;       /* (query, ref) lanes with ed <= budget */
 	uint64_t n_hits;           /* records returned */
 	uint64_t acx_entries_read; /* list entries gathered by the prefilter */
@@ -123,9 +123,11 @@ int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint64_t cap, u
  * unique queries [u, u+B) is two spans), so nothing is gathered on the host.  Entry j of EVERY span shares slot j (a forward
  * entry and its reverse complement: UniBin.six, burst.c:3106) and is reported as BhipHit.q = q_base + j.
  * The call only ENQUEUES the copies and the device-side routing (length classes, prefilter / exhaustive route, seed plans)
- * on the library's staging stream and returns; the arrays must stay valid until the batch has been aligned.  Two batches
- * can be staged at a time; bhip_align_staged always takes the oldest one that has not been aligned yet (and, when none
- * is waiting, runs the last one again).  Page-locked arrays (bhip_alloc_host / bhip_host_register) make the copies
+ * on the library's staging stream and returns; the arrays must stay valid until the batch has been aligned.  Three staging
+ * slots: beside the batch being aligned, two more can be staged; bhip_align_staged always takes the oldest one that has
+ * not been aligned yet (and, when none is waiting, runs the last one again).  With a batch staged AHEAD of the one being
+ * aligned -- a caller that stages two batches ahead, as bh_align_ranges does -- the library runs that batch's seed lookups
+ * and match profiles beside the current batch's sweeps (option "seed_ahead", default 1).  Page-locked arrays (bhip_alloc_host / bhip_host_register) make the copies
  * asynchronous; pageable ones work too.  max_len = an upper bound of the entry lengths (0 = computed from the offsets). */
 typedef struct BhipQuerySpan {
 	const uint8_t  *codes;   /* symbol codes; entry j = codes[off[j] .. off[j+1]) */
@@ -201,7 +203,8 @@ int bhip_sync_hits(void *handle);
  * "rescore_reg": 1 (default) = register-band re-scorer for narrow bands, 0 = LDS band only.
  * "host_routing": 0 (default) = batches are routed (length classes, seed plans, lists) by a device kernel, 1 = by the host pass
  * that otherwise only handles batches with query symbols outside the alphabet.  "discard_staged": forget batches that were
- * staged and not aligned (after an error).
+ * staged and not aligned (after an error).  "seed_ahead": 1 (default) = the seed lookups and match profiles of the next staged
+ * batch run while the current one is swept, 0 = in place.
  * None of these changes a result. */
 int bhip_set_option(void *handle, const char *name, long long value);
 
