@@ -279,6 +279,16 @@ def main():
         ms_dom, bytes_dom, bound_dom = kernels[dom]
         achieved = bytes_dom / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
         pmc = pmc_table()
+        try:
+            mix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "valu_mix.json")))
+        except Exception:
+            mix = {}
+        def valu_weight(kname):
+            base = kname.split("<")[0].replace("_*", "_reg")
+            for mk, mv in mix.items():
+                if mk.split("<")[0] == base:
+                    return mv.get("weight")
+            return None
         def pmc_of(kname):
             return pmc.get(kname.split("<")[0].replace("_*", "_reg"), {})
         per_kernel = {}
@@ -291,6 +301,9 @@ def main():
                     e["traffic_gather_calibrated"] = pk["hbm_bytes_per_launch_gather_calibrated"]
             if pk.get("valu_frac") is not None:
                 e["valu_frac"] = pk["valu_frac"]
+                w = valu_weight(k)
+                if w:      # tools/valu_mix.py: half-rate VOP3 forms cost two issue slots, and the clock under load is 2.05 GHz
+                    e["valu_issue_frac"] = pk["valu_frac"] * w
             per_kernel[k] = e
         cells = (st["n_task_columns"] if masked else st["n_columns"] * 16.0) * min(args.read_len, 32.0 * max(1, st["prefix_words"])) + st["n_window_columns"] * float(args.read_len)
         ms_sweeps = st["ms_myers"]
