@@ -43,7 +43,7 @@ class BhipQuerySpan(C.Structure):
 
 EXPORTS = ["bhip_init", "bhip_stage_queries", "bhip_align_staged", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_set_option", "bhip_get_stats",
            "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version", "bhip_copy_hits_device", "bhip_sync_hits",
-           "bhip_comm_create", "bhip_comm_gather_hits", "bhip_comm_destroy", "bhip_reserve", "bhip_stage_spans", "bhip_alloc_host", "bhip_free_host", "bhip_host_register", "bhip_host_unregister"]
+           "bhip_comm_create", "bhip_comm_gather_hits", "bhip_comm_destroy", "bhip_reserve", "bhip_sort_queries", "bhip_stage_spans", "bhip_alloc_host", "bhip_free_host", "bhip_host_register", "bhip_host_unregister"]
 
 
 class BurstHipError(RuntimeError):

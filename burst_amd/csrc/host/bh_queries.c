@@ -68,6 +68,9 @@ static int slurp_queries(const char *path, char **out, uint64_t *out_sz) {
  * the loop (measured on 2 x EPYC 9575F: 0.84 s with all 256 threads) */
 static int bh_ingest_threads(void) { const int n = omp_get_max_threads(); return n > 32 ? 32 : n; }
 
+static int g_sort_device = 0;          /* device of the query sort (bhip_sort_queries); < 0 = host sort */
+void bh_queries_sort_device(int device) { g_sort_device = device; }
+
 static int qref_cmp(const void *a, const void *b) {
 	const QRef *A = a, *B = b;
 	uint32_t n = A->len < B->len ? A->len : B->len;
@@ -181,17 +184,41 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 		return bh_set_error(BH_E_USAGE, "ERROR: query of %u symbols exceeds the device limit of %d", maxLen, BHIP_MAX_QLEN);
 	}
 	QPH("translate");
-	int rc = sort_qrefs(refs, totQ);
-	QPH("sort");
-	if (rc) { free(heads); free(refs); bh_queries_free(Q); return rc; }
-	/* uniqueness (burst.c:3036-3053) */
 	uint64_t numUniq = 0;
 	uint8_t *isNew = malloc(totQ + 1);            /* 1 where a sorted record differs from its predecessor */
 	if (!isNew) { free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_OOM, "OOM:dedupe"); }
+	int rc = 0, on_device = 0;
+	/* Large inputs: sort and duplicate marking on the device (bhip_sort_queries: LSD radix sort over 16-symbol keys; the same
+	 * order as qref_cmp).  It runs before the database is uploaded, on the device the search will use.  Small inputs, and
+	 * hosts told so (BURST_HOST_SORT=1 / bh_queries_sort_device(-1)), take the host path below. */
+	if (totQ >= (1u << 18) && totQ < 0x7FFFFFFFull && g_sort_device >= 0 && !getenv("BURST_HOST_SORT")) {
+		uint64_t *start = malloc(totQ * sizeof(*start));
+		uint32_t *lens = malloc(totQ * sizeof(*lens)), *perm = malloc(totQ * sizeof(*perm));
+		QRef *tmp = malloc(totQ * sizeof(*tmp));
+		if (start && lens && perm && tmp) {
+			#pragma omp parallel for num_threads(bh_ingest_threads())
+			for (uint64_t i = 0; i < totQ; ++i) { start[i] = (uint64_t)((char *)refs[i].s - dump); lens[i] = refs[i].len; }
+			if (!bhip_sort_queries(g_sort_device, (const uint8_t *)dump, sz, start, lens, totQ, maxLen, perm, isNew)) {
+				#pragma omp parallel for num_threads(bh_ingest_threads()) reduction(+:numUniq)
+				for (uint64_t i = 0; i < totQ; ++i) { tmp[i] = refs[perm[i]]; numUniq += isNew[i]; }
+				{ QRef *t = refs; refs = tmp; tmp = t; }          /* the permuted table is the table from here on */
+				on_device = 1;
+			} else if (dbg) fprintf(stderr, "[bh_queries] device sort not available (%s): sorting on the host\n", bhip_last_error());
+		}
+		free(start); free(lens); free(perm); free(tmp);
+		QPH("sort + duplicates (device)");
+	}
+	if (!on_device) {
+	rc = sort_qrefs(refs, totQ);
+	QPH("sort");
+	if (rc) { free(isNew); free(heads); free(refs); bh_queries_free(Q); return rc; }
+	/* uniqueness (burst.c:3036-3053) */
+	numUniq = 0;
 	#pragma omp parallel for num_threads(bh_ingest_threads()) reduction(+:numUniq) schedule(static)
 	for (uint64_t i = 0; i < totQ; ++i) {
 		isNew[i] = !i || refs[i].len != refs[i - 1].len || memcmp(refs[i].s, refs[i - 1].s, refs[i].len);
 		numUniq += isNew[i];
+	}
 	}
 	const uint64_t numEntries = numUniq * (do_rc ? 2 : 1);
 	Q->heads = malloc(totQ * sizeof(*Q->heads));
@@ -206,15 +233,34 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 	if (!Q->heads || !Q->offset || !Q->qoff || !Q->six || !Q->rc || !Q->flags || !Q->emac || !Q->len || !Q->ed) {
 		free(isNew); free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_OOM, "OOM building query tables");
 	}
-	uint64_t u = 0, totLen = 0;
-	for (uint64_t i = 0; i < totQ; ++i) {
-		Q->heads[i] = heads[refs[i].ix];
-		if (isNew[i]) {
-			Q->offset[u] = i;
-			Q->len[u] = refs[i].len;
-			Q->ed[u] = (uint16_t)bh_error_budget(thres, refs[i].len);                  /* burst.c:3074-3076 */
-			totLen += refs[i].len;
-			++u;
+	uint64_t totLen = 0;
+	{	/* in slices: the rank of a unique query = the number of marks in front of its slice + inside it */
+		const int nt = bh_ingest_threads();
+		uint64_t first[65];
+		const int ns = nt > 64 ? 64 : (nt < 1 ? 1 : nt);
+		#pragma omp parallel for num_threads(ns) schedule(static, 1)
+		for (int t = 0; t < ns; ++t) {
+			const uint64_t a = totQ * (uint64_t)t / ns, b = totQ * (uint64_t)(t + 1) / ns;
+			uint64_t c = 0;
+			for (uint64_t i = a; i < b; ++i) c += isNew[i];
+			first[t + 1] = c;
+		}
+		first[0] = 0;
+		for (int t = 0; t < ns; ++t) first[t + 1] += first[t];
+		#pragma omp parallel for num_threads(ns) schedule(static, 1) reduction(+:totLen)
+		for (int t = 0; t < ns; ++t) {
+			const uint64_t a = totQ * (uint64_t)t / ns, b = totQ * (uint64_t)(t + 1) / ns;
+			uint64_t u = first[t];
+			for (uint64_t i = a; i < b; ++i) {
+				Q->heads[i] = heads[refs[i].ix];
+				if (isNew[i]) {
+					Q->offset[u] = i;
+					Q->len[u] = refs[i].len;
+					Q->ed[u] = (uint16_t)bh_error_budget(thres, refs[i].len);                  /* burst.c:3074-3076 */
+					totLen += refs[i].len;
+					++u;
+				}
+			}
 		}
 	}
 	Q->offset[numUniq] = totQ;

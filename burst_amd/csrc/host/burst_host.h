@@ -93,6 +93,8 @@ typedef struct BhQueries {
 	int pinned;            /* codes / qoff are page-locked (bh_queries_pin) */
 } BhQueries;
 
+/* device that sorts and de-duplicates large query files (default 0; < 0 = always on the host) */
+void bh_queries_sort_device(int device);
 int  bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespace, int do_accel, int K, int z,
                      int skip_ambig, BhQueries *q);
 void bh_queries_free(BhQueries *q);

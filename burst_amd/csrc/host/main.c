@@ -200,6 +200,7 @@ int main(int argc, char **argv) {
 	}
 	PHASE("database read");
 	BhQueries Q;
+	bh_queries_sort_device(n_dev_list ? dev_list[0] : (n_gpus_given ? 0 : device));      /* large query files are sorted on the (first) search device */
 	if ((rc = bh_queries_load(query_FN, thres, do_rc, incl_ws, do_accel, K ? K : 12, z, skip_ambig, &Q))) DIE(rc);
 	printf("Parsed %lu queries, %lu unique [min %u, max %u, maxED %u]; clear %lu, ambiguous %lu, bad %lu\n", (unsigned long)Q.totQ,
 	       (unsigned long)Q.numUniq, Q.minLen, Q.maxLen, Q.maxED, (unsigned long)Q.nClear, (unsigned long)Q.nAmbig, (unsigned long)Q.nBad);

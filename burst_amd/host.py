@@ -53,6 +53,8 @@ def lib():
         capi.lib()   # libburst_hip.so first (rpath covers it, this gives the clearer error)
         L = C.CDLL(LIB_PATH)
         L.bh_last_error.restype = C.c_char_p
+        L.bh_queries_sort_device.argtypes = [C.c_int]
+        L.bh_queries_sort_device.restype = None
         L.bh_queries_load.argtypes = [C.c_char_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(BhQueries)]
         L.bh_queries_free.argtypes = [C.POINTER(BhQueries)]
         L.bh_queries_pin.argtypes = [C.POINTER(BhQueries)]

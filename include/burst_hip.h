@@ -186,6 +186,15 @@ int bhip_copy_hits_device(void *handle, void *dst_device, uint64_t cap_records, 
  * No reference counterpart (the reference appends ResultPods in place, burst.c:4230-4238). */
 int bhip_sync_hits(void *handle);
 
+/* Query ingest: sort n records of symbol codes (record r = codes[start[r] .. start[r] + len[r]), codes 0..15) in the order
+ * of the reference's query sort -- byte-wise over the common length, the shorter record first, equal records in input order
+ * (burst.c:363-366, 636-690) -- and mark the first record of every run of identical ones (the uniqueness pass of
+ * burst.c:3036-3053).  perm[i] = input number of the i-th record in sorted order, is_new[i] = 1 iff it differs from the
+ * (i-1)-th.  A device-side LSD radix sort over 16-symbol keys; needs no handle (it runs before the database is uploaded) and
+ * about codes_bytes + 40 n bytes of device memory for the duration of the call.  max_len >= every len[r]. */
+int bhip_sort_queries(int device, const uint8_t *codes, uint64_t codes_bytes, const uint64_t *start, const uint32_t *len,
+                      uint64_t n, uint32_t max_len, uint32_t *perm, uint8_t *is_new);
+
 /* Tuning knobs.  "prefilter_stride": 0 (default) = automatic sparse seeds -- per query the largest stride s <= K for
  * which an alignment within budget still keeps >= 3 of the words starting at 0, s, 2s, ... (one edit destroys at most
  * ceil(K/s) of them), fewest .acx look-ups with the same no-false-negative guarantee; s >= 1 forces every s-th word,

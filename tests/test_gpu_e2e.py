@@ -3,6 +3,7 @@
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 import goldenlib as gl
@@ -212,3 +213,62 @@ def test_cli_reads_fastq_gz(tmp_path):
     out = str(tmp_path / "o.b6")
     subprocess.check_call([CLI, "-r", ref, "-a", acx_for("dna", 1, str(tmp_path)), "-q", fq, "-o", out, "-m", "ALLPATHS", "-i", "0.95", "-fr"], stdout=subprocess.DEVNULL)
     assert sorted(open(out, "rb").read().splitlines()) == gl.golden_lines(c)
+
+
+@pytest.mark.gpu
+def test_device_query_sort_equals_host_sort(tmp_path, monkeypatch, capfd):
+    """bhip_sort_queries (LSD radix sort of the query records on the device + duplicate marking) against the host's sort of
+    the same file: 300 k reads of mixed lengths with exact duplicates, records that are prefixes of others, IUPAC codes,
+    symbols outside the alphabet (code 0) -- every table the loader builds (order of the headers, offsets of the unique
+    queries, lengths, budgets, symbol codes, strands) must be identical, with and without reverse complements."""
+    import ctypes as C
+    from burst_amd import host
+    rng = np.random.default_rng(77)
+    n = 300_000
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    base = [alpha[rng.integers(0, 4, int(L))] for L in rng.integers(30, 260, 4000)]
+    recs = []
+    for i in range(n):
+        b = base[int(rng.integers(0, len(base)))]
+        k = rng.random()
+        if k < 0.35:
+            s = b.copy()                                         # exact duplicate of a base
+        elif k < 0.6:
+            s = b[:int(rng.integers(1, len(b) + 1))].copy()      # a prefix of it
+        else:
+            s = b.copy()
+            for _ in range(int(rng.integers(1, 4))):
+                s[int(rng.integers(0, len(s)))] = alpha[int(rng.integers(0, 4))]
+        if k > 0.97:
+            s[int(rng.integers(0, len(s)))] = ord("NRYK@-"[int(rng.integers(0, 6))])       # IUPAC, and symbols of code 0
+        recs.append(b">r%d\n" % i + s.tobytes() + b"\n")
+    fa = tmp_path / "mixed.fa"
+    fa.write_bytes(b"".join(recs))
+
+    def load(host_sort, rc):
+        if host_sort:
+            monkeypatch.setenv("BURST_HOST_SORT", "1")
+        else:
+            monkeypatch.delenv("BURST_HOST_SORT", raising=False)
+        qs = host.QuerySet(str(fa), 0.97, rc=rc, accel=True, K=12)
+        c = qs.c
+        heads = np.ctypeslib.as_array(C.cast(c.heads, C.POINTER(C.c_uint64)), (qs.n_reads,)).copy() - int(c.dump or 0)
+        qoff = host._view(c.qoff, qs.n_entries + 1, np.uint64).copy()
+        out = dict(n=(qs.n_reads, qs.n_uniq, qs.n_entries, int(c.maxLen), int(c.minLen), int(c.maxED), int(c.nClear), int(c.nAmbig), int(c.nBad)),
+                   heads=heads, offset=host._view(c.offset, qs.n_uniq + 1, np.uint64).copy(), qoff=qoff,
+                   codes=host._view(c.codes, int(qoff[-1]), np.uint8).copy(), len=host._view(c.len, qs.n_uniq, np.uint32).copy(),
+                   emac=host._view(c.emac, qs.n_entries, np.uint16).copy(), rc=host._view(c.rc, qs.n_entries, np.uint8).copy(),
+                   flags=host._view(c.flags, qs.n_entries, np.uint8).copy())
+        qs.close()
+        return out
+    monkeypatch.setenv("BURST_HOST_DEBUG", "1")
+    for rc in (False, True):
+        a = load(True, rc)
+        capfd.readouterr()
+        b = load(False, rc)
+        err = capfd.readouterr().err
+        assert "sort + duplicates (device)" in err and "not available" not in err, err       # the device path really ran
+        assert a["n"] == b["n"] and a["n"][1] < a["n"][0]          # duplicates were folded
+        for k in a:
+            if k != "n":
+                assert np.array_equal(a[k], b[k]), (rc, k)
