@@ -193,9 +193,19 @@ def main():
         b0, b1 = b * U // P, (b + 1) * U // P
         n = b1 - b0
         return (b0 + rank * n // world, b0 + (rank + 1) * n // world)
+    # N > 1 (strong scaling: the job = `steps` batches of --reads reads, whatever N is): with at least two batches per rank the
+    # ranks take WHOLE batches in turn (batch k -> rank k mod N; every device call keeps its 2 M reads and the per-batch fixed
+    # costs are not multiplied by N); with fewer, every rank takes its 1/N slice of every batch
+    whole = world > 1 and args.steps >= 2 * world
+    def pool_range(b):
+        return (b * U // P, (b + 1) * U // P)
     def step_ranges(first, count):
+        if whole:
+            return [pool_range((first + k) % P) for k in range(count) if k % world == rank]
         return [rank_range((first + k) % P) for k in range(count)]
-    batch_uniq = max(1, (U // P + world - 1) // world + 1)         # one device batch per step and rank
+    def prime_ranges(count):        # setup only: every rank runs the same number of full-size device calls
+        return [pool_range(k % P) if whole else rank_range(k % P) for k in range(count)]
+    batch_uniq = max(1, U // P + 1) if whole else max(1, (U // P + world - 1) // world + 1)         # one device batch per step (and rank)
     reads_per_pool_batch = [qs.reads_in(b * U // P, (b + 1) * U // P) for b in range(P)]
 
     def gather(run):
@@ -215,14 +225,14 @@ def main():
     # warm-up: sizes the library's grow-only buffers for this workload and runs W untimed steps
     # (the page-locked record buffer is allocated once, outside the timed region: the command line does it once per job as well)
     run = host.Run()
-    ent_per_step = max(r[1] - r[0] for r in step_ranges(0, P)) * (2 if args.fr else 1)
+    ent_per_step = max(r[1] - r[0] for r in prime_ranges(P)) * (2 if args.fr else 1)
     run.reserve(int(ent_per_step * max(4, args.warmup, args.steps) * (4.0 if args.mode in ("FORAGE", "ALLPATHS") else 1.5)) + (1 << 20))
     # (bhip_reserve = the command line's "batch buffers" phase: device buffers for this batch size + the library's own warm-up pass)
     dev.reserve(int(ent_per_step), int(args.read_len))
     # one priming call of four batches (setup, not a warm-up step): the first call long enough to have two batches' staging copies
     # queued when a batch's records are handed over pays ~17 ms once per process inside the runtime's asynchronous copy (seen with
     # --warmup 1 in front of the timed region's second batch)
-    run = host.align_ranges(dev, qs, step_ranges(0, 4), args.mode, batch_uniq, run=run)
+    run = host.align_ranges(dev, qs, prime_ranges(4), args.mode, batch_uniq, run=run)
     run = host.align_ranges(dev, qs, step_ranges(0, max(1, args.warmup)), args.mode, batch_uniq, run=run)
     if use_dist:
         gather(run)
@@ -317,7 +327,7 @@ def main():
                                    "(%.2f Gbp; %d clumps; .edx %.2f GB + DB%d .acx %.2f GB); every step stages its batch afresh through the product's batch scheduler"
                                    % (world, args.reads, args.read_len, args.mode, args.id, args.n_base * args.n_variants, args.ref_len,
                                       args.n_base * args.n_variants * args.ref_len / 1e9, db.c.numRclumps, edx_bytes / 1e9, args.K, acx_bytes / 1e9),
-                       "parallelism": "query-sharded x%d, DB replicated, one RCCL gather of hit records" % world,
+                       "parallelism": "query-sharded x%d (%s), DB replicated, one RCCL gather of hit records" % (world, "whole batches in turn" if whole else "1/N slice of every batch"),
                        "timed_region": "bh_align_ranges over %d batches (copies + device routing two batches ahead, seed lookups + profiles one batch ahead, alignment, records to host memory)%s" % (nb, " + RCCL gather" if use_dist else ""),
                        "extrapolation": {"metric_database": "31.5 GB RefSeq .edx", "this_edx_bytes": edx_bytes, "size_ratio": scale_to_metric,
                                          "acx_records_per_read_here": st["acx_entries_read"] / max(1.0, float(st["n_queries"])),
