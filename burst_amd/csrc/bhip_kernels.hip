@@ -713,9 +713,9 @@ __global__ __launch_bounds__(256) void k_seed_ranges(
 		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint32_t *__restrict__ qlist, uint32_t n_list,
 		BhipAcxView acx, int K, const uint32_t *__restrict__ plan, uint32_t W16,
 		uint2 *__restrict__ ranges, uint2 *__restrict__ hdr, const uint32_t *__restrict__ qpack, uint32_t qw, const uint16_t *__restrict__ qemac) {
-	const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	// (grid-stride: run ahead beside another batch's sweeps, the kernel is launched with a few blocks per CU only)
+	for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < (uint64_t)n_list * W16; t += (uint64_t)gridDim.x * 256) {
 	const uint32_t li = (uint32_t)(t / W16), j = (uint32_t)(t % W16);
-	if (li >= n_list) return;
 	const uint32_t q = qlist ? qlist[li] : li;
 	const uint64_t b = qoff[q];
 	const uint32_t len = (uint32_t)(qoff[q + 1] - b);
@@ -767,6 +767,7 @@ __global__ __launch_bounds__(256) void k_seed_ranges(
 	ranges[t] = r;
 	// header: need | words << 16 ; length | budget << 12 | (words one edit can destroy = ceil(K / stride)) << 20
 	if (j == 0) hdr[li] = make_uint2((need > 0xFFFFu ? 0xFFFFu : need) | nwords << 16, len | (uint32_t)(qemac[q] > 255 ? 255 : qemac[q]) << 12 | ((uint32_t)(K + stride - 1) / stride) << 20);
+	}
 }
 
 template <int HTB>

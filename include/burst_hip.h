@@ -213,7 +213,8 @@ int bhip_sort_queries(int device, const uint8_t *codes, uint64_t codes_bytes, co
  * "host_routing": 0 (default) = batches are routed (length classes, seed plans, lists) by a device kernel, 1 = by the host pass
  * that otherwise only handles batches with query symbols outside the alphabet.  "discard_staged": forget batches that were
  * staged and not aligned (after an error).  "seed_ahead": 1 (default) = the seed lookups and match profiles of the next staged
- * batch run while the current one is swept, 0 = in place.
+ * batch run while the current one is swept, 0 = in place; "seed_ahead_blocks" (default 2, 0 = unlimited) / "peq_ahead_blocks"
+ * (default 16) = 256-thread blocks per CU those kernels get while they share the device with the sweeps.
  * None of these changes a result. */
 int bhip_set_option(void *handle, const char *name, long long value);
 
