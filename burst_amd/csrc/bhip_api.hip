@@ -237,6 +237,7 @@ struct Lane {
 	bool masked = false;
 };
 
+struct SharedCtr { uint32_t n_out, err; };
 struct Handle {
 	int device = 0, n_cu = 0;
 	char dev_name[256];
@@ -272,6 +273,7 @@ struct Handle {
 	int opt_host_routing = 0;             // 1 = route every batch on the host (the pass that handles symbols of code 0); test hook
 	// batch-wide buffers
 	DBuf best, out, shared_ctr, mins, pairs;
+	SharedCtr *hsc_pinned = nullptr;      // read-back of shared_ctr behind the chain (pinned: no blocking copy on the way out of a batch)
 	const uint8_t *s_codes() const { return cur->st_has_junk ? cur->qcodes_s.as<uint8_t>() : cur->qcodes.as<uint8_t>(); }
 	const uint64_t *s_off() const { return cur->st_has_junk ? cur->qoff_s.as<uint64_t>() : cur->qoff.as<uint64_t>(); }
 	const uint16_t *s_emac() const { return cur->st_has_junk ? cur->qemac_s.as<uint16_t>() : cur->qemac.as<uint16_t>(); }
@@ -306,7 +308,6 @@ struct Handle {
 	int opt_peq_ahead_blocks = 16; // 256-thread blocks per CU of a profile build that runs ahead
 	double acx_wmean = 0.0;       // occurrence-weighted mean .acx list length
 };
-struct SharedCtr { uint32_t n_out, err; };
 
 static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 
@@ -360,6 +361,7 @@ extern "C" void bhip_destroy(void *handle) {
 	if (h->post_stream) (void)hipStreamSynchronize(h->post_stream);
 	if (h->stage_stream) (void)hipStreamSynchronize(h->stage_stream);
 	for (StageSlot &S : h->slots) S.release_all();
+	if (h->hsc_pinned) (void)hipHostFree(h->hsc_pinned);
 	for (Lane *L : h->lanes) lane_destroy(L);
 	DBuf *all[] = {&h->ref, &h->ref_lane, &h->ref_off, &h->clump_len, &h->lut, &h->acx_lines, &h->acx_rec, &h->bad,
 		&h->best, &h->out, &h->shared_ctr, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx,
@@ -1739,6 +1741,8 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			HIPCHK(hipEventRecord(h->ev[5], h->post_stream));
 			sorted_ahead = true;
 		}
+		if (!h->hsc_pinned) HIPCHK(hipHostMalloc((void **)&h->hsc_pinned, sizeof(SharedCtr), hipHostMallocDefault));
+		HIPCHK(hipMemcpyAsync(h->hsc_pinned, h->shared_ctr.p, sizeof(SharedCtr), hipMemcpyDeviceToHost, h->post_stream));
 		HIPCHK(hipEventRecord(h->ev[3], h->post_stream));
 		seed_next_batch(h, slot, h->ev[3]);
 		HIPCHK(hipEventSynchronize(h->ev[2]));
@@ -1794,7 +1798,8 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			HIPCHK(hipStreamSynchronize(h->post_stream));
 			if (L->hc.scratch_used > L->scratch_cap) { L->scratch_cap = (uint64_t)L->hc.scratch_used + 1024; scratch_retry = true; }
 		}
-		HIPCHK(hipMemcpy(&hsc, h->shared_ctr.p, sizeof hsc, hipMemcpyDeviceToHost));
+		if (sorted_ahead) hsc = *h->hsc_pinned;      // (nothing ran after the chain: the copy behind it is current)
+		else HIPCHK(hipMemcpy(&hsc, h->shared_ctr.p, sizeof hsc, hipMemcpyDeviceToHost));
 		if (scratch_retry || (hsc.err & 2u)) continue;
 		if (hsc.err & 1u) return fail(BHIP_E_RESCORE, "re-scoring could not reproduce a hit found by the edit-distance kernel (a query starting with a symbol outside the alphabet? the reference stops here as well: CRITICAL ERROR: Truncation within known good path, burst.c:812-816)");
 		if (hsc.n_out > h->out_cap) { h->out_cap = (uint64_t)hsc.n_out + hsc.n_out / 8 + 1024; continue; }
