@@ -1709,7 +1709,9 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		HIPCHK(hipMemsetAsync(h->shared_ctr.p, 0, sizeof(SharedCtr), h->stream));
 		HIPCHK(hipEventRecord(h->ev[1], h->stream));
 		HIPCHK(hipStreamWaitEvent(h->sweep_stream, h->ev[1], 0));
-		HIPCHK(hipStreamWaitEvent(h->pf_stream, h->ev[1], 0));
+		// (the prefilter stream does not wait for these fills: nothing it runs touches `best` or the shared counters -- the sweeps and the
+		// re-scorer do, on the stream the fills are on -- and the previous batch has been waited for by the host: the prefilter starts
+		// ~75 us earlier)
 		HIPCHK(hipStreamWaitEvent(h->post_stream, h->ev[1], 0));
 		for (uint32_t l = 0; l < nl; ++l) if (h->lanes[l]->n_entries) if ((rc = enqueue_lane(h, h->lanes[l], all_hits, h->ev[1], band_rows, qw, rw))) return rc;
 		HIPCHK(hipEventRecord(h->ev[2], h->pf_stream));          // this batch's share of the prefilter stream ends here
