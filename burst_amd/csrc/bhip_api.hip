@@ -237,7 +237,11 @@ struct Lane {
 	bool masked = false;
 };
 
-struct SharedCtr { uint32_t n_out, err; };
+// counters all lanes of a batch share; behind them the per-query record counters and the rank array of the counting sort: the
+// re-scoring kernels take rank[pos] = cnt[q]++ when they write a record (bhip_hit_rank in bhip_internal.h reads the two pointers
+// through the n_out pointer they already get), so that no separate counting pass runs between the re-scorer and the scatter
+struct SharedCtr { uint32_t n_out, err; uint32_t *cnt; uint32_t *rank; };
+__global__ void k_set_rank_ptrs(SharedCtr *sc, uint32_t *cnt, uint32_t *rank) { sc->cnt = cnt; sc->rank = rank; }
 struct Handle {
 	int device = 0, n_cu = 0;
 	char dev_name[256];
@@ -1706,7 +1710,12 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		if ((rc = h->shared_ctr.reserve(sizeof(SharedCtr)))) return rc;
 		HIPCHK(hipEventRecord(h->ev[0], h->stream));
 		HIPCHK(hipMemsetAsync(h->best.p, 0xFF, (size_t)n_shared * 4, h->stream));
-		HIPCHK(hipMemsetAsync(h->shared_ctr.p, 0, sizeof(SharedCtr), h->stream));
+		HIPCHK(hipMemsetAsync(h->shared_ctr.p, 0, 2 * sizeof(uint32_t), h->stream));
+		{	// the counting sort's counters (zeroed here, off the critical path) and ranks, for the re-scoring kernels
+			if ((rc = h->sort_idx.reserve((size_t)h->out_cap * 4)) || (rc = h->sort_keys.reserve((size_t)(n_q + 1) * 4))) return rc;
+			HIPCHK(hipMemsetAsync(h->sort_keys.p, 0, (size_t)(n_q + 1) * 4, h->stream));
+			hipLaunchKernelGGL(k_set_rank_ptrs, dim3(1), dim3(1), 0, h->stream, h->shared_ctr.as<SharedCtr>(), h->sort_keys.as<uint32_t>(), h->sort_idx.as<uint32_t>());
+		}
 		HIPCHK(hipEventRecord(h->ev[1], h->stream));
 		HIPCHK(hipStreamWaitEvent(h->sweep_stream, h->ev[1], 0));
 		// (the prefilter stream does not wait for these fills: nothing it runs touches `best` or the shared counters -- the sweeps and the
@@ -1733,8 +1742,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			const uint32_t g = (uint32_t)h->n_cu * 8;
 			if (h->copy_pending[o_ahead]) HIPCHK(hipStreamWaitEvent(h->post_stream, h->ev_copied[o_ahead], 0));      // the copy that last read this buffer
 			HIPCHK(hipEventRecord(h->ev[4], h->post_stream));
-			HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(n_q + 1) * 4, h->post_stream));
-			hipLaunchKernelGGL(k_hit_count, dim3(g), dim3(256), 0, h->post_stream, h->out.as<BhipHit>(), (uint32_t)h->out_cap, &sc->n_out, cnt, rank);
+			// (counts and ranks were taken by the re-scoring kernels as they wrote the records)
 			HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->sort_tmp.p, tmp_bytes, cnt, off, (int)(n_q + 1), h->post_stream));
 			hipLaunchKernelGGL(k_hit_scatter, dim3(g), dim3(256), 0, h->post_stream, h->out.as<BhipHit>(), (uint32_t)h->out_cap, &sc->n_out, off, rank, sorted.as<BhipHit>(),
 				h->cur->has_qmap ? h->cur->qmap.as<uint32_t>() : (const uint32_t *)nullptr);
@@ -1744,7 +1752,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			sorted_ahead = true;
 		}
 		if (!h->hsc_pinned) HIPCHK(hipHostMalloc((void **)&h->hsc_pinned, sizeof(SharedCtr), hipHostMallocDefault));
-		HIPCHK(hipMemcpyAsync(h->hsc_pinned, h->shared_ctr.p, sizeof(SharedCtr), hipMemcpyDeviceToHost, h->post_stream));
+		HIPCHK(hipMemcpyAsync(h->hsc_pinned, h->shared_ctr.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->post_stream));
 		HIPCHK(hipEventRecord(h->ev[3], h->post_stream));
 		seed_next_batch(h, slot, h->ev[3]);
 		HIPCHK(hipEventSynchronize(h->ev[2]));
@@ -1801,7 +1809,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			if (L->hc.scratch_used > L->scratch_cap) { L->scratch_cap = (uint64_t)L->hc.scratch_used + 1024; scratch_retry = true; }
 		}
 		if (sorted_ahead) hsc = *h->hsc_pinned;      // (nothing ran after the chain: the copy behind it is current)
-		else HIPCHK(hipMemcpy(&hsc, h->shared_ctr.p, sizeof hsc, hipMemcpyDeviceToHost));
+		else HIPCHK(hipMemcpy(&hsc, h->shared_ctr.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
 		if (scratch_retry || (hsc.err & 2u)) continue;
 		if (hsc.err & 1u) return fail(BHIP_E_RESCORE, "re-scoring could not reproduce a hit found by the edit-distance kernel (a query starting with a symbol outside the alphabet? the reference stops here as well: CRITICAL ERROR: Truncation within known good path, burst.c:812-816)");
 		if (hsc.n_out > h->out_cap) { h->out_cap = (uint64_t)hsc.n_out + hsc.n_out / 8 + 1024; continue; }

@@ -110,6 +110,14 @@ __device__ __forceinline__ uint2 bhip_acx_rec_decode(uint2 raw, uint32_t shift8,
 	const uint32_t m = valid ? 0xFFFFFFFFu : 0u;
 	return make_uint2(((uint32_t)v & 0xFFFFFFu) | ~m, (uint32_t)(v >> 24) & 0xFFFFu & m);
 }
+// Counting sort of the records by query, first half: behind the shared record counter (n_out, err) sit the pointers to the
+// per-query counters and to the rank array (SharedCtr in bhip_api.hip; null when the caller sorts differently).  Called by the
+// kernels that write BhipHit records, with the position they reserved.
+__device__ __forceinline__ void bhip_hit_rank(uint32_t *n_out, uint32_t pos, uint32_t q) {
+	uint32_t *const *pp = (uint32_t *const *)(n_out + 2);
+	uint32_t *cnt = pp[0], *rank = pp[1];
+	if (cnt) rank[pos] = atomicAdd(&cnt[q], 1u);
+}
 __device__ __forceinline__ uint32_t bhip_acx_clump(const uint8_t *rec, unsigned long long e) { return bhip_acx_rec(rec, e).x; }
 #endif
 

@@ -2159,6 +2159,7 @@ __global__ __launch_bounds__(64) void k_rescore(
 				BhipHit o; o.q = q; o.refIx = h.refIx; o.finalPos = (uint32_t)e2; o.score = 1.0f - 0.0f / (float)m;
 				o.ed = 0; o.gapR = 0; o.gapQ = 0; o.rc = qrc ? qrc[q] : 0;
 				out[pos] = o;
+				bhip_hit_rank(n_out, pos, q);
 			}
 			continue;
 		}
@@ -2264,6 +2265,7 @@ __global__ __launch_bounds__(64) void k_rescore(
 			o.score = 1.0f - (float)bs / ((float)m + (float)bh);                                  // burst.c:844-847
 			o.ed = (uint8_t)B; o.gapR = (uint8_t)bv; o.gapQ = (uint8_t)bh; o.rc = qrc ? qrc[q] : 0;
 			out[pos] = o;
+			bhip_hit_rank(n_out, pos, q);
 		}
 	}
 }
@@ -2328,6 +2330,7 @@ __global__ __launch_bounds__(256) void k_rescore_classify(
 					BhipHit o; o.q = qv[t]; o.refIx = rv[t]; o.finalPos = e2v[t]; o.score = 1.0f - 0.0f / (float)mv[t];
 					o.ed = 0; o.gapR = 0; o.gapQ = 0; o.rc = qrc ? qrc[qv[t]] : 0;
 					out[pos] = o;
+					bhip_hit_rank(n_out, pos, qv[t]);
 				}
 			} else if (bk == 10) wide[pos] = i;
 			else lists[(size_t)bk * raw_cap + pos] = i;
@@ -2458,6 +2461,7 @@ __device__ __forceinline__ void rescore_reg_one(
 				o.score = 1.0f - (float)bs / ((float)m + (float)bh);                                  // burst.c:844-847
 				o.ed = (uint8_t)B; o.gapR = (uint8_t)bv; o.gapQ = (uint8_t)bh; o.rc = qrc ? qrc[hq] : 0;
 				out[pos] = o;
+				bhip_hit_rank(n_out, pos, hq);
 			}
 		}
 	}
