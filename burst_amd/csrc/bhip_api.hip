@@ -897,7 +897,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
                                  uint32_t *n_cand_dev, Counters *dc, int prune) {
 	int rc;
 	if ((rc = L->fb_list.reserve((size_t)n_list * 4 + 16))) return rc;
-	HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 4, st));
+	if (L->pf_launches) HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 4, st));      // (the lane's first class finds the whole counter block zeroed by enqueue_lane)
 	const uint32_t W16 = seed_row_words(maxwords);
 	// the lookups of this batch may have run ahead (seed_next_batch, during the previous call)
 	if (!(L->seeded_ok[cls] && L->seeded_seq[cls] == h->cur->seq && L->seeded_n[cls] == n_list && L->seeded_W16[cls] == W16))
