@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--edits", default="0,1,2", help="edit counts sampled per read")
     ap.add_argument("--opt", action="append", default=[], help="library tuning option name=value (bhip_set_option), repeatable")
     ap.add_argument("--no-pin", action="store_true", help="leave the query arrays pageable")
+    ap.add_argument("--no-prime", action="store_true", help="skip bhip_reserve and the priming call (profiling: every dispatch of the run is then a full-size batch)")
     args = ap.parse_args()
     args.n_base = int(round(args.n_base * args.db_scale))
 
@@ -228,11 +229,13 @@ def main():
     ent_per_step = max(r[1] - r[0] for r in prime_ranges(P)) * (2 if args.fr else 1)
     run.reserve(int(ent_per_step * max(4, args.warmup, args.steps) * (4.0 if args.mode in ("FORAGE", "ALLPATHS") else 1.5)) + (1 << 20))
     # (bhip_reserve = the command line's "batch buffers" phase: device buffers for this batch size + the library's own warm-up pass)
-    dev.reserve(int(ent_per_step), int(args.read_len))
+    if not args.no_prime:
+        dev.reserve(int(ent_per_step), int(args.read_len))
     # one priming call of four batches (setup, not a warm-up step): the first call long enough to have two batches' staging copies
     # queued when a batch's records are handed over pays ~17 ms once per process inside the runtime's asynchronous copy (seen with
     # --warmup 1 in front of the timed region's second batch)
-    run = host.align_ranges(dev, qs, prime_ranges(4), args.mode, batch_uniq, run=run)
+    if not args.no_prime:
+        run = host.align_ranges(dev, qs, prime_ranges(4), args.mode, batch_uniq, run=run)
     run = host.align_ranges(dev, qs, step_ranges(0, max(1, args.warmup)), args.mode, batch_uniq, run=run)
     if use_dist:
         gather(run)
