@@ -173,6 +173,7 @@ def main():
     db = host.Db.read(edx, acx, K=args.K)
     t_db = time.time() - t
     t = time.time()
+    host.lib().bh_queries_sort_device(local_rank)          # large query files are sorted on this rank's own device
     qs = host.QuerySet(reads_fa, args.id, rc=args.fr, accel=True, K=args.K)
     t_q = time.time() - t
     t = time.time()

@@ -44,6 +44,7 @@ def main(argv=None):
     z = 0 if args.nwildcard else 1
     db = host.Db.read(args.references, args.accelerator, K=args.k, z=z)
     K = int(db.c.K) if args.accelerator else 12
+    host.lib().bh_queries_sort_device(local_rank)          # large query files are sorted on this rank's own device
     qs = host.QuerySet(args.queries, args.id, rc=args.forwardreverse, accel=bool(args.accelerator), K=K, z=z)
     # the database was sheared for queries up to shear * id long: longer ones would lose alignments across shear boundaries
     # (burst.c:5152-5156: "DB incompatible with selected queries/identity", exit 1)
