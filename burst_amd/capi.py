@@ -43,7 +43,7 @@ class BhipQuerySpan(C.Structure):
 
 EXPORTS = ["bhip_init", "bhip_stage_queries", "bhip_align_staged", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_set_option", "bhip_get_stats",
            "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version", "bhip_copy_hits_device", "bhip_sync_hits",
-           "bhip_comm_create", "bhip_comm_gather_hits", "bhip_comm_destroy", "bhip_reserve", "bhip_sort_queries", "bhip_stage_spans", "bhip_alloc_host", "bhip_free_host", "bhip_host_register", "bhip_host_unregister"]
+           "bhip_comm_create", "bhip_comm_gather_hits", "bhip_comm_destroy", "bhip_acx_export", "bhip_reserve", "bhip_sort_queries", "bhip_stage_spans", "bhip_alloc_host", "bhip_free_host", "bhip_host_register", "bhip_host_unregister"]
 
 
 class BurstHipError(RuntimeError):
@@ -98,6 +98,8 @@ def _load():
     lib.bhip_host_register.restype = i32
     lib.bhip_host_unregister.argtypes = [vp]
     lib.bhip_host_unregister.restype = i32
+    lib.bhip_acx_export.argtypes = [vp, vp, vp, vp, u64, C.POINTER(u64), vp, u32, C.POINTER(u32)]
+    lib.bhip_acx_export.restype = i32
     return lib
 
 
@@ -145,8 +147,12 @@ class Device:
     """One handle = one database resident on one GPU (bhip_init .. bhip_destroy)."""
 
     def __init__(self, edx_packed, clump_len, tot_refs, score_lut, acx_lens=None, acx_lists=None, acx_fmt=0, K=12,
-                 badlist=None, device=0, xalpha=0):
+                 badlist=None, device=0, xalpha=0, build_acx=False):
+        """acx_lens / acx_lists: the tables of an .acx file; build_acx=True (and no tables): the device builds the accelerator
+        for word length K from the references alone"""
         self._h = C.c_void_p()
+        if acx_lens is None and not build_acx:
+            K = 0
         edx_packed = _arr(edx_packed, np.uint8)
         clump_len = _arr(clump_len, np.uint32)
         score_lut = _arr(score_lut, np.uint8)
@@ -176,6 +182,17 @@ class Device:
         hbm = C.c_uint64()
         _chk(lib().bhip_device_info(self._h, name, 256, C.byref(ncu), C.byref(hbm)))
         return {"name": name.value.decode(), "n_cu": ncu.value, "hbm_bytes": hbm.value}
+
+    def acx_export(self, K, masks=True):
+        """the handle's accelerator in the file's terms: (Lens[4^K], clump ids in word order, lane masks or None, BadList)"""
+        n, nb = C.c_uint64(), C.c_uint32()
+        _chk(lib().bhip_acx_export(self._h, None, None, None, 0, C.byref(n), None, 0, C.byref(nb)))
+        lens = np.zeros(1 << (2 * K), np.uint32)
+        clumps = np.zeros(max(1, n.value), np.uint32)
+        mk = np.zeros(max(1, n.value), np.uint16) if masks else None
+        bad = np.zeros(max(1, nb.value), np.uint32)
+        _chk(lib().bhip_acx_export(self._h, _ptr(lens), _ptr(clumps), _ptr(mk), n.value, C.byref(n), _ptr(bad), nb.value, C.byref(nb)))
+        return lens, clumps[:n.value], (mk[:n.value] if masks else None), bad[:nb.value]
 
     def set_option(self, name, value):
         _chk(lib().bhip_set_option(self._h, name.encode(), int(value)))

@@ -1,0 +1,640 @@
+// burst_amd/csrc/bhip_acx.hip -- the accelerator (.acx, burst.c:3535-3594) as it lives in HBM (BhipAcxView, bhip_internal.h):
+// 5-byte (clump, lane mask) records in word order + one 64-byte offset line per 14 words.  Three ways to get there:
+//   bhip_load_accelerator   from the file's Lens[4^K] + packed lists (read_accelerator, burst.c:3535-3594): decoded on the device,
+//                           lane masks derived from the references (build_lane_masks);
+//   bhip_build_accelerator  from the references alone, on the device (make_accelerator, burst.c:3304-3532): every K-mer of every
+//                           lane -- expanded over IUPAC codes, clumps whose expansion exceeds the reference's budget on the BadList --
+//                           as (word, clump, lane) tuples, radix-sorted and folded to one record per (word, clump) with its lane mask:
+//                           the same entries in the same order as the file, without the file;
+//   bhip_acx_export         back to the host as Lens[4^K] + clump ids (+ masks, BadList), e.g. to write the .acx.
+#include "bhip_handle.h"
+
+// ------------------------------------------------------------------------------------------------
+// .acx offsets: Lens[4^K] (burst.c:3558) -> exclusive prefix inside each block of 256 words (`delta`) and the block sums
+// (scanned to 64-bit block bases by the caller).  WHAT = 0: list lengths (entries); 1: bytes of the packed SMALL lists
+// (pairs of 20-bit ids in 5 bytes with a 3-byte odd tail, burst.c:3516-3527); 2: bytes of the LARGE lists (3 per id).
+// One 256-thread workgroup per block of words.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_acx_offsets(const uint32_t *__restrict__ lens, uint64_t n_words, int what,
+                                                     uint32_t *__restrict__ delta, unsigned long long *__restrict__ blocksum) {
+	__shared__ uint32_t s_w[4];
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint64_t n_blocks = (n_words + 255) >> 8;
+	for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+		const uint64_t w = blk * 256 + tid;
+		const uint32_t len = w < n_words ? lens[w] : 0u;
+		const uint32_t v = what == 0 ? len : what == 1 ? 5u * (len >> 1) + 3u * (len & 1u) : 3u * len;
+		uint32_t ps = v;
+		#pragma unroll
+		for (uint32_t o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(ps, o); if (lane >= o) ps += t; }
+		__syncthreads();
+		if (lane == 63) s_w[wv] = ps;
+		__syncthreads();
+		uint32_t add = 0;
+		for (uint32_t k = 0; k < wv; ++k) add += s_w[k];
+		if (w < n_words) delta[w] = add + ps - v;
+		if (tid == 255) blocksum[blk] = (unsigned long long)add + ps;
+	}
+}
+
+// .acx offsets as 64-byte lines (BhipAcxView): pass 0 writes the sum of every block of 14 lengths, the caller scans them into
+// 64-bit bases (hipCUB), pass 1 writes base + inclusive prefix sums.  One thread per line.
+__global__ void k_acx_lines(const uint32_t *__restrict__ lens, uint64_t n_words, int pass, unsigned long long *__restrict__ blk, uint4 *__restrict__ lines) {
+	const uint64_t n_lines = (n_words + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS;
+	for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < n_lines; b += (uint64_t)gridDim.x * blockDim.x) {
+		uint32_t d[14], run = 0;
+		#pragma unroll
+		for (uint32_t j = 0; j < 14; ++j) { const uint64_t w = b * BHIP_ACX_LINE_WORDS + j; run += w < n_words ? lens[w] : 0u; d[j] = run; }
+		if (pass == 0) { blk[b] = run; continue; }
+		const unsigned long long base = blk[b];
+		lines[4 * b + 0] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), d[0], d[1]);
+		lines[4 * b + 1] = make_uint4(d[2], d[3], d[4], d[5]);
+		lines[4 * b + 2] = make_uint4(d[6], d[7], d[8], d[9]);
+		lines[4 * b + 3] = make_uint4(d[10], d[11], d[12], d[13]);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// .acx list area -> 5-byte records (24-bit clump id, 16-bit lane mask preset to "every lane"), on the device (the packed bytes
+// are what is uploaded): SMALL lists are pairs of 20-bit ids in 5 bytes with a 3-byte odd tail (burst.c:3265-3274), LARGE
+// lists 3 bytes per id (3245-3248).  One thread per word; `bad` is raised when an id is not a clump of the database.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bhip_rec_store(uint8_t *rec, unsigned long long e, uint32_t clump, uint32_t mask) {
+	uint8_t *p = rec + e * (unsigned long long)BHIP_REC_BYTES;
+	p[0] = (uint8_t)clump; p[1] = (uint8_t)(clump >> 8); p[2] = (uint8_t)(clump >> 16); p[3] = (uint8_t)mask; p[4] = (uint8_t)(mask >> 8);
+}
+__global__ void k_acx_decode(const uint8_t *__restrict__ lists, const unsigned long long *__restrict__ byte_base, const uint32_t *__restrict__ byte_delta,
+                             BhipAcxView acx, uint64_t n_words, int fmt, uint32_t n_clumps, uint8_t *__restrict__ rec, uint32_t *__restrict__ bad) {
+	for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+		unsigned long long e; uint32_t n;
+		bhip_acx_range(acx, (uint32_t)w, e, n);
+		if (!n) continue;
+		const uint8_t *p = lists + byte_base[w >> 8] + byte_delta[w];
+		uint32_t worst = 0;
+		if (fmt == 1) {
+			for (; n; --n, p += 3) { const uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); bhip_rec_store(rec, e++, v, 0xFFFFu); worst = v > worst ? v : worst; }
+		} else {
+			for (; n >= 2; n -= 2, p += 5) {
+				const unsigned long long v = (unsigned long long)p[0] | ((unsigned long long)p[1] << 8) | ((unsigned long long)p[2] << 16) |
+				                             ((unsigned long long)p[3] << 24) | ((unsigned long long)p[4] << 32);
+				const uint32_t a = (uint32_t)(v & 0xFFFFF), b = (uint32_t)((v >> 20) & 0xFFFFF);
+				bhip_rec_store(rec, e++, a, 0xFFFFu); bhip_rec_store(rec, e++, b, 0xFFFFu);
+				worst = a > worst ? a : worst; worst = b > worst ? b : worst;
+			}
+			if (n) { const uint32_t v = ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)) & 0xFFFFF; bhip_rec_store(rec, e++, v, 0xFFFFu); worst = v > worst ? v : worst; }
+		}
+		if (worst >= n_clumps) atomicMax(bad, worst);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lane-resolved accelerator.  The .acx says which CLUMPS contain a word; at upload we also work out which of the 16
+// LANES of the clump contain it (a 16-bit mask per list entry), so that the prefilter can count seed words per reference
+// lane and hand only the lanes that can hold an alignment to the edit-distance kernels (2-3 lanes per candidate clump
+// instead of all 16).  k_extract_kmers emits (word << 24 | clump, 1 << lane) for every A/C/G/T-only K-mer of every lane,
+// a device radix sort + OR-reduce-by-key gives one mask per (word, clump), and k_attach_masks looks every .acx entry up.
+// Entries the extraction does not know (words the reference added by IUPAC expansion, burst.c:3368-3377) get 0xFFFF:
+// every lane, i.e. the clump-level behaviour.  Masks only ever add lanes, never drop one, so results are unchanged.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_extract_kmers(const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
+                                const uint64_t *__restrict__ key_off, uint32_t c0, uint32_t c1, int K,     // clumps [c0, c1): one slice of the database
+                                unsigned long long *__restrict__ keys, uint16_t *__restrict__ vals, uint32_t *__restrict__ ambig_lanes) {
+	const uint64_t n_threads = (uint64_t)(c1 - c0) * 16;
+	const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_threads; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t c = c0 + (uint32_t)(i >> 4), z = (uint32_t)(i & 15), L = clump_len[c], nchunks = (L + 31) >> 5;
+		const uint4 *rp = ref + ref_off[c] * 16 + z;
+		unsigned long long *kout = keys + (key_off[c] - key_off[c0]) + (uint64_t)z * L;
+		uint16_t *vout = vals + (key_off[c] - key_off[c0]) + (uint64_t)z * L;
+		uint32_t w = 0, run = 0, amb = 0;
+		for (uint32_t t = 0; t < nchunks; ++t) {
+			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
+			for (uint32_t k = 0; k < 32; ++k) {
+				const uint32_t pos = t * 32 + k;
+				if (pos >= L) break;
+				const uint32_t sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
+				amb |= sym > 4u;
+				run = (sym - 1u) < 4u ? run + 1 : 0;
+				w = ((w << 2) | ((sym - 1u) & 3u)) & wmask;
+				// the word ENDING at pos is stored in slot pos (slots 0..K-2 and words with other symbols are invalid)
+				kout[pos] = run >= (uint32_t)K ? (((unsigned long long)w << 24) | c) : ~0ull;
+				vout[pos] = (uint16_t)(1u << z);
+			}
+		}
+		// a lane with IUPAC / N symbols can match words it does not literally contain (the .acx lists them for the clump
+		// through the reference's expansion): such a lane takes part in every entry of its clump
+		if (amb) atomicOr(&ambig_lanes[c], 1u << z);
+	}
+}
+
+__global__ void k_attach_masks(BhipAcxView acx, uint64_t n_words,
+                               const unsigned long long *__restrict__ ukeys, const uint16_t *__restrict__ umasks, uint32_t n_unique,
+                               const uint32_t *__restrict__ ambig_lanes, uint8_t *__restrict__ rec,     // mask bytes of the 5-byte records
+                               uint32_t c0, uint32_t c1) {                                                 // only entries of clumps [c0, c1)
+	// one thread per word walks its list (a few entries); the key of an entry is (word, clump), looked up in the folded tuples
+	for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+		unsigned long long e; uint32_t n;
+		bhip_acx_range(acx, (uint32_t)w, e, n);
+		for (; n; --n, ++e) {
+			const uint32_t ce = bhip_acx_clump(acx.rec, e);
+			if (ce < c0 || ce >= c1) continue;
+			const unsigned long long key = ((unsigned long long)w << 24) | ce;
+			uint32_t a = 0, b = n_unique;
+			while (a < b) { const uint32_t mid = a + ((b - a) >> 1); if (ukeys[mid] < key) a = mid + 1; else b = mid; }
+			const uint32_t m = ((a < n_unique && ukeys[a] == key) ? (uint32_t)umasks[a] : 0xFFFFu) | (ambig_lanes[ce] & 0xFFFFu);
+			uint8_t *p = rec + e * (unsigned long long)BHIP_REC_BYTES;
+			p[3] = (uint8_t)m; p[4] = (uint8_t)(m >> 8);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host side.  Temporary device buffers are released when they go out of scope.
+// ------------------------------------------------------------------------------------------------
+struct DTmp : DBuf { ~DTmp() { release(); } };
+#define ARC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+// Offset lines, total and statistics from the list lengths on the device (Lens[4^K], burst.c:3558): sums of 14 -> 64-bit bases
+// (hipCUB scan) -> lines; occurrence-weighted mean list length (sizes the prefilter's per-query tables) and the longest list.
+static int acx_lines_from_lens(Handle *h, const uint32_t *d_lens, uint64_t nw, uint64_t *tot_out, uint32_t *maxlen_out) {
+	const uint64_t n_lines = (nw + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS;
+	DTmp d_red, d_tmp, d_lsum, d_lbase;
+	ARC(d_red.reserve(64));
+	ARC(h->acx_lines.reserve((n_lines + 1) * 64));
+	ARC(d_lsum.reserve((n_lines + 2) * 8));
+	ARC(d_lbase.reserve((n_lines + 2) * 8));
+	auto to_sq = [] __host__ __device__(uint32_t n) -> double { return (double)n * (double)n; };
+	hipcub::TransformInputIterator<double, decltype(to_sq), const uint32_t *> it_sq(d_lens, to_sq);
+	unsigned long long *r_tot = d_red.as<unsigned long long>(); double *r_sq = (double *)(r_tot + 1); uint32_t *r_max = (uint32_t *)(r_tot + 2);
+	size_t tb = 0, tb1 = 0;
+	HIPCHK(hipcub::DeviceReduce::Sum(nullptr, tb1, it_sq, r_sq, (int)nw, h->stream)); tb = std::max(tb, tb1);
+	HIPCHK(hipcub::DeviceReduce::Max(nullptr, tb1, d_lens, r_max, (int)nw, h->stream)); tb = std::max(tb, tb1);
+	HIPCHK(hipcub::DeviceScan::ExclusiveScan(nullptr, tb1, d_lsum.as<unsigned long long>(), d_lbase.as<unsigned long long>(), hipcub::Sum(), 0ull, (int)(n_lines + 1), h->stream)); tb = std::max(tb, tb1);
+	ARC(d_tmp.reserve(tb + 16));
+	tb1 = tb; HIPCHK(hipcub::DeviceReduce::Sum(d_tmp.p, tb1, it_sq, r_sq, (int)nw, h->stream));
+	tb1 = tb; HIPCHK(hipcub::DeviceReduce::Max(d_tmp.p, tb1, d_lens, r_max, (int)nw, h->stream));
+	const uint32_t lg = (uint32_t)std::min<uint64_t>((n_lines + 255) / 256, (uint64_t)h->n_cu * 32);
+	HIPCHK(hipMemsetAsync(d_lsum.p, 0, (n_lines + 2) * 8, h->stream));
+	hipLaunchKernelGGL(k_acx_lines, dim3(lg), dim3(256), 0, h->stream, d_lens, nw, 0, d_lsum.as<unsigned long long>(), h->acx_lines.as<uint4>());
+	HIPCHK(hipGetLastError());
+	tb1 = tb; HIPCHK(hipcub::DeviceScan::ExclusiveScan(d_tmp.p, tb1, d_lsum.as<unsigned long long>(), d_lbase.as<unsigned long long>(), hipcub::Sum(), (unsigned long long)h->acx_bias, (int)(n_lines + 1), h->stream));
+	hipLaunchKernelGGL(k_acx_lines, dim3(lg), dim3(256), 0, h->stream, d_lens, nw, 1, d_lbase.as<unsigned long long>(), h->acx_lines.as<uint4>());
+	HIPCHK(hipGetLastError());
+	unsigned long long red[3], tot_b = 0;
+	HIPCHK(hipMemcpyAsync(red, d_red.p, 24, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipMemcpyAsync(&tot_b, d_lbase.as<unsigned long long>() + n_lines, 8, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	const uint64_t tot = tot_b - h->acx_bias;
+	double sq; memcpy(&sq, &red[1], 8);
+	uint32_t maxlen; memcpy(&maxlen, &red[2], 4);
+	h->acx_wmean = tot ? sq / (double)tot : 0.0;
+	if (maxlen > h->n_clumps || maxlen >= (1u << 24)) return fail(BHIP_E_ARG, "an accelerator list has %u entries, the database %u clumps (wrong K for this file?)", maxlen, h->n_clumps);
+	if (tot_b >= (1ull << 40)) return fail(BHIP_E_ARG, "accelerator with %llu entries exceeds the 40-bit entry numbers of the device layout", (unsigned long long)tot);
+	*tot_out = tot; *maxlen_out = maxlen;
+	return 0;
+}
+
+static int set_badlist(Handle *h, const uint32_t *badlist, uint32_t n_bad) {
+	h->n_bad = n_bad;
+	ARC(h->bad.reserve(((size_t)n_bad + 1) * sizeof(uint32_t)));
+	for (uint32_t i = 0; i < n_bad; ++i) if (badlist[i] >= h->n_clumps) return fail(BHIP_E_ARG, "BadList entry out of range");
+	if (n_bad) HIPCHK(hipMemcpy(h->bad.p, badlist, (size_t)n_bad * sizeof(uint32_t), hipMemcpyHostToDevice));
+	return 0;
+}
+
+// per-entry lane masks of a LOADED accelerator (see "Lane-resolved accelerator" above).  Skipped (has_masks stays false, clump-level
+// behaviour) when the scratch does not fit.
+struct BitOrU16 { __host__ __device__ uint16_t operator()(const uint16_t &a, const uint16_t &b) const { return (uint16_t)(a | b); } };
+static int build_lane_masks(Handle *h) {
+	const uint32_t nC = h->n_clumps;
+	std::vector<uint64_t> key_off(nC + 1);
+	key_off[0] = 0;
+	for (uint32_t c = 0; c < nC; ++c) key_off[c + 1] = key_off[c] + 16ull * h->h_clump_len[c];
+	if (key_off[nC] == 0 || !h->n_ent) return 0;
+	// The (word, clump, lane) tuples of the whole database may not fit next to it (26 bytes of sort space per reference
+	// position): the clumps are processed in slices, each slice sorted and folded on its own and joined to the list entries
+	// of its clumps.  BHIP_MASK_SLICE (reference positions per slice) is the test hook for small databases.
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+	const double after_masks = (double)free_b - 4.0 * (double)nC - 65536.0;      // the masks go into the records that are already there
+	if (after_masks <= 0) return 0;
+	uint64_t slice_items = (uint64_t)std::min<double>(2147483000.0, after_masks * 0.8 / 26.0);
+	if (const char *ev = getenv("BHIP_MASK_SLICE")) { const long long v = atoll(ev); if (v > 0) slice_items = (uint64_t)v; }
+	uint64_t biggest = 0;
+	for (uint32_t c = 0; c < nC; ++c) biggest = std::max(biggest, key_off[c + 1] - key_off[c]);
+	if (slice_items < biggest) { if ((double)biggest * 26.0 > after_masks) return 0; slice_items = biggest; }
+	DTmp d_koff, k0, k1, v0, v1, nruns, tmp, amb;
+	const uint64_t cap_items = std::min<uint64_t>(slice_items, key_off[nC]);
+	ARC(d_koff.reserve((nC + 1) * 8)); ARC(k0.reserve(cap_items * 8)); ARC(k1.reserve(cap_items * 8)); ARC(v0.reserve(cap_items * 2)); ARC(v1.reserve(cap_items * 2));
+	ARC(nruns.reserve(16)); ARC(amb.reserve((size_t)nC * 4 + 16));
+	HIPCHK(hipMemsetAsync(amb.p, 0, (size_t)nC * 4, h->stream));
+	HIPCHK(hipMemcpyAsync(d_koff.p, key_off.data(), (nC + 1) * 8, hipMemcpyHostToDevice, h->stream));
+	const int end_bit = 2 * h->K + 24;
+	uint32_t n_slices = 0;
+	for (uint32_t c0 = 0; c0 < nC;) {
+		uint32_t c1 = c0 + 1;
+		while (c1 < nC && key_off[c1 + 1] - key_off[c0] <= slice_items) ++c1;
+		const uint64_t n_items = key_off[c1] - key_off[c0];
+		++n_slices;
+		hipLaunchKernelGGL(k_extract_kmers, dim3(std::min<uint32_t>(((c1 - c0) * 16 + 255) / 256, (uint32_t)h->n_cu * 16)), dim3(256), 0, h->stream, h->ref.as<uint4>(),
+			h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_koff.as<uint64_t>(), c0, c1, h->K, k0.as<unsigned long long>(), v0.as<uint16_t>(), amb.as<uint32_t>());
+		HIPCHK(hipGetLastError());
+		size_t tb = 0;
+		hipcub::DoubleBuffer<unsigned long long> dk(k0.as<unsigned long long>(), k1.as<unsigned long long>());
+		hipcub::DoubleBuffer<uint16_t> dv(v0.as<uint16_t>(), v1.as<uint16_t>());
+		HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (int)n_items, 0, end_bit, h->stream));
+		ARC(tmp.reserve(tb));
+		HIPCHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, dk, dv, (int)n_items, 0, end_bit, h->stream));
+		// invalid slots carry key ~0, which after masking to end_bit sorts last (all ones) -- their run is simply never looked up
+		unsigned long long *skeys = dk.Current(); uint16_t *svals = dv.Current();
+		unsigned long long *ukeys = dk.Alternate(); uint16_t *umasks = dv.Alternate();
+		size_t tb2 = 0;
+		HIPCHK(hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, skeys, ukeys, svals, umasks, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
+		ARC(tmp.reserve(tb2));
+		HIPCHK(hipcub::DeviceReduce::ReduceByKey(tmp.p, tb2, skeys, ukeys, svals, umasks, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
+		uint32_t n_unique = 0;
+		HIPCHK(hipMemcpyAsync(&n_unique, nruns.p, 4, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		hipLaunchKernelGGL(k_attach_masks, dim3((uint32_t)h->n_cu * 32), dim3(256), 0, h->stream,
+			h->acx_view(), (uint64_t)(1ull << (2 * h->K)), ukeys, umasks, n_unique, amb.as<uint32_t>(), (uint8_t *)h->acx_view().rec, c0, c1);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipStreamSynchronize(h->stream));
+		c0 = c1;
+	}
+	if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] lane masks: %llu reference positions in %u slice(s)\n", (unsigned long long)key_off[nC], n_slices);
+	h->has_masks = true;
+	return 0;
+}
+
+// The accelerator of a file: Lens[4^K] goes up as it is; offsets, the byte positions of the packed lists, the total and the
+// statistics are scans / reductions on the device (at K = 15 the table has 2^30 words); the packed list area goes up as it is
+// on disk and is decoded to 5-byte records by the device.
+int bhip_load_accelerator(Handle *h, const uint32_t *acx_lens, const void *acx_lists, int acx_fmt, int K, const uint32_t *badlist, uint32_t n_bad) {
+	const uint64_t nw = 1ull << (2 * K), nblk = (nw + 255) >> 8;
+	DTmp d_lens, d_tmp, d_bsum, d_bdelta, d_bbase, d_lists, d_flag;
+	if (const char *ev = getenv("BHIP_TEST_ENTRY_BIAS")) h->acx_bias = strtoull(ev, nullptr, 0);
+	ARC(d_lens.reserve(nw * sizeof(uint32_t)));
+	ARC(d_bsum.reserve((nblk + 2) * 8));
+	ARC(d_bdelta.reserve(nw * sizeof(uint32_t) + 16));
+	ARC(d_bbase.reserve((nblk + 2) * 8));
+	HIPCHK(hipMemcpyAsync(d_lens.p, acx_lens, nw * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+	uint64_t tot = 0; uint32_t maxlen = 0;
+	ARC(acx_lines_from_lens(h, d_lens.as<uint32_t>(), nw, &tot, &maxlen));
+	// byte offsets of the packed lists on disk
+	const uint32_t og = (uint32_t)std::min<uint64_t>(nblk, (uint64_t)h->n_cu * 16);
+	HIPCHK(hipMemsetAsync(d_bsum.p, 0, (nblk + 2) * 8, h->stream));
+	hipLaunchKernelGGL(k_acx_offsets, dim3(og), dim3(256), 0, h->stream, d_lens.as<uint32_t>(), nw, acx_fmt == 1 ? 2 : 1, d_bdelta.as<uint32_t>(), d_bsum.as<unsigned long long>());
+	HIPCHK(hipGetLastError());
+	size_t tb = 0;
+	HIPCHK(hipcub::DeviceScan::ExclusiveScan(nullptr, tb, d_bsum.as<unsigned long long>(), d_bbase.as<unsigned long long>(), hipcub::Sum(), 0ull, (int)(nblk + 1), h->stream));
+	ARC(d_tmp.reserve(tb + 16));
+	HIPCHK(hipcub::DeviceScan::ExclusiveScan(d_tmp.p, tb, d_bsum.as<unsigned long long>(), d_bbase.as<unsigned long long>(), hipcub::Sum(), 0ull, (int)(nblk + 1), h->stream));
+	unsigned long long bytes = 0;
+	HIPCHK(hipMemcpyAsync(&bytes, d_bbase.as<unsigned long long>() + nblk, 8, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	ARC(h->acx_rec.reserve(tot * BHIP_REC_BYTES + 16));
+	ARC(d_lists.reserve(bytes + 16)); ARC(d_flag.reserve(16));
+	if (bytes) HIPCHK(hipMemcpyAsync(d_lists.p, acx_lists, bytes, hipMemcpyHostToDevice, h->stream));
+	HIPCHK(hipMemsetAsync(d_flag.p, 0, 16, h->stream));
+	hipLaunchKernelGGL(k_acx_decode, dim3((uint32_t)h->n_cu * 32), dim3(256), 0, h->stream, d_lists.as<uint8_t>(), d_bbase.as<unsigned long long>(),
+		d_bdelta.as<uint32_t>(), h->acx_view(), nw, acx_fmt, h->n_clumps, (uint8_t *)h->acx_view().rec, d_flag.as<uint32_t>());
+	HIPCHK(hipGetLastError());
+	uint32_t worst = 0;
+	HIPCHK(hipMemcpyAsync(&worst, d_flag.p, 4, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	if (worst) return fail(BHIP_E_ARG, "an accelerator entry refers to clump %u >= %u", worst, h->n_clumps);
+	d_lists.release(); d_lens.release(); d_bdelta.release(); d_bsum.release(); d_bbase.release();
+	if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] accelerator: K=%d, %llu entries (first entry number %llu), %.2f B per entry on the device (records %d B + offsets)\n", K,
+		(unsigned long long)tot, (unsigned long long)h->acx_bias, tot ? (double)(tot * BHIP_REC_BYTES + ((nw + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS) * 64) / (double)tot : 0.0, BHIP_REC_BYTES);
+	ARC(set_badlist(h, badlist, n_bad));
+	h->has_acx = true; h->K = K; h->n_ent = tot;
+	if (!getenv("BHIP_NO_LANE_MASKS")) ARC(build_lane_masks(h));
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Accelerator built on the device from the references alone (make_accelerator, burst.c:3304-3532).
+// A list entry (word, clump) exists iff the word is one of the IUPAC expansions (AMBIGS, burst.c:1372-1375) of a K-symbol
+// window of one of the clump's lanes; windows with a symbol of code 0 have none, windows with N none when N is penalised
+// (burst.c:3368-3374).  The reference first estimates every clump's expansion -- sum over the windows of 3^a (N penalised) or
+// "4^a" (its table says 61 for a = 3) where a counts the ambiguous symbols among the K - 1 symbols BEFORE the window's last
+// (burst.c:3343-3351: the count is taken before the last symbol is added) -- and puts a clump whose estimate reaches 2^24
+// (2^31 - 1 for K = 15) on the BadList instead of indexing it (burst.c:3322, 3351).  Reproduced literally: same entries, same
+// BadList.  One thread per (clump, lane), symbol after symbol, the last K symbol codes in one 64-bit register.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t amb_count(uint32_t code) { return (uint32_t)((0x3333222222411110ull >> (4u * code)) & 15u); }
+__device__ __forceinline__ uint32_t amb_bases(uint32_t code) {      // up to four 2-bit bases, first option in the low bits
+	return (uint32_t)(((code < 8 ? 0x040EE40302010000ull : 0x383424390C090D08ull) >> (8u * (code & 7u))) & 255u);
+}
+__device__ __forceinline__ unsigned long long amb_product(unsigned long long win, int K) {
+	unsigned long long p = 1;
+	for (int t = 0; t < K; ++t) p *= amb_count((uint32_t)(win >> (4 * t)) & 15u);
+	return p;
+}
+__device__ const unsigned long long c_ipow[2][16] = {
+	{1, 4, 16, 61, 256, 1024, 4096, 16384, 65536, 262144, 1048576, 4194304, 16777216, 67108864, 268435456, 1073741824},      // N matches everything (-y)
+	{1, 3, 9, 27, 81, 243, 729, 2187, 6561, 19683, 59049, 177147, 531441, 1594323, 4782969, 14348907}};                     // N penalised (default)
+
+// per clump: the reference's expansion estimate (tsum) and the true number of words its ambiguous windows expand to (nexp)
+__global__ void k_acx_budget(const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len, uint32_t n_clumps, uint32_t tot_refs,
+                             int K, int z, unsigned long long *__restrict__ tsum, unsigned long long *__restrict__ nexp) {
+	const uint64_t n_threads = (uint64_t)n_clumps * 16;
+	const uint32_t AMBIG = 4u + (uint32_t)z;
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_threads; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t c = (uint32_t)(i >> 4), zz = (uint32_t)(i & 15);
+		if (16ull * c + zz >= tot_refs) continue;                                    // burst.c:3336: lanes beyond the last reference
+		const uint32_t L = clump_len[c], nchunks = (L + 31) >> 5;
+		const uint4 *rp = ref + ref_off[c] * 16 + zz;
+		// the lane's own length: pads (code 0) at the end do not count
+		uint32_t ll = 0;
+		for (uint32_t t = nchunks; t-- > 0 && !ll;) {
+			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
+			for (int k = 31; k >= 0; --k) if ((dw[k >> 3] >> (4 * (k & 7))) & 15u) { ll = t * 32 + (uint32_t)k + 1; break; }
+		}
+		if (ll > L) ll = L;
+		if (ll < (uint32_t)K) continue;
+		unsigned long long win = 0, ts = 0, nx = 0;
+		uint32_t asum = 0, run = 0, lit = 0;
+		for (uint32_t t = 0; t * 32 < ll; ++t) {
+			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
+			for (uint32_t k = 0; k < 32 && t * 32 + k < ll; ++k) {
+				const uint32_t j = t * 32 + k, sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
+				if (j >= (uint32_t)K - 1) { ts += c_ipow[z ? 1 : 0][asum & 15u]; if (((uint32_t)(win >> (4 * (K - 2))) & 15u) > AMBIG) --asum; }
+				if (sym > AMBIG) ++asum;
+				run = (sym >= 1u && !(z && sym == 5u)) ? run + 1 : 0;
+				lit = (sym - 1u) < 4u ? lit + 1 : 0;
+				win = (win << 4) | sym;
+				if (run >= (uint32_t)K && lit < (uint32_t)K) nx += amb_product(win, K);
+			}
+		}
+		atomicAdd(&tsum[c], ts);
+		if (nx) atomicAdd(&nexp[c], nx);
+	}
+}
+
+// (word << 24 | clump, 1 << lane) for every window of the clumps [c0, c1): unambiguous windows into the slot of their last
+// position (slot_off: 16 x ClumpLen slots per clump), the expansions of ambiguous ones appended behind the slots of the slice
+// (`extra`, one atomic reservation per window); windows without a word, and every window of a BadList clump, leave key ~0.
+__global__ void k_acx_extract(const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
+                              const uint64_t *__restrict__ slot_off, const uint8_t *__restrict__ is_bad, uint32_t c0, uint32_t c1, uint32_t tot_refs, int K, int z,
+                              unsigned long long *__restrict__ keys, uint16_t *__restrict__ vals, unsigned long long extra_base, unsigned long long *__restrict__ extra_cursor) {
+	const uint64_t n_threads = (uint64_t)(c1 - c0) * 16;
+	const uint32_t wmask = (1u << (2 * K)) - 1u;
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_threads; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t c = c0 + (uint32_t)(i >> 4), zz = (uint32_t)(i & 15), L = clump_len[c], nchunks = (L + 31) >> 5;
+		const uint4 *rp = ref + ref_off[c] * 16 + zz;
+		unsigned long long *kout = keys + (slot_off[c] - slot_off[c0]) + (uint64_t)zz * L;
+		uint16_t *vout = vals + (slot_off[c] - slot_off[c0]) + (uint64_t)zz * L;
+		const bool live = !is_bad[c] && 16ull * c + zz < tot_refs;
+		const uint16_t bit = (uint16_t)(1u << zz);
+		unsigned long long win = 0;
+		uint32_t w = 0, run = 0, lit = 0;
+		for (uint32_t t = 0; t < nchunks; ++t) {
+			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
+			for (uint32_t k = 0; k < 32; ++k) {
+				const uint32_t pos = t * 32 + k;
+				if (pos >= L) break;
+				const uint32_t sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
+				run = (sym >= 1u && !(z && sym == 5u)) ? run + 1 : 0;
+				lit = (sym - 1u) < 4u ? lit + 1 : 0;
+				w = ((w << 2) | ((sym - 1u) & 3u)) & wmask;
+				win = (win << 4) | sym;
+				kout[pos] = (live && lit >= (uint32_t)K) ? (((unsigned long long)w << 24) | c) : ~0ull;
+				vout[pos] = bit;
+				if (live && run >= (uint32_t)K && lit < (uint32_t)K) {
+					const unsigned long long prod = amb_product(win, K);
+					unsigned long long e = extra_base + atomicAdd(extra_cursor, prod);
+					for (unsigned long long idx = 0; idx < prod; ++idx, ++e) {
+						unsigned long long r = idx; uint32_t word = 0;
+						for (int s = 0; s < K; ++s) {          // symbol s counted from the window's end: 2-bit digit s of the word
+							const uint32_t code = (uint32_t)(win >> (4 * s)) & 15u, n = amb_count(code), d = (uint32_t)(r % n);
+							r /= n;
+							word |= ((amb_bases(code) >> (2u * d)) & 3u) << (2 * s);
+						}
+						keys[e] = ((unsigned long long)word << 24) | c;
+						vals[e] = bit;
+					}
+				}
+			}
+		}
+	}
+}
+
+// list lengths: one count per distinct (word, clump); keys that are not words (~0: bits above end_bit set) are skipped
+__global__ void k_acx_hist(const unsigned long long *__restrict__ ukeys, uint32_t n_unique, int end_bit, uint32_t *__restrict__ lens) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_unique; i += gridDim.x * blockDim.x) {
+		const unsigned long long key = ukeys[i];
+		if (key >> end_bit) continue;
+		atomicAdd(&lens[(uint32_t)(key >> 24)], 1u);
+	}
+}
+// head[i] = i for the first tuple of every word, 0 elsewhere: an inclusive max-scan turns it into "first tuple of my word"
+__global__ void k_acx_heads(const unsigned long long *__restrict__ ukeys, uint32_t n_unique, uint32_t *__restrict__ head) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_unique; i += gridDim.x * blockDim.x)
+		head[i] = (i && (ukeys[i] >> 24) != (ukeys[i - 1] >> 24)) ? i : 0u;
+}
+// records of one slice: tuple i of word w goes to entry first(w) + (entries of w written by earlier slices) + (rank inside the word);
+// the tuples are sorted by (word, clump) and the slices are ascending clump ranges, so every list ends up in ascending clump order
+// (what the reference writes with one thread)
+__global__ void k_acx_fill(BhipAcxView acx, const unsigned long long *__restrict__ ukeys, const uint16_t *__restrict__ umasks, const uint32_t *__restrict__ head,
+                           uint32_t n_unique, int end_bit, const uint32_t *__restrict__ cursor, uint8_t *__restrict__ rec, uint32_t all_lanes) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_unique; i += gridDim.x * blockDim.x) {
+		const unsigned long long key = ukeys[i];
+		if (key >> end_bit) continue;
+		const uint32_t w = (uint32_t)(key >> 24);
+		unsigned long long beg; uint32_t n;
+		bhip_acx_range(acx, w, beg, n);
+		bhip_rec_store(rec, beg + (cursor ? cursor[w] : 0u) + (i - head[i]), (uint32_t)key & 0xFFFFFFu, all_lanes ? 0xFFFFu : (uint32_t)umasks[i]);
+	}
+}
+__global__ void k_acx_advance(const unsigned long long *__restrict__ ukeys, const uint32_t *__restrict__ head, uint32_t n_unique, int end_bit, uint32_t *__restrict__ cursor) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_unique; i += gridDim.x * blockDim.x) {
+		const unsigned long long key = ukeys[i];
+		if (key >> end_bit) continue;
+		if (i + 1 == n_unique || (ukeys[i + 1] >> 24) != (key >> 24)) cursor[(uint32_t)(key >> 24)] += i - head[i] + 1;      // last tuple of its word in this slice
+	}
+}
+// back to the file's tables
+__global__ void k_acx_lens_from_lines(BhipAcxView acx, uint64_t n_words, uint32_t *__restrict__ lens) {
+	for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+		unsigned long long e; uint32_t n;
+		bhip_acx_range(acx, (uint32_t)w, e, n);
+		lens[w] = n;
+	}
+}
+__global__ void k_acx_rec_export(const uint8_t *__restrict__ rec, unsigned long long e0, uint64_t n, uint32_t *__restrict__ clumps, uint16_t *__restrict__ masks) {
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint2 r = bhip_acx_rec(rec, e0 + i);
+		clumps[i] = r.x;
+		if (masks) masks[i] = (uint16_t)r.y;
+	}
+}
+
+int bhip_build_accelerator(Handle *h, int K, int z) {
+	const uint32_t nC = h->n_clumps;
+	const uint64_t nw = 1ull << (2 * K);
+	const int end_bit = 2 * K + 24;
+	const bool dbg = getenv("BHIP_DEBUG") != nullptr;
+	const auto t_begin = std::chrono::steady_clock::now();
+	auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+	if (const char *ev = getenv("BHIP_TEST_ENTRY_BIAS")) h->acx_bias = strtoull(ev, nullptr, 0);
+	h->K = K;
+	// 1. expansion estimate and true expansion per clump -> BadList
+	std::vector<unsigned long long> tsum(nC), nexp(nC);
+	std::vector<uint8_t> is_bad(nC, 0);
+	std::vector<uint32_t> badlist;
+	DTmp d_bad, d_soff;
+	{
+		DTmp d_ts, d_nx;
+		ARC(d_ts.reserve((size_t)nC * 8)); ARC(d_nx.reserve((size_t)nC * 8));
+		HIPCHK(hipMemsetAsync(d_ts.p, 0, (size_t)nC * 8, h->stream)); HIPCHK(hipMemsetAsync(d_nx.p, 0, (size_t)nC * 8, h->stream));
+		hipLaunchKernelGGL(k_acx_budget, dim3(std::min<uint32_t>((nC * 16u + 255u) / 256u, (uint32_t)h->n_cu * 16)), dim3(256), 0, h->stream, h->ref.as<uint4>(), h->ref_off.as<uint64_t>(),
+			h->clump_len.as<uint32_t>(), nC, h->tot_refs, K, z ? 1 : 0, d_ts.as<unsigned long long>(), d_nx.as<unsigned long long>());
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(tsum.data(), d_ts.p, (size_t)nC * 8, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(nexp.data(), d_nx.p, (size_t)nC * 8, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+	}
+	const unsigned long long full_size = K > 14 ? 0x7FFFFFFFull : (1ull << 24);      // burst.c:3322
+	for (uint32_t c = 0; c < nC; ++c) if (tsum[c] >= full_size) { is_bad[c] = 1; badlist.push_back(c); nexp[c] = 0; }
+	std::vector<uint64_t> slot_off(nC + 1), item_off(nC + 1);
+	slot_off[0] = item_off[0] = 0;
+	for (uint32_t c = 0; c < nC; ++c) { slot_off[c + 1] = slot_off[c] + 16ull * h->h_clump_len[c]; item_off[c + 1] = item_off[c] + 16ull * h->h_clump_len[c] + nexp[c]; }
+	ARC(d_bad.reserve((size_t)nC + 16)); ARC(d_soff.reserve(((size_t)nC + 1) * 8));
+	HIPCHK(hipMemcpyAsync(d_bad.p, is_bad.data(), nC, hipMemcpyHostToDevice, h->stream));
+	HIPCHK(hipMemcpyAsync(d_soff.p, slot_off.data(), ((size_t)nC + 1) * 8, hipMemcpyHostToDevice, h->stream));
+	// 2. slices of clumps whose tuples fit the sort buffers (26 bytes per tuple) next to everything that is still to come: the
+	// length table, the running list positions (several slices only), the offset lines and the records (at most one per tuple)
+	DTmp d_lens, d_cursor, k0, k1, v0, v1, nruns, tmp, d_xcur;
+	ARC(d_lens.reserve(nw * 4 + 16));
+	HIPCHK(hipMemsetAsync(d_lens.p, 0, nw * 4, h->stream));
+	size_t free_b = 0, total_b = 0;
+	HIPCHK(hipMemGetInfo(&free_b, &total_b));
+	const uint64_t n_lines = (nw + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS;
+	const double room = (double)free_b - (double)nw * 4.0 - (double)n_lines * 64.0 * 1.3 - (double)item_off[nC] * BHIP_REC_BYTES * 1.3 - (double)(64u << 20);
+	uint64_t biggest = 0;
+	for (uint32_t c = 0; c < nC; ++c) biggest = std::max(biggest, item_off[c + 1] - item_off[c]);
+	uint64_t slice_items = room > 0 ? (uint64_t)std::min<double>(2147483000.0, room * 0.8 / 26.0) : 0;
+	if (const char *ev = getenv("BHIP_MASK_SLICE")) { const long long v = atoll(ev); if (v > 0) slice_items = std::max<uint64_t>((uint64_t)v, biggest); }
+	if (slice_items < biggest || biggest > 2147483000ull)
+		return fail(BHIP_E_DEVICE, "not enough device memory to build the accelerator (a clump alone has %llu word tuples, %.1f GB free)", (unsigned long long)biggest, (double)free_b / 1e9);
+	std::vector<uint32_t> cuts(1, 0);
+	for (uint32_t c0 = 0; c0 < nC;) {
+		uint32_t c1 = c0 + 1;
+		while (c1 < nC && item_off[c1 + 1] - item_off[c0] <= slice_items) ++c1;
+		cuts.push_back(c1); c0 = c1;
+	}
+	const uint32_t n_slices = (uint32_t)cuts.size() - 1;
+	uint64_t cap_items = 0;
+	for (uint32_t s = 0; s < n_slices; ++s) cap_items = std::max(cap_items, item_off[cuts[s + 1]] - item_off[cuts[s]]);
+	ARC(k0.reserve(cap_items * 8 + 16)); ARC(k1.reserve(cap_items * 8 + 16)); ARC(v0.reserve(cap_items * 2 + 16)); ARC(v1.reserve(cap_items * 2 + 16));
+	ARC(nruns.reserve(16)); ARC(d_xcur.reserve(16));
+	unsigned long long *ukeys = nullptr; uint16_t *umasks = nullptr; unsigned long long *spare = nullptr; uint32_t n_unique = 0;
+	// tuples of slice s, sorted and folded: ukeys / umasks / n_unique (spare = the other key buffer, free for scratch)
+	auto fold_slice = [&](uint32_t s) -> int {
+		const uint32_t c0 = cuts[s], c1 = cuts[s + 1];
+		const uint64_t n_slots = slot_off[c1] - slot_off[c0], n_items = item_off[c1] - item_off[c0];
+		n_unique = 0;
+		if (!n_items) return 0;
+		HIPCHK(hipMemsetAsync(d_xcur.p, 0, 8, h->stream));
+		hipLaunchKernelGGL(k_acx_extract, dim3(std::min<uint32_t>(((c1 - c0) * 16 + 255) / 256, (uint32_t)h->n_cu * 16)), dim3(256), 0, h->stream, h->ref.as<uint4>(),
+			h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_soff.as<uint64_t>(), d_bad.as<uint8_t>(), c0, c1, h->tot_refs, K, z ? 1 : 0,
+			k0.as<unsigned long long>(), v0.as<uint16_t>(), (unsigned long long)n_slots, d_xcur.as<unsigned long long>());
+		HIPCHK(hipGetLastError());
+		size_t tb = 0;
+		hipcub::DoubleBuffer<unsigned long long> dk(k0.as<unsigned long long>(), k1.as<unsigned long long>());
+		hipcub::DoubleBuffer<uint16_t> dv(v0.as<uint16_t>(), v1.as<uint16_t>());
+		HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (int)n_items, 0, end_bit, h->stream));
+		ARC(tmp.reserve(tb));
+		HIPCHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, dk, dv, (int)n_items, 0, end_bit, h->stream));
+		unsigned long long *skeys = dk.Current(); uint16_t *svals = dv.Current();
+		ukeys = dk.Alternate(); umasks = dv.Alternate(); spare = skeys;
+		size_t tb2 = 0;
+		HIPCHK(hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, skeys, ukeys, svals, umasks, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
+		ARC(tmp.reserve(tb2));
+		HIPCHK(hipcub::DeviceReduce::ReduceByKey(tmp.p, tb2, skeys, ukeys, svals, umasks, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
+		HIPCHK(hipMemcpyAsync(&n_unique, nruns.p, 4, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		return 0;
+	};
+	const uint32_t g = (uint32_t)h->n_cu * 16;
+	// 3. first pass: list lengths
+	for (uint32_t s = 0; s < n_slices; ++s) {
+		ARC(fold_slice(s));
+		if (n_unique) { hipLaunchKernelGGL(k_acx_hist, dim3(g), dim3(256), 0, h->stream, ukeys, n_unique, end_bit, d_lens.as<uint32_t>()); HIPCHK(hipGetLastError()); }
+	}
+	const double t_pass1 = since();
+	uint64_t tot = 0; uint32_t maxlen = 0;
+	ARC(acx_lines_from_lens(h, d_lens.as<uint32_t>(), nw, &tot, &maxlen));
+	ARC(h->acx_rec.reserve(tot * BHIP_REC_BYTES + 16));
+	if (n_slices > 1) { d_cursor.p = d_lens.p; d_cursor.cap = d_lens.cap; d_lens.p = nullptr; d_lens.cap = 0; HIPCHK(hipMemsetAsync(d_cursor.p, 0, nw * 4, h->stream)); }      // (the length table's memory)
+	else d_lens.release();
+	// 4. second pass: the records (one slice: the folded tuples are still there)
+	const uint32_t all_lanes = getenv("BHIP_NO_LANE_MASKS") ? 1u : 0u;
+	for (uint32_t s = 0; s < n_slices; ++s) {
+		if (n_slices > 1) ARC(fold_slice(s));
+		if (!n_unique) continue;
+		uint32_t *head_in = (uint32_t *)spare, *head = head_in + n_unique;      // 8 bytes per tuple of scratch: the sorted key buffer
+		hipLaunchKernelGGL(k_acx_heads, dim3(g), dim3(256), 0, h->stream, ukeys, n_unique, head_in);
+		HIPCHK(hipGetLastError());
+		size_t tb = 0;
+		HIPCHK(hipcub::DeviceScan::InclusiveScan(nullptr, tb, head_in, head, hipcub::Max(), (int)n_unique, h->stream));
+		ARC(tmp.reserve(tb));
+		HIPCHK(hipcub::DeviceScan::InclusiveScan(tmp.p, tb, head_in, head, hipcub::Max(), (int)n_unique, h->stream));
+		hipLaunchKernelGGL(k_acx_fill, dim3(g), dim3(256), 0, h->stream, h->acx_view(), ukeys, umasks, head, n_unique, end_bit,
+			n_slices > 1 ? d_cursor.as<uint32_t>() : (const uint32_t *)nullptr, (uint8_t *)h->acx_view().rec, all_lanes);
+		HIPCHK(hipGetLastError());
+		if (n_slices > 1) { hipLaunchKernelGGL(k_acx_advance, dim3(g), dim3(256), 0, h->stream, ukeys, head, n_unique, end_bit, d_cursor.as<uint32_t>()); HIPCHK(hipGetLastError()); }
+		HIPCHK(hipStreamSynchronize(h->stream));
+	}
+	ARC(set_badlist(h, badlist.data(), (uint32_t)badlist.size()));
+	h->has_acx = true; h->n_ent = tot; h->has_masks = !all_lanes;
+	if (dbg) fprintf(stderr, "[bhip] accelerator built on the device: K=%d, %llu entries from %llu word tuples in %u slice(s), %zu clump(s) on the BadList, %.2f B per entry; %.2f s (%.2f s for the list lengths)\n",
+		K, (unsigned long long)tot, (unsigned long long)item_off[nC], n_slices, badlist.size(), tot ? (double)(tot * BHIP_REC_BYTES + n_lines * 64) / (double)tot : 0.0, since(), t_pass1);
+	return 0;
+}
+
+// the accelerator of a handle in the file's terms: Lens[4^K] (burst.c:3558), the clump ids of all lists in word order (and
+// their lane masks), the BadList.  Any pointer may be NULL; *n_entries / *n_bad are always set.
+extern "C" int bhip_acx_export(void *handle, uint32_t *lens, uint32_t *clumps, uint16_t *masks, uint64_t cap_entries, uint64_t *n_entries,
+                               uint32_t *badlist, uint32_t cap_bad, uint32_t *n_bad) {
+	Handle *h = (Handle *)handle;
+	if (!h) return fail(BHIP_E_ARG, "null handle");
+	if (!h->has_acx) return fail(BHIP_E_ARG, "handle has no accelerator");
+	HIPCHK(hipSetDevice(h->device));
+	if (n_entries) *n_entries = h->n_ent;
+	if (n_bad) *n_bad = h->n_bad;
+	const uint64_t nw = 1ull << (2 * h->K);
+	if (lens) {
+		DTmp d;
+		ARC(d.reserve(nw * 4));
+		hipLaunchKernelGGL(k_acx_lens_from_lines, dim3((uint32_t)h->n_cu * 32), dim3(256), 0, h->stream, h->acx_view(), nw, d.as<uint32_t>());
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(lens, d.p, nw * 4, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+	}
+	if (clumps) {
+		if (cap_entries < h->n_ent) return fail(BHIP_E_CAPACITY, "entry buffer holds %llu, %llu needed", (unsigned long long)cap_entries, (unsigned long long)h->n_ent);
+		const uint64_t piece = 1ull << 26;
+		DTmp dc, dm;
+		ARC(dc.reserve(piece * 4)); if (masks) ARC(dm.reserve(piece * 2));
+		for (uint64_t e = 0; e < h->n_ent; e += piece) {
+			const uint64_t n = std::min(piece, h->n_ent - e);
+			hipLaunchKernelGGL(k_acx_rec_export, dim3((uint32_t)h->n_cu * 16), dim3(256), 0, h->stream, h->acx_view().rec, (unsigned long long)(h->acx_bias + e), n,
+				dc.as<uint32_t>(), masks ? dm.as<uint16_t>() : (uint16_t *)nullptr);
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipMemcpyAsync(clumps + e, dc.p, n * 4, hipMemcpyDeviceToHost, h->stream));
+			if (masks) HIPCHK(hipMemcpyAsync(masks + e, dm.p, n * 2, hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipStreamSynchronize(h->stream));
+		}
+	}
+	if (badlist) {
+		if (cap_bad < h->n_bad) return fail(BHIP_E_CAPACITY, "BadList buffer holds %u, %u needed", cap_bad, h->n_bad);
+		if (h->n_bad) HIPCHK(hipMemcpy(badlist, h->bad.p, (size_t)h->n_bad * 4, hipMemcpyDeviceToHost));
+	}
+	return BHIP_OK;
+}

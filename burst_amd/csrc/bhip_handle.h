@@ -1,0 +1,274 @@
+// burst_amd/csrc/bhip_handle.h -- the device handle behind the C ABI (include/burst_hip.h) and what the translation units of
+// libburst_hip.so share: kernel declarations (bhip_kernels.hip), the grow-only device buffer, the staged-batch slots, the
+// sub-pipeline lanes, the handle itself and the few host functions that cross files (bhip_init.hip: handle life cycle, database
+// upload, accelerator; bhip_stage.hip: staging and routing of batches; bhip_align.hip: the alignment chain and the kernel-level
+// entry points).
+#ifndef BHIP_HANDLE_H
+#define BHIP_HANDLE_H
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <string>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include <chrono>
+#include <thread>
+#include "burst_hip.h"
+#include "bhip_internal.h"
+
+// ---- kernels (bhip_kernels.hip) -------------------------------------------------------------------
+__global__ void k_acx_offsets(const uint32_t *, uint64_t, int, uint32_t *, unsigned long long *);
+__global__ void k_acx_lines(const uint32_t *, uint64_t, int, unsigned long long *, uint4 *);
+__global__ void k_acx_decode(const uint8_t *, const unsigned long long *, const uint32_t *, BhipAcxView, uint64_t, int, uint32_t, uint8_t *, uint32_t *);
+__global__ void k_transpose_refs(const uint8_t *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint4 *, uint4 *);
+__global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, int, int, BhipMatchMask, uint32_t *, const uint32_t *, uint32_t);
+template <bool LDS_CNT> __global__ void k_prefilter(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
+	BhipAcxView, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t,
+	unsigned long long *, const uint32_t *, const uint32_t *, const uint32_t *);
+__global__ void k_prefilter_hash(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t, BhipAcxView, int,
+	const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *, uint32_t *, uint32_t *);
+template <typename CNT> __global__ void k_prefilter_wave(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
+	BhipAcxView, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *,
+	const uint32_t *, const uint32_t *);
+template <int NW> __global__ void k_myers(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
+	const uint64_t *, const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t,
+	BhipRawHit *, uint32_t *, uint32_t, uint32_t *, uint8_t *, unsigned long long *, unsigned long long *);
+template <int NWP> __global__ void k_myers_prefix(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
+	const uint64_t *, const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t, BhipWin *, uint32_t *, uint32_t,
+	unsigned long long *, unsigned long long *);
+template <int NW> __global__ void k_myers_window(const BhipWin *, const uint32_t *, uint32_t, int, const uint32_t *, const uint32_t *, const uint64_t *,
+	const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *,
+	unsigned long long *);
+__global__ void k_extract_kmers(const uint4 *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint32_t, int, unsigned long long *, uint16_t *, uint32_t *);
+__global__ void k_attach_masks(BhipAcxView, uint64_t, const unsigned long long *, const uint16_t *, uint32_t, const uint32_t *, uint8_t *, uint32_t, uint32_t);
+template <int HTB> __global__ void k_prefilter_mask(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *,
+	uint2 *, uint32_t *, uint32_t);
+template <int CB> __global__ void k_prefilter_cf(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *,
+	uint2 *, uint32_t *, int);
+__global__ void k_task_filter(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, uint2 *, uint32_t *);
+__global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, BhipAcxView, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t, const uint16_t *);
+template <int NWP> __global__ void k_myers_prefix_task(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *,
+	const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *);
+template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *,
+	const uint32_t *, int, const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t *, const uint64_t *,
+	const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *,
+	unsigned long long, uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t);
+__global__ void k_pack_queries(const uint8_t *, const uint64_t *, uint32_t, uint32_t, uint32_t *);
+__global__ void k_unpack4(const uint8_t *, uint64_t, uint64_t, uint8_t *);
+__global__ void k_span_fill(const uint64_t *, uint32_t, uint32_t, uint64_t, uint32_t, uint64_t *, uint32_t *, uint32_t *);
+__global__ void k_route(const uint64_t *, const uint32_t *, uint32_t, const uint16_t *, const uint32_t *, const uint8_t *, uint32_t, uint32_t, uint32_t, int, int, int,
+	uint32_t *, uint8_t *, uint32_t *, BhipStageInfo *);
+__global__ void k_rescore_classify(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, int, const uint64_t *, const uint32_t *, const uint8_t *,
+	const uint32_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t, int);
+template <int SET> __global__ void k_rescore_reg(const BhipRawHit *, const uint32_t *, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, const uint32_t *, uint32_t,
+	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *);
+// error text of the calling thread (bhip_last_error); defined in bhip_init.hip
+int bhip_fail_msg(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+#define fail(...) bhip_fail_msg(__VA_ARGS__)
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+	return fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
+
+// grow-only device buffer
+struct DBuf {
+	void *p = nullptr; size_t cap = 0;
+	int reserve(size_t bytes) {
+		if (bytes <= cap) return 0;
+		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+		size_t want = bytes + bytes / 4 + 256;
+		hipError_t e = hipMalloc(&p, want);
+		if (e != hipSuccess) { p = nullptr; return fail(BHIP_E_DEVICE, "hipMalloc(%zu): %s", want, hipGetErrorString(e)); }
+		cap = want; return 0;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	template <class T> T *as() const { return (T *)p; }
+};
+
+static const int kClasses[] = {2, 4, 6, 8, 10, 16, 32};
+static const int kNumClasses = 7;
+static inline int class_of_len(uint32_t len) {
+	for (int i = 0; i < kNumClasses; ++i) if (len <= 32u * kClasses[i]) return i;
+	return -1;
+}
+
+// device-side counters, one block copied back per call
+struct Counters {
+	uint32_t n_cand, n_raw, n_out, n_wide, err, pad0;
+	uint32_t n_cand_cls[8];
+	uint32_t n_wins_cls[8];
+	uint32_t n_fb, pad2;
+	uint32_t n_tasks_cls[8];
+	uint32_t n_tasks2_cls[8];  // deferred lane tasks (lower bound above the query's best bound)
+	uint32_t n_tasks2k_cls[8]; // ... of which kept by k_task_filter
+	uint32_t n_wins2_cls[8];   // windows flagged by the second sweep
+	uint32_t n_rs[12];         // re-scorer buckets: hits per band-width class
+	unsigned long long wcol_sum, tcol_sum, unit_sum;
+	unsigned long long col_sum, qlen_sum, ent_read, scratch_used;
+	unsigned long long surv_sum;           // list records that passed the counting filter (k_prefilter_cf)
+};
+
+// One staged batch.  Query symbols with code 0 (anything outside the IUPAC nucleotide alphabet) cost 255 against every
+// reference symbol (burst.c:170-190): such a symbol can only be aligned opposite a gap, so the edit distance of the query is
+// (number of such symbols) + edit distance of the query without them, end columns unchanged.  When a staged batch holds any,
+// the SEARCH kernels (seeds, prefilter, profiles, sweeps) work on a second view of the batch with those symbols removed and
+// the budgets reduced (qcodes_s ...); k_junk_adjust adds the counts back before the re-scorer, which works on the original
+// queries with the real cost table.  Without such symbols the search view is the batch itself.
+struct StageSlot {
+	DBuf qcodes, qcodes4, qoff, qemac, qsix, qrc, qflags, qmap, off_raw, plan, qpack, key, key_sorted, idx, idx_sorted, sort_tmp, info;
+	DBuf qcodes_s, qoff_s, qemac_s, qpack_s, nx, nx_six;
+	BhipStageInfo *info_pinned = nullptr;
+	hipEvent_t ev_begin = nullptr, ev_done = nullptr;
+	int state = 0;                        // 0 empty, 1 staged (not aligned yet), 2 active (aligned; may be run again)
+	uint64_t seq = 0;
+	bool resolved = false;                // routing read back, lists assigned
+	bool st_valid = false, st_has_six = false, st_has_rc = false, st_has_junk = false, has_flags = false, has_qmap = false;
+	uint32_t st_nq = 0, st_nshared = 0, st_maxlen = 0, st_maxE = 0, st_lanes = 1;
+	float st_ms_h2d = 0;
+	std::vector<BhipQuerySpan> spans;     // the caller's arrays (valid until the batch has been aligned): the host pass reads them
+	const uint32_t *six_explicit = nullptr;
+	uint32_t npf[16][7], nex[16][7], maxE[16][7], maxwords[16][7], qlist_off[16][7], maxlen_lane[16], n_entries_lane[16];
+	uint64_t seed_words[16][7];
+	void release_all() {
+		DBuf *b[] = {&qcodes, &qcodes4, &qoff, &qemac, &qsix, &qrc, &qflags, &qmap, &off_raw, &plan, &qpack, &key, &key_sorted, &idx, &idx_sorted,
+			&sort_tmp, &info, &qcodes_s, &qoff_s, &qemac_s, &qpack_s, &nx, &nx_six};
+		for (DBuf *x : b) x->release();
+		if (info_pinned) { (void)hipHostFree(info_pinned); info_pinned = nullptr; }
+		if (ev_begin) { (void)hipEventDestroy(ev_begin); ev_begin = nullptr; }
+		if (ev_done) { (void)hipEventDestroy(ev_done); ev_done = nullptr; }
+	}
+};
+
+// One independent sub-pipeline of a staged batch: its own stream and scratch, a contiguous range of shared slots
+// (so a forward entry and its reverse-complement twin are always in the same lane and `best[six]` is final when the
+// lane's re-scorer runs).  Lanes overlap each other's latency-bound kernels (prefilter, window, re-scorer) with the
+// VALU-bound column sweep, which itself is serialised on one dedicated stream (Handle::sweep_stream).
+struct Lane {
+	hipStream_t stream = nullptr;
+	hipEvent_t ev_cls[kNumClasses][8];   // per class: 0 start, 1 peq done (sweep stream), 7 prefilter start, 2 prefilter done, 6 sweep start, 3 sweep(pf) done, 4 sweep(ex) done, 5 window done
+	hipEvent_t ev_rs[2];
+	hipEvent_t ev_ph[kNumClasses][2];    // per class: first window sweep done, second task sweep done
+	hipEvent_t ev_pf[kNumClasses][3];    // per class: seed lookup start, hash kernel start, hash kernel done
+	uint64_t seed_words[kNumClasses] = {0};
+	uint32_t pf_launches = 0;
+	bool pf_masked[kNumClasses] = {false};
+	bool pruned[kNumClasses] = {false};   // a second (filtered) sweep ran for this class
+	int pf_algo_used = 0;
+	int pf_algo = 0;              // algorithm of this lane's next prefilter launches (follows opt_pf_algo: -1 = adapt)
+	const uint32_t *qlist[kNumClasses] = {nullptr};      // (lane, class) lists of the current batch: entries of the slot's sorted index array
+	DBuf peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters, tasks, tasks2, tasks2k, wins2, rs_lists;
+	// seed lookups (k_seed_ranges) per class: list ranges + query headers for the prefilter.  They depend on the staged batch alone,
+	// so the lookups of batch k+1 run on the prefilter stream WHILE batch k is swept and re-scored (seed_ahead): memory-latency-bound
+	// work beside VALU-bound work.  seeded_* say which staged batch the buffers of a class hold.
+	DBuf ranges_c[kNumClasses], hdr_c[kNumClasses];
+	bool seeded_ok[kNumClasses] = {false};
+	uint64_t seeded_seq[kNumClasses] = {0};
+	uint32_t seeded_n[kNumClasses] = {0}, seeded_W16[kNumClasses] = {0};
+	hipEvent_t ev_seed[2][kNumClasses][2];   // [batch parity][class]: seed lookup start, done
+	// match profiles built ahead for the next staged batch (when it has a single class in this lane): swapped in by enqueue_lane
+	DBuf peq_alt, peqp_alt;
+	bool alt_ok = false; uint64_t alt_seq = 0; int alt_cls = 0, alt_nwp = 0; uint32_t alt_n = 0;
+	hipEvent_t ev_peq_alt[2], ev_peq_cur[2];  // profile build start, done: of the buffers built ahead / of the ones in use
+	bool peq_ahead[kNumClasses] = {false};    // this batch's profiles of the class came from the build ahead
+	uint64_t task_cap = 1 << 20;
+	uint64_t cand_cap = 1 << 18, raw_cap = 1 << 18, win_cap = 1 << 20, scratch_cap = 1 << 18;
+	uint32_t npf[kNumClasses] = {0}, nex[kNumClasses] = {0}, maxE[kNumClasses] = {0}, maxwords[kNumClasses] = {0}, maxlen = 0, n_entries = 0;
+	Counters *hc_pinned = nullptr;        // pinned, so that the read-back of the counters does not block the enqueueing thread
+	Counters hc;
+	uint32_t launches = 0, prefix_words = 0;
+	uint64_t n_pairs_ex = 0;
+	bool masked = false;
+};
+
+// counters all lanes of a batch share; behind them the per-query record counters and the rank array of the counting sort: the
+// re-scoring kernels take rank[pos] = cnt[q]++ when they write a record (bhip_hit_rank in bhip_internal.h reads the two pointers
+// through the n_out pointer they already get), so that no separate counting pass runs between the re-scorer and the scatter
+struct SharedCtr { uint32_t n_out, err; uint32_t *cnt; uint32_t *rank; };
+__global__ void k_set_rank_ptrs(SharedCtr *sc, uint32_t *cnt, uint32_t *rank);
+struct Handle {
+	int device = 0, n_cu = 0;
+	char dev_name[256];
+	uint64_t hbm = 0;
+	hipStream_t stream = nullptr;         // staging, sort, copies
+	// software pipeline over lanes: stage streams run the same stage of consecutive lanes back to back, so that lane k+1's
+	// prefilter and lane k-1's window/re-scoring overlap lane k's column sweep
+	hipStream_t pf_stream = nullptr;      // peq + prefilter of every lane, in lane order
+	hipStream_t sweep_stream = nullptr;   // every k_myers_prefix / k_myers launch, in lane order
+	hipStream_t post_stream = nullptr;    // window stage + re-scorer + counter read-back, in lane order
+	hipEvent_t ev[10];
+	// database
+	uint32_t n_clumps = 0, tot_refs = 0, max_clump_len = 0;
+	DBuf ref, ref_lane, ref_off, clump_len, lut;      // ref: 16 lanes interleaved per 32-column chunk; ref_lane: each lane contiguous
+	BhipMatchMask mm;
+	bool has_acx = false; int K = 0;
+	// accelerator: two-level offsets + 5-byte (clump, lane mask) records (bhip_internal.h); entry numbers start at acx_bias
+	// (0, or the test hook BHIP_TEST_ENTRY_BIAS that pushes a small database's offsets beyond 2^32)
+	DBuf acx_lines, acx_rec, bad; uint32_t n_bad = 0; uint64_t n_ent = 0, acx_bias = 0;
+	BhipAcxView acx_view() const {
+		BhipAcxView v; v.lines = acx_lines.as<uint4>();
+		v.rec = acx_rec.as<uint8_t>() - acx_bias * (uint64_t)BHIP_REC_BYTES; return v;
+	}
+	bool has_masks = false;       // per-entry lane masks were built at upload (lane-resolved prefilter)
+	int opt_lane_masks = 1;       // use them
+	// staged batches: two slots, so that the upload and routing of batch k+1 (stage_stream) run while batch k is aligned
+	StageSlot slots[3];                   // one batch being aligned, one staged (its seed lookups and profiles run ahead), one being staged
+	StageSlot *cur = &slots[0];           // slot of the batch being aligned
+	uint64_t stage_seq = 0;
+	hipStream_t stage_stream = nullptr;
+	// records of the last aligned batch, complete but not delivered (the caller's buffer was too small): delivered by the next call
+	bool res_valid = false; uint64_t res_seq = 0; int res_all_hits = 0; uint32_t res_n = 0; BhipStats res_stats;
+	int opt_host_routing = 0;             // 1 = route every batch on the host (the pass that handles symbols of code 0); test hook
+	// batch-wide buffers
+	DBuf best, out, shared_ctr, mins, pairs;
+	SharedCtr *hsc_pinned = nullptr;      // read-back of shared_ctr behind the chain (pinned: no blocking copy on the way out of a batch)
+	const uint8_t *s_codes() const { return cur->st_has_junk ? cur->qcodes_s.as<uint8_t>() : cur->qcodes.as<uint8_t>(); }
+	const uint64_t *s_off() const { return cur->st_has_junk ? cur->qoff_s.as<uint64_t>() : cur->qoff.as<uint64_t>(); }
+	const uint16_t *s_emac() const { return cur->st_has_junk ? cur->qemac_s.as<uint16_t>() : cur->qemac.as<uint16_t>(); }
+	const uint32_t *s_pack() const { return cur->st_has_junk ? cur->qpack_s.as<uint32_t>() : cur->qpack.as<uint32_t>(); }
+	DBuf sort_keys, sort_keys2, sort_idx, sort_tmp, out_sorted, out_sorted2;   // sort_keys / sort_keys2: per-query record counts / offsets; sort_idx: rank of a record inside its query
+	uint64_t out_cap = 1 << 20;
+	std::vector<uint32_t> h_clump_len;
+	BhipStats stats;
+	std::vector<Lane *> lanes;
+	int opt_two_stage = 1;        // 1 = prefix filter + windowed full-length stage when it pays, 0 = always the one-stage sweep
+	int opt_prefilter_stride = 0; // 0 = automatic sparse seeds, s > 0 = every s-th word (1 = the reference's scheme)
+	int opt_lanes = 1;            // sub-pipelines per staged batch (the stage kernels fill the chip on their own; > 1 only helps small batches)
+	int opt_sweep_blocks = 8;     // 256-thread blocks per CU of the column-sweep kernels
+	// asynchronous hand-over of the records (option "async_d2h"): two device buffers alternate, the copy of call k runs on its
+	// own stream while call k+1 computes; the caller's buffers are page-locked once and stay registered
+	int opt_async_d2h = 0, out_idx = 0;
+	hipStream_t copy_stream = nullptr;
+	hipEvent_t ev_sorted = nullptr, ev_copied[2] = {nullptr, nullptr};
+	bool copy_pending[2] = {false, false};
+	void *reg_ptr[2] = {nullptr, nullptr}; size_t reg_bytes[2] = {0, 0};
+	int last_out = 0;             // which of the two sorted buffers holds the last call's records
+	uint64_t last_n_out = 0;      // records of the last bhip_align_staged call, still resident (sorted) in out_sorted
+	int opt_prune = 1;            // second sweep for lanes whose seed count bounds their edit distance above the first sweep's best
+	int opt_lane_min = 32768;     // fewest entries a sub-pipeline is worth opening for
+	int opt_rescore_reg = 1;      // register-band re-scorer for narrow bands (0 = LDS band only)
+	int opt_pf_waves = 0;         // single-wave blocks per CU of the lane-resolved prefilter (0 = as many as the LDS allows, <= 12)
+	int opt_pf_algo = -1;         // 0 = counting filter + exact lane table (k_prefilter_cf), 1 = exact clump hash table in two passes
+	                              // (k_prefilter_mask), -1 = start with 0 and switch a lane to 1 when more than 20 % of its records survive the filter
+	int opt_pf_table = 0;         // log2 of the per-query hash table (0 = from the workload: 9, 10 or 11)
+	int opt_seed_ahead = 1;       // seed lookups of the next staged batch run while the current one is swept
+	int opt_seed_ahead_blocks = 2; // 256-thread blocks per CU of a seed kernel that runs ahead (0 = one block per 256 lookups, as in place); 2: +2.3 % on the bench
+	int opt_peq_ahead_blocks = 16; // 256-thread blocks per CU of a profile build that runs ahead
+	double acx_wmean = 0.0;       // occurrence-weighted mean .acx list length
+};
+
+static inline float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+
+// ---- host functions shared between the files of the library ----
+int  ensure_lanes(Handle *h, uint32_t n);                                    // bhip_init.hip
+uint32_t make_seed_plan(const uint8_t *s, uint32_t len, uint32_t E, uint32_t K, int stride_opt);   // bhip_stage.hip
+int  slot_init(StageSlot *S);
+int  resolve_slot(Handle *h, StageSlot *S);
+void apply_slot(Handle *h, StageSlot *S);
+void lane_capacity_floor(Handle *h, Lane *L, uint64_t n);
+int  bhip_load_accelerator(Handle *h, const uint32_t *acx_lens, const void *acx_lists, int acx_fmt, int K, const uint32_t *badlist, uint32_t n_bad);   // bhip_acx.hip
+int  bhip_build_accelerator(Handle *h, int K, int z);
+#endif

@@ -3,8 +3,7 @@
 // What the reference computes with 16-lane SSE rows (burst.c:1003-1204 aded_*, 713-886 reScoreM_*,
 // 3238-3282 postScour*) is re-designed here for 64-wide wavefronts:
 //
-//   k_transpose_refs, k_acx_decode, k_extract_kmers, k_attach_masks : database set-up (two reference layouts, u32 list
-//                      entries from the packed .acx, 16-bit lane masks per list entry derived from the references).
+//   k_transpose_refs : database set-up (two reference layouts; the accelerator kernels are in bhip_acx.hip).
 //   k_pack_queries, k_build_peq : 4-bit packed queries; per query 16 match bit-vectors (one per reference symbol).
 //   k_seed_ranges, k_prefilter_cf / k_prefilter_mask : sampled words -> .acx list ranges -> per-query counts in LDS,
 //                      resolved to single reference lanes -> (query, lane) tasks, split by a lower bound on their
@@ -51,83 +50,6 @@ __global__ void k_transpose_refs(const uint8_t *__restrict__ src, const uint64_t
 	}
 }
 
-// ------------------------------------------------------------------------------------------------
-// .acx offsets: Lens[4^K] (burst.c:3558) -> exclusive prefix inside each block of 256 words (`delta`) and the block sums
-// (scanned to 64-bit block bases by the caller).  WHAT = 0: list lengths (entries); 1: bytes of the packed SMALL lists
-// (pairs of 20-bit ids in 5 bytes with a 3-byte odd tail, burst.c:3516-3527); 2: bytes of the LARGE lists (3 per id).
-// One 256-thread workgroup per block of words.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_acx_offsets(const uint32_t *__restrict__ lens, uint64_t n_words, int what,
-                                                     uint32_t *__restrict__ delta, unsigned long long *__restrict__ blocksum) {
-	__shared__ uint32_t s_w[4];
-	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const uint64_t n_blocks = (n_words + 255) >> 8;
-	for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-		const uint64_t w = blk * 256 + tid;
-		const uint32_t len = w < n_words ? lens[w] : 0u;
-		const uint32_t v = what == 0 ? len : what == 1 ? 5u * (len >> 1) + 3u * (len & 1u) : 3u * len;
-		uint32_t ps = v;
-		#pragma unroll
-		for (uint32_t o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(ps, o); if (lane >= o) ps += t; }
-		__syncthreads();
-		if (lane == 63) s_w[wv] = ps;
-		__syncthreads();
-		uint32_t add = 0;
-		for (uint32_t k = 0; k < wv; ++k) add += s_w[k];
-		if (w < n_words) delta[w] = add + ps - v;
-		if (tid == 255) blocksum[blk] = (unsigned long long)add + ps;
-	}
-}
-
-// .acx offsets as 64-byte lines (BhipAcxView): pass 0 writes the sum of every block of 14 lengths, the caller scans them into
-// 64-bit bases (hipCUB), pass 1 writes base + inclusive prefix sums.  One thread per line.
-__global__ void k_acx_lines(const uint32_t *__restrict__ lens, uint64_t n_words, int pass, unsigned long long *__restrict__ blk, uint4 *__restrict__ lines) {
-	const uint64_t n_lines = (n_words + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS;
-	for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < n_lines; b += (uint64_t)gridDim.x * blockDim.x) {
-		uint32_t d[14], run = 0;
-		#pragma unroll
-		for (uint32_t j = 0; j < 14; ++j) { const uint64_t w = b * BHIP_ACX_LINE_WORDS + j; run += w < n_words ? lens[w] : 0u; d[j] = run; }
-		if (pass == 0) { blk[b] = run; continue; }
-		const unsigned long long base = blk[b];
-		lines[4 * b + 0] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), d[0], d[1]);
-		lines[4 * b + 1] = make_uint4(d[2], d[3], d[4], d[5]);
-		lines[4 * b + 2] = make_uint4(d[6], d[7], d[8], d[9]);
-		lines[4 * b + 3] = make_uint4(d[10], d[11], d[12], d[13]);
-	}
-}
-
-// ------------------------------------------------------------------------------------------------
-// .acx list area -> 5-byte records (24-bit clump id, 16-bit lane mask preset to "every lane"), on the device (the packed bytes
-// are what is uploaded): SMALL lists are pairs of 20-bit ids in 5 bytes with a 3-byte odd tail (burst.c:3265-3274), LARGE
-// lists 3 bytes per id (3245-3248).  One thread per word; `bad` is raised when an id is not a clump of the database.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bhip_rec_store(uint8_t *rec, unsigned long long e, uint32_t clump, uint32_t mask) {
-	uint8_t *p = rec + e * (unsigned long long)BHIP_REC_BYTES;
-	p[0] = (uint8_t)clump; p[1] = (uint8_t)(clump >> 8); p[2] = (uint8_t)(clump >> 16); p[3] = (uint8_t)mask; p[4] = (uint8_t)(mask >> 8);
-}
-__global__ void k_acx_decode(const uint8_t *__restrict__ lists, const unsigned long long *__restrict__ byte_base, const uint32_t *__restrict__ byte_delta,
-                             BhipAcxView acx, uint64_t n_words, int fmt, uint32_t n_clumps, uint8_t *__restrict__ rec, uint32_t *__restrict__ bad) {
-	for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
-		unsigned long long e; uint32_t n;
-		bhip_acx_range(acx, (uint32_t)w, e, n);
-		if (!n) continue;
-		const uint8_t *p = lists + byte_base[w >> 8] + byte_delta[w];
-		uint32_t worst = 0;
-		if (fmt == 1) {
-			for (; n; --n, p += 3) { const uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); bhip_rec_store(rec, e++, v, 0xFFFFu); worst = v > worst ? v : worst; }
-		} else {
-			for (; n >= 2; n -= 2, p += 5) {
-				const unsigned long long v = (unsigned long long)p[0] | ((unsigned long long)p[1] << 8) | ((unsigned long long)p[2] << 16) |
-				                             ((unsigned long long)p[3] << 24) | ((unsigned long long)p[4] << 32);
-				const uint32_t a = (uint32_t)(v & 0xFFFFF), b = (uint32_t)((v >> 20) & 0xFFFFF);
-				bhip_rec_store(rec, e++, a, 0xFFFFu); bhip_rec_store(rec, e++, b, 0xFFFFu);
-				worst = a > worst ? a : worst; worst = b > worst ? b : worst;
-			}
-			if (n) { const uint32_t v = ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)) & 0xFFFFF; bhip_rec_store(rec, e++, v, 0xFFFFu); worst = v > worst ? v : worst; }
-		}
-		if (worst >= n_clumps) atomicMax(bad, worst);
-	}
-}
 
 // ------------------------------------------------------------------------------------------------
 // Match bit-vectors (DIAGSC_MAT16, burst.c:700: SCOREFAST[qLet] shuffled by the reference symbol).
@@ -586,67 +508,6 @@ __global__ __launch_bounds__(64) void k_prefilter_hash(
 	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Lane-resolved accelerator.  The .acx says which CLUMPS contain a word; at upload we also work out which of the 16
-// LANES of the clump contain it (a 16-bit mask per list entry), so that the prefilter can count seed words per reference
-// lane and hand only the lanes that can hold an alignment to the edit-distance kernels (2-3 lanes per candidate clump
-// instead of all 16).  k_extract_kmers emits (word << 24 | clump, 1 << lane) for every A/C/G/T-only K-mer of every lane,
-// a device radix sort + OR-reduce-by-key gives one mask per (word, clump), and k_attach_masks looks every .acx entry up.
-// Entries the extraction does not know (words the reference added by IUPAC expansion, burst.c:3368-3377) get 0xFFFF:
-// every lane, i.e. the clump-level behaviour.  Masks only ever add lanes, never drop one, so results are unchanged.
-// ------------------------------------------------------------------------------------------------
-__global__ void k_extract_kmers(const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
-                                const uint64_t *__restrict__ key_off, uint32_t c0, uint32_t c1, int K,     // clumps [c0, c1): one slice of the database
-                                unsigned long long *__restrict__ keys, uint16_t *__restrict__ vals, uint32_t *__restrict__ ambig_lanes) {
-	const uint64_t n_threads = (uint64_t)(c1 - c0) * 16;
-	const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
-	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_threads; i += (uint64_t)gridDim.x * blockDim.x) {
-		const uint32_t c = c0 + (uint32_t)(i >> 4), z = (uint32_t)(i & 15), L = clump_len[c], nchunks = (L + 31) >> 5;
-		const uint4 *rp = ref + ref_off[c] * 16 + z;
-		unsigned long long *kout = keys + (key_off[c] - key_off[c0]) + (uint64_t)z * L;
-		uint16_t *vout = vals + (key_off[c] - key_off[c0]) + (uint64_t)z * L;
-		uint32_t w = 0, run = 0, amb = 0;
-		for (uint32_t t = 0; t < nchunks; ++t) {
-			const uint4 ch = rp[(uint64_t)t * 16];
-			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
-			for (uint32_t k = 0; k < 32; ++k) {
-				const uint32_t pos = t * 32 + k;
-				if (pos >= L) break;
-				const uint32_t sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
-				amb |= sym > 4u;
-				run = (sym - 1u) < 4u ? run + 1 : 0;
-				w = ((w << 2) | ((sym - 1u) & 3u)) & wmask;
-				// the word ENDING at pos is stored in slot pos (slots 0..K-2 and words with other symbols are invalid)
-				kout[pos] = run >= (uint32_t)K ? (((unsigned long long)w << 24) | c) : ~0ull;
-				vout[pos] = (uint16_t)(1u << z);
-			}
-		}
-		// a lane with IUPAC / N symbols can match words it does not literally contain (the .acx lists them for the clump
-		// through the reference's expansion): such a lane takes part in every entry of its clump
-		if (amb) atomicOr(&ambig_lanes[c], 1u << z);
-	}
-}
-
-__global__ void k_attach_masks(BhipAcxView acx, uint64_t n_words,
-                               const unsigned long long *__restrict__ ukeys, const uint16_t *__restrict__ umasks, uint32_t n_unique,
-                               const uint32_t *__restrict__ ambig_lanes, uint8_t *__restrict__ rec,     // mask bytes of the 5-byte records
-                               uint32_t c0, uint32_t c1) {                                                 // only entries of clumps [c0, c1)
-	// one thread per word walks its list (a few entries); the key of an entry is (word, clump), looked up in the folded tuples
-	for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
-		unsigned long long e; uint32_t n;
-		bhip_acx_range(acx, (uint32_t)w, e, n);
-		for (; n; --n, ++e) {
-			const uint32_t ce = bhip_acx_clump(acx.rec, e);
-			if (ce < c0 || ce >= c1) continue;
-			const unsigned long long key = ((unsigned long long)w << 24) | ce;
-			uint32_t a = 0, b = n_unique;
-			while (a < b) { const uint32_t mid = a + ((b - a) >> 1); if (ukeys[mid] < key) a = mid + 1; else b = mid; }
-			const uint32_t m = ((a < n_unique && ukeys[a] == key) ? (uint32_t)umasks[a] : 0xFFFFu) | (ambig_lanes[ce] & 0xFFFFu);
-			uint8_t *p = rec + e * (unsigned long long)BHIP_REC_BYTES;
-			p[3] = (uint8_t)m; p[4] = (uint8_t)(m >> 8);
-		}
-	}
-}
 
 // Prefilter with per-lane counts, in two passes over the query's .acx lists so that the wide per-lane counters are
 // touched only for clumps that can matter:

@@ -11,15 +11,18 @@
 
 static double now_sec(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
-int bh_device_open(const BhDb *db, int device, int z, void **hip_handle) {
+int bh_device_open_ex(const BhDb *db, int device, int z, int build_K, void **hip_handle) {
 	uint8_t lut[256];
 	bh_score_lut(z, lut);
+	/* a database read with its .acx goes up with the file's tables; without one, build_K > 0 has the device build the accelerator
+	 * from the references (make_accelerator, burst.c:3304-3532, as device kernels) */
 	int rc = bhip_init(device, db->packed, db->clumpLen, db->numRclumps, db->totR,
-	                   db->hasAcx ? db->acxLens : NULL, db->hasAcx ? db->acxLists : NULL, db->acxFmt, db->K,
+	                   db->hasAcx ? db->acxLens : NULL, db->hasAcx ? db->acxLists : NULL, db->acxFmt, db->hasAcx ? db->K : build_K,
 	                   db->badList, db->badSz, lut, db->xalpha, hip_handle);
 	if (rc) return bh_set_error(rc == BHIP_E_ARG ? BH_E_USAGE : BH_E_DEVICE, "libburst_hip: %s", bhip_last_error());
 	return BH_OK;
 }
+int bh_device_open(const BhDb *db, int device, int z, void **hip_handle) { return bh_device_open_ex(db, device, z, 0, hip_handle); }
 
 static void add_stats(BhipStats *t, const BhipStats *s) {
 	t->n_queries += s->n_queries; t->n_pairs += s->n_pairs; t->n_columns += s->n_columns; t->n_raw_hits += s->n_raw_hits;

@@ -171,7 +171,7 @@ int bh_acx_read(const char *path, int K, int z, BhDb *db) {
 		return bh_set_error(BH_E_USAGE, "ERROR: accelerator %s is neither a complete K=12 nor a complete K=15 accelerator", path);
 	}
 	K = foundK;
-	own(db, lens);
+	if (!own(db, lens)) { fclose(in); return bh_set_error(BH_E_OOM, "OOM:WordDump_rd"); }
 	uint32_t *bl = own(db, malloc(((size_t)szBL + 1) * 4));
 	uint8_t *lists = own(db, malloc(bytes + 16));
 	if (!bl || !lists) { fclose(in); return bh_set_error(BH_E_OOM, "OOM:WordDump_rd"); }
@@ -559,6 +559,54 @@ int bh_acx_build(BhDb *db, int K, int z) {
 	}
 	memset(p, 0, 16);
 	free(ent); free(offs);
+	db->hasAcx = 1; db->K = K; db->acxFmt = fmt; db->acxZ = z ? 1 : 0;
+	db->acxLens = lens; db->acxLists = lists; db->acxListBytes = bytes; db->badList = bl; db->badSz = nb;
+	return BH_OK;
+}
+
+int bh_acx_from_device(BhDb *db, void *hh, int K, int z) {
+	uint64_t tot = 0; uint32_t nb = 0;
+	if (bhip_acx_export(hh, NULL, NULL, NULL, 0, &tot, NULL, 0, &nb)) return bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error());
+	const uint64_t nw = 1ull << (2 * K);
+	uint32_t *lens = malloc(nw * 4), *ent = malloc((tot + 1) * 4), *bl = malloc(((size_t)nb + 1) * 4);
+	if (!lens || !ent || !bl) { free(lens); free(ent); free(bl); return bh_set_error(BH_E_OOM, "OOM:Accelerant.Refs"); }
+	if (bhip_acx_export(hh, lens, ent, NULL, tot, &tot, bl, nb, &nb)) { free(lens); free(ent); free(bl); return bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error()); }
+	/* pack (burst.c:3501-3528): byte position of every 65536th word first, then the blocks in parallel */
+	const int fmt = db->numRclumps > 1048574 ? 1 : 0;
+	const uint64_t BW = 65536, nblk = (nw + BW - 1) / BW;
+	uint64_t *bbyte = malloc((nblk + 1) * 8), *bent = malloc((nblk + 1) * 8);
+	if (!bbyte || !bent) { free(lens); free(ent); free(bl); free(bbyte); free(bent); return bh_set_error(BH_E_OOM, "OOM:WordDump"); }
+	#pragma omp parallel for schedule(static)
+	for (uint64_t b = 0; b < nblk; ++b) {
+		uint64_t by = 0, en = 0;
+		const uint64_t w1 = (b + 1) * BW < nw ? (b + 1) * BW : nw;
+		for (uint64_t w = b * BW; w < w1; ++w) { en += lens[w]; by += fmt ? (uint64_t)lens[w] * 3 : (uint64_t)(lens[w] / 2u) * 5 + (lens[w] & 1) * 3; }
+		bbyte[b + 1] = by; bent[b + 1] = en;
+	}
+	bbyte[0] = bent[0] = 0;
+	for (uint64_t b = 0; b < nblk; ++b) { bbyte[b + 1] += bbyte[b]; bent[b + 1] += bent[b]; }
+	const uint64_t bytes = bbyte[nblk];
+	uint8_t *lists = malloc(bytes + 16);
+	if (!lists) { free(lens); free(ent); free(bl); free(bbyte); free(bent); return bh_set_error(BH_E_OOM, "OOM:WordDump"); }
+	#pragma omp parallel for schedule(dynamic, 16)
+	for (uint64_t b = 0; b < nblk; ++b) {
+		uint8_t *p = lists + bbyte[b];
+		const uint32_t *l = ent + bent[b];
+		const uint64_t w1 = (b + 1) * BW < nw ? (b + 1) * BW : nw;
+		for (uint64_t w = b * BW; w < w1; ++w) {
+			const uint32_t n = lens[w];
+			if (fmt) for (uint32_t i = 0; i < n; ++i) { p[0] = (uint8_t)l[i]; p[1] = (uint8_t)(l[i] >> 8); p[2] = (uint8_t)(l[i] >> 16); p += 3; }
+			else {
+				uint32_t i = 0;
+				for (; i + 1 < n; i += 2) { const uint64_t v = (uint64_t)l[i] | ((uint64_t)l[i + 1] << 20); memcpy(p, &v, 5); p += 5; }
+				if (i < n) { const uint64_t v = l[i]; memcpy(p, &v, 3); p += 3; }
+			}
+			l += n;
+		}
+	}
+	memset(lists + bytes, 0, 16);
+	free(ent); free(bbyte); free(bent);
+	if (!own(db, lens) || !own(db, lists) || !own(db, bl)) return bh_set_error(BH_E_OOM, "OOM:Accelerant.Refs");
 	db->hasAcx = 1; db->K = K; db->acxFmt = fmt; db->acxZ = z ? 1 : 0;
 	db->acxLens = lens; db->acxLists = lists; db->acxListBytes = bytes; db->badList = bl; db->badSz = nb;
 	return BH_OK;

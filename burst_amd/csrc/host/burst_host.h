@@ -68,6 +68,10 @@ void bh_set_latency(uint32_t bases);
 /* -sa for the accelerator builder: leave out every word that holds an ambiguous symbol (burst.c:3360-3366) */
 void bh_set_skip_ambig(int on);
 int  bh_acx_build(BhDb *db, int K, int z);
+/* the accelerator tables of `db` from a device handle that holds this database's accelerator (bhip_acx_export), packed as the
+ * reference writes them (burst.c:3501-3530): with a handle whose accelerator was built on the device this is make_accelerator
+ * without the host pass */
+int  bh_acx_from_device(BhDb *db, void *hip_handle, int K, int z);
 /* view of the clumps [c0, c1) with the accelerator restricted to them (database sharding); `db` must outlive the view */
 int  bh_db_slice(const BhDb *db, uint32_t c0, uint32_t c1, BhDb *out);
 int  bh_acx_write(const BhDb *db, const char *path);
@@ -122,6 +126,8 @@ int  bh_align_ranges_reuse(void *hip_handle, const BhQueries *q, const uint64_t 
 int  bh_run_reserve(BhRun *run, uint64_t cap_records);
 void bh_run_free(BhRun *run);
 int  bh_device_open(const BhDb *db, int device, int z, void **hip_handle);
+/* build_K > 0 and a database without accelerator tables: the device builds the accelerator itself (no .acx file) */
+int  bh_device_open_ex(const BhDb *db, int device, int z, int build_K, void **hip_handle);
 
 /* ---- consolidation and .b6 output (burst.c:4553-4891); hits must be sorted by (q, refIx) ---- */
 int  bh_report(FILE *out, const BhDb *db, const BhQueries *q, const BhipHit *hits, uint64_t nHits, BhMode mode, uint64_t *nLines);

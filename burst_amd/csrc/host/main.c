@@ -20,6 +20,22 @@ static int code_to_exit(int rc) { return rc == BH_E_USAGE ? 1 : rc == BH_E_IO ? 
 #define DIE(rc) do { fprintf(stderr, "%s\n", bh_last_error()); return code_to_exit(rc); } while (0)
 #define NEEDARG(name) do { if (++i == argc || argv[i][0] == '-') { printf("ERROR: %s requires an argument\n", name); return 1; } } while (0)
 
+/* make_accelerator (burst.c:3304-3532): on the device when there is one (tuples of every lane, radix sort, fold: bhip_init
+ * with K and no tables, then bhip_acx_export), else -- or with --host-acx / -sa -- by the host builder.  Same bytes either way. */
+static int build_accelerator(BhDb *db, int K, int z, int device, int on_host) {
+	if (!on_host) {
+		void *hh = NULL;
+		if (!bh_device_open_ex(db, device, z, K, &hh)) {
+			const int rc = bh_acx_from_device(db, hh, K, z);
+			bhip_destroy(hh);
+			if (!rc) printf(" --> accelerator built on device %d\n", device);
+			return rc;
+		}
+		printf(" --> no device accelerator build (%s); using the host builder\n", bh_last_error());
+	}
+	return bh_acx_build(db, K, z);
+}
+
 static void usage(void) {
 	puts("\nburst_hip: BURST-compatible optimal aligner, MI355X (gfx950) device path");
 	puts("--references (-r) <name>: FASTA/edx DB of reference sequences [required]");
@@ -31,6 +47,8 @@ static void usage(void) {
 	puts("--taxonomy (-b) <name>, --taxacut (-bc) <num>, --taxa_ncbi (-bn), --taxasuppress (-bs) [STRICT]: taxonomy column (interpolated in CAPITALIST)");
 	puts("--gpus <int> [--devices a,b,...] [--gather rccl|host]: shard the queries over the GPUs of this node (one RCCL gather of the records)");
 	puts("--device <int>, --batch <int>, -k <12|15>, --make-acx <name> (with -r DB.edx: rebuild the accelerator of a database)");
+	puts("--accelerator-device (-ad): no .acx file, the device builds the accelerator from the .edx (word length -k, default 12)");
+	puts("--host-acx: build accelerators (-d ... -a, --make-acx) with the host builder instead of the device");
 }
 
 int main(int argc, char **argv) {
@@ -38,7 +56,7 @@ int main(int argc, char **argv) {
 	float thres = 0.97f;                            /* burst.c:93 */
 	int z = 1, do_rc = 0, incl_ws = 0, makedb = 0, do_shear = 0, do_accel = 0, dedupe = 0, device = 0, K = 0, skip_ambig = 0, threads = 0, rep_flags = 0;
 	long shear_amt = 500, db_qlen = 500;            /* burst.c:94 */
-	int n_gpus = 1, n_gpus_given = 0, gather_host = 0, n_dev_list = 0, dev_list[BH_MAX_GPUS];
+	int n_gpus = 1, n_gpus_given = 0, gather_host = 0, n_dev_list = 0, dev_list[BH_MAX_GPUS], accel_dev = 0, host_acx = 0;
 	uint64_t batch = 1u << 21;      /* unique queries per device batch: the fixed cost of a batch (launches, synchronisation) is about 1 ms of device time */
 	const char *ref_FN = 0, *query_FN = 0, *output_FN = 0, *xcel_FN = 0, *mkacx_FN = 0, *tax_FN = 0;
 	BhTax taxonomy; memset(&taxonomy, 0, sizeof taxonomy);
@@ -52,6 +70,8 @@ int main(int argc, char **argv) {
 		else if (!strcmp(a, "--queries") || !strcmp(a, "-q")) { NEEDARG("--queries"); query_FN = argv[i]; }
 		else if (!strcmp(a, "--output") || !strcmp(a, "-o")) { NEEDARG("--output"); output_FN = argv[i]; }
 		else if (!strcmp(a, "--accelerator") || !strcmp(a, "-a")) { NEEDARG("--accelerator"); xcel_FN = argv[i]; do_accel = 1; }
+		else if (!strcmp(a, "--accelerator-device") || !strcmp(a, "-ad")) { accel_dev = 1; do_accel = 1; }
+		else if (!strcmp(a, "--host-acx")) host_acx = 1;
 		else if (!strcmp(a, "--forwardreverse") || !strcmp(a, "-fr")) do_rc = 1;
 		else if (!strcmp(a, "--whitespace") || !strcmp(a, "-w")) incl_ws = 1;
 		else if (!strcmp(a, "--npenalize") || !strcmp(a, "-n")) z = 1;
@@ -144,7 +164,7 @@ int main(int argc, char **argv) {
 		if (!ref_FN) { puts("ERROR: --make-acx needs -r DB.edx"); return 1; }
 		BhDb db; int rc0;
 		if ((rc0 = bh_edx_read(ref_FN, &db))) DIE(rc0);
-		if ((rc0 = bh_acx_build(&db, K ? K : 12, z))) DIE(rc0);
+		if ((rc0 = build_accelerator(&db, K ? K : 12, z, device, host_acx || skip_ambig))) DIE(rc0);
 		if ((rc0 = bh_acx_write(&db, mkacx_FN))) DIE(rc0);
 		printf("Accelerator written: K=%d, %s format, %u ambiguous clumps\n", db.K, db.acxFmt ? "LARGE" : "SMALL", db.badSz);
 		bh_db_free(&db);
@@ -169,8 +189,9 @@ int main(int argc, char **argv) {
 		printf("Database written: %u refs [%u orig], %u clumps, %u maxR\n", db.totR, db.origTotR, db.numRclumps, db.maxLenR);
 		if (do_accel) {
 			if (!K) K = 12;
+			if (accel_dev || !xcel_FN) { puts("ERROR: -ad builds the accelerator at search time; give -a <name> to write one"); return 1; }
 			printf("Generating accelerator '%s' (K=%d)\n", xcel_FN, K);
-			if ((rc = bh_acx_build(&db, K, z))) DIE(rc);
+			if ((rc = build_accelerator(&db, K, z, device, host_acx || skip_ambig))) DIE(rc);
 			if ((rc = bh_acx_write(&db, xcel_FN))) DIE(rc);
 		}
 		bh_db_free(&db);
@@ -188,7 +209,11 @@ int main(int argc, char **argv) {
 		if (db.xalpha) { fputs("ERROR: DB made with Xalpha; queries can't use Xalpha.\n", stderr); return 1; }
 		printf(" --> EDB: %u refs [%u orig], %u clumps, %u maxR\n", db.totR, db.origTotR, db.numRclumps, db.maxLenR);
 	}
-	if (do_accel) {
+	if (do_accel && accel_dev) {
+		if (!usedb) { fputs("ERROR: an accelerator needs an .edx database\n", stderr); return 1; }
+		if (!K) K = 12;
+		printf(" --> [Accel] K=%d, built on the device from the database\n", K);
+	} else if (do_accel) {
 		if (!usedb) { fputs("ERROR: an accelerator needs an .edx database\n", stderr); return 1; }
 		if ((rc = bh_acx_read(xcel_FN, K, z, &db))) DIE(rc);      /* K = 0: 12 or 15, whichever the file's exact size says */
 		K = db.K;
@@ -225,7 +250,7 @@ int main(int argc, char **argv) {
 	#pragma omp parallel num_threads(n_gpus)
 	{
 		const int r = omp_get_thread_num();
-		if ((rcs[r] = bh_device_open(&db, dev_list[r], z, &hhs[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
+		if ((rcs[r] = bh_device_open_ex(&db, dev_list[r], z, accel_dev ? K : 0, &hhs[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
 	}
 	for (int r = 0; r < n_gpus; ++r) if (rcs[r]) { fprintf(stderr, "%s\n", errs[r]); return 4; }
 	void *hh = hhs[0];

@@ -67,6 +67,8 @@ def lib():
         L.bh_db_slice.argtypes = [C.POINTER(BhDb), C.c_uint32, C.c_uint32, C.POINTER(BhDb)]
         L.bh_db_free.argtypes = [C.POINTER(BhDb)]
         L.bh_device_open.argtypes = [C.POINTER(BhDb), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.bh_device_open_ex.argtypes = [C.POINTER(BhDb), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.bh_acx_from_device.argtypes = [C.POINTER(BhDb), C.c_void_p, C.c_int, C.c_int]
         L.bh_align.argtypes = [C.c_void_p, C.POINTER(BhQueries), C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(BhRun)]
         L.bh_align_ranges.argtypes = [C.c_void_p, C.POINTER(BhQueries), u64p, u64p, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(BhRun)]
         L.bh_align_ranges_reuse.argtypes = L.bh_align_ranges.argtypes
@@ -130,14 +132,19 @@ class Db:
         d._parent = self               # the view points into the parent's clump area
         return d
 
-    def open_device(self, device=0, z=1):
+    def open_device(self, device=0, z=1, build_K=0):
+        """build_K > 0 for a database read without its .acx: the device builds the accelerator (bhip_init with K and no tables)"""
         h = C.c_void_p()
-        _chk(lib().bh_device_open(C.byref(self.c), device, z, C.byref(h)))
+        _chk(lib().bh_device_open_ex(C.byref(self.c), device, z, build_K, C.byref(h)))
         dev = capi.Device.__new__(capi.Device)
         dev._h = h
         dev.n_clumps = self.c.numRclumps
         dev.clump_len = _view(self.c.clumpLen, self.c.numRclumps, np.uint32)
         return dev
+
+    def acx_from_device(self, dev, K, z=1):
+        """accelerator tables of this database from a device handle that built them (bh_acx_from_device): write() then saves the .acx"""
+        _chk(lib().bh_acx_from_device(C.byref(self.c), dev._h, K, z))
 
     def close(self):
         if self._open:

@@ -21,6 +21,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libburst_hip.so is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table */
+#define BHIP_API __attribute__((visibility("default")))
 
 #define BHIP_OK            0
 #define BHIP_E_ARG        -1   /* invalid argument */
@@ -80,13 +82,15 @@ typedef struct BhipStats {
  *   edx_packed : the clump area of an .edx exactly as on disk (burst.c:2810-2824): for clump c,
  *                ceil(clump_len[c]/2) 16-byte words; byte k of a word = lane k; low nibble = even position.
  *   clump_len  : ClumpLen[n_clumps] (burst.c:2918);  tot_refs = totR (lanes >= tot_refs never hit, burst.c:4229)
- *   acx_lens   : Lens[4^K] of the .acx (burst.c:3558) or NULL when no accelerator is used
+ *   acx_lens   : Lens[4^K] of the .acx (burst.c:3558), or NULL: with K = 0 no accelerator is used, with K in 4..15 the accelerator
+ *                is BUILT ON THE DEVICE from the references alone (what make_accelerator does, burst.c:3304-3532: same entries in
+ *                the same order, same BadList; acx_lists / acx_fmt / badlist are then ignored) -- no .acx file, no upload
  *   acx_lists  : the packed list area (burst.c:3569); acx_fmt 0 = SMALL 20-bit pairs (3265-3274), 1 = LARGE 24-bit (3245-3248)
  *   badlist    : BadList[n_bad] (burst.c:3571): clumps every prefiltered query must be aligned against
  *   score_lut  : 16x16 cost table lut[16*q + r] in {0,1,255} = SCOREFAST after setScore() (burst.c:1310-1328)
  *   xalpha     : must be 0 (alphabet-agnostic -x mode is not implemented on the device)
  */
-int bhip_init(int device, const void *edx_packed, const uint32_t *clump_len, uint32_t n_clumps, uint32_t tot_refs,
+BHIP_API int bhip_init(int device, const void *edx_packed, const uint32_t *clump_len, uint32_t n_clumps, uint32_t tot_refs,
               const uint32_t *acx_lens, const void *acx_lists, int acx_fmt, int K,
               const uint32_t *badlist, uint32_t n_bad,
               const uint8_t score_lut[256], int xalpha, void **handle);
@@ -105,7 +109,7 @@ int bhip_init(int device, const void *edx_packed, const uint32_t *clump_len, uin
  *             1 = FORAGE semantics (every lane with ed <= budget, burst.c:4224)
  *   hits/cap: caller's buffer; on BHIP_E_CAPACITY *n_hits is the number required and nothing is returned.
  * Records are returned sorted by (q, refIx). */
-int bhip_align_batch(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
+BHIP_API int bhip_align_batch(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
                      const uint32_t *q_six, const uint8_t *q_rc, const uint8_t *q_flags,
                      uint32_t n_q, uint32_t n_shared, int all_hits,
                      BhipHit *hits, uint64_t cap, uint64_t *n_hits);
@@ -113,9 +117,9 @@ int bhip_align_batch(void *handle, const uint8_t *q_codes, const uint64_t *q_off
 /* The same in two steps.  bhip_stage_queries is synchronous (the caller's arrays are free again at return) and replaces any
  * batch that was waiting; bhip_align_staged may then run any number of times on the resident batch.
  * bhip_align_batch(...) == bhip_stage_queries(...) followed by bhip_align_staged(...). */
-int bhip_stage_queries(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
+BHIP_API int bhip_stage_queries(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
                        const uint32_t *q_six, const uint8_t *q_rc, const uint8_t *q_flags, uint32_t n_q, uint32_t n_shared);
-int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint64_t cap, uint64_t *n_hits);
+BHIP_API int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint64_t cap, uint64_t *n_hits);
 
 /* Pipelined staging for a batch scheduler (the replacement of the OpenMP loops burst.c:4050-4078 / 4326-4344 hands batch k+1
  * to the device while batch k is being aligned).  A batch is given as up to a few SPANS of consecutive entries of the caller's
@@ -140,51 +144,58 @@ typedef struct BhipQuerySpan {
 	uint32_t n;
 	uint32_t q_base;         /* BhipHit.q of the span's first entry */
 } BhipQuerySpan;
-int bhip_stage_spans(void *handle, const BhipQuerySpan *spans, uint32_t n_spans, uint32_t n_shared, uint32_t max_len);
+BHIP_API int bhip_stage_spans(void *handle, const BhipQuerySpan *spans, uint32_t n_spans, uint32_t n_shared, uint32_t max_len);
 
 /* Optional: allocate now what batches of up to n_entries entries of up to max_len symbols will need, so that no allocation
  * (each one synchronises the device) falls into the first batches. */
-int bhip_reserve(void *handle, uint32_t n_entries, uint32_t max_len);
+BHIP_API int bhip_reserve(void *handle, uint32_t n_entries, uint32_t max_len);
 
 /* Page-locked host memory (hipHostMalloc / hipHostRegister behind the C ABI, for callers that are plain C): copies from and to
  * it run asynchronously beside the kernels.  bhip_alloc_host returns NULL when no device is present. */
-void *bhip_alloc_host(uint64_t bytes);
-void  bhip_free_host(void *p);
-int   bhip_host_register(void *p, uint64_t bytes);
-int   bhip_host_unregister(void *p);
+BHIP_API void *bhip_alloc_host(uint64_t bytes);
+BHIP_API void  bhip_free_host(void *p);
+BHIP_API int   bhip_host_register(void *p, uint64_t bytes);
+BHIP_API int   bhip_host_unregister(void *p);
 
 /* Multi-GPU (no reference counterpart): the unique queries are sharded across the GPUs of a node -- one handle and
  * one host thread per device, the database replicated -- and the hit records travel to rank 0 in one variable-length gather
  * over RCCL / xGMI (ncclAllGather of the counts + grouped ncclSend / ncclRecv of the 20-byte records).  bhip_comm_create sets up
  * the ranks of THIS process (ncclCommInitAll); every rank's thread then calls bhip_comm_gather_hits with its records (host
  * memory); rank 0 gets all of them in rank order, counts[n_ranks] the per-rank numbers.  BHIP_E_CAPACITY: *n_total needed. */
-int  bhip_comm_create(int n_ranks, const int *devices, void **comm);
-int  bhip_comm_gather_hits(void *comm, int rank, const BhipHit *hits, uint64_t n, BhipHit *out, uint64_t cap, uint64_t *n_total, uint64_t *counts);
-void bhip_comm_destroy(void *comm);
+BHIP_API int  bhip_comm_create(int n_ranks, const int *devices, void **comm);
+BHIP_API int  bhip_comm_gather_hits(void *comm, int rank, const BhipHit *hits, uint64_t n, BhipHit *out, uint64_t cap, uint64_t *n_total, uint64_t *counts);
+BHIP_API void bhip_comm_destroy(void *comm);
+
+/* The accelerator of a handle in the file's terms (read_accelerator's tables, burst.c:3535-3594): Lens[4^K], the clump ids of all
+ * lists in word order (ascending inside a list, as the reference writes them with one thread), their 16-bit lane masks (device
+ * layout only: bit z = lane z of the clump holds the word), the BadList.  For a handle whose accelerator was built on the device
+ * this is what make_accelerator (burst.c:3304-3532) would have written.  Any output pointer may be NULL. */
+BHIP_API int bhip_acx_export(void *handle, uint32_t *lens, uint32_t *clumps, uint16_t *masks, uint64_t cap_entries, uint64_t *n_entries,
+                    uint32_t *badlist, uint32_t cap_bad, uint32_t *n_bad);
 
 /* Kernel-level entry (what one aded_mat16 call returns, burst.c:1078-1094): for explicit (query, clump)
  * pairs, mins[16*p + z] = edit distance of lane z (255 when > budget of the pair's query). */
-int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
+BHIP_API int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
                      uint32_t n_q, const uint32_t *pair_q, const uint32_t *pair_clump, uint64_t n_pairs,
                      uint8_t *mins);
 
 /* Kernel-level entry for the prefilter alone: candidate (query, clump, count) triples with
  * count > max(len-(E+1)K, 0) (burst.c:4091-4092, 4126), BadList clumps not included.
  * Output sorted by (q, clump).  On BHIP_E_CAPACITY *n_out is the number required. */
-int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
+BHIP_API int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
                    uint32_t n_q, uint32_t *out_q, uint32_t *out_clump, uint32_t *out_count,
                    uint64_t cap, uint64_t *n_out);
 
 /* The records of the last bhip_align_staged / bhip_align_batch call stay resident on the device (same order as the host
  * copy; `hits` may be NULL there to skip the host copy altogether).  This copies them into caller-owned DEVICE memory,
  * e.g. the send buffer of an RCCL gather (no reference counterpart: multi-GPU).  Synchronous. */
-int bhip_copy_hits_device(void *handle, void *dst_device, uint64_t cap_records, uint64_t *n_records);
+BHIP_API int bhip_copy_hits_device(void *handle, void *dst_device, uint64_t cap_records, uint64_t *n_records);
 
 /* With option "async_d2h" = 1 the records of bhip_align_staged / bhip_align_batch reach the caller's buffer BEHIND the call:
  * *n_hits is final at return, the bytes are not until bhip_sync_hits() (or bhip_destroy).  The copy of call k then
  * overlaps the kernels of call k+1; callers alternate between two result buffers (the library page-locks them once).
  * No reference counterpart (the reference appends ResultPods in place, burst.c:4230-4238). */
-int bhip_sync_hits(void *handle);
+BHIP_API int bhip_sync_hits(void *handle);
 
 /* Query ingest: sort n records of symbol codes (record r = codes[start[r] .. start[r] + len[r]), codes 0..15) in the order
  * of the reference's query sort -- byte-wise over the common length, the shorter record first, equal records in input order
@@ -192,7 +203,7 @@ int bhip_sync_hits(void *handle);
  * burst.c:3036-3053).  perm[i] = input number of the i-th record in sorted order, is_new[i] = 1 iff it differs from the
  * (i-1)-th.  A device-side LSD radix sort over 16-symbol keys; needs no handle (it runs before the database is uploaded) and
  * about codes_bytes + 40 n bytes of device memory for the duration of the call.  max_len >= every len[r]. */
-int bhip_sort_queries(int device, const uint8_t *codes, uint64_t codes_bytes, const uint64_t *start, const uint32_t *len,
+BHIP_API int bhip_sort_queries(int device, const uint8_t *codes, uint64_t codes_bytes, const uint64_t *start, const uint32_t *len,
                       uint64_t n, uint32_t max_len, uint32_t *perm, uint8_t *is_new);
 
 /* Tuning knobs.  "prefilter_stride": 0 (default) = automatic sparse seeds -- per query the largest stride s <= K for
@@ -216,17 +227,17 @@ int bhip_sort_queries(int device, const uint8_t *codes, uint64_t codes_bytes, co
  * batch run while the current one is swept, 0 = in place; "seed_ahead_blocks" (default 2, 0 = unlimited) / "peq_ahead_blocks"
  * (default 16) = 256-thread blocks per CU those kernels get while they share the device with the sweeps.
  * None of these changes a result. */
-int bhip_set_option(void *handle, const char *name, long long value);
+BHIP_API int bhip_set_option(void *handle, const char *name, long long value);
 
 /* Stats of the last call; device properties (name, CU count) for reports. */
-int bhip_get_stats(void *handle, BhipStats *out);
-int bhip_device_info(void *handle, char *name, int name_cap, int *n_cu, uint64_t *hbm_bytes);
+BHIP_API int bhip_get_stats(void *handle, BhipStats *out);
+BHIP_API int bhip_device_info(void *handle, char *name, int name_cap, int *n_cu, uint64_t *hbm_bytes);
 
-void bhip_destroy(void *handle);
-const char *bhip_last_error(void);
+BHIP_API void bhip_destroy(void *handle);
+BHIP_API const char *bhip_last_error(void);
 /* ABI version of this header */
-int bhip_abi_version(void);
-#define BHIP_ABI_VERSION 2
+BHIP_API int bhip_abi_version(void);
+#define BHIP_ABI_VERSION 3
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,119 @@
+"""The accelerator built ON THE DEVICE from the references alone (bhip_init with K and no tables: make_accelerator,
+burst.c:3304-3532, as gfx950 kernels -- word tuples of every lane, IUPAC expansion, the reference's BadList budget, radix sort,
+fold) against the tables of the .acx path: the host builder's (itself byte-identical to the compiled reference's files,
+tests/test_host_cpu.py) loaded through read_accelerator's layout, and against the compiled reference directly."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import goldenlib as gl
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(gl.ROOT, "burst_amd", "burst_hip")
+
+
+def _compare_built_with_loaded(db_path_or_db, K, z, from_fasta=None):
+    from burst_amd import host
+    L = host.lib()
+    import ctypes as C
+    # tables of the file path: host builder -> upload -> export
+    if from_fasta:
+        a = host.Db.from_fasta(from_fasta, 120, 0.95, shear_len=500, K=K, z=z)
+        b = host.Db.from_fasta(from_fasta, 120, 0.95, shear_len=500)
+    else:
+        a = host.Db.read(db_path_or_db)
+        host._chk(L.bh_acx_build(C.byref(a.c), K, z))
+        b = host.Db.read(db_path_or_db)
+    dev_a = a.open_device(0, z)
+    lens_a, clumps_a, masks_a, bad_a = dev_a.acx_export(K)
+    dev_a.close()
+    # what went up is what the host builder made
+    assert np.array_equal(lens_a, host._view(a.c.acxLens, 1 << (2 * K), np.uint32))
+    assert np.array_equal(bad_a, host._view(a.c.badList, a.c.badSz, np.uint32))
+    dev_b = b.open_device(0, z, build_K=K)
+    lens_b, clumps_b, masks_b, bad_b = dev_b.acx_export(K)
+    assert np.array_equal(lens_a, lens_b)
+    assert np.array_equal(clumps_a, clumps_b)
+    assert np.array_equal(bad_a, bad_b)
+    # lane masks: the built ones are exact per lane; the loaded path adds every lane of a clump that holds IUPAC symbols
+    # (and every lane for words it knows from the expansion only): a superset, equal where no ambiguity is involved
+    assert not np.any(masks_b & ~masks_a)
+    assert np.all(masks_b != 0)
+    # the .acx the host writes from the device's tables is the host builder's, byte for byte
+    b.acx_from_device(dev_b, K, z)
+    assert b.c.acxFmt == a.c.acxFmt and b.c.acxListBytes == a.c.acxListBytes
+    assert np.array_equal(host._view(b.c.acxLists, b.c.acxListBytes, np.uint8), host._view(a.c.acxLists, a.c.acxListBytes, np.uint8))
+    dev_b.close()
+    n = len(clumps_a)
+    a.close(); b.close()
+    return n, len(bad_a), int(np.count_nonzero(masks_a != masks_b))
+
+
+@pytest.mark.parametrize("db,K,z", [("dna", 12, 1), ("dna", 12, 0), ("quick", 12, 1), ("quick", 10, 0), ("quick", 15, 1)])
+def test_device_built_accelerator_equals_file(db, K, z, monkeypatch):
+    """golden databases (references with IUPAC codes and N): same list lengths, same clump ids in the same order, same BadList"""
+    n, nbad, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z)
+    assert n > 10000
+    if K == 12:      # the same in slices of a few clumps (two passes: list lengths, then records at running list positions)
+        monkeypatch.setenv("BHIP_MASK_SLICE", "40000")
+        n2, _, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z)
+        assert n2 == n
+
+
+def test_device_built_accelerator_expansion_and_badlist(tmp_path, monkeypatch):
+    """heavy ambiguity: runs of three-way codes (hundreds of thousands of expanded words per clump), N runs, and a run long
+    enough for the reference's estimate to put its clump on the BadList (burst.c:3341-3354)"""
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    recs = []
+    for i in range(40):
+        s = acgt[rng.integers(0, 4, size=int(rng.integers(300, 900)))].copy()
+        if i % 4 == 1:
+            m = rng.random(len(s)) < 0.03
+            s[m] = np.frombuffer(b"RYKMSWBDHVN", np.uint8)[rng.integers(0, 11, size=int(m.sum()))]
+        if i == 6:
+            s[100:109] = np.frombuffer(b"BDHVBDHVB", np.uint8)          # 3^9 words per window around it
+        if i == 9:
+            s[50:90] = ord("N")
+        if i == 21:
+            s[100:500] = np.frombuffer(b"RY", np.uint8)[rng.integers(0, 2, size=400)]     # estimate 3^11 per window x 400: BadList
+        recs.append(s.tobytes().decode())
+    fa = str(tmp_path / "amb.fa")
+    with open(fa, "w") as f:
+        for i, s in enumerate(recs):
+            f.write(">r%d\n%s\n" % (i, s))
+    for z in (1, 0):
+        n, nbad, ndiff = _compare_built_with_loaded(None, 12, z, from_fasta=fa)
+        assert nbad >= 1 and n > 50000 and ndiff > 0
+    monkeypatch.setenv("BHIP_MASK_SLICE", "30000")
+    _compare_built_with_loaded(None, 12, 1, from_fasta=fa)
+
+
+@pytest.mark.parametrize("name", ["dna_q100_allpaths_fr", "dna_q100_best", "dna_q100_allpaths_y", "quick_q100_capitalist_fr", "quick_q292_best_fr", "dna_q292_forage_fr"])
+def test_cli_with_device_built_accelerator(name, tmp_path):
+    """burst_hip -ad: no .acx file anywhere -- golden outputs of the accelerated cases"""
+    c = [x for x in gl.cases() if x["name"] == name][0]
+    ref, q, fr, z, shear = gl.case_args(c)
+    out = str(tmp_path / "o.b6")
+    cmd = [CLI, "-r", ref, "-q", q, "-o", out, "-m", c["mode"], "-i", c["id"], "-ad"] + gl.cli_extra(c)
+
+    def run(extra=()):
+        r = subprocess.run(cmd + list(extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0 and "built on the device" in r.stdout, r.stdout
+        return sorted(open(out, "rb").read().splitlines())
+    got = run()
+    nd = run(["--no-dupe-hunt"]) if gl.order_sensitive(c) else None
+    gl.compare(c, got, nd)
+
+
+def test_device_builder_differential_against_the_reference(tmp_path):
+    """tools/db_diff.py on the GPU box: `burst_hip -d QUICK ... -a` now builds the accelerator on the device; its .acx must be
+    the compiled reference's, byte for byte, on random and awkward FASTA files (heavy IUPAC, N runs, -y, duplicates, ...)"""
+    if not os.path.exists(os.path.join(gl.ROOT, "oracle", "_ref", "burst12")):
+        pytest.skip("compiled reference not present")
+    r = subprocess.run([sys.executable, os.path.join(gl.ROOT, "tools", "db_diff.py"), "6", str(tmp_path)], env=dict(os.environ, DB_DIFF_EXPECT_DEVICE="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-4000:]

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Differential run of the two database builders (no GPU involved): `burst_hip -d QUICK` vs the compiled reference
+"""Differential run of the two database builders: `burst_hip -d QUICK` (accelerator on the device when there is one -- DB_DIFF_EXPECT_DEVICE=1
+insists on it --, else the host builder) vs the compiled reference
 (oracle/_ref/burst12) on random and awkward reference FASTA files -- the .edx files must be byte-identical and the .acx
 files too.
    python tools/db_diff.py [n_random] [workdir]"""
@@ -93,6 +94,8 @@ for name, fa in cases:
             r = subprocess.run([exe, "-r", fa, "-o", edx, "-a", acx] + par + tail, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             outs.append((r.returncode, open(edx, "rb").read() if os.path.exists(edx) else None, open(acx, "rb").read() if os.path.exists(acx) else None, r.stdout[-400:]))
         same = outs[0][0] == outs[1][0] and (outs[0][0] != 0 or (outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]))
+        if os.environ.get("DB_DIFF_EXPECT_DEVICE") == "1" and outs[1][0] == 0 and "-sa" not in par and "built on device" not in outs[1][3]:
+            same = False
         print("%-18s %-44s ref rc=%d hip rc=%d edx %s acx %s  %s" % (name, " ".join(par), outs[0][0], outs[1][0],
               "same" if outs[0][1] == outs[1][1] else "DIFFERENT", "same" if outs[0][2] == outs[1][2] else "DIFFERENT", "ok" if same else "DIFF"))
         if not same:
