@@ -3,9 +3,10 @@
 
 Workload (BASELINE.json configs[3] / `metric`, at the size one GPU box can build in a bench run): synthetic 100-bp reads
 (0-2 edits, LLsim-style) against a RefSeq stand-in database with a DB15 (K = 15) accelerator, `-m BEST -i 0.98`.  The real
-31.5 GB RefSeq subset is not reachable offline; the database is the synthetic family generator of DESIGN.md section 5
-scaled up (default 990 000 references / 1.39 Gbp: 0.86 GB .edx + 7.4 GB .acx; --db-scale 3 gives the 4.2 Gbp one), and
-`config.extrapolation` says how far that is from the metric's database.
+31.5 GB RefSeq subset is not reachable offline; the stand-in is a low-redundancy synthetic database (default 1.6 M random base
+sequences x 2 variants at 5 % divergence = 3.2 M references, 4.5 Gbp: every 15-mer has ~4 unrelated list entries, as a
+collision-dominated RefSeq-scale DB15 would have many more), its accelerator BUILT ON THE DEVICE from the .edx (no .acx is read
+or uploaded), and `config.extrapolation` carries the slope measured over several database sizes (profiles/r03_slope.json).
 
 A step = one batch of reads through the WHOLE device path as the product runs it: bench.py calls the C batch scheduler of
 the `burst_hip` command line (bh_align_ranges, burst_amd/csrc/host/bh_align.c) -- each step's batch is staged afresh from
@@ -19,9 +20,12 @@ gather brings the hit records to rank 0 inside the timed region.
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel by time (HIP events on the stream it runs on);
 `roofline.per_kernel` lists the others with their own bound; PMC-derived traffic / VALU figures come from profiles/
 (tools/profile_round.sh).  `cpu_baseline` is the compiled reference itself (oracle/_ref/burst15, all host cores) on a
-bounded sample of the same reads and database: differential wall time of two sample sizes, which cancels its database load.
+bounded sample of the same reads and database (its .acx is written from the device-built tables): differential wall time of
+two sample sizes, which cancels its database load.  `parity_vs_reference`: the .b6 the reference wrote for that sample against
+the .b6 of the device path for the same reads (outside the timed region).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import subprocess
@@ -57,13 +61,24 @@ def build_db(workdir, args, rank=0):
         t = time.time()
         host.synth_refs(refs, args.n_base, args.n_variants, args.ref_len, args.variant_rate, 7)
         t1 = time.time()
-        db = host.Db.from_fasta(refs, args.db_qlen, args.id, shear_len=500, K=args.K)
+        db = host.Db.from_fasta(refs, args.db_qlen, args.id, shear_len=500)
         t2 = time.time()
-        db.write(edx, acx, db_qlen=args.db_qlen, thres=args.id)
+        db.write(edx, None, db_qlen=args.db_qlen, thres=args.id)
         db.close()
         open(done, "w").write("ok")
-        log("[bench] database built in %.1f s (references %.1f s, clumps + accelerator %.1f s, files %.1f s)" % (time.time() - t, t1 - t, t2 - t1, time.time() - t2))
+        log("[bench] database built in %.1f s (references %.1f s, clumps %.1f s, .edx %.1f s); the accelerator is built on the device" % (time.time() - t, t1 - t, t2 - t1, time.time() - t2))
     return refs, edx, acx, done
+
+
+def ensure_acx(edx, acx, K):
+    """an .acx FILE for the database (the compiled reference reads one; so does burst_hip -a): `burst_hip --make-acx`, which builds the
+    accelerator on the device when there is one"""
+    if not os.path.exists(acx + ".done"):
+        t = time.time()
+        subprocess.check_call([os.path.join(ROOT, "burst_amd", "burst_hip"), "-r", edx, "--make-acx", acx, "-k", str(K)], stdout=subprocess.DEVNULL)
+        open(acx + ".done", "w").write("ok")
+        log("[bench] %s written in %.1f s" % (acx, time.time() - t))
+    return acx
 
 
 def build_inputs(workdir, args, rank):
@@ -103,11 +118,31 @@ def cpu_baseline(edx, acx, reads_fa, args):
             return None
         times.append(time.time() - t)
     dt = max(times[1] - times[0], 1e-6)
+    cpu_baseline.sample_fa, cpu_baseline.sample_b6 = sample, sample + ".b6"        # the larger sample: parity_vs_reference compares with it
     return {"value": (n2 - n1) / dt, "unit": "reads/s", "cores": cores, "kind": "reference",
             "sample": "oracle/_ref/burst%d (reference compiled with gcc -O3 -march=x86-64-v3 -fopenmp) -t %d, same .edx/.acx, "
                       "-m %s -i %s; differential wall time of the first %d vs %d reads of the pool (%.2f s vs %.2f s) = its align "
                       "phase incl. parse/sort/output of the extra reads, database load cancelled"
                       % (args.K, cores, args.mode, args.id, n1, n2, times[0], times[1])}
+
+
+def parity_vs_reference(dev, db, args, batch_uniq):
+    """the reference's .b6 for the cpu_baseline sample against the device path's for the same reads (same database, same flags)"""
+    from burst_amd import host
+    sample, ref_b6 = getattr(cpu_baseline, "sample_fa", None), getattr(cpu_baseline, "sample_b6", None)
+    if not sample or not os.path.exists(ref_b6):
+        return None
+    qs = host.QuerySet(sample, args.id, rc=args.fr, accel=True, K=args.K)
+    run = host.align_ranges(dev, qs, [(0, qs.n_uniq)], args.mode, batch_uniq)
+    out = sample + ".hip.b6"
+    host.report(out, db, qs, run.hits, args.mode, 0)
+    a = sorted(open(ref_b6, "rb").read().splitlines())
+    b = sorted(open(out, "rb").read().splitlines())
+    sa, sb = set(a), set(b)
+    res = {"reads": qs.n_reads, "lines_reference": len(a), "lines": len(b), "identical": a == b, "only_reference": len(sa - sb), "only_device": len(sb - sa),
+           "what": "sorted .b6 of oracle/_ref/burst%d vs the device path (bh_align_ranges + bh_report) on the first %d reads of the pool, -m %s -i %s" % (args.K, qs.n_reads, args.mode, args.id)}
+    run.close(); qs.close()
+    return res
 
 
 def pmc_table():
@@ -130,9 +165,9 @@ def main():
     ap.add_argument("--reads", type=int, default=2000000, help="reads per step (whole job, all GPUs together)")
     ap.add_argument("--pool", type=int, default=4, help="distinct batches the steps cycle through")
     ap.add_argument("--read-len", type=int, default=100)
-    ap.add_argument("--db-scale", type=float, default=1.0, help="multiplies --n-base (1 = 990 000 references / 1.39 Gbp, 3 = 4.2 Gbp)")
-    ap.add_argument("--n-base", type=int, default=33000)
-    ap.add_argument("--n-variants", type=int, default=30)
+    ap.add_argument("--db-scale", type=float, default=1.0, help="multiplies --n-base (1 = 3.2 M references / 4.5 Gbp)")
+    ap.add_argument("--n-base", type=int, default=1600000, help="random base sequences (round 2's family-dominated database: --n-base 33000 --n-variants 30)")
+    ap.add_argument("--n-variants", type=int, default=2)
     ap.add_argument("--ref-len", type=int, default=1400)
     ap.add_argument("--variant-rate", type=float, default=0.05)
     ap.add_argument("--id", type=float, default=0.98)
@@ -147,6 +182,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="library tuning option name=value (bhip_set_option), repeatable")
     ap.add_argument("--no-pin", action="store_true", help="leave the query arrays pageable")
     ap.add_argument("--no-prime", action="store_true", help="skip bhip_reserve and the priming call (profiling: every dispatch of the run is then a full-size batch)")
+    ap.add_argument("--acx-file", action="store_true", help="round 2's path: the accelerator from an .acx file (built by the host builder) instead of the device build")
     args = ap.parse_args()
     args.n_base = int(round(args.n_base * args.db_scale))
 
@@ -170,14 +206,22 @@ def main():
         time.sleep(0.2)
 
     t = time.time()
-    db = host.Db.read(edx, acx, K=args.K)
+    if args.acx_file and not os.path.exists(acx):
+        if rank == 0:
+            dbb = host.Db.read(edx)
+            host._chk(host.lib().bh_acx_build(C.byref(dbb.c), args.K, 1))
+            host._chk(host.lib().bh_acx_write(C.byref(dbb.c), acx.encode()))
+            dbb.close()
+        if use_dist:
+            dist.barrier()
+    db = host.Db.read(edx, acx if args.acx_file else None, K=args.K)
     t_db = time.time() - t
     t = time.time()
     host.lib().bh_queries_sort_device(local_rank)          # large query files are sorted on this rank's own device
     qs = host.QuerySet(reads_fa, args.id, rc=args.fr, accel=True, K=args.K)
     t_q = time.time() - t
     t = time.time()
-    dev = db.open_device(local_rank)
+    dev = db.open_device(local_rank, build_K=0 if args.acx_file else args.K)      # references up, both layouts; accelerator built on the device
     t_dev = time.time() - t
     for kv in args.opt:
         name, _, val = kv.partition("=")
@@ -185,9 +229,13 @@ def main():
     if not args.no_pin:
         qs.pin()
     info = dev.info()
-    edx_bytes, acx_bytes = os.path.getsize(edx), os.path.getsize(acx)
-    log("[bench] rank %d: db %d refs / %d clumps (.edx %.2f GB, .acx %.2f GB; read %.1f s, device upload %.1f s), %d reads -> %d unique (ingest %.1f s) on %s"
-        % (rank, db.c.totR, db.c.numRclumps, edx_bytes / 1e9, acx_bytes / 1e9, t_db, t_dev, qs.n_reads, qs.n_uniq, t_q, info["name"]))
+    edx_bytes = os.path.getsize(edx)
+    n_ent = C.c_uint64()
+    capi._chk(capi.lib().bhip_acx_export(dev._h, None, None, None, 0, C.byref(n_ent), None, 0, None))
+    acx_entries = int(n_ent.value)
+    acx_bytes = 5 + 4 * (1 << (2 * args.K)) + 3 * acx_entries          # what the LARGE-format file holds
+    log("[bench] rank %d: db %d refs / %d clumps (.edx %.2f GB, accelerator %.2f G entries; read %.1f s, device upload + accelerator build %.1f s), %d reads -> %d unique (ingest %.1f s) on %s"
+        % (rank, db.c.totR, db.c.numRclumps, edx_bytes / 1e9, acx_entries / 1e9, t_db, t_dev, qs.n_reads, qs.n_uniq, t_q, info["name"]))
 
     # pool batch b = unique queries [b U / P, (b+1) U / P); this rank's share of it = its 1/world slice
     U, P = qs.n_uniq, args.pool
@@ -322,6 +370,16 @@ def main():
         cells = (st["n_task_columns"] if masked else st["n_columns"] * 16.0) * min(args.read_len, 32.0 * max(1, st["prefix_words"])) + st["n_window_columns"] * float(args.read_len)
         ms_sweeps = st["ms_myers"]
         scale_to_metric = 31.5e9 / max(1, edx_bytes)
+        rec_per_read = st["acx_entries_read"] / max(1.0, float(st["n_queries"]))
+        # measured slope over database sizes (tools/slope_fit.py over the bench lines kept under profiles/): ms per batch of --reads reads
+        # = a + b x accelerator records per read; the metric's database has ~63 G list entries
+        extrap = {"metric_database": "31.5 GB RefSeq .edx", "this_edx_bytes": edx_bytes, "size_ratio": scale_to_metric,
+                  "acx_entries_here": acx_entries, "acx_records_per_read_here": rec_per_read}
+        try:
+            fit = json.load(open(os.path.join(ROOT, "profiles", "r03_slope.json")))
+            extrap["fit"] = fit
+        except Exception:
+            extrap["fit"] = None
         res = {
             "metric": "aligned reads/sec (node), %d-bp synthetic reads @%s id vs RefSeq stand-in .edx/.acx (DB%d), -m %s; %d GPU" % (args.read_len, args.id, args.K, args.mode, world),
             "value": total_reads / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -333,10 +391,7 @@ def main():
                                       args.n_base * args.n_variants * args.ref_len / 1e9, db.c.numRclumps, edx_bytes / 1e9, args.K, acx_bytes / 1e9),
                        "parallelism": "query-sharded x%d (%s), DB replicated, one RCCL gather of hit records" % (world, "whole batches in turn" if whole else "1/N slice of every batch"),
                        "timed_region": "bh_align_ranges over %d batches (copies + device routing two batches ahead, seed lookups + profiles one batch ahead, alignment, records to host memory)%s" % (nb, " + RCCL gather" if use_dist else ""),
-                       "extrapolation": {"metric_database": "31.5 GB RefSeq .edx", "this_edx_bytes": edx_bytes, "size_ratio": scale_to_metric,
-                                         "acx_records_per_read_here": st["acx_entries_read"] / max(1.0, float(st["n_queries"])),
-                                         "note": "K = 15 lists grow linearly with the database: about size_ratio x the records per read at the metric's size; "
-                                                 "not measured, the database cannot be built offline"},
+                       "extrapolation": extrap,
                        "device": info["name"], "n_cu": info["n_cu"]},
             "roofline": {"bound": "hbm" if bound_dom == "hbm" else "valu", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": pmc_of(dom).get("hbm_bytes_per_launch"),
@@ -353,9 +408,21 @@ def main():
                      "seed_words_per_read": st["n_seed_words"] / max(1.0, float(st["n_queries"]))},
             "host": {"db_read_s": t_db, "device_upload_s": t_dev, "query_ingest_s": t_q, "sec_in_device_calls": float(run.c.secAlign)},
         }
-        res["cpu_baseline"] = cpu_baseline(edx, acx, reads_fa, args) if world == 1 else None      # N = 1 only (the contract); the other ranks would sit in the barrier meanwhile
+        res["cpu_baseline"] = None
+        if world == 1 and not args.no_cpu_baseline and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "burst%d" % args.K)):      # N = 1 only (the contract); the other ranks would sit in the barrier meanwhile
+            if not os.path.exists(acx + ".done"):      # the reference reads an .acx FILE: written here from the tables the device built
+                t = time.time()
+                db.acx_from_device(dev, args.K, 1)
+                host._chk(host.lib().bh_acx_write(C.byref(db.c), acx.encode()))
+                open(acx + ".done", "w").write("ok")
+                log("[bench] .acx for the reference written from the device-built tables in %.1f s (%.2f GB)" % (time.time() - t, os.path.getsize(acx) / 1e9))
+            res["cpu_baseline"] = cpu_baseline(edx, acx, reads_fa, args)
         if res["cpu_baseline"]:
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+            try:
+                res["parity_vs_reference"] = parity_vs_reference(dev, db, args, batch_uniq)
+            except Exception as e:      # reported, never fatal for the measurement
+                res["parity_vs_reference"] = {"error": str(e)}
         print(json.dumps(res), flush=True)
     run.close()
     if use_dist:

@@ -269,12 +269,18 @@ static void tux_bucket_sort(Tux *pack, uint32_t n) {
 	}
 	qsort(np, n, sizeof(*np), nibpos_cmp);                 /* buckets ascending, members in input order */
 	for (uint32_t i = 0; i < n; ++i) tmp[i] = pack[np[i].pos];
+	/* the buckets are independent of each other: sorted side by side (each by the same libc qsort call as a serial pass makes) */
+	uint32_t nb = 0, *bstart = malloc(((size_t)(n < (1u << 20) ? n : (1u << 20)) + 2) * 4);
 	for (uint32_t a = 0; a < n;) {
 		uint32_t b = a + 1;
 		while (b < n && np[b].nib == np[a].nib) ++b;
-		qsort(tmp + a, b - a, sizeof(*tmp), tux_bucket_cmp);
+		bstart[nb++] = a;
 		a = b;
 	}
+	bstart[nb] = n;
+	#pragma omp parallel for schedule(dynamic, 1) if (n > 65536)
+	for (uint32_t k = 0; k < nb; ++k) qsort(tmp + bstart[k], bstart[k + 1] - bstart[k], sizeof(*tmp), tux_bucket_cmp);
+	free(bstart);
 	memcpy(pack, tmp, (size_t)n * sizeof(*tmp));
 	free(np); free(tmp);
 }
@@ -372,16 +378,21 @@ int bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_she
 	}
 	uint8_t *packed = own(db, calloc(words + 1, 16));
 	if (!packed) { free(head); free(seq); free(len); free(R); bh_db_free(db); return bh_set_error(BH_E_OOM, "OOM:RefClump"); }
-	uint64_t w0 = 0;
+	uint64_t *cw = malloc(((size_t)nC + 1) * 8);
+	if (!cw) { free(head); free(seq); free(len); free(R); bh_db_free(db); return bh_set_error(BH_E_OOM, "OOM:RefClump"); }
+	cw[0] = 0;
+	for (uint32_t c = 0; c < nC; ++c) cw[c + 1] = cw[c] + cl[c] / 2u + (cl[c] & 1);
+	#pragma omp parallel for schedule(static, 256)
 	for (uint32_t c = 0; c < nC; ++c) {
+		const uint64_t w0 = cw[c];
 		for (uint32_t k = 16 * c; k < nU && k < 16 * c + 16; ++k) {
 			const uint32_t r = db->refIxSrt[k], L = len[r];
 			const uint8_t *s = seq[r];
 			for (uint32_t j = 0; j < cl[c] && j <= L; ++j)
 				packed[(w0 + j / 2) * 16 + (k & 15)] |= (uint8_t)((s[j] & 15) << (4 * (j & 1)));
 		}
-		w0 += cl[c] / 2u + (cl[c] & 1);
 	}
+	free(cw);
 	db->clumpLen = cl; db->numRclumps = nC; db->packed = packed; db->packedWords = words; db->maxLenR = maxLenR;
 	/* headers: one per sheared reference; RefMap = unique header index, built as dump_edb does (burst.c:2769-2786) */
 	db->refHead = own(db, malloc((size_t)totR * sizeof(char *)));

@@ -18,25 +18,45 @@ int bh_synth_refs(const char *fasta_out, uint32_t n_base, uint32_t n_variants, u
 	FILE *o = fopen(fasta_out, "wb");
 	if (!o) return bh_set_error(BH_E_IO, "cannot write %s", fasta_out);
 	setvbuf(o, NULL, _IOFBF, 1 << 22);
-	uint64_t s = seed * 0x9E3779B97F4A7C15ULL + 0x1234567ULL;
-	char *base = malloc(length + 1), *var = malloc(2 * (size_t)length + 16);
-	for (uint32_t b = 0; b < n_base; ++b) {
-		for (uint32_t i = 0; i < length; ++i) base[i] = BASES[rng_next(&s) & 3];
-		for (uint32_t v = 0; v < n_variants; ++v) {
-			uint32_t n = 0;
-			for (uint32_t i = 0; i < length; ++i) {
-				if (v && rng_unit(&s) < rate) {
-					uint32_t k = (uint32_t)(rng_next(&s) % 5);
-					if (k < 3) { char c; do c = BASES[rng_next(&s) & 3]; while (c == base[i]); var[n++] = c; }
-					else if (k == 3) { /* deletion */ }
-					else { var[n++] = BASES[rng_next(&s) & 3]; var[n++] = base[i]; }
-				} else var[n++] = base[i];
+	/* every base sequence has a generator of its own (seeded by its number): blocks of families are made side by side and
+	 * written in order, so the file does not depend on the number of threads */
+	const uint32_t BLK = 4096;
+	const size_t per_fam = (size_t)n_variants * (2 * (size_t)length + 48);
+	char *buf = malloc((size_t)BLK * per_fam);
+	size_t *used = malloc((size_t)BLK * sizeof(*used));
+	if (!buf || !used) { free(buf); free(used); fclose(o); return bh_set_error(BH_E_OOM, "OOM:synth"); }
+	for (uint32_t b0 = 0; b0 < n_base; b0 += BLK) {
+		const uint32_t nb = n_base - b0 < BLK ? n_base - b0 : BLK;
+		#pragma omp parallel
+		{
+			char *base = malloc(length + 1);
+			#pragma omp for schedule(dynamic, 16)
+			for (uint32_t k = 0; k < nb; ++k) {
+				const uint32_t b = b0 + k;
+				uint64_t s = (seed * 0x9E3779B97F4A7C15ULL + 0x1234567ULL) ^ ((uint64_t)(b + 1) * 0xD6E8FEB86659FD93ULL);
+				if (!s) s = 1;
+				(void)rng_next(&s); (void)rng_next(&s);
+				char *w = buf + (size_t)k * per_fam;
+				for (uint32_t i = 0; i < length; ++i) base[i] = BASES[rng_next(&s) & 3];
+				for (uint32_t v = 0; v < n_variants; ++v) {
+					w += sprintf(w, ">ref_b%u_v%u\n", b, v);
+					for (uint32_t i = 0; i < length; ++i) {
+						if (v && rng_unit(&s) < rate) {
+							uint32_t kk = (uint32_t)(rng_next(&s) % 5);
+							if (kk < 3) { char c; do c = BASES[rng_next(&s) & 3]; while (c == base[i]); *w++ = c; }
+							else if (kk == 3) { /* deletion */ }
+							else { *w++ = BASES[rng_next(&s) & 3]; *w++ = base[i]; }
+						} else *w++ = base[i];
+					}
+					*w++ = '\n';
+				}
+				used[k] = (size_t)(w - (buf + (size_t)k * per_fam));
 			}
-			fprintf(o, ">ref_b%u_v%u\n", b, v);
-			fwrite(var, 1, n, o); fputc('\n', o);
+			free(base);
 		}
+		for (uint32_t k = 0; k < nb; ++k) fwrite(buf + (size_t)k * per_fam, 1, used[k], o);
 	}
-	free(base); free(var);
+	free(buf); free(used);
 	if (fclose(o)) return bh_set_error(BH_E_IO, "write failed: %s", fasta_out);
 	return BH_OK;
 }

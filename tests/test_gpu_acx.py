@@ -69,7 +69,7 @@ def test_device_built_accelerator_expansion_and_badlist(tmp_path, monkeypatch):
     rng = np.random.default_rng(5)
     acgt = np.frombuffer(b"ACGT", np.uint8)
     recs = []
-    for i in range(40):
+    for i in range(240):
         s = acgt[rng.integers(0, 4, size=int(rng.integers(300, 900)))].copy()
         if i % 4 == 1:
             m = rng.random(len(s)) < 0.03
@@ -87,7 +87,7 @@ def test_device_built_accelerator_expansion_and_badlist(tmp_path, monkeypatch):
             f.write(">r%d\n%s\n" % (i, s))
     for z in (1, 0):
         n, nbad, ndiff = _compare_built_with_loaded(None, 12, z, from_fasta=fa)
-        assert nbad >= 1 and n > 50000 and ndiff > 0
+        assert 1 <= nbad <= 4 and n > 50000 and ndiff > 0, (n, nbad, ndiff)
     monkeypatch.setenv("BHIP_MASK_SLICE", "30000")
     _compare_built_with_loaded(None, 12, 1, from_fasta=fa)
 

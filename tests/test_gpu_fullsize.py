@@ -25,6 +25,7 @@ def test_one_million_reads_properties(tmp_path_factory):
     a.read_len, a.n_base, a.n_variants, a.ref_len, a.variant_rate, a.id, a.K = 100, 3300, 30, 1400, 0.05, 0.97, 12
     work = os.environ.get("BURST_BENCH_DIR", "/tmp/burst_amd_bench")
     refs, edx, acx, done = bench.build_db(work, a)
+    bench.ensure_acx(edx, acx, 12)
     reads = os.path.join(work, "fullsize_reads.fa")
     n_reads = 1000000
     if not os.path.exists(reads):
@@ -81,16 +82,17 @@ def test_one_million_reads_properties(tmp_path_factory):
     dev.close()
 
 
-def _bench_db(read_len, thres, K=12):
+def _bench_db(read_len, thres, K=12, n_base=3300, n_variants=30):
     sys.path.insert(0, ROOT)
     import bench
 
     class A:
         pass
     a = A()
-    a.read_len, a.n_base, a.n_variants, a.ref_len, a.variant_rate, a.id, a.K = read_len, 3300, 30, 1400, 0.05, thres, K
+    a.read_len, a.n_base, a.n_variants, a.ref_len, a.variant_rate, a.id, a.K = read_len, n_base, n_variants, 1400, 0.05, thres, K
     work = os.environ.get("BURST_BENCH_DIR", "/tmp/burst_amd_bench")
     refs, edx, acx, done = bench.build_db(work, a)
+    bench.ensure_acx(edx, acx, K)
     return work, refs, edx, acx
 
 
@@ -186,3 +188,70 @@ def test_configs2_twelve_million_292bp_reads_allpaths():
         lines, out = _scale_diff(100000, dict(BURST_BENCH_DIR=work, SD_EDX=edx, SD_READS=reads, SD_MODES="BEST ALLPATHS", SD_IDS="0.97"))
         assert len(lines) == 2, out[-3000:]
         _check_diff_lines(lines, 100000)
+
+
+def test_bench_workload_db15_parity():
+    """The bench's own workload against the compiled reference: bench.py's database generator (low-redundancy: random base
+    sequences x 2 variants; here 800 000 bases = half the bench's default size, 2.2 Gbp -- the accelerator is built on the device
+    in two slices of clumps), DB15, 100-bp reads with 0-2 edits, -m BEST -i 0.98.  oracle/_ref/burst15 reads the .acx written from
+    the device-built tables; burst_hip builds its accelerator itself (-ad -k 15).  BEST must be identical line for line."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "burst15")):
+        pytest.skip("compiled reference not present")
+    work, refs, edx, acx = _bench_db(100, 0.98, K=15, n_base=800000, n_variants=2)
+    from burst_amd import host
+    reads = os.path.join(work, "parity15_reads_300k.fa")
+    if not os.path.exists(reads + ".done"):
+        host.synth_reads(refs, reads, 300000, 100, [0, 1, 2], rc=False, iupac=0.0, seed=42)
+        open(reads + ".done", "w").write("ok")
+    lines, out = _scale_diff(200000, dict(BURST_BENCH_DIR=work, SD_EDX=edx, SD_READS=reads, SD_MODES="BEST", SD_IDS="0.98", SD_REF=os.path.join(ROOT, "oracle", "_ref", "burst15"),
+                                          SD_HIP_ACCEL="-ad -k 15"))
+    assert len(lines) == 1 and "IDENTICAL" in lines[0], out[-3000:]
+    n_lines = int(re.search(r"(\d+) reference lines", lines[0]).group(1))
+    assert n_lines > 190000, lines[0]
+
+
+def test_configs4_shape_full_size():
+    """BASELINE configs[4]'s shape at a size one device call cycle covers: 2 M 320-bp reads with 1 % IUPAC codes, both strands (-fr),
+    -m FORAGE -i 0.95 (every placement within budget, burst.c:4224; ambiguous words burst.c:3232-3236), through the product's batch
+    scheduler.  Size-independent properties: every read's home placement is reported (a read carries <= 12 edits <= its budget of
+    16), every record within budget, the f32 identity of every record, positions inside the clump, records ordered by (query,
+    reference) without duplicates, both strands present; and the first 1 500 reads are diffed against the compiled reference
+    (FORAGE and BEST; FORAGE under the "every differing line explained" rule of _check_diff_lines)."""
+    work, refs, edx, acx = _bench_db(320, 0.95)
+    from burst_amd import host
+    n_reads = 2000000
+    reads = os.path.join(work, "cfg4_reads_2m_320_iupac_fr.fa")
+    if not os.path.exists(reads + ".done"):
+        host.synth_reads(refs, reads, n_reads, 320, [0, 2, 4, 8, 12], rc=True, iupac=0.01, seed=99)
+        open(reads + ".done", "w").write("ok")
+    db = host.Db.read(edx, acx)
+    qs = host.QuerySet(reads, 0.95, rc=True, accel=True, K=int(db.c.K))
+    assert qs.n_reads == n_reads and qs.n_entries == 2 * qs.n_uniq
+    dev = db.open_device(0)
+    qs.pin()
+    run = host.align_ranges(dev, qs, [(0, qs.n_uniq)], "FORAGE", 1 << 19)
+    h = run.hits
+    q = h["q"].astype(np.int64)
+    emac = host._view(qs.c.emac, qs.n_entries, np.uint16)
+    qoff = host._view(qs.c.qoff, qs.n_entries + 1, np.uint64).astype(np.int64)
+    six = q % qs.n_uniq                                     # entry -> unique query (forward entries first, then the reverse complements)
+    found = np.zeros(qs.n_uniq, bool)
+    found[six] = True
+    assert found.all(), "%d unique queries without a record" % (~found).sum()
+    assert (h["ed"] <= emac[q]).all()
+    assert (h["rc"] == (q >= qs.n_uniq)).all() and h["rc"].any() and not h["rc"].all()
+    ln = (qoff[q + 1] - qoff[q]).astype(np.float32)
+    want = (np.float32(1.0) - h["ed"].astype(np.float32) / (ln + h["gapQ"].astype(np.float32))).astype(np.float32)
+    assert want.tobytes() == h["score"].astype(np.float32).tobytes()
+    clump_len = host._view(db.c.clumpLen, db.c.numRclumps, np.uint32)
+    assert (h["refIx"] < db.c.totR).all()
+    assert (h["finalPos"] >= 1).all() and (h["finalPos"] <= clump_len[h["refIx"] >> 4]).all()
+    key = (q << 32) | h["refIx"].astype(np.int64)
+    assert (np.diff(key) > 0).all()                          # sorted by (query entry, reference), no duplicates
+    assert len(h) > qs.n_uniq                                # FORAGE: more than one placement per query on a database of families
+    run.close()
+    dev.close()
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "burst12")):
+        lines, out = _scale_diff(1500, dict(BURST_BENCH_DIR=work, SD_EDX=edx, SD_READS=reads, SD_MODES="FORAGE BEST", SD_IDS="0.95", SD_EXTRA="-fr"))
+        assert len(lines) == 2, out[-3000:]
+        _check_diff_lines(lines, 1500)

@@ -9,6 +9,7 @@ class A: pass
 a = A(); a.read_len, a.n_base, a.n_variants, a.ref_len, a.variant_rate, a.id, a.K = 100, 3300, 30, 1400, 0.05, 0.97, 12
 work = "/tmp/burst_amd_bench"
 refs, edx, acx, done = bench.build_db(work, a)
+bench.ensure_acx(edx, acx, 12)
 reads = os.path.join(work, "fullsize_reads.fa")
 if not os.path.exists(reads):
     host.synth_reads(refs, reads, 1000000, 100, [0, 1, 2, 3], rc=False, iupac=0.0, seed=4242)

@@ -15,12 +15,13 @@ IDS=${SD_IDS:-"0.97 0.98"}
 EXTRA=${SD_EXTRA:-}
 REFBIN=${SD_REF:-$ROOT/oracle/_ref/burst12}      # DB15 accelerators: SD_REF=oracle/_ref/burst15 SD_HIP_EXTRA="-k 15"
 HIPX=${SD_HIP_EXTRA:-}
+HIPACC=${SD_HIP_ACCEL:-"-a $ACX"}                # burst_hip without the file: SD_HIP_ACCEL="-ad -k 15" (accelerator built on the device)
 head -n $((2 * N)) $READS > $W/sd_reads.fa
 secs() { awk -v a=$1 -v b=$2 'BEGIN { printf "%.2f", b - a }'; }
 for MODE in ${SD_MODES:-BEST ALLPATHS}; do
   for ID in $IDS; do
     T0=$(date +%s.%N); $REFBIN -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_ref.b6 -m $MODE -i $ID $EXTRA -t $(nproc) --noprogress > $W/sd_ref.log 2>&1; T1=$(date +%s.%N)
-    $ROOT/burst_amd/burst_hip -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_hip.b6 -m $MODE -i $ID $EXTRA $HIPX > $W/sd_hip.log 2>&1; T2=$(date +%s.%N)
+    $ROOT/burst_amd/burst_hip -r $EDX $HIPACC -q $W/sd_reads.fa -o $W/sd_hip.b6 -m $MODE -i $ID $EXTRA $HIPX > $W/sd_hip.log 2>&1; T2=$(date +%s.%N)
     sort $W/sd_ref.b6 > $W/sd_ref.s; sort $W/sd_hip.b6 > $W/sd_hip.s
     NR=$(wc -l < $W/sd_ref.s); NH=$(wc -l < $W/sd_hip.s)
     if cmp -s $W/sd_ref.s $W/sd_hip.s; then R=IDENTICAL
@@ -31,12 +32,12 @@ for MODE in ${SD_MODES:-BEST ALLPATHS}; do
         QD=$(diff <(cut -f1 $W/sd_ref.s | uniq) <(cut -f1 $W/sd_hip.s | uniq) | wc -l)
         # every reference line must be one of the query's minimum-edit-distance placements (what -m ALLPATHS --no-dupe-hunt prints):
         # which of several equally voted ones is kept depends on the reference's hit order (burst.c:4763-4776)
-        $ROOT/burst_amd/burst_hip -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_nd.b6 -m ALLPATHS -i $ID $EXTRA $HIPX --no-dupe-hunt > /dev/null 2>&1
+        $ROOT/burst_amd/burst_hip -r $EDX $HIPACC -q $W/sd_reads.fa -o $W/sd_nd.b6 -m ALLPATHS -i $ID $EXTRA $HIPX --no-dupe-hunt > /dev/null 2>&1
         sort -u $W/sd_nd.b6 > $W/sd_nd.s
         MISSING=$(comm -23 $W/sd_ref.s $W/sd_nd.s | wc -l)
         R="$R (equally voted placements, decided by the reference's hit order); reference lines that are not a placement burst_hip computed: $MISSING; queries reported by only one program: $QD; line counts $NR / $NH"
       elif [ $MODE != BEST ]; then
-        $ROOT/burst_amd/burst_hip -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_nd.b6 -m $MODE -i $ID $EXTRA $HIPX --no-dupe-hunt > /dev/null 2>&1
+        $ROOT/burst_amd/burst_hip -r $EDX $HIPACC -q $W/sd_reads.fa -o $W/sd_nd.b6 -m $MODE -i $ID $EXTRA $HIPX --no-dupe-hunt > /dev/null 2>&1
         sort -u $W/sd_nd.b6 > $W/sd_nd.s
         MISSING=$(comm -23 $W/sd_ref.s $W/sd_nd.s | wc -l)
         QD=$(diff <(cut -f1 $W/sd_ref.s | uniq) <(cut -f1 $W/sd_hip.s | uniq) | wc -l)

@@ -5,7 +5,9 @@ import bench
 from burst_amd import host
 class A: pass
 a = A(); a.read_len = 100; a.n_base = 3300; a.n_variants = 30; a.ref_len = 1400; a.variant_rate = 0.05; a.id = 0.97
+a.K = 12
 refs, edx, acx, done = bench.build_db("/tmp/burst_amd_bench", a)
+bench.ensure_acx(edx, acx, 12)
 reads = "/tmp/burst_amd_bench/st_reads.fa"
 if not os.path.exists(reads):
     host.synth_reads(refs, reads, 1000000, 100, [0, 1, 2, 3], rc=False, iupac=0.0, seed=42)
