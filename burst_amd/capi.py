@@ -43,7 +43,7 @@ class BhipQuerySpan(C.Structure):
 
 EXPORTS = ["bhip_init", "bhip_stage_queries", "bhip_align_staged", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_set_option", "bhip_get_stats",
            "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version", "bhip_copy_hits_device", "bhip_sync_hits",
-           "bhip_comm_create", "bhip_comm_gather_hits", "bhip_comm_destroy", "bhip_acx_export", "bhip_reserve", "bhip_sort_queries", "bhip_stage_spans", "bhip_alloc_host", "bhip_free_host", "bhip_host_register", "bhip_host_unregister"]
+           "bhip_comm_create", "bhip_comm_unique_id", "bhip_comm_create_rank", "bhip_comm_allreduce_min", "bhip_comm_fetch_gathered", "bhip_comm_gather_hits", "bhip_comm_destroy", "bhip_acx_export", "bhip_reserve", "bhip_reserve_symbols", "bhip_sort_queries", "bhip_stage_spans", "bhip_alloc_host", "bhip_free_host", "bhip_host_register", "bhip_host_unregister"]
 
 
 class BurstHipError(RuntimeError):
@@ -90,6 +90,8 @@ def _load():
     lib.bhip_reserve.argtypes = [vp, u32, u32]
     lib.bhip_reserve.restype = i32
     lib.bhip_stage_spans.restype = i32
+    lib.bhip_reserve_symbols.argtypes = [vp, u32, u32, u64]
+    lib.bhip_reserve_symbols.restype = i32
     lib.bhip_alloc_host.argtypes = [u64]
     lib.bhip_alloc_host.restype = vp
     lib.bhip_free_host.argtypes = [vp]
@@ -98,6 +100,12 @@ def _load():
     lib.bhip_host_register.restype = i32
     lib.bhip_host_unregister.argtypes = [vp]
     lib.bhip_host_unregister.restype = i32
+    lib.bhip_comm_unique_id.argtypes = [vp]
+    lib.bhip_comm_unique_id.restype = i32
+    lib.bhip_comm_create_rank.argtypes = [i32, i32, i32, vp, C.POINTER(vp)]
+    lib.bhip_comm_create_rank.restype = i32
+    lib.bhip_comm_destroy.argtypes = [vp]
+    lib.bhip_comm_destroy.restype = None
     lib.bhip_acx_export.argtypes = [vp, vp, vp, vp, u64, C.POINTER(u64), vp, u32, C.POINTER(u32)]
     lib.bhip_acx_export.restype = i32
     return lib

@@ -326,14 +326,20 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 // Allocate, ahead of the first batch, what batches of up to n_entries entries of up to max_len symbols need (both staging slots,
 // the scratch of the alignment kernels, the record buffers): a batch scheduler calls it once so that no allocation -- each one
 // synchronises the device -- falls into its first batches.
-extern "C" int bhip_reserve(void *handle, uint32_t n_entries, uint32_t max_len) {
+extern "C" int bhip_reserve(void *handle, uint32_t n_entries, uint32_t max_len) { return bhip_reserve_symbols(handle, n_entries, max_len, 0); }
+// total_symbols > 0: the symbols of the largest batch that will be staged (sum of its entries' lengths).  Buffers that hold the
+// symbols themselves and the match profiles are then sized from it -- one 1 000-symbol read among millions of 100-symbol ones
+// must not make every buffer n_entries x max_len large -- while the fixed-stride tables keep their max_len stride.
+extern "C" int bhip_reserve_symbols(void *handle, uint32_t n_entries, uint32_t max_len, uint64_t total_symbols) {
 	Handle *h = (Handle *)handle;
 	if (!h) return fail(BHIP_E_ARG, "null handle");
 	if (!n_entries) return BHIP_OK;
 	if (!max_len || max_len > BHIP_MAX_QLEN) max_len = BHIP_MAX_QLEN;
 	HIPCHK(hipSetDevice(h->device));
 	int rc;
-	const size_t n = n_entries, nb = n * max_len, qw = (max_len + 7) / 8;
+	const size_t n = n_entries, nb = total_symbols ? (size_t)std::min<uint64_t>(total_symbols + 64, (uint64_t)n * max_len) : n * max_len, qw = (max_len + 7) / 8;
+	// profile words: an entry of len symbols has a vector of at most 2 x (len / 32 + 1) words (class rounding), 16 rows of them
+	const size_t peq_words = total_symbols ? std::min<size_t>(n * (size_t)kClasses[class_of_len(max_len)], 2 * (nb / 32 + n)) : n * (size_t)kClasses[class_of_len(max_len)];
 	for (StageSlot &S : h->slots) {
 		if ((rc = slot_init(&S))) return rc;
 		if ((rc = S.qcodes4.reserve(nb / 2 + 128)) || (rc = S.qcodes.reserve(nb + 128)) || (rc = S.qoff.reserve((n + 1) * 8)) || (rc = S.qemac.reserve((n + 1) * 2)) ||
@@ -351,8 +357,8 @@ extern "C" int bhip_reserve(void *handle, uint32_t n_entries, uint32_t max_len) 
 	if ((rc = L->cand.reserve(L->cand_cap * sizeof(uint2))) || (rc = L->raw.reserve(L->raw_cap * sizeof(BhipRawHit))) || (rc = L->wide.reserve(L->raw_cap * sizeof(uint32_t))) ||
 	    (rc = L->rs_lists.reserve(L->raw_cap * sizeof(uint32_t) * 10)) || (rc = L->scratch.reserve(L->scratch_cap * sizeof(uint32_t))) || (rc = L->wins.reserve(L->win_cap * sizeof(BhipWin))) ||
 	    (rc = L->tasks.reserve(L->task_cap * sizeof(uint2))) || (rc = L->tasks2.reserve(L->task_cap * sizeof(uint2))) || (rc = L->tasks2k.reserve(L->task_cap * sizeof(uint2))) ||
-	    (rc = L->wins2.reserve(L->win_cap * sizeof(BhipWin))) || (rc = L->peq.reserve(n * 16 * kClasses[cls] * 4)) || (rc = L->peqp.reserve(n * 16 * 6 * 4)) ||
-	    (rc = L->peq_alt.reserve(n * 16 * kClasses[cls] * 4)) || (rc = L->peqp_alt.reserve(n * 16 * 6 * 4)) ||
+	    (rc = L->wins2.reserve(L->win_cap * sizeof(BhipWin))) || (rc = L->peq.reserve(peq_words * 16 * 4)) || (rc = L->peqp.reserve(n * 16 * 6 * 4)) ||
+	    (rc = L->peq_alt.reserve(peq_words * 16 * 4)) || (rc = L->peqp_alt.reserve(n * 16 * 6 * 4)) ||
 	    (rc = L->fb_list.reserve(n * 4 + 16)) || (rc = L->ranges_c[cls].reserve(n * 16 * 8 + 16)) || (rc = L->hdr_c[cls].reserve(n * 8 + 16))) return rc;
 	if ((rc = h->best.reserve((n + 1) * 4)) || (rc = h->out.reserve(h->out_cap * sizeof(BhipHit))) || (rc = h->shared_ctr.reserve(sizeof(SharedCtr))) ||
 	    (rc = h->sort_idx.reserve(h->out_cap * 4)) || (rc = h->sort_keys.reserve((n + 1) * 4)) || (rc = h->sort_keys2.reserve((n + 1) * 4)) ||

@@ -1,9 +1,17 @@
-// burst_amd/csrc/bhip_comm.hip -- the one exchange step of the multi-GPU path (no reference counterpart: the reference is one
-// process with shared memory): unique queries are sharded across the GPUs of a node, every device aligns
-// its shard independently against its own copy of the database, and the hit records travel to rank 0 in ONE variable-length
-// gather over xGMI: ncclAllGather of the record counts + grouped ncclSend / ncclRecv of the 20-byte BhipHit records (RCCL has
-// no gatherv).  One host thread per device (ncclCommInitAll: all ranks in this process); every thread calls
-// bhip_comm_gather_hits with its own rank.
+// burst_amd/csrc/bhip_comm.hip -- the exchange steps of the multi-GPU path (no reference counterpart: the reference is one
+// process with shared memory).
+//   Query-sharded (the database replicated): every device aligns its range of unique queries independently and the hit records
+//   travel to rank 0 in ONE variable-length gather over xGMI: ncclAllGather of the record counts + grouped ncclSend / ncclRecv of
+//   the 20-byte BhipHit records (RCCL has no gatherv; 7 peers -> 7 different links into rank 0).
+//   Database-sharded (databases beyond one device): every device aligns ALL queries against its range of clumps; the hits of a
+//   query are the references at its GLOBAL minimum edit distance (burst.c:4217-4277), so the ranks combine one byte per unique
+//   query with ncclAllReduce(MIN) before the same gather.
+// The ranks are either the threads of one process (bhip_comm_create: ncclCommInitAll) or one process each (bhip_comm_unique_id
+// on one rank, the 128 bytes handed to the others by whatever launched them, bhip_comm_create_rank: ncclCommInitRank); every
+// rank's thread calls the collectives with its own rank.
+// Failures: everything a rank can fail on locally (allocations, copies) happens BEFORE its first collective of a call and is
+// exchanged with the counts, so that all ranks leave together with an error instead of one rank returning and the others
+// waiting for it; nothing returns between ncclGroupStart and ncclGroupEnd; a failed collective aborts the communicator.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
@@ -13,50 +21,108 @@
 #include <vector>
 #include "burst_hip.h"
 
-extern "C" const char *bhip_last_error(void);
-int bhip_fail_msg(int code, const char *fmt, ...);      // bhip_api.hip: sets the calling thread's error text
+int bhip_fail_msg(int code, const char *fmt, ...);      // bhip_init.hip: sets the calling thread's error text
 
-struct Comm {
-	int n = 0;
-	std::vector<int> dev;
-	std::vector<ncclComm_t> comm;
-	std::vector<hipStream_t> stream;
-	std::vector<void *> d_send, d_counts;       // per rank: send buffer (grow-only) and the gathered counts
-	std::vector<size_t> send_cap;
-	void *d_recv = nullptr; size_t recv_cap = 0; // rank 0
+struct Peer {                                      // one rank that lives in this process
+	int rank = 0, dev = 0;
+	ncclComm_t comm = nullptr;
+	hipStream_t stream = nullptr;
+	void *d_send = nullptr; size_t send_cap = 0;   // records out / bytes of the reduction
+	void *d_counts = nullptr;                      // 2 x (n + 1) x u64: gathered counts, gathered flags
+	void *d_recv = nullptr; size_t recv_cap = 0;   // rank 0
+	uint64_t recv_total = 0;                       // records of the last gather, resident in d_recv
+	bool broken = false;
 };
-#define CCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return bhip_fail_msg(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
-#define NCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return bhip_fail_msg(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, ncclGetErrorString(r_)); } while (0)
+struct Comm { int n = 0; std::vector<Peer> local; };
+static const unsigned long long FAILED = ~0ull;
+
+static Peer *peer_of(Comm *C, int rank) {
+	if (!C) return nullptr;
+	for (Peer &p : C->local) if (p.rank == rank) return &p;
+	return nullptr;
+}
+static bool grow(void **p, size_t *cap, size_t bytes) {
+	if (bytes <= *cap) return true;
+	if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+	const size_t want = bytes + bytes / 8 + 4096;
+	if (hipMalloc(p, want) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
+	*cap = want;
+	return true;
+}
+static int peer_init(Peer &p, int n) {
+	if (hipSetDevice(p.dev) != hipSuccess || hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipMalloc(&p.d_counts, sizeof(unsigned long long) * 2 * (size_t)(n + 1)) != hipSuccess) { (void)hipGetLastError(); return -1; }
+	return 0;
+}
+static void abort_peer(Peer &p) { if (p.comm && !p.broken) { (void)ncclCommAbort(p.comm); p.comm = nullptr; } p.broken = true; }
+
+extern "C" void bhip_comm_destroy(void *comm) {
+	Comm *C = (Comm *)comm;
+	if (!C) return;
+	for (Peer &p : C->local) {
+		(void)hipSetDevice(p.dev);
+		if (p.stream) { (void)hipStreamSynchronize(p.stream); (void)hipStreamDestroy(p.stream); }
+		if (p.d_send) (void)hipFree(p.d_send);
+		if (p.d_counts) (void)hipFree(p.d_counts);
+		if (p.d_recv) (void)hipFree(p.d_recv);
+		if (p.comm) (void)ncclCommDestroy(p.comm);
+	}
+	(void)hipGetLastError();
+	delete C;
+}
 
 extern "C" int bhip_comm_create(int n_ranks, const int *devices, void **comm_out) {
 	if (!comm_out || n_ranks < 1 || !devices) return bhip_fail_msg(BHIP_E_ARG, "bad communicator arguments");
 	*comm_out = nullptr;
 	Comm *C = new Comm();
-	C->n = n_ranks; C->dev.assign(devices, devices + n_ranks); C->comm.resize(n_ranks); C->stream.assign(n_ranks, nullptr);
-	C->d_send.assign(n_ranks, nullptr); C->d_counts.assign(n_ranks, nullptr); C->send_cap.assign(n_ranks, 0);
-	ncclResult_t r = ncclCommInitAll(C->comm.data(), n_ranks, C->dev.data());
+	C->n = n_ranks; C->local.resize((size_t)n_ranks);
+	std::vector<ncclComm_t> cs((size_t)n_ranks, nullptr);
+	ncclResult_t r = ncclCommInitAll(cs.data(), n_ranks, devices);
 	if (r != ncclSuccess) { delete C; return bhip_fail_msg(BHIP_E_DEVICE, "ncclCommInitAll(%d ranks): %s", n_ranks, ncclGetErrorString(r)); }
-	for (int k = 0; k < n_ranks; ++k) {
-		CCHK(hipSetDevice(devices[k]));
-		CCHK(hipStreamCreateWithFlags(&C->stream[k], hipStreamNonBlocking));
-		CCHK(hipMalloc(&C->d_counts[k], sizeof(unsigned long long) * (size_t)(n_ranks + 1)));
-	}
+	for (int k = 0; k < n_ranks; ++k) { C->local[k].rank = k; C->local[k].dev = devices[k]; C->local[k].comm = cs[k]; }
+	for (int k = 0; k < n_ranks; ++k) if (peer_init(C->local[k], n_ranks)) { bhip_comm_destroy(C); return bhip_fail_msg(BHIP_E_DEVICE, "communicator set-up failed on device %d", devices[k]); }
 	*comm_out = C;
 	return BHIP_OK;
 }
 
-extern "C" void bhip_comm_destroy(void *comm) {
-	Comm *C = (Comm *)comm;
-	if (!C) return;
-	for (int k = 0; k < C->n; ++k) {
-		(void)hipSetDevice(C->dev[k]);
-		if (C->stream[k]) { (void)hipStreamSynchronize(C->stream[k]); (void)hipStreamDestroy(C->stream[k]); }
-		if (C->d_send[k]) (void)hipFree(C->d_send[k]);
-		if (C->d_counts[k]) (void)hipFree(C->d_counts[k]);
-		if (k == 0 && C->d_recv) (void)hipFree(C->d_recv);
-		(void)ncclCommDestroy(C->comm[k]);
-	}
-	delete C;
+extern "C" int bhip_comm_unique_id(void *id128) {
+	if (!id128) return bhip_fail_msg(BHIP_E_ARG, "null id");
+	static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+	ncclUniqueId id;
+	ncclResult_t r = ncclGetUniqueId(&id);
+	if (r != ncclSuccess) return bhip_fail_msg(BHIP_E_DEVICE, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+	memcpy(id128, &id, sizeof id);
+	return BHIP_OK;
+}
+
+extern "C" int bhip_comm_create_rank(int n_ranks, int rank, int device, const void *id128, void **comm_out) {
+	if (!comm_out || n_ranks < 1 || rank < 0 || rank >= n_ranks || !id128) return bhip_fail_msg(BHIP_E_ARG, "bad communicator arguments");
+	*comm_out = nullptr;
+	if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return bhip_fail_msg(BHIP_E_DEVICE, "device %d not present", device); }
+	ncclUniqueId id;
+	memcpy(&id, id128, sizeof id);
+	Comm *C = new Comm();
+	C->n = n_ranks; C->local.resize(1);
+	C->local[0].rank = rank; C->local[0].dev = device;
+	ncclResult_t r = ncclCommInitRank(&C->local[0].comm, n_ranks, id, rank);
+	if (r != ncclSuccess) { C->local[0].comm = nullptr; bhip_comm_destroy(C); return bhip_fail_msg(BHIP_E_DEVICE, "ncclCommInitRank(rank %d of %d): %s", rank, n_ranks, ncclGetErrorString(r)); }
+	if (peer_init(C->local[0], n_ranks)) { bhip_comm_destroy(C); return bhip_fail_msg(BHIP_E_DEVICE, "communicator set-up failed on device %d", device); }
+	*comm_out = C;
+	return BHIP_OK;
+}
+
+// every rank contributes one 64-bit word (FAILED = "I cannot go on"); all[n] is the same on every rank afterwards.
+// which = 0 / 1: the two halves of d_counts (counts, flags).
+static int exchange_word(Comm *C, Peer *P, int which, unsigned long long mine, std::vector<unsigned long long> &all) {
+	unsigned long long *dc = (unsigned long long *)P->d_counts + (size_t)which * (size_t)(C->n + 1);
+	all.assign((size_t)C->n, 0);
+	if (P->broken) return bhip_fail_msg(BHIP_E_DEVICE, "communicator was aborted by an earlier failure");
+	bool ok = hipMemcpyAsync(dc + C->n, &mine, sizeof mine, hipMemcpyHostToDevice, P->stream) == hipSuccess;
+	ncclResult_t r = ncclAllGather(dc + C->n, dc, 1, ncclUint64, P->comm, P->stream);
+	ok = ok && r == ncclSuccess && hipMemcpyAsync(all.data(), dc, sizeof(unsigned long long) * (size_t)C->n, hipMemcpyDeviceToHost, P->stream) == hipSuccess
+	     && hipStreamSynchronize(P->stream) == hipSuccess;
+	if (!ok) { (void)hipGetLastError(); abort_peer(*P); return bhip_fail_msg(BHIP_E_DEVICE, "count exchange failed on rank %d%s%s", P->rank, r != ncclSuccess ? ": " : "", r != ncclSuccess ? ncclGetErrorString(r) : ""); }
+	return BHIP_OK;
 }
 
 // Called by the host thread of every rank (all n_ranks calls must be in flight together).  hits / n: the rank's records in
@@ -64,55 +130,96 @@ extern "C" void bhip_comm_destroy(void *comm) {
 // per-rank numbers on every rank.  BHIP_E_CAPACITY when out is too small (*n_total is what is needed; nothing is copied).
 extern "C" int bhip_comm_gather_hits(void *comm, int rank, const BhipHit *hits, uint64_t n, BhipHit *out, uint64_t cap, uint64_t *n_total, uint64_t *counts) {
 	Comm *C = (Comm *)comm;
-	if (!C || rank < 0 || rank >= C->n || !n_total) return bhip_fail_msg(BHIP_E_ARG, "bad gather arguments");
-	CCHK(hipSetDevice(C->dev[rank]));
-	hipStream_t st = C->stream[rank];
+	Peer *P = peer_of(C, rank);
+	if (!P || !n_total) return bhip_fail_msg(BHIP_E_ARG, "bad gather arguments");
+	*n_total = 0;
+	// 0. local preparation: send buffer + copy (a failure is announced with the count)
+	bool ok = hipSetDevice(P->dev) == hipSuccess;
 	const size_t bytes = (size_t)n * sizeof(BhipHit);
-	if (bytes > C->send_cap[rank]) {
-		if (C->d_send[rank]) CCHK(hipFree(C->d_send[rank]));
-		C->send_cap[rank] = bytes + bytes / 8 + 4096;
-		CCHK(hipMalloc(&C->d_send[rank], C->send_cap[rank]));
-	}
-	if (bytes) CCHK(hipMemcpyAsync(C->d_send[rank], hits, bytes, hipMemcpyHostToDevice, st));
+	ok = ok && (!bytes || hits) && grow(&P->d_send, &P->send_cap, bytes ? bytes : 1);
+	if (ok && bytes) ok = hipMemcpyAsync(P->d_send, hits, bytes, hipMemcpyHostToDevice, P->stream) == hipSuccess;
+	if (!ok) (void)hipGetLastError();
 	// 1. everybody learns everybody's count
-	unsigned long long *dc = (unsigned long long *)C->d_counts[rank];
-	unsigned long long mine = n;
-	CCHK(hipMemcpyAsync(dc + C->n, &mine, sizeof mine, hipMemcpyHostToDevice, st));
-	NCHK(ncclAllGather(dc + C->n, dc, 1, ncclUint64, C->comm[rank], st));
-	std::vector<unsigned long long> hc((size_t)C->n);
-	CCHK(hipMemcpyAsync(hc.data(), dc, sizeof(unsigned long long) * (size_t)C->n, hipMemcpyDeviceToHost, st));
-	CCHK(hipStreamSynchronize(st));
+	std::vector<unsigned long long> hc;
+	int rc = exchange_word(C, P, 0, ok ? (unsigned long long)n : FAILED, hc);
+	if (rc) return rc;
+	for (int k = 0; k < C->n; ++k) if (hc[k] == FAILED) return bhip_fail_msg(BHIP_E_DEVICE, "rank %d could not stage its records for the gather (device memory?)", k);
 	uint64_t total = 0;
 	for (int k = 0; k < C->n; ++k) { if (counts) counts[k] = hc[k]; total += hc[k]; }
 	*n_total = total;
+	// 2. rank 0 makes room, and says so (the capacity decision is rank 0's alone, but every rank must take the same path through
+	// the collectives: rank 0 receives into its device buffer in any case, only the copy to the caller's memory depends on `cap`)
 	const bool fits = total <= cap || rank != 0;
-	// (the capacity decision is rank 0's alone, but every rank must take the same path through the collectives: rank 0 receives
-	// into its device buffer in any case and only the copy to the caller's memory is skipped when it does not fit)
-	if (rank == 0) {
-		const size_t need = (size_t)total * sizeof(BhipHit);
-		if (need > C->recv_cap) {
-			if (C->d_recv) CCHK(hipFree(C->d_recv));
-			C->recv_cap = need + need / 8 + 4096;
-			CCHK(hipMalloc(&C->d_recv, C->recv_cap));
-		}
+	bool ready = true;
+	if (rank == 0) ready = grow(&P->d_recv, &P->recv_cap, total ? (size_t)total * sizeof(BhipHit) : 1) && (out || !total || !fits);
+	std::vector<unsigned long long> flags;
+	if ((rc = exchange_word(C, P, 1, ready ? 1ull : FAILED, flags))) return rc;
+	if (flags[0] == FAILED) return bhip_fail_msg(BHIP_E_DEVICE, "rank 0 has no room for the %llu gathered records", (unsigned long long)total);
+	// 3. the records: grouped point-to-point
+	ncclResult_t r = ncclGroupStart(), r2 = ncclSuccess;
+	hipError_t he = hipSuccess;
+	if (r == ncclSuccess) {
+		if (rank == 0) {
+			size_t off = 0;
+			for (int k = 0; k < C->n; ++k) {
+				const size_t b = (size_t)hc[k] * sizeof(BhipHit);
+				if (k == 0) { if (b && he == hipSuccess) he = hipMemcpyAsync((char *)P->d_recv + off, P->d_send, b, hipMemcpyDeviceToDevice, P->stream); }
+				else if (b && r2 == ncclSuccess) r2 = ncclRecv((char *)P->d_recv + off, b, ncclUint8, k, P->comm, P->stream);
+				off += b;
+			}
+		} else if (bytes) r2 = ncclSend(P->d_send, bytes, ncclUint8, 0, P->comm, P->stream);
+		r = ncclGroupEnd();
 	}
-	// 2. the records: grouped point-to-point, 7 peers -> 7 different xGMI links into rank 0
-	NCHK(ncclGroupStart());
-	if (rank == 0) {
-		size_t off = 0;
-		for (int k = 0; k < C->n; ++k) {
-			const size_t b = (size_t)hc[k] * sizeof(BhipHit);
-			if (k == 0) { if (b) CCHK(hipMemcpyAsync((char *)C->d_recv + off, C->d_send[0], b, hipMemcpyDeviceToDevice, st)); }
-			else if (b) NCHK(ncclRecv((char *)C->d_recv + off, b, ncclUint8, k, C->comm[0], st));
-			off += b;
-		}
-	} else if (bytes) NCHK(ncclSend(C->d_send[rank], bytes, ncclUint8, 0, C->comm[rank], st));
-	NCHK(ncclGroupEnd());
-	if (rank == 0 && fits && total) {
-		if (!out) return bhip_fail_msg(BHIP_E_ARG, "null output");
-		CCHK(hipMemcpyAsync(out, C->d_recv, (size_t)total * sizeof(BhipHit), hipMemcpyDeviceToHost, st));
+	if (r == ncclSuccess && r2 == ncclSuccess && he == hipSuccess && rank == 0 && fits && total)
+		he = hipMemcpyAsync(out, P->d_recv, (size_t)total * sizeof(BhipHit), hipMemcpyDeviceToHost, P->stream);
+	if (he == hipSuccess) he = hipStreamSynchronize(P->stream);
+	if (r != ncclSuccess || r2 != ncclSuccess || he != hipSuccess) {
+		(void)hipGetLastError(); abort_peer(*P);
+		return bhip_fail_msg(BHIP_E_DEVICE, "record gather failed on rank %d: %s", rank, r != ncclSuccess ? ncclGetErrorString(r) : r2 != ncclSuccess ? ncclGetErrorString(r2) : hipGetErrorString(he));
 	}
-	CCHK(hipStreamSynchronize(st));
+	if (rank == 0) P->recv_total = total;
 	if (!fits) return bhip_fail_msg(BHIP_E_CAPACITY, "record buffer holds %llu records, %llu needed", (unsigned long long)cap, (unsigned long long)total);
+	return BHIP_OK;
+}
+
+// rank 0, after a gather that ended with BHIP_E_CAPACITY: the gathered records are still on its device; this copies them into a
+// buffer that is large enough.  No collective -- the other ranks are not involved.
+extern "C" int bhip_comm_fetch_gathered(void *comm, BhipHit *out, uint64_t cap, uint64_t *n_total) {
+	Comm *C = (Comm *)comm;
+	Peer *P = peer_of(C, 0);
+	if (!P || !n_total) return bhip_fail_msg(BHIP_E_ARG, "rank 0 does not live in this process");
+	*n_total = P->recv_total;
+	if (P->recv_total > cap) return bhip_fail_msg(BHIP_E_CAPACITY, "record buffer holds %llu records, %llu needed", (unsigned long long)cap, (unsigned long long)P->recv_total);
+	if (!P->recv_total) return BHIP_OK;
+	if (!out) return bhip_fail_msg(BHIP_E_ARG, "null output");
+	if (hipSetDevice(P->dev) != hipSuccess || hipMemcpyAsync(out, P->d_recv, (size_t)P->recv_total * sizeof(BhipHit), hipMemcpyDeviceToHost, P->stream) != hipSuccess ||
+	    hipStreamSynchronize(P->stream) != hipSuccess) { (void)hipGetLastError(); return bhip_fail_msg(BHIP_E_DEVICE, "copy of the gathered records failed"); }
+	return BHIP_OK;
+}
+
+// element-wise minimum over the ranks of n bytes of host memory, in place (database-sharded mode: one byte per unique query =
+// the smallest edit distance any reference of the rank's clump range reaches, 255 = none)
+extern "C" int bhip_comm_allreduce_min(void *comm, int rank, uint8_t *buf, uint64_t n) {
+	Comm *C = (Comm *)comm;
+	Peer *P = peer_of(C, rank);
+	if (!P || (n && !buf)) return bhip_fail_msg(BHIP_E_ARG, "bad reduction arguments");
+	bool ok = hipSetDevice(P->dev) == hipSuccess && grow(&P->d_send, &P->send_cap, n ? n : 1);
+	if (ok && n) ok = hipMemcpyAsync(P->d_send, buf, n, hipMemcpyHostToDevice, P->stream) == hipSuccess;
+	if (!ok) (void)hipGetLastError();
+	std::vector<unsigned long long> all;
+	int rc = exchange_word(C, P, 0, ok ? (unsigned long long)n : FAILED, all);
+	if (rc) return rc;
+	for (int k = 0; k < C->n; ++k) {
+		if (all[k] == FAILED) return bhip_fail_msg(BHIP_E_DEVICE, "rank %d could not stage its minima for the reduction", k);
+		if (all[k] != n) return bhip_fail_msg(BHIP_E_ARG, "ranks disagree on the number of queries (%llu on rank %d, %llu on rank %d)", (unsigned long long)all[k], k, (unsigned long long)n, rank);
+	}
+	if (!n) return BHIP_OK;
+	ncclResult_t r = ncclAllReduce(P->d_send, P->d_send, n, ncclUint8, ncclMin, P->comm, P->stream);
+	hipError_t he = r == ncclSuccess ? hipMemcpyAsync(buf, P->d_send, n, hipMemcpyDeviceToHost, P->stream) : hipSuccess;
+	if (he == hipSuccess) he = hipStreamSynchronize(P->stream);
+	if (r != ncclSuccess || he != hipSuccess) {
+		(void)hipGetLastError(); abort_peer(*P);
+		return bhip_fail_msg(BHIP_E_DEVICE, "minimum reduction failed on rank %d: %s", rank, r != ncclSuccess ? ncclGetErrorString(r) : hipGetErrorString(he));
+	}
 	return BHIP_OK;
 }

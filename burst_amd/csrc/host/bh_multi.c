@@ -1,0 +1,172 @@
+/* bh_multi.c -- the multi-GPU search of a node (no reference counterpart: the reference is one process), shared by
+ * the burst_hip command line (ranks = threads of one process, one device handle each) and bench.py (one process per GPU).
+ *
+ *   query-sharded   the database replicated on every device; rank r aligns its ranges of unique queries (a query and its reverse
+ *                   complement stay together: they share the running minimum, burst.c:277-280, 4218); ONE exchange: the gather of
+ *                   the 20-byte records to rank 0 (bhip_comm_gather_hits: RCCL over xGMI, or -- all ranks in one process --
+ *                   concatenation in host memory).
+ *   database-sharded  for databases beyond one device: rank r holds the clumps [c0, c1) (bh_clump_shard: about the same number of
+ *                   reference columns each) and aligns ALL queries against them.  What the reference keeps per query are the
+ *                   references at the query's minimum edit distance over the WHOLE database (Sb->ed, burst.c:4217-4277), so the
+ *                   ranks combine one byte per unique query (bhip_comm_allreduce_min = ncclAllReduce MIN, or a host loop), drop
+ *                   what lies above it (not in FORAGE, which keeps everything within budget, burst.c:4224), and gather as before;
+ *                   rank 0 puts the records in (query, reference) order: the set a single device holding everything produces.
+ */
+#include "burst_host.h"
+#include <stdlib.h>
+#include <string.h>
+#include <omp.h>
+
+void bh_clump_shard(const BhDb *db, int n_ranks, int rank, uint32_t *c0, uint32_t *c1) {
+	uint64_t total = 0;
+	for (uint32_t c = 0; c < db->numRclumps; ++c) total += db->clumpLen[c];
+	/* cut k = first clump at which the running sum reaches total * k / n */
+	uint32_t cut[2] = {0, db->numRclumps};
+	uint64_t run = 0; uint32_t c = 0;
+	for (int k = 0; k < 2; ++k) {
+		const int r = rank + k;
+		if (r <= 0) { cut[k] = 0; continue; }
+		if (r >= n_ranks) { cut[k] = db->numRclumps; continue; }
+		const double want = (double)total * (double)r / (double)n_ranks;
+		while (c < db->numRclumps && (double)(run + db->clumpLen[c]) < want) run += db->clumpLen[c++];
+		cut[k] = c;
+	}
+	*c0 = cut[0]; *c1 = cut[1] < cut[0] ? cut[0] : cut[1];
+}
+
+/* smallest edit distance per unique query among a rank's records (255 = none) */
+static void shard_minima(const BhQueries *Q, const BhRun *run, uint8_t *best) {
+	memset(best, 255, Q->numUniq);
+	for (uint64_t i = 0; i < run->nHits; ++i) {
+		const uint32_t q = run->hits[i].q, s = q < Q->numUniq ? q : q - (uint32_t)Q->numUniq;
+		if (run->hits[i].ed < best[s]) best[s] = run->hits[i].ed;
+	}
+}
+static void shard_filter(const BhQueries *Q, BhRun *run, const uint8_t *best) {
+	uint64_t k = 0;
+	for (uint64_t i = 0; i < run->nHits; ++i) {
+		const uint32_t q = run->hits[i].q, s = q < Q->numUniq ? q : q - (uint32_t)Q->numUniq;
+		if (run->hits[i].ed == best[s]) run->hits[k++] = run->hits[i];
+	}
+	run->nHits = k;
+}
+/* records gathered in rank order -> (query entry, reference) order: a stable counting sort by entry (inside an entry the ranks'
+ * clump ranges ascend, and so do the references) */
+static int shard_order(BhRun *all, uint64_t n_entries) {
+	if (all->nHits < 2) return BH_OK;
+	uint64_t *pos = calloc(n_entries + 1, sizeof(*pos));
+	BhipHit *tmp = malloc(all->nHits * sizeof(*tmp));
+	if (!pos || !tmp) { free(pos); free(tmp); return bh_set_error(BH_E_OOM, "OOM:shard_order"); }
+	for (uint64_t i = 0; i < all->nHits; ++i) ++pos[(uint64_t)all->hits[i].q + 1];
+	for (uint64_t e = 0; e < n_entries; ++e) pos[e + 1] += pos[e];
+	for (uint64_t i = 0; i < all->nHits; ++i) tmp[pos[all->hits[i].q]++] = all->hits[i];
+	memcpy(all->hits, tmp, all->nHits * sizeof(*tmp));
+	free(pos); free(tmp);
+	return BH_OK;
+}
+
+int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const BhQueries *Q, BhMode mode, uint64_t batch, int shard_db, BhRun *all, uint64_t *counts) {
+	if (n_local < 1 || n_local > n_ranks || n_ranks > BH_MAX_RANKS) return bh_set_error(BH_E_USAGE, "bad rank layout (%d local of %d)", n_local, n_ranks);
+	if (!comm && n_local != n_ranks) return bh_set_error(BH_E_USAGE, "without a communicator every rank must live in this process");
+	int rcs[BH_MAX_RANKS]; char errs[BH_MAX_RANKS][512];
+	uint8_t *best[BH_MAX_RANKS];
+	for (int i = 0; i < n_local; ++i) { rcs[i] = BH_E_INTERNAL; snprintf(errs[i], sizeof errs[i], "rank %d never ran (OpenMP gave the team fewer than %d threads)", R[i].rank, n_local); best[i] = NULL; }
+	const int reduce = shard_db && mode != BH_FORAGE && n_ranks > 1;
+	/* one host thread per local rank; the runtime must grant all of them -- a missing rank would leave the others waiting in the
+	 * collectives -- so dynamic team sizes are switched off and the team is checked before anything is enqueued */
+	const int dyn = omp_get_dynamic();
+	omp_set_dynamic(0);
+	int team_ok = 1;
+	#pragma omp parallel num_threads(n_local)
+	{
+		#pragma omp single
+		team_ok = omp_get_num_threads() == n_local;
+	}
+	if (!team_ok) { omp_set_dynamic(dyn); return bh_set_error(BH_E_INTERNAL, "OpenMP does not grant %d threads (OMP_THREAD_LIMIT?): one host thread per GPU is required", n_local); }
+	/* 1. every rank aligns its share */
+	#pragma omp parallel num_threads(n_local)
+	{
+		const int i = omp_get_thread_num();
+		BhMultiRank *r = &R[i];
+		rcs[i] = bh_align_ranges_reuse(r->hh, Q, r->r0, r->r1, r->n_ranges, mode, batch, &r->run);
+		if (rcs[i]) snprintf(errs[i], sizeof errs[i], "%s", bh_last_error());
+		else if (shard_db) {
+			for (uint64_t k = 0; k < r->run.nHits; ++k) r->run.hits[k].refIx += 16u * r->c0;
+			if (reduce) {
+				best[i] = malloc(Q->numUniq + 1);
+				if (!best[i]) { rcs[i] = BH_E_OOM; snprintf(errs[i], sizeof errs[i], "OOM:minima"); }
+				else shard_minima(Q, &r->run, best[i]);
+			}
+		}
+	}
+	/* (a rank that failed still has to walk through the collectives its peers are in: it takes part with nothing) */
+	/* 2. database-sharded: the per-query minimum over all ranks */
+	if (reduce) {
+		if (comm) {
+			#pragma omp parallel num_threads(n_local)
+			{
+				const int i = omp_get_thread_num();
+				uint8_t *b = best[i];
+				uint8_t *tmp = NULL;
+				if (!b) { tmp = malloc(Q->numUniq + 1); if (tmp) memset(tmp, 255, Q->numUniq); b = tmp; }
+				const int rc = b ? bhip_comm_allreduce_min(comm, R[i].rank, b, Q->numUniq) : BHIP_E_DEVICE;
+				if (rc && !rcs[i]) { rcs[i] = BH_E_DEVICE; snprintf(errs[i], sizeof errs[i], "libburst_hip: %s", bhip_last_error()); }
+				free(tmp);
+			}
+		} else {
+			for (int i = 1; i < n_local; ++i) if (best[0] && best[i]) for (uint64_t s = 0; s < Q->numUniq; ++s) if (best[i][s] < best[0][s]) best[0][s] = best[i][s];
+			for (int i = 1; i < n_local; ++i) if (best[0] && best[i]) memcpy(best[i], best[0], Q->numUniq);
+		}
+		for (int i = 0; i < n_local; ++i) if (!rcs[i]) shard_filter(Q, &R[i].run, best[i]);
+	}
+	for (int i = 0; i < n_local; ++i) free(best[i]);
+	/* 3. the records to rank 0 */
+	int i0 = -1;
+	for (int i = 0; i < n_local; ++i) if (R[i].rank == 0) i0 = i;
+	uint64_t tot_local = 0;
+	for (int i = 0; i < n_local; ++i) tot_local += rcs[i] ? 0 : R[i].run.nHits;
+	int rc = BH_OK;
+	if (comm) {
+		/* rank 0's buffer is sized from its own share; when the gathered total does not fit (BHIP_E_CAPACITY) the records stay on
+		 * rank 0's device and are fetched into a larger buffer without another collective */
+		if (i0 >= 0 && bh_run_reserve(all, tot_local * (uint64_t)(n_ranks > n_local ? n_ranks / n_local : 1) + (tot_local >> 2) + (1u << 16))) {
+			for (int i = 0; i < n_local; ++i) if (!rcs[i]) { rcs[i] = BH_E_OOM; snprintf(errs[i], sizeof errs[i], "OOM:hits"); }
+		}
+		int again = 0; uint64_t need = 0;
+		#pragma omp parallel num_threads(n_local)
+		{
+			const int i = omp_get_thread_num();
+			uint64_t n_total = 0;
+			const int g = bhip_comm_gather_hits(comm, R[i].rank, rcs[i] ? NULL : R[i].run.hits, rcs[i] ? 0 : R[i].run.nHits, i == i0 ? all->hits : NULL,
+			                                    i == i0 ? all->capHits : 0, &n_total, i == i0 ? counts : NULL);
+			if (i == i0) need = n_total;
+			if (g == BHIP_E_CAPACITY && i == i0) again = 1;
+			else if (g && g != BHIP_E_CAPACITY && !rcs[i]) { rcs[i] = BH_E_DEVICE; snprintf(errs[i], sizeof errs[i], "libburst_hip: %s", bhip_last_error()); }
+		}
+		if (i0 >= 0 && again && !rcs[i0]) {
+			if (bh_run_reserve(all, need + 1)) { rcs[i0] = BH_E_OOM; snprintf(errs[i0], sizeof errs[i0], "OOM:hits"); }
+			else if (bhip_comm_fetch_gathered(comm, all->hits, all->capHits, &need)) { rcs[i0] = BH_E_DEVICE; snprintf(errs[i0], sizeof errs[i0], "libburst_hip: %s", bhip_last_error()); }
+		}
+		if (i0 >= 0) all->nHits = need;
+	} else {
+		if (bh_run_reserve(all, tot_local + 1)) rc = bh_set_error(BH_E_OOM, "OOM:hits");
+		else {
+			uint64_t o = 0;
+			for (int i = 0; i < n_local; ++i) {      /* local ranks are listed in rank order */
+				const uint64_t n = rcs[i] ? 0 : R[i].run.nHits;
+				if (n) memcpy(all->hits + o, R[i].run.hits, n * sizeof(BhipHit));
+				if (counts) counts[R[i].rank] = n;
+				o += n;
+			}
+			all->nHits = o;
+		}
+	}
+	omp_set_dynamic(dyn);
+	for (int i = 0; i < n_local; ++i) if (rcs[i]) return bh_set_error(rcs[i], "%s", errs[i]);
+	if (rc) return rc;
+	if (i0 >= 0) {
+		for (int i = 0; i < n_local; ++i) { all->nBatches += R[i].run.nBatches; all->secAlign += i == i0 ? R[i].run.secAlign : 0; }
+		if (shard_db && n_ranks > 1) rc = shard_order(all, Q->numEntries);
+	}
+	return rc;
+}

@@ -125,6 +125,23 @@ int  bh_align_ranges(void *hip_handle, const BhQueries *q, const uint64_t *u0, c
 int  bh_align_ranges_reuse(void *hip_handle, const BhQueries *q, const uint64_t *u0, const uint64_t *u1, uint32_t n_ranges, BhMode mode, uint64_t batch_uniq, BhRun *run);
 int  bh_run_reserve(BhRun *run, uint64_t cap_records);
 void bh_run_free(BhRun *run);
+/* ---- multi-GPU search (bh_multi.c) ---- */
+#define BH_MAX_RANKS 16
+typedef struct BhMultiRank {
+	int rank;                     /* rank of the node-wide job */
+	void *hh;                     /* its device handle */
+	const uint64_t *r0, *r1; uint32_t n_ranges;   /* ranges of unique queries it aligns (database-sharded: normally one range, everything) */
+	uint32_t c0;                  /* database-sharded: first clump of its slice (added to the records' reference numbers) */
+	BhRun run;                    /* its own records (the page-locked buffer is reused between calls) */
+} BhMultiRank;
+/* clump range of rank `rank` of `n_ranks`: contiguous, about the same number of reference columns each */
+void bh_clump_shard(const BhDb *db, int n_ranks, int rank, uint32_t *c0, uint32_t *c1);
+/* The search of the n_local ranks that live in this process (listed in rank order; one host thread each) as part of a job of
+ * n_ranks: align, [database-sharded: combine the per-query minimum, drop what lies above it], gather the records to rank 0.
+ * comm = communicator over all n_ranks (bhip_comm_create / bhip_comm_create_rank), or NULL when all ranks are local: records
+ * and minima then meet in host memory.  all = the gathered records where rank 0 lives (sorted by (query entry, reference));
+ * counts[n_ranks] (optional, rank 0's process) = records per rank. */
+int  bh_search_multi(BhMultiRank *ranks, int n_local, int n_ranks, void *comm, const BhQueries *q, BhMode mode, uint64_t batch_uniq, int shard_db, BhRun *all, uint64_t *counts);
 int  bh_device_open(const BhDb *db, int device, int z, void **hip_handle);
 /* build_K > 0 and a database without accelerator tables: the device builds the accelerator itself (no .acx file) */
 int  bh_device_open_ex(const BhDb *db, int device, int z, int build_K, void **hip_handle);

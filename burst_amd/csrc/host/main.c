@@ -14,7 +14,7 @@
 #include <time.h>
 #include <omp.h>
 
-#define BH_MAX_GPUS 16
+#define BH_MAX_GPUS BH_MAX_RANKS
 static double wall(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 static int code_to_exit(int rc) { return rc == BH_E_USAGE ? 1 : rc == BH_E_IO ? 2 : rc == BH_E_OOM ? 3 : 4; }
 #define DIE(rc) do { fprintf(stderr, "%s\n", bh_last_error()); return code_to_exit(rc); } while (0)
@@ -46,6 +46,8 @@ static void usage(void) {
 	puts("--makedb (-d) [name qLen], --id (-i) <decimal>, --threads (-t) <int>, --shear (-s) [len], --noprogress");
 	puts("--taxonomy (-b) <name>, --taxacut (-bc) <num>, --taxa_ncbi (-bn), --taxasuppress (-bs) [STRICT]: taxonomy column (interpolated in CAPITALIST)");
 	puts("--gpus <int> [--devices a,b,...] [--gather rccl|host]: shard the queries over the GPUs of this node (one RCCL gather of the records)");
+	puts("--shard queries|db: with --gpus, cut the queries (database replicated; default) or the database (every rank holds a range of");
+	puts("                    clumps and aligns all queries; one all-reduce of the per-query minimum) -- for databases beyond one device");
 	puts("--device <int>, --batch <int>, -k <12|15>, --make-acx <name> (with -r DB.edx: rebuild the accelerator of a database)");
 	puts("--accelerator-device (-ad): no .acx file, the device builds the accelerator from the .edx (word length -k, default 12)");
 	puts("--host-acx: build accelerators (-d ... -a, --make-acx) with the host builder instead of the device");
@@ -56,7 +58,7 @@ int main(int argc, char **argv) {
 	float thres = 0.97f;                            /* burst.c:93 */
 	int z = 1, do_rc = 0, incl_ws = 0, makedb = 0, do_shear = 0, do_accel = 0, dedupe = 0, device = 0, K = 0, skip_ambig = 0, threads = 0, rep_flags = 0;
 	long shear_amt = 500, db_qlen = 500;            /* burst.c:94 */
-	int n_gpus = 1, n_gpus_given = 0, gather_host = 0, n_dev_list = 0, dev_list[BH_MAX_GPUS], accel_dev = 0, host_acx = 0;
+	int n_gpus = 1, n_gpus_given = 0, gather_host = 0, n_dev_list = 0, dev_list[BH_MAX_GPUS], accel_dev = 0, host_acx = 0, shard_db = 0;
 	uint64_t batch = 1u << 21;      /* unique queries per device batch: the fixed cost of a batch (launches, synchronisation) is about 1 ms of device time */
 	const char *ref_FN = 0, *query_FN = 0, *output_FN = 0, *xcel_FN = 0, *mkacx_FN = 0, *tax_FN = 0;
 	BhTax taxonomy; memset(&taxonomy, 0, sizeof taxonomy);
@@ -115,6 +117,7 @@ int main(int argc, char **argv) {
 			for (char *t = strtok(argv[i], ","); t && n_dev_list < BH_MAX_GPUS; t = strtok(NULL, ",")) dev_list[n_dev_list++] = atoi(t);
 		}
 		else if (!strcmp(a, "--gather")) { NEEDARG("--gather"); gather_host = !strcmp(argv[i], "host"); if (!gather_host && strcmp(argv[i], "rccl")) { puts("ERROR: --gather rccl|host"); return 1; } }
+		else if (!strcmp(a, "--shard")) { NEEDARG("--shard"); shard_db = !strcmp(argv[i], "db"); if (!shard_db && strcmp(argv[i], "queries")) { puts("ERROR: --shard queries|db"); return 1; } }
 		else if (!strcmp(a, "--batch")) { NEEDARG("--batch"); batch = strtoull(argv[i], 0, 10); }
 		else if (!strcmp(a, "-k")) { NEEDARG("-k"); K = atoi(argv[i]); if (K != 12 && K != 15) { puts("ERROR: -k must be 12 or 15"); return 1; } }
 		else if (!strcmp(a, "--help") || !strcmp(a, "-h")) { usage(); return 1; }
@@ -236,72 +239,82 @@ int main(int argc, char **argv) {
 	} else if (db.shear && (uint32_t)(Q.maxLen / thres) > db.shear) {                /* burst.c:5152-5156 */
 		fputs("ERROR: DB incompatible with selected queries/identity.\n", stderr); return 1;
 	}
-	/* Multi-GPU (--gpus N): one host thread and one device handle per GPU, the database replicated, unique queries [r U / N,
-	 * (r+1) U / N) on rank r (a forward entry and its reverse complement stay together), then ONE gather of the hit records to
-	 * rank 0 over RCCL / xGMI (bhip_comm_gather_hits: ncclAllGather of the counts + grouped ncclSend / ncclRecv), where the
-	 * reference's consolidation (incl. CAPITALIST's global vote) runs.  --gpus 1 takes the same path with one rank. */
+	/* Multi-GPU (--gpus N): one host thread and one device handle per GPU (bh_search_multi, bh_multi.c).  --shard queries (default):
+	 * the database replicated, unique queries [r U / N, (r+1) U / N) on rank r (a forward entry and its reverse complement stay
+	 * together); --shard db: every rank holds a range of the database's clumps and aligns all queries, the per-query minimum is
+	 * combined over the ranks (ncclAllReduce MIN).  Then ONE gather of the hit records to rank 0 over RCCL / xGMI
+	 * (bhip_comm_gather_hits: ncclAllGather of the counts + grouped ncclSend / ncclRecv), where the reference's consolidation
+	 * (incl. CAPITALIST's global vote) runs.  --gpus 1 takes the same path with one rank. */
 	if (n_gpus > BH_MAX_GPUS) { printf("ERROR: --gpus %d (max %d)\n", n_gpus, BH_MAX_GPUS); return 1; }
-	void *hhs[BH_MAX_GPUS]; BhRun runs[BH_MAX_GPUS]; int rcs[BH_MAX_GPUS]; char errs[BH_MAX_GPUS][512];
-	memset(hhs, 0, sizeof hhs); memset(runs, 0, sizeof runs); memset(rcs, 0, sizeof rcs);
+	void *hhs[BH_MAX_GPUS]; int rcs[BH_MAX_GPUS]; char errs[BH_MAX_GPUS][512];
+	BhMultiRank ranks[BH_MAX_GPUS]; BhDb slices[BH_MAX_GPUS]; uint64_t ru0[BH_MAX_GPUS], ru1[BH_MAX_GPUS];
+	memset(hhs, 0, sizeof hhs); memset(ranks, 0, sizeof ranks); memset(slices, 0, sizeof slices);
+	for (int r = 0; r < BH_MAX_GPUS; ++r) rcs[r] = BH_E_INTERNAL;
 	void *comm = NULL;
 	const int use_rccl = n_gpus_given && !gather_host;
+	if (shard_db && n_gpus > 1 && (uint32_t)n_gpus > db.numRclumps) { puts("ERROR: --shard db with more ranks than clumps"); return 1; }
 	if (!n_dev_list) for (int r = 0; r < n_gpus; ++r) dev_list[r] = n_gpus_given ? r : device;
 	if (use_rccl && bhip_comm_create(n_gpus, dev_list, &comm)) { fprintf(stderr, "libburst_hip: %s\n", bhip_last_error()); return 4; }
+	omp_set_dynamic(0);
 	#pragma omp parallel num_threads(n_gpus)
 	{
 		const int r = omp_get_thread_num();
-		if ((rcs[r] = bh_device_open_ex(&db, dev_list[r], z, accel_dev ? K : 0, &hhs[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
+		const BhDb *part = &db;
+		rcs[r] = BH_OK;
+		if (shard_db && n_gpus > 1) {      /* this rank's clumps: a view of the clump area + (with an .acx) the lists restricted to it */
+			uint32_t c0, c1;
+			bh_clump_shard(&db, n_gpus, r, &c0, &c1);
+			ranks[r].c0 = c0;
+			if ((rcs[r] = bh_db_slice(&db, c0, c1, &slices[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
+			part = &slices[r];
+		}
+		if (!rcs[r] && (rcs[r] = bh_device_open_ex(part, dev_list[r], z, accel_dev ? K : 0, &hhs[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
 	}
-	for (int r = 0; r < n_gpus; ++r) if (rcs[r]) { fprintf(stderr, "%s\n", errs[r]); return 4; }
-	void *hh = hhs[0];
+	for (int r = 0; r < n_gpus; ++r) if (rcs[r]) { fprintf(stderr, "%s\n", rcs[r] == BH_E_INTERNAL ? "OpenMP did not start one host thread per GPU" : errs[r]); return 4; }
 	for (int r = 0; r < n_gpus; ++r) { char nm[256]; int ncu = 0; uint64_t hbm = 0; if (!bhip_device_info(hhs[r], nm, sizeof nm, &ncu, &hbm)) printf("Device %d: %s, %d CUs, %.0f GiB\n", dev_list[r], nm, ncu, hbm / 1073741824.0); }
+	if (shard_db && n_gpus > 1) for (int r = 0; r < n_gpus; ++r) printf("Rank %d: clumps [%u, %u)\n", r, ranks[r].c0, ranks[r].c0 + slices[r].numRclumps);
 	PHASE("device database upload");
 	bh_queries_pin(&Q);
 	PHASE("query arrays page-locked");
-	{	/* device and record buffers for the batches to come (allocations synchronise the device: not inside the search) */
-		const uint64_t perRank = Q.numUniq / (uint64_t)n_gpus + 1, B = perRank < batch ? perRank : batch, strands = Q.numEntries > Q.numUniq ? 2 : 1;
+	for (int r = 0; r < n_gpus; ++r) {
+		ranks[r].rank = r; ranks[r].hh = hhs[r];
+		if (shard_db && n_gpus > 1) { ru0[r] = 0; ru1[r] = Q.numUniq; }
+		else { ru0[r] = Q.numUniq * (uint64_t)r / (uint64_t)n_gpus; ru1[r] = Q.numUniq * (uint64_t)(r + 1) / (uint64_t)n_gpus; }
+		ranks[r].r0 = &ru0[r]; ranks[r].r1 = &ru1[r]; ranks[r].n_ranges = 1;
+	}
+	{	/* device and record buffers for the batches to come (allocations synchronise the device: not inside the search), sized from
+		 * the batches that will really be staged: their entry count and their symbols (one long read among millions of short ones
+		 * must not size every buffer for n_entries x max_len) */
+		const uint64_t strands = Q.numEntries > Q.numUniq ? 2 : 1;
 		#pragma omp parallel num_threads(n_gpus)
 		{
 			const int r = omp_get_thread_num();
-			bh_run_reserve(&runs[r], perRank * strands + perRank / 2 + (1u << 20));
-			bhip_reserve(hhs[r], (uint32_t)(B * strands), Q.maxLen);      /* last: it ends with a warm-up pass, the search follows at once */
+			const uint64_t n = ru1[r] - ru0[r], B = n < batch ? n : batch;
+			uint64_t sym = 0;
+			for (uint64_t u = ru0[r]; u < ru1[r]; u += B ? B : 1) {
+				const uint64_t e = u + B < ru1[r] ? u + B : ru1[r];
+				uint64_t sy = Q.qoff[e] - Q.qoff[u];
+				if (strands == 2) sy += Q.qoff[Q.numUniq + e] - Q.qoff[Q.numUniq + u];
+				if (sy > sym) sym = sy;
+			}
+			bh_run_reserve(&ranks[r].run, n * strands + n / 2 + (1u << 20));
+			if (B && bhip_reserve_symbols(hhs[r], (uint32_t)(B * strands), Q.maxLen, sym))      /* last: it ends with a warm-up pass, the search follows at once */
+				fprintf(stderr, " --> WARNING: batch buffers not reserved on device %d (%s); they are allocated batch by batch\n", dev_list[r], bhip_last_error());
 		}
 	}
 	PHASE("batch buffers");
 	BhRun run; memset(&run, 0, sizeof run);
 	const double t0 = wall();
 	uint64_t cnts[BH_MAX_GPUS]; memset(cnts, 0, sizeof cnts);
-	#pragma omp parallel num_threads(n_gpus)
-	{
-		const int r = omp_get_thread_num();
-		const uint64_t u0 = Q.numUniq * (uint64_t)r / (uint64_t)n_gpus, u1 = Q.numUniq * (uint64_t)(r + 1) / (uint64_t)n_gpus;
-		if ((rcs[r] = bh_align_ranges_reuse(hhs[r], &Q, &u0, &u1, 1, mode, batch, &runs[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
-	}
-	for (int r = 0; r < n_gpus; ++r) if (rcs[r]) { fprintf(stderr, "%s\n", errs[r]); return rcs[r] == BH_E_USAGE ? 1 : 4; }
-	if (n_gpus == 1 && !use_rccl) run = runs[0];
-	else {
-		uint64_t tot = 0;
-		for (int r = 0; r < n_gpus; ++r) tot += runs[r].nHits;
-		if (bh_run_reserve(&run, tot + 1)) DIE(BH_E_OOM);
-		if (use_rccl) {
-			#pragma omp parallel num_threads(n_gpus)
-			{
-				const int r = omp_get_thread_num();
-				uint64_t n_total = 0;
-				if ((rcs[r] = bhip_comm_gather_hits(comm, r, runs[r].hits, runs[r].nHits, r ? NULL : run.hits, tot + 1, &n_total, r ? NULL : cnts)))
-					snprintf(errs[r], sizeof errs[r], "libburst_hip: %s", bhip_last_error());
-			}
-			for (int r = 0; r < n_gpus; ++r) if (rcs[r]) { fprintf(stderr, "%s\n", errs[r]); return 4; }
-			printf("RCCL gather: %d rank(s), records per rank:", n_gpus);
-			for (int r = 0; r < n_gpus; ++r) printf(" %lu", (unsigned long)cnts[r]);
-			printf("\n");
-		} else {        /* --gather host: the ranks are threads of one process, their records are already in its memory */
-			uint64_t o = 0;
-			for (int r = 0; r < n_gpus; ++r) { if (runs[r].nHits) memcpy(run.hits + o, runs[r].hits, runs[r].nHits * sizeof(BhipHit)); o += runs[r].nHits; }
-			printf("host gather: %d rank(s)\n", n_gpus);
-		}
-		run.nHits = tot;
-		for (int r = 0; r < n_gpus; ++r) { run.nBatches += runs[r].nBatches; run.total.n_pairs += runs[r].total.n_pairs; bh_run_free(&runs[r]); }
+	if (n_gpus == 1 && !use_rccl) {
+		if ((rc = bh_align_ranges_reuse(hhs[0], &Q, &ru0[0], &ru1[0], 1, mode, batch, &ranks[0].run))) { fprintf(stderr, "%s\n", bh_last_error()); return rc == BH_E_USAGE ? 1 : 4; }
+		run = ranks[0].run; memset(&ranks[0].run, 0, sizeof ranks[0].run);
+	} else {
+		if ((rc = bh_search_multi(ranks, n_gpus, n_gpus, comm, &Q, mode, batch, shard_db && n_gpus > 1, &run, cnts))) { fprintf(stderr, "%s\n", bh_last_error()); return rc == BH_E_USAGE ? 1 : 4; }
+		printf("%s: %d rank(s)%s, records per rank:", use_rccl ? "RCCL gather" : "host gather", n_gpus, shard_db && n_gpus > 1 ? ", database-sharded" : "");
+		for (int r = 0; r < n_gpus; ++r) printf(" %lu", (unsigned long)cnts[r]);
+		printf("\n");
+		for (int r = 0; r < n_gpus; ++r) { run.total.n_pairs += ranks[r].run.total.n_pairs; bh_run_free(&ranks[r].run); }
 	}
 	const double t1 = wall();
 	printf("Search complete [%f s, %u batches, %lu candidate (query, clump) pairs, %lu hits]. Consolidating results...\n", t1 - t0, run.nBatches,
@@ -314,8 +327,7 @@ int main(int argc, char **argv) {
 	printf("Wrote %lu alignments\n", (unsigned long)lines);
 	PHASE("consolidation, output");
 	if (comm) bhip_comm_destroy(comm);
-	for (int r = 0; r < n_gpus; ++r) bhip_destroy(hhs[r]);
-	(void)hh;
+	for (int r = 0; r < n_gpus; ++r) { bhip_destroy(hhs[r]); if (slices[r].numRclumps) bh_db_free(&slices[r]); }
 	bh_run_free(&run); bh_queries_free(&Q); bh_db_free(&db); bh_tax_free(&taxonomy);
 	printf("\nAlignment time: %f seconds\n", wall() - start);
 	return 0;

@@ -149,6 +149,9 @@ BHIP_API int bhip_stage_spans(void *handle, const BhipQuerySpan *spans, uint32_t
 /* Optional: allocate now what batches of up to n_entries entries of up to max_len symbols will need, so that no allocation
  * (each one synchronises the device) falls into the first batches. */
 BHIP_API int bhip_reserve(void *handle, uint32_t n_entries, uint32_t max_len);
+/* the same with the symbol count of the largest batch to come (sum of its entries' lengths; 0 = n_entries x max_len): what holds
+ * symbols and match profiles is sized from it, so that one long read among millions of short ones does not multiply every buffer */
+BHIP_API int bhip_reserve_symbols(void *handle, uint32_t n_entries, uint32_t max_len, uint64_t total_symbols);
 
 /* Page-locked host memory (hipHostMalloc / hipHostRegister behind the C ABI, for callers that are plain C): copies from and to
  * it run asynchronously beside the kernels.  bhip_alloc_host returns NULL when no device is present. */
@@ -157,13 +160,22 @@ BHIP_API void  bhip_free_host(void *p);
 BHIP_API int   bhip_host_register(void *p, uint64_t bytes);
 BHIP_API int   bhip_host_unregister(void *p);
 
-/* Multi-GPU (no reference counterpart): the unique queries are sharded across the GPUs of a node -- one handle and
- * one host thread per device, the database replicated -- and the hit records travel to rank 0 in one variable-length gather
- * over RCCL / xGMI (ncclAllGather of the counts + grouped ncclSend / ncclRecv of the 20-byte records).  bhip_comm_create sets up
- * the ranks of THIS process (ncclCommInitAll); every rank's thread then calls bhip_comm_gather_hits with its records (host
- * memory); rank 0 gets all of them in rank order, counts[n_ranks] the per-rank numbers.  BHIP_E_CAPACITY: *n_total needed. */
+/* Multi-GPU (no reference counterpart).  Query-sharded: the unique queries are cut across the GPUs of a node -- one
+ * handle per device, the database replicated -- and the hit records travel to rank 0 in one variable-length gather over RCCL / xGMI
+ * (ncclAllGather of the counts + grouped ncclSend / ncclRecv of the 20-byte records).  Database-sharded (databases beyond one
+ * device): every rank holds a range of clumps and aligns all queries; the hits of a query are the references at its GLOBAL minimum
+ * edit distance (burst.c:4217-4277), so the ranks combine one byte per unique query with bhip_comm_allreduce_min (ncclAllReduce,
+ * MIN) before the same gather.  The ranks are the threads of one process (bhip_comm_create: ncclCommInitAll over `devices`) or one
+ * process each (bhip_comm_unique_id on one of them, the 128 bytes carried to the others by the launcher, bhip_comm_create_rank:
+ * ncclCommInitRank); every rank's thread calls the collectives with its own rank, all ranks' calls in flight together.
+ * bhip_comm_gather_hits: rank 0 gets all records in rank order, counts[n_ranks] the per-rank numbers; BHIP_E_CAPACITY: *n_total
+ * needed.  A rank that cannot take part (out of memory ...) makes the call fail on EVERY rank instead of leaving them waiting. */
 BHIP_API int  bhip_comm_create(int n_ranks, const int *devices, void **comm);
+BHIP_API int  bhip_comm_unique_id(void *id128);
+BHIP_API int  bhip_comm_create_rank(int n_ranks, int rank, int device, const void *id128, void **comm);
 BHIP_API int  bhip_comm_gather_hits(void *comm, int rank, const BhipHit *hits, uint64_t n, BhipHit *out, uint64_t cap, uint64_t *n_total, uint64_t *counts);
+BHIP_API int  bhip_comm_fetch_gathered(void *comm, BhipHit *out, uint64_t cap, uint64_t *n_total);      /* rank 0 after BHIP_E_CAPACITY: no collective, the records are still on its device */
+BHIP_API int  bhip_comm_allreduce_min(void *comm, int rank, uint8_t *buf, uint64_t n);
 BHIP_API void bhip_comm_destroy(void *comm);
 
 /* The accelerator of a handle in the file's terms (read_accelerator's tables, burst.c:3535-3594): Lens[4^K], the clump ids of all

@@ -183,16 +183,25 @@ def test_reference_host_with_device_binding(c, tmp_path_factory):
 @pytest.mark.parametrize("name,flags,expect", [("dna_q100_best_fr", ["--gpus", "1"], "RCCL gather: 1 rank(s)"),
                                                ("dna_q100_allpaths_fr", ["--gpus", "1", "--batch", "29"], "RCCL gather: 1 rank(s)"),
                                                ("dna_q100_allpaths_fr", ["--gpus", "3", "--devices", "0,0,0", "--gather", "host"], "host gather: 3 rank(s)"),
-                                               ("dna_q100_capitalist_noacx_t1_fr", ["--gpus", "2", "--devices", "0,0", "--gather", "host"], "host gather: 2 rank(s)")])
+                                               ("dna_q100_capitalist_noacx_t1_fr", ["--gpus", "2", "--devices", "0,0", "--gather", "host"], "host gather: 2 rank(s)"),
+                                               ("dna_q100_allpaths_fr", ["--gpus", "3", "--devices", "0,0,0", "--gather", "host", "--shard", "db"], "host gather: 3 rank(s), database-sharded"),
+                                               ("dna_q100_best_fr", ["--gpus", "4", "--devices", "0,0,0,0", "--gather", "host", "--shard", "db", "-ad"], "host gather: 4 rank(s), database-sharded"),
+                                               ("dna_q100_capitalist_fr", ["--gpus", "2", "--devices", "0,0", "--gather", "host", "--shard", "db", "--batch", "41"], "host gather: 2 rank(s), database-sharded"),
+                                               ("dna_q292_forage_fr", ["--gpus", "3", "--devices", "0,0,0", "--gather", "host", "--shard", "db", "-ad"], "host gather: 3 rank(s), database-sharded"),
+                                               ("quick_q100_capitalist_noacx_t1", ["--gpus", "2", "--devices", "0,0", "--gather", "host", "--shard", "db"], "host gather: 2 rank(s), database-sharded"),
+                                               ("dna_q100_allpaths_fr", ["--gpus", "1", "--shard", "db"], "RCCL gather: 1 rank(s)")])
 def test_cli_multi_gpu_paths(name, flags, expect, tmp_path):
     """burst_hip --gpus N: one host thread + one device handle per rank, the unique queries sharded, the records gathered to
     rank 0 (ncclAllGather of the counts + grouped ncclSend / ncclRecv in libburst_hip; `--gather host` when the ranks share a
-    device, as they must on a one-GPU box).  --gpus 1 goes through the RCCL code with one rank.  Same .b6 as one device."""
+    device, as they must on a one-GPU box).  --gpus 1 goes through the RCCL code with one rank.  Same .b6 as one device.
+    --shard db (bh_search_multi): every rank holds a range of clumps -- the .acx lists restricted to it (bh_db_slice), or with -ad an
+    accelerator the rank's device builds for its slice -- aligns all queries, the per-query minimum is combined over the ranks and
+    the gathered records are put in (query, reference) order: the golden lines of the whole database."""
     c = [x for x in gl.cases() if x["name"] == name][0]
     ref, q, fr, z, shear = gl.case_args(c)
     out = str(tmp_path / "o.b6")
     cmd = [CLI, "-r", ref, "-q", q, "-o", out, "-m", c["mode"], "-i", c["id"]] + gl.cli_extra(c) + flags
-    if c["accel"]:
+    if c["accel"] and "-ad" not in flags:
         cmd += ["-a", acx_for(c["db"], z, str(tmp_path))]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0 and expect in r.stdout, r.stdout[-2000:]

@@ -246,8 +246,11 @@ def test_configs4_shape_full_size():
     clump_len = host._view(db.c.clumpLen, db.c.numRclumps, np.uint32)
     assert (h["refIx"] < db.c.totR).all()
     assert (h["finalPos"] >= 1).all() and (h["finalPos"] <= clump_len[h["refIx"] >> 4]).all()
-    key = (q << 32) | h["refIx"].astype(np.int64)
-    assert (np.diff(key) > 0).all()                          # sorted by (query entry, reference), no duplicates
+    # records of an entry contiguous and ascending by reference, no duplicates; entries ascending inside a batch (a batch = its
+    # forward entries, then their reverse complements)
+    same = np.diff(q) == 0
+    assert (np.diff(h["refIx"].astype(np.int64))[same] > 0).all()
+    assert int((~same).sum()) + 1 == len(np.unique(q))
     assert len(h) > qs.n_uniq                                # FORAGE: more than one placement per query on a database of families
     run.close()
     dev.close()
