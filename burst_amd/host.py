@@ -38,6 +38,10 @@ class BhRun(C.Structure):
     _fields_ = [("hits", C.c_void_p), ("nHits", C.c_uint64), ("secAlign", C.c_double), ("total", capi.BhipStats), ("nBatches", C.c_uint32), ("hitsPinned", C.c_int), ("capHits", C.c_uint64)]
 
 
+class BhMultiRank(C.Structure):
+    _fields_ = [("rank", C.c_int), ("hh", C.c_void_p), ("r0", u64p), ("r1", u64p), ("n_ranges", C.c_uint32), ("c0", C.c_uint32), ("run", BhRun)]
+
+
 class HostError(RuntimeError):
     pass
 
@@ -72,6 +76,9 @@ def lib():
         L.bh_align.argtypes = [C.c_void_p, C.POINTER(BhQueries), C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(BhRun)]
         L.bh_align_ranges.argtypes = [C.c_void_p, C.POINTER(BhQueries), u64p, u64p, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(BhRun)]
         L.bh_align_ranges_reuse.argtypes = L.bh_align_ranges.argtypes
+        L.bh_search_multi.argtypes = [C.POINTER(BhMultiRank), C.c_int, C.c_int, C.c_void_p, C.POINTER(BhQueries), C.c_int, C.c_uint64, C.c_int, C.POINTER(BhRun), u64p]
+        L.bh_clump_shard.argtypes = [C.POINTER(BhDb), C.c_int, C.c_int, u32p, u32p]
+        L.bh_clump_shard.restype = None
         L.bh_run_reserve.argtypes = [C.POINTER(BhRun), C.c_uint64]
         L.bh_run_free.argtypes = [C.POINTER(BhRun)]
         L.bh_report_ex.argtypes = [C.c_void_p, C.POINTER(BhDb), C.POINTER(BhQueries), C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
@@ -249,6 +256,38 @@ def align_ranges(dev, qs, ranges, mode, batch_uniq=1 << 18, run=None):
     run = run or Run()
     _chk(lib().bh_align_ranges_reuse(dev._h, C.byref(qs.c), r0.ctypes.data_as(u64p), r1.ctypes.data_as(u64p), len(ranges), MODES[mode], batch_uniq, C.byref(run.c)))
     return run
+
+
+class RankSearch:
+    """this process's rank of a node-wide job through the C host's multi-GPU search (bh_search_multi: align, [database-sharded:
+    per-query minimum over the ranks,] gather of the records to rank 0 over the library's RCCL communicator)"""
+
+    def __init__(self, dev, rank, world, comm, c0=0):
+        self.mr = BhMultiRank()
+        self.mr.rank, self.mr.hh, self.mr.c0 = rank, dev._h, c0
+        self.world, self.comm = world, comm
+        self.all = Run()
+
+    def reserve(self, cap_records):
+        _chk(lib().bh_run_reserve(C.byref(self.mr.run), int(cap_records)))
+
+    def search(self, qs, ranges, mode, batch_uniq, shard_db=False):
+        """ranges: this rank's [(u0, u1), ...]; returns the gathered Run on rank 0 (its own elsewhere)"""
+        r0 = np.ascontiguousarray([r[0] for r in ranges] or [0], np.uint64)
+        r1 = np.ascontiguousarray([r[1] for r in ranges] or [0], np.uint64)
+        self.mr.r0, self.mr.r1, self.mr.n_ranges = r0.ctypes.data_as(u64p), r1.ctypes.data_as(u64p), len(ranges)
+        self._keep = (r0, r1)
+        self.counts = np.zeros(self.world, np.uint64)
+        _chk(lib().bh_search_multi(C.byref(self.mr), 1, self.world, self.comm, C.byref(qs.c), MODES[mode], batch_uniq, int(bool(shard_db)), C.byref(self.all.c),
+                                   self.counts.ctypes.data_as(u64p)))
+        return self.all
+
+    def own_stats(self):
+        return self.mr.run.total.as_dict(), int(self.mr.run.nBatches), float(self.mr.run.secAlign)
+
+    def close(self):
+        lib().bh_run_free(C.byref(self.mr.run))
+        self.all.close()
 
 
 libc = C.CDLL(None)
