@@ -126,6 +126,21 @@ def cpu_baseline(edx, acx, reads_fa, args):
                       % (args.K, cores, args.mode, args.id, n1, n2, times[0], times[1])}
 
 
+def share_of_job(ranges, rank, world):
+    """the rank-th of `world` equal parts of a job given as ranges of unique queries aligned one after the other: the ranges (or
+    pieces of them) that make up [rank, rank + 1) / world of the job's total"""
+    if world == 1:
+        return list(ranges)
+    total = sum(b - a for a, b in ranges)
+    lo, hi, out, pos = total * rank // world, total * (rank + 1) // world, [], 0
+    for a, b in ranges:
+        x0, x1 = max(lo, pos), min(hi, pos + (b - a))
+        if x1 > x0:
+            out.append((a + x0 - pos, a + x1 - pos))
+        pos += b - a
+    return out
+
+
 def parity_vs_reference(dev, db, args, batch_uniq):
     """the reference's .b6 for the cpu_baseline sample against the device path's for the same reads (same database, same flags)"""
     from burst_amd import host
@@ -237,46 +252,49 @@ def main():
     log("[bench] rank %d: db %d refs / %d clumps (.edx %.2f GB, accelerator %.2f G entries; read %.1f s, device upload + accelerator build %.1f s), %d reads -> %d unique (ingest %.1f s) on %s"
         % (rank, db.c.totR, db.c.numRclumps, edx_bytes / 1e9, acx_entries / 1e9, t_db, t_dev, qs.n_reads, qs.n_uniq, t_q, info["name"]))
 
-    # pool batch b = unique queries [b U / P, (b+1) U / P); this rank's share of it = its 1/world slice
+    # pool batch b = unique queries [b U / P, (b+1) U / P).  The job = `steps` pool batches in a row (strong scaling: the same job
+    # whatever N is); rank r aligns the r-th N-th of that sequence of unique queries -- every rank the same number of reads, in pieces
+    # of at most one pool batch per device call, so the per-batch fixed costs are not multiplied by N
     U, P = qs.n_uniq, args.pool
-    def rank_range(b):
-        b0, b1 = b * U // P, (b + 1) * U // P
-        n = b1 - b0
-        return (b0 + rank * n // world, b0 + (rank + 1) * n // world)
-    # N > 1 (strong scaling: the job = `steps` batches of --reads reads, whatever N is): with at least two batches per rank the
-    # ranks take WHOLE batches in turn (batch k -> rank k mod N; every device call keeps its 2 M reads and the per-batch fixed
-    # costs are not multiplied by N); with fewer, every rank takes its 1/N slice of every batch
-    whole = world > 1 and args.steps >= 2 * world
     def pool_range(b):
         return (b * U // P, (b + 1) * U // P)
-    def step_ranges(first, count):
-        if whole:
-            return [pool_range((first + k) % P) for k in range(count) if k % world == rank]
-        return [rank_range((first + k) % P) for k in range(count)]
-    def prime_ranges(count):        # setup only: every rank runs the same number of full-size device calls
-        return [pool_range(k % P) if whole else rank_range(k % P) for k in range(count)]
-    batch_uniq = max(1, U // P + 1) if whole else max(1, (U // P + world - 1) // world + 1)         # one device batch per step (and rank)
+    def job_share(first, count, r=rank):
+        return share_of_job([pool_range((first + k) % P) for k in range(count)], r, world)
+    batch_uniq = max(1, U // P + 1)         # at most one pool batch per device call
     reads_per_pool_batch = [qs.reads_in(b * U // P, (b + 1) * U // P) for b in range(P)]
 
-    def gather(run):
-        """one variable-length gather of the rank's hit records to rank 0 (all_gather of counts + padded gather)"""
-        h = run.hits
-        n = torch.tensor([len(h)], dtype=torch.int64, device="cuda")
-        counts = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(counts, n)
-        mx = max(int(c.item()) for c in counts)
-        send = torch.zeros(mx * 20, dtype=torch.uint8, device="cuda")
-        if len(h):
-            send[:len(h) * 20] = torch.from_numpy(h.view(np.uint8).reshape(-1)).cuda(non_blocking=True)
-        recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
-        dist.gather(send, recv, dst=0)
-        return sum(int(c.item()) for c in counts)
+    # N > 1: the product's own exchange -- the library's RCCL communicator over the ranks (one process per GPU: the 128-byte id
+    # travels through torch.distributed, which is plumbing here) and bh_search_multi, the function `burst_hip --gpus N` runs
+    comm = None
+    if use_dist:
+        idt = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            capi._chk(capi.lib().bhip_comm_unique_id(buf))
+            idt = torch.tensor(list(buf), dtype=torch.uint8)
+        idt = idt.cuda()
+        dist.broadcast(idt, 0)
+        idb = (C.c_uint8 * 128)(*idt.cpu().tolist())
+        comm = C.c_void_p()
+        capi._chk(capi.lib().bhip_comm_create_rank(world, rank, local_rank, idb, C.byref(comm)))
+    rs = host.RankSearch(dev, rank, world, comm)
+
+    def search(ranges):
+        """one job share through the product's scheduler; N > 1: + the gather of the records to rank 0"""
+        if use_dist:
+            return rs.search(qs, ranges, args.mode, batch_uniq)
+        return host.align_ranges(dev, qs, ranges, args.mode, batch_uniq, run=_own)
 
     # warm-up: sizes the library's grow-only buffers for this workload and runs W untimed steps
     # (the page-locked record buffer is allocated once, outside the timed region: the command line does it once per job as well)
-    run = host.Run()
-    ent_per_step = max(r[1] - r[0] for r in prime_ranges(P)) * (2 if args.fr else 1)
-    run.reserve(int(ent_per_step * max(4, args.warmup, args.steps) * (4.0 if args.mode in ("FORAGE", "ALLPATHS") else 1.5)) + (1 << 20))
+    _own = host.Run()
+    ent_per_step = min(batch_uniq, max((b - a for a, b in job_share(0, P)), default=1)) * (2 if args.fr else 1)
+    share = max(1, sum(b - a for a, b in job_share(args.warmup, args.steps))) * (2 if args.fr else 1)
+    cap_rec = int(max(share, 4 * ent_per_step) * (4.0 if args.mode in ("FORAGE", "ALLPATHS") else 1.5)) + (1 << 20)
+    if use_dist:
+        rs.reserve(cap_rec)
+    else:
+        _own.reserve(cap_rec)
     # (bhip_reserve = the command line's "batch buffers" phase: device buffers for this batch size + the library's own warm-up pass)
     if not args.no_prime:
         dev.reserve(int(ent_per_step), int(args.read_len))
@@ -284,16 +302,14 @@ def main():
     # queued when a batch's records are handed over pays ~17 ms once per process inside the runtime's asynchronous copy (seen with
     # --warmup 1 in front of the timed region's second batch)
     if not args.no_prime:
-        run = host.align_ranges(dev, qs, prime_ranges(4), args.mode, batch_uniq, run=run)
-    run = host.align_ranges(dev, qs, step_ranges(0, max(1, args.warmup)), args.mode, batch_uniq, run=run)
-    if use_dist:
-        gather(run)
+        search([pool_range(k % P) for k in range(4)] if world == 1 else job_share(0, 4 * world))
+    search(job_share(0, max(1, args.warmup)))
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
-    run = host.align_ranges(dev, qs, step_ranges(args.warmup, args.steps), args.mode, batch_uniq, run=run)
-    n_records = gather(run) if use_dist else int(run.c.nHits)
+    run = search(job_share(args.warmup, args.steps))
+    n_records = int(run.c.nHits)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -302,6 +318,9 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        nr = torch.tensor([n_records if rank == 0 else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(nr)
+        n_records = int(nr.item())
     total_reads = sum(reads_per_pool_batch[(args.warmup + k) % P] for k in range(args.steps))
 
     if rank == 0 and os.environ.get("BHIP_PROF"):      # library built with EXTRA_HIPFLAGS=-DPFM_PROF: wave-cycles per prefilter phase
@@ -313,8 +332,8 @@ def main():
             tot = float(sum(arr)) or 1.0
             log("[bench] prefilter phase share: " + " ".join("%d:%.1f%%" % (i, 100.0 * v / tot) for i, v in enumerate(arr)) + "  total wave-cycles %.3g" % tot)
     if rank == 0:
-        st = run.stats()
-        nb = max(1, int(run.c.nBatches))
+        st, nb, sec_align = rs.own_stats() if use_dist else (run.stats(), int(run.c.nBatches), float(run.c.secAlign))
+        nb = max(1, nb)
         per = lambda k: float(st[k]) / nb
         two_stage = st["prefix_words"] > 0
         masked = st["prefilter_launches"] > 0
@@ -389,7 +408,8 @@ def main():
                                    "(%.2f Gbp; %d clumps; .edx %.2f GB + DB%d .acx %.2f GB); every step stages its batch afresh through the product's batch scheduler"
                                    % (world, args.reads, args.read_len, args.mode, args.id, args.n_base * args.n_variants, args.ref_len,
                                       args.n_base * args.n_variants * args.ref_len / 1e9, db.c.numRclumps, edx_bytes / 1e9, args.K, acx_bytes / 1e9),
-                       "parallelism": "query-sharded x%d (%s), DB replicated, one RCCL gather of hit records" % (world, "whole batches in turn" if whole else "1/N slice of every batch"),
+                       "parallelism": "query-sharded x%d (rank r aligns the r-th N-th of the job's unique queries in device batches of up to %d), DB replicated, one RCCL gather of the hit records to rank 0 "
+                                      "(bhip_comm_gather_hits inside bh_search_multi, the function burst_hip --gpus N runs)" % (world, batch_uniq),
                        "timed_region": "bh_align_ranges over %d batches (copies + device routing two batches ahead, seed lookups + profiles one batch ahead, alignment, records to host memory)%s" % (nb, " + RCCL gather" if use_dist else ""),
                        "extrapolation": extrap,
                        "device": info["name"], "n_cu": info["n_cu"]},
@@ -406,7 +426,7 @@ def main():
                      "acx_entries_per_read": st["acx_entries_read"] / max(1.0, float(st["n_queries"])), "windows": st["n_windows"], "window_columns": st["n_window_columns"],
                      "lane_tasks_per_read": st["n_lane_tasks"] / max(1.0, float(st["n_queries"])), "task_columns": st["n_task_columns"],
                      "seed_words_per_read": st["n_seed_words"] / max(1.0, float(st["n_queries"]))},
-            "host": {"db_read_s": t_db, "device_upload_s": t_dev, "query_ingest_s": t_q, "sec_in_device_calls": float(run.c.secAlign)},
+            "host": {"db_read_s": t_db, "device_upload_s": t_dev, "query_ingest_s": t_q, "sec_in_device_calls": sec_align},
         }
         res["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "burst%d" % args.K)):      # N = 1 only (the contract); the other ranks would sit in the barrier meanwhile
@@ -424,7 +444,10 @@ def main():
             except Exception as e:      # reported, never fatal for the measurement
                 res["parity_vs_reference"] = {"error": str(e)}
         print(json.dumps(res), flush=True)
-    run.close()
+    rs.close()
+    _own.close()
+    if comm:
+        capi.lib().bhip_comm_destroy(comm)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

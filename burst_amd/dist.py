@@ -89,57 +89,3 @@ def run_db_sharded(clump_len, shared_of_entry, n_shared, align_slice, rank, worl
     if out is None:
         return None
     return out[np.lexsort((out["refIx"], out["q"]))]
-
-
-class PaddedGather:
-    """Gather of fixed-capacity record buffers that never leaves the devices: every rank fills `send` (uint8 view of `cap`
-    20-byte records, first 8 bytes of a 32-byte header = record count), rank `dst` receives world buffers into memory it
-    keeps resident.  Two buffer sets alternate so that the gather of one batch overlaps the alignment of the next (xGMI is
-    point to point: the 7 peers of an 8-GPU node send on 7 different links).  Works on any torch device (gloo in the tests)."""
-    HDR = 32
-
-    def __init__(self, cap_records, rank, world, device, dst=0):
-        import torch
-        self.rank, self.world, self.dst, self.cap = rank, world, dst, int(cap_records)
-        nbytes = self.HDR + self.cap * capi.HIT_DTYPE.itemsize
-        self.send = [torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(2)]
-        self.recv = [[torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(world)] for _ in range(2)] if rank == dst else [None, None]
-        self.work = [None, None]
-        self.turn = 0
-
-    def buffer(self):
-        """send buffer of the next post() (waits for the gather that last used it)"""
-        self.wait(self.turn)
-        return self.send[self.turn]
-
-    def payload_ptr(self):
-        return self.buffer().data_ptr() + self.HDR
-
-    def post(self, n_records):
-        import torch
-        import torch.distributed as dist
-        t = self.turn
-        self.send[t][:8] = torch.tensor([n_records], dtype=torch.int64).view(torch.uint8).to(self.send[t].device)
-        self.work[t] = dist.gather(self.send[t], self.recv[t], dst=self.dst, async_op=True)
-        self.turn ^= 1
-        return t
-
-    def wait(self, t=None):
-        for i in ((0, 1) if t is None else (t,)):
-            if self.work[i] is not None:
-                self.work[i].wait()
-                if self.send[i].is_cuda:      # NCCL's wait() only orders the current stream: block the host as well, the
-                    import torch              # library fills the send buffer from its own stream
-                    torch.cuda.current_stream().synchronize()
-                self.work[i] = None
-
-    def records(self, t):
-        """rank dst, after wait(t): concatenated records of all ranks (host copy)"""
-        if self.rank != self.dst:
-            return None
-        import torch
-        parts = []
-        for buf in self.recv[t]:
-            n = int(buf[:8].cpu().view(torch.int64)[0])
-            parts.append(buf[self.HDR:self.HDR + n * capi.HIT_DTYPE.itemsize].cpu().numpy().view(capi.HIT_DTYPE))
-        return np.concatenate(parts) if parts else np.zeros(0, capi.HIT_DTYPE)

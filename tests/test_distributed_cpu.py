@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 import goldenlib as gl
@@ -62,46 +63,43 @@ def test_shard_ranges_partition():
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
 
 
-PG_WORKER = r"""
-import os, sys
-import numpy as np
-sys.path.insert(0, sys.argv[1])
-import torch, torch.distributed as dist
-from burst_amd import capi, dist as bdist
-rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo")
-pg = bdist.PaddedGather(100, rank, world, "cpu")
-exp = []
-for step in range(5):                      # more steps than buffer sets: exercises the reuse of a posted buffer
-    n = (7 * step + 13 * rank) % 90
-    rec = np.zeros(n, capi.HIT_DTYPE); rec["q"] = np.arange(n) + 1000 * rank + 100000 * step; rec["refIx"] = step
-    buf = pg.buffer()
-    buf[pg.HDR:pg.HDR + rec.nbytes] = torch.from_numpy(rec.view(np.uint8).reshape(-1))
-    t = pg.post(n)
-    pg.wait(t)
-    got = pg.records(t)
-    if rank == 0:
-        want = []
+def test_job_shares_partition_the_job():
+    """bench.py N > 1: rank r aligns the r-th N-th of the job (a sequence of pool batches): the shares are disjoint, in order,
+    cover the job exactly and differ by at most one query"""
+    import bench
+    U, P = 7999135, 4
+    pool = [(b * U // P, (b + 1) * U // P) for b in range(P)]
+    for steps in (1, 3, 5, 20):
+        job = [pool[(5 + k) % P] for k in range(steps)]
+        flat = np.concatenate([np.arange(a, b) for a, b in job]) if steps < 5 else None
+        total = sum(b - a for a, b in job)
+        for world in (1, 2, 3, 8):
+            shares = [bench.share_of_job(job, r, world) for r in range(world)]
+            sizes = [sum(b - a for a, b in sh) for sh in shares]
+            assert sum(sizes) == total and max(sizes) - min(sizes) <= 1
+            assert all(b > a for sh in shares for a, b in sh)
+            if flat is not None:
+                got = np.concatenate([np.arange(a, b) for sh in shares for a, b in sh])
+                assert np.array_equal(got, flat)
+
+
+def test_clump_shards_partition_the_database():
+    """bh_clump_shard (the C host's --shard db): contiguous clump ranges that cover the database, about the same number of
+    reference columns each -- the same cuts as the Python launcher's clump_shard_range"""
+    import ctypes as C
+    from burst_amd import dist as bdist, host
+    db = host.Db.read(os.path.join(gl.G, "dna.edx"))
+    cl = host._view(db.c.clumpLen, db.c.numRclumps, np.uint32)
+    for world in (1, 2, 3, 5, 8):
+        prev = 0
         for r in range(world):
-            m = (7 * step + 13 * r) % 90
-            w = np.zeros(m, capi.HIT_DTYPE); w["q"] = np.arange(m) + 1000 * r + 100000 * step; w["refIx"] = step
-            want.append(w)
-        want = np.concatenate(want)
-        assert got.tobytes() == want.tobytes(), step
-    else:
-        assert got is None
-dist.barrier(); dist.destroy_process_group()
-print("ok")
-"""
-
-
-def test_padded_gather_two_ranks(tmp_path):
-    """the per-step device-side gather of bench.py (fixed-capacity buffers, count in a header, two alternating buffer sets)"""
-    w = tmp_path / "pg_worker.py"
-    w.write_text(PG_WORKER)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29519", str(w), gl.ROOT], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.count("ok") == 2, r.stdout[-3000:]
+            c0, c1 = C.c_uint32(), C.c_uint32()
+            host.lib().bh_clump_shard(C.byref(db.c), world, r, C.byref(c0), C.byref(c1))
+            assert c0.value == prev and c1.value >= c0.value
+            assert (c0.value, c1.value) == bdist.clump_shard_range(cl, world, r)
+            prev = c1.value
+        assert prev == db.c.numRclumps
+    db.close()
 
 
 DB_WORKER = r"""

@@ -295,3 +295,23 @@ def test_device_query_sort_equals_host_sort(tmp_path, monkeypatch, capfd):
         for k in a:
             if k != "n":
                 assert np.array_equal(a[k], b[k]), (rc, k)
+
+
+def test_bench_multi_rank_path_with_one_process(tmp_path):
+    """bench.py's N > 1 code path on the one GPU of the test box (BURST_BENCH_DIST1=1 under torch.distributed.run with one process):
+    the library's RCCL communicator made from a broadcast id (bhip_comm_unique_id / bhip_comm_create_rank) and bh_search_multi --
+    align + bhip_comm_gather_hits inside the timed region -- on a small database; the JSON line must carry the same record count as
+    the plain single-process run of the same job"""
+    import json
+    import sys
+    bench = os.path.join(gl.ROOT, "bench.py")
+    common = ["--n-base", "20000", "--reads", "100000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--workdir", str(tmp_path / "w")]
+    r1 = subprocess.run([sys.executable, bench] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    a = json.loads(r1.stdout.strip().splitlines()[-1])
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29611", bench, "--gpus", "1"] + common,
+                        env=dict(os.environ, BURST_BENCH_DIST1="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    b = json.loads([ln for ln in r2.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert a["work"]["records"] == b["work"]["records"] > 250000
+    assert "RCCL gather" in b["config"]["parallelism"] and b["n_gpus"] == 1
