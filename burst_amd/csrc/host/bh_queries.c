@@ -9,7 +9,9 @@
 #include <string.h>
 #include <omp.h>
 #include <zlib.h>
+#include <unistd.h>
 
+static int bh_ingest_threads(void);
 typedef struct { const uint8_t *s; uint32_t len; uint64_t ix; } QRef;
 
 /* Whole query file into memory.  gzip files (magic 1f 8b) are inflated; FASTQ (first byte '@': four-line records) is rewritten
@@ -42,8 +44,25 @@ static int slurp_queries(const char *path, char **out, uint64_t *out_sz) {
 		rewind(f);
 		dump = malloc(sz + 17);
 		if (!dump) { fclose(f); return bh_set_error(BH_E_OOM, "OOM reading queries"); }
-		if (fread(dump, 1, sz, f) != sz) { fclose(f); free(dump); return bh_set_error(BH_E_IO, "short read on %s", path); }
+		/* pieces of 32 MB side by side (a single fread of a cached multi-gigabyte file is one thread's memcpy) */
+		const int fd = fileno(f);
+		const uint64_t piece = 32u << 20, np = (sz + piece - 1) / piece;
+		int bad = 0;
+		#pragma omp parallel for num_threads(bh_ingest_threads()) schedule(dynamic, 1) if (np > 1)
+		for (uint64_t k = 0; k < np; ++k) {
+			uint64_t o = k * piece; const uint64_t e = o + piece < sz ? o + piece : sz;
+			while (o < e) {
+				const ssize_t g = pread(fd, dump + o, (size_t)(e - o), (off_t)o);
+				if (g <= 0) {
+					#pragma omp atomic write
+					bad = 1;
+					break;
+				}
+				o += (uint64_t)g;
+			}
+		}
 		fclose(f);
+		if (bad) { free(dump); return bh_set_error(BH_E_IO, "short read on %s", path); }
 	}
 	if (sz && dump[0] == '@') {      /* FASTQ: keep lines 1 and 2 of every four, '@' -> '>' */
 		uint64_t r = 0, w = 0, line = 0;
@@ -119,6 +138,38 @@ void bh_queries_free(BhQueries *q) {
 	memset(q, 0, sizeof *q);
 }
 
+/* accelerator bins (burst.c:3124-3141): bad = too short / too many errors for the k-mer guarantee / > 5 strongly
+ * ambiguous symbols; ambiguous = any symbol beyond A/C/G/T.  Clear and ambiguous entries use the device prefilter
+ * (words with ambiguous symbols simply do not vote there and the guaranteed count shrinks accordingly; the library
+ * falls back to the exhaustive route by itself when no word is guaranteed); bad ones are exhaustive (burst.c:4320).
+ * Separate from bh_queries_load so that a caller that reads the queries BESIDE the database (the accelerator file says
+ * which K it was built with) can bin them afterwards. */
+void bh_queries_bins(BhQueries *Q, int do_accel, int K, int z) {
+	const uint64_t numEntries = Q->numEntries;
+	uint64_t nClear = 0, nAmbig = 0, nBad = 0;
+	#pragma omp parallel for num_threads(bh_ingest_threads()) reduction(+:nClear, nAmbig, nBad) schedule(static)
+	for (uint64_t e = 0; e < numEntries; ++e) {
+		if (!do_accel) { Q->flags[e] = BHIP_Q_EXHAUSTIVE; continue; }
+		const uint32_t len = Q->len[Q->six[e]], ed = Q->ed[Q->six[e]];
+		const uint8_t *s = Q->codes + Q->qoff[e];
+		int stat = 1;
+		if (len < (uint32_t)K || ed >= len / (uint32_t)K) stat = 2;
+		else {
+			uint32_t totN = 0;
+			for (uint32_t j = 0; j < len; ++j) {
+				if ((totN += s[j] > 4 + z) > 5) { stat = 2; break; }
+				else if (s[j] > 4) stat = 0;
+			}
+		}
+		/* the reference demotes every "bad" entry to the exhaustive path because its word expansion explodes (burst.c:3134);
+		 * on the device only entries shorter than K must go there -- for the rest libburst_hip works out per entry whether
+		 * any k-mer is still guaranteed (and aligns exhaustively by itself if not), with identical results */
+		Q->flags[e] = len < (uint32_t)K ? BHIP_Q_EXHAUSTIVE : BHIP_Q_PREFILTER;
+		if (stat == 1) ++nClear; else if (stat == 0) ++nAmbig; else ++nBad;
+	}
+	Q->nClear = nClear; Q->nAmbig = nAmbig; Q->nBad = nBad;
+}
+
 int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespace, int do_accel, int K, int z,
                     int skip_ambig, BhQueries *Q) {
 	memset(Q, 0, sizeof *Q);
@@ -144,31 +195,63 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 	if (!heads || !refs) { free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_OOM, "OOM indexing queries"); }
 	uint8_t c2n[256];
 	bh_char2code(c2n);
-	{
-		uint64_t i = 0, n = 0;
-		while (i < sz && n < totQ) {
-			/* header line */
-			char *h = dump + i + 1;
-			char *nl = memchr(h, '\n', sz - (i + 1));
-			if (!nl) nl = dump + sz;
-			char *he = nl;
-			/* the reference strips a carriage return from every record but the FIRST (burst.c:664-668 vs 677-684): there it
-			 * stays in the header and becomes a last query symbol of code 0 */
-			if (n && he > h && he[-1] == '\r') --he;
-			*he = 0; *nl = 0;
-			if (!incl_whitespace) for (char *p = h; *p; ++p) if (*p == ' ' || *p == '\t') { *p = 0; break; }   /* burst.c:2987-2992 */
-			/* sequence line */
-			char *s = nl + 1 <= dump + sz ? nl + 1 : dump + sz;
-			char *nl2 = s < dump + sz ? memchr(s, '\n', (size_t)(dump + sz - s)) : NULL;
-			if (!nl2) nl2 = dump + sz;
-			char *se = nl2;
-			if (n && se > s && se[-1] == '\r') --se;
-			heads[n] = h;
-			refs[n].s = (uint8_t *)s; refs[n].len = (uint32_t)(se - s); refs[n].ix = n;
-			++n;
-			i = (uint64_t)(nl2 - dump) + 1;
+	{	/* Lines alternate header / sequence (burst.c:636-690).  The file is cut into byte ranges; a range owns the lines that START
+		 * in it.  The number of line ends in front of a range gives the number of its first line, so all ranges index their
+		 * records side by side; the line ends are only overwritten (NUL) after every range has found its first line. */
+		const int nt = bh_ingest_threads();
+		uint64_t nr = sz < (1u << 22) ? 1 : (uint64_t)nt * 8;
+		if (getenv("BURST_HOST_INGEST_RANGES") && atoll(getenv("BURST_HOST_INGEST_RANGES")) > 0) nr = (uint64_t)atoll(getenv("BURST_HOST_INGEST_RANGES"));      /* test hook */
+		if (nr > sz) nr = sz ? sz : 1;
+		uint64_t *nlBefore = calloc(nr + 2, sizeof(*nlBefore)), *first = malloc((nr + 2) * sizeof(*first)), *firstLine = malloc((nr + 2) * sizeof(*firstLine));
+		if (!nlBefore || !first || !firstLine) { free(nlBefore); free(first); free(firstLine); free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_OOM, "OOM indexing queries"); }
+		#pragma omp parallel for num_threads(nt) schedule(static, 1)
+		for (uint64_t t = 0; t < nr; ++t) {
+			const uint64_t a = sz * t / nr, b = sz * (t + 1) / nr;
+			uint64_t c = 0;
+			for (const char *p = dump + a, *e = dump + b; p < e && (p = memchr(p, '\n', (size_t)(e - p))); ++p) ++c;
+			nlBefore[t + 1] = c;
+			if (!a) first[t] = 0;
+			else if (dump[a - 1] == '\n') first[t] = a;
+			else { const char *q = memchr(dump + a, '\n', (size_t)(sz - a)); first[t] = q ? (uint64_t)(q - dump) + 1 : sz; }
 		}
-		if (n != totQ) { free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_USAGE, "ERROR: line count != '>' * 2"); }
+		for (uint64_t t = 0; t < nr; ++t) nlBefore[t + 1] += nlBefore[t];
+		for (uint64_t t = 0; t < nr; ++t) {      /* number of the first line that starts in range t = line ends in front of it */
+			const uint64_t a = sz * t / nr;
+			firstLine[t] = nlBefore[t] + ((a && dump[a - 1] != '\n') ? 1 : 0);
+		}
+		/* a record whose lines are missing (a header at the very end of the file has no sequence line) is an empty query */
+		#pragma omp parallel for num_threads(nt) schedule(static)
+		for (uint64_t n = 0; n < totQ; ++n) { heads[n] = dump + sz; refs[n].s = (uint8_t *)dump + sz; refs[n].len = 0; refs[n].ix = n; }
+		#pragma omp parallel for num_threads(nt) schedule(static, 1)
+		for (uint64_t t = 0; t < nr; ++t) {
+			const uint64_t b = sz * (t + 1) / nr;
+			uint64_t i = first[t], line = firstLine[t];
+			for (; i < b && i < sz && line < 2 * totQ; ++line) {
+				char *l = dump + i;
+				char *nl = memchr(l, '\n', (size_t)(sz - i));
+				if (!nl) nl = dump + sz;
+				char *le = nl;
+				const uint64_t n = line >> 1;
+				/* the reference strips a carriage return from every record but the FIRST (burst.c:664-668 vs 677-684): there it
+				 * stays in the header and becomes a last query symbol of code 0 */
+				if (n && le > l && le[-1] == '\r') --le;
+				if (!(line & 1)) {      /* header line */
+					heads[n] = l + 1 <= nl ? l + 1 : nl;
+				} else { refs[n].s = (uint8_t *)l; refs[n].len = (uint32_t)(le - l); refs[n].ix = n; }
+				i = (uint64_t)(nl - dump) + 1;
+			}
+		}
+		/* the line ends (and carriage returns, and the first blank of a header) become terminators: a second sweep, so that no range
+		 * searches for a line end its neighbour has already overwritten */
+		#pragma omp parallel for num_threads(nt) schedule(static)
+		for (uint64_t n = 0; n < totQ; ++n) {
+			char *h = heads[n];
+			char *he = h + strcspn(h, "\n");
+			if (n && he > h && he[-1] == '\r') --he;
+			*he = 0;
+			if (!incl_whitespace) for (char *p = h; *p; ++p) if (*p == ' ' || *p == '\t') { *p = 0; break; }   /* burst.c:2987-2992 */
+		}
+		free(nlBefore); free(first); free(firstLine);
 	}
 	QPH("record index");
 	uint32_t maxLen = 0, minLen = UINT32_MAX;
@@ -285,10 +368,6 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 			Q->six[numUniq + i] = (uint32_t)i; Q->rc[numUniq + i] = 1; Q->emac[numUniq + i] = Q->ed[i];
 		}
 	}
-	/* accelerator bins (burst.c:3124-3141): bad = too short / too many errors for the k-mer guarantee / > 5 strongly
-	 * ambiguous symbols; ambiguous = any symbol beyond A/C/G/T.  Clear and ambiguous entries use the device prefilter
-	 * (words with ambiguous symbols simply do not vote there and the guaranteed count shrinks accordingly; the library
-	 * falls back to the exhaustive route by itself when no word is guaranteed); bad ones are exhaustive (burst.c:4320). */
 	{	/* nibble-packed copy: half the bytes over PCIe per batch */
 		const uint64_t tot = Q->qoff[numEntries], nb4 = (tot + 1) / 2;
 		Q->codes4 = malloc(nb4 + 16);
@@ -299,31 +378,10 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 		memset(Q->codes4 + nb4, 0, 16);
 	}
 	QPH("copy + reverse complement");
-	uint64_t nClear = 0, nAmbig = 0, nBad = 0;
-	#pragma omp parallel for num_threads(bh_ingest_threads()) reduction(+:nClear, nAmbig, nBad) schedule(static)
-	for (uint64_t e = 0; e < numEntries; ++e) {
-		if (!do_accel) { Q->flags[e] = BHIP_Q_EXHAUSTIVE; continue; }
-		const uint32_t len = Q->len[Q->six[e]], ed = Q->ed[Q->six[e]];
-		const uint8_t *s = Q->codes + Q->qoff[e];
-		int stat = 1;
-		if (len < (uint32_t)K || ed >= len / (uint32_t)K) stat = 2;
-		else {
-			uint32_t totN = 0;
-			for (uint32_t j = 0; j < len; ++j) {
-				if ((totN += s[j] > 4 + z) > 5) { stat = 2; break; }
-				else if (s[j] > 4) stat = 0;
-			}
-		}
-		/* the reference demotes every "bad" entry to the exhaustive path because its word expansion explodes (burst.c:3134);
-		 * on the device only entries shorter than K must go there -- for the rest libburst_hip works out per entry whether
-		 * any k-mer is still guaranteed (and aligns exhaustively by itself if not), with identical results */
-		Q->flags[e] = len < (uint32_t)K ? BHIP_Q_EXHAUSTIVE : BHIP_Q_PREFILTER;
-		if (stat == 1) ++nClear; else if (stat == 0) ++nAmbig; else ++nBad;
-	}
-	QPH("bins");
 	Q->totQ = totQ; Q->numUniq = numUniq; Q->numEntries = numEntries;
+	if (!do_accel || K > 0) bh_queries_bins(Q, do_accel, K, z);      /* (K = 0 with an accelerator: the caller does it once K is known) */
+	QPH("bins");
 	Q->maxLen = maxLen; Q->minLen = minLen; Q->maxED = maxED;
-	Q->nClear = nClear; Q->nAmbig = nAmbig; Q->nBad = nBad;
 	free(heads); free(refs);
 	return BH_OK;
 }

@@ -17,6 +17,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <omp.h>
+#include <unistd.h>
+#include <sys/types.h>
 
 typedef struct { const BhipHit *h; } Pod;
 
@@ -26,18 +28,63 @@ static inline void coords(const BhDb *db, const BhipHit *rp, uint32_t rix, uint3
 	if (rp->rc) { *st = b; *ed = a; } else { *st = a; *ed = b; }
 }
 
-static void print_line_tax(FILE *out, const char *qh, const char *rh, const BhipHit *rp, uint32_t qlen, uint32_t st, uint32_t ed, uint64_t col12,
+/* One chunk's text.  The lines are formatted by hand -- a dozen integer conversions and one "%f" per line through fprintf were
+ * most of the report's time -- and must be byte-identical to the reference's fprintf (burst.c:4553-4562). */
+typedef struct { char *p; size_t len, cap; int oom; } LineBuf;
+static inline int lb_room(LineBuf *b, size_t n) {
+	if (b->len + n <= b->cap) return 1;
+	size_t nc = b->cap ? b->cap * 2 : (1u << 20);
+	while (nc < b->len + n) nc *= 2;
+	char *np = realloc(b->p, nc);
+	if (!np) { b->oom = 1; return 0; }
+	b->p = np; b->cap = nc;
+	return 1;
+}
+static inline void lb_str(LineBuf *b, const char *s) { const size_t n = strlen(s); if (lb_room(b, n + 1)) { memcpy(b->p + b->len, s, n); b->len += n; } }
+static inline void lb_chr(LineBuf *b, char c) { if (lb_room(b, 1)) b->p[b->len++] = c; }
+static inline void lb_u64(LineBuf *b, uint64_t v) {
+	char t[24]; int n = 0;
+	do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+	if (lb_room(b, (size_t)n)) while (n) b->p[b->len++] = t[--n];
+}
+static inline void lb_i32(LineBuf *b, int32_t v) { if (v < 0) { lb_chr(b, '-'); lb_u64(b, (uint64_t)(-(int64_t)v)); } else lb_u64(b, (uint64_t)v); }
+/* "%f" of a float promoted to double: a float below 2^24 times 10^6 = 15625 * 2^6 is exact in a double (24 + 14 significant
+ * bits), so rounding that product to the nearest integer, ties to even, IS the correctly rounded six-decimal expansion printf
+ * gives.  Anything else (negative, huge, not finite) goes through snprintf. */
+static inline void lb_pct(LineBuf *b, float pct) {
+	if (!(pct >= 0.0f && pct < 16777216.0f)) { char t[64]; snprintf(t, sizeof t, "%f", pct); lb_str(b, t); return; }
+	const uint64_t n = (uint64_t)__builtin_nearbyint((double)pct * 1e6);
+	lb_u64(b, n / 1000000u);
+	if (lb_room(b, 7)) {
+		uint32_t fr = (uint32_t)(n % 1000000u);
+		char *o = b->p + b->len;
+		o[0] = '.';
+		for (int k = 6; k >= 1; --k) { o[k] = (char)('0' + fr % 10); fr /= 10; }
+		b->len += 7;
+	}
+}
+/* (test entry: the identities of n records as the report prints them, one per line; returns the text length or 0) */
+uint64_t bh_report_format_identities(const float *score, uint64_t n, char *out, uint64_t cap) {
+	LineBuf b = {NULL, 0, 0, 0};
+	for (uint64_t i = 0; i < n; ++i) { lb_pct(&b, score[i] * 100); lb_chr(&b, '\n'); }
+	uint64_t len = b.oom || b.len > cap ? 0 : b.len;
+	if (len) memcpy(out, b.p, len);
+	free(b.p);
+	return len;
+}
+static void print_line_tax(LineBuf *out, const char *qh, const char *rh, const BhipHit *rp, uint32_t qlen, uint32_t st, uint32_t ed, uint64_t col12,
                            int with_tax, const char *taxon) {
 	uint32_t numGap = (uint32_t)rp->gapR + rp->gapQ, numMis = rp->ed - numGap, alLen = qlen + numGap;
 	float pct = rp->score * 100;                                                           /* f32 product, then %f (burst.c:4555) */
-	if (!with_tax)
-		fprintf(out, "%s\t%s\t%f\t%u\t%u\t%u\t%u\t%u\t%d\t%u\t%u\t%lu\n", qh, rh, pct, alLen, numMis, numGap, 1, qlen, (int)st, ed,
-		        (unsigned)rp->ed, (unsigned long)col12);
-	else                                                                                   /* PRINT_MATCH_TAX, burst.c:4558-4562 */
-		fprintf(out, "%s\t%s\t%f\t%u\t%u\t%u\t%u\t%u\t%d\t%u\t%u\t%lu\t%s\n", qh, rh, pct, alLen, numMis, numGap, 1, qlen, (int)st, ed,
-		        (unsigned)rp->ed, (unsigned long)col12, taxon ? taxon : "(null)");
+	/* "%s\t%s\t%f\t%u\t%u\t%u\t%u\t%u\t%d\t%u\t%u\t%lu[\t%s]\n" (PRINT_MATCH / PRINT_MATCH_TAX, burst.c:4553-4562) */
+	lb_str(out, qh); lb_chr(out, '\t'); lb_str(out, rh); lb_chr(out, '\t'); lb_pct(out, pct); lb_chr(out, '\t');
+	lb_u64(out, alLen); lb_chr(out, '\t'); lb_u64(out, numMis); lb_chr(out, '\t'); lb_u64(out, numGap); lb_chr(out, '\t'); lb_chr(out, '1'); lb_chr(out, '\t');
+	lb_u64(out, qlen); lb_chr(out, '\t'); lb_i32(out, (int32_t)st); lb_chr(out, '\t'); lb_u64(out, ed); lb_chr(out, '\t'); lb_u64(out, (unsigned)rp->ed); lb_chr(out, '\t');
+	lb_u64(out, col12);
+	if (with_tax) { lb_chr(out, '\t'); lb_str(out, taxon ? taxon : "(null)"); }
+	lb_chr(out, '\n');
 }
-static void print_line(FILE *out, const char *qh, const char *rh, const BhipHit *rp, uint32_t qlen, uint32_t st, uint32_t ed, uint64_t col12) {
+static void print_line(LineBuf *out, const char *qh, const char *rh, const BhipHit *rp, uint32_t qlen, uint32_t st, uint32_t ed, uint64_t col12) {
 	print_line_tax(out, qh, rh, rp, qlen, st, ed, col12, 0, NULL);
 }
 
@@ -183,8 +230,14 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 		if (oom) { free(start); free(count); free(RefCounts); return bh_set_error(BH_E_OOM, "OOM:report"); }
 	}
 	const uint64_t CH = chunkQ, nChunks = (nU + CH - 1) / CH, chunkGroup = (uint64_t)nThreads * 8;
-	char **cbuf = calloc(nChunks + 1, sizeof(*cbuf)); size_t *clen = calloc(nChunks + 1, sizeof(*clen));
-	if (!cbuf || !clen) { free(cbuf); free(clen); free(start); free(count); free(RefCounts); return bh_set_error(BH_E_OOM, "OOM:report"); }
+	LineBuf *cbuf = calloc(nChunks + 1, sizeof(*cbuf)); uint64_t *coff = calloc(nChunks + 2, sizeof(*coff));
+	if (!cbuf || !coff) { free(cbuf); free(coff); free(start); free(count); free(RefCounts); return bh_set_error(BH_E_OOM, "OOM:report"); }
+	/* the rendered chunks of a group are written side by side at their offsets (pwrite) when the output is a seekable file: one
+	 * thread copying gigabytes into the page cache was the other half of the report's time */
+	fflush(real_out);
+	const int out_fd = fileno(real_out);
+	off_t file_pos = out_fd >= 0 ? lseek(out_fd, 0, SEEK_CUR) : (off_t)-1;
+	const int use_pwrite = file_pos != (off_t)-1;
 	#pragma omp parallel num_threads(nThreads) reduction(+:lines)
 	{
 	uint32_t *RefCache = malloc(capX * 4 + 4), *StCache = malloc(capX * 4 + 4), *RIXcache = malloc(capX * 4 + 4);
@@ -206,13 +259,7 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 	#pragma omp for schedule(dynamic, 1)
 	for (uint64_t ch = cg0; ch < cg1; ++ch) {
 	if (oom) continue;
-	FILE *cs = open_memstream(&cbuf[ch], &clen[ch]);
-	if (!cs) {
-		#pragma omp atomic write
-		oom = 1;
-		continue;
-	}
-	FILE *out = cs;                                          /* the loop body below prints to `out` */
+	LineBuf *out = &cbuf[ch];                                /* the loop body below prints to `out` */
 	const uint64_t i0 = ch * CH, i1 = i0 + CH < nU ? i0 + CH : nU;
 	for (uint64_t i = i0; i < i1; ++i) {
 		uint32_t n; BUILD_LIST(i, n);
@@ -335,17 +382,43 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 			for (uint64_t j = Q->offset[i]; j < Q->offset[i + 1]; ++j) { print_line_tax(out, Q->heads[j], db->refHead[bestrix], best, qlen, st, ed, i, wt, Final); ++lines; }
 		}
 	}
-	fclose(cs);
+	if (out->oom) {
+		#pragma omp atomic write
+		oom = 1;
+	}
 	}
 	#pragma omp single
-	for (uint64_t ch = cg0; ch < cg1; ++ch) {                /* chunks in query order */
-		if (!oom && cbuf[ch] && clen[ch] && fwrite(cbuf[ch], 1, clen[ch], real_out) != clen[ch]) wr = 1;
-		free(cbuf[ch]); cbuf[ch] = NULL;
+	{
+		coff[cg0] = 0;
+		for (uint64_t ch = cg0; ch < cg1; ++ch) coff[ch + 1] = coff[ch] + cbuf[ch].len;      /* chunks in query order */
+		if (!use_pwrite) for (uint64_t ch = cg0; ch < cg1; ++ch) {
+			if (!oom && cbuf[ch].len && fwrite(cbuf[ch].p, 1, cbuf[ch].len, real_out) != cbuf[ch].len) wr = 1;
+			free(cbuf[ch].p); cbuf[ch].p = NULL;
+		}
+	}
+	if (use_pwrite) {
+		#pragma omp for schedule(dynamic, 1)
+		for (uint64_t ch = cg0; ch < cg1; ++ch) {
+			size_t done = 0;
+			while (!oom && done < cbuf[ch].len) {
+				const ssize_t w = pwrite(out_fd, cbuf[ch].p + done, cbuf[ch].len - done, file_pos + (off_t)(coff[ch] + done));
+				if (w <= 0) {
+					#pragma omp atomic write
+					wr = 1;
+					break;
+				}
+				done += (size_t)w;
+			}
+			free(cbuf[ch].p); cbuf[ch].p = NULL;
+		}
+		#pragma omp single
+		file_pos += (off_t)coff[cg1];
 	}
 	}
 	free(RefCache); free(StCache); free(RIXcache); free(RPcache); free(list); free(Taxon); free(Taxa); free(Divergence);
 	}
-	free(cbuf); free(clen);
+	if (use_pwrite && lseek(out_fd, file_pos, SEEK_SET) == (off_t)-1) wr = 1;      /* the stream continues behind what was written */
+	free(cbuf); free(coff);
 	free(start); free(count); free(RefCounts);
 	if (oom) return bh_set_error(BH_E_OOM, "OOM:report");
 	if (wr) return bh_set_error(BH_E_IO, "short write on the output file");

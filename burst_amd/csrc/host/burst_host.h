@@ -101,6 +101,9 @@ typedef struct BhQueries {
 void bh_queries_sort_device(int device);
 int  bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespace, int do_accel, int K, int z,
                      int skip_ambig, BhQueries *q);
+/* prefilter / exhaustive route per entry and the clear / ambiguous / bad counts; bh_queries_load does it itself unless it was
+ * called with do_accel and K = 0 (queries read beside the database, K not known yet) */
+void bh_queries_bins(BhQueries *q, int do_accel, int K, int z);
 void bh_queries_free(BhQueries *q);
 /* page-lock the arrays the device batches are copied from, so that the copies of batch k+1 run beside the kernels of batch k
  * (optional; needs a device) */
@@ -153,6 +156,7 @@ int  bh_report(FILE *out, const BhDb *db, const BhQueries *q, const BhipHit *hit
  * BH_REP_NO_DUPE_HUNT = print every (hit, reference) expansion (diagnostics / tests). */
 #define BH_REP_MERGED_LIST  1
 #define BH_REP_NO_DUPE_HUNT 2
+uint64_t bh_report_format_identities(const float *score, uint64_t n, char *out, uint64_t cap);      /* test entry: "%f" of score * 100 as the report prints it */
 int  bh_report_ex(FILE *out, const BhDb *db, const BhQueries *q, const BhipHit *hits, uint64_t nHits, BhMode mode, int flags, uint64_t *nLines);
 
 /* ---- taxonomy (column 13; parse_taxonomy burst.c:447-479, taxa_lookup 409-440, CAPITALIST interpolation 4781-4829, -bs 4820-4828) ---- */

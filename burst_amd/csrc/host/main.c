@@ -13,6 +13,7 @@
 #include <sys/stat.h>
 #include <time.h>
 #include <omp.h>
+#include <pthread.h>
 
 #define BH_MAX_GPUS BH_MAX_RANKS
 static double wall(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
@@ -34,6 +35,19 @@ static int build_accelerator(BhDb *db, int K, int z, int device, int on_host) {
 		printf(" --> no device accelerator build (%s); using the host builder\n", bh_last_error());
 	}
 	return bh_acx_build(db, K, z);
+}
+
+/* the query pipeline (process_queries, burst.c:2980-3223) on a thread of its own: with an .edx database nothing in it depends on
+ * the database, so the file is read, indexed, sorted and de-duplicated while the main thread reads the database and brings it
+ * onto the devices */
+typedef struct { const char *fn; float thres; int do_rc, incl_ws, do_accel, K, z, skip_ambig; BhQueries *Q; int rc; char err[512]; double secs; } Ingest;
+static void *ingest_main(void *p) {
+	Ingest *a = p;
+	const double t0 = wall();
+	a->rc = bh_queries_load(a->fn, a->thres, a->do_rc, a->incl_ws, a->do_accel, a->K, a->z, a->skip_ambig, a->Q);
+	if (a->rc) snprintf(a->err, sizeof a->err, "%s", bh_last_error());
+	a->secs = wall() - t0;
+	return NULL;
 }
 
 static void usage(void) {
@@ -206,10 +220,18 @@ int main(int argc, char **argv) {
 	#define PHASE(name) do { const double t_ = wall(); printf(" [%-28s %8.3f s]\n", name, t_ - tp); tp = t_; } while (0)
 	int usedb = bh_is_edx(ref_FN);
 	if (usedb < 0) DIE(usedb);
+	BhQueries Q; memset(&Q, 0, sizeof Q);
+	Ingest ing = {query_FN, thres, do_rc, incl_ws, do_accel, K ? K : (accel_dev || !do_accel ? 12 : 0), z, skip_ambig, &Q, 0, "", 0.0};
+	pthread_t ing_thread; int ing_running = 0;
+	bh_queries_sort_device(n_dev_list ? dev_list[0] : (n_gpus_given ? 0 : device));      /* large query files are sorted on the (first) search device */
+	if (usedb && !getenv("BURST_HOST_SERIAL_INGEST")) ing_running = !pthread_create(&ing_thread, NULL, ingest_main, &ing);
+	const int ing_started = ing_running;
+	#define JOIN_INGEST() do { if (ing_running) { pthread_join(ing_thread, NULL); ing_running = 0; } } while (0)
+	#define DIEJ(rc) do { JOIN_INGEST(); DIE(rc); } while (0)
 	if (usedb) {
 		puts("\nEDB database provided. Parsing...");
-		if ((rc = bh_edx_read(ref_FN, &db))) DIE(rc);
-		if (db.xalpha) { fputs("ERROR: DB made with Xalpha; queries can't use Xalpha.\n", stderr); return 1; }
+		if ((rc = bh_edx_read(ref_FN, &db))) DIEJ(rc);
+		if (db.xalpha) { JOIN_INGEST(); fputs("ERROR: DB made with Xalpha; queries can't use Xalpha.\n", stderr); return 1; }
 		printf(" --> EDB: %u refs [%u orig], %u clumps, %u maxR\n", db.totR, db.origTotR, db.numRclumps, db.maxLenR);
 	}
 	if (do_accel && accel_dev) {
@@ -218,26 +240,23 @@ int main(int argc, char **argv) {
 		printf(" --> [Accel] K=%d, built on the device from the database\n", K);
 	} else if (do_accel) {
 		if (!usedb) { fputs("ERROR: an accelerator needs an .edx database\n", stderr); return 1; }
-		if ((rc = bh_acx_read(xcel_FN, K, z, &db))) DIE(rc);      /* K = 0: 12 or 15, whichever the file's exact size says */
+		if ((rc = bh_acx_read(xcel_FN, K, z, &db))) DIEJ(rc);      /* K = 0: 12 or 15, whichever the file's exact size says */
 		K = db.K;
 		printf(" --> [Accel] K=%d, %s format, %u ambiguous clumps\n", K, db.acxFmt ? "LARGE" : "SMALL", db.badSz);
 	}
 	if (tax_FN) {                                                                    /* burst.c:5142-5149 */
-		if ((rc = bh_tax_load(tax_FN, &taxonomy))) DIE(rc);
+		if ((rc = bh_tax_load(tax_FN, &taxonomy))) DIEJ(rc);
 		txo.tax = &taxonomy;
 	}
 	PHASE("database read");
-	BhQueries Q;
-	bh_queries_sort_device(n_dev_list ? dev_list[0] : (n_gpus_given ? 0 : device));      /* large query files are sorted on the (first) search device */
-	if ((rc = bh_queries_load(query_FN, thres, do_rc, incl_ws, do_accel, K ? K : 12, z, skip_ambig, &Q))) DIE(rc);
-	printf("Parsed %lu queries, %lu unique [min %u, max %u, maxED %u]; clear %lu, ambiguous %lu, bad %lu\n", (unsigned long)Q.totQ,
-	       (unsigned long)Q.numUniq, Q.minLen, Q.maxLen, Q.maxED, (unsigned long)Q.nClear, (unsigned long)Q.nAmbig, (unsigned long)Q.nBad);
-	PHASE("queries parsed, sorted");
-	if (!usedb) {
+	if (!usedb) {      /* direct FASTA references: their clumps depend on the longest query (burst.c:5151), the queries come first */
+		ingest_main(&ing);
+		if (ing.rc) { fprintf(stderr, "%s\n", ing.err); return code_to_exit(ing.rc); }
+		printf("Parsed %lu queries, %lu unique [min %u, max %u, maxED %u]; clear %lu, ambiguous %lu, bad %lu\n", (unsigned long)Q.totQ,
+		       (unsigned long)Q.numUniq, Q.minLen, Q.maxLen, Q.maxED, (unsigned long)Q.nClear, (unsigned long)Q.nAmbig, (unsigned long)Q.nBad);
+		PHASE("queries parsed, sorted");
 		if ((rc = bh_db_from_fasta(ref_FN, Q.maxLen, thres, do_shear, shear_amt, dedupe, &db))) DIE(rc);
 		printf("There are %u references and hence %u clumps\n", db.totR, db.numRclumps);
-	} else if (db.shear && (uint32_t)(Q.maxLen / thres) > db.shear) {                /* burst.c:5152-5156 */
-		fputs("ERROR: DB incompatible with selected queries/identity.\n", stderr); return 1;
 	}
 	/* Multi-GPU (--gpus N): one host thread and one device handle per GPU (bh_search_multi, bh_multi.c).  --shard queries (default):
 	 * the database replicated, unique queries [r U / N, (r+1) U / N) on rank r (a forward entry and its reverse complement stay
@@ -274,6 +293,19 @@ int main(int argc, char **argv) {
 	for (int r = 0; r < n_gpus; ++r) { char nm[256]; int ncu = 0; uint64_t hbm = 0; if (!bhip_device_info(hhs[r], nm, sizeof nm, &ncu, &hbm)) printf("Device %d: %s, %d CUs, %.0f GiB\n", dev_list[r], nm, ncu, hbm / 1073741824.0); }
 	if (shard_db && n_gpus > 1) for (int r = 0; r < n_gpus; ++r) printf("Rank %d: clumps [%u, %u)\n", r, ranks[r].c0, ranks[r].c0 + slices[r].numRclumps);
 	PHASE("device database upload");
+	if (usedb) {
+		JOIN_INGEST();
+		if (!ing_started) ingest_main(&ing);      /* (no thread: read them now) */
+		if (ing.rc) { fprintf(stderr, "%s\n", ing.err); return code_to_exit(ing.rc); }
+		if (do_accel && !ing.K) bh_queries_bins(&Q, do_accel, K, z);        /* K came with the accelerator file */
+		printf("Parsed %lu queries, %lu unique [min %u, max %u, maxED %u]; clear %lu, ambiguous %lu, bad %lu\n", (unsigned long)Q.totQ,
+		       (unsigned long)Q.numUniq, Q.minLen, Q.maxLen, Q.maxED, (unsigned long)Q.nClear, (unsigned long)Q.nAmbig, (unsigned long)Q.nBad);
+		if (db.shear && (uint32_t)(Q.maxLen / thres) > db.shear) {                /* burst.c:5152-5156 */
+			fputs("ERROR: DB incompatible with selected queries/identity.\n", stderr); return 1;
+		}
+		printf(" [%-28s %8.3f s%s; waited for %.3f s]\n", "queries parsed, sorted", ing.secs, ing_started ? ", on a thread beside the database phases" : "", wall() - tp);
+		tp = wall();
+	}
 	bh_queries_pin(&Q);
 	PHASE("query arrays page-locked");
 	for (int r = 0; r < n_gpus; ++r) {

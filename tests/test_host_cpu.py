@@ -142,3 +142,29 @@ def test_fastq_and_gzip_queries_load_like_fasta(tmp_path):
     c4 = np.frombuffer(base[7], np.uint8)
     pad = np.concatenate([codes, np.zeros(1, np.uint8)])
     assert np.array_equal(c4, (pad[0:len(c4) * 2:2] & 15) | ((pad[1:len(c4) * 2:2] & 15) << 4))
+
+
+def test_report_identity_column_equals_printf():
+    """the report formats its lines by hand; column 3 must be what the reference's fprintf("%f") prints for the f32 product
+    score * 100 (burst.c:4553-4557) -- compared for every identity 1 - ed / (len + gapQ) with len up to 1 100, for the products'
+    float neighbours, and for values outside the usual range (which take the snprintf path)"""
+    import ctypes as C
+    import numpy as np
+    lib = C.CDLL(os.path.join(ROOT, "burst_amd", "libburst_host.so"))
+    lib.bh_report_format_identities.restype = C.c_uint64
+    lib.bh_report_format_identities.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64]
+    ln = np.arange(1, 1101, dtype=np.float32)[None, :, None]
+    ed = np.arange(0, 255, dtype=np.float32)[:, None, None]
+    gq = np.arange(0, 4, dtype=np.float32)[None, None, :]
+    score = (np.float32(1.0) - ed / (ln + gq)).astype(np.float32).reshape(-1)
+    score = np.unique(score)
+    extra = np.array([0.0, 1.0, 0.5, 1e-7, 0.999999, 0.9999995, 123456.789, -0.25, 3.0e7, np.inf], np.float32)
+    vals = np.concatenate([score, np.nextafter(score, np.float32(2)), np.nextafter(score, np.float32(-2)), extra]).astype(np.float32)
+    buf = C.create_string_buffer(len(vals) * 48)
+    n = lib.bh_report_format_identities(vals.ctypes.data, len(vals), buf, len(buf))
+    got = buf.raw[:n].decode().split("\n")[:-1]
+    pct = (vals * np.float32(100)).astype(np.float32)
+    want = ["%f" % float(v) for v in pct]
+    assert len(got) == len(want) > 500000
+    bad = [(g, w) for g, w in zip(got, want) if g != w]
+    assert not bad, bad[:5]

@@ -3,8 +3,8 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-$R/gpurun_out/cli_phases.txt}
 D=${BURST_BENCH_DIR:-/tmp/burst_amd_bench}
-python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2>&1
-EDX=$(ls $D/db_*_k15.edx | head -1); ACX=${EDX%.edx}.acx; READS=$(ls $D/reads_8000000_l100_*.fa | head -1)
+python $R/bench.py --no-cpu-baseline --no-end-to-end --steps 2 --warmup 1 > /dev/null 2>&1
+EDX=$(ls $D/db_*_k15.edx | head -1); READS=$(ls $D/reads_8000000_l100_*.fa | head -1)
 if [ -n "$CLI_READS" ]; then      # a longer job: CLI_READS distinct synthetic reads of the same kind (other seed)
   BIG=$D/cli_reads_$CLI_READS.fa
   [ -f $BIG ] || python3 -c "
@@ -15,9 +15,9 @@ host.synth_reads(glob.glob('$D/refs_*_k15.fa')[0], '$BIG', $CLI_READS, 100, [0, 
   READS=$BIG
 fi
 {
-  echo "# burst_hip -r $(basename $EDX) -a $(basename $ACX) -q $(basename $READS) -m BEST -i 0.98   (2 M-read batches)"
+  echo "# burst_hip -r $(basename $EDX) -ad -k 15 -q $(basename $READS) -m BEST -i 0.98   (accelerator built on the device, 2 M-read batches)"
   for i in 1 2; do
-    $R/burst_amd/burst_hip -r $EDX -a $ACX -q $READS -o $D/cli.b6 -m BEST -i 0.98 | grep -E "^ \[|Search complete|Parsed|Alignment time|Wrote"
+    BURST_HOST_DEBUG=1 $R/burst_amd/burst_hip -r $EDX -ad -k 15 -q $READS -o $D/cli.b6 -m BEST -i 0.98 2>&1 | grep -E "^ \[|Search complete|Parsed|Alignment time|Wrote|bh_queries\]|query sort"
     echo
   done
   NR=$(grep -c '^>' $READS)
