@@ -34,6 +34,7 @@ int bh_is_edx(const char *path) {
 #define ALLOC(dst, bytes) do { (dst) = own(db, malloc((size_t)(bytes) + 1)); if (!(dst)) { fclose(in); bh_db_free(db); \
 	return bh_set_error(BH_E_OOM, "OOM:read_edb"); } } while (0)
 
+static int read_region(const char *path, uint64_t off, void *dst, uint64_t n);
 static int derive_refixsrt(BhDb *db) {
 	if (db->refDedupIx) {                                        /* burst.c:3688-3693 */
 		db->refIxSrt = own(db, malloc((size_t)db->totR * sizeof(uint32_t) + 4));
@@ -92,7 +93,10 @@ int bh_edx_read(const char *path, BhDb *db) {
 	}
 	db->maxLenR = maxL;
 	ALLOC(db->packed, (words + 1) * 16);
-	RD(db->packed, 16, words);
+	if (words * 16 < (64u << 20)) RD(db->packed, 16, words);
+	else if (read_region(path, (uint64_t)ftello(in), db->packed, words * 16)) {      /* gigabytes: several threads copy out of the page cache */
+		fclose(in); bh_db_free(db); return bh_set_error(BH_E_USAGE, "ERROR: truncated database %s", path);
+	}
 	db->packedWords = words;
 	(void)hasFP;   /* fingerprint tables, if any, follow and are ignored (-f is out of scope) */
 	fclose(in);
@@ -115,7 +119,7 @@ static int read_region(const char *path, uint64_t off, void *dst, uint64_t n) {
 	const uint64_t chunk = 64ull << 20;
 	const uint64_t nchunks = (n + chunk - 1) / chunk;
 	int bad = 0;
-	int team = omp_get_max_threads(); if (team > 8) team = 8;
+	int team = omp_get_max_threads(); if (team > 16) team = 16;
 	#pragma omp parallel num_threads(team)
 	{
 		FILE *f = fopen(path, "rb");

@@ -19,6 +19,9 @@
 #include <omp.h>
 #include <unistd.h>
 #include <sys/types.h>
+#include <sys/stat.h>
+#include <sys/mman.h>
+#include <fcntl.h>
 
 typedef struct { const BhipHit *h; } Pod;
 
@@ -134,6 +137,9 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 	const int merged = flags & BH_REP_MERGED_LIST, nodupe = flags & BH_REP_NO_DUPE_HUNT;
 	uint64_t lines = 0;
 	g_nodupe = nodupe;
+	const int dbg = getenv("BURST_HOST_DEBUG") != NULL;
+	const double t_begin = omp_get_wtime();
+	double t_render = 0, t_write = 0;
 	/* per-entry ranges (records of one entry are contiguous) */
 	uint64_t *start = calloc(nE + 1, sizeof(*start)); uint32_t *count = calloc(nE + 1, sizeof(*count));
 	if (!start || !count) { free(start); free(count); return bh_set_error(BH_E_OOM, "OOM:report"); }
@@ -229,6 +235,7 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 		}
 		if (oom) { free(start); free(count); free(RefCounts); return bh_set_error(BH_E_OOM, "OOM:report"); }
 	}
+	const double t_pre = omp_get_wtime();
 	const uint64_t CH = chunkQ, nChunks = (nU + CH - 1) / CH, chunkGroup = (uint64_t)nThreads * 8;
 	LineBuf *cbuf = calloc(nChunks + 1, sizeof(*cbuf)); uint64_t *coff = calloc(nChunks + 2, sizeof(*coff));
 	if (!cbuf || !coff) { free(cbuf); free(coff); free(start); free(count); free(RefCounts); return bh_set_error(BH_E_OOM, "OOM:report"); }
@@ -237,7 +244,18 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 	fflush(real_out);
 	const int out_fd = fileno(real_out);
 	off_t file_pos = out_fd >= 0 ? lseek(out_fd, 0, SEEK_CUR) : (off_t)-1;
-	const int use_pwrite = file_pos != (off_t)-1;
+	int use_pwrite = file_pos != (off_t)-1;      /* 0 = fwrite by one thread, 1 = pwrite side by side, 2 = copies into a shared mapping side by side */
+	/* measured on the GPU box (32 M lines, 2.4 GB, 32 threads): one thread's fwrite 0.3-0.5 s, pwrite side by side 0.6 s (the
+	 * writers queue on the file's lock), a shared mapping 1.6 s (page faults): one writer it is, beside the next group's rendering */
+	use_pwrite = 0;
+	if (getenv("BURST_HOST_REPORT_WRITE")) { const int w_ = atoi(getenv("BURST_HOST_REPORT_WRITE")); if (w_ >= 0 && w_ <= 2 && (use_pwrite || !w_)) use_pwrite = w_; }      /* tuning / test hook */
+	char *map_base = NULL; size_t map_len = 0, map_skew = 0;
+	int map_fd = -1;      /* a shared writable mapping needs a descriptor opened for reading and writing: the caller's stream is write-only */
+	if (use_pwrite == 2) {
+		char pth[64]; snprintf(pth, sizeof pth, "/proc/self/fd/%d", out_fd);
+		map_fd = open(pth, O_RDWR);
+		if (map_fd < 0) use_pwrite = 1;
+	}
 	#pragma omp parallel num_threads(nThreads) reduction(+:lines)
 	{
 	uint32_t *RefCache = malloc(capX * 4 + 4), *StCache = malloc(capX * 4 + 4), *RIXcache = malloc(capX * 4 + 4);
@@ -256,11 +274,48 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 	 * memory stays bounded however many queries there are */
 	for (uint64_t cg0 = 0; cg0 < nChunks; cg0 += chunkGroup) {
 	const uint64_t cg1 = cg0 + chunkGroup < nChunks ? cg0 + chunkGroup : nChunks;
+	const double tg0 = omp_get_wtime();
 	#pragma omp for schedule(dynamic, 1)
 	for (uint64_t ch = cg0; ch < cg1; ++ch) {
 	if (oom) continue;
 	LineBuf *out = &cbuf[ch];                                /* the loop body below prints to `out` */
 	const uint64_t i0 = ch * CH, i1 = i0 + CH < nU ? i0 + CH : nU;
+	if (mode == BH_BEST && !wt) {
+		/* BEST without taxonomy, the bulk case (one line per read): a line touches half a dozen unrelated places -- the read's header
+		 * in the query file, the record, the reference's number, its header pointer, its header, its offset -- and formatting it is
+		 * a few hundred instructions, too many for the core to overlap the misses of consecutive lines on its own.  Blocks of 64
+		 * queries go through short loops instead: pick the record (the misses of a block overlap), ask for what the line needs, print. */
+		enum { BLK = 64 };
+		const BhipHit *bb[BLK]; uint32_t brix[BLK]; uint64_t bi[BLK];
+		for (uint64_t ib = i0; ib < i1; ib += BLK) {
+			const uint64_t ie = ib + BLK < i1 ? ib + BLK : i1;
+			uint32_t nb = 0;
+			for (uint64_t i = ib; i < ie; ++i) {
+				uint32_t n; BUILD_LIST(i, n);
+				if (!n) continue;
+				const BhipHit *best = list[0];
+				for (uint32_t k = 1; k < n; ++k) {
+					const BhipHit *rp = list[k];
+					if (rp->ed < best->ed || (rp->ed == best->ed && rp->score > best->score) ||
+					    (rp->ed == best->ed && rp->score == best->score && db->refIxSrt[rp->refIx] < db->refIxSrt[best->refIx])) best = rp;
+				}
+				bb[nb] = best; bi[nb] = i; ++nb;
+				__builtin_prefetch(&db->refIxSrt[best->refIx]);
+				__builtin_prefetch(Q->heads[Q->offset[i]]);
+			}
+			for (uint32_t k = 0; k < nb; ++k) {
+				brix[k] = db->refIxSrt[bb[k]->refIx];
+				__builtin_prefetch(&db->refHead[brix[k]]);
+				if (db->refStart) __builtin_prefetch(&db->refStart[brix[k]]);
+			}
+			for (uint32_t k = 0; k < nb; ++k) __builtin_prefetch(db->refHead[brix[k]]);
+			for (uint32_t k = 0; k < nb; ++k) {
+				const uint64_t i = bi[k]; const uint32_t qlen = Q->len[i];
+				uint32_t st, ed; coords(db, bb[k], brix[k], qlen, &st, &ed);
+				for (uint64_t j = Q->offset[i]; j < Q->offset[i + 1]; ++j) { print_line_tax(out, Q->heads[j], db->refHead[brix[k]], bb[k], qlen, st, ed, i, 0, NULL); ++lines; }
+			}
+		}
+	} else
 	for (uint64_t i = i0; i < i1; ++i) {
 		uint32_t n; BUILD_LIST(i, n);
 		if (!n) continue;
@@ -387,16 +442,46 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 		oom = 1;
 	}
 	}
+	if (!use_pwrite) {
+		/* one thread writes the group (chunks in query order) while the others go on to render the next one: the writer joins them
+		 * when it is done (the loop's schedule is dynamic), and the barrier behind every group keeps at most two groups in memory */
+		#pragma omp single nowait
+		{
+			t_render += omp_get_wtime() - tg0;
+			for (uint64_t ch = cg0; ch < cg1; ++ch) {
+				if (!oom && cbuf[ch].len && fwrite(cbuf[ch].p, 1, cbuf[ch].len, real_out) != cbuf[ch].len) wr = 1;
+				free(cbuf[ch].p); cbuf[ch].p = NULL;
+			}
+			t_write += omp_get_wtime() - tg0;
+		}
+		continue;
+	}
 	#pragma omp single
 	{
+		t_render += omp_get_wtime() - tg0;
 		coff[cg0] = 0;
 		for (uint64_t ch = cg0; ch < cg1; ++ch) coff[ch + 1] = coff[ch] + cbuf[ch].len;      /* chunks in query order */
-		if (!use_pwrite) for (uint64_t ch = cg0; ch < cg1; ++ch) {
-			if (!oom && cbuf[ch].len && fwrite(cbuf[ch].p, 1, cbuf[ch].len, real_out) != cbuf[ch].len) wr = 1;
+	}
+	if (use_pwrite == 2) {      /* the group's range of the file mapped: the threads copy their chunks into the page cache side by side */
+		#pragma omp single
+		{
+			map_base = NULL;
+			const off_t lo = file_pos & ~(off_t)4095;
+			map_len = (size_t)(file_pos - lo) + (size_t)coff[cg1];
+			if (coff[cg1] && !oom) {
+				if (posix_fallocate(out_fd, file_pos, (off_t)coff[cg1])) wr = 1;
+				else { map_base = mmap(NULL, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, map_fd, lo); if (map_base == MAP_FAILED) { map_base = NULL; wr = 1; } }
+			}
+			map_skew = (size_t)(file_pos - lo);
+		}
+		#pragma omp for schedule(dynamic, 1)
+		for (uint64_t ch = cg0; ch < cg1; ++ch) {
+			if (map_base && cbuf[ch].len) memcpy(map_base + map_skew + coff[ch], cbuf[ch].p, cbuf[ch].len);
 			free(cbuf[ch].p); cbuf[ch].p = NULL;
 		}
-	}
-	if (use_pwrite) {
+		#pragma omp single
+		{ if (map_base) munmap(map_base, map_len); file_pos += (off_t)coff[cg1]; }
+	} else if (use_pwrite) {
 		#pragma omp for schedule(dynamic, 1)
 		for (uint64_t ch = cg0; ch < cg1; ++ch) {
 			size_t done = 0;
@@ -412,11 +497,15 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 			free(cbuf[ch].p); cbuf[ch].p = NULL;
 		}
 		#pragma omp single
-		file_pos += (off_t)coff[cg1];
+		{ file_pos += (off_t)coff[cg1]; }
 	}
+	#pragma omp master
+	t_write += omp_get_wtime() - tg0;      /* (pwrite / mapping variants: rendering + writing of the group) */
 	}
 	free(RefCache); free(StCache); free(RIXcache); free(RPcache); free(list); free(Taxon); free(Taxa); free(Divergence);
 	}
+	if (dbg) fprintf(stderr, "[bh_report] %lu lines: tables %.3f s, rendering %.3f s, writing %.3f s (%d threads, %s)\n", (unsigned long)lines, t_pre - t_begin, t_render, t_write - t_render, nThreads, use_pwrite == 2 ? "shared mapping" : use_pwrite ? "pwrite" : "fwrite");
+	if (map_fd >= 0) close(map_fd);
 	if (use_pwrite && lseek(out_fd, file_pos, SEEK_SET) == (off_t)-1) wr = 1;      /* the stream continues behind what was written */
 	free(cbuf); free(coff);
 	free(start); free(count); free(RefCounts);
