@@ -182,6 +182,7 @@ struct Lane {
 	uint32_t launches = 0, prefix_words = 0;
 	uint64_t n_pairs_ex = 0;
 	bool masked = false;
+	bool lean = false;            // the rarely needed launches are left out of this lane's next chain (bhip_align_staged verifies and repeats)
 };
 
 // counters all lanes of a batch share; behind them the per-query record counters and the rank array of the counting sort: the
@@ -250,6 +251,7 @@ struct Handle {
 	int opt_prune = 1;            // second sweep for lanes whose seed count bounds their edit distance above the first sweep's best
 	int opt_lane_min = 32768;     // fewest entries a sub-pipeline is worth opening for
 	int opt_rescore_reg = 1;      // register-band re-scorer for narrow bands (0 = LDS band only)
+	int opt_lean = 1;             // 1 = lanes whose last batch needed none of the rarely used kernels leave them out of the next chain
 	int opt_pf_waves = 0;         // single-wave blocks per CU of the lane-resolved prefilter (0 = as many as the LDS allows, <= 12)
 	int opt_pf_algo = -1;         // 0 = counting filter + exact lane table (k_prefilter_cf), 1 = exact clump hash table in two passes
 	                              // (k_prefilter_mask), -1 = start with 0 and switch a lane to 1 when more than 20 % of its records survive the filter

@@ -93,13 +93,26 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 		if (r0[i] < b) { nBatches += (b - r0[i] + batch_uniq - 1) / batch_uniq; totU += b - r0[i]; }
 	}
 	if (!nBatches) return BH_OK;
-	uint64_t *bu = malloc(nBatches * 2 * sizeof(*bu));
+	uint64_t *bu = malloc((nBatches + 2) * 2 * sizeof(*bu));
 	if (!bu) return bh_set_error(BH_E_OOM, "OOM:batches");
 	{
 		uint64_t k = 0;
 		for (uint32_t i = 0; i < n_ranges; ++i) {
 			const uint64_t b = r1[i] > Q->numUniq ? Q->numUniq : r1[i];
-			for (uint64_t u = r0[i]; u < b; u += batch_uniq) { bu[2 * k] = u; bu[2 * k + 1] = u + batch_uniq <= b ? batch_uniq : b - u; ++k; }
+			for (uint64_t u = r0[i]; u < b; u += batch_uniq) {
+				const uint64_t B = u + batch_uniq <= b ? batch_uniq : b - u;
+				/* The first batch of a call has nothing to hide its staging behind (copies + routing of 2 M reads take about as long as
+				 * aligning them): it goes in three pieces, so that the second and third are staged while the first and second are
+				 * aligned -- two more device calls (each has a fixed cost of a few hundred microseconds), but ~1.5 ms less in front of
+				 * the first records.  BURST_HOST_NO_RAMP=1 keeps it whole. */
+				if (!k && B >= (3u << 17) && !getenv("BURST_HOST_NO_RAMP")) {
+					const uint64_t p = B / 3;
+					bu[0] = u; bu[1] = p; bu[2] = u + p; bu[3] = p; bu[4] = u + 2 * p; bu[5] = B - 2 * p;
+					k = 3; nBatches += 2;
+					continue;
+				}
+				bu[2 * k] = u; bu[2 * k + 1] = B; ++k;
+			}
 		}
 	}
 	const int twoStrand = Q->numEntries > Q->numUniq;

@@ -238,6 +238,8 @@ BHIP_API int bhip_sort_queries(int device, const uint8_t *codes, uint64_t codes_
  * staged and not aligned (after an error).  "seed_ahead": 1 (default) = the seed lookups and match profiles of the next staged
  * batch run while the current one is swept, 0 = in place; "seed_ahead_blocks" (default 2, 0 = unlimited) / "peq_ahead_blocks"
  * (default 16) = 256-thread blocks per CU those kernels get while they share the device with the sweeps.
+ * "lean_launches": 1 (default) = a batch leaves out the launches that only serve rare cases (overflow fallback of the prefilter, clump-level
+ * sweep of its pairs, re-scorers for wide bands) when the previous batch needed none of them; it is run again in full if it turns out to.
  * None of these changes a result. */
 BHIP_API int bhip_set_option(void *handle, const char *name, long long value);
 
