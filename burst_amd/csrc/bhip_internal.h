@@ -15,11 +15,12 @@ struct BhipRawHit {
 	uint32_t e_last;   // (may run into trailing pad columns; k_rescore clamps to ClumpLen)
 };
 
-// A reference lane whose prefix filter fired: flags bit b covers chunks [b << fshift, (b+1) << fshift) of 32 columns.
+// A reference lane whose prefix filter fired: the first and the last group of 8 columns (columns 8g + 1 .. 8g + 8, 1-based) that
+// hold a column with prefix score <= budget.  (32-column flags cost the full-length stage 24 columns of slack per window.)
 struct BhipWin {
 	uint32_t li;       // list position of the query (peq row)
 	uint32_t refIx;
-	uint32_t flags;
+	uint32_t g_first, g_last;
 };
 
 // Routing of a staged batch, filled on the device by k_route (or by the host pass that handles batches with query symbols

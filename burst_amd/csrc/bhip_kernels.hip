@@ -1530,8 +1530,6 @@ __global__ __launch_bounds__(256) void k_myers_prefix(
 		const uint32_t m = (uint32_t)(qoff[q + 1] - qoff[q]), E = qemac[q];
 		const uint32_t P = m < 32u * NWP ? m : 32u * NWP;
 		const uint32_t L = clump_len[c], nchunks = (L + 31) >> 5;
-		uint32_t fshift = 0;
-		while ((nchunks >> fshift) > 32) ++fshift;
 		uint32_t Pv[NWP], Mv[NWP];
 		#pragma unroll
 		for (int w = 0; w < NWP; ++w) {
@@ -1540,28 +1538,34 @@ __global__ __launch_bounds__(256) void k_myers_prefix(
 			Mv[w] = 0;
 		}
 		int score = (int)P;
-		uint32_t flags = 0;
+		uint32_t g_first = 0xFFFFFFFFu, g_last = 0;
 		const uint4 *rp = ref + ref_off[c] * 16 + z;
 		const uint32_t *tab = &s_peq[g][0];
 		for (uint32_t t = 0; t < nchunks; ++t) {
 			const uint4 ch = rp[(uint64_t)t * 16];
 			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
-			int cmin = 0x7FFFFFFF;
 			#pragma unroll
-			for (int i = 0; i < 32; ++i) {
-				const uint32_t sym = (dw[i >> 3] >> (4 * (i & 7))) & 15u;
-				uint32_t Eq[NWP];
+			for (int i8 = 0; i8 < 4; ++i8) {
+				int cmin = 0x7FFFFFFF;
 				#pragma unroll
-				for (int w = 0; w < NWP; ++w) Eq[w] = tab[sym * NWP + w];
-				myers_step<NWP>(Eq, Pv, Mv, score);
-				cmin = score < cmin ? score : cmin;
+				for (int i = 8 * i8; i < 8 * i8 + 8; ++i) {
+					const uint32_t sym = (dw[i >> 3] >> (4 * (i & 7))) & 15u;
+					uint32_t Eq[NWP];
+					#pragma unroll
+					for (int w = 0; w < NWP; ++w) Eq[w] = tab[sym * NWP + w];
+					myers_step<NWP>(Eq, Pv, Mv, score);
+					cmin = score < cmin ? score : cmin;
+				}
+				const bool fl = (uint32_t)cmin <= E;
+				const uint32_t gi = t * 4 + (uint32_t)i8;
+				g_first = fl && gi < g_first ? gi : g_first;
+				g_last = fl ? gi : g_last;
 			}
-			flags |= ((uint32_t)cmin <= E ? 1u : 0u) << (t >> fshift);
 		}
 		const uint32_t refIx = c * 16 + z;
-		if (flags && refIx < tot_refs) {
+		if (g_first != 0xFFFFFFFFu && refIx < tot_refs) {
 			const uint32_t pos = atomicAdd(n_wins, 1u);
-			if (pos < win_cap) { BhipWin w; w.li = li; w.refIx = refIx; w.flags = flags; wins[pos] = w; }
+			if (pos < win_cap) { BhipWin w; w.li = li; w.refIx = refIx; w.g_first = g_first; w.g_last = g_last; wins[pos] = w; }
 		}
 		if (z == 0) { my_cols += L; my_qlen += m; }
 	}
@@ -1605,8 +1609,6 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 		const uint32_t m = (uint32_t)(qoff[q + 1] - qoff[q]), E = qemac[q];
 		const uint32_t P = m < 32u * NWP ? m : 32u * NWP;
 		const uint32_t L = clump_len[c], nchunks = (L + 31) >> 5;
-		uint32_t fshift = 0;
-		while ((nchunks >> fshift) > 32) ++fshift;
 		uint32_t Pv[NWP], Mv[NWP];
 		#pragma unroll
 		for (int w = 0; w < NWP; ++w) {
@@ -1615,7 +1617,7 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 			Mv[w] = 0;
 		}
 		int score = (int)P;
-		uint32_t flags = 0;
+		uint32_t g_first = 0xFFFFFFFFu, g_last = 0;
 		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)z * nchunks;        // lane-major copy
 		const uint32_t *gtab = peqp + (uint64_t)li * 16 * NWP;
 		for (uint32_t t0 = 0; t0 < nchunks; t0 += 4) {      // 4 chunks = 64 contiguous bytes of this lane per round of loads
@@ -1627,22 +1629,28 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 				const uint32_t t = t0 + u;
 				if (t >= nchunks) break;
 				const uint32_t dw[4] = {chs[u].x, chs[u].y, chs[u].z, chs[u].w};
-				int cmin = 0x7FFFFFFF;
 				#pragma unroll
-				for (int k = 0; k < 32; ++k) {
-					const uint32_t sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
-					uint32_t Eq[NWP];
+				for (int k8 = 0; k8 < 4; ++k8) {      // per dword of symbols: the flagged range is kept at a granularity of 8 columns
+					int cmin = 0x7FFFFFFF;
 					#pragma unroll
-					for (int w = 0; w < NWP; ++w) Eq[w] = LDS_TAB ? s_peq[LDS_TAB ? sym * NWP + w : 0][tid] : gtab[sym * NWP + w];
-					myers_step<NWP>(Eq, Pv, Mv, score);
-					cmin = score < cmin ? score : cmin;
+					for (int k = 8 * k8; k < 8 * k8 + 8; ++k) {
+						const uint32_t sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
+						uint32_t Eq[NWP];
+						#pragma unroll
+						for (int w = 0; w < NWP; ++w) Eq[w] = LDS_TAB ? s_peq[LDS_TAB ? sym * NWP + w : 0][tid] : gtab[sym * NWP + w];
+						myers_step<NWP>(Eq, Pv, Mv, score);
+						cmin = score < cmin ? score : cmin;
+					}
+					const bool fl = (uint32_t)cmin <= E;
+					const uint32_t gi = t * 4 + (uint32_t)k8;
+					g_first = fl && gi < g_first ? gi : g_first;
+					g_last = fl ? gi : g_last;
 				}
-				flags |= ((uint32_t)cmin <= E ? 1u : 0u) << (t >> fshift);
 			}
 		}
-		if (flags) {
+		if (g_first != 0xFFFFFFFFu) {
 			const uint32_t pos = atomicAdd(n_wins, 1u);
-			if (pos < win_cap) { BhipWin w; w.li = li; w.refIx = refIx; w.flags = flags; wins[pos] = w; }
+			if (pos < win_cap) { BhipWin w; w.li = li; w.refIx = refIx; w.g_first = g_first; w.g_last = g_last; wins[pos] = w; }
 		}
 		my_cols += L;
 	}
@@ -1709,18 +1717,17 @@ __global__ __launch_bounds__(256) void k_myers_window(
 		const uint32_t m = (uint32_t)(qoff[q + 1] - qoff[q]), E = qemac[q];
 		const uint32_t P = m < 32u * (uint32_t)NWP ? m : 32u * (uint32_t)NWP;
 		const uint32_t c = w.refIx >> 4, z = w.refIx & 15, L = clump_len[c], nchunks = (L + 31) >> 5;
-		uint32_t fshift = 0;
-		while ((nchunks >> fshift) > 32) ++fshift;
-		const uint32_t fA = (uint32_t)__builtin_ctz(w.flags) << fshift;                       // first flagged chunk
-		uint32_t fB = ((32u - (uint32_t)__builtin_clz(w.flags)) << fshift) - 1u;             // last flagged chunk
-		if (fB >= nchunks) fB = nchunks - 1;
-		const int col_lo = (int)(fA * 32 + 2) - (int)(P + E), col_hi = (int)((fB + 1) * 32 + (m - P) + E);
+		// prefix ends lie in the 1-based columns 8 g_first + 1 .. 8 g_last + 8: an alignment ending its prefix there starts no earlier
+		// than P + E - 1 columns before and ends no later than (m - P) + E columns behind
+		uint32_t gB = w.g_last;
+		if (gB >= nchunks * 4) gB = nchunks * 4 - 1;
+		const int col_lo = (int)(w.g_first * 8 + 2) - (int)(P + E), col_hi = (int)((gB + 1) * 8 + (m - P) + E);
 		// swept columns [c_lo, c_hi] (0-based), at a granularity of 8 (one dword of reference symbols): a fresh column state is a
 		// valid start anywhere (free start of the semi-global alignment), so nothing before the first needed column is swept
 		const uint32_t c_lo = col_lo > 1 ? (uint32_t)(col_lo - 1) : 0u;
 		uint32_t c_hi = (uint32_t)(col_hi - 1);
 		if (c_hi >= nchunks * 32) c_hi = nchunks * 32 - 1;
-		const uint32_t tA = c_lo >> 5, tB = c_hi >> 5, gA = (c_lo & 31u) >> 3, gB = (c_hi & 31u) >> 3;
+		const uint32_t tA = c_lo >> 5, tB = c_hi >> 5, gA = (c_lo & 31u) >> 3, gE = (c_hi & 31u) >> 3;
 		uint32_t Pv[NW], Mv[NW];
 		#pragma unroll
 		for (int k = 0; k < NW; ++k) {
@@ -1740,7 +1747,7 @@ __global__ __launch_bounds__(256) void k_myers_window(
 		for (uint32_t t = tA; t <= tB; ++t) {
 			const uint4 ch = ch_next;
 			if (t < tB) ch_next = rp[t + 1];          // the next 16 bytes of this lane while this chunk is swept
-			const uint32_t g0 = t == tA ? gA : 0u, g1 = t == tB ? gB : 3u;
+			const uint32_t g0 = t == tA ? gA : 0u, g1 = t == tB ? gE : 3u;
 			for (uint32_t gq = g0; gq <= g1; ++gq) {
 				const uint32_t d = gq == 0 ? ch.x : gq == 1 ? ch.y : gq == 2 ? ch.z : ch.w;
 				#pragma unroll
@@ -1763,7 +1770,7 @@ __global__ __launch_bounds__(256) void k_myers_window(
 				}
 			}
 		}
-		my_cols += ((tB * 4 + gB) - (tA * 4 + gA) + 1) * 8;
+		my_cols += ((tB * 4 + gE) - (tA * 4 + gA) + 1) * 8;
 		if ((uint32_t)bestS <= E) {
 			const uint32_t pos = atomicAdd(n_raw, 1u);
 			if (pos < raw_cap) {
