@@ -239,6 +239,7 @@ def main():
 
     from burst_amd import capi, host
     refs, edx, acx, reads_fa, done = build_inputs(args.workdir, args, rank)
+    os.sync()          # the files just written go to disk now, not beside the timed region (their write-back shares the PCIe root and the memory bus)
     if use_dist:
         dist.barrier()
     while not (os.path.exists(done) and os.path.exists(reads_fa + ".done")):

@@ -38,7 +38,7 @@ class BhipStats(C.Structure):
 
 class BhipQuerySpan(C.Structure):
     _fields_ = [("codes", C.c_void_p), ("codes4", C.c_void_p), ("off", C.c_void_p), ("emac", C.c_void_p), ("rc", C.c_void_p), ("flags", C.c_void_p),
-                ("n", C.c_uint32), ("q_base", C.c_uint32)]
+                ("n", C.c_uint32), ("q_base", C.c_uint32), ("codes2", C.c_void_p), ("len", C.c_void_p)]
 
 
 EXPORTS = ["bhip_init", "bhip_stage_queries", "bhip_align_staged", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_set_option", "bhip_get_stats",
@@ -253,6 +253,10 @@ class Device:
             arr[k].rc = rc.ctypes.data if rc is not None else None
             arr[k].flags = fl.ctypes.data if fl is not None else None
             arr[k].n, arr[k].q_base = n, int(sp.get("q_base", 0))
+            c2, ln = _arr(sp.get("codes2"), np.uint8), _arr(sp.get("len"), np.uint16)
+            keep += [c2, ln]
+            arr[k].codes2 = c2.ctypes.data if c2 is not None else None
+            arr[k].len = ln.ctypes.data if ln is not None else None
             n_tot += n
         self._span_keep = getattr(self, "_span_keep", [])[-2:] + [keep]
         self._staged_n = n_tot

@@ -297,8 +297,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	HIPCHK(hipEventRecord(L->ev_pf[cls][2], st));
 	++L->pf_launches;
 	L->pf_algo_used = algo;
-	// dense fallback for overflowed queries (clump-level pairs); left out while the lane runs lean (see Lane::lean)
-	if (L->lean) return 0;
+	// dense fallback for overflowed queries (clump-level pairs)
 	const uint32_t *bad = h->bad.as<uint32_t>();
 	const bool narrow = h->cur->st_maxlen < 255u + (uint32_t)h->K;
 	const size_t lds_w = ((size_t)(h->n_clumps + (narrow ? 3 : 1)) / (narrow ? 4 : 2)) * 4 + 1536u * 4 + 512u * 8 + 512u * 4 + 16;
@@ -496,7 +495,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		HIPCHK(hipEventRecord(ce[6], sw));
 		if (n_pf) {
 			if (masked) launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 4u * (uint32_t)h->opt_sweep_blocks, L->tasks.as<uint2>(), &dc->n_tasks_cls[cls], qlist, L->wins.as<BhipWin>(), &dc->n_wins_cls[cls], dc);
-			if (NWP) { if (!(masked && L->lean)) launch_prefix(h, L, sw, NWP, grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, &dc->n_wins_cls[cls], dc); }
+			if (NWP) launch_prefix(h, L, sw, NWP, grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, &dc->n_wins_cls[cls], dc);
 			else launch_myers(h, L, sw, cls, grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, L->raw.as<BhipRawHit>(),
 				&dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
 			HIPCHK(hipGetLastError());
@@ -557,17 +556,15 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 			h->ref_lane.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, &sc->err)
 		RS_LAUNCH(0, 16);
 		HIPCHK(hipGetLastError());
-		if (!L->lean) {
-			RS_LAUNCH(1, 12);
-			HIPCHK(hipGetLastError());
-			RS_LAUNCH(2, 8);          // 32 / 40 / 48 diagonals (usually empty lists: large budgets, or repeats that stretch the end-column range)
-			HIPCHK(hipGetLastError());
-		}
+		RS_LAUNCH(1, 12);
+		HIPCHK(hipGetLastError());
+		RS_LAUNCH(2, 8);          // 32 / 40 / 48 diagonals (usually empty lists: large budgets, or repeats that stretch the end-column range)
+		HIPCHK(hipGetLastError());
 #undef RS_LAUNCH
 	}
 	const uint32_t grid_rs = (uint32_t)h->n_cu * (h->opt_rescore_reg ? 4 : 16);
 	const size_t lds_rs = (size_t)(band_rows + 1 + qw + rw) * 256;
-	if (!(L->lean && h->opt_rescore_reg)) hipLaunchKernelGGL(k_rescore<false>, dim3(grid_rs), dim3(64), lds_rs, po, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap,
+	hipLaunchKernelGGL(k_rescore<false>, dim3(grid_rs), dim3(64), lds_rs, po, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap,
 		L->rs_lists.as<uint32_t>() + (size_t)9 * L->raw_cap, &dc->n_rs[9], h->best.as<uint32_t>(), all_hits, h->cur->qcodes.as<uint8_t>(), h->cur->qoff.as<uint64_t>(),
 		h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr, h->cur->st_has_rc ? h->cur->qrc.as<uint8_t>() : nullptr, h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(),
 		h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, L->wide.as<uint32_t>(),
@@ -723,22 +720,6 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		}
 		// capacity checks (first call of a workload: grow and redo)
 		bool retry = false;
-		// Lean chains.  Six of a batch's launches serve cases most workloads never produce: the dense fallback prefilter for queries
-		// whose table overflowed, the clump-level prefix sweep over its pairs, the re-scorers for bands of 16 diagonals and more.
-		// Each costs a dispatch and a dependency on the chain although it finds its list empty.  A lane whose last batch needed
-		// none of them runs the next batch without them; the counters that say whether one WAS needed come from kernels that always
-		// run (the prefilter, the classifier), so a lean batch that turns out to need one is simply run again in full.
-		for (uint32_t l = 0; l < nl; ++l) {
-			Lane *L = h->lanes[l];
-			if (!L->n_entries) continue;
-			const Counters &c = L->hc;
-			bool rare = c.n_fb != 0 || c.n_wide != 0;
-			for (int cls = 0; cls < kNumClasses; ++cls) rare |= L->pf_masked[cls] && c.n_cand_cls[cls] != 0;
-			for (int k = 4; k <= 9; ++k) rare |= c.n_rs[k] != 0;
-			if (L->lean && rare) { L->lean = false; retry = true; }                        // this batch again, with everything
-			else if (!rare && h->opt_lean && L->masked && h->opt_rescore_reg) L->lean = true;   // the next batch of this lane runs lean
-			else if (rare || !h->opt_lean) L->lean = false;
-		}
 		for (uint32_t l = 0; l < nl; ++l) {
 			Lane *L = h->lanes[l];
 			if (!L->n_entries) continue;

@@ -61,6 +61,7 @@ template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_
 	unsigned long long, uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t);
 __global__ void k_pack_queries(const uint8_t *, const uint64_t *, uint32_t, uint32_t, uint32_t *);
 __global__ void k_unpack4(const uint8_t *, uint64_t, uint64_t, uint8_t *);
+__global__ void k_unpack2(const uint8_t *, uint64_t, uint64_t, uint8_t *);
 __global__ void k_span_fill(const uint64_t *, uint32_t, uint32_t, uint64_t, uint32_t, uint64_t *, uint32_t *, uint32_t *);
 __global__ void k_route(const uint64_t *, const uint32_t *, uint32_t, const uint16_t *, const uint32_t *, const uint8_t *, uint32_t, uint32_t, uint32_t, int, int, int,
 	uint32_t *, uint8_t *, uint32_t *, BhipStageInfo *);
@@ -119,7 +120,7 @@ struct Counters {
 // the budgets reduced (qcodes_s ...); k_junk_adjust adds the counts back before the re-scorer, which works on the original
 // queries with the real cost table.  Without such symbols the search view is the batch itself.
 struct StageSlot {
-	DBuf qcodes, qcodes4, qoff, qemac, qsix, qrc, qflags, qmap, off_raw, plan, qpack, key, key_sorted, idx, idx_sorted, sort_tmp, info;
+	DBuf qcodes, qcodes4, qlen16, qoff, qemac, qsix, qrc, qflags, qmap, off_raw, plan, qpack, key, key_sorted, idx, idx_sorted, sort_tmp, info;
 	DBuf qcodes_s, qoff_s, qemac_s, qpack_s, nx, nx_six;
 	BhipStageInfo *info_pinned = nullptr;
 	hipEvent_t ev_begin = nullptr, ev_done = nullptr;
@@ -134,7 +135,7 @@ struct StageSlot {
 	uint32_t npf[16][7], nex[16][7], maxE[16][7], maxwords[16][7], qlist_off[16][7], maxlen_lane[16], n_entries_lane[16];
 	uint64_t seed_words[16][7];
 	void release_all() {
-		DBuf *b[] = {&qcodes, &qcodes4, &qoff, &qemac, &qsix, &qrc, &qflags, &qmap, &off_raw, &plan, &qpack, &key, &key_sorted, &idx, &idx_sorted,
+		DBuf *b[] = {&qcodes, &qcodes4, &qlen16, &qoff, &qemac, &qsix, &qrc, &qflags, &qmap, &off_raw, &plan, &qpack, &key, &key_sorted, &idx, &idx_sorted,
 			&sort_tmp, &info, &qcodes_s, &qoff_s, &qemac_s, &qpack_s, &nx, &nx_six};
 		for (DBuf *x : b) x->release();
 		if (info_pinned) { (void)hipHostFree(info_pinned); info_pinned = nullptr; }
@@ -182,7 +183,6 @@ struct Lane {
 	uint32_t launches = 0, prefix_words = 0;
 	uint64_t n_pairs_ex = 0;
 	bool masked = false;
-	bool lean = false;            // the rarely needed launches are left out of this lane's next chain (bhip_align_staged verifies and repeats)
 };
 
 // counters all lanes of a batch share; behind them the per-query record counters and the rank array of the counting sort: the
@@ -251,7 +251,6 @@ struct Handle {
 	int opt_prune = 1;            // second sweep for lanes whose seed count bounds their edit distance above the first sweep's best
 	int opt_lane_min = 32768;     // fewest entries a sub-pipeline is worth opening for
 	int opt_rescore_reg = 1;      // register-band re-scorer for narrow bands (0 = LDS band only)
-	int opt_lean = 1;             // 1 = lanes whose last batch needed none of the rarely used kernels leave them out of the next chain
 	int opt_pf_waves = 0;         // single-wave blocks per CU of the lane-resolved prefilter (0 = as many as the LDS allows, <= 12)
 	int opt_pf_algo = -1;         // 0 = counting filter + exact lane table (k_prefilter_cf), 1 = exact clump hash table in two passes
 	                              // (k_prefilter_mask), -1 = start with 0 and switch a lane to 1 when more than 20 % of its records survive the filter

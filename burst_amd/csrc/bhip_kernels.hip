@@ -1885,6 +1885,32 @@ __global__ void k_unpack4(const uint8_t *__restrict__ packed, uint64_t src0, uin
 	}
 }
 
+// the same for symbols uploaded FOUR per byte (spans of A/C/G/T only: code - 1 in two bits): n_sym symbols starting at symbol
+// src0 of `packed` go to dst[0 .. n_sym) as codes 1..4
+__global__ void k_unpack2(const uint8_t *__restrict__ packed, uint64_t src0, uint64_t n_sym, uint8_t *__restrict__ dst) {
+	const uint32_t head = (uint32_t)((uintptr_t)dst & 3u);
+	uint8_t *base = dst - head;
+	const uint32_t phead = (uint32_t)((uintptr_t)packed & 3u);
+	const uint32_t *pw = (const uint32_t *)(packed - phead);
+	const uint64_t n_words = (head + n_sym + 3) >> 2;
+	for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < n_words; t += (uint64_t)gridDim.x * blockDim.x) {
+		const long long i0 = (long long)(4 * t) - (long long)head;            // symbol index of byte 0 of this output dword
+		const long long sn = (long long)src0 + i0 + 16ll * phead;             // its position (in symbols) counted from pw
+		uint32_t two = 0;
+		if (sn >= 0) {
+			const uint64_t w = (uint64_t)sn >> 4;
+			const unsigned long long x = (unsigned long long)pw[w] | (unsigned long long)pw[w + 1] << 32;
+			two = (uint32_t)(x >> (2u * (uint32_t)(sn & 15))) & 0xFFu;
+		} else {      // only the first dword of a span can start before the data
+			const unsigned long long x = (unsigned long long)pw[0] | (unsigned long long)pw[1] << 32;
+			two = (uint32_t)(x << (2u * (uint32_t)(-sn))) & 0xFFu;
+		}
+		const uint32_t v = ((two & 3u) | (two & 0xCu) << 6 | (two & 0x30u) << 12 | (two & 0xC0u) << 18) + 0x01010101u;
+		if (i0 >= 0 && (uint64_t)i0 + 4 <= n_sym) ((uint32_t *)base)[t] = v;
+		else for (uint32_t b2 = 0; b2 < 4; ++b2) { const long long idx = i0 + b2; if (idx >= 0 && (uint64_t)idx < n_sym) base[4 * t + b2] = (uint8_t)(v >> (8 * b2)); }
+	}
+}
+
 // seed plan of one entry: same choice as make_seed_plan (bhip_api.hip); vb = bit p set iff the word at p holds only A/C/G/T
 __device__ uint32_t bhip_seed_plan(uint32_t len, uint32_t E, uint32_t K, int stride_opt, bool clean, const uint32_t *vb) {
 	if (len < K) return 1u;

@@ -61,14 +61,14 @@ static int stage_enqueue(Handle *h, StageSlot *S, const BhipQuerySpan *spans, ui
 	if ((rc = slot_init(S))) return rc;
 	hipStream_t st = h->stage_stream;
 	uint64_t n_q64 = 0, nb = 0;
-	bool any_rc = false, any_flags = false, all_flags = true, any_qbase = false, all_packed = true;
+	bool any_rc = false, any_flags = false, all_flags = true, any_qbase = false, all_packed = true, all_packed2 = true, all_len = true;
 	for (uint32_t k = 0; k < n_spans; ++k) {
 		const BhipQuerySpan &sp = spans[k];
 		if (!sp.n) continue;
 		if (!sp.codes || !sp.off || !sp.emac) return fail(BHIP_E_ARG, "null query arrays");
 		if (share_by_position && sp.n > n_shared) return fail(BHIP_E_ARG, "span %u has %u entries for %u shared slots", k, sp.n, n_shared);
 		n_q64 += sp.n; nb += sp.off[sp.n] - sp.off[0];
-		all_packed &= sp.codes4 != nullptr;
+		all_packed &= sp.codes4 != nullptr; all_packed2 &= sp.codes2 != nullptr; all_len &= sp.len != nullptr;
 		any_rc |= sp.rc != nullptr; any_flags |= sp.flags != nullptr; all_flags &= sp.flags != nullptr; any_qbase |= sp.q_base != 0 || k > 0;
 	}
 	if (n_q64 > 0xFFFFFFF0ull) return fail(BHIP_E_ARG, "too many entries in one batch");
@@ -93,19 +93,30 @@ static int stage_enqueue(Handle *h, StageSlot *S, const BhipQuerySpan *spans, ui
 	if (max_len > BHIP_MAX_QLEN) return fail(BHIP_E_QUERYLEN, "queries of up to %u symbols (max %d)", max_len, BHIP_MAX_QLEN);
 	S->st_maxlen = max_len;
 	const uint32_t qw = (max_len + 7) / 8;
-	if (all_packed && (rc = S->qcodes4.reserve(nb / 2 + 2 * (size_t)n_spans + 64))) return rc;
+	if (all_packed2) all_packed = false;      // four symbols per byte beat two
+	if ((all_packed || all_packed2) && (rc = S->qcodes4.reserve(nb / 2 + 2 * (size_t)n_spans + 64))) return rc;
+	if (all_len && (rc = S->qlen16.reserve(((size_t)n_q + n_spans + 1) * 2 + 64))) return rc;
 	if ((rc = S->qcodes.reserve(nb + 2 * (size_t)n_spans + 64)) || (rc = S->qoff.reserve(((size_t)n_q + 1) * 8)) || (rc = S->qemac.reserve(((size_t)n_q + 1) * 2)) ||
 	    (rc = S->qsix.reserve(((size_t)n_q + 1) * 4)) || (rc = S->qrc.reserve((size_t)n_q + 1)) || (rc = S->qflags.reserve((size_t)n_q + 1)) ||
 	    (rc = S->qmap.reserve(((size_t)n_q + 1) * 4)) || (rc = S->off_raw.reserve(((size_t)n_q + n_spans + 1) * 8)) || (rc = S->plan.reserve((size_t)n_q * 4 + 16)) ||
 	    (rc = S->qpack.reserve((size_t)n_q * qw * 4 + 64)) || (rc = S->key.reserve((size_t)n_q + 16)) || (rc = S->key_sorted.reserve((size_t)n_q + 16)) ||
 	    (rc = S->idx.reserve((size_t)n_q * 4 + 16)) || (rc = S->idx_sorted.reserve((size_t)n_q * 4 + 16))) return rc;
 	HIPCHK(hipEventRecord(S->ev_begin, st));
-	uint32_t ebase = 0; uint64_t pos = 0, pos4 = 0;      // pos: symbols of the batch so far; pos4: nibbles of the packed staging area
+	uint32_t ebase = 0; uint64_t pos = 0, pos4 = 0;      // pos: symbols of the batch so far; pos4: nibbles (or 2-bit symbols) of the packed staging area
 	for (uint32_t k = 0; k < n_spans; ++k) {
 		const BhipQuerySpan &sp = spans[k];
 		if (!sp.n) continue;
 		const uint64_t bytes = sp.off[sp.n] - sp.off[0];
-		if (all_packed) {      // in the staging area the span starts on a byte of its own, at the nibble parity it has in the caller's array
+		if (all_packed2) {     // four symbols per byte: the span starts on a byte of its own, at the phase (symbol number mod 4) it has in the caller's array
+			pos4 = ((pos4 + 3) & ~3ull) + (sp.off[0] & 3ull);
+			if (bytes) {
+				HIPCHK(hipMemcpyAsync(S->qcodes4.as<uint8_t>() + (pos4 >> 2), sp.codes2 + (sp.off[0] >> 2), ((sp.off[sp.n] + 3) >> 2) - (sp.off[0] >> 2), hipMemcpyHostToDevice, st));
+				hipLaunchKernelGGL(k_unpack2, dim3((uint32_t)std::min<uint64_t>((bytes / 4 + 256) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, st, S->qcodes4.as<uint8_t>(), pos4, bytes,
+					S->qcodes.as<uint8_t>() + pos);
+				HIPCHK(hipGetLastError());
+			}
+			pos4 += bytes;
+		} else if (all_packed) {      // in the staging area the span starts on a byte of its own, at the nibble parity it has in the caller's array
 			pos4 = ((pos4 + 1) & ~1ull) + (sp.off[0] & 1ull);
 			if (bytes) {
 				HIPCHK(hipMemcpyAsync(S->qcodes4.as<uint8_t>() + (pos4 >> 1), sp.codes4 + (sp.off[0] >> 1), ((sp.off[sp.n] + 1) >> 1) - (sp.off[0] >> 1), hipMemcpyHostToDevice, st));
@@ -116,7 +127,17 @@ static int stage_enqueue(Handle *h, StageSlot *S, const BhipQuerySpan *spans, ui
 			pos4 += bytes;
 		} else if (bytes) HIPCHK(hipMemcpyAsync(S->qcodes.as<uint8_t>() + pos, sp.codes + sp.off[0], bytes, hipMemcpyHostToDevice, st));
 		uint64_t *raw = S->off_raw.as<uint64_t>() + ebase + k;
-		HIPCHK(hipMemcpyAsync(raw, sp.off, ((size_t)sp.n + 1) * 8, hipMemcpyHostToDevice, st));
+		if (all_len) {         // lengths up (2 bytes per entry), offsets by a prefix sum on the device: raw[0 .. n] relative to the span's start
+			uint16_t *dl = S->qlen16.as<uint16_t>() + ebase + k;
+			HIPCHK(hipMemcpyAsync(dl, sp.len, (size_t)sp.n * 2, hipMemcpyHostToDevice, st));
+			HIPCHK(hipMemsetAsync(dl + sp.n, 0, 2, st));
+			auto widen = [] __host__ __device__(uint16_t v) -> unsigned long long { return (unsigned long long)v; };
+			hipcub::TransformInputIterator<unsigned long long, decltype(widen), const uint16_t *> it(dl, widen);
+			size_t tb = 0;
+			HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, (unsigned long long *)raw, (int)(sp.n + 1), st));
+			if ((rc = S->sort_tmp.reserve(tb + 16))) return rc;
+			HIPCHK(hipcub::DeviceScan::ExclusiveSum(S->sort_tmp.p, tb, it, (unsigned long long *)raw, (int)(sp.n + 1), st));
+		} else HIPCHK(hipMemcpyAsync(raw, sp.off, ((size_t)sp.n + 1) * 8, hipMemcpyHostToDevice, st));
 		HIPCHK(hipMemcpyAsync(S->qemac.as<uint16_t>() + ebase, sp.emac, (size_t)sp.n * 2, hipMemcpyHostToDevice, st));
 		if (sp.rc) HIPCHK(hipMemcpyAsync(S->qrc.as<uint8_t>() + ebase, sp.rc, sp.n, hipMemcpyHostToDevice, st));
 		else if (any_rc) HIPCHK(hipMemsetAsync(S->qrc.as<uint8_t>() + ebase, 0, sp.n, st));

@@ -55,6 +55,8 @@ int bh_queries_pin(BhQueries *Q) {
 	if (!bhip_host_register(Q->emac, Q->numEntries * sizeof(*Q->emac))) Q->pinned |= 2;
 	if (!bhip_host_register(Q->rc, Q->numEntries)) Q->pinned |= 4;
 	if (!bhip_host_register(Q->flags, Q->numEntries)) Q->pinned |= 8;
+	if (Q->codes2 && !bhip_host_register(Q->codes2, (Q->qoff[Q->numEntries] + 3) / 4 + 16)) Q->pinned |= 16;
+	if (Q->len16 && !bhip_host_register(Q->len16, (Q->numUniq + 1) * sizeof(*Q->len16))) Q->pinned |= 32;
 	return BH_OK;
 }
 
@@ -93,7 +95,7 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 		if (r0[i] < b) { nBatches += (b - r0[i] + batch_uniq - 1) / batch_uniq; totU += b - r0[i]; }
 	}
 	if (!nBatches) return BH_OK;
-	uint64_t *bu = malloc((nBatches + 2) * 2 * sizeof(*bu));
+	uint64_t *bu = malloc(nBatches * 2 * sizeof(*bu));
 	if (!bu) return bh_set_error(BH_E_OOM, "OOM:batches");
 	{
 		uint64_t k = 0;
@@ -101,16 +103,6 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 			const uint64_t b = r1[i] > Q->numUniq ? Q->numUniq : r1[i];
 			for (uint64_t u = r0[i]; u < b; u += batch_uniq) {
 				const uint64_t B = u + batch_uniq <= b ? batch_uniq : b - u;
-				/* The first batch of a call has nothing to hide its staging behind (copies + routing of 2 M reads take about as long as
-				 * aligning them): it goes in three pieces, so that the second and third are staged while the first and second are
-				 * aligned -- two more device calls (each has a fixed cost of a few hundred microseconds), but ~1.5 ms less in front of
-				 * the first records.  BURST_HOST_NO_RAMP=1 keeps it whole. */
-				if (!k && B >= (3u << 17) && !getenv("BURST_HOST_NO_RAMP")) {
-					const uint64_t p = B / 3;
-					bu[0] = u; bu[1] = p; bu[2] = u + p; bu[3] = p; bu[4] = u + 2 * p; bu[5] = B - 2 * p;
-					k = 3; nBatches += 2;
-					continue;
-				}
 				bu[2 * k] = u; bu[2 * k + 1] = B; ++k;
 			}
 		}
@@ -130,6 +122,10 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 		const uint64_t u_ = bu[2 * (k)], B_ = bu[2 * (k) + 1]; \
 		BhipQuerySpan sp_[2]; \
 		memset(sp_, 0, sizeof sp_); \
+		/* a batch of A/C/G/T-only queries travels four symbols per byte, every batch with 2-byte lengths (same for both strands) */ \
+		const int clean_ = Q->codes2 && Q->ambBefore && Q->ambBefore[u_ + B_] == Q->ambBefore[u_] && !getenv("BURST_HOST_NO_PACK2"); \
+		if (clean_) sp_[0].codes2 = sp_[1].codes2 = Q->codes2; \
+		if (Q->len16 && !getenv("BURST_HOST_NO_PACK2")) sp_[0].len = sp_[1].len = Q->len16 + u_; \
 		sp_[0].codes = Q->codes; sp_[0].codes4 = Q->codes4; sp_[0].off = Q->qoff + u_; sp_[0].emac = Q->emac + u_; sp_[0].rc = Q->rc + u_; sp_[0].flags = Q->flags + u_; sp_[0].n = (uint32_t)B_; sp_[0].q_base = (uint32_t)u_; \
 		if (twoStrand) { const uint64_t e_ = Q->numUniq + u_; \
 			sp_[1].codes = Q->codes; sp_[1].codes4 = Q->codes4; sp_[1].off = Q->qoff + e_; sp_[1].emac = Q->emac + e_; sp_[1].rc = Q->rc + e_; sp_[1].flags = Q->flags + e_; sp_[1].n = (uint32_t)B_; sp_[1].q_base = (uint32_t)e_; } \

@@ -133,6 +133,9 @@ void bh_queries_free(BhQueries *q) {
 		if (q->pinned & 4) bhip_host_unregister(q->rc);
 		if (q->pinned & 8) bhip_host_unregister(q->flags);
 	}
+	if (q->pinned & 16) bhip_host_unregister(q->codes2);
+	if (q->pinned & 32) bhip_host_unregister(q->len16);
+	free(q->codes2); free(q->len16); free(q->ambBefore);
 	free(q->dump); free(q->heads); free(q->offset); free(q->codes); free(q->codes4); free(q->qoff); free(q->six); free(q->rc);
 	free(q->flags); free(q->emac); free(q->len); free(q->ed);
 	memset(q, 0, sizeof *q);
@@ -349,7 +352,7 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 	Q->offset[numUniq] = totQ;
 	free(isNew);
 	QPH("dedupe");
-	Q->codes = malloc(totLen * (do_rc ? 2 : 1) + 16);
+	Q->codes = malloc(totLen * (do_rc ? 2 : 1) + 32);
 	if (!Q->codes) { free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_OOM, "OOM copying queries"); }
 	Q->qoff[0] = 0;
 	for (uint64_t i = 0; i < numUniq; ++i) Q->qoff[i + 1] = Q->qoff[i] + Q->len[i];
@@ -376,6 +379,26 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 		#pragma omp parallel for num_threads(bh_ingest_threads()) schedule(static)
 		for (uint64_t b = 0; b < nb4; ++b) Q->codes4[b] = (uint8_t)((Q->codes[2 * b] & 15) | (Q->codes[2 * b + 1] & 15) << 4);
 		memset(Q->codes4 + nb4, 0, 16);
+		/* four symbols per byte for the batches that hold A/C/G/T only (a quarter of the bytes over PCIe), 2-byte lengths instead
+		 * of 8-byte offsets, and per unique query whether it holds anything else (its reverse complement then does too) */
+		const uint64_t nb2 = (tot + 3) / 4;
+		Q->codes2 = malloc(nb2 + 16); Q->len16 = malloc((numUniq + 1) * sizeof(*Q->len16)); Q->ambBefore = malloc((numUniq + 2) * sizeof(*Q->ambBefore));
+		if (!Q->codes2 || !Q->len16 || !Q->ambBefore) { free(heads); free(refs); bh_queries_free(Q); return bh_set_error(BH_E_OOM, "OOM packing queries"); }
+		Q->codes[tot + 1] = Q->codes[tot + 2] = 0;
+		#pragma omp parallel for num_threads(bh_ingest_threads()) schedule(static)
+		for (uint64_t b = 0; b < nb2; ++b)
+			Q->codes2[b] = (uint8_t)(((Q->codes[4 * b] - 1u) & 3u) | ((Q->codes[4 * b + 1] - 1u) & 3u) << 2 | ((Q->codes[4 * b + 2] - 1u) & 3u) << 4 | ((Q->codes[4 * b + 3] - 1u) & 3u) << 6);
+		memset(Q->codes2 + nb2, 0, 16);
+		#pragma omp parallel for num_threads(bh_ingest_threads()) schedule(static)
+		for (uint64_t i = 0; i < numUniq; ++i) {
+			const uint8_t *s = Q->codes + Q->qoff[i];
+			uint32_t amb = 0;
+			for (uint32_t j = 0; j < Q->len[i]; ++j) amb |= (uint32_t)(s[j] - 1u) > 3u;
+			Q->ambBefore[i + 1] = amb;
+			Q->len16[i] = (uint16_t)Q->len[i];
+		}
+		Q->ambBefore[0] = 0;
+		for (uint64_t i = 0; i < numUniq; ++i) Q->ambBefore[i + 1] += Q->ambBefore[i];
 	}
 	QPH("copy + reverse complement");
 	Q->totQ = totQ; Q->numUniq = numUniq; Q->numEntries = numEntries;

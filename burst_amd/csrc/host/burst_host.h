@@ -85,6 +85,9 @@ typedef struct BhQueries {
 	uint64_t *offset;      /* [numUniq+1] Offset: reads of unique query i are heads[offset[i]..offset[i+1]) */
 	uint8_t *codes;        /* concatenated symbol codes of all entries */
 	uint8_t *codes4;       /* the same, two symbols per byte (low nibble first): what the device batches are copied from */
+	uint8_t *codes2;       /* the same, four symbols per byte (code - 1 in two bits; symbols beyond A/C/G/T read as A): batches without such symbols are copied from here */
+	uint16_t *len16;       /* [numUniq] ShrBin.len again, as the 2-byte lengths the device batches carry instead of 8-byte offsets */
+	uint32_t *ambBefore;   /* [numUniq+1] unique queries in front of i that hold a symbol beyond A/C/G/T (a batch [u, u+B) is clean iff the counts at its ends agree) */
 	uint64_t *qoff;        /* [numEntries+1] */
 	uint32_t *six;         /* [numEntries] shared slot = unique query index */
 	uint8_t *rc;           /* [numEntries] */

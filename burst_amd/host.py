@@ -28,7 +28,7 @@ class BhDb(C.Structure):
 
 class BhQueries(C.Structure):
     _fields_ = [("totQ", C.c_uint64), ("numUniq", C.c_uint64), ("numEntries", C.c_uint64),
-                ("dump", C.c_void_p), ("heads", C.c_void_p), ("offset", u64p), ("codes", u8p), ("codes4", u8p), ("qoff", u64p),
+                ("dump", C.c_void_p), ("heads", C.c_void_p), ("offset", u64p), ("codes", u8p), ("codes4", u8p), ("codes2", u8p), ("len16", u16p), ("ambBefore", u32p), ("qoff", u64p),
                 ("six", u32p), ("rc", u8p), ("flags", u8p), ("emac", u16p), ("len", u32p), ("ed", u16p),
                 ("maxLen", C.c_uint32), ("minLen", C.c_uint32), ("maxED", C.c_uint32),
                 ("nClear", C.c_uint64), ("nAmbig", C.c_uint64), ("nBad", C.c_uint64), ("pinned", C.c_int)]

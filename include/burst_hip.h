@@ -143,6 +143,12 @@ typedef struct BhipQuerySpan {
 	const uint8_t  *flags;   /* n BHIP_Q_*, or NULL (all spans or none) */
 	uint32_t n;
 	uint32_t q_base;         /* BhipHit.q of the span's first entry */
+	const uint8_t  *codes2;  /* optional, for spans whose every symbol is A, C, G or T (codes 1..4): the array packed four symbols per byte
+	                            (symbol i = ((codes2[i >> 2] >> 2 * (i & 3)) & 3) + 1); when every span of a batch has it, it is what crosses
+	                            PCIe (a quarter of the bytes) */
+	const uint16_t *len;     /* optional: the n entry lengths off[j+1] - off[j]; when every span has it, the lengths cross PCIe instead of the
+	                            8-byte offsets (prefix sum on the device).  `codes` and `off` are still required in full: the host pass that
+	                            handles batches with symbols outside the alphabet reads them */
 } BhipQuerySpan;
 BHIP_API int bhip_stage_spans(void *handle, const BhipQuerySpan *spans, uint32_t n_spans, uint32_t n_shared, uint32_t max_len);
 
@@ -238,8 +244,6 @@ BHIP_API int bhip_sort_queries(int device, const uint8_t *codes, uint64_t codes_
  * staged and not aligned (after an error).  "seed_ahead": 1 (default) = the seed lookups and match profiles of the next staged
  * batch run while the current one is swept, 0 = in place; "seed_ahead_blocks" (default 2, 0 = unlimited) / "peq_ahead_blocks"
  * (default 16) = 256-thread blocks per CU those kernels get while they share the device with the sweeps.
- * "lean_launches": 1 (default) = a batch leaves out the launches that only serve rare cases (overflow fallback of the prefilter, clump-level
- * sweep of its pairs, re-scorers for wide bands) when the previous batch needed none of them; it is run again in full if it turns out to.
  * None of these changes a result. */
 BHIP_API int bhip_set_option(void *handle, const char *name, long long value);
 
@@ -251,7 +255,7 @@ BHIP_API void bhip_destroy(void *handle);
 BHIP_API const char *bhip_last_error(void);
 /* ABI version of this header */
 BHIP_API int bhip_abi_version(void);
-#define BHIP_ABI_VERSION 3
+#define BHIP_ABI_VERSION 4
 
 #ifdef __cplusplus
 }

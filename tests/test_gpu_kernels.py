@@ -397,14 +397,26 @@ def test_pipelined_spans_equal_one_call_batches(junk):
     cuts = [0, 50, 51, 100, U]
     padded = np.concatenate([big.codes, np.zeros(2, np.uint8)])
     codes4 = (padded[0:len(big.codes) + 1:2][:(len(big.codes) + 1) // 2] & 15) | ((padded[1:len(big.codes) + 2:2][:(len(big.codes) + 1) // 2] & 15) << 4)
+    # four symbols per byte (A/C/G/T only: code - 1) and 2-byte lengths: what batches without other symbols carry over PCIe
+    pad4 = np.concatenate([big.codes, np.zeros(4, np.uint8)])
+    nb2 = (len(big.codes) + 3) // 4
+    two = ((pad4 - 1) & 3).astype(np.uint8)
+    codes2 = (two[0::4][:nb2] | (two[1::4][:nb2] << 2) | (two[2::4][:nb2] << 4) | (two[3::4][:nb2] << 6)).astype(np.uint8)
+    len16 = np.diff(big.off).astype(np.uint16)
     packed_upload = [False]
     def spans_of(u0, u1):
         out = []
         for base in (0, U):
             out.append(dict(codes=big.codes, off=big.off[base + u0:base + u1 + 1], emac=big.emac[base + u0:base + u1], rc=big.rc[base + u0:base + u1],
                             flags=big.flags[base + u0:base + u1], q_base=base + u0))
-            if packed_upload[0]:
+            if packed_upload[0] == 1:
                 out[-1]["codes4"] = codes4        # two symbols per byte: what then crosses PCIe
+            elif packed_upload[0] == 2:
+                out[-1]["len"] = len16[base + u0:base + u1]
+                if not junk:
+                    out[-1]["codes2"] = codes2
+                else:
+                    out[-1]["codes4"] = codes4
         return out
     def expected(u0, u1, all_hits):
         sub = capi.Queries(reads[u0:u1] + allq[U + u0:U + u1], E[u0:u1] * 2, list(range(u1 - u0)) * 2, [0] * (u1 - u0) + [1] * (u1 - u0))
@@ -415,7 +427,7 @@ def test_pipelined_spans_equal_one_call_batches(junk):
     for host_routing in (0, 1):
         dev.set_option("host_routing", host_routing)
         for all_hits in (False, True):
-            packed_upload[0] = all_hits != bool(host_routing)
+            packed_upload[0] = (2 if all_hits else 1) if not host_routing else (0 if all_hits else 2)
             # two batches ahead, as bh_align does: the seed lookups and profiles of batch k+1 run while batch k is aligned
             dev.stage_spans(spans_of(cuts[0], cuts[1]), cuts[1] - cuts[0], 150)
             dev.stage_spans(spans_of(cuts[1], cuts[2]), cuts[2] - cuts[1], 0)
