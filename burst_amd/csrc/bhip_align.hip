@@ -495,7 +495,9 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		HIPCHK(hipEventRecord(ce[6], sw));
 		if (n_pf) {
 			if (masked) launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 4u * (uint32_t)h->opt_sweep_blocks, L->tasks.as<uint2>(), &dc->n_tasks_cls[cls], qlist, L->wins.as<BhipWin>(), &dc->n_wins_cls[cls], dc);
-			if (NWP) launch_prefix(h, L, sw, NWP, grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, &dc->n_wins_cls[cls], dc);
+			// (beside the lane tasks the clump-level pairs are the rare overflow of the prefilter, usually none at all: a small grid --
+			// an empty launch of 2 048 workgroups waited ~0.24 ms for slots on a device busy with the next batch's seed lookups and staging)
+			if (NWP) launch_prefix(h, L, sw, NWP, masked ? std::min<uint32_t>(grid_my, (uint32_t)h->n_cu) : grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, &dc->n_wins_cls[cls], dc);
 			else launch_myers(h, L, sw, cls, grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, L->raw.as<BhipRawHit>(),
 				&dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
 			HIPCHK(hipGetLastError());
