@@ -11,6 +11,9 @@
  *                   ranks combine one byte per unique query (bhip_comm_allreduce_min = ncclAllReduce MIN, or a host loop), drop
  *                   what lies above it (not in FORAGE, which keeps everything within budget, burst.c:4224), and gather as before;
  *                   rank 0 puts the records in (query, reference) order: the set a single device holding everything produces.
+ *   both            S shards x G replica groups (rank = group * S + shard): a database that needs S devices, its queries cut over
+ *                   the G groups -- e.g. the metric's 31.5 GB database on 8 GPUs as 2 shards x 4 groups, each group aligning a
+ *                   quarter of the reads at the rate one device reaches on half the database.
  */
 #include "burst_host.h"
 #include <stdlib.h>
@@ -66,12 +69,16 @@ static int shard_order(BhRun *all, uint64_t n_entries) {
 }
 
 int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const BhQueries *Q, BhMode mode, uint64_t batch, int shard_db, BhRun *all, uint64_t *counts) {
+	/* shard_db = number of database shards S (0 / 1: none).  S < n_ranks: the ranks form n_ranks / S replica groups of S shards each
+	 * (rank = group * S + shard); the caller gives every rank its group's query ranges and its shard's first clump.  The minima
+	 * are combined over ALL ranks at once: the groups' queries are disjoint and a rank says 255 ("none") for queries that are not
+	 * its group's, so the minimum over everybody is the minimum over the group. */
 	if (n_local < 1 || n_local > n_ranks || n_ranks > BH_MAX_RANKS) return bh_set_error(BH_E_USAGE, "bad rank layout (%d local of %d)", n_local, n_ranks);
 	if (!comm && n_local != n_ranks) return bh_set_error(BH_E_USAGE, "without a communicator every rank must live in this process");
 	int rcs[BH_MAX_RANKS]; char errs[BH_MAX_RANKS][512];
 	uint8_t *best[BH_MAX_RANKS];
 	for (int i = 0; i < n_local; ++i) { rcs[i] = BH_E_INTERNAL; snprintf(errs[i], sizeof errs[i], "rank %d never ran (OpenMP gave the team fewer than %d threads)", R[i].rank, n_local); best[i] = NULL; }
-	const int reduce = shard_db && mode != BH_FORAGE && n_ranks > 1;
+	const int reduce = shard_db > 1 && mode != BH_FORAGE && n_ranks > 1;
 	/* one host thread per local rank; the runtime must grant all of them -- a missing rank would leave the others waiting in the
 	 * collectives -- so dynamic team sizes are switched off and the team is checked before anything is enqueued */
 	const int dyn = omp_get_dynamic();
@@ -90,7 +97,7 @@ int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const 
 		BhMultiRank *r = &R[i];
 		rcs[i] = bh_align_ranges_reuse(r->hh, Q, r->r0, r->r1, r->n_ranges, mode, batch, &r->run);
 		if (rcs[i]) snprintf(errs[i], sizeof errs[i], "%s", bh_last_error());
-		else if (shard_db) {
+		else if (shard_db > 1) {
 			for (uint64_t k = 0; k < r->run.nHits; ++k) r->run.hits[k].refIx += 16u * r->c0;
 			if (reduce) {
 				best[i] = malloc(Q->numUniq + 1);
@@ -166,7 +173,7 @@ int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const 
 	if (rc) return rc;
 	if (i0 >= 0) {
 		for (int i = 0; i < n_local; ++i) { all->nBatches += R[i].run.nBatches; all->secAlign += i == i0 ? R[i].run.secAlign : 0; }
-		if (shard_db && n_ranks > 1) rc = shard_order(all, Q->numEntries);
+		if (shard_db > 1 && n_ranks > 1) rc = shard_order(all, Q->numEntries);
 	}
 	return rc;
 }

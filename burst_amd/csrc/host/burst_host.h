@@ -144,6 +144,8 @@ typedef struct BhMultiRank {
 void bh_clump_shard(const BhDb *db, int n_ranks, int rank, uint32_t *c0, uint32_t *c1);
 /* The search of the n_local ranks that live in this process (listed in rank order; one host thread each) as part of a job of
  * n_ranks: align, [database-sharded: combine the per-query minimum, drop what lies above it], gather the records to rank 0.
+ * shard_db = number of database shards (0 / 1 = none: query-sharded; n_ranks = every rank its own shard; a divisor S of n_ranks =
+ * n_ranks / S replica groups of S shards, rank = group * S + shard, the caller passes each rank its group's ranges and its shard's c0).
  * comm = communicator over all n_ranks (bhip_comm_create / bhip_comm_create_rank), or NULL when all ranks are local: records
  * and minima then meet in host memory.  all = the gathered records where rank 0 lives (sorted by (query entry, reference));
  * counts[n_ranks] (optional, rank 0's process) = records per rank. */

@@ -63,6 +63,7 @@ static void usage(void) {
 	puts("--gpus <int> [--devices a,b,...] [--gather rccl|host]: shard the queries over the GPUs of this node (one RCCL gather of the records)");
 	puts("--shard queries|db: with --gpus, cut the queries (database replicated; default) or the database (every rank holds a range of");
 	puts("                    clumps and aligns all queries; one all-reduce of the per-query minimum) -- for databases beyond one device");
+	puts("--shards <S>: database shards (implies --shard db; default = --gpus): the ranks form gpus / S replica groups of S shards, the queries cut over the groups");
 	puts("--device <int>, --batch <int>, -k <12|15>, --make-acx <name> (with -r DB.edx: rebuild the accelerator of a database)");
 	puts("--accelerator-device (-ad): no .acx file, the device builds the accelerator from the .edx (word length -k, default 12)");
 	puts("--host-acx: build accelerators (-d ... -a, --make-acx) with the host builder instead of the device");
@@ -73,7 +74,7 @@ int main(int argc, char **argv) {
 	float thres = 0.97f;                            /* burst.c:93 */
 	int z = 1, do_rc = 0, incl_ws = 0, makedb = 0, do_shear = 0, do_accel = 0, dedupe = 0, device = 0, K = 0, skip_ambig = 0, threads = 0, rep_flags = 0;
 	long shear_amt = 500, db_qlen = 500;            /* burst.c:94 */
-	int n_gpus = 1, n_gpus_given = 0, gather_host = 0, n_dev_list = 0, dev_list[BH_MAX_GPUS], accel_dev = 0, host_acx = 0, shard_db = 0;
+	int n_gpus = 1, n_gpus_given = 0, gather_host = 0, n_dev_list = 0, dev_list[BH_MAX_GPUS], accel_dev = 0, host_acx = 0, shard_db = 0, n_shards = 0;
 	uint64_t batch = 1u << 21;      /* unique queries per device batch: the fixed cost of a batch (launches, synchronisation) is about 1 ms of device time */
 	const char *ref_FN = 0, *query_FN = 0, *output_FN = 0, *xcel_FN = 0, *mkacx_FN = 0, *tax_FN = 0;
 	BhTax taxonomy; memset(&taxonomy, 0, sizeof taxonomy);
@@ -133,6 +134,7 @@ int main(int argc, char **argv) {
 		}
 		else if (!strcmp(a, "--gather")) { NEEDARG("--gather"); gather_host = !strcmp(argv[i], "host"); if (!gather_host && strcmp(argv[i], "rccl")) { puts("ERROR: --gather rccl|host"); return 1; } }
 		else if (!strcmp(a, "--shard")) { NEEDARG("--shard"); shard_db = !strcmp(argv[i], "db"); if (!shard_db && strcmp(argv[i], "queries")) { puts("ERROR: --shard queries|db"); return 1; } }
+		else if (!strcmp(a, "--shards")) { NEEDARG("--shards"); n_shards = atoi(argv[i]); if (n_shards < 1) { puts("ERROR: --shards must be >= 1"); return 1; } shard_db = 1; }
 		else if (!strcmp(a, "--batch")) { NEEDARG("--batch"); batch = strtoull(argv[i], 0, 10); }
 		else if (!strcmp(a, "-k")) { NEEDARG("-k"); K = atoi(argv[i]); if (K != 12 && K != 15) { puts("ERROR: -k must be 12 or 15"); return 1; } }
 		else if (!strcmp(a, "--help") || !strcmp(a, "-h")) { usage(); return 1; }
@@ -272,7 +274,11 @@ int main(int argc, char **argv) {
 	for (int r = 0; r < BH_MAX_GPUS; ++r) rcs[r] = BH_E_INTERNAL;
 	void *comm = NULL;
 	const int use_rccl = n_gpus_given && !gather_host;
-	if (shard_db && n_gpus > 1 && (uint32_t)n_gpus > db.numRclumps) { puts("ERROR: --shard db with more ranks than clumps"); return 1; }
+	if (shard_db && !n_shards) n_shards = n_gpus;
+	if (!shard_db || n_shards < 2) { shard_db = 0; n_shards = 1; }
+	if (n_gpus % n_shards) { printf("ERROR: --shards %d does not divide --gpus %d\n", n_shards, n_gpus); return 1; }
+	const int n_groups = n_gpus / n_shards;
+	if (shard_db && (uint32_t)n_shards > db.numRclumps) { puts("ERROR: more database shards than clumps"); return 1; }
 	if (!n_dev_list) for (int r = 0; r < n_gpus; ++r) dev_list[r] = n_gpus_given ? r : device;
 	if (use_rccl && bhip_comm_create(n_gpus, dev_list, &comm)) { fprintf(stderr, "libburst_hip: %s\n", bhip_last_error()); return 4; }
 	omp_set_dynamic(0);
@@ -281,9 +287,9 @@ int main(int argc, char **argv) {
 		const int r = omp_get_thread_num();
 		const BhDb *part = &db;
 		rcs[r] = BH_OK;
-		if (shard_db && n_gpus > 1) {      /* this rank's clumps: a view of the clump area + (with an .acx) the lists restricted to it */
+		if (shard_db) {      /* this rank's clumps: a view of the clump area + (with an .acx) the lists restricted to it */
 			uint32_t c0, c1;
-			bh_clump_shard(&db, n_gpus, r, &c0, &c1);
+			bh_clump_shard(&db, n_shards, r % n_shards, &c0, &c1);
 			ranks[r].c0 = c0;
 			if ((rcs[r] = bh_db_slice(&db, c0, c1, &slices[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
 			part = &slices[r];
@@ -292,7 +298,7 @@ int main(int argc, char **argv) {
 	}
 	for (int r = 0; r < n_gpus; ++r) if (rcs[r]) { fprintf(stderr, "%s\n", rcs[r] == BH_E_INTERNAL ? "OpenMP did not start one host thread per GPU" : errs[r]); return 4; }
 	for (int r = 0; r < n_gpus; ++r) { char nm[256]; int ncu = 0; uint64_t hbm = 0; if (!bhip_device_info(hhs[r], nm, sizeof nm, &ncu, &hbm)) printf("Device %d: %s, %d CUs, %.0f GiB\n", dev_list[r], nm, ncu, hbm / 1073741824.0); }
-	if (shard_db && n_gpus > 1) for (int r = 0; r < n_gpus; ++r) printf("Rank %d: clumps [%u, %u)\n", r, ranks[r].c0, ranks[r].c0 + slices[r].numRclumps);
+	if (shard_db) for (int r = 0; r < n_gpus; ++r) printf("Rank %d: replica group %d, clumps [%u, %u)\n", r, r / n_shards, ranks[r].c0, ranks[r].c0 + slices[r].numRclumps);
 	PHASE("device database upload");
 	if (usedb) {
 		JOIN_INGEST();
@@ -311,8 +317,8 @@ int main(int argc, char **argv) {
 	PHASE("query arrays page-locked");
 	for (int r = 0; r < n_gpus; ++r) {
 		ranks[r].rank = r; ranks[r].hh = hhs[r];
-		if (shard_db && n_gpus > 1) { ru0[r] = 0; ru1[r] = Q.numUniq; }
-		else { ru0[r] = Q.numUniq * (uint64_t)r / (uint64_t)n_gpus; ru1[r] = Q.numUniq * (uint64_t)(r + 1) / (uint64_t)n_gpus; }
+		const int grp = r / n_shards;      /* the ranks of a replica group align the same queries, each against its shard */
+		ru0[r] = Q.numUniq * (uint64_t)grp / (uint64_t)n_groups; ru1[r] = Q.numUniq * (uint64_t)(grp + 1) / (uint64_t)n_groups;
 		ranks[r].r0 = &ru0[r]; ranks[r].r1 = &ru1[r]; ranks[r].n_ranges = 1;
 	}
 	{	/* device and record buffers for the batches to come (allocations synchronise the device: not inside the search), sized from
@@ -343,8 +349,8 @@ int main(int argc, char **argv) {
 		if ((rc = bh_align_ranges_reuse(hhs[0], &Q, &ru0[0], &ru1[0], 1, mode, batch, &ranks[0].run))) { fprintf(stderr, "%s\n", bh_last_error()); return rc == BH_E_USAGE ? 1 : 4; }
 		run = ranks[0].run; memset(&ranks[0].run, 0, sizeof ranks[0].run);
 	} else {
-		if ((rc = bh_search_multi(ranks, n_gpus, n_gpus, comm, &Q, mode, batch, shard_db && n_gpus > 1, &run, cnts))) { fprintf(stderr, "%s\n", bh_last_error()); return rc == BH_E_USAGE ? 1 : 4; }
-		printf("%s: %d rank(s)%s, records per rank:", use_rccl ? "RCCL gather" : "host gather", n_gpus, shard_db && n_gpus > 1 ? ", database-sharded" : "");
+		if ((rc = bh_search_multi(ranks, n_gpus, n_gpus, comm, &Q, mode, batch, shard_db ? n_shards : 0, &run, cnts))) { fprintf(stderr, "%s\n", bh_last_error()); return rc == BH_E_USAGE ? 1 : 4; }
+		printf("%s: %d rank(s)%s, records per rank:", use_rccl ? "RCCL gather" : "host gather", n_gpus, shard_db ? ", database-sharded" : "");
 		for (int r = 0; r < n_gpus; ++r) printf(" %lu", (unsigned long)cnts[r]);
 		printf("\n");
 		for (int r = 0; r < n_gpus; ++r) { run.total.n_pairs += ranks[r].run.total.n_pairs; bh_run_free(&ranks[r].run); }

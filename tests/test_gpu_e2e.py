@@ -189,6 +189,8 @@ def test_reference_host_with_device_binding(c, tmp_path_factory):
                                                ("dna_q100_capitalist_fr", ["--gpus", "2", "--devices", "0,0", "--gather", "host", "--shard", "db", "--batch", "41"], "host gather: 2 rank(s), database-sharded"),
                                                ("dna_q292_forage_fr", ["--gpus", "3", "--devices", "0,0,0", "--gather", "host", "--shard", "db", "-ad"], "host gather: 3 rank(s), database-sharded"),
                                                ("quick_q100_capitalist_noacx_t1", ["--gpus", "2", "--devices", "0,0", "--gather", "host", "--shard", "db"], "host gather: 2 rank(s), database-sharded"),
+                                               ("dna_q100_allpaths_fr", ["--gpus", "4", "--devices", "0,0,0,0", "--gather", "host", "--shards", "2"], "host gather: 4 rank(s), database-sharded"),
+                                               ("dna_q100_capitalist_fr", ["--gpus", "6", "--devices", "0,0,0,0,0,0", "--gather", "host", "--shards", "3", "-ad", "--batch", "53"], "host gather: 6 rank(s), database-sharded"),
                                                ("dna_q100_allpaths_fr", ["--gpus", "1", "--shard", "db"], "RCCL gather: 1 rank(s)")])
 def test_cli_multi_gpu_paths(name, flags, expect, tmp_path):
     """burst_hip --gpus N: one host thread + one device handle per rank, the unique queries sharded, the records gathered to
@@ -196,7 +198,8 @@ def test_cli_multi_gpu_paths(name, flags, expect, tmp_path):
     device, as they must on a one-GPU box).  --gpus 1 goes through the RCCL code with one rank.  Same .b6 as one device.
     --shard db (bh_search_multi): every rank holds a range of clumps -- the .acx lists restricted to it (bh_db_slice), or with -ad an
     accelerator the rank's device builds for its slice -- aligns all queries, the per-query minimum is combined over the ranks and
-    the gathered records are put in (query, reference) order: the golden lines of the whole database."""
+    the gathered records are put in (query, reference) order: the golden lines of the whole database.  --shards S with more ranks:
+    replica groups of S shards, the queries cut over the groups."""
     c = [x for x in gl.cases() if x["name"] == name][0]
     ref, q, fr, z, shear = gl.case_args(c)
     out = str(tmp_path / "o.b6")
@@ -206,11 +209,11 @@ def test_cli_multi_gpu_paths(name, flags, expect, tmp_path):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0 and expect in r.stdout, r.stdout[-2000:]
     got = open(out, "rb").read()
-    if "--shard" in flags:
+    if "--shard" in flags or "--shards" in flags:
         # the record set and its order are those of one device holding the whole database: the .b6 must be the single-device run's,
         # byte for byte in the same order (also in the modes whose golden depends on the reference's thread timing)
         single = [x for x in cmd if x not in ("--shard", "db", "--gather", "host")]
-        for opt in ("--gpus", "--devices", "--batch"):
+        for opt in ("--gpus", "--devices", "--batch", "--shards"):
             if opt in single:
                 k = single.index(opt)
                 del single[k:k + 2]
