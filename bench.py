@@ -177,7 +177,17 @@ def parity_vs_reference(dev, db, args, batch_uniq):
     a = sorted(open(ref_b6, "rb").read().splitlines())
     b = sorted(open(out, "rb").read().splitlines())
     sa, sb = set(a), set(b)
-    res = {"reads": qs.n_reads, "lines_reference": len(a), "lines": len(b), "identical": a == b, "only_reference": len(sa - sb), "only_device": len(sb - sa),
+    explained = None
+    if a != b and args.mode != "BEST":
+        # the modes that print several placements per query keep, of two overlapping ones, whichever the reference's threads met first
+        # (DUPE_HUNT, burst.c:4563-4570; equally voted references in CAPITALIST, 4763-4776): a differing reference line is explained
+        # when it is one of the placements the device path computes for that query (printed without the duplicate hunt)
+        nd = sample + ".hip.nd.b6"
+        host.report(nd, db, qs, run.hits, "ALLPATHS" if args.mode == "CAPITALIST" else args.mode, host.REP_NO_DUPE_HUNT)
+        allp = set(open(nd, "rb").read().splitlines())
+        explained = {"reference_lines_not_computed_by_the_device": len([x for x in sa - sb if x not in allp]), "same_line_count": len(a) == len(b),
+                     "same_queries": sorted({x.split(b"\t")[0] for x in a}) == sorted({x.split(b"\t")[0] for x in b})}
+    res = {"reads": qs.n_reads, "lines_reference": len(a), "lines": len(b), "identical": a == b, "only_reference": len(sa - sb), "only_device": len(sb - sa), "order_dependent_lines_explained": explained,
            "what": "sorted .b6 of oracle/_ref/burst%d vs the device path (bh_align_ranges + bh_report) on the first %d reads of the pool, -m %s -i %s" % (args.K, qs.n_reads, args.mode, args.id)}
     run.close(); qs.close()
     return res
