@@ -162,7 +162,7 @@ def test_configs2_twelve_million_292bp_reads_allpaths():
     qs.pin()
     run = host.align_ranges(dev, qs, [(0, qs.n_uniq)], "ALLPATHS", 1 << 21)
     h = run.hits
-    assert int(run.c.nBatches) == ((qs.n_uniq + (1 << 21) - 1) >> 21) + 2      # the first batch of a call goes in three pieces
+    assert int(run.c.nBatches) == (qs.n_uniq + (1 << 21) - 1) >> 21
     q = h["q"].astype(np.int64)
     emac = host._view(qs.c.emac, qs.n_entries, np.uint16)
     qoff = host._view(qs.c.qoff, qs.n_entries + 1, np.uint64).astype(np.int64)
