@@ -65,17 +65,26 @@ static int slurp_queries(const char *path, char **out, uint64_t *out_sz) {
 		if (bad) { free(dump); return bh_set_error(BH_E_IO, "short read on %s", path); }
 	}
 	if (sz && dump[0] == '@') {      /* FASTQ: keep lines 1 and 2 of every four, '@' -> '>' */
-		uint64_t r = 0, w = 0, line = 0;
+		/* four-line records only (sequence and qualities on one line each); empty lines between records and at the end of the
+		 * file are passed over, the separator line must start with '+' -- a wrapped (multi-line) FASTQ file fails that test
+		 * and is refused with a message that says so instead of being read as garbage */
+		uint64_t r = 0, w = 0, line = 0, rec = 0;
 		while (r < sz) {
 			char *nl = memchr(dump + r, '\n', sz - r);
 			const uint64_t e = nl ? (uint64_t)(nl - dump) + 1 : sz;
-			if ((line & 3) < 2) {
-				if ((line & 3) == 0) { if (dump[r] != '@') { free(dump); return bh_set_error(BH_E_USAGE, "ERROR: Malformatted FASTQ file (record %lu).", (unsigned long)(line / 4 + 1)); } dump[r] = '>'; }
-				memmove(dump + w, dump + r, e - r);
-				w += e - r;
+			const uint64_t body = e - r - (nl ? 1 : 0) - ((e - r >= 2 && dump[e - 2] == '\r' && nl) ? 1 : 0);
+			if ((line & 3) == 0 && body == 0) { r = e; continue; }      /* blank line at a record boundary */
+			if ((line & 3) == 0) {
+				++rec;
+				if (dump[r] != '@') { free(dump); return bh_set_error(BH_E_USAGE, "ERROR: Malformatted FASTQ file (record %lu does not start with '@'; sequences wrapped over several lines are not supported).", (unsigned long)rec); }
+				dump[r] = '>';
+			} else if ((line & 3) == 2 && dump[r] != '+') {
+				free(dump); return bh_set_error(BH_E_USAGE, "ERROR: Malformatted FASTQ file (record %lu: the third line does not start with '+'; sequences wrapped over several lines are not supported).", (unsigned long)rec);
 			}
+			if ((line & 3) < 2) { memmove(dump + w, dump + r, e - r); w += e - r; }
 			r = e; ++line;
 		}
+		if (line & 3) { free(dump); return bh_set_error(BH_E_USAGE, "ERROR: Malformatted FASTQ file (the last record is incomplete)."); }
 		sz = w;
 	}
 	memset(dump + sz, 0, 17);
@@ -289,7 +298,7 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 				for (uint64_t i = 0; i < totQ; ++i) { tmp[i] = refs[perm[i]]; numUniq += isNew[i]; }
 				{ QRef *t = refs; refs = tmp; tmp = t; }          /* the permuted table is the table from here on */
 				on_device = 1;
-			} else if (dbg) fprintf(stderr, "[bh_queries] device sort not available (%s): sorting on the host\n", bhip_last_error());
+			} else fprintf(stderr, " --> NOTE: query sort on device %d not available (%s): sorting on the host\n", g_sort_device, bhip_last_error());
 		}
 		free(start); free(lens); free(perm); free(tmp);
 		QPH("sort + duplicates (device)");

@@ -135,8 +135,38 @@ def test_fastq_and_gzip_queries_load_like_fasta(tmp_path):
         return t
     base = tables(src)
     assert base[0] == len(recs) // 2 and base[1] > 0
-    for p in (fq, fagz, fqgz):
+    # blank lines between records and at the end of the file, CRLF line ends
+    fq2 = tmp_path / "q_blank.fastq"
+    with open(fq2, "w", newline="") as f:
+        for k, (h, s) in enumerate(zip(recs[0::2], recs[1::2])):
+            f.write("@%s\n%s\n+%s\n%s\n" % (h[1:], s, h[1:] if k % 3 == 0 else "", "I" * len(s)))
+            if k % 5 == 0:
+                f.write("\n")
+        f.write("\n\n")
+    for p in (fq, fagz, fqgz, fq2):
         assert tables(p) == base, p
+    # wrapped records, a missing separator and a truncated last record are refused with a message, not read as garbage
+    for name, text in (("wrapped", "@r1\nACGT\nACGT\n+\nIIII\nIIII\n"), ("nosep", "@r1\nACGT\nIIII\n@r2\nACGT\n+\nIIII\n"), ("short", "@r1\nACGT\n+\nIIII\n@r2\nACGT\n")):
+        bad = tmp_path / (name + ".fastq")
+        bad.write_text(text)
+        with pytest.raises(host.HostError) as e:
+            host.QuerySet(str(bad), 0.95, rc=False, accel=True, K=12)
+        assert "FASTQ" in str(e.value)
+    # the other packed copies: four symbols per byte for A/C/G/T (code - 1), 2-byte lengths, clean-batch counts
+    qs = host.QuerySet(str(src), 0.95, rc=True, accel=True, K=12)
+    off = host._view(qs.c.qoff, qs.n_entries + 1, np.uint64)
+    codes_all = host._view(qs.c.codes, int(off[-1]), np.uint8)
+    c2 = host._view(qs.c.codes2, (int(off[-1]) + 3) // 4, np.uint8)
+    pad4 = np.concatenate([codes_all, np.ones(4, np.uint8)])
+    two = ((pad4 - 1) & 3).astype(np.uint8)
+    n2 = len(c2)
+    want2 = two[0::4][:n2] | (two[1::4][:n2] << 2) | (two[2::4][:n2] << 4) | (two[3::4][:n2] << 6)
+    assert np.array_equal(c2[:-1], want2[:-1])
+    assert np.array_equal(host._view(qs.c.len16, qs.n_uniq, np.uint16), np.diff(off[:qs.n_uniq + 1]).astype(np.uint16))
+    amb = host._view(qs.c.ambBefore, qs.n_uniq + 1, np.uint32)
+    per = np.array([int(((codes_all[int(off[i]):int(off[i + 1])] - 1) > 3).any()) for i in range(qs.n_uniq)])
+    assert amb[0] == 0 and np.array_equal(np.diff(amb.astype(np.int64)), per) and per.sum() > 0
+    qs.close()
     # packed copy: two symbols per byte, low nibble first
     codes = np.frombuffer(base[3], np.uint8)
     c4 = np.frombuffer(base[7], np.uint8)
