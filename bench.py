@@ -93,6 +93,8 @@ def build_inputs(workdir, args, rank):
         host.synth_reads(refs, reads_fa, n_pool_reads, args.read_len, edits, rc=args.fr, iupac=args.iupac, seed=42)
         open(reads_fa + ".done", "w").write("ok")
         log("[bench] %d reads written in %.1f s" % (n_pool_reads, time.time() - t))
+    if rank == 0 and getattr(args, "drop_refs", False) and os.path.exists(refs):
+        os.remove(refs)          # very large databases: the FASTA (as large as the database in bases) is not needed once reads and .edx exist
     return refs, edx, acx, reads_fa, done
 
 
@@ -230,6 +232,7 @@ def main():
     ap.add_argument("--edits", default="0,1,2", help="edit counts sampled per read")
     ap.add_argument("--opt", action="append", default=[], help="library tuning option name=value (bhip_set_option), repeatable")
     ap.add_argument("--no-pin", action="store_true", help="leave the query arrays pageable")
+    ap.add_argument("--drop-refs", action="store_true", help="delete the reference FASTA once the reads and the .edx exist (disk space of very large databases)")
     ap.add_argument("--no-prime", action="store_true", help="skip bhip_reserve and the priming call (profiling: every dispatch of the run is then a full-size batch)")
     ap.add_argument("--acx-file", action="store_true", help="round 2's path: the accelerator from an .acx file (built by the host builder) instead of the device build")
     args = ap.parse_args()

@@ -161,7 +161,7 @@ static int acx_lines_from_lens(Handle *h, const uint32_t *d_lens, uint64_t nw, u
 	const uint64_t n_lines = (nw + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS;
 	DTmp d_red, d_tmp, d_lsum, d_lbase;
 	ARC(d_red.reserve(64));
-	ARC(h->acx_lines.reserve((n_lines + 1) * 64));
+	ARC(h->acx_lines.reserve_exact((n_lines + 1) * 64));
 	ARC(d_lsum.reserve((n_lines + 2) * 8));
 	ARC(d_lbase.reserve((n_lines + 2) * 8));
 	auto to_sq = [] __host__ __device__(uint32_t n) -> double { return (double)n * (double)n; };
@@ -293,7 +293,7 @@ int bhip_load_accelerator(Handle *h, const uint32_t *acx_lens, const void *acx_l
 	unsigned long long bytes = 0;
 	HIPCHK(hipMemcpyAsync(&bytes, d_bbase.as<unsigned long long>() + nblk, 8, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
-	ARC(h->acx_rec.reserve(tot * BHIP_REC_BYTES + 16));
+	ARC(h->acx_rec.reserve_exact(tot * BHIP_REC_BYTES + 16));
 	ARC(d_lists.reserve(bytes + 16)); ARC(d_flag.reserve(16));
 	if (bytes) HIPCHK(hipMemcpyAsync(d_lists.p, acx_lists, bytes, hipMemcpyHostToDevice, h->stream));
 	HIPCHK(hipMemsetAsync(d_flag.p, 0, 16, h->stream));
@@ -515,10 +515,10 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 	size_t free_b = 0, total_b = 0;
 	HIPCHK(hipMemGetInfo(&free_b, &total_b));
 	const uint64_t n_lines = (nw + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS;
-	const double room = (double)free_b - (double)nw * 4.0 - (double)n_lines * 64.0 * 1.3 - (double)item_off[nC] * BHIP_REC_BYTES * 1.3 - (double)(64u << 20);
+	const double room = (double)free_b - (double)nw * 4.0 - (double)n_lines * 64.0 - (double)item_off[nC] * BHIP_REC_BYTES - (double)(256u << 20);
 	uint64_t biggest = 0;
 	for (uint32_t c = 0; c < nC; ++c) biggest = std::max(biggest, item_off[c + 1] - item_off[c]);
-	uint64_t slice_items = room > 0 ? (uint64_t)std::min<double>(2147483000.0, room * 0.8 / 26.0) : 0;
+	uint64_t slice_items = room > 0 ? (uint64_t)std::min<double>(2147483000.0, room * 0.8 / 33.0) : 0;      // (26 B per tuple in the sort buffers, which grow with a quarter of slack)
 	if (const char *ev = getenv("BHIP_MASK_SLICE")) { const long long v = atoll(ev); if (v > 0) slice_items = std::max<uint64_t>((uint64_t)v, biggest); }
 	if (slice_items < biggest || biggest > 2147483000ull)
 		return fail(BHIP_E_DEVICE, "not enough device memory to build the accelerator (a clump alone has %llu word tuples, %.1f GB free)", (unsigned long long)biggest, (double)free_b / 1e9);
@@ -570,7 +570,7 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 	const double t_pass1 = since();
 	uint64_t tot = 0; uint32_t maxlen = 0;
 	ARC(acx_lines_from_lens(h, d_lens.as<uint32_t>(), nw, &tot, &maxlen));
-	ARC(h->acx_rec.reserve(tot * BHIP_REC_BYTES + 16));
+	ARC(h->acx_rec.reserve_exact(tot * BHIP_REC_BYTES + 16));
 	if (n_slices > 1) { d_cursor.p = d_lens.p; d_cursor.cap = d_lens.cap; d_lens.p = nullptr; d_lens.cap = 0; HIPCHK(hipMemsetAsync(d_cursor.p, 0, nw * 4, h->stream)); }      // (the length table's memory)
 	else d_lens.release();
 	// 4. second pass: the records (one slice: the folded tuples are still there)

@@ -86,6 +86,15 @@ struct DBuf {
 		if (e != hipSuccess) { p = nullptr; return fail(BHIP_E_DEVICE, "hipMalloc(%zu): %s", want, hipGetErrorString(e)); }
 		cap = want; return 0;
 	}
+	// the same without the growth slack: for the database-sized buffers that are allocated once (a quarter more of a 170 GB record
+	// area is what decides whether a database fits the device)
+	int reserve_exact(size_t bytes) {
+		if (bytes <= cap) return 0;
+		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+		hipError_t e = hipMalloc(&p, bytes);
+		if (e != hipSuccess) { p = nullptr; return fail(BHIP_E_DEVICE, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+		cap = bytes; return 0;
+	}
 	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 	template <class T> T *as() const { return (T *)p; }
 };

@@ -134,8 +134,8 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		DBuf d_src, d_srcoff;
 		INITRC(d_src.reserve(src_off[n_clumps] * 16 + 16));
 		INITRC(d_srcoff.reserve((n_clumps + 1) * sizeof(uint64_t)));
-		INITRC(h->ref.reserve(dst_off[n_clumps] * 256 + 256));
-		INITRC(h->ref_lane.reserve(dst_off[n_clumps] * 256 + 256));
+		INITRC(h->ref.reserve_exact(dst_off[n_clumps] * 256 + 256));
+		INITRC(h->ref_lane.reserve_exact(dst_off[n_clumps] * 256 + 256));
 		INITRC(h->ref_off.reserve((n_clumps + 1) * sizeof(uint64_t)));
 		INITRC(h->clump_len.reserve(n_clumps * sizeof(uint32_t)));
 		INITRC(h->lut.reserve(256));
