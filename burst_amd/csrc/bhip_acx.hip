@@ -149,34 +149,6 @@ __global__ void k_attach_masks(BhipAcxView acx, uint64_t n_words,
 	}
 }
 
-// The merge prefilter walks a word's list in ascending clump order.  The device builder writes lists that way and so does the
-// reference with one thread; a multi-threaded reference run leaves a list in the order its threads finished their clumps
-// (burst.c:3378-3388 under `omp for`).  After decoding a file, one thread per word checks its list and sorts it in place when
-// needed (Shell sort over the 24-bit ids; the mask bytes are still "every lane" at this point).  `n_sorted` counts such lists.
-__global__ void k_acx_sort_lists(BhipAcxView acx, uint64_t n_words, uint8_t *__restrict__ rec, unsigned long long *__restrict__ n_sorted) {
-	unsigned long long mine = 0;
-	for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
-		unsigned long long e; uint32_t n;
-		bhip_acx_range(acx, (uint32_t)w, e, n);
-		if (n < 2) continue;
-		bool asc = true;
-		uint32_t prev = bhip_acx_clump(rec, e);
-		for (uint32_t i = 1; i < n && asc; ++i) { const uint32_t c = bhip_acx_clump(rec, e + i); asc = c >= prev; prev = c; }
-		if (asc) continue;
-		++mine;
-		uint32_t gap = 1;
-		while (gap < n / 3) gap = 3 * gap + 1;
-		for (; gap >= 1; gap /= 3)
-			for (uint32_t i = gap; i < n; ++i) {
-				const uint32_t v = bhip_acx_clump(rec, e + i);
-				uint32_t j = i;
-				for (; j >= gap && bhip_acx_clump(rec, e + j - gap) > v; j -= gap) bhip_rec_store(rec, e + j, bhip_acx_clump(rec, e + j - gap), 0xFFFFu);
-				bhip_rec_store(rec, e + j, v, 0xFFFFu);
-			}
-	}
-	if (mine) atomicAdd(n_sorted, mine);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Host side.  Temporary device buffers are released when they go out of scope.
 // ------------------------------------------------------------------------------------------------
@@ -332,15 +304,6 @@ int bhip_load_accelerator(Handle *h, const uint32_t *acx_lens, const void *acx_l
 	HIPCHK(hipMemcpyAsync(&worst, d_flag.p, 4, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
 	if (worst) return fail(BHIP_E_ARG, "an accelerator entry refers to clump %u >= %u", worst, h->n_clumps);
-	{	// lists in ascending clump order (see k_acx_sort_lists)
-		HIPCHK(hipMemsetAsync(d_flag.p, 0, 16, h->stream));
-		hipLaunchKernelGGL(k_acx_sort_lists, dim3((uint32_t)h->n_cu * 32), dim3(256), 0, h->stream, h->acx_view(), nw, (uint8_t *)h->acx_view().rec, d_flag.as<unsigned long long>());
-		HIPCHK(hipGetLastError());
-		unsigned long long n_sorted = 0;
-		HIPCHK(hipMemcpyAsync(&n_sorted, d_flag.p, 8, hipMemcpyDeviceToHost, h->stream));
-		HIPCHK(hipStreamSynchronize(h->stream));
-		if (n_sorted && getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] accelerator: %llu lists were not in ascending clump order and have been sorted\n", n_sorted);
-	}
 	d_lists.release(); d_lens.release(); d_bdelta.release(); d_bsum.release(); d_bbase.release();
 	if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] accelerator: K=%d, %llu entries (first entry number %llu), %.2f B per entry on the device (records %d B + offsets)\n", K,
 		(unsigned long long)tot, (unsigned long long)h->acx_bias, tot ? (double)(tot * BHIP_REC_BYTES + ((nw + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS) * 64) / (double)tot : 0.0, BHIP_REC_BYTES);

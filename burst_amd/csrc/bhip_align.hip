@@ -240,13 +240,6 @@ static int launch_seed(Handle *h, Lane *L, hipStream_t st, StageSlot *S, int cls
 	return 0;
 }
 
-// prefilter kernel of a (lane, class) list: 2 = merge (queries of at most 8 sampled words: the kernel keeps eight list heads),
-// 0 = counting filter, 1 = exact table; option "prefilter_algo" forces one, otherwise the lane's own choice
-static int effective_pf_algo(const Handle *h, const Lane *L, uint32_t maxwords) {
-	int algo = h->opt_pf_algo >= 0 ? h->opt_pf_algo : L->pf_algo;
-	if (algo == 2 && seed_row_words(maxwords) > 8) algo = h->opt_pf_algo >= 0 ? 0 : L->pf_algo_wide;
-	return algo;
-}
 // dense clump-level kernels into L->cand as (list position, clump) pairs
 static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, const uint32_t *d_qlist, uint32_t n_list, uint32_t maxwords, uint32_t *n_tasks_dev,
                                  uint32_t *n_cand_dev, Counters *dc, int prune) {
@@ -257,18 +250,8 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	// the lookups of this batch may have run ahead (seed_next_batch, during the previous call)
 	if (!(L->seeded_ok[cls] && L->seeded_seq[cls] == h->cur->seq && L->seeded_n[cls] == n_list && L->seeded_W16[cls] == W16))
 		if ((rc = launch_seed(h, L, st, h->cur, cls, d_qlist, n_list, maxwords))) return rc;
-	const int algo = effective_pf_algo(h, L, maxwords);
+	const int algo = h->opt_pf_algo >= 0 ? h->opt_pf_algo : L->pf_algo;
 	const uint32_t n_quads = (n_list + 3) / 4;
-	if (algo == 2) {
-		HIPCHK(hipEventRecord(L->ev_pf[cls][1], st));
-		hipLaunchKernelGGL(k_prefilter_merge, dim3(std::min<uint32_t>((n_list + 63) / 64, (uint32_t)h->n_cu * 32)), dim3(64), 0, st, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list,
-			h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read,
-			L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->qlen_sum, L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], prune);
-		HIPCHK(hipGetLastError());
-		HIPCHK(hipEventRecord(L->ev_pf[cls][2], st));
-		++L->pf_launches;
-		L->pf_algo_used = 2;
-	} else {
 	// hash table size per query from the expected number of distinct clumps (sampled words x occurrence-weighted mean list
 	// length): 512 slots keep 12 single-wave blocks on a CU, 1024 -> 7, 2048 -> 4
 	const double expect = (n_list ? (double)L->seed_words[cls] / (double)n_list : (double)maxwords) * h->acx_wmean;   // mean, not max: outliers use the fallback
@@ -314,7 +297,6 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	HIPCHK(hipEventRecord(L->ev_pf[cls][2], st));
 	++L->pf_launches;
 	L->pf_algo_used = algo;
-	}
 	// dense fallback for overflowed queries (clump-level pairs)
 	const uint32_t *bad = h->bad.as<uint32_t>();
 	const bool narrow = h->cur->st_maxlen < 255u + (uint32_t)h->K;
@@ -500,7 +482,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		const bool masked = NWP && n_pf && h->has_masks && h->opt_lane_masks;
 		// lower-bound pruning (second sweep) only when the minimum per shared slot is all that is wanted, with the counting-filter
 		// kernel (it sees all lane counts of a query at once) and while a list position fits the 24 bits next to the bound
-		const int prune = masked && !all_hits && h->opt_prune && n_list < (1u << 24) && effective_pf_algo(h, L, L->maxwords[cls]) != 1;
+		const int prune = masked && !all_hits && h->opt_prune && n_list < (1u << 24) && (h->opt_pf_algo >= 0 ? h->opt_pf_algo : L->pf_algo) == 0;
 		if (n_pf) {
 			if (masked) { if ((rc = launch_prefilter_mask(h, L, pf, cls, qlist, n_pf, L->maxwords[cls], &dc->n_tasks_cls[cls], &dc->n_cand_cls[cls], dc, prune))) return rc; }
 			else if ((rc = launch_prefilter(h, L, pf, qlist, n_pf, L->cand.as<uint2>(), nullptr, (uint32_t)L->cand_cap, true, &dc->n_cand_cls[cls], dc))) return rc;
@@ -728,9 +710,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			Lane *L = h->lanes[l];
 			// (with the minimum-only semantics the counting-filter kernel also splits off the lanes that cannot hold a minimum --
 			// the second sweep -- which the exact-table kernel does not: it only takes over when most records survive)
-			if (L->n_entries && L->pf_launches && L->pf_algo_used == 0 && L->hc.ent_read > 100000 && (double)L->hc.surv_sum > (all_hits ? 0.20 : 0.50) * (double)L->hc.ent_read) {
-				if (L->pf_algo == 0) L->pf_algo = 1; else L->pf_algo_wide = 1;
-			}
+			if (L->n_entries && L->pf_algo == 0 && L->hc.ent_read > 100000 && (double)L->hc.surv_sum > (all_hits ? 0.20 : 0.50) * (double)L->hc.ent_read) L->pf_algo = 1;
 		}
 		if (getenv("BHIP_DEBUG")) for (uint32_t l = 0; l < nl; ++l) {
 			const Lane *L = h->lanes[l];

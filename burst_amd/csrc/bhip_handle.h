@@ -51,8 +51,6 @@ template <int HTB> __global__ void k_prefilter_mask(const uint2 *, const uint2 *
 template <int CB> __global__ void k_prefilter_cf(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *,
 	uint2 *, uint32_t *, int);
-__global__ void k_prefilter_merge(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, uint32_t, uint2 *, uint32_t *, uint32_t,
-	unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, int);
 __global__ void k_task_filter(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, uint2 *, uint32_t *);
 __global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, BhipAcxView, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t, const uint16_t *);
 template <int NWP> __global__ void k_myers_prefix_task(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *,
@@ -170,8 +168,7 @@ struct Lane {
 	bool pf_masked[kNumClasses] = {false};
 	bool pruned[kNumClasses] = {false};   // a second (filtered) sweep ran for this class
 	int pf_algo_used = 0;
-	int pf_algo_wide = 0;         // ... for classes whose queries sample more than 8 words: 0 = counting filter, 1 = exact table (when most records survive the filter)
-	int pf_algo = 2;              // algorithm of this lane's next prefilter launches (follows opt_pf_algo: -1 = merge, or counting filter / exact table for queries with more than 8 words)
+	int pf_algo = 0;              // algorithm of this lane's next prefilter launches (follows opt_pf_algo: -1 = adapt)
 	const uint32_t *qlist[kNumClasses] = {nullptr};      // (lane, class) lists of the current batch: entries of the slot's sorted index array
 	DBuf peq, peqp, cand, candcnt, wins, raw, wide, scratch, fb_list, gcnt, counters, tasks, tasks2, tasks2k, wins2, rs_lists;
 	// seed lookups (k_seed_ranges) per class: list ranges + query headers for the prefilter.  They depend on the staged batch alone,

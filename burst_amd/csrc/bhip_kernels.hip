@@ -1346,149 +1346,6 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 	if (n_list == 0xFFFFFFFFu) { fb_list[0] = sink; fb_list[1] = sink_h; }       // never: keeps the record loads unconditional
 	if (my_units) { atomicAdd(unit_sum, my_units); atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
 }
-// ------------------------------------------------------------------------------------------------
-// Lane-resolved prefilter, MERGE variant (same inputs and outputs as k_prefilter_cf; queries with at most 8 sampled words).
-// The lists of an accelerator are sorted by clump (the device builder writes them that way, so does the reference with one
-// thread), so "which clumps occur in at least `need` of this query's lists" is a k-way merge: ONE THREAD PER QUERY keeps the
-// head of each of its (up to 8) lists in registers, takes the smallest clump id, counts the lists whose head equals it and
-// moves those on.  No table, no counters, no second look at the records, no LDS round trips between the lanes of a wave -- the
-// counting-filter kernel spends its time on exactly those (two LDS atomics and a ballot per record, 30 % bank conflicts) -- and
-// nothing that can overflow.  Only when `need` lists agree (a few times per query) are the lane masks of the agreeing records
-// added up, bit-sliced, to per-lane counts.  The cursors (40-bit entry number, records left) live in LDS columns private to the
-// thread, because the list that moves on is picked at run time.
-// Queries whose lists hold more than MERGE_CAP records in all (one thread would walk them alone), with more than MERGE_NC
-// candidate clumps, or whose lists are not ascending (an .acx written by a multi-threaded reference run keeps the order its
-// threads finished in: the merge notices a descending step) go to the overflow list and through the dense fallback, as the
-// table overflows of the other kernels do.
-// ------------------------------------------------------------------------------------------------
-#define MERGE_CAP 3072u
-#define MERGE_NC 6u
-__global__ __launch_bounds__(64) void k_prefilter_merge(
-		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
-		const uint8_t *__restrict__ ent, const uint32_t *__restrict__ bad, uint32_t n_bad, uint32_t tot_refs,
-		uint2 *__restrict__ tasks, uint32_t *__restrict__ n_tasks, uint32_t task_cap,
-		unsigned long long *__restrict__ ent_read, uint32_t *__restrict__ fb_list, uint32_t *__restrict__ n_fb,
-		unsigned long long *__restrict__ unit_sum, unsigned long long *__restrict__ qlen_sum,
-		uint2 *__restrict__ tasks2, uint32_t *__restrict__ n_tasks2, int prune) {
-	__shared__ uint32_t s_lo[8][64], s_hi[8][64], s_rem[8][64];
-	__shared__ uint32_t s_cc[MERGE_NC][64];                 // candidate clumps of the thread's query
-	__shared__ unsigned long long s_cn[MERGE_NC][64];       // ... and their sixteen 4-bit lane counts
-	const uint32_t lane = threadIdx.x;
-	unsigned long long my_ent = 0, my_units = 0, my_qlen = 0;
-	for (uint32_t li0 = blockIdx.x * 64u; li0 < n_list; li0 += gridDim.x * 64u) {      // (uniform: the wave reserves its output together)
-		const uint32_t li = li0 + lane;
-		bool live = li < n_list;
-		const uint2 hd = live ? hdr[li] : make_uint2(0, 0);
-		const uint32_t need = hd.x & 0xFFFFu, nwords = live ? hd.x >> 16 : 0u, len = hd.y & 0xFFFu;
-		const uint32_t budget = (hd.y >> 12) & 255u, dper = (hd.y >> 20) & 15u ? (hd.y >> 20) & 15u : 1u;
-		const uint32_t thr = need ? need : 1u;
-		uint32_t h[8], mk[8], T = 0;
-		#pragma unroll
-		for (uint32_t j = 0; j < 8; ++j) {
-			uint2 r = make_uint2(0, 0);
-			if (live && j < nwords && j < W16) r = ranges[(size_t)li * W16 + j];
-			const uint32_t n = r.y & 0xFFFFFFu;
-			s_lo[j][lane] = r.x; s_hi[j][lane] = r.y >> 24; s_rem[j][lane] = n;
-			T += n;
-			h[j] = 0xFFFFFFFFu; mk[j] = 0;
-			if (n) { const uint2 rec = bhip_acx_rec(ent, (unsigned long long)r.x | (unsigned long long)(r.y >> 24) << 32); h[j] = rec.x; mk[j] = rec.y; }
-		}
-		bool spill = live && (T > MERGE_CAP || nwords > 8u);
-		uint32_t ncand = 0, cmax = 0, last = 0;
-		if (live && !spill) {
-			my_ent += T;
-			for (;;) {
-				const uint32_t m01 = h[0] < h[1] ? h[0] : h[1], m23 = h[2] < h[3] ? h[2] : h[3], m45 = h[4] < h[5] ? h[4] : h[5], m67 = h[6] < h[7] ? h[6] : h[7];
-				const uint32_t ma = m01 < m23 ? m01 : m23, mb = m45 < m67 ? m45 : m67, m = ma < mb ? ma : mb;
-				if (m == 0xFFFFFFFFu) break;
-				if (m < last) { spill = true; break; }          // a list that is not ascending: not for a merge
-				last = m;
-				uint32_t eq = 0;
-				#pragma unroll
-				for (uint32_t j = 0; j < 8; ++j) eq |= (h[j] == m ? 1u : 0u) << j;
-				if ((uint32_t)__popc(eq) >= thr) {
-					// per-lane counts of the agreeing lists: bit-sliced adders over their 16-bit lane masks
-					uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-					#pragma unroll
-					for (uint32_t j = 0; j < 8; ++j) {
-						const uint32_t x = (eq >> j) & 1u ? mk[j] : 0u;
-						const uint32_t c0 = b0 & x; b0 ^= x;
-						const uint32_t c1 = b1 & c0; b1 ^= c0;
-						const uint32_t c2 = b2 & c1; b2 ^= c1;
-						b3 |= c2;
-					}
-					const uint32_t first = m * 16u, nv = first < tot_refs ? (tot_refs - first < 16u ? tot_refs - first : 16u) : 0u;     // lanes of the clump that exist
-					unsigned long long cn = 0; uint32_t any = 0;
-					for (uint32_t z = 0; z < nv; ++z) {
-						const uint32_t c = ((b0 >> z) & 1u) | ((b1 >> z) & 1u) << 1 | ((b2 >> z) & 1u) << 2 | ((b3 >> z) & 1u) << 3;
-						if (c >= thr) { cn |= (unsigned long long)c << (4u * z); any = 1; cmax = c > cmax ? c : cmax; }
-					}
-					if (any) {
-						if (ncand < MERGE_NC) { s_cc[ncand][lane] = m; s_cn[ncand][lane] = cn; }
-						++ncand;
-					}
-				}
-				for (uint32_t e = eq; e; e &= e - 1u) {
-					const uint32_t j = (uint32_t)__builtin_ctz(e);
-					const uint32_t rem = s_rem[j][lane] - 1u;
-					s_rem[j][lane] = rem;
-					uint32_t nh = 0xFFFFFFFFu, nm = 0;
-					if (rem) {
-						const uint32_t lo = s_lo[j][lane] + 1u, hi = s_hi[j][lane] + (lo == 0u ? 1u : 0u);
-						s_lo[j][lane] = lo; s_hi[j][lane] = hi;
-						const uint2 rec = bhip_acx_rec(ent, (unsigned long long)lo | (unsigned long long)hi << 32);
-						nh = rec.x; nm = rec.y;
-					}
-					#pragma unroll
-					for (uint32_t k = 0; k < 8; ++k) { h[k] = k == j ? nh : h[k]; mk[k] = k == j ? nm : mk[k]; }
-				}
-			}
-			if (ncand > MERGE_NC) spill = true;
-		}
-		if (spill) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
-		const bool em = live && !spill;
-		// tasks of this query: candidates' lanes (split by the lower bound when only minima are wanted) + every lane of the BadList clumps
-		const uint32_t inv_dper = 65536u / dper + 1u, cut = cmax > thr ? cmax : thr;
-		uint32_t n0 = 0, n1 = 0;
-		if (em) {
-			for (uint32_t k = 0; k < ncand; ++k) {
-				const unsigned long long cn = s_cn[k][lane];
-				for (uint32_t z = 0; z < 16; ++z) { const uint32_t c = (uint32_t)(cn >> (4u * z)) & 15u; if (c) { if (!prune || c >= cut) ++n0; else ++n1; } }
-			}
-			for (uint32_t i = 0; i < n_bad; ++i) { const uint32_t f = bad[i] * 16u; n0 += f < tot_refs ? (tot_refs - f < 16u ? tot_refs - f : 16u) : 0u; }
-		}
-		const uint32_t i0 = wave_incl_scan_u32(n0), i1 = wave_incl_scan_u32(n1);
-		const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
-		uint32_t base0 = 0, base1 = 0;
-		if (lane == 0) { if (t0) base0 = atomicAdd(n_tasks, t0); if (t1) base1 = atomicAdd(n_tasks2, t1); }
-		base0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)base0); base1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)base1);
-		if (em) {
-			uint32_t p0 = base0 + i0 - n0, p1 = base1 + i1 - n1;
-			for (uint32_t k = 0; k < ncand; ++k) {
-				const unsigned long long cn = s_cn[k][lane];
-				const uint32_t c = s_cc[k][lane];
-				for (uint32_t z = 0; z < 16; ++z) {
-					const uint32_t v = (uint32_t)(cn >> (4u * z)) & 15u;
-					if (!v) continue;
-					uint32_t lb = 0;
-					if (prune) { const uint32_t gain = ((v - need) * inv_dper) >> 16; lb = gain >= budget ? 0u : budget - gain; }
-					const uint2 task = make_uint2(li | lb << 24, c * 16u + z);
-					if (!prune || v >= cut) { if (p0 < task_cap) tasks[p0] = task; ++p0; }
-					else { if (p1 < task_cap) tasks2[p1] = task; ++p1; }
-				}
-				++my_units; my_qlen += len;
-			}
-			for (uint32_t i = 0; i < n_bad; ++i) {         // burst.c:4136-4138, 4282-4283: every lane of the ambiguous clumps
-				const uint32_t c = bad[i];
-				for (uint32_t z = 0; z < 16 && c * 16u + z < tot_refs; ++z) { if (p0 < task_cap) tasks[p0] = make_uint2(li, c * 16u + z); ++p0; }
-				++my_units; my_qlen += len;
-			}
-		}
-	}
-	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
-	if (my_units) { atomicAdd(unit_sum, my_units); atomicAdd(qlen_sum, my_qlen); }
-}
-
 #define BHIP_INST_PFCF(CB) \
 	template __global__ void k_prefilter_cf<CB>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, \
 		uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *, \

@@ -43,7 +43,7 @@ def test_one_million_reads_properties(tmp_path_factory):
     assert again.tobytes() == base.tobytes()
     # invariance under the tuning options (independent code paths)
     for opts in ({"lanes": 3}, {"prefilter_table": 10, "rescore_reg": 0}, {"lane_masks": 0}, {"two_stage": 0}, {"prefilter_stride": 6}, {"prune": 0},
-                 {"prefilter_algo": 1}, {"prefilter_algo": 0, "prune": 1}, {"prefilter_algo": 2, "prune": 0}):
+                 {"prefilter_algo": 1}, {"prefilter_algo": 0, "prune": 1}):
         for k, v in opts.items():
             dev.set_option(k, v)
         if "lanes" in opts:

@@ -239,15 +239,8 @@ def test_tuning_options_do_not_change_results(qlen, stride, thres):
                 dev.set_option("prefilter_table", table)
                 dev.set_option("rescore_reg", reg)
                 dev.set_option("lanes", lanes)
-                dev.set_option("prefilter_algo", 0 if table != 10 else -1)      # (-1: the merge kernel where a query samples at most 8 words)
                 got = dev.align_batch(q, all_hits=False)
                 assert_hits_equal(got, exp)
-    for algo in (2, 1, 0, -1):
-        for prune in (1, 0):
-            dev.set_option("prefilter_algo", algo)
-            dev.set_option("prune", prune)
-            assert_hits_equal(dev.align_batch(q, all_hits=False), exp)
-    dev.set_option("prune", 1)
     dev.set_option("prefilter_table", 0)
     dev.set_option("rescore_reg", 1)
     exp_all = oracle_hits(packed, clump_len, tot, q, lut, True)
@@ -273,41 +266,10 @@ def test_prefilter_overflow_paths():
     for all_hits in (False, True):
         exp = oracle_hits(packed, clump_len, tot, q, lut, all_hits)
         assert len(exp) > 12
-        for algo, table in ((0, 9), (0, 11), (0, 0), (2, 0), (-1, 0)):      # (merge kernel: far more than its 6 candidate clumps per query -> overflow list)
-            dev.set_option("prefilter_algo", algo)
+        for table in (9, 11, 0):
             dev.set_option("prefilter_table", table)
             assert_hits_equal(dev.align_batch(q, all_hits=all_hits), exp)
     dev.close()
-
-
-def test_accelerator_lists_out_of_order():
-    """an .acx written by a multi-threaded reference run keeps every list in the order its threads finished their clumps
-    (burst.c:3378-3388 under `omp for`); the merge prefilter walks lists in ascending clump order, so the loader sorts what is
-    not (k_acx_sort_lists).  Lists shuffled here, both formats: the oracle's records with every prefilter kernel."""
-    from burst_amd import capi
-    K = 12
-    seqs = family_db(161, 7, 40, 500, rate=0.04)
-    packed, clump_len, tot = dbutil.pack_clumps(seqs)
-    lens, entries, offs = dbutil.build_acx(seqs, K)
-    rng = np.random.default_rng(5)
-    shuffled = entries.copy()
-    for w in np.flatnonzero(lens > 1):
-        a, b = int(offs[w]), int(offs[w + 1])
-        shuffled[a:b] = rng.permutation(shuffled[a:b])
-    assert not np.array_equal(shuffled, entries)
-    lut = ol.score_lut(1)
-    q, _ = make_queries(seqs, 80, 100, [0, 1, 2, 3], 163, thres=0.97)
-    q.flags = np.zeros(q.n, np.uint8)
-    exp = oracle_hits(packed, clump_len, tot, q, lut, False)
-    assert len(exp) > 40
-    for fmt in (0, 1):
-        dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=dbutil.pack_acx_lists(lens, shuffled, fmt), acx_fmt=fmt, K=K)
-        _, clumps, _, _ = dev.acx_export(K)
-        assert np.array_equal(clumps, entries)                 # ascending again
-        for algo in (2, 0, 1):
-            dev.set_option("prefilter_algo", algo)
-            assert_hits_equal(dev.align_batch(q, all_hits=False), exp)
-        dev.close()
 
 
 def test_randomised_configurations():
@@ -379,7 +341,7 @@ for fmt in (0, 1):
     for all_hits in (False, True):
         exp = T.oracle_hits(packed, clump_len, tot, q, lut, all_hits)
         assert len(exp) > 40
-        for opts in ({"lane_masks": 1, "prefilter_algo": 0}, {"lane_masks": 1, "prefilter_algo": 1}, {"lane_masks": 1, "prefilter_algo": 2}, {"lane_masks": 0}):
+        for opts in ({"lane_masks": 1, "prefilter_algo": 0}, {"lane_masks": 1, "prefilter_algo": 1}, {"lane_masks": 0}):
             for k, v in opts.items():
                 dev.set_option(k, v)
             got = dev.align_batch(q, all_hits=all_hits)
