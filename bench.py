@@ -475,10 +475,13 @@ def main():
                 res["cpu_baseline_skipped"] = "the reference reads an .acx file of %.1f GB; the work directory has %.1f GB free" % (acx_bytes / 1e9, shutil.disk_usage(os.path.dirname(acx)).free / 1e9)
             elif not os.path.exists(acx + ".done"):      # the reference reads an .acx FILE: written here from the tables the device built
                 t = time.time()
-                db.acx_from_device(dev, args.K, 1)
-                host._chk(host.lib().bh_acx_write(C.byref(db.c), acx.encode()))
-                open(acx + ".done", "w").write("ok")
-                log("[bench] .acx for the reference written from the device-built tables in %.1f s (%.2f GB)" % (time.time() - t, os.path.getsize(acx) / 1e9))
+                try:
+                    db.acx_from_device(dev, args.K, 1)
+                    host._chk(host.lib().bh_acx_write(C.byref(db.c), acx.encode()))
+                    open(acx + ".done", "w").write("ok")
+                    log("[bench] .acx for the reference written from the device-built tables in %.1f s (%.2f GB)" % (time.time() - t, os.path.getsize(acx) / 1e9))
+                except Exception as e:
+                    res["cpu_baseline_skipped"] = "could not write the reference's .acx: %s" % e
             if os.path.exists(acx + ".done"):
                 try:
                     res["cpu_baseline"] = cpu_baseline(edx, acx, reads_fa, args)
