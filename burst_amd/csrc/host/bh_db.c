@@ -289,10 +289,11 @@ static void tux_bucket_sort(Tux *pack, uint32_t n) {
 	free(np); free(tmp);
 }
 
-static uint32_t g_latency = 16;
-void bh_set_latency(uint32_t bases) { g_latency = bases; }
 
 int bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_shear, long shear_len, int dedupe, BhDb *db) {
+	return bh_db_from_fasta_ex(path, maxLenQ, thres, do_shear, shear_len, dedupe, 16, db);      /* LATENCY, burst.c:83 */
+}
+int bh_db_from_fasta_ex(const char *path, uint32_t maxLenQ, float thres, int do_shear, long shear_len, int dedupe, uint32_t latency, BhDb *db) {
 	memset(db, 0, sizeof *db);
 	RefRec *R = NULL; uint32_t nR = 0; char *dump = NULL;
 	int rc = parse_ref_fasta(path, &R, &nR, &dump);
@@ -332,14 +333,14 @@ int bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_she
 	 * (burst.c:2149-2186); `-l 0` keeps the input order (2187-2189) */
 	uint32_t *srt = own(db, malloc(((size_t)totR + 1) * 4));
 	uint32_t maxLenR = 0;
-	if (g_latency) {
+	if (latency) {
 		Tux *T = malloc((size_t)totR * sizeof(*T));
 		for (uint32_t i = 0; i < totR; ++i) T[i].s = seq[i], T[i].len = len[i], T[i].ix = i;
 		qsort(T, totR, sizeof(*T), tux_len_cmp);
 		maxLenR = T[totR - 1].len;
 		uint32_t prev = 0, tol = T[0].len;
 		for (uint32_t i = 1; i < totR; ++i) {
-			if (T[i].len > tol + g_latency) {
+			if (T[i].len > tol + latency) {
 				tol = T[i].len;
 				if (i - prev > 1) { if (i - prev > 256) tux_bucket_sort(T + prev, i - prev); else qsort(T + prev, i - prev, sizeof(*T), tux_rest_cmp); }
 				prev = i;
@@ -468,10 +469,10 @@ static void expand_word(const uint8_t *s, int K, int ix, uint32_t w, uint8_t *se
 	for (int i = 0; i < AMB_N[s[ix]]; ++i) expand_word(s, K, ix + 1, (w << 2) | AMB[s[ix]][i], seen, cache, n);
 }
 
-static int g_skip_ambig = 0;
-void bh_set_skip_ambig(int on) { g_skip_ambig = on; }     /* -sa: words holding any ambiguous symbol are left out, no BadList (burst.c:3341, 3360-3366) */
 
-int bh_acx_build(BhDb *db, int K, int z) {
+int bh_acx_build(BhDb *db, int K, int z) { return bh_acx_build_ex(db, K, z, 0); }
+/* skip_ambig = -sa: words holding any ambiguous symbol are left out, no BadList (burst.c:3341, 3360-3366) */
+int bh_acx_build_ex(BhDb *db, int K, int z, int skip_ambig) {
 	const uint64_t nw = 1ull << (2 * K);
 	const uint32_t nC = db->numRclumps;
 	const uint64_t fullSize = K > 14 ? 0x7FFFFFFFull : (1ull << 24);
@@ -509,7 +510,7 @@ int bh_acx_build(BhDb *db, int K, int z) {
 				if (ll < (uint32_t)K) continue;
 				/* expansion budget as the reference estimates it: 3^a (N penalised) or 4^a per window (burst.c:3322-3353) */
 				uint32_t asum = 0;
-				for (uint32_t j = 0; j < ll && !g_skip_ambig; ++j) {
+				for (uint32_t j = 0; j < ll && !skip_ambig; ++j) {
 					if (j >= (uint32_t)K - 1) {
 						tsum += powx[asum & 15];
 						if (lane[j - (K - 1)] > 4 + z) --asum;
@@ -520,7 +521,7 @@ int bh_acx_build(BhDb *db, int K, int z) {
 				if (bad) break;
 				for (uint32_t j = 0; j + K <= ll; ++j) {
 					int skip = 0;
-					if (g_skip_ambig) { for (int k = 0; k < K; ++k) if (lane[j + k] >= 5) { j += k; skip = 1; break; } }
+					if (skip_ambig) { for (int k = 0; k < K; ++k) if (lane[j + k] >= 5) { j += k; skip = 1; break; } }
 					else if (z) for (int k = 0; k < K; ++k) if (lane[j + k] == 5) { j += k; skip = 1; break; }
 					if (skip) continue;
 					uint64_t need = 1; for (int k = 0; k < K; ++k) need *= AMB_N[lane[j + k]];

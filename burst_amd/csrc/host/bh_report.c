@@ -100,9 +100,8 @@ static int cmp_str(const void *a, const void *b) { return strcmp(*(char *const *
 
 /* DUPE_HUNT (burst.c:4563-4570): reject a (hit, rix) whose original reference and start lie within qlen/2 of an
  * accepted one.  wide = 1 reproduces the 64-bit ql2 of the ALLPATHS/FORAGE blocks, 0 the 32-bit one of CAPITALIST. */
-static int g_nodupe;   /* BH_REP_NO_DUPE_HUNT of the current bh_report_ex call (the report is single-threaded) */
-static int dupe_hunt(uint32_t *RC, uint32_t *SC, uint64_t *ddix, uint32_t mapped, uint32_t st, uint32_t ql2, int wide) {
-	if (g_nodupe) return 0;
+static int dupe_hunt(int nodupe, uint32_t *RC, uint32_t *SC, uint64_t *ddix, uint32_t mapped, uint32_t st, uint32_t ql2, int wide) {
+	if (nodupe) return 0;      /* BH_REP_NO_DUPE_HUNT of this call */
 	for (uint64_t d = 0; d < *ddix; ++d) {
 		if (RC[d] != mapped) continue;
 		if (wide) { if ((uint64_t)SC[d] + ql2 > st && (uint64_t)SC[d] < (uint64_t)st + ql2) return 1; }
@@ -136,7 +135,6 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 	const float *LEVELS = tx && tx->strict ? LEVELS_STRICT : LEVELS_LENIENT;
 	const int merged = flags & BH_REP_MERGED_LIST, nodupe = flags & BH_REP_NO_DUPE_HUNT;
 	uint64_t lines = 0;
-	g_nodupe = nodupe;
 	const int dbg = getenv("BURST_HOST_DEBUG") != NULL;
 	const double t_begin = omp_get_wtime();
 	double t_render = 0, t_write = 0;
@@ -226,7 +224,7 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 						FOR_EXPANSIONS(rp, rix, {
 							uint32_t st, ed; coords(db, rp, rix, qlen, &st, &ed); (void)ed;
 							uint32_t mapped = MAPPED(rix);
-							if (!dupe_hunt(RefCache, StCache, &ddix, mapped, st, ql2, 0)) { _Pragma("omp atomic") ++RefCounts[mapped]; }
+							if (!dupe_hunt(nodupe, RefCache, StCache, &ddix, mapped, st, ql2, 0)) { _Pragma("omp atomic") ++RefCounts[mapped]; }
 						});
 					}
 				}
@@ -360,7 +358,7 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 				if (mode == BH_ALLPATHS && rp->ed != list[b]->ed) continue;
 				FOR_EXPANSIONS(rp, rix, {
 					uint32_t st, ed; coords(db, rp, rix, qlen, &st, &ed); (void)ed;
-					if (!dupe_hunt(RefCache, StCache, &ddix, MAPPED(rix), st, ql2, 1)) { RPcache[rix_ix] = rp; RIXcache[rix_ix++] = rix; }
+					if (!dupe_hunt(nodupe, RefCache, StCache, &ddix, MAPPED(rix), st, ql2, 1)) { RPcache[rix_ix] = rp; RIXcache[rix_ix++] = rix; }
 				});
 			}
 			for (uint64_t j = Q->offset[i]; j < Q->offset[i + 1]; ++j) for (uint64_t zz = 0; zz < rix_ix; ++zz) {
@@ -381,7 +379,7 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 				FOR_EXPANSIONS(rp, rix, {
 					uint32_t st, ed; coords(db, rp, rix, qlen, &st, &ed); (void)ed;
 					uint32_t mapped = MAPPED(rix);
-					if (!dupe_hunt(RefCache, StCache, &ddix, mapped, st, ql2, 0)) {
+					if (!dupe_hunt(nodupe, RefCache, StCache, &ddix, mapped, st, ql2, 0)) {
 						if (wt) { Taxa[tix++] = bh_tax_lookup(T, db->refHead[rix], ncbi); best_score = rp->score > best_score ? rp->score : best_score; }   /* burst.c:4760-4762 */
 						if (best == rp || RefCounts[mapped] > RefCounts[bestmap] || (RefCounts[mapped] == RefCounts[bestmap] && mapped < bestmap)) {
 							best = rp; bestmap = mapped; bestrix = rix; have = 1;

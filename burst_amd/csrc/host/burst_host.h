@@ -63,11 +63,11 @@ int  bh_acx_read(const char *path, int K, int z, BhDb *db);
 int  bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_shear, long shear_len, int dedupe, BhDb *db);
 /* DB construction (tooling for tests/bench) */
 int  bh_edx_write(const BhDb *db, const char *path, long db_qlen, float thres);
-/* clump formation tolerance of bh_db_from_fasta, the reference's `-l` (LATENCY, burst.c:83): default 16, 0 = input order */
-void bh_set_latency(uint32_t bases);
-/* -sa for the accelerator builder: leave out every word that holds an ambiguous symbol (burst.c:3360-3366) */
-void bh_set_skip_ambig(int on);
+/* latency = clump formation tolerance, the reference's `-l` (LATENCY, burst.c:83): 16 in bh_db_from_fasta, 0 = input order */
+int  bh_db_from_fasta_ex(const char *path, uint32_t maxLenQ, float thres, int do_shear, long shear_len, int dedupe, uint32_t latency, BhDb *db);
 int  bh_acx_build(BhDb *db, int K, int z);
+/* skip_ambig = -sa: leave out every word that holds an ambiguous symbol (burst.c:3360-3366) */
+int  bh_acx_build_ex(BhDb *db, int K, int z, int skip_ambig);
 /* the accelerator tables of `db` from a device handle that holds this database's accelerator (bhip_acx_export), packed as the
  * reference writes them (burst.c:3501-3530): with a handle whose accelerator was built on the device this is make_accelerator
  * without the host pass */

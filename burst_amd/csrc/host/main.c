@@ -24,8 +24,8 @@ static int code_to_exit(int rc) { return rc == BH_E_USAGE ? 1 : rc == BH_E_IO ? 
 
 /* make_accelerator (burst.c:3304-3532): on the device when there is one (tuples of every lane, radix sort, fold: bhip_init
  * with K and no tables, then bhip_acx_export), else -- or with --host-acx / -sa -- by the host builder.  Same bytes either way. */
-static int build_accelerator(BhDb *db, int K, int z, int device, int on_host) {
-	if (!on_host) {
+static int build_accelerator(BhDb *db, int K, int z, int device, int on_host, int skip_ambig) {
+	if (!on_host && !skip_ambig) {
 		void *hh = NULL;
 		if (!bh_device_open_ex(db, device, z, K, &hh)) {
 			const int rc = bh_acx_from_device(db, hh, K, z);
@@ -35,7 +35,7 @@ static int build_accelerator(BhDb *db, int K, int z, int device, int on_host) {
 		}
 		printf(" --> no device accelerator build (%s); using the host builder\n", bh_last_error());
 	}
-	return bh_acx_build(db, K, z);
+	return bh_acx_build_ex(db, K, z, skip_ambig);
 }
 
 /* the query pipeline (process_queries, burst.c:2980-3223) on a thread of its own: with an .edx database nothing in it depends on
@@ -74,6 +74,7 @@ int main(int argc, char **argv) {
 	float thres = 0.97f;                            /* burst.c:93 */
 	int z = 1, do_rc = 0, incl_ws = 0, makedb = 0, do_shear = 0, do_accel = 0, dedupe = 0, device = 0, K = 0, skip_ambig = 0, threads = 0, rep_flags = 0;
 	long shear_amt = 500, db_qlen = 500;            /* burst.c:94 */
+	uint32_t latency = 16;                          /* burst.c:83 */
 	int n_gpus = 1, n_gpus_given = 0, gather_host = 0, n_dev_list = 0, dev_list[BH_MAX_GPUS], accel_dev = 0, host_acx = 0, shard_db = 0, n_shards = 0;
 	uint64_t batch = 1u << 21;      /* unique queries per device batch: the fixed cost of a batch (launches, synchronisation) is about 1 ms of device time */
 	const char *ref_FN = 0, *query_FN = 0, *output_FN = 0, *xcel_FN = 0, *mkacx_FN = 0, *tax_FN = 0;
@@ -122,7 +123,7 @@ int main(int argc, char **argv) {
 			if (!shear_amt) do_shear = 0;
 		}
 		else if (!strcmp(a, "--unique") || !strcmp(a, "-u")) dedupe = 1;
-		else if (!strcmp(a, "--skipambig") || !strcmp(a, "-sa")) { skip_ambig = 1; bh_set_skip_ambig(1); }
+		else if (!strcmp(a, "--skipambig") || !strcmp(a, "-sa")) skip_ambig = 1;
 		else if (!strcmp(a, "--noprogress")) { }
 		else if (!strcmp(a, "--no-dupe-hunt")) rep_flags |= BH_REP_NO_DUPE_HUNT;   /* diagnostics: print every (hit, reference) expansion */
 		else if (!strcmp(a, "--make-acx")) { NEEDARG("--make-acx"); mkacx_FN = argv[i]; }
@@ -166,7 +167,7 @@ int main(int argc, char **argv) {
 		}
 		else if (!strcmp(a, "--latency") || !strcmp(a, "-l")) {                         /* burst.c:5085-5090 */
 			if (++i == argc || argv[i][0] == '-') { puts("ERROR: --latency requires integer argument"); return 1; }
-			bh_set_latency((uint32_t)atoi(argv[i]));
+			latency = (uint32_t)atoi(argv[i]);
 			printf(" --> Setting clump formation latency to %d bases\n", atoi(argv[i]));
 		}
 		else if (!strcmp(a, "--clustradius") || !strcmp(a, "-cr") || !strcmp(a, "--dbpartition") || !strcmp(a, "-dp")) {
@@ -184,7 +185,7 @@ int main(int argc, char **argv) {
 		if (!ref_FN) { puts("ERROR: --make-acx needs -r DB.edx"); return 1; }
 		BhDb db; int rc0;
 		if ((rc0 = bh_edx_read(ref_FN, &db))) DIE(rc0);
-		if ((rc0 = build_accelerator(&db, K ? K : 12, z, device, host_acx || skip_ambig))) DIE(rc0);
+		if ((rc0 = build_accelerator(&db, K ? K : 12, z, device, host_acx, skip_ambig))) DIE(rc0);
 		if ((rc0 = bh_acx_write(&db, mkacx_FN))) DIE(rc0);
 		printf("Accelerator written: K=%d, %s format, %u ambiguous clumps\n", db.K, db.acxFmt ? "LARGE" : "SMALL", db.badSz);
 		bh_db_free(&db);
@@ -203,7 +204,7 @@ int main(int argc, char **argv) {
 		if (e) { fputs("ERROR: DBs can't make DBs.\n", stderr); return 1; }
 		BhDb db;
 		if (!do_shear) db_qlen = 0;                                             /* burst.c:5121 */
-		if ((rc = bh_db_from_fasta(ref_FN, (uint32_t)db_qlen, thres, do_shear, shear_amt, 1, &db))) DIE(rc);
+		if ((rc = bh_db_from_fasta_ex(ref_FN, (uint32_t)db_qlen, thres, do_shear, shear_amt, 1, latency, &db))) DIE(rc);
 		puts("Writing database...");
 		if ((rc = bh_edx_write(&db, output_FN, db_qlen, thres))) DIE(rc);
 		printf("Database written: %u refs [%u orig], %u clumps, %u maxR\n", db.totR, db.origTotR, db.numRclumps, db.maxLenR);
@@ -211,7 +212,7 @@ int main(int argc, char **argv) {
 			if (!K) K = 12;
 			if (accel_dev || !xcel_FN) { puts("ERROR: -ad builds the accelerator at search time; give -a <name> to write one"); return 1; }
 			printf("Generating accelerator '%s' (K=%d)\n", xcel_FN, K);
-			if ((rc = build_accelerator(&db, K, z, device, host_acx || skip_ambig))) DIE(rc);
+			if ((rc = build_accelerator(&db, K, z, device, host_acx, skip_ambig))) DIE(rc);
 			if ((rc = bh_acx_write(&db, xcel_FN))) DIE(rc);
 		}
 		bh_db_free(&db);
@@ -258,7 +259,7 @@ int main(int argc, char **argv) {
 		printf("Parsed %lu queries, %lu unique [min %u, max %u, maxED %u]; clear %lu, ambiguous %lu, bad %lu\n", (unsigned long)Q.totQ,
 		       (unsigned long)Q.numUniq, Q.minLen, Q.maxLen, Q.maxED, (unsigned long)Q.nClear, (unsigned long)Q.nAmbig, (unsigned long)Q.nBad);
 		PHASE("queries parsed, sorted");
-		if ((rc = bh_db_from_fasta(ref_FN, Q.maxLen, thres, do_shear, shear_amt, dedupe, &db))) DIE(rc);
+		if ((rc = bh_db_from_fasta_ex(ref_FN, Q.maxLen, thres, do_shear, shear_amt, dedupe, latency, &db))) DIE(rc);
 		printf("There are %u references and hence %u clumps\n", db.totR, db.numRclumps);
 	}
 	/* Multi-GPU (--gpus N): one host thread and one device handle per GPU (bh_search_multi, bh_multi.c).  --shard queries (default):
