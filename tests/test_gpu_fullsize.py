@@ -216,7 +216,7 @@ def test_configs4_shape_full_size():
     -m FORAGE -i 0.95 (every placement within budget, burst.c:4224; ambiguous words burst.c:3232-3236), through the product's batch
     scheduler.  Size-independent properties: every read's home placement is reported (a read carries <= 12 edits <= its budget of
     16), every record within budget, the f32 identity of every record, positions inside the clump, records ordered by (query,
-    reference) without duplicates, both strands present; and the first 1 500 reads are diffed against the compiled reference
+    reference) without duplicates, both strands present; and the first 800 reads are diffed against the compiled reference (which needs a minute and a half for them on 256 threads)
     (FORAGE and BEST; FORAGE under the "every differing line explained" rule of _check_diff_lines)."""
     work, refs, edx, acx = _bench_db(320, 0.95)
     from burst_amd import host
@@ -256,6 +256,6 @@ def test_configs4_shape_full_size():
     run.close()
     dev.close()
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "burst12")):
-        lines, out = _scale_diff(1500, dict(BURST_BENCH_DIR=work, SD_EDX=edx, SD_READS=reads, SD_MODES="FORAGE BEST", SD_IDS="0.95", SD_EXTRA="-fr"))
+        lines, out = _scale_diff(800, dict(BURST_BENCH_DIR=work, SD_EDX=edx, SD_READS=reads, SD_MODES="FORAGE BEST", SD_IDS="0.95", SD_EXTRA="-fr"))
         assert len(lines) == 2, out[-3000:]
-        _check_diff_lines(lines, 1500, frac=0.02)
+        _check_diff_lines(lines, 800, frac=0.02)
