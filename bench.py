@@ -389,7 +389,8 @@ def main():
             cols = st["n_task_columns"] if masked else st["n_columns"] * 16
             units = st["n_lane_tasks"] if masked else st["n_pairs"] * 16
             kernels["k_myers_prefix%s<%d>" % ("_task" if masked else "", st["prefix_words"])] = (st["ms_myers_prefix"] / n, (0.5 * cols + units * (args.read_len / 2.0 + 12.0)) / n, "valu")
-            kernels["k_myers_window<%d>" % ((args.read_len + 31) // 32)] = (st["ms_myers_window"] / n, (0.5 * st["n_window_columns"] + st["n_windows"] * (args.read_len / 2.0 + 12.0)) / n, "valu")
+            nw_ = (args.read_len + 31) // 32      # three words and more: the banded kernel takes the windows (k_myers_window_band<2> at E <= 9)
+            kernels["k_myers_window_band<2>" if nw_ >= 3 else "k_myers_window<%d>" % nw_] = (st["ms_myers_window"] / n, (0.5 * st["n_window_columns"] + st["n_windows"] * (args.read_len / 2.0 + 12.0)) / n, "valu")
         else:
             kernels["k_myers<%d>" % ((args.read_len + 31) // 32)] = (st["ms_myers"] / n, st["bytes_algorithmic"] / n, "valu")
         kernels["k_rescore_*"] = (st["ms_rescore"] / nb, (st["n_raw_hits"] * (20.0 + args.read_len / 2.0 + (args.read_len + 16) / 2.0) + st["n_hits"] * 20.0) / nb, "hbm")

@@ -67,7 +67,7 @@ static void launch_prefix(Handle *h, Lane *L, hipStream_t st, int NWP, uint32_t 
 		uint64_t n_pairs_host, uint32_t li_base, const uint32_t *qlist, uint32_t *n_wins, Counters *dc) {
 	#define LP(N) hipLaunchKernelGGL(k_myers_prefix<N>, dim3(grid), dim3(256), 0, st, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist, \
 		L->peqp.as<uint32_t>(), h->s_off(), h->s_emac(), h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
-		h->tot_refs, L->wins.as<BhipWin>(), n_wins, (uint32_t)L->win_cap, &dc->col_sum, &dc->qlen_sum)
+		h->tot_refs, L->wins.as<BhipWin>(), n_wins, (uint32_t)L->win_cap, &dc->col_sum, &dc->qlen_sum, dc->win_class_seen)
 	if (NWP == 1) LP(1); else if (NWP == 2) LP(2); else if (NWP == 3) LP(3); else if (NWP == 4) LP(4); else LP(6);
 	#undef LP
 }
@@ -75,7 +75,7 @@ static void launch_prefix_task(Handle *h, Lane *L, hipStream_t st, int NWP, uint
 		BhipWin *wins, uint32_t *n_wins, Counters *dc) {
 	#define LT(N) hipLaunchKernelGGL(k_myers_prefix_task<N>, dim3(grid), dim3(64), 0, st, tasks, n_tasks_dev, (uint32_t)L->task_cap, qlist, \
 		L->peqp.as<uint32_t>(), h->s_off(), h->s_emac(), h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
-		wins, n_wins, (uint32_t)L->win_cap, &dc->tcol_sum)
+		wins, n_wins, (uint32_t)L->win_cap, &dc->tcol_sum, dc->win_class_seen)
 	if (NWP == 1) LT(1); else if (NWP == 2) LT(2); else if (NWP == 3) LT(3); else if (NWP == 4) LT(4); else LT(6);
 	#undef LT
 }
@@ -93,13 +93,29 @@ static uint32_t blocks_per_cu(const void *fn, uint32_t threads, size_t dyn_lds) 
 	return std::max(1u, std::min(by_reg, by_lds));
 }
 
-static void launch_window(Handle *h, Lane *L, hipStream_t wst, int cls, int NWP, uint32_t grid_cap, const uint32_t *qlist, const BhipWin *wins, const uint32_t *n_wins, Counters *dc) {
+static void launch_window(Handle *h, Lane *L, hipStream_t wst, int cls, int NWP, uint32_t grid_cap, const BhipWin *wins, const uint32_t *n_wins, Counters *dc) {
+	const uint32_t *six = h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr;
+	const int NWc = kClasses[cls];
+	// queries of three words and more: the windows whose flagged diagonals fit the two-word band go to k_myers_window_band, the
+	// full-column kernel takes the rest (flag BHIP_WIN_WIDE, set by the prefix kernels)
+	// the windows whose flagged diagonals fit a band of 2, 3 or 4 words (class 0 .. 2 in the record, set by the prefix kernels) go to
+	// k_myers_window_band<2 .. 4> where the query has more words than that; the full-column kernel takes the rest
+	const int min_class = h->opt_no_band ? 0 : NWc >= 8 ? 3 : NWc >= 6 ? 2 : NWc >= 4 ? 1 : 0;
+	#define LB(BW) { uint32_t per_cu = blocks_per_cu((const void *)k_myers_window_band<BW>, 64u, 0); \
+		if (h->opt_band_blocks > 0 && (uint32_t)h->opt_band_blocks < per_cu) per_cu = (uint32_t)h->opt_band_blocks; \
+		const uint32_t grid = std::min<uint32_t>(grid_cap * 4u, (uint32_t)h->n_cu * per_cu); \
+		hipLaunchKernelGGL(k_myers_window_band<BW>, dim3(grid), dim3(64), 0, wst, wins, n_wins, (uint32_t)L->win_cap, NWP, NWc, L->peq.as<uint32_t>(), six, \
+			h->ref_lane.as<uint4>(), L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), &dc->wcol_sum, dc->win_class_seen); }
+	if (min_class >= 1) LB(2);
+	if (min_class >= 2) LB(3);
+	if (min_class >= 3) LB(4);
+	#undef LB
 	#define LW(N) { const uint32_t thr = (N) <= 8 ? 64u : 256u;      /* NW <= 8: per-thread A/C/G/T profile rows in LDS, 64-thread blocks */ \
 		const uint32_t grid = std::min<uint32_t>(grid_cap * (256u / thr), (uint32_t)h->n_cu * blocks_per_cu((const void *)k_myers_window<N>, thr, 0)); \
-		hipLaunchKernelGGL(k_myers_window<N>, dim3(grid), dim3(thr), 0, wst, wins, n_wins, (uint32_t)L->win_cap, NWP, qlist, \
-		L->peq.as<uint32_t>(), h->s_off(), h->s_emac(), h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr, h->ref_lane.as<uint4>(), \
-		h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), &dc->wcol_sum); }
-	switch (kClasses[cls]) { case 2: LW(2); break; case 4: LW(4); break; case 6: LW(6); break; case 8: LW(8); break; case 10: LW(10); break;
+		hipLaunchKernelGGL(k_myers_window<N>, dim3(grid), dim3(thr), 0, wst, wins, n_wins, (uint32_t)L->win_cap, NWP, min_class, \
+		L->peq.as<uint32_t>(), six, h->ref_lane.as<uint4>(), \
+		L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), &dc->wcol_sum, dc->win_class_seen); }
+	switch (NWc) { case 2: LW(2); break; case 4: LW(4); break; case 6: LW(6); break; case 8: LW(8); break; case 10: LW(10); break;
 		case 16: LW(16); break; default: LW(32); break; }
 	#undef LW
 }
@@ -516,7 +532,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		}
 		HIPCHK(hipEventRecord(ce[4], sw));
 		HIPCHK(hipStreamWaitEvent(po, ce[4], 0));
-		if (NWP) { launch_window(h, L, po, cls, NWP, grid_my, qlist, L->wins.as<BhipWin>(), &dc->n_wins_cls[cls], dc); HIPCHK(hipGetLastError()); }
+		if (NWP) { launch_window(h, L, po, cls, NWP, grid_my, L->wins.as<BhipWin>(), &dc->n_wins_cls[cls], dc); HIPCHK(hipGetLastError()); }
 		L->pruned[cls] = masked && prune && n_pf;
 		if (masked && prune && n_pf) {
 			// second sweep: the deferred lanes whose lower bound is not above the minimum found by the first sweep
@@ -528,7 +544,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipEventRecord(L->ev_ph[cls][1], sw));
 			HIPCHK(hipStreamWaitEvent(po, L->ev_ph[cls][1], 0));
-			launch_window(h, L, po, cls, NWP, grid_my, qlist, L->wins2.as<BhipWin>(), &dc->n_wins2_cls[cls], dc);
+			launch_window(h, L, po, cls, NWP, grid_my, L->wins2.as<BhipWin>(), &dc->n_wins2_cls[cls], dc);
 			HIPCHK(hipGetLastError());
 		}
 		HIPCHK(hipEventRecord(ce[5], po));

@@ -39,10 +39,11 @@ template <int NW> __global__ void k_myers(const uint2 *, const uint32_t *, uint6
 	BhipRawHit *, uint32_t *, uint32_t, uint32_t *, uint8_t *, unsigned long long *, unsigned long long *);
 template <int NWP> __global__ void k_myers_prefix(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
 	const uint64_t *, const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t, BhipWin *, uint32_t *, uint32_t,
-	unsigned long long *, unsigned long long *);
-template <int NW> __global__ void k_myers_window(const BhipWin *, const uint32_t *, uint32_t, int, const uint32_t *, const uint32_t *, const uint64_t *,
-	const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *,
-	unsigned long long *);
+	unsigned long long *, unsigned long long *, uint32_t *);
+template <int NW> __global__ void k_myers_window(const BhipWin *, const uint32_t *, uint32_t, int, int, const uint32_t *, const uint32_t *,
+	const uint4 *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *, unsigned long long *, const uint32_t *);
+template <int BW> __global__ void k_myers_window_band(const BhipWin *, const uint32_t *, uint32_t, int, int, const uint32_t *, const uint32_t *,
+	const uint4 *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *, unsigned long long *, const uint32_t *);
 __global__ void k_extract_kmers(const uint4 *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint32_t, int, unsigned long long *, uint16_t *, uint32_t *);
 __global__ void k_attach_masks(BhipAcxView, uint64_t, const unsigned long long *, const uint16_t *, uint32_t, const uint32_t *, uint8_t *, uint32_t, uint32_t);
 template <int HTB> __global__ void k_prefilter_mask(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
@@ -54,7 +55,7 @@ template <int CB> __global__ void k_prefilter_cf(const uint2 *, const uint2 *, u
 __global__ void k_task_filter(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, uint2 *, uint32_t *);
 __global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, BhipAcxView, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t, const uint16_t *);
 template <int NWP> __global__ void k_myers_prefix_task(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *,
-	const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *);
+	const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *, uint32_t *);
 template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *,
 	const uint32_t *, int, const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t *, const uint64_t *,
 	const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *,
@@ -120,6 +121,7 @@ struct Counters {
 	unsigned long long wcol_sum, tcol_sum, unit_sum;
 	unsigned long long col_sum, qlen_sum, ent_read, scratch_used;
 	unsigned long long surv_sum;           // list records that passed the counting filter (k_prefilter_cf)
+	uint32_t win_class_seen[4];            // [c] != 0: a window of band class c >= 1 was flagged in this call (kernels of unused classes return at once)
 };
 
 // One staged batch.  Query symbols with code 0 (anything outside the IUPAC nucleotide alphabet) cost 255 against every
@@ -248,6 +250,8 @@ struct Handle {
 	int opt_prefilter_stride = 0; // 0 = automatic sparse seeds, s > 0 = every s-th word (1 = the reference's scheme)
 	int opt_lanes = 1;            // sub-pipelines per staged batch (the stage kernels fill the chip on their own; > 1 only helps small batches)
 	int opt_sweep_blocks = 8;     // 256-thread blocks per CU of the column-sweep kernels
+	int opt_band_blocks = 0;      // 64-thread blocks per CU of k_myers_window_band (0: as many as fit)
+	int opt_no_band = 0;          // 1 = every window through the full-column kernel (option "band" 0; the parity tests run both)
 	// asynchronous hand-over of the records (option "async_d2h"): two device buffers alternate, the copy of call k runs on its
 	// own stream while call k+1 computes; the caller's buffers are page-locked once and stay registered
 	int opt_async_d2h = 0, out_idx = 0;

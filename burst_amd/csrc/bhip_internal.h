@@ -17,11 +17,25 @@ struct BhipRawHit {
 
 // A reference lane whose prefix filter fired: the first and the last group of 8 columns (columns 8g + 1 .. 8g + 8, 1-based) that
 // hold a column with prefix score <= budget.  (32-column flags cost the full-length stage 24 columns of slack per window.)
+// The record carries what the full-length stage needs to start (query number, length, budget, where the lane's symbols are),
+// so that stage opens with one load instead of a chain of four dependent ones.
+#define BHIP_WIN_GMASK 0x3FFFFFFFu  // g_first proper; its two top bits: the band class (0 .. 2: a band of 2 .. 4 words holds the flagged diagonals, 3: none does)
 struct BhipWin {
 	uint32_t li;       // list position of the query (peq row)
 	uint32_t refIx;
 	uint32_t g_first, g_last;
+	uint32_t q;        // batch index of the query entry
+	uint32_t mE;       // query length | budget << 16
+	uint32_t nchunks;  // 32-column chunks of the lane
+	uint32_t pad;
+	uint64_t rbase;    // uint4 index of the lane's first chunk in the lane-major copy of the references
+	uint64_t pad2;
 };
+// a band of BW words holds 32 (BW - 1) - 6 diagonals (k_myers_window_band); the flagged ones are 8 (g_last - g_first) + 8 + 2 E
+__host__ __device__ inline uint32_t bhip_win_class(uint32_t g_first, uint32_t g_last, uint32_t E) {
+	const uint64_t diags = 8ull * (g_last - g_first) + 8u + 2u * E;
+	return diags <= 26 ? 0u : diags <= 58 ? 1u : diags <= 90 ? 2u : 3u;
+}
 
 // Routing of a staged batch, filled on the device by k_route (or by the host pass that handles batches with query symbols
 // outside the alphabet): a query entry belongs to the list of its key = ((lane * 7 + length class) * 2 + exhaustive).

@@ -17,6 +17,7 @@
 // No MFMA: the recurrence is integer min-plus / bit logic (VALU + LDS bound).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "burst_hip.h"
 #include "bhip_internal.h"
 
@@ -1504,7 +1505,7 @@ __global__ __launch_bounds__(256) void k_myers_prefix(
 		const uint16_t *__restrict__ qemac,
 		const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
 		uint32_t tot_refs, BhipWin *__restrict__ wins, uint32_t *__restrict__ n_wins, uint32_t win_cap,
-		unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum) {
+		unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum, uint32_t *__restrict__ cls_seen) {
 	__shared__ __attribute__((aligned(16))) uint32_t s_peq[16][16 * NWP];
 	const uint32_t tid = threadIdx.x, g = tid >> 4, z = tid & 15;
 	const uint64_t n_pairs = n_pairs_dev ? ((uint64_t)*n_pairs_dev < n_pairs_host ? (uint64_t)*n_pairs_dev : n_pairs_host) : n_pairs_host;
@@ -1565,7 +1566,13 @@ __global__ __launch_bounds__(256) void k_myers_prefix(
 		const uint32_t refIx = c * 16 + z;
 		if (g_first != 0xFFFFFFFFu && refIx < tot_refs) {
 			const uint32_t pos = atomicAdd(n_wins, 1u);
-			if (pos < win_cap) { BhipWin w; w.li = li; w.refIx = refIx; w.g_first = g_first; w.g_last = g_last; wins[pos] = w; }
+			if (pos < win_cap) {
+				const uint32_t wc = bhip_win_class(g_first, g_last, E);
+				if (wc && !__builtin_nontemporal_load(&cls_seen[wc])) cls_seen[wc] = 1;
+				BhipWin w; w.li = li; w.refIx = refIx; w.g_first = g_first | wc << 30; w.g_last = g_last;
+				w.q = q; w.mE = m | E << 16; w.nchunks = nchunks; w.pad = 0; w.rbase = ref_off[c] * 16 + (uint64_t)z * nchunks; w.pad2 = 0;
+				wins[pos] = w;
+			}
 		}
 		if (z == 0) { my_cols += L; my_qlen += m; }
 	}
@@ -1581,7 +1588,8 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 		const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ peqp, const uint64_t *__restrict__ qoff,
 		const uint16_t *__restrict__ qemac,
 		const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
-		BhipWin *__restrict__ wins, uint32_t *__restrict__ n_wins, uint32_t win_cap, unsigned long long *__restrict__ tcol_sum) {
+		BhipWin *__restrict__ wins, uint32_t *__restrict__ n_wins, uint32_t win_cap, unsigned long long *__restrict__ tcol_sum,
+		uint32_t *__restrict__ cls_seen) {
 	// NWP <= 2: the 16-row prefix table of the task sits in a private LDS column; wider prefixes would leave room for only
 	// 2-3 waves per SIMD that way, so they read the rows from global memory (L1/L2 hits, one dwordx2/x4 load per column)
 	constexpr bool LDS_TAB = NWP <= 2;
@@ -1650,7 +1658,13 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 		}
 		if (g_first != 0xFFFFFFFFu) {
 			const uint32_t pos = atomicAdd(n_wins, 1u);
-			if (pos < win_cap) { BhipWin w; w.li = li; w.refIx = refIx; w.g_first = g_first; w.g_last = g_last; wins[pos] = w; }
+			if (pos < win_cap) {
+				const uint32_t wc = bhip_win_class(g_first, g_last, E);
+				if (wc && !__builtin_nontemporal_load(&cls_seen[wc])) cls_seen[wc] = 1;
+				BhipWin w; w.li = li; w.refIx = refIx; w.g_first = g_first | wc << 30; w.g_last = g_last;
+				w.q = q; w.mE = m | E << 16; w.nchunks = nchunks; w.pad = 0; w.rbase = (uint64_t)(rp - ref); w.pad2 = 0;
+				wins[pos] = w;
+			}
 		}
 		my_cols += L;
 	}
@@ -1692,20 +1706,24 @@ __global__ __launch_bounds__(256) void k_task_filter(const uint2 *__restrict__ i
 
 #define BHIP_INST_PREFIX_TASK(NWP) \
 	template __global__ void k_myers_prefix_task<NWP>(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *, \
-		const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *);
+		const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *, uint32_t *);
 BHIP_INST_PREFIX_TASK(1) BHIP_INST_PREFIX_TASK(2) BHIP_INST_PREFIX_TASK(3) BHIP_INST_PREFIX_TASK(4) BHIP_INST_PREFIX_TASK(6)
 
 template <int NW>
 __global__ __launch_bounds__(256) void k_myers_window(
-		const BhipWin *__restrict__ wins, const uint32_t *__restrict__ n_wins_dev, uint32_t win_cap, int NWP,
-		const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ peq, const uint64_t *__restrict__ qoff,
-		const uint16_t *__restrict__ qemac, const uint32_t *__restrict__ qsix,
-		const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
+		const BhipWin *__restrict__ wins, const uint32_t *__restrict__ n_wins_dev, uint32_t win_cap, int NWP, int min_class,
+		const uint32_t *__restrict__ peq, const uint32_t *__restrict__ qsix, const uint4 *__restrict__ ref,
 		BhipRawHit *__restrict__ raw, uint32_t *__restrict__ n_raw, uint32_t raw_cap, uint32_t *__restrict__ best,
-		unsigned long long *__restrict__ wcol_sum) {
+		unsigned long long *__restrict__ wcol_sum, const uint32_t *__restrict__ cls_seen) {
+	if (min_class > 0) {      // no window of a class left to this kernel was flagged in this call: nothing to look for
+		uint32_t any = 0;
+		for (int c = min_class; c < 4; ++c) any |= cls_seen[c];
+		if (!any) return;
+	}
 	// NW <= 8: the profile rows of A, C, G, T (all a reference without IUPAC codes ever asks for) sit in a private LDS column
 	// (64-thread blocks, 16 * NW bytes per thread); the other twelve rows stay in global memory.  Read from global memory
 	// alone the tables fight over the 32 KB L1 (the kernel then ran fastest at 2 of 8 possible waves per SIMD).
+	// min_class: the windows k_myers_window_band<2 .. 4> take (band class below min_class) are passed over.
 	constexpr bool LDS_TAB = NW <= 8;
 	__shared__ uint32_t s_tab[LDS_TAB ? 4 * NW : 1][LDS_TAB ? 64 : 1];
 	uint32_t n = *n_wins_dev;
@@ -1713,15 +1731,14 @@ __global__ __launch_bounds__(256) void k_myers_window(
 	unsigned long long my_cols = 0;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const BhipWin w = wins[i];
-		const uint32_t li = w.li, q = qlist ? qlist[li] : li;
-		const uint32_t m = (uint32_t)(qoff[q + 1] - qoff[q]), E = qemac[q];
+		if ((int)(w.g_first >> 30) < min_class) continue;
+		const uint32_t li = w.li, q = w.q;
+		const uint32_t m = w.mE & 0xFFFFu, E = w.mE >> 16;
 		const uint32_t P = m < 32u * (uint32_t)NWP ? m : 32u * (uint32_t)NWP;
-		const uint32_t c = w.refIx >> 4, z = w.refIx & 15, L = clump_len[c], nchunks = (L + 31) >> 5;
+		const uint32_t nchunks = w.nchunks, gA8 = w.g_first & BHIP_WIN_GMASK;
 		// prefix ends lie in the 1-based columns 8 g_first + 1 .. 8 g_last + 8: an alignment ending its prefix there starts no earlier
 		// than P + E - 1 columns before and ends no later than (m - P) + E columns behind
-		uint32_t gB = w.g_last;
-		if (gB >= nchunks * 4) gB = nchunks * 4 - 1;
-		const int col_lo = (int)(w.g_first * 8 + 2) - (int)(P + E), col_hi = (int)((gB + 1) * 8 + (m - P) + E);
+		const int col_lo = (int)(gA8 * 8 + 2) - (int)(P + E), col_hi = (int)((w.g_last + 1) * 8 + (m - P) + E);
 		// swept columns [c_lo, c_hi] (0-based), at a granularity of 8 (one dword of reference symbols): a fresh column state is a
 		// valid start anywhere (free start of the semi-global alignment), so nothing before the first needed column is swept
 		const uint32_t c_lo = col_lo > 1 ? (uint32_t)(col_lo - 1) : 0u;
@@ -1737,7 +1754,7 @@ __global__ __launch_bounds__(256) void k_myers_window(
 		}
 		int score = (int)m, bestS = 0x7FFFFFFF;
 		uint32_t first = 0, last = 0;
-		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)z * nchunks;        // lane-major copy
+		const uint4 *rp = ref + w.rbase;        // lane-major copy
 		const uint32_t *tab = peq + (uint64_t)li * 16 * NW;
 		if (LDS_TAB) {          // rows of the codes 1..4 = dwords NW .. 5 * NW - 1 of the table
 			#pragma unroll
@@ -1783,15 +1800,178 @@ __global__ __launch_bounds__(256) void k_myers_window(
 	if (wcol_sum && my_cols) atomicAdd(wcol_sum, my_cols);
 }
 
+// The same sweep for the windows whose flagged diagonals fit a band of BW words (bhip_win_class == BW - 2), whatever the query
+// length class NW > BW.
+// Band: a cell (P, x) of an alignment within E edits has x in the flagged columns, so it lies on a diagonal x - y in
+// [8 g_first + 1 - P, 8 g_last + 8 - P], and every other cell of that alignment within E diagonals of it: dmax - dmin + 1 =
+// 8 (g_last - g_first) + 8 + 2 E diagonals.  While at most 32 (BW - 1) - 6 of them, the rows any such alignment touches
+// within one dword of reference symbols (8 columns, the band climbs 8 rows) fit in BW consecutive words of the column: only
+// those are stepped, and they move up one word when the band has left the lowest one.  The row under the lowest word is
+// taken to grow by one per column, and a word not reached yet keeps its column-0 deltas (+1 per row): both are upper bounds
+// of the true cells, so every cell outside the band is over-estimated, every cell an alignment within E edits passes through
+// is exact, and (minimum, first and last end column) come out as from the full column whenever the minimum is <= E -- which
+// is all that is ever reported.  The A/C/G/T rows of the BW words sit in LDS (4 BW dwords per thread); the rows of the word
+// above wait in registers, loaded one move ahead, so that a move never waits for memory.
+template <int BW>
+__global__ __launch_bounds__(64) void k_myers_window_band(
+		const BhipWin *__restrict__ wins, const uint32_t *__restrict__ n_wins_dev, uint32_t win_cap, int NWP, int NW,
+		const uint32_t *__restrict__ peq, const uint32_t *__restrict__ qsix, const uint4 *__restrict__ ref,
+		BhipRawHit *__restrict__ raw, uint32_t *__restrict__ n_raw, uint32_t raw_cap, uint32_t *__restrict__ best,
+		unsigned long long *__restrict__ wcol_sum, const uint32_t *__restrict__ cls_seen) {
+	if (BW > 2 && !cls_seen[BW - 2]) return;
+	__shared__ uint32_t s_tab[4 * BW][64];          // [BW * (code - 1) + word of the band][thread]
+	const uint32_t tid = threadIdx.x;
+	uint32_t n = *n_wins_dev;
+	if (n > win_cap) n = win_cap;
+	unsigned long long my_cols = 0;
+	for (uint32_t i = blockIdx.x * 64u + tid; i < n; i += gridDim.x * 64u) {
+		const BhipWin w = wins[i];
+		if (w.g_first >> 30 != (uint32_t)(BW - 2)) continue;
+		const uint32_t m = w.mE & 0xFFFFu, E = w.mE >> 16, g_first = w.g_first & BHIP_WIN_GMASK;
+		const uint32_t P = m < 32u * (uint32_t)NWP ? m : 32u * (uint32_t)NWP;
+		const uint32_t nchunks = w.nchunks;
+		const int col_lo = (int)(g_first * 8 + 2) - (int)(P + E), col_hi = (int)((w.g_last + 1) * 8 + (m - P) + E);
+		const uint32_t c_lo = col_lo > 1 ? (uint32_t)(col_lo - 1) : 0u;
+		uint32_t c_hi = (uint32_t)(col_hi - 1);
+		if (c_hi >= nchunks * 32) c_hi = nchunks * 32 - 1;
+		const uint32_t jA = c_lo >> 3, jB = c_hi >> 3, tB = jB >> 2;      // dwords of 8 symbols / last chunk of 32
+		const int dmax = (int)(w.g_last * 8 + 8) - (int)P + (int)E;
+		const int shift = 32 * NW - (int)m;           // filler rows under the query (bit of query row y = shift + y - 1)
+		int ylo = (int)(jA * 8 + 1) - dmax; if (ylo < 0) ylo = 0;      // lowest row needed in the first column (0: the free-start row)
+		int wb = (shift - 1 + ylo) >> 5;
+		wb = wb < 0 ? 0 : (wb > NW - BW ? NW - BW : wb);
+		auto init_word = [&](int k) -> uint32_t { const int lo = shift - 32 * k; return lo <= 0 ? 0xFFFFFFFFu : (lo >= 32 ? 0u : (0xFFFFFFFFu << lo)); };
+		uint32_t Pb[BW], Mb[BW];
+		#pragma unroll
+		for (int k = 0; k < BW; ++k) { Pb[k] = init_word(wb + k); Mb[k] = 0; }
+		int sc = 32 * (wb + BW) - shift; sc = sc < 0 ? 0 : sc;   // D at the top row of the highest word, one column before the first
+		uint32_t hb = 32 * wb > shift ? 1u : 0u;                 // the row under the lowest word is a query row: +1 per column
+		bool top = wb == NW - BW;                                // the last query row is in the band's words: its score is compared
+		int bestS = 0x7FFFFFFF;
+		uint32_t first = 0, last = 0;
+		const uint4 *rp = ref + w.rbase;
+		const uint32_t *tab = peq + (uint64_t)w.li * 16 * (uint32_t)NW;
+		uint32_t nx[4];                              // the rows of the word above, fetched a move ahead
+		#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			#pragma unroll
+			for (int k = 0; k < BW; ++k) s_tab[BW * r + k][tid] = tab[(r + 1) * NW + wb + k];
+			nx[r] = tab[(r + 1) * NW + (wb + BW < NW ? wb + BW : NW - 1)];
+		}
+		// track: the highest word is the query's last, so sc is D[m][col] -- before that there is nothing to compare
+		auto step = [&](auto track, const uint32_t (&Eq)[BW], uint32_t col) {
+			uint32_t Ph[BW], Mh[BW];
+			uint32_t carry = 0;
+			#pragma unroll
+			for (int k = 0; k < BW; ++k) {
+				uint32_t co;
+				const uint32_t sum = __builtin_addc(Eq[k] & Pb[k], Pb[k], carry, &co);
+				carry = co;
+				const uint32_t Xh = (sum ^ Pb[k]) | Eq[k];
+				Ph[k] = Mb[k] | ~(Xh | Pb[k]);
+				Mh[k] = Pb[k] & Xh;
+			}
+			uint32_t cP = 0, cM = 0;
+			#pragma unroll
+			for (int k = 0; k < BW; ++k) {
+				uint32_t co;
+				Ph[k] = __builtin_addc(Ph[k], Ph[k], cP, &co); cP = co;
+				Mh[k] = __builtin_addc(Mh[k], Mh[k], cM, &co); cM = co;
+			}
+			Ph[0] |= hb;
+			sc += (int)cP - (int)cM;
+			#pragma unroll
+			for (int k = 0; k < BW; ++k) {
+				const uint32_t Xv = Eq[k] | Mb[k];
+				Pb[k] = Mh[k] | ~(Xv | Ph[k]);
+				Mb[k] = Ph[k] & Xv;
+			}
+			if constexpr (decltype(track)::value) {
+				const bool lt = sc < bestS, le = sc <= bestS;
+				bestS = lt ? sc : bestS;
+				first = lt ? col : first;
+				last = le ? col : last;
+			}
+		};
+		auto sweep8 = [&](auto track, uint32_t d, uint32_t col0) {
+			const uint32_t dm = d - 0x11111111u;
+			if ((dm & 0xCCCCCCCCu) == 0) {       // eight of A, C, G, T: rows from LDS, no test per symbol
+				#pragma unroll
+				for (int k8 = 0; k8 < 8; ++k8) {
+					const uint32_t r = ((dm >> (4 * k8)) & 3u) * (uint32_t)BW;
+					uint32_t Eq[BW];
+					#pragma unroll
+					for (int k = 0; k < BW; ++k) Eq[k] = s_tab[r + k][tid];
+					step(track, Eq, col0 + (uint32_t)k8);
+				}
+			} else {
+				#pragma unroll
+				for (int k8 = 0; k8 < 8; ++k8) {
+					const uint32_t sym = (d >> (4 * k8)) & 15u;
+					uint32_t Eq[BW];
+					#pragma unroll
+					for (int k = 0; k < BW; ++k) Eq[k] = tab[sym * NW + wb + k];
+					step(track, Eq, col0 + (uint32_t)k8);
+				}
+			}
+		};
+		uint32_t tcur = jA >> 2;
+		// the dword in turn is always c0: the chunk is a shift register of four scalars (a component of a uint4 picked by j & 3, or
+		// shifted in place, sent both chunks to scratch memory); n0..n3 = the next 16 bytes of this lane, loaded a chunk ahead
+		uint32_t c0, c1, c2, c3, n0, n1, n2, n3;
+		{ const uint4 v = rp[tcur]; c0 = v.x; c1 = v.y; c2 = v.z; c3 = v.w; }
+		{ const uint4 v = tcur < tB ? rp[tcur + 1] : make_uint4(0, 0, 0, 0); n0 = v.x; n1 = v.y; n2 = v.z; n3 = v.w; }
+		for (uint32_t r = 0; r < (jA & 3u); ++r) { c0 = c1; c1 = c2; c2 = c3; }
+		for (uint32_t j = jA; j <= jB; ++j) {
+			const uint32_t d = c0;
+			const uint32_t col0 = j * 8 + 1;
+			if (wb < NW - BW && (int)col0 - dmax + shift - 1 >= 32 * (wb + 1)) {     // the band has left the lowest word
+				++wb;
+				#pragma unroll
+				for (int k = 0; k + 1 < BW; ++k) { Pb[k] = Pb[k + 1]; Mb[k] = Mb[k + 1]; }
+				Pb[BW - 1] = init_word(wb + BW - 1); Mb[BW - 1] = 0;
+				sc += __popc(Pb[BW - 1]);
+				hb = 32 * wb > shift ? 1u : 0u;
+				top = wb == NW - BW;
+				#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					#pragma unroll
+					for (int k = 0; k + 1 < BW; ++k) s_tab[BW * r + k][tid] = s_tab[BW * r + k + 1][tid];
+					s_tab[BW * r + BW - 1][tid] = nx[r];
+					nx[r] = tab[(r + 1) * NW + (wb + BW < NW ? wb + BW : NW - 1)];
+				}
+			}
+			if (top) sweep8(std::true_type(), d, col0); else sweep8(std::false_type(), d, col0);
+			if ((j & 3u) == 3u) {
+				c0 = n0; c1 = n1; c2 = n2; c3 = n3; ++tcur;
+				if (tcur < tB) { const uint4 v = rp[tcur + 1]; n0 = v.x; n1 = v.y; n2 = v.z; n3 = v.w; }
+			} else { c0 = c1; c1 = c2; c2 = c3; }
+		}
+		my_cols += (jB - jA + 1) * 8;
+		if ((uint32_t)bestS <= E) {
+			const uint32_t pos = atomicAdd(n_raw, 1u);
+			if (pos < raw_cap) {
+				BhipRawHit h; h.q = w.q; h.refIx = w.refIx; h.ed = (uint32_t)bestS; h.e_first = first; h.e_last = last;
+				raw[pos] = h;
+			}
+			if (best) atomicMin(&best[qsix ? qsix[w.q] : w.q], (uint32_t)bestS);
+		}
+	}
+	if (wcol_sum && my_cols) atomicAdd(wcol_sum, my_cols);
+}
+#define BHIP_INST_BAND(BW) \
+	template __global__ void k_myers_window_band<BW>(const BhipWin *, const uint32_t *, uint32_t, int, int, const uint32_t *, const uint32_t *, \
+		const uint4 *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *, unsigned long long *, const uint32_t *);
+BHIP_INST_BAND(2) BHIP_INST_BAND(3) BHIP_INST_BAND(4)
+
 #define BHIP_INST_PREFIX(NWP) \
 	template __global__ void k_myers_prefix<NWP>(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *, \
 		const uint64_t *, const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t, BhipWin *, uint32_t *, uint32_t, \
-		unsigned long long *, unsigned long long *);
+		unsigned long long *, unsigned long long *, uint32_t *);
 BHIP_INST_PREFIX(1) BHIP_INST_PREFIX(2) BHIP_INST_PREFIX(3) BHIP_INST_PREFIX(4) BHIP_INST_PREFIX(6)
 #define BHIP_INST_WINDOW(NW) \
-	template __global__ void k_myers_window<NW>(const BhipWin *, const uint32_t *, uint32_t, int, const uint32_t *, const uint32_t *, const uint64_t *, \
-		const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *, \
-		unsigned long long *);
+	template __global__ void k_myers_window<NW>(const BhipWin *, const uint32_t *, uint32_t, int, int, const uint32_t *, const uint32_t *, \
+		const uint4 *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *, unsigned long long *, const uint32_t *);
 BHIP_INST_WINDOW(2) BHIP_INST_WINDOW(4) BHIP_INST_WINDOW(6) BHIP_INST_WINDOW(8) BHIP_INST_WINDOW(10) BHIP_INST_WINDOW(16) BHIP_INST_WINDOW(32)
 
 #define BHIP_INST_MYERS(NW) \

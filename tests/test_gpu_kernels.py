@@ -248,6 +248,48 @@ def test_tuning_options_do_not_change_results(qlen, stride, thres):
     dev.close()
 
 
+@pytest.mark.parametrize("qlen,thres,edits", [(100, 0.97, [0, 1, 2, 3]), (150, 0.95, [0, 3, 7]), (200, 0.97, [0, 2, 6]), (292, 0.97, [0, 4, 8, 9]),
+                                              (320, 0.95, [0, 8, 16]), (400, 0.9, [0, 10, 40]), (700, 0.98, [0, 5, 14])])
+def test_banded_window_equals_full_column(qlen, thres, edits):
+    """k_myers_window_band<2..4> steps only the words of the column the flagged diagonals cross; the full-column kernel takes the
+    windows no band holds.  Option "band" 0 sends every window through the full column: same records, both equal to the oracle.
+    References with tandem repeats flag long runs of columns (wide windows, several classes in one batch); reads from the first and
+    last columns of a lane put the band against the matrix edges."""
+    from burst_amd import capi
+    K = 12
+    rng = np.random.default_rng(7 * qlen)
+    seqs = family_db(300 + qlen, 5, 20 if qlen <= 200 else 8, qlen + 260, rate=0.03)
+    unit = rng.integers(1, 5, size=int(rng.integers(3, 9)), dtype=np.uint8)
+    for i in range(0, len(seqs), 4):                       # a tandem repeat inside every fourth reference
+        sq = np.array(seqs[i], np.uint8); a = int(rng.integers(20, len(sq) - 120)); n = int(rng.integers(40, 100))
+        sq[a:a + n] = np.resize(unit, n); seqs[i] = sq
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lens, entries, offs = dbutil.build_acx(seqs, K)
+    lut = ol.score_lut(1)
+    q, allq = make_queries(seqs, 70 if qlen <= 200 else 30, qlen, edits, 500 + qlen, thres=thres)
+    # reads cut from the two ends of references
+    ends = []
+    for i in range(0, len(seqs), 7):
+        sq = np.array(seqs[i], np.uint8)
+        ends += [sq[:qlen].copy(), sq[len(sq) - qlen:].copy(), sq[1:qlen + 1].copy()]
+    nq = len(ends)
+    allr = ends + [synth.revcomp(r) for r in ends]
+    q2 = capi.Queries(allr, [budget(thres, qlen)] * (2 * nq), list(range(nq)) * 2, [0] * nq + [1] * nq)
+    exps = {(i, ah): oracle_hits(packed, clump_len, tot, qq, lut, ah) for i, qq in enumerate((q, q2)) for ah in (False, True)}
+    assert all(len(e) > 10 for e in exps.values())
+    for accel in (True, False):
+        kw = dict(acx_lens=lens, acx_lists=dbutil.pack_acx_lists(lens, entries, 0), acx_fmt=0, K=K) if accel else {}
+        dev = capi.Device(packed, clump_len, tot, lut, **kw)
+        dev.set_option("lane_min_entries", 8)
+        for i, qq in enumerate((q, q2)):
+            qq.flags = np.zeros(qq.n, np.uint8) if accel else None
+            for all_hits in (False, True):
+                for band in (1, 0):
+                    dev.set_option("band", band)
+                    assert_hits_equal(dev.align_batch(qq, all_hits=all_hits), exps[(i, all_hits)])
+        dev.close()
+
+
 def test_prefilter_overflow_paths():
     """one huge family: every query meets > 300 clumps.  With the 512-slot table the per-query hash overflows (dense
     fallback kernel); with 2048 slots it fits but there are far more than 24 candidate clumps per query (clump-level

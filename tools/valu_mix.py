@@ -7,7 +7,7 @@ v_lshlrev_b32 and DPP moves.  valu_frac in profiles/pmc_summary.json counts ever
 (whole kernel body); the hot kernels are dominated by their unrolled inner loops."""
 import json, os, re, subprocess, sys, tempfile
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {"k_myers_prefix_task<1>": "_Z19k_myers_prefix_taskILi1E", "k_myers_window<4>": "_Z14k_myers_windowILi4E", "k_rescore_reg<0>": "_Z13k_rescore_regILi0E",
+KERNELS = {"k_myers_prefix_task<1>": "_Z19k_myers_prefix_taskILi1E", "k_myers_window<4>": "_Z14k_myers_windowILi4E", "k_myers_window_band<2>": "_Z19k_myers_window_bandILi2E", "k_rescore_reg<0>": "_Z13k_rescore_regILi0E",
            "k_prefilter_cf<9>": "_Z14k_prefilter_cfILi9E", "k_seed_ranges": "_Z13k_seed_ranges", "k_build_peq": "_Z11k_build_peq"}
 HALF_E32 = ("v_lshlrev_b32", "v_addc_co_u32", "v_subb_co_u32", "v_subbrev_co_u32", "v_mul_")
 def cost(m):
