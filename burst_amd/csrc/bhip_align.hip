@@ -102,8 +102,8 @@ static void launch_window(Handle *h, Lane *L, hipStream_t wst, int cls, int NWP,
 	// k_myers_window_band<2 .. 4> where the query has more words than that; the full-column kernel takes the rest
 	const int min_class = h->opt_no_band ? 0 : NWc >= 8 ? 3 : NWc >= 6 ? 2 : NWc >= 4 ? 1 : 0;
 	#define LB(BW) { uint32_t per_cu = blocks_per_cu((const void *)k_myers_window_band<BW>, 64u, 0); \
-		if (h->opt_band_blocks > 0 && (uint32_t)h->opt_band_blocks < per_cu) per_cu = (uint32_t)h->opt_band_blocks; \
-		const uint32_t grid = std::min<uint32_t>(grid_cap * 4u, (uint32_t)h->n_cu * per_cu); \
+		if (h->opt_band_blocks > 0) per_cu = (uint32_t)h->opt_band_blocks; \
+		const uint32_t grid = (uint32_t)h->n_cu * per_cu * (uint32_t)h->opt_oversub; \
 		hipLaunchKernelGGL(k_myers_window_band<BW>, dim3(grid), dim3(64), 0, wst, wins, n_wins, (uint32_t)L->win_cap, NWP, NWc, L->peq.as<uint32_t>(), six, \
 			h->ref_lane.as<uint4>(), L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), &dc->wcol_sum, dc->win_class_seen); }
 	if (min_class >= 1) LB(2);
@@ -510,7 +510,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		HIPCHK(hipStreamWaitEvent(sw, ce[2], 0));
 		HIPCHK(hipEventRecord(ce[6], sw));
 		if (n_pf) {
-			if (masked) launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 4u * (uint32_t)h->opt_sweep_blocks, L->tasks.as<uint2>(), &dc->n_tasks_cls[cls], qlist, L->wins.as<BhipWin>(), &dc->n_wins_cls[cls], dc);
+			if (masked) launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 4u * (uint32_t)h->opt_sweep_blocks * (uint32_t)h->opt_oversub, L->tasks.as<uint2>(), &dc->n_tasks_cls[cls], qlist, L->wins.as<BhipWin>(), &dc->n_wins_cls[cls], dc);
 			// (beside the lane tasks the clump-level pairs are the rare overflow of the prefilter, usually none at all: a small grid --
 			// an empty launch of 2 048 workgroups waited ~0.24 ms for slots on a device busy with the next batch's seed lookups and staging)
 			if (NWP) launch_prefix(h, L, sw, NWP, masked ? std::min<uint32_t>(grid_my, (uint32_t)h->n_cu) : grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, &dc->n_wins_cls[cls], dc);
@@ -540,7 +540,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 			HIPCHK(hipStreamWaitEvent(sw, L->ev_ph[cls][0], 0));
 			hipLaunchKernelGGL(k_task_filter, dim3((uint32_t)h->n_cu * 8), dim3(256), 0, sw, L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], (uint32_t)L->task_cap, qlist,
 				h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr, h->best.as<uint32_t>(), L->tasks2k.as<uint2>(), &dc->n_tasks2k_cls[cls]);
-			launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 4u * (uint32_t)h->opt_sweep_blocks, L->tasks2k.as<uint2>(), &dc->n_tasks2k_cls[cls], qlist, L->wins2.as<BhipWin>(), &dc->n_wins2_cls[cls], dc);
+			launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 4u * (uint32_t)h->opt_sweep_blocks * (uint32_t)h->opt_oversub, L->tasks2k.as<uint2>(), &dc->n_tasks2k_cls[cls], qlist, L->wins2.as<BhipWin>(), &dc->n_wins2_cls[cls], dc);
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipEventRecord(L->ev_ph[cls][1], sw));
 			HIPCHK(hipStreamWaitEvent(po, L->ev_ph[cls][1], 0));
@@ -569,7 +569,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		band_rows, h->opt_rescore_reg);
 	HIPCHK(hipGetLastError());
 	if (h->opt_rescore_reg) {
-#define RS_LAUNCH(SET, BLOCKS) hipLaunchKernelGGL(k_rescore_reg<SET>, dim3((uint32_t)h->n_cu * std::min<uint32_t>(32u, blocks_per_cu((const void *)k_rescore_reg<SET>, 64, 0))), dim3(64), 0, po, L->raw.as<BhipRawHit>(), L->rs_lists.as<uint32_t>(), dc->n_rs, (uint32_t)L->raw_cap, \
+#define RS_LAUNCH(SET, BLOCKS) hipLaunchKernelGGL(k_rescore_reg<SET>, dim3((uint32_t)h->n_cu * std::min<uint32_t>(32u, blocks_per_cu((const void *)k_rescore_reg<SET>, 64, 0)) * (uint32_t)h->opt_oversub), dim3(64), 0, po, L->raw.as<BhipRawHit>(), L->rs_lists.as<uint32_t>(), dc->n_rs, (uint32_t)L->raw_cap, \
 			h->cur->qoff.as<uint64_t>(), h->cur->st_has_rc ? h->cur->qrc.as<uint8_t>() : nullptr, h->cur->qpack.as<uint32_t>(), qw_g, \
 			h->ref_lane.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, &sc->err)
 		RS_LAUNCH(0, 16);

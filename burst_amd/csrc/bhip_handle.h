@@ -250,6 +250,7 @@ struct Handle {
 	int opt_prefilter_stride = 0; // 0 = automatic sparse seeds, s > 0 = every s-th word (1 = the reference's scheme)
 	int opt_lanes = 1;            // sub-pipelines per staged batch (the stage kernels fill the chip on their own; > 1 only helps small batches)
 	int opt_sweep_blocks = 8;     // 256-thread blocks per CU of the column-sweep kernels
+	int opt_oversub = 2;          // blocks launched per resident block slot of the per-item kernels (prefix tasks, windows, re-scoring)
 	int opt_band_blocks = 0;      // 64-thread blocks per CU of k_myers_window_band (0: as many as fit)
 	int opt_no_band = 0;          // 1 = every window through the full-column kernel (option "band" 0; the parity tests run both)
 	// asynchronous hand-over of the records (option "async_d2h"): two device buffers alternate, the copy of call k runs on its

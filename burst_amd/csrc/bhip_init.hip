@@ -186,7 +186,8 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 	if (!strcmp(name, "seed_ahead")) { h->opt_seed_ahead = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "peq_ahead_blocks")) { if (value < 1 || value > 16) return fail(BHIP_E_ARG, "peq_ahead_blocks must be 1 .. 16"); h->opt_peq_ahead_blocks = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "seed_ahead_blocks")) { if (value < 0 || value > 64) return fail(BHIP_E_ARG, "seed_ahead_blocks must be 0 .. 64"); h->opt_seed_ahead_blocks = (int)value; return BHIP_OK; }
-	if (!strcmp(name, "band_blocks")) { if (value < 0 || value > 32) return fail(BHIP_E_ARG, "band_blocks must be 0 .. 32"); h->opt_band_blocks = (int)value; return BHIP_OK; }
+	if (!strcmp(name, "band_blocks")) { if (value < 0 || value > 1024) return fail(BHIP_E_ARG, "band_blocks must be 0 .. 1024"); h->opt_band_blocks = (int)value; return BHIP_OK; }
+	if (!strcmp(name, "oversub")) { if (value < 1 || value > 16) return fail(BHIP_E_ARG, "oversub must be 1 .. 16"); h->opt_oversub = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "band")) { h->opt_no_band = value == 0; return BHIP_OK; }
 	if (!strcmp(name, "prune")) { h->opt_prune = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "rescore_reg")) { h->opt_rescore_reg = value != 0; return BHIP_OK; }

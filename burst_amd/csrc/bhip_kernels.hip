@@ -2444,6 +2444,11 @@ __device__ __forceinline__ void rescore_reg_one(
 		uint32_t d[NW];
 		#pragma unroll
 		for (int i = 0; i < NW; ++i) d[i] = ref_dword_lane(refw, cbase, z, j8 + i, nchunks);
+		auto all_acgt = [&]() { uint32_t bad = 0;
+			#pragma unroll
+			for (int i = 0; i < NW; ++i) bad |= (d[i] - 0x11111111u) & 0xCCCCCCCCu;
+			return bad == 0; };
+		bool dclean = all_acgt();                 // every symbol of the register window is one of A, C, G, T (codes 1..4)
 		// the symbols ahead of the window come 32 at a time (one 16-byte load per 32 rows instead of a 4-byte load per 8 rows)
 		int jn = j8 + NW;                                      // dword index of the next refill
 		uint4 ahead = ref_chunk_lane(refw, cbase, z, jn >> 2, nchunks);
@@ -2478,6 +2483,28 @@ __device__ __forceinline__ void rescore_reg_one(
 					prev_sym = r;
 					bd[k] = cell;
 				}
+			} else if (x0 >= 1 && dclean && qc - 1u < 4u && (mrow & 0x1Eu) == (1u << qc)) {
+				// the usual row: query symbol and all reference symbols in reach are A/C/G/T, of which only the equal one costs 0 --
+				// the eight costs of a dword come from three integer operations (a nibble of x is zero iff the symbols are equal;
+				// bit 3 of (x & 7 + 7) | x is set iff the nibble is not), and no cell of the row lies left of column 1
+				uint32_t nz[NW - 1];
+				#pragma unroll
+				for (int i = 0; i < NW - 1; ++i) { const uint32_t x = dd[i] ^ (qc * 0x11111111u); nz[i] = ((x & 0x77777777u) + 0x77777777u) | x; }
+				uint32_t left = (x0 - 1 == 0) ? col0 : INVALID;
+				uint32_t dg = bd[0];
+				#pragma unroll
+				for (int k = 0; k < WB; ++k) {
+					const uint32_t up = bd[k + 1];
+					const uint32_t cD = dg + (((nz[k >> 3] >> (4 * (k & 7) + 3)) & 1u) << SS), cU = up + STEP_U, cL = left + STEP_L;
+					uint32_t cm = cD < cU ? cD : cU;
+					cm = cm < cL ? cm : cL;
+					cm &= ~0x300u;
+					uint32_t cell = cm >= LIM ? INVALID : cm;
+					if (k > kmax) cell = INVALID;
+					bd[k] = cell;
+					left = cell;
+					dg = up;
+				}
 			} else {
 				uint32_t left = (x0 - 1 == 0) ? col0 : INVALID;
 				uint32_t dg = bd[0];
@@ -2503,6 +2530,7 @@ __device__ __forceinline__ void rescore_reg_one(
 				#pragma unroll
 				for (int i = 0; i < NW - 1; ++i) d[i] = d[i + 1];
 				d[NW - 1] = pick4(ahead, (uint32_t)jn & 3u);
+				dclean = all_acgt();
 				++j8; ++jn;
 				if ((jn & 3) == 0) ahead = ref_chunk_lane(refw, cbase, z, jn >> 2, nchunks);
 			}

@@ -243,6 +243,9 @@ def test_tuning_options_do_not_change_results(qlen, stride, thres):
                 assert_hits_equal(got, exp)
     dev.set_option("prefilter_table", 0)
     dev.set_option("rescore_reg", 1)
+    for oversub, band, band_blocks in ((1, 1, 0), (4, 0, 0), (3, 1, 5), (2, 1, 0)):      # grids of the per-item kernels, banded / full-column windows
+        dev.set_option("oversub", oversub); dev.set_option("band", band); dev.set_option("band_blocks", band_blocks)
+        assert_hits_equal(dev.align_batch(q, all_hits=False), exp)
     exp_all = oracle_hits(packed, clump_len, tot, q, lut, True)
     assert_hits_equal(dev.align_batch(q, all_hits=True), exp_all)
     dev.close()
@@ -320,7 +323,7 @@ def test_randomised_configurations():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_gpu.py"), "20", "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_gpu.py"), "45", "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-3000:]
 
 
