@@ -27,7 +27,7 @@ __global__ void k_hit_scatter(const BhipHit *__restrict__ in, uint32_t n, const 
 __global__ void k_junk_adjust_raw(BhipRawHit *__restrict__ raw, const uint32_t *__restrict__ n_raw_dev, uint32_t raw_cap, const uint8_t *__restrict__ nx) {
 	uint32_t n = *n_raw_dev;
 	if (n > raw_cap) n = raw_cap;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) raw[i].ed += nx[raw[i].q];
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const uint32_t x = nx[raw[i].q]; raw[i].ed += x; raw[i].m += x; }
 }
 __global__ void k_junk_adjust_best(uint32_t *__restrict__ best, const uint8_t *__restrict__ nx_six, uint32_t s0, uint32_t s1) {
 	for (uint32_t s = s0 + blockIdx.x * blockDim.x + threadIdx.x; s < s1; s += gridDim.x * blockDim.x)

@@ -13,6 +13,12 @@ struct BhipRawHit {
 	uint32_t ed;
 	uint32_t e_first;  // first / last 1-based end column whose last-row score equals ed
 	uint32_t e_last;   // (may run into trailing pad columns; k_rescore clamps to ClumpLen)
+	// what the re-scoring kernels would otherwise look up through four more random sectors per hit (query offsets, shared-slot
+	// table, clump lengths, clump offsets): the sweeps have these at hand when they write the record
+	uint32_t m;        // query length (k_junk_adjust_raw adds the symbols the search view left out)
+	uint32_t L;        // ClumpLen of the lane's clump
+	uint32_t six;      // shared slot of the query (index into best[])
+	uint64_t rbase;    // uint4 index of the lane's first chunk in the lane-major copy of the references
 };
 
 // A reference lane whose prefix filter fired: the first and the last group of 8 columns (columns 8g + 1 .. 8g + 8, 1-based) that
@@ -27,7 +33,7 @@ struct BhipWin {
 	uint32_t q;        // batch index of the query entry
 	uint32_t mE;       // query length | budget << 16
 	uint32_t nchunks;  // 32-column chunks of the lane
-	uint32_t pad;
+	uint32_t L;        // ClumpLen of the lane's clump
 	uint64_t rbase;    // uint4 index of the lane's first chunk in the lane-major copy of the references
 	uint64_t pad2;
 };

@@ -1479,6 +1479,7 @@ __global__ __launch_bounds__(256) void k_myers(
 			const uint32_t pos = atomicAdd(n_raw, 1u);
 			if (pos < raw_cap) {
 				BhipRawHit h; h.q = q; h.refIx = refIx; h.ed = (uint32_t)bestS; h.e_first = first; h.e_last = last;
+				h.m = m; h.L = L; h.six = qsix ? qsix[q] : q; h.rbase = ref_off[c] * 16 + (uint64_t)z * nchunks;
 				raw[pos] = h;
 			}
 			if (best) atomicMin(&best[qsix ? qsix[q] : q], (uint32_t)bestS);
@@ -1570,7 +1571,7 @@ __global__ __launch_bounds__(256) void k_myers_prefix(
 				const uint32_t wc = bhip_win_class(g_first, g_last, E);
 				if (wc && !__builtin_nontemporal_load(&cls_seen[wc])) cls_seen[wc] = 1;
 				BhipWin w; w.li = li; w.refIx = refIx; w.g_first = g_first | wc << 30; w.g_last = g_last;
-				w.q = q; w.mE = m | E << 16; w.nchunks = nchunks; w.pad = 0; w.rbase = ref_off[c] * 16 + (uint64_t)z * nchunks; w.pad2 = 0;
+				w.q = q; w.mE = m | E << 16; w.nchunks = nchunks; w.L = L; w.rbase = ref_off[c] * 16 + (uint64_t)z * nchunks; w.pad2 = 0;
 				wins[pos] = w;
 			}
 		}
@@ -1662,7 +1663,7 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 				const uint32_t wc = bhip_win_class(g_first, g_last, E);
 				if (wc && !__builtin_nontemporal_load(&cls_seen[wc])) cls_seen[wc] = 1;
 				BhipWin w; w.li = li; w.refIx = refIx; w.g_first = g_first | wc << 30; w.g_last = g_last;
-				w.q = q; w.mE = m | E << 16; w.nchunks = nchunks; w.pad = 0; w.rbase = (uint64_t)(rp - ref); w.pad2 = 0;
+				w.q = q; w.mE = m | E << 16; w.nchunks = nchunks; w.L = L; w.rbase = (uint64_t)(rp - ref); w.pad2 = 0;
 				wins[pos] = w;
 			}
 		}
@@ -1792,6 +1793,7 @@ __global__ __launch_bounds__(256) void k_myers_window(
 			const uint32_t pos = atomicAdd(n_raw, 1u);
 			if (pos < raw_cap) {
 				BhipRawHit h; h.q = q; h.refIx = w.refIx; h.ed = (uint32_t)bestS; h.e_first = first; h.e_last = last;
+				h.m = m; h.L = w.L; h.six = qsix ? qsix[q] : q; h.rbase = w.rbase;
 				raw[pos] = h;
 			}
 			if (best) atomicMin(&best[qsix ? qsix[q] : q], (uint32_t)bestS);
@@ -1952,6 +1954,7 @@ __global__ __launch_bounds__(64) void k_myers_window_band(
 			const uint32_t pos = atomicAdd(n_raw, 1u);
 			if (pos < raw_cap) {
 				BhipRawHit h; h.q = w.q; h.refIx = w.refIx; h.ed = (uint32_t)bestS; h.e_first = first; h.e_last = last;
+				h.m = m; h.L = w.L; h.six = qsix ? qsix[w.q] : w.q; h.rbase = w.rbase;
 				raw[pos] = h;
 			}
 			if (best) atomicMin(&best[qsix ? qsix[w.q] : w.q], (uint32_t)bestS);
@@ -2002,6 +2005,15 @@ __device__ __forceinline__ uint4 ref_chunk_lane(const uint32_t *__restrict__ ref
 	if (t4 < 0 || (uint32_t)t4 >= nchunks) return make_uint4(0, 0, 0, 0);
 	return ((const uint4 *)refw_lane)[clump_base * 16 + (uint64_t)z * nchunks + (uint32_t)t4];
 }
+// the same two reads from the lane's own address (BhipRawHit::rbase, in uint4 units)
+__device__ __forceinline__ uint4 ref_chunk_at(const uint32_t *__restrict__ refw_lane, uint64_t rbase, int t4, uint32_t nchunks) {
+	if (t4 < 0 || (uint32_t)t4 >= nchunks) return make_uint4(0, 0, 0, 0);
+	return ((const uint4 *)refw_lane)[rbase + (uint32_t)t4];
+}
+__device__ __forceinline__ uint32_t ref_dword_at(const uint32_t *__restrict__ refw_lane, uint64_t rbase, int j8, uint32_t nchunks) {
+	if (j8 < 0 || (uint32_t)j8 >= nchunks * 4) return 0u;
+	return refw_lane[rbase * 4 + (uint32_t)j8];
+}
 __device__ __forceinline__ uint32_t pick4(const uint4 v, uint32_t i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 __device__ __forceinline__ uint32_t ref_dword_lane(const uint32_t *__restrict__ refw_lane, uint64_t clump_base, uint32_t z, int j8, uint32_t nchunks) {
 	if (j8 < 0 || (uint32_t)j8 >= nchunks * 4) return 0u;
@@ -2011,13 +2023,30 @@ __device__ __forceinline__ uint32_t ref_dword_lane(const uint32_t *__restrict__ 
 // 4-bit packing of the queries at a fixed stride of qw dwords per query (k_rescore preloads them into LDS)
 __global__ void k_pack_queries(const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, uint32_t n_q, uint32_t qw,
                                uint32_t *__restrict__ qpack) {
+	// one thread per output dword = 8 symbols: their 8 bytes come as three aligned dwords and two byte-funnel shifts (eight byte loads
+	// per thread made this kernel the slowest of the staging: 0.40 ms for 2 M reads), the low nibbles are squeezed together with
+	// three shift-or-mask steps per half
 	const uint64_t total = (uint64_t)n_q * qw;
+	const uint32_t head = (uint32_t)((uintptr_t)qcodes & 3u);
+	const uint32_t *cw = (const uint32_t *)(qcodes - head);
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-		const uint32_t q = (uint32_t)(i / qw), j = (uint32_t)(i % qw);
+		uint32_t q, j;
+		if (total <= 0xFFFFFFFFull) { q = (uint32_t)i / qw; j = (uint32_t)i - q * qw; } else { q = (uint32_t)(i / qw); j = (uint32_t)(i % qw); }
 		const uint64_t b = qoff[q];
 		const uint32_t len = (uint32_t)(qoff[q + 1] - b);
 		uint32_t v = 0;
-		for (uint32_t k = 0; k < 8; ++k) { const uint32_t pos = 8 * j + k; if (pos < len) v |= (uint32_t)(qcodes[b + pos] & 15) << (4 * k); }
+		if (8 * j < len) {
+			const uint32_t nsym = len - 8 * j < 8 ? len - 8 * j : 8u;
+			const uint64_t a = b + 8ull * j + head;              // byte address counted from cw
+			const uint64_t w = a >> 2;
+			const uint32_t sh = (uint32_t)a & 3u, last = (uint32_t)((a + nsym - 1) >> 2) - (uint32_t)w;      // dwords beyond the first that hold a needed byte
+			const uint32_t w0 = cw[w], w1 = last >= 1 ? cw[w + 1] : 0u, w2 = last >= 2 ? cw[w + 2] : 0u;
+			uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh), hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+			lo &= 0x0F0F0F0Fu; lo = (lo | lo >> 4) & 0x00FF00FFu; lo = (lo | lo >> 8) & 0xFFFFu;
+			hi &= 0x0F0F0F0Fu; hi = (hi | hi >> 4) & 0x00FF00FFu; hi = (hi | hi >> 8) & 0xFFFFu;
+			v = lo | hi << 16;
+			if (nsym < 8) v &= (1u << (4 * nsym)) - 1u;
+		}
 		qpack[i] = v;
 	}
 }
@@ -2136,9 +2165,13 @@ __global__ __launch_bounds__(256) void k_route(
 			const uint32_t *qp = qpack + (uint64_t)i * qw;
 			// one pass over the symbols: anything outside A/C/G/T? any code 0?
 			uint32_t n_zero = 0, n_other = 0;
-			for (uint32_t j = 0; j < (len + 7) >> 3; ++j) {
+			for (uint32_t j = 0; j < (len + 7) >> 3; ++j) {      // eight symbols per step: bit 3 of a nibble of `zero` / `other` flags that symbol
 				const uint32_t d = qp[j], nsym = len - 8 * j < 8 ? len - 8 * j : 8u;
-				for (uint32_t k = 0; k < nsym; ++k) { const uint32_t c = (d >> (4 * k)) & 15u; n_zero += c == 0; n_other += (c - 1u) >= 4u; }
+				const uint32_t valid = nsym >= 8 ? 0x88888888u : (0x88888888u & ((1u << (4 * nsym)) - 1u));
+				const uint32_t zero = ~(((d & 0x77777777u) + 0x77777777u) | d);                          // code 0
+				const uint32_t ge5 = d | ((d << 1) & ((d << 2) | (d << 3)));                             // code >= 5: bit 3, or bit 2 with bit 1 or bit 0
+				n_zero += __popc(zero & valid);
+				n_other += __popc((zero | ge5) & valid);
 			}
 			if (n_zero) atomicOr(&s_misc[0], 1u);
 			const uint32_t six = qsix ? qsix[i] : i;
@@ -2374,12 +2407,11 @@ __global__ __launch_bounds__(256) void k_rescore_classify(
 			bucket[t] = -1; rank[t] = 0; e2v[t] = 0; mv[t] = 0; qv[t] = 0; rv[t] = 0;
 			if (i < n) {
 				const BhipRawHit h = raw[i];
-				const uint32_t six = qsix ? qsix[h.q] : h.q;
-				if (all_hits || h.ed == best[six]) {
-					const uint32_t L = clump_len[h.refIx >> 4];
+				if (all_hits || h.ed == best[h.six]) {          // (slot, clump length and query length travel in the record)
+					const uint32_t L = h.L;
 					const uint32_t e2 = h.e_last < L ? h.e_last : L;
 					qv[t] = h.q; rv[t] = h.refIx; e2v[t] = e2;
-					if (h.ed == 0) { bucket[t] = 11; mv[t] = (uint32_t)(qoff[h.q + 1] - qoff[h.q]); }     // exact match
+					if (h.ed == 0) { bucket[t] = 11; mv[t] = h.m; }     // exact match
 					else {
 						const uint32_t Wd = e2 - h.e_first + 2 * h.ed + 1;
 						int bk = !use_reg || h.ed > 254u ? 9 : Wd <= 4 ? 0 : Wd <= 6 ? 1 : Wd <= 8 ? 2 : Wd <= 12 ? 3 : Wd <= 16 ? 4 : Wd <= 24 ? 5 : Wd <= 32 ? 6 : Wd <= 40 ? 7 : Wd <= 48 ? 8 : 9;
@@ -2415,7 +2447,7 @@ __global__ __launch_bounds__(256) void k_rescore_classify(
 
 template <int WB>
 __device__ __forceinline__ void rescore_reg_one(
-		const BhipRawHit *__restrict__ hp, bool live, uint32_t *s_mm, uint32_t lane,
+		const BhipRawHit *__restrict__ hp, bool live, uint32_t *s_mm, uint32_t fastq, uint32_t lane,
 		const uint64_t *__restrict__ qoff, const uint8_t *__restrict__ qrc, const uint32_t *__restrict__ qpack, uint32_t qw,
 		const uint32_t *__restrict__ refw, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
 		BhipHit *__restrict__ out, uint32_t *__restrict__ n_out, uint32_t out_cap, uint32_t *__restrict__ err_flags) {
@@ -2429,12 +2461,11 @@ __device__ __forceinline__ void rescore_reg_one(
 		hq = q; hrefIx = hp->refIx;
 		B = hp->ed;
 		const uint32_t h_first = hp->e_first, h_last = hp->e_last;
-		const uint32_t c = hrefIx >> 4, z = hrefIx & 15, L = clump_len[c], nchunks = (L + 31) >> 5;
-		const uint64_t qb = qoff[q];
-		m = (uint32_t)(qoff[q + 1] - qb);
+		const uint32_t L = hp->L, nchunks = (L + 31) >> 5;      // clump length, query length and the lane's address come with the record
+		m = hp->m;
 		const int e2 = (int)(h_last < L ? h_last : L), e1 = (int)h_first;
 		const int dlo = e1 - (int)m - (int)B, Wd = e2 - e1 + 2 * (int)B + 1;
-		const uint64_t cbase = ref_off[c];
+		const uint64_t rbase = hp->rbase;
 		const uint32_t LIM = (B + 1) << SS;
 		uint32_t bd[WB + 1];
 		#pragma unroll
@@ -2443,7 +2474,7 @@ __device__ __forceinline__ void rescore_reg_one(
 		int p = dlo, j8 = dlo >> 3;               // p = 0-based reference position under cell k = 0 of the current row
 		uint32_t d[NW];
 		#pragma unroll
-		for (int i = 0; i < NW; ++i) d[i] = ref_dword_lane(refw, cbase, z, j8 + i, nchunks);
+		for (int i = 0; i < NW; ++i) d[i] = ref_dword_at(refw, rbase, j8 + i, nchunks);
 		auto all_acgt = [&]() { uint32_t bad = 0;
 			#pragma unroll
 			for (int i = 0; i < NW; ++i) bad |= (d[i] - 0x11111111u) & 0xCCCCCCCCu;
@@ -2451,17 +2482,19 @@ __device__ __forceinline__ void rescore_reg_one(
 		bool dclean = all_acgt();                 // every symbol of the register window is one of A, C, G, T (codes 1..4)
 		// the symbols ahead of the window come 32 at a time (one 16-byte load per 32 rows instead of a 4-byte load per 8 rows)
 		int jn = j8 + NW;                                      // dword index of the next refill
-		uint4 ahead = ref_chunk_lane(refw, cbase, z, jn >> 2, nchunks);
+		uint4 ahead = ref_chunk_at(refw, rbase, jn >> 2, nchunks);
 		const uint32_t *qp = qpack + (uint64_t)q * qw;
 		uint32_t qd = qp[0], q_next = qw > 1 ? qp[1] : 0u;
-		uint32_t prev_sym = (ref_dword_lane(refw, cbase, z, (p - 1) >> 3, nchunks) >> (4 * ((p - 1) & 7))) & 15u;
+		uint32_t prev_sym = (ref_dword_at(refw, rbase, (p - 1) >> 3, nchunks) >> (4 * ((p - 1) & 7))) & 15u;
 		for (int y = 1; y <= (int)m; ++y) {
 			const uint32_t qi = (uint32_t)(y - 1);
 			if ((qi & 7u) == 0 && qi) { qd = q_next; q_next = (qi >> 3) + 1 < qw ? qp[(qi >> 3) + 1] : 0u; }
 			const uint32_t qc = (qd >> (4 * (qi & 7u))) & 15u;
-			const uint32_t mrow = s_mm[qc], m1 = qc ? 0xFFFEu : 0u;
+			const uint32_t m1 = qc ? 0xFFFEu : 0u;
 			const uint32_t col0 = (uint32_t)y <= B ? (((uint32_t)y << SS) | Z0 | (uint32_t)y) : INVALID;   // D=y, H=0, V=y (burst.c:747-750)
 			const int x0 = y + dlo;
+			const bool fast_row = y > 1 && x0 >= 1 && dclean && ((fastq >> qc) & 1u);
+			const uint32_t mrow = fast_row ? 0u : s_mm[qc];      // (the usual row needs no table: no LDS round trip per row)
 			uint32_t dd[NW - 1];
 			{
 				const uint32_t sh = 4u * ((uint32_t)p & 7u);
@@ -2483,7 +2516,7 @@ __device__ __forceinline__ void rescore_reg_one(
 					prev_sym = r;
 					bd[k] = cell;
 				}
-			} else if (x0 >= 1 && dclean && qc - 1u < 4u && (mrow & 0x1Eu) == (1u << qc)) {
+			} else if (fast_row) {
 				// the usual row: query symbol and all reference symbols in reach are A/C/G/T, of which only the equal one costs 0 --
 				// the eight costs of a dword come from three integer operations (a nibble of x is zero iff the symbols are equal;
 				// bit 3 of (x & 7 + 7) | x is set iff the nibble is not), and no cell of the row lies left of column 1
@@ -2532,7 +2565,7 @@ __device__ __forceinline__ void rescore_reg_one(
 				d[NW - 1] = pick4(ahead, (uint32_t)jn & 3u);
 				dclean = all_acgt();
 				++j8; ++jn;
-				if ((jn & 3) == 0) ahead = ref_chunk_lane(refw, cbase, z, jn >> 2, nchunks);
+				if ((jn & 3) == 0) ahead = ref_chunk_at(refw, rbase, jn >> 2, nchunks);
 			}
 		}
 		// final selection over the last row (burst.c:824-842) and end position (862-879)
@@ -2580,6 +2613,9 @@ __global__ __launch_bounds__(64) void k_rescore_reg(
 	const uint32_t tid = threadIdx.x;
 	if (tid < 16) { uint32_t mm = 0; for (int r = 0; r < 16; ++r) mm |= (lut[16 * tid + r] == 0 ? 1u : 0u) << r; s_mm[tid] = mm; }
 	__syncthreads();
+	// bit q: query symbol q is one of A, C, G, T and among those four matches only itself (the rows whose costs need no table)
+	uint32_t fastq = 0;
+	for (uint32_t qc = 1; qc <= 4; ++qc) if ((s_mm[qc] & 0x1Eu) == (1u << qc)) fastq |= 1u << qc;
 	const uint32_t *refw = (const uint32_t *)refb;
 #define BHIP_RS_RUN(b, WB) { \
 		uint32_t n = counts[b]; if (n > raw_cap) n = raw_cap; \
@@ -2587,7 +2623,7 @@ __global__ __launch_bounds__(64) void k_rescore_reg(
 		const uint32_t n_round = (n + 63u) & ~63u; \
 		for (uint32_t i = blockIdx.x * 64 + tid; i < n_round; i += gridDim.x * 64) { \
 			const bool live = i < n; \
-			rescore_reg_one<WB>(raw + (live ? lst[i] : 0u), live, s_mm, tid, qoff, qrc, qpack, qw, refw, ref_off, clump_len, out, n_out, out_cap, err_flags); \
+			rescore_reg_one<WB>(raw + (live ? lst[i] : 0u), live, s_mm, fastq, tid, qoff, qrc, qpack, qw, refw, ref_off, clump_len, out, n_out, out_cap, err_flags); \
 		} }
 	if (SET == 0) { BHIP_RS_RUN(0, 4) BHIP_RS_RUN(1, 6) BHIP_RS_RUN(2, 8) BHIP_RS_RUN(3, 12) }
 	else if (SET == 1) { BHIP_RS_RUN(4, 16) BHIP_RS_RUN(5, 24) }
