@@ -220,13 +220,13 @@ static int launch_peq(Handle *h, hipStream_t st, StageSlot *S, const uint32_t *d
 	{
 		const uint32_t qb = 256u / (uint32_t)NW;
 		const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + qb - 1) / qb, (uint64_t)h->n_cu * blocks_per_cu);
-		hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, st, codes, off, d_qlist, n_list, NW, 0, h->mm, peq.as<uint32_t>(), pack, (S->st_maxlen + 7) / 8);
+		hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, st, codes, off, d_qlist, n_list, NW, 0, h->mm, peq.as<uint32_t>(), pack, (S->st_maxlen + 7) / 8, h->peq_rows);
 		HIPCHK(hipGetLastError());
 	}
 	if (NWP) {
 		const uint32_t qb = 256u / (uint32_t)NWP;
 		const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_list + qb - 1) / qb, (uint64_t)h->n_cu * blocks_per_cu);
-		hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, st, codes, off, d_qlist, n_list, NWP, 32 * NWP, h->mm, peqp.as<uint32_t>(), pack, (S->st_maxlen + 7) / 8);
+		hipLaunchKernelGGL(k_build_peq, dim3(grid), dim3(256), 0, st, codes, off, d_qlist, n_list, NWP, 32 * NWP, h->mm, peqp.as<uint32_t>(), pack, (S->st_maxlen + 7) / 8, h->peq_rows);
 		HIPCHK(hipGetLastError());
 	}
 	return 0;
@@ -928,7 +928,7 @@ extern "C" int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint
 	Counters *dc = L->counters.as<Counters>();
 	const uint32_t qb = 256u / (uint32_t)NW;
 	hipLaunchKernelGGL(k_build_peq, dim3((uint32_t)std::min<uint64_t>(((uint64_t)n_q + qb - 1) / qb, (uint64_t)h->n_cu * 16)), dim3(256), 0, st,
-		h->cur->qcodes.as<uint8_t>(), h->cur->qoff.as<uint64_t>(), (const uint32_t *)nullptr, n_q, NW, 0, h->mm, L->peq.as<uint32_t>(), (const uint32_t *)nullptr, 0u);
+		h->cur->qcodes.as<uint8_t>(), h->cur->qoff.as<uint64_t>(), (const uint32_t *)nullptr, n_q, NW, 0, h->mm, L->peq.as<uint32_t>(), (const uint32_t *)nullptr, 0u, h->peq_rows);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(h->ev[0], st));
 	launch_myers(h, L, st, cls, (uint32_t)std::min<uint64_t>((n_pairs + 15) / 16, (uint64_t)h->n_cu * 8), h->pairs.as<uint2>(), nullptr, n_pairs, 0, nullptr,

@@ -25,7 +25,7 @@ __global__ void k_acx_offsets(const uint32_t *, uint64_t, int, uint32_t *, unsig
 __global__ void k_acx_lines(const uint32_t *, uint64_t, int, unsigned long long *, uint4 *);
 __global__ void k_acx_decode(const uint8_t *, const unsigned long long *, const uint32_t *, BhipAcxView, uint64_t, int, uint32_t, uint8_t *, uint32_t *);
 __global__ void k_transpose_refs(const uint8_t *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint4 *, uint4 *);
-__global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, int, int, BhipMatchMask, uint32_t *, const uint32_t *, uint32_t);
+__global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, int, int, BhipMatchMask, uint32_t *, const uint32_t *, uint32_t, uint32_t);
 template <bool LDS_CNT> __global__ void k_prefilter(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
 	BhipAcxView, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t,
 	unsigned long long *, const uint32_t *, const uint32_t *, const uint32_t *);
@@ -250,6 +250,7 @@ struct Handle {
 	int opt_prefilter_stride = 0; // 0 = automatic sparse seeds, s > 0 = every s-th word (1 = the reference's scheme)
 	int opt_lanes = 1;            // sub-pipelines per staged batch (the stage kernels fill the chip on their own; > 1 only helps small batches)
 	int opt_sweep_blocks = 8;     // 256-thread blocks per CU of the column-sweep kernels
+	uint32_t peq_rows = 16;       // rows of a match profile that are built: 5 (pad, A, C, G, T) when no reference holds another symbol
 	int opt_oversub = 2;          // blocks launched per resident block slot of the per-item kernels (prefix tasks, windows, re-scoring)
 	int opt_band_blocks = 0;      // 64-thread blocks per CU of k_myers_window_band (0: as many as fit)
 	int opt_no_band = 0;          // 1 = every window through the full-column kernel (option "band" 0; the parity tests run both)

@@ -3,6 +3,16 @@
 #include "bhip_handle.h"
 
 static thread_local char g_err[512] = "";
+
+// *flag != 0 afterwards iff some 4-bit symbol of the packed references (two per byte, as in the .edx) is not pad, A, C, G or T
+__global__ void k_ref_symbol_scan(const uint32_t *__restrict__ w, uint64_t n_words, uint32_t *__restrict__ flag) {
+	uint32_t any = 0;
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t d = w[i];
+		any |= (d | ((d << 1) & ((d << 2) | (d << 3)))) & 0x88888888u;      // code >= 5: bit 3, or bit 2 with bit 1 or bit 0
+	}
+	if (any) *flag = 1u;
+}
 int bhip_fail_msg(int code, const char *fmt, ...) {
 	va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
 	return code;
@@ -148,8 +158,17 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		hipLaunchKernelGGL(k_transpose_refs, dim3(grid), dim3(256), 0, h->stream, d_src.as<uint8_t>(), d_srcoff.as<uint64_t>(),
 			h->clump_len.as<uint32_t>(), h->ref_off.as<uint64_t>(), n_clumps, h->ref.as<uint4>(), h->ref_lane.as<uint4>());
 		INITCHK(hipGetLastError());
+		// any reference symbol beyond A/C/G/T?  (decides how many rows of the match profiles are built per batch)
+		DBuf d_flag;
+		INITRC(d_flag.reserve(sizeof(uint32_t)));
+		INITCHK(hipMemsetAsync(d_flag.p, 0, sizeof(uint32_t), h->stream));
+		hipLaunchKernelGGL(k_ref_symbol_scan, dim3((uint32_t)h->n_cu * 8), dim3(256), 0, h->stream, d_src.as<uint32_t>(), src_off[n_clumps] * 4, d_flag.as<uint32_t>());
+		INITCHK(hipGetLastError());
+		uint32_t any_other = 1;
+		INITCHK(hipMemcpyAsync(&any_other, d_flag.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
 		INITCHK(hipStreamSynchronize(h->stream));
-		d_src.release(); d_srcoff.release();
+		h->peq_rows = any_other ? 16u : 5u;
+		d_src.release(); d_srcoff.release(); d_flag.release();
 	}
 	// accelerator: from the file's tables, or -- acx_lens == NULL and K given -- built here from the references alone
 	if (acx_lens) INITRC(bhip_load_accelerator(h, acx_lens, acx_lists, acx_fmt, K, badlist, n_bad));

@@ -62,7 +62,9 @@ __global__ void k_transpose_refs(const uint8_t *__restrict__ src, const uint64_t
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_build_peq(const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff,
                             const uint32_t *__restrict__ qlist, uint32_t n_list, int NW, int prefix_len,
-                            BhipMatchMask mm, uint32_t *__restrict__ peq, const uint32_t *__restrict__ qpack, uint32_t qw) {
+                            BhipMatchMask mm, uint32_t *__restrict__ peq, const uint32_t *__restrict__ qpack, uint32_t qw, uint32_t n_rows) {
+	// n_rows: 16, or 5 when no reference holds a symbol beyond A/C/G/T (codes 1..4; 0 = pad): the rows 5..15 of every table would be
+	// written -- 11/16 of 1.3 GB per 2 M-read batch -- and never read.  The table keeps its 16-row stride.
 	// One thread per (query, word) reads its 32 symbols once and produces the 16 symbol rows of that word.  A block owns
 	// QB = 256 / NW whole queries; the rows go through LDS so that the block's 16*NW*QB output words leave as one
 	// contiguous, fully coalesced stream (the natural per-thread stores hit 16 B pieces of 16 different lines).
@@ -72,7 +74,6 @@ __global__ __launch_bounds__(256) void k_build_peq(const uint8_t *__restrict__ q
 	if (tid < 16) s_mm[tid] = mm.m[tid];
 	const uint32_t QB = 256u / (uint32_t)NW, per_q = 16u * (uint32_t)NW;
 	const uint32_t lq = tid / (uint32_t)NW, w = tid % (uint32_t)NW;
-	const uint32_t step_q = 256u / per_q, step_r = 256u % per_q;
 	for (uint32_t q0 = blockIdx.x * QB; q0 < n_list; q0 += gridDim.x * QB) {
 		__syncthreads();
 		const uint32_t li = q0 + lq;
@@ -122,13 +123,15 @@ __global__ __launch_bounds__(256) void k_build_peq(const uint8_t *__restrict__ q
 			for (int c = 0; c < 16; ++c) s_out[lq * (per_q + 1) + (uint32_t)c * (uint32_t)NW + w] = row[c];     // +1: bank spread
 		}
 		__syncthreads();
-		const uint32_t nq = n_list - q0 < QB ? n_list - q0 : QB, total = nq * per_q;
+		const uint32_t nq = n_list - q0 < QB ? n_list - q0 : QB;
+		const uint32_t per_w = n_rows * (uint32_t)NW, total = nq * per_w;      // dwords written per query
 		uint32_t *dst = peq + (uint64_t)q0 * per_q;
-		uint32_t oq = tid / per_q, orr = tid % per_q;
+		const uint32_t st_q = 256u / per_w, st_r = 256u % per_w;
+		uint32_t oq = tid / per_w, orr = tid % per_w;
 		for (uint32_t idx = tid; idx < total; idx += 256) {
-			dst[idx] = s_out[oq * (per_q + 1) + orr];
-			oq += step_q; orr += step_r;
-			if (orr >= per_q) { orr -= per_q; ++oq; }
+			dst[oq * per_q + orr] = s_out[oq * (per_q + 1) + orr];
+			oq += st_q; orr += st_r;
+			if (orr >= per_w) { orr -= per_w; ++oq; }
 		}
 	}
 }
