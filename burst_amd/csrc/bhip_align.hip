@@ -67,15 +67,15 @@ static void launch_prefix(Handle *h, Lane *L, hipStream_t st, int NWP, uint32_t 
 		uint64_t n_pairs_host, uint32_t li_base, const uint32_t *qlist, uint32_t *n_wins, Counters *dc) {
 	#define LP(N) hipLaunchKernelGGL(k_myers_prefix<N>, dim3(grid), dim3(256), 0, st, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist, \
 		L->peqp.as<uint32_t>(), h->s_off(), h->s_emac(), h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
-		h->tot_refs, L->wins.as<BhipWin>(), n_wins, (uint32_t)L->win_cap, &dc->col_sum, &dc->qlen_sum, dc->win_class_seen)
+		h->tot_refs, L->wins.as<BhipWin>(), n_wins, (uint32_t)L->win_cap, &dc->col_sum, &dc->qlen_sum, dc->win_class_seen, h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr)
 	if (NWP == 1) LP(1); else if (NWP == 2) LP(2); else if (NWP == 3) LP(3); else if (NWP == 4) LP(4); else LP(6);
 	#undef LP
 }
 static void launch_prefix_task(Handle *h, Lane *L, hipStream_t st, int NWP, uint32_t grid, const uint2 *tasks, const uint32_t *n_tasks_dev, const uint32_t *qlist,
-		BhipWin *wins, uint32_t *n_wins, Counters *dc) {
+		BhipWin *wins, uint32_t *n_wins, Counters *dc, const uint4 *qmeta) {
 	#define LT(N) hipLaunchKernelGGL(k_myers_prefix_task<N>, dim3(grid), dim3(64), 0, st, tasks, n_tasks_dev, (uint32_t)L->task_cap, qlist, \
 		L->peqp.as<uint32_t>(), h->s_off(), h->s_emac(), h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
-		wins, n_wins, (uint32_t)L->win_cap, &dc->tcol_sum, dc->win_class_seen)
+		wins, n_wins, (uint32_t)L->win_cap, &dc->tcol_sum, dc->win_class_seen, qmeta, h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr)
 	if (NWP == 1) LT(1); else if (NWP == 2) LT(2); else if (NWP == 3) LT(3); else if (NWP == 4) LT(4); else LT(6);
 	#undef LT
 }
@@ -238,6 +238,9 @@ static int launch_seed(Handle *h, Lane *L, hipStream_t st, StageSlot *S, int cls
 	L->seeded_ok[cls] = false;
 	if ((rc = L->ranges_c[cls].reserve((size_t)n_list * W16 * 8 + 16))) return rc;
 	if ((rc = L->hdr_c[cls].reserve((size_t)n_list * 8 + 16))) return rc;
+	DBuf &qm = L->qmeta_c[S->seq & 1][cls];
+	if ((rc = qm.reserve((size_t)n_list * 16 + 16))) return rc;
+	L->qmeta_seq[S->seq & 1][cls] = 0;
 	const uint64_t n_thr = (uint64_t)n_list * W16;
 	hipEvent_t *ev = L->ev_seed[S->seq & 1][cls];
 	const bool junk = S->st_has_junk;
@@ -249,9 +252,10 @@ static int launch_seed(Handle *h, Lane *L, hipStream_t st, StageSlot *S, int cls
 	hipLaunchKernelGGL(k_seed_ranges, dim3(grid), dim3(256), 0, st,
 		junk ? S->qcodes_s.as<uint8_t>() : S->qcodes.as<uint8_t>(), junk ? S->qoff_s.as<uint64_t>() : S->qoff.as<uint64_t>(), d_qlist, n_list,
 		h->acx_view(), h->K, S->plan.as<uint32_t>(), W16, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(),
-		junk ? S->qpack_s.as<uint32_t>() : S->qpack.as<uint32_t>(), (S->st_maxlen + 7) / 8, junk ? S->qemac_s.as<uint16_t>() : S->qemac.as<uint16_t>());
+		junk ? S->qpack_s.as<uint32_t>() : S->qpack.as<uint32_t>(), (S->st_maxlen + 7) / 8, junk ? S->qemac_s.as<uint16_t>() : S->qemac.as<uint16_t>(), qm.as<uint4>(), S->st_has_six ? S->qsix.as<uint32_t>() : nullptr);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(ev[1], st));
+	L->qmeta_seq[S->seq & 1][cls] = S->seq + 1;
 	L->seeded_ok[cls] = true; L->seeded_seq[cls] = S->seq; L->seeded_n[cls] = n_list; L->seeded_W16[cls] = W16;
 	return 0;
 }
@@ -503,6 +507,8 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 			if (masked) { if ((rc = launch_prefilter_mask(h, L, pf, cls, qlist, n_pf, L->maxwords[cls], &dc->n_tasks_cls[cls], &dc->n_cand_cls[cls], dc, prune))) return rc; }
 			else if ((rc = launch_prefilter(h, L, pf, qlist, n_pf, L->cand.as<uint2>(), nullptr, (uint32_t)L->cand_cap, true, &dc->n_cand_cls[cls], dc))) return rc;
 		}
+		// (query, length, budget) per list position, written by this batch's k_seed_ranges: what the prefix sweeps of the tasks start from
+		const uint4 *qmeta_cls = (masked && L->qmeta_seq[h->cur->seq & 1][cls] == h->cur->seq + 1) ? L->qmeta_c[h->cur->seq & 1][cls].as<uint4>() : nullptr;
 		L->masked = masked;
 		L->pf_masked[cls] = masked && n_pf;
 		HIPCHK(hipEventRecord(ce[2], pf));
@@ -510,7 +516,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 		HIPCHK(hipStreamWaitEvent(sw, ce[2], 0));
 		HIPCHK(hipEventRecord(ce[6], sw));
 		if (n_pf) {
-			if (masked) launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 4u * (uint32_t)h->opt_sweep_blocks * (uint32_t)h->opt_oversub, L->tasks.as<uint2>(), &dc->n_tasks_cls[cls], qlist, L->wins.as<BhipWin>(), &dc->n_wins_cls[cls], dc);
+			if (masked) launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 4u * (uint32_t)h->opt_sweep_blocks * (uint32_t)h->opt_oversub, L->tasks.as<uint2>(), &dc->n_tasks_cls[cls], qlist, L->wins.as<BhipWin>(), &dc->n_wins_cls[cls], dc, qmeta_cls);
 			// (beside the lane tasks the clump-level pairs are the rare overflow of the prefilter, usually none at all: a small grid --
 			// an empty launch of 2 048 workgroups waited ~0.24 ms for slots on a device busy with the next batch's seed lookups and staging)
 			if (NWP) launch_prefix(h, L, sw, NWP, masked ? std::min<uint32_t>(grid_my, (uint32_t)h->n_cu) : grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, &dc->n_wins_cls[cls], dc);
@@ -540,7 +546,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 			HIPCHK(hipStreamWaitEvent(sw, L->ev_ph[cls][0], 0));
 			hipLaunchKernelGGL(k_task_filter, dim3((uint32_t)h->n_cu * 8), dim3(256), 0, sw, L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], (uint32_t)L->task_cap, qlist,
 				h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr, h->best.as<uint32_t>(), L->tasks2k.as<uint2>(), &dc->n_tasks2k_cls[cls]);
-			launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 4u * (uint32_t)h->opt_sweep_blocks * (uint32_t)h->opt_oversub, L->tasks2k.as<uint2>(), &dc->n_tasks2k_cls[cls], qlist, L->wins2.as<BhipWin>(), &dc->n_wins2_cls[cls], dc);
+			launch_prefix_task(h, L, sw, NWP, (uint32_t)h->n_cu * 4u * (uint32_t)h->opt_sweep_blocks * (uint32_t)h->opt_oversub, L->tasks2k.as<uint2>(), &dc->n_tasks2k_cls[cls], qlist, L->wins2.as<BhipWin>(), &dc->n_wins2_cls[cls], dc, qmeta_cls);
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipEventRecord(L->ev_ph[cls][1], sw));
 			HIPCHK(hipStreamWaitEvent(po, L->ev_ph[cls][1], 0));

@@ -39,7 +39,7 @@ template <int NW> __global__ void k_myers(const uint2 *, const uint32_t *, uint6
 	BhipRawHit *, uint32_t *, uint32_t, uint32_t *, uint8_t *, unsigned long long *, unsigned long long *);
 template <int NWP> __global__ void k_myers_prefix(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
 	const uint64_t *, const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t, BhipWin *, uint32_t *, uint32_t,
-	unsigned long long *, unsigned long long *, uint32_t *);
+	unsigned long long *, unsigned long long *, uint32_t *, const uint32_t *);
 template <int NW> __global__ void k_myers_window(const BhipWin *, const uint32_t *, uint32_t, int, int, const uint32_t *, const uint32_t *,
 	const uint4 *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *, unsigned long long *, const uint32_t *);
 template <int BW> __global__ void k_myers_window_band(const BhipWin *, const uint32_t *, uint32_t, int, int, const uint32_t *, const uint32_t *,
@@ -53,9 +53,9 @@ template <int CB> __global__ void k_prefilter_cf(const uint2 *, const uint2 *, u
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *,
 	uint2 *, uint32_t *, int);
 __global__ void k_task_filter(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, uint2 *, uint32_t *);
-__global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, BhipAcxView, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t, const uint16_t *);
+__global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, BhipAcxView, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t, const uint16_t *, uint4 *, const uint32_t *);
 template <int NWP> __global__ void k_myers_prefix_task(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *,
-	const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *, uint32_t *);
+	const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, const uint4 *, const uint32_t *);
 template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *,
 	const uint32_t *, int, const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t *, const uint64_t *,
 	const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *,
@@ -177,6 +177,8 @@ struct Lane {
 	// so the lookups of batch k+1 run on the prefilter stream WHILE batch k is swept and re-scored (seed_ahead): memory-latency-bound
 	// work beside VALU-bound work.  seeded_* say which staged batch the buffers of a class hold.
 	DBuf ranges_c[kNumClasses], hdr_c[kNumClasses];
+	DBuf qmeta_c[2][kNumClasses];          // (query, length | budget << 16, shared slot) per list position, by batch parity: the prefix sweeps of batch k read theirs while the seeds of batch k + 1 are written
+	uint64_t qmeta_seq[2][kNumClasses] = {};   // batch the entries belong to (+1; 0 = none)
 	bool seeded_ok[kNumClasses] = {false};
 	uint64_t seeded_seq[kNumClasses] = {0};
 	uint32_t seeded_n[kNumClasses] = {0}, seeded_W16[kNumClasses] = {0};

@@ -30,6 +30,7 @@ static void lane_destroy(Lane *L) {
 	for (auto &e : L->ev_peq_cur) if (e) (void)hipEventDestroy(e);
 	for (DBuf &b : L->ranges_c) b.release();
 	for (DBuf &b : L->hdr_c) b.release();
+	for (auto &pb : L->qmeta_c) for (DBuf &b : pb) b.release();
 	for (auto &pe : L->ev_seed) for (auto &ce : pe) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
 	for (auto &ce : L->ev_cls) for (auto &e : ce) if (e) (void)hipEventDestroy(e);
 	for (auto &e : L->ev_rs) if (e) (void)hipEventDestroy(e);

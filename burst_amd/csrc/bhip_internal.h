@@ -35,7 +35,8 @@ struct BhipWin {
 	uint32_t nchunks;  // 32-column chunks of the lane
 	uint32_t L;        // ClumpLen of the lane's clump
 	uint64_t rbase;    // uint4 index of the lane's first chunk in the lane-major copy of the references
-	uint64_t pad2;
+	uint32_t six;      // shared slot of the query (index into best[])
+	uint32_t pad2;
 };
 // a band of BW words holds 32 (BW - 1) - 6 diagonals (k_myers_window_band); the flagged ones are 8 (g_last - g_first) + 8 + 2 E
 __host__ __device__ inline uint32_t bhip_win_class(uint32_t g_first, uint32_t g_last, uint32_t E) {

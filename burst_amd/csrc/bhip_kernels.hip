@@ -577,7 +577,8 @@ __device__ __forceinline__ void pfm_bump4(uint32_t *tab, uint32_t *dummy, const 
 __global__ __launch_bounds__(256) void k_seed_ranges(
 		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint32_t *__restrict__ qlist, uint32_t n_list,
 		BhipAcxView acx, int K, const uint32_t *__restrict__ plan, uint32_t W16,
-		uint2 *__restrict__ ranges, uint2 *__restrict__ hdr, const uint32_t *__restrict__ qpack, uint32_t qw, const uint16_t *__restrict__ qemac) {
+		uint2 *__restrict__ ranges, uint2 *__restrict__ hdr, const uint32_t *__restrict__ qpack, uint32_t qw, const uint16_t *__restrict__ qemac,
+		uint4 *__restrict__ qmeta, const uint32_t *__restrict__ qsix) {       // qmeta[list position] = (query entry, length | budget << 16, shared slot): one sector for the prefix sweep instead of three
 	// (grid-stride: run ahead beside another batch's sweeps, the kernel is launched with a few blocks per CU only)
 	for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < (uint64_t)n_list * W16; t += (uint64_t)gridDim.x * 256) {
 	const uint32_t li = (uint32_t)(t / W16), j = (uint32_t)(t % W16);
@@ -631,7 +632,11 @@ __global__ __launch_bounds__(256) void k_seed_ranges(
 	}
 	ranges[t] = r;
 	// header: need | words << 16 ; length | budget << 12 | (words one edit can destroy = ceil(K / stride)) << 20
-	if (j == 0) hdr[li] = make_uint2((need > 0xFFFFu ? 0xFFFFu : need) | nwords << 16, len | (uint32_t)(qemac[q] > 255 ? 255 : qemac[q]) << 12 | ((uint32_t)(K + stride - 1) / stride) << 20);
+	if (j == 0) {
+		const uint32_t Eq_ = qemac[q];
+		hdr[li] = make_uint2((need > 0xFFFFu ? 0xFFFFu : need) | nwords << 16, len | (uint32_t)(Eq_ > 255 ? 255 : Eq_) << 12 | ((uint32_t)(K + stride - 1) / stride) << 20);
+		if (qmeta) qmeta[li] = make_uint4(q, len | Eq_ << 16, qsix ? qsix[q] : q, 0u);
+	}
 	}
 }
 
@@ -1509,7 +1514,8 @@ __global__ __launch_bounds__(256) void k_myers_prefix(
 		const uint16_t *__restrict__ qemac,
 		const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
 		uint32_t tot_refs, BhipWin *__restrict__ wins, uint32_t *__restrict__ n_wins, uint32_t win_cap,
-		unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum, uint32_t *__restrict__ cls_seen) {
+		unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum, uint32_t *__restrict__ cls_seen,
+		const uint32_t *__restrict__ qsix) {
 	__shared__ __attribute__((aligned(16))) uint32_t s_peq[16][16 * NWP];
 	const uint32_t tid = threadIdx.x, g = tid >> 4, z = tid & 15;
 	const uint64_t n_pairs = n_pairs_dev ? ((uint64_t)*n_pairs_dev < n_pairs_host ? (uint64_t)*n_pairs_dev : n_pairs_host) : n_pairs_host;
@@ -1574,7 +1580,7 @@ __global__ __launch_bounds__(256) void k_myers_prefix(
 				const uint32_t wc = bhip_win_class(g_first, g_last, E);
 				if (wc && !__builtin_nontemporal_load(&cls_seen[wc])) cls_seen[wc] = 1;
 				BhipWin w; w.li = li; w.refIx = refIx; w.g_first = g_first | wc << 30; w.g_last = g_last;
-				w.q = q; w.mE = m | E << 16; w.nchunks = nchunks; w.L = L; w.rbase = ref_off[c] * 16 + (uint64_t)z * nchunks; w.pad2 = 0;
+				w.q = q; w.mE = m | E << 16; w.nchunks = nchunks; w.L = L; w.rbase = ref_off[c] * 16 + (uint64_t)z * nchunks; w.six = qsix ? qsix[q] : q; w.pad2 = 0;
 				wins[pos] = w;
 			}
 		}
@@ -1593,7 +1599,7 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 		const uint16_t *__restrict__ qemac,
 		const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
 		BhipWin *__restrict__ wins, uint32_t *__restrict__ n_wins, uint32_t win_cap, unsigned long long *__restrict__ tcol_sum,
-		uint32_t *__restrict__ cls_seen) {
+		uint32_t *__restrict__ cls_seen, const uint4 *__restrict__ qmeta, const uint32_t *__restrict__ qsix) {      // qmeta (from k_seed_ranges) replaces qlist / qoff / qemac / qsix
 	// NWP <= 2: the 16-row prefix table of the task sits in a private LDS column; wider prefixes would leave room for only
 	// 2-3 waves per SIMD that way, so they read the rows from global memory (L1/L2 hits, one dwordx2/x4 load per column)
 	constexpr bool LDS_TAB = NWP <= 2;
@@ -1617,8 +1623,9 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 		}
 		if (!live) continue;        // the table column is private to the thread: no barrier needed
 		const uint32_t li = tk.x, refIx = tk.y, c = refIx >> 4, z = refIx & 15;
-		const uint32_t q = qlist ? qlist[li] : li;
-		const uint32_t m = (uint32_t)(qoff[q + 1] - qoff[q]), E = qemac[q];
+		uint32_t q, m, E, six;
+		if (qmeta) { const uint4 qm = qmeta[li]; q = qm.x; m = qm.y & 0xFFFFu; E = qm.y >> 16; six = qm.z; }
+		else { q = qlist ? qlist[li] : li; m = (uint32_t)(qoff[q + 1] - qoff[q]); E = qemac[q]; six = qsix ? qsix[q] : q; }
 		const uint32_t P = m < 32u * NWP ? m : 32u * NWP;
 		const uint32_t L = clump_len[c], nchunks = (L + 31) >> 5;
 		uint32_t Pv[NWP], Mv[NWP];
@@ -1666,7 +1673,7 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 				const uint32_t wc = bhip_win_class(g_first, g_last, E);
 				if (wc && !__builtin_nontemporal_load(&cls_seen[wc])) cls_seen[wc] = 1;
 				BhipWin w; w.li = li; w.refIx = refIx; w.g_first = g_first | wc << 30; w.g_last = g_last;
-				w.q = q; w.mE = m | E << 16; w.nchunks = nchunks; w.L = L; w.rbase = (uint64_t)(rp - ref); w.pad2 = 0;
+				w.q = q; w.mE = m | E << 16; w.nchunks = nchunks; w.L = L; w.rbase = (uint64_t)(rp - ref); w.six = six; w.pad2 = 0;
 				wins[pos] = w;
 			}
 		}
@@ -1710,7 +1717,7 @@ __global__ __launch_bounds__(256) void k_task_filter(const uint2 *__restrict__ i
 
 #define BHIP_INST_PREFIX_TASK(NWP) \
 	template __global__ void k_myers_prefix_task<NWP>(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *, \
-		const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *, uint32_t *);
+		const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, const uint4 *, const uint32_t *);
 BHIP_INST_PREFIX_TASK(1) BHIP_INST_PREFIX_TASK(2) BHIP_INST_PREFIX_TASK(3) BHIP_INST_PREFIX_TASK(4) BHIP_INST_PREFIX_TASK(6)
 
 template <int NW>
@@ -1796,10 +1803,10 @@ __global__ __launch_bounds__(256) void k_myers_window(
 			const uint32_t pos = atomicAdd(n_raw, 1u);
 			if (pos < raw_cap) {
 				BhipRawHit h; h.q = q; h.refIx = w.refIx; h.ed = (uint32_t)bestS; h.e_first = first; h.e_last = last;
-				h.m = m; h.L = w.L; h.six = qsix ? qsix[q] : q; h.rbase = w.rbase;
+				h.m = m; h.L = w.L; h.six = w.six; h.rbase = w.rbase;
 				raw[pos] = h;
 			}
-			if (best) atomicMin(&best[qsix ? qsix[q] : q], (uint32_t)bestS);
+			if (best) atomicMin(&best[w.six], (uint32_t)bestS);
 		}
 	}
 	if (wcol_sum && my_cols) atomicAdd(wcol_sum, my_cols);
@@ -1957,10 +1964,10 @@ __global__ __launch_bounds__(64) void k_myers_window_band(
 			const uint32_t pos = atomicAdd(n_raw, 1u);
 			if (pos < raw_cap) {
 				BhipRawHit h; h.q = w.q; h.refIx = w.refIx; h.ed = (uint32_t)bestS; h.e_first = first; h.e_last = last;
-				h.m = m; h.L = w.L; h.six = qsix ? qsix[w.q] : w.q; h.rbase = w.rbase;
+				h.m = m; h.L = w.L; h.six = w.six; h.rbase = w.rbase;
 				raw[pos] = h;
 			}
-			if (best) atomicMin(&best[qsix ? qsix[w.q] : w.q], (uint32_t)bestS);
+			if (best) atomicMin(&best[w.six], (uint32_t)bestS);
 		}
 	}
 	if (wcol_sum && my_cols) atomicAdd(wcol_sum, my_cols);
@@ -1973,7 +1980,7 @@ BHIP_INST_BAND(2) BHIP_INST_BAND(3) BHIP_INST_BAND(4)
 #define BHIP_INST_PREFIX(NWP) \
 	template __global__ void k_myers_prefix<NWP>(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *, \
 		const uint64_t *, const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t, BhipWin *, uint32_t *, uint32_t, \
-		unsigned long long *, unsigned long long *, uint32_t *);
+		unsigned long long *, unsigned long long *, uint32_t *, const uint32_t *);
 BHIP_INST_PREFIX(1) BHIP_INST_PREFIX(2) BHIP_INST_PREFIX(3) BHIP_INST_PREFIX(4) BHIP_INST_PREFIX(6)
 #define BHIP_INST_WINDOW(NW) \
 	template __global__ void k_myers_window<NW>(const BhipWin *, const uint32_t *, uint32_t, int, int, const uint32_t *, const uint32_t *, \
