@@ -580,6 +580,8 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 			h->ref_lane.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, &sc->err)
 		RS_LAUNCH(0, 16);
 		HIPCHK(hipGetLastError());
+		RS_LAUNCH(3, 16);         // 12 diagonals: a kernel of its own, so that the 4 / 6 / 8 variants run at 80 registers (6 waves per SIMD instead of 4)
+		HIPCHK(hipGetLastError());
 		RS_LAUNCH(1, 12);
 		HIPCHK(hipGetLastError());
 		RS_LAUNCH(2, 8);          // 32 / 40 / 48 diagonals (usually empty lists: large budgets, or repeats that stretch the end-column range)

@@ -2612,7 +2612,7 @@ __device__ __forceinline__ void rescore_reg_one(
 	}
 }
 
-template <int SET>       // 0: bands of 4 / 6 / 8 / 12 diagonals, 1: 16 / 24, 2: 32 / 40 / 48 (separate kernels: the register budget of the wide ones would halve the occupancy of the narrow ones)
+template <int SET>       // 0: bands of 4 / 6 / 8 diagonals, 3: 12, 1: 16 / 24, 2: 32 / 40 / 48 (separate kernels: the register budget of the wide ones would halve the occupancy of the narrow ones)
 __global__ __launch_bounds__(64) void k_rescore_reg(
 		const BhipRawHit *__restrict__ raw, const uint32_t *__restrict__ lists, const uint32_t *__restrict__ counts, uint32_t raw_cap,
 		const uint64_t *__restrict__ qoff, const uint8_t *__restrict__ qrc, const uint32_t *__restrict__ qpack, uint32_t qw,
@@ -2635,7 +2635,8 @@ __global__ __launch_bounds__(64) void k_rescore_reg(
 			const bool live = i < n; \
 			rescore_reg_one<WB>(raw + (live ? lst[i] : 0u), live, s_mm, fastq, tid, qoff, qrc, qpack, qw, refw, ref_off, clump_len, out, n_out, out_cap, err_flags); \
 		} }
-	if (SET == 0) { BHIP_RS_RUN(0, 4) BHIP_RS_RUN(1, 6) BHIP_RS_RUN(2, 8) BHIP_RS_RUN(3, 12) }
+	if (SET == 0) { BHIP_RS_RUN(0, 4) BHIP_RS_RUN(1, 6) BHIP_RS_RUN(2, 8) }
+	else if (SET == 3) { BHIP_RS_RUN(3, 12) }
 	else if (SET == 1) { BHIP_RS_RUN(4, 16) BHIP_RS_RUN(5, 24) }
 	else { BHIP_RS_RUN(6, 32) BHIP_RS_RUN(7, 40) BHIP_RS_RUN(8, 48) }
 #undef BHIP_RS_RUN
@@ -2645,6 +2646,8 @@ template __global__ void k_rescore_reg<0>(const BhipRawHit *, const uint32_t *, 
 template __global__ void k_rescore_reg<1>(const BhipRawHit *, const uint32_t *, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, const uint32_t *, uint32_t,
 	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *);
 template __global__ void k_rescore_reg<2>(const BhipRawHit *, const uint32_t *, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, const uint32_t *, uint32_t,
+	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *);
+template __global__ void k_rescore_reg<3>(const BhipRawHit *, const uint32_t *, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, const uint32_t *, uint32_t,
 	const uint8_t *, const uint64_t *, const uint32_t *, const uint8_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *);
 
 template __global__ void k_rescore<false>(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, int,
