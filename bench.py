@@ -17,7 +17,7 @@ batches of the sorted unique queries.  N > 1 (one process per GPU, torch.distrib
 every rank aligns its contiguous share of every batch (strong scaling: the read set is fixed) and one variable-length
 gather brings the hit records to rank 0 inside the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel by time (HIP events on the stream it runs on);
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel by time on the critical path (HIP events on the stream it runs on);
 `roofline.per_kernel` lists the others with their own bound; PMC-derived traffic / VALU figures come from profiles/
 (tools/profile_round.sh).  `cpu_baseline` is the compiled reference itself (oracle/_ref/burst15, all host cores) on a
 bounded sample of the same reads and database (its .acx is written from the device-built tables): differential wall time of
@@ -395,7 +395,10 @@ def main():
             kernels["k_myers<%d>" % ((args.read_len + 31) // 32)] = (st["ms_myers"] / n, st["bytes_algorithmic"] / n, "valu")
         kernels["k_rescore_*"] = (st["ms_rescore"] / nb, (st["n_raw_hits"] * (20.0 + args.read_len / 2.0 + (args.read_len + 16) / 2.0) + st["n_hits"] * 20.0) / nb, "hbm")
         tot_ms = lambda k: kernels[k][0] * (st["prefilter_launches"] if k.startswith("k_prefilter") or k == "k_seed_ranges" else nb if k == "k_rescore_*" else n)
-        dom = max(kernels, key=tot_ms)
+        # dominant = the longest kernel ON THE CRITICAL PATH (prefilter -> sweeps -> re-scoring): k_seed_ranges works for the NEXT batch, on its
+        # own stream and deliberately with a few blocks per CU (option seed_ahead_blocks), so its elapsed time says how slowly it was allowed
+        # to run beside the chain, not what bounds the step; it stays in per_kernel, marked off_critical_path
+        dom = max((k for k in kernels if k != "k_seed_ranges"), key=tot_ms)
         ms_dom, bytes_dom, bound_dom = kernels[dom]
         achieved = bytes_dom / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
         pmc = pmc_table()
@@ -424,6 +427,8 @@ def main():
                 w = valu_weight(k)
                 if w:      # tools/valu_mix.py: half-rate VOP3 forms cost two issue slots, and the clock under load is 2.05 GHz
                     e["valu_issue_frac"] = pk["valu_frac"] * w
+            if k == "k_seed_ranges":
+                e["off_critical_path"] = True
             per_kernel[k] = e
         cells = (st["n_task_columns"] if masked else st["n_columns"] * 16.0) * min(args.read_len, 32.0 * max(1, st["prefix_words"])) + st["n_window_columns"] * float(args.read_len)
         ms_sweeps = st["ms_myers"]
@@ -455,7 +460,7 @@ def main():
             "roofline": {"bound": "hbm" if bound_dom == "hbm" else "valu", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": pmc_of(dom).get("hbm_bytes_per_launch"),
                          "traffic_gather_calibrated": pmc_of(dom).get("hbm_bytes_per_launch_gather_calibrated") if bound_dom == "hbm" else None,
-                         "note": "dominant kernel by time (HIP events on its stream); per_kernel gives each kernel's own bound: the prefilter and the re-scorer are "
+                         "note": "dominant kernel by time on the critical path (HIP events on its stream; k_seed_ranges works for the next batch beside the chain, throttled: off_critical_path in per_kernel); per_kernel gives each kernel's own bound: the prefilter and the re-scorer are "
                                  "bound by HBM/LDS latency of short gathers, the k_myers_* sweeps by integer VALU issue (valu_frac = issued VALU instructions x 2 cycles / peak, from the PMC pass; half-rate VOP3 forms count once). traffic follows the guide's 2 x FETCH_SIZE rule; traffic_gather_calibrated = FETCH_SIZE + WRITE_SIZE, which is what a sector gather really moves (profiles/r02k_fetch_calibration.txt)",
                          "algorithmic_bytes_per_launch": bytes_dom, "ms_per_launch": ms_dom,
                          "per_kernel": per_kernel,
