@@ -239,6 +239,10 @@ BHIP_API int bhip_sort_queries(int device, const uint8_t *codes, uint64_t codes_
  * above the query's best bound are swept only if the first sweep leaves room for them (exact: the bound is a lower bound).
  * "async_d2h": 0 (default) / 1 = asynchronous hand-over of the records, see bhip_sync_hits.
  * "rescore_reg": 1 (default) = register-band re-scorer for narrow bands, 0 = LDS band only.
+ * "band": 1 (default) = windows whose flagged diagonals fit two to four words of the bit-vector column are swept by the banded kernel
+ * (only those words are stepped; exact), 0 = every window through the full column.  "oversub": 1..16 (default 2) = blocks launched per
+ * resident block slot of the per-item kernels (prefix tasks, windows, re-scoring); "band_blocks": 0 (default, as many as fit) or the
+ * 64-thread blocks per CU of the banded kernel.
  * "host_routing": 0 (default) = batches are routed (length classes, seed plans, lists) by a device kernel, 1 = by the host pass
  * that otherwise only handles batches with query symbols outside the alphabet.  "discard_staged": forget batches that were
  * staged and not aligned (after an error).  "seed_ahead": 1 (default) = the seed lookups and match profiles of the next staged
