@@ -95,7 +95,9 @@ int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const 
 	{
 		const int i = omp_get_thread_num();
 		BhMultiRank *r = &R[i];
+		const double t0 = omp_get_wtime();
 		rcs[i] = bh_align_ranges_reuse(r->hh, Q, r->r0, r->r1, r->n_ranges, mode, batch, &r->run);
+		r->secSearch = omp_get_wtime() - t0;
 		if (rcs[i]) snprintf(errs[i], sizeof errs[i], "%s", bh_last_error());
 		else if (shard_db > 1) {
 			for (uint64_t k = 0; k < r->run.nHits; ++k) r->run.hits[k].refIx += 16u * r->c0;

@@ -139,6 +139,7 @@ typedef struct BhMultiRank {
 	const uint64_t *r0, *r1; uint32_t n_ranges;   /* ranges of unique queries it aligns (database-sharded: normally one range, everything) */
 	uint32_t c0;                  /* database-sharded: first clump of its slice (added to the records' reference numbers) */
 	BhRun run;                    /* its own records (the page-locked buffer is reused between calls) */
+	double secSearch;             /* out: wall time of this rank's align phase (before the minima / the gather) */
 } BhMultiRank;
 /* clump range of rank `rank` of `n_ranks`: contiguous, about the same number of reference columns each */
 void bh_clump_shard(const BhDb *db, int n_ranks, int rank, uint32_t *c0, uint32_t *c1);

@@ -353,6 +353,8 @@ int main(int argc, char **argv) {
 		if ((rc = bh_search_multi(ranks, n_gpus, n_gpus, comm, &Q, mode, batch, shard_db ? n_shards : 0, &run, cnts))) { fprintf(stderr, "%s\n", bh_last_error()); return rc == BH_E_USAGE ? 1 : 4; }
 		printf("%s: %d rank(s)%s, records per rank:", use_rccl ? "RCCL gather" : "host gather", n_gpus, shard_db ? ", database-sharded" : "");
 		for (int r = 0; r < n_gpus; ++r) printf(" %lu", (unsigned long)cnts[r]);
+		printf("; align phase per rank [s]:");
+		for (int r = 0; r < n_gpus; ++r) printf(" %.4f", ranks[r].secSearch);
 		printf("\n");
 		for (int r = 0; r < n_gpus; ++r) { run.total.n_pairs += ranks[r].run.total.n_pairs; bh_run_free(&ranks[r].run); }
 	}

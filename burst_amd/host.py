@@ -39,7 +39,7 @@ class BhRun(C.Structure):
 
 
 class BhMultiRank(C.Structure):
-    _fields_ = [("rank", C.c_int), ("hh", C.c_void_p), ("r0", u64p), ("r1", u64p), ("n_ranges", C.c_uint32), ("c0", C.c_uint32), ("run", BhRun)]
+    _fields_ = [("rank", C.c_int), ("hh", C.c_void_p), ("r0", u64p), ("r1", u64p), ("n_ranges", C.c_uint32), ("c0", C.c_uint32), ("run", BhRun), ("secSearch", C.c_double)]
 
 
 class HostError(RuntimeError):
