@@ -282,6 +282,8 @@ int main(int argc, char **argv) {
 	if (shard_db && (uint32_t)n_shards > db.numRclumps) { puts("ERROR: more database shards than clumps"); return 1; }
 	if (!n_dev_list) for (int r = 0; r < n_gpus; ++r) dev_list[r] = n_gpus_given ? r : device;
 	if (use_rccl && bhip_comm_create(n_gpus, dev_list, &comm)) { fprintf(stderr, "libburst_hip: %s\n", bhip_last_error()); return 4; }
+	int shared_dev = 0;
+	for (int a = 0; a < n_gpus; ++a) for (int b = a + 1; b < n_gpus; ++b) shared_dev |= dev_list[a] == dev_list[b];
 	omp_set_dynamic(0);
 	#pragma omp parallel num_threads(n_gpus)
 	{
@@ -295,7 +297,12 @@ int main(int argc, char **argv) {
 			if ((rcs[r] = bh_db_slice(&db, c0, c1, &slices[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
 			part = &slices[r];
 		}
-		if (!rcs[r] && (rcs[r] = bh_device_open_ex(part, dev_list[r], z, accel_dev ? K : 0, &hhs[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
+		/* ranks that share a device (--devices 0,0,...: diagnostics on a one-GPU machine) open their handles one after the other:
+		 * the accelerator build sizes its scratch from the memory that is free when it starts */
+		if (!rcs[r] && shared_dev) {
+			#pragma omp critical (bh_device_open)
+			if ((rcs[r] = bh_device_open_ex(part, dev_list[r], z, accel_dev ? K : 0, &hhs[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
+		} else if (!rcs[r] && (rcs[r] = bh_device_open_ex(part, dev_list[r], z, accel_dev ? K : 0, &hhs[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
 	}
 	for (int r = 0; r < n_gpus; ++r) if (rcs[r]) { fprintf(stderr, "%s\n", rcs[r] == BH_E_INTERNAL ? "OpenMP did not start one host thread per GPU" : errs[r]); return 4; }
 	for (int r = 0; r < n_gpus; ++r) { char nm[256]; int ncu = 0; uint64_t hbm = 0; if (!bhip_device_info(hhs[r], nm, sizeof nm, &ncu, &hbm)) printf("Device %d: %s, %d CUs, %.0f GiB\n", dev_list[r], nm, ncu, hbm / 1073741824.0); }
