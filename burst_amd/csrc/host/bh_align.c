@@ -72,6 +72,13 @@ int bh_run_reserve(BhRun *run, uint64_t cap) {
 	run->hits = hits_alloc(cap, &run->hitsPinned); run->capHits = run->hits ? cap : 0; run->nHits = 0;
 	return run->hits ? BH_OK : bh_set_error(BH_E_OOM, "OOM:hits");
 }
+/* the same in pageable memory (a buffer no device copy lands in: the gathered records of ranks that live in one process) */
+int bh_run_reserve_plain(BhRun *run, uint64_t cap) {
+	if (run->hits && run->capHits >= cap) return BH_OK;
+	if (run->hits) hits_free(run->hits, run->hitsPinned);
+	run->hits = malloc(cap * sizeof(BhipHit)); run->hitsPinned = 0; run->capHits = run->hits ? cap : 0; run->nHits = 0;
+	return run->hits ? BH_OK : bh_set_error(BH_E_OOM, "OOM:hits");
+}
 static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const uint64_t *r1, uint32_t n_ranges, BhMode mode, uint64_t batch_uniq, BhRun *run);
 int bh_align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const uint64_t *r1, uint32_t n_ranges, BhMode mode, uint64_t batch_uniq, BhRun *run) {
 	memset(run, 0, sizeof *run);

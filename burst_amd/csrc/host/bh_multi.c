@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <omp.h>
+#include <sys/mman.h>
 
 void bh_clump_shard(const BhDb *db, int n_ranks, int rank, uint32_t *c0, uint32_t *c1) {
 	uint64_t total = 0;
@@ -53,19 +54,109 @@ static void shard_filter(const BhQueries *Q, BhRun *run, const uint8_t *best) {
 	}
 	run->nHits = k;
 }
-/* records gathered in rank order -> (query entry, reference) order: a stable counting sort by entry (inside an entry the ranks'
- * clump ranges ascend, and so do the references) */
-static int shard_order(BhRun *all, uint64_t n_entries) {
-	if (all->nHits < 2) return BH_OK;
-	uint64_t *pos = calloc(n_entries + 1, sizeof(*pos));
-	BhipHit *tmp = malloc(all->nHits * sizeof(*tmp));
-	if (!pos || !tmp) { free(pos); free(tmp); return bh_set_error(BH_E_OOM, "OOM:shard_order"); }
-	for (uint64_t i = 0; i < all->nHits; ++i) ++pos[(uint64_t)all->hits[i].q + 1];
-	for (uint64_t e = 0; e < n_entries; ++e) pos[e + 1] += pos[e];
-	for (uint64_t i = 0; i < all->nHits; ++i) tmp[pos[all->hits[i].q]++] = all->hits[i];
-	memcpy(all->hits, tmp, all->nHits * sizeof(*tmp));
-	free(pos); free(tmp);
-	return BH_OK;
+/* Records in any order -> (query entry, reference) order: what a single device holding the whole database produces.
+ * (query entry, reference) pairs are unique -- the ranks' clump ranges are disjoint -- so the order is fully determined by the
+ * two keys and the sort need not be stable: a counting sort by entry whose counts and slots are taken with relaxed atomics by a
+ * team of threads (neighbouring records belong to neighbouring entries, so the threads rarely meet), a two-level scan, and a
+ * pass that puts the few records of each entry in reference order.  The sources are the ranks' runs where they lie (all ranks
+ * in one process: no concatenation, no scratch copy) or the gathered array (in place through a scratch array). */
+static int by_ref(const void *a, const void *b) {
+	const uint32_t x = ((const BhipHit *)a)->refIx, y = ((const BhipHit *)b)->refIx;
+	return x < y ? -1 : x > y;
+}
+static int order_into(const BhipHit *const *src, const uint64_t *cnt, int n_src, BhipHit *dst, uint64_t n_entries) {
+	uint64_t n = 0;
+	for (int r = 0; r < n_src; ++r) n += cnt[r];
+	if (!n) return BH_OK;
+	uint64_t *c = calloc(n_entries + 1, sizeof(*c));
+	int nt = omp_get_max_threads(); if (nt > 32) nt = 32; if (nt < 1 || n < (1u << 16)) nt = 1;
+	uint64_t *bs = calloc((size_t)nt + 1, sizeof(*bs));
+	if (!c || !bs) { free(c); free(bs); return bh_set_error(BH_E_OOM, "OOM:order_records"); }
+	int bad = 0;
+	#pragma omp parallel num_threads(nt)
+	{
+		const int t = omp_get_thread_num(), T = omp_get_num_threads();
+		/* 1. records per entry */
+		int mybad = 0;
+		for (int r = 0; r < n_src; ++r) {
+			const BhipHit *h = src[r];
+			#pragma omp for schedule(static) nowait
+			for (uint64_t i = 0; i < cnt[r]; ++i) {
+				const uint64_t q = h[i].q;
+				if (q >= n_entries) mybad = 1; else __atomic_fetch_add(&c[q], 1, __ATOMIC_RELAXED);
+			}
+		}
+		if (mybad) {
+			#pragma omp atomic write
+			bad = 1;
+		}
+		#pragma omp barrier
+		/* 2. exclusive scan: c[e] = first slot of entry e */
+		const uint64_t lo = n_entries * (uint64_t)t / (uint64_t)T, hi = n_entries * (uint64_t)(t + 1) / (uint64_t)T;
+		uint64_t sum = 0;
+		for (uint64_t e = lo; e < hi; ++e) sum += c[e];
+		bs[t + 1] = sum;
+		#pragma omp barrier
+		#pragma omp single
+		for (int k = 0; k < T; ++k) bs[k + 1] += bs[k];
+		uint64_t run = bs[t];
+		for (uint64_t e = lo; e < hi; ++e) { const uint64_t k = c[e]; c[e] = run; run += k; }
+		#pragma omp barrier
+		if (!bad) {
+			/* 3. scatter: afterwards c[e] = one past the last slot of entry e */
+			for (int r = 0; r < n_src; ++r) {
+				const BhipHit *h = src[r];
+				#pragma omp for schedule(static) nowait
+				for (uint64_t i = 0; i < cnt[r]; ++i) dst[__atomic_fetch_add(&c[h[i].q], 1, __ATOMIC_RELAXED)] = h[i];
+			}
+			#pragma omp barrier
+			/* 4. the records of an entry by reference */
+			#pragma omp for schedule(static)
+			for (uint64_t e = 0; e < n_entries; ++e) {
+				const uint64_t a = e ? c[e - 1] : 0, b = c[e];
+				if (b - a > 24) qsort(dst + a, b - a, sizeof(*dst), by_ref);
+				else for (uint64_t i = a + 1; i < b; ++i) {
+					const BhipHit h = dst[i]; uint64_t k = i;
+					while (k > a && dst[k - 1].refIx > h.refIx) { dst[k] = dst[k - 1]; --k; }
+					dst[k] = h;
+				}
+			}
+		}
+	}
+	free(c); free(bs);
+	return bad ? bh_set_error(BH_E_INTERNAL, "a record refers to an entry beyond %lu", (unsigned long)n_entries) : BH_OK;
+}
+int bh_order_records(BhipHit *hits, uint64_t n, uint64_t n_entries) {
+	if (n < 2) return n && hits[0].q >= n_entries ? bh_set_error(BH_E_INTERNAL, "a record refers to an entry beyond %lu", (unsigned long)n_entries) : BH_OK;
+	/* scratch of the array's size: 2 MB-aligned and advised for huge pages (its first touch is the scatter itself) */
+	const size_t bytes = ((size_t)n * sizeof(BhipHit) + ((size_t)1 << 21) - 1) & ~(((size_t)1 << 21) - 1);
+	BhipHit *tmp = aligned_alloc((size_t)1 << 21, bytes);
+	if (!tmp) return bh_set_error(BH_E_OOM, "OOM:order_records");
+	(void)madvise(tmp, bytes, MADV_HUGEPAGE);
+	const BhipHit *src = hits;
+	const int rc = order_into(&src, &n, 1, tmp, n_entries);
+	if (!rc) {
+		#pragma omp parallel for schedule(static)
+		for (uint64_t blk = 0; blk < (n + 65535) / 65536; ++blk) {
+			const uint64_t a = blk * 65536, b = a + 65536 < n ? a + 65536 : n;
+			memcpy(hits + a, tmp + a, (b - a) * sizeof(*tmp));
+		}
+	}
+	free(tmp);
+	return rc;
+}
+/* element-wise minimum of the ranks' per-query minima into best[0] (all ranks in one process, no communicator) */
+void bh_minima_merge(uint8_t *const *best, int n, uint64_t len) {
+	#pragma omp parallel for schedule(static)
+	for (uint64_t blk = 0; blk < (len + 65535) / 65536; ++blk) {
+		const uint64_t a = blk * 65536, b = a + 65536 < len ? a + 65536 : len;
+		uint8_t *d = best[0];
+		for (int i = 1; i < n; ++i) {
+			const uint8_t *s = best[i];
+			if (!s) continue;
+			for (uint64_t k = a; k < b; ++k) d[k] = s[k] < d[k] ? s[k] : d[k];
+		}
+	}
 }
 
 int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const BhQueries *Q, BhMode mode, uint64_t batch, int shard_db, BhRun *all, uint64_t *counts) {
@@ -122,11 +213,12 @@ int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const 
 				if (rc && !rcs[i]) { rcs[i] = BH_E_DEVICE; snprintf(errs[i], sizeof errs[i], "libburst_hip: %s", bhip_last_error()); }
 				free(tmp);
 			}
-		} else {
-			for (int i = 1; i < n_local; ++i) if (best[0] && best[i]) for (uint64_t s = 0; s < Q->numUniq; ++s) if (best[i][s] < best[0][s]) best[0][s] = best[i][s];
-			for (int i = 1; i < n_local; ++i) if (best[0] && best[i]) memcpy(best[i], best[0], Q->numUniq);
+		} else if (best[0]) {      /* (a rank without its table has failed: the call returns its error below) */
+			bh_minima_merge(best, n_local, Q->numUniq);
+			for (int i = 1; i < n_local; ++i) if (best[i]) { free(best[i]); best[i] = NULL; }
 		}
-		for (int i = 0; i < n_local; ++i) if (!rcs[i]) shard_filter(Q, &R[i].run, best[i]);
+		#pragma omp parallel for schedule(dynamic, 1) num_threads(n_local)
+		for (int i = 0; i < n_local; ++i) if (!rcs[i] && (best[i] || (!comm && best[0]))) shard_filter(Q, &R[i].run, best[i] ? best[i] : best[0]);
 	}
 	for (int i = 0; i < n_local; ++i) free(best[i]);
 	/* 3. the records to rank 0 */
@@ -134,7 +226,7 @@ int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const 
 	for (int i = 0; i < n_local; ++i) if (R[i].rank == 0) i0 = i;
 	uint64_t tot_local = 0;
 	for (int i = 0; i < n_local; ++i) tot_local += rcs[i] ? 0 : R[i].run.nHits;
-	int rc = BH_OK;
+	int rc = BH_OK, ordered = 0;
 	if (comm) {
 		/* rank 0's buffer is sized from its own share; when the gathered total does not fit (BHIP_E_CAPACITY) the records stay on
 		 * rank 0's device and are fetched into a larger buffer without another collective */
@@ -158,14 +250,21 @@ int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const 
 		}
 		if (i0 >= 0) all->nHits = need;
 	} else {
-		if (bh_run_reserve(all, tot_local + 1)) rc = bh_set_error(BH_E_OOM, "OOM:hits");
+		/* all ranks in this process: their runs meet in host memory (the buffer need not be page-locked: no device writes to it) */
+		if (bh_run_reserve_plain(all, tot_local + 1)) rc = bh_set_error(BH_E_OOM, "OOM:hits");
 		else {
-			uint64_t o = 0;
+			uint64_t o = 0, at[BH_MAX_RANKS], cnt[BH_MAX_RANKS]; const BhipHit *src[BH_MAX_RANKS];
 			for (int i = 0; i < n_local; ++i) {      /* local ranks are listed in rank order */
-				const uint64_t n = rcs[i] ? 0 : R[i].run.nHits;
-				if (n) memcpy(all->hits + o, R[i].run.hits, n * sizeof(BhipHit));
-				if (counts) counts[R[i].rank] = n;
-				o += n;
+				cnt[i] = rcs[i] ? 0 : R[i].run.nHits; src[i] = R[i].run.hits;
+				if (counts) counts[R[i].rank] = cnt[i];
+				at[i] = o; o += cnt[i];
+			}
+			if (shard_db > 1 && n_ranks > 1) {      /* database-sharded: straight into (query entry, reference) order */
+				rc = order_into(src, cnt, n_local, all->hits, Q->numEntries);
+				ordered = 1;
+			} else {
+				#pragma omp parallel for schedule(dynamic, 1) num_threads(n_local)
+				for (int i = 0; i < n_local; ++i) if (cnt[i]) memcpy(all->hits + at[i], src[i], cnt[i] * sizeof(BhipHit));
 			}
 			all->nHits = o;
 		}
@@ -175,7 +274,7 @@ int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const 
 	if (rc) return rc;
 	if (i0 >= 0) {
 		for (int i = 0; i < n_local; ++i) { all->nBatches += R[i].run.nBatches; all->secAlign += i == i0 ? R[i].run.secAlign : 0; }
-		if (shard_db > 1 && n_ranks > 1) rc = shard_order(all, Q->numEntries);
+		if (shard_db > 1 && n_ranks > 1 && !ordered) rc = bh_order_records(all->hits, all->nHits, Q->numEntries);
 	}
 	return rc;
 }

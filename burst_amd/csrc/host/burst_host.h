@@ -130,6 +130,7 @@ int  bh_align_ranges(void *hip_handle, const BhQueries *q, const uint64_t *u0, c
 /* into a BhRun used before (or zeroed): keeps its page-locked record buffer */
 int  bh_align_ranges_reuse(void *hip_handle, const BhQueries *q, const uint64_t *u0, const uint64_t *u1, uint32_t n_ranges, BhMode mode, uint64_t batch_uniq, BhRun *run);
 int  bh_run_reserve(BhRun *run, uint64_t cap_records);
+int  bh_run_reserve_plain(BhRun *run, uint64_t cap_records);      /* pageable memory */
 void bh_run_free(BhRun *run);
 /* ---- multi-GPU search (bh_multi.c) ---- */
 #define BH_MAX_RANKS 16
@@ -151,6 +152,10 @@ void bh_clump_shard(const BhDb *db, int n_ranks, int rank, uint32_t *c0, uint32_
  * and minima then meet in host memory.  all = the gathered records where rank 0 lives (sorted by (query entry, reference));
  * counts[n_ranks] (optional, rank 0's process) = records per rank. */
 int  bh_search_multi(BhMultiRank *ranks, int n_local, int n_ranks, void *comm, const BhQueries *q, BhMode mode, uint64_t batch_uniq, int shard_db, BhRun *all, uint64_t *counts);
+/* pieces of the database-sharded search, exported for the tests: records in any order -> (query entry, reference) order in place
+ * ((entry, reference) pairs must be unique); element-wise minimum of n tables of len bytes into best[0] (NULL tables are skipped) */
+int  bh_order_records(BhipHit *hits, uint64_t n, uint64_t n_entries);
+void bh_minima_merge(uint8_t *const *best, int n, uint64_t len);
 int  bh_device_open(const BhDb *db, int device, int z, void **hip_handle);
 /* build_K > 0 and a database without accelerator tables: the device builds the accelerator itself (no .acx file) */
 int  bh_device_open_ex(const BhDb *db, int device, int z, int build_K, void **hip_handle);

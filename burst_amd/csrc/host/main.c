@@ -349,8 +349,11 @@ int main(int argc, char **argv) {
 				fprintf(stderr, " --> WARNING: batch buffers not reserved on device %d (%s); they are allocated batch by batch\n", dev_list[r], bhip_last_error());
 		}
 	}
-	PHASE("batch buffers");
 	BhRun run; memset(&run, 0, sizeof run);
+	/* several ranks: the buffer their records meet in, made here and not inside the search (page-locked when a device copy lands
+	 * in it, i.e. with the RCCL gather; bh_search_multi grows it if the job brings more) */
+	if (n_gpus > 1 || use_rccl) { const uint64_t cap = Q.numEntries + Q.numEntries / 2 + (1u << 20); if (use_rccl) bh_run_reserve(&run, cap); else bh_run_reserve_plain(&run, cap); }
+	PHASE("batch buffers");
 	const double t0 = wall();
 	uint64_t cnts[BH_MAX_GPUS]; memset(cnts, 0, sizeof cnts);
 	if (n_gpus == 1 && !use_rccl) {

@@ -174,3 +174,48 @@ def test_database_slice_accelerator_equals_rebuilt():
             assert a.c.badSz == b.c.badSz and a.c.totR == min(db.c.totR, 16 * c1) - 16 * c0
             total += int(la.sum(dtype=np.uint64))
         assert total == int(host._view(db.c.acxLens, 1 << 24, np.uint32).sum(dtype=np.uint64))
+
+
+@pytest.mark.parametrize("n,n_entries,per_entry", [(0, 5, 1), (1, 5, 1), (1000, 300, 8), (300000, 90000, 6), (200000, 50, 9000)])
+def test_order_records_equals_a_sort_by_entry_and_reference(n, n_entries, per_entry):
+    """bh_order_records (the last step of a database-sharded search: the ranks' records into the order one device holding the
+    whole database produces) against numpy's sort by (entry, reference): every field of every record, for a few and for many
+    records per entry (FORAGE); below 65 536 records one thread works, above a team does"""
+    import ctypes as C
+    from burst_amd import capi, host
+    L = host.lib()
+    L.bh_order_records.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    L.bh_order_records.restype = C.c_int
+    rng = np.random.default_rng(n + per_entry)
+    # unique (entry, reference) pairs, then shuffled the way rank runs arrive: runs that are sorted inside, concatenated
+    q = rng.integers(0, n_entries, size=n, dtype=np.uint32)
+    ref = rng.integers(0, 1 << 22, size=n, dtype=np.uint32)
+    key = np.unique(q.astype(np.uint64) << 32 | ref)
+    h = np.zeros(len(key), dtype=capi.HIT_DTYPE)
+    h["q"] = (key >> 32).astype(np.uint32); h["refIx"] = (key & 0xFFFFFFFF).astype(np.uint32)
+    h["finalPos"] = rng.integers(0, 1 << 30, size=len(h)); h["score"] = rng.random(len(h), dtype=np.float32); h["ed"] = rng.integers(0, 255, size=len(h))
+    want = h.copy()                                                   # np.unique sorted the keys
+    ranks = rng.integers(0, 8, size=len(h))
+    got = np.concatenate([h[ranks == r] for r in range(8)]) if len(h) else h.copy()
+    a = np.ascontiguousarray(got.copy())
+    assert L.bh_order_records(a.ctypes.data, len(a), n_entries) == 0
+    assert a.tobytes() == want.tobytes()
+    if len(h):
+        bad = got.copy(); bad["q"][0] = n_entries
+        assert L.bh_order_records(bad.ctypes.data, len(bad), n_entries) != 0 or len(bad) < 2
+
+
+def test_minima_merge_is_the_elementwise_minimum():
+    """bh_minima_merge (database-sharded ranks in one process: one byte per unique query, 255 = no hit on that rank)"""
+    import ctypes as C
+    from burst_amd import host
+    L = host.lib()
+    L.bh_minima_merge.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_uint64]
+    L.bh_minima_merge.restype = None
+    rng = np.random.default_rng(5)
+    for n in (1, 70001, 300000):
+        tabs = [rng.integers(0, 256, size=n, dtype=np.uint8) for _ in range(5)]
+        want = np.minimum.reduce([tabs[0], tabs[1], tabs[3], tabs[4]])
+        ptrs = (C.c_void_p * 5)(tabs[0].ctypes.data, tabs[1].ctypes.data, None, tabs[3].ctypes.data, tabs[4].ctypes.data)      # a NULL table is skipped
+        L.bh_minima_merge(ptrs, 5, n)
+        assert np.array_equal(tabs[0], want)
