@@ -234,6 +234,7 @@ def main():
     ap.add_argument("--no-pin", action="store_true", help="leave the query arrays pageable")
     ap.add_argument("--drop-refs", action="store_true", help="delete the reference FASTA once the reads and the .edx exist (disk space of very large databases)")
     ap.add_argument("--no-prime", action="store_true", help="skip bhip_reserve and the priming call (profiling: every dispatch of the run is then a full-size batch)")
+    ap.add_argument("--gather", default="shm", choices=["shm", "rccl"], help="N > 1: how the ranks' records reach rank 0 -- shared-memory segments rank 0 maps (default; no collective) or the library's RCCL gather")
     ap.add_argument("--acx-file", action="store_true", help="round 2's path: the accelerator from an .acx file (built by the host builder) instead of the device build")
     args = ap.parse_args()
     args.n_base = int(round(args.n_base * args.db_scale))
@@ -245,10 +246,22 @@ def main():
     import torch
     # BURST_BENCH_DIST1=1 (test hook, under torch.distributed.run with one process): take the N > 1 code path on a single GPU
     use_dist = world > 1 or (os.environ.get("BURST_BENCH_DIST1") == "1" and "MASTER_ADDR" in os.environ)
+    # BURST_BENCH_DEVICE=<d> (test hook): every rank on device d -- the N > 1 command line of the driver on a one-GPU box.  RCCL
+    # refuses two ranks on one device, so the launcher's plumbing (barriers, the max over ranks) is gloo then and the records take
+    # the shared-memory hand-over, which needs no communicator
+    one_dev = os.environ.get("BURST_BENCH_DEVICE")
+    if one_dev is not None:
+        local_rank = int(one_dev)
+        if args.gather == "rccl" and world > 1:
+            raise SystemExit("BURST_BENCH_DEVICE puts every rank on one device: --gather shm only")
+    pdev = "cpu" if one_dev is not None else "cuda"          # where the plumbing's tensors live
     if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_dev is not None:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from burst_amd import capi, host
     refs, edx, acx, reads_fa, done = build_inputs(args.workdir, args, rank)
@@ -274,7 +287,13 @@ def main():
     qs = host.QuerySet(reads_fa, args.id, rc=args.fr, accel=True, K=args.K)
     t_q = time.time() - t
     t = time.time()
+    if one_dev is not None and use_dist:      # ranks sharing the device build one after the other (the build sizes its scratch from what is free when it starts)
+        for r in range(rank):
+            dist.barrier()
     dev = db.open_device(local_rank, build_K=0 if args.acx_file else args.K)      # references up, both layouts; accelerator built on the device
+    if one_dev is not None and use_dist:
+        for r in range(rank, world):
+            dist.barrier()
     t_dev = time.time() - t
     for kv in args.opt:
         name, _, val = kv.partition("=")
@@ -304,7 +323,8 @@ def main():
     # N > 1: the product's own exchange -- the library's RCCL communicator over the ranks (one process per GPU: the 128-byte id
     # travels through torch.distributed, which is plumbing here) and bh_search_multi, the function `burst_hip --gpus N` runs
     comm = None
-    if use_dist:
+    node = None
+    if use_dist and args.gather == "rccl":
         idt = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             buf = (C.c_uint8 * 128)()
@@ -315,8 +335,7 @@ def main():
         idb = (C.c_uint8 * 128)(*idt.cpu().tolist())
         comm = C.c_void_p()
         capi._chk(capi.lib().bhip_comm_create_rank(world, rank, local_rank, idb, C.byref(comm)))
-    rs = host.RankSearch(dev, rank, world, comm)
-
+    rs = None
     def search(ranges):
         """one job share through the product's scheduler; N > 1: + the gather of the records to rank 0"""
         if use_dist:
@@ -330,6 +349,18 @@ def main():
     share = max(1, sum(b - a for a, b in job_share(args.warmup, args.steps))) * (2 if args.fr else 1)
     cap_rec = int(max(share, 4 * ent_per_step) * (4.0 if args.mode in ("FORAGE", "ALLPATHS") else 1.5)) + (1 << 20)
     if use_dist:
+        if args.gather == "shm":
+            # the ranks' record buffers are shared-memory segments rank 0 maps (bh_node.c): no collective on the data path.  The job
+            # name travels through the launcher (plumbing); rank 0 opens first
+            jt = torch.tensor([int.from_bytes(os.urandom(6), "little") if rank == 0 else 0], dtype=torch.int64, device=pdev)
+            dist.broadcast(jt, 0)
+            job = "bench%x" % int(jt.item())
+            if rank == 0:
+                node = host.Node(job, rank, world, cap_rec)
+            dist.barrier()
+            if rank != 0:
+                node = host.Node(job, rank, world, cap_rec)
+        rs = host.RankSearch(dev, rank, world, comm, node=node)
         rs.reserve(cap_rec)
     else:
         _own.reserve(cap_rec)
@@ -353,10 +384,10 @@ def main():
         dist.barrier()
     elapsed = time.time() - t0
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=pdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        nr = torch.tensor([n_records if rank == 0 else 0], dtype=torch.int64, device="cuda")
+        nr = torch.tensor([n_records if rank == 0 else 0], dtype=torch.int64, device=pdev)
         dist.all_reduce(nr)
         n_records = int(nr.item())
     total_reads = sum(reads_per_pool_batch[(args.warmup + k) % P] for k in range(args.steps))
@@ -452,9 +483,12 @@ def main():
                                    "(%.2f Gbp; %d clumps; .edx %.2f GB + DB%d .acx %.2f GB); every step stages its batch afresh through the product's batch scheduler"
                                    % (world, args.reads, args.read_len, args.mode, args.id, args.n_base * args.n_variants, args.ref_len,
                                       args.n_base * args.n_variants * args.ref_len / 1e9, db.c.numRclumps, edx_bytes / 1e9, args.K, acx_bytes / 1e9),
-                       "parallelism": "query-sharded x%d (rank r aligns the r-th N-th of the job's unique queries in device batches of up to %d), DB replicated, one RCCL gather of the hit records to rank 0 "
-                                      "(bhip_comm_gather_hits inside bh_search_multi, the function burst_hip --gpus N runs)" % (world, batch_uniq),
-                       "timed_region": "bh_align_ranges over %d batches (copies + device routing two batches ahead, seed lookups + profiles one batch ahead, alignment, records to host memory)%s" % (nb, " + RCCL gather" if use_dist else ""),
+                       "parallelism": ("query-sharded x%d (rank r aligns the r-th N-th of the job's unique queries in device batches of up to %d), DB replicated; " % (world, batch_uniq)) +
+                                      ("no collective on the data path: every rank's record buffer is a page-locked shared-memory segment (its batches' records land there over its own PCIe link, behind the "
+                                       "batch), rank 0 maps the segments and concatenates (bh_node.c inside bh_search_multi_ex)" if use_dist and args.gather == "shm" else
+                                       "one RCCL gather of the hit records to rank 0 (bhip_comm_gather_hits inside bh_search_multi, the function burst_hip --gpus N --gather rccl runs)"),
+                       "timed_region": "bh_align_ranges over %d batches (copies + device routing two batches ahead, seed lookups + profiles one batch ahead, alignment, records to host memory)%s" %
+                                       (nb, (" + hand-over of all ranks' records to rank 0 (shared memory)" if args.gather == "shm" else " + RCCL gather") if use_dist else ""),
                        "extrapolation": extrap,
                        "device": info["name"], "n_cu": info["n_cu"]},
             "roofline": {"bound": "hbm" if bound_dom == "hbm" else "valu", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
@@ -507,7 +541,8 @@ def main():
             except Exception as e:      # reported, never fatal for the measurement
                 res["parity_vs_reference"] = {"error": str(e)}
         print(json.dumps(res), flush=True)
-    rs.close()
+    if rs is not None:
+        rs.close()
     _own.close()
     if comm:
         capi.lib().bhip_comm_destroy(comm)

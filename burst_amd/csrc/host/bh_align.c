@@ -41,7 +41,8 @@ static BhipHit *hits_alloc(uint64_t cap, int *pinned) {
 	if (!p) p = malloc(cap * sizeof(BhipHit));
 	return p;
 }
-static void hits_free(BhipHit *p, int pinned) { if (pinned) bhip_free_host(p); else free(p); }
+/* (pinned == 2: memory the run does not own -- a shared-memory segment of bh_node.c) */
+static void hits_free(BhipHit *p, int pinned) { if (pinned == 2) return; if (pinned) bhip_free_host(p); else free(p); }
 
 void bh_run_free(BhRun *run) { if (run) { if (run->hits) hits_free(run->hits, run->hitsPinned); memset(run, 0, sizeof *run); } }
 

@@ -16,6 +16,7 @@
  *                   quarter of the reads at the rate one device reaches on half the database.
  */
 #include "burst_host.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <omp.h>
@@ -160,12 +161,20 @@ void bh_minima_merge(uint8_t *const *best, int n, uint64_t len) {
 }
 
 int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const BhQueries *Q, BhMode mode, uint64_t batch, int shard_db, BhRun *all, uint64_t *counts) {
+	return bh_search_multi_ex(R, n_local, n_ranks, comm, NULL, Q, mode, batch, shard_db, all, counts);
+}
+int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhNode *node, const BhQueries *Q, BhMode mode, uint64_t batch, int shard_db, BhRun *all, uint64_t *counts) {
 	/* shard_db = number of database shards S (0 / 1: none).  S < n_ranks: the ranks form n_ranks / S replica groups of S shards each
 	 * (rank = group * S + shard); the caller gives every rank its group's query ranges and its shard's first clump.  The minima
 	 * are combined over ALL ranks at once: the groups' queries are disjoint and a rank says 255 ("none") for queries that are not
 	 * its group's, so the minimum over everybody is the minimum over the group. */
 	if (n_local < 1 || n_local > n_ranks || n_ranks > BH_MAX_RANKS) return bh_set_error(BH_E_USAGE, "bad rank layout (%d local of %d)", n_local, n_ranks);
-	if (!comm && n_local != n_ranks) return bh_set_error(BH_E_USAGE, "without a communicator every rank must live in this process");
+	if (!comm && !node && n_local != n_ranks) return bh_set_error(BH_E_USAGE, "without a communicator every rank must live in this process");
+	if (node && n_local != 1) return bh_set_error(BH_E_USAGE, "the shared-memory hand-over is for one rank per process");
+	if (node && !comm && shard_db > 1 && mode != BH_FORAGE && n_ranks > 1) return bh_set_error(BH_E_USAGE, "database-sharded ranks in different processes need the communicator for the minima");
+	const int dbg = getenv("BURST_HOST_DEBUG") != NULL;
+	double tp[5]; tp[0] = omp_get_wtime();
+	if (node) { int b = bh_node_begin(node); if (b) return b; bh_node_attach(node, &R[0].run); }
 	int rcs[BH_MAX_RANKS]; char errs[BH_MAX_RANKS][512];
 	uint8_t *best[BH_MAX_RANKS];
 	for (int i = 0; i < n_local; ++i) { rcs[i] = BH_E_INTERNAL; snprintf(errs[i], sizeof errs[i], "rank %d never ran (OpenMP gave the team fewer than %d threads)", R[i].rank, n_local); best[i] = NULL; }
@@ -199,6 +208,7 @@ int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const 
 			}
 		}
 	}
+	tp[1] = omp_get_wtime();
 	/* (a rank that failed still has to walk through the collectives its peers are in: it takes part with nothing) */
 	/* 2. database-sharded: the per-query minimum over all ranks */
 	if (reduce) {
@@ -221,13 +231,22 @@ int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const 
 		for (int i = 0; i < n_local; ++i) if (!rcs[i] && (best[i] || (!comm && best[0]))) shard_filter(Q, &R[i].run, best[i] ? best[i] : best[0]);
 	}
 	for (int i = 0; i < n_local; ++i) free(best[i]);
+	tp[2] = omp_get_wtime();
 	/* 3. the records to rank 0 */
 	int i0 = -1;
 	for (int i = 0; i < n_local; ++i) if (R[i].rank == 0) i0 = i;
 	uint64_t tot_local = 0;
 	for (int i = 0; i < n_local; ++i) tot_local += rcs[i] ? 0 : R[i].run.nHits;
 	int rc = BH_OK, ordered = 0;
-	if (comm) {
+	if (node) {
+		/* one rank per process, the records already lie in this rank's shared-memory segment: say so; rank 0 takes everybody's */
+		const int p = bh_node_publish(node, &R[0].run, rcs[0]);
+		if (p && !rcs[0]) { rcs[0] = p; snprintf(errs[0], sizeof errs[0], "%s", bh_last_error()); }
+		if (i0 >= 0) {
+			const int c = bh_node_collect(node, all, counts);
+			if (c && !rcs[0]) { rcs[0] = c; snprintf(errs[0], sizeof errs[0], "%s", bh_last_error()); }
+		}
+	} else if (comm) {
 		/* rank 0's buffer is sized from its own share; when the gathered total does not fit (BHIP_E_CAPACITY) the records stay on
 		 * rank 0's device and are fetched into a larger buffer without another collective */
 		if (i0 >= 0 && bh_run_reserve(all, tot_local * (uint64_t)(n_ranks > n_local ? n_ranks / n_local : 1) + (tot_local >> 2) + (1u << 16))) {
@@ -269,6 +288,7 @@ int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const 
 			all->nHits = o;
 		}
 	}
+	tp[3] = omp_get_wtime();
 	omp_set_dynamic(dyn);
 	for (int i = 0; i < n_local; ++i) if (rcs[i]) return bh_set_error(rcs[i], "%s", errs[i]);
 	if (rc) return rc;
@@ -276,5 +296,6 @@ int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const 
 		for (int i = 0; i < n_local; ++i) { all->nBatches += R[i].run.nBatches; all->secAlign += i == i0 ? R[i].run.secAlign : 0; }
 		if (shard_db > 1 && n_ranks > 1 && !ordered) rc = bh_order_records(all->hits, all->nHits, Q->numEntries);
 	}
+	if (dbg) fprintf(stderr, "[bh_search_multi] rank %d of %d: align %.4f s, minima + filter %.4f s, hand-over %.4f s, order %.4f s\n", R[0].rank, n_ranks, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], omp_get_wtime() - tp[3]);
 	return rc;
 }

@@ -156,6 +156,19 @@ int  bh_search_multi(BhMultiRank *ranks, int n_local, int n_ranks, void *comm, c
  * ((entry, reference) pairs must be unique); element-wise minimum of n tables of len bytes into best[0] (NULL tables are skipped) */
 int  bh_order_records(BhipHit *hits, uint64_t n, uint64_t n_entries);
 void bh_minima_merge(uint8_t *const *best, int n, uint64_t len);
+/* ---- ranks of one node in different processes: the records meet in shared memory (bh_node.c) ---- */
+typedef struct BhNode BhNode;
+/* job: a name all ranks of the job share (and no other job on the machine); cap_records: what the rank expects to deliver per
+ * search (a search that brings up to four times as many still fits).  Every rank opens; rank 0 first or at the same time. */
+int  bh_node_open(const char *job, int rank, int n_ranks, uint64_t cap_records, BhNode **node);
+void bh_node_close(BhNode *node);
+void bh_node_attach(BhNode *node, BhRun *run);                        /* the rank's record buffer = its segment */
+int  bh_node_begin(BhNode *node);                                     /* a new search: rank 0 has read the previous one's records */
+int  bh_node_publish(BhNode *node, const BhRun *run, int status);     /* this rank's records of the search are complete */
+int  bh_node_collect(BhNode *node, BhRun *all, uint64_t *counts);     /* rank 0: everybody's records, rank order */
+/* bh_search_multi with the hand-over through `node` instead of the communicator's gather (one rank per process: n_local = 1;
+ * comm is then only needed for the minima of a database-sharded search) */
+int  bh_search_multi_ex(BhMultiRank *ranks, int n_local, int n_ranks, void *comm, BhNode *node, const BhQueries *q, BhMode mode, uint64_t batch_uniq, int shard_db, BhRun *all, uint64_t *counts);
 int  bh_device_open(const BhDb *db, int device, int z, void **hip_handle);
 /* build_K > 0 and a database without accelerator tables: the device builds the accelerator itself (no .acx file) */
 int  bh_device_open_ex(const BhDb *db, int device, int z, int build_K, void **hip_handle);

@@ -60,7 +60,8 @@ static void usage(void) {
 	puts("--forwardreverse (-fr), --whitespace (-w), --nwildcard (-y), --mode (-m) BEST|ALLPATHS|CAPITALIST|FORAGE|ANY");
 	puts("--makedb (-d) [name qLen], --id (-i) <decimal>, --threads (-t) <int>, --shear (-s) [len], --noprogress");
 	puts("--taxonomy (-b) <name>, --taxacut (-bc) <num>, --taxa_ncbi (-bn), --taxasuppress (-bs) [STRICT]: taxonomy column (interpolated in CAPITALIST)");
-	puts("--gpus <int> [--devices a,b,...] [--gather rccl|host]: shard the queries over the GPUs of this node (one RCCL gather of the records)");
+	puts("--gpus <int> [--devices a,b,...] [--gather host|rccl]: shard the queries over the GPUs of this node; every rank's records reach host");
+	puts("   memory over its own PCIe link and meet there (host, default) or are gathered over RCCL / xGMI to rank 0's device first (rccl)");
 	puts("--shard queries|db: with --gpus, cut the queries (database replicated; default) or the database (every rank holds a range of");
 	puts("                    clumps and aligns all queries; one all-reduce of the per-query minimum) -- for databases beyond one device");
 	puts("--shards <S>: database shards (implies --shard db; default = --gpus): the ranks form gpus / S replica groups of S shards, the queries cut over the groups");
@@ -75,7 +76,7 @@ int main(int argc, char **argv) {
 	int z = 1, do_rc = 0, incl_ws = 0, makedb = 0, do_shear = 0, do_accel = 0, dedupe = 0, device = 0, K = 0, skip_ambig = 0, threads = 0, rep_flags = 0;
 	long shear_amt = 500, db_qlen = 500;            /* burst.c:94 */
 	uint32_t latency = 16;                          /* burst.c:83 */
-	int n_gpus = 1, n_gpus_given = 0, gather_host = 0, n_dev_list = 0, dev_list[BH_MAX_GPUS], accel_dev = 0, host_acx = 0, shard_db = 0, n_shards = 0;
+	int n_gpus = 1, n_gpus_given = 0, gather_host = 1, n_dev_list = 0, dev_list[BH_MAX_GPUS], accel_dev = 0, host_acx = 0, shard_db = 0, n_shards = 0;
 	uint64_t batch = 1u << 21;      /* unique queries per device batch: the fixed cost of a batch (launches, synchronisation) is about 1 ms of device time */
 	const char *ref_FN = 0, *query_FN = 0, *output_FN = 0, *xcel_FN = 0, *mkacx_FN = 0, *tax_FN = 0;
 	BhTax taxonomy; memset(&taxonomy, 0, sizeof taxonomy);
@@ -265,9 +266,12 @@ int main(int argc, char **argv) {
 	/* Multi-GPU (--gpus N): one host thread and one device handle per GPU (bh_search_multi, bh_multi.c).  --shard queries (default):
 	 * the database replicated, unique queries [r U / N, (r+1) U / N) on rank r (a forward entry and its reverse complement stay
 	 * together); --shard db: every rank holds a range of the database's clumps and aligns all queries, the per-query minimum is
-	 * combined over the ranks (ncclAllReduce MIN).  Then ONE gather of the hit records to rank 0 over RCCL / xGMI
-	 * (bhip_comm_gather_hits: ncclAllGather of the counts + grouped ncclSend / ncclRecv), where the reference's consolidation
-	 * (incl. CAPITALIST's global vote) runs.  --gpus 1 takes the same path with one rank. */
+	 * combined over the ranks.  Then the records meet where the reference's consolidation (incl. CAPITALIST's global vote) runs,
+	 * in host memory.  The ranks are threads of this process and every rank's records are in host memory already when its last
+	 * batch ends (copied behind each batch over the rank's own PCIe link), so the default hand-over is a concatenation there
+	 * (--gather host).  --gather rccl takes them over RCCL / xGMI to rank 0's device first (bhip_comm_gather_hits: ncclAllGather of
+	 * the counts + grouped ncclSend / ncclRecv; minima by ncclAllReduce MIN) -- N shares through rank 0's one PCIe link: the path
+	 * for ranks that cannot see each other's memory.  --gpus 1 --gather rccl takes the RCCL path with one rank. */
 	if (n_gpus > BH_MAX_GPUS) { printf("ERROR: --gpus %d (max %d)\n", n_gpus, BH_MAX_GPUS); return 1; }
 	void *hhs[BH_MAX_GPUS]; int rcs[BH_MAX_GPUS]; char errs[BH_MAX_GPUS][512];
 	BhMultiRank ranks[BH_MAX_GPUS]; BhDb slices[BH_MAX_GPUS]; uint64_t ru0[BH_MAX_GPUS], ru1[BH_MAX_GPUS];

@@ -77,6 +77,15 @@ def lib():
         L.bh_align_ranges.argtypes = [C.c_void_p, C.POINTER(BhQueries), u64p, u64p, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(BhRun)]
         L.bh_align_ranges_reuse.argtypes = L.bh_align_ranges.argtypes
         L.bh_search_multi.argtypes = [C.POINTER(BhMultiRank), C.c_int, C.c_int, C.c_void_p, C.POINTER(BhQueries), C.c_int, C.c_uint64, C.c_int, C.POINTER(BhRun), u64p]
+        L.bh_search_multi_ex.argtypes = [C.POINTER(BhMultiRank), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(BhQueries), C.c_int, C.c_uint64, C.c_int, C.POINTER(BhRun), u64p]
+        L.bh_node_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]
+        L.bh_node_close.argtypes = [C.c_void_p]
+        L.bh_node_close.restype = None
+        L.bh_node_attach.argtypes = [C.c_void_p, C.POINTER(BhRun)]
+        L.bh_node_attach.restype = None
+        L.bh_node_begin.argtypes = [C.c_void_p]
+        L.bh_node_publish.argtypes = [C.c_void_p, C.POINTER(BhRun), C.c_int]
+        L.bh_node_collect.argtypes = [C.c_void_p, C.POINTER(BhRun), u64p]
         L.bh_clump_shard.argtypes = [C.POINTER(BhDb), C.c_int, C.c_int, u32p, u32p]
         L.bh_clump_shard.restype = None
         L.bh_run_reserve.argtypes = [C.POINTER(BhRun), C.c_uint64]
@@ -258,18 +267,34 @@ def align_ranges(dev, qs, ranges, mode, batch_uniq=1 << 18, run=None):
     return run
 
 
-class RankSearch:
-    """this process's rank of a node-wide job through the C host's multi-GPU search (bh_search_multi: align, [database-sharded:
-    per-query minimum over the ranks,] gather of the records to rank 0 over the library's RCCL communicator)"""
+class Node:
+    """the shared-memory hand-over of the records between the ranks of one node that live in different processes (bh_node.c):
+    every rank's record buffer is a segment rank 0 maps; no collective"""
 
-    def __init__(self, dev, rank, world, comm, c0=0):
+    def __init__(self, job, rank, world, cap_records):
+        self.h = C.c_void_p()
+        _chk(lib().bh_node_open(job.encode(), rank, world, int(cap_records), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().bh_node_close(self.h)
+            self.h = C.c_void_p()
+
+
+class RankSearch:
+    """this process's rank of a node-wide job through the C host's multi-GPU search (bh_search_multi_ex: align, [database-sharded:
+    per-query minimum over the ranks,] the records to rank 0 -- through the shared-memory segments of `node`, or gathered over the
+    library's RCCL communicator)"""
+
+    def __init__(self, dev, rank, world, comm, c0=0, node=None):
         self.mr = BhMultiRank()
         self.mr.rank, self.mr.hh, self.mr.c0 = rank, dev._h, c0
-        self.world, self.comm = world, comm
+        self.world, self.comm, self.node = world, comm, node
         self.all = Run()
 
     def reserve(self, cap_records):
-        _chk(lib().bh_run_reserve(C.byref(self.mr.run), int(cap_records)))
+        if self.node is None:      # (with a node the rank's buffer is its segment, sized at bh_node_open)
+            _chk(lib().bh_run_reserve(C.byref(self.mr.run), int(cap_records)))
 
     def search(self, qs, ranges, mode, batch_uniq, shard_db=False):
         """ranges: this rank's [(u0, u1), ...]; returns the gathered Run on rank 0 (its own elsewhere)"""
@@ -278,8 +303,8 @@ class RankSearch:
         self.mr.r0, self.mr.r1, self.mr.n_ranges = r0.ctypes.data_as(u64p), r1.ctypes.data_as(u64p), len(ranges)
         self._keep = (r0, r1)
         self.counts = np.zeros(self.world, np.uint64)
-        _chk(lib().bh_search_multi(C.byref(self.mr), 1, self.world, self.comm, C.byref(qs.c), MODES[mode], batch_uniq, int(bool(shard_db)), C.byref(self.all.c),
-                                   self.counts.ctypes.data_as(u64p)))
+        _chk(lib().bh_search_multi_ex(C.byref(self.mr), 1, self.world, self.comm, self.node.h if self.node is not None else None, C.byref(qs.c), MODES[mode], batch_uniq,
+                                      int(bool(shard_db)), C.byref(self.all.c), self.counts.ctypes.data_as(u64p)))
         return self.all
 
     def own_stats(self):
@@ -288,6 +313,8 @@ class RankSearch:
     def close(self):
         lib().bh_run_free(C.byref(self.mr.run))
         self.all.close()
+        if self.node is not None:
+            self.node.close()
 
 
 libc = C.CDLL(None)

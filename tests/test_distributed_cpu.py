@@ -219,3 +219,77 @@ def test_minima_merge_is_the_elementwise_minimum():
         ptrs = (C.c_void_p * 5)(tabs[0].ctypes.data, tabs[1].ctypes.data, None, tabs[3].ctypes.data, tabs[4].ctypes.data)      # a NULL table is skipped
         L.bh_minima_merge(ptrs, 5, n)
         assert np.array_equal(tabs[0], want)
+
+
+NODE_WORKER = r'''
+import ctypes as C, os, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from burst_amd import capi, host
+job, rank, world, cap, mode = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+L = host.lib()
+node = host.Node(job, rank, world, cap)
+run, allr = host.BhRun(), host.BhRun()
+def records(r, call, n):
+    h = np.zeros(n, dtype=capi.HIT_DTYPE)
+    h["q"] = np.arange(n, dtype=np.uint32) + 1000003 * r; h["refIx"] = call; h["finalPos"] = r; h["score"] = np.float32(0.5) * call
+    return h
+def count(r, call):
+    return [0, 17, cap, 3 * cap + 5, 1, cap // 2][call % 6] + r      # empty, small, full, beyond the allocated part (private buffer), ...
+for call in range(1, 8):
+    host._chk(L.bh_node_begin(node.h))
+    L.bh_node_attach(node.h, C.byref(run))
+    n = count(rank, call)
+    keep = None
+    if n > run.capHits:                     # what bh_align_ranges does when a search outgrows the buffer: a private, larger one
+        keep = records(rank, call, n); run.hits = keep.ctypes.data; run.capHits = n; run.hitsPinned = 2
+    else:
+        src = records(rank, call, n); C.memmove(run.hits, src.ctypes.data, n * 20)
+    run.nHits = n
+    status = 7 if (mode == "fail" and rank == 1 and call == 3) else 0
+    if mode == "late" and rank == 1 and call == 2:
+        time.sleep(1.0)
+    if mode == "dead" and rank == 1 and call == 2:
+        sys.exit(0)                         # never publishes
+    host._chk(L.bh_node_publish(node.h, C.byref(run), status))
+    if keep is not None:
+        run.hits = None; run.capHits = 0; run.hitsPinned = 0
+    if rank == 0:
+        counts = np.zeros(world, np.uint64)
+        rc = L.bh_node_collect(node.h, C.byref(allr), counts.ctypes.data_as(host.u64p))
+        if mode == "fail" and call == 3:
+            assert rc != 0 and b"rank 1 failed" in L.bh_last_error(), L.bh_last_error()
+            continue
+        if mode == "dead" and call == 2:
+            assert rc != 0 and b"rank 1 did not deliver" in L.bh_last_error(), L.bh_last_error()
+            print("NODE_OK"); sys.exit(0)
+        assert rc == 0, L.bh_last_error()
+        want = np.concatenate([records(r, call, count(r, call)) for r in range(world)])
+        assert [int(c) for c in counts] == [count(r, call) for r in range(world)]
+        got = np.frombuffer((C.c_uint8 * (int(allr.nHits) * 20)).from_address(allr.hits), dtype=capi.HIT_DTYPE) if allr.nHits else np.zeros(0, capi.HIT_DTYPE)
+        assert got.tobytes() == want.tobytes(), (call, len(got), len(want))
+run.hits = None
+node.close()
+print("NODE_OK")
+'''
+
+
+@pytest.mark.parametrize("mode,world", [("plain", 3), ("late", 2), ("fail", 2), ("dead", 2)])
+def test_node_exchange_between_processes(mode, world, tmp_path):
+    """bh_node.c, the hand-over of the records between the processes of one node (bench.py --gpus N, one process per GPU): every
+    rank's records lie in its shared-memory segment, rank 0 concatenates them in rank order.  Seven searches in a row with empty,
+    small, full and outgrown buffers; a rank that is late; a rank that fails (rank 0 says which); a rank that dies (rank 0 gives
+    up after BURST_NODE_TIMEOUT instead of waiting for ever); no segment is left in /dev/shm"""
+    job = "t%d%s" % (os.getpid(), mode)
+    env = dict(os.environ, BURST_NODE_TIMEOUT="3" if mode == "dead" else "60")
+    ps = [subprocess.Popen([sys.executable, "-c", NODE_WORKER, gl.ROOT, job, str(r), str(world), "5000", mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+          for r in range(world)]
+    outs = [p.communicate(timeout=120) for p in ps]
+    assert "NODE_OK" in outs[0][0], outs[0]
+    for r, p in enumerate(ps):
+        assert p.returncode == 0, outs[r]
+    left = [f for f in os.listdir("/dev/shm") if job in f]
+    if mode != "dead":      # (the rank that died could not unlink its segment: the next job of that name does)
+        assert not left, left
+    for f in left:
+        os.unlink(os.path.join("/dev/shm", f))

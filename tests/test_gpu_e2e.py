@@ -180,8 +180,8 @@ def test_reference_host_with_device_binding(c, tmp_path_factory):
     assert sorted(open(out, "rb").read().splitlines()) == gl.golden_lines(c)
 
 
-@pytest.mark.parametrize("name,flags,expect", [("dna_q100_best_fr", ["--gpus", "1"], "RCCL gather: 1 rank(s)"),
-                                               ("dna_q100_allpaths_fr", ["--gpus", "1", "--batch", "29"], "RCCL gather: 1 rank(s)"),
+@pytest.mark.parametrize("name,flags,expect", [("dna_q100_best_fr", ["--gpus", "1", "--gather", "rccl"], "RCCL gather: 1 rank(s)"),
+                                               ("dna_q100_allpaths_fr", ["--gpus", "1", "--batch", "29", "--gather", "rccl"], "RCCL gather: 1 rank(s)"),
                                                ("dna_q100_allpaths_fr", ["--gpus", "3", "--devices", "0,0,0", "--gather", "host"], "host gather: 3 rank(s)"),
                                                ("dna_q100_capitalist_noacx_t1_fr", ["--gpus", "2", "--devices", "0,0", "--gather", "host"], "host gather: 2 rank(s)"),
                                                ("dna_q100_allpaths_fr", ["--gpus", "3", "--devices", "0,0,0", "--gather", "host", "--shard", "db"], "host gather: 3 rank(s), database-sharded"),
@@ -191,7 +191,7 @@ def test_reference_host_with_device_binding(c, tmp_path_factory):
                                                ("quick_q100_capitalist_noacx_t1", ["--gpus", "2", "--devices", "0,0", "--gather", "host", "--shard", "db"], "host gather: 2 rank(s), database-sharded"),
                                                ("dna_q100_allpaths_fr", ["--gpus", "4", "--devices", "0,0,0,0", "--gather", "host", "--shards", "2"], "host gather: 4 rank(s), database-sharded"),
                                                ("dna_q100_capitalist_fr", ["--gpus", "6", "--devices", "0,0,0,0,0,0", "--gather", "host", "--shards", "3", "-ad", "--batch", "53"], "host gather: 6 rank(s), database-sharded"),
-                                               ("dna_q100_allpaths_fr", ["--gpus", "1", "--shard", "db"], "RCCL gather: 1 rank(s)")])
+                                               ("dna_q100_allpaths_fr", ["--gpus", "1", "--shard", "db", "--gather", "rccl"], "RCCL gather: 1 rank(s)")])
 def test_cli_multi_gpu_paths(name, flags, expect, tmp_path):
     """burst_hip --gpus N: one host thread + one device handle per rank, the unique queries sharded, the records gathered to
     rank 0 (ncclAllGather of the counts + grouped ncclSend / ncclRecv in libburst_hip; `--gather host` when the ranks share a
@@ -212,7 +212,7 @@ def test_cli_multi_gpu_paths(name, flags, expect, tmp_path):
     if "--shard" in flags or "--shards" in flags:
         # the record set and its order are those of one device holding the whole database: the .b6 must be the single-device run's,
         # byte for byte in the same order (also in the modes whose golden depends on the reference's thread timing)
-        single = [x for x in cmd if x not in ("--shard", "db", "--gather", "host")]
+        single = [x for x in cmd if x not in ("--shard", "db", "--gather", "host", "rccl")]
         for opt in ("--gpus", "--devices", "--batch", "--shards"):
             if opt in single:
                 k = single.index(opt)
@@ -301,20 +301,30 @@ def test_device_query_sort_equals_host_sort(tmp_path, monkeypatch, capfd):
 
 
 def test_bench_multi_rank_path_with_one_process(tmp_path):
-    """bench.py's N > 1 code path on the one GPU of the test box (BURST_BENCH_DIST1=1 under torch.distributed.run with one process):
-    the library's RCCL communicator made from a broadcast id (bhip_comm_unique_id / bhip_comm_create_rank) and bh_search_multi --
-    align + bhip_comm_gather_hits inside the timed region -- on a small database; the JSON line must carry the same record count as
-    the plain single-process run of the same job"""
+    """bench.py's N > 1 code paths on the one GPU of the test box, on a small database; each JSON line must carry the same record
+    count as the plain single-process run of the same job:
+    * --gather rccl with one process (BURST_BENCH_DIST1=1 under torch.distributed.run): the library's RCCL communicator made from a
+      broadcast id (bhip_comm_unique_id / bhip_comm_create_rank) and bh_search_multi -- align + bhip_comm_gather_hits in the timed region;
+    * the default hand-over with the driver's own command line for N = 2 (two processes, BURST_BENCH_DEVICE=0 puts both ranks on the
+      one device): every rank's records in its shared-memory segment, rank 0 maps and concatenates (bh_node.c), no collective"""
     import json
     import sys
     bench = os.path.join(gl.ROOT, "bench.py")
-    common = ["--n-base", "20000", "--reads", "100000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--workdir", str(tmp_path / "w")]
+    common = ["--n-base", "20000", "--reads", "100000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end", "--workdir", str(tmp_path / "w")]
     r1 = subprocess.run([sys.executable, bench] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r1.returncode == 0, r1.stderr[-3000:]
     a = json.loads(r1.stdout.strip().splitlines()[-1])
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29611", bench, "--gpus", "1"] + common,
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--master-addr", "127.0.0.1"]
+    r2 = subprocess.run(launch + ["--nproc-per-node", "1", "--master-port", "29611", bench, "--gpus", "1", "--gather", "rccl"] + common,
                         env=dict(os.environ, BURST_BENCH_DIST1="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r2.returncode == 0, r2.stderr[-3000:]
     b = json.loads([ln for ln in r2.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert a["work"]["records"] == b["work"]["records"] > 250000
     assert "RCCL gather" in b["config"]["parallelism"] and b["n_gpus"] == 1
+    r3 = subprocess.run(launch + ["--nproc-per-node", "2", "--master-port", "29612", bench, "--gpus", "2"] + common,
+                        env=dict(os.environ, BURST_BENCH_DEVICE="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r3.returncode == 0, r3.stderr[-3000:]
+    c = json.loads([ln for ln in r3.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert c["work"]["records"] == a["work"]["records"]
+    assert "shared-memory" in c["config"]["parallelism"] and c["n_gpus"] == 2 and c["scaling"] == "strong"
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("burst_hip.bench")]

@@ -20,7 +20,7 @@ run() {   # name, flags...
   echo "## burst_hip -r $(basename $EDX) -ad -k 15 -q <$N reads> -m BEST -i 0.98 $*"
   BURST_HOST_DEBUG=1 timeout 600 $R/burst_amd/burst_hip -r $EDX -ad -k 15 -q $READS -o $D/mr_$name.b6 -m BEST -i 0.98 "$@" > $D/mr_$name.log 2>&1
   local rc=$?
-  grep -E "^Rank|gather:|Search complete|search \(all|device database upload|Alignment time|Wrote" $D/mr_$name.log
+  grep -E "^Rank|gather:|bh_search_multi|Search complete|search \(all|device database upload|Alignment time|Wrote" $D/mr_$name.log
   if [ $rc -ne 0 ]; then echo "exit code $rc; last lines:"; tail -5 $D/mr_$name.log; fi
   echo
 }
