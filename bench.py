@@ -362,6 +362,8 @@ def main():
                 node = host.Node(job, rank, world, cap_rec)
         rs = host.RankSearch(dev, rank, world, comm, node=node)
         rs.reserve(cap_rec)
+        if rank == 0:      # the buffer all ranks' records meet in: made (and touched) here, as burst_hip does in its "batch buffers" phase
+            rs.reserve_all(world * cap_rec, pinned=args.gather == "rccl")
     else:
         _own.reserve(cap_rec)
     # (bhip_reserve = the command line's "batch buffers" phase: device buffers for this batch size + the library's own warm-up pass)

@@ -189,7 +189,8 @@ int bh_node_collect(BhNode *N, BhRun *all, uint64_t *counts) {
 		const uint64_t piece = (4u << 20) / sizeof(BhipHit);
 		uint64_t n_pieces = 0, first[BH_MAX_RANKS + 1]; first[0] = 0;
 		for (int r = 0; r < N->n_ranks; ++r) { n_pieces += (N->peer[r]->n_hits + piece - 1) / piece; first[r + 1] = n_pieces; }
-		#pragma omp parallel for schedule(static)
+		const int nt = omp_get_max_threads() > 16 ? 16 : omp_get_max_threads();      /* memory-bound: more threads do not copy faster */
+		#pragma omp parallel for schedule(static) num_threads(nt)
 		for (uint64_t p = 0; p < n_pieces; ++p) {
 			int r = 0;
 			while (p >= first[r + 1]) ++r;

@@ -370,12 +370,13 @@ int main(int argc, char **argv) {
 		printf("; align phase per rank [s]:");
 		for (int r = 0; r < n_gpus; ++r) printf(" %.4f", ranks[r].secSearch);
 		printf("\n");
-		for (int r = 0; r < n_gpus; ++r) { run.total.n_pairs += ranks[r].run.total.n_pairs; bh_run_free(&ranks[r].run); }
+		for (int r = 0; r < n_gpus; ++r) run.total.n_pairs += ranks[r].run.total.n_pairs;
 	}
 	const double t1 = wall();
 	printf("Search complete [%f s, %u batches, %lu candidate (query, clump) pairs, %lu hits]. Consolidating results...\n", t1 - t0, run.nBatches,
 	       (unsigned long)run.total.n_pairs, (unsigned long)run.nHits);
 	PHASE("search (all batches)");
+	if (n_gpus > 1 || use_rccl) for (int r = 0; r < n_gpus; ++r) bh_run_free(&ranks[r].run);      /* (unpinning a rank's buffer takes ~10 ms: not on the search's clock) */
 	uint64_t lines = 0;
 	setvbuf(output, NULL, _IOFBF, 1 << 22);
 	if ((rc = bh_report_tax(output, &db, &Q, run.hits, run.nHits, mode, (do_accel ? 0 : BH_REP_MERGED_LIST) | rep_flags, tax_FN ? &txo : NULL, &lines))) DIE(rc);

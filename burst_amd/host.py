@@ -89,6 +89,7 @@ def lib():
         L.bh_clump_shard.argtypes = [C.POINTER(BhDb), C.c_int, C.c_int, u32p, u32p]
         L.bh_clump_shard.restype = None
         L.bh_run_reserve.argtypes = [C.POINTER(BhRun), C.c_uint64]
+        L.bh_run_reserve_plain.argtypes = [C.POINTER(BhRun), C.c_uint64]
         L.bh_run_free.argtypes = [C.POINTER(BhRun)]
         L.bh_report_ex.argtypes = [C.c_void_p, C.POINTER(BhDb), C.POINTER(BhQueries), C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         L.bh_synth_refs.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint64]
@@ -295,6 +296,10 @@ class RankSearch:
     def reserve(self, cap_records):
         if self.node is None:      # (with a node the rank's buffer is its segment, sized at bh_node_open)
             _chk(lib().bh_run_reserve(C.byref(self.mr.run), int(cap_records)))
+
+    def reserve_all(self, cap_records, pinned=False):
+        """rank 0: room for everybody's records (page-locked when a device copy lands in it: the RCCL gather)"""
+        _chk((lib().bh_run_reserve if pinned else lib().bh_run_reserve_plain)(C.byref(self.all.c), int(cap_records)))
 
     def search(self, qs, ranges, mode, batch_uniq, shard_db=False):
         """ranges: this rank's [(u0, u1), ...]; returns the gathered Run on rank 0 (its own elsewhere)"""
