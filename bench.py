@@ -487,7 +487,7 @@ def main():
                                       args.n_base * args.n_variants * args.ref_len / 1e9, db.c.numRclumps, edx_bytes / 1e9, args.K, acx_bytes / 1e9),
                        "parallelism": ("query-sharded x%d (rank r aligns the r-th N-th of the job's unique queries in device batches of up to %d), DB replicated; " % (world, batch_uniq)) +
                                       ("no collective on the data path: every rank's record buffer is a page-locked shared-memory segment (its batches' records land there over its own PCIe link, behind the "
-                                       "batch), rank 0 maps the segments and concatenates (bh_node.c inside bh_search_multi_ex)" if use_dist and args.gather == "shm" else
+                                       "batch), rank 0 has the segments mapped side by side and reads the records where they lie (bh_node.c inside bh_search_multi_ex; bh_report_view consumes such a view) -- no copy" if use_dist and args.gather == "shm" else
                                        "one RCCL gather of the hit records to rank 0 (bhip_comm_gather_hits inside bh_search_multi, the function burst_hip --gpus N --gather rccl runs)"),
                        "timed_region": "bh_align_ranges over %d batches (copies + device routing two batches ahead, seed lookups + profiles one batch ahead, alignment, records to host memory)%s" %
                                        (nb, (" + hand-over of all ranks' records to rank 0 (shared memory)" if args.gather == "shm" else " + RCCL gather") if use_dist else ""),
@@ -542,6 +542,11 @@ def main():
                 res["parity_vs_reference"] = parity_vs_reference(dev, db, args, batch_uniq)
             except Exception as e:      # reported, never fatal for the measurement
                 res["parity_vs_reference"] = {"error": str(e)}
+        if use_dist:      # what rank 0 holds after the timed search, read once through (outside the timed region): every rank's run, its records
+            runs = rs.view.runs()
+            res["handover"] = {"kind": "view over the ranks' shared-memory segments" if (node is not None and rs.view.n_runs == world and world > 1) else "one array",
+                               "records_per_run": [int(len(x)) for x in runs], "entries_ascend_within_runs": bool(all(len(x) < 2 or int(x["q"][-1]) >= int(x["q"][0]) for x in runs)),
+                               "xor_of_reference_numbers": int(np.bitwise_xor.reduce(np.concatenate([x["refIx"] for x in runs]))) if sum(len(x) for x in runs) else 0}
         print(json.dumps(res), flush=True)
     if rs is not None:
         rs.close()

@@ -166,9 +166,10 @@ void bh_minima_merge(uint8_t *const *best, int n, uint64_t len) {
 }
 
 int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const BhQueries *Q, BhMode mode, uint64_t batch, int shard_db, BhRun *all, uint64_t *counts) {
-	return bh_search_multi_ex(R, n_local, n_ranks, comm, NULL, Q, mode, batch, shard_db, all, counts);
+	return bh_search_multi_ex(R, n_local, n_ranks, comm, NULL, Q, mode, batch, shard_db, all, counts, NULL);
 }
-int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhNode *node, const BhQueries *Q, BhMode mode, uint64_t batch, int shard_db, BhRun *all, uint64_t *counts) {
+int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhNode *node, const BhQueries *Q, BhMode mode, uint64_t batch, int shard_db, BhRun *all, uint64_t *counts,
+                       BhRunView *view) {
 	/* shard_db = number of database shards S (0 / 1: none).  S < n_ranks: the ranks form n_ranks / S replica groups of S shards each
 	 * (rank = group * S + shard); the caller gives every rank its group's query ranges and its shard's first clump.  The minima
 	 * are combined over ALL ranks at once: the groups' queries are disjoint and a rank says 255 ("none") for queries that are not
@@ -242,13 +243,18 @@ int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhN
 	for (int i = 0; i < n_local; ++i) if (R[i].rank == 0) i0 = i;
 	uint64_t tot_local = 0;
 	for (int i = 0; i < n_local; ++i) tot_local += rcs[i] ? 0 : R[i].run.nHits;
-	int rc = BH_OK, ordered = 0;
+	int rc = BH_OK, ordered = 0, viewed = 0;
 	if (node) {
 		/* one rank per process, the records already lie in this rank's shared-memory segment: say so; rank 0 takes everybody's */
 		const int p = bh_node_publish(node, &R[0].run, rcs[0]);
 		if (p && !rcs[0]) { rcs[0] = p; snprintf(errs[0], sizeof errs[0], "%s", bh_last_error()); }
 		if (i0 >= 0) {
-			const int c = bh_node_collect(node, all, counts);
+			/* query-sharded and the caller takes a view: the records stay where they are (rank 0 has every rank's segment mapped side
+			 * by side) -- the hand-over is the word per rank.  Otherwise (database-sharded: they have to be put in order anyway; a
+			 * search that outgrew its segment; no view wanted) one concatenation into `all`. */
+			int c = BH_E_CAPACITY;
+			if (view && !(shard_db > 1 && n_ranks > 1)) { c = bh_node_collect_view(node, view, counts); if (!c) { viewed = 1; all->nHits = view->total; } }
+			if (c == BH_E_CAPACITY) c = bh_node_collect(node, all, counts);
 			if (c && !rcs[0]) { rcs[0] = c; snprintf(errs[0], sizeof errs[0], "%s", bh_last_error()); }
 		}
 	} else if (comm) {
@@ -301,6 +307,7 @@ int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhN
 		for (int i = 0; i < n_local; ++i) { all->nBatches += R[i].run.nBatches; all->secAlign += i == i0 ? R[i].run.secAlign : 0; }
 		if (shard_db > 1 && n_ranks > 1 && !ordered) rc = bh_order_records(all->hits, all->nHits, Q->numEntries);
 	}
+	if (view && !viewed && !rc) { view->base = all->hits; view->n_runs = 1; view->off[0] = 0; view->n[0] = all->nHits; view->total = all->nHits; }
 	if (dbg) fprintf(stderr, "[bh_search_multi] rank %d of %d: align %.4f s, minima + filter %.4f s, hand-over %.4f s, order %.4f s\n", R[0].rank, n_ranks, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], omp_get_wtime() - tp[3]);
 	return rc;
 }

@@ -47,6 +47,8 @@ struct BhNode {
 	NodeHdr *own; size_t own_bytes;
 	NodeHdr *peer[BH_MAX_RANKS]; size_t peer_bytes[BH_MAX_RANKS];      /* rank 0: everybody's segment; others: [0] = rank 0's */
 	uint64_t seq;                             /* calls begun */
+	char *view; size_t stride;                /* rank 0: one address range, slot r = the allocated records of rank r's segment */
+	uint8_t in_view[BH_MAX_RANKS]; int lent;  /* lent: the last hand-over gave out a view; it ends when rank 0 begins its next search */
 	double timeout;
 };
 
@@ -64,6 +66,20 @@ static int wait_for(const uint64_t *word, uint64_t want, double timeout) {
 	}
 }
 
+/* rank 0: the allocated records of rank r's segment (file offset NODE_HDR) at slot r of the view, read-only, populated now */
+#ifndef MADV_POPULATE_READ
+#define MADV_POPULATE_READ 22
+#endif
+static void view_slot(BhNode *N, int r, int fd, uint64_t cap) {
+	if (!N->view || N->in_view[r]) return;
+	const size_t len = ((size_t)cap * sizeof(BhipHit) + 4095) & ~(size_t)4095;
+	if (len > N->stride) return;                                        /* a rank with a larger segment than rank 0's: it is copied */
+	void *p = mmap(N->view + (size_t)r * N->stride, len, PROT_READ, MAP_SHARED | MAP_FIXED, fd, NODE_HDR);
+	if (p == MAP_FAILED) return;
+	if (madvise(p, len, MADV_POPULATE_READ)) { volatile const char *c = p; char sink = 0; for (size_t o = 0; o < len; o += 4096) sink ^= c[o]; (void)sink; }
+	N->in_view[r] = 1;
+}
+
 static NodeHdr *map_peer(BhNode *N, int rank, size_t *bytes) {
 	char nm[160];
 	seg_name(N, rank, nm, sizeof nm);
@@ -74,23 +90,16 @@ static NodeHdr *map_peer(BhNode *N, int rank, size_t *bytes) {
 			struct stat sb;
 			if (!fstat(fd, &sb) && (size_t)sb.st_size >= NODE_HDR) {
 				NodeHdr *h = mmap(NULL, (size_t)sb.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-				close(fd);
-				if (h == MAP_FAILED) return NULL;
+				if (h == MAP_FAILED) { close(fd); return NULL; }
 				if (!wait_for(&h->magic, NODE_MAGIC, N->timeout) && h->magic == NODE_MAGIC) {
-					/* the allocated part into THIS process's page tables now (set-up), not page by page inside the first large
-					 * hand-over: 0.4 GB of a peer's records = 100 000 minor faults = more time than copying them.  (Not the
-					 * unallocated tail: touching a hole of a tmpfs file allocates it.) */
-					const size_t locked = NODE_HDR + (size_t)h->cap * sizeof(BhipHit);
-					#ifndef MADV_POPULATE_READ
-					#define MADV_POPULATE_READ 22
-					#endif
-					if (madvise(h, locked, MADV_POPULATE_READ)) {
-						volatile const char *c = (volatile const char *)h; char sink = 0;
-						for (size_t o = 0; o < locked; o += 4096) sink ^= c[o];
-						(void)sink;
-					}
+					/* into THIS process's page tables now (set-up), not page by page inside the first large hand-over: 0.4 GB of a
+					 * peer's records = 100 000 minor faults = more time than copying them.  (Only the allocated part: touching a
+					 * hole of a tmpfs file allocates it.) */
+					if (N->rank == 0) view_slot(N, rank, fd, h->cap);
+					close(fd);
 					*bytes = (size_t)sb.st_size; return h;
 				}
+				close(fd);
 				munmap(h, (size_t)sb.st_size);
 				return NULL;
 			}
@@ -125,7 +134,13 @@ int bh_node_open(const char *job, int rank, int n_ranks, uint64_t cap_records, B
 	/* page-locked: the asynchronous device copies of the records land here (without a device -- tests -- it stays pageable) */
 	N->locked = bhip_host_register(seg_records(h), (uint64_t)cap_records * sizeof(BhipHit)) == 0;
 	__atomic_store_n(&h->magic, NODE_MAGIC, __ATOMIC_RELEASE);
-	if (rank == 0) { N->peer[0] = h; N->peer_bytes[0] = bytes; }
+	if (rank == 0) {
+		N->peer[0] = h; N->peer_bytes[0] = bytes;
+		/* one address range over everybody's records: slots of a stride that is a multiple of the page and of the record size */
+		N->stride = (((size_t)cap_records * sizeof(BhipHit) + 20479) / 20480) * 20480;
+		void *v = mmap(NULL, N->stride * (size_t)n_ranks, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+		if (v != MAP_FAILED) { N->view = v; view_slot(N, 0, fd, cap_records); }
+	}
 	else if (!(N->peer[0] = map_peer(N, 0, &N->peer_bytes[0]))) { bh_node_close(N); return bh_set_error(BH_E_IO, "rank 0's shared-memory segment did not appear (job %s)", job); }
 	*out = N;
 	return BH_OK;
@@ -134,6 +149,7 @@ int bh_node_open(const char *job, int rank, int n_ranks, uint64_t cap_records, B
 void bh_node_close(BhNode *N) {
 	if (!N) return;
 	for (int r = 0; r < N->n_ranks; ++r) if (N->peer[r] && N->peer[r] != N->own) munmap(N->peer[r], N->peer_bytes[r]);
+	if (N->view) munmap(N->view, N->stride * (size_t)N->n_ranks);
 	if (N->own) {
 		if (N->locked) (void)bhip_host_unregister(seg_records(N->own));
 		munmap(N->own, N->own_bytes);
@@ -157,6 +173,7 @@ void bh_node_attach(BhNode *N, BhRun *run) {
 /* before a rank writes records of a new call into its segment: rank 0 must have read the previous call's */
 int bh_node_begin(BhNode *N) {
 	const uint64_t s = ++N->seq;
+	if (N->lent) { N->lent = 0; __atomic_store_n(&N->own->consumed, s - 1, __ATOMIC_RELEASE); }      /* rank 0 is done with the view it was given */
 	if (s > 1 && wait_for(&N->peer[0]->consumed, s - 1, N->timeout)) return bh_set_error(BH_E_INTERNAL, "rank 0 has not taken the records of call %lu (job %s)", (unsigned long)(s - 1), N->job);
 	return BH_OK;
 }
@@ -179,32 +196,41 @@ int bh_node_publish(BhNode *N, const BhRun *run, int status) {
 	return status == BH_E_OOM && !n && run->nHits ? bh_set_error(BH_E_OOM, "%lu records do not fit the shared-memory segment (%lu allocated)", (unsigned long)run->nHits, (unsigned long)h->cap) : BH_OK;
 }
 
-/* rank 0: every rank's records of the current call, in rank order, into `all` (page-locked or not: no device writes to it);
- * counts[n_ranks] optional.  A rank that failed or does not answer makes the call fail -- nobody waits for ever. */
-int bh_node_collect(BhNode *N, BhRun *all, uint64_t *counts) {
+/* rank 0: wait until every rank has delivered the current call; at[r] = records of the ranks before r */
+static int wait_all(BhNode *N, uint64_t *at, uint64_t *counts) {
 	if (N->rank != 0) return bh_set_error(BH_E_USAGE, "only rank 0 collects");
-	int rc = BH_OK;
-	uint64_t at[BH_MAX_RANKS + 1]; at[0] = 0;
-	for (int r = 0; r < N->n_ranks && !rc; ++r) {
+	at[0] = 0;
+	for (int r = 0; r < N->n_ranks; ++r) {
 		if (!N->peer[r]) {
-			if (!(N->peer[r] = map_peer(N, r, &N->peer_bytes[r]))) { rc = bh_set_error(BH_E_IO, "rank %d's shared-memory segment did not appear (job %s)", r, N->job); break; }
+			if (!(N->peer[r] = map_peer(N, r, &N->peer_bytes[r]))) return bh_set_error(BH_E_IO, "rank %d's shared-memory segment did not appear (job %s)", r, N->job);
 			/* mapped: the name has done its work (a job that dies later leaves nothing of this rank in /dev/shm) */
 			char nm[160]; seg_name(N, r, nm, sizeof nm); (void)shm_unlink(nm);
 		}
-		if (wait_for(&N->peer[r]->published, N->seq, N->timeout)) { rc = bh_set_error(BH_E_INTERNAL, "rank %d did not deliver the records of call %lu within %.0f s", r, (unsigned long)N->seq, N->timeout); break; }
-		if (N->peer[r]->status) { rc = bh_set_error(BH_E_DEVICE, "rank %d failed in its search (code %ld)", r, (long)N->peer[r]->status); break; }
-		if (N->peer[r]->n_hits > N->peer[r]->virt) { rc = bh_set_error(BH_E_INTERNAL, "rank %d announces %lu records in a segment of %lu", r, (unsigned long)N->peer[r]->n_hits, (unsigned long)N->peer[r]->virt); break; }
+		if (wait_for(&N->peer[r]->published, N->seq, N->timeout)) return bh_set_error(BH_E_INTERNAL, "rank %d did not deliver the records of call %lu within %.0f s", r, (unsigned long)N->seq, N->timeout);
+		if (N->peer[r]->status) return bh_set_error(BH_E_DEVICE, "rank %d failed in its search (code %ld)", r, (long)N->peer[r]->status);
+		if (N->peer[r]->n_hits > N->peer[r]->virt) return bh_set_error(BH_E_INTERNAL, "rank %d announces %lu records in a segment of %lu", r, (unsigned long)N->peer[r]->n_hits, (unsigned long)N->peer[r]->virt);
 		at[r + 1] = at[r] + N->peer[r]->n_hits;
 		if (counts) counts[r] = N->peer[r]->n_hits;
 	}
+	return BH_OK;
+}
+
+/* rank 0: every rank's records of the current call, in rank order, into `all` (page-locked or not: no device writes to it);
+ * counts[n_ranks] optional.  A rank that failed or does not answer makes the call fail -- nobody waits for ever. */
+int bh_node_collect(BhNode *N, BhRun *all, uint64_t *counts) {
+	uint64_t at[BH_MAX_RANKS + 1];
+	int rc = wait_all(N, at, counts);
+	if (rc == BH_E_USAGE) return rc;
 	if (!rc && bh_run_reserve_plain(all, at[N->n_ranks] + 1)) rc = BH_E_OOM;
 	if (!rc) {
-		/* pieces of 4 MB over a team: the concatenation of 0.8 GB (40 M reads, BEST) is memory-bound, one thread copies ~10 GB/s */
-		const uint64_t piece = (4u << 20) / sizeof(BhipHit);
+		/* one piece per thread where that is >= 4 MB (0.8 GB for 40 M reads: memory-bound; long copies take the C library's
+		 * streaming stores and spare the read of the destination) */
+		const int nt = omp_get_max_threads() > 16 ? 16 : omp_get_max_threads();
+		uint64_t piece = (at[N->n_ranks] + (uint64_t)nt - 1) / (uint64_t)nt;
+		if (piece < (4u << 20) / sizeof(BhipHit)) piece = (4u << 20) / sizeof(BhipHit);
 		uint64_t n_pieces = 0, first[BH_MAX_RANKS + 1]; first[0] = 0;
 		for (int r = 0; r < N->n_ranks; ++r) { n_pieces += (N->peer[r]->n_hits + piece - 1) / piece; first[r + 1] = n_pieces; }
-		const int nt = omp_get_max_threads() > 16 ? 16 : omp_get_max_threads();      /* memory-bound: more threads do not copy faster */
-		#pragma omp parallel for schedule(static) num_threads(nt)
+		#pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
 		for (uint64_t p = 0; p < n_pieces; ++p) {
 			int r = 0;
 			while (p >= first[r + 1]) ++r;
@@ -214,6 +240,22 @@ int bh_node_collect(BhNode *N, BhRun *all, uint64_t *counts) {
 		all->nHits = at[N->n_ranks];
 	}
 	/* read or given up: the ranks may overwrite their segments */
+	N->lent = 0;
 	__atomic_store_n(&N->own->consumed, N->seq, __ATOMIC_RELEASE);
 	return rc;
+}
+
+/* rank 0, without a copy: the records where they lie, as runs of one address range (v->base + v->off[r], v->n[r] records, rank
+ * order).  The ranks' segments stay untouched until rank 0 begins its next search (bh_node_begin) or collects.  Returns
+ * BH_E_CAPACITY -- nothing consumed, call bh_node_collect -- when a rank's records do not lie inside its slot (a search that
+ * outgrew its segment, or a rank with a segment of another size). */
+int bh_node_collect_view(BhNode *N, BhRunView *v, uint64_t *counts) {
+	uint64_t at[BH_MAX_RANKS + 1];
+	int rc = wait_all(N, at, counts);
+	if (rc) { if (rc != BH_E_USAGE) { N->lent = 0; __atomic_store_n(&N->own->consumed, N->seq, __ATOMIC_RELEASE); } return rc; }
+	for (int r = 0; r < N->n_ranks; ++r) if (!N->view || !N->in_view[r] || N->peer[r]->n_hits > N->peer[r]->cap || N->peer[r]->cap * sizeof(BhipHit) > N->stride) return BH_E_CAPACITY;
+	v->base = (const BhipHit *)N->view; v->n_runs = N->n_ranks; v->total = at[N->n_ranks];
+	for (int r = 0; r < N->n_ranks; ++r) { v->off[r] = (uint64_t)r * (N->stride / sizeof(BhipHit)); v->n[r] = N->peer[r]->n_hits; }
+	N->lent = 1;
+	return BH_OK;
 }

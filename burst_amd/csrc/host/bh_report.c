@@ -127,6 +127,15 @@ int bh_report_ex(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *h
 
 int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *hits, uint64_t nHits, BhMode mode, int flags, const BhTaxOpts *tx,
                   uint64_t *nLines) {
+	BhRunView v; v.base = hits; v.n_runs = 1; v.off[0] = 0; v.n[0] = nHits; v.total = nHits;
+	return bh_report_view(out, db, Q, &v, mode, flags, tx, nLines);
+}
+/* The records may lie in several runs of one address range (ranks of a node whose record buffers rank 0 maps side by side,
+ * bh_node.c): everything below reaches a record as hits + start[entry] + k, so only the pass that finds the entries' ranges
+ * walks the runs. */
+int bh_report_view(FILE *out, const BhDb *db, const BhQueries *Q, const BhRunView *view, BhMode mode, int flags, const BhTaxOpts *tx,
+                   uint64_t *nLines) {
+	const BhipHit *hits = view->base;
 	const uint64_t nU = Q->numUniq, nE = Q->numEntries;
 	FILE *const real_out = out;
 	const BhTax *T = tx ? tx->tax : NULL;
@@ -141,7 +150,7 @@ int bh_report_tax(FILE *out, const BhDb *db, const BhQueries *Q, const BhipHit *
 	/* per-entry ranges (records of one entry are contiguous) */
 	uint64_t *start = calloc(nE + 1, sizeof(*start)); uint32_t *count = calloc(nE + 1, sizeof(*count));
 	if (!start || !count) { free(start); free(count); return bh_set_error(BH_E_OOM, "OOM:report"); }
-	for (uint64_t k = 0; k < nHits; ++k) {
+	for (int r = 0; r < view->n_runs; ++r) for (uint64_t k = view->off[r]; k < view->off[r] + view->n[r]; ++k) {
 		const uint32_t e = hits[k].q;
 		if (e >= nE) { free(start); free(count); return bh_set_error(BH_E_INTERNAL, "hit refers to entry %u of %lu", e, (unsigned long)nE); }
 		if (!count[e]) start[e] = k;

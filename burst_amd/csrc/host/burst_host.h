@@ -22,6 +22,7 @@ extern "C" {
 #define BH_E_OOM    -3   /* reference exit(3) */
 #define BH_E_INTERNAL -4
 #define BH_E_DEVICE -5
+#define BH_E_CAPACITY -6   /* not an error of the job: the caller has to take the other path (bh_node_collect_view) */
 
 typedef enum { BH_FORAGE = 0, BH_BEST, BH_ALLPATHS, BH_CAPITALIST, BH_ANY } BhMode;   /* burst.c:75-78 */
 
@@ -166,9 +167,16 @@ void bh_node_attach(BhNode *node, BhRun *run);                        /* the ran
 int  bh_node_begin(BhNode *node);                                     /* a new search: rank 0 has read the previous one's records */
 int  bh_node_publish(BhNode *node, const BhRun *run, int status);     /* this rank's records of the search are complete */
 int  bh_node_collect(BhNode *node, BhRun *all, uint64_t *counts);     /* rank 0: everybody's records, rank order */
+/* records as runs of one address range: run r = base[off[r] .. off[r] + n[r]); what lies between the runs is not records */
+typedef struct BhRunView { const BhipHit *base; int n_runs; uint64_t off[BH_MAX_RANKS], n[BH_MAX_RANKS]; uint64_t total; } BhRunView;
+int  bh_node_collect_view(BhNode *node, BhRunView *view, uint64_t *counts);   /* rank 0, no copy; BH_E_CAPACITY = use bh_node_collect */
 /* bh_search_multi with the hand-over through `node` instead of the communicator's gather (one rank per process: n_local = 1;
  * comm is then only needed for the minima of a database-sharded search) */
-int  bh_search_multi_ex(BhMultiRank *ranks, int n_local, int n_ranks, void *comm, BhNode *node, const BhQueries *q, BhMode mode, uint64_t batch_uniq, int shard_db, BhRun *all, uint64_t *counts);
+int  bh_search_multi_ex(BhMultiRank *ranks, int n_local, int n_ranks, void *comm, BhNode *node, const BhQueries *q, BhMode mode, uint64_t batch_uniq, int shard_db, BhRun *all, uint64_t *counts,
+                        BhRunView *view);
+/* view (optional; rank 0's process): how to read the result -- with a node and a query-sharded search the ranks' records where they
+ * lie, no copy (all->nHits is their number, all->hits is NOT their place); otherwise the one run all->hits[0 .. all->nHits).
+ * Valid until this rank's next search.  bh_report_view consumes it. */
 int  bh_device_open(const BhDb *db, int device, int z, void **hip_handle);
 /* build_K > 0 and a database without accelerator tables: the device builds the accelerator itself (no .acx file) */
 int  bh_device_open_ex(const BhDb *db, int device, int z, int build_K, void **hip_handle);
@@ -196,6 +204,8 @@ int  bh_tax_load(const char *file, BhTax *T);
 void bh_tax_free(BhTax *T);
 const char *bh_tax_lookup(const BhTax *T, const char *ref_header, int ncbi);
 int  bh_report_tax(FILE *out, const BhDb *db, const BhQueries *q, const BhipHit *hits, uint64_t nHits, BhMode mode, int flags, const BhTaxOpts *tx, uint64_t *nLines);
+/* the same over records that lie in several runs (the records of an entry inside one run, contiguous) */
+int  bh_report_view(FILE *out, const BhDb *db, const BhQueries *q, const BhRunView *view, BhMode mode, int flags, const BhTaxOpts *tx, uint64_t *nLines);
 
 const char *bh_last_error(void);
 int bh_set_error(int code, const char *fmt, ...);

@@ -42,6 +42,22 @@ class BhMultiRank(C.Structure):
     _fields_ = [("rank", C.c_int), ("hh", C.c_void_p), ("r0", u64p), ("r1", u64p), ("n_ranges", C.c_uint32), ("c0", C.c_uint32), ("run", BhRun), ("secSearch", C.c_double)]
 
 
+class BhRunView(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("n_runs", C.c_int), ("off", C.c_uint64 * 16), ("n", C.c_uint64 * 16), ("total", C.c_uint64)]
+
+    def runs(self):
+        """the records, run by run (numpy views of the memory they lie in)"""
+        out = []
+        for r in range(self.n_runs):
+            n = int(self.n[r])
+            if n:
+                buf = (C.c_uint8 * (n * capi.HIT_DTYPE.itemsize)).from_address(self.base + int(self.off[r]) * capi.HIT_DTYPE.itemsize)
+                out.append(np.frombuffer(buf, dtype=capi.HIT_DTYPE))
+            else:
+                out.append(np.zeros(0, capi.HIT_DTYPE))
+        return out
+
+
 class HostError(RuntimeError):
     pass
 
@@ -77,7 +93,9 @@ def lib():
         L.bh_align_ranges.argtypes = [C.c_void_p, C.POINTER(BhQueries), u64p, u64p, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(BhRun)]
         L.bh_align_ranges_reuse.argtypes = L.bh_align_ranges.argtypes
         L.bh_search_multi.argtypes = [C.POINTER(BhMultiRank), C.c_int, C.c_int, C.c_void_p, C.POINTER(BhQueries), C.c_int, C.c_uint64, C.c_int, C.POINTER(BhRun), u64p]
-        L.bh_search_multi_ex.argtypes = [C.POINTER(BhMultiRank), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(BhQueries), C.c_int, C.c_uint64, C.c_int, C.POINTER(BhRun), u64p]
+        L.bh_search_multi_ex.argtypes = [C.POINTER(BhMultiRank), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(BhQueries), C.c_int, C.c_uint64, C.c_int, C.POINTER(BhRun), u64p, C.POINTER(BhRunView)]
+        L.bh_node_collect_view.argtypes = [C.c_void_p, C.POINTER(BhRunView), u64p]
+        L.bh_report_view.argtypes = [C.c_void_p, C.POINTER(BhDb), C.POINTER(BhQueries), C.POINTER(BhRunView), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
         L.bh_node_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]
         L.bh_node_close.argtypes = [C.c_void_p]
         L.bh_node_close.restype = None
@@ -308,9 +326,10 @@ class RankSearch:
         self.mr.r0, self.mr.r1, self.mr.n_ranges = r0.ctypes.data_as(u64p), r1.ctypes.data_as(u64p), len(ranges)
         self._keep = (r0, r1)
         self.counts = np.zeros(self.world, np.uint64)
+        self.view = BhRunView()
         _chk(lib().bh_search_multi_ex(C.byref(self.mr), 1, self.world, self.comm, self.node.h if self.node is not None else None, C.byref(qs.c), MODES[mode], batch_uniq,
-                                      int(bool(shard_db)), C.byref(self.all.c), self.counts.ctypes.data_as(u64p)))
-        return self.all
+                                      int(bool(shard_db)), C.byref(self.all.c), self.counts.ctypes.data_as(u64p), C.byref(self.view)))
+        return self.all      # (rank 0: self.view says where the records are -- with a node they stay in the ranks' segments)
 
     def own_stats(self):
         return self.mr.run.total.as_dict(), int(self.mr.run.nBatches), float(self.mr.run.secAlign)
@@ -337,6 +356,19 @@ def report(path, db, qs, hits, mode, flags=0):
     hits = np.ascontiguousarray(hits)
     try:
         _chk(lib().bh_report_ex(f, C.byref(db.c), C.byref(qs.c), hits.ctypes.data_as(C.c_void_p), len(hits), MODES[mode], flags, C.byref(n)))
+    finally:
+        libc.fclose(f)
+    return int(n.value)
+
+
+def report_view(path, db, qs, view, mode, flags=0):
+    """the same from a BhRunView (records in several runs: RankSearch.view)"""
+    f = libc.fopen(path.encode(), b"wb")
+    if not f:
+        raise HostError("cannot open %s" % path)
+    n = C.c_uint64()
+    try:
+        _chk(lib().bh_report_view(f, C.byref(db.c), C.byref(qs.c), C.byref(view), MODES[mode], flags, None, C.byref(n)))
     finally:
         libc.fclose(f)
     return int(n.value)

@@ -5,8 +5,10 @@
       -m burst_amd.run -r DB.edx -a DB.acx -q reads.fa -o out.b6 -m CAPITALIST -i 0.97 [-fr] [-y]
 
 Every rank loads the database and the queries through the C host (libburst_host.so), aligns its contiguous shard of
-unique queries with the C batch scheduler (bh_align -> libburst_hip.so), the hit records are gathered to rank 0 over
-RCCL, and rank 0 writes the .b6 with the C consolidation code.  With one process it is equivalent to burst_hip.
+unique queries with the C batch scheduler (bh_align_ranges -> libburst_hip.so); every rank's record buffer is a shared-memory
+segment rank 0 has mapped (bh_node.c: no collective on the data path, the records cross each rank's own PCIe link behind its
+batches), and rank 0 writes the .b6 with the C consolidation code straight from the segments (bh_report_view).  With one process
+it is equivalent to burst_hip.
 `--shard db` cuts the database instead of the queries (burst_amd/dist.py: one all_reduce(MIN) of the per-query minimum
 before the gather) for databases that do not fit one device."""
 import argparse
@@ -36,10 +38,19 @@ def main(argv=None):
     args = ap.parse_args(argv)
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     import torch
+    one_dev = os.environ.get("BURST_RUN_DEVICE")      # test hook: every rank on this device (gloo plumbing; RCCL refuses two ranks on one device)
+    if one_dev is not None:
+        local_rank = int(one_dev)
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_dev is not None:
+            if args.shard == "db":
+                sys.stderr.write("BURST_RUN_DEVICE: --shard queries only (the minima of --shard db are reduced over RCCL)\n")
+                return 1
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from burst_amd import capi, dist as bdist, host
     z = 0 if args.nwildcard else 1
     db = host.Db.read(args.references, args.accelerator, K=args.k, z=z)
@@ -76,8 +87,31 @@ def main(argv=None):
     if args.shard == "db" and world > 1:
         hits = bdist.run_db_sharded(host._view(db.c.clumpLen, db.c.numRclumps, np.uint32), host._view(qs.c.six, qs.n_entries, np.uint32),
                                     qs.n_uniq, align_slice, rank, world, "cuda", args.mode == "FORAGE")
+    elif world > 1:
+        # query-sharded: the C host's multi-rank search with the shared-memory hand-over; rank 0 reports from the ranks' segments
+        pdev = "cpu" if one_dev is not None else "cuda"
+        jt = torch.tensor([int.from_bytes(os.urandom(6), "little") if rank == 0 else 0], dtype=torch.int64, device=pdev)
+        dist.broadcast(jt, 0)
+        u0, u1 = bdist.shard_range(qs.n_uniq, world, rank)
+        strands = 2 if qs.n_entries > qs.n_uniq else 1
+        cap = int((u1 - u0) * strands * (4.0 if args.mode in ("FORAGE", "ALLPATHS") else 1.5)) + (1 << 20)
+        node = None
+        if rank == 0:
+            node = host.Node("run%x" % int(jt.item()), rank, world, cap)
+        dist.barrier()
+        if rank != 0:
+            node = host.Node("run%x" % int(jt.item()), rank, world, cap)
+        rs = host.RankSearch(dev, rank, world, None, node=node)
+        rs.search(qs, [(u0, u1)], args.mode, args.batch)
+        if rank == 0:
+            n = host.report_view(args.output, db, qs, rs.view, args.mode, 0 if args.accelerator else host.REP_MERGED_LIST)
+            print("rank 0: %d hit records from %d rank(s) in %.3f s, %d alignments written" % (int(rs.view.total), world, time.time() - t0, n))
+        dist.barrier()      # (the ranks' segments live until rank 0 has written the report)
+        rs.close()
+        dist.destroy_process_group()
+        return 0
     else:
-        hits = bdist.run_sharded(qs.n_uniq, align_range, rank, world, "cuda" if world > 1 else "cpu")
+        hits = bdist.run_sharded(qs.n_uniq, align_range, rank, world, "cpu")
     if rank == 0:
         n = host.report(args.output, db, qs, hits, args.mode, 0 if args.accelerator else host.REP_MERGED_LIST)
         print("rank 0: %d hit records from %d rank(s) in %.3f s, %d alignments written" % (len(hits), world, time.time() - t0, n))

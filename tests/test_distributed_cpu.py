@@ -256,7 +256,12 @@ for call in range(1, 8):
         run.hits = None; run.capHits = 0; run.hitsPinned = 0
     if rank == 0:
         counts = np.zeros(world, np.uint64)
-        rc = L.bh_node_collect(node.h, C.byref(allr), counts.ctypes.data_as(host.u64p))
+        view = host.BhRunView()
+        rc = L.bh_node_collect_view(node.h, C.byref(view), counts.ctypes.data_as(host.u64p)) if mode != "copy" else -6
+        viewed = rc == 0
+        if rc == -6:                        # BH_E_CAPACITY: a rank's records are not inside its slot (it outgrew its segment): one copy
+            assert mode == "copy" or max(count(r, call) for r in range(world)) > cap, (call, rc)
+            rc = L.bh_node_collect(node.h, C.byref(allr), counts.ctypes.data_as(host.u64p))
         if mode == "fail" and call == 3:
             assert rc != 0 and b"rank 1 failed" in L.bh_last_error(), L.bh_last_error()
             continue
@@ -266,7 +271,11 @@ for call in range(1, 8):
         assert rc == 0, L.bh_last_error()
         want = np.concatenate([records(r, call, count(r, call)) for r in range(world)])
         assert [int(c) for c in counts] == [count(r, call) for r in range(world)]
-        got = np.frombuffer((C.c_uint8 * (int(allr.nHits) * 20)).from_address(allr.hits), dtype=capi.HIT_DTYPE) if allr.nHits else np.zeros(0, capi.HIT_DTYPE)
+        if viewed:
+            assert max(count(r, call) for r in range(world)) <= cap and view.total == len(want) and view.n_runs == world
+            got = np.concatenate(view.runs())
+        else:
+            got = np.frombuffer((C.c_uint8 * (int(allr.nHits) * 20)).from_address(allr.hits), dtype=capi.HIT_DTYPE) if allr.nHits else np.zeros(0, capi.HIT_DTYPE)
         assert got.tobytes() == want.tobytes(), (call, len(got), len(want))
 run.hits = None
 node.close()
@@ -274,10 +283,11 @@ print("NODE_OK")
 '''
 
 
-@pytest.mark.parametrize("mode,world", [("plain", 3), ("late", 2), ("fail", 2), ("dead", 2)])
+@pytest.mark.parametrize("mode,world", [("plain", 3), ("copy", 2), ("late", 2), ("fail", 2), ("dead", 2)])
 def test_node_exchange_between_processes(mode, world, tmp_path):
     """bh_node.c, the hand-over of the records between the processes of one node (bench.py --gpus N, one process per GPU): every
-    rank's records lie in its shared-memory segment, rank 0 concatenates them in rank order.  Seven searches in a row with empty,
+    rank's records lie in its shared-memory segment; rank 0 reads them where they lie (a view over the segments, mapped side by
+    side) or -- "copy", and whenever a rank outgrew its segment -- concatenates them in rank order.  Seven searches in a row with empty,
     small, full and outgrown buffers; a rank that is late; a rank that fails (rank 0 says which); a rank that dies (rank 0 gives
     up after BURST_NODE_TIMEOUT instead of waiting for ever); no segment is left in /dev/shm"""
     job = "t%d%s" % (os.getpid(), mode)
@@ -293,3 +303,42 @@ def test_node_exchange_between_processes(mode, world, tmp_path):
         assert not left, left
     for f in left:
         os.unlink(os.path.join("/dev/shm", f))
+
+
+@pytest.mark.parametrize("name", ["dna_q100_capitalist_noacx_t1_fr", "quick_q292_best_fr"])
+def test_report_from_runs_equals_report_from_one_array(name, tmp_path):
+    """bh_report_view: the records of a search lying in several runs of one address range with something else between them (what
+    rank 0 sees of a node's ranks: their shared-memory segments side by side) give the same .b6, byte for byte, as the same
+    records in one array -- and that is the reference's golden output.  Records from the oracle, three ranks' shares, the runs in
+    a buffer whose gaps hold records that must not be read (entry numbers beyond the job)."""
+    import ctypes as C
+    from burst_amd import capi, dist as bdist, host
+    import oraclelib as ol
+    c = [x for x in gl.cases() if x["name"] == name][0]
+    ref, q, fr, z, shear = gl.case_args(c)
+    db = host.Db.read(ref)
+    qs = host.QuerySet(q, float(c["id"]), rc=bool(fr), accel=False)
+    lut = ol.score_lut(1)
+    clump_len = host._view(db.c.clumpLen, db.c.numRclumps, np.uint32)
+    packed = host._view(db.c.packed, db.c.packedWords * 16, np.uint8)
+    shares = []
+    for r in range(3):
+        u0, u1 = bdist.shard_range(qs.n_uniq, 3, r)
+        b = qs.batch(u0, u1)
+        h = ol.search(packed, clump_len, db.c.totR, b.codes, b.off, b.emac.astype(np.uint32), b.six, b.rc, b.n_shared, lut, c["mode"] == "FORAGE")
+        h = h.copy(); h["q"] = b.entry_index[h["q"]].astype(np.uint32)
+        shares.append(h.view(capi.HIT_DTYPE))
+    one = str(tmp_path / "one.b6"); runs = str(tmp_path / "runs.b6")
+    host.report(one, db, qs, np.concatenate(shares), c["mode"], host.REP_MERGED_LIST)
+    gap = 1000
+    buf = np.zeros(sum(len(s) for s in shares) + 4 * gap, dtype=capi.HIT_DTYPE)
+    buf["q"] = 0xFFFFFFFF
+    v = host.BhRunView(); v.base = buf.ctypes.data; v.n_runs = 3
+    at = gap
+    for r, s in enumerate(shares):
+        buf[at:at + len(s)] = s
+        v.off[r] = at; v.n[r] = len(s); at += len(s) + gap
+    v.total = sum(len(s) for s in shares)
+    host.report_view(runs, db, qs, v, c["mode"], host.REP_MERGED_LIST)
+    assert open(one, "rb").read() == open(runs, "rb").read()
+    assert sorted(open(runs, "rb").read().splitlines()) == gl.golden_lines(c)

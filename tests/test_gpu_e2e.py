@@ -160,6 +160,24 @@ def test_python_launcher_single_process(tmp_path):
     assert sorted(open(out, "rb").read().splitlines()) == gl.golden_lines(c)
 
 
+@pytest.mark.parametrize("name,world", [("dna_q100_capitalist_fr", 2), ("dna_q292_forage_fr", 3)])
+def test_python_launcher_processes_share_the_records_in_shared_memory(name, world, tmp_path):
+    """python -m burst_amd.run under torch.distributed.run with several processes (BURST_RUN_DEVICE=0: all on the one device of the
+    test box): every rank aligns its share of the unique queries, its records lie in its shared-memory segment, rank 0 writes the
+    report straight from the segments (bh_node.c + bh_report_view; CAPITALIST's vote runs over all of them): the golden lines"""
+    import sys
+    c = [x for x in gl.cases() if x["name"] == name][0]
+    ref, q, fr, z, shear = gl.case_args(c)
+    out = str(tmp_path / "o.b6")
+    env = dict(os.environ, PYTHONPATH=gl.ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), BURST_RUN_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(29620 + world),
+           "-m", "burst_amd.run", "-r", ref, "-a", acx_for(c["db"], z, str(tmp_path)), "-q", q, "-o", out, "-m", c["mode"], "-i", c["id"]] + (["-fr"] if fr else [])
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=gl.ROOT, timeout=600)
+    assert r.returncode == 0 and "from %d rank(s)" % world in r.stdout, r.stdout[-3000:]
+    gl.compare(c, sorted(open(out, "rb").read().splitlines()), None)
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("burst_hip.run")]
+
+
 @pytest.mark.parametrize("c", [x for x in gl.cases() if x["db"] != "fasta" and (x["mode"] == "BEST" or (x["mode"] == "ALLPATHS" and x["accel"])) and "-b" not in x["extra"]], ids=lambda c: c["name"])
 def test_reference_host_with_device_binding(c, tmp_path_factory):
     """INTEGRATION.md made executable: oracle/_ref/burst12_hip is the reference's own burst.c with oracle/burst_hip_binding.inc
@@ -327,4 +345,7 @@ def test_bench_multi_rank_path_with_one_process(tmp_path):
     c = json.loads([ln for ln in r3.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert c["work"]["records"] == a["work"]["records"]
     assert "shared-memory" in c["config"]["parallelism"] and c["n_gpus"] == 2 and c["scaling"] == "strong"
+    # rank 0 read every rank's records where they lie (no copy): two runs, together the single-process run's records
+    assert c["handover"]["kind"].startswith("view") and len(c["handover"]["records_per_run"]) == 2 and sum(c["handover"]["records_per_run"]) == a["work"]["records"]
+    assert min(c["handover"]["records_per_run"]) > 100000 and c["handover"]["entries_ascend_within_runs"]
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("burst_hip.bench")]
