@@ -545,7 +545,7 @@ def main():
         if use_dist:      # what rank 0 holds after the timed search, read once through (outside the timed region): every rank's run, its records
             runs = rs.view.runs()
             res["handover"] = {"kind": "view over the ranks' shared-memory segments" if (node is not None and rs.view.n_runs == world and world > 1) else "one array",
-                               "records_per_run": [int(len(x)) for x in runs], "entries_ascend_within_runs": bool(all(len(x) < 2 or int(x["q"][-1]) >= int(x["q"][0]) for x in runs)),
+                               "records_per_run": [int(len(x)) for x in runs], "distinct_entries": int(sum(len(np.unique(x["q"])) for x in runs)),
                                "xor_of_reference_numbers": int(np.bitwise_xor.reduce(np.concatenate([x["refIx"] for x in runs]))) if sum(len(x) for x in runs) else 0}
         print(json.dumps(res), flush=True)
     if rs is not None:
