@@ -16,6 +16,7 @@
  *                   quarter of the reads at the rate one device reaches on half the database.
  */
 #include "burst_host.h"
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -280,8 +281,26 @@ int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhN
 		}
 		if (i0 >= 0) all->nHits = need;
 	} else {
-		/* all ranks in this process: their runs meet in host memory (the buffer need not be page-locked: no device writes to it) */
-		if (bh_run_reserve_plain(all, tot_local + 1)) rc = bh_set_error(BH_E_OOM, "OOM:hits");
+		/* all ranks in this process: their runs are in host memory already.  Query-sharded and the caller takes a view: when the runs
+		 * lie a whole number of records apart (the caller gave the ranks slices of one block) they are read where they lie */
+		if (view && !(shard_db > 1 && n_ranks > 1)) {
+			const char *base = NULL;
+			for (int i = 0; i < n_local; ++i) if (!rcs[i] && R[i].run.nHits && (!base || (const char *)R[i].run.hits < base)) base = (const char *)R[i].run.hits;
+			int ok = 1;
+			for (int i = 0; i < n_local; ++i) if (!rcs[i] && R[i].run.nHits && ((const char *)R[i].run.hits - base) % (ptrdiff_t)sizeof(BhipHit)) ok = 0;
+			if (ok) {
+				view->base = (const BhipHit *)base; view->n_runs = n_local; view->total = 0;
+				for (int i = 0; i < n_local; ++i) {
+					const uint64_t n = rcs[i] ? 0 : R[i].run.nHits;
+					view->off[i] = n ? (uint64_t)(((const char *)R[i].run.hits - base) / (ptrdiff_t)sizeof(BhipHit)) : 0; view->n[i] = n; view->total += n;
+					if (counts) counts[R[i].rank] = n;
+				}
+				all->nHits = view->total;
+				viewed = 1;
+			}
+		}
+		if (viewed) { }
+		else if (bh_run_reserve_plain(all, tot_local + 1)) rc = bh_set_error(BH_E_OOM, "OOM:hits");
 		else {
 			uint64_t o = 0, at[BH_MAX_RANKS], cnt[BH_MAX_RANKS]; const BhipHit *src[BH_MAX_RANKS];
 			for (int i = 0; i < n_local; ++i) {      /* local ranks are listed in rank order */

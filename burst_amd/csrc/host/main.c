@@ -333,6 +333,15 @@ int main(int argc, char **argv) {
 		ru0[r] = Q.numUniq * (uint64_t)grp / (uint64_t)n_groups; ru1[r] = Q.numUniq * (uint64_t)(grp + 1) / (uint64_t)n_groups;
 		ranks[r].r0 = &ru0[r]; ranks[r].r1 = &ru1[r]; ranks[r].n_ranges = 1;
 	}
+	BhRun block; memset(&block, 0, sizeof block);
+	if (n_gpus > 1 && !use_rccl && !shard_db) {
+		/* the ranks' record buffers as slices of ONE page-locked block: what they deliver is then read where it lies (a view over the
+		 * block, bh_report_view) instead of being concatenated first */
+		uint64_t off[BH_MAX_GPUS + 1]; off[0] = 0;
+		const uint64_t strands = Q.numEntries > Q.numUniq ? 2 : 1;
+		for (int r = 0; r < n_gpus; ++r) { const uint64_t n = ru1[r] - ru0[r]; off[r + 1] = off[r] + n * strands + n / 2 + (1u << 20); }
+		if (!bh_run_reserve(&block, off[n_gpus])) for (int r = 0; r < n_gpus; ++r) { ranks[r].run.hits = block.hits + off[r]; ranks[r].run.capHits = off[r + 1] - off[r]; ranks[r].run.hitsPinned = 2; }
+	}
 	{	/* device and record buffers for the batches to come (allocations synchronise the device: not inside the search), sized from
 		 * the batches that will really be staged: their entry count and their symbols (one long read among millions of short ones
 		 * must not size every buffer for n_entries x max_len) */
@@ -348,23 +357,25 @@ int main(int argc, char **argv) {
 				if (strands == 2) sy += Q.qoff[Q.numUniq + e] - Q.qoff[Q.numUniq + u];
 				if (sy > sym) sym = sy;
 			}
-			bh_run_reserve(&ranks[r].run, n * strands + n / 2 + (1u << 20));
+			if (!ranks[r].run.hits) bh_run_reserve(&ranks[r].run, n * strands + n / 2 + (1u << 20));      /* (no slice of the block below) */
 			if (B && bhip_reserve_symbols(hhs[r], (uint32_t)(B * strands), Q.maxLen, sym))      /* last: it ends with a warm-up pass, the search follows at once */
 				fprintf(stderr, " --> WARNING: batch buffers not reserved on device %d (%s); they are allocated batch by batch\n", dev_list[r], bhip_last_error());
 		}
 	}
 	BhRun run; memset(&run, 0, sizeof run);
+	BhRunView view; memset(&view, 0, sizeof view);
 	/* several ranks: the buffer their records meet in, made here and not inside the search (page-locked when a device copy lands
 	 * in it, i.e. with the RCCL gather; bh_search_multi grows it if the job brings more) */
-	if (n_gpus > 1 || use_rccl) { const uint64_t cap = Q.numEntries + Q.numEntries / 2 + (1u << 20); if (use_rccl) bh_run_reserve(&run, cap); else bh_run_reserve_plain(&run, cap); }
+	if ((n_gpus > 1 || use_rccl) && !block.hits) { const uint64_t cap = Q.numEntries + Q.numEntries / 2 + (1u << 20); if (use_rccl) bh_run_reserve(&run, cap); else bh_run_reserve_plain(&run, cap); }
 	PHASE("batch buffers");
 	const double t0 = wall();
 	uint64_t cnts[BH_MAX_GPUS]; memset(cnts, 0, sizeof cnts);
 	if (n_gpus == 1 && !use_rccl) {
 		if ((rc = bh_align_ranges_reuse(hhs[0], &Q, &ru0[0], &ru1[0], 1, mode, batch, &ranks[0].run))) { fprintf(stderr, "%s\n", bh_last_error()); return rc == BH_E_USAGE ? 1 : 4; }
 		run = ranks[0].run; memset(&ranks[0].run, 0, sizeof ranks[0].run);
+		view.base = run.hits; view.n_runs = 1; view.off[0] = 0; view.n[0] = run.nHits; view.total = run.nHits;
 	} else {
-		if ((rc = bh_search_multi(ranks, n_gpus, n_gpus, comm, &Q, mode, batch, shard_db ? n_shards : 0, &run, cnts))) { fprintf(stderr, "%s\n", bh_last_error()); return rc == BH_E_USAGE ? 1 : 4; }
+		if ((rc = bh_search_multi_ex(ranks, n_gpus, n_gpus, comm, NULL, &Q, mode, batch, shard_db ? n_shards : 0, &run, cnts, &view))) { fprintf(stderr, "%s\n", bh_last_error()); return rc == BH_E_USAGE ? 1 : 4; }
 		printf("%s: %d rank(s)%s, records per rank:", use_rccl ? "RCCL gather" : "host gather", n_gpus, shard_db ? ", database-sharded" : "");
 		for (int r = 0; r < n_gpus; ++r) printf(" %lu", (unsigned long)cnts[r]);
 		printf("; align phase per rank [s]:");
@@ -376,10 +387,9 @@ int main(int argc, char **argv) {
 	printf("Search complete [%f s, %u batches, %lu candidate (query, clump) pairs, %lu hits]. Consolidating results...\n", t1 - t0, run.nBatches,
 	       (unsigned long)run.total.n_pairs, (unsigned long)run.nHits);
 	PHASE("search (all batches)");
-	if (n_gpus > 1 || use_rccl) for (int r = 0; r < n_gpus; ++r) bh_run_free(&ranks[r].run);      /* (unpinning a rank's buffer takes ~10 ms: not on the search's clock) */
 	uint64_t lines = 0;
 	setvbuf(output, NULL, _IOFBF, 1 << 22);
-	if ((rc = bh_report_tax(output, &db, &Q, run.hits, run.nHits, mode, (do_accel ? 0 : BH_REP_MERGED_LIST) | rep_flags, tax_FN ? &txo : NULL, &lines))) DIE(rc);
+	if ((rc = bh_report_view(output, &db, &Q, &view, mode, (do_accel ? 0 : BH_REP_MERGED_LIST) | rep_flags, tax_FN ? &txo : NULL, &lines))) DIE(rc);
 	fclose(output);
 	printf("Wrote %lu alignments\n", (unsigned long)lines);
 	PHASE("consolidation, output");
@@ -391,6 +401,7 @@ int main(int argc, char **argv) {
 	if (!getenv("BURST_HOST_TEARDOWN")) _exit(0);
 	if (comm) bhip_comm_destroy(comm);
 	for (int r = 0; r < n_gpus; ++r) { bhip_destroy(hhs[r]); if (slices[r].numRclumps) bh_db_free(&slices[r]); }
-	bh_run_free(&run); bh_queries_free(&Q); bh_db_free(&db); bh_tax_free(&taxonomy);
+	for (int r = 0; r < n_gpus; ++r) bh_run_free(&ranks[r].run);
+	bh_run_free(&block); bh_run_free(&run); bh_queries_free(&Q); bh_db_free(&db); bh_tax_free(&taxonomy);
 	return 0;
 }
