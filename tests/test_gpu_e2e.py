@@ -347,5 +347,5 @@ def test_bench_multi_rank_path_with_one_process(tmp_path):
     assert "shared-memory" in c["config"]["parallelism"] and c["n_gpus"] == 2 and c["scaling"] == "strong"
     # rank 0 read every rank's records where they lie (no copy): two runs, together the single-process run's records
     assert c["handover"]["kind"].startswith("view") and len(c["handover"]["records_per_run"]) == 2 and sum(c["handover"]["records_per_run"]) == a["work"]["records"]
-    assert min(c["handover"]["records_per_run"]) > 100000 and c["handover"]["distinct_entries"] > 250000
+    assert min(c["handover"]["records_per_run"]) > 100000 and c["handover"]["distinct_entries"] > 100000
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("burst_hip.bench")]
