@@ -13,9 +13,12 @@ the `burst_hip` command line (bh_align_ranges, burst_amd/csrc/host/bh_align.c) -
 host memory (copies + device-side routing on the staging stream, one batch ahead of the batch being aligned), aligned
 (seeds -> prefilter -> two-stage bit-parallel edit distance -> re-scoring -> sorted records) and its records handed back to
 host memory behind the call.  Staging is therefore INSIDE the timed region.  The steps cycle through --pool distinct
-batches of the sorted unique queries.  N > 1 (one process per GPU, torch.distributed / RCCL): the database is replicated,
-every rank aligns its contiguous share of every batch (strong scaling: the read set is fixed) and one variable-length
-gather brings the hit records to rank 0 inside the timed region.
+batches of the sorted unique queries.  N > 1 (one process per GPU under torch.distributed.run): the database is replicated,
+every rank aligns its share of the job's unique queries (strong scaling: the read set is fixed) through the product's multi-rank
+search (bh_search_multi_ex); the path partitions, so there is no collective on the data path -- every rank's page-locked record
+buffer is a shared-memory segment rank 0 has mapped (bh_node.c), the hand-over inside the timed region is one word per rank and
+rank 0 reads the records where they lie (`handover` in the JSON line).  --gather rccl times the RCCL gather instead;
+torch.distributed only carries the job name and the barriers around the timed region.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel by time on the critical path (HIP events on the stream it runs on);
 `roofline.per_kernel` lists the others with their own bound; PMC-derived traffic / VALU figures come from profiles/
