@@ -14,8 +14,8 @@ host memory (copies + device-side routing on the staging stream, one batch ahead
 (seeds -> prefilter -> two-stage bit-parallel edit distance -> re-scoring -> sorted records) and its records handed back to
 host memory behind the call.  Staging is therefore INSIDE the timed region.  The steps cycle through --pool distinct
 batches of the sorted unique queries.  N > 1 (one process per GPU under torch.distributed.run): the database is replicated,
-every rank aligns its share of the job's unique queries (strong scaling: the read set is fixed) through the product's multi-rank
-search (bh_search_multi_ex); the path partitions, so there is no collective on the data path -- every rank's page-locked record
+every rank aligns --steps batches of its own (weak scaling, the default: the job is N times the single-GPU job; --scaling strong
+cuts the single-GPU job into N equal shares instead) through the product's multi-rank search (bh_search_multi_ex); the path partitions, so there is no collective on the data path -- every rank's page-locked record
 buffer is a shared-memory segment rank 0 has mapped (bh_node.c), the hand-over inside the timed region is one word per rank and
 rank 0 reads the records where they lie (`handover` in the JSON line).  --gather rccl times the RCCL gather instead;
 torch.distributed only carries the job name and the barriers around the timed region.
@@ -215,7 +215,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--reads", type=int, default=2000000, help="reads per step (whole job, all GPUs together)")
+    ap.add_argument("--reads", type=int, default=2000000, help="reads per step (per rank with --scaling weak, all GPUs together with --scaling strong)")
     ap.add_argument("--pool", type=int, default=4, help="distinct batches the steps cycle through")
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--db-scale", type=float, default=1.0, help="multiplies --n-base (1 = 3.2 M references / 4.5 Gbp)")
@@ -237,6 +237,8 @@ def main():
     ap.add_argument("--no-pin", action="store_true", help="leave the query arrays pageable")
     ap.add_argument("--drop-refs", action="store_true", help="delete the reference FASTA once the reads and the .edx exist (disk space of very large databases)")
     ap.add_argument("--no-prime", action="store_true", help="skip bhip_reserve and the priming call (profiling: every dispatch of the run is then a full-size batch)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = every rank aligns --steps batches of --reads reads (the job grows with N; default: the path partitions and "
+                    "has no data-path collective), strong = the single-GPU job of --steps batches cut into N equal shares")
     ap.add_argument("--gather", default="shm", choices=["shm", "rccl"], help="N > 1: how the ranks' records reach rank 0 -- shared-memory segments rank 0 maps (default; no collective) or the library's RCCL gather")
     ap.add_argument("--acx-file", action="store_true", help="round 2's path: the accelerator from an .acx file (built by the host builder) instead of the device build")
     args = ap.parse_args()
@@ -318,7 +320,13 @@ def main():
     U, P = qs.n_uniq, args.pool
     def pool_range(b):
         return (b * U // P, (b + 1) * U // P)
+    weak = args.scaling == "weak"
     def job_share(first, count, r=rank):
+        # weak scaling (default; the path partitions, every rank does what the single GPU does): rank r aligns `count` pool batches
+        # of its own, starting r batches further into the pool so that the ranks are not on the same reads at the same time.
+        # strong scaling: the single-GPU job cut into N equal shares
+        if weak:
+            return [pool_range((first + k + r) % P) for k in range(count)]
         return share_of_job([pool_range((first + k) % P) for k in range(count)], r, world)
     batch_uniq = max(1, U // P + 1)         # at most one pool batch per device call
     reads_per_pool_batch = [qs.reads_in(b * U // P, (b + 1) * U // P) for b in range(P)]
@@ -365,8 +373,8 @@ def main():
                 node = host.Node(job, rank, world, cap_rec)
         rs = host.RankSearch(dev, rank, world, comm, node=node)
         rs.reserve(cap_rec)
-        if rank == 0:      # the buffer all ranks' records meet in: made (and touched) here, as burst_hip does in its "batch buffers" phase
-            rs.reserve_all(world * cap_rec, pinned=args.gather == "rccl")
+        if rank == 0 and args.gather == "rccl":      # the buffer the gathered records land in: made here, as burst_hip does in its "batch buffers" phase
+            rs.reserve_all(world * cap_rec, pinned=True)      # (shared memory: rank 0 reads the ranks' segments where they lie, nothing to reserve)
     else:
         _own.reserve(cap_rec)
     # (bhip_reserve = the command line's "batch buffers" phase: device buffers for this batch size + the library's own warm-up pass)
@@ -376,7 +384,7 @@ def main():
     # queued when a batch's records are handed over pays ~17 ms once per process inside the runtime's asynchronous copy (seen with
     # --warmup 1 in front of the timed region's second batch)
     if not args.no_prime:
-        search([pool_range(k % P) for k in range(4)] if world == 1 else job_share(0, 4 * world))
+        search([pool_range(k % P) for k in range(4)] if world == 1 else job_share(0, 4 if weak else 4 * world))
     search(job_share(0, max(1, args.warmup)))
     if use_dist:
         dist.barrier()
@@ -396,6 +404,8 @@ def main():
         dist.all_reduce(nr)
         n_records = int(nr.item())
     total_reads = sum(reads_per_pool_batch[(args.warmup + k) % P] for k in range(args.steps))
+    if weak and world > 1:      # every rank its own `steps` batches
+        total_reads = sum(reads_per_pool_batch[(args.warmup + k + r) % P] for r in range(world) for k in range(args.steps))
 
     if rank == 0 and os.environ.get("BHIP_PROF"):      # library built with EXTRA_HIPFLAGS=-DPFM_PROF: wave-cycles per prefilter phase
         import ctypes
@@ -482,13 +492,14 @@ def main():
         res = {
             "metric": "aligned reads/sec (node), %d-bp synthetic reads @%s id vs RefSeq stand-in .edx/.acx (DB%d), -m %s; %d GPU" % (args.read_len, args.id, args.K, args.mode, world),
             "value": total_reads / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u32 bit-vectors (u8 edit distances)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3] shape on %d GPU(s): %d synthetic %d-bp reads per step (0-2 edits), -m %s -i %s, vs %d references x %d bp "
                                    "(%.2f Gbp; %d clumps; .edx %.2f GB + DB%d .acx %.2f GB); every step stages its batch afresh through the product's batch scheduler"
                                    % (world, args.reads, args.read_len, args.mode, args.id, args.n_base * args.n_variants, args.ref_len,
                                       args.n_base * args.n_variants * args.ref_len / 1e9, db.c.numRclumps, edx_bytes / 1e9, args.K, acx_bytes / 1e9),
-                       "parallelism": ("query-sharded x%d (rank r aligns the r-th N-th of the job's unique queries in device batches of up to %d), DB replicated; " % (world, batch_uniq)) +
+                       "parallelism": ("query-sharded x%d (%s, in device batches of up to %d), DB replicated; " % (world, "weak scaling: every rank aligns %d batches of its own, the job is N times the single-GPU job" % args.steps
+                                                                                                                     if weak else "strong scaling: rank r aligns the r-th N-th of the single-GPU job's unique queries", batch_uniq)) +
                                       ("no collective on the data path: every rank's record buffer is a page-locked shared-memory segment (its batches' records land there over its own PCIe link, behind the "
                                        "batch), rank 0 has the segments mapped side by side and reads the records where they lie (bh_node.c inside bh_search_multi_ex; bh_report_view consumes such a view) -- no copy" if use_dist and args.gather == "shm" else
                                        "one RCCL gather of the hit records to rank 0 (bhip_comm_gather_hits inside bh_search_multi, the function burst_hip --gpus N --gather rccl runs)"),

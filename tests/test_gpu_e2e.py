@@ -324,7 +324,7 @@ def test_bench_multi_rank_path_with_one_process(tmp_path):
     * --gather rccl with one process (BURST_BENCH_DIST1=1 under torch.distributed.run): the library's RCCL communicator made from a
       broadcast id (bhip_comm_unique_id / bhip_comm_create_rank) and bh_search_multi -- align + bhip_comm_gather_hits in the timed region;
     * the default hand-over with the driver's own command line for N = 2 (two processes, BURST_BENCH_DEVICE=0 puts both ranks on the
-      one device): every rank's records in its shared-memory segment, rank 0 maps and concatenates (bh_node.c), no collective"""
+      one device), strong and weak scaling: every rank's records in its shared-memory segment, rank 0 reads them there (bh_node.c)"""
     import json
     import sys
     bench = os.path.join(gl.ROOT, "bench.py")
@@ -339,7 +339,7 @@ def test_bench_multi_rank_path_with_one_process(tmp_path):
     b = json.loads([ln for ln in r2.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert a["work"]["records"] == b["work"]["records"] > 250000
     assert "RCCL gather" in b["config"]["parallelism"] and b["n_gpus"] == 1
-    r3 = subprocess.run(launch + ["--nproc-per-node", "2", "--master-port", "29612", bench, "--gpus", "2"] + common,
+    r3 = subprocess.run(launch + ["--nproc-per-node", "2", "--master-port", "29612", bench, "--gpus", "2", "--scaling", "strong"] + common,
                         env=dict(os.environ, BURST_BENCH_DEVICE="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r3.returncode == 0, r3.stderr[-3000:]
     c = json.loads([ln for ln in r3.stdout.strip().splitlines() if ln.startswith("{")][-1])
@@ -348,4 +348,11 @@ def test_bench_multi_rank_path_with_one_process(tmp_path):
     # rank 0 read every rank's records where they lie (no copy): two runs, together the single-process run's records
     assert c["handover"]["kind"].startswith("view") and len(c["handover"]["records_per_run"]) == 2 and sum(c["handover"]["records_per_run"]) == a["work"]["records"]
     assert min(c["handover"]["records_per_run"]) > 100000 and c["handover"]["distinct_entries"] > 100000
+    # the default: weak scaling -- every rank its own three batches, twice the single-process job's reads and (about) records
+    r4 = subprocess.run(launch + ["--nproc-per-node", "2", "--master-port", "29613", bench, "--gpus", "2"] + common,
+                        env=dict(os.environ, BURST_BENCH_DEVICE="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r4.returncode == 0, r4.stderr[-3000:]
+    d = json.loads([ln for ln in r4.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["scaling"] == "weak" and d["n_gpus"] == 2 and len(d["handover"]["records_per_run"]) == 2
+    assert 1.9 * a["work"]["records"] < d["work"]["records"] < 2.1 * a["work"]["records"] and min(d["handover"]["records_per_run"]) > 0.9 * a["work"]["records"]
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("burst_hip.bench")]
