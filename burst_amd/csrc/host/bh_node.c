@@ -92,9 +92,9 @@ static NodeHdr *map_peer(BhNode *N, int rank, size_t *bytes) {
 				NodeHdr *h = mmap(NULL, (size_t)sb.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
 				if (h == MAP_FAILED) { close(fd); return NULL; }
 				if (!wait_for(&h->magic, NODE_MAGIC, N->timeout) && h->magic == NODE_MAGIC) {
-					/* into THIS process's page tables now (set-up), not page by page inside the first large hand-over: 0.4 GB of a
-					 * peer's records = 100 000 minor faults = more time than copying them.  (Only the allocated part: touching a
-					 * hole of a tmpfs file allocates it.) */
+					/* rank 0: the records' pages into THIS process's page tables now (set-up), not page by page inside the first large
+					 * hand-over: 0.4 GB of a peer's records = 100 000 minor faults = more time than copying them.  (Only the
+					 * allocated part: touching a hole of a tmpfs file allocates it.) */
 					if (N->rank == 0) view_slot(N, rank, fd, h->cap);
 					close(fd);
 					*bytes = (size_t)sb.st_size; return h;
@@ -235,7 +235,9 @@ int bh_node_collect(BhNode *N, BhRun *all, uint64_t *counts) {
 			int r = 0;
 			while (p >= first[r + 1]) ++r;
 			const uint64_t a = (p - first[r]) * piece, n = N->peer[r]->n_hits, b = a + piece < n ? a + piece : n;
-			memcpy(all->hits + at[r] + a, seg_records(N->peer[r]) + a, (b - a) * sizeof(BhipHit));
+			/* (from the view's slot where the records lie inside it: that mapping was populated when it was made) */
+			const BhipHit *src = N->view && N->in_view[r] && n <= N->peer[r]->cap ? (const BhipHit *)(N->view + (size_t)r * N->stride) : seg_records(N->peer[r]);
+			memcpy(all->hits + at[r] + a, src + a, (b - a) * sizeof(BhipHit));
 		}
 		all->nHits = at[N->n_ranks];
 	}
