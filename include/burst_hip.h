@@ -167,8 +167,11 @@ BHIP_API int   bhip_host_register(void *p, uint64_t bytes);
 BHIP_API int   bhip_host_unregister(void *p);
 
 /* Multi-GPU (no reference counterpart).  Query-sharded: the unique queries are cut across the GPUs of a node -- one
- * handle per device, the database replicated -- and the hit records travel to rank 0 in one variable-length gather over RCCL / xGMI
- * (ncclAllGather of the counts + grouped ncclSend / ncclRecv of the 20-byte records).  Database-sharded (databases beyond one
+ * handle per device, the database replicated.  The hit records are wanted in rank 0's HOST memory (the consolidation runs there):
+ * inside one node the host library lets them meet there without a collective (every rank's records reach host memory over its own
+ * PCIe link behind its batches; host/bh_multi.c, host/bh_node.c) -- these entry points are the exchange for ranks that cannot see
+ * each other's memory, and the option --gather rccl: one variable-length gather over RCCL / xGMI to rank 0's device
+ * (ncclAllGather of the counts + grouped ncclSend / ncclRecv of the 20-byte records) and one copy to its host.  Database-sharded (databases beyond one
  * device): every rank holds a range of clumps and aligns all queries; the hits of a query are the references at its GLOBAL minimum
  * edit distance (burst.c:4217-4277), so the ranks combine one byte per unique query with bhip_comm_allreduce_min (ncclAllReduce,
  * MIN) before the same gather.  The ranks are the threads of one process (bhip_comm_create: ncclCommInitAll over `devices`) or one
