@@ -291,7 +291,7 @@ def test_node_exchange_between_processes(mode, world, tmp_path):
     small, full and outgrown buffers; a rank that is late; a rank that fails (rank 0 says which); a rank that dies (rank 0 gives
     up after BURST_NODE_TIMEOUT instead of waiting for ever); no segment is left in /dev/shm"""
     job = "t%d%s" % (os.getpid(), mode)
-    env = dict(os.environ, BURST_NODE_TIMEOUT="3" if mode == "dead" else "60")
+    env = dict(os.environ, BURST_NODE_TIMEOUT="10" if mode == "dead" else "90")
     ps = [subprocess.Popen([sys.executable, "-c", NODE_WORKER, gl.ROOT, job, str(r), str(world), "5000", mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
           for r in range(world)]
     outs = [p.communicate(timeout=120) for p in ps]
