@@ -335,7 +335,7 @@ def main():
     # travels through torch.distributed, which is plumbing here) and bh_search_multi, the function `burst_hip --gpus N` runs
     comm = None
     node = None
-    if use_dist and args.gather == "rccl":
+    def make_comm():
         idt = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             buf = (C.c_uint8 * 128)()
@@ -344,8 +344,9 @@ def main():
         idt = idt.cuda()
         dist.broadcast(idt, 0)
         idb = (C.c_uint8 * 128)(*idt.cpu().tolist())
-        comm = C.c_void_p()
-        capi._chk(capi.lib().bhip_comm_create_rank(world, rank, local_rank, idb, C.byref(comm)))
+        c = C.c_void_p()
+        capi._chk(capi.lib().bhip_comm_create_rank(world, rank, local_rank, idb, C.byref(c)))
+        return c
     rs = None
     def search(ranges):
         """one job share through the product's scheduler; N > 1: + the gather of the records to rank 0"""
@@ -366,11 +367,30 @@ def main():
             jt = torch.tensor([int.from_bytes(os.urandom(6), "little") if rank == 0 else 0], dtype=torch.int64, device=pdev)
             dist.broadcast(jt, 0)
             job = "bench%x" % int(jt.item())
+            why = ""
+            def try_open():
+                try:
+                    return host.Node(job, rank, world, cap_rec), ""
+                except host.HostError as e:      # /dev/shm too small for the segment, or none
+                    return None, str(e)
             if rank == 0:
-                node = host.Node(job, rank, world, cap_rec)
-            dist.barrier()
-            if rank != 0:
-                node = host.Node(job, rank, world, cap_rec)
+                node, why = try_open()
+            ok = torch.tensor([1 if (rank != 0 or node is not None) else 0], dtype=torch.int64, device=pdev)
+            dist.broadcast(ok, 0)                # (rank 0 first: the others map its segment when they open theirs)
+            if int(ok.item()) and rank != 0:
+                node, why = try_open()
+            ok = torch.tensor([1 if node is not None else 0], dtype=torch.int64, device=pdev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not int(ok.item()):               # some rank has no segment: every rank takes the RCCL gather instead
+                if node is not None:
+                    node.close()
+                    node = None
+                if one_dev is not None:
+                    raise SystemExit("BURST_BENCH_DEVICE: the shared-memory hand-over is the only one for ranks on one device (%s)" % why)
+                log("[bench] rank %d: no shared-memory hand-over%s: RCCL gather" % (rank, " (%s)" % why if why else ""))
+                args.gather = "rccl"
+        if args.gather == "rccl":
+            comm = make_comm()
         rs = host.RankSearch(dev, rank, world, comm, node=node)
         rs.reserve(cap_rec)
         if rank == 0 and args.gather == "rccl":      # the buffer the gathered records land in: made here, as burst_hip does in its "batch buffers" phase

@@ -342,3 +342,50 @@ def test_report_from_runs_equals_report_from_one_array(name, tmp_path):
     host.report_view(runs, db, qs, v, c["mode"], host.REP_MERGED_LIST)
     assert open(one, "rb").read() == open(runs, "rb").read()
     assert sorted(open(runs, "rb").read().splitlines()) == gl.golden_lines(c)
+
+
+HANDOVER_HARNESS = r'''
+import os, sys, textwrap, types
+sys.path.insert(0, sys.argv[2])
+import torch, torch.distributed as dist
+from burst_amd import host
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+src = open(os.path.join(sys.argv[2], "bench.py")).read()
+a = src.index("            jt = torch.tensor([int.from_bytes(os.urandom(6)")
+b = src.index('                args.gather = "rccl"\n') + len('                args.gather = "rccl"\n')
+block = textwrap.dedent(src[a:b])
+args = types.SimpleNamespace(gather="shm")
+cap_rec, pdev, one_dev, node = 5000, "cpu", None, None
+def log(m): print(m, flush=True)
+mode = sys.argv[1]
+if mode == "fail1" and rank == 1:
+    real = host.Node
+    def bad(*a, **k): raise host.HostError("simulated: no room in /dev/shm")
+    host.Node = bad
+if mode == "fail0" and rank == 0:
+    def bad(*a, **k): raise host.HostError("simulated: no room in /dev/shm")
+    host.Node = bad
+g = dict(globals())
+exec(block, g)
+node, gather = g["node"], g["args"].gather
+print("rank", rank, "mode", mode, "node", node is not None, "gather", gather, flush=True)
+assert (mode == "ok") == (node is not None) and gather == ("shm" if mode == "ok" else "rccl")
+if node is not None: node.close()
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("mode,port", [("ok", 29741), ("fail1", 29742), ("fail0", 29743)])
+def test_bench_chooses_the_handover_together(mode, port, tmp_path):
+    """bench.py, N > 1: the block that opens the ranks' shared-memory segments (run verbatim out of bench.py, two gloo processes):
+    all ranks end with a segment, or -- when any rank cannot have one (simulated: /dev/shm full on rank 1 / on rank 0) -- all of them
+    close what they opened and take the RCCL gather; nobody is left waiting and nothing stays in /dev/shm"""
+    w = tmp_path / "harness.py"
+    w.write_text(HANDOVER_HARNESS)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port), str(w), mode, gl.ROOT],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    want = "gather shm" if mode == "ok" else "gather rccl"
+    assert r.stdout.count(want) == 2, r.stdout[-2000:]
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("burst_hip.bench")]
