@@ -370,6 +370,7 @@ g = dict(globals())
 exec(block, g)
 node, gather = g["node"], g["args"].gather
 print("rank", rank, "mode", mode, "node", node is not None, "gather", gather, flush=True)
+open(os.path.join(sys.argv[3], "result.%d" % rank), "w").write("%d %s" % (int(node is not None), gather))
 assert (mode == "ok") == (node is not None) and gather == ("shm" if mode == "ok" else "rccl")
 if node is not None: node.close()
 dist.barrier(); dist.destroy_process_group()
@@ -383,9 +384,14 @@ def test_bench_chooses_the_handover_together(mode, port, tmp_path):
     close what they opened and take the RCCL gather; nobody is left waiting and nothing stays in /dev/shm"""
     w = tmp_path / "harness.py"
     w.write_text(HANDOVER_HARNESS)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port), str(w), mode, gl.ROOT],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    import socket
+    with socket.socket() as sk:          # a port nobody holds right now (the fixed one may still be in TIME_WAIT from an earlier run)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port), str(w), mode, gl.ROOT,
+                        str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
-    want = "gather shm" if mode == "ok" else "gather rccl"
-    assert r.stdout.count(want) == 2, r.stdout[-2000:]
+    want = "1 shm" if mode == "ok" else "0 rccl"
+    for rk in range(2):                  # (files, not the launcher's merged stdout: two processes' lines can interleave there)
+        assert open(str(tmp_path / ("result.%d" % rk))).read() == want, r.stdout[-2000:]
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("burst_hip.bench")]
