@@ -241,6 +241,8 @@ def main():
                     "has no data-path collective), strong = the single-GPU job of --steps batches cut into N equal shares")
     ap.add_argument("--gather", default="shm", choices=["shm", "rccl"], help="N > 1: how the ranks' records reach rank 0 -- shared-memory segments rank 0 maps (default; no collective) or the library's RCCL gather")
     ap.add_argument("--acx-file", action="store_true", help="round 2's path: the accelerator from an .acx file (built by the host builder) instead of the device build")
+    ap.add_argument("--ab", action="append", default=[], help="N = 1: after the timed region, time the same steps again with these library options (name=value[,name=value]; repeatable) "
+                    "on the same resident database -- extra key `ab` of the JSON line, an A/B on one box in one process")
     args = ap.parse_args()
     args.n_base = int(round(args.n_base * args.db_scale))
 
@@ -295,7 +297,7 @@ def main():
     if one_dev is not None and use_dist:      # ranks sharing the device build one after the other (the build sizes its scratch from what is free when it starts)
         for r in range(rank):
             dist.barrier()
-    dev = db.open_device(local_rank, build_K=0 if args.acx_file else args.K)      # references up, both layouts; accelerator built on the device
+    dev = db.open_device(local_rank, build_K=0 if args.acx_file else args.K)      # references up (lane-major layout); accelerator built on the device
     if one_dev is not None and use_dist:
         for r in range(rank, world):
             dist.barrier()
@@ -310,7 +312,7 @@ def main():
     n_ent = C.c_uint64()
     capi._chk(capi.lib().bhip_acx_export(dev._h, None, None, None, 0, C.byref(n_ent), None, 0, None))
     acx_entries = int(n_ent.value)
-    acx_bytes = 5 + 4 * (1 << (2 * args.K)) + 3 * acx_entries          # what the LARGE-format file holds
+    acx_bytes = 5 + 4 * (1 << (2 * args.K)) + 3 * acx_entries          # what the LARGE-format file holds (the SMALL format, 2.5 B per entry, below 2^20 clumps)
     log("[bench] rank %d: db %d refs / %d clumps (.edx %.2f GB, accelerator %.2f G entries; read %.1f s, device upload + accelerator build %.1f s), %d reads -> %d unique (ingest %.1f s) on %s"
         % (rank, db.c.totR, db.c.numRclumps, edx_bytes / 1e9, acx_entries / 1e9, t_db, t_dev, qs.n_reads, qs.n_uniq, t_q, info["name"]))
 
@@ -542,6 +544,30 @@ def main():
                      "seed_words_per_read": st["n_seed_words"] / max(1.0, float(st["n_queries"]))},
             "host": {"db_read_s": t_db, "device_upload_s": t_dev, "query_ingest_s": t_q, "sec_in_device_calls": sec_align},
         }
+        if world == 1 and args.ab:
+            # A/B on the resident database: the same warm-up and steps under other tuning options, the default options' line again at the end
+            defaults = {"prefilter_rb": 0, "seed_min_need": 3, "seed_drop_len": 8, "prefilter_table": 0, "prefilter_waves": 0, "prefilter_algo": -1, "prune": 1, "oversub": 2, "band": 1, "seed_ahead": 1}
+            res["ab"] = []
+            for spec in list(args.ab) + [""]:
+                kv = dict(x.split("=") for x in spec.split(",") if x)
+                for name, val in kv.items():
+                    dev.set_option(name, int(val))
+                search(job_share(0, max(1, args.warmup)))
+                torch.cuda.synchronize()
+                ta = time.time()
+                r2 = search(job_share(args.warmup, args.steps))
+                torch.cuda.synchronize()
+                ea = time.time() - ta
+                st2, nb2 = r2.stats(), max(1, int(r2.c.nBatches))
+                res["ab"].append({"opts": spec or "(defaults again)", "value": total_reads / ea, "ms_per_step": ea / args.steps * 1e3, "records": int(r2.c.nHits),
+                                  "acx_entries_per_read": st2["acx_entries_read"] / max(1.0, float(st2["n_queries"])), "lane_tasks_per_read": st2["n_lane_tasks"] / max(1.0, float(st2["n_queries"])),
+                                  "ms_prefilter_kernel": st2["ms_prefilter_hash"] / max(1, st2["prefilter_launches"]), "ms_myers": st2["ms_myers"] / nb2, "ms_rescore": st2["ms_rescore"] / nb2,
+                                  "prefilter_algo": st2["prefilter_algo"]})
+                log("[bench] ab %s: %.1f M reads/s, %.3f ms per step, prefilter kernel %.3f ms, %.1f records per read, %.2f lane tasks per read, %d records"
+                    % (spec or "(defaults)", total_reads / ea / 1e6, ea / args.steps * 1e3, res["ab"][-1]["ms_prefilter_kernel"], res["ab"][-1]["acx_entries_per_read"], res["ab"][-1]["lane_tasks_per_read"], int(r2.c.nHits)))
+                for name in kv:
+                    if name in defaults:
+                        dev.set_option(name, defaults[name])
         res["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "burst%d" % args.K)):      # N = 1 only (the contract); the other ranks would sit in the barrier meanwhile
             import shutil

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libburst_hip.so")
+# BURST_AMD_LIBDIR: a directory with another build of the two libraries (tools/build_prof.sh: the phase-timer build)
+LIB_PATH = os.path.join(os.environ.get("BURST_AMD_LIBDIR") or _HERE, "libburst_hip.so")
 
 BHIP_OK, BHIP_E_ARG, BHIP_E_DEVICE, BHIP_E_CAPACITY, BHIP_E_QUERYLEN, BHIP_E_INTERNAL, BHIP_E_RESCORE = 0, -1, -2, -3, -4, -5, -6
 BHIP_Q_PREFILTER, BHIP_Q_EXHAUSTIVE = 0, 1

@@ -1,10 +1,10 @@
 // burst_amd/csrc/bhip_acx.hip -- the accelerator (.acx, burst.c:3535-3594) as it lives in HBM (BhipAcxView, bhip_internal.h):
-// 5-byte (clump, lane mask) records in word order + one 64-byte offset line per 14 words.  Three ways to get there:
+// 4-byte (clump, lane-set code) records in word order + one 64-byte offset line per 14 words.  Three ways to get there:
 //   bhip_load_accelerator   from the file's Lens[4^K] + packed lists (read_accelerator, burst.c:3535-3594): decoded on the device,
 //                           lane masks derived from the references (build_lane_masks);
 //   bhip_build_accelerator  from the references alone, on the device (make_accelerator, burst.c:3304-3532): every K-mer of every
 //                           lane -- expanded over IUPAC codes, clumps whose expansion exceeds the reference's budget on the BadList --
-//                           as (word, clump, lane) tuples, radix-sorted and folded to one record per (word, clump) with its lane mask:
+//                           as (word, clump, lane) tuples, radix-sorted and folded to one record per (word, clump) with its lane set:
 //                           the same entries in the same order as the file, without the file;
 //   bhip_acx_export         back to the host as Lens[4^K] + clump ids (+ masks, BadList), e.g. to write the .acx.
 #include "bhip_handle.h"
@@ -55,16 +55,15 @@ __global__ void k_acx_lines(const uint32_t *__restrict__ lens, uint64_t n_words,
 }
 
 // ------------------------------------------------------------------------------------------------
-// .acx list area -> 5-byte records (24-bit clump id, 16-bit lane mask preset to "every lane"), on the device (the packed bytes
+// .acx list area -> 4-byte records (24-bit clump id, lane-set code preset to "every lane"), on the device (the packed bytes
 // are what is uploaded): SMALL lists are pairs of 20-bit ids in 5 bytes with a 3-byte odd tail (burst.c:3265-3274), LARGE
 // lists 3 bytes per id (3245-3248).  One thread per word; `bad` is raised when an id is not a clump of the database.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bhip_rec_store(uint8_t *rec, unsigned long long e, uint32_t clump, uint32_t mask) {
-	uint8_t *p = rec + e * (unsigned long long)BHIP_REC_BYTES;
-	p[0] = (uint8_t)clump; p[1] = (uint8_t)(clump >> 8); p[2] = (uint8_t)(clump >> 16); p[3] = (uint8_t)mask; p[4] = (uint8_t)(mask >> 8);
+__device__ __forceinline__ void bhip_rec_store(uint32_t *rec, unsigned long long e, uint32_t clump, uint32_t mask) {
+	rec[e] = (clump & 0xFFFFFFu) | bhip_lane_mask_code(mask) << 24;
 }
 __global__ void k_acx_decode(const uint8_t *__restrict__ lists, const unsigned long long *__restrict__ byte_base, const uint32_t *__restrict__ byte_delta,
-                             BhipAcxView acx, uint64_t n_words, int fmt, uint32_t n_clumps, uint8_t *__restrict__ rec, uint32_t *__restrict__ bad) {
+                             BhipAcxView acx, uint64_t n_words, int fmt, uint32_t n_clumps, uint32_t *__restrict__ rec, uint32_t *__restrict__ bad) {
 	for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
 		unsigned long long e; uint32_t n;
 		bhip_acx_range(acx, (uint32_t)w, e, n);
@@ -103,12 +102,12 @@ __global__ void k_extract_kmers(const uint4 *__restrict__ ref, const uint64_t *_
 	const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_threads; i += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t c = c0 + (uint32_t)(i >> 4), z = (uint32_t)(i & 15), L = clump_len[c], nchunks = (L + 31) >> 5;
-		const uint4 *rp = ref + ref_off[c] * 16 + z;
+		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)z * nchunks;       // lane-major: [clump][lane][chunk]
 		unsigned long long *kout = keys + (key_off[c] - key_off[c0]) + (uint64_t)z * L;
 		uint16_t *vout = vals + (key_off[c] - key_off[c0]) + (uint64_t)z * L;
 		uint32_t w = 0, run = 0, amb = 0;
 		for (uint32_t t = 0; t < nchunks; ++t) {
-			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint4 ch = rp[t];
 			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
 			for (uint32_t k = 0; k < 32; ++k) {
 				const uint32_t pos = t * 32 + k;
@@ -130,7 +129,7 @@ __global__ void k_extract_kmers(const uint4 *__restrict__ ref, const uint64_t *_
 
 __global__ void k_attach_masks(BhipAcxView acx, uint64_t n_words,
                                const unsigned long long *__restrict__ ukeys, const uint16_t *__restrict__ umasks, uint32_t n_unique,
-                               const uint32_t *__restrict__ ambig_lanes, uint8_t *__restrict__ rec,     // mask bytes of the 5-byte records
+                               const uint32_t *__restrict__ ambig_lanes, uint32_t *__restrict__ rec,    // the code bytes of the records are rewritten
                                uint32_t c0, uint32_t c1) {                                                 // only entries of clumps [c0, c1)
 	// one thread per word walks its list (a few entries); the key of an entry is (word, clump), looked up in the folded tuples
 	for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
@@ -143,8 +142,7 @@ __global__ void k_attach_masks(BhipAcxView acx, uint64_t n_words,
 			uint32_t a = 0, b = n_unique;
 			while (a < b) { const uint32_t mid = a + ((b - a) >> 1); if (ukeys[mid] < key) a = mid + 1; else b = mid; }
 			const uint32_t m = ((a < n_unique && ukeys[a] == key) ? (uint32_t)umasks[a] : 0xFFFFu) | (ambig_lanes[ce] & 0xFFFFu);
-			uint8_t *p = rec + e * (unsigned long long)BHIP_REC_BYTES;
-			p[3] = (uint8_t)m; p[4] = (uint8_t)(m >> 8);
+			bhip_rec_store(rec, e, ce, m);
 		}
 	}
 }
@@ -237,7 +235,7 @@ static int build_lane_masks(Handle *h) {
 		while (c1 < nC && key_off[c1 + 1] - key_off[c0] <= slice_items) ++c1;
 		const uint64_t n_items = key_off[c1] - key_off[c0];
 		++n_slices;
-		hipLaunchKernelGGL(k_extract_kmers, dim3(std::min<uint32_t>(((c1 - c0) * 16 + 255) / 256, (uint32_t)h->n_cu * 16)), dim3(256), 0, h->stream, h->ref.as<uint4>(),
+		hipLaunchKernelGGL(k_extract_kmers, dim3(std::min<uint32_t>(((c1 - c0) * 16 + 255) / 256, (uint32_t)h->n_cu * 16)), dim3(256), 0, h->stream, h->ref_lane.as<uint4>(),
 			h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_koff.as<uint64_t>(), c0, c1, h->K, k0.as<unsigned long long>(), v0.as<uint16_t>(), amb.as<uint32_t>());
 		HIPCHK(hipGetLastError());
 		size_t tb = 0;
@@ -257,7 +255,7 @@ static int build_lane_masks(Handle *h) {
 		HIPCHK(hipMemcpyAsync(&n_unique, nruns.p, 4, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		hipLaunchKernelGGL(k_attach_masks, dim3((uint32_t)h->n_cu * 32), dim3(256), 0, h->stream,
-			h->acx_view(), (uint64_t)(1ull << (2 * h->K)), ukeys, umasks, n_unique, amb.as<uint32_t>(), (uint8_t *)h->acx_view().rec, c0, c1);
+			h->acx_view(), (uint64_t)(1ull << (2 * h->K)), ukeys, umasks, n_unique, amb.as<uint32_t>(), (uint32_t *)h->acx_view().rec, c0, c1);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipStreamSynchronize(h->stream));
 		c0 = c1;
@@ -298,7 +296,7 @@ int bhip_load_accelerator(Handle *h, const uint32_t *acx_lens, const void *acx_l
 	if (bytes) HIPCHK(hipMemcpyAsync(d_lists.p, acx_lists, bytes, hipMemcpyHostToDevice, h->stream));
 	HIPCHK(hipMemsetAsync(d_flag.p, 0, 16, h->stream));
 	hipLaunchKernelGGL(k_acx_decode, dim3((uint32_t)h->n_cu * 32), dim3(256), 0, h->stream, d_lists.as<uint8_t>(), d_bbase.as<unsigned long long>(),
-		d_bdelta.as<uint32_t>(), h->acx_view(), nw, acx_fmt, h->n_clumps, (uint8_t *)h->acx_view().rec, d_flag.as<uint32_t>());
+		d_bdelta.as<uint32_t>(), h->acx_view(), nw, acx_fmt, h->n_clumps, (uint32_t *)h->acx_view().rec, d_flag.as<uint32_t>());
 	HIPCHK(hipGetLastError());
 	uint32_t worst = 0;
 	HIPCHK(hipMemcpyAsync(&worst, d_flag.p, 4, hipMemcpyDeviceToHost, h->stream));
@@ -345,11 +343,11 @@ __global__ void k_acx_budget(const uint4 *__restrict__ ref, const uint64_t *__re
 		const uint32_t c = (uint32_t)(i >> 4), zz = (uint32_t)(i & 15);
 		if (16ull * c + zz >= tot_refs) continue;                                    // burst.c:3336: lanes beyond the last reference
 		const uint32_t L = clump_len[c], nchunks = (L + 31) >> 5;
-		const uint4 *rp = ref + ref_off[c] * 16 + zz;
+		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)zz * nchunks;
 		// the lane's own length: pads (code 0) at the end do not count
 		uint32_t ll = 0;
 		for (uint32_t t = nchunks; t-- > 0 && !ll;) {
-			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint4 ch = rp[t];
 			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
 			for (int k = 31; k >= 0; --k) if ((dw[k >> 3] >> (4 * (k & 7))) & 15u) { ll = t * 32 + (uint32_t)k + 1; break; }
 		}
@@ -358,7 +356,7 @@ __global__ void k_acx_budget(const uint4 *__restrict__ ref, const uint64_t *__re
 		unsigned long long win = 0, ts = 0, nx = 0;
 		uint32_t asum = 0, run = 0, lit = 0;
 		for (uint32_t t = 0; t * 32 < ll; ++t) {
-			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint4 ch = rp[t];
 			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
 			for (uint32_t k = 0; k < 32 && t * 32 + k < ll; ++k) {
 				const uint32_t j = t * 32 + k, sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
@@ -385,7 +383,7 @@ __global__ void k_acx_extract(const uint4 *__restrict__ ref, const uint64_t *__r
 	const uint32_t wmask = (1u << (2 * K)) - 1u;
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_threads; i += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t c = c0 + (uint32_t)(i >> 4), zz = (uint32_t)(i & 15), L = clump_len[c], nchunks = (L + 31) >> 5;
-		const uint4 *rp = ref + ref_off[c] * 16 + zz;
+		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)zz * nchunks;
 		unsigned long long *kout = keys + (slot_off[c] - slot_off[c0]) + (uint64_t)zz * L;
 		uint16_t *vout = vals + (slot_off[c] - slot_off[c0]) + (uint64_t)zz * L;
 		const bool live = !is_bad[c] && 16ull * c + zz < tot_refs;
@@ -393,7 +391,7 @@ __global__ void k_acx_extract(const uint4 *__restrict__ ref, const uint64_t *__r
 		unsigned long long win = 0;
 		uint32_t w = 0, run = 0, lit = 0;
 		for (uint32_t t = 0; t < nchunks; ++t) {
-			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint4 ch = rp[t];
 			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
 			for (uint32_t k = 0; k < 32; ++k) {
 				const uint32_t pos = t * 32 + k;
@@ -441,7 +439,7 @@ __global__ void k_acx_heads(const unsigned long long *__restrict__ ukeys, uint32
 // the tuples are sorted by (word, clump) and the slices are ascending clump ranges, so every list ends up in ascending clump order
 // (what the reference writes with one thread)
 __global__ void k_acx_fill(BhipAcxView acx, const unsigned long long *__restrict__ ukeys, const uint16_t *__restrict__ umasks, const uint32_t *__restrict__ head,
-                           uint32_t n_unique, int end_bit, const uint32_t *__restrict__ cursor, uint8_t *__restrict__ rec, uint32_t all_lanes) {
+                           uint32_t n_unique, int end_bit, const uint32_t *__restrict__ cursor, uint32_t *__restrict__ rec, uint32_t all_lanes) {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_unique; i += gridDim.x * blockDim.x) {
 		const unsigned long long key = ukeys[i];
 		if (key >> end_bit) continue;
@@ -466,7 +464,7 @@ __global__ void k_acx_lens_from_lines(BhipAcxView acx, uint64_t n_words, uint32_
 		lens[w] = n;
 	}
 }
-__global__ void k_acx_rec_export(const uint8_t *__restrict__ rec, unsigned long long e0, uint64_t n, uint32_t *__restrict__ clumps, uint16_t *__restrict__ masks) {
+__global__ void k_acx_rec_export(const uint32_t *__restrict__ rec, unsigned long long e0, uint64_t n, uint32_t *__restrict__ clumps, uint16_t *__restrict__ masks) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
 		const uint2 r = bhip_acx_rec(rec, e0 + i);
 		clumps[i] = r.x;
@@ -492,7 +490,7 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 		DTmp d_ts, d_nx;
 		ARC(d_ts.reserve((size_t)nC * 8)); ARC(d_nx.reserve((size_t)nC * 8));
 		HIPCHK(hipMemsetAsync(d_ts.p, 0, (size_t)nC * 8, h->stream)); HIPCHK(hipMemsetAsync(d_nx.p, 0, (size_t)nC * 8, h->stream));
-		hipLaunchKernelGGL(k_acx_budget, dim3(std::min<uint32_t>((nC * 16u + 255u) / 256u, (uint32_t)h->n_cu * 16)), dim3(256), 0, h->stream, h->ref.as<uint4>(), h->ref_off.as<uint64_t>(),
+		hipLaunchKernelGGL(k_acx_budget, dim3(std::min<uint32_t>((nC * 16u + 255u) / 256u, (uint32_t)h->n_cu * 16)), dim3(256), 0, h->stream, h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(),
 			h->clump_len.as<uint32_t>(), nC, h->tot_refs, K, z ? 1 : 0, d_ts.as<unsigned long long>(), d_nx.as<unsigned long long>());
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipMemcpyAsync(tsum.data(), d_ts.p, (size_t)nC * 8, hipMemcpyDeviceToHost, h->stream));
@@ -507,31 +505,45 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 	ARC(d_bad.reserve((size_t)nC + 16)); ARC(d_soff.reserve(((size_t)nC + 1) * 8));
 	HIPCHK(hipMemcpyAsync(d_bad.p, is_bad.data(), nC, hipMemcpyHostToDevice, h->stream));
 	HIPCHK(hipMemcpyAsync(d_soff.p, slot_off.data(), ((size_t)nC + 1) * 8, hipMemcpyHostToDevice, h->stream));
-	// 2. slices of clumps whose tuples fit the sort buffers (26 bytes per tuple) next to everything that is still to come: the
-	// length table, the running list positions (several slices only), the offset lines and the records (at most one per tuple)
+	// 2. slices of clumps whose tuples fit the sort buffers (26 bytes per tuple) next to what is resident at that time.  The records
+	// (4 bytes per entry; their number is only known after the first pass) are not there yet while the lists are counted: the first
+	// pass runs over slices as large as the sort allows, the second over slices that fit next to the records -- unless everything
+	// fits at once under the safe estimate "one record per tuple", in which case one slice serves both passes and is sorted once.
 	DTmp d_lens, d_cursor, k0, k1, v0, v1, nruns, tmp, d_xcur;
 	ARC(d_lens.reserve(nw * 4 + 16));
 	HIPCHK(hipMemsetAsync(d_lens.p, 0, nw * 4, h->stream));
 	size_t free_b = 0, total_b = 0;
 	HIPCHK(hipMemGetInfo(&free_b, &total_b));
 	const uint64_t n_lines = (nw + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS;
-	const double room = (double)free_b - (double)nw * 4.0 - (double)n_lines * 64.0 - (double)item_off[nC] * BHIP_REC_BYTES - (double)(256u << 20);
 	uint64_t biggest = 0;
 	for (uint32_t c = 0; c < nC; ++c) biggest = std::max(biggest, item_off[c + 1] - item_off[c]);
-	uint64_t slice_items = room > 0 ? (uint64_t)std::min<double>(2147483000.0, room * 0.8 / 33.0) : 0;      // (26 B per tuple in the sort buffers, which grow with a quarter of slack)
-	if (const char *ev = getenv("BHIP_MASK_SLICE")) { const long long v = atoll(ev); if (v > 0) slice_items = std::max<uint64_t>((uint64_t)v, biggest); }
-	if (slice_items < biggest || biggest > 2147483000ull)
-		return fail(BHIP_E_DEVICE, "not enough device memory to build the accelerator (a clump alone has %llu word tuples, %.1f GB free)", (unsigned long long)biggest, (double)free_b / 1e9);
-	std::vector<uint32_t> cuts(1, 0);
-	for (uint32_t c0 = 0; c0 < nC;) {
-		uint32_t c1 = c0 + 1;
-		while (c1 < nC && item_off[c1 + 1] - item_off[c0] <= slice_items) ++c1;
-		cuts.push_back(c1); c0 = c1;
-	}
-	const uint32_t n_slices = (uint32_t)cuts.size() - 1;
+	if (biggest > 2147483000ull) return fail(BHIP_E_DEVICE, "a clump alone has %llu word tuples", (unsigned long long)biggest);
+	long long forced_slice = 0;
+	if (const char *ev = getenv("BHIP_MASK_SLICE")) forced_slice = atoll(ev);
+	std::vector<uint32_t> cuts;
+	uint32_t n_slices = 0;
 	uint64_t cap_items = 0;
-	for (uint32_t s = 0; s < n_slices; ++s) cap_items = std::max(cap_items, item_off[cuts[s + 1]] - item_off[cuts[s]]);
-	ARC(k0.reserve(cap_items * 8 + 16)); ARC(k1.reserve(cap_items * 8 + 16)); ARC(v0.reserve(cap_items * 2 + 16)); ARC(v1.reserve(cap_items * 2 + 16));
+	auto plan_slices = [&](double room) -> int {       // (26 B per tuple in the sort buffers, which grow with a quarter of slack)
+		uint64_t slice_items = room > 0 ? (uint64_t)std::min<double>(2147483000.0, room * 0.8 / 33.0) : 0;
+		if (forced_slice > 0) slice_items = std::max<uint64_t>((uint64_t)forced_slice, biggest);
+		if (slice_items < biggest)
+			return fail(BHIP_E_DEVICE, "not enough device memory to build the accelerator (a clump alone has %llu word tuples, %.1f GB to sort in)", (unsigned long long)biggest, room / 1e9);
+		cuts.assign(1, 0);
+		for (uint32_t c0 = 0; c0 < nC;) {
+			uint32_t c1 = c0 + 1;
+			while (c1 < nC && item_off[c1 + 1] - item_off[c0] <= slice_items) ++c1;
+			cuts.push_back(c1); c0 = c1;
+		}
+		n_slices = (uint32_t)cuts.size() - 1;
+		cap_items = 0;
+		for (uint32_t s = 0; s < n_slices; ++s) cap_items = std::max(cap_items, item_off[cuts[s + 1]] - item_off[cuts[s]]);
+		k0.release(); k1.release(); v0.release(); v1.release(); tmp.release();
+		ARC(k0.reserve_exact(cap_items * 8 + 16)); ARC(k1.reserve_exact(cap_items * 8 + 16)); ARC(v0.reserve_exact(cap_items * 2 + 16)); ARC(v1.reserve_exact(cap_items * 2 + 16));
+		return 0;
+	};
+	const double room_once = (double)free_b - (double)n_lines * 64.0 - (double)item_off[nC] * BHIP_REC_BYTES - (double)(256u << 20);
+	bool one_plan = forced_slice > 0 || (room_once > 0 && room_once * 0.8 / 33.0 >= (double)item_off[nC] && item_off[nC] <= 2147483000ull);
+	ARC(plan_slices(one_plan ? room_once : (double)free_b - (double)n_lines * 64.0 - (double)(256u << 20)));
 	ARC(nruns.reserve(16)); ARC(d_xcur.reserve(16));
 	unsigned long long *ukeys = nullptr; uint16_t *umasks = nullptr; unsigned long long *spare = nullptr; uint32_t n_unique = 0;
 	// tuples of slice s, sorted and folded: ukeys / umasks / n_unique (spare = the other key buffer, free for scratch)
@@ -541,7 +553,7 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 		n_unique = 0;
 		if (!n_items) return 0;
 		HIPCHK(hipMemsetAsync(d_xcur.p, 0, 8, h->stream));
-		hipLaunchKernelGGL(k_acx_extract, dim3(std::min<uint32_t>(((c1 - c0) * 16 + 255) / 256, (uint32_t)h->n_cu * 16)), dim3(256), 0, h->stream, h->ref.as<uint4>(),
+		hipLaunchKernelGGL(k_acx_extract, dim3(std::min<uint32_t>(((c1 - c0) * 16 + 255) / 256, (uint32_t)h->n_cu * 16)), dim3(256), 0, h->stream, h->ref_lane.as<uint4>(),
 			h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_soff.as<uint64_t>(), d_bad.as<uint8_t>(), c0, c1, h->tot_refs, K, z ? 1 : 0,
 			k0.as<unsigned long long>(), v0.as<uint16_t>(), (unsigned long long)n_slots, d_xcur.as<unsigned long long>());
 		HIPCHK(hipGetLastError());
@@ -570,13 +582,20 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 	const double t_pass1 = since();
 	uint64_t tot = 0; uint32_t maxlen = 0;
 	ARC(acx_lines_from_lens(h, d_lens.as<uint32_t>(), nw, &tot, &maxlen));
+	const uint32_t n_slices_1 = n_slices;
+	if (!one_plan) { k0.release(); k1.release(); v0.release(); v1.release(); tmp.release(); }      // the first pass's sort buffers make room for the records
 	ARC(h->acx_rec.reserve_exact(tot * BHIP_REC_BYTES + 16));
-	if (n_slices > 1) { d_cursor.p = d_lens.p; d_cursor.cap = d_lens.cap; d_lens.p = nullptr; d_lens.cap = 0; HIPCHK(hipMemsetAsync(d_cursor.p, 0, nw * 4, h->stream)); }      // (the length table's memory)
+	if (!one_plan) {
+		HIPCHK(hipMemGetInfo(&free_b, &total_b));
+		ARC(plan_slices((double)free_b - (double)(256u << 20)));
+	}
+	if (n_slices > 1 || !one_plan) { d_cursor.p = d_lens.p; d_cursor.cap = d_lens.cap; d_lens.p = nullptr; d_lens.cap = 0; HIPCHK(hipMemsetAsync(d_cursor.p, 0, nw * 4, h->stream)); }      // (the length table's memory)
 	else d_lens.release();
+	const bool refold = n_slices > 1 || !one_plan;
 	// 4. second pass: the records (one slice: the folded tuples are still there)
 	const uint32_t all_lanes = getenv("BHIP_NO_LANE_MASKS") ? 1u : 0u;
 	for (uint32_t s = 0; s < n_slices; ++s) {
-		if (n_slices > 1) ARC(fold_slice(s));
+		if (refold) ARC(fold_slice(s));
 		if (!n_unique) continue;
 		uint32_t *head_in = (uint32_t *)spare, *head = head_in + n_unique;      // 8 bytes per tuple of scratch: the sorted key buffer
 		hipLaunchKernelGGL(k_acx_heads, dim3(g), dim3(256), 0, h->stream, ukeys, n_unique, head_in);
@@ -586,15 +605,15 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 		ARC(tmp.reserve(tb));
 		HIPCHK(hipcub::DeviceScan::InclusiveScan(tmp.p, tb, head_in, head, hipcub::Max(), (int)n_unique, h->stream));
 		hipLaunchKernelGGL(k_acx_fill, dim3(g), dim3(256), 0, h->stream, h->acx_view(), ukeys, umasks, head, n_unique, end_bit,
-			n_slices > 1 ? d_cursor.as<uint32_t>() : (const uint32_t *)nullptr, (uint8_t *)h->acx_view().rec, all_lanes);
+			refold ? d_cursor.as<uint32_t>() : (const uint32_t *)nullptr, (uint32_t *)h->acx_view().rec, all_lanes);
 		HIPCHK(hipGetLastError());
-		if (n_slices > 1) { hipLaunchKernelGGL(k_acx_advance, dim3(g), dim3(256), 0, h->stream, ukeys, head, n_unique, end_bit, d_cursor.as<uint32_t>()); HIPCHK(hipGetLastError()); }
+		if (refold) { hipLaunchKernelGGL(k_acx_advance, dim3(g), dim3(256), 0, h->stream, ukeys, head, n_unique, end_bit, d_cursor.as<uint32_t>()); HIPCHK(hipGetLastError()); }
 		HIPCHK(hipStreamSynchronize(h->stream));
 	}
 	ARC(set_badlist(h, badlist.data(), (uint32_t)badlist.size()));
 	h->has_acx = true; h->n_ent = tot; h->has_masks = !all_lanes;
-	if (dbg) fprintf(stderr, "[bhip] accelerator built on the device: K=%d, %llu entries from %llu word tuples in %u slice(s), %zu clump(s) on the BadList, %.2f B per entry; %.2f s (%.2f s for the list lengths)\n",
-		K, (unsigned long long)tot, (unsigned long long)item_off[nC], n_slices, badlist.size(), tot ? (double)(tot * BHIP_REC_BYTES + n_lines * 64) / (double)tot : 0.0, since(), t_pass1);
+	if (dbg) fprintf(stderr, "[bhip] accelerator built on the device: K=%d, %llu entries from %llu word tuples in %u + %u slice(s), %zu clump(s) on the BadList, %.2f B per entry; %.2f s (%.2f s for the list lengths)\n",
+		K, (unsigned long long)tot, (unsigned long long)item_off[nC], n_slices_1, n_slices, badlist.size(), tot ? (double)(tot * BHIP_REC_BYTES + n_lines * 64) / (double)tot : 0.0, since(), t_pass1);
 	return 0;
 }
 

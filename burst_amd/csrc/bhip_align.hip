@@ -58,7 +58,7 @@ static void launch_myers(Handle *h, Lane *L, hipStream_t st, int cls, uint32_t g
 		uint8_t *mins, Counters *dc) {
 	#define LM(N) hipLaunchKernelGGL(k_myers<N>, dim3(grid), dim3(256), 0, st, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist, \
 		L->peq.as<uint32_t>(), h->s_off(), h->s_emac(), (best && h->cur->st_has_six) ? h->cur->qsix.as<uint32_t>() : nullptr, \
-		h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->tot_refs, raw, n_raw, raw_cap, best, mins, &dc->col_sum, &dc->qlen_sum)
+		h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->tot_refs, raw, n_raw, raw_cap, best, mins, &dc->col_sum, &dc->qlen_sum)
 	switch (kClasses[cls]) { case 2: LM(2); break; case 4: LM(4); break; case 6: LM(6); break; case 8: LM(8); break; case 10: LM(10); break;
 		case 16: LM(16); break; default: LM(32); break; }
 	#undef LM
@@ -66,7 +66,7 @@ static void launch_myers(Handle *h, Lane *L, hipStream_t st, int cls, uint32_t g
 static void launch_prefix(Handle *h, Lane *L, hipStream_t st, int NWP, uint32_t grid, const uint2 *pairs, const uint32_t *n_pairs_dev,
 		uint64_t n_pairs_host, uint32_t li_base, const uint32_t *qlist, uint32_t *n_wins, Counters *dc) {
 	#define LP(N) hipLaunchKernelGGL(k_myers_prefix<N>, dim3(grid), dim3(256), 0, st, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist, \
-		L->peqp.as<uint32_t>(), h->s_off(), h->s_emac(), h->ref.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
+		L->peqp.as<uint32_t>(), h->s_off(), h->s_emac(), h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), \
 		h->tot_refs, L->wins.as<BhipWin>(), n_wins, (uint32_t)L->win_cap, &dc->col_sum, &dc->qlen_sum, dc->win_class_seen, h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr)
 	if (NWP == 1) LP(1); else if (NWP == 2) LP(2); else if (NWP == 3) LP(3); else if (NWP == 4) LP(4); else LP(6);
 	#undef LP
@@ -252,7 +252,8 @@ static int launch_seed(Handle *h, Lane *L, hipStream_t st, StageSlot *S, int cls
 	hipLaunchKernelGGL(k_seed_ranges, dim3(grid), dim3(256), 0, st,
 		junk ? S->qcodes_s.as<uint8_t>() : S->qcodes.as<uint8_t>(), junk ? S->qoff_s.as<uint64_t>() : S->qoff.as<uint64_t>(), d_qlist, n_list,
 		h->acx_view(), h->K, S->plan.as<uint32_t>(), W16, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(),
-		junk ? S->qpack_s.as<uint32_t>() : S->qpack.as<uint32_t>(), (S->st_maxlen + 7) / 8, junk ? S->qemac_s.as<uint16_t>() : S->qemac.as<uint16_t>(), qm.as<uint4>(), S->st_has_six ? S->qsix.as<uint32_t>() : nullptr);
+		junk ? S->qpack_s.as<uint32_t>() : S->qpack.as<uint32_t>(), (S->st_maxlen + 7) / 8, junk ? S->qemac_s.as<uint16_t>() : S->qemac.as<uint16_t>(), qm.as<uint4>(), S->st_has_six ? S->qsix.as<uint32_t>() : nullptr,
+		(uint32_t)h->opt_seed_min_need, (uint32_t)h->opt_seed_drop_len);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(ev[1], st));
 	L->qmeta_seq[S->seq & 1][cls] = S->seq + 1;
@@ -284,26 +285,33 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	// partition of the list: one block too many per CU would run after the others and double the time.
 	hipFuncAttributes fa;
 	memset(&fa, 0, sizeof fa);
+	// record blocks (64 per query) the counting-filter kernel keeps in registers: the expected stream of a query after the longest
+	// lists have been left out (expect counts them all: an upper bound), 2 .. 4; the wider tables only come with 2 or 4
+	int rb = h->opt_pf_rb ? h->opt_pf_rb : (expect <= 110.0 ? 2 : expect <= 230.0 ? 3 : 4);
+	if (htb != 9 && rb == 3) rb = 4;
 	{
 		const void *fp = algo == 0
-			? (htb == 9 ? (const void *)k_prefilter_cf<9> : htb == 10 ? (const void *)k_prefilter_cf<10> : (const void *)k_prefilter_cf<11>)
+			? (htb == 9 ? (rb == 2 ? (const void *)k_prefilter_cf<9, 2> : rb == 3 ? (const void *)k_prefilter_cf<9, 3> : (const void *)k_prefilter_cf<9, 4>)
+			   : htb == 10 ? (rb == 2 ? (const void *)k_prefilter_cf<10, 2> : (const void *)k_prefilter_cf<10, 4>) : (rb == 2 ? (const void *)k_prefilter_cf<11, 2> : (const void *)k_prefilter_cf<11, 4>))
 			: (htb == 9 ? (const void *)k_prefilter_mask<9> : htb == 10 ? (const void *)k_prefilter_mask<10> : (const void *)k_prefilter_mask<11>);
 		if (hipFuncGetAttributes(&fa, fp) != hipSuccess) { fa.sharedSizeBytes = 48 * 1024; fa.numRegs = 128; }
 	}
 	const uint32_t by_lds = (148u * 1024u) / (uint32_t)std::max<size_t>(512, (fa.sharedSizeBytes + 511) & ~(size_t)511);
 	const uint32_t by_reg = 4u * (512u / (uint32_t)std::max(8, (fa.numRegs + 7) & ~7));
 	const uint32_t fit = std::max<uint32_t>(1u, std::min<uint32_t>(12u, std::min(by_lds, by_reg)));
-	if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] prefilter kernel: table 2^%d, %zu B LDS, %d VGPRs -> %u blocks per CU\n", htb, fa.sharedSizeBytes, fa.numRegs, fit);
+	if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] prefilter kernel: table 2^%d, %d record blocks in registers, %zu B LDS, %d VGPRs -> %u blocks per CU\n", htb, rb, fa.sharedSizeBytes, fa.numRegs, fit);
 	const uint32_t waves = h->opt_pf_waves ? std::min<uint32_t>((uint32_t)h->opt_pf_waves, fit) : fit;
 	const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * waves);
 	HIPCHK(hipEventRecord(L->ev_pf[cls][1], st));
 	if (algo == 0) {
-#define PFC_LAUNCH(B) hipLaunchKernelGGL(k_prefilter_cf<B>, dim3(grid), dim3(64), 0, st, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list, \
+#define PFC_LAUNCH(B, R) hipLaunchKernelGGL((k_prefilter_cf<B, R>), dim3(grid), dim3(64), 0, st, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list, \
 		h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, \
 		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
 		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum, \
 		L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], prune)
-		if (htb == 9) PFC_LAUNCH(9); else if (htb == 10) PFC_LAUNCH(10); else PFC_LAUNCH(11);
+		if (htb == 9) { if (rb == 2) PFC_LAUNCH(9, 2); else if (rb == 3) PFC_LAUNCH(9, 3); else PFC_LAUNCH(9, 4); }
+		else if (htb == 10) { if (rb == 2) PFC_LAUNCH(10, 2); else PFC_LAUNCH(10, 4); }
+		else { if (rb == 2) PFC_LAUNCH(11, 2); else PFC_LAUNCH(11, 4); }
 #undef PFC_LAUNCH
 	} else {
 #define PFM_LAUNCH(B) hipLaunchKernelGGL(k_prefilter_mask<B>, dim3(grid), dim3(64), 0, st, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list, \
@@ -592,7 +600,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	const size_t lds_rs = (size_t)(band_rows + 1 + qw + rw) * 256;
 	hipLaunchKernelGGL(k_rescore<false>, dim3(grid_rs), dim3(64), lds_rs, po, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap,
 		L->rs_lists.as<uint32_t>() + (size_t)9 * L->raw_cap, &dc->n_rs[9], h->best.as<uint32_t>(), all_hits, h->cur->qcodes.as<uint8_t>(), h->cur->qoff.as<uint64_t>(),
-		h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr, h->cur->st_has_rc ? h->cur->qrc.as<uint8_t>() : nullptr, h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(),
+		h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr, h->cur->st_has_rc ? h->cur->qrc.as<uint8_t>() : nullptr, h->ref_lane.as<uint8_t>(), h->ref_off.as<uint64_t>(),
 		h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(), &sc->n_out, (uint32_t)h->out_cap, L->wide.as<uint32_t>(),
 		&dc->n_wide, (uint32_t *)nullptr, &dc->scratch_used, 0ull, &sc->err, qw ? h->cur->qpack.as<uint32_t>() : nullptr, band_rows, qw, rw);
 	HIPCHK(hipGetLastError());
@@ -771,7 +779,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			hipLaunchKernelGGL(k_rescore<true>, dim3(std::min<uint32_t>((L->hc.n_wide + 63) / 64, (uint32_t)h->n_cu * 16)), dim3(64), 256, h->post_stream,
 				L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap, L->wide.as<uint32_t>(), &dc->n_wide, h->best.as<uint32_t>(), all_hits,
 				h->cur->qcodes.as<uint8_t>(), h->cur->qoff.as<uint64_t>(), h->cur->st_has_six ? h->cur->qsix.as<uint32_t>() : nullptr, h->cur->st_has_rc ? h->cur->qrc.as<uint8_t>() : nullptr,
-				h->ref.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(),
+				h->ref_lane.as<uint8_t>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->lut.as<uint8_t>(), h->out.as<BhipHit>(),
 				&sc->n_out, (uint32_t)h->out_cap, (uint32_t *)nullptr, (uint32_t *)nullptr, L->scratch.as<uint32_t>(), &dc->scratch_used,
 				(unsigned long long)L->scratch_cap, &sc->err, (const uint32_t *)nullptr, 0u, 0u, 0u);
 			HIPCHK(hipGetLastError());

@@ -23,8 +23,8 @@
 // ---- kernels (bhip_kernels.hip) -------------------------------------------------------------------
 __global__ void k_acx_offsets(const uint32_t *, uint64_t, int, uint32_t *, unsigned long long *);
 __global__ void k_acx_lines(const uint32_t *, uint64_t, int, unsigned long long *, uint4 *);
-__global__ void k_acx_decode(const uint8_t *, const unsigned long long *, const uint32_t *, BhipAcxView, uint64_t, int, uint32_t, uint8_t *, uint32_t *);
-__global__ void k_transpose_refs(const uint8_t *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint4 *, uint4 *);
+__global__ void k_acx_decode(const uint8_t *, const unsigned long long *, const uint32_t *, BhipAcxView, uint64_t, int, uint32_t, uint32_t *, uint32_t *);
+__global__ void k_transpose_refs(const uint8_t *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint4 *);
 __global__ void k_build_peq(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, int, int, BhipMatchMask, uint32_t *, const uint32_t *, uint32_t, uint32_t);
 template <bool LDS_CNT> __global__ void k_prefilter(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
 	BhipAcxView, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t,
@@ -45,15 +45,15 @@ template <int NW> __global__ void k_myers_window(const BhipWin *, const uint32_t
 template <int BW> __global__ void k_myers_window_band(const BhipWin *, const uint32_t *, uint32_t, int, int, const uint32_t *, const uint32_t *,
 	const uint4 *, BhipRawHit *, uint32_t *, uint32_t, uint32_t *, unsigned long long *, const uint32_t *);
 __global__ void k_extract_kmers(const uint4 *, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t, uint32_t, int, unsigned long long *, uint16_t *, uint32_t *);
-__global__ void k_attach_masks(BhipAcxView, uint64_t, const unsigned long long *, const uint16_t *, uint32_t, const uint32_t *, uint8_t *, uint32_t, uint32_t);
-template <int HTB> __global__ void k_prefilter_mask(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+__global__ void k_attach_masks(BhipAcxView, uint64_t, const unsigned long long *, const uint16_t *, uint32_t, const uint32_t *, uint32_t *, uint32_t, uint32_t);
+template <int HTB> __global__ void k_prefilter_mask(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *,
 	uint2 *, uint32_t *, uint32_t);
-template <int CB> __global__ void k_prefilter_cf(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+template <int CB, int RBT> __global__ void k_prefilter_cf(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *,
 	uint2 *, uint32_t *, int);
 __global__ void k_task_filter(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, uint2 *, uint32_t *);
-__global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, BhipAcxView, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t, const uint16_t *, uint4 *, const uint32_t *);
+__global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, BhipAcxView, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t, const uint16_t *, uint4 *, const uint32_t *, uint32_t, uint32_t);
 template <int NWP> __global__ void k_myers_prefix_task(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *,
 	const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, const uint4 *, const uint32_t *);
 template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *,
@@ -216,15 +216,15 @@ struct Handle {
 	hipEvent_t ev[10];
 	// database
 	uint32_t n_clumps = 0, tot_refs = 0, max_clump_len = 0;
-	DBuf ref, ref_lane, ref_off, clump_len, lut;      // ref: 16 lanes interleaved per 32-column chunk; ref_lane: each lane contiguous
+	DBuf ref_lane, ref_off, clump_len, lut;           // ref_lane: [clump][lane][32-column chunk][16 B], each lane contiguous inside its clump's area
 	BhipMatchMask mm;
 	bool has_acx = false; int K = 0;
-	// accelerator: two-level offsets + 5-byte (clump, lane mask) records (bhip_internal.h); entry numbers start at acx_bias
+	// accelerator: offset lines + 4-byte (clump, lane-set code) records (bhip_internal.h); entry numbers start at acx_bias
 	// (0, or the test hook BHIP_TEST_ENTRY_BIAS that pushes a small database's offsets beyond 2^32)
 	DBuf acx_lines, acx_rec, bad; uint32_t n_bad = 0; uint64_t n_ent = 0, acx_bias = 0;
 	BhipAcxView acx_view() const {
 		BhipAcxView v; v.lines = acx_lines.as<uint4>();
-		v.rec = acx_rec.as<uint8_t>() - acx_bias * (uint64_t)BHIP_REC_BYTES; return v;
+		v.rec = acx_rec.as<uint32_t>() - acx_bias; return v;
 	}
 	bool has_masks = false;       // per-entry lane masks were built at upload (lane-resolved prefilter)
 	int opt_lane_masks = 1;       // use them
@@ -272,9 +272,12 @@ struct Handle {
 	int opt_pf_algo = -1;         // 0 = counting filter + exact lane table (k_prefilter_cf), 1 = exact clump hash table in two passes
 	                              // (k_prefilter_mask), -1 = start with 0 and switch a lane to 1 when more than 20 % of its records survive the filter
 	int opt_pf_table = 0;         // log2 of the per-query hash table (0 = from the workload: 9, 10 or 11)
+	int opt_pf_rb = 0;            // 64-record blocks per query the counting-filter kernel fetches a quad ahead and keeps in registers (0 = from the workload: 2, 3 or 4)
 	int opt_seed_ahead = 1;       // seed lookups of the next staged batch run while the current one is swept
 	int opt_seed_ahead_blocks = 2; // 256-thread blocks per CU of a seed kernel that runs ahead (0 = one block per 256 lookups, as in place); 2: +2.3 % on the bench
 	int opt_peq_ahead_blocks = 16; // 256-thread blocks per CU of a profile build that runs ahead
+	int opt_seed_min_need = 3;    // the longest lists of a query's sampled words are left out while its guaranteed count stays >= this (0 = keep every list)
+	int opt_seed_drop_len = 8;    // ... lists shorter than this are always kept (leaving them out saves nothing and costs selectivity)
 	double acx_wmean = 0.0;       // occurrence-weighted mean .acx list length
 };
 

@@ -71,7 +71,7 @@ extern "C" void bhip_destroy(void *handle) {
 	for (StageSlot &S : h->slots) S.release_all();
 	if (h->hsc_pinned) (void)hipHostFree(h->hsc_pinned);
 	for (Lane *L : h->lanes) lane_destroy(L);
-	DBuf *all[] = {&h->ref, &h->ref_lane, &h->ref_off, &h->clump_len, &h->lut, &h->acx_lines, &h->acx_rec, &h->bad,
+	DBuf *all[] = {&h->ref_lane, &h->ref_off, &h->clump_len, &h->lut, &h->acx_lines, &h->acx_rec, &h->bad,
 		&h->best, &h->out, &h->shared_ctr, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx,
 		&h->sort_tmp, &h->out_sorted, &h->out_sorted2};
 	for (int o = 0; o < 2; ++o) {
@@ -145,7 +145,6 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		DBuf d_src, d_srcoff;
 		INITRC(d_src.reserve(src_off[n_clumps] * 16 + 16));
 		INITRC(d_srcoff.reserve((n_clumps + 1) * sizeof(uint64_t)));
-		INITRC(h->ref.reserve_exact(dst_off[n_clumps] * 256 + 256));
 		INITRC(h->ref_lane.reserve_exact(dst_off[n_clumps] * 256 + 256));
 		INITRC(h->ref_off.reserve((n_clumps + 1) * sizeof(uint64_t)));
 		INITRC(h->clump_len.reserve(n_clumps * sizeof(uint32_t)));
@@ -157,7 +156,7 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		INITCHK(hipMemcpyAsync(h->lut.p, score_lut, 256, hipMemcpyHostToDevice, h->stream));
 		const uint32_t grid = std::min<uint32_t>(n_clumps, (uint32_t)h->n_cu * 8);
 		hipLaunchKernelGGL(k_transpose_refs, dim3(grid), dim3(256), 0, h->stream, d_src.as<uint8_t>(), d_srcoff.as<uint64_t>(),
-			h->clump_len.as<uint32_t>(), h->ref_off.as<uint64_t>(), n_clumps, h->ref.as<uint4>(), h->ref_lane.as<uint4>());
+			h->clump_len.as<uint32_t>(), h->ref_off.as<uint64_t>(), n_clumps, h->ref_lane.as<uint4>());
 		INITCHK(hipGetLastError());
 		// any reference symbol beyond A/C/G/T?  (decides how many rows of the match profiles are built per batch)
 		DBuf d_flag;
@@ -175,6 +174,17 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 	if (acx_lens) INITRC(bhip_load_accelerator(h, acx_lens, acx_lists, acx_fmt, K, badlist, n_bad));
 	else if (K) INITRC(bhip_build_accelerator(h, K, score_lut[16 * 5 + 5] != 0));      // N penalised (burst.c:164, -y clears it): N costs 1 even against N
 	INITRC(ensure_lanes(h, 1));
+	// BHIP_OPTS="name=value,name=value": tuning options for callers that have no other way to pass them (A/B runs of the command line)
+	if (const char *ev = getenv("BHIP_OPTS")) {
+		std::string all(ev);
+		for (size_t a = 0; a < all.size();) {
+			size_t b = all.find(',', a); if (b == std::string::npos) b = all.size();
+			const std::string kv = all.substr(a, b - a); a = b + 1;
+			const size_t eq = kv.find('=');
+			if (eq == std::string::npos || eq == 0) continue;
+			INITRC(bhip_set_option(h, kv.substr(0, eq).c_str(), atoll(kv.c_str() + eq + 1)));
+		}
+	}
 	*handle = h;
 	return BHIP_OK;
 }
@@ -211,9 +221,12 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 	if (!strcmp(name, "band")) { h->opt_no_band = value == 0; return BHIP_OK; }
 	if (!strcmp(name, "prune")) { h->opt_prune = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "rescore_reg")) { h->opt_rescore_reg = value != 0; return BHIP_OK; }
+	if (!strcmp(name, "seed_min_need")) { if (value < 0 || value > 255) return fail(BHIP_E_ARG, "seed_min_need must be 0 .. 255"); h->opt_seed_min_need = (int)value; return BHIP_OK; }
+	if (!strcmp(name, "seed_drop_len")) { if (value < 0 || value > (1 << 24)) return fail(BHIP_E_ARG, "seed_drop_len must be 0 .. 2^24"); h->opt_seed_drop_len = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_waves")) { if (value < 0 || value > 16) return fail(BHIP_E_ARG, "prefilter_waves must be 0 .. 16"); h->opt_pf_waves = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_algo")) { if (value < -1 || value > 1) return fail(BHIP_E_ARG, "prefilter_algo must be -1, 0 or 1"); h->opt_pf_algo = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_table")) { if (value != 0 && (value < 9 || value > 11)) return fail(BHIP_E_ARG, "prefilter_table must be 0, 9, 10 or 11"); h->opt_pf_table = (int)value; return BHIP_OK; }
+	if (!strcmp(name, "prefilter_rb")) { if (value != 0 && (value < 2 || value > 4)) return fail(BHIP_E_ARG, "prefilter_rb must be 0, 2, 3 or 4"); h->opt_pf_rb = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "lanes")) {
 		if (value < 1 || value > 16) return fail(BHIP_E_ARG, "lanes must be 1 .. 16");
 		h->opt_lanes = (int)value; for (StageSlot &S : h->slots) { S.state = 0; S.st_valid = false; } return BHIP_OK;

@@ -62,9 +62,15 @@ struct BhipStageInfo {
 
 // ------------------------------------------------------------------------------------------------
 // Accelerator (.acx, burst.c:3535-3594) as it lives in HBM.
-//   Lists: one 5-byte record per list entry, in the file's word order: bytes 0-2 = clump id (the 24 bits of the LARGE format,
-//   burst.c:3245-3248), bytes 3-4 = 16-bit lane mask (bit z: lane z of the clump really holds the word; 0xFFFF when the
-//   masks were not built).  Offsets: the file's Lens[4^K] (burst.c:3558) becomes a table of 64-byte LINES, one per block of 14
+//   Lists: one aligned 4-byte record per list entry, in the file's word order: bits 0-23 = clump id (the 24 bits of the LARGE
+//   format, burst.c:3245-3248), bits 24-31 = a LANE-SET CODE: which of the clump's 16 lanes really hold the word (the .acx is
+//   clump-granular; the lanes are worked out on the device).  The code names a superset of the true lane set that is exact for
+//   one lane (codes 0..15) and for two (16..135, the 120 pairs) -- 99.9 % of the entries of a low-redundancy database --, and the
+//   smallest enclosing quad pattern beyond: three or four lanes of one aligned quad (136..155), a union of quads (156..166; 166 =
+//   every lane, also what records without lane information carry).  A superset never loses a candidate lane, it only costs a
+//   sweep.  Round 3 kept a full 16-bit mask (5 bytes, two loads and a funnel shift per record); 4 bytes are what lets the
+//   metric's database (~54 G entries) stay resident on one 288 GB device, and one dword load per record.
+//   Offsets: the file's Lens[4^K] (burst.c:3558) becomes a table of 64-byte LINES, one per block of 14
 //   words: a 64-bit entry number of the block's first list followed by the fourteen 32-bit inclusive prefix sums of the list
 //   lengths inside the block -- the range of a word is ONE 64-byte sector at a random address (a flat offset array costs two,
 //   a two-level table three).  A list is shorter than 2^24 entries (one per clump at most, burst.c:3385-3386, clump ids have
@@ -74,13 +80,17 @@ struct BhipStageInfo {
 //   databases exercise offsets beyond 2^32); only entry numbers >= the bias are ever dereferenced.
 // ------------------------------------------------------------------------------------------------
 #define BHIP_ACX_LINE_WORDS 14u
-#define BHIP_REC_BYTES 5
+#define BHIP_REC_BYTES 4
+#define BHIP_REC_PAD 0xFFFFFFFFu     // not a record (code 255 is never stored)
 struct BhipAcxView {
 	const uint4 *lines;                  // [ceil(n_words / 14)] x 64 bytes
-	const uint8_t *rec;                  // 5 bytes per entry
+	const uint32_t *rec;                 // 4 bytes per entry
 };
 
+#include "bhip_lanecode.h"
+
 #ifdef __HIPCC__
+typedef const uint32_t __attribute__((address_space(1))) *bhip_gptr_t;
 // entry range of word w: first entry and length
 __device__ __forceinline__ void bhip_acx_range(const BhipAcxView &a, uint32_t w, unsigned long long &beg, uint32_t &n) {
 	const uint32_t blk = w / BHIP_ACX_LINE_WORDS, j = w - blk * BHIP_ACX_LINE_WORDS;
@@ -91,46 +101,28 @@ __device__ __forceinline__ void bhip_acx_range(const BhipAcxView &a, uint32_t w,
 	beg = b0 + lo;
 	n = hi - lo;
 }
-// record e as (clump, lane mask): two aligned dword loads around the 5 bytes
-__device__ __forceinline__ uint2 bhip_acx_rec(const uint8_t *rec, unsigned long long e) {
-	const uintptr_t addr = (uintptr_t)rec + e * (unsigned long long)BHIP_REC_BYTES;
-	typedef const uint32_t __attribute__((address_space(1))) *gptr_t;
-	gptr_t p = (gptr_t)(addr & ~(uintptr_t)3);
-	const uint32_t d0 = p[0], d1 = p[1];
-	const unsigned long long v = (((unsigned long long)d1 << 32) | d0) >> (8u * (uint32_t)(addr & 3u));
-	return make_uint2((uint32_t)v & 0xFFFFFFu, (uint32_t)(v >> 24) & 0xFFFFu);
+// record e as (clump, lane mask) -- the decoding of the code is a loop: for the kernels off the hot path
+__device__ __forceinline__ uint2 bhip_acx_rec(const uint32_t *rec, unsigned long long e) {
+	const uint32_t v = rec[e];
+	return make_uint2(v & 0xFFFFFFu, bhip_lane_code_mask(v >> 24));
 }
-// the same without a branch around the loads: lanes without a record read `dummy` (any mapped, 8-byte readable address) and get
-// the padding record.  A conditional load is compiled as a divergent branch with its own s_waitcnt vmcnt(0) -- a sequence of
-// them is fully serialised, one memory latency each -- and the compiler turns a select around a load back into that branch
-// unless the loaded words are used on every path: they are folded into `sink`, which the caller stores under a condition
-// that never holds.
-__device__ __forceinline__ uint2 bhip_acx_rec_or_pad(const uint8_t *rec, unsigned long long e, bool valid, const void *dummy, uint32_t &sink) {
-	const uintptr_t addr = valid ? (uintptr_t)rec + e * (unsigned long long)BHIP_REC_BYTES : (uintptr_t)dummy;
-	// (a global-address-space pointer: a flat load also counts as an LDS operation, and every s_waitcnt lgkmcnt(0) in front of
-	// the next ds_bpermute would wait for it)
-	typedef const uint32_t __attribute__((address_space(1))) *gptr_t;
-	gptr_t p = (gptr_t)(addr & ~(uintptr_t)3);
-	const uint32_t d0 = p[0], d1 = p[1];
-	sink ^= d0 + d1;
-	const unsigned long long v = (((unsigned long long)d1 << 32) | d0) >> (8u * (uint32_t)(addr & 3u));
-	// (mask arithmetic instead of a select around the decoding, which the compiler would put -- with its wait -- under a branch)
-	const uint32_t m = valid ? 0xFFFFFFFFu : 0u;
-	return make_uint2(((uint32_t)v & 0xFFFFFFu) | ~m, (uint32_t)(v >> 24) & 0xFFFFu & m);
+__device__ __forceinline__ uint32_t bhip_acx_clump(const uint32_t *rec, unsigned long long e) { return rec[e] & 0xFFFFFFu; }
+// The raw record word for the hot kernels, without a branch around the load: lanes without a record read `dummy` (any mapped,
+// 4-byte readable address) and get BHIP_REC_PAD.  A conditional load is compiled as a divergent branch with its own
+// s_waitcnt vmcnt(0) -- a sequence of them is fully serialised, one memory latency each -- and the compiler turns a select
+// around a load back into that branch unless the loaded word is used on every path: it is folded into `sink`, which the caller
+// stores under a condition that never holds.  (A global-address-space pointer: a flat load also counts as an LDS operation,
+// and every s_waitcnt lgkmcnt(0) in front of the next LDS round trip would wait for it.)
+__device__ __forceinline__ uint32_t bhip_acx_raw_issue(const uint32_t *rec, unsigned long long e, bool valid, const void *dummy) {
+	const uintptr_t addr = valid ? (uintptr_t)(rec + e) : (uintptr_t)dummy;
+	return ((bhip_gptr_t)addr)[0];
 }
-// split form for a software pipeline: issue the two loads now (raw words), decode where the record is consumed
-__device__ __forceinline__ uint2 bhip_acx_rec_issue(const uint8_t *rec, unsigned long long e, bool valid, const void *dummy, uint32_t &shift8) {
-	typedef const uint32_t __attribute__((address_space(1))) *gptr_t;
-	const uintptr_t addr = valid ? (uintptr_t)rec + e * (unsigned long long)BHIP_REC_BYTES : (uintptr_t)dummy;
-	gptr_t p = (gptr_t)(addr & ~(uintptr_t)3);
-	shift8 = 8u * (uint32_t)(addr & 3u);
-	return make_uint2(p[0], p[1]);
+__device__ __forceinline__ uint32_t bhip_acx_raw_finish(uint32_t raw, bool valid, uint32_t &sink) {
+	sink ^= raw;
+	return valid ? raw : BHIP_REC_PAD;
 }
-__device__ __forceinline__ uint2 bhip_acx_rec_decode(uint2 raw, uint32_t shift8, bool valid, uint32_t &sink) {
-	sink ^= raw.x + raw.y;
-	const unsigned long long v = (((unsigned long long)raw.y << 32) | raw.x) >> shift8;
-	const uint32_t m = valid ? 0xFFFFFFFFu : 0u;
-	return make_uint2(((uint32_t)v & 0xFFFFFFu) | ~m, (uint32_t)(v >> 24) & 0xFFFFu & m);
+__device__ __forceinline__ uint32_t bhip_acx_raw_or_pad(const uint32_t *rec, unsigned long long e, bool valid, const void *dummy, uint32_t &sink) {
+	return bhip_acx_raw_finish(bhip_acx_raw_issue(rec, e, valid, dummy), valid, sink);
 }
 // Counting sort of the records by query, first half: behind the shared record counter (n_out, err) sit the pointers to the
 // per-query counters and to the rank array (SharedCtr in bhip_api.hip; null when the caller sorts differently).  Called by the
@@ -140,7 +132,6 @@ __device__ __forceinline__ void bhip_hit_rank(uint32_t *n_out, uint32_t pos, uin
 	uint32_t *cnt = pp[0], *rank = pp[1];
 	if (cnt) rank[pos] = atomicAdd(&cnt[q], 1u);
 }
-__device__ __forceinline__ uint32_t bhip_acx_clump(const uint8_t *rec, unsigned long long e) { return bhip_acx_rec(rec, e).x; }
 #endif
 
 #endif

@@ -3,7 +3,7 @@
 // What the reference computes with 16-lane SSE rows (burst.c:1003-1204 aded_*, 713-886 reScoreM_*,
 // 3238-3282 postScour*) is re-designed here for 64-wide wavefronts:
 //
-//   k_transpose_refs : database set-up (two reference layouts; the accelerator kernels are in bhip_acx.hip).
+//   k_transpose_refs : database set-up (the lane-major reference layout; the accelerator kernels are in bhip_acx.hip).
 //   k_pack_queries, k_build_peq : 4-bit packed queries; per query 16 match bit-vectors (one per reference symbol).
 //   k_seed_ranges, k_prefilter_cf / k_prefilter_mask : sampled words -> .acx list ranges -> per-query counts in LDS,
 //                      resolved to single reference lanes -> (query, lane) tasks, split by a lower bound on their
@@ -24,15 +24,16 @@
 // ------------------------------------------------------------------------------------------------
 // DB upload: byte transpose of the .edx clump area
 // src: for clump c, rows j = 0..ceil(L/2)-1 of 16 bytes (byte z = lane z, nibbles = positions 2j, 2j+1)
-// dst: for clump c, chunk t, lane z: 16 bytes, byte i = src row (16t+i) byte z  (zero beyond the clump)
+// dst_lane: for clump c, lane z, chunk t: 16 bytes, byte i = src row (16t+i) byte z  (zero beyond the clump)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_transpose_refs(const uint8_t *__restrict__ src, const uint64_t *__restrict__ src_off,
                                  const uint32_t *__restrict__ clump_len, const uint64_t *__restrict__ dst_off,
-                                 uint32_t n_clumps, uint4 *__restrict__ dst, uint4 *__restrict__ dst_lane) {
-	// one 16-thread group per (clump, chunk); grid-stride over clumps.  Two layouts of the same words: `dst` interleaves the
-	// 16 lanes of a chunk (16 threads of the clump-level kernels read 256 contiguous bytes), `dst_lane` keeps each lane's
-	// chunks contiguous inside the clump's area (the one-thread-per-lane kernels stream 16 B after 16 B of one cache line
-	// instead of touching a new 128-byte line for every 32 columns)
+                                 uint32_t n_clumps, uint4 *__restrict__ dst_lane) {
+	// one 16-thread group per (clump, chunk); grid-stride over clumps.  ONE layout: `dst_lane` keeps each lane's chunks
+	// contiguous inside the clump's area (the one-thread-per-lane kernels stream 16 B after 16 B of one cache line instead of
+	// touching a new 128-byte line for every 32 columns).  Rounds 1-3 kept a second, chunk-interleaved copy for the clump-level
+	// kernels (16 threads = 16 lanes reading 256 contiguous bytes); those kernels execute hundreds of instructions per 16-byte
+	// load and read the lane-major words just as well -- the copy was 31 GB of the metric's database for nothing
 	const uint32_t z = threadIdx.x & 15, g = threadIdx.x >> 4, gpb = blockDim.x >> 4;
 	for (uint32_t c = blockIdx.x; c < n_clumps; c += gridDim.x) {
 		const uint32_t L = clump_len[c], nrows = (L + 1) >> 1, nchunks = (L + 31) >> 5;
@@ -45,7 +46,6 @@ __global__ void k_transpose_refs(const uint8_t *__restrict__ src, const uint64_t
 				uint32_t b = row < nrows ? s[(uint64_t)row * 16 + z] : 0u;
 				w[i >> 2] |= b << (8 * (i & 3));
 			}
-			dst[(dst_off[c] + t) * 16 + z] = make_uint4(w[0], w[1], w[2], w[3]);
 			dst_lane[dst_off[c] * 16 + (uint64_t)z * nchunks + t] = make_uint4(w[0], w[1], w[2], w[3]);
 		}
 	}
@@ -578,7 +578,8 @@ __global__ __launch_bounds__(256) void k_seed_ranges(
 		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint32_t *__restrict__ qlist, uint32_t n_list,
 		BhipAcxView acx, int K, const uint32_t *__restrict__ plan, uint32_t W16,
 		uint2 *__restrict__ ranges, uint2 *__restrict__ hdr, const uint32_t *__restrict__ qpack, uint32_t qw, const uint16_t *__restrict__ qemac,
-		uint4 *__restrict__ qmeta, const uint32_t *__restrict__ qsix) {       // qmeta[list position] = (query entry, length | budget << 16, shared slot): one sector for the prefix sweep instead of three
+		uint4 *__restrict__ qmeta, const uint32_t *__restrict__ qsix,         // qmeta[list position] = (query entry, length | budget << 16, shared slot): one sector for the prefix sweep instead of three
+		uint32_t min_need, uint32_t drop_len) {                               // the longest lists of a query are left out while `need` stays >= min_need (0: never), lists shorter than drop_len stay
 	// (grid-stride: run ahead beside another batch's sweeps, the kernel is launched with a few blocks per CU only)
 	for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < (uint64_t)n_list * W16; t += (uint64_t)gridDim.x * 256) {
 	const uint32_t li = (uint32_t)(t / W16), j = (uint32_t)(t % W16);
@@ -630,6 +631,25 @@ __global__ __launch_bounds__(256) void k_seed_ranges(
 			r.x = (uint32_t)beg; r.y = n | (uint32_t)(beg >> 32) << 24;
 		}
 	}
+	// Every sampled word is one vote and `need` of the nwords votes survive E edits -- of ANY subset of n' of those words, need - (nwords - n')
+	// do.  The lists have very different lengths (and their sum is what the prefilter walks: the whole slope of a batch's time over
+	// the database size), so the longest ones are left out as long as the smaller `need` still says something.  The words of a query
+	// are W16 (8 or 16) consecutive lanes of one row; a left-out list is an empty range and one vote less in the header.
+	if (min_need && W16 <= 16u) {
+		const uint32_t n_mine = r.y & 0xFFFFFFu;
+		uint32_t rank = 0;
+		for (uint32_t k = 0; k < W16; ++k) {
+			const uint32_t n_k = (uint32_t)__shfl((int)n_mine, (int)k, (int)W16);
+			rank += (n_k > n_mine || (n_k == n_mine && k < j)) ? 1u : 0u;
+		}
+		const uint32_t allowed = need > min_need ? need - min_need : 0u;
+		const bool drop = rank < allowed && n_mine >= drop_len && n_mine > 0u;
+		const unsigned long long bal = __ballot(drop);
+		const uint32_t row0 = (threadIdx.x & 63u) - j;
+		const uint32_t ndrop = (uint32_t)__popcll((bal >> row0) & ((1ull << W16) - 1ull));
+		if (drop) r = make_uint2(0, 0);
+		need -= ndrop;
+	}
 	ranges[t] = r;
 	// header: need | words << 16 ; length | budget << 12 | (words one edit can destroy = ceil(K / stride)) << 20
 	if (j == 0) {
@@ -643,7 +663,7 @@ __global__ __launch_bounds__(256) void k_seed_ranges(
 template <int HTB>
 __global__ __launch_bounds__(64) void k_prefilter_mask(
 		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
-		const uint8_t *__restrict__ ent,   // 5-byte (clump, lane mask) records
+		const uint32_t *__restrict__ ent,   // 4-byte (clump, lane-set code) records
 		const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ clump_len, uint32_t tot_refs,
 		uint2 *__restrict__ tasks, uint32_t *__restrict__ n_tasks, uint32_t task_cap,
 		unsigned long long *__restrict__ ent_read,
@@ -660,8 +680,10 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 	__shared__ uint32_t s_ctr[12];          // [g] touched count, [4] staged, [5+g] candidates of group g
 	__shared__ uint32_t s_ovf[4];
 	__shared__ uint32_t s_dummy[64];
+	__shared__ uint16_t s_lut[256];         // lane-set code -> lane mask
 	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
 	s_dummy[lane] = 0;
+	for (uint32_t i = lane; i < 256; i += 64) s_lut[i] = (uint16_t)bhip_lane_code_mask(i);
 	for (uint32_t i = lane; i < 4 * (1u << HTB); i += 64) (&s_tab[0][0])[i] = 0;
 	for (uint32_t i = lane; i < 4 * CAND * 2; i += 64) (&s_cc[0][0][0])[i] = 0;
 	if (lane < 12) s_ctr[lane] = 0;
@@ -692,7 +714,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 		__syncthreads();
 	};
 	uint32_t tcnt = 0;                      // touched slots of this lane's own group (replicated in its 16 lanes)
-	auto lanes_add = [&](uint32_t tg, uint32_t c, uint32_t mask) {   // pass 2: only candidate clumps have a non-zero low byte
+	auto lanes_add = [&](uint32_t tg, uint32_t c, uint32_t code) {   // pass 2: only candidate clumps have a non-zero low byte
 		const uint32_t key = (c + 1u) << 8;
 		uint32_t slot = (c * 0x9E3779B1u) >> (32 - HTB);
 		const uint32_t *tab = s_tab[tg];
@@ -702,6 +724,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 			if ((v & 0xFFFFFF00u) == key) {
 				const uint32_t ci = v & 255u;
 				if (ci) {
+					const uint32_t mask = s_lut[code & 255u];
 					if (mask & 0xFFu) atomicAdd(&s_cc[tg][ci - 1][0], spread8(mask & 0xFFu));
 					if (mask >> 8) atomicAdd(&s_cc[tg][ci - 1][1], spread8(mask >> 8));
 				}
@@ -765,7 +788,8 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 				kk += __shfl(ex, kk + 2, 16) <= i ? 2u : 0u;
 				kk += __shfl(ex, kk + 1, 16) <= i ? 1u : 0u;
 				const unsigned long long addr = __shfl(dl, kk, 16) + i;
-				rec[u] = bhip_acx_rec_or_pad(ent, addr, i < T, hdr, sink);
+				const uint32_t v = bhip_acx_raw_or_pad(ent, addr, i < T, hdr, sink);
+				rec[u] = make_uint2(v == BHIP_REC_PAD ? 0xFFFFFFFFu : v & 0xFFFFFFu, v >> 24);      // .y = lane-set code
 			}
 		};
 		auto bump_block = [&](uint2 (&rec)[4]) {
@@ -789,7 +813,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 		group_scan(n0, T0, ex0);
 		const unsigned long long dl0 = beg - ex0;
 		const uint32_t nblk0 = wave_blocks(T0);
-		uint2 rc[PFM_RB][4];           // .x = clump, .y = lane mask | slot << 16
+		uint2 rc[PFM_RB][4];           // .x = clump, .y = lane-set code | slot << 16
 		#pragma unroll
 		for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) load4(ex0, dl0, T0, b, rc[b]);
 		PFM_T(6);
@@ -840,7 +864,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 				for (int u = 0; u < 4; ++u) ci[u] = s_tab[g][rc[b][u].y >> 16];      // slot 0 for padding records: harmless read
 				#pragma unroll
 				for (int u = 0; u < 4; ++u) {
-					const uint32_t tag = ci[u] & 255u, mask = rc[b][u].y & 0xFFFFu;
+					const uint32_t tag = ci[u] & 255u, mask = s_lut[rc[b][u].y & 255u];
 					if (mine && rc[b][u].x != 0xFFFFFFFFu && tag) {
 						if (mask & 0xFFu) atomicAdd(&s_cc[g][tag - 1][0], spread8(mask & 0xFFu));
 						if (mask >> 8) atomicAdd(&s_cc[g][tag - 1][1], spread8(mask >> 8));
@@ -934,10 +958,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
 	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);    // row_bcast:31 -> rows 2, 3
 	return (uint32_t)v;
 }
-template <int CB>
+template <int CB, int RBT>
 __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
-		const uint8_t *__restrict__ ent,   // 5-byte (clump, lane mask) records
+		const uint32_t *__restrict__ ent,   // 4-byte (clump, lane-set code) records
 		const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ clump_len, uint32_t tot_refs,
 		uint2 *__restrict__ tasks, uint32_t *__restrict__ n_tasks, uint32_t task_cap,
 		unsigned long long *__restrict__ ent_read,
@@ -952,13 +976,15 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 	__shared__ __attribute__((aligned(16))) uint32_t s_cnt[4][NCNT / 2];
 	__shared__ uint32_t s_key[4][LT];
 	__shared__ unsigned long long s_lc[4][LT][2];
-	__shared__ uint2 s_ring[4][RING];
+	__shared__ uint32_t s_ring[4][RING];                                   // raw record words
+	__shared__ uint16_t s_lut[256];                                        // lane-set code -> lane mask
 	__shared__ uint8_t s_used[4][LT];                                      // slots of the lane table in use (LT <= 256)
 	__shared__ uint2 s_stage[2][CF_STAGE];
 	__shared__ uint32_t s_ovf[4];
 	__shared__ uint32_t s_dummy[16];          // compare-and-swap target of idle lanes (never written: the compare value cannot match)
 	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
 	if (lane < 16) s_dummy[lane] = 0;
+	for (uint32_t i = lane; i < 256; i += 64) s_lut[i] = (uint16_t)bhip_lane_code_mask(i);
 	for (uint32_t i = lane; i < 4 * NCNT / 2; i += 64) (&s_cnt[0][0])[i] = 0;
 	for (uint32_t i = lane; i < 4 * LT; i += 64) { (&s_key[0][0])[i] = 0; (&s_lc[0][0][0])[2 * i] = 0; (&s_lc[0][0][0])[2 * i + 1] = 0; }
 	if (lane < 4) s_ovf[lane] = 0;
@@ -997,7 +1023,9 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 	auto flush = [&]() { flush_one(0); flush_one(1); };
 
 	const uint32_t n_quads = (n_list + 3) >> 2;
-	constexpr uint32_t RB = 2;               // blocks of 64 records per query that stay in registers between the two looks
+	constexpr uint32_t RB = RBT;             // blocks of 64 records per query that are fetched one quad ahead and stay in registers between the two looks
+	                                         // (2, 3 or 4: the launcher takes the smallest that holds the expected record stream of a query -- what lies
+	                                         // beyond is loaded where it is consumed, twice, with its latency exposed: 40 % of the kernel at 150 records per read)
 	// (cross-lane moves by data-parallel primitives and lane reads where the pattern is fixed: a shuffle is an LDS round trip, and
 	// this kernel's time is the sum of its dependent LDS round trips)
 #define GROUP_PICK(v, l) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x150 + (l), 0xF, 0xF, false))      /* lane l (0..15, a constant) of the own group: row_newbcast */
@@ -1017,7 +1045,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		excl = (uint32_t)ps - n;
 	};
 	auto wave_blocks = [&](uint32_t T) -> uint32_t { return (wave_max4(T) + 63) >> 6; };
-	auto load4 = [&](uint32_t ex, unsigned long long dl, uint32_t T, uint32_t b, uint2 (&rec)[4]) {      // see k_prefilter_mask
+	auto load4 = [&](uint32_t ex, unsigned long long dl, uint32_t T, uint32_t b, uint32_t (&rec)[4]) {      // see k_prefilter_mask
 		#pragma unroll
 		for (uint32_t u = 0; u < 4; ++u) {
 			const uint32_t i = (b * 4 + u) * 16 + gl;
@@ -1027,7 +1055,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 			kk += __shfl(ex, kk + 2, 16) <= i ? 2u : 0u;
 			kk += __shfl(ex, kk + 1, 16) <= i ? 1u : 0u;
 			const unsigned long long addr = __shfl(dl, kk, 16) + i;
-			rec[u] = bhip_acx_rec_or_pad(ent, addr, i < T, hdr, sink);
+			rec[u] = bhip_acx_raw_or_pad(ent, addr, i < T, hdr, sink);
 		}
 	};
 	// Software pipeline over the quads of this block: the header and list ranges (k_seed_ranges made them) are fetched TWO
@@ -1053,8 +1081,8 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		rg = make_uint2((uint32_t)r & mr, (uint32_t)(r >> 32) & mr);
 	};
 	auto fetch_hdr = [&](uint32_t quad, uint2 &hd, uint2 &rg) { unsigned long long h, r; fetch_hdr_issue(quad, h, r); fetch_hdr_finish(quad, h, r, hd, rg); };
-	// issue: the raw words of the first RB blocks of a quad's record stream (nothing here waits for them); sh = byte shift of each
-	auto start_stream = [&](uint32_t quad, const uint2 &rg, uint32_t &T, uint32_t &ex, unsigned long long &dl, uint32_t &nblk, uint2 (&raw)[RB][4], uint32_t (&sh)[RB]) -> uint32_t {
+	// issue: the record words of the first RB blocks of a quad's record stream (nothing here waits for them)
+	auto start_stream = [&](uint32_t quad, const uint2 &rg, uint32_t &T, uint32_t &ex, unsigned long long &dl, uint32_t &nblk, uint32_t (&raw)[RB][4]) -> uint32_t {
 		const bool lv = quad < n_quads && quad * 4 + g < n_list;
 		const unsigned long long beg = lv ? ((unsigned long long)rg.x | (unsigned long long)(rg.y >> 24) << 32) : 0ull;
 		const uint32_t n0 = lv ? rg.y & 0xFFFFFFu : 0u;
@@ -1096,33 +1124,29 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		for (uint32_t j = 0; j < RB * 4; ++j) base[j] = __shfl(dl, kk[j], 16);
 		#pragma unroll
 		for (uint32_t b = 0; b < RB; ++b) {
-			sh[b] = 0;
 			#pragma unroll
 			for (uint32_t u = 0; u < 4; ++u) {
 				const uint32_t i = (b * 4 + u) * 16 + gl;
-				uint32_t s8;
-				raw[b][u] = bhip_acx_rec_issue(ent, base[b * 4 + u] + i, i < T, hdr, s8);
-				sh[b] |= s8 << (5 * u);                  // 0, 8, 16 or 24: five bits each
+				raw[b][u] = bhip_acx_raw_issue(ent, base[b * 4 + u] + i, i < T, hdr);
 			}
 		}
 		return n0;
 	};
-	// consume: raw words -> (clump, mask) records, padding where the stream has ended
-	auto finish_stream = [&](uint32_t T, const uint2 (&raw)[RB][4], const uint32_t (&sh)[RB], uint2 (&r)[RB][4]) {
+	// consume: padding where the stream has ended
+	auto finish_stream = [&](uint32_t T, const uint32_t (&raw)[RB][4], uint32_t (&r)[RB][4]) {
 		#pragma unroll
 		for (uint32_t b = 0; b < RB; ++b) {
 			#pragma unroll
-			for (uint32_t u = 0; u < 4; ++u) r[b][u] = bhip_acx_rec_decode(raw[b][u], (sh[b] >> (5 * u)) & 31u, (b * 4 + u) * 16 + gl < T, sink);
+			for (uint32_t u = 0; u < 4; ++u) r[b][u] = bhip_acx_raw_finish(raw[b][u], (b * 4 + u) * 16 + gl < T, sink);
 		}
 	};
 	uint2 hd_c, rg_c, hd_n, rg_n;
 	fetch_hdr(blockIdx.x, hd_c, rg_c);
 	fetch_hdr(blockIdx.x + gridDim.x, hd_n, rg_n);
 	uint32_t T0, ex0, nblk0; unsigned long long dl0;
-	uint2 rc[RB][4], raw[RB][4];
-	uint32_t shf[RB];
-	uint32_t n0 = start_stream(blockIdx.x, rg_c, T0, ex0, dl0, nblk0, raw, shf);
-	finish_stream(T0, raw, shf, rc);
+	uint32_t rc[RB][4], raw[RB][4];          // record words: clump | lane-set code << 24, BHIP_REC_PAD beyond the stream
+	uint32_t n0 = start_stream(blockIdx.x, rg_c, T0, ex0, dl0, nblk0, raw);
+	finish_stream(T0, raw, rc);
 	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
 		const uint32_t li = quad * 4 + g;
 		const bool live = li < n_list;
@@ -1130,7 +1154,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		unsigned long long h_raw, r_raw;
 		fetch_hdr_issue(quad + 2 * gridDim.x, h_raw, r_raw);
 		uint32_t T1, ex1, nblk1; unsigned long long dl1;
-		const uint32_t n1 = start_stream(quad + gridDim.x, rg_n, T1, ex1, dl1, nblk1, raw, shf);
+		const uint32_t n1 = start_stream(quad + gridDim.x, rg_n, T1, ex1, dl1, nblk1, raw);
 		const uint32_t need = hd.x & 0xFFFFu, nwords = live ? hd.x >> 16 : 0u, len = hd.y & 0xFFFu;
 		const uint32_t budget = (hd.y >> 12) & 255u, dper = (hd.y >> 20) & 15u ? (hd.y >> 20) & 15u : 1u;
 		const uint32_t thr = need ? need : 1u;
@@ -1140,10 +1164,10 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 			if (live && j < nwords) r = ranges[(size_t)li * W16 + j];
 			beg = (unsigned long long)r.x | (unsigned long long)(r.y >> 24) << 32; n = r.y & 0xFFFFFFu;
 		};
-		auto count4 = [&](const uint2 (&rec)[4]) {     // phase A: approximate counters, no return values
+		auto count4 = [&](const uint32_t (&rec)[4]) {     // phase A: approximate counters, no return values
 			#pragma unroll
-			for (int u = 0; u < 4; ++u) if (rec[u].x != 0xFFFFFFFFu) {
-				const uint32_t h = (rec[u].x * 0x9E3779B1u) >> (32 - CB);
+			for (int u = 0; u < 4; ++u) if (rec[u] != BHIP_REC_PAD) {
+				const uint32_t h = ((rec[u] & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - CB);
 				atomicAdd(&s_cnt[g][h >> 1], 1u << (16 * (h & 1u)));
 			}
 		};
@@ -1153,9 +1177,10 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 			const uint32_t take = pending < 16 ? pending : 16;
 			const bool active = gl < take;
 			const uint32_t hpos = (head + gl) & (RING - 1);
-			const uint2 rec = active ? s_ring[g][hpos] : make_uint2(0, 0);
-			const uint32_t key = rec.x + 1u;
-			uint32_t slot = (rec.x * 0x85EBCA6Bu) >> (32 - (CB <= 9 ? 6 : (CB == 10 ? 7 : 8)));
+			const uint32_t rec = active ? s_ring[g][hpos] : 0u;
+			const uint32_t clump = rec & 0xFFFFFFu, mask = s_lut[rec >> 24];
+			const uint32_t key = clump + 1u;
+			uint32_t slot = (clump * 0x85EBCA6Bu) >> (32 - (CB <= 9 ? 6 : (CB == 10 ? 7 : 8)));
 			bool act = active, found = false, fresh = false;
 			for (uint32_t probes = 0; __any(act) && probes < LT; ++probes) {
 				const uint32_t old = atomicCAS(act ? &s_key[g][slot] : &s_dummy[gl], act ? 0u : 0xFFFFFFFFu, key);
@@ -1172,28 +1197,27 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 				nused += __popc(m16);
 			}
 			if (found) {
-				const uint32_t mask = rec.y;
 				if (mask & 0xFFu) atomicAdd(&s_lc[g][slot][0], spread8(mask & 0xFFu));
 				if (mask >> 8) atomicAdd(&s_lc[g][slot][1], spread8(mask >> 8));
 			}
 			head = (head + take) & (RING - 1);
 			pending -= take;
 		};
-		auto offer4 = [&](const uint2 (&rec)[4]) {    // phase B: survivors of the counter test go to the ring
+		auto offer4 = [&](const uint32_t (&rec)[4]) {    // phase B: survivors of the counter test go to the ring
 			uint32_t cv[4];
 			#pragma unroll
 			for (int u = 0; u < 4; ++u) {
-				const uint32_t h = rec[u].x != 0xFFFFFFFFu ? (rec[u].x * 0x9E3779B1u) >> (32 - CB) : 0u;
+				const uint32_t h = rec[u] != BHIP_REC_PAD ? ((rec[u] & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - CB) : 0u;
 				cv[u] = (s_cnt[g][h >> 1] >> (16 * (h & 1u))) & 0xFFFFu;
 			}
 			#pragma unroll
 			for (int u = 0; u < 4; ++u) {
-				const bool surv = rec[u].x != 0xFFFFFFFFu && cv[u] >= thr;
+				const bool surv = rec[u] != BHIP_REC_PAD && cv[u] >= thr;
 				const uint32_t m16 = (uint32_t)(__ballot(surv) >> (lane & 48u)) & 0xFFFFu;
 				if (surv) {
 					uint32_t pos = head + pending + __popc(m16 & ((1u << gl) - 1u));
 					pos &= RING - 1;
-					s_ring[g][pos] = make_uint2(rec[u].x, rec[u].y & 0xFFFFu);
+					s_ring[g][pos] = rec[u];
 				}
 				pending += __popc(m16);
 				if (gl == 0) my_surv += __popc(m16);
@@ -1206,27 +1230,38 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		// ---- phase A over every record of the query
 		#pragma unroll
 		for (uint32_t b = 0; b < RB; ++b) if (b < nblk0) count4(rc[b]);
-		for (uint32_t b = RB; b < nblk0; ++b) { uint2 rec[4]; load4(ex0, dl0, T0, b, rec); count4(rec); }
+		for (uint32_t b = RB; b < nblk0; b += 2) {      // (two blocks' loads in flight together)
+			uint32_t rec[4], rec2[4];
+			load4(ex0, dl0, T0, b, rec); load4(ex0, dl0, T0, b + 1, rec2);      // (a block beyond the stream is all padding)
+			count4(rec); count4(rec2);
+		}
+		uint32_t gtot = T0;                        // records of this group's query (16-bit counters: beyond 65 535 the query takes the dense fallback)
 		for (uint32_t base = 16; base < maxw; base += 16) {
 			unsigned long long xb; uint32_t xn, T, ex;
 			word_range(base + gl, xb, xn);
 			my_ent += xn;
 			group_scan(xn, T, ex);
+			gtot = gtot + T < gtot ? 0xFFFFFFFFu : gtot + T;
 			const uint32_t nb = wave_blocks(T);
-			for (uint32_t b = 0; b < nb; ++b) { uint2 rec[4]; load4(ex, xb - ex, T, b, rec); count4(rec); }
+			for (uint32_t b = 0; b < nb; ++b) { uint32_t rec[4]; load4(ex, xb - ex, T, b, rec); count4(rec); }
 		}
+		if (gtot > 65535u && gl == 0) s_ovf[g] = 1;
 		__syncthreads();
 		PFM_T(7);
 		// ---- phase B: second look at every record (registers for the first blocks, L2 for the rest)
 		#pragma unroll
 		for (uint32_t b = 0; b < RB; ++b) if (b < nblk0) offer4(rc[b]);
-		for (uint32_t b = RB; b < nblk0; ++b) { uint2 rec[4]; load4(ex0, dl0, T0, b, rec); offer4(rec); }
+		for (uint32_t b = RB; b < nblk0; b += 2) {
+			uint32_t rec[4], rec2[4];
+			load4(ex0, dl0, T0, b, rec); load4(ex0, dl0, T0, b + 1, rec2);
+			offer4(rec); offer4(rec2);
+		}
 		for (uint32_t base = 16; base < maxw; base += 16) {
 			unsigned long long xb; uint32_t xn, T, ex;
 			word_range(base + gl, xb, xn);
 			group_scan(xn, T, ex);
 			const uint32_t nb = wave_blocks(T);
-			for (uint32_t b = 0; b < nb; ++b) { uint2 rec[4]; load4(ex, xb - ex, T, b, rec); offer4(rec); }
+			for (uint32_t b = 0; b < nb; ++b) { uint32_t rec[4]; load4(ex, xb - ex, T, b, rec); offer4(rec); }
 		}
 		PFM_T(2);
 		while (__any(pending > 0)) c_round();
@@ -1343,7 +1378,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		fetch_hdr_finish(quad + 2 * gridDim.x, h_raw, r_raw, hd_nn, rg_nn);
 		hd_c = hd_n; hd_n = hd_nn; rg_n = rg_nn;
 		T0 = T1; ex0 = ex1; dl0 = dl1; nblk0 = nblk1; n0 = n1;
-		finish_stream(T0, raw, shf, rc);          // the records fetched during this iteration are first looked at here
+		finish_stream(T0, raw, rc);          // the records fetched during this iteration are first looked at here
 		PFM_T(6);
 	}
 	flush();
@@ -1355,17 +1390,17 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 	if (n_list == 0xFFFFFFFFu) { fb_list[0] = sink; fb_list[1] = sink_h; }       // never: keeps the record loads unconditional
 	if (my_units) { atomicAdd(unit_sum, my_units); atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
 }
-#define BHIP_INST_PFCF(CB) \
-	template __global__ void k_prefilter_cf<CB>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, \
+#define BHIP_INST_PFCF(CB, RB) \
+	template __global__ void k_prefilter_cf<CB, RB>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, \
 		uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *, \
 		uint2 *, uint32_t *, int);
-BHIP_INST_PFCF(9) BHIP_INST_PFCF(10) BHIP_INST_PFCF(11)
+BHIP_INST_PFCF(9, 2) BHIP_INST_PFCF(9, 3) BHIP_INST_PFCF(9, 4) BHIP_INST_PFCF(10, 2) BHIP_INST_PFCF(10, 4) BHIP_INST_PFCF(11, 2) BHIP_INST_PFCF(11, 4)
 
-template __global__ void k_prefilter_mask<9>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+template __global__ void k_prefilter_mask<9>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, uint32_t);
-template __global__ void k_prefilter_mask<10>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+template __global__ void k_prefilter_mask<10>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, uint32_t);
-template __global__ void k_prefilter_mask<11>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+template __global__ void k_prefilter_mask<11>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, uint32_t);
 
 // ------------------------------------------------------------------------------------------------
@@ -1460,10 +1495,10 @@ __global__ __launch_bounds__(256) void k_myers(
 		}
 		int score = (int)m, bestS = 0x7FFFFFFF;
 		uint32_t first = 0, last = 0;
-		const uint4 *rp = ref + ref_off[c] * 16 + z;
+		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)z * nchunks;      // lane-major: [clump][lane][chunk]
 		const uint32_t *tab = &s_peq[g][0];
 		for (uint32_t t = 0; t < nchunks; ++t) {
-			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint4 ch = rp[t];
 			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
 			#pragma unroll
 			for (int i = 0; i < 32; ++i) {
@@ -1550,10 +1585,10 @@ __global__ __launch_bounds__(256) void k_myers_prefix(
 		}
 		int score = (int)P;
 		uint32_t g_first = 0xFFFFFFFFu, g_last = 0;
-		const uint4 *rp = ref + ref_off[c] * 16 + z;
+		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)z * nchunks;      // lane-major: [clump][lane][chunk]
 		const uint32_t *tab = &s_peq[g][0];
 		for (uint32_t t = 0; t < nchunks; ++t) {
-			const uint4 ch = rp[(uint64_t)t * 16];
+			const uint4 ch = rp[t];
 			const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
 			#pragma unroll
 			for (int i8 = 0; i8 < 4; ++i8) {
@@ -2004,12 +2039,6 @@ BHIP_INST_MYERS(16) BHIP_INST_MYERS(32)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t sat8u(uint32_t v) { return v > 255u ? 255u : v; }
 
-// 8 consecutive reference symbols (positions 8*j8 .. 8*j8+7 of lane z) as one dword of nibbles; 0 outside the clump
-__device__ __forceinline__ uint32_t ref_dword(const uint32_t *__restrict__ refw, uint64_t clump_base, uint32_t z, int j8, uint32_t nchunks) {
-	if (j8 < 0 || (uint32_t)j8 >= nchunks * 4) return 0u;
-	return refw[((clump_base + ((uint32_t)j8 >> 2)) * 16 + z) * 4 + ((uint32_t)j8 & 3)];
-}
-
 // 32 consecutive reference symbols of one lane (chunk t4 of the lane-major copy); zeros outside the clump
 __device__ __forceinline__ uint4 ref_chunk_lane(const uint32_t *__restrict__ refw_lane, uint64_t clump_base, uint32_t z, int t4, uint32_t nchunks) {
 	if (t4 < 0 || (uint32_t)t4 >= nchunks) return make_uint4(0, 0, 0, 0);
@@ -2310,9 +2339,9 @@ __global__ __launch_bounds__(64) void k_rescore(
 		if (pre) {
 			const uint32_t *qp = qpack + (uint64_t)q * qw;
 			for (uint32_t j = 0; j < (uint32_t)(m + 7) >> 3; ++j) s_q[j * 64] = qp[j];
-			for (int j = j8_0; j <= j8_1; ++j) s_r[(uint32_t)(j - j8_0) * 64] = ref_dword(refw, cbase, z, j, nchunks);
+			for (int j = j8_0; j <= j8_1; ++j) s_r[(uint32_t)(j - j8_0) * 64] = ref_dword_lane(refw, cbase, z, j, nchunks);
 		}
-		auto rdw = [&](int j8) -> uint32_t { return pre ? s_r[(uint32_t)(j8 - j8_0) * 64] : ref_dword(refw, cbase, z, j8, nchunks); };
+		auto rdw = [&](int j8) -> uint32_t { return pre ? s_r[(uint32_t)(j8 - j8_0) * 64] : ref_dword_lane(refw, cbase, z, j8, nchunks); };
 		// row 0: D = 0 wherever the column exists (burst.c:4052), else invalid
 		for (int k = 0; k <= Wd; ++k) {
 			const int x = dlo + k;

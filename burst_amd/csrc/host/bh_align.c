@@ -113,6 +113,22 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 		if (r0[i] < b) { nBatches += (b - r0[i] + batch_uniq - 1) / batch_uniq; totU += b - r0[i]; }
 	}
 	if (!nBatches) return BH_OK;
+	/* A job of one or two batches (a rank's share of a short job: 10 M reads over 8 GPUs are 1.25 M reads each) has nothing to overlap
+	 * its staging, seed lookups and match profiles with -- they are paid in full in front of the chain.  Cut into a few pieces, piece
+	 * k + 1 is staged and seeded while piece k is aligned (BURST_HOST_PIECES: pieces of such a job, default 4; 1 = leave it whole). */
+	if (nBatches <= 2 && totU >= ((uint64_t)1 << 18)) {
+		const char *ev = getenv("BURST_HOST_PIECES");
+		const uint64_t pieces = ev && atoi(ev) > 0 ? (uint64_t)atoi(ev) : 4u;
+		const uint64_t per = (totU + pieces - 1) / pieces;
+		if (pieces > 1 && per < batch_uniq) {
+			batch_uniq = per < ((uint64_t)1 << 16) ? ((uint64_t)1 << 16) : per;
+			nBatches = 0;
+			for (uint32_t i = 0; i < n_ranges; ++i) {
+				const uint64_t b = r1[i] > Q->numUniq ? Q->numUniq : r1[i];
+				if (r0[i] < b) nBatches += (b - r0[i] + batch_uniq - 1) / batch_uniq;
+			}
+		}
+	}
 	uint64_t *bu = malloc(nBatches * 2 * sizeof(*bu));
 	if (!bu) return bh_set_error(BH_E_OOM, "OOM:batches");
 	{

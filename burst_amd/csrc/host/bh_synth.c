@@ -6,6 +6,11 @@
 #include "burst_host.h"
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <sys/uio.h>
+#include <unistd.h>
+
+static double bh_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 static inline uint64_t rng_next(uint64_t *s) {            /* xorshift64* */
 	uint64_t x = *s; x ^= x >> 12; x ^= x << 25; x ^= x >> 27; *s = x;
@@ -14,50 +19,85 @@ static inline uint64_t rng_next(uint64_t *s) {            /* xorshift64* */
 static inline double rng_unit(uint64_t *s) { return (rng_next(s) >> 11) * (1.0 / 9007199254740992.0); }
 static const char BASES[4] = {'A', 'C', 'G', 'T'};
 
+static void synth_family(char *w0, size_t *used, char *base, uint32_t b, uint32_t n_variants, uint32_t length, double rate, uint64_t seed) {
+	uint64_t s = (seed * 0x9E3779B97F4A7C15ULL + 0x1234567ULL) ^ ((uint64_t)(b + 1) * 0xD6E8FEB86659FD93ULL);
+	if (!s) s = 1;
+	(void)rng_next(&s); (void)rng_next(&s);
+	char *w = w0;
+	for (uint32_t i = 0; i < length; ++i) base[i] = BASES[rng_next(&s) & 3];
+	for (uint32_t v = 0; v < n_variants; ++v) {
+		w += sprintf(w, ">ref_b%u_v%u\n", b, v);
+		for (uint32_t i = 0; i < length; ++i) {
+			if (v && rng_unit(&s) < rate) {
+				uint32_t kk = (uint32_t)(rng_next(&s) % 5);
+				if (kk < 3) { char c; do c = BASES[rng_next(&s) & 3]; while (c == base[i]); *w++ = c; }
+				else if (kk == 3) { /* deletion */ }
+				else { *w++ = BASES[rng_next(&s) & 3]; *w++ = base[i]; }
+			} else *w++ = base[i];
+		}
+		*w++ = '\n';
+	}
+	*used = (size_t)(w - w0);
+}
+
 int bh_synth_refs(const char *fasta_out, uint32_t n_base, uint32_t n_variants, uint32_t length, double rate, uint64_t seed) {
 	FILE *o = fopen(fasta_out, "wb");
 	if (!o) return bh_set_error(BH_E_IO, "cannot write %s", fasta_out);
-	setvbuf(o, NULL, _IOFBF, 1 << 22);
-	/* every base sequence has a generator of its own (seeded by its number): blocks of families are made side by side and
-	 * written in order, so the file does not depend on the number of threads */
-	const uint32_t BLK = 4096;
+	setvbuf(o, NULL, _IONBF, 0);
+	/* every base sequence has a generator of its own (seeded by its number), so the file does not depend on the number of threads:
+	 * blocks of families are made side by side, squeezed together and written in order -- one thread writes block k while the team
+	 * makes block k + 1 (two buffers) */
+	const uint32_t BLK = 32768;
 	const size_t per_fam = (size_t)n_variants * (2 * (size_t)length + 48);
-	char *buf = malloc((size_t)BLK * per_fam);
-	size_t *used = malloc((size_t)BLK * sizeof(*used));
-	if (!buf || !used) { free(buf); free(used); fclose(o); return bh_set_error(BH_E_OOM, "OOM:synth"); }
-	for (uint32_t b0 = 0; b0 < n_base; b0 += BLK) {
-		const uint32_t nb = n_base - b0 < BLK ? n_base - b0 : BLK;
+	char *buf[2] = {malloc((size_t)BLK * per_fam), malloc((size_t)BLK * per_fam)};
+	size_t *used = malloc((size_t)BLK * sizeof(*used)), *at = malloc(((size_t)BLK + 1) * sizeof(*at));      /* piece lengths of the two buffers */
+	if (!buf[0] || !buf[1] || !used || !at) { free(buf[0]); free(buf[1]); free(used); free(at); fclose(o); return bh_set_error(BH_E_OOM, "OOM:synth"); }
+	const int dbg = getenv("BURST_HOST_DEBUG") != NULL;
+	double t_make = 0, t_all = bh_now();
+	/* the pieces of a block (one per family, at a fixed stride) go to the file with writev: no copy to squeeze them together */
+	size_t *used2[2] = {used, at};
+	uint32_t pend_n = 0; int pend_buf = 0, io_err = 0;
+	const int fd = fileno(o);
+	for (uint32_t b0 = 0, it = 0; b0 < n_base || pend_n; b0 += BLK, ++it) {
+		const uint32_t nb = b0 < n_base ? (n_base - b0 < BLK ? n_base - b0 : BLK) : 0;
+		char *mine = buf[it & 1];
+		size_t *mused = used2[it & 1];
+		const double t0 = bh_now();
 		#pragma omp parallel
 		{
 			char *base = malloc(length + 1);
-			#pragma omp for schedule(dynamic, 16)
-			for (uint32_t k = 0; k < nb; ++k) {
-				const uint32_t b = b0 + k;
-				uint64_t s = (seed * 0x9E3779B97F4A7C15ULL + 0x1234567ULL) ^ ((uint64_t)(b + 1) * 0xD6E8FEB86659FD93ULL);
-				if (!s) s = 1;
-				(void)rng_next(&s); (void)rng_next(&s);
-				char *w = buf + (size_t)k * per_fam;
-				for (uint32_t i = 0; i < length; ++i) base[i] = BASES[rng_next(&s) & 3];
-				for (uint32_t v = 0; v < n_variants; ++v) {
-					w += sprintf(w, ">ref_b%u_v%u\n", b, v);
-					for (uint32_t i = 0; i < length; ++i) {
-						if (v && rng_unit(&s) < rate) {
-							uint32_t kk = (uint32_t)(rng_next(&s) % 5);
-							if (kk < 3) { char c; do c = BASES[rng_next(&s) & 3]; while (c == base[i]); *w++ = c; }
-							else if (kk == 3) { /* deletion */ }
-							else { *w++ = BASES[rng_next(&s) & 3]; *w++ = base[i]; }
-						} else *w++ = base[i];
+			/* the block before goes to the file meanwhile (one thread; the others start on the loop at once) */
+			#pragma omp single nowait
+			{
+				struct iovec iov[512];
+				const char *pb = buf[pend_buf]; const size_t *pu = used2[pend_buf];
+				for (uint32_t k = 0; k < pend_n && !io_err;) {
+					int n = 0; size_t want = 0;
+					for (; n < 512 && k + (uint32_t)n < pend_n; ++n) { iov[n].iov_base = (void *)(pb + (size_t)(k + (uint32_t)n) * per_fam); iov[n].iov_len = pu[k + (uint32_t)n]; want += pu[k + (uint32_t)n]; }
+					ssize_t got = writev(fd, iov, n);
+					if (got < 0) { io_err = 1; break; }
+					if ((size_t)got < want) {      /* short write: finish this group piece by piece */
+						size_t done = (size_t)got;
+						for (int j = 0; j < n && !io_err; ++j) {
+							if (done >= iov[j].iov_len) { done -= iov[j].iov_len; continue; }
+							const char *p = (const char *)iov[j].iov_base + done; size_t left = iov[j].iov_len - done; done = 0;
+							while (left) { ssize_t g = write(fd, p, left); if (g <= 0) { io_err = 1; break; } p += g; left -= (size_t)g; }
+						}
 					}
-					*w++ = '\n';
+					k += (uint32_t)n;
 				}
-				used[k] = (size_t)(w - (buf + (size_t)k * per_fam));
 			}
+			#pragma omp for schedule(dynamic, 64)
+			for (uint32_t k = 0; k < nb; ++k) synth_family(mine + (size_t)k * per_fam, &mused[k], base, b0 + k, n_variants, length, rate, seed);
 			free(base);
 		}
-		for (uint32_t k = 0; k < nb; ++k) fwrite(buf + (size_t)k * per_fam, 1, used[k], o);
+		pend_n = nb; pend_buf = (int)(it & 1);
+		t_make += bh_now() - t0;
+		if (!nb) break;
 	}
-	free(buf); free(used);
-	if (fclose(o)) return bh_set_error(BH_E_IO, "write failed: %s", fasta_out);
+	free(buf[0]); free(buf[1]); free(used); free(at);
+	if (dbg) fprintf(stderr, "[host] synthetic references: %.2f s (%.2f s in the generate + write-behind loop)\n", bh_now() - t_all, t_make);
+	if (fclose(o) || io_err) return bh_set_error(BH_E_IO, "write failed: %s", fasta_out);
 	return BH_OK;
 }
 

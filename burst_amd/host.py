@@ -8,7 +8,8 @@ import numpy as np
 from . import capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libburst_host.so")
+# BURST_AMD_LIBDIR: a directory with another build of the two libraries (tools/build_prof.sh: the phase-timer build)
+LIB_PATH = os.path.join(os.environ.get("BURST_AMD_LIBDIR") or _HERE, "libburst_host.so")
 MODES = {"FORAGE": 0, "BEST": 1, "ALLPATHS": 2, "CAPITALIST": 3, "ANY": 4}
 REP_MERGED_LIST, REP_NO_DUPE_HUNT = 1, 2
 

@@ -49,3 +49,34 @@ def test_argument_validation():
     with pytest.raises(capi.BurstHipError) as e:
         capi.Device(np.zeros(64, np.uint8), np.array([8], np.uint32), 1, np.zeros(256, np.uint8), xalpha=1)
     assert e.value.code == capi.BHIP_E_ARG
+
+
+def test_lane_set_codes_cover_every_mask(tmp_path):
+    """the top byte of a 4-byte accelerator record (burst_amd/csrc/bhip_lanecode.h): every 16-bit lane mask gets the code of a
+    superset, exact for one and two lanes, the smallest superset any code offers beyond; 167 codes, no two alike"""
+    import ctypes as C
+    import subprocess
+    import numpy as np
+    src = tmp_path / "lc.c"
+    src.write_text('#include "bhip_lanecode.h"\n'
+                   'unsigned enc(unsigned m) { return bhip_lane_mask_code(m); }\n'
+                   'unsigned dec(unsigned c) { return bhip_lane_code_mask(c); }\n')
+    so = tmp_path / "lc.so"
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-I", os.path.join(ROOT, "burst_amd", "csrc"), str(src), "-o", str(so)])
+    L = C.CDLL(str(so))
+    L.enc.restype = L.dec.restype = C.c_uint
+    dec = np.array([L.dec(c) for c in range(256)], np.uint32)
+    assert len(set(dec[:167].tolist())) == 167 and dec[166] == 0xFFFF and np.all(dec[167:] == 0xFFFF)
+    pc = np.array([bin(x).count("1") for x in range(1 << 16)], np.uint32)
+    masks = np.arange(1, 1 << 16, dtype=np.uint32)
+    codes = np.array([L.enc(int(m)) for m in masks], np.uint32)
+    assert codes.max() == 166 and L.enc(0) == 166
+    got = dec[codes]
+    assert np.all(got & masks == masks)
+    assert np.all(got[pc[masks] <= 2] == masks[pc[masks] <= 2])
+    # no code names a smaller superset
+    best = np.full(len(masks), 17, np.uint32)
+    for c in range(167):
+        ok = (dec[c] & masks) == masks
+        best[ok] = np.minimum(best[ok], pc[dec[c]])
+    assert np.array_equal(pc[got], best)

@@ -117,3 +117,58 @@ def test_device_builder_differential_against_the_reference(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(gl.ROOT, "tools", "db_diff.py"), "6", str(tmp_path)], env=dict(os.environ, DB_DIFF_EXPECT_DEVICE="1"),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-4000:]
+
+
+@pytest.mark.parametrize("build", [True, False])
+def test_record_lane_sets_are_the_coded_exact_masks(build):
+    """the 4-byte records carry a lane-SET CODE: exact for one and two lanes, the smallest enclosing quad pattern beyond
+    (burst_amd/csrc/bhip_lanecode.h).  Families of 1 .. 6 near-identical sequences inside a clump make every class of set occur;
+    the exported masks must be exactly decode(encode(true lane mask)) -- built on the device and derived for a loaded .acx."""
+    import dbutil
+    import oraclelib as ol
+    from burst_amd import capi, synth
+    rng = np.random.default_rng(17)
+    seqs = []
+    while len(seqs) < 16 * 24:
+        base = rng.integers(1, 5, size=260, dtype=np.uint8)
+        seqs += synth.mutate_family(base, int(rng.integers(1, 7)), 0.02, rng)
+    seqs = seqs[:16 * 24]
+    order = rng.permutation(len(seqs))          # families scattered over the lanes of their clumps
+    seqs = [seqs[i] for i in order]
+    K = 10
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lens, entries, offs = dbutil.build_acx(seqs, K)
+    # true lane masks per (word, clump) in list order
+    pairs = {}
+    for i, s in enumerate(seqs):
+        s = np.asarray(s, np.int64) - 1
+        w = np.zeros(len(s) - K + 1, np.int64)
+        for k in range(K):
+            w = (w << 2) | s[k:len(s) - K + 1 + k]
+        for x in np.unique(w):
+            pairs[(int(x), i // 16)] = pairs.get((int(x), i // 16), 0) | (1 << (i % 16))
+    words = np.repeat(np.arange(len(lens)), lens)
+    true = np.array([pairs[(int(w), int(c))] for w, c in zip(words, entries)], np.uint32)
+
+    def enc(m):
+        pc = bin(m).count("1")
+        if pc <= 2:
+            return m
+        qm = [q for q in range(4) if (m >> (4 * q)) & 15]
+        if len(qm) == 1:
+            sub = (m >> (4 * qm[0])) & 15
+            return (sub if bin(sub).count("1") == 3 else 15) << (4 * qm[0])
+        return sum(15 << (4 * q) for q in qm)
+    want = np.array([enc(int(m)) for m in true], np.uint32)
+    lut = ol.score_lut(1)
+    if build:
+        dev = capi.Device(packed, clump_len, tot, lut, K=K, build_acx=True)
+    else:
+        dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=dbutil.pack_acx_lists(lens, entries, 1), acx_fmt=1, K=K)
+    lens_d, clumps_d, masks_d, _ = dev.acx_export(K)
+    dev.close()
+    assert np.array_equal(lens_d, lens) and np.array_equal(clumps_d, entries)
+    assert np.array_equal(masks_d.astype(np.uint32), want)
+    # every class occurs: single lanes, pairs, quad patterns, unions of quads
+    pcs = np.array([bin(int(m)).count("1") for m in true])
+    assert (pcs == 1).any() and (pcs == 2).any() and (pcs >= 3).any() and (want != true).any()

@@ -411,7 +411,7 @@ print("ok")
         assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
         acc = [ln for ln in r.stderr.splitlines() if "[bhip] accelerator:" in ln]
         assert acc and ("first entry number %s)" % bias) in acc[-1], acc
-        assert "records 5 B" in acc[-1]
+        assert "records 4 B" in acc[-1]
 
 
 @pytest.mark.parametrize("junk", [False, True])
