@@ -48,28 +48,167 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# database sizes `--db-scale auto` chooses from: the metric's own (31.5 GB .edx), the largest of round 3's slope runs, ... the
+# database of rounds 1-3 (2.77 GB)
+AUTO_SCALES = (11.37, 7.0, 4.0, 2.0, 1.0)
+# per unit of scale (measured, profiles/): 4.48 Gbp of references = 4.6 GB of FASTA, .edx 2.77 GB, 4.75 G accelerator entries
+# (device: 4 B each; the reference's .acx file: 3 B each + a 4.3 GB length table), 4.9 GB of offset lines on the device whatever the size
+UNIT_FASTA, UNIT_EDX, UNIT_ENTRIES = 4.6e9, 2.77e9, 4.75e9
+
+
+def memory_limit():
+    """bytes of host memory this job may use: the machine's, or the container's (cgroup v2 / v1) when that is less -- files in a
+    RAM-backed work directory (/dev/shm) count against it"""
+    try:
+        lim = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        lim = 64 << 30
+    for f in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            v = open(f).read().strip()
+            if v.isdigit() and 0 < int(v) < lim:
+                lim = int(v)
+        except OSError:
+            pass
+    return lim
+
+
+def memory_in_use():
+    for f in ("/sys/fs/cgroup/memory.current", "/sys/fs/cgroup/memory/memory.usage_in_bytes"):
+        try:
+            return int(open(f).read().strip())
+        except (OSError, ValueError):
+            pass
+    return 0
+
+
+def effective_cores():
+    """host cores this job can really use: the visible ones, or the container's CPU quota (cgroup cpu.max) when that is less"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(round(int(q) / int(per)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def sizes_at(sc):
+    """(bytes of the .edx, of the device copy, of the .acx file the reference reads) at a database scale"""
+    edx = sc * UNIT_EDX
+    return edx, edx * 1.06 + sc * UNIT_ENTRIES * 4 + 4.9e9 + 14e9, sc * UNIT_ENTRIES * 3 + 4.3e9
+
+
+def host_need(sc, with_reference, ram_backed):
+    """host memory a run at this scale touches at its worst moment.  Building: one part (2.5 units: FASTA + ~5 bytes per base in the
+    QUICK builder) beside the parts' .edx files and, at the end, the merged file.  Running: the .edx file and this process's copy.
+    With the reference: its .acx file, and the reference's own copies of .edx and .acx (it reads both into memory) -- this process
+    lets go of its copy of the database meanwhile.  Files only count when the work directory is RAM-backed"""
+    edx, _, acx = sizes_at(sc)
+    part = min(sc, 2.5) * UNIT_FASTA
+    files = (2 * edx + 1.5e9) if ram_backed else 0
+    build = part * (6 if ram_backed else 5) + files
+    run = edx + files / 2 + 8e9
+    ref = ((edx + acx if ram_backed else 0) + edx + acx + 10e9) if with_reference else 0
+    return max(build, run, ref) + 6e9
+
+
+def pick_setup(args, free_hbm, want_cpu_baseline):
+    """(db-scale, work directory): the largest database of AUTO_SCALES this box holds -- on the device (references + 4-byte records +
+    offset lines + batch buffers), in the host memory the job may use (see host_need; with 8 % of slack) and in the work directory
+    (FASTA parts, .edx, reads, the .acx file the compiled reference reads)"""
+    import shutil
+    def free_of(d):
+        try:
+            while not os.path.exists(d):
+                d = os.path.dirname(d) or "/"
+            return shutil.disk_usage(d).free
+        except OSError:
+            return 0
+    ram = memory_limit() * 0.92
+    dirs = [args.workdir] if args.workdir else ["/dev/shm/burst_amd_bench", "/tmp/burst_amd_bench"]
+    scales = AUTO_SCALES if args.db_scale == "auto" else (float(args.db_scale),)
+    for sc in scales:
+        edx, dev_need, acx_file = sizes_at(sc)
+        for with_ref in ((True, False) if args.db_scale != "auto" else (want_cpu_baseline,)):      # (auto: a size at which the reference runs beside it, if one is wanted)
+            disk_need = min(sc, 2.5) * UNIT_FASTA + 2 * edx + (acx_file if with_ref else 0) + 4e9
+            for d in dirs:
+                if dev_need <= free_hbm and disk_need <= free_of(d) and host_need(sc, with_ref, d.startswith("/dev/shm")) <= ram:
+                    return sc, d
+    if args.db_scale != "auto":      # an explicit size is taken at its word (the allocation says when it does not fit)
+        return float(args.db_scale), dirs[0]
+    return 0.5, dirs[-1]
+
+
 def db_paths(workdir, args):
     args.db_qlen = args.read_len + max(10, args.read_len // 10)
     tag = "b%d_v%d_l%d_q%d_i%s_k%d" % (args.n_base, args.n_variants, args.ref_len, args.db_qlen, args.id, args.K)
     return (os.path.join(workdir, "refs_%s.fa" % tag), os.path.join(workdir, "db_%s.edx" % tag), os.path.join(workdir, "db_%s.acx" % tag))
 
 
-def build_db(workdir, args, rank=0):
-    """rank 0 writes the shared database (args: read_len, n_base, n_variants, ref_len, variant_rate, id, K); returns (refs, edx, acx, done marker)"""
+def reads_path(workdir, args):
+    edits = [int(x) for x in args.edits.split(",")]
+    return os.path.join(workdir, "reads_%d_l%d_e%s_u%s_f%d.fa" % (args.reads * args.pool, args.read_len, "-".join(map(str, edits)), args.iupac, int(args.fr)))
+
+
+# A database is BUILT in parts of at most this many base sequences (x variants; 2.5 units of scale = 11 Gbp of FASTA): the QUICK
+# builder holds about five bytes per base while it sorts the fragments, and the GPU boxes give a job 300 GB.  A part is what
+# `-d QUICK` makes of its share of the references; the parts are laid end to end (bh_edx_merge).  Up to 2.5 units the database is
+# one part -- the same file as in rounds 1-3.
+PART_BASES = 4000000
+
+
+def build_db(workdir, args, rank=0, reads_fa=None):
+    """rank 0 writes the shared database (args: read_len, n_base, n_variants, ref_len, variant_rate, id, K) -- and, with reads_fa, the
+    read pool drawn from its references (part by part: the reference FASTA of a part is deleted once its clumps and reads exist, unless
+    the database is a single part and args.drop_refs is off); returns (refs, edx, acx, done marker)"""
     from burst_amd import host
     os.makedirs(workdir, exist_ok=True)
     refs, edx, acx = db_paths(workdir, args)
     done = edx + ".done"
-    if rank == 0 and not os.path.exists(done):
+    if rank == 0 and not (os.path.exists(done) and (reads_fa is None or os.path.exists(reads_fa + ".done"))):
         t = time.time()
-        host.synth_refs(refs, args.n_base, args.n_variants, args.ref_len, args.variant_rate, 7)
-        t1 = time.time()
-        db = host.Db.from_fasta(refs, args.db_qlen, args.id, shear_len=500)
-        t2 = time.time()
-        db.write(edx, None, db_qlen=args.db_qlen, thres=args.id)
-        db.close()
+        edits = [int(x) for x in args.edits.split(",")] if reads_fa else []
+        n_parts = max(1, -(-args.n_base // PART_BASES))
+        per = -(-args.n_base // n_parts)
+        per += (-per) % 8          # (x 2 variants x 3 fragments: every part but the last fills its last clump)
+        n_pool = args.reads * args.pool if reads_fa else 0
+        t_ref = t_cl = t_rd = 0.0
+        parts, first_read = [], 0
+        for p in range(n_parts):
+            b0, b1 = p * per, min(args.n_base, (p + 1) * per)
+            if b1 <= b0:
+                break
+            fa = refs if n_parts == 1 else refs + ".part%d" % p
+            ex = edx if n_parts == 1 else edx + ".part%d" % p
+            t0 = time.time()
+            host.synth_refs(fa, b1 - b0, args.n_variants, args.ref_len, args.variant_rate, 7, first_base=b0)
+            t1 = time.time()
+            if not os.path.exists(done):
+                db = host.Db.from_fasta(fa, args.db_qlen, args.id, shear_len=500)
+                db.write(ex, None, db_qlen=args.db_qlen, thres=args.id)
+                db.close()
+            t2 = time.time()
+            if reads_fa and not os.path.exists(reads_fa + ".done"):
+                n_here = n_pool * (b1 - b0) // args.n_base if p + 1 < n_parts else n_pool - first_read
+                host.synth_reads(fa, reads_fa, n_here, args.read_len, edits, rc=args.fr, iupac=args.iupac, seed=42 + p, first_read=first_read, append=p > 0)
+                first_read += n_here
+            t3 = time.time()
+            if n_parts > 1 or getattr(args, "drop_refs", False):
+                os.remove(fa)      # (as large as the database in bases)
+            parts.append(ex)
+            t_ref += t1 - t0; t_cl += t2 - t1; t_rd += t3 - t2
+        t4 = time.time()
+        if n_parts > 1 and not os.path.exists(done):
+            host.edx_merge(parts, edx)
+            for ex in parts:
+                os.remove(ex)
         open(done, "w").write("ok")
-        log("[bench] database built in %.1f s (references %.1f s, clumps %.1f s, .edx %.1f s); the accelerator is built on the device" % (time.time() - t, t1 - t, t2 - t1, time.time() - t2))
+        if reads_fa:
+            open(reads_fa + ".done", "w").write("ok")
+        log("[bench] database built in %.1f s in %d part(s) (references %.1f s, clumps + .edx %.1f s, reads %.1f s, merge %.1f s); the accelerator is built on the device"
+            % (time.time() - t, len(parts), t_ref, t_cl, t_rd, time.time() - t4))
     return refs, edx, acx, done
 
 
@@ -86,18 +225,10 @@ def ensure_acx(edx, acx, K):
 
 def build_inputs(workdir, args, rank):
     """rank 0 writes the shared database and the shared read pool"""
-    from burst_amd import host
-    refs, edx, acx, done = build_db(workdir, args, rank)
-    edits = [int(x) for x in args.edits.split(",")]
-    n_pool_reads = args.reads * args.pool
-    reads_fa = os.path.join(workdir, "reads_%d_l%d_e%s_u%s_f%d.fa" % (n_pool_reads, args.read_len, "-".join(map(str, edits)), args.iupac, int(args.fr)))
-    if rank == 0 and not os.path.exists(reads_fa + ".done"):
-        t = time.time()
-        host.synth_reads(refs, reads_fa, n_pool_reads, args.read_len, edits, rc=args.fr, iupac=args.iupac, seed=42)
-        open(reads_fa + ".done", "w").write("ok")
-        log("[bench] %d reads written in %.1f s" % (n_pool_reads, time.time() - t))
-    if rank == 0 and getattr(args, "drop_refs", False) and os.path.exists(refs):
-        os.remove(refs)          # very large databases: the FASTA (as large as the database in bases) is not needed once reads and .edx exist
+    os.makedirs(workdir, exist_ok=True)
+    db_paths(workdir, args)          # (sets args.db_qlen)
+    reads_fa = reads_path(workdir, args)
+    refs, edx, acx, done = build_db(workdir, args, rank, reads_fa)
     return refs, edx, acx, reads_fa, done
 
 
@@ -106,7 +237,7 @@ def cpu_baseline(edx, acx, reads_fa, args):
     exe = os.path.join(ROOT, "oracle", "_ref", "burst%d" % args.K)
     if args.no_cpu_baseline or not os.path.exists(exe):
         return None
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     n1, n2 = args.cpu_sample // 6, args.cpu_sample
     tmp = os.path.dirname(reads_fa)
     times = []
@@ -125,10 +256,34 @@ def cpu_baseline(edx, acx, reads_fa, args):
     dt = max(times[1] - times[0], 1e-6)
     cpu_baseline.sample_fa, cpu_baseline.sample_b6 = sample, sample + ".b6"        # the larger sample: parity_vs_reference compares with it
     return {"value": (n2 - n1) / dt, "unit": "reads/s", "cores": cores, "kind": "reference",
-            "sample": "oracle/_ref/burst%d (reference compiled with gcc -O3 -march=x86-64-v3 -fopenmp) -t %d, same .edx/.acx, "
+            "sample": "oracle/_ref/burst%d (reference compiled with gcc -O3 -march=x86-64-v3 -fopenmp) -t %d (%d hardware threads visible%s), same .edx/.acx, "
                       "-m %s -i %s; differential wall time of the first %d vs %d reads of the pool (%.2f s vs %.2f s) = its align "
                       "phase incl. parse/sort/output of the extra reads, database load cancelled"
-                      % (args.K, cores, args.mode, args.id, n1, n2, times[0], times[1])}
+                      % (args.K, cores, os.cpu_count() or 1, "; the job's CPU quota is %d" % cores if cores < (os.cpu_count() or 1) else "", args.mode, args.id, n1, n2, times[0], times[1])}
+
+
+def exhaustive_reference_sample(edx, reads_fa, args, n_clumps):
+    """When the reference's accelerated run does not fit this box (it holds the .edx and the .acx in memory next to the .acx FILE), its
+    exhaustive path (no -a: every query against every clump, burst.c:4320-4488) gives the same hits by construction -- on a sample
+    sized for about two minutes of the host cores (14 us of one core per query and clump, measured).  Sets the sample for
+    parity_vs_reference; returns a description"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "burst%d" % args.K)
+    cores = effective_cores()
+    n = int(max(8, min(2000, 120.0 * cores / (max(1, n_clumps) * 14e-6))))
+    sample = os.path.join(os.path.dirname(reads_fa), "ref_exhaustive_%d.fa" % n)
+    with open(reads_fa, "rb") as f, open(sample, "wb") as o:
+        for _ in range(2 * n):
+            o.write(f.readline())
+    t = time.time()
+    r = subprocess.run([exe, "-r", edx, "-q", sample, "-o", sample + ".b6", "-m", args.mode, "-i", str(args.id), "-t", str(cores), "--noprogress"] + (["-fr"] if args.fr else []),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        log("[bench] reference (exhaustive) failed:", r.stdout[-400:])
+        return None
+    cpu_baseline.sample_fa, cpu_baseline.sample_b6 = sample, sample + ".b6"
+    return {"reads": n, "seconds": time.time() - t, "cores": cores,
+            "what": "oracle/_ref/burst%d WITHOUT its accelerator (exhaustive: every query against every clump) on the first %d reads of the pool, -t %d: the accelerated run "
+                    "needs the .edx and the .acx in memory beside the .acx file, which this box's memory limit does not allow at this database size" % (args.K, n, cores)}
 
 
 def end_to_end(edx, reads_fa, args, device):
@@ -218,7 +373,8 @@ def main():
     ap.add_argument("--reads", type=int, default=2000000, help="reads per step (per rank with --scaling weak, all GPUs together with --scaling strong)")
     ap.add_argument("--pool", type=int, default=4, help="distinct batches the steps cycle through")
     ap.add_argument("--read-len", type=int, default=100)
-    ap.add_argument("--db-scale", type=float, default=1.0, help="multiplies --n-base (1 = 3.2 M references / 4.5 Gbp)")
+    ap.add_argument("--db-scale", default="auto", help="multiplies --n-base (1 = 3.2 M references / 4.5 Gbp / .edx 2.77 GB; 11.37 = the metric's 31.5 GB .edx); "
+                    "auto (default) = the largest of %s that the device, the host memory and the work directory hold" % (AUTO_SCALES,))
     ap.add_argument("--n-base", type=int, default=1600000, help="random base sequences (round 2's family-dominated database: --n-base 33000 --n-variants 30)")
     ap.add_argument("--n-variants", type=int, default=2)
     ap.add_argument("--ref-len", type=int, default=1400)
@@ -226,7 +382,10 @@ def main():
     ap.add_argument("--id", type=float, default=0.98)
     ap.add_argument("--K", type=int, default=15, choices=[12, 15], help="accelerator word length (the reference's DB12 / DB15 builds)")
     ap.add_argument("--mode", default="BEST")
-    ap.add_argument("--workdir", default=os.environ.get("BURST_BENCH_DIR", "/tmp/burst_amd_bench"))
+    ap.add_argument("--workdir", default=os.environ.get("BURST_BENCH_DIR"), help="where the database, the reads and the reference's .acx are written (default: /dev/shm/burst_amd_bench when "
+                    "/dev/shm has the room a large database needs, else /tmp/burst_amd_bench)")
+    ap.add_argument("--no-continuity", action="store_true", help="skip the extra run on the small database of rounds 1-3 (key `continuity_small_db`)")
+    ap.add_argument("--keep-files", action="store_true", help="leave the large files (reference FASTA, .acx) in the work directory")
     ap.add_argument("--cpu-sample", type=int, default=600000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the burst_hip command-line run on the read pool (end_to_end_reads_per_s)")
@@ -237,14 +396,13 @@ def main():
     ap.add_argument("--no-pin", action="store_true", help="leave the query arrays pageable")
     ap.add_argument("--drop-refs", action="store_true", help="delete the reference FASTA once the reads and the .edx exist (disk space of very large databases)")
     ap.add_argument("--no-prime", action="store_true", help="skip bhip_reserve and the priming call (profiling: every dispatch of the run is then a full-size batch)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = every rank aligns --steps batches of --reads reads (the job grows with N; default: the path partitions and "
-                    "has no data-path collective), strong = the single-GPU job of --steps batches cut into N equal shares")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"], help="N > 1: strong (default) = the single-GPU job of --steps batches cut into N equal shares of unique queries (the fixed job "
+                    "north_star asks about); weak = every rank aligns --steps batches of --reads reads of its own (the job grows with N).  The line carries the other one as an extra key")
     ap.add_argument("--gather", default="shm", choices=["shm", "rccl"], help="N > 1: how the ranks' records reach rank 0 -- shared-memory segments rank 0 maps (default; no collective) or the library's RCCL gather")
     ap.add_argument("--acx-file", action="store_true", help="round 2's path: the accelerator from an .acx file (built by the host builder) instead of the device build")
     ap.add_argument("--ab", action="append", default=[], help="N = 1: after the timed region, time the same steps again with these library options (name=value[,name=value]; repeatable) "
                     "on the same resident database -- extra key `ab` of the JSON line, an A/B on one box in one process")
     args = ap.parse_args()
-    args.n_base = int(round(args.n_base * args.db_scale))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -265,12 +423,30 @@ def main():
     if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        import datetime
+        long_wait = datetime.timedelta(hours=2)          # (the other ranks sit in a barrier while rank 0 writes a large database)
         if one_dev is not None:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=long_wait)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=long_wait)
 
     from burst_amd import capi, host
+    # the size of the database and where its files go: rank 0 decides (from its device's free memory, the host's memory and the
+    # room in the work directory), every rank takes its word
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "burst%d" % args.K)
+    want_base = world == 1 and not args.no_cpu_baseline and os.path.exists(ref_exe)
+    try:
+        free_hbm = torch.cuda.mem_get_info(local_rank)[0]
+    except Exception:
+        free_hbm = 0
+    setup = [pick_setup(args, free_hbm, want_base)]
+    if use_dist:
+        dist.broadcast_object_list(setup, src=0)
+    args.db_scale, args.workdir = float(setup[0][0]), setup[0][1]
+    args.n_base = int(round(args.n_base * args.db_scale))
+    args.drop_refs = args.drop_refs or (args.db_scale >= 2 and not args.keep_files)
+    if rank == 0:
+        log("[bench] database scale %.2f (.edx ~%.1f GB), work directory %s" % (args.db_scale, args.db_scale * UNIT_EDX / 1e9, args.workdir))
     refs, edx, acx, reads_fa, done = build_inputs(args.workdir, args, rank)
     os.sync()          # the files just written go to disk now, not beside the timed region (their write-back shares the PCIe root and the memory bus)
     if use_dist:
@@ -309,6 +485,7 @@ def main():
         qs.pin()
     info = dev.info()
     edx_bytes = os.path.getsize(edx)
+    n_clumps = int(db.c.numRclumps)
     n_ent = C.c_uint64()
     capi._chk(capi.lib().bhip_acx_export(dev._h, None, None, None, 0, C.byref(n_ent), None, 0, None))
     acx_entries = int(n_ent.value)
@@ -323,13 +500,17 @@ def main():
     def pool_range(b):
         return (b * U // P, (b + 1) * U // P)
     weak = args.scaling == "weak"
-    def job_share(first, count, r=rank):
-        # weak scaling (default; the path partitions, every rank does what the single GPU does): rank r aligns `count` pool batches
-        # of its own, starting r batches further into the pool so that the ranks are not on the same reads at the same time.
-        # strong scaling: the single-GPU job cut into N equal shares
+    def job_share(first, count, r=rank, weak=weak):
+        # strong scaling (default: the fixed job north_star asks about): the single-GPU job of `count` pool batches cut into N equal
+        # shares of unique queries.  weak scaling: rank r aligns `count` pool batches of its own, starting r batches further into the
+        # pool so that the ranks are not on the same reads at the same time
         if weak:
             return [pool_range((first + k + r) % P) for k in range(count)]
         return share_of_job([pool_range((first + k) % P) for k in range(count)], r, world)
+    def job_reads(first, count, weak=weak):
+        if weak and world > 1:
+            return sum(reads_per_pool_batch[(first + k + r) % P] for r in range(world) for k in range(count))
+        return sum(reads_per_pool_batch[(first + k) % P] for k in range(count))
     batch_uniq = max(1, U // P + 1)         # at most one pool batch per device call
     reads_per_pool_batch = [qs.reads_in(b * U // P, (b + 1) * U // P) for b in range(P)]
 
@@ -350,17 +531,37 @@ def main():
         capi._chk(capi.lib().bhip_comm_create_rank(world, rank, local_rank, idb, C.byref(c)))
         return c
     rs = None
-    def search(ranges):
-        """one job share through the product's scheduler; N > 1: + the gather of the records to rank 0"""
+    def search(ranges, engine=None):
+        """one job share through the product's scheduler; N > 1: + the hand-over of the records to rank 0"""
         if use_dist:
-            return rs.search(qs, ranges, args.mode, batch_uniq)
+            return (engine or rs).search(qs, ranges, args.mode, batch_uniq)
         return host.align_ranges(dev, qs, ranges, args.mode, batch_uniq, run=_own)
+    def timed(ranges, engine=None):
+        """(seconds: the slowest rank's, barrier to barrier; records rank 0 holds; the Run)"""
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_ = time.time()
+        run_ = search(ranges, engine)
+        n_ = int(run_.c.nHits)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        e_ = time.time() - t_
+        if use_dist:
+            tt_ = torch.tensor([e_], dtype=torch.float64, device=pdev)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            e_ = float(tt_.item())
+            nr_ = torch.tensor([n_ if rank == 0 else 0], dtype=torch.int64, device=pdev)
+            dist.all_reduce(nr_)
+            n_ = int(nr_.item())
+        return e_, n_, run_
 
     # warm-up: sizes the library's grow-only buffers for this workload and runs W untimed steps
     # (the page-locked record buffer is allocated once, outside the timed region: the command line does it once per job as well)
     _own = host.Run()
     ent_per_step = min(batch_uniq, max((b - a for a, b in job_share(0, P)), default=1)) * (2 if args.fr else 1)
-    share = max(1, sum(b - a for a, b in job_share(args.warmup, args.steps))) * (2 if args.fr else 1)
+    share = max(1, max(sum(b - a for a, b in job_share(args.warmup, args.steps, weak=w_)) for w_ in ((False, True) if world > 1 else (weak,)))) * (2 if args.fr else 1)
     cap_rec = int(max(share, 4 * ent_per_step) * (4.0 if args.mode in ("FORAGE", "ALLPATHS") else 1.5)) + (1 << 20)
     if use_dist:
         if args.gather == "shm":
@@ -408,26 +609,49 @@ def main():
     if not args.no_prime:
         search([pool_range(k % P) for k in range(4)] if world == 1 else job_share(0, 4 if weak else 4 * world))
     search(job_share(0, max(1, args.warmup)))
+    elapsed, n_records, run = timed(job_share(args.warmup, args.steps))
+    total_reads = job_reads(args.warmup, args.steps)
+    own_main = rs.own_stats() if use_dist else None          # (this rank's counters of the timed job: the extra jobs below overwrite them)
+    handover_main = None
+    if use_dist and rank == 0:      # what rank 0 holds after the timed search, read once through (outside the timed region): every rank's run, its records
+        runs_ = rs.view.runs()
+        handover_main = {"kind": "view over the ranks' shared-memory segments" if (node is not None and rs.view.n_runs == world and world > 1) else "one array",
+                         "records_per_run": [int(len(x)) for x in runs_], "distinct_entries": int(sum(len(np.unique(x["q"])) for x in runs_)),
+                         "xor_of_reference_numbers": int(np.bitwise_xor.reduce(np.concatenate([x["refIx"] for x in runs_]))) if sum(len(x) for x in runs_) else 0}
+    # N > 1: the same ranks again on (a) the other scaling, (b) BASELINE configs[3]'s job -- 10 M reads over all GPUs, one or two batches
+    # per rank --, (c) the main job with the records gathered over RCCL (bhip_comm_gather_hits across all N ranks) instead of
+    # meeting in shared memory.  Extra keys of the line; `value` stays the main job's
+    extra = {}
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.time()
-    run = search(job_share(args.warmup, args.steps))
-    n_records = int(run.c.nHits)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.time() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=pdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        nr = torch.tensor([n_records if rank == 0 else 0], dtype=torch.int64, device=pdev)
-        dist.all_reduce(nr)
-        n_records = int(nr.item())
-    total_reads = sum(reads_per_pool_batch[(args.warmup + k) % P] for k in range(args.steps))
-    if weak and world > 1:      # every rank its own `steps` batches
-        total_reads = sum(reads_per_pool_batch[(args.warmup + k + r) % P] for r in range(world) for k in range(args.steps))
+        if world > 1:
+            e2, n2, _ = timed(job_share(args.warmup, args.steps, weak=not weak))
+            r2 = job_reads(args.warmup, args.steps, weak=not weak)
+            extra["weak_scaling" if not weak else "strong_scaling"] = {"value": r2 / e2, "unit": "reads/s", "reads": r2, "seconds": e2, "records": n2,
+                "what": ("every rank aligns %d batches of its own: the job is N times the single-GPU job" % args.steps) if not weak else "the single-GPU job cut into N equal shares"}
+        nb3 = max(1, int(round(10e6 / max(1, args.reads))))
+        search(job_share(0, nb3, weak=False))
+        e3, n3, _ = timed(job_share(args.warmup, nb3, weak=False))
+        r3 = job_reads(args.warmup, nb3, weak=False)
+        extra["configs3_job"] = {"value": r3 / e3, "unit": "reads/s", "reads": r3, "seconds": e3, "records": n3, "reads_per_rank": r3 // world,
+                                 "what": "BASELINE configs[3]'s job size: %d reads cut over %d GPUs (strong scaling; a rank's share of at most two batches is aligned in four pieces, bh_align.c)" % (r3, world)}
+        if one_dev is None and args.gather == "shm":
+            try:
+                comm2 = make_comm()
+                rs2 = host.RankSearch(dev, rank, world, comm2, node=None)
+                rs2.reserve(cap_rec)
+                if rank == 0:
+                    rs2.reserve_all(world * cap_rec, pinned=True)
+                search(job_share(0, max(1, args.warmup)), rs2)
+                e4, n4, _ = timed(job_share(args.warmup, args.steps), rs2)
+                al = torch.tensor([float(rs2.mr.secSearch)], dtype=torch.float64, device=pdev)
+                dist.all_reduce(al, op=dist.ReduceOp.MAX)
+                extra["rccl"] = {"rccl_ranks": world, "value": total_reads / e4, "unit": "reads/s", "seconds": e4, "records": n4, "rccl_gather_ms": max(0.0, e4 - float(al.item())) * 1e3,
+                                 "what": "the main job with the records gathered to rank 0 by bhip_comm_gather_hits (ncclAllGather of the counts + grouped ncclSend/ncclRecv over xGMI, one copy to the "
+                                         "host) inside the timed region instead of the shared-memory hand-over; rccl_gather_ms = that time minus the slowest rank's align phase"}
+                rs2.close()
+                capi.lib().bhip_comm_destroy(comm2)
+            except Exception as e:
+                extra["rccl"] = {"error": str(e)}
 
     if rank == 0 and os.environ.get("BHIP_PROF"):      # library built with EXTRA_HIPFLAGS=-DPFM_PROF: wave-cycles per prefilter phase
         import ctypes
@@ -438,7 +662,7 @@ def main():
             tot = float(sum(arr)) or 1.0
             log("[bench] prefilter phase share: " + " ".join("%d:%.1f%%" % (i, 100.0 * v / tot) for i, v in enumerate(arr)) + "  total wave-cycles %.3g" % tot)
     if rank == 0:
-        st, nb, sec_align = rs.own_stats() if use_dist else (run.stats(), int(run.c.nBatches), float(run.c.secAlign))
+        st, nb, sec_align = own_main if use_dist else (run.stats(), int(run.c.nBatches), float(run.c.secAlign))
         nb = max(1, nb)
         per = lambda k: float(st[k]) / nb
         two_stage = st["prefix_words"] > 0
@@ -568,27 +792,74 @@ def main():
                 for name in kv:
                     if name in defaults:
                         dev.set_option(name, defaults[name])
+        res.update(extra)
         res["cpu_baseline"] = None
-        if world == 1 and not args.no_cpu_baseline and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "burst%d" % args.K)):      # N = 1 only (the contract); the other ranks would sit in the barrier meanwhile
+        ref_note = None
+        if want_base:      # N = 1 only (the contract); the other ranks would sit in the barrier meanwhile
             import shutil
-            need_disk = acx_bytes + (2 << 30)
-            if not os.path.exists(acx + ".done") and shutil.disk_usage(os.path.dirname(acx)).free < need_disk:
-                log("[bench] no room for the reference's .acx (%.1f GB needed in %s): cpu_baseline skipped" % (need_disk / 1e9, os.path.dirname(acx)))
-                res["cpu_baseline_skipped"] = "the reference reads an .acx file of %.1f GB; the work directory has %.1f GB free" % (acx_bytes / 1e9, shutil.disk_usage(os.path.dirname(acx)).free / 1e9)
+            ram_backed = args.workdir.startswith("/dev/shm")
+            fits = host_need(args.db_scale, True, ram_backed) <= memory_limit() * 0.92 and \
+                (os.path.exists(acx + ".done") or shutil.disk_usage(os.path.dirname(acx)).free >= acx_bytes + (2 << 30))
+            if not fits:
+                res["cpu_baseline_skipped"] = ("the reference's accelerated run needs %.0f GB of host memory at this database size (.edx %.1f GB + .acx %.1f GB in its memory%s); "
+                                               "this job may use %.0f GB" % (host_need(args.db_scale, True, ram_backed) / 1e9, edx_bytes / 1e9, acx_bytes / 1e9,
+                                                                             ", the .acx file in a RAM-backed directory" if ram_backed else "", memory_limit() / 1e9))
+                log("[bench] " + res["cpu_baseline_skipped"])
+                try:
+                    db.close()
+                    ref_note = exhaustive_reference_sample(edx, reads_fa, args, n_clumps)
+                    db = host.Db.read(edx, None, K=args.K)
+                except Exception as e:
+                    ref_note = {"error": str(e)}
             elif not os.path.exists(acx + ".done"):      # the reference reads an .acx FILE: written here from the tables the device built
                 t = time.time()
                 try:
-                    db.acx_from_device(dev, args.K, 1)
-                    host._chk(host.lib().bh_acx_write(C.byref(db.c), acx.encode()))
+                    db.acx_write_from_device(dev, args.K, acx)      # (streamed: the host never holds the lists)
                     open(acx + ".done", "w").write("ok")
                     log("[bench] .acx for the reference written from the device-built tables in %.1f s (%.2f GB)" % (time.time() - t, os.path.getsize(acx) / 1e9))
                 except Exception as e:
                     res["cpu_baseline_skipped"] = "could not write the reference's .acx: %s" % e
-            if os.path.exists(acx + ".done"):
+            if fits and os.path.exists(acx + ".done"):
                 try:
-                    res["cpu_baseline"] = cpu_baseline(edx, acx, reads_fa, args)
+                    t = time.time()
+                    db.close()          # (this process's copy of the database: the reference holds its own, and the memory is shared)
+                    room = memory_limit() - memory_in_use()
+                    if memory_in_use() and room < edx_bytes + acx_bytes + (12 << 30):
+                        res["cpu_baseline_skipped"] = "%.0f GB of the job's memory are free, the reference needs %.0f" % (room / 1e9, (edx_bytes + acx_bytes) / 1e9 + 12)
+                    else:
+                        res["cpu_baseline"] = cpu_baseline(edx, acx, reads_fa, args)
+                    db = host.Db.read(edx, None, K=args.K)
+                    log("[bench] reference on the host cores: %.1f s" % (time.time() - t))
                 except Exception as e:
                     res["cpu_baseline_skipped"] = "reference run failed: %s" % e
+        if res["cpu_baseline"]:
+            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+        if res["cpu_baseline"] or (ref_note and "error" not in ref_note):
+            try:
+                res["parity_vs_reference"] = parity_vs_reference(dev, db, args, batch_uniq)
+                if ref_note and res["parity_vs_reference"]:
+                    res["parity_vs_reference"]["reference_run"] = ref_note
+                    res["parity_vs_reference"]["what"] = res["parity_vs_reference"]["what"].replace("oracle/_ref/burst%d" % args.K, "oracle/_ref/burst%d without -a (exhaustive)" % args.K)
+            except Exception as e:      # reported, never fatal for the measurement
+                res["parity_vs_reference"] = {"error": str(e)}
+        elif ref_note:
+            res["parity_vs_reference"] = ref_note
+        if want_base and not args.keep_files:      # the reference's .acx (3 B per entry: 100 GB and more) has served
+            for f in (acx, acx + ".done"):
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
+        if handover_main is not None:
+            res["handover"] = handover_main
+        if world == 1 and (not args.no_end_to_end or (not args.no_continuity and args.db_scale > 1.5)):
+            # the command line and the small-database run are processes of their own with a database of their own on the device: this
+            # process lets go of its copy first (a large database does not fit twice)
+            if rs is not None:
+                rs.close(); rs = None
+            _own.close(); _own = None
+            dev.close()
+            db.close()
         if world == 1 and not args.no_end_to_end:
             try:
                 res["end_to_end"] = end_to_end(edx, reads_fa, args, local_rank)
@@ -596,21 +867,27 @@ def main():
                 res["end_to_end"] = {"error": str(e)}
             if res["end_to_end"] and "reads_per_s" in res["end_to_end"]:
                 res["end_to_end_reads_per_s"] = res["end_to_end"]["reads_per_s"]
-        if res["cpu_baseline"]:
-            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+        if world == 1 and not args.no_continuity and args.db_scale > 1.5:
+            # rounds 1-3 quoted the rate on the 2.77 GB database: the same steps on it, for continuity (a child process; extra key)
             try:
-                res["parity_vs_reference"] = parity_vs_reference(dev, db, args, batch_uniq)
-            except Exception as e:      # reported, never fatal for the measurement
-                res["parity_vs_reference"] = {"error": str(e)}
-        if use_dist:      # what rank 0 holds after the timed search, read once through (outside the timed region): every rank's run, its records
-            runs = rs.view.runs()
-            res["handover"] = {"kind": "view over the ranks' shared-memory segments" if (node is not None and rs.view.n_runs == world and world > 1) else "one array",
-                               "records_per_run": [int(len(x)) for x in runs], "distinct_entries": int(sum(len(np.unique(x["q"])) for x in runs)),
-                               "xor_of_reference_numbers": int(np.bitwise_xor.reduce(np.concatenate([x["refIx"] for x in runs]))) if sum(len(x) for x in runs) else 0}
+                t = time.time()
+                cmd = [sys.executable, os.path.abspath(__file__), "--db-scale", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--reads", str(args.reads), "--pool", str(args.pool),
+                       "--no-cpu-baseline", "--no-end-to-end", "--no-continuity", "--workdir", os.path.join(args.workdir, "small")] + [x for kv in args.opt for x in ("--opt", kv)]
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                res["continuity_small_db"] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "workload": d["config"]["workload"],
+                                              "acx_entries_per_read": d["work"]["acx_entries_per_read"], "seconds_spent": time.time() - t,
+                                              "what": "the database of rounds 1-3 (BENCH_r03: 556 M reads/s), same steps, same kernels"}
+            except Exception as e:
+                res["continuity_small_db"] = {"error": str(e)}
         print(json.dumps(res), flush=True)
+    if not args.keep_files and rank == 0 and args.db_scale >= 2:      # a RAM-backed work directory is given back
+        import shutil
+        shutil.rmtree(args.workdir, ignore_errors=True)
     if rs is not None:
         rs.close()
-    _own.close()
+    if _own is not None:
+        _own.close()
     if comm:
         capi.lib().bhip_comm_destroy(comm)
     if use_dist:

@@ -617,6 +617,29 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 	return 0;
 }
 
+// entries [first, first + n) of the record area (word order), as clump ids (+ lane masks): for callers that write the lists piece by
+// piece instead of holding all of them (33 G entries are 134 GB as 32-bit numbers)
+extern "C" int bhip_acx_export_entries(void *handle, uint64_t first, uint64_t n_entries, uint32_t *clumps, uint16_t *masks) {
+	Handle *h = (Handle *)handle;
+	if (!h || (!clumps && n_entries)) return fail(BHIP_E_ARG, "null argument");
+	if (!h->has_acx) return fail(BHIP_E_ARG, "handle has no accelerator");
+	if (first > h->n_ent || n_entries > h->n_ent - first) return fail(BHIP_E_ARG, "entries [%llu, +%llu) beyond the accelerator's %llu", (unsigned long long)first, (unsigned long long)n_entries, (unsigned long long)h->n_ent);
+	HIPCHK(hipSetDevice(h->device));
+	const uint64_t piece = 1ull << 26;
+	DTmp dc, dm;
+	ARC(dc.reserve(std::min(piece, n_entries + 1) * 4)); if (masks) ARC(dm.reserve(std::min(piece, n_entries + 1) * 2));
+	for (uint64_t e = 0; e < n_entries; e += piece) {
+		const uint64_t n = std::min(piece, n_entries - e);
+		hipLaunchKernelGGL(k_acx_rec_export, dim3((uint32_t)h->n_cu * 16), dim3(256), 0, h->stream, h->acx_view().rec, (unsigned long long)(h->acx_bias + first + e), n,
+			dc.as<uint32_t>(), masks ? dm.as<uint16_t>() : (uint16_t *)nullptr);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(clumps + e, dc.p, n * 4, hipMemcpyDeviceToHost, h->stream));
+		if (masks) HIPCHK(hipMemcpyAsync(masks + e, dm.p, n * 2, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+	}
+	return BHIP_OK;
+}
+
 // the accelerator of a handle in the file's terms: Lens[4^K] (burst.c:3558), the clump ids of all lists in word order (and
 // their lane masks), the BadList.  Any pointer may be NULL; *n_entries / *n_bad are always set.
 extern "C" int bhip_acx_export(void *handle, uint32_t *lens, uint32_t *clumps, uint16_t *masks, uint64_t cap_entries, uint64_t *n_entries,
@@ -638,18 +661,7 @@ extern "C" int bhip_acx_export(void *handle, uint32_t *lens, uint32_t *clumps, u
 	}
 	if (clumps) {
 		if (cap_entries < h->n_ent) return fail(BHIP_E_CAPACITY, "entry buffer holds %llu, %llu needed", (unsigned long long)cap_entries, (unsigned long long)h->n_ent);
-		const uint64_t piece = 1ull << 26;
-		DTmp dc, dm;
-		ARC(dc.reserve(piece * 4)); if (masks) ARC(dm.reserve(piece * 2));
-		for (uint64_t e = 0; e < h->n_ent; e += piece) {
-			const uint64_t n = std::min(piece, h->n_ent - e);
-			hipLaunchKernelGGL(k_acx_rec_export, dim3((uint32_t)h->n_cu * 16), dim3(256), 0, h->stream, h->acx_view().rec, (unsigned long long)(h->acx_bias + e), n,
-				dc.as<uint32_t>(), masks ? dm.as<uint16_t>() : (uint16_t *)nullptr);
-			HIPCHK(hipGetLastError());
-			HIPCHK(hipMemcpyAsync(clumps + e, dc.p, n * 4, hipMemcpyDeviceToHost, h->stream));
-			if (masks) HIPCHK(hipMemcpyAsync(masks + e, dm.p, n * 2, hipMemcpyDeviceToHost, h->stream));
-			HIPCHK(hipStreamSynchronize(h->stream));
-		}
+		ARC(bhip_acx_export_entries(handle, 0, h->n_ent, clumps, masks));
 	}
 	if (badlist) {
 		if (cap_bad < h->n_bad) return fail(BHIP_E_CAPACITY, "BadList buffer holds %u, %u needed", cap_bad, h->n_bad);

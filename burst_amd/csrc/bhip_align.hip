@@ -656,6 +656,13 @@ static void seed_next_batch(Handle *h, StageSlot *cur, hipEvent_t cur_done) {
 	}
 }
 
+extern "C" int bhip_set_enqueued_hook(void *handle, void (*fn)(void *), void *ctx) {
+	Handle *h = (Handle *)handle;
+	if (!h) return fail(BHIP_E_ARG, "null handle");
+	h->enqueued_hook = fn; h->enqueued_ctx = ctx;
+	return BHIP_OK;
+}
+
 extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint64_t cap, uint64_t *n_hits) {
 	Handle *h = (Handle *)handle;
 	if (!h || !n_hits) return fail(BHIP_E_ARG, "null argument");
@@ -734,6 +741,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		HIPCHK(hipMemcpyAsync(h->hsc_pinned, h->shared_ctr.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->post_stream));
 		HIPCHK(hipEventRecord(h->ev[3], h->post_stream));
 		seed_next_batch(h, slot, h->ev[3]);
+		if (h->enqueued_hook && attempt == 0) h->enqueued_hook(h->enqueued_ctx);      // the caller's host work for later batches, while the device is busy with this one
 		HIPCHK(hipEventSynchronize(h->ev[2]));
 		HIPCHK(hipStreamSynchronize(h->sweep_stream));
 		HIPCHK(hipStreamSynchronize(h->post_stream));

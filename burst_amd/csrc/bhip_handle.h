@@ -276,6 +276,7 @@ struct Handle {
 	int opt_seed_ahead = 1;       // seed lookups of the next staged batch run while the current one is swept
 	int opt_seed_ahead_blocks = 2; // 256-thread blocks per CU of a seed kernel that runs ahead (0 = one block per 256 lookups, as in place); 2: +2.3 % on the bench
 	int opt_peq_ahead_blocks = 16; // 256-thread blocks per CU of a profile build that runs ahead
+	void (*enqueued_hook)(void *) = nullptr; void *enqueued_ctx = nullptr;      // bhip_set_enqueued_hook
 	int opt_seed_min_need = 3;    // the longest lists of a query's sampled words are left out while its guaranteed count stays >= this (0 = keep every list)
 	int opt_seed_drop_len = 8;    // ... lists shorter than this are always kept (leaving them out saves nothing and costs selectivity)
 	double acx_wmean = 0.0;       // occurrence-weighted mean .acx list length

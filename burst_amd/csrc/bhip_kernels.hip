@@ -2689,7 +2689,7 @@ template __global__ void k_rescore<true>(const BhipRawHit *, const uint32_t *, u
 	const uint32_t *, uint32_t, uint32_t, uint32_t);
 
 #ifdef PFM_PROF
-extern "C" int bhip_debug_prof(unsigned long long *out, int reset) {
+extern "C" BHIP_API int bhip_debug_prof(unsigned long long *out, int reset) {
 	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pfm_prof), 64) != hipSuccess) return -1;
 	if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pfm_prof), z, 64) != hipSuccess) return -1; }
 	return 0;

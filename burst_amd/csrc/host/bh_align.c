@@ -103,6 +103,37 @@ int bh_align_ranges_reuse(void *hh, const BhQueries *Q, const uint64_t *r0, cons
 	run->hits = keep; run->capHits = cap; run->hitsPinned = pin;
 	return align_ranges(hh, Q, r0, r1, n_ranges, mode, batch_uniq, run);
 }
+/* staging of batch k of a job: a batch of unique queries [u, u + B) is two spans of the caller's arrays (forward entries, then their
+ * reverse complements, burst.c:3087-3109); only copies and launches are enqueued here */
+typedef struct StageCtx {
+	void *hh; const BhQueries *Q; const uint64_t *bu; uint64_t nBatches; int twoStrand; BhRun *run;
+	uint64_t hook_next;      /* batch the library's "chain enqueued" hook stages (0 = none) */
+	int rc; double secHook;
+} StageCtx;
+static void stage_batch(StageCtx *c, uint64_t k) {
+	const BhQueries *Q = c->Q;
+	const uint64_t u_ = c->bu[2 * k], B_ = c->bu[2 * k + 1];
+	BhipQuerySpan sp_[2];
+	memset(sp_, 0, sizeof sp_);
+	/* a batch of A/C/G/T-only queries travels four symbols per byte, every batch with 2-byte lengths (same for both strands) */
+	const int clean_ = Q->codes2 && Q->ambBefore && Q->ambBefore[u_ + B_] == Q->ambBefore[u_] && !getenv("BURST_HOST_NO_PACK2");
+	if (clean_) sp_[0].codes2 = sp_[1].codes2 = Q->codes2;
+	if (Q->len16 && !getenv("BURST_HOST_NO_PACK2")) sp_[0].len = sp_[1].len = Q->len16 + u_;
+	sp_[0].codes = Q->codes; sp_[0].codes4 = Q->codes4; sp_[0].off = Q->qoff + u_; sp_[0].emac = Q->emac + u_; sp_[0].rc = Q->rc + u_; sp_[0].flags = Q->flags + u_; sp_[0].n = (uint32_t)B_; sp_[0].q_base = (uint32_t)u_;
+	if (c->twoStrand) { const uint64_t e_ = Q->numUniq + u_;
+		sp_[1].codes = Q->codes; sp_[1].codes4 = Q->codes4; sp_[1].off = Q->qoff + e_; sp_[1].emac = Q->emac + e_; sp_[1].rc = Q->rc + e_; sp_[1].flags = Q->flags + e_; sp_[1].n = (uint32_t)B_; sp_[1].q_base = (uint32_t)e_; }
+	const double ts_ = now_sec();
+	if (bhip_stage_spans(c->hh, sp_, c->twoStrand ? 2 : 1, (uint32_t)B_, Q->maxLen)) c->rc = bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error());
+	c->run->secAlign += now_sec() - ts_;
+}
+/* called by the library from inside bhip_align_staged, when the chain of the current batch has been enqueued and before it waits for
+ * the device: the batch after next is staged NOW, beside the kernels, instead of between two batches with the device idle */
+static void stage_hook(void *p) {
+	StageCtx *c = (StageCtx *)p;
+	if (c->hook_next && c->hook_next < c->nBatches && !c->rc) { const double t0 = now_sec(); stage_batch(c, c->hook_next); c->secHook += now_sec() - t0; }
+	c->hook_next = 0;
+}
+
 static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const uint64_t *r1, uint32_t n_ranges, BhMode mode, uint64_t batch_uniq, BhRun *run) {
 	if (!batch_uniq) batch_uniq = 1u << 18;
 	if (batch_uniq > 0x7FFFFFFFu) batch_uniq = 0x7FFFFFFFu;
@@ -152,20 +183,8 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 	if (!hits) { free(bu); return bh_set_error(BH_E_OOM, "OOM:hits"); }
 	bhip_set_option(hh, "async_d2h", 1);
 	int rc = BH_OK;
-	#define STAGE(k) do { \
-		const uint64_t u_ = bu[2 * (k)], B_ = bu[2 * (k) + 1]; \
-		BhipQuerySpan sp_[2]; \
-		memset(sp_, 0, sizeof sp_); \
-		/* a batch of A/C/G/T-only queries travels four symbols per byte, every batch with 2-byte lengths (same for both strands) */ \
-		const int clean_ = Q->codes2 && Q->ambBefore && Q->ambBefore[u_ + B_] == Q->ambBefore[u_] && !getenv("BURST_HOST_NO_PACK2"); \
-		if (clean_) sp_[0].codes2 = sp_[1].codes2 = Q->codes2; \
-		if (Q->len16 && !getenv("BURST_HOST_NO_PACK2")) sp_[0].len = sp_[1].len = Q->len16 + u_; \
-		sp_[0].codes = Q->codes; sp_[0].codes4 = Q->codes4; sp_[0].off = Q->qoff + u_; sp_[0].emac = Q->emac + u_; sp_[0].rc = Q->rc + u_; sp_[0].flags = Q->flags + u_; sp_[0].n = (uint32_t)B_; sp_[0].q_base = (uint32_t)u_; \
-		if (twoStrand) { const uint64_t e_ = Q->numUniq + u_; \
-			sp_[1].codes = Q->codes; sp_[1].codes4 = Q->codes4; sp_[1].off = Q->qoff + e_; sp_[1].emac = Q->emac + e_; sp_[1].rc = Q->rc + e_; sp_[1].flags = Q->flags + e_; sp_[1].n = (uint32_t)B_; sp_[1].q_base = (uint32_t)e_; } \
-		const double ts_ = now_sec(); \
-		if (bhip_stage_spans(hh, sp_, twoStrand ? 2 : 1, (uint32_t)B_, Q->maxLen)) rc = bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error()); \
-		run->secAlign += now_sec() - ts_; } while (0)
+	StageCtx sc = {hh, Q, bu, nBatches, twoStrand, run, 0, BH_OK, 0.0};
+	#define STAGE(k) do { stage_batch(&sc, (k)); if (sc.rc) rc = sc.rc; } while (0)
 	const int dbg = getenv("BURST_HOST_DEBUG") != NULL;
 	const double tb0 = now_sec();
 	/* two batches ahead: while batch k is aligned, batch k+1 is staged already (the library runs its seed lookups and profile
@@ -174,9 +193,12 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 	 * calling thread for 11 ms (measured, ROCm 7.2) */
 	STAGE((uint64_t)0);
 	if (nBatches > 1 && rc == BH_OK) STAGE((uint64_t)1);
+	const int use_hook = !getenv("BURST_HOST_NO_HOOK") && bhip_set_enqueued_hook(hh, stage_hook, &sc) == 0;
 	for (uint64_t k = 0; k < nBatches && rc == BH_OK; ++k) {
 		const double tk0 = now_sec();
-		if (k > 0 && k + 2 < nBatches) { STAGE(k + 2); if (rc) break; }
+		/* batch k + 2: staged from inside bhip_align_staged(k), once the chain of batch k is enqueued (the slot of batch k - 1 is free by
+		 * then); without the hook, here -- between two batches */
+		if (k > 0 && k + 2 < nBatches) { if (use_hook) sc.hook_next = k + 2; else { STAGE(k + 2); if (rc) break; } }
 		const double tk1 = now_sec();
 		for (;;) {
 			uint64_t n = 0;
@@ -199,6 +221,8 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 				rc = bh_set_error(BH_E_USAGE, "libburst_hip: %s", bhip_last_error()); break;
 			}
 			if (r) { rc = bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error()); break; }
+			if (sc.rc) { rc = sc.rc; break; }
+			if (sc.hook_next) { STAGE(sc.hook_next); sc.hook_next = 0; if (rc) break; }      /* (the hook did not run: a call that only delivered resident records) */
 			nHits += n;
 			if (k == 0 && nBatches > 2) STAGE((uint64_t)2);      /* (the third batch only now: see the note at the loop) */
 			BhipStats st;
@@ -212,6 +236,8 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 		}
 	}
 	#undef STAGE
+	bhip_set_enqueued_hook(hh, NULL, NULL);
+	if (dbg) fprintf(stderr, "[bh_align] %lu batches; %.3f ms of staging calls ran inside bhip_align_staged (chain enqueued, device busy)\n", (unsigned long)nBatches, 1e3 * sc.secHook);
 	free(bu);
 	{ const double t0 = now_sec(); bhip_sync_hits(hh); run->secAlign += now_sec() - t0; }
 	bhip_set_option(hh, "async_d2h", 0);

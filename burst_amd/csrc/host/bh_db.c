@@ -449,6 +449,89 @@ int bh_edx_write(const BhDb *db, const char *path, long db_qlen, float thres) {
 	return BH_OK;
 }
 
+/* Several .edx files -> one, section by section (no chunk is ever held in memory): the databases are laid end to end -- headers,
+ * reference maps (shifted by the headers in front), fragment starts, sort permutations (shifted by the fragments in front), clump
+ * lengths, clump areas.  What makes that a valid database: reference number = 16 * clump + lane, so every part but the last must
+ * fill its last clump (totR a multiple of 16), and no part may carry duplicate-fragment tables (totR == origTotR).  For databases
+ * too large to be BUILT in one piece in the host memory at hand (bench.py: the metric's 31.5 GB stand-in in a 300 GB container);
+ * each part is what -d QUICK makes of its share of the references.  No reference counterpart. */
+typedef struct EdxHead { uint8_t ctrl; uint64_t hl; uint32_t shear, totR, origTotR, numRclumps, maxLenR, nH; uint64_t off_heads, off_map, off_start, off_rix, off_clen, off_packed, words; } EdxHead;
+static int edx_head(const char *path, EdxHead *h) {
+	FILE *f = fopen(path, "rb");
+	if (!f) return bh_set_error(BH_E_IO, "cannot read %s", path);
+	int ok = fread(&h->ctrl, 1, 1, f) == 1 && fread(&h->hl, 8, 1, f) == 1 && fread(&h->shear, 4, 1, f) == 1 && fread(&h->totR, 4, 1, f) == 1 &&
+	         fread(&h->origTotR, 4, 1, f) == 1 && fread(&h->numRclumps, 4, 1, f) == 1 && fread(&h->maxLenR, 4, 1, f) == 1;
+	h->off_heads = 29;
+	if (ok) ok = !fseeko(f, (off_t)(h->off_heads + h->hl), SEEK_SET) && fread(&h->nH, 4, 1, f) == 1;
+	h->off_map = h->off_heads + h->hl + 4;
+	const int rebase = (h->ctrl >> 6) & 1;
+	h->off_start = h->off_map + 4ull * h->origTotR;
+	h->off_rix = h->off_start + (rebase ? 4ull * h->origTotR : 0);
+	h->off_clen = h->off_rix + 4ull * h->origTotR;
+	h->off_packed = h->off_clen + 4ull * h->numRclumps;
+	h->words = 0;
+	if (ok && h->totR == h->origTotR) {
+		ok = !fseeko(f, (off_t)h->off_clen, SEEK_SET);
+		uint32_t buf[4096];
+		for (uint32_t c = 0; ok && c < h->numRclumps;) {
+			const uint32_t n = h->numRclumps - c < 4096 ? h->numRclumps - c : 4096;
+			ok = fread(buf, 4, n, f) == n;
+			for (uint32_t i = 0; i < n; ++i) h->words += buf[i] / 2u + (buf[i] & 1u);
+			c += n;
+		}
+	}
+	fclose(f);
+	return ok ? BH_OK : bh_set_error(BH_E_IO, "truncated database %s", path);
+}
+/* copy n bytes of `in` (from offset off) to `out`; add > 0: the bytes are 32-bit numbers and `add` is added to each */
+static int copy_section(FILE *out, const char *path, uint64_t off, uint64_t n, uint32_t add) {
+	FILE *f = fopen(path, "rb");
+	if (!f || fseeko(f, (off_t)off, SEEK_SET)) { if (f) fclose(f); return bh_set_error(BH_E_IO, "cannot read %s", path); }
+	const size_t B = 8u << 20;
+	uint8_t *buf = malloc(B);
+	if (!buf) { fclose(f); return bh_set_error(BH_E_OOM, "OOM:merge"); }
+	int rc = BH_OK;
+	while (n && !rc) {
+		const size_t k = n < B ? (size_t)n : B;
+		if (fread(buf, 1, k, f) != k) { rc = bh_set_error(BH_E_IO, "truncated database %s", path); break; }
+		if (add) { uint32_t *w = (uint32_t *)buf; for (size_t i = 0; i < k / 4; ++i) w[i] += add; }
+		if (fwrite(buf, 1, k, out) != k) rc = bh_set_error(BH_E_IO, "write failed");
+		n -= k;
+	}
+	free(buf); fclose(f);
+	return rc;
+}
+int bh_edx_merge(const char *const *paths, int n, const char *out_path) {
+	if (n < 1 || n > 64) return bh_set_error(BH_E_USAGE, "bad number of databases to merge (%d)", n);
+	EdxHead h[64];
+	uint64_t hl = 0, totR = 0, orig = 0, clumps = 0, nH = 0; uint32_t maxL = 0;
+	for (int i = 0; i < n; ++i) {
+		int rc = edx_head(paths[i], &h[i]);
+		if (rc) return rc;
+		if (h[i].totR != h[i].origTotR) return bh_set_error(BH_E_USAGE, "%s holds duplicate fragments (RefDedupIx): such databases cannot be laid end to end", paths[i]);
+		if (i + 1 < n && (h[i].totR & 15u)) return bh_set_error(BH_E_USAGE, "%s does not fill its last clump (%u references): only the last part may end in a partial clump", paths[i], h[i].totR);
+		if (h[i].ctrl != h[0].ctrl || h[i].shear != h[0].shear) return bh_set_error(BH_E_USAGE, "%s was built with other settings than %s", paths[i], paths[0]);
+		hl += h[i].hl; totR += h[i].totR; orig += h[i].origTotR; clumps += h[i].numRclumps; nH += h[i].nH;
+		if (h[i].maxLenR > maxL) maxL = h[i].maxLenR;
+	}
+	if (totR > 0xFFFFFFFFull || clumps >= (1ull << 24) || nH > 0xFFFFFFFFull) return bh_set_error(BH_E_USAGE, "the merged database would have %lu references in %lu clumps: beyond the format", (unsigned long)totR, (unsigned long)clumps);
+	FILE *o = fopen(out_path, "wb");
+	if (!o) return bh_set_error(BH_E_IO, "ERROR: Cannot open output: %s", out_path);
+	setvbuf(o, NULL, _IOFBF, 8u << 20);
+	const uint32_t totR32 = (uint32_t)totR, orig32 = (uint32_t)orig, cl32 = (uint32_t)clumps, nH32 = (uint32_t)nH;
+	fwrite(&h[0].ctrl, 1, 1, o); fwrite(&hl, 8, 1, o); fwrite(&h[0].shear, 4, 1, o); fwrite(&totR32, 4, 1, o); fwrite(&orig32, 4, 1, o); fwrite(&cl32, 4, 1, o); fwrite(&maxL, 4, 1, o);
+	int rc = BH_OK;
+	for (int i = 0; i < n && !rc; ++i) rc = copy_section(o, paths[i], h[i].off_heads, h[i].hl, 0);
+	if (!rc) fwrite(&nH32, 4, 1, o);
+	{ uint64_t hb = 0; for (int i = 0; i < n && !rc; ++i) { rc = copy_section(o, paths[i], h[i].off_map, 4ull * h[i].origTotR, (uint32_t)hb); hb += h[i].nH; } }
+	if ((h[0].ctrl >> 6) & 1) for (int i = 0; i < n && !rc; ++i) rc = copy_section(o, paths[i], h[i].off_start, 4ull * h[i].origTotR, 0);
+	{ uint64_t ob = 0; for (int i = 0; i < n && !rc; ++i) { rc = copy_section(o, paths[i], h[i].off_rix, 4ull * h[i].origTotR, (uint32_t)ob); ob += h[i].origTotR; } }
+	for (int i = 0; i < n && !rc; ++i) rc = copy_section(o, paths[i], h[i].off_clen, 4ull * h[i].numRclumps, 0);
+	for (int i = 0; i < n && !rc; ++i) rc = copy_section(o, paths[i], h[i].off_packed, 16ull * h[i].words, 0);
+	if (fclose(o) && !rc) rc = bh_set_error(BH_E_IO, "ERROR: write failed: %s", out_path);
+	return rc;
+}
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Accelerator: for every clump the set of K-mers (2 bits per base, first base most significant, burst.c:4097-4102)
  * occurring in any of its 16 lanes, expanded over IUPAC codes (AMBIGS, burst.c:1372-1375); words containing N are
@@ -626,6 +709,63 @@ int bh_acx_from_device(BhDb *db, void *hh, int K, int z) {
 	db->hasAcx = 1; db->K = K; db->acxFmt = fmt; db->acxZ = z ? 1 : 0;
 	db->acxLens = lens; db->acxLists = lists; db->acxListBytes = bytes; db->badList = bl; db->badSz = nb;
 	return BH_OK;
+}
+
+/* The .acx of a database straight from the device that holds its accelerator, list area streamed: the length table comes over
+ * whole (4 bytes per word), the entries in runs of whole words of about 2^27 entries, packed (burst.c:3501-3528) and written as they
+ * come -- the host never holds more than one run (bh_acx_from_device + bh_acx_write hold 4 + 3 bytes of EVERY entry: 230 GB for
+ * the 33 G entries of a 19 GB database). */
+int bh_acx_write_from_device(const BhDb *db, void *hh, int K, int z, const char *path) {
+	uint64_t tot = 0; uint32_t nb = 0;
+	if (bhip_acx_export(hh, NULL, NULL, NULL, 0, &tot, NULL, 0, &nb)) return bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error());
+	const uint64_t nw = 1ull << (2 * K);
+	uint32_t *lens = malloc(nw * 4), *bl = malloc(((size_t)nb + 1) * 4);
+	if (!lens || !bl) { free(lens); free(bl); return bh_set_error(BH_E_OOM, "OOM:Accelerant.Refs"); }
+	if (bhip_acx_export(hh, lens, NULL, NULL, 0, &tot, bl, nb, &nb)) { free(lens); free(bl); return bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error()); }
+	const int fmt = db->numRclumps > 1048574 ? 1 : 0;
+	FILE *o = fopen(path, "wb");
+	if (!o) { free(lens); free(bl); return bh_set_error(BH_E_USAGE, "Cannot write accelerator '%s'", path); }
+	setvbuf(o, NULL, _IOFBF, 8u << 20);
+	const uint8_t vers = (uint8_t)(1 << 7 | (z ? 1 : 0) << 6 | fmt);
+	fwrite(&vers, 1, 1, o); fwrite(&nb, 4, 1, o);
+	fwrite(lens, 4, nw, o);
+	const uint64_t RUN = 1ull << 27;
+	uint32_t *ent = malloc((RUN + (1u << 24)) * 4);
+	uint8_t *out = malloc((RUN + (1u << 24)) * 3 + 16);
+	int rc = (ent && out) ? BH_OK : bh_set_error(BH_E_OOM, "OOM:WordDump");
+	uint64_t e0 = 0;
+	for (uint64_t w0 = 0; w0 < nw && !rc;) {
+		uint64_t w1 = w0, n = 0;
+		while (w1 < nw && w1 - w0 < (1u << 24) && n < RUN) n += lens[w1++];      /* (a list has fewer than 2^24 entries: the buffers hold RUN + 2^24) */
+		if (n && bhip_acx_export_entries(hh, e0, n, ent, NULL)) { rc = bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error()); break; }
+		/* byte position of every word of the run, then the words side by side */
+		const uint64_t nwr = w1 - w0;
+		uint64_t *pos = malloc((nwr + 1) * 16);
+		if (!pos) { rc = bh_set_error(BH_E_OOM, "OOM:WordDump"); break; }
+		uint64_t *epos = pos + nwr + 1;
+		pos[0] = 0; epos[0] = 0;
+		for (uint64_t k = 0; k < nwr; ++k) { const uint32_t l = lens[w0 + k]; pos[k + 1] = pos[k] + (fmt ? (uint64_t)l * 3 : (uint64_t)(l / 2u) * 5 + (l & 1u) * 3); epos[k + 1] = epos[k] + l; }
+		#pragma omp parallel for schedule(static)
+		for (uint64_t k = 0; k < nwr; ++k) {
+			uint8_t *p = out + pos[k];
+			const uint32_t *l = ent + epos[k];
+			const uint32_t m = lens[w0 + k];
+			if (fmt) for (uint32_t i = 0; i < m; ++i) { p[0] = (uint8_t)l[i]; p[1] = (uint8_t)(l[i] >> 8); p[2] = (uint8_t)(l[i] >> 16); p += 3; }
+			else {
+				uint32_t i = 0;
+				for (; i + 1 < m; i += 2) { const uint64_t v = (uint64_t)l[i] | ((uint64_t)l[i + 1] << 20); memcpy(p, &v, 5); p += 5; }
+				if (i < m) { const uint64_t v = l[i]; memcpy(p, &v, 3); p += 3; }
+			}
+		}
+		if (pos[nwr] && fwrite(out, 1, pos[nwr], o) != pos[nwr]) rc = bh_set_error(BH_E_IO, "ERROR: write failed: %s", path);
+		free(pos);
+		e0 += n; w0 = w1;
+	}
+	if (!rc && e0 != tot) rc = bh_set_error(BH_E_INTERNAL, "accelerator lists: %lu entries written, %lu expected", (unsigned long)e0, (unsigned long)tot);
+	if (!rc) fwrite(bl, 4, nb, o);
+	free(ent); free(out); free(lens); free(bl);
+	if (fclose(o) && !rc) rc = bh_set_error(BH_E_IO, "ERROR: write failed: %s", path);
+	return rc;
 }
 
 int bh_acx_write(const BhDb *db, const char *path) {

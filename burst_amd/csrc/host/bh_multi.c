@@ -330,3 +330,61 @@ int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhN
 	if (dbg) fprintf(stderr, "[bh_search_multi] rank %d of %d: align %.4f s, minima + filter %.4f s, hand-over %.4f s, order %.4f s\n", R[0].rank, n_ranks, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], omp_get_wtime() - tp[3]);
 	return rc;
 }
+
+/* A database of S shards on FEWER devices than shards -- here: on one.  The shards take turns on the device: shard s goes up (with
+ * -ad its accelerator is built there from the slice alone), ALL queries are aligned against it, its records and per-query minima
+ * come back to host memory, the device is given to the next shard.  What bh_search_multi_ex does between ranks happens between
+ * turns: minimum over the shards (Sb->ed over the whole database, burst.c:4217-4277), what lies above it dropped (not in FORAGE),
+ * the rest put in (query entry, reference) order -- the records one device holding everything produces.  A database larger than the
+ * device is served this way at the price of S uploads; `secs[s]` = align phase of shard s, `up[s]` = its upload (+ build). */
+int bh_search_serial_shards(const BhDb *db, int device, int n_shards, int z, int build_K, const BhQueries *Q, BhMode mode, uint64_t batch, BhRun *all, double *secs, double *up) {
+	if (n_shards < 1 || n_shards > BH_MAX_RANKS) return bh_set_error(BH_E_USAGE, "bad number of shards (%d)", n_shards);
+	BhRun runs[BH_MAX_RANKS]; memset(runs, 0, sizeof runs);
+	uint8_t *best = NULL, *mine = NULL;
+	const int reduce = n_shards > 1 && mode != BH_FORAGE;
+	int rc = BH_OK;
+	if (reduce) {
+		best = malloc(Q->numUniq + 1); mine = malloc(Q->numUniq + 1);
+		if (!best || !mine) { free(best); free(mine); return bh_set_error(BH_E_OOM, "OOM:minima"); }
+		memset(best, 255, Q->numUniq);
+	}
+	const uint64_t strands = Q->numEntries > Q->numUniq ? 2 : 1;
+	for (int s = 0; s < n_shards && !rc; ++s) {
+		uint32_t c0, c1;
+		bh_clump_shard(db, n_shards, s, &c0, &c1);
+		BhDb slice; memset(&slice, 0, sizeof slice);
+		void *hh = NULL;
+		double t0 = omp_get_wtime();
+		if ((rc = bh_db_slice(db, c0, c1, &slice))) break;
+		if ((rc = bh_device_open_ex(&slice, device, z, build_K, &hh))) { bh_db_free(&slice); break; }
+		const uint64_t B = Q->numUniq < batch ? Q->numUniq : batch;
+		if (B) (void)bhip_reserve_symbols(hh, (uint32_t)(B * strands), Q->maxLen, 0);
+		if (up) up[s] = omp_get_wtime() - t0;
+		t0 = omp_get_wtime();
+		const uint64_t u0 = 0, u1 = Q->numUniq;
+		rc = bh_align_ranges(hh, Q, &u0, &u1, 1, mode, batch, &runs[s]);
+		if (secs) secs[s] = omp_get_wtime() - t0;
+		bhip_destroy(hh);
+		bh_db_free(&slice);
+		if (rc) break;
+		for (uint64_t k = 0; k < runs[s].nHits; ++k) runs[s].hits[k].refIx += 16u * c0;
+		if (reduce) {
+			shard_minima(Q, &runs[s], mine);
+			uint8_t *both[2] = {best, mine};
+			bh_minima_merge(both, 2, Q->numUniq);
+		}
+		all->nBatches += runs[s].nBatches; all->secAlign += runs[s].secAlign;
+		all->total.n_pairs += runs[s].total.n_pairs;
+	}
+	if (!rc) {
+		const BhipHit *src[BH_MAX_RANKS]; uint64_t cnt[BH_MAX_RANKS], tot = 0;
+		for (int s = 0; s < n_shards; ++s) { if (reduce) shard_filter(Q, &runs[s], best); src[s] = runs[s].hits; cnt[s] = runs[s].nHits; tot += runs[s].nHits; }
+		if (bh_run_reserve_plain(all, tot + 1)) rc = bh_set_error(BH_E_OOM, "OOM:hits");
+		else if (n_shards == 1) { if (tot) memcpy(all->hits, src[0], tot * sizeof(BhipHit)); all->nHits = tot; }
+		else { rc = order_into(src, cnt, n_shards, all->hits, Q->numEntries); all->nHits = tot; }
+	}
+	for (int s = 0; s < n_shards; ++s) bh_run_free(&runs[s]);
+	free(best); free(mine);
+	return rc;
+}
+

@@ -41,6 +41,11 @@ static void synth_family(char *w0, size_t *used, char *base, uint32_t b, uint32_
 }
 
 int bh_synth_refs(const char *fasta_out, uint32_t n_base, uint32_t n_variants, uint32_t length, double rate, uint64_t seed) {
+	return bh_synth_refs_range(fasta_out, 0, n_base, n_variants, length, rate, seed);
+}
+/* base sequences [first_base, first_base + n_base) of the same family of sequences (a sequence depends on the seed and its number only):
+ * a large set of references written part by part */
+int bh_synth_refs_range(const char *fasta_out, uint32_t first_base, uint32_t n_base, uint32_t n_variants, uint32_t length, double rate, uint64_t seed) {
 	FILE *o = fopen(fasta_out, "wb");
 	if (!o) return bh_set_error(BH_E_IO, "cannot write %s", fasta_out);
 	setvbuf(o, NULL, _IONBF, 0);
@@ -88,7 +93,7 @@ int bh_synth_refs(const char *fasta_out, uint32_t n_base, uint32_t n_variants, u
 				}
 			}
 			#pragma omp for schedule(dynamic, 64)
-			for (uint32_t k = 0; k < nb; ++k) synth_family(mine + (size_t)k * per_fam, &mused[k], base, b0 + k, n_variants, length, rate, seed);
+			for (uint32_t k = 0; k < nb; ++k) synth_family(mine + (size_t)k * per_fam, &mused[k], base, first_base + b0 + k, n_variants, length, rate, seed);
 			free(base);
 		}
 		pend_n = nb; pend_buf = (int)(it & 1);
@@ -107,6 +112,12 @@ static const char *COMPAT[4] = {"MRWVHD", "MYSBVH", "KRSBVD", "KYWBHD"};
 
 int bh_synth_reads(const char *refs_fasta, const char *fasta_out, uint64_t n_reads, uint32_t read_len, const uint32_t *edit_choices,
                    uint32_t n_choices, int rc, double iupac_rate, uint64_t seed) {
+	return bh_synth_reads_ex(refs_fasta, fasta_out, n_reads, read_len, edit_choices, n_choices, rc, iupac_rate, seed, 0, 0);
+}
+/* first_read: number of the first read in the names (reads drawn part by part from the parts of a large set of references keep
+ * unique names); append: add to the file instead of replacing it */
+int bh_synth_reads_ex(const char *refs_fasta, const char *fasta_out, uint64_t n_reads, uint32_t read_len, const uint32_t *edit_choices,
+                      uint32_t n_choices, int rc, double iupac_rate, uint64_t seed, uint64_t first_read, int append) {
 	FILE *f = fopen(refs_fasta, "rb");
 	if (!f) return bh_set_error(BH_E_IO, "Cannot open FASTA file: %s.", refs_fasta);
 	fseeko(f, 0, SEEK_END); uint64_t sz = (uint64_t)ftello(f); rewind(f);
@@ -127,7 +138,7 @@ int bh_synth_reads(const char *refs_fasta, const char *fasta_out, uint64_t n_rea
 	uint64_t nOk = 0;
 	for (uint64_t i = 0; i < n; ++i) nOk += len[i] > read_len;
 	if (!nOk) { free(dump); free(seq); free(len); return bh_set_error(BH_E_USAGE, "no reference longer than %u", read_len); }
-	FILE *o = fopen(fasta_out, "wb");
+	FILE *o = fopen(fasta_out, append ? "ab" : "wb");
 	if (!o) { free(dump); free(seq); free(len); return bh_set_error(BH_E_IO, "cannot write %s", fasta_out); }
 	setvbuf(o, NULL, _IOFBF, 1 << 22);
 	uint64_t s = seed * 0xD1B54A32D192ED03ULL + 0x7654321ULL;
@@ -164,7 +175,7 @@ int bh_synth_reads(const char *refs_fasta, const char *fasta_out, uint64_t n_rea
 				/* complement of an IUPAC symbol */
 				static const char *from = "KMRYSWBVHDN", *to = "MKYRSWVBDHN"; const char *q = strchr(from, rd[i]); if (q) rd[i] = to[q - from]; } }
 		}
-		fprintf(o, ">read%lu_g%lu_p%u_e%u%s\n", (unsigned long)r, (unsigned long)gi, st, ne, isrc ? "_rc" : "");
+		fprintf(o, ">read%lu_g%lu_p%u_e%u%s\n", (unsigned long)(first_read + r), (unsigned long)gi, st, ne, isrc ? "_rc" : "");
 		fwrite(rd, 1, m, o); fputc('\n', o);
 	}
 	free(rd); free(pos); free(kind); free(dump); free(seq); free(len);

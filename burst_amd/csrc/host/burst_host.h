@@ -66,6 +66,9 @@ int  bh_db_from_fasta(const char *path, uint32_t maxLenQ, float thres, int do_sh
 int  bh_edx_write(const BhDb *db, const char *path, long db_qlen, float thres);
 /* latency = clump formation tolerance, the reference's `-l` (LATENCY, burst.c:83): 16 in bh_db_from_fasta, 0 = input order */
 int  bh_db_from_fasta_ex(const char *path, uint32_t maxLenQ, float thres, int do_shear, long shear_len, int dedupe, uint32_t latency, BhDb *db);
+/* n .edx files laid end to end into one (every part but the last must fill its last clump; no duplicate-fragment tables): a
+ * database too large to be built in one piece in the memory at hand, built part by part */
+int  bh_edx_merge(const char *const *paths, int n, const char *out_path);
 int  bh_acx_build(BhDb *db, int K, int z);
 /* skip_ambig = -sa: leave out every word that holds an ambiguous symbol (burst.c:3360-3366) */
 int  bh_acx_build_ex(BhDb *db, int K, int z, int skip_ambig);
@@ -73,6 +76,8 @@ int  bh_acx_build_ex(BhDb *db, int K, int z, int skip_ambig);
  * reference writes them (burst.c:3501-3530): with a handle whose accelerator was built on the device this is make_accelerator
  * without the host pass */
 int  bh_acx_from_device(BhDb *db, void *hip_handle, int K, int z);
+/* the same tables written to an .acx file without being held on the host (the list area is streamed from the device run by run) */
+int  bh_acx_write_from_device(const BhDb *db, void *hip_handle, int K, int z, const char *path);
 /* view of the clumps [c0, c1) with the accelerator restricted to them (database sharding); `db` must outlive the view */
 int  bh_db_slice(const BhDb *db, uint32_t c0, uint32_t c1, BhDb *out);
 int  bh_acx_write(const BhDb *db, const char *path);
@@ -157,6 +162,10 @@ int  bh_search_multi(BhMultiRank *ranks, int n_local, int n_ranks, void *comm, c
  * ((entry, reference) pairs must be unique); element-wise minimum of n tables of len bytes into best[0] (NULL tables are skipped) */
 int  bh_order_records(BhipHit *hits, uint64_t n, uint64_t n_entries);
 void bh_minima_merge(uint8_t *const *best, int n, uint64_t len);
+/* n_shards database shards taking turns on ONE device (a database larger than the device): every shard is uploaded, searched with all
+ * queries and released; minima over the shards, filter, (query entry, reference) order -- the records of a single device holding
+ * everything.  secs / up (n_shards each, may be NULL): align phase and upload (+ accelerator build with build_K) of every shard */
+int  bh_search_serial_shards(const BhDb *db, int device, int n_shards, int z, int build_K, const BhQueries *Q, BhMode mode, uint64_t batch, BhRun *all, double *secs, double *up);
 /* ---- ranks of one node in different processes: the records meet in shared memory (bh_node.c) ---- */
 typedef struct BhNode BhNode;
 /* job: a name all ranks of the job share (and no other job on the machine); cap_records: what the rank expects to deliver per
@@ -212,8 +221,11 @@ int bh_set_error(int code, const char *fmt, ...);
 
 /* ---- synthetic data (tests / bench tooling; behaviour modelled on embalmlets/LLsim.c:175-231) ---- */
 int bh_synth_refs(const char *fasta_out, uint32_t n_base, uint32_t n_variants, uint32_t length, double variant_rate, uint64_t seed);
+int  bh_synth_refs_range(const char *fasta_out, uint32_t first_base, uint32_t n_base, uint32_t n_variants, uint32_t length, double rate, uint64_t seed);
 int bh_synth_reads(const char *refs_fasta, const char *fasta_out, uint64_t n_reads, uint32_t read_len, const uint32_t *edit_choices,
                    uint32_t n_choices, int rc, double iupac_rate, uint64_t seed);
+int  bh_synth_reads_ex(const char *refs_fasta, const char *fasta_out, uint64_t n_reads, uint32_t read_len, const uint32_t *edit_choices,
+                       uint32_t n_choices, int rc, double iupac_rate, uint64_t seed, uint64_t first_read, int append);
 
 #ifdef __cplusplus
 }

@@ -281,6 +281,45 @@ int main(int argc, char **argv) {
 	const int use_rccl = n_gpus_given && !gather_host;
 	if (shard_db && !n_shards) n_shards = n_gpus;
 	if (!shard_db || n_shards < 2) { shard_db = 0; n_shards = 1; }
+	if (shard_db && n_gpus == 1 && n_shards > 1 && !use_rccl) {
+		/* more shards than devices: the shards take turns on the one device (bh_search_serial_shards) -- a database larger than the
+		 * device's memory, at the price of one upload per shard */
+		if ((uint32_t)n_shards > db.numRclumps) { puts("ERROR: more database shards than clumps"); return 1; }
+		if (n_shards > BH_MAX_GPUS) { printf("ERROR: --shards %d (max %d)\n", n_shards, BH_MAX_GPUS); return 1; }
+		if (!n_dev_list) dev_list[0] = device;
+		JOIN_INGEST();
+		if (!ing_started && usedb) ingest_main(&ing);
+		if (ing.rc) { fprintf(stderr, "%s\n", ing.err); return code_to_exit(ing.rc); }
+		if (usedb && do_accel && !ing.K) bh_queries_bins(&Q, do_accel, K, z);
+		printf("Parsed %lu queries, %lu unique [min %u, max %u, maxED %u]; clear %lu, ambiguous %lu, bad %lu\n", (unsigned long)Q.totQ,
+		       (unsigned long)Q.numUniq, Q.minLen, Q.maxLen, Q.maxED, (unsigned long)Q.nClear, (unsigned long)Q.nAmbig, (unsigned long)Q.nBad);
+		if (db.shear && (uint32_t)(Q.maxLen / thres) > db.shear) { fputs("ERROR: DB incompatible with selected queries/identity.\n", stderr); return 1; }
+		bh_queries_pin(&Q);
+		PHASE("queries parsed, page-locked");
+		BhRun srun; memset(&srun, 0, sizeof srun);
+		double secs[BH_MAX_GPUS], ups[BH_MAX_GPUS];
+		const double ts0 = wall();
+		if ((rc = bh_search_serial_shards(&db, dev_list[0], n_shards, z, accel_dev ? K : 0, &Q, mode, batch, &srun, secs, ups))) { fprintf(stderr, "%s\n", bh_last_error()); return rc == BH_E_USAGE ? 1 : 4; }
+		printf("serial shards: %d shard(s) taking turns on device %d; upload (+ accelerator build) per shard [s]:", n_shards, dev_list[0]);
+		for (int r = 0; r < n_shards; ++r) printf(" %.3f", ups[r]);
+		printf("; align phase per shard [s]:");
+		for (int r = 0; r < n_shards; ++r) printf(" %.4f", secs[r]);
+		printf("\n");
+		printf("Search complete [%f s, %u batches, %lu candidate (query, clump) pairs, %lu hits]. Consolidating results...\n", wall() - ts0, srun.nBatches,
+		       (unsigned long)srun.total.n_pairs, (unsigned long)srun.nHits);
+		PHASE("search (all shards, uploads included)");
+		uint64_t slines = 0;
+		setvbuf(output, NULL, _IOFBF, 1 << 22);
+		BhRunView sview; memset(&sview, 0, sizeof sview);
+		sview.base = srun.hits; sview.n_runs = 1; sview.off[0] = 0; sview.n[0] = srun.nHits; sview.total = srun.nHits;
+		if ((rc = bh_report_view(output, &db, &Q, &sview, mode, (do_accel ? 0 : BH_REP_MERGED_LIST) | rep_flags, tax_FN ? &txo : NULL, &slines))) DIE(rc);
+		if (fclose(output)) { fprintf(stderr, "ERROR: write failed: %s\n", output_FN); return 2; }
+		printf("Wrote %lu alignments\n", (unsigned long)slines);
+		PHASE("consolidation, output");
+		printf("\nAlignment time: %f seconds\n", wall() - start);
+		fflush(NULL);
+		_exit(0);
+	}
 	if (n_gpus % n_shards) { printf("ERROR: --shards %d does not divide --gpus %d\n", n_shards, n_gpus); return 1; }
 	const int n_groups = n_gpus / n_shards;
 	if (shard_db && (uint32_t)n_shards > db.numRclumps) { puts("ERROR: more database shards than clumps"); return 1; }
@@ -390,7 +429,7 @@ int main(int argc, char **argv) {
 	uint64_t lines = 0;
 	setvbuf(output, NULL, _IOFBF, 1 << 22);
 	if ((rc = bh_report_view(output, &db, &Q, &view, mode, (do_accel ? 0 : BH_REP_MERGED_LIST) | rep_flags, tax_FN ? &txo : NULL, &lines))) DIE(rc);
-	fclose(output);
+	if (fclose(output)) { fprintf(stderr, "ERROR: write failed: %s\n", output_FN); return 2; }      /* (the last buffer of the report: a full disk must not end in exit code 0) */
 	printf("Wrote %lu alignments\n", (unsigned long)lines);
 	PHASE("consolidation, output");
 	printf("\nAlignment time: %f seconds\n", wall() - start);

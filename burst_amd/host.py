@@ -113,6 +113,9 @@ def lib():
         L.bh_report_ex.argtypes = [C.c_void_p, C.POINTER(BhDb), C.POINTER(BhQueries), C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         L.bh_synth_refs.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint64]
         L.bh_synth_reads.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint32, u32p, C.c_uint32, C.c_int, C.c_double, C.c_uint64]
+        L.bh_synth_refs_range.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint64]
+        L.bh_synth_reads_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint32, u32p, C.c_uint32, C.c_int, C.c_double, C.c_uint64, C.c_uint64, C.c_int]
+        L.bh_edx_merge.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_char_p]
         L.bh_score_lut.argtypes = [C.c_int, C.c_void_p]
         _lib = L
     return _lib
@@ -181,6 +184,10 @@ class Db:
     def acx_from_device(self, dev, K, z=1):
         """accelerator tables of this database from a device handle that built them (bh_acx_from_device): write() then saves the .acx"""
         _chk(lib().bh_acx_from_device(C.byref(self.c), dev._h, K, z))
+
+    def acx_write_from_device(self, dev, K, path, z=1):
+        """the .acx of this database written straight from the tables a device handle built, list area streamed (bh_acx_write_from_device)"""
+        _chk(lib().bh_acx_write_from_device(C.byref(self.c), dev._h, K, z, path.encode()))
 
     def close(self):
         if self._open:
@@ -375,10 +382,17 @@ def report_view(path, db, qs, view, mode, flags=0):
     return int(n.value)
 
 
-def synth_refs(path, n_base, n_variants, length, rate, seed):
-    _chk(lib().bh_synth_refs(path.encode(), n_base, n_variants, length, rate, seed))
+def synth_refs(path, n_base, n_variants, length, rate, seed, first_base=0):
+    """base sequences [first_base, first_base + n_base) with their variants: a sequence depends on the seed and its number only"""
+    _chk(lib().bh_synth_refs_range(path.encode(), first_base, n_base, n_variants, length, rate, seed))
 
 
-def synth_reads(refs, path, n_reads, read_len, edits, rc=False, iupac=0.0, seed=42):
+def edx_merge(paths, out):
+    """several .edx files laid end to end into one (bh_edx_merge)"""
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    _chk(lib().bh_edx_merge(arr, len(paths), out.encode()))
+
+
+def synth_reads(refs, path, n_reads, read_len, edits, rc=False, iupac=0.0, seed=42, first_read=0, append=False):
     e = np.ascontiguousarray(edits, np.uint32)
-    _chk(lib().bh_synth_reads(refs.encode(), path.encode(), n_reads, read_len, e.ctypes.data_as(u32p), len(e), int(rc), iupac, seed))
+    _chk(lib().bh_synth_reads_ex(refs.encode(), path.encode(), n_reads, read_len, e.ctypes.data_as(u32p), len(e), int(rc), iupac, seed, first_read, int(append)))

@@ -152,6 +152,13 @@ typedef struct BhipQuerySpan {
 } BhipQuerySpan;
 BHIP_API int bhip_stage_spans(void *handle, const BhipQuerySpan *spans, uint32_t n_spans, uint32_t n_shared, uint32_t max_len);
 
+/* Optional: a function the library calls from inside bhip_align_staged once the whole chain of the batch (and the seed lookups of the
+ * next staged one) has been ENQUEUED and before it waits for the device -- the moment a batch scheduler has for its own host work
+ * (staging the batch after next: ~20 asynchronous copies and launches) without leaving the device idle between two batches.  The
+ * hook may call bhip_stage_spans on the same handle; nothing else.  fn = NULL removes it.  No reference counterpart (the reference's
+ * scheduler is the OpenMP loop burst.c:4077). */
+BHIP_API int bhip_set_enqueued_hook(void *handle, void (*fn)(void *ctx), void *ctx);
+
 /* Optional: allocate now what batches of up to n_entries entries of up to max_len symbols will need, so that no allocation
  * (each one synchronises the device) falls into the first batches. */
 BHIP_API int bhip_reserve(void *handle, uint32_t n_entries, uint32_t max_len);
@@ -193,6 +200,9 @@ BHIP_API void bhip_comm_destroy(void *comm);
  * this is what make_accelerator (burst.c:3304-3532) would have written.  Any output pointer may be NULL. */
 BHIP_API int bhip_acx_export(void *handle, uint32_t *lens, uint32_t *clumps, uint16_t *masks, uint64_t cap_entries, uint64_t *n_entries,
                     uint32_t *badlist, uint32_t cap_bad, uint32_t *n_bad);
+/* The same lists piece by piece: entries [first, first + n_entries) in word order (a RefSeq-scale accelerator has tens of billions of
+ * entries: a caller that writes the .acx streams them instead of holding 4 bytes of each); masks may be NULL. */
+BHIP_API int bhip_acx_export_entries(void *handle, uint64_t first, uint64_t n_entries, uint32_t *clumps, uint16_t *masks);
 
 /* Kernel-level entry (what one aded_mat16 call returns, burst.c:1078-1094): for explicit (query, clump)
  * pairs, mins[16*p + z] = edit distance of lane z (255 when > budget of the pair's query). */
@@ -262,7 +272,7 @@ BHIP_API void bhip_destroy(void *handle);
 BHIP_API const char *bhip_last_error(void);
 /* ABI version of this header */
 BHIP_API int bhip_abi_version(void);
-#define BHIP_ABI_VERSION 4
+#define BHIP_ABI_VERSION 5
 
 #ifdef __cplusplus
 }

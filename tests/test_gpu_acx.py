@@ -46,6 +46,13 @@ def _compare_built_with_loaded(db_path_or_db, K, z, from_fasta=None):
     b.acx_from_device(dev_b, K, z)
     assert b.c.acxFmt == a.c.acxFmt and b.c.acxListBytes == a.c.acxListBytes
     assert np.array_equal(host._view(b.c.acxLists, b.c.acxListBytes, np.uint8), host._view(a.c.acxLists, a.c.acxListBytes, np.uint8))
+    # ... and so is the file streamed from the device run by run (bh_acx_write_from_device: what bench.py writes for the reference)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        f1, f2 = os.path.join(td, "held.acx"), os.path.join(td, "streamed.acx")
+        host._chk(L.bh_acx_write(C.byref(b.c), f1.encode()))
+        b.acx_write_from_device(dev_b, K, f2, z)
+        assert open(f1, "rb").read() == open(f2, "rb").read()
     dev_b.close()
     n = len(clumps_a)
     a.close(); b.close()

@@ -328,7 +328,7 @@ def test_bench_multi_rank_path_with_one_process(tmp_path):
     import json
     import sys
     bench = os.path.join(gl.ROOT, "bench.py")
-    common = ["--n-base", "20000", "--reads", "100000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end", "--workdir", str(tmp_path / "w")]
+    common = ["--db-scale", "1", "--n-base", "20000", "--reads", "100000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end", "--no-continuity", "--workdir", str(tmp_path / "w")]
     r1 = subprocess.run([sys.executable, bench] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r1.returncode == 0, r1.stderr[-3000:]
     a = json.loads(r1.stdout.strip().splitlines()[-1])
@@ -339,7 +339,8 @@ def test_bench_multi_rank_path_with_one_process(tmp_path):
     b = json.loads([ln for ln in r2.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert a["work"]["records"] == b["work"]["records"] > 250000
     assert "RCCL gather" in b["config"]["parallelism"] and b["n_gpus"] == 1
-    r3 = subprocess.run(launch + ["--nproc-per-node", "2", "--master-port", "29612", bench, "--gpus", "2", "--scaling", "strong"] + common,
+    # the default line for N > 1 is the FIXED job (strong scaling), with the weak-scaling figure and configs[3]'s 10 M-read job as extra keys
+    r3 = subprocess.run(launch + ["--nproc-per-node", "2", "--master-port", "29612", bench, "--gpus", "2"] + common,
                         env=dict(os.environ, BURST_BENCH_DEVICE="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r3.returncode == 0, r3.stderr[-3000:]
     c = json.loads([ln for ln in r3.stdout.strip().splitlines() if ln.startswith("{")][-1])
@@ -348,11 +349,23 @@ def test_bench_multi_rank_path_with_one_process(tmp_path):
     # rank 0 read every rank's records where they lie (no copy): two runs, together the single-process run's records
     assert c["handover"]["kind"].startswith("view") and len(c["handover"]["records_per_run"]) == 2 and sum(c["handover"]["records_per_run"]) == a["work"]["records"]
     assert min(c["handover"]["records_per_run"]) > 100000 and c["handover"]["distinct_entries"] > 100000
-    # the default: weak scaling -- every rank its own three batches, twice the single-process job's reads and (about) records
-    r4 = subprocess.run(launch + ["--nproc-per-node", "2", "--master-port", "29613", bench, "--gpus", "2"] + common,
+    assert c["weak_scaling"]["reads"] == 2 * 300000 and 1.9 * a["work"]["records"] < c["weak_scaling"]["records"] < 2.1 * a["work"]["records"]
+    assert c["configs3_job"]["reads"] > 0 and c["configs3_job"]["records"] > 0 and c["configs3_job"]["value"] > 0
+    assert "rccl" not in c          # (two ranks on one device: RCCL refuses; on a multi-GPU node the key is there, see r5)
+    # --scaling weak: every rank its own three batches, twice the single-process job's reads and (about) records
+    r4 = subprocess.run(launch + ["--nproc-per-node", "2", "--master-port", "29613", bench, "--gpus", "2", "--scaling", "weak"] + common,
                         env=dict(os.environ, BURST_BENCH_DEVICE="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r4.returncode == 0, r4.stderr[-3000:]
     d = json.loads([ln for ln in r4.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert d["scaling"] == "weak" and d["n_gpus"] == 2 and len(d["handover"]["records_per_run"]) == 2
     assert 1.9 * a["work"]["records"] < d["work"]["records"] < 2.1 * a["work"]["records"] and min(d["handover"]["records_per_run"]) > 0.9 * a["work"]["records"]
+    assert d["strong_scaling"]["records"] == a["work"]["records"]
+    # the RCCL keys of the N > 1 line: the launcher's code path with one process (the only way to have a communicator on a one-GPU box):
+    # the shared-memory hand-over is timed as `value`, then the same job with bhip_comm_gather_hits inside the timed region
+    r5 = subprocess.run(launch + ["--nproc-per-node", "1", "--master-port", "29614", bench, "--gpus", "1"] + common,
+                        env=dict(os.environ, BURST_BENCH_DIST1="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r5.returncode == 0, r5.stderr[-3000:]
+    e = json.loads([ln for ln in r5.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert e["work"]["records"] == a["work"]["records"] and "shared-memory" in e["config"]["parallelism"]
+    assert e["rccl"]["rccl_ranks"] == 1 and e["rccl"]["records"] == a["work"]["records"] and e["rccl"]["value"] > 0 and e["rccl"]["rccl_gather_ms"] >= 0
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("burst_hip.bench")]

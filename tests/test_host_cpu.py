@@ -198,3 +198,60 @@ def test_report_identity_column_equals_printf():
     assert len(got) == len(want) > 500000
     bad = [(g, w) for g, w in zip(got, want) if g != w]
     assert not bad, bad[:5]
+
+
+def test_database_built_in_parts_is_the_same_set_of_references(tmp_path):
+    """bh_edx_merge: a database built part by part (bench.py, databases too large to be sorted in one piece in the memory at hand) and
+    laid end to end holds the same fragments as the one-piece build, and every reference number still resolves to the header and the
+    start of the sequence its lane was cut from"""
+    import ctypes as C
+    import sys
+    import types
+    import numpy as np
+    sys.path.insert(0, gl.ROOT)
+    import bench
+    from burst_amd import host
+    a = types.SimpleNamespace(read_len=100, n_base=5000, n_variants=2, ref_len=900, variant_rate=0.05, id=0.98, K=15, edits="0,1,2", reads=500, pool=4, iupac=0.0, fr=False, drop_refs=False)
+    old = bench.PART_BASES
+    try:
+        bench.PART_BASES = 2000          # three parts
+        _, edx3, _, reads3, _ = bench.build_inputs(str(tmp_path / "parts"), types.SimpleNamespace(**vars(a)), 0)
+        bench.PART_BASES = old
+        refs1, edx1, _, _, _ = bench.build_inputs(str(tmp_path / "one"), types.SimpleNamespace(**vars(a)), 0)
+    finally:
+        bench.PART_BASES = old
+    names = [ln[1:].strip() for ln in open(reads3) if ln.startswith(">")]
+    assert len(names) == 2000 and len({n.split("_")[0] for n in names}) == 2000          # unique read names over the parts
+    fasta = {}
+    with open(refs1) as f:
+        for h in f:
+            fasta[h[1:].strip().encode()] = f.readline().strip().encode()
+    code = {65: 1, 67: 2, 71: 3, 84: 4}
+
+    def lanes(path):
+        db = host.Db.read(path)
+        cl = host._view(db.c.clumpLen, db.c.numRclumps, np.uint32)
+        pk = host._view(db.c.packed, db.c.packedWords * 16, np.uint8)
+        srt = host._view(db.c.refIxSrt, db.c.totR, np.uint32)
+        start = host._view(db.c.refStart, db.c.origTotR, np.uint32)
+        heads = C.cast(db.c.refHead, C.POINTER(C.c_char_p))
+        out, w = [], 0
+        for c in range(db.c.numRclumps):
+            L = int(cl[c]); rows = (L + 1) // 2
+            blk = pk[w * 16:(w + rows) * 16].reshape(rows, 16); w += rows
+            full = np.empty((rows * 2, 16), np.uint8)
+            full[0::2] = blk & 15; full[1::2] = blk >> 4
+            for z in range(16):
+                i = 16 * c + z
+                if i < db.c.totR:
+                    seq = bytes(full[:L, z]).rstrip(b"\0")
+                    out.append((seq, heads[int(srt[i])], int(start[int(srt[i])])))
+        tot = (db.c.totR, db.c.origTotR, db.c.numRclumps, db.c.numRefHeads)
+        db.close()
+        return out, tot
+    l3, t3 = lanes(edx3)
+    l1, t1 = lanes(edx1)
+    assert t3 == t1 and sorted(x[0] for x in l3) == sorted(x[0] for x in l1)
+    for seq, head, st in l3[::7]:
+        src = fasta[head][st:st + len(seq)]
+        assert bytes(code[b] for b in src) == seq, (head, st)
