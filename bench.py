@@ -612,6 +612,16 @@ def main():
     elapsed, n_records, run = timed(job_share(args.warmup, args.steps))
     total_reads = job_reads(args.warmup, args.steps)
     own_main = rs.own_stats() if use_dist else None          # (this rank's counters of the timed job: the extra jobs below overwrite them)
+    # what the records are for: rank 0's consolidation of the timed job's records into .b6 lines (bh_report_view: per-mode selection,
+    # coordinates, formatting), written to /dev/null -- outside the timed region, reported beside it
+    consolidation = None
+    if rank == 0:
+        try:
+            t_ = time.time()
+            n_lines_ = host.report_view(os.devnull, db, qs, rs.view, args.mode, 0) if use_dist else host.report(os.devnull, db, qs, run.hits, args.mode, 0)
+            consolidation = {"seconds": time.time() - t_, "lines": int(n_lines_), "what": "rank 0: bh_report over the timed job's records (all ranks'), .b6 lines to /dev/null; not part of `value`"}
+        except Exception as e:
+            consolidation = {"error": str(e)}
     handover_main = None
     if use_dist and rank == 0:      # what rank 0 holds after the timed search, read once through (outside the timed region): every rank's run, its records
         runs_ = rs.view.runs()
@@ -793,6 +803,7 @@ def main():
                     if name in defaults:
                         dev.set_option(name, defaults[name])
         res.update(extra)
+        res["consolidation"] = consolidation
         res["cpu_baseline"] = None
         ref_note = None
         if want_base:      # N = 1 only (the contract); the other ranks would sit in the barrier meanwhile

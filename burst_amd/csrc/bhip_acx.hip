@@ -538,12 +538,25 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 		cap_items = 0;
 		for (uint32_t s = 0; s < n_slices; ++s) cap_items = std::max(cap_items, item_off[cuts[s + 1]] - item_off[cuts[s]]);
 		k0.release(); k1.release(); v0.release(); v1.release(); tmp.release();
-		ARC(k0.reserve_exact(cap_items * 8 + 16)); ARC(k1.reserve_exact(cap_items * 8 + 16)); ARC(v0.reserve_exact(cap_items * 2 + 16)); ARC(v1.reserve_exact(cap_items * 2 + 16));
+		if (k0.reserve_exact(cap_items * 8 + 16) || k1.reserve_exact(cap_items * 8 + 16) || v0.reserve_exact(cap_items * 2 + 16) || v1.reserve_exact(cap_items * 2 + 16)) {
+			// somebody else took memory of this device since it was measured (a query sort on the ingest thread, another rank): smaller slices
+			k0.release(); k1.release(); v0.release(); v1.release();
+			(void)hipGetLastError();
+			return 1;
+		}
 		return 0;
+	};
+	auto plan_slices_retry = [&](double room) -> int {
+		for (int attempt = 0; attempt < 5; ++attempt, room *= 0.5) {
+			const int rc = plan_slices(room);
+			if (rc <= 0) return rc;
+			if (forced_slice > 0) break;
+		}
+		return fail(BHIP_E_DEVICE, "not enough device memory for the accelerator build's sort buffers");
 	};
 	const double room_once = (double)free_b - (double)n_lines * 64.0 - (double)item_off[nC] * BHIP_REC_BYTES - (double)(256u << 20);
 	bool one_plan = forced_slice > 0 || (room_once > 0 && room_once * 0.8 / 33.0 >= (double)item_off[nC] && item_off[nC] <= 2147483000ull);
-	ARC(plan_slices(one_plan ? room_once : (double)free_b - (double)n_lines * 64.0 - (double)(256u << 20)));
+	ARC(plan_slices_retry(one_plan ? room_once : (double)free_b - (double)n_lines * 64.0 - (double)(256u << 20)));
 	ARC(nruns.reserve(16)); ARC(d_xcur.reserve(16));
 	unsigned long long *ukeys = nullptr; uint16_t *umasks = nullptr; unsigned long long *spare = nullptr; uint32_t n_unique = 0;
 	// tuples of slice s, sorted and folded: ukeys / umasks / n_unique (spare = the other key buffer, free for scratch)
@@ -587,7 +600,7 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 	ARC(h->acx_rec.reserve_exact(tot * BHIP_REC_BYTES + 16));
 	if (!one_plan) {
 		HIPCHK(hipMemGetInfo(&free_b, &total_b));
-		ARC(plan_slices((double)free_b - (double)(256u << 20)));
+		ARC(plan_slices_retry((double)free_b - (double)(256u << 20)));
 	}
 	if (n_slices > 1 || !one_plan) { d_cursor.p = d_lens.p; d_cursor.cap = d_lens.cap; d_lens.p = nullptr; d_lens.cap = 0; HIPCHK(hipMemsetAsync(d_cursor.p, 0, nw * 4, h->stream)); }      // (the length table's memory)
 	else d_lens.release();

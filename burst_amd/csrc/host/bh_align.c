@@ -90,6 +90,17 @@ int bh_run_reserve_plain(BhRun *run, uint64_t cap) {
 	for (size_t o = 0; o < bytes; o += (size_t)1 << 21) memset((char *)run->hits + o, 0, (size_t)1 << 21);
 	return BH_OK;
 }
+/* records made elsewhere (a rank's align back end: BhMultiRank.align) into a run */
+int bh_run_put(BhRun *run, const BhipHit *hits, uint64_t n) {
+	if (run->capHits < n || !run->hits) {
+		if (run->hits && run->hitsPinned == 2) return bh_set_error(BH_E_CAPACITY, "the rank's shared-memory segment holds %lu records, %lu needed", (unsigned long)run->capHits, (unsigned long)n);
+		int rc = bh_run_reserve_plain(run, n + 1);
+		if (rc) return rc;
+	}
+	if (n) memcpy(run->hits, hits, n * sizeof(BhipHit));
+	run->nHits = n;
+	return BH_OK;
+}
 static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const uint64_t *r1, uint32_t n_ranges, BhMode mode, uint64_t batch_uniq, BhRun *run);
 int bh_align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const uint64_t *r1, uint32_t n_ranges, BhMode mode, uint64_t batch_uniq, BhRun *run) {
 	memset(run, 0, sizeof *run);

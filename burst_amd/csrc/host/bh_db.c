@@ -782,7 +782,7 @@ int bh_acx_write(const BhDb *db, const char *path) {
 }
 
 /* ---------------------------------------------------------------------------------------------------------------
- * Database sharding (multi-GPU mode for databases that do not fit one device, burst_amd/dist.py): a view of the
+ * Database sharding (multi-GPU mode for databases that do not fit one device, host/bh_multi.c): a view of the
  * clumps [c0, c1) of `db` -- clump area, lengths and reference count are pointers into `db` (which must outlive the
  * view), the accelerator is the sub-list of every word restricted to those clumps, renumbered from 0, in the .acx
  * packing (burst.c:3501-3528) its clump count asks for.  Reference index of a slice hit + 16*c0 = index in `db`. */

@@ -178,7 +178,7 @@ int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhN
 	if (n_local < 1 || n_local > n_ranks || n_ranks > BH_MAX_RANKS) return bh_set_error(BH_E_USAGE, "bad rank layout (%d local of %d)", n_local, n_ranks);
 	if (!comm && !node && n_local != n_ranks) return bh_set_error(BH_E_USAGE, "without a communicator every rank must live in this process");
 	if (node && n_local != 1) return bh_set_error(BH_E_USAGE, "the shared-memory hand-over is for one rank per process");
-	if (node && !comm && shard_db > 1 && mode != BH_FORAGE && n_ranks > 1) return bh_set_error(BH_E_USAGE, "database-sharded ranks in different processes need the communicator for the minima");
+	if (node && !comm && !R[0].reduce_min && shard_db > 1 && mode != BH_FORAGE && n_ranks > 1) return bh_set_error(BH_E_USAGE, "database-sharded ranks in different processes need a communicator (or the launcher's reduce_min) for the minima");
 	const int dbg = getenv("BURST_HOST_DEBUG") != NULL;
 	double tp[5]; tp[0] = omp_get_wtime();
 	if (node) { int b = bh_node_begin(node); if (b) return b; bh_node_attach(node, &R[0].run); }
@@ -186,6 +186,14 @@ int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhN
 	uint8_t *best[BH_MAX_RANKS];
 	for (int i = 0; i < n_local; ++i) { rcs[i] = BH_E_INTERNAL; snprintf(errs[i], sizeof errs[i], "rank %d never ran (OpenMP gave the team fewer than %d threads)", R[i].rank, n_local); best[i] = NULL; }
 	const int reduce = shard_db > 1 && mode != BH_FORAGE && n_ranks > 1;
+	/* the per-query minima tables are taken NOW: a rank that found no memory for its table after the search would stay out of a
+	 * collective its peers are in.  Here the call fails before anything has started (peers in other processes give up on this rank
+	 * through the hand-over's time-out) */
+	if (reduce) for (int i = 0; i < n_local; ++i) {
+		best[i] = malloc(Q->numUniq + 1);
+		if (!best[i]) { for (int k = 0; k < i; ++k) free(best[k]); return bh_set_error(BH_E_OOM, "OOM:minima"); }
+		memset(best[i], 255, Q->numUniq);
+	}
 	/* one host thread per local rank; the runtime must grant all of them -- a missing rank would leave the others waiting in the
 	 * collectives -- so dynamic team sizes are switched off and the team is checked before anything is enqueued */
 	const int dyn = omp_get_dynamic();
@@ -196,41 +204,41 @@ int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhN
 		#pragma omp single
 		team_ok = omp_get_num_threads() == n_local;
 	}
-	if (!team_ok) { omp_set_dynamic(dyn); return bh_set_error(BH_E_INTERNAL, "OpenMP does not grant %d threads (OMP_THREAD_LIMIT?): one host thread per GPU is required", n_local); }
+	if (!team_ok) {
+		omp_set_dynamic(dyn);
+		for (int i = 0; i < n_local; ++i) free(best[i]);
+		if (node) (void)bh_node_publish(node, &R[0].run, BH_E_INTERNAL);      /* (the peers must not wait for this rank's records) */
+		return bh_set_error(BH_E_INTERNAL, "OpenMP does not grant %d threads (OMP_THREAD_LIMIT?): one host thread per GPU is required", n_local);
+	}
 	/* 1. every rank aligns its share */
 	#pragma omp parallel num_threads(n_local)
 	{
 		const int i = omp_get_thread_num();
 		BhMultiRank *r = &R[i];
 		const double t0 = omp_get_wtime();
-		rcs[i] = bh_align_ranges_reuse(r->hh, Q, r->r0, r->r1, r->n_ranges, mode, batch, &r->run);
+		rcs[i] = r->align ? r->align(r->ctx, Q, r->r0, r->r1, r->n_ranges, (int)mode, batch, &r->run)
+		                  : bh_align_ranges_reuse(r->hh, Q, r->r0, r->r1, r->n_ranges, mode, batch, &r->run);
 		r->secSearch = omp_get_wtime() - t0;
-		if (rcs[i]) snprintf(errs[i], sizeof errs[i], "%s", bh_last_error());
+		if (rcs[i]) snprintf(errs[i], sizeof errs[i], "%s", r->align ? "the rank's align back end failed" : bh_last_error());
 		else if (shard_db > 1) {
 			for (uint64_t k = 0; k < r->run.nHits; ++k) r->run.hits[k].refIx += 16u * r->c0;
-			if (reduce) {
-				best[i] = malloc(Q->numUniq + 1);
-				if (!best[i]) { rcs[i] = BH_E_OOM; snprintf(errs[i], sizeof errs[i], "OOM:minima"); }
-				else shard_minima(Q, &r->run, best[i]);
-			}
+			if (reduce) shard_minima(Q, &r->run, best[i]);
 		}
 	}
 	tp[1] = omp_get_wtime();
 	/* (a rank that failed still has to walk through the collectives its peers are in: it takes part with nothing) */
 	/* 2. database-sharded: the per-query minimum over all ranks */
 	if (reduce) {
-		if (comm) {
+		if (comm || R[0].reduce_min) {
+			/* (a rank whose search failed takes part with its table of 255s: nobody is left waiting) */
 			#pragma omp parallel num_threads(n_local)
 			{
 				const int i = omp_get_thread_num();
-				uint8_t *b = best[i];
-				uint8_t *tmp = NULL;
-				if (!b) { tmp = malloc(Q->numUniq + 1); if (tmp) memset(tmp, 255, Q->numUniq); b = tmp; }
-				const int rc = b ? bhip_comm_allreduce_min(comm, R[i].rank, b, Q->numUniq) : BHIP_E_DEVICE;
-				if (rc && !rcs[i]) { rcs[i] = BH_E_DEVICE; snprintf(errs[i], sizeof errs[i], "libburst_hip: %s", bhip_last_error()); }
-				free(tmp);
+				if (rcs[i]) memset(best[i], 255, Q->numUniq);
+				const int rc = comm ? bhip_comm_allreduce_min(comm, R[i].rank, best[i], Q->numUniq) : R[i].reduce_min(R[i].ctx, best[i], Q->numUniq);
+				if (rc && !rcs[i]) { rcs[i] = BH_E_DEVICE; snprintf(errs[i], sizeof errs[i], "%s%s", comm ? "libburst_hip: " : "the launcher's reduce_min failed", comm ? bhip_last_error() : ""); }
 			}
-		} else if (best[0]) {      /* (a rank without its table has failed: the call returns its error below) */
+		} else if (best[0]) {
 			bh_minima_merge(best, n_local, Q->numUniq);
 			for (int i = 1; i < n_local; ++i) if (best[i]) { free(best[i]); best[i] = NULL; }
 		}

@@ -147,7 +147,16 @@ typedef struct BhMultiRank {
 	uint32_t c0;                  /* database-sharded: first clump of its slice (added to the records' reference numbers) */
 	BhRun run;                    /* its own records (the page-locked buffer is reused between calls) */
 	double secSearch;             /* out: wall time of this rank's align phase (before the minima / the gather) */
+	/* Optional back ends (NULL = the device path).  `align`: in place of the device scheduler bh_align_ranges_reuse(hh, ...) -- it
+	 * fills `run` (bh_run_put) with the records of the ranges, q = entry index, sorted by (q, refIx); the CPU tests of the multi-rank
+	 * search put the oracle here.  `reduce_min`: the element-wise minimum of `buf` over all ranks, in place, for ranks in different
+	 * processes that have no library communicator (a launcher's own collective: torch.distributed all_reduce MIN). */
+	int (*align)(void *ctx, const BhQueries *q, const uint64_t *u0, const uint64_t *u1, uint32_t n_ranges, int mode, uint64_t batch_uniq, BhRun *run);
+	int (*reduce_min)(void *ctx, uint8_t *buf, uint64_t n);
+	void *ctx;
 } BhMultiRank;
+/* n records into a run's buffer (grown when the run owns it; a shared-memory segment must be large enough) */
+int  bh_run_put(BhRun *run, const BhipHit *hits, uint64_t n);
 /* clump range of rank `rank` of `n_ranks`: contiguous, about the same number of reference columns each */
 void bh_clump_shard(const BhDb *db, int n_ranks, int rank, uint32_t *c0, uint32_t *c1);
 /* The search of the n_local ranks that live in this process (listed in rank order; one host thread each) as part of a job of

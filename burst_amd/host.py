@@ -39,8 +39,13 @@ class BhRun(C.Structure):
     _fields_ = [("hits", C.c_void_p), ("nHits", C.c_uint64), ("secAlign", C.c_double), ("total", capi.BhipStats), ("nBatches", C.c_uint32), ("hitsPinned", C.c_int), ("capHits", C.c_uint64)]
 
 
+ALIGN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, u64p, u64p, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(BhRun))
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, u8p, C.c_uint64)
+
+
 class BhMultiRank(C.Structure):
-    _fields_ = [("rank", C.c_int), ("hh", C.c_void_p), ("r0", u64p), ("r1", u64p), ("n_ranges", C.c_uint32), ("c0", C.c_uint32), ("run", BhRun), ("secSearch", C.c_double)]
+    _fields_ = [("rank", C.c_int), ("hh", C.c_void_p), ("r0", u64p), ("r1", u64p), ("n_ranges", C.c_uint32), ("c0", C.c_uint32), ("run", BhRun), ("secSearch", C.c_double),
+                ("align", ALIGN_FN), ("reduce_min", REDUCE_FN), ("ctx", C.c_void_p)]
 
 
 class BhRunView(C.Structure):
@@ -108,6 +113,7 @@ def lib():
         L.bh_clump_shard.argtypes = [C.POINTER(BhDb), C.c_int, C.c_int, u32p, u32p]
         L.bh_clump_shard.restype = None
         L.bh_run_reserve.argtypes = [C.POINTER(BhRun), C.c_uint64]
+        L.bh_run_put.argtypes = [C.POINTER(BhRun), C.c_void_p, C.c_uint64]
         L.bh_run_reserve_plain.argtypes = [C.POINTER(BhRun), C.c_uint64]
         L.bh_run_free.argtypes = [C.POINTER(BhRun)]
         L.bh_report_ex.argtypes = [C.c_void_p, C.POINTER(BhDb), C.POINTER(BhQueries), C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
@@ -313,11 +319,39 @@ class RankSearch:
     per-query minimum over the ranks,] the records to rank 0 -- through the shared-memory segments of `node`, or gathered over the
     library's RCCL communicator)"""
 
-    def __init__(self, dev, rank, world, comm, c0=0, node=None):
+    def __init__(self, dev, rank, world, comm, c0=0, node=None, align=None, reduce_min=None):
+        """align(ranges, mode_number) -> HIT_DTYPE records (q = global entry index, sorted by (q, refIx)): a back end in place of the
+        device scheduler (the CPU tests put the oracle here; dev may then be None).  reduce_min(uint8 array) -> None: the element-wise
+        minimum over all ranks, in place (database-sharded ranks in different processes without a library communicator: the
+        launcher's own collective)"""
         self.mr = BhMultiRank()
-        self.mr.rank, self.mr.hh, self.mr.c0 = rank, dev._h, c0
+        self.mr.rank, self.mr.hh, self.mr.c0 = rank, (dev._h if dev is not None else None), c0
         self.world, self.comm, self.node = world, comm, node
         self.all = Run()
+        self._cb = []
+        if align is not None:
+            def _align(ctx, q, u0, u1, n, mode, batch, run):
+                try:
+                    h = np.ascontiguousarray(align([(int(u0[i]), int(u1[i])) for i in range(n)], int(mode)), dtype=capi.HIT_DTYPE)
+                    return int(lib().bh_run_put(run, h.ctypes.data_as(C.c_void_p), len(h)))
+                except Exception as e:      # (an exception must not cross the C frame)
+                    import traceback
+                    traceback.print_exc()
+                    return -5
+            self._cb.append(ALIGN_FN(_align))
+            self.mr.align = self._cb[-1]
+        if reduce_min is not None:
+            def _reduce(ctx, buf, n):
+                try:
+                    a = np.ctypeslib.as_array(buf, shape=(int(n),))
+                    reduce_min(a)
+                    return 0
+                except Exception:
+                    import traceback
+                    traceback.print_exc()
+                    return -5
+            self._cb.append(REDUCE_FN(_reduce))
+            self.mr.reduce_min = self._cb[-1]
 
     def reserve(self, cap_records):
         if self.node is None:      # (with a node the rank's buffer is its segment, sized at bh_node_open)
@@ -335,8 +369,9 @@ class RankSearch:
         self._keep = (r0, r1)
         self.counts = np.zeros(self.world, np.uint64)
         self.view = BhRunView()
+        n_shards = int(shard_db) if shard_db is not True else self.world      # (True: every rank its own shard)
         _chk(lib().bh_search_multi_ex(C.byref(self.mr), 1, self.world, self.comm, self.node.h if self.node is not None else None, C.byref(qs.c), MODES[mode], batch_uniq,
-                                      int(bool(shard_db)), C.byref(self.all.c), self.counts.ctypes.data_as(u64p), C.byref(self.view)))
+                                      n_shards, C.byref(self.all.c), self.counts.ctypes.data_as(u64p), C.byref(self.view)))
         return self.all      # (rank 0: self.view says where the records are -- with a node they stay in the ranks' segments)
 
     def own_stats(self):
@@ -353,6 +388,21 @@ libc = C.CDLL(None)
 libc.fopen.restype = C.c_void_p
 libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
 libc.fclose.argtypes = [C.c_void_p]
+
+
+def shard_range(n_uniq, world, rank):
+    """unique queries of rank `rank` of `world`: contiguous, sizes differing by at most one (a query and its reverse-complement twin
+    are one unique query: they stay together)"""
+    base, rem = divmod(n_uniq, world)
+    u0 = rank * base + min(rank, rem)
+    return u0, u0 + base + (1 if rank < rem else 0)
+
+
+def clump_shard(db, world, rank):
+    """clump range of database shard `rank` of `world` (bh_clump_shard: about the same number of reference columns each)"""
+    c0, c1 = C.c_uint32(), C.c_uint32()
+    lib().bh_clump_shard(C.byref(db.c), world, rank, C.byref(c0), C.byref(c1))
+    return int(c0.value), int(c1.value)
 
 
 def report(path, db, qs, hits, mode, flags=0):

@@ -9,8 +9,9 @@ unique queries with the C batch scheduler (bh_align_ranges -> libburst_hip.so); 
 segment rank 0 has mapped (bh_node.c: no collective on the data path, the records cross each rank's own PCIe link behind its
 batches), and rank 0 writes the .b6 with the C consolidation code straight from the segments (bh_report_view).  With one process
 it is equivalent to burst_hip.
-`--shard db` cuts the database instead of the queries (burst_amd/dist.py: one all_reduce(MIN) of the per-query minimum
-before the gather) for databases that do not fit one device."""
+`--shard db` cuts the database instead of the queries (every rank aligns all queries against its clumps; one all_reduce(MIN) of the
+per-query minimum -- the launcher's collective handed to bh_search_multi_ex as its reduce_min -- before the same hand-over) for
+databases that do not fit one device."""
 import argparse
 import ctypes as C
 import os
@@ -45,13 +46,10 @@ def main(argv=None):
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if one_dev is not None:
-            if args.shard == "db":
-                sys.stderr.write("BURST_RUN_DEVICE: --shard queries only (the minima of --shard db are reduced over RCCL)\n")
-                return 1
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from burst_amd import capi, dist as bdist, host
+    from burst_amd import host
     z = 0 if args.nwildcard else 1
     db = host.Db.read(args.references, args.accelerator, K=args.k, z=z)
     K = int(db.c.K) if args.accelerator else 12
@@ -62,62 +60,67 @@ def main(argv=None):
     if db.c.shear and int(np.float32(qs.c.maxLen) / np.float32(args.id)) > db.c.shear:
         sys.stderr.write("ERROR: DB incompatible with selected queries/identity.\n")
         return 1
-    L = host.lib()
     c0 = 0
     part = db
-    if args.shard == "db" and world > 1:
-        c0, c1 = bdist.clump_shard_range(host._view(db.c.clumpLen, db.c.numRclumps, np.uint32), world, rank)
+    shard_db = args.shard == "db" and world > 1
+    if shard_db:
+        c0, c1 = host.clump_shard(db, world, rank)
         part = db.slice(c0, c1) if c1 > c0 else None
     dev = part.open_device(local_rank, z) if part is not None else None
     if dev is not None:
         qs.pin()
-
-    def align_range(u0, u1):
-        run = host.BhRun()
-        host._chk(L.bh_align(dev._h, C.byref(qs.c), u0, u1, host.MODES[args.mode], args.batch, C.byref(run)))
-        n = int(run.nHits)
-        out = np.ctypeslib.as_array(C.cast(run.hits, C.POINTER(C.c_uint8)), shape=(n * 20,)).view(capi.HIT_DTYPE).copy() if n else np.zeros(0, capi.HIT_DTYPE)
-        L.bh_run_free(C.byref(run))
-        return out
-    def align_slice(_c0, _c1):
-        h = align_range(0, qs.n_uniq)
-        h["refIx"] += np.uint32(16 * c0)
-        return h
     t0 = time.time()
-    if args.shard == "db" and world > 1:
-        hits = bdist.run_db_sharded(host._view(db.c.clumpLen, db.c.numRclumps, np.uint32), host._view(qs.c.six, qs.n_entries, np.uint32),
-                                    qs.n_uniq, align_slice, rank, world, "cuda", args.mode == "FORAGE")
-    elif world > 1:
-        # query-sharded: the C host's multi-rank search with the shared-memory hand-over; rank 0 reports from the ranks' segments
-        pdev = "cpu" if one_dev is not None else "cuda"
-        jt = torch.tensor([int.from_bytes(os.urandom(6), "little") if rank == 0 else 0], dtype=torch.int64, device=pdev)
-        dist.broadcast(jt, 0)
-        u0, u1 = bdist.shard_range(qs.n_uniq, world, rank)
-        strands = 2 if qs.n_entries > qs.n_uniq else 1
-        cap = int((u1 - u0) * strands * (4.0 if args.mode in ("FORAGE", "ALLPATHS") else 1.5)) + (1 << 20)
-        node = None
-        if rank == 0:
-            node = host.Node("run%x" % int(jt.item()), rank, world, cap)
-        dist.barrier()
-        if rank != 0:
-            node = host.Node("run%x" % int(jt.item()), rank, world, cap)
-        rs = host.RankSearch(dev, rank, world, None, node=node)
-        rs.search(qs, [(u0, u1)], args.mode, args.batch)
-        if rank == 0:
-            n = host.report_view(args.output, db, qs, rs.view, args.mode, 0 if args.accelerator else host.REP_MERGED_LIST)
-            print("rank 0: %d hit records from %d rank(s) in %.3f s, %d alignments written" % (int(rs.view.total), world, time.time() - t0, n))
-        dist.barrier()      # (the ranks' segments live until rank 0 has written the report)
-        rs.close()
-        dist.destroy_process_group()
+    if world == 1:
+        run = host.align_ranges(dev, qs, [(0, qs.n_uniq)], args.mode, args.batch)
+        n = host.report(args.output, db, qs, run.hits, args.mode, 0 if args.accelerator else host.REP_MERGED_LIST)
+        print("rank 0: %d hit records from 1 rank(s) in %.3f s, %d alignments written" % (int(run.c.nHits), time.time() - t0, n))
         return 0
-    else:
-        hits = bdist.run_sharded(qs.n_uniq, align_range, rank, world, "cpu")
+    # several ranks, one process each: the C host's multi-rank search (bh_search_multi_ex), the function behind burst_hip --gpus N.
+    # Query-sharded: rank r aligns the r-th share of the unique queries, no collective on the data path.  Database-sharded: every
+    # rank aligns all queries against its clumps and the per-query minimum is combined over the ranks -- the launcher's own
+    # all_reduce(MIN) (RCCL under the nccl backend) handed to the search as its reduce_min.  Either way every rank's record buffer is
+    # a shared-memory segment rank 0 has mapped (bh_node.c) and rank 0 reports from there.
+    pdev = "cpu" if one_dev is not None else "cuda"
+    jt = torch.tensor([int.from_bytes(os.urandom(6), "little") if rank == 0 else 0], dtype=torch.int64, device=pdev)
+    dist.broadcast(jt, 0)
+    job = "run%x" % int(jt.item())
+    u0, u1 = (0, qs.n_uniq) if shard_db else host.shard_range(qs.n_uniq, world, rank)
+    strands = 2 if qs.n_entries > qs.n_uniq else 1
+    cap = int((u1 - u0) * strands * (4.0 if args.mode in ("FORAGE", "ALLPATHS") else 1.5)) + (1 << 20)
+    # the segments are opened TOGETHER: rank 0 first (the others map its segment), and if any rank cannot have one (/dev/shm too small)
+    # every rank hears of it and the job ends with the reason on all of them instead of leaving the others in a barrier
+    node, why = None, ""
+    def try_open():
+        try:
+            return host.Node(job, rank, world, cap), ""
+        except host.HostError as e:
+            return None, str(e)
     if rank == 0:
-        n = host.report(args.output, db, qs, hits, args.mode, 0 if args.accelerator else host.REP_MERGED_LIST)
-        print("rank 0: %d hit records from %d rank(s) in %.3f s, %d alignments written" % (len(hits), world, time.time() - t0, n))
-    if world > 1:
-        dist.barrier()
+        node, why = try_open()
+    ok = torch.tensor([1 if (rank != 0 or node is not None) else 0], dtype=torch.int64, device=pdev)
+    dist.broadcast(ok, 0)
+    if int(ok.item()) and rank != 0:
+        node, why = try_open()
+    ok = torch.tensor([1 if (node is not None and (dev is not None or not shard_db)) else 0], dtype=torch.int64, device=pdev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if not int(ok.item()):
+        if node is not None:
+            node.close()
+        sys.stderr.write("rank %d: the ranks' shared-memory hand-over could not be set up%s\n" % (rank, ": " + why if why else " (another rank failed)"))
         dist.destroy_process_group()
+        return 4
+    def reduce_min(a):
+        t = torch.from_numpy(a).to(pdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        a[:] = t.cpu().numpy()
+    rs = host.RankSearch(dev, rank, world, None, c0=c0, node=node, reduce_min=reduce_min if shard_db else None)
+    rs.search(qs, [(u0, u1)], args.mode, args.batch, shard_db=world if shard_db else 0)
+    if rank == 0:
+        n = host.report_view(args.output, db, qs, rs.view, args.mode, 0 if args.accelerator else host.REP_MERGED_LIST)
+        print("rank 0: %d hit records from %d rank(s) in %.3f s, %d alignments written" % (int(rs.view.total), world, time.time() - t0, n))
+    dist.barrier()      # (the ranks' segments live until rank 0 has written the report)
+    rs.close()
+    dist.destroy_process_group()
     return 0
 
 

@@ -1,7 +1,9 @@
-"""The N > 1 path on CPU: two gloo processes shard the unique queries, produce hit records for their shard (here with
-the ORACLE in place of the device call), gather them to rank 0 with burst_amd.dist, and rank 0 consolidates with the
-C host.  The .b6 must equal the reference's golden output -- this pins shard boundaries, the entry-index mapping,
-the variable-length gather and the global CAPITALIST vote."""
+"""The N > 1 path on CPU: two gloo processes run the product's multi-rank search (bh_search_multi_ex through host.RankSearch, the
+function behind burst_hip --gpus N, bench.py --gpus N and python -m burst_amd.run) with the ORACLE as the ranks' align back end
+in place of the device scheduler: every rank's records land in its shared-memory segment (bh_node.c), rank 0 reports from the
+segments where they lie (bh_report_view).  The .b6 must equal the reference's golden output -- this pins the shares of unique
+queries, the entry numbers, the hand-over and the global CAPITALIST vote; the database-sharded variant adds the clump shards, the
+per-query minimum over the ranks (the launcher's all_reduce as reduce_min), the filter and the (query, reference) order."""
 import os
 import subprocess
 import sys
@@ -15,50 +17,82 @@ WORKER = r'''
 import os, sys
 import numpy as np
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
-import torch.distributed as dist
-from burst_amd import capi, dist as bdist, host
+import torch, torch.distributed as dist
+from burst_amd import capi, host
 import oraclelib as ol
-edx, qfa, out, mode, ident, fr = sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], float(sys.argv[6]), int(sys.argv[7])
+edx, qfa, out, mode, ident, fr, shard_db = sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], float(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 db = host.Db.read(edx)
 qs = host.QuerySet(qfa, ident, rc=bool(fr), accel=False)
 lut = ol.score_lut(1)
-clump_len = host._view(db.c.clumpLen, db.c.numRclumps, np.uint32)
-packed = host._view(db.c.packed, db.c.packedWords * 16, np.uint8)
-def align_range(u0, u1):
-    q = qs.batch(u0, u1)
-    h = ol.search(packed, clump_len, db.c.totR, q.codes, q.off, q.emac.astype(np.uint32), q.six, q.rc, q.n_shared, lut, mode == "FORAGE")
-    h = h.copy(); h["q"] = q.entry_index[h["q"]].astype(np.uint32)      # local entry -> global entry
-    return h.view(capi.HIT_DTYPE)
-hits = bdist.run_sharded(qs.n_uniq, align_range, rank, world, "cpu")
+c0, part = 0, db
+if shard_db:
+    c0, c1 = host.clump_shard(db, world, rank)
+    part = db.slice(c0, c1)
+clump_len = host._view(part.c.clumpLen, part.c.numRclumps, np.uint32)
+packed = host._view(part.c.packed, part.c.packedWords * 16, np.uint8)
+def align(ranges, mode_no):          # the rank's back end: the oracle on its ranges of unique queries (and its clumps)
+    parts = []
+    for u0, u1 in ranges:
+        q = qs.batch(u0, u1)
+        h = ol.search(packed, clump_len, part.c.totR, q.codes, q.off, q.emac.astype(np.uint32), q.six, q.rc, q.n_shared, lut, mode == "FORAGE")
+        h = h.copy(); h["q"] = q.entry_index[h["q"]].astype(np.uint32)      # local entry -> global entry
+        parts.append(h.view(capi.HIT_DTYPE))
+    h = np.concatenate(parts) if parts else np.zeros(0, capi.HIT_DTYPE)
+    return h[np.lexsort((h["refIx"], h["q"]))]
+def reduce_min(a):
+    t = torch.from_numpy(a)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+jt = torch.tensor([int.from_bytes(os.urandom(6), "little") if rank == 0 else 0], dtype=torch.int64)
+dist.broadcast(jt, 0)
+job = "t%x" % int(jt.item())
+node = host.Node(job, rank, world, 200000) if rank == 0 else None
+dist.barrier()
+if rank != 0:
+    node = host.Node(job, rank, world, 200000)
+rs = host.RankSearch(None, rank, world, None, c0=c0, node=node, align=align, reduce_min=reduce_min if shard_db else None)
+u0, u1 = (0, qs.n_uniq) if shard_db else host.shard_range(qs.n_uniq, world, rank)
+rs.search(qs, [(u0, u1)], mode, 1 << 18, shard_db=world if shard_db else 0)
 if rank == 0:
-    host.report(out, db, qs, hits, mode, host.REP_MERGED_LIST)
-dist.barrier(); dist.destroy_process_group()
+    assert int(rs.counts.sum()) == int(rs.view.total) and (shard_db or rs.view.n_runs == world)
+    host.report_view(out, db, qs, rs.view, mode, host.REP_MERGED_LIST)
+dist.barrier()
+rs.close()
+assert not [f for f in os.listdir("/dev/shm") if job in f] or rank != 0
+dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("name", ["dna_q100_capitalist_noacx_t1_fr", "quick_q292_best_fr"])
-def test_two_rank_gloo_matches_reference(name, tmp_path):
+def _run_two_ranks(tmp_path, name, shard_db):
+    import socket
     c = [x for x in gl.cases() if x["name"] == name][0]
     ref, q, fr, z, shear = gl.case_args(c)
     out = str(tmp_path / "o.b6")
     w = tmp_path / "worker.py"
     w.write_text(WORKER)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, OMP_NUM_THREADS="4")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", str(w), gl.ROOT, ref, q, out, c["mode"], c["id"], str(fr)],
+                        "--master-port", str(port), str(w), gl.ROOT, ref, q, out, c["mode"], c["id"], str(fr), str(int(shard_db))],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
-    got = sorted(open(out, "rb").read().splitlines())
-    assert got == gl.golden_lines(c)
+    assert sorted(open(out, "rb").read().splitlines()) == gl.golden_lines(c)
+
+
+@pytest.mark.parametrize("name", ["dna_q100_capitalist_noacx_t1_fr", "quick_q292_best_fr"])
+def test_two_rank_gloo_matches_reference(name, tmp_path):
+    """query-sharded: the database replicated, every rank its share of the unique queries"""
+    _run_two_ranks(tmp_path, name, False)
 
 
 def test_shard_ranges_partition():
-    from burst_amd import dist as bdist
+    from burst_amd import host
     for n in (0, 1, 7, 8, 1000003):
         for w in (1, 2, 3, 8):
-            r = [bdist.shard_range(n, w, k) for k in range(w)]
+            r = [host.shard_range(n, w, k) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
 
@@ -84,70 +118,28 @@ def test_job_shares_partition_the_job():
 
 
 def test_clump_shards_partition_the_database():
-    """bh_clump_shard (the C host's --shard db): contiguous clump ranges that cover the database, about the same number of
-    reference columns each -- the same cuts as the Python launcher's clump_shard_range"""
-    import ctypes as C
-    from burst_amd import dist as bdist, host
+    """bh_clump_shard (--shard db): contiguous clump ranges that cover the database, about the same number of reference columns each"""
+    from burst_amd import host
     db = host.Db.read(os.path.join(gl.G, "dna.edx"))
-    cl = host._view(db.c.clumpLen, db.c.numRclumps, np.uint32)
+    cl = host._view(db.c.clumpLen, db.c.numRclumps, np.uint32).astype(np.int64)
     for world in (1, 2, 3, 5, 8):
-        prev = 0
+        prev, cols = 0, []
         for r in range(world):
-            c0, c1 = C.c_uint32(), C.c_uint32()
-            host.lib().bh_clump_shard(C.byref(db.c), world, r, C.byref(c0), C.byref(c1))
-            assert c0.value == prev and c1.value >= c0.value
-            assert (c0.value, c1.value) == bdist.clump_shard_range(cl, world, r)
-            prev = c1.value
+            c0, c1 = host.clump_shard(db, world, r)
+            assert c0 == prev and c1 >= c0
+            cols.append(int(cl[c0:c1].sum()))
+            prev = c1
         assert prev == db.c.numRclumps
+        assert max(cols) - min(cols) <= 2 * int(cl.max())
     db.close()
-
-
-DB_WORKER = r"""
-import os, sys
-import numpy as np
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
-import torch.distributed as dist
-from burst_amd import capi, dist as bdist, host
-import oraclelib as ol
-edx, qfa, out, mode, ident, fr = sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], float(sys.argv[6]), int(sys.argv[7])
-rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo")
-db = host.Db.read(edx)
-qs = host.QuerySet(qfa, ident, rc=bool(fr), accel=False)
-lut = ol.score_lut(1)
-q = qs.batch()
-def align_slice(c0, c1):
-    part = db.slice(c0, c1)
-    cl = host._view(part.c.clumpLen, part.c.numRclumps, np.uint32)
-    pk = host._view(part.c.packed, part.c.packedWords * 16, np.uint8)
-    h = ol.search(pk, cl, part.c.totR, q.codes, q.off, q.emac.astype(np.uint32), q.six, q.rc, q.n_shared, lut, mode == "FORAGE")
-    h = h.view(capi.HIT_DTYPE).copy()
-    h["q"] = q.entry_index[h["q"]].astype(np.uint32)
-    h["refIx"] += np.uint32(16 * c0)
-    return h
-hits = bdist.run_db_sharded(host._view(db.c.clumpLen, db.c.numRclumps, np.uint32), host._view(qs.c.six, qs.n_entries, np.uint32), qs.n_uniq,
-                            align_slice, rank, world, "cpu", mode == "FORAGE")
-if rank == 0:
-    host.report(out, db, qs, hits, mode, host.REP_MERGED_LIST)
-dist.barrier(); dist.destroy_process_group()
-"""
 
 
 @pytest.mark.parametrize("name", ["dna_q100_capitalist_noacx_t1_fr", "dna_q292_forage_noacx_t1_fr"])
 def test_two_rank_database_sharding_matches_reference(name, tmp_path):
-    """the second multi-GPU mode: the DATABASE is cut (bh_db_slice), every rank searches all queries in its clumps (oracle in
-    place of the device), one all_reduce(MIN) of the per-query minimum decides which records survive, then the gather"""
-    c = [x for x in gl.cases() if x["name"] == name][0]
-    ref, q, fr, z, shear = gl.case_args(c)
-    out = str(tmp_path / "o.b6")
-    w = tmp_path / "db_worker.py"
-    w.write_text(DB_WORKER)
-    env = dict(os.environ, OMP_NUM_THREADS="4")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29521", str(w), gl.ROOT, ref, q, out, c["mode"], c["id"], str(fr)],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:]
-    assert sorted(open(out, "rb").read().splitlines()) == gl.golden_lines(c)
+    """the second multi-GPU mode: the DATABASE is cut (bh_clump_shard, bh_db_slice), every rank searches all queries in its clumps
+    (oracle in place of the device), the per-query minimum is combined over the ranks (not in FORAGE), what lies above it is dropped,
+    rank 0 puts the records of both segments in (query, reference) order"""
+    _run_two_ranks(tmp_path, name, True)
 
 
 def test_database_slice_accelerator_equals_rebuilt():
@@ -155,7 +147,7 @@ def test_database_slice_accelerator_equals_rebuilt():
     makes for the slice alone (same lengths, same packed lists, same BadList), and the slices partition the entries"""
     import ctypes as C
     import numpy as np
-    from burst_amd import dist as bdist, host
+    from burst_amd import host
     db = host.Db.read(os.path.join(gl.G, "dna.edx"))
     host._chk(host.lib().bh_acx_build(C.byref(db.c), 12, 1))
     plain = host.Db.read(os.path.join(gl.G, "dna.edx"))
@@ -164,7 +156,7 @@ def test_database_slice_accelerator_equals_rebuilt():
     for world in (1, 3):
         total = 0
         for rank in range(world):
-            c0, c1 = bdist.clump_shard_range(cl, world, rank)
+            c0, c1 = host.clump_shard(db, world, rank)
             a = db.slice(c0, c1)
             b = plain.slice(c0, c1)
             host._chk(host.lib().bh_acx_build(C.byref(b.c), 12, 1))
@@ -312,7 +304,7 @@ def test_report_from_runs_equals_report_from_one_array(name, tmp_path):
     records in one array -- and that is the reference's golden output.  Records from the oracle, three ranks' shares, the runs in
     a buffer whose gaps hold records that must not be read (entry numbers beyond the job)."""
     import ctypes as C
-    from burst_amd import capi, dist as bdist, host
+    from burst_amd import capi, host
     import oraclelib as ol
     c = [x for x in gl.cases() if x["name"] == name][0]
     ref, q, fr, z, shear = gl.case_args(c)
@@ -323,7 +315,7 @@ def test_report_from_runs_equals_report_from_one_array(name, tmp_path):
     packed = host._view(db.c.packed, db.c.packedWords * 16, np.uint8)
     shares = []
     for r in range(3):
-        u0, u1 = bdist.shard_range(qs.n_uniq, 3, r)
+        u0, u1 = host.shard_range(qs.n_uniq, 3, r)
         b = qs.batch(u0, u1)
         h = ol.search(packed, clump_len, db.c.totR, b.codes, b.off, b.emac.astype(np.uint32), b.six, b.rc, b.n_shared, lut, c["mode"] == "FORAGE")
         h = h.copy(); h["q"] = b.entry_index[h["q"]].astype(np.uint32)

@@ -99,7 +99,7 @@ def test_database_shards_on_one_device_equal_whole(mode, ident):
     combined as the all_reduce would, and the surviving records must be byte-identical to the whole database's"""
     import ctypes as C
     import numpy as np
-    from burst_amd import capi, dist as bdist, host
+    from burst_amd import capi, host
     db = host.Db.read(os.path.join(gl.G, "dna.edx"))
     host._chk(host.lib().bh_acx_build(C.byref(db.c), 12, 1))
     qs = host.QuerySet(os.path.join(gl.G, "q100.fa"), ident, rc=True, accel=True, K=12)
@@ -120,13 +120,15 @@ def test_database_shards_on_one_device_equal_whole(mode, ident):
     six = host._view(qs.c.six, qs.n_entries, np.uint32)
     parts = []
     for rank in range(3):
-        c0, c1 = bdist.clump_shard_range(cl, 3, rank)
+        c0, c1 = host.clump_shard(db, 3, rank)
         h = search(db.slice(c0, c1))
         h["refIx"] += np.uint32(16 * c0)
         parts.append(h)
-    if mode != "FORAGE":
-        gmin = np.minimum.reduce([bdist.local_minimum(h, six, qs.n_uniq) for h in parts])
-        parts = [bdist.filter_minimum(h, six, gmin) for h in parts]
+    if mode != "FORAGE":      # what the all_reduce(MIN) of the ranks' per-query minima does, and the filter behind it
+        gmin = np.full(qs.n_uniq, 255, np.uint8)
+        for h in parts:
+            np.minimum.at(gmin, six[h["q"]], h["ed"])
+        parts = [h[h["ed"] == gmin[six[h["q"]]]] for h in parts]
     got = np.concatenate(parts)
     got = got[np.lexsort((got["refIx"], got["q"]))]
     assert got.tobytes() == whole[np.lexsort((whole["refIx"], whole["q"]))].tobytes()
@@ -209,11 +211,17 @@ def test_reference_host_with_device_binding(c, tmp_path_factory):
                                                ("quick_q100_capitalist_noacx_t1", ["--gpus", "2", "--devices", "0,0", "--gather", "host", "--shard", "db"], "host gather: 2 rank(s), database-sharded"),
                                                ("dna_q100_allpaths_fr", ["--gpus", "4", "--devices", "0,0,0,0", "--gather", "host", "--shards", "2"], "host gather: 4 rank(s), database-sharded"),
                                                ("dna_q100_capitalist_fr", ["--gpus", "6", "--devices", "0,0,0,0,0,0", "--gather", "host", "--shards", "3", "-ad", "--batch", "53"], "host gather: 6 rank(s), database-sharded"),
-                                               ("dna_q100_allpaths_fr", ["--gpus", "1", "--shard", "db", "--gather", "rccl"], "RCCL gather: 1 rank(s)")])
+                                               ("dna_q100_allpaths_fr", ["--gpus", "1", "--shard", "db", "--gather", "rccl"], "RCCL gather: 1 rank(s)"),
+                                               # more shards than devices: the shards take turns on the one device (bh_search_serial_shards)
+                                               ("dna_q100_allpaths_fr", ["--gpus", "1", "--shards", "3"], "serial shards: 3 shard(s) taking turns"),
+                                               ("dna_q100_capitalist_fr", ["--gpus", "1", "--shards", "2", "-ad", "--batch", "37"], "serial shards: 2 shard(s) taking turns"),
+                                               ("dna_q292_forage_fr", ["--gpus", "1", "--shards", "4", "-ad"], "serial shards: 4 shard(s) taking turns"),
+                                               ("dna_q100_best_tax_fr", ["--gpus", "1", "--shards", "2"], "serial shards: 2 shard(s) taking turns")])
 def test_cli_multi_gpu_paths(name, flags, expect, tmp_path):
     """burst_hip --gpus N: one host thread + one device handle per rank, the unique queries sharded, the records gathered to
     rank 0 (ncclAllGather of the counts + grouped ncclSend / ncclRecv in libburst_hip; `--gather host` when the ranks share a
     device, as they must on a one-GPU box).  --gpus 1 goes through the RCCL code with one rank.  Same .b6 as one device.
+    --gpus 1 --shards S: a database of S shards on one device, the shards taking turns (bh_search_serial_shards).
     --shard db (bh_search_multi): every rank holds a range of clumps -- the .acx lists restricted to it (bh_db_slice), or with -ad an
     accelerator the rank's device builds for its slice -- aligns all queries, the per-query minimum is combined over the ranks and
     the gathered records are put in (query, reference) order: the golden lines of the whole database.  --shards S with more ranks:
