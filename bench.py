@@ -353,16 +353,23 @@ def parity_vs_reference(dev, db, args, batch_uniq):
     return res
 
 
-def pmc_table():
-    """per-kernel PMC figures of the last profiling pass kept under profiles/ (tools/profile_round.sh)"""
-    for name in ("pmc_summary.json", "traffic.json"):
-        f = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(f):
-            try:
-                return json.load(open(f))
-            except Exception:
-                pass
-    return {}
+def pmc_table(kernel_names):
+    """(per-kernel PMC figures of the last profiling pass kept under profiles/ (tools/profile_round.sh), where they come from).  The
+    table is a measurement of an EARLIER run of the same kernels, not of this one: it carries the commit and the command it was made
+    with (`_meta`), and it is refused -- not silently used -- when it was made before the 4-byte accelerator records or does not
+    know the kernels this run timed"""
+    f = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        t = json.load(open(f))
+    except Exception:
+        return {}, "none (profiles/pmc_summary.json missing)"
+    meta = t.pop("_meta", None)
+    if not meta or meta.get("record_bytes") != 4:
+        return {}, "profiles/pmc_summary.json refused: made before this round's kernels (no _meta / other record format)"
+    missing = [k for k in kernel_names if k.split("<")[0].replace("_*", "_reg") not in t]
+    if missing:
+        return {}, "profiles/pmc_summary.json @ %s refused: it does not know %s" % (meta.get("commit"), ", ".join(missing))
+    return t, "profiles/pmc_summary.json = %s @ commit %s (%s)" % (meta.get("tag"), meta.get("commit"), meta.get("command"))
 
 
 def main():
@@ -703,7 +710,7 @@ def main():
         dom = max((k for k in kernels if k != "k_seed_ranges"), key=tot_ms)
         ms_dom, bytes_dom, bound_dom = kernels[dom]
         achieved = bytes_dom / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
-        pmc = pmc_table()
+        pmc, pmc_source = pmc_table([k for k in kernels if k != "k_seed_ranges"])
         try:
             mix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "valu_mix.json")))
         except Exception:
@@ -764,9 +771,9 @@ def main():
                        "extrapolation": extrap,
                        "device": info["name"], "n_cu": info["n_cu"]},
             "roofline": {"bound": "hbm" if bound_dom == "hbm" else "valu", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": pmc_of(dom).get("hbm_bytes_per_launch"),
+                         "traffic": pmc_of(dom).get("hbm_bytes_per_launch"), "pmc_source": pmc_source,
                          "traffic_gather_calibrated": pmc_of(dom).get("hbm_bytes_per_launch_gather_calibrated") if bound_dom == "hbm" else None,
-                         "note": "dominant kernel by time on the critical path (HIP events on its stream; k_seed_ranges works for the next batch beside the chain, throttled: off_critical_path in per_kernel); per_kernel gives each kernel's own bound: the prefilter and the re-scorer are "
+                         "note": "achieved / frac are measured by THIS run (HIP events); traffic, valu_frac and the other counter-derived fields come from the kept profiling pass named in pmc_source (an earlier run of the same kernels), null when that table is refused. Dominant kernel by time on the critical path (HIP events on its stream; k_seed_ranges works for the next batch beside the chain, throttled: off_critical_path in per_kernel); per_kernel gives each kernel's own bound: the prefilter and the re-scorer are "
                                  "bound by HBM/LDS latency of short gathers, the k_myers_* sweeps by integer VALU issue (valu_frac = issued VALU instructions x 2 cycles / peak, from the PMC pass; half-rate VOP3 forms count once). traffic follows the guide's 2 x FETCH_SIZE rule; traffic_gather_calibrated = FETCH_SIZE + WRITE_SIZE, which is what a sector gather really moves (profiles/r02k_fetch_calibration.txt)",
                          "algorithmic_bytes_per_launch": bytes_dom, "ms_per_launch": ms_dom,
                          "per_kernel": per_kernel,
@@ -780,7 +787,7 @@ def main():
         }
         if world == 1 and args.ab:
             # A/B on the resident database: the same warm-up and steps under other tuning options, the default options' line again at the end
-            defaults = {"prefilter_rb": 0, "seed_min_need": 3, "seed_drop_len": 8, "prefilter_table": 0, "prefilter_waves": 0, "prefilter_algo": -1, "prune": 1, "oversub": 2, "band": 1, "seed_ahead": 1}
+            defaults = {"prefilter_rb": 0, "seed_min_need": -1, "seed_drop_len": 8, "prefilter_table": 0, "prefilter_waves": 0, "prefilter_algo": -1, "prune": 1, "oversub": 2, "band": 1, "seed_ahead": 1}
             res["ab"] = []
             for spec in list(args.ab) + [""]:
                 kv = dict(x.split("=") for x in spec.split(",") if x)

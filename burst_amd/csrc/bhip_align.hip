@@ -232,7 +232,24 @@ static int launch_peq(Handle *h, hipStream_t st, StageSlot *S, const uint32_t *d
 	return 0;
 }
 // k_seed_ranges for one (lane, class) list of staged batch S into the lane's per-class buffers
-static int launch_seed(Handle *h, Lane *L, hipStream_t st, StageSlot *S, int cls, const uint32_t *d_qlist, uint32_t n_list, uint32_t maxwords, bool ahead = false) {
+// per-query counters of the counting-filter prefilter for an expected record stream (sampled words x occurrence-weighted mean list length)
+static int pf_table_bits(const Handle *h, int algo, double expect) {
+	return h->opt_pf_table ? h->opt_pf_table : algo == 0 ? (expect <= 600.0 ? 9 : expect <= 1200.0 ? 10 : 11) : (expect <= 230.0 ? 9 : expect <= 470.0 ? 10 : 11);
+}
+// Leaving out a query's longest list (k_seed_ranges: its guaranteed count drops from 4 to 3 for a 100-bp read at 98 %) walks ~21 % fewer
+// records -- and lets more of them through the counting filter: a record survives when its counter holds need - 1 OTHER records, and a
+// survivor costs about eight records' worth of work (exact-table insertion).  Measured at three database sizes:
+// it pays while the remaining stream loads the counters below ~0.35 per counter (19 GB database: 152 records on 512 counters, +6 %) and
+// costs at the metric's size (246 records: 8 % survivors instead of 2.5 %, -6 %); on small databases the kernel's time does not depend on
+// the records at all and the extra candidates only cost sweeps.  -1 = by that rule, 0 = never, n = whenever the count stays >= n.
+static uint32_t seed_min_need_for(const Handle *h, double mean_words) {
+	if (h->opt_seed_min_need >= 0) return (uint32_t)h->opt_seed_min_need;
+	const double t_all = mean_words * h->acx_wmean;
+	const double t_less = t_all * (mean_words > 1.0 ? (mean_words - 1.0) / mean_words : 1.0) * 0.93;
+	const double counters = (double)(1u << pf_table_bits(h, 0, t_all));
+	return (t_all >= 100.0 && t_less / counters <= 0.35) ? 3u : 0u;
+}
+static int launch_seed(Handle *h, Lane *L, hipStream_t st, StageSlot *S, int cls, const uint32_t *d_qlist, uint32_t n_list, uint32_t maxwords, double mean_words, bool ahead = false) {
 	int rc;
 	const uint32_t W16 = seed_row_words(maxwords);
 	L->seeded_ok[cls] = false;
@@ -253,7 +270,7 @@ static int launch_seed(Handle *h, Lane *L, hipStream_t st, StageSlot *S, int cls
 		junk ? S->qcodes_s.as<uint8_t>() : S->qcodes.as<uint8_t>(), junk ? S->qoff_s.as<uint64_t>() : S->qoff.as<uint64_t>(), d_qlist, n_list,
 		h->acx_view(), h->K, S->plan.as<uint32_t>(), W16, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(),
 		junk ? S->qpack_s.as<uint32_t>() : S->qpack.as<uint32_t>(), (S->st_maxlen + 7) / 8, junk ? S->qemac_s.as<uint16_t>() : S->qemac.as<uint16_t>(), qm.as<uint4>(), S->st_has_six ? S->qsix.as<uint32_t>() : nullptr,
-		(uint32_t)h->opt_seed_min_need, (uint32_t)h->opt_seed_drop_len);
+		seed_min_need_for(h, mean_words), (uint32_t)h->opt_seed_drop_len);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(ev[1], st));
 	L->qmeta_seq[S->seq & 1][cls] = S->seq + 1;
@@ -265,12 +282,14 @@ static int launch_seed(Handle *h, Lane *L, hipStream_t st, StageSlot *S, int cls
 static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, const uint32_t *d_qlist, uint32_t n_list, uint32_t maxwords, uint32_t *n_tasks_dev,
                                  uint32_t *n_cand_dev, Counters *dc, int prune) {
 	int rc;
-	if ((rc = L->fb_list.reserve((size_t)n_list * 4 + 16))) return rc;
-	if (L->pf_launches) HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 4, st));      // (the lane's first class finds the whole counter block zeroed by enqueue_lane)
+	if ((rc = L->fb_list.reserve((size_t)n_list * 8 + 64))) return rc;      // two lists: the queries that overflowed the first pass, and the second
+	if (L->pf_launches) HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 8, st));      // (n_fb, n_fb2; the lane's first class finds the whole counter block zeroed by enqueue_lane)
+	uint32_t *fb1 = L->fb_list.as<uint32_t>(), *fb2 = fb1 + n_list + 8, *fb_dense = fb1;
+	uint32_t *n_fb_dense = &dc->n_fb;
 	const uint32_t W16 = seed_row_words(maxwords);
 	// the lookups of this batch may have run ahead (seed_next_batch, during the previous call)
 	if (!(L->seeded_ok[cls] && L->seeded_seq[cls] == h->cur->seq && L->seeded_n[cls] == n_list && L->seeded_W16[cls] == W16))
-		if ((rc = launch_seed(h, L, st, h->cur, cls, d_qlist, n_list, maxwords))) return rc;
+		if ((rc = launch_seed(h, L, st, h->cur, cls, d_qlist, n_list, maxwords, n_list ? (double)L->seed_words[cls] / (double)n_list : (double)maxwords))) return rc;
 	const int algo = h->opt_pf_algo >= 0 ? h->opt_pf_algo : L->pf_algo;
 	const uint32_t n_quads = (n_list + 3) / 4;
 	// hash table size per query from the expected number of distinct clumps (sampled words x occurrence-weighted mean list
@@ -279,7 +298,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	// (the touched list holds half the slots; a query that exceeds it is re-done by the dense fallback, so the estimate -- an
 	// upper bound, every repeated clump counted once per word -- may be cut close)
 	// (counting filter: the approximate counters tolerate a load around 1 -- false survivors only cost work)
-	const int htb = h->opt_pf_table ? h->opt_pf_table : algo == 0 ? (expect <= 600.0 ? 9 : expect <= 1200.0 ? 10 : 11) : (expect <= 230.0 ? 9 : expect <= 470.0 ? 10 : 11);
+	const int htb = pf_table_bits(h, algo, expect);
 	// resident single-wave blocks per CU from the kernel's static LDS / register use (measured on gfx950: 11 blocks of 13 144 B
 	// fit a CU and 12 do not, 10 of 14 168 B fit and 11 do not: about 148 KB of the 160 KB are available to them; 512 VGPRs per SIMD lane in steps of 8).  The kernel is a persistent loop over a static
 	// partition of the list: one block too many per CU would run after the others and double the time.
@@ -307,17 +326,28 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 #define PFC_LAUNCH(B, R) hipLaunchKernelGGL((k_prefilter_cf<B, R>), dim3(grid), dim3(64), 0, st, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list, \
 		h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, \
 		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
-		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum, \
-		L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], prune)
+		fb1, &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum, \
+		L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], prune, (const uint32_t *)nullptr, (const uint32_t *)nullptr)
 		if (htb == 9) { if (rb == 2) PFC_LAUNCH(9, 2); else if (rb == 3) PFC_LAUNCH(9, 3); else PFC_LAUNCH(9, 4); }
 		else if (htb == 10) { if (rb == 2) PFC_LAUNCH(10, 2); else PFC_LAUNCH(10, 4); }
 		else { if (rb == 2) PFC_LAUNCH(11, 2); else PFC_LAUNCH(11, 4); }
 #undef PFC_LAUNCH
+		if (htb != 11) {
+			// second pass: the few queries whose record stream overflowed the exact lane table of the first pass (50 of 2 M at the
+			// metric's database size) once more through the same kernel with its largest tables -- the dense per-clump fallback
+			// behind it costs 12 ms per launch at 6.8 M clumps, whatever the number of queries
+			HIPCHK(hipGetLastError());
+			hipLaunchKernelGGL((k_prefilter_cf<11, 4>), dim3((uint32_t)h->n_cu), dim3(64), 0, st, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list,
+				h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read,
+				fb2, &dc->n_fb2, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum, L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], prune,
+				(const uint32_t *)fb1, (const uint32_t *)&dc->n_fb);
+			fb_dense = fb2; n_fb_dense = &dc->n_fb2;
+		}
 	} else {
 #define PFM_LAUNCH(B) hipLaunchKernelGGL(k_prefilter_mask<B>, dim3(grid), dim3(64), 0, st, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list, \
 		h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, \
 		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
-		L->fb_list.as<uint32_t>(), &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, L->cand.as<uint2>(), n_cand_dev, (uint32_t)L->cand_cap)
+		fb1, &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, L->cand.as<uint2>(), n_cand_dev, (uint32_t)L->cand_cap)
 		if (htb == 9) PFM_LAUNCH(9); else if (htb == 10) PFM_LAUNCH(10); else PFM_LAUNCH(11);
 #undef PFM_LAUNCH
 	}
@@ -335,17 +365,17 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 		const uint32_t g2 = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * per_cu);
 		if (narrow) hipLaunchKernelGGL(k_prefilter_wave<uint8_t>, dim3(g2), dim3(64), lds_w, st, h->s_codes(), h->s_off(),
 			h->s_emac(), d_qlist, n_list, h->acx_view(), h->K, h->n_clumps, bad, h->n_bad, L->cand.as<uint2>(),
-			(uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read, h->cur->plan.as<uint32_t>(), L->fb_list.as<uint32_t>(), &dc->n_fb);
+			(uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read, h->cur->plan.as<uint32_t>(), fb_dense, n_fb_dense);
 		else hipLaunchKernelGGL(k_prefilter_wave<uint16_t>, dim3(g2), dim3(64), lds_w, st, h->s_codes(), h->s_off(),
 			h->s_emac(), d_qlist, n_list, h->acx_view(), h->K, h->n_clumps, bad, h->n_bad, L->cand.as<uint2>(),
-			(uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read, h->cur->plan.as<uint32_t>(), L->fb_list.as<uint32_t>(), &dc->n_fb);
+			(uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read, h->cur->plan.as<uint32_t>(), fb_dense, n_fb_dense);
 	} else {
 		uint32_t g2 = std::min<uint32_t>(n_list, (uint32_t)h->n_cu * 2);
 		if ((rc = L->gcnt.reserve((size_t)g2 * nw32 * 4))) return rc;
 		hipLaunchKernelGGL(k_prefilter<false>, dim3(g2), dim3(256), 0, st, h->s_codes(), h->s_off(),
 			h->s_emac(), d_qlist, n_list, h->acx_view(), h->K, h->n_clumps,
 			L->gcnt.as<uint32_t>(), bad, h->n_bad, L->cand.as<uint2>(), (uint32_t *)nullptr, n_cand_dev, (uint32_t)L->cand_cap, &dc->ent_read,
-			L->fb_list.as<uint32_t>(), &dc->n_fb, h->cur->plan.as<uint32_t>());
+			fb_dense, n_fb_dense, h->cur->plan.as<uint32_t>());
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -387,7 +417,7 @@ extern "C" int bhip_reserve_symbols(void *handle, uint32_t n_entries, uint32_t m
 	    (rc = L->tasks.reserve(L->task_cap * sizeof(uint2))) || (rc = L->tasks2.reserve(L->task_cap * sizeof(uint2))) || (rc = L->tasks2k.reserve(L->task_cap * sizeof(uint2))) ||
 	    (rc = L->wins2.reserve(L->win_cap * sizeof(BhipWin))) || (rc = L->peq.reserve(peq_words * 16 * 4)) || (rc = L->peqp.reserve(n * 16 * 6 * 4)) ||
 	    (rc = L->peq_alt.reserve(peq_words * 16 * 4)) || (rc = L->peqp_alt.reserve(n * 16 * 6 * 4)) ||
-	    (rc = L->fb_list.reserve(n * 4 + 16)) || (rc = L->ranges_c[cls].reserve(n * 16 * 8 + 16)) || (rc = L->hdr_c[cls].reserve(n * 8 + 16))) return rc;
+	    (rc = L->fb_list.reserve(n * 8 + 64)) || (rc = L->ranges_c[cls].reserve(n * 16 * 8 + 16)) || (rc = L->hdr_c[cls].reserve(n * 8 + 16))) return rc;
 	if ((rc = h->best.reserve((n + 1) * 4)) || (rc = h->out.reserve(h->out_cap * sizeof(BhipHit))) || (rc = h->shared_ctr.reserve(sizeof(SharedCtr))) ||
 	    (rc = h->sort_idx.reserve(h->out_cap * 4)) || (rc = h->sort_keys.reserve((n + 1) * 4)) || (rc = h->sort_keys2.reserve((n + 1) * 4)) ||
 	    (rc = h->out_sorted.reserve(h->out_cap * sizeof(BhipHit))) || (rc = h->out_sorted2.reserve(h->out_cap * sizeof(BhipHit)))) return rc;
@@ -638,7 +668,7 @@ static void seed_next_batch(Handle *h, StageSlot *cur, hipEvent_t cur_done) {
 			const uint32_t n_pf = N->npf[l][cls];
 			if (!n_pf || !class_prefix_words(h, N->maxE[l][cls], kClasses[cls])) continue;      // (lane-resolved prefilter only)
 			if (L->seeded_ok[cls] && L->seeded_seq[cls] == N->seq) continue;
-			if (launch_seed(h, L, h->pf_stream, N, cls, N->idx_sorted.as<uint32_t>() + N->qlist_off[l][cls], n_pf, N->maxwords[l][cls], true)) { (void)hipGetLastError(); return; }
+			if (launch_seed(h, L, h->pf_stream, N, cls, N->idx_sorted.as<uint32_t>() + N->qlist_off[l][cls], n_pf, N->maxwords[l][cls], (double)N->seed_words[l][cls] / (double)n_pf, true)) { (void)hipGetLastError(); return; }
 		}
 		// the match profiles as well, when the lane has a single class (its two buffer pairs then simply alternate): built in place
 		// they would run beside the prefilter -- which no longer has its seed lookups in front -- and slow it down
@@ -759,6 +789,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			for (int cls = 0; cls < kNumClasses; ++cls) if (L->npf[cls] + L->nex[cls])
 				fprintf(stderr, "[bhip] lane %u class NW=%d: prefiltered %u exhaustive %u maxE %u maxwords %u | tasks %u + deferred %u (kept %u) clump pairs %u windows %u + %u | fallback queries(last class) %u raw %u\n",
 					l, kClasses[cls], L->npf[cls], L->nex[cls], L->maxE[cls], L->maxwords[cls], L->hc.n_tasks_cls[cls], L->hc.n_tasks2_cls[cls], L->hc.n_tasks2k_cls[cls], L->hc.n_cand_cls[cls], L->hc.n_wins_cls[cls], L->hc.n_wins2_cls[cls], L->hc.n_fb, L->hc.n_raw);
+			if (L->hc.n_fb) fprintf(stderr, "[bhip] lane %u: %u queries overflowed the first prefilter pass, %u the second (dense fallback)\n", l, L->hc.n_fb, L->hc.n_fb2);
 		}
 		// capacity checks (first call of a workload: grow and redo)
 		bool retry = false;

@@ -51,7 +51,7 @@ template <int HTB> __global__ void k_prefilter_mask(const uint2 *, const uint2 *
 	uint2 *, uint32_t *, uint32_t);
 template <int CB, int RBT> __global__ void k_prefilter_cf(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *,
-	uint2 *, uint32_t *, int);
+	uint2 *, uint32_t *, int, const uint32_t *, const uint32_t *);
 __global__ void k_task_filter(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, uint2 *, uint32_t *);
 __global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, BhipAcxView, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t, const uint16_t *, uint4 *, const uint32_t *, uint32_t, uint32_t);
 template <int NWP> __global__ void k_myers_prefix_task(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *,
@@ -112,7 +112,7 @@ struct Counters {
 	uint32_t n_cand, n_raw, n_out, n_wide, err, pad0;
 	uint32_t n_cand_cls[8];
 	uint32_t n_wins_cls[8];
-	uint32_t n_fb, pad2;
+	uint32_t n_fb, n_fb2;      // queries that overflowed the first / the second (largest tables) pass of the counting-filter prefilter
 	uint32_t n_tasks_cls[8];
 	uint32_t n_tasks2_cls[8];  // deferred lane tasks (lower bound above the query's best bound)
 	uint32_t n_tasks2k_cls[8]; // ... of which kept by k_task_filter
@@ -277,7 +277,7 @@ struct Handle {
 	int opt_seed_ahead_blocks = 2; // 256-thread blocks per CU of a seed kernel that runs ahead (0 = one block per 256 lookups, as in place); 2: +2.3 % on the bench
 	int opt_peq_ahead_blocks = 16; // 256-thread blocks per CU of a profile build that runs ahead
 	void (*enqueued_hook)(void *) = nullptr; void *enqueued_ctx = nullptr;      // bhip_set_enqueued_hook
-	int opt_seed_min_need = 3;    // the longest lists of a query's sampled words are left out while its guaranteed count stays >= this (0 = keep every list)
+	int opt_seed_min_need = -1;   // the longest lists of a query's sampled words are left out while its guaranteed count stays >= this (0 = keep every list, -1 = 3 when the rule of seed_min_need_for says it pays)
 	int opt_seed_drop_len = 8;    // ... lists shorter than this are always kept (leaving them out saves nothing and costs selectivity)
 	double acx_wmean = 0.0;       // occurrence-weighted mean .acx list length
 };

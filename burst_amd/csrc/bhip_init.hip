@@ -221,7 +221,7 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 	if (!strcmp(name, "band")) { h->opt_no_band = value == 0; return BHIP_OK; }
 	if (!strcmp(name, "prune")) { h->opt_prune = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "rescore_reg")) { h->opt_rescore_reg = value != 0; return BHIP_OK; }
-	if (!strcmp(name, "seed_min_need")) { if (value < 0 || value > 255) return fail(BHIP_E_ARG, "seed_min_need must be 0 .. 255"); h->opt_seed_min_need = (int)value; return BHIP_OK; }
+	if (!strcmp(name, "seed_min_need")) { if (value < -1 || value > 255) return fail(BHIP_E_ARG, "seed_min_need must be -1 (by rule) or 0 .. 255"); h->opt_seed_min_need = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "seed_drop_len")) { if (value < 0 || value > (1 << 24)) return fail(BHIP_E_ARG, "seed_drop_len must be 0 .. 2^24"); h->opt_seed_drop_len = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_waves")) { if (value < 0 || value > 16) return fail(BHIP_E_ARG, "prefilter_waves must be 0 .. 16"); h->opt_pf_waves = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_algo")) { if (value < -1 || value > 1) return fail(BHIP_E_ARG, "prefilter_algo must be -1, 0 or 1"); h->opt_pf_algo = (int)value; return BHIP_OK; }

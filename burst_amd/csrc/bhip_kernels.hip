@@ -946,6 +946,15 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 #ifndef CF_MINWAVES
 #define CF_MINWAVES 3
 #endif
+// The workgroup of this kernel is ONE wave: its LDS operations are issued and completed in program order, so a later read sees an
+// earlier update by any lane without a barrier.  __syncthreads() would still cost an s_waitcnt vmcnt(0) lgkmcnt(0) -- a wait for
+// every load in flight, i.e. for the record prefetch of the NEXT quad that the software pipeline has just issued.  What the phases
+// need between them is only that the compiler keeps their LDS accesses in order.  (-DCF_BARRIERS=1 puts the barriers back.)
+#if defined(CF_BARRIERS) && CF_BARRIERS
+#define CF_WAVE_ORDER() __syncthreads()
+#else
+#define CF_WAVE_ORDER() __asm__ volatile("" ::: "memory")
+#endif
 // inclusive prefix sum over the 64 lanes of a wave (all lanes active): four shifts inside each row of 16 lanes, then lane 15 of
 // rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3 -- data-parallel-primitive moves, no LDS round trip
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
@@ -968,7 +977,9 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		uint32_t *__restrict__ fb_list, uint32_t *__restrict__ n_fb,
 		unsigned long long *__restrict__ unit_sum, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum,
 		unsigned long long *__restrict__ surv_sum,
-		uint2 *__restrict__ tasks2, uint32_t *__restrict__ n_tasks2, int prune) {   // prune: lanes that cannot hold a minimum go to tasks2 with their lower bound
+		uint2 *__restrict__ tasks2, uint32_t *__restrict__ n_tasks2, int prune,     // prune: lanes that cannot hold a minimum go to tasks2 with their lower bound
+		const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel_dev) { // optional: only the list positions sel[0 .. *n_sel_dev) -- the second pass over the
+		                                                                            // queries that overflowed the first pass's tables, with the largest tables
 	constexpr uint32_t NCNT = 1u << CB;                                   // approximate counters per query (16 bit each)
 	constexpr uint32_t LT = CB <= 9 ? 64u : (CB == 10 ? 128u : 256u);     // exact lane-table slots per query
 	constexpr uint32_t CF_STAGE = 64u;                                     // staged tasks per output list
@@ -1022,7 +1033,8 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 	};
 	auto flush = [&]() { flush_one(0); flush_one(1); };
 
-	const uint32_t n_quads = (n_list + 3) >> 2;
+	const uint32_t n_items = sel ? (*n_sel_dev < n_list ? *n_sel_dev : n_list) : n_list;      // queries this launch works on
+	const uint32_t n_quads = (n_items + 3) >> 2;
 	constexpr uint32_t RB = RBT;             // blocks of 64 records per query that are fetched one quad ahead and stay in registers between the two looks
 	                                         // (2, 3 or 4: the launcher takes the smallest that holds the expected record stream of a query -- what lies
 	                                         // beyond is loaded where it is consumed, twice, with its latency exposed: 40 % of the kernel at 150 records per read)
@@ -1067,14 +1079,15 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 	// for every other load in flight)
 	typedef const unsigned long long __attribute__((address_space(1))) *g64_t;
 	auto fetch_hdr_issue = [&](uint32_t quad, unsigned long long &h, unsigned long long &r) {      // raw words; nothing here waits for them
-		const uint32_t li = quad * 4 + g;
-		const bool ok = li < n_list, okw = ok && gl < W16;         // (li < n_list implies quad < n_quads)
-		const uint32_t lic = ok ? li : 0u;
+		const uint32_t it = quad * 4 + g;
+		const bool ok = it < n_items, okw = ok && gl < W16;         // (it < n_items implies quad < n_quads)
+		uint32_t lic = ok ? it : 0u;
+		if (sel) lic = n_items ? sel[lic] : 0u;                     // (wave-uniform branch; the first pass has no selection)
 		h = ((g64_t)(uintptr_t)(hdr + lic))[0]; r = ((g64_t)(uintptr_t)(ranges + ((size_t)lic * W16 + (okw ? gl : 0u))))[0];
 	};
 	auto fetch_hdr_finish = [&](uint32_t quad, unsigned long long h, unsigned long long r, uint2 &hd, uint2 &rg) {
-		const uint32_t li = quad * 4 + g;
-		const bool ok = li < n_list, okw = ok && gl < W16;
+		const uint32_t it = quad * 4 + g;
+		const bool ok = it < n_items, okw = ok && gl < W16;
 		sink_h ^= (uint32_t)h + (uint32_t)r;         // (its own chain: folded into `sink`, the compiler consumes the words where that chain is first touched)
 		const uint32_t mh = ok ? 0xFFFFFFFFu : 0u, mr = okw ? 0xFFFFFFFFu : 0u;
 		hd = make_uint2((uint32_t)h & mh, (uint32_t)(h >> 32) & mh);
@@ -1083,7 +1096,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 	auto fetch_hdr = [&](uint32_t quad, uint2 &hd, uint2 &rg) { unsigned long long h, r; fetch_hdr_issue(quad, h, r); fetch_hdr_finish(quad, h, r, hd, rg); };
 	// issue: the record words of the first RB blocks of a quad's record stream (nothing here waits for them)
 	auto start_stream = [&](uint32_t quad, const uint2 &rg, uint32_t &T, uint32_t &ex, unsigned long long &dl, uint32_t &nblk, uint32_t (&raw)[RB][4]) -> uint32_t {
-		const bool lv = quad < n_quads && quad * 4 + g < n_list;
+		const bool lv = quad < n_quads && quad * 4 + g < n_items;
 		const unsigned long long beg = lv ? ((unsigned long long)rg.x | (unsigned long long)(rg.y >> 24) << 32) : 0ull;
 		const uint32_t n0 = lv ? rg.y & 0xFFFFFFu : 0u;
 		group_scan(n0, T, ex);
@@ -1148,8 +1161,8 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 	uint32_t n0 = start_stream(blockIdx.x, rg_c, T0, ex0, dl0, nblk0, raw);
 	finish_stream(T0, raw, rc);
 	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
-		const uint32_t li = quad * 4 + g;
-		const bool live = li < n_list;
+		const bool live = quad * 4 + g < n_items;
+		const uint32_t li = sel ? (live ? sel[quad * 4 + g] : 0u) : quad * 4 + g;      // list position of this group's query
 		const uint2 hd = hd_c;
 		unsigned long long h_raw, r_raw;
 		fetch_hdr_issue(quad + 2 * gridDim.x, h_raw, r_raw);
@@ -1246,7 +1259,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 			for (uint32_t b = 0; b < nb; ++b) { uint32_t rec[4]; load4(ex, xb - ex, T, b, rec); count4(rec); }
 		}
 		if (gtot > 65535u && gl == 0) s_ovf[g] = 1;
-		__syncthreads();
+		CF_WAVE_ORDER();
 		PFM_T(7);
 		// ---- phase B: second look at every record (registers for the first blocks, L2 for the rest)
 		#pragma unroll
@@ -1265,7 +1278,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		}
 		PFM_T(2);
 		while (__any(pending > 0)) c_round();
-		__syncthreads();
+		CF_WAVE_ORDER();
 		PFM_T(3);
 		// ---- emit the lanes that reach the threshold, clear the tables
 		// Slot-parallel: lane gl of a group owns the group's gl-th used slot.  The positions of its tasks in the two staged lists
@@ -1369,9 +1382,9 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 			uint4 *cz = (uint4 *)&s_cnt[g][0];
 			for (uint32_t i = gl; i < NCNT / 8; i += 16) cz[i] = make_uint4(0, 0, 0, 0);
 		}
-		__syncthreads();
+		CF_WAVE_ORDER();
 		if (gl == 0) s_ovf[g] = 0;
-		__syncthreads();
+		CF_WAVE_ORDER();
 		PFM_T(5);
 		// rotate the pipeline
 		uint2 hd_nn, rg_nn;
@@ -1393,7 +1406,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 #define BHIP_INST_PFCF(CB, RB) \
 	template __global__ void k_prefilter_cf<CB, RB>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, \
 		uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *, \
-		uint2 *, uint32_t *, int);
+		uint2 *, uint32_t *, int, const uint32_t *, const uint32_t *);
 BHIP_INST_PFCF(9, 2) BHIP_INST_PFCF(9, 3) BHIP_INST_PFCF(9, 4) BHIP_INST_PFCF(10, 2) BHIP_INST_PFCF(10, 4) BHIP_INST_PFCF(11, 2) BHIP_INST_PFCF(11, 4)
 
 template __global__ void k_prefilter_mask<9>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,

@@ -261,7 +261,13 @@ BHIP_API int bhip_sort_queries(int device, const uint8_t *codes, uint64_t codes_
  * staged and not aligned (after an error).  "seed_ahead": 1 (default) = the seed lookups and match profiles of the next staged
  * batch run while the current one is swept, 0 = in place; "seed_ahead_blocks" (default 2, 0 = unlimited) / "peq_ahead_blocks"
  * (default 16) = 256-thread blocks per CU those kernels get while they share the device with the sweeps.
- * None of these changes a result. */
+ * "seed_min_need": -1 (default) / 0 / n -- of a query's sampled words the ones with the LONGEST accelerator lists are left out while the
+ * number of words an alignment within budget is guaranteed to keep stays >= n (any subset of the sampled words gives the same
+ * no-false-negative guarantee with a correspondingly smaller count); 0 = every list is walked; -1 = n = 3 when the expected record
+ * stream is long enough to matter and short enough for the counting filter to stay selective (bhip_align.hip seed_min_need_for).
+ * "seed_drop_len" (default 8): lists shorter than this are never left out.  "prefilter_rb": 0 (default, from the expected stream) or
+ * 2 / 3 / 4 = blocks of 64 list records per query the counting-filter kernel fetches one quad ahead and keeps in registers.
+ * None of these changes a result.  BHIP_OPTS="name=value,..." in the environment sets options at bhip_init. */
 BHIP_API int bhip_set_option(void *handle, const char *name, long long value);
 
 /* Stats of the last call; device properties (name, CU count) for reports. */

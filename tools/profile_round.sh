@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; TAG=$1; shift
 O=$R/gpurun_out; mkdir -p $O
-B="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end --no-prime $*"      # --no-prime: every dispatch of a batch kernel is a full-size batch
+B="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end --no-continuity --keep-files --no-prime $*"      # --no-prime: every dispatch of a batch kernel is a full-size batch; --keep-files: the five passes share the database
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -- $B > $O/${TAG}_kt.log 2>&1
 grep '^{' $O/${TAG}_kt.log | tail -1 > $O/${TAG}_bench_under_rocprof.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_fetch -- $B > $O/${TAG}_fetch.log 2>&1
@@ -72,6 +72,9 @@ for k in sorted(set(list(fa) + list(sa)), key=weight):      # template variants 
         v2 = s2.get(k, {})
         if v2.get('SQ_LDS_IDX_ACTIVE'):
             e["lds_bank_conflict_frac"] = v2.get('SQ_LDS_BANK_CONFLICT', 0.0) / v2['SQ_LDS_IDX_ACTIVE']
+import os
+summary["_meta"] = {"tag": TAG, "commit": os.environ.get("PROFILE_COMMIT", "unknown"), "command": CMD, "record_bytes": 4,
+                    "kernels": sorted(set(avg_ns)), "made_by": "tools/profile_round.sh (five rocprofv3 passes: --kernel-trace --stats, then one --pmc pass per counter set)"}
 json.dump(summary, open('%s/%s_pmc_summary.json' % (O, TAG), 'w'), indent=1)
 print('\n'.join(out[:16])); print('\n'.join(lines[:8]))
 PY
