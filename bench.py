@@ -407,6 +407,7 @@ def main():
                     "north_star asks about); weak = every rank aligns --steps batches of --reads reads of its own (the job grows with N).  The line carries the other one as an extra key")
     ap.add_argument("--gather", default="shm", choices=["shm", "rccl"], help="N > 1: how the ranks' records reach rank 0 -- shared-memory segments rank 0 maps (default; no collective) or the library's RCCL gather")
     ap.add_argument("--acx-file", action="store_true", help="round 2's path: the accelerator from an .acx file (built by the host builder) instead of the device build")
+    ap.add_argument("--ab-host", action="store_true", help="N = 1: also time the job with the scheduler's staging between the batches instead of inside them (key `ab_host`)")
     ap.add_argument("--ab", action="append", default=[], help="N = 1: after the timed region, time the same steps again with these library options (name=value[,name=value]; repeatable) "
                     "on the same resident database -- extra key `ab` of the JSON line, an A/B on one box in one process")
     args = ap.parse_args()
@@ -785,6 +786,42 @@ def main():
                      "seed_words_per_read": st["n_seed_words"] / max(1.0, float(st["n_queries"]))},
             "host": {"db_read_s": t_db, "device_upload_s": t_dev, "query_ingest_s": t_q, "sec_in_device_calls": sec_align},
         }
+        if world == 1:
+            # One rank's share of BASELINE configs[3]'s job on 8 GPUs: 10 M reads / 8 = 1.25 M reads = less than one batch.  A job that
+            # short has nothing to hide its staging, seed lookups and match profiles behind; the scheduler cuts it into four pieces
+            # (bh_align.c, BURST_HOST_PIECES) so that piece k + 1 is prepared while piece k is aligned.  Both ways, one device.
+            try:
+                u_short = max(1, int(U * min(1.0, 1250000.0 / max(1, qs.n_reads))))
+                sj = {"reads": qs.reads_in(0, u_short), "what": "one job of 1.25 M reads (the share of one of 8 GPUs of configs[3]'s 10 M reads) through bh_align_ranges: "
+                      "wall ms from the call to the last record in host memory; whole = one batch, in_pieces = the scheduler's default for jobs of at most two batches (four pieces)"}
+                for label, pieces in (("ms_whole", "1"), ("ms_in_pieces", "4")):
+                    os.environ["BURST_HOST_PIECES"] = pieces
+                    search([(0, u_short)])
+                    best_ = None
+                    for _ in range(5):
+                        torch.cuda.synchronize(); t_ = time.time(); search([(0, u_short)]); torch.cuda.synchronize()
+                        e_ = (time.time() - t_) * 1e3
+                        best_ = e_ if best_ is None else min(best_, e_)
+                    sj[label] = best_
+                os.environ.pop("BURST_HOST_PIECES", None)
+                res["one_rank_share_of_configs3"] = sj
+                log("[bench] 1.25 M-read job: %.2f ms whole, %.2f ms in four pieces" % (sj["ms_whole"], sj["ms_in_pieces"]))
+            except Exception as e:
+                res["one_rank_share_of_configs3"] = {"error": str(e)}
+        if world == 1 and args.ab_host:
+            # the same job with the scheduler staging the batch after next BETWEEN two batches (device idle) instead of from the
+            # library's "chain enqueued" hook (device busy): BURST_HOST_NO_HOOK
+            res["ab_host"] = []
+            for label, env in (("no_enqueued_hook", {"BURST_HOST_NO_HOOK": "1"}), ("default", {})):
+                for k_, v_ in env.items():
+                    os.environ[k_] = v_
+                search(job_share(0, max(1, args.warmup)))
+                torch.cuda.synchronize(); ta = time.time(); search(job_share(args.warmup, args.steps)); torch.cuda.synchronize()
+                ea = time.time() - ta
+                res["ab_host"].append({"variant": label, "value": total_reads / ea, "ms_per_step": ea / args.steps * 1e3})
+                log("[bench] ab_host %s: %.1f M reads/s, %.3f ms per step" % (label, total_reads / ea / 1e6, ea / args.steps * 1e3))
+                for k_ in env:
+                    os.environ.pop(k_, None)
         if world == 1 and args.ab:
             # A/B on the resident database: the same warm-up and steps under other tuning options, the default options' line again at the end
             defaults = {"prefilter_rb": 0, "seed_min_need": -1, "seed_drop_len": 8, "prefilter_table": 0, "prefilter_waves": 0, "prefilter_algo": -1, "prune": 1, "oversub": 2, "band": 1, "seed_ahead": 1}

@@ -357,7 +357,8 @@ def test_bench_multi_rank_path_with_one_process(tmp_path):
     # rank 0 read every rank's records where they lie (no copy): two runs, together the single-process run's records
     assert c["handover"]["kind"].startswith("view") and len(c["handover"]["records_per_run"]) == 2 and sum(c["handover"]["records_per_run"]) == a["work"]["records"]
     assert min(c["handover"]["records_per_run"]) > 100000 and c["handover"]["distinct_entries"] > 100000
-    assert c["weak_scaling"]["reads"] == 2 * 300000 and 1.9 * a["work"]["records"] < c["weak_scaling"]["records"] < 2.1 * a["work"]["records"]
+    assert abs(c["weak_scaling"]["reads"] - 2 * 300000) < 3000          # (a pool batch is a range of UNIQUE queries: about --reads reads)
+    assert 1.9 * a["work"]["records"] < c["weak_scaling"]["records"] < 2.1 * a["work"]["records"]
     assert c["configs3_job"]["reads"] > 0 and c["configs3_job"]["records"] > 0 and c["configs3_job"]["value"] > 0
     assert "rccl" not in c          # (two ranks on one device: RCCL refuses; on a multi-GPU node the key is there, see r5)
     # --scaling weak: every rank its own three batches, twice the single-process job's reads and (about) records
