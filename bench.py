@@ -407,6 +407,7 @@ def main():
                     "north_star asks about); weak = every rank aligns --steps batches of --reads reads of its own (the job grows with N).  The line carries the other one as an extra key")
     ap.add_argument("--gather", default="shm", choices=["shm", "rccl"], help="N > 1: how the ranks' records reach rank 0 -- shared-memory segments rank 0 maps (default; no collective) or the library's RCCL gather")
     ap.add_argument("--acx-file", action="store_true", help="round 2's path: the accelerator from an .acx file (built by the host builder) instead of the device build")
+    ap.add_argument("--no-short-job", action="store_true", help="skip the 1.25 M-read job (key `one_rank_share_of_configs3`)")
     ap.add_argument("--ab-host", action="store_true", help="N = 1: also time the job with the scheduler's staging between the batches instead of inside them (key `ab_host`)")
     ap.add_argument("--ab", action="append", default=[], help="N = 1: after the timed region, time the same steps again with these library options (name=value[,name=value]; repeatable) "
                     "on the same resident database -- extra key `ab` of the JSON line, an A/B on one box in one process")
@@ -570,6 +571,8 @@ def main():
     _own = host.Run()
     ent_per_step = min(batch_uniq, max((b - a for a, b in job_share(0, P)), default=1)) * (2 if args.fr else 1)
     share = max(1, max(sum(b - a for a, b in job_share(args.warmup, args.steps, weak=w_)) for w_ in ((False, True) if world > 1 else (weak,)))) * (2 if args.fr else 1)
+    if use_dist:      # (the extra jobs of the N > 1 line use the same record buffers: configs[3]'s 10 M reads over the ranks)
+        share = max(share, sum(b - a for a, b in job_share(args.warmup, max(1, int(round(10e6 / max(1, args.reads)))), weak=False)) * (2 if args.fr else 1))
     cap_rec = int(max(share, 4 * ent_per_step) * (4.0 if args.mode in ("FORAGE", "ALLPATHS") else 1.5)) + (1 << 20)
     if use_dist:
         if args.gather == "shm":
@@ -651,7 +654,7 @@ def main():
         e3, n3, _ = timed(job_share(args.warmup, nb3, weak=False))
         r3 = job_reads(args.warmup, nb3, weak=False)
         extra["configs3_job"] = {"value": r3 / e3, "unit": "reads/s", "reads": r3, "seconds": e3, "records": n3, "reads_per_rank": r3 // world,
-                                 "what": "BASELINE configs[3]'s job size: %d reads cut over %d GPUs (strong scaling; a rank's share of at most two batches is aligned in four pieces, bh_align.c)" % (r3, world)}
+                                 "what": "BASELINE configs[3]'s job size: %d reads cut over %d GPUs (strong scaling)" % (r3, world)}
         if one_dev is None and args.gather == "shm":
             try:
                 comm2 = make_comm()
@@ -786,14 +789,14 @@ def main():
                      "seed_words_per_read": st["n_seed_words"] / max(1.0, float(st["n_queries"]))},
             "host": {"db_read_s": t_db, "device_upload_s": t_dev, "query_ingest_s": t_q, "sec_in_device_calls": sec_align},
         }
-        if world == 1:
+        if world == 1 and not args.no_short_job:
             # One rank's share of BASELINE configs[3]'s job on 8 GPUs: 10 M reads / 8 = 1.25 M reads = less than one batch.  A job that
-            # short has nothing to hide its staging, seed lookups and match profiles behind; the scheduler cuts it into four pieces
-            # (bh_align.c, BURST_HOST_PIECES) so that piece k + 1 is prepared while piece k is aligned.  Both ways, one device.
+            # short has nothing to hide its staging, seed lookups and match profiles behind.  Whole, and cut into four pieces so that
+            # piece k + 1 is prepared while piece k is aligned (bh_align.c, BURST_HOST_PIECES): the pieces' fixed costs eat the overlap.
             try:
                 u_short = max(1, int(U * min(1.0, 1250000.0 / max(1, qs.n_reads))))
                 sj = {"reads": qs.reads_in(0, u_short), "what": "one job of 1.25 M reads (the share of one of 8 GPUs of configs[3]'s 10 M reads) through bh_align_ranges: "
-                      "wall ms from the call to the last record in host memory; whole = one batch, in_pieces = the scheduler's default for jobs of at most two batches (four pieces)"}
+                      "wall ms from the call to the last record in host memory; whole = one batch (the scheduler's default), in_pieces = cut into four (BURST_HOST_PIECES=4), which does not pay"}
                 for label, pieces in (("ms_whole", "1"), ("ms_in_pieces", "4")):
                     os.environ["BURST_HOST_PIECES"] = pieces
                     search([(0, u_short)])

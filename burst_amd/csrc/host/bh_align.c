@@ -156,13 +156,14 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 	}
 	if (!nBatches) return BH_OK;
 	/* A job of one or two batches (a rank's share of a short job: 10 M reads over 8 GPUs are 1.25 M reads each) has nothing to overlap
-	 * its staging, seed lookups and match profiles with -- they are paid in full in front of the chain.  Cut into a few pieces, piece
-	 * k + 1 is staged and seeded while piece k is aligned (BURST_HOST_PIECES: pieces of such a job, default 4; 1 = leave it whole). */
-	if (nBatches <= 2 && totU >= ((uint64_t)1 << 18)) {
-		const char *ev = getenv("BURST_HOST_PIECES");
-		const uint64_t pieces = ev && atoi(ev) > 0 ? (uint64_t)atoi(ev) : 4u;
+	 * its staging, seed lookups and match profiles with -- they are paid in full in front of the chain.  Cutting it into pieces so that
+	 * piece k + 1 is prepared while piece k is aligned was MEASURED and does not pay: every piece brings the fixed costs of a batch
+	 * (about twenty dependent launches, the prefilter's floor) -- 1.25 M reads against the 19 GB database: 4.49 ms whole, 6.11 ms in four
+	 * pieces (profiles/r04h_bench.json).  BURST_HOST_PIECES = n > 1 still cuts such a job into n pieces, for experiments. */
+	if (nBatches <= 2 && totU >= ((uint64_t)1 << 18) && getenv("BURST_HOST_PIECES") && atoi(getenv("BURST_HOST_PIECES")) > 1) {
+		const uint64_t pieces = (uint64_t)atoi(getenv("BURST_HOST_PIECES"));
 		const uint64_t per = (totU + pieces - 1) / pieces;
-		if (pieces > 1 && per < batch_uniq) {
+		if (per < batch_uniq) {
 			batch_uniq = per < ((uint64_t)1 << 16) ? ((uint64_t)1 << 16) : per;
 			nBatches = 0;
 			for (uint32_t i = 0; i < n_ranges; ++i) {

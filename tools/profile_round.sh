@@ -2,10 +2,9 @@
 # Collect the rocprofv3 evidence of one round on the GPU box: tools/profile_round.sh <tag> [bench args...]
 # Writes gpurun_out/<tag>_{kernel_stats.txt,pmc.txt,traffic.json,bench.json}; copy what should be judged into profiles/.
 cd /tmp && export TMPDIR=/tmp
-export BURST_HOST_PIECES=1      # (the one-batch warm-up job is not cut into pieces: every dispatch of a batch kernel is a full-size batch)
 R=/root/repo; TAG=$1; shift
 O=$R/gpurun_out; mkdir -p $O
-B="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end --no-continuity --keep-files --no-prime $*"      # --no-prime: every dispatch of a batch kernel is a full-size batch; --keep-files: the five passes share the database
+B="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end --no-continuity --no-short-job --keep-files --no-prime $*"      # --no-prime: every dispatch of a batch kernel is a full-size batch; --keep-files: the five passes share the database
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -- $B > $O/${TAG}_kt.log 2>&1
 grep '^{' $O/${TAG}_kt.log | tail -1 > $O/${TAG}_bench_under_rocprof.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_fetch -- $B > $O/${TAG}_fetch.log 2>&1
