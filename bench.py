@@ -6,25 +6,29 @@ Workload (BASELINE.json configs[3] / `metric`, at the size one GPU box can build
 31.5 GB RefSeq subset is not reachable offline; the stand-in is a low-redundancy synthetic database (default 1.6 M random base
 sequences x 2 variants at 5 % divergence = 3.2 M references, 4.5 Gbp: every 15-mer has ~4 unrelated list entries, as a
 collision-dominated RefSeq-scale DB15 would have many more), its accelerator BUILT ON THE DEVICE from the .edx (no .acx is read
-or uploaded), and `config.extrapolation` carries the slope measured over several database sizes (profiles/r03_slope.json).
+or uploaded).  The database is as large as the box holds (--db-scale auto: 19.4 GB .edx on a 288 GB device in a 300 GB container; 31.5 GB with
+--db-scale 11.37); `config.extrapolation.measured_sizes` carries the bench line measured at three sizes up to the metric's own (profiles/r04_sizes.json).
 
 A step = one batch of reads through the WHOLE device path as the product runs it: bench.py calls the C batch scheduler of
 the `burst_hip` command line (bh_align_ranges, burst_amd/csrc/host/bh_align.c) -- each step's batch is staged afresh from
 host memory (copies + device-side routing on the staging stream, one batch ahead of the batch being aligned), aligned
 (seeds -> prefilter -> two-stage bit-parallel edit distance -> re-scoring -> sorted records) and its records handed back to
 host memory behind the call.  Staging is therefore INSIDE the timed region.  The steps cycle through --pool distinct
-batches of the sorted unique queries.  N > 1 (one process per GPU under torch.distributed.run): the database is replicated,
-every rank aligns --steps batches of its own (weak scaling, the default: the job is N times the single-GPU job; --scaling strong
-cuts the single-GPU job into N equal shares instead) through the product's multi-rank search (bh_search_multi_ex); the path partitions, so there is no collective on the data path -- every rank's page-locked record
-buffer is a shared-memory segment rank 0 has mapped (bh_node.c), the hand-over inside the timed region is one word per rank and
-rank 0 reads the records where they lie (`handover` in the JSON line).  --gather rccl times the RCCL gather instead;
-torch.distributed only carries the job name and the barriers around the timed region.
+batches of the sorted unique queries.  N > 1 (one process per GPU under torch.distributed.run): the database is replicated and the
+single-GPU job of --steps batches is cut into N equal shares of unique queries (strong scaling, the default: the fixed job north_star
+asks about) through the product's multi-rank search (bh_search_multi_ex); the path partitions, so there is no collective on the
+data path -- every rank's page-locked record buffer is a shared-memory segment rank 0 has mapped (bh_node.c), the hand-over inside
+the timed region is one word per rank and rank 0 reads the records where they lie (`handover` in the JSON line).  Extra keys of the
+N > 1 line: `weak_scaling` (every rank --steps batches of its own), `configs3_job` (10 M reads over the N GPUs), `rccl` (the same job
+with bhip_comm_gather_hits across all N ranks inside the timed region: rccl_ranks, rccl_gather_ms).  torch.distributed only carries the
+job name and the barriers around the timed regions.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel by time on the critical path (HIP events on the stream it runs on);
 `roofline.per_kernel` lists the others with their own bound; PMC-derived traffic / VALU figures come from profiles/
-(tools/profile_round.sh).  `cpu_baseline` is the compiled reference itself (oracle/_ref/burst15, all host cores) on a
-bounded sample of the same reads and database (its .acx is written from the device-built tables): differential wall time of
-two sample sizes, which cancels its database load.  `parity_vs_reference`: the .b6 the reference wrote for that sample against
+(tools/profile_round.sh).  `cpu_baseline` is the compiled reference itself (oracle/_ref/burst15, one thread per core of the job's
+CPU quota) on a bounded sample of the same reads and database (its .acx is streamed to a file from the device-built tables):
+differential wall time of two sample sizes, which cancels its database load.  Where the reference's accelerated run cannot fit the
+job's memory (it holds the .edx and the .acx next to the .acx file) the parity check runs its exhaustive path on a small sample.  `parity_vs_reference`: the .b6 the reference wrote for that sample against
 the .b6 of the device path for the same reads (outside the timed region).
 """
 import argparse
@@ -747,15 +751,14 @@ def main():
         ms_sweeps = st["ms_myers"]
         scale_to_metric = 31.5e9 / max(1, edx_bytes)
         rec_per_read = st["acx_entries_read"] / max(1.0, float(st["n_queries"]))
-        # measured slope over database sizes (tools/slope_fit.py over the bench lines kept under profiles/): ms per batch of --reads reads
-        # = a + b x accelerator records per read; the metric's database has ~63 G list entries
+        # the metric's database is 31.5 GB of .edx: how this run's database compares, and where the bench line measured AT that size is kept
+        # (profiles/r04_sizes.json: three sizes, same kernels; round 3 could only extrapolate -- 5-byte records did not fit the device)
         extrap = {"metric_database": "31.5 GB RefSeq .edx", "this_edx_bytes": edx_bytes, "size_ratio": scale_to_metric,
-                  "acx_entries_here": acx_entries, "acx_records_per_read_here": rec_per_read}
+                  "acx_entries_here": acx_entries, "acx_records_per_read_here": rec_per_read, "this_run_is_at_metric_size": edx_bytes >= 31.0e9}
         try:
-            fit = json.load(open(os.path.join(ROOT, "profiles", "r03_slope.json")))
-            extrap["fit"] = fit
+            extrap["measured_sizes"] = json.load(open(os.path.join(ROOT, "profiles", "r04_sizes.json")))
         except Exception:
-            extrap["fit"] = None
+            extrap["measured_sizes"] = None
         res = {
             "metric": "aligned reads/sec (node), %d-bp synthetic reads @%s id vs RefSeq stand-in .edx/.acx (DB%d), -m %s; %d GPU" % (args.read_len, args.id, args.K, args.mode, world),
             "value": total_reads / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
