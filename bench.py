@@ -626,23 +626,26 @@ def main():
     search(job_share(0, max(1, args.warmup)))
     elapsed, n_records, run = timed(job_share(args.warmup, args.steps))
     total_reads = job_reads(args.warmup, args.steps)
-    own_main = rs.own_stats() if use_dist else None          # (this rank's counters of the timed job: the extra jobs below overwrite them)
-    # what the records are for: rank 0's consolidation of the timed job's records into .b6 lines (bh_report_view: per-mode selection,
-    # coordinates, formatting), written to /dev/null -- outside the timed region, reported beside it
-    consolidation = None
-    if rank == 0:
-        try:
-            t_ = time.time()
-            n_lines_ = host.report_view(os.devnull, db, qs, rs.view, args.mode, 0) if use_dist else host.report(os.devnull, db, qs, run.hits, args.mode, 0)
-            consolidation = {"seconds": time.time() - t_, "lines": int(n_lines_), "what": "rank 0: bh_report over the timed job's records (all ranks'), .b6 lines to /dev/null; not part of `value`"}
-        except Exception as e:
-            consolidation = {"error": str(e)}
+    own_main = rs.own_stats() if use_dist else (run.stats(), int(run.c.nBatches), float(run.c.secAlign))          # (this rank's counters of the timed job: the jobs below overwrite them)
     handover_main = None
     if use_dist and rank == 0:      # what rank 0 holds after the timed search, read once through (outside the timed region): every rank's run, its records
         runs_ = rs.view.runs()
         handover_main = {"kind": "view over the ranks' shared-memory segments" if (node is not None and rs.view.n_runs == world and world > 1) else "one array",
                          "records_per_run": [int(len(x)) for x in runs_], "distinct_entries": int(sum(len(np.unique(x["q"])) for x in runs_)),
                          "xor_of_reference_numbers": int(np.bitwise_xor.reduce(np.concatenate([x["refIx"] for x in runs_]))) if sum(len(x) for x in runs_) else 0}
+    # what the records are for: rank 0's consolidation of the timed job's records into .b6 lines (bh_report_view: per-mode selection,
+    # coordinates, formatting), written to /dev/null -- outside the timed region, reported beside it
+    consolidation = None
+    # (the timed job cycles through the pool: a query appears several times in its records, which no report accepts; one pass over the pool)
+    cons_run = search(job_share(0, P, weak=False))
+    if rank == 0:
+        try:
+            t_ = time.time()
+            n_lines_ = host.report_view(os.devnull, db, qs, rs.view, args.mode, 0) if use_dist else host.report(os.devnull, db, qs, cons_run.hits, args.mode, 0)
+            consolidation = {"seconds": time.time() - t_, "lines": int(n_lines_), "reads": int(qs.n_reads),
+                             "what": "rank 0: bh_report over the records of ONE pass over the read pool (every unique query once; all ranks' records), .b6 lines to /dev/null; not part of `value`"}
+        except Exception as e:
+            consolidation = {"error": str(e)}
     # N > 1: the same ranks again on (a) the other scaling, (b) BASELINE configs[3]'s job -- 10 M reads over all GPUs, one or two batches
     # per rank --, (c) the main job with the records gathered over RCCL (bhip_comm_gather_hits across all N ranks) instead of
     # meeting in shared memory.  Extra keys of the line; `value` stays the main job's
@@ -687,7 +690,7 @@ def main():
             tot = float(sum(arr)) or 1.0
             log("[bench] prefilter phase share: " + " ".join("%d:%.1f%%" % (i, 100.0 * v / tot) for i, v in enumerate(arr)) + "  total wave-cycles %.3g" % tot)
     if rank == 0:
-        st, nb, sec_align = own_main if use_dist else (run.stats(), int(run.c.nBatches), float(run.c.secAlign))
+        st, nb, sec_align = own_main
         nb = max(1, nb)
         per = lambda k: float(st[k]) / nb
         two_stage = st["prefix_words"] > 0
