@@ -862,11 +862,13 @@ def main():
         if want_base:      # N = 1 only (the contract); the other ranks would sit in the barrier meanwhile
             import shutil
             ram_backed = args.workdir.startswith("/dev/shm")
-            fits = host_need(args.db_scale, True, ram_backed) <= memory_limit() * 0.92 and \
+            # (the sizes of THIS database, not the estimate the size was picked with: other read lengths shear the references differently)
+            need_now = (edx_bytes + acx_bytes if ram_backed else 0) + edx_bytes + acx_bytes + 24e9
+            fits = need_now <= memory_limit() * 0.92 and host_need(args.db_scale, True, ram_backed) <= memory_limit() * 0.92 and \
                 (os.path.exists(acx + ".done") or shutil.disk_usage(os.path.dirname(acx)).free >= acx_bytes + (2 << 30))
             if not fits:
                 res["cpu_baseline_skipped"] = ("the reference's accelerated run needs %.0f GB of host memory at this database size (.edx %.1f GB + .acx %.1f GB in its memory%s); "
-                                               "this job may use %.0f GB" % (host_need(args.db_scale, True, ram_backed) / 1e9, edx_bytes / 1e9, acx_bytes / 1e9,
+                                               "this job may use %.0f GB" % (max(need_now, host_need(args.db_scale, True, ram_backed)) / 1e9, edx_bytes / 1e9, acx_bytes / 1e9,
                                                                              ", the .acx file in a RAM-backed directory" if ram_backed else "", memory_limit() / 1e9))
                 log("[bench] " + res["cpu_baseline_skipped"])
                 try:

@@ -21,7 +21,7 @@ for f in glob.glob('%s/%s_kt/**/*kernel_stats.csv' % (O, TAG), recursive=True):
     tot = sum(float(r['TotalDurationNs']) for r in rows)
     out.append('command: rocprofv3 --kernel-trace --stats -- %s' % CMD)
     out.append('%-50s %7s %12s %12s %7s' % ('kernel', 'calls', 'avg_us', 'total_ms', 'share'))
-    for r in rows[:30]:
+    for r in rows[:70]:
         out.append('%-50s %7s %12.1f %12.3f %6.1f%%' % (short(r['Name']), r['Calls'], float(r['AverageNs']) / 1e3, float(r['TotalDurationNs']) / 1e6, 100 * float(r['TotalDurationNs']) / tot))
 open('%s/%s_kernel_stats.txt' % (O, TAG), 'w').write('\n'.join(out) + '\n')
 def pmc(sub):
