@@ -246,7 +246,8 @@ static uint32_t seed_min_need_for(const Handle *h, double mean_words) {
 	if (h->opt_seed_min_need >= 0) return (uint32_t)h->opt_seed_min_need;
 	const double t_all = mean_words * h->acx_wmean;
 	const double t_less = t_all * (mean_words > 1.0 ? (mean_words - 1.0) / mean_words : 1.0) * 0.93;
-	const double counters = (double)(1u << pf_table_bits(h, 0, t_all));
+	// (a stream of at most 255 records counts in bytes: twice the counters; the streams of a batch scatter around their mean)
+	const double counters = (double)(1u << pf_table_bits(h, 0, t_all)) * (h->opt_pf_bytes && t_less <= 200.0 ? 2.0 : 1.0);
 	return (t_all >= 100.0 && t_less / counters <= 0.35) ? 3u : 0u;
 }
 static int launch_seed(Handle *h, Lane *L, hipStream_t st, StageSlot *S, int cls, const uint32_t *d_qlist, uint32_t n_list, uint32_t maxwords, double mean_words, bool ahead = false) {
@@ -327,7 +328,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 		h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, \
 		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
 		fb1, &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum, \
-		L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], prune, (const uint32_t *)nullptr, (const uint32_t *)nullptr)
+		L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], prune, (const uint32_t *)nullptr, (const uint32_t *)nullptr, h->opt_pf_bytes)
 		if (htb == 9) { if (rb == 2) PFC_LAUNCH(9, 2); else if (rb == 3) PFC_LAUNCH(9, 3); else PFC_LAUNCH(9, 4); }
 		else if (htb == 10) { if (rb == 2) PFC_LAUNCH(10, 2); else PFC_LAUNCH(10, 4); }
 		else { if (rb == 2) PFC_LAUNCH(11, 2); else PFC_LAUNCH(11, 4); }
@@ -340,7 +341,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 			hipLaunchKernelGGL((k_prefilter_cf<11, 4>), dim3((uint32_t)h->n_cu), dim3(64), 0, st, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list,
 				h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read,
 				fb2, &dc->n_fb2, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum, L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], prune,
-				(const uint32_t *)fb1, (const uint32_t *)&dc->n_fb);
+				(const uint32_t *)fb1, (const uint32_t *)&dc->n_fb, h->opt_pf_bytes);
 			fb_dense = fb2; n_fb_dense = &dc->n_fb2;
 		}
 	} else {

@@ -978,7 +978,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 		unsigned long long *__restrict__ unit_sum, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum,
 		unsigned long long *__restrict__ surv_sum,
 		uint2 *__restrict__ tasks2, uint32_t *__restrict__ n_tasks2, int prune,     // prune: lanes that cannot hold a minimum go to tasks2 with their lower bound
-		const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel_dev) { // optional: only the list positions sel[0 .. *n_sel_dev) -- the second pass over the
+		const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel_dev, int byte_counters) { // sel: optional: only the list positions sel[0 .. *n_sel_dev) -- the second pass over the
 		                                                                            // queries that overflowed the first pass's tables, with the largest tables
 	constexpr uint32_t NCNT = 1u << CB;                                   // approximate counters per query (16 bit each)
 	constexpr uint32_t LT = CB <= 9 ? 64u : (CB == 10 ? 128u : 256u);     // exact lane-table slots per query
@@ -1177,11 +1177,16 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 			if (live && j < nwords) r = ranges[(size_t)li * W16 + j];
 			beg = (unsigned long long)r.x | (unsigned long long)(r.y >> 24) << 32; n = r.y & 0xFFFFFFu;
 		};
+		// A query whose whole record stream is at most 255 records cannot drive a counter beyond 255: its counters are BYTES, twice as
+		// many in the same LDS (2 << CB per query) -- half the load per counter, a third to a quarter of the false survivors (a survivor
+		// costs about eight records' worth of work).  Longer streams keep the 16-bit counters.  cshift = log2 of the counter's bits.
+		const bool nar = byte_counters && nwords <= 16u && T0 <= 255u;
+		const uint32_t cshift = nar ? 3u : 4u, cper = nar ? 3u : 1u, cmask = nar ? 0xFFu : 0xFFFFu, hsh = nar ? 0u : 1u;      // (group-uniform)
 		auto count4 = [&](const uint32_t (&rec)[4]) {     // phase A: approximate counters, no return values
 			#pragma unroll
 			for (int u = 0; u < 4; ++u) if (rec[u] != BHIP_REC_PAD) {
-				const uint32_t h = ((rec[u] & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - CB);
-				atomicAdd(&s_cnt[g][h >> 1], 1u << (16 * (h & 1u)));
+				const uint32_t h = (((rec[u] & 0xFFFFFFu) * 0x9E3779B1u) >> (31 - CB)) >> hsh;      // CB + 1 bits (bytes) or CB bits
+				atomicAdd(&s_cnt[g][h >> (5u - cshift)], 1u << ((h & cper) << cshift));
 			}
 		};
 		uint32_t pending = 0, head = 0;          // survivors waiting in this group's ring (replicated in its 16 lanes)
@@ -1220,8 +1225,8 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 			uint32_t cv[4];
 			#pragma unroll
 			for (int u = 0; u < 4; ++u) {
-				const uint32_t h = rec[u] != BHIP_REC_PAD ? ((rec[u] & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - CB) : 0u;
-				cv[u] = (s_cnt[g][h >> 1] >> (16 * (h & 1u))) & 0xFFFFu;
+				const uint32_t h = rec[u] != BHIP_REC_PAD ? (((rec[u] & 0xFFFFFFu) * 0x9E3779B1u) >> (31 - CB)) >> hsh : 0u;
+				cv[u] = (s_cnt[g][h >> (5u - cshift)] >> ((h & cper) << cshift)) & cmask;
 			}
 			#pragma unroll
 			for (int u = 0; u < 4; ++u) {
@@ -1406,7 +1411,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 #define BHIP_INST_PFCF(CB, RB) \
 	template __global__ void k_prefilter_cf<CB, RB>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, \
 		uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *, \
-		uint2 *, uint32_t *, int, const uint32_t *, const uint32_t *);
+		uint2 *, uint32_t *, int, const uint32_t *, const uint32_t *, int);
 BHIP_INST_PFCF(9, 2) BHIP_INST_PFCF(9, 3) BHIP_INST_PFCF(9, 4) BHIP_INST_PFCF(10, 2) BHIP_INST_PFCF(10, 4) BHIP_INST_PFCF(11, 2) BHIP_INST_PFCF(11, 4)
 
 template __global__ void k_prefilter_mask<9>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,

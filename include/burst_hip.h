@@ -267,6 +267,7 @@ BHIP_API int bhip_sort_queries(int device, const uint8_t *codes, uint64_t codes_
  * stream is long enough to matter and short enough for the counting filter to stay selective (bhip_align.hip seed_min_need_for).
  * "seed_drop_len" (default 8): lists shorter than this are never left out.  "prefilter_rb": 0 (default, from the expected stream) or
  * 2 / 3 / 4 = blocks of 64 list records per query the counting-filter kernel fetches one quad ahead and keeps in registers.
+ * "prefilter_bytes": 1 (default) = a query whose record stream is at most 255 records counts in bytes (twice the counters in the same LDS).
  * None of these changes a result.  BHIP_OPTS="name=value,..." in the environment sets options at bhip_init. */
 BHIP_API int bhip_set_option(void *handle, const char *name, long long value);
 
