@@ -104,7 +104,7 @@ def sizes_at(sc):
     return edx, edx * 1.06 + sc * UNIT_ENTRIES * 4 + 4.9e9 + 14e9, sc * UNIT_ENTRIES * 3 + 4.3e9
 
 
-def host_need(sc, with_reference, ram_backed):
+def host_need(sc, with_reference, ram_backed, world=1):
     """host memory a run at this scale touches at its worst moment.  Building: one part (2.5 units: FASTA + ~5 bytes per base in the
     QUICK builder) beside the parts' .edx files and, at the end, the merged file.  Running: the .edx file and this process's copy.
     With the reference: its .acx file, and the reference's own copies of .edx and .acx (it reads both into memory) -- this process
@@ -113,12 +113,12 @@ def host_need(sc, with_reference, ram_backed):
     part = min(sc, 2.5) * UNIT_FASTA
     files = (2 * edx + 1.5e9) if ram_backed else 0
     build = part * (6 if ram_backed else 5) + files
-    run = edx + files / 2 + 8e9
+    run = world * (edx + 4e9) + files / 2 + 8e9          # (every rank's process holds its own copy of the database for the upload)
     ref = ((edx + acx if ram_backed else 0) + edx + acx + 10e9) if with_reference else 0
     return max(build, run, ref) + 6e9
 
 
-def pick_setup(args, free_hbm, want_cpu_baseline):
+def pick_setup(args, free_hbm, want_cpu_baseline, world=1):
     """(db-scale, work directory): the largest database of AUTO_SCALES this box holds -- on the device (references + 4-byte records +
     offset lines + batch buffers), in the host memory the job may use (see host_need; with 8 % of slack) and in the work directory
     (FASTA parts, .edx, reads, the .acx file the compiled reference reads)"""
@@ -138,7 +138,7 @@ def pick_setup(args, free_hbm, want_cpu_baseline):
         for with_ref in ((True, False) if args.db_scale != "auto" else (want_cpu_baseline,)):      # (auto: a size at which the reference runs beside it, if one is wanted)
             disk_need = min(sc, 2.5) * UNIT_FASTA + 2 * edx + (acx_file if with_ref else 0) + 4e9
             for d in dirs:
-                if dev_need <= free_hbm and disk_need <= free_of(d) and host_need(sc, with_ref, d.startswith("/dev/shm")) <= ram:
+                if dev_need <= free_hbm and disk_need <= free_of(d) and host_need(sc, with_ref, d.startswith("/dev/shm"), world) <= ram:
                     return sc, d
     if args.db_scale != "auto":      # an explicit size is taken at its word (the allocation says when it does not fit)
         return float(args.db_scale), dirs[0]
@@ -456,7 +456,7 @@ def main():
         free_hbm = torch.cuda.mem_get_info(local_rank)[0]
     except Exception:
         free_hbm = 0
-    setup = [pick_setup(args, free_hbm, want_base)]
+    setup = [pick_setup(args, free_hbm, want_base, world)]
     if use_dist:
         dist.broadcast_object_list(setup, src=0)
     args.db_scale, args.workdir = float(setup[0][0]), setup[0][1]
