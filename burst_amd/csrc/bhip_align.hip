@@ -271,7 +271,7 @@ static int launch_seed(Handle *h, Lane *L, hipStream_t st, StageSlot *S, int cls
 		junk ? S->qcodes_s.as<uint8_t>() : S->qcodes.as<uint8_t>(), junk ? S->qoff_s.as<uint64_t>() : S->qoff.as<uint64_t>(), d_qlist, n_list,
 		h->acx_view(), h->K, S->plan.as<uint32_t>(), W16, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(),
 		junk ? S->qpack_s.as<uint32_t>() : S->qpack.as<uint32_t>(), (S->st_maxlen + 7) / 8, junk ? S->qemac_s.as<uint16_t>() : S->qemac.as<uint16_t>(), qm.as<uint4>(), S->st_has_six ? S->qsix.as<uint32_t>() : nullptr,
-		seed_min_need_for(h, mean_words), (uint32_t)h->opt_seed_drop_len);
+		seed_min_need_for(h, mean_words), (uint32_t)h->opt_seed_drop_len, h->alt);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(ev[1], st));
 	L->qmeta_seq[S->seq & 1][cls] = S->seq + 1;
@@ -1018,7 +1018,7 @@ extern "C" int bhip_prefilter(void *handle, const uint8_t *q_codes, const uint64
 		if ((rc = upload_queries(h, q_codes, q_off, q_emac, nullptr, nullptr, n_q))) return rc;
 		{
 			std::vector<uint32_t> plan(n_q, 1u);
-			for (uint32_t i = 0; i < n_q; ++i) plan[i] = make_seed_plan(q_codes + q_off[i], (uint32_t)(q_off[i + 1] - q_off[i]), q_emac[i], (uint32_t)h->K, h->opt_prefilter_stride);
+			for (uint32_t i = 0; i < n_q; ++i) plan[i] = make_seed_plan(q_codes + q_off[i], (uint32_t)(q_off[i + 1] - q_off[i]), q_emac[i], (uint32_t)h->K, h->opt_prefilter_stride, h->alt);
 			if ((rc = upload_plan(h, q_codes, q_off, q_emac, n_q, plan))) return rc;
 	{	// 4-bit packed copy of the queries at a fixed stride (layout used by the seed, profile and re-scoring kernels)
 		const uint32_t qw_g = (h->cur->st_maxlen + 7) / 8;

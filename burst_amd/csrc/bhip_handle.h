@@ -53,7 +53,7 @@ template <int CB, int RBT> __global__ void k_prefilter_cf(const uint2 *, const u
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *,
 	uint2 *, uint32_t *, int, const uint32_t *, const uint32_t *, int);
 __global__ void k_task_filter(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, uint2 *, uint32_t *);
-__global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, BhipAcxView, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t, const uint16_t *, uint4 *, const uint32_t *, uint32_t, uint32_t);
+__global__ void k_seed_ranges(const uint8_t *, const uint64_t *, const uint32_t *, uint32_t, BhipAcxView, int, const uint32_t *, uint32_t, uint2 *, uint2 *, const uint32_t *, uint32_t, const uint16_t *, uint4 *, const uint32_t *, uint32_t, uint32_t, BhipAlt);
 template <int NWP> __global__ void k_myers_prefix_task(const uint2 *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, const uint64_t *,
 	const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, BhipWin *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, const uint4 *, const uint32_t *);
 template <bool WIDE> __global__ void k_rescore(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, const uint32_t *,
@@ -65,7 +65,7 @@ __global__ void k_unpack4(const uint8_t *, uint64_t, uint64_t, uint8_t *);
 __global__ void k_unpack2(const uint8_t *, uint64_t, uint64_t, uint8_t *);
 __global__ void k_span_fill(const uint64_t *, uint32_t, uint32_t, uint64_t, uint32_t, uint64_t *, uint32_t *, uint32_t *);
 __global__ void k_route(const uint64_t *, const uint32_t *, uint32_t, const uint16_t *, const uint32_t *, const uint8_t *, uint32_t, uint32_t, uint32_t, int, int, int,
-	uint32_t *, uint8_t *, uint32_t *, BhipStageInfo *);
+	uint32_t *, uint8_t *, uint32_t *, BhipStageInfo *, BhipAlt);
 __global__ void k_rescore_classify(const BhipRawHit *, const uint32_t *, uint32_t, const uint32_t *, int, const uint64_t *, const uint32_t *, const uint8_t *,
 	const uint32_t *, BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t, int);
 template <int SET> __global__ void k_rescore_reg(const BhipRawHit *, const uint32_t *, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, const uint32_t *, uint32_t,
@@ -218,6 +218,7 @@ struct Handle {
 	uint32_t n_clumps = 0, tot_refs = 0, max_clump_len = 0;
 	DBuf ref_lane, ref_off, clump_len, lut;           // ref_lane: [clump][lane][32-column chunk][16 B], each lane contiguous inside its clump's area
 	BhipMatchMask mm;
+	BhipAlt alt;                  // compatible bases of every query symbol code (from the cost table): which ambiguous query words can vote through expansions
 	bool has_acx = false; int K = 0;
 	// accelerator: offset lines + 4-byte (clump, lane-set code) records (bhip_internal.h); entry numbers start at acx_bias
 	// (0, or the test hook BHIP_TEST_ENTRY_BIAS that pushes a small database's offsets beyond 2^32)
@@ -287,7 +288,7 @@ static inline float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipE
 
 // ---- host functions shared between the files of the library ----
 int  ensure_lanes(Handle *h, uint32_t n);                                    // bhip_init.hip
-uint32_t make_seed_plan(const uint8_t *s, uint32_t len, uint32_t E, uint32_t K, int stride_opt);   // bhip_stage.hip
+uint32_t make_seed_plan(const uint8_t *s, uint32_t len, uint32_t E, uint32_t K, int stride_opt, const BhipAlt &A);   // bhip_stage.hip
 int  slot_init(StageSlot *S);
 int  resolve_slot(Handle *h, StageSlot *S);
 void apply_slot(Handle *h, StageSlot *S);

@@ -132,6 +132,10 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		uint16_t m = 0;
 		for (int b = 0; b < 16; ++b) if (score_lut[16 * a + b] == 0) m |= (uint16_t)(1u << b);
 		h->mm.m[a] = m;
+		// the bases among A, C, G, T (codes 1..4) that cost nothing against query code a
+		uint8_t n = 0, bases = 0;
+		for (int b = 1; b <= 4; ++b) if (m & (1u << b)) { bases |= (uint8_t)((b - 1) << (2 * n)); ++n; }
+		h->alt.n[a] = n; h->alt.base[a] = bases;
 	}
 	// reference area: upload as on disk, transpose on the device
 	std::vector<uint64_t> src_off(n_clumps + 1), dst_off(n_clumps + 1);

@@ -44,6 +44,52 @@ __host__ __device__ inline uint32_t bhip_win_class(uint32_t g_first, uint32_t g_
 	return diags <= 26 ? 0u : diags <= 58 ? 1u : diags <= 90 ? 2u : 3u;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Seed plan of one query entry: plan = stride | need << 8 | x << 24 | used << 28.
+//   stride  sampled words start at 0, s, 2s, ...
+//   need    words an alignment within budget is guaranteed to keep = (voting words) - E * ceil(K / s); 0 = none (exhaustive route)
+//   x, used only when stride == K (the words do not overlap): x words that hold exactly ONE ambiguous query symbol with 2..4
+//           compatible bases vote through their EXPANSIONS (the reference expands ambiguous query words too: storeAmbigWords,
+//           burst.c:3232-3236) -- the first alternative in the word's own slot, the others in `used` (<= BHIP_EXPAND_SLOTS) extra
+//           word slots behind the positional ones.  An expansion is a vote of its own: a reference holding two expansions of a word
+//           counts twice, which only adds candidates.  `need` includes the x words; the kernels that count strictly (words of
+//           A/C/G/T only: the clump-level fallbacks) use need - x and take every clump when that is below 1.
+// Words with more ambiguity, with a symbol outside the alphabet, or beyond the slot budget do not vote, as before.
+// ------------------------------------------------------------------------------------------------
+#define BHIP_PLAN_STRIDE(p) ((p) & 255u)
+#define BHIP_PLAN_NEED(p)   (((p) >> 8) & 0xFFFFu)
+#define BHIP_PLAN_X(p)      (((p) >> 24) & 15u)
+#define BHIP_PLAN_USED(p)   ((p) >> 28)
+#define BHIP_EXPAND_SLOTS 8u
+// compatible bases of a query symbol code: n[c] = how many of A/C/G/T cost 0 against it (0: a symbol that matches nothing, 1: a base),
+// base[c] = those bases, two bits each, first alternative in the low bits.  Made from the cost table at bhip_init.
+struct BhipAlt { uint8_t n[16]; uint8_t base[16]; };
+
+// class of the word of K symbols starting at p: 0 does not vote, 1 A/C/G/T only, 2 expandable (amb_k = offset of its ambiguous symbol, extra = alternatives - 1)
+template <class Sym>
+__host__ __device__ inline uint32_t bhip_word_class(Sym sym, uint32_t p, uint32_t K, const BhipAlt &A, uint32_t &amb_k, uint32_t &extra) {
+	uint32_t namb = 0, bad = 0;
+	amb_k = 0; extra = 0;
+	for (uint32_t k = 0; k < K; ++k) {
+		const uint32_t n = A.n[sym(p + k) & 15u];
+		if (n == 0u) bad = 1u;
+		else if (n > 1u) { ++namb; amb_k = k; extra = n - 1u; }
+	}
+	return (bad || namb > 1u) ? 0u : (namb ? 2u : 1u);
+}
+// walk over the non-overlapping words 0, K, 2K, ... [0, upto): voting words (strict + expanded within the slot budget), expanded words, slots used.
+// The SAME walk decides everywhere (plan, seed lookups) which expandable words fit the budget: position order, first come first served.
+template <class Sym>
+__host__ __device__ inline void bhip_expand_walk(Sym sym, uint32_t K, uint32_t upto, const BhipAlt &A, uint32_t &w_strict, uint32_t &x, uint32_t &used) {
+	w_strict = 0; x = 0; used = 0;
+	for (uint32_t j = 0; j < upto; ++j) {
+		uint32_t ak, ex;
+		const uint32_t c = bhip_word_class(sym, j * K, K, A, ak, ex);
+		if (c == 1u) ++w_strict;
+		else if (c == 2u && used + ex <= BHIP_EXPAND_SLOTS) { ++x; used += ex; }
+	}
+}
+
 // Routing of a staged batch, filled on the device by k_route (or by the host pass that handles batches with query symbols
 // outside the alphabet): a query entry belongs to the list of its key = ((lane * 7 + length class) * 2 + exhaustive).
 #define BHIP_ROUTE_KEYS 224          // 16 lanes x 7 classes x {prefilter, exhaustive}

@@ -200,16 +200,20 @@ __global__ __launch_bounds__(256) void k_prefilter(
 			}
 		}
 		__syncthreads();
-		const uint32_t need1 = plan ? plan[q] >> 8 : 0u;
+		// (this kernel counts words of A/C/G/T only: of the plan's need, the x words that vote through expansions are not seen here; when
+		// nothing is left of it every clump is a candidate)
+		const uint32_t px = plan ? BHIP_PLAN_X(plan[q]) : 0u, pn = plan ? BHIP_PLAN_NEED(plan[q]) : 0u;
+		const uint32_t need1 = pn > px ? pn - px : 0u;
+		const bool takeall = px && !need1;
 		const uint32_t kload = E * K + K, mmatch = plan ? (need1 ? need1 - 1 : 0u) : (kload < len ? len - kload : 0);
 		for (uint32_t c = tid; c < n_clumps; c += 256) {
 			const uint32_t v = (cnt[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu;
-			if (v > mmatch) {
+			if (v > mmatch || takeall) {
 				const uint32_t pos = atomicAdd(n_cand, 1u);
 				if (pos < cand_cap) { cand[pos] = make_uint2(li, c); if (cand_cnt_out) cand_cnt_out[pos] = v; }
 			}
 		}
-		for (uint32_t i = tid; i < n_bad; i += 256) {          // burst.c:4136-4138, 4282-4283
+		for (uint32_t i = tid; i < n_bad && !takeall; i += 256) {          // burst.c:4136-4138, 4282-4283 (with every clump taken they are in already)
 			const uint32_t pos = atomicAdd(n_cand, 1u);
 			if (pos < cand_cap) { cand[pos] = make_uint2(li, bad[i]); if (cand_cnt_out) cand_cnt_out[pos] = 0xFFFFFFFFu; }
 		}
@@ -301,7 +305,9 @@ __global__ __launch_bounds__(64) void k_prefilter_wave(
 		const uint32_t q = qlist ? qlist[li] : li;
 		const uint64_t b = qoff[q];
 		const uint32_t len = (uint32_t)(qoff[q + 1] - b), E = qemac[q];
-		const uint32_t stride = plan[q] & 255u, need = plan[q] >> 8;
+		const uint32_t stride = plan[q] & 255u, px_ = BHIP_PLAN_X(plan[q]), pn_ = BHIP_PLAN_NEED(plan[q]);
+		const uint32_t need = pn_ > px_ ? pn_ - px_ : 0u;      // (strict counting: without the words that vote through expansions)
+		const bool takeall = px_ && !need;
 		(void)E;
 		if (len >= (uint32_t)K) {
 			const uint32_t nwords = (len - K) / stride + 1;
@@ -337,7 +343,10 @@ __global__ __launch_bounds__(64) void k_prefilter_wave(
 		__syncthreads();
 		const uint32_t mmatch = need ? need - 1 : 0;      // candidate iff count >= need (count > 0 when no words are guaranteed)
 		const uint32_t nt = ctr[0];
-		if (nt <= PF2_TL) {
+		if (takeall) {      // nothing of the guarantee is visible to strict counting: every clump
+			for (uint32_t i = lane; i < nw32; i += 64) cnt[i] = 0;
+			for (uint32_t c = lane; c < n_clumps; c += 64) push(li, c, 0);
+		} else if (nt <= PF2_TL) {
 			for (uint32_t i = lane; i < nt; i += 64) {
 				const uint32_t c = tl[i], sh = (c % PER) * BITS;
 				const uint32_t v = (cnt[c / PER] >> sh) & MASK;
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(64) void k_prefilter_wave(
 				}
 			}
 		}
-		for (uint32_t i = lane; i < n_bad; i += 64) push(li, bad[i], 0xFFFFFFFFu);          // burst.c:4136-4138, 4282-4283
+		for (uint32_t i = lane; i < n_bad && !takeall; i += 64) push(li, bad[i], 0xFFFFFFFFu);          // burst.c:4136-4138, 4282-4283 (with every clump taken they are in already)
 		__syncthreads();
 		if (lane == 0) ctr[0] = 0;
 		if (ctr[1] >= PF2_STAGE / 2) flush(); else __syncthreads();
@@ -453,7 +462,8 @@ __global__ __launch_bounds__(64) void k_prefilter_hash(
 			b = qoff[q];
 			len = (uint32_t)(qoff[q + 1] - b);
 			if (len >= (uint32_t)K) {
-				stride = plan[q] & 255u; need = plan[q] >> 8;      // the host keeps (len-K)/stride + 1 <= 255 (8-bit counts)
+				stride = plan[q] & 255u;      // the host keeps (len-K)/stride + 1 <= 255 (8-bit counts)
+				{ const uint32_t px_ = BHIP_PLAN_X(plan[q]), pn_ = BHIP_PLAN_NEED(plan[q]); need = pn_ > px_ ? pn_ - px_ : 0u; if (px_ && !need) s_ovf[g] = 1; }      // (strict counting; nothing left of the guarantee: the dense kernels take every clump)
 				nwords = (len - K) / stride + 1;
 			}
 		}
@@ -579,18 +589,50 @@ __global__ __launch_bounds__(256) void k_seed_ranges(
 		BhipAcxView acx, int K, const uint32_t *__restrict__ plan, uint32_t W16,
 		uint2 *__restrict__ ranges, uint2 *__restrict__ hdr, const uint32_t *__restrict__ qpack, uint32_t qw, const uint16_t *__restrict__ qemac,
 		uint4 *__restrict__ qmeta, const uint32_t *__restrict__ qsix,         // qmeta[list position] = (query entry, length | budget << 16, shared slot): one sector for the prefix sweep instead of three
-		uint32_t min_need, uint32_t drop_len) {                               // the longest lists of a query are left out while `need` stays >= min_need (0: never), lists shorter than drop_len stay
+		uint32_t min_need, uint32_t drop_len,                                 // the longest lists of a query are left out while `need` stays >= min_need (0: never), lists shorter than drop_len stay
+		BhipAlt alt) {                                                        // compatible bases per query symbol code: expansions of ambiguous words (plan bits 24..31)
 	// (grid-stride: run ahead beside another batch's sweeps, the kernel is launched with a few blocks per CU only)
 	for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < (uint64_t)n_list * W16; t += (uint64_t)gridDim.x * 256) {
 	const uint32_t li = (uint32_t)(t / W16), j = (uint32_t)(t % W16);
 	const uint32_t q = qlist ? qlist[li] : li;
 	const uint64_t b = qoff[q];
 	const uint32_t len = (uint32_t)(qoff[q + 1] - b);
-	uint32_t stride = 1, need = 0, nwords = 0;
-	if (len >= (uint32_t)K) { const uint32_t pl = plan[q]; stride = pl & 255u; need = pl >> 8; nwords = (len - K) / stride + 1; }
+	uint32_t stride = 1, need = 0, nwords = 0, n_exp = 0, n_pos = 0;
+	if (len >= (uint32_t)K) { const uint32_t pl = plan[q]; stride = pl & 255u; need = BHIP_PLAN_NEED(pl); n_pos = (len - K) / stride + 1; n_exp = BHIP_PLAN_X(pl) ? BHIP_PLAN_USED(pl) : 0u; nwords = n_pos + n_exp; }
 	if (nwords > W16) nwords = W16;
 	uint2 r = make_uint2(0, 0);
-	if (j < nwords) {
+	if (n_exp && j < nwords) {
+		// A query with expanded words (rare: plan bits 24..31; stride == K, the words do not overlap).  Slot j < n_pos is the word at j K:
+		// a word of A/C/G/T as usual, an expandable one -- if the budget walk reaches it -- with the FIRST compatible base in place of its
+		// ambiguous symbol; slot n_pos + e is the e-th further alternative, found by the same walk.  Symbol by symbol: this path is
+		// off the critical path and taken by a handful of queries per batch.
+		const uint32_t *qp = qpack + (uint64_t)q * qw;
+		auto sym = [&](uint32_t i) -> uint32_t { return qpack ? (qp[i >> 3] >> (4u * (i & 7u))) & 15u : (uint32_t)qcodes[b + i]; };
+		const uint32_t Ku = (uint32_t)K;
+		uint32_t wj = 0xFFFFFFFFu, alt_ix = 0, amb_k = 0;      // the word this slot looks up: its number, which alternative, where its ambiguous symbol is
+		uint32_t used = 0;
+		const uint32_t upto = j < n_pos ? j + 1 : n_pos;
+		for (uint32_t t = 0; t < upto && wj == 0xFFFFFFFFu; ++t) {
+			uint32_t ak, ex;
+			const uint32_t c = bhip_word_class(sym, t * Ku, Ku, alt, ak, ex);
+			const bool fits = c == 2u && used + ex <= BHIP_EXPAND_SLOTS;
+			if (j < n_pos) { if (t == j && (c == 1u || fits)) { wj = t; alt_ix = 0; amb_k = c == 2u ? ak : 0xFFFFFFFFu; } }
+			else if (fits && j - n_pos >= used && j - n_pos < used + ex) { wj = t; alt_ix = 1u + (j - n_pos - used); amb_k = ak; }
+			if (fits) used += ex;
+		}
+		if (wj != 0xFFFFFFFFu) {
+			uint32_t w = 0;
+			for (uint32_t k = 0; k < Ku; ++k) {
+				const uint32_t c = sym(wj * Ku + k);
+				const uint32_t base = k == amb_k ? ((uint32_t)alt.base[c] >> (2u * alt_ix)) & 3u : (c - 1u) & 3u;
+				w = (w << 2) | base;
+			}
+			w &= Ku == 16 ? 0xFFFFFFFFu : ((1u << (2 * Ku)) - 1u);
+			unsigned long long beg; uint32_t n;
+			bhip_acx_range(acx, w, beg, n);
+			r.x = (uint32_t)beg; r.y = n | (uint32_t)(beg >> 32) << 24;
+		}
+	} else if (j < nwords) {
 		const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
 		const uint32_t p = j * stride;
 		uint32_t w = 0, ok = 1;
@@ -2178,12 +2220,18 @@ __global__ void k_unpack2(const uint8_t *__restrict__ packed, uint64_t src0, uin
 }
 
 // seed plan of one entry: same choice as make_seed_plan (bhip_api.hip); vb = bit p set iff the word at p holds only A/C/G/T
-__device__ uint32_t bhip_seed_plan(uint32_t len, uint32_t E, uint32_t K, int stride_opt, bool clean, const uint32_t *vb) {
+// (qp = the entry's 4-bit packed symbols: with non-overlapping words -- stride K -- the words that hold one ambiguous symbol vote through their expansions,
+// bhip_internal.h; the same walk as the host's)
+__device__ uint32_t bhip_seed_plan(uint32_t len, uint32_t E, uint32_t K, int stride_opt, bool clean, const uint32_t *vb, const uint32_t *qp, const BhipAlt &A) {
 	if (len < K) return 1u;
 	const uint32_t npos = len - K + 1;
+	uint32_t xk = 0, usedk = 0;
+	auto sym = [&](uint32_t i) -> uint32_t { return (qp[i >> 3] >> (4u * (i & 7u))) & 15u; };
 	auto need_of = [&](uint32_t st) -> int {
 		uint32_t W = 0;
-		if (clean) W = (len - K) / st + 1; else for (uint32_t p = 0; p < npos; p += st) W += (vb[p >> 5] >> (p & 31u)) & 1u;
+		if (clean) W = (len - K) / st + 1;
+		else if (st == K) { uint32_t ws; bhip_expand_walk(sym, K, (len - K) / K + 1, A, ws, xk, usedk); W = ws + xk; }
+		else for (uint32_t p = 0; p < npos; p += st) W += (vb[p >> 5] >> (p & 31u)) & 1u;
 		return (int)W - (int)(E * ((K + st - 1) / st));
 	};
 	const uint32_t smin = (len - K) / 254 + 1, smax = K > smin ? K : smin;
@@ -2196,14 +2244,15 @@ __device__ uint32_t bhip_seed_plan(uint32_t len, uint32_t E, uint32_t K, int str
 	}
 	if (best_n < 1) best_n = 0;
 	if (best_n > 0xFFFF) best_n = 0xFFFF;
-	return (best_s & 255u) | ((uint32_t)best_n << 8);
+	const bool ex = !clean && best_s == K && best_n > 0 && xk > 0;
+	return (best_s & 255u) | ((uint32_t)best_n << 8) | (ex ? xk << 24 | usedk << 28 : 0u);
 }
 
 __global__ __launch_bounds__(256) void k_route(
 		const uint64_t *__restrict__ qoff, const uint32_t *__restrict__ qpack, uint32_t qw, const uint16_t *__restrict__ qemac,
 		const uint32_t *__restrict__ qsix, const uint8_t *__restrict__ qflags, uint32_t n_q, uint32_t n_shared, uint32_t n_lanes,
 		int has_acx, int K, int stride_opt,
-		uint32_t *__restrict__ plan, uint8_t *__restrict__ key_out, uint32_t *__restrict__ idx_out, BhipStageInfo *__restrict__ info) {
+		uint32_t *__restrict__ plan, uint8_t *__restrict__ key_out, uint32_t *__restrict__ idx_out, BhipStageInfo *__restrict__ info, BhipAlt alt) {
 	__shared__ uint32_t s_count[256], s_maxE[BHIP_ROUTE_KEYS / 2], s_maxw[BHIP_ROUTE_KEYS / 2], s_seed[BHIP_ROUTE_KEYS / 2], s_maxlen[16], s_nent[16], s_misc[4];
 	const uint32_t tid = threadIdx.x;
 	s_count[tid] = 0;
@@ -2248,15 +2297,15 @@ __global__ __launch_bounds__(256) void k_route(
 						if (p + 1 >= (uint32_t)K && run >= (uint32_t)K) { const uint32_t w0 = p + 1 - K; vb[w0 >> 5] |= 1u << (w0 & 31u); }
 					}
 				}
-				pl = bhip_seed_plan(len, E, (uint32_t)K, stride_opt, clean, vb);
-				if ((pl >> 8) == 0) ex = 1;        // no word is guaranteed to survive: exhaustive (burst.c:3130-3131 does the same for "bad" queries)
+				pl = bhip_seed_plan(len, E, (uint32_t)K, stride_opt, clean, vb, qp, alt);
+				if (BHIP_PLAN_NEED(pl) == 0) ex = 1;        // no word is guaranteed to survive: exhaustive (burst.c:3130-3131 does the same for "bad" queries)
 			}
 			const uint32_t lc = l * 7 + cls;
 			key = lc * 2 + ex;
 			atomicAdd(&s_count[key], 1u);
 			atomicMax(&s_maxE[lc], E);
 			if (!ex && len >= (uint32_t)K) {
-				const uint32_t nwd = (len - K) / (pl & 255u) + 1;
+				const uint32_t nwd = (len - K) / (pl & 255u) + 1 + BHIP_PLAN_USED(pl);      // (+ the slots of expanded words)
 				atomicMax(&s_maxw[lc], nwd);
 				atomicAdd(&s_seed[lc], nwd);
 			}

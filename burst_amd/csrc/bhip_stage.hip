@@ -3,9 +3,10 @@
 // host pass for batches with symbols outside the alphabet, and the page-locked host memory helpers.
 #include "bhip_handle.h"
 
-// Seed plan of one query entry (see bhip_kernels.hip): returns stride | need << 8, need = 0 when no stride guarantees a
-// surviving word (the caller then aligns the entry against every clump).  stride_opt > 0 forces the stride.
-uint32_t make_seed_plan(const uint8_t *s, uint32_t len, uint32_t E, uint32_t K, int stride_opt) {
+// Seed plan of one query entry (bhip_internal.h: stride | need << 8 | x << 24 | used << 28), need = 0 when no stride guarantees a
+// surviving word (the caller then aligns the entry against every clump).  stride_opt > 0 forces the stride.  The same choice as
+// bhip_seed_plan (k_route, bhip_kernels.hip).
+uint32_t make_seed_plan(const uint8_t *s, uint32_t len, uint32_t E, uint32_t K, int stride_opt, const BhipAlt &A) {
 	if (len < K) return 1u;
 	const uint32_t npos = len - K + 1;
 	bool clean = true;
@@ -16,9 +17,13 @@ uint32_t make_seed_plan(const uint8_t *s, uint32_t len, uint32_t E, uint32_t K, 
 		uint32_t run = 0;
 		for (uint32_t i = 0; i < len; ++i) { run = ((uint32_t)(s[i] - 1u) < 4u) ? run + 1 : 0; if (i + 1 >= K && run >= K) valid[i + 1 - K] = 1; }
 	}
+	uint32_t xk = 0, usedk = 0;      // expansions: with non-overlapping words (stride K) only
+	auto sym = [&](uint32_t i) -> uint32_t { return s[i]; };
 	auto need_of = [&](uint32_t st) -> int {
 		uint32_t W = 0;
-		if (clean) W = (len - K) / st + 1; else for (uint32_t p = 0; p < npos; p += st) W += valid[p];
+		if (clean) W = (len - K) / st + 1;
+		else if (st == K) { uint32_t ws; bhip_expand_walk(sym, K, (len - K) / K + 1, A, ws, xk, usedk); W = ws + xk; }
+		else for (uint32_t p = 0; p < npos; p += st) W += valid[p];
 		return (int)W - (int)(E * ((K + st - 1) / st));
 	};
 	const uint32_t smin = (len - K) / 254 + 1;      // keeps the number of sampled words <= 255 (8-bit counters)
@@ -31,7 +36,8 @@ uint32_t make_seed_plan(const uint8_t *s, uint32_t len, uint32_t E, uint32_t K, 
 	}
 	if (best_n < 1) best_n = 0;
 	if (best_n > 0xFFFF) best_n = 0xFFFF;
-	return (best_s & 255u) | ((uint32_t)best_n << 8);
+	const bool ex = !clean && best_s == K && best_n > 0 && xk > 0;
+	return (best_s & 255u) | ((uint32_t)best_n << 8) | (ex ? xk << 24 | usedk << 28 : 0u);
 }
 
 // ---- staged batches -------------------------------------------------------------------------------------------------
@@ -158,7 +164,7 @@ static int stage_enqueue(Handle *h, StageSlot *S, const BhipQuerySpan *spans, ui
 	hipLaunchKernelGGL(k_route, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, st, S->qoff.as<uint64_t>(), S->qpack.as<uint32_t>(), qw,
 		S->qemac.as<uint16_t>(), S->st_has_six ? S->qsix.as<uint32_t>() : (const uint32_t *)nullptr, any_flags ? S->qflags.as<uint8_t>() : (const uint8_t *)nullptr,
 		n_q, S->st_nshared, S->st_lanes, h->has_acx ? 1 : 0, h->K, h->opt_prefilter_stride, S->plan.as<uint32_t>(), S->key.as<uint8_t>(), S->idx.as<uint32_t>(),
-		S->info.as<BhipStageInfo>());
+		S->info.as<BhipStageInfo>(), h->alt);
 	HIPCHK(hipGetLastError());
 	{
 		size_t tb = 0;
@@ -257,14 +263,14 @@ static int host_route(Handle *h, StageSlot *S) {
 			int ex = q_flags ? (q_flags[i] == BHIP_Q_EXHAUSTIVE) : !h->has_acx;
 			if (!h->has_acx) ex = 1;
 			if (!ex) {
-				plan[i] = make_seed_plan(codes_i, (uint32_t)len, E_i, (uint32_t)h->K, h->opt_prefilter_stride);
-				if ((plan[i] >> 8) == 0) ex = 1;           // no word is guaranteed to survive: exhaustive (burst.c:3130-3131 does the same for "bad" queries)
+				plan[i] = make_seed_plan(codes_i, (uint32_t)len, E_i, (uint32_t)h->K, h->opt_prefilter_stride, h->alt);
+				if (BHIP_PLAN_NEED(plan[i]) == 0) ex = 1;           // no word is guaranteed to survive: exhaustive (burst.c:3130-3131 does the same for "bad" queries)
 			}
 			const size_t lc = (size_t)l * kNumClasses + cls;
 			P.lists[lc * 2 + ex].push_back(i);
 			P.maxE[lc] = std::max<uint32_t>(P.maxE[lc], E_i);
 			if (!ex && len >= (uint64_t)h->K) {
-				const uint32_t nwd = (uint32_t)((len - h->K) / (plan[i] & 255u) + 1);
+				const uint32_t nwd = (uint32_t)((len - h->K) / (plan[i] & 255u) + 1) + BHIP_PLAN_USED(plan[i]);      // (+ the slots of expanded words)
 				P.maxwords[lc] = std::max<uint32_t>(P.maxwords[lc], nwd);
 				P.seed_words[lc] += nwd;
 			}

@@ -199,10 +199,13 @@ def test_ambiguous_queries_through_the_prefilter(thres, iupac):
     K = 12
     seqs = family_db(91, 14, 9, 480, iupac=0.003)
     packed, clump_len, tot = dbutil.pack_clumps(seqs)
-    lens, entries, offs = dbutil.build_acx(seqs, K)
+    # (clumps holding an ambiguous reference symbol on the BadList: the test builder does not expand ambiguous reference words the way
+    # make_accelerator does -- burst.c:3368-3377 --, so their lanes must not depend on votes)
+    bad = sorted({i // 16 for i, s in enumerate(seqs) if (np.asarray(s) > 4).any()})
+    lens, entries, offs = dbutil.build_acx(seqs, K, skip_clumps=tuple(bad))
     lists = dbutil.pack_acx_lists(lens, entries, 0)
     lut = ol.score_lut(1)
-    dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=lists, acx_fmt=0, K=K)
+    dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=lists, acx_fmt=0, K=K, badlist=np.array(bad, np.uint32))
     q, allq = make_queries(seqs, 80, 100, [0, 1, 2, 3], 93, iupac=iupac, thres=thres)
     assert sum(int((np.asarray(r) > 4).any()) for r in allq) > 20
     q.flags = np.zeros(q.n, np.uint8)
@@ -211,6 +214,36 @@ def test_ambiguous_queries_through_the_prefilter(thres, iupac):
         exp = oracle_hits(packed, clump_len, tot, q, lut, all_hits)
         assert len(exp) > 20
         assert_hits_equal(got, exp)
+    dev.close()
+
+
+@pytest.mark.parametrize("K,qlen,thres,iupac,z", [(12, 100, 0.97, 0.03, 1), (12, 150, 0.95, 0.05, 1), (10, 250, 0.95, 0.03, 0), (15, 320, 0.95, 0.015, 1), (12, 100, 0.97, 0.08, 0)])
+def test_ambiguous_words_vote_through_expansions(K, qlen, thres, iupac, z):
+    """with non-overlapping sampled words (stride K) a word that holds ONE ambiguous symbol votes through its expansions (the first
+    alternative in the word's slot, the others in spare word slots: bhip_internal.h, k_seed_ranges; the reference expands query words
+    too, burst.c:3232-3236), so reads with several IUPAC codes keep a guaranteed count and stay on the accelerated route.  Identical
+    records to the oracle -- with the stride left to the library and forced to K, both prefilter kernels, the clump-level path (whose
+    kernels count strictly and take need - x), minima and every hit; z = 0: N matches everything and expands four ways"""
+    from burst_amd import capi
+    seqs = family_db(300 + K + qlen, 12, 9, qlen + 260, iupac=0.002)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lut = ol.score_lut(z)
+    # the accelerator built on the device: ambiguous REFERENCE words are expanded into the lists as make_accelerator does (a list
+    # without them breaks the vote guarantee for lanes with IUPAC symbols, whoever counts)
+    dev = capi.Device(packed, clump_len, tot, lut, K=K, build_acx=True)
+    q, allq = make_queries(seqs, 120, qlen, [0, 1, 2, 3], 400 + K, iupac=iupac, thres=thres)
+    namb = np.array([int((np.asarray(r) > 4).sum()) for r in allq])
+    assert (namb >= 2).sum() > 40 and (namb >= 4).sum() > 5
+    q.flags = np.zeros(q.n, np.uint8)
+    exp = {ah: oracle_hits(packed, clump_len, tot, q, lut, ah) for ah in (False, True)}
+    assert len(exp[False]) > 40
+    for opts in ({}, {"prefilter_stride": K}, {"prefilter_stride": K, "prefilter_algo": 1}, {"prefilter_stride": K, "lane_masks": 0}, {"prefilter_stride": K, "prefilter_table": 9, "prune": 0}):
+        for k, v in opts.items():
+            dev.set_option(k, v)
+        for all_hits in (False, True):
+            assert_hits_equal(dev.align_batch(q, all_hits=all_hits), exp[all_hits])
+        for k in opts:
+            dev.set_option(k, {"prefilter_stride": 0, "prefilter_algo": -1, "lane_masks": 1, "prefilter_table": 0, "prune": 1}[k])
     dev.close()
 
 
