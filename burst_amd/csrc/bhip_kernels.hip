@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void k_seed_ranges(
 	if (len >= (uint32_t)K) { const uint32_t pl = plan[q]; stride = pl & 255u; need = BHIP_PLAN_NEED(pl); n_pos = (len - K) / stride + 1; n_exp = BHIP_PLAN_X(pl) ? BHIP_PLAN_USED(pl) : 0u; nwords = n_pos + n_exp; }
 	if (nwords > W16) nwords = W16;
 	uint2 r = make_uint2(0, 0);
-	if (n_exp && j < nwords) {
+	if (n_exp) {
 		// A query with expanded words (rare: plan bits 24..31; stride == K, the words do not overlap).  Slot j < n_pos is the word at j K:
 		// a word of A/C/G/T as usual, an expandable one -- if the budget walk reaches it -- with the FIRST compatible base in place of its
 		// ambiguous symbol; slot n_pos + e is the e-th further alternative, found by the same walk.  Symbol by symbol: this path is
@@ -611,14 +611,31 @@ __global__ __launch_bounds__(256) void k_seed_ranges(
 		const uint32_t Ku = (uint32_t)K;
 		uint32_t wj = 0xFFFFFFFFu, alt_ix = 0, amb_k = 0;      // the word this slot looks up: its number, which alternative, where its ambiguous symbol is
 		uint32_t used = 0;
-		const uint32_t upto = j < n_pos ? j + 1 : n_pos;
-		for (uint32_t t = 0; t < upto && wj == 0xFFFFFFFFu; ++t) {
-			uint32_t ak, ex;
-			const uint32_t c = bhip_word_class(sym, t * Ku, Ku, alt, ak, ex);
-			const bool fits = c == 2u && used + ex <= BHIP_EXPAND_SLOTS;
-			if (j < n_pos) { if (t == j && (c == 1u || fits)) { wj = t; alt_ix = 0; amb_k = c == 2u ? ak : 0xFFFFFFFFu; } }
-			else if (fits && j - n_pos >= used && j - n_pos < used + ex) { wj = t; alt_ix = 1u + (j - n_pos - used); amb_k = ak; }
-			if (fits) used += ex;
+		if ((W16 & (W16 - 1u)) == 0u && W16 <= 64u) {
+			// the slots of a query are W16 consecutive lanes of one wave: every lane classifies ITS word once, the classes go round by
+			// lane reads, and each lane walks the budget over them (n_pos reads instead of n_pos x K symbol extractions per lane)
+			uint32_t ak0 = 0, ex0 = 0;
+			const uint32_t c0 = j < n_pos ? bhip_word_class(sym, j * Ku, Ku, alt, ak0, ex0) : 0u;
+			const uint32_t mine = c0 | ex0 << 2 | ak0 << 4;
+			for (uint32_t t = 0; t < n_pos; ++t) {
+				const uint32_t v = (uint32_t)__shfl((int)mine, (int)t, (int)W16);
+				const uint32_t c = v & 3u, ex = (v >> 2) & 3u, ak = v >> 4;
+				const bool fits = c == 2u && used + ex <= BHIP_EXPAND_SLOTS;
+				if (j < n_pos) { if (t == j && (c == 1u || fits)) { wj = t; alt_ix = 0; amb_k = c == 2u ? ak : 0xFFFFFFFFu; } }
+				else if (wj == 0xFFFFFFFFu && fits && j - n_pos >= used && j - n_pos < used + ex) { wj = t; alt_ix = 1u + (j - n_pos - used); amb_k = ak; }
+				if (fits) used += ex;
+			}
+			if (j >= nwords) wj = 0xFFFFFFFFu;
+		} else if (j < nwords) {
+			const uint32_t upto = j < n_pos ? j + 1 : n_pos;
+			for (uint32_t t = 0; t < upto && wj == 0xFFFFFFFFu; ++t) {
+				uint32_t ak, ex;
+				const uint32_t c = bhip_word_class(sym, t * Ku, Ku, alt, ak, ex);
+				const bool fits = c == 2u && used + ex <= BHIP_EXPAND_SLOTS;
+				if (j < n_pos) { if (t == j && (c == 1u || fits)) { wj = t; alt_ix = 0; amb_k = c == 2u ? ak : 0xFFFFFFFFu; } }
+				else if (fits && j - n_pos >= used && j - n_pos < used + ex) { wj = t; alt_ix = 1u + (j - n_pos - used); amb_k = ak; }
+				if (fits) used += ex;
+			}
 		}
 		if (wj != 0xFFFFFFFFu) {
 			uint32_t w = 0;
