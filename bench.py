@@ -236,38 +236,71 @@ def build_inputs(workdir, args, rank):
     return refs, edx, acx, reads_fa, done
 
 
+def run_reference_timed(cmd):
+    """run the compiled reference with its stdout on a pseudo-terminal (so that it is line-buffered) and stamp its own progress lines:
+    returns (return code, whole wall time, seconds between its "Using ACCELERATOR to align ..." (burst.c:4048; without -a: "Searching best
+    paths ...", 4325) line and its "Search complete" line (4525) -- the alignment loops of do_alignments -- or None when the lines were
+    not seen, the output's tail)"""
+    import pty
+    import select
+    master, slave = pty.openpty()
+    t0 = time.time()
+    p = subprocess.Popen(cmd, stdout=slave, stderr=slave, close_fds=True)
+    os.close(slave)
+    buf, t_search, t_done, tail = b"", None, None, []
+    while True:
+        try:
+            r, _, _ = select.select([master], [], [], 0.5)
+            if r:
+                chunk = os.read(master, 65536)
+                if not chunk:
+                    break
+                now = time.time()
+                buf += chunk
+                while b"\n" in buf:
+                    line, buf = buf.split(b"\n", 1)
+                    tail.append(line.decode("utf-8", "replace").strip())
+                    if t_search is None and (b"Using ACCELERATOR" in line or b"Searching best paths" in line):
+                        t_search = now
+                    elif t_search is not None and t_done is None and b"Search complete" in line:
+                        t_done = now
+            elif p.poll() is not None:
+                break
+        except OSError:      # (the child closed its side)
+            break
+    rc = p.wait()
+    os.close(master)
+    return rc, time.time() - t0, (t_done - t_search) if (t_search is not None and t_done is not None) else None, "\n".join(tail[-12:])
+
+
 def cpu_baseline(edx, acx, reads_fa, args):
-    """the compiled reference on the host cores: differential timing of two sample sizes cancels its DB load time"""
+    """the compiled reference on the host cores, ONE run on the sample: its align phase is the time between its own "Searching best
+    paths ..." and "Search complete" lines (the OpenMP loops this repository replaces: scour + aded_mat16 + reScoreM + hit capture),
+    stamped as they arrive on a pseudo-terminal.  (Rounds 1-3 took the difference of two runs' wall times, which at 40 s of database
+    load per run had a spread as large as the 2-4 s it was after.)"""
     exe = os.path.join(ROOT, "oracle", "_ref", "burst%d" % args.K)
     if args.no_cpu_baseline or not os.path.exists(exe):
         return None
     cores = effective_cores()
-    n1, n2 = args.cpu_sample // 6, args.cpu_sample
-    tmp = os.path.dirname(reads_fa)
-    times = []
-    for n in (n1, n2):
-        sample = os.path.join(tmp, "cpu_sample_%d.fa" % n)
-        with open(reads_fa, "rb") as f, open(sample, "wb") as o:
-            for _ in range(2 * n):
-                o.write(f.readline())
-        t = time.time()
-        r = subprocess.run([exe, "-r", edx, "-a", acx, "-q", sample, "-o", sample + ".b6", "-m", args.mode, "-i", str(args.id),
-                            "-t", str(cores), "--noprogress"] + (["-fr"] if args.fr else []), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        if r.returncode != 0:
-            log("[bench] reference failed:", r.stdout[-400:])
-            return None
-        times.append(time.time() - t)
-    dt = times[1] - times[0]
-    if dt < 0.02 * times[1] or dt < 0.5:      # the extra reads' align time drowns in the run-to-run spread of the database load: no figure
-        cpu_baseline.sample_fa, cpu_baseline.sample_b6 = sample, sample + ".b6"
-        cpu_baseline.too_small = "the reference's wall time for %d and %d reads (%.2f s, %.2f s: database load) does not resolve its align phase" % (n1, n2, times[0], times[1])
+    n = args.cpu_sample
+    sample = os.path.join(os.path.dirname(reads_fa), "cpu_sample_%d.fa" % n)
+    with open(reads_fa, "rb") as f, open(sample, "wb") as o:
+        for _ in range(2 * n):
+            o.write(f.readline())
+    rc, wall, align_s, tail = run_reference_timed([exe, "-r", edx, "-a", acx, "-q", sample, "-o", sample + ".b6", "-m", args.mode, "-i", str(args.id),
+                                                   "-t", str(cores)] + (["-fr"] if args.fr else []))
+    if rc != 0:
+        log("[bench] reference failed:", tail[-400:])
         return None
-    cpu_baseline.sample_fa, cpu_baseline.sample_b6 = sample, sample + ".b6"        # the larger sample: parity_vs_reference compares with it
-    return {"value": (n2 - n1) / dt, "unit": "reads/s", "cores": cores, "kind": "reference",
+    cpu_baseline.sample_fa, cpu_baseline.sample_b6 = sample, sample + ".b6"        # parity_vs_reference compares with it
+    if align_s is None or align_s < 0.2:
+        cpu_baseline.too_small = "the reference's align phase on %d reads was not resolvable (%s s of %.1f s wall)" % (n, "no progress lines" if align_s is None else "%.3f" % align_s, wall)
+        return None
+    return {"value": n / align_s, "unit": "reads/s", "cores": cores, "kind": "reference",
             "sample": "oracle/_ref/burst%d (reference compiled with gcc -O3 -march=x86-64-v3 -fopenmp) -t %d (%d hardware threads visible%s), same .edx/.acx, "
-                      "-m %s -i %s; differential wall time of the first %d vs %d reads of the pool (%.2f s vs %.2f s) = its align "
-                      "phase incl. parse/sort/output of the extra reads, database load cancelled"
-                      % (args.K, cores, os.cpu_count() or 1, "; the job's CPU quota is %d" % cores if cores < (os.cpu_count() or 1) else "", args.mode, args.id, n1, n2, times[0], times[1])}
+                      "-m %s -i %s, the first %d reads of the pool: %.2f s between its own 'Using ACCELERATOR to align' and 'Search complete' lines (its alignment loops, "
+                      "burst.c:4048-4525; whole run %.1f s, most of it the database load)"
+                      % (args.K, cores, os.cpu_count() or 1, "; the job's CPU quota is %d" % cores if cores < (os.cpu_count() or 1) else "", args.mode, args.id, n, align_s, wall)}
 
 
 def exhaustive_reference_sample(edx, reads_fa, args, n_clumps):
