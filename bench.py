@@ -27,7 +27,8 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel by time on
 `roofline.per_kernel` lists the others with their own bound; PMC-derived traffic / VALU figures come from profiles/
 (tools/profile_round.sh).  `cpu_baseline` is the compiled reference itself (oracle/_ref/burst15, one thread per core of the job's
 CPU quota) on a bounded sample of the same reads and database (its .acx is streamed to a file from the device-built tables):
-differential wall time of two sample sizes, which cancels its database load.  Where the reference's accelerated run cannot fit the
+one run, its alignment loops timed between its own progress lines ("Using ACCELERATOR to align" .. "Search complete", burst.c:4048-4525)
+read line by line (pseudo-terminal, or `stdbuf -oL` on a pipe; without either, the differential wall time of two sample sizes).  Where the reference's accelerated run cannot fit the
 job's memory (it holds the .edx and the .acx next to the .acx file) the parity check runs its exhaustive path on a small sample.  `parity_vs_reference`: the .b6 the reference wrote for that sample against
 the .b6 of the device path for the same reads (outside the timed region).
 """

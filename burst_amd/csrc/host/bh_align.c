@@ -5,6 +5,7 @@
  * the batch being aligned (bhip_align_staged).
  */
 #include "burst_host.h"
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -13,14 +14,25 @@
 
 static double now_sec(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
+/* one user of a device's free memory at a time among this process's set-up steps: the device build of an accelerator sizes its slices
+ * from the memory that is free when it starts (bhip_acx.hip), so the query sort of the ingest thread (bh_queries.c) on the same device
+ * waits for an upload in progress, and the upload for a sort in progress */
+static pthread_mutex_t g_dev_gate[64] = { [0 ... 63] = PTHREAD_MUTEX_INITIALIZER };
+void bh_device_gate(int device, int take) {
+	if (device < 0) return;
+	if (take) pthread_mutex_lock(&g_dev_gate[device & 63]); else pthread_mutex_unlock(&g_dev_gate[device & 63]);
+}
+
 int bh_device_open_ex(const BhDb *db, int device, int z, int build_K, void **hip_handle) {
 	uint8_t lut[256];
 	bh_score_lut(z, lut);
+	bh_device_gate(device, 1);
 	/* a database read with its .acx goes up with the file's tables; without one, build_K > 0 has the device build the accelerator
 	 * from the references (make_accelerator, burst.c:3304-3532, as device kernels) */
 	int rc = bhip_init(device, db->packed, db->clumpLen, db->numRclumps, db->totR,
 	                   db->hasAcx ? db->acxLens : NULL, db->hasAcx ? db->acxLists : NULL, db->acxFmt, db->hasAcx ? db->K : build_K,
 	                   db->badList, db->badSz, lut, db->xalpha, hip_handle);
+	bh_device_gate(device, 0);
 	if (rc) return bh_set_error(rc == BHIP_E_ARG ? BH_E_USAGE : BH_E_DEVICE, "libburst_hip: %s", bhip_last_error());
 	return BH_OK;
 }

@@ -191,7 +191,7 @@ int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhN
 	 * through the hand-over's time-out) */
 	if (reduce) for (int i = 0; i < n_local; ++i) {
 		best[i] = malloc(Q->numUniq + 1);
-		if (!best[i]) { for (int k = 0; k < i; ++k) free(best[k]); return bh_set_error(BH_E_OOM, "OOM:minima"); }
+		if (!best[i]) { for (int k = 0; k < i; ++k) free(best[k]); if (node) (void)bh_node_publish(node, &R[0].run, BH_E_OOM); return bh_set_error(BH_E_OOM, "OOM:minima"); }
 		memset(best[i], 255, Q->numUniq);
 	}
 	/* one host thread per local rank; the runtime must grant all of them -- a missing rank would leave the others waiting in the

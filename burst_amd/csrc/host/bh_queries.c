@@ -293,7 +293,10 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 		if (start && lens && perm && tmp) {
 			#pragma omp parallel for num_threads(bh_ingest_threads())
 			for (uint64_t i = 0; i < totQ; ++i) { start[i] = (uint64_t)((char *)refs[i].s - dump); lens[i] = refs[i].len; }
-			if (!bhip_sort_queries(g_sort_device, (const uint8_t *)dump, sz, start, lens, totQ, maxLen, perm, isNew)) {
+			bh_device_gate(g_sort_device, 1);          /* (not while a database goes up to this device: bh_device_open_ex) */
+			const int sort_rc = bhip_sort_queries(g_sort_device, (const uint8_t *)dump, sz, start, lens, totQ, maxLen, perm, isNew);
+			bh_device_gate(g_sort_device, 0);
+			if (!sort_rc) {
 				#pragma omp parallel for num_threads(bh_ingest_threads()) reduction(+:numUniq)
 				for (uint64_t i = 0; i < totQ; ++i) { tmp[i] = refs[perm[i]]; numUniq += isNew[i]; }
 				{ QRef *t = refs; refs = tmp; tmp = t; }          /* the permuted table is the table from here on */

@@ -108,6 +108,7 @@ typedef struct BhQueries {
 
 /* device that sorts and de-duplicates large query files (default 0; < 0 = always on the host) */
 void bh_queries_sort_device(int device);
+void bh_device_gate(int device, int take);      /* bh_align.c: serialises the set-up steps that size themselves from a device's free memory */
 int  bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespace, int do_accel, int K, int z,
                      int skip_ambig, BhQueries *q);
 /* prefilter / exhaustive route per entry and the clear / ambiguous / bad counts; bh_queries_load does it itself unless it was
@@ -177,7 +178,8 @@ void bh_minima_merge(uint8_t *const *best, int n, uint64_t len);
 int  bh_search_serial_shards(const BhDb *db, int device, int n_shards, int z, int build_K, const BhQueries *Q, BhMode mode, uint64_t batch, BhRun *all, double *secs, double *up);
 /* ---- ranks of one node in different processes: the records meet in shared memory (bh_node.c) ---- */
 typedef struct BhNode BhNode;
-/* job: a name all ranks of the job share (and no other job on the machine); cap_records: what the rank expects to deliver per
+/* job: a name all ranks of the job share and no other job on the machine, before or after, uses again (a peer that opens early would
+ * map the segment a dead job of the same name left behind: the launchers draw 48 random bits per job); cap_records: what the rank expects to deliver per
  * search (a search that brings up to four times as many still fits).  Every rank opens; rank 0 first or at the same time. */
 int  bh_node_open(const char *job, int rank, int n_ranks, uint64_t cap_records, BhNode **node);
 void bh_node_close(BhNode *node);
