@@ -905,7 +905,7 @@ def main():
                     os.environ.pop(k_, None)
         if world == 1 and args.ab:
             # A/B on the resident database: the same warm-up and steps under other tuning options, the default options' line again at the end
-            defaults = {"prefilter_bytes": 1, "prefilter_rb": 0, "seed_min_need": -1, "seed_drop_len": 8, "prefilter_table": 0, "prefilter_waves": 0, "prefilter_algo": -1, "prune": 1, "oversub": 2, "band": 1, "seed_ahead": 1, "seed_ahead_blocks": 2, "peq_ahead_blocks": 16, "sweep_blocks": 8}
+            defaults = {"prefilter_bytes": 1, "prefilter_rb": 0, "seed_min_need": -1, "seed_drop_len": 8, "prefilter_table": 0, "prefilter_waves": 0, "prefilter_algo": -1, "prune": 1, "oversub": 2, "band": 1, "seed_ahead": 1, "seed_ahead_blocks": 2, "peq_ahead_blocks": 16, "sweep_blocks": 8, "lanes": 1}
             res["ab"] = []
             for spec in list(args.ab) + [""]:
                 kv = dict(x.split("=") for x in spec.split(",") if x)

@@ -255,3 +255,29 @@ def test_database_built_in_parts_is_the_same_set_of_references(tmp_path):
     for seq, head, st in l3[::7]:
         src = fasta[head][st:st + len(seq)]
         assert bytes(code[b] for b in src) == seq, (head, st)
+
+
+@pytest.mark.parametrize("no_pty", [False, True])
+def test_reference_align_phase_is_stamped_with_and_without_a_pty(tmp_path, monkeypatch, no_pty):
+    """bench.py's cpu_baseline times the reference's alignment loops between two of its own progress lines; the GPU box has no pty
+    devices (`out of pty devices`), so the lines must also arrive one by one through `stdbuf -oL` on a pipe"""
+    import shutil
+    import sys
+    sys.path.insert(0, gl.ROOT)
+    import bench
+    exe = os.path.join(gl.ROOT, "oracle", "_ref", "burst12")
+    if not os.path.exists(exe):
+        pytest.skip("compiled reference not built")
+    if no_pty:
+        if not shutil.which("stdbuf"):
+            pytest.skip("no stdbuf")
+        import pty
+
+        def refuse():
+            raise OSError("out of pty devices")
+        monkeypatch.setattr(pty, "openpty", refuse)
+    out = str(tmp_path / "o.b6")
+    rc, wall, align, tail = bench.run_reference_timed([exe, "-r", os.path.join(gl.G, "dna.edx"), "-q", os.path.join(gl.G, "q100.fa"), "-o", out, "-m", "BEST", "-i", "0.97", "-t", "2"])
+    assert rc == 0, tail
+    assert align is not None and 0 < align <= wall
+    assert sorted(open(out)) == sorted(open(os.path.join(gl.G, "dna_q100_best.b6")))
