@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.environ.get("BURST_AMD_LIBDIR") or _HERE, "libburst_h
 
 BHIP_OK, BHIP_E_ARG, BHIP_E_DEVICE, BHIP_E_CAPACITY, BHIP_E_QUERYLEN, BHIP_E_INTERNAL, BHIP_E_RESCORE = 0, -1, -2, -3, -4, -5, -6
 BHIP_Q_PREFILTER, BHIP_Q_EXHAUSTIVE = 0, 1
-BHIP_MAX_QLEN = 1024
+BHIP_MAX_QLEN = 4095
 
 # BhipHit, 20 bytes (include/burst_hip.h)
 HIT_DTYPE = np.dtype([("q", "<u4"), ("refIx", "<u4"), ("finalPos", "<u4"), ("score", "<f4"),

@@ -53,13 +53,19 @@ __global__ void k_hit_fix(BhipHit *__restrict__ out, const uint32_t *__restrict_
 __global__ void k_set_rank_ptrs(SharedCtr *sc, uint32_t *cnt, uint32_t *rank) { sc->cnt = cnt; sc->rank = rank; }
 
 // ---- kernel launch helpers (st = stream to launch on) ---------------------------------------------------------------
-static void launch_myers(Handle *h, Lane *L, hipStream_t st, int cls, uint32_t grid, const uint2 *pairs, const uint32_t *n_pairs_dev,
+static void launch_myers(Handle *h, Lane *L, hipStream_t st, int NW, uint32_t grid, const uint2 *pairs, const uint32_t *n_pairs_dev,
 		uint64_t n_pairs_host, uint32_t li_base, const uint32_t *qlist, BhipRawHit *raw, uint32_t *n_raw, uint32_t raw_cap, uint32_t *best,
 		uint8_t *mins, Counters *dc) {
+	if (NW > 32) {      // queries beyond 1 024 symbols: the vector lives in LDS (2 x NW words per thread, one wave per block)
+		hipLaunchKernelGGL(k_myers_long, dim3(grid * 4u), dim3(64), (size_t)NW * 512u, st, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist,
+			L->peq.as<uint32_t>(), h->s_off(), h->s_emac(), (best && h->cur->st_has_six) ? h->cur->qsix.as<uint32_t>() : nullptr,
+			h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->tot_refs, raw, n_raw, raw_cap, best, mins, &dc->col_sum, &dc->qlen_sum, (uint32_t)NW);
+		return;
+	}
 	#define LM(N) hipLaunchKernelGGL(k_myers<N>, dim3(grid), dim3(256), 0, st, pairs, n_pairs_dev, n_pairs_host, h->n_clumps, li_base, qlist, \
 		L->peq.as<uint32_t>(), h->s_off(), h->s_emac(), (best && h->cur->st_has_six) ? h->cur->qsix.as<uint32_t>() : nullptr, \
 		h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), h->tot_refs, raw, n_raw, raw_cap, best, mins, &dc->col_sum, &dc->qlen_sum)
-	switch (kClasses[cls]) { case 2: LM(2); break; case 4: LM(4); break; case 6: LM(6); break; case 8: LM(8); break; case 10: LM(10); break;
+	switch (NW) { case 2: LM(2); break; case 4: LM(4); break; case 6: LM(6); break; case 8: LM(8); break; case 10: LM(10); break;
 		case 16: LM(16); break; default: LM(32); break; }
 	#undef LM
 }
@@ -202,7 +208,7 @@ static int launch_prefilter(Handle *h, Lane *L, hipStream_t pf_st, const uint32_
 static uint32_t seed_row_words(uint32_t maxwords) { return maxwords <= 8 ? 8u : std::max<uint32_t>(16u, (maxwords + 15u) & ~15u); }
 // prefix words of the two-stage sweep for a class (0 = one-stage sweep): about 6 prefix symbols per allowed edit, shorter than the query vector
 static int class_prefix_words(const Handle *h, uint32_t maxE, int NW) {
-	if (!h->opt_two_stage) return 0;
+	if (!h->opt_two_stage || NW > 32) return 0;      // (beyond 1 024 symbols: single stage, k_myers_long)
 	const uint32_t want = (6 * maxE + 31) / 32;
 	int NWP = want <= 1 ? 1 : (want <= 2 ? 2 : (want <= 3 ? 3 : (want <= 4 ? 4 : (want <= 6 ? 6 : 0))));
 	if (NWP >= NW) NWP = 0;
@@ -398,7 +404,8 @@ extern "C" int bhip_reserve_symbols(void *handle, uint32_t n_entries, uint32_t m
 	int rc;
 	const size_t n = n_entries, nb = total_symbols ? (size_t)std::min<uint64_t>(total_symbols + 64, (uint64_t)n * max_len) : n * max_len, qw = (max_len + 7) / 8;
 	// profile words: an entry of len symbols has a vector of at most 2 x (len / 32 + 1) words (class rounding), 16 rows of them
-	const size_t peq_words = total_symbols ? std::min<size_t>(n * (size_t)kClasses[class_of_len(max_len)], 2 * (nb / 32 + n)) : n * (size_t)kClasses[class_of_len(max_len)];
+	const size_t cw = (size_t)class_words(class_of_len(max_len), max_len);
+	const size_t peq_words = total_symbols ? std::min<size_t>(n * cw, 2 * (nb / 32 + n)) : n * cw;
 	for (StageSlot &S : h->slots) {
 		if ((rc = slot_init(&S))) return rc;
 		if ((rc = S.qcodes4.reserve(nb / 2 + 128)) || (rc = S.qcodes.reserve(nb + 128)) || (rc = S.qoff.reserve((n + 1) * 8)) || (rc = S.qemac.reserve((n + 1) * 2)) ||
@@ -520,7 +527,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	for (int cls = 0; cls < kNumClasses; ++cls) {
 		const uint32_t n_pf = L->npf[cls], n_ex = L->nex[cls], n_list = n_pf + n_ex;
 		if (!n_list) continue;
-		const int NW = kClasses[cls];
+		const int NW = class_words(cls, L->maxlen);
 		const uint32_t *qlist = L->qlist[cls];
 		hipEvent_t *ce = L->ev_cls[cls];
 		// the lane's peq buffers are reused class after class: do not rebuild them before the previous class's window stage is done
@@ -559,7 +566,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 			// (beside the lane tasks the clump-level pairs are the rare overflow of the prefilter, usually none at all: a small grid --
 			// an empty launch of 2 048 workgroups waited ~0.24 ms for slots on a device busy with the next batch's seed lookups and staging)
 			if (NWP) launch_prefix(h, L, sw, NWP, masked ? std::min<uint32_t>(grid_my, (uint32_t)h->n_cu) : grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, &dc->n_wins_cls[cls], dc);
-			else launch_myers(h, L, sw, cls, grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, L->raw.as<BhipRawHit>(),
+			else launch_myers(h, L, sw, NW, grid_my, L->cand.as<uint2>(), &dc->n_cand_cls[cls], L->cand_cap, 0, qlist, L->raw.as<BhipRawHit>(),
 				&dc->n_raw, (uint32_t)L->raw_cap, h->best.as<uint32_t>(), nullptr, dc);
 			HIPCHK(hipGetLastError());
 			++L->launches;
@@ -569,7 +576,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 			const uint64_t np = (uint64_t)n_ex * h->n_clumps;
 			const uint32_t g = (uint32_t)std::min<uint64_t>((np + 15) / 16, grid_my);
 			if (NWP) launch_prefix(h, L, sw, NWP, g, nullptr, nullptr, np, n_pf, qlist, &dc->n_wins_cls[cls], dc);
-			else launch_myers(h, L, sw, cls, g, nullptr, nullptr, np, n_pf, qlist, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap,
+			else launch_myers(h, L, sw, NW, g, nullptr, nullptr, np, n_pf, qlist, L->raw.as<BhipRawHit>(), &dc->n_raw, (uint32_t)L->raw_cap,
 				h->best.as<uint32_t>(), nullptr, dc);
 			HIPCHK(hipGetLastError());
 			++L->launches;
@@ -667,7 +674,7 @@ static void seed_next_batch(Handle *h, StageSlot *cur, hipEvent_t cur_done) {
 		Lane *L = h->lanes[l];
 		for (int cls = 0; cls < kNumClasses; ++cls) {
 			const uint32_t n_pf = N->npf[l][cls];
-			if (!n_pf || !class_prefix_words(h, N->maxE[l][cls], kClasses[cls])) continue;      // (lane-resolved prefilter only)
+			if (!n_pf || !class_prefix_words(h, N->maxE[l][cls], class_words(cls, N->maxlen_lane[l]))) continue;      // (lane-resolved prefilter only)
 			if (L->seeded_ok[cls] && L->seeded_seq[cls] == N->seq) continue;
 			if (launch_seed(h, L, h->pf_stream, N, cls, N->idx_sorted.as<uint32_t>() + N->qlist_off[l][cls], n_pf, N->maxwords[l][cls], (double)N->seed_words[l][cls] / (double)n_pf, true)) { (void)hipGetLastError(); return; }
 		}
@@ -677,7 +684,7 @@ static void seed_next_batch(Handle *h, StageSlot *cur, hipEvent_t cur_done) {
 		for (int cls = 0; cls < kNumClasses; ++cls) if (N->npf[l][cls] + N->nex[l][cls]) { only = cls; ++n_cls; }
 		if (n_cls == 1 && !(L->alt_ok && L->alt_seq == N->seq)) {
 			const uint32_t n_list = N->npf[l][only] + N->nex[l][only];
-			const int NW = kClasses[only], NWP = class_prefix_words(h, N->maxE[l][only], NW);
+			const int NW = class_words(only, N->maxlen_lane[l]), NWP = class_prefix_words(h, N->maxE[l][only], NW);
 			L->alt_ok = false;
 			if (hipEventRecord(L->ev_peq_alt[0], h->pf_stream) != hipSuccess ||
 			    launch_peq(h, h->pf_stream, N, N->idx_sorted.as<uint32_t>() + N->qlist_off[l][only], n_list, NW, NWP, L->peq_alt, L->peqp_alt, (uint32_t)h->opt_peq_ahead_blocks) ||
@@ -967,7 +974,7 @@ extern "C" int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint
 	uint32_t maxlen = 0;
 	for (uint32_t i = 0; i < n_q; ++i) maxlen = std::max<uint32_t>(maxlen, (uint32_t)(q_off[i + 1] - q_off[i]));
 	if (maxlen > BHIP_MAX_QLEN) return fail(BHIP_E_QUERYLEN, "query longer than %d", BHIP_MAX_QLEN);
-	const int cls = class_of_len(std::max<uint32_t>(maxlen, 1)), NW = kClasses[cls];
+	const int cls = class_of_len(std::max<uint32_t>(maxlen, 1)), NW = class_words(cls, maxlen);
 	std::vector<uint2> pr(n_pairs);
 	for (uint64_t p = 0; p < n_pairs; ++p) {
 		if (pair_q[p] >= n_q || pair_clump[p] >= h->n_clumps) return fail(BHIP_E_ARG, "pair %llu out of range", (unsigned long long)p);
@@ -987,7 +994,7 @@ extern "C" int bhip_align_pairs(void *handle, const uint8_t *q_codes, const uint
 		h->cur->qcodes.as<uint8_t>(), h->cur->qoff.as<uint64_t>(), (const uint32_t *)nullptr, n_q, NW, 0, h->mm, L->peq.as<uint32_t>(), (const uint32_t *)nullptr, 0u, h->peq_rows);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(h->ev[0], st));
-	launch_myers(h, L, st, cls, (uint32_t)std::min<uint64_t>((n_pairs + 15) / 16, (uint64_t)h->n_cu * 8), h->pairs.as<uint2>(), nullptr, n_pairs, 0, nullptr,
+	launch_myers(h, L, st, NW, (uint32_t)std::min<uint64_t>((n_pairs + 15) / 16, (uint64_t)h->n_cu * 8), h->pairs.as<uint2>(), nullptr, n_pairs, 0, nullptr,
 		nullptr, nullptr, 0, nullptr, h->mins.as<uint8_t>(), dc);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(h->ev[1], st));

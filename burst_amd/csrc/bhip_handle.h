@@ -37,6 +37,9 @@ template <typename CNT> __global__ void k_prefilter_wave(const uint8_t *, const 
 template <int NW> __global__ void k_myers(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
 	const uint64_t *, const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t,
 	BhipRawHit *, uint32_t *, uint32_t, uint32_t *, uint8_t *, unsigned long long *, unsigned long long *);
+__global__ void k_myers_long(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
+	const uint64_t *, const uint16_t *, const uint32_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t,
+	BhipRawHit *, uint32_t *, uint32_t, uint32_t *, uint8_t *, unsigned long long *, unsigned long long *, uint32_t);
 template <int NWP> __global__ void k_myers_prefix(const uint2 *, const uint32_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
 	const uint64_t *, const uint16_t *, const uint4 *, const uint64_t *, const uint32_t *, uint32_t, BhipWin *, uint32_t *, uint32_t,
 	unsigned long long *, unsigned long long *, uint32_t *, const uint32_t *);
@@ -104,8 +107,11 @@ static const int kClasses[] = {2, 4, 6, 8, 10, 16, 32};
 static const int kNumClasses = 7;
 static inline int class_of_len(uint32_t len) {
 	for (int i = 0; i < kNumClasses; ++i) if (len <= 32u * kClasses[i]) return i;
-	return -1;
+	return kNumClasses - 1;      // 1 025 .. BHIP_MAX_QLEN symbols: the last class, with as many words as its longest query needs (class_words)
 }
+// words of the bit-vector of a class: the class's own, or -- last class of a lane whose longest query is beyond 1 024 symbols -- what that
+// query needs (k_myers_long: any number of words, single-stage sweep)
+static inline int class_words(int cls, uint32_t maxlen) { return (cls == kNumClasses - 1 && maxlen > 1024u) ? (int)((maxlen + 31u) / 32u) : kClasses[cls]; }
 
 // device-side counters, one block copied back per call
 struct Counters {

@@ -1609,6 +1609,84 @@ __global__ __launch_bounds__(256) void k_myers(
 	if (col_sum && my_cols) { atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
 }
 
+// Queries beyond 1 024 symbols (up to BHIP_MAX_QLEN): the same recurrence with the vertical deltas of a (query, reference lane) pair in
+// LDS -- NW words each of Pv and Mv per thread, [word][thread] so that a wave's access to one word is one conflict-free row -- and the
+// match rows read from the profile table in global memory (a pair's 16 lanes read the same few rows: L1 hits).  One wave = four pairs.
+// Single stage, every column of the clump: long queries are rare, the kernel is there so that they are aligned at all.
+__global__ __launch_bounds__(64) void k_myers_long(
+		const uint2 *__restrict__ pairs, const uint32_t *__restrict__ n_pairs_dev, uint64_t n_pairs_host, uint32_t n_clumps_implicit, uint32_t li_base,
+		const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ peq, const uint64_t *__restrict__ qoff, const uint16_t *__restrict__ qemac,
+		const uint32_t *__restrict__ qsix, const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
+		uint32_t tot_refs, BhipRawHit *__restrict__ raw, uint32_t *__restrict__ n_raw, uint32_t raw_cap, uint32_t *__restrict__ best,
+		uint8_t *__restrict__ mins_out, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum, uint32_t NW) {
+	extern __shared__ uint32_t s_long[];                      // Pv[NW][64] | Mv[NW][64]
+	const uint32_t tid = threadIdx.x, g = tid >> 4, z = tid & 15;
+	uint32_t *sP = s_long + tid, *sM = s_long + (size_t)NW * 64 + tid;
+	const uint64_t n_pairs = n_pairs_dev ? ((uint64_t)*n_pairs_dev < n_pairs_host ? (uint64_t)*n_pairs_dev : n_pairs_host) : n_pairs_host;
+	const uint64_t n_tiles = (n_pairs + 3) >> 2;
+	unsigned long long my_cols = 0, my_qlen = 0;
+	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint64_t p = tile * 4 + g;
+		if (p >= n_pairs) continue;                          // (no barriers in this kernel: a thread only ever touches its own LDS column)
+		uint32_t li, c;
+		if (pairs) { const uint2 pr = pairs[p]; li = pr.x; c = pr.y; }
+		else { li = li_base + (uint32_t)(p / n_clumps_implicit); c = (uint32_t)(p % n_clumps_implicit); }
+		const uint32_t q = qlist ? qlist[li] : li;
+		const uint32_t m = (uint32_t)(qoff[q + 1] - qoff[q]), E = qemac[q];
+		const uint32_t L = clump_len[c], nchunks = (L + 31) >> 5;
+		for (uint32_t w = 0; w < NW; ++w) {                  // column 0: D[y][0] = y on the query rows, 0 on the filler rows below them
+			const int lo = 32 * (int)NW - (int)m - 32 * (int)w;
+			sP[w * 64] = lo <= 0 ? 0xFFFFFFFFu : (lo >= 32 ? 0u : (0xFFFFFFFFu << lo));
+			sM[w * 64] = 0;
+		}
+		int score = (int)m, bestS = 0x7FFFFFFF;
+		uint32_t first = 0, last = 0;
+		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)z * nchunks;
+		const uint32_t *tab = peq + (uint64_t)li * 16 * NW;
+		for (uint32_t t = 0; t < nchunks; ++t) {
+			const uint4 ch = rp[t];
+			#pragma unroll 1
+			for (uint32_t i = 0; i < 32; ++i) {
+				const uint32_t d = i < 8 ? ch.x : i < 16 ? ch.y : i < 24 ? ch.z : ch.w;
+				const uint32_t *row = tab + ((d >> (4 * (i & 7))) & 15u) * NW;
+				uint32_t carry = 0, cP = 0, cM = 0;
+				for (uint32_t w = 0; w < NW; ++w) {          // one pass: the three carries all run from word 0 upwards
+					const uint32_t Eq = row[w], Pv = sP[w * 64], Mv = sM[w * 64];
+					uint32_t co;
+					const uint32_t s = __builtin_addc(Eq & Pv, Pv, carry, &co); carry = co;
+					const uint32_t Xh = (s ^ Pv) | Eq;
+					uint32_t Ph = Mv | ~(Xh | Pv), Mh = Pv & Xh;
+					Ph = __builtin_addc(Ph, Ph, cP, &co); cP = co;
+					Mh = __builtin_addc(Mh, Mh, cM, &co); cM = co;
+					const uint32_t Xv = Eq | Mv;
+					sP[w * 64] = Mh | ~(Xv | Ph);
+					sM[w * 64] = Ph & Xv;
+				}
+				score += (int)cP - (int)cM;
+				const uint32_t col = t * 32 + i + 1;
+				const bool lt = score < bestS, le = score <= bestS;
+				bestS = lt ? score : bestS;
+				first = lt ? col : first;
+				last = le ? col : last;
+			}
+		}
+		const uint32_t refIx = c * 16 + z;
+		const bool hit = (uint32_t)bestS <= E && refIx < tot_refs;
+		if (mins_out) mins_out[p * 16 + z] = (uint32_t)bestS <= E ? (uint8_t)bestS : (uint8_t)255;
+		if (hit && raw) {
+			const uint32_t pos = atomicAdd(n_raw, 1u);
+			if (pos < raw_cap) {
+				BhipRawHit h; h.q = q; h.refIx = refIx; h.ed = (uint32_t)bestS; h.e_first = first; h.e_last = last;
+				h.m = m; h.L = L; h.six = qsix ? qsix[q] : q; h.rbase = ref_off[c] * 16 + (uint64_t)z * nchunks;
+				raw[pos] = h;
+			}
+			if (best) atomicMin(&best[qsix ? qsix[q] : q], (uint32_t)bestS);
+		}
+		if (z == 0) { my_cols += L; my_qlen += m; }
+	}
+	if (col_sum && my_cols) { atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Two-stage edit distance.  An alignment of the whole query with <= E edits contains an alignment of its first
 // P symbols with <= E edits, ending at some column x.  Stage A (k_myers_prefix<NWP>) therefore sweeps every column of
@@ -2248,7 +2326,12 @@ __device__ uint32_t bhip_seed_plan(uint32_t len, uint32_t E, uint32_t K, int str
 		uint32_t W = 0;
 		if (clean) W = (len - K) / st + 1;
 		else if (st == K) { uint32_t ws; bhip_expand_walk(sym, K, (len - K) / K + 1, A, ws, xk, usedk); W = ws + xk; }
-		else for (uint32_t p = 0; p < npos; p += st) W += (vb[p >> 5] >> (p & 31u)) & 1u;
+		else if (len <= 1024u) for (uint32_t p = 0; p < npos; p += st) W += (vb[p >> 5] >> (p & 31u)) & 1u;
+		else for (uint32_t p = 0; p < npos; p += st) {      // (beyond the bitmap's 1 024 positions: the K symbols of every sampled word)
+			uint32_t ok = 1u;
+			for (uint32_t k = 0; k < K; ++k) ok &= (sym(p + k) - 1u) < 4u ? 1u : 0u;
+			W += ok;
+		}
 		return (int)W - (int)(E * ((K + st - 1) / st));
 	};
 	const uint32_t smin = (len - K) / 254 + 1, smax = K > smin ? K : smin;
@@ -2305,7 +2388,7 @@ __global__ __launch_bounds__(256) void k_route(
 			if (!ex) {
 				uint32_t vb[32];
 				const bool clean = n_other == 0;
-				if (!clean && len >= (uint32_t)K) {
+				if (!clean && len >= (uint32_t)K && len <= 1024u) {
 					for (uint32_t w = 0; w < 32; ++w) vb[w] = 0;
 					uint32_t run = 0;
 					for (uint32_t p = 0; p < len; ++p) {

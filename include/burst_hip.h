@@ -34,7 +34,7 @@ extern "C" {
                                  Truncation within known good path" and exits (burst.c:812-816) -- a query whose FIRST symbol has code 0
                                  (row 1 of reScoreM takes the substitution cost alone, burst.c:722-739, while the search may gap it) */
 
-#define BHIP_MAX_QLEN   1024   /* bit-vector kernels are instantiated up to 32 x 32-bit words */
+#define BHIP_MAX_QLEN   4095   /* up to 1 024 symbols: register bit-vector kernels (2 .. 32 words); beyond: k_myers_long (vector in LDS, single-stage sweep) */
 
 /* One alignment result = ResultPod (burst.c:3998-4004) minus the list pointer, plus the query index. */
 typedef struct BhipHit {

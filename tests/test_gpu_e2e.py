@@ -147,6 +147,62 @@ def test_cli_differential_on_awkward_inputs(tmp_path):
     assert "ALL OK" in r.stdout
 
 
+def test_command_line_with_reads_beyond_1024_symbols(tmp_path):
+    """burst_hip next to the compiled reference (-t 1: its deterministic configuration) on reads of 1 100 .. 4 000 symbols mixed with
+    100-symbol reads, against unsheared 5 000-symbol references searched directly and through a database with an accelerator"""
+    import numpy as np
+    ref_exe = os.path.join(gl.ROOT, "oracle", "_ref", "burst12")
+    cli = os.path.join(gl.ROOT, "burst_amd", "burst_hip")
+    if not os.path.exists(ref_exe):
+        pytest.skip("compiled reference not present")
+    rng = np.random.default_rng(77)
+    A = np.array(list("ACGT"))
+
+    def mutate(x, n):
+        x = list(x)
+        for _ in range(n):
+            k = int(rng.integers(3)); i = int(rng.integers(1, len(x) - 1))
+            if k == 0:
+                x[i] = "ACGT"[("ACGT".index(x[i]) + 1 + int(rng.integers(3))) % 4]
+            elif k == 1:
+                del x[i]
+            else:
+                x.insert(i, "ACGT"[int(rng.integers(4))])
+        return "".join(x)
+    refs = []
+    for f in range(4):
+        base = "".join(A[rng.integers(0, 4, size=5000)])
+        refs += [("fam%d_v%d" % (f, v), mutate(base, 40 * v)) for v in range(5)]
+    refs_fa = str(tmp_path / "refs.fa")
+    open(refs_fa, "w").write("".join(">%s\n%s\n" % r for r in refs))
+    reads = []
+    for i in range(36):
+        h, s = refs[int(rng.integers(len(refs)))]
+        n = 100 if i % 3 == 2 else int(rng.integers(1100, 4001))
+        st = int(rng.integers(0, len(s) - n))
+        reads.append(("r%d_%s" % (i, h), mutate(s[st:st + n], int(rng.integers(0, max(2, n // 60))))))
+    reads.append(("ambig_long", reads[0][1][:700] + "N" + reads[0][1][701:1500] + "R" + reads[0][1][1501:]))
+    q_fa = str(tmp_path / "q.fa")
+    open(q_fa, "w").write("".join(">%s\n%s\n" % r for r in reads))
+    edx, acx = str(tmp_path / "db.edx"), str(tmp_path / "db.acx")
+    subprocess.check_call([ref_exe, "-r", refs_fa, "-d", "QUICK", "4200", "-o", edx, "-a", acx, "-t", "1", "--noprogress"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    n_lines = 0
+    for mode, ident, extra in (("BEST", "0.97", ["-r", refs_fa]), ("ALLPATHS", "0.96", ["-r", refs_fa, "-fr"]), ("CAPITALIST", "0.97", ["-r", refs_fa, "-fr"]),
+                               ("FORAGE", "0.95", ["-r", refs_fa]), ("BEST", "0.97", ["-r", edx, "-a", acx]), ("ALLPATHS", "0.96", ["-r", edx, "-a", acx, "-fr"])):
+        outs = []
+        for exe, tail in ((ref_exe, ["-t", "1", "--noprogress"]), (cli, [])):
+            o = str(tmp_path / ("out_%s.b6" % ("ref" if exe == ref_exe else "hip")))
+            if os.path.exists(o):
+                os.remove(o)
+            r = subprocess.run([exe, "-q", q_fa, "-o", o, "-m", mode, "-i", ident] + extra + tail, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+            assert r.returncode == 0, (exe, mode, r.stdout[-1500:])
+            outs.append(sorted(open(o, "rb").read().splitlines()))
+        assert outs[0] == outs[1], (mode, extra[2:], len(outs[0]), len(outs[1]), sorted(set(outs[0]) ^ set(outs[1]))[:4])
+        assert len(outs[0]) >= 30
+        n_lines += len(outs[0])
+    assert n_lines > 300
+
+
 def test_python_launcher_single_process(tmp_path):
     """python -m burst_amd.run (the multi-GPU front end) with one process is equivalent to burst_hip"""
     import sys

@@ -97,6 +97,68 @@ def test_align_batch_exhaustive_matches_oracle(qlen, edits, thres, iupac, seed, 
     dev.close()
 
 
+@pytest.mark.parametrize("qlen,edits,thres,seed", [(1025, [0, 3, 20], 0.98, 61), (1500, [0, 10, 44], 0.97, 62), (2600, [0, 25], 0.99, 63), (4050, [0, 12, 40], 0.99, 64)])
+def test_queries_beyond_1024_symbols(qlen, edits, thres, seed):
+    """k_myers_long (vector in LDS, any number of words up to BHIP_MAX_QLEN symbols): the sweep on its own against aded of the oracle,
+    then whole batches -- exhaustive, and through an accelerator with a few ambiguous symbols in the reads and mixed with short reads
+    (one lane then holds classes of 4 and of ceil(len / 32) words) -- record for record against the oracle's search"""
+    from burst_amd import capi
+    assert capi.BHIP_MAX_QLEN == 4095
+    seqs = family_db(seed, 3, 6, qlen + 120, short=False)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lut = ol.score_lut(1)
+    dev = capi.Device(packed, clump_len, tot, lut)
+    q, allq = make_queries(seqs, 5, qlen, edits, seed, thres=thres)
+    nc = len(clump_len)
+    pq = np.repeat(np.arange(q.n, dtype=np.uint32), nc)
+    pc = np.tile(np.arange(nc, dtype=np.uint32), q.n)
+    mins = dev.align_pairs(q, pq, pc)
+    n_le = 0
+    for p in range(len(pq)):
+        rows = dbutil.clump_rows(seqs, int(pc[p]))
+        _, omins = ol.aded_clump(rows, allq[pq[p]], int(q.emac[pq[p]]), lut)
+        assert np.array_equal(mins[p], omins), (p, mins[p], omins)
+        n_le += int((omins != 255).sum())
+    assert n_le > 0
+    for all_hits in (False, True):
+        got = dev.align_batch(q, all_hits=all_hits)
+        exp = oracle_hits(packed, clump_len, tot, q, lut, all_hits)
+        assert len(exp) >= 5
+        assert_hits_equal(got, exp)
+    dev.close()
+    # with an accelerator: long reads (some with ambiguous symbols) beside short ones
+    K = 12
+    lens, entries, offs = dbutil.build_acx(seqs, K)
+    lists = dbutil.pack_acx_lists(lens, entries, 0)
+    dev = capi.Device(packed, clump_len, tot, lut, acx_lens=lens, acx_lists=lists, acx_fmt=0, K=K)
+    long_reads, _ = synth.make_reads(seqs, 4, qlen, edits, seed + 1, rc_frac=0.0, iupac_frac=0.002)
+    short_reads, _ = synth.make_reads(seqs, 6, 100, [0, 1, 2], seed + 2, rc_frac=0.0)
+    reads = [long_reads[0], short_reads[0], short_reads[1], long_reads[1], short_reads[2], long_reads[2], short_reads[3], short_reads[4], long_reads[3], short_reads[5]]
+    E = [budget(thres, len(r)) for r in reads]
+    qa = capi.Queries(reads, E, list(range(len(reads))), [0] * len(reads))
+    for all_hits in (False, True):
+        got = dev.align_batch(qa, all_hits=all_hits)
+        exp = oracle_hits(packed, clump_len, tot, qa, lut, all_hits)
+        assert len(exp) >= 8
+        assert_hits_equal(got, exp)
+    st = dev.stats()
+    assert st["n_pairs"] <= qa.n * nc
+    dev.close()
+    # exactly BHIP_MAX_QLEN symbols (128 words: all of the 64 KB of LDS a block may ask for); one symbol more is refused, loudly
+    if qlen == 4050:
+        dev = capi.Device(packed, clump_len, tot, lut)
+        src = max(seqs, key=len)
+        assert len(src) >= 4096
+        q1 = capi.Queries([src[:4095].copy()], [budget(thres, 4095)], [0], [0])
+        got = dev.align_batch(q1, all_hits=True)
+        exp = oracle_hits(packed, clump_len, tot, q1, lut, True)
+        assert len(exp) >= 1
+        assert_hits_equal(got, exp)
+        with pytest.raises(capi.BurstHipError):
+            dev.align_batch(capi.Queries([src[:4096].copy()], [10], [0], [0]))
+        dev.close()
+
+
 def test_mixed_lengths_and_empty():
     from burst_amd import capi
     seqs = family_db(31, 4, 16, 500)
