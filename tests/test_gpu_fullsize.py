@@ -106,7 +106,7 @@ def _scale_diff(n_reads, env):
 def _check_diff_lines(lines, n_reads, frac=0.005):
     """BEST: identical.  The other modes print, where the reference's own thread timing decides (DUPE_HUNT between overlapping
     shears, burst.c:4563-4570; equally voted references in CAPITALIST, 4763-4776), one of several placements: there the
-    contract is: same number of lines, same queries, at most 0.5 % of the lines differ (2 % for long reads on both strands in FORAGE,
+    contract is: same number of lines, same queries, at most 0.5 % of the lines differ (4 % for long reads on both strands in FORAGE,
     where a third of the reads lie across a shear boundary: the bound of tests/goldenlib.py) and every differing reference line is
     EXPLAINED -- one of the placements burst_hip computes for that query (--no-dupe-hunt prints them all; for CAPITALIST: one
     of the query's minimum placements)."""
@@ -258,4 +258,6 @@ def test_configs4_shape_full_size():
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "burst12")):
         lines, out = _scale_diff(800, dict(BURST_BENCH_DIR=work, SD_EDX=edx, SD_READS=reads, SD_MODES="FORAGE BEST", SD_IDS="0.95", SD_EXTRA="-fr"))
         assert len(lines) == 2, out[-3000:]
-        _check_diff_lines(lines, 800, frac=0.02)
+        # (which of two overlapping shears the reference prints depends on the order its 256 threads found them in: 12 .. 26 of ~1 280 lines
+        # from run to run on the same inputs -- the count is bounded loosely, what is strict is that every one of them is explained)
+        _check_diff_lines(lines, 800, frac=0.04)
