@@ -132,6 +132,10 @@ def pick_setup(args, free_hbm, want_cpu_baseline, world=1):
         except OSError:
             return 0
     ram = memory_limit() * 0.92
+    try:      # what other jobs left in RAM-backed files counts against the same limit and cannot be reclaimed
+        ram -= shutil.disk_usage("/dev/shm").used
+    except OSError:
+        pass
     dirs = [args.workdir] if args.workdir else ["/dev/shm/burst_amd_bench", "/tmp/burst_amd_bench"]
     scales = AUTO_SCALES if args.db_scale == "auto" else (float(args.db_scale),)
     for sc in scales:
