@@ -281,3 +281,47 @@ def test_reference_align_phase_is_stamped_with_and_without_a_pty(tmp_path, monke
     assert rc == 0, tail
     assert align is not None and 0 < align <= wall
     assert sorted(open(out)) == sorted(open(os.path.join(gl.G, "dna_q100_best.b6")))
+
+
+def test_host_pipeline_with_reads_beyond_1024_symbols(exe, tmp_path):
+    """reads of 1 100 .. 3 900 symbols (and a few of 100) against unsheared 4 500-symbol references searched directly: the C host on both
+    sides of the oracle against the compiled reference run here (-t 1) -- ingest, budgets, consolidation and coordinates for queries the
+    rounds before refused; the device side of the same thing is tests/test_gpu_e2e.py::test_command_line_with_reads_beyond_1024_symbols"""
+    import numpy as np
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "burst12")
+    if not os.path.exists(ref_exe):
+        pytest.skip("compiled reference not built")
+    rng = np.random.default_rng(5)
+    A = np.array(list("ACGT"))
+
+    def mutate(x, n):
+        x = list(x)
+        for _ in range(n):
+            k = int(rng.integers(3)); i = int(rng.integers(1, len(x) - 1))
+            if k == 0:
+                x[i] = "ACGT"[("ACGT".index(x[i]) + 1 + int(rng.integers(3))) % 4]
+            elif k == 1:
+                del x[i]
+            else:
+                x.insert(i, "ACGT"[int(rng.integers(4))])
+        return "".join(x)
+    refs = []
+    for f in range(2):
+        base = "".join(A[rng.integers(0, 4, size=4500)])
+        refs += [("fam%d_v%d" % (f, v), mutate(base, 30 * v)) for v in range(4)]
+    refs_fa, q_fa = str(tmp_path / "refs.fa"), str(tmp_path / "q.fa")
+    open(refs_fa, "w").write("".join(">%s\n%s\n" % r for r in refs))
+    reads = []
+    for i in range(12):
+        h, s = refs[int(rng.integers(len(refs)))]
+        n = 100 if i % 4 == 3 else int(rng.integers(1100, 3901))
+        st = int(rng.integers(0, len(s) - n))
+        reads.append(("r%d_%s" % (i, h), mutate(s[st:st + n], int(rng.integers(0, max(2, n // 60))))))
+    open(q_fa, "w").write("".join(">%s\n%s\n" % r for r in reads))
+    for mode, ident, fr in (("BEST", "0.97", 0), ("ALLPATHS", "0.96", 1), ("FORAGE", "0.95", 0)):
+        want, got = str(tmp_path / "ref.b6"), str(tmp_path / "hip.b6")
+        subprocess.check_call([ref_exe, "-r", refs_fa, "-q", q_fa, "-o", want, "-m", mode, "-i", ident, "-t", "1", "--noprogress"] + (["-fr"] if fr else []),
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.check_call([exe, refs_fa, q_fa, got, mode, ident, str(fr), "1", "-1", "1", "", "0", "0", "10"])
+        a, b = sorted(open(want, "rb").read().splitlines()), sorted(open(got, "rb").read().splitlines())
+        assert len(a) >= 12 and a == b, (mode, len(a), len(b), sorted(set(a) ^ set(b))[:4])
