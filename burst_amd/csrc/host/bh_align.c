@@ -22,6 +22,9 @@ void bh_device_gate(int device, int take) {
 	if (device < 0) return;
 	if (take) pthread_mutex_lock(&g_dev_gate[device & 63]); else pthread_mutex_unlock(&g_dev_gate[device & 63]);
 }
+int bh_device_gate_try(int device) {      /* 1 = taken (release with bh_device_gate(device, 0)), 0 = somebody else is setting up on this device */
+	return device < 0 ? 1 : pthread_mutex_trylock(&g_dev_gate[device & 63]) == 0;
+}
 
 int bh_device_open_ex(const BhDb *db, int device, int z, int build_K, void **hip_handle) {
 	uint8_t lut[256];

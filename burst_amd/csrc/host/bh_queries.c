@@ -286,16 +286,16 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 	/* Large inputs: sort and duplicate marking on the device (bhip_sort_queries: LSD radix sort over 16-symbol keys; the same
 	 * order as qref_cmp).  It runs before the database is uploaded, on the device the search will use.  Small inputs, and
 	 * hosts told so (BURST_HOST_SORT=1 / bh_queries_sort_device(-1)), take the host path below. */
-	if (totQ >= (1u << 18) && totQ < 0x7FFFFFFFull && g_sort_device >= 0 && !getenv("BURST_HOST_SORT")) {
+	/* (a database going up to that device right now sizes its accelerator build from the free memory it found: the sort does not
+	 * squeeze in beside it, and it does not wait tens of seconds for it either -- the host sorts) */
+	if (totQ >= (1u << 18) && totQ < 0x7FFFFFFFull && g_sort_device >= 0 && !getenv("BURST_HOST_SORT") && bh_device_gate_try(g_sort_device)) {
 		uint64_t *start = malloc(totQ * sizeof(*start));
 		uint32_t *lens = malloc(totQ * sizeof(*lens)), *perm = malloc(totQ * sizeof(*perm));
 		QRef *tmp = malloc(totQ * sizeof(*tmp));
 		if (start && lens && perm && tmp) {
 			#pragma omp parallel for num_threads(bh_ingest_threads())
 			for (uint64_t i = 0; i < totQ; ++i) { start[i] = (uint64_t)((char *)refs[i].s - dump); lens[i] = refs[i].len; }
-			bh_device_gate(g_sort_device, 1);          /* (not while a database goes up to this device: bh_device_open_ex) */
 			const int sort_rc = bhip_sort_queries(g_sort_device, (const uint8_t *)dump, sz, start, lens, totQ, maxLen, perm, isNew);
-			bh_device_gate(g_sort_device, 0);
 			if (!sort_rc) {
 				#pragma omp parallel for num_threads(bh_ingest_threads()) reduction(+:numUniq)
 				for (uint64_t i = 0; i < totQ; ++i) { tmp[i] = refs[perm[i]]; numUniq += isNew[i]; }
@@ -303,6 +303,7 @@ int bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespa
 				on_device = 1;
 			} else fprintf(stderr, " --> NOTE: query sort on device %d not available (%s): sorting on the host\n", g_sort_device, bhip_last_error());
 		}
+		bh_device_gate(g_sort_device, 0);
 		free(start); free(lens); free(perm); free(tmp);
 		QPH("sort + duplicates (device)");
 	}

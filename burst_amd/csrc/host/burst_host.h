@@ -108,7 +108,8 @@ typedef struct BhQueries {
 
 /* device that sorts and de-duplicates large query files (default 0; < 0 = always on the host) */
 void bh_queries_sort_device(int device);
-void bh_device_gate(int device, int take);      /* bh_align.c: serialises the set-up steps that size themselves from a device's free memory */
+void bh_device_gate(int device, int take);
+int  bh_device_gate_try(int device);      /* bh_align.c: serialises the set-up steps that size themselves from a device's free memory */
 int  bh_queries_load(const char *fasta, float thres, int do_rc, int incl_whitespace, int do_accel, int K, int z,
                      int skip_ambig, BhQueries *q);
 /* prefilter / exhaustive route per entry and the clear / ambiguous / bad counts; bh_queries_load does it itself unless it was
