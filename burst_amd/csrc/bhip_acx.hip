@@ -373,21 +373,25 @@ __global__ void k_acx_budget(const uint4 *__restrict__ ref, const uint64_t *__re
 	}
 }
 
-// (word << 24 | clump, 1 << lane) for every window of the clumps [c0, c1): unambiguous windows into the slot of their last
-// position (slot_off: 16 x ClumpLen slots per clump), the expansions of ambiguous ones appended behind the slots of the slice
-// (`extra`, one atomic reservation per window); windows without a word, and every window of a BadList clump, leave key ~0.
+// One 64-bit tuple for every window of the clumps [c0, c1): lane bit << 48 | word << cb | (clump - c0), cb = bits of a clump number
+// inside the slice (2 K + cb <= 47).  The lane bit rides above the 48 bits the radix sort looks at -- keys only, six passes, no value
+// array -- and is OR-ed over equal (word, clump) by the fold behind the sort.  Unambiguous windows go into the slot of their last
+// position (slot_off: 16 x ClumpLen slots per clump), the expansions of ambiguous ones are appended behind the slots of the slice
+// (`extra`, one atomic reservation per window); windows without a word, and every window of a BadList clump, leave BHIP_ACX_NOKEY
+// (bit 47: sorts behind every word).
+#define BHIP_ACX_NOKEY (1ull << 47)
+#define BHIP_ACX_KEYBITS 48
 __global__ void k_acx_extract(const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
-                              const uint64_t *__restrict__ slot_off, const uint8_t *__restrict__ is_bad, uint32_t c0, uint32_t c1, uint32_t tot_refs, int K, int z,
-                              unsigned long long *__restrict__ keys, uint16_t *__restrict__ vals, unsigned long long extra_base, unsigned long long *__restrict__ extra_cursor) {
+                              const uint64_t *__restrict__ slot_off, const uint8_t *__restrict__ is_bad, uint32_t c0, uint32_t c1, uint32_t tot_refs, int K, int z, int cb,
+                              unsigned long long *__restrict__ keys, unsigned long long extra_base, unsigned long long *__restrict__ extra_cursor) {
 	const uint64_t n_threads = (uint64_t)(c1 - c0) * 16;
 	const uint32_t wmask = (1u << (2 * K)) - 1u;
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_threads; i += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t c = c0 + (uint32_t)(i >> 4), zz = (uint32_t)(i & 15), L = clump_len[c], nchunks = (L + 31) >> 5;
 		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)zz * nchunks;
 		unsigned long long *kout = keys + (slot_off[c] - slot_off[c0]) + (uint64_t)zz * L;
-		uint16_t *vout = vals + (slot_off[c] - slot_off[c0]) + (uint64_t)zz * L;
 		const bool live = !is_bad[c] && 16ull * c + zz < tot_refs;
-		const uint16_t bit = (uint16_t)(1u << zz);
+		const unsigned long long tag = (1ull << (48 + zz)) | (unsigned long long)(c - c0);      // lane bit and slice-local clump number
 		unsigned long long win = 0;
 		uint32_t w = 0, run = 0, lit = 0;
 		for (uint32_t t = 0; t < nchunks; ++t) {
@@ -401,8 +405,7 @@ __global__ void k_acx_extract(const uint4 *__restrict__ ref, const uint64_t *__r
 				lit = (sym - 1u) < 4u ? lit + 1 : 0;
 				w = ((w << 2) | ((sym - 1u) & 3u)) & wmask;
 				win = (win << 4) | sym;
-				kout[pos] = (live && lit >= (uint32_t)K) ? (((unsigned long long)w << 24) | c) : ~0ull;
-				vout[pos] = bit;
+				kout[pos] = (live && lit >= (uint32_t)K) ? (((unsigned long long)w << cb) | tag) : BHIP_ACX_NOKEY;
 				if (live && run >= (uint32_t)K && lit < (uint32_t)K) {
 					const unsigned long long prod = amb_product(win, K);
 					unsigned long long e = extra_base + atomicAdd(extra_cursor, prod);
@@ -413,47 +416,49 @@ __global__ void k_acx_extract(const uint4 *__restrict__ ref, const uint64_t *__r
 							r /= n;
 							word |= ((amb_bases(code) >> (2u * d)) & 3u) << (2 * s);
 						}
-						keys[e] = ((unsigned long long)word << 24) | c;
-						vals[e] = bit;
+						keys[e] = ((unsigned long long)word << cb) | tag;
 					}
 				}
 			}
 		}
 	}
 }
+// what the fold reads out of a sorted tuple: the 48 sorted bits as the key, the lane bits as the value
+struct AcxKeyOf { __host__ __device__ unsigned long long operator()(const unsigned long long &t) const { return t & ((1ull << BHIP_ACX_KEYBITS) - 1ull); } };
+struct AcxLanesOf { __host__ __device__ uint16_t operator()(const unsigned long long &t) const { return (uint16_t)(t >> 48); } };
 
-// list lengths: one count per distinct (word, clump); keys that are not words (~0: bits above end_bit set) are skipped
-__global__ void k_acx_hist(const unsigned long long *__restrict__ ukeys, uint32_t n_unique, int end_bit, uint32_t *__restrict__ lens) {
+// list lengths: one count per distinct (word, clump); the run of tuples that are not words (BHIP_ACX_NOKEY) is skipped
+__global__ void k_acx_hist(const unsigned long long *__restrict__ ukeys, uint32_t n_unique, int cb, uint32_t *__restrict__ lens) {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_unique; i += gridDim.x * blockDim.x) {
 		const unsigned long long key = ukeys[i];
-		if (key >> end_bit) continue;
-		atomicAdd(&lens[(uint32_t)(key >> 24)], 1u);
+		if (key >> 47) continue;
+		atomicAdd(&lens[(uint32_t)(key >> cb)], 1u);
 	}
 }
 // head[i] = i for the first tuple of every word, 0 elsewhere: an inclusive max-scan turns it into "first tuple of my word"
-__global__ void k_acx_heads(const unsigned long long *__restrict__ ukeys, uint32_t n_unique, uint32_t *__restrict__ head) {
+__global__ void k_acx_heads(const unsigned long long *__restrict__ ukeys, uint32_t n_unique, int cb, uint32_t *__restrict__ head) {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_unique; i += gridDim.x * blockDim.x)
-		head[i] = (i && (ukeys[i] >> 24) != (ukeys[i - 1] >> 24)) ? i : 0u;
+		head[i] = (i && (ukeys[i] >> cb) != (ukeys[i - 1] >> cb)) ? i : 0u;
 }
 // records of one slice: tuple i of word w goes to entry first(w) + (entries of w written by earlier slices) + (rank inside the word);
 // the tuples are sorted by (word, clump) and the slices are ascending clump ranges, so every list ends up in ascending clump order
 // (what the reference writes with one thread)
 __global__ void k_acx_fill(BhipAcxView acx, const unsigned long long *__restrict__ ukeys, const uint16_t *__restrict__ umasks, const uint32_t *__restrict__ head,
-                           uint32_t n_unique, int end_bit, const uint32_t *__restrict__ cursor, uint32_t *__restrict__ rec, uint32_t all_lanes) {
+                           uint32_t n_unique, int cb, uint32_t c0, const uint32_t *__restrict__ cursor, uint32_t *__restrict__ rec, uint32_t all_lanes) {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_unique; i += gridDim.x * blockDim.x) {
 		const unsigned long long key = ukeys[i];
-		if (key >> end_bit) continue;
-		const uint32_t w = (uint32_t)(key >> 24);
+		if (key >> 47) continue;
+		const uint32_t w = (uint32_t)(key >> cb);
 		unsigned long long beg; uint32_t n;
 		bhip_acx_range(acx, w, beg, n);
-		bhip_rec_store(rec, beg + (cursor ? cursor[w] : 0u) + (i - head[i]), (uint32_t)key & 0xFFFFFFu, all_lanes ? 0xFFFFu : (uint32_t)umasks[i]);
+		bhip_rec_store(rec, beg + (cursor ? cursor[w] : 0u) + (i - head[i]), c0 + ((uint32_t)key & ((1u << cb) - 1u)), all_lanes ? 0xFFFFu : (uint32_t)umasks[i]);
 	}
 }
-__global__ void k_acx_advance(const unsigned long long *__restrict__ ukeys, const uint32_t *__restrict__ head, uint32_t n_unique, int end_bit, uint32_t *__restrict__ cursor) {
+__global__ void k_acx_advance(const unsigned long long *__restrict__ ukeys, const uint32_t *__restrict__ head, uint32_t n_unique, int cb, uint32_t *__restrict__ cursor) {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_unique; i += gridDim.x * blockDim.x) {
 		const unsigned long long key = ukeys[i];
-		if (key >> end_bit) continue;
-		if (i + 1 == n_unique || (ukeys[i + 1] >> 24) != (key >> 24)) cursor[(uint32_t)(key >> 24)] += i - head[i] + 1;      // last tuple of its word in this slice
+		if (key >> 47) continue;
+		if (i + 1 == n_unique || (ukeys[i + 1] >> cb) != (key >> cb)) cursor[(uint32_t)(key >> cb)] += i - head[i] + 1;      // last tuple of its word in this slice
 	}
 }
 // back to the file's tables
@@ -475,7 +480,8 @@ __global__ void k_acx_rec_export(const uint32_t *__restrict__ rec, unsigned long
 int bhip_build_accelerator(Handle *h, int K, int z) {
 	const uint32_t nC = h->n_clumps;
 	const uint64_t nw = 1ull << (2 * K);
-	const int end_bit = 2 * K + 24;
+	const int cb = std::min(24, 47 - 2 * K);      // bits of a clump number inside a slice: word << cb | clump fits below the lane bits and the no-word bit
+	if (cb < 1) return fail(BHIP_E_ARG, "word length %d is beyond the device builder", K);
 	const bool dbg = getenv("BHIP_DEBUG") != nullptr;
 	const auto t_begin = std::chrono::steady_clock::now();
 	auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
@@ -505,7 +511,8 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 	ARC(d_bad.reserve((size_t)nC + 16)); ARC(d_soff.reserve(((size_t)nC + 1) * 8));
 	HIPCHK(hipMemcpyAsync(d_bad.p, is_bad.data(), nC, hipMemcpyHostToDevice, h->stream));
 	HIPCHK(hipMemcpyAsync(d_soff.p, slot_off.data(), ((size_t)nC + 1) * 8, hipMemcpyHostToDevice, h->stream));
-	// 2. slices of clumps whose tuples fit the sort buffers (26 bytes per tuple) next to what is resident at that time.  The records
+	// 2. slices of clumps whose tuples fit the sort buffers (two 8-byte tuple arrays + the folded lane masks: 18 bytes per tuple, planned
+	// with slack) next to what is resident at that time, of at most 2^cb clumps each (the slice-local clump number in the tuple).  The records
 	// (4 bytes per entry; their number is only known after the first pass) are not there yet while the lists are counted: the first
 	// pass runs over slices as large as the sort allows, the second over slices that fit next to the records -- unless everything
 	// fits at once under the safe estimate "one record per tuple", in which case one slice serves both passes and is sorted once.
@@ -531,14 +538,14 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 		cuts.assign(1, 0);
 		for (uint32_t c0 = 0; c0 < nC;) {
 			uint32_t c1 = c0 + 1;
-			while (c1 < nC && item_off[c1 + 1] - item_off[c0] <= slice_items) ++c1;
+			while (c1 < nC && item_off[c1 + 1] - item_off[c0] <= slice_items && c1 - c0 < (1u << cb)) ++c1;
 			cuts.push_back(c1); c0 = c1;
 		}
 		n_slices = (uint32_t)cuts.size() - 1;
 		cap_items = 0;
 		for (uint32_t s = 0; s < n_slices; ++s) cap_items = std::max(cap_items, item_off[cuts[s + 1]] - item_off[cuts[s]]);
 		k0.release(); k1.release(); v0.release(); v1.release(); tmp.release();
-		if (k0.reserve_exact(cap_items * 8 + 16) || k1.reserve_exact(cap_items * 8 + 16) || v0.reserve_exact(cap_items * 2 + 16) || v1.reserve_exact(cap_items * 2 + 16)) {
+		if (k0.reserve_exact(cap_items * 8 + 16) || k1.reserve_exact(cap_items * 8 + 16) || v0.reserve_exact(cap_items * 2 + 16)) {
 			// somebody else took memory of this device since it was measured (a query sort on the ingest thread, another rank): smaller slices
 			k0.release(); k1.release(); v0.release(); v1.release();
 			(void)hipGetLastError();
@@ -568,20 +575,21 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 		HIPCHK(hipMemsetAsync(d_xcur.p, 0, 8, h->stream));
 		hipLaunchKernelGGL(k_acx_extract, dim3(std::min<uint32_t>(((c1 - c0) * 16 + 255) / 256, (uint32_t)h->n_cu * 16)), dim3(256), 0, h->stream, h->ref_lane.as<uint4>(),
 			h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_soff.as<uint64_t>(), d_bad.as<uint8_t>(), c0, c1, h->tot_refs, K, z ? 1 : 0,
-			k0.as<unsigned long long>(), v0.as<uint16_t>(), (unsigned long long)n_slots, d_xcur.as<unsigned long long>());
+			cb, k0.as<unsigned long long>(), (unsigned long long)n_slots, d_xcur.as<unsigned long long>());
 		HIPCHK(hipGetLastError());
 		size_t tb = 0;
 		hipcub::DoubleBuffer<unsigned long long> dk(k0.as<unsigned long long>(), k1.as<unsigned long long>());
-		hipcub::DoubleBuffer<uint16_t> dv(v0.as<uint16_t>(), v1.as<uint16_t>());
-		HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, (int)n_items, 0, end_bit, h->stream));
+		HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, dk, (int)n_items, 0, BHIP_ACX_KEYBITS, h->stream));
 		ARC(tmp.reserve(tb));
-		HIPCHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, dk, dv, (int)n_items, 0, end_bit, h->stream));
-		unsigned long long *skeys = dk.Current(); uint16_t *svals = dv.Current();
-		ukeys = dk.Alternate(); umasks = dv.Alternate(); spare = skeys;
+		HIPCHK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, dk, (int)n_items, 0, BHIP_ACX_KEYBITS, h->stream));
+		unsigned long long *skeys = dk.Current();
+		ukeys = dk.Alternate(); umasks = v0.as<uint16_t>(); spare = skeys;
+		hipcub::TransformInputIterator<unsigned long long, AcxKeyOf, const unsigned long long *> kin(skeys, AcxKeyOf());
+		hipcub::TransformInputIterator<uint16_t, AcxLanesOf, const unsigned long long *> vin(skeys, AcxLanesOf());
 		size_t tb2 = 0;
-		HIPCHK(hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, skeys, ukeys, svals, umasks, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
+		HIPCHK(hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, kin, ukeys, vin, umasks, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
 		ARC(tmp.reserve(tb2));
-		HIPCHK(hipcub::DeviceReduce::ReduceByKey(tmp.p, tb2, skeys, ukeys, svals, umasks, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
+		HIPCHK(hipcub::DeviceReduce::ReduceByKey(tmp.p, tb2, kin, ukeys, vin, umasks, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
 		HIPCHK(hipMemcpyAsync(&n_unique, nruns.p, 4, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		return 0;
@@ -590,13 +598,14 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 	// 3. first pass: list lengths
 	for (uint32_t s = 0; s < n_slices; ++s) {
 		ARC(fold_slice(s));
-		if (n_unique) { hipLaunchKernelGGL(k_acx_hist, dim3(g), dim3(256), 0, h->stream, ukeys, n_unique, end_bit, d_lens.as<uint32_t>()); HIPCHK(hipGetLastError()); }
+		if (n_unique) { hipLaunchKernelGGL(k_acx_hist, dim3(g), dim3(256), 0, h->stream, ukeys, n_unique, cb, d_lens.as<uint32_t>()); HIPCHK(hipGetLastError()); }
 	}
 	const double t_pass1 = since();
 	uint64_t tot = 0; uint32_t maxlen = 0;
 	ARC(acx_lines_from_lens(h, d_lens.as<uint32_t>(), nw, &tot, &maxlen));
 	const uint32_t n_slices_1 = n_slices;
-	if (!one_plan) { k0.release(); k1.release(); v0.release(); v1.release(); tmp.release(); }      // the first pass's sort buffers make room for the records
+	const double t_a0 = since();
+	if (!one_plan) { k0.release(); k1.release(); v0.release(); tmp.release(); }      // the first pass's sort buffers make room for the records
 	ARC(h->acx_rec.reserve_exact(tot * BHIP_REC_BYTES + 16));
 	if (!one_plan) {
 		HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -605,28 +614,29 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 	if (n_slices > 1 || !one_plan) { d_cursor.p = d_lens.p; d_cursor.cap = d_lens.cap; d_lens.p = nullptr; d_lens.cap = 0; HIPCHK(hipMemsetAsync(d_cursor.p, 0, nw * 4, h->stream)); }      // (the length table's memory)
 	else d_lens.release();
 	const bool refold = n_slices > 1 || !one_plan;
+	const double t_alloc = since() - t_a0;      // the record area and the second plan's sort buffers: allocations
 	// 4. second pass: the records (one slice: the folded tuples are still there)
 	const uint32_t all_lanes = getenv("BHIP_NO_LANE_MASKS") ? 1u : 0u;
 	for (uint32_t s = 0; s < n_slices; ++s) {
 		if (refold) ARC(fold_slice(s));
 		if (!n_unique) continue;
 		uint32_t *head_in = (uint32_t *)spare, *head = head_in + n_unique;      // 8 bytes per tuple of scratch: the sorted key buffer
-		hipLaunchKernelGGL(k_acx_heads, dim3(g), dim3(256), 0, h->stream, ukeys, n_unique, head_in);
+		hipLaunchKernelGGL(k_acx_heads, dim3(g), dim3(256), 0, h->stream, ukeys, n_unique, cb, head_in);
 		HIPCHK(hipGetLastError());
 		size_t tb = 0;
 		HIPCHK(hipcub::DeviceScan::InclusiveScan(nullptr, tb, head_in, head, hipcub::Max(), (int)n_unique, h->stream));
 		ARC(tmp.reserve(tb));
 		HIPCHK(hipcub::DeviceScan::InclusiveScan(tmp.p, tb, head_in, head, hipcub::Max(), (int)n_unique, h->stream));
-		hipLaunchKernelGGL(k_acx_fill, dim3(g), dim3(256), 0, h->stream, h->acx_view(), ukeys, umasks, head, n_unique, end_bit,
+		hipLaunchKernelGGL(k_acx_fill, dim3(g), dim3(256), 0, h->stream, h->acx_view(), ukeys, umasks, head, n_unique, cb, cuts[s],
 			refold ? d_cursor.as<uint32_t>() : (const uint32_t *)nullptr, (uint32_t *)h->acx_view().rec, all_lanes);
 		HIPCHK(hipGetLastError());
-		if (refold) { hipLaunchKernelGGL(k_acx_advance, dim3(g), dim3(256), 0, h->stream, ukeys, head, n_unique, end_bit, d_cursor.as<uint32_t>()); HIPCHK(hipGetLastError()); }
+		if (refold) { hipLaunchKernelGGL(k_acx_advance, dim3(g), dim3(256), 0, h->stream, ukeys, head, n_unique, cb, d_cursor.as<uint32_t>()); HIPCHK(hipGetLastError()); }
 		HIPCHK(hipStreamSynchronize(h->stream));
 	}
 	ARC(set_badlist(h, badlist.data(), (uint32_t)badlist.size()));
 	h->has_acx = true; h->n_ent = tot; h->has_masks = !all_lanes;
-	if (dbg) fprintf(stderr, "[bhip] accelerator built on the device: K=%d, %llu entries from %llu word tuples in %u + %u slice(s), %zu clump(s) on the BadList, %.2f B per entry; %.2f s (%.2f s for the list lengths)\n",
-		K, (unsigned long long)tot, (unsigned long long)item_off[nC], n_slices_1, n_slices, badlist.size(), tot ? (double)(tot * BHIP_REC_BYTES + n_lines * 64) / (double)tot : 0.0, since(), t_pass1);
+	if (dbg) fprintf(stderr, "[bhip] accelerator built on the device: K=%d, %llu entries from %llu word tuples in %u + %u slice(s), %zu clump(s) on the BadList, %.2f B per entry; %.2f s (%.2f s for the list lengths, %.2f s allocating the records and the second pass's buffers)\n",
+		K, (unsigned long long)tot, (unsigned long long)item_off[nC], n_slices_1, n_slices, badlist.size(), tot ? (double)(tot * BHIP_REC_BYTES + n_lines * 64) / (double)tot : 0.0, since(), t_pass1, t_alloc);
 	return 0;
 }
 
