@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 4: accelerator build A/B on one box: packed 48-bit tuples (new) vs (word << 24 | clump, lane bit) pairs (old, burst_amd/acxold/)
+# round 4: accelerator build A/B on one box: packed 48-bit tuples (new) vs (word << 24 | clump, lane bit) pairs (old: the two libraries built from
+# bhip_acx.hip of commit 0d1864f^ -- the parent of the packed-tuple change -- into burst_amd/acxold/, which is not kept in the tree)
 R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out; mkdir -p $O; cd $R
 C="--db-scale 7 --workdir /dev/shm/acxab --keep-files --no-cpu-baseline --no-continuity --no-short-job --no-end-to-end --steps 3 --warmup 1"
 for round in 1 2 3; do
