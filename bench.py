@@ -738,24 +738,52 @@ def main():
         r3 = job_reads(args.warmup, nb3, weak=False)
         extra["configs3_job"] = {"value": r3 / e3, "unit": "reads/s", "reads": r3, "seconds": e3, "records": n3, "reads_per_rank": r3 // world,
                                  "what": "BASELINE configs[3]'s job size: %d reads cut over %d GPUs (strong scaling)" % (r3, world)}
-        if one_dev is None and args.gather == "shm":
-            try:
-                comm2 = make_comm()
-                rs2 = host.RankSearch(dev, rank, world, comm2, node=None)
-                rs2.reserve(cap_rec)
-                if rank == 0:
-                    rs2.reserve_all(world * cap_rec, pinned=True)
-                search(job_share(0, max(1, args.warmup)), rs2)
-                e4, n4, _ = timed(job_share(args.warmup, args.steps), rs2)
-                al = torch.tensor([float(rs2.mr.secSearch)], dtype=torch.float64, device=pdev)
-                dist.all_reduce(al, op=dist.ReduceOp.MAX)
-                extra["rccl"] = {"rccl_ranks": world, "value": total_reads / e4, "unit": "reads/s", "seconds": e4, "records": n4, "rccl_gather_ms": max(0.0, e4 - float(al.item())) * 1e3,
-                                 "what": "the main job with the records gathered to rank 0 by bhip_comm_gather_hits (ncclAllGather of the counts + grouped ncclSend/ncclRecv over xGMI, one copy to the "
-                                         "host) inside the timed region instead of the shared-memory hand-over; rccl_gather_ms = that time minus the slowest rank's align phase"}
-                rs2.close()
-                capi.lib().bhip_comm_destroy(comm2)
-            except Exception as e:
-                extra["rccl"] = {"error": str(e)}
+    # The RCCL gather across all ranks in the same run (second measurement of the main job, records through bhip_comm_gather_hits inside the
+    # timed region).  It runs LAST -- rank 0 has the whole line ready by then -- and under a watchdog: this exchange has never met two
+    # devices (every box so far had one), and a collective that does not come back must not take the run's measurement with it.
+    want_rccl = use_dist and one_dev is None and args.gather == "shm"
+
+    def rccl_extra():
+        comm2 = make_comm()
+        rs2 = host.RankSearch(dev, rank, world, comm2, node=None)
+        rs2.reserve(cap_rec)
+        if rank == 0:
+            rs2.reserve_all(world * cap_rec, pinned=True)
+        search(job_share(0, max(1, args.warmup)), rs2)
+        e4, n4, _ = timed(job_share(args.warmup, args.steps), rs2)
+        al = torch.tensor([float(rs2.mr.secSearch)], dtype=torch.float64, device=pdev)
+        dist.all_reduce(al, op=dist.ReduceOp.MAX)
+        out = {"rccl_ranks": world, "value": total_reads / e4, "unit": "reads/s", "seconds": e4, "records": n4, "rccl_gather_ms": max(0.0, e4 - float(al.item())) * 1e3,
+               "what": "the main job with the records gathered to rank 0 by bhip_comm_gather_hits (ncclAllGather of the counts + grouped ncclSend/ncclRecv over xGMI, one copy to the "
+                       "host) inside the timed region instead of the shared-memory hand-over; rccl_gather_ms = that time minus the slowest rank's align phase"}
+        rs2.close()
+        capi.lib().bhip_comm_destroy(comm2)
+        return out
+
+    def rccl_guarded(line_so_far):
+        """rccl_extra under a watchdog; when it does not answer in time rank 0 prints the line it has (line_so_far) and every rank leaves"""
+        import threading
+        limit = float(os.environ.get("BURST_BENCH_RCCL_TIMEOUT", "240")) + (0.0 if rank == 0 else 120.0)      # (the other ranks wait for rank 0 first)
+
+        def give_up():
+            if rank == 0 and line_so_far is not None:
+                line_so_far["rccl"] = {"error": "the RCCL gather across %d ranks did not answer within %.0f s (the line's other figures were measured before it)" % (world, limit)}
+                print(json.dumps(line_so_far), flush=True)
+            os._exit(0)
+        t = threading.Timer(limit, give_up)
+        t.daemon = True
+        t.start()
+        try:
+            return rccl_extra()
+        except Exception as e:
+            return {"error": str(e)}
+        finally:
+            t.cancel()
+    rccl_early = None
+    if want_rccl and world == 1:
+        rccl_early = rccl_guarded(None)          # (one process under torch.distributed.run, BURST_BENCH_DIST1: the device is closed further down)
+    elif want_rccl and rank != 0:
+        rccl_guarded(None)          # (waits in the communicator's creation until rank 0 has put its line together)
 
     if rank == 0 and os.environ.get("BHIP_PROF"):      # library built with EXTRA_HIPFLAGS=-DPFM_PROF: wave-cycles per prefilter phase
         import ctypes
@@ -1025,6 +1053,8 @@ def main():
                                               "what": "the database of rounds 1-3 (BENCH_r03: 556 M reads/s), same steps, same kernels"}
             except Exception as e:
                 res["continuity_small_db"] = {"error": str(e)}
+        if want_rccl:
+            res["rccl"] = rccl_early if world == 1 else rccl_guarded(res)
         print(json.dumps(res), flush=True)
     if not args.keep_files and rank == 0 and args.db_scale >= 2:      # a RAM-backed work directory is given back
         import shutil
