@@ -6,8 +6,9 @@ Workload (BASELINE.json configs[3] / `metric`, at the size one GPU box can build
 31.5 GB RefSeq subset is not reachable offline; the stand-in is a low-redundancy synthetic database (default 1.6 M random base
 sequences x 2 variants at 5 % divergence = 3.2 M references, 4.5 Gbp: every 15-mer has ~4 unrelated list entries, as a
 collision-dominated RefSeq-scale DB15 would have many more), its accelerator BUILT ON THE DEVICE from the .edx (no .acx is read
-or uploaded).  The database is as large as the box holds (--db-scale auto: 19.4 GB .edx on a 288 GB device in a 300 GB container; 31.5 GB with
---db-scale 11.37); `config.extrapolation.measured_sizes` carries the bench line measured at three sizes up to the metric's own (profiles/r04_sizes.json).
+or uploaded).  The database is as large as the box holds (--db-scale auto: the metric's own 31.5 GB .edx = 11.37 units on a 288 GB device in a
+300 GB container, with the compiled reference run on it beside the device path); `config.extrapolation.measured_sizes` carries the bench line
+measured at three sizes up to the metric's own (profiles/r04_sizes.json).
 
 A step = one batch of reads through the WHOLE device path as the product runs it: bench.py calls the C batch scheduler of
 the `burst_hip` command line (bh_align_ranges, burst_amd/csrc/host/bh_align.c) -- each step's batch is staged afresh from
@@ -26,10 +27,11 @@ job name and the barriers around the timed regions.
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel by time on the critical path (HIP events on the stream it runs on);
 `roofline.per_kernel` lists the others with their own bound; PMC-derived traffic / VALU figures come from profiles/
 (tools/profile_round.sh).  `cpu_baseline` is the compiled reference itself (oracle/_ref/burst15, one thread per core of the job's
-CPU quota) on a bounded sample of the same reads and database (its .acx is streamed to a file from the device-built tables):
+CPU quota) on a bounded sample of the same reads and database (its .acx is a NAMED PIPE fed from the device-built tables while it reads
+them -- read_accelerator, burst.c:3535-3594, only reads forward -- so the 167 GB accelerator of the metric's database never exists as a file):
 one run, its alignment loops timed between its own progress lines ("Using ACCELERATOR to align" .. "Search complete", burst.c:4048-4525)
 read line by line (pseudo-terminal, or `stdbuf -oL` on a pipe; without either, the differential wall time of two sample sizes).  Where the reference's accelerated run cannot fit the
-job's memory (it holds the .edx and the .acx next to the .acx file) the parity check runs its exhaustive path on a small sample.  `parity_vs_reference`: the .b6 the reference wrote for that sample against
+job's memory (it holds the .edx and the .acx) the parity check runs its exhaustive path on a small sample.  `parity_vs_reference`: the .b6 the reference wrote for that sample against
 the .b6 of the device path for the same reads (outside the timed region).
 """
 import argparse
@@ -87,6 +89,13 @@ def memory_in_use():
     return 0
 
 
+def memory_peak_str():
+    try:
+        return "%.0f GB" % (int(open("/sys/fs/cgroup/memory.peak").read().strip()) / 1e9)
+    except (OSError, ValueError):
+        return "unknown"
+
+
 def effective_cores():
     """host cores this job can really use: the visible ones, or the container's CPU quota (cgroup cpu.max) when that is less"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -105,24 +114,31 @@ def sizes_at(sc):
     return edx, edx * 1.06 + sc * UNIT_ENTRIES * 4 + 4.9e9 + 14e9, sc * UNIT_ENTRIES * 3 + 4.3e9
 
 
-def host_need(sc, with_reference, ram_backed, world=1):
+def reference_memory(edx, acx_file, K):
+    """bytes the compiled reference holds while it aligns: its copy of the .edx (read_edb, burst.c:2842-2975), the whole .acx -- length
+    table and lists (read_accelerator, 3535-3594) --, one pointer per word (`Forest`, 8 B x 4^K) and its threads' scratch"""
+    return edx + acx_file + 8.0 * 4 ** K + 8e9
+
+
+def host_need(sc, with_reference, ram_backed, world=1, K=15):
     """host memory a run at this scale touches at its worst moment.  Building: one part (2.5 units: FASTA + ~5 bytes per base in the
     QUICK builder) beside the parts' .edx files and, at the end, the merged file.  Running: the .edx file and this process's copy.
-    With the reference: its .acx file, and the reference's own copies of .edx and .acx (it reads both into memory) -- this process
-    lets go of its copy of the database meanwhile.  Files only count when the work directory is RAM-backed"""
+    With the reference: what the reference holds (reference_memory) beside the .edx FILE -- its .acx is a named pipe fed from the device
+    (AcxFeed), not a file, and this process lets go of its copy of the database meanwhile.  Files only count when the work directory is
+    RAM-backed"""
     edx, _, acx = sizes_at(sc)
     part = min(sc, 2.5) * UNIT_FASTA
     files = (2 * edx + 1.5e9) if ram_backed else 0
     build = part * (6 if ram_backed else 5) + files
     run = world * (edx + 4e9) + files / 2 + 8e9          # (every rank's process holds its own copy of the database for the upload)
-    ref = ((edx + acx if ram_backed else 0) + edx + acx + 10e9) if with_reference else 0
+    ref = ((edx if ram_backed else 0) + reference_memory(edx, acx, K) + 10e9) if with_reference else 0
     return max(build, run, ref) + 6e9
 
 
 def pick_setup(args, free_hbm, want_cpu_baseline, world=1):
     """(db-scale, work directory): the largest database of AUTO_SCALES this box holds -- on the device (references + 4-byte records +
     offset lines + batch buffers), in the host memory the job may use (see host_need; with 8 % of slack) and in the work directory
-    (FASTA parts, .edx, reads, the .acx file the compiled reference reads)"""
+    (FASTA parts, .edx, reads; the .acx the compiled reference reads is a named pipe)"""
     import shutil
     def free_of(d):
         try:
@@ -141,9 +157,9 @@ def pick_setup(args, free_hbm, want_cpu_baseline, world=1):
     for sc in scales:
         edx, dev_need, acx_file = sizes_at(sc)
         for with_ref in ((True, False) if args.db_scale != "auto" else (want_cpu_baseline,)):      # (auto: a size at which the reference runs beside it, if one is wanted)
-            disk_need = min(sc, 2.5) * UNIT_FASTA + 2 * edx + (acx_file if with_ref else 0) + 4e9
+            disk_need = min(sc, 2.5) * UNIT_FASTA + 2 * edx + 4e9
             for d in dirs:
-                if dev_need <= free_hbm and disk_need <= free_of(d) and host_need(sc, with_ref, d.startswith("/dev/shm"), world) <= ram:
+                if dev_need <= free_hbm and disk_need <= free_of(d) and host_need(sc, with_ref, d.startswith("/dev/shm"), world, args.K) <= ram:
                     return sc, d
     if args.db_scale != "auto":      # an explicit size is taken at its word (the allocation says when it does not fit)
         return float(args.db_scale), dirs[0]
@@ -241,7 +257,58 @@ def build_inputs(workdir, args, rank):
     return refs, edx, acx, reads_fa, done
 
 
-def run_reference_timed(cmd):
+class AcxFeed:
+    """The reference's .acx as a NAMED PIPE fed from the tables the device built.  read_accelerator (burst.c:3535-3594) is fopen + fgetc +
+    four sequential fread calls and never seeks, so the file it is given can be a FIFO: bh_acx_write_from_device writes the header, the
+    length table, the lists (run by run, fetched from the device and packed as they go) and the BadList into it while the reference
+    reads them into its own memory -- the 167 GB accelerator of the metric's database never exists as a file, which is what lets the
+    reference's accelerated run fit the job's memory beside the .edx.  One feed per reference run (start before the run, finish after)."""
+
+    def __init__(self, dev, n_clumps, K, path):
+        self.dev, self.n_clumps, self.K, self.path = dev, n_clumps, K, path
+        self.thread = self.error = None
+        self.seconds = 0.0
+
+    def start(self):
+        import threading
+        from burst_amd import host
+        try:
+            os.remove(self.path)
+        except OSError:
+            pass
+        os.mkfifo(self.path)
+        stub = host.Db()                      # (the writer wants the clump count -- the list format -- and nothing else of the database)
+        stub.c.numRclumps = self.n_clumps
+        def work():
+            t = time.time()
+            try:
+                stub.acx_write_from_device(self.dev, self.K, self.path)      # (blocks in fopen until the reference opens its end)
+            except Exception as e:
+                self.error = str(e)
+            self.seconds = time.time() - t
+        self.error = None
+        self.thread = threading.Thread(target=work, daemon=True)
+        self.thread.start()
+
+    def finish(self):
+        """after the reference has ended: a writer still waiting for a reader (the reference died before it opened the pipe) is released"""
+        if self.thread is not None and self.thread.is_alive():
+            try:
+                fd = os.open(self.path, os.O_RDONLY | os.O_NONBLOCK)
+                time.sleep(0.2)
+                os.close(fd)          # (the writer's next write fails with EPIPE; Python ignores SIGPIPE)
+            except OSError:
+                pass
+            self.thread.join(60)
+        self.thread = None
+        try:
+            os.remove(self.path)
+        except OSError:
+            pass
+        return self.error
+
+
+def run_reference_timed(cmd, feed=None):
     """run the compiled reference with its stdout line-buffered -- on a pseudo-terminal, or (no pty devices in the container) through a
     pipe under `stdbuf -oL` -- and stamp its own progress lines: returns (return code, whole wall time, seconds between its "Using
     ACCELERATOR to align ..." (burst.c:4048; without -a: "Searching best paths ...", 4325) line and its "Search complete" line (4525) --
@@ -254,6 +321,8 @@ def run_reference_timed(cmd):
         master, slave = pty.openpty()
     except Exception:
         master = slave = None
+    if feed is not None:
+        feed.start()
     t0 = time.time()
     if master is not None:
         p = subprocess.Popen(cmd, stdout=slave, stderr=slave, close_fds=True)
@@ -288,14 +357,18 @@ def run_reference_timed(cmd):
     wall = time.time() - t0
     if master is not None:
         os.close(master)
+    if feed is not None:
+        err = feed.finish()
+        if err:
+            tail.append("[.acx feed] " + err)
     align = (t_done - t_search) if (t_search is not None and t_done is not None) else None
     if master is None and not sb:      # a fully buffered pipe delivers the lines together at the end: not a measurement
         align = None
     return rc, wall, align, "\n".join(tail[-12:])
 
 
-def cpu_baseline(edx, acx, reads_fa, args):
-    """the compiled reference on the host cores, ONE run on the sample: its align phase is the time between its own "Searching best
+def cpu_baseline(edx, acx, reads_fa, args, feed=None):
+    """the compiled reference on the host cores, ONE run on the sample (feed: its .acx is the named pipe `acx`, fed from the device): its align phase is the time between its own "Searching best
     paths ..." and "Search complete" lines (the OpenMP loops this repository replaces: scour + aded_mat16 + reScoreM + hit capture),
     stamped as they arrive on a pseudo-terminal.  (Rounds 1-3 took the difference of two runs' wall times, which at 40 s of database
     load per run had a spread as large as the 2-4 s it was after.)"""
@@ -309,7 +382,8 @@ def cpu_baseline(edx, acx, reads_fa, args):
         for _ in range(2 * n):
             o.write(f.readline())
     rc, wall, align_s, tail = run_reference_timed([exe, "-r", edx, "-a", acx, "-q", sample, "-o", sample + ".b6", "-m", args.mode, "-i", str(args.id),
-                                                   "-t", str(cores)] + (["-fr"] if args.fr else []))
+                                                   "-t", str(cores)] + (["-fr"] if args.fr else []), feed)
+    cpu_baseline.wall, cpu_baseline.feed_s = wall, (feed.seconds if feed is not None else None)
     if rc != 0:
         log("[bench] reference failed:", tail[-400:])
         return None
@@ -321,10 +395,14 @@ def cpu_baseline(edx, acx, reads_fa, args):
         with open(reads_fa, "rb") as f, open(small, "wb") as o:
             for _ in range(2 * n1):
                 o.write(f.readline())
+        if feed is not None:
+            feed.start()
         t_ = time.time()
         r_ = subprocess.run([exe, "-r", edx, "-a", acx, "-q", small, "-o", small + ".b6", "-m", args.mode, "-i", str(args.id), "-t", str(cores), "--noprogress"] + (["-fr"] if args.fr else []),
                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         w1 = time.time() - t_
+        if feed is not None:
+            feed.finish()
         dt = wall - w1
         if r_.returncode != 0 or dt < 0.02 * wall or dt < 0.5:
             cpu_baseline.too_small = "the reference's wall time for %d and %d reads (%.2f s, %.2f s: database load) does not resolve its align phase" % (n1, n, w1, wall)
@@ -967,13 +1045,12 @@ def main():
             import shutil
             ram_backed = args.workdir.startswith("/dev/shm")
             # (the sizes of THIS database, not the estimate the size was picked with: other read lengths shear the references differently)
-            need_now = (edx_bytes + acx_bytes if ram_backed else 0) + edx_bytes + acx_bytes + 24e9
-            fits = need_now <= memory_limit() * 0.92 and host_need(args.db_scale, True, ram_backed) <= memory_limit() * 0.92 and \
-                (os.path.exists(acx + ".done") or shutil.disk_usage(os.path.dirname(acx)).free >= acx_bytes + (2 << 30))
+            need_now = (edx_bytes if ram_backed else 0) + reference_memory(edx_bytes, acx_bytes, args.K) + 16e9
+            fits = need_now <= memory_limit() * 0.92
             if not fits:
                 res["cpu_baseline_skipped"] = ("the reference's accelerated run needs %.0f GB of host memory at this database size (.edx %.1f GB + .acx %.1f GB in its memory%s); "
-                                               "this job may use %.0f GB" % (max(need_now, host_need(args.db_scale, True, ram_backed)) / 1e9, edx_bytes / 1e9, acx_bytes / 1e9,
-                                                                             ", the .acx file in a RAM-backed directory" if ram_backed else "", memory_limit() / 1e9))
+                                               "this job may use %.0f GB" % (need_now / 1e9, edx_bytes / 1e9, acx_bytes / 1e9,
+                                                                             ", the .edx file in a RAM-backed directory" if ram_backed else "", memory_limit() / 1e9))
                 log("[bench] " + res["cpu_baseline_skipped"])
                 try:
                     db.close()
@@ -981,28 +1058,24 @@ def main():
                     db = host.Db.read(edx, None, K=args.K)
                 except Exception as e:
                     ref_note = {"error": str(e)}
-            elif not os.path.exists(acx + ".done"):      # the reference reads an .acx FILE: written here from the tables the device built
-                t = time.time()
-                try:
-                    db.acx_write_from_device(dev, args.K, acx)      # (streamed: the host never holds the lists)
-                    open(acx + ".done", "w").write("ok")
-                    log("[bench] .acx for the reference written from the device-built tables in %.1f s (%.2f GB)" % (time.time() - t, os.path.getsize(acx) / 1e9))
-                except Exception as e:
-                    res["cpu_baseline_skipped"] = "could not write the reference's .acx: %s" % e
-            if fits and os.path.exists(acx + ".done"):
+            else:
+                # the reference reads an .acx FILE: a named pipe, fed from the tables the device built while the reference reads it
                 try:
                     t = time.time()
                     db.close()          # (this process's copy of the database: the reference holds its own, and the memory is shared)
                     room = memory_limit() - memory_in_use()
-                    if memory_in_use() and room < edx_bytes + acx_bytes + (12 << 30):
-                        res["cpu_baseline_skipped"] = "%.0f GB of the job's memory are free, the reference needs %.0f" % (room / 1e9, (edx_bytes + acx_bytes) / 1e9 + 12)
+                    if memory_in_use() and room < reference_memory(edx_bytes, acx_bytes, args.K) + (8 << 30):
+                        res["cpu_baseline_skipped"] = "%.0f GB of the job's memory are free, the reference needs %.0f" % (room / 1e9, reference_memory(edx_bytes, acx_bytes, args.K) / 1e9 + 8)
                     else:
-                        res["cpu_baseline"] = cpu_baseline(edx, acx, reads_fa, args)
+                        res["cpu_baseline"] = cpu_baseline(edx, acx + ".pipe", reads_fa, args, AcxFeed(dev, n_clumps, args.K, acx + ".pipe"))
                         if res["cpu_baseline"] is None and getattr(cpu_baseline, "too_small", None):
                             res["cpu_baseline_skipped"] = cpu_baseline.too_small
                             ref_note = {"what": "the reference WITH its accelerator, same .edx/.acx (its timing was not resolvable: cpu_baseline_skipped)"}
+                        if res["cpu_baseline"]:
+                            res["cpu_baseline"]["acx"] = ("%.1f GB .acx streamed to the reference through a named pipe from the device-built tables (bh_acx_write_from_device, %.0f s of its %.0f s run): "
+                                                          "it never exists as a file" % (acx_bytes / 1e9, getattr(cpu_baseline, "feed_s", 0.0) or 0.0, getattr(cpu_baseline, "wall", 0.0)))
                     db = host.Db.read(edx, None, K=args.K)
-                    log("[bench] reference on the host cores: %.1f s" % (time.time() - t))
+                    log("[bench] reference on the host cores: %.1f s (peak memory of the job so far: %s)" % (time.time() - t, memory_peak_str()))
                 except Exception as e:
                     res["cpu_baseline_skipped"] = "reference run failed: %s" % e
         if res["cpu_baseline"]:
@@ -1017,12 +1090,6 @@ def main():
                 res["parity_vs_reference"] = {"error": str(e)}
         elif ref_note:
             res["parity_vs_reference"] = ref_note
-        if want_base and not args.keep_files:      # the reference's .acx (3 B per entry: 100 GB and more) has served
-            for f in (acx, acx + ".done"):
-                try:
-                    os.remove(f)
-                except OSError:
-                    pass
         if handover_main is not None:
             res["handover"] = handover_main
         if world == 1 and (not args.no_end_to_end or (not args.no_continuity and args.db_scale > 1.5)):

@@ -2,10 +2,14 @@
  * clumping used when -r is not a database (process_references QUICK path, burst.c:1840-1858, 2109-2190, 2687-2741),
  * and writers/builders for both formats (dump_edb 2758-2839, make_accelerator 3304-3532) used by the tests and the bench.
  */
+#define _GNU_SOURCE
 #include "burst_host.h"
 #include <stdlib.h>
 #include <string.h>
 #include <omp.h>
+#include <fcntl.h>
+#include <pthread.h>
+#include <unistd.h>
 #include <sys/stat.h>
 
 static void *own(BhDb *db, void *p) {      /* a full table does not lose track of the block: it is given back and the caller sees an allocation failure */
@@ -711,10 +715,37 @@ int bh_acx_from_device(BhDb *db, void *hh, int K, int z) {
 	return BH_OK;
 }
 
+/* One packed run of the list area on its way to the file while the next one is fetched and packed: the writer thread of
+ * bh_acx_write_from_device.  `len` of slot s is set by the producer (0 = nothing queued), cleared by the writer. */
+typedef struct {
+	FILE *o; pthread_mutex_t mu; pthread_cond_t cv;
+	uint8_t *buf[2]; uint64_t len[2]; int stop, failed;
+} AcxWriter;
+
+static void *acx_writer_main(void *arg) {
+	AcxWriter *w = arg;
+	for (int s = 0;; s ^= 1) {
+		pthread_mutex_lock(&w->mu);
+		while (!w->len[s] && !w->stop) pthread_cond_wait(&w->cv, &w->mu);
+		const uint64_t n = w->len[s];
+		pthread_mutex_unlock(&w->mu);
+		if (!n) break;                                  /* (stop, nothing queued) */
+		const int bad = fwrite(w->buf[s], 1, n, w->o) != n;
+		pthread_mutex_lock(&w->mu);
+		w->len[s] = 0; if (bad) w->failed = 1;
+		pthread_cond_broadcast(&w->cv);
+		pthread_mutex_unlock(&w->mu);
+	}
+	return NULL;
+}
+
 /* The .acx of a database straight from the device that holds its accelerator, list area streamed: the length table comes over
  * whole (4 bytes per word), the entries in runs of whole words of about 2^27 entries, packed (burst.c:3501-3528) and written as they
- * come -- the host never holds more than one run (bh_acx_from_device + bh_acx_write hold 4 + 3 bytes of EVERY entry: 230 GB for
- * the 33 G entries of a 19 GB database). */
+ * come -- the host never holds more than two runs (bh_acx_from_device + bh_acx_write hold 4 + 3 bytes of EVERY entry: 230 GB for
+ * the 33 G entries of a 19 GB database).  The file is written front to back and never sought, so `path` may be a FIFO: the
+ * reference's read_accelerator (burst.c:3535-3594) is fopen + fgetc + four sequential fread calls, and a 167 GB accelerator then
+ * never exists as a file (bench.py's cpu_baseline at the metric's size).  A run is written by a thread of its own while the next
+ * one is fetched from the device and packed. */
 int bh_acx_write_from_device(const BhDb *db, void *hh, int K, int z, const char *path) {
 	uint64_t tot = 0; uint32_t nb = 0;
 	if (bhip_acx_export(hh, NULL, NULL, NULL, 0, &tot, NULL, 0, &nb)) return bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error());
@@ -723,17 +754,28 @@ int bh_acx_write_from_device(const BhDb *db, void *hh, int K, int z, const char 
 	if (!lens || !bl) { free(lens); free(bl); return bh_set_error(BH_E_OOM, "OOM:Accelerant.Refs"); }
 	if (bhip_acx_export(hh, lens, NULL, NULL, 0, &tot, bl, nb, &nb)) { free(lens); free(bl); return bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error()); }
 	const int fmt = db->numRclumps > 1048574 ? 1 : 0;
-	FILE *o = fopen(path, "wb");
+	FILE *o = fopen(path, "wb");                            /* (a FIFO: returns once the reader has opened its end) */
 	if (!o) { free(lens); free(bl); return bh_set_error(BH_E_USAGE, "Cannot write accelerator '%s'", path); }
+	struct stat st;
+	if (!fstat(fileno(o), &st) && S_ISFIFO(st.st_mode))     /* the largest pipe buffer the kernel grants: fewer sleeps per gigabyte */
+		for (int sz = 64 << 20; sz >= (1 << 20) && fcntl(fileno(o), F_SETPIPE_SZ, sz) < 0; sz >>= 1) ;
 	setvbuf(o, NULL, _IOFBF, 8u << 20);
 	const uint8_t vers = (uint8_t)(1 << 7 | (z ? 1 : 0) << 6 | fmt);
-	fwrite(&vers, 1, 1, o); fwrite(&nb, 4, 1, o);
-	fwrite(lens, 4, nw, o);
+	int rc = BH_OK;
+	if (fwrite(&vers, 1, 1, o) != 1 || fwrite(&nb, 4, 1, o) != 1 || fwrite(lens, 4, nw, o) != nw) rc = bh_set_error(BH_E_IO, "ERROR: write failed: %s", path);
 	const uint64_t RUN = 1ull << 27;
 	uint32_t *ent = malloc((RUN + (1u << 24)) * 4);
-	uint8_t *out = malloc((RUN + (1u << 24)) * 3 + 16);
-	int rc = (ent && out) ? BH_OK : bh_set_error(BH_E_OOM, "OOM:WordDump");
+	AcxWriter w; memset(&w, 0, sizeof w); w.o = o;
+	w.buf[0] = malloc((RUN + (1u << 24)) * 3 + 16); w.buf[1] = malloc((RUN + (1u << 24)) * 3 + 16);
+	pthread_t th; int have_th = 0;
+	if (!rc && !(ent && w.buf[0] && w.buf[1])) rc = bh_set_error(BH_E_OOM, "OOM:WordDump");
+	if (!rc) {
+		pthread_mutex_init(&w.mu, NULL); pthread_cond_init(&w.cv, NULL);
+		if (pthread_create(&th, NULL, acx_writer_main, &w)) rc = bh_set_error(BH_E_INTERNAL, "no writer thread");
+		else have_th = 1;
+	}
 	uint64_t e0 = 0;
+	int slot = 0;
 	for (uint64_t w0 = 0; w0 < nw && !rc;) {
 		uint64_t w1 = w0, n = 0;
 		while (w1 < nw && w1 - w0 < (1u << 24) && n < RUN) n += lens[w1++];      /* (a list has fewer than 2^24 entries: the buffers hold RUN + 2^24) */
@@ -745,6 +787,12 @@ int bh_acx_write_from_device(const BhDb *db, void *hh, int K, int z, const char 
 		uint64_t *epos = pos + nwr + 1;
 		pos[0] = 0; epos[0] = 0;
 		for (uint64_t k = 0; k < nwr; ++k) { const uint32_t l = lens[w0 + k]; pos[k + 1] = pos[k] + (fmt ? (uint64_t)l * 3 : (uint64_t)(l / 2u) * 5 + (l & 1u) * 3); epos[k + 1] = epos[k] + l; }
+		pthread_mutex_lock(&w.mu);                          /* the slot's previous run has left */
+		while (w.len[slot] && !w.failed) pthread_cond_wait(&w.cv, &w.mu);
+		const int failed = w.failed;
+		pthread_mutex_unlock(&w.mu);
+		if (failed) { free(pos); break; }
+		uint8_t *out = w.buf[slot];
 		#pragma omp parallel for schedule(static)
 		for (uint64_t k = 0; k < nwr; ++k) {
 			uint8_t *p = out + pos[k];
@@ -757,13 +805,29 @@ int bh_acx_write_from_device(const BhDb *db, void *hh, int K, int z, const char 
 				if (i < m) { const uint64_t v = l[i]; memcpy(p, &v, 3); p += 3; }
 			}
 		}
-		if (pos[nwr] && fwrite(out, 1, pos[nwr], o) != pos[nwr]) rc = bh_set_error(BH_E_IO, "ERROR: write failed: %s", path);
+		if (pos[nwr]) {
+			pthread_mutex_lock(&w.mu);
+			w.len[slot] = pos[nwr];
+			pthread_cond_broadcast(&w.cv);
+			pthread_mutex_unlock(&w.mu);
+			slot ^= 1;
+		}
 		free(pos);
 		e0 += n; w0 = w1;
 	}
+	if (have_th) {
+		pthread_mutex_lock(&w.mu);
+		while ((w.len[0] || w.len[1]) && !w.failed) pthread_cond_wait(&w.cv, &w.mu);
+		w.stop = 1;
+		pthread_cond_broadcast(&w.cv);
+		pthread_mutex_unlock(&w.mu);
+		pthread_join(th, NULL);
+		pthread_mutex_destroy(&w.mu); pthread_cond_destroy(&w.cv);
+		if (w.failed && !rc) rc = bh_set_error(BH_E_IO, "ERROR: write failed: %s", path);
+	}
 	if (!rc && e0 != tot) rc = bh_set_error(BH_E_INTERNAL, "accelerator lists: %lu entries written, %lu expected", (unsigned long)e0, (unsigned long)tot);
-	if (!rc) fwrite(bl, 4, nb, o);
-	free(ent); free(out); free(lens); free(bl);
+	if (!rc && fwrite(bl, 4, nb, o) != nb) rc = bh_set_error(BH_E_IO, "ERROR: write failed: %s", path);
+	free(ent); free(w.buf[0]); free(w.buf[1]); free(lens); free(bl);
 	if (fclose(o) && !rc) rc = bh_set_error(BH_E_IO, "ERROR: write failed: %s", path);
 	return rc;
 }
