@@ -883,7 +883,7 @@ def main():
         kernels = {}
         if masked and st["ms_prefilter_hash"] > 0:
             n = max(1, st["prefilter_launches"])
-            pf_name = "k_prefilter_cf" if st["prefilter_algo"] == 0 else "k_prefilter_mask"
+            pf_name = {0: "k_prefilter_cf", 2: "k_prefilter_cw"}.get(st["prefilter_algo"], "k_prefilter_mask")
             kernels[pf_name] = (st["ms_prefilter_hash"] / n, (8.0 * st["n_seed_words"] + 3.0 * st["acx_entries_read"] + 8.0 * st["n_lane_tasks"]) / n, "hbm")
             kernels["k_seed_ranges"] = (st["ms_seed"] / n, (8.0 * st["n_seed_words"] + 8.0 * st["n_seed_words"]) / n, "hbm")
         n = max(1, st["myers_launches"])
@@ -1015,7 +1015,7 @@ def main():
                     os.environ.pop(k_, None)
         if world == 1 and args.ab:
             # A/B on the resident database: the same warm-up and steps under other tuning options, the default options' line again at the end
-            defaults = {"prefilter_bytes": 1, "prefilter_rb": 0, "seed_min_need": -1, "seed_drop_len": 8, "prefilter_table": 0, "prefilter_waves": 0, "prefilter_algo": -1, "prune": 1, "oversub": 2, "band": 1, "seed_ahead": 1, "seed_ahead_blocks": 2, "peq_ahead_blocks": 16, "sweep_blocks": 8, "lanes": 1}
+            defaults = {"prefilter_cw": 0, "prefilter_bytes": 1, "prefilter_rb": 0, "seed_min_need": -1, "seed_drop_len": 8, "prefilter_table": 0, "prefilter_waves": 0, "prefilter_algo": -1, "prune": 1, "oversub": 2, "band": 1, "seed_ahead": 1, "seed_ahead_blocks": 2, "peq_ahead_blocks": 16, "sweep_blocks": 8, "lanes": 1}
             res["ab"] = []
             for spec in list(args.ab) + [""]:
                 kv = dict(x.split("=") for x in spec.split(",") if x)

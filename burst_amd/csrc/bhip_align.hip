@@ -248,12 +248,13 @@ static int pf_table_bits(const Handle *h, int algo, double expect) {
 // it pays while the remaining stream loads the counters below ~0.35 per counter (19 GB database: 152 records on 512 counters, +6 %) and
 // costs at the metric's size (246 records: 8 % survivors instead of 2.5 %, -6 %); on small databases the kernel's time does not depend on
 // the records at all and the extra candidates only cost sweeps.  -1 = by that rule, 0 = never, n = whenever the count stays >= n.
-static uint32_t seed_min_need_for(const Handle *h, double mean_words) {
+static uint32_t seed_min_need_for(const Handle *h, double mean_words, uint32_t W16) {
 	if (h->opt_seed_min_need >= 0) return (uint32_t)h->opt_seed_min_need;
 	const double t_all = mean_words * h->acx_wmean;
 	const double t_less = t_all * (mean_words > 1.0 ? (mean_words - 1.0) / mean_words : 1.0) * 0.93;
-	// (a stream of at most 255 records counts in bytes: twice the counters; the streams of a batch scatter around their mean)
-	const double counters = (double)(1u << pf_table_bits(h, 0, t_all)) * (h->opt_pf_bytes && t_less <= 200.0 ? 2.0 : 1.0);
+	// (k_prefilter_cf: a stream of at most 255 records counts in bytes: twice the counters; the streams of a batch scatter around their mean.
+	// k_prefilter_cw: 1 024 byte slots of list masks for up to 8 lists whatever the stream's length, 512 halfword slots beyond)
+	const double counters = h->opt_pf_cw ? (W16 <= 8 ? 1024.0 : 512.0) : (double)(1u << pf_table_bits(h, 0, t_all)) * (h->opt_pf_bytes && t_less <= 200.0 ? 2.0 : 1.0);
 	return (t_all >= 100.0 && t_less / counters <= 0.35) ? 3u : 0u;
 }
 static int launch_seed(Handle *h, Lane *L, hipStream_t st, StageSlot *S, int cls, const uint32_t *d_qlist, uint32_t n_list, uint32_t maxwords, double mean_words, bool ahead = false) {
@@ -277,7 +278,7 @@ static int launch_seed(Handle *h, Lane *L, hipStream_t st, StageSlot *S, int cls
 		junk ? S->qcodes_s.as<uint8_t>() : S->qcodes.as<uint8_t>(), junk ? S->qoff_s.as<uint64_t>() : S->qoff.as<uint64_t>(), d_qlist, n_list,
 		h->acx_view(), h->K, S->plan.as<uint32_t>(), W16, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(),
 		junk ? S->qpack_s.as<uint32_t>() : S->qpack.as<uint32_t>(), (S->st_maxlen + 7) / 8, junk ? S->qemac_s.as<uint16_t>() : S->qemac.as<uint16_t>(), qm.as<uint4>(), S->st_has_six ? S->qsix.as<uint32_t>() : nullptr,
-		seed_min_need_for(h, mean_words), (uint32_t)h->opt_seed_drop_len, h->alt);
+		seed_min_need_for(h, mean_words, W16), (uint32_t)h->opt_seed_drop_len, h->alt);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(ev[1], st));
 	L->qmeta_seq[S->seq & 1][cls] = S->seq + 1;
@@ -315,8 +316,11 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	// lists have been left out (expect counts them all: an upper bound), 2 .. 4; the wider tables only come with 2 or 4
 	int rb = h->opt_pf_rb ? h->opt_pf_rb : (expect <= 110.0 ? 2 : expect <= 230.0 ? 3 : 4);
 	if (htb != 9 && rb == 3) rb = 4;
+	const bool cw = algo == 0 && h->opt_pf_cw;      // one query per wave (k_prefilter_cw): its slot layout follows the number of lists a query can have
+	const int cw_mode = W16 <= 8 ? 0 : W16 <= 16 ? 1 : 2;
 	{
-		const void *fp = algo == 0
+		const void *fp = cw ? (cw_mode == 0 ? (const void *)k_prefilter_cw<0, 0> : cw_mode == 1 ? (const void *)k_prefilter_cw<1, 0> : (const void *)k_prefilter_cw<2, 0>)
+			: algo == 0
 			? (htb == 9 ? (rb == 2 ? (const void *)k_prefilter_cf<9, 2> : rb == 3 ? (const void *)k_prefilter_cf<9, 3> : (const void *)k_prefilter_cf<9, 4>)
 			   : htb == 10 ? (rb == 2 ? (const void *)k_prefilter_cf<10, 2> : (const void *)k_prefilter_cf<10, 4>) : (rb == 2 ? (const void *)k_prefilter_cf<11, 2> : (const void *)k_prefilter_cf<11, 4>))
 			: (htb == 9 ? (const void *)k_prefilter_mask<9> : htb == 10 ? (const void *)k_prefilter_mask<10> : (const void *)k_prefilter_mask<11>);
@@ -324,11 +328,32 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	}
 	const uint32_t by_lds = (148u * 1024u) / (uint32_t)std::max<size_t>(512, (fa.sharedSizeBytes + 511) & ~(size_t)511);
 	const uint32_t by_reg = 4u * (512u / (uint32_t)std::max(8, (fa.numRegs + 7) & ~7));
-	const uint32_t fit = std::max<uint32_t>(1u, std::min<uint32_t>(12u, std::min(by_lds, by_reg)));
-	if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] prefilter kernel: table 2^%d, %d record blocks in registers, %zu B LDS, %d VGPRs -> %u blocks per CU\n", htb, rb, fa.sharedSizeBytes, fa.numRegs, fit);
+	const uint32_t fit = std::max<uint32_t>(1u, std::min<uint32_t>(cw ? 32u : 12u, std::min(by_lds, by_reg)));
+	if (getenv("BHIP_DEBUG")) {
+		if (cw) fprintf(stderr, "[bhip] prefilter kernel: one query per wave, slot mode %d, %zu B LDS, %d VGPRs -> %u blocks per CU\n", cw_mode, fa.sharedSizeBytes, fa.numRegs, fit);
+		else fprintf(stderr, "[bhip] prefilter kernel: table 2^%d, %d record blocks in registers, %zu B LDS, %d VGPRs -> %u blocks per CU\n", htb, rb, fa.sharedSizeBytes, fa.numRegs, fit);
+	}
 	const uint32_t waves = h->opt_pf_waves ? std::min<uint32_t>((uint32_t)h->opt_pf_waves, fit) : fit;
-	const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * waves);
+	const uint32_t grid = std::min<uint32_t>(cw ? n_list : n_quads, (uint32_t)h->n_cu * waves);
 	HIPCHK(hipEventRecord(L->ev_pf[cls][1], st));
+	if (cw) {
+#define PFW_ARGS(FB, NFB, SEL, NSEL) L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list, \
+		h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, \
+		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
+		FB, NFB, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum, \
+		L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], prune, SEL, NSEL, 0
+		// first pass, then the queries whose survivors overflowed its 64-slot lane table once more with four times the slots and the table
+		if (cw_mode == 0) hipLaunchKernelGGL((k_prefilter_cw<0, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
+		else if (cw_mode == 1) hipLaunchKernelGGL((k_prefilter_cw<1, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
+		else hipLaunchKernelGGL((k_prefilter_cw<2, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
+		HIPCHK(hipGetLastError());
+		const uint32_t g2 = (uint32_t)h->n_cu;
+		if (cw_mode == 0) hipLaunchKernelGGL((k_prefilter_cw<0, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
+		else if (cw_mode == 1) hipLaunchKernelGGL((k_prefilter_cw<1, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
+		else hipLaunchKernelGGL((k_prefilter_cw<2, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
+#undef PFW_ARGS
+		fb_dense = fb2; n_fb_dense = &dc->n_fb2;
+	} else
 	if (algo == 0) {
 #define PFC_LAUNCH(B, R) hipLaunchKernelGGL((k_prefilter_cf<B, R>), dim3(grid), dim3(64), 0, st, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list, \
 		h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, \
@@ -361,7 +386,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(L->ev_pf[cls][2], st));
 	++L->pf_launches;
-	L->pf_algo_used = algo;
+	L->pf_algo_used = cw ? 2 : algo;
 	// dense fallback for overflowed queries (clump-level pairs)
 	const uint32_t *bad = h->bad.as<uint32_t>();
 	const bool narrow = h->cur->st_maxlen < 255u + (uint32_t)h->K;

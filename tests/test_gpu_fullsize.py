@@ -10,6 +10,8 @@ import sys
 import numpy as np
 import pytest
 
+CW_DEFAULT = 0          # library default of option prefilter_cw (see tests/test_gpu_kernels.py)
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -43,7 +45,7 @@ def test_one_million_reads_properties(tmp_path_factory):
     assert again.tobytes() == base.tobytes()
     # invariance under the tuning options (independent code paths)
     for opts in ({"lanes": 3}, {"prefilter_table": 10, "rescore_reg": 0}, {"lane_masks": 0}, {"two_stage": 0}, {"prefilter_stride": 6}, {"prune": 0},
-                 {"prefilter_algo": 1}, {"prefilter_algo": 0, "prune": 1}):
+                 {"prefilter_algo": 1}, {"prefilter_algo": 0, "prune": 1}, {"prefilter_cw": 1}, {"prefilter_cw": 0}):
         for k, v in opts.items():
             dev.set_option(k, v)
         if "lanes" in opts:
@@ -51,7 +53,7 @@ def test_one_million_reads_properties(tmp_path_factory):
         got, _ = dev.align_staged(False)
         assert got.tobytes() == base.tobytes(), opts
         for k in opts:
-            dev.set_option(k, {"lanes": 1, "prefilter_table": 0, "rescore_reg": 1, "lane_masks": 1, "two_stage": 1, "prefilter_stride": 0, "prune": 1, "prefilter_algo": -1}[k])
+            dev.set_option(k, {"lanes": 1, "prefilter_table": 0, "rescore_reg": 1, "lane_masks": 1, "two_stage": 1, "prefilter_stride": 0, "prune": 1, "prefilter_algo": -1, "prefilter_cw": CW_DEFAULT}[k])
         if "lanes" in opts:
             dev.stage(q)
     # sensitivity: a read carries at most 3 edits, so every entry whose budget is 3 must be found; the only entries that may
