@@ -477,7 +477,299 @@ __global__ void k_acx_rec_export(const uint32_t *__restrict__ rec, unsigned long
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same accelerator built in slices of the WORD space (round 5).  The builder above cuts the database into ranges of clumps: a
+// word's list then gets entries from every slice, so the list lengths must be known before a record can be placed -- every slice
+// is extracted, sorted over 48 bits and folded TWICE (46 % of the build was the radix sort).  Cut by word ranges instead, slice s
+// holds EVERY tuple of the words [w0, w1): sorted and folded once, its unique tuples ARE the records of those words, in place
+// and in order -- no second pass, no cursor per word, and:
+//  * the tuples of a slice are written in ascending clump order (a per-clump offset from one counting scan over the database), so
+//    the stable radix sort only has to order the word bits of the slice -- 24 bits, three passes, instead of 48 bits in six;
+//  * what a slice costs instead is one more scan over the references (33 GB, ~20 ms) to pick out its words.
+// The record area is one address range that grows by mapped chunks (DBuf::reserve_growable): its size is known when it is full.
+// Returns 1 (nothing changed) when this box cannot do it -- no virtual memory management, one bucket of words with more tuples than
+// a sort takes, not enough room -- and the clump-sliced builder takes over.
+// ------------------------------------------------------------------------------------------------
+// every word of one reference lane: emit(word) for each window of K symbols A/C/G/T, and for each IUPAC expansion of an ambiguous one
+template <class F>
+__device__ __forceinline__ void acx_lane_words(const uint4 *__restrict__ rp, uint32_t L, uint32_t nchunks, int K, int z, F &&emit) {
+	const uint32_t wmask = (1u << (2 * K)) - 1u;
+	unsigned long long win = 0;
+	uint32_t w = 0, run = 0, lit = 0;
+	for (uint32_t t = 0; t < nchunks; ++t) {
+		const uint4 ch = rp[t];
+		const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
+		for (uint32_t k = 0; k < 32; ++k) {
+			if (t * 32 + k >= L) break;
+			const uint32_t sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
+			run = (sym >= 1u && !(z && sym == 5u)) ? run + 1 : 0;
+			lit = (sym - 1u) < 4u ? lit + 1 : 0;
+			w = ((w << 2) | ((sym - 1u) & 3u)) & wmask;
+			win = (win << 4) | sym;
+			if (lit >= (uint32_t)K) emit(w);
+			else if (run >= (uint32_t)K) {
+				const unsigned long long prod = amb_product(win, K);
+				for (unsigned long long idx = 0; idx < prod; ++idx) {
+					unsigned long long r = idx; uint32_t word = 0;
+					for (int s = 0; s < K; ++s) {          // symbol s counted from the window's end: 2-bit digit s of the word
+						const uint32_t code = (uint32_t)(win >> (4 * s)) & 15u, n = amb_count(code), d = (uint32_t)(r % n);
+						r /= n;
+						word |= ((amb_bases(code) >> (2u * d)) & 3u) << (2 * s);
+					}
+					emit(word);
+				}
+			}
+		}
+	}
+}
+// tuples per bucket of 2^shift words, whole database (one LDS histogram per block)
+__global__ __launch_bounds__(256) void k_acx_whist(const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
+		const uint8_t *__restrict__ is_bad, uint32_t n_clumps, uint32_t tot_refs, int K, int z, uint32_t shift, uint32_t n_buckets, unsigned long long *__restrict__ hist) {
+	__shared__ uint32_t s_h[4096];
+	for (uint32_t i = threadIdx.x; i < n_buckets; i += 256) s_h[i] = 0;
+	__syncthreads();
+	const uint64_t n_threads = (uint64_t)n_clumps * 16;
+	for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n_threads; i += (uint64_t)gridDim.x * 256ull) {
+		const uint32_t c = (uint32_t)(i >> 4), zz = (uint32_t)(i & 15);
+		if (is_bad[c] || 16ull * c + zz >= tot_refs) continue;
+		const uint32_t L = clump_len[c], nchunks = (L + 31) >> 5;
+		acx_lane_words(ref + ref_off[c] * 16 + (uint64_t)zz * nchunks, L, nchunks, K, z, [&](uint32_t w) { atomicAdd(&s_h[w >> shift], 1u); });
+	}
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < n_buckets; i += 256) if (s_h[i]) atomicAdd(&hist[i], (unsigned long long)s_h[i]);
+}
+// tuples per (slice, clump): counts[s * n_clumps + c]; a block = 16 clumps at a time
+#define BHIP_ACX_MAX_SLICES 256u
+__global__ __launch_bounds__(256) void k_acx_wcount(const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
+		const uint8_t *__restrict__ is_bad, uint32_t n_clumps, uint32_t tot_refs, int K, int z, uint32_t shift, uint32_t n_buckets, const uint8_t *__restrict__ b2s, uint32_t n_slices,
+		uint32_t *__restrict__ counts) {
+	__shared__ uint8_t s_b2s[4096];
+	__shared__ uint32_t s_cnt[16][BHIP_ACX_MAX_SLICES];
+	for (uint32_t i = threadIdx.x; i < n_buckets; i += 256) s_b2s[i] = b2s[i];
+	const uint32_t cl = threadIdx.x >> 4, zz = threadIdx.x & 15u;
+	const uint32_t n_groups = (n_clumps + 15u) >> 4;
+	for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+		for (uint32_t i = threadIdx.x; i < 16u * n_slices; i += 256) s_cnt[i / n_slices][i % n_slices] = 0;
+		__syncthreads();
+		const uint32_t c = grp * 16u + cl;
+		if (c < n_clumps && !is_bad[c] && 16ull * c + zz < tot_refs) {
+			const uint32_t L = clump_len[c], nchunks = (L + 31) >> 5;
+			acx_lane_words(ref + ref_off[c] * 16 + (uint64_t)zz * nchunks, L, nchunks, K, z, [&](uint32_t w) { atomicAdd(&s_cnt[cl][s_b2s[w >> shift]], 1u); });
+		}
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < 16u * n_slices; i += 256) {
+			const uint32_t s = i >> 4, k = i & 15u;
+			if (grp * 16u + k < n_clumps) counts[(uint64_t)s * n_clumps + grp * 16u + k] = s_cnt[k][s];
+		}
+		__syncthreads();
+	}
+}
+// the tuples of the words [w0, w1): lane << 60 | (word - w0) << cbits | clump, those of clump c at off[c] .. (any order inside a clump)
+__global__ __launch_bounds__(256) void k_acx_wwrite(const uint4 *__restrict__ ref, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
+		const uint8_t *__restrict__ is_bad, uint32_t n_clumps, uint32_t tot_refs, int K, int z, uint32_t w0, uint32_t w1, uint32_t cbits, const uint32_t *__restrict__ off,
+		unsigned long long *__restrict__ keys) {
+	__shared__ uint32_t s_cur[16];
+	const uint32_t cl = threadIdx.x >> 4, zz = threadIdx.x & 15u;
+	const uint32_t n_groups = (n_clumps + 15u) >> 4;
+	for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+		if (threadIdx.x < 16) s_cur[threadIdx.x] = 0;
+		__syncthreads();
+		const uint32_t c = grp * 16u + cl;
+		if (c < n_clumps && !is_bad[c] && 16ull * c + zz < tot_refs) {
+			const uint32_t L = clump_len[c], nchunks = (L + 31) >> 5, base = off[c];
+			const unsigned long long tag = (unsigned long long)zz << 60 | c;
+			acx_lane_words(ref + ref_off[c] * 16 + (uint64_t)zz * nchunks, L, nchunks, K, z, [&](uint32_t w) {
+				if (w >= w0 && w < w1) keys[base + atomicAdd(&s_cur[cl], 1u)] = tag | (unsigned long long)(w - w0) << cbits;
+			});
+		}
+		__syncthreads();
+	}
+}
+struct AcxWKeyOf { __host__ __device__ unsigned long long operator()(const unsigned long long &t) const { return t & ((1ull << 60) - 1ull); } };
+struct AcxWLaneOf { __host__ __device__ uint16_t operator()(const unsigned long long &t) const { return (uint16_t)(1u << (uint32_t)(t >> 60)); } };
+// unique tuple i of a slice = record rec0 + i; one count per record for its word's list length
+__global__ void k_acx_wfill(const unsigned long long *__restrict__ ukeys, const uint16_t *__restrict__ umasks, uint32_t n_unique, uint32_t w0, uint32_t cbits,
+		uint32_t *__restrict__ rec, uint32_t *__restrict__ lens, uint32_t all_lanes) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_unique; i += gridDim.x * blockDim.x) {
+		const unsigned long long key = ukeys[i];
+		bhip_rec_store(rec, i, (uint32_t)key & ((1u << cbits) - 1u), all_lanes ? 0xFFFFu : (uint32_t)umasks[i]);
+		atomicAdd(&lens[w0 + (uint32_t)(key >> cbits)], 1u);
+	}
+}
+
+static int build_accelerator_by_words(Handle *h, int K, int z) {
+	const uint32_t nC = h->n_clumps;
+	const uint64_t nw = 1ull << (2 * K);
+	const bool dbg = getenv("BHIP_DEBUG") != nullptr;
+	const auto t_begin = std::chrono::steady_clock::now();
+	auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+	uint32_t cbits = 1; while ((1ull << cbits) < nC) ++cbits;
+	if (cbits > 24) return 1;
+	// 1. expansion estimate per clump -> BadList (as the clump-sliced builder)
+	std::vector<unsigned long long> tsum(nC), nexp(nC);
+	std::vector<uint8_t> is_bad(nC, 0);
+	std::vector<uint32_t> badlist;
+	DTmp d_bad;
+	{
+		DTmp d_ts, d_nx;
+		ARC(d_ts.reserve((size_t)nC * 8)); ARC(d_nx.reserve((size_t)nC * 8));
+		HIPCHK(hipMemsetAsync(d_ts.p, 0, (size_t)nC * 8, h->stream)); HIPCHK(hipMemsetAsync(d_nx.p, 0, (size_t)nC * 8, h->stream));
+		hipLaunchKernelGGL(k_acx_budget, dim3(std::min<uint32_t>((nC * 16u + 255u) / 256u, (uint32_t)h->n_cu * 16)), dim3(256), 0, h->stream, h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(),
+			h->clump_len.as<uint32_t>(), nC, h->tot_refs, K, z ? 1 : 0, d_ts.as<unsigned long long>(), d_nx.as<unsigned long long>());
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(tsum.data(), d_ts.p, (size_t)nC * 8, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(nexp.data(), d_nx.p, (size_t)nC * 8, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+	}
+	const unsigned long long full_size = K > 14 ? 0x7FFFFFFFull : (1ull << 24);      // burst.c:3322
+	uint64_t upper = 0;            // tuples of the whole database: an upper bound of its list entries
+	for (uint32_t c = 0; c < nC; ++c) {
+		if (tsum[c] >= full_size) { is_bad[c] = 1; badlist.push_back(c); continue; }
+		const uint64_t n = 16ull * h->h_clump_len[c] + nexp[c];
+		if (n >= (1ull << 31)) return 1;
+		upper += n;
+	}
+	ARC(d_bad.reserve((size_t)nC + 16));
+	HIPCHK(hipMemcpyAsync(d_bad.p, is_bad.data(), nC, hipMemcpyHostToDevice, h->stream));
+	// 2. tuples per bucket of words -> slices: runs of buckets with at most `target` tuples and at most 2^24 words (three sort passes)
+	const uint32_t bb = (uint32_t)std::min(12, 2 * K), shift = (uint32_t)(2 * K) - bb, n_buckets = 1u << bb;
+	const uint32_t g = (uint32_t)h->n_cu * 16;
+	std::vector<unsigned long long> hist(n_buckets);
+	{
+		DTmp d_hist;
+		ARC(d_hist.reserve((size_t)n_buckets * 8));
+		HIPCHK(hipMemsetAsync(d_hist.p, 0, (size_t)n_buckets * 8, h->stream));
+		hipLaunchKernelGGL(k_acx_whist, dim3(g), dim3(256), 0, h->stream, h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_bad.as<uint8_t>(),
+			nC, h->tot_refs, K, z ? 1 : 0, shift, n_buckets, d_hist.as<unsigned long long>());
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(hist.data(), d_hist.p, (size_t)n_buckets * 8, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+	}
+	const double t_hist = since();
+	uint64_t total = 0, biggest = 0;
+	for (uint32_t b = 0; b < n_buckets; ++b) { total += hist[b]; biggest = std::max<uint64_t>(biggest, hist[b]); }
+	size_t free_b = 0, total_b = 0;
+	HIPCHK(hipMemGetInfo(&free_b, &total_b));
+	const uint64_t n_lines = (nw + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS;
+	long long forced_slice = 0;
+	if (const char *ev = getenv("BHIP_MASK_SLICE")) forced_slice = atoll(ev);
+	// room for the sort of a slice (two 8-byte tuple arrays + the folded lane masks + the sort's own scratch: 19 bytes per tuple) next to
+	// everything that is or will be resident: the records (4 bytes per tuple at most), the length table and the offset lines, the counts
+	const double fixed = (double)total * BHIP_REC_BYTES + (double)nw * 4.0 + (double)n_lines * 64.0 * 1.2 + (double)nC * 8.0 + (double)(2u << 30);
+	std::vector<uint32_t> cuts;        // bucket boundaries of the slices
+	uint64_t cap_items = 0;
+	auto plan = [&](uint64_t target) -> uint32_t {
+		cuts.assign(1, 0); cap_items = 0;
+		const uint32_t max_b = 24 > shift ? 1u << (24 - shift) : 1u;      // buckets whose words together span at most 2^24
+		for (uint32_t b0 = 0; b0 < n_buckets;) {
+			uint32_t b1 = b0 + 1; uint64_t n = hist[b0];
+			while (b1 < n_buckets && b1 - b0 < max_b && n + hist[b1] <= target) n += hist[b1++];
+			cuts.push_back(b1); cap_items = std::max(cap_items, n); b0 = b1;
+		}
+		return (uint32_t)cuts.size() - 1;
+	};
+	uint32_t n_slices = 0;
+	if (forced_slice > 0) n_slices = plan(std::max<uint64_t>((uint64_t)forced_slice, biggest));
+	else {
+		const uint32_t min_s = 24 > shift ? std::max(1u, n_buckets >> (24 - shift)) : n_buckets;
+		for (uint32_t want = min_s; want <= BHIP_ACX_MAX_SLICES; want *= 2) {
+			const uint64_t target = std::max<uint64_t>(biggest, (uint64_t)((double)total / want * 1.15) + 1);
+			n_slices = plan(target);
+			const double need = fixed + (double)n_slices * nC * 4.0 + (double)cap_items * 19.0 + (double)(64u << 20);
+			if (n_slices <= BHIP_ACX_MAX_SLICES && cap_items < 2147483000ull && need <= (double)free_b) break;
+			n_slices = 0;
+		}
+	}
+	if (!n_slices || n_slices > BHIP_ACX_MAX_SLICES || cap_items >= 2147483000ull) return 1;
+	if (!total) return 1;
+	// the record area: an address range for the upper bound, memory as the records come
+	if (h->acx_rec.reserve_growable((size_t)total * BHIP_REC_BYTES + 16, h->device)) return 1;
+	if (const char *ev = getenv("BHIP_TEST_ENTRY_BIAS")) h->acx_bias = strtoull(ev, nullptr, 0);
+	h->K = K;
+	// 3. tuples per (slice, clump) in one scan
+	std::vector<uint8_t> b2s(n_buckets);
+	for (uint32_t s = 0; s < n_slices; ++s) for (uint32_t b = cuts[s]; b < cuts[s + 1]; ++b) b2s[b] = (uint8_t)s;
+	DTmp d_b2s, d_counts, d_off, d_lens, k0, k1, v0, nruns, tmp;
+	ARC(d_b2s.reserve(n_buckets)); ARC(d_counts.reserve_exact((size_t)n_slices * nC * 4 + 16)); ARC(d_off.reserve((size_t)nC * 4 + 16));
+	ARC(d_lens.reserve(nw * 4 + 16));
+	HIPCHK(hipMemsetAsync(d_lens.p, 0, nw * 4, h->stream));
+	HIPCHK(hipMemcpyAsync(d_b2s.p, b2s.data(), n_buckets, hipMemcpyHostToDevice, h->stream));
+	hipLaunchKernelGGL(k_acx_wcount, dim3(g), dim3(256), 0, h->stream, h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_bad.as<uint8_t>(),
+		nC, h->tot_refs, K, z ? 1 : 0, shift, n_buckets, d_b2s.as<uint8_t>(), n_slices, d_counts.as<uint32_t>());
+	HIPCHK(hipGetLastError());
+	ARC(k0.reserve_exact(cap_items * 8 + 16)); ARC(k1.reserve_exact(cap_items * 8 + 16)); ARC(v0.reserve_exact(cap_items * 2 + 16)); ARC(nruns.reserve(16));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	const double t_count = since();
+	// 4. slice after slice: offsets, tuples, sort over the slice's word bits, fold, records
+	const uint32_t all_lanes = getenv("BHIP_NO_LANE_MASKS") ? 1u : 0u;
+	uint64_t rec_n = 0;
+	double t_sort = 0;
+	for (uint32_t s = 0; s < n_slices; ++s) {
+		uint64_t n_items = 0;
+		for (uint32_t b = cuts[s]; b < cuts[s + 1]; ++b) n_items += hist[b];
+		if (!n_items) continue;
+		const uint64_t w0 = (uint64_t)cuts[s] << shift, w1 = (uint64_t)cuts[s + 1] << shift;
+		uint32_t wl = 1; while ((1ull << wl) < w1 - w0) ++wl;
+		const uint32_t *cnt_s = d_counts.as<uint32_t>() + (size_t)s * nC;
+		size_t tb = 0;
+		HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt_s, d_off.as<uint32_t>(), (int)nC, h->stream));
+		ARC(tmp.reserve(tb));
+		HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, cnt_s, d_off.as<uint32_t>(), (int)nC, h->stream));
+		hipLaunchKernelGGL(k_acx_wwrite, dim3(g), dim3(256), 0, h->stream, h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_bad.as<uint8_t>(),
+			nC, h->tot_refs, K, z ? 1 : 0, (uint32_t)w0, (uint32_t)std::min<uint64_t>(w1, 0xFFFFFFFFull), cbits, d_off.as<uint32_t>(), k0.as<unsigned long long>());
+		HIPCHK(hipGetLastError());
+		const auto ts0 = std::chrono::steady_clock::now();
+		hipcub::DoubleBuffer<unsigned long long> dk(k0.as<unsigned long long>(), k1.as<unsigned long long>());
+		HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, dk, (int)n_items, (int)cbits, (int)(cbits + wl), h->stream));
+		ARC(tmp.reserve(tb));
+		HIPCHK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, dk, (int)n_items, (int)cbits, (int)(cbits + wl), h->stream));
+		unsigned long long *skeys = dk.Current(), *ukeys = dk.Alternate();
+		hipcub::TransformInputIterator<unsigned long long, AcxWKeyOf, const unsigned long long *> kin(skeys, AcxWKeyOf());
+		hipcub::TransformInputIterator<uint16_t, AcxWLaneOf, const unsigned long long *> vin(skeys, AcxWLaneOf());
+		size_t tb2 = 0;
+		HIPCHK(hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, kin, ukeys, vin, v0.as<uint16_t>(), nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
+		ARC(tmp.reserve(tb2));
+		HIPCHK(hipcub::DeviceReduce::ReduceByKey(tmp.p, tb2, kin, ukeys, vin, v0.as<uint16_t>(), nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
+		uint32_t n_unique = 0;
+		HIPCHK(hipMemcpyAsync(&n_unique, nruns.p, 4, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		if (dbg) t_sort += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
+		ARC(h->acx_rec.grow_to((rec_n + n_unique) * BHIP_REC_BYTES + 16));
+		hipLaunchKernelGGL(k_acx_wfill, dim3(g), dim3(256), 0, h->stream, ukeys, v0.as<uint16_t>(), n_unique, (uint32_t)w0, cbits,
+			h->acx_rec.as<uint32_t>() + rec_n, d_lens.as<uint32_t>(), all_lanes);
+		HIPCHK(hipGetLastError());
+		rec_n += n_unique;
+		HIPCHK(hipStreamSynchronize(h->stream));
+	}
+	k0.release(); k1.release(); v0.release(); tmp.release(); d_counts.release();
+	uint64_t tot = 0; uint32_t maxlen = 0;
+	ARC(acx_lines_from_lens(h, d_lens.as<uint32_t>(), nw, &tot, &maxlen));
+	if (tot != rec_n) return fail(BHIP_E_INTERNAL, "accelerator build: %llu records written, the list lengths add up to %llu", (unsigned long long)rec_n, (unsigned long long)tot);
+	ARC(set_badlist(h, badlist.data(), (uint32_t)badlist.size()));
+	h->has_acx = true; h->n_ent = tot; h->has_masks = !all_lanes;
+	if (dbg) fprintf(stderr, "[bhip] accelerator built on the device by word ranges: K=%d, %llu entries from %llu word tuples in %u slice(s) of at most %llu tuples, %zu clump(s) on the BadList, %.2f B per entry; "
+		"%.2f s (%.2f s histogram, %.2f s counts, %.2f s sort + fold)\n", K, (unsigned long long)tot, (unsigned long long)total, n_slices, (unsigned long long)cap_items, badlist.size(),
+		tot ? (double)(h->acx_rec.cap + n_lines * 64) / (double)tot : 0.0, since(), t_hist, t_count - t_hist, t_sort);
+	(void)upper;
+	return 0;
+}
+
+static int build_accelerator_by_clumps(Handle *h, int K, int z);
+// BHIP_ACX_BUILD=clumps / words forces one builder (A/B, tests); by default the word-sliced one, the clump-sliced one where that cannot run
 int bhip_build_accelerator(Handle *h, int K, int z) {
+	const char *how = getenv("BHIP_ACX_BUILD");
+	if (!how || strcmp(how, "clumps")) {
+		const int rc = build_accelerator_by_words(h, K, z);
+		if (rc == 0 || (rc < 0 && rc != BHIP_E_DEVICE)) return rc;      // (1: cannot run here; a device error -- memory, most likely -- : the other builder plans differently)
+		h->acx_rec.release(); h->acx_lines.release(); h->has_acx = false;
+		(void)hipGetLastError();
+		if (how && !strcmp(how, "words")) return fail(BHIP_E_DEVICE, "BHIP_ACX_BUILD=words: the word-sliced accelerator build cannot run here");
+		if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] word-sliced accelerator build not possible here: clump-sliced build\n");
+	}
+	return build_accelerator_by_clumps(h, K, z);
+}
+
+static int build_accelerator_by_clumps(Handle *h, int K, int z) {
 	const uint32_t nC = h->n_clumps;
 	const uint64_t nw = 1ull << (2 * K);
 	const int cb = std::min(24, 47 - 2 * K);      // bits of a clump number inside a slice: word << cb | clump fits below the lane bits and the no-word bit

@@ -85,9 +85,14 @@ int bhip_fail_msg(int code, const char *fmt, ...) __attribute__((format(printf, 
 // grow-only device buffer
 struct DBuf {
 	void *p = nullptr; size_t cap = 0;
+	// growable variant (reserve_growable / grow_to): ONE address range whose physical memory is mapped chunk by chunk as the array
+	// grows (HIP virtual memory management) -- for the accelerator's record area, whose size is only known when it has been built
+	bool vmm = false; size_t va_size = 0; int vmm_device = 0;
+	std::vector<hipMemGenericAllocationHandle_t> chunks;
+	static constexpr size_t kChunk = 1ull << 30;
 	int reserve(size_t bytes) {
 		if (bytes <= cap) return 0;
-		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+		release();
 		size_t want = bytes + bytes / 4 + 256;
 		hipError_t e = hipMalloc(&p, want);
 		if (e != hipSuccess) { p = nullptr; return fail(BHIP_E_DEVICE, "hipMalloc(%zu): %s", want, hipGetErrorString(e)); }
@@ -97,12 +102,49 @@ struct DBuf {
 	// area is what decides whether a database fits the device)
 	int reserve_exact(size_t bytes) {
 		if (bytes <= cap) return 0;
-		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+		release();
 		hipError_t e = hipMalloc(&p, bytes);
 		if (e != hipSuccess) { p = nullptr; return fail(BHIP_E_DEVICE, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
 		cap = bytes; return 0;
 	}
-	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	// an address range for up to max_bytes with nothing behind it yet; non-zero (and no error text) when the runtime cannot do it
+	int reserve_growable(size_t max_bytes, int device) {
+		release();
+		int ok = 0;
+		if (hipDeviceGetAttribute(&ok, hipDeviceAttributeVirtualMemoryManagementSupported, device) != hipSuccess || !ok) { (void)hipGetLastError(); return 1; }
+		const size_t sz = ((max_bytes + kChunk - 1) / kChunk + 1) * kChunk;
+		if (hipMemAddressReserve(&p, sz, kChunk, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return 1; }
+		vmm = true; va_size = sz; vmm_device = device; cap = 0;
+		return 0;
+	}
+	int grow_to(size_t bytes) {
+		if (!vmm) return fail(BHIP_E_INTERNAL, "grow_to on a fixed buffer");
+		if (bytes > va_size) return fail(BHIP_E_DEVICE, "record area: %zu bytes wanted, %zu reserved", bytes, va_size);
+		hipMemAllocationProp prop = {};
+		prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = vmm_device;
+		hipMemAccessDesc acc = {};
+		acc.location.type = hipMemLocationTypeDevice; acc.location.id = vmm_device; acc.flags = hipMemAccessFlagsProtReadWrite;
+		while (cap < bytes) {
+			hipMemGenericAllocationHandle_t hnd;
+			hipError_t e = hipMemCreate(&hnd, kChunk, &prop, 0);
+			if (e != hipSuccess) return fail(BHIP_E_DEVICE, "hipMemCreate(%zu) at %zu mapped bytes: %s", kChunk, cap, hipGetErrorString(e));
+			e = hipMemMap((char *)p + cap, kChunk, 0, hnd, 0);
+			if (e == hipSuccess) e = hipMemSetAccess((char *)p + cap, kChunk, &acc, 1);
+			if (e != hipSuccess) { (void)hipMemRelease(hnd); return fail(BHIP_E_DEVICE, "hipMemMap at %zu mapped bytes: %s", cap, hipGetErrorString(e)); }
+			chunks.push_back(hnd);
+			cap += kChunk;
+		}
+		return 0;
+	}
+	void release() {
+		if (vmm) {
+			for (size_t i = 0; i < chunks.size(); ++i) { (void)hipMemUnmap((char *)p + i * kChunk, kChunk); (void)hipMemRelease(chunks[i]); }
+			chunks.clear();
+			if (p) (void)hipMemAddressFree(p, va_size);
+			vmm = false; va_size = 0;
+		} else if (p) (void)hipFree(p);
+		p = nullptr; cap = 0;
+	}
 	template <class T> T *as() const { return (T *)p; }
 };
 

@@ -1540,6 +1540,9 @@ __global__ __launch_bounds__(64) void k_prefilter_cw(
 	__syncthreads();
 	unsigned long long my_ent = 0, my_units = 0, my_qlen = 0, my_surv = 0;
 	const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#ifdef PFM_PROF
+	unsigned long long my_t[8] = {0,0,0,0,0,0,0,0}, t_last = wall_clock64();      // 0 lists + addresses + load issue, 1 first look (waits for the records), 2 second look, 3 survivor rounds, 4 emit, 5 clear, 6 loop top
+#endif
 	uint32_t nst[2] = {0u, 0u};
 	auto flush_one = [&](uint32_t which) {
 		const uint32_t n = nst[which];
@@ -1582,6 +1585,7 @@ __global__ __launch_bounds__(64) void k_prefilter_cw(
 		const uint32_t budget = (hd.y >> 12) & 255u, dper = (hd.y >> 20) & 15u ? (hd.y >> 20) & 15u : 1u;
 		const uint32_t thr = need ? need : 1u;
 		uint32_t pend = 0, head = 0, nused = 0, ovf = 0;                  // wave-uniform
+		PFM_T(6);
 		// ---- the lists of one chunk: lane l = list l.  eend = end of the list in the chunk's flattened stream; ab = biased address:
 		// the record at stream position i of list l is at ab_l + 4 i
 		uint32_t eend; unsigned long long ab; uint32_t T, nl;
@@ -1677,6 +1681,7 @@ __global__ __launch_bounds__(64) void k_prefilter_cw(
 				uint32_t ic[R];
 				#pragma unroll
 				for (uint32_t r = 0; r < R; ++r) if (r < rows) rc[r] = row_addr(r, ic[r], kr[r])[0];
+				PFM_T(0);
 				#pragma unroll
 				for (uint32_t r = 0; r < R; ++r) if (r < rows) count1(rc[r], kr[r], r * 64u + lane);
 				r0 = R;
@@ -1690,6 +1695,7 @@ __global__ __launch_bounds__(64) void k_prefilter_cw(
 		my_ent += gtot;
 		if (MODE == 2 && gtot > 65535ull) ovf = 1u;
 		CF_WAVE_ORDER();
+		PFM_T(1);
 		// ---- second look
 		if (!ovf) for (uint32_t c = 0; c < n_chunks; ++c) {
 			uint32_t rows, r0 = 0;
@@ -1706,8 +1712,10 @@ __global__ __launch_bounds__(64) void k_prefilter_cw(
 				offer1(rec, r * 64u + lane);
 			}
 		}
+		PFM_T(2);
 		while (pend) c_round();
 		CF_WAVE_ORDER();
+		PFM_T(3);
 		// ---- emit: four table slots x sixteen reference lanes per pass.  A lane with c matching words lost (W_valid - c) words, one edit
 		// destroys at most `dper` of them: its edit distance is at least budget - (c - need) / dper.  Unless every hit within budget is
 		// wanted, only the lanes with the query's largest count are swept at once; the others wait for the minimum those produce.
@@ -1754,13 +1762,18 @@ __global__ __launch_bounds__(64) void k_prefilter_cw(
 			for (uint32_t i = lane; i < LT; i += 64) { s_key[i] = 0; s_lc[i][0] = 0; s_lc[i][1] = 0; }
 			if (lane == 0) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
 		}
+		PFM_T(4);
 		{
 			uint4 *cz4 = (uint4 *)&s_cnt[0];
 			for (uint32_t i = lane; i < NDW / 4u; i += 64) cz4[i] = make_uint4(0, 0, 0, 0);
 		}
 		CF_WAVE_ORDER();
+		PFM_T(5);
 	}
 	flush_one(0); flush_one(1);
+#ifdef PFM_PROF
+	if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_pfm_prof[i], my_t[i]);
+#endif
 	if (lane == 0) {
 		if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
 		if (surv_sum && my_surv) atomicAdd(surv_sum, my_surv);

@@ -200,7 +200,7 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 		}
 	}
 	const int twoStrand = Q->numEntries > Q->numUniq;
-	const int all_hits = mode == BH_FORAGE;
+	const int all_hits = mode == BH_FORAGE || mode == BH_ANY;      /* ANY: any hit within budget will do (burst.c:4224) -- the report picks the one the reference meets first */
 	uint64_t capHits = totU * (twoStrand ? 2 : 1) + totU / 2 + (1u << 20), nHits = 0;
 	int pinned = run->hitsPinned;
 	BhipHit *hits = run->hits;

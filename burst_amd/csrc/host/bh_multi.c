@@ -178,14 +178,14 @@ int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhN
 	if (n_local < 1 || n_local > n_ranks || n_ranks > BH_MAX_RANKS) return bh_set_error(BH_E_USAGE, "bad rank layout (%d local of %d)", n_local, n_ranks);
 	if (!comm && !node && n_local != n_ranks) return bh_set_error(BH_E_USAGE, "without a communicator every rank must live in this process");
 	if (node && n_local != 1) return bh_set_error(BH_E_USAGE, "the shared-memory hand-over is for one rank per process");
-	if (node && !comm && !R[0].reduce_min && shard_db > 1 && mode != BH_FORAGE && n_ranks > 1) return bh_set_error(BH_E_USAGE, "database-sharded ranks in different processes need a communicator (or the launcher's reduce_min) for the minima");
+	if (node && !comm && !R[0].reduce_min && shard_db > 1 && mode != BH_FORAGE && mode != BH_ANY && n_ranks > 1) return bh_set_error(BH_E_USAGE, "database-sharded ranks in different processes need a communicator (or the launcher's reduce_min) for the minima");
 	const int dbg = getenv("BURST_HOST_DEBUG") != NULL;
 	double tp[5]; tp[0] = omp_get_wtime();
 	if (node) { int b = bh_node_begin(node); if (b) return b; bh_node_attach(node, &R[0].run); }
 	int rcs[BH_MAX_RANKS]; char errs[BH_MAX_RANKS][512];
 	uint8_t *best[BH_MAX_RANKS];
 	for (int i = 0; i < n_local; ++i) { rcs[i] = BH_E_INTERNAL; snprintf(errs[i], sizeof errs[i], "rank %d never ran (OpenMP gave the team fewer than %d threads)", R[i].rank, n_local); best[i] = NULL; }
-	const int reduce = shard_db > 1 && mode != BH_FORAGE && n_ranks > 1;
+	const int reduce = shard_db > 1 && mode != BH_FORAGE && mode != BH_ANY && n_ranks > 1;
 	/* the per-query minima tables are taken NOW: a rank that found no memory for its table after the search would stay out of a
 	 * collective its peers are in.  Here the call fails before anything has started (peers in other processes give up on this rank
 	 * through the hand-over's time-out) */
@@ -349,7 +349,7 @@ int bh_search_serial_shards(const BhDb *db, int device, int n_shards, int z, int
 	if (n_shards < 1 || n_shards > BH_MAX_RANKS) return bh_set_error(BH_E_USAGE, "bad number of shards (%d)", n_shards);
 	BhRun runs[BH_MAX_RANKS]; memset(runs, 0, sizeof runs);
 	uint8_t *best = NULL, *mine = NULL;
-	const int reduce = n_shards > 1 && mode != BH_FORAGE;
+	const int reduce = n_shards > 1 && mode != BH_FORAGE && mode != BH_ANY;
 	int rc = BH_OK;
 	if (reduce) {
 		best = malloc(Q->numUniq + 1); mine = malloc(Q->numUniq + 1);

@@ -351,7 +351,12 @@ int bh_report_view(FILE *out, const BhDb *db, const BhQueries *Q, const BhRunVie
 			}
 			for (uint64_t j = Q->offset[i]; j < Q->offset[i + 1]; ++j) { print_line_tax(out, Q->heads[j], db->refHead[rix], best, qlen, st, ed, i, wt, FinalTaxon); ++lines; }
 		} else if (mode == BH_ANY) {                                         /* any valid hit; column 12 = duplicate flag (burst.c:4268-4272) */
-			const BhipHit *rp = list[0];
+			/* The reference prints the first hit within budget a thread meets and marks the query spent (burst.c:4239-4275, 4457-4475).
+			 * Exhaustive path, one thread: clumps ascending, the entries of a clump in sorted order, lanes ascending -- the LAST
+			 * element of the merged list (a LIFO).  Accelerated path: the clumps come by descending k-mer count of a bunch of queries,
+			 * which depends on the thread count: not reproducible, the hit with the fewest edits (first in list order) stands in. */
+			const BhipHit *rp = list[merged ? n - 1 : 0];
+			if (!merged) for (uint32_t k = 1; k < n; ++k) if (list[k]->ed < rp->ed) rp = list[k];
 			const uint32_t rix = db->refIxSrt[rp->refIx];
 			uint32_t st, ed; coords(db, rp, rix, qlen, &st, &ed);
 			for (uint64_t j = Q->offset[i]; j < Q->offset[i + 1]; ++j) { print_line(out, Q->heads[j], db->refHead[rix], rp, qlen, st, ed, j > Q->offset[i]); ++lines; }
