@@ -755,10 +755,11 @@ static int build_accelerator_by_words(Handle *h, int K, int z) {
 }
 
 static int build_accelerator_by_clumps(Handle *h, int K, int z);
-// BHIP_ACX_BUILD=clumps / words forces one builder (A/B, tests); by default the word-sliced one, the clump-sliced one where that cannot run
+// BHIP_ACX_BUILD=words asks for the word-sliced builder (experimental: one scan of the references per slice costs more than the second
+// sort it saves -- 14.6 s against 10.1 s at the metric's size, gpurun_out/r05c); the clump-sliced one is the default
 int bhip_build_accelerator(Handle *h, int K, int z) {
 	const char *how = getenv("BHIP_ACX_BUILD");
-	if (!how || strcmp(how, "clumps")) {
+	if (how && !strcmp(how, "words")) {
 		const int rc = build_accelerator_by_words(h, K, z);
 		if (rc == 0 || (rc < 0 && rc != BHIP_E_DEVICE)) return rc;      // (1: cannot run here; a device error -- memory, most likely -- : the other builder plans differently)
 		h->acx_rec.release(); h->acx_lines.release(); h->has_acx = false;
@@ -871,9 +872,13 @@ static int build_accelerator_by_clumps(Handle *h, int K, int z) {
 		HIPCHK(hipGetLastError());
 		size_t tb = 0;
 		hipcub::DoubleBuffer<unsigned long long> dk(k0.as<unsigned long long>(), k1.as<unsigned long long>());
-		HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, dk, (int)n_items, 0, BHIP_ACX_KEYBITS, h->stream));
+		// The slots of a slice are laid out clump after clump, and the radix sort is stable: ordering the WORD bits (and the no-word bit
+		// above them) leaves the tuples of a word in ascending clump order -- 2 K + 1 bits, four passes, instead of 48 bits in six.  Only
+		// a slice with IUPAC expansions (appended behind the slots, out of clump order) needs the clump bits sorted as well.
+		const int bit0 = n_items == n_slots ? cb : 0;
+		HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, dk, (int)n_items, bit0, BHIP_ACX_KEYBITS, h->stream));
 		ARC(tmp.reserve(tb));
-		HIPCHK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, dk, (int)n_items, 0, BHIP_ACX_KEYBITS, h->stream));
+		HIPCHK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, dk, (int)n_items, bit0, BHIP_ACX_KEYBITS, h->stream));
 		unsigned long long *skeys = dk.Current();
 		ukeys = dk.Alternate(); umasks = v0.as<uint16_t>(); spare = skeys;
 		hipcub::TransformInputIterator<unsigned long long, AcxKeyOf, const unsigned long long *> kin(skeys, AcxKeyOf());

@@ -1588,7 +1588,7 @@ __global__ __launch_bounds__(64) void k_prefilter_cw(
 		PFM_T(6);
 		// ---- the lists of one chunk: lane l = list l.  eend = end of the list in the chunk's flattened stream; ab = biased address:
 		// the record at stream position i of list l is at ab_l + 4 i
-		uint32_t eend; unsigned long long ab; uint32_t T, nl;
+		uint32_t eend; unsigned long long ab; uint32_t T;
 		auto chunk_lists = [&](uint32_t c) {
 			unsigned long long rr = r_c;
 			if (c) { rr = 0; if (c * 64u + lane < W16) rr = ((const unsigned long long *)ranges)[(size_t)li * W16 + c * 64u + lane]; }
@@ -1598,27 +1598,31 @@ __global__ __launch_bounds__(64) void k_prefilter_cw(
 			eend = wave_incl_scan_u32(n);
 			T = (uint32_t)__builtin_amdgcn_readlane((int)eend, 63);
 			ab = (unsigned long long)(uintptr_t)ent + 4ull * (beg - (unsigned long long)(eend - n));
-			nl = W16 - c * 64u < 64u ? W16 - c * 64u : 64u;
 			if (__builtin_amdgcn_readfirstlane((int)(eend < n))) T = 0xFFFFFFFFu;      // (never: 64 lists of < 2^24 entries)
 		};
-		// scalar cursor over the lists while the rows are walked in order: k = list that holds the row's first position
-		uint32_t ck, cnxt;
-		auto cursor_reset = [&]() { ck = 0; cnxt = (uint32_t)__builtin_amdgcn_readlane((int)eend, 0); };
-		auto rl = [&](uint32_t v, uint32_t k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)k); };
-		auto row_addr = [&](uint32_t r, uint32_t &ic, uint32_t &kreg) -> bhip_gptr_t {
-			const uint32_t lo = r * 64u, hi = lo + 64u;
-			const uint32_t i = lo + lane;
-			ic = i < T ? i : T - 1u;                                      // beyond the stream: its last record once more (OR is idempotent; the second look tests i < T)
-			while (ck + 1u < nl && cnxt <= lo) { ++ck; cnxt = rl(eend, ck); }
-			uint32_t a_lo = rl((uint32_t)ab, ck), a_hi = rl((uint32_t)(ab >> 32), ck);
-			kreg = ck;
-			while (ck + 1u < nl && cnxt < hi) {                           // list ck ends inside this row: positions >= cnxt belong to a later list
-				const uint32_t b = cnxt;
-				++ck; cnxt = rl(eend, ck);
-				const uint32_t n_lo = rl((uint32_t)ab, ck), n_hi = rl((uint32_t)(ab >> 32), ck);
-				const bool later = ic >= b;
-				a_lo = later ? n_lo : a_lo; a_hi = later ? n_hi : a_hi; kreg = later ? ck : kreg;
+		// which list does stream position i belong to: the number of lists that end at or before it.  The ends are WAVE-UNIFORM (lane l
+		// holds list l's): up to 8 lists, seven scalar boundaries and a compare + add each; beyond, a binary search over the lanes.  The
+		// list's biased base address then comes from its lane (two cross-lane reads) -- no loop, no branch, the same for every row.
+		uint32_t eb[7] = {0, 0, 0, 0, 0, 0, 0};
+		auto list_ends = [&]() {
+			if (MODE == 0) {
+				#pragma unroll
+				for (uint32_t j = 0; j < 7; ++j) eb[j] = (uint32_t)__builtin_amdgcn_readlane((int)eend, (int)j);
 			}
+		};
+		auto row_addr = [&](uint32_t r, uint32_t &kreg) -> bhip_gptr_t {
+			const uint32_t i = r * 64u + lane;
+			const uint32_t ic = i < T ? i : T - 1u;                       // beyond the stream: its last record once more (OR is idempotent; the second look tests i < T)
+			uint32_t kk = 0;
+			if (MODE == 0) {
+				#pragma unroll
+				for (uint32_t j = 0; j < 7; ++j) kk += eb[j] <= ic ? 1u : 0u;
+			} else {
+				#pragma unroll
+				for (uint32_t step = 32; step >= 1; step >>= 1) kk += (uint32_t)__shfl((int)eend, (int)(kk + step - 1u), 64) <= ic ? step : 0u;      // (lanes without a list end at T > ic)
+			}
+			const uint32_t a_lo = (uint32_t)__shfl((int)(uint32_t)ab, (int)kk, 64), a_hi = (uint32_t)__shfl((int)(uint32_t)(ab >> 32), (int)kk, 64);
+			kreg = kk;
 			return (bhip_gptr_t)(uintptr_t)(((unsigned long long)a_hi << 32 | a_lo) + 4ull * ic);
 		};
 		auto slot_dw = [&](uint32_t rec) -> uint32_t { return (rec & (NS - 1u)) >> SB; };
@@ -1661,7 +1665,7 @@ __global__ __launch_bounds__(64) void k_prefilter_cw(
 			if (m) {
 				if (surv) s_ring[(head + pend + (uint32_t)__popcll(m & lt_mask)) & (RING - 1u)] = rec;
 				pend += (uint32_t)__popcll(m);
-				if (lane == 0) my_surv += (uint32_t)__popcll(m);
+				my_surv += (uint32_t)__popcll(m);
 				if (pend >= 64u) c_round();
 			}
 		};
@@ -1674,21 +1678,20 @@ __global__ __launch_bounds__(64) void k_prefilter_cw(
 			if (T == 0xFFFFFFFFu) { ovf = 1u; break; }
 			gtot += T;
 			const uint32_t rows = (T + 63u) >> 6;
-			cursor_reset();
+			list_ends();
 			uint32_t r0 = 0;
 			if (c == 0) {
 				T0 = T; rows0 = rows;
-				uint32_t ic[R];
 				#pragma unroll
-				for (uint32_t r = 0; r < R; ++r) if (r < rows) rc[r] = row_addr(r, ic[r], kr[r])[0];
+				for (uint32_t r = 0; r < R; ++r) if (r < rows) rc[r] = row_addr(r, kr[r])[0];
 				PFM_T(0);
 				#pragma unroll
 				for (uint32_t r = 0; r < R; ++r) if (r < rows) count1(rc[r], kr[r], r * 64u + lane);
 				r0 = R;
 			}
 			for (uint32_t r = r0; r < rows; ++r) {
-				uint32_t ic, k;
-				const uint32_t rec = row_addr(r, ic, k)[0];
+				uint32_t k;
+				const uint32_t rec = row_addr(r, k)[0];
 				count1(rec, k, r * 64u + lane);
 			}
 		}
@@ -1704,11 +1707,11 @@ __global__ __launch_bounds__(64) void k_prefilter_cw(
 				#pragma unroll
 				for (uint32_t r = 0; r < R; ++r) if (r < rows) offer1(rc[r], r * 64u + lane);
 				r0 = R;
-				if (rows > R) { chunk_lists(0); cursor_reset(); }      // (the lists again: later chunks have been through the registers; row_addr catches the cursor up)
-			} else { chunk_lists(c); rows = (T + 63u) >> 6; cursor_reset(); }
+				if (rows > R) { chunk_lists(0); list_ends(); }      // (the lists again: later chunks have been through the registers)
+			} else { chunk_lists(c); rows = (T + 63u) >> 6; list_ends(); }
 			for (uint32_t r = r0; r < rows; ++r) {
-				uint32_t ic, k;
-				const uint32_t rec = row_addr(r, ic, k)[0];
+				uint32_t k;
+				const uint32_t rec = row_addr(r, k)[0];
 				offer1(rec, r * 64u + lane);
 			}
 		}
@@ -1729,16 +1732,7 @@ __global__ __launch_bounds__(64) void k_prefilter_cw(
 				cz = ((const uint8_t *)&s_lc[slot][0])[z];
 				return has && c * 16u + z < tot_refs && cz >= thr;
 			};
-			uint32_t t0 = thr;
-			if (prune) {
-				uint32_t cmax = 0;
-				for (uint32_t p = 0; p * 4u < nused; ++p) { uint32_t sl, c, cz; if (look(p, sl, c, cz)) cmax = cz > cmax ? cz : cmax; }
-				const uint32_t cm = wave_max_u32(cmax);
-				t0 = cm > thr ? cm : thr;
-			}
-			for (uint32_t p = 0; p * 4u < nused; ++p) {
-				uint32_t slot, c, cz;
-				const bool ok = look(p, slot, c, cz);
+			auto emit_pass = [&](uint32_t p, bool ok, uint32_t slot, uint32_t c, uint32_t cz, uint32_t t0) {
 				const bool has = p * 4u + sg < nused;
 				CF_WAVE_ORDER();
 				if (has && z < 2u) s_lc[slot][z] = 0;                     // (this wave's reads of the slot are done: LDS operations of one wave stay in order)
@@ -1750,13 +1744,33 @@ __global__ __launch_bounds__(64) void k_prefilter_cw(
 				put(1, ok && !first, li | lb << 24, c * 16u + z);
 				const unsigned long long mo = __ballot(ok);
 				const uint32_t units = ((mo & 0xFFFFull) ? 1u : 0u) + ((mo >> 16 & 0xFFFFull) ? 1u : 0u) + ((mo >> 32 & 0xFFFFull) ? 1u : 0u) + ((mo >> 48) ? 1u : 0u);
-				if (lane == 0) { my_units += units; my_qlen += (unsigned long long)units * len; }
+				my_units += units; my_qlen += (unsigned long long)units * len;
+			};
+			if (nused <= 4u) {                                            // the usual case: every used slot in one pass, looked at once
+				uint32_t slot, c, cz;
+				const bool ok = look(0, slot, c, cz);
+				uint32_t t0 = thr;
+				if (prune) { const uint32_t cm = wave_max_u32(ok ? cz : 0u); t0 = cm > thr ? cm : thr; }
+				if (nused) emit_pass(0, ok, slot, c, cz, t0);
+			} else {
+				uint32_t t0 = thr;
+				if (prune) {
+					uint32_t cmax = 0;
+					for (uint32_t p = 0; p * 4u < nused; ++p) { uint32_t sl, c, cz; if (look(p, sl, c, cz)) cmax = cz > cmax ? cz : cmax; }
+					const uint32_t cm = wave_max_u32(cmax);
+					t0 = cm > thr ? cm : thr;
+				}
+				for (uint32_t p = 0; p * 4u < nused; ++p) {
+					uint32_t slot, c, cz;
+					const bool ok = look(p, slot, c, cz);
+					emit_pass(p, ok, slot, c, cz, t0);
+				}
 			}
 			for (uint32_t i = 0; i < n_bad; i += 4) {                     // burst.c:4136-4138, 4282-4283: every lane of the ambiguous clumps
 				const bool in = i + sg < n_bad;
 				const uint32_t c = in ? bad[i + sg] : 0u;
 				put(0, in && c * 16u + z < tot_refs, li, c * 16u + z);
-				if (lane == 0) { const uint32_t nb4 = n_bad - i < 4u ? n_bad - i : 4u; my_units += nb4; my_qlen += (unsigned long long)nb4 * len; }
+				{ const uint32_t nb4 = n_bad - i < 4u ? n_bad - i : 4u; my_units += nb4; my_qlen += (unsigned long long)nb4 * len; }
 			}
 		} else {
 			for (uint32_t i = lane; i < LT; i += 64) { s_key[i] = 0; s_lc[i][0] = 0; s_lc[i][1] = 0; }

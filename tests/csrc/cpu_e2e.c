@@ -14,7 +14,7 @@ int main(int argc, char **argv) {
 	if (argc < 10) { fprintf(stderr, "usage\n"); return 1; }
 	const char *ref = argv[1], *qf = argv[2], *outp = argv[3], *ms = argv[4];
 	float thres = (float)atof(argv[5]); int fr = atoi(argv[6]), z = atoi(argv[7]); long shear = atol(argv[8]);
-	BhMode mode = !strcmp(ms, "BEST") ? BH_BEST : !strcmp(ms, "ALLPATHS") ? BH_ALLPATHS : !strcmp(ms, "FORAGE") ? BH_FORAGE : BH_CAPITALIST;
+	BhMode mode = !strcmp(ms, "BEST") ? BH_BEST : !strcmp(ms, "ALLPATHS") ? BH_ALLPATHS : !strcmp(ms, "FORAGE") ? BH_FORAGE : !strcmp(ms, "ANY") ? BH_ANY : BH_CAPITALIST;
 	BhQueries Q; BhDb db; int rc;
 	if ((rc = bh_queries_load(qf, thres, fr, 0, 0, 12, z, 0, &Q))) { fprintf(stderr, "%s\n", bh_last_error()); return 2; }
 	int isdb = bh_is_edx(ref);
@@ -26,7 +26,7 @@ int main(int argc, char **argv) {
 	uint64_t cap = 1 << 22;
 	OrcHit *hits = malloc(cap * sizeof(*hits));
 	uint64_t n = orc_search(db.packed, db.clumpLen, db.numRclumps, db.totR, Q.codes, Q.qoff, E, Q.six, Q.rc, (uint32_t)Q.numEntries,
-	                        (uint32_t)Q.numUniq, lut, mode == BH_FORAGE, hits, cap);
+	                        (uint32_t)Q.numUniq, lut, mode == BH_FORAGE || mode == BH_ANY, hits, cap);
 	if (n > cap) { fprintf(stderr, "too many hits\n"); return 3; }
 	FILE *o = fopen(outp, "wb");
 	uint64_t lines = 0;

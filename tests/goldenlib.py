@@ -37,13 +37,30 @@ def golden_lines(c):
 def order_sensitive(c):
     """Cases whose reference output depends on the reference's thread-dependent hit-list order: DUPE_HUNT (FORAGE, and
     CAPITALIST votes) on the accelerated multi-thread path (burst.c:4019-4021, 4130, 4563-4570)."""
-    return c["accel"] and c["mode"] in ("CAPITALIST", "FORAGE")
+    return c["accel"] and c["mode"] in ("CAPITALIST", "FORAGE", "ANY")
 
 
 def compare(c, got_sorted, no_dupe_sorted=None):
     """exact comparison, or -- for order-sensitive cases -- the relaxed contract: same number of lines, same set of
     query names, and every reference line is one of the (hit, reference) placements we computed"""
     exp = golden_lines(c)
+    if order_sensitive(c) and c["mode"] == "ANY":
+        # ANY with the accelerator prints the first hit within budget a thread meets, in an order that follows the bunch k-mer counts and
+        # the thread count (burst.c:4130, 4239-4275): same number of lines, the same reads, as many duplicate flags, and every reference
+        # line must be a placement the device path computes (no_dupe_sorted = the same reads with -m FORAGE --no-dupe-hunt: columns
+        # 1-11 are the placement, column 12 is the query number there and the duplicate flag here)
+        assert len(got_sorted) == len(exp)
+        head = lambda ln: ln.split(b"\t")[0]
+        flag = lambda ln: ln.split(b"\t")[11]
+        assert sorted(map(head, got_sorted)) == sorted(map(head, exp))
+        # (which of several identical reads counts as the first is decided by the reference's unstable sorts and differs between its own
+        # runs with and without the accelerator: the number of flagged lines is what is fixed)
+        assert sorted(map(flag, got_sorted)) == sorted(map(flag, exp))
+        place = lambda ln: tuple(ln.split(b"\t")[:11])
+        mine = {place(ln) for ln in no_dupe_sorted}
+        assert all(place(ln) in mine for ln in exp), "reference printed a placement we never computed"
+        assert all(place(ln) in mine for ln in got_sorted)
+        return "relaxed(%d)" % len(set(exp) - set(got_sorted))
     if not order_sensitive(c):
         assert got_sorted == exp, "%s: %d lines vs %d expected" % (c["name"], len(got_sorted), len(exp))
         return "exact"

@@ -16,7 +16,9 @@ SUBSET = ["dna_q100_best_fr", "dna_q100_allpaths_y", "dna_q100_capitalist_noacx_
           # column 13 (taxonomy): lookup, CAPITALIST interpolation, -bc, -bs / -bs STRICT
           # (the other taxonomy cases run through the command line in the gpu suite)
           "dna_q100_capitalist_tax_noacx_t1_fr", "dna_q100_capitalist_tax_bs_noacx_t1_fr", "dna_q100_capitalist_tax_bc3_noacx_t1_fr",
-          "dna_q100_best_tax_bs_strict_fr", "dna_q100_forage_tax_noacx_t1_fr"]
+          "dna_q100_best_tax_bs_strict_fr", "dna_q100_forage_tax_noacx_t1_fr",
+          # ANY = the first hit within budget the reference's single thread meets (exact), column 12 = duplicate flag
+          "dna_q100_any_noacx_t1_fr", "quick_q100_any_noacx_t1", "dna_q292_any_noacx_t1_fr", "dna_q100_any_fr", "quick_q100_any"]
 
 
 @pytest.fixture(scope="module")
@@ -36,13 +38,14 @@ def test_host_pipeline_matches_reference(exe, name, tmp_path):
     ref, q, fr, z, shear = gl.case_args(c)
     out = str(tmp_path / "o.b6")
 
-    def run(flags):
+    def run(flags, mode=None):
         tax, bs, strict, cut = gl.tax_args(c)
-        subprocess.check_call([exe, ref, q, out, c["mode"], c["id"], str(fr), str(z), "0" if shear else "-1", str(flags), tax, str(bs), str(strict), str(cut)])
+        subprocess.check_call([exe, ref, q, out, mode or c["mode"], c["id"], str(fr), str(z), "0" if shear else "-1", str(flags), tax, str(bs), str(strict), str(cut)])
         return sorted(open(out, "rb").read().splitlines())
     base = 0 if c["accel"] else 1
     got = run(base)
-    nd = run(base | 2) if gl.order_sensitive(c) else None
+    # (the placements an order-dependent line may be: everything the mode computes, without the duplicate hunt; ANY: what FORAGE computes)
+    nd = run(base | 2, "FORAGE" if c["mode"] == "ANY" else None) if gl.order_sensitive(c) else None
     gl.compare(c, got, nd)
 
 
