@@ -168,13 +168,14 @@ def pick_setup(args, free_hbm, want_cpu_baseline, world=1):
 
 def db_paths(workdir, args):
     args.db_qlen = args.read_len + max(10, args.read_len // 10)
-    tag = "b%d_v%d_l%d_q%d_i%s_k%d" % (args.n_base, args.n_variants, args.ref_len, args.db_qlen, args.id, args.K)
+    tag = "b%d_v%d_l%d_q%d_i%s_k%d%s" % (args.n_base, args.n_variants, args.ref_len, args.db_qlen, args.id, args.K, "" if getattr(args, "db_profile", "pairs") == "pairs" else "_" + args.db_profile)
     return (os.path.join(workdir, "refs_%s.fa" % tag), os.path.join(workdir, "db_%s.edx" % tag), os.path.join(workdir, "db_%s.acx" % tag))
 
 
 def reads_path(workdir, args):
     edits = [int(x) for x in args.edits.split(",")]
-    return os.path.join(workdir, "reads_%d_l%d_e%s_u%s_f%d.fa" % (args.reads * args.pool, args.read_len, "-".join(map(str, edits)), args.iupac, int(args.fr)))
+    return os.path.join(workdir, "reads_%d_l%d_e%s_u%s_f%d%s.fa" % (args.reads * args.pool, args.read_len, "-".join(map(str, edits)), args.iupac, int(args.fr),
+                                                                    "" if getattr(args, "db_profile", "pairs") == "pairs" else "_" + args.db_profile))
 
 
 # A database is BUILT in parts of at most this many base sequences (x variants; 2.5 units of scale = 11 Gbp of FASTA): the QUICK
@@ -184,9 +185,33 @@ def reads_path(workdir, args):
 PART_BASES = 4000000
 
 
+def db_parts(args):
+    """the parts a database is built in: (first base sequence, base sequences, variants per base sequence, divergence, seed).  Default
+    profile: every base sequence with --n-variants variants at --variant-rate (low redundancy: what the headline is quoted on).  Profile
+    `strains`: 70 % of the content as that, 30 % in families of near-identical sequences -- 60 / 200 / 500 variants at 1 / 0.5 / 0.1 %
+    divergence, a tenth of the content each -- the strain-level redundancy of complete-genome collections: a read from such a family has
+    dozens to hundreds of candidate references"""
+    def cut(first, n, nv, rate, seed):
+        per = max(1, PART_BASES * 2 // nv)          # (a part holds about PART_BASES x 2 sequences)
+        k = max(1, -(-n // per))
+        size = -(-n // k)
+        size += (-size) % 8                         # (x variants x 3 fragments: every part but the last fills its last clump)
+        return [(first + i * size, min(n, (i + 1) * size) - i * size, nv, rate, seed) for i in range(k) if i * size < n]
+    if getattr(args, "db_profile", "pairs") != "strains":
+        return cut(0, args.n_base, args.n_variants, args.variant_rate, 7)
+    seqs = args.n_base * args.n_variants
+    parts = cut(0, int(args.n_base * 0.7), args.n_variants, args.variant_rate, 7)
+    first = args.n_base
+    for nv, rate, seed in ((60, 0.01, 11), (200, 0.005, 12), (500, 0.001, 13)):
+        n = max(1, int(seqs * 0.1 / nv))
+        parts += cut(first, n, nv, rate, seed)
+        first += n + 8
+    return parts
+
+
 def build_db(workdir, args, rank=0, reads_fa=None):
-    """rank 0 writes the shared database (args: read_len, n_base, n_variants, ref_len, variant_rate, id, K) -- and, with reads_fa, the
-    read pool drawn from its references (part by part: the reference FASTA of a part is deleted once its clumps and reads exist, unless
+    """rank 0 writes the shared database (args: read_len, n_base, n_variants, ref_len, variant_rate, id, K, db_profile) -- and, with reads_fa,
+    the read pool drawn from its references (part by part: the reference FASTA of a part is deleted once its clumps and reads exist, unless
     the database is a single part and args.drop_refs is off); returns (refs, edx, acx, done marker)"""
     from burst_amd import host
     os.makedirs(workdir, exist_ok=True)
@@ -195,20 +220,17 @@ def build_db(workdir, args, rank=0, reads_fa=None):
     if rank == 0 and not (os.path.exists(done) and (reads_fa is None or os.path.exists(reads_fa + ".done"))):
         t = time.time()
         edits = [int(x) for x in args.edits.split(",")] if reads_fa else []
-        n_parts = max(1, -(-args.n_base // PART_BASES))
-        per = -(-args.n_base // n_parts)
-        per += (-per) % 8          # (x 2 variants x 3 fragments: every part but the last fills its last clump)
+        specs = db_parts(args)
+        n_parts = len(specs)
+        tot_seqs = sum(n * nv for _, n, nv, _, _ in specs)
         n_pool = args.reads * args.pool if reads_fa else 0
         t_ref = t_cl = t_rd = 0.0
         parts, first_read = [], 0
-        for p in range(n_parts):
-            b0, b1 = p * per, min(args.n_base, (p + 1) * per)
-            if b1 <= b0:
-                break
+        for p, (b0, nb, nv, rate, seed) in enumerate(specs):
             fa = refs if n_parts == 1 else refs + ".part%d" % p
             ex = edx if n_parts == 1 else edx + ".part%d" % p
             t0 = time.time()
-            host.synth_refs(fa, b1 - b0, args.n_variants, args.ref_len, args.variant_rate, 7, first_base=b0)
+            host.synth_refs(fa, nb, nv, args.ref_len, rate, seed, first_base=b0)
             t1 = time.time()
             if not os.path.exists(done):
                 db = host.Db.from_fasta(fa, args.db_qlen, args.id, shear_len=500)
@@ -216,7 +238,7 @@ def build_db(workdir, args, rank=0, reads_fa=None):
                 db.close()
             t2 = time.time()
             if reads_fa and not os.path.exists(reads_fa + ".done"):
-                n_here = n_pool * (b1 - b0) // args.n_base if p + 1 < n_parts else n_pool - first_read
+                n_here = n_pool * (nb * nv) // tot_seqs if p + 1 < n_parts else n_pool - first_read      # (reads in proportion to the part's share of the content)
                 host.synth_reads(fa, reads_fa, n_here, args.read_len, edits, rc=args.fr, iupac=args.iupac, seed=42 + p, first_read=first_read, append=p > 0)
                 first_read += n_here
             t3 = time.time()
@@ -542,6 +564,8 @@ def main():
                     "auto (default) = the largest of %s that the device, the host memory and the work directory hold" % (AUTO_SCALES,))
     ap.add_argument("--n-base", type=int, default=1600000, help="random base sequences (round 2's family-dominated database: --n-base 33000 --n-variants 30)")
     ap.add_argument("--n-variants", type=int, default=2)
+    ap.add_argument("--db-profile", default="pairs", choices=["pairs", "strains"], help="pairs (default, what the headline is quoted on): every base sequence with --n-variants variants at --variant-rate; "
+                    "strains: 30 %% of the content in families of 60 / 200 / 500 near-identical sequences (1 / 0.5 / 0.1 %% divergence), the rest as pairs -- the redundancy of complete-genome collections")
     ap.add_argument("--ref-len", type=int, default=1400)
     ap.add_argument("--variant-rate", type=float, default=0.05)
     ap.add_argument("--id", type=float, default=0.98)
@@ -883,7 +907,7 @@ def main():
         kernels = {}
         if masked and st["ms_prefilter_hash"] > 0:
             n = max(1, st["prefilter_launches"])
-            pf_name = {0: "k_prefilter_cf", 2: "k_prefilter_cw"}.get(st["prefilter_algo"], "k_prefilter_mask")
+            pf_name = {0: "k_prefilter_cf", 2: "k_prefilter_cw", 3: "k_prefilter_cq"}.get(st["prefilter_algo"], "k_prefilter_mask")
             kernels[pf_name] = (st["ms_prefilter_hash"] / n, (8.0 * st["n_seed_words"] + 3.0 * st["acx_entries_read"] + 8.0 * st["n_lane_tasks"]) / n, "hbm")
             kernels["k_seed_ranges"] = (st["ms_seed"] / n, (8.0 * st["n_seed_words"] + 8.0 * st["n_seed_words"]) / n, "hbm")
         n = max(1, st["myers_launches"])

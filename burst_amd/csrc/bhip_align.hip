@@ -316,10 +316,12 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	// lists have been left out (expect counts them all: an upper bound), 2 .. 4; the wider tables only come with 2 or 4
 	int rb = h->opt_pf_rb ? h->opt_pf_rb : (expect <= 110.0 ? 2 : expect <= 230.0 ? 3 : 4);
 	if (htb != 9 && rb == 3) rb = 4;
-	const bool cw = algo == 0 && h->opt_pf_cw;      // one query per wave (k_prefilter_cw): its slot layout follows the number of lists a query can have
+	const bool cw = algo == 0 && h->opt_pf_cw;      // k_prefilter_cw / k_prefilter_cq: the slot layout follows the number of lists a query can have
 	const int cw_mode = W16 <= 8 ? 0 : W16 <= 16 ? 1 : 2;
+	const bool cq = cw && h->opt_pf_cw == 2 && cw_mode < 2;      // four queries per wave, streams walked by the whole wave (up to 16 lists per query)
 	{
-		const void *fp = cw ? (cw_mode == 0 ? (const void *)k_prefilter_cw<0, 0> : cw_mode == 1 ? (const void *)k_prefilter_cw<1, 0> : (const void *)k_prefilter_cw<2, 0>)
+		const void *fp = cq ? (cw_mode == 0 ? (const void *)k_prefilter_cq<0, 0> : (const void *)k_prefilter_cq<1, 0>)
+			: cw ? (cw_mode == 0 ? (const void *)k_prefilter_cw<0, 0> : cw_mode == 1 ? (const void *)k_prefilter_cw<1, 0> : (const void *)k_prefilter_cw<2, 0>)
 			: algo == 0
 			? (htb == 9 ? (rb == 2 ? (const void *)k_prefilter_cf<9, 2> : rb == 3 ? (const void *)k_prefilter_cf<9, 3> : (const void *)k_prefilter_cf<9, 4>)
 			   : htb == 10 ? (rb == 2 ? (const void *)k_prefilter_cf<10, 2> : (const void *)k_prefilter_cf<10, 4>) : (rb == 2 ? (const void *)k_prefilter_cf<11, 2> : (const void *)k_prefilter_cf<11, 4>))
@@ -330,11 +332,11 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	const uint32_t by_reg = 4u * (512u / (uint32_t)std::max(8, (fa.numRegs + 7) & ~7));
 	const uint32_t fit = std::max<uint32_t>(1u, std::min<uint32_t>(cw ? 32u : 12u, std::min(by_lds, by_reg)));
 	if (getenv("BHIP_DEBUG")) {
-		if (cw) fprintf(stderr, "[bhip] prefilter kernel: one query per wave, slot mode %d, %zu B LDS, %d VGPRs -> %u blocks per CU\n", cw_mode, fa.sharedSizeBytes, fa.numRegs, fit);
+		if (cw) fprintf(stderr, "[bhip] prefilter kernel: %s, slot mode %d, %zu B LDS, %d VGPRs -> %u blocks per CU\n", cq ? "four queries per wave, streams by the whole wave" : "one query per wave", cw_mode, fa.sharedSizeBytes, fa.numRegs, fit);
 		else fprintf(stderr, "[bhip] prefilter kernel: table 2^%d, %d record blocks in registers, %zu B LDS, %d VGPRs -> %u blocks per CU\n", htb, rb, fa.sharedSizeBytes, fa.numRegs, fit);
 	}
 	const uint32_t waves = h->opt_pf_waves ? std::min<uint32_t>((uint32_t)h->opt_pf_waves, fit) : fit;
-	const uint32_t grid = std::min<uint32_t>(cw ? n_list : n_quads, (uint32_t)h->n_cu * waves);
+	const uint32_t grid = std::min<uint32_t>(cw && !cq ? n_list : n_quads, (uint32_t)h->n_cu * waves);
 	HIPCHK(hipEventRecord(L->ev_pf[cls][1], st));
 	if (cw) {
 #define PFW_ARGS(FB, NFB, SEL, NSEL) L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list, \
@@ -343,12 +345,16 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 		FB, NFB, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum, \
 		L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], prune, SEL, NSEL, 0
 		// first pass, then the queries whose survivors overflowed its 64-slot lane table once more with four times the slots and the table
-		if (cw_mode == 0) hipLaunchKernelGGL((k_prefilter_cw<0, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
+		if (cq && cw_mode == 0) hipLaunchKernelGGL((k_prefilter_cq<0, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
+		else if (cq) hipLaunchKernelGGL((k_prefilter_cq<1, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
+		else if (cw_mode == 0) hipLaunchKernelGGL((k_prefilter_cw<0, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
 		else if (cw_mode == 1) hipLaunchKernelGGL((k_prefilter_cw<1, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
 		else hipLaunchKernelGGL((k_prefilter_cw<2, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
 		HIPCHK(hipGetLastError());
 		const uint32_t g2 = (uint32_t)h->n_cu;
-		if (cw_mode == 0) hipLaunchKernelGGL((k_prefilter_cw<0, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
+		if (cq && cw_mode == 0) hipLaunchKernelGGL((k_prefilter_cq<0, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
+		else if (cq) hipLaunchKernelGGL((k_prefilter_cq<1, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
+		else if (cw_mode == 0) hipLaunchKernelGGL((k_prefilter_cw<0, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
 		else if (cw_mode == 1) hipLaunchKernelGGL((k_prefilter_cw<1, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
 		else hipLaunchKernelGGL((k_prefilter_cw<2, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
 #undef PFW_ARGS
@@ -386,7 +392,7 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(L->ev_pf[cls][2], st));
 	++L->pf_launches;
-	L->pf_algo_used = cw ? 2 : algo;
+	L->pf_algo_used = cq ? 3 : cw ? 2 : algo;
 	// dense fallback for overflowed queries (clump-level pairs)
 	const uint32_t *bad = h->bad.as<uint32_t>();
 	const bool narrow = h->cur->st_maxlen < 255u + (uint32_t)h->K;

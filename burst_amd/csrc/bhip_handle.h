@@ -55,6 +55,9 @@ template <int HTB> __global__ void k_prefilter_mask(const uint2 *, const uint2 *
 template <int CB, int RBT> __global__ void k_prefilter_cf(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *,
 	uint2 *, uint32_t *, int, const uint32_t *, const uint32_t *, int);
+template <int MODE, int BIG> __global__ void k_prefilter_cq(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
+	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *,
+	uint2 *, uint32_t *, int, const uint32_t *, const uint32_t *, int);
 template <int MODE, int BIG> __global__ void k_prefilter_cw(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
 	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *,
 	uint2 *, uint32_t *, int, const uint32_t *, const uint32_t *, int);
@@ -324,7 +327,8 @@ struct Handle {
 	int opt_pf_algo = -1;         // 0 = counting filter + exact lane table (k_prefilter_cf), 1 = exact clump hash table in two passes
 	                              // (k_prefilter_mask), -1 = start with 0 and switch a lane to 1 when more than 20 % of its records survive the filter
 	int opt_pf_table = 0;         // log2 of the per-query hash table (0 = from the workload: 9, 10 or 11)
-	int opt_pf_cw = 0;            // the counting filter as k_prefilter_cw (one query per wave, list-mask slots) instead of k_prefilter_cf (four queries per wave)
+	int opt_pf_cw = 0;            // the counting filter as: 0 k_prefilter_cf (four queries per wave, 16 lanes each), 1 k_prefilter_cw (one query per wave, list-mask slots),
+	                              // 2 k_prefilter_cq (four queries per wave, their record streams walked by the whole wave; plans beyond 16 lists: k_prefilter_cw)
 	int opt_pf_bytes = 1;         // byte counters (twice as many) for queries whose record stream is at most 255 records
 	int opt_pf_rb = 0;            // 64-record blocks per query the counting-filter kernel fetches a quad ahead and keeps in registers (0 = from the workload: 2, 3 or 4)
 	int opt_seed_ahead = 1;       // seed lookups of the next staged batch run while the current one is swept

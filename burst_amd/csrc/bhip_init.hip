@@ -230,7 +230,7 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 	if (!strcmp(name, "prefilter_waves")) { if (value < 0 || value > 16) return fail(BHIP_E_ARG, "prefilter_waves must be 0 .. 16"); h->opt_pf_waves = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_algo")) { if (value < -1 || value > 1) return fail(BHIP_E_ARG, "prefilter_algo must be -1, 0 or 1"); h->opt_pf_algo = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_table")) { if (value != 0 && (value < 9 || value > 11)) return fail(BHIP_E_ARG, "prefilter_table must be 0, 9, 10 or 11"); h->opt_pf_table = (int)value; return BHIP_OK; }
-	if (!strcmp(name, "prefilter_cw")) { h->opt_pf_cw = value != 0; return BHIP_OK; }
+	if (!strcmp(name, "prefilter_cw")) { if (value < 0 || value > 2) return fail(BHIP_E_ARG, "prefilter_cw must be 0, 1 or 2"); h->opt_pf_cw = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_bytes")) { h->opt_pf_bytes = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_rb")) { if (value != 0 && (value < 2 || value > 4)) return fail(BHIP_E_ARG, "prefilter_rb must be 0, 2, 3 or 4"); h->opt_pf_rb = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "lanes")) {

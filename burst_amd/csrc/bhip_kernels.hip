@@ -1795,6 +1795,310 @@ __global__ __launch_bounds__(64) void k_prefilter_cw(
 	}
 	(void)clump_len; (void)col_sum;
 }
+// ------------------------------------------------------------------------------------------------
+// Lane-resolved prefilter, counting filter, FOUR queries per wave with the record streams walked by the WHOLE wave (round 5).
+// k_prefilter_cw (one query per wave) showed two things on the device (PMC, gpurun_out/r05d): walking a query's stream with 64 lanes and
+// wave-uniform list boundaries costs ~30 vector instructions per 64 records where k_prefilter_cf spends ~75 -- and everything ELSE a query
+// needs (list scan, survivor insertion, emit, clearing: ~230 vector and ~250 scalar instructions) is then paid per query by a wave in which
+// a handful of lanes do the work, which is why it loses to k_prefilter_cf on small databases (260 against 187 vector instructions per query
+// at 35 records per read) and wins only 20 % at the metric's size.  This kernel keeps both halves where they are cheap:
+//  * per QUAD of queries, group-parallel as in k_prefilter_cf (16 lanes per query): list lengths -> stream positions (row DPP scans), the
+//    survivor rounds (16 survivors of each query per round), the emit (one exact-table slot of each query per pass, its 16 reference lanes
+//    in the group's lanes), the table clears -- a quarter of the per-query cost;
+//  * per QUERY of the quad, wave-parallel as in k_prefilter_cw: the list ends of the query become seven scalars (v_readlane from its
+//    group), a row of 64 stream positions finds its list with a compare + add per boundary, the two looks at the records are the
+//    list-mask slots of k_prefilter_cw (1 024 byte slots per query for up to 8 lists, OR instead of ADD, positions beyond the stream
+//    repeat its last record), the records of the first R rows stay in registers between the looks.
+// For lists per query <= 16 (MODE 0: <= 8, byte slots; MODE 1: halfword slots); longer plans keep k_prefilter_cw<2>.  BIG = 1: the second
+// pass over queries whose survivors overflowed the 32-slot exact table of the first, with four times the slots and the table.
+// ------------------------------------------------------------------------------------------------
+template <int MODE, int BIG>
+__global__ __launch_bounds__(64) void k_prefilter_cq(
+		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
+		const uint32_t *__restrict__ ent,   // 4-byte (clump, lane-set code) records
+		const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ clump_len, uint32_t tot_refs,
+		uint2 *__restrict__ tasks, uint32_t *__restrict__ n_tasks, uint32_t task_cap,
+		unsigned long long *__restrict__ ent_read,
+		uint32_t *__restrict__ fb_list, uint32_t *__restrict__ n_fb,
+		unsigned long long *__restrict__ unit_sum, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum,
+		unsigned long long *__restrict__ surv_sum,
+		uint2 *__restrict__ tasks2, uint32_t *__restrict__ n_tasks2, int prune,
+		const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel_dev, int) {
+	constexpr uint32_t FB = MODE == 0 ? 8u : 16u;                         // bits per slot
+	constexpr uint32_t SB = MODE == 0 ? 2u : 1u;                          // log2 slots per dword
+	constexpr uint32_t NDW = BIG ? 1024u : 256u;                          // dwords of slots per query: 1 KB (4 KB)
+	constexpr uint32_t NS = NDW << SB;                                    // slots per query
+	constexpr uint32_t LTB = BIG ? 7u : 5u, LT = 1u << LTB;               // exact lane-table slots per query
+	constexpr uint32_t RING = 64u;                                        // survivors of a query waiting for the rounds at the end of the quad (a power of two, >= one row)
+	constexpr uint32_t CQ_STAGE = 64u;
+	constexpr uint32_t R = 6u;                                            // rows of 64 records of a query that stay in registers between the two looks
+	__shared__ __attribute__((aligned(16))) uint32_t s_cnt[4][NDW];
+	__shared__ uint32_t s_key[4][LT];
+	__shared__ unsigned long long s_lc[4][LT][2];
+	__shared__ uint32_t s_ring[4][RING];
+	__shared__ uint16_t s_lut[256];
+	__shared__ uint8_t s_used[4][LT];
+	__shared__ uint2 s_stage[2][CQ_STAGE];
+	__shared__ uint32_t s_dummy[16];          // compare-and-swap target of idle lanes (never written: the compare value cannot match)
+	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15u;
+	if (lane < 16) s_dummy[lane] = 0;
+	for (uint32_t i = lane; i < 256; i += 64) s_lut[i] = (uint16_t)bhip_lane_code_mask(i);
+	for (uint32_t i = lane; i < 4 * NDW; i += 64) (&s_cnt[0][0])[i] = 0;
+	for (uint32_t i = lane; i < 4 * LT; i += 64) { (&s_key[0][0])[i] = 0; (&s_lc[0][0][0])[2 * i] = 0; (&s_lc[0][0][0])[2 * i + 1] = 0; }
+	__syncthreads();
+	uint32_t my_ent = 0, my_units = 0, my_qlen = 0, my_surv = 0;         // (per wave and launch: well inside 32 bits)
+	const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#ifdef PFM_PROF
+	unsigned long long my_t[8] = {0,0,0,0,0,0,0,0}, t_last = wall_clock64();      // 0 addresses + load issue, 1 first look (waits for the records), 2 second look, 3 survivor rounds, 4 emit, 5 clear, 6 quad setup
+#endif
+	uint32_t nst[2] = {0u, 0u};
+	auto flush_one = [&](uint32_t which) {
+		const uint32_t n = nst[which];
+		if (n) {
+			uint32_t base = 0;
+			if (lane == 0) base = atomicAdd(which ? n_tasks2 : n_tasks, n);
+			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+			uint2 *dst = which ? tasks2 : tasks;
+			if (lane < n && base + lane < task_cap) dst[base + lane] = s_stage[which][lane];
+			CF_WAVE_ORDER();
+		}
+		nst[which] = 0;
+	};
+	auto put = [&](uint32_t which, bool mine, uint32_t a, uint32_t b) {      // wave-uniform call; `mine`: this lane has a task for list `which`
+		const unsigned long long m = __ballot(mine);
+		const uint32_t cnt = (uint32_t)__popcll(m);
+		if (!cnt) return;
+		if (nst[which] + cnt > CQ_STAGE) flush_one(which);
+		if (mine) s_stage[which][nst[which] + (uint32_t)__popcll(m & lt_mask)] = make_uint2(a, b);
+		nst[which] += cnt;
+	};
+	auto group_scan = [&](uint32_t n) -> uint32_t {                       // inclusive prefix sum inside each group of 16 lanes
+		int ps = (int)n;
+		ps += __builtin_amdgcn_update_dpp(0, ps, 0x111, 0xF, 0xF, false);    // row_shr:1 (a row = the 16 lanes of a group; lanes without a source add 0)
+		ps += __builtin_amdgcn_update_dpp(0, ps, 0x112, 0xF, 0xF, false);
+		ps += __builtin_amdgcn_update_dpp(0, ps, 0x114, 0xF, 0xF, false);
+		ps += __builtin_amdgcn_update_dpp(0, ps, 0x118, 0xF, 0xF, false);
+		return (uint32_t)ps;
+	};
+	auto group_max = [&](uint32_t v) -> uint32_t {                        // maximum over the 16 lanes of the group, in every lane
+		int t;
+		t = __builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;     // quad_perm:[1,0,3,2]
+		t = __builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;     // quad_perm:[2,3,0,1]
+		t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;    // row_half_mirror
+		t = __builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;    // row_mirror
+		return v;
+	};
+	auto wave_max4 = [&](uint32_t v) -> uint32_t {                        // maximum over the four groups of a group-uniform value
+		const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
+			c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+		const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+		return ab > cd ? ab : cd;
+	};
+	auto spread4 = [](uint32_t nib) -> uint32_t { return (nib * 0x00204081u) & 0x01010101u; };      // bit i of a nibble -> bit 8 i
+	const uint32_t n_items = sel ? (*n_sel_dev < n_list ? *n_sel_dev : n_list) : n_list;
+	const uint32_t n_quads = (n_items + 3) >> 2;
+	typedef const unsigned long long __attribute__((address_space(1))) *g64_t;
+	auto fetch = [&](uint32_t quad, unsigned long long &h, unsigned long long &r) {      // header of this group's query and range gl of it (clamped: always a valid address)
+		const uint32_t it = quad * 4 + g;
+		const uint32_t itc = it < n_items ? it : 0u;
+		const uint32_t lic = sel ? (n_items ? sel[itc] : 0u) : itc;
+		h = ((g64_t)(uintptr_t)(hdr + lic))[0];
+		r = ((g64_t)(uintptr_t)(ranges + ((size_t)lic * W16 + (gl < W16 ? gl : 0u))))[0];
+	};
+	unsigned long long h_n, r_n;
+	fetch(blockIdx.x, h_n, r_n);
+	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
+		const bool live = quad * 4 + g < n_items;
+		const uint32_t li = sel ? (live ? sel[quad * 4 + g] : 0u) : quad * 4 + g;      // list position of this group's query
+		const uint2 hd = make_uint2((uint32_t)h_n, (uint32_t)(h_n >> 32));
+		const unsigned long long r_c = r_n;
+		fetch(quad + gridDim.x, h_n, r_n);                                // one quad ahead
+		const uint32_t need = hd.x & 0xFFFFu, len = hd.y & 0xFFFu;
+		const uint32_t budget = (hd.y >> 12) & 255u, dper = (hd.y >> 20) & 15u ? (hd.y >> 20) & 15u : 1u;
+		const uint32_t thr = need ? need : 1u;                            // (group-uniform)
+		// ---- the lists of the quad's queries: lane gl of group g = list gl of query g.  eend = end of the list in its query's flattened
+		// stream; ab = biased address: the record at stream position i of the list is at ab + 4 i
+		const uint32_t rx = (uint32_t)r_c, ry = (uint32_t)(r_c >> 32);
+		const uint32_t n0 = (live && gl < W16) ? ry & 0xFFFFFFu : 0u;
+		const unsigned long long beg = (unsigned long long)rx | (unsigned long long)(ry >> 24) << 32;
+		const uint32_t eend = group_scan(n0);
+		const unsigned long long ab = (unsigned long long)(uintptr_t)ent + 4ull * (beg - (unsigned long long)(eend - n0));
+		uint32_t pend[4] = {0u, 0u, 0u, 0u};                              // survivors waiting in the queries' rings (wave-uniform)
+		uint32_t nused = 0, ovf = 0;                                      // slots of this group's lane table in use / table overflow (replicated in the group)
+		// ---- survivor rounds: every group moves up to 16 survivors of its query into its exact lane table
+		auto drain = [&]() {
+			uint32_t pv = g == 0 ? pend[0] : g == 1 ? pend[1] : g == 2 ? pend[2] : pend[3];
+			uint32_t head = 0;
+			while (__any(pv > 0)) {
+				const uint32_t take = pv < 16u ? pv : 16u;
+				const bool active = gl < take;
+				const uint32_t rec = active ? s_ring[g][head + gl] : 0u;
+				const uint32_t clump = rec & 0xFFFFFFu, key = clump + 1u, mask = s_lut[rec >> 24];
+				uint32_t slot = (clump * 0x85EBCA6Bu) >> (32u - LTB);
+				bool act = active, found = false, fresh = false;
+				for (uint32_t probes = 0; __any(act) && probes < LT; ++probes) {
+					const uint32_t old = atomicCAS(act ? &s_key[g][slot] : &s_dummy[gl], act ? 0u : 0xFFFFFFFFu, key);
+					const bool ok = act && (old == 0u || old == key);
+					fresh |= act && old == 0u;
+					found |= ok;
+					act = act && !ok;
+					slot = act ? (slot + 1u) & (LT - 1u) : slot;
+				}
+				const uint32_t m_act = (uint32_t)(__ballot(act) >> (lane & 48u)) & 0xFFFFu;
+				if (m_act) ovf = 1u;
+				const uint32_t m16 = (uint32_t)(__ballot(fresh) >> (lane & 48u)) & 0xFFFFu;
+				if (fresh) s_used[g][nused + __popc(m16 & ((1u << gl) - 1u))] = (uint8_t)slot;
+				nused += __popc(m16);
+				if (found) {
+					const unsigned long long lo = (unsigned long long)spread4((mask >> 4) & 15u) << 32 | spread4(mask & 15u);
+					const unsigned long long hi = (unsigned long long)spread4(mask >> 12) << 32 | spread4((mask >> 8) & 15u);
+					if (lo) atomicAdd(&s_lc[g][slot][0], lo);
+					if (hi) atomicAdd(&s_lc[g][slot][1], hi);
+				}
+				head += take; pv -= take;
+			}
+			pend[0] = pend[1] = pend[2] = pend[3] = 0;
+		};
+		PFM_T(6);
+		// ---- the record streams, query after query, 64 stream positions per row
+		#pragma unroll
+		for (uint32_t q = 0; q < 4; ++q) {
+			const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)eend, (int)(q * 16u + 15u));
+			if (T == 0u) continue;                                        // (wave-uniform)
+			my_ent += T;
+			uint32_t eb[MODE == 0 ? 7 : 15];                              // ends of the query's lists but the last: wave-uniform
+			#pragma unroll
+			for (uint32_t j = 0; j < (MODE == 0 ? 7u : 15u); ++j) eb[j] = (uint32_t)__builtin_amdgcn_readlane((int)eend, (int)(q * 16u + j));
+			const uint32_t thr_q = (uint32_t)__builtin_amdgcn_readlane((int)thr, (int)(q * 16u));
+			const uint32_t rows = (T + 63u) >> 6;
+			auto row_rec = [&](uint32_t r, uint32_t &kreg) -> uint32_t {
+				const uint32_t i = r * 64u + lane;
+				const uint32_t ic = i < T ? i : T - 1u;                   // beyond the stream: its last record once more (OR is idempotent; the second look tests i < T)
+				uint32_t kk = 0;
+				#pragma unroll
+				for (uint32_t j = 0; j < (MODE == 0 ? 7u : 15u); ++j) kk += eb[j] <= ic ? 1u : 0u;      // lists that end at or before the position = its list
+				const uint32_t src = q * 16u + kk;
+				const uint32_t a_lo = (uint32_t)__shfl((int)(uint32_t)ab, (int)src, 64), a_hi = (uint32_t)__shfl((int)(uint32_t)(ab >> 32), (int)src, 64);
+				kreg = kk;
+				return ((bhip_gptr_t)(uintptr_t)(((unsigned long long)a_hi << 32 | a_lo) + 4ull * ic))[0];
+			};
+			auto count1 = [&](uint32_t rec, uint32_t kreg) {             // first look: the record's list leaves its bit in the record's slot
+				atomicOr(&s_cnt[q][(rec & (NS - 1u)) >> SB], 1u << ((rec & ((1u << SB) - 1u)) * FB + kreg));
+			};
+			auto offer1 = [&](uint32_t rec, uint32_t i) {                 // second look: records whose slot names enough lists go to the query's ring
+				const uint32_t f = (s_cnt[q][(rec & (NS - 1u)) >> SB] >> ((rec & ((1u << SB) - 1u)) * FB)) & ((1u << FB) - 1u);
+				const bool surv = (uint32_t)__popc(f) >= thr_q && i < T;
+				const unsigned long long m = __ballot(surv);
+				if (m) {
+					const uint32_t cnt = (uint32_t)__popcll(m);
+					if (pend[q] + cnt > RING) drain();                    // (rare: the rings are drained at the end of every quad)
+					if (surv) s_ring[q][pend[q] + (uint32_t)__popcll(m & lt_mask)] = rec;
+					pend[q] += cnt;
+					my_surv += cnt;
+				}
+			};
+			uint32_t rc[R], kr[R];
+			#pragma unroll
+			for (uint32_t r = 0; r < R; ++r) if (r < rows) rc[r] = row_rec(r, kr[r]);
+			PFM_T(0);
+			#pragma unroll
+			for (uint32_t r = 0; r < R; ++r) if (r < rows) count1(rc[r], kr[r]);
+			for (uint32_t r = R; r < rows; ++r) { uint32_t k; const uint32_t rec = row_rec(r, k); count1(rec, k); }
+			CF_WAVE_ORDER();
+			PFM_T(1);
+			#pragma unroll
+			for (uint32_t r = 0; r < R; ++r) if (r < rows) offer1(rc[r], r * 64u + lane);
+			for (uint32_t r = R; r < rows; ++r) { uint32_t k; const uint32_t rec = row_rec(r, k); offer1(rec, r * 64u + lane); }
+			PFM_T(2);
+		}
+		drain();
+		CF_WAVE_ORDER();
+		PFM_T(3);
+		// ---- emit, one used slot of every query per pass: lane gl of group g = reference lane gl of the slot's clump.  A lane with c
+		// matching words lost (W_valid - c) words, one edit destroys at most `dper` of them: its edit distance is at least
+		// budget - (c - need) / dper.  Unless every hit within budget is wanted, only the lanes with the query's largest count are swept at
+		// once; the others wait for the minimum those produce (k_task_filter).
+		const bool em = live && !ovf;
+		const uint32_t nu = em ? nused : 0u;
+		const uint32_t nu_max = wave_max4(nu);
+		const uint32_t inv_dper = 65536u / dper + 1u;                     // x / dper == (x * inv_dper) >> 16 for x < 256, dper < 16
+		auto look = [&](uint32_t p, uint32_t &slot, uint32_t &c, uint32_t &cz) -> bool {
+			const bool has = p < nu;
+			slot = has ? (uint32_t)s_used[g][p] : 0u;
+			c = s_key[g][slot] - 1u;
+			cz = ((const uint8_t *)&s_lc[g][slot][0])[gl];
+			return has && c * 16u + gl < tot_refs && cz >= thr;
+		};
+		auto emit_pass = [&](uint32_t p, bool ok, uint32_t slot, uint32_t c, uint32_t cz, uint32_t t0) {
+			CF_WAVE_ORDER();
+			if (p < nused && gl < 2u) s_lc[g][slot][gl] = 0;              // (this wave's reads of the slot are done: LDS operations of one wave stay in order)
+			if (p < nused && gl == 2u) s_key[g][slot] = 0;
+			const bool first = ok && (!prune || cz >= t0);
+			uint32_t lb = 0;
+			if (prune) { const uint32_t gain = ((cz - need) * inv_dper) >> 16; lb = gain >= budget ? 0u : budget - gain; }
+			put(0, first, li, c * 16u + gl);
+			put(1, ok && !first, li | lb << 24, c * 16u + gl);
+			const unsigned long long mo = __ballot(ok);
+			const uint32_t m16 = (uint32_t)(mo >> (lane & 48u)) & 0xFFFFu;
+			if (gl == 0 && m16) { ++my_units; my_qlen += len; }            // (per group: summed over the wave at the end)
+		};
+		// (an overflowed table is cleared as a whole below; its used slots must not be emitted)
+		if (nu_max <= 1u) {                                               // the usual case: at most one candidate clump per query
+			uint32_t slot, c, cz;
+			const bool ok = look(0, slot, c, cz);
+			uint32_t t0 = thr;
+			if (prune) { const uint32_t cm = group_max(ok ? cz : 0u); t0 = cm > thr ? cm : thr; }
+			if (nu_max) emit_pass(0, ok, slot, c, cz, t0);
+		} else {
+			uint32_t t0 = thr;
+			if (prune) {
+				uint32_t cmax = 0;
+				for (uint32_t p = 0; p < nu_max; ++p) { uint32_t sl, c, cz; if (look(p, sl, c, cz)) cmax = cz > cmax ? cz : cmax; }
+				const uint32_t cm = group_max(cmax);
+				t0 = cm > thr ? cm : thr;
+			}
+			for (uint32_t p = 0; p < nu_max; ++p) {
+				uint32_t slot, c, cz;
+				const bool ok = look(p, slot, c, cz);
+				emit_pass(p, ok, slot, c, cz, t0);
+			}
+		}
+		for (uint32_t i = 0; i < n_bad; ++i) {                            // burst.c:4136-4138, 4282-4283: every lane of the ambiguous clumps
+			const uint32_t c = bad[i];
+			put(0, em && c * 16u + gl < tot_refs, li, c * 16u + gl);
+			if (em && gl == 0) { ++my_units; my_qlen += len; }
+		}
+		if (__any(ovf != 0u)) {
+			if (ovf) {
+				for (uint32_t i = gl; i < LT; i += 16) { s_key[g][i] = 0; s_lc[g][i][0] = 0; s_lc[g][i][1] = 0; }
+				if (live && gl == 0) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
+			}
+		}
+		PFM_T(4);
+		{
+			uint4 *cz4 = (uint4 *)&s_cnt[0][0];
+			for (uint32_t i = lane; i < 4u * NDW / 4u; i += 64) cz4[i] = make_uint4(0, 0, 0, 0);
+		}
+		CF_WAVE_ORDER();
+		PFM_T(5);
+	}
+	flush_one(0); flush_one(1);
+#ifdef PFM_PROF
+	if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_pfm_prof[i], my_t[i]);
+#endif
+	if (lane == 0) {
+		if (ent_read && my_ent) atomicAdd(ent_read, (unsigned long long)my_ent);
+		if (surv_sum && my_surv) atomicAdd(surv_sum, (unsigned long long)my_surv);
+	}
+	if (my_units) { atomicAdd(unit_sum, (unsigned long long)my_units); atomicAdd(qlen_sum, (unsigned long long)my_qlen); }
+	(void)clump_len; (void)col_sum;
+}
+#define BHIP_INST_PFCQ(M, B) \
+	template __global__ void k_prefilter_cq<M, B>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, \
+		uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *, \
+		uint2 *, uint32_t *, int, const uint32_t *, const uint32_t *, int);
+BHIP_INST_PFCQ(0, 0) BHIP_INST_PFCQ(1, 0) BHIP_INST_PFCQ(0, 1) BHIP_INST_PFCQ(1, 1)
+
 #define BHIP_INST_PFCW(M, B) \
 	template __global__ void k_prefilter_cw<M, B>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, \
 		uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *, \

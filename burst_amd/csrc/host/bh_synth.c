@@ -52,8 +52,11 @@ int bh_synth_refs_range(const char *fasta_out, uint32_t first_base, uint32_t n_b
 	/* every base sequence has a generator of its own (seeded by its number), so the file does not depend on the number of threads:
 	 * blocks of families are made side by side, squeezed together and written in order -- one thread writes block k while the team
 	 * makes block k + 1 (two buffers) */
-	const uint32_t BLK = 32768;
 	const size_t per_fam = (size_t)n_variants * (2 * (size_t)length + 48);
+	/* families per block: 32 768 pairs of 1.4-kb sequences are 190 MB; families of hundreds of variants (the "strains" profile of the
+	 * bench) keep the block near that size */
+	uint32_t BLK = 32768;
+	while (BLK > 64 && (size_t)BLK * per_fam > ((size_t)256 << 20)) BLK >>= 1;
 	char *buf[2] = {malloc((size_t)BLK * per_fam), malloc((size_t)BLK * per_fam)};
 	size_t *used = malloc((size_t)BLK * sizeof(*used)), *at = malloc(((size_t)BLK + 1) * sizeof(*at));      /* piece lengths of the two buffers */
 	if (!buf[0] || !buf[1] || !used || !at) { free(buf[0]); free(buf[1]); free(used); free(at); fclose(o); return bh_set_error(BH_E_OOM, "OOM:synth"); }

@@ -20,7 +20,7 @@ while time.time() - t0 < budget_s:
                q_iupac=float(rng.choice([0, 0, 0.01, 0.03])), K=int(rng.choice([8, 10, 12, 12])), fmt=int(rng.integers(2)), accel=bool(rng.integers(4) > 0),
                all_hits=bool(rng.integers(2)), nq=int(rng.integers(5, 60)),
                stride=int(rng.choice([0, 0, 0, 1, 3, 7, 12, 18])), algo=int(rng.integers(-1, 2)), table=int(rng.choice([0, 0, 9, 10, 11])), reg=int(rng.integers(2)), lanes=int(rng.choice([1, 1, 2, 5])),
-               prune=int(rng.integers(3) > 0), two_stage=int(rng.integers(4) > 0), lane_masks=int(rng.integers(4) > 0), y=int(rng.integers(4) == 0), band=int(rng.integers(4) > 0), oversub=int(rng.choice([1, 2, 2, 5])), cw=int(rng.integers(2)))
+               prune=int(rng.integers(3) > 0), two_stage=int(rng.integers(4) > 0), lane_masks=int(rng.integers(4) > 0), y=int(rng.integers(4) == 0), band=int(rng.integers(4) > 0), oversub=int(rng.choice([1, 2, 2, 5])), cw=int(rng.integers(3)))
     seqs = T.family_db(cfg["seed"], cfg["n_base"], cfg["n_var"], cfg["length"], rate=cfg["rate"], short=cfg["short"], iupac=cfg["db_iupac"])
     if cfg["qlen"] + 10 > min(len(s) for s in seqs):
         cfg["qlen"] = max(20, min(len(s) for s in seqs) - 10)

@@ -45,7 +45,7 @@ def test_one_million_reads_properties(tmp_path_factory):
     assert again.tobytes() == base.tobytes()
     # invariance under the tuning options (independent code paths)
     for opts in ({"lanes": 3}, {"prefilter_table": 10, "rescore_reg": 0}, {"lane_masks": 0}, {"two_stage": 0}, {"prefilter_stride": 6}, {"prune": 0},
-                 {"prefilter_algo": 1}, {"prefilter_algo": 0, "prune": 1}, {"prefilter_cw": 1}, {"prefilter_cw": 0}):
+                 {"prefilter_algo": 1}, {"prefilter_algo": 0, "prune": 1}, {"prefilter_cw": 1}, {"prefilter_cw": 2}, {"prefilter_cw": 0}):
         for k, v in opts.items():
             dev.set_option(k, v)
         if "lanes" in opts:
@@ -84,7 +84,7 @@ def test_one_million_reads_properties(tmp_path_factory):
     dev.close()
 
 
-def _bench_db(read_len, thres, K=12, n_base=3300, n_variants=30):
+def _bench_db(read_len, thres, K=12, n_base=3300, n_variants=30, want_acx=True):
     sys.path.insert(0, ROOT)
     import bench
 
@@ -94,7 +94,8 @@ def _bench_db(read_len, thres, K=12, n_base=3300, n_variants=30):
     a.read_len, a.n_base, a.n_variants, a.ref_len, a.variant_rate, a.id, a.K = read_len, n_base, n_variants, 1400, 0.05, thres, K
     work = os.environ.get("BURST_BENCH_DIR", "/tmp/burst_amd_bench")
     refs, edx, acx, done = bench.build_db(work, a)
-    bench.ensure_acx(edx, acx, K)
+    if want_acx:
+        bench.ensure_acx(edx, acx, K)
     return work, refs, edx, acx
 
 
@@ -142,6 +143,27 @@ def test_reference_binary_parity_at_bench_size():
     lines, out = _scale_diff(200000, dict(env, SD_MODES="CAPITALIST FORAGE", SD_IDS="0.97"))
     assert len(lines) == 2, out[-3000:]
     _check_diff_lines(lines, 200000)
+
+
+def test_deterministic_reference_leg_is_identical_in_every_mode():
+    """The reference's DETERMINISTIC configuration -- one thread, no accelerator: one hit list per query, clumps ascending
+    (burst.c:4344-4476) -- on the bench workload's family database cut to a size its exhaustive path finishes in a minute or two
+    (1 800 references in families of 30, ~340 clumps; 14 us of one core per query and clump): 2 400 reads of 100 symbols on both
+    strands in the three modes whose output depends on the hit-list order, and configs[4]'s shape (800 reads of 320 symbols with IUPAC
+    codes, FORAGE at 95 %).  Where the multi-threaded legs of this file may differ in thread-order-dependent lines (bounded and
+    explained), this one must be IDENTICAL byte for byte: CAPITALIST votes and ties, the ALLPATHS / FORAGE duplicate hunt, the strand merge."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "burst12")):
+        pytest.skip("compiled reference not present")
+    from burst_amd import host
+    for read_len, thres, modes, iupac, edits, n_reads in ((100, 0.97, "CAPITALIST ALLPATHS FORAGE", 0.0, [0, 1, 2, 3], 2400), (320, 0.95, "FORAGE", 0.01, [0, 2, 4, 8, 12], 800)):
+        work, refs, edx, acx = _bench_db(read_len, thres, n_base=60, n_variants=30, want_acx=False)
+        reads = os.path.join(work, "det_reads_l%d.fa" % read_len)
+        if not os.path.exists(reads):
+            host.synth_reads(refs, reads, n_reads, read_len, edits, rc=True, iupac=iupac, seed=91)
+        lines, out = _scale_diff(n_reads, dict(BURST_BENCH_DIR=work, SD_EDX=edx, SD_READS=reads, SD_MODES=modes, SD_IDS=str(thres), SD_EXTRA="-fr", SD_EXHAUSTIVE="1", SD_THREADS="1"))
+        assert len(lines) == len(modes.split()), out[-3000:]
+        for ln in lines:
+            assert "IDENTICAL" in ln, ln
 
 
 def test_configs2_twelve_million_292bp_reads_allpaths():

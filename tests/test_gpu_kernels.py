@@ -301,8 +301,8 @@ def test_ambiguous_words_vote_through_expansions(K, qlen, thres, iupac, z):
     q.flags = np.zeros(q.n, np.uint8)
     exp = {ah: oracle_hits(packed, clump_len, tot, q, lut, ah) for ah in (False, True)}
     assert len(exp[False]) > 40
-    for opts in ({}, {"prefilter_stride": K}, {"prefilter_stride": K, "prefilter_cw": 1 - CW_DEFAULT}, {"prefilter_stride": K, "prefilter_algo": 1}, {"prefilter_stride": K, "lane_masks": 0},
-                 {"prefilter_stride": K, "prefilter_table": 9, "prune": 0}, {"prefilter_stride": K, "prefilter_cw": 1 - CW_DEFAULT, "prune": 0}):
+    for opts in ({}, {"prefilter_stride": K}, {"prefilter_stride": K, "prefilter_cw": 0}, {"prefilter_stride": K, "prefilter_cw": 1}, {"prefilter_stride": K, "prefilter_cw": 2}, {"prefilter_stride": K, "prefilter_algo": 1},
+                 {"prefilter_stride": K, "lane_masks": 0}, {"prefilter_stride": K, "prefilter_table": 9, "prune": 0}, {"prefilter_stride": K, "prefilter_cw": 1, "prune": 0}, {"prefilter_stride": K, "prefilter_cw": 2, "prune": 0}):
         for k, v in opts.items():
             dev.set_option(k, v)
         for all_hits in (False, True):
@@ -337,13 +337,16 @@ def test_tuning_options_do_not_change_results(qlen, stride, thres):
                 dev.set_option("prefilter_table", table)
                 dev.set_option("rescore_reg", reg)
                 dev.set_option("lanes", lanes)
-                dev.set_option("prefilter_cw", int(table == 9 and reg == 1) ^ CW_DEFAULT)      # (the table size is k_prefilter_cf's knob)
+                dev.set_option("prefilter_cw", 0)      # (the table size is k_prefilter_cf's knob)
                 got = dev.align_batch(q, all_hits=False)
                 assert_hits_equal(got, exp)
     dev.set_option("prefilter_cw", CW_DEFAULT)
-    for cw, prune in ((0, 1), (0, 0), (1, 1), (1, 0)):          # both counting-filter kernels, with and without the deferred second sweep
-        dev.set_option("prefilter_cw", cw); dev.set_option("prune", prune)
-        assert_hits_equal(dev.align_batch(q, all_hits=False), exp)
+    for cw, prune in ((0, 1), (0, 0), (1, 1), (1, 0), (2, 1), (2, 0)):          # the three counting-filter kernels, with and without the deferred second sweep
+        for lanes in (1, 3):
+            dev.set_option("lanes", lanes)
+            dev.set_option("prefilter_cw", cw); dev.set_option("prune", prune)
+            assert_hits_equal(dev.align_batch(q, all_hits=False), exp)
+    dev.set_option("lanes", 1)
     dev.set_option("prefilter_cw", CW_DEFAULT); dev.set_option("prune", 1)
     dev.set_option("prefilter_table", 0)
     dev.set_option("rescore_reg", 1)
@@ -418,9 +421,10 @@ def test_prefilter_overflow_paths():
         for table in (9, 11, 0):
             dev.set_option("prefilter_table", table)
             assert_hits_equal(dev.align_batch(q, all_hits=all_hits), exp)
-        # k_prefilter_cw: > 64 surviving clumps overflow the first pass's lane table, > 256 the second pass's (dense fallback)
-        dev.set_option("prefilter_cw", 1)
-        assert_hits_equal(dev.align_batch(q, all_hits=all_hits), exp)
+        # k_prefilter_cw / k_prefilter_cq: > 64 / > 32 surviving clumps overflow the first pass's lane table, > 256 / > 128 the second pass's (dense fallback)
+        for cw in (1, 2):
+            dev.set_option("prefilter_cw", cw)
+            assert_hits_equal(dev.align_batch(q, all_hits=all_hits), exp)
         dev.set_option("prefilter_cw", CW_DEFAULT)
     dev.close()
 
@@ -494,7 +498,8 @@ for fmt in (0, 1):
     for all_hits in (False, True):
         exp = T.oracle_hits(packed, clump_len, tot, q, lut, all_hits)
         assert len(exp) > 40
-        for opts in ({"lane_masks": 1, "prefilter_algo": 0, "prefilter_cw": 0}, {"lane_masks": 1, "prefilter_algo": 0, "prefilter_cw": 1}, {"lane_masks": 1, "prefilter_algo": 1}, {"lane_masks": 0}):
+        for opts in ({"lane_masks": 1, "prefilter_algo": 0, "prefilter_cw": 0}, {"lane_masks": 1, "prefilter_algo": 0, "prefilter_cw": 1}, {"lane_masks": 1, "prefilter_algo": 0, "prefilter_cw": 2},
+                     {"lane_masks": 1, "prefilter_algo": 1}, {"lane_masks": 0}):
             for k, v in opts.items():
                 dev.set_option(k, v)
             got = dev.align_batch(q, all_hits=all_hits)

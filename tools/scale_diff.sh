@@ -16,11 +16,15 @@ EXTRA=${SD_EXTRA:-}
 REFBIN=${SD_REF:-$ROOT/oracle/_ref/burst12}      # DB15 accelerators: SD_REF=oracle/_ref/burst15 SD_HIP_EXTRA="-k 15"
 HIPX=${SD_HIP_EXTRA:-}
 HIPACC=${SD_HIP_ACCEL:-"-a $ACX"}                # burst_hip without the file: SD_HIP_ACCEL="-ad -k 15" (accelerator built on the device)
+REFACC="-a $ACX"; THREADS=${SD_THREADS:-$(nproc)}
+# SD_EXHAUSTIVE=1: both programs without an accelerator; with SD_THREADS=1 that is the reference's DETERMINISTIC configuration (one hit list
+# per query, clumps ascending: bh_report.c) -- every mode must then be identical byte for byte
+if [ "${SD_EXHAUSTIVE:-0}" = 1 ]; then HIPACC=""; REFACC=""; fi
 head -n $((2 * N)) $READS > $W/sd_reads.fa
 secs() { awk -v a=$1 -v b=$2 'BEGIN { printf "%.2f", b - a }'; }
 for MODE in ${SD_MODES:-BEST ALLPATHS}; do
   for ID in $IDS; do
-    T0=$(date +%s.%N); $REFBIN -r $EDX -a $ACX -q $W/sd_reads.fa -o $W/sd_ref.b6 -m $MODE -i $ID $EXTRA -t $(nproc) --noprogress > $W/sd_ref.log 2>&1; T1=$(date +%s.%N)
+    T0=$(date +%s.%N); $REFBIN -r $EDX $REFACC -q $W/sd_reads.fa -o $W/sd_ref.b6 -m $MODE -i $ID $EXTRA -t $THREADS --noprogress > $W/sd_ref.log 2>&1; T1=$(date +%s.%N)
     $ROOT/burst_amd/burst_hip -r $EDX $HIPACC -q $W/sd_reads.fa -o $W/sd_hip.b6 -m $MODE -i $ID $EXTRA $HIPX > $W/sd_hip.log 2>&1; T2=$(date +%s.%N)
     sort $W/sd_ref.b6 > $W/sd_ref.s; sort $W/sd_hip.b6 > $W/sd_hip.s
     NR=$(wc -l < $W/sd_ref.s); NH=$(wc -l < $W/sd_hip.s)
@@ -44,6 +48,6 @@ for MODE in ${SD_MODES:-BEST ALLPATHS}; do
         R="$R; reference lines that are not a placement burst_hip computed: $MISSING; queries reported by only one program: $QD; line counts $NR / $NH"
       fi
     fi
-    echo "$MODE -i $ID: $N reads, $NR reference lines, $NH burst_hip lines: $R   [reference $(secs $T0 $T1) s on $(nproc) threads, burst_hip $(secs $T1 $T2) s, both incl. database load]"
+    echo "$MODE -i $ID: $N reads, $NR reference lines, $NH burst_hip lines: $R   [reference $(secs $T0 $T1) s on $THREADS threads, burst_hip $(secs $T1 $T2) s, both incl. database load]"
   done
 done
