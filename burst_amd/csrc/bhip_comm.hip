@@ -31,6 +31,8 @@ struct Peer {                                      // one rank that lives in thi
 	void *d_counts = nullptr;                      // 2 x (n + 1) x u64: gathered counts, gathered flags
 	void *d_recv = nullptr; size_t recv_cap = 0;   // rank 0
 	uint64_t recv_total = 0;                       // records of the last gather, resident in d_recv
+	uint64_t staged = 0;                           // records put into d_send device to device (bhip_comm_stage_device) since the last gather
+	bool stage_failed = false;
 	bool broken = false;
 };
 struct Comm { int n = 0; std::vector<Peer> local; };
@@ -47,6 +49,17 @@ static bool grow(void **p, size_t *cap, size_t bytes) {
 	const size_t want = bytes + bytes / 8 + 4096;
 	if (hipMalloc(p, want) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
 	*cap = want;
+	return true;
+}
+// the same, keeping the first `keep` bytes
+static bool grow_keep(void **p, size_t *cap, size_t bytes, size_t keep, hipStream_t st) {
+	if (bytes <= *cap) return true;
+	const size_t want = bytes + bytes / 2 + 4096;
+	void *n = nullptr;
+	if (hipMalloc(&n, want) != hipSuccess) { (void)hipGetLastError(); return false; }
+	if (keep && *p && (hipMemcpyAsync(n, *p, keep, hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) { (void)hipGetLastError(); (void)hipFree(n); return false; }
+	if (*p) (void)hipFree(*p);
+	*p = n; *cap = want;
 	return true;
 }
 static int peer_init(Peer &p, int n) {
@@ -128,16 +141,21 @@ static int exchange_word(Comm *C, Peer *P, int which, unsigned long long mine, s
 // Called by the host thread of every rank (all n_ranks calls must be in flight together).  hits / n: the rank's records in
 // host memory.  Rank 0 receives every rank's records, rank order, into out (capacity cap records); counts[n_ranks] gets the
 // per-rank numbers on every rank.  BHIP_E_CAPACITY when out is too small (*n_total is what is needed; nothing is copied).
-extern "C" int bhip_comm_gather_hits(void *comm, int rank, const BhipHit *hits, uint64_t n, BhipHit *out, uint64_t cap, uint64_t *n_total, uint64_t *counts) {
-	Comm *C = (Comm *)comm;
+// staged = true: the rank's n records are in its send buffer already (bhip_comm_stage_device put them there device to device, batch
+// after batch); false: they are uploaded from `hits`
+static int gather_impl(Comm *C, int rank, const BhipHit *hits, bool staged, uint64_t n, BhipHit *out, uint64_t cap, uint64_t *n_total, uint64_t *counts) {
 	Peer *P = peer_of(C, rank);
 	if (!P || !n_total) return bhip_fail_msg(BHIP_E_ARG, "bad gather arguments");
 	*n_total = 0;
 	// 0. local preparation: send buffer + copy (a failure is announced with the count)
 	bool ok = hipSetDevice(P->dev) == hipSuccess;
 	const size_t bytes = (size_t)n * sizeof(BhipHit);
-	ok = ok && (!bytes || hits) && grow(&P->d_send, &P->send_cap, bytes ? bytes : 1);
-	if (ok && bytes) ok = hipMemcpyAsync(P->d_send, hits, bytes, hipMemcpyHostToDevice, P->stream) == hipSuccess;
+	if (staged) ok = ok && !P->stage_failed && P->staged == n && (!bytes || (P->d_send && P->send_cap >= bytes));
+	else {
+		ok = ok && (!bytes || hits) && grow(&P->d_send, &P->send_cap, bytes ? bytes : 1);
+		if (ok && bytes) ok = hipMemcpyAsync(P->d_send, hits, bytes, hipMemcpyHostToDevice, P->stream) == hipSuccess;
+	}
+	P->staged = 0; P->stage_failed = false;
 	if (!ok) (void)hipGetLastError();
 	// 1. everybody learns everybody's count
 	std::vector<unsigned long long> hc;
@@ -180,6 +198,38 @@ extern "C" int bhip_comm_gather_hits(void *comm, int rank, const BhipHit *hits, 
 	if (rank == 0) P->recv_total = total;
 	if (!fits) return bhip_fail_msg(BHIP_E_CAPACITY, "record buffer holds %llu records, %llu needed", (unsigned long long)cap, (unsigned long long)total);
 	return BHIP_OK;
+}
+extern "C" int bhip_comm_gather_hits(void *comm, int rank, const BhipHit *hits, uint64_t n, BhipHit *out, uint64_t cap, uint64_t *n_total, uint64_t *counts) {
+	return gather_impl((Comm *)comm, rank, hits, false, n, out, cap, n_total, counts);
+}
+// The records of the handle's LAST alignment call (still resident on its device) into the rank's send buffer, behind the
+// `first_record` records staged before: device to device, no second trip over PCIe.  A failure (memory) is remembered and makes
+// bhip_comm_gather_staged report this rank as failed -- the caller then falls back on bhip_comm_gather_hits for everybody.
+extern "C" int bhip_comm_stage_device(void *comm, int rank, void *handle, uint64_t first_record, uint64_t *n_records) {
+	Comm *C = (Comm *)comm;
+	Peer *P = peer_of(C, rank);
+	if (!P || !handle) return bhip_fail_msg(BHIP_E_ARG, "bad staging arguments");
+	if (first_record != P->staged) { P->stage_failed = true; return bhip_fail_msg(BHIP_E_ARG, "records staged out of order (%llu staged, batch starts at %llu)", (unsigned long long)P->staged, (unsigned long long)first_record); }
+	uint64_t n = 0;
+	int rc = bhip_copy_hits_device(handle, nullptr, 0, &n);      // (how many)
+	if (rc && rc != BHIP_E_CAPACITY) { P->stage_failed = true; return rc; }
+	if (hipSetDevice(P->dev) != hipSuccess || !grow_keep(&P->d_send, &P->send_cap, (size_t)(first_record + n) * sizeof(BhipHit) + 1, (size_t)first_record * sizeof(BhipHit), P->stream)) {
+		(void)hipGetLastError(); P->stage_failed = true;
+		return bhip_fail_msg(BHIP_E_DEVICE, "no device memory for %llu staged records", (unsigned long long)(first_record + n));
+	}
+	if (n && (rc = bhip_copy_hits_device(handle, (char *)P->d_send + (size_t)first_record * sizeof(BhipHit), n, &n))) { P->stage_failed = true; return rc; }
+	P->staged = first_record + n;
+	if (n_records) *n_records = n;
+	return BHIP_OK;
+}
+// the gather of bhip_comm_gather_hits with the rank's n records taken from its send buffer (staged batch by batch)
+extern "C" int bhip_comm_gather_staged(void *comm, int rank, uint64_t n, BhipHit *out, uint64_t cap, uint64_t *n_total, uint64_t *counts) {
+	return gather_impl((Comm *)comm, rank, nullptr, true, n, out, cap, n_total, counts);
+}
+// forget what has been staged (a search that ends without a gather)
+extern "C" void bhip_comm_stage_reset(void *comm, int rank) {
+	Peer *P = peer_of((Comm *)comm, rank);
+	if (P) { P->staged = 0; P->stage_failed = false; }
 }
 
 // rank 0, after a gather that ended with BHIP_E_CAPACITY: the gathered records are still on its device; this copies them into a

@@ -1960,31 +1960,63 @@ __global__ __launch_bounds__(64) void k_prefilter_cq(
 			pend[0] = pend[1] = pend[2] = pend[3] = 0;
 		};
 		PFM_T(6);
-		// ---- the record streams, query after query, 64 stream positions per row
+		// ---- the record streams, 64 stream positions per row.  The loads of ALL four queries are issued first (their gathers are in flight
+		// together: a wave waits for memory once per quad, not once per query), then the first look over the four queries, then the second.
+		constexpr uint32_t NB = MODE == 0 ? 7u : 15u, KB = MODE == 0 ? 3u : 4u;      // list ends that matter / bits of a list number
+		uint32_t rc[4][R], krp[4];                                        // records of the resident rows, their list numbers (KB bits per row)
+		uint32_t Tq[4];
+		auto row_rec = [&](uint32_t q, uint32_t T, const uint32_t (&eb)[NB], uint32_t r, uint32_t &kreg) -> uint32_t {
+			const uint32_t i = r * 64u + lane;
+			const uint32_t ic = i < T ? i : T - 1u;                       // beyond the stream: its last record once more (OR is idempotent; the second look tests i < T)
+			uint32_t kk = 0;
+			#pragma unroll
+			for (uint32_t j = 0; j < NB; ++j) kk += eb[j] <= ic ? 1u : 0u;          // lists that end at or before the position = its list
+			const uint32_t src = q * 16u + kk;
+			const uint32_t a_lo = (uint32_t)__shfl((int)(uint32_t)ab, (int)src, 64), a_hi = (uint32_t)__shfl((int)(uint32_t)(ab >> 32), (int)src, 64);
+			kreg = kk;
+			return ((bhip_gptr_t)(uintptr_t)(((unsigned long long)a_hi << 32 | a_lo) + 4ull * ic))[0];
+		};
+		auto list_ends = [&](uint32_t q, uint32_t (&eb)[NB]) {           // ends of the query's lists but the last: wave-uniform
+			#pragma unroll
+			for (uint32_t j = 0; j < NB; ++j) eb[j] = (uint32_t)__builtin_amdgcn_readlane((int)eend, (int)(q * 16u + j));
+		};
 		#pragma unroll
 		for (uint32_t q = 0; q < 4; ++q) {
 			const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)eend, (int)(q * 16u + 15u));
+			Tq[q] = T; krp[q] = 0;
 			if (T == 0u) continue;                                        // (wave-uniform)
 			my_ent += T;
-			uint32_t eb[MODE == 0 ? 7 : 15];                              // ends of the query's lists but the last: wave-uniform
-			#pragma unroll
-			for (uint32_t j = 0; j < (MODE == 0 ? 7u : 15u); ++j) eb[j] = (uint32_t)__builtin_amdgcn_readlane((int)eend, (int)(q * 16u + j));
-			const uint32_t thr_q = (uint32_t)__builtin_amdgcn_readlane((int)thr, (int)(q * 16u));
+			uint32_t eb[NB];
+			list_ends(q, eb);
 			const uint32_t rows = (T + 63u) >> 6;
-			auto row_rec = [&](uint32_t r, uint32_t &kreg) -> uint32_t {
-				const uint32_t i = r * 64u + lane;
-				const uint32_t ic = i < T ? i : T - 1u;                   // beyond the stream: its last record once more (OR is idempotent; the second look tests i < T)
-				uint32_t kk = 0;
-				#pragma unroll
-				for (uint32_t j = 0; j < (MODE == 0 ? 7u : 15u); ++j) kk += eb[j] <= ic ? 1u : 0u;      // lists that end at or before the position = its list
-				const uint32_t src = q * 16u + kk;
-				const uint32_t a_lo = (uint32_t)__shfl((int)(uint32_t)ab, (int)src, 64), a_hi = (uint32_t)__shfl((int)(uint32_t)(ab >> 32), (int)src, 64);
-				kreg = kk;
-				return ((bhip_gptr_t)(uintptr_t)(((unsigned long long)a_hi << 32 | a_lo) + 4ull * ic))[0];
-			};
-			auto count1 = [&](uint32_t rec, uint32_t kreg) {             // first look: the record's list leaves its bit in the record's slot
-				atomicOr(&s_cnt[q][(rec & (NS - 1u)) >> SB], 1u << ((rec & ((1u << SB) - 1u)) * FB + kreg));
-			};
+			#pragma unroll
+			for (uint32_t r = 0; r < R; ++r) if (r < rows) { uint32_t kr; rc[q][r] = row_rec(q, T, eb, r, kr); krp[q] |= kr << (KB * r); }
+		}
+		PFM_T(0);
+		auto count1 = [&](uint32_t q, uint32_t rec, uint32_t kreg) {     // first look: the record's list leaves its bit in the record's slot
+			atomicOr(&s_cnt[q][(rec & (NS - 1u)) >> SB], 1u << ((rec & ((1u << SB) - 1u)) * FB + kreg));
+		};
+		#pragma unroll
+		for (uint32_t q = 0; q < 4; ++q) {
+			const uint32_t T = Tq[q];
+			if (T == 0u) continue;
+			const uint32_t rows = (T + 63u) >> 6;
+			#pragma unroll
+			for (uint32_t r = 0; r < R; ++r) if (r < rows) count1(q, rc[q][r], (krp[q] >> (KB * r)) & ((1u << KB) - 1u));
+			if (rows > R) {                                               // (streams beyond R rows: loaded where they are looked at, twice)
+				uint32_t eb[NB];
+				list_ends(q, eb);
+				for (uint32_t r = R; r < rows; ++r) { uint32_t kr; const uint32_t rec = row_rec(q, T, eb, r, kr); count1(q, rec, kr); }
+			}
+		}
+		CF_WAVE_ORDER();
+		PFM_T(1);
+		#pragma unroll
+		for (uint32_t q = 0; q < 4; ++q) {
+			const uint32_t T = Tq[q];
+			if (T == 0u) continue;
+			const uint32_t rows = (T + 63u) >> 6;
+			const uint32_t thr_q = (uint32_t)__builtin_amdgcn_readlane((int)thr, (int)(q * 16u));
 			auto offer1 = [&](uint32_t rec, uint32_t i) {                 // second look: records whose slot names enough lists go to the query's ring
 				const uint32_t f = (s_cnt[q][(rec & (NS - 1u)) >> SB] >> ((rec & ((1u << SB) - 1u)) * FB)) & ((1u << FB) - 1u);
 				const bool surv = (uint32_t)__popc(f) >= thr_q && i < T;
@@ -1997,71 +2029,95 @@ __global__ __launch_bounds__(64) void k_prefilter_cq(
 					my_surv += cnt;
 				}
 			};
-			uint32_t rc[R], kr[R];
 			#pragma unroll
-			for (uint32_t r = 0; r < R; ++r) if (r < rows) rc[r] = row_rec(r, kr[r]);
-			PFM_T(0);
-			#pragma unroll
-			for (uint32_t r = 0; r < R; ++r) if (r < rows) count1(rc[r], kr[r]);
-			for (uint32_t r = R; r < rows; ++r) { uint32_t k; const uint32_t rec = row_rec(r, k); count1(rec, k); }
-			CF_WAVE_ORDER();
-			PFM_T(1);
-			#pragma unroll
-			for (uint32_t r = 0; r < R; ++r) if (r < rows) offer1(rc[r], r * 64u + lane);
-			for (uint32_t r = R; r < rows; ++r) { uint32_t k; const uint32_t rec = row_rec(r, k); offer1(rec, r * 64u + lane); }
-			PFM_T(2);
+			for (uint32_t r = 0; r < R; ++r) if (r < rows) offer1(rc[q][r], r * 64u + lane);
+			if (rows > R) {
+				uint32_t eb[NB];
+				list_ends(q, eb);
+				for (uint32_t r = R; r < rows; ++r) { uint32_t kr; const uint32_t rec = row_rec(q, T, eb, r, kr); offer1(rec, r * 64u + lane); }
+			}
 		}
+		PFM_T(2);
 		drain();
 		CF_WAVE_ORDER();
 		PFM_T(3);
-		// ---- emit, one used slot of every query per pass: lane gl of group g = reference lane gl of the slot's clump.  A lane with c
-		// matching words lost (W_valid - c) words, one edit destroys at most `dper` of them: its edit distance is at least
+		// ---- emit the lanes that reach the threshold, clear the tables.  Slot-parallel, as in k_prefilter_cf: lane gl of a group owns the
+		// group's gl-th used slot (most used slots are false survivors without a single passing lane: a byte-parallel compare says so at
+		// once).  The positions of a lane's tasks in the two staged lists come from ONE wave-wide prefix sum over the per-lane counts.
+		// A lane with c matching words lost (W_valid - c) words, one edit destroys at most `dper` of them: its edit distance is at least
 		// budget - (c - need) / dper.  Unless every hit within budget is wanted, only the lanes with the query's largest count are swept at
 		// once; the others wait for the minimum those produce (k_task_filter).
 		const bool em = live && !ovf;
 		const uint32_t nu = em ? nused : 0u;
 		const uint32_t nu_max = wave_max4(nu);
 		const uint32_t inv_dper = 65536u / dper + 1u;                     // x / dper == (x * inv_dper) >> 16 for x < 256, dper < 16
-		auto look = [&](uint32_t p, uint32_t &slot, uint32_t &c, uint32_t &cz) -> bool {
-			const bool has = p < nu;
-			slot = has ? (uint32_t)s_used[g][p] : 0u;
-			c = s_key[g][slot] - 1u;
-			cz = ((const uint8_t *)&s_lc[g][slot][0])[gl];
-			return has && c * 16u + gl < tot_refs && cz >= thr;
+		auto lanes_ge = [&](unsigned long long lo, unsigned long long hi, uint32_t t) -> uint32_t {      // 16-bit set of the slot's lane counters >= t (t < 128)
+			const unsigned long long H = 0x8080808080808080ull, L1 = 0x0101010101010101ull, G = 0x0102040810204080ull;
+			const unsigned long long tl = ((lo | H) - t * L1) & H, th = ((hi | H) - t * L1) & H;
+			return (uint32_t)(((tl >> 7) * G) >> 56) | ((uint32_t)(((th >> 7) * G) >> 56) << 8);
 		};
-		auto emit_pass = [&](uint32_t p, bool ok, uint32_t slot, uint32_t c, uint32_t cz, uint32_t t0) {
-			CF_WAVE_ORDER();
-			if (p < nused && gl < 2u) s_lc[g][slot][gl] = 0;              // (this wave's reads of the slot are done: LDS operations of one wave stay in order)
-			if (p < nused && gl == 2u) s_key[g][slot] = 0;
-			const bool first = ok && (!prune || cz >= t0);
-			uint32_t lb = 0;
-			if (prune) { const uint32_t gain = ((cz - need) * inv_dper) >> 16; lb = gain >= budget ? 0u : budget - gain; }
-			put(0, first, li, c * 16u + gl);
-			put(1, ok && !first, li | lb << 24, c * 16u + gl);
-			const unsigned long long mo = __ballot(ok);
-			const uint32_t m16 = (uint32_t)(mo >> (lane & 48u)) & 0xFFFFu;
-			if (gl == 0 && m16) { ++my_units; my_qlen += len; }            // (per group: summed over the wave at the end)
+		auto lanes_ge_any = [&](unsigned long long lo, unsigned long long hi, uint32_t t) -> uint32_t {
+			if (t < 128u) return lanes_ge(lo, hi, t);
+			uint32_t m16 = 0;
+			#pragma unroll
+			for (uint32_t zz = 0; zz < 16; ++zz) m16 |= ((uint32_t)(((zz < 8 ? lo : hi) >> (8 * (zz & 7))) & 255u) >= t ? 1u : 0u) << zz;
+			return m16;
 		};
-		// (an overflowed table is cleared as a whole below; its used slots must not be emitted)
-		if (nu_max <= 1u) {                                               // the usual case: at most one candidate clump per query
-			uint32_t slot, c, cz;
-			const bool ok = look(0, slot, c, cz);
-			uint32_t t0 = thr;
-			if (prune) { const uint32_t cm = group_max(ok ? cz : 0u); t0 = cm > thr ? cm : thr; }
-			if (nu_max) emit_pass(0, ok, slot, c, cz, t0);
-		} else {
-			uint32_t t0 = thr;
-			if (prune) {
-				uint32_t cmax = 0;
-				for (uint32_t p = 0; p < nu_max; ++p) { uint32_t sl, c, cz; if (look(p, sl, c, cz)) cmax = cz > cmax ? cz : cmax; }
-				const uint32_t cm = group_max(cmax);
-				t0 = cm > thr ? cm : thr;
+		auto look = [&](uint32_t iu, uint32_t &slot, uint32_t &c, unsigned long long &lo, unsigned long long &hi) -> uint32_t {
+			const bool has = iu < nu;
+			slot = has ? (uint32_t)s_used[g][iu] : 0u;
+			c = s_key[g][slot] - 1u; lo = s_lc[g][slot][0]; hi = s_lc[g][slot][1];
+			const uint32_t first = c * 16u, nv = first < tot_refs ? (tot_refs - first < 16u ? tot_refs - first : 16u) : 0u;     // lanes of the clump that exist
+			return has ? lanes_ge_any(lo, hi, thr) & ((1u << nv) - 1u) : 0u;
+		};
+		auto byte_of = [&](unsigned long long lo, unsigned long long hi, uint32_t zz) -> uint32_t { return (uint32_t)((zz < 8 ? lo : hi) >> (8u * (zz & 7u))) & 255u; };
+		uint32_t slot0, c0; unsigned long long lo0, hi0;
+		const uint32_t m16_0 = look(gl, slot0, c0, lo0, hi0);
+		uint32_t cmax_all = 0;
+		if (prune) {
+			uint32_t cmax = 0;
+			for (uint32_t m = m16_0; m; m &= m - 1) { const uint32_t v = byte_of(lo0, hi0, (uint32_t)__builtin_ctz(m)); cmax = v > cmax ? v : cmax; }
+			for (uint32_t iu0 = 16; iu0 < nu_max; iu0 += 16) {
+				uint32_t sl, c; unsigned long long lo, hi;
+				for (uint32_t m = look(iu0 + gl, sl, c, lo, hi); m; m &= m - 1) { const uint32_t v = byte_of(lo, hi, (uint32_t)__builtin_ctz(m)); cmax = v > cmax ? v : cmax; }
 			}
-			for (uint32_t p = 0; p < nu_max; ++p) {
-				uint32_t slot, c, cz;
-				const bool ok = look(p, slot, c, cz);
-				emit_pass(p, ok, slot, c, cz, t0);
+			cmax_all = group_max(cmax);
+		}
+		auto emit_slots = [&](uint32_t iu, uint32_t slot, uint32_t c, unsigned long long lo, unsigned long long hi, uint32_t m16) {
+			if (iu < nused) { s_key[g][slot] = 0; s_lc[g][slot][0] = 0; s_lc[g][slot][1] = 0; }     // (this wave's reads of the slot are done: LDS operations of one wave stay in order)
+			const uint32_t m0 = prune ? m16 & lanes_ge_any(lo, hi, cmax_all > thr ? cmax_all : thr) : m16, m1 = m16 & ~m0;
+			const uint32_t cnt = (uint32_t)__popc(m0) | (uint32_t)__popc(m1) << 16;
+			const uint32_t incl = wave_incl_scan_u32(cnt), tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), excl = incl - cnt;
+			if (!tot) return;                         // wave-uniform
+			const uint32_t tot0 = tot & 0xFFFFu, tot1 = tot >> 16;
+			uint32_t p[2]; bool direct[2];
+			#pragma unroll
+			for (uint32_t w = 0; w < 2; ++w) {
+				const uint32_t tw = w ? tot1 : tot0, ew = w ? excl >> 16 : excl & 0xFFFFu;
+				direct[w] = false;
+				if (tw && nst[w] + tw > CQ_STAGE) flush_one(w);
+				if (tw > CQ_STAGE) {                  // more than the stage holds in one go: straight to the list
+					uint32_t base = 0;
+					if (lane == 0) base = atomicAdd(w ? n_tasks2 : n_tasks, tw);
+					p[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + ew; direct[w] = true;
+				} else { p[w] = nst[w] + ew; nst[w] += tw; }
 			}
+			for (uint32_t m = m16; m; m &= m - 1) {
+				const uint32_t zz = (uint32_t)__builtin_ctz(m), w = (m1 >> zz) & 1u;
+				uint32_t lb = 0;
+				if (prune) { const uint32_t gain = ((byte_of(lo, hi, zz) - need) * inv_dper) >> 16; lb = gain >= budget ? 0u : budget - gain; }
+				const uint2 task = make_uint2(li | lb << 24, c * 16u + zz);
+				const uint32_t pos = p[w]; p[w] = pos + 1;
+				if (direct[w]) { if (pos < task_cap) (w ? tasks2 : tasks)[pos] = task; }
+				else s_stage[w][pos] = task;
+			}
+			if (m16) { ++my_units; my_qlen += len; }       // (the swept columns of lane tasks are counted by the sweep: tcol_sum)
+		};
+		if (nu_max) emit_slots(gl, slot0, c0, lo0, hi0, m16_0);
+		for (uint32_t iu0 = 16; iu0 < nu_max; iu0 += 16) {
+			uint32_t sl, c; unsigned long long lo, hi;
+			const uint32_t m16 = look(iu0 + gl, sl, c, lo, hi);
+			emit_slots(iu0 + gl, sl, c, lo, hi, m16);
 		}
 		for (uint32_t i = 0; i < n_bad; ++i) {                            // burst.c:4136-4138, 4282-4283: every lane of the ambiguous clumps
 			const uint32_t c = bad[i];

@@ -250,6 +250,7 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 			if (r) { rc = bh_set_error(BH_E_DEVICE, "libburst_hip: %s", bhip_last_error()); break; }
 			if (sc.rc) { rc = sc.rc; break; }
 			if (sc.hook_next) { STAGE(sc.hook_next); sc.hook_next = 0; if (rc) break; }      /* (the hook did not run: a call that only delivered resident records) */
+			if (run->onBatch) run->onBatch(run->onBatchCtx, hh, nHits, n);      /* (the batch's records are still resident on the device) */
 			nHits += n;
 			if (k == 0 && nBatches > 2) STAGE((uint64_t)2);      /* (the third batch only now: see the note at the loop) */
 			BhipStats st;

@@ -11,6 +11,7 @@
 #include <pthread.h>
 #include <unistd.h>
 #include <sys/stat.h>
+#include <sys/mman.h>
 
 static void *own(BhDb *db, void *p) {      /* a full table does not lose track of the block: it is given back and the caller sees an allocation failure */
 	if (p && db->nOwned >= 32) { free(p); return NULL; }
@@ -21,6 +22,7 @@ static void *own(BhDb *db, void *p) {      /* a full table does not lose track o
 void bh_db_free(BhDb *db) {
 	if (!db) return;
 	for (int i = 0; i < db->nOwned; ++i) free(db->owned[i]);
+	if (db->mapBase) munmap(db->mapBase, (size_t)db->mapLen);
 	memset(db, 0, sizeof *db);
 }
 
@@ -96,10 +98,37 @@ int bh_edx_read(const char *path, BhDb *db) {
 		words += db->clumpLen[i] / 2u + (db->clumpLen[i] & 1);
 	}
 	db->maxLenR = maxL;
-	ALLOC(db->packed, (words + 1) * 16);
-	if (words * 16 < (64u << 20)) RD(db->packed, 16, words);
-	else if (read_region(path, (uint64_t)ftello(in), db->packed, words * 16)) {      /* gigabytes: several threads copy out of the page cache */
-		fclose(in); bh_db_free(db); return bh_set_error(BH_E_USAGE, "ERROR: truncated database %s", path);
+	/* The clump area.  Gigabytes of it are MAPPED, not copied: the file's pages (page cache, or RAM itself when the file lies in /dev/shm)
+	 * are this process's copy and every other process's that reads the same database -- the ranks of a node, one process per GPU, used to
+	 * hold one 31.5 GB copy each.  The upload reads it once, front to back.  BURST_HOST_EDX_COPY=1: the private copy of rounds 1-4. */
+	const uint64_t at = (uint64_t)ftello(in);
+	int mapped = 0;
+	if (words * 16 >= (64u << 20) && !(getenv("BURST_HOST_EDX_COPY") && atoi(getenv("BURST_HOST_EDX_COPY")))) {
+		struct stat st;
+		const long pg = sysconf(_SC_PAGESIZE);
+		if (!fstat(fileno(in), &st) && (uint64_t)st.st_size >= at + words * 16 && pg > 0) {
+			const uint64_t a0 = at & ~((uint64_t)pg - 1);
+			void *m = mmap(NULL, (size_t)(at + words * 16 - a0), PROT_READ, MAP_SHARED, fileno(in), (off_t)a0);
+			if (m != MAP_FAILED) {
+				db->mapBase = m; db->mapLen = at + words * 16 - a0;
+				db->packed = (uint8_t *)m + (at - a0);
+				(void)madvise(m, (size_t)db->mapLen, MADV_WILLNEED);
+				/* the page-table entries now, by a team: the upload's copy thread would otherwise take 8 M page faults one by one */
+				const uint64_t np = (db->mapLen + (uint64_t)pg - 1) / (uint64_t)pg;
+				uint64_t sum = 0;
+				#pragma omp parallel for schedule(static) reduction(+:sum) num_threads(omp_get_max_threads() > 16 ? 16 : omp_get_max_threads())
+				for (uint64_t i = 0; i < np; ++i) sum += ((volatile const uint8_t *)m)[i * (uint64_t)pg];
+				db->mapLen += sum & 0;      /* (keeps the reads) */
+				mapped = 1;
+			}
+		}
+	}
+	if (!mapped) {
+		ALLOC(db->packed, (words + 1) * 16);
+		if (words * 16 < (64u << 20)) RD(db->packed, 16, words);
+		else if (read_region(path, at, db->packed, words * 16)) {      /* gigabytes: several threads copy out of the page cache */
+			fclose(in); bh_db_free(db); return bh_set_error(BH_E_USAGE, "ERROR: truncated database %s", path);
+		}
 	}
 	db->packedWords = words;
 	(void)hasFP;   /* fingerprint tables, if any, follow and are ignored (-f is out of scope) */
@@ -455,11 +484,14 @@ int bh_edx_write(const BhDb *db, const char *path, long db_qlen, float thres) {
 
 /* Several .edx files -> one, section by section (no chunk is ever held in memory): the databases are laid end to end -- headers,
  * reference maps (shifted by the headers in front), fragment starts, sort permutations (shifted by the fragments in front), clump
- * lengths, clump areas.  What makes that a valid database: reference number = 16 * clump + lane, so every part but the last must
- * fill its last clump (totR a multiple of 16), and no part may carry duplicate-fragment tables (totR == origTotR).  For databases
- * too large to be BUILT in one piece in the host memory at hand (bench.py: the metric's 31.5 GB stand-in in a 300 GB container);
- * each part is what -d QUICK makes of its share of the references.  No reference counterpart. */
-typedef struct EdxHead { uint8_t ctrl; uint64_t hl; uint32_t shear, totR, origTotR, numRclumps, maxLenR, nH; uint64_t off_heads, off_map, off_start, off_rix, off_clen, off_packed, words; } EdxHead;
+ * lengths, clump areas.  Reference number = 16 * clump + lane, so a part that does not fill its last clump leaves lanes of padding
+ * in the middle of the merged database: those, and parts that carry duplicate-fragment tables (totR != origTotR: strain-level
+ * redundancy, bench.py --db-profile strains), are expressed through the merged file's own RefDedupIx -- a padding lane is a unique
+ * reference with NO original (an empty range; its symbols are pads, nothing aligns to it), a part without a table contributes the
+ * identity.  Without either the merged file has no table, as before.  For databases too large to be BUILT in one piece in the
+ * host memory at hand (bench.py: the metric's 31.5 GB stand-in in a 300 GB container); each part is what -d QUICK makes of its
+ * share of the references.  No reference counterpart. */
+typedef struct EdxHead { uint8_t ctrl; uint64_t hl; uint32_t shear, totR, origTotR, numRclumps, maxLenR, nH; uint64_t off_heads, off_map, off_start, off_dedup, off_rix, off_clen, off_packed, words; } EdxHead;
 static int edx_head(const char *path, EdxHead *h) {
 	FILE *f = fopen(path, "rb");
 	if (!f) return bh_set_error(BH_E_IO, "cannot read %s", path);
@@ -470,11 +502,12 @@ static int edx_head(const char *path, EdxHead *h) {
 	h->off_map = h->off_heads + h->hl + 4;
 	const int rebase = (h->ctrl >> 6) & 1;
 	h->off_start = h->off_map + 4ull * h->origTotR;
-	h->off_rix = h->off_start + (rebase ? 4ull * h->origTotR : 0);
+	h->off_dedup = h->off_start + (rebase ? 4ull * h->origTotR : 0);
+	h->off_rix = h->off_dedup + (h->totR != h->origTotR ? 4ull * ((uint64_t)h->totR + 1) : 0);      /* RefDedupIx[totR + 1] only in databases with duplicates (burst.c:2911-2916) */
 	h->off_clen = h->off_rix + 4ull * h->origTotR;
 	h->off_packed = h->off_clen + 4ull * h->numRclumps;
 	h->words = 0;
-	if (ok && h->totR == h->origTotR) {
+	if (ok) {
 		ok = !fseeko(f, (off_t)h->off_clen, SEEK_SET);
 		uint32_t buf[4096];
 		for (uint32_t c = 0; ok && c < h->numRclumps;) {
@@ -509,26 +542,51 @@ int bh_edx_merge(const char *const *paths, int n, const char *out_path) {
 	if (n < 1 || n > 64) return bh_set_error(BH_E_USAGE, "bad number of databases to merge (%d)", n);
 	EdxHead h[64];
 	uint64_t hl = 0, totR = 0, orig = 0, clumps = 0, nH = 0; uint32_t maxL = 0;
+	int dd = 0;          /* the merged file carries a RefDedupIx: some part has one, or leaves padding lanes in the middle */
 	for (int i = 0; i < n; ++i) {
 		int rc = edx_head(paths[i], &h[i]);
 		if (rc) return rc;
-		if (h[i].totR != h[i].origTotR) return bh_set_error(BH_E_USAGE, "%s holds duplicate fragments (RefDedupIx): such databases cannot be laid end to end", paths[i]);
-		if (i + 1 < n && (h[i].totR & 15u)) return bh_set_error(BH_E_USAGE, "%s does not fill its last clump (%u references): only the last part may end in a partial clump", paths[i], h[i].totR);
+		if (h[i].totR != h[i].origTotR || (i + 1 < n && (h[i].totR & 15u))) dd = 1;
+		if (h[i].numRclumps != (h[i].totR + 15u) / 16u) return bh_set_error(BH_E_USAGE, "%s: %u references in %u clumps", paths[i], h[i].totR, h[i].numRclumps);
 		if (h[i].ctrl != h[0].ctrl || h[i].shear != h[0].shear) return bh_set_error(BH_E_USAGE, "%s was built with other settings than %s", paths[i], paths[0]);
-		hl += h[i].hl; totR += h[i].totR; orig += h[i].origTotR; clumps += h[i].numRclumps; nH += h[i].nH;
+		hl += h[i].hl; orig += h[i].origTotR; clumps += h[i].numRclumps; nH += h[i].nH;
+		totR += i + 1 < n ? 16ull * h[i].numRclumps : h[i].totR;      /* (a part in the middle counts with the padding lanes of its last clump) */
 		if (h[i].maxLenR > maxL) maxL = h[i].maxLenR;
 	}
-	if (totR > 0xFFFFFFFFull || clumps >= (1ull << 24) || nH > 0xFFFFFFFFull) return bh_set_error(BH_E_USAGE, "the merged database would have %lu references in %lu clumps: beyond the format", (unsigned long)totR, (unsigned long)clumps);
+	if (totR > 0xFFFFFFFFull || orig > 0xFFFFFFFFull || clumps >= (1ull << 24) || nH > 0xFFFFFFFFull) return bh_set_error(BH_E_USAGE, "the merged database would have %lu references in %lu clumps: beyond the format", (unsigned long)totR, (unsigned long)clumps);
+	if (dd && totR == orig) return bh_set_error(BH_E_USAGE, "the merged database would have as many unique references as originals: its duplicate table could not be told from none");
 	FILE *o = fopen(out_path, "wb");
 	if (!o) return bh_set_error(BH_E_IO, "ERROR: Cannot open output: %s", out_path);
 	setvbuf(o, NULL, _IOFBF, 8u << 20);
 	const uint32_t totR32 = (uint32_t)totR, orig32 = (uint32_t)orig, cl32 = (uint32_t)clumps, nH32 = (uint32_t)nH;
-	fwrite(&h[0].ctrl, 1, 1, o); fwrite(&hl, 8, 1, o); fwrite(&h[0].shear, 4, 1, o); fwrite(&totR32, 4, 1, o); fwrite(&orig32, 4, 1, o); fwrite(&cl32, 4, 1, o); fwrite(&maxL, 4, 1, o);
 	int rc = BH_OK;
+	if (fwrite(&h[0].ctrl, 1, 1, o) != 1 || fwrite(&hl, 8, 1, o) != 1 || fwrite(&h[0].shear, 4, 1, o) != 1 || fwrite(&totR32, 4, 1, o) != 1 || fwrite(&orig32, 4, 1, o) != 1 ||
+	    fwrite(&cl32, 4, 1, o) != 1 || fwrite(&maxL, 4, 1, o) != 1) rc = bh_set_error(BH_E_IO, "ERROR: write failed: %s", out_path);
 	for (int i = 0; i < n && !rc; ++i) rc = copy_section(o, paths[i], h[i].off_heads, h[i].hl, 0);
-	if (!rc) fwrite(&nH32, 4, 1, o);
+	if (!rc && fwrite(&nH32, 4, 1, o) != 1) rc = bh_set_error(BH_E_IO, "ERROR: write failed: %s", out_path);
 	{ uint64_t hb = 0; for (int i = 0; i < n && !rc; ++i) { rc = copy_section(o, paths[i], h[i].off_map, 4ull * h[i].origTotR, (uint32_t)hb); hb += h[i].nH; } }
 	if ((h[0].ctrl >> 6) & 1) for (int i = 0; i < n && !rc; ++i) rc = copy_section(o, paths[i], h[i].off_start, 4ull * h[i].origTotR, 0);
+	if (dd) {          /* RefDedupIx[totR + 1]: where the originals of unique reference i start in the list of originals below */
+		uint64_t ob = 0;
+		uint32_t *buf = malloc((size_t)(1u << 20) * 4);
+		if (!buf) rc = bh_set_error(BH_E_OOM, "OOM:merge");
+		for (int i = 0; i < n && !rc; ++i) {
+			const uint64_t lanes = i + 1 < n ? 16ull * h[i].numRclumps : h[i].totR;
+			if (h[i].totR != h[i].origTotR) rc = copy_section(o, paths[i], h[i].off_dedup, 4ull * h[i].totR, (uint32_t)ob);
+			else for (uint64_t k = 0; k < h[i].totR && !rc;) {
+				const uint32_t m = h[i].totR - k < (1u << 20) ? (uint32_t)(h[i].totR - k) : (1u << 20);
+				for (uint32_t j = 0; j < m; ++j) buf[j] = (uint32_t)(ob + k + j);
+				if (fwrite(buf, 4, m, o) != m) rc = bh_set_error(BH_E_IO, "ERROR: write failed: %s", out_path);
+				k += m;
+			}
+			ob += h[i].origTotR;
+			const uint32_t end = (uint32_t)ob;          /* padding lanes: no originals */
+			for (uint64_t k = h[i].totR; k < lanes && !rc; ++k) if (fwrite(&end, 4, 1, o) != 1) rc = bh_set_error(BH_E_IO, "ERROR: write failed: %s", out_path);
+		}
+		const uint32_t end = (uint32_t)ob;
+		if (!rc && fwrite(&end, 4, 1, o) != 1) rc = bh_set_error(BH_E_IO, "ERROR: write failed: %s", out_path);
+		free(buf);
+	}
 	{ uint64_t ob = 0; for (int i = 0; i < n && !rc; ++i) { rc = copy_section(o, paths[i], h[i].off_rix, 4ull * h[i].origTotR, (uint32_t)ob); ob += h[i].origTotR; } }
 	for (int i = 0; i < n && !rc; ++i) rc = copy_section(o, paths[i], h[i].off_clen, 4ull * h[i].numRclumps, 0);
 	for (int i = 0; i < n && !rc; ++i) rc = copy_section(o, paths[i], h[i].off_packed, 16ull * h[i].words, 0);

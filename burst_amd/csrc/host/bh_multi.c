@@ -169,6 +169,15 @@ void bh_minima_merge(uint8_t *const *best, int n, uint64_t len) {
 int bh_search_multi(BhMultiRank *R, int n_local, int n_ranks, void *comm, const BhQueries *Q, BhMode mode, uint64_t batch, int shard_db, BhRun *all, uint64_t *counts) {
 	return bh_search_multi_ex(R, n_local, n_ranks, comm, NULL, Q, mode, batch, shard_db, all, counts, NULL);
 }
+/* per-batch hook of a rank's bh_align_ranges (BhRun.onBatch): the batch's records, still resident on the device, into the send buffer of
+ * the RCCL gather.  A failure is remembered by the communicator and announced with the counts of the gather. */
+typedef struct { void *comm; int rank; int failed; } StageCb;
+static void stage_batch_cb(void *ctx, void *hh, uint64_t first, uint64_t n) {
+	StageCb *c = (StageCb *)ctx;
+	uint64_t got = 0;
+	if (bhip_comm_stage_device(c->comm, c->rank, hh, first, &got) || got != n) c->failed = 1;
+}
+
 int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhNode *node, const BhQueries *Q, BhMode mode, uint64_t batch, int shard_db, BhRun *all, uint64_t *counts,
                        BhRunView *view) {
 	/* shard_db = number of database shards S (0 / 1: none).  S < n_ranks: the ranks form n_ranks / S replica groups of S shards each
@@ -210,6 +219,19 @@ int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhN
 		if (node) (void)bh_node_publish(node, &R[0].run, BH_E_INTERNAL);      /* (the peers must not wait for this rank's records) */
 		return bh_set_error(BH_E_INTERNAL, "OpenMP does not grant %d threads (OMP_THREAD_LIMIT?): one host thread per GPU is required", n_local);
 	}
+	/* With the RCCL gather of a query-sharded search the records go from device to device: every batch's records are copied into the
+	 * communicator's send buffer while they are still resident (stage_batch_cb), so that the gather does not upload the host copy again
+	 * (host -> device -> xGMI used to be the first two legs).  Database-sharded searches filter the records on the host first. */
+	int staged_ok[BH_MAX_RANKS]; StageCb scb[BH_MAX_RANKS];
+	for (int i = 0; i < n_local; ++i) {
+		staged_ok[i] = 0;
+		if (comm && !node && !R[i].align && !(shard_db > 1) && !getenv("BURST_HOST_GATHER_UPLOAD")) {
+			scb[i].comm = comm; scb[i].rank = R[i].rank; scb[i].failed = 0;
+			bhip_comm_stage_reset(comm, R[i].rank);
+			R[i].run.onBatch = stage_batch_cb; R[i].run.onBatchCtx = &scb[i];
+			staged_ok[i] = 1;
+		}
+	}
 	/* 1. every rank aligns its share */
 	#pragma omp parallel num_threads(n_local)
 	{
@@ -218,6 +240,7 @@ int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhN
 		const double t0 = omp_get_wtime();
 		rcs[i] = r->align ? r->align(r->ctx, Q, r->r0, r->r1, r->n_ranges, (int)mode, batch, &r->run)
 		                  : bh_align_ranges_reuse(r->hh, Q, r->r0, r->r1, r->n_ranges, mode, batch, &r->run);
+		r->run.onBatch = NULL; r->run.onBatchCtx = NULL;
 		r->secSearch = omp_get_wtime() - t0;
 		if (rcs[i]) snprintf(errs[i], sizeof errs[i], "%s", r->align ? "the rank's align back end failed" : bh_last_error());
 		else if (shard_db > 1) {
@@ -277,7 +300,10 @@ int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhN
 		{
 			const int i = omp_get_thread_num();
 			uint64_t n_total = 0;
-			const int g = bhip_comm_gather_hits(comm, R[i].rank, rcs[i] ? NULL : R[i].run.hits, rcs[i] ? 0 : R[i].run.nHits, i == i0 ? all->hits : NULL,
+			/* the records were staged on the device batch by batch (stage_batch_cb): sent from there; otherwise the host copy goes up again */
+			int g = staged_ok[i] ? bhip_comm_gather_staged(comm, R[i].rank, rcs[i] ? 0 : R[i].run.nHits, i == i0 ? all->hits : NULL, i == i0 ? all->capHits : 0, &n_total, i == i0 ? counts : NULL) : 1;
+			/* (a rank that could not stage -- device memory -- says so with its count: the call fails on every rank, and every rank comes here) */
+			if (g && g != BHIP_E_CAPACITY) g = bhip_comm_gather_hits(comm, R[i].rank, rcs[i] ? NULL : R[i].run.hits, rcs[i] ? 0 : R[i].run.nHits, i == i0 ? all->hits : NULL,
 			                                    i == i0 ? all->capHits : 0, &n_total, i == i0 ? counts : NULL);
 			if (i == i0) need = n_total;
 			if (g == BHIP_E_CAPACITY && i == i0) again = 1;

@@ -55,6 +55,7 @@ typedef struct BhDb {
 	/* bookkeeping */
 	int identityMap;         /* direct-FASTA runs: RefMap is the identity (burst.c:4545-4551) */
 	void *owned[32]; int nOwned;
+	void *mapBase; uint64_t mapLen;      /* the clump area of a large .edx is a read-only mapping of the file (bh_edx_read): the processes of a node share one copy */
 } BhDb;
 
 int  bh_is_edx(const char *path);                       /* burst.c:4894-4901: first byte has bit 7 set; <0 on IO error */
@@ -128,6 +129,10 @@ typedef struct BhRun {
 	uint32_t nBatches;
 	int hitsPinned;                       /* hits is page-locked memory of the device library */
 	uint64_t capHits;                     /* records the buffer holds */
+	/* optional: called after every batch with the device handle (whose records of that batch are still resident) and the batch's place in
+	 * `hits` -- the RCCL gather of bh_search_multi_ex stages the records device to device instead of uploading the host copy again */
+	void (*onBatch)(void *ctx, void *hip_handle, uint64_t first_record, uint64_t n_records);
+	void *onBatchCtx;
 } BhRun;
 /* entry range [e0, e1) of unique queries [u0, u1): forward entries u0..u1-1 and (if numEntries > numUniq) their RC twins
  * are always sent together because they share the running minimum (burst.c:277-280, 4218). */

@@ -24,7 +24,7 @@ class BhDb(C.Structure):
                 ("tmpRIX", u32p), ("refIxSrt", u32p), ("clumpLen", u32p), ("packed", u8p), ("packedWords", C.c_uint64),
                 ("hasAcx", C.c_int), ("K", C.c_int), ("acxFmt", C.c_int), ("acxZ", C.c_int),
                 ("acxLens", u32p), ("acxLists", u8p), ("acxListBytes", C.c_uint64), ("badList", u32p), ("badSz", C.c_uint32),
-                ("identityMap", C.c_int), ("owned", C.c_void_p * 32), ("nOwned", C.c_int)]
+                ("identityMap", C.c_int), ("owned", C.c_void_p * 32), ("nOwned", C.c_int), ("mapBase", C.c_void_p), ("mapLen", C.c_uint64)]
 
 
 class BhQueries(C.Structure):
@@ -36,7 +36,8 @@ class BhQueries(C.Structure):
 
 
 class BhRun(C.Structure):
-    _fields_ = [("hits", C.c_void_p), ("nHits", C.c_uint64), ("secAlign", C.c_double), ("total", capi.BhipStats), ("nBatches", C.c_uint32), ("hitsPinned", C.c_int), ("capHits", C.c_uint64)]
+    _fields_ = [("hits", C.c_void_p), ("nHits", C.c_uint64), ("secAlign", C.c_double), ("total", capi.BhipStats), ("nBatches", C.c_uint32), ("hitsPinned", C.c_int), ("capHits", C.c_uint64),
+                ("onBatch", C.c_void_p), ("onBatchCtx", C.c_void_p)]
 
 
 ALIGN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, u64p, u64p, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(BhRun))

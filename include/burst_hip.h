@@ -190,6 +190,13 @@ BHIP_API int  bhip_comm_create(int n_ranks, const int *devices, void **comm);
 BHIP_API int  bhip_comm_unique_id(void *id128);
 BHIP_API int  bhip_comm_create_rank(int n_ranks, int rank, int device, const void *id128, void **comm);
 BHIP_API int  bhip_comm_gather_hits(void *comm, int rank, const BhipHit *hits, uint64_t n, BhipHit *out, uint64_t cap, uint64_t *n_total, uint64_t *counts);
+/* The same gather fed from the DEVICE: bhip_comm_stage_device after every batch copies the records of the handle's last alignment call
+ * (still resident there) into the rank's send buffer, device to device, behind the `first_record` records staged before;
+ * bhip_comm_gather_staged then sends the n staged records without uploading the host copy again.  A rank whose staging failed makes
+ * the gather fail on every rank (the caller falls back on bhip_comm_gather_hits); bhip_comm_stage_reset forgets what was staged. */
+BHIP_API int  bhip_comm_stage_device(void *comm, int rank, void *handle, uint64_t first_record, uint64_t *n_records);
+BHIP_API int  bhip_comm_gather_staged(void *comm, int rank, uint64_t n, BhipHit *out, uint64_t cap, uint64_t *n_total, uint64_t *counts);
+BHIP_API void bhip_comm_stage_reset(void *comm, int rank);
 BHIP_API int  bhip_comm_fetch_gathered(void *comm, BhipHit *out, uint64_t cap, uint64_t *n_total);      /* rank 0 after BHIP_E_CAPACITY: no collective, the records are still on its device */
 BHIP_API int  bhip_comm_allreduce_min(void *comm, int rank, uint8_t *buf, uint64_t n);
 BHIP_API void bhip_comm_destroy(void *comm);
@@ -279,7 +286,7 @@ BHIP_API void bhip_destroy(void *handle);
 BHIP_API const char *bhip_last_error(void);
 /* ABI version of this header */
 BHIP_API int bhip_abi_version(void);
-#define BHIP_ABI_VERSION 5
+#define BHIP_ABI_VERSION 6
 
 #ifdef __cplusplus
 }

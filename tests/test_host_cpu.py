@@ -260,6 +260,84 @@ def test_database_built_in_parts_is_the_same_set_of_references(tmp_path):
         assert bytes(code[b] for b in src) == seq, (head, st)
 
 
+def test_database_parts_with_duplicate_fragments_and_partial_clumps(tmp_path):
+    """bh_edx_merge on parts that carry duplicate-fragment tables (bench.py --db-profile strains: families of near-identical sequences
+    shear into identical fragments) and do not fill their last clump: the merged file's own RefDedupIx holds the parts' tables, the
+    identity for parts without one and EMPTY ranges for the padding lanes in the middle.  Every unique reference of the merged database
+    resolves to exactly the originals (header, start) whose sequence it is, every original belongs to one unique reference, and the
+    compiled reference reads the file and reports on it what it reports on the parts' union of sequences."""
+    import ctypes as C
+    import subprocess
+    import sys
+    import types
+    import numpy as np
+    sys.path.insert(0, gl.ROOT)
+    import bench
+    from burst_amd import host
+    a = types.SimpleNamespace(read_len=100, n_base=3000, n_variants=2, ref_len=900, variant_rate=0.05, id=0.98, K=12, edits="0,1,2", reads=150, pool=2, iupac=0.0, fr=False,
+                              drop_refs=False, db_profile="strains")
+    old = bench.PART_BASES
+    try:
+        bench.PART_BASES = 1000
+        specs = bench.db_parts(a)
+        assert len(specs) >= 5 and {nv for _, _, nv, _, _ in specs} == {2, 60, 200, 500}
+        _, edx, _, reads, _ = bench.build_inputs(str(tmp_path / "strains"), a, 0)
+    finally:
+        bench.PART_BASES = old
+    db = host.Db.read(edx)
+    totR, orig = int(db.c.totR), int(db.c.origTotR)
+    assert totR < orig and db.c.refDedupIx                     # duplicates exist and are folded
+    dd = host._view(db.c.refDedupIx, totR + 1, np.uint32).astype(np.int64)
+    rix = host._view(db.c.tmpRIX, orig, np.uint32)
+    start = host._view(db.c.refStart, orig, np.uint32)
+    cl = host._view(db.c.clumpLen, db.c.numRclumps, np.uint32)
+    pk = host._view(db.c.packed, db.c.packedWords * 16, np.uint8)
+    heads = C.cast(db.c.refHead, C.POINTER(C.c_char_p))
+    assert dd[0] == 0 and dd[-1] == orig and (np.diff(dd) >= 0).all()
+    assert sorted(rix.tolist()) == list(range(orig))          # every original fragment belongs to exactly one unique reference
+    n_pad = int((np.diff(dd) == 0).sum())
+    assert 0 < n_pad < 16 * len(specs)                          # padding lanes: at most one partial clump per part
+    # regenerate the sequences the parts were built from (a sequence depends on the seed and its number only) and check a sample of lanes
+    code = {65: 1, 67: 2, 71: 3, 84: 4}
+    fasta = {}
+    for p, (b0, nb, nv, rate, seed) in enumerate(specs):
+        fa = str(tmp_path / ("p%d.fa" % p))
+        host.synth_refs(fa, nb, nv, a.ref_len, rate, seed, first_base=b0)
+        with open(fa) as f:
+            for hline in f:
+                fasta[hline[1:].strip().encode()] = f.readline().strip().encode()
+    w, checked = 0, 0
+    for c in range(db.c.numRclumps):
+        L = int(cl[c]); rows = (L + 1) // 2
+        if c % 7 == 0:
+            blk = pk[w * 16:(w + rows) * 16].reshape(rows, 16)
+            full = np.empty((rows * 2, 16), np.uint8)
+            full[0::2] = blk & 15; full[1::2] = blk >> 4
+            for z in range(16):
+                i = 16 * c + z
+                if i >= totR:
+                    continue
+                seq = bytes(full[:L, z]).rstrip(b"\0")
+                if dd[i] == dd[i + 1]:
+                    assert seq == b""                          # a padding lane: nothing but pads
+                    continue
+                for k in range(int(dd[i]), int(dd[i + 1])):
+                    o = int(rix[k])
+                    src = fasta[heads[o]][int(start[o]):int(start[o]) + len(seq)]
+                    assert bytes(code[b] for b in src) == seq, (i, o)
+                    checked += 1
+        w += rows
+    assert checked > 1000
+    db.close()
+    exe = os.path.join(gl.ROOT, "oracle", "_ref", "burst12")
+    if os.path.exists(exe):          # the compiled reference accepts the merged file and finds the reads in it
+        out = str(tmp_path / "ref.b6")
+        r = subprocess.run([exe, "-r", edx, "-q", reads, "-o", out, "-m", "BEST", "-i", "0.98", "-t", "4", "--noprogress"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-500:]
+        lines = open(out).read().splitlines()
+        assert len(lines) >= 0.97 * 300                             # (reads of 97 symbols with two edits are beyond the budget)
+
+
 @pytest.mark.parametrize("no_pty", [False, True])
 def test_reference_align_phase_is_stamped_with_and_without_a_pty(tmp_path, monkeypatch, no_pty):
     """bench.py's cpu_baseline times the reference's alignment loops between two of its own progress lines; the GPU box has no pty
