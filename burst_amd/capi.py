@@ -44,7 +44,7 @@ class BhipQuerySpan(C.Structure):
 
 EXPORTS = ["bhip_init", "bhip_stage_queries", "bhip_align_staged", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_set_option", "bhip_get_stats",
            "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version", "bhip_copy_hits_device", "bhip_sync_hits",
-           "bhip_comm_create", "bhip_comm_unique_id", "bhip_comm_create_rank", "bhip_comm_allreduce_min", "bhip_comm_fetch_gathered", "bhip_comm_gather_hits", "bhip_comm_destroy", "bhip_acx_export", "bhip_reserve", "bhip_reserve_symbols", "bhip_sort_queries", "bhip_stage_spans", "bhip_alloc_host", "bhip_free_host", "bhip_host_register", "bhip_host_unregister", "bhip_set_enqueued_hook", "bhip_acx_export_entries"]
+           "bhip_comm_create", "bhip_comm_unique_id", "bhip_comm_create_rank", "bhip_comm_allreduce_min", "bhip_comm_fetch_gathered", "bhip_comm_gather_hits", "bhip_comm_stage_device", "bhip_comm_gather_staged", "bhip_comm_stage_reset", "bhip_comm_destroy", "bhip_acx_export", "bhip_reserve", "bhip_reserve_symbols", "bhip_sort_queries", "bhip_stage_spans", "bhip_alloc_host", "bhip_free_host", "bhip_host_register", "bhip_host_unregister", "bhip_set_enqueued_hook", "bhip_acx_export_entries"]
 
 
 class BurstHipError(RuntimeError):

@@ -804,7 +804,7 @@ static int build_accelerator_by_clumps(Handle *h, int K, int z) {
 	ARC(d_bad.reserve((size_t)nC + 16)); ARC(d_soff.reserve(((size_t)nC + 1) * 8));
 	HIPCHK(hipMemcpyAsync(d_bad.p, is_bad.data(), nC, hipMemcpyHostToDevice, h->stream));
 	HIPCHK(hipMemcpyAsync(d_soff.p, slot_off.data(), ((size_t)nC + 1) * 8, hipMemcpyHostToDevice, h->stream));
-	// 2. slices of clumps whose tuples fit the sort buffers (two 8-byte tuple arrays + the folded lane masks: 18 bytes per tuple, planned
+	// 2. slices of clumps whose tuples fit the sort buffers (two 8-byte tuple arrays + the folded lane masks + the sort's own scratch; ONE budget: 33 bytes per tuple, planned
 	// with slack) next to what is resident at that time, of at most 2^cb clumps each (the slice-local clump number in the tuple).  The records
 	// (4 bytes per entry; their number is only known after the first pass) are not there yet while the lists are counted: the first
 	// pass runs over slices as large as the sort allows, the second over slices that fit next to the records -- unless everything
@@ -823,7 +823,7 @@ static int build_accelerator_by_clumps(Handle *h, int K, int z) {
 	std::vector<uint32_t> cuts;
 	uint32_t n_slices = 0;
 	uint64_t cap_items = 0;
-	auto plan_slices = [&](double room) -> int {       // (26 B per tuple in the sort buffers, which grow with a quarter of slack)
+	auto plan_slices = [&](double room) -> int {       // (33 B of room per tuple: 18 B of tuple arrays and masks, rocPRIM's scratch, and 20 % of slack for whoever else allocates meanwhile)
 		uint64_t slice_items = room > 0 ? (uint64_t)std::min<double>(2147483000.0, room * 0.8 / 33.0) : 0;
 		if (forced_slice > 0) slice_items = std::max<uint64_t>((uint64_t)forced_slice, biggest);
 		if (slice_items < biggest)

@@ -327,7 +327,7 @@ struct Handle {
 	int opt_pf_algo = -1;         // 0 = counting filter + exact lane table (k_prefilter_cf), 1 = exact clump hash table in two passes
 	                              // (k_prefilter_mask), -1 = start with 0 and switch a lane to 1 when more than 20 % of its records survive the filter
 	int opt_pf_table = 0;         // log2 of the per-query hash table (0 = from the workload: 9, 10 or 11)
-	int opt_pf_cw = 0;            // the counting filter as: 0 k_prefilter_cf (four queries per wave, 16 lanes each), 1 k_prefilter_cw (one query per wave, list-mask slots),
+	int opt_pf_cw = 2;            // the counting filter as: 0 k_prefilter_cf (four queries per wave, 16 lanes each), 1 k_prefilter_cw (one query per wave, list-mask slots),
 	                              // 2 k_prefilter_cq (four queries per wave, their record streams walked by the whole wave; plans beyond 16 lists: k_prefilter_cw)
 	int opt_pf_bytes = 1;         // byte counters (twice as many) for queries whose record stream is at most 255 records
 	int opt_pf_rb = 0;            // 64-record blocks per query the counting-filter kernel fetches a quad ahead and keeps in registers (0 = from the workload: 2, 3 or 4)

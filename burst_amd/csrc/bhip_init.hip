@@ -178,15 +178,19 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 	if (acx_lens) INITRC(bhip_load_accelerator(h, acx_lens, acx_lists, acx_fmt, K, badlist, n_bad));
 	else if (K) INITRC(bhip_build_accelerator(h, K, score_lut[16 * 5 + 5] != 0));      // N penalised (burst.c:164, -y clears it): N costs 1 even against N
 	INITRC(ensure_lanes(h, 1));
-	// BHIP_OPTS="name=value,name=value": tuning options for callers that have no other way to pass them (A/B runs of the command line)
+	// BHIP_OPTS="name=value,name=value": tuning options for callers that have no other way to pass them (A/B runs of the command line, the
+	// tests).  Checked BEFORE the upload (bhip_opts_check below: a misspelt name must not cost a database build); here an entry that does
+	// not parse or that the library does not know is skipped with a warning.
 	if (const char *ev = getenv("BHIP_OPTS")) {
 		std::string all(ev);
 		for (size_t a = 0; a < all.size();) {
 			size_t b = all.find(',', a); if (b == std::string::npos) b = all.size();
 			const std::string kv = all.substr(a, b - a); a = b + 1;
 			const size_t eq = kv.find('=');
-			if (eq == std::string::npos || eq == 0) continue;
-			INITRC(bhip_set_option(h, kv.substr(0, eq).c_str(), atoll(kv.c_str() + eq + 1)));
+			char *end = nullptr;
+			const long long v = eq == std::string::npos ? 0 : strtoll(kv.c_str() + eq + 1, &end, 0);
+			if (eq == std::string::npos || eq == 0 || !end || end == kv.c_str() + eq + 1 || *end) { fprintf(stderr, "[bhip] BHIP_OPTS: '%s' is not name=<integer>: ignored\n", kv.c_str()); continue; }
+			if (bhip_set_option(h, kv.substr(0, eq).c_str(), v)) fprintf(stderr, "[bhip] BHIP_OPTS: %s: ignored\n", bhip_last_error());
 		}
 	}
 	*handle = h;

@@ -237,12 +237,14 @@ template __global__ void k_prefilter<false>(const uint8_t *, const uint64_t *, c
 //   * candidates are staged in LDS and flushed with ONE global atomic per flush instead of one returning atomic per
 //     candidate (2.2 M same-address atomics per launch saturated the L2 atomic unit at ~90/us).
 // ------------------------------------------------------------------------------------------------
-// Seed plan of one query (made on the host at staging time, bhip_api.hip make_seed_plan): word starts 0, s, 2s, ... <= len-K
-// are sampled; words containing a symbol outside A/C/G/T are skipped (storeAmbigWords expansion, burst.c:3232-3236, is
-// not needed: a skipped word simply does not vote).  One edit destroys at most ceil(K/s) sampled words, so an alignment
-// with <= E edits keeps need = W_valid - E*ceil(K/s) of them.  s = 1 with no ambiguity is the reference's scheme
-// (need = len-K+1-E*K = mmatch+1, burst.c:4091-4092).  plan[q] = stride | need << 8; queries with need < 1 never reach
-// these kernels (the host routes them to the exhaustive path).
+// Seed plan of one query (k_route on the device, make_seed_plan on the host: bhip_seed_plan; layout BHIP_PLAN_* in bhip_internal.h:
+// stride | need << 8 | x << 24 | used << 28): word starts 0, s, 2s, ... <= len-K are sampled.  A word of A/C/G/T votes; with
+// non-overlapping words (s = K) a word holding exactly ONE ambiguous symbol with 2..4 compatible bases votes through its expansions
+// (x such words, `used` extra word slots: the reference's storeAmbigWords, burst.c:3232-3236, restricted to one ambiguous symbol per
+// word); any other word does not vote.  One edit destroys at most ceil(K/s) sampled words, so an alignment with <= E edits keeps
+// need = W_voting - E*ceil(K/s) of them.  s = 1 with no ambiguity is the reference's scheme (need = len-K+1-E*K = mmatch+1,
+// burst.c:4091-4092).  Queries with need < 1 never reach these kernels (they are routed to the exhaustive path); the clump-level
+// kernels below count strictly (words of A/C/G/T only): need - x, and every clump when nothing is left.
 #define PF2_TL 1536u      // touched-list capacity (clump ids, u32)
 #define PF2_STAGE 512u    // staged candidates (uint2)
 template <typename CNT>
@@ -749,7 +751,7 @@ __global__ __launch_bounds__(64) void k_prefilter_mask(
 	if (lane < 4) s_ovf[lane] = 0;
 	__syncthreads();
 	unsigned long long my_ent = 0, my_units = 0, my_cols = 0, my_qlen = 0;
-	uint32_t sink = 0;                      // see bhip_acx_rec_or_pad
+	uint32_t sink = 0;                      // see bhip_acx_raw_or_pad (bhip_internal.h)
 #ifdef PFM_PROF
 	unsigned long long my_t[8] = {0,0,0,0,0,0,0,0}, t_last = wall_clock64();
 #endif
@@ -1060,7 +1062,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 	if (lane < 4) s_ovf[lane] = 0;
 	__syncthreads();
 	unsigned long long my_ent = 0, my_units = 0, my_cols = 0, my_qlen = 0, my_surv = 0;
-	uint32_t sink = 0, sink_h = 0;          // see bhip_acx_rec_or_pad
+	uint32_t sink = 0, sink_h = 0;          // see bhip_acx_raw_or_pad (bhip_internal.h)
 #ifdef PFM_PROF
 	unsigned long long my_t[8] = {0,0,0,0,0,0,0,0}, t_last = wall_clock64();
 #endif

@@ -320,6 +320,7 @@ int main(int argc, char **argv) {
 		fflush(NULL);
 		_exit(0);
 	}
+	if (shard_db && n_gpus == 1 && n_shards > 1) { printf("ERROR: --gpus 1 --shards %d takes the shards in turns on one device, which has no exchange: drop --gather rccl\n", n_shards); return 1; }
 	if (n_gpus % n_shards) { printf("ERROR: --shards %d does not divide --gpus %d\n", n_shards, n_gpus); return 1; }
 	const int n_groups = n_gpus / n_shards;
 	if (shard_db && (uint32_t)n_shards > db.numRclumps) { puts("ERROR: more database shards than clumps"); return 1; }

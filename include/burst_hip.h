@@ -203,7 +203,9 @@ BHIP_API void bhip_comm_destroy(void *comm);
 
 /* The accelerator of a handle in the file's terms (read_accelerator's tables, burst.c:3535-3594): Lens[4^K], the clump ids of all
  * lists in word order (ascending inside a list, as the reference writes them with one thread), their 16-bit lane masks (device
- * layout only: bit z = lane z of the clump holds the word), the BadList.  For a handle whose accelerator was built on the device
+ * layout only: bit z = lane z of the clump MAY hold the word -- since the 4-byte records of ABI 5 the device keeps a lane-set CODE
+ * per entry, and the mask returned here is decode(code): the exact set for one or two lanes, the smallest enclosing quad pattern
+ * beyond (csrc/bhip_lanecode.h); a superset never loses a lane), the BadList.  For a handle whose accelerator was built on the device
  * this is what make_accelerator (burst.c:3304-3532) would have written.  Any output pointer may be NULL. */
 BHIP_API int bhip_acx_export(void *handle, uint32_t *lens, uint32_t *clumps, uint16_t *masks, uint64_t cap_entries, uint64_t *n_entries,
                     uint32_t *badlist, uint32_t cap_bad, uint32_t *n_bad);

@@ -434,4 +434,7 @@ def test_bench_multi_rank_path_with_one_process(tmp_path):
     e = json.loads([ln for ln in r5.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert e["work"]["records"] == a["work"]["records"] and "shared-memory" in e["config"]["parallelism"]
     assert e["rccl"]["rccl_ranks"] == 1 and e["rccl"]["records"] == a["work"]["records"] and e["rccl"]["value"] > 0 and e["rccl"]["rccl_gather_ms"] >= 0
+    # at the top level and in `config` too (what the driver's parsed view keeps), and gathered from the device-resident records
+    assert e["rccl_ranks"] == 1 == e["config"]["rccl_ranks"] and e["rccl_gather_ms"] == e["rccl"]["rccl_gather_ms"] == e["config"]["rccl_gather_ms"]
+    assert e["config"]["rccl_records_from"].startswith("device")
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("burst_hip.bench")]

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-CW_DEFAULT = 0          # library default of option prefilter_cw (see tests/test_gpu_kernels.py)
+CW_DEFAULT = 2          # library default of option prefilter_cw (see tests/test_gpu_kernels.py)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -8,7 +8,7 @@ import pytest
 import dbutil
 import oraclelib as ol
 
-CW_DEFAULT = 0          # library default of option prefilter_cw (the tests run the other counting-filter kernel as a variant)
+CW_DEFAULT = 2          # library default of option prefilter_cw (the tests run the other counting-filter kernel as a variant)
 from burst_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -418,6 +418,7 @@ def test_prefilter_overflow_paths():
     for all_hits in (False, True):
         exp = oracle_hits(packed, clump_len, tot, q, lut, all_hits)
         assert len(exp) > 12
+        dev.set_option("prefilter_cw", 0)          # (the table sizes are k_prefilter_cf's)
         for table in (9, 11, 0):
             dev.set_option("prefilter_table", table)
             assert_hits_equal(dev.align_batch(q, all_hits=all_hits), exp)
