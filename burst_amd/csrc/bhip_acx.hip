@@ -435,6 +435,17 @@ __global__ void k_acx_hist(const unsigned long long *__restrict__ ukeys, uint32_
 		atomicAdd(&lens[(uint32_t)(key >> cb)], 1u);
 	}
 }
+// the same straight from the SORTED tuples of a slice, without folding them first (the first pass only wants the lengths): one count
+// per tuple whose (word, clump) differs from its predecessor's
+__global__ void k_acx_hist_sorted(const unsigned long long *__restrict__ skeys, uint32_t n, int cb, uint32_t *__restrict__ lens) {
+	const unsigned long long KM = (1ull << BHIP_ACX_KEYBITS) - 1ull;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const unsigned long long key = skeys[i] & KM;
+		if (key >> 47) continue;
+		if (i && (skeys[i - 1] & KM) == key) continue;
+		atomicAdd(&lens[(uint32_t)(key >> cb)], 1u);
+	}
+}
 // head[i] = i for the first tuple of every word, 0 elsewhere: an inclusive max-scan turns it into "first tuple of my word"
 __global__ void k_acx_heads(const unsigned long long *__restrict__ ukeys, uint32_t n_unique, int cb, uint32_t *__restrict__ head) {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_unique; i += gridDim.x * blockDim.x)
@@ -856,11 +867,32 @@ static int build_accelerator_by_clumps(Handle *h, int K, int z) {
 	};
 	const double room_once = (double)free_b - (double)n_lines * 64.0 - (double)item_off[nC] * BHIP_REC_BYTES - (double)(256u << 20);
 	bool one_plan = forced_slice > 0 || (room_once > 0 && room_once * 0.8 / 33.0 >= (double)item_off[nC] && item_off[nC] <= 2147483000ull);
+	if (getenv("BHIP_TEST_TWO_PLANS") && forced_slice <= 0) one_plan = false;      // (test hook: a small database through the large databases' path -- counting pass, record area mapped beside it, second plan)
 	ARC(plan_slices_retry(one_plan ? room_once : (double)free_b - (double)n_lines * 64.0 - (double)(256u << 20)));
 	ARC(nruns.reserve(16)); ARC(d_xcur.reserve(16));
+	// The record area is taken WHILE the first pass counts: one address range for the upper bound (a record per tuple), its memory mapped
+	// chunk by chunk by a thread of its own (DBuf::reserve_growable) -- a process that follows another one on the device waits seconds for
+	// its first large allocations (the memory of the process before is not back at once: 0.8 .. 5.5 s for these 216 GB, measured), and
+	// that wait now lies beside 3.7 s of sorting instead of behind them.  What is mapped beyond the real size goes back after the pass.
+	// Not with one plan (everything fits at once: the records are small) and not where the runtime has no virtual memory management.
+	std::thread mapper;
+	int map_rc = 0;
+	bool rec_vmm = false;
+	if (!one_plan && !getenv("BHIP_ACX_NO_PREMAP")) {
+		size_t fb2 = 0, tb2 = 0;
+		if (hipMemGetInfo(&fb2, &tb2) == hipSuccess && h->acx_rec.reserve_growable((size_t)item_off[nC] * BHIP_REC_BYTES + 16, h->device) == 0) {
+			rec_vmm = true;
+			const size_t spare_b = (size_t)6 << 30;      // (rocPRIM's scratch, the offset lines' scratch)
+			const size_t limit = fb2 > spare_b ? std::min<size_t>((size_t)item_off[nC] * BHIP_REC_BYTES + 16, fb2 - spare_b) : 0;
+			const int dev = h->device;
+			DBuf *rec = &h->acx_rec;
+			if (limit) mapper = std::thread([rec, limit, dev, &map_rc]() { if (hipSetDevice(dev) != hipSuccess) { map_rc = 1; return; } map_rc = rec->grow_to(limit) ? 1 : 0; });
+		}
+	}
+	struct JoinMapper { std::thread &t; ~JoinMapper() { if (t.joinable()) t.join(); } } join_mapper{mapper};
 	unsigned long long *ukeys = nullptr; uint16_t *umasks = nullptr; unsigned long long *spare = nullptr; uint32_t n_unique = 0;
 	// tuples of slice s, sorted and folded: ukeys / umasks / n_unique (spare = the other key buffer, free for scratch)
-	auto fold_slice = [&](uint32_t s) -> int {
+	auto fold_slice = [&](uint32_t s, bool count_only) -> int {
 		const uint32_t c0 = cuts[s], c1 = cuts[s + 1];
 		const uint64_t n_slots = slot_off[c1] - slot_off[c0], n_items = item_off[c1] - item_off[c0];
 		n_unique = 0;
@@ -880,6 +912,12 @@ static int build_accelerator_by_clumps(Handle *h, int K, int z) {
 		ARC(tmp.reserve(tb));
 		HIPCHK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, dk, (int)n_items, bit0, BHIP_ACX_KEYBITS, h->stream));
 		unsigned long long *skeys = dk.Current();
+		if (count_only) {      // first pass: the list lengths from the sorted tuples themselves (no folded copy is written or read)
+			hipLaunchKernelGGL(k_acx_hist_sorted, dim3((uint32_t)h->n_cu * 16), dim3(256), 0, h->stream, skeys, (uint32_t)n_items, cb, d_lens.as<uint32_t>());
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipStreamSynchronize(h->stream));
+			return 0;
+		}
 		ukeys = dk.Alternate(); umasks = v0.as<uint16_t>(); spare = skeys;
 		hipcub::TransformInputIterator<unsigned long long, AcxKeyOf, const unsigned long long *> kin(skeys, AcxKeyOf());
 		hipcub::TransformInputIterator<uint16_t, AcxLanesOf, const unsigned long long *> vin(skeys, AcxLanesOf());
@@ -893,17 +931,24 @@ static int build_accelerator_by_clumps(Handle *h, int K, int z) {
 	};
 	const uint32_t g = (uint32_t)h->n_cu * 16;
 	// 3. first pass: list lengths
+	// (one slice serves both passes when everything fits at once: it is folded, and its folded tuples stay for the second pass)
 	for (uint32_t s = 0; s < n_slices; ++s) {
-		ARC(fold_slice(s));
-		if (n_unique) { hipLaunchKernelGGL(k_acx_hist, dim3(g), dim3(256), 0, h->stream, ukeys, n_unique, cb, d_lens.as<uint32_t>()); HIPCHK(hipGetLastError()); }
+		const bool keep = one_plan && n_slices == 1;
+		ARC(fold_slice(s, !keep));
+		if (keep && n_unique) { hipLaunchKernelGGL(k_acx_hist, dim3(g), dim3(256), 0, h->stream, ukeys, n_unique, cb, d_lens.as<uint32_t>()); HIPCHK(hipGetLastError()); }
 	}
 	const double t_pass1 = since();
+	if (!one_plan) { k0.release(); k1.release(); v0.release(); tmp.release(); }      // the first pass's sort buffers make room for the offset lines and the records
 	uint64_t tot = 0; uint32_t maxlen = 0;
 	ARC(acx_lines_from_lens(h, d_lens.as<uint32_t>(), nw, &tot, &maxlen));
 	const uint32_t n_slices_1 = n_slices;
 	const double t_a0 = since();
-	if (!one_plan) { k0.release(); k1.release(); v0.release(); tmp.release(); }      // the first pass's sort buffers make room for the records
-	ARC(h->acx_rec.reserve_exact(tot * BHIP_REC_BYTES + 16));
+	if (mapper.joinable()) mapper.join();
+	if (rec_vmm && !map_rc) {
+		h->acx_rec.shrink_to(tot * BHIP_REC_BYTES + 16);
+		if (h->acx_rec.grow_to(tot * BHIP_REC_BYTES + 16)) { h->acx_rec.release(); rec_vmm = false; (void)hipGetLastError(); }
+	} else if (rec_vmm) { h->acx_rec.release(); rec_vmm = false; (void)hipGetLastError(); }
+	if (!rec_vmm) ARC(h->acx_rec.reserve_exact(tot * BHIP_REC_BYTES + 16));
 	if (!one_plan) {
 		HIPCHK(hipMemGetInfo(&free_b, &total_b));
 		ARC(plan_slices_retry((double)free_b - (double)(256u << 20)));
@@ -915,7 +960,7 @@ static int build_accelerator_by_clumps(Handle *h, int K, int z) {
 	// 4. second pass: the records (one slice: the folded tuples are still there)
 	const uint32_t all_lanes = getenv("BHIP_NO_LANE_MASKS") ? 1u : 0u;
 	for (uint32_t s = 0; s < n_slices; ++s) {
-		if (refold) ARC(fold_slice(s));
+		if (refold) ARC(fold_slice(s, false));
 		if (!n_unique) continue;
 		uint32_t *head_in = (uint32_t *)spare, *head = head_in + n_unique;      // 8 bytes per tuple of scratch: the sorted key buffer
 		hipLaunchKernelGGL(k_acx_heads, dim3(g), dim3(256), 0, h->stream, ukeys, n_unique, cb, head_in);
@@ -933,7 +978,8 @@ static int build_accelerator_by_clumps(Handle *h, int K, int z) {
 	ARC(set_badlist(h, badlist.data(), (uint32_t)badlist.size()));
 	h->has_acx = true; h->n_ent = tot; h->has_masks = !all_lanes;
 	if (dbg) fprintf(stderr, "[bhip] accelerator built on the device: K=%d, %llu entries from %llu word tuples in %u + %u slice(s), %zu clump(s) on the BadList, %.2f B per entry; %.2f s (%.2f s for the list lengths, %.2f s allocating the records and the second pass's buffers)\n",
-		K, (unsigned long long)tot, (unsigned long long)item_off[nC], n_slices_1, n_slices, badlist.size(), tot ? (double)(tot * BHIP_REC_BYTES + n_lines * 64) / (double)tot : 0.0, since(), t_pass1, t_alloc);
+		K, (unsigned long long)tot, (unsigned long long)item_off[nC], n_slices_1, n_slices, badlist.size(), tot ? (double)(h->acx_rec.cap + n_lines * 64) / (double)tot : 0.0, since(), t_pass1, t_alloc);
+	if (dbg && rec_vmm) fprintf(stderr, "[bhip] record area: %zu chunks of 1 GiB mapped beside the first pass\n", h->acx_rec.chunks.size());
 	return 0;
 }
 

@@ -139,6 +139,15 @@ struct DBuf {
 		}
 		return 0;
 	}
+	// give back the chunks beyond `bytes` (the array was mapped ahead of knowing its size)
+	void shrink_to(size_t bytes) {
+		if (!vmm) return;
+		const size_t keep = (bytes + kChunk - 1) / kChunk;
+		while (chunks.size() > keep) {
+			(void)hipMemUnmap((char *)p + (chunks.size() - 1) * kChunk, kChunk); (void)hipMemRelease(chunks.back());
+			chunks.pop_back(); cap -= kChunk;
+		}
+	}
 	void release() {
 		if (vmm) {
 			for (size_t i = 0; i < chunks.size(); ++i) { (void)hipMemUnmap((char *)p + i * kChunk, kChunk); (void)hipMemRelease(chunks[i]); }

@@ -68,6 +68,15 @@ def test_device_built_accelerator_equals_file(db, K, z, monkeypatch):
         monkeypatch.setenv("BHIP_MASK_SLICE", "40000")
         n2, _, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z)
         assert n2 == n
+        monkeypatch.delenv("BHIP_MASK_SLICE")
+    # ... and through the path of the large databases (BHIP_TEST_TWO_PLANS: a counting pass over the sorted tuples, the record area one
+    # address range whose memory is mapped by a thread beside that pass and cut back to the real size, a second plan for the records)
+    monkeypatch.setenv("BHIP_TEST_TWO_PLANS", "1")
+    n3, _, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z)
+    assert n3 == n
+    monkeypatch.setenv("BHIP_ACX_NO_PREMAP", "1")          # (the same with the record area allocated in one piece after the counting pass)
+    n4, _, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z)
+    assert n4 == n
 
 
 def test_device_built_accelerator_expansion_and_badlist(tmp_path, monkeypatch):
