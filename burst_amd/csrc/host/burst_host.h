@@ -29,6 +29,9 @@ typedef enum { BH_FORAGE = 0, BH_BEST, BH_ALLPATHS, BH_CAPITALIST, BH_ANY } BhMo
 /* ---- tables (burst.c:164-192, 1237-1329) ---- */
 void bh_score_lut(int z, uint8_t lut[256]);        /* SCOREFAST after setScore(): lut[16*q+r] in {0,1,255} */
 void bh_char2code(uint8_t map[256]);               /* CHAR2NUM, bytes >= 128 map to 0 */
+void bh_set_alphabet(const uint8_t map[256]);      /* -x: byte -> code 1..15 of a caller-made alphabet (NULL: back to CHAR2NUM); bh_score_lut is then the identity table */
+int  bh_alphabet_is_set(void);
+int  bh_alphabet_from_files(const char *ref_fa, const char *query_fa, uint8_t map[256], int *n_symbols);      /* BH_E_USAGE beyond 15 symbols */
 uint8_t bh_rc_code(uint8_t c);                     /* RVT */
 uint32_t bh_error_budget(float thres, uint32_t len);   /* burst.c:3069-3076 */
 

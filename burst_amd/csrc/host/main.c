@@ -73,6 +73,7 @@ static void usage(void) {
 int main(int argc, char **argv) {
 	BhMode mode = BH_CAPITALIST;                    /* burst.c:81 */
 	float thres = 0.97f;                            /* burst.c:93 */
+	int xalpha = 0;
 	int z = 1, do_rc = 0, incl_ws = 0, makedb = 0, do_shear = 0, do_accel = 0, dedupe = 0, device = 0, K = 0, skip_ambig = 0, threads = 0, rep_flags = 0;
 	long shear_amt = 500, db_qlen = 500;            /* burst.c:94 */
 	uint32_t latency = 16;                          /* burst.c:83 */
@@ -174,8 +175,9 @@ int main(int argc, char **argv) {
 		else if (!strcmp(a, "--clustradius") || !strcmp(a, "-cr") || !strcmp(a, "--dbpartition") || !strcmp(a, "-dp")) {
 			printf("ERROR: option %s belongs to the compressive (-d DNA/RNA) database builder, which burst_hip does not include; use -d QUICK\n", a); return 1;
 		}
+		else if (!strcmp(a, "--xalphabet") || !strcmp(a, "-x")) { xalpha = 1; printf(" --> Allowing any alphabet (unambiguous ID matching)\n"); }
 		else if (!strcmp(a, "--fingerprint") || !strcmp(a, "-f") || !strcmp(a, "--prepass") ||
-		         !strcmp(a, "-p") || !strcmp(a, "--xalphabet") || !strcmp(a, "-x") || !strcmp(a, "--heuristic") || !strcmp(a, "-hr")) {
+		         !strcmp(a, "-p") || !strcmp(a, "--heuristic") || !strcmp(a, "-hr")) {
 			printf("ERROR: option %s is outside the device hot path and not supported by burst_hip\n", a); return 1;
 		}
 		else { printf("ERROR: Unrecognized command-line option: %s\n", a); puts("See help by running with just '-h'"); return 1; }
@@ -198,6 +200,7 @@ int main(int argc, char **argv) {
 	if (!output) { fprintf(stderr, "ERROR: Cannot open output: %s\n", output_FN); return 2; }
 	const double start = wall();
 	int rc;
+	if (makedb && xalpha) { puts("ERROR: -x with -d: a database nibble-packs its symbols whatever the alphabet (burst.c:2810-2824): -x works against FASTA references only"); return 1; }
 	if (makedb) {
 		fclose(output);
 		int e = bh_is_edx(ref_FN);
@@ -225,6 +228,18 @@ int main(int argc, char **argv) {
 	#define PHASE(name) do { const double t_ = wall(); printf(" [%-28s %8.3f s]\n", name, t_ - tp); tp = t_; } while (0)
 	int usedb = bh_is_edx(ref_FN);
 	if (usedb < 0) DIE(usedb);
+	if (xalpha) {
+		/* -x: raw symbols compared for equality (aded_xalpha / reScoreM_xalpha, burst.c:696-697, 894, 1099).  Upstream that only works
+		 * against FASTA references (a database nibble-packs every symbol whatever the alphabet, burst.c:2810-2824) and on the forward
+		 * strand (its reverse complement indexes a 16-entry table with the raw byte, burst.c:168, 3102): the same here, said aloud. */
+		if (usedb) { fputs("ERROR: DB made without Xalpha; queries can't use Xalpha.\n", stderr); return 1; }      /* (the reference's message, burst.c:2859-2862) */
+		if (do_rc) { puts("ERROR: -x compares raw symbols: there is no reverse complement of an arbitrary alphabet (drop -fr)"); return 1; }
+		uint8_t map[256];
+		int n_sym = 0;
+		if ((rc = bh_alphabet_from_files(ref_FN, query_FN, map, &n_sym))) { fprintf(stderr, "%s\n", bh_last_error()); return rc == BH_E_IO ? 2 : 1; }
+		printf(" --> Alphabet of %d symbols\n", n_sym);
+		bh_set_alphabet(map);
+	}
 	BhQueries Q; memset(&Q, 0, sizeof Q);
 	Ingest ing = {query_FN, thres, do_rc, incl_ws, do_accel, K ? K : (accel_dev || !do_accel ? 12 : 0), z, skip_ambig, &Q, 0, "", 0.0};
 	pthread_t ing_thread; int ing_running = 0;

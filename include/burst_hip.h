@@ -88,7 +88,9 @@ typedef struct BhipStats {
  *   acx_lists  : the packed list area (burst.c:3569); acx_fmt 0 = SMALL 20-bit pairs (3265-3274), 1 = LARGE 24-bit (3245-3248)
  *   badlist    : BadList[n_bad] (burst.c:3571): clumps every prefiltered query must be aligned against
  *   score_lut  : 16x16 cost table lut[16*q + r] in {0,1,255} = SCOREFAST after setScore() (burst.c:1310-1328)
- *   xalpha     : must be 0 (alphabet-agnostic -x mode is not implemented on the device)
+ *   xalpha     : must be 0.  The alphabet-agnostic mode (-x; aded_xalpha / reScoreM_xalpha, burst.c:696-697, 894, 1099) needs no device
+ *                switch: the host maps the run's alphabet (up to 15 symbols) onto the codes 1..15 and passes the IDENTITY cost table
+ *                (0 iff equal, 1 otherwise, the padding code 0 included) as score_lut -- burst_hip -x, host/main.c
  */
 BHIP_API int bhip_init(int device, const void *edx_packed, const uint32_t *clump_len, uint32_t n_clumps, uint32_t tot_refs,
               const uint32_t *acx_lens, const void *acx_lists, int acx_fmt, int K,

@@ -16,6 +16,11 @@ int main(int argc, char **argv) {
 	float thres = (float)atof(argv[5]); int fr = atoi(argv[6]), z = atoi(argv[7]); long shear = atol(argv[8]);
 	BhMode mode = !strcmp(ms, "BEST") ? BH_BEST : !strcmp(ms, "ALLPATHS") ? BH_ALLPATHS : !strcmp(ms, "FORAGE") ? BH_FORAGE : !strcmp(ms, "ANY") ? BH_ANY : BH_CAPITALIST;
 	BhQueries Q; BhDb db; int rc;
+	if (getenv("BURST_XALPHA")) {      /* -x: the run's own alphabet, as the command line sets it up */
+		uint8_t map[256]; int ns = 0;
+		if (bh_alphabet_from_files(ref, qf, map, &ns)) { fprintf(stderr, "%s\n", bh_last_error()); return 1; }
+		bh_set_alphabet(map);
+	}
 	if ((rc = bh_queries_load(qf, thres, fr, 0, 0, 12, z, 0, &Q))) { fprintf(stderr, "%s\n", bh_last_error()); return 2; }
 	int isdb = bh_is_edx(ref);
 	if (isdb > 0) rc = bh_edx_read(ref, &db); else rc = bh_db_from_fasta(ref, Q.maxLen, thres, shear >= 0, shear > 0 ? shear : 500, 0, &db);

@@ -438,3 +438,31 @@ def test_bench_multi_rank_path_with_one_process(tmp_path):
     assert e["rccl_ranks"] == 1 == e["config"]["rccl_ranks"] and e["rccl_gather_ms"] == e["rccl"]["rccl_gather_ms"] == e["config"]["rccl_gather_ms"]
     assert e["config"]["rccl_records_from"].startswith("device")
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("burst_hip.bench")]
+
+
+@pytest.mark.parametrize("alphabet,mode", [("ACDEFGHIKLMN", "BEST"), ("ACDEFGHIKLMN", "ALLPATHS"), ("ACGTacgtN", "CAPITALIST"), ("01", "FORAGE")])
+def test_cli_xalphabet_matches_the_reference(tmp_path, alphabet, mode):
+    """burst_hip -x (any alphabet of up to 15 symbols, compared for equality: aded_xalpha / reScoreM_xalpha, burst.c:696-697, 894, 1099)
+    on the device against the compiled reference with -x on the same sequences over bytes its query sort survives (tests/xalpha_util.py);
+    more than 15 symbols, -fr and databases are refused as upstream cannot do them either"""
+    ref_exe = os.path.join(gl.ROOT, "oracle", "_ref", "burst12")
+    if not os.path.exists(ref_exe):
+        pytest.skip("compiled reference not present")
+    import xalpha_util
+    rf, qf, rf_low, qf_low = xalpha_util.write_inputs(tmp_path, alphabet, len(alphabet) * 11 + len(mode), n_refs=60, n_queries=400)
+    out_ref, out = str(tmp_path / "ref.b6"), str(tmp_path / "hip.b6")
+    r = subprocess.run([ref_exe, "-x", "-r", rf_low, "-q", qf_low, "-o", out_ref, "-m", mode, "-i", "0.93", "-t", "1", "--noprogress"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-800:]
+    r = subprocess.run([CLI, "-x", "-r", rf, "-q", qf, "-o", out, "-m", mode, "-i", "0.93"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-800:]
+    a, b = sorted(open(out_ref, "rb").read().splitlines()), sorted(open(out, "rb").read().splitlines())
+    assert len(a) > 250 and a == b
+    # what upstream cannot do is refused, with its own message where it has one
+    r = subprocess.run([CLI, "-x", "-r", os.path.join(gl.G, "dna.edx"), "-q", qf, "-o", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 1 and "Xalpha" in r.stdout
+    r = subprocess.run([CLI, "-x", "-fr", "-r", rf, "-q", qf, "-o", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 1
+    with open(str(tmp_path / "wide.fa"), "wb") as f:
+        f.write(b">w\nABCDEFGHIJKLMNOPQRSTUVWXYZ\n")
+    r = subprocess.run([CLI, "-x", "-r", str(tmp_path / "wide.fa"), "-q", qf, "-o", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 1 and "distinct symbols" in r.stdout + (r.stderr or "")

@@ -406,3 +406,28 @@ def test_host_pipeline_with_reads_beyond_1024_symbols(exe, tmp_path):
         subprocess.check_call([exe, refs_fa, q_fa, got, mode, ident, str(fr), "1", "-1", "1", "", "0", "0", "10"])
         a, b = sorted(open(want, "rb").read().splitlines()), sorted(open(got, "rb").read().splitlines())
         assert len(a) >= 12 and a == b, (mode, len(a), len(b), sorted(set(a) ^ set(b))[:4])
+
+
+@pytest.mark.parametrize("alphabet,mode", [("ACDEFGHIKLMN", "BEST"), ("ACDEFGHIKLMN", "ALLPATHS"), ("ACGTacgtN", "ALLPATHS"), ("01", "FORAGE"), ("ACDEFGHIKLMNPQR", "CAPITALIST")])
+def test_xalphabet_matches_the_reference(exe, tmp_path, alphabet, mode):
+    """-x ("any alphabet, unambiguous ID matching": aded_xalpha / reScoreM_xalpha, burst.c:696-697, 894, 1099): raw symbols compared for
+    equality, against FASTA references, forward strand.  The device layout has four bits per symbol, so the run's alphabet (up to 15
+    distinct bytes) is mapped onto codes 1..15 in byte order and scored by the identity table.  Upstream, -x only survives symbols whose
+    BYTE VALUE is below 16: its query sort buckets the first five raw bytes as nibbles (NIB5, burst.c:383-387) and writes out of bounds
+    for any printable letter (segmentation fault in "Sorting queries...").  The compiled reference therefore gets the same sequences
+    with the symbols renamed to the bytes 1, 2, ... (skipping 10 and 13, the line ends) in the same order -- a .b6 holds no sequence, so
+    the two outputs must be identical: protein-like letters, case-sensitive nucleotides (a != A), a binary alphabet, fifteen symbols."""
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "burst12")
+    if not os.path.exists(ref_exe):
+        pytest.skip("compiled reference not present")
+    import xalpha_util
+    files = xalpha_util.write_inputs(tmp_path, alphabet, len(alphabet) * 7 + len(mode))
+    if files is None:
+        pytest.skip("fifteen symbols need a byte beyond 15 once the line ends are left out: the reference cannot run this one")
+    rf, qf, rf_low, qf_low = files
+    out_ref, out_mine = str(tmp_path / "ref.b6"), str(tmp_path / "mine.b6")
+    r = subprocess.run([ref_exe, "-x", "-r", rf_low, "-q", qf_low, "-o", out_ref, "-m", mode, "-i", "0.93", "-t", "1", "--noprogress"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-800:]
+    subprocess.check_call([exe, rf, qf, out_mine, mode, "0.93", "0", "1", "-1", "1", "", "0", "0", "10"], env=dict(os.environ, BURST_XALPHA="1"))
+    a, b = sorted(open(out_ref, "rb").read().splitlines()), sorted(open(out_mine, "rb").read().splitlines())
+    assert len(a) > 100 and a == b
