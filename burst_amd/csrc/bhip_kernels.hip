@@ -1814,8 +1814,17 @@ __global__ __launch_bounds__(64) void k_prefilter_cw(
 // For lists per query <= 16 (MODE 0: <= 8, byte slots; MODE 1: halfword slots); longer plans keep k_prefilter_cw<2>.  BIG = 1: the second
 // pass over queries whose survivors overflowed the 32-slot exact table of the first, with four times the slots and the table.
 // ------------------------------------------------------------------------------------------------
+#ifndef CQ_MINWAVES
+#define CQ_MINWAVES 1          // waves per SIMD the register allocation aims at (tools/build_variant.sh: -DCQ_MINWAVES=5 -DCQ_LTB=4 -DCQ_STAGE_N=32 for the occupancy A/B)
+#endif
+#ifndef CQ_LTB
+#define CQ_LTB 5
+#endif
+#ifndef CQ_STAGE_N
+#define CQ_STAGE_N 64
+#endif
 template <int MODE, int BIG>
-__global__ __launch_bounds__(64) void k_prefilter_cq(
+__global__ __launch_bounds__(64, CQ_MINWAVES) void k_prefilter_cq(
 		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
 		const uint32_t *__restrict__ ent,   // 4-byte (clump, lane-set code) records
 		const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ clump_len, uint32_t tot_refs,
@@ -1830,9 +1839,9 @@ __global__ __launch_bounds__(64) void k_prefilter_cq(
 	constexpr uint32_t SB = MODE == 0 ? 2u : 1u;                          // log2 slots per dword
 	constexpr uint32_t NDW = BIG ? 1024u : 256u;                          // dwords of slots per query: 1 KB (4 KB)
 	constexpr uint32_t NS = NDW << SB;                                    // slots per query
-	constexpr uint32_t LTB = BIG ? 7u : 5u, LT = 1u << LTB;               // exact lane-table slots per query
+	constexpr uint32_t LTB = BIG ? 7u : (uint32_t)CQ_LTB, LT = 1u << LTB;               // exact lane-table slots per query
 	constexpr uint32_t RING = 64u;                                        // survivors of a query waiting for the rounds at the end of the quad (a power of two, >= one row)
-	constexpr uint32_t CQ_STAGE = 64u;
+	constexpr uint32_t CQ_STAGE = (uint32_t)CQ_STAGE_N;
 	constexpr uint32_t R = 6u;                                            // rows of 64 records of a query that stay in registers between the two looks
 	__shared__ __attribute__((aligned(16))) uint32_t s_cnt[4][NDW];
 	__shared__ uint32_t s_key[4][LT];
@@ -1870,6 +1879,13 @@ __global__ __launch_bounds__(64) void k_prefilter_cq(
 		const unsigned long long m = __ballot(mine);
 		const uint32_t cnt = (uint32_t)__popcll(m);
 		if (!cnt) return;
+		if (cnt > CQ_STAGE) {                     // more than the stage holds in one go: straight to the list
+			uint32_t base = 0;
+			if (lane == 0) base = atomicAdd(which ? n_tasks2 : n_tasks, cnt);
+			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + (uint32_t)__popcll(m & lt_mask);
+			if (mine && base < task_cap) (which ? tasks2 : tasks)[base] = make_uint2(a, b);
+			return;
+		}
 		if (nst[which] + cnt > CQ_STAGE) flush_one(which);
 		if (mine) s_stage[which][nst[which] + (uint32_t)__popcll(m & lt_mask)] = make_uint2(a, b);
 		nst[which] += cnt;
