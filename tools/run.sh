@@ -19,7 +19,7 @@ tests)
 	timeout ${LIMIT:-2400} python -m pytest ${@:-tests} -q -m gpu > $O/${TAG}_gputests.txt 2>&1; echo "tests exit $? after $((SECONDS - T0)) s" >> $O/${TAG}_gputests.txt
 	grep -n "^FAILED\|^ERROR\|passed\|failed\|tests exit" $O/${TAG}_gputests.txt | tail -12 ;;
 bench)
-	(while true; do echo "$(date +%s) $(cat /sys/fs/cgroup/memory.current 2>/dev/null) $(df --output=used -B1 /dev/shm | tail -1)"; sleep 2; done) > $O/${TAG}_mem.txt & MW=$!
+	(while true; do echo "$(date +%s) $(cat /sys/fs/cgroup/memory.current 2>/dev/null) $(df --output=used -B1 /dev/shm | tail -1) $(grep -E '^(anon|file|shmem|file_mapped|kernel) ' /sys/fs/cgroup/memory.stat 2>/dev/null | tr '\n' ' ')"; sleep 2; done) > $O/${TAG}_mem.txt & MW=$!
 	T0=$SECONDS
 	timeout ${LIMIT:-2400} python bench.py --gpus 1 --steps 20 --warmup 5 "$@" > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 	echo "bench exit $? after $((SECONDS - T0)) s"; kill $MW
