@@ -78,3 +78,8 @@ summary["_meta"] = {"tag": TAG, "commit": os.environ.get("PROFILE_COMMIT", "unkn
 json.dump(summary, open('%s/%s_pmc_summary.json' % (O, TAG), 'w'), indent=1)
 print('\n'.join(out[:16])); print('\n'.join(lines[:8]))
 PY
+# the raw rocprofv3 output is tens of megabytes per pass (gpurun brings back at most 64 MiB): keep the kernel trace of the first pass (the
+# batch timeline is made from it, tools/timeline.py) compressed, drop the rest
+python $R/tools/timeline.py $O/${TAG}_kt 2 > $O/${TAG}_batch_timeline.txt 2>&1
+for f in $(find $O/${TAG}_kt -name '*kernel_trace.csv' | head -1); do grep -v "rocprim\|k_acx\|fillBuffer" $f | gzip -c > $O/${TAG}_kernel_trace.csv.gz; done
+rm -rf $O/${TAG}_kt $O/${TAG}_fetch $O/${TAG}_write $O/${TAG}_sq $O/${TAG}_sq2

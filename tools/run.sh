@@ -52,9 +52,9 @@ shape)
 	echo "$1 exit $?"; sum "$1" $O/${TAG}_$1.json; rm -rf $W.$1 ;;
 cli)
 	S=$1; shift
-	python bench.py --workdir $W --db-scale $S --keep-files $QUIET --steps 2 --warmup 1 > /dev/null 2> $O/${TAG}_cli_setup.err
+	if ! ls $W/db_*.edx > /dev/null 2>&1; then python bench.py --workdir $W --db-scale $S --keep-files $QUIET --steps 2 --warmup 1 > /dev/null 2> $O/${TAG}_cli_setup.err; fi
 	EDX=$(ls $W/db_*.edx | head -1); RD=$(ls $W/reads_*.fa | head -1)
 	BHIP_DEBUG=1 BURST_HOST_DEBUG=1 timeout ${LIMIT:-900} burst_amd/burst_hip -r $EDX -ad -k 15 -q $RD -o $W/cli.b6 -m BEST -i 0.98 "$@" > $O/${TAG}_cli.txt 2>&1
-	echo "cli exit $?"; grep "Alignment time\|\] *[0-9.]* s\|accelerator built" $O/${TAG}_cli.txt | cut -c1-300; rm -f $W/cli.b6 ;;
+	echo "cli exit $?"; grep "Alignment time\| s\]\|accelerator built\|record area" $O/${TAG}_cli.txt | cut -c1-300; rm -f $W/cli.b6 ;;
 *) sed -n 2,12p "$0"; exit 1 ;;
 esac

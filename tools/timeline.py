@@ -4,7 +4,9 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_prefilter_cf" in r["Kernel_Name"] or "k_prefilter_mask" in r["Kernel_Name"]]
+def first_pass(n):      # the prefilter kernel that opens a batch's chain (not the second pass over overflowed queries: k_prefilter_cq<M, 1>, k_prefilter_cf<11, 4>)
+    return ("k_prefilter_cq<" in n and ", 0>" in n) or ("k_prefilter_cw<" in n and ", 0>" in n) or ("k_prefilter_cf<" in n and "<11, 4>" not in n) or "k_prefilter_mask" in n
+idx = [i for i, r in enumerate(rows) if first_pass(r["Kernel_Name"])]
 if len(idx) < back + 1:
     idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_seed_ranges")]
 i0, i1 = idx[-back], idx[-back + 1]
