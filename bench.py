@@ -801,7 +801,17 @@ def main():
     # --warmup 1 in front of the timed region's second batch)
     if not args.no_prime:
         search([pool_range(k % P) for k in range(4)] if world == 1 else job_share(0, 4 if weak else 4 * world))
-    search(job_share(0, max(1, args.warmup)))
+    w_run = search(job_share(0, max(1, args.warmup)))
+    # The record buffer is sized from what the warm-up found: a database with strain-level redundancy returns twenty equally good references
+    # per read where the default one returns one, and a buffer that has to grow inside the timed region (page-locked memory, a copy of
+    # everything held so far) would be the measurement.  The command line sizes its buffer once per job as well.
+    if not use_dist:
+        per_step = int(w_run.c.nHits) / max(1, args.warmup)
+        need_rec = int(per_step * args.steps * 1.15) + (1 << 20)
+        if need_rec > cap_rec:
+            cap_rec = need_rec
+            _own.reserve(cap_rec)
+            search(job_share(0, 1))          # (one batch into the new buffer: its pages touched outside the timed region)
     elapsed, n_records, run = timed(job_share(args.warmup, args.steps))
     total_reads = job_reads(args.warmup, args.steps)
     own_main = rs.own_stats() if use_dist else (run.stats(), int(run.c.nBatches), float(run.c.secAlign))          # (this rank's counters of the timed job: the jobs below overwrite them)
