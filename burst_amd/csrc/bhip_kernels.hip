@@ -3151,12 +3151,13 @@ __global__ __launch_bounds__(64) void k_rescore(
 		uint32_t *__restrict__ err_flags,
 		const uint32_t *__restrict__ qpack, uint32_t band_rows, uint32_t qw, uint32_t rw) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-	__shared__ uint32_t s_mm[16];      // match masks: bit r of s_mm[q] = (cost(q, r) == 0)
+	__shared__ uint32_t s_mm[16];      // match masks: bit r of s_mm[q] = (cost(q, r) == 0), bit 16 + r = (cost(q, r) != 255): a finite cost is 0 or 1
+	                                   // (nucleotide table: 255 exactly against the pad code 0; -x: the identity table, a pad costs 1 like any other symbol, burst.c:696-697)
 	const uint32_t tid = threadIdx.x;
 	uint32_t *s_band = smem + tid;                              // [k * 64]
 	uint32_t *s_q = smem + (size_t)(band_rows + 1) * 64 + tid;  // [j * 64]
 	uint32_t *s_r = s_q + (size_t)qw * 64;                      // [j * 64]
-	if (tid < 16) { uint32_t m = 0; for (int r = 0; r < 16; ++r) m |= (lut[16 * tid + r] == 0 ? 1u : 0u) << r; s_mm[tid] = m; }
+	if (tid < 16) { uint32_t m = 0; for (int r = 0; r < 16; ++r) m |= (lut[16 * tid + r] == 0 ? 1u : 0u) << r | (lut[16 * tid + r] != 255 ? 1u : 0u) << (16 + r); s_mm[tid] = m; }
 	__syncthreads();
 	const uint32_t *refw = (const uint32_t *)refb;
 	uint32_t n = wide_in ? *n_wide_in : *n_raw_dev;
@@ -3225,7 +3226,7 @@ __global__ __launch_bounds__(64) void k_rescore(
 			uint32_t qc;
 			if (pre) { if (((y - 1) & 7) == 0) qdw = s_q[(uint32_t)((y - 1) >> 3) * 64]; qc = (qdw >> (4 * ((y - 1) & 7))) & 15u; }
 			else qc = qcodes[qb + y - 1] & 15u;
-			const uint32_t mrow = s_mm[qc], m1 = qc ? 0xFFFEu : 0u;
+			const uint32_t mrow = s_mm[qc], m1 = mrow >> 16;
 			const uint32_t col0 = (uint32_t)y <= B ? (((uint32_t)y << SS) | (255u << GS) | (uint32_t)y) : INVALID;   // D=y, H=0, V=y (burst.c:747-750)
 			const int x0 = y + dlo;
 			uint32_t left = (x0 - 1 == 0) ? col0 : INVALID;
@@ -3402,11 +3403,11 @@ __device__ __forceinline__ void rescore_reg_one(
 			const uint32_t qi = (uint32_t)(y - 1);
 			if ((qi & 7u) == 0 && qi) { qd = q_next; q_next = (qi >> 3) + 1 < qw ? qp[(qi >> 3) + 1] : 0u; }
 			const uint32_t qc = (qd >> (4 * (qi & 7u))) & 15u;
-			const uint32_t m1 = qc ? 0xFFFEu : 0u;
 			const uint32_t col0 = (uint32_t)y <= B ? (((uint32_t)y << SS) | Z0 | (uint32_t)y) : INVALID;   // D=y, H=0, V=y (burst.c:747-750)
 			const int x0 = y + dlo;
 			const bool fast_row = y > 1 && x0 >= 1 && dclean && ((fastq >> qc) & 1u);
 			const uint32_t mrow = fast_row ? 0u : s_mm[qc];      // (the usual row needs no table: no LDS round trip per row)
+			const uint32_t m1 = mrow >> 16;                      // (costs that are finite: all but the pad column with the nucleotide table)
 			uint32_t dd[NW - 1];
 			{
 				const uint32_t sh = 4u * ((uint32_t)p & 7u);
@@ -3521,9 +3522,10 @@ __global__ __launch_bounds__(64) void k_rescore_reg(
 		const uint8_t *__restrict__ refb, const uint64_t *__restrict__ ref_off, const uint32_t *__restrict__ clump_len,
 		const uint8_t *__restrict__ lut,
 		BhipHit *__restrict__ out, uint32_t *__restrict__ n_out, uint32_t out_cap, uint32_t *__restrict__ err_flags) {
-	__shared__ uint32_t s_mm[16];      // match masks: bit r of s_mm[q] = (cost(q, r) == 0)
+	__shared__ uint32_t s_mm[16];      // match masks: bit r of s_mm[q] = (cost(q, r) == 0), bit 16 + r = (cost(q, r) != 255): a finite cost is 0 or 1
+	                                   // (nucleotide table: 255 exactly against the pad code 0; -x: the identity table, a pad costs 1 like any other symbol, burst.c:696-697)
 	const uint32_t tid = threadIdx.x;
-	if (tid < 16) { uint32_t mm = 0; for (int r = 0; r < 16; ++r) mm |= (lut[16 * tid + r] == 0 ? 1u : 0u) << r; s_mm[tid] = mm; }
+	if (tid < 16) { uint32_t mm = 0; for (int r = 0; r < 16; ++r) mm |= (lut[16 * tid + r] == 0 ? 1u : 0u) << r | (lut[16 * tid + r] != 255 ? 1u : 0u) << (16 + r); s_mm[tid] = mm; }
 	__syncthreads();
 	// bit q: query symbol q is one of A, C, G, T and among those four matches only itself (the rows whose costs need no table)
 	uint32_t fastq = 0;
