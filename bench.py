@@ -985,9 +985,12 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u32 bit-vectors (u8 edit distances)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3] shape on %d GPU(s): %d synthetic %d-bp reads per step (0-2 edits), -m %s -i %s, vs %d references x %d bp "
-                                   "(%.2f Gbp; %d clumps; .edx %.2f GB + DB%d .acx %.2f GB); every step stages its batch afresh through the product's batch scheduler"
+                                   "(%.2f Gbp; %s%d clumps; .edx %.2f GB + DB%d .acx %.2f GB); every step stages its batch afresh through the product's batch scheduler"
                                    % (world, args.reads, args.read_len, args.mode, args.id, args.n_base * args.n_variants, args.ref_len,
-                                      args.n_base * args.n_variants * args.ref_len / 1e9, db.c.numRclumps, edx_bytes / 1e9, args.K, acx_bytes / 1e9),
+                                      args.n_base * args.n_variants * args.ref_len / 1e9,
+                                      "" if args.db_profile == "pairs" else "--db-profile strains: 70 % pairs at 5 %, 30 % families of 60 / 200 / 500 strains at 1 / 0.5 / 0.1 %; ",
+                                      db.c.numRclumps, edx_bytes / 1e9, args.K, acx_bytes / 1e9),
+                       "db_profile": args.db_profile,
                        "parallelism": ("query-sharded x%d (%s, in device batches of up to %d), DB replicated; " % (world, "weak scaling: every rank aligns %d batches of its own, the job is N times the single-GPU job" % args.steps
                                                                                                                      if weak else "strong scaling: rank r aligns the r-th N-th of the single-GPU job's unique queries", batch_uniq)) +
                                       ("no collective on the data path: every rank's record buffer is a page-locked shared-memory segment (its batches' records land there over its own PCIe link, behind the "

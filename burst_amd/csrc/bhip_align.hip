@@ -34,20 +34,64 @@ __global__ void k_junk_adjust_best(uint32_t *__restrict__ best, const uint8_t *_
 		if (nx_six[s] && best[s] != 0xFFFFFFFFu) best[s] += nx_six[s];
 }
 
-__global__ void k_hit_fix(BhipHit *__restrict__ out, const uint32_t *__restrict__ off, const uint32_t *__restrict__ cnt, uint32_t n_q) {
-	for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_q; q += gridDim.x * blockDim.x) {
-		const uint32_t n = cnt[q];
-		if (n < 2) continue;
-		BhipHit *a = out + off[q];
-		uint32_t gap = 1;
-		while (gap < n / 3) gap = 3 * gap + 1;          // Shell sort (plain insertion sort for the usual 2..4 records)
-		for (; gap >= 1; gap /= 3)
-			for (uint32_t i = gap; i < n; ++i) {
-				const BhipHit v = a[i];
-				uint32_t j = i;
-				for (; j >= gap && a[j - gap].refIx > v.refIx; j -= gap) a[j] = a[j - gap];
-				a[j] = v;
+// The records of a query, scattered in arrival order, into reference order.  Round 5: one WAVE per group that needs it, a rank sort --
+// lane l holds record l, its place is the number of records of the group with a smaller reference number ((query, reference) pairs are
+// unique) -- instead of one thread per query shell-sorting 20-byte records in global memory: with strain-level redundancy every read
+// has twenty equally good references (and some hundreds), and a wave took as long as its longest query: 330 of a batch's 410 ms.
+// Groups of up to 64 records are permuted through registers; larger ones go through `scratch` (a buffer of their own,
+// same size, same offsets) 64 records at a time, each ranked against the whole group.
+__global__ __launch_bounds__(256) void k_hit_fix(BhipHit *__restrict__ out, const uint32_t *__restrict__ off, const uint32_t *__restrict__ cnt, uint32_t n_q,
+                                               BhipHit *__restrict__ scratch, uint32_t scratch_cap) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+	struct Rec { uint32_t w[5]; };
+	static_assert(sizeof(BhipHit) == 20, "BhipHit is five dwords");
+	for (uint32_t q0 = wave * 64u; q0 < n_q; q0 += n_waves * 64u) {
+		const uint32_t q = q0 + lane;
+		const uint32_t n_mine = q < n_q ? cnt[q] : 0u, o_mine = q < n_q ? off[q] : 0u;
+		unsigned long long todo = __ballot(n_mine >= 2u);
+		while (todo) {
+			const int b = __builtin_ctzll(todo);
+			todo &= todo - 1ull;
+			const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)n_mine, b), o = (uint32_t)__builtin_amdgcn_readlane((int)o_mine, b);
+			Rec *grp = (Rec *)(out + o);
+			if (n <= 64u) {
+				Rec r = {};
+				if (lane < n) r = grp[lane];
+				const uint32_t key = lane < n ? r.w[1] : 0xFFFFFFFFu;          // refIx
+				uint32_t rank = 0;
+				for (uint32_t j = 0; j < n; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)key, (int)j) < key ? 1u : 0u;
+				if (lane < n) grp[rank] = r;                                   // (every lane's load is complete before the first store: the rank depends on all keys)
+			} else if ((uint64_t)o + n <= scratch_cap) {
+				Rec *tmp = (Rec *)(scratch + o);
+				for (uint32_t i = lane; i < n; i += 64u) tmp[i] = grp[i];
+				__threadfence();
+				for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+					const uint32_t i = i0 + lane;
+					Rec r = {};
+					if (i < n) r = tmp[i];
+					const uint32_t key = i < n ? r.w[1] : 0xFFFFFFFFu;
+					uint32_t rank = 0;
+					for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
+						const uint32_t kj = j0 + lane < n ? tmp[j0 + lane].w[1] : 0xFFFFFFFFu;
+						const uint32_t m = n - j0 < 64u ? n - j0 : 64u;
+						for (uint32_t j = 0; j < m; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)kj, (int)j) < key ? 1u : 0u;
+					}
+					if (i < n) grp[rank] = r;
+				}
+			} else if (lane == 0) {                                            // (no scratch of that size: the serial sort)
+				BhipHit *a = out + o;
+				uint32_t gap = 1;
+				while (gap < n / 3) gap = 3 * gap + 1;
+				for (; gap >= 1; gap /= 3)
+					for (uint32_t i = gap; i < n; ++i) {
+						const BhipHit v = a[i];
+						uint32_t j = i;
+						for (; j >= gap && a[j - gap].refIx > v.refIx; j -= gap) a[j] = a[j - gap];
+						a[j] = v;
+					}
 			}
+		}
 	}
 }
 __global__ void k_set_rank_ptrs(SharedCtr *sc, uint32_t *cnt, uint32_t *rank) { sc->cnt = cnt; sc->rank = rank; }
@@ -789,7 +833,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			size_t tmp_bytes = 0;
 			uint32_t *cnt = nullptr, *off = nullptr, *rank = nullptr;
 			if ((rc = h->sort_idx.reserve((size_t)h->out_cap * 4)) || (rc = h->sort_keys.reserve((size_t)(n_q + 1) * 4)) || (rc = h->sort_keys2.reserve((size_t)(n_q + 1) * 4)) ||
-			    (rc = sorted.reserve((size_t)h->out_cap * sizeof(BhipHit)))) return rc;
+			    (rc = sorted.reserve((size_t)h->out_cap * sizeof(BhipHit))) || (rc = h->sort_scratch.reserve((size_t)h->out_cap * sizeof(BhipHit)))) return rc;
 			cnt = h->sort_keys.as<uint32_t>(); off = h->sort_keys2.as<uint32_t>(); rank = h->sort_idx.as<uint32_t>();
 			HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, off, (int)(n_q + 1), h->post_stream));
 			if ((rc = h->sort_tmp.reserve(tmp_bytes))) return rc;
@@ -801,7 +845,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->sort_tmp.p, tmp_bytes, cnt, off, (int)(n_q + 1), h->post_stream));
 			hipLaunchKernelGGL(k_hit_scatter, dim3(g), dim3(256), 0, h->post_stream, h->out.as<BhipHit>(), (uint32_t)h->out_cap, &sc->n_out, off, rank, sorted.as<BhipHit>(),
 				h->cur->has_qmap ? h->cur->qmap.as<uint32_t>() : (const uint32_t *)nullptr);
-			hipLaunchKernelGGL(k_hit_fix, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, h->post_stream, sorted.as<BhipHit>(), off, cnt, n_q);
+			hipLaunchKernelGGL(k_hit_fix, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, h->post_stream, sorted.as<BhipHit>(), off, cnt, n_q, h->sort_scratch.as<BhipHit>(), (uint32_t)(h->sort_scratch.cap / sizeof(BhipHit)));
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipEventRecord(h->ev[5], h->post_stream));
 			sorted_ahead = true;
@@ -917,7 +961,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			if (sorted_ahead && o == o_ahead) tq1 = tq();          // grouped already, behind the re-scorer
 			else {
 			if (h->copy_pending[o]) { HIPCHK(hipEventSynchronize(h->ev_copied[o])); h->copy_pending[o] = false; }    // the copy that last read this buffer
-			if ((rc = sorted.reserve((size_t)n * sizeof(BhipHit)))) return rc;
+			if ((rc = sorted.reserve((size_t)n * sizeof(BhipHit))) || (rc = h->sort_scratch.reserve((size_t)n * sizeof(BhipHit)))) return rc;
 			uint32_t *cnt = h->sort_keys.as<uint32_t>(), *off = h->sort_keys2.as<uint32_t>(), *rank = h->sort_idx.as<uint32_t>();
 			const uint32_t g = std::min<uint32_t>((n + 255) / 256, (uint32_t)h->n_cu * 8);
 			HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(n_q + 1) * 4, h->stream));
@@ -929,7 +973,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->sort_tmp.p, tmp_bytes, cnt, off, (int)(n_q + 1), h->stream));
 			hipLaunchKernelGGL(k_hit_scatter, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, (const uint32_t *)nullptr, off, rank, sorted.as<BhipHit>(),
 				h->cur->has_qmap ? h->cur->qmap.as<uint32_t>() : (const uint32_t *)nullptr);
-			hipLaunchKernelGGL(k_hit_fix, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, h->stream, sorted.as<BhipHit>(), off, cnt, n_q);
+			hipLaunchKernelGGL(k_hit_fix, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, h->stream, sorted.as<BhipHit>(), off, cnt, n_q, h->sort_scratch.as<BhipHit>(), (uint32_t)(h->sort_scratch.cap / sizeof(BhipHit)));
 			HIPCHK(hipGetLastError());
 			}
 			tq2 = tq();

@@ -307,7 +307,7 @@ struct Handle {
 	const uint64_t *s_off() const { return cur->st_has_junk ? cur->qoff_s.as<uint64_t>() : cur->qoff.as<uint64_t>(); }
 	const uint16_t *s_emac() const { return cur->st_has_junk ? cur->qemac_s.as<uint16_t>() : cur->qemac.as<uint16_t>(); }
 	const uint32_t *s_pack() const { return cur->st_has_junk ? cur->qpack_s.as<uint32_t>() : cur->qpack.as<uint32_t>(); }
-	DBuf sort_keys, sort_keys2, sort_idx, sort_tmp, out_sorted, out_sorted2;   // sort_keys / sort_keys2: per-query record counts / offsets; sort_idx: rank of a record inside its query
+	DBuf sort_keys, sort_keys2, sort_idx, sort_tmp, out_sorted, out_sorted2, sort_scratch;   // sort_keys / sort_keys2: per-query record counts / offsets; sort_idx: rank of a record inside its query
 	uint64_t out_cap = 1 << 20;
 	std::vector<uint32_t> h_clump_len;
 	BhipStats stats;

@@ -73,7 +73,7 @@ extern "C" void bhip_destroy(void *handle) {
 	for (Lane *L : h->lanes) lane_destroy(L);
 	DBuf *all[] = {&h->ref_lane, &h->ref_off, &h->clump_len, &h->lut, &h->acx_lines, &h->acx_rec, &h->bad,
 		&h->best, &h->out, &h->shared_ctr, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx,
-		&h->sort_tmp, &h->out_sorted, &h->out_sorted2};
+		&h->sort_tmp, &h->out_sorted, &h->out_sorted2, &h->sort_scratch};
 	for (int o = 0; o < 2; ++o) {
 		if (h->copy_pending[o] && h->ev_copied[o]) (void)hipEventSynchronize(h->ev_copied[o]);
 		if (h->reg_ptr[o]) (void)hipHostUnregister(h->reg_ptr[o]);

@@ -99,6 +99,25 @@ def test_align_batch_exhaustive_matches_oracle(qlen, edits, thres, iupac, seed, 
     dev.close()
 
 
+@pytest.mark.parametrize("n_var", [40, 70, 150, 333])
+def test_many_records_per_query_come_out_in_the_oracle_order(n_var):
+    """k_hit_fix: a query's records leave the device ordered like the host's list (reference number, then the rest) whatever the order the
+    lanes finished in -- groups of up to 64 records ranked in registers, larger ones through the scratch copy 64 at a time"""
+    from burst_amd import capi
+    seqs = family_db(700 + n_var, 2, n_var, 260, rate=0.004)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lut = ol.score_lut(1)
+    dev = capi.Device(packed, clump_len, tot, lut)
+    q, _ = make_queries(seqs, 30, 100, [0, 1, 2], 700 + n_var, thres=0.95)
+    for all_hits in (True, False):
+        got = dev.align_batch(q, all_hits=all_hits)
+        exp = oracle_hits(packed, clump_len, tot, q, lut, all_hits)
+        if all_hits:
+            assert np.bincount(exp["q"]).max() > min(n_var, 300) * 0.8       # groups on both sides of 64 and of a multiple of it
+        assert_hits_equal(got, exp)
+    dev.close()
+
+
 @pytest.mark.parametrize("qlen,edits,thres,seed", [(1025, [0, 3, 20], 0.98, 61), (1500, [0, 10, 44], 0.97, 62), (2600, [0, 25], 0.99, 63), (4050, [0, 12, 40], 0.99, 64)])
 def test_queries_beyond_1024_symbols(qlen, edits, thres, seed):
     """k_myers_long (vector in LDS, any number of words up to BHIP_MAX_QLEN symbols): the sweep on its own against aded of the oracle,
