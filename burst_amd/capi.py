@@ -44,7 +44,8 @@ class BhipQuerySpan(C.Structure):
 
 EXPORTS = ["bhip_init", "bhip_stage_queries", "bhip_align_staged", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_set_option", "bhip_get_stats",
            "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version", "bhip_copy_hits_device", "bhip_sync_hits",
-           "bhip_comm_create", "bhip_comm_unique_id", "bhip_comm_create_rank", "bhip_comm_allreduce_min", "bhip_comm_fetch_gathered", "bhip_comm_gather_hits", "bhip_comm_stage_device", "bhip_comm_gather_staged", "bhip_comm_stage_reset", "bhip_comm_destroy", "bhip_acx_export", "bhip_reserve", "bhip_reserve_symbols", "bhip_sort_queries", "bhip_stage_spans", "bhip_alloc_host", "bhip_free_host", "bhip_host_register", "bhip_host_unregister", "bhip_set_enqueued_hook", "bhip_acx_export_entries"]
+           "bhip_comm_create", "bhip_comm_unique_id", "bhip_comm_create_rank", "bhip_comm_allreduce_min", "bhip_comm_fetch_gathered", "bhip_comm_gather_hits", "bhip_comm_stage_device", "bhip_comm_gather_staged", "bhip_comm_stage_reset", "bhip_comm_destroy", "bhip_acx_export", "bhip_reserve", "bhip_reserve_symbols", "bhip_sort_queries", "bhip_stage_spans", "bhip_alloc_host", "bhip_free_host", "bhip_host_register", "bhip_host_unregister", "bhip_set_enqueued_hook", "bhip_acx_export_entries",
+           "bhip_build_accelerator_shared", "bhip_comm_share", "bhip_team_create", "bhip_team_destroy", "bhip_team_share", "bhip_device_copy"]
 
 
 class BurstHipError(RuntimeError):
@@ -109,6 +110,14 @@ def _load():
     lib.bhip_comm_destroy.restype = None
     lib.bhip_acx_export.argtypes = [vp, vp, vp, vp, u64, C.POINTER(u64), vp, u32, C.POINTER(u32)]
     lib.bhip_acx_export.restype = i32
+    lib.bhip_build_accelerator_shared.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.bhip_build_accelerator_shared.restype = i32
+    lib.bhip_team_create.argtypes = [i32, C.POINTER(vp)]
+    lib.bhip_team_create.restype = i32
+    lib.bhip_team_destroy.argtypes = [vp]
+    lib.bhip_team_destroy.restype = None
+    lib.bhip_device_copy.argtypes = [vp, vp, u64, i32]
+    lib.bhip_device_copy.restype = i32
     return lib
 
 

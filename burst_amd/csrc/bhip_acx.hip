@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void k_acx_wcount(const uint4 *__restrict__ re
 		const uint32_t c = grp * 16u + cl;
 		if (c < n_clumps && !is_bad[c] && 16ull * c + zz < tot_refs) {
 			const uint32_t L = clump_len[c], nchunks = (L + 31) >> 5;
-			acx_lane_words(ref + ref_off[c] * 16 + (uint64_t)zz * nchunks, L, nchunks, K, z, [&](uint32_t w) { atomicAdd(&s_cnt[cl][s_b2s[w >> shift]], 1u); });
+			acx_lane_words(ref + ref_off[c] * 16 + (uint64_t)zz * nchunks, L, nchunks, K, z, [&](uint32_t w) { const uint32_t sl = s_b2s[w >> shift]; if (sl != 0xFFu) atomicAdd(&s_cnt[cl][sl], 1u); });      // (0xFF: another rank's words, cooperative build)
 		}
 		__syncthreads();
 		for (uint32_t i = threadIdx.x; i < 16u * n_slices; i += 256) {
@@ -632,18 +632,62 @@ __global__ void k_acx_wfill(const unsigned long long *__restrict__ ukeys, const 
 	}
 }
 
-static int build_accelerator_by_words(Handle *h, int K, int z) {
+// Cooperative form (n_parts > 1; bhip_build_accelerator_shared): the database is replicated over n_parts devices and every one of them needs
+// the whole accelerator.  Rank `part` builds the lists of ITS run of word buckets only -- the runs are cut from the bucket histogram, which
+// every rank computes alike, so that they hold equal numbers of tuples; a run's records are one contiguous region of the record area and its
+// list lengths one contiguous range of Lens -- and the ranks then complete each other's arrays through `share` (bhip_share_fn: RCCL
+// broadcasts over xGMI, peer copies between the threads of one process, or whatever the caller has): first Lens (4^K x 4 bytes in all),
+// from which everyone derives the same offset lines and the regions' places, then the records.  A rank's work is 1/n_parts of the sort
+// and fold plus the scans over the whole database (the histogram, the counts, one per slice); what crosses the links is (n - 1)/n of the
+// tables INTO every rank.  A rank that cannot do its share says so in the first exchange and ALL ranks return 1 (the caller builds alone).
+struct U32To64 { __host__ __device__ unsigned long long operator()(const uint32_t &x) const { return (unsigned long long)x; } };
+// [0, bytes) of `base` moved up by `shift` bytes (the ranges may overlap: from the top down, in pieces no longer than the shift; a small
+// shift goes through a bounce buffer)
+static int acx_move_up(Handle *h, char *base, size_t bytes, size_t shift) {
+	if (!shift || !bytes) return 0;
+	const size_t kPiece = (size_t)256 << 20;
+	if (shift >= bytes) { HIPCHK(hipMemcpyAsync(base + shift, base, bytes, hipMemcpyDeviceToDevice, h->stream)); return 0; }
+	if (shift >= ((size_t)16 << 20)) {
+		const size_t piece = std::min(shift, kPiece);
+		for (size_t end = bytes; end > 0;) { const size_t n = std::min(piece, end); end -= n; HIPCHK(hipMemcpyAsync(base + end + shift, base + end, n, hipMemcpyDeviceToDevice, h->stream)); }
+		return 0;
+	}
+	DTmp bounce;
+	ARC(bounce.reserve(kPiece));
+	for (size_t end = bytes; end > 0;) {
+		const size_t n = std::min(kPiece, end); end -= n;
+		HIPCHK(hipMemcpyAsync(bounce.p, base + end, n, hipMemcpyDeviceToDevice, h->stream));
+		HIPCHK(hipMemcpyAsync(base + end + shift, bounce.p, n, hipMemcpyDeviceToDevice, h->stream));
+	}
+	HIPCHK(hipStreamSynchronize(h->stream));
+	return 0;
+}
+static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int n_parts = 1, bhip_share_fn share = nullptr, void *share_ctx = nullptr) {
+	const bool coop = n_parts > 1;
 	const uint32_t nC = h->n_clumps;
 	const uint64_t nw = 1ull << (2 * K);
 	const bool dbg = getenv("BHIP_DEBUG") != nullptr;
 	const auto t_begin = std::chrono::steady_clock::now();
 	auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
 	uint32_t cbits = 1; while ((1ull << cbits) < nC) ++cbits;
+	const uint32_t bb = (uint32_t)std::min(12, 2 * K), shift = (uint32_t)(2 * K) - bb, n_buckets = 1u << bb;
+	const uint32_t g = (uint32_t)h->n_cu * 16;
+	const uint64_t n_lines = (nw + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS;
+	const uint32_t all_lanes = getenv("BHIP_NO_LANE_MASKS") ? 1u : 0u;
+	std::vector<uint32_t> badlist;
+	std::vector<uint32_t> rb((size_t)n_parts + 1, 0);      // bucket boundaries of the ranks' runs
+	DTmp d_lens;
+	uint64_t rec_n = 0, total = 0, cap_items = 0;
+	uint32_t n_slices = 0;
+	double t_hist = 0, t_count = 0, t_sort = 0;
+	// everything a rank does on its own: 0 = its lists are built (records [0, rec_n) of the record area, their lengths in d_lens),
+	// 1 = cannot run here, < 0 = error
+	auto local_part = [&]() -> int {
 	if (cbits > 24) return 1;
+	if (coop) if (const char *ev = getenv("BHIP_TEST_COOP_FAIL_RANK")) if (atoi(ev) == part) return 1;      // (test hook: this rank cannot -> all ranks build alone)
 	// 1. expansion estimate per clump -> BadList (as the clump-sliced builder)
 	std::vector<unsigned long long> tsum(nC), nexp(nC);
 	std::vector<uint8_t> is_bad(nC, 0);
-	std::vector<uint32_t> badlist;
 	DTmp d_bad;
 	{
 		DTmp d_ts, d_nx;
@@ -657,18 +701,14 @@ static int build_accelerator_by_words(Handle *h, int K, int z) {
 		HIPCHK(hipStreamSynchronize(h->stream));
 	}
 	const unsigned long long full_size = K > 14 ? 0x7FFFFFFFull : (1ull << 24);      // burst.c:3322
-	uint64_t upper = 0;            // tuples of the whole database: an upper bound of its list entries
 	for (uint32_t c = 0; c < nC; ++c) {
 		if (tsum[c] >= full_size) { is_bad[c] = 1; badlist.push_back(c); continue; }
-		const uint64_t n = 16ull * h->h_clump_len[c] + nexp[c];
-		if (n >= (1ull << 31)) return 1;
-		upper += n;
+		if (16ull * h->h_clump_len[c] + nexp[c] >= (1ull << 31)) return 1;
 	}
 	ARC(d_bad.reserve((size_t)nC + 16));
 	HIPCHK(hipMemcpyAsync(d_bad.p, is_bad.data(), nC, hipMemcpyHostToDevice, h->stream));
-	// 2. tuples per bucket of words -> slices: runs of buckets with at most `target` tuples and at most 2^24 words (three sort passes)
-	const uint32_t bb = (uint32_t)std::min(12, 2 * K), shift = (uint32_t)(2 * K) - bb, n_buckets = 1u << bb;
-	const uint32_t g = (uint32_t)h->n_cu * 16;
+	// 2. tuples per bucket of words -> the ranks' runs of buckets (equal numbers of tuples), and inside this rank's run the slices: runs of
+	// buckets with at most `target` tuples and at most 2^24 words (three sort passes)
 	std::vector<unsigned long long> hist(n_buckets);
 	{
 		DTmp d_hist;
@@ -680,65 +720,77 @@ static int build_accelerator_by_words(Handle *h, int K, int z) {
 		HIPCHK(hipMemcpyAsync(hist.data(), d_hist.p, (size_t)n_buckets * 8, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 	}
-	const double t_hist = since();
-	uint64_t total = 0, biggest = 0;
-	for (uint32_t b = 0; b < n_buckets; ++b) { total += hist[b]; biggest = std::max<uint64_t>(biggest, hist[b]); }
+	t_hist = since();
+	uint64_t biggest = 0;
+	total = 0;
+	for (uint32_t b = 0; b < n_buckets; ++b) total += hist[b];
+	if (!total) return 1;
+	{
+		uint64_t run = 0; int r = 1;
+		for (uint32_t b = 0; b < n_buckets && r < n_parts; ++b) {
+			while (r < n_parts && run >= (uint64_t)((double)total * r / n_parts)) rb[r++] = b;      // (run = tuples of the buckets before b)
+			run += hist[b];
+		}
+		for (; r < n_parts; ++r) rb[r] = n_buckets;
+		rb[n_parts] = n_buckets;
+	}
+	const uint32_t own0 = rb[part], own1 = rb[part + 1];
+	uint64_t total_own = 0;
+	for (uint32_t b = own0; b < own1; ++b) { total_own += hist[b]; biggest = std::max<uint64_t>(biggest, hist[b]); }
 	size_t free_b = 0, total_b = 0;
 	HIPCHK(hipMemGetInfo(&free_b, &total_b));
-	const uint64_t n_lines = (nw + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS;
 	long long forced_slice = 0;
 	if (const char *ev = getenv("BHIP_MASK_SLICE")) forced_slice = atoll(ev);
 	// room for the sort of a slice (two 8-byte tuple arrays + the folded lane masks + the sort's own scratch: 19 bytes per tuple) next to
 	// everything that is or will be resident: the records (4 bytes per tuple at most), the length table and the offset lines, the counts
 	const double fixed = (double)total * BHIP_REC_BYTES + (double)nw * 4.0 + (double)n_lines * 64.0 * 1.2 + (double)nC * 8.0 + (double)(2u << 30);
 	std::vector<uint32_t> cuts;        // bucket boundaries of the slices
-	uint64_t cap_items = 0;
 	auto plan = [&](uint64_t target) -> uint32_t {
-		cuts.assign(1, 0); cap_items = 0;
+		cuts.assign(1, own0); cap_items = 0;
 		const uint32_t max_b = 24 > shift ? 1u << (24 - shift) : 1u;      // buckets whose words together span at most 2^24
-		for (uint32_t b0 = 0; b0 < n_buckets;) {
+		for (uint32_t b0 = own0; b0 < own1;) {
 			uint32_t b1 = b0 + 1; uint64_t n = hist[b0];
-			while (b1 < n_buckets && b1 - b0 < max_b && n + hist[b1] <= target) n += hist[b1++];
+			while (b1 < own1 && b1 - b0 < max_b && n + hist[b1] <= target) n += hist[b1++];
 			cuts.push_back(b1); cap_items = std::max(cap_items, n); b0 = b1;
 		}
 		return (uint32_t)cuts.size() - 1;
 	};
-	uint32_t n_slices = 0;
-	if (forced_slice > 0) n_slices = plan(std::max<uint64_t>((uint64_t)forced_slice, biggest));
-	else {
-		const uint32_t min_s = 24 > shift ? std::max(1u, n_buckets >> (24 - shift)) : n_buckets;
-		for (uint32_t want = min_s; want <= BHIP_ACX_MAX_SLICES; want *= 2) {
-			const uint64_t target = std::max<uint64_t>(biggest, (uint64_t)((double)total / want * 1.15) + 1);
-			n_slices = plan(target);
-			const double need = fixed + (double)n_slices * nC * 4.0 + (double)cap_items * 19.0 + (double)(64u << 20);
-			if (n_slices <= BHIP_ACX_MAX_SLICES && cap_items < 2147483000ull && need <= (double)free_b) break;
-			n_slices = 0;
+	const uint32_t max_slices = coop ? BHIP_ACX_MAX_SLICES - 1u : BHIP_ACX_MAX_SLICES;      // (slice number 0xFF marks another rank's buckets)
+	if (own1 > own0 && total_own) {
+		if (forced_slice > 0) n_slices = plan(std::max<uint64_t>((uint64_t)forced_slice, biggest));
+		else {
+			const uint32_t own_b = own1 - own0;
+			const uint32_t min_s = 24 > shift ? std::max(1u, (own_b + (1u << (24 - shift)) - 1u) >> (24 - shift)) : own_b;
+			for (uint32_t want = min_s; want <= 2u * BHIP_ACX_MAX_SLICES; want *= 2) {
+				const uint64_t target = std::max<uint64_t>(biggest, (uint64_t)((double)total_own / want * 1.15) + 1);
+				n_slices = plan(target);
+				const double need = fixed + (double)n_slices * nC * 4.0 + (double)cap_items * 19.0 + (double)(64u << 20);
+				if (n_slices <= max_slices && cap_items < 2147483000ull && need <= (double)free_b) break;
+				n_slices = 0;
+			}
 		}
+		if (!n_slices || n_slices > max_slices || cap_items >= 2147483000ull) return 1;
 	}
-	if (!n_slices || n_slices > BHIP_ACX_MAX_SLICES || cap_items >= 2147483000ull) return 1;
-	if (!total) return 1;
 	// the record area: an address range for the upper bound, memory as the records come
 	if (h->acx_rec.reserve_growable((size_t)total * BHIP_REC_BYTES + 16, h->device)) return 1;
 	if (const char *ev = getenv("BHIP_TEST_ENTRY_BIAS")) h->acx_bias = strtoull(ev, nullptr, 0);
 	h->K = K;
-	// 3. tuples per (slice, clump) in one scan
-	std::vector<uint8_t> b2s(n_buckets);
-	for (uint32_t s = 0; s < n_slices; ++s) for (uint32_t b = cuts[s]; b < cuts[s + 1]; ++b) b2s[b] = (uint8_t)s;
-	DTmp d_b2s, d_counts, d_off, d_lens, k0, k1, v0, nruns, tmp;
-	ARC(d_b2s.reserve(n_buckets)); ARC(d_counts.reserve_exact((size_t)n_slices * nC * 4 + 16)); ARC(d_off.reserve((size_t)nC * 4 + 16));
 	ARC(d_lens.reserve(nw * 4 + 16));
 	HIPCHK(hipMemsetAsync(d_lens.p, 0, nw * 4, h->stream));
+	if (!n_slices) { HIPCHK(hipStreamSynchronize(h->stream)); return 0; }      // (a rank whose run of buckets is empty: it only receives)
+	// 3. tuples per (slice, clump) in one scan
+	std::vector<uint8_t> b2s(n_buckets, 0xFF);
+	for (uint32_t s = 0; s < n_slices; ++s) for (uint32_t b = cuts[s]; b < cuts[s + 1]; ++b) b2s[b] = (uint8_t)s;
+	DTmp d_b2s, d_counts, d_off, k0, k1, v0, nruns, tmp;
+	ARC(d_b2s.reserve(n_buckets)); ARC(d_counts.reserve_exact((size_t)n_slices * nC * 4 + 16)); ARC(d_off.reserve((size_t)nC * 4 + 16));
 	HIPCHK(hipMemcpyAsync(d_b2s.p, b2s.data(), n_buckets, hipMemcpyHostToDevice, h->stream));
 	hipLaunchKernelGGL(k_acx_wcount, dim3(g), dim3(256), 0, h->stream, h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_bad.as<uint8_t>(),
 		nC, h->tot_refs, K, z ? 1 : 0, shift, n_buckets, d_b2s.as<uint8_t>(), n_slices, d_counts.as<uint32_t>());
 	HIPCHK(hipGetLastError());
 	ARC(k0.reserve_exact(cap_items * 8 + 16)); ARC(k1.reserve_exact(cap_items * 8 + 16)); ARC(v0.reserve_exact(cap_items * 2 + 16)); ARC(nruns.reserve(16));
 	HIPCHK(hipStreamSynchronize(h->stream));
-	const double t_count = since();
+	t_count = since();
 	// 4. slice after slice: offsets, tuples, sort over the slice's word bits, fold, records
-	const uint32_t all_lanes = getenv("BHIP_NO_LANE_MASKS") ? 1u : 0u;
-	uint64_t rec_n = 0;
-	double t_sort = 0;
 	for (uint32_t s = 0; s < n_slices; ++s) {
 		uint64_t n_items = 0;
 		for (uint32_t b = cuts[s]; b < cuts[s + 1]; ++b) n_items += hist[b];
@@ -776,16 +828,60 @@ static int build_accelerator_by_words(Handle *h, int K, int z) {
 		rec_n += n_unique;
 		HIPCHK(hipStreamSynchronize(h->stream));
 	}
-	k0.release(); k1.release(); v0.release(); tmp.release(); d_counts.release();
+	return 0;
+	};
+	int rc = local_part();
+	std::vector<uint64_t> boff((size_t)n_parts + 1, 0);
+	if (coop) {      // the list lengths of the other ranks' words (a rank that could not build its own says so: everyone leaves)
+		for (int r = 0; r <= n_parts; ++r) boff[r] = ((uint64_t)rb[r] << shift) * 4ull;
+		const int st = share(share_ctx, d_lens.p, boff.data(), part, n_parts, rc != 0);
+		if (rc < 0) return rc;
+		if (st < 0) return fail(BHIP_E_DEVICE, "cooperative accelerator build: the exchange of the list lengths failed");
+		if (rc || st) return 1;
+	} else if (rc) return rc;
+	const double t_own = since();
 	uint64_t tot = 0; uint32_t maxlen = 0;
-	ARC(acx_lines_from_lens(h, d_lens.as<uint32_t>(), nw, &tot, &maxlen));
-	if (tot != rec_n) return fail(BHIP_E_INTERNAL, "accelerator build: %llu records written, the list lengths add up to %llu", (unsigned long long)rec_n, (unsigned long long)tot);
+	rc = acx_lines_from_lens(h, d_lens.as<uint32_t>(), nw, &tot, &maxlen);
+	std::vector<unsigned long long> eoff((size_t)n_parts + 1, 0);      // first record of every rank's region
+	if (coop && !rc) {
+		DTmp d_sum, tmp;
+		rc = d_sum.reserve((size_t)n_parts * 8);
+		hipcub::TransformInputIterator<unsigned long long, U32To64, const uint32_t *> in(d_lens.as<uint32_t>(), U32To64());
+		for (int r = 0; r < n_parts && !rc; ++r) {
+			const uint64_t w0 = (uint64_t)rb[r] << shift, w1 = (uint64_t)rb[r + 1] << shift;
+			size_t tb = 0;
+			if (hipcub::DeviceReduce::Sum(nullptr, tb, in + w0, d_sum.as<unsigned long long>() + r, (int)(w1 - w0), h->stream) != hipSuccess || (rc = tmp.reserve(tb)) ||
+			    hipcub::DeviceReduce::Sum(tmp.p, tb, in + w0, d_sum.as<unsigned long long>() + r, (int)(w1 - w0), h->stream) != hipSuccess) { if (!rc) rc = fail(BHIP_E_DEVICE, "cooperative accelerator build: region sizes"); }
+		}
+		if (!rc && (hipMemcpyAsync(eoff.data() + 1, d_sum.p, (size_t)n_parts * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess))
+			rc = fail(BHIP_E_DEVICE, "cooperative accelerator build: region sizes");
+		for (int r = 0; r < n_parts; ++r) eoff[r + 1] += eoff[r];
+		if (!rc && (eoff[n_parts] != tot || eoff[part + 1] - eoff[part] != rec_n))
+			rc = fail(BHIP_E_INTERNAL, "cooperative accelerator build: rank %d wrote %llu records, its lists add up to %llu (all: %llu of %llu)", part, (unsigned long long)rec_n,
+				(unsigned long long)(eoff[part + 1] - eoff[part]), (unsigned long long)eoff[n_parts], (unsigned long long)tot);
+		// the whole record area, this rank's region moved to its place, the other regions from their builders
+		if (!rc) rc = h->acx_rec.grow_to(tot * BHIP_REC_BYTES + 16);
+		if (!rc) rc = acx_move_up(h, h->acx_rec.as<char>(), rec_n * BHIP_REC_BYTES, eoff[part] * BHIP_REC_BYTES);
+		if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(BHIP_E_DEVICE, "cooperative accelerator build: moving the region");
+		for (int r = 0; r <= n_parts; ++r) boff[r] = eoff[r] * BHIP_REC_BYTES;
+		const int st = share(share_ctx, h->acx_rec.p, boff.data(), part, n_parts, rc != 0);
+		if (rc < 0) { h->acx_rec.release(); h->acx_lines.release(); return rc; }
+		if (st < 0) { h->acx_rec.release(); h->acx_lines.release(); return fail(BHIP_E_DEVICE, "cooperative accelerator build: the exchange of the records failed"); }
+		if (st) return 1;
+	} else if (coop) {      // (the offset lines failed here: the others must not wait)
+		(void)share(share_ctx, h->acx_rec.p, boff.data(), part, n_parts, 1);
+		return rc;
+	}
+	if (rc) return rc;
+	d_lens.release();
+	if (!coop && tot != rec_n) return fail(BHIP_E_INTERNAL, "accelerator build: %llu records written, the list lengths add up to %llu", (unsigned long long)rec_n, (unsigned long long)tot);
 	ARC(set_badlist(h, badlist.data(), (uint32_t)badlist.size()));
 	h->has_acx = true; h->n_ent = tot; h->has_masks = !all_lanes;
-	if (dbg) fprintf(stderr, "[bhip] accelerator built on the device by word ranges: K=%d, %llu entries from %llu word tuples in %u slice(s) of at most %llu tuples, %zu clump(s) on the BadList, %.2f B per entry; "
-		"%.2f s (%.2f s histogram, %.2f s counts, %.2f s sort + fold)\n", K, (unsigned long long)tot, (unsigned long long)total, n_slices, (unsigned long long)cap_items, badlist.size(),
-		tot ? (double)(h->acx_rec.cap + n_lines * 64) / (double)tot : 0.0, since(), t_hist, t_count - t_hist, t_sort);
-	(void)upper;
+	if (dbg) fprintf(stderr, "[bhip] accelerator built on the device by word ranges%s: K=%d, %llu entries from %llu word tuples, %u slice(s) of at most %llu tuples here (%llu records), %zu clump(s) on the BadList, %.2f B per entry; "
+		"%.2f s (%.2f s histogram, %.2f s counts, %.2f s sort + fold, %.2f s until the own lists stood)\n", coop ? " (cooperative)" : "", K, (unsigned long long)tot, (unsigned long long)total, n_slices,
+		(unsigned long long)cap_items, (unsigned long long)rec_n, badlist.size(), tot ? (double)(h->acx_rec.cap + n_lines * 64) / (double)tot : 0.0, since(), t_hist, t_count - t_hist, t_sort, t_own);
+	if (dbg && coop) fprintf(stderr, "[bhip] rank %d of %d: words [%llu, %llu), records [%llu, %llu)\n", part, n_parts, (unsigned long long)rb[part] << shift, (unsigned long long)rb[part + 1] << shift,
+		eoff[part], eoff[part + 1]);
 	return 0;
 }
 
@@ -803,6 +899,23 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 		if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] word-sliced accelerator build not possible here: clump-sliced build\n");
 	}
 	return build_accelerator_by_clumps(h, K, z);
+}
+// The accelerator of a handle that has none (bhip_init with K = 0), built together with the other handles of a replicated database
+// (include/burst_hip.h).  1 from the cooperative builder = not possible here, on some rank: every rank then builds the whole thing itself.
+extern "C" int bhip_build_accelerator_shared(void *handle, int K, int part, int n_parts, bhip_share_fn share, void *ctx) {
+	Handle *h = (Handle *)handle;
+	if (!h) return fail(BHIP_E_ARG, "null handle");
+	if (h->has_acx) return fail(BHIP_E_ARG, "the handle has an accelerator already");
+	if (K < 4 || K > 15 || n_parts < 1 || part < 0 || part >= n_parts || (n_parts > 1 && !share)) return fail(BHIP_E_ARG, "bad arguments of the cooperative accelerator build");
+	HIPCHK(hipSetDevice(h->device));
+	if (n_parts > 1) {
+		const int rc = build_accelerator_by_words(h, K, h->acx_z, part, n_parts, share, ctx);
+		if (rc <= 0) return rc;
+		h->acx_rec.release(); h->acx_lines.release(); h->has_acx = false;
+		(void)hipGetLastError();
+		if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] cooperative accelerator build not possible here (rank %d of %d): every rank builds alone\n", part, n_parts);
+	}
+	return bhip_build_accelerator(h, K, h->acx_z);
 }
 
 static int build_accelerator_by_clumps(Handle *h, int K, int z) {
@@ -1005,6 +1118,13 @@ static int build_accelerator_by_clumps(Handle *h, int K, int z) {
 		K, (unsigned long long)tot, (unsigned long long)item_off[nC], n_slices_1, n_slices, badlist.size(), tot ? (double)(h->acx_rec.cap + n_lines * 64) / (double)tot : 0.0, since(), t_pass1, t_alloc);
 	if (dbg && rec_vmm) fprintf(stderr, "[bhip] record area: %zu chunks of 1 GiB mapped beside the first pass\n", h->acx_rec.chunks.size());
 	return 0;
+}
+
+// a piece of a device array to or from host memory (for exchanges the caller stages itself)
+extern "C" int bhip_device_copy(void *dst, const void *src, uint64_t bytes, int to_device) {
+	if (bytes && (!dst || !src)) return fail(BHIP_E_ARG, "bad copy arguments");
+	if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+	return BHIP_OK;
 }
 
 // entries [first, first + n) of the record area (word order), as clump ids (+ lane masks): for callers that write the lists piece by

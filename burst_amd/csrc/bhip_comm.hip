@@ -18,6 +18,8 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <string.h>
+#include <pthread.h>
+#include <algorithm>
 #include <vector>
 #include "burst_hip.h"
 
@@ -272,4 +274,86 @@ extern "C" int bhip_comm_allreduce_min(void *comm, int rank, uint8_t *buf, uint6
 		return bhip_fail_msg(BHIP_E_DEVICE, "minimum reduction failed on rank %d: %s", rank, r != ncclSuccess ? ncclGetErrorString(r) : hipGetErrorString(he));
 	}
 	return BHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exchanges of the cooperative accelerator build (bhip_build_accelerator_shared, bhip_acx.hip): region r of an array that every rank
+// holds is valid on rank r and must become valid everywhere.
+// RCCL: the statuses with the count exchange, then ONE group of n broadcasts, every region in place from its builder (n - 1 regions
+// arrive over n - 1 different xGMI links; pieces of at most 1 GiB so that no count exceeds what a transport takes in one call).
+extern "C" int bhip_comm_share(void *comm_rank, void *device_base, const uint64_t *byte_off, int part, int n_parts, int status) {
+	BhipCommRank *cr = (BhipCommRank *)comm_rank;
+	Comm *C = cr ? (Comm *)cr->comm : nullptr;
+	Peer *P = cr ? peer_of(C, cr->rank) : nullptr;
+	if (!P || !byte_off || C->n != n_parts || cr->rank != part) return bhip_fail_msg(BHIP_E_ARG, "bad arguments of the region exchange");
+	if (hipSetDevice(P->dev) != hipSuccess) { (void)hipGetLastError(); status = 1; }
+	std::vector<unsigned long long> all;
+	if (exchange_word(C, P, 0, status ? FAILED : (unsigned long long)byte_off[n_parts], all)) return -1;
+	for (int k = 0; k < n_parts; ++k) if (all[k] == FAILED) return 1;
+	for (int k = 0; k < n_parts; ++k) if (all[k] != byte_off[n_parts]) { bhip_fail_msg(BHIP_E_ARG, "ranks disagree on the size of the shared array"); return -1; }
+	const size_t kPiece = (size_t)1 << 30;
+	ncclResult_t r = ncclGroupStart();
+	for (int k = 0; k < n_parts && r == ncclSuccess; ++k)
+		for (uint64_t a = byte_off[k]; a < byte_off[k + 1] && r == ncclSuccess; a += kPiece) {
+			char *p = (char *)device_base + a;
+			r = ncclBroadcast(p, p, (size_t)std::min<uint64_t>(kPiece, byte_off[k + 1] - a), ncclInt8, k, P->comm, P->stream);
+		}
+	ncclResult_t r2 = ncclGroupEnd();
+	if (r == ncclSuccess) r = r2;
+	hipError_t he = r == ncclSuccess ? hipStreamSynchronize(P->stream) : hipSuccess;
+	if (r != ncclSuccess || he != hipSuccess) {
+		(void)hipGetLastError(); abort_peer(*P);
+		bhip_fail_msg(BHIP_E_DEVICE, "region exchange failed on rank %d: %s", part, r != ncclSuccess ? ncclGetErrorString(r) : hipGetErrorString(he));
+		return -1;
+	}
+	return 0;
+}
+
+// The threads of one process (burst_hip --gpus N): a barrier, every rank's array published, every rank PULLS the other regions device
+// to device (hipMemcpyPeerAsync: over xGMI between two devices, an ordinary copy when the ranks share one), a barrier.
+struct Team {
+	int n = 0;
+	pthread_barrier_t bar;
+	std::vector<void *> base; std::vector<int> dev, status, failed;
+};
+extern "C" int bhip_team_create(int n_ranks, void **team) {
+	if (!team || n_ranks < 1) return bhip_fail_msg(BHIP_E_ARG, "bad team arguments");
+	Team *T = new Team();
+	T->n = n_ranks; T->base.assign((size_t)n_ranks, nullptr); T->dev.assign((size_t)n_ranks, 0); T->status.assign((size_t)n_ranks, 0); T->failed.assign((size_t)n_ranks, 0);
+	if (pthread_barrier_init(&T->bar, nullptr, (unsigned)n_ranks)) { delete T; return bhip_fail_msg(BHIP_E_INTERNAL, "no barrier for %d ranks", n_ranks); }
+	*team = T;
+	return BHIP_OK;
+}
+extern "C" void bhip_team_destroy(void *team) { Team *T = (Team *)team; if (!T) return; pthread_barrier_destroy(&T->bar); delete T; }
+extern "C" int bhip_team_share(void *team, void *device_base, const uint64_t *byte_off, int part, int n_parts, int status) {
+	Team *T = (Team *)team;
+	if (!T || !byte_off || T->n != n_parts || part < 0 || part >= n_parts) return bhip_fail_msg(BHIP_E_ARG, "bad arguments of the region exchange");
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); status = 1; }
+	T->base[(size_t)part] = device_base; T->dev[(size_t)part] = dev; T->status[(size_t)part] = status; T->failed[(size_t)part] = 0;
+	pthread_barrier_wait(&T->bar);
+	int any = 0;
+	for (int k = 0; k < n_parts; ++k) any |= T->status[(size_t)k];
+	if (!any) {
+		hipStream_t st = nullptr;
+		bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+		const size_t kPiece = (size_t)1 << 30;
+		for (int k = 0; k < n_parts && ok; ++k) {
+			if (k == part) continue;
+			for (uint64_t a = byte_off[k]; a < byte_off[k + 1] && ok; a += kPiece) {
+				const size_t n = (size_t)std::min<uint64_t>(kPiece, byte_off[k + 1] - a);
+				ok = (T->dev[(size_t)k] == dev ? hipMemcpyAsync((char *)device_base + a, (const char *)T->base[(size_t)k] + a, n, hipMemcpyDeviceToDevice, st)
+				                              : hipMemcpyPeerAsync((char *)device_base + a, dev, (const char *)T->base[(size_t)k] + a, T->dev[(size_t)k], n, st)) == hipSuccess;
+			}
+		}
+		ok = ok && hipStreamSynchronize(st) == hipSuccess;
+		if (st) (void)hipStreamDestroy(st);
+		if (!ok) { bhip_fail_msg(BHIP_E_DEVICE, "region exchange (peer copies) failed on rank %d: %s", part, hipGetErrorString(hipGetLastError())); T->failed[(size_t)part] = 1; }
+	}
+	pthread_barrier_wait(&T->bar);      // nobody touches its array while a peer still reads it
+	if (any) return 1;
+	int bad = 0;
+	for (int k = 0; k < n_parts; ++k) bad |= T->failed[(size_t)k];
+	pthread_barrier_wait(&T->bar);      // (the flags are read before the next exchange resets them)
+	return bad ? -1 : 0;
 }

@@ -283,6 +283,7 @@ struct Handle {
 	BhipMatchMask mm;
 	BhipAlt alt;                  // compatible bases of every query symbol code (from the cost table): which ambiguous query words can vote through expansions
 	bool has_acx = false; int K = 0;
+	int acx_z = 0;                // N penalised (the cost table's N-against-N entry): what an accelerator built on the device expands
 	// accelerator: offset lines + 4-byte (clump, lane-set code) records (bhip_internal.h); entry numbers start at acx_bias
 	// (0, or the test hook BHIP_TEST_ENTRY_BIAS that pushes a small database's offsets beyond 2^32)
 	DBuf acx_lines, acx_rec, bad; uint32_t n_bad = 0; uint64_t n_ent = 0, acx_bias = 0;

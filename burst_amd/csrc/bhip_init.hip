@@ -175,8 +175,9 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		d_src.release(); d_srcoff.release(); d_flag.release();
 	}
 	// accelerator: from the file's tables, or -- acx_lens == NULL and K given -- built here from the references alone
+	h->acx_z = score_lut[16 * 5 + 5] != 0;      // N penalised (burst.c:164, -y clears it): N costs 1 even against N
 	if (acx_lens) INITRC(bhip_load_accelerator(h, acx_lens, acx_lists, acx_fmt, K, badlist, n_bad));
-	else if (K) INITRC(bhip_build_accelerator(h, K, score_lut[16 * 5 + 5] != 0));      // N penalised (burst.c:164, -y clears it): N costs 1 even against N
+	else if (K) INITRC(bhip_build_accelerator(h, K, h->acx_z));
 	INITRC(ensure_lanes(h, 1));
 	// BHIP_OPTS="name=value,name=value": tuning options for callers that have no other way to pass them (A/B runs of the command line, the
 	// tests).  Checked BEFORE the upload (bhip_opts_check below: a misspelt name must not cost a database build); here an entry that does

@@ -41,6 +41,22 @@ int bh_device_open_ex(const BhDb *db, int device, int z, int build_K, void **hip
 }
 int bh_device_open(const BhDb *db, int device, int z, void **hip_handle) { return bh_device_open_ex(db, device, z, 0, hip_handle); }
 
+/* One of n_parts handles of a REPLICATED database whose accelerator the devices build together (bhip_build_accelerator_shared: every rank
+ * the lists of its share of the words, two exchanges through `share`).  The handle goes up without an accelerator first; all ranks must be
+ * in this call together.  The caller holds the devices' gates (bh_device_gate) around the ranks' calls: ranks that share a device wait for
+ * each other inside. */
+int bh_device_open_shared(const BhDb *db, int device, int z, int build_K, int part, int n_parts, bhip_share_fn share, void *ctx, void **hip_handle) {
+	uint8_t lut[256];
+	bh_score_lut(z, lut);
+	if (db->hasAcx || db->xalpha || build_K <= 0) return bh_set_error(BH_E_USAGE, "the cooperative build is for databases without an accelerator file");
+	int rc = bhip_init(device, db->packed, db->clumpLen, db->numRclumps, db->totR, NULL, NULL, 0, 0, db->badList, db->badSz, lut, 0, hip_handle);
+	/* (a rank that has no handle still answers the first exchange, or the others would wait for it) */
+	if (rc) { static const uint64_t none[BH_MAX_RANKS + 1] = {0}; if (n_parts > 1 && n_parts <= BH_MAX_RANKS) (void)share(ctx, NULL, none, part, n_parts, 1); }
+	else rc = bhip_build_accelerator_shared(*hip_handle, build_K, part, n_parts, share, ctx);
+	if (rc) return bh_set_error(rc == BHIP_E_ARG ? BH_E_USAGE : BH_E_DEVICE, "libburst_hip: %s", bhip_last_error());
+	return BH_OK;
+}
+
 static void add_stats(BhipStats *t, const BhipStats *s) {
 	t->n_queries += s->n_queries; t->n_pairs += s->n_pairs; t->n_columns += s->n_columns; t->n_raw_hits += s->n_raw_hits;
 	t->n_hits += s->n_hits; t->acx_entries_read += s->acx_entries_read; t->bytes_algorithmic += s->bytes_algorithmic;

@@ -209,6 +209,8 @@ int  bh_search_multi_ex(BhMultiRank *ranks, int n_local, int n_ranks, void *comm
 int  bh_device_open(const BhDb *db, int device, int z, void **hip_handle);
 /* build_K > 0 and a database without accelerator tables: the device builds the accelerator itself (no .acx file) */
 int  bh_device_open_ex(const BhDb *db, int device, int z, int build_K, void **hip_handle);
+/* the same for one of n_parts handles of a replicated database that build the accelerator together (bhip_build_accelerator_shared) */
+int  bh_device_open_shared(const BhDb *db, int device, int z, int build_K, int part, int n_parts, bhip_share_fn share, void *ctx, void **hip_handle);
 
 /* ---- consolidation and .b6 output (burst.c:4553-4891); hits must be sorted by (q, refIx) ---- */
 int  bh_report(FILE *out, const BhDb *db, const BhQueries *q, const BhipHit *hits, uint64_t nHits, BhMode mode, uint64_t *nLines);

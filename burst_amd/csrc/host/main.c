@@ -344,11 +344,25 @@ int main(int argc, char **argv) {
 	int shared_dev = 0;
 	for (int a = 0; a < n_gpus; ++a) for (int b = a + 1; b < n_gpus; ++b) shared_dev |= dev_list[a] == dev_list[b];
 	omp_set_dynamic(0);
+	/* A replicated database whose accelerator is built on the devices (-ad): the ranks build it TOGETHER, each the lists of 1/N of the words,
+	 * and complete each other's tables device to device (bhip_build_accelerator_shared + bhip_team_share; BURST_HIP_SOLO_BUILD=1: every
+	 * rank builds the whole thing as before).  The gates of the devices are held here, around the ranks: ranks on one device meet inside. */
+	void *team = NULL;
+	const int coop = n_gpus > 1 && !shard_db && accel_dev && !db.hasAcx && !getenv("BURST_HIP_SOLO_BUILD");
+	if (coop && bhip_team_create(n_gpus, &team)) { fprintf(stderr, "libburst_hip: %s\n", bhip_last_error()); return 4; }
+	if (coop) {
+		for (int a = 0; a < n_gpus; ++a) { int seen = 0; for (int b = 0; b < a; ++b) seen |= dev_list[a] == dev_list[b]; if (!seen) bh_device_gate(dev_list[a], 1); }
+		printf("Accelerator: built by the %d ranks together (word ranges, device-to-device exchange)\n", n_gpus);
+	}
 	#pragma omp parallel num_threads(n_gpus)
 	{
 		const int r = omp_get_thread_num();
 		const BhDb *part = &db;
 		rcs[r] = BH_OK;
+		if (coop) {
+			if (omp_get_num_threads() != n_gpus) rcs[r] = BH_E_INTERNAL;      /* (no team: nobody enters the exchange) */
+			else if ((rcs[r] = bh_device_open_shared(&db, dev_list[r], z, K, r, n_gpus, bhip_team_share, team, &hhs[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
+		} else {
 		if (shard_db) {      /* this rank's clumps: a view of the clump area + (with an .acx) the lists restricted to it */
 			uint32_t c0, c1;
 			bh_clump_shard(&db, n_shards, r % n_shards, &c0, &c1);
@@ -362,7 +376,10 @@ int main(int argc, char **argv) {
 			#pragma omp critical (bh_device_open)
 			if ((rcs[r] = bh_device_open_ex(part, dev_list[r], z, accel_dev ? K : 0, &hhs[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
 		} else if (!rcs[r] && (rcs[r] = bh_device_open_ex(part, dev_list[r], z, accel_dev ? K : 0, &hhs[r]))) snprintf(errs[r], sizeof errs[r], "%s", bh_last_error());
+		}
 	}
+	if (coop) for (int a = 0; a < n_gpus; ++a) { int seen = 0; for (int b = 0; b < a; ++b) seen |= dev_list[a] == dev_list[b]; if (!seen) bh_device_gate(dev_list[a], 0); }
+	if (team) bhip_team_destroy(team);
 	for (int r = 0; r < n_gpus; ++r) if (rcs[r]) { fprintf(stderr, "%s\n", rcs[r] == BH_E_INTERNAL ? "OpenMP did not start one host thread per GPU" : errs[r]); return 4; }
 	for (int r = 0; r < n_gpus; ++r) { char nm[256]; int ncu = 0; uint64_t hbm = 0; if (!bhip_device_info(hhs[r], nm, sizeof nm, &ncu, &hbm)) printf("Device %d: %s, %d CUs, %.0f GiB\n", dev_list[r], nm, ncu, hbm / 1073741824.0); }
 	if (shard_db) for (int r = 0; r < n_gpus; ++r) printf("Rank %d: replica group %d, clumps [%u, %u)\n", r, r / n_shards, ranks[r].c0, ranks[r].c0 + slices[r].numRclumps);

@@ -2,6 +2,7 @@
 multi-GPU driver.  All logic lives in C; this module only moves pointers."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -95,6 +96,7 @@ def lib():
         L.bh_db_free.argtypes = [C.POINTER(BhDb)]
         L.bh_device_open.argtypes = [C.POINTER(BhDb), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.bh_device_open_ex.argtypes = [C.POINTER(BhDb), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.bh_device_open_shared.argtypes = [C.POINTER(BhDb), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.bh_acx_from_device.argtypes = [C.POINTER(BhDb), C.c_void_p, C.c_int, C.c_int]
         L.bh_align.argtypes = [C.c_void_p, C.POINTER(BhQueries), C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(BhRun)]
         L.bh_align_ranges.argtypes = [C.c_void_p, C.POINTER(BhQueries), u64p, u64p, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(BhRun)]
@@ -187,6 +189,48 @@ class Db:
         dev.n_clumps = self.c.numRclumps
         dev.clump_len = _view(self.c.clumpLen, self.c.numRclumps, np.uint32)
         return dev
+
+    def _wrap(self, h):
+        dev = capi.Device.__new__(capi.Device)
+        dev._h = h
+        dev.n_clumps = self.c.numRclumps
+        dev.clump_len = _view(self.c.clumpLen, self.c.numRclumps, np.uint32)
+        return dev
+
+    def open_devices_team(self, devices, z=1, build_K=12):
+        """This (replicated) database on len(devices) handles whose accelerator the ranks build TOGETHER: one thread per rank, as
+        burst_hip --gpus N does (bh_device_open_shared with bhip_team_share: every rank the lists of its share of the words, the tables
+        completed device to device).  The devices may repeat (ranks sharing a device: what a one-GPU machine can test)."""
+        import threading
+        n = len(devices)
+        team = C.c_void_p()
+        capi._chk(capi.lib().bhip_team_create(n, C.byref(team)))
+        hs, rcs, errs = [C.c_void_p() for _ in range(n)], [0] * n, [""] * n
+        share = C.cast(capi.lib().bhip_team_share, C.c_void_p)
+        def work(r):
+            rcs[r] = lib().bh_device_open_shared(C.byref(self.c), devices[r], z, build_K, r, n, share, team, C.byref(hs[r]))
+            if rcs[r]:
+                errs[r] = lib().bh_last_error().decode()
+        ts = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        capi.lib().bhip_team_destroy(team)
+        devs = [self._wrap(h) if not rc else None for h, rc in zip(hs, rcs)]
+        if any(rcs):
+            for d in devs:
+                if d is not None:
+                    d.close()
+            raise HostError(next(rc for rc in rcs if rc), "; ".join(e for e in errs if e))
+        return devs
+
+    def open_device_shared(self, device, z, build_K, part, n_parts, share, ctx=None):
+        """one of n_parts handles (one process each) that build the accelerator together; `share` = a bhip_share_fn (dist_share(...),
+        or capi.lib().bhip_comm_share with ctx = a BhipCommRank)"""
+        h = C.c_void_p()
+        _chk(lib().bh_device_open_shared(C.byref(self.c), device, z, build_K, part, n_parts, C.cast(share, C.c_void_p), ctx, C.byref(h)))
+        return self._wrap(h)
 
     def acx_from_device(self, dev, K, z=1):
         """accelerator tables of this database from a device handle that built them (bh_acx_from_device): write() then saves the .acx"""
@@ -389,6 +433,69 @@ libc = C.CDLL(None)
 libc.fopen.restype = C.c_void_p
 libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
 libc.fclose.argtypes = [C.c_void_p]
+
+
+SHARE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_int)
+
+
+def share_regions(off, part, n_parts, status, fetch, store, broadcast, any_failed, piece=64 << 20):
+    """The exchange of the cooperative accelerator build (bhip_share_fn, include/burst_hip.h) over a launcher's own collectives, for ranks
+    that have no RCCL communicator (the gloo back end; ranks sharing a device): region r of every rank's array, [off[r], off[r + 1]),
+    travels from its builder to everybody, piece by piece through host memory.  fetch(a, n) -> bytes of the own array as a uint8 array,
+    store(a, buf), broadcast(buf, root) -> buf, any_failed(status) -> bool.  Returns 0, or 1 when some rank announced a failure."""
+    if any_failed(status):
+        return 1
+    for r in range(n_parts):
+        a = int(off[r])
+        while a < int(off[r + 1]):
+            n = min(piece, int(off[r + 1]) - a)
+            buf = fetch(a, n) if r == part else np.empty(n, np.uint8)
+            buf = broadcast(buf, r)
+            if r != part:
+                store(a, buf)
+            a += n
+    return 0
+
+
+def dist_share(dist, pdev="cpu"):
+    """bhip_share_fn over torch.distributed (any back end): returns (callback, keep-alive) for Db.open_device_shared"""
+    import torch
+    def any_failed(status):
+        t = torch.tensor([1 if status else 0], dtype=torch.int64, device=pdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(int(t.item()))
+    def broadcast(buf, root):
+        t = torch.from_numpy(buf).to(pdev)
+        dist.broadcast(t, root)
+        return t.cpu().numpy()
+    class _Raw:          # a piece of the device array as a tensor, no copy (the nccl back end broadcasts it in place: RCCL over xGMI)
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+    def cb(ctx, base, off, part, n_parts, status):
+        try:
+            if pdev != "cpu":
+                if any_failed(status):
+                    return 1
+                for r in range(n_parts):
+                    a = int(off[r])
+                    while a < int(off[r + 1]):
+                        n = min(1 << 30, int(off[r + 1]) - a)
+                        dist.broadcast(torch.as_tensor(_Raw(base + a, n), device=pdev), r)
+                        a += n
+                torch.cuda.synchronize()
+                return 0
+            def fetch(a, n):
+                out = np.empty(n, np.uint8)
+                capi._chk(capi.lib().bhip_device_copy(out.ctypes.data, base + a, n, 0))
+                return out
+            def store(a, buf):
+                buf = np.ascontiguousarray(buf)
+                capi._chk(capi.lib().bhip_device_copy(base + a, buf.ctypes.data, len(buf), 1))
+            return share_regions([off[i] for i in range(n_parts + 1)], part, n_parts, status, fetch, store, broadcast, any_failed)
+        except Exception as e:          # (an exception must not unwind through the C caller)
+            sys.stderr.write("dist_share: %s\n" % e)
+            return -1
+    return SHARE_FN(cb)
 
 
 def shard_range(n_uniq, world, rank):

@@ -25,6 +25,8 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="burst_amd.run")
     ap.add_argument("-r", "--references", required=True)
     ap.add_argument("-a", "--accelerator")
+    ap.add_argument("-ad", "--accelerator-device", action="store_true", help="no .acx file: the accelerator is built on the devices from the database "
+                    "(with several ranks and a replicated database: together, every rank the lists of its share of the words)")
     ap.add_argument("-q", "--queries", required=True)
     ap.add_argument("-o", "--output", required=True)
     ap.add_argument("-m", "--mode", default="CAPITALIST", choices=["BEST", "ALLPATHS", "CAPITALIST", "FORAGE", "ANY"])
@@ -51,10 +53,14 @@ def main(argv=None):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from burst_amd import host
     z = 0 if args.nwildcard else 1
+    if args.accelerator_device and args.accelerator:
+        sys.stderr.write("ERROR: -ad builds the accelerator on the device; drop -a\n")
+        return 1
     db = host.Db.read(args.references, args.accelerator, K=args.k, z=z)
-    K = int(db.c.K) if args.accelerator else 12
+    K = int(db.c.K) if args.accelerator else (args.k or 12)
+    accel = bool(args.accelerator or args.accelerator_device)
     host.lib().bh_queries_sort_device(local_rank)          # large query files are sorted on this rank's own device
-    qs = host.QuerySet(args.queries, args.id, rc=args.forwardreverse, accel=bool(args.accelerator), K=K, z=z)
+    qs = host.QuerySet(args.queries, args.id, rc=args.forwardreverse, accel=accel, K=K, z=z)
     # the database was sheared for queries up to shear * id long: longer ones would lose alignments across shear boundaries
     # (burst.c:5152-5156: "DB incompatible with selected queries/identity", exit 1)
     if db.c.shear and int(np.float32(qs.c.maxLen) / np.float32(args.id)) > db.c.shear:
@@ -66,13 +72,20 @@ def main(argv=None):
     if shard_db:
         c0, c1 = host.clump_shard(db, world, rank)
         part = db.slice(c0, c1) if c1 > c0 else None
-    dev = part.open_device(local_rank, z) if part is not None else None
+    build_K = K if args.accelerator_device else 0
+    if build_K and world > 1 and not shard_db and not os.environ.get("BURST_HIP_SOLO_BUILD"):
+        # the replicated database's accelerator, built by the ranks together (bhip_build_accelerator_shared); the regions travel over the
+        # launcher's process group: in place between the devices under the nccl back end (RCCL), through host memory under gloo
+        share = host.dist_share(dist, "cpu" if one_dev is not None else "cuda")
+        dev = db.open_device_shared(local_rank, z, build_K, rank, world, share)
+    else:
+        dev = part.open_device(local_rank, z, build_K=build_K) if part is not None else None
     if dev is not None:
         qs.pin()
     t0 = time.time()
     if world == 1:
         run = host.align_ranges(dev, qs, [(0, qs.n_uniq)], args.mode, args.batch)
-        n = host.report(args.output, db, qs, run.hits, args.mode, 0 if args.accelerator else host.REP_MERGED_LIST)
+        n = host.report(args.output, db, qs, run.hits, args.mode, 0 if accel else host.REP_MERGED_LIST)
         print("rank 0: %d hit records from 1 rank(s) in %.3f s, %d alignments written" % (int(run.c.nHits), time.time() - t0, n))
         return 0
     # several ranks, one process each: the C host's multi-rank search (bh_search_multi_ex), the function behind burst_hip --gpus N.
@@ -116,7 +129,7 @@ def main(argv=None):
     rs = host.RankSearch(dev, rank, world, None, c0=c0, node=node, reduce_min=reduce_min if shard_db else None)
     rs.search(qs, [(u0, u1)], args.mode, args.batch, shard_db=world if shard_db else 0)
     if rank == 0:
-        n = host.report_view(args.output, db, qs, rs.view, args.mode, 0 if args.accelerator else host.REP_MERGED_LIST)
+        n = host.report_view(args.output, db, qs, rs.view, args.mode, 0 if accel else host.REP_MERGED_LIST)
         print("rank 0: %d hit records from %d rank(s) in %.3f s, %d alignments written" % (int(rs.view.total), world, time.time() - t0, n))
     dist.barrier()      # (the ranks' segments live until rank 0 has written the report)
     rs.close()

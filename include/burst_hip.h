@@ -203,6 +203,30 @@ BHIP_API int  bhip_comm_fetch_gathered(void *comm, BhipHit *out, uint64_t cap, u
 BHIP_API int  bhip_comm_allreduce_min(void *comm, int rank, uint8_t *buf, uint64_t n);
 BHIP_API void bhip_comm_destroy(void *comm);
 
+/* Cooperative accelerator build (no reference counterpart: make_accelerator, burst.c:3304-3532, is one process).  With the database
+ * replicated over n_parts devices every handle needs the whole accelerator, and building it is most of what a job waits for before its
+ * first batch; so every handle -- initialised with K = 0, i.e. without one -- builds the lists of 1/n_parts of the WORD space (runs of
+ * words with equal numbers of window tuples, cut alike by every rank from a histogram of the database), and the ranks complete each
+ * other's tables in two exchanges: Lens (4^K x 4 bytes in all), then the 4-byte records.  The result on every handle is what bhip_init
+ * with K would have built alone, bit for bit (tests/test_gpu_acx.py).
+ *   bhip_share_fn: called by every rank at the same two points with ITS array (a device pointer) and the same byte offsets
+ *     byte_off[0 .. n_parts]: region [byte_off[r], byte_off[r + 1]) is valid on rank r when the call is made and on every rank when it
+ *     returns.  status != 0 announces that this rank could not do its part: the function then moves nothing and returns 1 on EVERY rank
+ *     (all handles fall back to building alone); < 0 = the exchange itself failed.
+ *   Ready-made exchanges: bhip_comm_share (ctx = BhipCommRank: ncclBroadcast of every region from its builder, one group, over xGMI),
+ *   bhip_team_share (ctx = a team of the threads of ONE process: peer copies device to device behind a barrier; the ranks may share a
+ *   device), or the caller's own (python -m burst_amd.run stages through torch.distributed where its ranks have no RCCL communicator:
+ *   bhip_device_copy moves a region between a device array and host memory).
+ * bhip_build_accelerator_shared with n_parts = 1 builds alone (share may be NULL).  All ranks must call it together. */
+typedef int (*bhip_share_fn)(void *ctx, void *device_base, const uint64_t *byte_off, int part, int n_parts, int status);
+typedef struct { void *comm; int rank; } BhipCommRank;
+BHIP_API int  bhip_build_accelerator_shared(void *handle, int K, int part, int n_parts, bhip_share_fn share, void *ctx);
+BHIP_API int  bhip_comm_share(void *comm_rank, void *device_base, const uint64_t *byte_off, int part, int n_parts, int status);
+BHIP_API int  bhip_team_create(int n_ranks, void **team);
+BHIP_API void bhip_team_destroy(void *team);
+BHIP_API int  bhip_team_share(void *team, void *device_base, const uint64_t *byte_off, int part, int n_parts, int status);
+BHIP_API int  bhip_device_copy(void *dst, const void *src, uint64_t bytes, int to_device);      /* (device addresses are unified: whichever device the calling thread is on) */
+
 /* The accelerator of a handle in the file's terms (read_accelerator's tables, burst.c:3535-3594): Lens[4^K], the clump ids of all
  * lists in word order (ascending inside a list, as the reference writes them with one thread), their 16-bit lane masks (device
  * layout only: bit z = lane z of the clump MAY hold the word -- since the 4-byte records of ABI 5 the device keeps a lane-set CODE
@@ -290,7 +314,7 @@ BHIP_API void bhip_destroy(void *handle);
 BHIP_API const char *bhip_last_error(void);
 /* ABI version of this header */
 BHIP_API int bhip_abi_version(void);
-#define BHIP_ABI_VERSION 6
+#define BHIP_ABI_VERSION 7
 
 #ifdef __cplusplus
 }

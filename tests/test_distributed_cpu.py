@@ -387,3 +387,71 @@ def test_bench_chooses_the_handover_together(mode, port, tmp_path):
     for rk in range(2):                  # (files, not the launcher's merged stdout: two processes' lines can interleave there)
         assert open(str(tmp_path / ("result.%d" % rk))).read() == want, r.stdout[-2000:]
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("burst_hip.bench")]
+
+
+SHARE_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import ctypes as C
+import torch, torch.distributed as dist
+from burst_amd import host
+edx, K, fail_rank = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+# the tables of the single-rank build: the host builder's Lens and list area (what every rank must hold in the end)
+db = host.Db.read(edx)
+host._chk(host.lib().bh_acx_build(C.byref(db.c), K, 1))
+nw = 1 << (2 * K)
+lens = host._view(db.c.acxLens, nw, np.uint32).copy()
+lists = host._view(db.c.acxLists, db.c.acxListBytes, np.uint8).copy()
+per = {0: 5, 1: 3}[int(db.c.acxFmt)]          # bytes of a pair of entries (SMALL) / of an entry (LARGE)
+# the ranks' runs of words: equal numbers of entries, on word boundaries (as the device builder cuts them from its histogram)
+cum = np.concatenate(([0], np.cumsum(lens, dtype=np.uint64)))
+cuts = [0] + [int(np.searchsorted(cum, cum[-1] * r // world)) for r in range(1, world)] + [nw]
+if int(db.c.acxFmt) == 0:                  # (SMALL packs two entries into five bytes: regions on even entry numbers)
+    cuts = [0] + [int(c) for c in cuts[1:-1] if cum[c] % 2 == 0] + [nw]
+    cuts += [nw] * (world + 1 - len(cuts))
+def entry_bytes(w):
+    e = int(cum[w]); return e * 3 if per == 3 else (e // 2) * 5 + (e % 2) * 3
+loff = [c * 4 for c in cuts]
+roff = [entry_bytes(c) for c in cuts[:-1]] + [len(lists)]
+# a rank holds ITS region only (the rest is junk), as after the device builder's own part
+rng = np.random.default_rng(rank + 7)
+def own_only(full, off):
+    a = rng.integers(0, 256, len(full), dtype=np.uint8)
+    a[off[rank]:off[rank + 1]] = full[off[rank]:off[rank + 1]]
+    return a
+my_lens, my_lists = own_only(lens.view(np.uint8), loff), own_only(lists, roff)
+def any_failed(status):
+    t = torch.tensor([1 if status else 0]); dist.all_reduce(t, op=dist.ReduceOp.MAX); return bool(int(t.item()))
+def broadcast(buf, root):
+    t = torch.from_numpy(buf); dist.broadcast(t, root); return t.numpy()
+def share(arr, off, status=0):
+    def fetch(a, n): return arr[a:a + n].copy()
+    def store(a, buf): arr[a:a + len(buf)] = buf
+    return host.share_regions(off, rank, world, status, fetch, store, broadcast, any_failed, piece=70001)
+st = share(my_lens, loff, 1 if rank == fail_rank else 0)
+if fail_rank >= 0:
+    assert st == 1 and not np.array_equal(my_lens, lens.view(np.uint8))      # announced: nothing moved, on every rank
+else:
+    assert st == 0 and np.array_equal(my_lens, lens.view(np.uint8))
+    assert share(my_lists, roff) == 0 and np.array_equal(my_lists, lists)
+print("rank %d ok: %d words, %d list bytes, regions %s" % (rank, nw, len(lists), roff), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world,K,fail_rank,port", [(2, 10, -1, 29751), (3, 8, -1, 29752), (2, 10, 1, 29753)])
+def test_cooperative_build_exchange_over_gloo(world, K, fail_rank, port, tmp_path):
+    """The exchange of the cooperative accelerator build (bhip_share_fn) as python -m burst_amd.run does it for ranks without an RCCL
+    communicator: host.share_regions over the launcher's process group.  Every rank holds the single-rank tables (the host builder's Lens
+    and list area) in its own run of words only; after the two exchanges -- list lengths, then the lists -- every rank holds all of them.
+    A rank that announces a failure makes the exchange return 1 everywhere with nothing moved.  (The device builder itself: -m gpu,
+    tests/test_gpu_acx.py::test_cooperative_build_equals_the_single_rank_build.)"""
+    w = tmp_path / "w.py"
+    w.write_text(SHARE_WORKER)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port), str(w),
+                        gl.ROOT, os.path.join(gl.G, "quick.edx"), str(K), str(fail_rank)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.count(" ok: ") == world, r.stdout[-3000:]

@@ -125,6 +125,97 @@ def test_cli_with_device_built_accelerator(name, tmp_path):
     gl.compare(c, got, nd)
 
 
+def _export(dev, K):
+    lens, clumps, masks, bad = dev.acx_export(K)
+    return lens, clumps, masks, bad
+
+
+@pytest.mark.parametrize("db,K,z,n_ranks,slice_items", [("dna", 12, 1, 2, 0), ("dna", 12, 0, 3, 30000), ("quick", 15, 1, 2, 0), ("quick", 10, 1, 4, 0), ("quick", 12, 1, 5, 50000),
+                                                        ("dna", 6, 1, 3, 0)])
+def test_cooperative_build_equals_the_single_rank_build(db, K, z, n_ranks, slice_items, monkeypatch):
+    """bhip_build_accelerator_shared: n_ranks handles of the replicated database (here: on one device, one thread each, as burst_hip --gpus N
+    --devices 0,0,.. runs them) build the lists of their shares of the words and complete each other's tables (bhip_team_share) -- every
+    handle must end up with the tables of the single-rank build, bit for bit: list lengths, clump ids in list order, lane sets, BadList.
+    Also the word-sliced builder alone (BHIP_ACX_BUILD=words), which is the cooperative builder with one rank."""
+    from burst_amd import host
+    d = host.Db.read(os.path.join(gl.G, db + ".edx"))
+    solo = d.open_device(0, z, build_K=K)
+    want = _export(solo, K)
+    solo.close()
+    assert len(want[1]) > 1000
+    if slice_items:
+        monkeypatch.setenv("BHIP_MASK_SLICE", str(slice_items))      # (several slices inside a rank's share)
+    monkeypatch.setenv("BHIP_ACX_BUILD", "words")
+    w = d.open_device(0, z, build_K=K)
+    got = _export(w, K)
+    w.close()
+    monkeypatch.delenv("BHIP_ACX_BUILD")
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+    devs = d.open_devices_team([0] * n_ranks, z, build_K=K)
+    for dev in devs:
+        got = _export(dev, K)
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b)
+        dev.close()
+    d.close()
+
+
+def test_cooperative_build_falls_back_together(monkeypatch):
+    """a rank that cannot do its share announces it in the first exchange and EVERY rank builds alone (nobody waits, same tables)"""
+    from burst_amd import host
+    d = host.Db.read(os.path.join(gl.G, "quick.edx"))
+    solo = d.open_device(0, 1, build_K=12)
+    want = _export(solo, 12)
+    solo.close()
+    monkeypatch.setenv("BHIP_TEST_COOP_FAIL_RANK", "1")
+    devs = d.open_devices_team([0, 0, 0], 1, build_K=12)
+    for dev in devs:
+        for a, b in zip(want, _export(dev, 12)):
+            assert np.array_equal(a, b)
+        dev.close()
+    d.close()
+
+
+@pytest.mark.parametrize("name,n", [("dna_q100_allpaths_fr", 2), ("quick_q100_capitalist_fr", 3), ("quick_q292_best_fr", 2)])
+def test_cli_ranks_build_the_accelerator_together(name, n, tmp_path):
+    """burst_hip --gpus N --devices 0,0,.. -ad: the ranks of a replicated database build ONE accelerator between them; golden outputs"""
+    c = [x for x in gl.cases() if x["name"] == name][0]
+    ref, q, fr, z, shear = gl.case_args(c)
+    out = str(tmp_path / "o.b6")
+    cmd = [CLI, "-r", ref, "-q", q, "-o", out, "-m", c["mode"], "-i", c["id"], "-ad", "--gpus", str(n), "--devices", ",".join(["0"] * n), "--gather", "host"] + gl.cli_extra(c)
+
+    def run(extra=()):
+        r = subprocess.run(cmd + list(extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, BHIP_DEBUG="1"))
+        assert r.returncode == 0 and "built by the %d ranks together" % n in r.stdout and r.stdout.count("(cooperative)") == n, r.stdout
+        return sorted(open(out, "rb").read().splitlines())
+    got = run()
+    nd = run(["--no-dupe-hunt"]) if gl.order_sensitive(c) else None
+    gl.compare(c, got, nd)
+
+
+def test_launcher_ranks_build_the_accelerator_together(tmp_path):
+    """python -m burst_amd.run -ad with two processes (gloo; both on device 0): the exchange goes through the launcher's process group
+    (host.dist_share), the .b6 is the one-process run's"""
+    c = [x for x in gl.cases() if x["name"] == "quick_q100_capitalist_fr"][0]
+    ref, q, fr, z, shear = gl.case_args(c)
+    outs = []
+    for world in (1, 2):
+        out = str(tmp_path / ("o%d.b6" % world))
+        args = ["-m", "burst_amd.run", "-r", ref, "-q", q, "-o", out, "-m", c["mode"], "-i", c["id"], "-ad"] + (["-fr"] if fr else [])
+        cmd = [sys.executable] + args if world == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                                          "--master-port", "29771"] + args
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, cwd=gl.ROOT,
+                           env=dict(os.environ, BURST_RUN_DEVICE="0", BHIP_DEBUG="1", PYTHONPATH=gl.ROOT))
+        assert r.returncode == 0, r.stdout[-3000:]
+        if world == 2:
+            assert r.stdout.count("(cooperative)") == 2, r.stdout[-3000:]
+        outs.append(sorted(open(out, "rb").read().splitlines()))
+    assert outs[0] == outs[1] and len(outs[0]) > 100
+    if not gl.order_sensitive(c):
+        gl.compare(c, outs[1], None)
+
+
 def test_device_builder_differential_against_the_reference(tmp_path):
     """tools/db_diff.py on the GPU box: `burst_hip -d QUICK ... -a` now builds the accelerator on the device; its .acx must be
     the compiled reference's, byte for byte, on random and awkward FASTA files (heavy IUPAC, N runs, -y, duplicates, ...)"""
