@@ -741,17 +741,34 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	HIPCHK(hipMemGetInfo(&free_b, &total_b));
 	long long forced_slice = 0;
 	if (const char *ev = getenv("BHIP_MASK_SLICE")) forced_slice = atoll(ev);
-	// room for the sort of a slice (two 8-byte tuple arrays + the folded lane masks + the sort's own scratch: 19 bytes per tuple) next to
-	// everything that is or will be resident: the records (4 bytes per tuple at most), the length table and the offset lines, the counts
-	const double fixed = (double)total * BHIP_REC_BYTES + (double)nw * 4.0 + (double)n_lines * 64.0 * 1.2 + (double)nC * 8.0 + (double)(2u << 30);
+	// Slices: runs of buckets whose tuples fit the sort (two 8-byte tuple arrays + the folded lane masks + the sort's own scratch: 19 bytes
+	// per tuple, and 4 for the records they become) next to what is resident WHEN THE SLICE IS SORTED -- the records of the slices before
+	// it (at most 4 bytes per tuple so far), not those of the whole database: the early slices take as many tuples as one sort call takes
+	// (2^31), the last ones what is left beside 216 GB of records.  Every slice costs one scan of the references, so fewer, larger slices
+	// are what makes this builder cheap: 29 slices instead of 64 at the metric's size.  A slice spans at most 2^26 words (four sort passes).
 	std::vector<uint32_t> cuts;        // bucket boundaries of the slices
-	auto plan = [&](uint64_t target) -> uint32_t {
-		cuts.assign(1, own0); cap_items = 0;
-		const uint32_t max_b = 24 > shift ? 1u << (24 - shift) : 1u;      // buckets whose words together span at most 2^24
+	std::vector<uint64_t> slice_items;
+	const uint32_t max_b = 26 > shift ? 1u << (26 - shift) : 1u;
+	auto plan = [&](uint64_t target) -> uint32_t {      // (BHIP_MASK_SLICE: slices of a given size)
+		cuts.assign(1, own0); slice_items.clear(); cap_items = 0;
 		for (uint32_t b0 = own0; b0 < own1;) {
 			uint32_t b1 = b0 + 1; uint64_t n = hist[b0];
 			while (b1 < own1 && b1 - b0 < max_b && n + hist[b1] <= target) n += hist[b1++];
-			cuts.push_back(b1); cap_items = std::max(cap_items, n); b0 = b1;
+			cuts.push_back(b1); slice_items.push_back(n); cap_items = std::max(cap_items, n); b0 = b1;
+		}
+		return (uint32_t)cuts.size() - 1;
+	};
+	auto plan_by_room = [&](uint32_t assumed_slices) -> uint32_t {
+		cuts.assign(1, own0); slice_items.clear(); cap_items = 0;
+		const double base = (double)free_b - (double)nw * 4.0 - (double)nC * 8.0 - (double)assumed_slices * nC * 4.0 - (double)(3ull << 30);
+		uint64_t before = 0;
+		for (uint32_t b0 = own0; b0 < own1;) {
+			const double room = base - (double)before * BHIP_REC_BYTES;
+			const uint64_t target = room > 0 ? (uint64_t)std::min(2147483000.0, room / 23.0) : 0;
+			if (hist[b0] > target) return 0;
+			uint32_t b1 = b0 + 1; uint64_t n = hist[b0];
+			while (b1 < own1 && b1 - b0 < max_b && n + hist[b1] <= target) n += hist[b1++];
+			cuts.push_back(b1); slice_items.push_back(n); cap_items = std::max(cap_items, n); before += n; b0 = b1;
 		}
 		return (uint32_t)cuts.size() - 1;
 	};
@@ -759,15 +776,8 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	if (own1 > own0 && total_own) {
 		if (forced_slice > 0) n_slices = plan(std::max<uint64_t>((uint64_t)forced_slice, biggest));
 		else {
-			const uint32_t own_b = own1 - own0;
-			const uint32_t min_s = 24 > shift ? std::max(1u, (own_b + (1u << (24 - shift)) - 1u) >> (24 - shift)) : own_b;
-			for (uint32_t want = min_s; want <= 2u * BHIP_ACX_MAX_SLICES; want *= 2) {
-				const uint64_t target = std::max<uint64_t>(biggest, (uint64_t)((double)total_own / want * 1.15) + 1);
-				n_slices = plan(target);
-				const double need = fixed + (double)n_slices * nC * 4.0 + (double)cap_items * 19.0 + (double)(64u << 20);
-				if (n_slices <= max_slices && cap_items < 2147483000ull && need <= (double)free_b) break;
-				n_slices = 0;
-			}
+			n_slices = plan_by_room(32);
+			if (n_slices > 32) n_slices = plan_by_room(n_slices + 8);
 		}
 		if (!n_slices || n_slices > max_slices || cap_items >= 2147483000ull) return 1;
 	}
@@ -787,14 +797,17 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	hipLaunchKernelGGL(k_acx_wcount, dim3(g), dim3(256), 0, h->stream, h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_bad.as<uint8_t>(),
 		nC, h->tot_refs, K, z ? 1 : 0, shift, n_buckets, d_b2s.as<uint8_t>(), n_slices, d_counts.as<uint32_t>());
 	HIPCHK(hipGetLastError());
-	ARC(k0.reserve_exact(cap_items * 8 + 16)); ARC(k1.reserve_exact(cap_items * 8 + 16)); ARC(v0.reserve_exact(cap_items * 2 + 16)); ARC(nruns.reserve(16));
+	// (the sort buffers follow the slices' sizes: address ranges for the largest slice, memory for the one at hand)
+	if (k0.reserve_growable(cap_items * 8 + 16, h->device) || k1.reserve_growable(cap_items * 8 + 16, h->device) || v0.reserve_growable(cap_items * 2 + 16, h->device)) return 1;
+	ARC(nruns.reserve(16));
 	HIPCHK(hipStreamSynchronize(h->stream));
 	t_count = since();
 	// 4. slice after slice: offsets, tuples, sort over the slice's word bits, fold, records
 	for (uint32_t s = 0; s < n_slices; ++s) {
-		uint64_t n_items = 0;
-		for (uint32_t b = cuts[s]; b < cuts[s + 1]; ++b) n_items += hist[b];
+		const uint64_t n_items = slice_items[s];
 		if (!n_items) continue;
+		k0.shrink_to(n_items * 8 + 16); k1.shrink_to(n_items * 8 + 16); v0.shrink_to(n_items * 2 + 16);
+		ARC(k0.grow_to(n_items * 8 + 16)); ARC(k1.grow_to(n_items * 8 + 16)); ARC(v0.grow_to(n_items * 2 + 16));
 		const uint64_t w0 = (uint64_t)cuts[s] << shift, w1 = (uint64_t)cuts[s + 1] << shift;
 		uint32_t wl = 1; while ((1ull << wl) < w1 - w0) ++wl;
 		const uint32_t *cnt_s = d_counts.as<uint32_t>() + (size_t)s * nC;
