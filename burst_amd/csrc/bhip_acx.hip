@@ -526,34 +526,71 @@ __global__ void k_acx_rec_export(const uint32_t *__restrict__ rec, unsigned long
 // a sort takes, not enough room -- and the clump-sliced builder takes over.
 // ------------------------------------------------------------------------------------------------
 // every word of one reference lane: emit(word) for each window of K symbols A/C/G/T, and for each IUPAC expansion of an ambiguous one
+// (the order of the calls is not the order of the positions' -- nobody needs it).
+// A dword of eight symbols at a time: where all eight are A/C/G/T (every dword of a database without ambiguity codes, nearly every one of
+// a real one) their 2-bit codes are packed with bit tricks, newest symbol lowest, behind the codes of the dwords before in one 64-bit
+// register, and the eight windows are eight shifts of it -- 8 instructions per position instead of 22 for the symbol-by-symbol walk, which
+// is what a scan of the references costs (and this builder scans them once per slice).  A dword with anything else in it (ambiguity codes,
+// padding, the lane's end) takes the symbol-by-symbol walk, its window state rebuilt from the two dwords before (16 symbols >= K - 1).
 template <class F>
 __device__ __forceinline__ void acx_lane_words(const uint4 *__restrict__ rp, uint32_t L, uint32_t nchunks, int K, int z, F &&emit) {
 	const uint32_t wmask = (1u << (2 * K)) - 1u;
-	unsigned long long win = 0;
-	uint32_t w = 0, run = 0, lit = 0;
+	unsigned long long S = 0;          // 2-bit codes of the symbols so far, the newest in the lowest bits
+	uint32_t litrun = 0;               // A/C/G/T symbols in a row up to the end of the dword before (saturating)
+	uint32_t prev1 = 0, prev2 = 0;     // the two dwords before (prev1 the nearer)
 	for (uint32_t t = 0; t < nchunks; ++t) {
 		const uint4 ch = rp[t];
 		const uint32_t dw[4] = {ch.x, ch.y, ch.z, ch.w};
-		for (uint32_t k = 0; k < 32; ++k) {
-			if (t * 32 + k >= L) break;
-			const uint32_t sym = (dw[k >> 3] >> (4 * (k & 7))) & 15u;
-			run = (sym >= 1u && !(z && sym == 5u)) ? run + 1 : 0;
-			lit = (sym - 1u) < 4u ? lit + 1 : 0;
-			w = ((w << 2) | ((sym - 1u) & 3u)) & wmask;
-			win = (win << 4) | sym;
-			if (lit >= (uint32_t)K) emit(w);
-			else if (run >= (uint32_t)K) {
-				const unsigned long long prod = amb_product(win, K);
-				for (unsigned long long idx = 0; idx < prod; ++idx) {
-					unsigned long long r = idx; uint32_t word = 0;
-					for (int s = 0; s < K; ++s) {          // symbol s counted from the window's end: 2-bit digit s of the word
-						const uint32_t code = (uint32_t)(win >> (4 * s)) & 15u, n = amb_count(code), d = (uint32_t)(r % n);
-						r /= n;
-						word |= ((amb_bases(code) >> (2u * d)) & 3u) << (2 * s);
+		#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j) {
+			const uint32_t base = t * 32 + j * 8;
+			if (base >= L) return;
+			const uint32_t x = dw[j];
+			const uint32_t y = (x | 0x88888888u) - 0x11111111u;                       // per nibble: (symbol - 1) mod 8 in the low three bits
+			const uint32_t litm = (~y >> 2) & (~x >> 3) & 0x11111111u;                // bit 4k: symbol k is one of 1..4
+			uint32_t p = y & 0x33333333u;                                             // 2-bit codes, one per nibble ...
+			p = (p | (p >> 2)) & 0x0F0F0F0Fu; p = (p | (p >> 4)) & 0x00FF00FFu; p = (p | (p >> 8)) & 0xFFFFu;      // ... side by side, symbol 0 lowest
+			uint32_t r = __brev(p) >> 16;                                             // symbol 7 lowest (the bits of a code swapped: put back)
+			r = ((r & 0x5555u) << 1) | ((r >> 1) & 0x5555u);
+			S = (S << 16) | r;
+			if (litm == 0x11111111u && base + 8 <= L) {
+				const uint32_t first = litrun + 1 >= (uint32_t)K ? 0u : (uint32_t)K - 1u - litrun;      // first position of the dword with K literals behind it
+				#pragma unroll
+				for (uint32_t k = 0; k < 8; ++k) if (k >= first) emit((uint32_t)(S >> (2u * (7u - k))) & wmask);
+				litrun = litrun + 8 > 64 ? 64 : litrun + 8;
+			} else {
+				unsigned long long win = 0;
+				uint32_t w = 0, run = 0, lit = 0;
+				const uint32_t g = base >> 3;
+				for (uint32_t d = g >= 2 ? 0u : 2u - g; d < 3; ++d) {      // d = 0, 1: warm-up over prev2, prev1 (as far as the lane has them); 2: this dword
+					const uint32_t v = d == 0 ? prev2 : d == 1 ? prev1 : x;
+					#pragma unroll
+					for (uint32_t k = 0; k < 8; ++k) {
+						const uint32_t sym = (v >> (4 * k)) & 15u;
+						run = (sym >= 1u && !(z && sym == 5u)) ? run + 1 : 0;
+						lit = (sym - 1u) < 4u ? lit + 1 : 0;
+						w = ((w << 2) | ((sym - 1u) & 3u)) & wmask;
+						win = (win << 4) | sym;
+						if (d != 2 || base + k >= L) continue;
+						if (lit >= (uint32_t)K) emit(w);
+						else if (run >= (uint32_t)K) {
+							const unsigned long long prod = amb_product(win, K);
+							for (unsigned long long idx = 0; idx < prod; ++idx) {
+								unsigned long long rr = idx; uint32_t word = 0;
+								for (int q = 0; q < K; ++q) {          // symbol q counted from the window's end: 2-bit digit q of the word
+									const uint32_t code = (uint32_t)(win >> (4 * q)) & 15u, n = amb_count(code), dgt = (uint32_t)(rr % n);
+									rr /= n;
+									word |= ((amb_bases(code) >> (2u * dgt)) & 3u) << (2 * q);
+								}
+								emit(word);
+							}
+						}
 					}
-					emit(word);
 				}
+				const uint32_t inv = ~litm & 0x11111111u;      // literals at the dword's end: the nibbles above the highest one that is not
+				litrun = inv ? (uint32_t)(__clz((int)inv) - 3) >> 2 : (litrun + 8 > 64 ? 64 : litrun + 8);
 			}
+			prev2 = prev1; prev1 = x;
 		}
 	}
 }
@@ -802,12 +839,39 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	ARC(nruns.reserve(16));
 	HIPCHK(hipStreamSynchronize(h->stream));
 	t_count = since();
-	// 4. slice after slice: offsets, tuples, sort over the slice's word bits, fold, records
+	// 4. slice after slice: offsets, tuples, sort over the slice's word bits, fold, records.  The record area's memory is mapped by a thread
+	// of its own, one slice's worth (its tuples: an upper bound of its records) while that slice is scanned and sorted -- mapping 216 GB in
+	// 1 GiB chunks takes seconds, which now lie beside the kernels; what was mapped beyond the records goes back at the end.
+	std::atomic<int> slice_now(-1), map_failed(0), stop(0);
+	std::atomic<size_t> mapped(0);
+	std::thread mapper;
+	struct JoinMapper { std::thread &t; std::atomic<int> &stop; ~JoinMapper() { stop = 1; if (t.joinable()) t.join(); } } join_mapper{mapper, stop};
+	{
+		DBuf *rec = &h->acx_rec;
+		const int dev = h->device;
+		const std::vector<uint64_t> *items = &slice_items;
+		mapper = std::thread([rec, dev, items, &slice_now, &map_failed, &stop, &mapped]() {
+			if (hipSetDevice(dev) != hipSuccess) { map_failed = 1; return; }
+			uint64_t upto = 0;
+			for (size_t s = 0; s < items->size(); ++s) {
+				while (slice_now.load() < (int)s && !stop.load()) std::this_thread::yield();
+				if (stop.load()) return;
+				upto += (*items)[s];
+				if (rec->grow_to((size_t)upto * BHIP_REC_BYTES + 16)) { map_failed = 1; return; }
+				mapped = rec->cap;
+			}
+		});
+	}
+	double t_map = 0, t_scan = 0, t_fill = 0, t_wait = 0;
+	auto lap = [&](double &acc, const std::chrono::steady_clock::time_point &from) { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - from).count(); };
 	for (uint32_t s = 0; s < n_slices; ++s) {
 		const uint64_t n_items = slice_items[s];
+		slice_now = (int)s;
 		if (!n_items) continue;
+		const auto tm0 = std::chrono::steady_clock::now();
 		k0.shrink_to(n_items * 8 + 16); k1.shrink_to(n_items * 8 + 16); v0.shrink_to(n_items * 2 + 16);
 		ARC(k0.grow_to(n_items * 8 + 16)); ARC(k1.grow_to(n_items * 8 + 16)); ARC(v0.grow_to(n_items * 2 + 16));
+		lap(t_map, tm0);
 		const uint64_t w0 = (uint64_t)cuts[s] << shift, w1 = (uint64_t)cuts[s + 1] << shift;
 		uint32_t wl = 1; while ((1ull << wl) < w1 - w0) ++wl;
 		const uint32_t *cnt_s = d_counts.as<uint32_t>() + (size_t)s * nC;
@@ -818,6 +882,7 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 		hipLaunchKernelGGL(k_acx_wwrite, dim3(g), dim3(256), 0, h->stream, h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_bad.as<uint8_t>(),
 			nC, h->tot_refs, K, z ? 1 : 0, (uint32_t)w0, (uint32_t)std::min<uint64_t>(w1, 0xFFFFFFFFull), cbits, d_off.as<uint32_t>(), k0.as<unsigned long long>());
 		HIPCHK(hipGetLastError());
+		if (dbg) { const auto tc0 = std::chrono::steady_clock::now(); HIPCHK(hipStreamSynchronize(h->stream)); lap(t_scan, tc0); }      // (BHIP_DEBUG: the scan timed on its own)
 		const auto ts0 = std::chrono::steady_clock::now();
 		hipcub::DoubleBuffer<unsigned long long> dk(k0.as<unsigned long long>(), k1.as<unsigned long long>());
 		HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, dk, (int)n_items, (int)cbits, (int)(cbits + wl), h->stream));
@@ -834,13 +899,22 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 		HIPCHK(hipMemcpyAsync(&n_unique, nruns.p, 4, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		if (dbg) t_sort += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
-		ARC(h->acx_rec.grow_to((rec_n + n_unique) * BHIP_REC_BYTES + 16));
+		const auto tw0 = std::chrono::steady_clock::now();
+		while (mapped.load() < (rec_n + n_unique) * BHIP_REC_BYTES + 16 && !map_failed.load()) std::this_thread::yield();
+		lap(t_wait, tw0);
+		if (map_failed.load()) return fail(BHIP_E_DEVICE, "accelerator build: the record area could not be mapped (%llu records so far)", (unsigned long long)rec_n);
+		const auto tf0 = std::chrono::steady_clock::now();
 		hipLaunchKernelGGL(k_acx_wfill, dim3(g), dim3(256), 0, h->stream, ukeys, v0.as<uint16_t>(), n_unique, (uint32_t)w0, cbits,
 			h->acx_rec.as<uint32_t>() + rec_n, d_lens.as<uint32_t>(), all_lanes);
 		HIPCHK(hipGetLastError());
 		rec_n += n_unique;
 		HIPCHK(hipStreamSynchronize(h->stream));
+		lap(t_fill, tf0);
 	}
+	slice_now = (int)n_slices;
+	if (mapper.joinable()) mapper.join();
+	h->acx_rec.shrink_to(rec_n * BHIP_REC_BYTES + 16);
+	if (dbg) fprintf(stderr, "[bhip] word-sliced build, inside the slices: %.2f s scans, %.2f s sort + fold, %.2f s records, %.2f s mapping the sort buffers, %.2f s waiting for the record area\n", t_scan, t_sort, t_fill, t_map, t_wait);
 	return 0;
 	};
 	int rc = local_part();
@@ -855,6 +929,7 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	const double t_own = since();
 	uint64_t tot = 0; uint32_t maxlen = 0;
 	rc = acx_lines_from_lens(h, d_lens.as<uint32_t>(), nw, &tot, &maxlen);
+	const double t_lines = since() - t_own;
 	std::vector<unsigned long long> eoff((size_t)n_parts + 1, 0);      // first record of every rank's region
 	if (coop && !rc) {
 		DTmp d_sum, tmp;
@@ -891,8 +966,8 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	ARC(set_badlist(h, badlist.data(), (uint32_t)badlist.size()));
 	h->has_acx = true; h->n_ent = tot; h->has_masks = !all_lanes;
 	if (dbg) fprintf(stderr, "[bhip] accelerator built on the device by word ranges%s: K=%d, %llu entries from %llu word tuples, %u slice(s) of at most %llu tuples here (%llu records), %zu clump(s) on the BadList, %.2f B per entry; "
-		"%.2f s (%.2f s histogram, %.2f s counts, %.2f s sort + fold, %.2f s until the own lists stood)\n", coop ? " (cooperative)" : "", K, (unsigned long long)tot, (unsigned long long)total, n_slices,
-		(unsigned long long)cap_items, (unsigned long long)rec_n, badlist.size(), tot ? (double)(h->acx_rec.cap + n_lines * 64) / (double)tot : 0.0, since(), t_hist, t_count - t_hist, t_sort, t_own);
+		"%.2f s (%.2f s histogram, %.2f s counts, %.2f s sort + fold, %.2f s until the own lists stood, %.2f s offset lines)\n", coop ? " (cooperative)" : "", K, (unsigned long long)tot, (unsigned long long)total, n_slices,
+		(unsigned long long)cap_items, (unsigned long long)rec_n, badlist.size(), tot ? (double)(h->acx_rec.cap + n_lines * 64) / (double)tot : 0.0, since(), t_hist, t_count - t_hist, t_sort, t_own, t_lines);
 	if (dbg && coop) fprintf(stderr, "[bhip] rank %d of %d: words [%llu, %llu), records [%llu, %llu)\n", part, n_parts, (unsigned long long)rb[part] << shift, (unsigned long long)rb[part + 1] << shift,
 		eoff[part], eoff[part + 1]);
 	return 0;
