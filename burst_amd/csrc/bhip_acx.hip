@@ -158,10 +158,12 @@ struct DTmp : DBuf { ~DTmp() { release(); } };
 static int acx_lines_from_lens(Handle *h, const uint32_t *d_lens, uint64_t nw, uint64_t *tot_out, uint32_t *maxlen_out) {
 	const uint64_t n_lines = (nw + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS;
 	DTmp d_red, d_tmp, d_lsum, d_lbase;
+	const auto t_a0 = std::chrono::steady_clock::now();
 	ARC(d_red.reserve(64));
 	ARC(h->acx_lines.reserve_exact((n_lines + 1) * 64));
 	ARC(d_lsum.reserve((n_lines + 2) * 8));
 	ARC(d_lbase.reserve((n_lines + 2) * 8));
+	if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] offset lines: %.3f s allocating %.1f GB\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a0).count(), ((n_lines + 1) * 64 + (n_lines + 2) * 16) / 1e9);
 	auto to_sq = [] __host__ __device__(uint32_t n) -> double { return (double)n * (double)n; };
 	hipcub::TransformInputIterator<double, decltype(to_sq), const uint32_t *> it_sq(d_lens, to_sq);
 	unsigned long long *r_tot = d_red.as<unsigned long long>(); double *r_sq = (double *)(r_tot + 1); uint32_t *r_max = (uint32_t *)(r_tot + 2);
@@ -529,7 +531,7 @@ __global__ void k_acx_rec_export(const uint32_t *__restrict__ rec, unsigned long
 // (the order of the calls is not the order of the positions' -- nobody needs it).
 // A dword of eight symbols at a time: where all eight are A/C/G/T (every dword of a database without ambiguity codes, nearly every one of
 // a real one) their 2-bit codes are packed with bit tricks, newest symbol lowest, behind the codes of the dwords before in one 64-bit
-// register, and the eight windows are eight shifts of it -- 8 instructions per position instead of 22 for the symbol-by-symbol walk, which
+// register, and -- with K - 1 such symbols in front of the dword -- the eight windows are eight shifts of it -- 8 instructions per position instead of 22 for the symbol-by-symbol walk, which
 // is what a scan of the references costs (and this builder scans them once per slice).  A dword with anything else in it (ambiguity codes,
 // padding, the lane's end) takes the symbol-by-symbol walk, its window state rebuilt from the two dwords before (16 symbols >= K - 1).
 template <class F>
@@ -553,10 +555,9 @@ __device__ __forceinline__ void acx_lane_words(const uint4 *__restrict__ rp, uin
 			uint32_t r = __brev(p) >> 16;                                             // symbol 7 lowest (the bits of a code swapped: put back)
 			r = ((r & 0x5555u) << 1) | ((r >> 1) & 0x5555u);
 			S = (S << 16) | r;
-			if (litm == 0x11111111u && base + 8 <= L) {
-				const uint32_t first = litrun + 1 >= (uint32_t)K ? 0u : (uint32_t)K - 1u - litrun;      // first position of the dword with K literals behind it
+			if (litm == 0x11111111u && base + 8 <= L && litrun + 1 >= (uint32_t)K) {      // (K - 1 literals before the dword: none of its windows reaches an ambiguity code)
 				#pragma unroll
-				for (uint32_t k = 0; k < 8; ++k) if (k >= first) emit((uint32_t)(S >> (2u * (7u - k))) & wmask);
+				for (uint32_t k = 0; k < 8; ++k) emit((uint32_t)(S >> (2u * (7u - k))) & wmask);
 				litrun = litrun + 8 > 64 ? 64 : litrun + 8;
 			} else {
 				unsigned long long win = 0;
@@ -659,13 +660,27 @@ __global__ __launch_bounds__(256) void k_acx_wwrite(const uint4 *__restrict__ re
 }
 struct AcxWKeyOf { __host__ __device__ unsigned long long operator()(const unsigned long long &t) const { return t & ((1ull << 60) - 1ull); } };
 struct AcxWLaneOf { __host__ __device__ uint16_t operator()(const unsigned long long &t) const { return (uint16_t)(1u << (uint32_t)(t >> 60)); } };
-// unique tuple i of a slice = record rec0 + i; one count per record for its word's list length
-__global__ void k_acx_wfill(const unsigned long long *__restrict__ ukeys, const uint16_t *__restrict__ umasks, uint32_t n_unique, uint32_t w0, uint32_t cbits,
+// unique tuple i of a slice = record rec0 + i, and one count for its word's list length -- added per WORD and wave (the tuples of a word
+// are neighbours: the first lane of a word's run inside the wave adds the run's length; one atomic per record on 50 equal addresses in a
+// row made this kernel 2.75 s of a 6.8 s build)
+__global__ __launch_bounds__(256) void k_acx_wfill(const unsigned long long *__restrict__ ukeys, const uint16_t *__restrict__ umasks, uint32_t n_unique, uint32_t w0, uint32_t cbits,
 		uint32_t *__restrict__ rec, uint32_t *__restrict__ lens, uint32_t all_lanes) {
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_unique; i += gridDim.x * blockDim.x) {
-		const unsigned long long key = ukeys[i];
-		bhip_rec_store(rec, i, (uint32_t)key & ((1u << cbits) - 1u), all_lanes ? 0xFFFFu : (uint32_t)umasks[i]);
-		atomicAdd(&lens[w0 + (uint32_t)(key >> cbits)], 1u);
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t n64 = (n_unique + 63u) & ~63u;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n64; i += gridDim.x * blockDim.x) {
+		const bool in = i < n_unique;
+		const unsigned long long key = in ? ukeys[i] : 0ull;
+		const uint32_t word = (uint32_t)(key >> cbits);
+		if (in) bhip_rec_store(rec, i, (uint32_t)key & ((1u << cbits) - 1u), all_lanes ? 0xFFFFu : (uint32_t)umasks[i]);
+		const uint32_t before = __shfl_up(word, 1);
+		const bool lead = in && (lane == 0 || word != before);
+		const unsigned long long lm = __ballot(lead), im = __ballot(in);
+		if (lead) {
+			const unsigned long long rest = lane < 63u ? lm >> (lane + 1u) : 0ull;
+			const uint32_t hi = rest ? lane + 1u + (uint32_t)__builtin_ctzll(rest) : 64u;      // the next word's first lane
+			const unsigned long long range = (hi == 64u ? ~0ull : (1ull << hi) - 1ull) & ~((1ull << lane) - 1ull);
+			atomicAdd(&lens[w0 + word], (uint32_t)__popcll(im & range));
+		}
 	}
 }
 
@@ -797,7 +812,7 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	};
 	auto plan_by_room = [&](uint32_t assumed_slices) -> uint32_t {
 		cuts.assign(1, own0); slice_items.clear(); cap_items = 0;
-		const double base = (double)free_b - (double)nw * 4.0 - (double)nC * 8.0 - (double)assumed_slices * nC * 4.0 - (double)(3ull << 30);
+		const double base = (double)free_b - (double)nw * 4.0 - (double)(n_lines + 1) * 64.0 - (double)nC * 8.0 - (double)assumed_slices * nC * 4.0 - (double)(3ull << 30);
 		uint64_t before = 0;
 		for (uint32_t b0 = own0; b0 < own1;) {
 			const double room = base - (double)before * BHIP_REC_BYTES;
@@ -824,6 +839,7 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	h->K = K;
 	ARC(d_lens.reserve(nw * 4 + 16));
 	HIPCHK(hipMemsetAsync(d_lens.p, 0, nw * 4, h->stream));
+	ARC(h->acx_lines.reserve_exact((n_lines + 1) * 64));      // (now, while the device has room: an allocation next to 216 GB of mapped records takes a second)
 	if (!n_slices) { HIPCHK(hipStreamSynchronize(h->stream)); return 0; }      // (a rank whose run of buckets is empty: it only receives)
 	// 3. tuples per (slice, clump) in one scan
 	std::vector<uint8_t> b2s(n_buckets, 0xFF);
