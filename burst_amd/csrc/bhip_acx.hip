@@ -858,22 +858,19 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	// 4. slice after slice: offsets, tuples, sort over the slice's word bits, fold, records.  The record area's memory is mapped by a thread
 	// of its own, one slice's worth (its tuples: an upper bound of its records) while that slice is scanned and sorted -- mapping 216 GB in
 	// 1 GiB chunks takes seconds, which now lie beside the kernels; what was mapped beyond the records goes back at the end.
-	std::atomic<int> slice_now(-1), map_failed(0), stop(0);
-	std::atomic<size_t> mapped(0);
+	std::atomic<int> map_failed(0), stop(0);
+	std::atomic<size_t> mapped(0), map_target(0);
 	std::thread mapper;
 	struct JoinMapper { std::thread &t; std::atomic<int> &stop; ~JoinMapper() { stop = 1; if (t.joinable()) t.join(); } } join_mapper{mapper, stop};
 	{
 		DBuf *rec = &h->acx_rec;
 		const int dev = h->device;
-		const std::vector<uint64_t> *items = &slice_items;
-		mapper = std::thread([rec, dev, items, &slice_now, &map_failed, &stop, &mapped]() {
+		mapper = std::thread([rec, dev, &map_target, &map_failed, &stop, &mapped]() {
 			if (hipSetDevice(dev) != hipSuccess) { map_failed = 1; return; }
-			uint64_t upto = 0;
-			for (size_t s = 0; s < items->size(); ++s) {
-				while (slice_now.load() < (int)s && !stop.load()) std::this_thread::yield();
-				if (stop.load()) return;
-				upto += (*items)[s];
-				if (rec->grow_to((size_t)upto * BHIP_REC_BYTES + 16)) { map_failed = 1; return; }
+			while (!stop.load()) {
+				const size_t want = map_target.load();
+				if (want <= rec->cap) { std::this_thread::yield(); continue; }
+				if (rec->grow_to(want)) { map_failed = 1; return; }
 				mapped = rec->cap;
 			}
 		});
@@ -882,8 +879,8 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	auto lap = [&](double &acc, const std::chrono::steady_clock::time_point &from) { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - from).count(); };
 	for (uint32_t s = 0; s < n_slices; ++s) {
 		const uint64_t n_items = slice_items[s];
-		slice_now = (int)s;
 		if (!n_items) continue;
+		map_target = (size_t)(rec_n + n_items) * BHIP_REC_BYTES + 16;      // (the records so far are known, this slice's are at most its tuples)
 		const auto tm0 = std::chrono::steady_clock::now();
 		k0.shrink_to(n_items * 8 + 16); k1.shrink_to(n_items * 8 + 16); v0.shrink_to(n_items * 2 + 16);
 		ARC(k0.grow_to(n_items * 8 + 16)); ARC(k1.grow_to(n_items * 8 + 16)); ARC(v0.grow_to(n_items * 2 + 16));
@@ -927,7 +924,7 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 		HIPCHK(hipStreamSynchronize(h->stream));
 		lap(t_fill, tf0);
 	}
-	slice_now = (int)n_slices;
+	stop = 1;
 	if (mapper.joinable()) mapper.join();
 	h->acx_rec.shrink_to(rec_n * BHIP_REC_BYTES + 16);
 	if (dbg) fprintf(stderr, "[bhip] word-sliced build, inside the slices: %.2f s scans, %.2f s sort + fold, %.2f s records, %.2f s mapping the sort buffers, %.2f s waiting for the record area\n", t_scan, t_sort, t_fill, t_map, t_wait);
@@ -997,9 +994,10 @@ int bhip_build_accelerator(Handle *h, int K, int z) {
 	if (how && !strcmp(how, "words")) {
 		const int rc = build_accelerator_by_words(h, K, z);
 		if (rc == 0 || (rc < 0 && rc != BHIP_E_DEVICE)) return rc;      // (1: cannot run here; a device error -- memory, most likely -- : the other builder plans differently)
+		const std::string why = rc < 0 ? bhip_last_error() : "";
 		h->acx_rec.release(); h->acx_lines.release(); h->has_acx = false;
 		(void)hipGetLastError();
-		if (how && !strcmp(how, "words")) return fail(BHIP_E_DEVICE, "BHIP_ACX_BUILD=words: the word-sliced accelerator build cannot run here");
+		if (how && !strcmp(how, "words")) return fail(BHIP_E_DEVICE, "BHIP_ACX_BUILD=words: the word-sliced accelerator build cannot run here (%s)", rc == 1 ? "its preconditions" : why.c_str());
 		if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] word-sliced accelerator build not possible here: clump-sliced build\n");
 	}
 	return build_accelerator_by_clumps(h, K, z);

@@ -153,10 +153,12 @@ def test_cooperative_build_equals_the_single_rank_build(db, K, z, n_ranks, slice
     for a, b in zip(want, got):
         assert np.array_equal(a, b)
     devs = d.open_devices_team([0] * n_ranks, z, build_K=K)
-    for dev in devs:
+    for r, dev in enumerate(devs):
         got = _export(dev, K)
-        for a, b in zip(want, got):
-            assert np.array_equal(a, b)
+        for name, a, b in zip(("list lengths", "clump ids", "lane sets", "BadList"), want, got):
+            bad = np.flatnonzero(a != b) if a.shape == b.shape else None
+            assert np.array_equal(a, b), "rank %d's %s differ at %s of %d: want %s, got %s" % (r, name, None if bad is None else (bad[:5], bad[-5:], len(bad)), len(a),
+                                                                                               None if bad is None else a[bad[:8]], None if bad is None else b[bad[:8]])
         dev.close()
     d.close()
 
