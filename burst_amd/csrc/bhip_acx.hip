@@ -987,18 +987,21 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 }
 
 static int build_accelerator_by_clumps(Handle *h, int K, int z);
-// BHIP_ACX_BUILD=words asks for the word-sliced builder (experimental: one scan of the references per slice costs more than the second
-// sort it saves -- 14.6 s against 10.1 s at the metric's size, gpurun_out/r05c); the clump-sliced one is the default
+// The word-sliced builder is the default since the end of round 5 (4.2 s against 7.7 s at the metric's size on a quiet device,
+// profiles/r05q_*); where it cannot run (no virtual memory management, more than 2^24 clumps, not enough room for its plan) the clump-sliced
+// one takes over.  BHIP_ACX_BUILD=clumps asks for that one (and so do the test hooks of its large-database path), =words for the other only.
 int bhip_build_accelerator(Handle *h, int K, int z) {
 	const char *how = getenv("BHIP_ACX_BUILD");
-	if (how && !strcmp(how, "words")) {
+	const bool only_words = how && !strcmp(how, "words");
+	const bool clumps = (how && !strcmp(how, "clumps")) || ((getenv("BHIP_TEST_TWO_PLANS") || getenv("BHIP_ACX_NO_PREMAP")) && !only_words);
+	if (!clumps) {
 		const int rc = build_accelerator_by_words(h, K, z);
 		if (rc == 0 || (rc < 0 && rc != BHIP_E_DEVICE)) return rc;      // (1: cannot run here; a device error -- memory, most likely -- : the other builder plans differently)
 		const std::string why = rc < 0 ? bhip_last_error() : "";
 		h->acx_rec.release(); h->acx_lines.release(); h->has_acx = false;
 		(void)hipGetLastError();
-		if (how && !strcmp(how, "words")) return fail(BHIP_E_DEVICE, "BHIP_ACX_BUILD=words: the word-sliced accelerator build cannot run here (%s)", rc == 1 ? "its preconditions" : why.c_str());
-		if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] word-sliced accelerator build not possible here: clump-sliced build\n");
+		if (only_words) return fail(BHIP_E_DEVICE, "BHIP_ACX_BUILD=words: the word-sliced accelerator build cannot run here (%s)", rc == 1 ? "its preconditions" : why.c_str());
+		if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] word-sliced accelerator build not possible here (%s): clump-sliced build\n", rc == 1 ? "its preconditions" : why.c_str());
 	}
 	return build_accelerator_by_clumps(h, K, z);
 }

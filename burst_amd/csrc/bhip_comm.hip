@@ -330,6 +330,8 @@ extern "C" int bhip_team_share(void *team, void *device_base, const uint64_t *by
 	if (!T || !byte_off || T->n != n_parts || part < 0 || part >= n_parts) return bhip_fail_msg(BHIP_E_ARG, "bad arguments of the region exchange");
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); status = 1; }
+	// (everything this rank has enqueued on its device -- whatever the stream -- has happened before a peer reads its region)
+	if (!status && hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); status = 1; }
 	T->base[(size_t)part] = device_base; T->dev[(size_t)part] = dev; T->status[(size_t)part] = status; T->failed[(size_t)part] = 0;
 	pthread_barrier_wait(&T->bar);
 	int any = 0;
@@ -346,7 +348,7 @@ extern "C" int bhip_team_share(void *team, void *device_base, const uint64_t *by
 				                              : hipMemcpyPeerAsync((char *)device_base + a, dev, (const char *)T->base[(size_t)k] + a, T->dev[(size_t)k], n, st)) == hipSuccess;
 			}
 		}
-		ok = ok && hipStreamSynchronize(st) == hipSuccess;
+		ok = ok && hipStreamSynchronize(st) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
 		if (st) (void)hipStreamDestroy(st);
 		if (!ok) { bhip_fail_msg(BHIP_E_DEVICE, "region exchange (peer copies) failed on rank %d: %s", part, hipGetErrorString(hipGetLastError())); T->failed[(size_t)part] = 1; }
 	}

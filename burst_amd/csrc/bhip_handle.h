@@ -15,6 +15,7 @@
 #include <string.h>
 #include <algorithm>
 #include <vector>
+#include <mutex>
 #include <chrono>
 #include <thread>
 #include "burst_hip.h"
@@ -86,6 +87,10 @@ int bhip_fail_msg(int code, const char *fmt, ...) __attribute__((format(printf, 
 	return fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
 
 // grow-only device buffer
+// (address-range reservations, mappings and unmappings of ALL handles of the process go one at a time: ranks that share a process -- one
+// thread each -- build their accelerators at the same moment, and concurrent hipMemMap / hipMemUnmap calls lost mappings: a region of
+// records read back as zeros in one run of six, tests/test_gpu_acx.py::test_cooperative_build_equals_the_single_rank_build)
+inline std::mutex &bhip_vmm_mutex() { static std::mutex m; return m; }
 struct DBuf {
 	void *p = nullptr; size_t cap = 0;
 	// growable variant (reserve_growable / grow_to): ONE address range whose physical memory is mapped chunk by chunk as the array
@@ -113,6 +118,7 @@ struct DBuf {
 	// an address range for up to max_bytes with nothing behind it yet; non-zero (and no error text) when the runtime cannot do it
 	int reserve_growable(size_t max_bytes, int device) {
 		release();
+		std::lock_guard<std::mutex> lk(bhip_vmm_mutex());
 		int ok = 0;
 		if (hipDeviceGetAttribute(&ok, hipDeviceAttributeVirtualMemoryManagementSupported, device) != hipSuccess || !ok) { (void)hipGetLastError(); return 1; }
 		const size_t sz = ((max_bytes + kChunk - 1) / kChunk + 1) * kChunk;
@@ -128,6 +134,7 @@ struct DBuf {
 		hipMemAccessDesc acc = {};
 		acc.location.type = hipMemLocationTypeDevice; acc.location.id = vmm_device; acc.flags = hipMemAccessFlagsProtReadWrite;
 		while (cap < bytes) {
+			std::lock_guard<std::mutex> lk(bhip_vmm_mutex());
 			hipMemGenericAllocationHandle_t hnd;
 			hipError_t e = hipMemCreate(&hnd, kChunk, &prop, 0);
 			if (e != hipSuccess) return fail(BHIP_E_DEVICE, "hipMemCreate(%zu) at %zu mapped bytes: %s", kChunk, cap, hipGetErrorString(e));
@@ -143,6 +150,7 @@ struct DBuf {
 	void shrink_to(size_t bytes) {
 		if (!vmm) return;
 		const size_t keep = (bytes + kChunk - 1) / kChunk;
+		std::lock_guard<std::mutex> lk(bhip_vmm_mutex());
 		while (chunks.size() > keep) {
 			(void)hipMemUnmap((char *)p + (chunks.size() - 1) * kChunk, kChunk); (void)hipMemRelease(chunks.back());
 			chunks.pop_back(); cap -= kChunk;
@@ -150,6 +158,7 @@ struct DBuf {
 	}
 	void release() {
 		if (vmm) {
+			std::lock_guard<std::mutex> lk(bhip_vmm_mutex());
 			for (size_t i = 0; i < chunks.size(); ++i) { (void)hipMemUnmap((char *)p + i * kChunk, kChunk); (void)hipMemRelease(chunks[i]); }
 			chunks.clear();
 			if (p) (void)hipMemAddressFree(p, va_size);

@@ -62,13 +62,19 @@ def _compare_built_with_loaded(db_path_or_db, K, z, from_fasta=None):
 @pytest.mark.parametrize("db,K,z", [("dna", 12, 1), ("dna", 12, 0), ("quick", 12, 1), ("quick", 10, 0), ("quick", 15, 1)])
 def test_device_built_accelerator_equals_file(db, K, z, monkeypatch):
     """golden databases (references with IUPAC codes and N): same list lengths, same clump ids in the same order, same BadList"""
-    n, nbad, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z)
+    n, nbad, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z)      # (the default builder: slices of the word space)
     assert n > 10000
-    if K == 12:      # the same in slices of a few clumps (two passes: list lengths, then records at running list positions)
-        monkeypatch.setenv("BHIP_MASK_SLICE", "40000")
-        n2, _, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z)
-        assert n2 == n
-        monkeypatch.delenv("BHIP_MASK_SLICE")
+    monkeypatch.setenv("BHIP_ACX_BUILD", "clumps")                                         # the clump-sliced builder, everything at once
+    n1, _, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z)
+    assert n1 == n
+    if K == 12:      # both in small slices (words: several scans; clumps: two passes -- list lengths, then records at running list positions)
+        for how in ("clumps", "words"):
+            monkeypatch.setenv("BHIP_ACX_BUILD", how)
+            monkeypatch.setenv("BHIP_MASK_SLICE", "40000")
+            n2, _, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z)
+            assert n2 == n
+            monkeypatch.delenv("BHIP_MASK_SLICE")
+    monkeypatch.delenv("BHIP_ACX_BUILD")
     # ... and through the path of the large databases (BHIP_TEST_TWO_PLANS: a counting pass over the sorted tuples, the record area one
     # address range whose memory is mapped by a thread beside that pass and cut back to the real size, a second plan for the records)
     monkeypatch.setenv("BHIP_TEST_TWO_PLANS", "1")
@@ -136,9 +142,11 @@ def test_cooperative_build_equals_the_single_rank_build(db, K, z, n_ranks, slice
     """bhip_build_accelerator_shared: n_ranks handles of the replicated database (here: on one device, one thread each, as burst_hip --gpus N
     --devices 0,0,.. runs them) build the lists of their shares of the words and complete each other's tables (bhip_team_share) -- every
     handle must end up with the tables of the single-rank build, bit for bit: list lengths, clump ids in list order, lane sets, BadList.
-    Also the word-sliced builder alone (BHIP_ACX_BUILD=words), which is the cooperative builder with one rank."""
+    The single-rank tables come from the clump-sliced builder; the word-sliced one alone (the default; the cooperative builder with one
+    rank) is compared on the way."""
     from burst_amd import host
     d = host.Db.read(os.path.join(gl.G, db + ".edx"))
+    monkeypatch.setenv("BHIP_ACX_BUILD", "clumps")
     solo = d.open_device(0, z, build_K=K)
     want = _export(solo, K)
     solo.close()
@@ -167,9 +175,11 @@ def test_cooperative_build_falls_back_together(monkeypatch):
     """a rank that cannot do its share announces it in the first exchange and EVERY rank builds alone (nobody waits, same tables)"""
     from burst_amd import host
     d = host.Db.read(os.path.join(gl.G, "quick.edx"))
+    monkeypatch.setenv("BHIP_ACX_BUILD", "clumps")
     solo = d.open_device(0, 1, build_K=12)
     want = _export(solo, 12)
     solo.close()
+    monkeypatch.delenv("BHIP_ACX_BUILD")
     monkeypatch.setenv("BHIP_TEST_COOP_FAIL_RANK", "1")
     devs = d.open_devices_team([0, 0, 0], 1, build_K=12)
     for dev in devs:
