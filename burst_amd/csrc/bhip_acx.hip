@@ -155,23 +155,30 @@ struct DTmp : DBuf { ~DTmp() { release(); } };
 
 // Offset lines, total and statistics from the list lengths on the device (Lens[4^K], burst.c:3558): sums of 14 -> 64-bit bases
 // (hipCUB scan) -> lines; occurrence-weighted mean list length (sizes the prefilter's per-query tables) and the longest list.
-static int acx_lines_from_lens(Handle *h, const uint32_t *d_lens, uint64_t nw, uint64_t *tot_out, uint32_t *maxlen_out) {
+// (`scratch`: memory the caller took while the device still had room -- acx_lines_scratch_bytes of it: an allocation next to 216 GB of mapped
+// records takes half a second each, 1.1 s of a 4.2 s build for these four)
+static size_t acx_lines_scratch_bytes(uint64_t nw) { return (size_t)(((nw + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS + 2) * 16 + ((size_t)64 << 20)); }
+static int acx_lines_from_lens(Handle *h, const uint32_t *d_lens, uint64_t nw, uint64_t *tot_out, uint32_t *maxlen_out, DBuf *scratch = nullptr) {
 	const uint64_t n_lines = (nw + BHIP_ACX_LINE_WORDS - 1) / BHIP_ACX_LINE_WORDS;
 	DTmp d_red, d_tmp, d_lsum, d_lbase;
 	const auto t_a0 = std::chrono::steady_clock::now();
-	ARC(d_red.reserve(64));
 	ARC(h->acx_lines.reserve_exact((n_lines + 1) * 64));
-	ARC(d_lsum.reserve((n_lines + 2) * 8));
-	ARC(d_lbase.reserve((n_lines + 2) * 8));
-	if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] offset lines: %.3f s allocating %.1f GB\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a0).count(), ((n_lines + 1) * 64 + (n_lines + 2) * 16) / 1e9);
 	auto to_sq = [] __host__ __device__(uint32_t n) -> double { return (double)n * (double)n; };
 	hipcub::TransformInputIterator<double, decltype(to_sq), const uint32_t *> it_sq(d_lens, to_sq);
-	unsigned long long *r_tot = d_red.as<unsigned long long>(); double *r_sq = (double *)(r_tot + 1); uint32_t *r_max = (uint32_t *)(r_tot + 2);
 	size_t tb = 0, tb1 = 0;
-	HIPCHK(hipcub::DeviceReduce::Sum(nullptr, tb1, it_sq, r_sq, (int)nw, h->stream)); tb = std::max(tb, tb1);
-	HIPCHK(hipcub::DeviceReduce::Max(nullptr, tb1, d_lens, r_max, (int)nw, h->stream)); tb = std::max(tb, tb1);
-	HIPCHK(hipcub::DeviceScan::ExclusiveScan(nullptr, tb1, d_lsum.as<unsigned long long>(), d_lbase.as<unsigned long long>(), hipcub::Sum(), 0ull, (int)(n_lines + 1), h->stream)); tb = std::max(tb, tb1);
-	ARC(d_tmp.reserve(tb + 16));
+	HIPCHK(hipcub::DeviceReduce::Sum(nullptr, tb1, it_sq, (double *)nullptr, (int)nw, h->stream)); tb = std::max(tb, tb1);
+	HIPCHK(hipcub::DeviceReduce::Max(nullptr, tb1, d_lens, (uint32_t *)nullptr, (int)nw, h->stream)); tb = std::max(tb, tb1);
+	HIPCHK(hipcub::DeviceScan::ExclusiveScan(nullptr, tb1, (unsigned long long *)nullptr, (unsigned long long *)nullptr, hipcub::Sum(), 0ull, (int)(n_lines + 1), h->stream)); tb = std::max(tb, tb1);
+	const size_t sum_b = ((n_lines + 2) * 8 + 255) & ~(size_t)255;
+	const bool carved = scratch && scratch->p && scratch->cap >= 256 + 2 * sum_b + tb + 16;
+	if (carved) {          // (borrowed: the DTmp wrappers must not free them)
+		d_red.p = scratch->p; d_lsum.p = (char *)scratch->p + 256; d_lbase.p = (char *)d_lsum.p + sum_b; d_tmp.p = (char *)d_lbase.p + sum_b;
+	} else {
+		ARC(d_red.reserve(64)); ARC(d_lsum.reserve((n_lines + 2) * 8)); ARC(d_lbase.reserve((n_lines + 2) * 8)); ARC(d_tmp.reserve(tb + 16));
+	}
+	struct Unborrow { DTmp &a, &b, &c, &d; bool on; ~Unborrow() { if (on) { a.p = b.p = c.p = d.p = nullptr; a.cap = b.cap = c.cap = d.cap = 0; } } } unborrow{d_red, d_lsum, d_lbase, d_tmp, carved};
+	if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] offset lines: %.3f s allocating (%s)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a0).count(), carved ? "scratch taken before the build" : "now");
+	unsigned long long *r_tot = d_red.as<unsigned long long>(); double *r_sq = (double *)(r_tot + 1); uint32_t *r_max = (uint32_t *)(r_tot + 2);
 	tb1 = tb; HIPCHK(hipcub::DeviceReduce::Sum(d_tmp.p, tb1, it_sq, r_sq, (int)nw, h->stream));
 	tb1 = tb; HIPCHK(hipcub::DeviceReduce::Max(d_tmp.p, tb1, d_lens, r_max, (int)nw, h->stream));
 	const uint32_t lg = (uint32_t)std::min<uint64_t>((n_lines + 255) / 256, (uint64_t)h->n_cu * 32);
@@ -728,7 +735,7 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	const uint32_t all_lanes = getenv("BHIP_NO_LANE_MASKS") ? 1u : 0u;
 	std::vector<uint32_t> badlist;
 	std::vector<uint32_t> rb((size_t)n_parts + 1, 0);      // bucket boundaries of the ranks' runs
-	DTmp d_lens;
+	DTmp d_lens, lines_scratch;
 	uint64_t rec_n = 0, total = 0, cap_items = 0;
 	uint32_t n_slices = 0;
 	double t_hist = 0, t_count = 0, t_sort = 0;
@@ -793,30 +800,48 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	HIPCHK(hipMemGetInfo(&free_b, &total_b));
 	long long forced_slice = 0;
 	if (const char *ev = getenv("BHIP_MASK_SLICE")) forced_slice = atoll(ev);
-	// Slices: runs of buckets whose tuples fit the sort (two 8-byte tuple arrays + the folded lane masks + the sort's own scratch: 19 bytes
-	// per tuple, and 4 for the records they become) next to what is resident WHEN THE SLICE IS SORTED -- the records of the slices before
-	// it (at most 4 bytes per tuple so far), not those of the whole database: the early slices take as many tuples as one sort call takes
-	// (2^31), the last ones what is left beside 216 GB of records.  Every slice costs one scan of the references, so fewer, larger slices
-	// are what makes this builder cheap: 29 slices instead of 64 at the metric's size.  A slice spans at most 2^26 words (four sort passes).
+	// The record area is ONE address range (DBuf::reserve_growable) and the sort works inside it: the records fill it from the bottom, the
+	// slice at hand is sorted and folded at its TOP -- two 8-byte tuple arrays and the folded lane masks, 18 bytes per tuple -- in the part
+	// the records have not reached yet.  So a slice may have as many tuples as fit between the records so far and the top,
+	// 4 (before + n) + 18 n <= range: the early slices take what one sort call takes (2^31 tuples), the last ones what is left beside
+	// 216 GB of records -- 28 slices at the metric's size, where "one record per tuple, and the sort buffers beside them" gave 64.  Every
+	// slice costs one scan of the references, so fewer, larger slices are what makes this builder cheap.  Nothing is unmapped before the
+	// build is over (first version: sort buffers of their own, mapped and unmapped slice by slice -- ranks building side by side read each
+	// other's regions back as zeros once in three runs; with ordinary allocations of a fixed size: never in 48).
+	// A slice spans at most 2^26 words (four sort passes).
 	std::vector<uint32_t> cuts;        // bucket boundaries of the slices
 	std::vector<uint64_t> slice_items;
 	const uint32_t max_b = 26 > shift ? 1u << (26 - shift) : 1u;
+	auto buf_bytes = [](uint64_t n) -> size_t { return 2 * ((size_t)(n * 8 + 16 + 255) & ~(size_t)255) + ((size_t)(n * 2 + 16 + 255) & ~(size_t)255); };
+	// the range: the final size (a record per tuple of the whole database at most) and room for the largest slice's sort on top of the own
+	// records, as far as the device has it
+	const double other = (double)nw * 4.0 + (double)(n_lines + 1) * 64.0 + (double)acx_lines_scratch_bytes(nw) + (double)nC * 8.0 + 40.0 * nC * 4.0 + (double)(3ull << 30);
+	const double avail = (double)free_b - other;
+	const uint64_t biggest_sort = std::min<uint64_t>(total_own, 2147483000ull);
+	double want_va = std::max((double)total * BHIP_REC_BYTES + 16.0, (double)total_own * BHIP_REC_BYTES + (double)buf_bytes(biggest_sort)) + 4096.0;
+	if (want_va > avail) want_va = avail;
+	if (want_va < (double)total * BHIP_REC_BYTES + 16.0 + 4096.0) return 1;      // (not even the records fit)
+	// (reserve_growable rounds up to whole chunks and adds one: planned with the two chunks taken off)
+	const size_t va_plan = (size_t)want_va > 2 * DBuf::kChunk + ((size_t)total * BHIP_REC_BYTES + 16) ? (size_t)want_va - 2 * DBuf::kChunk : (size_t)total * BHIP_REC_BYTES + 16;
+	if (h->acx_rec.reserve_growable(va_plan, h->device)) return 1;
+	const size_t va_size = h->acx_rec.va_size;
 	auto plan = [&](uint64_t target) -> uint32_t {      // (BHIP_MASK_SLICE: slices of a given size)
 		cuts.assign(1, own0); slice_items.clear(); cap_items = 0;
+		uint64_t before = 0;
 		for (uint32_t b0 = own0; b0 < own1;) {
 			uint32_t b1 = b0 + 1; uint64_t n = hist[b0];
 			while (b1 < own1 && b1 - b0 < max_b && n + hist[b1] <= target) n += hist[b1++];
-			cuts.push_back(b1); slice_items.push_back(n); cap_items = std::max(cap_items, n); b0 = b1;
+			if ((before + n) * BHIP_REC_BYTES + 16 + buf_bytes(n) > va_size) return 0;
+			cuts.push_back(b1); slice_items.push_back(n); cap_items = std::max(cap_items, n); before += n; b0 = b1;
 		}
 		return (uint32_t)cuts.size() - 1;
 	};
-	auto plan_by_room = [&](uint32_t assumed_slices) -> uint32_t {
+	auto plan_by_room = [&]() -> uint32_t {
 		cuts.assign(1, own0); slice_items.clear(); cap_items = 0;
-		const double base = (double)free_b - (double)nw * 4.0 - (double)(n_lines + 1) * 64.0 - (double)nC * 8.0 - (double)assumed_slices * nC * 4.0 - (double)(3ull << 30);
 		uint64_t before = 0;
 		for (uint32_t b0 = own0; b0 < own1;) {
-			const double room = base - (double)before * BHIP_REC_BYTES;
-			const uint64_t target = room > 0 ? (uint64_t)std::min(2147483000.0, room / 23.0) : 0;
+			const double room = (double)va_size - (double)before * BHIP_REC_BYTES - 4096.0;
+			const uint64_t target = room > 0 ? (uint64_t)std::min(2147483000.0, room / 22.0) : 0;
 			if (hist[b0] > target) return 0;
 			uint32_t b1 = b0 + 1; uint64_t n = hist[b0];
 			while (b1 < own1 && b1 - b0 < max_b && n + hist[b1] <= target) n += hist[b1++];
@@ -826,98 +851,103 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	};
 	const uint32_t max_slices = coop ? BHIP_ACX_MAX_SLICES - 1u : BHIP_ACX_MAX_SLICES;      // (slice number 0xFF marks another rank's buckets)
 	if (own1 > own0 && total_own) {
-		if (forced_slice > 0) n_slices = plan(std::max<uint64_t>((uint64_t)forced_slice, biggest));
-		else {
-			n_slices = plan_by_room(32);
-			if (n_slices > 32) n_slices = plan_by_room(n_slices + 8);
-		}
+		n_slices = forced_slice > 0 ? plan(std::max<uint64_t>((uint64_t)forced_slice, biggest)) : plan_by_room();
 		if (!n_slices || n_slices > max_slices || cap_items >= 2147483000ull) return 1;
 	}
-	// the record area: an address range for the upper bound, memory as the records come
-	if (h->acx_rec.reserve_growable((size_t)total * BHIP_REC_BYTES + 16, h->device)) return 1;
 	if (const char *ev = getenv("BHIP_TEST_ENTRY_BIAS")) h->acx_bias = strtoull(ev, nullptr, 0);
 	h->K = K;
 	ARC(d_lens.reserve(nw * 4 + 16));
 	HIPCHK(hipMemsetAsync(d_lens.p, 0, nw * 4, h->stream));
-	ARC(h->acx_lines.reserve_exact((n_lines + 1) * 64));      // (now, while the device has room: an allocation next to 216 GB of mapped records takes a second)
+	ARC(h->acx_lines.reserve_exact((n_lines + 1) * 64));      // (now, while the device has room: an allocation next to 216 GB of mapped records takes half a second)
+	ARC(lines_scratch.reserve(acx_lines_scratch_bytes(nw)));
 	if (!n_slices) { HIPCHK(hipStreamSynchronize(h->stream)); return 0; }      // (a rank whose run of buckets is empty: it only receives)
 	// 3. tuples per (slice, clump) in one scan
 	std::vector<uint8_t> b2s(n_buckets, 0xFF);
 	for (uint32_t s = 0; s < n_slices; ++s) for (uint32_t b = cuts[s]; b < cuts[s + 1]; ++b) b2s[b] = (uint8_t)s;
-	DTmp d_b2s, d_counts, d_off, k0, k1, v0, nruns, tmp;
+	DTmp d_b2s, d_counts, d_off, nruns, tmp;
 	ARC(d_b2s.reserve(n_buckets)); ARC(d_counts.reserve_exact((size_t)n_slices * nC * 4 + 16)); ARC(d_off.reserve((size_t)nC * 4 + 16));
 	HIPCHK(hipMemcpyAsync(d_b2s.p, b2s.data(), n_buckets, hipMemcpyHostToDevice, h->stream));
 	hipLaunchKernelGGL(k_acx_wcount, dim3(g), dim3(256), 0, h->stream, h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_bad.as<uint8_t>(),
 		nC, h->tot_refs, K, z ? 1 : 0, shift, n_buckets, d_b2s.as<uint8_t>(), n_slices, d_counts.as<uint32_t>());
 	HIPCHK(hipGetLastError());
-	// (the sort buffers follow the slices' sizes: address ranges for the largest slice, memory for the one at hand)
-	if (k0.reserve_growable(cap_items * 8 + 16, h->device) || k1.reserve_growable(cap_items * 8 + 16, h->device) || v0.reserve_growable(cap_items * 2 + 16, h->device)) return 1;
 	ARC(nruns.reserve(16));
+	{	// the library calls' own scratch for the largest slice, once
+		size_t tb = 0, tb1 = 0;
+		hipcub::DoubleBuffer<unsigned long long> dk((unsigned long long *)nullptr, (unsigned long long *)nullptr);
+		HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, dk, (int)cap_items, (int)cbits, (int)(cbits + 26), h->stream)); tb = std::max(tb, tb1);
+		hipcub::TransformInputIterator<unsigned long long, AcxWKeyOf, const unsigned long long *> kin((const unsigned long long *)nullptr, AcxWKeyOf());
+		hipcub::TransformInputIterator<uint16_t, AcxWLaneOf, const unsigned long long *> vin((const unsigned long long *)nullptr, AcxWLaneOf());
+		HIPCHK(hipcub::DeviceReduce::ReduceByKey(nullptr, tb1, kin, (unsigned long long *)nullptr, vin, (uint16_t *)nullptr, (uint32_t *)nullptr, BitOrU16(), (int)cap_items, h->stream)); tb = std::max(tb, tb1);
+		HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)nC, h->stream)); tb = std::max(tb, tb1);
+		ARC(tmp.reserve(tb + tb / 4 + 4096));
+	}
 	HIPCHK(hipStreamSynchronize(h->stream));
 	t_count = since();
-	// 4. slice after slice: offsets, tuples, sort over the slice's word bits, fold, records.  The record area's memory is mapped by a thread
-	// of its own, one slice's worth (its tuples: an upper bound of its records) while that slice is scanned and sorted -- mapping 216 GB in
-	// 1 GiB chunks takes seconds, which now lie beside the kernels; what was mapped beyond the records goes back at the end.
+	// 4. slice after slice: offsets, tuples, sort over the slice's word bits, fold, records.  The range's memory is mapped by a thread of
+	// its own -- the top for the slice's sort, the bottom for the records so far plus this slice's (at most its tuples) -- while the slice
+	// before is at work: mapping 230 GB in 1 GiB chunks takes seconds, which lie beside the kernels.
 	std::atomic<int> map_failed(0), stop(0);
-	std::atomic<size_t> mapped(0), map_target(0);
+	std::atomic<size_t> mapped_lo(0), mapped_top(0), want_lo(0), want_top(0);
 	std::thread mapper;
 	struct JoinMapper { std::thread &t; std::atomic<int> &stop; ~JoinMapper() { stop = 1; if (t.joinable()) t.join(); } } join_mapper{mapper, stop};
 	{
 		DBuf *rec = &h->acx_rec;
 		const int dev = h->device;
-		mapper = std::thread([rec, dev, &map_target, &map_failed, &stop, &mapped]() {
+		mapper = std::thread([rec, dev, &want_lo, &want_top, &mapped_lo, &mapped_top, &map_failed, &stop]() {
 			if (hipSetDevice(dev) != hipSuccess) { map_failed = 1; return; }
+			size_t top = 0;
 			while (!stop.load()) {
-				const size_t want = map_target.load();
-				if (want <= rec->cap) { std::this_thread::yield(); continue; }
-				if (rec->grow_to(want)) { map_failed = 1; return; }
-				mapped = rec->cap;
+				const size_t wt = want_top.load(), wl = want_lo.load();
+				if (wt > top) { if (rec->grow_top_to(wt)) { map_failed = 1; return; } top = (wt + DBuf::kChunk - 1) / DBuf::kChunk * DBuf::kChunk; mapped_top = top; }
+				else if (wl > rec->cap) { if (rec->grow_to(wl)) { map_failed = 1; return; } mapped_lo = rec->cap; }
+				else std::this_thread::yield();
 			}
 		});
 	}
+	char *const va_end = h->acx_rec.as<char>() + va_size;
 	double t_map = 0, t_scan = 0, t_fill = 0, t_wait = 0;
 	auto lap = [&](double &acc, const std::chrono::steady_clock::time_point &from) { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - from).count(); };
 	for (uint32_t s = 0; s < n_slices; ++s) {
 		const uint64_t n_items = slice_items[s];
 		if (!n_items) continue;
-		map_target = (size_t)(rec_n + n_items) * BHIP_REC_BYTES + 16;      // (the records so far are known, this slice's are at most its tuples)
+		want_top = buf_bytes(n_items);
+		want_lo = (size_t)(rec_n + n_items) * BHIP_REC_BYTES + 16;      // (the records so far are known, this slice's are at most its tuples)
+		if ((size_t)(rec_n + n_items) * BHIP_REC_BYTES + 16 + buf_bytes(n_items) > va_size) return fail(BHIP_E_INTERNAL, "accelerator build: slice %u does not fit its plan", s);
 		const auto tm0 = std::chrono::steady_clock::now();
-		k0.shrink_to(n_items * 8 + 16); k1.shrink_to(n_items * 8 + 16); v0.shrink_to(n_items * 2 + 16);
-		ARC(k0.grow_to(n_items * 8 + 16)); ARC(k1.grow_to(n_items * 8 + 16)); ARC(v0.grow_to(n_items * 2 + 16));
+		while (mapped_top.load() < buf_bytes(n_items) && !map_failed.load()) std::this_thread::yield();
 		lap(t_map, tm0);
+		if (map_failed.load()) return fail(BHIP_E_DEVICE, "accelerator build: the sort's part of the record area could not be mapped");
+		unsigned long long *const k0 = (unsigned long long *)(va_end - buf_bytes(n_items));
+		unsigned long long *const k1 = (unsigned long long *)((char *)k0 + ((size_t)(n_items * 8 + 16 + 255) & ~(size_t)255));
+		uint16_t *const v0 = (uint16_t *)((char *)k1 + ((size_t)(n_items * 8 + 16 + 255) & ~(size_t)255));
 		const uint64_t w0 = (uint64_t)cuts[s] << shift, w1 = (uint64_t)cuts[s + 1] << shift;
 		uint32_t wl = 1; while ((1ull << wl) < w1 - w0) ++wl;
 		const uint32_t *cnt_s = d_counts.as<uint32_t>() + (size_t)s * nC;
-		size_t tb = 0;
-		HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt_s, d_off.as<uint32_t>(), (int)nC, h->stream));
-		ARC(tmp.reserve(tb));
+		size_t tb = tmp.cap;
 		HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, cnt_s, d_off.as<uint32_t>(), (int)nC, h->stream));
 		hipLaunchKernelGGL(k_acx_wwrite, dim3(g), dim3(256), 0, h->stream, h->ref_lane.as<uint4>(), h->ref_off.as<uint64_t>(), h->clump_len.as<uint32_t>(), d_bad.as<uint8_t>(),
-			nC, h->tot_refs, K, z ? 1 : 0, (uint32_t)w0, (uint32_t)std::min<uint64_t>(w1, 0xFFFFFFFFull), cbits, d_off.as<uint32_t>(), k0.as<unsigned long long>());
+			nC, h->tot_refs, K, z ? 1 : 0, (uint32_t)w0, (uint32_t)std::min<uint64_t>(w1, 0xFFFFFFFFull), cbits, d_off.as<uint32_t>(), k0);
 		HIPCHK(hipGetLastError());
 		if (dbg) { const auto tc0 = std::chrono::steady_clock::now(); HIPCHK(hipStreamSynchronize(h->stream)); lap(t_scan, tc0); }      // (BHIP_DEBUG: the scan timed on its own)
 		const auto ts0 = std::chrono::steady_clock::now();
-		hipcub::DoubleBuffer<unsigned long long> dk(k0.as<unsigned long long>(), k1.as<unsigned long long>());
-		HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, dk, (int)n_items, (int)cbits, (int)(cbits + wl), h->stream));
-		ARC(tmp.reserve(tb));
+		hipcub::DoubleBuffer<unsigned long long> dk(k0, k1);
+		tb = tmp.cap;
 		HIPCHK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, dk, (int)n_items, (int)cbits, (int)(cbits + wl), h->stream));
 		unsigned long long *skeys = dk.Current(), *ukeys = dk.Alternate();
 		hipcub::TransformInputIterator<unsigned long long, AcxWKeyOf, const unsigned long long *> kin(skeys, AcxWKeyOf());
 		hipcub::TransformInputIterator<uint16_t, AcxWLaneOf, const unsigned long long *> vin(skeys, AcxWLaneOf());
-		size_t tb2 = 0;
-		HIPCHK(hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, kin, ukeys, vin, v0.as<uint16_t>(), nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
-		ARC(tmp.reserve(tb2));
-		HIPCHK(hipcub::DeviceReduce::ReduceByKey(tmp.p, tb2, kin, ukeys, vin, v0.as<uint16_t>(), nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
+		tb = tmp.cap;
+		HIPCHK(hipcub::DeviceReduce::ReduceByKey(tmp.p, tb, kin, ukeys, vin, v0, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
 		uint32_t n_unique = 0;
 		HIPCHK(hipMemcpyAsync(&n_unique, nruns.p, 4, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		if (dbg) t_sort += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
 		const auto tw0 = std::chrono::steady_clock::now();
-		while (mapped.load() < (rec_n + n_unique) * BHIP_REC_BYTES + 16 && !map_failed.load()) std::this_thread::yield();
+		while (mapped_lo.load() < (rec_n + n_unique) * BHIP_REC_BYTES + 16 && !map_failed.load()) std::this_thread::yield();
 		lap(t_wait, tw0);
 		if (map_failed.load()) return fail(BHIP_E_DEVICE, "accelerator build: the record area could not be mapped (%llu records so far)", (unsigned long long)rec_n);
 		const auto tf0 = std::chrono::steady_clock::now();
-		hipLaunchKernelGGL(k_acx_wfill, dim3(g), dim3(256), 0, h->stream, ukeys, v0.as<uint16_t>(), n_unique, (uint32_t)w0, cbits,
+		hipLaunchKernelGGL(k_acx_wfill, dim3(g), dim3(256), 0, h->stream, ukeys, v0, n_unique, (uint32_t)w0, cbits,
 			h->acx_rec.as<uint32_t>() + rec_n, d_lens.as<uint32_t>(), all_lanes);
 		HIPCHK(hipGetLastError());
 		rec_n += n_unique;
@@ -926,8 +956,8 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	}
 	stop = 1;
 	if (mapper.joinable()) mapper.join();
-	h->acx_rec.shrink_to(rec_n * BHIP_REC_BYTES + 16);
-	if (dbg) fprintf(stderr, "[bhip] word-sliced build, inside the slices: %.2f s scans, %.2f s sort + fold, %.2f s records, %.2f s mapping the sort buffers, %.2f s waiting for the record area\n", t_scan, t_sort, t_fill, t_map, t_wait);
+	// (nothing is unmapped here: the range is cut back to its final size when that is known -- behind the offset lines)
+	if (dbg) fprintf(stderr, "[bhip] word-sliced build, inside the slices: %.2f s scans, %.2f s sort + fold, %.2f s records, %.2f s waiting for the sort's part of the range, %.2f s for the records' part\n", t_scan, t_sort, t_fill, t_map, t_wait);
 	return 0;
 	};
 	int rc = local_part();
@@ -941,7 +971,7 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	} else if (rc) return rc;
 	const double t_own = since();
 	uint64_t tot = 0; uint32_t maxlen = 0;
-	rc = acx_lines_from_lens(h, d_lens.as<uint32_t>(), nw, &tot, &maxlen);
+	rc = acx_lines_from_lens(h, d_lens.as<uint32_t>(), nw, &tot, &maxlen, &lines_scratch);
 	const double t_lines = since() - t_own;
 	std::vector<unsigned long long> eoff((size_t)n_parts + 1, 0);      // first record of every rank's region
 	if (coop && !rc) {
@@ -976,6 +1006,8 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	if (rc) return rc;
 	d_lens.release();
 	if (!coop && tot != rec_n) return fail(BHIP_E_INTERNAL, "accelerator build: %llu records written, the list lengths add up to %llu", (unsigned long long)rec_n, (unsigned long long)tot);
+	ARC(h->acx_rec.grow_to(tot * BHIP_REC_BYTES + 16));
+	h->acx_rec.shrink_to(tot * BHIP_REC_BYTES + 16);      // (the sort's part of the range and what was mapped ahead of the records go back)
 	ARC(set_badlist(h, badlist.data(), (uint32_t)badlist.size()));
 	h->has_acx = true; h->n_ent = tot; h->has_masks = !all_lanes;
 	if (dbg) fprintf(stderr, "[bhip] accelerator built on the device by word ranges%s: K=%d, %llu entries from %llu word tuples, %u slice(s) of at most %llu tuples here (%llu records), %zu clump(s) on the BadList, %.2f B per entry; "
@@ -1221,7 +1253,7 @@ static int build_accelerator_by_clumps(Handle *h, int K, int z) {
 	h->has_acx = true; h->n_ent = tot; h->has_masks = !all_lanes;
 	if (dbg) fprintf(stderr, "[bhip] accelerator built on the device: K=%d, %llu entries from %llu word tuples in %u + %u slice(s), %zu clump(s) on the BadList, %.2f B per entry; %.2f s (%.2f s for the list lengths, %.2f s allocating the records and the second pass's buffers)\n",
 		K, (unsigned long long)tot, (unsigned long long)item_off[nC], n_slices_1, n_slices, badlist.size(), tot ? (double)(h->acx_rec.cap + n_lines * 64) / (double)tot : 0.0, since(), t_pass1, t_alloc);
-	if (dbg && rec_vmm) fprintf(stderr, "[bhip] record area: %zu chunks of 1 GiB mapped beside the first pass\n", h->acx_rec.chunks.size());
+	if (dbg && rec_vmm) fprintf(stderr, "[bhip] record area: %zu chunks of 1 GiB mapped beside the first pass\n", h->acx_rec.n_mapped);
 	return 0;
 }
 

@@ -88,15 +88,19 @@ int bhip_fail_msg(int code, const char *fmt, ...) __attribute__((format(printf, 
 
 // grow-only device buffer
 // (address-range reservations, mappings and unmappings of ALL handles of the process go one at a time: ranks that share a process -- one
-// thread each -- build their accelerators at the same moment, and concurrent hipMemMap / hipMemUnmap calls lost mappings: a region of
-// records read back as zeros in one run of six, tests/test_gpu_acx.py::test_cooperative_build_equals_the_single_rank_build)
+// thread each -- build their accelerators at the same moment)
 inline std::mutex &bhip_vmm_mutex() { static std::mutex m; return m; }
 struct DBuf {
 	void *p = nullptr; size_t cap = 0;
 	// growable variant (reserve_growable / grow_to): ONE address range whose physical memory is mapped chunk by chunk as the array
-	// grows (HIP virtual memory management) -- for the accelerator's record area, whose size is only known when it has been built
+	// grows (HIP virtual memory management) -- for the accelerator's record area, whose size is only known when it has been built.
+	// Chunks can also be mapped from the TOP of the range downwards (grow_top_to): the word-sliced accelerator build sorts in the part of
+	// the record area its records have not reached yet.  A chunk that has been unmapped is never mapped again while the range lives (an
+	// address that changed its memory under running ranks read back as zeros in one run of three: tests/test_gpu_acx.py, round 5) --
+	// shrink_to is for the END of a build.
 	bool vmm = false; size_t va_size = 0; int vmm_device = 0;
-	std::vector<hipMemGenericAllocationHandle_t> chunks;
+	std::vector<hipMemGenericAllocationHandle_t> chunks;      // one per chunk of the range, nullptr = not mapped
+	size_t n_mapped = 0;
 	static constexpr size_t kChunk = 1ull << 30;
 	int reserve(size_t bytes) {
 		if (bytes <= cap) return 0;
@@ -123,44 +127,61 @@ struct DBuf {
 		if (hipDeviceGetAttribute(&ok, hipDeviceAttributeVirtualMemoryManagementSupported, device) != hipSuccess || !ok) { (void)hipGetLastError(); return 1; }
 		const size_t sz = ((max_bytes + kChunk - 1) / kChunk + 1) * kChunk;
 		if (hipMemAddressReserve(&p, sz, kChunk, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return 1; }
-		vmm = true; va_size = sz; vmm_device = device; cap = 0;
+		vmm = true; va_size = sz; vmm_device = device; cap = 0; n_mapped = 0;
+		chunks.assign(sz / kChunk, nullptr);
+		return 0;
+	}
+	// memory behind the chunks [c0, c1) that have none yet
+	int map_chunks(size_t c0, size_t c1) {
+		if (!vmm) return fail(BHIP_E_INTERNAL, "map_chunks on a fixed buffer");
+		if (c1 > chunks.size()) return fail(BHIP_E_DEVICE, "record area: chunk %zu wanted, %zu reserved", c1, chunks.size());
+		hipMemAllocationProp prop = {};
+		prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = vmm_device;
+		hipMemAccessDesc acc = {};
+		acc.location.type = hipMemLocationTypeDevice; acc.location.id = vmm_device; acc.flags = hipMemAccessFlagsProtReadWrite;
+		for (size_t c = c0; c < c1; ++c) {
+			if (chunks[c]) continue;
+			std::lock_guard<std::mutex> lk(bhip_vmm_mutex());
+			hipMemGenericAllocationHandle_t hnd;
+			hipError_t e = hipMemCreate(&hnd, kChunk, &prop, 0);
+			if (e != hipSuccess) return fail(BHIP_E_DEVICE, "hipMemCreate(%zu) with %zu chunks mapped: %s", kChunk, n_mapped, hipGetErrorString(e));
+			e = hipMemMap((char *)p + c * kChunk, kChunk, 0, hnd, 0);
+			if (e == hipSuccess) e = hipMemSetAccess((char *)p + c * kChunk, kChunk, &acc, 1);
+			if (e != hipSuccess) { (void)hipMemRelease(hnd); return fail(BHIP_E_DEVICE, "hipMemMap with %zu chunks mapped: %s", n_mapped, hipGetErrorString(e)); }
+			chunks[c] = hnd; ++n_mapped;
+		}
+		size_t pre = cap / kChunk;
+		while (pre < chunks.size() && chunks[pre]) ++pre;
+		cap = pre * kChunk;      // (the mapped prefix: what the array may use)
 		return 0;
 	}
 	int grow_to(size_t bytes) {
 		if (!vmm) return fail(BHIP_E_INTERNAL, "grow_to on a fixed buffer");
 		if (bytes > va_size) return fail(BHIP_E_DEVICE, "record area: %zu bytes wanted, %zu reserved", bytes, va_size);
-		hipMemAllocationProp prop = {};
-		prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = vmm_device;
-		hipMemAccessDesc acc = {};
-		acc.location.type = hipMemLocationTypeDevice; acc.location.id = vmm_device; acc.flags = hipMemAccessFlagsProtReadWrite;
-		while (cap < bytes) {
-			std::lock_guard<std::mutex> lk(bhip_vmm_mutex());
-			hipMemGenericAllocationHandle_t hnd;
-			hipError_t e = hipMemCreate(&hnd, kChunk, &prop, 0);
-			if (e != hipSuccess) return fail(BHIP_E_DEVICE, "hipMemCreate(%zu) at %zu mapped bytes: %s", kChunk, cap, hipGetErrorString(e));
-			e = hipMemMap((char *)p + cap, kChunk, 0, hnd, 0);
-			if (e == hipSuccess) e = hipMemSetAccess((char *)p + cap, kChunk, &acc, 1);
-			if (e != hipSuccess) { (void)hipMemRelease(hnd); return fail(BHIP_E_DEVICE, "hipMemMap at %zu mapped bytes: %s", cap, hipGetErrorString(e)); }
-			chunks.push_back(hnd);
-			cap += kChunk;
-		}
-		return 0;
+		return map_chunks(0, (bytes + kChunk - 1) / kChunk);
 	}
-	// give back the chunks beyond `bytes` (the array was mapped ahead of knowing its size)
+	// the last `bytes` of the range
+	int grow_top_to(size_t bytes) {
+		if (!vmm) return fail(BHIP_E_INTERNAL, "grow_top_to on a fixed buffer");
+		if (bytes > va_size) return fail(BHIP_E_DEVICE, "record area: %zu bytes wanted at its top, %zu reserved", bytes, va_size);
+		return map_chunks(chunks.size() - (bytes + kChunk - 1) / kChunk, chunks.size());
+	}
+	// give back every chunk beyond `bytes` (the array was mapped ahead of knowing its size)
 	void shrink_to(size_t bytes) {
 		if (!vmm) return;
 		const size_t keep = (bytes + kChunk - 1) / kChunk;
 		std::lock_guard<std::mutex> lk(bhip_vmm_mutex());
-		while (chunks.size() > keep) {
-			(void)hipMemUnmap((char *)p + (chunks.size() - 1) * kChunk, kChunk); (void)hipMemRelease(chunks.back());
-			chunks.pop_back(); cap -= kChunk;
+		for (size_t c = keep; c < chunks.size(); ++c) if (chunks[c]) {
+			(void)hipMemUnmap((char *)p + c * kChunk, kChunk); (void)hipMemRelease(chunks[c]);
+			chunks[c] = nullptr; --n_mapped;
 		}
+		if (cap > keep * kChunk) cap = keep * kChunk;
 	}
 	void release() {
 		if (vmm) {
 			std::lock_guard<std::mutex> lk(bhip_vmm_mutex());
-			for (size_t i = 0; i < chunks.size(); ++i) { (void)hipMemUnmap((char *)p + i * kChunk, kChunk); (void)hipMemRelease(chunks[i]); }
-			chunks.clear();
+			for (size_t c = 0; c < chunks.size(); ++c) if (chunks[c]) { (void)hipMemUnmap((char *)p + c * kChunk, kChunk); (void)hipMemRelease(chunks[c]); }
+			chunks.clear(); n_mapped = 0;
 			if (p) (void)hipMemAddressFree(p, va_size);
 			vmm = false; va_size = 0;
 		} else if (p) (void)hipFree(p);
