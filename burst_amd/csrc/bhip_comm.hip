@@ -350,6 +350,20 @@ extern "C" int bhip_team_share(void *team, void *device_base, const uint64_t *by
 		}
 		ok = ok && hipStreamSynchronize(st) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
 		if (st) (void)hipStreamDestroy(st);
+		if (!ok) {      // the peers' memory is not reachable device to device here: the same regions through host memory, 256 MiB at a time
+			(void)hipGetLastError();
+			const size_t kHop = (size_t)256 << 20;
+			void *hop = nullptr;
+			ok = hipHostMalloc(&hop, kHop, hipHostMallocDefault) == hipSuccess;
+			for (int k = 0; k < n_parts && ok; ++k) {
+				if (k == part) continue;
+				for (uint64_t a = byte_off[k]; a < byte_off[k + 1] && ok; a += kHop) {
+					const size_t n = (size_t)std::min<uint64_t>(kHop, byte_off[k + 1] - a);
+					ok = hipMemcpy(hop, (const char *)T->base[(size_t)k] + a, n, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy((char *)device_base + a, hop, n, hipMemcpyHostToDevice) == hipSuccess;
+				}
+			}
+			if (hop) (void)hipHostFree(hop);
+		}
 		if (!ok) { bhip_fail_msg(BHIP_E_DEVICE, "region exchange (peer copies) failed on rank %d: %s", part, hipGetErrorString(hipGetLastError())); T->failed[(size_t)part] = 1; }
 	}
 	pthread_barrier_wait(&T->bar);      // nobody touches its array while a peer still reads it

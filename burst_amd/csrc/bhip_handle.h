@@ -129,8 +129,15 @@ struct DBuf {
 		if (hipMemAddressReserve(&p, sz, kChunk, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return 1; }
 		vmm = true; va_size = sz; vmm_device = device; cap = 0; n_mapped = 0;
 		chunks.assign(sz / kChunk, nullptr);
+		// (devices that can read this device's memory over xGMI get access to the range as well: the peers of a cooperative accelerator
+		// build copy regions out of it, bhip_team_share)
+		peers.clear();
+		int n_dev = 0;
+		if (hipGetDeviceCount(&n_dev) == hipSuccess) for (int d = 0; d < n_dev; ++d) { int can = 0; if (d != device && hipDeviceCanAccessPeer(&can, d, device) == hipSuccess && can) peers.push_back(d); }
+		(void)hipGetLastError();
 		return 0;
 	}
+	std::vector<int> peers;
 	// memory behind the chunks [c0, c1) that have none yet
 	int map_chunks(size_t c0, size_t c1) {
 		if (!vmm) return fail(BHIP_E_INTERNAL, "map_chunks on a fixed buffer");
@@ -146,7 +153,12 @@ struct DBuf {
 			hipError_t e = hipMemCreate(&hnd, kChunk, &prop, 0);
 			if (e != hipSuccess) return fail(BHIP_E_DEVICE, "hipMemCreate(%zu) with %zu chunks mapped: %s", kChunk, n_mapped, hipGetErrorString(e));
 			e = hipMemMap((char *)p + c * kChunk, kChunk, 0, hnd, 0);
-			if (e == hipSuccess) e = hipMemSetAccess((char *)p + c * kChunk, kChunk, &acc, 1);
+			if (e == hipSuccess && !peers.empty()) {
+				std::vector<hipMemAccessDesc> all(1 + peers.size(), acc);
+				for (size_t k = 0; k < peers.size(); ++k) all[1 + k].location.id = peers[k];
+				if (hipMemSetAccess((char *)p + c * kChunk, kChunk, all.data(), all.size()) != hipSuccess) { (void)hipGetLastError(); peers.clear(); }      // (own device only, then)
+			}
+			if (e == hipSuccess && peers.empty()) e = hipMemSetAccess((char *)p + c * kChunk, kChunk, &acc, 1);
 			if (e != hipSuccess) { (void)hipMemRelease(hnd); return fail(BHIP_E_DEVICE, "hipMemMap with %zu chunks mapped: %s", n_mapped, hipGetErrorString(e)); }
 			chunks[c] = hnd; ++n_mapped;
 		}
