@@ -898,9 +898,10 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 			size_t top = 0;
 			while (!stop.load()) {
 				const size_t wt = want_top.load(), wl = want_lo.load();
-				if (wt > top) { if (rec->grow_top_to(wt)) { map_failed = 1; return; } top = (wt + DBuf::kChunk - 1) / DBuf::kChunk * DBuf::kChunk; mapped_top = top; }
-				else if (wl > rec->cap) { if (rec->grow_to(wl)) { map_failed = 1; return; } mapped_lo = rec->cap; }
+				if (wt > top) { if (rec->grow_top_to(wt)) { map_failed = 1; return; } top = (wt + DBuf::kChunk - 1) / DBuf::kChunk * DBuf::kChunk; }
+				else if (wl > rec->cap) { if (rec->grow_to(wl)) { map_failed = 1; return; } }
 				else std::this_thread::yield();
+				mapped_top = top; mapped_lo = rec->cap;      // (both, every time: in a small range the top's chunks ARE the records' -- the prefix grows without grow_to)
 			}
 		});
 	}
