@@ -8,7 +8,7 @@ sequences x 2 variants at 5 % divergence = 3.2 M references, 4.5 Gbp: every 15-m
 collision-dominated RefSeq-scale DB15 would have many more), its accelerator BUILT ON THE DEVICE from the .edx (no .acx is read
 or uploaded).  The database is as large as the box holds (--db-scale auto: the metric's own 31.5 GB .edx = 11.37 units on a 288 GB device in a
 300 GB container, with the compiled reference run on it beside the device path); `config.extrapolation.measured_sizes` carries the bench line
-measured on the small database of rounds 1-3 and at the metric's own size (profiles/r05_sizes.json).
+measured at three database sizes up to the metric's own (profiles/r05_sizes.json).
 
 A step = one batch of reads through the WHOLE device path as the product runs it: bench.py calls the C batch scheduler of
 the `burst_hip` command line (bh_align_ranges, burst_amd/csrc/host/bh_align.c) -- each step's batch is staged afresh from
