@@ -472,8 +472,15 @@ def end_to_end(edx, reads_fa, args, device):
     import re
     out = reads_fa + ".e2e.b6"
     cmd = [os.path.join(ROOT, "burst_amd", "burst_hip"), "-r", edx, "-ad", "-k", str(args.K), "-q", reads_fa, "-o", out, "-m", args.mode, "-i", str(args.id), "--device", str(device)] + (["-fr"] if args.fr else [])
-    best = None
-    for _ in range(2):      # the second run has the files in the page cache, as the bench's own inputs are
+    best, first = None, None
+    # Two runs.  The first follows whatever held the device a moment ago (this process's own handle: 255 GB at the metric's size) and pays for
+    # it -- the memory of the process before is not back at once, its first large allocations wait seconds; the second
+    # starts after a pause on a quiet device with the files in the page cache, as the bench's own inputs are: that one is reported, the
+    # first beside it as `right_behind_another_process_s`.
+    settle = 20.0 if os.path.getsize(edx) > 8e9 else 0.0
+    for it in range(2):
+        if it and settle:
+            time.sleep(settle)
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         m = re.search(r"Alignment time: ([\d.]+) seconds", r.stdout)
         if r.returncode != 0 or not m:
@@ -481,7 +488,11 @@ def end_to_end(edx, reads_fa, args, device):
         n = int(re.search(r"Parsed (\d+) queries", r.stdout).group(1))
         best = {"reads": n, "seconds": float(m.group(1)), "reads_per_s": n / float(m.group(1)), "lines": int(re.search(r"Wrote (\d+) alignments", r.stdout).group(1)),
                 "phases_s": {k.strip(): float(v) for k, v in re.findall(r"\[([a-z ,()+.]+?)\s+([\d.]+) s", r.stdout)},
-                "command": "burst_hip -r DB.edx -ad -k %d -q <%d reads> -o out.b6 -m %s -i %s (second of two runs)" % (args.K, n, args.mode, args.id)}
+                "command": "burst_hip -r DB.edx -ad -k %d -q <%d reads> -o out.b6 -m %s -i %s (second of two runs%s)" % (args.K, n, args.mode, args.id, ", %.0f s after the first" % settle if settle else "")}
+        if it == 0:
+            first = best["seconds"]
+    if best is not None:
+        best["right_behind_another_process_s"] = first
     try:
         os.remove(out)
     except OSError:
