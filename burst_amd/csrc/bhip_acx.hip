@@ -528,11 +528,13 @@ __global__ void k_acx_rec_export(const uint32_t *__restrict__ rec, unsigned long
 // holds EVERY tuple of the words [w0, w1): sorted and folded once, its unique tuples ARE the records of those words, in place
 // and in order -- no second pass, no cursor per word, and:
 //  * the tuples of a slice are written in ascending clump order (a per-clump offset from one counting scan over the database), so
-//    the stable radix sort only has to order the word bits of the slice -- 24 bits, three passes, instead of 48 bits in six;
-//  * what a slice costs instead is one more scan over the references (33 GB, ~20 ms) to pick out its words.
-// The record area is one address range that grows by mapped chunks (DBuf::reserve_growable): its size is known when it is full.
-// Returns 1 (nothing changed) when this box cannot do it -- no virtual memory management, one bucket of words with more tuples than
-// a sort takes, not enough room -- and the clump-sliced builder takes over.
+//    the stable radix sort only has to order the word bits of the slice -- at most 26 bits, four passes, instead of 48 bits in six;
+//  * what a slice costs instead is one more scan over the references (33 GB at the metric's size: 36 ms) to pick out its words.
+// The record area is one address range (DBuf::reserve_growable) whose memory is mapped as the records come -- its size is known when
+// it is full -- and the sort of a slice works at the range's top, in the part the records have not reached yet (below).
+// The default builder since the end of round 5: 3.1 s at the metric's size.  Returns 1 (nothing changed) when this box cannot do it
+// -- no virtual memory management, more than 2^24 clumps, a bucket of words with more tuples than a sort takes, not enough room --
+// and the clump-sliced builder takes over.
 // ------------------------------------------------------------------------------------------------
 // every word of one reference lane: emit(word) for each window of K symbols A/C/G/T, and for each IUPAC expansion of an ambiguous one
 // (the order of the calls is not the order of the positions' -- nobody needs it).
