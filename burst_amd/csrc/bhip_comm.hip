@@ -22,6 +22,8 @@
 #include <algorithm>
 #include <vector>
 #include "burst_hip.h"
+#include <atomic>
+std::atomic<int> &bhip_vmm_peer_access_flag();
 
 int bhip_fail_msg(int code, const char *fmt, ...);      // bhip_init.hip: sets the calling thread's error text
 
@@ -321,6 +323,7 @@ extern "C" int bhip_team_create(int n_ranks, void **team) {
 	Team *T = new Team();
 	T->n = n_ranks; T->base.assign((size_t)n_ranks, nullptr); T->dev.assign((size_t)n_ranks, 0); T->status.assign((size_t)n_ranks, 0); T->failed.assign((size_t)n_ranks, 0);
 	if (pthread_barrier_init(&T->bar, nullptr, (unsigned)n_ranks)) { delete T; return bhip_fail_msg(BHIP_E_INTERNAL, "no barrier for %d ranks", n_ranks); }
+	if (n_ranks > 1) bhip_vmm_peer_access_flag() = 1;      // (record areas reserved from here on are readable by the peer devices)
 	*team = T;
 	return BHIP_OK;
 }

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <vector>
 #include <mutex>
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include "burst_hip.h"
@@ -90,6 +91,9 @@ int bhip_fail_msg(int code, const char *fmt, ...) __attribute__((format(printf, 
 // (address-range reservations, mappings and unmappings of ALL handles of the process go one at a time: ranks that share a process -- one
 // thread each -- build their accelerators at the same moment)
 inline std::mutex &bhip_vmm_mutex() { static std::mutex m; return m; }
+// (set by bhip_team_create: the ranks are threads of THIS process on several devices and will copy regions out of each other's record
+// areas -- only then are a range's chunks made accessible to the peer devices; a process with one rank never touches the other devices)
+inline std::atomic<int> &bhip_vmm_peer_access() { static std::atomic<int> f(0); return f; }
 struct DBuf {
 	void *p = nullptr; size_t cap = 0;
 	// growable variant (reserve_growable / grow_to): ONE address range whose physical memory is mapped chunk by chunk as the array
@@ -133,7 +137,7 @@ struct DBuf {
 		// build copy regions out of it, bhip_team_share)
 		peers.clear();
 		int n_dev = 0;
-		if (hipGetDeviceCount(&n_dev) == hipSuccess) for (int d = 0; d < n_dev; ++d) { int can = 0; if (d != device && hipDeviceCanAccessPeer(&can, d, device) == hipSuccess && can) peers.push_back(d); }
+		if (bhip_vmm_peer_access().load() && hipGetDeviceCount(&n_dev) == hipSuccess) for (int d = 0; d < n_dev; ++d) { int can = 0; if (d != device && hipDeviceCanAccessPeer(&can, d, device) == hipSuccess && can) peers.push_back(d); }
 		(void)hipGetLastError();
 		return 0;
 	}

@@ -20,6 +20,7 @@ int bhip_fail_msg(int code, const char *fmt, ...) {
 
 extern "C" const char *bhip_last_error(void) { return g_err; }
 extern "C" int bhip_abi_version(void) { return BHIP_ABI_VERSION; }
+std::atomic<int> &bhip_vmm_peer_access_flag() { return bhip_vmm_peer_access(); }      // (for bhip_comm.hip, which does not see the handle's header)
 
 static void lane_destroy(Lane *L) {
 	if (!L) return;
