@@ -431,3 +431,15 @@ def test_xalphabet_matches_the_reference(exe, tmp_path, alphabet, mode):
     subprocess.check_call([exe, rf, qf, out_mine, mode, "0.93", "0", "1", "-1", "1", "", "0", "0", "10"], env=dict(os.environ, BURST_XALPHA="1"))
     a, b = sorted(open(out_ref, "rb").read().splitlines()), sorted(open(out_mine, "rb").read().splitlines())
     assert len(a) > 100 and a == b
+
+
+def test_accelerator_window_walk_eight_symbols_at_a_time(tmp_path):
+    """burst_amd/csrc/bhip_acx_words.h (acx_lane_words: the scans of the device's accelerator builders) on the host: where a dword of
+    symbols is all A/C/G/T with K - 1 such symbols in front, the eight windows are shifts of one register of packed 2-bit codes; anywhere
+    else the symbol-by-symbol walk of make_accelerator (burst.c:3343-3377) with IUPAC expansion.  Same multiset of words as that walk
+    alone on random lanes -- ambiguity codes at 0 / 0.4 / 3 / 20 %, padding inside and junk behind the lane, K = 4 .. 15, both N rules."""
+    exe = str(tmp_path / "acx_words_host")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "burst_amd", "csrc"), os.path.join(ROOT, "tests", "csrc", "acx_words_host.cpp"), "-o", exe])
+    for seed in (5, 11):
+        r = subprocess.run([exe, "12000", str(seed)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
