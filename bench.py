@@ -876,8 +876,11 @@ def main():
         e4, n4, _ = timed(job_share(args.warmup, args.steps), rs2)
         al = torch.tensor([float(rs2.mr.secSearch)], dtype=torch.float64, device=pdev)
         dist.all_reduce(al, op=dist.ReduceOp.MAX)
+        gp = int(rs2.mr.gatherPath)      # which gather this rank's records really took (BhMultiRank.gatherPath, set by bh_search_multi_ex)
         out = {"rccl_ranks": world, "value": total_reads / e4, "unit": "reads/s", "seconds": e4, "records": n4, "rccl_gather_ms": max(0.0, e4 - float(al.item())) * 1e3,
-               "records_from": "device (every batch's records staged into the send buffer while resident: bhip_comm_stage_device)",
+               "records_from": ("device (every batch's records staged into the send buffer while resident: bhip_comm_stage_device -> bhip_comm_gather_staged)" if gp == 1 else
+                                "host (the staged gather was refused, the host copy went up again: bhip_comm_gather_hits)" if gp == 2 else "no collective ran (gatherPath 0)"),
+               "gather_path": gp,
                "what": "the main job with the records gathered to rank 0 by bhip_comm_gather_staged (ncclAllGather of the counts + grouped ncclSend/ncclRecv over xGMI from the ranks' device-resident "
                        "records, one copy to rank 0's host) inside the timed region instead of the shared-memory hand-over; rccl_gather_ms = that time minus the slowest rank's align phase"}
         rs2.close()

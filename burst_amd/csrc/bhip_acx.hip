@@ -775,7 +775,7 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 		}
 		return (uint32_t)cuts.size() - 1;
 	};
-	const uint32_t max_slices = coop ? BHIP_ACX_MAX_SLICES - 1u : BHIP_ACX_MAX_SLICES;      // (slice number 0xFF marks another rank's buckets)
+	const uint32_t max_slices = BHIP_ACX_MAX_SLICES - 1u;      // (slice number 0xFF marks "not this build's bucket" in the one-byte bucket -> slice table, in every mode)
 	if (own1 > own0 && total_own) {
 		n_slices = forced_slice > 0 ? plan(std::max<uint64_t>((uint64_t)forced_slice, biggest)) : plan_by_room();
 		if (!n_slices || n_slices > max_slices || cap_items >= 2147483000ull) return 1;
@@ -815,17 +815,20 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	std::atomic<int> map_failed(0), stop(0);
 	std::atomic<size_t> mapped_lo(0), mapped_top(0), want_lo(0), want_top(0);
 	std::thread mapper;
+	char map_err[400] = "";      // the mapper thread's own error text (hipMemCreate / hipMemMap ...), written before map_failed is set
 	struct JoinMapper { std::thread &t; std::atomic<int> &stop; ~JoinMapper() { stop = 1; if (t.joinable()) t.join(); } } join_mapper{mapper, stop};
 	{
 		DBuf *rec = &h->acx_rec;
 		const int dev = h->device;
-		mapper = std::thread([rec, dev, &want_lo, &want_top, &mapped_lo, &mapped_top, &map_failed, &stop]() {
-			if (hipSetDevice(dev) != hipSuccess) { map_failed = 1; return; }
+		char *const merr = map_err;
+		mapper = std::thread([rec, dev, merr, &want_lo, &want_top, &mapped_lo, &mapped_top, &map_failed, &stop]() {
+			auto give_up = [&](const char *what) { snprintf(merr, 400, "%s: %s", what, bhip_last_error()); (void)hipGetLastError(); map_failed = 1; };
+			if (hipSetDevice(dev) != hipSuccess) { give_up("hipSetDevice in the mapping thread"); return; }
 			size_t top = 0;
 			while (!stop.load()) {
 				const size_t wt = want_top.load(), wl = want_lo.load();
-				if (wt > top) { if (rec->grow_top_to(wt)) { map_failed = 1; return; } top = (wt + DBuf::kChunk - 1) / DBuf::kChunk * DBuf::kChunk; }
-				else if (wl > rec->cap) { if (rec->grow_to(wl)) { map_failed = 1; return; } }
+				if (wt > top) { if (rec->grow_top_to(wt)) { give_up("mapping the top of the range"); return; } top = (wt + DBuf::kChunk - 1) / DBuf::kChunk * DBuf::kChunk; }
+				else if (wl > rec->cap) { if (rec->grow_to(wl)) { give_up("mapping the records' part of the range"); return; } }
 				else std::this_thread::yield();
 				mapped_top = top; mapped_lo = rec->cap;      // (both, every time: in a small range the top's chunks ARE the records' -- the prefix grows without grow_to)
 			}
@@ -843,7 +846,7 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 		const auto tm0 = std::chrono::steady_clock::now();
 		while (mapped_top.load() < buf_bytes(n_items) && !map_failed.load()) std::this_thread::yield();
 		lap(t_map, tm0);
-		if (map_failed.load()) return fail(BHIP_E_DEVICE, "accelerator build: the sort's part of the record area could not be mapped");
+		if (map_failed.load()) return fail(BHIP_E_DEVICE, "accelerator build: the sort's part of the record area could not be mapped (%s)", map_err);
 		unsigned long long *const k0 = (unsigned long long *)(va_end - buf_bytes(n_items));
 		unsigned long long *const k1 = (unsigned long long *)((char *)k0 + ((size_t)(n_items * 8 + 16 + 255) & ~(size_t)255));
 		uint16_t *const v0 = (uint16_t *)((char *)k1 + ((size_t)(n_items * 8 + 16 + 255) & ~(size_t)255));
@@ -865,14 +868,19 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 		hipcub::TransformInputIterator<uint16_t, AcxWLaneOf, const unsigned long long *> vin(skeys, AcxWLaneOf());
 		tb = tmp.cap;
 		HIPCHK(hipcub::DeviceReduce::ReduceByKey(tmp.p, tb, kin, ukeys, vin, v0, nruns.as<uint32_t>(), BitOrU16(), (int)n_items, h->stream));
-		uint32_t n_unique = 0;
+		uint32_t n_unique = 0, last_off = 0, last_cnt = 0;
 		HIPCHK(hipMemcpyAsync(&n_unique, nruns.p, 4, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(&last_off, d_off.as<uint32_t>() + (nC - 1), 4, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(&last_cnt, cnt_s + (nC - 1), 4, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
+		// (the tuples the counting scan attributed to this slice are the tuples the plan sized its buffers for: anything else means
+		// the write pass and the sort did not see the same data -- stop before the records are stored)
+		if ((uint64_t)last_off + last_cnt != n_items) return fail(BHIP_E_INTERNAL, "accelerator build: slice %u holds %llu tuples, its plan says %llu", s, (unsigned long long)last_off + last_cnt, (unsigned long long)n_items);
 		if (dbg) t_sort += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
 		const auto tw0 = std::chrono::steady_clock::now();
 		while (mapped_lo.load() < (rec_n + n_unique) * BHIP_REC_BYTES + 16 && !map_failed.load()) std::this_thread::yield();
 		lap(t_wait, tw0);
-		if (map_failed.load()) return fail(BHIP_E_DEVICE, "accelerator build: the record area could not be mapped (%llu records so far)", (unsigned long long)rec_n);
+		if (map_failed.load()) return fail(BHIP_E_DEVICE, "accelerator build: the record area could not be mapped (%llu records so far; %s)", (unsigned long long)rec_n, map_err);
 		const auto tf0 = std::chrono::steady_clock::now();
 		hipLaunchKernelGGL(k_acx_wfill, dim3(g), dim3(256), 0, h->stream, ukeys, v0, n_unique, (uint32_t)w0, cbits,
 			h->acx_rec.as<uint32_t>() + rec_n, d_lens.as<uint32_t>(), all_lanes);

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void k_hit_fix(BhipHit *__restrict__ out, cons
 				if (lane < n) r = grp[lane];
 				const uint32_t key = lane < n ? r.w[1] : 0xFFFFFFFFu;          // refIx
 				uint32_t rank = 0;
-				for (uint32_t j = 0; j < n; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)key, (int)j) < key ? 1u : 0u;
+				// (stable: equal keys -- which the (query, reference) uniqueness of the records rules out -- would keep their order instead of colliding)
+				for (uint32_t j = 0; j < n; ++j) { const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)j); rank += (kj < key || (kj == key && j < lane)) ? 1u : 0u; }
 				if (lane < n) grp[rank] = r;                                   // (every lane's load is complete before the first store: the rank depends on all keys)
 			} else if ((uint64_t)o + n <= scratch_cap) {
 				Rec *tmp = (Rec *)(scratch + o);
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void k_hit_fix(BhipHit *__restrict__ out, cons
 					for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
 						const uint32_t kj = j0 + lane < n ? tmp[j0 + lane].w[1] : 0xFFFFFFFFu;
 						const uint32_t m = n - j0 < 64u ? n - j0 : 64u;
-						for (uint32_t j = 0; j < m; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)kj, (int)j) < key ? 1u : 0u;
+						for (uint32_t j = 0; j < m; ++j) { const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)kj, (int)j); rank += (kk < key || (kk == key && j0 + j < i)) ? 1u : 0u; }
 					}
 					if (i < n) grp[rank] = r;
 				}
@@ -1151,7 +1152,8 @@ extern "C" int bhip_copy_hits_device(void *handle, void *dst_device, uint64_t ca
 	if (!h || !n_records) return fail(BHIP_E_ARG, "null argument");
 	*n_records = h->last_n_out;
 	if (!h->last_n_out) return BHIP_OK;
-	if (!dst_device) return fail(BHIP_E_ARG, "null destination");
+	// (a count query -- no destination, no room -- is answered like any buffer that is too small: BHIP_E_CAPACITY with *n_records set)
+	if (!dst_device && cap_records) return fail(BHIP_E_ARG, "null destination");
 	if (h->last_n_out > cap_records) return fail(BHIP_E_CAPACITY, "device buffer holds %llu records, %llu needed", (unsigned long long)cap_records, (unsigned long long)h->last_n_out);
 	HIPCHK(hipSetDevice(h->device));
 	HIPCHK(hipMemcpyAsync(dst_device, (h->last_out ? h->out_sorted2 : h->out_sorted).p, (size_t)h->last_n_out * sizeof(BhipHit), hipMemcpyDeviceToDevice, h->stream));

@@ -323,11 +323,17 @@ extern "C" int bhip_team_create(int n_ranks, void **team) {
 	Team *T = new Team();
 	T->n = n_ranks; T->base.assign((size_t)n_ranks, nullptr); T->dev.assign((size_t)n_ranks, 0); T->status.assign((size_t)n_ranks, 0); T->failed.assign((size_t)n_ranks, 0);
 	if (pthread_barrier_init(&T->bar, nullptr, (unsigned)n_ranks)) { delete T; return bhip_fail_msg(BHIP_E_INTERNAL, "no barrier for %d ranks", n_ranks); }
-	if (n_ranks > 1) bhip_vmm_peer_access_flag() = 1;      // (record areas reserved from here on are readable by the peer devices)
+	if (n_ranks > 1) bhip_vmm_peer_access_flag().fetch_add(1);      // (record areas reserved while a team of several ranks exists are readable by the peer devices)
 	*team = T;
 	return BHIP_OK;
 }
-extern "C" void bhip_team_destroy(void *team) { Team *T = (Team *)team; if (!T) return; pthread_barrier_destroy(&T->bar); delete T; }
+extern "C" void bhip_team_destroy(void *team) {
+	Team *T = (Team *)team;
+	if (!T) return;
+	if (T->n > 1) bhip_vmm_peer_access_flag().fetch_sub(1);      // (the last team gone: a process with one rank touches no other device again)
+	pthread_barrier_destroy(&T->bar);
+	delete T;
+}
 extern "C" int bhip_team_share(void *team, void *device_base, const uint64_t *byte_off, int part, int n_parts, int status) {
 	Team *T = (Team *)team;
 	if (!T || !byte_off || T->n != n_parts || part < 0 || part >= n_parts) return bhip_fail_msg(BHIP_E_ARG, "bad arguments of the region exchange");

@@ -193,6 +193,7 @@ int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhN
 	if (node) { int b = bh_node_begin(node); if (b) return b; bh_node_attach(node, &R[0].run); }
 	int rcs[BH_MAX_RANKS]; char errs[BH_MAX_RANKS][512];
 	uint8_t *best[BH_MAX_RANKS];
+	for (int i = 0; i < n_local; ++i) R[i].gatherPath = 0;
 	for (int i = 0; i < n_local; ++i) { rcs[i] = BH_E_INTERNAL; snprintf(errs[i], sizeof errs[i], "rank %d never ran (OpenMP gave the team fewer than %d threads)", R[i].rank, n_local); best[i] = NULL; }
 	const int reduce = shard_db > 1 && mode != BH_FORAGE && mode != BH_ANY && n_ranks > 1;
 	/* the per-query minima tables are taken NOW: a rank that found no memory for its table after the search would stay out of a
@@ -303,6 +304,7 @@ int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhN
 			/* the records were staged on the device batch by batch (stage_batch_cb): sent from there; otherwise the host copy goes up again */
 			int g = staged_ok[i] ? bhip_comm_gather_staged(comm, R[i].rank, rcs[i] ? 0 : R[i].run.nHits, i == i0 ? all->hits : NULL, i == i0 ? all->capHits : 0, &n_total, i == i0 ? counts : NULL) : 1;
 			/* (a rank that could not stage -- device memory -- says so with its count: the call fails on every rank, and every rank comes here) */
+			R[i].gatherPath = (!g || g == BHIP_E_CAPACITY) ? 1 : 2;
 			if (g && g != BHIP_E_CAPACITY) g = bhip_comm_gather_hits(comm, R[i].rank, rcs[i] ? NULL : R[i].run.hits, rcs[i] ? 0 : R[i].run.nHits, i == i0 ? all->hits : NULL,
 			                                    i == i0 ? all->capHits : 0, &n_total, i == i0 ? counts : NULL);
 			if (i == i0) need = n_total;

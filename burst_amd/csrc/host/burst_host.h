@@ -157,6 +157,8 @@ typedef struct BhMultiRank {
 	uint32_t c0;                  /* database-sharded: first clump of its slice (added to the records' reference numbers) */
 	BhRun run;                    /* its own records (the page-locked buffer is reused between calls) */
 	double secSearch;             /* out: wall time of this rank's align phase (before the minima / the gather) */
+	int gatherPath;               /* out: how this rank's records reached rank 0 -- 0 no collective (host memory), 1 RCCL gather fed from the device
+	                               * (bhip_comm_gather_staged), 2 RCCL gather of the host copy uploaded again (bhip_comm_gather_hits) */
 	/* Optional back ends (NULL = the device path).  `align`: in place of the device scheduler bh_align_ranges_reuse(hh, ...) -- it
 	 * fills `run` (bh_run_put) with the records of the ranges, q = entry index, sorted by (q, refIx); the CPU tests of the multi-rank
 	 * search put the oracle here.  `reduce_min`: the element-wise minimum of `buf` over all ranks, in place, for ranks in different

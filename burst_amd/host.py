@@ -46,7 +46,7 @@ REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, u8p, C.c_uint64)
 
 
 class BhMultiRank(C.Structure):
-    _fields_ = [("rank", C.c_int), ("hh", C.c_void_p), ("r0", u64p), ("r1", u64p), ("n_ranges", C.c_uint32), ("c0", C.c_uint32), ("run", BhRun), ("secSearch", C.c_double),
+    _fields_ = [("rank", C.c_int), ("hh", C.c_void_p), ("r0", u64p), ("r1", u64p), ("n_ranges", C.c_uint32), ("c0", C.c_uint32), ("run", BhRun), ("secSearch", C.c_double), ("gatherPath", C.c_int),
                 ("align", ALIGN_FN), ("reduce_min", REDUCE_FN), ("ctx", C.c_void_p)]
 
 
@@ -442,23 +442,38 @@ def share_regions(off, part, n_parts, status, fetch, store, broadcast, any_faile
     """The exchange of the cooperative accelerator build (bhip_share_fn, include/burst_hip.h) over a launcher's own collectives, for ranks
     that have no RCCL communicator (the gloo back end; ranks sharing a device): region r of every rank's array, [off[r], off[r + 1]),
     travels from its builder to everybody, piece by piece through host memory.  fetch(a, n) -> bytes of the own array as a uint8 array,
-    store(a, buf), broadcast(buf, root) -> buf, any_failed(status) -> bool.  Returns 0, or 1 when some rank announced a failure."""
+    store(a, buf), broadcast(buf, root) -> buf, any_failed(status) -> bool.  Returns 0, 1 when some rank announced a failure before the
+    exchange, -1 (on every rank) when a rank failed inside it."""
     if any_failed(status):
         return 1
+    # A local failure in the middle (a device copy) must not leave the peers waiting in the next broadcast: the rank notes it, keeps
+    # taking part with whatever buffer it has, and the ranks agree on the outcome in one more reduction at the end.
+    broken = None
     for r in range(n_parts):
         a = int(off[r])
         while a < int(off[r + 1]):
             n = min(piece, int(off[r + 1]) - a)
-            buf = fetch(a, n) if r == part else np.empty(n, np.uint8)
+            buf = np.empty(n, np.uint8)
+            if r == part and broken is None:
+                try:
+                    buf = fetch(a, n)
+                except Exception as e:
+                    broken = e
             buf = broadcast(buf, r)
-            if r != part:
-                store(a, buf)
+            if r != part and broken is None:
+                try:
+                    store(a, buf)
+                except Exception as e:
+                    broken = e
             a += n
-    return 0
+    if broken is not None:
+        sys.stderr.write("share_regions: rank %d: %s\n" % (part, broken))
+    return -1 if any_failed(broken is not None) else 0
 
 
 def dist_share(dist, pdev="cpu"):
-    """bhip_share_fn over torch.distributed (any back end): returns (callback, keep-alive) for Db.open_device_shared"""
+    """bhip_share_fn over torch.distributed (any back end): returns the ctypes callback object for Db.open_device_shared -- the CALLER keeps
+    it alive (a reference held) for as long as the library may call it, i.e. across bh_device_open_shared"""
     import torch
     def any_failed(status):
         t = torch.tensor([1 if status else 0], dtype=torch.int64, device=pdev)

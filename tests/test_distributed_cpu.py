@@ -427,12 +427,18 @@ def any_failed(status):
     t = torch.tensor([1 if status else 0]); dist.all_reduce(t, op=dist.ReduceOp.MAX); return bool(int(t.item()))
 def broadcast(buf, root):
     t = torch.from_numpy(buf); dist.broadcast(t, root); return t.numpy()
+calls = [0]
 def share(arr, off, status=0):
     def fetch(a, n): return arr[a:a + n].copy()
-    def store(a, buf): arr[a:a + len(buf)] = buf
+    def store(a, buf):
+        calls[0] += 1
+        if fail_rank >= 100 and rank == fail_rank - 100 and calls[0] == 2: raise RuntimeError("device copy failed (test)")
+        arr[a:a + len(buf)] = buf
     return host.share_regions(off, rank, world, status, fetch, store, broadcast, any_failed, piece=70001)
 st = share(my_lens, loff, 1 if rank == fail_rank else 0)
-if fail_rank >= 0:
+if fail_rank >= 100:
+    assert st == -1          # a rank failed INSIDE the exchange: every rank walked through all broadcasts and learnt it at the end (no hang)
+elif fail_rank >= 0:
     assert st == 1 and not np.array_equal(my_lens, lens.view(np.uint8))      # announced: nothing moved, on every rank
 else:
     assert st == 0 and np.array_equal(my_lens, lens.view(np.uint8))
@@ -443,12 +449,13 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("world,K,fail_rank,port", [(2, 10, -1, 29751), (3, 8, -1, 29752), (2, 10, 1, 29753)])
+@pytest.mark.parametrize("world,K,fail_rank,port", [(2, 10, -1, 29751), (3, 8, -1, 29752), (2, 10, 1, 29753), (3, 10, 101, 29754)])
 def test_cooperative_build_exchange_over_gloo(world, K, fail_rank, port, tmp_path):
     """The exchange of the cooperative accelerator build (bhip_share_fn) as python -m burst_amd.run does it for ranks without an RCCL
     communicator: host.share_regions over the launcher's process group.  Every rank holds the single-rank tables (the host builder's Lens
     and list area) in its own run of words only; after the two exchanges -- list lengths, then the lists -- every rank holds all of them.
-    A rank that announces a failure makes the exchange return 1 everywhere with nothing moved.  (The device builder itself: -m gpu,
+    A rank that announces a failure makes the exchange return 1 everywhere with nothing moved; a rank whose copy fails in the MIDDLE
+    (fail_rank = 100 + rank) keeps taking part and all ranks return -1 together.  (The device builder itself: -m gpu,
     tests/test_gpu_acx.py::test_cooperative_build_equals_the_single_rank_build.)"""
     w = tmp_path / "w.py"
     w.write_text(SHARE_WORKER)

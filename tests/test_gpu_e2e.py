@@ -436,7 +436,7 @@ def test_bench_multi_rank_path_with_one_process(tmp_path):
     assert e["rccl"]["rccl_ranks"] == 1 and e["rccl"]["records"] == a["work"]["records"] and e["rccl"]["value"] > 0 and e["rccl"]["rccl_gather_ms"] >= 0
     # at the top level and in `config` too (what the driver's parsed view keeps), and gathered from the device-resident records
     assert e["rccl_ranks"] == 1 == e["config"]["rccl_ranks"] and e["rccl_gather_ms"] == e["rccl"]["rccl_gather_ms"] == e["config"]["rccl_gather_ms"]
-    assert e["config"]["rccl_records_from"].startswith("device")
+    assert e["config"]["rccl_records_from"].startswith("device") and e["rccl"]["gather_path"] == 1      # (BhMultiRank.gatherPath: the staged gather really ran)
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("burst_hip.bench")]
 
 
