@@ -43,7 +43,7 @@ class BhipQuerySpan(C.Structure):
 
 
 EXPORTS = ["bhip_init", "bhip_stage_queries", "bhip_align_staged", "bhip_align_batch", "bhip_align_pairs", "bhip_prefilter", "bhip_set_option", "bhip_get_stats",
-           "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version", "bhip_copy_hits_device", "bhip_sync_hits",
+           "bhip_device_info", "bhip_destroy", "bhip_last_error", "bhip_abi_version", "bhip_set_ref_order", "bhip_copy_hits_device", "bhip_sync_hits",
            "bhip_comm_create", "bhip_comm_unique_id", "bhip_comm_create_rank", "bhip_comm_allreduce_min", "bhip_comm_fetch_gathered", "bhip_comm_gather_hits", "bhip_comm_stage_device", "bhip_comm_gather_staged", "bhip_comm_stage_reset", "bhip_comm_destroy", "bhip_acx_export", "bhip_reserve", "bhip_reserve_symbols", "bhip_sort_queries", "bhip_stage_spans", "bhip_alloc_host", "bhip_free_host", "bhip_host_register", "bhip_host_unregister", "bhip_set_enqueued_hook", "bhip_acx_export_entries",
            "bhip_build_accelerator_shared", "bhip_comm_share", "bhip_team_create", "bhip_team_destroy", "bhip_team_share", "bhip_device_copy"]
 
@@ -86,6 +86,8 @@ def _load():
     lib.bhip_destroy.restype = None
     lib.bhip_last_error.argtypes = []
     lib.bhip_last_error.restype = C.c_char_p
+    lib.bhip_set_ref_order.argtypes = [vp, vp, u32]
+    lib.bhip_set_ref_order.restype = i32
     lib.bhip_abi_version.argtypes = []
     lib.bhip_abi_version.restype = i32
     lib.bhip_stage_spans.argtypes = [vp, C.POINTER(BhipQuerySpan), u32, u32, u32]
@@ -122,6 +124,11 @@ def _load():
 
 
 _lib = None
+
+
+def _hits_mode(all_hits):
+    """False / True (every hit within budget) as before; 2 or "best" = BHIP_HITS_BEST (one record per entry, chosen on the device)"""
+    return 2 if all_hits in (2, "best") else int(bool(all_hits))
 
 
 def lib():
@@ -226,13 +233,18 @@ class Device:
         _chk(lib().bhip_get_stats(self._h, C.byref(s)))
         return s if raw else s.as_dict()
 
+    def set_ref_order(self, order):
+        """BEST's tie-break table (order[refIx] = RefIxSrt[refIx]) for all_hits = 2 / "best" (bhip_set_ref_order)"""
+        order = _arr(order, np.uint32)
+        _chk(lib().bhip_set_ref_order(self._h, _ptr(order), len(order)))
+
     def align_batch(self, q, all_hits=False, cap=None):
         cap = cap or max(1 << 16, 4 * q.n)
         while True:
             hits = np.zeros(cap, dtype=HIT_DTYPE)
             n = C.c_uint64()
             rc = lib().bhip_align_batch(self._h, _ptr(q.codes), _ptr(q.off), _ptr(q.emac), _ptr(q.six), _ptr(q.rc), _ptr(q.flags),
-                                        q.n, q.n_shared, int(bool(all_hits)), _ptr(hits), cap, C.byref(n))
+                                        q.n, q.n_shared, _hits_mode(all_hits), _ptr(hits), cap, C.byref(n))
             if rc == BHIP_E_CAPACITY:
                 cap = int(n.value) + 16
                 continue
@@ -277,7 +289,7 @@ class Device:
         hits = out if out is not None else np.zeros(max(1 << 16, 4 * (self._staged.n if getattr(self, "_staged", None) is not None else getattr(self, "_staged_n", 0))), dtype=HIT_DTYPE)
         while True:
             n = C.c_uint64()
-            rc = lib().bhip_align_staged(self._h, int(bool(all_hits)), _ptr(hits), len(hits), C.byref(n))
+            rc = lib().bhip_align_staged(self._h, _hits_mode(all_hits), _ptr(hits), len(hits), C.byref(n))
             if rc == BHIP_E_CAPACITY:
                 hits = np.zeros(int(n.value) + 16, dtype=HIT_DTYPE)
                 continue

@@ -97,6 +97,50 @@ __global__ __launch_bounds__(256) void k_hit_fix(BhipHit *__restrict__ out, cons
 }
 __global__ void k_set_rank_ptrs(SharedCtr *sc, uint32_t *cnt, uint32_t *rank) { sc->cnt = cnt; sc->rank = rank; }
 
+// ---- BEST on the device (all_hits = BHIP_HITS_BEST) ----------------------------------------------------------------
+// The reference's BEST keeps, of a query's hits, the one with the fewest edits, then the higher f32 identity, then the lower original
+// reference number RefIxSrt[refIx] (burst.c:4847-4891).  With the minimum-only semantics every record of an entry carries the same edit
+// distance (k_rescore_classify lets ed == best[six] through and nothing else), so the choice inside an ENTRY is the minimum of the 64-bit
+// key (~score bits, order[refIx]) -- scores are non-negative floats, their bit patterns order like their values; (entry, refIx) pairs
+// are unique, so no two records of an entry share a key.  With strain-level redundancy a read has twenty equally good references:
+// one record per entry leaves the device instead of all of them, and the counting sort of the records (a scatter of 20-byte records
+// and a rank sort per group) is replaced by two streaming passes.  The choice between the two strands of a query (one entry each)
+// stays with the host's consolidation, which knows the list order the reference would have met them in.
+__device__ __forceinline__ unsigned long long best_key_of(const BhipHit &h, const uint32_t *__restrict__ order) {
+	return (unsigned long long)(~__float_as_uint(h.score)) << 32 | order[h.refIx];
+}
+__global__ void k_best_key(const BhipHit *__restrict__ hits, uint32_t n, const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ order, unsigned long long *__restrict__ key) {
+	if (n_dev) n = *n_dev < n ? *n_dev : n;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const BhipHit h = hits[i]; atomicMin(&key[h.q], best_key_of(h, order)); }
+}
+__global__ void k_best_flag(uint32_t *__restrict__ cnt, uint32_t n_q) {      // records per entry -> 1 where the entry has any
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_q; i += gridDim.x * blockDim.x) cnt[i] = cnt[i] ? 1u : 0u;
+}
+__global__ void k_best_emit(const BhipHit *__restrict__ hits, uint32_t n, const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ order, const unsigned long long *__restrict__ key,
+                            const uint32_t *__restrict__ off, BhipHit *__restrict__ out, const uint32_t *__restrict__ qmap) {
+	if (n_dev) n = *n_dev < n ? *n_dev : n;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		BhipHit h = hits[i];
+		if (best_key_of(h, order) != key[h.q]) continue;
+		const uint32_t dst = off[h.q];
+		if (qmap) h.q = qmap[h.q];
+		out[dst] = h;
+	}
+}
+extern "C" int bhip_set_ref_order(void *handle, const uint32_t *order, uint32_t n) {
+	Handle *h = (Handle *)handle;
+	if (!h) return fail(BHIP_E_ARG, "null handle");
+	if (!order) return h->n_order ? 1 : 0;
+	if (n < h->tot_refs) return fail(BHIP_E_ARG, "reference order table holds %u entries, the database has %u references", n, h->tot_refs);
+	HIPCHK(hipSetDevice(h->device));
+	int rc;
+	h->n_order = 0;
+	if ((rc = h->ref_order.reserve((size_t)h->tot_refs * 4 + 16))) return rc;
+	HIPCHK(hipMemcpy(h->ref_order.p, order, (size_t)h->tot_refs * 4, hipMemcpyHostToDevice));
+	h->n_order = h->tot_refs;
+	return BHIP_OK;
+}
+
 // ---- kernel launch helpers (st = stream to launch on) ---------------------------------------------------------------
 static void launch_myers(Handle *h, Lane *L, hipStream_t st, int NW, uint32_t grid, const uint2 *pairs, const uint32_t *n_pairs_dev,
 		uint64_t n_pairs_host, uint32_t li_base, const uint32_t *qlist, BhipRawHit *raw, uint32_t *n_raw, uint32_t raw_cap, uint32_t *best,
@@ -777,10 +821,14 @@ extern "C" int bhip_set_enqueued_hook(void *handle, void (*fn)(void *), void *ct
 	return BHIP_OK;
 }
 
-extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint64_t cap, uint64_t *n_hits) {
+extern "C" int bhip_align_staged(void *handle, int all_hits_arg, BhipHit *hits, uint64_t cap, uint64_t *n_hits) {
 	Handle *h = (Handle *)handle;
 	if (!h || !n_hits) return fail(BHIP_E_ARG, "null argument");
 	*n_hits = 0;
+	if (all_hits_arg < 0 || all_hits_arg > BHIP_HITS_BEST) return fail(BHIP_E_ARG, "all_hits must be 0, 1 or 2 (BHIP_HITS_BEST)");
+	const int all_hits = all_hits_arg == BHIP_HITS_ALL ? 1 : 0;      // what the kernels are told: every hit within budget, or the minimum per shared slot
+	const bool sel_best = all_hits_arg == BHIP_HITS_BEST;            // ... and of those one record per entry, chosen on the device
+	if (sel_best && !h->n_order) return fail(BHIP_E_ARG, "BHIP_HITS_BEST needs the reference order table (bhip_set_ref_order)");
 	memset(&h->stats, 0, sizeof h->stats);
 	HIPCHK(hipSetDevice(h->device));
 	// the batch: the oldest one staged and not aligned yet, else the one aligned last (staged once, run any number of times)
@@ -797,12 +845,35 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 	uint32_t qw = (h->cur->st_maxlen + 7) / 8, rw = (h->cur->st_maxlen + band_rows + 24) / 8 + 2;
 	if ((size_t)(band_rows + 1 + qw + rw) * 256 > 40 * 1024) { qw = 0; rw = 0; }      // long queries: per-row global reads instead
 	SharedCtr hsc;
+	uint32_t n_deliver = 0;                // records the caller gets: all of them, or one per entry (sel_best)
 	bool sorted_ahead = false; int o_ahead = 0;
+	if (sel_best) { int rcs; if ((rcs = h->best_key.reserve((size_t)(n_q + 1) * 8))) return rcs;
+		if (!h->nsel_pinned) HIPCHK(hipHostMalloc((void **)&h->nsel_pinned, 64, hipHostMallocDefault)); }
+	// the grouping of the records on `st` into `sorted`: the counting sort by entry (scatter + a rank sort inside every group), or -- sel_best --
+	// the choice of one record per entry (two streaming passes).  cnt = records per entry (from the re-scoring kernels, or k_hit_count)
+	auto enqueue_grouping = [&](hipStream_t st, uint32_t n_host, const uint32_t *n_dev, DBuf &sorted, uint32_t *cnt, uint32_t *off, uint32_t *rank, size_t tmp_bytes) -> int {
+		const uint32_t g = (uint32_t)h->n_cu * 8;
+		const uint32_t *qmap = h->cur->has_qmap ? h->cur->qmap.as<uint32_t>() : (const uint32_t *)nullptr;
+		if (sel_best) {
+			hipLaunchKernelGGL(k_best_key, dim3(g), dim3(256), 0, st, h->out.as<BhipHit>(), n_host, n_dev, h->ref_order.as<uint32_t>(), h->best_key.as<unsigned long long>());
+			hipLaunchKernelGGL(k_best_flag, dim3(std::min<uint32_t>((n_q + 255) / 256, g)), dim3(256), 0, st, cnt, n_q);
+			HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->sort_tmp.p, tmp_bytes, cnt, off, (int)(n_q + 1), st));
+			hipLaunchKernelGGL(k_best_emit, dim3(g), dim3(256), 0, st, h->out.as<BhipHit>(), n_host, n_dev, h->ref_order.as<uint32_t>(), h->best_key.as<unsigned long long>(), off, sorted.as<BhipHit>(), qmap);
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipMemcpyAsync(h->nsel_pinned, off + n_q, 4, hipMemcpyDeviceToHost, st));      // (the scan runs over n_q + 1 counters, the last one zero: its offset is the total)
+			return 0;
+		}
+		HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->sort_tmp.p, tmp_bytes, cnt, off, (int)(n_q + 1), st));
+		hipLaunchKernelGGL(k_hit_scatter, dim3(g), dim3(256), 0, st, h->out.as<BhipHit>(), n_host, n_dev, off, rank, sorted.as<BhipHit>(), qmap);
+		hipLaunchKernelGGL(k_hit_fix, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, st, sorted.as<BhipHit>(), off, cnt, n_q, h->sort_scratch.as<BhipHit>(), (uint32_t)(h->sort_scratch.cap / sizeof(BhipHit)));
+		HIPCHK(hipGetLastError());
+		return 0;
+	};
 	for (int attempt = 0; attempt < 24; ++attempt) {
 		int rc;
 		sorted_ahead = false;
 		// the records of this batch are still resident when the previous call only failed for the size of the caller's buffer
-		if (h->res_valid && h->res_seq == slot->seq && h->res_all_hits == all_hits) { hsc.n_out = h->res_n; hsc.err = 0; h->stats = h->res_stats; *n_hits = hsc.n_out; }
+		if (h->res_valid && h->res_seq == slot->seq && h->res_all_hits == all_hits_arg) { hsc.n_out = h->res_n_raw; hsc.err = 0; h->stats = h->res_stats; n_deliver = h->res_n; *n_hits = n_deliver; }
 		else {
 		h->res_valid = false;
 		if ((rc = h->best.reserve((size_t)(n_shared + 1) * 4))) return rc;
@@ -814,6 +885,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		{	// the counting sort's counters (zeroed here, off the critical path) and ranks, for the re-scoring kernels
 			if ((rc = h->sort_idx.reserve((size_t)h->out_cap * 4)) || (rc = h->sort_keys.reserve((size_t)(n_q + 1) * 4))) return rc;
 			HIPCHK(hipMemsetAsync(h->sort_keys.p, 0, (size_t)(n_q + 1) * 4, h->stream));
+			if (sel_best) HIPCHK(hipMemsetAsync(h->best_key.p, 0xFF, (size_t)(n_q + 1) * 8, h->stream));
 			hipLaunchKernelGGL(k_set_rank_ptrs, dim3(1), dim3(1), 0, h->stream, h->shared_ctr.as<SharedCtr>(), h->sort_keys.as<uint32_t>(), h->sort_idx.as<uint32_t>());
 		}
 		HIPCHK(hipEventRecord(h->ev[1], h->stream));
@@ -839,15 +911,10 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, off, (int)(n_q + 1), h->post_stream));
 			if ((rc = h->sort_tmp.reserve(tmp_bytes))) return rc;
 			SharedCtr *sc = h->shared_ctr.as<SharedCtr>();
-			const uint32_t g = (uint32_t)h->n_cu * 8;
 			if (h->copy_pending[o_ahead]) HIPCHK(hipStreamWaitEvent(h->post_stream, h->ev_copied[o_ahead], 0));      // the copy that last read this buffer
 			HIPCHK(hipEventRecord(h->ev[4], h->post_stream));
 			// (counts and ranks were taken by the re-scoring kernels as they wrote the records)
-			HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->sort_tmp.p, tmp_bytes, cnt, off, (int)(n_q + 1), h->post_stream));
-			hipLaunchKernelGGL(k_hit_scatter, dim3(g), dim3(256), 0, h->post_stream, h->out.as<BhipHit>(), (uint32_t)h->out_cap, &sc->n_out, off, rank, sorted.as<BhipHit>(),
-				h->cur->has_qmap ? h->cur->qmap.as<uint32_t>() : (const uint32_t *)nullptr);
-			hipLaunchKernelGGL(k_hit_fix, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, h->post_stream, sorted.as<BhipHit>(), off, cnt, n_q, h->sort_scratch.as<BhipHit>(), (uint32_t)(h->sort_scratch.cap / sizeof(BhipHit)));
-			HIPCHK(hipGetLastError());
+			if ((rc = enqueue_grouping(h->post_stream, (uint32_t)h->out_cap, &sc->n_out, sorted, cnt, off, rank, tmp_bytes))) return rc;
 			HIPCHK(hipEventRecord(h->ev[5], h->post_stream));
 			sorted_ahead = true;
 		}
@@ -864,7 +931,11 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			Lane *L = h->lanes[l];
 			// (with the minimum-only semantics the counting-filter kernel also splits off the lanes that cannot hold a minimum --
 			// the second sweep -- which the exact-table kernel does not: it only takes over when most records survive)
-			if (L->n_entries && L->pf_algo == 0 && L->hc.ent_read > 100000 && (double)L->hc.surv_sum > (all_hits ? 0.20 : 0.50) * (double)L->hc.ent_read) L->pf_algo = 1;
+			// Round 6: measured again with k_prefilter_cq on a database with strain-level redundancy (57 % of the records survive its filter: a read
+			// of a 500-strain family meets the family's clumps in every one of its lists): the exact-table kernel took 61.5 ms per 2 M reads where
+			// k_prefilter_cq takes 8.5 (gpurun_out/r06a, r06b) -- with the minimum-only semantics the switch is off while that kernel is in use
+			const bool cq_min_only = !all_hits && h->opt_pf_cw == 2 && L->pf_algo_used == 3;
+			if (L->n_entries && L->pf_algo == 0 && !cq_min_only && L->hc.ent_read > 100000 && (double)L->hc.surv_sum > (all_hits ? 0.20 : 0.50) * (double)L->hc.ent_read) L->pf_algo = 1;
 		}
 		if (getenv("BHIP_DEBUG")) for (uint32_t l = 0; l < nl; ++l) {
 			const Lane *L = h->lanes[l];
@@ -915,11 +986,12 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 		if (scratch_retry || (hsc.err & 2u)) continue;
 		if (hsc.err & 1u) return fail(BHIP_E_RESCORE, "re-scoring could not reproduce a hit found by the edit-distance kernel (a query starting with a symbol outside the alphabet? the reference stops here as well: CRITICAL ERROR: Truncation within known good path, burst.c:812-816)");
 		if (hsc.n_out > h->out_cap) { h->out_cap = (uint64_t)hsc.n_out + hsc.n_out / 8 + 1024; continue; }
-		*n_hits = hsc.n_out;
+		n_deliver = sel_best ? (sorted_ahead ? *h->nsel_pinned : std::min<uint32_t>(hsc.n_out, n_q)) : hsc.n_out;      // (not grouped yet: an upper bound; the grouping below gives the number)
+		*n_hits = n_deliver;
 		h->last_n_out = 0;
 		// statistics
 		BhipStats &S = h->stats;
-		S.n_queries = n_q; S.n_hits = hsc.n_out;
+		S.n_queries = n_q; S.n_hits = n_deliver;
 		uint64_t qlen_sum = 0;
 		for (uint32_t l = 0; l < nl; ++l) {
 			Lane *L = h->lanes[l];
@@ -943,10 +1015,10 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			S.ms_rescore += ev_ms(L->ev_rs[0], L->ev_rs[1]);
 		}
 		S.bytes_algorithmic = 8ull * S.n_columns + qlen_sum / 2 + 192ull * S.n_pairs;
-		h->res_valid = true; h->res_seq = slot->seq; h->res_all_hits = all_hits; h->res_n = hsc.n_out; h->res_stats = h->stats;
+		h->res_valid = true; h->res_seq = slot->seq; h->res_all_hits = all_hits_arg; h->res_n = n_deliver; h->res_n_raw = hsc.n_out; h->res_stats = h->stats;
 		}
 		BhipStats &S = h->stats;
-		if (hits && hsc.n_out > cap) return fail(BHIP_E_CAPACITY, "hit buffer holds %llu records, %u needed", (unsigned long long)cap, hsc.n_out);
+		if (hits && n_deliver > cap) return fail(BHIP_E_CAPACITY, "hit buffer holds %llu records, %u needed", (unsigned long long)cap, n_deliver);
 		HIPCHK(hipEventRecord(h->ev[8], h->stream));
 		const bool dbg_t = getenv("BHIP_DEBUG_TIMES") != nullptr;
 		const auto tq0 = std::chrono::steady_clock::now();
@@ -966,19 +1038,21 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 			uint32_t *cnt = h->sort_keys.as<uint32_t>(), *off = h->sort_keys2.as<uint32_t>(), *rank = h->sort_idx.as<uint32_t>();
 			const uint32_t g = std::min<uint32_t>((n + 255) / 256, (uint32_t)h->n_cu * 8);
 			HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(n_q + 1) * 4, h->stream));
+			if (sel_best) HIPCHK(hipMemsetAsync(h->best_key.p, 0xFF, (size_t)(n_q + 1) * 8, h->stream));
 			tq1 = tq();
 			hipLaunchKernelGGL(k_hit_count, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, (const uint32_t *)nullptr, cnt, rank);
 			size_t tmp_bytes = 0;
 			HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, off, (int)(n_q + 1), h->stream));
 			if ((rc = h->sort_tmp.reserve(tmp_bytes))) return rc;
-			HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->sort_tmp.p, tmp_bytes, cnt, off, (int)(n_q + 1), h->stream));
-			hipLaunchKernelGGL(k_hit_scatter, dim3(g), dim3(256), 0, h->stream, h->out.as<BhipHit>(), n, (const uint32_t *)nullptr, off, rank, sorted.as<BhipHit>(),
-				h->cur->has_qmap ? h->cur->qmap.as<uint32_t>() : (const uint32_t *)nullptr);
-			hipLaunchKernelGGL(k_hit_fix, dim3(std::min<uint32_t>((n_q + 255) / 256, (uint32_t)h->n_cu * 8)), dim3(256), 0, h->stream, sorted.as<BhipHit>(), off, cnt, n_q, h->sort_scratch.as<BhipHit>(), (uint32_t)(h->sort_scratch.cap / sizeof(BhipHit)));
-			HIPCHK(hipGetLastError());
+			if ((rc = enqueue_grouping(h->stream, n, (const uint32_t *)nullptr, sorted, cnt, off, rank, tmp_bytes))) return rc;
+			if (sel_best) {      // (the number of selected records is only known now: rare path -- records that stayed resident, wide bands)
+				HIPCHK(hipStreamSynchronize(h->stream));
+				n_deliver = *h->nsel_pinned; *n_hits = n_deliver; S.n_hits = n_deliver; h->res_n = n_deliver;
+				if (hits && n_deliver > cap) return fail(BHIP_E_CAPACITY, "hit buffer holds %llu records, %u needed", (unsigned long long)cap, n_deliver);
+			}
 			}
 			tq2 = tq();
-			const size_t bytes = (size_t)n * sizeof(BhipHit);
+			const size_t bytes = (size_t)n_deliver * sizeof(BhipHit);
 			bool queued = false;
 			if (async) {
 				// page-lock the caller's buffer (kept registered: callers alternate between two buffers), then copy on the copy stream
@@ -1010,7 +1084,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint
 				}
 			}
 			if (hits && !queued) HIPCHK(hipMemcpyAsync(hits, sorted.p, bytes, hipMemcpyDeviceToHost, h->stream));
-			h->last_n_out = n; h->last_out = o;
+			h->last_n_out = n_deliver; h->last_out = o;
 		}
 		tq4 = tq();
 		HIPCHK(hipEventRecord(h->ev[9], h->stream));

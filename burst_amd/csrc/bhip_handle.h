@@ -206,15 +206,13 @@ struct DBuf {
 	template <class T> T *as() const { return (T *)p; }
 };
 
-static const int kClasses[] = {2, 4, 6, 8, 10, 16, 32};
-static const int kNumClasses = 7;
+static const int kClasses[] = {2, 4, 6, 8, 10, 16, 32, 128};      // (the last: 1 025 .. BHIP_MAX_QLEN symbols, as many words as the lane's longest query needs)
+static const int kNumClasses = BHIP_N_CLASSES;
 static inline int class_of_len(uint32_t len) {
-	for (int i = 0; i < kNumClasses; ++i) if (len <= 32u * kClasses[i]) return i;
-	return kNumClasses - 1;      // 1 025 .. BHIP_MAX_QLEN symbols: the last class, with as many words as its longest query needs (class_words)
+	for (int i = 0; i < kNumClasses - 1; ++i) if (len <= 32u * kClasses[i]) return i;
+	return kNumClasses - 1;      // 1 025 .. BHIP_MAX_QLEN symbols: a class of their own (round 6: one such read used to drag every 513 .. 1 024-symbol query of its lane into k_myers_long)
 }
-// words of the bit-vector of a class: the class's own, or -- last class of a lane whose longest query is beyond 1 024 symbols -- what that
-// query needs (k_myers_long: any number of words, single-stage sweep)
-static inline int class_words(int cls, uint32_t maxlen) { return (cls == kNumClasses - 1 && maxlen > 1024u) ? (int)((maxlen + 31u) / 32u) : kClasses[cls]; }
+static inline int class_words(int cls, uint32_t maxlen) { return cls == kNumClasses - 1 ? (int)((std::max<uint32_t>(maxlen, 1025u) + 31u) / 32u) : kClasses[cls]; }
 
 // device-side counters, one block copied back per call
 struct Counters {
@@ -252,8 +250,8 @@ struct StageSlot {
 	float st_ms_h2d = 0;
 	std::vector<BhipQuerySpan> spans;     // the caller's arrays (valid until the batch has been aligned): the host pass reads them
 	const uint32_t *six_explicit = nullptr;
-	uint32_t npf[16][7], nex[16][7], maxE[16][7], maxwords[16][7], qlist_off[16][7], maxlen_lane[16], n_entries_lane[16];
-	uint64_t seed_words[16][7];
+	uint32_t npf[16][BHIP_N_CLASSES], nex[16][BHIP_N_CLASSES], maxE[16][BHIP_N_CLASSES], maxwords[16][BHIP_N_CLASSES], qlist_off[16][BHIP_N_CLASSES], maxlen_lane[16], n_entries_lane[16];
+	uint64_t seed_words[16][BHIP_N_CLASSES];
 	void release_all() {
 		DBuf *b[] = {&qcodes, &qcodes4, &qlen16, &qoff, &qemac, &qsix, &qrc, &qflags, &qmap, &off_raw, &plan, &qpack, &key, &key_sorted, &idx, &idx_sorted,
 			&sort_tmp, &info, &qcodes_s, &qoff_s, &qemac_s, &qpack_s, &nx, &nx_six};
@@ -349,6 +347,10 @@ struct Handle {
 	int opt_host_routing = 0;             // 1 = route every batch on the host (the pass that handles symbols of code 0); test hook
 	// batch-wide buffers
 	DBuf best, out, shared_ctr, mins, pairs;
+	// BEST on the device (bhip_align_staged with all_hits = BHIP_HITS_BEST): RefIxSrt per reference, the per-entry minimum key of a batch
+	DBuf ref_order, best_key; uint32_t n_order = 0;
+	uint32_t *nsel_pinned = nullptr;      // read-back of the number of selected records
+	bool res_sel = false; uint32_t res_n_raw = 0;      // the resident records of a batch that did not fit the caller's buffer: selected? how many before the selection?
 	SharedCtr *hsc_pinned = nullptr;      // read-back of shared_ctr behind the chain (pinned: no blocking copy on the way out of a batch)
 	const uint8_t *s_codes() const { return cur->st_has_junk ? cur->qcodes_s.as<uint8_t>() : cur->qcodes.as<uint8_t>(); }
 	const uint64_t *s_off() const { return cur->st_has_junk ? cur->qoff_s.as<uint64_t>() : cur->qoff.as<uint64_t>(); }

@@ -71,10 +71,11 @@ extern "C" void bhip_destroy(void *handle) {
 	if (h->stage_stream) (void)hipStreamSynchronize(h->stage_stream);
 	for (StageSlot &S : h->slots) S.release_all();
 	if (h->hsc_pinned) (void)hipHostFree(h->hsc_pinned);
+	if (h->nsel_pinned) (void)hipHostFree(h->nsel_pinned);
 	for (Lane *L : h->lanes) lane_destroy(L);
 	DBuf *all[] = {&h->ref_lane, &h->ref_off, &h->clump_len, &h->lut, &h->acx_lines, &h->acx_rec, &h->bad,
 		&h->best, &h->out, &h->shared_ctr, &h->mins, &h->pairs, &h->sort_keys, &h->sort_keys2, &h->sort_idx,
-		&h->sort_tmp, &h->out_sorted, &h->out_sorted2, &h->sort_scratch};
+		&h->sort_tmp, &h->out_sorted, &h->out_sorted2, &h->sort_scratch, &h->ref_order, &h->best_key};
 	for (int o = 0; o < 2; ++o) {
 		if (h->copy_pending[o] && h->ev_copied[o]) (void)hipEventSynchronize(h->ev_copied[o]);
 		if (h->reg_ptr[o]) (void)hipHostUnregister(h->reg_ptr[o]);
@@ -240,7 +241,7 @@ extern "C" int bhip_set_option(void *handle, const char *name, long long value) 
 	if (!strcmp(name, "prefilter_bytes")) { h->opt_pf_bytes = value != 0; return BHIP_OK; }
 	if (!strcmp(name, "prefilter_rb")) { if (value != 0 && (value < 2 || value > 4)) return fail(BHIP_E_ARG, "prefilter_rb must be 0, 2, 3 or 4"); h->opt_pf_rb = (int)value; return BHIP_OK; }
 	if (!strcmp(name, "lanes")) {
-		if (value < 1 || value > 16) return fail(BHIP_E_ARG, "lanes must be 1 .. 16");
+		if (value < 1 || value > BHIP_MAX_LANES) return fail(BHIP_E_ARG, "lanes must be 1 .. %d", BHIP_MAX_LANES);
 		h->opt_lanes = (int)value; for (StageSlot &S : h->slots) { S.state = 0; S.st_valid = false; } return BHIP_OK;
 	}
 	return fail(BHIP_E_ARG, "unknown option '%s'", name);

@@ -91,8 +91,10 @@ __host__ __device__ inline void bhip_expand_walk(Sym sym, uint32_t K, uint32_t u
 }
 
 // Routing of a staged batch, filled on the device by k_route (or by the host pass that handles batches with query symbols
-// outside the alphabet): a query entry belongs to the list of its key = ((lane * 7 + length class) * 2 + exhaustive).
-#define BHIP_ROUTE_KEYS 224          // 16 lanes x 7 classes x {prefilter, exhaustive}
+// outside the alphabet): a query entry belongs to the list of its key = ((lane * BHIP_N_CLASSES + length class) * 2 + exhaustive).
+#define BHIP_N_CLASSES  8            // length classes: vectors of 2, 4, 6, 8, 10, 16, 32 words, and the queries beyond 1 024 symbols
+#define BHIP_MAX_LANES  15           // sub-pipelines of a batch (the keys are bytes and 255 means "in no list")
+#define BHIP_ROUTE_KEYS 240          // 15 lanes x 8 classes x {prefilter, exhaustive}
 #define BHIP_ROUTE_SKIP 255          // empty entries (and entries a batch error was raised for): in no list
 struct BhipStageInfo {
 	uint32_t count[256];               // entries per key

@@ -1417,6 +1417,7 @@ __global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
 					p[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + ew; direct[w] = true;
 				} else { p[w] = nst[w] + ew; nst[w] += tw; }
 			}
+			PFM_T(5);
 			for (uint32_t m = m16; m; m &= m - 1) {
 				const uint32_t z = (uint32_t)__builtin_ctz(m), w = (m1 >> z) & 1u;
 				uint32_t lb = 0;
@@ -2101,6 +2102,7 @@ __global__ __launch_bounds__(64, CQ_MINWAVES) void k_prefilter_cq(
 			}
 			cmax_all = group_max(cmax);
 		}
+		PFM_T(7);
 		auto emit_slots = [&](uint32_t iu, uint32_t slot, uint32_t c, unsigned long long lo, unsigned long long hi, uint32_t m16) {
 			if (iu < nused) { s_key[g][slot] = 0; s_lc[g][slot][0] = 0; s_lc[g][slot][1] = 0; }     // (this wave's reads of the slot are done: LDS operations of one wave stay in order)
 			const uint32_t m0 = prune ? m16 & lanes_ge_any(lo, hi, cmax_all > thr ? cmax_all : thr) : m16, m1 = m16 & ~m0;
@@ -2120,6 +2122,7 @@ __global__ __launch_bounds__(64, CQ_MINWAVES) void k_prefilter_cq(
 					p[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + ew; direct[w] = true;
 				} else { p[w] = nst[w] + ew; nst[w] += tw; }
 			}
+			PFM_T(5);
 			for (uint32_t m = m16; m; m &= m - 1) {
 				const uint32_t zz = (uint32_t)__builtin_ctz(m), w = (m1 >> zz) & 1u;
 				uint32_t lb = 0;
@@ -2130,6 +2133,7 @@ __global__ __launch_bounds__(64, CQ_MINWAVES) void k_prefilter_cq(
 				else s_stage[w][pos] = task;
 			}
 			if (m16) { ++my_units; my_qlen += len; }       // (the swept columns of lane tasks are counted by the sweep: tcol_sum)
+			PFM_T(4);
 		};
 		if (nu_max) emit_slots(gl, slot0, c0, lo0, hi0, m16_0);
 		for (uint32_t iu0 = 16; iu0 < nu_max; iu0 += 16) {
@@ -2148,7 +2152,7 @@ __global__ __launch_bounds__(64, CQ_MINWAVES) void k_prefilter_cq(
 				if (live && gl == 0) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
 			}
 		}
-		PFM_T(4);
+		PFM_T(3);
 		{
 			uint4 *cz4 = (uint4 *)&s_cnt[0][0];
 			for (uint32_t i = lane; i < 4u * NDW / 4u; i += 64) cz4[i] = make_uint4(0, 0, 0, 0);
@@ -3088,7 +3092,7 @@ __global__ __launch_bounds__(256) void k_route(
 			if (n_zero) atomicOr(&s_misc[0], 1u);
 			const uint32_t six = qsix ? qsix[i] : i;
 			const uint32_t l = (uint32_t)(((unsigned long long)six * n_lanes) / n_shared);
-			const uint32_t cls = len <= 64 ? 0u : len <= 128 ? 1u : len <= 192 ? 2u : len <= 256 ? 3u : len <= 320 ? 4u : len <= 512 ? 5u : 6u;
+			const uint32_t cls = len <= 64 ? 0u : len <= 128 ? 1u : len <= 192 ? 2u : len <= 256 ? 3u : len <= 320 ? 4u : len <= 512 ? 5u : len <= 1024 ? 6u : 7u;
 			uint32_t ex = qflags ? (qflags[i] == BHIP_Q_EXHAUSTIVE) : !has_acx;
 			if (!has_acx) ex = 1;
 			if (!ex) {
@@ -3106,7 +3110,7 @@ __global__ __launch_bounds__(256) void k_route(
 				pl = bhip_seed_plan(len, E, (uint32_t)K, stride_opt, clean, vb, qp, alt);
 				if (BHIP_PLAN_NEED(pl) == 0) ex = 1;        // no word is guaranteed to survive: exhaustive (burst.c:3130-3131 does the same for "bad" queries)
 			}
-			const uint32_t lc = l * 7 + cls;
+			const uint32_t lc = l * BHIP_N_CLASSES + cls;
 			key = lc * 2 + ex;
 			atomicAdd(&s_count[key], 1u);
 			atomicMax(&s_maxE[lc], E);

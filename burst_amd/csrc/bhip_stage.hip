@@ -182,7 +182,7 @@ static void slot_take_info(StageSlot *S, const BhipStageInfo &I) {
 	uint32_t off = 0;
 	for (uint32_t l = 0; l < 16; ++l) {
 		for (int c = 0; c < kNumClasses; ++c) {
-			const uint32_t lc = l * 7 + (uint32_t)c;
+			const uint32_t lc = l * BHIP_N_CLASSES + (uint32_t)c;
 			S->npf[l][c] = I.count[lc * 2]; S->nex[l][c] = I.count[lc * 2 + 1];
 			S->qlist_off[l][c] = off; off += S->npf[l][c] + S->nex[l][c];
 			S->maxE[l][c] = I.maxE[lc]; S->maxwords[l][c] = I.maxwords[lc]; S->seed_words[l][c] = I.seed_words[lc];
@@ -294,10 +294,10 @@ static int host_route(Handle *h, StageSlot *S) {
 	std::vector<uint32_t> sorted; sorted.reserve(n_q);
 	for (uint32_t l = 0; l < nl; ++l) for (int c = 0; c < kNumClasses; ++c) for (int ex = 0; ex < 2; ++ex) {
 		const size_t lc = (size_t)l * kNumClasses + c, k = lc * 2 + ex;
-		for (const Part &P : parts) { sorted.insert(sorted.end(), P.lists[k].begin(), P.lists[k].end()); I.count[(l * 7 + c) * 2 + ex] += (uint32_t)P.lists[k].size(); }
+		for (const Part &P : parts) { sorted.insert(sorted.end(), P.lists[k].begin(), P.lists[k].end()); I.count[(l * BHIP_N_CLASSES + c) * 2 + ex] += (uint32_t)P.lists[k].size(); }
 		if (!ex) for (const Part &P : parts) {
-			I.maxE[l * 7 + c] = std::max(I.maxE[l * 7 + c], P.maxE[lc]); I.maxwords[l * 7 + c] = std::max(I.maxwords[l * 7 + c], P.maxwords[lc]);
-			I.seed_words[l * 7 + c] += P.seed_words[lc];
+			I.maxE[l * BHIP_N_CLASSES + c] = std::max(I.maxE[l * BHIP_N_CLASSES + c], P.maxE[lc]); I.maxwords[l * BHIP_N_CLASSES + c] = std::max(I.maxwords[l * BHIP_N_CLASSES + c], P.maxwords[lc]);
+			I.seed_words[l * BHIP_N_CLASSES + c] += P.seed_words[lc];
 		}
 	}
 	for (uint32_t l = 0; l < nl; ++l) for (const Part &P : parts) { I.maxlen_lane[l] = std::max(I.maxlen_lane[l], P.maxlen[l]); I.n_entries_lane[l] += P.n_entries[l]; }

@@ -26,6 +26,12 @@ int bh_device_gate_try(int device) {      /* 1 = taken (release with bh_device_g
 	return device < 0 ? 1 : pthread_mutex_trylock(&g_dev_gate[device & 63]) == 0;
 }
 
+/* BEST's tie-break table (RefIxSrt, burst.c:3688-3693, 4865-4868) goes to the device with the database, so that -m BEST can have the
+ * device keep one record per entry (bhip_align_staged with BHIP_HITS_BEST).  A database without the table (a view made for a
+ * kernel test) simply keeps the choice on the host; so does a failed upload (436 MB at the metric's size). */
+static void give_ref_order(const BhDb *db, void *hh) {
+	if (db->refIxSrt && db->totR && !getenv("BURST_HOST_BEST_ON_HOST")) (void)bhip_set_ref_order(hh, db->refIxSrt, db->totR);
+}
 int bh_device_open_ex(const BhDb *db, int device, int z, int build_K, void **hip_handle) {
 	uint8_t lut[256];
 	bh_score_lut(z, lut);
@@ -37,6 +43,7 @@ int bh_device_open_ex(const BhDb *db, int device, int z, int build_K, void **hip
 	                   db->badList, db->badSz, lut, db->xalpha, hip_handle);
 	bh_device_gate(device, 0);
 	if (rc) return bh_set_error(rc == BHIP_E_ARG ? BH_E_USAGE : BH_E_DEVICE, "libburst_hip: %s", bhip_last_error());
+	give_ref_order(db, *hip_handle);
 	return BH_OK;
 }
 int bh_device_open(const BhDb *db, int device, int z, void **hip_handle) { return bh_device_open_ex(db, device, z, 0, hip_handle); }
@@ -54,6 +61,7 @@ int bh_device_open_shared(const BhDb *db, int device, int z, int build_K, int pa
 	if (rc) { static const uint64_t none[BH_MAX_RANKS + 1] = {0}; if (n_parts > 1 && n_parts <= BH_MAX_RANKS) (void)share(ctx, NULL, none, part, n_parts, 1); }
 	else rc = bhip_build_accelerator_shared(*hip_handle, build_K, part, n_parts, share, ctx);
 	if (rc) return bh_set_error(rc == BHIP_E_ARG ? BH_E_USAGE : BH_E_DEVICE, "libburst_hip: %s", bhip_last_error());
+	give_ref_order(db, *hip_handle);
 	return BH_OK;
 }
 
@@ -141,8 +149,9 @@ int bh_align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const uint
  * only when needed -- page-locking hundreds of megabytes costs more than aligning a batch */
 int bh_align_ranges_reuse(void *hh, const BhQueries *Q, const uint64_t *r0, const uint64_t *r1, uint32_t n_ranges, BhMode mode, uint64_t batch_uniq, BhRun *run) {
 	BhipHit *keep = run->hits; const uint64_t cap = run->capHits; const int pin = run->hitsPinned;
+	void (*const cb)(void *, void *, uint64_t, uint64_t) = run->onBatch; void *const cbctx = run->onBatchCtx;      /* (the caller's per-batch hook survives the reset) */
 	memset(run, 0, sizeof *run);
-	run->hits = keep; run->capHits = cap; run->hitsPinned = pin;
+	run->hits = keep; run->capHits = cap; run->hitsPinned = pin; run->onBatch = cb; run->onBatchCtx = cbctx;
 	return align_ranges(hh, Q, r0, r1, n_ranges, mode, batch_uniq, run);
 }
 /* staging of batch k of a job: a batch of unique queries [u, u + B) is two spans of the caller's arrays (forward entries, then their
@@ -216,7 +225,9 @@ static int align_ranges(void *hh, const BhQueries *Q, const uint64_t *r0, const 
 		}
 	}
 	const int twoStrand = Q->numEntries > Q->numUniq;
-	const int all_hits = mode == BH_FORAGE || mode == BH_ANY;      /* ANY: any hit within budget will do (burst.c:4224) -- the report picks the one the reference meets first */
+	/* ANY: any hit within budget will do (burst.c:4224) -- the report picks the one the reference meets first.  BEST: the device keeps one
+	 * record per entry when it holds the tie-break table (the report's scan over an entry's records then meets a single one) */
+	const int all_hits = (mode == BH_FORAGE || mode == BH_ANY) ? BHIP_HITS_ALL : (mode == BH_BEST && !getenv("BURST_HOST_BEST_ON_HOST") && bhip_set_ref_order(hh, NULL, 0) == 1) ? BHIP_HITS_BEST : BHIP_HITS_MIN;
 	uint64_t capHits = totU * (twoStrand ? 2 : 1) + totU / 2 + (1u << 20), nHits = 0;
 	int pinned = run->hitsPinned;
 	BhipHit *hits = run->hits;

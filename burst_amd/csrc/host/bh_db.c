@@ -929,6 +929,7 @@ int bh_db_slice(const BhDb *db, uint32_t c0, uint32_t c1, BhDb *out) {
 	out->packed = db->packed + w0 * 16;
 	out->packedWords = wn;
 	out->identityMap = 1;                 /* header tables stay with the full database */
+	if (db->refIxSrt) out->refIxSrt = db->refIxSrt + 16ull * c0;      /* (a view, not owned: BEST's tie-break table for the slice's own device, bh_device_open_ex) */
 	if (!db->hasAcx) return BH_OK;
 	const int K = db->K, fmtIn = db->acxFmt, fmtOut = out->numRclumps > 1048574 ? 1 : 0;
 	const uint64_t nw = 1ull << (2 * K);

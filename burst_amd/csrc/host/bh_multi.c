@@ -175,7 +175,10 @@ typedef struct { void *comm; int rank; int failed; } StageCb;
 static void stage_batch_cb(void *ctx, void *hh, uint64_t first, uint64_t n) {
 	StageCb *c = (StageCb *)ctx;
 	uint64_t got = 0;
-	if (bhip_comm_stage_device(c->comm, c->rank, hh, first, &got) || got != n) c->failed = 1;
+	if (bhip_comm_stage_device(c->comm, c->rank, hh, first, &got) || got != n) {
+		if (!c->failed && getenv("BURST_HOST_DEBUG")) fprintf(stderr, "[bh_multi] rank %d: staging the records of a batch on the device failed (%s): the gather will upload the host copy\n", c->rank, bhip_last_error());
+		c->failed = 1;
+	}
 }
 
 int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhNode *node, const BhQueries *Q, BhMode mode, uint64_t batch, int shard_db, BhRun *all, uint64_t *counts,
@@ -305,6 +308,7 @@ int bh_search_multi_ex(BhMultiRank *R, int n_local, int n_ranks, void *comm, BhN
 			int g = staged_ok[i] ? bhip_comm_gather_staged(comm, R[i].rank, rcs[i] ? 0 : R[i].run.nHits, i == i0 ? all->hits : NULL, i == i0 ? all->capHits : 0, &n_total, i == i0 ? counts : NULL) : 1;
 			/* (a rank that could not stage -- device memory -- says so with its count: the call fails on every rank, and every rank comes here) */
 			R[i].gatherPath = (!g || g == BHIP_E_CAPACITY) ? 1 : 2;
+			if (staged_ok[i] && R[i].gatherPath == 2 && dbg) fprintf(stderr, "[bh_multi] rank %d: the device-fed gather was refused (%s)\n", R[i].rank, bhip_last_error());
 			if (g && g != BHIP_E_CAPACITY) g = bhip_comm_gather_hits(comm, R[i].rank, rcs[i] ? NULL : R[i].run.hits, rcs[i] ? 0 : R[i].run.nHits, i == i0 ? all->hits : NULL,
 			                                    i == i0 ? all->capHits : 0, &n_total, i == i0 ? counts : NULL);
 			if (i == i0) need = n_total;

@@ -108,7 +108,11 @@ BHIP_API int bhip_init(int device, const void *edx_packed, const uint32_t *clump
  *   q_flags : BHIP_Q_PREFILTER / BHIP_Q_EXHAUSTIVE per entry (NULL = all exhaustive when the handle has no
  *             accelerator, all prefiltered otherwise)
  *   all_hits: 0 = BEST/ALLPATHS/CAPITALIST semantics (only lanes with ed == minimum over the shared slot),
- *             1 = FORAGE semantics (every lane with ed <= budget, burst.c:4224)
+ *             1 = FORAGE semantics (every lane with ed <= budget, burst.c:4224),
+ *             2 = BHIP_HITS_BEST: the minimum-only semantics with BEST's choice made on the device -- per query ENTRY the one
+ *                 record the reference's BEST scan keeps among that entry's records (burst.c:4847-4891: equal ed, then the higher
+ *                 f32 score, then the lower RefIxSrt[refIx]; needs bhip_set_ref_order).  One record per entry with a hit crosses
+ *                 PCIe instead of every equally good reference; the choice between a query's two strands stays with the caller.
  *   hits/cap: caller's buffer; on BHIP_E_CAPACITY *n_hits is the number required and nothing is returned.
  * Records are returned sorted by (q, refIx). */
 BHIP_API int bhip_align_batch(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
@@ -122,6 +126,13 @@ BHIP_API int bhip_align_batch(void *handle, const uint8_t *q_codes, const uint64
 BHIP_API int bhip_stage_queries(void *handle, const uint8_t *q_codes, const uint64_t *q_off, const uint16_t *q_emac,
                        const uint32_t *q_six, const uint8_t *q_rc, const uint8_t *q_flags, uint32_t n_q, uint32_t n_shared);
 BHIP_API int bhip_align_staged(void *handle, int all_hits, BhipHit *hits, uint64_t cap, uint64_t *n_hits);
+#define BHIP_HITS_MIN   0
+#define BHIP_HITS_ALL   1
+#define BHIP_HITS_BEST  2
+/* The tie-break table of all_hits = BHIP_HITS_BEST: order[refIx] = RefIxSrt[refIx] (burst.c:3688-3693; the reference's BEST prefers the
+ * lower original reference number among equally good hits, burst.c:4865-4868), n = tot_refs.  Copied to the device.  order = NULL:
+ * nothing is changed, the return value says whether the handle holds a table (1) or not (0). */
+BHIP_API int bhip_set_ref_order(void *handle, const uint32_t *order, uint32_t n);
 
 /* Pipelined staging for a batch scheduler (the replacement of the OpenMP loops burst.c:4050-4078 / 4326-4344 hands batch k+1
  * to the device while batch k is being aligned).  A batch is given as up to a few SPANS of consecutive entries of the caller's
@@ -277,7 +288,7 @@ BHIP_API int bhip_sort_queries(int device, const uint8_t *codes, uint64_t codes_
  * ceil(K/s) of them), fewest .acx look-ups with the same no-false-negative guarantee; s >= 1 forces every s-th word,
  * 1 = every word = the reference's own threshold count > len-(E+1)K (burst.c:4091-4092, 4126).
  * "two_stage": 1 (default) = prefix filter + windowed full-length edit distance, 0 = one full-length sweep.
- * "lanes": 1..16 (default 1) sub-pipelines a staged batch is cut into; their prefilter / sweep / window+re-score stages
+ * "lanes": 1..15 (default 1) sub-pipelines a staged batch is cut into; their prefilter / sweep / window+re-score stages
  * run as a software pipeline on three HIP streams; "lane_min_entries" (default 32768) = fewest entries worth a lane.
  * "sweep_blocks": 1..8 workgroups per CU of the sweep kernels.  "lane_masks": 1 (default) = lane-resolved prefilter.
  * "prefilter_table": 0 (default, chosen from the accelerator's list lengths) or 9/10/11 = log2 slots of the per-query
@@ -314,7 +325,7 @@ BHIP_API void bhip_destroy(void *handle);
 BHIP_API const char *bhip_last_error(void);
 /* ABI version of this header */
 BHIP_API int bhip_abi_version(void);
-#define BHIP_ABI_VERSION 7
+#define BHIP_ABI_VERSION 8
 
 #ifdef __cplusplus
 }

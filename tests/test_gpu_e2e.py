@@ -132,6 +132,14 @@ def test_database_shards_on_one_device_equal_whole(mode, ident):
         parts = [h[h["ed"] == gmin[six[h["q"]]]] for h in parts]
     got = np.concatenate(parts)
     got = got[np.lexsort((got["refIx"], got["q"]))]
+    if mode == "BEST":
+        # -m BEST keeps ONE record per entry on the device (BHIP_HITS_BEST: higher score, then lower RefIxSrt, burst.c:4847-4891), every shard
+        # its own; of the shards' survivors the same rule must leave the whole database's choice
+        order = host._view(db.c.refIxSrt, db.c.totR, np.uint32)
+        pick = np.lexsort((order[got["refIx"]], -got["score"].astype(np.float64), got["q"]))
+        got = got[pick]
+        got = got[np.concatenate(([True], got["q"][1:] != got["q"][:-1]))]
+        assert len(whole) == len(np.unique(whole["q"]))
     assert got.tobytes() == whole[np.lexsort((whole["refIx"], whole["q"]))].tobytes()
 
 

@@ -118,6 +118,76 @@ def test_many_records_per_query_come_out_in_the_oracle_order(n_var):
     dev.close()
 
 
+def test_one_long_read_does_not_move_the_others_to_the_long_kernel(capfd, monkeypatch):
+    """Reads of 513 .. 1 024 symbols keep the register kernel of 32 words (k_myers<32>) when ONE read of the batch is longer than 1 024
+    symbols: the long ones are a length class of their own (round 6; before, the last class took the word count of the lane's longest
+    query and every read in it went through k_myers_long).  Records against the oracle, the classes from the library's debug lines."""
+    from burst_amd import capi
+    seqs = family_db(4242, 3, 5, 3300, short=False)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lut = ol.score_lut(1)
+    dev = capi.Device(packed, clump_len, tot, lut)
+    reads = []
+    for n, qlen, edits, seed in ((6, 600, [0, 5], 1), (6, 1000, [0, 9], 2), (1, 3000, [12], 3), (8, 100, [0, 2], 4)):
+        reads += synth.make_reads(seqs, n, qlen, edits, 4242 + seed, rc_frac=0.0)[0]
+    E = [budget(0.98, len(r)) for r in reads]
+    q = capi.Queries(reads, E, list(range(len(reads))), [0] * len(reads))
+    monkeypatch.setenv("BHIP_DEBUG", "1")
+    capfd.readouterr()
+    got = dev.align_batch(q, all_hits=False)
+    err = capfd.readouterr().err
+    monkeypatch.delenv("BHIP_DEBUG")
+    exp = oracle_hits(packed, clump_len, tot, q, lut, False)
+    assert len(exp) >= len(reads)
+    assert_hits_equal(got, exp)
+    cls = {int(ln.split("class NW=")[1].split(":")[0]): ln for ln in err.splitlines() if "class NW=" in ln}
+    assert 32 in cls and "exhaustive 12 " in cls[32], cls                 # the twelve 600- and 1 000-symbol reads: the 32-word class
+    assert 128 in cls and "exhaustive 1 " in cls[128], cls                # the 3 000-symbol read alone in the class beyond 1 024 symbols
+    assert 4 in cls
+    dev.close()
+
+
+@pytest.mark.parametrize("n_var,with_acx", [(40, False), (150, False), (90, True)])
+def test_best_record_per_entry_chosen_on_the_device(n_var, with_acx):
+    """all_hits = 2 (BHIP_HITS_BEST): of an entry's minimum-edit records the device returns the ONE the reference's BEST scan keeps --
+    higher f32 score, then lower RefIxSrt[refIx] (burst.c:4847-4891) -- computed here from the oracle's full record set with a random
+    permutation as RefIxSrt.  Families of near-identical references: dozens of equally good records per entry, both strands."""
+    from burst_amd import capi
+    seqs = family_db(900 + n_var, 2, n_var, 260, rate=0.004)
+    packed, clump_len, tot = dbutil.pack_clumps(seqs)
+    lut = ol.score_lut(1)
+    kw = {}
+    if with_acx:
+        lens, entries, _ = dbutil.build_acx(seqs, 10)
+        kw = dict(acx_lens=lens, acx_lists=dbutil.pack_acx_lists(lens, entries, 0), acx_fmt=0, K=10)
+    dev = capi.Device(packed, clump_len, tot, lut, **kw)
+    q, _ = make_queries(seqs, 30, 100, [0, 1, 2, 3], 900 + n_var, thres=0.95)
+    with pytest.raises(capi.BurstHipError):
+        dev.align_batch(q, all_hits=2)                    # no table yet
+    order = np.random.default_rng(n_var).permutation(tot).astype(np.uint32)
+    dev.set_ref_order(order)
+    exp_all = oracle_hits(packed, clump_len, tot, q, lut, False)
+    assert np.bincount(exp_all["q"]).max() > 20
+    # the reference's choice inside each entry: ed is the same for all of an entry's records here; max score, then min order
+    keep = {}
+    for r in exp_all:
+        k = int(r["q"])
+        b = keep.get(k)
+        if b is None or r["ed"] < b["ed"] or (r["ed"] == b["ed"] and (r["score"] > b["score"] or (r["score"] == b["score"] and order[r["refIx"]] < order[b["refIx"]]))):
+            keep[k] = r
+    exp = np.array([keep[k] for k in sorted(keep)], dtype=exp_all.dtype)
+    got = dev.align_batch(q, all_hits=2)
+    assert len(got) == len(exp) == len(set(exp_all["q"].tolist()))
+    assert_hits_equal(got, exp)
+    assert_hits_equal(dev.align_batch(q, all_hits=False), exp_all)      # (and the plain mode is untouched by the table)
+    # a caller's buffer that is too small: the count comes back, the resident records are delivered by the next call
+    dev.stage(q)
+    small = np.zeros(3, dtype=capi.HIT_DTYPE)
+    got2, _ = dev.align_staged(all_hits=2, out=small)
+    assert_hits_equal(got2, exp)
+    dev.close()
+
+
 @pytest.mark.parametrize("qlen,edits,thres,seed", [(1025, [0, 3, 20], 0.98, 61), (1500, [0, 10, 44], 0.97, 62), (2600, [0, 25], 0.99, 63), (4050, [0, 12, 40], 0.99, 64)])
 def test_queries_beyond_1024_symbols(qlen, edits, thres, seed):
     """k_myers_long (vector in LDS, any number of words up to BHIP_MAX_QLEN symbols): the sweep on its own against aded of the oracle,
