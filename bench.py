@@ -166,6 +166,21 @@ def pick_setup(args, free_hbm, want_cpu_baseline, world=1):
     return 0.5, dirs[-1]
 
 
+# What FETCH_SIZE means on gfx950, measured on the prefilter's own access pattern (round 6; tools/calibrate_fetch.sh runs
+# tools/ubench/run_gather -- runs of N consecutive dwords at random 4-byte-aligned addresses, 64 adjacent lanes on 64 adjacent
+# positions, every byte and every line known to the host -- under rocprofv3 --pmc FETCH_SIZE).
+TRAFFIC_CALIBRATION = {
+    "source": "profiles/r06e_fetch_calibration_runs.txt (tools/calibrate_fetch.sh)",
+    "finding": "FETCH_SIZE x 1024 = 64 B x the number of DISTINCT 128-BYTE LINES a dispatch requests, whatever the pattern: ratio 0.500 / 0.500 / 0.503 / 0.503 "
+               "against the known line count for runs of 1 / 16 / 40 / 164 dwords (single dwords: = 1.000 x 64-byte sectors, which is what profiles/r02k_fetch_calibration.txt "
+               "saw and rounds 2-5 took for 'the counter is exact for gathers')",
+    "reading": "`traffic` (2 x FETCH_SIZE + WRITE_SIZE) = the bytes of every requested line = what moved if lines move whole; `traffic_half_lines` (FETCH_SIZE + WRITE_SIZE) = one "
+               "64-byte half per requested line, what moved if a line of which one half is wanted moves that half only.  The counter cannot tell the two apart; a list of "
+               "~41 four-byte records at a random address spans 2.25 lines but 3.5 64-byte sectors, so the truth for k_prefilter_cq lies between the two and both are above "
+               "the device-record bytes only in the first reading",
+}
+
+
 def db_paths(workdir, args):
     args.db_qlen = args.read_len + max(10, args.read_len // 10)
     tag = "b%d_v%d_l%d_q%d_i%s_k%d%s" % (args.n_base, args.n_variants, args.ref_len, args.db_qlen, args.id, args.K, "" if getattr(args, "db_profile", "pairs") == "pairs" else "_" + args.db_profile)
@@ -585,6 +600,9 @@ def main():
     ap.add_argument("--workdir", default=os.environ.get("BURST_BENCH_DIR"), help="where the database, the reads and the reference's .acx are written (default: /dev/shm/burst_amd_bench when "
                     "/dev/shm has the room a large database needs, else /tmp/burst_amd_bench)")
     ap.add_argument("--no-continuity", action="store_true", help="skip the extra run on the small database of rounds 1-3 (key `continuity_small_db`)")
+    ap.add_argument("--no-strains", action="store_true", help="skip the extra run on a database with strain-level redundancy (key `strains`: --db-profile strains at --strains-scale, with the reference beside it)")
+    ap.add_argument("--strains-scale", default="1", help="database size of the `strains` leg in units of --db-scale (default 1 = 2.6 GB of .edx: the leg must fit the default run's few minutes; "
+                    "the regime -- lane tasks and records per read -- does not depend on the size, the prefilter's share does: profiles/ keeps a 30 GB run)")
     ap.add_argument("--keep-files", action="store_true", help="leave the large files (reference FASTA, .acx) in the work directory")
     ap.add_argument("--cpu-sample", type=int, default=600000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -971,8 +989,8 @@ def main():
             pk = pmc_of(k)
             if pk.get("hbm_bytes_per_launch") is not None:
                 e["traffic"] = pk["hbm_bytes_per_launch"]
-                if v[2] == "hbm" and pk.get("hbm_bytes_per_launch_gather_calibrated"):      # sector gathers: profiles/r02k_fetch_calibration.txt
-                    e["traffic_gather_calibrated"] = pk["hbm_bytes_per_launch_gather_calibrated"]
+                if v[2] == "hbm" and pk.get("hbm_bytes_per_launch_gather_calibrated"):      # the other bound: one 64-byte half per requested line (TRAFFIC_CALIBRATION below)
+                    e["traffic_half_lines"] = pk["hbm_bytes_per_launch_gather_calibrated"]
             if pk.get("valu_frac") is not None:
                 e["valu_frac"] = pk["valu_frac"]
                 w = valu_weight(k)
@@ -1016,16 +1034,19 @@ def main():
                        "device": info["name"], "n_cu": info["n_cu"]},
             "roofline": {"bound": "hbm" if bound_dom == "hbm" else "valu", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": pmc_of(dom).get("hbm_bytes_per_launch"), "pmc_source": pmc_source,
-                         "traffic_gather_calibrated": pmc_of(dom).get("hbm_bytes_per_launch_gather_calibrated") if bound_dom == "hbm" else None,
+                         "traffic_half_lines": pmc_of(dom).get("hbm_bytes_per_launch_gather_calibrated") if bound_dom == "hbm" else None,
+                         "traffic_calibration": dict(TRAFFIC_CALIBRATION, device_record_bytes_per_launch=(
+                             (st["acx_entries_read"] * 4.0 + st["n_seed_words"] * 8.0 + st["n_lane_tasks"] * 8.0) / max(1, st["prefilter_launches"]) if dom.startswith("k_prefilter") else None)),
                          "note": "achieved / frac are measured by THIS run (HIP events); traffic, valu_frac and the other counter-derived fields come from the kept profiling pass named in pmc_source (an earlier run of the same kernels), null when that table is refused. Dominant kernel by time on the critical path (HIP events on its stream; k_seed_ranges works for the next batch beside the chain, throttled: off_critical_path in per_kernel); per_kernel gives each kernel's own bound: the prefilter and the re-scorer are "
-                                 "bound by HBM/LDS latency of short gathers, the k_myers_* sweeps by integer VALU issue (valu_frac = issued VALU instructions x 2 cycles / peak, from the PMC pass; half-rate VOP3 forms count once). traffic follows the guide's 2 x FETCH_SIZE rule; traffic_gather_calibrated = FETCH_SIZE + WRITE_SIZE, which is what a sector gather really moves (profiles/r02k_fetch_calibration.txt)",
+                                 "bound by HBM/LDS latency of short gathers, the k_myers_* sweeps by integer VALU issue (valu_frac = issued VALU instructions x 2 cycles / peak, from the PMC pass; half-rate VOP3 forms count once). traffic follows the guide's 2 x FETCH_SIZE rule = the bytes of every 128-byte line the kernel REQUESTED (an upper bound of what moved); traffic_half_lines = FETCH_SIZE + WRITE_SIZE = one 64-byte half per requested line (the lower bound): see traffic_calibration (round 6; rounds 2-5 read the second as 'what a sector gather really moves', profiles/r02k_fetch_calibration.txt)",
                          "algorithmic_bytes_per_launch": bytes_dom, "ms_per_launch": ms_dom,
                          "per_kernel": per_kernel,
                          "gcups_sweeps": cells / (ms_sweeps * 1e-3) / 1e9 if ms_sweeps > 0 else 0.0},
-            "phases_ms_per_batch": {k: per(k) for k in ("ms_h2d", "ms_peq", "ms_prefilter", "ms_seed", "ms_prefilter_hash", "ms_myers", "ms_myers_prefix", "ms_myers_window", "ms_rescore", "ms_d2h", "ms_total")},
+            "phases_ms_per_batch": {k: per(k) for k in ("ms_h2d", "ms_stage_copy", "ms_stage_route", "ms_peq", "ms_prefilter", "ms_seed", "ms_prefilter_hash", "ms_myers", "ms_myers_prefix", "ms_myers_window", "ms_rescore", "ms_d2h", "ms_total")},
             "work": {"records": n_records, "entries_per_batch": st["n_queries"] / nb, "raw_hits": st["n_raw_hits"], "hits": st["n_hits"],
                      "acx_entries_per_read": st["acx_entries_read"] / max(1.0, float(st["n_queries"])), "windows": st["n_windows"], "window_columns": st["n_window_columns"],
                      "lane_tasks_per_read": st["n_lane_tasks"] / max(1.0, float(st["n_queries"])), "task_columns": st["n_task_columns"],
+                     "raw_hits_per_read": st["n_raw_hits"] / max(1.0, float(st["n_queries"])), "records_per_read": st["n_hits"] / max(1.0, float(st["n_queries"])),
                      "seed_words_per_read": st["n_seed_words"] / max(1.0, float(st["n_queries"]))},
             "host": {"db_read_s": t_db, "device_upload_s": t_dev, "query_ingest_s": t_q, "sec_in_device_calls": sec_align},
         }
@@ -1172,6 +1193,29 @@ def main():
                                               "what": "the database of rounds 1-3 (BENCH_r03: 556 M reads/s), same steps, same kernels"}
             except Exception as e:
                 res["continuity_small_db"] = {"error": str(e)}
+        if world == 1 and not args.no_strains and args.db_profile == "pairs" and args.db_scale > 1.5:
+            # The redundancy regime, driver-timed (round 5's verdict: the headline's stand-in is low-redundancy on purpose; a database with
+            # families of near-identical strains moves the work from the prefilter to the sweeps and the rate by an order of magnitude, while
+            # the reference does not move).  A child process with its own database; its reference leg and parity check included.
+            try:
+                t = time.time()
+                cmd = [sys.executable, os.path.abspath(__file__), "--db-profile", "strains", "--db-scale", str(args.strains_scale), "--steps", str(max(4, args.steps // 2)), "--warmup", str(min(args.warmup, 3)),
+                       "--reads", str(args.reads), "--pool", str(args.pool), "--cpu-sample", "100000", "--no-end-to-end", "--no-continuity", "--no-strains", "--no-short-job",
+                       "--workdir", os.path.join(args.workdir, "strains")] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + [x for kv in args.opt for x in ("--opt", kv)]
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                cb = d.get("cpu_baseline") or {}
+                res["strains"] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "workload": d["config"]["workload"],
+                                  "lane_tasks_per_read": d["work"]["lane_tasks_per_read"], "lanes_within_budget_per_read": d["work"]["raw_hits_per_read"], "records_delivered_per_read": d["work"]["records_per_read"],
+                                  "phases_ms_per_batch": d["phases_ms_per_batch"],
+                                  "reference_reads_per_s": cb.get("value"), "reference_cores": cb.get("cores"), "parity_vs_reference": d.get("parity_vs_reference"),
+                                  "seconds_spent": time.time() - t,
+                                  "what": "--db-profile strains (70 % of the content as the headline's pairs, 30 % in families of 60 / 200 / 500 strains at 1 / 0.5 / 0.1 % divergence), same reads per step, "
+                                          "-m BEST with the choice made on the device; the 30 GB run of this profile is kept under profiles/"}
+                import shutil
+                shutil.rmtree(os.path.join(args.workdir, "strains"), ignore_errors=True)
+            except Exception as e:
+                res["strains"] = {"error": str(e)}
         if want_rccl:
             res["rccl"] = rccl_early if world == 1 else rccl_guarded(res)
             # (the driver's parsed view keeps `config` and the top-level scalars: whether RCCL saw N ranks must be answerable from there)

@@ -31,6 +31,7 @@ class BhipStats(C.Structure):
                 ("ms_h2d", C.c_float), ("ms_prefilter", C.c_float), ("ms_peq", C.c_float), ("ms_myers", C.c_float),
                 ("ms_rescore", C.c_float), ("ms_d2h", C.c_float), ("ms_total", C.c_float),
                 ("ms_myers_prefix", C.c_float), ("ms_myers_window", C.c_float), ("ms_prefilter_hash", C.c_float), ("ms_seed", C.c_float),
+                ("ms_stage_copy", C.c_float), ("ms_stage_route", C.c_float),
                 ("myers_launches", C.c_uint32), ("prefix_words", C.c_uint32), ("prefilter_launches", C.c_uint32), ("prefilter_algo", C.c_uint32)]
 
     def as_dict(self):
@@ -54,10 +55,20 @@ class BurstHipError(RuntimeError):
         self.code = code
 
 
+LOAD_LEGACY_PREFILTERS = False
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: the HIP extension has not been built (run __graft_entry__.build()); "
                           "burst_amd has no CPU fallback" % LIB_PATH)
+    # The superseded prefilter kernels (options prefilter_cw = 0 / 1) are NOT in libburst_hip.so: the tests ask for the test-only library
+    # that holds them (tests/conftest.py sets LOAD_LEGACY_PREFILTERS in THIS process; child processes -- bench.py, burst_hip -- run the
+    # product library alone).  Loaded first and globally, so that the product library's two weak references (bhip_internal.h:
+    # bhip_legacy_pf_launch / _attrs) resolve to it.
+    legacy = os.path.join(os.path.dirname(LIB_PATH), "libburst_hip_legacy.so")
+    if LOAD_LEGACY_PREFILTERS and os.path.exists(legacy):
+        globals()["_legacy_lib"] = C.CDLL(legacy, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     lib.bhip_init.argtypes = [i32, vp, vp, u32, u32, vp, vp, i32, i32, vp, u32, vp, i32, C.POINTER(vp)]

@@ -408,14 +408,18 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	const bool cw = algo == 0 && h->opt_pf_cw;      // k_prefilter_cw / k_prefilter_cq: the slot layout follows the number of lists a query can have
 	const int cw_mode = W16 <= 8 ? 0 : W16 <= 16 ? 1 : 2;
 	const bool cq = cw && h->opt_pf_cw == 2 && cw_mode < 2;      // four queries per wave, streams walked by the whole wave (up to 16 lists per query)
+	// (the superseded counting-filter kernels -- k_prefilter_cf, k_prefilter_cw<0 / 1>: options prefilter_cw = 0 / 1 -- are not in this library:
+	// libburst_hip_legacy.so, which the tests load in front of it, provides them through two weak symbols)
+	const bool legacy = algo == 0 && !cq && !(cw && cw_mode == 2);
+	if (legacy && (!bhip_legacy_pf_launch || !bhip_legacy_pf_attrs))
+		return fail(BHIP_E_ARG, "option prefilter_cw = %d selects a superseded prefilter kernel that is not part of libburst_hip.so (tests: libburst_hip_legacy.so is loaded first)", h->opt_pf_cw);
 	{
 		const void *fp = cq ? (cw_mode == 0 ? (const void *)k_prefilter_cq<0, 0> : (const void *)k_prefilter_cq<1, 0>)
-			: cw ? (cw_mode == 0 ? (const void *)k_prefilter_cw<0, 0> : cw_mode == 1 ? (const void *)k_prefilter_cw<1, 0> : (const void *)k_prefilter_cw<2, 0>)
-			: algo == 0
-			? (htb == 9 ? (rb == 2 ? (const void *)k_prefilter_cf<9, 2> : rb == 3 ? (const void *)k_prefilter_cf<9, 3> : (const void *)k_prefilter_cf<9, 4>)
-			   : htb == 10 ? (rb == 2 ? (const void *)k_prefilter_cf<10, 2> : (const void *)k_prefilter_cf<10, 4>) : (rb == 2 ? (const void *)k_prefilter_cf<11, 2> : (const void *)k_prefilter_cf<11, 4>))
+			: cw && cw_mode == 2 ? (const void *)k_prefilter_cw<2, 0>
+			: algo == 0 ? nullptr
 			: (htb == 9 ? (const void *)k_prefilter_mask<9> : htb == 10 ? (const void *)k_prefilter_mask<10> : (const void *)k_prefilter_mask<11>);
-		if (hipFuncGetAttributes(&fa, fp) != hipSuccess) { fa.sharedSizeBytes = 48 * 1024; fa.numRegs = 128; }
+		if (legacy) { size_t lds = 0; int regs = 0; if (bhip_legacy_pf_attrs(cw ? 1 : 0, htb, rb, cw_mode, &lds, &regs)) { lds = 48 * 1024; regs = 128; } fa.sharedSizeBytes = lds; fa.numRegs = regs; }
+		else if (hipFuncGetAttributes(&fa, fp) != hipSuccess) { fa.sharedSizeBytes = 48 * 1024; fa.numRegs = 128; }
 	}
 	const uint32_t by_lds = (148u * 1024u) / (uint32_t)std::max<size_t>(512, (fa.sharedSizeBytes + 511) & ~(size_t)511);
 	const uint32_t by_reg = 4u * (512u / (uint32_t)std::max(8, (fa.numRegs + 7) & ~7));
@@ -427,49 +431,45 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
 	const uint32_t waves = h->opt_pf_waves ? std::min<uint32_t>((uint32_t)h->opt_pf_waves, fit) : fit;
 	const uint32_t grid = std::min<uint32_t>(cw && !cq ? n_list : n_quads, (uint32_t)h->n_cu * waves);
 	HIPCHK(hipEventRecord(L->ev_pf[cls][1], st));
-	if (cw) {
+	if (cw || algo == 0) {
+		// first pass, then the queries whose survivors overflowed its exact lane table once more with the largest tables (BIG / <11, 4>);
+		// an empty second pass costs ~10 us, the dense per-clump fallback behind it 12 ms per launch at 6.8 M clumps whatever the number of queries
 #define PFW_ARGS(FB, NFB, SEL, NSEL) L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list, \
 		h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, \
 		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
 		FB, NFB, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum, \
 		L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], prune, SEL, NSEL, 0
-		// first pass, then the queries whose survivors overflowed its 64-slot lane table once more with four times the slots and the table
-		if (cq && cw_mode == 0) hipLaunchKernelGGL((k_prefilter_cq<0, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
-		else if (cq) hipLaunchKernelGGL((k_prefilter_cq<1, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
-		else if (cw_mode == 0) hipLaunchKernelGGL((k_prefilter_cw<0, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
-		else if (cw_mode == 1) hipLaunchKernelGGL((k_prefilter_cw<1, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
-		else hipLaunchKernelGGL((k_prefilter_cw<2, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
-		HIPCHK(hipGetLastError());
-		const uint32_t g2 = (uint32_t)h->n_cu;
-		if (cq && cw_mode == 0) hipLaunchKernelGGL((k_prefilter_cq<0, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
-		else if (cq) hipLaunchKernelGGL((k_prefilter_cq<1, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
-		else if (cw_mode == 0) hipLaunchKernelGGL((k_prefilter_cw<0, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
-		else if (cw_mode == 1) hipLaunchKernelGGL((k_prefilter_cw<1, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
-		else hipLaunchKernelGGL((k_prefilter_cw<2, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
-#undef PFW_ARGS
-		fb_dense = fb2; n_fb_dense = &dc->n_fb2;
-	} else
-	if (algo == 0) {
-#define PFC_LAUNCH(B, R) hipLaunchKernelGGL((k_prefilter_cf<B, R>), dim3(grid), dim3(64), 0, st, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list, \
-		h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, \
-		h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read, \
-		fb1, &dc->n_fb, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum, \
-		L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], prune, (const uint32_t *)nullptr, (const uint32_t *)nullptr, h->opt_pf_bytes)
-		if (htb == 9) { if (rb == 2) PFC_LAUNCH(9, 2); else if (rb == 3) PFC_LAUNCH(9, 3); else PFC_LAUNCH(9, 4); }
-		else if (htb == 10) { if (rb == 2) PFC_LAUNCH(10, 2); else PFC_LAUNCH(10, 4); }
-		else { if (rb == 2) PFC_LAUNCH(11, 2); else PFC_LAUNCH(11, 4); }
-#undef PFC_LAUNCH
-		if (htb != 11) {
-			// second pass: the few queries whose record stream overflowed the exact lane table of the first pass (50 of 2 M at the
-			// metric's database size) once more through the same kernel with its largest tables -- the dense per-clump fallback
-			// behind it costs 12 ms per launch at 6.8 M clumps, whatever the number of queries
+		// the second pass of a strain-rich batch is not a handful of queries (round 5 gave it one block per CU): as many blocks as fit
+		const uint32_t g2 = (uint32_t)h->n_cu * std::max<uint32_t>(1u, std::min<uint32_t>(4u, blocks_per_cu(cw_mode == 0 ? (const void *)k_prefilter_cq<0, 1> : (const void *)k_prefilter_cq<1, 1>, 64u, 0)));
+		const bool two_pass = cw || htb != 11;
+		if (legacy) {
+			BhipPfLaunch a;
+			memset(&a, 0, sizeof a);
+			a.kind = cw ? 1 : 0; a.htb = htb; a.rb = rb; a.cw_mode = cw_mode; a.big = 0; a.grid = grid; a.stream = (void *)st;
+			a.ranges = L->ranges_c[cls].as<uint2>(); a.hdr = L->hdr_c[cls].as<uint2>(); a.W16 = W16; a.n_list = n_list; a.ent = h->acx_view().rec; a.bad = h->bad.as<uint32_t>(); a.n_bad = h->n_bad;
+			a.clump_len = h->clump_len.as<uint32_t>(); a.tot_refs = h->tot_refs; a.tasks = L->tasks.as<uint2>(); a.n_tasks = n_tasks_dev; a.task_cap = (uint32_t)L->task_cap; a.ent_read = &dc->ent_read;
+			a.fb = fb1; a.n_fb = &dc->n_fb; a.unit_sum = &dc->unit_sum; a.col_sum = &dc->col_sum; a.qlen_sum = &dc->qlen_sum; a.surv_sum = &dc->surv_sum;
+			a.tasks2 = L->tasks2.as<uint2>(); a.n_tasks2 = &dc->n_tasks2_cls[cls]; a.prune = prune; a.sel = nullptr; a.n_sel = nullptr; a.bytes = cw ? 0 : h->opt_pf_bytes;
+			if (bhip_legacy_pf_launch(&a)) return fail(BHIP_E_DEVICE, "launch of a legacy prefilter kernel failed");
+			if (two_pass) {
+				a.big = 1; a.htb = 11; a.rb = 4; a.grid = (uint32_t)h->n_cu; a.fb = fb2; a.n_fb = &dc->n_fb2; a.sel = fb1; a.n_sel = &dc->n_fb;
+				if (bhip_legacy_pf_launch(&a)) return fail(BHIP_E_DEVICE, "launch of a legacy prefilter kernel failed");
+			}
+		} else if (cq && cw_mode == 0) {
+			hipLaunchKernelGGL((k_prefilter_cq<0, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
 			HIPCHK(hipGetLastError());
-			hipLaunchKernelGGL((k_prefilter_cf<11, 4>), dim3((uint32_t)h->n_cu), dim3(64), 0, st, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list,
-				h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, h->clump_len.as<uint32_t>(), h->tot_refs, L->tasks.as<uint2>(), n_tasks_dev, (uint32_t)L->task_cap, &dc->ent_read,
-				fb2, &dc->n_fb2, &dc->unit_sum, &dc->col_sum, &dc->qlen_sum, &dc->surv_sum, L->tasks2.as<uint2>(), &dc->n_tasks2_cls[cls], prune,
-				(const uint32_t *)fb1, (const uint32_t *)&dc->n_fb, h->opt_pf_bytes);
-			fb_dense = fb2; n_fb_dense = &dc->n_fb2;
+			hipLaunchKernelGGL((k_prefilter_cq<0, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
+		} else if (cq) {
+			hipLaunchKernelGGL((k_prefilter_cq<1, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
+			HIPCHK(hipGetLastError());
+			hipLaunchKernelGGL((k_prefilter_cq<1, 1>), dim3(g2), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
+		} else {      // plans beyond 16 lists per query: one query per wave
+			hipLaunchKernelGGL((k_prefilter_cw<2, 0>), dim3(grid), dim3(64), 0, st, PFW_ARGS(fb1, &dc->n_fb, (const uint32_t *)nullptr, (const uint32_t *)nullptr));
+			HIPCHK(hipGetLastError());
+			hipLaunchKernelGGL((k_prefilter_cw<2, 1>), dim3((uint32_t)h->n_cu), dim3(64), 0, st, PFW_ARGS(fb2, &dc->n_fb2, (const uint32_t *)fb1, (const uint32_t *)&dc->n_fb));
 		}
+#undef PFW_ARGS
+		if (two_pass) { fb_dense = fb2; n_fb_dense = &dc->n_fb2; }
 	} else {
 #define PFM_LAUNCH(B) hipLaunchKernelGGL(k_prefilter_mask<B>, dim3(grid), dim3(64), 0, st, L->ranges_c[cls].as<uint2>(), L->hdr_c[cls].as<uint2>(), W16, n_list, \
 		h->acx_view().rec, h->bad.as<uint32_t>(), h->n_bad, \
@@ -1090,7 +1090,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits_arg, BhipHit *hits, 
 		HIPCHK(hipEventRecord(h->ev[9], h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		if (dbg_t) fprintf(stderr, "[bhip] delivery host ms: reserve+memset %.3f, sort launches %.3f, pointer check %.3f, copy enqueue %.3f, sync %.3f\n", tq1, tq2 - tq1, tq3 - tq2, tq4 - tq3, tq() - tq4);
-		S.ms_h2d = h->cur->st_ms_h2d; S.ms_d2h = ev_ms(h->ev[8], h->ev[9]) + (sorted_ahead ? ev_ms(h->ev[4], h->ev[5]) : 0.0f); S.ms_total = ev_ms(h->ev[0], h->ev[9]);
+		S.ms_h2d = h->cur->st_ms_h2d; S.ms_stage_copy = h->cur->st_ms_copy; S.ms_stage_route = h->cur->st_ms_route; S.ms_d2h = ev_ms(h->ev[8], h->ev[9]) + (sorted_ahead ? ev_ms(h->ev[4], h->ev[5]) : 0.0f); S.ms_total = ev_ms(h->ev[0], h->ev[9]);
 		slot->state = 2;
 		h->res_valid = false;
 		return BHIP_OK;

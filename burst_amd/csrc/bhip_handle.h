@@ -241,13 +241,13 @@ struct StageSlot {
 	DBuf qcodes, qcodes4, qlen16, qoff, qemac, qsix, qrc, qflags, qmap, off_raw, plan, qpack, key, key_sorted, idx, idx_sorted, sort_tmp, info;
 	DBuf qcodes_s, qoff_s, qemac_s, qpack_s, nx, nx_six;
 	BhipStageInfo *info_pinned = nullptr;
-	hipEvent_t ev_begin = nullptr, ev_done = nullptr;
+	hipEvent_t ev_begin = nullptr, ev_done = nullptr, ev_copied = nullptr;      // staging: start, end, and the point between the copies and the routing kernels
 	int state = 0;                        // 0 empty, 1 staged (not aligned yet), 2 active (aligned; may be run again)
 	uint64_t seq = 0;
 	bool resolved = false;                // routing read back, lists assigned
 	bool st_valid = false, st_has_six = false, st_has_rc = false, st_has_junk = false, has_flags = false, has_qmap = false;
 	uint32_t st_nq = 0, st_nshared = 0, st_maxlen = 0, st_maxE = 0, st_lanes = 1;
-	float st_ms_h2d = 0;
+	float st_ms_h2d = 0, st_ms_copy = 0, st_ms_route = 0;
 	std::vector<BhipQuerySpan> spans;     // the caller's arrays (valid until the batch has been aligned): the host pass reads them
 	const uint32_t *six_explicit = nullptr;
 	uint32_t npf[16][BHIP_N_CLASSES], nex[16][BHIP_N_CLASSES], maxE[16][BHIP_N_CLASSES], maxwords[16][BHIP_N_CLASSES], qlist_off[16][BHIP_N_CLASSES], maxlen_lane[16], n_entries_lane[16];
@@ -259,6 +259,7 @@ struct StageSlot {
 		if (info_pinned) { (void)hipHostFree(info_pinned); info_pinned = nullptr; }
 		if (ev_begin) { (void)hipEventDestroy(ev_begin); ev_begin = nullptr; }
 		if (ev_done) { (void)hipEventDestroy(ev_done); ev_done = nullptr; }
+		if (ev_copied) { (void)hipEventDestroy(ev_copied); ev_copied = nullptr; }
 	}
 };
 

@@ -106,6 +106,21 @@ struct BhipStageInfo {
 	uint32_t maxE_all, maxlen_all;
 };
 
+// A launch of one of the SUPERSEDED counting-filter prefilter kernels (k_prefilter_cf<CB, RB>, k_prefilter_cw<0 / 1, BIG>: options
+// prefilter_cw = 0 / 1).  They are not part of libburst_hip.so: bhip_prefilter_legacy.hip builds them into libburst_hip_legacy.so, which
+// the tests load in front of the product library; the product reaches them through these two WEAK symbols and refuses the options when
+// they are not there.  Same arguments as k_prefilter_cq.
+struct BhipPfLaunch {
+	int kind;                              // 0 = k_prefilter_cf<htb, rb>, 1 = k_prefilter_cw<cw_mode, big>
+	int htb, rb, cw_mode, big;
+	uint32_t grid; void *stream;
+	const uint2 *ranges, *hdr; uint32_t W16, n_list; const uint32_t *ent, *bad; uint32_t n_bad; const uint32_t *clump_len; uint32_t tot_refs;
+	uint2 *tasks; uint32_t *n_tasks; uint32_t task_cap; unsigned long long *ent_read; uint32_t *fb, *n_fb;
+	unsigned long long *unit_sum, *col_sum, *qlen_sum, *surv_sum; uint2 *tasks2; uint32_t *n_tasks2; int prune; const uint32_t *sel, *n_sel; int bytes;
+};
+extern "C" int bhip_legacy_pf_attrs(int kind, int htb, int rb, int cw_mode, size_t *lds_bytes, int *regs) __attribute__((weak));      // 0 = ok
+extern "C" int bhip_legacy_pf_launch(const BhipPfLaunch *a) __attribute__((weak));                                                   // hipError_t of the launch
+
 #define BHIP_RESCORE_WMAX 48   // band widths up to this many diagonals are handled in LDS
 
 // ------------------------------------------------------------------------------------------------

@@ -137,2060 +137,6 @@ __global__ __launch_bounds__(256) void k_build_peq(const uint8_t *__restrict__ q
 }
 
 // ------------------------------------------------------------------------------------------------
-// Prefilter (burst.c:4096-4133 + postScour 3238-3282, per query instead of per bunch of 16).
-// counter[c] = number of query k-mer positions whose word occurs in clump c.  A clump is a candidate iff
-// counter > mmatch, mmatch = max(len - (E+1)K, 0): every alignment with <= E edits keeps at least
-// len-K+1-E*K = mmatch+1 intact words (burst.c:4091-4092, 4163-4164), so no valid clump is dropped.
-// Words containing a symbol outside A/C/G/T are skipped here; the host routes such queries to the
-// exhaustive path.
-// ------------------------------------------------------------------------------------------------
-template <bool LDS_CNT>
-__global__ __launch_bounds__(256) void k_prefilter(
-		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint16_t *__restrict__ qemac,
-		const uint32_t *__restrict__ qlist, uint32_t n_list,
-		BhipAcxView acx, int K, uint32_t n_clumps,
-		uint32_t *__restrict__ g_cnt, const uint32_t *__restrict__ bad, uint32_t n_bad,
-		uint2 *__restrict__ cand, uint32_t *__restrict__ cand_cnt_out, uint32_t *__restrict__ n_cand, uint32_t cand_cap,
-		unsigned long long *__restrict__ ent_read, const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel_dev,
-		const uint32_t *__restrict__ plan) {   // plan made with stride 1 for this kernel
-	extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];
-	const uint32_t nw32 = (n_clumps + 1) >> 1;
-	uint32_t *cnt = LDS_CNT ? s_cnt : g_cnt + (uint64_t)blockIdx.x * nw32;
-	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
-	unsigned long long my_ent = 0;
-	const uint32_t n_iter = sel ? (*n_sel_dev < n_list ? *n_sel_dev : n_list) : n_list;
-	for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
-		const uint32_t li = sel ? sel[it] : it;
-		const uint32_t q = qlist ? qlist[li] : li;
-		const uint64_t b = qoff[q];
-		const uint32_t len = (uint32_t)(qoff[q + 1] - b), E = qemac[q];
-		for (uint32_t i = tid; i < nw32; i += 256) cnt[i] = 0;
-		__syncthreads();
-		if (len >= (uint32_t)K) {
-			const uint32_t nwords = len - K + 1;
-			// 64 word positions per wave pass: lane j builds the word starting at base+j
-			for (uint32_t base = wave * 64; base < nwords; base += 256) {
-				const uint32_t p = base + lane;
-				uint32_t w = 0, ok = p < nwords;
-				if (ok) for (int k = 0; k < K; ++k) {
-					uint32_t c = qcodes[b + p + k];
-					ok &= (c - 1u) < 4u;
-					w = (w << 2) | ((c - 1u) & 3u);
-				}
-				w &= wmask;
-				unsigned long long beg = 0; uint32_t n = 0;
-				if (ok) bhip_acx_range(acx, w, beg, n);
-				my_ent += n;
-				// short lists: each lane walks its own; long lists: the wave walks them together
-				unsigned long long longm = __ballot(n > 32);
-				if (n <= 32) for (uint32_t e = 0; e < n; ++e) {
-					uint32_t c = bhip_acx_clump(acx.rec, beg + e);
-					atomicAdd(&cnt[c >> 1], 1u << ((c & 1) * 16));
-				}
-				while (longm) {
-					const int src = __builtin_ctzll(longm);
-					longm &= longm - 1;
-					const unsigned long long lb = __shfl(beg, src); const uint32_t ln = __shfl(n, src);
-					for (uint32_t e = lane; e < ln; e += 64) {
-						uint32_t c = bhip_acx_clump(acx.rec, lb + e);
-						atomicAdd(&cnt[c >> 1], 1u << ((c & 1) * 16));
-					}
-				}
-			}
-		}
-		__syncthreads();
-		// (this kernel counts words of A/C/G/T only: of the plan's need, the x words that vote through expansions are not seen here; when
-		// nothing is left of it every clump is a candidate)
-		const uint32_t px = plan ? BHIP_PLAN_X(plan[q]) : 0u, pn = plan ? BHIP_PLAN_NEED(plan[q]) : 0u;
-		const uint32_t need1 = pn > px ? pn - px : 0u;
-		const bool takeall = px && !need1;
-		const uint32_t kload = E * K + K, mmatch = plan ? (need1 ? need1 - 1 : 0u) : (kload < len ? len - kload : 0);
-		for (uint32_t c = tid; c < n_clumps; c += 256) {
-			const uint32_t v = (cnt[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu;
-			if (v > mmatch || takeall) {
-				const uint32_t pos = atomicAdd(n_cand, 1u);
-				if (pos < cand_cap) { cand[pos] = make_uint2(li, c); if (cand_cnt_out) cand_cnt_out[pos] = v; }
-			}
-		}
-		for (uint32_t i = tid; i < n_bad && !takeall; i += 256) {          // burst.c:4136-4138, 4282-4283 (with every clump taken they are in already)
-			const uint32_t pos = atomicAdd(n_cand, 1u);
-			if (pos < cand_cap) { cand[pos] = make_uint2(li, bad[i]); if (cand_cnt_out) cand_cnt_out[pos] = 0xFFFFFFFFu; }
-		}
-		__syncthreads();
-	}
-	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
-}
-
-template __global__ void k_prefilter<false>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	BhipAcxView, int, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *,
-	const uint32_t *, const uint32_t *, const uint32_t *);
-
-
-// ------------------------------------------------------------------------------------------------
-// Prefilter, wave-per-query variant (used whenever the per-clump counters of one query fit a wave's LDS slice).
-// Differences to k_prefilter above, all aimed at what the round-1 profile showed to dominate (profiles/r01_*):
-//   * one 64-lane wave owns a query (no workgroup barriers), several waves per CU run independent queries;
-//   * counters are bytes (CNT = uint8_t, four per dword) while len-K+1 <= 255, else 16-bit;
-//   * no dense zero/scan per query: the first increment of a counter (atomic returns 0) appends the clump to a
-//     touched list; only touched counters are tested against the threshold and reset.  Dense fallback if the list overflows;
-//   * candidates are staged in LDS and flushed with ONE global atomic per flush instead of one returning atomic per
-//     candidate (2.2 M same-address atomics per launch saturated the L2 atomic unit at ~90/us).
-// ------------------------------------------------------------------------------------------------
-// Seed plan of one query (k_route on the device, make_seed_plan on the host: bhip_seed_plan; layout BHIP_PLAN_* in bhip_internal.h:
-// stride | need << 8 | x << 24 | used << 28): word starts 0, s, 2s, ... <= len-K are sampled.  A word of A/C/G/T votes; with
-// non-overlapping words (s = K) a word holding exactly ONE ambiguous symbol with 2..4 compatible bases votes through its expansions
-// (x such words, `used` extra word slots: the reference's storeAmbigWords, burst.c:3232-3236, restricted to one ambiguous symbol per
-// word); any other word does not vote.  One edit destroys at most ceil(K/s) sampled words, so an alignment with <= E edits keeps
-// need = W_voting - E*ceil(K/s) of them.  s = 1 with no ambiguity is the reference's scheme (need = len-K+1-E*K = mmatch+1,
-// burst.c:4091-4092).  Queries with need < 1 never reach these kernels (they are routed to the exhaustive path); the clump-level
-// kernels below count strictly (words of A/C/G/T only): need - x, and every clump when nothing is left.
-#define PF2_TL 1536u      // touched-list capacity (clump ids, u32)
-#define PF2_STAGE 512u    // staged candidates (uint2)
-template <typename CNT>
-__global__ __launch_bounds__(64) void k_prefilter_wave(
-		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint16_t *__restrict__ qemac,
-		const uint32_t *__restrict__ qlist, uint32_t n_list,
-		BhipAcxView acx, int K, uint32_t n_clumps,
-		const uint32_t *__restrict__ bad, uint32_t n_bad,
-		uint2 *__restrict__ cand, uint32_t *__restrict__ cand_cnt_out, uint32_t *__restrict__ n_cand, uint32_t cand_cap,
-		unsigned long long *__restrict__ ent_read, const uint32_t *__restrict__ plan,
-		const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel_dev) {   // optional: only list positions sel[0..*n_sel_dev)
-	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-	constexpr uint32_t PER = 4 / sizeof(CNT), BITS = 8 * sizeof(CNT), MASK = (1u << BITS) - 1u;
-	const uint32_t nw32 = (n_clumps + PER - 1) / PER;
-	uint32_t *cnt = smem;                       // [nw32]
-	uint32_t *tl = cnt + nw32;                  // [PF2_TL]
-	uint2 *stage = (uint2 *)(tl + PF2_TL);      // [PF2_STAGE]
-	uint32_t *stage_v = (uint32_t *)(stage + PF2_STAGE);   // [PF2_STAGE] counts (only written when cand_cnt_out)
-	uint32_t *ctr = stage_v + PF2_STAGE;        // [0] touched count, [1] staged count
-	const uint32_t lane = threadIdx.x;
-	const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
-	for (uint32_t i = lane; i < nw32; i += 64) cnt[i] = 0;
-	if (lane < 2) ctr[lane] = 0;
-	__syncthreads();
-	unsigned long long my_ent = 0;
-
-	auto push = [&](uint32_t li, uint32_t c, uint32_t v) {
-		const uint32_t pos = atomicAdd(&ctr[1], 1u);
-		if (pos < PF2_STAGE) { stage[pos] = make_uint2(li, c); if (cand_cnt_out) stage_v[pos] = v; }
-		else {   // staging buffer full inside one query (very permissive threshold): direct append
-			const uint32_t g = atomicAdd(n_cand, 1u);
-			if (g < cand_cap) { cand[g] = make_uint2(li, c); if (cand_cnt_out) cand_cnt_out[g] = v; }
-		}
-	};
-	auto flush = [&]() {
-		__syncthreads();
-		const uint32_t n = ctr[1] < PF2_STAGE ? ctr[1] : PF2_STAGE;
-		uint32_t base = 0;
-		if (n) {
-			if (lane == 0) base = atomicAdd(n_cand, n);
-			base = __shfl(base, 0);
-			for (uint32_t i = lane; i < n; i += 64) if (base + i < cand_cap) { cand[base + i] = stage[i]; if (cand_cnt_out) cand_cnt_out[base + i] = stage_v[i]; }
-		}
-		__syncthreads();
-		if (lane == 0) ctr[1] = 0;
-		__syncthreads();
-	};
-	auto bump = [&](uint32_t c) {
-		const uint32_t sh = (c % PER) * BITS;
-		const uint32_t old = atomicAdd(&cnt[c / PER], 1u << sh);
-		if (((old >> sh) & MASK) == 0) {
-			const uint32_t pos = atomicAdd(&ctr[0], 1u);
-			if (pos < PF2_TL) tl[pos] = c;
-		}
-	};
-
-	const uint32_t n_iter = sel ? (*n_sel_dev < n_list ? *n_sel_dev : n_list) : n_list;
-	for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
-		const uint32_t li = sel ? sel[it] : it;
-		const uint32_t q = qlist ? qlist[li] : li;
-		const uint64_t b = qoff[q];
-		const uint32_t len = (uint32_t)(qoff[q + 1] - b), E = qemac[q];
-		const uint32_t stride = plan[q] & 255u, px_ = BHIP_PLAN_X(plan[q]), pn_ = BHIP_PLAN_NEED(plan[q]);
-		const uint32_t need = pn_ > px_ ? pn_ - px_ : 0u;      // (strict counting: without the words that vote through expansions)
-		const bool takeall = px_ && !need;
-		(void)E;
-		if (len >= (uint32_t)K) {
-			const uint32_t nwords = (len - K) / stride + 1;
-			for (uint32_t base = 0; base < nwords; base += 64) {
-				const uint32_t j = base + lane, p = j * stride;
-				uint32_t w = 0, ok = j < nwords;
-				if (ok) for (int k = 0; k < K; ++k) {
-					const uint32_t c = qcodes[b + p + k];
-					ok &= (c - 1u) < 4u;
-					w = (w << 2) | ((c - 1u) & 3u);
-				}
-				w &= wmask;
-				unsigned long long beg = 0; uint32_t n = 0;
-				if (ok) bhip_acx_range(acx, w, beg, n);
-				my_ent += n;
-				unsigned long long longm = __ballot(n > 32);
-				if (n <= 32) {
-					uint32_t e = 0;
-					for (; e + 4 <= n; e += 4) {   // four independent loads in flight
-						const uint32_t c0 = bhip_acx_clump(acx.rec, beg + e), c1 = bhip_acx_clump(acx.rec, beg + e + 1), c2 = bhip_acx_clump(acx.rec, beg + e + 2), c3 = bhip_acx_clump(acx.rec, beg + e + 3);
-						bump(c0); bump(c1); bump(c2); bump(c3);
-					}
-					for (; e < n; ++e) bump(bhip_acx_clump(acx.rec, beg + e));
-				}
-				while (longm) {
-					const int src = __builtin_ctzll(longm);
-					longm &= longm - 1;
-					const unsigned long long lb = __shfl(beg, src); const uint32_t ln = __shfl(n, src);
-					for (uint32_t e = lane; e < ln; e += 64) bump(bhip_acx_clump(acx.rec, lb + e));
-				}
-			}
-		}
-		__syncthreads();
-		const uint32_t mmatch = need ? need - 1 : 0;      // candidate iff count >= need (count > 0 when no words are guaranteed)
-		const uint32_t nt = ctr[0];
-		if (takeall) {      // nothing of the guarantee is visible to strict counting: every clump
-			for (uint32_t i = lane; i < nw32; i += 64) cnt[i] = 0;
-			for (uint32_t c = lane; c < n_clumps; c += 64) push(li, c, 0);
-		} else if (nt <= PF2_TL) {
-			for (uint32_t i = lane; i < nt; i += 64) {
-				const uint32_t c = tl[i], sh = (c % PER) * BITS;
-				const uint32_t v = (cnt[c / PER] >> sh) & MASK;
-				atomicAnd(&cnt[c / PER], ~(MASK << sh));
-				if (v > mmatch) push(li, c, v);
-			}
-		} else {   // touched list overflowed: dense pass
-			for (uint32_t i = lane; i < nw32; i += 64) {
-				const uint32_t word = cnt[i];
-				if (word) {
-					cnt[i] = 0;
-					for (uint32_t j = 0; j < PER; ++j) { const uint32_t v = (word >> (j * BITS)) & MASK; if (v > mmatch && i * PER + j < n_clumps) push(li, i * PER + j, v); }
-				}
-			}
-		}
-		for (uint32_t i = lane; i < n_bad && !takeall; i += 64) push(li, bad[i], 0xFFFFFFFFu);          // burst.c:4136-4138, 4282-4283 (with every clump taken they are in already)
-		__syncthreads();
-		if (lane == 0) ctr[0] = 0;
-		if (ctr[1] >= PF2_STAGE / 2) flush(); else __syncthreads();
-	}
-	flush();
-	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
-}
-template __global__ void k_prefilter_wave<uint8_t>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	BhipAcxView, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *,
-	const uint32_t *, const uint32_t *);
-template __global__ void k_prefilter_wave<uint16_t>(const uint8_t *, const uint64_t *, const uint16_t *, const uint32_t *, uint32_t,
-	BhipAcxView, int, uint32_t, const uint32_t *, uint32_t, uint2 *, uint32_t *, uint32_t *, uint32_t, unsigned long long *, const uint32_t *,
-	const uint32_t *, const uint32_t *);
-
-// ------------------------------------------------------------------------------------------------
-// Prefilter, hashed variant: FOUR queries per wave (16 lanes each), per-query open-addressing table in LDS instead of
-// dense per-clump counters, so LDS use no longer depends on the database size (RefSeq-scale DBs have millions of
-// clumps) and 4-6x more queries are in flight per CU -- the kernel is bound by the latency of the random .acx list
-// reads, not by arithmetic.  Slot = (clump+1) << 8 | count (clump ids are < 2^24 by the .acx format, burst.c:3509;
-// counts <= 255 is guaranteed by the seed plan).  New keys go to a per-query touched list; the final pass reads and
-// clears only touched slots.  A query that overflows its table or list is handed to the dense kernel (sel list).
-// ------------------------------------------------------------------------------------------------
-#define PFH_HT 1024u
-#define PFH_TL 448u
-#define PFH_STAGE 512u
-__global__ __launch_bounds__(64) void k_prefilter_hash(
-		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint16_t *__restrict__ qemac,
-		const uint32_t *__restrict__ qlist, uint32_t n_list,
-		BhipAcxView acx, int K,
-		const uint32_t *__restrict__ bad, uint32_t n_bad,
-		uint2 *__restrict__ cand, uint32_t *__restrict__ cand_cnt_out, uint32_t *__restrict__ n_cand, uint32_t cand_cap,
-		unsigned long long *__restrict__ ent_read, const uint32_t *__restrict__ plan,
-		uint32_t *__restrict__ fb_list, uint32_t *__restrict__ n_fb) {
-	__shared__ uint32_t s_tab[4][PFH_HT];
-	__shared__ uint16_t s_tl[4][PFH_TL];
-	__shared__ uint2 s_stage[PFH_STAGE];
-	__shared__ uint32_t s_stage_v[PFH_STAGE];
-	__shared__ uint32_t s_ctr[8];           // [g] touched count of group g, [4] staged, [5+..] unused
-	__shared__ uint32_t s_ovf[4];
-	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
-	const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
-	for (uint32_t i = lane; i < 4 * PFH_HT; i += 64) (&s_tab[0][0])[i] = 0;
-	if (lane < 8) s_ctr[lane] = 0;
-	if (lane < 4) s_ovf[lane] = 0;
-	__syncthreads();
-	unsigned long long my_ent = 0;
-
-	auto push = [&](uint32_t li, uint32_t c, uint32_t v) {
-		const uint32_t pos = atomicAdd(&s_ctr[4], 1u);
-		if (pos < PFH_STAGE) { s_stage[pos] = make_uint2(li, c); if (cand_cnt_out) s_stage_v[pos] = v; }
-		else {
-			const uint32_t gp = atomicAdd(n_cand, 1u);
-			if (gp < cand_cap) { cand[gp] = make_uint2(li, c); if (cand_cnt_out) cand_cnt_out[gp] = v; }
-		}
-	};
-	auto flush = [&]() {
-		__syncthreads();
-		const uint32_t n = s_ctr[4] < PFH_STAGE ? s_ctr[4] : PFH_STAGE;
-		uint32_t base = 0;
-		if (n) {
-			if (lane == 0) base = atomicAdd(n_cand, n);
-			base = __shfl(base, 0);
-			for (uint32_t i = lane; i < n; i += 64) if (base + i < cand_cap) { cand[base + i] = s_stage[i]; if (cand_cnt_out) cand_cnt_out[base + i] = s_stage_v[i]; }
-		}
-		__syncthreads();
-		if (lane == 0) s_ctr[4] = 0;
-		__syncthreads();
-	};
-	// insert-or-increment clump c in the table of group tg
-	auto bump = [&](uint32_t tg, uint32_t c) {
-		const uint32_t key = (c + 1u) << 8;
-		uint32_t slot = (c * 0x9E3779B1u) >> (32 - 10);
-		uint32_t *tab = s_tab[tg];
-		for (uint32_t probes = 0; probes < PFH_HT; ++probes, slot = (slot + 1) & (PFH_HT - 1)) {
-			uint32_t old = tab[slot];
-			if (old == 0) {
-				old = atomicCAS(&tab[slot], 0u, key | 1u);
-				if (old == 0) {   // new key
-					const uint32_t pos = atomicAdd(&s_ctr[tg], 1u);
-					if (pos < PFH_TL) s_tl[tg][pos] = (uint16_t)slot; else s_ovf[tg] = 1;
-					return;
-				}
-			}
-			if ((old & 0xFFFFFF00u) == key) { atomicAdd(&tab[slot], 1u); return; }
-		}
-		s_ovf[tg] = 1;
-	};
-
-	const uint32_t n_quads = (n_list + 3) >> 2;
-	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
-		const uint32_t li = quad * 4 + g;
-		const bool live = li < n_list;
-		uint32_t q = 0, len = 0, stride = 1, need = 0, nwords = 0;
-		uint64_t b = 0;
-		if (live) {
-			q = qlist ? qlist[li] : li;
-			b = qoff[q];
-			len = (uint32_t)(qoff[q + 1] - b);
-			if (len >= (uint32_t)K) {
-				stride = plan[q] & 255u;      // the host keeps (len-K)/stride + 1 <= 255 (8-bit counts)
-				{ const uint32_t px_ = BHIP_PLAN_X(plan[q]), pn_ = BHIP_PLAN_NEED(plan[q]); need = pn_ > px_ ? pn_ - px_ : 0u; if (px_ && !need) s_ovf[g] = 1; }      // (strict counting; nothing left of the guarantee: the dense kernels take every clump)
-				nwords = (len - K) / stride + 1;
-			}
-		}
-		uint32_t maxw = nwords;
-		#pragma unroll
-		for (int o = 32; o >= 1; o >>= 1) { const uint32_t t = __shfl_xor(maxw, o); maxw = t > maxw ? t : maxw; }
-		for (uint32_t base = 0; base < maxw; base += 16) {
-			const uint32_t j = base + gl, p = j * stride;
-			uint32_t w = 0, ok = live && j < nwords;
-			if (ok) for (int k = 0; k < K; ++k) {
-				const uint32_t c = qcodes[b + p + k];
-				ok &= (c - 1u) < 4u;
-				w = (w << 2) | ((c - 1u) & 3u);
-			}
-			w &= wmask;
-			unsigned long long beg = 0; uint32_t n = 0;
-			if (ok) bhip_acx_range(acx, w, beg, n);
-			my_ent += n;
-			unsigned long long longm = __ballot(n > 48);
-			if (n <= 48) {
-				uint32_t e = 0;
-				for (; e + 4 <= n; e += 4) {
-					const uint32_t c0 = bhip_acx_clump(acx.rec, beg + e), c1 = bhip_acx_clump(acx.rec, beg + e + 1), c2 = bhip_acx_clump(acx.rec, beg + e + 2), c3 = bhip_acx_clump(acx.rec, beg + e + 3);
-					bump(g, c0); bump(g, c1); bump(g, c2); bump(g, c3);
-				}
-				for (; e < n; ++e) bump(g, bhip_acx_clump(acx.rec, beg + e));
-			}
-			while (longm) {   // long lists: the whole wave walks them, inserting into the owner's table
-				const int src = __builtin_ctzll(longm);
-				longm &= longm - 1;
-				const unsigned long long lb = __shfl(beg, src); const uint32_t ln = __shfl(n, src), tg = (uint32_t)src >> 4;
-				for (uint32_t e = lane; e < ln; e += 64) bump(tg, bhip_acx_clump(acx.rec, lb + e));
-			}
-		}
-		__syncthreads();
-		// evaluate and clear the touched slots of the own group
-		const uint32_t nt = s_ctr[g] < PFH_TL ? s_ctr[g] : PFH_TL;
-		const uint32_t ovf = s_ovf[g];
-		const uint32_t thr = need ? need - 1 : 0;
-		if (live && !ovf) {
-			for (uint32_t i = gl; i < nt; i += 16) {
-				const uint32_t slot = s_tl[g][i], v = s_tab[g][slot];
-				s_tab[g][slot] = 0;
-				if ((v & 255u) > thr) push(li, (v >> 8) - 1u, v & 255u);
-			}
-			for (uint32_t i = gl; i < n_bad; i += 16) push(li, bad[i], 0xFFFFFFFFu);       // burst.c:4136-4138, 4282-4283
-		} else if (ovf) {
-			for (uint32_t i = gl; i < PFH_HT; i += 16) s_tab[g][i] = 0;
-			if (live && gl == 0) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
-		}
-		__syncthreads();
-		if (gl == 0) { s_ctr[g] = 0; s_ovf[g] = 0; }
-		if (s_ctr[4] >= PFH_STAGE / 2) flush(); else __syncthreads();
-	}
-	flush();
-	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
-}
-
-
-// Prefilter with per-lane counts, in two passes over the query's .acx lists so that the wide per-lane counters are
-// touched only for clumps that can matter:
-//   pass 1  clump-level counts exactly as k_prefilter_hash (slot = (clump+1) << 8 | count);
-//   select  clumps with count >= need become "candidates" (a clump-level count below need implies every lane is below);
-//           the slot's low byte is re-used for the candidate index, all other touched slots keep their key (probe chains
-//           stay intact) with a zero byte;
-//   pass 2  the lists are walked again (L2-resident by now); entries of candidate clumps add their 16-bit lane mask into
-//           sixteen 8-bit lane counters (two 64-bit LDS atomics, ~3 % of the entries);
-//   emit    (list position, reference lane) TASKS for lanes with count >= need -> k_myers_prefix_task.
-// More candidate clumps in one query than the lane counters hold (24 with the 512-slot table, 80 above): the surplus clumps are emitted as clump-level pairs (16-lane kernel).
-#ifdef PFM_PROF
-__device__ unsigned long long g_pfm_prof[8];
-#if PFM_PROF == 2      // without draining the memory pipeline: issue + stall time of each phase as it really runs
-#define PFM_T(i) do { const unsigned long long t_ = wall_clock64(); if (lane == 0) my_t[i] += t_ - t_last; t_last = t_; } while (0)
-#else
-#define PFM_T(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = wall_clock64(); if (lane == 0) my_t[i] += t_ - t_last; t_last = t_; } while (0)
-#endif
-#else
-#define PFM_T(i) do {} while (0)
-#endif
-#define PFM_STAGE 128u
-#define PFM_RB 3u            // blocks of 64 records per query kept in registers between the passes
-__device__ __forceinline__ unsigned long long spread8(uint32_t m8) {   // bit i of m8 -> bit 8*i
-	unsigned long long x = m8;
-	x = (x | (x << 28)) & 0x0000000F0000000Full;
-	x = (x | (x << 14)) & 0x0003000300030003ull;
-	x = (x | (x << 7)) & 0x0101010101010101ull;
-	return x;
-}
-// Four hash-table updates in lock step (independent LDS round trips overlap).  CAS first: most updates of a
-// query are first sightings of a clump, which complete in one round trip; a key hit costs one more (no-return) add.
-template <int HTB>
-__device__ __forceinline__ void pfm_bump4(uint32_t *tab, uint32_t *dummy, const uint32_t (&c)[4], const bool (&valid)[4], uint32_t (&slot)[4], bool (&ins)[4], bool &fail) {
-	uint32_t key[4]; bool act[4];
-	#pragma unroll
-	for (int k = 0; k < 4; ++k) { key[k] = (c[k] + 1u) << 8; slot[k] = (c[k] * 0x9E3779B1u) >> (32 - HTB); act[k] = valid[k]; ins[k] = false; }
-	bool any = valid[0] | valid[1] | valid[2] | valid[3];
-	for (uint32_t probes = 0; any && probes < (1u << HTB); ++probes) {
-		uint32_t old[4];
-		// finished chains compare-and-swap a private dummy word with a value that never matches: no branches between the
-		// four LDS round trips, so they are in flight together
-		#pragma unroll
-		for (int k = 0; k < 4; ++k) old[k] = atomicCAS(act[k] ? &tab[slot[k]] : dummy, act[k] ? 0u : 0xFFFFFFFFu, key[k] | 1u);
-		any = false;
-		#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const bool hit = act[k] && (old[k] & 0xFFFFFF00u) == key[k];
-			const bool fresh = act[k] && old[k] == 0;
-			const bool step = act[k] && !hit && !fresh;
-			if (hit) atomicAdd(&tab[slot[k]], 1u);
-			ins[k] |= fresh;
-			slot[k] = step ? (slot[k] + 1) & ((1u << HTB) - 1) : slot[k];
-			act[k] = step;
-			any |= step;
-		}
-	}
-	fail = any;
-}
-// Seed lookup for the lane-resolved prefilter: one thread per (query of the list, sampled word) turns the word into its
-// .acx list range; the header carries need | words << 16 and the length.  Keeps the dependent chain
-// list -> offsets -> symbols -> acx offsets out of the hash kernel (fully parallel here, four round trips there).
-__global__ __launch_bounds__(256) void k_seed_ranges(
-		const uint8_t *__restrict__ qcodes, const uint64_t *__restrict__ qoff, const uint32_t *__restrict__ qlist, uint32_t n_list,
-		BhipAcxView acx, int K, const uint32_t *__restrict__ plan, uint32_t W16,
-		uint2 *__restrict__ ranges, uint2 *__restrict__ hdr, const uint32_t *__restrict__ qpack, uint32_t qw, const uint16_t *__restrict__ qemac,
-		uint4 *__restrict__ qmeta, const uint32_t *__restrict__ qsix,         // qmeta[list position] = (query entry, length | budget << 16, shared slot): one sector for the prefix sweep instead of three
-		uint32_t min_need, uint32_t drop_len,                                 // the longest lists of a query are left out while `need` stays >= min_need (0: never), lists shorter than drop_len stay
-		BhipAlt alt) {                                                        // compatible bases per query symbol code: expansions of ambiguous words (plan bits 24..31)
-	// (grid-stride: run ahead beside another batch's sweeps, the kernel is launched with a few blocks per CU only)
-	for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < (uint64_t)n_list * W16; t += (uint64_t)gridDim.x * 256) {
-	const uint32_t li = (uint32_t)(t / W16), j = (uint32_t)(t % W16);
-	const uint32_t q = qlist ? qlist[li] : li;
-	const uint64_t b = qoff[q];
-	const uint32_t len = (uint32_t)(qoff[q + 1] - b);
-	uint32_t stride = 1, need = 0, nwords = 0, n_exp = 0, n_pos = 0;
-	if (len >= (uint32_t)K) { const uint32_t pl = plan[q]; stride = pl & 255u; need = BHIP_PLAN_NEED(pl); n_pos = (len - K) / stride + 1; n_exp = BHIP_PLAN_X(pl) ? BHIP_PLAN_USED(pl) : 0u; nwords = n_pos + n_exp; }
-	if (nwords > W16) nwords = W16;
-	uint2 r = make_uint2(0, 0);
-	if (n_exp) {
-		// A query with expanded words (rare: plan bits 24..31; stride == K, the words do not overlap).  Slot j < n_pos is the word at j K:
-		// a word of A/C/G/T as usual, an expandable one -- if the budget walk reaches it -- with the FIRST compatible base in place of its
-		// ambiguous symbol; slot n_pos + e is the e-th further alternative, found by the same walk.  Symbol by symbol: this path is
-		// off the critical path and taken by a handful of queries per batch.
-		const uint32_t *qp = qpack + (uint64_t)q * qw;
-		auto sym = [&](uint32_t i) -> uint32_t { return qpack ? (qp[i >> 3] >> (4u * (i & 7u))) & 15u : (uint32_t)qcodes[b + i]; };
-		const uint32_t Ku = (uint32_t)K;
-		uint32_t wj = 0xFFFFFFFFu, alt_ix = 0, amb_k = 0;      // the word this slot looks up: its number, which alternative, where its ambiguous symbol is
-		uint32_t used = 0;
-		if ((W16 & (W16 - 1u)) == 0u && W16 <= 64u) {
-			// the slots of a query are W16 consecutive lanes of one wave: every lane classifies ITS word once, the classes go round by
-			// lane reads, and each lane walks the budget over them (n_pos reads instead of n_pos x K symbol extractions per lane)
-			uint32_t ak0 = 0, ex0 = 0;
-			const uint32_t c0 = j < n_pos ? bhip_word_class(sym, j * Ku, Ku, alt, ak0, ex0) : 0u;
-			const uint32_t mine = c0 | ex0 << 2 | ak0 << 4;
-			for (uint32_t t = 0; t < n_pos; ++t) {
-				const uint32_t v = (uint32_t)__shfl((int)mine, (int)t, (int)W16);
-				const uint32_t c = v & 3u, ex = (v >> 2) & 3u, ak = v >> 4;
-				const bool fits = c == 2u && used + ex <= BHIP_EXPAND_SLOTS;
-				if (j < n_pos) { if (t == j && (c == 1u || fits)) { wj = t; alt_ix = 0; amb_k = c == 2u ? ak : 0xFFFFFFFFu; } }
-				else if (wj == 0xFFFFFFFFu && fits && j - n_pos >= used && j - n_pos < used + ex) { wj = t; alt_ix = 1u + (j - n_pos - used); amb_k = ak; }
-				if (fits) used += ex;
-			}
-			if (j >= nwords) wj = 0xFFFFFFFFu;
-		} else if (j < nwords) {
-			const uint32_t upto = j < n_pos ? j + 1 : n_pos;
-			for (uint32_t t = 0; t < upto && wj == 0xFFFFFFFFu; ++t) {
-				uint32_t ak, ex;
-				const uint32_t c = bhip_word_class(sym, t * Ku, Ku, alt, ak, ex);
-				const bool fits = c == 2u && used + ex <= BHIP_EXPAND_SLOTS;
-				if (j < n_pos) { if (t == j && (c == 1u || fits)) { wj = t; alt_ix = 0; amb_k = c == 2u ? ak : 0xFFFFFFFFu; } }
-				else if (fits && j - n_pos >= used && j - n_pos < used + ex) { wj = t; alt_ix = 1u + (j - n_pos - used); amb_k = ak; }
-				if (fits) used += ex;
-			}
-		}
-		if (wj != 0xFFFFFFFFu) {
-			uint32_t w = 0;
-			for (uint32_t k = 0; k < Ku; ++k) {
-				const uint32_t c = sym(wj * Ku + k);
-				const uint32_t base = k == amb_k ? ((uint32_t)alt.base[c] >> (2u * alt_ix)) & 3u : (c - 1u) & 3u;
-				w = (w << 2) | base;
-			}
-			w &= Ku == 16 ? 0xFFFFFFFFu : ((1u << (2 * Ku)) - 1u);
-			unsigned long long beg; uint32_t n;
-			bhip_acx_range(acx, w, beg, n);
-			r.x = (uint32_t)beg; r.y = n | (uint32_t)(beg >> 32) << 24;
-		}
-	} else if (j < nwords) {
-		const uint32_t wmask = K == 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
-		const uint32_t p = j * stride;
-		uint32_t w = 0, ok = 1;
-		if (qpack) {   // K <= 15 symbols = at most three dwords of 4-bit codes
-			const uint32_t *qp = qpack + (uint64_t)q * qw;
-			const uint32_t j0 = p >> 3, sh = 4u * (p & 7u);
-			const uint32_t d0 = qp[j0], d1 = j0 + 1 < qw ? qp[j0 + 1] : 0u, d2 = j0 + 2 < qw ? qp[j0 + 2] : 0u;
-			const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
-			// eight 4-bit codes -> eight 2-bit symbols, first symbol most significant, all at once (codes 1..4 = A C G T;
-			// any other code in the word's first n nibbles clears `good`)
-			auto pack8 = [](uint32_t x, uint32_t n, bool &good) -> uint32_t {
-				const uint32_t keep = n >= 8 ? 0xFFFFFFFFu : ((1u << (4 * n)) - 1u);
-				const uint32_t xm = (x & keep) | (0x11111111u & ~keep);            // unused nibbles read as A
-				const uint32_t zero = (xm - 0x11111111u) & ~xm & 0x88888888u;       // a nibble of code 0 (would borrow below)
-				const uint32_t t = xm - 0x11111111u;                                // code - 1 per nibble
-				good = good && !zero && !(t & 0xCCCCCCCCu);
-				uint32_t y = (t | (t >> 2)) & 0x0F0F0F0Fu;
-				y = (y | (y >> 4)) & 0x00FF00FFu;
-				y = (y | (y >> 8)) & 0xFFFFu;                                       // symbol k at bits 2k, 2k + 1
-				const uint32_t r = __brev(y) >> 16;                                 // order reversed, bits of a pair swapped
-				return ((r & 0x5555u) << 1) | ((r >> 1) & 0x5555u);               // 16 bits, symbol 0 on top
-			};
-			bool good = true;
-			const uint32_t Ku = (uint32_t)K;
-			const uint32_t w_lo = pack8(lo, Ku < 8 ? Ku : 8u, good);
-			if (Ku <= 8) w = w_lo >> (16 - 2 * Ku);
-			else { const uint32_t w_hi = pack8(hi, Ku - 8, good); w = (w_lo << (2 * (Ku - 8))) | (w_hi >> (16 - 2 * (Ku - 8))); }
-			ok = good ? 1u : 0u;
-		} else for (int k = 0; k < K; ++k) {
-			const uint32_t c = qcodes[b + p + k];
-			ok &= (c - 1u) < 4u;
-			w = (w << 2) | ((c - 1u) & 3u);
-		}
-		w &= wmask;
-		if (ok) {      // range = first entry (40 bits) and length (24 bits): x = low 32 bits of the entry, y = length | high bits << 24
-			unsigned long long beg; uint32_t n;
-			bhip_acx_range(acx, w, beg, n);
-			r.x = (uint32_t)beg; r.y = n | (uint32_t)(beg >> 32) << 24;
-		}
-	}
-	// Every sampled word is one vote and `need` of the nwords votes survive E edits -- of ANY subset of n' of those words, need - (nwords - n')
-	// do.  The lists have very different lengths (and their sum is what the prefilter walks: the whole slope of a batch's time over
-	// the database size), so the longest ones are left out as long as the smaller `need` still says something.  The words of a query
-	// are W16 (8 or 16) consecutive lanes of one row; a left-out list is an empty range and one vote less in the header.
-	if (min_need && W16 <= 16u) {
-		const uint32_t n_mine = r.y & 0xFFFFFFu;
-		uint32_t rank = 0;
-		for (uint32_t k = 0; k < W16; ++k) {
-			const uint32_t n_k = (uint32_t)__shfl((int)n_mine, (int)k, (int)W16);
-			rank += (n_k > n_mine || (n_k == n_mine && k < j)) ? 1u : 0u;
-		}
-		const uint32_t allowed = need > min_need ? need - min_need : 0u;
-		const bool drop = rank < allowed && n_mine >= drop_len && n_mine > 0u;
-		const unsigned long long bal = __ballot(drop);
-		const uint32_t row0 = (threadIdx.x & 63u) - j;
-		const uint32_t ndrop = (uint32_t)__popcll((bal >> row0) & ((1ull << W16) - 1ull));
-		if (drop) r = make_uint2(0, 0);
-		need -= ndrop;
-	}
-	ranges[t] = r;
-	// header: need | words << 16 ; length | budget << 12 | (words one edit can destroy = ceil(K / stride)) << 20
-	if (j == 0) {
-		const uint32_t Eq_ = qemac[q];
-		hdr[li] = make_uint2((need > 0xFFFFu ? 0xFFFFu : need) | nwords << 16, len | (uint32_t)(Eq_ > 255 ? 255 : Eq_) << 12 | ((uint32_t)(K + stride - 1) / stride) << 20);
-		if (qmeta) qmeta[li] = make_uint4(q, len | Eq_ << 16, qsix ? qsix[q] : q, 0u);
-	}
-	}
-}
-
-template <int HTB>
-__global__ __launch_bounds__(64) void k_prefilter_mask(
-		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
-		const uint32_t *__restrict__ ent,   // 4-byte (clump, lane-set code) records
-		const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ clump_len, uint32_t tot_refs,
-		uint2 *__restrict__ tasks, uint32_t *__restrict__ n_tasks, uint32_t task_cap,
-		unsigned long long *__restrict__ ent_read,
-		uint32_t *__restrict__ fb_list, uint32_t *__restrict__ n_fb,
-		unsigned long long *__restrict__ unit_sum, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum,
-		uint2 *__restrict__ pairs, uint32_t *__restrict__ n_pairs, uint32_t pair_cap) {
-
-	__shared__ uint32_t s_tab[4][(1u << HTB)];
-	__shared__ uint16_t s_tl[4][(1u << (HTB - 1))];
-	constexpr uint32_t CAND = HTB <= 9 ? 24u : 80u;      // candidate clumps per query with lane counters (LDS: 20 B each)
-	__shared__ unsigned long long s_cc[4][CAND][2];
-	__shared__ uint32_t s_cclump[4][CAND];
-	__shared__ uint2 s_stage[PFM_STAGE];
-	__shared__ uint32_t s_ctr[12];          // [g] touched count, [4] staged, [5+g] candidates of group g
-	__shared__ uint32_t s_ovf[4];
-	__shared__ uint32_t s_dummy[64];
-	__shared__ uint16_t s_lut[256];         // lane-set code -> lane mask
-	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
-	s_dummy[lane] = 0;
-	for (uint32_t i = lane; i < 256; i += 64) s_lut[i] = (uint16_t)bhip_lane_code_mask(i);
-	for (uint32_t i = lane; i < 4 * (1u << HTB); i += 64) (&s_tab[0][0])[i] = 0;
-	for (uint32_t i = lane; i < 4 * CAND * 2; i += 64) (&s_cc[0][0][0])[i] = 0;
-	if (lane < 12) s_ctr[lane] = 0;
-	if (lane < 4) s_ovf[lane] = 0;
-	__syncthreads();
-	unsigned long long my_ent = 0, my_units = 0, my_cols = 0, my_qlen = 0;
-	uint32_t sink = 0;                      // see bhip_acx_raw_or_pad (bhip_internal.h)
-#ifdef PFM_PROF
-	unsigned long long my_t[8] = {0,0,0,0,0,0,0,0}, t_last = wall_clock64();
-#endif
-
-	auto push = [&](uint32_t li, uint32_t refIx) {
-		const uint32_t pos = atomicAdd(&s_ctr[4], 1u);
-		if (pos < PFM_STAGE) s_stage[pos] = make_uint2(li, refIx);
-		else { const uint32_t gp = atomicAdd(n_tasks, 1u); if (gp < task_cap) tasks[gp] = make_uint2(li, refIx); }
-	};
-	auto flush = [&]() {
-		__syncthreads();
-		const uint32_t n = s_ctr[4] < PFM_STAGE ? s_ctr[4] : PFM_STAGE;
-		uint32_t base = 0;
-		if (n) {
-			if (lane == 0) base = atomicAdd(n_tasks, n);
-			base = __shfl(base, 0);
-			for (uint32_t i = lane; i < n; i += 64) if (base + i < task_cap) tasks[base + i] = s_stage[i];
-		}
-		__syncthreads();
-		if (lane == 0) s_ctr[4] = 0;
-		__syncthreads();
-	};
-	uint32_t tcnt = 0;                      // touched slots of this lane's own group (replicated in its 16 lanes)
-	auto lanes_add = [&](uint32_t tg, uint32_t c, uint32_t code) {   // pass 2: only candidate clumps have a non-zero low byte
-		const uint32_t key = (c + 1u) << 8;
-		uint32_t slot = (c * 0x9E3779B1u) >> (32 - HTB);
-		const uint32_t *tab = s_tab[tg];
-		for (uint32_t probes = 0; probes < (1u << HTB); ++probes, slot = (slot + 1) & ((1u << HTB) - 1)) {
-			const uint32_t v = tab[slot];
-			if (v == 0) return;
-			if ((v & 0xFFFFFF00u) == key) {
-				const uint32_t ci = v & 255u;
-				if (ci) {
-					const uint32_t mask = s_lut[code & 255u];
-					if (mask & 0xFFu) atomicAdd(&s_cc[tg][ci - 1][0], spread8(mask & 0xFFu));
-					if (mask >> 8) atomicAdd(&s_cc[tg][ci - 1][1], spread8(mask >> 8));
-				}
-				return;
-			}
-		}
-	};
-
-	const uint32_t n_quads = (n_list + 3) >> 2;
-	// (need, words, length) and the first 16 list ranges of the next quad are fetched one iteration ahead (k_seed_ranges
-	// produced them), so the only exposed memory round trip per quad is the list records themselves
-	uint2 hd_n = make_uint2(0, 0), rg_n = make_uint2(0, 0);
-	if (blockIdx.x * 4 + g < n_list) { hd_n = hdr[blockIdx.x * 4 + g]; if (gl < W16) rg_n = ranges[(size_t)(blockIdx.x * 4 + g) * W16 + gl]; }
-	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
-		const uint32_t li = quad * 4 + g;
-		const bool live = li < n_list;
-		tcnt = 0;
-		const uint2 hd = hd_n, rg = rg_n;
-		{
-			const uint32_t li_n = (quad + gridDim.x) * 4 + g;
-			hd_n = make_uint2(0, 0); rg_n = make_uint2(0, 0);
-			if (quad + gridDim.x < n_quads && li_n < n_list) { hd_n = hdr[li_n]; if (gl < W16) rg_n = ranges[(size_t)li_n * W16 + gl]; }
-		}
-		const uint32_t need = hd.x & 0xFFFFu, nwords = live ? hd.x >> 16 : 0u, len = hd.y & 0xFFFu;
-		uint32_t maxw = nwords;
-		#pragma unroll
-		for (int o = 32; o >= 1; o >>= 1) { const uint32_t t = __shfl_xor(maxw, o); maxw = t > maxw ? t : maxw; }
-		auto word_range = [&](uint32_t j, unsigned long long &beg, uint32_t &n) {
-			uint2 r = make_uint2(0, 0);
-			if (live && j < nwords) r = ranges[(size_t)li * W16 + j];
-			beg = (unsigned long long)r.x | (unsigned long long)(r.y >> 24) << 32; n = r.y & 0xFFFFFFu;
-		};
-		PFM_T(0);
-		// ---- pass 1: clump-level counts.  The (up to 16) lists of a query are walked as ONE flattened record stream by the
-		// 16 lanes of its group: record i belongs to the list k with excl[k] <= i < excl[k+1] (4-step search over the group's
-		// exclusive prefix sums), so the lanes stay busy whatever the individual list lengths.  Blocks of 4 rounds (64
-		// records per query) are loaded together and updated in lock step; the first PFM_RB blocks stay in registers for pass 2.
-		const unsigned long long beg = live ? ((unsigned long long)rg.x | (unsigned long long)(rg.y >> 24) << 32) : 0ull;
-		const uint32_t n0 = live ? rg.y & 0xFFFFFFu : 0u;
-		my_ent += n0;
-		auto group_scan = [&](uint32_t n, uint32_t &T, uint32_t &excl) {
-			uint32_t ps = n;
-			#pragma unroll
-			for (uint32_t o = 1; o < 16; o <<= 1) { const uint32_t t = __shfl_up(ps, o, 16); if (gl >= o) ps += t; }
-			T = __shfl(ps, 15, 16);
-			excl = ps - n;
-		};
-		auto wave_blocks = [&](uint32_t T) -> uint32_t {
-			uint32_t m = T, t;
-			t = __shfl_xor(m, 16); m = t > m ? t : m;
-			t = __shfl_xor(m, 32); m = t > m ? t : m;
-			return (m + 63) >> 6;
-		};
-		auto load4 = [&](uint32_t ex, unsigned long long dl, uint32_t T, uint32_t b, uint2 (&rec)[4]) {
-			#pragma unroll
-			for (uint32_t u = 0; u < 4; ++u) {
-				const uint32_t i = (b * 4 + u) * 16 + gl;
-				uint32_t kk = 0;
-				kk += __shfl(ex, 8, 16) <= i ? 8u : 0u;
-				kk += __shfl(ex, kk + 4, 16) <= i ? 4u : 0u;
-				kk += __shfl(ex, kk + 2, 16) <= i ? 2u : 0u;
-				kk += __shfl(ex, kk + 1, 16) <= i ? 1u : 0u;
-				const unsigned long long addr = __shfl(dl, kk, 16) + i;
-				const uint32_t v = bhip_acx_raw_or_pad(ent, addr, i < T, hdr, sink);
-				rec[u] = make_uint2(v == BHIP_REC_PAD ? 0xFFFFFFFFu : v & 0xFFFFFFu, v >> 24);      // .y = lane-set code
-			}
-		};
-		auto bump_block = [&](uint2 (&rec)[4]) {
-			const uint32_t c[4] = {rec[0].x, rec[1].x, rec[2].x, rec[3].x};
-			const bool valid[4] = {c[0] != 0xFFFFFFFFu, c[1] != 0xFFFFFFFFu, c[2] != 0xFFFFFFFFu, c[3] != 0xFFFFFFFFu};
-			uint32_t slot[4]; bool ins[4], fail;
-			pfm_bump4<HTB>(s_tab[g], &s_dummy[lane], c, valid, slot, ins, fail);
-			if (fail) s_ovf[g] = 1;
-			#pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				rec[u].y |= slot[u] << 16;
-				const uint32_t m16 = (uint32_t)(__ballot(ins[u]) >> (lane & 48u)) & 0xFFFFu;
-				if (ins[u]) {
-					const uint32_t pos = tcnt + __popc(m16 & ((1u << gl) - 1u));
-					if (pos < (1u << (HTB - 1))) s_tl[g][pos] = (uint16_t)slot[u]; else s_ovf[g] = 1;
-				}
-				tcnt += __popc(m16);
-			}
-		};
-		uint32_t T0, ex0;
-		group_scan(n0, T0, ex0);
-		const unsigned long long dl0 = beg - ex0;
-		const uint32_t nblk0 = wave_blocks(T0);
-		uint2 rc[PFM_RB][4];           // .x = clump, .y = lane-set code | slot << 16
-		#pragma unroll
-		for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) load4(ex0, dl0, T0, b, rc[b]);
-		PFM_T(6);
-		#pragma unroll
-		for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) bump_block(rc[b]);
-		PFM_T(7);
-		for (uint32_t b = PFM_RB; b < nblk0; ++b) { uint2 rec[4]; load4(ex0, dl0, T0, b, rec); bump_block(rec); }
-		for (uint32_t base = 16; base < maxw; base += 16) {       // queries with more than 16 sampled words: further chunks, not cached
-			unsigned long long xb; uint32_t xn, T, ex;
-			word_range(base + gl, xb, xn);
-			my_ent += xn;
-			group_scan(xn, T, ex);
-			const uint32_t nb = wave_blocks(T);
-			for (uint32_t b = 0; b < nb; ++b) { uint2 rec[4]; load4(ex, xb - ex, T, b, rec); bump_block(rec); }
-		}
-		__syncthreads();
-		PFM_T(2);
-		// ---- select candidates
-		const uint32_t nt = tcnt < (1u << (HTB - 1)) ? tcnt : (1u << (HTB - 1));
-		const uint32_t ovf = s_ovf[g];
-		const uint32_t thr = need ? need : 1u;          // a lane (hence its clump) is a candidate iff count >= max(need, 1)
-		if (live && !ovf) {
-			for (uint32_t i = gl; i < nt; i += 16) {
-				const uint32_t slot = s_tl[g][i], v = s_tab[g][slot];
-				uint32_t tag = 0;
-				if ((v & 255u) >= thr) {
-					const uint32_t ci = atomicAdd(&s_ctr[5 + g], 1u);
-					const uint32_t c = (v >> 8) - 1u;
-					if (ci < CAND) { tag = ci + 1; s_cclump[g][ci] = c; }
-					else {   // too many candidate clumps for the lane counters: hand the clump to the 16-lane kernel
-						const uint32_t gp = atomicAdd(n_pairs, 1u);
-						if (gp < pair_cap) pairs[gp] = make_uint2(li, c);
-					}
-				}
-				s_tab[g][slot] = (v & 0xFFFFFF00u) | tag;
-			}
-		}
-		__syncthreads();
-		PFM_T(3);
-		// ---- pass 2: lane counters of the candidate clumps
-		const uint32_t ncand = s_ctr[5 + g] < CAND ? s_ctr[5 + g] : CAND;
-		const bool mine = live && !ovf && ncand > 0;
-		if (__any(mine)) {
-			#pragma unroll
-			for (uint32_t b = 0; b < PFM_RB; ++b) if (b < nblk0) {
-				uint32_t ci[4];
-				#pragma unroll
-				for (int u = 0; u < 4; ++u) ci[u] = s_tab[g][rc[b][u].y >> 16];      // slot 0 for padding records: harmless read
-				#pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const uint32_t tag = ci[u] & 255u, mask = s_lut[rc[b][u].y & 255u];
-					if (mine && rc[b][u].x != 0xFFFFFFFFu && tag) {
-						if (mask & 0xFFu) atomicAdd(&s_cc[g][tag - 1][0], spread8(mask & 0xFFu));
-						if (mask >> 8) atomicAdd(&s_cc[g][tag - 1][1], spread8(mask >> 8));
-					}
-				}
-			}
-			for (uint32_t b = PFM_RB; b < nblk0; ++b) {
-				uint2 rec[4];
-				load4(ex0, dl0, T0, b, rec);
-				#pragma unroll
-				for (int u = 0; u < 4; ++u) if (mine && rec[u].x != 0xFFFFFFFFu) lanes_add(g, rec[u].x, rec[u].y);
-			}
-			for (uint32_t base = 16; base < maxw; base += 16) {
-				unsigned long long xb; uint32_t xn, T, ex;
-				word_range(base + gl, xb, xn);
-				group_scan(xn, T, ex);
-				const uint32_t nb = wave_blocks(T);
-				for (uint32_t b = 0; b < nb; ++b) {
-					uint2 rec[4];
-					load4(ex, xb - ex, T, b, rec);
-					#pragma unroll
-					for (int u = 0; u < 4; ++u) if (mine && rec[u].x != 0xFFFFFFFFu) lanes_add(g, rec[u].x, rec[u].y);
-				}
-			}
-		}
-		__syncthreads();
-		PFM_T(4);
-		// ---- emit tasks, clear
-		if (live && !ovf) {
-			for (uint32_t i = gl; i < ncand; i += 16) {
-				const uint32_t c = s_cclump[g][i];
-				const unsigned long long lo = s_cc[g][i][0], hi = s_cc[g][i][1];
-				s_cc[g][i][0] = 0; s_cc[g][i][1] = 0;
-				uint32_t any = 0;
-				#pragma unroll
-				for (uint32_t z = 0; z < 16; ++z) {
-					const uint32_t v = (uint32_t)(((z < 8 ? lo : hi) >> (8 * (z & 7))) & 255u);
-					const uint32_t refIx = c * 16 + z;
-					if (v >= thr && refIx < tot_refs) { push(li, refIx); any = 1; }
-				}
-				if (any) { ++my_units; my_cols += clump_len[c]; my_qlen += len; }
-			}
-			for (uint32_t i = gl; i < nt; i += 16) s_tab[g][s_tl[g][i]] = 0;
-			for (uint32_t i = gl; i < n_bad; i += 16) {        // burst.c:4136-4138, 4282-4283: every lane of the ambiguous clumps
-				const uint32_t c = bad[i];
-				for (uint32_t z = 0; z < 16; ++z) if (c * 16 + z < tot_refs) push(li, c * 16 + z);
-				++my_units; my_cols += clump_len[c]; my_qlen += len;
-			}
-		} else if (ovf) {
-			for (uint32_t i = gl; i < (1u << HTB); i += 16) s_tab[g][i] = 0;
-			for (uint32_t i = gl; i < CAND; i += 16) { s_cc[g][i][0] = 0; s_cc[g][i][1] = 0; }
-			if (live && gl == 0) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
-		}
-		__syncthreads();
-		if (gl == 0) { s_ctr[g] = 0; s_ctr[5 + g] = 0; s_ovf[g] = 0; }
-		if (s_ctr[4] >= PFM_STAGE / 2) flush(); else __syncthreads();
-		PFM_T(5);
-	}
-	flush();
-#ifdef PFM_PROF
-	if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_pfm_prof[i], my_t[i]);
-#endif
-	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
-	if (my_units) { atomicAdd(unit_sum, my_units); atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
-	if (n_list == 0xFFFFFFFFu) fb_list[0] = sink;       // never: keeps the record loads unconditional
-}
-
-// ------------------------------------------------------------------------------------------------
-// Lane-resolved prefilter, counting-filter variant (same inputs and outputs as k_prefilter_mask).
-// Most list records of a query belong to clumps that share only one or two words with it; the exact per-clump hash
-// table of k_prefilter_mask pays a returning compare-and-swap for each of them.  Here every record first bumps one of
-// 1 << CB approximate 16-bit counters (hash of the clump id, fire-and-forget LDS adds, no key, no probing).  A record
-// whose counter stays below `need` cannot belong to a candidate clump (its counter is an upper bound of its clump's
-// count), so only the survivors -- about one record in six on the bench workload -- are looked at again: they are
-// compacted through a small LDS ring so that 16 lanes work on 16 survivors, inserted by clump id into a small exact
-// table that carries the sixteen 8-bit lane counters directly, and the lanes that reach `need` are emitted.  No
-// false negatives: a record of a clump with count >= need always survives; false survivors only cost work.
-// ------------------------------------------------------------------------------------------------
-#ifndef CF_MINWAVES
-#define CF_MINWAVES 3
-#endif
-// The workgroup of this kernel is ONE wave: its LDS operations are issued and completed in program order, so a later read sees an
-// earlier update by any lane without a barrier.  __syncthreads() would still cost an s_waitcnt vmcnt(0) lgkmcnt(0) -- a wait for
-// every load in flight, i.e. for the record prefetch of the NEXT quad that the software pipeline has just issued.  What the phases
-// need between them is only that the compiler keeps their LDS accesses in order.  (-DCF_BARRIERS=1 puts the barriers back.)
-#if defined(CF_BARRIERS) && CF_BARRIERS
-#define CF_WAVE_ORDER() __syncthreads()
-#else
-#define CF_WAVE_ORDER() __asm__ volatile("" ::: "memory")
-#endif
-// inclusive prefix sum over the 64 lanes of a wave (all lanes active): four shifts inside each row of 16 lanes, then lane 15 of
-// rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3 -- data-parallel-primitive moves, no LDS round trip
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
-	int v = (int)x;
-	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);    // row_shr:1
-	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);    // row_shr:2
-	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);    // row_shr:4
-	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);    // row_shr:8
-	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);    // row_bcast:15 -> rows 1, 3
-	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);    // row_bcast:31 -> rows 2, 3
-	return (uint32_t)v;
-}
-template <int CB, int RBT>
-__global__ __launch_bounds__(64, CF_MINWAVES) void k_prefilter_cf(
-		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
-		const uint32_t *__restrict__ ent,   // 4-byte (clump, lane-set code) records
-		const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ clump_len, uint32_t tot_refs,
-		uint2 *__restrict__ tasks, uint32_t *__restrict__ n_tasks, uint32_t task_cap,
-		unsigned long long *__restrict__ ent_read,
-		uint32_t *__restrict__ fb_list, uint32_t *__restrict__ n_fb,
-		unsigned long long *__restrict__ unit_sum, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum,
-		unsigned long long *__restrict__ surv_sum,
-		uint2 *__restrict__ tasks2, uint32_t *__restrict__ n_tasks2, int prune,     // prune: lanes that cannot hold a minimum go to tasks2 with their lower bound
-		const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel_dev, int byte_counters) { // sel: optional: only the list positions sel[0 .. *n_sel_dev) -- the second pass over the
-		                                                                            // queries that overflowed the first pass's tables, with the largest tables
-	constexpr uint32_t NCNT = 1u << CB;                                   // approximate counters per query (16 bit each)
-	constexpr uint32_t LT = CB <= 9 ? 64u : (CB == 10 ? 128u : 256u);     // exact lane-table slots per query
-	constexpr uint32_t CF_STAGE = 64u;                                     // staged tasks per output list
-	constexpr uint32_t RING = 32u;                                         // >= 15 pending + 16 new survivors (the ring is drained after every 16 offered records); a power of two
-	__shared__ __attribute__((aligned(16))) uint32_t s_cnt[4][NCNT / 2];
-	__shared__ uint32_t s_key[4][LT];
-	__shared__ unsigned long long s_lc[4][LT][2];
-	__shared__ uint32_t s_ring[4][RING];                                   // raw record words
-	__shared__ uint16_t s_lut[256];                                        // lane-set code -> lane mask
-	__shared__ uint8_t s_used[4][LT];                                      // slots of the lane table in use (LT <= 256)
-	__shared__ uint2 s_stage[2][CF_STAGE];
-	__shared__ uint32_t s_ovf[4];
-	__shared__ uint32_t s_dummy[16];          // compare-and-swap target of idle lanes (never written: the compare value cannot match)
-	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
-	if (lane < 16) s_dummy[lane] = 0;
-	for (uint32_t i = lane; i < 256; i += 64) s_lut[i] = (uint16_t)bhip_lane_code_mask(i);
-	for (uint32_t i = lane; i < 4 * NCNT / 2; i += 64) (&s_cnt[0][0])[i] = 0;
-	for (uint32_t i = lane; i < 4 * LT; i += 64) { (&s_key[0][0])[i] = 0; (&s_lc[0][0][0])[2 * i] = 0; (&s_lc[0][0][0])[2 * i + 1] = 0; }
-	if (lane < 4) s_ovf[lane] = 0;
-	__syncthreads();
-	unsigned long long my_ent = 0, my_units = 0, my_cols = 0, my_qlen = 0, my_surv = 0;
-	uint32_t sink = 0, sink_h = 0;          // see bhip_acx_raw_or_pad (bhip_internal.h)
-#ifdef PFM_PROF
-	unsigned long long my_t[8] = {0,0,0,0,0,0,0,0}, t_last = wall_clock64();
-#endif
-
-	// Staged tasks: this block is ONE wave, so the fill counts of the two output lists are wave-uniform registers and the
-	// positions of a lane's tasks come from a prefix sum over the wave: no LDS atomics, no per-task round trip.
-	// which = 0: first sweep, 1: deferred (li_lb = li | bound << 24).
-	uint32_t nst[2] = {0u, 0u};
-	const unsigned long long lt_mask = (1ull << lane) - 1ull;
-	auto flush_one = [&](uint32_t which) {
-		const uint32_t n = nst[which];
-		if (n) {
-			uint32_t base = 0;
-			if (lane == 0) base = atomicAdd(which ? n_tasks2 : n_tasks, n);
-			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-			uint2 *dst = which ? tasks2 : tasks;
-			if (lane < n && base + lane < task_cap) dst[base + lane] = s_stage[which][lane];
-			__syncthreads();
-		}
-		nst[which] = 0;
-	};
-	auto put_row = [&](uint32_t which, bool mine, uint32_t li_lb, uint32_t refIx) {     // wave-uniform call; `mine`: this lane has a task for list `which`
-		const unsigned long long m = __ballot(mine);
-		const uint32_t cnt = (uint32_t)__popcll(m);
-		if (!cnt) return;
-		if (nst[which] + cnt > CF_STAGE) flush_one(which);
-		if (mine) s_stage[which][nst[which] + (uint32_t)__popcll(m & lt_mask)] = make_uint2(li_lb, refIx);
-		nst[which] += cnt;
-	};
-	auto flush = [&]() { flush_one(0); flush_one(1); };
-
-	const uint32_t n_items = sel ? (*n_sel_dev < n_list ? *n_sel_dev : n_list) : n_list;      // queries this launch works on
-	const uint32_t n_quads = (n_items + 3) >> 2;
-	constexpr uint32_t RB = RBT;             // blocks of 64 records per query that are fetched one quad ahead and stay in registers between the two looks
-	                                         // (2, 3 or 4: the launcher takes the smallest that holds the expected record stream of a query -- what lies
-	                                         // beyond is loaded where it is consumed, twice, with its latency exposed: 40 % of the kernel at 150 records per read)
-	// (cross-lane moves by data-parallel primitives and lane reads where the pattern is fixed: a shuffle is an LDS round trip, and
-	// this kernel's time is the sum of its dependent LDS round trips)
-#define GROUP_PICK(v, l) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x150 + (l), 0xF, 0xF, false))      /* lane l (0..15, a constant) of the own group: row_newbcast */
-	auto wave_max4 = [&](uint32_t v) -> uint32_t {                    // maximum over the four groups of a group-uniform value
-		const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
-			c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-		const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
-		return ab > cd ? ab : cd;
-	};
-	auto group_scan = [&](uint32_t n, uint32_t &T, uint32_t &excl) {
-		int ps = (int)n;
-		ps += __builtin_amdgcn_update_dpp(0, ps, 0x111, 0xF, 0xF, false);    // row_shr:1 (a row = the 16 lanes of a group; lanes without a source add 0)
-		ps += __builtin_amdgcn_update_dpp(0, ps, 0x112, 0xF, 0xF, false);    // row_shr:2
-		ps += __builtin_amdgcn_update_dpp(0, ps, 0x114, 0xF, 0xF, false);    // row_shr:4
-		ps += __builtin_amdgcn_update_dpp(0, ps, 0x118, 0xF, 0xF, false);    // row_shr:8
-		T = GROUP_PICK(ps, 15);
-		excl = (uint32_t)ps - n;
-	};
-	auto wave_blocks = [&](uint32_t T) -> uint32_t { return (wave_max4(T) + 63) >> 6; };
-	auto load4 = [&](uint32_t ex, unsigned long long dl, uint32_t T, uint32_t b, uint32_t (&rec)[4]) {      // see k_prefilter_mask
-		#pragma unroll
-		for (uint32_t u = 0; u < 4; ++u) {
-			const uint32_t i = (b * 4 + u) * 16 + gl;
-			uint32_t kk = 0;
-			if (W16 > 8) kk += __shfl(ex, 8, 16) <= i ? 8u : 0u;      // (uniform) with 8 words per query the upper half is empty
-			kk += __shfl(ex, kk + 4, 16) <= i ? 4u : 0u;
-			kk += __shfl(ex, kk + 2, 16) <= i ? 2u : 0u;
-			kk += __shfl(ex, kk + 1, 16) <= i ? 1u : 0u;
-			const unsigned long long addr = __shfl(dl, kk, 16) + i;
-			rec[u] = bhip_acx_raw_or_pad(ent, addr, i < T, hdr, sink);
-		}
-	};
-	// Software pipeline over the quads of this block: the header and list ranges (k_seed_ranges made them) are fetched TWO
-	// iterations ahead and the first RB blocks of list records ONE iteration ahead, so that the gather of a quad's records --
-	// short reads at random addresses, 43 % of the wave cycles when it was waited for in place -- runs while the previous
-	// quad is counted.
-	// (unconditional loads from clamped, always valid addresses, masked afterwards: a load under a condition is compiled as a
-	// branch with an s_waitcnt vmcnt(0) at its join, which would expose the latency this prefetch is there to hide -- and wait
-	// for every other load in flight)
-	typedef const unsigned long long __attribute__((address_space(1))) *g64_t;
-	auto fetch_hdr_issue = [&](uint32_t quad, unsigned long long &h, unsigned long long &r) {      // raw words; nothing here waits for them
-		const uint32_t it = quad * 4 + g;
-		const bool ok = it < n_items, okw = ok && gl < W16;         // (it < n_items implies quad < n_quads)
-		uint32_t lic = ok ? it : 0u;
-		if (sel) lic = n_items ? sel[lic] : 0u;                     // (wave-uniform branch; the first pass has no selection)
-		h = ((g64_t)(uintptr_t)(hdr + lic))[0]; r = ((g64_t)(uintptr_t)(ranges + ((size_t)lic * W16 + (okw ? gl : 0u))))[0];
-	};
-	auto fetch_hdr_finish = [&](uint32_t quad, unsigned long long h, unsigned long long r, uint2 &hd, uint2 &rg) {
-		const uint32_t it = quad * 4 + g;
-		const bool ok = it < n_items, okw = ok && gl < W16;
-		sink_h ^= (uint32_t)h + (uint32_t)r;         // (its own chain: folded into `sink`, the compiler consumes the words where that chain is first touched)
-		const uint32_t mh = ok ? 0xFFFFFFFFu : 0u, mr = okw ? 0xFFFFFFFFu : 0u;
-		hd = make_uint2((uint32_t)h & mh, (uint32_t)(h >> 32) & mh);
-		rg = make_uint2((uint32_t)r & mr, (uint32_t)(r >> 32) & mr);
-	};
-	auto fetch_hdr = [&](uint32_t quad, uint2 &hd, uint2 &rg) { unsigned long long h, r; fetch_hdr_issue(quad, h, r); fetch_hdr_finish(quad, h, r, hd, rg); };
-	// issue: the record words of the first RB blocks of a quad's record stream (nothing here waits for them)
-	auto start_stream = [&](uint32_t quad, const uint2 &rg, uint32_t &T, uint32_t &ex, unsigned long long &dl, uint32_t &nblk, uint32_t (&raw)[RB][4]) -> uint32_t {
-		const bool lv = quad < n_quads && quad * 4 + g < n_items;
-		const unsigned long long beg = lv ? ((unsigned long long)rg.x | (unsigned long long)(rg.y >> 24) << 32) : 0ull;
-		const uint32_t n0 = lv ? rg.y & 0xFFFFFFu : 0u;
-		group_scan(n0, T, ex);
-		dl = beg - ex;
-		nblk = wave_blocks(T);
-		// which list does stream position i belong to: the search over the group's exclusive prefix sums, all RB * 4 positions of
-		// this lane stage by stage (their cross-lane reads are in flight together: one LDS round trip per stage, not per position)
-		uint32_t kk[RB * 4];
-		if (W16 <= 8) {
-			// eight lists: the seven inner boundaries are broadcast inside the group (data-parallel moves) and the binary search
-			// becomes a selection tree in registers -- no LDS round trip at all
-			const uint32_t e1 = GROUP_PICK(ex, 1), e2 = GROUP_PICK(ex, 2), e3 = GROUP_PICK(ex, 3), e4 = GROUP_PICK(ex, 4),
-				e5 = GROUP_PICK(ex, 5), e6 = GROUP_PICK(ex, 6), e7 = GROUP_PICK(ex, 7);
-			#pragma unroll
-			for (uint32_t j = 0; j < RB * 4; ++j) {
-				const uint32_t i = j * 16 + gl;
-				const bool a = e4 <= i;
-				const bool b = (a ? e6 : e2) <= i;
-				const uint32_t lo13 = b ? e3 : e1, hi57 = b ? e7 : e5;
-				const bool c = (a ? hi57 : lo13) <= i;
-				kk[j] = (a ? 4u : 0u) + (b ? 2u : 0u) + (c ? 1u : 0u);
-			}
-		} else {
-			const uint32_t e8 = GROUP_PICK(ex, 8);
-			#pragma unroll
-			for (uint32_t j = 0; j < RB * 4; ++j) kk[j] = e8 <= j * 16 + gl ? 8u : 0u;
-			#pragma unroll
-			for (uint32_t step = 4; step >= 1; step >>= 1) {
-				uint32_t t[RB * 4];
-				#pragma unroll
-				for (uint32_t j = 0; j < RB * 4; ++j) t[j] = __shfl(ex, kk[j] + step, 16);
-				#pragma unroll
-				for (uint32_t j = 0; j < RB * 4; ++j) kk[j] += t[j] <= j * 16 + gl ? step : 0u;
-			}
-		}
-		unsigned long long base[RB * 4];
-		#pragma unroll
-		for (uint32_t j = 0; j < RB * 4; ++j) base[j] = __shfl(dl, kk[j], 16);
-		#pragma unroll
-		for (uint32_t b = 0; b < RB; ++b) {
-			#pragma unroll
-			for (uint32_t u = 0; u < 4; ++u) {
-				const uint32_t i = (b * 4 + u) * 16 + gl;
-				raw[b][u] = bhip_acx_raw_issue(ent, base[b * 4 + u] + i, i < T, hdr);
-			}
-		}
-		return n0;
-	};
-	// consume: padding where the stream has ended
-	auto finish_stream = [&](uint32_t T, const uint32_t (&raw)[RB][4], uint32_t (&r)[RB][4]) {
-		#pragma unroll
-		for (uint32_t b = 0; b < RB; ++b) {
-			#pragma unroll
-			for (uint32_t u = 0; u < 4; ++u) r[b][u] = bhip_acx_raw_finish(raw[b][u], (b * 4 + u) * 16 + gl < T, sink);
-		}
-	};
-	uint2 hd_c, rg_c, hd_n, rg_n;
-	fetch_hdr(blockIdx.x, hd_c, rg_c);
-	fetch_hdr(blockIdx.x + gridDim.x, hd_n, rg_n);
-	uint32_t T0, ex0, nblk0; unsigned long long dl0;
-	uint32_t rc[RB][4], raw[RB][4];          // record words: clump | lane-set code << 24, BHIP_REC_PAD beyond the stream
-	uint32_t n0 = start_stream(blockIdx.x, rg_c, T0, ex0, dl0, nblk0, raw);
-	finish_stream(T0, raw, rc);
-	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
-		const bool live = quad * 4 + g < n_items;
-		const uint32_t li = sel ? (live ? sel[quad * 4 + g] : 0u) : quad * 4 + g;      // list position of this group's query
-		const uint2 hd = hd_c;
-		unsigned long long h_raw, r_raw;
-		fetch_hdr_issue(quad + 2 * gridDim.x, h_raw, r_raw);
-		uint32_t T1, ex1, nblk1; unsigned long long dl1;
-		const uint32_t n1 = start_stream(quad + gridDim.x, rg_n, T1, ex1, dl1, nblk1, raw);
-		const uint32_t need = hd.x & 0xFFFFu, nwords = live ? hd.x >> 16 : 0u, len = hd.y & 0xFFFu;
-		const uint32_t budget = (hd.y >> 12) & 255u, dper = (hd.y >> 20) & 15u ? (hd.y >> 20) & 15u : 1u;
-		const uint32_t thr = need ? need : 1u;
-		const uint32_t maxw = wave_max4(nwords);          // (nwords is the same in the 16 lanes of a group)
-		auto word_range = [&](uint32_t j, unsigned long long &beg, uint32_t &n) {
-			uint2 r = make_uint2(0, 0);
-			if (live && j < nwords) r = ranges[(size_t)li * W16 + j];
-			beg = (unsigned long long)r.x | (unsigned long long)(r.y >> 24) << 32; n = r.y & 0xFFFFFFu;
-		};
-		// A query whose whole record stream is at most 255 records cannot drive a counter beyond 255: its counters are BYTES, twice as
-		// many in the same LDS (2 << CB per query) -- half the load per counter, a third to a quarter of the false survivors (a survivor
-		// costs about eight records' worth of work).  Longer streams keep the 16-bit counters.  cshift = log2 of the counter's bits.
-		const bool nar = byte_counters && nwords <= 16u && T0 <= 255u;
-		const uint32_t cshift = nar ? 3u : 4u, cper = nar ? 3u : 1u, cmask = nar ? 0xFFu : 0xFFFFu, hsh = nar ? 0u : 1u;      // (group-uniform)
-		auto count4 = [&](const uint32_t (&rec)[4]) {     // phase A: approximate counters, no return values
-			#pragma unroll
-			for (int u = 0; u < 4; ++u) if (rec[u] != BHIP_REC_PAD) {
-				const uint32_t h = (((rec[u] & 0xFFFFFFu) * 0x9E3779B1u) >> (31 - CB)) >> hsh;      // CB + 1 bits (bytes) or CB bits
-				atomicAdd(&s_cnt[g][h >> (5u - cshift)], 1u << ((h & cper) << cshift));
-			}
-		};
-		uint32_t pending = 0, head = 0;          // survivors waiting in this group's ring (replicated in its 16 lanes)
-		uint32_t nused = 0;                      // slots of this group's lane table in use (replicated)
-		auto c_round = [&]() {                    // wave-uniform: every group moves up to 16 survivors into its lane table
-			const uint32_t take = pending < 16 ? pending : 16;
-			const bool active = gl < take;
-			const uint32_t hpos = (head + gl) & (RING - 1);
-			const uint32_t rec = active ? s_ring[g][hpos] : 0u;
-			const uint32_t clump = rec & 0xFFFFFFu, mask = s_lut[rec >> 24];
-			const uint32_t key = clump + 1u;
-			uint32_t slot = (clump * 0x85EBCA6Bu) >> (32 - (CB <= 9 ? 6 : (CB == 10 ? 7 : 8)));
-			bool act = active, found = false, fresh = false;
-			for (uint32_t probes = 0; __any(act) && probes < LT; ++probes) {
-				const uint32_t old = atomicCAS(act ? &s_key[g][slot] : &s_dummy[gl], act ? 0u : 0xFFFFFFFFu, key);
-				const bool ok = act && (old == 0 || old == key);
-				fresh |= act && old == 0;
-				found |= ok;
-				act = act && !ok;
-				slot = act ? (slot + 1) & (LT - 1) : slot;
-			}
-			if (act) s_ovf[g] = 1;
-			{
-				const uint32_t m16 = (uint32_t)(__ballot(fresh) >> (lane & 48u)) & 0xFFFFu;
-				if (fresh) s_used[g][nused + __popc(m16 & ((1u << gl) - 1u))] = (uint8_t)slot;
-				nused += __popc(m16);
-			}
-			if (found) {
-				if (mask & 0xFFu) atomicAdd(&s_lc[g][slot][0], spread8(mask & 0xFFu));
-				if (mask >> 8) atomicAdd(&s_lc[g][slot][1], spread8(mask >> 8));
-			}
-			head = (head + take) & (RING - 1);
-			pending -= take;
-		};
-		auto offer4 = [&](const uint32_t (&rec)[4]) {    // phase B: survivors of the counter test go to the ring
-			uint32_t cv[4];
-			#pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				const uint32_t h = rec[u] != BHIP_REC_PAD ? (((rec[u] & 0xFFFFFFu) * 0x9E3779B1u) >> (31 - CB)) >> hsh : 0u;
-				cv[u] = (s_cnt[g][h >> (5u - cshift)] >> ((h & cper) << cshift)) & cmask;
-			}
-			#pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				const bool surv = rec[u] != BHIP_REC_PAD && cv[u] >= thr;
-				const uint32_t m16 = (uint32_t)(__ballot(surv) >> (lane & 48u)) & 0xFFFFu;
-				if (surv) {
-					uint32_t pos = head + pending + __popc(m16 & ((1u << gl) - 1u));
-					pos &= RING - 1;
-					s_ring[g][pos] = rec[u];
-				}
-				pending += __popc(m16);
-				if (gl == 0) my_surv += __popc(m16);
-				while (__any(pending >= 16)) c_round();       // (at most 15 + 16 pending: the ring holds 32)
-			}
-		};
-
-		PFM_T(0);
-		my_ent += n0;
-		// ---- phase A over every record of the query
-		#pragma unroll
-		for (uint32_t b = 0; b < RB; ++b) if (b < nblk0) count4(rc[b]);
-		for (uint32_t b = RB; b < nblk0; b += 2) {      // (two blocks' loads in flight together)
-			uint32_t rec[4], rec2[4];
-			load4(ex0, dl0, T0, b, rec); load4(ex0, dl0, T0, b + 1, rec2);      // (a block beyond the stream is all padding)
-			count4(rec); count4(rec2);
-		}
-		uint32_t gtot = T0;                        // records of this group's query (16-bit counters: beyond 65 535 the query takes the dense fallback)
-		for (uint32_t base = 16; base < maxw; base += 16) {
-			unsigned long long xb; uint32_t xn, T, ex;
-			word_range(base + gl, xb, xn);
-			my_ent += xn;
-			group_scan(xn, T, ex);
-			gtot = gtot + T < gtot ? 0xFFFFFFFFu : gtot + T;
-			const uint32_t nb = wave_blocks(T);
-			for (uint32_t b = 0; b < nb; ++b) { uint32_t rec[4]; load4(ex, xb - ex, T, b, rec); count4(rec); }
-		}
-		if (gtot > 65535u && gl == 0) s_ovf[g] = 1;
-		CF_WAVE_ORDER();
-		PFM_T(7);
-		// ---- phase B: second look at every record (registers for the first blocks, L2 for the rest)
-		#pragma unroll
-		for (uint32_t b = 0; b < RB; ++b) if (b < nblk0) offer4(rc[b]);
-		for (uint32_t b = RB; b < nblk0; b += 2) {
-			uint32_t rec[4], rec2[4];
-			load4(ex0, dl0, T0, b, rec); load4(ex0, dl0, T0, b + 1, rec2);
-			offer4(rec); offer4(rec2);
-		}
-		for (uint32_t base = 16; base < maxw; base += 16) {
-			unsigned long long xb; uint32_t xn, T, ex;
-			word_range(base + gl, xb, xn);
-			group_scan(xn, T, ex);
-			const uint32_t nb = wave_blocks(T);
-			for (uint32_t b = 0; b < nb; ++b) { uint32_t rec[4]; load4(ex, xb - ex, T, b, rec); offer4(rec); }
-		}
-		PFM_T(2);
-		while (__any(pending > 0)) c_round();
-		CF_WAVE_ORDER();
-		PFM_T(3);
-		// ---- emit the lanes that reach the threshold, clear the tables
-		// Slot-parallel: lane gl of a group owns the group's gl-th used slot.  The positions of its tasks in the two staged lists
-		// come from ONE wave-wide prefix sum over the per-lane counts (DPP, no LDS round trip); the stores are fire-and-forget.
-		// A lane with c matching words lost (W_valid - c) words, one edit destroys at most `dper` of them: its edit distance
-		// is at least budget - (c - need) / dper.  Unless every hit within budget is wanted, only the lanes with the
-		// smallest bound are swept at once; the others wait for the minimum those produce (k_task_filter).
-		const uint32_t ovf = s_ovf[g];
-		const bool em = live && !ovf;
-		const uint32_t nu = em ? nused : 0u;
-		const uint32_t nu_max = wave_max4(nu);
-		const uint32_t inv_dper = 65536u / dper + 1u;        // x / dper == (x * inv_dper) >> 16 for x < 256, dper < 16
-		auto lanes_ge = [&](unsigned long long lo, unsigned long long hi, uint32_t t) -> uint32_t {
-			uint32_t m16 = 0;
-			if (nwords < 128) {      // byte-parallel compare: (b | 0x80) - t keeps its top bit iff b >= t; top bits gathered by a multiply
-				const unsigned long long H = 0x8080808080808080ull, L1 = 0x0101010101010101ull, G = 0x0102040810204080ull;
-				const unsigned long long tl = ((lo | H) - t * L1) & H, th = ((hi | H) - t * L1) & H;
-				m16 = (uint32_t)(((tl >> 7) * G) >> 56) | ((uint32_t)(((th >> 7) * G) >> 56) << 8);
-			} else {
-				#pragma unroll
-				for (uint32_t z = 0; z < 16; ++z) m16 |= ((uint32_t)(((z < 8 ? lo : hi) >> (8 * (z & 7))) & 255u) >= t ? 1u : 0u) << z;
-			}
-			return m16;
-		};
-		auto look = [&](uint32_t iu, uint32_t &slot, uint32_t &c, unsigned long long &lo, unsigned long long &hi) -> uint32_t {
-			const bool has = iu < nu;
-			slot = has ? (uint32_t)s_used[g][iu] : 0u;
-			c = s_key[g][slot] - 1u; lo = s_lc[g][slot][0]; hi = s_lc[g][slot][1];
-			const uint32_t first = c * 16u, nv = first < tot_refs ? (tot_refs - first < 16u ? tot_refs - first : 16u) : 0u;     // lanes of the clump that exist
-			return has ? lanes_ge(lo, hi, thr) & ((1u << nv) - 1u) : 0u;
-		};
-		auto byte_of = [&](unsigned long long lo, unsigned long long hi, uint32_t z) -> uint32_t { return (uint32_t)((z < 8 ? lo : hi) >> (8u * (z & 7u))) & 255u; };
-		auto group_max = [&](uint32_t v) -> uint32_t {      // maximum over the 16 lanes of the group: neighbours, pairs of neighbours, then the two mirror moves
-			int t;
-			t = __builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;     // quad_perm:[1,0,3,2]
-			t = __builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;     // quad_perm:[2,3,0,1]
-			t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;    // row_half_mirror
-			t = __builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;    // row_mirror
-			return v;
-		};
-		uint32_t slot0, c0; unsigned long long lo0, hi0;
-		const uint32_t m16_0 = look(gl, slot0, c0, lo0, hi0);
-		uint32_t cmax_all = 0;
-		if (prune) {
-			uint32_t cmax = 0;
-			for (uint32_t m = m16_0; m; m &= m - 1) { const uint32_t v = byte_of(lo0, hi0, (uint32_t)__builtin_ctz(m)); cmax = v > cmax ? v : cmax; }
-			for (uint32_t iu0 = 16; iu0 < nu_max; iu0 += 16) {
-				uint32_t sl, c; unsigned long long lo, hi;
-				for (uint32_t m = look(iu0 + gl, sl, c, lo, hi); m; m &= m - 1) { const uint32_t v = byte_of(lo, hi, (uint32_t)__builtin_ctz(m)); cmax = v > cmax ? v : cmax; }
-			}
-			cmax_all = group_max(cmax);
-		}
-		PFM_T(1);
-		auto emit_slots = [&](uint32_t iu, uint32_t slot, uint32_t c, unsigned long long lo, unsigned long long hi, uint32_t m16) {
-			if (iu < nu) { s_key[g][slot] = 0; s_lc[g][slot][0] = 0; s_lc[g][slot][1] = 0; }     // (this wave's reads of the slot are done: LDS operations of one wave stay in order)
-			const uint32_t m0 = prune ? m16 & lanes_ge(lo, hi, cmax_all > thr ? cmax_all : thr) : m16, m1 = m16 & ~m0;
-			const uint32_t cnt = (uint32_t)__popc(m0) | (uint32_t)__popc(m1) << 16;
-			const uint32_t incl = wave_incl_scan_u32(cnt), tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), excl = incl - cnt;
-			if (!tot) return;                         // wave-uniform
-			const uint32_t tot0 = tot & 0xFFFFu, tot1 = tot >> 16;
-			uint32_t p[2]; bool direct[2];
-			#pragma unroll
-			for (uint32_t w = 0; w < 2; ++w) {
-				const uint32_t tw = w ? tot1 : tot0, ew = w ? excl >> 16 : excl & 0xFFFFu;
-				direct[w] = false;
-				if (tw && nst[w] + tw > CF_STAGE) flush_one(w);
-				if (tw > CF_STAGE) {                  // more than the stage holds in one go: straight to the list
-					uint32_t base = 0;
-					if (lane == 0) base = atomicAdd(w ? n_tasks2 : n_tasks, tw);
-					p[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + ew; direct[w] = true;
-				} else { p[w] = nst[w] + ew; nst[w] += tw; }
-			}
-			PFM_T(5);
-			for (uint32_t m = m16; m; m &= m - 1) {
-				const uint32_t z = (uint32_t)__builtin_ctz(m), w = (m1 >> z) & 1u;
-				uint32_t lb = 0;
-				if (prune) { const uint32_t gain = ((byte_of(lo, hi, z) - need) * inv_dper) >> 16; lb = gain >= budget ? 0u : budget - gain; }
-				const uint2 task = make_uint2(li | lb << 24, c * 16u + z);
-				const uint32_t pos = p[w]; p[w] = pos + 1;
-				if (direct[w]) { if (pos < task_cap) (w ? tasks2 : tasks)[pos] = task; }
-				else s_stage[w][pos] = task;
-			}
-			if (m16) { ++my_units; my_qlen += len; }       // (the swept columns of lane tasks are counted by the sweep: tcol_sum)
-		};
-		emit_slots(gl, slot0, c0, lo0, hi0, m16_0);
-		for (uint32_t iu0 = 16; iu0 < nu_max; iu0 += 16) {
-			uint32_t sl, c; unsigned long long lo, hi;
-			const uint32_t m16 = look(iu0 + gl, sl, c, lo, hi);
-			emit_slots(iu0 + gl, sl, c, lo, hi, m16);
-		}
-		for (uint32_t i = 0; i < n_bad; ++i) {         // burst.c:4136-4138, 4282-4283: every lane of the ambiguous clumps
-			const uint32_t c = bad[i];
-			put_row(0, em && c * 16u + gl < tot_refs, li, c * 16u + gl);
-			if (em && gl == 0) { ++my_units; my_qlen += len; }
-		}
-		if (ovf) {
-			for (uint32_t i = gl; i < LT; i += 16) { s_key[g][i] = 0; s_lc[g][i][0] = 0; s_lc[g][i][1] = 0; }
-			if (live && gl == 0) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
-		}
-		PFM_T(4);
-		{
-			uint4 *cz = (uint4 *)&s_cnt[g][0];
-			for (uint32_t i = gl; i < NCNT / 8; i += 16) cz[i] = make_uint4(0, 0, 0, 0);
-		}
-		CF_WAVE_ORDER();
-		if (gl == 0) s_ovf[g] = 0;
-		CF_WAVE_ORDER();
-		PFM_T(5);
-		// rotate the pipeline
-		uint2 hd_nn, rg_nn;
-		fetch_hdr_finish(quad + 2 * gridDim.x, h_raw, r_raw, hd_nn, rg_nn);
-		hd_c = hd_n; hd_n = hd_nn; rg_n = rg_nn;
-		T0 = T1; ex0 = ex1; dl0 = dl1; nblk0 = nblk1; n0 = n1;
-		finish_stream(T0, raw, rc);          // the records fetched during this iteration are first looked at here
-		PFM_T(6);
-	}
-	flush();
-#ifdef PFM_PROF
-	if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_pfm_prof[i], my_t[i]);
-#endif
-	if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
-	if (surv_sum && my_surv) atomicAdd(surv_sum, my_surv);
-	if (n_list == 0xFFFFFFFFu) { fb_list[0] = sink; fb_list[1] = sink_h; }       // never: keeps the record loads unconditional
-	if (my_units) { atomicAdd(unit_sum, my_units); atomicAdd(col_sum, my_cols); atomicAdd(qlen_sum, my_qlen); }
-}
-#define BHIP_INST_PFCF(CB, RB) \
-	template __global__ void k_prefilter_cf<CB, RB>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, \
-		uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *, \
-		uint2 *, uint32_t *, int, const uint32_t *, const uint32_t *, int);
-BHIP_INST_PFCF(9, 2) BHIP_INST_PFCF(9, 3) BHIP_INST_PFCF(9, 4) BHIP_INST_PFCF(10, 2) BHIP_INST_PFCF(10, 4) BHIP_INST_PFCF(11, 2) BHIP_INST_PFCF(11, 4)
-
-// ------------------------------------------------------------------------------------------------
-// Lane-resolved prefilter, counting filter with ONE QUERY PER WAVE (round 5; same inputs and outputs as k_prefilter_cf).
-// k_prefilter_cf gives a query 16 lanes and a wave four queries: right while a query's record stream is a few dozen records
-// (databases of a few GB), and register-bound beyond -- at the metric's size a query walks ~310 records, the kernel keeps 16
-// record registers per lane plus the next quad's 16 in flight (168 VGPRs: 3 waves per SIMD) and spends a quarter of its time
-// finding, per lane and stream position, which list the position belongs to (a selection tree over per-group boundaries).
-// Here the 64 lanes walk ONE query's stream, 64 records per row:
-//  * the list boundaries are WAVE-UNIFORM: lane l holds list l's end position and biased base address, a scalar cursor walks
-//    them (v_readlane with a scalar index), and a row costs one address select per list boundary that falls into it -- about
-//    1.4 per row instead of a tree per position;
-//  * a row is one VGPR: 6 resident rows (384 records) + their list numbers are 12 registers, the kernel runs at 8 waves per
-//    SIMD and hides its gather behind the other waves instead of behind a software pipeline;
-//  * the approximate counters are LIST MASKS: a slot holds one bit per list (a list names a clump at most once, burst.c:3385-3386,
-//    so "lists with a record in this slot" is the same upper bound of a clump's count as "records in this slot") -- a byte per slot
-//    for up to 8 lists, whatever the stream's length: 1 024 slots in the kilobyte that held 512 sixteen-bit counters, OR instead of
-//    ADD (idempotent: the lanes beyond the stream's end repeat its last record instead of being masked), no overflow;
-//    MODE 1: 16 lists, 512 halfword slots; MODE 2: any number of lists, 512 sixteen-bit counters as before;
-//  * the slot of a clump is its low bits: the clump numbers of a list are unrelated, a multiply per record buys nothing;
-//  * the exact lane table, the survivor ring and the emit work on 64 survivors / 4 table slots x 16 reference lanes at a time.
-// No false negatives, as before: a record of a clump that >= need lists name finds >= need bits in its slot.
-// BIG = 1: four times the slots and the lane table, for the second pass over queries that overflowed the first.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {      // maximum over the 64 lanes (all active), in every lane
-	int v = (int)x, t;
-	t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false); v = (uint32_t)t > (uint32_t)v ? t : v;    // row_shr:1
-	t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false); v = (uint32_t)t > (uint32_t)v ? t : v;    // row_shr:2
-	t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false); v = (uint32_t)t > (uint32_t)v ? t : v;    // row_shr:4
-	t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false); v = (uint32_t)t > (uint32_t)v ? t : v;    // row_shr:8
-	const uint32_t a = (uint32_t)__builtin_amdgcn_readlane(v, 15), b = (uint32_t)__builtin_amdgcn_readlane(v, 31),
-		c = (uint32_t)__builtin_amdgcn_readlane(v, 47), d = (uint32_t)__builtin_amdgcn_readlane(v, 63);
-	const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
-	return ab > cd ? ab : cd;
-}
-template <int MODE, int BIG>
-__global__ __launch_bounds__(64) void k_prefilter_cw(
-		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
-		const uint32_t *__restrict__ ent,   // 4-byte (clump, lane-set code) records
-		const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ clump_len, uint32_t tot_refs,
-		uint2 *__restrict__ tasks, uint32_t *__restrict__ n_tasks, uint32_t task_cap,
-		unsigned long long *__restrict__ ent_read,
-		uint32_t *__restrict__ fb_list, uint32_t *__restrict__ n_fb,
-		unsigned long long *__restrict__ unit_sum, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum,
-		unsigned long long *__restrict__ surv_sum,
-		uint2 *__restrict__ tasks2, uint32_t *__restrict__ n_tasks2, int prune,
-		const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel_dev, int) {
-	constexpr uint32_t FB = MODE == 0 ? 8u : 16u;                         // bits per slot
-	constexpr uint32_t SB = MODE == 0 ? 2u : 1u;                          // log2 slots per dword
-	constexpr uint32_t NDW = BIG ? 1024u : 256u;                          // dwords of slots: 1 KB (4 KB)
-	constexpr uint32_t NS = NDW << SB;                                    // slots
-	constexpr uint32_t LTB = BIG ? 8u : 6u, LT = 1u << LTB;               // exact lane-table slots
-	constexpr uint32_t RING = 128u;                                       // <= 63 pending + 64 new survivors
-	constexpr uint32_t CW_STAGE = 64u;
-	constexpr uint32_t R = 6u;                                            // rows of 64 records that stay in registers between the two looks
-	__shared__ __attribute__((aligned(16))) uint32_t s_cnt[NDW];
-	__shared__ uint32_t s_key[LT];
-	__shared__ unsigned long long s_lc[LT][2];
-	__shared__ uint32_t s_ring[RING];
-	__shared__ uint16_t s_lut[256];
-	__shared__ uint8_t s_used[LT];
-	__shared__ uint2 s_stage[2][CW_STAGE];
-	const uint32_t lane = threadIdx.x, z = lane & 15u, sg = lane >> 4;
-	for (uint32_t i = lane; i < 256; i += 64) s_lut[i] = (uint16_t)bhip_lane_code_mask(i);
-	for (uint32_t i = lane; i < NDW; i += 64) s_cnt[i] = 0;
-	for (uint32_t i = lane; i < LT; i += 64) { s_key[i] = 0; s_lc[i][0] = 0; s_lc[i][1] = 0; }
-	__syncthreads();
-	unsigned long long my_ent = 0, my_units = 0, my_qlen = 0, my_surv = 0;
-	const unsigned long long lt_mask = (1ull << lane) - 1ull;
-#ifdef PFM_PROF
-	unsigned long long my_t[8] = {0,0,0,0,0,0,0,0}, t_last = wall_clock64();      // 0 lists + addresses + load issue, 1 first look (waits for the records), 2 second look, 3 survivor rounds, 4 emit, 5 clear, 6 loop top
-#endif
-	uint32_t nst[2] = {0u, 0u};
-	auto flush_one = [&](uint32_t which) {
-		const uint32_t n = nst[which];
-		if (n) {
-			uint32_t base = 0;
-			if (lane == 0) base = atomicAdd(which ? n_tasks2 : n_tasks, n);
-			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-			uint2 *dst = which ? tasks2 : tasks;
-			if (lane < n && base + lane < task_cap) dst[base + lane] = s_stage[which][lane];
-			CF_WAVE_ORDER();
-		}
-		nst[which] = 0;
-	};
-	auto put = [&](uint32_t which, bool mine, uint32_t a, uint32_t b) {      // wave-uniform call; `mine`: this lane has a task for list `which`
-		const unsigned long long m = __ballot(mine);
-		const uint32_t cnt = (uint32_t)__popcll(m);
-		if (!cnt) return;
-		if (nst[which] + cnt > CW_STAGE) flush_one(which);
-		if (mine) s_stage[which][nst[which] + (uint32_t)__popcll(m & lt_mask)] = make_uint2(a, b);
-		nst[which] += cnt;
-	};
-	const uint32_t n_items = sel ? (*n_sel_dev < n_list ? *n_sel_dev : n_list) : n_list;
-	const uint32_t Wc = W16 < 64u ? W16 : 64u;                            // lists of the first chunk (lane l holds list l)
-	const uint32_t n_chunks = (W16 + 63u) >> 6;
-	typedef const unsigned long long __attribute__((address_space(1))) *g64_t;
-	auto fetch = [&](uint32_t q, unsigned long long &h, unsigned long long &r) {      // header and the first 64 list ranges of item q (clamped: always a valid address)
-		const uint32_t qc = q < n_items ? q : 0u;
-		const uint32_t lic = sel ? (n_items ? sel[qc] : 0u) : qc;
-		h = ((g64_t)(uintptr_t)(hdr + lic))[0];
-		r = ((g64_t)(uintptr_t)(ranges + ((size_t)lic * W16 + (lane < Wc ? lane : 0u))))[0];
-	};
-	unsigned long long h_n, r_n;
-	fetch(blockIdx.x, h_n, r_n);
-	for (uint32_t q = blockIdx.x; q < n_items; q += gridDim.x) {
-		const uint32_t li = sel ? sel[q] : q;
-		const uint2 hd = make_uint2((uint32_t)h_n, (uint32_t)(h_n >> 32));
-		const unsigned long long r_c = r_n;
-		fetch(q + gridDim.x, h_n, r_n);                                   // one query ahead: the only exposed latency of a query is its records'
-		const uint32_t need = hd.x & 0xFFFFu, len = hd.y & 0xFFFu;
-		const uint32_t budget = (hd.y >> 12) & 255u, dper = (hd.y >> 20) & 15u ? (hd.y >> 20) & 15u : 1u;
-		const uint32_t thr = need ? need : 1u;
-		uint32_t pend = 0, head = 0, nused = 0, ovf = 0;                  // wave-uniform
-		PFM_T(6);
-		// ---- the lists of one chunk: lane l = list l.  eend = end of the list in the chunk's flattened stream; ab = biased address:
-		// the record at stream position i of list l is at ab_l + 4 i
-		uint32_t eend; unsigned long long ab; uint32_t T;
-		auto chunk_lists = [&](uint32_t c) {
-			unsigned long long rr = r_c;
-			if (c) { rr = 0; if (c * 64u + lane < W16) rr = ((const unsigned long long *)ranges)[(size_t)li * W16 + c * 64u + lane]; }
-			const uint32_t rx = (uint32_t)rr, ry = (uint32_t)(rr >> 32);
-			const uint32_t n = (c * 64u + lane < W16) ? ry & 0xFFFFFFu : 0u;
-			const unsigned long long beg = (unsigned long long)rx | (unsigned long long)(ry >> 24) << 32;
-			eend = wave_incl_scan_u32(n);
-			T = (uint32_t)__builtin_amdgcn_readlane((int)eend, 63);
-			ab = (unsigned long long)(uintptr_t)ent + 4ull * (beg - (unsigned long long)(eend - n));
-			if (__builtin_amdgcn_readfirstlane((int)(eend < n))) T = 0xFFFFFFFFu;      // (never: 64 lists of < 2^24 entries)
-		};
-		// which list does stream position i belong to: the number of lists that end at or before it.  The ends are WAVE-UNIFORM (lane l
-		// holds list l's): up to 8 lists, seven scalar boundaries and a compare + add each; beyond, a binary search over the lanes.  The
-		// list's biased base address then comes from its lane (two cross-lane reads) -- no loop, no branch, the same for every row.
-		uint32_t eb[7] = {0, 0, 0, 0, 0, 0, 0};
-		auto list_ends = [&]() {
-			if (MODE == 0) {
-				#pragma unroll
-				for (uint32_t j = 0; j < 7; ++j) eb[j] = (uint32_t)__builtin_amdgcn_readlane((int)eend, (int)j);
-			}
-		};
-		auto row_addr = [&](uint32_t r, uint32_t &kreg) -> bhip_gptr_t {
-			const uint32_t i = r * 64u + lane;
-			const uint32_t ic = i < T ? i : T - 1u;                       // beyond the stream: its last record once more (OR is idempotent; the second look tests i < T)
-			uint32_t kk = 0;
-			if (MODE == 0) {
-				#pragma unroll
-				for (uint32_t j = 0; j < 7; ++j) kk += eb[j] <= ic ? 1u : 0u;
-			} else {
-				#pragma unroll
-				for (uint32_t step = 32; step >= 1; step >>= 1) kk += (uint32_t)__shfl((int)eend, (int)(kk + step - 1u), 64) <= ic ? step : 0u;      // (lanes without a list end at T > ic)
-			}
-			const uint32_t a_lo = (uint32_t)__shfl((int)(uint32_t)ab, (int)kk, 64), a_hi = (uint32_t)__shfl((int)(uint32_t)(ab >> 32), (int)kk, 64);
-			kreg = kk;
-			return (bhip_gptr_t)(uintptr_t)(((unsigned long long)a_hi << 32 | a_lo) + 4ull * ic);
-		};
-		auto slot_dw = [&](uint32_t rec) -> uint32_t { return (rec & (NS - 1u)) >> SB; };
-		auto slot_sh = [&](uint32_t rec) -> uint32_t { return (rec & ((1u << SB) - 1u)) * FB; };
-		auto count1 = [&](uint32_t rec, uint32_t kreg, uint32_t i) {     // first look
-			if (MODE == 2) atomicAdd(&s_cnt[slot_dw(rec)], (i < T ? 1u : 0u) << slot_sh(rec));
-			else atomicOr(&s_cnt[slot_dw(rec)], 1u << (slot_sh(rec) + kreg));
-		};
-		auto c_round = [&]() {                                            // up to 64 survivors into the exact lane table
-			const uint32_t take = pend < 64u ? pend : 64u;
-			const bool active = lane < take;
-			const uint32_t rec = active ? s_ring[(head + lane) & (RING - 1u)] : 0u;
-			const uint32_t clump = rec & 0xFFFFFFu, key = clump + 1u, mask = s_lut[rec >> 24];
-			uint32_t slot = (clump * 0x85EBCA6Bu) >> (32u - LTB);
-			bool act = active, found = false, fresh = false;
-			for (uint32_t probes = 0; __any(act) && probes < LT; ++probes) {
-				uint32_t old = 0xFFFFFFFFu;
-				if (act) old = atomicCAS(&s_key[slot], 0u, key);
-				const bool ok = act && (old == 0u || old == key);
-				fresh |= act && old == 0u;
-				found |= ok;
-				act = act && !ok;
-				slot = act ? (slot + 1u) & (LT - 1u) : slot;
-			}
-			if (__any(act)) ovf = 1u;
-			const unsigned long long mf = __ballot(fresh);
-			if (fresh) s_used[nused + (uint32_t)__popcll(mf & lt_mask)] = (uint8_t)slot;
-			nused += (uint32_t)__popcll(mf);
-			if (found) {
-				if (mask & 0xFFu) atomicAdd(&s_lc[slot][0], spread8(mask & 0xFFu));
-				if (mask >> 8) atomicAdd(&s_lc[slot][1], spread8(mask >> 8));
-			}
-			head = (head + take) & (RING - 1u);
-			pend -= take;
-		};
-		auto offer1 = [&](uint32_t rec, uint32_t i) {                     // second look: survivors of the slot test go to the ring
-			const uint32_t f = (s_cnt[slot_dw(rec)] >> slot_sh(rec)) & ((1u << FB) - 1u);
-			const bool surv = (MODE == 2 ? f : (uint32_t)__popc(f)) >= thr && i < T;
-			const unsigned long long m = __ballot(surv);
-			if (m) {
-				if (surv) s_ring[(head + pend + (uint32_t)__popcll(m & lt_mask)) & (RING - 1u)] = rec;
-				pend += (uint32_t)__popcll(m);
-				my_surv += (uint32_t)__popcll(m);
-				if (pend >= 64u) c_round();
-			}
-		};
-		// ---- first look over every record; the first R rows of the first chunk stay in registers
-		uint32_t rc[R], kr[R];
-		uint32_t T0 = 0, rows0 = 0;
-		unsigned long long gtot = 0;
-		for (uint32_t c = 0; c < n_chunks; ++c) {
-			chunk_lists(c);
-			if (T == 0xFFFFFFFFu) { ovf = 1u; break; }
-			gtot += T;
-			const uint32_t rows = (T + 63u) >> 6;
-			list_ends();
-			uint32_t r0 = 0;
-			if (c == 0) {
-				T0 = T; rows0 = rows;
-				#pragma unroll
-				for (uint32_t r = 0; r < R; ++r) if (r < rows) rc[r] = row_addr(r, kr[r])[0];
-				PFM_T(0);
-				#pragma unroll
-				for (uint32_t r = 0; r < R; ++r) if (r < rows) count1(rc[r], kr[r], r * 64u + lane);
-				r0 = R;
-			}
-			for (uint32_t r = r0; r < rows; ++r) {
-				uint32_t k;
-				const uint32_t rec = row_addr(r, k)[0];
-				count1(rec, k, r * 64u + lane);
-			}
-		}
-		my_ent += gtot;
-		if (MODE == 2 && gtot > 65535ull) ovf = 1u;
-		CF_WAVE_ORDER();
-		PFM_T(1);
-		// ---- second look
-		if (!ovf) for (uint32_t c = 0; c < n_chunks; ++c) {
-			uint32_t rows, r0 = 0;
-			if (c == 0) {
-				T = T0; rows = rows0;
-				#pragma unroll
-				for (uint32_t r = 0; r < R; ++r) if (r < rows) offer1(rc[r], r * 64u + lane);
-				r0 = R;
-				if (rows > R) { chunk_lists(0); list_ends(); }      // (the lists again: later chunks have been through the registers)
-			} else { chunk_lists(c); rows = (T + 63u) >> 6; list_ends(); }
-			for (uint32_t r = r0; r < rows; ++r) {
-				uint32_t k;
-				const uint32_t rec = row_addr(r, k)[0];
-				offer1(rec, r * 64u + lane);
-			}
-		}
-		PFM_T(2);
-		while (pend) c_round();
-		CF_WAVE_ORDER();
-		PFM_T(3);
-		// ---- emit: four table slots x sixteen reference lanes per pass.  A lane with c matching words lost (W_valid - c) words, one edit
-		// destroys at most `dper` of them: its edit distance is at least budget - (c - need) / dper.  Unless every hit within budget is
-		// wanted, only the lanes with the query's largest count are swept at once; the others wait for the minimum those produce.
-		if (!ovf) {
-			const uint32_t inv_dper = 65536u / dper + 1u;                 // x / dper == (x * inv_dper) >> 16 for x < 256, dper < 16
-			auto look = [&](uint32_t p, uint32_t &slot, uint32_t &c, uint32_t &cz) -> bool {
-				const uint32_t iu = p * 4u + sg;
-				const bool has = iu < nused;
-				slot = has ? (uint32_t)s_used[iu] : 0u;
-				c = s_key[slot] - 1u;
-				cz = ((const uint8_t *)&s_lc[slot][0])[z];
-				return has && c * 16u + z < tot_refs && cz >= thr;
-			};
-			auto emit_pass = [&](uint32_t p, bool ok, uint32_t slot, uint32_t c, uint32_t cz, uint32_t t0) {
-				const bool has = p * 4u + sg < nused;
-				CF_WAVE_ORDER();
-				if (has && z < 2u) s_lc[slot][z] = 0;                     // (this wave's reads of the slot are done: LDS operations of one wave stay in order)
-				if (has && z == 2u) s_key[slot] = 0;
-				const bool first = ok && (!prune || cz >= t0);
-				uint32_t lb = 0;
-				if (prune) { const uint32_t gain = ((cz - need) * inv_dper) >> 16; lb = gain >= budget ? 0u : budget - gain; }
-				put(0, first, li, c * 16u + z);
-				put(1, ok && !first, li | lb << 24, c * 16u + z);
-				const unsigned long long mo = __ballot(ok);
-				const uint32_t units = ((mo & 0xFFFFull) ? 1u : 0u) + ((mo >> 16 & 0xFFFFull) ? 1u : 0u) + ((mo >> 32 & 0xFFFFull) ? 1u : 0u) + ((mo >> 48) ? 1u : 0u);
-				my_units += units; my_qlen += (unsigned long long)units * len;
-			};
-			if (nused <= 4u) {                                            // the usual case: every used slot in one pass, looked at once
-				uint32_t slot, c, cz;
-				const bool ok = look(0, slot, c, cz);
-				uint32_t t0 = thr;
-				if (prune) { const uint32_t cm = wave_max_u32(ok ? cz : 0u); t0 = cm > thr ? cm : thr; }
-				if (nused) emit_pass(0, ok, slot, c, cz, t0);
-			} else {
-				uint32_t t0 = thr;
-				if (prune) {
-					uint32_t cmax = 0;
-					for (uint32_t p = 0; p * 4u < nused; ++p) { uint32_t sl, c, cz; if (look(p, sl, c, cz)) cmax = cz > cmax ? cz : cmax; }
-					const uint32_t cm = wave_max_u32(cmax);
-					t0 = cm > thr ? cm : thr;
-				}
-				for (uint32_t p = 0; p * 4u < nused; ++p) {
-					uint32_t slot, c, cz;
-					const bool ok = look(p, slot, c, cz);
-					emit_pass(p, ok, slot, c, cz, t0);
-				}
-			}
-			for (uint32_t i = 0; i < n_bad; i += 4) {                     // burst.c:4136-4138, 4282-4283: every lane of the ambiguous clumps
-				const bool in = i + sg < n_bad;
-				const uint32_t c = in ? bad[i + sg] : 0u;
-				put(0, in && c * 16u + z < tot_refs, li, c * 16u + z);
-				{ const uint32_t nb4 = n_bad - i < 4u ? n_bad - i : 4u; my_units += nb4; my_qlen += (unsigned long long)nb4 * len; }
-			}
-		} else {
-			for (uint32_t i = lane; i < LT; i += 64) { s_key[i] = 0; s_lc[i][0] = 0; s_lc[i][1] = 0; }
-			if (lane == 0) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
-		}
-		PFM_T(4);
-		{
-			uint4 *cz4 = (uint4 *)&s_cnt[0];
-			for (uint32_t i = lane; i < NDW / 4u; i += 64) cz4[i] = make_uint4(0, 0, 0, 0);
-		}
-		CF_WAVE_ORDER();
-		PFM_T(5);
-	}
-	flush_one(0); flush_one(1);
-#ifdef PFM_PROF
-	if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_pfm_prof[i], my_t[i]);
-#endif
-	if (lane == 0) {
-		if (ent_read && my_ent) atomicAdd(ent_read, my_ent);
-		if (surv_sum && my_surv) atomicAdd(surv_sum, my_surv);
-		if (my_units) { atomicAdd(unit_sum, my_units); atomicAdd(qlen_sum, my_qlen); }
-	}
-	(void)clump_len; (void)col_sum;
-}
-// ------------------------------------------------------------------------------------------------
-// Lane-resolved prefilter, counting filter, FOUR queries per wave with the record streams walked by the WHOLE wave (round 5).
-// k_prefilter_cw (one query per wave) showed two things on the device (PMC, gpurun_out/r05d): walking a query's stream with 64 lanes and
-// wave-uniform list boundaries costs ~30 vector instructions per 64 records where k_prefilter_cf spends ~75 -- and everything ELSE a query
-// needs (list scan, survivor insertion, emit, clearing: ~230 vector and ~250 scalar instructions) is then paid per query by a wave in which
-// a handful of lanes do the work, which is why it loses to k_prefilter_cf on small databases (260 against 187 vector instructions per query
-// at 35 records per read) and wins only 20 % at the metric's size.  This kernel keeps both halves where they are cheap:
-//  * per QUAD of queries, group-parallel as in k_prefilter_cf (16 lanes per query): list lengths -> stream positions (row DPP scans), the
-//    survivor rounds (16 survivors of each query per round), the emit (one exact-table slot of each query per pass, its 16 reference lanes
-//    in the group's lanes), the table clears -- a quarter of the per-query cost;
-//  * per QUERY of the quad, wave-parallel as in k_prefilter_cw: the list ends of the query become seven scalars (v_readlane from its
-//    group), a row of 64 stream positions finds its list with a compare + add per boundary, the two looks at the records are the
-//    list-mask slots of k_prefilter_cw (1 024 byte slots per query for up to 8 lists, OR instead of ADD, positions beyond the stream
-//    repeat its last record), the records of the first R rows stay in registers between the looks.
-// For lists per query <= 16 (MODE 0: <= 8, byte slots; MODE 1: halfword slots); longer plans keep k_prefilter_cw<2>.  BIG = 1: the second
-// pass over queries whose survivors overflowed the 32-slot exact table of the first, with four times the slots and the table.
-// ------------------------------------------------------------------------------------------------
-#ifndef CQ_MINWAVES
-#define CQ_MINWAVES 1          // waves per SIMD the register allocation aims at (tools/build_variant.sh: -DCQ_MINWAVES=5 -DCQ_LTB=4 -DCQ_STAGE_N=32 for the occupancy A/B)
-#endif
-#ifndef CQ_LTB
-#define CQ_LTB 5
-#endif
-#ifndef CQ_STAGE_N
-#define CQ_STAGE_N 64
-#endif
-template <int MODE, int BIG>
-__global__ __launch_bounds__(64, CQ_MINWAVES) void k_prefilter_cq(
-		const uint2 *__restrict__ ranges, const uint2 *__restrict__ hdr, uint32_t W16, uint32_t n_list,
-		const uint32_t *__restrict__ ent,   // 4-byte (clump, lane-set code) records
-		const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ clump_len, uint32_t tot_refs,
-		uint2 *__restrict__ tasks, uint32_t *__restrict__ n_tasks, uint32_t task_cap,
-		unsigned long long *__restrict__ ent_read,
-		uint32_t *__restrict__ fb_list, uint32_t *__restrict__ n_fb,
-		unsigned long long *__restrict__ unit_sum, unsigned long long *__restrict__ col_sum, unsigned long long *__restrict__ qlen_sum,
-		unsigned long long *__restrict__ surv_sum,
-		uint2 *__restrict__ tasks2, uint32_t *__restrict__ n_tasks2, int prune,
-		const uint32_t *__restrict__ sel, const uint32_t *__restrict__ n_sel_dev, int) {
-	constexpr uint32_t FB = MODE == 0 ? 8u : 16u;                         // bits per slot
-	constexpr uint32_t SB = MODE == 0 ? 2u : 1u;                          // log2 slots per dword
-	constexpr uint32_t NDW = BIG ? 1024u : 256u;                          // dwords of slots per query: 1 KB (4 KB)
-	constexpr uint32_t NS = NDW << SB;                                    // slots per query
-	constexpr uint32_t LTB = BIG ? 7u : (uint32_t)CQ_LTB, LT = 1u << LTB;               // exact lane-table slots per query
-	constexpr uint32_t RING = 64u;                                        // survivors of a query waiting for the rounds at the end of the quad (a power of two, >= one row)
-	constexpr uint32_t CQ_STAGE = (uint32_t)CQ_STAGE_N;
-	constexpr uint32_t R = 6u;                                            // rows of 64 records of a query that stay in registers between the two looks
-	__shared__ __attribute__((aligned(16))) uint32_t s_cnt[4][NDW];
-	__shared__ uint32_t s_key[4][LT];
-	__shared__ unsigned long long s_lc[4][LT][2];
-	__shared__ uint32_t s_ring[4][RING];
-	__shared__ uint16_t s_lut[256];
-	__shared__ uint8_t s_used[4][LT];
-	__shared__ uint2 s_stage[2][CQ_STAGE];
-	__shared__ uint32_t s_dummy[16];          // compare-and-swap target of idle lanes (never written: the compare value cannot match)
-	const uint32_t lane = threadIdx.x, g = lane >> 4, gl = lane & 15u;
-	if (lane < 16) s_dummy[lane] = 0;
-	for (uint32_t i = lane; i < 256; i += 64) s_lut[i] = (uint16_t)bhip_lane_code_mask(i);
-	for (uint32_t i = lane; i < 4 * NDW; i += 64) (&s_cnt[0][0])[i] = 0;
-	for (uint32_t i = lane; i < 4 * LT; i += 64) { (&s_key[0][0])[i] = 0; (&s_lc[0][0][0])[2 * i] = 0; (&s_lc[0][0][0])[2 * i + 1] = 0; }
-	__syncthreads();
-	uint32_t my_ent = 0, my_units = 0, my_qlen = 0, my_surv = 0;         // (per wave and launch: well inside 32 bits)
-	const unsigned long long lt_mask = (1ull << lane) - 1ull;
-#ifdef PFM_PROF
-	unsigned long long my_t[8] = {0,0,0,0,0,0,0,0}, t_last = wall_clock64();      // 0 addresses + load issue, 1 first look (waits for the records), 2 second look, 3 survivor rounds, 4 emit, 5 clear, 6 quad setup
-#endif
-	uint32_t nst[2] = {0u, 0u};
-	auto flush_one = [&](uint32_t which) {
-		const uint32_t n = nst[which];
-		if (n) {
-			uint32_t base = 0;
-			if (lane == 0) base = atomicAdd(which ? n_tasks2 : n_tasks, n);
-			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-			uint2 *dst = which ? tasks2 : tasks;
-			if (lane < n && base + lane < task_cap) dst[base + lane] = s_stage[which][lane];
-			CF_WAVE_ORDER();
-		}
-		nst[which] = 0;
-	};
-	auto put = [&](uint32_t which, bool mine, uint32_t a, uint32_t b) {      // wave-uniform call; `mine`: this lane has a task for list `which`
-		const unsigned long long m = __ballot(mine);
-		const uint32_t cnt = (uint32_t)__popcll(m);
-		if (!cnt) return;
-		if (cnt > CQ_STAGE) {                     // more than the stage holds in one go: straight to the list
-			uint32_t base = 0;
-			if (lane == 0) base = atomicAdd(which ? n_tasks2 : n_tasks, cnt);
-			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + (uint32_t)__popcll(m & lt_mask);
-			if (mine && base < task_cap) (which ? tasks2 : tasks)[base] = make_uint2(a, b);
-			return;
-		}
-		if (nst[which] + cnt > CQ_STAGE) flush_one(which);
-		if (mine) s_stage[which][nst[which] + (uint32_t)__popcll(m & lt_mask)] = make_uint2(a, b);
-		nst[which] += cnt;
-	};
-	auto group_scan = [&](uint32_t n) -> uint32_t {                       // inclusive prefix sum inside each group of 16 lanes
-		int ps = (int)n;
-		ps += __builtin_amdgcn_update_dpp(0, ps, 0x111, 0xF, 0xF, false);    // row_shr:1 (a row = the 16 lanes of a group; lanes without a source add 0)
-		ps += __builtin_amdgcn_update_dpp(0, ps, 0x112, 0xF, 0xF, false);
-		ps += __builtin_amdgcn_update_dpp(0, ps, 0x114, 0xF, 0xF, false);
-		ps += __builtin_amdgcn_update_dpp(0, ps, 0x118, 0xF, 0xF, false);
-		return (uint32_t)ps;
-	};
-	auto group_max = [&](uint32_t v) -> uint32_t {                        // maximum over the 16 lanes of the group, in every lane
-		int t;
-		t = __builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;     // quad_perm:[1,0,3,2]
-		t = __builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;     // quad_perm:[2,3,0,1]
-		t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;    // row_half_mirror
-		t = __builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false); v = (uint32_t)t > v ? (uint32_t)t : v;    // row_mirror
-		return v;
-	};
-	auto wave_max4 = [&](uint32_t v) -> uint32_t {                        // maximum over the four groups of a group-uniform value
-		const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
-			c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-		const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
-		return ab > cd ? ab : cd;
-	};
-	auto spread4 = [](uint32_t nib) -> uint32_t { return (nib * 0x00204081u) & 0x01010101u; };      // bit i of a nibble -> bit 8 i
-	const uint32_t n_items = sel ? (*n_sel_dev < n_list ? *n_sel_dev : n_list) : n_list;
-	const uint32_t n_quads = (n_items + 3) >> 2;
-	typedef const unsigned long long __attribute__((address_space(1))) *g64_t;
-	auto fetch = [&](uint32_t quad, unsigned long long &h, unsigned long long &r) {      // header of this group's query and range gl of it (clamped: always a valid address)
-		const uint32_t it = quad * 4 + g;
-		const uint32_t itc = it < n_items ? it : 0u;
-		const uint32_t lic = sel ? (n_items ? sel[itc] : 0u) : itc;
-		h = ((g64_t)(uintptr_t)(hdr + lic))[0];
-		r = ((g64_t)(uintptr_t)(ranges + ((size_t)lic * W16 + (gl < W16 ? gl : 0u))))[0];
-	};
-	unsigned long long h_n, r_n;
-	fetch(blockIdx.x, h_n, r_n);
-	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
-		const bool live = quad * 4 + g < n_items;
-		const uint32_t li = sel ? (live ? sel[quad * 4 + g] : 0u) : quad * 4 + g;      // list position of this group's query
-		const uint2 hd = make_uint2((uint32_t)h_n, (uint32_t)(h_n >> 32));
-		const unsigned long long r_c = r_n;
-		fetch(quad + gridDim.x, h_n, r_n);                                // one quad ahead
-		const uint32_t need = hd.x & 0xFFFFu, len = hd.y & 0xFFFu;
-		const uint32_t budget = (hd.y >> 12) & 255u, dper = (hd.y >> 20) & 15u ? (hd.y >> 20) & 15u : 1u;
-		const uint32_t thr = need ? need : 1u;                            // (group-uniform)
-		// ---- the lists of the quad's queries: lane gl of group g = list gl of query g.  eend = end of the list in its query's flattened
-		// stream; ab = biased address: the record at stream position i of the list is at ab + 4 i
-		const uint32_t rx = (uint32_t)r_c, ry = (uint32_t)(r_c >> 32);
-		const uint32_t n0 = (live && gl < W16) ? ry & 0xFFFFFFu : 0u;
-		const unsigned long long beg = (unsigned long long)rx | (unsigned long long)(ry >> 24) << 32;
-		const uint32_t eend = group_scan(n0);
-		const unsigned long long ab = (unsigned long long)(uintptr_t)ent + 4ull * (beg - (unsigned long long)(eend - n0));
-		uint32_t pend[4] = {0u, 0u, 0u, 0u};                              // survivors waiting in the queries' rings (wave-uniform)
-		uint32_t nused = 0, ovf = 0;                                      // slots of this group's lane table in use / table overflow (replicated in the group)
-		// ---- survivor rounds: every group moves up to 16 survivors of its query into its exact lane table
-		auto drain = [&]() {
-			uint32_t pv = g == 0 ? pend[0] : g == 1 ? pend[1] : g == 2 ? pend[2] : pend[3];
-			uint32_t head = 0;
-			while (__any(pv > 0)) {
-				const uint32_t take = pv < 16u ? pv : 16u;
-				const bool active = gl < take;
-				const uint32_t rec = active ? s_ring[g][head + gl] : 0u;
-				const uint32_t clump = rec & 0xFFFFFFu, key = clump + 1u, mask = s_lut[rec >> 24];
-				uint32_t slot = (clump * 0x85EBCA6Bu) >> (32u - LTB);
-				bool act = active, found = false, fresh = false;
-				for (uint32_t probes = 0; __any(act) && probes < LT; ++probes) {
-					const uint32_t old = atomicCAS(act ? &s_key[g][slot] : &s_dummy[gl], act ? 0u : 0xFFFFFFFFu, key);
-					const bool ok = act && (old == 0u || old == key);
-					fresh |= act && old == 0u;
-					found |= ok;
-					act = act && !ok;
-					slot = act ? (slot + 1u) & (LT - 1u) : slot;
-				}
-				const uint32_t m_act = (uint32_t)(__ballot(act) >> (lane & 48u)) & 0xFFFFu;
-				if (m_act) ovf = 1u;
-				const uint32_t m16 = (uint32_t)(__ballot(fresh) >> (lane & 48u)) & 0xFFFFu;
-				if (fresh) s_used[g][nused + __popc(m16 & ((1u << gl) - 1u))] = (uint8_t)slot;
-				nused += __popc(m16);
-				if (found) {
-					const unsigned long long lo = (unsigned long long)spread4((mask >> 4) & 15u) << 32 | spread4(mask & 15u);
-					const unsigned long long hi = (unsigned long long)spread4(mask >> 12) << 32 | spread4((mask >> 8) & 15u);
-					if (lo) atomicAdd(&s_lc[g][slot][0], lo);
-					if (hi) atomicAdd(&s_lc[g][slot][1], hi);
-				}
-				head += take; pv -= take;
-			}
-			pend[0] = pend[1] = pend[2] = pend[3] = 0;
-		};
-		PFM_T(6);
-		// ---- the record streams, 64 stream positions per row.  The loads of ALL four queries are issued first (their gathers are in flight
-		// together: a wave waits for memory once per quad, not once per query), then the first look over the four queries, then the second.
-		constexpr uint32_t NB = MODE == 0 ? 7u : 15u, KB = MODE == 0 ? 3u : 4u;      // list ends that matter / bits of a list number
-		uint32_t rc[4][R], krp[4];                                        // records of the resident rows, their list numbers (KB bits per row)
-		uint32_t Tq[4];
-		auto row_rec = [&](uint32_t q, uint32_t T, const uint32_t (&eb)[NB], uint32_t r, uint32_t &kreg) -> uint32_t {
-			const uint32_t i = r * 64u + lane;
-			const uint32_t ic = i < T ? i : T - 1u;                       // beyond the stream: its last record once more (OR is idempotent; the second look tests i < T)
-			uint32_t kk = 0;
-			#pragma unroll
-			for (uint32_t j = 0; j < NB; ++j) kk += eb[j] <= ic ? 1u : 0u;          // lists that end at or before the position = its list
-			const uint32_t src = q * 16u + kk;
-			const uint32_t a_lo = (uint32_t)__shfl((int)(uint32_t)ab, (int)src, 64), a_hi = (uint32_t)__shfl((int)(uint32_t)(ab >> 32), (int)src, 64);
-			kreg = kk;
-			return ((bhip_gptr_t)(uintptr_t)(((unsigned long long)a_hi << 32 | a_lo) + 4ull * ic))[0];
-		};
-		auto list_ends = [&](uint32_t q, uint32_t (&eb)[NB]) {           // ends of the query's lists but the last: wave-uniform
-			#pragma unroll
-			for (uint32_t j = 0; j < NB; ++j) eb[j] = (uint32_t)__builtin_amdgcn_readlane((int)eend, (int)(q * 16u + j));
-		};
-		#pragma unroll
-		for (uint32_t q = 0; q < 4; ++q) {
-			const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)eend, (int)(q * 16u + 15u));
-			Tq[q] = T; krp[q] = 0;
-			if (T == 0u) continue;                                        // (wave-uniform)
-			my_ent += T;
-			uint32_t eb[NB];
-			list_ends(q, eb);
-			const uint32_t rows = (T + 63u) >> 6;
-			#pragma unroll
-			for (uint32_t r = 0; r < R; ++r) if (r < rows) { uint32_t kr; rc[q][r] = row_rec(q, T, eb, r, kr); krp[q] |= kr << (KB * r); }
-		}
-		PFM_T(0);
-		auto count1 = [&](uint32_t q, uint32_t rec, uint32_t kreg) {     // first look: the record's list leaves its bit in the record's slot
-			atomicOr(&s_cnt[q][(rec & (NS - 1u)) >> SB], 1u << ((rec & ((1u << SB) - 1u)) * FB + kreg));
-		};
-		#pragma unroll
-		for (uint32_t q = 0; q < 4; ++q) {
-			const uint32_t T = Tq[q];
-			if (T == 0u) continue;
-			const uint32_t rows = (T + 63u) >> 6;
-			#pragma unroll
-			for (uint32_t r = 0; r < R; ++r) if (r < rows) count1(q, rc[q][r], (krp[q] >> (KB * r)) & ((1u << KB) - 1u));
-			if (rows > R) {                                               // (streams beyond R rows: loaded where they are looked at, twice)
-				uint32_t eb[NB];
-				list_ends(q, eb);
-				for (uint32_t r = R; r < rows; ++r) { uint32_t kr; const uint32_t rec = row_rec(q, T, eb, r, kr); count1(q, rec, kr); }
-			}
-		}
-		CF_WAVE_ORDER();
-		PFM_T(1);
-		#pragma unroll
-		for (uint32_t q = 0; q < 4; ++q) {
-			const uint32_t T = Tq[q];
-			if (T == 0u) continue;
-			const uint32_t rows = (T + 63u) >> 6;
-			const uint32_t thr_q = (uint32_t)__builtin_amdgcn_readlane((int)thr, (int)(q * 16u));
-			auto offer1 = [&](uint32_t rec, uint32_t i) {                 // second look: records whose slot names enough lists go to the query's ring
-				const uint32_t f = (s_cnt[q][(rec & (NS - 1u)) >> SB] >> ((rec & ((1u << SB) - 1u)) * FB)) & ((1u << FB) - 1u);
-				const bool surv = (uint32_t)__popc(f) >= thr_q && i < T;
-				const unsigned long long m = __ballot(surv);
-				if (m) {
-					const uint32_t cnt = (uint32_t)__popcll(m);
-					if (pend[q] + cnt > RING) drain();                    // (rare: the rings are drained at the end of every quad)
-					if (surv) s_ring[q][pend[q] + (uint32_t)__popcll(m & lt_mask)] = rec;
-					pend[q] += cnt;
-					my_surv += cnt;
-				}
-			};
-			#pragma unroll
-			for (uint32_t r = 0; r < R; ++r) if (r < rows) offer1(rc[q][r], r * 64u + lane);
-			if (rows > R) {
-				uint32_t eb[NB];
-				list_ends(q, eb);
-				for (uint32_t r = R; r < rows; ++r) { uint32_t kr; const uint32_t rec = row_rec(q, T, eb, r, kr); offer1(rec, r * 64u + lane); }
-			}
-		}
-		PFM_T(2);
-		drain();
-		CF_WAVE_ORDER();
-		PFM_T(3);
-		// ---- emit the lanes that reach the threshold, clear the tables.  Slot-parallel, as in k_prefilter_cf: lane gl of a group owns the
-		// group's gl-th used slot (most used slots are false survivors without a single passing lane: a byte-parallel compare says so at
-		// once).  The positions of a lane's tasks in the two staged lists come from ONE wave-wide prefix sum over the per-lane counts.
-		// A lane with c matching words lost (W_valid - c) words, one edit destroys at most `dper` of them: its edit distance is at least
-		// budget - (c - need) / dper.  Unless every hit within budget is wanted, only the lanes with the query's largest count are swept at
-		// once; the others wait for the minimum those produce (k_task_filter).
-		const bool em = live && !ovf;
-		const uint32_t nu = em ? nused : 0u;
-		const uint32_t nu_max = wave_max4(nu);
-		const uint32_t inv_dper = 65536u / dper + 1u;                     // x / dper == (x * inv_dper) >> 16 for x < 256, dper < 16
-		auto lanes_ge = [&](unsigned long long lo, unsigned long long hi, uint32_t t) -> uint32_t {      // 16-bit set of the slot's lane counters >= t (t < 128)
-			const unsigned long long H = 0x8080808080808080ull, L1 = 0x0101010101010101ull, G = 0x0102040810204080ull;
-			const unsigned long long tl = ((lo | H) - t * L1) & H, th = ((hi | H) - t * L1) & H;
-			return (uint32_t)(((tl >> 7) * G) >> 56) | ((uint32_t)(((th >> 7) * G) >> 56) << 8);
-		};
-		auto lanes_ge_any = [&](unsigned long long lo, unsigned long long hi, uint32_t t) -> uint32_t {
-			if (t < 128u) return lanes_ge(lo, hi, t);
-			uint32_t m16 = 0;
-			#pragma unroll
-			for (uint32_t zz = 0; zz < 16; ++zz) m16 |= ((uint32_t)(((zz < 8 ? lo : hi) >> (8 * (zz & 7))) & 255u) >= t ? 1u : 0u) << zz;
-			return m16;
-		};
-		auto look = [&](uint32_t iu, uint32_t &slot, uint32_t &c, unsigned long long &lo, unsigned long long &hi) -> uint32_t {
-			const bool has = iu < nu;
-			slot = has ? (uint32_t)s_used[g][iu] : 0u;
-			c = s_key[g][slot] - 1u; lo = s_lc[g][slot][0]; hi = s_lc[g][slot][1];
-			const uint32_t first = c * 16u, nv = first < tot_refs ? (tot_refs - first < 16u ? tot_refs - first : 16u) : 0u;     // lanes of the clump that exist
-			return has ? lanes_ge_any(lo, hi, thr) & ((1u << nv) - 1u) : 0u;
-		};
-		auto byte_of = [&](unsigned long long lo, unsigned long long hi, uint32_t zz) -> uint32_t { return (uint32_t)((zz < 8 ? lo : hi) >> (8u * (zz & 7u))) & 255u; };
-		uint32_t slot0, c0; unsigned long long lo0, hi0;
-		const uint32_t m16_0 = look(gl, slot0, c0, lo0, hi0);
-		uint32_t cmax_all = 0;
-		if (prune) {
-			uint32_t cmax = 0;
-			for (uint32_t m = m16_0; m; m &= m - 1) { const uint32_t v = byte_of(lo0, hi0, (uint32_t)__builtin_ctz(m)); cmax = v > cmax ? v : cmax; }
-			for (uint32_t iu0 = 16; iu0 < nu_max; iu0 += 16) {
-				uint32_t sl, c; unsigned long long lo, hi;
-				for (uint32_t m = look(iu0 + gl, sl, c, lo, hi); m; m &= m - 1) { const uint32_t v = byte_of(lo, hi, (uint32_t)__builtin_ctz(m)); cmax = v > cmax ? v : cmax; }
-			}
-			cmax_all = group_max(cmax);
-		}
-		PFM_T(7);
-		auto emit_slots = [&](uint32_t iu, uint32_t slot, uint32_t c, unsigned long long lo, unsigned long long hi, uint32_t m16) {
-			if (iu < nused) { s_key[g][slot] = 0; s_lc[g][slot][0] = 0; s_lc[g][slot][1] = 0; }     // (this wave's reads of the slot are done: LDS operations of one wave stay in order)
-			const uint32_t m0 = prune ? m16 & lanes_ge_any(lo, hi, cmax_all > thr ? cmax_all : thr) : m16, m1 = m16 & ~m0;
-			const uint32_t cnt = (uint32_t)__popc(m0) | (uint32_t)__popc(m1) << 16;
-			const uint32_t incl = wave_incl_scan_u32(cnt), tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), excl = incl - cnt;
-			if (!tot) return;                         // wave-uniform
-			const uint32_t tot0 = tot & 0xFFFFu, tot1 = tot >> 16;
-			uint32_t p[2]; bool direct[2];
-			#pragma unroll
-			for (uint32_t w = 0; w < 2; ++w) {
-				const uint32_t tw = w ? tot1 : tot0, ew = w ? excl >> 16 : excl & 0xFFFFu;
-				direct[w] = false;
-				if (tw && nst[w] + tw > CQ_STAGE) flush_one(w);
-				if (tw > CQ_STAGE) {                  // more than the stage holds in one go: straight to the list
-					uint32_t base = 0;
-					if (lane == 0) base = atomicAdd(w ? n_tasks2 : n_tasks, tw);
-					p[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + ew; direct[w] = true;
-				} else { p[w] = nst[w] + ew; nst[w] += tw; }
-			}
-			PFM_T(5);
-			for (uint32_t m = m16; m; m &= m - 1) {
-				const uint32_t zz = (uint32_t)__builtin_ctz(m), w = (m1 >> zz) & 1u;
-				uint32_t lb = 0;
-				if (prune) { const uint32_t gain = ((byte_of(lo, hi, zz) - need) * inv_dper) >> 16; lb = gain >= budget ? 0u : budget - gain; }
-				const uint2 task = make_uint2(li | lb << 24, c * 16u + zz);
-				const uint32_t pos = p[w]; p[w] = pos + 1;
-				if (direct[w]) { if (pos < task_cap) (w ? tasks2 : tasks)[pos] = task; }
-				else s_stage[w][pos] = task;
-			}
-			if (m16) { ++my_units; my_qlen += len; }       // (the swept columns of lane tasks are counted by the sweep: tcol_sum)
-			PFM_T(4);
-		};
-		if (nu_max) emit_slots(gl, slot0, c0, lo0, hi0, m16_0);
-		for (uint32_t iu0 = 16; iu0 < nu_max; iu0 += 16) {
-			uint32_t sl, c; unsigned long long lo, hi;
-			const uint32_t m16 = look(iu0 + gl, sl, c, lo, hi);
-			emit_slots(iu0 + gl, sl, c, lo, hi, m16);
-		}
-		for (uint32_t i = 0; i < n_bad; ++i) {                            // burst.c:4136-4138, 4282-4283: every lane of the ambiguous clumps
-			const uint32_t c = bad[i];
-			put(0, em && c * 16u + gl < tot_refs, li, c * 16u + gl);
-			if (em && gl == 0) { ++my_units; my_qlen += len; }
-		}
-		if (__any(ovf != 0u)) {
-			if (ovf) {
-				for (uint32_t i = gl; i < LT; i += 16) { s_key[g][i] = 0; s_lc[g][i][0] = 0; s_lc[g][i][1] = 0; }
-				if (live && gl == 0) { const uint32_t pos = atomicAdd(n_fb, 1u); fb_list[pos] = li; }
-			}
-		}
-		PFM_T(3);
-		{
-			uint4 *cz4 = (uint4 *)&s_cnt[0][0];
-			for (uint32_t i = lane; i < 4u * NDW / 4u; i += 64) cz4[i] = make_uint4(0, 0, 0, 0);
-		}
-		CF_WAVE_ORDER();
-		PFM_T(5);
-	}
-	flush_one(0); flush_one(1);
-#ifdef PFM_PROF
-	if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_pfm_prof[i], my_t[i]);
-#endif
-	if (lane == 0) {
-		if (ent_read && my_ent) atomicAdd(ent_read, (unsigned long long)my_ent);
-		if (surv_sum && my_surv) atomicAdd(surv_sum, (unsigned long long)my_surv);
-	}
-	if (my_units) { atomicAdd(unit_sum, (unsigned long long)my_units); atomicAdd(qlen_sum, (unsigned long long)my_qlen); }
-	(void)clump_len; (void)col_sum;
-}
-#define BHIP_INST_PFCQ(M, B) \
-	template __global__ void k_prefilter_cq<M, B>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, \
-		uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *, \
-		uint2 *, uint32_t *, int, const uint32_t *, const uint32_t *, int);
-BHIP_INST_PFCQ(0, 0) BHIP_INST_PFCQ(1, 0) BHIP_INST_PFCQ(0, 1) BHIP_INST_PFCQ(1, 1)
-
-#define BHIP_INST_PFCW(M, B) \
-	template __global__ void k_prefilter_cw<M, B>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t, \
-		uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, unsigned long long *, \
-		uint2 *, uint32_t *, int, const uint32_t *, const uint32_t *, int);
-BHIP_INST_PFCW(0, 0) BHIP_INST_PFCW(1, 0) BHIP_INST_PFCW(2, 0) BHIP_INST_PFCW(0, 1) BHIP_INST_PFCW(1, 1) BHIP_INST_PFCW(2, 1)
-
-template __global__ void k_prefilter_mask<9>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
-	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, uint32_t);
-template __global__ void k_prefilter_mask<10>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
-	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, uint32_t);
-template __global__ void k_prefilter_mask<11>(const uint2 *, const uint2 *, uint32_t, uint32_t, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *, uint32_t,
-	uint2 *, uint32_t *, uint32_t, unsigned long long *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, unsigned long long *, uint2 *, uint32_t *, uint32_t);
-
-// ------------------------------------------------------------------------------------------------
 // Bit-parallel semi-global edit distance (Myers 1999 / Hyyro 2003), NW x 32-bit words per DP column.
 // State per (query, reference lane): vertical deltas Pv/Mv of the current column; the tracked score is
 // D[m][x] = min over start positions of the edit distance of the query against ref[..x], i.e. the last-row
@@ -2539,14 +485,19 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 		uint32_t g_first = 0xFFFFFFFFu, g_last = 0;
 		const uint4 *rp = ref + ref_off[c] * 16 + (uint64_t)z * nchunks;        // lane-major copy
 		const uint32_t *gtab = peqp + (uint64_t)li * 16 * NWP;
-		for (uint32_t t0 = 0; t0 < nchunks; t0 += 4) {      // 4 chunks = 64 contiguous bytes of this lane per round of loads
+		// The rest of the query (m - P symbols) needs at least m - P - E more columns behind the prefix's end: a prefix that ends beyond
+		// column L - (m - P) + E belongs to no alignment within budget, and the chunks that only hold such columns are not swept
+		// (round 6: 2 of a 612-column lane's 20 chunks for a 100-symbol read)
+		const uint32_t x_max = L + E > m - P ? L + E - (m - P) : 0u;
+		const uint32_t t_end = x_max / 32u + 1u < nchunks ? x_max / 32u + 1u : nchunks;
+		for (uint32_t t0 = 0; t0 < t_end; t0 += 4) {      // 4 chunks = 64 contiguous bytes of this lane per round of loads
 			uint4 chs[4];
 			#pragma unroll
-			for (uint32_t u = 0; u < 4; ++u) chs[u] = t0 + u < nchunks ? rp[t0 + u] : make_uint4(0, 0, 0, 0);
+			for (uint32_t u = 0; u < 4; ++u) chs[u] = t0 + u < t_end ? rp[t0 + u] : make_uint4(0, 0, 0, 0);
 			#pragma unroll
 			for (uint32_t u = 0; u < 4; ++u) {
 				const uint32_t t = t0 + u;
-				if (t >= nchunks) break;
+				if (t >= t_end) break;
 				const uint32_t dw[4] = {chs[u].x, chs[u].y, chs[u].z, chs[u].w};
 				#pragma unroll
 				for (int k8 = 0; k8 < 4; ++k8) {      // per dword of symbols: the flagged range is kept at a granularity of 8 columns
@@ -2577,7 +528,7 @@ __global__ __launch_bounds__(64) void k_myers_prefix_task(
 				wins[pos] = w;
 			}
 		}
-		my_cols += L;
+		my_cols += t_end * 32u < L ? t_end * 32u : L;
 	}
 	if (tcol_sum && my_cols) atomicAdd(tcol_sum, my_cols);
 }
@@ -3567,10 +1518,3 @@ template __global__ void k_rescore<true>(const BhipRawHit *, const uint32_t *, u
 	BhipHit *, uint32_t *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *, unsigned long long, uint32_t *,
 	const uint32_t *, uint32_t, uint32_t, uint32_t);
 
-#ifdef PFM_PROF
-extern "C" BHIP_API int bhip_debug_prof(unsigned long long *out, int reset) {
-	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pfm_prof), 64) != hipSuccess) return -1;
-	if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pfm_prof), z, 64) != hipSuccess) return -1; }
-	return 0;
-}
-#endif

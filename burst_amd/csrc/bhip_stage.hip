@@ -49,7 +49,7 @@ uint32_t make_seed_plan(const uint8_t *s, uint32_t len, uint32_t E, uint32_t K, 
 // rare batch with query symbols of code 0, runs the host pass that builds the search view.
 int slot_init(StageSlot *S) {
 	if (S->ev_done) return 0;
-	if (hipEventCreate(&S->ev_begin) != hipSuccess || hipEventCreate(&S->ev_done) != hipSuccess) return fail(BHIP_E_DEVICE, "hipEventCreate failed");
+	if (hipEventCreate(&S->ev_begin) != hipSuccess || hipEventCreate(&S->ev_done) != hipSuccess || hipEventCreate(&S->ev_copied) != hipSuccess) return fail(BHIP_E_DEVICE, "hipEventCreate failed");
 	if (hipHostMalloc((void **)&S->info_pinned, sizeof(BhipStageInfo), hipHostMallocDefault) != hipSuccess) return fail(BHIP_E_DEVICE, "hipHostMalloc failed");
 	int rc = S->info.reserve(sizeof(BhipStageInfo));
 	return rc;
@@ -154,6 +154,7 @@ static int stage_enqueue(Handle *h, StageSlot *S, const BhipQuerySpan *spans, ui
 		HIPCHK(hipGetLastError());
 		ebase += sp.n; pos += bytes;
 	}
+	HIPCHK(hipEventRecord(S->ev_copied, st));      // (ms_stage_copy ends / ms_stage_route starts here)
 	{	// 4-bit packed copy of the queries at a fixed stride (layout used by the routing, seed, profile and re-scoring kernels)
 		const uint64_t total = (uint64_t)n_q * qw;
 		if (total) hipLaunchKernelGGL(k_pack_queries, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->n_cu * 16)), dim3(256), 0, st,
@@ -352,6 +353,7 @@ int resolve_slot(Handle *h, StageSlot *S) {
 	if (I.err == 1) return fail(BHIP_E_QUERYLEN, "query %u has %u symbols (max %d)", I.err_i, I.err_len, BHIP_MAX_QLEN);
 	if (I.err == 2) return fail(BHIP_E_ARG, "q_six[%u] out of range", I.err_i);
 	S->st_ms_h2d = ev_ms(S->ev_begin, S->ev_done);
+	S->st_ms_copy = ev_ms(S->ev_begin, S->ev_copied); S->st_ms_route = ev_ms(S->ev_copied, S->ev_done);
 	if (I.junk || h->opt_host_routing) { int rc = host_route(h, S); if (rc) return rc; }
 	else slot_take_info(S, I);
 	S->resolved = true; S->st_valid = true;

@@ -72,7 +72,7 @@ static void add_stats(BhipStats *t, const BhipStats *s) {
 	t->ms_rescore += s->ms_rescore; t->ms_d2h += s->ms_d2h; t->ms_total += s->ms_total; t->myers_launches += s->myers_launches;
 	t->n_windows += s->n_windows; t->n_window_columns += s->n_window_columns; t->n_lane_tasks += s->n_lane_tasks; t->n_task_columns += s->n_task_columns; t->ms_myers_prefix += s->ms_myers_prefix;
 	t->ms_myers_window += s->ms_myers_window; t->prefix_words = s->prefix_words;
-	t->n_seed_words += s->n_seed_words; t->ms_prefilter_hash += s->ms_prefilter_hash; t->ms_seed += s->ms_seed; t->prefilter_launches += s->prefilter_launches; t->prefilter_algo = s->prefilter_algo;
+	t->n_seed_words += s->n_seed_words; t->ms_prefilter_hash += s->ms_prefilter_hash; t->ms_seed += s->ms_seed; t->ms_stage_copy += s->ms_stage_copy; t->ms_stage_route += s->ms_stage_route; t->prefilter_launches += s->prefilter_launches; t->prefilter_algo = s->prefilter_algo;
 }
 
 /* page-locked result buffer: the records of batch k are copied out behind bhip_align_staged while batch k+1 computes */

@@ -72,6 +72,8 @@ typedef struct BhipStats {
 	float ms_myers_window;     /* part of ms_myers spent in k_myers_window */
 	float ms_prefilter_hash;   /* part of ms_prefilter spent in k_prefilter_mask (HIP events around that kernel alone) */
 	float ms_seed;             /* part of ms_prefilter spent in k_seed_ranges */
+	float ms_stage_copy;       /* of ms_h2d (the staging of this batch, on the staging stream, two batches ahead): the copies over PCIe with the unpack kernels and offset scans between them */
+	float ms_stage_route;      /* of ms_h2d: k_pack_queries, k_route and the radix sort of the entry lists behind the copies (kernels that share the CUs with the batch being aligned) */
 	uint32_t myers_launches;   /* launches of the column-sweeping kernel (k_myers_prefix, or k_myers on the one-stage path) */
 	uint32_t prefix_words;     /* NWP of the last launch, 0 = one-stage path */
 	uint32_t prefilter_launches; /* launches of the lane-resolved prefilter kernel */

@@ -7,6 +7,7 @@ import numpy as np
 import test_gpu_kernels as T          # family_db, make_queries, oracle_hits
 import dbutil, oraclelib as ol
 from burst_amd import capi
+capi.LOAD_LEGACY_PREFILTERS = True          # (the fuzzer also draws the superseded prefilter kernels: the test-only library in front of the product's)
 
 budget_s = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1

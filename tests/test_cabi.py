@@ -24,7 +24,7 @@ def test_header_symbols_exported():
     for s in syms:
         assert hasattr(lib, s), s
     assert lib.bhip_abi_version() == 8
-    assert ctypes.sizeof(capi.BhipStats) == 12 * 8 + 11 * 4 + 4 * 4 + 4      # 12 u64 + 11 f32 + 4 u32, padded to 8
+    assert ctypes.sizeof(capi.BhipStats) == 12 * 8 + 13 * 4 + 4 * 4 + 4      # 12 u64 + 13 f32 + 4 u32, padded to 8
     assert capi.HIT_DTYPE.itemsize == 20
 
 

@@ -106,6 +106,14 @@ def _scale_diff(n_reads, env):
     return [ln for ln in r.stdout.splitlines() if ln.startswith(("BEST", "ALLPATHS", "CAPITALIST", "FORAGE"))], r.stdout
 
 
+def _scale_diffs_side_by_side(jobs):
+    """several tools/scale_diff.sh runs at once (jobs: (n_reads, env) -- a one-thread reference leaves 15 of the job's 16 cores idle; SD_TAG
+    keeps their scratch files apart): the list of (lines, output) in the order given"""
+    import concurrent.futures
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(jobs)) as pool:
+        return list(pool.map(lambda j: _scale_diff(j[1][0], dict(j[1][1], SD_TAG="_%d" % j[0])), enumerate(jobs)))
+
+
 def _check_diff_lines(lines, n_reads, frac=0.005):
     """BEST: identical.  The other modes print, where the reference's own thread timing decides (DUPE_HUNT between overlapping
     shears, burst.c:4563-4570; equally voted references in CAPITALIST, 4763-4776), one of several placements: there the
@@ -155,15 +163,17 @@ def test_deterministic_reference_leg_is_identical_in_every_mode():
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "burst12")):
         pytest.skip("compiled reference not present")
     from burst_amd import host
+    jobs = []
     for read_len, thres, modes, iupac, edits, n_reads in ((100, 0.97, "CAPITALIST ALLPATHS FORAGE", 0.0, [0, 1, 2, 3], 2400), (320, 0.95, "FORAGE", 0.01, [0, 2, 4, 8, 12], 800)):
         work, refs, edx, acx = _bench_db(read_len, thres, n_base=60, n_variants=30, want_acx=False)
         reads = os.path.join(work, "det_reads_l%d.fa" % read_len)
         if not os.path.exists(reads):
             host.synth_reads(refs, reads, n_reads, read_len, edits, rc=True, iupac=iupac, seed=91)
-        lines, out = _scale_diff(n_reads, dict(BURST_BENCH_DIR=work, SD_EDX=edx, SD_READS=reads, SD_MODES=modes, SD_IDS=str(thres), SD_EXTRA="-fr", SD_EXHAUSTIVE="1", SD_THREADS="1"))
-        assert len(lines) == len(modes.split()), out[-3000:]
-        for ln in lines:
-            assert "IDENTICAL" in ln, ln
+        for mode in modes.split():      # (the four one-thread reference runs side by side: 131 s one after the other in round 5's suite)
+            jobs.append((n_reads, dict(BURST_BENCH_DIR=work, SD_EDX=edx, SD_READS=reads, SD_MODES=mode, SD_IDS=str(thres), SD_EXTRA="-fr", SD_EXHAUSTIVE="1", SD_THREADS="1")))
+    for lines, out in _scale_diffs_side_by_side(jobs):
+        assert len(lines) == 1, out[-3000:]
+        assert "IDENTICAL" in lines[0], lines[0]
 
 
 def test_configs2_twelve_million_292bp_reads_allpaths():
@@ -240,7 +250,7 @@ def test_configs4_shape_full_size():
     -m FORAGE -i 0.95 (every placement within budget, burst.c:4224; ambiguous words burst.c:3232-3236), through the product's batch
     scheduler.  Size-independent properties: every read's home placement is reported (a read carries <= 12 edits <= its budget of
     16), every record within budget, the f32 identity of every record, positions inside the clump, records ordered by (query,
-    reference) without duplicates, both strands present; and the first 800 reads are diffed against the compiled reference (which needs a minute and a half for them on 256 threads)
+    reference) without duplicates, both strands present; and the first 400 reads are diffed against the compiled reference (which needs most of a minute for them on 256 threads)
     (FORAGE and BEST; FORAGE under the "every differing line explained" rule of _check_diff_lines)."""
     work, refs, edx, acx = _bench_db(320, 0.95)
     from burst_amd import host
@@ -280,8 +290,8 @@ def test_configs4_shape_full_size():
     run.close()
     dev.close()
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "burst12")):
-        lines, out = _scale_diff(800, dict(BURST_BENCH_DIR=work, SD_EDX=edx, SD_READS=reads, SD_MODES="FORAGE BEST", SD_IDS="0.95", SD_EXTRA="-fr"))
+        lines, out = _scale_diff(400, dict(BURST_BENCH_DIR=work, SD_EDX=edx, SD_READS=reads, SD_MODES="FORAGE BEST", SD_IDS="0.95", SD_EXTRA="-fr"))      # (800 reads until round 6: the reference needs 45 s per mode for them)
         assert len(lines) == 2, out[-3000:]
         # (which of two overlapping shears the reference prints depends on the order its 256 threads found them in: 12 .. 26 of ~1 280 lines
         # from run to run on the same inputs -- the count is bounded loosely, what is strict is that every one of them is explained)
-        _check_diff_lines(lines, 800, frac=0.04)
+        _check_diff_lines(lines, 400, frac=0.04)

@@ -1,12 +1,15 @@
 """Parity of the HIP path (through the C ABI of include/burst_hip.h) against the oracle on seeded inputs.
 Bit-exact: edit distances, hit sets, gap counts, end positions and the f32 identity score."""
 import os
+import sys
 
 import numpy as np
 import pytest
 
 import dbutil
 import oraclelib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CW_DEFAULT = 2          # library default of option prefilter_cw (the tests run the other counting-filter kernel as a variant)
 from burst_amd import synth
@@ -116,6 +119,36 @@ def test_many_records_per_query_come_out_in_the_oracle_order(n_var):
             assert np.bincount(exp["q"]).max() > min(n_var, 300) * 0.8       # groups on both sides of 64 and of a multiple of it
         assert_hits_equal(got, exp)
     dev.close()
+
+
+def test_product_library_alone_refuses_the_superseded_prefilter_kernels():
+    """k_prefilter_cf and k_prefilter_cw<0 / 1> are not part of libburst_hip.so (round 6): a process that has not loaded the test-only
+    libburst_hip_legacy.so gets an error for prefilter_cw = 0 / 1, and the same batch through the default kernel"""
+    import subprocess
+    code = (
+        "import sys, numpy as np; sys.path[:0] = [%r, %r]\n"
+        "import dbutil, oraclelib as ol\n"
+        "from burst_amd import capi, synth\n"
+        "assert not capi.LOAD_LEGACY_PREFILTERS\n"
+        "rng = np.random.default_rng(5); seqs = []\n"
+        "for _ in range(4): seqs += synth.mutate_family(rng.integers(1, 5, size=400, dtype=np.uint8), 8, 0.03, rng)\n"
+        "packed, clump_len, tot = dbutil.pack_clumps(seqs)\n"
+        "lens, entries, offs = dbutil.build_acx(seqs, 10)\n"
+        "dev = capi.Device(packed, clump_len, tot, ol.score_lut(1), acx_lens=lens, acx_lists=dbutil.pack_acx_lists(lens, entries, 0), acx_fmt=0, K=10)\n"
+        "reads, _ = synth.make_reads(seqs, 16, 100, [0, 1, 2], 3)\n"
+        "q = capi.Queries(reads, [3] * 16, list(range(16)), [0] * 16)\n"
+        "base = dev.align_batch(q)\n"
+        "for cw in (0, 1):\n"
+        "    dev.set_option('prefilter_cw', cw)\n"
+        "    try:\n"
+        "        dev.align_batch(q); print('NOT REFUSED', cw)\n"
+        "    except capi.BurstHipError as e:\n"
+        "        print('refused', cw, 'superseded' in str(e))\n"
+        "dev.set_option('prefilter_cw', 2)\n"
+        "print('same', dev.align_batch(q).tobytes() == base.tobytes(), len(base))\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "refused 0 True" in r.stdout and "refused 1 True" in r.stdout and "NOT REFUSED" not in r.stdout and "same True" in r.stdout, r.stdout
 
 
 def test_one_long_read_does_not_move_the_others_to_the_long_kernel(capfd, monkeypatch):
@@ -540,6 +573,7 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "t
 import numpy as np
 import test_gpu_kernels as T, dbutil, oraclelib as ol
 from burst_amd import capi
+capi.LOAD_LEGACY_PREFILTERS = True          # (the superseded kernels run as variants here: the test-only library in front of the product's)
 seqs = T.family_db(151, 9, 21, 480, rate=0.05)
 packed, clump_len, tot = dbutil.pack_clumps(seqs)
 lens, entries, offs = dbutil.build_acx(seqs, 12)
@@ -576,6 +610,7 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "t
 import numpy as np
 import test_gpu_kernels as T, dbutil, oraclelib as ol
 from burst_amd import capi
+capi.LOAD_LEGACY_PREFILTERS = True          # (the superseded kernels run as variants here: the test-only library in front of the product's)
 K = 12
 seqs = T.family_db(191, 10, 20, 480, rate=0.05)
 packed, clump_len, tot = dbutil.pack_clumps(seqs)

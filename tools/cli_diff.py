@@ -100,43 +100,55 @@ runs = [("CAPITALIST", "0.95", ["-fr", "-b", tax]), ("BEST", "0.95", ["-b", tax,
         ("BEST", "0.95", ["-w"]), ("BEST", "0.96", ["-a", acx]), ("ALLPATHS", "0.95", ["-fr", "-a", acx]), ("ALLPATHS", "0.95", ["-r", odd_refs, "-s"]),
         ("BEST", "0.97", ["-r", odd_refs, "-fr"]), ("ALLPATHS", "0.95", ["-fr", "-sa"]), ("BEST", "0.95", ["-r", odd_refs, "-u"]),
         ("CAPITALIST", "0.95", ["-r", odd_refs, "-s", "-u", "-sa"])]
+# every (case, run) pair is two short processes (the reference with one thread, burst_hip): run a few pairs side by side -- 560 process
+# starts one after the other were 140 s of the GPU suite (round 6) -- and print the lines in the order of the loops
+import concurrent.futures
+
+
+def one_pair(job):
+    k, name, q, mode, ident, extra = job
+    if name == "short_reads" and "-a" in extra:
+        # documented divergences of the reference's accelerated path: a read of exactly (E+1)*K symbols is
+        # dropped by its per-query floor, and which strand of a tiny two-strand tie survives depends on its hit-list order
+        return 0, ["%-18s %-10s %-5s (accelerated: documented divergences for reads of <= K symbols, not compared)" % (name, mode, ident)]
+    outs = []
+    ref_db = os.path.join(G, "dna.edx")
+    if "-r" in extra:
+        ref_db = extra[extra.index("-r") + 1]
+        extra = [e for i, e in enumerate(extra) if e != "-r" and (i == 0 or extra[i - 1] != "-r")]
+    for exe, tail in ((REF, ["-t", "1", "--noprogress"]), (CLI, [])):
+        o = os.path.join(work, "out_%d_%s.b6" % (k, "ref" if exe == REF else "hip"))
+        if os.path.exists(o):
+            os.remove(o)
+        r = subprocess.run([exe, "-r", ref_db, "-q", q, "-o", o, "-m", mode, "-i", ident] + extra + tail,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        lines = sorted(open(o, "rb").read().splitlines()) if os.path.exists(o) else None
+        if os.path.exists(o):
+            os.remove(o)
+        outs.append((r.returncode, lines, r.stdout[-300:]))
+    same = outs[0][0] == outs[1][0] and (outs[0][1] == outs[1][1] or outs[0][0] != 0)      # after an error stop the partial output is not compared
+    if outs[0][0] < 0:
+        return 0, ["%-18s %-10s %-5s %-8s the reference crashed (signal %d); burst_hip rc=%d, %d lines -- not compared" % (name, mode, ident, " ".join(extra), -outs[0][0], outs[1][0], len(outs[1][1] or []))]
+    text = ["%-18s %-10s %-5s %-8s ref rc=%d %s lines | hip rc=%d %s lines  %s" % (name, mode, ident, " ".join(os.path.basename(e) for e in extra), outs[0][0], len(outs[0][1] or []), outs[1][0],
+                                                                                  len(outs[1][1] or []), "ok" if same else "DIFF")]
+    if not same:
+        if outs[0][1] is not None and outs[1][1] is not None:
+            a, b = set(outs[0][1]), set(outs[1][1])
+            for ln in sorted(a - b)[:3]:
+                text.append("   only ref: " + ln.decode("utf-8", "replace"))
+            for ln in sorted(b - a)[:3]:
+                text.append("   only hip: " + ln.decode("utf-8", "replace"))
+        else:
+            text.append("   ref tail: " + outs[0][2].replace("\n", " | "))
+            text.append("   hip tail: " + outs[1][2].replace("\n", " | "))
+    return (0 if same else 1), text
+
+
+jobs = [(k, name, q, mode, ident, list(extra)) for k, (name, q, (mode, ident, extra)) in enumerate((name, q, run) for name, q in cases for run in runs)]
 bad = 0
-for name, q in cases:
-    for mode, ident, extra in runs:
-        if name == "short_reads" and "-a" in extra:
-            # documented divergences of the reference's accelerated path: a read of exactly (E+1)*K symbols is
-            # dropped by its per-query floor, and which strand of a tiny two-strand tie survives depends on its hit-list order
-            print("%-18s %-10s %-5s (accelerated: documented divergences for reads of <= K symbols, not compared)" % (name, mode, ident))
-            continue
-        outs = []
-        ref_db = os.path.join(G, "dna.edx")
-        if "-r" in extra:
-            ref_db = extra[extra.index("-r") + 1]
-            extra = [e for i, e in enumerate(extra) if e != "-r" and (i == 0 or extra[i - 1] != "-r")]
-        for exe, tail in ((REF, ["-t", "1", "--noprogress"]), (CLI, [])):
-            o = os.path.join(work, "out_%s.b6" % ("ref" if exe == REF else "hip"))
-            if os.path.exists(o):
-                os.remove(o)
-            r = subprocess.run([exe, "-r", ref_db, "-q", q, "-o", o, "-m", mode, "-i", ident] + extra + tail,
-                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-            lines = sorted(open(o, "rb").read().splitlines()) if os.path.exists(o) else None
-            outs.append((r.returncode, lines, r.stdout[-300:]))
-        same = outs[0][0] == outs[1][0] and (outs[0][1] == outs[1][1] or outs[0][0] != 0)      # after an error stop the partial output is not compared
-        if outs[0][0] < 0:
-            print("%-18s %-10s %-5s %-8s the reference crashed (signal %d); burst_hip rc=%d, %d lines -- not compared" % (name, mode, ident, " ".join(extra), -outs[0][0], outs[1][0], len(outs[1][1] or [])))
-            continue
-        print("%-18s %-10s %-5s %-8s ref rc=%d %s lines | hip rc=%d %s lines  %s" % (name, mode, ident, " ".join(os.path.basename(e) for e in extra), outs[0][0], len(outs[0][1] or []), outs[1][0],
-                                                                                 len(outs[1][1] or []), "ok" if same else "DIFF"))
-        if not same:
-            bad += 1
-            if outs[0][1] is not None and outs[1][1] is not None:
-                a, b = set(outs[0][1]), set(outs[1][1])
-                for ln in sorted(a - b)[:3]:
-                    print("   only ref:", ln.decode("utf-8", "replace"))
-                for ln in sorted(b - a)[:3]:
-                    print("   only hip:", ln.decode("utf-8", "replace"))
-            else:
-                print("   ref tail:", outs[0][2].replace("\n", " | "))
-                print("   hip tail:", outs[1][2].replace("\n", " | "))
+with concurrent.futures.ThreadPoolExecutor(max_workers=int(os.environ.get("CLI_DIFF_JOBS", "8"))) as pool:
+    for b_, text in pool.map(one_pair, jobs):
+        bad += b_
+        print("\n".join(text), flush=True)
 print("cli_diff:", "ALL OK" if not bad else "%d differing runs" % bad)
 sys.exit(1 if bad else 0)

@@ -82,25 +82,38 @@ write(os.path.join(work, "nrun.fa"), [(h, s[:200] + "N" * 60 + s[260:]) for h, s
 params = [["-d", "QUICK", "100", "-s", "500", "-i", "0.97"], ["-d", "QUICK", "320", "-s", "-i", "0.95"], ["-d", "QUICK", "150", "-i", "0.98"],
           ["-d", "QUICK", "100", "-s", "200", "-i", "0.9", "-y"], ["-d", "QUICK", "250", "-s", "1000", "-i", "0.97", "-l", "0"],
           ["-d", "QUICK", "120", "-s", "400", "-i", "0.96", "-sa"]]
+# (case, parameters) pairs side by side, a few at a time: each is two short processes; the lines are printed in the order of the loops
+import concurrent.futures
+
+
+def one_pair(job):
+    k, name, fa, par = job
+    outs = []
+    for exe, tail, tag in ((REF, ["-t", "1"], "ref"), (CLI, [], "hip")):
+        edx, acx = os.path.join(work, "%s_%d.edx" % (tag, k)), os.path.join(work, "%s_%d.acx" % (tag, k))
+        for f in (edx, acx):
+            if os.path.exists(f):
+                os.remove(f)
+        r = subprocess.run([exe, "-r", fa, "-o", edx, "-a", acx] + par + tail, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        outs.append((r.returncode, open(edx, "rb").read() if os.path.exists(edx) else None, open(acx, "rb").read() if os.path.exists(acx) else None, r.stdout[-400:]))
+        for f in (edx, acx):
+            if os.path.exists(f):
+                os.remove(f)
+    same = outs[0][0] == outs[1][0] and (outs[0][0] != 0 or (outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]))
+    if os.environ.get("DB_DIFF_EXPECT_DEVICE") == "1" and outs[1][0] == 0 and "-sa" not in par and "built on device" not in outs[1][3]:
+        same = False
+    text = ["%-18s %-44s ref rc=%d hip rc=%d edx %s acx %s  %s" % (name, " ".join(par), outs[0][0], outs[1][0],
+            "same" if outs[0][1] == outs[1][1] else "DIFFERENT", "same" if outs[0][2] == outs[1][2] else "DIFFERENT", "ok" if same else "DIFF")]
+    if not same:
+        text += ["   ref: " + outs[0][3].replace("\n", " | ")[-300:], "   hip: " + outs[1][3].replace("\n", " | ")[-300:]]
+    return (0 if same else 1), text
+
+
 bad = 0
-for name, fa in cases:
-    for par in params:
-        outs = []
-        for exe, tail, tag in ((REF, ["-t", "1"], "ref"), (CLI, [], "hip")):
-            edx, acx = os.path.join(work, tag + ".edx"), os.path.join(work, tag + ".acx")
-            for f in (edx, acx):
-                if os.path.exists(f):
-                    os.remove(f)
-            r = subprocess.run([exe, "-r", fa, "-o", edx, "-a", acx] + par + tail, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-            outs.append((r.returncode, open(edx, "rb").read() if os.path.exists(edx) else None, open(acx, "rb").read() if os.path.exists(acx) else None, r.stdout[-400:]))
-        same = outs[0][0] == outs[1][0] and (outs[0][0] != 0 or (outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]))
-        if os.environ.get("DB_DIFF_EXPECT_DEVICE") == "1" and outs[1][0] == 0 and "-sa" not in par and "built on device" not in outs[1][3]:
-            same = False
-        print("%-18s %-44s ref rc=%d hip rc=%d edx %s acx %s  %s" % (name, " ".join(par), outs[0][0], outs[1][0],
-              "same" if outs[0][1] == outs[1][1] else "DIFFERENT", "same" if outs[0][2] == outs[1][2] else "DIFFERENT", "ok" if same else "DIFF"))
-        if not same:
-            bad += 1
-            print("   ref:", outs[0][3].replace("\n", " | ")[-300:])
-            print("   hip:", outs[1][3].replace("\n", " | ")[-300:])
+jobs = [(k, name, fa, par) for k, (name, fa, par) in enumerate((name, fa, par) for name, fa in cases for par in params)]
+with concurrent.futures.ThreadPoolExecutor(max_workers=int(os.environ.get("DB_DIFF_JOBS", "6"))) as pool:
+    for b_, text in pool.map(one_pair, jobs):
+        bad += b_
+        print("\n".join(text), flush=True)
 print("db_diff:", "ALL OK" if not bad else "%d differing runs" % bad)
 sys.exit(1 if bad else 0)

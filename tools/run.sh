@@ -16,7 +16,7 @@ sum() { python tools/bsum.py "$1" < "$2"; }
 case "$WHAT" in
 tests)
 	T0=$SECONDS
-	timeout ${LIMIT:-2400} python -m pytest "${@:-tests}" -q -m gpu > $O/${TAG}_gputests.txt 2>&1; echo "tests exit $? after $((SECONDS - T0)) s" >> $O/${TAG}_gputests.txt
+	timeout ${LIMIT:-2400} python -m pytest "${@:-tests}" -q -m gpu --durations=40 > $O/${TAG}_gputests.txt 2>&1; echo "tests exit $? after $((SECONDS - T0)) s" >> $O/${TAG}_gputests.txt
 	grep -n "^FAILED\|^ERROR\|passed\|failed\|tests exit" $O/${TAG}_gputests.txt | tail -12 ;;
 bench)
 	(while true; do echo "$(date +%s) $(cat /sys/fs/cgroup/memory.current 2>/dev/null) $(df --output=used -B1 /dev/shm | tail -1) $(grep -E '^(anon|file|shmem|file_mapped|kernel) ' /sys/fs/cgroup/memory.stat 2>/dev/null | tr '\n' ' ')"; sleep 2; done) > $O/${TAG}_mem.txt & MW=$!

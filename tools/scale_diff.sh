@@ -17,34 +17,35 @@ REFBIN=${SD_REF:-$ROOT/oracle/_ref/burst12}      # DB15 accelerators: SD_REF=ora
 HIPX=${SD_HIP_EXTRA:-}
 HIPACC=${SD_HIP_ACCEL:-"-a $ACX"}                # burst_hip without the file: SD_HIP_ACCEL="-ad -k 15" (accelerator built on the device)
 REFACC="-a $ACX"; THREADS=${SD_THREADS:-$(nproc)}
+T=${SD_TAG:-}                                    # several runs side by side in one work directory: a tag of their own for the scratch files
 # SD_EXHAUSTIVE=1: both programs without an accelerator; with SD_THREADS=1 that is the reference's DETERMINISTIC configuration (one hit list
 # per query, clumps ascending: bh_report.c) -- every mode must then be identical byte for byte
 if [ "${SD_EXHAUSTIVE:-0}" = 1 ]; then HIPACC=""; REFACC=""; fi
-head -n $((2 * N)) $READS > $W/sd_reads.fa
+head -n $((2 * N)) $READS > $W/sd_reads$T.fa
 secs() { awk -v a=$1 -v b=$2 'BEGIN { printf "%.2f", b - a }'; }
 for MODE in ${SD_MODES:-BEST ALLPATHS}; do
   for ID in $IDS; do
-    T0=$(date +%s.%N); $REFBIN -r $EDX $REFACC -q $W/sd_reads.fa -o $W/sd_ref.b6 -m $MODE -i $ID $EXTRA -t $THREADS --noprogress > $W/sd_ref.log 2>&1; T1=$(date +%s.%N)
-    $ROOT/burst_amd/burst_hip -r $EDX $HIPACC -q $W/sd_reads.fa -o $W/sd_hip.b6 -m $MODE -i $ID $EXTRA $HIPX > $W/sd_hip.log 2>&1; T2=$(date +%s.%N)
-    sort $W/sd_ref.b6 > $W/sd_ref.s; sort $W/sd_hip.b6 > $W/sd_hip.s
-    NR=$(wc -l < $W/sd_ref.s); NH=$(wc -l < $W/sd_hip.s)
-    if cmp -s $W/sd_ref.s $W/sd_hip.s; then R=IDENTICAL
+    T0=$(date +%s.%N); $REFBIN -r $EDX $REFACC -q $W/sd_reads$T.fa -o $W/sd_ref$T.b6 -m $MODE -i $ID $EXTRA -t $THREADS --noprogress > $W/sd_ref$T.log 2>&1; T1=$(date +%s.%N)
+    $ROOT/burst_amd/burst_hip -r $EDX $HIPACC -q $W/sd_reads$T.fa -o $W/sd_hip$T.b6 -m $MODE -i $ID $EXTRA $HIPX > $W/sd_hip$T.log 2>&1; T2=$(date +%s.%N)
+    sort $W/sd_ref$T.b6 > $W/sd_ref$T.s; sort $W/sd_hip$T.b6 > $W/sd_hip$T.s
+    NR=$(wc -l < $W/sd_ref$T.s); NH=$(wc -l < $W/sd_hip$T.s)
+    if cmp -s $W/sd_ref$T.s $W/sd_hip$T.s; then R=IDENTICAL
     else
-      ND=$(diff $W/sd_ref.s $W/sd_hip.s | grep -c '^<')
+      ND=$(diff $W/sd_ref$T.s $W/sd_hip$T.s | grep -c '^<')
       R="$ND of $NR lines differ"
       if [ $MODE = CAPITALIST ]; then
-        QD=$(diff <(cut -f1 $W/sd_ref.s | uniq) <(cut -f1 $W/sd_hip.s | uniq) | wc -l)
+        QD=$(diff <(cut -f1 $W/sd_ref$T.s | uniq) <(cut -f1 $W/sd_hip$T.s | uniq) | wc -l)
         # every reference line must be one of the query's minimum-edit-distance placements (what -m ALLPATHS --no-dupe-hunt prints):
         # which of several equally voted ones is kept depends on the reference's hit order (burst.c:4763-4776)
-        $ROOT/burst_amd/burst_hip -r $EDX $HIPACC -q $W/sd_reads.fa -o $W/sd_nd.b6 -m ALLPATHS -i $ID $EXTRA $HIPX --no-dupe-hunt > /dev/null 2>&1
-        sort -u $W/sd_nd.b6 > $W/sd_nd.s
-        MISSING=$(comm -23 $W/sd_ref.s $W/sd_nd.s | wc -l)
+        $ROOT/burst_amd/burst_hip -r $EDX $HIPACC -q $W/sd_reads$T.fa -o $W/sd_nd$T.b6 -m ALLPATHS -i $ID $EXTRA $HIPX --no-dupe-hunt > /dev/null 2>&1
+        sort -u $W/sd_nd$T.b6 > $W/sd_nd$T.s
+        MISSING=$(comm -23 $W/sd_ref$T.s $W/sd_nd$T.s | wc -l)
         R="$R (equally voted placements, decided by the reference's hit order); reference lines that are not a placement burst_hip computed: $MISSING; queries reported by only one program: $QD; line counts $NR / $NH"
       elif [ $MODE != BEST ]; then
-        $ROOT/burst_amd/burst_hip -r $EDX $HIPACC -q $W/sd_reads.fa -o $W/sd_nd.b6 -m $MODE -i $ID $EXTRA $HIPX --no-dupe-hunt > /dev/null 2>&1
-        sort -u $W/sd_nd.b6 > $W/sd_nd.s
-        MISSING=$(comm -23 $W/sd_ref.s $W/sd_nd.s | wc -l)
-        QD=$(diff <(cut -f1 $W/sd_ref.s | uniq) <(cut -f1 $W/sd_hip.s | uniq) | wc -l)
+        $ROOT/burst_amd/burst_hip -r $EDX $HIPACC -q $W/sd_reads$T.fa -o $W/sd_nd$T.b6 -m $MODE -i $ID $EXTRA $HIPX --no-dupe-hunt > /dev/null 2>&1
+        sort -u $W/sd_nd$T.b6 > $W/sd_nd$T.s
+        MISSING=$(comm -23 $W/sd_ref$T.s $W/sd_nd$T.s | wc -l)
+        QD=$(diff <(cut -f1 $W/sd_ref$T.s | uniq) <(cut -f1 $W/sd_hip$T.s | uniq) | wc -l)
         R="$R; reference lines that are not a placement burst_hip computed: $MISSING; queries reported by only one program: $QD; line counts $NR / $NH"
       fi
     fi
