@@ -493,21 +493,30 @@ def end_to_end(edx, reads_fa, args, device):
     # starts after a pause on a quiet device with the files in the page cache, as the bench's own inputs are: that one is reported, the
     # first beside it as `right_behind_another_process_s`.
     settle = 20.0 if os.path.getsize(edx) > 8e9 else 0.0
-    for it in range(2):
+    failed = []          # a run that did not end with its "Alignment time" line: exit code and the end of its output are kept, and one more run is made
+    it = 0
+    while it < 2:
         if it and settle:
             time.sleep(settle)
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         m = re.search(r"Alignment time: ([\d.]+) seconds", r.stdout)
         if r.returncode != 0 or not m:
-            return {"error": r.stdout[-400:]}
+            failed.append({"returncode": r.returncode, "after_runs": it, "output_tail": r.stdout[-1500:]})
+            if len(failed) > 1:
+                return {"error": failed[-1]["output_tail"][-400:], "failed_runs": failed}
+            time.sleep(5.0)
+            continue
         n = int(re.search(r"Parsed (\d+) queries", r.stdout).group(1))
         best = {"reads": n, "seconds": float(m.group(1)), "reads_per_s": n / float(m.group(1)), "lines": int(re.search(r"Wrote (\d+) alignments", r.stdout).group(1)),
                 "phases_s": {k.strip(): float(v) for k, v in re.findall(r"\[([a-z ,()+.]+?)\s+([\d.]+) s", r.stdout)},
                 "command": "burst_hip -r DB.edx -ad -k %d -q <%d reads> -o out.b6 -m %s -i %s (second of two runs%s)" % (args.K, n, args.mode, args.id, ", %.0f s after the first" % settle if settle else "")}
         if it == 0:
             first = best["seconds"]
+        it += 1
     if best is not None:
         best["right_behind_another_process_s"] = first
+        if failed:
+            best["failed_runs"] = failed
     try:
         os.remove(out)
     except OSError:
@@ -1031,7 +1040,12 @@ def main():
                        "timed_region": "bh_align_ranges over %d batches (copies + device routing two batches ahead, seed lookups + profiles one batch ahead, alignment, records to host memory)%s" %
                                        (nb, (" + hand-over of all ranks' records to rank 0 (shared memory)" if args.gather == "shm" else " + RCCL gather") if use_dist else ""),
                        "extrapolation": extrap,
-                       "device": info["name"], "n_cu": info["n_cu"]},
+                       "device": info["name"], "n_cu": info["n_cu"],
+                       # which exchange built the accelerator (round 5's verdict: "did RCCL see N ranks" must be answerable for both collectives): the
+                       # bench's ranks each build the whole accelerator on their own device (outside the timed region: host.device_upload_s) -- no exchange;
+                       # the cooperative build (bhip_build_accelerator_shared over bhip_comm_share / RCCL broadcasts) is what burst_hip --gpus N and
+                       # python -m burst_amd.run use, measured on one device only
+                       "accelerator_build": {"by": "every rank on its own device (bhip_init with K)" if not args.acx_file else "loaded from the .acx file", "exchange": None, "ranks_in_exchange": 0}},
             "roofline": {"bound": "hbm" if bound_dom == "hbm" else "valu", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": pmc_of(dom).get("hbm_bytes_per_launch"), "pmc_source": pmc_source,
                          "traffic_half_lines": pmc_of(dom).get("hbm_bytes_per_launch_gather_calibrated") if bound_dom == "hbm" else None,
@@ -1067,6 +1081,9 @@ def main():
                         e_ = (time.time() - t_) * 1e3
                         best_ = e_ if best_ is None else min(best_, e_)
                     sj[label] = best_
+                    if pieces == "1":      # where the one-batch job's device time goes (HIP events of one more run): nothing overlaps here, so the phases add up
+                        st_ = search([(0, u_short)]).stats()
+                        sj["phases_ms_whole"] = {k: float(st_[k]) for k in ("ms_h2d", "ms_stage_copy", "ms_stage_route", "ms_seed", "ms_peq", "ms_prefilter_hash", "ms_myers_prefix", "ms_myers_window", "ms_rescore", "ms_d2h", "ms_total")}
                 os.environ.pop("BURST_HOST_PIECES", None)
                 res["one_rank_share_of_configs3"] = sj
                 log("[bench] 1.25 M-read job: %.2f ms whole, %.2f ms in four pieces" % (sj["ms_whole"], sj["ms_in_pieces"]))

@@ -546,6 +546,8 @@ extern "C" int bhip_reserve_symbols(void *handle, uint32_t n_entries, uint32_t m
 	    (rc = L->wins2.reserve(L->win_cap * sizeof(BhipWin))) || (rc = L->peq.reserve(peq_words * 16 * 4)) || (rc = L->peqp.reserve(n * 16 * 6 * 4)) ||
 	    (rc = L->peq_alt.reserve(peq_words * 16 * 4)) || (rc = L->peqp_alt.reserve(n * 16 * 6 * 4)) ||
 	    (rc = L->fb_list.reserve(n * 8 + 64)) || (rc = L->ranges_c[cls].reserve(n * 16 * 8 + 16)) || (rc = L->hdr_c[cls].reserve(n * 8 + 16))) return rc;
+	// (BEST on the device: its per-entry keys and the read-back word as well -- nothing is allocated inside the first batch)
+	if (h->n_order) { if ((rc = h->best_key.reserve((n + 1) * 8))) return rc; if (!h->nsel_pinned) HIPCHK(hipHostMalloc((void **)&h->nsel_pinned, 64, hipHostMallocDefault)); }
 	if ((rc = h->best.reserve((n + 1) * 4)) || (rc = h->out.reserve(h->out_cap * sizeof(BhipHit))) || (rc = h->shared_ctr.reserve(sizeof(SharedCtr))) ||
 	    (rc = h->sort_idx.reserve(h->out_cap * 4)) || (rc = h->sort_keys.reserve((n + 1) * 4)) || (rc = h->sort_keys2.reserve((n + 1) * 4)) ||
 	    (rc = h->out_sorted.reserve(h->out_cap * sizeof(BhipHit))) || (rc = h->out_sorted2.reserve(h->out_cap * sizeof(BhipHit)))) return rc;

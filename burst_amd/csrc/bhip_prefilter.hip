@@ -279,22 +279,67 @@ __global__ __launch_bounds__(64, CQ_MINWAVES) void k_prefilter_cq(
 	};
 	unsigned long long h_n, r_n;
 	fetch(blockIdx.x, h_n, r_n);
-	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
-		const bool live = quad * 4 + g < n_items;
-		const uint32_t li = sel ? (live ? sel[quad * 4 + g] : 0u) : quad * 4 + g;      // list position of this group's query
-		const uint2 hd = make_uint2((uint32_t)h_n, (uint32_t)(h_n >> 32));
+	// ---- Software pipeline over the quads (round 6).  Until then a quad was: set up, issue the record loads of its four queries, WAIT, two
+	// looks, survivor rounds, emit, clear -- a third of the kernel's time was that wait (phase timers with the memory pipeline drained at
+	// every boundary, gpurun_out/r06g_prof: 34 %).  The record registers are dead once the second look is over, so the NEXT quad is set up and
+	// its loads are issued right there (`prep`), and they are in flight during this quad's survivor rounds, emit and table clears.  What a quad
+	// needs after its second look (list position, threshold, budget, ...) is copied out of the carried state at the top of its iteration.
+	constexpr uint32_t NB = MODE == 0 ? 7u : 15u, KB = MODE == 0 ? 3u : 4u;      // list ends that matter / bits of a list number
+	uint32_t rc[4][R];                                                // records of the resident rows of the quad that is looked at next
+	bool n_live = false; uint32_t n_li = 0, n_hx = 0, n_hy = 0, n_eend = 0, n_krp[4] = {0u, 0u, 0u, 0u}; unsigned long long n_ab = 0;
+	auto row_rec_of = [&](uint32_t q, uint32_t T, const uint32_t (&eb)[NB], uint32_t r, uint32_t &kreg, unsigned long long ab_) -> uint32_t {
+		const uint32_t i = r * 64u + lane;
+		const uint32_t ic = i < T ? i : T - 1u;                       // beyond the stream: its last record once more (OR is idempotent; the second look tests i < T)
+		uint32_t kk = 0;
+		#pragma unroll
+		for (uint32_t j = 0; j < NB; ++j) kk += eb[j] <= ic ? 1u : 0u;          // lists that end at or before the position = its list
+		const uint32_t src = q * 16u + kk;
+		const uint32_t a_lo = (uint32_t)__shfl((int)(uint32_t)ab_, (int)src, 64), a_hi = (uint32_t)__shfl((int)(uint32_t)(ab_ >> 32), (int)src, 64);
+		kreg = kk;
+		return ((bhip_gptr_t)(uintptr_t)(((unsigned long long)a_hi << 32 | a_lo) + 4ull * ic))[0];
+	};
+	auto list_ends_of = [&](uint32_t q, uint32_t (&eb)[NB], uint32_t eend_) {           // ends of the query's lists but the last: wave-uniform
+		#pragma unroll
+		for (uint32_t j = 0; j < NB; ++j) eb[j] = (uint32_t)__builtin_amdgcn_readlane((int)eend_, (int)(q * 16u + j));
+	};
+	// the lists of quad `quad`'s queries (lane gl of group g = list gl of query g; eend = end of the list in its query's flattened stream;
+	// ab = biased address: the record at stream position i of the list is at ab + 4 i), the loads of the first R rows of ALL four queries
+	// (their gathers are in flight together), and the header / ranges of the quad after it
+	auto prep = [&](uint32_t quad) {
+		n_live = quad * 4 + g < n_items;
+		n_li = sel ? (n_live ? sel[quad * 4 + g] : 0u) : quad * 4 + g;      // list position of this group's query
+		n_hx = (uint32_t)h_n; n_hy = (uint32_t)(h_n >> 32);
 		const unsigned long long r_c = r_n;
 		fetch(quad + gridDim.x, h_n, r_n);                                // one quad ahead
+		const uint32_t rx = (uint32_t)r_c, ry = (uint32_t)(r_c >> 32);
+		const uint32_t n0 = (n_live && gl < W16) ? ry & 0xFFFFFFu : 0u;
+		const unsigned long long beg = (unsigned long long)rx | (unsigned long long)(ry >> 24) << 32;
+		n_eend = group_scan(n0);
+		n_ab = (unsigned long long)(uintptr_t)ent + 4ull * (beg - (unsigned long long)(n_eend - n0));
+		#pragma unroll
+		for (uint32_t q = 0; q < 4; ++q) {
+			const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)n_eend, (int)(q * 16u + 15u));
+			n_krp[q] = 0;
+			if (T == 0u) continue;                                        // (wave-uniform)
+			my_ent += T;
+			uint32_t eb[NB];
+			list_ends_of(q, eb, n_eend);
+			const uint32_t rows = (T + 63u) >> 6;
+			#pragma unroll
+			for (uint32_t r = 0; r < R; ++r) if (r < rows) { uint32_t kr; rc[q][r] = row_rec_of(q, T, eb, r, kr, n_ab); n_krp[q] |= kr << (KB * r); }
+		}
+	};
+	if (blockIdx.x < n_quads) prep(blockIdx.x);
+	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
+		const bool live = n_live;
+		const uint32_t li = n_li;
+		const uint2 hd = make_uint2(n_hx, n_hy);
 		const uint32_t need = hd.x & 0xFFFFu, len = hd.y & 0xFFFu;
 		const uint32_t budget = (hd.y >> 12) & 255u, dper = (hd.y >> 20) & 15u ? (hd.y >> 20) & 15u : 1u;
 		const uint32_t thr = need ? need : 1u;                            // (group-uniform)
-		// ---- the lists of the quad's queries: lane gl of group g = list gl of query g.  eend = end of the list in its query's flattened
-		// stream; ab = biased address: the record at stream position i of the list is at ab + 4 i
-		const uint32_t rx = (uint32_t)r_c, ry = (uint32_t)(r_c >> 32);
-		const uint32_t n0 = (live && gl < W16) ? ry & 0xFFFFFFu : 0u;
-		const unsigned long long beg = (unsigned long long)rx | (unsigned long long)(ry >> 24) << 32;
-		const uint32_t eend = group_scan(n0);
-		const unsigned long long ab = (unsigned long long)(uintptr_t)ent + 4ull * (beg - (unsigned long long)(eend - n0));
+		const uint32_t eend = n_eend;
+		const unsigned long long ab = n_ab;
+		const uint32_t krp[4] = {n_krp[0], n_krp[1], n_krp[2], n_krp[3]};
 		uint32_t pend[4] = {0u, 0u, 0u, 0u};                              // survivors waiting in the queries' rings (wave-uniform)
 		uint32_t nused = 0, ovf = 0;                                      // slots of this group's lane table in use / table overflow (replicated in the group)
 		// ---- survivor rounds: every group moves up to 16 survivors of its query into its exact lane table
@@ -332,38 +377,12 @@ __global__ __launch_bounds__(64, CQ_MINWAVES) void k_prefilter_cq(
 			pend[0] = pend[1] = pend[2] = pend[3] = 0;
 		};
 		PFM_T(6);
-		// ---- the record streams, 64 stream positions per row.  The loads of ALL four queries are issued first (their gathers are in flight
-		// together: a wave waits for memory once per quad, not once per query), then the first look over the four queries, then the second.
-		constexpr uint32_t NB = MODE == 0 ? 7u : 15u, KB = MODE == 0 ? 3u : 4u;      // list ends that matter / bits of a list number
-		uint32_t rc[4][R], krp[4];                                        // records of the resident rows, their list numbers (KB bits per row)
+		// ---- the record streams, 64 stream positions per row: the first R rows of the four queries are in `rc` (issued by prep one quad ago)
 		uint32_t Tq[4];
-		auto row_rec = [&](uint32_t q, uint32_t T, const uint32_t (&eb)[NB], uint32_t r, uint32_t &kreg) -> uint32_t {
-			const uint32_t i = r * 64u + lane;
-			const uint32_t ic = i < T ? i : T - 1u;                       // beyond the stream: its last record once more (OR is idempotent; the second look tests i < T)
-			uint32_t kk = 0;
-			#pragma unroll
-			for (uint32_t j = 0; j < NB; ++j) kk += eb[j] <= ic ? 1u : 0u;          // lists that end at or before the position = its list
-			const uint32_t src = q * 16u + kk;
-			const uint32_t a_lo = (uint32_t)__shfl((int)(uint32_t)ab, (int)src, 64), a_hi = (uint32_t)__shfl((int)(uint32_t)(ab >> 32), (int)src, 64);
-			kreg = kk;
-			return ((bhip_gptr_t)(uintptr_t)(((unsigned long long)a_hi << 32 | a_lo) + 4ull * ic))[0];
-		};
-		auto list_ends = [&](uint32_t q, uint32_t (&eb)[NB]) {           // ends of the query's lists but the last: wave-uniform
-			#pragma unroll
-			for (uint32_t j = 0; j < NB; ++j) eb[j] = (uint32_t)__builtin_amdgcn_readlane((int)eend, (int)(q * 16u + j));
-		};
 		#pragma unroll
-		for (uint32_t q = 0; q < 4; ++q) {
-			const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)eend, (int)(q * 16u + 15u));
-			Tq[q] = T; krp[q] = 0;
-			if (T == 0u) continue;                                        // (wave-uniform)
-			my_ent += T;
-			uint32_t eb[NB];
-			list_ends(q, eb);
-			const uint32_t rows = (T + 63u) >> 6;
-			#pragma unroll
-			for (uint32_t r = 0; r < R; ++r) if (r < rows) { uint32_t kr; rc[q][r] = row_rec(q, T, eb, r, kr); krp[q] |= kr << (KB * r); }
-		}
+		for (uint32_t q = 0; q < 4; ++q) Tq[q] = (uint32_t)__builtin_amdgcn_readlane((int)eend, (int)(q * 16u + 15u));
+		auto row_rec = [&](uint32_t q, uint32_t T, const uint32_t (&eb)[NB], uint32_t r, uint32_t &kreg) -> uint32_t { return row_rec_of(q, T, eb, r, kreg, ab); };
+		auto list_ends = [&](uint32_t q, uint32_t (&eb)[NB]) { list_ends_of(q, eb, eend); };
 		PFM_T(0);
 		auto count1 = [&](uint32_t q, uint32_t rec, uint32_t kreg) {     // first look: the record's list leaves its bit in the record's slot
 			atomicOr(&s_cnt[q][(rec & (NS - 1u)) >> SB], 1u << ((rec & ((1u << SB) - 1u)) * FB + kreg));
@@ -410,6 +429,8 @@ __global__ __launch_bounds__(64, CQ_MINWAVES) void k_prefilter_cq(
 			}
 		}
 		PFM_T(2);
+		if (quad + gridDim.x < n_quads) prep(quad + gridDim.x);      // the record registers are free: the next quad's gathers fly during the rounds, the emit and the clears below
+		PFM_T(0);
 		drain();
 		CF_WAVE_ORDER();
 		PFM_T(3);

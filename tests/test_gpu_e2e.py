@@ -445,6 +445,8 @@ def test_bench_multi_rank_path_with_one_process(tmp_path):
     # at the top level and in `config` too (what the driver's parsed view keeps), and gathered from the device-resident records
     assert e["rccl_ranks"] == 1 == e["config"]["rccl_ranks"] and e["rccl_gather_ms"] == e["rccl"]["rccl_gather_ms"] == e["config"]["rccl_gather_ms"]
     assert e["config"]["rccl_records_from"].startswith("device") and e["rccl"]["gather_path"] == 1      # (BhMultiRank.gatherPath: the staged gather really ran)
+    # ... and which exchange built the accelerator: the bench's ranks each build their own, no collective (the line says so)
+    assert e["config"]["accelerator_build"]["exchange"] is None and e["config"]["accelerator_build"]["ranks_in_exchange"] == 0
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("burst_hip.bench")]
 
 

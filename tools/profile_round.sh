@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; TAG=$1; shift
 O=$R/gpurun_out; mkdir -p $O
-B="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end --no-continuity --no-short-job --keep-files --no-prime $*"      # --no-prime: every dispatch of a batch kernel is a full-size batch; --keep-files: the five passes share the database
+B="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end --no-continuity --no-short-job --no-strains --keep-files --no-prime $*"      # --no-prime: every dispatch of a batch kernel is a full-size batch; --keep-files: the five passes share the database
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -- $B > $O/${TAG}_kt.log 2>&1
 grep '^{' $O/${TAG}_kt.log | tail -1 > $O/${TAG}_bench_under_rocprof.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_fetch -- $B > $O/${TAG}_fetch.log 2>&1

@@ -11,7 +11,7 @@
 R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out; mkdir -p $O; cd $R
 TAG=${TAG:-run}; WHAT=$1; shift
 W=${WORKDIR:-/dev/shm/burst_amd_bench}
-QUIET="--no-cpu-baseline --no-end-to-end --no-continuity --no-short-job"
+QUIET="--no-cpu-baseline --no-end-to-end --no-continuity --no-short-job --no-strains"
 sum() { python tools/bsum.py "$1" < "$2"; }
 case "$WHAT" in
 tests)
@@ -45,10 +45,10 @@ shape)
 	case "$1" in
 	configs1) A="--K 12 --n-base 3300 --n-variants 30 --db-scale 1 --mode CAPITALIST --id 0.97 --cpu-sample 300000" ;;
 	configs2) A="--K 12 --n-base 3300 --n-variants 30 --db-scale 1 --mode ALLPATHS --id 0.97 --read-len 292 --edits 0,2,4,8 --cpu-sample 60000" ;;
-	configs4) A="--db-scale 5 --read-len 320 --mode FORAGE --id 0.95 --fr --iupac 0.001 --edits 0,2,4,8,12 --reads 500000 --cpu-sample 600" ;;
+	configs4) A="--db-scale 5 --read-len 320 --mode FORAGE --id 0.95 --fr --iupac 0.001 --edits 0,2,4,8,12 --reads 500000 --cpu-sample ${CPU_SAMPLE:-20000}" ;;
 	*) echo "shape configs1|configs2|configs4"; exit 1 ;;
 	esac
-	timeout ${LIMIT:-2400} python bench.py --workdir $W.$1 --no-end-to-end --no-continuity --no-short-job $A > $O/${TAG}_$1.json 2> $O/${TAG}_$1.err
+	timeout ${LIMIT:-2400} python bench.py --workdir $W.$1 --no-end-to-end --no-continuity --no-short-job --no-strains $A ${SHAPE_EXTRA:-} > $O/${TAG}_$1.json 2> $O/${TAG}_$1.err
 	echo "$1 exit $?"; sum "$1" $O/${TAG}_$1.json; rm -rf $W.$1 ;;
 cli)
 	S=$1; shift
