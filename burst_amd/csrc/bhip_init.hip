@@ -106,13 +106,6 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 	HIPCHK(hipGetDeviceCount(&ndev));
 	if (device < 0 || device >= ndev) return fail(BHIP_E_DEVICE, "device %d not present (%d visible)", device, ndev);
 	HIPCHK(hipSetDevice(device));
-	// BHIP_SYNC=spin|yield|block: how the host thread waits in the library's synchronisation points (hipSetDeviceFlags; a batch scheduler
-	// has one thread per device that does nothing else between two batches, and the wake-up after a batch's chain is part of the ~0.3 ms
-	// between two batches).  Unset: the runtime's default.  A device whose flags were fixed earlier in the process keeps them.
-	if (const char *sy = getenv("BHIP_SYNC")) {
-		const unsigned fl = !strcmp(sy, "spin") ? hipDeviceScheduleSpin : !strcmp(sy, "yield") ? hipDeviceScheduleYield : !strcmp(sy, "block") ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
-		if (hipSetDeviceFlags(fl) != hipSuccess) (void)hipGetLastError();
-	}
 	Handle *h = new Handle();
 	memset(h->ev, 0, sizeof h->ev);
 	memset(&h->stats, 0, sizeof h->stats);

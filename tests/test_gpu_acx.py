@@ -15,24 +15,36 @@ pytestmark = pytest.mark.gpu
 CLI = os.path.join(gl.ROOT, "burst_amd", "burst_hip")
 
 
-def _compare_built_with_loaded(db_path_or_db, K, z, from_fasta=None):
+_FILE_SIDE = {}          # (path, K, z) -> the tables of the file path, kept while one test builds the same database several ways
+
+
+def _compare_built_with_loaded(db_path_or_db, K, z, from_fasta=None, files=True):
     from burst_amd import host
     L = host.lib()
     import ctypes as C
-    # tables of the file path: host builder -> upload -> export
+    # tables of the file path: host builder -> upload -> export (once per database / K / z: at K = 15 the table of list lengths alone is
+    # 4.3 GB, and a test that builds the same database four ways was rebuilding and re-exporting it four times)
+    key = (from_fasta or db_path_or_db, K, z)
     if from_fasta:
-        a = host.Db.from_fasta(from_fasta, 120, 0.95, shear_len=500, K=K, z=z)
         b = host.Db.from_fasta(from_fasta, 120, 0.95, shear_len=500)
     else:
-        a = host.Db.read(db_path_or_db)
-        host._chk(L.bh_acx_build(C.byref(a.c), K, z))
         b = host.Db.read(db_path_or_db)
-    dev_a = a.open_device(0, z)
-    lens_a, clumps_a, masks_a, bad_a = dev_a.acx_export(K)
-    dev_a.close()
-    # what went up is what the host builder made
-    assert np.array_equal(lens_a, host._view(a.c.acxLens, 1 << (2 * K), np.uint32))
-    assert np.array_equal(bad_a, host._view(a.c.badList, a.c.badSz, np.uint32))
+    if key not in _FILE_SIDE:
+        if from_fasta:
+            a = host.Db.from_fasta(from_fasta, 120, 0.95, shear_len=500, K=K, z=z)
+        else:
+            a = host.Db.read(db_path_or_db)
+            host._chk(L.bh_acx_build(C.byref(a.c), K, z))
+        dev_a = a.open_device(0, z)
+        lens_a, clumps_a, masks_a, bad_a = dev_a.acx_export(K)
+        dev_a.close()
+        # what went up is what the host builder made
+        assert np.array_equal(lens_a, host._view(a.c.acxLens, 1 << (2 * K), np.uint32))
+        assert np.array_equal(bad_a, host._view(a.c.badList, a.c.badSz, np.uint32))
+        _FILE_SIDE.clear()
+        _FILE_SIDE[key] = (lens_a, clumps_a, masks_a, bad_a, int(a.c.acxFmt), host._view(a.c.acxLists, a.c.acxListBytes, np.uint8).copy())
+        a.close()
+    lens_a, clumps_a, masks_a, bad_a, fmt_a, lists_a = _FILE_SIDE[key]
     dev_b = b.open_device(0, z, build_K=K)
     lens_b, clumps_b, masks_b, bad_b = dev_b.acx_export(K)
     assert np.array_equal(lens_a, lens_b)
@@ -44,18 +56,20 @@ def _compare_built_with_loaded(db_path_or_db, K, z, from_fasta=None):
     assert np.all(masks_b != 0)
     # the .acx the host writes from the device's tables is the host builder's, byte for byte
     b.acx_from_device(dev_b, K, z)
-    assert b.c.acxFmt == a.c.acxFmt and b.c.acxListBytes == a.c.acxListBytes
-    assert np.array_equal(host._view(b.c.acxLists, b.c.acxListBytes, np.uint8), host._view(a.c.acxLists, a.c.acxListBytes, np.uint8))
+    assert b.c.acxFmt == fmt_a and b.c.acxListBytes == len(lists_a)
+    assert np.array_equal(host._view(b.c.acxLists, b.c.acxListBytes, np.uint8), lists_a)
     # ... and so is the file streamed from the device run by run (bh_acx_write_from_device: what bench.py writes for the reference)
-    import tempfile
-    with tempfile.TemporaryDirectory() as td:
-        f1, f2 = os.path.join(td, "held.acx"), os.path.join(td, "streamed.acx")
-        host._chk(L.bh_acx_write(C.byref(b.c), f1.encode()))
-        b.acx_write_from_device(dev_b, K, f2, z)
-        assert open(f1, "rb").read() == open(f2, "rb").read()
+    # (files=False: a repeated build of the same database through another builder path -- the files, 4.3 GB each at K = 15, were compared by the first)
+    if files:
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            f1, f2 = os.path.join(td, "held.acx"), os.path.join(td, "streamed.acx")
+            host._chk(L.bh_acx_write(C.byref(b.c), f1.encode()))
+            b.acx_write_from_device(dev_b, K, f2, z)
+            assert open(f1, "rb").read() == open(f2, "rb").read()
     dev_b.close()
     n = len(clumps_a)
-    a.close(); b.close()
+    b.close()
     return n, len(bad_a), int(np.count_nonzero(masks_a != masks_b))
 
 
@@ -65,24 +79,25 @@ def test_device_built_accelerator_equals_file(db, K, z, monkeypatch):
     n, nbad, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z)      # (the default builder: slices of the word space)
     assert n > 10000
     monkeypatch.setenv("BHIP_ACX_BUILD", "clumps")                                         # the clump-sliced builder, everything at once
-    n1, _, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z)
+    n1, _, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z, files=False)
     assert n1 == n
     if K == 12:      # both in small slices (words: several scans; clumps: two passes -- list lengths, then records at running list positions)
         for how in ("clumps", "words"):
             monkeypatch.setenv("BHIP_ACX_BUILD", how)
             monkeypatch.setenv("BHIP_MASK_SLICE", "40000")
-            n2, _, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z)
+            n2, _, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z, files=False)
             assert n2 == n
             monkeypatch.delenv("BHIP_MASK_SLICE")
     monkeypatch.delenv("BHIP_ACX_BUILD")
     # ... and through the path of the large databases (BHIP_TEST_TWO_PLANS: a counting pass over the sorted tuples, the record area one
     # address range whose memory is mapped by a thread beside that pass and cut back to the real size, a second plan for the records)
     monkeypatch.setenv("BHIP_TEST_TWO_PLANS", "1")
-    n3, _, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z)
+    n3, _, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z, files=False)
     assert n3 == n
     monkeypatch.setenv("BHIP_ACX_NO_PREMAP", "1")          # (the same with the record area allocated in one piece after the counting pass)
-    n4, _, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z)
+    n4, _, _ = _compare_built_with_loaded(os.path.join(gl.G, db + ".edx"), K, z, files=False)
     assert n4 == n
+    _FILE_SIDE.clear()
 
 
 def test_device_built_accelerator_expansion_and_badlist(tmp_path, monkeypatch):
