@@ -181,6 +181,13 @@ TRAFFIC_CALIBRATION = {
 }
 
 
+def shape_name(args):
+    """which BASELINE.json configuration the run's shape is (read length, mode, identity, strands): the line's workload says so"""
+    key = (args.read_len, args.mode, float(args.id), bool(args.fr))
+    return {(100, "BEST", 0.98, False): "BASELINE configs[3] shape", (100, "CAPITALIST", 0.97, False): "BASELINE configs[1] shape",
+            (292, "ALLPATHS", 0.97, False): "BASELINE configs[2] shape", (320, "FORAGE", 0.95, True): "BASELINE configs[4] shape"}.get(key, "a shape of its own")
+
+
 def db_paths(workdir, args):
     args.db_qlen = args.read_len + max(10, args.read_len // 10)
     tag = "b%d_v%d_l%d_q%d_i%s_k%d%s" % (args.n_base, args.n_variants, args.ref_len, args.db_qlen, args.id, args.K, "" if getattr(args, "db_profile", "pairs") == "pairs" else "_" + args.db_profile)
@@ -1025,9 +1032,10 @@ def main():
             "value": total_reads / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u32 bit-vectors (u8 edit distances)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[3] shape on %d GPU(s): %d synthetic %d-bp reads per step (0-2 edits), -m %s -i %s, vs %d references x %d bp "
+            "config": {"workload": "%s on %d GPU(s): %d synthetic %d-bp reads per step (%s edits%s%s), -m %s -i %s, vs %d references x %d bp "
                                    "(%.2f Gbp; %s%d clumps; .edx %.2f GB + DB%d .acx %.2f GB); every step stages its batch afresh through the product's batch scheduler"
-                                   % (world, args.reads, args.read_len, args.mode, args.id, args.n_base * args.n_variants, args.ref_len,
+                                   % (shape_name(args), world, args.reads, args.read_len, args.edits.replace(",", "/"), ", both strands" if args.fr else "", (", %g of the bases IUPAC codes" % args.iupac) if args.iupac else "",
+                                      args.mode, args.id, args.n_base * args.n_variants, args.ref_len,
                                       args.n_base * args.n_variants * args.ref_len / 1e9,
                                       "" if args.db_profile == "pairs" else "--db-profile strains: 70 % pairs at 5 %, 30 % families of 60 / 200 / 500 strains at 1 / 0.5 / 0.1 %; ",
                                       db.c.numRclumps, edx_bytes / 1e9, args.K, acx_bytes / 1e9),
