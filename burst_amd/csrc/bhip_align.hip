@@ -109,19 +109,24 @@ __global__ void k_set_rank_ptrs(SharedCtr *sc, uint32_t *cnt, uint32_t *rank) { 
 __device__ __forceinline__ unsigned long long best_key_of(const BhipHit &h, const uint32_t *__restrict__ order) {
 	return (unsigned long long)(~__float_as_uint(h.score)) << 32 | order[h.refIx];
 }
-__global__ void k_best_key(const BhipHit *__restrict__ hits, uint32_t n, const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ order, unsigned long long *__restrict__ key) {
+// (an entry with ONE record -- the rule on a low-redundancy database -- has nothing to choose: no table look-up, no atomic, for it)
+__global__ void k_best_key(const BhipHit *__restrict__ hits, uint32_t n, const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ order, const uint32_t *__restrict__ cnt,
+                           unsigned long long *__restrict__ key) {
 	if (n_dev) n = *n_dev < n ? *n_dev : n;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const BhipHit h = hits[i]; atomicMin(&key[h.q], best_key_of(h, order)); }
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const BhipHit h = hits[i];
+		if (cnt[h.q] > 1u) atomicMin(&key[h.q], best_key_of(h, order));
+	}
 }
-__global__ void k_best_flag(uint32_t *__restrict__ cnt, uint32_t n_q) {      // records per entry -> 1 where the entry has any
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_q; i += gridDim.x * blockDim.x) cnt[i] = cnt[i] ? 1u : 0u;
+__global__ void k_best_flag(const uint32_t *__restrict__ cnt, uint32_t n_q, uint32_t *__restrict__ flag) {      // records per entry -> 1 where the entry has any (flag[n_q] = 0: the scan's total)
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n_q; i += gridDim.x * blockDim.x) flag[i] = i < n_q && cnt[i] ? 1u : 0u;
 }
-__global__ void k_best_emit(const BhipHit *__restrict__ hits, uint32_t n, const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ order, const unsigned long long *__restrict__ key,
-                            const uint32_t *__restrict__ off, BhipHit *__restrict__ out, const uint32_t *__restrict__ qmap) {
+__global__ void k_best_emit(const BhipHit *__restrict__ hits, uint32_t n, const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ order, const uint32_t *__restrict__ cnt,
+                            const unsigned long long *__restrict__ key, const uint32_t *__restrict__ off, BhipHit *__restrict__ out, const uint32_t *__restrict__ qmap) {
 	if (n_dev) n = *n_dev < n ? *n_dev : n;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		BhipHit h = hits[i];
-		if (best_key_of(h, order) != key[h.q]) continue;
+		if (cnt[h.q] > 1u && best_key_of(h, order) != key[h.q]) continue;
 		const uint32_t dst = off[h.q];
 		if (qmap) h.q = qmap[h.q];
 		out[dst] = h;
@@ -547,7 +552,7 @@ extern "C" int bhip_reserve_symbols(void *handle, uint32_t n_entries, uint32_t m
 	    (rc = L->peq_alt.reserve(peq_words * 16 * 4)) || (rc = L->peqp_alt.reserve(n * 16 * 6 * 4)) ||
 	    (rc = L->fb_list.reserve(n * 8 + 64)) || (rc = L->ranges_c[cls].reserve(n * 16 * 8 + 16)) || (rc = L->hdr_c[cls].reserve(n * 8 + 16))) return rc;
 	// (BEST on the device: its per-entry keys and the read-back word as well -- nothing is allocated inside the first batch)
-	if (h->n_order) { if ((rc = h->best_key.reserve((n + 1) * 8))) return rc; if (!h->nsel_pinned) HIPCHK(hipHostMalloc((void **)&h->nsel_pinned, 64, hipHostMallocDefault)); }
+	if (h->n_order) { if ((rc = h->best_key.reserve((n + 1) * 8)) || (rc = h->sort_idx.reserve(std::max<size_t>((size_t)h->out_cap, n + 1) * 4))) return rc; if (!h->nsel_pinned) HIPCHK(hipHostMalloc((void **)&h->nsel_pinned, 64, hipHostMallocDefault)); }
 	if ((rc = h->best.reserve((n + 1) * 4)) || (rc = h->out.reserve(h->out_cap * sizeof(BhipHit))) || (rc = h->shared_ctr.reserve(sizeof(SharedCtr))) ||
 	    (rc = h->sort_idx.reserve(h->out_cap * 4)) || (rc = h->sort_keys.reserve((n + 1) * 4)) || (rc = h->sort_keys2.reserve((n + 1) * 4)) ||
 	    (rc = h->out_sorted.reserve(h->out_cap * sizeof(BhipHit))) || (rc = h->out_sorted2.reserve(h->out_cap * sizeof(BhipHit)))) return rc;
@@ -849,7 +854,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits_arg, BhipHit *hits, 
 	SharedCtr hsc;
 	uint32_t n_deliver = 0;                // records the caller gets: all of them, or one per entry (sel_best)
 	bool sorted_ahead = false; int o_ahead = 0;
-	if (sel_best) { int rcs; if ((rcs = h->best_key.reserve((size_t)(n_q + 1) * 8))) return rcs;
+	if (sel_best) { int rcs; if ((rcs = h->best_key.reserve((size_t)(n_q + 1) * 8)) || (rcs = h->sort_idx.reserve(std::max<size_t>((size_t)h->out_cap, (size_t)n_q + 1) * 4))) return rcs;      // (the rank array doubles as the per-entry flags)
 		if (!h->nsel_pinned) HIPCHK(hipHostMalloc((void **)&h->nsel_pinned, 64, hipHostMallocDefault)); }
 	// the grouping of the records on `st` into `sorted`: the counting sort by entry (scatter + a rank sort inside every group), or -- sel_best --
 	// the choice of one record per entry (two streaming passes).  cnt = records per entry (from the re-scoring kernels, or k_hit_count)
@@ -857,10 +862,11 @@ extern "C" int bhip_align_staged(void *handle, int all_hits_arg, BhipHit *hits, 
 		const uint32_t g = (uint32_t)h->n_cu * 8;
 		const uint32_t *qmap = h->cur->has_qmap ? h->cur->qmap.as<uint32_t>() : (const uint32_t *)nullptr;
 		if (sel_best) {
-			hipLaunchKernelGGL(k_best_key, dim3(g), dim3(256), 0, st, h->out.as<BhipHit>(), n_host, n_dev, h->ref_order.as<uint32_t>(), h->best_key.as<unsigned long long>());
-			hipLaunchKernelGGL(k_best_flag, dim3(std::min<uint32_t>((n_q + 255) / 256, g)), dim3(256), 0, st, cnt, n_q);
-			HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->sort_tmp.p, tmp_bytes, cnt, off, (int)(n_q + 1), st));
-			hipLaunchKernelGGL(k_best_emit, dim3(g), dim3(256), 0, st, h->out.as<BhipHit>(), n_host, n_dev, h->ref_order.as<uint32_t>(), h->best_key.as<unsigned long long>(), off, sorted.as<BhipHit>(), qmap);
+			// (flags into the rank array: the ranks the re-scoring kernels took are not needed when nothing is sorted)
+			hipLaunchKernelGGL(k_best_key, dim3(g), dim3(256), 0, st, h->out.as<BhipHit>(), n_host, n_dev, h->ref_order.as<uint32_t>(), cnt, h->best_key.as<unsigned long long>());
+			hipLaunchKernelGGL(k_best_flag, dim3(std::min<uint32_t>((n_q + 256) / 256, g)), dim3(256), 0, st, cnt, n_q, rank);
+			HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->sort_tmp.p, tmp_bytes, rank, off, (int)(n_q + 1), st));
+			hipLaunchKernelGGL(k_best_emit, dim3(g), dim3(256), 0, st, h->out.as<BhipHit>(), n_host, n_dev, h->ref_order.as<uint32_t>(), cnt, h->best_key.as<unsigned long long>(), off, sorted.as<BhipHit>(), qmap);
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipMemcpyAsync(h->nsel_pinned, off + n_q, 4, hipMemcpyDeviceToHost, st));      // (the scan runs over n_q + 1 counters, the last one zero: its offset is the total)
 			return 0;
@@ -1028,7 +1034,7 @@ extern "C" int bhip_align_staged(void *handle, int all_hits_arg, BhipHit *hits, 
 		double tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0;
 		if (hsc.n_out) {
 			const uint32_t n = hsc.n_out;
-			if ((rc = h->sort_idx.reserve((size_t)n * 4)) || (rc = h->sort_keys.reserve((size_t)(n_q + 1) * 4)) || (rc = h->sort_keys2.reserve((size_t)(n_q + 1) * 4)) ||
+			if ((rc = h->sort_idx.reserve(std::max<size_t>((size_t)n, sel_best ? (size_t)n_q + 1 : 0) * 4)) || (rc = h->sort_keys.reserve((size_t)(n_q + 1) * 4)) || (rc = h->sort_keys2.reserve((size_t)(n_q + 1) * 4)) ||
 			    0) return rc;
 			const bool async = h->opt_async_d2h && hits;
 			const int o = async ? (h->out_idx ^= 1) : 0;

@@ -687,8 +687,20 @@ __global__ __launch_bounds__(64) void k_myers_window_band(
 	uint32_t n = *n_wins_dev;
 	if (n > win_cap) n = win_cap;
 	unsigned long long my_cols = 0;
+#ifndef WB_PREFETCH
+#define WB_PREFETCH 0          // 1: the next window's record is loaded while the current one is swept (tools/build_variant.sh ... -DWB_PREFETCH=1; measured, §3)
+#endif
+#if WB_PREFETCH
+	BhipWin w_next;
+	if (blockIdx.x * 64u + tid < n) w_next = wins[blockIdx.x * 64u + tid];
+#endif
 	for (uint32_t i = blockIdx.x * 64u + tid; i < n; i += gridDim.x * 64u) {
+#if WB_PREFETCH
+		const BhipWin w = w_next;
+		if (i + gridDim.x * 64u < n) w_next = wins[i + gridDim.x * 64u];
+#else
 		const BhipWin w = wins[i];
+#endif
 		if (w.g_first >> 30 != (uint32_t)(BW - 2)) continue;
 		const uint32_t m = w.mE & 0xFFFFu, E = w.mE >> 16, g_first = w.g_first & BHIP_WIN_GMASK;
 		const uint32_t P = m < 32u * (uint32_t)NWP ? m : 32u * (uint32_t)NWP;

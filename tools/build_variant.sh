@@ -8,6 +8,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 N=$1; shift
 T=$(mktemp -d)
 mkdir -p $T/burst_amd && cp -r $R/burst_amd/csrc $T/burst_amd/ && cp -r $R/include $T/
-(cd $T/burst_amd/csrc && rm -f bhip_prefilter.o bhip_prefilter_alt.o bhip_prefilter_legacy.o && make -s -j3 all EXTRA_HIPFLAGS="$*") || exit 1
+KO=""; case "$*" in *WB_*) KO=bhip_kernels.o ;; esac      # (switches of the sweep kernels: that translation unit as well)
+(cd $T/burst_amd/csrc && rm -f bhip_prefilter.o bhip_prefilter_alt.o bhip_prefilter_legacy.o $KO && make -s -j3 all EXTRA_HIPFLAGS="$*") || exit 1
 mkdir -p $R/burst_amd/$N && cp $T/burst_amd/libburst_hip.so $T/burst_amd/libburst_host.so $R/burst_amd/$N/
 rm -rf $T

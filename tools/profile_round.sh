@@ -40,8 +40,8 @@ for k in sorted(fa, key=lambda k: -fa[k].get('FETCH_SIZE', 0)):
     if k.replace('void ', '').split('<')[0] in traffic: continue      # template variants share a name: sorted by bytes, the heaviest is first
     traffic[k.replace('void ', '').split('<')[0]] = {"kernel": k, "dispatches": n, "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB_raw": write_kb, "hbm_bytes_per_launch": hbm,
         "hbm_bytes_per_launch_gather_calibrated": (fetch_kb * 1024 + write_kb * 1024) / n,
-        "gather_note": "for kernels whose reads are random 64-byte sectors (k_seed_ranges, k_prefilter_cf, k_rescore_*) FETCH_SIZE already counts the full bytes (profiles/r02k_fetch_calibration.txt: ratio 1.00 on a kernel with known traffic): fetch + write without the factor 2",
-        "correction": "gfx950: FETCH_SIZE reports half the bytes of a coalesced read stream (MI355X_MICROARCH.md, HBM section): fetch bytes = 2 * FETCH_SIZE KB * 1024; WRITE_SIZE as reported"}
+        "gather_note": "FETCH_SIZE x 1024 = 64 B x the distinct 128-byte lines a dispatch requests, whatever the pattern (profiles/r06e_fetch_calibration_runs.txt, tools/calibrate_fetch.sh): hbm_bytes_per_launch = every requested line moved whole (upper bound), this figure = one 64-byte half per requested line (lower bound)",
+        "correction": "gfx950: FETCH_SIZE tallies a 128-byte line request as 64 B (MI355X_MICROARCH.md, HBM section; calibrated on runs of 1 / 16 / 40 / 164 dwords in round 6); WRITE_SIZE as reported"}
 lines.append('')
 for k in sorted(sa, key=lambda k: -sa[k].get('SQ_WAVE_CYCLES', 0)):
     v = dict(sa[k]); v.update(s2.get(k, {})); wc_ = max(1.0, v.get('SQ_WAVE_CYCLES', 1.0))
