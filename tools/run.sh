@@ -5,6 +5,7 @@
 #   bench [bench.py args]        the driver's command line (python bench.py --gpus 1 --steps 20 --warmup 5) with the job's memory sampled beside it
 #   ab <db-scale> <spec> ...     bench.py --ab <spec> ... on one resident database (spec = name=value[,name=value]; library options of bhip_set_option)
 #   variant <libdir> [args]      bench.py with the libraries of burst_amd/<libdir> (tools/build_variant.sh: prof = phase timers, ...)
+#   benchprof [bench.py args]    the driver's command line under rocprofv3 --kernel-trace --stats: bench line + kernel statistics of one process
 #   profile [bench.py args]      tools/profile_round.sh: rocprofv3 --kernel-trace --stats + the PMC passes -> kernel_stats / pmc / pmc_summary
 #   shape configs1|configs2|configs4   the other BASELINE shapes on their own databases, one bench line each with the reference beside it
 #   cli <db-scale> [burst_hip args]    the burst_hip command line on the bench's database and read pool, BHIP_DEBUG phase lines kept
@@ -31,6 +32,38 @@ for k in ("cpu_baseline", "cpu_baseline_skipped", "parity_vs_reference", "gpu_ov
 print("at metric size:", d["config"]["extrapolation"]["this_run_is_at_metric_size"], "| roofline", d["roofline"]["kernel"], "%.4f" % d["roofline"]["frac"])
 PY
 	echo "peak memory: $(sort -k2 -n $O/${TAG}_mem.txt | tail -1)" ;;
+benchprof)
+	# the driver's command line UNDER rocprofv3 --kernel-trace --stats: the bench line (HIP events) and the kernel statistics of ONE process,
+	# so that roofline.frac can be recomputed from the profiler's average of the same launches (round 5's verdict: 9 % between two runs)
+	cd /tmp && export TMPDIR=/tmp
+	T0=$SECONDS
+	timeout ${LIMIT:-2400} rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-end-to-end --no-continuity --no-strains --no-short-job "$@" > $O/${TAG}_benchprof.log 2> $O/${TAG}_benchprof.err
+	echo "benchprof exit $? after $((SECONDS - T0)) s"
+	grep '^{' $O/${TAG}_benchprof.log | tail -1 > $O/${TAG}_bench_under_rocprof_driver_line.json
+	python - "$O" "$TAG" <<'PY'
+import csv, glob, json, sys, os
+O, TAG = sys.argv[1:3]
+best = None
+for f in glob.glob('%s/%s_kt/**/*kernel_stats.csv' % (O, TAG), recursive=True):      # (child processes -- the reference is no HIP program -- leave none; the bench's own is the one with the prefilter kernel)
+    rows = list(csv.DictReader(open(f)))
+    if any('k_prefilter_cq' in r['Name'] for r in rows) and (best is None or len(rows) > len(best)): best = rows
+d = json.loads(open('%s/%s_bench_under_rocprof_driver_line.json' % (O, TAG)).read())
+out = ['command: rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-end-to-end --no-continuity --no-strains --no-short-job   (same process as %s_bench_under_rocprof_driver_line.json)' % TAG,
+       '%-50s %7s %12s %12s' % ('kernel', 'calls', 'avg_us', 'total_ms')]
+for r in (best or [])[:60]:
+    n = r['Name'].replace('HIP_vector_type<unsigned int, 2u>', 'uint2').split('(')[0][:48]
+    if n.startswith(('void rocprim', 'k_acx', '__amd_rocclr')): continue
+    out.append('%-50s %7s %12.1f %12.3f' % (n, r['Calls'], float(r['AverageNs']) / 1e3, float(r['TotalDurationNs']) / 1e6))
+ro = d['roofline']
+avg = next((float(r['AverageNs']) for r in (best or []) if ro['kernel'].split('<')[0] in r['Name'] and ('<0, 0>' in r['Name'] or '<' not in ro['kernel'])), None)
+out.append('')
+out.append('bench line of this process: value %.1f M reads/s, dominant kernel %s: %.1f us per launch by HIP events in the pipeline, frac %.4f' % (d['value'] / 1e6, ro['kernel'], ro['ms_per_launch'] * 1e3, ro['frac']))
+if avg:
+    out.append('rocprofv3 average of the same kernel in the same process (all launches, the warm-up and the reference leg\'s included): %.1f us -> frac %.4f' % (avg / 1e3, ro['algorithmic_bytes_per_launch'] / (avg * 1e-9) / 1e9 / 8000.0))
+open('%s/%s_kernel_stats_driver_line.txt' % (O, TAG), 'w').write('\n'.join(out) + '\n')
+print('\n'.join(out[-3:]))
+PY
+	rm -rf $O/${TAG}_kt ;;
 ab)
 	S=$1; shift; AB=""; for x in "$@"; do AB="$AB --ab $x"; done
 	BHIP_DEBUG=1 timeout ${LIMIT:-1500} python bench.py --workdir $W --db-scale $S --keep-files $QUIET $AB > $O/${TAG}_ab.json 2> $O/${TAG}_ab.err
