@@ -509,6 +509,10 @@ def end_to_end(edx, reads_fa, args, device):
         m = re.search(r"Alignment time: ([\d.]+) seconds", r.stdout)
         if r.returncode != 0 or not m:
             failed.append({"returncode": r.returncode, "after_runs": it, "output_tail": r.stdout[-1500:]})
+            try:
+                open(out + ".failed%d.log" % len(failed), "w").write(r.stdout)
+            except OSError:
+                pass
             if len(failed) > 1:
                 return {"error": failed[-1]["output_tail"][-400:], "failed_runs": failed}
             time.sleep(5.0)
@@ -1198,6 +1202,13 @@ def main():
             _own.close(); _own = None
             dev.close()
             db.close()
+            try:      # (what the processes that follow find on the device: this one should have given everything back)
+                torch.cuda.synchronize()
+                f_, t_ = torch.cuda.mem_get_info(local_rank)
+                res["device_memory_after_release"] = {"free_GB": f_ / 1e9, "total_GB": t_ / 1e9}
+                log("[bench] device memory after this process let go of its database: %.1f GB free of %.1f" % (f_ / 1e9, t_ / 1e9))
+            except Exception:
+                pass
         if world == 1 and not args.no_end_to_end:
             try:
                 res["end_to_end"] = end_to_end(edx, reads_fa, args, local_rank)

@@ -751,6 +751,7 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	const size_t va_plan = (size_t)want_va > 2 * DBuf::kChunk + ((size_t)total * BHIP_REC_BYTES + 16) ? (size_t)want_va - 2 * DBuf::kChunk : (size_t)total * BHIP_REC_BYTES + 16;
 	if (h->acx_rec.reserve_growable(va_plan, h->device)) return 1;
 	const size_t va_size = h->acx_rec.va_size;
+	if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] word-sliced build: %.2f GB free at its start, %.2f GB set aside for the rest, range of %.2f GB for %.2f GB of records at most\n", free_b / 1e9, other / 1e9, va_size / 1e9, (double)total * BHIP_REC_BYTES / 1e9);
 	auto plan = [&](uint64_t target) -> uint32_t {      // (BHIP_MASK_SLICE: slices of a given size)
 		cuts.assign(1, own0); slice_items.clear(); cap_items = 0;
 		uint64_t before = 0;
@@ -948,6 +949,7 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	if (dbg) fprintf(stderr, "[bhip] accelerator built on the device by word ranges%s: K=%d, %llu entries from %llu word tuples, %u slice(s) of at most %llu tuples here (%llu records), %zu clump(s) on the BadList, %.2f B per entry; "
 		"%.2f s (%.2f s histogram, %.2f s counts, %.2f s sort + fold, %.2f s until the own lists stood, %.2f s offset lines)\n", coop ? " (cooperative)" : "", K, (unsigned long long)tot, (unsigned long long)total, n_slices,
 		(unsigned long long)cap_items, (unsigned long long)rec_n, badlist.size(), tot ? (double)(h->acx_rec.cap + n_lines * 64) / (double)tot : 0.0, since(), t_hist, t_count - t_hist, t_sort, t_own, t_lines);
+	if (dbg) { size_t f_ = 0, t_ = 0; if (hipMemGetInfo(&f_, &t_) == hipSuccess) fprintf(stderr, "[bhip] after the build: %.2f GB of the device's %.2f free (record area %.2f GB mapped of a %.2f GB range)\n", f_ / 1e9, t_ / 1e9, h->acx_rec.cap / 1e9, h->acx_rec.va_size / 1e9); }
 	if (dbg && coop) fprintf(stderr, "[bhip] rank %d of %d: words [%llu, %llu), records [%llu, %llu)\n", part, n_parts, (unsigned long long)rb[part] << shift, (unsigned long long)rb[part + 1] << shift,
 		eoff[part], eoff[part + 1]);
 	return 0;

@@ -527,6 +527,7 @@ extern "C" int bhip_reserve_symbols(void *handle, uint32_t n_entries, uint32_t m
 	if (!max_len || max_len > BHIP_MAX_QLEN) max_len = BHIP_MAX_QLEN;
 	HIPCHK(hipSetDevice(h->device));
 	int rc;
+	if (getenv("BHIP_DEBUG")) { size_t f_ = 0, t_ = 0; if (hipMemGetInfo(&f_, &t_) == hipSuccess) fprintf(stderr, "[bhip] reserve for %u entries of up to %u symbols: %.2f GB of the device's %.2f free\n", n_entries, max_len, f_ / 1e9, t_ / 1e9); }
 	const size_t n = n_entries, nb = total_symbols ? (size_t)std::min<uint64_t>(total_symbols + 64, (uint64_t)n * max_len) : n * max_len, qw = (max_len + 7) / 8;
 	// profile words: an entry of len symbols has a vector of at most 2 x (len / 32 + 1) words (class rounding), 16 rows of them
 	const size_t cw = (size_t)class_words(class_of_len(max_len), max_len);

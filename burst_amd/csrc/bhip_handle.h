@@ -106,11 +106,36 @@ struct DBuf {
 	std::vector<hipMemGenericAllocationHandle_t> chunks;      // one per chunk of the range, nullptr = not mapped
 	size_t n_mapped = 0;
 	static constexpr size_t kChunk = 1ull << 30;
+	// Memory that has just been given back -- by this process (the accelerator build returns the 39 GB its sort worked in; the upload buffer
+	// of the references) or by the process that held the device before -- is not allocatable at once: hipMemGetInfo sees it come back over
+	// some hundred milliseconds (round 6: `burst_hip` at the metric's size, 255 GB resident, found 16 GB free right behind its build where
+	// 55 GB are free a moment later, and an 8 GB reservation of batch buffers failed by 100 MB).  An allocation that fails for memory is
+	// therefore tried again for a few seconds while the free memory is still growing.
+	static hipError_t malloc_patiently(void **q, size_t want) {
+		hipError_t e = hipMalloc(q, want);
+		if (e != hipErrorOutOfMemory) return e;
+		(void)hipGetLastError();
+		size_t last_free = 0, total = 0;
+		(void)hipMemGetInfo(&last_free, &total);
+		int still = 0;
+		for (int tries = 0; tries < 100 && still < 10; ++tries) {      // at most ~5 s; gives up half a second after the free memory stopped growing
+			(void)hipDeviceSynchronize();
+			std::this_thread::sleep_for(std::chrono::milliseconds(50));
+			e = hipMalloc(q, want);
+			if (e != hipErrorOutOfMemory) return e;
+			(void)hipGetLastError();
+			size_t f = 0;
+			(void)hipMemGetInfo(&f, &total);
+			still = f > last_free + (8u << 20) ? 0 : still + 1;
+			last_free = f > last_free ? f : last_free;
+		}
+		return e;
+	}
 	int reserve(size_t bytes) {
 		if (bytes <= cap) return 0;
 		release();
 		size_t want = bytes + bytes / 4 + 256;
-		hipError_t e = hipMalloc(&p, want);
+		hipError_t e = malloc_patiently(&p, want);
 		if (e != hipSuccess) { p = nullptr; return fail(BHIP_E_DEVICE, "hipMalloc(%zu): %s", want, hipGetErrorString(e)); }
 		cap = want; return 0;
 	}
@@ -119,7 +144,7 @@ struct DBuf {
 	int reserve_exact(size_t bytes) {
 		if (bytes <= cap) return 0;
 		release();
-		hipError_t e = hipMalloc(&p, bytes);
+		hipError_t e = malloc_patiently(&p, bytes);
 		if (e != hipSuccess) { p = nullptr; return fail(BHIP_E_DEVICE, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
 		cap = bytes; return 0;
 	}

@@ -176,6 +176,7 @@ extern "C" int bhip_init(int device, const void *edx_packed, const uint32_t *clu
 		h->peq_rows = any_other ? 16u : 5u;
 		d_src.release(); d_srcoff.release(); d_flag.release();
 	}
+	if (getenv("BHIP_DEBUG")) { size_t f_ = 0, t_ = 0; if (hipMemGetInfo(&f_, &t_) == hipSuccess) fprintf(stderr, "[bhip] references on the device (%.2f GB, upload buffer released): %.2f GB of the device's %.2f free\n", h->ref_lane.cap / 1e9, f_ / 1e9, t_ / 1e9); }
 	// accelerator: from the file's tables, or -- acx_lens == NULL and K given -- built here from the references alone
 	h->acx_z = score_lut[16 * 5 + 5] != 0;      // N penalised (burst.c:164, -y clears it): N costs 1 even against N
 	if (acx_lens) INITRC(bhip_load_accelerator(h, acx_lens, acx_lists, acx_fmt, K, badlist, n_bad));
