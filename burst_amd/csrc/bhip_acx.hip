@@ -741,7 +741,11 @@ static int build_accelerator_by_words(Handle *h, int K, int z, int part = 0, int
 	auto buf_bytes = [](uint64_t n) -> size_t { return 2 * ((size_t)(n * 8 + 16 + 255) & ~(size_t)255) + ((size_t)(n * 2 + 16 + 255) & ~(size_t)255); };
 	// the range: the final size (a record per tuple of the whole database at most) and room for the largest slice's sort on top of the own
 	// records, as far as the device has it
-	const double other = (double)nw * 4.0 + (double)(n_lines + 1) * 64.0 + (double)acx_lines_scratch_bytes(nw) + (double)nC * 8.0 + 40.0 * nC * 4.0 + (double)(3ull << 30);
+	// (round 6: 24 GB instead of 3 left alone beyond the tables.  What the sort's part of the range gives back at the end of the build is not
+	// allocatable at once -- nor is all of what a process that held the device a moment ago gave back, whatever hipMemGetInfo says: behind a
+	// parent that had opened and closed the same database, `burst_hip` at the metric's size could allocate 2.5 GB with 16 GB reported free -- and
+	// the caller's batch buffers, 7.4 GB for 2 M-entry batches, are reserved right behind the build.  The price: the last slices sort in less room.)
+	const double other = (double)nw * 4.0 + (double)(n_lines + 1) * 64.0 + (double)acx_lines_scratch_bytes(nw) + (double)nC * 8.0 + 40.0 * nC * 4.0 + (double)(24ull << 30);
 	const double avail = (double)free_b - other;
 	const uint64_t biggest_sort = std::min<uint64_t>(total_own, 2147483000ull);
 	double want_va = std::max((double)total * BHIP_REC_BYTES + 16.0, (double)total_own * BHIP_REC_BYTES + (double)buf_bytes(biggest_sort)) + 4096.0;

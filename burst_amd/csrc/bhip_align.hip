@@ -542,6 +542,7 @@ extern "C" int bhip_reserve_symbols(void *handle, uint32_t n_entries, uint32_t m
 		HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, S.key.as<uint8_t>(), S.key_sorted.as<uint8_t>(), S.idx.as<uint32_t>(), S.idx_sorted.as<uint32_t>(), (int)n, 0, 8, h->stage_stream));
 		if ((rc = S.sort_tmp.reserve(tb + 16))) return rc;
 	}
+	if (getenv("BHIP_DEBUG")) { size_t f_ = 0, t_ = 0; if (hipMemGetInfo(&f_, &t_) == hipSuccess) fprintf(stderr, "[bhip] ... staging slots reserved: %.2f GB free\n", f_ / 1e9); }
 	if ((rc = ensure_lanes(h, 1))) return rc;
 	Lane *L = h->lanes[0];
 	lane_capacity_floor(h, L, n);
@@ -562,6 +563,7 @@ extern "C" int bhip_reserve_symbols(void *handle, uint32_t n_entries, uint32_t m
 		HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, h->sort_keys.as<uint32_t>(), h->sort_keys2.as<uint32_t>(), (int)(n + 1), h->stream));
 		if ((rc = h->sort_tmp.reserve(tb))) return rc;
 	}
+	if (getenv("BHIP_DEBUG")) { size_t f_ = 0, t_ = 0; if (hipMemGetInfo(&f_, &t_) == hipSuccess) fprintf(stderr, "[bhip] ... lane and record buffers reserved: %.2f GB free\n", f_ / 1e9); }
 	if (!h->copy_stream) { HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&h->ev_sorted, hipEventDisableTiming));
 		for (auto &e : h->ev_copied) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
 	{	// A synthetic batch through the whole path, the way a batch scheduler drives it (page-locked arrays, asynchronous copies

@@ -110,24 +110,21 @@ struct DBuf {
 	// of the references) or by the process that held the device before -- is not allocatable at once: hipMemGetInfo sees it come back over
 	// some hundred milliseconds (round 6: `burst_hip` at the metric's size, 255 GB resident, found 16 GB free right behind its build where
 	// 55 GB are free a moment later, and an 8 GB reservation of batch buffers failed by 100 MB).  An allocation that fails for memory is
-	// therefore tried again for a few seconds while the free memory is still growing.
+	// therefore tried again for a few seconds.
 	static hipError_t malloc_patiently(void **q, size_t want) {
 		hipError_t e = hipMalloc(q, want);
 		if (e != hipErrorOutOfMemory) return e;
 		(void)hipGetLastError();
 		size_t last_free = 0, total = 0;
 		(void)hipMemGetInfo(&last_free, &total);
-		int still = 0;
-		for (int tries = 0; tries < 100 && still < 10; ++tries) {      // at most ~5 s; gives up half a second after the free memory stopped growing
-			(void)hipDeviceSynchronize();
-			std::this_thread::sleep_for(std::chrono::milliseconds(50));
+		const bool dbg = getenv("BHIP_DEBUG") != nullptr;
+		if (dbg) fprintf(stderr, "[bhip] hipMalloc(%zu) found no memory with %.2f GB reported free: waiting for memory that is on its way back\n", want, last_free / 1e9);
+		for (int tries = 0; tries < 80; ++tries) {      // at most ~8 s (no device synchronisation here: the caller may have work enqueued that waits for events it has yet to record)
+			std::this_thread::sleep_for(std::chrono::milliseconds(100));
 			e = hipMalloc(q, want);
-			if (e != hipErrorOutOfMemory) return e;
+			if (e != hipErrorOutOfMemory) { if (dbg) fprintf(stderr, "[bhip] ... there after %d ms\n", 100 * (tries + 1)); return e; }
 			(void)hipGetLastError();
-			size_t f = 0;
-			(void)hipMemGetInfo(&f, &total);
-			still = f > last_free + (8u << 20) ? 0 : still + 1;
-			last_free = f > last_free ? f : last_free;
+			if (dbg && tries % 10 == 9) { size_t f = 0; (void)hipMemGetInfo(&f, &total); fprintf(stderr, "[bhip] ... %d ms: %.2f GB reported free\n", 100 * (tries + 1), f / 1e9); }
 		}
 		return e;
 	}
