@@ -61,7 +61,10 @@ avg, n_full, n_all = None, 0, 0
 for f in glob.glob('%s/%s_kt/**/*kernel_trace.csv' % (O, TAG), recursive=True):
     du = [float(r['End_Timestamp']) - float(r['Start_Timestamp']) for r in csv.DictReader(open(f)) if ro['kernel'].split('<')[0] in r['Kernel_Name'] and ('<0, 0>' in r['Kernel_Name'] or '<' not in ro['kernel'])]
     if du and len(du) > n_all:
-        full = [x for x in du if x >= 0.75 * max(du)]
+        ref = sorted(du, reverse=True)[min(len(du) - 1, 7)]      # (the 8th longest: a few dispatches are stretched by whatever ran beside them)
+        full = sorted(x for x in du if 0.6 * ref <= x)
+        med = full[len(full) // 2]
+        full = [x for x in full if x <= 1.25 * med]                # ... and are left out of the average
         avg, n_full, n_all = sum(full) / len(full), len(full), len(du)
 out.append('')
 out.append('bench line of this process: value %.1f M reads/s, dominant kernel %s: %.1f us per launch by HIP events in the pipeline, frac %.4f' % (d['value'] / 1e6, ro['kernel'], ro['ms_per_launch'] * 1e3, ro['frac']))
