@@ -73,6 +73,16 @@ while time.time() - t0 < budget_s:
                 print("  first differing record", i, got[i], exp[i])
             sys.exit(1)
         recs += len(exp)
+        if not cfg["all_hits"] and rng.integers(2):
+            # BEST chosen on the device (BHIP_HITS_BEST) under the same random options: the reference's choice computed from the oracle's records
+            order = rng.permutation(tot).astype(np.uint32)
+            dev.set_ref_order(order)
+            expb = T.best_per_entry(exp, order)
+            gotb = dev.align_batch(q, all_hits=2)
+            if len(gotb) != len(expb) or gotb.tobytes() != expb.tobytes():
+                print("MISMATCH (BEST on the device) at iteration %d: %r\n got %d records, expected %d" % (it, cfg, len(gotb), len(expb)))
+                sys.exit(1)
+            recs += len(expb)
     finally:
         dev.close()
 print("fuzz ok: %d configurations, %d records compared in %.0f s (seed %d)" % (it, recs, time.time() - t0, seed0))

@@ -33,6 +33,17 @@ def family_db(seed, n_base, n_var, length, rate=0.03, short=False, iupac=0.0):
     return [seqs[i] for i in order]
 
 
+def best_per_entry(recs, order):
+    """the reference's BEST scan inside each entry (burst.c:4847-4891): fewest edits, then the higher score, then the lower RefIxSrt"""
+    keep = {}
+    for r in recs:
+        k = int(r["q"])
+        b = keep.get(k)
+        if b is None or r["ed"] < b["ed"] or (r["ed"] == b["ed"] and (r["score"] > b["score"] or (r["score"] == b["score"] and order[r["refIx"]] < order[b["refIx"]]))):
+            keep[k] = r
+    return np.array([keep[k] for k in sorted(keep)], dtype=recs.dtype)
+
+
 def budget(thres, n):
     return int(ol.oracle().orc_error_budget(thres, n))
 
@@ -202,13 +213,7 @@ def test_best_record_per_entry_chosen_on_the_device(n_var, with_acx):
     exp_all = oracle_hits(packed, clump_len, tot, q, lut, False)
     assert np.bincount(exp_all["q"]).max() > 20
     # the reference's choice inside each entry: ed is the same for all of an entry's records here; max score, then min order
-    keep = {}
-    for r in exp_all:
-        k = int(r["q"])
-        b = keep.get(k)
-        if b is None or r["ed"] < b["ed"] or (r["ed"] == b["ed"] and (r["score"] > b["score"] or (r["score"] == b["score"] and order[r["refIx"]] < order[b["refIx"]]))):
-            keep[k] = r
-    exp = np.array([keep[k] for k in sorted(keep)], dtype=exp_all.dtype)
+    exp = best_per_entry(exp_all, order)
     got = dev.align_batch(q, all_hits=2)
     assert len(got) == len(exp) == len(set(exp_all["q"].tolist()))
     assert_hits_equal(got, exp)
