@@ -8,7 +8,7 @@ sequences x 2 variants at 5 % divergence = 3.2 M references, 4.5 Gbp: every 15-m
 collision-dominated RefSeq-scale DB15 would have many more), its accelerator BUILT ON THE DEVICE from the .edx (no .acx is read
 or uploaded).  The database is as large as the box holds (--db-scale auto: the metric's own 31.5 GB .edx = 11.37 units on a 288 GB device in a
 300 GB container, with the compiled reference run on it beside the device path); `config.extrapolation.measured_sizes` carries the bench line
-measured at three database sizes up to the metric's own (profiles/r05_sizes.json).
+measured at three database sizes up to the metric's own (profiles/r06_sizes.json).
 
 A step = one batch of reads through the WHOLE device path as the product runs it: bench.py calls the C batch scheduler of
 the `burst_hip` command line (bh_align_ranges, burst_amd/csrc/host/bh_align.c) -- each step's batch is staged afresh from
@@ -1028,7 +1028,7 @@ def main():
         extrap = {"metric_database": "31.5 GB RefSeq .edx", "this_edx_bytes": edx_bytes, "size_ratio": scale_to_metric,
                   "acx_entries_here": acx_entries, "acx_records_per_read_here": rec_per_read, "this_run_is_at_metric_size": edx_bytes >= 31.0e9}
         try:
-            extrap["measured_sizes"] = json.load(open(os.path.join(ROOT, "profiles", "r05_sizes.json")))
+            extrap["measured_sizes"] = json.load(open(os.path.join(ROOT, "profiles", "r06_sizes.json")))
         except Exception:
             extrap["measured_sizes"] = None
         res = {
