@@ -264,6 +264,7 @@ static int launch_prefilter(Handle *h, Lane *L, hipStream_t pf_st, const uint32_
 	// main pass: hashed counters, four queries per wave (any database size)
 	if ((rc = L->fb_list.reserve((size_t)n_list * 4 + 16))) return rc;
 	HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 4, st));
+	L->fb_dirty = true;      // (the overflow list and its counter are shared with launch_prefilter_mask: a later class of this lane must not find them)
 	{
 		const uint32_t n_quads = (n_list + 3) / 4;
 		const uint32_t grid = std::min<uint32_t>(n_quads, (uint32_t)h->n_cu * 6);
@@ -385,7 +386,11 @@ static int launch_prefilter_mask(Handle *h, Lane *L, hipStream_t st, int cls, co
                                  uint32_t *n_cand_dev, Counters *dc, int prune) {
 	int rc;
 	if ((rc = L->fb_list.reserve((size_t)n_list * 8 + 64))) return rc;      // two lists: the queries that overflowed the first pass, and the second
-	if (L->pf_launches) HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 8, st));      // (n_fb, n_fb2; the lane's first class finds the whole counter block zeroed by enqueue_lane)
+	// (n_fb, n_fb2; the lane's first class finds the whole counter block zeroed by enqueue_lane -- unless an earlier class went through the
+	// clump-level prefilter, which counts ITS overflowed queries in n_fb: round 6's fuzzer under BHIP_POISON met a second pass that took the
+	// list positions of a 2-word class for those of the 4-word class behind it)
+	if (L->pf_launches || L->fb_dirty) HIPCHK(hipMemsetAsync(&dc->n_fb, 0, 8, st));
+	L->fb_dirty = false;
 	uint32_t *fb1 = L->fb_list.as<uint32_t>(), *fb2 = fb1 + n_list + 8, *fb_dense = fb1;
 	uint32_t *n_fb_dense = &dc->n_fb;
 	const uint32_t W16 = seed_row_words(maxwords);
@@ -650,7 +655,7 @@ static int enqueue_lane(Handle *h, Lane *L, int all_hits, hipEvent_t start, uint
 	HIPCHK(hipMemsetAsync(L->counters.p, 0, sizeof(Counters), pf));
 	Counters *dc = L->counters.as<Counters>();
 	SharedCtr *sc = h->shared_ctr.as<SharedCtr>();
-	L->launches = 0; L->prefix_words = 0; L->n_pairs_ex = 0; L->pf_launches = 0;
+	L->launches = 0; L->prefix_words = 0; L->n_pairs_ex = 0; L->pf_launches = 0; L->fb_dirty = false;
 	for (int c = 0; c < kNumClasses; ++c) { L->pf_masked[c] = false; L->pruned[c] = false; }
 	const uint32_t grid_my = (uint32_t)h->n_cu * (uint32_t)h->opt_sweep_blocks;   // < 8 leaves wave slots for the other stages' kernels
 	(void)start;

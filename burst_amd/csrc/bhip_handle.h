@@ -84,8 +84,12 @@ template <int SET> __global__ void k_rescore_reg(const BhipRawHit *, const uint3
 // error text of the calling thread (bhip_last_error); defined in bhip_init.hip
 int bhip_fail_msg(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 #define fail(...) bhip_fail_msg(__VA_ARGS__)
+// BHIP_TRACE_SYNC=1 (debugging a device fault, which ends the process without a Python frame): every checked call is followed by a line on
+// stderr and a device synchronisation -- the last line names the call behind which the device died
+inline bool bhip_trace_sync() { static const bool on = getenv("BHIP_TRACE_SYNC") != nullptr; return on; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
-	return fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
+	return fail(BHIP_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+	if (bhip_trace_sync()) { fprintf(stderr, "[bhip sync] %s:%d\n", __FILE__, __LINE__); (void)hipDeviceSynchronize(); } } while (0)
 
 // grow-only device buffer
 // (address-range reservations, mappings and unmappings of ALL handles of the process go one at a time: ranks that share a process -- one
@@ -128,12 +132,19 @@ struct DBuf {
 		}
 		return e;
 	}
+	// BHIP_POISON=<byte> (tests, tools/fuzz_repro.sh): fresh device memory is filled with that byte instead of whatever the last owner left
+	// there -- a kernel that reads what nobody wrote then fails at once and not in the 235th configuration of one process
+	static void poison(void *q, size_t n) {
+		static const char *ev = getenv("BHIP_POISON");
+		if (ev && q) { (void)hipMemset(q, atoi(ev) & 255, n); (void)hipDeviceSynchronize(); if (getenv("BHIP_DEBUG")) fprintf(stderr, "[bhip] buffer %p .. %p (%zu bytes)\n", q, (void *)((char *)q + n), n); }
+	}
 	int reserve(size_t bytes) {
 		if (bytes <= cap) return 0;
 		release();
 		size_t want = bytes + bytes / 4 + 256;
 		hipError_t e = malloc_patiently(&p, want);
 		if (e != hipSuccess) { p = nullptr; return fail(BHIP_E_DEVICE, "hipMalloc(%zu): %s", want, hipGetErrorString(e)); }
+		poison(p, want);
 		cap = want; return 0;
 	}
 	// the same without the growth slack: for the database-sized buffers that are allocated once (a quarter more of a 170 GB record
@@ -143,6 +154,7 @@ struct DBuf {
 		release();
 		hipError_t e = malloc_patiently(&p, bytes);
 		if (e != hipSuccess) { p = nullptr; return fail(BHIP_E_DEVICE, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+		poison(p, bytes);
 		cap = bytes; return 0;
 	}
 	// an address range for up to max_bytes with nothing behind it yet; non-zero (and no error text) when the runtime cannot do it
@@ -297,6 +309,7 @@ struct Lane {
 	hipEvent_t ev_pf[kNumClasses][3];    // per class: seed lookup start, hash kernel start, hash kernel done
 	uint64_t seed_words[kNumClasses] = {0};
 	uint32_t pf_launches = 0;
+	bool fb_dirty = false;                 // the clump-level prefilter of an earlier class of this call left its overflow count in the shared counter
 	bool pf_masked[kNumClasses] = {false};
 	bool pruned[kNumClasses] = {false};   // a second (filtered) sweep ran for this class
 	int pf_algo_used = 0;

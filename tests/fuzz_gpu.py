@@ -22,6 +22,8 @@ while time.time() - t0 < budget_s:
                all_hits=bool(rng.integers(2)), nq=int(rng.integers(5, 60)),
                stride=int(rng.choice([0, 0, 0, 1, 3, 7, 12, 18])), algo=int(rng.integers(-1, 2)), table=int(rng.choice([0, 0, 9, 10, 11])), reg=int(rng.integers(2)), lanes=int(rng.choice([1, 1, 2, 5])),
                prune=int(rng.integers(3) > 0), two_stage=int(rng.integers(4) > 0), lane_masks=int(rng.integers(4) > 0), y=int(rng.integers(4) == 0), band=int(rng.integers(4) > 0), oversub=int(rng.choice([1, 2, 2, 5])), cw=int(rng.integers(3)))
+    if os.environ.get("FUZZ_LOG"):                  # (a crash of the device leaves no Python frame behind: the configuration in hand, line by line)
+        with open(os.environ["FUZZ_LOG"], "a") as lf: lf.write("%d %r\n" % (it, cfg))
     seqs = T.family_db(cfg["seed"], cfg["n_base"], cfg["n_var"], cfg["length"], rate=cfg["rate"], short=cfg["short"], iupac=cfg["db_iupac"])
     if cfg["qlen"] + 10 > min(len(s) for s in seqs):
         cfg["qlen"] = max(20, min(len(s) for s in seqs) - 10)
@@ -58,6 +60,14 @@ while time.time() - t0 < budget_s:
     q = capi.Queries(allq, [T.budget(cfg["thres"], len(r)) for r in reads] * 2, list(range(nq_)) * 2, [0] * nq_ + [1] * nq_)
     if cfg["accel"]:
         q.flags = np.zeros(q.n, np.uint8)
+    for kv in filter(None, os.environ.get("FUZZ_OVERRIDE", "").split(",")):      # e.g. FUZZ_OVERRIDE=cw=2,lanes=1 while narrowing a failure down
+        cfg[kv.split("=")[0]] = type(cfg[kv.split("=")[0]])(int(kv.split("=")[1]))
+    if os.environ.get("FUZZ_LOG"):
+        with open(os.environ["FUZZ_LOG"], "a") as lf: lf.write("%d FULL %r\n" % (it, cfg))
+    if it < int(os.environ.get("FUZZ_SKIP_TO", "0")):      # fast-forward to a configuration of a logged run: the same draws, no device work
+        if not cfg["all_hits"] and rng.integers(2):
+            rng.permutation(tot)
+        continue
     dev = capi.Device(packed, clump_len, tot, lut, **kw)
     try:
         for name, key in (("prefilter_stride", "stride"), ("prefilter_algo", "algo"), ("prefilter_table", "table"), ("rescore_reg", "reg"), ("lanes", "lanes"), ("two_stage", "two_stage"), ("lane_masks", "lane_masks"), ("prune", "prune"), ("band", "band"), ("oversub", "oversub"), ("prefilter_cw", "cw")):
@@ -85,4 +95,6 @@ while time.time() - t0 < budget_s:
             recs += len(expb)
     finally:
         dev.close()
+    if it >= int(os.environ.get("FUZZ_STOP_AFTER", "1000000000")):
+        break
 print("fuzz ok: %d configurations, %d records compared in %.0f s (seed %d)" % (it, recs, time.time() - t0, seed0))

@@ -563,8 +563,25 @@ def test_randomised_configurations():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_gpu.py"), "45", "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    # BHIP_POISON: every device buffer starts as 0xA5 bytes instead of what its last owner left -- a kernel that reads what nobody wrote
+    # fails here and not in the 235th configuration of one long process (round 6)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_gpu.py"), "45", "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                       env=dict(os.environ, BHIP_POISON="165"))
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_overflow_list_of_an_earlier_length_class_is_not_taken_for_this_one():
+    """Round 6, found by a five-minute fuzzer run (seed 2026, configuration 235; reproduced under BHIP_POISON): 64-symbol reads with a
+    budget of 6 take the one-stage sweep and the clump-level prefilter, whose overflowed queries are counted in the lane's shared
+    counter; the 65 / 66-symbol reads of the same batch sit in the next length class, whose lane-resolved prefilter found that count
+    and ran its second pass over list positions of the OTHER class -- reads beyond its seed ranges (a device fault when the memory
+    behind them holds anything but small numbers).  The configuration itself, fast-forwarded, under poisoned allocations."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_gpu.py"), "100000", "2026"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                       env=dict(os.environ, BHIP_POISON="165", FUZZ_SKIP_TO="235", FUZZ_STOP_AFTER="235"))
+    assert r.returncode == 0 and "fuzz ok: 235 configurations" in r.stdout, r.stdout[-3000:]
 
 
 def test_lane_masks_built_in_slices():
